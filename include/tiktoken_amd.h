@@ -1,0 +1,106 @@
+/* C ABI of libtiktoken_amd.so -- the MI355X-native replacement for the reference's Rust
+ * `_tiktoken` extension on the BPE encode path.
+ *
+ * Each entry point names the reference interface it replaces (paths into openai/tiktoken v0.14.0).
+ * The reference-side binding a maintainer would add is shown in INTEGRATION.md; the Python shim
+ * that ships here is tiktoken_amd/_tiktoken.py (ctypes).  All pointers are plain host pointers
+ * unless the name says `_device`; no torch/HIP types appear in any signature.
+ *
+ * Status codes: every function returning int returns one of TK_OK ... TK_UNSUPPORTED; on failure
+ * tk_last_error() holds a message (thread-local).  The Python shim maps them to the reference's
+ * exception types: TK_VALUE_ERROR -> ValueError (src/py.rs:21-22,46), TK_KEY_ERROR -> KeyError
+ * (src/py.rs:142,160,171), TK_RUNTIME_ERROR -> RuntimeError (HIP failures; no reference analogue).
+ *
+ * There is no CPU implementation behind these calls: without a usable HIP device tk_create fails
+ * with TK_RUNTIME_ERROR.
+ */
+#ifndef TIKTOKEN_AMD_H
+#define TIKTOKEN_AMD_H
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+enum { TK_OK = 0, TK_VALUE_ERROR = 1, TK_KEY_ERROR = 2, TK_RUNTIME_ERROR = 3, TK_UNSUPPORTED = 4 };
+
+typedef struct tk_core tk_core;
+
+const char* tk_last_error(void);
+int tk_device_count(void);
+
+/* CoreBPE.__new__(encoder, special_tokens_encoder, pattern)            src/py.rs:15-23, src/lib.rs:618-663
+ * ranks: n_ranks byte strings ranks_blob[ranks_off[i]..ranks_off[i+1]) with ids ranks_ids[i];
+ * specials likewise (UTF-8).  pat_str must be one of the stock patterns of
+ * tiktoken_ext/openai_public.py:12-14,89,104-114 (TK_UNSUPPORTED otherwise).  Duplicate ranks ->
+ * TK_VALUE_ERROR (the reference panics, src/lib.rs:636-641).  device = HIP device ordinal. */
+int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uint32_t* ranks_ids, uint64_t n_ranks,
+              const uint8_t* spec_blob, const uint64_t* spec_off, const uint32_t* spec_ids, uint64_t n_spec,
+              const char* pat_str, int device, tk_core** out);
+void tk_destroy(tk_core* core);
+
+/* Pattern id (0 r50k/gpt2, 1 cl100k, 2 o200k) for a pat_str, or -1 if it is not a stock pattern. */
+int tk_pattern_id(const char* pat_str);
+
+/* Encoding.encode_ordinary_batch / encode_batch                        tiktoken/core.py:164-206
+ * == ThreadPool map of CoreBPE.encode_ordinary / encode                src/py.rs:29-49, src/lib.rs:360-442
+ * Documents are packed back to back in `utf8`; doc_off has n_docs+1 entries (doc_off[0] == 0).
+ * use_special = 0: encode_ordinary semantics.  use_special = 1: special tokens whose id is in
+ * allowed_ids[0..n_allowed) are emitted as their id, all other text is ordinary text.
+ * On success *tokens_out (library-owned, release with tk_free) holds the token ids of all
+ * documents back to back and tok_off_out[0..n_docs] (caller-owned array) their boundaries. */
+int tk_encode_batch(tk_core* core, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special,
+                    const uint32_t* allowed_ids, uint64_t n_allowed, uint32_t** tokens_out, uint64_t* n_tokens_out,
+                    uint64_t* tok_off_out);
+
+/* Same, with inputs already resident in HBM and results left in HBM (bench / torch interop).
+ * d_utf8 must be readable for 64 bytes past n_bytes.  d_doc_off: uint64[n_docs+1] on the device,
+ * h_doc_off: the same offsets on the host (needed only when n_bytes exceeds the per-launch chunk,
+ * may be NULL otherwise).  stream: a hipStream_t (NULL = the library's own stream).  The returned
+ * device pointers are owned by the core and stay valid until its next encode call. */
+int tk_encode_batch_device(tk_core* core, const void* d_utf8, uint64_t n_bytes, const void* d_doc_off,
+                           const uint64_t* h_doc_off, uint64_t n_docs, int use_special, const uint32_t* allowed_ids,
+                           uint64_t n_allowed, void* stream, const uint32_t** d_tokens_out, uint64_t* n_tokens_out,
+                           const uint64_t** d_tok_off_out);
+
+/* Test / debug entry with no reference counterpart: the piece boundaries the GPU pre-tokeniser
+ * finds, i.e. what `regex.find_iter` yields at src/lib.rs:365 and :405.  *starts_out receives
+ * n_pieces+1 ascending uint32 offsets (last = total bytes); release with tk_free.  Single chunk. */
+int tk_pretokenize_batch(tk_core* core, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special,
+                         const uint32_t* allowed_ids, uint64_t n_allowed, uint32_t** starts_out, uint64_t* n_out);
+
+/* CoreBPE.encode_ordinary(text) / CoreBPE.encode(text, allowed_special)  src/py.rs:29-49
+ * (also backs encode_to_tiktoken_buffer, src/py.rs:51-70: the result is a plain uint32 buffer). */
+int tk_encode_ordinary(tk_core* core, const uint8_t* utf8, uint64_t len, uint32_t** tokens_out, uint64_t* n_tokens_out);
+int tk_encode(tk_core* core, const uint8_t* utf8, uint64_t len, const uint32_t* allowed_ids, uint64_t n_allowed,
+              uint32_t** tokens_out, uint64_t* n_tokens_out);
+
+/* CoreBPE.encode_single_piece(piece): BPE of raw bytes without regex splitting   src/py.rs:145-150 */
+int tk_encode_single_piece(tk_core* core, const uint8_t* piece, uint64_t len, uint32_t** tokens_out,
+                           uint64_t* n_tokens_out);
+/* CoreBPE.encode_single_token(piece)   TK_KEY_ERROR if absent                     src/py.rs:133-143 */
+int tk_encode_single_token(tk_core* core, const uint8_t* piece, uint64_t len, uint32_t* token_out);
+/* CoreBPE.decode_bytes(tokens)         TK_KEY_ERROR "Invalid token for decoding: N"  src/py.rs:156-162, lib.rs:345-358 */
+int tk_decode_bytes(tk_core* core, const uint32_t* tokens, uint64_t n, uint8_t** bytes_out, uint64_t* len_out);
+/* CoreBPE.decode_single_token_bytes(token)  (pointer into the core; do not free)  src/py.rs:164-172 */
+int tk_decode_single_token_bytes(tk_core* core, uint32_t token, const uint8_t** bytes_out, uint64_t* len_out);
+/* CoreBPE.token_byte_values(): tokens in lexicographic byte order                  src/py.rs:178-183, lib.rs:648-650 */
+uint64_t tk_n_tokens(tk_core* core);
+int tk_sorted_token(tk_core* core, uint64_t i, const uint8_t** bytes_out, uint64_t* len_out, uint32_t* rank_out);
+
+void tk_free(void* p);
+
+/* Instrumentation for bench.py: when enabled, every kernel launch of the next encode call is
+ * bracketed by HIP events on the stream it runs on; tk_get_kernel_ms returns the summed
+ * duration and launch count per kernel name since the last tk_reset_kernel_ms. */
+void tk_set_profiling(tk_core* core, int enabled);
+void tk_reset_kernel_ms(tk_core* core);
+int tk_get_kernel_ms(tk_core* core, const char* kernel_name, double* ms_out, uint64_t* launches_out);
+/* Pieces / tokens / bytes handled by the last encode call (for roofline accounting). */
+void tk_last_stats(tk_core* core, uint64_t* n_bytes, uint64_t* n_pieces, uint64_t* n_tokens, uint64_t* n_docs,
+                   uint64_t* n_medium, uint64_t* n_long);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

@@ -1,0 +1,170 @@
+"""Shared test helpers: vocabularies, golden fixtures, corpus generator, oracle handles."""
+from __future__ import annotations
+
+import base64
+import ctypes
+import functools
+import gzip
+import json
+import os
+import subprocess
+import sys
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+from oracle import c_oracle, py_oracle  # noqa: E402  (tests are allowed to use the oracle)
+
+SPECIALS = {
+    "gpt2_shaped": {"<|endoftext|>": 50256},
+    "cl100k_shaped": {"<|endoftext|>": 100257, "<|fim_prefix|>": 100258, "<|fim_middle|>": 100259,
+                      "<|fim_suffix|>": 100260, "<|endofprompt|>": 100276},
+    "o200k_shaped": {"<|endoftext|>": 199999, "<|endofprompt|>": 200018},
+}
+PATTERN_OF = {"gpt2_shaped": 0, "cl100k_shaped": 1, "o200k_shaped": 2, "edu600": 0}
+PAT_STR = {0: py_oracle.R50K_PAT, 1: py_oracle.CL100K_PAT, 2: py_oracle.O200K_PAT}
+ENCODING_NAMES = ["gpt2_shaped", "cl100k_shaped", "o200k_shaped"]
+
+
+@functools.lru_cache(maxsize=None)
+def load_vocab(name: str) -> dict[bytes, int]:
+    d = {}
+    with gzip.open(os.path.join(ROOT, "tiktoken_amd", "vocab", name + ".tiktoken.gz")) as f:
+        for line in f.read().splitlines():
+            t, r = line.split()
+            d[base64.b64decode(t)] = int(r)
+    return d
+
+
+@functools.lru_cache(maxsize=None)
+def load_golden(name: str) -> dict:
+    with gzip.open(os.path.join(ROOT, "tests", "golden", name + ".json.gz")) as f:
+        g = json.loads(f.read())
+    for c in g["cases"]:
+        c["text"] = base64.b64decode(c["text"])
+    if g.get("mergeable_ranks"):
+        g["mergeable_ranks"] = {base64.b64decode(k): v for k, v in g["mergeable_ranks"]}
+    return g
+
+
+def golden_vocab(name: str) -> dict[bytes, int]:
+    g = load_golden(name)
+    return g["mergeable_ranks"] if g.get("mergeable_ranks") else load_vocab(g["vocab"])
+
+
+@functools.lru_cache(maxsize=None)
+def c_oracle_for(name: str) -> c_oracle.COracle:
+    g = load_golden(name) if os.path.exists(os.path.join(ROOT, "tests", "golden", name + ".json.gz")) else None
+    specials = g["special_tokens"] if g else SPECIALS[name]
+    return c_oracle.COracle(PATTERN_OF[name], golden_vocab(name) if g else load_vocab(name), specials)
+
+
+# ---------------------------------------------------------------- corpus
+_corpus_lib = None
+
+
+def corpus_lib():
+    global _corpus_lib
+    if _corpus_lib is None:
+        path = os.path.join(ROOT, "tiktoken_amd", "csrc", "libtkcorpus.so")
+        if not os.path.exists(path):
+            subprocess.check_call(["make", "-s", "-C", os.path.dirname(path), "libtkcorpus.so"])
+        lib = ctypes.CDLL(path)
+        lib.tkc_generate.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p,
+                                     ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int]
+        _corpus_lib = lib
+    return _corpus_lib
+
+
+def gen_corpus(seed: int, mix: int, nbytes: int, threads: int = 8):
+    """(blob uint8[nbytes], doc_off uint64[n_docs+1]) -- SURVEY.md 8(d) synthetic corpora."""
+    out = np.empty(nbytes + 64, np.uint8)
+    out[nbytes:] = 0
+    maxd = nbytes // 64 + 2
+    off = np.empty(maxd + 1, np.uint64)
+    nd = ctypes.c_uint64()
+    rc = corpus_lib().tkc_generate(seed, mix, nbytes, out.ctypes.data, off.ctypes.data, maxd, ctypes.byref(nd), threads)
+    assert rc == 0
+    return out[:nbytes], off[: nd.value + 1].copy()
+
+
+LOREM = ("Lorem ipsum dolor sit amet, consectetur adipiscing elit, sed do eiusmod tempor incididunt ut labore et "
+         "dolore magna aliqua. Ut enim ad minim veniam, quis nostrud exercitation ullamco laboris nisi ut aliquip ex "
+         "ea commodo consequat. Duis aute irure dolor in reprehenderit in voluptate velit esse cillum dolore eu "
+         "fugiat nulla pariatur. Excepteur sint occaecat cupidatat non proident, sunt in culpa qui officia deserunt "
+         "mollit anim id est laborum. ")
+
+
+def lorem(nbytes: int) -> bytes:
+    return (LOREM * (nbytes // len(LOREM) + 1))[:nbytes].encode()
+
+
+ADV = list("aAsStTlLvVeErRdDmMxZ") + ["ſ", "中", "́", "ʰ", "ǅ", "1", "2", "²", "٣", " ", " ", "\t", "\r", "\n", "　",
+                                        "\x85", "'", "/", "!", ".", "\x1c", "é", "Ω", "я", "ก", "ั", "😀", "’", "hello",
+                                        " world", "ing", "tion", "<|", "|>", "<|endoftext|>"]
+
+
+def pack(docs: list[bytes]):
+    blob = np.frombuffer(b"".join(docs) + b"\0" * 64, np.uint8)
+    off = np.zeros(len(docs) + 1, np.uint64)
+    if docs:
+        off[1:] = np.cumsum([len(d) for d in docs], dtype=np.uint64)
+    return blob[: int(off[-1])] if len(docs) else blob[:0], off
+
+
+# ---------------------------------------------------------------- CPU simulation of the device logic
+_sim_lib = None
+
+
+def sim_lib():
+    global _sim_lib
+    if _sim_lib is None:
+        d = os.path.join(ROOT, "tests", "hostsim")
+        so = os.path.join(d, "libtk_hostsim.so")
+        srcs = [os.path.join(d, "tk_hostsim.cpp")] + [os.path.join(ROOT, "tiktoken_amd", "csrc", f)
+                                                       for f in ("tk_tables.cpp", "tk_device.h", "tk_common.h", "tk_tables.h")]
+        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", srcs[0], srcs[1], "-o", so])
+        L = ctypes.CDLL(so)
+        vp, u64 = ctypes.c_void_p, ctypes.c_uint64
+        L.tks_create.restype = vp
+        L.tks_create.argtypes = [vp, vp, vp, u64, vp, vp, vp, u64, ctypes.c_char_p, ctypes.c_char_p, u64]
+        L.tks_destroy.argtypes = [vp]
+        L.tks_n_pairs.restype = u64
+        L.tks_n_pairs.argtypes = [vp]
+        L.tks_pretok.restype = u64
+        L.tks_pretok.argtypes = [vp, vp, u64, vp, u64, vp]
+        L.tks_encode_piece.restype = ctypes.c_int64
+        L.tks_encode_piece.argtypes = [vp, vp, ctypes.c_uint32, vp]
+        _sim_lib = L
+    return _sim_lib
+
+
+class HostSim:
+    def __init__(self, pat_str: str, ranks: dict[bytes, int], specials: dict[str, int]):
+        rb, ro, ri = c_oracle._pack(list(ranks.items()))
+        sb, so, si = c_oracle._pack([(k.encode(), v) for k, v in specials.items()])
+        err = ctypes.create_string_buffer(512)
+        self._h = sim_lib().tks_create(rb.ctypes.data, ro.ctypes.data, ri.ctypes.data, len(ri), sb.ctypes.data,
+                                       so.ctypes.data, si.ctypes.data, len(si), pat_str.encode(), err, 512)
+        if not self._h:
+            raise ValueError(err.value.decode())
+
+    def n_pairs(self):
+        return sim_lib().tks_n_pairs(self._h)
+
+    def piece_ends(self, blob: np.ndarray, doc_off: np.ndarray):
+        n = len(blob)
+        starts = np.zeros(max(n, 1), np.uint8)
+        b = np.ascontiguousarray(blob) if n else np.zeros(1, np.uint8)
+        nc = sim_lib().tks_pretok(self._h, b.ctypes.data, n, doc_off.ctypes.data, len(doc_off) - 1, starts.ctypes.data)
+        idx = np.flatnonzero(starts[:n])
+        return np.concatenate([idx[1:], [n]]).astype(np.uint64) if n else np.zeros(0, np.uint64), nc
+
+    def encode_piece(self, piece: bytes) -> list[int]:
+        out = np.empty(max(len(piece), 1), np.uint32)
+        b = np.frombuffer(piece, np.uint8)
+        n = sim_lib().tks_encode_piece(self._h, b.ctypes.data, len(piece), out.ctypes.data)
+        return out[:n].tolist()

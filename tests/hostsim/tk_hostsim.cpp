@@ -1,0 +1,155 @@
+// CPU-side simulation of the device logic, for `-m "not gpu"` unit tests ONLY.
+//
+// It compiles the product's host/device header (tiktoken_amd/csrc/tk_device.h) with g++ and runs
+// the same functions the kernels run -- class bytes, certain-start segmentation, tk_piece_end,
+// table probes, the per-lane merge -- in a sequential loop that mirrors tk_k_pretok / tk_k_lookup.
+// It lets logic errors surface in the container (no GPU here).  It is NOT a product path: the
+// library never links it, and it does not replace the GPU parity tests.
+#include <stdint.h>
+#include <string.h>
+
+#include <string>
+#include <vector>
+
+#include "../../tiktoken_amd/csrc/tk_device.h"
+#include "../../tiktoken_amd/csrc/tk_tables.h"
+#include "../../tiktoken_amd/csrc/tk_unicode_tables.inc"
+
+struct Sim {
+    TkHostTables H;
+    TkTables T;
+};
+
+struct FlatAcc {
+    const uint8_t* cls_;
+    const uint8_t* text;
+    uint64_t n;
+    uint32_t cls(uint64_t pos) const { return pos >= n ? (uint32_t)TK_C_END : cls_[pos]; }
+    uint32_t byte(uint64_t pos) const { return text[pos]; }
+};
+
+extern "C" {
+
+void* tks_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uint32_t* ranks_ids, uint64_t n_ranks,
+                 const uint8_t* spec_blob, const uint64_t* spec_off, const uint32_t* spec_ids, uint64_t n_spec,
+                 const char* pat_str, char* err, uint64_t errcap) {
+    Sim* s = new Sim();
+    std::string e = tk_build_tables(ranks_blob, ranks_off, ranks_ids, n_ranks, spec_blob, spec_off, spec_ids, n_spec, pat_str, &s->H);
+    if (!e.empty()) {
+        strncpy(err, e.c_str(), errcap - 1);
+        err[errcap - 1] = 0;
+        delete s;
+        return nullptr;
+    }
+    TkHostTables& H = s->H;
+    TkTables& D = s->T;
+    D.uc_stage1 = tk_uc_stage1;
+    D.uc_stage2 = tk_uc_stage2;
+    D.piece = H.piece.data();
+    D.piece_off = H.piece_off.data();
+    D.piece_mask = H.piece_mask;
+    D.tok_bytes = H.tok_bytes.data();
+    D.pair = H.pair.data();
+    D.pair_mask = H.pair_mask;
+    D.pair2 = H.pair2.data();
+    D.byte_rank = H.byte_rank;
+    D.spec_bytes = H.spec_bytes.data();
+    D.spec_off = H.spec_off.data();
+    D.spec_id = H.spec_id.data();
+    D.n_spec = (uint32_t)H.spec_id.size();
+    memcpy(D.spec_first, H.spec_first, sizeof D.spec_first);
+    D.pattern = H.pattern;
+    return s;
+}
+void tks_destroy(void* p) { delete (Sim*)p; }
+uint64_t tks_n_pairs(void* p) { return ((Sim*)p)->H.n_pairs; }
+
+// Mirror of tk_k_pretok: class bytes, certain starts, scanner from each certain start.
+// doc_off marks hard starts.  Writes a byte per position: 1 = piece start.  Returns the number of
+// certain starts (for statistics).
+uint64_t tks_pretok(void* p, const uint8_t* text_in, uint64_t n, const uint64_t* doc_off, uint64_t n_docs, uint8_t* starts) {
+    Sim* s = (Sim*)p;
+    std::vector<uint8_t> text(text_in, text_in + n);
+    text.resize(n + 64, 0);
+    std::vector<uint32_t> brk((n + 31) / 32 + 2, 0);
+    for (uint64_t d = 0; d < n_docs; ++d)
+        if (doc_off[d] < n) brk[doc_off[d] >> 5] |= 1u << (doc_off[d] & 31);
+    std::vector<uint8_t> cls(n + 8, TK_C_END);
+    for (uint64_t i = 0; i < n; ++i) cls[i] = (uint8_t)tk_class_byte(s->T, text.data(), i, n, brk.data(), nullptr, nullptr);
+    memset(starts, 0, n);
+    FlatAcc acc{cls.data(), text.data(), n};
+    const int pat = s->T.pattern;
+    uint64_t n_certain = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t c = cls[i];
+        if ((c & 15u) == TK_C_CONT) continue;
+        bool certain = (c & TK_F_HARD) != 0;
+        if (!certain) {
+            if (i == 0) continue;  // the kernel sees TK_C_END to the left of position 0
+            uint64_t j = i - 1;
+            while (j > 0 && cls[j] == TK_C_CONT) --j;
+            certain = tk_certain_start(pat, cls[j] & 15u, c & 15u);
+        }
+        if (!certain) continue;
+        ++n_certain;
+        starts[i] = 1;
+        uint64_t q = i;
+        for (;;) {
+            uint64_t e = tk_piece_end(acc, q, pat);
+            if (e <= q) e = tk_next_char(acc, q);
+            if (e >= n) break;
+            uint32_t ce = acc.cls(e);
+            if (ce & TK_F_HARD) break;
+            uint64_t j = e - 1;
+            while (acc.cls(j) == TK_C_CONT) --j;
+            if (tk_certain_start(pat, acc.cls(j) & 15u, ce & 15u)) break;
+            starts[e] = 1;
+            q = e;
+        }
+    }
+    return n_certain;
+}
+
+// Mirror of the per-piece work of tk_k_lookup for pieces of <= 16 bytes; longer pieces use the
+// same probes with a simple sequential merge over ids (the wave / tree kernels cannot run here).
+int64_t tks_encode_piece(void* p, const uint8_t* piece, uint32_t len, uint32_t* out) {
+    Sim* s = (Sim*)p;
+    std::vector<uint8_t> text(piece, piece + len);
+    text.resize(len + 64, 0);
+    uint32_t r = tk_lookup_text_piece(s->T, text.data(), 0, len);
+    if (r != TK_RANK_MAX) {
+        out[0] = r;
+        return 1;
+    }
+    if (len <= 16) {
+        uint32_t s_id[16], s_rk[16], one = 0;
+        uint32_t c = tk_lane_merge<1>(s->T, text.data(), 0, len, s_id, s_rk, &one, out);
+        if (c == 1) out[0] = one;
+        return c;
+    }
+    std::vector<uint32_t> id(len), rk(len);
+    for (uint32_t k = 0; k < len; ++k) {
+        id[k] = s->T.byte_rank[text[k]];
+        rk[k] = k + 1 < len ? s->T.pair2[((uint32_t)text[k] << 8) | text[k + 1]] : TK_RANK_MAX;
+    }
+    std::vector<uint32_t> ids(id), rks(rk);
+    for (;;) {
+        uint32_t best = TK_RANK_MAX;
+        size_t bi = 0;
+        for (size_t k = 0; k + 1 < ids.size(); ++k)
+            if (rks[k] < best) {
+                best = rks[k];
+                bi = k;
+            }
+        if (best == TK_RANK_MAX) break;
+        ids[bi] = best;
+        ids.erase(ids.begin() + bi + 1);
+        rks.erase(rks.begin() + bi + 1);
+        rks[bi] = bi + 1 < ids.size() ? tk_probe_pair(s->T, ids[bi], ids[bi + 1]) : TK_RANK_MAX;
+        if (bi > 0) rks[bi - 1] = tk_probe_pair(s->T, ids[bi - 1], ids[bi]);
+    }
+    for (size_t k = 0; k < ids.size(); ++k) out[k] = ids[k];
+    return (int64_t)ids.size();
+}
+
+}  // extern "C"

@@ -1,0 +1,161 @@
+"""GPU parity tests: the HIP encode path (through the C ABI) against the CPU oracle and the golden
+fixtures generated from the reference's own Python code (tools/gen_golden.py).  Bit-exact."""
+import numpy as np
+import pytest
+
+import helpers as h
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def cores():
+    from tiktoken_amd import CoreBPE
+
+    out = {}
+    for name in h.ENCODING_NAMES + ["edu600"]:
+        g = h.load_golden(name)
+        out[name] = CoreBPE(h.golden_vocab(name), g["special_tokens"], g["pat_str"])
+    return out
+
+
+@pytest.mark.parametrize("name", h.ENCODING_NAMES + ["edu600"])
+def test_golden_vectors(cores, name):
+    """Every fixture case, all ordinary cases in ONE batch call (documents never interact, core.py:174-176)."""
+    g = h.load_golden(name)
+    core = cores[name]
+    ordinary = [c for c in g["cases"] if c["allowed"] is None]
+    blob, off = h.pack([c["text"] for c in ordinary])
+    toks, toff = core.encode_batch_packed(blob, off)
+    bad = []
+    for i, c in enumerate(ordinary):
+        got = toks[int(toff[i]):int(toff[i + 1])].tolist()
+        if got != c["tokens"]:
+            bad.append((c["name"], c["text"][:60], got[:12], c["tokens"][:12]))
+    assert not bad, bad[:5]
+    # special-token cases, grouped by allowed set (src/lib.rs:375-442)
+    groups = {}
+    for c in g["cases"]:
+        if c["allowed"] is not None:
+            groups.setdefault(tuple(c["allowed"]), []).append(c)
+    for allowed, cs in groups.items():
+        blob, off = h.pack([c["text"] for c in cs])
+        toks, toff = core.encode_batch_packed(blob, off, set(allowed))
+        for i, c in enumerate(cs):
+            got = toks[int(toff[i]):int(toff[i + 1])].tolist()
+            assert got == c["tokens"], (c["name"], c["text"], allowed, got, c["tokens"])
+
+
+@pytest.mark.parametrize("name", h.ENCODING_NAMES)
+def test_pretokenizer_matches_oracle_split(cores, name):
+    """Piece boundaries from tk_k_pretok == the sequential scanner == regex.findall (src/lib.rs:365)."""
+    core, C = cores[name], h.c_oracle_for(name)
+    blob, off = h.gen_corpus(0xABC0 + h.PATTERN_OF[name], h.PATTERN_OF[name] % 2, 2 << 20)
+    starts = core.pretokenize_packed(blob, off)
+    bb = blob.tobytes()
+    ref = []
+    for d in range(len(off) - 1):
+        a, b = int(off[d]), int(off[d + 1])
+        ref += [a] + [a + e for e in C.split(bb[a:b])[:-1]] if b > a else []
+    ref.append(len(bb))
+    assert starts.tolist() == ref
+
+
+@pytest.mark.parametrize("name,mix,nbytes", [("gpt2_shaped", 2, 1 << 20), ("cl100k_shaped", 0, 8 << 20), ("o200k_shaped", 1, 8 << 20)])
+def test_corpus_batch_equals_oracle(cores, name, mix, nbytes):
+    core, C = cores[name], h.c_oracle_for(name)
+    if name == "gpt2_shaped":  # config C1: one 1 MiB ASCII Lorem-ipsum document
+        data = h.lorem(nbytes)
+        blob, off = h.pack([data])
+    else:
+        blob, off = h.gen_corpus(0x5EED0000 + mix + 7, mix, nbytes)
+    toks, toff = core.encode_batch_packed(blob, off)
+    rt, ro = C.encode_batch(blob, off, None, 8)
+    assert np.array_equal(toff, ro)
+    assert np.array_equal(toks, rt)
+
+
+def test_edge_cases(cores):
+    core, C = cores["o200k_shaped"], h.c_oracle_for("o200k_shaped")
+    # empty batch members, empty batch, ragged sizes (tests/test_encoding.py:81-83, 239-252)
+    docs = [b"", b"hello world", b"", b"", "goodbye world 中文".encode(), b"x", b""]
+    blob, off = h.pack(docs)
+    toks, toff = core.encode_batch_packed(blob, off)
+    for i, d in enumerate(docs):
+        assert toks[int(toff[i]):int(toff[i + 1])].tolist() == C.encode_ordinary(d).tolist()
+    toks, toff = core.encode_batch_packed(np.zeros(0, np.uint8), np.zeros(1, np.uint64))
+    assert len(toks) == 0 and toff.tolist() == [0]
+    assert core.encode_ordinary("") == []
+    # documents must not interact: "'" + "s", " " + "x", digits across a boundary
+    docs = [b"it'", b"s", b"a ", b" x", b"12", b"345", b"\n", b"\n", b"A", b"b"]
+    blob, off = h.pack(docs)
+    toks, toff = core.encode_batch_packed(blob, off)
+    for i, d in enumerate(docs):
+        assert toks[int(toff[i]):int(toff[i + 1])].tolist() == C.encode_ordinary(d).tolist(), d
+
+
+@pytest.mark.parametrize("name", ["cl100k_shaped", "o200k_shaped", "gpt2_shaped"])
+def test_catastrophically_repetitive(cores, name):
+    """tests/test_encoding.py:113-124 at the reference's size (10_000 repeats)."""
+    core, C = cores[name], h.c_oracle_for(name)
+    docs = []
+    for c in ["^", "0", "a", "'s", " ", "\n"]:
+        big = c * 10_000
+        docs += [big.encode(), (" " + big).encode(), (" " + big + "\n").encode()]
+    blob, off = h.pack(docs)
+    toks, toff = core.encode_batch_packed(blob, off)
+    for i, d in enumerate(docs):
+        got = toks[int(toff[i]):int(toff[i + 1])]
+        assert np.array_equal(got, C.encode_ordinary(d)), d[:20]
+        assert core.decode_bytes(got.tolist()) == d
+
+
+def test_large_repeated(cores):
+    """tests/test_encoding.py:52-57: 'x' * 1_000_000 on the o200k pattern is one giant piece."""
+    core, C = cores["o200k_shaped"], h.c_oracle_for("o200k_shaped")
+    data = b"x" * 1_000_000
+    toks = core._encode_np(data, None)
+    assert len(toks) > 0
+    assert np.array_equal(toks, C.encode_ordinary(data))
+
+
+def test_long_pieces(cores):
+    """Pieces in every merge path: <=16 (lane), 17..64 (wave), >64 (tree)."""
+    rng = np.random.default_rng(5)
+    for name in h.ENCODING_NAMES:
+        core, C = cores[name], h.c_oracle_for(name)
+        for n in [2, 3, 8, 9, 15, 16, 17, 31, 33, 63, 64, 65, 100, 127, 128, 129, 1000, 4097, 70000]:
+            for alphabet in ("ab", "abcdefgh", "中文字", "etaoinshr"):
+                s = "".join(rng.choice(list(alphabet), size=n))
+                piece = s.encode()[: n if alphabet != "中文字" else 3 * (n // 3 + 1)]
+                assert core.encode_single_piece(piece) == C.encode_piece(piece), (name, n, alphabet)
+
+
+def test_vocab_free_vectors():
+    """src/lib.rs:685-701: {ab:0, cd:1} -- byte_pair_split("abcd") = [ab, cd]; ("abab") = [ab, ab].
+    The reference test uses a 2-entry map; a CoreBPE needs every single byte too, so they are appended
+    after the two merges (which keeps ab/cd the lowest ranks)."""
+    from tiktoken_amd import CoreBPE
+
+    ranks = {b"ab": 0, b"cd": 1}
+    for b in range(256):
+        ranks[bytes([b])] = 2 + b
+    core = CoreBPE(ranks, {}, h.PAT_STR[0])
+    assert core.encode_single_piece(b"abcd") == [0, 1]
+    assert core.encode_single_piece(b"abab") == [0, 0]
+    assert core.encode_ordinary("abcd abab") == [0, 1, ranks[b" "], 0, 0]
+
+
+def test_single_token_and_decode(cores):
+    core = cores["cl100k_shaped"]
+    ranks = h.load_vocab("cl100k_shaped")
+    for tb, r in list(ranks.items())[::997]:
+        assert core.encode_single_token(tb) == r
+        assert core.decode_single_token_bytes(r) == tb
+    assert core.encode_single_token(b"<|endoftext|>") == 100257
+    with pytest.raises(KeyError):
+        core.encode_single_token(b"\xff\xfe\xfd not a token")
+    with pytest.raises(KeyError):
+        core.decode_bytes([4_000_000_000])
+    vals = core.token_byte_values()
+    assert vals == sorted(ranks.keys())

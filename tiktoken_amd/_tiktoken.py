@@ -1,0 +1,287 @@
+"""`CoreBPE` -- the drop-in for the reference's Rust extension class `tiktoken._tiktoken.CoreBPE`
+(reference src/py.rs:13-184), implemented as a thin ctypes shim over the HIP library.
+
+Same constructor and the same eleven methods, same exception types.  Two additive entry points,
+`encode_batch_packed` and `pretokenize_packed`, expose the batch shape the GPU actually runs
+(one launch sequence per batch instead of one FFI call per document).
+"""
+from __future__ import annotations
+
+import ctypes
+from typing import AbstractSet, Sequence
+
+import numpy as np
+
+from . import _lib
+
+
+def _pack_pairs(items: Sequence[tuple[bytes, int]]):
+    blob = b"".join(k for k, _ in items)
+    off = np.zeros(len(items) + 1, dtype=np.uint64)
+    if items:
+        np.cumsum(np.fromiter((len(k) for k, _ in items), dtype=np.uint64, count=len(items)), out=off[1:])
+    ids = np.fromiter((v for _, v in items), dtype=np.uint32, count=len(items))
+    data = np.frombuffer(blob, dtype=np.uint8) if blob else np.zeros(1, dtype=np.uint8)
+    return data, off, ids if len(items) else np.zeros(1, dtype=np.uint32)
+
+
+def _take_u32(ptr: ctypes.c_void_p, n: int) -> np.ndarray:
+    """Copy a library-owned uint32 buffer into a numpy array and release it."""
+    if n:
+        out = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint32)), shape=(n,)).copy()
+    else:
+        out = np.zeros(0, dtype=np.uint32)
+    _lib.lib().tk_free(ptr)
+    return out
+
+
+class CoreBPE:
+    def __init__(self, encoder: dict[bytes, int], special_tokens_encoder: dict[str, int], pattern: str, *,
+                 device: int = 0):
+        L = _lib.lib()
+        for v in encoder.values():
+            if not 0 <= v <= 0xFFFFFFFF:
+                raise OverflowError("rank does not fit in u32")  # PyO3 would refuse the conversion too
+        self._specials = dict(special_tokens_encoder)
+        rb, ro, ri = _pack_pairs(list(encoder.items()))
+        sb, so, si = _pack_pairs([(k.encode("utf-8"), v) for k, v in self._specials.items()])
+        h = ctypes.c_void_p()
+        rc = L.tk_create(rb.ctypes.data, ro.ctypes.data, ri.ctypes.data, len(encoder), sb.ctypes.data, so.ctypes.data,
+                         si.ctypes.data, len(self._specials), pattern.encode("utf-8"), device, ctypes.byref(h))
+        _lib.raise_for(rc)
+        self._h = h
+        self._L = L
+        self.device = device
+
+    def __del__(self):
+        h, self._h = getattr(self, "_h", None), None
+        if h:
+            try:
+                self._L.tk_destroy(h)
+            except Exception:
+                pass
+
+    # ------------------------------------------------------------------ helpers
+    def _allowed_ids(self, allowed_special: AbstractSet[str]) -> tuple[np.ndarray, int]:
+        ids = [self._specials[s] for s in allowed_special if s in self._specials]
+        return np.asarray(ids if ids else [0], dtype=np.uint32), len(ids)
+
+    @staticmethod
+    def _as_u8(data: bytes) -> np.ndarray:
+        return np.frombuffer(data, dtype=np.uint8) if data else np.zeros(1, dtype=np.uint8)
+
+    def _encode_np(self, data: bytes, allowed_special: AbstractSet[str] | None) -> np.ndarray:
+        buf = self._as_u8(data)
+        out, n = ctypes.c_void_p(), ctypes.c_uint64()
+        if allowed_special is None:
+            rc = self._L.tk_encode_ordinary(self._h, buf.ctypes.data, len(data), ctypes.byref(out), ctypes.byref(n))
+        else:
+            ids, k = self._allowed_ids(allowed_special)
+            rc = self._L.tk_encode(self._h, buf.ctypes.data, len(data), ids.ctypes.data, k, ctypes.byref(out), ctypes.byref(n))
+        _lib.raise_for(rc)
+        return _take_u32(out, n.value)
+
+    # ------------------------------------------------------------------ encoding (src/py.rs:29-131)
+    def encode_ordinary(self, text: str) -> list[int]:
+        # str.encode raises UnicodeEncodeError on lone surrogates, as PyO3's &str extraction does;
+        # Encoding.encode_ordinary relies on that to trigger its repair path (core.py:77-80)
+        return self._encode_np(text.encode("utf-8"), None).tolist()
+
+    def encode(self, text: str, allowed_special: AbstractSet[str]) -> list[int]:
+        return self._encode_np(text.encode("utf-8"), allowed_special).tolist()
+
+    def encode_to_tiktoken_buffer(self, text: str, allowed_special: AbstractSet[str]):
+        """Object with the buffer protocol: read-only, 1-D, itemsize 4, format 'I' (src/py.rs:186-249)."""
+        arr = self._encode_np(text.encode("utf-8"), allowed_special)
+        arr.setflags(write=False)
+        return arr
+
+    def encode_batch_packed(self, blob: np.ndarray, doc_off: np.ndarray, allowed_special: AbstractSet[str] | None = None):
+        """One GPU batch: `blob` = documents packed back to back (uint8), `doc_off` = uint64[n+1].
+        Returns (tokens uint32[T], tok_off uint64[n+1])."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        doc_off = np.ascontiguousarray(doc_off, dtype=np.uint64)
+        n_docs = len(doc_off) - 1
+        tok_off = np.empty(n_docs + 1, dtype=np.uint64)
+        out, n = ctypes.c_void_p(), ctypes.c_uint64()
+        src = blob if len(blob) else np.zeros(1, dtype=np.uint8)
+        if allowed_special is None:
+            ids, k, mode = np.zeros(1, dtype=np.uint32), 0, 0
+        else:
+            ids, k = self._allowed_ids(allowed_special)
+            mode = 1
+        rc = self._L.tk_encode_batch(self._h, src.ctypes.data, doc_off.ctypes.data, n_docs, mode, ids.ctypes.data, k,
+                                     ctypes.byref(out), ctypes.byref(n), tok_off.ctypes.data)
+        _lib.raise_for(rc)
+        return _take_u32(out, n.value), tok_off
+
+    def pretokenize_packed(self, blob: np.ndarray, doc_off: np.ndarray, allowed_special: AbstractSet[str] | None = None) -> np.ndarray:
+        """Piece start offsets (uint32, ascending, plus a final sentinel = total bytes) of a packed batch --
+        what `regex.find_iter` yields at src/lib.rs:365/405, computed by the GPU pre-tokeniser."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        doc_off = np.ascontiguousarray(doc_off, dtype=np.uint64)
+        out, n = ctypes.c_void_p(), ctypes.c_uint64()
+        src = blob if len(blob) else np.zeros(1, dtype=np.uint8)
+        if allowed_special is None:
+            ids, k, mode = np.zeros(1, dtype=np.uint32), 0, 0
+        else:
+            ids, k = self._allowed_ids(allowed_special)
+            mode = 1
+        rc = self._L.tk_pretokenize_batch(self._h, src.ctypes.data, doc_off.ctypes.data, len(doc_off) - 1, mode,
+                                          ids.ctypes.data, k, ctypes.byref(out), ctypes.byref(n))
+        _lib.raise_for(rc)
+        return _take_u32(out, n.value)
+
+    def encode_single_token(self, piece: bytes) -> int:
+        tok = ctypes.c_uint32()
+        rc = self._L.tk_encode_single_token(self._h, self._as_u8(piece).ctypes.data, len(piece), ctypes.byref(tok))
+        _lib.raise_for(rc, key=piece)
+        return tok.value
+
+    def encode_single_piece(self, piece: bytes) -> list[int]:
+        out, n = ctypes.c_void_p(), ctypes.c_uint64()
+        rc = self._L.tk_encode_single_piece(self._h, self._as_u8(piece).ctypes.data, len(piece), ctypes.byref(out), ctypes.byref(n))
+        _lib.raise_for(rc)
+        return _take_u32(out, n.value).tolist()
+
+    # -- byte-level / unstable entry points: host logic over the primitives above
+    def _last_piece_token_len(self, data: bytes, allowed_special: AbstractSet[str] | None = None) -> int:
+        """Tokens contributed by the last regex piece (second value of CoreBPE::encode, src/lib.rs:439-441);
+        0 when the text ends with an allowed special token (lib.rs:433)."""
+        if not data:
+            return 0
+        starts = self.pretokenize_packed(np.frombuffer(data, dtype=np.uint8), np.array([0, len(data)], dtype=np.uint64),
+                                         allowed_special)
+        tail = data[int(starts[-2]):]
+        if allowed_special and any(tail == s.encode("utf-8") for s in allowed_special if s in self._specials):
+            return 0
+        return len(self.encode_single_piece(tail))
+
+    def _token_is_all_space(self, token: int) -> bool:
+        try:
+            b = self.decode_single_token_bytes(token)
+        except KeyError:
+            return False
+        return all(c in b" \n\t" for c in b)
+
+    def _increase_last_piece_token_len(self, tokens: list[int], last: int) -> int:
+        # src/lib.rs:444-481
+        if last > 0 and self._token_is_all_space(tokens[len(tokens) - last]):
+            while last < len(tokens) and self._token_is_all_space(tokens[len(tokens) - last - 1]):
+                last += 1
+        return last
+
+    def _encode_bytes(self, data: bytes) -> list[int]:
+        """src/py.rs:72-115: bytes that may end in (or contain) invalid UTF-8."""
+        try:
+            data.decode("utf-8")
+            return self._encode_np(data, None).tolist()
+        except UnicodeDecodeError as e:
+            valid = e.start
+        head = data[:valid]
+        tokens = self._encode_np(head, None).tolist()
+        last = self._increase_last_piece_token_len(tokens, self._last_piece_token_len(head)) if tokens else 0
+        if tokens and last > 0:
+            unstable = self.decode_bytes(tokens[len(tokens) - last:]) + data[valid:]
+            del tokens[len(tokens) - last:]
+        else:
+            unstable = data[valid:]
+        if unstable:
+            tokens.extend(self.encode_single_piece(unstable))
+        return tokens
+
+    def encode_with_unstable(self, text: str, allowed_special: AbstractSet[str]):
+        """src/lib.rs:483-599 (`_encode_unstable_native`), restated on the host over the GPU primitives."""
+        data = text.encode("utf-8")
+        tokens = self._encode_np(data, allowed_special).tolist()
+        last = self._last_piece_token_len(data, allowed_special)
+        if last == 0:
+            return tokens, []
+        last = self._increase_last_piece_token_len(tokens, last)
+        unstable = self.decode_bytes(tokens[len(tokens) - last:])
+        del tokens[len(tokens) - last:]
+        completions: set[tuple[int, ...]] = set()
+        if not unstable:
+            return tokens, []
+        import bisect
+
+        sorted_tokens = self.token_byte_values()
+        point = bisect.bisect_left(sorted_tokens, unstable)
+        while point < len(sorted_tokens) and sorted_tokens[point].startswith(unstable):
+            completions.add((self.encode_single_token(sorted_tokens[point]),))
+            point += 1
+        for i in range(1, len(unstable)):
+            prefix, suffix = unstable[:i], unstable[i:]
+            point = bisect.bisect_left(sorted_tokens, suffix)
+            while point < len(sorted_tokens) and sorted_tokens[point].startswith(suffix):
+                possibility = prefix + sorted_tokens[point]
+                try:
+                    possibility.decode("utf-8")
+                    encoded = self._encode_np(possibility, None).tolist()
+                except UnicodeDecodeError:
+                    encoded = self.encode_single_piece(possibility)
+                seq, seq_len = [], 0
+                for t in encoded:
+                    seq.append(t)
+                    seq_len += len(self.decode_single_token_bytes(t))
+                    if seq_len >= len(unstable):
+                        break
+                completions.add(tuple(seq))
+                point += 1
+        if len(unstable) > 1:
+            # last (possibly partial) char: bstr::decode_last_utf8 (lib.rs:581-596)
+            k = len(unstable) - 1
+            while k > 0 and (unstable[k] & 0xC0) == 0x80 and len(unstable) - k < 4:
+                k -= 1
+            try:
+                ch = unstable[k:].decode("utf-8")
+                ok = len(ch) == 1
+            except UnicodeDecodeError:
+                ch, ok, k = "", False, len(unstable) - 1
+            if len(unstable) - (len(unstable) - k) > 0 and ok and ch.isspace():
+                re = self.encode_single_piece(unstable[:k]) + self.encode_single_piece(unstable[k:])
+                completions.add(tuple(re))
+        return tokens, [list(c) for c in completions]
+
+    # ------------------------------------------------------------------ decoding (src/py.rs:156-183)
+    def decode_bytes(self, tokens: Sequence[int]) -> bytes:
+        arr = np.asarray(tokens, dtype=np.uint32) if len(tokens) else np.zeros(1, dtype=np.uint32)
+        out, n = ctypes.c_void_p(), ctypes.c_uint64()
+        rc = self._L.tk_decode_bytes(self._h, arr.ctypes.data, len(tokens), ctypes.byref(out), ctypes.byref(n))
+        _lib.raise_for(rc)
+        data = ctypes.string_at(out, n.value)
+        self._L.tk_free(out)
+        return data
+
+    def decode_single_token_bytes(self, token: int) -> bytes:
+        if not 0 <= token <= 0xFFFFFFFF:
+            raise KeyError(str(token))
+        p, n = ctypes.c_void_p(), ctypes.c_uint64()
+        rc = self._L.tk_decode_single_token_bytes(self._h, token, ctypes.byref(p), ctypes.byref(n))
+        _lib.raise_for(rc, key=str(token))
+        return ctypes.string_at(p, n.value)
+
+    def token_byte_values(self) -> list[bytes]:
+        out = []
+        p, n = ctypes.c_void_p(), ctypes.c_uint64()
+        for i in range(self._L.tk_n_tokens(self._h)):
+            _lib.raise_for(self._L.tk_sorted_token(self._h, i, ctypes.byref(p), ctypes.byref(n), None))
+            out.append(ctypes.string_at(p, n.value))
+        return out
+
+    # ------------------------------------------------------------------ instrumentation
+    def set_profiling(self, on: bool):
+        self._L.tk_set_profiling(self._h, 1 if on else 0)
+
+    def reset_kernel_ms(self):
+        self._L.tk_reset_kernel_ms(self._h)
+
+    def kernel_ms(self, name: str) -> tuple[float, int]:
+        ms, n = ctypes.c_double(), ctypes.c_uint64()
+        self._L.tk_get_kernel_ms(self._h, name.encode(), ctypes.byref(ms), ctypes.byref(n))
+        return ms.value, n.value
+
+    def last_stats(self) -> dict:
+        v = [ctypes.c_uint64() for _ in range(6)]
+        self._L.tk_last_stats(self._h, *[ctypes.byref(x) for x in v])
+        return dict(zip(("bytes", "pieces", "tokens", "docs", "medium_pieces", "long_pieces"), (x.value for x in v)))

@@ -1,0 +1,615 @@
+// C ABI + host orchestration of the MI355X BPE encode path (see include/tiktoken_amd.h).
+// Host code here only builds tables, moves buffers and launches kernels; every byte of
+// pre-tokenisation and merging is done by the kernels in tk_kernels.h.  There is no CPU path.
+#include <hip/hip_runtime.h>
+#include <stdlib.h>
+#include <string.h>
+
+#include <map>
+#include <mutex>
+#include <string>
+#include <vector>
+
+#include "../../include/tiktoken_amd.h"
+#include "tk_kernels.h"
+#include "tk_tables.h"
+#include "tk_unicode_tables.inc"
+
+static thread_local std::string g_err;
+static int fail(int code, const std::string& msg) {
+    g_err = msg;
+    return code;
+}
+#define HIPCHK(expr)                                                                                    \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e__) + " at " #expr); \
+    } while (0)
+
+struct Buf {
+    void* p = nullptr;
+    size_t cap = 0;
+    template <class T>
+    T* as() const { return (T*)p; }
+};
+static int ensure(Buf& b, size_t bytes) {
+    if (bytes <= b.cap && b.p) return TK_OK;
+    if (b.p) HIPCHK(hipFree(b.p));
+    b.p = nullptr;
+    b.cap = 0;
+    size_t want = bytes + bytes / 8 + 256;
+    HIPCHK(hipMalloc(&b.p, want));
+    b.cap = want;
+    return TK_OK;
+}
+static void release(Buf& b) {
+    if (b.p) (void)hipFree(b.p);
+    b.p = nullptr;
+    b.cap = 0;
+}
+
+struct KernelStat {
+    double ms = 0;
+    uint64_t launches = 0;
+};
+
+struct tk_core {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    TkHostTables H;
+    TkTables D;  // device view
+    Buf t_stage1, t_stage2, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_spec_bytes, t_spec_off, t_spec_id;
+    uint32_t spec_max_len = 0;
+    std::mutex mu;
+    // workspace
+    Buf text, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, tok1, cnt, tokbase, staging, listB, listC,
+        counters, total, partial, g_id, g_rk, g_nx, g_pv, g_lv, out_tokens, out_tok_off, allowed;
+    uint64_t chunk_bytes = 1ull << 30;
+    // instrumentation
+    bool profiling = false;
+    std::map<std::string, KernelStat> stats;
+    std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
+    uint64_t st_bytes = 0, st_pieces = 0, st_tokens = 0, st_docs = 0, st_medium = 0, st_long = 0;
+};
+
+template <class F>
+static int timed(tk_core* c, hipStream_t s, const char* name, F&& f) {
+    if (!c->profiling) {
+        f();
+        HIPCHK(hipGetLastError());
+        return TK_OK;
+    }
+    hipEvent_t a, b;
+    HIPCHK(hipEventCreate(&a));
+    HIPCHK(hipEventCreate(&b));
+    HIPCHK(hipEventRecord(a, s));
+    f();
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipEventRecord(b, s));
+    c->pending.push_back({name, {a, b}});
+    return TK_OK;
+}
+static int drain_events(tk_core* c) {
+    for (auto& pe : c->pending) {
+        float ms = 0;
+        HIPCHK(hipEventSynchronize(pe.second.second));
+        HIPCHK(hipEventElapsedTime(&ms, pe.second.first, pe.second.second));
+        KernelStat& ks = c->stats[pe.first];
+        ks.ms += ms;
+        ks.launches += 1;
+        (void)hipEventDestroy(pe.second.first);
+        (void)hipEventDestroy(pe.second.second);
+    }
+    c->pending.clear();
+    return TK_OK;
+}
+#define TRY(x)                      \
+    do {                            \
+        int rc__ = (x);             \
+        if (rc__ != TK_OK) return rc__; \
+    } while (0)
+
+static int upload(Buf& b, const void* src, size_t bytes) {
+    TRY(ensure(b, bytes ? bytes : 16));
+    if (bytes) HIPCHK(hipMemcpy(b.p, src, bytes, hipMemcpyHostToDevice));
+    return TK_OK;
+}
+
+extern "C" const char* tk_last_error(void) { return g_err.c_str(); }
+
+extern "C" int tk_device_count(void) {
+    int n = 0;
+    if (hipGetDeviceCount(&n) != hipSuccess) return 0;
+    return n;
+}
+
+extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uint32_t* ranks_ids, uint64_t n_ranks,
+                         const uint8_t* spec_blob, const uint64_t* spec_off, const uint32_t* spec_ids, uint64_t n_spec,
+                         const char* pat_str, int device, tk_core** out) {
+    if (!out) return fail(TK_VALUE_ERROR, "out is null");
+    *out = nullptr;
+    if (tk_pattern_id(pat_str) < 0)
+        return fail(TK_UNSUPPORTED, std::string("unsupported pat_str (only the stock r50k/gpt2, cl100k and o200k patterns "
+                                                "have compiled scanners): ") + (pat_str ? pat_str : "(null)"));
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
+        return fail(TK_RUNTIME_ERROR, "no HIP device available: tiktoken_amd has no CPU path");
+    if (device < 0 || device >= ndev) return fail(TK_VALUE_ERROR, "device ordinal out of range");
+    tk_core* c = new tk_core();
+    c->device = device;
+    std::string err = tk_build_tables(ranks_blob, ranks_off, ranks_ids, n_ranks, spec_blob, spec_off, spec_ids, n_spec, pat_str, &c->H);
+    if (!err.empty()) {
+        delete c;
+        return fail(TK_VALUE_ERROR, err);
+    }
+    auto bail = [&](int rc) {
+        tk_destroy(c);
+        return rc;
+    };
+    if (hipSetDevice(device) != hipSuccess) return bail(fail(TK_RUNTIME_ERROR, "hipSetDevice failed"));
+    if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(TK_RUNTIME_ERROR, "hipStreamCreate failed"));
+    const TkHostTables& H = c->H;
+    int rc;
+    if ((rc = upload(c->t_stage1, tk_uc_stage1, sizeof tk_uc_stage1))) return bail(rc);
+    if ((rc = upload(c->t_stage2, tk_uc_stage2, sizeof tk_uc_stage2))) return bail(rc);
+    if ((rc = upload(c->t_piece, H.piece.data(), H.piece.size() * sizeof(TkPieceSlot)))) return bail(rc);
+    if ((rc = upload(c->t_piece_off, H.piece_off.data(), H.piece_off.size() * 4))) return bail(rc);
+    if ((rc = upload(c->t_tok_bytes, H.tok_bytes.data(), H.tok_bytes.size()))) return bail(rc);
+    if ((rc = upload(c->t_pair, H.pair.data(), H.pair.size() * sizeof(TkPairSlot)))) return bail(rc);
+    if ((rc = upload(c->t_pair2, H.pair2.data(), H.pair2.size() * 4))) return bail(rc);
+    if ((rc = upload(c->t_byte_rank, H.byte_rank, sizeof H.byte_rank))) return bail(rc);
+    if ((rc = upload(c->t_spec_bytes, H.spec_bytes.data(), H.spec_bytes.size()))) return bail(rc);
+    if ((rc = upload(c->t_spec_off, H.spec_off.data(), H.spec_off.size() * 4))) return bail(rc);
+    if ((rc = upload(c->t_spec_id, H.spec_id.data(), H.spec_id.size() * 4))) return bail(rc);
+    TkTables& D = c->D;
+    D.uc_stage1 = c->t_stage1.as<uint8_t>();
+    D.uc_stage2 = c->t_stage2.as<uint8_t>();
+    D.piece = c->t_piece.as<TkPieceSlot>();
+    D.piece_off = c->t_piece_off.as<uint32_t>();
+    D.piece_mask = H.piece_mask;
+    D.tok_bytes = c->t_tok_bytes.as<uint8_t>();
+    D.pair = c->t_pair.as<TkPairSlot>();
+    D.pair_mask = H.pair_mask;
+    D.pair2 = c->t_pair2.as<uint32_t>();
+    D.byte_rank = c->t_byte_rank.as<uint32_t>();
+    D.spec_bytes = c->t_spec_bytes.as<uint8_t>();
+    D.spec_off = c->t_spec_off.as<uint32_t>();
+    D.spec_id = c->t_spec_id.as<uint32_t>();
+    D.n_spec = (uint32_t)H.spec_id.size();
+    memcpy(D.spec_first, H.spec_first, sizeof D.spec_first);
+    D.pattern = H.pattern;
+    for (size_t k = 0; k + 1 < H.spec_off.size(); ++k) c->spec_max_len = std::max(c->spec_max_len, H.spec_off[k + 1] - H.spec_off[k]);
+    if (const char* e = getenv("TIKTOKEN_AMD_CHUNK_BYTES")) {
+        uint64_t v = strtoull(e, nullptr, 10);
+        if (v >= 4096 && v <= (3ull << 30)) c->chunk_bytes = v;
+    }
+    *out = c;
+    return TK_OK;
+}
+
+extern "C" void tk_destroy(tk_core* c) {
+    if (!c) return;
+    (void)hipSetDevice(c->device);
+    for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_piece, &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2,
+                   &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off, &c->brk, &c->docb,
+                   &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->tok1, &c->cnt, &c->tokbase, &c->staging,
+                   &c->listB, &c->listC, &c->counters, &c->total, &c->partial, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv,
+                   &c->out_tokens, &c->out_tok_off, &c->allowed})
+        release(*b);
+    if (c->stream) (void)hipStreamDestroy(c->stream);
+    delete c;
+}
+
+static uint32_t grid_for(uint64_t items, uint32_t per_block, uint32_t cap) {
+    uint64_t g = (items + per_block - 1) / per_block;
+    if (g < 1) g = 1;
+    if (g > cap) g = cap;
+    return (uint32_t)g;
+}
+
+// One chunk (n < 4 GiB bytes) of packed documents, everything device resident.
+//   d_text: chunk text (readable 64 bytes past n); d_doc_off: uint64 offsets of the chunk's
+//   documents (n_docs+1 entries, absolute; `base` is subtracted); single_piece: the whole buffer
+//   is one piece (encode_single_piece), no pre-tokenisation.
+static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t n, const uint64_t* d_doc_off, uint64_t n_docs,
+                     uint64_t base, bool use_special, bool single_piece, uint32_t* d_out, uint64_t tok_base_global,
+                     uint64_t* d_tok_off, uint64_t* n_tokens_out, bool pretok_only = false) {
+    const TkTables& T = c->D;
+    const uint64_t nwords = (n + 31) / 32;
+    const uint64_t nblk = (nwords + 255) / 256;
+    TRY(ensure(c->brk, (nwords + 2) * 4));
+    TRY(ensure(c->starts, (nwords + 2) * 4));
+    TRY(ensure(c->blockcnt, (nblk + 2) * 4));
+    TRY(ensure(c->counters, TK_CNT_N * 4));
+    TRY(ensure(c->total, 16));
+    HIPCHK(hipMemsetAsync(c->brk.p, 0, (nwords + 2) * 4, s));
+    HIPCHK(hipMemsetAsync(c->starts.p, 0, (nwords + 2) * 4, s));
+    HIPCHK(hipMemsetAsync(c->counters.p, 0, TK_CNT_N * 4, s));
+    uint32_t *brk = c->brk.as<uint32_t>(), *starts = c->starts.as<uint32_t>();
+    uint32_t *ss = nullptr, *si = nullptr, *docb = nullptr;
+    uint64_t P = 0;
+    if (n > 0 && !single_piece) {
+        if (use_special) {
+            TRY(ensure(c->docb, (nwords + 2) * 4));
+            TRY(ensure(c->cand, (nwords + 2) * 4));
+            TRY(ensure(c->ss, (nwords + 2) * 4));
+            TRY(ensure(c->si, (nwords + 2) * 4));
+            for (Buf* b : {&c->docb, &c->cand, &c->ss, &c->si}) HIPCHK(hipMemsetAsync(b->p, 0, (nwords + 2) * 4, s));
+            docb = c->docb.as<uint32_t>();
+            ss = c->ss.as<uint32_t>();
+            si = c->si.as<uint32_t>();
+        }
+        TRY(timed(c, s, "tk_k_mark_docs", [&] {
+            hipLaunchKernelGGL(tk_k_mark_docs, dim3(grid_for(n_docs, 256, 4096)), dim3(256), 0, s, d_doc_off, n_docs, base, n, brk, docb);
+        }));
+        if (use_special) {
+            const uint8_t* allowed = c->allowed.as<uint8_t>();
+            uint32_t* cand = c->cand.as<uint32_t>();
+            TRY(timed(c, s, "tk_k_spec_cand", [&] {
+                hipLaunchKernelGGL(tk_k_spec_cand, dim3(grid_for(n, 256, 16384)), dim3(256), 0, s, T, d_text, n, allowed, docb, cand);
+            }));
+            TRY(timed(c, s, "tk_k_spec_resolve", [&] {
+                hipLaunchKernelGGL(tk_k_spec_resolve, dim3(grid_for(n, 256, 16384)), dim3(256), 0, s, T, d_text, n, allowed, docb, cand,
+                                   c->spec_max_len, ss, si, brk);
+            }));
+        }
+        TRY(timed(c, s, "tk_k_pretok", [&] {
+            hipLaunchKernelGGL(tk_k_pretok, dim3((uint32_t)((n + TK_TILE - 1) / TK_TILE)), dim3(256), 0, s, T, d_text, n, brk, ss, si, starts);
+        }));
+        TRY(timed(c, s, "tk_k_count", [&] {
+            hipLaunchKernelGGL(tk_k_count, dim3((uint32_t)nblk), dim3(256), 0, s, starts, nwords, c->blockcnt.as<uint32_t>());
+        }));
+        TRY(timed(c, s, "tk_k_scan_small", [&] {
+            hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, c->blockcnt.as<uint32_t>(), nblk, c->total.as<uint64_t>());
+        }));
+        HIPCHK(hipMemcpyAsync(&P, c->total.p, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+    } else if (n > 0) {
+        P = 1;
+    }
+    TRY(ensure(c->pstart, (P + 2) * 4));
+    TRY(ensure(c->tok1, (P + 2) * 4));
+    TRY(ensure(c->cnt, (P + 2) * 4));
+    TRY(ensure(c->tokbase, (P + 2) * 4));
+    uint32_t* pstart = c->pstart.as<uint32_t>();
+    uint32_t* tokbase = c->tokbase.as<uint32_t>();
+    uint64_t T_total = 0;
+    uint64_t nB = 0, nC = 0;
+    if (P > 0) {
+        if (single_piece) {
+            uint32_t two[2] = {0, (uint32_t)n};
+            HIPCHK(hipMemcpyAsync(pstart, two, 8, hipMemcpyHostToDevice, s));
+        } else {
+            TRY(timed(c, s, "tk_k_emit", [&] {
+                hipLaunchKernelGGL(tk_k_emit, dim3((uint32_t)nblk), dim3(256), 0, s, starts, nwords, c->blockcnt.as<uint32_t>(), pstart, P, n);
+            }));
+        }
+        if (pretok_only) {
+            *n_tokens_out = P;
+            return TK_OK;
+        }
+        TRY(ensure(c->staging, (n + 64) * 4));
+        TRY(ensure(c->listB, (n / 17 + 64) * 4));
+        TRY(ensure(c->listC, (n / 65 + 64) * 12));
+        uint32_t* counters = c->counters.as<uint32_t>();
+        TRY(timed(c, s, "tk_k_lookup", [&] {
+            hipLaunchKernelGGL(tk_k_lookup, dim3(grid_for(P, 256 * TK_PPT, 4096)), dim3(256), 0, s, T, d_text, pstart, P, ss,
+                               c->tok1.as<uint32_t>(), c->cnt.as<uint32_t>(), c->staging.as<uint32_t>(), c->listB.as<uint32_t>(),
+                               c->listC.as<uint32_t>(), counters);
+        }));
+        uint32_t hc[TK_CNT_N];
+        HIPCHK(hipMemcpyAsync(hc, counters, sizeof hc, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        nB = hc[TK_CNT_B];
+        nC = hc[TK_CNT_C];
+        if (nB) {
+            TRY(timed(c, s, "tk_k_merge_wave", [&] {
+                hipLaunchKernelGGL(tk_k_merge_wave, dim3(grid_for(nB, 4, 8192)), dim3(256), 0, s, T, d_text, pstart, c->listB.as<uint32_t>(),
+                                   (uint32_t)nB, c->tok1.as<uint32_t>(), c->cnt.as<uint32_t>(), c->staging.as<uint32_t>());
+            }));
+        }
+        if (nC) {
+            uint64_t lb = hc[TK_CNT_CBYTES], lvls = hc[TK_CNT_CLEVELS];
+            TRY(ensure(c->g_id, (lb + 64) * 4));
+            TRY(ensure(c->g_rk, (lb + 64) * 4));
+            TRY(ensure(c->g_nx, (lb + 64) * 4));
+            TRY(ensure(c->g_pv, (lb + 64) * 4));
+            TRY(ensure(c->g_lv, (lvls + 64) * 8));
+            TRY(timed(c, s, "tk_k_merge_long", [&] {
+                hipLaunchKernelGGL(tk_k_merge_long, dim3(grid_for(nC, 4, 8192)), dim3(256), 0, s, T, d_text, pstart, c->listC.as<uint32_t>(),
+                                   (uint32_t)nC, c->g_id.as<uint32_t>(), c->g_rk.as<uint32_t>(), c->g_nx.as<uint32_t>(),
+                                   c->g_pv.as<uint32_t>(), c->g_lv.as<uint64_t>(), c->tok1.as<uint32_t>(), c->cnt.as<uint32_t>(),
+                                   c->staging.as<uint32_t>());
+            }));
+        }
+        // token counts -> offsets
+        const uint64_t nsb = (P + 256 * TK_SCAN_EPT - 1) / (256 * TK_SCAN_EPT);
+        TRY(ensure(c->partial, (nsb + 2) * 4));
+        TRY(timed(c, s, "tk_k_scan_reduce", [&] {
+            hipLaunchKernelGGL(tk_k_scan_reduce, dim3((uint32_t)nsb), dim3(256), 0, s, c->cnt.as<uint32_t>(), P, c->partial.as<uint32_t>());
+        }));
+        TRY(timed(c, s, "tk_k_scan_small", [&] {
+            hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, c->partial.as<uint32_t>(), nsb, c->total.as<uint64_t>());
+        }));
+        TRY(timed(c, s, "tk_k_scan_down", [&] {
+            hipLaunchKernelGGL(tk_k_scan_down, dim3((uint32_t)nsb), dim3(256), 0, s, c->cnt.as<uint32_t>(), P, c->partial.as<uint32_t>(), tokbase);
+        }));
+        HIPCHK(hipMemcpyAsync(&T_total, c->total.p, 8, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        TRY(timed(c, s, "tk_k_gather", [&] {
+            hipLaunchKernelGGL(tk_k_gather, dim3(grid_for(P, 256, 8192)), dim3(256), 0, s, pstart, P, c->cnt.as<uint32_t>(), tokbase,
+                               c->tok1.as<uint32_t>(), c->staging.as<uint32_t>(), d_out);
+        }));
+    } else {
+        HIPCHK(hipMemsetAsync(tokbase, 0, 8, s));
+        if (pretok_only) {
+            uint32_t zero = 0;
+            HIPCHK(hipMemcpyAsync(pstart, &zero, 4, hipMemcpyHostToDevice, s));
+            HIPCHK(hipStreamSynchronize(s));
+            *n_tokens_out = 0;
+            return TK_OK;
+        }
+    }
+    if (d_tok_off) {
+        TRY(timed(c, s, "tk_k_docoff", [&] {
+            hipLaunchKernelGGL(tk_k_docoff, dim3(grid_for(n_docs + 1, 256, 4096)), dim3(256), 0, s, d_doc_off, n_docs, base, n, starts,
+                               c->blockcnt.as<uint32_t>(), tokbase, P, tok_base_global, d_tok_off);
+        }));
+    }
+    c->st_bytes += n;
+    c->st_pieces += P;
+    c->st_tokens += T_total;
+    c->st_medium += nB;
+    c->st_long += nC;
+    *n_tokens_out = T_total;
+    return TK_OK;
+}
+
+static int prepare_allowed(tk_core* c, hipStream_t s, const uint32_t* allowed_ids, uint64_t n_allowed, bool* any) {
+    const TkHostTables& H = c->H;
+    std::vector<uint8_t> a(H.spec_id.size() + 16, 0);
+    *any = false;
+    for (size_t k = 0; k < H.spec_id.size(); ++k)
+        for (uint64_t j = 0; j < n_allowed; ++j)
+            if (H.spec_id[k] == allowed_ids[j]) {
+                a[k] = 1;
+                *any = true;
+            }
+    TRY(ensure(c->allowed, a.size()));
+    HIPCHK(hipMemcpyAsync(c->allowed.p, a.data(), a.size(), hipMemcpyHostToDevice, s));
+    HIPCHK(hipStreamSynchronize(s));  // `a` goes out of scope
+    return TK_OK;
+}
+
+// Device-resident batch: chunk by documents, run the pipeline per chunk.
+static int encode_device_locked(tk_core* c, hipStream_t s, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
+                                const uint64_t* h_doc_off, uint64_t n_docs, bool use_special, uint64_t* n_tokens_out) {
+    c->st_bytes = c->st_pieces = c->st_tokens = c->st_medium = c->st_long = 0;
+    c->st_docs = n_docs;
+    TRY(ensure(c->out_tokens, (n_bytes + 64) * 4));
+    TRY(ensure(c->out_tok_off, (n_docs + 2) * 8));
+    uint32_t* d_out = c->out_tokens.as<uint32_t>();
+    uint64_t* d_tok_off = c->out_tok_off.as<uint64_t>();
+    uint64_t total = 0;
+    if (n_bytes <= c->chunk_bytes) {
+        TRY(run_chunk(c, s, d_utf8, n_bytes, d_doc_off, n_docs, 0, use_special, false, d_out, 0, d_tok_off, &total));
+    } else {
+        if (!h_doc_off) return fail(TK_VALUE_ERROR, "h_doc_off is required when n_bytes exceeds the chunk size");
+        uint64_t d0 = 0;
+        while (d0 < n_docs) {
+            uint64_t d1 = d0 + 1;
+            while (d1 < n_docs && h_doc_off[d1 + 1] - h_doc_off[d0] <= c->chunk_bytes) ++d1;
+            uint64_t b = h_doc_off[d0], nn = h_doc_off[d1] - b;
+            if (nn >= (4ull << 30) - 65536) return fail(TK_VALUE_ERROR, "a single document of 4 GiB or more is not supported");
+            uint64_t t = 0;
+            TRY(run_chunk(c, s, d_utf8 + b, nn, d_doc_off + d0, d1 - d0, b, use_special, false, d_out + total, total, d_tok_off + d0, &t));
+            total += t;
+            d0 = d1;
+        }
+    }
+    HIPCHK(hipStreamSynchronize(s));
+    TRY(drain_events(c));
+    *n_tokens_out = total;
+    return TK_OK;
+}
+
+extern "C" int tk_encode_batch_device(tk_core* c, const void* d_utf8, uint64_t n_bytes, const void* d_doc_off,
+                                      const uint64_t* h_doc_off, uint64_t n_docs, int use_special, const uint32_t* allowed_ids,
+                                      uint64_t n_allowed, void* stream, const uint32_t** d_tokens_out, uint64_t* n_tokens_out,
+                                      const uint64_t** d_tok_off_out) {
+    if (!c) return fail(TK_VALUE_ERROR, "core is null");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    bool any = false;
+    if (use_special) TRY(prepare_allowed(c, s, allowed_ids, n_allowed, &any));
+    uint64_t total = 0;
+    TRY(encode_device_locked(c, s, (const uint8_t*)d_utf8, n_bytes, (const uint64_t*)d_doc_off, h_doc_off, n_docs, use_special && any, &total));
+    if (d_tokens_out) *d_tokens_out = c->out_tokens.as<uint32_t>();
+    if (d_tok_off_out) *d_tok_off_out = c->out_tok_off.as<uint64_t>();
+    if (n_tokens_out) *n_tokens_out = total;
+    return TK_OK;
+}
+
+extern "C" int tk_encode_batch(tk_core* c, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special,
+                               const uint32_t* allowed_ids, uint64_t n_allowed, uint32_t** tokens_out, uint64_t* n_tokens_out,
+                               uint64_t* tok_off_out) {
+    if (!c) return fail(TK_VALUE_ERROR, "core is null");
+    if (!doc_off || !tokens_out || !n_tokens_out) return fail(TK_VALUE_ERROR, "null argument");
+    if (doc_off[0] != 0) return fail(TK_VALUE_ERROR, "doc_off[0] must be 0");
+    for (uint64_t d = 0; d < n_docs; ++d)
+        if (doc_off[d + 1] < doc_off[d]) return fail(TK_VALUE_ERROR, "doc_off must be non-decreasing");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const uint64_t n_bytes = doc_off[n_docs];
+    TRY(ensure(c->text, n_bytes + 256));
+    TRY(ensure(c->doc_off, (n_docs + 2) * 8));
+    if (n_bytes) HIPCHK(hipMemcpyAsync(c->text.p, utf8, n_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync((uint8_t*)c->text.p + n_bytes, 0, 128, s));
+    HIPCHK(hipMemcpyAsync(c->doc_off.p, doc_off, (n_docs + 1) * 8, hipMemcpyHostToDevice, s));
+    bool any = false;
+    if (use_special) TRY(prepare_allowed(c, s, allowed_ids, n_allowed, &any));
+    uint64_t total = 0;
+    TRY(encode_device_locked(c, s, c->text.as<uint8_t>(), n_bytes, c->doc_off.as<uint64_t>(), doc_off, n_docs, use_special && any, &total));
+    uint32_t* host = (uint32_t*)malloc((total ? total : 1) * 4);
+    if (!host) return fail(TK_RUNTIME_ERROR, "out of host memory");
+    if (total) HIPCHK(hipMemcpy(host, c->out_tokens.p, total * 4, hipMemcpyDeviceToHost));
+    if (tok_off_out) HIPCHK(hipMemcpy(tok_off_out, c->out_tok_off.p, (n_docs + 1) * 8, hipMemcpyDeviceToHost));
+    *tokens_out = host;
+    *n_tokens_out = total;
+    return TK_OK;
+}
+
+// Debug / test entry: the piece-start offsets the GPU pre-tokeniser produces for a packed batch
+// (what regex.find_iter yields at src/lib.rs:365 and :405).  *starts_out gets n_pieces+1 uint32
+// values (ascending piece starts, then the total byte count); release with tk_free.
+extern "C" int tk_pretokenize_batch(tk_core* c, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special,
+                                    const uint32_t* allowed_ids, uint64_t n_allowed, uint32_t** starts_out, uint64_t* n_out) {
+    if (!c) return fail(TK_VALUE_ERROR, "core is null");
+    if (!doc_off || doc_off[0] != 0) return fail(TK_VALUE_ERROR, "doc_off[0] must be 0");
+    const uint64_t n_bytes = doc_off[n_docs];
+    if (n_bytes > c->chunk_bytes) return fail(TK_VALUE_ERROR, "tk_pretokenize_batch handles a single chunk only");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    TRY(ensure(c->text, n_bytes + 256));
+    TRY(ensure(c->doc_off, (n_docs + 2) * 8));
+    if (n_bytes) HIPCHK(hipMemcpyAsync(c->text.p, utf8, n_bytes, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync((uint8_t*)c->text.p + n_bytes, 0, 128, s));
+    HIPCHK(hipMemcpyAsync(c->doc_off.p, doc_off, (n_docs + 1) * 8, hipMemcpyHostToDevice, s));
+    bool any = false;
+    if (use_special) TRY(prepare_allowed(c, s, allowed_ids, n_allowed, &any));
+    uint64_t P = 0;
+    TRY(run_chunk(c, s, c->text.as<uint8_t>(), n_bytes, c->doc_off.as<uint64_t>(), n_docs, 0, use_special && any, false, nullptr, 0,
+                  nullptr, &P, true));
+    HIPCHK(hipStreamSynchronize(s));
+    TRY(drain_events(c));
+    uint32_t* host = (uint32_t*)malloc((P + 1) * 4);
+    HIPCHK(hipMemcpy(host, c->pstart.p, (P + 1) * 4, hipMemcpyDeviceToHost));
+    *starts_out = host;
+    *n_out = P + 1;
+    return TK_OK;
+}
+
+extern "C" int tk_encode_ordinary(tk_core* c, const uint8_t* utf8, uint64_t len, uint32_t** tokens_out, uint64_t* n_tokens_out) {
+    uint64_t off[2] = {0, len};
+    return tk_encode_batch(c, utf8, off, 1, 0, nullptr, 0, tokens_out, n_tokens_out, nullptr);
+}
+
+extern "C" int tk_encode(tk_core* c, const uint8_t* utf8, uint64_t len, const uint32_t* allowed_ids, uint64_t n_allowed,
+                         uint32_t** tokens_out, uint64_t* n_tokens_out) {
+    uint64_t off[2] = {0, len};
+    return tk_encode_batch(c, utf8, off, 1, 1, allowed_ids, n_allowed, tokens_out, n_tokens_out, nullptr);
+}
+
+extern "C" int tk_encode_single_piece(tk_core* c, const uint8_t* piece, uint64_t len, uint32_t** tokens_out, uint64_t* n_tokens_out) {
+    if (!c) return fail(TK_VALUE_ERROR, "core is null");
+    if (len >= (4ull << 30) - 65536) return fail(TK_VALUE_ERROR, "piece too long");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    c->st_bytes = c->st_pieces = c->st_tokens = c->st_medium = c->st_long = 0;
+    TRY(ensure(c->text, len + 256));
+    if (len) HIPCHK(hipMemcpyAsync(c->text.p, piece, len, hipMemcpyHostToDevice, s));
+    HIPCHK(hipMemsetAsync((uint8_t*)c->text.p + len, 0, 128, s));
+    TRY(ensure(c->out_tokens, (len + 64) * 4));
+    uint64_t total = 0;
+    TRY(run_chunk(c, s, c->text.as<uint8_t>(), len, nullptr, 0, 0, false, true, c->out_tokens.as<uint32_t>(), 0, nullptr, &total));
+    HIPCHK(hipStreamSynchronize(s));
+    TRY(drain_events(c));
+    uint32_t* host = (uint32_t*)malloc((total ? total : 1) * 4);
+    if (total) HIPCHK(hipMemcpy(host, c->out_tokens.p, total * 4, hipMemcpyDeviceToHost));
+    *tokens_out = host;
+    *n_tokens_out = total;
+    return TK_OK;
+}
+
+extern "C" int tk_encode_single_token(tk_core* c, const uint8_t* piece, uint64_t len, uint32_t* token_out) {
+    if (!c) return fail(TK_VALUE_ERROR, "core is null");
+    uint32_t r = len < 0xFFFFFFFFull ? c->H.lookup_piece(piece, (uint32_t)len) : TK_RANK_MAX;
+    if (r == TK_RANK_MAX) {
+        const TkHostTables& H = c->H;
+        for (size_t k = 0; k + 1 < H.spec_off.size(); ++k)
+            if (H.spec_off[k + 1] - H.spec_off[k] == len && memcmp(H.spec_bytes.data() + H.spec_off[k], piece, len) == 0) r = H.spec_id[k];
+    }
+    if (r == TK_RANK_MAX) return fail(TK_KEY_ERROR, "token not found");
+    *token_out = r;
+    return TK_OK;
+}
+
+extern "C" int tk_decode_single_token_bytes(tk_core* c, uint32_t token, const uint8_t** bytes_out, uint64_t* len_out) {
+    if (!c) return fail(TK_VALUE_ERROR, "core is null");
+    auto it = c->H.decoder.find(token);
+    if (it != c->H.decoder.end()) {
+        *bytes_out = c->H.tok_bytes.data() + it->second.first;
+        *len_out = it->second.second;
+        return TK_OK;
+    }
+    it = c->H.spec_decoder.find(token);
+    if (it != c->H.spec_decoder.end()) {
+        *bytes_out = c->H.spec_bytes.data() + it->second.first;
+        *len_out = it->second.second;
+        return TK_OK;
+    }
+    return fail(TK_KEY_ERROR, std::to_string(token));
+}
+
+extern "C" int tk_decode_bytes(tk_core* c, const uint32_t* tokens, uint64_t n, uint8_t** bytes_out, uint64_t* len_out) {
+    if (!c) return fail(TK_VALUE_ERROR, "core is null");
+    std::string acc;
+    acc.reserve(n * 4);
+    for (uint64_t i = 0; i < n; ++i) {
+        const uint8_t* p;
+        uint64_t l;
+        if (tk_decode_single_token_bytes(c, tokens[i], &p, &l) != TK_OK)
+            return fail(TK_KEY_ERROR, "Invalid token for decoding: " + std::to_string(tokens[i]));
+        acc.append((const char*)p, l);
+    }
+    uint8_t* host = (uint8_t*)malloc(acc.size() ? acc.size() : 1);
+    memcpy(host, acc.data(), acc.size());
+    *bytes_out = host;
+    *len_out = acc.size();
+    return TK_OK;
+}
+
+extern "C" uint64_t tk_n_tokens(tk_core* c) { return c ? c->H.n_ranks : 0; }
+
+extern "C" int tk_sorted_token(tk_core* c, uint64_t i, const uint8_t** bytes_out, uint64_t* len_out, uint32_t* rank_out) {
+    if (!c || i >= c->H.sorted_ranks.size()) return fail(TK_VALUE_ERROR, "index out of range");
+    uint32_t r = c->H.sorted_ranks[i];
+    if (rank_out) *rank_out = r;
+    return tk_decode_single_token_bytes(c, r, bytes_out, len_out);
+}
+
+extern "C" void tk_free(void* p) { free(p); }
+
+extern "C" void tk_set_profiling(tk_core* c, int enabled) {
+    if (c) c->profiling = enabled != 0;
+}
+extern "C" void tk_reset_kernel_ms(tk_core* c) {
+    if (c) c->stats.clear();
+}
+extern "C" int tk_get_kernel_ms(tk_core* c, const char* name, double* ms_out, uint64_t* launches_out) {
+    if (!c) return TK_VALUE_ERROR;
+    auto it = c->stats.find(name);
+    if (it == c->stats.end()) {
+        if (ms_out) *ms_out = 0;
+        if (launches_out) *launches_out = 0;
+        return TK_KEY_ERROR;
+    }
+    if (ms_out) *ms_out = it->second.ms;
+    if (launches_out) *launches_out = it->second.launches;
+    return TK_OK;
+}
+extern "C" void tk_last_stats(tk_core* c, uint64_t* n_bytes, uint64_t* n_pieces, uint64_t* n_tokens, uint64_t* n_docs,
+                              uint64_t* n_medium, uint64_t* n_long) {
+    if (!c) return;
+    if (n_bytes) *n_bytes = c->st_bytes;
+    if (n_pieces) *n_pieces = c->st_pieces;
+    if (n_tokens) *n_tokens = c->st_tokens;
+    if (n_docs) *n_docs = c->st_docs;
+    if (n_medium) *n_medium = c->st_medium;
+    if (n_long) *n_long = c->st_long;
+}

@@ -1,0 +1,107 @@
+// Shared host/device definitions for the MI355X BPE encode path.
+//
+// Table layouts live in HBM and are read-only after tk_create(); they replace the reference's
+// `encoder: FxHashMap<Vec<u8>, Rank>` (src/lib.rs:321) with three exact structures:
+//   * piece table  : open-addressed {key64, rank, len} keyed by the piece's BYTES.  Keys of <= 8
+//                    bytes are stored inline (little-endian packed) and compared exactly; longer
+//                    keys store a 64-bit hash and are verified against the token-bytes blob, so a
+//                    hit is always an exact byte match (never a fingerprint alone).  This is the
+//                    whole-piece probe of src/lib.rs:367-368.
+//   * pair table   : open-addressed {(id_left << 32) | id_right -> id_merged} for every vocabulary
+//                    token T and every split T = A || B with A and B both vocabulary tokens.  Every
+//                    part that ever exists during _byte_pair_merge (src/lib.rs:140-196) is itself
+//                    a vocabulary token (single bytes are, and a merge only happens when the
+//                    concatenation is a key), and concatenation is unique, so probing this table
+//                    with the two part ids is exactly `ranks.get(&piece[a..c])` (lib.rs:150,165-167).
+//   * pair2 table  : direct 65536-entry table for the initial two-byte probes (lib.rs:150).
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define TK_HD __host__ __device__ __forceinline__
+#else
+#define TK_HD inline
+#endif
+
+#define TK_RANK_MAX 0xFFFFFFFFu
+
+enum { TK_PAT_R50K = 0, TK_PAT_CL100K = 1, TK_PAT_O200K = 2 };
+
+// Character classes (tools/gen_unicode_tables.py).  Stored one byte per TEXT byte; the low
+// nibble is the class, TK_F_HARD marks a position where a new haystack begins (document start,
+// special-token start, first byte after a special token): look-ahead from the left sees
+// end-of-text there, exactly like the slice `&text[start..end]` of src/lib.rs:405.
+enum {
+    TK_C_CONT = 0,  // UTF-8 continuation byte (or interior of a special token)
+    TK_C_NL = 1,
+    TK_C_SP = 2,
+    TK_C_WSO = 3,
+    TK_C_LU = 4,
+    TK_C_LL = 5,
+    TK_C_LC = 6,
+    TK_C_MK = 7,
+    TK_C_NU = 8,
+    TK_C_AP = 9,
+    TK_C_SL = 10,
+    TK_C_OT = 11,
+    TK_C_END = 12,
+    TK_C_SPEC = 13,  // first byte of an allowed special token occurrence
+};
+#define TK_F_HARD 0x80u
+#define TK_CB(c) (1u << (c))
+#define TK_M_WS (TK_CB(TK_C_NL) | TK_CB(TK_C_SP) | TK_CB(TK_C_WSO))
+#define TK_M_L (TK_CB(TK_C_LU) | TK_CB(TK_C_LL) | TK_CB(TK_C_LC))
+#define TK_M_OTHER (TK_CB(TK_C_MK) | TK_CB(TK_C_AP) | TK_CB(TK_C_SL) | TK_CB(TK_C_OT))
+#define TK_M_WORD (TK_M_L | TK_CB(TK_C_MK))
+#define TK_M_UPPERISH (TK_CB(TK_C_LU) | TK_CB(TK_C_LC) | TK_CB(TK_C_MK))
+#define TK_M_LOWERISH (TK_CB(TK_C_LL) | TK_CB(TK_C_LC) | TK_CB(TK_C_MK))
+
+struct TkPieceSlot {  // 16 bytes
+    uint64_t key;     // packed bytes (len <= 8) or tk_hash_bytes (len > 8); ~0 = empty
+    uint32_t rank;
+    uint32_t len;
+};
+struct TkPairSlot {  // 16 bytes
+    uint64_t key;    // (id_left << 32) | id_right; ~0 = empty
+    uint32_t rank;
+    uint32_t pad;
+};
+#define TK_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
+
+// Device-resident view of one encoding's tables.
+struct TkTables {
+    const uint8_t* uc_stage1;   // [0x1100]
+    const uint8_t* uc_stage2;   // [nblocks*256]
+    const TkPieceSlot* piece;   // [piece_mask+1]
+    const uint32_t* piece_off;  // [piece_mask+1] offset of the slot's key bytes in tok_bytes
+    uint64_t piece_mask;
+    const uint8_t* tok_bytes;   // all token byte strings, concatenated
+    const TkPairSlot* pair;     // [pair_mask+1]
+    uint64_t pair_mask;
+    const uint32_t* pair2;      // [65536]  rank of the 2-byte string (b0, b1) or TK_RANK_MAX
+    const uint32_t* byte_rank;  // [256]
+    // special tokens (sorted by bytes); spec_first marks possible first bytes
+    const uint8_t* spec_bytes;
+    const uint32_t* spec_off;  // [n_spec+1]
+    const uint32_t* spec_id;   // [n_spec]
+    uint32_t n_spec;
+    uint32_t spec_first[8];  // 256-bit set of first bytes
+    int pattern;
+};
+
+TK_HD uint64_t tk_mix64(uint64_t x) {
+    x ^= x >> 32;
+    x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    x *= 0xD6E8FEB86659FD93ull;
+    x ^= x >> 32;
+    return x;
+}
+
+TK_HD uint64_t tk_piece_slot_hash(uint64_t key, uint32_t len) { return tk_mix64(key + (uint64_t)len * 0x9E3779B97F4A7C15ull); }
+TK_HD uint64_t tk_pair_slot_hash(uint64_t key) { return tk_mix64(key * 0x9FB21C651E98DF25ull + 0x2545F4914F6CDD1Dull); }
+
+// streaming hash for keys longer than 8 bytes: fold 8-byte little-endian words (last one zero padded)
+TK_HD uint64_t tk_hash_step(uint64_t h, uint64_t w) { return tk_mix64(h ^ w) + 0x9E3779B97F4A7C15ull; }
+#define TK_HASH_SEED 0x243F6A8885A308D3ull

@@ -1,0 +1,419 @@
+// Device functions of the BPE encode path (host-compilable for the CPU-side unit tests of the
+// logic; the kernels in tk_kernels.hip are the only product callers).
+//
+//   tk_classify_*      UTF-8 decode + two-stage Unicode class table (what \p{L}, \p{N}, \p{M}, \s
+//                      mean to the regex at reference src/lib.rs:365)
+//   tk_piece_end       the pre-tokeniser: end of the regex match that starts at p, for the three
+//                      stock patterns (tiktoken_ext/openai_public.py:12-14, :89, :104-114)
+//   tk_certain_start   class pairs after which a piece boundary is certain whatever precedes
+//   tk_probe_piece / tk_probe_pair   exact table probes (src/lib.rs:367, :150, :165-167)
+#pragma once
+#include "tk_common.h"
+
+// ------------------------------------------------------------------------------------------
+// classification
+// ------------------------------------------------------------------------------------------
+TK_HD uint32_t tk_class_of_cp(const TkTables& T, uint32_t cp) {
+    if (cp > 0x10FFFFu) return TK_C_OT;
+    return T.uc_stage2[(uint32_t)T.uc_stage1[cp >> 8] * 256u + (cp & 255u)];
+}
+
+// Class of the text byte at `pos` (TK_C_CONT for continuation bytes).  `n` bounds the reads.
+TK_HD uint32_t tk_classify_text(const TkTables& T, const uint8_t* __restrict__ text, uint64_t pos, uint64_t n) {
+    uint32_t b = text[pos];
+    if (b < 0x80u) return tk_class_of_cp(T, b);
+    if ((b & 0xC0u) == 0x80u) return TK_C_CONT;
+    uint32_t len = b >= 0xF0u ? 4u : (b >= 0xE0u ? 3u : 2u);
+    if (pos + len > n) return TK_C_OT;  // truncated sequence (invalid UTF-8): treated as OTHER
+    uint32_t cp;
+    if (len == 2u)
+        cp = ((b & 0x1Fu) << 6) | (text[pos + 1] & 0x3Fu);
+    else if (len == 3u)
+        cp = ((b & 0x0Fu) << 12) | ((uint32_t)(text[pos + 1] & 0x3Fu) << 6) | (text[pos + 2] & 0x3Fu);
+    else
+        cp = ((b & 0x07u) << 18) | ((uint32_t)(text[pos + 1] & 0x3Fu) << 12) |
+             ((uint32_t)(text[pos + 2] & 0x3Fu) << 6) | (text[pos + 3] & 0x3Fu);
+    return tk_class_of_cp(T, cp);
+}
+
+TK_HD bool tk_bit(const uint32_t* __restrict__ bm, uint64_t pos) { return (bm[pos >> 5] >> (pos & 31u)) & 1u; }
+
+// Class byte (class | flags) of position pos < n, combining the text class with the break and
+// special-token bitmaps (either of the latter may be null).
+TK_HD uint32_t tk_class_byte(const TkTables& T, const uint8_t* __restrict__ text, uint64_t pos, uint64_t n,
+                             const uint32_t* __restrict__ brk, const uint32_t* __restrict__ spec_start,
+                             const uint32_t* __restrict__ spec_in) {
+    if (spec_in && tk_bit(spec_in, pos)) return TK_C_CONT;
+    if (spec_start && tk_bit(spec_start, pos)) return TK_C_SPEC | TK_F_HARD;
+    uint32_t c = tk_classify_text(T, text, pos, n);
+    if (c != TK_C_CONT && brk && tk_bit(brk, pos)) c |= TK_F_HARD;
+    return c;
+}
+
+// ------------------------------------------------------------------------------------------
+// Certain piece starts.  CERT[pat][a] is the set of classes b such that a char of class b that
+// follows a char of class a ALWAYS starts a new piece, whatever the left context.  Derived by
+// exhaustive comparison against Python `regex` (tests/test_oracle.py re-derives it), e.g. a
+// letter is never followed inside its piece by white space, and digits only ever share a piece
+// with digits.  They make work units independent: any scanner started at a certain start is in
+// phase with the sequential regex.
+// ------------------------------------------------------------------------------------------
+#define TK_ALLC (TK_CB(TK_C_NL) | TK_CB(TK_C_SP) | TK_CB(TK_C_WSO) | TK_M_L | TK_M_OTHER | TK_CB(TK_C_NU))
+TK_HD bool tk_certain_start(int pat, uint32_t a, uint32_t b) {
+    uint32_t m = 0;
+    const uint32_t WS3 = TK_M_WS, NU = TK_CB(TK_C_NU);
+    if (pat == TK_PAT_R50K) {
+        switch (a) {
+            case TK_C_NL: case TK_C_WSO: m = TK_M_L | TK_M_OTHER | NU; break;
+            case TK_C_LU: case TK_C_LL: case TK_C_LC: m = WS3 | TK_M_OTHER | NU; break;
+            case TK_C_MK: case TK_C_SL: case TK_C_OT: m = WS3 | TK_M_L | NU; break;
+            case TK_C_AP: m = WS3 | TK_CB(TK_C_LU) | TK_CB(TK_C_LC) | NU; break;
+            case TK_C_NU: m = TK_ALLC & ~NU; break;
+            default: m = 0;
+        }
+    } else if (pat == TK_PAT_CL100K) {
+        switch (a) {
+            case TK_C_NL: m = TK_M_L | TK_M_OTHER | NU; break;
+            case TK_C_SP: m = NU; break;
+            case TK_C_WSO: m = TK_M_OTHER | NU; break;
+            case TK_C_LU: case TK_C_LL: case TK_C_LC: m = WS3 | TK_M_OTHER | NU; break;
+            case TK_C_MK: case TK_C_AP: case TK_C_SL: case TK_C_OT: m = TK_CB(TK_C_SP) | TK_CB(TK_C_WSO) | NU; break;
+            case TK_C_NU: m = TK_ALLC & ~NU; break;
+            default: m = 0;
+        }
+    } else {
+        switch (a) {
+            case TK_C_NL: m = TK_M_L | TK_CB(TK_C_MK) | NU | TK_CB(TK_C_AP) | TK_CB(TK_C_OT); break;
+            case TK_C_SP: m = NU; break;
+            case TK_C_WSO: m = NU | TK_CB(TK_C_AP) | TK_CB(TK_C_SL) | TK_CB(TK_C_OT); break;
+            // (a lower-case letter followed by an upper-case one is NOT certain: "'lL" is a contraction)
+            case TK_C_LU: case TK_C_LL: case TK_C_LC: m = WS3 | NU | TK_CB(TK_C_SL) | TK_CB(TK_C_OT); break;
+            case TK_C_MK: case TK_C_AP: case TK_C_SL: case TK_C_OT: m = TK_CB(TK_C_SP) | TK_CB(TK_C_WSO) | NU; break;
+            case TK_C_NU: m = TK_ALLC & ~NU; break;
+            default: m = 0;
+        }
+    }
+    return (m >> b) & 1u;
+}
+
+// ------------------------------------------------------------------------------------------
+// The scanner.  `A` is an accessor: A::cls(pos) -> class byte of position pos (TK_C_END at and
+// beyond the end of the buffer), A::byte(pos) -> raw text byte.
+// ------------------------------------------------------------------------------------------
+template <class A>
+TK_HD uint32_t tk_la(A& a, uint64_t pos) {  // look-ahead class: a hard start looks like end-of-text
+    uint32_t c = a.cls(pos);
+    return (c & TK_F_HARD) ? (uint32_t)TK_C_END : (c & 15u);
+}
+
+template <class A>
+TK_HD uint64_t tk_next_char(A& a, uint64_t pos) {  // pos is a char start; returns the next char start
+    ++pos;
+    while (a.cls(pos) == TK_C_CONT) ++pos;
+    return pos;
+}
+
+template <class A>
+TK_HD uint64_t tk_run_end(A& a, uint64_t s, uint32_t mask) {
+    while ((mask >> tk_la(a, s)) & 1u) s = tk_next_char(a, s);
+    return s;
+}
+
+// byte length of a contraction whose apostrophe is at p, or 0 (case-insensitive forms fold
+// U+017F to 's', as Unicode simple case folding does in both regex engines)
+template <class A>
+TK_HD uint32_t tk_contraction_len(A& a, uint64_t p, bool ci) {
+    if (tk_la(a, p + 1) == TK_C_END) return 0;
+    uint32_t b1 = a.byte(p + 1);
+    if (ci) {
+        if (b1 == 0xC5u) return (a.cls(p + 2) == TK_C_CONT && a.byte(p + 2) == 0xBFu) ? 3u : 0u;
+        uint32_t al = b1 | 0x20u;
+        if (b1 >= 0x80u || al < 'a' || al > 'z') return 0;
+        if (al == 's' || al == 'd' || al == 'm' || al == 't') return 2;
+        if (tk_la(a, p + 2) == TK_C_END) return 0;
+        uint32_t b2 = a.byte(p + 2), bl = b2 | 0x20u;
+        if (b2 >= 0x80u) return 0;
+        if ((al == 'l' && bl == 'l') || (al == 'v' && bl == 'e') || (al == 'r' && bl == 'e')) return 3;
+        return 0;
+    }
+    if (b1 == 's' || b1 == 'd' || b1 == 'm' || b1 == 't') return 2;
+    if (tk_la(a, p + 2) == TK_C_END) return 0;
+    uint32_t b2 = a.byte(p + 2);
+    if ((b1 == 'l' && b2 == 'l') || (b1 == 'v' && b2 == 'e') || (b1 == 'r' && b2 == 'e')) return 3;
+    return 0;
+}
+
+// \s++$ | \s*[\r\n]+? | \s+(?!\S) | \s  -- p is a white-space char
+template <class A>
+TK_HD uint64_t tk_ws_tail(A& a, uint64_t p, int pat) {
+    uint64_t q = p, last_start = p, after_last_nl = 0;
+    uint32_t nchars = 0;
+    bool has_nl = false;
+    uint32_t c = a.cls(p) & 15u;  // p itself is a piece start: its own hard-start flag is not an end
+    for (;;) {
+        if (!((TK_M_WS >> c) & 1u)) break;
+        last_start = q;
+        q = tk_next_char(a, q);
+        ++nchars;
+        if (c == TK_C_NL) {
+            has_nl = true;
+            after_last_nl = q;
+        }
+        c = tk_la(a, q);
+    }
+    bool at_end = (c == TK_C_END);
+    if (pat != TK_PAT_O200K && at_end) return q;
+    if (pat != TK_PAT_R50K && has_nl) return after_last_nl;
+    if (at_end) return q;
+    if (nchars >= 2) return last_start;
+    return q;
+}
+
+// o200k letter alternatives from s (s is the first letter-ish char; its flags were already
+// handled by the caller)
+template <class A>
+TK_HD uint64_t tk_o200k_word(A& a, uint64_t s, uint32_t c_first) {
+    uint64_t r_end = s, after_last_c = 0;
+    bool has_c = false;
+    uint32_t c = c_first;
+    while ((TK_M_UPPERISH >> c) & 1u) {
+        r_end = tk_next_char(a, r_end);
+        if (c != TK_C_LU) {
+            has_c = true;
+            after_last_c = r_end;
+        }
+        c = tk_la(a, r_end);
+    }
+    uint64_t t_end = r_end;
+    while ((TK_M_LOWERISH >> c) & 1u) {
+        t_end = tk_next_char(a, t_end);
+        c = tk_la(a, t_end);
+    }
+    uint64_t e;
+    if (t_end > r_end) {
+        e = t_end;
+    } else if (has_c) {
+        e = after_last_c;
+        c = tk_la(a, e);
+    } else {
+        e = r_end;
+    }
+    if (c == TK_C_AP) e += tk_contraction_len(a, e, true);
+    return e;
+}
+
+template <class A>
+TK_HD uint64_t tk_digits3(A& a, uint64_t p) {
+    uint64_t e = tk_next_char(a, p);
+    for (int i = 0; i < 2; ++i) {
+        if (tk_la(a, e) != TK_C_NU) break;
+        e = tk_next_char(a, e);
+    }
+    return e;
+}
+
+// End (exclusive) of the piece that starts at p.  p must be a true piece start.
+template <class A>
+TK_HD uint64_t tk_piece_end(A& a, uint64_t p, int pat) {
+    uint32_t c = a.cls(p) & 15u;
+    uint64_t p1 = tk_next_char(a, p);
+    if (c == TK_C_SPEC) return p1;  // a whole special token (its interior bytes are TK_C_CONT)
+    uint32_t nxt = tk_la(a, p1);
+    if (pat == TK_PAT_R50K) {
+        if (c == TK_C_AP) {
+            uint32_t k = tk_contraction_len(a, p, false);
+            if (k) return p + k;
+        }
+        uint64_t s = p;
+        uint32_t k = c;
+        if (c == TK_C_SP && nxt != TK_C_END) {
+            s = p1;
+            k = nxt;
+        }
+        if ((TK_M_L >> k) & 1u) return tk_run_end(a, tk_next_char(a, s), TK_M_L);
+        if (k == TK_C_NU) return tk_run_end(a, tk_next_char(a, s), TK_CB(TK_C_NU));
+        if ((TK_M_OTHER >> k) & 1u) return tk_run_end(a, tk_next_char(a, s), TK_M_OTHER);
+        return tk_ws_tail(a, p, pat);
+    }
+    if (pat == TK_PAT_CL100K) {
+        if (c == TK_C_AP) {
+            uint32_t k = tk_contraction_len(a, p, true);
+            if (k) return p + k;
+        }
+        if (((TK_M_L >> c) & 1u) || (c != TK_C_NL && c != TK_C_NU && ((TK_M_L >> nxt) & 1u)))
+            return tk_run_end(a, p1, TK_M_L);
+        if (c == TK_C_NU) return tk_digits3(a, p);
+        uint64_t s = p;
+        uint32_t k = c;
+        if (c == TK_C_SP && nxt != TK_C_END) {
+            s = p1;
+            k = nxt;
+        }
+        if ((TK_M_OTHER >> k) & 1u) {
+            uint64_t e = tk_run_end(a, tk_next_char(a, s), TK_M_OTHER);
+            return tk_run_end(a, e, TK_CB(TK_C_NL));
+        }
+        return tk_ws_tail(a, p, pat);
+    }
+    // o200k
+    if ((TK_M_WORD >> c) & 1u) return tk_o200k_word(a, p, c);
+    if (c != TK_C_NL && c != TK_C_NU && ((TK_M_WORD >> nxt) & 1u)) return tk_o200k_word(a, p1, nxt);
+    if (c == TK_C_NU) return tk_digits3(a, p);
+    uint64_t s = p;
+    uint32_t k = c;
+    if (c == TK_C_SP && nxt != TK_C_END) {
+        s = p1;
+        k = nxt;
+    }
+    if ((TK_M_OTHER >> k) & 1u) {
+        uint64_t e = tk_run_end(a, tk_next_char(a, s), TK_M_OTHER);
+        return tk_run_end(a, e, TK_CB(TK_C_NL) | TK_CB(TK_C_SL));
+    }
+    return tk_ws_tail(a, p, pat);
+}
+
+// ------------------------------------------------------------------------------------------
+// table probes
+// ------------------------------------------------------------------------------------------
+// Exact bytes -> rank probe.  `key` = packed bytes (len <= 8) or tk hash (len > 8); for len > 8
+// the candidate is verified byte for byte against the token blob through `cmp(off)`.
+template <class Verify>
+TK_HD uint32_t tk_probe_piece(const TkTables& T, uint64_t key, uint32_t len, Verify verify) {
+    uint64_t i = tk_piece_slot_hash(key, len) & T.piece_mask;
+    for (;;) {
+        TkPieceSlot s = T.piece[i];
+        if (s.key == TK_EMPTY_KEY && s.len == 0u) return TK_RANK_MAX;
+        if (s.key == key && s.len == len) {
+            if (len <= 8u || verify(T.piece_off[i])) return s.rank;
+        }
+        i = (i + 1) & T.piece_mask;
+    }
+}
+
+TK_HD uint32_t tk_probe_pair(const TkTables& T, uint32_t a, uint32_t b) {
+    uint64_t key = ((uint64_t)a << 32) | b;
+    uint64_t i = tk_pair_slot_hash(key) & T.pair_mask;
+    for (;;) {
+        TkPairSlot s = T.pair[i];
+        if (s.key == key) return s.rank;
+        if (s.key == TK_EMPTY_KEY) return TK_RANK_MAX;
+        i = (i + 1) & T.pair_mask;
+    }
+}
+
+// 8 text bytes starting at byte offset `pos` (little-endian), from a buffer that is readable
+// for 16 bytes past `pos` (callers pad).  Built from two aligned 8-byte loads.
+TK_HD uint64_t tk_load8(const uint8_t* __restrict__ text, uint64_t pos) {
+    uintptr_t a = (uintptr_t)(text + pos);
+    const uint64_t* w = (const uint64_t*)(a & ~(uintptr_t)7);
+    uint32_t sh = (uint32_t)(a & 7u) * 8u;
+    uint64_t lo = w[0];
+    if (sh == 0) return lo;
+    uint64_t hi = w[1];
+    return (lo >> sh) | (hi << (64u - sh));
+}
+
+TK_HD uint64_t tk_mask_low_bytes(uint64_t w, uint32_t nbytes) {  // keep the low nbytes (1..8)
+    return nbytes >= 8u ? w : (w & ((1ull << (nbytes * 8u)) - 1ull));
+}
+
+// key of text[pos .. pos+len) (same function as host tk_key_of_bytes)
+TK_HD uint64_t tk_key_of_text(const uint8_t* __restrict__ text, uint64_t pos, uint32_t len) {
+    if (len <= 8u) return tk_mask_low_bytes(tk_load8(text, pos), len);
+    uint64_t h = TK_HASH_SEED;
+    uint32_t i = 0;
+    for (; i + 8u <= len; i += 8u) h = tk_hash_step(h, tk_load8(text, pos + i));
+    if (i < len) h = tk_hash_step(h, tk_mask_low_bytes(tk_load8(text, pos + i), len - i));
+    if (h == TK_EMPTY_KEY) h = 0;
+    return h;
+}
+
+// exact compare of text[pos..pos+len) with tok_bytes[off..off+len)
+TK_HD bool tk_equal_bytes(const uint8_t* __restrict__ text, uint64_t pos, const uint8_t* __restrict__ blob, uint32_t off,
+                          uint32_t len) {
+    uint32_t i = 0;
+    for (; i + 8u <= len; i += 8u)
+        if (tk_load8(text, pos + i) != tk_load8(blob, (uint64_t)off + i)) return false;
+    if (i < len) {
+        uint32_t r = len - i;
+        if (tk_mask_low_bytes(tk_load8(text, pos + i), r) != tk_mask_low_bytes(tk_load8(blob, (uint64_t)off + i), r)) return false;
+    }
+    return true;
+}
+
+// Whole-piece probe of text[pos..pos+len)  (src/lib.rs:367)
+TK_HD uint32_t tk_lookup_text_piece(const TkTables& T, const uint8_t* __restrict__ text, uint64_t pos, uint32_t len) {
+    uint64_t key = tk_key_of_text(text, pos, len);
+    return tk_probe_piece(T, key, len, [&](uint32_t off) { return tk_equal_bytes(text, pos, T.tok_bytes, off, len); });
+}
+
+// ------------------------------------------------------------------------------------------
+// bit helpers usable from host test builds as well
+// ------------------------------------------------------------------------------------------
+#if defined(__HIP_DEVICE_COMPILE__)
+TK_HD int tk_ffs32(uint32_t v) { return __ffs((int)v); }
+TK_HD int tk_clz32(uint32_t v) { return __clz((int)v); }
+TK_HD int tk_popc32(uint32_t v) { return __popc(v); }
+#else
+TK_HD int tk_ffs32(uint32_t v) { return __builtin_ffs((int)v); }
+TK_HD int tk_clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
+TK_HD int tk_popc32(uint32_t v) { return __builtin_popcount(v); }
+#endif
+
+// byte_pair_merge (src/lib.rs:140-196) for a piece of n <= TK_LANE_MAX bytes, one lane per piece.
+// parts are the byte positions still alive (bit k of `alive`); s_id[k]/s_rk[k] hold the id of the
+// part starting at k and the rank of the pair (part k, next part).  Returns the token count and
+// writes the tokens (ids of the surviving parts, left to right) to out[].
+template <int STRIDE>
+TK_HD uint32_t tk_lane_merge(const TkTables& T, const uint8_t* __restrict__ text, uint64_t s, uint32_t n,
+                                                  uint32_t* s_id, uint32_t* s_rk, uint32_t* out1, uint32_t* __restrict__ out) {
+    uint64_t w0 = tk_load8(text, s), w1 = n > 8 ? tk_load8(text, s + 8) : 0;
+    uint32_t prev_b = (uint32_t)(w0 & 0xFF);
+    for (uint32_t k = 0; k < n; ++k) {
+        uint32_t nb = 0;
+        if (k + 1 < n) nb = (uint32_t)(((k + 1 < 8 ? w0 >> ((k + 1) * 8) : w1 >> ((k + 1 - 8) * 8))) & 0xFF);
+        s_id[k * STRIDE] = T.byte_rank[prev_b];
+        s_rk[k * STRIDE] = (k + 1 < n) ? T.pair2[(prev_b << 8) | nb] : TK_RANK_MAX;
+        prev_b = nb;
+    }
+    uint32_t alive = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+    for (;;) {
+        uint32_t best = TK_RANK_MAX, bi = 0;
+        for (uint32_t k = 0; k + 1 < n; ++k) {
+            uint32_t r = s_rk[k * STRIDE];
+            if (r < best) {  // strict '<' keeps the leftmost minimum (lib.rs:151,190)
+                best = r;
+                bi = k;
+            }
+        }
+        if (best == TK_RANK_MAX) break;
+        uint32_t i = bi;
+        uint32_t after = alive & ~((2u << i) - 1u);  // alive positions > i
+        uint32_t j = tk_ffs32(after) - 1;                // the part being absorbed (exists: rank was valid)
+        alive &= ~(1u << j);
+        s_id[i * STRIDE] = best;
+        s_rk[j * STRIDE] = TK_RANK_MAX;
+        after &= ~(1u << j);
+        uint32_t before = alive & ((1u << i) - 1u);
+        uint32_t r_i = TK_RANK_MAX, r_p = TK_RANK_MAX;
+        int pp = before ? 31 - tk_clz32(before) : -1;
+        if (after) r_i = tk_probe_pair(T, best, s_id[(tk_ffs32(after) - 1) * STRIDE]);
+        if (pp >= 0) r_p = tk_probe_pair(T, s_id[pp * STRIDE], best);
+        s_rk[i * STRIDE] = r_i;
+        if (pp >= 0) s_rk[pp * STRIDE] = r_p;
+    }
+    uint32_t cnt = tk_popc32(alive);
+    if (cnt == 1) {
+        *out1 = s_id[0];
+    } else {
+        uint32_t t = 0;
+        uint32_t m = alive;
+        while (m) {
+            uint32_t k = tk_ffs32(m) - 1;
+            m &= m - 1;
+            out[t++] = s_id[k * STRIDE];
+        }
+    }
+    return cnt;
+}
+

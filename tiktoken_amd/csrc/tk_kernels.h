@@ -1,0 +1,617 @@
+// HIP kernels of the MI355X BPE encode path (gfx950, wave64).  Included by tk_api.hip only.
+//
+// Pipeline (one launch sequence per <= 4 GiB chunk of packed documents, all intermediates in HBM):
+//
+//   tk_k_mark_docs      document starts -> break bitmap                      (core.py:174-176: documents
+//                                                                              never interact)
+//   tk_k_spec_*         (encode() path only) special-token occurrences -> start / interior / break
+//                       bitmaps                                               (src/lib.rs:386-402)
+//   tk_k_pretok         regex pre-tokenisation -> piece-start bitmap          (src/lib.rs:365)
+//   tk_k_count/_scan/_emit   bitmap -> packed piece offsets
+//   tk_k_lookup         whole-piece probe + per-lane byte_pair_merge of short pieces
+//                                                                              (src/lib.rs:367-369, 140-196)
+//   tk_k_merge_wave     one wavefront per 17..64-byte piece, min-rank by wave reduction
+//   tk_k_merge_long     one wavefront per longer piece, 64-ary min tree in HBM scratch
+//                                                                              (same result as lib.rs:47-138)
+//   tk_k_scan_*         token counts -> token offsets
+//   tk_k_gather         tokens into their final packed order; tk_k_docoff per-document offsets
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "tk_device.h"
+
+#define TK_TILE 4096
+#define TK_HALO_L 4
+#define TK_HALO_R 252
+#define TK_WIN (TK_HALO_L + TK_TILE + TK_HALO_R)
+#define TK_LANE_MAX 16   // longest piece merged by a single lane
+#define TK_WAVE_MAX 64   // longest piece merged by one wavefront in registers
+#define TK_PPT 4         // pieces per thread per block iteration in tk_k_lookup
+
+// counters (device uint32 array)
+enum { TK_CNT_B = 0, TK_CNT_C = 1, TK_CNT_CBYTES = 2, TK_CNT_CLEVELS = 3, TK_CNT_N = 8 };
+
+// ------------------------------------------------------------------------------------------
+// wave helpers (wave64)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ uint32_t tk_wave_min_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint32_t w = __shfl_xor(v, o, 64);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint64_t tk_wave_min_u64(uint64_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        uint64_t w = __shfl_xor(v, o, 64);
+        v = w < v ? w : v;
+    }
+    return v;
+}
+__device__ __forceinline__ uint32_t tk_wave_sum_u32(uint32_t v) {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+}
+// inclusive prefix sum across the wave
+__device__ __forceinline__ uint32_t tk_wave_scan_u32(uint32_t v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        uint32_t w = __shfl_up(v, o, 64);
+        if (lane >= o) v += w;
+    }
+    return v;
+}
+// block-wide (256 threads) exclusive scan; returns the exclusive prefix, *total gets the block sum
+__device__ __forceinline__ uint32_t tk_block_exscan_256(uint32_t v, uint32_t* total, uint32_t* sh /*[8]*/) {
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t inc = tk_wave_scan_u32(v, lane);
+    if (lane == 63) sh[wid] = inc;
+    __syncthreads();
+    uint32_t base = 0, tot = 0;
+#pragma unroll
+    for (int w = 0; w < 4; ++w) {
+        uint32_t s = sh[w];
+        if (w < wid) base += s;
+        tot += s;
+    }
+    __syncthreads();
+    *total = tot;
+    return base + inc - v;
+}
+
+// ------------------------------------------------------------------------------------------
+// document starts -> bitmaps
+// ------------------------------------------------------------------------------------------
+__global__ void tk_k_mark_docs(const uint64_t* __restrict__ doc_off, uint64_t n_docs, uint64_t base, uint64_t n,
+                               uint32_t* __restrict__ brk, uint32_t* __restrict__ docb) {
+    for (uint64_t d = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; d < n_docs; d += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t pos = doc_off[d] - base;
+        if (pos < n) {
+            atomicOr(&brk[pos >> 5], 1u << (pos & 31));
+            if (docb) atomicOr(&docb[pos >> 5], 1u << (pos & 31));
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// special tokens (encode() with allowed_special; src/lib.rs:386-402, 426-434)
+// ------------------------------------------------------------------------------------------
+// Longest allowed special token that matches at text[pos..] without crossing a document start.
+// Returns its length (0 = none) and index.
+__device__ __forceinline__ uint32_t tk_special_at(const TkTables& T, const uint8_t* __restrict__ text, uint64_t pos, uint64_t n,
+                                                  const uint8_t* __restrict__ allowed, const uint32_t* __restrict__ docb,
+                                                  uint32_t* idx_out) {
+    uint32_t b0 = text[pos];
+    if (!((T.spec_first[b0 >> 5] >> (b0 & 31)) & 1u)) return 0;
+    uint32_t best = 0, bi = 0;
+    for (uint32_t k = 0; k < T.n_spec; ++k) {
+        if (allowed && !allowed[k]) continue;
+        uint32_t o = T.spec_off[k], len = T.spec_off[k + 1] - o;
+        if (len <= best || pos + len > n || T.spec_bytes[o] != b0) continue;
+        bool ok = true;
+        for (uint32_t i = 1; i < len && ok; ++i) ok = (text[pos + i] == T.spec_bytes[o + i]) && !(docb && tk_bit(docb, pos + i));
+        if (ok) {
+            best = len;
+            bi = k;
+        }
+    }
+    *idx_out = bi;
+    return best;
+}
+
+__global__ void tk_k_spec_cand(TkTables T, const uint8_t* __restrict__ text, uint64_t n, const uint8_t* __restrict__ allowed,
+                               const uint32_t* __restrict__ docb, uint32_t* __restrict__ cand) {
+    for (uint64_t pos = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; pos < n; pos += (uint64_t)gridDim.x * blockDim.x) {
+        uint32_t idx;
+        if (tk_special_at(T, text, pos, n, allowed, docb, &idx)) atomicOr(&cand[pos >> 5], 1u << (pos & 31));
+    }
+}
+
+// Resolve overlapping candidates exactly as a left-to-right search would (src/lib.rs:389-401,432):
+// a candidate is taken iff the greedy non-overlapping walk from the head of its overlap cluster
+// lands on it.
+__global__ void tk_k_spec_resolve(TkTables T, const uint8_t* __restrict__ text, uint64_t n, const uint8_t* __restrict__ allowed,
+                                  const uint32_t* __restrict__ docb, const uint32_t* __restrict__ cand, uint32_t max_len,
+                                  uint32_t* __restrict__ spec_start, uint32_t* __restrict__ spec_in, uint32_t* __restrict__ brk) {
+    for (uint64_t pos = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; pos < n; pos += (uint64_t)gridDim.x * blockDim.x) {
+        if (!tk_bit(cand, pos)) continue;
+        uint32_t idx;
+        // head of the overlap cluster: walk left while some earlier candidate's span covers `h`
+        uint64_t h = pos;
+        for (;;) {
+            bool moved = false;
+            uint64_t lo = h >= (uint64_t)(max_len - 1) ? h - (max_len - 1) : 0;
+            for (uint64_t j = h; j-- > lo;) {
+                if (tk_bit(cand, j) && j + tk_special_at(T, text, j, n, allowed, docb, &idx) > h) {
+                    h = j;
+                    moved = true;
+                    break;
+                }
+            }
+            if (!moved) break;
+        }
+        // greedy walk from the head
+        uint64_t cur = h;
+        bool taken = false;
+        while (cur <= pos) {
+            if (cur == pos) {
+                taken = true;
+                break;
+            }
+            uint64_t nx = cur + tk_special_at(T, text, cur, n, allowed, docb, &idx);
+            while (nx <= pos && !tk_bit(cand, nx)) ++nx;
+            cur = nx;
+        }
+        if (!taken) continue;
+        uint32_t len = tk_special_at(T, text, pos, n, allowed, docb, &idx);
+        atomicOr(&spec_start[pos >> 5], 1u << (pos & 31));
+        atomicOr(&brk[pos >> 5], 1u << (pos & 31));
+        for (uint64_t j = pos + 1; j < pos + len; ++j) atomicOr(&spec_in[j >> 5], 1u << (j & 31));
+        if (pos + len < n) atomicOr(&brk[(pos + len) >> 5], 1u << ((pos + len) & 31));
+    }
+}
+
+// id of the special token whose bytes are text[pos..pos+len)
+__device__ __forceinline__ uint32_t tk_special_id(const TkTables& T, const uint8_t* __restrict__ text, uint64_t pos, uint32_t len) {
+    for (uint32_t k = 0; k < T.n_spec; ++k) {
+        uint32_t o = T.spec_off[k];
+        if (T.spec_off[k + 1] - o != len) continue;
+        bool ok = true;
+        for (uint32_t i = 0; i < len && ok; ++i) ok = text[pos + i] == T.spec_bytes[o + i];
+        if (ok) return T.spec_id[k];
+    }
+    return TK_RANK_MAX;
+}
+
+// ------------------------------------------------------------------------------------------
+// pre-tokenisation
+// ------------------------------------------------------------------------------------------
+struct TkWinAcc {
+    const uint8_t* win;  // LDS window of class bytes
+    int64_t base;        // text position of win[0]
+    const TkTables* T;
+    const uint8_t* text;
+    uint64_t n;
+    const uint32_t *brk, *ss, *si;
+    __device__ __forceinline__ uint32_t cls(uint64_t pos) const {
+        if (pos >= n) return TK_C_END;
+        int64_t r = (int64_t)pos - base;
+        if (r >= 0 && r < TK_WIN) return win[r];
+        return tk_class_byte(*T, text, pos, n, brk, ss, si);  // beyond the window: classify from HBM
+    }
+    __device__ __forceinline__ uint32_t byte(uint64_t pos) const { return text[pos]; }
+};
+
+// One workgroup per 4 KiB tile.  Class bytes of the tile (+ a 4-byte left and 252-byte right halo)
+// are staged in LDS; every char that is a *certain* piece start (tk_certain_start) runs the
+// sequential scanner from there until it reaches the next certain start, marking the uncertain
+// boundaries it finds on the way.  Certain starts are dense in real text (every word), so a lane
+// typically evaluates one piece.  Units never communicate: the rule only needs the previous char.
+__global__ __launch_bounds__(256) void tk_k_pretok(TkTables T, const uint8_t* __restrict__ text, uint64_t n,
+                                                   const uint32_t* __restrict__ brk, const uint32_t* __restrict__ ss,
+                                                   const uint32_t* __restrict__ si, uint32_t* __restrict__ starts) {
+    __shared__ uint8_t win[TK_WIN];
+    __shared__ uint32_t bits[TK_TILE / 32];
+    const uint64_t tile_start = (uint64_t)blockIdx.x * TK_TILE;
+    const int64_t base = (int64_t)tile_start - TK_HALO_L;
+    for (int w = threadIdx.x; w < TK_WIN; w += 256) {
+        int64_t gp = base + w;
+        uint32_t c = TK_C_END;
+        if (gp >= 0 && (uint64_t)gp < n) c = tk_class_byte(T, text, (uint64_t)gp, n, brk, ss, si);
+        win[w] = (uint8_t)c;
+    }
+    if (threadIdx.x < TK_TILE / 32) bits[threadIdx.x] = 0;
+    __syncthreads();
+    TkWinAcc acc{win, base, &T, text, n, brk, ss, si};
+    const int pat = T.pattern;
+    for (int k = 0; k < TK_TILE / 256; ++k) {
+        uint32_t il = threadIdx.x + k * 256;
+        uint64_t gp = tile_start + il;
+        if (gp >= n) break;
+        uint32_t c = win[TK_HALO_L + il];
+        if ((c & 15u) == TK_C_CONT) continue;
+        bool certain = (c & TK_F_HARD) != 0;
+        if (!certain) {
+            int j = (int)(TK_HALO_L + il) - 1;
+            while (j > 0 && win[j] == TK_C_CONT) --j;
+            certain = tk_certain_start(pat, win[j] & 15u, c & 15u);
+        }
+        if (!certain) continue;
+        atomicOr(&bits[il >> 5], 1u << (il & 31));
+        uint64_t p = gp;
+        for (;;) {
+            uint64_t e = tk_piece_end(acc, p, pat);
+            if (e <= p) e = tk_next_char(acc, p);  // defensive; cannot happen
+            if (e >= n) break;
+            uint32_t ce = acc.cls(e);
+            if (ce & TK_F_HARD) break;
+            uint64_t j = e - 1;
+            while (acc.cls(j) == TK_C_CONT) --j;
+            if (tk_certain_start(pat, acc.cls(j) & 15u, ce & 15u)) break;
+            if (e < tile_start + TK_TILE)
+                atomicOr(&bits[(uint32_t)(e - tile_start) >> 5], 1u << ((uint32_t)(e - tile_start) & 31));
+            else
+                atomicOr(&starts[e >> 5], 1u << (e & 31));
+            p = e;
+        }
+    }
+    __syncthreads();
+    if (threadIdx.x < TK_TILE / 32) {
+        uint32_t v = bits[threadIdx.x];
+        uint64_t wi = tile_start / 32 + threadIdx.x;
+        if (v) atomicOr(&starts[wi], v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// bitmap -> piece offsets
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tk_k_count(const uint32_t* __restrict__ starts, uint64_t nwords, uint32_t* __restrict__ blockcnt) {
+    __shared__ uint32_t sh[8];
+    uint64_t w = blockIdx.x * 256ull + threadIdx.x;
+    uint32_t c = w < nwords ? __popc(starts[w]) : 0;
+    c = tk_wave_sum_u32(c);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0) blockcnt[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+// single-workgroup exclusive scan of a (small) uint32 array in place; total -> total_out[0] (u64)
+__global__ __launch_bounds__(1024) void tk_k_scan_small(uint32_t* __restrict__ a, uint64_t n, uint64_t* __restrict__ total_out) {
+    __shared__ uint32_t wsum[16];
+    __shared__ uint64_t carry_sh;
+    if (threadIdx.x == 0) carry_sh = 0;
+    __syncthreads();
+    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    for (uint64_t base = 0; base < n; base += 1024) {
+        uint64_t i = base + threadIdx.x;
+        uint32_t v = i < n ? a[i] : 0;
+        uint32_t inc = tk_wave_scan_u32(v, lane);
+        if (lane == 63) wsum[wid] = inc;
+        __syncthreads();
+        uint32_t wbase = 0, tot = 0;
+        for (int w = 0; w < 16; ++w) {
+            if (w < wid) wbase += wsum[w];
+            tot += wsum[w];
+        }
+        uint64_t carry = carry_sh;
+        if (i < n) a[i] = (uint32_t)(carry + wbase + inc - v);
+        __syncthreads();
+        if (threadIdx.x == 0) carry_sh = carry + tot;
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) total_out[0] = carry_sh;
+}
+
+__global__ __launch_bounds__(256) void tk_k_emit(const uint32_t* __restrict__ starts, uint64_t nwords, const uint32_t* __restrict__ blockpre,
+                                                 uint32_t* __restrict__ pstart, uint64_t P, uint64_t n) {
+    __shared__ uint32_t sh[8];
+    uint64_t w = blockIdx.x * 256ull + threadIdx.x;
+    uint32_t v = w < nwords ? starts[w] : 0;
+    uint32_t tot;
+    uint32_t ex = tk_block_exscan_256(__popc(v), &tot, sh);
+    uint64_t o = (uint64_t)blockpre[blockIdx.x] + ex;
+    while (v) {
+        uint32_t b = __ffs(v) - 1;
+        v &= v - 1;
+        pstart[o++] = (uint32_t)(w * 32 + b);
+    }
+    if (blockIdx.x == 0 && threadIdx.x == 0) pstart[P] = (uint32_t)n;
+}
+
+// ------------------------------------------------------------------------------------------
+// whole-piece probe + per-lane merge of short pieces
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ pstart,
+                                                   uint64_t P, const uint32_t* __restrict__ ss, uint32_t* __restrict__ tok1,
+                                                   uint32_t* __restrict__ cnt, uint32_t* __restrict__ staging,
+                                                   uint32_t* __restrict__ listB, uint32_t* __restrict__ listC,
+                                                   uint32_t* __restrict__ counters) {
+    __shared__ uint32_t q[256 * TK_PPT];
+    __shared__ uint32_t qn;
+    __shared__ uint32_t s_id[TK_LANE_MAX * 256];
+    __shared__ uint32_t s_rk[TK_LANE_MAX * 256];
+    const uint32_t tid = threadIdx.x;
+    for (uint64_t base = (uint64_t)blockIdx.x * (256 * TK_PPT); base < P; base += (uint64_t)gridDim.x * (256 * TK_PPT)) {
+        if (tid == 0) qn = 0;
+        __syncthreads();
+#pragma unroll
+        for (int k = 0; k < TK_PPT; ++k) {
+            uint64_t p = base + (uint64_t)k * 256 + tid;
+            if (p >= P) continue;
+            uint32_t s = pstart[p], len = pstart[p + 1] - s;
+            if (ss && tk_bit(ss, s)) {
+                tok1[p] = tk_special_id(T, text, s, len);
+                cnt[p] = 1;
+                continue;
+            }
+            uint32_t r = tk_lookup_text_piece(T, text, s, len);
+            if (r != TK_RANK_MAX) {
+                tok1[p] = r;
+                cnt[p] = 1;
+            } else if (len <= TK_LANE_MAX) {
+                q[atomicAdd(&qn, 1u)] = (uint32_t)(p - base);
+            } else if (len <= TK_WAVE_MAX) {
+                listB[atomicAdd(&counters[TK_CNT_B], 1u)] = (uint32_t)p;
+            } else {
+                // scratch for the long path: 4 uint32 per byte + the 64-ary min-tree levels
+                uint32_t lv = 0, c = len;
+                do {
+                    c = (c + 63) >> 6;
+                    lv += c;
+                } while (c > 64);
+                uint32_t i = atomicAdd(&counters[TK_CNT_C], 1u);
+                listC[3 * (uint64_t)i] = (uint32_t)p;
+                listC[3 * (uint64_t)i + 1] = atomicAdd(&counters[TK_CNT_CBYTES], len);
+                listC[3 * (uint64_t)i + 2] = atomicAdd(&counters[TK_CNT_CLEVELS], lv);
+            }
+        }
+        __syncthreads();
+        const uint32_t nq = qn;
+        for (uint32_t r0 = 0; r0 < nq; r0 += 256) {
+            if (r0 + tid < nq) {
+                uint64_t p = base + q[r0 + tid];
+                uint32_t s = pstart[p], len = pstart[p + 1] - s;
+                uint32_t one = 0;
+                uint32_t c = tk_lane_merge<256>(T, text, s, len, s_id + tid, s_rk + tid, &one, staging + s);
+                cnt[p] = c;
+                if (c == 1) tok1[p] = one;
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// one wavefront per piece of 17..64 bytes: lane k owns byte k
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tk_k_merge_wave(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ pstart,
+                                                       const uint32_t* __restrict__ listB, uint32_t nB, uint32_t* __restrict__ tok1,
+                                                       uint32_t* __restrict__ cnt, uint32_t* __restrict__ staging) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+    for (uint32_t w = wave; w < nB; w += nwaves) {
+        uint32_t p = listB[w];
+        uint32_t s = pstart[p], n = pstart[p + 1] - s;
+        uint32_t b0 = (uint32_t)lane < n ? text[s + lane] : 0, b1 = (uint32_t)lane + 1 < n ? text[s + lane + 1] : 0;
+        uint32_t id = T.byte_rank[b0];
+        uint32_t rk = (uint32_t)lane + 1 < n ? T.pair2[(b0 << 8) | b1] : TK_RANK_MAX;
+        uint64_t alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+        for (;;) {
+            uint32_t m = tk_wave_min_u32(rk);
+            if (m == TK_RANK_MAX) break;
+            uint64_t bal = __ballot(rk == m);
+            int i = __ffsll((unsigned long long)bal) - 1;  // leftmost minimum
+            uint64_t after = alive & ~((2ull << i) - 1ull);
+            int j = __ffsll((unsigned long long)after) - 1;
+            alive &= ~(1ull << j);
+            after &= ~(1ull << j);
+            uint64_t before = alive & ((1ull << i) - 1ull);
+            int nn = after ? __ffsll((unsigned long long)after) - 1 : -1;
+            int pp = before ? 63 - __clzll((unsigned long long)before) : -1;
+            if (lane == i) id = m;
+            if (lane == j) rk = TK_RANK_MAX;
+            uint32_t id_nn = __shfl(id, nn < 0 ? 0 : nn, 64), id_pp = __shfl(id, pp < 0 ? 0 : pp, 64);
+            if (lane == i) rk = nn >= 0 ? tk_probe_pair(T, m, id_nn) : TK_RANK_MAX;
+            if (lane == pp) rk = tk_probe_pair(T, id_pp, m);
+        }
+        uint32_t c = __popcll(alive);
+        bool mine = (alive >> lane) & 1ull;
+        uint32_t t = __popcll(alive & ((1ull << lane) - 1ull));
+        if (c == 1) {
+            if (lane == 0) {
+                tok1[p] = id;
+                cnt[p] = 1;
+            }
+        } else {
+            if (mine) staging[s + t] = id;
+            if (lane == 0) cnt[p] = c;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// one wavefront per piece longer than 64 bytes.  Parts form a doubly linked list in HBM scratch;
+// a 64-ary tree of (rank << 32 | position) minima gives the lowest-rank, leftmost pair in one
+// wave reduction over the root level; each merge touches <= 3 leaves and re-reduces their
+// ancestors.  Same result as the heap formulation of src/lib.rs:47-138 (ordered by (rank, start)).
+// ------------------------------------------------------------------------------------------
+#define TK_MAX_LEVELS 6
+__global__ __launch_bounds__(256) void tk_k_merge_long(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ pstart,
+                                                       const uint32_t* __restrict__ listC, uint32_t nC, uint32_t* __restrict__ g_id,
+                                                       uint32_t* __restrict__ g_rk, uint32_t* __restrict__ g_nx, uint32_t* __restrict__ g_pv,
+                                                       uint64_t* __restrict__ g_lv, uint32_t* __restrict__ tok1, uint32_t* __restrict__ cnt,
+                                                       uint32_t* __restrict__ staging) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+    for (uint32_t w = wave; w < nC; w += nwaves) {
+        const uint32_t p = listC[3 * (uint64_t)w];
+        const uint32_t s = pstart[p], n = pstart[p + 1] - s;
+        uint32_t* id = g_id + listC[3 * (uint64_t)w + 1];
+        uint32_t* rk = g_rk + listC[3 * (uint64_t)w + 1];
+        uint32_t* nx = g_nx + listC[3 * (uint64_t)w + 1];
+        uint32_t* pv = g_pv + listC[3 * (uint64_t)w + 1];
+        uint64_t* lv = g_lv + listC[3 * (uint64_t)w + 2];
+        // level geometry: cntl[0] = n leaves (rk), cntl[l] = ceil(cntl[l-1]/64); the top level has <= 64 entries
+        uint32_t cntl[TK_MAX_LEVELS + 1], offl[TK_MAX_LEVELS + 1];
+        int nl = 0;
+        cntl[0] = n;
+        offl[0] = 0;
+        {
+            uint32_t c = n, o = 0;
+            do {
+                c = (c + 63) >> 6;
+                ++nl;
+                cntl[nl] = c;
+                offl[nl] = o;
+                o += c;
+            } while (c > 64);
+        }
+        for (uint32_t k = lane; k < n; k += 64) {
+            uint32_t b0 = text[s + k];
+            id[k] = T.byte_rank[b0];
+            rk[k] = k + 1 < n ? T.pair2[(b0 << 8) | text[s + k + 1]] : TK_RANK_MAX;
+            nx[k] = k + 1;
+            pv[k] = k - 1;  // k == 0 -> 0xFFFFFFFF (none)
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        for (int l = 1; l <= nl; ++l) {
+            for (uint32_t b = 0; b < cntl[l]; ++b) {
+                uint32_t k = b * 64 + lane;
+                uint64_t key = ~0ull;
+                if (k < cntl[l - 1]) key = l == 1 ? (((uint64_t)rk[k] << 32) | k) : lv[offl[l - 1] + k];
+                key = tk_wave_min_u64(key);
+                if (lane == 0) lv[offl[l] + b] = key;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+        uint32_t ntok = n;
+        for (;;) {
+            uint64_t top = (uint32_t)lane < cntl[nl] ? lv[offl[nl] + lane] : ~0ull;
+            top = tk_wave_min_u64(top);
+            uint32_t m = (uint32_t)(top >> 32);
+            if (m == TK_RANK_MAX) break;
+            const uint32_t i = (uint32_t)top;
+            const uint32_t j = nx[i];
+            const uint32_t nn = nx[j];
+            const uint32_t pp = pv[i];
+            uint32_t newr = TK_RANK_MAX;
+            if (lane == 0 && nn < n) newr = tk_probe_pair(T, m, id[nn]);
+            if (lane == 1 && pp != 0xFFFFFFFFu) newr = tk_probe_pair(T, id[pp], m);
+            if (lane == 0) {
+                id[i] = m;
+                nx[i] = nn;
+                if (nn < n) pv[nn] = i;
+                rk[j] = TK_RANK_MAX;
+                rk[i] = newr;
+            }
+            if (lane == 1 && pp != 0xFFFFFFFFu) rk[pp] = newr;
+            --ntok;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            // re-reduce the ancestors of leaves pp, i, j
+            uint32_t bi = i, bj = j, bp = pp != 0xFFFFFFFFu ? pp : i;
+            for (int l = 1; l <= nl; ++l) {
+                bi >>= 6;
+                bj >>= 6;
+                bp >>= 6;
+                for (int t = 0; t < 3; ++t) {
+                    uint32_t b = t == 0 ? bp : (t == 1 ? bi : bj);
+                    if ((t == 1 && bi == bp) || (t == 2 && (bj == bi || bj == bp))) continue;
+                    uint32_t k = b * 64 + lane;
+                    uint64_t key = ~0ull;
+                    if (k < cntl[l - 1]) key = l == 1 ? (((uint64_t)rk[k] << 32) | k) : lv[offl[l - 1] + k];
+                    key = tk_wave_min_u64(key);
+                    if (lane == 0) lv[offl[l] + b] = key;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            }
+        }
+        // emit the surviving parts in order
+        if (ntok == 1) {
+            if (lane == 0) {
+                tok1[p] = id[0];
+                cnt[p] = 1;
+            }
+        } else {
+            if (lane == 0) {
+                uint32_t t = 0;
+                for (uint32_t k = 0; k < n; k = nx[k]) staging[s + t++] = id[k];
+                cnt[p] = t;
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// exclusive scan of a large uint32 array (token counts): reduce / scan partials / downsweep
+// ------------------------------------------------------------------------------------------
+#define TK_SCAN_EPT 16  // elements per thread -> 4096 per workgroup
+__global__ __launch_bounds__(256) void tk_k_scan_reduce(const uint32_t* __restrict__ a, uint64_t n, uint32_t* __restrict__ partial) {
+    __shared__ uint32_t sh[8];
+    uint64_t base = (uint64_t)blockIdx.x * (256 * TK_SCAN_EPT);
+    uint32_t sum = 0;
+    for (int k = 0; k < TK_SCAN_EPT; ++k) {
+        uint64_t i = base + (uint64_t)k * 256 + threadIdx.x;
+        if (i < n) sum += a[i];
+    }
+    sum = tk_wave_sum_u32(sum);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = sum;
+    __syncthreads();
+    if (threadIdx.x == 0) partial[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
+}
+// out[i] = exclusive prefix of a (out has n+1 entries; out[n] = total)
+__global__ __launch_bounds__(256) void tk_k_scan_down(const uint32_t* __restrict__ a, uint64_t n, const uint32_t* __restrict__ partial_pre,
+                                                      uint32_t* __restrict__ out) {
+    __shared__ uint32_t sh[8];
+    uint64_t base = (uint64_t)blockIdx.x * (256 * TK_SCAN_EPT);
+    uint32_t carry = partial_pre[blockIdx.x];
+    for (int k = 0; k < TK_SCAN_EPT; ++k) {
+        uint64_t i = base + (uint64_t)k * 256 + threadIdx.x;
+        uint32_t v = i < n ? a[i] : 0;
+        uint32_t tot;
+        uint32_t ex = tk_block_exscan_256(v, &tot, sh);
+        if (i < n) out[i] = carry + ex;
+        if (i + 1 == n) out[n] = carry + ex + v;
+        carry += tot;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// final packing
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tk_k_gather(const uint32_t* __restrict__ pstart, uint64_t P, const uint32_t* __restrict__ cnt,
+                                                   const uint32_t* __restrict__ tokbase, const uint32_t* __restrict__ tok1,
+                                                   const uint32_t* __restrict__ staging, uint32_t* __restrict__ out) {
+    for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < P; p += (uint64_t)gridDim.x * 256) {
+        uint32_t c = cnt[p], b = tokbase[p];
+        if (c == 1) {
+            out[b] = tok1[p];
+        } else {
+            const uint32_t* src = staging + pstart[p];
+            for (uint32_t t = 0; t < c; ++t) out[b + t] = src[t];
+        }
+    }
+}
+
+// tok_off[d] = number of tokens before document d  (= tokbase[#pieces that start before doc_off[d]])
+__global__ __launch_bounds__(256) void tk_k_docoff(const uint64_t* __restrict__ doc_off, uint64_t n_docs, uint64_t base, uint64_t n,
+                                                   const uint32_t* __restrict__ starts, const uint32_t* __restrict__ blockpre,
+                                                   const uint32_t* __restrict__ tokbase, uint64_t P, uint64_t tok_base_global,
+                                                   uint64_t* __restrict__ tok_off) {
+    for (uint64_t d = blockIdx.x * 256ull + threadIdx.x; d <= n_docs; d += (uint64_t)gridDim.x * 256) {
+        uint64_t pos = doc_off[d] - base;
+        uint64_t idx;
+        if (pos >= n) {
+            idx = P;
+        } else {
+            uint64_t w = pos >> 5, blk = w >> 8;
+            idx = blockpre[blk];
+            for (uint64_t k = blk << 8; k < w; ++k) idx += __popc(starts[k]);
+            idx += __popc(starts[w] & ((1u << (pos & 31)) - 1u));
+        }
+        tok_off[d] = tok_base_global + tokbase[idx];
+    }
+}

@@ -1,0 +1,182 @@
+#include "tk_tables.h"
+
+#include <string.h>
+
+#include <algorithm>
+#include <numeric>
+
+static const char* const PAT_R50K =
+    R"('(?:[sdmt]|ll|ve|re)| ?\p{L}++| ?\p{N}++| ?[^\s\p{L}\p{N}]++|\s++$|\s+(?!\S)|\s)";
+static const char* const PAT_GPT2_ORIG =
+    R"('s|'t|'re|'ve|'m|'ll|'d| ?[\p{L}]+| ?[\p{N}]+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+)";
+static const char* const PAT_CL100K =
+    R"('(?i:[sdmt]|ll|ve|re)|[^\r\n\p{L}\p{N}]?+\p{L}++|\p{N}{1,3}+| ?[^\s\p{L}\p{N}]++[\r\n]*+|\s++$|\s*[\r\n]|\s+(?!\S)|\s)";
+static const char* const PAT_O200K =
+    R"([^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]*[\p{Ll}\p{Lm}\p{Lo}\p{M}]+(?i:'s|'t|'re|'ve|'m|'ll|'d)?|)"
+    R"([^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]+[\p{Ll}\p{Lm}\p{Lo}\p{M}]*(?i:'s|'t|'re|'ve|'m|'ll|'d)?|)"
+    R"(\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n/]*|\s*[\r\n]+|\s+(?!\S)|\s+)";
+
+int tk_pattern_id(const char* pat_str) {
+    if (!pat_str) return -1;
+    if (!strcmp(pat_str, PAT_R50K) || !strcmp(pat_str, PAT_GPT2_ORIG)) return TK_PAT_R50K;
+    if (!strcmp(pat_str, PAT_CL100K)) return TK_PAT_CL100K;
+    if (!strcmp(pat_str, PAT_O200K)) return TK_PAT_O200K;
+    return -1;
+}
+
+uint64_t tk_key_of_bytes(const uint8_t* p, uint32_t len) {
+    if (len <= 8) {
+        uint64_t k = 0;
+        memcpy(&k, p, len);
+        return k;
+    }
+    uint64_t h = TK_HASH_SEED;
+    uint32_t i = 0;
+    for (; i + 8 <= len; i += 8) {
+        uint64_t w;
+        memcpy(&w, p + i, 8);
+        h = tk_hash_step(h, w);
+    }
+    if (i < len) {
+        uint64_t w = 0;
+        memcpy(&w, p + i, len - i);
+        h = tk_hash_step(h, w);
+    }
+    if (h == TK_EMPTY_KEY) h = 0;  // reserve the empty marker
+    return h;
+}
+
+uint32_t TkHostTables::lookup_piece(const uint8_t* p, uint32_t len) const {
+    if (len == 0) return TK_RANK_MAX;
+    uint64_t key = tk_key_of_bytes(p, len);
+    uint64_t i = tk_piece_slot_hash(key, len) & piece_mask;
+    for (;;) {
+        const TkPieceSlot& s = piece[i];
+        if (s.key == TK_EMPTY_KEY && s.len == 0) return TK_RANK_MAX;
+        if (s.key == key && s.len == len) {
+            if (len <= 8 || memcmp(tok_bytes.data() + piece_off[i], p, len) == 0) return s.rank;
+        }
+        i = (i + 1) & piece_mask;
+    }
+}
+
+uint32_t TkHostTables::lookup_pair(uint32_t a, uint32_t b) const {
+    uint64_t key = ((uint64_t)a << 32) | b;
+    uint64_t i = tk_pair_slot_hash(key) & pair_mask;
+    for (;;) {
+        const TkPairSlot& s = pair[i];
+        if (s.key == TK_EMPTY_KEY) return TK_RANK_MAX;
+        if (s.key == key) return s.rank;
+        i = (i + 1) & pair_mask;
+    }
+}
+
+std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uint32_t* ranks_ids,
+                            uint64_t n_ranks, const uint8_t* spec_blob, const uint64_t* spec_off,
+                            const uint32_t* spec_ids, uint64_t n_spec, const char* pat_str, TkHostTables* out) {
+    TkHostTables& T = *out;
+    T.pattern = tk_pattern_id(pat_str);
+    if (T.pattern < 0)
+        return std::string("unsupported pat_str: this build carries hand-compiled scanners for the stock patterns of "
+                           "tiktoken_ext/openai_public.py (r50k/gpt2, cl100k, o200k) only; got: ") +
+               (pat_str ? pat_str : "(null)");
+    if (n_ranks == 0) return "mergeable_ranks is empty";
+    if (ranks_off[n_ranks] >= 0xFFFFFFFFull) return "vocabulary byte blob too large";
+    T.n_ranks = n_ranks;
+    T.tok_bytes.assign(ranks_blob, ranks_blob + ranks_off[n_ranks]);
+    T.tok_bytes.resize(T.tok_bytes.size() + 16, 0);  // device verification reads whole 8-byte words
+
+    // piece table (bytes -> rank)
+    uint64_t cap = 64;
+    while (cap < 2 * n_ranks + 2) cap <<= 1;
+    T.piece_mask = cap - 1;
+    T.piece.assign(cap, TkPieceSlot{TK_EMPTY_KEY, TK_RANK_MAX, 0});
+    T.piece_off.assign(cap, 0);
+    for (int b = 0; b < 256; ++b) T.byte_rank[b] = TK_RANK_MAX;
+    T.pair2.assign(65536, TK_RANK_MAX);
+    T.decoder.reserve(n_ranks * 2);
+    for (uint64_t k = 0; k < n_ranks; ++k) {
+        uint64_t o = ranks_off[k], len64 = ranks_off[k + 1] - o;
+        if (len64 == 0) return "mergeable_ranks contains an empty key";
+        uint32_t len = (uint32_t)len64, rank = ranks_ids[k];
+        if (rank == TK_RANK_MAX) return "rank 0xFFFFFFFF is reserved (Rank::MAX sentinel, src/lib.rs:53)";
+        const uint8_t* p = ranks_blob + o;
+        if (T.lookup_piece(p, len) != TK_RANK_MAX) return "duplicate key in mergeable_ranks";
+        if (!T.decoder.emplace(rank, std::make_pair((uint32_t)o, len)).second)
+            return "Encoder and decoder must be of equal length. Maybe you had duplicate token indices in your "
+                   "encoder?";  // src/lib.rs:636-641
+        uint64_t key = tk_key_of_bytes(p, len);
+        uint64_t i = tk_piece_slot_hash(key, len) & T.piece_mask;
+        while (!(T.piece[i].key == TK_EMPTY_KEY && T.piece[i].len == 0)) i = (i + 1) & T.piece_mask;
+        T.piece[i] = TkPieceSlot{key, rank, len};
+        T.piece_off[i] = (uint32_t)o;
+        if (len == 1) T.byte_rank[p[0]] = rank;
+        if (len == 2) T.pair2[((uint32_t)p[0] << 8) | p[1]] = rank;
+        if (len > T.max_token_len) T.max_token_len = len;
+    }
+    for (int b = 0; b < 256; ++b)
+        if (T.byte_rank[b] == TK_RANK_MAX)
+            return "every single byte must be a key of mergeable_ranks (byte_pair_encode indexes ranks[piece] for "
+                   "1-byte pieces, src/lib.rs:201-203)";
+
+    // pair table: all splits of all tokens into two vocabulary tokens
+    std::vector<TkPairSlot> entries;
+    entries.reserve(n_ranks * 3);
+    for (uint64_t k = 0; k < n_ranks; ++k) {
+        uint64_t o = ranks_off[k];
+        uint32_t len = (uint32_t)(ranks_off[k + 1] - o), rank = ranks_ids[k];
+        const uint8_t* p = ranks_blob + o;
+        for (uint32_t s = 1; s < len; ++s) {
+            uint32_t a = T.lookup_piece(p, s);
+            if (a == TK_RANK_MAX) continue;
+            uint32_t b = T.lookup_piece(p + s, len - s);
+            if (b == TK_RANK_MAX) continue;
+            entries.push_back(TkPairSlot{((uint64_t)a << 32) | b, rank, 0});
+        }
+    }
+    T.n_pairs = entries.size();
+    cap = 64;
+    while (cap < 2 * entries.size() + 2) cap <<= 1;
+    T.pair_mask = cap - 1;
+    T.pair.assign(cap, TkPairSlot{TK_EMPTY_KEY, TK_RANK_MAX, 0});
+    for (const TkPairSlot& e : entries) {
+        uint64_t i = tk_pair_slot_hash(e.key) & T.pair_mask;
+        while (T.pair[i].key != TK_EMPTY_KEY) i = (i + 1) & T.pair_mask;
+        T.pair[i] = e;
+    }
+
+    // special tokens, sorted by bytes (deterministic order; the reference's alternation order is
+    // hash-map order, src/lib.rs:625-631)
+    std::vector<uint64_t> order(n_spec);
+    std::iota(order.begin(), order.end(), 0);
+    auto sbytes = [&](uint64_t k) { return std::string((const char*)spec_blob + spec_off[k], spec_off[k + 1] - spec_off[k]); };
+    std::sort(order.begin(), order.end(), [&](uint64_t a, uint64_t b) { return sbytes(a) < sbytes(b); });
+    memset(T.spec_first, 0, sizeof T.spec_first);
+    T.spec_off.push_back(0);
+    for (uint64_t idx : order) {
+        std::string s = sbytes(idx);
+        if (s.empty()) return "empty special token";
+        if (!T.spec_decoder.emplace(spec_ids[idx], std::make_pair((uint32_t)T.spec_bytes.size(), (uint32_t)s.size())).second)
+            return "duplicate special token id";
+        T.spec_bytes.insert(T.spec_bytes.end(), s.begin(), s.end());
+        T.spec_off.push_back((uint32_t)T.spec_bytes.size());
+        T.spec_id.push_back(spec_ids[idx]);
+        unsigned char f = (unsigned char)s[0];
+        T.spec_first[f >> 5] |= 1u << (f & 31);
+    }
+    for (size_t i = 1; i < order.size(); ++i)
+        if (sbytes(order[i]) == sbytes(order[i - 1])) return "duplicate special token string";
+    T.spec_bytes.resize(T.spec_bytes.size() + 16, 0);
+
+    // sorted token bytes (token_byte_values, src/lib.rs:648-650, src/py.rs:178-183)
+    std::vector<uint64_t> idx(n_ranks);
+    std::iota(idx.begin(), idx.end(), 0);
+    std::sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b) {
+        uint64_t la = ranks_off[a + 1] - ranks_off[a], lb = ranks_off[b + 1] - ranks_off[b];
+        int c = memcmp(ranks_blob + ranks_off[a], ranks_blob + ranks_off[b], la < lb ? la : lb);
+        return c < 0 || (c == 0 && la < lb);
+    });
+    T.sorted_ranks.resize(n_ranks);
+    for (uint64_t i = 0; i < n_ranks; ++i) T.sorted_ranks[i] = ranks_ids[idx[i]];
+    return "";
+}

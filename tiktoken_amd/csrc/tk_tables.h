@@ -1,0 +1,47 @@
+// Host-side construction of the device tables (the analogue of CoreBPE::new_internal,
+// reference src/lib.rs:618-663: build encoder/decoder maps, check for duplicate ranks).
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "tk_common.h"
+
+struct TkHostTables {
+    int pattern = -1;
+    std::vector<uint8_t> tok_bytes;
+    std::vector<TkPieceSlot> piece;
+    std::vector<uint32_t> piece_off;
+    uint64_t piece_mask = 0;
+    std::vector<TkPairSlot> pair;
+    uint64_t pair_mask = 0;
+    uint64_t n_pairs = 0;
+    std::vector<uint32_t> pair2;
+    uint32_t byte_rank[256];
+    std::vector<uint8_t> spec_bytes;
+    std::vector<uint32_t> spec_off, spec_id;
+    uint32_t spec_first[8];
+    // decoder side (src/lib.rs:323-324): rank -> (offset into tok_bytes / spec_bytes, length)
+    std::unordered_map<uint32_t, std::pair<uint32_t, uint32_t>> decoder, spec_decoder;
+    std::vector<uint32_t> sorted_ranks;  // ranks ordered by token bytes (lib.rs:648-650)
+    uint32_t max_token_len = 0;
+    uint64_t n_ranks = 0;
+
+    // exact host lookups through the same tables the device uses
+    uint32_t lookup_piece(const uint8_t* p, uint32_t len) const;
+    uint32_t lookup_pair(uint32_t a, uint32_t b) const;
+};
+
+// key of a byte string as stored in the piece table
+uint64_t tk_key_of_bytes(const uint8_t* p, uint32_t len);
+
+// Returns "" on success or an error message.  pat_str must be one of the stock patterns of
+// reference tiktoken_ext/openai_public.py:12-14,89,104-114 (or the GPT-2 spelling at :9-11).
+std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uint32_t* ranks_ids,
+                            uint64_t n_ranks, const uint8_t* spec_blob, const uint64_t* spec_off,
+                            const uint32_t* spec_ids, uint64_t n_spec, const char* pat_str, TkHostTables* out);
+
+// pattern id for a pat_str, or -1 (exported through the C ABI, include/tiktoken_amd.h)
+extern "C" int tk_pattern_id(const char* pat_str);

@@ -1,0 +1,5 @@
+set -x
+mkdir -p gpurun_out
+rocminfo | grep -E "gfx|Marketing" | head -4
+python -m pytest tests/test_gpu_parity.py -m gpu -x -q 2>&1 | tail -40 > gpurun_out/pytest1.log
+cat gpurun_out/pytest1.log
