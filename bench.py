@@ -1,0 +1,220 @@
+#!/usr/bin/env python3
+"""Headline benchmark: GB/s of UTF-8 text encoded by the MI355X BPE path (BASELINE.json metric).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+A step is one pass of the hot path (encode_ordinary_batch semantics, reference
+tiktoken/core.py:164-176 / src/lib.rs:360-373) over one batch of synthetic documents that is
+already resident in HBM: the o200k-shaped encoding on a 1 GiB synthetic web-text corpus per GPU
+(BASELINE.json configs[2]; seeds and mix per SURVEY.md 8(d)).  With N > 1 every rank encodes its
+own 1 GiB shard (weak scaling, documents never interact) and rank 0 gathers the token-id buffers
+with one padded RCCL gather per step, inside the timed region.
+
+Protocol = the reference's scripts/benchmark.py:15-26: bytes = sum of UTF-8 lengths, warm-up first,
+wall clock around the timed calls (here: barrier + synchronize on both sides, max over ranks).
+Rank 0 prints ONE JSON line; `roofline` is for the dominant kernel (HIP-event durations measured
+here, on the stream the kernels run on), `cpu_baseline` is the C oracle timed on the host cores
+over a bounded sample of the same corpus -- and compared token-for-token with the GPU result.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
+KERNELS = ["tk_k_mark_docs", "tk_k_pretok", "tk_k_count", "tk_k_scan_small", "tk_k_emit", "tk_k_lookup", "tk_k_merge_wave",
+           "tk_k_merge_long", "tk_k_scan_reduce", "tk_k_scan_down", "tk_k_gather", "tk_k_docoff"]
+
+
+def gen_corpus(seed: int, mix: int, nbytes: int, threads: int):
+    lib = ctypes.CDLL(os.path.join(ROOT, "tiktoken_amd", "csrc", "libtkcorpus.so"))
+    lib.tkc_generate.argtypes = [ctypes.c_uint64, ctypes.c_int, ctypes.c_uint64, ctypes.c_void_p, ctypes.c_void_p,
+                                 ctypes.c_uint64, ctypes.c_void_p, ctypes.c_int]
+    out = np.zeros(nbytes + 64, np.uint8)
+    maxd = nbytes // 64 + 2
+    off = np.empty(maxd + 1, np.uint64)
+    nd = ctypes.c_uint64()
+    rc = lib.tkc_generate(seed, mix, nbytes, out.ctypes.data, off.ctypes.data, maxd, ctypes.byref(nd), threads)
+    assert rc == 0, rc
+    return out, off[: nd.value + 1].copy()
+
+
+class DevArray:
+    """Zero-copy view of library-owned device memory for torch (via __cuda_array_interface__)."""
+
+    def __init__(self, ptr: int, n: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--mib", type=int, default=1024, help="corpus size per GPU in MiB (headline: 1024)")
+    ap.add_argument("--encoding", default="o200k_shaped")
+    ap.add_argument("--cpu-sample-mib", type=int, default=256)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    torch.cuda.set_device(local_rank)
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+
+    import tiktoken_amd  # noqa: F401
+    from tiktoken_amd.distributed import gather_tokens
+
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    nbytes = args.mib << 20
+    mix = 1  # web text
+    seed = 0x5EED0003 if world == 1 else 0x5EED0004 + rank
+    t0 = time.time()
+    blob, doc_off = gen_corpus(seed, mix, nbytes, min(ncpu, 32))
+    n_docs = len(doc_off) - 1
+    t_gen = time.time() - t0
+
+    # one process per GPU: the encoding's tables live on this rank's device
+    from tiktoken_amd._tiktoken import CoreBPE
+    from tiktoken_ext import amd_shaped
+
+    spec = amd_shaped.ENCODING_CONSTRUCTORS[args.encoding]()
+    core = CoreBPE(spec["mergeable_ranks"], spec["special_tokens"], spec["pat_str"], device=local_rank)
+
+    d_text = torch.from_numpy(blob).cuda()          # nbytes + 64 readable bytes, resident in HBM
+    d_off = torch.from_numpy(doc_off.view(np.int64)).cuda()
+    torch.cuda.synchronize()
+
+    def step():
+        dt, nt, do = core.encode_batch_device(d_text.data_ptr(), nbytes, d_off.data_ptr(), doc_off, n_docs)
+        if world > 1:
+            toks = torch.as_tensor(DevArray(dt, max(nt, 1), "<i4"), device="cuda")
+            gather_tokens(toks, nt, rank, world, dist, torch)
+        return dt, nt, do
+
+    for _ in range(args.warmup):
+        step()
+    if dist:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dt, nt, do = step()
+    torch.cuda.synchronize()
+    if dist:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if dist:
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        elapsed = float(tmax.item())
+        tot = torch.tensor([nbytes, nt], dtype=torch.int64, device="cuda")
+        dist.all_reduce(tot)
+        total_bytes, total_tokens = int(tot[0].item()), int(tot[1].item())
+    else:
+        total_bytes, total_tokens = nbytes, nt
+    ms_per_step = elapsed / args.steps * 1e3
+    value = total_bytes * args.steps / elapsed / 1e9
+
+    # ---- per-kernel durations (HIP events on the library's stream), one profiled pass
+    core.set_profiling(True)
+    core.reset_kernel_ms()
+    prof_steps = 2
+    for _ in range(prof_steps):
+        core.encode_batch_device(d_text.data_ptr(), nbytes, d_off.data_ptr(), doc_off, n_docs)
+    core.set_profiling(False)
+    kern = {}
+    for k in KERNELS:
+        ms, n = core.kernel_ms(k)
+        if n:
+            kern[k] = {"ms_total": ms, "launches": n, "ms_avg": ms / n}
+    stats = core.last_stats()
+    b_alg = nbytes + 4 * stats["tokens"] + 16 * (n_docs + 1)  # text in + u32 ids out + offsets in/out
+    dom = max(kern, key=lambda k: kern[k]["ms_total"]) if kern else None
+    sum_ms = sum(v["ms_total"] for v in kern.values()) / prof_steps if kern else None
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "traffic.json")
+    if os.path.exists(tpath) and dom:
+        try:
+            tj = json.load(open(tpath))
+            if tj.get("workload_mib") == args.mib and tj.get("encoding") == args.encoding:
+                traffic = tj.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    roofline = None
+    if dom:
+        achieved = b_alg / (kern[dom]["ms_avg"] * 1e-3) / 1e9
+        roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                    "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
+                    "algorithmic_bytes_per_launch": b_alg, "kernel_ms_avg": round(kern[dom]["ms_avg"], 4),
+                    "all_kernels_ms_per_step": round(sum_ms, 4),
+                    "pipeline_achieved": round(b_alg / (sum_ms * 1e-3) / 1e9, 2),
+                    "kernels_ms_avg": {k: round(v["ms_avg"], 4) for k, v in kern.items()}}
+
+    # ---- CPU baseline (rank 0, N = 1 only) + token-for-token comparison on the sample
+    cpu = None
+    parity = None
+    if rank == 0 and world == 1 and not args.no_cpu_baseline:
+        from oracle import c_oracle
+
+        pat_id = {"gpt2_shaped": 0, "cl100k_shaped": 1, "o200k_shaped": 2, "o200k_custom8": 2}[args.encoding]
+        C = c_oracle.COracle(pat_id, spec["mergeable_ranks"], spec["special_tokens"])
+        sample_bytes = min(nbytes, args.cpu_sample_mib << 20)
+        nd_s = int(np.searchsorted(doc_off, sample_bytes, side="right")) - 1
+        nd_s = max(nd_s, 1)
+        sb = int(doc_off[nd_s])
+        C.encode_batch(blob[: min(sb, 8 << 20)], doc_off[: int(np.searchsorted(doc_off, min(sb, 8 << 20), side="right"))], None, ncpu)  # warm-up
+        t0 = time.perf_counter()
+        ctoks, coff = C.encode_batch(blob[:sb], doc_off[: nd_s + 1], None, ncpu)
+        dt_cpu = time.perf_counter() - t0
+        cpu = {"value": round(sb / dt_cpu / 1e9, 4), "unit": "GB/s", "cores": ncpu, "kind": "port",
+               "sample": f"first {nd_s} documents ({sb} bytes) of the same corpus, C restatement of CoreBPE "
+                         f"(oracle/tk_oracle.c), {ncpu} threads over documents, packed u32 output"}
+        # parity: the GPU tokens of the same documents
+        g_tok_off = torch.as_tensor(DevArray(do, n_docs + 1, "<i8"), device="cuda")[: nd_s + 1].cpu().numpy().astype(np.uint64)
+        g_toks = torch.as_tensor(DevArray(dt, max(nt, 1), "<i4"), device="cuda")[: int(g_tok_off[-1])].cpu().numpy().view(np.uint32)
+        parity = bool(np.array_equal(g_tok_off, coff) and np.array_equal(g_toks, ctoks))
+
+    if rank == 0:
+        line = {
+            "metric": "GB/s text encoded (o200k_base-shaped vocab, 1 GiB corpus per GPU), bit-exact vs CoreBPE restatement",
+            "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u8", "data": "synthetic",
+            "config": {"workload": f"{args.encoding} encode_ordinary_batch, {args.mib} MiB synthetic web-text per GPU "
+                                   f"(tkc_generate mix=1, seed {'0x5EED0003' if world == 1 else '0x5EED0004+rank'}), "
+                                   f"{n_docs} docs on rank 0, inputs resident in HBM, packed u32 output",
+                       "encoding": args.encoding, "bytes_per_gpu": nbytes, "docs_rank0": n_docs,
+                       "tokens_total": total_tokens, "pieces_rank0": stats["pieces"],
+                       "parallelism": f"doc-sharded x{world}" + (" + RCCL gather of token ids to rank 0" if world > 1 else "")},
+            "roofline": roofline, "cpu_baseline": cpu, "parity_vs_oracle_on_cpu_sample": parity,
+            "host": {"cpus": ncpu, "corpus_gen_s": round(t_gen, 2)},
+        }
+        print(json.dumps(line), flush=True)
+    if dist:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,113 @@
+"""The product's device functions (tiktoken_amd/csrc/tk_device.h: class bytes, certain-start rule,
+tk_piece_end scanner, table probes, per-lane merge) compiled for the HOST and run in a sequential loop
+that mirrors tk_k_pretok / tk_k_lookup, against the oracle.  This is how logic errors are caught in a
+container without a GPU; the real kernels are checked by the `-m gpu` tests."""
+import itertools
+import random
+
+import numpy as np
+import pytest
+
+import helpers as h
+
+
+@pytest.fixture(scope="module")
+def sims():
+    return {n: h.HostSim(h.PAT_STR[h.PATTERN_OF[n]], h.load_vocab(n), h.SPECIALS[n]) for n in h.ENCODING_NAMES}
+
+
+def _ref_ends(C, docs, off):
+    ref = []
+    for d, dd in enumerate(docs):
+        ref += [int(off[d]) + e for e in C.split(dd)]
+    return ref
+
+
+@pytest.mark.parametrize("name", h.ENCODING_NAMES)
+def test_pretok_sim_on_adversarial_batches(sims, name):
+    sim, C = sims[name], h.c_oracle_for(name)
+    rng = random.Random(11)
+    for _ in range(3000):
+        docs = ["".join(rng.choice(h.ADV) for _ in range(rng.randint(0, 30))).encode() for _ in range(rng.randint(1, 4))]
+        blob, off = h.pack(docs)
+        ends, _ = sim.piece_ends(blob, off)
+        assert ends.tolist() == _ref_ends(C, docs, off), docs
+
+
+REPS = {  # one or two representatives per character class, incl. every contraction letter in both cases
+    "NL": ["\n", "\r"], "SP": [" "], "WSO": ["\t", "　"], "LU": ["S", "L", "E", "Z", "ǅ"], "LL": ["s", "l", "e", "ſ", "x", "t"],
+    "LC": ["中", "ʰ"], "MK": ["́"], "NU": ["1", "²"], "AP": ["'"], "SL": ["/"], "OT": ["!", "\x1c"],
+}
+
+
+@pytest.mark.parametrize("name", h.ENCODING_NAMES)
+def test_certain_start_rule_exhaustive_short_strings(sims, name):
+    """Every string of length <= 4 over the class representatives (plus random longer ones): the
+    segmentation that starts scanners only at `tk_certain_start` positions must equal the sequential
+    split.  A wrong entry in the certain-start table shows up here as a spurious or missing boundary."""
+    sim, C = sims[name], h.c_oracle_for(name)
+    alpha = [c for v in REPS.values() for c in v]
+    docs = []
+    for n in (1, 2, 3):
+        docs += ["".join(t).encode() for t in itertools.product(alpha, repeat=n)]
+    rng = random.Random(5)
+    docs += ["".join(rng.choice(alpha) for _ in range(rng.randint(4, 9))).encode() for _ in range(20000)]
+    for i in range(0, len(docs), 512):
+        chunk = docs[i:i + 512]
+        blob, off = h.pack(chunk)
+        ends, _ = sim.piece_ends(blob, off)
+        assert ends.tolist() == _ref_ends(C, chunk, off)
+
+
+@pytest.mark.parametrize("name,mix", [("gpt2_shaped", 1), ("cl100k_shaped", 0), ("o200k_shaped", 1)])
+def test_pretok_and_pieces_on_corpus(sims, name, mix):
+    sim, C = sims[name], h.c_oracle_for(name)
+    blob, off = h.gen_corpus(0x51 + mix, mix, 1 << 19)
+    bb = blob.tobytes()
+    docs = [bb[int(off[d]):int(off[d + 1])] for d in range(len(off) - 1)]
+    ends, n_certain = sim.piece_ends(blob, off)
+    ref = _ref_ends(C, docs, off)
+    assert ends.tolist() == ref
+    assert n_certain / len(ref) > 0.9  # certain starts must stay dense or the pre-tokeniser loses parallelism
+    p = 0
+    for e in ref[:20000]:
+        piece = bb[p:e]
+        p = e
+        assert sim.encode_piece(piece) == C.encode_piece(piece), piece
+
+
+@pytest.mark.parametrize("name", h.ENCODING_NAMES + ["edu600"])
+def test_piece_encode_sim_on_golden_pieces(sims, name):
+    """Whole-piece probe + merge through the device tables == golden tokens, piece by piece."""
+    g = h.load_golden(name)
+    sim = sims[name] if name in sims else h.HostSim(g["pat_str"], h.golden_vocab(name), g["special_tokens"])
+    C = h.c_oracle_for(name)
+    for c in g["cases"][:200]:
+        if c["allowed"] is not None:
+            continue
+        got, p = [], 0
+        for e in C.split(c["text"]):
+            got += sim.encode_piece(c["text"][p:e])
+            p = e
+        assert got == c["tokens"], c["name"]
+
+
+def test_pair_table_is_exactly_the_set_of_token_splits():
+    """(id_a, id_b) -> id_ab must exist iff bytes(a)+bytes(b) is a vocabulary key (tk_common.h)."""
+    ranks = h.load_vocab("gpt2_shaped")
+    sim = h.HostSim(h.PAT_STR[0], ranks, {})
+    n = 0
+    for tb in list(ranks)[::17]:
+        for s in range(1, len(tb)):
+            if tb[:s] in ranks and tb[s:] in ranks:
+                n += 1
+    assert sim.n_pairs() >= n > 0
+
+
+def test_rejects_bad_vocabularies():
+    with pytest.raises(ValueError):  # duplicate ranks (src/lib.rs:636-641 panics)
+        h.HostSim(h.PAT_STR[0], {**{bytes([b]): b for b in range(256)}, b"ab": 5}, {})
+    with pytest.raises(ValueError):  # a missing single byte (src/lib.rs:201-203 would panic at encode time)
+        h.HostSim(h.PAT_STR[0], {bytes([b]): b for b in range(255)}, {})
+    with pytest.raises(ValueError):  # pattern without a compiled scanner
+        h.HostSim(r"\w+|\s+", {bytes([b]): b for b in range(256)}, {})

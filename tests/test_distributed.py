@@ -1,0 +1,75 @@
+"""The N > 1 path on CPU: two processes, gloo backend, 127.0.0.1 rendezvous.
+
+What is exercised is the sharding and the exchange -- `partition_by_bytes`, the count all-gather and the
+single padded gather of token buffers (tiktoken_amd/distributed.py, the same functions bench.py uses with
+the nccl/RCCL backend).  There is no CPU encode path in the product, so each rank's *encoder* here is the
+C oracle (tests may use it); the assertion is that the gathered result equals the oracle's encoding of
+the undivided batch, i.e. sharding + gather preserve order and content."""
+import os
+import socket
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+import helpers as h
+from tiktoken_amd.distributed import encode_ordinary_batch_sharded, partition_by_bytes
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    try:
+        C = h.c_oracle_for("cl100k_shaped")
+        blob, off = h.gen_corpus(0xD157, 0, 1 << 19, threads=1)
+        res = encode_ordinary_batch_sharded(lambda b, o: C.encode_batch(b, o, None, 1), blob, off, rank, world, dist, torch)
+        if rank == 0:
+            toks, toff = res
+            rt, ro = C.encode_batch(blob, off, None, 1)
+            q.put(bool(np.array_equal(toks, rt) and np.array_equal(toff, ro)))
+        else:
+            assert res is None
+        dist.barrier()
+    finally:
+        dist.destroy_process_group()
+
+
+@pytest.mark.timeout(180)
+def test_two_rank_gloo_shard_and_gather():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    ok = q.get(timeout=150)
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    assert ok
+
+
+def test_partition_by_bytes_is_contiguous_and_balanced():
+    rng = np.random.default_rng(0)
+    lens = rng.integers(0, 5000, size=1000)
+    off = np.zeros(1001, np.uint64)
+    off[1:] = np.cumsum(lens)
+    for world in (1, 2, 3, 8):
+        parts = partition_by_bytes(off, world)
+        assert parts[0][0] == 0 and parts[-1][1] == 1000
+        assert all(a[1] == b[0] for a, b in zip(parts[:-1], parts[1:]))
+        sizes = [int(off[b] - off[a]) for a, b in parts]
+        assert max(sizes) - min(sizes) <= 2 * 5000
+    assert partition_by_bytes(np.zeros(1, np.uint64), 4) == [(0, 0)] * 4  # empty batch
+    assert partition_by_bytes(np.array([0, 10], np.uint64), 4)[-1] == (0, 1) or sum(b - a for a, b in partition_by_bytes(np.array([0, 10], np.uint64), 4)) == 1

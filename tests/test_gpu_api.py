@@ -1,0 +1,210 @@
+"""The reference's own public test-suite shapes (tests/test_encoding.py, test_simple_public.py,
+test_pickle.py, test_offsets.py, test_misc.py) run against the MI355X path through the identical
+`Encoding` API.  Real-vocabulary known answers need files that are not available offline (they run when
+present in $TIKTOKEN_CACHE_DIR); everything else uses the "-shaped" encodings and compares with the oracle."""
+import os
+import pickle
+
+import hypothesis
+import hypothesis.strategies as st
+import numpy as np
+import pytest
+
+import helpers as h
+import tiktoken_amd as tiktoken
+
+pytestmark = pytest.mark.gpu
+MAX_EXAMPLES = int(os.environ.get("TIKTOKEN_MAX_EXAMPLES", "60"))
+ENCS = ["gpt2_shaped", "cl100k_shaped", "o200k_shaped"]
+
+
+def oracle_encode(name, text, allowed=None):
+    C = h.c_oracle_for(name)
+    b = text.encode("utf-8")
+    return (C.encode_ordinary(b) if allowed is None else C.encode(b, allowed)).tolist()
+
+
+@pytest.mark.parametrize("name", ENCS)
+def test_simple_and_single_token_roundtrip(name):
+    enc = tiktoken.get_encoding(name)
+    assert enc.encode("hello world") == oracle_encode(name, "hello world")
+    assert enc.decode(enc.encode("hello world")) == "hello world"
+    eot = enc.eot_token
+    assert enc.encode("hello <|endoftext|>", allowed_special="all") == oracle_encode(name, "hello ") + [eot]
+    for token in range(0, min(10_000, enc.max_token_value - 1), 37):
+        assert enc.encode_single_token(enc.decode_single_token_bytes(token)) == token
+    assert enc.encode("") == []
+
+
+@pytest.mark.parametrize("name", ENCS)
+def test_basic_roundtrip(name):
+    enc = tiktoken.get_encoding(name)
+    for value in ("hello", "hello ", "hello  ", " hello", " hello ", " hello  ", "hello world", "请考试我的软件！12345"):
+        assert value == enc.decode(enc.encode(value))
+        assert value == enc.decode(enc.encode_ordinary(value))
+
+
+@pytest.mark.parametrize("name", ENCS)
+@hypothesis.given(text=st.text())
+@hypothesis.settings(deadline=None, max_examples=MAX_EXAMPLES)
+def test_hyp_roundtrip_and_oracle(name, text):
+    enc = tiktoken.get_encoding(name)
+    toks = enc.encode(text, disallowed_special=())
+    assert text == enc.decode(toks)
+    fixed = text.encode("utf-16", "surrogatepass").decode("utf-16", "replace")
+    assert toks == oracle_encode(name, fixed)
+    assert enc.encode_ordinary(text) == toks  # test_hyp_special_ordinary
+
+
+@pytest.mark.parametrize("name", ENCS)
+@hypothesis.given(batch=st.lists(st.text()))
+@hypothesis.settings(deadline=None, max_examples=MAX_EXAMPLES // 2)
+def test_hyp_batch_roundtrip(name, batch):
+    enc = tiktoken.get_encoding(name)
+    encoded = enc.encode_batch(batch, allowed_special="all")
+    assert encoded == [enc.encode(t, allowed_special="all") for t in batch]
+    assert enc.decode_batch(encoded) == batch
+
+
+@pytest.mark.parametrize("name", ENCS)
+@hypothesis.given(bytestring=st.binary())
+@hypothesis.settings(deadline=None, max_examples=MAX_EXAMPLES // 2)
+def test_hyp_encode_bytes(name, bytestring):
+    enc = tiktoken.get_encoding(name)
+    assert enc.decode_bytes(enc._encode_bytes(bytestring)) == bytestring
+
+
+def test_encode_bytes_invalid_tail():
+    enc = tiktoken.get_encoding("cl100k_shaped")
+    for i in range(10):
+        bs = b"\x80" * i
+        assert enc.decode_bytes(enc._encode_bytes(bs)) == bs
+    bs = " 실".encode()[:-1] + b"\xed"
+    assert enc.decode_bytes(enc._encode_bytes(bs)) == bs
+
+
+def test_surrogate_pairs():
+    enc = tiktoken.get_encoding("cl100k_shaped")
+    assert enc.encode("👍") == enc.encode("👍")
+    assert enc.encode("\ud83d") == enc.encode("�")
+    assert enc.encode_ordinary_batch(["a\ud83db", "👍"]) == [enc.encode("a�b"), enc.encode("👍")]
+
+
+def test_special_token_policy_matrix():
+    """tests/test_encoding.py:175-223."""
+    enc = tiktoken.get_encoding("cl100k_shaped")
+    eot, fip, fim = (enc.encode_single_token(s) for s in ("<|endoftext|>", "<|fim_prefix|>", "<|fim_middle|>"))
+    assert eot == enc.eot_token
+    text = "<|endoftext|> hello <|fim_prefix|>"
+    assert eot not in enc.encode(text, disallowed_special=())
+    for kw in ({}, {"disallowed_special": "all"}, {"disallowed_special": {"<|endoftext|>"}}, {"disallowed_special": {"<|fim_prefix|>"}}):
+        with pytest.raises(ValueError, match="disallowed special token"):
+            enc.encode(text, **kw)
+    text = "<|endoftext|> hello <|fim_prefix|> there <|fim_middle|>"
+    t = enc.encode(text, disallowed_special=())
+    assert eot not in t and fip not in t and fim not in t
+    for kw in ({"allowed_special": "all", "disallowed_special": ()}, {"allowed_special": "all", "disallowed_special": "all"}):
+        t = enc.encode(text, **kw)
+        assert eot in t and fip in t and fim in t
+    for allowed, present in (({"<|fim_prefix|>"}, fip), ({"<|endoftext|>"}, eot), ({"<|fim_middle|>"}, fim)):
+        t = enc.encode(text, allowed_special=allowed, disallowed_special=())
+        assert present in t and sum(x in t for x in (eot, fip, fim)) == 1
+        assert t == oracle_encode("cl100k_shaped", text, allowed)
+    with pytest.raises(ValueError):
+        enc.encode_batch(["fine", text])
+
+
+@pytest.mark.parametrize("name", ENCS)
+def test_batch_encode(name):
+    enc = tiktoken.get_encoding(name)
+    t1, t2 = "hello world", "goodbye world"
+    assert enc.encode_batch([t1]) == [enc.encode(t1)]
+    assert enc.encode_batch([t1, t2]) == [enc.encode(t1), enc.encode(t2)]
+    assert enc.encode_ordinary_batch([t1, t2], num_threads=3) == [enc.encode_ordinary(t1), enc.encode_ordinary(t2)]
+    assert enc.encode_ordinary_batch([]) == []
+
+
+def test_encode_to_numpy_and_buffer_protocol():
+    enc = tiktoken.get_encoding("o200k_shaped")
+    arr = enc.encode_to_numpy("hello world 123")
+    assert arr.dtype == np.uint32 and arr.tolist() == enc.encode("hello world 123")
+    buf = enc._core_bpe.encode_to_tiktoken_buffer("hello", set())
+    mv = memoryview(buf)
+    assert mv.readonly and mv.ndim == 1 and mv.itemsize == 4 and mv.format in ("I", "<I", "L", "<L")
+
+
+def test_offsets_and_tokens_bytes():
+    """tests/test_offsets.py:28-46 (property) on fixed prompts."""
+    enc = tiktoken.get_encoding("cl100k_shaped")
+    for prompt in ["hello world", "hello world<|endoftext|> green cow", "我非常渴望与人工智能一起工作", "நடிகர் சூர்யா", " Ġ除"]:
+        toks = enc.encode(prompt, allowed_special="all")
+        text, offsets = enc.decode_with_offsets(toks)
+        assert text == prompt
+        slow, pos = [], 0
+        for tb in enc.decode_tokens_bytes(toks):
+            # first character that contains a byte of this token
+            slow.append(len(prompt.encode()[:pos].decode("utf-8", errors="ignore")) if not (0x80 <= tb[0] < 0xC0) else
+                        len(prompt.encode()[:pos].decode("utf-8", errors="ignore")))
+            pos += len(tb)
+        assert offsets == sorted(offsets) and len(offsets) == len(toks) and offsets[0] == 0
+
+
+def test_pickle():
+    enc = tiktoken.get_encoding("gpt2_shaped")
+    assert pickle.loads(pickle.dumps(enc)).encode("hello world") == enc.encode("hello world")
+    custom = tiktoken.Encoding(name="my_new", pat_str=enc._pat_str, mergeable_ranks=enc._mergeable_ranks,
+                               special_tokens={**enc._special_tokens, "<|pickle|>": 100_000})
+    again = pickle.loads(pickle.dumps(custom))
+    assert again.encode("<|pickle|>", allowed_special="all") == [100_000]
+    assert again.encode("hello world") == enc.encode("hello world")
+
+
+def test_custom8_special_tokens_batch():
+    """BASELINE.json config 5 shape: o200k + 8 custom specials, encode_batch(allowed_special='all')."""
+    enc = tiktoken.get_encoding("o200k_custom8")
+    C = h.c_oracle.COracle(2, enc._mergeable_ranks, enc._special_tokens)
+    blob, off = h.gen_corpus(0x5EED0005, 1, 1 << 20)
+    bb = blob.tobytes()
+    docs = []
+    rng = np.random.default_rng(1)
+    decoys = ["<|custom_9|>", "<|endoftext", "<|custom_3|", "<|", "|>"]
+    for d in range(len(off) - 1):
+        t = bb[int(off[d]):int(off[d + 1])].decode()
+        k = int(rng.integers(0, len(t) + 1))
+        ins = f"<|custom_{int(rng.integers(0, 8))}|>" if rng.random() < 0.7 else decoys[int(rng.integers(0, len(decoys)))]
+        docs.append(t[:k] + ins + t[k:])
+    got = enc.encode_batch(docs, allowed_special="all")
+    for t, g in zip(docs, got):
+        assert g == C.encode(t.encode(), "all").tolist()
+
+
+def test_encode_with_unstable_contract():
+    """core.py:227-230: stable tokens decode to a prefix; every completion continues to cover the text."""
+    enc = tiktoken.get_encoding("gpt2_shaped")
+    for text in ["hello fanta", "hello wor", "  ", "a\n\n", "12345"]:
+        stable, completions = enc.encode_with_unstable(text)
+        assert text.encode().startswith(enc.decode_bytes(stable))
+        assert all(enc.decode_bytes(stable + seq).startswith(text.encode()) for seq in completions)
+
+
+def test_threads_share_one_encoding():
+    """The reference object is frozen and entered from many Python threads (core.py:175); ours serialises calls."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    enc = tiktoken.get_encoding("cl100k_shaped")
+    texts = [f"thread {i} says hello world {i * 7919}" for i in range(64)]
+    with ThreadPoolExecutor(8) as ex:
+        got = list(ex.map(enc.encode_ordinary, texts))
+    assert got == [oracle_encode("cl100k_shaped", t) for t in texts]
+
+
+def test_real_vocab_known_answers_if_available():
+    """Appendix B of SURVEY.md: runs only when the sha256-pinned stock files are in $TIKTOKEN_CACHE_DIR."""
+    cache = os.environ.get("TIKTOKEN_CACHE_DIR")
+    if not cache or not os.path.exists(os.path.join(cache, "9b5ad71b2ce5302211f9c61530b329a4922fc6a4")):
+        pytest.skip("stock vocabulary files not available offline")
+    enc = tiktoken.get_encoding("cl100k_base")
+    assert enc.encode("hello world") == [15339, 1917]
+    assert enc.encode("rer") == [38149] and enc.encode("'rer") == [2351, 81]
+    assert enc.encode("today\n ") == [31213, 198, 220] and enc.encode("today\n \n") == [31213, 27907]
+    assert enc.encode(" \x850") == [220, 126, 227, 15]

@@ -115,6 +115,26 @@ class CoreBPE:
         _lib.raise_for(rc)
         return _take_u32(out, n.value), tok_off
 
+    def encode_batch_device(self, d_text_ptr: int, n_bytes: int, d_doc_off_ptr: int, h_doc_off: np.ndarray | None,
+                            n_docs: int, allowed_special: AbstractSet[str] | None = None, stream: int = 0):
+        """Device-resident batch (tk_encode_batch_device): inputs already in HBM, results stay in HBM.
+        Returns (d_tokens_ptr, n_tokens, d_tok_off_ptr); the pointers are owned by this CoreBPE and valid
+        until its next encode call.  d_text must be readable 64 bytes past n_bytes."""
+        dt, dn, do = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_void_p()
+        if allowed_special is None:
+            ids, k, mode = np.zeros(1, dtype=np.uint32), 0, 0
+        else:
+            ids, k = self._allowed_ids(allowed_special)
+            mode = 1
+        h_ptr = None
+        if h_doc_off is not None:
+            h_doc_off = np.ascontiguousarray(h_doc_off, dtype=np.uint64)
+            h_ptr = h_doc_off.ctypes.data
+        rc = self._L.tk_encode_batch_device(self._h, d_text_ptr, n_bytes, d_doc_off_ptr, h_ptr, n_docs, mode, ids.ctypes.data, k,
+                                            stream or None, ctypes.byref(dt), ctypes.byref(dn), ctypes.byref(do))
+        _lib.raise_for(rc)
+        return dt.value, dn.value, do.value
+
     def pretokenize_packed(self, blob: np.ndarray, doc_off: np.ndarray, allowed_special: AbstractSet[str] | None = None) -> np.ndarray:
         """Piece start offsets (uint32, ascending, plus a final sentinel = total bytes) of a packed batch --
         what `regex.find_iter` yields at src/lib.rs:365/405, computed by the GPU pre-tokeniser."""

@@ -1,0 +1,67 @@
+"""Multi-GPU plumbing: one process per GPU (torch.distributed; backend "nccl" is RCCL on ROCm).
+
+The encode path shards by document and needs no data-path collective (documents never interact,
+reference tiktoken/core.py:174-176); the only exchange is returning the token-id buffers to a root
+rank: one count all-gather (8 bytes per rank) plus ONE padded gather of the u32 buffers -- 7 peers
+send to the root over 7 separate xGMI links, so nothing is ring-serialised.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+
+def partition_by_bytes(doc_off: np.ndarray, world: int) -> list[tuple[int, int]]:
+    """Split documents into `world` contiguous ranges of (nearly) equal bytes, preserving order.
+    doc_off: uint64[n_docs+1].  Returns [(first_doc, last_doc_exclusive)] per rank."""
+    doc_off = np.asarray(doc_off, dtype=np.uint64)
+    n_docs = len(doc_off) - 1
+    total = int(doc_off[-1])
+    cuts = [0]
+    for r in range(1, world):
+        target = total * r // world
+        d = int(np.searchsorted(doc_off, target, side="left"))
+        cuts.append(min(max(d, cuts[-1]), n_docs))
+    cuts.append(n_docs)
+    return [(cuts[r], cuts[r + 1]) for r in range(world)]
+
+
+def gather_tokens(tokens, n_tokens: int, rank: int, world: int, dist, torch, dst: int = 0):
+    """Gather per-rank token buffers (1-D integer tensors, first n_tokens entries valid) on rank `dst`.
+    Returns (list of per-rank tensors in rank order, counts) on dst and (None, counts) elsewhere."""
+    mine = torch.tensor([n_tokens], dtype=torch.int64, device=tokens.device)
+    parts = [torch.zeros(1, dtype=torch.int64, device=tokens.device) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    counts = [int(p.item()) for p in parts]
+    cmax = max(max(counts), 1)
+    if tokens.numel() >= cmax:
+        send = tokens[:cmax].contiguous()
+    else:
+        send = torch.cat([tokens, tokens.new_zeros(cmax - tokens.numel())])
+    if rank == dst:
+        bufs = [torch.empty(cmax, dtype=tokens.dtype, device=tokens.device) for _ in range(world)]
+        dist.gather(send, bufs, dst=dst)
+        return [b[:c] for b, c in zip(bufs, counts)], counts
+    dist.gather(send, None, dst=dst)
+    return None, counts
+
+
+def encode_ordinary_batch_sharded(encode_packed, blob: np.ndarray, doc_off: np.ndarray, rank: int, world: int, dist, torch,
+                                  device="cpu"):
+    """Doc-sharded encode: every rank encodes its contiguous byte-balanced range with
+    `encode_packed(blob_slice, doc_off_slice) -> (tokens uint32[T], tok_off uint64[n+1])`, rank 0 gets
+    (tokens, tok_off) of the whole batch in document order, other ranks get None."""
+    first, last = partition_by_bytes(doc_off, world)[rank]
+    a, b = int(doc_off[first]), int(doc_off[last])
+    toks, toff = encode_packed(blob[a:b], (doc_off[first:last + 1] - doc_off[first]).astype(np.uint64))
+    t = torch.from_numpy(np.ascontiguousarray(toks).view(np.int32)).to(device)
+    parts, counts = gather_tokens(t, len(toks), rank, world, dist, torch)
+    # per-document token counts travel the same way (tiny next to the ids)
+    dcount = torch.from_numpy(np.diff(toff).astype(np.int64)).to(device)
+    dparts, _ = gather_tokens(dcount, len(dcount), rank, world, dist, torch)
+    if rank != 0:
+        return None
+    all_toks = np.concatenate([p.cpu().numpy().view(np.uint32) for p in parts]) if parts else np.zeros(0, np.uint32)
+    all_counts = np.concatenate([p.cpu().numpy() for p in dparts]).astype(np.uint64)
+    tok_off = np.zeros(len(all_counts) + 1, np.uint64)
+    np.cumsum(all_counts, out=tok_off[1:])
+    return all_toks, tok_off
