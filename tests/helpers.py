@@ -136,6 +136,8 @@ def sim_lib():
         L.tks_n_pairs.argtypes = [vp]
         L.tks_pretok.restype = u64
         L.tks_pretok.argtypes = [vp, vp, u64, vp, u64, vp]
+        L.tks_pretok_bits.restype = u64
+        L.tks_pretok_bits.argtypes = [vp, vp, u64, vp, u64, vp]
         L.tks_encode_piece.restype = ctypes.c_int64
         L.tks_encode_piece.argtypes = [vp, vp, ctypes.c_uint32, vp]
         _sim_lib = L
@@ -155,11 +157,15 @@ class HostSim:
     def n_pairs(self):
         return sim_lib().tks_n_pairs(self._h)
 
-    def piece_ends(self, blob: np.ndarray, doc_off: np.ndarray):
+    def piece_ends(self, blob: np.ndarray, doc_off: np.ndarray, bits: bool = False):
+        """Piece end offsets from the simulated pre-tokeniser; bits=True mirrors the bit-parallel kernel
+        (second value = pieces that fell back to the byte-walking scanner), else the byte-walking one
+        (second value = number of certain starts)."""
         n = len(blob)
         starts = np.zeros(max(n, 1), np.uint8)
         b = np.ascontiguousarray(blob) if n else np.zeros(1, np.uint8)
-        nc = sim_lib().tks_pretok(self._h, b.ctypes.data, n, doc_off.ctypes.data, len(doc_off) - 1, starts.ctypes.data)
+        fn = sim_lib().tks_pretok_bits if bits else sim_lib().tks_pretok
+        nc = fn(self._h, b.ctypes.data, n, doc_off.ctypes.data, len(doc_off) - 1, starts.ctypes.data)
         idx = np.flatnonzero(starts[:n])
         return np.concatenate([idx[1:], [n]]).astype(np.uint64) if n else np.zeros(0, np.uint64), nc
 

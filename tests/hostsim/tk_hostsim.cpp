@@ -110,6 +110,116 @@ uint64_t tks_pretok(void* p, const uint8_t* text_in, uint64_t n, const uint64_t*
     return n_certain;
 }
 
+// Mirror of tk_k_pretok2 (bit-parallel scanner): class bytes with the char's class propagated onto
+// continuation bytes, per-class bitmaps, 64-bit windows at each piece start, tk_piece_len_bits with the
+// byte-walking scanner as the fallback.  Returns the number of pieces that needed the fallback.
+struct PropAcc {  // accessor over the propagated class array (0x40 = continuation byte)
+    const uint8_t* cls2;
+    const uint8_t* text;
+    uint64_t n;
+    uint32_t cls(uint64_t pos) const {
+        if (pos >= n) return (uint32_t)TK_C_END;
+        uint32_t c = cls2[pos];
+        return (c & 0x40u) ? (uint32_t)TK_C_CONT : (c & 0x8Fu);
+    }
+    uint32_t byte(uint64_t pos) const { return text[pos]; }
+};
+
+static uint64_t win_of(const std::vector<uint8_t>& bm, uint64_t p) {
+    uint64_t w = 0;
+    for (uint32_t k = 0; k < 64; ++k)
+        if (p + k < bm.size() && bm[p + k]) w |= 1ull << k;
+    return w;
+}
+
+uint64_t tks_pretok_bits(void* pv, const uint8_t* text_in, uint64_t n, const uint64_t* doc_off, uint64_t n_docs, uint8_t* starts) {
+    Sim* s = (Sim*)pv;
+    std::vector<uint8_t> text(text_in, text_in + n);
+    text.resize(n + 64, 0);
+    std::vector<uint32_t> brk((n + 31) / 32 + 2, 0);
+    for (uint64_t d = 0; d < n_docs; ++d)
+        if (doc_off[d] < n) brk[doc_off[d] >> 5] |= 1u << (doc_off[d] & 31);
+    std::vector<uint8_t> cls2(n + 80, TK_C_END | 0x80);
+    uint8_t last = TK_C_OT;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t c = tk_class_byte(s->T, text.data(), i, n, brk.data(), nullptr, nullptr);
+        if ((c & 15u) == TK_C_CONT) cls2[i] = (uint8_t)(last | 0x40);
+        else {
+            cls2[i] = (uint8_t)c;
+            last = (uint8_t)(c & 15u);
+        }
+    }
+    // bitmaps (one byte per bit here; the kernel packs them with __ballot)
+    const size_t m = n + 80;
+    std::vector<uint8_t> b_start(m, 0), b_hard(m, 0), b_L(m, 0), b_up(m, 0), b_low(m, 0), b_cas(m, 0), b_oth(m, 0), b_ws(m, 0),
+        b_nl(m, 0), b_nu(m, 0), b_nlsl(m, 0);
+    for (uint64_t i = 0; i < m; ++i) {
+        if (i >= n) {
+            b_start[i] = 1;
+            b_hard[i] = 1;
+            continue;
+        }
+        uint32_t c = cls2[i], k = c & 15u;
+        b_start[i] = !(c & 0x40u);
+        b_hard[i] = (c & 0x80u) != 0;
+        b_L[i] = (TK_M_L >> k) & 1u;
+        b_up[i] = (TK_M_UPPERISH >> k) & 1u;
+        b_low[i] = (TK_M_LOWERISH >> k) & 1u;
+        b_cas[i] = k == TK_C_LC || k == TK_C_MK;
+        b_oth[i] = (TK_M_OTHER >> k) & 1u;
+        b_ws[i] = (TK_M_WS >> k) & 1u;
+        b_nl[i] = k == TK_C_NL;
+        b_nu[i] = k == TK_C_NU;
+        b_nlsl[i] = k == TK_C_NL || k == TK_C_SL;
+    }
+    memset(starts, 0, n);
+    PropAcc acc{cls2.data(), text.data(), n};
+    const int pat = s->T.pattern;
+    uint64_t n_fallback = 0;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t c = cls2[i];
+        if (c & 0x40u) continue;
+        bool certain = (c & 0x80u) != 0;
+        if (!certain) {
+            if (i == 0) continue;
+            certain = tk_certain_start(pat, cls2[i - 1] & 15u, c & 15u);  // propagated class: no walking back
+        }
+        if (!certain) continue;
+        starts[i] = 1;
+        uint64_t q = i;
+        for (;;) {
+            TkWin w;
+            w.start = win_of(b_start, q);
+            w.stop = win_of(b_hard, q) & ~1ull;
+            w.L = win_of(b_L, q);
+            w.up = win_of(b_up, q);
+            w.low = win_of(b_low, q);
+            w.cas = win_of(b_cas, q);
+            w.oth = win_of(b_oth, q);
+            w.ws = win_of(b_ws, q);
+            w.nl = win_of(b_nl, q);
+            w.nu = win_of(b_nu, q);
+            w.nlsl = win_of(b_nlsl, q);
+            uint32_t len = tk_piece_len_bits(w, acc, q, cls2[q] & 15u, pat);
+            uint64_t e;
+            if (len) {
+                e = q + len;
+            } else {
+                ++n_fallback;
+                e = tk_piece_end(acc, q, pat);
+            }
+            if (e <= q) e = tk_next_char(acc, q);
+            if (e >= n) break;
+            uint32_t ce = cls2[e];
+            if (ce & 0x80u) break;
+            if (tk_certain_start(pat, cls2[e - 1] & 15u, ce & 15u)) break;
+            starts[e] = 1;
+            q = e;
+        }
+    }
+    return n_fallback;
+}
+
 // Mirror of the per-piece work of tk_k_lookup for pieces of <= 16 bytes; longer pieces use the
 // same probes with a simple sequential merge over ids (the wave / tree kernels cannot run here).
 int64_t tks_encode_piece(void* p, const uint8_t* piece, uint32_t len, uint32_t* out) {

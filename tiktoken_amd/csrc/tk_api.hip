@@ -66,6 +66,7 @@ struct tk_core {
     Buf text, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, tok1, cnt, tokbase, staging, listB, listC,
         counters, total, partial, g_id, g_rk, g_nx, g_pv, g_lv, out_tokens, out_tok_off, allowed;
     uint64_t chunk_bytes = 1ull << 30;
+    int dbg = 0;
     // instrumentation
     bool profiling = false;
     std::map<std::string, KernelStat> stats;
@@ -184,6 +185,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
         uint64_t v = strtoull(e, nullptr, 10);
         if (v >= 4096 && v <= (3ull << 30)) c->chunk_bytes = v;
     }
+    if (const char* e = getenv("TIKTOKEN_AMD_DEBUG")) c->dbg = atoi(e);
     *out = c;
     return TK_OK;
 }
@@ -254,9 +256,15 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
                                    c->spec_max_len, ss, si, brk);
             }));
         }
-        TRY(timed(c, s, "tk_k_pretok", [&] {
-            hipLaunchKernelGGL(tk_k_pretok, dim3((uint32_t)((n + TK_TILE - 1) / TK_TILE)), dim3(256), 0, s, T, d_text, n, brk, ss, si, starts);
-        }));
+        if (c->dbg & 32) {
+            TRY(timed(c, s, "tk_k_pretok", [&] {
+                hipLaunchKernelGGL(tk_k_pretok, dim3((uint32_t)((n + TK_TILE - 1) / TK_TILE)), dim3(256), 0, s, T, d_text, n, brk, ss, si, starts, c->dbg);
+            }));
+        } else {
+            TRY(timed(c, s, "tk_k_pretok2", [&] {
+                hipLaunchKernelGGL(tk_k_pretok2, dim3((uint32_t)((n + TK_TILE - 1) / TK_TILE)), dim3(256), 0, s, T, d_text, n, brk, ss, si, starts);
+            }));
+        }
         TRY(timed(c, s, "tk_k_count", [&] {
             hipLaunchKernelGGL(tk_k_count, dim3((uint32_t)nblk), dim3(256), 0, s, starts, nwords, c->blockcnt.as<uint32_t>());
         }));
@@ -296,7 +304,7 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         TRY(timed(c, s, "tk_k_lookup", [&] {
             hipLaunchKernelGGL(tk_k_lookup, dim3(grid_for(P, 256 * TK_PPT, 4096)), dim3(256), 0, s, T, d_text, pstart, P, ss,
                                c->tok1.as<uint32_t>(), c->cnt.as<uint32_t>(), c->staging.as<uint32_t>(), c->listB.as<uint32_t>(),
-                               c->listC.as<uint32_t>(), counters);
+                               c->listC.as<uint32_t>(), counters, c->dbg);
         }));
         uint32_t hc[TK_CNT_N];
         HIPCHK(hipMemcpyAsync(hc, counters, sizeof hc, hipMemcpyDeviceToHost, s));

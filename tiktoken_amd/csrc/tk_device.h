@@ -273,6 +273,148 @@ TK_HD uint64_t tk_piece_end(A& a, uint64_t p, int pat) {
 }
 
 // ------------------------------------------------------------------------------------------
+// Bit-parallel form of the scanner.  The pre-tokeniser kernel keeps, per tile, one bitmap per class
+// set (bit = text byte; continuation bytes carry the class of their char).  At a piece start p it
+// extracts 64-bit windows (bit k <-> position p + k); run ends are then `ctz` of a masked window
+// instead of a byte-walking loop.  Returns the piece length in bytes, or 0 when the piece is not
+// resolved inside the window (caller falls back to tk_piece_end).
+// ------------------------------------------------------------------------------------------
+struct TkWin {
+    uint64_t start;  // char starts
+    uint64_t stop;   // positions k >= 1 where look-ahead sees end-of-text (hard start or past the end)
+    uint64_t L, up, low, cas, oth, ws, nl, nu, nlsl;
+};
+
+#if defined(__HIP_DEVICE_COMPILE__)
+TK_HD uint32_t tk_ctz64(uint64_t v) { return v ? (uint32_t)(__ffsll((unsigned long long)v) - 1) : 64u; }
+TK_HD uint32_t tk_clz64(uint64_t v) { return v ? (uint32_t)__clzll((long long)v) : 64u; }
+TK_HD uint32_t tk_popc64(uint64_t v) { return (uint32_t)__popcll(v); }
+#else
+TK_HD uint32_t tk_ctz64(uint64_t v) { return v ? (uint32_t)__builtin_ctzll(v) : 64u; }
+TK_HD uint32_t tk_clz64(uint64_t v) { return v ? (uint32_t)__builtin_clzll(v) : 64u; }
+TK_HD uint32_t tk_popc64(uint64_t v) { return (uint32_t)__builtin_popcountll(v); }
+#endif
+
+TK_HD uint64_t tk_below(uint32_t b) { return b >= 64u ? ~0ull : ((1ull << b) - 1ull); }  // bits [0, b)
+// number of consecutive positions k >= from whose bit is set and that are not stops
+TK_HD uint32_t tk_run(uint64_t bits, uint64_t stop, uint32_t from) {
+    if (from >= 64u) return 0;
+    uint64_t x = (bits & ~stop) >> from;
+    return tk_ctz64(~x);  // zeros shifted in from the top bound the result by 64 - from
+}
+
+#define TK_WIN_SAFE 58u  // results beyond this relative position are treated as unresolved
+
+template <class A>
+TK_HD uint32_t tk_contraction_bits(const TkWin& w, A& a, uint64_t p, uint32_t e, bool ci) {
+    if ((w.stop >> (e + 1)) & 1ull) return 0;
+    uint32_t b1 = a.byte(p + e + 1);
+    if (ci) {
+        if (b1 == 0xC5u) return (!((w.start >> (e + 2)) & 1ull) && !((w.stop >> (e + 2)) & 1ull) && a.byte(p + e + 2) == 0xBFu) ? 3u : 0u;
+        uint32_t al = b1 | 0x20u;
+        if (b1 >= 0x80u || al < 'a' || al > 'z') return 0;
+        if (al == 's' || al == 'd' || al == 'm' || al == 't') return 2;
+        if ((w.stop >> (e + 2)) & 1ull) return 0;
+        uint32_t b2 = a.byte(p + e + 2), bl = b2 | 0x20u;
+        if (b2 >= 0x80u) return 0;
+        if ((al == 'l' && bl == 'l') || (al == 'v' && bl == 'e') || (al == 'r' && bl == 'e')) return 3;
+        return 0;
+    }
+    if (b1 == 's' || b1 == 'd' || b1 == 'm' || b1 == 't') return 2;
+    if ((w.stop >> (e + 2)) & 1ull) return 0;
+    uint32_t b2 = a.byte(p + e + 2);
+    if ((b1 == 'l' && b2 == 'l') || (b1 == 'v' && b2 == 'e') || (b1 == 'r' && b2 == 'e')) return 3;
+    return 0;
+}
+
+// c = class nibble of the char at p
+template <class A>
+TK_HD uint32_t tk_piece_len_bits(const TkWin& w, A& a, uint64_t p, uint32_t c, int pat) {
+    const uint64_t stop = w.stop;
+    // length of the first char: next char start or stop after position 0
+    const uint32_t k1 = 1u + tk_ctz64((w.start | stop) >> 1);
+    if (k1 > 4u) return 0;  // (special-token pieces and anything odd go through the generic scanner)
+    if (c == TK_C_SPEC) return 0;
+    const bool nxt_end = (stop >> k1) & 1ull;
+    uint32_t e = 0;
+    if (pat == TK_PAT_O200K) {
+        const uint64_t word = w.up | w.low;
+        uint32_t ks = 64;
+        if ((TK_M_WORD >> c) & 1u) ks = 0;
+        else if (c != TK_C_NL && c != TK_C_NU && !nxt_end && ((word >> k1) & 1ull)) ks = k1;
+        if (ks != 64u) {
+            uint32_t re = ks + tk_run(w.up, stop, ks);
+            uint32_t te = re + tk_run(w.low, stop, re);
+            if (te > TK_WIN_SAFE) return 0;
+            if (te > re) {
+                e = te;
+            } else {
+                uint64_t x = w.cas & ~stop & tk_below(re) & ~tk_below(ks);
+                e = x ? 64u - tk_clz64(x) : re;
+            }
+            if (!((stop >> e) & 1ull) && a.byte(p + e) == '\'') e += tk_contraction_bits(w, a, p, e, true);
+            return e;
+        }
+    } else if (pat == TK_PAT_CL100K) {
+        if (c == TK_C_AP) {
+            uint32_t k = tk_contraction_bits(w, a, p, 0, true);
+            if (k) return k;
+        }
+        if ((TK_M_L >> c) & 1u) {
+            e = tk_run(w.L, stop, 0);
+            return e > TK_WIN_SAFE ? 0 : e;
+        }
+        if (c != TK_C_NL && c != TK_C_NU && !nxt_end && ((w.L >> k1) & 1ull)) {
+            e = k1 + tk_run(w.L, stop, k1);
+            return e > TK_WIN_SAFE ? 0 : e;
+        }
+    } else {
+        if (c == TK_C_AP) {
+            uint32_t k = tk_contraction_bits(w, a, p, 0, false);
+            if (k) return k;
+        }
+    }
+    if (pat != TK_PAT_R50K && c == TK_C_NU) {
+        uint32_t r = tk_run(w.nu, stop, 0);
+        uint64_t sx = w.start & tk_below(r);
+        sx &= sx - 1;
+        sx &= sx - 1;
+        sx &= sx - 1;
+        e = sx ? tk_ctz64(sx) : r;
+        return e > TK_WIN_SAFE ? 0 : e;
+    }
+    // optional single space, then a run of one kind (r50k: letters / digits / other; others: other only)
+    uint32_t s = 0;
+    bool s_ok = true;
+    if (c == TK_C_SP && !nxt_end) s = k1;
+    if (pat == TK_PAT_R50K) {
+        if ((w.L >> s) & 1ull) e = s + tk_run(w.L, stop, s);
+        else if ((w.nu >> s) & 1ull) e = s + tk_run(w.nu, stop, s);
+        else if ((w.oth >> s) & 1ull) e = s + tk_run(w.oth, stop, s);
+        else s_ok = false;
+    } else if ((w.oth >> s) & 1ull) {
+        uint32_t e1 = s + tk_run(w.oth, stop, s);
+        e = e1 + tk_run(pat == TK_PAT_O200K ? w.nlsl : w.nl, stop, e1);
+    } else {
+        s_ok = false;
+    }
+    if (s_ok) return e > TK_WIN_SAFE ? 0 : e;
+    // white space
+    {
+        uint32_t q = tk_run(w.ws, stop, 0);
+        if (q > TK_WIN_SAFE) return 0;
+        uint64_t rng = tk_below(q);
+        bool at_end = (stop >> q) & 1ull;
+        uint64_t nlr = w.nl & rng, st = w.start & rng;
+        if (pat != TK_PAT_O200K && at_end) return q;
+        if (pat != TK_PAT_R50K && nlr) return 64u - tk_clz64(nlr);
+        if (at_end) return q;
+        if (tk_popc64(st) >= 2u) return 63u - tk_clz64(st);
+        return q;
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // table probes
 // ------------------------------------------------------------------------------------------
 // Exact bytes -> rank probe.  `key` = packed bytes (len <= 8) or tk hash (len > 8); for len > 8

@@ -82,6 +82,17 @@ __device__ __forceinline__ uint32_t tk_block_exscan_256(uint32_t v, uint32_t* to
     return base + inc - v;
 }
 
+// wave-aggregated append: every lane with `want` gets a distinct slot index from the LDS counter
+__device__ __forceinline__ uint32_t tk_wave_append(bool want, uint32_t* counter, int lane) {
+    uint64_t m = __ballot(want);
+    if (!m) return 0;
+    int leader = __ffsll((unsigned long long)m) - 1;
+    uint32_t base = 0;
+    if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
 // ------------------------------------------------------------------------------------------
 // document starts -> bitmaps
 // ------------------------------------------------------------------------------------------
@@ -212,7 +223,7 @@ struct TkWinAcc {
 // typically evaluates one piece.  Units never communicate: the rule only needs the previous char.
 __global__ __launch_bounds__(256) void tk_k_pretok(TkTables T, const uint8_t* __restrict__ text, uint64_t n,
                                                    const uint32_t* __restrict__ brk, const uint32_t* __restrict__ ss,
-                                                   const uint32_t* __restrict__ si, uint32_t* __restrict__ starts) {
+                                                   const uint32_t* __restrict__ si, uint32_t* __restrict__ starts, int dbg) {
     __shared__ uint8_t win[TK_WIN];
     __shared__ uint32_t bits[TK_TILE / 32];
     const uint64_t tile_start = (uint64_t)blockIdx.x * TK_TILE;
@@ -242,6 +253,7 @@ __global__ __launch_bounds__(256) void tk_k_pretok(TkTables T, const uint8_t* __
         if (!certain) continue;
         atomicOr(&bits[il >> 5], 1u << (il & 31));
         uint64_t p = gp;
+        if (dbg & 16) continue;
         for (;;) {
             uint64_t e = tk_piece_end(acc, p, pat);
             if (e <= p) e = tk_next_char(acc, p);  // defensive; cannot happen
@@ -263,6 +275,220 @@ __global__ __launch_bounds__(256) void tk_k_pretok(TkTables T, const uint8_t* __
         uint32_t v = bits[threadIdx.x];
         uint64_t wi = tile_start / 32 + threadIdx.x;
         if (v) atomicOr(&starts[wi], v);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// pre-tokenisation, bit-parallel (the production kernel; tk_k_pretok above is the byte-walking
+// original, kept as the reference implementation behind TIKTOKEN_AMD_DEBUG=32)
+//
+// One workgroup per 4 KiB tile; window = 64 B left context + tile + 192 B right halo (68 wave-sized
+// segments).  Phase A: 16-byte vector loads of the window into LDS.  Phase B: one wave per 64-byte
+// segment, lane = byte: class of every byte (continuation bytes inherit their char's class), then
+// eleven `__ballot`s give one 64-bit word of each class bitmap.  Phase C: certain piece starts
+// (previous byte's class x this class) are compacted into an LDS list.  Phase D: one lane per certain
+// start evaluates pieces with tk_piece_len_bits -- run ends are `ctz` on 64-bit bitmap windows --
+// until the next certain start.  Phase E: the tile's 512-byte slice of the start bitmap is OR-ed out.
+// ------------------------------------------------------------------------------------------
+#define TK2_LEFT 64
+#define TK2_RIGHT 192
+#define TK2_WIN (TK2_LEFT + TK_TILE + TK2_RIGHT)  // 4352
+#define TK2_NSEG (TK2_WIN / 64)                   // 68
+enum { TKB_START = 0, TKB_HARD, TKB_L, TKB_UP, TKB_LOW, TKB_CAS, TKB_OTH, TKB_WS, TKB_NL, TKB_NU, TKB_NLSL, TKB_KINDS };
+
+struct TkWin2Acc {  // byte-walking fallback: propagated classes inside the window, HBM outside
+    const uint8_t* cls2;
+    const uint8_t* raw;
+    int64_t base;
+    const TkTables* T;
+    const uint8_t* text;
+    uint64_t n;
+    const uint32_t *brk, *ss, *si;
+    __device__ __forceinline__ uint32_t cls(uint64_t pos) const {
+        if (pos >= n) return TK_C_END;
+        int64_t r = (int64_t)pos - base;
+        if (r >= 0 && r < TK2_WIN) {
+            uint32_t c = cls2[r];
+            return (c & 0x40u) ? (uint32_t)TK_C_CONT : (c & 0x8Fu);
+        }
+        return tk_class_byte(*T, text, pos, n, brk, ss, si);
+    }
+    __device__ __forceinline__ uint32_t byte(uint64_t pos) const {
+        int64_t r = (int64_t)pos - base;
+        if (r >= 0 && r < TK2_WIN) return raw[r];
+        return text[pos];
+    }
+};
+
+__global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* __restrict__ text, uint64_t n,
+                                                    const uint32_t* __restrict__ brk, const uint32_t* __restrict__ ss,
+                                                    const uint32_t* __restrict__ si, uint32_t* __restrict__ starts) {
+    __shared__ __attribute__((aligned(16))) uint8_t raw[TK2_WIN + 16];
+    __shared__ uint8_t cls2[TK2_WIN];
+    __shared__ uint64_t bm[TKB_KINDS][TK2_NSEG + 2];
+    __shared__ uint32_t bits[TK_TILE / 32];
+    __shared__ uint16_t clist[TK_TILE];
+    __shared__ uint32_t cn;
+    __shared__ uint8_t c1[128];
+    const uint32_t tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const uint64_t tile_start = (uint64_t)blockIdx.x * TK_TILE;
+    const int64_t base = (int64_t)tile_start - TK2_LEFT;
+    // ---- A: window -> LDS
+    for (uint32_t v = tid; v < (TK2_WIN + 16) / 16; v += 256) {
+        int64_t gp = base + (int64_t)v * 16;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (gp >= 0 && (uint64_t)gp < n) x = *(const uint4*)(text + gp);  // text is readable 64 bytes past n
+        *(uint4*)(raw + v * 16) = x;
+    }
+    if (tid < 128) c1[tid] = (uint8_t)tk_class_of_cp(T, tid);
+    if (tid < TK_TILE / 32) bits[tid] = 0;
+    if (tid == 0) cn = 0;
+    if (tid < TKB_KINDS) {
+        bm[tid][TK2_NSEG] = tid <= TKB_HARD ? ~0ull : 0ull;  // beyond the window: unknown -> "stop"
+        bm[tid][TK2_NSEG + 1] = tid <= TKB_HARD ? ~0ull : 0ull;
+    }
+    __syncthreads();
+    // ---- B: classes + bitmaps, one wave per segment
+    for (int g = wid; g < TK2_NSEG; g += 4) {
+        const uint32_t pl = g * 64 + lane;
+        const int64_t gp = base + pl;
+        const bool valid = gp >= 0 && (uint64_t)gp < n;
+        const uint32_t b = raw[pl];
+        bool cont = valid && (b & 0xC0u) == 0x80u;
+        uint32_t c = TK_C_OT;
+        bool hard = false;
+        if (!valid) {
+            c = TK_C_END;
+            hard = gp >= 0;  // past the end: look-ahead stops here
+        } else {
+            bool spec_s = ss && tk_bit(ss, (uint64_t)gp), spec_i = si && tk_bit(si, (uint64_t)gp);
+            if (spec_i) {
+                cont = true;
+            } else if (spec_s) {
+                cont = false;
+                c = TK_C_SPEC;
+                hard = true;
+            } else if (!cont) {
+                if (b < 0x80u) {
+                    c = c1[b];
+                } else {
+                    uint32_t len = b >= 0xF0u ? 4u : (b >= 0xE0u ? 3u : 2u), cp;
+                    if ((uint64_t)gp + len > n) {
+                        c = TK_C_OT;
+                    } else {
+                        if (len == 2u) cp = ((b & 0x1Fu) << 6) | (raw[pl + 1] & 0x3Fu);
+                        else if (len == 3u) cp = ((b & 0x0Fu) << 12) | ((uint32_t)(raw[pl + 1] & 0x3Fu) << 6) | (raw[pl + 2] & 0x3Fu);
+                        else cp = ((b & 0x07u) << 18) | ((uint32_t)(raw[pl + 1] & 0x3Fu) << 12) | ((uint32_t)(raw[pl + 2] & 0x3Fu) << 6) | (raw[pl + 3] & 0x3Fu);
+                        c = tk_class_of_cp(T, cp);
+                    }
+                }
+                hard = tk_bit(brk, (uint64_t)gp);
+            }
+        }
+        // continuation bytes (and special-token interiors) inherit the class of their lead byte
+        const uint64_t leadm = __ballot(!cont);
+        const uint64_t below = leadm & ((2ull << lane) - 1ull);
+        uint32_t src = below ? 63u - (uint32_t)__clzll((long long)below) : 0u;
+        uint32_t cl = __shfl(c, (int)src, 64);
+        if (cont) {
+            if (below) {
+                c = cl;
+            } else {  // the lead byte is in an earlier segment: classify it from the window / HBM
+                int64_t q = gp - 1;
+                while (q > 0 && (tk_class_byte(T, text, (uint64_t)q, n, nullptr, ss, si) & 15u) == TK_C_CONT) --q;
+                c = q >= 0 ? (tk_class_byte(T, text, (uint64_t)q, n, nullptr, ss, si) & 15u) : (uint32_t)TK_C_OT;
+            }
+        }
+        cls2[pl] = (uint8_t)(c | (cont ? 0x40u : 0u) | (hard ? 0x80u : 0u));
+        const uint64_t w_start = __ballot(!cont), w_hard = __ballot(hard), w_L = __ballot((TK_M_L >> c) & 1u),
+                       w_up = __ballot((TK_M_UPPERISH >> c) & 1u), w_low = __ballot((TK_M_LOWERISH >> c) & 1u),
+                       w_cas = __ballot(c == TK_C_LC || c == TK_C_MK), w_oth = __ballot((TK_M_OTHER >> c) & 1u),
+                       w_ws = __ballot((TK_M_WS >> c) & 1u), w_nl = __ballot(c == TK_C_NL), w_nu = __ballot(c == TK_C_NU),
+                       w_nlsl = __ballot(c == TK_C_NL || c == TK_C_SL);
+        if (lane == 0) {
+            bm[TKB_START][g] = w_start;
+            bm[TKB_HARD][g] = w_hard;
+            bm[TKB_L][g] = w_L;
+            bm[TKB_UP][g] = w_up;
+            bm[TKB_LOW][g] = w_low;
+            bm[TKB_CAS][g] = w_cas;
+            bm[TKB_OTH][g] = w_oth;
+            bm[TKB_WS][g] = w_ws;
+            bm[TKB_NL][g] = w_nl;
+            bm[TKB_NU][g] = w_nu;
+            bm[TKB_NLSL][g] = w_nlsl;
+        }
+    }
+    __syncthreads();
+    // ---- C: certain starts of the tile -> list
+    const int pat = T.pattern;
+    for (int k = 0; k < TK_TILE / 256; ++k) {
+        const uint32_t il = tid + k * 256, pl = TK2_LEFT + il;
+        const uint32_t c = cls2[pl];
+        bool certain = false;
+        if (tile_start + il < n && !(c & 0x40u)) certain = (c & 0x80u) || tk_certain_start(pat, cls2[pl - 1] & 15u, c & 15u);
+        uint32_t idx = tk_wave_append(certain, &cn, lane);
+        if (certain) {
+            clist[idx] = (uint16_t)pl;
+            atomicOr(&bits[il >> 5], 1u << (il & 31));
+        }
+    }
+    __syncthreads();
+    // ---- D: one lane per certain start
+    TkWin2Acc acc{cls2, raw, base, &T, text, n, brk, ss, si};
+    const uint32_t ncert = cn;
+    for (uint32_t i = tid; i < ncert; i += 256) {
+        uint64_t p = (uint64_t)(base + clist[i]);
+        for (;;) {
+            const int64_t r = (int64_t)p - base;
+            uint32_t len = 0;
+            if (r >= 0 && r + 64 <= TK2_WIN) {
+                const uint32_t wi = (uint32_t)r >> 6, sh = (uint32_t)r & 63u;
+                TkWin w;
+#define TK_FUNNEL(kind) (sh ? ((bm[kind][wi] >> sh) | (bm[kind][wi + 1] << (64u - sh))) : bm[kind][wi])
+                w.start = TK_FUNNEL(TKB_START);
+                w.stop = TK_FUNNEL(TKB_HARD) & ~1ull;
+                w.L = TK_FUNNEL(TKB_L);
+                w.up = TK_FUNNEL(TKB_UP);
+                w.low = TK_FUNNEL(TKB_LOW);
+                w.cas = TK_FUNNEL(TKB_CAS);
+                w.oth = TK_FUNNEL(TKB_OTH);
+                w.ws = TK_FUNNEL(TKB_WS);
+                w.nl = TK_FUNNEL(TKB_NL);
+                w.nu = TK_FUNNEL(TKB_NU);
+                w.nlsl = TK_FUNNEL(TKB_NLSL);
+#undef TK_FUNNEL
+                len = tk_piece_len_bits(w, acc, p, cls2[r] & 15u, pat);
+            }
+            uint64_t e = len ? p + len : tk_piece_end(acc, p, pat);
+            if (e <= p) e = tk_next_char(acc, p);
+            if (e >= n) break;
+            const int64_t re = (int64_t)e - base;
+            uint32_t ce, pc;
+            if (re < TK2_WIN) {
+                ce = cls2[re];
+                pc = cls2[re - 1] & 15u;
+            } else {
+                ce = acc.cls(e);
+                uint64_t j = e - 1;
+                while (acc.cls(j) == TK_C_CONT) --j;
+                pc = acc.cls(j) & 15u;
+            }
+            if (ce & 0x80u) break;
+            if (tk_certain_start(pat, pc, ce & 15u)) break;
+            if (e < tile_start + TK_TILE)
+                atomicOr(&bits[(uint32_t)(e - tile_start) >> 5], 1u << ((uint32_t)(e - tile_start) & 31));
+            else
+                atomicOr(&starts[e >> 5], 1u << (e & 31));
+            p = e;
+        }
+    }
+    __syncthreads();
+    // ---- E
+    if (tid < TK_TILE / 32) {
+        uint32_t v = bits[tid];
+        if (v) atomicOr(&starts[tile_start / 32 + tid], v);
     }
 }
 
@@ -329,54 +555,100 @@ __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __
                                                    uint64_t P, const uint32_t* __restrict__ ss, uint32_t* __restrict__ tok1,
                                                    uint32_t* __restrict__ cnt, uint32_t* __restrict__ staging,
                                                    uint32_t* __restrict__ listB, uint32_t* __restrict__ listC,
-                                                   uint32_t* __restrict__ counters) {
-    __shared__ uint32_t q[256 * TK_PPT];
-    __shared__ uint32_t qn;
+                                                   uint32_t* __restrict__ counters, int dbg) {
+    __shared__ uint32_t q[256 * TK_PPT];   // short misses (block-relative piece index)
+    __shared__ uint32_t qB[256 * TK_PPT];  // 17..64-byte misses
+    __shared__ uint32_t qC[3 * 64];        // longer misses: {piece, bytes before it, levels before it} (spill handled below)
+    __shared__ uint32_t sh_cnt[8];         // 0 qn, 1 nB, 2 nC, 3 cbytes, 4 clevels, 5 gB, 6 gC/gbytes/glv base follow
     __shared__ uint32_t s_id[TK_LANE_MAX * 256];
     __shared__ uint32_t s_rk[TK_LANE_MAX * 256];
     const uint32_t tid = threadIdx.x;
+    const int lane = tid & 63;
     for (uint64_t base = (uint64_t)blockIdx.x * (256 * TK_PPT); base < P; base += (uint64_t)gridDim.x * (256 * TK_PPT)) {
-        if (tid == 0) qn = 0;
+        if (tid < 8) sh_cnt[tid] = 0;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < TK_PPT; ++k) {
             uint64_t p = base + (uint64_t)k * 256 + tid;
-            if (p >= P) continue;
-            uint32_t s = pstart[p], len = pstart[p + 1] - s;
-            if (ss && tk_bit(ss, s)) {
-                tok1[p] = tk_special_id(T, text, s, len);
-                cnt[p] = 1;
-                continue;
+            bool missA = false, missB = false, missC = false;
+            uint32_t s = 0, len = 0;
+            if (p < P) {
+                s = pstart[p];
+                len = pstart[p + 1] - s;
+                if (ss && tk_bit(ss, s)) {
+                    tok1[p] = tk_special_id(T, text, s, len);
+                    cnt[p] = 1;
+                } else {
+                    uint32_t r = (dbg & 2) ? len : tk_lookup_text_piece(T, text, s, len);
+                    if ((dbg & 8) && r == TK_RANK_MAX) r = 0;
+                    if (r != TK_RANK_MAX) {
+                        if (!(dbg & 4)) {
+                            tok1[p] = r;
+                            cnt[p] = 1;
+                        }
+                    } else if (len <= TK_LANE_MAX) {
+                        missA = true;
+                    } else if (len <= TK_WAVE_MAX) {
+                        missB = true;
+                    } else {
+                        missC = true;
+                    }
+                }
             }
-            uint32_t r = tk_lookup_text_piece(T, text, s, len);
-            if (r != TK_RANK_MAX) {
-                tok1[p] = r;
-                cnt[p] = 1;
-            } else if (len <= TK_LANE_MAX) {
-                q[atomicAdd(&qn, 1u)] = (uint32_t)(p - base);
-            } else if (len <= TK_WAVE_MAX) {
-                listB[atomicAdd(&counters[TK_CNT_B], 1u)] = (uint32_t)p;
-            } else {
+            uint32_t ia = tk_wave_append(missA, &sh_cnt[0], lane);
+            if (missA) q[ia] = (uint32_t)(p - base);
+            uint32_t ib = tk_wave_append(missB, &sh_cnt[1], lane);
+            if (missB) qB[ib] = (uint32_t)p;
+            if (missC) {
                 // scratch for the long path: 4 uint32 per byte + the 64-ary min-tree levels
                 uint32_t lv = 0, c = len;
                 do {
                     c = (c + 63) >> 6;
                     lv += c;
                 } while (c > 64);
-                uint32_t i = atomicAdd(&counters[TK_CNT_C], 1u);
-                listC[3 * (uint64_t)i] = (uint32_t)p;
-                listC[3 * (uint64_t)i + 1] = atomicAdd(&counters[TK_CNT_CBYTES], len);
-                listC[3 * (uint64_t)i + 2] = atomicAdd(&counters[TK_CNT_CLEVELS], lv);
+                uint32_t i = atomicAdd(&sh_cnt[2], 1u);
+                if (i < 64) {
+                    qC[3 * i] = (uint32_t)p;
+                    qC[3 * i + 1] = atomicAdd(&sh_cnt[3], len);
+                    qC[3 * i + 2] = atomicAdd(&sh_cnt[4], lv);
+                } else {  // more than 64 long pieces in 1024: straight to the global list
+                    uint32_t gi = atomicAdd(&counters[TK_CNT_C], 1u);
+                    listC[3 * (uint64_t)gi] = (uint32_t)p;
+                    listC[3 * (uint64_t)gi + 1] = atomicAdd(&counters[TK_CNT_CBYTES], len);
+                    listC[3 * (uint64_t)gi + 2] = atomicAdd(&counters[TK_CNT_CLEVELS], lv);
+                }
             }
         }
         __syncthreads();
-        const uint32_t nq = qn;
+        // one global reservation per list per block iteration (a single shared counter saturates at
+        // ~90 M atomics/s when every wave hits it)
+        if (tid == 0) {
+            uint32_t nB = sh_cnt[1], nC = sh_cnt[2] < 64 ? sh_cnt[2] : 64;
+            sh_cnt[5] = nB ? atomicAdd(&counters[TK_CNT_B], nB) : 0;
+            if (nC) {
+                sh_cnt[6] = atomicAdd(&counters[TK_CNT_C], nC);
+                sh_cnt[7] = atomicAdd(&counters[TK_CNT_CBYTES], sh_cnt[3]);
+                sh_cnt[3] = atomicAdd(&counters[TK_CNT_CLEVELS], sh_cnt[4]);
+            }
+        }
+        __syncthreads();
+        {
+            const uint32_t nB = sh_cnt[1], nC = sh_cnt[2] < 64 ? sh_cnt[2] : 64;
+            const uint32_t gB = sh_cnt[5], gC = sh_cnt[6], gbytes = sh_cnt[7], glv = sh_cnt[3];
+            for (uint32_t i = tid; i < nB; i += 256) listB[gB + i] = qB[i];
+            if (tid < nC) {
+                listC[3 * (uint64_t)(gC + tid)] = qC[3 * tid];
+                listC[3 * (uint64_t)(gC + tid) + 1] = gbytes + qC[3 * tid + 1];
+                listC[3 * (uint64_t)(gC + tid) + 2] = glv + qC[3 * tid + 2];
+            }
+        }
+        const uint32_t nq = sh_cnt[0];
         for (uint32_t r0 = 0; r0 < nq; r0 += 256) {
             if (r0 + tid < nq) {
                 uint64_t p = base + q[r0 + tid];
                 uint32_t s = pstart[p], len = pstart[p + 1] - s;
                 uint32_t one = 0;
-                uint32_t c = tk_lane_merge<256>(T, text, s, len, s_id + tid, s_rk + tid, &one, staging + s);
+                uint32_t c = (dbg & 1) ? 1u : tk_lane_merge<256>(T, text, s, len, s_id + tid, s_rk + tid, &one, staging + s);
                 cnt[p] = c;
                 if (c == 1) tok1[p] = one;
             }
