@@ -2,6 +2,7 @@
 // Host code here only builds tables, moves buffers and launches kernels; every byte of
 // pre-tokenisation and merging is done by the kernels in tk_kernels.h.  There is no CPU path.
 #include <hip/hip_runtime.h>
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
@@ -64,7 +65,7 @@ struct tk_core {
     std::mutex mu;
     // workspace
     Buf text, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, tok1, cnt, tokbase, staging, listB, listC,
-        counters, total, partial, g_id, g_rk, g_nx, g_pv, g_lv, out_tokens, out_tok_off, allowed;
+        counters, total, partial, rkb, g_id, g_rk, g_nx, g_pv, g_lv, out_tokens, out_tok_off, allowed;
     uint64_t chunk_bytes = 1ull << 30;
     int dbg = 0;
     // instrumentation
@@ -196,7 +197,7 @@ extern "C" void tk_destroy(tk_core* c) {
     for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_piece, &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2,
                    &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off, &c->brk, &c->docb,
                    &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->tok1, &c->cnt, &c->tokbase, &c->staging,
-                   &c->listB, &c->listC, &c->counters, &c->total, &c->partial, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv,
+                   &c->listB, &c->listC, &c->counters, &c->total, &c->partial, &c->rkb, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv,
                    &c->out_tokens, &c->out_tok_off, &c->allowed})
         release(*b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -298,24 +299,45 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
             return TK_OK;
         }
         TRY(ensure(c->staging, (n + 64) * 4));
-        TRY(ensure(c->listB, (n / 17 + 64) * 4));
+        TkBins bins;
+        uint64_t pool = 0;
+        for (int b = 0; b < TK_NBIN; ++b) {
+            bins.off[b] = (uint32_t)pool;
+            pool += n / tk_bin_lo(b) + 64;
+        }
+        TRY(ensure(c->listB, pool * 4));
         TRY(ensure(c->listC, (n / 65 + 64) * 12));
         uint32_t* counters = c->counters.as<uint32_t>();
         TRY(timed(c, s, "tk_k_lookup", [&] {
             hipLaunchKernelGGL(tk_k_lookup, dim3(grid_for(P, 256 * TK_PPT, 4096)), dim3(256), 0, s, T, d_text, pstart, P, ss,
-                               c->tok1.as<uint32_t>(), c->cnt.as<uint32_t>(), c->staging.as<uint32_t>(), c->listB.as<uint32_t>(),
+                               c->tok1.as<uint32_t>(), c->cnt.as<uint32_t>(), c->staging.as<uint32_t>(), c->listB.as<uint32_t>(), bins,
                                c->listC.as<uint32_t>(), counters, c->dbg);
         }));
         uint32_t hc[TK_CNT_N];
         HIPCHK(hipMemcpyAsync(hc, counters, sizeof hc, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
-        nB = hc[TK_CNT_B];
         nC = hc[TK_CNT_C];
+        for (int b = 0; b < TK_NBIN; ++b) nB += hc[TK_CNT_BIN0 + b];
         if (nB) {
-            TRY(timed(c, s, "tk_k_merge_wave", [&] {
-                hipLaunchKernelGGL(tk_k_merge_wave, dim3(grid_for(nB, 4, 8192)), dim3(256), 0, s, T, d_text, pstart, c->listB.as<uint32_t>(),
-                                   (uint32_t)nB, c->tok1.as<uint32_t>(), c->cnt.as<uint32_t>(), c->staging.as<uint32_t>());
-            }));
+            static const char* const names[TK_NBIN] = {"tk_k_merge_llane_24", "tk_k_merge_llane_32", "tk_k_merge_llane_48",
+                                                       "tk_k_merge_llane_64", "tk_k_merge_llane_96", "tk_k_merge_llane_128"};
+            for (int b = 0; b < TK_NBIN; ++b) {
+                uint32_t cntb = hc[TK_CNT_BIN0 + b];
+                if (!cntb) continue;
+                if (c->dbg & 64) fprintf(stderr, "bin %d (%u..%u bytes): %u pieces\n", b, tk_bin_lo(b), tk_bin_hi(b), cntb);
+                const uint32_t* lst = c->listB.as<uint32_t>() + bins.off[b];
+                uint32_t *t1 = c->tok1.as<uint32_t>(), *cn = c->cnt.as<uint32_t>(), *stg = c->staging.as<uint32_t>();
+                TRY(timed(c, s, names[b], [&] {
+                    switch (b) {
+                        case 0: hipLaunchKernelGGL((tk_k_merge_llane<24, 256>), dim3(grid_for(cntb, 256, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
+                        case 1: hipLaunchKernelGGL((tk_k_merge_llane<32, 256>), dim3(grid_for(cntb, 256, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
+                        case 2: hipLaunchKernelGGL((tk_k_merge_llane<48, 128>), dim3(grid_for(cntb, 128, 16384)), dim3(128), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
+                        case 3: hipLaunchKernelGGL((tk_k_merge_llane<64, 128>), dim3(grid_for(cntb, 128, 16384)), dim3(128), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
+                        case 4: hipLaunchKernelGGL((tk_k_merge_llane<96, 64>), dim3(grid_for(cntb, 64, 16384)), dim3(64), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
+                        default: hipLaunchKernelGGL((tk_k_merge_llane<128, 64>), dim3(grid_for(cntb, 64, 16384)), dim3(64), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
+                    }
+                }));
+            }
         }
         if (nC) {
             uint64_t lb = hc[TK_CNT_CBYTES], lvls = hc[TK_CNT_CLEVELS];

@@ -24,12 +24,29 @@
 #define TK_HALO_L 4
 #define TK_HALO_R 252
 #define TK_WIN (TK_HALO_L + TK_TILE + TK_HALO_R)
-#define TK_LANE_MAX 16   // longest piece merged by a single lane
-#define TK_WAVE_MAX 64   // longest piece merged by one wavefront in registers
+#define TK_LANE_MAX 16   // longest piece merged by a single lane inside tk_k_lookup (LDS scratch)
 #define TK_PPT 4         // pieces per thread per block iteration in tk_k_lookup
 
+// Deferred pieces are binned by length so that the 64 lanes of a wave run similar trip counts.
+#define TK_NBIN 6
+#define TK_GLANE_MAX 128  // longest piece merged one-lane-per-piece; longer ones go to the tree kernel
+__host__ __device__ inline uint32_t tk_bin_hi(int b) {
+    const uint32_t hi[TK_NBIN] = {24, 32, 48, 64, 96, TK_GLANE_MAX};
+    return hi[b];
+}
+__host__ __device__ inline uint32_t tk_bin_lo(int b) { return b == 0 ? TK_LANE_MAX + 1 : tk_bin_hi(b - 1) + 1; }
+__device__ __forceinline__ int tk_bin_of(uint32_t len) {
+    int b = 0;
+#pragma unroll
+    for (int i = 0; i < TK_NBIN - 1; ++i) b += len > tk_bin_hi(i);
+    return b;
+}
+struct TkBins {
+    uint32_t off[TK_NBIN];  // start of each bin's list inside the pool
+};
+
 // counters (device uint32 array)
-enum { TK_CNT_B = 0, TK_CNT_C = 1, TK_CNT_CBYTES = 2, TK_CNT_CLEVELS = 3, TK_CNT_N = 8 };
+enum { TK_CNT_B = 0, TK_CNT_C = 1, TK_CNT_CBYTES = 2, TK_CNT_CLEVELS = 3, TK_CNT_BIN0 = 8, TK_CNT_N = 8 + TK_NBIN + 1 };
 
 // ------------------------------------------------------------------------------------------
 // wave helpers (wave64)
@@ -554,10 +571,12 @@ __global__ __launch_bounds__(256) void tk_k_emit(const uint32_t* __restrict__ st
 __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ pstart,
                                                    uint64_t P, const uint32_t* __restrict__ ss, uint32_t* __restrict__ tok1,
                                                    uint32_t* __restrict__ cnt, uint32_t* __restrict__ staging,
-                                                   uint32_t* __restrict__ listB, uint32_t* __restrict__ listC,
+                                                   uint32_t* __restrict__ listM, TkBins bins, uint32_t* __restrict__ listC,
                                                    uint32_t* __restrict__ counters, int dbg) {
     __shared__ uint32_t q[256 * TK_PPT];   // short misses (block-relative piece index)
-    __shared__ uint32_t qB[256 * TK_PPT];  // 17..64-byte misses
+    __shared__ uint32_t qB[256 * TK_PPT];  // 17..4096-byte misses: piece index
+    __shared__ uint32_t qBs[256 * TK_PPT]; //   ... and (bin << 16) | slot within this block's share of the bin
+    __shared__ uint32_t sh_bin[TK_NBIN], sh_binbase[TK_NBIN];
     __shared__ uint32_t qC[3 * 64];        // longer misses: {piece, bytes before it, levels before it} (spill handled below)
     __shared__ uint32_t sh_cnt[8];         // 0 qn, 1 nB, 2 nC, 3 cbytes, 4 clevels, 5 gB, 6 gC/gbytes/glv base follow
     __shared__ uint32_t s_id[TK_LANE_MAX * 256];
@@ -566,6 +585,7 @@ __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __
     const int lane = tid & 63;
     for (uint64_t base = (uint64_t)blockIdx.x * (256 * TK_PPT); base < P; base += (uint64_t)gridDim.x * (256 * TK_PPT)) {
         if (tid < 8) sh_cnt[tid] = 0;
+        if (tid < TK_NBIN) sh_bin[tid] = 0;
         __syncthreads();
 #pragma unroll
         for (int k = 0; k < TK_PPT; ++k) {
@@ -588,7 +608,7 @@ __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __
                         }
                     } else if (len <= TK_LANE_MAX) {
                         missA = true;
-                    } else if (len <= TK_WAVE_MAX) {
+                    } else if (len <= TK_GLANE_MAX) {
                         missB = true;
                     } else {
                         missC = true;
@@ -598,7 +618,11 @@ __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __
             uint32_t ia = tk_wave_append(missA, &sh_cnt[0], lane);
             if (missA) q[ia] = (uint32_t)(p - base);
             uint32_t ib = tk_wave_append(missB, &sh_cnt[1], lane);
-            if (missB) qB[ib] = (uint32_t)p;
+            if (missB) {
+                int b = tk_bin_of(len);
+                qB[ib] = (uint32_t)p;
+                qBs[ib] = ((uint32_t)b << 16) | atomicAdd(&sh_bin[b], 1u);
+            }
             if (missC) {
                 // scratch for the long path: 4 uint32 per byte + the 64-ary min-tree levels
                 uint32_t lv = 0, c = len;
@@ -622,9 +646,9 @@ __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __
         __syncthreads();
         // one global reservation per list per block iteration (a single shared counter saturates at
         // ~90 M atomics/s when every wave hits it)
+        if (tid < TK_NBIN && sh_bin[tid]) sh_binbase[tid] = bins.off[tid] + atomicAdd(&counters[TK_CNT_BIN0 + tid], sh_bin[tid]);
         if (tid == 0) {
-            uint32_t nB = sh_cnt[1], nC = sh_cnt[2] < 64 ? sh_cnt[2] : 64;
-            sh_cnt[5] = nB ? atomicAdd(&counters[TK_CNT_B], nB) : 0;
+            uint32_t nC = sh_cnt[2] < 64 ? sh_cnt[2] : 64;
             if (nC) {
                 sh_cnt[6] = atomicAdd(&counters[TK_CNT_C], nC);
                 sh_cnt[7] = atomicAdd(&counters[TK_CNT_CBYTES], sh_cnt[3]);
@@ -634,8 +658,11 @@ __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __
         __syncthreads();
         {
             const uint32_t nB = sh_cnt[1], nC = sh_cnt[2] < 64 ? sh_cnt[2] : 64;
-            const uint32_t gB = sh_cnt[5], gC = sh_cnt[6], gbytes = sh_cnt[7], glv = sh_cnt[3];
-            for (uint32_t i = tid; i < nB; i += 256) listB[gB + i] = qB[i];
+            const uint32_t gC = sh_cnt[6], gbytes = sh_cnt[7], glv = sh_cnt[3];
+            for (uint32_t i = tid; i < nB; i += 256) {
+                uint32_t bs = qBs[i];
+                listM[sh_binbase[bs >> 16] + (bs & 0xFFFFu)] = qB[i];
+            }
             if (tid < nC) {
                 listC[3 * (uint64_t)(gC + tid)] = qC[3 * tid];
                 listC[3 * (uint64_t)(gC + tid) + 1] = gbytes + qC[3 * tid + 1];
@@ -658,50 +685,90 @@ __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __
 }
 
 // ------------------------------------------------------------------------------------------
-// one wavefront per piece of 17..64 bytes: lane k owns byte k
+// One LANE per deferred piece of 17..128 bytes, lists binned by length so the 64 lanes of a wave run
+// similar trip counts.  byte_pair_merge (src/lib.rs:140-196): ids and pair ranks of the piece's
+// parts live in LDS (k-major, lane-minor: conflict-free), alive positions in a 128-bit register
+// mask, so the only memory latency per merge is the pair of table probes.  What this buys over
+// one-wave-per-piece is 64 independent probe chains per wavefront.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tk_k_merge_wave(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ pstart,
-                                                       const uint32_t* __restrict__ listB, uint32_t nB, uint32_t* __restrict__ tok1,
-                                                       uint32_t* __restrict__ cnt, uint32_t* __restrict__ staging) {
-    const int lane = threadIdx.x & 63;
-    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
-    for (uint32_t w = wave; w < nB; w += nwaves) {
-        uint32_t p = listB[w];
-        uint32_t s = pstart[p], n = pstart[p + 1] - s;
-        uint32_t b0 = (uint32_t)lane < n ? text[s + lane] : 0, b1 = (uint32_t)lane + 1 < n ? text[s + lane + 1] : 0;
-        uint32_t id = T.byte_rank[b0];
-        uint32_t rk = (uint32_t)lane + 1 < n ? T.pair2[(b0 << 8) | b1] : TK_RANK_MAX;
-        uint64_t alive = n >= 64 ? ~0ull : ((1ull << n) - 1ull);
+struct TkMask128 {
+    uint64_t lo, hi;
+    __device__ __forceinline__ void clear(uint32_t k) {
+        if (k < 64u) lo &= ~(1ull << k);
+        else hi &= ~(1ull << (k - 64u));
+    }
+    // lowest set position > k, or 128
+    __device__ __forceinline__ uint32_t next_after(uint32_t k) const {
+        if (k < 63u) {
+            uint64_t l = lo & ~((2ull << k) - 1ull);
+            if (l) return (uint32_t)__ffsll((unsigned long long)l) - 1u;
+        }
+        uint64_t h = hi;
+        if (k >= 127u) h = 0;
+        else if (k >= 64u) h &= ~((2ull << (k - 64u)) - 1ull);
+        if (h) return 64u + (uint32_t)__ffsll((unsigned long long)h) - 1u;
+        return 128u;
+    }
+    // highest set position < k, or -1
+    __device__ __forceinline__ int prev_before(uint32_t k) const {
+        uint64_t h = k > 64u ? hi & ((1ull << (k - 64u)) - 1ull) : 0ull;
+        if (h) return 127 - (int)__clzll((long long)h);
+        uint64_t l = k >= 64u ? lo : lo & ((1ull << k) - 1ull);
+        if (l) return 63 - (int)__clzll((long long)l);
+        return -1;
+    }
+};
+
+template <int NMAX, int THREADS>
+__global__ __launch_bounds__(THREADS) void tk_k_merge_llane(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ pstart,
+                                                            const uint32_t* __restrict__ list, uint32_t count, uint32_t* __restrict__ tok1,
+                                                            uint32_t* __restrict__ cnt, uint32_t* __restrict__ staging) {
+    __shared__ uint32_t s_id[NMAX * THREADS];
+    __shared__ uint32_t s_rk[NMAX * THREADS];
+    uint32_t* id = s_id + threadIdx.x;
+    uint32_t* rk = s_rk + threadIdx.x;
+    for (uint32_t it = blockIdx.x * THREADS + threadIdx.x; it < count; it += gridDim.x * THREADS) {
+        const uint32_t p = list[it];
+        const uint32_t s = pstart[p], n = pstart[p + 1] - s;
+        uint32_t pb = text[s];
+        for (uint32_t k = 0; k < n; ++k) {
+            uint32_t nb = k + 1 < n ? text[s + k + 1] : 0u;
+            id[k * THREADS] = T.byte_rank[pb];
+            rk[k * THREADS] = k + 1 < n ? T.pair2[(pb << 8) | nb] : TK_RANK_MAX;
+            pb = nb;
+        }
+        TkMask128 alive;
+        alive.lo = n >= 64u ? ~0ull : ((1ull << n) - 1ull);
+        alive.hi = n > 64u ? (n >= 128u ? ~0ull : ((1ull << (n - 64u)) - 1ull)) : 0ull;
         for (;;) {
-            uint32_t m = tk_wave_min_u32(rk);
-            if (m == TK_RANK_MAX) break;
-            uint64_t bal = __ballot(rk == m);
-            int i = __ffsll((unsigned long long)bal) - 1;  // leftmost minimum
-            uint64_t after = alive & ~((2ull << i) - 1ull);
-            int j = __ffsll((unsigned long long)after) - 1;
-            alive &= ~(1ull << j);
-            after &= ~(1ull << j);
-            uint64_t before = alive & ((1ull << i) - 1ull);
-            int nn = after ? __ffsll((unsigned long long)after) - 1 : -1;
-            int pp = before ? 63 - __clzll((unsigned long long)before) : -1;
-            if (lane == i) id = m;
-            if (lane == j) rk = TK_RANK_MAX;
-            uint32_t id_nn = __shfl(id, nn < 0 ? 0 : nn, 64), id_pp = __shfl(id, pp < 0 ? 0 : pp, 64);
-            if (lane == i) rk = nn >= 0 ? tk_probe_pair(T, m, id_nn) : TK_RANK_MAX;
-            if (lane == pp) rk = tk_probe_pair(T, id_pp, m);
-        }
-        uint32_t c = __popcll(alive);
-        bool mine = (alive >> lane) & 1ull;
-        uint32_t t = __popcll(alive & ((1ull << lane) - 1ull));
-        if (c == 1) {
-            if (lane == 0) {
-                tok1[p] = id;
-                cnt[p] = 1;
+            uint32_t best = TK_RANK_MAX, bi = 0;
+            for (uint32_t k = 0; k + 1 < n; ++k) {
+                uint32_t r = rk[k * THREADS];
+                if (r < best) {  // strict '<': leftmost minimum (lib.rs:151,190)
+                    best = r;
+                    bi = k;
+                }
             }
-        } else {
-            if (mine) staging[s + t] = id;
-            if (lane == 0) cnt[p] = c;
+            if (best == TK_RANK_MAX) break;
+            const uint32_t j = alive.next_after(bi);  // the part being absorbed
+            alive.clear(j);
+            id[bi * THREADS] = best;
+            rk[j * THREADS] = TK_RANK_MAX;
+            const uint32_t nn = alive.next_after(bi);
+            const int pp = alive.prev_before(bi);
+            uint32_t r_i = TK_RANK_MAX, r_p = TK_RANK_MAX;
+            if (nn < 128u) r_i = tk_probe_pair(T, best, id[nn * THREADS]);
+            if (pp >= 0) r_p = tk_probe_pair(T, id[pp * THREADS], best);
+            rk[bi * THREADS] = r_i;
+            if (pp >= 0) rk[pp * THREADS] = r_p;
         }
+        uint32_t t = 0;
+        for (uint32_t k = 0; k < n; ++k) {
+            bool a = k < 64u ? (alive.lo >> k) & 1ull : (alive.hi >> (k - 64u)) & 1ull;
+            if (a) staging[s + t++] = id[k * THREADS];
+        }
+        cnt[p] = t;
+        if (t == 1) tok1[p] = id[0];
     }
 }
 
