@@ -49,7 +49,8 @@ void* tks_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uin
     D.piece_off = H.piece_off.data();
     D.piece_mask = H.piece_mask;
     D.tok_bytes = H.tok_bytes.data();
-    D.pair = H.pair.data();
+    D.pair = H.pair8.empty() ? H.pair.data() : nullptr;
+    D.pair8 = H.pair8.empty() ? nullptr : H.pair8.data();
     D.pair_mask = H.pair_mask;
     D.pair2 = H.pair2.data();
     D.byte_rank = H.byte_rank;

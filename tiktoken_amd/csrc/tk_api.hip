@@ -65,7 +65,7 @@ struct tk_core {
     std::mutex mu;
     // workspace
     Buf text, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, tok1, cnt, tokbase, staging, listB, listC,
-        counters, total, partial, rkb, g_id, g_rk, g_nx, g_pv, g_lv, out_tokens, out_tok_off, allowed;
+        counters, total, partial, rkb, prof, g_id, g_rk, g_nx, g_pv, g_lv, out_tokens, out_tok_off, allowed;
     uint64_t chunk_bytes = 1ull << 30;
     int dbg = 0;
     // instrumentation
@@ -158,7 +158,8 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     if ((rc = upload(c->t_piece, H.piece.data(), H.piece.size() * sizeof(TkPieceSlot)))) return bail(rc);
     if ((rc = upload(c->t_piece_off, H.piece_off.data(), H.piece_off.size() * 4))) return bail(rc);
     if ((rc = upload(c->t_tok_bytes, H.tok_bytes.data(), H.tok_bytes.size()))) return bail(rc);
-    if ((rc = upload(c->t_pair, H.pair.data(), H.pair.size() * sizeof(TkPairSlot)))) return bail(rc);
+    if ((rc = upload(c->t_pair, H.pair8.empty() ? (const void*)H.pair.data() : (const void*)H.pair8.data(),
+                     H.pair8.empty() ? H.pair.size() * sizeof(TkPairSlot) : H.pair8.size() * 8))) return bail(rc);
     if ((rc = upload(c->t_pair2, H.pair2.data(), H.pair2.size() * 4))) return bail(rc);
     if ((rc = upload(c->t_byte_rank, H.byte_rank, sizeof H.byte_rank))) return bail(rc);
     if ((rc = upload(c->t_spec_bytes, H.spec_bytes.data(), H.spec_bytes.size()))) return bail(rc);
@@ -171,7 +172,8 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     D.piece_off = c->t_piece_off.as<uint32_t>();
     D.piece_mask = H.piece_mask;
     D.tok_bytes = c->t_tok_bytes.as<uint8_t>();
-    D.pair = c->t_pair.as<TkPairSlot>();
+    D.pair = H.pair8.empty() ? c->t_pair.as<TkPairSlot>() : nullptr;
+    D.pair8 = H.pair8.empty() ? nullptr : c->t_pair.as<uint64_t>();
     D.pair_mask = H.pair_mask;
     D.pair2 = c->t_pair2.as<uint32_t>();
     D.byte_rank = c->t_byte_rank.as<uint32_t>();
@@ -197,7 +199,7 @@ extern "C" void tk_destroy(tk_core* c) {
     for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_piece, &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2,
                    &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off, &c->brk, &c->docb,
                    &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->tok1, &c->cnt, &c->tokbase, &c->staging,
-                   &c->listB, &c->listC, &c->counters, &c->total, &c->partial, &c->rkb, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv,
+                   &c->listB, &c->listC, &c->counters, &c->total, &c->partial, &c->rkb, &c->prof, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv,
                    &c->out_tokens, &c->out_tok_off, &c->allowed})
         release(*b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -226,6 +228,11 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
     TRY(ensure(c->blockcnt, (nblk + 2) * 4));
     TRY(ensure(c->counters, TK_CNT_N * 4));
     TRY(ensure(c->total, 16));
+    if (c->dbg & 128) {
+        bool fresh = c->prof.p == nullptr;
+        TRY(ensure(c->prof, 64));
+        if (fresh) HIPCHK(hipMemsetAsync(c->prof.p, 0, 64, s));
+    }
     HIPCHK(hipMemsetAsync(c->brk.p, 0, (nwords + 2) * 4, s));
     HIPCHK(hipMemsetAsync(c->starts.p, 0, (nwords + 2) * 4, s));
     HIPCHK(hipMemsetAsync(c->counters.p, 0, TK_CNT_N * 4, s));
@@ -263,8 +270,16 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
             }));
         } else {
             TRY(timed(c, s, "tk_k_pretok2", [&] {
-                hipLaunchKernelGGL(tk_k_pretok2, dim3((uint32_t)((n + TK_TILE - 1) / TK_TILE)), dim3(256), 0, s, T, d_text, n, brk, ss, si, starts);
+                hipLaunchKernelGGL(tk_k_pretok2, dim3((uint32_t)((n + TK_TILE - 1) / TK_TILE)), dim3(256), 0, s, T, d_text, n, brk, ss, si, starts,
+                                   (c->dbg & 128) ? c->prof.as<unsigned long long>() : nullptr);
             }));
+            if (c->dbg & 128) {
+                unsigned long long h[8];
+                HIPCHK(hipMemcpyAsync(h, c->prof.p, sizeof h, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+                fprintf(stderr, "pretok2 phase cycles (thread 0 of each block, summed): A=%llu B=%llu C=%llu D=%llu E=%llu\n", h[0], h[1], h[2], h[3], h[4]);
+                HIPCHK(hipMemsetAsync(c->prof.p, 0, 64, s));
+            }
         }
         TRY(timed(c, s, "tk_k_count", [&] {
             hipLaunchKernelGGL(tk_k_count, dim3((uint32_t)nblk), dim3(256), 0, s, starts, nwords, c->blockcnt.as<uint32_t>());

@@ -13,6 +13,8 @@
 //                    a vocabulary token (single bytes are, and a merge only happens when the
 //                    concatenation is a key), and concatenation is unique, so probing this table
 //                    with the two part ids is exactly `ranks.get(&piece[a..c])` (lib.rs:150,165-167).
+//                    Stored packed in 8 bytes per slot when every id fits 21 bits (all stock
+//                    vocabularies), which keeps the whole table at 4 MB -- L2-sized.
 //   * pair2 table  : direct 65536-entry table for the initial two-byte probes (lib.rs:150).
 #pragma once
 #include <stdint.h>
@@ -77,8 +79,9 @@ struct TkTables {
     const uint32_t* piece_off;  // [piece_mask+1] offset of the slot's key bytes in tok_bytes
     uint64_t piece_mask;
     const uint8_t* tok_bytes;   // all token byte strings, concatenated
-    const TkPairSlot* pair;     // [pair_mask+1]
-    uint64_t pair_mask;
+    const TkPairSlot* pair;     // [pair_mask+1] wide 16-byte slots (only when some id needs more than 21 bits)
+    const uint64_t* pair8;      // [(pair_mask+1)*4] packed 8-byte slots in 4-slot buckets: (id_left:21 | id_right:21 | id_merged:22), ~0 = empty
+    uint64_t pair_mask;         // wide: slot mask; packed: BUCKET mask
     const uint32_t* pair2;      // [65536]  rank of the 2-byte string (b0, b1) or TK_RANK_MAX
     const uint32_t* byte_rank;  // [256]
     // special tokens (sorted by bytes); spec_first marks possible first bytes
@@ -105,3 +108,5 @@ TK_HD uint64_t tk_pair_slot_hash(uint64_t key) { return tk_mix64(key * 0x9FB21C6
 // streaming hash for keys longer than 8 bytes: fold 8-byte little-endian words (last one zero padded)
 TK_HD uint64_t tk_hash_step(uint64_t h, uint64_t w) { return tk_mix64(h ^ w) + 0x9E3779B97F4A7C15ull; }
 #define TK_HASH_SEED 0x243F6A8885A308D3ull
+#define TK_PAIR8_ID_BITS 21
+#define TK_PAIR8_MAX_ID ((1u << TK_PAIR8_ID_BITS) - 2u)  // ids above this force the wide format

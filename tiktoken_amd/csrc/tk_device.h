@@ -432,7 +432,29 @@ TK_HD uint32_t tk_probe_piece(const TkTables& T, uint64_t key, uint32_t len, Ver
     }
 }
 
+// Pair probe.  Packed format: 4-slot (32-byte, 32-byte-aligned) buckets; a bucket is fetched with two
+// 16-byte loads issued together, so a probe is one memory round trip.  A key lives in the first bucket
+// of its probe sequence that had a free slot at build time, so a bucket with a free slot ends the search.
 TK_HD uint32_t tk_probe_pair(const TkTables& T, uint32_t a, uint32_t b) {
+    if (T.pair8) {
+        const uint64_t key = ((uint64_t)a << TK_PAIR8_ID_BITS) | b;  // 42 bits
+        uint64_t bk = tk_pair_slot_hash(key) & T.pair_mask;          // pair_mask counts buckets here
+        for (;;) {
+            const uint64_t* p = T.pair8 + bk * 4;
+#if defined(__HIP_DEVICE_COMPILE__)
+            const ulonglong2 v0 = *(const ulonglong2*)p, v1 = *(const ulonglong2*)(p + 2);
+            const uint64_t s0 = v0.x, s1 = v0.y, s2 = v1.x, s3 = v1.y;
+#else
+            const uint64_t s0 = p[0], s1 = p[1], s2 = p[2], s3 = p[3];
+#endif
+            if ((s0 >> 22) == key) return (uint32_t)(s0 & 0x3FFFFFu);
+            if ((s1 >> 22) == key) return (uint32_t)(s1 & 0x3FFFFFu);
+            if ((s2 >> 22) == key) return (uint32_t)(s2 & 0x3FFFFFu);
+            if ((s3 >> 22) == key) return (uint32_t)(s3 & 0x3FFFFFu);
+            if (s3 == TK_EMPTY_KEY) return TK_RANK_MAX;  // slots fill in order, so s3 empty <=> bucket not full
+            bk = (bk + 1) & T.pair_mask;
+        }
+    }
     uint64_t key = ((uint64_t)a << 32) | b;
     uint64_t i = tk_pair_slot_hash(key) & T.pair_mask;
     for (;;) {

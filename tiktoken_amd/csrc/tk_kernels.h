@@ -339,7 +339,15 @@ struct TkWin2Acc {  // byte-walking fallback: propagated classes inside the wind
 
 __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* __restrict__ text, uint64_t n,
                                                     const uint32_t* __restrict__ brk, const uint32_t* __restrict__ ss,
-                                                    const uint32_t* __restrict__ si, uint32_t* __restrict__ starts) {
+                                                    const uint32_t* __restrict__ si, uint32_t* __restrict__ starts,
+                                                    unsigned long long* __restrict__ prof) {
+#define TK_PROF(slot)                                                             \
+    if (prof && threadIdx.x == 0) {                                               \
+        long long t__ = __builtin_readcyclecounter();                             \
+        atomicAdd(&prof[slot], (unsigned long long)(t__ - t_prev));               \
+        t_prev = t__;                                                             \
+    }
+    long long t_prev = prof ? __builtin_readcyclecounter() : 0;
     __shared__ __attribute__((aligned(16))) uint8_t raw[TK2_WIN + 16];
     __shared__ uint8_t cls2[TK2_WIN];
     __shared__ uint64_t bm[TKB_KINDS][TK2_NSEG + 2];
@@ -366,6 +374,7 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
         bm[tid][TK2_NSEG + 1] = tid <= TKB_HARD ? ~0ull : 0ull;
     }
     __syncthreads();
+    TK_PROF(0)
     // ---- B: classes + bitmaps, one wave per segment
     for (int g = wid; g < TK2_NSEG; g += 4) {
         const uint32_t pl = g * 64 + lane;
@@ -438,6 +447,7 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
         }
     }
     __syncthreads();
+    TK_PROF(1)
     // ---- C: certain starts of the tile -> list
     const int pat = T.pattern;
     for (int k = 0; k < TK_TILE / 256; ++k) {
@@ -452,6 +462,7 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
         }
     }
     __syncthreads();
+    TK_PROF(2)
     // ---- D: one lane per certain start
     TkWin2Acc acc{cls2, raw, base, &T, text, n, brk, ss, si};
     const uint32_t ncert = cn;
@@ -502,11 +513,14 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
         }
     }
     __syncthreads();
+    TK_PROF(3)
     // ---- E
     if (tid < TK_TILE / 32) {
         uint32_t v = bits[tid];
         if (v) atomicOr(&starts[tile_start / 32 + tid], v);
     }
+    TK_PROF(4)
+#undef TK_PROF
 }
 
 // ------------------------------------------------------------------------------------------

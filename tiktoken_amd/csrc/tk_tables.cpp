@@ -61,6 +61,18 @@ uint32_t TkHostTables::lookup_piece(const uint8_t* p, uint32_t len) const {
 }
 
 uint32_t TkHostTables::lookup_pair(uint32_t a, uint32_t b) const {
+    if (!pair8.empty()) {
+        const uint64_t key = ((uint64_t)a << TK_PAIR8_ID_BITS) | b;
+        uint64_t bk = tk_pair_slot_hash(key) & pair_mask;
+        for (;;) {
+            for (int j = 0; j < 4; ++j) {
+                uint64_t s = pair8[bk * 4 + j];
+                if ((s >> 22) == key) return (uint32_t)(s & 0x3FFFFFu);
+                if (s == TK_EMPTY_KEY) return TK_RANK_MAX;
+            }
+            bk = (bk + 1) & pair_mask;
+        }
+    }
     uint64_t key = ((uint64_t)a << 32) | b;
     uint64_t i = tk_pair_slot_hash(key) & pair_mask;
     for (;;) {
@@ -135,14 +147,38 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
         }
     }
     T.n_pairs = entries.size();
-    cap = 64;
-    while (cap < 2 * entries.size() + 2) cap <<= 1;
-    T.pair_mask = cap - 1;
-    T.pair.assign(cap, TkPairSlot{TK_EMPTY_KEY, TK_RANK_MAX, 0});
-    for (const TkPairSlot& e : entries) {
-        uint64_t i = tk_pair_slot_hash(e.key) & T.pair_mask;
-        while (T.pair[i].key != TK_EMPTY_KEY) i = (i + 1) & T.pair_mask;
-        T.pair[i] = e;
+    uint32_t max_id = 0;
+    for (uint64_t k = 0; k < n_ranks; ++k) max_id = std::max(max_id, ranks_ids[k]);
+    if (max_id <= TK_PAIR8_MAX_ID) {
+        // packed: 4-slot buckets, load factor <= 0.5; each key goes to the first bucket of its probe
+        // sequence with a free slot, slots of a bucket fill in order
+        uint64_t nb = 16;
+        while ((double)nb * 4 * 0.5 < (double)entries.size() + 1) nb <<= 1;
+        T.pair_mask = nb - 1;
+        T.pair8.assign(nb * 4, TK_EMPTY_KEY);
+        for (const TkPairSlot& e : entries) {
+            const uint64_t key = ((e.key >> 32) << TK_PAIR8_ID_BITS) | (e.key & 0xFFFFFFFFull);
+            uint64_t bk = tk_pair_slot_hash(key) & T.pair_mask;
+            for (;;) {
+                int j = 0;
+                while (j < 4 && T.pair8[bk * 4 + j] != TK_EMPTY_KEY) ++j;
+                if (j < 4) {
+                    T.pair8[bk * 4 + j] = (key << 22) | e.rank;
+                    break;
+                }
+                bk = (bk + 1) & T.pair_mask;
+            }
+        }
+    } else {
+        cap = 64;
+        while ((double)cap * 0.4 < (double)entries.size() + 1) cap <<= 1;
+        T.pair_mask = cap - 1;
+        T.pair.assign(cap, TkPairSlot{TK_EMPTY_KEY, TK_RANK_MAX, 0});
+        for (const TkPairSlot& e : entries) {
+            uint64_t i = tk_pair_slot_hash(e.key) & T.pair_mask;
+            while (T.pair[i].key != TK_EMPTY_KEY) i = (i + 1) & T.pair_mask;
+            T.pair[i] = e;
+        }
     }
 
     // special tokens, sorted by bytes (deterministic order; the reference's alternation order is

@@ -15,7 +15,8 @@ struct TkHostTables {
     std::vector<TkPieceSlot> piece;
     std::vector<uint32_t> piece_off;
     uint64_t piece_mask = 0;
-    std::vector<TkPairSlot> pair;
+    std::vector<TkPairSlot> pair;   // wide format (empty when packed)
+    std::vector<uint64_t> pair8;    // packed format (empty when wide)
     uint64_t pair_mask = 0;
     uint64_t n_pairs = 0;
     std::vector<uint32_t> pair2;
