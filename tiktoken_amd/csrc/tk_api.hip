@@ -334,8 +334,8 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         nC = hc[TK_CNT_C];
         for (int b = 0; b < TK_NBIN; ++b) nB += hc[TK_CNT_BIN0 + b];
         if (nB) {
-            static const char* const names[TK_NBIN] = {"tk_k_merge_llane_24", "tk_k_merge_llane_32", "tk_k_merge_llane_48",
-                                                       "tk_k_merge_llane_64", "tk_k_merge_llane_96", "tk_k_merge_llane_128"};
+            static const char* const names[TK_NBIN] = {"tk_k_merge_llane_24", "tk_k_merge_llane_32", "tk_k_merge_llane_48", "tk_k_merge_llane_64",
+                                                       "tk_k_merge_group_8", "tk_k_merge_group_16", "tk_k_merge_group_32", "tk_k_merge_group_64"};
             for (int b = 0; b < TK_NBIN; ++b) {
                 uint32_t cntb = hc[TK_CNT_BIN0 + b];
                 if (!cntb) continue;
@@ -348,8 +348,10 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
                         case 1: hipLaunchKernelGGL((tk_k_merge_llane<32, 256>), dim3(grid_for(cntb, 256, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
                         case 2: hipLaunchKernelGGL((tk_k_merge_llane<48, 128>), dim3(grid_for(cntb, 128, 16384)), dim3(128), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
                         case 3: hipLaunchKernelGGL((tk_k_merge_llane<64, 128>), dim3(grid_for(cntb, 128, 16384)), dim3(128), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
-                        case 4: hipLaunchKernelGGL((tk_k_merge_llane<96, 64>), dim3(grid_for(cntb, 64, 16384)), dim3(64), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
-                        default: hipLaunchKernelGGL((tk_k_merge_llane<128, 64>), dim3(grid_for(cntb, 64, 16384)), dim3(64), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
+                        case 4: hipLaunchKernelGGL((tk_k_merge_group<8>), dim3(grid_for(cntb, 32, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
+                        case 5: hipLaunchKernelGGL((tk_k_merge_group<16>), dim3(grid_for(cntb, 16, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
+                        case 6: hipLaunchKernelGGL((tk_k_merge_group<32>), dim3(grid_for(cntb, 8, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
+                        default: hipLaunchKernelGGL((tk_k_merge_group<64>), dim3(grid_for(cntb, 4, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
                     }
                 }));
             }

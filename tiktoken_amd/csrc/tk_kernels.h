@@ -28,10 +28,10 @@
 #define TK_PPT 4         // pieces per thread per block iteration in tk_k_lookup
 
 // Deferred pieces are binned by length so that the 64 lanes of a wave run similar trip counts.
-#define TK_NBIN 6
-#define TK_GLANE_MAX 128  // longest piece merged one-lane-per-piece; longer ones go to the tree kernel
+#define TK_NBIN 8
+#define TK_GLANE_MAX 1024  // longest piece handled by the lane / lane-group kernels; longer ones go to the tree kernel
 __host__ __device__ inline uint32_t tk_bin_hi(int b) {
-    const uint32_t hi[TK_NBIN] = {24, 32, 48, 64, 96, TK_GLANE_MAX};
+    const uint32_t hi[TK_NBIN] = {24, 32, 48, 64, 128, 256, 512, TK_GLANE_MAX};
     return hi[b];
 }
 __host__ __device__ inline uint32_t tk_bin_lo(int b) { return b == 0 ? TK_LANE_MAX + 1 : tk_bin_hi(b - 1) + 1; }
@@ -311,6 +311,7 @@ __global__ __launch_bounds__(256) void tk_k_pretok(TkTables T, const uint8_t* __
 #define TK2_RIGHT 192
 #define TK2_WIN (TK2_LEFT + TK_TILE + TK2_RIGHT)  // 4352
 #define TK2_NSEG (TK2_WIN / 64)                   // 68
+#define TK2_CLIST 1536
 enum { TKB_START = 0, TKB_HARD, TKB_L, TKB_UP, TKB_LOW, TKB_CAS, TKB_OTH, TKB_WS, TKB_NL, TKB_NU, TKB_NLSL, TKB_KINDS };
 
 struct TkWin2Acc {  // byte-walking fallback: propagated classes inside the window, HBM outside
@@ -352,9 +353,11 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
     __shared__ uint8_t cls2[TK2_WIN];
     __shared__ uint64_t bm[TKB_KINDS][TK2_NSEG + 2];
     __shared__ uint32_t bits[TK_TILE / 32];
-    __shared__ uint16_t clist[TK_TILE];
+    __shared__ uint16_t clist[TK2_CLIST];  // certain starts of the tile (overflow handled in place)
     __shared__ uint32_t cn;
     __shared__ uint8_t c1[128];
+    __shared__ uint32_t brkw[TK2_WIN / 32 + 1], ssw[TK2_WIN / 32 + 1], siw[TK2_WIN / 32 + 1];
+    __shared__ __attribute__((aligned(16))) uint8_t st1[0x1100];
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     const uint64_t tile_start = (uint64_t)blockIdx.x * TK_TILE;
@@ -367,6 +370,14 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
         *(uint4*)(raw + v * 16) = x;
     }
     if (tid < 128) c1[tid] = (uint8_t)tk_class_of_cp(T, tid);
+    for (uint32_t v = tid; v < 0x1100 / 16; v += 256) *(uint4*)(st1 + v * 16) = *(const uint4*)(T.uc_stage1 + v * 16);
+    if (tid < TK2_WIN / 32) {  // break / special bitmaps of the window (the window base is 32-aligned)
+        int64_t wgp = base + (int64_t)tid * 32;
+        bool in = wgp >= 0 && (uint64_t)wgp < n;
+        brkw[tid] = in ? brk[wgp >> 5] : 0u;
+        ssw[tid] = (in && ss) ? ss[wgp >> 5] : 0u;
+        siw[tid] = (in && si) ? si[wgp >> 5] : 0u;
+    }
     if (tid < TK_TILE / 32) bits[tid] = 0;
     if (tid == 0) cn = 0;
     if (tid < TKB_KINDS) {
@@ -388,7 +399,7 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
             c = TK_C_END;
             hard = gp >= 0;  // past the end: look-ahead stops here
         } else {
-            bool spec_s = ss && tk_bit(ss, (uint64_t)gp), spec_i = si && tk_bit(si, (uint64_t)gp);
+            const bool spec_s = (ssw[pl >> 5] >> (pl & 31u)) & 1u, spec_i = (siw[pl >> 5] >> (pl & 31u)) & 1u;
             if (spec_i) {
                 cont = true;
             } else if (spec_s) {
@@ -406,10 +417,10 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
                         if (len == 2u) cp = ((b & 0x1Fu) << 6) | (raw[pl + 1] & 0x3Fu);
                         else if (len == 3u) cp = ((b & 0x0Fu) << 12) | ((uint32_t)(raw[pl + 1] & 0x3Fu) << 6) | (raw[pl + 2] & 0x3Fu);
                         else cp = ((b & 0x07u) << 18) | ((uint32_t)(raw[pl + 1] & 0x3Fu) << 12) | ((uint32_t)(raw[pl + 2] & 0x3Fu) << 6) | (raw[pl + 3] & 0x3Fu);
-                        c = tk_class_of_cp(T, cp);
+                        c = cp > 0x10FFFFu ? (uint32_t)TK_C_OT : T.uc_stage2[(uint32_t)st1[cp >> 8] * 256u + (cp & 255u)];
                     }
                 }
-                hard = tk_bit(brk, (uint64_t)gp);
+                hard = (brkw[pl >> 5] >> (pl & 31u)) & 1u;
             }
         }
         // continuation bytes (and special-token interiors) inherit the class of their lead byte
@@ -448,26 +459,10 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
     }
     __syncthreads();
     TK_PROF(1)
-    // ---- C: certain starts of the tile -> list
+    // ---- C: certain starts of the tile -> list (a lane whose entry does not fit keeps it for itself)
     const int pat = T.pattern;
-    for (int k = 0; k < TK_TILE / 256; ++k) {
-        const uint32_t il = tid + k * 256, pl = TK2_LEFT + il;
-        const uint32_t c = cls2[pl];
-        bool certain = false;
-        if (tile_start + il < n && !(c & 0x40u)) certain = (c & 0x80u) || tk_certain_start(pat, cls2[pl - 1] & 15u, c & 15u);
-        uint32_t idx = tk_wave_append(certain, &cn, lane);
-        if (certain) {
-            clist[idx] = (uint16_t)pl;
-            atomicOr(&bits[il >> 5], 1u << (il & 31));
-        }
-    }
-    __syncthreads();
-    TK_PROF(2)
-    // ---- D: one lane per certain start
     TkWin2Acc acc{cls2, raw, base, &T, text, n, brk, ss, si};
-    const uint32_t ncert = cn;
-    for (uint32_t i = tid; i < ncert; i += 256) {
-        uint64_t p = (uint64_t)(base + clist[i]);
+    auto scan_from = [&](uint64_t p) {
         for (;;) {
             const int64_t r = (int64_t)p - base;
             uint32_t len = 0;
@@ -511,6 +506,29 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
                 atomicOr(&starts[e >> 5], 1u << (e & 31));
             p = e;
         }
+    };
+    uint32_t spill_mask = 0;  // bit k: this thread's k-th position is a certain start that did not fit the list
+    for (int k = 0; k < TK_TILE / 256; ++k) {
+        const uint32_t il = tid + k * 256, pl = TK2_LEFT + il;
+        const uint32_t c = cls2[pl];
+        bool certain = false;
+        if (tile_start + il < n && !(c & 0x40u)) certain = (c & 0x80u) || tk_certain_start(pat, cls2[pl - 1] & 15u, c & 15u);
+        uint32_t idx = tk_wave_append(certain, &cn, lane);
+        if (certain) {
+            if (idx < TK2_CLIST) clist[idx] = (uint16_t)pl;
+            else spill_mask |= 1u << k;
+            atomicOr(&bits[il >> 5], 1u << (il & 31));
+        }
+    }
+    __syncthreads();
+    TK_PROF(2)
+    // ---- D: one lane per certain start
+    const uint32_t ncert = cn < TK2_CLIST ? cn : TK2_CLIST;
+    for (uint32_t i = tid; i < ncert; i += 256) scan_from((uint64_t)(base + clist[i]));
+    while (spill_mask) {
+        int k = __ffs((int)spill_mask) - 1;
+        spill_mask &= spill_mask - 1;
+        scan_from(tile_start + tid + (uint32_t)k * 256u);
     }
     __syncthreads();
     TK_PROF(3)
@@ -783,6 +801,167 @@ __global__ __launch_bounds__(THREADS) void tk_k_merge_llane(TkTables T, const ui
         }
         cnt[p] = t;
         if (t == 1) tok1[p] = id[0];
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// G lanes per deferred piece (G = 8 / 16 / 32 / 64 for pieces of <= 128 / 256 / 512 / 1024 bytes).
+// Lane g of a group owns part positions [16 g, 16 g + 16): ids and pair ranks in LDS, an alive
+// bitmask and the cached minimum (rank << 32 | position) of its chunk in registers.  One merge =
+// a log2(G)-step shuffle reduction of the cached minima (leftmost lowest rank, lib.rs:151,190),
+// neighbour search through the alive masks, two pair probes (by two different lanes), and a
+// re-scan of the <= 3 chunks that changed.  64/G pieces per wavefront, 8 KiB of LDS per wavefront.
+// ------------------------------------------------------------------------------------------
+template <int G>
+__global__ __launch_bounds__(256) void tk_k_merge_group(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ pstart,
+                                                        const uint32_t* __restrict__ list, uint32_t count, uint32_t* __restrict__ tok1,
+                                                        uint32_t* __restrict__ cnt, uint32_t* __restrict__ staging) {
+    constexpr int C = 16, NMAX = G * C, PPW = 64 / G;
+    constexpr uint32_t NONE = 0xFFFFu;
+    __shared__ __attribute__((aligned(16))) uint32_t s_id[4][1024];
+    __shared__ __attribute__((aligned(16))) uint32_t s_rk[4][1024];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int g = lane & (G - 1), grp = lane / G, gbase = grp * G;
+    uint32_t* id = s_id[wid] + grp * NMAX;
+    uint32_t* rk = s_rk[wid] + grp * NMAX;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+    auto local_min = [&]() -> uint64_t {
+        uint64_t m = ~0ull;
+        const uint4* q = (const uint4*)(rk + g * C);
+#pragma unroll
+        for (int v = 0; v < C / 4; ++v) {
+            uint4 x = q[v];
+            uint32_t k0 = g * C + v * 4;
+            uint64_t a = ((uint64_t)x.x << 32) | k0, b = ((uint64_t)x.y << 32) | (k0 + 1), c = ((uint64_t)x.z << 32) | (k0 + 2),
+                     d = ((uint64_t)x.w << 32) | (k0 + 3);
+            a = a < b ? a : b;
+            c = c < d ? c : d;
+            a = a < c ? a : c;
+            m = m < a ? m : a;
+        }
+        return m;
+    };
+    for (uint32_t e0 = wave * PPW; e0 < count; e0 += nwaves * PPW) {  // wave-uniform trip count
+        const uint32_t e = e0 + grp;
+        const bool valid = e < count;
+        uint32_t p = 0, s = 0, n = 0;
+        if (valid) {
+            p = list[e];
+            s = pstart[p];
+            n = pstart[p + 1] - s;
+        }
+        uint32_t mask = 0;
+#pragma unroll 4
+        for (int c = 0; c < C; ++c) {
+            const uint32_t k = g * C + c;
+            uint32_t r = TK_RANK_MAX;
+            if (k < n) {
+                const uint32_t b0 = text[s + k];
+                id[k] = T.byte_rank[b0];
+                if (k + 1 < n) r = T.pair2[(b0 << 8) | text[s + k + 1]];
+                mask |= 1u << c;
+            }
+            rk[k] = r;
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint64_t lk = local_min();
+        for (;;) {
+            uint64_t m = lk;
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) {
+                uint64_t w = __shfl_xor(m, o, 64);
+                m = w < m ? w : m;
+            }
+            const uint32_t best = (uint32_t)(m >> 32);
+            const bool fin = best == TK_RANK_MAX;
+            if (__all(fin)) break;
+            // everything below is computed by every lane (shuffles must not sit under divergent control flow);
+            // writes and probes are predicated on !fin
+            const uint32_t bi = (uint32_t)m & (NMAX - 1), ob = bi / C, bl = bi % C;
+            const uint64_t nbw = __ballot(mask != 0);
+            const uint64_t nb = G == 64 ? nbw : ((nbw >> gbase) & ((1ull << (G & 63)) - 1ull));
+            const uint32_t my_first = mask ? (uint32_t)(g * C + __ffs((int)mask) - 1) : NONE;
+            const uint32_t my_last = mask ? (uint32_t)(g * C + 31 - __clz((int)mask)) : NONE;
+            const uint32_t om = __shfl(mask, gbase + (int)ob, 64);
+            // j: the part absorbed = next alive after bi
+            uint32_t j;
+            {
+                const uint32_t hi = om & ~((2u << bl) - 1u);
+                const uint64_t la = nb & ~((2ull << ob) - 1ull);
+                const int lj = la ? __ffsll((unsigned long long)la) - 1 : 0;
+                const uint32_t fj = __shfl(my_first, gbase + lj, 64);
+                j = hi ? ob * C + (uint32_t)__ffs((int)hi) - 1u : fj;
+            }
+            j &= (NMAX - 1);
+            const uint32_t oj = j / C, jl = j % C;
+            // nn: next alive after j
+            uint32_t nn;
+            {
+                const uint32_t ojm = __shfl(mask, gbase + (int)oj, 64);
+                const uint32_t hi = ojm & ~((2u << jl) - 1u);
+                const uint64_t la = nb & ~((2ull << oj) - 1ull);
+                const int ln = la ? __ffsll((unsigned long long)la) - 1 : 0;
+                const uint32_t fn = __shfl(my_first, gbase + ln, 64);
+                nn = hi ? oj * C + (uint32_t)__ffs((int)hi) - 1u : (la ? fn : NONE);
+            }
+            // pp: previous alive before bi
+            uint32_t pp;
+            {
+                const uint32_t lo = om & ((1u << bl) - 1u);
+                const uint64_t lb = nb & ((1ull << ob) - 1ull);
+                const int lp = lb ? 63 - __clzll((long long)lb) : 0;
+                const uint32_t fl = __shfl(my_last, gbase + lp, 64);
+                pp = lo ? ob * C + 31u - (uint32_t)__clz((int)lo) : (lb ? fl : NONE);
+            }
+            uint32_t newr = TK_RANK_MAX;
+            if (!fin) {
+                if (g == 0 && nn != NONE) newr = tk_probe_pair(T, best, id[nn]);
+                if (g == 1 && pp != NONE) newr = tk_probe_pair(T, id[pp], best);
+            }
+            const uint32_t newr_i = __shfl(newr, gbase, 64), newr_p = __shfl(newr, gbase + 1, 64);
+            __builtin_amdgcn_wave_barrier();
+            bool touched = false;
+            if (!fin) {
+                if (g == (int)ob) {
+                    id[bi] = best;
+                    rk[bi] = newr_i;
+                    touched = true;
+                }
+                if (g == (int)oj) {
+                    mask &= ~(1u << jl);
+                    rk[j] = TK_RANK_MAX;
+                    touched = true;
+                }
+                if (pp != NONE && g == (int)(pp / C)) {
+                    rk[pp] = newr_p;
+                    touched = true;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (touched) lk = local_min();
+        }
+        // emit surviving parts, left to right
+        const uint32_t mine = __popc(mask);
+        uint32_t inc = mine;
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) {
+            uint32_t w = __shfl_up(inc, o, 64);
+            if (g >= o) inc += w;
+        }
+        const uint32_t total = __shfl(inc, gbase + G - 1, 64);
+        if (valid) {
+            uint32_t t = inc - mine, mm = mask;
+            while (mm) {
+                const int c = __ffs((int)mm) - 1;
+                mm &= mm - 1;
+                staging[s + t++] = id[g * C + c];
+            }
+            if (g == 0) {
+                cnt[p] = total;
+                if (total == 1) tok1[p] = id[0];
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
     }
 }
 
