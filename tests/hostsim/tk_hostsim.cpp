@@ -232,11 +232,9 @@ int64_t tks_encode_piece(void* p, const uint8_t* piece, uint32_t len, uint32_t* 
         out[0] = r;
         return 1;
     }
-    if (len <= 16) {
-        uint32_t s_id[16], s_rk[16], one = 0;
-        uint32_t c = tk_lane_merge<1>(s->T, text.data(), 0, len, s_id, s_rk, &one, out);
-        if (c == 1) out[0] = one;
-        return c;
+    if (len <= 128) {  // the production per-lane merge (tk_k_merge_llane), stride 1
+        uint32_t s_id[128], s_rk[128];
+        return tk_lane_merge<1>(s->T, text.data(), 0, len, s_id, s_rk, out);
     }
     std::vector<uint32_t> id(len), rk(len);
     for (uint32_t k = 0; k < len; ++k) {

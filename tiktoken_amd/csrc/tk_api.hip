@@ -325,7 +325,7 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         uint32_t* counters = c->counters.as<uint32_t>();
         TRY(timed(c, s, "tk_k_lookup", [&] {
             hipLaunchKernelGGL(tk_k_lookup, dim3(grid_for(P, 256 * TK_PPT, 4096)), dim3(256), 0, s, T, d_text, pstart, P, ss,
-                               c->tok1.as<uint32_t>(), c->cnt.as<uint32_t>(), c->staging.as<uint32_t>(), c->listB.as<uint32_t>(), bins,
+                               c->tok1.as<uint32_t>(), c->cnt.as<uint32_t>(), c->listB.as<uint32_t>(), bins,
                                c->listC.as<uint32_t>(), counters, c->dbg);
         }));
         uint32_t hc[TK_CNT_N];
@@ -334,7 +334,7 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         nC = hc[TK_CNT_C];
         for (int b = 0; b < TK_NBIN; ++b) nB += hc[TK_CNT_BIN0 + b];
         if (nB) {
-            static const char* const names[TK_NBIN] = {"tk_k_merge_llane_24", "tk_k_merge_llane_32", "tk_k_merge_llane_48", "tk_k_merge_llane_64",
+            static const char* const names[TK_NBIN] = {"tk_k_merge_llane_16", "tk_k_merge_llane_24", "tk_k_merge_llane_32", "tk_k_merge_llane_48", "tk_k_merge_llane_64",
                                                        "tk_k_merge_group_8", "tk_k_merge_group_16", "tk_k_merge_group_32", "tk_k_merge_group_64"};
             for (int b = 0; b < TK_NBIN; ++b) {
                 uint32_t cntb = hc[TK_CNT_BIN0 + b];
@@ -344,13 +344,14 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
                 uint32_t *t1 = c->tok1.as<uint32_t>(), *cn = c->cnt.as<uint32_t>(), *stg = c->staging.as<uint32_t>();
                 TRY(timed(c, s, names[b], [&] {
                     switch (b) {
-                        case 0: hipLaunchKernelGGL((tk_k_merge_llane<24, 256>), dim3(grid_for(cntb, 256, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
-                        case 1: hipLaunchKernelGGL((tk_k_merge_llane<32, 256>), dim3(grid_for(cntb, 256, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
-                        case 2: hipLaunchKernelGGL((tk_k_merge_llane<48, 128>), dim3(grid_for(cntb, 128, 16384)), dim3(128), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
-                        case 3: hipLaunchKernelGGL((tk_k_merge_llane<64, 128>), dim3(grid_for(cntb, 128, 16384)), dim3(128), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
-                        case 4: hipLaunchKernelGGL((tk_k_merge_group<8>), dim3(grid_for(cntb, 32, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
-                        case 5: hipLaunchKernelGGL((tk_k_merge_group<16>), dim3(grid_for(cntb, 16, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
-                        case 6: hipLaunchKernelGGL((tk_k_merge_group<32>), dim3(grid_for(cntb, 8, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
+                        case 0: hipLaunchKernelGGL((tk_k_merge_llane<16, 256>), dim3(grid_for(cntb, 256, 32768)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
+                        case 1: hipLaunchKernelGGL((tk_k_merge_llane<24, 256>), dim3(grid_for(cntb, 256, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
+                        case 2: hipLaunchKernelGGL((tk_k_merge_llane<32, 256>), dim3(grid_for(cntb, 256, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
+                        case 3: hipLaunchKernelGGL((tk_k_merge_llane<48, 128>), dim3(grid_for(cntb, 128, 16384)), dim3(128), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
+                        case 4: hipLaunchKernelGGL((tk_k_merge_llane<64, 128>), dim3(grid_for(cntb, 128, 16384)), dim3(128), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
+                        case 5: hipLaunchKernelGGL((tk_k_merge_group<8>), dim3(grid_for(cntb, 32, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
+                        case 6: hipLaunchKernelGGL((tk_k_merge_group<16>), dim3(grid_for(cntb, 16, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
+                        case 7: hipLaunchKernelGGL((tk_k_merge_group<32>), dim3(grid_for(cntb, 8, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
                         default: hipLaunchKernelGGL((tk_k_merge_group<64>), dim3(grid_for(cntb, 4, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
                     }
                 }));

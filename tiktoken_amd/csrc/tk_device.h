@@ -524,60 +524,78 @@ TK_HD int tk_clz32(uint32_t v) { return v ? __builtin_clz(v) : 32; }
 TK_HD int tk_popc32(uint32_t v) { return __builtin_popcount(v); }
 #endif
 
-// byte_pair_merge (src/lib.rs:140-196) for a piece of n <= TK_LANE_MAX bytes, one lane per piece.
-// parts are the byte positions still alive (bit k of `alive`); s_id[k]/s_rk[k] hold the id of the
-// part starting at k and the rank of the pair (part k, next part).  Returns the token count and
-// writes the tokens (ids of the surviving parts, left to right) to out[].
-template <int STRIDE>
-TK_HD uint32_t tk_lane_merge(const TkTables& T, const uint8_t* __restrict__ text, uint64_t s, uint32_t n,
-                                                  uint32_t* s_id, uint32_t* s_rk, uint32_t* out1, uint32_t* __restrict__ out) {
-    uint64_t w0 = tk_load8(text, s), w1 = n > 8 ? tk_load8(text, s + 8) : 0;
-    uint32_t prev_b = (uint32_t)(w0 & 0xFF);
-    for (uint32_t k = 0; k < n; ++k) {
-        uint32_t nb = 0;
-        if (k + 1 < n) nb = (uint32_t)(((k + 1 < 8 ? w0 >> ((k + 1) * 8) : w1 >> ((k + 1 - 8) * 8))) & 0xFF);
-        s_id[k * STRIDE] = T.byte_rank[prev_b];
-        s_rk[k * STRIDE] = (k + 1 < n) ? T.pair2[(prev_b << 8) | nb] : TK_RANK_MAX;
-        prev_b = nb;
+// ------------------------------------------------------------------------------------------
+// byte_pair_merge (src/lib.rs:140-196) for a piece of 2..128 bytes handled by ONE lane: ids and pair
+// ranks of the parts in a strided scratch (LDS: k-major, lane-minor), alive positions in a 128-bit
+// register mask, so the only memory latency per merge is the pair of table probes.  Tokens (ids of
+// the surviving parts, left to right) go to out[0..count).
+// ------------------------------------------------------------------------------------------
+struct TkMask128 {
+    uint64_t lo, hi;
+    TK_HD void clear(uint32_t k) {
+        if (k < 64u) lo &= ~(1ull << k);
+        else hi &= ~(1ull << (k - 64u));
     }
-    uint32_t alive = n >= 32 ? 0xFFFFFFFFu : ((1u << n) - 1u);
+    TK_HD bool test(uint32_t k) const { return k < 64u ? (lo >> k) & 1ull : (hi >> (k - 64u)) & 1ull; }
+    // lowest set position > k, or 128
+    TK_HD uint32_t next_after(uint32_t k) const {
+        if (k < 63u) {
+            uint64_t l = lo & ~((2ull << k) - 1ull);
+            if (l) return tk_ctz64(l);
+        }
+        uint64_t h = hi;
+        if (k >= 127u) h = 0;
+        else if (k >= 64u) h &= ~((2ull << (k - 64u)) - 1ull);
+        if (h) return 64u + tk_ctz64(h);
+        return 128u;
+    }
+    // highest set position < k, or -1
+    TK_HD int prev_before(uint32_t k) const {
+        uint64_t h = k > 64u ? hi & ((1ull << (k - 64u)) - 1ull) : 0ull;
+        if (h) return 127 - (int)tk_clz64(h);
+        uint64_t l = k >= 64u ? lo : lo & ((1ull << k) - 1ull);
+        if (l) return 63 - (int)tk_clz64(l);
+        return -1;
+    }
+};
+
+template <int STRIDE>
+TK_HD uint32_t tk_lane_merge(const TkTables& T, const uint8_t* __restrict__ text, uint64_t s, uint32_t n, uint32_t* id, uint32_t* rk,
+                             uint32_t* __restrict__ out) {
+    uint32_t pb = text[s];
+    for (uint32_t k = 0; k < n; ++k) {
+        uint32_t nb = k + 1 < n ? text[s + k + 1] : 0u;
+        id[k * STRIDE] = T.byte_rank[pb];
+        rk[k * STRIDE] = k + 1 < n ? T.pair2[(pb << 8) | nb] : TK_RANK_MAX;
+        pb = nb;
+    }
+    TkMask128 alive;
+    alive.lo = n >= 64u ? ~0ull : ((1ull << n) - 1ull);
+    alive.hi = n > 64u ? (n >= 128u ? ~0ull : ((1ull << (n - 64u)) - 1ull)) : 0ull;
     for (;;) {
         uint32_t best = TK_RANK_MAX, bi = 0;
         for (uint32_t k = 0; k + 1 < n; ++k) {
-            uint32_t r = s_rk[k * STRIDE];
-            if (r < best) {  // strict '<' keeps the leftmost minimum (lib.rs:151,190)
+            uint32_t r = rk[k * STRIDE];
+            if (r < best) {  // strict '<': leftmost minimum (lib.rs:151,190)
                 best = r;
                 bi = k;
             }
         }
         if (best == TK_RANK_MAX) break;
-        uint32_t i = bi;
-        uint32_t after = alive & ~((2u << i) - 1u);  // alive positions > i
-        uint32_t j = tk_ffs32(after) - 1;                // the part being absorbed (exists: rank was valid)
-        alive &= ~(1u << j);
-        s_id[i * STRIDE] = best;
-        s_rk[j * STRIDE] = TK_RANK_MAX;
-        after &= ~(1u << j);
-        uint32_t before = alive & ((1u << i) - 1u);
+        const uint32_t j = alive.next_after(bi);  // the part being absorbed
+        alive.clear(j);
+        id[bi * STRIDE] = best;
+        rk[j * STRIDE] = TK_RANK_MAX;
+        const uint32_t nn = alive.next_after(bi);
+        const int pp = alive.prev_before(bi);
         uint32_t r_i = TK_RANK_MAX, r_p = TK_RANK_MAX;
-        int pp = before ? 31 - tk_clz32(before) : -1;
-        if (after) r_i = tk_probe_pair(T, best, s_id[(tk_ffs32(after) - 1) * STRIDE]);
-        if (pp >= 0) r_p = tk_probe_pair(T, s_id[pp * STRIDE], best);
-        s_rk[i * STRIDE] = r_i;
-        if (pp >= 0) s_rk[pp * STRIDE] = r_p;
+        if (nn < 128u) r_i = tk_probe_pair(T, best, id[nn * STRIDE]);
+        if (pp >= 0) r_p = tk_probe_pair(T, id[pp * STRIDE], best);
+        rk[bi * STRIDE] = r_i;
+        if (pp >= 0) rk[pp * STRIDE] = r_p;
     }
-    uint32_t cnt = tk_popc32(alive);
-    if (cnt == 1) {
-        *out1 = s_id[0];
-    } else {
-        uint32_t t = 0;
-        uint32_t m = alive;
-        while (m) {
-            uint32_t k = tk_ffs32(m) - 1;
-            m &= m - 1;
-            out[t++] = s_id[k * STRIDE];
-        }
-    }
-    return cnt;
+    uint32_t t = 0;
+    for (uint32_t k = 0; k < n; ++k)
+        if (alive.test(k)) out[t++] = id[k * STRIDE];
+    return t;
 }
-

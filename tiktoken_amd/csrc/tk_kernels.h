@@ -28,13 +28,13 @@
 #define TK_PPT 4         // pieces per thread per block iteration in tk_k_lookup
 
 // Deferred pieces are binned by length so that the 64 lanes of a wave run similar trip counts.
-#define TK_NBIN 8
+#define TK_NBIN 9
 #define TK_GLANE_MAX 1024  // longest piece handled by the lane / lane-group kernels; longer ones go to the tree kernel
 __host__ __device__ inline uint32_t tk_bin_hi(int b) {
-    const uint32_t hi[TK_NBIN] = {24, 32, 48, 64, 128, 256, 512, TK_GLANE_MAX};
+    const uint32_t hi[TK_NBIN] = {16, 24, 32, 48, 64, 128, 256, 512, TK_GLANE_MAX};
     return hi[b];
 }
-__host__ __device__ inline uint32_t tk_bin_lo(int b) { return b == 0 ? TK_LANE_MAX + 1 : tk_bin_hi(b - 1) + 1; }
+__host__ __device__ inline uint32_t tk_bin_lo(int b) { return b == 0 ? 2u : tk_bin_hi(b - 1) + 1; }
 __device__ __forceinline__ int tk_bin_of(uint32_t len) {
     int b = 0;
 #pragma unroll
@@ -602,17 +602,13 @@ __global__ __launch_bounds__(256) void tk_k_emit(const uint32_t* __restrict__ st
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ pstart,
                                                    uint64_t P, const uint32_t* __restrict__ ss, uint32_t* __restrict__ tok1,
-                                                   uint32_t* __restrict__ cnt, uint32_t* __restrict__ staging,
-                                                   uint32_t* __restrict__ listM, TkBins bins, uint32_t* __restrict__ listC,
-                                                   uint32_t* __restrict__ counters, int dbg) {
-    __shared__ uint32_t q[256 * TK_PPT];   // short misses (block-relative piece index)
-    __shared__ uint32_t qB[256 * TK_PPT];  // 17..4096-byte misses: piece index
-    __shared__ uint32_t qBs[256 * TK_PPT]; //   ... and (bin << 16) | slot within this block's share of the bin
+                                                   uint32_t* __restrict__ cnt, uint32_t* __restrict__ listM, TkBins bins,
+                                                   uint32_t* __restrict__ listC, uint32_t* __restrict__ counters, int dbg) {
+    __shared__ uint32_t qB[256 * TK_PPT];   // misses of 2..1024 bytes: piece index
+    __shared__ uint32_t qBs[256 * TK_PPT];  //   ... and (bin << 16) | slot within this block's share of the bin
     __shared__ uint32_t sh_bin[TK_NBIN], sh_binbase[TK_NBIN];
-    __shared__ uint32_t qC[3 * 64];        // longer misses: {piece, bytes before it, levels before it} (spill handled below)
-    __shared__ uint32_t sh_cnt[8];         // 0 qn, 1 nB, 2 nC, 3 cbytes, 4 clevels, 5 gB, 6 gC/gbytes/glv base follow
-    __shared__ uint32_t s_id[TK_LANE_MAX * 256];
-    __shared__ uint32_t s_rk[TK_LANE_MAX * 256];
+    __shared__ uint32_t qC[3 * 64];         // longer misses: {piece, bytes before it, levels before it}
+    __shared__ uint32_t sh_cnt[8];          // 1 nB, 2 nC, 3 cbytes, 4 clevels, 6.. global bases
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63;
     for (uint64_t base = (uint64_t)blockIdx.x * (256 * TK_PPT); base < P; base += (uint64_t)gridDim.x * (256 * TK_PPT)) {
@@ -622,7 +618,7 @@ __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __
 #pragma unroll
         for (int k = 0; k < TK_PPT; ++k) {
             uint64_t p = base + (uint64_t)k * 256 + tid;
-            bool missA = false, missB = false, missC = false;
+            bool missB = false, missC = false;
             uint32_t s = 0, len = 0;
             if (p < P) {
                 s = pstart[p];
@@ -638,8 +634,6 @@ __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __
                             tok1[p] = r;
                             cnt[p] = 1;
                         }
-                    } else if (len <= TK_LANE_MAX) {
-                        missA = true;
                     } else if (len <= TK_GLANE_MAX) {
                         missB = true;
                     } else {
@@ -647,8 +641,6 @@ __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __
                     }
                 }
             }
-            uint32_t ia = tk_wave_append(missA, &sh_cnt[0], lane);
-            if (missA) q[ia] = (uint32_t)(p - base);
             uint32_t ib = tk_wave_append(missB, &sh_cnt[1], lane);
             if (missB) {
                 int b = tk_bin_of(len);
@@ -656,7 +648,7 @@ __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __
                 qBs[ib] = ((uint32_t)b << 16) | atomicAdd(&sh_bin[b], 1u);
             }
             if (missC) {
-                // scratch for the long path: 4 uint32 per byte + the 64-ary min-tree levels
+                // scratch for the tree path: 4 uint32 per byte + the 64-ary min-tree levels
                 uint32_t lv = 0, c = len;
                 do {
                     c = (c + 63) >> 6;
@@ -667,7 +659,7 @@ __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __
                     qC[3 * i] = (uint32_t)p;
                     qC[3 * i + 1] = atomicAdd(&sh_cnt[3], len);
                     qC[3 * i + 2] = atomicAdd(&sh_cnt[4], lv);
-                } else {  // more than 64 long pieces in 1024: straight to the global list
+                } else {  // more than 64 such pieces among 1024: straight to the global list
                     uint32_t gi = atomicAdd(&counters[TK_CNT_C], 1u);
                     listC[3 * (uint64_t)gi] = (uint32_t)p;
                     listC[3 * (uint64_t)gi + 1] = atomicAdd(&counters[TK_CNT_CBYTES], len);
@@ -701,56 +693,17 @@ __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __
                 listC[3 * (uint64_t)(gC + tid) + 2] = glv + qC[3 * tid + 2];
             }
         }
-        const uint32_t nq = sh_cnt[0];
-        for (uint32_t r0 = 0; r0 < nq; r0 += 256) {
-            if (r0 + tid < nq) {
-                uint64_t p = base + q[r0 + tid];
-                uint32_t s = pstart[p], len = pstart[p + 1] - s;
-                uint32_t one = 0;
-                uint32_t c = (dbg & 1) ? 1u : tk_lane_merge<256>(T, text, s, len, s_id + tid, s_rk + tid, &one, staging + s);
-                cnt[p] = c;
-                if (c == 1) tok1[p] = one;
-            }
-        }
         __syncthreads();
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// One LANE per deferred piece of 17..128 bytes, lists binned by length so the 64 lanes of a wave run
+// One LANE per deferred piece of 2..64 bytes, lists binned by length so the 64 lanes of a wave run
 // similar trip counts.  byte_pair_merge (src/lib.rs:140-196): ids and pair ranks of the piece's
 // parts live in LDS (k-major, lane-minor: conflict-free), alive positions in a 128-bit register
 // mask, so the only memory latency per merge is the pair of table probes.  What this buys over
 // one-wave-per-piece is 64 independent probe chains per wavefront.
 // ------------------------------------------------------------------------------------------
-struct TkMask128 {
-    uint64_t lo, hi;
-    __device__ __forceinline__ void clear(uint32_t k) {
-        if (k < 64u) lo &= ~(1ull << k);
-        else hi &= ~(1ull << (k - 64u));
-    }
-    // lowest set position > k, or 128
-    __device__ __forceinline__ uint32_t next_after(uint32_t k) const {
-        if (k < 63u) {
-            uint64_t l = lo & ~((2ull << k) - 1ull);
-            if (l) return (uint32_t)__ffsll((unsigned long long)l) - 1u;
-        }
-        uint64_t h = hi;
-        if (k >= 127u) h = 0;
-        else if (k >= 64u) h &= ~((2ull << (k - 64u)) - 1ull);
-        if (h) return 64u + (uint32_t)__ffsll((unsigned long long)h) - 1u;
-        return 128u;
-    }
-    // highest set position < k, or -1
-    __device__ __forceinline__ int prev_before(uint32_t k) const {
-        uint64_t h = k > 64u ? hi & ((1ull << (k - 64u)) - 1ull) : 0ull;
-        if (h) return 127 - (int)__clzll((long long)h);
-        uint64_t l = k >= 64u ? lo : lo & ((1ull << k) - 1ull);
-        if (l) return 63 - (int)__clzll((long long)l);
-        return -1;
-    }
-};
-
 template <int NMAX, int THREADS>
 __global__ __launch_bounds__(THREADS) void tk_k_merge_llane(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ pstart,
                                                             const uint32_t* __restrict__ list, uint32_t count, uint32_t* __restrict__ tok1,
@@ -762,43 +715,7 @@ __global__ __launch_bounds__(THREADS) void tk_k_merge_llane(TkTables T, const ui
     for (uint32_t it = blockIdx.x * THREADS + threadIdx.x; it < count; it += gridDim.x * THREADS) {
         const uint32_t p = list[it];
         const uint32_t s = pstart[p], n = pstart[p + 1] - s;
-        uint32_t pb = text[s];
-        for (uint32_t k = 0; k < n; ++k) {
-            uint32_t nb = k + 1 < n ? text[s + k + 1] : 0u;
-            id[k * THREADS] = T.byte_rank[pb];
-            rk[k * THREADS] = k + 1 < n ? T.pair2[(pb << 8) | nb] : TK_RANK_MAX;
-            pb = nb;
-        }
-        TkMask128 alive;
-        alive.lo = n >= 64u ? ~0ull : ((1ull << n) - 1ull);
-        alive.hi = n > 64u ? (n >= 128u ? ~0ull : ((1ull << (n - 64u)) - 1ull)) : 0ull;
-        for (;;) {
-            uint32_t best = TK_RANK_MAX, bi = 0;
-            for (uint32_t k = 0; k + 1 < n; ++k) {
-                uint32_t r = rk[k * THREADS];
-                if (r < best) {  // strict '<': leftmost minimum (lib.rs:151,190)
-                    best = r;
-                    bi = k;
-                }
-            }
-            if (best == TK_RANK_MAX) break;
-            const uint32_t j = alive.next_after(bi);  // the part being absorbed
-            alive.clear(j);
-            id[bi * THREADS] = best;
-            rk[j * THREADS] = TK_RANK_MAX;
-            const uint32_t nn = alive.next_after(bi);
-            const int pp = alive.prev_before(bi);
-            uint32_t r_i = TK_RANK_MAX, r_p = TK_RANK_MAX;
-            if (nn < 128u) r_i = tk_probe_pair(T, best, id[nn * THREADS]);
-            if (pp >= 0) r_p = tk_probe_pair(T, id[pp * THREADS], best);
-            rk[bi * THREADS] = r_i;
-            if (pp >= 0) rk[pp * THREADS] = r_p;
-        }
-        uint32_t t = 0;
-        for (uint32_t k = 0; k < n; ++k) {
-            bool a = k < 64u ? (alive.lo >> k) & 1ull : (alive.hi >> (k - 64u)) & 1ull;
-            if (a) staging[s + t++] = id[k * THREADS];
-        }
+        const uint32_t t = tk_lane_merge<THREADS>(T, text, s, n, id, rk, staging + s);
         cnt[p] = t;
         if (t == 1) tok1[p] = id[0];
     }
