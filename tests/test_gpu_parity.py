@@ -159,3 +159,21 @@ def test_single_token_and_decode(cores):
         core.decode_bytes([4_000_000_000])
     vals = core.token_byte_values()
     assert vals == sorted(ranks.keys())
+
+
+@pytest.mark.parametrize("dbg", ["512", "256"])
+def test_dedup_collision_and_disabled_paths(dbg, monkeypatch):
+    """The in-call de-duplication of missed pieces must never change results: 512 truncates the table hash
+    to 12 bits so that different pieces collide constantly (every duplicate candidate is byte-verified and
+    real collisions are re-encoded on their own); 256 switches the table off."""
+    from tiktoken_amd import CoreBPE
+
+    monkeypatch.setenv("TIKTOKEN_AMD_DEBUG", dbg)
+    g = h.load_golden("o200k_shaped")
+    core = CoreBPE(h.golden_vocab("o200k_shaped"), g["special_tokens"], g["pat_str"])
+    monkeypatch.delenv("TIKTOKEN_AMD_DEBUG")
+    C = h.c_oracle_for("o200k_shaped")
+    blob, off = h.gen_corpus(0xDED0, 0, 4 << 20)
+    toks, toff = core.encode_batch_packed(blob, off)
+    rt, ro = C.encode_batch(blob, off, None, 8)
+    assert np.array_equal(toff, ro) and np.array_equal(toks, rt)

@@ -58,6 +58,8 @@ struct KernelStat {
 struct tk_core {
     int device = 0;
     hipStream_t stream = nullptr;
+    hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};  // side streams: the merge kernels are independent of each other
+    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
     TkHostTables H;
     TkTables D;  // device view
     Buf t_stage1, t_stage2, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_spec_bytes, t_spec_off, t_spec_id;
@@ -65,7 +67,7 @@ struct tk_core {
     std::mutex mu;
     // workspace
     Buf text, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, tok1, cnt, tokbase, staging, listB, listC,
-        counters, total, partial, rkb, prof, g_id, g_rk, g_nx, g_pv, g_lv, out_tokens, out_tok_off, allowed;
+        counters, total, partial, rkb, prof, mt_key, mt_rep, dup_list, coll_list, g_id, g_rk, g_nx, g_pv, g_lv, out_tokens, out_tok_off, allowed;
     uint64_t chunk_bytes = 1ull << 30;
     int dbg = 0;
     // instrumentation
@@ -151,6 +153,10 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     };
     if (hipSetDevice(device) != hipSuccess) return bail(fail(TK_RUNTIME_ERROR, "hipSetDevice failed"));
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(TK_RUNTIME_ERROR, "hipStreamCreate failed"));
+    for (int i = 0; i < 4; ++i)
+        if (hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess)
+            return bail(fail(TK_RUNTIME_ERROR, "hipStreamCreate failed"));
+    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return bail(fail(TK_RUNTIME_ERROR, "hipEventCreate failed"));
     const TkHostTables& H = c->H;
     int rc;
     if ((rc = upload(c->t_stage1, tk_uc_stage1, sizeof tk_uc_stage1))) return bail(rc);
@@ -199,10 +205,15 @@ extern "C" void tk_destroy(tk_core* c) {
     for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_piece, &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2,
                    &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off, &c->brk, &c->docb,
                    &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->tok1, &c->cnt, &c->tokbase, &c->staging,
-                   &c->listB, &c->listC, &c->counters, &c->total, &c->partial, &c->rkb, &c->prof, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv,
+                   &c->listB, &c->listC, &c->counters, &c->total, &c->partial, &c->rkb, &c->prof, &c->mt_key, &c->mt_rep, &c->dup_list, &c->coll_list, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv,
                    &c->out_tokens, &c->out_tok_off, &c->allowed})
         release(*b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
+    for (int i = 0; i < 4; ++i) {
+        if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
+        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+    }
+    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     delete c;
 }
 
@@ -323,10 +334,21 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         TRY(ensure(c->listB, pool * 4));
         TRY(ensure(c->listC, (n / 65 + 64) * 12));
         uint32_t* counters = c->counters.as<uint32_t>();
+        TkMissTable mt{nullptr, nullptr, nullptr};
+        if (!single_piece && P > 4096) {
+            TRY(ensure(c->mt_key, (8ull << TK_MT_BITS)));
+            TRY(ensure(c->mt_rep, (4ull << TK_MT_BITS)));
+            TRY(ensure(c->dup_list, (n / 2 + 64) * 4));
+            TRY(ensure(c->coll_list, (n / 2 + 64) * 4));
+            HIPCHK(hipMemsetAsync(c->mt_key.p, 0xFF, (8ull << TK_MT_BITS), s));
+            mt.key = c->mt_key.as<unsigned long long>();
+            mt.rep = c->mt_rep.as<uint32_t>();
+            mt.dup_list = c->dup_list.as<uint32_t>();
+        }
         TRY(timed(c, s, "tk_k_lookup", [&] {
             hipLaunchKernelGGL(tk_k_lookup, dim3(grid_for(P, 256 * TK_PPT, 4096)), dim3(256), 0, s, T, d_text, pstart, P, ss,
                                c->tok1.as<uint32_t>(), c->cnt.as<uint32_t>(), c->listB.as<uint32_t>(), bins,
-                               c->listC.as<uint32_t>(), counters, c->dbg);
+                               c->listC.as<uint32_t>(), counters, mt, c->dbg);
         }));
         uint32_t hc[TK_CNT_N];
         HIPCHK(hipMemcpyAsync(hc, counters, sizeof hc, hipMemcpyDeviceToHost, s));
@@ -336,12 +358,20 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         if (nB) {
             static const char* const names[TK_NBIN] = {"tk_k_merge_llane_16", "tk_k_merge_llane_24", "tk_k_merge_llane_32", "tk_k_merge_llane_48", "tk_k_merge_llane_64",
                                                        "tk_k_merge_group_8", "tk_k_merge_group_16", "tk_k_merge_group_32", "tk_k_merge_group_64"};
-            for (int b = 0; b < TK_NBIN; ++b) {
+            // the bins are independent: spread them over the side streams, longest-tailed kernels first
+            HIPCHK(hipEventRecord(c->ev_fork, s));
+            for (int i = 0; i < 4; ++i) HIPCHK(hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
+            static const int order[TK_NBIN] = {8, 7, 6, 5, 0, 1, 4, 3, 2};
+            int slot = 0;
+            hipStream_t s_main = s;
+            for (int oi = 0; oi < TK_NBIN; ++oi) {
+                const int b = order[oi];
                 uint32_t cntb = hc[TK_CNT_BIN0 + b];
                 if (!cntb) continue;
                 if (c->dbg & 64) fprintf(stderr, "bin %d (%u..%u bytes): %u pieces\n", b, tk_bin_lo(b), tk_bin_hi(b), cntb);
                 const uint32_t* lst = c->listB.as<uint32_t>() + bins.off[b];
                 uint32_t *t1 = c->tok1.as<uint32_t>(), *cn = c->cnt.as<uint32_t>(), *stg = c->staging.as<uint32_t>();
+                hipStream_t s = c->aux[slot++ & 3];
                 TRY(timed(c, s, names[b], [&] {
                     switch (b) {
                         case 0: hipLaunchKernelGGL((tk_k_merge_llane<16, 256>), dim3(grid_for(cntb, 256, 32768)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
@@ -349,12 +379,16 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
                         case 2: hipLaunchKernelGGL((tk_k_merge_llane<32, 256>), dim3(grid_for(cntb, 256, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
                         case 3: hipLaunchKernelGGL((tk_k_merge_llane<48, 128>), dim3(grid_for(cntb, 128, 16384)), dim3(128), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
                         case 4: hipLaunchKernelGGL((tk_k_merge_llane<64, 128>), dim3(grid_for(cntb, 128, 16384)), dim3(128), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
-                        case 5: hipLaunchKernelGGL((tk_k_merge_group<8>), dim3(grid_for(cntb, 32, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
-                        case 6: hipLaunchKernelGGL((tk_k_merge_group<16>), dim3(grid_for(cntb, 16, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
-                        case 7: hipLaunchKernelGGL((tk_k_merge_group<32>), dim3(grid_for(cntb, 8, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
-                        default: hipLaunchKernelGGL((tk_k_merge_group<64>), dim3(grid_for(cntb, 4, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
+                        case 5: hipLaunchKernelGGL((tk_k_merge_group<8>), dim3(grid_for(cntb, 32, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg, (const uint32_t*)nullptr); break;
+                        case 6: hipLaunchKernelGGL((tk_k_merge_group<16>), dim3(grid_for(cntb, 16, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg, (const uint32_t*)nullptr); break;
+                        case 7: hipLaunchKernelGGL((tk_k_merge_group<32>), dim3(grid_for(cntb, 8, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg, (const uint32_t*)nullptr); break;
+                        default: hipLaunchKernelGGL((tk_k_merge_group<64>), dim3(grid_for(cntb, 4, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg, (const uint32_t*)nullptr); break;
                     }
                 }));
+            }
+            for (int i = 0; i < 4; ++i) {
+                HIPCHK(hipEventRecord(c->ev_join[i], c->aux[i]));
+                HIPCHK(hipStreamWaitEvent(s_main, c->ev_join[i], 0));
             }
         }
         if (nC) {
@@ -369,6 +403,18 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
                                    (uint32_t)nC, c->g_id.as<uint32_t>(), c->g_rk.as<uint32_t>(), c->g_nx.as<uint32_t>(),
                                    c->g_pv.as<uint32_t>(), c->g_lv.as<uint64_t>(), c->tok1.as<uint32_t>(), c->cnt.as<uint32_t>(),
                                    c->staging.as<uint32_t>());
+            }));
+        }
+        if (hc[TK_CNT_DUP]) {
+            const uint32_t n_dup = hc[TK_CNT_DUP];
+            TRY(timed(c, s, "tk_k_dup_fix", [&] {
+                hipLaunchKernelGGL(tk_k_dup_fix, dim3(grid_for(n_dup, 256, 16384)), dim3(256), 0, s, d_text, pstart, mt, n_dup,
+                                   c->tok1.as<uint32_t>(), c->cnt.as<uint32_t>(), c->coll_list.as<uint32_t>(), counters);
+            }));
+            // hash collisions (different bytes, same 64-bit hash) are encoded on their own; the list length lives on the device
+            TRY(timed(c, s, "tk_k_merge_group_64c", [&] {
+                hipLaunchKernelGGL((tk_k_merge_group<64>), dim3(256), dim3(256), 0, s, T, d_text, pstart, c->coll_list.as<uint32_t>(), 0u,
+                                   c->tok1.as<uint32_t>(), c->cnt.as<uint32_t>(), c->staging.as<uint32_t>(), counters + TK_CNT_COLL);
             }));
         }
         // token counts -> offsets

@@ -493,8 +493,7 @@ TK_HD uint64_t tk_key_of_text(const uint8_t* __restrict__ text, uint64_t pos, ui
 }
 
 // exact compare of text[pos..pos+len) with tok_bytes[off..off+len)
-TK_HD bool tk_equal_bytes(const uint8_t* __restrict__ text, uint64_t pos, const uint8_t* __restrict__ blob, uint32_t off,
-                          uint32_t len) {
+TK_HD bool tk_equal_bytes(const uint8_t* text, uint64_t pos, const uint8_t* blob, uint32_t off, uint32_t len) {
     uint32_t i = 0;
     for (; i + 8u <= len; i += 8u)
         if (tk_load8(text, pos + i) != tk_load8(blob, (uint64_t)off + i)) return false;

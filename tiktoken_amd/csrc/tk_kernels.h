@@ -46,7 +46,19 @@ struct TkBins {
 };
 
 // counters (device uint32 array)
-enum { TK_CNT_B = 0, TK_CNT_C = 1, TK_CNT_CBYTES = 2, TK_CNT_CLEVELS = 3, TK_CNT_BIN0 = 8, TK_CNT_N = 8 + TK_NBIN + 1 };
+enum { TK_CNT_B = 0, TK_CNT_C = 1, TK_CNT_CBYTES = 2, TK_CNT_CLEVELS = 3, TK_CNT_DUP = 4, TK_CNT_COLL = 5, TK_CNT_BIN0 = 8, TK_CNT_N = 8 + TK_NBIN + 1 };
+
+// In-call de-duplication of missed pieces (the same rare word occurs many times in a batch): a
+// best-effort open-addressed table {hash(bytes, len) -> first piece that claimed it}.  The claimant is
+// merged; later identical pieces are verified byte for byte against it (tk_k_dup_fix) and copy its
+// result.  Nothing is carried over between calls.
+#define TK_MT_BITS 22
+#define TK_MT_PROBES 8
+struct TkMissTable {
+    unsigned long long* key;  // [1 << TK_MT_BITS], ~0 = empty
+    uint32_t* rep;            // claimant piece index
+    uint32_t* dup_list;       // pieces that found an existing claim
+};
 
 // ------------------------------------------------------------------------------------------
 // wave helpers (wave64)
@@ -603,7 +615,8 @@ __global__ __launch_bounds__(256) void tk_k_emit(const uint32_t* __restrict__ st
 __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ pstart,
                                                    uint64_t P, const uint32_t* __restrict__ ss, uint32_t* __restrict__ tok1,
                                                    uint32_t* __restrict__ cnt, uint32_t* __restrict__ listM, TkBins bins,
-                                                   uint32_t* __restrict__ listC, uint32_t* __restrict__ counters, int dbg) {
+                                                   uint32_t* __restrict__ listC, uint32_t* __restrict__ counters, TkMissTable mt, int dbg) {
+    __shared__ uint32_t qD[256 * TK_PPT];   // duplicates of an already claimed missed piece
     __shared__ uint32_t qB[256 * TK_PPT];   // misses of 2..1024 bytes: piece index
     __shared__ uint32_t qBs[256 * TK_PPT];  //   ... and (bin << 16) | slot within this block's share of the bin
     __shared__ uint32_t sh_bin[TK_NBIN], sh_binbase[TK_NBIN];
@@ -618,7 +631,7 @@ __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __
 #pragma unroll
         for (int k = 0; k < TK_PPT; ++k) {
             uint64_t p = base + (uint64_t)k * 256 + tid;
-            bool missB = false, missC = false;
+            bool missB = false, missC = false, dup = false;
             uint32_t s = 0, len = 0;
             if (p < P) {
                 s = pstart[p];
@@ -627,20 +640,41 @@ __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __
                     tok1[p] = tk_special_id(T, text, s, len);
                     cnt[p] = 1;
                 } else {
-                    uint32_t r = (dbg & 2) ? len : tk_lookup_text_piece(T, text, s, len);
-                    if ((dbg & 8) && r == TK_RANK_MAX) r = 0;
+                    const uint64_t key = tk_key_of_text(text, s, len);
+                    uint32_t r = tk_probe_piece(T, key, len, [&](uint32_t off) { return tk_equal_bytes(text, s, T.tok_bytes, off, len); });
                     if (r != TK_RANK_MAX) {
-                        if (!(dbg & 4)) {
-                            tok1[p] = r;
-                            cnt[p] = 1;
-                        }
+                        tok1[p] = r;
+                        cnt[p] = 1;
                     } else if (len <= TK_GLANE_MAX) {
                         missB = true;
+                        if (mt.key && !(dbg & 256)) {
+                            unsigned long long k = tk_mix64(key ^ ((uint64_t)len * 0xA24BAED4963EE407ull));
+                            if (dbg & 512) k &= 0xFFFull;  // test hook: force collisions between different pieces
+                            if (k == TK_EMPTY_KEY) k = 0;
+                            uint32_t i = (uint32_t)(k >> 7) & ((1u << TK_MT_BITS) - 1u);
+                            for (int t = 0; t < TK_MT_PROBES; ++t) {
+                                unsigned long long cur = mt.key[i];
+                                if (cur == TK_EMPTY_KEY) cur = atomicCAS(&mt.key[i], TK_EMPTY_KEY, k);
+                                if (cur == TK_EMPTY_KEY) {  // claimed: this piece is the one that gets merged
+                                    mt.rep[i] = (uint32_t)p;
+                                    break;
+                                }
+                                if (cur == k) {
+                                    dup = true;
+                                    missB = false;
+                                    tok1[p] = i;
+                                    break;
+                                }
+                                i = (i + 1) & ((1u << TK_MT_BITS) - 1u);
+                            }
+                        }
                     } else {
                         missC = true;
                     }
                 }
             }
+            uint32_t idp = tk_wave_append(dup, &sh_cnt[0], lane);
+            if (dup) qD[idp] = (uint32_t)p;
             uint32_t ib = tk_wave_append(missB, &sh_cnt[1], lane);
             if (missB) {
                 int b = tk_bin_of(len);
@@ -673,6 +707,7 @@ __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __
         if (tid < TK_NBIN && sh_bin[tid]) sh_binbase[tid] = bins.off[tid] + atomicAdd(&counters[TK_CNT_BIN0 + tid], sh_bin[tid]);
         if (tid == 0) {
             uint32_t nC = sh_cnt[2] < 64 ? sh_cnt[2] : 64;
+            if (sh_cnt[0]) sh_cnt[5] = atomicAdd(&counters[TK_CNT_DUP], sh_cnt[0]);
             if (nC) {
                 sh_cnt[6] = atomicAdd(&counters[TK_CNT_C], nC);
                 sh_cnt[7] = atomicAdd(&counters[TK_CNT_CBYTES], sh_cnt[3]);
@@ -687,6 +722,8 @@ __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __
                 uint32_t bs = qBs[i];
                 listM[sh_binbase[bs >> 16] + (bs & 0xFFFFu)] = qB[i];
             }
+            const uint32_t nD = sh_cnt[0], gD = sh_cnt[5];
+            for (uint32_t i = tid; i < nD; i += 256) mt.dup_list[gD + i] = qD[i];
             if (tid < nC) {
                 listC[3 * (uint64_t)(gC + tid)] = qC[3 * tid];
                 listC[3 * (uint64_t)(gC + tid) + 1] = gbytes + qC[3 * tid + 1];
@@ -717,7 +754,7 @@ __global__ __launch_bounds__(THREADS) void tk_k_merge_llane(TkTables T, const ui
         const uint32_t s = pstart[p], n = pstart[p + 1] - s;
         const uint32_t t = tk_lane_merge<THREADS>(T, text, s, n, id, rk, staging + s);
         cnt[p] = t;
-        if (t == 1) tok1[p] = id[0];
+        tok1[p] = t == 1 ? id[0] : p;  // multi-token results are fetched from staging[pstart[tok1[p]]]
     }
 }
 
@@ -732,8 +769,10 @@ __global__ __launch_bounds__(THREADS) void tk_k_merge_llane(TkTables T, const ui
 template <int G>
 __global__ __launch_bounds__(256) void tk_k_merge_group(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ pstart,
                                                         const uint32_t* __restrict__ list, uint32_t count, uint32_t* __restrict__ tok1,
-                                                        uint32_t* __restrict__ cnt, uint32_t* __restrict__ staging) {
+                                                        uint32_t* __restrict__ cnt, uint32_t* __restrict__ staging,
+                                                        const uint32_t* __restrict__ count_ptr) {
     constexpr int C = 16, NMAX = G * C, PPW = 64 / G;
+    if (count_ptr) count = *count_ptr;  // list length produced on the device (collision list)
     constexpr uint32_t NONE = 0xFFFFu;
     __shared__ __attribute__((aligned(16))) uint32_t s_id[4][1024];
     __shared__ __attribute__((aligned(16))) uint32_t s_rk[4][1024];
@@ -875,7 +914,7 @@ __global__ __launch_bounds__(256) void tk_k_merge_group(TkTables T, const uint8_
             }
             if (g == 0) {
                 cnt[p] = total;
-                if (total == 1) tok1[p] = id[0];
+                tok1[p] = total == 1 ? id[0] : p;
             }
         }
         __builtin_amdgcn_wave_barrier();
@@ -989,6 +1028,7 @@ __global__ __launch_bounds__(256) void tk_k_merge_long(TkTables T, const uint8_t
                 uint32_t t = 0;
                 for (uint32_t k = 0; k < n; k = nx[k]) staging[s + t++] = id[k];
                 cnt[p] = t;
+                tok1[p] = p;
             }
         }
     }
@@ -1029,6 +1069,26 @@ __global__ __launch_bounds__(256) void tk_k_scan_down(const uint32_t* __restrict
 }
 
 // ------------------------------------------------------------------------------------------
+// duplicates of a claimed missed piece: verify the bytes against the claimant and copy its result
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tk_k_dup_fix(const uint8_t* __restrict__ text, const uint32_t* __restrict__ pstart,
+                                                    TkMissTable mt, uint32_t n_dup, uint32_t* __restrict__ tok1, uint32_t* __restrict__ cnt,
+                                                    uint32_t* __restrict__ coll_list, uint32_t* __restrict__ counters) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_dup; i += gridDim.x * 256u) {
+        const uint32_t p = mt.dup_list[i];
+        const uint32_t rep = mt.rep[tok1[p]];
+        const uint32_t s = pstart[p], len = pstart[p + 1] - s, rs = pstart[rep], rlen = pstart[rep + 1] - rs;
+        if (len == rlen && tk_equal_bytes(text, s, text, rs, len)) {
+            const uint32_t c = cnt[rep];
+            cnt[p] = c;
+            tok1[p] = c == 1 ? tok1[rep] : rep;
+        } else {  // different bytes behind the same 64-bit hash: encode this piece on its own
+            coll_list[atomicAdd(&counters[TK_CNT_COLL], 1u)] = p;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // final packing
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tk_k_gather(const uint32_t* __restrict__ pstart, uint64_t P, const uint32_t* __restrict__ cnt,
@@ -1039,7 +1099,7 @@ __global__ __launch_bounds__(256) void tk_k_gather(const uint32_t* __restrict__ 
         if (c == 1) {
             out[b] = tok1[p];
         } else {
-            const uint32_t* src = staging + pstart[p];
+            const uint32_t* src = staging + pstart[tok1[p]];  // own result, or the piece this one duplicates
             for (uint32_t t = 0; t < c; ++t) out[b + t] = src[t];
         }
     }
