@@ -126,6 +126,22 @@ struct PropAcc {  // accessor over the propagated class array (0x40 = continuati
     uint32_t byte(uint64_t pos) const { return text[pos]; }
 };
 
+struct SimExt {  // extension windows from the byte-per-bit arrays; `lim` mimics the LDS window edge of a tile
+    const std::vector<uint8_t>* bm[TKB_KINDS];
+    uint64_t p;
+    uint32_t lim;
+    uint64_t win(int kind, uint32_t j) const {
+        uint64_t w = 0;
+        const std::vector<uint8_t>& v = *bm[kind];
+        for (uint32_t k = 0; k < 64; ++k) {
+            uint64_t pos = p + 64ull * j + k;
+            if (pos < v.size() ? v[pos] : (kind == TKB_HARD || kind == TKB_START)) w |= 1ull << k;
+        }
+        return w;
+    }
+    uint32_t limit() const { return lim; }
+};
+
 static uint64_t win_of(const std::vector<uint8_t>& bm, uint64_t p) {
     uint64_t w = 0;
     for (uint32_t k = 0; k < 64; ++k)
@@ -201,7 +217,12 @@ uint64_t tks_pretok_bits(void* pv, const uint8_t* text_in, uint64_t n, const uin
             w.nl = win_of(b_nl, q);
             w.nu = win_of(b_nu, q);
             w.nlsl = win_of(b_nlsl, q);
-            uint32_t len = tk_piece_len_bits(w, acc, q, cls2[q] & 15u, pat);
+            SimExt ext;
+            const std::vector<uint8_t>* arr[TKB_KINDS] = {&b_start, &b_hard, &b_L, &b_up, &b_low, &b_cas, &b_oth, &b_ws, &b_nl, &b_nu, &b_nlsl};
+            for (int kk = 0; kk < TKB_KINDS; ++kk) ext.bm[kk] = arr[kk];
+            ext.p = q;
+            ext.lim = (uint32_t)(4096 + 192 - (q % 4096));  // like tk_k_pretok2: tile + right halo
+            uint32_t len = tk_piece_len_bits(w, acc, ext, q, cls2[q] & 15u, pat);
             uint64_t e;
             if (len) {
                 e = q + len;

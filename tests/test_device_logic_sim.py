@@ -23,15 +23,39 @@ def _ref_ends(C, docs, off):
     return ref
 
 
+@pytest.mark.parametrize("bits", [False, True], ids=["bytewalk", "bitparallel"])
 @pytest.mark.parametrize("name", h.ENCODING_NAMES)
-def test_pretok_sim_on_adversarial_batches(sims, name):
+def test_pretok_sim_on_adversarial_batches(sims, name, bits):
     sim, C = sims[name], h.c_oracle_for(name)
     rng = random.Random(11)
     for _ in range(3000):
         docs = ["".join(rng.choice(h.ADV) for _ in range(rng.randint(0, 30))).encode() for _ in range(rng.randint(1, 4))]
         blob, off = h.pack(docs)
-        ends, _ = sim.piece_ends(blob, off)
+        ends, _ = sim.piece_ends(blob, off, bits=bits)
         assert ends.tolist() == _ref_ends(C, docs, off), docs
+
+
+@pytest.mark.parametrize("name", h.ENCODING_NAMES)
+def test_bitparallel_long_runs_and_window_edges(sims, name):
+    """Runs longer than one 64-bit window (continued through the extension windows) and runs that reach the
+    edge of a tile's LDS window (4096 + 192 bytes: unresolved -> byte-walking fallback), at every alignment."""
+    sim, C = sims[name], h.c_oracle_for(name)
+    rng = random.Random(29)
+    units = ["a", "A", "1", " ", "\n", "!", "中", "́", "'s", "/", "\t", "ก", "é", "-", "="]
+    for _ in range(400):
+        parts = []
+        size = 0
+        while size < 9000:
+            u = rng.choice(units)
+            k = rng.choice([1, 2, 3, 30, 59, 64, 65, 130, 200, 700])
+            seg = rng.choice(["", " ", "x", "'", "X"]) + u * k + rng.choice(["", " ", "b", "B", "'ll", "\n", "9", "'S"])
+            parts.append(seg)
+            size += len(seg.encode())
+        doc = "".join(parts).encode()
+        pad = b"y" * rng.randint(0, 70)  # shift everything relative to the 4096-byte tiles
+        blob, off = h.pack([pad + doc])
+        ends, n_fallback = sim.piece_ends(blob, off, bits=True)
+        assert ends.tolist() == C.split(pad + doc)
 
 
 REPS = {  # one or two representatives per character class, incl. every contraction letter in both cases
@@ -55,8 +79,9 @@ def test_certain_start_rule_exhaustive_short_strings(sims, name):
     for i in range(0, len(docs), 512):
         chunk = docs[i:i + 512]
         blob, off = h.pack(chunk)
-        ends, _ = sim.piece_ends(blob, off)
-        assert ends.tolist() == _ref_ends(C, chunk, off)
+        ref = _ref_ends(C, chunk, off)
+        assert sim.piece_ends(blob, off)[0].tolist() == ref
+        assert sim.piece_ends(blob, off, bits=True)[0].tolist() == ref
 
 
 @pytest.mark.parametrize("name,mix", [("gpt2_shaped", 1), ("cl100k_shaped", 0), ("o200k_shaped", 1)])
@@ -69,6 +94,9 @@ def test_pretok_and_pieces_on_corpus(sims, name, mix):
     ref = _ref_ends(C, docs, off)
     assert ends.tolist() == ref
     assert n_certain / len(ref) > 0.9  # certain starts must stay dense or the pre-tokeniser loses parallelism
+    ends_b, n_fallback = sim.piece_ends(blob, off, bits=True)
+    assert ends_b.tolist() == ref
+    assert n_fallback / len(ref) < 0.001  # the byte-walking fallback must stay the exception
     p = 0
     for e in ref[:20000]:
         piece = bb[p:e]

@@ -303,7 +303,51 @@ TK_HD uint32_t tk_run(uint64_t bits, uint64_t stop, uint32_t from) {
     return tk_ctz64(~x);  // zeros shifted in from the top bound the result by 64 - from
 }
 
-#define TK_WIN_SAFE 58u  // results beyond this relative position are treated as unresolved
+#define TK_WIN_SAFE 58u  // results up to here are decided inside the first 64-bit window
+#define TK_UNRES 0xFFFFFFFFu
+enum { TKB_START = 0, TKB_HARD, TKB_L, TKB_UP, TKB_LOW, TKB_CAS, TKB_OTH, TKB_WS, TKB_NL, TKB_NU, TKB_NLSL, TKB_KINDS };
+
+// Runs that leave the first window continue through an extension provider X:
+//   x.win(kind, j) -> 64-bit window j (positions [64 j, 64 j + 64) relative to the piece start) of bitmap `kind`
+//   x.limit()      -> number of positions, counted from the piece start, for which windows are valid
+// A run that reaches the limit is unresolved (TK_UNRES) and the caller falls back to tk_piece_end.
+template <class X>
+TK_HD uint32_t tk_runx(uint64_t bits0, uint64_t stop0, X& x, int kind, uint32_t from) {
+    uint32_t pos = from;
+    if (from < 64u) {
+        uint32_t r = tk_run(bits0, stop0, from);
+        if (from + r < 64u) return r;
+        pos = 64u;
+    }
+    for (;;) {
+        if (pos + 64u > x.limit()) return TK_UNRES;
+        const uint32_t j = pos >> 6, o = pos & 63u;
+        const uint64_t bits = (x.win(kind, j) & ~x.win(TKB_HARD, j)) >> o;
+        const uint32_t r = tk_ctz64(~bits);
+        pos += r;
+        if (r < 64u - o) break;
+    }
+    return pos - from;
+}
+// highest set position of bitmap `kind` in [a, b), or -1 (b may lie beyond the first window)
+template <class X>
+TK_HD int tk_last_setx(uint64_t bits0, X& x, int kind, uint32_t a, uint32_t b) {
+    if (b <= a) return -1;
+    int j = (int)((b - 1u) >> 6);
+    const int ja = (int)(a >> 6);
+    for (; j >= ja; --j) {
+        uint64_t w = j == 0 ? bits0 : x.win(kind, (uint32_t)j);
+        const uint32_t hi = (uint32_t)j * 64u + 64u, lo = (uint32_t)j * 64u;
+        if (b < hi) w &= tk_below(b - lo);
+        if (a > lo) w &= ~tk_below(a - lo);
+        if (w) return (int)(lo + 63u - tk_clz64(w));
+    }
+    return -1;
+}
+template <class X>
+TK_HD bool tk_bitx(uint64_t bits0, X& x, int kind, uint32_t k) {
+    return k < 64u ? (bits0 >> k) & 1ull : (x.win(kind, k >> 6) >> (k & 63u)) & 1ull;
+}
 
 template <class A>
 TK_HD uint32_t tk_contraction_bits(const TkWin& w, A& a, uint64_t p, uint32_t e, bool ci) {
@@ -327,9 +371,9 @@ TK_HD uint32_t tk_contraction_bits(const TkWin& w, A& a, uint64_t p, uint32_t e,
     return 0;
 }
 
-// c = class nibble of the char at p
-template <class A>
-TK_HD uint32_t tk_piece_len_bits(const TkWin& w, A& a, uint64_t p, uint32_t c, int pat) {
+// c = class nibble of the char at p.  Returns the piece length, or 0 if unresolved.
+template <class A, class X>
+TK_HD uint32_t tk_piece_len_bits(const TkWin& w, A& a, X& x, uint64_t p, uint32_t c, int pat) {
     const uint64_t stop = w.stop;
     // length of the first char: next char start or stop after position 0
     const uint32_t k1 = 1u + tk_ctz64((w.start | stop) >> 1);
@@ -343,16 +387,28 @@ TK_HD uint32_t tk_piece_len_bits(const TkWin& w, A& a, uint64_t p, uint32_t c, i
         if ((TK_M_WORD >> c) & 1u) ks = 0;
         else if (c != TK_C_NL && c != TK_C_NU && !nxt_end && ((word >> k1) & 1ull)) ks = k1;
         if (ks != 64u) {
-            uint32_t re = ks + tk_run(w.up, stop, ks);
-            uint32_t te = re + tk_run(w.low, stop, re);
-            if (te > TK_WIN_SAFE) return 0;
+            uint32_t r = tk_runx(w.up, stop, x, TKB_UP, ks);
+            if (r == TK_UNRES) return 0;
+            const uint32_t re = ks + r;
+            uint32_t t = tk_runx(w.low, stop, x, TKB_LOW, re);
+            if (t == TK_UNRES) return 0;
+            const uint32_t te = re + t;
             if (te > re) {
                 e = te;
+            } else if (re <= TK_WIN_SAFE) {
+                uint64_t xx = w.cas & ~stop & tk_below(re) & ~tk_below(ks);
+                e = xx ? 64u - tk_clz64(xx) : re;
             } else {
-                uint64_t x = w.cas & ~stop & tk_below(re) & ~tk_below(ks);
-                e = x ? 64u - tk_clz64(x) : re;
+                int lc = tk_last_setx(w.cas, x, TKB_CAS, ks, re);  // (stops cannot lie inside a run)
+                e = lc >= 0 ? (uint32_t)lc + 1u : re;
             }
-            if (!((stop >> e) & 1ull) && a.byte(p + e) == '\'') e += tk_contraction_bits(w, a, p, e, true);
+            if (e <= TK_WIN_SAFE) {
+                if (!((stop >> e) & 1ull) && a.byte(p + e) == '\'') e += tk_contraction_bits(w, a, p, e, true);
+            } else if (e + 4u <= x.limit()) {
+                if (!tk_bitx(w.stop, x, TKB_HARD, e) && a.byte(p + e) == '\'') e += tk_contraction_len(a, p + e, true);
+            } else {
+                return 0;
+            }
             return e;
         }
     } else if (pat == TK_PAT_CL100K) {
@@ -361,12 +417,12 @@ TK_HD uint32_t tk_piece_len_bits(const TkWin& w, A& a, uint64_t p, uint32_t c, i
             if (k) return k;
         }
         if ((TK_M_L >> c) & 1u) {
-            e = tk_run(w.L, stop, 0);
-            return e > TK_WIN_SAFE ? 0 : e;
+            uint32_t r = tk_runx(w.L, stop, x, TKB_L, 0);
+            return r == TK_UNRES ? 0 : r;
         }
         if (c != TK_C_NL && c != TK_C_NU && !nxt_end && ((w.L >> k1) & 1ull)) {
-            e = k1 + tk_run(w.L, stop, k1);
-            return e > TK_WIN_SAFE ? 0 : e;
+            uint32_t r = tk_runx(w.L, stop, x, TKB_L, k1);
+            return r == TK_UNRES ? 0 : k1 + r;
         }
     } else {
         if (c == TK_C_AP) {
@@ -388,29 +444,49 @@ TK_HD uint32_t tk_piece_len_bits(const TkWin& w, A& a, uint64_t p, uint32_t c, i
     bool s_ok = true;
     if (c == TK_C_SP && !nxt_end) s = k1;
     if (pat == TK_PAT_R50K) {
-        if ((w.L >> s) & 1ull) e = s + tk_run(w.L, stop, s);
-        else if ((w.nu >> s) & 1ull) e = s + tk_run(w.nu, stop, s);
-        else if ((w.oth >> s) & 1ull) e = s + tk_run(w.oth, stop, s);
-        else s_ok = false;
+        int kind = -1;
+        uint64_t b0 = 0;
+        if ((w.L >> s) & 1ull) { kind = TKB_L; b0 = w.L; }
+        else if ((w.nu >> s) & 1ull) { kind = TKB_NU; b0 = w.nu; }
+        else if ((w.oth >> s) & 1ull) { kind = TKB_OTH; b0 = w.oth; }
+        if (kind >= 0) {
+            uint32_t r = tk_runx(b0, stop, x, kind, s);
+            return r == TK_UNRES ? 0 : s + r;
+        }
+        s_ok = false;
     } else if ((w.oth >> s) & 1ull) {
-        uint32_t e1 = s + tk_run(w.oth, stop, s);
-        e = e1 + tk_run(pat == TK_PAT_O200K ? w.nlsl : w.nl, stop, e1);
+        uint32_t r = tk_runx(w.oth, stop, x, TKB_OTH, s);
+        if (r == TK_UNRES) return 0;
+        const uint32_t e1 = s + r;
+        uint32_t r2 = pat == TK_PAT_O200K ? tk_runx(w.nlsl, stop, x, TKB_NLSL, e1) : tk_runx(w.nl, stop, x, TKB_NL, e1);
+        return r2 == TK_UNRES ? 0 : e1 + r2;
     } else {
         s_ok = false;
     }
-    if (s_ok) return e > TK_WIN_SAFE ? 0 : e;
+    (void)s_ok;
     // white space
     {
-        uint32_t q = tk_run(w.ws, stop, 0);
-        if (q > TK_WIN_SAFE) return 0;
-        uint64_t rng = tk_below(q);
-        bool at_end = (stop >> q) & 1ull;
-        uint64_t nlr = w.nl & rng, st = w.start & rng;
+        uint32_t q = tk_runx(w.ws, stop, x, TKB_WS, 0);
+        if (q == TK_UNRES) return 0;
+        if (q <= TK_WIN_SAFE) {
+            uint64_t rng = tk_below(q);
+            bool at_end = (stop >> q) & 1ull;
+            uint64_t nlr = w.nl & rng, st = w.start & rng;
+            if (pat != TK_PAT_O200K && at_end) return q;
+            if (pat != TK_PAT_R50K && nlr) return 64u - tk_clz64(nlr);
+            if (at_end) return q;
+            if (tk_popc64(st) >= 2u) return 63u - tk_clz64(st);
+            return q;
+        }
+        if (q + 1u > x.limit()) return 0;
+        const bool at_end = tk_bitx(w.stop, x, TKB_HARD, q);
         if (pat != TK_PAT_O200K && at_end) return q;
-        if (pat != TK_PAT_R50K && nlr) return 64u - tk_clz64(nlr);
+        if (pat != TK_PAT_R50K) {
+            int ln = tk_last_setx(w.nl, x, TKB_NL, 0, q);
+            if (ln >= 0) return (uint32_t)ln + 1u;
+        }
         if (at_end) return q;
-        if (tk_popc64(st) >= 2u) return 63u - tk_clz64(st);
-        return q;
+        return (uint32_t)tk_last_setx(w.start, x, TKB_START, 0, q);  // a run this long has >= 2 chars
     }
 }
 

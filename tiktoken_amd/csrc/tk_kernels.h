@@ -324,7 +324,13 @@ __global__ __launch_bounds__(256) void tk_k_pretok(TkTables T, const uint8_t* __
 #define TK2_WIN (TK2_LEFT + TK_TILE + TK2_RIGHT)  // 4352
 #define TK2_NSEG (TK2_WIN / 64)                   // 68
 #define TK2_CLIST 1536
-enum { TKB_START = 0, TKB_HARD, TKB_L, TKB_UP, TKB_LOW, TKB_CAS, TKB_OTH, TKB_WS, TKB_NL, TKB_NU, TKB_NLSL, TKB_KINDS };
+
+// Out-of-line slow paths: they are rare, and inlining them at every call site of the scanner made the
+// kernel ~30k instructions (instruction-cache thrash).
+__device__ __noinline__ uint32_t tk_class_byte_slow(const TkTables* T, const uint8_t* text, uint64_t pos, uint64_t n, const uint32_t* brk,
+                                                    const uint32_t* ss, const uint32_t* si) {
+    return tk_class_byte(*T, text, pos, n, brk, ss, si);
+}
 
 struct TkWin2Acc {  // byte-walking fallback: propagated classes inside the window, HBM outside
     const uint8_t* cls2;
@@ -341,7 +347,7 @@ struct TkWin2Acc {  // byte-walking fallback: propagated classes inside the wind
             uint32_t c = cls2[r];
             return (c & 0x40u) ? (uint32_t)TK_C_CONT : (c & 0x8Fu);
         }
-        return tk_class_byte(*T, text, pos, n, brk, ss, si);
+        return tk_class_byte_slow(T, text, pos, n, brk, ss, si);
     }
     __device__ __forceinline__ uint32_t byte(uint64_t pos) const {
         int64_t r = (int64_t)pos - base;
@@ -349,6 +355,30 @@ struct TkWin2Acc {  // byte-walking fallback: propagated classes inside the wind
         return text[pos];
     }
 };
+
+struct TkBmExt {  // extension windows for runs longer than the first 64-bit window (LDS bitmaps of the tile)
+    const uint64_t (*bm)[TK2_NSEG + 2];
+    uint32_t wi, sh, lim;
+    __device__ __forceinline__ uint64_t win(int kind, uint32_t j) const {
+        const uint32_t w0 = wi + j;
+        if (w0 + 1 > TK2_NSEG + 1) return kind == TKB_HARD ? ~0ull : 0ull;
+        return sh ? ((bm[kind][w0] >> sh) | (bm[kind][w0 + 1] << (64u - sh))) : bm[kind][w0];
+    }
+    __device__ __forceinline__ uint32_t limit() const { return lim; }
+};
+
+__device__ __forceinline__ uint64_t tk_piece_end_slow(TkWin2Acc* acc, uint64_t p, int pat) {
+    uint64_t e = tk_piece_end(*acc, p, pat);
+    if (e <= p) e = tk_next_char(*acc, p);
+    return e;
+}
+// class byte of e (flags included) and class of the char before e, for positions outside the LDS window
+__device__ __forceinline__ uint32_t tk_boundary_classes_slow(const TkWin2Acc* acc, uint64_t e) {
+    uint32_t ce = acc->cls(e);
+    uint64_t j = e - 1;
+    while (acc->cls(j) == TK_C_CONT) --j;
+    return (ce & 0xFFu) | ((acc->cls(j) & 15u) << 8);
+}
 
 __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* __restrict__ text, uint64_t n,
                                                     const uint32_t* __restrict__ brk, const uint32_t* __restrict__ ss,
@@ -367,7 +397,6 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
     __shared__ uint32_t bits[TK_TILE / 32];
     __shared__ uint16_t clist[TK2_CLIST];  // certain starts of the tile (overflow handled in place)
     __shared__ uint32_t cn;
-    __shared__ uint8_t c1[128];
     __shared__ uint32_t brkw[TK2_WIN / 32 + 1], ssw[TK2_WIN / 32 + 1], siw[TK2_WIN / 32 + 1];
     __shared__ __attribute__((aligned(16))) uint8_t st1[0x1100];
     const uint32_t tid = threadIdx.x;
@@ -381,7 +410,6 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
         if (gp >= 0 && (uint64_t)gp < n) x = *(const uint4*)(text + gp);  // text is readable 64 bytes past n
         *(uint4*)(raw + v * 16) = x;
     }
-    if (tid < 128) c1[tid] = (uint8_t)tk_class_of_cp(T, tid);
     for (uint32_t v = tid; v < 0x1100 / 16; v += 256) *(uint4*)(st1 + v * 16) = *(const uint4*)(T.uc_stage1 + v * 16);
     if (tid < TK2_WIN / 32) {  // break / special bitmaps of the window (the window base is 32-aligned)
         int64_t wgp = base + (int64_t)tid * 32;
@@ -398,14 +426,45 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
     }
     __syncthreads();
     TK_PROF(0)
-    // ---- B: classes + bitmaps, one wave per segment
-    for (int g = wid; g < TK2_NSEG; g += 4) {
-        const uint32_t pl = g * 64 + lane;
+    // ---- B: classes + bitmaps, one wave per segment, lane = byte.
+    // B1 (branch-free, all 17 segments of this wave in flight together): every lane finds the lead byte of
+    // ITS char (0..3 bytes back), decodes the code point from the LDS copy of the text and issues the
+    // stage-2 class load.  Continuation bytes therefore get their char's class without any cross-lane step.
+    constexpr int NS = TK2_NSEG / 4;  // 17 segments per wave
+    uint32_t creg[NS];
+    {
+        const uint32_t* dw = (const uint32_t*)raw;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const uint32_t pl = (uint32_t)(wid + 4 * i) * 64u + lane;
+            const uint32_t wi = pl >> 2, sft = pl & 3u;
+            const uint32_t d0 = dw[wi ? wi - 1 : 0], d1 = dw[wi], d2 = dw[wi + 1];
+            const uint32_t fwd = __builtin_amdgcn_alignbyte(d2, d1, sft);                        // bytes pl .. pl+3
+            const uint32_t back = sft == 3u ? d1 : __builtin_amdgcn_alignbyte(d1, d0, sft + 1u);  // bytes pl-3 .. pl
+            const uint32_t b = fwd & 0xFFu;
+            uint32_t k = 0;
+            if ((b & 0xC0u) == 0x80u) k = ((back >> 16) & 0xC0u) != 0x80u ? 1u : (((back >> 8) & 0xC0u) != 0x80u ? 2u : 3u);
+            const uint64_t seven = ((uint64_t)fwd << 24) | (uint64_t)(back & 0xFFFFFFu);  // bytes pl-3 .. pl+3
+            const uint32_t ch = (uint32_t)(seven >> (8u * (3u - k)));                      // the char's bytes, lead first
+            const uint32_t l = ch & 0xFFu, c1b = (ch >> 8) & 0x3Fu, c2b = (ch >> 16) & 0x3Fu, c3b = (ch >> 24) & 0x3Fu;
+            uint32_t cp = l;
+            if (l >= 0xF0u) cp = ((l & 7u) << 18) | (c1b << 12) | (c2b << 6) | c3b;
+            else if (l >= 0xE0u) cp = ((l & 15u) << 12) | (c1b << 6) | c2b;
+            else if (l >= 0xC0u) cp = ((l & 31u) << 6) | c1b;
+            if (cp > 0x10FFFFu) cp = 0xFFFFu;  // (U+FFFF is unassigned: class OTHER)
+            creg[i] = T.uc_stage2[(uint32_t)st1[cp >> 8] * 256u + (cp & 255u)];
+        }
+    }
+    // B2: flags, class bytes, bitmaps
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int g = wid + 4 * i;
+        const uint32_t pl = (uint32_t)g * 64u + lane;
         const int64_t gp = base + pl;
         const bool valid = gp >= 0 && (uint64_t)gp < n;
         const uint32_t b = raw[pl];
         bool cont = valid && (b & 0xC0u) == 0x80u;
-        uint32_t c = TK_C_OT;
+        uint32_t c = creg[i];
         bool hard = false;
         if (!valid) {
             c = TK_C_END;
@@ -414,39 +473,13 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
             const bool spec_s = (ssw[pl >> 5] >> (pl & 31u)) & 1u, spec_i = (siw[pl >> 5] >> (pl & 31u)) & 1u;
             if (spec_i) {
                 cont = true;
+                c = TK_C_SPEC;
             } else if (spec_s) {
                 cont = false;
                 c = TK_C_SPEC;
                 hard = true;
             } else if (!cont) {
-                if (b < 0x80u) {
-                    c = c1[b];
-                } else {
-                    uint32_t len = b >= 0xF0u ? 4u : (b >= 0xE0u ? 3u : 2u), cp;
-                    if ((uint64_t)gp + len > n) {
-                        c = TK_C_OT;
-                    } else {
-                        if (len == 2u) cp = ((b & 0x1Fu) << 6) | (raw[pl + 1] & 0x3Fu);
-                        else if (len == 3u) cp = ((b & 0x0Fu) << 12) | ((uint32_t)(raw[pl + 1] & 0x3Fu) << 6) | (raw[pl + 2] & 0x3Fu);
-                        else cp = ((b & 0x07u) << 18) | ((uint32_t)(raw[pl + 1] & 0x3Fu) << 12) | ((uint32_t)(raw[pl + 2] & 0x3Fu) << 6) | (raw[pl + 3] & 0x3Fu);
-                        c = cp > 0x10FFFFu ? (uint32_t)TK_C_OT : T.uc_stage2[(uint32_t)st1[cp >> 8] * 256u + (cp & 255u)];
-                    }
-                }
                 hard = (brkw[pl >> 5] >> (pl & 31u)) & 1u;
-            }
-        }
-        // continuation bytes (and special-token interiors) inherit the class of their lead byte
-        const uint64_t leadm = __ballot(!cont);
-        const uint64_t below = leadm & ((2ull << lane) - 1ull);
-        uint32_t src = below ? 63u - (uint32_t)__clzll((long long)below) : 0u;
-        uint32_t cl = __shfl(c, (int)src, 64);
-        if (cont) {
-            if (below) {
-                c = cl;
-            } else {  // the lead byte is in an earlier segment: classify it from the window / HBM
-                int64_t q = gp - 1;
-                while (q > 0 && (tk_class_byte(T, text, (uint64_t)q, n, nullptr, ss, si) & 15u) == TK_C_CONT) --q;
-                c = q >= 0 ? (tk_class_byte(T, text, (uint64_t)q, n, nullptr, ss, si) & 15u) : (uint32_t)TK_C_OT;
             }
         }
         cls2[pl] = (uint8_t)(c | (cont ? 0x40u : 0u) | (hard ? 0x80u : 0u));
@@ -494,10 +527,10 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
                 w.nu = TK_FUNNEL(TKB_NU);
                 w.nlsl = TK_FUNNEL(TKB_NLSL);
 #undef TK_FUNNEL
-                len = tk_piece_len_bits(w, acc, p, cls2[r] & 15u, pat);
+                TkBmExt ext{bm, wi, sh, (uint32_t)(TK2_WIN - r)};
+                len = tk_piece_len_bits(w, acc, ext, p, cls2[r] & 15u, pat);
             }
-            uint64_t e = len ? p + len : tk_piece_end(acc, p, pat);
-            if (e <= p) e = tk_next_char(acc, p);
+            uint64_t e = len ? p + len : tk_piece_end_slow(&acc, p, pat);
             if (e >= n) break;
             const int64_t re = (int64_t)e - base;
             uint32_t ce, pc;
@@ -505,10 +538,9 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
                 ce = cls2[re];
                 pc = cls2[re - 1] & 15u;
             } else {
-                ce = acc.cls(e);
-                uint64_t j = e - 1;
-                while (acc.cls(j) == TK_C_CONT) --j;
-                pc = acc.cls(j) & 15u;
+                uint32_t both = tk_boundary_classes_slow(&acc, e);
+                ce = both & 0xFFu;
+                pc = both >> 8;
             }
             if (ce & 0x80u) break;
             if (tk_certain_start(pat, pc, ce & 15u)) break;
