@@ -334,16 +334,14 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         TRY(ensure(c->listB, pool * 4));
         TRY(ensure(c->listC, (n / 65 + 64) * 12));
         uint32_t* counters = c->counters.as<uint32_t>();
-        TkMissTable mt{nullptr, nullptr, nullptr};
+        TkMissTable mt{nullptr, nullptr};
         if (!single_piece && P > 4096) {
             TRY(ensure(c->mt_key, (8ull << TK_MT_BITS)));
             TRY(ensure(c->mt_rep, (4ull << TK_MT_BITS)));
-            TRY(ensure(c->dup_list, (n / 2 + 64) * 4));
             TRY(ensure(c->coll_list, (n / 2 + 64) * 4));
             HIPCHK(hipMemsetAsync(c->mt_key.p, 0xFF, (8ull << TK_MT_BITS), s));
             mt.key = c->mt_key.as<unsigned long long>();
             mt.rep = c->mt_rep.as<uint32_t>();
-            mt.dup_list = c->dup_list.as<uint32_t>();
         }
         TRY(timed(c, s, "tk_k_lookup", [&] {
             hipLaunchKernelGGL(tk_k_lookup, dim3(grid_for(P, 256 * TK_PPT, 4096)), dim3(256), 0, s, T, d_text, pstart, P, ss,
@@ -405,10 +403,9 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
                                    c->staging.as<uint32_t>());
             }));
         }
-        if (hc[TK_CNT_DUP]) {
-            const uint32_t n_dup = hc[TK_CNT_DUP];
+        if (mt.key) {
             TRY(timed(c, s, "tk_k_dup_fix", [&] {
-                hipLaunchKernelGGL(tk_k_dup_fix, dim3(grid_for(n_dup, 256, 16384)), dim3(256), 0, s, d_text, pstart, mt, n_dup,
+                hipLaunchKernelGGL(tk_k_dup_fix, dim3(grid_for(P, 256, 16384)), dim3(256), 0, s, d_text, pstart, P, mt,
                                    c->tok1.as<uint32_t>(), c->cnt.as<uint32_t>(), c->coll_list.as<uint32_t>(), counters);
             }));
             // hash collisions (different bytes, same 64-bit hash) are encoded on their own; the list length lives on the device

@@ -57,7 +57,6 @@ enum { TK_CNT_B = 0, TK_CNT_C = 1, TK_CNT_CBYTES = 2, TK_CNT_CLEVELS = 3, TK_CNT
 struct TkMissTable {
     unsigned long long* key;  // [1 << TK_MT_BITS], ~0 = empty
     uint32_t* rep;            // claimant piece index
-    uint32_t* dup_list;       // pieces that found an existing claim
 };
 
 // ------------------------------------------------------------------------------------------
@@ -644,125 +643,95 @@ __global__ __launch_bounds__(256) void tk_k_emit(const uint32_t* __restrict__ st
 // ------------------------------------------------------------------------------------------
 // whole-piece probe + per-lane merge of short pieces
 // ------------------------------------------------------------------------------------------
+#define TK_DUP_FLAG 0x80000000u  // cnt[p] = TK_DUP_FLAG | miss-table slot: resolved by tk_k_dup_fix
+
+// Whole-piece probe (src/lib.rs:367).  Wave-autonomous: no workgroup barriers.  A lane handles TK_PPT
+// pieces per iteration (coalesced piece offsets); hits write their token; misses try to claim a slot
+// of the miss table -- a later identical piece finds the claim and only records the slot -- and the
+// claimants are appended to the length-binned lists with one atomic per (wave, bin).
 __global__ __launch_bounds__(256) void tk_k_lookup(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ pstart,
                                                    uint64_t P, const uint32_t* __restrict__ ss, uint32_t* __restrict__ tok1,
                                                    uint32_t* __restrict__ cnt, uint32_t* __restrict__ listM, TkBins bins,
                                                    uint32_t* __restrict__ listC, uint32_t* __restrict__ counters, TkMissTable mt, int dbg) {
-    __shared__ uint32_t qD[256 * TK_PPT];   // duplicates of an already claimed missed piece
-    __shared__ uint32_t qB[256 * TK_PPT];   // misses of 2..1024 bytes: piece index
-    __shared__ uint32_t qBs[256 * TK_PPT];  //   ... and (bin << 16) | slot within this block's share of the bin
-    __shared__ uint32_t sh_bin[TK_NBIN], sh_binbase[TK_NBIN];
-    __shared__ uint32_t qC[3 * 64];         // longer misses: {piece, bytes before it, levels before it}
-    __shared__ uint32_t sh_cnt[8];          // 1 nB, 2 nC, 3 cbytes, 4 clevels, 6.. global bases
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63;
     for (uint64_t base = (uint64_t)blockIdx.x * (256 * TK_PPT); base < P; base += (uint64_t)gridDim.x * (256 * TK_PPT)) {
-        if (tid < 8) sh_cnt[tid] = 0;
-        if (tid < TK_NBIN) sh_bin[tid] = 0;
-        __syncthreads();
+        uint32_t cat[TK_PPT];  // 0: done, 1 + bin: append to that bin, 1 + TK_NBIN: tree list
+        uint32_t plen[TK_PPT];
 #pragma unroll
         for (int k = 0; k < TK_PPT; ++k) {
-            uint64_t p = base + (uint64_t)k * 256 + tid;
-            bool missB = false, missC = false, dup = false;
-            uint32_t s = 0, len = 0;
-            if (p < P) {
-                s = pstart[p];
-                len = pstart[p + 1] - s;
-                if (ss && tk_bit(ss, s)) {
-                    tok1[p] = tk_special_id(T, text, s, len);
-                    cnt[p] = 1;
-                } else {
-                    const uint64_t key = tk_key_of_text(text, s, len);
-                    uint32_t r = tk_probe_piece(T, key, len, [&](uint32_t off) { return tk_equal_bytes(text, s, T.tok_bytes, off, len); });
-                    if (r != TK_RANK_MAX) {
-                        tok1[p] = r;
-                        cnt[p] = 1;
-                    } else if (len <= TK_GLANE_MAX) {
-                        missB = true;
-                        if (mt.key && !(dbg & 256)) {
-                            unsigned long long k = tk_mix64(key ^ ((uint64_t)len * 0xA24BAED4963EE407ull));
-                            if (dbg & 512) k &= 0xFFFull;  // test hook: force collisions between different pieces
-                            if (k == TK_EMPTY_KEY) k = 0;
-                            uint32_t i = (uint32_t)(k >> 7) & ((1u << TK_MT_BITS) - 1u);
-                            for (int t = 0; t < TK_MT_PROBES; ++t) {
-                                unsigned long long cur = mt.key[i];
-                                if (cur == TK_EMPTY_KEY) cur = atomicCAS(&mt.key[i], TK_EMPTY_KEY, k);
-                                if (cur == TK_EMPTY_KEY) {  // claimed: this piece is the one that gets merged
-                                    mt.rep[i] = (uint32_t)p;
-                                    break;
-                                }
-                                if (cur == k) {
-                                    dup = true;
-                                    missB = false;
-                                    tok1[p] = i;
-                                    break;
-                                }
-                                i = (i + 1) & ((1u << TK_MT_BITS) - 1u);
-                            }
-                        }
-                    } else {
-                        missC = true;
+            const uint64_t p = base + (uint64_t)k * 256 + tid;
+            cat[k] = 0;
+            plen[k] = 0;
+            if (p >= P) continue;
+            const uint32_t s = pstart[p], len = pstart[p + 1] - s;
+            plen[k] = len;
+            if (ss && tk_bit(ss, s)) {
+                tok1[p] = tk_special_id(T, text, s, len);
+                cnt[p] = 1;
+                continue;
+            }
+            const uint64_t key = tk_key_of_text(text, s, len);
+            uint32_t r = (dbg & 2) ? len : tk_probe_piece(T, key, len, [&](uint32_t off) { return tk_equal_bytes(text, s, T.tok_bytes, off, len); });
+            if ((dbg & 8) && r == TK_RANK_MAX) r = 0;
+            if (r != TK_RANK_MAX) {
+                tok1[p] = r;
+                cnt[p] = 1;
+                continue;
+            }
+            if (len > TK_GLANE_MAX) {
+                cat[k] = 1 + TK_NBIN;
+                continue;
+            }
+            cat[k] = 1 + (uint32_t)tk_bin_of(len);
+            if (mt.key && !(dbg & 256)) {
+                unsigned long long kk = tk_mix64(key ^ ((uint64_t)len * 0xA24BAED4963EE407ull));
+                if (dbg & 512) kk &= 0xFFFull;  // test hook: force collisions between different pieces
+                if (kk == TK_EMPTY_KEY) kk = 0;
+                uint32_t i = (uint32_t)(kk >> 7) & ((1u << TK_MT_BITS) - 1u);
+                for (int t = 0; t < TK_MT_PROBES; ++t) {
+                    unsigned long long cur = mt.key[i];
+                    if (cur == TK_EMPTY_KEY) cur = atomicCAS(&mt.key[i], TK_EMPTY_KEY, kk);
+                    if (cur == TK_EMPTY_KEY) {  // claimed: this piece is the one that gets merged
+                        mt.rep[i] = (uint32_t)p;
+                        break;
                     }
+                    if (cur == kk) {  // an identical piece (to be verified) already claimed the slot
+                        cnt[p] = TK_DUP_FLAG | i;
+                        cat[k] = 0;
+                        break;
+                    }
+                    i = (i + 1) & ((1u << TK_MT_BITS) - 1u);
                 }
             }
-            uint32_t idp = tk_wave_append(dup, &sh_cnt[0], lane);
-            if (dup) qD[idp] = (uint32_t)p;
-            uint32_t ib = tk_wave_append(missB, &sh_cnt[1], lane);
-            if (missB) {
-                int b = tk_bin_of(len);
-                qB[ib] = (uint32_t)p;
-                qBs[ib] = ((uint32_t)b << 16) | atomicAdd(&sh_bin[b], 1u);
+        }
+        // appends: rare once duplicates are filtered, so one atomic per (wave, bin) is enough
+#pragma unroll
+        for (int k = 0; k < TK_PPT; ++k) {
+            if (!__ballot(cat[k] != 0)) continue;
+            const uint64_t p = base + (uint64_t)k * 256 + tid;
+            for (uint32_t b = 0; b < TK_NBIN; ++b) {
+                const uint64_t m = __ballot(cat[k] == 1 + b);
+                if (!m) continue;
+                const int leader = __ffsll((unsigned long long)m) - 1;
+                uint32_t at = 0;
+                if (lane == leader) at = atomicAdd(&counters[TK_CNT_BIN0 + b], (uint32_t)__popcll(m));
+                at = __shfl(at, leader, 64);
+                if (cat[k] == 1 + b) listM[bins.off[b] + at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = (uint32_t)p;
             }
-            if (missC) {
+            if (cat[k] == 1 + TK_NBIN) {
                 // scratch for the tree path: 4 uint32 per byte + the 64-ary min-tree levels
-                uint32_t lv = 0, c = len;
+                uint32_t lv = 0, c = plen[k];
                 do {
                     c = (c + 63) >> 6;
                     lv += c;
                 } while (c > 64);
-                uint32_t i = atomicAdd(&sh_cnt[2], 1u);
-                if (i < 64) {
-                    qC[3 * i] = (uint32_t)p;
-                    qC[3 * i + 1] = atomicAdd(&sh_cnt[3], len);
-                    qC[3 * i + 2] = atomicAdd(&sh_cnt[4], lv);
-                } else {  // more than 64 such pieces among 1024: straight to the global list
-                    uint32_t gi = atomicAdd(&counters[TK_CNT_C], 1u);
-                    listC[3 * (uint64_t)gi] = (uint32_t)p;
-                    listC[3 * (uint64_t)gi + 1] = atomicAdd(&counters[TK_CNT_CBYTES], len);
-                    listC[3 * (uint64_t)gi + 2] = atomicAdd(&counters[TK_CNT_CLEVELS], lv);
-                }
+                const uint32_t gi = atomicAdd(&counters[TK_CNT_C], 1u);
+                listC[3 * (uint64_t)gi] = (uint32_t)p;
+                listC[3 * (uint64_t)gi + 1] = atomicAdd(&counters[TK_CNT_CBYTES], plen[k]);
+                listC[3 * (uint64_t)gi + 2] = atomicAdd(&counters[TK_CNT_CLEVELS], lv);
             }
         }
-        __syncthreads();
-        // one global reservation per list per block iteration (a single shared counter saturates at
-        // ~90 M atomics/s when every wave hits it)
-        if (tid < TK_NBIN && sh_bin[tid]) sh_binbase[tid] = bins.off[tid] + atomicAdd(&counters[TK_CNT_BIN0 + tid], sh_bin[tid]);
-        if (tid == 0) {
-            uint32_t nC = sh_cnt[2] < 64 ? sh_cnt[2] : 64;
-            if (sh_cnt[0]) sh_cnt[5] = atomicAdd(&counters[TK_CNT_DUP], sh_cnt[0]);
-            if (nC) {
-                sh_cnt[6] = atomicAdd(&counters[TK_CNT_C], nC);
-                sh_cnt[7] = atomicAdd(&counters[TK_CNT_CBYTES], sh_cnt[3]);
-                sh_cnt[3] = atomicAdd(&counters[TK_CNT_CLEVELS], sh_cnt[4]);
-            }
-        }
-        __syncthreads();
-        {
-            const uint32_t nB = sh_cnt[1], nC = sh_cnt[2] < 64 ? sh_cnt[2] : 64;
-            const uint32_t gC = sh_cnt[6], gbytes = sh_cnt[7], glv = sh_cnt[3];
-            for (uint32_t i = tid; i < nB; i += 256) {
-                uint32_t bs = qBs[i];
-                listM[sh_binbase[bs >> 16] + (bs & 0xFFFFu)] = qB[i];
-            }
-            const uint32_t nD = sh_cnt[0], gD = sh_cnt[5];
-            for (uint32_t i = tid; i < nD; i += 256) mt.dup_list[gD + i] = qD[i];
-            if (tid < nC) {
-                listC[3 * (uint64_t)(gC + tid)] = qC[3 * tid];
-                listC[3 * (uint64_t)(gC + tid) + 1] = gbytes + qC[3 * tid + 1];
-                listC[3 * (uint64_t)(gC + tid) + 2] = glv + qC[3 * tid + 2];
-            }
-        }
-        __syncthreads();
     }
 }
 
@@ -1103,19 +1072,21 @@ __global__ __launch_bounds__(256) void tk_k_scan_down(const uint32_t* __restrict
 // ------------------------------------------------------------------------------------------
 // duplicates of a claimed missed piece: verify the bytes against the claimant and copy its result
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tk_k_dup_fix(const uint8_t* __restrict__ text, const uint32_t* __restrict__ pstart,
-                                                    TkMissTable mt, uint32_t n_dup, uint32_t* __restrict__ tok1, uint32_t* __restrict__ cnt,
+__global__ __launch_bounds__(256) void tk_k_dup_fix(const uint8_t* __restrict__ text, const uint32_t* __restrict__ pstart, uint64_t P,
+                                                    TkMissTable mt, uint32_t* __restrict__ tok1, uint32_t* __restrict__ cnt,
                                                     uint32_t* __restrict__ coll_list, uint32_t* __restrict__ counters) {
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < n_dup; i += gridDim.x * 256u) {
-        const uint32_t p = mt.dup_list[i];
-        const uint32_t rep = mt.rep[tok1[p]];
+    for (uint64_t p = blockIdx.x * 256ull + threadIdx.x; p < P; p += (uint64_t)gridDim.x * 256) {
+        const uint32_t c0 = cnt[p];
+        if (!(c0 & TK_DUP_FLAG)) continue;
+        const uint32_t rep = mt.rep[c0 & ~TK_DUP_FLAG];
         const uint32_t s = pstart[p], len = pstart[p + 1] - s, rs = pstart[rep], rlen = pstart[rep + 1] - rs;
         if (len == rlen && tk_equal_bytes(text, s, text, rs, len)) {
             const uint32_t c = cnt[rep];
-            cnt[p] = c;
             tok1[p] = c == 1 ? tok1[rep] : rep;
+            cnt[p] = c;
         } else {  // different bytes behind the same 64-bit hash: encode this piece on its own
-            coll_list[atomicAdd(&counters[TK_CNT_COLL], 1u)] = p;
+            cnt[p] = 0;
+            coll_list[atomicAdd(&counters[TK_CNT_COLL], 1u)] = (uint32_t)p;
         }
     }
 }
