@@ -184,13 +184,18 @@ def main():
         nd_s = int(np.searchsorted(doc_off, sample_bytes, side="right")) - 1
         nd_s = max(nd_s, 1)
         sb = int(doc_off[nd_s])
-        C.encode_batch(blob[: min(sb, 8 << 20)], doc_off[: int(np.searchsorted(doc_off, min(sb, 8 << 20), side="right"))], None, ncpu)  # warm-up
-        t0 = time.perf_counter()
-        ctoks, coff = C.encode_batch(blob[:sb], doc_off[: nd_s + 1], None, ncpu)
-        dt_cpu = time.perf_counter() - t0
+        bufs = (np.empty(sb, np.uint32), np.empty(nd_s + 1, np.uint64))
+        C.encode_batch(blob[:sb], doc_off[: nd_s + 1], None, ncpu, out=bufs)  # warm-up: same sample, buffers pre-faulted
+        best = None
+        for _ in range(3):
+            t0 = time.perf_counter()
+            ctoks, coff = C.encode_batch(blob[:sb], doc_off[: nd_s + 1], None, ncpu, out=bufs)
+            dt = time.perf_counter() - t0
+            best = dt if best is None else min(best, dt)
+        dt_cpu = best
         cpu = {"value": round(sb / dt_cpu / 1e9, 4), "unit": "GB/s", "cores": ncpu, "kind": "port",
                "sample": f"first {nd_s} documents ({sb} bytes) of the same corpus, C restatement of CoreBPE "
-                         f"(oracle/tk_oracle.c), {ncpu} threads over documents, packed u32 output"}
+                         f"(oracle/tk_oracle.c), {ncpu} threads over documents, packed u32 output, best of 3 after a warm-up"}
         # parity: the GPU tokens of the same documents
         g_tok_off = torch.as_tensor(DevArray(do, n_docs + 1, "<i8"), device="cuda")[: nd_s + 1].cpu().numpy().astype(np.uint64)
         g_toks = torch.as_tensor(DevArray(dt, max(nt, 1), "<i4"), device="cuda")[: int(g_tok_off[-1])].cpu().numpy().view(np.uint32)

@@ -107,14 +107,20 @@ class COracle:
         assert n >= 0
         return out[:n].copy()
 
-    def encode_batch(self, blob: np.ndarray, doc_off: np.ndarray, allowed_special=None, n_threads: int = 1):
-        """blob: uint8 array of packed documents; doc_off: uint64[n_docs+1].  Returns (tokens, tok_off)."""
+    def encode_batch(self, blob: np.ndarray, doc_off: np.ndarray, allowed_special=None, n_threads: int = 1, out=None):
+        """blob: uint8 array of packed documents; doc_off: uint64[n_docs+1].  Returns (tokens, tok_off).
+        `out` = (tokens uint32[>= total bytes], tok_off uint64[n_docs+1]) reuses caller buffers (so a timed
+        call does not pay first-touch page faults)."""
         blob = np.ascontiguousarray(blob, np.uint8)
         doc_off = np.ascontiguousarray(doc_off, np.uint64)
         n_docs = len(doc_off) - 1
         total = int(doc_off[-1])
-        tokens = np.empty(max(total, 1), np.uint32)
-        tok_off = np.empty(n_docs + 1, np.uint64)
+        if out is not None:
+            tokens, tok_off = out
+            assert len(tokens) >= max(total, 1) and len(tok_off) == n_docs + 1
+        else:
+            tokens = np.empty(max(total, 1), np.uint32)
+            tok_off = np.empty(n_docs + 1, np.uint64)
         if allowed_special is None:
             mode, ids, n_ids = 0, np.zeros(1, np.uint32), 0
         else:
