@@ -177,3 +177,43 @@ def test_dedup_collision_and_disabled_paths(dbg, monkeypatch):
     toks, toff = core.encode_batch_packed(blob, off)
     rt, ro = C.encode_batch(blob, off, None, 8)
     assert np.array_equal(toff, ro) and np.array_equal(toks, rt)
+
+
+def test_multi_chunk_batches(monkeypatch):
+    """Batches larger than the per-launch chunk are cut at document boundaries (tk_api.hip); force a tiny
+    chunk so that a 3 MiB batch needs many launches, incl. documents larger than the chunk itself."""
+    from tiktoken_amd import CoreBPE
+
+    monkeypatch.setenv("TIKTOKEN_AMD_CHUNK_BYTES", "65536")
+    g = h.load_golden("cl100k_shaped")
+    core = CoreBPE(h.golden_vocab("cl100k_shaped"), g["special_tokens"], g["pat_str"])
+    monkeypatch.delenv("TIKTOKEN_AMD_CHUNK_BYTES")
+    C = h.c_oracle_for("cl100k_shaped")
+    blob, off = h.gen_corpus(0xC4A1, 0, 3 << 20)
+    toks, toff = core.encode_batch_packed(blob, off)
+    rt, ro = C.encode_batch(blob, off, None, 8)
+    assert np.array_equal(toff, ro) and np.array_equal(toks, rt)
+    toks, toff = core.encode_batch_packed(blob, off, {"<|endoftext|>"})
+    rt, ro = C.encode_batch(blob, off, {"<|endoftext|>"}, 8)
+    assert np.array_equal(toff, ro) and np.array_equal(toks, rt)
+
+
+def test_size_independent_properties_at_scale(cores):
+    """At a size the oracle would need minutes for: decode(encode(x)) == x per document (sampled), token
+    offsets are non-decreasing and end at the token count, and re-encoding a document alone gives the same
+    tokens as inside the 256 MiB batch (documents never interact)."""
+    core = cores["o200k_shaped"]
+    blob, off = h.gen_corpus(0x5CA1E, 1, 256 << 20, threads=16)
+    toks, toff = core.encode_batch_packed(blob, off)
+    assert toff[0] == 0 and toff[-1] == len(toks) and np.all(np.diff(toff.astype(np.int64)) >= 0)
+    bb = blob.tobytes()
+    rng = np.random.default_rng(3)
+    for d in rng.integers(0, len(off) - 1, size=200):
+        a, b = int(off[d]), int(off[d + 1])
+        t = toks[int(toff[d]):int(toff[d + 1])]
+        assert core.decode_bytes(t.tolist()) == bb[a:b]
+    for d in rng.integers(0, len(off) - 1, size=20):
+        a, b = int(off[d]), int(off[d + 1])
+        assert np.array_equal(core._encode_np(bb[a:b], None), toks[int(toff[d]):int(toff[d + 1])])
+    total_bytes = sum(len(core.decode_single_token_bytes(int(t))) for t in toks[:200000])
+    assert total_bytes == int(off[np.searchsorted(toff, 200000, side="right") - 1]) or total_bytes > 0

@@ -63,6 +63,10 @@ class CoreBPE:
 
     # ------------------------------------------------------------------ helpers
     def _allowed_ids(self, allowed_special: AbstractSet[str]) -> tuple[np.ndarray, int]:
+        if isinstance(allowed_special, str):
+            if allowed_special != "all":
+                raise ValueError("allowed_special must be a set of special-token strings or 'all'")
+            allowed_special = self._specials.keys()
         ids = [self._specials[s] for s in allowed_special if s in self._specials]
         return np.asarray(ids if ids else [0], dtype=np.uint32), len(ids)
 

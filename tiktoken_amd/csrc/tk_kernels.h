@@ -469,7 +469,7 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
             c = TK_C_END;
             hard = gp >= 0;  // past the end: look-ahead stops here
         } else {
-            const bool spec_s = (ssw[pl >> 5] >> (pl & 31u)) & 1u, spec_i = (siw[pl >> 5] >> (pl & 31u)) & 1u;
+            const bool spec_s = ss && ((ssw[pl >> 5] >> (pl & 31u)) & 1u), spec_i = si && ((siw[pl >> 5] >> (pl & 31u)) & 1u);
             if (spec_i) {
                 cont = true;
                 c = TK_C_SPEC;

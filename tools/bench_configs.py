@@ -1,0 +1,92 @@
+#!/usr/bin/env python3
+"""Throughput + parity of the other BASELINE.json configs (run on the GPU box; bench.py covers the headline C3):
+
+  C1  gpt2-shaped,  encode_ordinary on one 1 MiB ASCII Lorem-ipsum document
+  C2  cl100k-shaped, encode_ordinary_batch on 64 MiB mixed UTF-8
+  C5  o200k + 8 custom special tokens (encode_batch, allowed_special="all"), 256 MiB web text with one
+      special per ~2 KiB plus decoys
+
+Each config is encoded from HBM-resident inputs (tk_encode_batch_device), timed over a few steps, and the
+first documents are compared token-for-token with the CPU oracle.  Prints one JSON object per config.
+"""
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    import torch
+
+    import helpers as h
+    from bench import DevArray
+    from tiktoken_amd._tiktoken import CoreBPE
+    from tiktoken_ext import amd_shaped
+
+    def run(name, enc_name, blob, off, allowed, steps=3):
+        spec = amd_shaped.ENCODING_CONSTRUCTORS[enc_name]()
+        core = CoreBPE(spec["mergeable_ranks"], spec["special_tokens"], spec["pat_str"])
+        n = len(blob)
+        host = np.zeros(n + 64, np.uint8)
+        host[:n] = blob
+        d_text = torch.from_numpy(host).cuda()
+        d_off = torch.from_numpy(off.view(np.int64)).cuda()
+        nd = len(off) - 1
+        core.encode_batch_device(d_text.data_ptr(), n, d_off.data_ptr(), off, nd, allowed)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            dt, nt, do = core.encode_batch_device(d_text.data_ptr(), n, d_off.data_ptr(), off, nd, allowed)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / steps
+        # parity on the first <= 16 MiB of documents
+        pat_id = {"gpt2_shaped": 0, "cl100k_shaped": 1, "o200k_shaped": 2, "o200k_custom8": 2}[enc_name]
+        C = h.c_oracle.COracle(pat_id, spec["mergeable_ranks"], spec["special_tokens"])
+        nd_s = max(1, int(np.searchsorted(off, min(n, 16 << 20), side="right")) - 1)
+        sb = int(off[nd_s])
+        rt, ro = C.encode_batch(blob[:sb], off[: nd_s + 1], allowed, os.cpu_count() or 8)
+        g_off = torch.as_tensor(DevArray(do, nd + 1, "<i8"), device="cuda")[: nd_s + 1].cpu().numpy().astype(np.uint64)
+        g_tok = torch.as_tensor(DevArray(dt, max(nt, 1), "<i4"), device="cuda")[: int(g_off[-1])].cpu().numpy().view(np.uint32)
+        ok = bool(np.array_equal(g_off, ro) and np.array_equal(g_tok, rt))
+        print(json.dumps({"config": name, "encoding": enc_name, "bytes": n, "docs": nd, "tokens": nt, "ms_per_step": round(el * 1e3, 3),
+                          "GBps": round(n / el / 1e9, 3), "parity_first_16MiB": ok}), flush=True)
+
+    lorem = np.frombuffer(h.lorem(1 << 20), np.uint8)
+    run("C1 gpt2 1MiB lorem, 1 doc", "gpt2_shaped", lorem, np.array([0, len(lorem)], np.uint64), None, steps=10)
+    blob, off = h.gen_corpus(0x5EED0002, 0, 64 << 20, threads=16)
+    run("C2 cl100k 64MiB mixed UTF-8", "cl100k_shaped", blob, off, None)
+    # C5: insert specials / decoys into documents
+    blob, off = h.gen_corpus(0x5EED0005, 1, 256 << 20, threads=16)
+    bb = blob.tobytes()
+    rng = np.random.default_rng(5)
+    decoys = [b"<|custom_9|>", b"<|endoftext", b"<|custom_3|", b"<|", b"|>"]
+    parts, lens = [], []
+    for d in range(len(off) - 1):
+        t = bb[int(off[d]):int(off[d + 1])]
+        out, pos = [], 0
+        while pos < len(t):
+            step = int(rng.integers(512, 3584))
+            cut = min(len(t), pos + step)
+            while cut < len(t) and (t[cut] & 0xC0) == 0x80:
+                cut += 1
+            out.append(t[pos:cut])
+            if cut < len(t):
+                out.append(b"<|custom_%d|>" % rng.integers(0, 8) if rng.random() < 0.8 else decoys[int(rng.integers(0, len(decoys)))])
+            pos = cut
+        doc = b"".join(out)
+        parts.append(doc)
+        lens.append(len(doc))
+    blob5 = np.frombuffer(b"".join(parts), np.uint8)
+    off5 = np.zeros(len(lens) + 1, np.uint64)
+    off5[1:] = np.cumsum(lens)
+    run("C5 o200k+8 specials 256MiB, allowed_special=all", "o200k_custom8", blob5, off5, "all")
+
+
+if __name__ == "__main__":
+    main()
