@@ -281,8 +281,11 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
             }));
         } else {
             TRY(timed(c, s, "tk_k_pretok2", [&] {
-                hipLaunchKernelGGL(tk_k_pretok2, dim3((uint32_t)((n + TK_TILE - 1) / TK_TILE)), dim3(256), 0, s, T, d_text, n, brk, ss, si, starts,
-                                   (c->dbg & 128) ? c->prof.as<unsigned long long>() : nullptr);
+                const dim3 grid((uint32_t)((n + TK_TILE - 1) / TK_TILE));
+                unsigned long long* prof = (c->dbg & 128) ? c->prof.as<unsigned long long>() : nullptr;
+                if (T.pattern == TK_PAT_R50K) hipLaunchKernelGGL((tk_k_pretok2<TK_PAT_R50K>), grid, dim3(256), 0, s, T, d_text, n, brk, ss, si, starts, prof);
+                else if (T.pattern == TK_PAT_CL100K) hipLaunchKernelGGL((tk_k_pretok2<TK_PAT_CL100K>), grid, dim3(256), 0, s, T, d_text, n, brk, ss, si, starts, prof);
+                else hipLaunchKernelGGL((tk_k_pretok2<TK_PAT_O200K>), grid, dim3(256), 0, s, T, d_text, n, brk, ss, si, starts, prof);
             }));
             if (c->dbg & 128) {
                 unsigned long long h[8];

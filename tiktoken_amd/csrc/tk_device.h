@@ -59,7 +59,8 @@ TK_HD uint32_t tk_class_byte(const TkTables& T, const uint8_t* __restrict__ text
 // phase with the sequential regex.
 // ------------------------------------------------------------------------------------------
 #define TK_ALLC (TK_CB(TK_C_NL) | TK_CB(TK_C_SP) | TK_CB(TK_C_WSO) | TK_M_L | TK_M_OTHER | TK_CB(TK_C_NU))
-TK_HD bool tk_certain_start(int pat, uint32_t a, uint32_t b) {
+// mask of classes b that certainly start a piece after class a
+TK_HD uint32_t tk_certain_mask(int pat, uint32_t a) {
     uint32_t m = 0;
     const uint32_t WS3 = TK_M_WS, NU = TK_CB(TK_C_NU);
     if (pat == TK_PAT_R50K) {
@@ -93,8 +94,9 @@ TK_HD bool tk_certain_start(int pat, uint32_t a, uint32_t b) {
             default: m = 0;
         }
     }
-    return (m >> b) & 1u;
+    return m;
 }
+TK_HD bool tk_certain_start(int pat, uint32_t a, uint32_t b) { return (tk_certain_mask(pat, a) >> b) & 1u; }
 
 // ------------------------------------------------------------------------------------------
 // The scanner.  `A` is an accessor: A::cls(pos) -> class byte of position pos (TK_C_END at and

@@ -379,6 +379,7 @@ __device__ __forceinline__ uint32_t tk_boundary_classes_slow(const TkWin2Acc* ac
     return (ce & 0xFFu) | ((acc->cls(j) & 15u) << 8);
 }
 
+template <int PAT>
 __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* __restrict__ text, uint64_t n,
                                                     const uint32_t* __restrict__ brk, const uint32_t* __restrict__ ss,
                                                     const uint32_t* __restrict__ si, uint32_t* __restrict__ starts,
@@ -396,6 +397,7 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
     __shared__ uint32_t bits[TK_TILE / 32];
     __shared__ uint16_t clist[TK2_CLIST];  // certain starts of the tile (overflow handled in place)
     __shared__ uint32_t cn;
+    __shared__ uint32_t certm[16];  // certain-start masks of this pattern, by class of the previous char
     __shared__ uint32_t brkw[TK2_WIN / 32 + 1], ssw[TK2_WIN / 32 + 1], siw[TK2_WIN / 32 + 1];
     __shared__ __attribute__((aligned(16))) uint8_t st1[0x1100];
     const uint32_t tid = threadIdx.x;
@@ -418,6 +420,7 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
         siw[tid] = (in && si) ? si[wgp >> 5] : 0u;
     }
     if (tid < TK_TILE / 32) bits[tid] = 0;
+    if (tid < 16) certm[tid] = tk_certain_mask(PAT, tid);
     if (tid == 0) cn = 0;
     if (tid < TKB_KINDS) {
         bm[tid][TK2_NSEG] = tid <= TKB_HARD ? ~0ull : 0ull;  // beyond the window: unknown -> "stop"
@@ -482,29 +485,39 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
             }
         }
         cls2[pl] = (uint8_t)(c | (cont ? 0x40u : 0u) | (hard ? 0x80u : 0u));
-        const uint64_t w_start = __ballot(!cont), w_hard = __ballot(hard), w_L = __ballot((TK_M_L >> c) & 1u),
-                       w_up = __ballot((TK_M_UPPERISH >> c) & 1u), w_low = __ballot((TK_M_LOWERISH >> c) & 1u),
-                       w_cas = __ballot(c == TK_C_LC || c == TK_C_MK), w_oth = __ballot((TK_M_OTHER >> c) & 1u),
-                       w_ws = __ballot((TK_M_WS >> c) & 1u), w_nl = __ballot(c == TK_C_NL), w_nu = __ballot(c == TK_C_NU),
-                       w_nlsl = __ballot(c == TK_C_NL || c == TK_C_SL);
+        // only the bitmaps this pattern's alternatives use
+        constexpr bool O2 = PAT == TK_PAT_O200K, R5 = PAT == TK_PAT_R50K;
+        const uint64_t w_start = __ballot(!cont), w_hard = __ballot(hard);
+        const uint64_t w_oth = __ballot((TK_M_OTHER >> c) & 1u), w_ws = __ballot((TK_M_WS >> c) & 1u), w_nu = __ballot(c == TK_C_NU);
+        uint64_t w_L = 0, w_up = 0, w_low = 0, w_cas = 0, w_nl = 0, w_nlsl = 0;
+        if constexpr (!O2) w_L = __ballot((TK_M_L >> c) & 1u);
+        if constexpr (O2) {
+            w_up = __ballot((TK_M_UPPERISH >> c) & 1u);
+            w_low = __ballot((TK_M_LOWERISH >> c) & 1u);
+            w_cas = __ballot(c == TK_C_LC || c == TK_C_MK);
+            w_nlsl = __ballot(c == TK_C_NL || c == TK_C_SL);
+        }
+        if constexpr (!R5) w_nl = __ballot(c == TK_C_NL);
         if (lane == 0) {
             bm[TKB_START][g] = w_start;
             bm[TKB_HARD][g] = w_hard;
-            bm[TKB_L][g] = w_L;
-            bm[TKB_UP][g] = w_up;
-            bm[TKB_LOW][g] = w_low;
-            bm[TKB_CAS][g] = w_cas;
             bm[TKB_OTH][g] = w_oth;
             bm[TKB_WS][g] = w_ws;
-            bm[TKB_NL][g] = w_nl;
             bm[TKB_NU][g] = w_nu;
-            bm[TKB_NLSL][g] = w_nlsl;
+            if constexpr (!O2) bm[TKB_L][g] = w_L;
+            if constexpr (O2) {
+                bm[TKB_UP][g] = w_up;
+                bm[TKB_LOW][g] = w_low;
+                bm[TKB_CAS][g] = w_cas;
+                bm[TKB_NLSL][g] = w_nlsl;
+            }
+            if constexpr (!R5) bm[TKB_NL][g] = w_nl;
         }
     }
     __syncthreads();
     TK_PROF(1)
     // ---- C: certain starts of the tile -> list (a lane whose entry does not fit keeps it for itself)
-    const int pat = T.pattern;
+    constexpr int pat = PAT;
     TkWin2Acc acc{cls2, raw, base, &T, text, n, brk, ss, si};
     auto scan_from = [&](uint64_t p) {
         for (;;) {
@@ -542,7 +555,7 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
                 pc = both >> 8;
             }
             if (ce & 0x80u) break;
-            if (tk_certain_start(pat, pc, ce & 15u)) break;
+            if ((certm[pc] >> (ce & 15u)) & 1u) break;
             if (e < tile_start + TK_TILE)
                 atomicOr(&bits[(uint32_t)(e - tile_start) >> 5], 1u << ((uint32_t)(e - tile_start) & 31));
             else
@@ -555,7 +568,7 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
         const uint32_t il = tid + k * 256, pl = TK2_LEFT + il;
         const uint32_t c = cls2[pl];
         bool certain = false;
-        if (tile_start + il < n && !(c & 0x40u)) certain = (c & 0x80u) || tk_certain_start(pat, cls2[pl - 1] & 15u, c & 15u);
+        if (tile_start + il < n && !(c & 0x40u)) certain = (c & 0x80u) || ((certm[cls2[pl - 1] & 15u] >> (c & 15u)) & 1u);
         uint32_t idx = tk_wave_append(certain, &cn, lane);
         if (certain) {
             if (idx < TK2_CLIST) clist[idx] = (uint16_t)pl;

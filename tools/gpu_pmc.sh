@@ -1,0 +1,23 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/pmc2
+cd /tmp && export TMPDIR=/tmp
+rocprofv3 -L 2>/dev/null | grep -oE "\b(SQ_[A-Z_0-9]+|GRBM_[A-Z_]+|TCP_[A-Z_0-9]+|TCC_[A-Z_0-9]+)\b" | sort -u > $R/gpurun_out/pmc2/counters.txt
+wc -l $R/gpurun_out/pmc2/counters.txt
+for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
+  T=$(echo $SET | cut -d' ' -f1)
+  rocprofv3 --pmc $SET --output-format csv -d $R/gpurun_out/pmc2/$T -o p -- python $R/bench.py --gpus 1 --steps 1 --warmup 0 --mib 1024 --no-cpu-baseline > $R/gpurun_out/pmc2/$T.log 2>&1
+done
+cd $R; python - <<'PY'
+import csv, glob, collections
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob("gpurun_out/pmc2/*/p_counter_collection.csv"):
+    for r in csv.DictReader(open(f)):
+        k = r["Kernel_Name"].split("(")[0]
+        if k.startswith("tk_k_pretok2") or k.startswith("tk_k_lookup") or k.startswith("tk_k_dup_fix") or k.startswith("tk_k_gather"):
+            agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
+for k, d in agg.items():
+    print(k)
+    for c, v in sorted(d.items()):
+        print("   %-24s %16.0f" % (c, max(v)))
+PY
+find gpurun_out/pmc2 -name '*.csv' -size +5M -delete
