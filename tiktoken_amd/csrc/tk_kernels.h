@@ -419,7 +419,6 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
         ssw[tid] = (in && ss) ? ss[wgp >> 5] : 0u;
         siw[tid] = (in && si) ? si[wgp >> 5] : 0u;
     }
-    if (tid < TK_TILE / 32) bits[tid] = 0;
     if (tid < 16) certm[tid] = tk_certain_mask(PAT, tid);
     if (tid == 0) cn = 0;
     if (tid < TKB_KINDS) {
@@ -438,7 +437,7 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
         const uint32_t* dw = (const uint32_t*)raw;
 #pragma unroll
         for (int i = 0; i < NS; ++i) {
-            const uint32_t pl = (uint32_t)(wid + 4 * i) * 64u + lane;
+            const uint32_t pl = (uint32_t)(wid * NS + i) * 64u + lane;
             const uint32_t wi = pl >> 2, sft = pl & 3u;
             const uint32_t d0 = dw[wi ? wi - 1 : 0], d1 = dw[wi], d2 = dw[wi + 1];
             const uint32_t fwd = __builtin_amdgcn_alignbyte(d2, d1, sft);                        // bytes pl .. pl+3
@@ -457,10 +456,36 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
             creg[i] = T.uc_stage2[(uint32_t)st1[cp >> 8] * 256u + (cp & 255u)];
         }
     }
-    // B2: flags, class bytes, bitmaps
+    // B2: flags, class bytes, bitmaps -- and, since a wave walks its 17 segments left to right, the certain
+    // piece starts of the tile (class of the previous byte = lane - 1, carried across segments in a register)
+    uint32_t carry = TK_C_END;
+    if (wid > 0) {  // class of the byte just before this wave's first segment (same decode as B1, wave-uniform)
+        const uint32_t* dw = (const uint32_t*)raw;
+        const uint32_t pl = (uint32_t)(wid * NS) * 64u - 1u;
+        const uint32_t wi = pl >> 2, sft = pl & 3u;
+        const uint32_t d0 = dw[wi - 1], d1 = dw[wi], d2 = dw[wi + 1];
+        const uint32_t fwd = __builtin_amdgcn_alignbyte(d2, d1, sft);
+        const uint32_t back = sft == 3u ? d1 : __builtin_amdgcn_alignbyte(d1, d0, sft + 1u);
+        const uint32_t b = fwd & 0xFFu;
+        uint32_t k = 0;
+        if ((b & 0xC0u) == 0x80u) k = ((back >> 16) & 0xC0u) != 0x80u ? 1u : (((back >> 8) & 0xC0u) != 0x80u ? 2u : 3u);
+        const uint64_t seven = ((uint64_t)fwd << 24) | (uint64_t)(back & 0xFFFFFFu);
+        const uint32_t ch = (uint32_t)(seven >> (8u * (3u - k)));
+        const uint32_t l = ch & 0xFFu, c1b = (ch >> 8) & 0x3Fu, c2b = (ch >> 16) & 0x3Fu, c3b = (ch >> 24) & 0x3Fu;
+        uint32_t cp = l;
+        if (l >= 0xF0u) cp = ((l & 7u) << 18) | (c1b << 12) | (c2b << 6) | c3b;
+        else if (l >= 0xE0u) cp = ((l & 15u) << 12) | (c1b << 6) | c2b;
+        else if (l >= 0xC0u) cp = ((l & 31u) << 6) | c1b;
+        if (cp > 0x10FFFFu) cp = 0xFFFFu;
+        carry = T.uc_stage2[(uint32_t)st1[cp >> 8] * 256u + (cp & 255u)];
+        const int64_t gpp = base + pl;
+        if (gpp < 0 || (uint64_t)gpp >= n) carry = TK_C_END;
+        else if ((ss && ((ssw[pl >> 5] >> (pl & 31u)) & 1u)) || (si && ((siw[pl >> 5] >> (pl & 31u)) & 1u))) carry = TK_C_SPEC;
+    }
+    uint32_t spill_mask = 0;  // bit i: this lane's certain start of segment i did not fit the list
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
-        const int g = wid + 4 * i;
+        const int g = wid * NS + i;
         const uint32_t pl = (uint32_t)g * 64u + lane;
         const int64_t gp = base + pl;
         const bool valid = gp >= 0 && (uint64_t)gp < n;
@@ -485,6 +510,28 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
             }
         }
         cls2[pl] = (uint8_t)(c | (cont ? 0x40u : 0u) | (hard ? 0x80u : 0u));
+        {
+            uint32_t prevc = __shfl_up(c, 1, 64);
+            if (lane == 0) prevc = carry;
+            carry = __shfl(c, 63, 64);
+            const bool cert = valid && !cont && g >= 1 && g <= TK_TILE / 64 && (hard || ((certm[prevc] >> c) & 1u));
+            const uint64_t certw = __ballot(cert);
+            if (g >= 1 && g <= TK_TILE / 64) {
+                if (lane == 0) {
+                    bits[(g - 1) * 2] = (uint32_t)certw;
+                    bits[(g - 1) * 2 + 1] = (uint32_t)(certw >> 32);
+                }
+                if (certw) {
+                    uint32_t at = 0;
+                    if (lane == 0) at = atomicAdd(&cn, (uint32_t)__popcll(certw));
+                    at = __shfl(at, 0, 64) + (uint32_t)__popcll(certw & ((1ull << lane) - 1ull));
+                    if (cert) {
+                        if (at < TK2_CLIST) clist[at] = (uint16_t)pl;
+                        else spill_mask |= 1u << i;
+                    }
+                }
+            }
+        }
         // only the bitmaps this pattern's alternatives use
         constexpr bool O2 = PAT == TK_PAT_O200K, R5 = PAT == TK_PAT_R50K;
         const uint64_t w_start = __ballot(!cont), w_hard = __ballot(hard);
@@ -516,7 +563,6 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
     }
     __syncthreads();
     TK_PROF(1)
-    // ---- C: certain starts of the tile -> list (a lane whose entry does not fit keeps it for itself)
     constexpr int pat = PAT;
     TkWin2Acc acc{cls2, raw, base, &T, text, n, brk, ss, si};
     auto scan_from = [&](uint64_t p) {
@@ -563,28 +609,13 @@ __global__ __launch_bounds__(256) void tk_k_pretok2(TkTables T, const uint8_t* _
             p = e;
         }
     };
-    uint32_t spill_mask = 0;  // bit k: this thread's k-th position is a certain start that did not fit the list
-    for (int k = 0; k < TK_TILE / 256; ++k) {
-        const uint32_t il = tid + k * 256, pl = TK2_LEFT + il;
-        const uint32_t c = cls2[pl];
-        bool certain = false;
-        if (tile_start + il < n && !(c & 0x40u)) certain = (c & 0x80u) || ((certm[cls2[pl - 1] & 15u] >> (c & 15u)) & 1u);
-        uint32_t idx = tk_wave_append(certain, &cn, lane);
-        if (certain) {
-            if (idx < TK2_CLIST) clist[idx] = (uint16_t)pl;
-            else spill_mask |= 1u << k;
-            atomicOr(&bits[il >> 5], 1u << (il & 31));
-        }
-    }
-    __syncthreads();
-    TK_PROF(2)
     // ---- D: one lane per certain start
     const uint32_t ncert = cn < TK2_CLIST ? cn : TK2_CLIST;
     for (uint32_t i = tid; i < ncert; i += 256) scan_from((uint64_t)(base + clist[i]));
     while (spill_mask) {
-        int k = __ffs((int)spill_mask) - 1;
+        int i = __ffs((int)spill_mask) - 1;
         spill_mask &= spill_mask - 1;
-        scan_from(tile_start + tid + (uint32_t)k * 256u);
+        scan_from((uint64_t)(base + (int64_t)((uint32_t)(wid * NS + i) * 64u + lane)));
     }
     __syncthreads();
     TK_PROF(3)
