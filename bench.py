@@ -190,8 +190,8 @@ def main():
         for _ in range(3):
             t0 = time.perf_counter()
             ctoks, coff = C.encode_batch(blob[:sb], doc_off[: nd_s + 1], None, ncpu, out=bufs)
-            dt = time.perf_counter() - t0
-            best = dt if best is None else min(best, dt)
+            el_c = time.perf_counter() - t0
+            best = el_c if best is None else min(best, el_c)
         dt_cpu = best
         cpu = {"value": round(sb / dt_cpu / 1e9, 4), "unit": "GB/s", "cores": ncpu, "kind": "port",
                "sample": f"first {nd_s} documents ({sb} bytes) of the same corpus, C restatement of CoreBPE "

@@ -25,7 +25,15 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 def per_kernel(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
-        agg[r["Kernel_Name"].split("(")[0]].append(float(r["Counter_Value"]))
+        name = r["Kernel_Name"].split("(")[0]
+        if name.startswith("void "):
+            name = name[5:]
+        # template instances keep their argument as a suffix: tk_k_merge_group<16> -> tk_k_merge_group_16,
+        # except the pattern-specialised pre-tokeniser, which bench.py reports under one name
+        if name.startswith("tk_k_pretok2<"):
+            name = "tk_k_pretok2"
+        name = name.replace("<", "_").replace(">", "").replace(", ", "x")
+        agg[name].append(float(r["Counter_Value"]))
     return agg
 
 
