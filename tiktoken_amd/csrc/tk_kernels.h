@@ -1,18 +1,21 @@
 // HIP kernels of the MI355X BPE encode path (gfx950, wave64).  Included by tk_api.hip only.
 //
-// Pipeline (one launch sequence per <= 4 GiB chunk of packed documents, all intermediates in HBM):
+// Pipeline (one launch sequence per chunk of packed documents, all intermediates in HBM):
 //
 //   tk_k_mark_docs      document starts -> break bitmap                      (core.py:174-176: documents
 //                                                                              never interact)
 //   tk_k_spec_*         (encode() path only) special-token occurrences -> start / interior / break
 //                       bitmaps                                               (src/lib.rs:386-402)
-//   tk_k_pretok         regex pre-tokenisation -> piece-start bitmap          (src/lib.rs:365)
+//   tk_k_pretok2<PAT>   regex pre-tokenisation -> piece-start bitmap          (src/lib.rs:365); bit-parallel
+//                       (tk_k_pretok is the byte-walking original, kept behind TIKTOKEN_AMD_DEBUG=32)
 //   tk_k_count/_scan/_emit   bitmap -> packed piece offsets
-//   tk_k_lookup         whole-piece probe + per-lane byte_pair_merge of short pieces
-//                                                                              (src/lib.rs:367-369, 140-196)
-//   tk_k_merge_wave     one wavefront per 17..64-byte piece, min-rank by wave reduction
+//   tk_k_lookup         whole-piece probe; misses are de-duplicated through a miss table and the
+//                       distinct ones appended to length-binned lists         (src/lib.rs:367-369)
+//   tk_k_merge_llane<N> one LANE per 2..64-byte piece: byte_pair_merge in LDS  (src/lib.rs:140-196)
+//   tk_k_merge_group<G> G lanes per 65..1024-byte piece
 //   tk_k_merge_long     one wavefront per longer piece, 64-ary min tree in HBM scratch
 //                                                                              (same result as lib.rs:47-138)
+//   tk_k_dup_fix        duplicates: byte-verify against the claimant, copy its result
 //   tk_k_scan_*         token counts -> token offsets
 //   tk_k_gather         tokens into their final packed order; tk_k_docoff per-document offsets
 #pragma once
