@@ -138,6 +138,8 @@ def sim_lib():
         L.tks_pretok.argtypes = [vp, vp, u64, vp, u64, vp]
         L.tks_pretok_bits.restype = u64
         L.tks_pretok_bits.argtypes = [vp, vp, u64, vp, u64, vp]
+        L.tks_pretok_tiles.restype = u64
+        L.tks_pretok_tiles.argtypes = [vp, vp, u64, vp, u64, vp, ctypes.c_uint32, ctypes.c_uint32]
         L.tks_encode_piece.restype = ctypes.c_int64
         L.tks_encode_piece.argtypes = [vp, vp, ctypes.c_uint32, vp]
         _sim_lib = L
@@ -168,6 +170,15 @@ class HostSim:
         nc = fn(self._h, b.ctypes.data, n, doc_off.ctypes.data, len(doc_off) - 1, starts.ctypes.data)
         idx = np.flatnonzero(starts[:n])
         return np.concatenate([idx[1:], [n]]).astype(np.uint64) if n else np.zeros(0, np.uint64), nc
+
+    def piece_ends_tiled(self, blob: np.ndarray, doc_off: np.ndarray, tile: int = 4096, left: int = 64):
+        """Piece ends from the per-tile rule of tk_k_front (second value: tiles that had to walk back)."""
+        n = len(blob)
+        starts = np.zeros(max(n, 1), np.uint8)
+        b = np.ascontiguousarray(blob) if n else np.zeros(1, np.uint8)
+        nw = sim_lib().tks_pretok_tiles(self._h, b.ctypes.data, n, doc_off.ctypes.data, len(doc_off) - 1, starts.ctypes.data, tile, left)
+        idx = np.flatnonzero(starts[:n])
+        return (np.concatenate([idx[1:], [n]]).astype(np.uint64) if n else np.zeros(0, np.uint64)), nw
 
     def encode_piece(self, piece: bytes) -> list[int]:
         out = np.empty(max(len(piece), 1), np.uint32)

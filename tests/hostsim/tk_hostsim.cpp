@@ -242,6 +242,86 @@ uint64_t tks_pretok_bits(void* pv, const uint8_t* text_in, uint64_t n, const uin
     return n_fallback;
 }
 
+// Mirror of the tile rule of tk_k_front: every tile derives the piece starts INSIDE ITS OWN byte range and
+// nothing else.  Scanners start at the certain starts of the tile plus the last certain start at or
+// before the tile (found in the 64-byte left context, else by walking back); a scanner only records
+// boundaries that fall inside the tile and stops at the tile end.  No state crosses tiles.
+uint64_t tks_pretok_tiles(void* pv, const uint8_t* text_in, uint64_t n, const uint64_t* doc_off, uint64_t n_docs, uint8_t* starts,
+                          uint32_t tile, uint32_t left) {
+    Sim* s = (Sim*)pv;
+    std::vector<uint8_t> text(text_in, text_in + n);
+    text.resize(n + 64, 0);
+    std::vector<uint32_t> brk((n + 31) / 32 + 2, 0);
+    for (uint64_t d = 0; d < n_docs; ++d)
+        if (doc_off[d] < n) brk[doc_off[d] >> 5] |= 1u << (doc_off[d] & 31);
+    std::vector<uint8_t> cls2(n + 80, TK_C_END | 0x80);
+    uint8_t last = TK_C_OT;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t c = tk_class_byte(s->T, text.data(), i, n, brk.data(), nullptr, nullptr);
+        if ((c & 15u) == TK_C_CONT) cls2[i] = (uint8_t)(last | 0x40);
+        else {
+            cls2[i] = (uint8_t)c;
+            last = (uint8_t)(c & 15u);
+        }
+    }
+    memset(starts, 0, n);
+    PropAcc acc{cls2.data(), text.data(), n};
+    const int pat = s->T.pattern;
+    auto certain_at = [&](uint64_t i) -> bool {
+        uint32_t c = cls2[i];
+        if (c & 0x40u) return false;
+        if (c & 0x80u) return true;
+        if (i == 0) return false;
+        return tk_certain_start(pat, cls2[i - 1] & 15u, c & 15u);
+    };
+    uint64_t n_walkback = 0;
+    for (uint64_t t0 = 0; t0 < n; t0 += tile) {
+        const uint64_t t1 = t0 + tile < n ? t0 + tile : n;
+        auto scan_from = [&](uint64_t q) {
+            for (;;) {
+                uint64_t e = tk_piece_end(acc, q, pat);
+                if (e <= q) e = tk_next_char(acc, q);
+                if (e >= t1) break;                // the next piece start belongs to a later tile
+                uint32_t ce = cls2[e];
+                if (e >= t0) {
+                    if (ce & 0x80u) break;
+                    if (tk_certain_start(pat, cls2[e - 1] & 15u, ce & 15u)) break;  // a scanner of this tile starts there
+                    starts[e] = 1;
+                } else if (certain_at(e)) {
+                    break;                            // cannot happen: q was the LAST certain start before the tile
+                }
+                q = e;
+            }
+        };
+        // first char start of the tile
+        uint64_t f = t0;
+        while (f < t1 && (cls2[f] & 0x40u)) ++f;
+        if (f < t1 && !certain_at(f)) {
+            // last certain start before the tile: the left context first, then walk back
+            uint64_t lo = t0 >= left ? t0 - left + 1 : 0;  // (the first context byte has no known predecessor)
+            int64_t found = -1;
+            for (int64_t j = (int64_t)t0 - 1; j >= (int64_t)lo; --j)
+                if (certain_at((uint64_t)j)) {
+                    found = j;
+                    break;
+                }
+            if (found < 0) {
+                ++n_walkback;
+                int64_t j = (int64_t)lo - 1;
+                while (j > 0 && !certain_at((uint64_t)j)) --j;
+                found = j < 0 ? 0 : j;
+            }
+            scan_from((uint64_t)found);
+        }
+        for (uint64_t i = t0; i < t1; ++i)
+            if (certain_at(i)) {
+                starts[i] = 1;
+                scan_from(i);
+            }
+    }
+    return n_walkback;
+}
+
 // Mirror of the per-piece work of tk_k_lookup for pieces of <= 16 bytes; longer pieces use the
 // same probes with a simple sequential merge over ids (the wave / tree kernels cannot run here).
 int64_t tks_encode_piece(void* p, const uint8_t* piece, uint32_t len, uint32_t* out) {

@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/tiktoken_amd.h"
+#include "tk_fused.h"
 #include "tk_kernels.h"
 #include "tk_tables.h"
 #include "tk_unicode_tables.inc"
@@ -67,7 +68,8 @@ struct tk_core {
     std::mutex mu;
     // workspace
     Buf text, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, tok1, cnt, tokbase, staging, listB, listC,
-        counters, total, partial, rkb, prof, mt_key, mt_rep, dup_list, coll_list, g_id, g_rk, g_nx, g_pv, g_lv, out_tokens, out_tok_off, allowed;
+        counters, total, partial, rkb, prof, mt_key, mt_rep, dup_list, coll_list, g_id, g_rk, g_nx, g_pv, g_lv, out_tokens, out_tok_off, allowed,
+        tile_np, tile_nt, doc_pid, mt_aux, mt_res_cnt, mt_res_tok;
     uint64_t chunk_bytes = 1ull << 30;
     int dbg = 0;
     // instrumentation
@@ -206,7 +208,8 @@ extern "C" void tk_destroy(tk_core* c) {
                    &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off, &c->brk, &c->docb,
                    &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->tok1, &c->cnt, &c->tokbase, &c->staging,
                    &c->listB, &c->listC, &c->counters, &c->total, &c->partial, &c->rkb, &c->prof, &c->mt_key, &c->mt_rep, &c->dup_list, &c->coll_list, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv,
-                   &c->out_tokens, &c->out_tok_off, &c->allowed})
+                   &c->out_tokens, &c->out_tok_off, &c->allowed, &c->tile_np, &c->tile_nt, &c->doc_pid, &c->mt_aux, &c->mt_res_cnt,
+                   &c->mt_res_tok})
         release(*b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (int i = 0; i < 4; ++i) {
@@ -228,7 +231,7 @@ static uint32_t grid_for(uint64_t items, uint32_t per_block, uint32_t cap) {
 //   d_text: chunk text (readable 64 bytes past n); d_doc_off: uint64 offsets of the chunk's
 //   documents (n_docs+1 entries, absolute; `base` is subtracted); single_piece: the whole buffer
 //   is one piece (encode_single_piece), no pre-tokenisation.
-static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t n, const uint64_t* d_doc_off, uint64_t n_docs,
+static int run_chunk_unfused(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t n, const uint64_t* d_doc_off, uint64_t n_docs,
                      uint64_t base, bool use_special, bool single_piece, uint32_t* d_out, uint64_t tok_base_global,
                      uint64_t* d_tok_off, uint64_t* n_tokens_out, bool pretok_only = false) {
     const TkTables& T = c->D;
@@ -453,6 +456,202 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
     }
     c->st_bytes += n;
     c->st_pieces += P;
+    c->st_tokens += T_total;
+    c->st_medium += nB;
+    c->st_long += nC;
+    *n_tokens_out = T_total;
+    return TK_OK;
+}
+
+// The production pipeline (kernels of tk_fused.h).  One host synchronisation in the middle (the sizes of the
+// deferred-piece lists decide the merge launches) and none after it: the token total is read by the caller's
+// final synchronisation.
+static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t n, const uint64_t* d_doc_off, uint64_t n_docs,
+                     uint64_t base, bool use_special, bool single_piece, uint32_t* d_out, uint64_t tok_base_global,
+                     uint64_t* d_tok_off, uint64_t* n_tokens_out, bool pretok_only = false) {
+    if (c->dbg & 1024) return run_chunk_unfused(c, s, d_text, n, d_doc_off, n_docs, base, use_special, single_piece, d_out, tok_base_global, d_tok_off, n_tokens_out, pretok_only);
+    const TkTables& T = c->D;
+    const uint64_t nwords = (n + 31) / 32;
+    const uint64_t nblk = (nwords + 255) / 256;
+    const uint64_t ntiles = (n && !single_piece) ? (n + TK_TILE - 1) / TK_TILE : 1;  // (single piece: one run of one piece)
+    TRY(ensure(c->brk, (nwords + 2) * 4));
+    TRY(ensure(c->starts, (nwords + 2) * 4));
+    TRY(ensure(c->blockcnt, (nblk + 2) * 4));
+    TRY(ensure(c->counters, TK_CNT_N * 4));
+    TRY(ensure(c->total, 16));
+    TRY(ensure(c->tile_np, (ntiles + 2) * 4));
+    TRY(ensure(c->tile_nt, (ntiles + 2) * 4));
+    TRY(ensure(c->doc_pid, (n_docs + 2) * 4));
+    TRY(ensure(c->tok1, ntiles * TKF_CAP * 4));
+    TRY(ensure(c->cnt, ntiles * TKF_CAP * 4));
+    TRY(ensure(c->staging, (n + 64) * 4));
+    TkBins bins;
+    uint64_t pool = 0;
+    for (int b = 0; b < TK_NBIN; ++b) {
+        bins.off[b] = (uint32_t)pool;
+        pool += n / tk_bin_lo(b) + 64;
+    }
+    TRY(ensure(c->listB, pool * 12));
+    TRY(ensure(c->listC, (n / 1025 + 64) * 20));
+    HIPCHK(hipMemsetAsync(c->brk.p, 0, (nwords + 2) * 4, s));
+    HIPCHK(hipMemsetAsync(c->counters.p, 0, TK_CNT_N * 4, s));
+    HIPCHK(hipMemsetAsync(c->total.p, 0, 16, s));
+    HIPCHK(hipMemsetAsync(c->doc_pid.p, 0xFF, (n_docs + 2) * 4, s));
+    uint32_t *brk = c->brk.as<uint32_t>(), *starts = c->starts.as<uint32_t>();
+    uint32_t *ss = nullptr, *si = nullptr, *docb = nullptr;
+    uint32_t* counters = c->counters.as<uint32_t>();
+    uint32_t *tok1 = c->tok1.as<uint32_t>(), *cnt = c->cnt.as<uint32_t>(), *stg = c->staging.as<uint32_t>();
+    TkFrontOut fo{starts, c->tile_np.as<uint32_t>(), tok1, cnt, c->listB.as<uint32_t>(), c->listC.as<uint32_t>(), counters, c->doc_pid.as<uint32_t>()};
+    TkMissTableF mt{nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint64_t nB = 0, nC = 0;
+    if (n > 0 && !single_piece) {
+        if (use_special) {
+            TRY(ensure(c->docb, (nwords + 2) * 4));
+            TRY(ensure(c->cand, (nwords + 2) * 4));
+            TRY(ensure(c->ss, (nwords + 2) * 4));
+            TRY(ensure(c->si, (nwords + 2) * 4));
+            for (Buf* b : {&c->docb, &c->cand, &c->ss, &c->si}) HIPCHK(hipMemsetAsync(b->p, 0, (nwords + 2) * 4, s));
+            docb = c->docb.as<uint32_t>();
+            ss = c->ss.as<uint32_t>();
+            si = c->si.as<uint32_t>();
+        }
+        TRY(timed(c, s, "tk_k_mark_docs", [&] {
+            hipLaunchKernelGGL(tk_k_mark_docs, dim3(grid_for(n_docs, 256, 4096)), dim3(256), 0, s, d_doc_off, n_docs, base, n, brk, docb);
+        }));
+        if (use_special) {
+            const uint8_t* allowed = c->allowed.as<uint8_t>();
+            uint32_t* cand = c->cand.as<uint32_t>();
+            TRY(timed(c, s, "tk_k_spec_cand", [&] {
+                hipLaunchKernelGGL(tk_k_spec_cand, dim3(grid_for(n, 256, 16384)), dim3(256), 0, s, T, d_text, n, allowed, docb, cand);
+            }));
+            TRY(timed(c, s, "tk_k_spec_resolve", [&] {
+                hipLaunchKernelGGL(tk_k_spec_resolve, dim3(grid_for(n, 256, 16384)), dim3(256), 0, s, T, d_text, n, allowed, docb, cand,
+                                   c->spec_max_len, ss, si, brk);
+            }));
+        }
+        if (n > 32768 && !pretok_only) {  // in-call de-duplication of missed pieces pays for its table resets only on real batches
+            TRY(ensure(c->mt_key, (8ull << TK_MT_BITS)));
+            TRY(ensure(c->mt_aux, (8ull << TK_MT_BITS)));
+            TRY(ensure(c->mt_rep, (4ull << TK_MT_BITS)));
+            TRY(ensure(c->mt_res_cnt, (4ull << TK_MT_BITS)));
+            TRY(ensure(c->mt_res_tok, (4ull << TK_MT_BITS)));
+            HIPCHK(hipMemsetAsync(c->mt_key.p, 0xFF, (8ull << TK_MT_BITS), s));
+            HIPCHK(hipMemsetAsync(c->mt_aux.p, 0xFF, (8ull << TK_MT_BITS), s));
+            mt = TkMissTableF{c->mt_key.as<unsigned long long>(), c->mt_aux.as<unsigned long long>(), c->mt_rep.as<uint32_t>(),
+                              c->mt_res_cnt.as<uint32_t>(), c->mt_res_tok.as<uint32_t>()};
+        }
+        TRY(timed(c, s, "tk_k_front", [&] {
+            const dim3 grid((uint32_t)ntiles);
+            if (T.pattern == TK_PAT_R50K) hipLaunchKernelGGL((tk_k_front<TK_PAT_R50K>), grid, dim3(256), 0, s, T, d_text, n, base, brk, docb, ss, si, d_doc_off, n_docs, fo, bins, mt, c->dbg);
+            else if (T.pattern == TK_PAT_CL100K) hipLaunchKernelGGL((tk_k_front<TK_PAT_CL100K>), grid, dim3(256), 0, s, T, d_text, n, base, brk, docb, ss, si, d_doc_off, n_docs, fo, bins, mt, c->dbg);
+            else hipLaunchKernelGGL((tk_k_front<TK_PAT_O200K>), grid, dim3(256), 0, s, T, d_text, n, base, brk, docb, ss, si, d_doc_off, n_docs, fo, bins, mt, c->dbg);
+        }));
+    } else if (n > 0) {
+        TRY(timed(c, s, "tk_k_single_front", [&] { hipLaunchKernelGGL(tk_k_single_front, dim3(1), dim3(64), 0, s, T, d_text, (uint32_t)n, fo, bins); }));
+    }
+    if (pretok_only) {  // debugging / test entry: piece offsets only
+        uint64_t P = 0;
+        TRY(ensure(c->pstart, 16));
+        if (n > 0) {
+            TRY(timed(c, s, "tk_k_count", [&] {
+                hipLaunchKernelGGL(tk_k_count, dim3((uint32_t)nblk), dim3(256), 0, s, starts, nwords, c->blockcnt.as<uint32_t>());
+            }));
+            TRY(timed(c, s, "tk_k_scan_small", [&] {
+                hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, c->blockcnt.as<uint32_t>(), nblk, c->total.as<uint64_t>());
+            }));
+            HIPCHK(hipMemcpyAsync(&P, c->total.p, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipStreamSynchronize(s));
+            TRY(ensure(c->pstart, (P + 2) * 4));
+            TRY(timed(c, s, "tk_k_emit", [&] {
+                hipLaunchKernelGGL(tk_k_emit, dim3((uint32_t)nblk), dim3(256), 0, s, starts, nwords, c->blockcnt.as<uint32_t>(),
+                                   c->pstart.as<uint32_t>(), P, n);
+            }));
+        } else {
+            HIPCHK(hipMemsetAsync(c->pstart.p, 0, 4, s));
+        }
+        *n_tokens_out = P;
+        return TK_OK;
+    }
+    if (n > 0) {
+        uint32_t hc[TK_CNT_N];
+        HIPCHK(hipMemcpyAsync(hc, counters, sizeof hc, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        nC = hc[TK_CNT_C];
+        for (int b = 0; b < TK_NBIN; ++b) nB += hc[TK_CNT_BIN0 + b];
+        if (nB) {
+            static const char* const names[TK_NBIN] = {"tk_k_merge_llane_16", "tk_k_merge_llane_24", "tk_k_merge_llane_32", "tk_k_merge_llane_48", "tk_k_merge_llane_64",
+                                                       "tk_k_merge_group_8", "tk_k_merge_group_16", "tk_k_merge_group_32", "tk_k_merge_group_64"};
+            // the bins are independent: spread them over the side streams, longest-tailed kernels first
+            HIPCHK(hipEventRecord(c->ev_fork, s));
+            for (int i = 0; i < 4; ++i) HIPCHK(hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
+            static const int order[TK_NBIN] = {8, 7, 6, 5, 0, 1, 4, 3, 2};
+            int slot = 0;
+            for (int oi = 0; oi < TK_NBIN; ++oi) {
+                const int b = order[oi];
+                const uint32_t cntb = hc[TK_CNT_BIN0 + b];
+                if (!cntb) continue;
+                if (c->dbg & 64) fprintf(stderr, "bin %d (%u..%u bytes): %u pieces\n", b, tk_bin_lo(b), tk_bin_hi(b), cntb);
+                const uint32_t* lst = c->listB.as<uint32_t>() + 3 * (uint64_t)bins.off[b];
+                hipStream_t sa = c->aux[slot++ & 3];
+                TRY(timed(c, sa, names[b], [&] {
+                    switch (b) {
+                        case 0: hipLaunchKernelGGL((tk_k_mergeF_llane<16, 256>), dim3(grid_for(cntb, 256, 32768)), dim3(256), 0, sa, T, d_text, lst, cntb, tok1, cnt, stg); break;
+                        case 1: hipLaunchKernelGGL((tk_k_mergeF_llane<24, 256>), dim3(grid_for(cntb, 256, 16384)), dim3(256), 0, sa, T, d_text, lst, cntb, tok1, cnt, stg); break;
+                        case 2: hipLaunchKernelGGL((tk_k_mergeF_llane<32, 256>), dim3(grid_for(cntb, 256, 16384)), dim3(256), 0, sa, T, d_text, lst, cntb, tok1, cnt, stg); break;
+                        case 3: hipLaunchKernelGGL((tk_k_mergeF_llane<48, 128>), dim3(grid_for(cntb, 128, 16384)), dim3(128), 0, sa, T, d_text, lst, cntb, tok1, cnt, stg); break;
+                        case 4: hipLaunchKernelGGL((tk_k_mergeF_llane<64, 128>), dim3(grid_for(cntb, 128, 16384)), dim3(128), 0, sa, T, d_text, lst, cntb, tok1, cnt, stg); break;
+                        case 5: hipLaunchKernelGGL((tk_k_mergeF_group<8>), dim3(grid_for(cntb, 32, 16384)), dim3(256), 0, sa, T, d_text, lst, cntb, tok1, cnt, stg); break;
+                        case 6: hipLaunchKernelGGL((tk_k_mergeF_group<16>), dim3(grid_for(cntb, 16, 16384)), dim3(256), 0, sa, T, d_text, lst, cntb, tok1, cnt, stg); break;
+                        case 7: hipLaunchKernelGGL((tk_k_mergeF_group<32>), dim3(grid_for(cntb, 8, 16384)), dim3(256), 0, sa, T, d_text, lst, cntb, tok1, cnt, stg); break;
+                        default: hipLaunchKernelGGL((tk_k_mergeF_group<64>), dim3(grid_for(cntb, 4, 16384)), dim3(256), 0, sa, T, d_text, lst, cntb, tok1, cnt, stg); break;
+                    }
+                }));
+            }
+            for (int i = 0; i < 4; ++i) {
+                HIPCHK(hipEventRecord(c->ev_join[i], c->aux[i]));
+                HIPCHK(hipStreamWaitEvent(s, c->ev_join[i], 0));
+            }
+        }
+        if (nC) {
+            const uint64_t lb = hc[TK_CNT_CBYTES], lvls = hc[TK_CNT_CLEVELS];
+            TRY(ensure(c->g_id, (lb + 64) * 4));
+            TRY(ensure(c->g_rk, (lb + 64) * 4));
+            TRY(ensure(c->g_nx, (lb + 64) * 4));
+            TRY(ensure(c->g_pv, (lb + 64) * 4));
+            TRY(ensure(c->g_lv, (lvls + 64) * 8));
+            TRY(timed(c, s, "tk_k_merge_long", [&] {
+                hipLaunchKernelGGL(tk_k_mergeF_long, dim3(grid_for(nC, 4, 8192)), dim3(256), 0, s, T, d_text, c->listC.as<uint32_t>(), (uint32_t)nC,
+                                   c->g_id.as<uint32_t>(), c->g_rk.as<uint32_t>(), c->g_nx.as<uint32_t>(), c->g_pv.as<uint32_t>(),
+                                   c->g_lv.as<uint64_t>(), tok1, cnt, stg);
+            }));
+        }
+        if (mt.key) {
+            TRY(timed(c, s, "tk_k_dup_publish", [&] { hipLaunchKernelGGL(tk_k_dup_publishF, dim3(4096), dim3(256), 0, s, mt, tok1, cnt); }));
+        }
+        TRY(timed(c, s, "tk_k_tile_finish", [&] {
+            hipLaunchKernelGGL(tk_k_tile_finish, dim3(grid_for(ntiles, 4, 4096)), dim3(256), 0, s, ntiles, c->tile_np.as<uint32_t>(), mt, tok1, cnt,
+                               c->tile_nt.as<uint32_t>(), c->total.as<unsigned long long>() + 1);
+        }));
+        TRY(timed(c, s, "tk_k_scan_small", [&] {
+            hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, c->tile_nt.as<uint32_t>(), ntiles, c->total.as<uint64_t>());
+        }));
+        TRY(timed(c, s, "tk_k_back", [&] {
+            hipLaunchKernelGGL(tk_k_back, dim3(grid_for(ntiles, 4, 16384)), dim3(256), 0, s, ntiles, c->tile_np.as<uint32_t>(), c->tile_nt.as<uint32_t>(),
+                               tok1, cnt, stg, d_out);
+        }));
+    }
+    if (d_tok_off) {
+        TRY(timed(c, s, "tk_k_docoff", [&] {
+            hipLaunchKernelGGL(tk_k_docoffF, dim3(grid_for(n_docs + 1, 256, 4096)), dim3(256), 0, s, n_docs, c->doc_pid.as<uint32_t>(),
+                               c->tile_nt.as<uint32_t>(), cnt, c->total.as<uint64_t>(), tok_base_global, d_tok_off);
+        }));
+    }
+    uint64_t tp[2] = {0, 0};  // tokens, pieces
+    HIPCHK(hipMemcpyAsync(tp, c->total.p, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    const uint64_t T_total = tp[0];
+    c->st_bytes += n;
+    c->st_pieces += tp[1];
     c->st_tokens += T_total;
     c->st_medium += nB;
     c->st_long += nC;

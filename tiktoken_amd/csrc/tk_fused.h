@@ -1,0 +1,837 @@
+// Fused encode pipeline (the production path; the unfused kernels of tk_kernels.h remain selectable with
+// TIKTOKEN_AMD_DEBUG=1024 as the A/B reference).
+//
+//   tk_k_front<PAT>     per 4 KiB tile: pre-tokenise (as tk_k_pretok2) -> enumerate the pieces that START in
+//                       the tile -> whole-piece probe from the LDS copy of the text -> results written as a
+//                       dense run at piece id  pid = tile * 4096 + k.  No piece offsets travel through HBM.
+//   tk_k_mergeF_*       the lane / lane-group / tree merges on {pid, start, length} list entries
+//   tk_k_dup_publish    claimant results -> miss-table slots
+//   tk_k_tile_finish    duplicates copy their claimant's result; token count per tile
+//   tk_k_scan_small     exclusive scan of the tile counts (262 144 entries per GiB)
+//   tk_k_back           per tile: local scan of the piece counts, tokens written to their final place
+//   tk_k_docoffF        per document: token offset of the piece that starts it
+//
+// Tile rule (verified on the CPU by tests/hostsim tks_pretok_tiles): a tile derives exactly the piece
+// starts inside its own byte range.  Scanners start at the tile's certain starts plus the last certain
+// start before the tile (64-byte left context, else a walk back through HBM), record only boundaries
+// inside the tile and stop at its end.  Nothing crosses tiles, so tiles are fully independent.
+#pragma once
+#include "tk_kernels.h"
+
+#define TKF_CAP 4096  // piece ids per tile (a tile of 4096 bytes starts at most 4096 pieces)
+#define TKF_NONE 0xFFFFFFFFu
+
+struct TkFrontOut {
+    uint32_t* starts;    // piece-start bitmap (n/32 words; each tile stores its own 128 words)
+    uint32_t* tile_np;   // pieces per tile
+    uint32_t* tok1;      // [ntiles * TKF_CAP] token (count 1) or staging position of the tokens (count > 1)
+    uint32_t* cnt;       // [ntiles * TKF_CAP] token count, or TK_DUP_FLAG | slot
+    uint32_t* listM;     // {pid, start, len} triples, binned by length
+    uint32_t* listC;     // {pid, start, len, scratch bytes before, tree levels before} for > 1 KiB pieces
+    uint32_t* counters;
+    uint32_t* doc_pid;   // [n_docs] piece id at which each document starts (TKF_NONE: no piece)
+};
+struct TkMissTableF {
+    unsigned long long* key;  // [1 << TK_MT_BITS], ~0 = empty
+    unsigned long long* aux;  // (claimant start << 32) | length, ~0 until the claimant has written it
+    uint32_t* rep;            // claimant pid
+    uint32_t* res_cnt;        // published after the merges
+    uint32_t* res_tok;
+};
+
+// last certain piece start at or before `pos` (exists: position 0 and document starts are hard starts)
+__device__ __noinline__ uint64_t tk_certain_before(const TkTables* T, const uint8_t* text, uint64_t n, const uint32_t* brk,
+                                                   const uint32_t* ss, const uint32_t* si, uint64_t pos, int pat) {
+    uint32_t c = tk_class_byte_slow(T, text, pos, n, brk, ss, si);
+    for (;;) {
+        while ((c & 15u) == TK_C_CONT && pos > 0) {
+            --pos;
+            c = tk_class_byte_slow(T, text, pos, n, brk, ss, si);
+        }
+        if ((c & TK_F_HARD) || pos == 0) return pos;
+        uint64_t j = pos - 1;
+        uint32_t pc = tk_class_byte_slow(T, text, j, n, brk, ss, si);
+        while ((pc & 15u) == TK_C_CONT && j > 0) {
+            --j;
+            pc = tk_class_byte_slow(T, text, j, n, brk, ss, si);
+        }
+        if (tk_certain_start(pat, pc & 15u, c & 15u)) return pos;
+        pos = j;
+        c = pc;
+    }
+}
+
+// 8 bytes of the LDS text copy starting at byte offset o (three aligned dword reads)
+__device__ __forceinline__ uint64_t tk_lds_load8(const uint8_t* raw, uint32_t o) {
+    const uint32_t* dw = (const uint32_t*)raw;
+    const uint32_t wi = o >> 2, sft = o & 3u;
+    const uint32_t d0 = dw[wi], d1 = dw[wi + 1], d2 = dw[wi + 2];
+    const uint32_t lo = __builtin_amdgcn_alignbyte(d1, d0, sft), hi = __builtin_amdgcn_alignbyte(d2, d1, sft);
+    return ((uint64_t)hi << 32) | lo;
+}
+__device__ __forceinline__ uint64_t tk_key_of_lds(const uint8_t* raw, uint32_t o, uint32_t len) {
+    if (len <= 8u) return tk_mask_low_bytes(tk_lds_load8(raw, o), len);
+    uint64_t h = TK_HASH_SEED;
+    uint32_t i = 0;
+    for (; i + 8u <= len; i += 8u) h = tk_hash_step(h, tk_lds_load8(raw, o + i));
+    if (i < len) h = tk_hash_step(h, tk_mask_low_bytes(tk_lds_load8(raw, o + i), len - i));
+    if (h == TK_EMPTY_KEY) h = 0;
+    return h;
+}
+
+template <int PAT>
+__global__ __launch_bounds__(256) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
+                                                  const uint32_t* __restrict__ brk, const uint32_t* __restrict__ docb,
+                                                  const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si,
+                                                  const uint64_t* __restrict__ doc_off, uint64_t n_docs, TkFrontOut out, TkBins bins,
+                                                  TkMissTableF mt, int dbg) {
+    constexpr int pat = PAT;
+    constexpr int BM_BYTES = TKB_KINDS * (TK2_NSEG + 2) * 8;
+    __shared__ __attribute__((aligned(16))) uint8_t raw[TK2_WIN + 16];
+    __shared__ uint8_t cls2[TK2_WIN];
+    __shared__ __attribute__((aligned(16))) uint8_t pool[BM_BYTES + TK2_CLIST * 2];  // bitmaps + certain list; later the piece list
+    __shared__ uint32_t bits[TK_TILE / 32];
+    __shared__ uint32_t woff[TK_TILE / 32 + 1];
+    __shared__ uint32_t cn, np_sh, need_walk, last_end_sh;
+    __shared__ uint32_t certm[16];
+    __shared__ uint32_t brkw[TK2_WIN / 32 + 1], ssw[TK2_WIN / 32 + 1], siw[TK2_WIN / 32 + 1], docw[TK2_WIN / 32 + 1];
+    __shared__ __attribute__((aligned(16))) uint8_t st1[0x1100];
+    __shared__ uint32_t scan_sh[8];
+    uint64_t(*bm)[TK2_NSEG + 2] = (uint64_t(*)[TK2_NSEG + 2])pool;
+    uint16_t* clist = (uint16_t*)(pool + BM_BYTES);
+    uint16_t* plist = (uint16_t*)pool;  // valid after the scanners are done
+    const uint32_t tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    const uint64_t tile = blockIdx.x;
+    const uint64_t tile_start = tile * TK_TILE;
+    const uint64_t tile_end = tile_start + TK_TILE < n ? tile_start + TK_TILE : n;
+    const int64_t base = (int64_t)tile_start - TK2_LEFT;
+    // ---- A: window -> LDS
+    for (uint32_t v = tid; v < (TK2_WIN + 16) / 16; v += 256) {
+        int64_t gp = base + (int64_t)v * 16;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (gp >= 0 && (uint64_t)gp < n) x = *(const uint4*)(text + gp);  // text is readable 64 bytes past n
+        *(uint4*)(raw + v * 16) = x;
+    }
+    for (uint32_t v = tid; v < 0x1100 / 16; v += 256) *(uint4*)(st1 + v * 16) = *(const uint4*)(T.uc_stage1 + v * 16);
+    if (tid < TK2_WIN / 32) {  // break / special bitmaps of the window (the window base is 32-aligned)
+        int64_t wgp = base + (int64_t)tid * 32;
+        bool in = wgp >= 0 && (uint64_t)wgp < n;
+        brkw[tid] = in ? brk[wgp >> 5] : 0u;
+        docw[tid] = in ? (docb ? docb[wgp >> 5] : brkw[tid]) : 0u;
+        ssw[tid] = (in && ss) ? ss[wgp >> 5] : 0u;
+        siw[tid] = (in && si) ? si[wgp >> 5] : 0u;
+    }
+    if (tid < 16) certm[tid] = tk_certain_mask(PAT, tid);
+    if (tid == 0) {
+        cn = 0;
+        need_walk = 0;
+        last_end_sh = (uint32_t)(tile_end - tile_start) + TK2_LEFT;
+    }
+    if (tid < TKB_KINDS) {
+        bm[tid][TK2_NSEG] = tid <= TKB_HARD ? ~0ull : 0ull;  // beyond the window: unknown -> "stop"
+        bm[tid][TK2_NSEG + 1] = tid <= TKB_HARD ? ~0ull : 0ull;
+    }
+    __syncthreads();
+    // ---- B1: class of every byte (branch-free; see tk_k_pretok2)
+    constexpr int NS = TK2_NSEG / 4;  // 17 segments per wave, contiguous
+    uint32_t creg[NS];
+    {
+        const uint32_t* dw = (const uint32_t*)raw;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) {
+            const uint32_t pl = (uint32_t)(wid * NS + i) * 64u + lane;
+            const uint32_t wi = pl >> 2, sft = pl & 3u;
+            const uint32_t d0 = dw[wi ? wi - 1 : 0], d1 = dw[wi], d2 = dw[wi + 1];
+            const uint32_t fwd = __builtin_amdgcn_alignbyte(d2, d1, sft);
+            const uint32_t back = sft == 3u ? d1 : __builtin_amdgcn_alignbyte(d1, d0, sft + 1u);
+            const uint32_t b = fwd & 0xFFu;
+            uint32_t k = 0;
+            if ((b & 0xC0u) == 0x80u) k = ((back >> 16) & 0xC0u) != 0x80u ? 1u : (((back >> 8) & 0xC0u) != 0x80u ? 2u : 3u);
+            const uint64_t seven = ((uint64_t)fwd << 24) | (uint64_t)(back & 0xFFFFFFu);
+            const uint32_t ch = (uint32_t)(seven >> (8u * (3u - k)));
+            const uint32_t l = ch & 0xFFu, c1b = (ch >> 8) & 0x3Fu, c2b = (ch >> 16) & 0x3Fu, c3b = (ch >> 24) & 0x3Fu;
+            uint32_t cp = l;
+            if (l >= 0xF0u) cp = ((l & 7u) << 18) | (c1b << 12) | (c2b << 6) | c3b;
+            else if (l >= 0xE0u) cp = ((l & 15u) << 12) | (c1b << 6) | c2b;
+            else if (l >= 0xC0u) cp = ((l & 31u) << 6) | c1b;
+            if (cp > 0x10FFFFu) cp = 0xFFFFu;
+            creg[i] = T.uc_stage2[(uint32_t)st1[cp >> 8] * 256u + (cp & 255u)];
+        }
+    }
+    // ---- B2: flags, class bytes, bitmaps, certain starts (previous class = lane - 1, carried across segments)
+    uint32_t carry = TK_C_END;
+    if (wid > 0) {
+        const uint32_t* dw = (const uint32_t*)raw;
+        const uint32_t pl = (uint32_t)(wid * NS) * 64u - 1u;
+        const uint32_t wi = pl >> 2, sft = pl & 3u;
+        const uint32_t d0 = dw[wi - 1], d1 = dw[wi], d2 = dw[wi + 1];
+        const uint32_t fwd = __builtin_amdgcn_alignbyte(d2, d1, sft);
+        const uint32_t back = sft == 3u ? d1 : __builtin_amdgcn_alignbyte(d1, d0, sft + 1u);
+        const uint32_t b = fwd & 0xFFu;
+        uint32_t k = 0;
+        if ((b & 0xC0u) == 0x80u) k = ((back >> 16) & 0xC0u) != 0x80u ? 1u : (((back >> 8) & 0xC0u) != 0x80u ? 2u : 3u);
+        const uint64_t seven = ((uint64_t)fwd << 24) | (uint64_t)(back & 0xFFFFFFu);
+        const uint32_t ch = (uint32_t)(seven >> (8u * (3u - k)));
+        const uint32_t l = ch & 0xFFu, c1b = (ch >> 8) & 0x3Fu, c2b = (ch >> 16) & 0x3Fu, c3b = (ch >> 24) & 0x3Fu;
+        uint32_t cp = l;
+        if (l >= 0xF0u) cp = ((l & 7u) << 18) | (c1b << 12) | (c2b << 6) | c3b;
+        else if (l >= 0xE0u) cp = ((l & 15u) << 12) | (c1b << 6) | c2b;
+        else if (l >= 0xC0u) cp = ((l & 31u) << 6) | c1b;
+        if (cp > 0x10FFFFu) cp = 0xFFFFu;
+        carry = T.uc_stage2[(uint32_t)st1[cp >> 8] * 256u + (cp & 255u)];
+        const int64_t gpp = base + pl;
+        if (gpp < 0 || (uint64_t)gpp >= n) carry = TK_C_END;
+        else if ((ss && ((ssw[pl >> 5] >> (pl & 31u)) & 1u)) || (si && ((siw[pl >> 5] >> (pl & 31u)) & 1u))) carry = TK_C_SPEC;
+    }
+    uint32_t spill_mask = 0;
+    uint64_t left_certw = 0;  // wave 0: certain starts inside the left context segment
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        const int g = wid * NS + i;
+        const uint32_t pl = (uint32_t)g * 64u + lane;
+        const int64_t gp = base + pl;
+        const bool valid = gp >= 0 && (uint64_t)gp < n;
+        const uint32_t b = raw[pl];
+        bool cont = valid && (b & 0xC0u) == 0x80u;
+        uint32_t c = creg[i];
+        bool hard = false;
+        if (!valid) {
+            c = TK_C_END;
+            hard = gp >= 0;
+        } else {
+            const bool spec_s = ss && ((ssw[pl >> 5] >> (pl & 31u)) & 1u), spec_i = si && ((siw[pl >> 5] >> (pl & 31u)) & 1u);
+            if (spec_i) {
+                cont = true;
+                c = TK_C_SPEC;
+            } else if (spec_s) {
+                cont = false;
+                c = TK_C_SPEC;
+                hard = true;
+            } else if (!cont) {
+                hard = (brkw[pl >> 5] >> (pl & 31u)) & 1u;
+            }
+        }
+        cls2[pl] = (uint8_t)(c | (cont ? 0x40u : 0u) | (hard ? 0x80u : 0u));
+        constexpr bool O2 = PAT == TK_PAT_O200K, R5 = PAT == TK_PAT_R50K;
+        const uint64_t w_start = __ballot(!cont), w_hard = __ballot(hard);
+        {
+            uint32_t prevc = __shfl_up(c, 1, 64);
+            if (lane == 0) prevc = carry;
+            carry = __shfl(c, 63, 64);
+            const bool in_tile = g >= 1 && g <= TK_TILE / 64;
+            // (lane 0 of the context segment has no known predecessor: never certain unless hard)
+            const bool cert = valid && !cont && (hard || ((g > 0 || lane > 0) && ((certm[prevc] >> c) & 1u)));
+            const uint64_t certw = __ballot(cert);
+            if (g == 0) left_certw = certw;
+            if (in_tile) {
+                if (lane == 0) {
+                    bits[(g - 1) * 2] = (uint32_t)certw;
+                    bits[(g - 1) * 2 + 1] = (uint32_t)(certw >> 32);
+                }
+                if (certw) {
+                    uint32_t at = 0;
+                    if (lane == 0) at = atomicAdd(&cn, (uint32_t)__popcll(certw));
+                    at = __shfl(at, 0, 64) + (uint32_t)__popcll(certw & ((1ull << lane) - 1ull));
+                    if (cert) {
+                        if (at < TK2_CLIST) clist[at] = (uint16_t)pl;
+                        else spill_mask |= 1u << i;
+                    }
+                }
+                if (g == 1 && lane == 0 && tile_start > 0) {
+                    // is the first char of the tile a certain start?  If not, the segment that crosses in from the
+                    // left must be re-scanned from ITS start: the last certain start in the left context, or further back
+                    const bool first_cert = w_start && ((certw >> (__ffsll((unsigned long long)w_start) - 1)) & 1ull);
+                    if (!first_cert) {
+                        if (left_certw) {
+                            uint32_t at2 = atomicAdd(&cn, 1u);
+                            if (at2 < TK2_CLIST) clist[at2] = (uint16_t)(63 - __clzll((long long)left_certw));
+                            else need_walk = 2;  // (list full: let the walk-back path handle it)
+                        } else {
+                            need_walk = 1;
+                        }
+                    }
+                }
+            }
+        }
+        const uint64_t w_oth = __ballot((TK_M_OTHER >> c) & 1u), w_ws = __ballot((TK_M_WS >> c) & 1u), w_nu = __ballot(c == TK_C_NU);
+        uint64_t w_L = 0, w_up = 0, w_low = 0, w_cas = 0, w_nl = 0, w_nlsl = 0;
+        if constexpr (!O2) w_L = __ballot((TK_M_L >> c) & 1u);
+        if constexpr (O2) {
+            w_up = __ballot((TK_M_UPPERISH >> c) & 1u);
+            w_low = __ballot((TK_M_LOWERISH >> c) & 1u);
+            w_cas = __ballot(c == TK_C_LC || c == TK_C_MK);
+            w_nlsl = __ballot(c == TK_C_NL || c == TK_C_SL);
+        }
+        if constexpr (!R5) w_nl = __ballot(c == TK_C_NL);
+        if (lane == 0) {
+            bm[TKB_START][g] = w_start;
+            bm[TKB_HARD][g] = w_hard;
+            bm[TKB_OTH][g] = w_oth;
+            bm[TKB_WS][g] = w_ws;
+            bm[TKB_NU][g] = w_nu;
+            if constexpr (!O2) bm[TKB_L][g] = w_L;
+            if constexpr (O2) {
+                bm[TKB_UP][g] = w_up;
+                bm[TKB_LOW][g] = w_low;
+                bm[TKB_CAS][g] = w_cas;
+                bm[TKB_NLSL][g] = w_nlsl;
+            }
+            if constexpr (!R5) bm[TKB_NL][g] = w_nl;
+        }
+    }
+    __syncthreads();
+    // ---- D: one lane per certain start; only boundaries inside the tile are recorded
+    TkWin2Acc acc{cls2, raw, base, &T, text, n, brk, ss, si};
+    auto scan_from = [&](uint64_t p) {
+        for (;;) {
+            const int64_t r = (int64_t)p - base;
+            uint32_t len = 0;
+            if (r >= 0 && r + 64 <= TK2_WIN) {
+                const uint32_t wi = (uint32_t)r >> 6, sh = (uint32_t)r & 63u;
+                TkWin w;
+#define TK_FUNNEL(kind) (sh ? ((bm[kind][wi] >> sh) | (bm[kind][wi + 1] << (64u - sh))) : bm[kind][wi])
+                w.start = TK_FUNNEL(TKB_START);
+                w.stop = TK_FUNNEL(TKB_HARD) & ~1ull;
+                w.L = TK_FUNNEL(TKB_L);
+                w.up = TK_FUNNEL(TKB_UP);
+                w.low = TK_FUNNEL(TKB_LOW);
+                w.cas = TK_FUNNEL(TKB_CAS);
+                w.oth = TK_FUNNEL(TKB_OTH);
+                w.ws = TK_FUNNEL(TKB_WS);
+                w.nl = TK_FUNNEL(TKB_NL);
+                w.nu = TK_FUNNEL(TKB_NU);
+                w.nlsl = TK_FUNNEL(TKB_NLSL);
+#undef TK_FUNNEL
+                TkBmExt ext{bm, wi, sh, (uint32_t)(TK2_WIN - r)};
+                len = tk_piece_len_bits(w, acc, ext, p, cls2[r] & 15u, pat);
+            }
+            uint64_t e = len ? p + len : tk_piece_end_slow(&acc, p, pat);
+            if (e > n) e = n;
+            if (e >= tile_end) {  // the piece that reaches the tile end: remember where it ends (clamped to the 32-bit window offset)
+                if (p < tile_end) {
+                    uint64_t rel = e - (uint64_t)base;
+                    last_end_sh = rel > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)rel;
+                }
+                break;
+            }
+            if (e >= tile_start) {
+                const int64_t re = (int64_t)e - base;  // inside the window (e < tile_end)
+                const uint32_t ce = cls2[re];
+                if (ce & 0x80u) break;
+                if ((certm[cls2[re - 1] & 15u] >> (ce & 15u)) & 1u) break;
+                atomicOr(&bits[(uint32_t)(e - tile_start) >> 5], 1u << ((uint32_t)(e - tile_start) & 31));
+            }
+            p = e;
+        }
+    };
+    {
+        const uint32_t ncert = cn < TK2_CLIST ? cn : TK2_CLIST;
+        for (uint32_t i = tid; i < ncert; i += 256) scan_from((uint64_t)(base + clist[i]));
+        while (spill_mask) {
+            int i = __ffs((int)spill_mask) - 1;
+            spill_mask &= spill_mask - 1;
+            scan_from((uint64_t)(base + (int64_t)((uint32_t)(wid * NS + i) * 64u + lane)));
+        }
+        if (tid == 0 && need_walk) scan_from(tk_certain_before(&T, text, n, brk, ss, si, tile_start - 1, pat));
+    }
+    __syncthreads();
+    // ---- E: enumerate the pieces of the tile (set bits of `bits`, in order) -> plist (aliases the bitmaps)
+    {
+        uint32_t pc = tid < TK_TILE / 32 ? __popc(bits[tid]) : 0u, tot;
+        uint32_t ex = tk_block_exscan_256(pc, &tot, scan_sh);
+        if (tid < TK_TILE / 32) woff[tid] = ex;
+        if (tid == 0) np_sh = tot;
+    }
+    __syncthreads();
+    const uint32_t np = np_sh;
+    if (tid < TK_TILE / 32) {
+        uint32_t v = bits[tid], o = woff[tid];
+        while (v) {
+            const uint32_t b = __ffs((int)v) - 1;
+            v &= v - 1;
+            plist[o++] = (uint16_t)(TK2_LEFT + tid * 32 + b);
+        }
+        const uint64_t wgp = tile_start / 32 + tid;
+        if (wgp * 32 < n) out.starts[wgp] = bits[tid];
+    }
+    if (tid == 0) out.tile_np[tile] = np;
+    __syncthreads();
+    // ---- F: whole-piece probe, one lane per piece
+    const uint32_t last_end = last_end_sh;
+    for (uint32_t k0 = 0; k0 < np; k0 += 256) {
+        const uint32_t k = k0 + tid;
+        uint32_t cat = 0, s_loc = 0, len = 0;
+        uint64_t gs = 0;
+        const uint64_t pid = tile * TKF_CAP + k;
+        if (k < np) {
+            s_loc = plist[k];
+            const uint32_t e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
+            len = e_loc - s_loc;
+            gs = (uint64_t)(base + s_loc);
+            const uint32_t cb = cls2[s_loc];
+            // documents that start at this piece
+            if ((docw[s_loc >> 5] >> (s_loc & 31u)) & 1u) {
+                const uint64_t want = gs + chunk_base;
+                uint64_t lo = 0, hi = n_docs;  // first d with doc_off[d] >= want
+                while (lo < hi) {
+                    uint64_t mid = (lo + hi) >> 1;
+                    if (doc_off[mid] < want) lo = mid + 1;
+                    else hi = mid;
+                }
+                for (; lo < n_docs && doc_off[lo] == want; ++lo) out.doc_pid[lo] = (uint32_t)pid;
+            }
+            if ((cb & 15u) == TK_C_SPEC) {
+                out.tok1[pid] = tk_special_id(T, text, gs, len);
+                out.cnt[pid] = 1;
+            } else {
+                const bool in_lds = e_loc + 8u <= (uint32_t)TK2_WIN;
+                const uint64_t key = in_lds ? tk_key_of_lds(raw, s_loc, len) : tk_key_of_text(text, gs, len);
+                uint32_t r = tk_probe_piece(T, key, len, [&](uint32_t off) { return tk_equal_bytes(text, gs, T.tok_bytes, off, len); });
+                if (r != TK_RANK_MAX) {
+                    out.tok1[pid] = r;
+                    out.cnt[pid] = 1;
+                } else if (len > TK_GLANE_MAX) {
+                    cat = 1 + TK_NBIN;
+                } else {
+                    cat = 1 + (uint32_t)tk_bin_of(len);
+                    if (mt.key && !(dbg & 256)) {
+                        unsigned long long kk = tk_mix64(key ^ ((uint64_t)len * 0xA24BAED4963EE407ull));
+                        if (dbg & 512) kk &= 0xFFFull;  // test hook: force collisions between different pieces
+                        if (kk == TK_EMPTY_KEY) kk = 0;
+                        uint32_t i = (uint32_t)(kk >> 7) & ((1u << TK_MT_BITS) - 1u);
+                        for (int t = 0; t < TK_MT_PROBES; ++t) {
+                            unsigned long long cur = mt.key[i];
+                            if (cur == TK_EMPTY_KEY) cur = atomicCAS(&mt.key[i], TK_EMPTY_KEY, kk);
+                            if (cur == TK_EMPTY_KEY) {  // claimed: this piece is the one that gets merged
+                                mt.rep[i] = (uint32_t)pid;
+                                __hip_atomic_store(&mt.aux[i], (gs << 32) | len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                            if (cur == kk) {
+                                // same hash: a duplicate only if the claimant's bytes are identical (verified here, now)
+                                const unsigned long long a = __hip_atomic_load(&mt.aux[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                if (a != TK_EMPTY_KEY && (uint32_t)a == len && tk_equal_bytes(text, gs, text, (uint32_t)(a >> 32), len)) {
+                                    out.cnt[pid] = TK_DUP_FLAG | i;
+                                    cat = 0;
+                                    break;
+                                }
+                                // claimant not visible yet, or different bytes: keep probing (ends as a merge of its own)
+                            }
+                            i = (i + 1) & ((1u << TK_MT_BITS) - 1u);
+                        }
+                    }
+                }
+            }
+        }
+        // appends: rare once duplicates are filtered -> one atomic per (wave, bin)
+        if (__ballot(cat != 0)) {
+            for (uint32_t b = 0; b < TK_NBIN; ++b) {
+                const uint64_t m = __ballot(cat == 1 + b);
+                if (!m) continue;
+                const int leader = __ffsll((unsigned long long)m) - 1;
+                uint32_t at = 0;
+                if (lane == leader) at = atomicAdd(&out.counters[TK_CNT_BIN0 + b], (uint32_t)__popcll(m));
+                at = __shfl(at, leader, 64);
+                if (cat == 1 + b) {
+                    uint32_t* e = out.listM + 3 * (uint64_t)(bins.off[b] + at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
+                    e[0] = (uint32_t)pid;
+                    e[1] = (uint32_t)gs;
+                    e[2] = len;
+                }
+            }
+            if (cat == 1 + TK_NBIN) {
+                uint32_t lv = 0, c = len;
+                do {
+                    c = (c + 63) >> 6;
+                    lv += c;
+                } while (c > 64);
+                const uint32_t gi = atomicAdd(&out.counters[TK_CNT_C], 1u);
+                uint32_t* e = out.listC + 5 * (uint64_t)gi;
+                e[0] = (uint32_t)pid;
+                e[1] = (uint32_t)gs;
+                e[2] = len;
+                e[3] = atomicAdd(&out.counters[TK_CNT_CBYTES], len);
+                e[4] = atomicAdd(&out.counters[TK_CNT_CLEVELS], lv);
+            }
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// merges on {pid, start, len} entries (same algorithms as tk_k_merge_llane / tk_k_merge_group / tk_k_merge_long)
+// result: cnt[pid] = token count; tok1[pid] = the token (count 1) or the staging position of the tokens
+// ------------------------------------------------------------------------------------------
+template <int NMAX, int THREADS>
+__global__ __launch_bounds__(THREADS) void tk_k_mergeF_llane(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ list,
+                                                             uint32_t count, uint32_t* __restrict__ tok1, uint32_t* __restrict__ cnt,
+                                                             uint32_t* __restrict__ staging) {
+    __shared__ uint32_t s_id[NMAX * THREADS];
+    __shared__ uint32_t s_rk[NMAX * THREADS];
+    uint32_t* id = s_id + threadIdx.x;
+    uint32_t* rk = s_rk + threadIdx.x;
+    for (uint32_t it = blockIdx.x * THREADS + threadIdx.x; it < count; it += gridDim.x * THREADS) {
+        const uint32_t pid = list[3 * (uint64_t)it], s = list[3 * (uint64_t)it + 1], n = list[3 * (uint64_t)it + 2];
+        const uint32_t t = tk_lane_merge<THREADS>(T, text, s, n, id, rk, staging + s);
+        cnt[pid] = t;
+        tok1[pid] = t == 1 ? id[0] : s;
+    }
+}
+
+template <int G>
+__global__ __launch_bounds__(256) void tk_k_mergeF_group(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ list,
+                                                         uint32_t count, uint32_t* __restrict__ tok1, uint32_t* __restrict__ cnt,
+                                                         uint32_t* __restrict__ staging) {
+    constexpr int C = 16, NMAX = G * C, PPW = 64 / G;
+    constexpr uint32_t NONE = 0xFFFFu;
+    __shared__ __attribute__((aligned(16))) uint32_t s_id[4][1024];
+    __shared__ __attribute__((aligned(16))) uint32_t s_rk[4][1024];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const int g = lane & (G - 1), grp = lane / G, gbase = grp * G;
+    uint32_t* id = s_id[wid] + grp * NMAX;
+    uint32_t* rk = s_rk[wid] + grp * NMAX;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+    auto local_min = [&]() -> uint64_t {
+        uint64_t m = ~0ull;
+        const uint4* q = (const uint4*)(rk + g * C);
+#pragma unroll
+        for (int v = 0; v < C / 4; ++v) {
+            uint4 x = q[v];
+            uint32_t k0 = g * C + v * 4;
+            uint64_t a = ((uint64_t)x.x << 32) | k0, b = ((uint64_t)x.y << 32) | (k0 + 1), c = ((uint64_t)x.z << 32) | (k0 + 2),
+                     d = ((uint64_t)x.w << 32) | (k0 + 3);
+            a = a < b ? a : b;
+            c = c < d ? c : d;
+            a = a < c ? a : c;
+            m = m < a ? m : a;
+        }
+        return m;
+    };
+    for (uint32_t e0 = wave * PPW; e0 < count; e0 += nwaves * PPW) {
+        const uint32_t e = e0 + grp;
+        const bool valid = e < count;
+        uint32_t pid = 0, s = 0, n = 0;
+        if (valid) {
+            pid = list[3 * (uint64_t)e];
+            s = list[3 * (uint64_t)e + 1];
+            n = list[3 * (uint64_t)e + 2];
+        }
+        uint32_t mask = 0;
+#pragma unroll 4
+        for (int c = 0; c < C; ++c) {
+            const uint32_t k = g * C + c;
+            uint32_t r = TK_RANK_MAX;
+            if (k < n) {
+                const uint32_t b0 = text[s + k];
+                id[k] = T.byte_rank[b0];
+                if (k + 1 < n) r = T.pair2[(b0 << 8) | text[s + k + 1]];
+                mask |= 1u << c;
+            }
+            rk[k] = r;
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint64_t lk = local_min();
+        for (;;) {
+            uint64_t m = lk;
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) {
+                uint64_t w = __shfl_xor(m, o, 64);
+                m = w < m ? w : m;
+            }
+            const uint32_t best = (uint32_t)(m >> 32);
+            const bool fin = best == TK_RANK_MAX;
+            if (__all(fin)) break;
+            const uint32_t bi = (uint32_t)m & (NMAX - 1), ob = bi / C, bl = bi % C;
+            const uint64_t nbw = __ballot(mask != 0);
+            const uint64_t nb = G == 64 ? nbw : ((nbw >> gbase) & ((1ull << (G & 63)) - 1ull));
+            const uint32_t my_first = mask ? (uint32_t)(g * C + __ffs((int)mask) - 1) : NONE;
+            const uint32_t my_last = mask ? (uint32_t)(g * C + 31 - __clz((int)mask)) : NONE;
+            const uint32_t om = __shfl(mask, gbase + (int)ob, 64);
+            uint32_t j;
+            {
+                const uint32_t hi = om & ~((2u << bl) - 1u);
+                const uint64_t la = nb & ~((2ull << ob) - 1ull);
+                const int lj = la ? __ffsll((unsigned long long)la) - 1 : 0;
+                const uint32_t fj = __shfl(my_first, gbase + lj, 64);
+                j = hi ? ob * C + (uint32_t)__ffs((int)hi) - 1u : fj;
+            }
+            j &= (NMAX - 1);
+            const uint32_t oj = j / C, jl = j % C;
+            uint32_t nn;
+            {
+                const uint32_t ojm = __shfl(mask, gbase + (int)oj, 64);
+                const uint32_t hi = ojm & ~((2u << jl) - 1u);
+                const uint64_t la = nb & ~((2ull << oj) - 1ull);
+                const int ln = la ? __ffsll((unsigned long long)la) - 1 : 0;
+                const uint32_t fn = __shfl(my_first, gbase + ln, 64);
+                nn = hi ? oj * C + (uint32_t)__ffs((int)hi) - 1u : (la ? fn : NONE);
+            }
+            uint32_t pp;
+            {
+                const uint32_t lo = om & ((1u << bl) - 1u);
+                const uint64_t lb = nb & ((1ull << ob) - 1ull);
+                const int lp = lb ? 63 - __clzll((long long)lb) : 0;
+                const uint32_t fl = __shfl(my_last, gbase + lp, 64);
+                pp = lo ? ob * C + 31u - (uint32_t)__clz((int)lo) : (lb ? fl : NONE);
+            }
+            uint32_t newr = TK_RANK_MAX;
+            if (!fin) {
+                if (g == 0 && nn != NONE) newr = tk_probe_pair(T, best, id[nn]);
+                if (g == 1 && pp != NONE) newr = tk_probe_pair(T, id[pp], best);
+            }
+            const uint32_t newr_i = __shfl(newr, gbase, 64), newr_p = __shfl(newr, gbase + 1, 64);
+            __builtin_amdgcn_wave_barrier();
+            bool touched = false;
+            if (!fin) {
+                if (g == (int)ob) {
+                    id[bi] = best;
+                    rk[bi] = newr_i;
+                    touched = true;
+                }
+                if (g == (int)oj) {
+                    mask &= ~(1u << jl);
+                    rk[j] = TK_RANK_MAX;
+                    touched = true;
+                }
+                if (pp != NONE && g == (int)(pp / C)) {
+                    rk[pp] = newr_p;
+                    touched = true;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (touched) lk = local_min();
+        }
+        const uint32_t mine = __popc(mask);
+        uint32_t inc = mine;
+#pragma unroll
+        for (int o = 1; o < G; o <<= 1) {
+            uint32_t w = __shfl_up(inc, o, 64);
+            if (g >= o) inc += w;
+        }
+        const uint32_t total = __shfl(inc, gbase + G - 1, 64);
+        if (valid) {
+            uint32_t t = inc - mine, mm = mask;
+            while (mm) {
+                const int c = __ffs((int)mm) - 1;
+                mm &= mm - 1;
+                staging[s + t++] = id[g * C + c];
+            }
+            if (g == 0) {
+                cnt[pid] = total;
+                tok1[pid] = total == 1 ? id[0] : s;
+            }
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+__global__ __launch_bounds__(256) void tk_k_mergeF_long(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listC,
+                                                        uint32_t nC, uint32_t* __restrict__ g_id, uint32_t* __restrict__ g_rk,
+                                                        uint32_t* __restrict__ g_nx, uint32_t* __restrict__ g_pv, uint64_t* __restrict__ g_lv,
+                                                        uint32_t* __restrict__ tok1, uint32_t* __restrict__ cnt, uint32_t* __restrict__ staging) {
+    const int lane = threadIdx.x & 63;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
+    for (uint32_t w = wave; w < nC; w += nwaves) {
+        const uint32_t* ent = listC + 5 * (uint64_t)w;
+        const uint32_t pid = ent[0], s = ent[1], n = ent[2];
+        uint32_t* id = g_id + ent[3];
+        uint32_t* rk = g_rk + ent[3];
+        uint32_t* nx = g_nx + ent[3];
+        uint32_t* pv = g_pv + ent[3];
+        uint64_t* lv = g_lv + ent[4];
+        uint32_t cntl[TK_MAX_LEVELS + 1], offl[TK_MAX_LEVELS + 1];
+        int nl = 0;
+        cntl[0] = n;
+        offl[0] = 0;
+        {
+            uint32_t c = n, o = 0;
+            do {
+                c = (c + 63) >> 6;
+                ++nl;
+                cntl[nl] = c;
+                offl[nl] = o;
+                o += c;
+            } while (c > 64);
+        }
+        for (uint32_t k = lane; k < n; k += 64) {
+            uint32_t b0 = text[s + k];
+            id[k] = T.byte_rank[b0];
+            rk[k] = k + 1 < n ? T.pair2[(b0 << 8) | text[s + k + 1]] : TK_RANK_MAX;
+            nx[k] = k + 1;
+            pv[k] = k - 1;
+        }
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        for (int l = 1; l <= nl; ++l) {
+            for (uint32_t b = 0; b < cntl[l]; ++b) {
+                uint32_t k = b * 64 + lane;
+                uint64_t key = ~0ull;
+                if (k < cntl[l - 1]) key = l == 1 ? (((uint64_t)rk[k] << 32) | k) : lv[offl[l - 1] + k];
+                key = tk_wave_min_u64(key);
+                if (lane == 0) lv[offl[l] + b] = key;
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        }
+        for (;;) {
+            uint64_t top = (uint32_t)lane < cntl[nl] ? lv[offl[nl] + lane] : ~0ull;
+            top = tk_wave_min_u64(top);
+            uint32_t m = (uint32_t)(top >> 32);
+            if (m == TK_RANK_MAX) break;
+            const uint32_t i = (uint32_t)top;
+            const uint32_t j = nx[i];
+            const uint32_t nn = nx[j];
+            const uint32_t pp = pv[i];
+            uint32_t newr = TK_RANK_MAX;
+            if (lane == 0 && nn < n) newr = tk_probe_pair(T, m, id[nn]);
+            if (lane == 1 && pp != 0xFFFFFFFFu) newr = tk_probe_pair(T, id[pp], m);
+            if (lane == 0) {
+                id[i] = m;
+                nx[i] = nn;
+                if (nn < n) pv[nn] = i;
+                rk[j] = TK_RANK_MAX;
+                rk[i] = newr;
+            }
+            if (lane == 1 && pp != 0xFFFFFFFFu) rk[pp] = newr;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            uint32_t bi = i, bj = j, bp = pp != 0xFFFFFFFFu ? pp : i;
+            for (int l = 1; l <= nl; ++l) {
+                bi >>= 6;
+                bj >>= 6;
+                bp >>= 6;
+                for (int t = 0; t < 3; ++t) {
+                    uint32_t b = t == 0 ? bp : (t == 1 ? bi : bj);
+                    if ((t == 1 && bi == bp) || (t == 2 && (bj == bi || bj == bp))) continue;
+                    uint32_t k = b * 64 + lane;
+                    uint64_t key = ~0ull;
+                    if (k < cntl[l - 1]) key = l == 1 ? (((uint64_t)rk[k] << 32) | k) : lv[offl[l - 1] + k];
+                    key = tk_wave_min_u64(key);
+                    if (lane == 0) lv[offl[l] + b] = key;
+                }
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            }
+        }
+        if (lane == 0) {
+            uint32_t t = 0;
+            for (uint32_t k = 0; k < n; k = nx[k]) staging[s + t++] = id[k];
+            cnt[pid] = t;
+            tok1[pid] = t == 1 ? staging[s] : s;
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// back end
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void tk_k_dup_publishF(TkMissTableF mt, const uint32_t* __restrict__ tok1, const uint32_t* __restrict__ cnt) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < (1u << TK_MT_BITS); i += gridDim.x * 256u) {
+        if (mt.key[i] == TK_EMPTY_KEY) continue;
+        const uint32_t rep = mt.rep[i];
+        mt.res_cnt[i] = cnt[rep];
+        mt.res_tok[i] = tok1[rep];
+    }
+}
+
+// one wavefront per tile: duplicates take their claimant's published result; token count of the tile
+__global__ __launch_bounds__(256) void tk_k_tile_finish(uint64_t ntiles, const uint32_t* __restrict__ tile_np, TkMissTableF mt,
+                                                        uint32_t* __restrict__ tok1, uint32_t* __restrict__ cnt, uint32_t* __restrict__ tile_nt,
+                                                        unsigned long long* __restrict__ n_pieces) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
+    unsigned long long pieces = 0;
+    for (uint64_t t = wave; t < ntiles; t += nwaves) {
+        const uint32_t np = tile_np[t];
+        pieces += np;
+        uint32_t sum = 0;
+        for (uint32_t k = lane; k < np; k += 64) {
+            const uint64_t pid = t * TKF_CAP + k;
+            uint32_t c = cnt[pid];
+            if (c & TK_DUP_FLAG) {
+                const uint32_t slot = c & ~TK_DUP_FLAG;
+                c = mt.res_cnt[slot];
+                cnt[pid] = c;
+                tok1[pid] = mt.res_tok[slot];
+            }
+            sum += c;
+        }
+        sum = tk_wave_sum_u32(sum);
+        if (lane == 0) tile_nt[t] = sum;
+    }
+    if (lane == 0 && pieces) atomicAdd(n_pieces, pieces);
+}
+
+// one wavefront per tile: local scan of the piece counts, tokens to their final positions
+__global__ __launch_bounds__(256) void tk_k_back(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_tb,
+                                                 const uint32_t* __restrict__ tok1, const uint32_t* __restrict__ cnt,
+                                                 const uint32_t* __restrict__ staging, uint32_t* __restrict__ out) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
+    for (uint64_t t = wave; t < ntiles; t += nwaves) {
+        const uint32_t np = tile_np[t];
+        uint32_t run = tile_tb[t];
+        for (uint32_t k0 = 0; k0 < np; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            const uint64_t pid = t * TKF_CAP + k;
+            const uint32_t c = k < np ? cnt[pid] : 0u;
+            const uint32_t inc = tk_wave_scan_u32(c, lane);
+            const uint32_t o = run + inc - c;
+            if (c == 1) {
+                out[o] = tok1[pid];
+            } else if (c > 1) {
+                const uint32_t* src = staging + tok1[pid];
+                for (uint32_t i = 0; i < c; ++i) out[o + i] = src[i];
+            }
+            run += __shfl(inc, 63, 64);
+        }
+    }
+}
+
+// tok_off[d] = tokens before the piece at which document d starts
+__global__ __launch_bounds__(256) void tk_k_docoffF(uint64_t n_docs, const uint32_t* __restrict__ doc_pid, const uint32_t* __restrict__ tile_tb,
+                                                    const uint32_t* __restrict__ cnt, const uint64_t* __restrict__ total,
+                                                    uint64_t tok_base_global, uint64_t* __restrict__ tok_off) {
+    for (uint64_t d = blockIdx.x * 256ull + threadIdx.x; d <= n_docs; d += (uint64_t)gridDim.x * 256) {
+        uint64_t v;
+        const uint32_t pid = d < n_docs ? doc_pid[d] : TKF_NONE;
+        if (pid == TKF_NONE) {
+            v = total[0];  // empty documents at the end of the chunk, and the closing offset
+        } else {
+            const uint32_t t = pid / TKF_CAP, k = pid % TKF_CAP;
+            uint32_t sum = tile_tb[t];
+            const uint32_t* c = cnt + (uint64_t)t * TKF_CAP;
+            for (uint32_t j = 0; j < k; ++j) sum += c[j];
+            v = sum;
+        }
+        tok_off[d] = tok_base_global + v;
+    }
+}
+
+// encode_single_piece (src/py.rs:145-150): the whole buffer is one piece, no pre-tokenisation
+__global__ void tk_k_single_front(TkTables T, const uint8_t* __restrict__ text, uint32_t n, TkFrontOut out, TkBins bins) {
+    if (blockIdx.x || threadIdx.x) return;
+    out.tile_np[0] = 1;
+    const uint32_t r = tk_lookup_text_piece(T, text, 0, n);
+    if (r != TK_RANK_MAX) {
+        out.tok1[0] = r;
+        out.cnt[0] = 1;
+    } else if (n > TK_GLANE_MAX) {
+        uint32_t lv = 0, c = n;
+        do {
+            c = (c + 63) >> 6;
+            lv += c;
+        } while (c > 64);
+        out.listC[0] = 0;
+        out.listC[1] = 0;
+        out.listC[2] = n;
+        out.listC[3] = 0;
+        out.listC[4] = 0;
+        out.counters[TK_CNT_C] = 1;
+        out.counters[TK_CNT_CBYTES] = n;
+        out.counters[TK_CNT_CLEVELS] = lv;
+    } else {
+        const int b = tk_bin_of(n);
+        uint32_t* e = out.listM + 3 * (uint64_t)bins.off[b];
+        e[0] = 0;
+        e[1] = 0;
+        e[2] = n;
+        out.counters[TK_CNT_BIN0 + b] = 1;
+    }
+}
