@@ -69,7 +69,7 @@ struct tk_core {
     // workspace
     Buf text, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, tok1, cnt, tokbase, staging, listB, listC,
         counters, total, partial, rkb, prof, mt_key, mt_rep, dup_list, coll_list, g_id, g_rk, g_nx, g_pv, g_lv, out_tokens, out_tok_off, allowed,
-        tile_np, tile_nt, doc_pid, mt_aux, mt_res_cnt, mt_res_tok;
+        tile_np, tile_nt, tile_nmiss, doc_pid, mt_slots, wbin, wave_pieces;
     uint64_t chunk_bytes = 1ull << 30;
     int dbg = 0;
     // instrumentation
@@ -208,8 +208,8 @@ extern "C" void tk_destroy(tk_core* c) {
                    &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off, &c->brk, &c->docb,
                    &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->tok1, &c->cnt, &c->tokbase, &c->staging,
                    &c->listB, &c->listC, &c->counters, &c->total, &c->partial, &c->rkb, &c->prof, &c->mt_key, &c->mt_rep, &c->dup_list, &c->coll_list, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv,
-                   &c->out_tokens, &c->out_tok_off, &c->allowed, &c->tile_np, &c->tile_nt, &c->doc_pid, &c->mt_aux, &c->mt_res_cnt,
-                   &c->mt_res_tok})
+                   &c->out_tokens, &c->out_tok_off, &c->allowed, &c->tile_np, &c->tile_nt, &c->tile_nmiss, &c->doc_pid, &c->mt_slots,
+                   &c->wbin, &c->wave_pieces})
         release(*b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (int i = 0; i < 4; ++i) {
@@ -219,6 +219,9 @@ extern "C" void tk_destroy(tk_core* c) {
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     delete c;
 }
+
+// entries of the piece-id space of an n-byte chunk: TKF_CAP per tile (a tile's pieces form a run at tile * TKF_CAP)
+static uint64_t tk_pid_cap(uint64_t n) { return (n / TK_TILE + 1) * TKF_CAP + 64; }
 
 static uint32_t grid_for(uint64_t items, uint32_t per_block, uint32_t cap) {
     uint64_t g = (items + per_block - 1) / per_block;
@@ -481,10 +484,18 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
     TRY(ensure(c->total, 16));
     TRY(ensure(c->tile_np, (ntiles + 2) * 4));
     TRY(ensure(c->tile_nt, (ntiles + 2) * 4));
+    TRY(ensure(c->tile_nmiss, (ntiles + 2) * 4));
     TRY(ensure(c->doc_pid, (n_docs + 2) * 4));
-    TRY(ensure(c->tok1, ntiles * TKF_CAP * 4));
-    TRY(ensure(c->cnt, ntiles * TKF_CAP * 4));
-    TRY(ensure(c->staging, (n + 64) * 4));
+    TRY(ensure(c->wbin, (TK_NBIN * TKD_WAVES + 2) * 4));
+    TRY(ensure(c->wave_pieces, 16384 * 4));
+    const uint64_t pid_cap = tk_pid_cap(n);
+    TRY(ensure(c->tok1, pid_cap * 4));
+    TRY(ensure(c->cnt, pid_cap * 4));
+    TRY(ensure(c->staging, pid_cap * 4));
+    if (pretok_only) {
+        TRY(ensure(c->out_tokens, pid_cap * 4));
+        d_out = c->out_tokens.as<uint32_t>();
+    }
     TkBins bins;
     uint64_t pool = 0;
     for (int b = 0; b < TK_NBIN; ++b) {
@@ -501,8 +512,11 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
     uint32_t *ss = nullptr, *si = nullptr, *docb = nullptr;
     uint32_t* counters = c->counters.as<uint32_t>();
     uint32_t *tok1 = c->tok1.as<uint32_t>(), *cnt = c->cnt.as<uint32_t>(), *stg = c->staging.as<uint32_t>();
-    TkFrontOut fo{starts, c->tile_np.as<uint32_t>(), tok1, cnt, c->listB.as<uint32_t>(), c->listC.as<uint32_t>(), counters, c->doc_pid.as<uint32_t>()};
-    TkMissTableF mt{nullptr, nullptr, nullptr, nullptr, nullptr};
+    uint32_t *tile_np = c->tile_np.as<uint32_t>(), *tile_nt = c->tile_nt.as<uint32_t>();
+    // The per-tile miss lists (indexed like piece ids) live in memory that is not needed until the merges start:
+    // starts in the staging area, index | length in the output region (both hold tk_pid_cap(n) entries).
+    TkFrontOut fo{starts, tile_np, tok1, cnt, c->tile_nmiss.as<uint32_t>(), stg, d_out, c->listC.as<uint32_t>(), counters, c->doc_pid.as<uint32_t>()};
+    TkMissSlot* mt = nullptr;
     uint64_t nB = 0, nC = 0;
     if (n > 0 && !single_piece) {
         if (use_special) {
@@ -529,25 +543,19 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
                                    c->spec_max_len, ss, si, brk);
             }));
         }
-        if (n > 32768 && !pretok_only) {  // in-call de-duplication of missed pieces pays for its table resets only on real batches
-            TRY(ensure(c->mt_key, (8ull << TK_MT_BITS)));
-            TRY(ensure(c->mt_aux, (8ull << TK_MT_BITS)));
-            TRY(ensure(c->mt_rep, (4ull << TK_MT_BITS)));
-            TRY(ensure(c->mt_res_cnt, (4ull << TK_MT_BITS)));
-            TRY(ensure(c->mt_res_tok, (4ull << TK_MT_BITS)));
-            HIPCHK(hipMemsetAsync(c->mt_key.p, 0xFF, (8ull << TK_MT_BITS), s));
-            HIPCHK(hipMemsetAsync(c->mt_aux.p, 0xFF, (8ull << TK_MT_BITS), s));
-            mt = TkMissTableF{c->mt_key.as<unsigned long long>(), c->mt_aux.as<unsigned long long>(), c->mt_rep.as<uint32_t>(),
-                              c->mt_res_cnt.as<uint32_t>(), c->mt_res_tok.as<uint32_t>()};
+        if (n > 32768 && !pretok_only) {  // in-call de-duplication of missed pieces pays for its table reset only on real batches
+            TRY(ensure(c->mt_slots, sizeof(TkMissSlot) << TK_MT_BITS));
+            HIPCHK(hipMemsetAsync(c->mt_slots.p, 0xFF, sizeof(TkMissSlot) << TK_MT_BITS, s));
+            mt = c->mt_slots.as<TkMissSlot>();
         }
         TRY(timed(c, s, "tk_k_front", [&] {
             const dim3 grid((uint32_t)ntiles);
-            if (T.pattern == TK_PAT_R50K) hipLaunchKernelGGL((tk_k_front<TK_PAT_R50K>), grid, dim3(256), 0, s, T, d_text, n, base, brk, docb, ss, si, d_doc_off, n_docs, fo, bins, mt, c->dbg);
-            else if (T.pattern == TK_PAT_CL100K) hipLaunchKernelGGL((tk_k_front<TK_PAT_CL100K>), grid, dim3(256), 0, s, T, d_text, n, base, brk, docb, ss, si, d_doc_off, n_docs, fo, bins, mt, c->dbg);
-            else hipLaunchKernelGGL((tk_k_front<TK_PAT_O200K>), grid, dim3(256), 0, s, T, d_text, n, base, brk, docb, ss, si, d_doc_off, n_docs, fo, bins, mt, c->dbg);
+            if (T.pattern == TK_PAT_R50K) hipLaunchKernelGGL((tk_k_front<TK_PAT_R50K>), grid, dim3(256), 0, s, T, d_text, n, base, brk, docb, ss, si, d_doc_off, n_docs, fo, c->dbg);
+            else if (T.pattern == TK_PAT_CL100K) hipLaunchKernelGGL((tk_k_front<TK_PAT_CL100K>), grid, dim3(256), 0, s, T, d_text, n, base, brk, docb, ss, si, d_doc_off, n_docs, fo, c->dbg);
+            else hipLaunchKernelGGL((tk_k_front<TK_PAT_O200K>), grid, dim3(256), 0, s, T, d_text, n, base, brk, docb, ss, si, d_doc_off, n_docs, fo, c->dbg);
         }));
     } else if (n > 0) {
-        TRY(timed(c, s, "tk_k_single_front", [&] { hipLaunchKernelGGL(tk_k_single_front, dim3(1), dim3(64), 0, s, T, d_text, (uint32_t)n, fo, bins); }));
+        TRY(timed(c, s, "tk_k_single_front", [&] { hipLaunchKernelGGL(tk_k_single_front, dim3(1), dim3(64), 0, s, T, d_text, (uint32_t)n, fo); }));
     }
     if (pretok_only) {  // debugging / test entry: piece offsets only
         uint64_t P = 0;
@@ -573,6 +581,17 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         return TK_OK;
     }
     if (n > 0) {
+        uint32_t* wbin = c->wbin.as<uint32_t>();
+        TRY(timed(c, s, "tk_k_dedup", [&] {
+            hipLaunchKernelGGL(tk_k_dedup, dim3(TKD_WAVES / 4), dim3(256), 0, s, d_text, ntiles, fo.tile_nmiss, fo.miss_s, fo.miss_kl, mt, cnt, wbin, c->dbg);
+        }));
+        TRY(timed(c, s, "tk_k_scan_small", [&] {
+            hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, wbin, (uint64_t)TK_NBIN * TKD_WAVES + 1, c->total.as<uint64_t>());
+        }));
+        TRY(timed(c, s, "tk_k_binfill", [&] {
+            hipLaunchKernelGGL(tk_k_binfill, dim3(TKD_WAVES / 4), dim3(256), 0, s, ntiles, fo.tile_nmiss, fo.miss_s, fo.miss_kl, wbin, c->listB.as<uint32_t>(), bins,
+                               counters);
+        }));
         uint32_t hc[TK_CNT_N];
         HIPCHK(hipMemcpyAsync(hc, counters, sizeof hc, hipMemcpyDeviceToHost, s));
         HIPCHK(hipStreamSynchronize(s));
@@ -625,25 +644,23 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
                                    c->g_lv.as<uint64_t>(), tok1, cnt, stg);
             }));
         }
-        if (mt.key) {
+        if (mt) {
             TRY(timed(c, s, "tk_k_dup_publish", [&] { hipLaunchKernelGGL(tk_k_dup_publishF, dim3(4096), dim3(256), 0, s, mt, tok1, cnt); }));
         }
         TRY(timed(c, s, "tk_k_tile_finish", [&] {
-            hipLaunchKernelGGL(tk_k_tile_finish, dim3(grid_for(ntiles, 4, 4096)), dim3(256), 0, s, ntiles, c->tile_np.as<uint32_t>(), mt, tok1, cnt,
-                               c->tile_nt.as<uint32_t>(), c->total.as<unsigned long long>() + 1);
+            hipLaunchKernelGGL(tk_k_tile_finish, dim3(4096), dim3(256), 0, s, ntiles, tile_np, mt, tok1, cnt, tile_nt, c->wave_pieces.as<uint32_t>());
         }));
+        hipLaunchKernelGGL(tk_k_sum_pieces, dim3(1), dim3(1024), 0, s, c->wave_pieces.as<uint32_t>(), 16384u, c->total.as<unsigned long long>() + 1);
         TRY(timed(c, s, "tk_k_scan_small", [&] {
-            hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, c->tile_nt.as<uint32_t>(), ntiles, c->total.as<uint64_t>());
+            hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, tile_nt, ntiles, c->total.as<uint64_t>());
         }));
         TRY(timed(c, s, "tk_k_back", [&] {
-            hipLaunchKernelGGL(tk_k_back, dim3(grid_for(ntiles, 4, 16384)), dim3(256), 0, s, ntiles, c->tile_np.as<uint32_t>(), c->tile_nt.as<uint32_t>(),
-                               tok1, cnt, stg, d_out);
+            hipLaunchKernelGGL(tk_k_back, dim3(grid_for(ntiles, 4, 16384)), dim3(256), 0, s, ntiles, tile_np, tile_nt, tok1, cnt, stg, d_out);
         }));
     }
     if (d_tok_off) {
         TRY(timed(c, s, "tk_k_docoff", [&] {
-            hipLaunchKernelGGL(tk_k_docoffF, dim3(grid_for(n_docs + 1, 256, 4096)), dim3(256), 0, s, n_docs, c->doc_pid.as<uint32_t>(),
-                               c->tile_nt.as<uint32_t>(), cnt, c->total.as<uint64_t>(), tok_base_global, d_tok_off);
+            hipLaunchKernelGGL(tk_k_docoffF, dim3(grid_for(n_docs + 1, 4, 8192)), dim3(256), 0, s, n_docs, c->doc_pid.as<uint32_t>(), tile_nt, cnt, c->total.as<uint64_t>(), tok_base_global, d_tok_off);
         }));
     }
     uint64_t tp[2] = {0, 0};  // tokens, pieces
@@ -680,7 +697,7 @@ static int encode_device_locked(tk_core* c, hipStream_t s, const uint8_t* d_utf8
                                 const uint64_t* h_doc_off, uint64_t n_docs, bool use_special, uint64_t* n_tokens_out) {
     c->st_bytes = c->st_pieces = c->st_tokens = c->st_medium = c->st_long = 0;
     c->st_docs = n_docs;
-    TRY(ensure(c->out_tokens, (n_bytes + 64) * 4));
+    TRY(ensure(c->out_tokens, tk_pid_cap(n_bytes) * 4));  // (the front kernel parks its miss lists here: tk_pid_cap entries)
     TRY(ensure(c->out_tok_off, (n_docs + 2) * 8));
     uint32_t* d_out = c->out_tokens.as<uint32_t>();
     uint64_t* d_tok_off = c->out_tok_off.as<uint64_t>();
@@ -807,7 +824,7 @@ extern "C" int tk_encode_single_piece(tk_core* c, const uint8_t* piece, uint64_t
     TRY(ensure(c->text, len + 256));
     if (len) HIPCHK(hipMemcpyAsync(c->text.p, piece, len, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync((uint8_t*)c->text.p + len, 0, 128, s));
-    TRY(ensure(c->out_tokens, (len + 64) * 4));
+    TRY(ensure(c->out_tokens, tk_pid_cap(len) * 4));
     uint64_t total = 0;
     TRY(run_chunk(c, s, c->text.as<uint8_t>(), len, nullptr, 0, 0, false, true, c->out_tokens.as<uint32_t>(), 0, nullptr, &total));
     HIPCHK(hipStreamSynchronize(s));

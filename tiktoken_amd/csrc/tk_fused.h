@@ -18,25 +18,29 @@
 #pragma once
 #include "tk_kernels.h"
 
-#define TKF_CAP 4096  // piece ids per tile (a tile of 4096 bytes starts at most 4096 pieces)
 #define TKF_NONE 0xFFFFFFFFu
+#define TKF_CAP 4096  // piece ids per tile: pid = tile * TKF_CAP + k (a 4096-byte tile starts at most 4096 pieces)
 
 struct TkFrontOut {
-    uint32_t* starts;    // piece-start bitmap (n/32 words; each tile stores its own 128 words)
-    uint32_t* tile_np;   // pieces per tile
-    uint32_t* tok1;      // [ntiles * TKF_CAP] token (count 1) or staging position of the tokens (count > 1)
-    uint32_t* cnt;       // [ntiles * TKF_CAP] token count, or TK_DUP_FLAG | slot
-    uint32_t* listM;     // {pid, start, len} triples, binned by length
-    uint32_t* listC;     // {pid, start, len, scratch bytes before, tree levels before} for > 1 KiB pieces
+    uint32_t* starts;     // piece-start bitmap (n/32 words; each tile stores its own 128 words)
+    uint32_t* tile_np;    // pieces per tile
+    uint32_t* tok1;       // [piece id] token (count 1) or staging position of the tokens (count > 1)
+    uint32_t* cnt;        // [piece id] token count, or TK_DUP_FLAG | slot
+    uint32_t* tile_nmiss; // pieces of the tile that are not a token (and at most TK_GLANE_MAX bytes long)
+    uint32_t* miss_s;     // [run base + j] their start ...
+    uint32_t* miss_kl;    // ... and (index in the run) | (length - 1) << 12; consumed by tk_k_dedup
+    uint32_t* listC;      // {pid, start, len, scratch bytes before, tree levels before} for > 1 KiB pieces
     uint32_t* counters;
-    uint32_t* doc_pid;   // [n_docs] piece id at which each document starts (TKF_NONE: no piece)
+    uint32_t* doc_pid;    // [n_docs] piece id at which each document starts (TKF_NONE: no piece)
 };
-struct TkMissTableF {
-    unsigned long long* key;  // [1 << TK_MT_BITS], ~0 = empty
-    unsigned long long* aux;  // (claimant start << 32) | length, ~0 until the claimant has written it
-    uint32_t* rep;            // claimant pid
-    uint32_t* res_cnt;        // published after the merges
-    uint32_t* res_tok;
+// In-call de-duplication of missed pieces: open-addressed, one 32-byte slot per distinct piece.
+struct TkMissSlot {
+    unsigned long long key;  // ~0 = empty
+    unsigned long long aux;  // (claimant start << 32) | length; ~0 until the claimant has written it
+    uint32_t pid;            // claimant piece id
+    uint32_t res_cnt;        // claimant's result, published after the merges
+    uint32_t res_tok;
+    uint32_t pad;
 };
 
 // last certain piece start at or before `pos` (exists: position 0 and document starts are hard starts)
@@ -79,12 +83,27 @@ __device__ __forceinline__ uint64_t tk_key_of_lds(const uint8_t* raw, uint32_t o
     return h;
 }
 
+// a piece for the tree kernel: reserve its scratch (4 uint32 per byte + the 64-ary min-tree levels)
+__device__ __forceinline__ void tk_append_tree(uint32_t* listC, uint32_t* counters, uint32_t pid, uint32_t s, uint32_t len) {
+    uint32_t lv = 0, c = len;
+    do {
+        c = (c + 63) >> 6;
+        lv += c;
+    } while (c > 64);
+    const uint32_t gi = atomicAdd(&counters[TK_CNT_C], 1u);
+    uint32_t* e = listC + 5 * (uint64_t)gi;
+    e[0] = pid;
+    e[1] = s;
+    e[2] = len;
+    e[3] = atomicAdd(&counters[TK_CNT_CBYTES], len);
+    e[4] = atomicAdd(&counters[TK_CNT_CLEVELS], lv);
+}
+
 template <int PAT>
 __global__ __launch_bounds__(256) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
                                                   const uint32_t* __restrict__ brk, const uint32_t* __restrict__ docb,
                                                   const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si,
-                                                  const uint64_t* __restrict__ doc_off, uint64_t n_docs, TkFrontOut out, TkBins bins,
-                                                  TkMissTableF mt, int dbg) {
+                                                  const uint64_t* __restrict__ doc_off, uint64_t n_docs, TkFrontOut out, int dbg) {
     constexpr int pat = PAT;
     constexpr int BM_BYTES = TKB_KINDS * (TK2_NSEG + 2) * 8;
     __shared__ __attribute__((aligned(16))) uint8_t raw[TK2_WIN + 16];
@@ -92,7 +111,7 @@ __global__ __launch_bounds__(256) void tk_k_front(TkTables T, const uint8_t* __r
     __shared__ __attribute__((aligned(16))) uint8_t pool[BM_BYTES + TK2_CLIST * 2];  // bitmaps + certain list; later the piece list
     __shared__ uint32_t bits[TK_TILE / 32];
     __shared__ uint32_t woff[TK_TILE / 32 + 1];
-    __shared__ uint32_t cn, np_sh, need_walk, last_end_sh;
+    __shared__ uint32_t cn, np_sh, nmiss_sh, need_walk, last_end_sh;
     __shared__ uint32_t certm[16];
     __shared__ uint32_t brkw[TK2_WIN / 32 + 1], ssw[TK2_WIN / 32 + 1], siw[TK2_WIN / 32 + 1], docw[TK2_WIN / 32 + 1];
     __shared__ __attribute__((aligned(16))) uint8_t st1[0x1100];
@@ -125,6 +144,7 @@ __global__ __launch_bounds__(256) void tk_k_front(TkTables T, const uint8_t* __r
     if (tid < 16) certm[tid] = tk_certain_mask(PAT, tid);
     if (tid == 0) {
         cn = 0;
+        nmiss_sh = 0;
         need_walk = 0;
         last_end_sh = (uint32_t)(tile_end - tile_start) + TK2_LEFT;
     }
@@ -341,10 +361,13 @@ __global__ __launch_bounds__(256) void tk_k_front(TkTables T, const uint8_t* __r
         uint32_t pc = tid < TK_TILE / 32 ? __popc(bits[tid]) : 0u, tot;
         uint32_t ex = tk_block_exscan_256(pc, &tot, scan_sh);
         if (tid < TK_TILE / 32) woff[tid] = ex;
-        if (tid == 0) np_sh = tot;
+        if (tid == 0) {
+            np_sh = tot;
+            out.tile_np[tile] = tot;
+        }
     }
     __syncthreads();
-    const uint32_t np = np_sh;
+    const uint32_t np = np_sh, run_base = (uint32_t)tile * TKF_CAP;
     if (tid < TK_TILE / 32) {
         uint32_t v = bits[tid], o = woff[tid];
         while (v) {
@@ -355,17 +378,16 @@ __global__ __launch_bounds__(256) void tk_k_front(TkTables T, const uint8_t* __r
         const uint64_t wgp = tile_start / 32 + tid;
         if (wgp * 32 < n) out.starts[wgp] = bits[tid];
     }
-    if (tid == 0) out.tile_np[tile] = np;
     __syncthreads();
     // ---- F: whole-piece probe, one lane per piece
     const uint32_t last_end = last_end_sh;
     for (uint32_t k0 = 0; k0 < np; k0 += 256) {
         const uint32_t k = k0 + tid;
-        uint32_t cat = 0, s_loc = 0, len = 0;
+        uint32_t cat = 0, len = 0;  // cat 1: not a token (-> miss list), 2: longer than the lane-group kernels take (-> tree list)
         uint64_t gs = 0;
-        const uint64_t pid = tile * TKF_CAP + k;
+        const uint32_t pid = run_base + k;
         if (k < np) {
-            s_loc = plist[k];
+            const uint32_t s_loc = plist[k];
             const uint32_t e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
             len = e_loc - s_loc;
             gs = (uint64_t)(base + s_loc);
@@ -379,7 +401,7 @@ __global__ __launch_bounds__(256) void tk_k_front(TkTables T, const uint8_t* __r
                     if (doc_off[mid] < want) lo = mid + 1;
                     else hi = mid;
                 }
-                for (; lo < n_docs && doc_off[lo] == want; ++lo) out.doc_pid[lo] = (uint32_t)pid;
+                for (; lo < n_docs && doc_off[lo] == want; ++lo) out.doc_pid[lo] = pid;
             }
             if ((cb & 15u) == TK_C_SPEC) {
                 out.tok1[pid] = tk_special_id(T, text, gs, len);
@@ -387,72 +409,170 @@ __global__ __launch_bounds__(256) void tk_k_front(TkTables T, const uint8_t* __r
             } else {
                 const bool in_lds = e_loc + 8u <= (uint32_t)TK2_WIN;
                 const uint64_t key = in_lds ? tk_key_of_lds(raw, s_loc, len) : tk_key_of_text(text, gs, len);
-                uint32_t r = tk_probe_piece(T, key, len, [&](uint32_t off) { return tk_equal_bytes(text, gs, T.tok_bytes, off, len); });
+                uint32_t r = (dbg & 2) ? len : tk_probe_piece(T, key, len, [&](uint32_t off) { return tk_equal_bytes(text, gs, T.tok_bytes, off, len); });
+                if ((dbg & 8) && r == TK_RANK_MAX) r = 0;  // (perf experiments: 2 = no probe, 8 = no deferred pieces)
                 if (r != TK_RANK_MAX) {
                     out.tok1[pid] = r;
                     out.cnt[pid] = 1;
-                } else if (len > TK_GLANE_MAX) {
-                    cat = 1 + TK_NBIN;
                 } else {
-                    cat = 1 + (uint32_t)tk_bin_of(len);
-                    if (mt.key && !(dbg & 256)) {
-                        unsigned long long kk = tk_mix64(key ^ ((uint64_t)len * 0xA24BAED4963EE407ull));
-                        if (dbg & 512) kk &= 0xFFFull;  // test hook: force collisions between different pieces
-                        if (kk == TK_EMPTY_KEY) kk = 0;
-                        uint32_t i = (uint32_t)(kk >> 7) & ((1u << TK_MT_BITS) - 1u);
-                        for (int t = 0; t < TK_MT_PROBES; ++t) {
-                            unsigned long long cur = mt.key[i];
-                            if (cur == TK_EMPTY_KEY) cur = atomicCAS(&mt.key[i], TK_EMPTY_KEY, kk);
-                            if (cur == TK_EMPTY_KEY) {  // claimed: this piece is the one that gets merged
-                                mt.rep[i] = (uint32_t)pid;
-                                __hip_atomic_store(&mt.aux[i], (gs << 32) | len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                break;
-                            }
-                            if (cur == kk) {
-                                // same hash: a duplicate only if the claimant's bytes are identical (verified here, now)
-                                const unsigned long long a = __hip_atomic_load(&mt.aux[i], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                if (a != TK_EMPTY_KEY && (uint32_t)a == len && tk_equal_bytes(text, gs, text, (uint32_t)(a >> 32), len)) {
-                                    out.cnt[pid] = TK_DUP_FLAG | i;
-                                    cat = 0;
-                                    break;
-                                }
-                                // claimant not visible yet, or different bytes: keep probing (ends as a merge of its own)
-                            }
-                            i = (i + 1) & ((1u << TK_MT_BITS) - 1u);
-                        }
-                    }
+                    cat = len > TK_GLANE_MAX ? 2u : 1u;
                 }
             }
         }
-        // appends: rare once duplicates are filtered -> one atomic per (wave, bin)
-        if (__ballot(cat != 0)) {
-            for (uint32_t b = 0; b < TK_NBIN; ++b) {
-                const uint64_t m = __ballot(cat == 1 + b);
-                if (!m) continue;
-                const int leader = __ffsll((unsigned long long)m) - 1;
-                uint32_t at = 0;
-                if (lane == leader) at = atomicAdd(&out.counters[TK_CNT_BIN0 + b], (uint32_t)__popcll(m));
-                at = __shfl(at, leader, 64);
-                if (cat == 1 + b) {
-                    uint32_t* e = out.listM + 3 * (uint64_t)(bins.off[b] + at + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
-                    e[0] = (uint32_t)pid;
-                    e[1] = (uint32_t)gs;
-                    e[2] = len;
+        const uint64_t m = __ballot(cat == 1u);
+        if (m) {  // the tile's own miss list (no global atomics)
+            const int leader = __ffsll((unsigned long long)m) - 1;
+            uint32_t at = 0;
+            if (lane == leader) at = atomicAdd(&nmiss_sh, (uint32_t)__popcll(m));
+            at = __shfl(at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (cat == 1u) {
+                out.miss_s[run_base + at] = (uint32_t)gs;
+                out.miss_kl[run_base + at] = k | ((len - 1u) << 12);
+            }
+        }
+        if (cat == 2u) tk_append_tree(out.listC, out.counters, pid, (uint32_t)gs, len);
+    }
+    __syncthreads();
+    if (tid == 0) out.tile_nmiss[tile] = nmiss_sh;
+}
+
+// Missed pieces -> claim a slot of the miss table (first occurrence: gets merged) or find the slot already
+// claimed by identical bytes (duplicate: cnt[pid] = TK_DUP_FLAG | slot, resolved after the merges).  Identity is
+// verified here, byte for byte against the claimant's text, so a hash collision only costs a redundant merge.
+//
+// The first occurrences then have to be listed by length bin for the merge kernels.  Same-address returning
+// atomics run at only 25..130 M/s on this multi-XCD part (one per (wave, bin) cost 4.5 ms per GiB, one per tile
+// 8 ms), so the lists are built without any: pass 1 (tk_k_dedup) marks the duplicates in the miss list and
+// counts per (wave, bin); tk_k_scan_small turns the counts into offsets; pass 2 (tk_k_binfill) walks the same
+// lists in the same order and writes the entries.  Both passes use the same fixed wave -> tile-group mapping.
+#define TKD_GROUP 4     // tiles per wave step
+#define TKD_WAVES 8192  // waves of the two passes (2048 workgroups)
+#define TKD_DUP 0x80000000u
+
+struct TkMissGroup {  // the miss lists of TKD_GROUP consecutive tiles, flattened
+    uint32_t pre[TKD_GROUP + 1];
+    __device__ __forceinline__ void load(const uint32_t* __restrict__ tile_nmiss, uint64_t t0, uint64_t ntiles, int lane) {
+        uint32_t nm_l = 0;
+        if (lane < TKD_GROUP && t0 + lane < ntiles) nm_l = tile_nmiss[t0 + lane];
+        pre[0] = 0;
+#pragma unroll
+        for (int q = 0; q < TKD_GROUP; ++q) pre[q + 1] = pre[q] + __shfl(nm_l, q, 64);
+    }
+    __device__ __forceinline__ uint32_t total() const { return pre[TKD_GROUP]; }
+    // flat index -> position in the miss arrays; *run_base gets the first piece id of that tile
+    __device__ __forceinline__ uint32_t locate(uint32_t f, uint64_t t0, uint32_t* run_base) const {
+        uint32_t q = 0;
+#pragma unroll
+        for (int i = 1; i < TKD_GROUP; ++i) q += f >= pre[i];
+        *run_base = (uint32_t)(t0 + q) * TKF_CAP;
+        return *run_base + (f - pre[q]);
+    }
+};
+
+__global__ __launch_bounds__(256) void tk_k_dedup(const uint8_t* __restrict__ text, uint64_t ntiles, const uint32_t* __restrict__ tile_nmiss,
+                                                  const uint32_t* __restrict__ miss_s, uint32_t* __restrict__ miss_kl,
+                                                  TkMissSlot* __restrict__ mt, uint32_t* __restrict__ cnt, uint32_t* __restrict__ wbin, int dbg) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t ngroups = (ntiles + TKD_GROUP - 1) / TKD_GROUP;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    uint32_t nb[TK_NBIN];
+#pragma unroll
+    for (int b = 0; b < TK_NBIN; ++b) nb[b] = 0;
+    for (uint64_t g = wave; g < ngroups; g += TKD_WAVES) {
+        const uint64_t t0 = g * TKD_GROUP;
+        TkMissGroup grp;
+        grp.load(tile_nmiss, t0, ntiles, lane);
+        for (uint32_t j0 = 0; j0 < grp.total(); j0 += 64) {
+            const uint32_t f = j0 + lane;
+            uint32_t bin = TK_NBIN;
+            if (f < grp.total()) {
+                uint32_t rb;
+                const uint32_t mi = grp.locate(f, t0, &rb);
+                const uint32_t kl = miss_kl[mi];
+                const uint32_t pid = rb + (kl & 4095u), s = miss_s[mi], len = ((kl >> 12) & 1023u) + 1u;
+                bin = (uint32_t)tk_bin_of(len);
+                if (mt && !(dbg & 256)) {
+                    const uint64_t key = tk_key_of_text(text, s, len);
+                    unsigned long long kk = tk_mix64(key ^ ((uint64_t)len * 0xA24BAED4963EE407ull));
+                    if (dbg & 512) kk &= 0xFFFull;  // test hook: force collisions between different pieces
+                    if (kk == TK_EMPTY_KEY) kk = 0;
+                    uint32_t i = (uint32_t)(kk >> 7) & ((1u << TK_MT_BITS) - 1u);
+                    for (int p = 0; p < TK_MT_PROBES; ++p) {
+                        // Slots are written once (empty -> final), so an ordinary cached load can only be stale towards
+                        // "empty"; then the atomic decides.  Hot duplicates are served from the XCD's L2 this way instead
+                        // of queueing at the memory side.
+                        const ulonglong2 ka = *(const ulonglong2*)&mt[i].key;
+                        unsigned long long cur = ka.x;
+                        if (cur == TK_EMPTY_KEY) cur = atomicCAS(&mt[i].key, TK_EMPTY_KEY, kk);
+                        if (cur == TK_EMPTY_KEY) {  // claimed: this piece is the one that gets merged
+                            mt[i].pid = pid;
+                            __hip_atomic_store(&mt[i].aux, ((unsigned long long)s << 32) | len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                        if (cur == kk) {
+                            unsigned long long a = ka.y;
+                            if (a == TK_EMPTY_KEY) a = __hip_atomic_load(&mt[i].aux, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            if (a != TK_EMPTY_KEY && (uint32_t)a == len && ((dbg & 2048) || tk_equal_bytes(text, s, text, (uint32_t)(a >> 32), len))) {
+                                if (!(dbg & 4096)) cnt[pid] = TK_DUP_FLAG | i;
+                                miss_kl[mi] = kl | TKD_DUP;
+                                bin = TK_NBIN;
+                                break;
+                            }
+                            // claimant not visible yet, or different bytes behind the same hash: keep probing
+                        }
+                        i = (i + 1) & ((1u << TK_MT_BITS) - 1u);
+                    }
                 }
             }
-            if (cat == 1 + TK_NBIN) {
-                uint32_t lv = 0, c = len;
-                do {
-                    c = (c + 63) >> 6;
-                    lv += c;
-                } while (c > 64);
-                const uint32_t gi = atomicAdd(&out.counters[TK_CNT_C], 1u);
-                uint32_t* e = out.listC + 5 * (uint64_t)gi;
-                e[0] = (uint32_t)pid;
-                e[1] = (uint32_t)gs;
-                e[2] = len;
-                e[3] = atomicAdd(&out.counters[TK_CNT_CBYTES], len);
-                e[4] = atomicAdd(&out.counters[TK_CNT_CLEVELS], lv);
+#pragma unroll
+            for (int b = 0; b < TK_NBIN; ++b) nb[b] += (uint32_t)__popcll(__ballot(bin == (uint32_t)b));
+        }
+    }
+    if (lane == 0) {
+#pragma unroll
+        for (int b = 0; b < TK_NBIN; ++b) wbin[(uint32_t)b * TKD_WAVES + wave] = nb[b];  // bin-major: one scan gives every offset
+    }
+}
+
+// pass 2: wscan = exclusive scan of wbin (TK_NBIN * TKD_WAVES + 1 entries; the last one is the grand total)
+__global__ __launch_bounds__(256) void tk_k_binfill(uint64_t ntiles, const uint32_t* __restrict__ tile_nmiss, const uint32_t* __restrict__ miss_s,
+                                                    const uint32_t* __restrict__ miss_kl, const uint32_t* __restrict__ wscan,
+                                                    uint32_t* __restrict__ listM, TkBins bins, uint32_t* __restrict__ counters) {
+    const int lane = threadIdx.x & 63;
+    const uint64_t ngroups = (ntiles + TKD_GROUP - 1) / TKD_GROUP;
+    const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    uint32_t at[TK_NBIN];
+#pragma unroll
+    for (int b = 0; b < TK_NBIN; ++b) at[b] = bins.off[b] + wscan[(uint32_t)b * TKD_WAVES + wave] - wscan[(uint32_t)b * TKD_WAVES];
+    if (wave == 0 && lane < TK_NBIN) counters[TK_CNT_BIN0 + lane] = wscan[(uint32_t)(lane + 1) * TKD_WAVES] - wscan[(uint32_t)lane * TKD_WAVES];
+    for (uint64_t g = wave; g < ngroups; g += TKD_WAVES) {
+        const uint64_t t0 = g * TKD_GROUP;
+        TkMissGroup grp;
+        grp.load(tile_nmiss, t0, ntiles, lane);
+        for (uint32_t j0 = 0; j0 < grp.total(); j0 += 64) {
+            const uint32_t f = j0 + lane;
+            uint32_t bin = TK_NBIN, pid = 0, s = 0, len = 0;
+            if (f < grp.total()) {
+                uint32_t rb;
+                const uint32_t mi = grp.locate(f, t0, &rb);
+                const uint32_t kl = miss_kl[mi];
+                if (!(kl & TKD_DUP)) {
+                    pid = rb + (kl & 4095u);
+                    s = miss_s[mi];
+                    len = ((kl >> 12) & 1023u) + 1u;
+                    bin = (uint32_t)tk_bin_of(len);
+                }
+            }
+#pragma unroll
+            for (int b = 0; b < TK_NBIN; ++b) {
+                const uint64_t m = __ballot(bin == (uint32_t)b);
+                if (bin == (uint32_t)b) {
+                    uint32_t* q = listM + 3 * (uint64_t)(at[b] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
+                    q[0] = pid;
+                    q[1] = s;
+                    q[2] = len;
+                }
+                at[b] += (uint32_t)__popcll(m);
             }
         }
     }
@@ -721,117 +841,177 @@ __global__ __launch_bounds__(256) void tk_k_mergeF_long(TkTables T, const uint8_
 // ------------------------------------------------------------------------------------------
 // back end
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tk_k_dup_publishF(TkMissTableF mt, const uint32_t* __restrict__ tok1, const uint32_t* __restrict__ cnt) {
+__global__ __launch_bounds__(256) void tk_k_dup_publishF(TkMissSlot* __restrict__ mt, const uint32_t* __restrict__ tok1,
+                                                         const uint32_t* __restrict__ cnt) {
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < (1u << TK_MT_BITS); i += gridDim.x * 256u) {
-        if (mt.key[i] == TK_EMPTY_KEY) continue;
-        const uint32_t rep = mt.rep[i];
-        mt.res_cnt[i] = cnt[rep];
-        mt.res_tok[i] = tok1[rep];
+        if (mt[i].key == TK_EMPTY_KEY) continue;
+        const uint32_t rep = mt[i].pid;
+        mt[i].res_cnt = cnt[rep];
+        mt[i].res_tok = tok1[rep];
     }
 }
 
-// one wavefront per tile: duplicates take their claimant's published result; token count of the tile
-__global__ __launch_bounds__(256) void tk_k_tile_finish(uint64_t ntiles, const uint32_t* __restrict__ tile_np, TkMissTableF mt,
+// one wavefront per tile, four consecutive pieces per lane (16-byte loads; runs start 16-byte aligned):
+// duplicates take their claimant's published result; token count of the tile
+__global__ __launch_bounds__(256) void tk_k_tile_finish(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const TkMissSlot* __restrict__ mt,
                                                         uint32_t* __restrict__ tok1, uint32_t* __restrict__ cnt, uint32_t* __restrict__ tile_nt,
-                                                        unsigned long long* __restrict__ n_pieces) {
+                                                        uint32_t* __restrict__ wave_pieces) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
-    unsigned long long pieces = 0;
+    uint32_t pieces = 0;
     for (uint64_t t = wave; t < ntiles; t += nwaves) {
-        const uint32_t np = tile_np[t];
+        const uint32_t np = tile_np[t], rb = (uint32_t)t * TKF_CAP;
         pieces += np;
         uint32_t sum = 0;
-        for (uint32_t k = lane; k < np; k += 64) {
-            const uint64_t pid = t * TKF_CAP + k;
-            uint32_t c = cnt[pid];
-            if (c & TK_DUP_FLAG) {
-                const uint32_t slot = c & ~TK_DUP_FLAG;
-                c = mt.res_cnt[slot];
-                cnt[pid] = c;
-                tok1[pid] = mt.res_tok[slot];
+        for (uint32_t k = lane * 4; k < np; k += 256) {
+            const uint32_t pid = rb + k;
+            const uint4 c4 = *(const uint4*)(cnt + pid);
+            uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+            uint2 res[4];
+            bool dup[4];
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {  // all four slot loads in flight together
+                dup[j] = k + j < np && (c[j] & TK_DUP_FLAG);
+                if (k + j >= np) c[j] = 0;
+                if (dup[j]) res[j] = *(const uint2*)&mt[c[j] & ~TK_DUP_FLAG].res_cnt;
             }
-            sum += c;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                if (dup[j]) {
+                    c[j] = res[j].x;
+                    tok1[pid + j] = res[j].y;
+                    cnt[pid + j] = c[j];
+                }
+                sum += c[j];
+            }
         }
         sum = tk_wave_sum_u32(sum);
         if (lane == 0) tile_nt[t] = sum;
     }
-    if (lane == 0 && pieces) atomicAdd(n_pieces, pieces);
+    if (lane == 0) wave_pieces[wave] = pieces;  // (summed by tk_k_sum_pieces: no same-address atomics)
 }
 
-// one wavefront per tile: local scan of the piece counts, tokens to their final positions
-__global__ __launch_bounds__(256) void tk_k_back(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_tb,
-                                                 const uint32_t* __restrict__ tok1, const uint32_t* __restrict__ cnt,
-                                                 const uint32_t* __restrict__ staging, uint32_t* __restrict__ out) {
+// one wavefront per tile, four consecutive pieces per lane: local scan of the piece counts, tokens to their final
+// positions.  Single tokens go out as one 16-byte store per lane; the tokens of a multi-token piece are copied
+// from the staging area by the whole wavefront.
+__global__ __launch_bounds__(256) void tk_k_back(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_tb, const uint32_t* __restrict__ tok1,
+                                                 const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ staging, uint32_t* __restrict__ out) {
+    __shared__ uint32_t mlist_sh[4][256 * 3];
     const int lane = threadIdx.x & 63;
+    uint32_t* mlist = mlist_sh[threadIdx.x >> 6];
     const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
     for (uint64_t t = wave; t < ntiles; t += nwaves) {
-        const uint32_t np = tile_np[t];
+        const uint32_t np = tile_np[t], rb = (uint32_t)t * TKF_CAP;
         uint32_t run = tile_tb[t];
-        for (uint32_t k0 = 0; k0 < np; k0 += 64) {
-            const uint32_t k = k0 + lane;
-            const uint64_t pid = t * TKF_CAP + k;
-            const uint32_t c = k < np ? cnt[pid] : 0u;
-            const uint32_t inc = tk_wave_scan_u32(c, lane);
-            const uint32_t o = run + inc - c;
-            if (c == 1) {
-                out[o] = tok1[pid];
-            } else if (c > 1) {
-                const uint32_t* src = staging + tok1[pid];
-                for (uint32_t i = 0; i < c; ++i) out[o + i] = src[i];
+        for (uint32_t k0 = 0; k0 < np; k0 += 256) {
+            const uint32_t k = k0 + lane * 4;
+            const uint32_t pid = rb + k;
+            uint4 c4 = make_uint4(0, 0, 0, 0), t4 = make_uint4(0, 0, 0, 0);
+            if (k < np) {
+                c4 = *(const uint4*)(cnt + pid);
+                t4 = *(const uint4*)(tok1 + pid);
+            }
+            uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
+            const uint32_t tk[4] = {t4.x, t4.y, t4.z, t4.w};
+#pragma unroll
+            for (int j = 0; j < 4; ++j)
+                if (k + j >= np) c[j] = 0;
+            const uint32_t mine = c[0] + c[1] + c[2] + c[3];
+            const uint32_t inc = tk_wave_scan_u32(mine, lane);
+            const uint32_t o = run + inc - mine;
+            const bool four = c[0] == 1u && c[1] == 1u && c[2] == 1u && c[3] == 1u;
+            if (four) {
+                *(uint4*)(out + o) = t4;  // (4-byte aligned 16-byte store)
+            } else {
+                uint32_t oo = o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (c[j] == 1u) out[oo] = tk[j];
+                    oo += c[j];
+                }
+            }
+            // multi-token pieces of this chunk -> a list in LDS, then eight lanes per piece copy its tokens
+            const uint32_t nmul = (c[0] > 1u) + (c[1] > 1u) + (c[2] > 1u) + (c[3] > 1u);
+            const uint32_t minc = tk_wave_scan_u32(nmul, lane);
+            const uint32_t ntot = __shfl(minc, 63, 64);
+            if (ntot) {
+                uint32_t at = minc - nmul, oj = o;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    if (c[j] > 1u) {
+                        mlist[at * 3] = tk[j];
+                        mlist[at * 3 + 1] = c[j];
+                        mlist[at * 3 + 2] = oj;
+                        ++at;
+                    }
+                    oj += c[j];
+                }
+                __builtin_amdgcn_wave_barrier();
+                for (uint32_t e0 = 0; e0 < ntot; e0 += 8) {
+                    const uint32_t e = e0 + (lane >> 3);
+                    if (e < ntot) {
+                        const uint32_t src = mlist[e * 3], cc = mlist[e * 3 + 1], dst = mlist[e * 3 + 2];
+                        for (uint32_t i = lane & 7; i < cc; i += 8) out[dst + i] = staging[src + i];
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
             }
             run += __shfl(inc, 63, 64);
         }
     }
 }
 
-// tok_off[d] = tokens before the piece at which document d starts
+__global__ __launch_bounds__(1024) void tk_k_sum_pieces(const uint32_t* __restrict__ wave_pieces, uint32_t n, unsigned long long* __restrict__ out) {
+    __shared__ unsigned long long sh[16];
+    unsigned long long v = 0;
+    for (uint32_t i = threadIdx.x; i < n; i += 1024) v += wave_pieces[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned long long t = 0;
+        for (int w = 0; w < 16; ++w) t += sh[w];
+        out[0] = t;
+    }
+}
+
+// tok_off[d] = tokens before the piece at which document d starts (one wavefront per document)
 __global__ __launch_bounds__(256) void tk_k_docoffF(uint64_t n_docs, const uint32_t* __restrict__ doc_pid, const uint32_t* __restrict__ tile_tb,
                                                     const uint32_t* __restrict__ cnt, const uint64_t* __restrict__ total,
                                                     uint64_t tok_base_global, uint64_t* __restrict__ tok_off) {
-    for (uint64_t d = blockIdx.x * 256ull + threadIdx.x; d <= n_docs; d += (uint64_t)gridDim.x * 256) {
-        uint64_t v;
+    const int lane = threadIdx.x & 63;
+    const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
+    for (uint64_t d = wave; d <= n_docs; d += nwaves) {
         const uint32_t pid = d < n_docs ? doc_pid[d] : TKF_NONE;
+        uint64_t v;
         if (pid == TKF_NONE) {
             v = total[0];  // empty documents at the end of the chunk, and the closing offset
         } else {
-            const uint32_t t = pid / TKF_CAP, k = pid % TKF_CAP;
-            uint32_t sum = tile_tb[t];
-            const uint32_t* c = cnt + (uint64_t)t * TKF_CAP;
-            for (uint32_t j = 0; j < k; ++j) sum += c[j];
-            v = sum;
+            const uint32_t t = pid / TKF_CAP, rb = t * TKF_CAP;
+            uint32_t sum = 0;
+            for (uint32_t j = rb + lane; j < pid; j += 64) sum += cnt[j];
+            v = (uint64_t)tile_tb[t] + tk_wave_sum_u32(sum);
         }
-        tok_off[d] = tok_base_global + v;
+        if (lane == 0) tok_off[d] = tok_base_global + v;
     }
 }
 
 // encode_single_piece (src/py.rs:145-150): the whole buffer is one piece, no pre-tokenisation
-__global__ void tk_k_single_front(TkTables T, const uint8_t* __restrict__ text, uint32_t n, TkFrontOut out, TkBins bins) {
+__global__ void tk_k_single_front(TkTables T, const uint8_t* __restrict__ text, uint32_t n, TkFrontOut out) {
     if (blockIdx.x || threadIdx.x) return;
     out.tile_np[0] = 1;
+    uint32_t nm = 0;
     const uint32_t r = tk_lookup_text_piece(T, text, 0, n);
     if (r != TK_RANK_MAX) {
         out.tok1[0] = r;
         out.cnt[0] = 1;
     } else if (n > TK_GLANE_MAX) {
-        uint32_t lv = 0, c = n;
-        do {
-            c = (c + 63) >> 6;
-            lv += c;
-        } while (c > 64);
-        out.listC[0] = 0;
-        out.listC[1] = 0;
-        out.listC[2] = n;
-        out.listC[3] = 0;
-        out.listC[4] = 0;
-        out.counters[TK_CNT_C] = 1;
-        out.counters[TK_CNT_CBYTES] = n;
-        out.counters[TK_CNT_CLEVELS] = lv;
+        tk_append_tree(out.listC, out.counters, 0, 0, n);
     } else {
-        const int b = tk_bin_of(n);
-        uint32_t* e = out.listM + 3 * (uint64_t)bins.off[b];
-        e[0] = 0;
-        e[1] = 0;
-        e[2] = n;
-        out.counters[TK_CNT_BIN0 + b] = 1;
+        out.miss_s[0] = 0;
+        out.miss_kl[0] = (n - 1u) << 12;
+        nm = 1;
     }
+    out.tile_nmiss[0] = nm;
 }

@@ -650,11 +650,17 @@ __global__ __launch_bounds__(1024) void tk_k_scan_small(uint32_t* __restrict__ a
     __shared__ uint64_t carry_sh;
     if (threadIdx.x == 0) carry_sh = 0;
     __syncthreads();
-    int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    for (uint64_t base = 0; base < n; base += 1024) {
-        uint64_t i = base + threadIdx.x;
-        uint32_t v = i < n ? a[i] : 0;
-        uint32_t inc = tk_wave_scan_u32(v, lane);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    constexpr int E = 8;  // consecutive elements per thread
+    for (uint64_t base = 0; base < n; base += 1024 * E) {
+        const uint64_t i0 = base + (uint64_t)threadIdx.x * E;
+        uint32_t v[E], mine = 0;
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            v[j] = i0 + j < n ? a[i0 + j] : 0;
+            mine += v[j];
+        }
+        const uint32_t inc = tk_wave_scan_u32(mine, lane);
         if (lane == 63) wsum[wid] = inc;
         __syncthreads();
         uint32_t wbase = 0, tot = 0;
@@ -662,8 +668,13 @@ __global__ __launch_bounds__(1024) void tk_k_scan_small(uint32_t* __restrict__ a
             if (w < wid) wbase += wsum[w];
             tot += wsum[w];
         }
-        uint64_t carry = carry_sh;
-        if (i < n) a[i] = (uint32_t)(carry + wbase + inc - v);
+        const uint64_t carry = carry_sh;
+        uint32_t run = (uint32_t)(carry + wbase + inc - mine);
+#pragma unroll
+        for (int j = 0; j < E; ++j) {
+            if (i0 + j < n) a[i0 + j] = run;
+            run += v[j];
+        }
         __syncthreads();
         if (threadIdx.x == 0) carry_sh = carry + tot;
         __syncthreads();
