@@ -466,6 +466,20 @@ static int run_chunk_unfused(tk_core* c, hipStream_t s, const uint8_t* d_text, u
     return TK_OK;
 }
 
+template <class... A>
+static void launch_front(int pattern, bool spec, dim3 grid, hipStream_t s, A... a) {
+    if (pattern == TK_PAT_R50K) {
+        if (spec) hipLaunchKernelGGL((tk_k_front<TK_PAT_R50K, true>), grid, dim3(256), 0, s, a...);
+        else hipLaunchKernelGGL((tk_k_front<TK_PAT_R50K, false>), grid, dim3(256), 0, s, a...);
+    } else if (pattern == TK_PAT_CL100K) {
+        if (spec) hipLaunchKernelGGL((tk_k_front<TK_PAT_CL100K, true>), grid, dim3(256), 0, s, a...);
+        else hipLaunchKernelGGL((tk_k_front<TK_PAT_CL100K, false>), grid, dim3(256), 0, s, a...);
+    } else {
+        if (spec) hipLaunchKernelGGL((tk_k_front<TK_PAT_O200K, true>), grid, dim3(256), 0, s, a...);
+        else hipLaunchKernelGGL((tk_k_front<TK_PAT_O200K, false>), grid, dim3(256), 0, s, a...);
+    }
+}
+
 // The production pipeline (kernels of tk_fused.h).  One host synchronisation in the middle (the sizes of the
 // deferred-piece lists decide the merge launches) and none after it: the token total is read by the caller's
 // final synchronisation.
@@ -550,9 +564,7 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         }
         TRY(timed(c, s, "tk_k_front", [&] {
             const dim3 grid((uint32_t)ntiles);
-            if (T.pattern == TK_PAT_R50K) hipLaunchKernelGGL((tk_k_front<TK_PAT_R50K>), grid, dim3(256), 0, s, T, d_text, n, base, brk, docb, ss, si, d_doc_off, n_docs, fo, c->dbg);
-            else if (T.pattern == TK_PAT_CL100K) hipLaunchKernelGGL((tk_k_front<TK_PAT_CL100K>), grid, dim3(256), 0, s, T, d_text, n, base, brk, docb, ss, si, d_doc_off, n_docs, fo, c->dbg);
-            else hipLaunchKernelGGL((tk_k_front<TK_PAT_O200K>), grid, dim3(256), 0, s, T, d_text, n, base, brk, docb, ss, si, d_doc_off, n_docs, fo, c->dbg);
+            launch_front(T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, d_doc_off, n_docs, fo, c->dbg);
         }));
     } else if (n > 0) {
         TRY(timed(c, s, "tk_k_single_front", [&] { hipLaunchKernelGGL(tk_k_single_front, dim3(1), dim3(64), 0, s, T, d_text, (uint32_t)n, fo); }));
@@ -583,7 +595,7 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
     if (n > 0) {
         uint32_t* wbin = c->wbin.as<uint32_t>();
         TRY(timed(c, s, "tk_k_dedup", [&] {
-            hipLaunchKernelGGL(tk_k_dedup, dim3(TKD_WAVES / 4), dim3(256), 0, s, d_text, ntiles, fo.tile_nmiss, fo.miss_s, fo.miss_kl, mt, cnt, wbin, c->dbg);
+            hipLaunchKernelGGL(tk_k_dedup, dim3(TKD_WAVES / 4), dim3(256), 0, s, d_text, ntiles, fo.tile_nmiss, fo.miss_s, fo.miss_kl, mt, tok1, cnt, wbin, c->dbg);
         }));
         TRY(timed(c, s, "tk_k_scan_small", [&] {
             hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, wbin, (uint64_t)TK_NBIN * TKD_WAVES + 1, c->total.as<uint64_t>());

@@ -281,10 +281,26 @@ TK_HD uint64_t tk_piece_end(A& a, uint64_t p, int pat) {
 // instead of a byte-walking loop.  Returns the piece length in bytes, or 0 when the piece is not
 // resolved inside the window (caller falls back to tk_piece_end).
 // ------------------------------------------------------------------------------------------
+enum { TKB_START = 0, TKB_HARD, TKB_L, TKB_UP, TKB_LOW, TKB_CAS, TKB_OTH, TKB_WS, TKB_NL, TKB_NU, TKB_NLSL, TKB_KINDS };
+// A window provider has `start`, `stop` and get(kind) for the class-set bitmaps; the scanner only asks for the
+// kinds its branch needs (the kernel's provider extracts them from the LDS bitmaps on demand).
 struct TkWin {
     uint64_t start;  // char starts
     uint64_t stop;   // positions k >= 1 where look-ahead sees end-of-text (hard start or past the end)
     uint64_t L, up, low, cas, oth, ws, nl, nu, nlsl;
+    TK_HD uint64_t get(int kind) const {
+        switch (kind) {
+            case TKB_L: return L;
+            case TKB_UP: return up;
+            case TKB_LOW: return low;
+            case TKB_CAS: return cas;
+            case TKB_OTH: return oth;
+            case TKB_WS: return ws;
+            case TKB_NL: return nl;
+            case TKB_NU: return nu;
+            default: return nlsl;
+        }
+    }
 };
 
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -307,8 +323,6 @@ TK_HD uint32_t tk_run(uint64_t bits, uint64_t stop, uint32_t from) {
 
 #define TK_WIN_SAFE 58u  // results up to here are decided inside the first 64-bit window
 #define TK_UNRES 0xFFFFFFFFu
-enum { TKB_START = 0, TKB_HARD, TKB_L, TKB_UP, TKB_LOW, TKB_CAS, TKB_OTH, TKB_WS, TKB_NL, TKB_NU, TKB_NLSL, TKB_KINDS };
-
 // Runs that leave the first window continue through an extension provider X:
 //   x.win(kind, j) -> 64-bit window j (positions [64 j, 64 j + 64) relative to the piece start) of bitmap `kind`
 //   x.limit()      -> number of positions, counted from the piece start, for which windows are valid
@@ -351,8 +365,8 @@ TK_HD bool tk_bitx(uint64_t bits0, X& x, int kind, uint32_t k) {
     return k < 64u ? (bits0 >> k) & 1ull : (x.win(kind, k >> 6) >> (k & 63u)) & 1ull;
 }
 
-template <class A>
-TK_HD uint32_t tk_contraction_bits(const TkWin& w, A& a, uint64_t p, uint32_t e, bool ci) {
+template <class W, class A>
+TK_HD uint32_t tk_contraction_bits(const W& w, A& a, uint64_t p, uint32_t e, bool ci) {
     if ((w.stop >> (e + 1)) & 1ull) return 0;
     uint32_t b1 = a.byte(p + e + 1);
     if (ci) {
@@ -374,8 +388,8 @@ TK_HD uint32_t tk_contraction_bits(const TkWin& w, A& a, uint64_t p, uint32_t e,
 }
 
 // c = class nibble of the char at p.  Returns the piece length, or 0 if unresolved.
-template <class A, class X>
-TK_HD uint32_t tk_piece_len_bits(const TkWin& w, A& a, X& x, uint64_t p, uint32_t c, int pat) {
+template <class W, class A, class X>
+TK_HD uint32_t tk_piece_len_bits(const W& w, A& a, X& x, uint64_t p, uint32_t c, int pat) {
     const uint64_t stop = w.stop;
     // length of the first char: next char start or stop after position 0
     const uint32_t k1 = 1u + tk_ctz64((w.start | stop) >> 1);
@@ -384,24 +398,24 @@ TK_HD uint32_t tk_piece_len_bits(const TkWin& w, A& a, X& x, uint64_t p, uint32_
     const bool nxt_end = (stop >> k1) & 1ull;
     uint32_t e = 0;
     if (pat == TK_PAT_O200K) {
-        const uint64_t word = w.up | w.low;
+        const uint64_t word = w.get(TKB_UP) | w.get(TKB_LOW);
         uint32_t ks = 64;
         if ((TK_M_WORD >> c) & 1u) ks = 0;
         else if (c != TK_C_NL && c != TK_C_NU && !nxt_end && ((word >> k1) & 1ull)) ks = k1;
         if (ks != 64u) {
-            uint32_t r = tk_runx(w.up, stop, x, TKB_UP, ks);
+            uint32_t r = tk_runx(w.get(TKB_UP), stop, x, TKB_UP, ks);
             if (r == TK_UNRES) return 0;
             const uint32_t re = ks + r;
-            uint32_t t = tk_runx(w.low, stop, x, TKB_LOW, re);
+            uint32_t t = tk_runx(w.get(TKB_LOW), stop, x, TKB_LOW, re);
             if (t == TK_UNRES) return 0;
             const uint32_t te = re + t;
             if (te > re) {
                 e = te;
             } else if (re <= TK_WIN_SAFE) {
-                uint64_t xx = w.cas & ~stop & tk_below(re) & ~tk_below(ks);
+                uint64_t xx = w.get(TKB_CAS) & ~stop & tk_below(re) & ~tk_below(ks);
                 e = xx ? 64u - tk_clz64(xx) : re;
             } else {
-                int lc = tk_last_setx(w.cas, x, TKB_CAS, ks, re);  // (stops cannot lie inside a run)
+                int lc = tk_last_setx(w.get(TKB_CAS), x, TKB_CAS, ks, re);  // (stops cannot lie inside a run)
                 e = lc >= 0 ? (uint32_t)lc + 1u : re;
             }
             if (e <= TK_WIN_SAFE) {
@@ -419,11 +433,11 @@ TK_HD uint32_t tk_piece_len_bits(const TkWin& w, A& a, X& x, uint64_t p, uint32_
             if (k) return k;
         }
         if ((TK_M_L >> c) & 1u) {
-            uint32_t r = tk_runx(w.L, stop, x, TKB_L, 0);
+            uint32_t r = tk_runx(w.get(TKB_L), stop, x, TKB_L, 0);
             return r == TK_UNRES ? 0 : r;
         }
-        if (c != TK_C_NL && c != TK_C_NU && !nxt_end && ((w.L >> k1) & 1ull)) {
-            uint32_t r = tk_runx(w.L, stop, x, TKB_L, k1);
+        if (c != TK_C_NL && c != TK_C_NU && !nxt_end && ((w.get(TKB_L) >> k1) & 1ull)) {
+            uint32_t r = tk_runx(w.get(TKB_L), stop, x, TKB_L, k1);
             return r == TK_UNRES ? 0 : k1 + r;
         }
     } else {
@@ -433,7 +447,7 @@ TK_HD uint32_t tk_piece_len_bits(const TkWin& w, A& a, X& x, uint64_t p, uint32_
         }
     }
     if (pat != TK_PAT_R50K && c == TK_C_NU) {
-        uint32_t r = tk_run(w.nu, stop, 0);
+        uint32_t r = tk_run(w.get(TKB_NU), stop, 0);
         uint64_t sx = w.start & tk_below(r);
         sx &= sx - 1;
         sx &= sx - 1;
@@ -448,19 +462,19 @@ TK_HD uint32_t tk_piece_len_bits(const TkWin& w, A& a, X& x, uint64_t p, uint32_
     if (pat == TK_PAT_R50K) {
         int kind = -1;
         uint64_t b0 = 0;
-        if ((w.L >> s) & 1ull) { kind = TKB_L; b0 = w.L; }
-        else if ((w.nu >> s) & 1ull) { kind = TKB_NU; b0 = w.nu; }
-        else if ((w.oth >> s) & 1ull) { kind = TKB_OTH; b0 = w.oth; }
+        if ((w.get(TKB_L) >> s) & 1ull) { kind = TKB_L; b0 = w.get(TKB_L); }
+        else if ((w.get(TKB_NU) >> s) & 1ull) { kind = TKB_NU; b0 = w.get(TKB_NU); }
+        else if ((w.get(TKB_OTH) >> s) & 1ull) { kind = TKB_OTH; b0 = w.get(TKB_OTH); }
         if (kind >= 0) {
             uint32_t r = tk_runx(b0, stop, x, kind, s);
             return r == TK_UNRES ? 0 : s + r;
         }
         s_ok = false;
-    } else if ((w.oth >> s) & 1ull) {
-        uint32_t r = tk_runx(w.oth, stop, x, TKB_OTH, s);
+    } else if ((w.get(TKB_OTH) >> s) & 1ull) {
+        uint32_t r = tk_runx(w.get(TKB_OTH), stop, x, TKB_OTH, s);
         if (r == TK_UNRES) return 0;
         const uint32_t e1 = s + r;
-        uint32_t r2 = pat == TK_PAT_O200K ? tk_runx(w.nlsl, stop, x, TKB_NLSL, e1) : tk_runx(w.nl, stop, x, TKB_NL, e1);
+        uint32_t r2 = pat == TK_PAT_O200K ? tk_runx(w.get(TKB_NLSL), stop, x, TKB_NLSL, e1) : tk_runx(w.get(TKB_NL), stop, x, TKB_NL, e1);
         return r2 == TK_UNRES ? 0 : e1 + r2;
     } else {
         s_ok = false;
@@ -468,12 +482,12 @@ TK_HD uint32_t tk_piece_len_bits(const TkWin& w, A& a, X& x, uint64_t p, uint32_
     (void)s_ok;
     // white space
     {
-        uint32_t q = tk_runx(w.ws, stop, x, TKB_WS, 0);
+        uint32_t q = tk_runx(w.get(TKB_WS), stop, x, TKB_WS, 0);
         if (q == TK_UNRES) return 0;
         if (q <= TK_WIN_SAFE) {
             uint64_t rng = tk_below(q);
             bool at_end = (stop >> q) & 1ull;
-            uint64_t nlr = w.nl & rng, st = w.start & rng;
+            uint64_t nlr = w.get(TKB_NL) & rng, st = w.start & rng;
             if (pat != TK_PAT_O200K && at_end) return q;
             if (pat != TK_PAT_R50K && nlr) return 64u - tk_clz64(nlr);
             if (at_end) return q;
@@ -484,7 +498,7 @@ TK_HD uint32_t tk_piece_len_bits(const TkWin& w, A& a, X& x, uint64_t p, uint32_
         const bool at_end = tk_bitx(w.stop, x, TKB_HARD, q);
         if (pat != TK_PAT_O200K && at_end) return q;
         if (pat != TK_PAT_R50K) {
-            int ln = tk_last_setx(w.nl, x, TKB_NL, 0, q);
+            int ln = tk_last_setx(w.get(TKB_NL), x, TKB_NL, 0, q);
             if (ln >= 0) return (uint32_t)ln + 1u;
         }
         if (at_end) return q;

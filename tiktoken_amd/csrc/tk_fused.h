@@ -36,7 +36,8 @@ struct TkFrontOut {
 // In-call de-duplication of missed pieces: open-addressed, one 32-byte slot per distinct piece.
 struct TkMissSlot {
     unsigned long long key;  // ~0 = empty
-    unsigned long long aux;  // (claimant start << 32) | length; ~0 until the claimant has written it
+    unsigned long long aux;  // identity of the claimant, ~0 until it has written it: pieces of <= 7 bytes: the bytes themselves
+                             // | length << 56; longer ones: 1 << 63 | length << 32 | start (compared in the text)
     uint32_t pid;            // claimant piece id
     uint32_t res_cnt;        // claimant's result, published after the merges
     uint32_t res_tok;
@@ -99,8 +100,21 @@ __device__ __forceinline__ void tk_append_tree(uint32_t* listC, uint32_t* counte
     e[4] = atomicAdd(&counters[TK_CNT_CLEVELS], lv);
 }
 
-template <int PAT>
-__global__ __launch_bounds__(256) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
+// window provider over the tile's LDS bitmaps: 64 positions from (segment wi, bit sh); kinds extracted on demand
+struct TkWinLds {
+    const uint64_t (*bm)[TK2_NSEG + 2];
+    uint32_t wi, sh;
+    uint64_t start, stop;
+    __device__ __forceinline__ uint64_t get(int kind) const { return sh ? ((bm[kind][wi] >> sh) | (bm[kind][wi + 1] << (64u - sh))) : bm[kind][wi]; }
+    __device__ __forceinline__ TkWinLds(const uint64_t (*bm_)[TK2_NSEG + 2], uint32_t wi_, uint32_t sh_) : bm(bm_), wi(wi_), sh(sh_) {
+        start = get(TKB_START);
+        stop = get(TKB_HARD) & ~1ull;
+    }
+};
+
+#define TKF_CLW (TK2_CLIST / 4)  // certain-start list entries per wave
+template <int PAT, bool SPEC>
+__global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
                                                   const uint32_t* __restrict__ brk, const uint32_t* __restrict__ docb,
                                                   const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si,
                                                   const uint64_t* __restrict__ doc_off, uint64_t n_docs, TkFrontOut out, int dbg) {
@@ -111,10 +125,9 @@ __global__ __launch_bounds__(256) void tk_k_front(TkTables T, const uint8_t* __r
     __shared__ __attribute__((aligned(16))) uint8_t pool[BM_BYTES + TK2_CLIST * 2];  // bitmaps + certain list; later the piece list
     __shared__ uint32_t bits[TK_TILE / 32];
     __shared__ uint32_t woff[TK_TILE / 32 + 1];
-    __shared__ uint32_t cn, np_sh, nmiss_sh, need_walk, last_end_sh;
+    __shared__ uint32_t cnw[8], np_sh, nmiss_sh, need_walk, last_end_sh;
     __shared__ uint32_t certm[16];
     __shared__ uint32_t brkw[TK2_WIN / 32 + 1], ssw[TK2_WIN / 32 + 1], siw[TK2_WIN / 32 + 1], docw[TK2_WIN / 32 + 1];
-    __shared__ __attribute__((aligned(16))) uint8_t st1[0x1100];
     __shared__ uint32_t scan_sh[8];
     uint64_t(*bm)[TK2_NSEG + 2] = (uint64_t(*)[TK2_NSEG + 2])pool;
     uint16_t* clist = (uint16_t*)(pool + BM_BYTES);
@@ -132,18 +145,16 @@ __global__ __launch_bounds__(256) void tk_k_front(TkTables T, const uint8_t* __r
         if (gp >= 0 && (uint64_t)gp < n) x = *(const uint4*)(text + gp);  // text is readable 64 bytes past n
         *(uint4*)(raw + v * 16) = x;
     }
-    for (uint32_t v = tid; v < 0x1100 / 16; v += 256) *(uint4*)(st1 + v * 16) = *(const uint4*)(T.uc_stage1 + v * 16);
     if (tid < TK2_WIN / 32) {  // break / special bitmaps of the window (the window base is 32-aligned)
         int64_t wgp = base + (int64_t)tid * 32;
         bool in = wgp >= 0 && (uint64_t)wgp < n;
         brkw[tid] = in ? brk[wgp >> 5] : 0u;
         docw[tid] = in ? (docb ? docb[wgp >> 5] : brkw[tid]) : 0u;
-        ssw[tid] = (in && ss) ? ss[wgp >> 5] : 0u;
-        siw[tid] = (in && si) ? si[wgp >> 5] : 0u;
+        ssw[tid] = (SPEC && in) ? ss[wgp >> 5] : 0u;
+        siw[tid] = (SPEC && in) ? si[wgp >> 5] : 0u;
     }
     if (tid < 16) certm[tid] = tk_certain_mask(PAT, tid);
     if (tid == 0) {
-        cn = 0;
         nmiss_sh = 0;
         need_walk = 0;
         last_end_sh = (uint32_t)(tile_end - tile_start) + TK2_LEFT;
@@ -153,39 +164,16 @@ __global__ __launch_bounds__(256) void tk_k_front(TkTables T, const uint8_t* __r
         bm[tid][TK2_NSEG + 1] = tid <= TKB_HARD ? ~0ull : 0ull;
     }
     __syncthreads();
-    // ---- B1: class of every byte (branch-free; see tk_k_pretok2)
+    // ---- B1: class of every byte (branch-free): every lane finds the lead byte of ITS char (0..3 bytes back),
+    // decodes the code point from the LDS copy of the text and issues the two table loads -- so continuation
+    // bytes get their char's class without any cross-lane step.  The loads of all 17 segments of the wave are in
+    // flight together.  (An all-ASCII fast path was tried: 97.6 % of the bench corpus' segments hold a non-ASCII byte.)
     constexpr int NS = TK2_NSEG / 4;  // 17 segments per wave, contiguous
     uint32_t creg[NS];
-    {
+    auto class_at = [&](uint32_t pl) -> uint32_t {
         const uint32_t* dw = (const uint32_t*)raw;
-#pragma unroll
-        for (int i = 0; i < NS; ++i) {
-            const uint32_t pl = (uint32_t)(wid * NS + i) * 64u + lane;
-            const uint32_t wi = pl >> 2, sft = pl & 3u;
-            const uint32_t d0 = dw[wi ? wi - 1 : 0], d1 = dw[wi], d2 = dw[wi + 1];
-            const uint32_t fwd = __builtin_amdgcn_alignbyte(d2, d1, sft);
-            const uint32_t back = sft == 3u ? d1 : __builtin_amdgcn_alignbyte(d1, d0, sft + 1u);
-            const uint32_t b = fwd & 0xFFu;
-            uint32_t k = 0;
-            if ((b & 0xC0u) == 0x80u) k = ((back >> 16) & 0xC0u) != 0x80u ? 1u : (((back >> 8) & 0xC0u) != 0x80u ? 2u : 3u);
-            const uint64_t seven = ((uint64_t)fwd << 24) | (uint64_t)(back & 0xFFFFFFu);
-            const uint32_t ch = (uint32_t)(seven >> (8u * (3u - k)));
-            const uint32_t l = ch & 0xFFu, c1b = (ch >> 8) & 0x3Fu, c2b = (ch >> 16) & 0x3Fu, c3b = (ch >> 24) & 0x3Fu;
-            uint32_t cp = l;
-            if (l >= 0xF0u) cp = ((l & 7u) << 18) | (c1b << 12) | (c2b << 6) | c3b;
-            else if (l >= 0xE0u) cp = ((l & 15u) << 12) | (c1b << 6) | c2b;
-            else if (l >= 0xC0u) cp = ((l & 31u) << 6) | c1b;
-            if (cp > 0x10FFFFu) cp = 0xFFFFu;
-            creg[i] = T.uc_stage2[(uint32_t)st1[cp >> 8] * 256u + (cp & 255u)];
-        }
-    }
-    // ---- B2: flags, class bytes, bitmaps, certain starts (previous class = lane - 1, carried across segments)
-    uint32_t carry = TK_C_END;
-    if (wid > 0) {
-        const uint32_t* dw = (const uint32_t*)raw;
-        const uint32_t pl = (uint32_t)(wid * NS) * 64u - 1u;
         const uint32_t wi = pl >> 2, sft = pl & 3u;
-        const uint32_t d0 = dw[wi - 1], d1 = dw[wi], d2 = dw[wi + 1];
+        const uint32_t d0 = dw[wi ? wi - 1 : 0], d1 = dw[wi], d2 = dw[wi + 1];
         const uint32_t fwd = __builtin_amdgcn_alignbyte(d2, d1, sft);
         const uint32_t back = sft == 3u ? d1 : __builtin_amdgcn_alignbyte(d1, d0, sft + 1u);
         const uint32_t b = fwd & 0xFFu;
@@ -199,79 +187,73 @@ __global__ __launch_bounds__(256) void tk_k_front(TkTables T, const uint8_t* __r
         else if (l >= 0xE0u) cp = ((l & 15u) << 12) | (c1b << 6) | c2b;
         else if (l >= 0xC0u) cp = ((l & 31u) << 6) | c1b;
         if (cp > 0x10FFFFu) cp = 0xFFFFu;
-        carry = T.uc_stage2[(uint32_t)st1[cp >> 8] * 256u + (cp & 255u)];
+        return T.uc_stage2[(uint32_t)T.uc_stage1[cp >> 8] * 256u + (cp & 255u)];
+    };
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+        creg[i] = class_at((uint32_t)(wid * NS + i) * 64u + lane);
+    }
+    // ---- B2: flags, class bytes, bitmaps, certain starts (previous class = lane - 1, carried across segments).
+    // Each wave keeps its own list of certain starts (no LDS atomics): starts that will scan a word from the front
+    // of its array, the rest from the back, so that the scanners of a wavefront mostly follow the same branch.
+    uint32_t carry = TK_C_END;
+    if (wid > 0) {
+        const uint32_t pl = (uint32_t)(wid * NS) * 64u - 1u;
+        carry = class_at(pl);
         const int64_t gpp = base + pl;
         if (gpp < 0 || (uint64_t)gpp >= n) carry = TK_C_END;
-        else if ((ss && ((ssw[pl >> 5] >> (pl & 31u)) & 1u)) || (si && ((siw[pl >> 5] >> (pl & 31u)) & 1u))) carry = TK_C_SPEC;
+        else if (SPEC && (((ssw[pl >> 5] >> (pl & 31u)) & 1u) || ((siw[pl >> 5] >> (pl & 31u)) & 1u))) carry = TK_C_SPEC;
     }
-    uint32_t spill_mask = 0;
-    uint64_t left_certw = 0;  // wave 0: certain starts inside the left context segment
+    uint32_t spill_mask = 0, extra_back = 0;
+    uint32_t cw_front = 0, cw_back = 0;  // wave-uniform
+    uint64_t left_certw = 0;             // wave 0: certain starts inside the left context segment
+    uint16_t* clw = clist + wid * TKF_CLW;
+    // window positions [lo_valid, hi_valid) are text; flags below are 0/1 integers (no short-circuit control flow)
+    const uint32_t lo_valid = base < 0 ? (uint32_t)(-base) : 0u;
+    const uint32_t hi_valid = (int64_t)n - base < (int64_t)TK2_WIN ? (uint32_t)((int64_t)n - base) : (uint32_t)TK2_WIN;
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         const int g = wid * NS + i;
         const uint32_t pl = (uint32_t)g * 64u + lane;
-        const int64_t gp = base + pl;
-        const bool valid = gp >= 0 && (uint64_t)gp < n;
+        const uint32_t past = pl >= hi_valid, valid = (uint32_t)(pl >= lo_valid) & (past ^ 1u);
         const uint32_t b = raw[pl];
-        bool cont = valid && (b & 0xC0u) == 0x80u;
-        uint32_t c = creg[i];
-        bool hard = false;
-        if (!valid) {
-            c = TK_C_END;
-            hard = gp >= 0;
-        } else {
-            const bool spec_s = ss && ((ssw[pl >> 5] >> (pl & 31u)) & 1u), spec_i = si && ((siw[pl >> 5] >> (pl & 31u)) & 1u);
-            if (spec_i) {
-                cont = true;
-                c = TK_C_SPEC;
-            } else if (spec_s) {
-                cont = false;
-                c = TK_C_SPEC;
-                hard = true;
-            } else if (!cont) {
-                hard = (brkw[pl >> 5] >> (pl & 31u)) & 1u;
-            }
+        uint32_t cont = valid & (uint32_t)((b & 0xC0u) == 0x80u);
+        uint32_t c = valid ? creg[i] : (uint32_t)TK_C_END;
+        uint32_t hard = past;  // positions after the end of the text stop every look-ahead
+        if constexpr (SPEC) {
+            const uint32_t spec_s = valid & (ssw[pl >> 5] >> (pl & 31u)) & 1u, spec_i = valid & (siw[pl >> 5] >> (pl & 31u)) & 1u;
+            if (spec_i | spec_s) c = TK_C_SPEC;
+            cont = spec_i | (cont & (spec_s ^ 1u));
+            hard |= spec_s & (spec_i ^ 1u);
         }
-        cls2[pl] = (uint8_t)(c | (cont ? 0x40u : 0u) | (hard ? 0x80u : 0u));
+        hard |= valid & (cont ^ 1u) & (brkw[pl >> 5] >> (pl & 31u)) & 1u;
+        cls2[pl] = (uint8_t)(c | (cont << 6) | (hard << 7));
         constexpr bool O2 = PAT == TK_PAT_O200K, R5 = PAT == TK_PAT_R50K;
-        const uint64_t w_start = __ballot(!cont), w_hard = __ballot(hard);
-        {
-            uint32_t prevc = __shfl_up(c, 1, 64);
-            if (lane == 0) prevc = carry;
-            carry = __shfl(c, 63, 64);
-            const bool in_tile = g >= 1 && g <= TK_TILE / 64;
-            // (lane 0 of the context segment has no known predecessor: never certain unless hard)
-            const bool cert = valid && !cont && (hard || ((g > 0 || lane > 0) && ((certm[prevc] >> c) & 1u)));
-            const uint64_t certw = __ballot(cert);
-            if (g == 0) left_certw = certw;
-            if (in_tile) {
-                if (lane == 0) {
-                    bits[(g - 1) * 2] = (uint32_t)certw;
-                    bits[(g - 1) * 2 + 1] = (uint32_t)(certw >> 32);
-                }
-                if (certw) {
-                    uint32_t at = 0;
-                    if (lane == 0) at = atomicAdd(&cn, (uint32_t)__popcll(certw));
-                    at = __shfl(at, 0, 64) + (uint32_t)__popcll(certw & ((1ull << lane) - 1ull));
-                    if (cert) {
-                        if (at < TK2_CLIST) clist[at] = (uint16_t)pl;
-                        else spill_mask |= 1u << i;
-                    }
-                }
-                if (g == 1 && lane == 0 && tile_start > 0) {
-                    // is the first char of the tile a certain start?  If not, the segment that crosses in from the
-                    // left must be re-scanned from ITS start: the last certain start in the left context, or further back
-                    const bool first_cert = w_start && ((certw >> (__ffsll((unsigned long long)w_start) - 1)) & 1ull);
-                    if (!first_cert) {
-                        if (left_certw) {
-                            uint32_t at2 = atomicAdd(&cn, 1u);
-                            if (at2 < TK2_CLIST) clist[at2] = (uint16_t)(63 - __clzll((long long)left_certw));
-                            else need_walk = 2;  // (list full: let the walk-back path handle it)
-                        } else {
-                            need_walk = 1;
-                        }
-                    }
-                }
+        const uint64_t w_start = __ballot(cont == 0u), w_hard = __ballot(hard != 0u);
+        uint32_t prevc = __shfl_up(c, 1, 64);
+        if (lane == 0) prevc = carry;
+        carry = __shfl(c, 63, 64);
+        const bool in_tile = g >= 1 && g <= TK_TILE / 64;
+        // (lane 0 of the context segment has no known predecessor: never certain unless hard)
+        const uint32_t has_prev = g > 0 ? 1u : (uint32_t)(lane > 0);
+        const uint32_t cert = valid & (cont ^ 1u) & (hard | (has_prev & (certm[prevc] >> c))) & 1u;
+        const uint64_t certw = __ballot(cert != 0u);
+        if (g == 0) left_certw = certw;
+        if (in_tile && certw) {
+            // kind of scan this start will run (a guess from the class of the next byte: only the grouping depends on it)
+            const uint32_t nc = __shfl_down(c, 1, 64);
+            constexpr uint32_t PREFIX_OK = ~(TK_CB(TK_C_NL) | TK_CB(TK_C_NU));
+            const uint32_t wordish = ((TK_M_WORD >> c) | ((PREFIX_OK >> c) & (TK_M_WORD >> nc) & (uint32_t)(lane < 63))) & 1u;
+            const uint64_t mw = __ballot((cert & wordish) != 0u), mr = certw & ~mw;
+            const uint32_t nw = (uint32_t)__popcll(mw), nr = (uint32_t)__popcll(mr);
+            if (cw_front + cw_back + nw + nr <= TKF_CLW) {
+                const uint64_t below = (1ull << lane) - 1ull;
+                const uint32_t at_w = cw_front + (uint32_t)__popcll(mw & below), at_r = TKF_CLW - 1u - cw_back - (uint32_t)__popcll(mr & below);
+                if (cert) clw[wordish ? at_w : at_r] = (uint16_t)pl;
+                cw_front += nw;
+                cw_back += nr;
+            } else if (cert) {
+                spill_mask |= 1u << i;  // list full: these lanes scan from their own positions
             }
         }
         const uint64_t w_oth = __ballot((TK_M_OTHER >> c) & 1u), w_ws = __ballot((TK_M_WS >> c) & 1u), w_nu = __ballot(c == TK_C_NU);
@@ -285,6 +267,23 @@ __global__ __launch_bounds__(256) void tk_k_front(TkTables T, const uint8_t* __r
         }
         if constexpr (!R5) w_nl = __ballot(c == TK_C_NL);
         if (lane == 0) {
+            if (in_tile) {
+                bits[(g - 1) * 2] = (uint32_t)certw;
+                bits[(g - 1) * 2 + 1] = (uint32_t)(certw >> 32);
+            }
+            if (g == 1 && tile_start > 0) {
+                // is the first char of the tile a certain start?  If not, the piece that crosses in from the left
+                // must be re-scanned from ITS start: the last certain start in the left context, or further back
+                const bool first_cert = w_start && ((certw >> (__ffsll((unsigned long long)w_start) - 1)) & 1ull);
+                if (!first_cert) {
+                    if (left_certw && cw_front + cw_back < TKF_CLW) {
+                        clw[TKF_CLW - 1u - cw_back] = (uint16_t)(63 - __clzll((long long)left_certw));
+                        extra_back = 1;
+                    } else {
+                        need_walk = 1;
+                    }
+                }
+            }
             bm[TKB_START][g] = w_start;
             bm[TKB_HARD][g] = w_hard;
             bm[TKB_OTH][g] = w_oth;
@@ -299,6 +298,11 @@ __global__ __launch_bounds__(256) void tk_k_front(TkTables T, const uint8_t* __r
             }
             if constexpr (!R5) bm[TKB_NL][g] = w_nl;
         }
+        if (g == 1) cw_back += __shfl(extra_back, 0, 64);  // (the entry lane 0 may have added above)
+    }
+    if (lane == 0) {
+        cnw[wid] = cw_front;
+        cnw[4 + wid] = cw_back;
     }
     __syncthreads();
     // ---- D: one lane per certain start; only boundaries inside the tile are recorded
@@ -309,20 +313,7 @@ __global__ __launch_bounds__(256) void tk_k_front(TkTables T, const uint8_t* __r
             uint32_t len = 0;
             if (r >= 0 && r + 64 <= TK2_WIN) {
                 const uint32_t wi = (uint32_t)r >> 6, sh = (uint32_t)r & 63u;
-                TkWin w;
-#define TK_FUNNEL(kind) (sh ? ((bm[kind][wi] >> sh) | (bm[kind][wi + 1] << (64u - sh))) : bm[kind][wi])
-                w.start = TK_FUNNEL(TKB_START);
-                w.stop = TK_FUNNEL(TKB_HARD) & ~1ull;
-                w.L = TK_FUNNEL(TKB_L);
-                w.up = TK_FUNNEL(TKB_UP);
-                w.low = TK_FUNNEL(TKB_LOW);
-                w.cas = TK_FUNNEL(TKB_CAS);
-                w.oth = TK_FUNNEL(TKB_OTH);
-                w.ws = TK_FUNNEL(TKB_WS);
-                w.nl = TK_FUNNEL(TKB_NL);
-                w.nu = TK_FUNNEL(TKB_NU);
-                w.nlsl = TK_FUNNEL(TKB_NLSL);
-#undef TK_FUNNEL
+                const TkWinLds w(bm, wi, sh);
                 TkBmExt ext{bm, wi, sh, (uint32_t)(TK2_WIN - r)};
                 len = tk_piece_len_bits(w, acc, ext, p, cls2[r] & 15u, pat);
             }
@@ -346,14 +337,36 @@ __global__ __launch_bounds__(256) void tk_k_front(TkTables T, const uint8_t* __r
         }
     };
     {
-        const uint32_t ncert = cn < TK2_CLIST ? cn : TK2_CLIST;
-        for (uint32_t i = tid; i < ncert; i += 256) scan_from((uint64_t)(base + clist[i]));
-        while (spill_mask) {
-            int i = __ffs((int)spill_mask) - 1;
-            spill_mask &= spill_mask - 1;
-            scan_from((uint64_t)(base + (int64_t)((uint32_t)(wid * NS + i) * 64u + lane)));
+        // work items: the four word lists, then the four other lists, then spilled lanes, then the walk-back start
+        uint32_t pre[9];
+        pre[0] = 0;
+#pragma unroll
+        for (int q = 0; q < 8; ++q) pre[q + 1] = pre[q] + cnw[q];
+        uint32_t i = (dbg & 16384) ? 0xFFFFFFFFu : tid;  // (perf experiment: no scanning)
+        bool walk = tid == 0 && need_walk;
+        if (dbg & 16384) spill_mask = 0, walk = false;
+        for (;;) {
+            uint64_t p;
+            if (i < pre[8]) {
+                uint32_t q = 0;
+#pragma unroll
+                for (int t = 1; t < 8; ++t) q += i >= pre[t];
+                const uint32_t off = i - pre[q];
+                const uint16_t* lw = clist + (q & 3u) * TKF_CLW;
+                p = (uint64_t)(base + (q < 4u ? lw[off] : lw[TKF_CLW - 1u - off]));
+                i += 256;
+            } else if (spill_mask) {
+                const int k = __ffs((int)spill_mask) - 1;
+                spill_mask &= spill_mask - 1;
+                p = (uint64_t)(base + (int64_t)((uint32_t)(wid * NS + k) * 64u + lane));
+            } else if (walk) {
+                walk = false;
+                p = tk_certain_before(&T, text, n, brk, ss, si, tile_start - 1, pat);
+            } else {
+                break;
+            }
+            scan_from(p);
         }
-        if (tid == 0 && need_walk) scan_from(tk_certain_before(&T, text, n, brk, ss, si, tile_start - 1, pat));
     }
     __syncthreads();
     // ---- E: enumerate the pieces of the tile (set bits of `bits`, in order) -> plist (aliases the bitmaps)
@@ -414,8 +427,12 @@ __global__ __launch_bounds__(256) void tk_k_front(TkTables T, const uint8_t* __r
                 if (r != TK_RANK_MAX) {
                     out.tok1[pid] = r;
                     out.cnt[pid] = 1;
+                } else if (len > TK_GLANE_MAX) {
+                    cat = 2u;
                 } else {
-                    cat = len > TK_GLANE_MAX ? 2u : 1u;
+                    cat = 1u;  // the key (exact bytes, or their hash) travels to tk_k_dedup in the piece's own result slots
+                    out.tok1[pid] = (uint32_t)key;
+                    out.cnt[pid] = (uint32_t)(key >> 32);
                 }
             }
         }
@@ -471,7 +488,8 @@ struct TkMissGroup {  // the miss lists of TKD_GROUP consecutive tiles, flattene
 
 __global__ __launch_bounds__(256) void tk_k_dedup(const uint8_t* __restrict__ text, uint64_t ntiles, const uint32_t* __restrict__ tile_nmiss,
                                                   const uint32_t* __restrict__ miss_s, uint32_t* __restrict__ miss_kl,
-                                                  TkMissSlot* __restrict__ mt, uint32_t* __restrict__ cnt, uint32_t* __restrict__ wbin, int dbg) {
+                                                  TkMissSlot* __restrict__ mt, const uint32_t* __restrict__ tok1, uint32_t* __restrict__ cnt,
+                                                  uint32_t* __restrict__ wbin, int dbg) {
     const int lane = threadIdx.x & 63;
     const uint64_t ngroups = (ntiles + TKD_GROUP - 1) / TKD_GROUP;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
@@ -492,7 +510,9 @@ __global__ __launch_bounds__(256) void tk_k_dedup(const uint8_t* __restrict__ te
                 const uint32_t pid = rb + (kl & 4095u), s = miss_s[mi], len = ((kl >> 12) & 1023u) + 1u;
                 bin = (uint32_t)tk_bin_of(len);
                 if (mt && !(dbg & 256)) {
-                    const uint64_t key = tk_key_of_text(text, s, len);
+                    const uint64_t key = ((uint64_t)cnt[pid] << 32) | tok1[pid];  // left there by the front kernel
+                    const unsigned long long ident = len <= 7u ? (key | ((unsigned long long)len << 56))
+                                                               : ((1ull << 63) | ((unsigned long long)len << 32) | s);
                     unsigned long long kk = tk_mix64(key ^ ((uint64_t)len * 0xA24BAED4963EE407ull));
                     if (dbg & 512) kk &= 0xFFFull;  // test hook: force collisions between different pieces
                     if (kk == TK_EMPTY_KEY) kk = 0;
@@ -506,14 +526,17 @@ __global__ __launch_bounds__(256) void tk_k_dedup(const uint8_t* __restrict__ te
                         if (cur == TK_EMPTY_KEY) cur = atomicCAS(&mt[i].key, TK_EMPTY_KEY, kk);
                         if (cur == TK_EMPTY_KEY) {  // claimed: this piece is the one that gets merged
                             mt[i].pid = pid;
-                            __hip_atomic_store(&mt[i].aux, ((unsigned long long)s << 32) | len, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            __hip_atomic_store(&mt[i].aux, ident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             break;
                         }
                         if (cur == kk) {
                             unsigned long long a = ka.y;
                             if (a == TK_EMPTY_KEY) a = __hip_atomic_load(&mt[i].aux, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            if (a != TK_EMPTY_KEY && (uint32_t)a == len && ((dbg & 2048) || tk_equal_bytes(text, s, text, (uint32_t)(a >> 32), len))) {
-                                if (!(dbg & 4096)) cnt[pid] = TK_DUP_FLAG | i;
+                            // short pieces: identical iff the packed bytes are; long ones: same length and same bytes in the text
+                            const bool same = len <= 7u ? a == ident
+                                                        : ((a >> 32) == (ident >> 32) && ((dbg & 2048) || tk_equal_bytes(text, s, text, (uint32_t)a, len)));
+                            if (a != TK_EMPTY_KEY && same) {
+                                cnt[pid] = TK_DUP_FLAG | i;
                                 miss_kl[mi] = kl | TKD_DUP;
                                 bin = TK_NBIN;
                                 break;
