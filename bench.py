@@ -34,10 +34,7 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 KERNELS = ["tk_k_mark_docs", "tk_k_front", "tk_k_single_front", "tk_k_dedup", "tk_k_binfill", *[f"tk_k_merge_llane_{i}" for i in (16, 24, 32, 48, 64)],
            *[f"tk_k_merge_group_{i}" for i in (8, 16, 32, 64)], "tk_k_merge_long", "tk_k_dup_publish", "tk_k_tile_finish",
-           "tk_k_scan_small", "tk_k_back", "tk_k_docoff",
-           # the unfused A/B pipeline (TIKTOKEN_AMD_DEBUG=1024)
-           "tk_k_pretok", "tk_k_pretok2", "tk_k_count", "tk_k_emit", "tk_k_lookup", "tk_k_dup_fix", "tk_k_merge_group_64c",
-           "tk_k_scan_reduce", "tk_k_scan_down", "tk_k_gather"]
+           "tk_k_scan_small", "tk_k_back", "tk_k_docoff"]
 
 
 def gen_corpus(seed: int, mix: int, nbytes: int, threads: int):

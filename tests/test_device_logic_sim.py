@@ -58,6 +58,34 @@ def test_bitparallel_long_runs_and_window_edges(sims, name):
         assert ends.tolist() == C.split(pad + doc)
 
 
+@pytest.mark.parametrize("name", h.ENCODING_NAMES)
+def test_tile_rule_of_the_front_kernel(sims, name):
+    """tk_k_front's tile rule (tk_fused.h): every tile derives exactly the piece starts inside its own byte range
+    from its certain starts plus the last certain start in a bounded left context (else a walk back).  Simulated
+    with tiny tiles (many tile boundaries inside pieces) and with the real 4096 / 64 geometry."""
+    sim, C = sims[name], h.c_oracle_for(name)
+    rng = random.Random(41)
+    for _ in range(600):
+        docs = ["".join(rng.choice(h.ADV) for _ in range(rng.randint(0, 60))).encode() for _ in range(rng.randint(1, 4))]
+        blob, off = h.pack(docs)
+        ref = _ref_ends(C, docs, off)
+        for tile, left in ((16, 8), (32, 32), (64, 16)):
+            ends, _ = sim.piece_ends_tiled(blob, off, tile=tile, left=left)
+            assert ends.tolist() == ref, (docs, tile, left)
+    units = ["a", "A", "1", " ", "\n", "!", "中", "́", "'s", "/", "\t", "é"]
+    for _ in range(40):  # long runs: pieces that span several tiles, left context without any certain start
+        doc = "".join(rng.choice(["", " ", "x"]) + rng.choice(units) * rng.choice([1, 3, 70, 300, 5000]) for _ in range(30)).encode()
+        blob, off = h.pack([doc])
+        for tile, left in ((64, 16), (4096, 64)):
+            ends, _ = sim.piece_ends_tiled(blob, off, tile=tile, left=left)
+            assert ends.tolist() == C.split(doc), (tile, left)
+    blob, off = h.gen_corpus(77, 0, 1 << 20)
+    ends, walked = sim.piece_ends_tiled(blob, off)
+    ref, _ = sim.piece_ends(blob, off, bits=False)
+    assert np.array_equal(ends, ref)
+    assert walked < len(blob) // 4096  # the walk-back is the exception, not the rule
+
+
 REPS = {  # one or two representatives per character class, incl. every contraction letter in both cases
     "NL": ["\n", "\r"], "SP": [" "], "WSO": ["\t", "　"], "LU": ["S", "L", "E", "Z", "ǅ"], "LL": ["s", "l", "e", "ſ", "x", "t"],
     "LC": ["中", "ʰ"], "MK": ["́"], "NU": ["1", "²"], "AP": ["'"], "SL": ["/"], "OT": ["!", "\x1c"],

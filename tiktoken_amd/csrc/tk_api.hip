@@ -1,6 +1,6 @@
 // C ABI + host orchestration of the MI355X BPE encode path (see include/tiktoken_amd.h).
 // Host code here only builds tables, moves buffers and launches kernels; every byte of
-// pre-tokenisation and merging is done by the kernels in tk_kernels.h.  There is no CPU path.
+// pre-tokenisation and merging is done by the kernels in tk_fused.h / tk_kernels.h.  There is no CPU path.
 #include <hip/hip_runtime.h>
 #include <stdio.h>
 #include <stdlib.h>
@@ -13,7 +13,6 @@
 
 #include "../../include/tiktoken_amd.h"
 #include "tk_fused.h"
-#include "tk_kernels.h"
 #include "tk_tables.h"
 #include "tk_unicode_tables.inc"
 
@@ -67,9 +66,8 @@ struct tk_core {
     uint32_t spec_max_len = 0;
     std::mutex mu;
     // workspace
-    Buf text, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, tok1, cnt, tokbase, staging, listB, listC,
-        counters, total, partial, rkb, prof, mt_key, mt_rep, dup_list, coll_list, g_id, g_rk, g_nx, g_pv, g_lv, out_tokens, out_tok_off, allowed,
-        tile_np, tile_nt, tile_nmiss, doc_pid, mt_slots, wbin, wave_pieces;
+    Buf text, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, tok1, cnt, staging, listB, listC, counters, total, g_id, g_rk, g_nx,
+        g_pv, g_lv, out_tokens, out_tok_off, allowed, tile_np, tile_nt, tile_nmiss, doc_pid, mt_slots, wbin, wave_pieces;
     uint64_t chunk_bytes = 1ull << 30;
     int dbg = 0;
     // instrumentation
@@ -206,10 +204,10 @@ extern "C" void tk_destroy(tk_core* c) {
     (void)hipSetDevice(c->device);
     for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_piece, &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2,
                    &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off, &c->brk, &c->docb,
-                   &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->tok1, &c->cnt, &c->tokbase, &c->staging,
-                   &c->listB, &c->listC, &c->counters, &c->total, &c->partial, &c->rkb, &c->prof, &c->mt_key, &c->mt_rep, &c->dup_list, &c->coll_list, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv,
-                   &c->out_tokens, &c->out_tok_off, &c->allowed, &c->tile_np, &c->tile_nt, &c->tile_nmiss, &c->doc_pid, &c->mt_slots,
-                   &c->wbin, &c->wave_pieces})
+                   &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->tok1, &c->cnt, &c->staging, &c->listB,
+                   &c->listC, &c->counters, &c->total, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv, &c->out_tokens,
+                   &c->out_tok_off, &c->allowed, &c->tile_np, &c->tile_nt, &c->tile_nmiss, &c->doc_pid, &c->mt_slots, &c->wbin,
+                   &c->wave_pieces})
         release(*b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (int i = 0; i < 4; ++i) {
@@ -234,238 +232,6 @@ static uint32_t grid_for(uint64_t items, uint32_t per_block, uint32_t cap) {
 //   d_text: chunk text (readable 64 bytes past n); d_doc_off: uint64 offsets of the chunk's
 //   documents (n_docs+1 entries, absolute; `base` is subtracted); single_piece: the whole buffer
 //   is one piece (encode_single_piece), no pre-tokenisation.
-static int run_chunk_unfused(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t n, const uint64_t* d_doc_off, uint64_t n_docs,
-                     uint64_t base, bool use_special, bool single_piece, uint32_t* d_out, uint64_t tok_base_global,
-                     uint64_t* d_tok_off, uint64_t* n_tokens_out, bool pretok_only = false) {
-    const TkTables& T = c->D;
-    const uint64_t nwords = (n + 31) / 32;
-    const uint64_t nblk = (nwords + 255) / 256;
-    TRY(ensure(c->brk, (nwords + 2) * 4));
-    TRY(ensure(c->starts, (nwords + 2) * 4));
-    TRY(ensure(c->blockcnt, (nblk + 2) * 4));
-    TRY(ensure(c->counters, TK_CNT_N * 4));
-    TRY(ensure(c->total, 16));
-    if (c->dbg & 128) {
-        bool fresh = c->prof.p == nullptr;
-        TRY(ensure(c->prof, 64));
-        if (fresh) HIPCHK(hipMemsetAsync(c->prof.p, 0, 64, s));
-    }
-    HIPCHK(hipMemsetAsync(c->brk.p, 0, (nwords + 2) * 4, s));
-    HIPCHK(hipMemsetAsync(c->starts.p, 0, (nwords + 2) * 4, s));
-    HIPCHK(hipMemsetAsync(c->counters.p, 0, TK_CNT_N * 4, s));
-    uint32_t *brk = c->brk.as<uint32_t>(), *starts = c->starts.as<uint32_t>();
-    uint32_t *ss = nullptr, *si = nullptr, *docb = nullptr;
-    uint64_t P = 0;
-    if (n > 0 && !single_piece) {
-        if (use_special) {
-            TRY(ensure(c->docb, (nwords + 2) * 4));
-            TRY(ensure(c->cand, (nwords + 2) * 4));
-            TRY(ensure(c->ss, (nwords + 2) * 4));
-            TRY(ensure(c->si, (nwords + 2) * 4));
-            for (Buf* b : {&c->docb, &c->cand, &c->ss, &c->si}) HIPCHK(hipMemsetAsync(b->p, 0, (nwords + 2) * 4, s));
-            docb = c->docb.as<uint32_t>();
-            ss = c->ss.as<uint32_t>();
-            si = c->si.as<uint32_t>();
-        }
-        TRY(timed(c, s, "tk_k_mark_docs", [&] {
-            hipLaunchKernelGGL(tk_k_mark_docs, dim3(grid_for(n_docs, 256, 4096)), dim3(256), 0, s, d_doc_off, n_docs, base, n, brk, docb);
-        }));
-        if (use_special) {
-            const uint8_t* allowed = c->allowed.as<uint8_t>();
-            uint32_t* cand = c->cand.as<uint32_t>();
-            TRY(timed(c, s, "tk_k_spec_cand", [&] {
-                hipLaunchKernelGGL(tk_k_spec_cand, dim3(grid_for(n, 256, 16384)), dim3(256), 0, s, T, d_text, n, allowed, docb, cand);
-            }));
-            TRY(timed(c, s, "tk_k_spec_resolve", [&] {
-                hipLaunchKernelGGL(tk_k_spec_resolve, dim3(grid_for(n, 256, 16384)), dim3(256), 0, s, T, d_text, n, allowed, docb, cand,
-                                   c->spec_max_len, ss, si, brk);
-            }));
-        }
-        if (c->dbg & 32) {
-            TRY(timed(c, s, "tk_k_pretok", [&] {
-                hipLaunchKernelGGL(tk_k_pretok, dim3((uint32_t)((n + TK_TILE - 1) / TK_TILE)), dim3(256), 0, s, T, d_text, n, brk, ss, si, starts, c->dbg);
-            }));
-        } else {
-            TRY(timed(c, s, "tk_k_pretok2", [&] {
-                const dim3 grid((uint32_t)((n + TK_TILE - 1) / TK_TILE));
-                unsigned long long* prof = (c->dbg & 128) ? c->prof.as<unsigned long long>() : nullptr;
-                if (T.pattern == TK_PAT_R50K) hipLaunchKernelGGL((tk_k_pretok2<TK_PAT_R50K>), grid, dim3(256), 0, s, T, d_text, n, brk, ss, si, starts, prof);
-                else if (T.pattern == TK_PAT_CL100K) hipLaunchKernelGGL((tk_k_pretok2<TK_PAT_CL100K>), grid, dim3(256), 0, s, T, d_text, n, brk, ss, si, starts, prof);
-                else hipLaunchKernelGGL((tk_k_pretok2<TK_PAT_O200K>), grid, dim3(256), 0, s, T, d_text, n, brk, ss, si, starts, prof);
-            }));
-            if (c->dbg & 128) {
-                unsigned long long h[8];
-                HIPCHK(hipMemcpyAsync(h, c->prof.p, sizeof h, hipMemcpyDeviceToHost, s));
-                HIPCHK(hipStreamSynchronize(s));
-                fprintf(stderr, "pretok2 phase cycles (thread 0 of each block, summed): A=%llu B=%llu C=%llu D=%llu E=%llu\n", h[0], h[1], h[2], h[3], h[4]);
-                HIPCHK(hipMemsetAsync(c->prof.p, 0, 64, s));
-            }
-        }
-        TRY(timed(c, s, "tk_k_count", [&] {
-            hipLaunchKernelGGL(tk_k_count, dim3((uint32_t)nblk), dim3(256), 0, s, starts, nwords, c->blockcnt.as<uint32_t>());
-        }));
-        TRY(timed(c, s, "tk_k_scan_small", [&] {
-            hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, c->blockcnt.as<uint32_t>(), nblk, c->total.as<uint64_t>());
-        }));
-        HIPCHK(hipMemcpyAsync(&P, c->total.p, 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-    } else if (n > 0) {
-        P = 1;
-    }
-    TRY(ensure(c->pstart, (P + 2) * 4));
-    TRY(ensure(c->tok1, (P + 2) * 4));
-    TRY(ensure(c->cnt, (P + 2) * 4));
-    TRY(ensure(c->tokbase, (P + 2) * 4));
-    uint32_t* pstart = c->pstart.as<uint32_t>();
-    uint32_t* tokbase = c->tokbase.as<uint32_t>();
-    uint64_t T_total = 0;
-    uint64_t nB = 0, nC = 0;
-    if (P > 0) {
-        if (single_piece) {
-            uint32_t two[2] = {0, (uint32_t)n};
-            HIPCHK(hipMemcpyAsync(pstart, two, 8, hipMemcpyHostToDevice, s));
-        } else {
-            TRY(timed(c, s, "tk_k_emit", [&] {
-                hipLaunchKernelGGL(tk_k_emit, dim3((uint32_t)nblk), dim3(256), 0, s, starts, nwords, c->blockcnt.as<uint32_t>(), pstart, P, n);
-            }));
-        }
-        if (pretok_only) {
-            *n_tokens_out = P;
-            return TK_OK;
-        }
-        TRY(ensure(c->staging, (n + 64) * 4));
-        TkBins bins;
-        uint64_t pool = 0;
-        for (int b = 0; b < TK_NBIN; ++b) {
-            bins.off[b] = (uint32_t)pool;
-            pool += n / tk_bin_lo(b) + 64;
-        }
-        TRY(ensure(c->listB, pool * 4));
-        TRY(ensure(c->listC, (n / 65 + 64) * 12));
-        uint32_t* counters = c->counters.as<uint32_t>();
-        TkMissTable mt{nullptr, nullptr};
-        if (!single_piece && P > 4096) {
-            TRY(ensure(c->mt_key, (8ull << TK_MT_BITS)));
-            TRY(ensure(c->mt_rep, (4ull << TK_MT_BITS)));
-            TRY(ensure(c->coll_list, (n / 2 + 64) * 4));
-            HIPCHK(hipMemsetAsync(c->mt_key.p, 0xFF, (8ull << TK_MT_BITS), s));
-            mt.key = c->mt_key.as<unsigned long long>();
-            mt.rep = c->mt_rep.as<uint32_t>();
-        }
-        TRY(timed(c, s, "tk_k_lookup", [&] {
-            hipLaunchKernelGGL(tk_k_lookup, dim3(grid_for(P, 256 * TK_PPT, 4096)), dim3(256), 0, s, T, d_text, pstart, P, ss,
-                               c->tok1.as<uint32_t>(), c->cnt.as<uint32_t>(), c->listB.as<uint32_t>(), bins,
-                               c->listC.as<uint32_t>(), counters, mt, c->dbg);
-        }));
-        uint32_t hc[TK_CNT_N];
-        HIPCHK(hipMemcpyAsync(hc, counters, sizeof hc, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        nC = hc[TK_CNT_C];
-        for (int b = 0; b < TK_NBIN; ++b) nB += hc[TK_CNT_BIN0 + b];
-        if (nB) {
-            static const char* const names[TK_NBIN] = {"tk_k_merge_llane_16", "tk_k_merge_llane_24", "tk_k_merge_llane_32", "tk_k_merge_llane_48", "tk_k_merge_llane_64",
-                                                       "tk_k_merge_group_8", "tk_k_merge_group_16", "tk_k_merge_group_32", "tk_k_merge_group_64"};
-            // the bins are independent: spread them over the side streams, longest-tailed kernels first
-            HIPCHK(hipEventRecord(c->ev_fork, s));
-            for (int i = 0; i < 4; ++i) HIPCHK(hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
-            static const int order[TK_NBIN] = {8, 7, 6, 5, 0, 1, 4, 3, 2};
-            int slot = 0;
-            hipStream_t s_main = s;
-            for (int oi = 0; oi < TK_NBIN; ++oi) {
-                const int b = order[oi];
-                uint32_t cntb = hc[TK_CNT_BIN0 + b];
-                if (!cntb) continue;
-                if (c->dbg & 64) fprintf(stderr, "bin %d (%u..%u bytes): %u pieces\n", b, tk_bin_lo(b), tk_bin_hi(b), cntb);
-                const uint32_t* lst = c->listB.as<uint32_t>() + bins.off[b];
-                uint32_t *t1 = c->tok1.as<uint32_t>(), *cn = c->cnt.as<uint32_t>(), *stg = c->staging.as<uint32_t>();
-                hipStream_t s = c->aux[slot++ & 3];
-                TRY(timed(c, s, names[b], [&] {
-                    switch (b) {
-                        case 0: hipLaunchKernelGGL((tk_k_merge_llane<16, 256>), dim3(grid_for(cntb, 256, 32768)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
-                        case 1: hipLaunchKernelGGL((tk_k_merge_llane<24, 256>), dim3(grid_for(cntb, 256, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
-                        case 2: hipLaunchKernelGGL((tk_k_merge_llane<32, 256>), dim3(grid_for(cntb, 256, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
-                        case 3: hipLaunchKernelGGL((tk_k_merge_llane<48, 128>), dim3(grid_for(cntb, 128, 16384)), dim3(128), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
-                        case 4: hipLaunchKernelGGL((tk_k_merge_llane<64, 128>), dim3(grid_for(cntb, 128, 16384)), dim3(128), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg); break;
-                        case 5: hipLaunchKernelGGL((tk_k_merge_group<8>), dim3(grid_for(cntb, 32, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg, (const uint32_t*)nullptr); break;
-                        case 6: hipLaunchKernelGGL((tk_k_merge_group<16>), dim3(grid_for(cntb, 16, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg, (const uint32_t*)nullptr); break;
-                        case 7: hipLaunchKernelGGL((tk_k_merge_group<32>), dim3(grid_for(cntb, 8, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg, (const uint32_t*)nullptr); break;
-                        default: hipLaunchKernelGGL((tk_k_merge_group<64>), dim3(grid_for(cntb, 4, 16384)), dim3(256), 0, s, T, d_text, pstart, lst, cntb, t1, cn, stg, (const uint32_t*)nullptr); break;
-                    }
-                }));
-            }
-            for (int i = 0; i < 4; ++i) {
-                HIPCHK(hipEventRecord(c->ev_join[i], c->aux[i]));
-                HIPCHK(hipStreamWaitEvent(s_main, c->ev_join[i], 0));
-            }
-        }
-        if (nC) {
-            uint64_t lb = hc[TK_CNT_CBYTES], lvls = hc[TK_CNT_CLEVELS];
-            TRY(ensure(c->g_id, (lb + 64) * 4));
-            TRY(ensure(c->g_rk, (lb + 64) * 4));
-            TRY(ensure(c->g_nx, (lb + 64) * 4));
-            TRY(ensure(c->g_pv, (lb + 64) * 4));
-            TRY(ensure(c->g_lv, (lvls + 64) * 8));
-            TRY(timed(c, s, "tk_k_merge_long", [&] {
-                hipLaunchKernelGGL(tk_k_merge_long, dim3(grid_for(nC, 4, 8192)), dim3(256), 0, s, T, d_text, pstart, c->listC.as<uint32_t>(),
-                                   (uint32_t)nC, c->g_id.as<uint32_t>(), c->g_rk.as<uint32_t>(), c->g_nx.as<uint32_t>(),
-                                   c->g_pv.as<uint32_t>(), c->g_lv.as<uint64_t>(), c->tok1.as<uint32_t>(), c->cnt.as<uint32_t>(),
-                                   c->staging.as<uint32_t>());
-            }));
-        }
-        if (mt.key) {
-            TRY(timed(c, s, "tk_k_dup_fix", [&] {
-                hipLaunchKernelGGL(tk_k_dup_fix, dim3(grid_for(P, 256, 16384)), dim3(256), 0, s, d_text, pstart, P, mt,
-                                   c->tok1.as<uint32_t>(), c->cnt.as<uint32_t>(), c->coll_list.as<uint32_t>(), counters);
-            }));
-            // hash collisions (different bytes, same 64-bit hash) are encoded on their own; the list length lives on the device
-            TRY(timed(c, s, "tk_k_merge_group_64c", [&] {
-                hipLaunchKernelGGL((tk_k_merge_group<64>), dim3(256), dim3(256), 0, s, T, d_text, pstart, c->coll_list.as<uint32_t>(), 0u,
-                                   c->tok1.as<uint32_t>(), c->cnt.as<uint32_t>(), c->staging.as<uint32_t>(), counters + TK_CNT_COLL);
-            }));
-        }
-        // token counts -> offsets
-        const uint64_t nsb = (P + 256 * TK_SCAN_EPT - 1) / (256 * TK_SCAN_EPT);
-        TRY(ensure(c->partial, (nsb + 2) * 4));
-        TRY(timed(c, s, "tk_k_scan_reduce", [&] {
-            hipLaunchKernelGGL(tk_k_scan_reduce, dim3((uint32_t)nsb), dim3(256), 0, s, c->cnt.as<uint32_t>(), P, c->partial.as<uint32_t>());
-        }));
-        TRY(timed(c, s, "tk_k_scan_small", [&] {
-            hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, c->partial.as<uint32_t>(), nsb, c->total.as<uint64_t>());
-        }));
-        TRY(timed(c, s, "tk_k_scan_down", [&] {
-            hipLaunchKernelGGL(tk_k_scan_down, dim3((uint32_t)nsb), dim3(256), 0, s, c->cnt.as<uint32_t>(), P, c->partial.as<uint32_t>(), tokbase);
-        }));
-        HIPCHK(hipMemcpyAsync(&T_total, c->total.p, 8, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        TRY(timed(c, s, "tk_k_gather", [&] {
-            hipLaunchKernelGGL(tk_k_gather, dim3(grid_for(P, 256, 8192)), dim3(256), 0, s, pstart, P, c->cnt.as<uint32_t>(), tokbase,
-                               c->tok1.as<uint32_t>(), c->staging.as<uint32_t>(), d_out);
-        }));
-    } else {
-        HIPCHK(hipMemsetAsync(tokbase, 0, 8, s));
-        if (pretok_only) {
-            uint32_t zero = 0;
-            HIPCHK(hipMemcpyAsync(pstart, &zero, 4, hipMemcpyHostToDevice, s));
-            HIPCHK(hipStreamSynchronize(s));
-            *n_tokens_out = 0;
-            return TK_OK;
-        }
-    }
-    if (d_tok_off) {
-        TRY(timed(c, s, "tk_k_docoff", [&] {
-            hipLaunchKernelGGL(tk_k_docoff, dim3(grid_for(n_docs + 1, 256, 4096)), dim3(256), 0, s, d_doc_off, n_docs, base, n, starts,
-                               c->blockcnt.as<uint32_t>(), tokbase, P, tok_base_global, d_tok_off);
-        }));
-    }
-    c->st_bytes += n;
-    c->st_pieces += P;
-    c->st_tokens += T_total;
-    c->st_medium += nB;
-    c->st_long += nC;
-    *n_tokens_out = T_total;
-    return TK_OK;
-}
-
 template <class... A>
 static void launch_front(int pattern, bool spec, dim3 grid, hipStream_t s, A... a) {
     if (pattern == TK_PAT_R50K) {
@@ -486,7 +252,6 @@ static void launch_front(int pattern, bool spec, dim3 grid, hipStream_t s, A... 
 static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t n, const uint64_t* d_doc_off, uint64_t n_docs,
                      uint64_t base, bool use_special, bool single_piece, uint32_t* d_out, uint64_t tok_base_global,
                      uint64_t* d_tok_off, uint64_t* n_tokens_out, bool pretok_only = false) {
-    if (c->dbg & 1024) return run_chunk_unfused(c, s, d_text, n, d_doc_off, n_docs, base, use_special, single_piece, d_out, tok_base_global, d_tok_off, n_tokens_out, pretok_only);
     const TkTables& T = c->D;
     const uint64_t nwords = (n + 31) / 32;
     const uint64_t nblk = (nwords + 255) / 256;

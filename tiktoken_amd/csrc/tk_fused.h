@@ -1,20 +1,31 @@
-// Fused encode pipeline (the production path; the unfused kernels of tk_kernels.h remain selectable with
-// TIKTOKEN_AMD_DEBUG=1024 as the A/B reference).
+// The encode pipeline (one launch sequence per chunk of packed documents).  Hot path of
+// Encoding.encode_ordinary_batch / encode_batch (tiktoken/core.py:164-206 -> src/lib.rs:360-457).
 //
-//   tk_k_front<PAT>     per 4 KiB tile: pre-tokenise (as tk_k_pretok2) -> enumerate the pieces that START in
-//                       the tile -> whole-piece probe from the LDS copy of the text -> results written as a
-//                       dense run at piece id  pid = tile * 4096 + k.  No piece offsets travel through HBM.
-//   tk_k_mergeF_*       the lane / lane-group / tree merges on {pid, start, length} list entries
-//   tk_k_dup_publish    claimant results -> miss-table slots
-//   tk_k_tile_finish    duplicates copy their claimant's result; token count per tile
-//   tk_k_scan_small     exclusive scan of the tile counts (262 144 entries per GiB)
-//   tk_k_back           per tile: local scan of the piece counts, tokens written to their final place
-//   tk_k_docoffF        per document: token offset of the piece that starts it
+//   tk_k_front<PAT,SPEC>  per 4 KiB tile: classify every byte, build the class-set bitmaps, find the piece starts
+//                         (regex pre-tokenisation, src/lib.rs:365), enumerate the pieces that START in the tile and
+//                         probe each one whole in the vocabulary (src/lib.rs:367) from the LDS copy of the text.
+//                         Results form a run at piece id  pid = tile * 4096 + k;  pieces that are not a token go
+//                         to the tile's miss list.  No piece offsets travel through HBM.
+//   tk_k_dedup            miss lists -> claim / find identical bytes in the in-call miss table (exact: verified)
+//   tk_k_scan_small + tk_k_binfill   first occurrences -> length-binned lists, without global atomics
+//   tk_k_mergeF_llane<N>  one LANE per 2..64-byte piece: byte_pair_merge in LDS           (src/lib.rs:140-196)
+//   tk_k_mergeF_group<G>  G lanes per 65..1024-byte piece
+//   tk_k_mergeF_long      one wavefront per longer piece, 64-ary min tree in HBM scratch  (same result as lib.rs:47-138)
+//   tk_k_dup_publishF     claimant results -> miss-table slots
+//   tk_k_tile_finish      duplicates copy their claimant's result; token count per tile
+//   tk_k_scan_small       exclusive scan of the tile counts (262 144 entries per GiB)
+//   tk_k_back             per tile: local scan of the piece counts, tokens written to their final place
+//   tk_k_docoffF          per document: token offset of the piece that starts it
 //
-// Tile rule (verified on the CPU by tests/hostsim tks_pretok_tiles): a tile derives exactly the piece
-// starts inside its own byte range.  Scanners start at the tile's certain starts plus the last certain
-// start before the tile (64-byte left context, else a walk back through HBM), record only boundaries
-// inside the tile and stop at its end.  Nothing crosses tiles, so tiles are fully independent.
+// Tile rule (checked on the CPU by tests/test_device_logic_sim.py): a tile derives exactly the piece starts
+// inside its own byte range.  Scanners start at the tile's certain starts plus the last certain start before the
+// tile (64-byte left context, else a walk back through HBM), record only boundaries inside the tile and stop at
+// its end.  Nothing crosses tiles, so tiles are fully independent.
+//
+// Two hardware facts shape the code (measured): tk_k_front is VALU-bound (a wave64 VALU
+// instruction occupies a SIMD16 for four cycles; 82 % VALU utilisation), so the classification loop is written
+// with integer flags instead of short-circuit control flow; and same-address returning atomics run at only
+// 25..130 M/s on this multi-XCD part, so nothing on the path allocates through a global counter.
 #pragma once
 #include "tk_kernels.h"
 
@@ -342,9 +353,8 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
         pre[0] = 0;
 #pragma unroll
         for (int q = 0; q < 8; ++q) pre[q + 1] = pre[q] + cnw[q];
-        uint32_t i = (dbg & 16384) ? 0xFFFFFFFFu : tid;  // (perf experiment: no scanning)
+        uint32_t i = tid;
         bool walk = tid == 0 && need_walk;
-        if (dbg & 16384) spill_mask = 0, walk = false;
         for (;;) {
             uint64_t p;
             if (i < pre[8]) {
@@ -534,7 +544,7 @@ __global__ __launch_bounds__(256) void tk_k_dedup(const uint8_t* __restrict__ te
                             if (a == TK_EMPTY_KEY) a = __hip_atomic_load(&mt[i].aux, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                             // short pieces: identical iff the packed bytes are; long ones: same length and same bytes in the text
                             const bool same = len <= 7u ? a == ident
-                                                        : ((a >> 32) == (ident >> 32) && ((dbg & 2048) || tk_equal_bytes(text, s, text, (uint32_t)a, len)));
+                                                        : ((a >> 32) == (ident >> 32) && tk_equal_bytes(text, s, text, (uint32_t)a, len));
                             if (a != TK_EMPTY_KEY && same) {
                                 cnt[pid] = TK_DUP_FLAG | i;
                                 miss_kl[mi] = kl | TKD_DUP;
