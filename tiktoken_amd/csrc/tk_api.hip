@@ -292,9 +292,10 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
     uint32_t* counters = c->counters.as<uint32_t>();
     uint32_t *tok1 = c->tok1.as<uint32_t>(), *cnt = c->cnt.as<uint32_t>(), *stg = c->staging.as<uint32_t>();
     uint32_t *tile_np = c->tile_np.as<uint32_t>(), *tile_nt = c->tile_nt.as<uint32_t>();
-    // The per-tile miss lists (indexed like piece ids) live in memory that is not needed until the merges start:
-    // starts in the staging area, index | length in the output region (both hold tk_pid_cap(n) entries).
-    TkFrontOut fo{starts, tile_np, tok1, cnt, c->tile_nmiss.as<uint32_t>(), stg, d_out, c->listC.as<uint32_t>(), counters, c->doc_pid.as<uint32_t>()};
+    // The per-tile miss lists (TKF_MISS_CAP entries per tile) live in memory that is not needed until the merges
+    // start: the keys in the staging area, starts and index | length in the two halves of the output region.
+    TkFrontOut fo{starts, tile_np, tok1, cnt, c->tile_nmiss.as<uint32_t>(), d_out, d_out ? d_out + ntiles * TKF_MISS_CAP : nullptr,
+                  (unsigned long long*)stg, c->listC.as<uint32_t>(), counters, c->doc_pid.as<uint32_t>()};
     TkMissSlot* mt = nullptr;
     uint64_t nB = 0, nC = 0;
     if (n > 0 && !single_piece) {
@@ -360,7 +361,7 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
     if (n > 0) {
         uint32_t* wbin = c->wbin.as<uint32_t>();
         TRY(timed(c, s, "tk_k_dedup", [&] {
-            hipLaunchKernelGGL(tk_k_dedup, dim3(TKD_WAVES / 4), dim3(256), 0, s, d_text, ntiles, fo.tile_nmiss, fo.miss_s, fo.miss_kl, mt, tok1, cnt, wbin, c->dbg);
+            hipLaunchKernelGGL(tk_k_dedup, dim3(TKD_WAVES / 4), dim3(256), 0, s, d_text, ntiles, fo.tile_nmiss, fo.miss_s, fo.miss_kl, fo.miss_key, mt, cnt, wbin, c->dbg);
         }));
         TRY(timed(c, s, "tk_k_scan_small", [&] {
             hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, wbin, (uint64_t)TK_NBIN * TKD_WAVES + 1, c->total.as<uint64_t>());

@@ -30,6 +30,7 @@
 #include "tk_kernels.h"
 
 #define TKF_NONE 0xFFFFFFFFu
+#define TKF_MISS_CAP 2048  // missed pieces per tile: each is at least two bytes long
 #define TKF_CAP 4096  // piece ids per tile: pid = tile * TKF_CAP + k (a 4096-byte tile starts at most 4096 pieces)
 
 struct TkFrontOut {
@@ -38,8 +39,9 @@ struct TkFrontOut {
     uint32_t* tok1;       // [piece id] token (count 1) or staging position of the tokens (count > 1)
     uint32_t* cnt;        // [piece id] token count, or TK_DUP_FLAG | slot
     uint32_t* tile_nmiss; // pieces of the tile that are not a token (and at most TK_GLANE_MAX bytes long)
-    uint32_t* miss_s;     // [run base + j] their start ...
-    uint32_t* miss_kl;    // ... and (index in the run) | (length - 1) << 12; consumed by tk_k_dedup
+    uint32_t* miss_s;     // [tile * TKF_MISS_CAP + j] their start ...
+    uint32_t* miss_kl;    // ... (index in the run) | (length - 1) << 12 ...
+    unsigned long long* miss_key;  // ... and key (exact bytes or hash); consumed by tk_k_dedup
     uint32_t* listC;      // {pid, start, len, scratch bytes before, tree levels before} for > 1 KiB pieces
     uint32_t* counters;
     uint32_t* doc_pid;    // [n_docs] piece id at which each document starts (TKF_NONE: no piece)
@@ -407,7 +409,7 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
     for (uint32_t k0 = 0; k0 < np; k0 += 256) {
         const uint32_t k = k0 + tid;
         uint32_t cat = 0, len = 0;  // cat 1: not a token (-> miss list), 2: longer than the lane-group kernels take (-> tree list)
-        uint64_t gs = 0;
+        uint64_t gs = 0, mkey = 0;
         const uint32_t pid = run_base + k;
         if (k < np) {
             const uint32_t s_loc = plist[k];
@@ -440,9 +442,8 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
                 } else if (len > TK_GLANE_MAX) {
                     cat = 2u;
                 } else {
-                    cat = 1u;  // the key (exact bytes, or their hash) travels to tk_k_dedup in the piece's own result slots
-                    out.tok1[pid] = (uint32_t)key;
-                    out.cnt[pid] = (uint32_t)(key >> 32);
+                    cat = 1u;
+                    mkey = key;  // (exact bytes, or their hash: travels to tk_k_dedup with the miss entry)
                 }
             }
         }
@@ -453,8 +454,10 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
             if (lane == leader) at = atomicAdd(&nmiss_sh, (uint32_t)__popcll(m));
             at = __shfl(at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
             if (cat == 1u) {
-                out.miss_s[run_base + at] = (uint32_t)gs;
-                out.miss_kl[run_base + at] = k | ((len - 1u) << 12);
+                const uint64_t mi = tile * TKF_MISS_CAP + at;
+                out.miss_s[mi] = (uint32_t)gs;
+                out.miss_kl[mi] = k | ((len - 1u) << 12);
+                out.miss_key[mi] = mkey;
             }
         }
         if (cat == 2u) tk_append_tree(out.listC, out.counters, pid, (uint32_t)gs, len);
@@ -492,14 +495,14 @@ struct TkMissGroup {  // the miss lists of TKD_GROUP consecutive tiles, flattene
 #pragma unroll
         for (int i = 1; i < TKD_GROUP; ++i) q += f >= pre[i];
         *run_base = (uint32_t)(t0 + q) * TKF_CAP;
-        return *run_base + (f - pre[q]);
+        return (uint32_t)(t0 + q) * TKF_MISS_CAP + (f - pre[q]);
     }
 };
 
 __global__ __launch_bounds__(256) void tk_k_dedup(const uint8_t* __restrict__ text, uint64_t ntiles, const uint32_t* __restrict__ tile_nmiss,
                                                   const uint32_t* __restrict__ miss_s, uint32_t* __restrict__ miss_kl,
-                                                  TkMissSlot* __restrict__ mt, const uint32_t* __restrict__ tok1, uint32_t* __restrict__ cnt,
-                                                  uint32_t* __restrict__ wbin, int dbg) {
+                                                  const unsigned long long* __restrict__ miss_key, TkMissSlot* __restrict__ mt,
+                                                  uint32_t* __restrict__ cnt, uint32_t* __restrict__ wbin, int dbg) {
     const int lane = threadIdx.x & 63;
     const uint64_t ngroups = (ntiles + TKD_GROUP - 1) / TKD_GROUP;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
@@ -520,7 +523,7 @@ __global__ __launch_bounds__(256) void tk_k_dedup(const uint8_t* __restrict__ te
                 const uint32_t pid = rb + (kl & 4095u), s = miss_s[mi], len = ((kl >> 12) & 1023u) + 1u;
                 bin = (uint32_t)tk_bin_of(len);
                 if (mt && !(dbg & 256)) {
-                    const uint64_t key = ((uint64_t)cnt[pid] << 32) | tok1[pid];  // left there by the front kernel
+                    const uint64_t key = miss_key[mi];
                     const unsigned long long ident = len <= 7u ? (key | ((unsigned long long)len << 56))
                                                                : ((1ull << 63) | ((unsigned long long)len << 32) | s);
                     unsigned long long kk = tk_mix64(key ^ ((uint64_t)len * 0xA24BAED4963EE407ull));
