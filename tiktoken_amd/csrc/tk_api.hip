@@ -59,7 +59,8 @@ struct tk_core {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};  // side streams: the merge kernels are independent of each other
-    hipEvent_t ev_fork = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t ev_fork = nullptr, ev_cnt = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    uint32_t* h_counters = nullptr;  // pinned
     TkHostTables H;
     TkTables D;  // device view
     Buf t_stage1, t_stage2, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_spec_bytes, t_spec_off, t_spec_id;
@@ -156,7 +157,9 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     for (int i = 0; i < 4; ++i)
         if (hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess)
             return bail(fail(TK_RUNTIME_ERROR, "hipStreamCreate failed"));
-    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess) return bail(fail(TK_RUNTIME_ERROR, "hipEventCreate failed"));
+    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_cnt, hipEventDisableTiming) != hipSuccess)
+        return bail(fail(TK_RUNTIME_ERROR, "hipEventCreate failed"));
+    if (hipHostMalloc((void**)&c->h_counters, 256, hipHostMallocDefault) != hipSuccess) return bail(fail(TK_RUNTIME_ERROR, "hipHostMalloc failed"));
     const TkHostTables& H = c->H;
     int rc;
     if ((rc = upload(c->t_stage1, tk_uc_stage1, sizeof tk_uc_stage1))) return bail(rc);
@@ -215,6 +218,8 @@ extern "C" void tk_destroy(tk_core* c) {
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
+    if (c->ev_cnt) (void)hipEventDestroy(c->ev_cnt);
+    if (c->h_counters) (void)hipHostFree(c->h_counters);
     delete c;
 }
 
@@ -335,6 +340,9 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
     } else if (n > 0) {
         TRY(timed(c, s, "tk_k_single_front", [&] { hipLaunchKernelGGL(tk_k_single_front, dim3(1), dim3(64), 0, s, T, d_text, (uint32_t)n, fo); }));
     }
+    // the front kernel's counters (pieces for the tree kernel) go back to the host while the next kernels run
+    HIPCHK(hipMemcpyAsync(c->h_counters, counters, TK_CNT_N * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(c->ev_cnt, s));
     if (pretok_only) {  // debugging / test entry: piece offsets only
         uint64_t P = 0;
         TRY(ensure(c->pstart, 16));
@@ -370,37 +378,39 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
             hipLaunchKernelGGL(tk_k_binfill, dim3(TKD_WAVES / 4), dim3(256), 0, s, ntiles, fo.tile_nmiss, fo.miss_s, fo.miss_kl, wbin, c->listB.as<uint32_t>(), bins,
                                counters);
         }));
-        uint32_t hc[TK_CNT_N];
-        HIPCHK(hipMemcpyAsync(hc, counters, sizeof hc, hipMemcpyDeviceToHost, s));
-        HIPCHK(hipStreamSynchronize(s));
-        nC = hc[TK_CNT_C];
-        for (int b = 0; b < TK_NBIN; ++b) nB += hc[TK_CNT_BIN0 + b];
-        if (nB) {
+        {
+            // The bins are independent: spread them over the side streams, longest-tailed kernels first.  List lengths are
+            // read on the device, so nothing waits for the host here; grids are sized by the most a bin can hold.
             static const char* const names[TK_NBIN] = {"tk_k_merge_llane_16", "tk_k_merge_llane_24", "tk_k_merge_llane_32", "tk_k_merge_llane_48", "tk_k_merge_llane_64",
                                                        "tk_k_merge_group_8", "tk_k_merge_group_16", "tk_k_merge_group_32", "tk_k_merge_group_64"};
-            // the bins are independent: spread them over the side streams, longest-tailed kernels first
+            uint32_t small_counts[TK_CNT_N];
+            const bool small = n <= 32768;  // small calls: a round trip is cheaper than launching kernels over empty lists
+            if (small) {
+                HIPCHK(hipMemcpyAsync(small_counts, counters, sizeof small_counts, hipMemcpyDeviceToHost, s));
+                HIPCHK(hipStreamSynchronize(s));
+            }
             HIPCHK(hipEventRecord(c->ev_fork, s));
             for (int i = 0; i < 4; ++i) HIPCHK(hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
             static const int order[TK_NBIN] = {8, 7, 6, 5, 0, 1, 4, 3, 2};
             int slot = 0;
             for (int oi = 0; oi < TK_NBIN; ++oi) {
                 const int b = order[oi];
-                const uint32_t cntb = hc[TK_CNT_BIN0 + b];
-                if (!cntb) continue;
-                if (c->dbg & 64) fprintf(stderr, "bin %d (%u..%u bytes): %u pieces\n", b, tk_bin_lo(b), tk_bin_hi(b), cntb);
+                if (n < tk_bin_lo(b) || (small && !small_counts[TK_CNT_BIN0 + b])) continue;
+                const uint64_t most = n / tk_bin_lo(b);
                 const uint32_t* lst = c->listB.as<uint32_t>() + 3 * (uint64_t)bins.off[b];
+                const uint32_t* cp = counters + TK_CNT_BIN0 + b;
                 hipStream_t sa = c->aux[slot++ & 3];
                 TRY(timed(c, sa, names[b], [&] {
                     switch (b) {
-                        case 0: hipLaunchKernelGGL((tk_k_mergeF_llane<16, 256>), dim3(grid_for(cntb, 256, 32768)), dim3(256), 0, sa, T, d_text, lst, cntb, tok1, cnt, stg); break;
-                        case 1: hipLaunchKernelGGL((tk_k_mergeF_llane<24, 256>), dim3(grid_for(cntb, 256, 16384)), dim3(256), 0, sa, T, d_text, lst, cntb, tok1, cnt, stg); break;
-                        case 2: hipLaunchKernelGGL((tk_k_mergeF_llane<32, 256>), dim3(grid_for(cntb, 256, 16384)), dim3(256), 0, sa, T, d_text, lst, cntb, tok1, cnt, stg); break;
-                        case 3: hipLaunchKernelGGL((tk_k_mergeF_llane<48, 128>), dim3(grid_for(cntb, 128, 16384)), dim3(128), 0, sa, T, d_text, lst, cntb, tok1, cnt, stg); break;
-                        case 4: hipLaunchKernelGGL((tk_k_mergeF_llane<64, 128>), dim3(grid_for(cntb, 128, 16384)), dim3(128), 0, sa, T, d_text, lst, cntb, tok1, cnt, stg); break;
-                        case 5: hipLaunchKernelGGL((tk_k_mergeF_group<8>), dim3(grid_for(cntb, 32, 16384)), dim3(256), 0, sa, T, d_text, lst, cntb, tok1, cnt, stg); break;
-                        case 6: hipLaunchKernelGGL((tk_k_mergeF_group<16>), dim3(grid_for(cntb, 16, 16384)), dim3(256), 0, sa, T, d_text, lst, cntb, tok1, cnt, stg); break;
-                        case 7: hipLaunchKernelGGL((tk_k_mergeF_group<32>), dim3(grid_for(cntb, 8, 16384)), dim3(256), 0, sa, T, d_text, lst, cntb, tok1, cnt, stg); break;
-                        default: hipLaunchKernelGGL((tk_k_mergeF_group<64>), dim3(grid_for(cntb, 4, 16384)), dim3(256), 0, sa, T, d_text, lst, cntb, tok1, cnt, stg); break;
+                        case 0: hipLaunchKernelGGL((tk_k_mergeF_llane<16, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
+                        case 1: hipLaunchKernelGGL((tk_k_mergeF_llane<24, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
+                        case 2: hipLaunchKernelGGL((tk_k_mergeF_llane<32, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
+                        case 3: hipLaunchKernelGGL((tk_k_mergeF_llane<48, 128>), dim3(grid_for(most, 128, 8192)), dim3(128), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
+                        case 4: hipLaunchKernelGGL((tk_k_mergeF_llane<64, 128>), dim3(grid_for(most, 128, 8192)), dim3(128), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
+                        case 5: hipLaunchKernelGGL((tk_k_mergeF_group<8>), dim3(grid_for(most, 32, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
+                        case 6: hipLaunchKernelGGL((tk_k_mergeF_group<16>), dim3(grid_for(most, 16, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
+                        case 7: hipLaunchKernelGGL((tk_k_mergeF_group<32>), dim3(grid_for(most, 8, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
+                        default: hipLaunchKernelGGL((tk_k_mergeF_group<64>), dim3(grid_for(most, 4, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
                     }
                 }));
             }
@@ -409,6 +419,11 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
                 HIPCHK(hipStreamWaitEvent(s, c->ev_join[i], 0));
             }
         }
+        // pieces longer than TK_GLANE_MAX were listed by the front kernel: their scratch is sized from its counters,
+        // which were copied back while the kernels above were being queued
+        HIPCHK(hipEventSynchronize(c->ev_cnt));
+        const uint32_t* hc = c->h_counters;
+        nC = hc[TK_CNT_C];
         if (nC) {
             const uint64_t lb = hc[TK_CNT_CBYTES], lvls = hc[TK_CNT_CLEVELS];
             TRY(ensure(c->g_id, (lb + 64) * 4));
@@ -442,8 +457,14 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         }));
     }
     uint64_t tp[2] = {0, 0};  // tokens, pieces
+    uint32_t hb[TK_CNT_N] = {0};
     HIPCHK(hipMemcpyAsync(tp, c->total.p, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(hb, counters, sizeof hb, hipMemcpyDeviceToHost, s));
     HIPCHK(hipStreamSynchronize(s));
+    for (int b = 0; b < TK_NBIN; ++b) {
+        nB += hb[TK_CNT_BIN0 + b];
+        if ((c->dbg & 64) && hb[TK_CNT_BIN0 + b]) fprintf(stderr, "bin %d (%u..%u bytes): %u pieces\n", b, tk_bin_lo(b), tk_bin_hi(b), hb[TK_CNT_BIN0 + b]);
+    }
     const uint64_t T_total = tp[0];
     c->st_bytes += n;
     c->st_pieces += tp[1];

@@ -620,8 +620,9 @@ __global__ __launch_bounds__(256) void tk_k_binfill(uint64_t ntiles, const uint3
 // ------------------------------------------------------------------------------------------
 template <int NMAX, int THREADS>
 __global__ __launch_bounds__(THREADS) void tk_k_mergeF_llane(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ list,
-                                                             uint32_t count, uint32_t* __restrict__ tok1, uint32_t* __restrict__ cnt,
-                                                             uint32_t* __restrict__ staging) {
+                                                             const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ tok1,
+                                                             uint32_t* __restrict__ cnt, uint32_t* __restrict__ staging) {
+    const uint32_t count = *count_ptr;  // list length produced on the device (tk_k_binfill): no host round trip before the merges
     __shared__ uint32_t s_id[NMAX * THREADS];
     __shared__ uint32_t s_rk[NMAX * THREADS];
     uint32_t* id = s_id + threadIdx.x;
@@ -636,8 +637,9 @@ __global__ __launch_bounds__(THREADS) void tk_k_mergeF_llane(TkTables T, const u
 
 template <int G>
 __global__ __launch_bounds__(256) void tk_k_mergeF_group(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ list,
-                                                         uint32_t count, uint32_t* __restrict__ tok1, uint32_t* __restrict__ cnt,
-                                                         uint32_t* __restrict__ staging) {
+                                                         const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ tok1,
+                                                         uint32_t* __restrict__ cnt, uint32_t* __restrict__ staging) {
+    const uint32_t count = *count_ptr;
     constexpr int C = 16, NMAX = G * C, PPW = 64 / G;
     constexpr uint32_t NONE = 0xFFFFu;
     __shared__ __attribute__((aligned(16))) uint32_t s_id[4][1024];
