@@ -302,6 +302,7 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
     TkFrontOut fo{starts, tile_np, tok1, cnt, c->tile_nmiss.as<uint32_t>(), d_out, d_out ? d_out + ntiles * TKF_MISS_CAP : nullptr,
                   (unsigned long long*)stg, c->listC.as<uint32_t>(), counters, c->doc_pid.as<uint32_t>()};
     TkMissSlot* mt = nullptr;
+    uint32_t mt_bits = 14;
     uint64_t nB = 0, nC = 0;
     if (n > 0 && !single_piece) {
         if (use_special) {
@@ -329,8 +330,9 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
             }));
         }
         if (n > 32768 && !pretok_only) {  // in-call de-duplication of missed pieces pays for its table reset only on real batches
-            TRY(ensure(c->mt_slots, sizeof(TkMissSlot) << TK_MT_BITS));
-            HIPCHK(hipMemsetAsync(c->mt_slots.p, 0xFF, sizeof(TkMissSlot) << TK_MT_BITS, s));
+            while (mt_bits < TK_MT_BITS && (1ull << mt_bits) < n / 128) ++mt_bits;  // 4 Mi slots from 512 MiB up
+            TRY(ensure(c->mt_slots, sizeof(TkMissSlot) << mt_bits));
+            HIPCHK(hipMemsetAsync(c->mt_slots.p, 0xFF, sizeof(TkMissSlot) << mt_bits, s));
             mt = c->mt_slots.as<TkMissSlot>();
         }
         TRY(timed(c, s, "tk_k_front", [&] {
@@ -368,14 +370,17 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
     }
     if (n > 0) {
         uint32_t* wbin = c->wbin.as<uint32_t>();
+        // the two list passes and the tile passes: as many workgroups as the chunk has work for (small calls are latency-bound)
+        const uint32_t dd_blocks = grid_for(ntiles, 4 * TKD_GROUP, TKD_WAVES / 4), tf_blocks = grid_for(ntiles, 4, 4096);
         TRY(timed(c, s, "tk_k_dedup", [&] {
-            hipLaunchKernelGGL(tk_k_dedup, dim3(TKD_WAVES / 4), dim3(256), 0, s, d_text, ntiles, fo.tile_nmiss, fo.miss_s, fo.miss_kl, fo.miss_key, mt, cnt, wbin, c->dbg);
+            hipLaunchKernelGGL(tk_k_dedup, dim3(dd_blocks), dim3(256), 0, s, d_text, ntiles, fo.tile_nmiss, fo.miss_s, fo.miss_kl, fo.miss_key, mt, (1u << mt_bits) - 1u, cnt, wbin,
+                               c->dbg);
         }));
         TRY(timed(c, s, "tk_k_scan_small", [&] {
-            hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, wbin, (uint64_t)TK_NBIN * TKD_WAVES + 1, c->total.as<uint64_t>());
+            hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, wbin, (uint64_t)TK_NBIN * dd_blocks * 4 + 1, c->total.as<uint64_t>());
         }));
         TRY(timed(c, s, "tk_k_binfill", [&] {
-            hipLaunchKernelGGL(tk_k_binfill, dim3(TKD_WAVES / 4), dim3(256), 0, s, ntiles, fo.tile_nmiss, fo.miss_s, fo.miss_kl, wbin, c->listB.as<uint32_t>(), bins,
+            hipLaunchKernelGGL(tk_k_binfill, dim3(dd_blocks), dim3(256), 0, s, ntiles, fo.tile_nmiss, fo.miss_s, fo.miss_kl, wbin, c->listB.as<uint32_t>(), bins,
                                counters);
         }));
         {
@@ -438,12 +443,12 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
             }));
         }
         if (mt) {
-            TRY(timed(c, s, "tk_k_dup_publish", [&] { hipLaunchKernelGGL(tk_k_dup_publishF, dim3(4096), dim3(256), 0, s, mt, tok1, cnt); }));
+            TRY(timed(c, s, "tk_k_dup_publish", [&] { hipLaunchKernelGGL(tk_k_dup_publishF, dim3(grid_for(1ull << mt_bits, 256, 4096)), dim3(256), 0, s, mt, 1u << mt_bits, tok1, cnt); }));
         }
         TRY(timed(c, s, "tk_k_tile_finish", [&] {
-            hipLaunchKernelGGL(tk_k_tile_finish, dim3(4096), dim3(256), 0, s, ntiles, tile_np, mt, tok1, cnt, tile_nt, c->wave_pieces.as<uint32_t>());
+            hipLaunchKernelGGL(tk_k_tile_finish, dim3(tf_blocks), dim3(256), 0, s, ntiles, tile_np, mt, tok1, cnt, tile_nt, c->wave_pieces.as<uint32_t>());
         }));
-        hipLaunchKernelGGL(tk_k_sum_pieces, dim3(1), dim3(1024), 0, s, c->wave_pieces.as<uint32_t>(), 16384u, c->total.as<unsigned long long>() + 1);
+        hipLaunchKernelGGL(tk_k_sum_pieces, dim3(1), dim3(1024), 0, s, c->wave_pieces.as<uint32_t>(), tf_blocks * 4u, c->total.as<unsigned long long>() + 1);
         TRY(timed(c, s, "tk_k_scan_small", [&] {
             hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, tile_nt, ntiles, c->total.as<uint64_t>());
         }));

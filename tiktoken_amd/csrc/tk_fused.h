@@ -476,7 +476,7 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
 // counts per (wave, bin); tk_k_scan_small turns the counts into offsets; pass 2 (tk_k_binfill) walks the same
 // lists in the same order and writes the entries.  Both passes use the same fixed wave -> tile-group mapping.
 #define TKD_GROUP 4     // tiles per wave step
-#define TKD_WAVES 8192  // waves of the two passes (2048 workgroups)
+#define TKD_WAVES 8192  // most waves of the two passes (2048 workgroups); small inputs launch fewer
 #define TKD_DUP 0x80000000u
 
 struct TkMissGroup {  // the miss lists of TKD_GROUP consecutive tiles, flattened
@@ -501,15 +501,16 @@ struct TkMissGroup {  // the miss lists of TKD_GROUP consecutive tiles, flattene
 
 __global__ __launch_bounds__(256) void tk_k_dedup(const uint8_t* __restrict__ text, uint64_t ntiles, const uint32_t* __restrict__ tile_nmiss,
                                                   const uint32_t* __restrict__ miss_s, uint32_t* __restrict__ miss_kl,
-                                                  const unsigned long long* __restrict__ miss_key, TkMissSlot* __restrict__ mt,
+                                                  const unsigned long long* __restrict__ miss_key, TkMissSlot* __restrict__ mt, uint32_t mt_mask,
                                                   uint32_t* __restrict__ cnt, uint32_t* __restrict__ wbin, int dbg) {
+    const uint32_t nwaves = gridDim.x * 4u;  // tk_k_binfill runs with the same grid: identical wave -> tile-group mapping
     const int lane = threadIdx.x & 63;
     const uint64_t ngroups = (ntiles + TKD_GROUP - 1) / TKD_GROUP;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
     uint32_t nb[TK_NBIN];
 #pragma unroll
     for (int b = 0; b < TK_NBIN; ++b) nb[b] = 0;
-    for (uint64_t g = wave; g < ngroups; g += TKD_WAVES) {
+    for (uint64_t g = wave; g < ngroups; g += nwaves) {
         const uint64_t t0 = g * TKD_GROUP;
         TkMissGroup grp;
         grp.load(tile_nmiss, t0, ntiles, lane);
@@ -529,7 +530,7 @@ __global__ __launch_bounds__(256) void tk_k_dedup(const uint8_t* __restrict__ te
                     unsigned long long kk = tk_mix64(key ^ ((uint64_t)len * 0xA24BAED4963EE407ull));
                     if (dbg & 512) kk &= 0xFFFull;  // test hook: force collisions between different pieces
                     if (kk == TK_EMPTY_KEY) kk = 0;
-                    uint32_t i = (uint32_t)(kk >> 7) & ((1u << TK_MT_BITS) - 1u);
+                    uint32_t i = (uint32_t)(kk >> 7) & mt_mask;
                     for (int p = 0; p < TK_MT_PROBES; ++p) {
                         // Slots are written once (empty -> final), so an ordinary cached load can only be stale towards
                         // "empty"; then the atomic decides.  Hot duplicates are served from the XCD's L2 this way instead
@@ -556,7 +557,7 @@ __global__ __launch_bounds__(256) void tk_k_dedup(const uint8_t* __restrict__ te
                             }
                             // claimant not visible yet, or different bytes behind the same hash: keep probing
                         }
-                        i = (i + 1) & ((1u << TK_MT_BITS) - 1u);
+                        i = (i + 1) & mt_mask;
                     }
                 }
             }
@@ -566,22 +567,23 @@ __global__ __launch_bounds__(256) void tk_k_dedup(const uint8_t* __restrict__ te
     }
     if (lane == 0) {
 #pragma unroll
-        for (int b = 0; b < TK_NBIN; ++b) wbin[(uint32_t)b * TKD_WAVES + wave] = nb[b];  // bin-major: one scan gives every offset
+        for (int b = 0; b < TK_NBIN; ++b) wbin[(uint32_t)b * nwaves + wave] = nb[b];  // bin-major: one scan gives every offset
     }
 }
 
-// pass 2: wscan = exclusive scan of wbin (TK_NBIN * TKD_WAVES + 1 entries; the last one is the grand total)
+// pass 2: wscan = exclusive scan of wbin (TK_NBIN * nwaves + 1 entries; the last one is the grand total)
 __global__ __launch_bounds__(256) void tk_k_binfill(uint64_t ntiles, const uint32_t* __restrict__ tile_nmiss, const uint32_t* __restrict__ miss_s,
                                                     const uint32_t* __restrict__ miss_kl, const uint32_t* __restrict__ wscan,
                                                     uint32_t* __restrict__ listM, TkBins bins, uint32_t* __restrict__ counters) {
     const int lane = threadIdx.x & 63;
     const uint64_t ngroups = (ntiles + TKD_GROUP - 1) / TKD_GROUP;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint32_t nwaves = gridDim.x * 4u;
     uint32_t at[TK_NBIN];
 #pragma unroll
-    for (int b = 0; b < TK_NBIN; ++b) at[b] = bins.off[b] + wscan[(uint32_t)b * TKD_WAVES + wave] - wscan[(uint32_t)b * TKD_WAVES];
-    if (wave == 0 && lane < TK_NBIN) counters[TK_CNT_BIN0 + lane] = wscan[(uint32_t)(lane + 1) * TKD_WAVES] - wscan[(uint32_t)lane * TKD_WAVES];
-    for (uint64_t g = wave; g < ngroups; g += TKD_WAVES) {
+    for (int b = 0; b < TK_NBIN; ++b) at[b] = bins.off[b] + wscan[(uint32_t)b * nwaves + wave] - wscan[(uint32_t)b * nwaves];
+    if (wave == 0 && lane < TK_NBIN) counters[TK_CNT_BIN0 + lane] = wscan[(uint32_t)(lane + 1) * nwaves] - wscan[(uint32_t)lane * nwaves];
+    for (uint64_t g = wave; g < ngroups; g += nwaves) {
         const uint64_t t0 = g * TKD_GROUP;
         TkMissGroup grp;
         grp.load(tile_nmiss, t0, ntiles, lane);
@@ -879,9 +881,9 @@ __global__ __launch_bounds__(256) void tk_k_mergeF_long(TkTables T, const uint8_
 // ------------------------------------------------------------------------------------------
 // back end
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tk_k_dup_publishF(TkMissSlot* __restrict__ mt, const uint32_t* __restrict__ tok1,
+__global__ __launch_bounds__(256) void tk_k_dup_publishF(TkMissSlot* __restrict__ mt, uint32_t mt_slots, const uint32_t* __restrict__ tok1,
                                                          const uint32_t* __restrict__ cnt) {
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < (1u << TK_MT_BITS); i += gridDim.x * 256u) {
+    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < mt_slots; i += gridDim.x * 256u) {
         if (mt[i].key == TK_EMPTY_KEY) continue;
         const uint32_t rep = mt[i].pid;
         mt[i].res_cnt = cnt[rep];

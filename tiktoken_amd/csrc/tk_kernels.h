@@ -34,7 +34,7 @@ struct TkBins {
 // counters (device uint32 array)
 enum { TK_CNT_B = 0, TK_CNT_C = 1, TK_CNT_CBYTES = 2, TK_CNT_CLEVELS = 3, TK_CNT_DUP = 4, TK_CNT_COLL = 5, TK_CNT_BIN0 = 8, TK_CNT_N = 8 + TK_NBIN + 1 };
 
-#define TK_MT_BITS 22   // slots of the in-call miss table (tk_fused.h)
+#define TK_MT_BITS 22   // most slots of the in-call miss table (tk_fused.h); sized by the chunk
 #define TK_MT_PROBES 8
 #define TK_DUP_FLAG 0x80000000u  // cnt[pid] = TK_DUP_FLAG | miss-table slot: a duplicate, resolved by tk_k_tile_finish
 #define TK_MAX_LEVELS 6          // 64-ary min-tree levels of the long-piece merge

@@ -13,7 +13,10 @@ agg = collections.defaultdict(lambda: collections.defaultdict(list))
 for f in glob.glob("gpurun_out/pmc2/*/p_counter_collection.csv"):
     for r in csv.DictReader(open(f)):
         k = r["Kernel_Name"].split("(")[0]
-        if k.startswith("tk_k_pretok2") or k.startswith("tk_k_lookup") or k.startswith("tk_k_dup_fix") or k.startswith("tk_k_gather"):
+        if k.startswith("void "):
+            k = k[5:]
+        k = k.split("<")[0]
+        if k in ("tk_k_front", "tk_k_dedup", "tk_k_tile_finish", "tk_k_back"):
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
     print(k)

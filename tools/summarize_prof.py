@@ -8,8 +8,9 @@
 
 Correction (MI355X_MICROARCH.md, HBM section): counters are in KB; on gfx950 FETCH_SIZE reports half of
 the bytes actually fetched, so hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  The same run calibrates
-it: tk_k_count reads the 128 MiB start bitmap once and reports FETCH_SIZE = 64 MiB; the 128 MiB
-hipMemset fills report WRITE_SIZE = 128 MiB (no correction on the write side).  FETCH_SIZE and
+it: tk_k_dup_publish streams the 128 MiB miss table once and reports FETCH_SIZE = 64 MiB (round 1 calibrated the
+same factor on a kernel that read the 128 MiB start bitmap); the 128 MiB hipMemset fills report WRITE_SIZE =
+128 MiB (no correction on the write side).  FETCH_SIZE and
 WRITE_SIZE are collected in separate passes (they do not fit one pass: TCC has 4 slots).
 """
 import collections
@@ -22,18 +23,28 @@ import sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
+def canonical(name):
+    """Kernel names as bench.py reports them: the pattern / special-token instances of the front kernel under one
+    name, merge kernels by their piece-length class."""
+    import re
+    if name.startswith("tk_k_front<"):
+        return "tk_k_front"
+    m = re.match(r"tk_k_mergeF_llane<(\d+)", name)
+    if m:
+        return "tk_k_merge_llane_" + m.group(1)
+    m = re.match(r"tk_k_mergeF_group<(\d+)", name)
+    if m:
+        return "tk_k_merge_group_" + m.group(1)
+    return {"tk_k_mergeF_long": "tk_k_merge_long", "tk_k_dup_publishF": "tk_k_dup_publish", "tk_k_docoffF": "tk_k_docoff"}.get(name, name)
+
+
 def per_kernel(path):
     agg = collections.defaultdict(list)
     for r in csv.DictReader(open(path)):
         name = r["Kernel_Name"].split("(")[0]
         if name.startswith("void "):
             name = name[5:]
-        # template instances keep their argument as a suffix: tk_k_merge_group<16> -> tk_k_merge_group_16,
-        # except the pattern-specialised pre-tokeniser, which bench.py reports under one name
-        if name.startswith("tk_k_pretok2<"):
-            name = "tk_k_pretok2"
-        name = name.replace("<", "_").replace(">", "").replace(", ", "x")
-        agg[name].append(float(r["Counter_Value"]))
+        agg[canonical(name)].append(float(r["Counter_Value"]))
     return agg
 
 
