@@ -192,7 +192,8 @@ uint64_t tks_pretok_bits(void* pv, const uint8_t* text_in, uint64_t n, const uin
     memset(starts, 0, n);
     PropAcc acc{cls2.data(), text.data(), n};
     const int pat = s->T.pattern;
-    uint64_t n_fallback = 0;
+    uint64_t n_fallback = 0, n_fast32 = 0;
+    (void)n_fast32;
     for (uint64_t i = 0; i < n; ++i) {
         uint32_t c = cls2[i];
         if (c & 0x40u) continue;
@@ -222,7 +223,14 @@ uint64_t tks_pretok_bits(void* pv, const uint8_t* text_in, uint64_t n, const uin
             for (int kk = 0; kk < TKB_KINDS; ++kk) ext.bm[kk] = arr[kk];
             ext.p = q;
             ext.lim = (uint32_t)(4096 + 192 - (q % 4096));  // like tk_k_pretok2: tile + right halo
-            uint32_t len = tk_piece_len_bits(w, acc, ext, q, cls2[q] & 15u, pat);
+            struct W32 {  // the kernel's 32-bit fast path sees the low halves of the same windows
+                const TkWin* w;
+                uint32_t start, stop;
+                uint32_t get(int kind) const { return (uint32_t)w->get(kind); }
+            } w32{&w, (uint32_t)w.start, (uint32_t)w.stop};
+            uint32_t len = tk_piece_len_bits32(w32, acc, q, cls2[q] & 15u, pat);
+            if (len) ++n_fast32;
+            else len = tk_piece_len_bits(w, acc, ext, q, cls2[q] & 15u, pat);
             uint64_t e;
             if (len) {
                 e = q + len;

@@ -507,6 +507,112 @@ TK_HD uint32_t tk_piece_len_bits(const W& w, A& a, X& x, uint64_t p, uint32_t c,
 }
 
 // ------------------------------------------------------------------------------------------
+// 32-bit fast path of the bit-parallel scanner.  Same rules as tk_piece_len_bits on windows of 32 positions;
+// it answers only when every run involved ends by position TK_WIN32_SAFE (so that all look-ahead bits lie inside
+// the window) and returns 0 otherwise -- the caller then runs the 64-bit scanner.  Most pieces are a few bytes
+// long, and 32-bit funnels, shifts and ctz cost a third of their 64-bit forms on the vector ALU.
+// W32 has uint32_t `start`, `stop` (bit 0 cleared) and get(kind).
+// ------------------------------------------------------------------------------------------
+#define TK_WIN32_SAFE 26u
+#if defined(__HIP_DEVICE_COMPILE__)
+TK_HD uint32_t tk_w32_ctz(uint32_t v) { return v ? (uint32_t)(__ffs((int)v) - 1) : 32u; }
+TK_HD uint32_t tk_w32_clz(uint32_t v) { return v ? (uint32_t)__clz((int)v) : 32u; }
+TK_HD uint32_t tk_w32_popc(uint32_t v) { return (uint32_t)__popc(v); }
+#else
+TK_HD uint32_t tk_w32_ctz(uint32_t v) { return v ? (uint32_t)__builtin_ctz(v) : 32u; }
+TK_HD uint32_t tk_w32_clz(uint32_t v) { return v ? (uint32_t)__builtin_clz(v) : 32u; }
+TK_HD uint32_t tk_w32_popc(uint32_t v) { return (uint32_t)__builtin_popcount(v); }
+#endif
+TK_HD uint32_t tk_below32(uint32_t b) { return b >= 32u ? ~0u : ((1u << b) - 1u); }  // bits [0, b)
+TK_HD uint32_t tk_run32(uint32_t bits, uint32_t stop, uint32_t from) {              // from <= TK_WIN32_SAFE
+    return tk_w32_ctz(~((bits & ~stop) >> from));
+}
+
+template <class W32, class A>
+TK_HD uint32_t tk_piece_len_bits32(const W32& w, A& a, uint64_t p, uint32_t c, int pat) {
+    const uint32_t stop = w.stop;
+    const uint32_t k1 = 1u + tk_w32_ctz((w.start | stop) >> 1);
+    if (k1 > 4u || c == TK_C_SPEC) return 0;
+    const bool nxt_end = (stop >> k1) & 1u;
+    uint32_t e = 0;
+    if (pat == TK_PAT_O200K) {
+        uint32_t ks = 64;
+        if ((TK_M_WORD >> c) & 1u) ks = 0;
+        else if (c != TK_C_NL && c != TK_C_NU && !nxt_end && (((w.get(TKB_UP) | w.get(TKB_LOW)) >> k1) & 1u)) ks = k1;
+        if (ks != 64u) {
+            const uint32_t re = ks + tk_run32(w.get(TKB_UP), stop, ks);
+            if (re > TK_WIN32_SAFE) return 0;
+            const uint32_t te = re + tk_run32(w.get(TKB_LOW), stop, re);
+            if (te > TK_WIN32_SAFE) return 0;
+            if (te > re) {
+                e = te;
+            } else {
+                const uint32_t xx = w.get(TKB_CAS) & ~stop & tk_below32(re) & ~tk_below32(ks);
+                e = xx ? 32u - tk_w32_clz(xx) : re;
+            }
+            if (!((stop >> e) & 1u) && a.byte(p + e) == '\'') e += tk_contraction_bits(w, a, p, e, true);
+            return e;
+        }
+    } else if (pat == TK_PAT_CL100K) {
+        if (c == TK_C_AP) {
+            const uint32_t k = tk_contraction_bits(w, a, p, 0, true);
+            if (k) return k;
+        }
+        if ((TK_M_L >> c) & 1u) {
+            const uint32_t r = tk_run32(w.get(TKB_L), stop, 0);
+            return r > TK_WIN32_SAFE ? 0 : r;
+        }
+        if (c != TK_C_NL && c != TK_C_NU && !nxt_end && ((w.get(TKB_L) >> k1) & 1u)) {
+            const uint32_t r = k1 + tk_run32(w.get(TKB_L), stop, k1);
+            return r > TK_WIN32_SAFE ? 0 : r;
+        }
+    } else {
+        if (c == TK_C_AP) {
+            const uint32_t k = tk_contraction_bits(w, a, p, 0, false);
+            if (k) return k;
+        }
+    }
+    if (pat != TK_PAT_R50K && c == TK_C_NU) {
+        const uint32_t r = tk_run32(w.get(TKB_NU), stop, 0);
+        uint32_t sx = w.start & tk_below32(r);
+        sx &= sx - 1;
+        sx &= sx - 1;
+        sx &= sx - 1;
+        e = sx ? tk_w32_ctz(sx) : r;
+        return e > TK_WIN32_SAFE ? 0 : e;
+    }
+    // optional single space, then a run of one kind (r50k: letters / digits / other; others: other only)
+    uint32_t s = 0;
+    if (c == TK_C_SP && !nxt_end) s = k1;
+    if (pat == TK_PAT_R50K) {
+        int kind = -1;
+        if ((w.get(TKB_L) >> s) & 1u) kind = TKB_L;
+        else if ((w.get(TKB_NU) >> s) & 1u) kind = TKB_NU;
+        else if ((w.get(TKB_OTH) >> s) & 1u) kind = TKB_OTH;
+        if (kind >= 0) {
+            const uint32_t r = s + tk_run32(w.get(kind), stop, s);
+            return r > TK_WIN32_SAFE ? 0 : r;
+        }
+    } else if ((w.get(TKB_OTH) >> s) & 1u) {
+        const uint32_t e1 = s + tk_run32(w.get(TKB_OTH), stop, s);
+        if (e1 > TK_WIN32_SAFE) return 0;
+        const uint32_t e2 = e1 + tk_run32(pat == TK_PAT_O200K ? w.get(TKB_NLSL) : w.get(TKB_NL), stop, e1);
+        return e2 > TK_WIN32_SAFE ? 0 : e2;
+    }
+    // white space
+    const uint32_t q = tk_run32(w.get(TKB_WS), stop, 0);
+    if (q > TK_WIN32_SAFE) return 0;
+    const uint32_t rng = tk_below32(q);
+    const bool at_end = (stop >> q) & 1u;
+    const uint32_t nlr = w.get(TKB_NL) & rng, st = w.start & rng;
+    if (pat != TK_PAT_O200K && at_end) return q;
+    if (pat != TK_PAT_R50K && nlr) return 32u - tk_w32_clz(nlr);
+    if (at_end) return q;
+    if (tk_w32_popc(st) >= 2u) return 31u - tk_w32_clz(st);
+    return q;
+}
+
+// ------------------------------------------------------------------------------------------
 // table probes
 // ------------------------------------------------------------------------------------------
 // Exact bytes -> rank probe.  `key` = packed bytes (len <= 8) or tk hash (len > 8); for len > 8

@@ -125,6 +125,17 @@ struct TkWinLds {
     }
 };
 
+struct TkWinLds32 {  // 32 positions from window offset r (the bitmaps seen as 32-bit words; one funnel = one v_alignbit)
+    const uint32_t (*bm)[2 * (TK2_NSEG + 2)];
+    uint32_t wi, sh;
+    uint32_t start, stop;
+    __device__ __forceinline__ uint32_t get(int kind) const { return __builtin_amdgcn_alignbit(bm[kind][wi + 1], bm[kind][wi], sh); }
+    __device__ __forceinline__ TkWinLds32(const uint32_t (*bm_)[2 * (TK2_NSEG + 2)], uint32_t r) : bm(bm_), wi(r >> 5), sh(r & 31u) {
+        start = get(TKB_START);
+        stop = get(TKB_HARD) & ~1u;
+    }
+};
+
 #define TKF_CLW (TK2_CLIST / 4)  // certain-start list entries per wave
 template <int PAT, bool SPEC>
 __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
@@ -326,9 +337,15 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
             uint32_t len = 0;
             if (r >= 0 && r + 64 <= TK2_WIN) {
                 const uint32_t wi = (uint32_t)r >> 6, sh = (uint32_t)r & 63u;
+                {  // most pieces are short: 32-position windows first (a third of the vector-ALU work of the 64-bit form)
+                    const TkWinLds32 w32((const uint32_t(*)[2 * (TK2_NSEG + 2)])bm, (uint32_t)r);
+                    len = tk_piece_len_bits32(w32, acc, p, cls2[r] & 15u, pat);
+                }
+                if (len == 0) {
                 const TkWinLds w(bm, wi, sh);
                 TkBmExt ext{bm, wi, sh, (uint32_t)(TK2_WIN - r)};
                 len = tk_piece_len_bits(w, acc, ext, p, cls2[r] & 15u, pat);
+                }
             }
             uint64_t e = len ? p + len : tk_piece_end_slow(&acc, p, pat);
             if (e > n) e = n;
