@@ -2,7 +2,7 @@
 //
 // It compiles the product's host/device header (tiktoken_amd/csrc/tk_device.h) with g++ and runs
 // the same functions the kernels run -- class bytes, certain-start segmentation, tk_piece_end,
-// table probes, the per-lane merge -- in a sequential loop that mirrors tk_k_pretok / tk_k_lookup.
+// table probes, the per-lane merge -- in a sequential loop that mirrors tk_k_front and the merge kernels.
 // It lets logic errors surface in the container (no GPU here).  It is NOT a product path: the
 // library never links it, and it does not replace the GPU parity tests.
 #include <stdint.h>
@@ -65,7 +65,7 @@ void* tks_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uin
 void tks_destroy(void* p) { delete (Sim*)p; }
 uint64_t tks_n_pairs(void* p) { return ((Sim*)p)->H.n_pairs; }
 
-// Mirror of tk_k_pretok: class bytes, certain starts, scanner from each certain start.
+// Mirror of the byte-walking scanner (the fallback of tk_k_front): class bytes, certain starts, scanner from each certain start.
 // doc_off marks hard starts.  Writes a byte per position: 1 = piece start.  Returns the number of
 // certain starts (for statistics).
 uint64_t tks_pretok(void* p, const uint8_t* text_in, uint64_t n, const uint64_t* doc_off, uint64_t n_docs, uint8_t* starts) {
@@ -111,7 +111,7 @@ uint64_t tks_pretok(void* p, const uint8_t* text_in, uint64_t n, const uint64_t*
     return n_certain;
 }
 
-// Mirror of tk_k_pretok2 (bit-parallel scanner): class bytes with the char's class propagated onto
+// Mirror of the bit-parallel scanners of tk_k_front: class bytes with the char's class propagated onto
 // continuation bytes, per-class bitmaps, 64-bit windows at each piece start, tk_piece_len_bits with the
 // byte-walking scanner as the fallback.  Returns the number of pieces that needed the fallback.
 struct PropAcc {  // accessor over the propagated class array (0x40 = continuation byte)
@@ -222,7 +222,7 @@ uint64_t tks_pretok_bits(void* pv, const uint8_t* text_in, uint64_t n, const uin
             const std::vector<uint8_t>* arr[TKB_KINDS] = {&b_start, &b_hard, &b_L, &b_up, &b_low, &b_cas, &b_oth, &b_ws, &b_nl, &b_nu, &b_nlsl};
             for (int kk = 0; kk < TKB_KINDS; ++kk) ext.bm[kk] = arr[kk];
             ext.p = q;
-            ext.lim = (uint32_t)(4096 + 192 - (q % 4096));  // like tk_k_pretok2: tile + right halo
+            ext.lim = (uint32_t)(4096 + 192 - (q % 4096));  // like tk_k_front: tile + look-ahead
             struct W32 {  // the kernel's 32-bit fast path sees the low halves of the same windows
                 const TkWin* w;
                 uint32_t start, stop;
@@ -330,7 +330,7 @@ uint64_t tks_pretok_tiles(void* pv, const uint8_t* text_in, uint64_t n, const ui
     return n_walkback;
 }
 
-// Mirror of the per-piece work of tk_k_lookup for pieces of <= 16 bytes; longer pieces use the
+// Mirror of the per-piece work (whole-piece probe, lane merge) for pieces of <= 16 bytes; longer pieces use the
 // same probes with a simple sequential merge over ids (the wave / tree kernels cannot run here).
 int64_t tks_encode_piece(void* p, const uint8_t* piece, uint32_t len, uint32_t* out) {
     Sim* s = (Sim*)p;

@@ -1,6 +1,6 @@
 """The product's device functions (tiktoken_amd/csrc/tk_device.h: class bytes, certain-start rule,
 tk_piece_end scanner, table probes, per-lane merge) compiled for the HOST and run in a sequential loop
-that mirrors tk_k_pretok / tk_k_lookup, against the oracle.  This is how logic errors are caught in a
+that mirrors tk_k_front (scanners, tile rule, whole-piece probe) and the lane merge, against the oracle.  This is how logic errors are caught in a
 container without a GPU; the real kernels are checked by the `-m gpu` tests."""
 import itertools
 import random

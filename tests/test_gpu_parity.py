@@ -48,7 +48,7 @@ def test_golden_vectors(cores, name):
 
 @pytest.mark.parametrize("name", h.ENCODING_NAMES)
 def test_pretokenizer_matches_oracle_split(cores, name):
-    """Piece boundaries from tk_k_pretok == the sequential scanner == regex.findall (src/lib.rs:365)."""
+    """Piece boundaries from tk_k_front == the sequential scanner == regex.findall (src/lib.rs:365)."""
     core, C = cores[name], h.c_oracle_for(name)
     blob, off = h.gen_corpus(0xABC0 + h.PATTERN_OF[name], h.PATTERN_OF[name] % 2, 2 << 20)
     starts = core.pretokenize_packed(blob, off)

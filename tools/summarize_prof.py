@@ -8,9 +8,8 @@
 
 Correction (MI355X_MICROARCH.md, HBM section): counters are in KB; on gfx950 FETCH_SIZE reports half of
 the bytes actually fetched, so hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024.  The same run calibrates
-it: tk_k_dup_publish streams the 128 MiB miss table once and reports FETCH_SIZE = 64 MiB (round 1 calibrated the
-same factor on a kernel that read the 128 MiB start bitmap); the 128 MiB hipMemset fills report WRITE_SIZE =
-128 MiB (no correction on the write side).  FETCH_SIZE and
+it: tk_k_scan_small reads and rewrites the 1 MiB array of tile token counts and reports FETCH_SIZE = 515 KB and
+WRITE_SIZE = 1024 KB (reads are counted at half, writes in full).  FETCH_SIZE and
 WRITE_SIZE are collected in separate passes (they do not fit one pass: TCC has 4 slots).
 """
 import collections
