@@ -16,7 +16,7 @@ for f in glob.glob("gpurun_out/pmc2/*/p_counter_collection.csv"):
         if k.startswith("void "):
             k = k[5:]
         k = k.split("<")[0]
-        if k in ("tk_k_front", "tk_k_dedup", "tk_k_tile_finish", "tk_k_back"):
+        if k.startswith("tk_k_"):
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
     print(k)
