@@ -9,7 +9,8 @@ tiktoken/core.py:164-176 / src/lib.rs:360-373) over one batch of synthetic docum
 already resident in HBM: the o200k-shaped encoding on a 1 GiB synthetic web-text corpus per GPU
 (BASELINE.json configs[2]; seeds and mix per SURVEY.md 8(d)).  With N > 1 every rank encodes its
 own 1 GiB shard (weak scaling, documents never interact) and rank 0 gathers the token-id buffers
-with one padded RCCL gather per step, inside the timed region.
+with one padded RCCL gather per step; the gather of step k overlaps with the encode of step k + 1 and
+the last one is waited for inside the timed region.
 
 Protocol = the reference's scripts/benchmark.py:15-26: bytes = sum of UTF-8 lengths, warm-up first,
 wall clock around the timed calls (here: barrier + synchronize on both sides, max over ranks).
@@ -107,21 +108,36 @@ def main():
     d_off = torch.from_numpy(doc_off.view(np.int64)).cuda()
     torch.cuda.synchronize()
 
+    # N > 1: rank 0 gathers every rank's token ids (one padded RCCL gather per step: 7 senders -> 7 xGMI links).  The
+    # transfer of step k runs while step k + 1 is being encoded (the library reuses its output buffer, so the ids
+    # are copied to a tensor first); drain() waits for the last one INSIDE the timed region.
+    pending = [None]
+
     def step():
         dt, nt, do = core.encode_batch_device(d_text.data_ptr(), nbytes, d_off.data_ptr(), doc_off, n_docs)
         if world > 1:
-            toks = torch.as_tensor(DevArray(dt, max(nt, 1), "<i4"), device="cuda")
-            gather_tokens(toks, nt, rank, world, dist, torch)
+            toks = torch.as_tensor(DevArray(dt, max(nt, 1), "<i4"), device="cuda").clone()
+            cur = gather_tokens(toks, nt, rank, world, dist, torch, async_op=True)
+            if pending[0] is not None:
+                pending[0].wait()
+            pending[0] = cur
         return dt, nt, do
+
+    def drain():
+        if pending[0] is not None:
+            pending[0].wait()
+            pending[0] = None
 
     for _ in range(args.warmup):
         step()
+    drain()
     if dist:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
     for _ in range(args.steps):
         dt, nt, do = step()
+    drain()
     torch.cuda.synchronize()
     if dist:
         dist.barrier()

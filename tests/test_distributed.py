@@ -15,7 +15,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import helpers as h
-from tiktoken_amd.distributed import encode_ordinary_batch_sharded, partition_by_bytes
+from tiktoken_amd.distributed import encode_ordinary_batch_sharded, gather_tokens, partition_by_bytes
 
 
 def _free_port():
@@ -40,6 +40,22 @@ def _worker(rank, world, port, q):
             q.put(bool(np.array_equal(toks, rt) and np.array_equal(toff, ro)))
         else:
             assert res is None
+        # the pipelined form bench.py uses for N > 1: the rank's documents in sub-batches, each gathered asynchronously
+        first, last = partition_by_bytes(off, world)[rank]
+        mine_off = off[first:last + 1]
+        pend = []
+        for a, b in partition_by_bytes(mine_off - mine_off[0], 3):
+            lo, hi = int(mine_off[a]), int(mine_off[b])
+            toks, _ = C.encode_batch(blob[lo:hi], (mine_off[a:b + 1] - mine_off[a]).astype(np.uint64), None, 1)
+            t = torch.from_numpy(np.ascontiguousarray(toks).view(np.int32).copy())
+            pend.append(gather_tokens(t, len(toks), rank, world, dist, torch, async_op=True))
+        got = [p.wait() for p in pend]
+        if rank == 0:
+            per_rank = [np.concatenate([g[0][r].numpy().view(np.uint32) for g in got]) for r in range(world)]
+            rt, _ = C.encode_batch(blob, off, None, 1)
+            q.put(bool(np.array_equal(np.concatenate(per_rank), rt)))
+        else:
+            assert all(g[0] is None for g in got)
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -53,7 +69,7 @@ def test_two_rank_gloo_shard_and_gather():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    ok = q.get(timeout=150)
+    ok = q.get(timeout=150) and q.get(timeout=150)  # plain and pipelined exchange
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

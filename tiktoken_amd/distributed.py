@@ -25,9 +25,29 @@ def partition_by_bytes(doc_off: np.ndarray, world: int) -> list[tuple[int, int]]
     return [(cuts[r], cuts[r + 1]) for r in range(world)]
 
 
-def gather_tokens(tokens, n_tokens: int, rank: int, world: int, dist, torch, dst: int = 0):
+class PendingGather:
+    """Handle of a token gather that may still be in flight (gather_tokens(..., async_op=True))."""
+
+    def __init__(self, work, bufs, counts, keep):
+        self._work, self._bufs, self.counts, self._keep = work, bufs, counts, keep
+
+    def wait(self):
+        """Blocks until the gather has completed.  Returns (per-rank tensors in rank order, counts) on the
+        destination rank and (None, counts) elsewhere."""
+        if self._work is not None:
+            self._work.wait()
+            self._work = None
+        self._keep = None
+        if self._bufs is None:
+            return None, self.counts
+        return [b[:c] for b, c in zip(self._bufs, self.counts)], self.counts
+
+
+def gather_tokens(tokens, n_tokens: int, rank: int, world: int, dist, torch, dst: int = 0, async_op: bool = False):
     """Gather per-rank token buffers (1-D integer tensors, first n_tokens entries valid) on rank `dst`.
-    Returns (list of per-rank tensors in rank order, counts) on dst and (None, counts) elsewhere."""
+    Returns (list of per-rank tensors in rank order, counts) on dst and (None, counts) elsewhere; with
+    async_op=True returns a PendingGather instead, so that the transfer over xGMI overlaps with the encode of the
+    next sub-batch (the counts are exchanged synchronously: 8 bytes per rank)."""
     mine = torch.tensor([n_tokens], dtype=torch.int64, device=tokens.device)
     parts = [torch.zeros(1, dtype=torch.int64, device=tokens.device) for _ in range(world)]
     dist.all_gather(parts, mine)
@@ -37,12 +57,10 @@ def gather_tokens(tokens, n_tokens: int, rank: int, world: int, dist, torch, dst
         send = tokens[:cmax].contiguous()
     else:
         send = torch.cat([tokens, tokens.new_zeros(cmax - tokens.numel())])
-    if rank == dst:
-        bufs = [torch.empty(cmax, dtype=tokens.dtype, device=tokens.device) for _ in range(world)]
-        dist.gather(send, bufs, dst=dst)
-        return [b[:c] for b, c in zip(bufs, counts)], counts
-    dist.gather(send, None, dst=dst)
-    return None, counts
+    bufs = [torch.empty(cmax, dtype=tokens.dtype, device=tokens.device) for _ in range(world)] if rank == dst else None
+    work = dist.gather(send, bufs, dst=dst, async_op=async_op)
+    pending = PendingGather(work if async_op else None, bufs, counts, send)
+    return pending if async_op else pending.wait()
 
 
 def encode_ordinary_batch_sharded(encode_packed, blob: np.ndarray, doc_off: np.ndarray, rank: int, world: int, dist, torch,
