@@ -322,10 +322,10 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
             const uint8_t* allowed = c->allowed.as<uint8_t>();
             uint32_t* cand = c->cand.as<uint32_t>();
             TRY(timed(c, s, "tk_k_spec_cand", [&] {
-                hipLaunchKernelGGL(tk_k_spec_cand, dim3(grid_for(n, 256, 16384)), dim3(256), 0, s, T, d_text, n, allowed, docb, cand);
+                hipLaunchKernelGGL(tk_k_spec_cand, dim3(grid_for(n / 16 + 1, 256, 65536)), dim3(256), 0, s, T, d_text, n, allowed, docb, cand);
             }));
             TRY(timed(c, s, "tk_k_spec_resolve", [&] {
-                hipLaunchKernelGGL(tk_k_spec_resolve, dim3(grid_for(n, 256, 16384)), dim3(256), 0, s, T, d_text, n, allowed, docb, cand,
+                hipLaunchKernelGGL(tk_k_spec_resolve, dim3(grid_for(nwords, 256, 65536)), dim3(256), 0, s, T, d_text, n, allowed, docb, cand,
                                    c->spec_max_len, ss, si, brk);
             }));
         }

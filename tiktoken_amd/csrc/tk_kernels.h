@@ -143,9 +143,22 @@ __device__ __forceinline__ uint32_t tk_special_at(const TkTables& T, const uint8
 
 __global__ void tk_k_spec_cand(TkTables T, const uint8_t* __restrict__ text, uint64_t n, const uint8_t* __restrict__ allowed,
                                const uint32_t* __restrict__ docb, uint32_t* __restrict__ cand) {
-    for (uint64_t pos = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; pos < n; pos += (uint64_t)gridDim.x * blockDim.x) {
-        uint32_t idx;
-        if (tk_special_at(T, text, pos, n, allowed, docb, &idx)) atomicOr(&cand[pos >> 5], 1u << (pos & 31));
+    // 16 text bytes per thread: almost every byte fails the first-byte test, so the kernel is one coalesced read of the text
+    for (uint64_t p0 = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) * 16; p0 < n; p0 += (uint64_t)gridDim.x * blockDim.x * 16) {
+        const uint4 v = *(const uint4*)(text + p0);  // (text is readable 64 bytes past n)
+        const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+        uint32_t hits = 0;
+#pragma unroll
+        for (int k = 0; k < 16; ++k) {
+            const uint32_t b = (w[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+            hits |= ((T.spec_first[b >> 5] >> (b & 31)) & 1u) << k;
+        }
+        while (hits) {
+            const uint64_t pos = p0 + (uint32_t)(__ffs((int)hits) - 1);
+            hits &= hits - 1;
+            uint32_t idx;
+            if (pos < n && tk_special_at(T, text, pos, n, allowed, docb, &idx)) atomicOr(&cand[pos >> 5], 1u << (pos & 31));
+        }
     }
 }
 
@@ -155,8 +168,11 @@ __global__ void tk_k_spec_cand(TkTables T, const uint8_t* __restrict__ text, uin
 __global__ void tk_k_spec_resolve(TkTables T, const uint8_t* __restrict__ text, uint64_t n, const uint8_t* __restrict__ allowed,
                                   const uint32_t* __restrict__ docb, const uint32_t* __restrict__ cand, uint32_t max_len,
                                   uint32_t* __restrict__ spec_start, uint32_t* __restrict__ spec_in, uint32_t* __restrict__ brk) {
-    for (uint64_t pos = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; pos < n; pos += (uint64_t)gridDim.x * blockDim.x) {
-        if (!tk_bit(cand, pos)) continue;
+    // one thread per 32-position word of the candidate bitmap (candidates are sparse)
+    const uint64_t nwords = (n + 31) / 32;
+    for (uint64_t wi = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; wi < nwords; wi += (uint64_t)gridDim.x * blockDim.x)
+      for (uint32_t cw = cand[wi]; cw; cw &= cw - 1) {
+        const uint64_t pos = wi * 32 + (uint32_t)(__ffs((int)cw) - 1);
         uint32_t idx;
         // head of the overlap cluster: walk left while some earlier candidate's span covers `h`
         uint64_t h = pos;
