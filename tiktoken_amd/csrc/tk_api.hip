@@ -371,17 +371,18 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
     if (n > 0) {
         uint32_t* wbin = c->wbin.as<uint32_t>();
         // the two list passes and the tile passes: as many workgroups as the chunk has work for (small calls are latency-bound)
-        const uint32_t dd_blocks = grid_for(ntiles, 4 * TKD_GROUP, TKD_WAVES / 4), tf_blocks = grid_for(ntiles, 4, 4096);
+        const uint32_t tpg = ntiles > 16384 ? TKD_GROUP : 1;
+        const uint32_t dd_blocks = grid_for(ntiles, 4 * tpg, TKD_WAVES / 4), tf_blocks = grid_for(ntiles, 4, 4096);
         TRY(timed(c, s, "tk_k_dedup", [&] {
             hipLaunchKernelGGL(tk_k_dedup, dim3(dd_blocks), dim3(256), 0, s, d_text, ntiles, fo.tile_nmiss, fo.miss_s, fo.miss_kl, fo.miss_key, mt, (1u << mt_bits) - 1u, cnt, wbin,
-                               c->dbg);
+                               tpg, c->dbg);
         }));
         TRY(timed(c, s, "tk_k_scan_small", [&] {
             hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, wbin, (uint64_t)TK_NBIN * dd_blocks * 4 + 1, c->total.as<uint64_t>());
         }));
         TRY(timed(c, s, "tk_k_binfill", [&] {
             hipLaunchKernelGGL(tk_k_binfill, dim3(dd_blocks), dim3(256), 0, s, ntiles, fo.tile_nmiss, fo.miss_s, fo.miss_kl, wbin, c->listB.as<uint32_t>(), bins,
-                               counters);
+                               counters, tpg);
         }));
         {
             // The bins are independent: spread them over the side streams, longest-tailed kernels first.  List lengths are
@@ -389,7 +390,7 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
             static const char* const names[TK_NBIN] = {"tk_k_merge_llane_16", "tk_k_merge_llane_24", "tk_k_merge_llane_32", "tk_k_merge_llane_48", "tk_k_merge_llane_64",
                                                        "tk_k_merge_group_8", "tk_k_merge_group_16", "tk_k_merge_group_32", "tk_k_merge_group_64"};
             uint32_t small_counts[TK_CNT_N];
-            const bool small = n <= 32768;  // small calls: a round trip is cheaper than launching kernels over empty lists
+            const bool small = n <= (4u << 20);  // small calls: a round trip is cheaper than launching kernels over empty lists
             if (small) {
                 HIPCHK(hipMemcpyAsync(small_counts, counters, sizeof small_counts, hipMemcpyDeviceToHost, s));
                 HIPCHK(hipStreamSynchronize(s));

@@ -498,9 +498,9 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
 
 struct TkMissGroup {  // the miss lists of TKD_GROUP consecutive tiles, flattened
     uint32_t pre[TKD_GROUP + 1];
-    __device__ __forceinline__ void load(const uint32_t* __restrict__ tile_nmiss, uint64_t t0, uint64_t ntiles, int lane) {
-        uint32_t nm_l = 0;
-        if (lane < TKD_GROUP && t0 + lane < ntiles) nm_l = tile_nmiss[t0 + lane];
+    __device__ __forceinline__ void load(const uint32_t* __restrict__ tile_nmiss, uint64_t t0, uint64_t ntiles, int lane, uint32_t tpg) {
+        uint32_t nm_l = 0;  // tpg = tiles per group: TKD_GROUP, or 1 for small chunks (more waves, shorter dependent chains)
+        if (lane < (int)tpg && t0 + lane < ntiles) nm_l = tile_nmiss[t0 + lane];
         pre[0] = 0;
 #pragma unroll
         for (int q = 0; q < TKD_GROUP; ++q) pre[q + 1] = pre[q] + __shfl(nm_l, q, 64);
@@ -519,18 +519,18 @@ struct TkMissGroup {  // the miss lists of TKD_GROUP consecutive tiles, flattene
 __global__ __launch_bounds__(256) void tk_k_dedup(const uint8_t* __restrict__ text, uint64_t ntiles, const uint32_t* __restrict__ tile_nmiss,
                                                   const uint32_t* __restrict__ miss_s, uint32_t* __restrict__ miss_kl,
                                                   const unsigned long long* __restrict__ miss_key, TkMissSlot* __restrict__ mt, uint32_t mt_mask,
-                                                  uint32_t* __restrict__ cnt, uint32_t* __restrict__ wbin, int dbg) {
+                                                  uint32_t* __restrict__ cnt, uint32_t* __restrict__ wbin, uint32_t tpg, int dbg) {
     const uint32_t nwaves = gridDim.x * 4u;  // tk_k_binfill runs with the same grid: identical wave -> tile-group mapping
     const int lane = threadIdx.x & 63;
-    const uint64_t ngroups = (ntiles + TKD_GROUP - 1) / TKD_GROUP;
+    const uint64_t ngroups = (ntiles + tpg - 1) / tpg;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
     uint32_t nb[TK_NBIN];
 #pragma unroll
     for (int b = 0; b < TK_NBIN; ++b) nb[b] = 0;
     for (uint64_t g = wave; g < ngroups; g += nwaves) {
-        const uint64_t t0 = g * TKD_GROUP;
+        const uint64_t t0 = g * tpg;
         TkMissGroup grp;
-        grp.load(tile_nmiss, t0, ntiles, lane);
+        grp.load(tile_nmiss, t0, ntiles, lane, tpg);
         for (uint32_t j0 = 0; j0 < grp.total(); j0 += 64) {
             const uint32_t f = j0 + lane;
             uint32_t bin = TK_NBIN;
@@ -591,9 +591,9 @@ __global__ __launch_bounds__(256) void tk_k_dedup(const uint8_t* __restrict__ te
 // pass 2: wscan = exclusive scan of wbin (TK_NBIN * nwaves + 1 entries; the last one is the grand total)
 __global__ __launch_bounds__(256) void tk_k_binfill(uint64_t ntiles, const uint32_t* __restrict__ tile_nmiss, const uint32_t* __restrict__ miss_s,
                                                     const uint32_t* __restrict__ miss_kl, const uint32_t* __restrict__ wscan,
-                                                    uint32_t* __restrict__ listM, TkBins bins, uint32_t* __restrict__ counters) {
+                                                    uint32_t* __restrict__ listM, TkBins bins, uint32_t* __restrict__ counters, uint32_t tpg) {
     const int lane = threadIdx.x & 63;
-    const uint64_t ngroups = (ntiles + TKD_GROUP - 1) / TKD_GROUP;
+    const uint64_t ngroups = (ntiles + tpg - 1) / tpg;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
     const uint32_t nwaves = gridDim.x * 4u;
     uint32_t at[TK_NBIN];
@@ -601,9 +601,9 @@ __global__ __launch_bounds__(256) void tk_k_binfill(uint64_t ntiles, const uint3
     for (int b = 0; b < TK_NBIN; ++b) at[b] = bins.off[b] + wscan[(uint32_t)b * nwaves + wave] - wscan[(uint32_t)b * nwaves];
     if (wave == 0 && lane < TK_NBIN) counters[TK_CNT_BIN0 + lane] = wscan[(uint32_t)(lane + 1) * nwaves] - wscan[(uint32_t)lane * nwaves];
     for (uint64_t g = wave; g < ngroups; g += nwaves) {
-        const uint64_t t0 = g * TKD_GROUP;
+        const uint64_t t0 = g * tpg;
         TkMissGroup grp;
-        grp.load(tile_nmiss, t0, ntiles, lane);
+        grp.load(tile_nmiss, t0, ntiles, lane, tpg);
         for (uint32_t j0 = 0; j0 < grp.total(); j0 += 64) {
             const uint32_t f = j0 + lane;
             uint32_t bin = TK_NBIN, pid = 0, s = 0, len = 0;
