@@ -408,15 +408,15 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
                 hipStream_t sa = c->aux[slot++ & 3];
                 TRY(timed(c, sa, names[b], [&] {
                     switch (b) {
-                        case 0: hipLaunchKernelGGL((tk_k_mergeF_llane<16, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
-                        case 1: hipLaunchKernelGGL((tk_k_mergeF_llane<24, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
-                        case 2: hipLaunchKernelGGL((tk_k_mergeF_llane<32, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
-                        case 3: hipLaunchKernelGGL((tk_k_mergeF_llane<48, 128>), dim3(grid_for(most, 128, 8192)), dim3(128), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
-                        case 4: hipLaunchKernelGGL((tk_k_mergeF_llane<64, 128>), dim3(grid_for(most, 128, 8192)), dim3(128), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
-                        case 5: hipLaunchKernelGGL((tk_k_mergeF_group<8>), dim3(grid_for(most, 32, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
-                        case 6: hipLaunchKernelGGL((tk_k_mergeF_group<16>), dim3(grid_for(most, 16, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
-                        case 7: hipLaunchKernelGGL((tk_k_mergeF_group<32>), dim3(grid_for(most, 8, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
-                        default: hipLaunchKernelGGL((tk_k_mergeF_group<64>), dim3(grid_for(most, 4, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
+                        case 0: hipLaunchKernelGGL((tk_k_merge_llane<16, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
+                        case 1: hipLaunchKernelGGL((tk_k_merge_llane<24, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
+                        case 2: hipLaunchKernelGGL((tk_k_merge_llane<32, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
+                        case 3: hipLaunchKernelGGL((tk_k_merge_llane<48, 128>), dim3(grid_for(most, 128, 8192)), dim3(128), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
+                        case 4: hipLaunchKernelGGL((tk_k_merge_llane<64, 128>), dim3(grid_for(most, 128, 8192)), dim3(128), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
+                        case 5: hipLaunchKernelGGL((tk_k_merge_group<8>), dim3(grid_for(most, 32, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
+                        case 6: hipLaunchKernelGGL((tk_k_merge_group<16>), dim3(grid_for(most, 16, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
+                        case 7: hipLaunchKernelGGL((tk_k_merge_group<32>), dim3(grid_for(most, 8, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
+                        default: hipLaunchKernelGGL((tk_k_merge_group<64>), dim3(grid_for(most, 4, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
                     }
                 }));
             }
@@ -438,13 +438,13 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
             TRY(ensure(c->g_pv, (lb + 64) * 4));
             TRY(ensure(c->g_lv, (lvls + 64) * 8));
             TRY(timed(c, s, "tk_k_merge_long", [&] {
-                hipLaunchKernelGGL(tk_k_mergeF_long, dim3(grid_for(nC, 4, 8192)), dim3(256), 0, s, T, d_text, c->listC.as<uint32_t>(), (uint32_t)nC,
+                hipLaunchKernelGGL(tk_k_merge_long, dim3(grid_for(nC, 4, 8192)), dim3(256), 0, s, T, d_text, c->listC.as<uint32_t>(), (uint32_t)nC,
                                    c->g_id.as<uint32_t>(), c->g_rk.as<uint32_t>(), c->g_nx.as<uint32_t>(), c->g_pv.as<uint32_t>(),
                                    c->g_lv.as<uint64_t>(), tok1, cnt, stg);
             }));
         }
         if (mt) {
-            TRY(timed(c, s, "tk_k_dup_publish", [&] { hipLaunchKernelGGL(tk_k_dup_publishF, dim3(grid_for(1ull << mt_bits, 256, 4096)), dim3(256), 0, s, mt, 1u << mt_bits, tok1, cnt); }));
+            TRY(timed(c, s, "tk_k_dup_publish", [&] { hipLaunchKernelGGL(tk_k_dup_publish, dim3(grid_for(1ull << mt_bits, 256, 4096)), dim3(256), 0, s, mt, 1u << mt_bits, tok1, cnt); }));
         }
         TRY(timed(c, s, "tk_k_tile_finish", [&] {
             hipLaunchKernelGGL(tk_k_tile_finish, dim3(tf_blocks), dim3(256), 0, s, ntiles, tile_np, mt, tok1, cnt, tile_nt, c->wave_pieces.as<uint32_t>());
@@ -459,7 +459,7 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
     }
     if (d_tok_off) {
         TRY(timed(c, s, "tk_k_docoff", [&] {
-            hipLaunchKernelGGL(tk_k_docoffF, dim3(grid_for(n_docs + 1, 4, 8192)), dim3(256), 0, s, n_docs, c->doc_pid.as<uint32_t>(), tile_nt, cnt, c->total.as<uint64_t>(), tok_base_global, d_tok_off);
+            hipLaunchKernelGGL(tk_k_docoff, dim3(grid_for(n_docs + 1, 4, 8192)), dim3(256), 0, s, n_docs, c->doc_pid.as<uint32_t>(), tile_nt, cnt, c->total.as<uint64_t>(), tok_base_global, d_tok_off);
         }));
     }
     uint64_t tp[2] = {0, 0};  // tokens, pieces

@@ -8,14 +8,14 @@
 //                         to the tile's miss list.  No piece offsets travel through HBM.
 //   tk_k_dedup            miss lists -> claim / find identical bytes in the in-call miss table (exact: verified)
 //   tk_k_scan_small + tk_k_binfill   first occurrences -> length-binned lists, without global atomics
-//   tk_k_mergeF_llane<N>  one LANE per 2..64-byte piece: byte_pair_merge in LDS           (src/lib.rs:140-196)
-//   tk_k_mergeF_group<G>  G lanes per 65..1024-byte piece
-//   tk_k_mergeF_long      one wavefront per longer piece, 64-ary min tree in HBM scratch  (same result as lib.rs:47-138)
-//   tk_k_dup_publishF     claimant results -> miss-table slots
+//   tk_k_merge_llane<N>  one LANE per 2..64-byte piece: byte_pair_merge in LDS           (src/lib.rs:140-196)
+//   tk_k_merge_group<G>  G lanes per 65..1024-byte piece
+//   tk_k_merge_long      one wavefront per longer piece, 64-ary min tree in HBM scratch  (same result as lib.rs:47-138)
+//   tk_k_dup_publish     claimant results -> miss-table slots
 //   tk_k_tile_finish      duplicates copy their claimant's result; token count per tile
 //   tk_k_scan_small       exclusive scan of the tile counts (262 144 entries per GiB)
 //   tk_k_back             per tile: local scan of the piece counts, tokens written to their final place
-//   tk_k_docoffF          per document: token offset of the piece that starts it
+//   tk_k_docoff          per document: token offset of the piece that starts it
 //
 // Tile rule (checked on the CPU by tests/test_device_logic_sim.py): a tile derives exactly the piece starts
 // inside its own byte range.  Scanners start at the tile's certain starts plus the last certain start before the
@@ -638,7 +638,7 @@ __global__ __launch_bounds__(256) void tk_k_binfill(uint64_t ntiles, const uint3
 // result: cnt[pid] = token count; tok1[pid] = the token (count 1) or the staging position of the tokens
 // ------------------------------------------------------------------------------------------
 template <int NMAX, int THREADS>
-__global__ __launch_bounds__(THREADS) void tk_k_mergeF_llane(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ list,
+__global__ __launch_bounds__(THREADS) void tk_k_merge_llane(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ list,
                                                              const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ tok1,
                                                              uint32_t* __restrict__ cnt, uint32_t* __restrict__ staging) {
     const uint32_t count = *count_ptr;  // list length produced on the device (tk_k_binfill): no host round trip before the merges
@@ -655,7 +655,7 @@ __global__ __launch_bounds__(THREADS) void tk_k_mergeF_llane(TkTables T, const u
 }
 
 template <int G>
-__global__ __launch_bounds__(256) void tk_k_mergeF_group(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ list,
+__global__ __launch_bounds__(256) void tk_k_merge_group(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ list,
                                                          const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ tok1,
                                                          uint32_t* __restrict__ cnt, uint32_t* __restrict__ staging) {
     const uint32_t count = *count_ptr;
@@ -802,7 +802,7 @@ __global__ __launch_bounds__(256) void tk_k_mergeF_group(TkTables T, const uint8
     }
 }
 
-__global__ __launch_bounds__(256) void tk_k_mergeF_long(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listC,
+__global__ __launch_bounds__(256) void tk_k_merge_long(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listC,
                                                         uint32_t nC, uint32_t* __restrict__ g_id, uint32_t* __restrict__ g_rk,
                                                         uint32_t* __restrict__ g_nx, uint32_t* __restrict__ g_pv, uint64_t* __restrict__ g_lv,
                                                         uint32_t* __restrict__ tok1, uint32_t* __restrict__ cnt, uint32_t* __restrict__ staging) {
@@ -898,7 +898,7 @@ __global__ __launch_bounds__(256) void tk_k_mergeF_long(TkTables T, const uint8_
 // ------------------------------------------------------------------------------------------
 // back end
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tk_k_dup_publishF(TkMissSlot* __restrict__ mt, uint32_t mt_slots, const uint32_t* __restrict__ tok1,
+__global__ __launch_bounds__(256) void tk_k_dup_publish(TkMissSlot* __restrict__ mt, uint32_t mt_slots, const uint32_t* __restrict__ tok1,
                                                          const uint32_t* __restrict__ cnt) {
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < mt_slots; i += gridDim.x * 256u) {
         if (mt[i].key == TK_EMPTY_KEY) continue;
@@ -1034,7 +1034,7 @@ __global__ __launch_bounds__(1024) void tk_k_sum_pieces(const uint32_t* __restri
 }
 
 // tok_off[d] = tokens before the piece at which document d starts (one wavefront per document)
-__global__ __launch_bounds__(256) void tk_k_docoffF(uint64_t n_docs, const uint32_t* __restrict__ doc_pid, const uint32_t* __restrict__ tile_tb,
+__global__ __launch_bounds__(256) void tk_k_docoff(uint64_t n_docs, const uint32_t* __restrict__ doc_pid, const uint32_t* __restrict__ tile_tb,
                                                     const uint32_t* __restrict__ cnt, const uint64_t* __restrict__ total,
                                                     uint64_t tok_base_global, uint64_t* __restrict__ tok_off) {
     const int lane = threadIdx.x & 63;

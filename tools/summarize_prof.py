@@ -28,13 +28,13 @@ def canonical(name):
     import re
     if name.startswith("tk_k_front<"):
         return "tk_k_front"
-    m = re.match(r"tk_k_mergeF_llane<(\d+)", name)
+    m = re.match(r"tk_k_merge_llane<(\d+)", name)
     if m:
         return "tk_k_merge_llane_" + m.group(1)
-    m = re.match(r"tk_k_mergeF_group<(\d+)", name)
+    m = re.match(r"tk_k_merge_group<(\d+)", name)
     if m:
         return "tk_k_merge_group_" + m.group(1)
-    return {"tk_k_mergeF_long": "tk_k_merge_long", "tk_k_dup_publishF": "tk_k_dup_publish", "tk_k_docoffF": "tk_k_docoff"}.get(name, name)
+    return name
 
 
 def per_kernel(path):
