@@ -531,28 +531,65 @@ __global__ __launch_bounds__(256) void tk_k_dedup(const uint8_t* __restrict__ te
         const uint64_t t0 = g * tpg;
         TkMissGroup grp;
         grp.load(tile_nmiss, t0, ntiles, lane, tpg);
-        for (uint32_t j0 = 0; j0 < grp.total(); j0 += 64) {
-            const uint32_t f = j0 + lane;
-            uint32_t bin = TK_NBIN;
-            if (f < grp.total()) {
+        // Three-stage software pipeline over the group's entries (the kernel is latency-bound: 88 % of the wave cycles
+        // wait on memory at full occupancy): while entry j is resolved, the table slot of entry j + 64 and the list
+        // record of entry j + 128 are already in flight.
+        struct Ent {
+            uint32_t mi, pid, s, len, kl;
+            uint64_t key;
+            bool valid;
+        };
+        struct Probe {
+            uint32_t i;
+            unsigned long long kk, ident;
+            ulonglong2 ka;
+        };
+        const bool use_table = mt && !(dbg & 256);
+        auto load_ent = [&](uint32_t f) -> Ent {
+            Ent e{0, 0, 0, 0, 0, 0, f < grp.total()};
+            if (e.valid) {
                 uint32_t rb;
-                const uint32_t mi = grp.locate(f, t0, &rb);
-                const uint32_t kl = miss_kl[mi];
-                const uint32_t pid = rb + (kl & 4095u), s = miss_s[mi], len = ((kl >> 12) & 1023u) + 1u;
+                e.mi = grp.locate(f, t0, &rb);
+                e.kl = miss_kl[e.mi];
+                e.s = miss_s[e.mi];
+                if (use_table) e.key = miss_key[e.mi];
+                e.pid = rb;  // (+ index in the run, once kl has arrived)
+            }
+            return e;
+        };
+        auto first_probe = [&](Ent& e) -> Probe {
+            Probe q{0, 0, 0, {0, 0}};
+            e.pid += e.kl & 4095u;
+            e.len = ((e.kl >> 12) & 1023u) + 1u;
+            if (e.valid && use_table) {
+                q.ident = e.len <= 7u ? (e.key | ((unsigned long long)e.len << 56)) : ((1ull << 63) | ((unsigned long long)e.len << 32) | e.s);
+                q.kk = tk_mix64(e.key ^ ((uint64_t)e.len * 0xA24BAED4963EE407ull));
+                if (dbg & 512) q.kk &= 0xFFFull;  // test hook: force collisions between different pieces
+                if (q.kk == TK_EMPTY_KEY) q.kk = 0;
+                q.i = (uint32_t)(q.kk >> 7) & mt_mask;
+                q.ka = *(const ulonglong2*)&mt[q.i].key;
+            }
+            return q;
+        };
+        Ent e1 = load_ent(lane);
+        Ent e2 = load_ent(64 + lane);
+        Probe q1 = first_probe(e1);
+        for (uint32_t j0 = 0; j0 < grp.total(); j0 += 64) {
+            Probe q2 = first_probe(e2);
+            Ent e3 = load_ent(j0 + 128 + lane);
+            uint32_t bin = TK_NBIN;
+            if (e1.valid) {
+                const uint32_t pid = e1.pid, s = e1.s, len = e1.len;
                 bin = (uint32_t)tk_bin_of(len);
-                if (mt && !(dbg & 256)) {
-                    const uint64_t key = miss_key[mi];
-                    const unsigned long long ident = len <= 7u ? (key | ((unsigned long long)len << 56))
-                                                               : ((1ull << 63) | ((unsigned long long)len << 32) | s);
-                    unsigned long long kk = tk_mix64(key ^ ((uint64_t)len * 0xA24BAED4963EE407ull));
-                    if (dbg & 512) kk &= 0xFFFull;  // test hook: force collisions between different pieces
-                    if (kk == TK_EMPTY_KEY) kk = 0;
-                    uint32_t i = (uint32_t)(kk >> 7) & mt_mask;
+                if (use_table) {
+                    const unsigned long long kk = q1.kk, ident = q1.ident;
+                    uint32_t i = q1.i;
+                    ulonglong2 ka = q1.ka;
                     for (int p = 0; p < TK_MT_PROBES; ++p) {
                         // Slots are written once (empty -> final), so an ordinary cached load can only be stale towards
                         // "empty"; then the atomic decides.  Hot duplicates are served from the XCD's L2 this way instead
                         // of queueing at the memory side.
-                        const ulonglong2 ka = *(const ulonglong2*)&mt[i].key;
+                        if (p) ka = *(const ulonglong2*)&mt[i].key;
                         unsigned long long cur = ka.x;
                         if (cur == TK_EMPTY_KEY) cur = atomicCAS(&mt[i].key, TK_EMPTY_KEY, kk);
                         if (cur == TK_EMPTY_KEY) {  // claimed: this piece is the one that gets merged
@@ -568,7 +605,7 @@ __global__ __launch_bounds__(256) void tk_k_dedup(const uint8_t* __restrict__ te
                                                         : ((a >> 32) == (ident >> 32) && tk_equal_bytes(text, s, text, (uint32_t)a, len));
                             if (a != TK_EMPTY_KEY && same) {
                                 cnt[pid] = TK_DUP_FLAG | i;
-                                miss_kl[mi] = kl | TKD_DUP;
+                                miss_kl[e1.mi] = e1.kl | TKD_DUP;
                                 bin = TK_NBIN;
                                 break;
                             }
@@ -580,6 +617,9 @@ __global__ __launch_bounds__(256) void tk_k_dedup(const uint8_t* __restrict__ te
             }
 #pragma unroll
             for (int b = 0; b < TK_NBIN; ++b) nb[b] += (uint32_t)__popcll(__ballot(bin == (uint32_t)b));
+            e1 = e2;
+            q1 = q2;
+            e2 = e3;
         }
     }
     if (lane == 0) {
