@@ -905,6 +905,7 @@ __global__ __launch_bounds__(256) void tk_k_merge_long(TkTables T, const uint8_t
                 nx[i] = nn;
                 if (nn < n) pv[nn] = i;
                 rk[j] = TK_RANK_MAX;
+                id[j] = TK_RANK_MAX;  // absorbed (no token has this id): the emit below compacts on it
                 rk[i] = newr;
             }
             if (lane == 1 && pp != 0xFFFFFFFFu) rk[pp] = newr;
@@ -926,11 +927,19 @@ __global__ __launch_bounds__(256) void tk_k_merge_long(TkTables T, const uint8_t
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             }
         }
+        // emit the surviving parts in order: wave-wide compaction, 64 positions per step
+        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        uint32_t t = 0;
+        for (uint32_t k0 = 0; k0 < n; k0 += 64) {
+            const uint32_t k = k0 + lane;
+            const uint32_t v = k < n ? id[k] : (uint32_t)TK_RANK_MAX;
+            const uint64_t m = __ballot(v != TK_RANK_MAX);
+            if (v != TK_RANK_MAX) staging[s + t + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = v;
+            t += (uint32_t)__popcll(m);
+        }
         if (lane == 0) {
-            uint32_t t = 0;
-            for (uint32_t k = 0; k < n; k = nx[k]) staging[s + t++] = id[k];
             cnt[pid] = t;
-            tok1[pid] = t == 1 ? staging[s] : s;
+            tok1[pid] = t == 1 ? id[0] : s;  // (the leftmost part always survives)
         }
     }
 }
