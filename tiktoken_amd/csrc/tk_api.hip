@@ -297,10 +297,10 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
     uint32_t* counters = c->counters.as<uint32_t>();
     uint32_t *tok1 = c->tok1.as<uint32_t>(), *cnt = c->cnt.as<uint32_t>(), *stg = c->staging.as<uint32_t>();
     uint32_t *tile_np = c->tile_np.as<uint32_t>(), *tile_nt = c->tile_nt.as<uint32_t>();
-    // The per-tile miss lists (TKF_MISS_CAP entries per tile) live in memory that is not needed until the merges
-    // start: the keys in the staging area, starts and index | length in the two halves of the output region.
+    // The per-tile miss lists (TKF_MISS_CAP entries per tile: start, index | length) live in memory that is not needed
+    // until the back kernel writes it: the two halves of the output region.
     TkFrontOut fo{starts, tile_np, tok1, cnt, c->tile_nmiss.as<uint32_t>(), d_out, d_out ? d_out + ntiles * TKF_MISS_CAP : nullptr,
-                  (unsigned long long*)stg, c->listC.as<uint32_t>(), counters, c->doc_pid.as<uint32_t>()};
+                  c->listC.as<uint32_t>(), counters, c->doc_pid.as<uint32_t>()};
     TkMissSlot* mt = nullptr;
     uint32_t mt_bits = 14;
     uint64_t nB = 0, nC = 0;
@@ -337,7 +337,8 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         }
         TRY(timed(c, s, "tk_k_front", [&] {
             const dim3 grid((uint32_t)ntiles);
-            launch_front(T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, d_doc_off, n_docs, fo, c->dbg);
+            launch_front(T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, d_doc_off, n_docs, fo,
+                         (c->dbg & 256) ? (TkMissSlot*)nullptr : mt, (1u << mt_bits) - 1u, c->dbg);
         }));
     } else if (n > 0) {
         TRY(timed(c, s, "tk_k_single_front", [&] { hipLaunchKernelGGL(tk_k_single_front, dim3(1), dim3(64), 0, s, T, d_text, (uint32_t)n, fo); }));
@@ -373,9 +374,8 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         // the two list passes and the tile passes: as many workgroups as the chunk has work for (small calls are latency-bound)
         const uint32_t tpg = ntiles > 16384 ? TKD_GROUP : 1;
         const uint32_t dd_blocks = grid_for(ntiles, 4 * tpg, TKD_WAVES / 4), tf_blocks = grid_for(ntiles, 4, 4096);
-        TRY(timed(c, s, "tk_k_dedup", [&] {
-            hipLaunchKernelGGL(tk_k_dedup, dim3(dd_blocks), dim3(256), 0, s, d_text, ntiles, fo.tile_nmiss, fo.miss_s, fo.miss_kl, fo.miss_key, mt, (1u << mt_bits) - 1u, cnt, wbin,
-                               tpg, c->dbg);
+        TRY(timed(c, s, "tk_k_bincount", [&] {
+            hipLaunchKernelGGL(tk_k_bincount, dim3(dd_blocks), dim3(256), 0, s, ntiles, fo.tile_nmiss, fo.miss_kl, wbin, tpg);
         }));
         TRY(timed(c, s, "tk_k_scan_small", [&] {
             hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, wbin, (uint64_t)TK_NBIN * dd_blocks * 4 + 1, c->total.as<uint64_t>());

@@ -4,10 +4,11 @@
 //   tk_k_front<PAT,SPEC>  per 4 KiB tile: classify every byte, build the class-set bitmaps, find the piece starts
 //                         (regex pre-tokenisation, src/lib.rs:365), enumerate the pieces that START in the tile and
 //                         probe each one whole in the vocabulary (src/lib.rs:367) from the LDS copy of the text.
-//                         Results form a run at piece id  pid = tile * 4096 + k;  pieces that are not a token go
-//                         to the tile's miss list.  No piece offsets travel through HBM.
-//   tk_k_dedup            miss lists -> claim / find identical bytes in the in-call miss table (exact: verified)
-//   tk_k_scan_small + tk_k_binfill   first occurrences -> length-binned lists, without global atomics
+//                         Results form a run at piece id  pid = tile * 4096 + k.  A piece that is not a token claims a
+//                         slot of the in-call miss table, or finds it claimed by identical bytes (exact: verified) and
+//                         records the slot; first occurrences go to the tile's miss list.  No piece offsets travel
+//                         through HBM.
+//   tk_k_bincount + tk_k_scan_small + tk_k_binfill   miss lists -> length-binned lists, without global atomics
 //   tk_k_merge_llane<N>  one LANE per 2..64-byte piece: byte_pair_merge in LDS           (src/lib.rs:140-196)
 //   tk_k_merge_group<G>  G lanes per 65..1024-byte piece
 //   tk_k_merge_long      one wavefront per longer piece, 64-ary min tree in HBM scratch  (same result as lib.rs:47-138)
@@ -38,10 +39,9 @@ struct TkFrontOut {
     uint32_t* tile_np;    // pieces per tile
     uint32_t* tok1;       // [piece id] token (count 1) or staging position of the tokens (count > 1)
     uint32_t* cnt;        // [piece id] token count, or TK_DUP_FLAG | slot
-    uint32_t* tile_nmiss; // pieces of the tile that are not a token (and at most TK_GLANE_MAX bytes long)
+    uint32_t* tile_nmiss; // pieces of the tile that have to be merged: not a token, not a duplicate, at most TK_GLANE_MAX bytes
     uint32_t* miss_s;     // [tile * TKF_MISS_CAP + j] their start ...
-    uint32_t* miss_kl;    // ... (index in the run) | (length - 1) << 12 ...
-    unsigned long long* miss_key;  // ... and key (exact bytes or hash); consumed by tk_k_dedup
+    uint32_t* miss_kl;    // ... and (index in the run) | (length - 1) << 12; consumed by tk_k_bincount / tk_k_binfill
     uint32_t* listC;      // {pid, start, len, scratch bytes before, tree levels before} for > 1 KiB pieces
     uint32_t* counters;
     uint32_t* doc_pid;    // [n_docs] piece id at which each document starts (TKF_NONE: no piece)
@@ -141,7 +141,8 @@ template <int PAT, bool SPEC>
 __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
                                                   const uint32_t* __restrict__ brk, const uint32_t* __restrict__ docb,
                                                   const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si,
-                                                  const uint64_t* __restrict__ doc_off, uint64_t n_docs, TkFrontOut out, int dbg) {
+                                                  const uint64_t* __restrict__ doc_off, uint64_t n_docs, TkFrontOut out,
+                                                  TkMissSlot* __restrict__ mt, uint32_t mt_mask, int dbg) {
     constexpr int pat = PAT;
     constexpr int BM_BYTES = TKB_KINDS * (TK2_NSEG + 2) * 8;
     __shared__ __attribute__((aligned(16))) uint8_t raw[TK2_WIN + 16];
@@ -426,7 +427,7 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
     for (uint32_t k0 = 0; k0 < np; k0 += 256) {
         const uint32_t k = k0 + tid;
         uint32_t cat = 0, len = 0;  // cat 1: not a token (-> miss list), 2: longer than the lane-group kernels take (-> tree list)
-        uint64_t gs = 0, mkey = 0;
+        uint64_t gs = 0;
         const uint32_t pid = run_base + k;
         if (k < np) {
             const uint32_t s_loc = plist[k];
@@ -460,7 +461,40 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
                     cat = 2u;
                 } else {
                     cat = 1u;
-                    mkey = key;  // (exact bytes, or their hash: travels to tk_k_dedup with the miss entry)
+                    // In-call de-duplication: claim a slot of the miss table (first occurrence: stays on the miss list and gets
+                    // merged) or find it claimed by IDENTICAL bytes -- pieces of <= 7 bytes carry their bytes in the slot, longer
+                    // ones are compared with the claimant's text -- and only record the slot (resolved by tk_k_tile_finish).
+                    // Slots are written once, so a cached load can only be stale towards "empty", where the atomic decides.
+                    if (mt) {
+                        const unsigned long long ident = len <= 7u ? (key | ((unsigned long long)len << 56))
+                                                                   : ((1ull << 63) | ((unsigned long long)len << 32) | (uint32_t)gs);
+                        unsigned long long kk = tk_mix64(key ^ ((uint64_t)len * 0xA24BAED4963EE407ull));
+                        if (dbg & 512) kk &= 0xFFFull;  // test hook: force collisions between different pieces
+                        if (kk == TK_EMPTY_KEY) kk = 0;
+                        uint32_t i = (uint32_t)(kk >> 7) & mt_mask;
+                        for (int p = 0; p < TK_MT_PROBES; ++p) {
+                            const ulonglong2 ka = *(const ulonglong2*)&mt[i].key;
+                            unsigned long long cur = ka.x;
+                            if (cur == TK_EMPTY_KEY) cur = atomicCAS(&mt[i].key, TK_EMPTY_KEY, kk);
+                            if (cur == TK_EMPTY_KEY) {
+                                mt[i].pid = pid;
+                                __hip_atomic_store(&mt[i].aux, ident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                break;
+                            }
+                            if (cur == kk) {
+                                unsigned long long a = ka.y;
+                                if (a == TK_EMPTY_KEY) a = __hip_atomic_load(&mt[i].aux, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                                const bool same = len <= 7u ? a == ident
+                                                            : ((a >> 32) == (ident >> 32) && tk_equal_bytes(text, gs, text, (uint32_t)a, len));
+                                if (a != TK_EMPTY_KEY && same) {
+                                    out.cnt[pid] = TK_DUP_FLAG | i;
+                                    cat = 0;
+                                    break;
+                                }
+                            }
+                            i = (i + 1) & mt_mask;
+                        }
+                    }
                 }
             }
         }
@@ -474,7 +508,6 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
                 const uint64_t mi = tile * TKF_MISS_CAP + at;
                 out.miss_s[mi] = (uint32_t)gs;
                 out.miss_kl[mi] = k | ((len - 1u) << 12);
-                out.miss_key[mi] = mkey;
             }
         }
         if (cat == 2u) tk_append_tree(out.listC, out.counters, pid, (uint32_t)gs, len);
@@ -483,18 +516,14 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
     if (tid == 0) out.tile_nmiss[tile] = nmiss_sh;
 }
 
-// Missed pieces -> claim a slot of the miss table (first occurrence: gets merged) or find the slot already
-// claimed by identical bytes (duplicate: cnt[pid] = TK_DUP_FLAG | slot, resolved after the merges).  Identity is
-// verified here, byte for byte against the claimant's text, so a hash collision only costs a redundant merge.
-//
-// The first occurrences then have to be listed by length bin for the merge kernels.  Same-address returning
-// atomics run at only 25..130 M/s on this multi-XCD part (one per (wave, bin) cost 4.5 ms per GiB, one per tile
-// 8 ms), so the lists are built without any: pass 1 (tk_k_dedup) marks the duplicates in the miss list and
-// counts per (wave, bin); tk_k_scan_small turns the counts into offsets; pass 2 (tk_k_binfill) walks the same
-// lists in the same order and writes the entries.  Both passes use the same fixed wave -> tile-group mapping.
+// The pieces on the tiles' miss lists (first occurrences: duplicates were resolved by the front kernel) have to be
+// listed by length bin for the merge kernels.  Same-address returning atomics run at only 25..130 M/s on this
+// multi-XCD part (one per (wave, bin) cost 4.5 ms per GiB, one per tile 8 ms), so the lists are built without
+// any: pass 1 (tk_k_bincount) counts per (wave, bin); tk_k_scan_small turns the counts into offsets; pass 2
+// (tk_k_binfill) walks the same lists in the same order and writes the entries.  Both passes use the same
+// fixed wave -> tile-group mapping.
 #define TKD_GROUP 4     // tiles per wave step
 #define TKD_WAVES 8192  // most waves of the two passes (2048 workgroups); small inputs launch fewer
-#define TKD_DUP 0x80000000u
 
 struct TkMissGroup {  // the miss lists of TKD_GROUP consecutive tiles, flattened
     uint32_t pre[TKD_GROUP + 1];
@@ -516,10 +545,8 @@ struct TkMissGroup {  // the miss lists of TKD_GROUP consecutive tiles, flattene
     }
 };
 
-__global__ __launch_bounds__(256) void tk_k_dedup(const uint8_t* __restrict__ text, uint64_t ntiles, const uint32_t* __restrict__ tile_nmiss,
-                                                  const uint32_t* __restrict__ miss_s, uint32_t* __restrict__ miss_kl,
-                                                  const unsigned long long* __restrict__ miss_key, TkMissSlot* __restrict__ mt, uint32_t mt_mask,
-                                                  uint32_t* __restrict__ cnt, uint32_t* __restrict__ wbin, uint32_t tpg, int dbg) {
+__global__ __launch_bounds__(256) void tk_k_bincount(uint64_t ntiles, const uint32_t* __restrict__ tile_nmiss, const uint32_t* __restrict__ miss_kl,
+                                                     uint32_t* __restrict__ wbin, uint32_t tpg) {
     const uint32_t nwaves = gridDim.x * 4u;  // tk_k_binfill runs with the same grid: identical wave -> tile-group mapping
     const int lane = threadIdx.x & 63;
     const uint64_t ngroups = (ntiles + tpg - 1) / tpg;
@@ -531,95 +558,16 @@ __global__ __launch_bounds__(256) void tk_k_dedup(const uint8_t* __restrict__ te
         const uint64_t t0 = g * tpg;
         TkMissGroup grp;
         grp.load(tile_nmiss, t0, ntiles, lane, tpg);
-        // Three-stage software pipeline over the group's entries (the kernel is latency-bound: 88 % of the wave cycles
-        // wait on memory at full occupancy): while entry j is resolved, the table slot of entry j + 64 and the list
-        // record of entry j + 128 are already in flight.
-        struct Ent {
-            uint32_t mi, pid, s, len, kl;
-            uint64_t key;
-            bool valid;
-        };
-        struct Probe {
-            uint32_t i;
-            unsigned long long kk, ident;
-            ulonglong2 ka;
-        };
-        const bool use_table = mt && !(dbg & 256);
-        auto load_ent = [&](uint32_t f) -> Ent {
-            Ent e{0, 0, 0, 0, 0, 0, f < grp.total()};
-            if (e.valid) {
-                uint32_t rb;
-                e.mi = grp.locate(f, t0, &rb);
-                e.kl = miss_kl[e.mi];
-                e.s = miss_s[e.mi];
-                if (use_table) e.key = miss_key[e.mi];
-                e.pid = rb;  // (+ index in the run, once kl has arrived)
-            }
-            return e;
-        };
-        auto first_probe = [&](Ent& e) -> Probe {
-            Probe q{0, 0, 0, {0, 0}};
-            e.pid += e.kl & 4095u;
-            e.len = ((e.kl >> 12) & 1023u) + 1u;
-            if (e.valid && use_table) {
-                q.ident = e.len <= 7u ? (e.key | ((unsigned long long)e.len << 56)) : ((1ull << 63) | ((unsigned long long)e.len << 32) | e.s);
-                q.kk = tk_mix64(e.key ^ ((uint64_t)e.len * 0xA24BAED4963EE407ull));
-                if (dbg & 512) q.kk &= 0xFFFull;  // test hook: force collisions between different pieces
-                if (q.kk == TK_EMPTY_KEY) q.kk = 0;
-                q.i = (uint32_t)(q.kk >> 7) & mt_mask;
-                q.ka = *(const ulonglong2*)&mt[q.i].key;
-            }
-            return q;
-        };
-        Ent e1 = load_ent(lane);
-        Ent e2 = load_ent(64 + lane);
-        Probe q1 = first_probe(e1);
         for (uint32_t j0 = 0; j0 < grp.total(); j0 += 64) {
-            Probe q2 = first_probe(e2);
-            Ent e3 = load_ent(j0 + 128 + lane);
+            const uint32_t f = j0 + lane;
             uint32_t bin = TK_NBIN;
-            if (e1.valid) {
-                const uint32_t pid = e1.pid, s = e1.s, len = e1.len;
-                bin = (uint32_t)tk_bin_of(len);
-                if (use_table) {
-                    const unsigned long long kk = q1.kk, ident = q1.ident;
-                    uint32_t i = q1.i;
-                    ulonglong2 ka = q1.ka;
-                    for (int p = 0; p < TK_MT_PROBES; ++p) {
-                        // Slots are written once (empty -> final), so an ordinary cached load can only be stale towards
-                        // "empty"; then the atomic decides.  Hot duplicates are served from the XCD's L2 this way instead
-                        // of queueing at the memory side.
-                        if (p) ka = *(const ulonglong2*)&mt[i].key;
-                        unsigned long long cur = ka.x;
-                        if (cur == TK_EMPTY_KEY) cur = atomicCAS(&mt[i].key, TK_EMPTY_KEY, kk);
-                        if (cur == TK_EMPTY_KEY) {  // claimed: this piece is the one that gets merged
-                            mt[i].pid = pid;
-                            __hip_atomic_store(&mt[i].aux, ident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            break;
-                        }
-                        if (cur == kk) {
-                            unsigned long long a = ka.y;
-                            if (a == TK_EMPTY_KEY) a = __hip_atomic_load(&mt[i].aux, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            // short pieces: identical iff the packed bytes are; long ones: same length and same bytes in the text
-                            const bool same = len <= 7u ? a == ident
-                                                        : ((a >> 32) == (ident >> 32) && tk_equal_bytes(text, s, text, (uint32_t)a, len));
-                            if (a != TK_EMPTY_KEY && same) {
-                                cnt[pid] = TK_DUP_FLAG | i;
-                                miss_kl[e1.mi] = e1.kl | TKD_DUP;
-                                bin = TK_NBIN;
-                                break;
-                            }
-                            // claimant not visible yet, or different bytes behind the same hash: keep probing
-                        }
-                        i = (i + 1) & mt_mask;
-                    }
-                }
+            if (f < grp.total()) {
+                uint32_t rb;
+                const uint32_t kl = miss_kl[grp.locate(f, t0, &rb)];
+                bin = (uint32_t)tk_bin_of(((kl >> 12) & 1023u) + 1u);
             }
 #pragma unroll
             for (int b = 0; b < TK_NBIN; ++b) nb[b] += (uint32_t)__popcll(__ballot(bin == (uint32_t)b));
-            e1 = e2;
-            q1 = q2;
-            e2 = e3;
         }
     }
     if (lane == 0) {
@@ -651,7 +599,7 @@ __global__ __launch_bounds__(256) void tk_k_binfill(uint64_t ntiles, const uint3
                 uint32_t rb;
                 const uint32_t mi = grp.locate(f, t0, &rb);
                 const uint32_t kl = miss_kl[mi];
-                if (!(kl & TKD_DUP)) {
+                {
                     pid = rb + (kl & 4095u);
                     s = miss_s[mi];
                     len = ((kl >> 12) & 1023u) + 1u;
