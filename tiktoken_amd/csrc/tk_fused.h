@@ -137,6 +137,18 @@ struct TkWinLds32 {  // 32 positions from window offset r (the bitmaps seen as 3
 };
 
 #define TKF_CLW (TK2_CLIST / 4)  // certain-start list entries per wave
+// exact compare of the piece at LDS offset o with text[pos .. pos+len) in HBM
+__device__ __forceinline__ bool tk_equal_lds_text(const uint8_t* raw, uint32_t o, const uint8_t* text, uint64_t pos, uint32_t len) {
+    uint32_t i = 0;
+    for (; i + 8u <= len; i += 8u)
+        if (tk_lds_load8(raw, o + i) != tk_load8(text, pos + i)) return false;
+    if (i < len) {
+        const uint32_t r = len - i;
+        if (tk_mask_low_bytes(tk_lds_load8(raw, o + i), r) != tk_mask_low_bytes(tk_load8(text, pos + i), r)) return false;
+    }
+    return true;
+}
+
 template <int PAT, bool SPEC>
 __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
                                                   const uint32_t* __restrict__ brk, const uint32_t* __restrict__ docb,
@@ -485,7 +497,9 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
                                 unsigned long long a = ka.y;
                                 if (a == TK_EMPTY_KEY) a = __hip_atomic_load(&mt[i].aux, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                                 const bool same = len <= 7u ? a == ident
-                                                            : ((a >> 32) == (ident >> 32) && tk_equal_bytes(text, gs, text, (uint32_t)a, len));
+                                                            : ((a >> 32) == (ident >> 32) &&
+                                                               (in_lds ? tk_equal_lds_text(raw, s_loc, text, (uint32_t)a, len)
+                                                                       : tk_equal_bytes(text, gs, text, (uint32_t)a, len)));
                                 if (a != TK_EMPTY_KEY && same) {
                                     out.cnt[pid] = TK_DUP_FLAG | i;
                                     cat = 0;
