@@ -464,7 +464,9 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
             } else {
                 const bool in_lds = e_loc + 8u <= (uint32_t)TK2_WIN;
                 const uint64_t key = in_lds ? tk_key_of_lds(raw, s_loc, len) : tk_key_of_text(text, gs, len);
-                uint32_t r = (dbg & 2) ? len : tk_probe_piece(T, key, len, [&](uint32_t off) { return tk_equal_bytes(text, gs, T.tok_bytes, off, len); });
+                uint32_t r = (dbg & 2) ? len : tk_probe_piece(T, key, len, [&](uint32_t off) {
+                    return in_lds ? tk_equal_lds_text(raw, s_loc, T.tok_bytes, off, len) : tk_equal_bytes(text, gs, T.tok_bytes, off, len);
+                });
                 if ((dbg & 8) && r == TK_RANK_MAX) r = 0;  // (perf experiments: 2 = no probe, 8 = no deferred pieces)
                 if (r != TK_RANK_MAX) {
                     out.tok1[pid] = r;
