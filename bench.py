@@ -185,7 +185,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                     # integer byte work: no MFMA; the dominant kernel is limited by vector-ALU issue
-                    "limiter": "valu issue (82% VALU utilisation, profiles/r01_sq_counters.csv)" if dom == "tk_k_front" else None,
+                    "limiter": "valu issue (85% VALU utilisation, profiles/r01_sq_counters.csv)" if dom == "tk_k_front" else None,
                     "algorithmic_bytes_per_launch": b_alg, "kernel_ms_avg": round(kern[dom]["ms_avg"], 4),
                     "all_kernels_ms_per_step": round(sum_ms, 4),
                     "pipeline_achieved": round(b_alg / (sum_ms * 1e-3) / 1e9, 2),

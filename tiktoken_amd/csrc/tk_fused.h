@@ -24,7 +24,7 @@
 // its end.  Nothing crosses tiles, so tiles are fully independent.
 //
 // Two hardware facts shape the code (measured): tk_k_front is VALU-bound (a wave64 VALU
-// instruction occupies a SIMD16 for four cycles; 82-90 % VALU utilisation), so the classification loop is written
+// instruction occupies a SIMD16 for four cycles; 85-90 % VALU utilisation), so the classification loop is written
 // with integer flags instead of short-circuit control flow; and same-address returning atomics run at only
 // 25..130 M/s on this multi-XCD part, so nothing on the path allocates through a global counter.
 #pragma once
