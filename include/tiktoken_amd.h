@@ -78,6 +78,9 @@ int tk_encode(tk_core* core, const uint8_t* utf8, uint64_t len, const uint32_t* 
 /* CoreBPE.encode_single_piece(piece): BPE of raw bytes without regex splitting   src/py.rs:145-150 */
 int tk_encode_single_piece(tk_core* core, const uint8_t* piece, uint64_t len, uint32_t** tokens_out,
                            uint64_t* n_tokens_out);
+/* byte_pair_encode(piece, &self.encoder) proper: the merge WITHOUT the whole-piece shortcut (single bytes map to their
+ * rank).  What `_encode_unstable_native` calls on re-split candidates      src/lib.rs:198-211, call sites :555,:585-590 */
+int tk_byte_pair_encode(tk_core* core, const uint8_t* piece, uint64_t len, uint32_t** tokens_out, uint64_t* n_tokens_out);
 /* CoreBPE.encode_single_token(piece)   TK_KEY_ERROR if absent                     src/py.rs:133-143 */
 int tk_encode_single_token(tk_core* core, const uint8_t* piece, uint64_t len, uint32_t* token_out);
 /* CoreBPE.decode_bytes(tokens)         TK_KEY_ERROR "Invalid token for decoding: N"  src/py.rs:156-162, lib.rs:345-358 */
@@ -87,6 +90,8 @@ int tk_decode_single_token_bytes(tk_core* core, uint32_t token, const uint8_t** 
 /* CoreBPE.token_byte_values(): tokens in lexicographic byte order                  src/py.rs:178-183, lib.rs:648-650 */
 uint64_t tk_n_tokens(tk_core* core);
 int tk_sorted_token(tk_core* core, uint64_t i, const uint8_t** bytes_out, uint64_t* len_out, uint32_t* rank_out);
+/* The same list in one call: packed bytes + n+1 offsets, owned by the core (valid until tk_destroy). */
+int tk_sorted_tokens_packed(tk_core* core, const uint8_t** blob_out, const uint64_t** off_out, uint64_t* n_out);
 
 void tk_free(void* p);
 

@@ -415,3 +415,134 @@ def encode(text: str, pat_str: str, ranks: dict[bytes, int], specials: dict[str,
         out.append(specials[hit[1]])
         start = hit[0] + len(hit[1])
     return out
+
+
+# ------------------------------------------------------------------------------------------
+# Byte-level and unstable entry points (src/lib.rs:444-599, src/py.rs:72-131), restated statement by statement.
+# Pure Python over the functions above; used by the tests to check CoreBPE._encode_bytes / encode_with_unstable.
+# ------------------------------------------------------------------------------------------
+def encode_with_last_len(text: str, pat_str: str, ranks: dict[bytes, int], specials: dict[str, int],
+                         allowed_special, splitter=None) -> tuple[list[int], int]:
+    """src/lib.rs:375-442 including its second result, `last_piece_token_len`: the number of tokens that came
+    from the last regex piece (0 right after a special token, lib.rs:433)."""
+    allowed = set(allowed_special) & set(specials)
+    out: list[int] = []
+    start, last = 0, 0
+    while True:
+        hit = find_special(text, specials, start, allowed) if allowed else None
+        end = hit[0] if hit else len(text)
+        sl = text[start:end]
+        for piece in (splitter(sl) if splitter else split_regex(pat_str, sl)):
+            toks = encode_single_piece(piece.encode("utf-8"), ranks)
+            last = len(toks)
+            out.extend(toks)
+        if hit is None:
+            break
+        out.append(specials[hit[1]])
+        start = hit[0] + len(hit[1])
+        last = 0
+    return out, last
+
+
+def increase_last_piece_token_len(tokens: list[int], last: int, decoder: dict[int, bytes]) -> int:
+    """src/lib.rs:444-481."""
+    def all_space(tok: int) -> bool:
+        b = decoder.get(tok)
+        return b is not None and all(c in b" \n\t" for c in b)
+
+    if last > 0 and all_space(tokens[len(tokens) - last]):
+        while last < len(tokens) and all_space(tokens[len(tokens) - last - 1]):
+            last += 1
+    assert last <= len(tokens)
+    return last
+
+
+# char::is_whitespace (Rust) = the Unicode White_Space property: 25 code points.  (Python's str.isspace() also accepts
+# U+001C..U+001F, which Rust does not.)
+RUST_WHITE_SPACE = frozenset(map(chr, [9, 10, 11, 12, 13, 32, 0x85, 0xA0, 0x1680, *range(0x2000, 0x200B), 0x2028, 0x2029, 0x202F,
+                                       0x205F, 0x3000]))
+
+
+def _decode_last_utf8(b: bytes) -> tuple[str | None, int]:
+    """bstr::decode_last_utf8 (bstr 1.x) as lib.rs:581 uses it: the last code point of `b` and its byte length;
+    (None, n) with n >= 1 when the tail is not valid UTF-8 (n = length of the maximal invalid suffix bstr reports:
+    at most 3 trailing bytes that do not form a complete scalar)."""
+    if not b:
+        return None, 0
+    start = len(b) - 1
+    limit = max(0, len(b) - 4)
+    while start > limit and (b[start] & 0xC0) == 0x80:
+        start -= 1
+    for s in range(start, len(b)):
+        try:
+            ch = b[s:].decode("utf-8")
+        except UnicodeDecodeError:
+            continue
+        if len(ch) == 1:
+            return ch, len(b) - s
+    return None, 1
+
+
+def encode_unstable_native(text: str, pat_str: str, ranks: dict[bytes, int], specials: dict[str, int],
+                           allowed_special, splitter=None) -> tuple[list[int], set[tuple[int, ...]]]:
+    """src/lib.rs:483-599."""
+    decoder = {v: k for k, v in ranks.items()}
+    tokens, last = encode_with_last_len(text, pat_str, ranks, specials, allowed_special, splitter)
+    if last == 0:
+        return tokens, set()
+    last = increase_last_piece_token_len(tokens, last, decoder)
+    unstable = b"".join(decoder[t] for t in tokens[len(tokens) - last:])
+    del tokens[len(tokens) - last:]
+    completions: set[tuple[int, ...]] = set()
+    if not unstable:
+        return tokens, completions
+    import bisect
+
+    sorted_tokens = sorted(ranks)
+    point = bisect.bisect_left(sorted_tokens, unstable)
+    while point < len(sorted_tokens) and sorted_tokens[point].startswith(unstable):
+        completions.add((ranks[sorted_tokens[point]],))
+        point += 1
+    for i in range(1, len(unstable)):
+        prefix, suffix = unstable[:i], unstable[i:]
+        point = bisect.bisect_left(sorted_tokens, suffix)
+        while point < len(sorted_tokens) and sorted_tokens[point].startswith(suffix):
+            possibility = prefix + sorted_tokens[point]
+            try:
+                encoded = encode_ordinary(possibility.decode("utf-8"), pat_str, ranks, splitter)
+            except UnicodeDecodeError:
+                encoded = byte_pair_encode(possibility, ranks)
+            seq, seq_len = [], 0
+            for t in encoded:
+                seq.append(t)
+                seq_len += len(decoder[t])
+                if seq_len >= len(unstable):
+                    break
+            completions.add(tuple(seq))
+            point += 1
+    if len(unstable) > 1:
+        ch, k = _decode_last_utf8(unstable)
+        if len(unstable) - k > 0 and ch is not None and ch in RUST_WHITE_SPACE:
+            re_enc = byte_pair_encode(unstable[:len(unstable) - k], ranks) + byte_pair_encode(unstable[len(unstable) - k:], ranks)
+            completions.add(tuple(re_enc))
+    return tokens, completions
+
+
+def encode_bytes(data: bytes, pat_str: str, ranks: dict[bytes, int], splitter=None) -> list[int]:
+    """src/py.rs:72-115."""
+    try:
+        return encode_ordinary(data.decode("utf-8"), pat_str, ranks, splitter)
+    except UnicodeDecodeError as e:
+        valid = e.start
+    decoder = {v: k for k, v in ranks.items()}
+    tokens, last = encode_with_last_len(data[:valid].decode("utf-8"), pat_str, ranks, {}, set(), splitter)
+    last = increase_last_piece_token_len(tokens, last, decoder)
+    if tokens and last > 0:
+        unstable = b"".join(decoder[t] for t in tokens[len(tokens) - last:]) + data[valid:]
+        del tokens[len(tokens) - last:]
+    else:
+        unstable = data[valid:]
+    if unstable:
+        t = ranks.get(unstable)
+        tokens.extend([t] if t is not None else byte_pair_encode(unstable, ranks))
+    return tokens

@@ -167,3 +167,13 @@ def test_rejects_bad_vocabularies():
         h.HostSim(h.PAT_STR[0], {bytes([b]): b for b in range(255)}, {})
     with pytest.raises(ValueError):  # pattern without a compiled scanner
         h.HostSim(r"\w+|\s+", {bytes([b]): b for b in range(256)}, {})
+
+
+def test_two_special_strings_may_share_an_id():
+    """o200k_harmony registers <|endofprompt|> and <|reserved_200018|> under the same id (reference
+    tiktoken_ext/openai_public.py:85-94); the reference accepts that (HashMap collect, src/lib.rs:643-646)."""
+    ranks = {bytes([b]): b for b in range(256)}
+    specials = {"<|endofprompt|>": 200018, "<|reserved_200018|>": 200018, "<|endoftext|>": 199999}
+    h.HostSim(h.PAT_STR[2], ranks, specials)  # builds
+    with pytest.raises(ValueError):  # (the same STRING twice cannot be expressed in a dict; two spellings that collide can)
+        h.HostSim(h.PAT_STR[2], ranks, {"<|a|>": 1000, "": 1001})

@@ -60,6 +60,8 @@ def lib() -> ctypes.CDLL:
         L.tk_encode.argtypes = [vp, vp, u64, vp, u64, P(vp), P(u64)]
         L.tk_encode_single_piece.restype = i32
         L.tk_encode_single_piece.argtypes = [vp, vp, u64, P(vp), P(u64)]
+        L.tk_byte_pair_encode.restype = i32
+        L.tk_byte_pair_encode.argtypes = [vp, vp, u64, P(vp), P(u64)]
         L.tk_encode_single_token.restype = i32
         L.tk_encode_single_token.argtypes = [vp, vp, u64, P(u32)]
         L.tk_decode_bytes.restype = i32
@@ -70,6 +72,8 @@ def lib() -> ctypes.CDLL:
         L.tk_n_tokens.argtypes = [vp]
         L.tk_sorted_token.restype = i32
         L.tk_sorted_token.argtypes = [vp, u64, P(vp), P(u64), P(u32)]
+        L.tk_sorted_tokens_packed.restype = i32
+        L.tk_sorted_tokens_packed.argtypes = [vp, P(vp), P(vp), P(u64)]
         L.tk_free.argtypes = [vp]
         L.tk_set_profiling.argtypes = [vp, i32]
         L.tk_reset_kernel_ms.argtypes = [vp]

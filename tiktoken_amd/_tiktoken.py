@@ -14,6 +14,9 @@ import numpy as np
 
 from . import _lib
 
+# char::is_whitespace (Rust, lib.rs:583) = the Unicode White_Space property
+_WHITE_SPACE = frozenset(map(chr, [9, 10, 11, 12, 13, 32, 0x85, 0xA0, 0x1680, *range(0x2000, 0x200B), 0x2028, 0x2029, 0x202F, 0x205F, 0x3000]))
+
 
 def _pack_pairs(items: Sequence[tuple[bytes, int]]):
     blob = b"".join(k for k, _ in items)
@@ -33,6 +36,16 @@ def _take_u32(ptr: ctypes.c_void_p, n: int) -> np.ndarray:
         out = np.zeros(0, dtype=np.uint32)
     _lib.lib().tk_free(ptr)
     return out
+
+
+def _check_packed(blob: np.ndarray, doc_off: np.ndarray) -> None:
+    """The C ABI reads doc_off[n_docs] bytes of the blob: refuse offsets that do not describe it."""
+    if doc_off.ndim != 1 or len(doc_off) < 1:
+        raise ValueError("doc_off must hold n_docs + 1 offsets (at least one)")
+    if int(doc_off[0]) != 0 or int(doc_off[-1]) != len(blob):
+        raise ValueError("doc_off[0] must be 0 and doc_off[-1] must equal len(blob)")
+    if len(doc_off) > 1 and bool(np.any(doc_off[1:] < doc_off[:-1])):
+        raise ValueError("doc_off must be non-decreasing")
 
 
 class CoreBPE:
@@ -105,6 +118,7 @@ class CoreBPE:
         Returns (tokens uint32[T], tok_off uint64[n+1])."""
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         doc_off = np.ascontiguousarray(doc_off, dtype=np.uint64)
+        _check_packed(blob, doc_off)
         n_docs = len(doc_off) - 1
         tok_off = np.empty(n_docs + 1, dtype=np.uint64)
         out, n = ctypes.c_void_p(), ctypes.c_uint64()
@@ -144,6 +158,7 @@ class CoreBPE:
         what `regex.find_iter` yields at src/lib.rs:365/405, computed by the GPU pre-tokeniser."""
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         doc_off = np.ascontiguousarray(doc_off, dtype=np.uint64)
+        _check_packed(blob, doc_off)
         out, n = ctypes.c_void_p(), ctypes.c_uint64()
         src = blob if len(blob) else np.zeros(1, dtype=np.uint8)
         if allowed_special is None:
@@ -165,6 +180,13 @@ class CoreBPE:
     def encode_single_piece(self, piece: bytes) -> list[int]:
         out, n = ctypes.c_void_p(), ctypes.c_uint64()
         rc = self._L.tk_encode_single_piece(self._h, self._as_u8(piece).ctypes.data, len(piece), ctypes.byref(out), ctypes.byref(n))
+        _lib.raise_for(rc)
+        return _take_u32(out, n.value).tolist()
+
+    def _byte_pair_encode(self, piece: bytes) -> list[int]:
+        """byte_pair_encode (src/lib.rs:198-211): the merge loop without the whole-piece shortcut."""
+        out, n = ctypes.c_void_p(), ctypes.c_uint64()
+        rc = self._L.tk_byte_pair_encode(self._h, self._as_u8(piece).ctypes.data, len(piece), ctypes.byref(out), ctypes.byref(n))
         _lib.raise_for(rc)
         return _take_u32(out, n.value).tolist()
 
@@ -229,7 +251,7 @@ class CoreBPE:
             return tokens, []
         import bisect
 
-        sorted_tokens = self.token_byte_values()
+        sorted_tokens = self._sorted_tokens()
         point = bisect.bisect_left(sorted_tokens, unstable)
         while point < len(sorted_tokens) and sorted_tokens[point].startswith(unstable):
             completions.add((self.encode_single_token(sorted_tokens[point]),))
@@ -243,7 +265,7 @@ class CoreBPE:
                     possibility.decode("utf-8")
                     encoded = self._encode_np(possibility, None).tolist()
                 except UnicodeDecodeError:
-                    encoded = self.encode_single_piece(possibility)
+                    encoded = self._byte_pair_encode(possibility)  # lib.rs:555
                 seq, seq_len = [], 0
                 for t in encoded:
                     seq.append(t)
@@ -253,17 +275,19 @@ class CoreBPE:
                 completions.add(tuple(seq))
                 point += 1
         if len(unstable) > 1:
-            # last (possibly partial) char: bstr::decode_last_utf8 (lib.rs:581-596)
-            k = len(unstable) - 1
-            while k > 0 and (unstable[k] & 0xC0) == 0x80 and len(unstable) - k < 4:
-                k -= 1
-            try:
-                ch = unstable[k:].decode("utf-8")
-                ok = len(ch) == 1
-            except UnicodeDecodeError:
-                ch, ok, k = "", False, len(unstable) - 1
-            if len(unstable) - (len(unstable) - k) > 0 and ok and ch.isspace():
-                re = self.encode_single_piece(unstable[:k]) + self.encode_single_piece(unstable[k:])
+            # last code point of the unstable bytes: bstr::decode_last_utf8 (lib.rs:581-596); char::is_whitespace is the
+            # Unicode White_Space property (not str.isspace(), which also accepts U+001C..U+001F)
+            ch, k = None, 1
+            for start in range(max(0, len(unstable) - 4), len(unstable)):
+                try:
+                    cand = unstable[start:].decode("utf-8")
+                except UnicodeDecodeError:
+                    continue
+                if len(cand) == 1:
+                    ch, k = cand, len(unstable) - start
+                    break
+            if ch is not None and len(unstable) - k > 0 and ch in _WHITE_SPACE:
+                re = self._byte_pair_encode(unstable[:len(unstable) - k]) + self._byte_pair_encode(unstable[len(unstable) - k:])
                 completions.add(tuple(re))
         return tokens, [list(c) for c in completions]
 
@@ -286,12 +310,19 @@ class CoreBPE:
         return ctypes.string_at(p, n.value)
 
     def token_byte_values(self) -> list[bytes]:
-        out = []
-        p, n = ctypes.c_void_p(), ctypes.c_uint64()
-        for i in range(self._L.tk_n_tokens(self._h)):
-            _lib.raise_for(self._L.tk_sorted_token(self._h, i, ctypes.byref(p), ctypes.byref(n), None))
-            out.append(ctypes.string_at(p, n.value))
-        return out
+        return list(self._sorted_tokens())
+
+    def _sorted_tokens(self) -> list[bytes]:
+        """All token byte strings in lexicographic order (lib.rs:648-650), fetched once per CoreBPE in one call."""
+        cached = getattr(self, "_sorted_cache", None)
+        if cached is None:
+            pb, po, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64()
+            _lib.raise_for(self._L.tk_sorted_tokens_packed(self._h, ctypes.byref(pb), ctypes.byref(po), ctypes.byref(n)))
+            off = np.ctypeslib.as_array(ctypes.cast(po, ctypes.POINTER(ctypes.c_uint64)), shape=(n.value + 1,))
+            blob = ctypes.string_at(pb, int(off[-1]))
+            bounds = off.tolist()
+            cached = self._sorted_cache = [blob[a:b] for a, b in zip(bounds[:-1], bounds[1:])]
+        return cached
 
     # ------------------------------------------------------------------ instrumentation
     def set_profiling(self, on: bool):

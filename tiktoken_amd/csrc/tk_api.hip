@@ -71,6 +71,8 @@ struct tk_core {
         g_pv, g_lv, out_tokens, out_tok_off, allowed, tile_np, tile_nt, tile_nmiss, doc_pid, mt_slots, wbin, wave_pieces;
     uint64_t chunk_bytes = 1ull << 30;
     int dbg = 0;
+    std::vector<uint8_t> sorted_blob;  // token_byte_values(), packed (built on first use)
+    std::vector<uint64_t> sorted_off;
     // instrumentation
     bool profiling = false;
     std::map<std::string, KernelStat> stats;
@@ -85,13 +87,20 @@ static int timed(tk_core* c, hipStream_t s, const char* name, F&& f) {
         HIPCHK(hipGetLastError());
         return TK_OK;
     }
-    hipEvent_t a, b;
-    HIPCHK(hipEventCreate(&a));
-    HIPCHK(hipEventCreate(&b));
-    HIPCHK(hipEventRecord(a, s));
-    f();
-    HIPCHK(hipGetLastError());
-    HIPCHK(hipEventRecord(b, s));
+    hipEvent_t a = nullptr, b = nullptr;
+    hipError_t e = hipEventCreate(&a);
+    if (e == hipSuccess) e = hipEventCreate(&b);
+    if (e == hipSuccess) e = hipEventRecord(a, s);
+    if (e == hipSuccess) {
+        f();
+        e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipEventRecord(b, s);
+    if (e != hipSuccess) {  // (no event pair is left behind by a failed launch)
+        if (a) (void)hipEventDestroy(a);
+        if (b) (void)hipEventDestroy(b);
+        return fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e) + " in " + name);
+    }
     c->pending.push_back({name, {a, b}});
     return TK_OK;
 }
@@ -256,7 +265,7 @@ static void launch_front(int pattern, bool spec, dim3 grid, hipStream_t s, A... 
 // final synchronisation.
 static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t n, const uint64_t* d_doc_off, uint64_t n_docs,
                      uint64_t base, bool use_special, bool single_piece, uint32_t* d_out, uint64_t tok_base_global,
-                     uint64_t* d_tok_off, uint64_t* n_tokens_out, bool pretok_only = false) {
+                     uint64_t* d_tok_off, uint64_t* n_tokens_out, bool pretok_only = false, bool no_lookup = false) {
     const TkTables& T = c->D;
     const uint64_t nwords = (n + 31) / 32;
     const uint64_t nblk = (nwords + 255) / 256;
@@ -341,7 +350,7 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
                          (c->dbg & 256) ? (TkMissSlot*)nullptr : mt, (1u << mt_bits) - 1u, c->dbg);
         }));
     } else if (n > 0) {
-        TRY(timed(c, s, "tk_k_single_front", [&] { hipLaunchKernelGGL(tk_k_single_front, dim3(1), dim3(64), 0, s, T, d_text, (uint32_t)n, fo); }));
+        TRY(timed(c, s, "tk_k_single_front", [&] { hipLaunchKernelGGL(tk_k_single_front, dim3(1), dim3(64), 0, s, T, d_text, (uint32_t)n, fo, no_lookup ? 1 : 0); }));
     }
     // the front kernel's counters (pieces for the tree kernel) go back to the host while the next kernels run
     HIPCHK(hipMemcpyAsync(c->h_counters, counters, TK_CNT_N * 4, hipMemcpyDeviceToHost, s));
@@ -583,7 +592,10 @@ extern "C" int tk_encode_batch(tk_core* c, const uint8_t* utf8, const uint64_t* 
 extern "C" int tk_pretokenize_batch(tk_core* c, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special,
                                     const uint32_t* allowed_ids, uint64_t n_allowed, uint32_t** starts_out, uint64_t* n_out) {
     if (!c) return fail(TK_VALUE_ERROR, "core is null");
-    if (!doc_off || doc_off[0] != 0) return fail(TK_VALUE_ERROR, "doc_off[0] must be 0");
+    if (!doc_off || !starts_out || !n_out) return fail(TK_VALUE_ERROR, "null argument");
+    if (doc_off[0] != 0) return fail(TK_VALUE_ERROR, "doc_off[0] must be 0");
+    for (uint64_t d = 0; d < n_docs; ++d)
+        if (doc_off[d + 1] < doc_off[d]) return fail(TK_VALUE_ERROR, "doc_off must be non-decreasing");
     const uint64_t n_bytes = doc_off[n_docs];
     if (n_bytes > c->chunk_bytes) return fail(TK_VALUE_ERROR, "tk_pretokenize_batch handles a single chunk only");
     std::lock_guard<std::mutex> lk(c->mu);
@@ -602,7 +614,14 @@ extern "C" int tk_pretokenize_batch(tk_core* c, const uint8_t* utf8, const uint6
     HIPCHK(hipStreamSynchronize(s));
     TRY(drain_events(c));
     uint32_t* host = (uint32_t*)malloc((P + 1) * 4);
-    HIPCHK(hipMemcpy(host, c->pstart.p, (P + 1) * 4, hipMemcpyDeviceToHost));
+    if (!host) return fail(TK_RUNTIME_ERROR, "out of host memory");
+    {
+        hipError_t e = hipMemcpy(host, c->pstart.p, (P + 1) * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            free(host);
+            return fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e));
+        }
+    }
     *starts_out = host;
     *n_out = P + 1;
     return TK_OK;
@@ -619,8 +638,9 @@ extern "C" int tk_encode(tk_core* c, const uint8_t* utf8, uint64_t len, const ui
     return tk_encode_batch(c, utf8, off, 1, 1, allowed_ids, n_allowed, tokens_out, n_tokens_out, nullptr);
 }
 
-extern "C" int tk_encode_single_piece(tk_core* c, const uint8_t* piece, uint64_t len, uint32_t** tokens_out, uint64_t* n_tokens_out) {
+static int single_piece(tk_core* c, const uint8_t* piece, uint64_t len, bool no_lookup, uint32_t** tokens_out, uint64_t* n_tokens_out) {
     if (!c) return fail(TK_VALUE_ERROR, "core is null");
+    if (!tokens_out || !n_tokens_out) return fail(TK_VALUE_ERROR, "null argument");
     if (len >= (4ull << 30) - 65536) return fail(TK_VALUE_ERROR, "piece too long");
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
@@ -631,14 +651,29 @@ extern "C" int tk_encode_single_piece(tk_core* c, const uint8_t* piece, uint64_t
     HIPCHK(hipMemsetAsync((uint8_t*)c->text.p + len, 0, 128, s));
     TRY(ensure(c->out_tokens, tk_pid_cap(len) * 4));
     uint64_t total = 0;
-    TRY(run_chunk(c, s, c->text.as<uint8_t>(), len, nullptr, 0, 0, false, true, c->out_tokens.as<uint32_t>(), 0, nullptr, &total));
+    TRY(run_chunk(c, s, c->text.as<uint8_t>(), len, nullptr, 0, 0, false, true, c->out_tokens.as<uint32_t>(), 0, nullptr, &total, false, no_lookup));
     HIPCHK(hipStreamSynchronize(s));
     TRY(drain_events(c));
     uint32_t* host = (uint32_t*)malloc((total ? total : 1) * 4);
-    if (total) HIPCHK(hipMemcpy(host, c->out_tokens.p, total * 4, hipMemcpyDeviceToHost));
+    if (!host) return fail(TK_RUNTIME_ERROR, "out of host memory");
+    if (total) {
+        hipError_t e = hipMemcpy(host, c->out_tokens.p, total * 4, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            free(host);
+            return fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e));
+        }
+    }
     *tokens_out = host;
     *n_tokens_out = total;
     return TK_OK;
+}
+
+extern "C" int tk_encode_single_piece(tk_core* c, const uint8_t* piece, uint64_t len, uint32_t** tokens_out, uint64_t* n_tokens_out) {
+    return single_piece(c, piece, len, false, tokens_out, n_tokens_out);
+}
+
+extern "C" int tk_byte_pair_encode(tk_core* c, const uint8_t* piece, uint64_t len, uint32_t** tokens_out, uint64_t* n_tokens_out) {
+    return single_piece(c, piece, len, true, tokens_out, n_tokens_out);
 }
 
 extern "C" int tk_encode_single_token(tk_core* c, const uint8_t* piece, uint64_t len, uint32_t* token_out) {
@@ -696,6 +731,28 @@ extern "C" int tk_sorted_token(tk_core* c, uint64_t i, const uint8_t** bytes_out
     uint32_t r = c->H.sorted_ranks[i];
     if (rank_out) *rank_out = r;
     return tk_decode_single_token_bytes(c, r, bytes_out, len_out);
+}
+
+// token_byte_values() in one call: all token byte strings in lexicographic order, packed (src/lib.rs:648-650, py.rs:178-183).
+// The arrays are owned by the core (built on first use) and stay valid until tk_destroy.
+extern "C" int tk_sorted_tokens_packed(tk_core* c, const uint8_t** blob_out, const uint64_t** off_out, uint64_t* n_out) {
+    if (!c || !blob_out || !off_out || !n_out) return fail(TK_VALUE_ERROR, "null argument");
+    std::lock_guard<std::mutex> lk(c->mu);
+    if (c->sorted_off.empty()) {
+        const TkHostTables& H = c->H;
+        c->sorted_off.reserve(H.sorted_ranks.size() + 1);
+        c->sorted_off.push_back(0);
+        for (uint32_t r : H.sorted_ranks) {
+            const auto& e = H.decoder.at(r);
+            c->sorted_blob.insert(c->sorted_blob.end(), H.tok_bytes.begin() + e.first, H.tok_bytes.begin() + e.first + e.second);
+            c->sorted_off.push_back(c->sorted_blob.size());
+        }
+        if (c->sorted_blob.empty()) c->sorted_blob.push_back(0);
+    }
+    *blob_out = c->sorted_blob.data();
+    *off_out = c->sorted_off.data();
+    *n_out = c->sorted_off.size() - 1;
+    return TK_OK;
 }
 
 extern "C" void tk_free(void* p) { free(p); }

@@ -201,6 +201,10 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
         bm[tid][TK2_NSEG + 1] = tid <= TKB_HARD ? ~0ull : 0ull;
     }
     __syncthreads();
+    if (dbg & 0x1000) {  // (perf experiments: stop after this phase)
+        if (tid == 0) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
+        return;
+    }
     // ---- B1: class of every byte (branch-free): every lane finds the lead byte of ITS char (0..3 bytes back),
     // decodes the code point from the LDS copy of the text and issues the two table loads -- so continuation
     // bytes get their char's class without any cross-lane step.  The loads of all 17 segments of the wave are in
@@ -229,6 +233,13 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
 #pragma unroll
     for (int i = 0; i < NS; ++i) {
         creg[i] = class_at((uint32_t)(wid * NS + i) * 64u + lane);
+    }
+    if (dbg & 0x2000) {  // (perf experiments: stop after the classification; the loads are waited for)
+        uint32_t x = 0;
+#pragma unroll
+        for (int i = 0; i < NS; ++i) x ^= creg[i];
+        if (tid == 0 || x == 0xFFFFFFFFu) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
+        return;
     }
     // ---- B2: flags, class bytes, bitmaps, certain starts (previous class = lane - 1, carried across segments).
     // Each wave keeps its own list of certain starts (no LDS atomics): starts that will scan a word from the front
@@ -342,6 +353,10 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
         cnw[4 + wid] = cw_back;
     }
     __syncthreads();
+    if (dbg & 0x4000) {  // (perf experiments: stop after this phase)
+        if (tid == 0) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
+        return;
+    }
     // ---- D: one lane per certain start; only boundaries inside the tile are recorded
     TkWin2Acc acc{cls2, raw, base, &T, text, n, brk, ss, si};
     auto scan_from = [&](uint64_t p) {
@@ -411,6 +426,10 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
         }
     }
     __syncthreads();
+    if (dbg & 0x8000) {  // (perf experiments: stop after this phase)
+        if (tid == 0) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
+        return;
+    }
     // ---- E: enumerate the pieces of the tile (set bits of `bits`, in order) -> plist (aliases the bitmaps)
     {
         uint32_t pc = tid < TK_TILE / 32 ? __popc(bits[tid]) : 0u, tot;
@@ -434,6 +453,10 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
         if (wgp * 32 < n) out.starts[wgp] = bits[tid];
     }
     __syncthreads();
+    if (dbg & 0x10000) {  // (perf experiments: stop after this phase)
+        if (tid == 0) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
+        return;
+    }
     // ---- F: whole-piece probe, one lane per piece
     const uint32_t last_end = last_end_sh;
     for (uint32_t k0 = 0; k0 < np; k0 += 256) {
@@ -1068,11 +1091,12 @@ __global__ __launch_bounds__(256) void tk_k_docoff(uint64_t n_docs, const uint32
 }
 
 // encode_single_piece (src/py.rs:145-150): the whole buffer is one piece, no pre-tokenisation
-__global__ void tk_k_single_front(TkTables T, const uint8_t* __restrict__ text, uint32_t n, TkFrontOut out) {
+// (no_lookup: byte_pair_encode proper, src/lib.rs:198-211 -- no whole-piece shortcut except for single bytes)
+__global__ void tk_k_single_front(TkTables T, const uint8_t* __restrict__ text, uint32_t n, TkFrontOut out, int no_lookup) {
     if (blockIdx.x || threadIdx.x) return;
     out.tile_np[0] = 1;
     uint32_t nm = 0;
-    const uint32_t r = tk_lookup_text_piece(T, text, 0, n);
+    const uint32_t r = (no_lookup && n > 1u) ? TK_RANK_MAX : tk_lookup_text_piece(T, text, 0, n);
     if (r != TK_RANK_MAX) {
         out.tok1[0] = r;
         out.cnt[0] = 1;

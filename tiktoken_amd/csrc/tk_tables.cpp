@@ -192,8 +192,10 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
     for (uint64_t idx : order) {
         std::string s = sbytes(idx);
         if (s.empty()) return "empty special token";
-        if (!T.spec_decoder.emplace(spec_ids[idx], std::make_pair((uint32_t)T.spec_bytes.size(), (uint32_t)s.size())).second)
-            return "duplicate special token id";
+        // Two special strings may share an id (o200k_harmony: <|endofprompt|> and <|reserved_200018|> are both 200018,
+        // openai_public.py:85-94); the reference's decoder map keeps one of them (HashMap collect, lib.rs:643-646), here the
+        // first in byte order.
+        T.spec_decoder.emplace(spec_ids[idx], std::make_pair((uint32_t)T.spec_bytes.size(), (uint32_t)s.size()));
         T.spec_bytes.insert(T.spec_bytes.end(), s.begin(), s.end());
         T.spec_off.push_back((uint32_t)T.spec_bytes.size());
         T.spec_id.push_back(spec_ids[idx]);

@@ -16,9 +16,11 @@ vocabulary key yields that single rank); the script asserts that the shortcut an
 merge agree for every such piece it meets, and that every vocabulary token re-encodes to
 itself on a sample, so the shortcut is not hiding a divergence.
 
-Special-token cases follow src/lib.rs:375-442: the text is cut at every allowed special
-(leftmost, longest on ties), each slice is encoded as an independent haystack by the reference
-code above, and the special's id is inserted.
+Special-token cases follow src/lib.rs:375-442 statement by statement: the next special is found with the
+reference's own `tiktoken.core._special_token_regex` (core.py:431-438), a disallowed hit resumes the search one
+char later, each slice is encoded as an independent haystack by the reference code above, and the special's
+id is inserted.  No fixture registers a special that is a prefix of another (there the reference's pick
+depends on hash-map order, lib.rs:625-631); the rule is recorded in the fixture as `special_tie_rule`.
 
 Usage: python tools/gen_golden.py
 """
@@ -53,7 +55,7 @@ from tiktoken.core import Encoding as RefEncoding  # noqa: E402
 assert tiktoken.__file__.startswith(REF), tiktoken.__file__
 
 sys.path.insert(0, os.path.join(ROOT, "oracle"))
-import py_oracle as po  # noqa: E402  (pattern strings + special-token search order only)
+import py_oracle as po  # noqa: E402  (pattern strings only)
 
 sys.path.insert(0, ROOT)
 
@@ -126,16 +128,36 @@ def ref_encode_ordinary(pat, ranks, text, stats):
 
 
 def ref_encode(pat, ranks, specials, text, allowed, stats):
-    allowed = set(allowed) & set(specials)
+    """src/lib.rs:375-442 statement by statement, with the REFERENCE's own special-token regex
+    (tiktoken.core._special_token_regex, core.py:431-438: the alternation of every REGISTERED special, escaped --
+    the same pattern CoreBPE::new_internal compiles at lib.rs:625-631)."""
+    from tiktoken.core import _special_token_regex
+
+    special_regex = _special_token_regex(frozenset(specials))
+    allowed = set(allowed)
     out, start = [], 0
     while True:
-        hit = po.find_special(text, specials, start, allowed) if allowed else None
-        end = hit[0] if hit else len(text)
+        start_find = start
+        while True:  # lib.rs:389-401: next ALLOWED special; a disallowed hit resumes one char after its start
+            m = special_regex.search(text, start_find) if specials else None
+            if m is None or m.group(0) in allowed:
+                break
+            start_find = m.start() + 1
+        end = m.start() if m else len(text)
         out += ref_encode_ordinary(pat, ranks, text[start:end], stats)
-        if not hit:
+        if m is None:
             return out
-        out.append(specials[hit[1]])
-        start = hit[0] + len(hit[1])
+        out.append(specials[m.group(0)])
+        start = m.end()
+
+
+def check_no_prefix_ties(specials):
+    """When one registered special is a prefix of another the reference's pick at that position depends on the
+    iteration order of a hash map (lib.rs:625-631) -- such sets are kept out of the fixtures."""
+    names = list(specials)
+    for a in names:
+        for b in names:
+            assert a == b or not b.startswith(a), (a, b)
 
 
 ENCODINGS = {
@@ -154,6 +176,7 @@ def main():
         ranks = load_vocab(vocab)
         # the reference's own constructor checks (core.py:47-57) accept this vocabulary
         RefEncoding(name, pat_str=pat_str, mergeable_ranks=ranks, special_tokens=specials)
+        check_no_prefix_ties(specials)
         pat = regex.compile(pat_str)
         stats = {"pieces": 0, "shortcut": 0}
         cases = []
@@ -197,7 +220,11 @@ def main():
             assert edu.bpe_encode(ranks, tb, visualise=None) == [r], tb
         path = os.path.join(ROOT, "tests/golden", name + ".json.gz")
         payload = json.dumps({"encoding": name, "pat_str": pat_str, "vocab": vocab, "special_tokens": specials,
-                              "generator": "tools/gen_golden.py (reference tiktoken/_educational.py bpe_encode + regex.findall)",
+                              "generator": "tools/gen_golden.py (reference tiktoken/_educational.py bpe_encode + regex.findall; "
+                                           "specials located by the reference's tiktoken.core._special_token_regex in the loop of src/lib.rs:386-402)",
+                              "special_tie_rule": "no registered special of this fixture is a prefix of another (checked at generation); "
+                                                  "there the reference's choice depends on hash-map order (lib.rs:625-631) and this "
+                                                  "implementation takes the longest allowed special",
                               "cases": cases}, ensure_ascii=True).encode()
         with open(path, "wb") as f:
             with gzip.GzipFile(fileobj=f, mode="wb", mtime=0, compresslevel=9) as gz:
