@@ -93,6 +93,11 @@ int tk_sorted_token(tk_core* core, uint64_t i, const uint8_t** bytes_out, uint64
 /* The same list in one call: packed bytes + n+1 offsets, owned by the core (valid until tk_destroy). */
 int tk_sorted_tokens_packed(tk_core* core, const uint8_t** blob_out, const uint64_t** off_out, uint64_t* n_out);
 
+/* Vocabulary wire format: the text of a `.tiktoken` file (`base64(token) SP rank` per line) -> the packed arrays tk_create takes.
+ * Replaces the per-line Python loop of tiktoken/load.py:159-171.  Release the three arrays with tk_free.  TK_VALUE_ERROR with
+ * "Error parsing line N ..." on malformed input. */
+int tk_parse_tiktoken_bpe(const uint8_t* text, uint64_t len, uint8_t** blob_out, uint64_t** off_out, uint32_t** ids_out, uint64_t* n_out);
+
 void tk_free(void* p);
 
 /* Instrumentation for bench.py: when enabled, every kernel launch of the next encode call is

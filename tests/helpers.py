@@ -90,6 +90,56 @@ def gen_corpus(seed: int, mix: int, nbytes: int, threads: int = 8):
     return out[:nbytes], off[: nd.value + 1].copy()
 
 
+def insert_specials(blob: np.ndarray, off: np.ndarray, seed: int = 5):
+    """Config C5: special tokens <|custom_0..7|> at a mean of one per ~2 KiB plus decoys (an unregistered
+    <|custom_9|>, truncated specials, bare delimiters), inserted at char boundaries of every document."""
+    bb = blob.tobytes()
+    rng = np.random.default_rng(seed)
+    decoys = [b"<|custom_9|>", b"<|endoftext", b"<|custom_3|", b"<|", b"|>"]
+    parts, lens = [], []
+    for d in range(len(off) - 1):
+        t = bb[int(off[d]):int(off[d + 1])]
+        out, pos = [], 0
+        while pos < len(t):
+            step = int(rng.integers(512, 3584))
+            cut = min(len(t), pos + step)
+            while cut < len(t) and (t[cut] & 0xC0) == 0x80:
+                cut += 1
+            out.append(t[pos:cut])
+            if cut < len(t):
+                out.append(b"<|custom_%d|>" % rng.integers(0, 8) if rng.random() < 0.8 else decoys[int(rng.integers(0, len(decoys)))])
+            pos = cut
+        doc = b"".join(out)
+        parts.append(doc)
+        lens.append(len(doc))
+    blob5 = np.frombuffer(b"".join(parts) + b"\0" * 64, np.uint8)
+    off5 = np.zeros(len(lens) + 1, np.uint64)
+    off5[1:] = np.cumsum(lens)
+    return blob5[: int(off5[-1])], off5
+
+
+CUSTOM8 = {**SPECIALS["o200k_shaped"], **{f"<|custom_{i}|>": 200019 + i for i in range(8)}}
+
+
+def baseline_config(cfg: str, threads: int = 16):
+    """(encoding name for the vocabulary, pattern id, special tokens, blob, doc_off, allowed_special) of a BASELINE.json config at its
+    FULL size (SURVEY.md 8d): C1 gpt2 1 MiB Lorem ipsum (one document); C2 cl100k 64 MiB mixed UTF-8; C3 o200k 1 GiB web text;
+    C5 o200k + 8 custom specials, 256 MiB web text, allowed_special='all'."""
+    if cfg == "C1":
+        blob, off = pack([lorem(1 << 20)])
+        return "gpt2_shaped", 0, SPECIALS["gpt2_shaped"], blob, off, None
+    if cfg == "C2":
+        blob, off = gen_corpus(0x5EED0002, 0, 64 << 20, threads)
+        return "cl100k_shaped", 1, SPECIALS["cl100k_shaped"], blob, off, None
+    if cfg == "C3":
+        blob, off = gen_corpus(0x5EED0003, 1, 1 << 30, threads)
+        return "o200k_shaped", 2, SPECIALS["o200k_shaped"], blob, off, None
+    if cfg == "C5":
+        blob, off = insert_specials(*gen_corpus(0x5EED0005, 1, 256 << 20, threads))
+        return "o200k_shaped", 2, CUSTOM8, blob, off, "all"
+    raise KeyError(cfg)
+
+
 LOREM = ("Lorem ipsum dolor sit amet, consectetur adipiscing elit, sed do eiusmod tempor incididunt ut labore et "
          "dolore magna aliqua. Ut enim ad minim veniam, quis nostrud exercitation ullamco laboris nisi ut aliquip ex "
          "ea commodo consequat. Duis aute irure dolor in reprehenderit in voluptate velit esse cillum dolore eu "

@@ -1,5 +1,4 @@
-"""Host-side mirror of the reference interface: names, signatures, registry/plugin mechanism, model table,
-vocabulary wire format.  (Anything that constructs a CoreBPE needs a GPU and lives in test_gpu_api.py.)"""
+"""Host-side mirror of the reference interface: names, signatures, the tiktoken_ext plugin surface, the vocabulary wire format.  (Anything that constructs a CoreBPE needs a GPU and lives in test_gpu_api.py.)"""
 import base64
 import hashlib
 import inspect
@@ -9,7 +8,7 @@ import pytest
 
 import helpers as h
 import tiktoken_amd
-from tiktoken_amd import load, model, registry
+from tiktoken_amd import vocab_io
 from tiktoken_amd.core import Encoding
 
 REFERENCE_ENCODING_API = {  # reference tiktoken/core.py:16-428
@@ -77,34 +76,40 @@ def test_stock_constructor_data():
                                               "o200k_harmony"}
 
 
-def test_model_table():
-    """reference tests/test_misc.py:7-21 (names only; constructing the encodings needs vocab files + GPU)."""
-    assert model.encoding_name_for_model("gpt2") == "gpt2"
-    assert model.encoding_name_for_model("text-davinci-003") == "p50k_base"
-    assert model.encoding_name_for_model("text-davinci-edit-001") == "p50k_edit"
-    assert model.encoding_name_for_model("gpt-3.5-turbo-0301") == "cl100k_base"
-    assert model.encoding_name_for_model("gpt-4") == "cl100k_base"
-    assert model.encoding_name_for_model("gpt-4o") == "o200k_base"
-    assert model.encoding_name_for_model("gpt-oss-120b") == "o200k_harmony"
-    with pytest.raises(KeyError):
-        model.encoding_name_for_model("not-a-model")
-
-
 def test_tiktoken_file_roundtrip_and_cache(tmp_path, monkeypatch):
-    """Wire format `base64(token) SP rank` (load.py:147-171) and the sha1-keyed, sha256-checked cache (:35-86)."""
-    ranks = {b"a": 0, b"b": 1, b"ab": 2, b"\xff\x00": 3}
+    """Wire format `base64(token) SP rank` (reference load.py:147-171) through the NATIVE parser (tk_parse_tiktoken_bpe), sha256 pinning,
+    and the reference's cache layout (file name = sha1 of the URL, load.py:51) for URL locations."""
+    ranks = {b"a": 0, b"b": 1, b"ab": 2, b"\xff\x00": 3, b"x" * 100: 4000000000}
     path = tmp_path / "tiny.tiktoken"
-    load.dump_tiktoken_bpe(ranks, str(path))
+    vocab_io.dump_tiktoken_bpe(ranks, str(path))
     assert path.read_bytes().splitlines()[2] == base64.b64encode(b"ab") + b" 2"
-    monkeypatch.setenv("TIKTOKEN_CACHE_DIR", str(tmp_path / "cache"))
     sha = hashlib.sha256(path.read_bytes()).hexdigest()
-    assert load.load_tiktoken_bpe(str(path), expected_hash=sha) == ranks
-    key = hashlib.sha1(str(path).encode()).hexdigest()
-    assert (tmp_path / "cache" / key).exists()
+    got = vocab_io.load_tiktoken_bpe(str(path), expected_hash=sha)
+    assert got == ranks and got.packed is not None and got.packed[2].tolist() == list(ranks.values())
+    got[b"zz"] = 9
+    assert got.packed is None  # a mutated table no longer vouches for its packed form
     with pytest.raises(ValueError, match="Hash mismatch"):
-        load.read_file_cached(str(path), expected_hash="0" * 64)
-    with pytest.raises(ValueError, match="Error parsing line"):
-        load.parse_tiktoken_bpe(b"!!notbase64 x\n")
+        vocab_io.load_tiktoken_bpe(str(path), expected_hash="0" * 64)
+    for bad in (b"!!notbase64 x\n", b"YQ== notanumber\n", b"YQ==\n", b"YQ= 1\n", b"YQ== 4294967296\n"):
+        with pytest.raises(ValueError, match="Error parsing line 1"):
+            vocab_io.parse_tiktoken_bpe(bad)
+    assert vocab_io.parse_tiktoken_bpe(b"") == {} and vocab_io.parse_tiktoken_bpe(b"\nYQ== 7\r\n\n") == {b"a": 7}
+    # a URL is served from the cache directory under sha1(url) without touching the network
+    url = "https://example.invalid/encodings/tiny.tiktoken"
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    (cache / hashlib.sha1(url.encode()).hexdigest()).write_bytes(path.read_bytes())
+    monkeypatch.setenv("TIKTOKEN_CACHE_DIR", str(cache))
+    assert vocab_io.load_tiktoken_bpe(url, expected_hash=sha) == ranks
+
+
+def test_native_parser_equals_python_on_the_shipped_vocabularies():
+    import gzip
+
+    for name in h.ENCODING_NAMES:
+        raw = gzip.open(os.path.join(h.ROOT, "tiktoken_amd", "vocab", name + ".tiktoken.gz")).read()
+        want = {base64.b64decode(t): int(r) for t, r in (line.split() for line in raw.splitlines() if line)}
+        assert vocab_io.parse_tiktoken_bpe(raw) == want
 
 
 def test_shaped_vocab_files_parse_like_reference_format():
@@ -113,5 +118,5 @@ def test_shaped_vocab_files_parse_like_reference_format():
 
     assert amd_shaped.gpt2_shaped()["mergeable_ranks"] == ranks
     assert sorted(ranks.values()) == list(range(50256))
-    order = load.data_gym_byte_order()
+    order = vocab_io.data_gym_byte_order()
     assert [ranks[bytes([b])] for b in order] == list(range(256))

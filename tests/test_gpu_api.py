@@ -208,3 +208,69 @@ def test_real_vocab_known_answers_if_available():
     assert enc.encode("rer") == [38149] and enc.encode("'rer") == [2351, 81]
     assert enc.encode("today\n ") == [31213, 198, 220] and enc.encode("today\n \n") == [31213, 27907]
     assert enc.encode(" \x850") == [220, 126, 227, 15]
+
+
+# ---------------------------------------------------------------- byte-level / unstable entry points vs the oracle
+# CoreBPE._encode_bytes (src/py.rs:72-115) and CoreBPE.encode_with_unstable (src/lib.rs:483-599) are compared with the
+# statement-by-statement restatement in oracle/py_oracle.py -- token for token and completion set for completion set.
+def _edu_core():
+    from oracle import py_oracle as po
+    from tiktoken_amd import CoreBPE
+
+    ranks = h.golden_vocab("edu600")
+    specials = {"<|endoftext|>": 600}
+    return CoreBPE(ranks, specials, po.R50K_PAT), ranks, specials, po
+
+
+UNSTABLE_TEXTS = ["hello fanta", "hello wor", "def f(x):\n    return x", "a\n\n", "tab\t\t", "x  ", "hello <|endoftext|>", "hello <|endoftext|> wor",
+                  "", " ", "\n", "ing", "the the the", "  \n  ", "naïve caf", "中文", "1234 56", "it's", "don'", " \x1c", "a　", "a  "]
+
+
+@pytest.mark.parametrize("allowed", [set(), {"<|endoftext|>"}])
+def test_encode_with_unstable_equals_oracle(allowed):
+    core, ranks, specials, po = _edu_core()
+    for text in UNSTABLE_TEXTS:
+        got_t, got_c = core.encode_with_unstable(text, allowed)
+        want_t, want_c = po.encode_unstable_native(text, po.R50K_PAT, ranks, specials, allowed)
+        assert got_t == want_t, (text, got_t, want_t)
+        assert {tuple(c) for c in got_c} == want_c, (text, sorted(map(tuple, got_c))[:5], sorted(want_c)[:5])
+
+
+@hypothesis.given(text=st.text(alphabet=st.sampled_from(list("abehlnort \n\t'.0x") + ["é", "中", "\x1c", "　"]), max_size=12))
+@hypothesis.settings(deadline=None, max_examples=MAX_EXAMPLES)
+def test_hyp_encode_with_unstable_equals_oracle(text):
+    core, ranks, specials, po = _edu_core()
+    got_t, got_c = core.encode_with_unstable(text, set())
+    want_t, want_c = po.encode_unstable_native(text, po.R50K_PAT, ranks, specials, set())
+    assert got_t == want_t and {tuple(c) for c in got_c} == want_c, text
+
+
+def test_encode_bytes_equals_oracle():
+    from oracle import py_oracle as po
+
+    rng = np.random.default_rng(11)
+    for name in ENCS:
+        enc = tiktoken.get_encoding(name)
+        ranks, pat = h.load_vocab(name), h.PAT_STR[h.PATTERN_OF[name]]
+        cases = [b"", b"hello world", b"hello wor\xff", b" \xec\x8b\xa4\xed", b"\x80" * 5, "naïve".encode()[:-1], "today\n ".encode() + b"\xe4\xb8",
+                 b"abc \n\t  \xf0\x9f\x91", b"\xff", b"a\xffb\xfec", "실 실".encode()[:-2]]
+        for _ in range(40):
+            base = "".join(rng.choice(h.ADV, size=int(rng.integers(1, 12)))).encode()
+            cut = int(rng.integers(0, len(base) + 1))
+            cases.append(base[:cut] + bytes(rng.integers(0x80, 0x100, size=int(rng.integers(0, 3)), dtype=np.uint8)))
+        for bs in cases:
+            assert enc._encode_bytes(bs) == po.encode_bytes(bs, pat, ranks), (name, bs)
+
+
+def test_byte_pair_encode_has_no_whole_piece_shortcut():
+    """tk_byte_pair_encode = byte_pair_encode (src/lib.rs:198-211): on a vocabulary where a key is NOT reachable by merges the
+    shortcut (encode_single_piece, py.rs:145-150) and the merge differ."""
+    from oracle import py_oracle as po
+    from tiktoken_amd import CoreBPE
+
+    ranks = {bytes([b]): b for b in range(256)}
+    ranks[b"abc"] = 256  # neither "ab" nor "bc" is a key: the merge loop can never build it
+    core = CoreBPE(ranks, {}, po.R50K_PAT)
+    assert core.encode_single_piece(b"abc") == [256] == po.encode_single_piece(b"abc", ranks)
+    assert core._byte_pair_encode(b"abc") == [97, 98, 99] == po.byte_pair_encode(b"abc", ranks)
+    assert core._byte_pair_encode(b"a") == [97]

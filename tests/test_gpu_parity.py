@@ -217,3 +217,29 @@ def test_size_independent_properties_at_scale(cores):
         assert np.array_equal(core._encode_np(bb[a:b], None), toks[int(toff[d]):int(toff[d + 1])])
     total_bytes = sum(len(core.decode_single_token_bytes(int(t))) for t in toks[:200000])
     assert total_bytes == int(off[np.searchsorted(toff, 200000, side="right") - 1]) or total_bytes > 0
+
+
+@pytest.mark.parametrize("cfg", ["C1", "C2", "C5", "C3"])
+def test_baseline_configs_at_full_size(cfg):
+    """Every BASELINE.json configuration at its FULL size (1 MiB / 64 MiB / 256 MiB with special tokens / 1 GiB), every token and
+    every offset compared with the C oracle (all host threads) -- not a sample."""
+    import os
+
+    from tiktoken_amd import CoreBPE
+
+    vocab, pat, specials, blob, off, allowed = h.baseline_config(cfg, threads=min(os.cpu_count() or 8, 32))
+    core = CoreBPE(h.load_vocab(vocab), specials, h.PAT_STR[pat])
+    C = h.c_oracle.COracle(pat, h.load_vocab(vocab), specials)
+    toks, toff = core.encode_batch_packed(blob, off, allowed)
+    rt, ro = C.encode_batch(blob, off, allowed, os.cpu_count() or 8)
+    assert len(toks) == len(rt), (cfg, len(toks), len(rt))
+    if not np.array_equal(toff, ro):
+        d = int(np.flatnonzero(toff != ro)[0]) - 1
+        a, b = int(off[d]), int(off[d + 1])
+        raise AssertionError((cfg, "first differing document", d, blob[a:b].tobytes()[:200]))
+    if not np.array_equal(toks, rt):
+        i = int(np.flatnonzero(toks != rt)[0])
+        d = int(np.searchsorted(ro, i, side="right")) - 1
+        raise AssertionError((cfg, "first differing token", i, "document", d, blob[int(off[d]):int(off[d + 1])].tobytes()[:200]))
+    if allowed:
+        assert np.isin(toks, np.array(sorted(specials.values()), np.uint32)).sum() > 0  # (specials were really exercised)

@@ -74,6 +74,8 @@ def lib() -> ctypes.CDLL:
         L.tk_sorted_token.argtypes = [vp, u64, P(vp), P(u64), P(u32)]
         L.tk_sorted_tokens_packed.restype = i32
         L.tk_sorted_tokens_packed.argtypes = [vp, P(vp), P(vp), P(u64)]
+        L.tk_parse_tiktoken_bpe.restype = i32
+        L.tk_parse_tiktoken_bpe.argtypes = [vp, u64, P(vp), P(vp), P(vp), P(u64)]
         L.tk_free.argtypes = [vp]
         L.tk_set_profiling.argtypes = [vp, i32]
         L.tk_reset_kernel_ms.argtypes = [vp]

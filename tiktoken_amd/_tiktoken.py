@@ -56,7 +56,8 @@ class CoreBPE:
             if not 0 <= v <= 0xFFFFFFFF:
                 raise OverflowError("rank does not fit in u32")  # PyO3 would refuse the conversion too
         self._specials = dict(special_tokens_encoder)
-        rb, ro, ri = _pack_pairs(list(encoder.items()))
+        packed = getattr(encoder, "packed", None)  # vocab_io.RankTable: arrays straight from the native parser
+        rb, ro, ri = packed if packed is not None and len(packed[2]) == len(encoder) else _pack_pairs(list(encoder.items()))
         sb, so, si = _pack_pairs([(k.encode("utf-8"), v) for k, v in self._specials.items()])
         h = ctypes.c_void_p()
         rc = L.tk_create(rb.ctypes.data, ro.ctypes.data, ri.ctypes.data, len(encoder), sb.ctypes.data, so.ctypes.data,

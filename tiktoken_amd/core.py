@@ -240,18 +240,18 @@ class Encoding:
         return self._core_bpe._encode_bytes(text)
 
     def __getstate__(self) -> object:
-        from . import registry
+        from . import plugins
 
-        if self is registry.ENCODINGS.get(self.name):
+        if plugins._CATALOGUE.registered(self):
             return self.name  # registered encodings pickle by name
         return {"name": self.name, "pat_str": self._pat_str, "mergeable_ranks": self._mergeable_ranks,
                 "special_tokens": self._special_tokens}
 
     def __setstate__(self, value: object) -> None:
-        from . import registry
+        from . import plugins
 
         if isinstance(value, str):
-            self.__dict__ = registry.get_encoding(value).__dict__
+            self.__dict__ = plugins.get_encoding(value).__dict__
             return
         self.__init__(**value)
 

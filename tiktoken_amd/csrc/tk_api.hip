@@ -755,6 +755,34 @@ extern "C" int tk_sorted_tokens_packed(tk_core* c, const uint8_t** blob_out, con
     return TK_OK;
 }
 
+// Vocabulary wire format: the contents of a `.tiktoken` file -> packed arrays in the layout tk_create takes (release each with tk_free).
+extern "C" int tk_parse_tiktoken_bpe(const uint8_t* text, uint64_t len, uint8_t** blob_out, uint64_t** off_out, uint32_t** ids_out,
+                                     uint64_t* n_out) {
+    if (!blob_out || !off_out || !ids_out || !n_out || (!text && len)) return fail(TK_VALUE_ERROR, "null argument");
+    std::vector<uint8_t> blob;
+    std::vector<uint64_t> off;
+    std::vector<uint32_t> ids;
+    const std::string err = tk_parse_tiktoken(text, len, &blob, &off, &ids);
+    if (!err.empty()) return fail(TK_VALUE_ERROR, err);
+    uint8_t* b = (uint8_t*)malloc(blob.size() ? blob.size() : 1);
+    uint64_t* o = (uint64_t*)malloc(off.size() * 8);
+    uint32_t* r = (uint32_t*)malloc(ids.size() ? ids.size() * 4 : 4);
+    if (!b || !o || !r) {
+        free(b);
+        free(o);
+        free(r);
+        return fail(TK_RUNTIME_ERROR, "out of host memory");
+    }
+    if (!blob.empty()) memcpy(b, blob.data(), blob.size());
+    memcpy(o, off.data(), off.size() * 8);
+    if (!ids.empty()) memcpy(r, ids.data(), ids.size() * 4);
+    *blob_out = b;
+    *off_out = o;
+    *ids_out = r;
+    *n_out = ids.size();
+    return TK_OK;
+}
+
 extern "C" void tk_free(void* p) { free(p); }
 
 extern "C" void tk_set_profiling(tk_core* c, int enabled) {

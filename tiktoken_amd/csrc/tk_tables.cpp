@@ -4,6 +4,7 @@
 
 #include <algorithm>
 #include <numeric>
+#include <thread>
 
 static const char* const PAT_R50K =
     R"('(?:[sdmt]|ll|ve|re)| ?\p{L}++| ?\p{N}++| ?[^\s\p{L}\p{N}]++|\s++$|\s+(?!\S)|\s)";
@@ -131,20 +132,38 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
             return "every single byte must be a key of mergeable_ranks (byte_pair_encode indexes ranks[piece] for "
                    "1-byte pieces, src/lib.rs:201-203)";
 
-    // pair table: all splits of all tokens into two vocabulary tokens
+    // pair table: all splits of all tokens into two vocabulary tokens (read-only lookups: split over host threads)
     std::vector<TkPairSlot> entries;
-    entries.reserve(n_ranks * 3);
-    for (uint64_t k = 0; k < n_ranks; ++k) {
-        uint64_t o = ranks_off[k];
-        uint32_t len = (uint32_t)(ranks_off[k + 1] - o), rank = ranks_ids[k];
-        const uint8_t* p = ranks_blob + o;
-        for (uint32_t s = 1; s < len; ++s) {
-            uint32_t a = T.lookup_piece(p, s);
-            if (a == TK_RANK_MAX) continue;
-            uint32_t b = T.lookup_piece(p + s, len - s);
-            if (b == TK_RANK_MAX) continue;
-            entries.push_back(TkPairSlot{((uint64_t)a << 32) | b, rank, 0});
-        }
+    {
+        unsigned nth = std::thread::hardware_concurrency();
+        nth = nth == 0 ? 1 : (nth > 16 ? 16 : nth);
+        if (n_ranks < 4096) nth = 1;
+        std::vector<std::vector<TkPairSlot>> part(nth);
+        auto work = [&](unsigned t) {
+            std::vector<TkPairSlot>& e = part[t];
+            e.reserve(n_ranks * 3 / nth + 16);
+            const uint64_t k0 = n_ranks * t / nth, k1 = n_ranks * (t + 1) / nth;
+            for (uint64_t k = k0; k < k1; ++k) {
+                uint64_t o = ranks_off[k];
+                uint32_t len = (uint32_t)(ranks_off[k + 1] - o), rank = ranks_ids[k];
+                const uint8_t* p = ranks_blob + o;
+                for (uint32_t s = 1; s < len; ++s) {
+                    uint32_t a = T.lookup_piece(p, s);
+                    if (a == TK_RANK_MAX) continue;
+                    uint32_t b = T.lookup_piece(p + s, len - s);
+                    if (b == TK_RANK_MAX) continue;
+                    e.push_back(TkPairSlot{((uint64_t)a << 32) | b, rank, 0});
+                }
+            }
+        };
+        std::vector<std::thread> th;
+        for (unsigned t = 1; t < nth; ++t) th.emplace_back(work, t);
+        work(0);
+        for (auto& x : th) x.join();
+        size_t tot = 0;
+        for (auto& e : part) tot += e.size();
+        entries.reserve(tot);
+        for (auto& e : part) entries.insert(entries.end(), e.begin(), e.end());  // (token order, as a single thread would produce)
     }
     T.n_pairs = entries.size();
     uint32_t max_id = 0;
@@ -216,5 +235,68 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
     });
     T.sorted_ranks.resize(n_ranks);
     for (uint64_t i = 0; i < n_ranks; ++i) T.sorted_ranks[i] = ranks_ids[idx[i]];
+    return "";
+}
+
+
+// ------------------------------------------------------------------------------------------
+// `.tiktoken` wire format (reference tiktoken/load.py:159-171: one `base64(token) SP rank` per line), parsed natively:
+// the stock o200k file is 200 k lines, which the reference parses in a Python loop.
+// ------------------------------------------------------------------------------------------
+std::string tk_parse_tiktoken(const uint8_t* text, uint64_t len, std::vector<uint8_t>* blob, std::vector<uint64_t>* off,
+                              std::vector<uint32_t>* ids) {
+    static int8_t dec[256];
+    static bool init = false;
+    if (!init) {
+        for (int i = 0; i < 256; ++i) dec[i] = -1;
+        const char* al = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
+        for (int i = 0; i < 64; ++i) dec[(unsigned char)al[i]] = (int8_t)i;
+        init = true;
+    }
+    blob->clear();
+    off->assign(1, 0);
+    ids->clear();
+    blob->reserve(len / 2);
+    uint64_t line_no = 0, i = 0;
+    auto bad = [&](const char* what) { return std::string("Error parsing line ") + std::to_string(line_no) + " of the .tiktoken data: " + what; };
+    while (i < len) {
+        ++line_no;
+        uint64_t e = i;
+        while (e < len && text[e] != '\n') ++e;
+        uint64_t a = i, b = e;
+        if (b > a && text[b - 1] == '\r') --b;
+        i = e + 1;
+        if (a == b) continue;  // empty line
+        uint64_t sp = a;
+        while (sp < b && text[sp] != ' ') ++sp;
+        if (sp == a || sp == b) return bad("expected `base64 SP rank`");
+        // base64 (standard alphabet, '=' padding)
+        uint64_t q = sp;
+        while (q > a && text[q - 1] == '=') --q;
+        const uint64_t n64 = q - a, pad = sp - q;
+        if ((n64 + pad) % 4 != 0 || pad > 2 || n64 % 4 == 1) return bad("bad base64 length");
+        uint32_t acc = 0;
+        int bits = 0;
+        for (uint64_t k = a; k < q; ++k) {
+            const int v = dec[text[k]];
+            if (v < 0) return bad("bad base64 character");
+            acc = (acc << 6) | (uint32_t)v;
+            bits += 6;
+            if (bits >= 8) {
+                bits -= 8;
+                blob->push_back((uint8_t)(acc >> bits));
+            }
+        }
+        // rank: decimal, fits u32
+        uint64_t r = 0, k = sp + 1;
+        if (k == b) return bad("missing rank");
+        for (; k < b; ++k) {
+            if (text[k] < '0' || text[k] > '9') return bad("rank is not a decimal number");
+            r = r * 10 + (uint64_t)(text[k] - '0');
+            if (r > 0xFFFFFFFFull) return bad("rank does not fit 32 bits");
+        }
+        off->push_back(blob->size());
+        ids->push_back((uint32_t)r);
+    }
     return "";
 }

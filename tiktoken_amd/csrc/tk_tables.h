@@ -46,3 +46,7 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
 
 // pattern id for a pat_str, or -1 (exported through the C ABI, include/tiktoken_amd.h)
 extern "C" int tk_pattern_id(const char* pat_str);
+
+// `.tiktoken` text -> packed token bytes + offsets + ranks (reference tiktoken/load.py:159-171).  "" or an error message.
+std::string tk_parse_tiktoken(const uint8_t* text, uint64_t len, std::vector<uint8_t>* blob, std::vector<uint64_t>* off,
+                              std::vector<uint32_t>* ids);

@@ -1,0 +1,149 @@
+"""Vocabulary files.  The `.tiktoken` wire format -- one `base64(token) SP rank` per line, reference
+tiktoken/load.py:147-171 -- is parsed by the native library (`tk_parse_tiktoken_bpe`, include/tiktoken_amd.h) instead of a
+per-line Python loop; the result keeps the packed arrays so that `CoreBPE(...)` hands them to `tk_create` without re-packing.
+The GPT-2 `vocab.bpe` + `encoder.json` pair (load.py:89-144) is converted here as well.
+
+Files are read from a local path, or -- for the URLs the stock constructors use -- from `$TIKTOKEN_CACHE_DIR` /
+`$DATA_GYM_CACHE_DIR` under the reference's cache key `sha1(url)` (so an existing tiktoken cache is picked up), and fetched
+over HTTP(S) only when absent.  A pinned sha256 is always verified.
+"""
+from __future__ import annotations
+
+import base64
+import ctypes
+import gzip
+import hashlib
+import json
+import os
+
+import numpy as np
+
+from . import _lib
+
+
+class RankTable(dict):
+    """`dict[bytes, int]` that also carries the packed (blob, offsets, ranks) arrays it was parsed from; any mutation
+    drops them, so a CoreBPE built from the table always sees the dict's current contents."""
+
+    packed = None
+
+    def _mutating(name):  # noqa: N805
+        def method(self, *a, **k):
+            self.packed = None
+            return getattr(dict, name)(self, *a, **k)
+
+        method.__name__ = name
+        return method
+
+    for _n in ("__setitem__", "__delitem__", "pop", "popitem", "clear", "update", "setdefault", "__ior__"):
+        locals()[_n] = _mutating(_n)
+    del _n, _mutating
+
+
+def parse_tiktoken_bpe(contents: bytes, source: str = "<bytes>") -> RankTable:
+    L = _lib.lib()
+    buf = np.frombuffer(contents, np.uint8) if contents else np.zeros(1, np.uint8)
+    pb, po, pi, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64()
+    rc = L.tk_parse_tiktoken_bpe(buf.ctypes.data, len(contents), ctypes.byref(pb), ctypes.byref(po), ctypes.byref(pi), ctypes.byref(n))
+    if rc != _lib.TK_OK:
+        raise ValueError(f"{_lib.last_error()} ({source})")
+    try:
+        cnt = n.value
+        off = np.ctypeslib.as_array(ctypes.cast(po, ctypes.POINTER(ctypes.c_uint64)), shape=(cnt + 1,)).copy()
+        ids = np.ctypeslib.as_array(ctypes.cast(pi, ctypes.POINTER(ctypes.c_uint32)), shape=(max(cnt, 1),))[:cnt].copy()
+        blob = ctypes.string_at(pb, int(off[-1]))
+    finally:
+        for p in (pb, po, pi):
+            L.tk_free(p)
+    bounds = off.tolist()
+    table = RankTable(zip((blob[a:b] for a, b in zip(bounds[:-1], bounds[1:])), ids.tolist()))
+    if len(table) == cnt:  # (duplicate keys collapse in the dict: then the packed form no longer matches it)
+        table.packed = (np.frombuffer(blob, np.uint8) if blob else np.zeros(1, np.uint8), off, ids)
+    return table
+
+
+def dump_tiktoken_bpe(bpe_ranks: dict[bytes, int], tiktoken_bpe_file: str) -> None:
+    with open(tiktoken_bpe_file, "wb") as f:
+        for token, rank in sorted(bpe_ranks.items(), key=lambda kv: kv[1]):
+            f.write(base64.b64encode(token) + b" %d\n" % rank)
+
+
+def _cache_root() -> str | None:
+    for var in ("TIKTOKEN_CACHE_DIR", "DATA_GYM_CACHE_DIR"):
+        if var in os.environ:
+            return os.environ[var] or None  # empty string: caching switched off
+    import tempfile
+
+    return os.path.join(tempfile.gettempdir(), "data-gym-cache")
+
+
+def fetch(location: str, expected_hash: str | None = None) -> bytes:
+    """Bytes of a local file or of an http(s) URL (cache first); raises ValueError when the sha256 does not match."""
+    def verified(data: bytes, where: str) -> bytes:
+        if expected_hash and hashlib.sha256(data).hexdigest() != expected_hash:
+            raise ValueError(f"Hash mismatch for data from {where} (expected sha256 {expected_hash})")
+        return data
+
+    if "://" not in location:
+        with open(location, "rb") as f:
+            return verified(f.read(), location)
+    root = _cache_root()
+    slot = os.path.join(root, hashlib.sha1(location.encode()).hexdigest()) if root else None
+    if slot and os.path.exists(slot):
+        with open(slot, "rb") as f:
+            data = f.read()
+        if not expected_hash or hashlib.sha256(data).hexdigest() == expected_hash:
+            return data
+    if not location.startswith(("http://", "https://")):
+        raise ValueError(f"unsupported location scheme: {location}")
+    import urllib.request
+
+    with urllib.request.urlopen(location) as resp:  # noqa: S310 (pinned by sha256 below)
+        data = verified(resp.read(), location)
+    if slot:
+        os.makedirs(root, exist_ok=True)
+        tmp = f"{slot}.{os.getpid()}.part"
+        with open(tmp, "wb") as f:
+            f.write(data)
+        os.replace(tmp, slot)
+    return data
+
+
+def load_tiktoken_bpe(tiktoken_bpe_file: str, expected_hash: str | None = None) -> RankTable:
+    contents = fetch(tiktoken_bpe_file, expected_hash)
+    if tiktoken_bpe_file.endswith(".gz"):
+        contents = gzip.decompress(contents)
+    return parse_tiktoken_bpe(contents, tiktoken_bpe_file)
+
+
+def data_gym_byte_order() -> list[int]:
+    """Printable non-space bytes first, then the rest: the GPT-2 byte <-> rank convention."""
+    order = [b for b in range(256) if chr(b).isprintable() and chr(b) != " "]
+    return order + [b for b in range(256) if b not in order]
+
+
+def data_gym_to_mergeable_bpe_ranks(vocab_bpe_file: str, encoder_json_file: str, vocab_bpe_hash: str | None = None,
+                                    encoder_json_hash: str | None = None, clobber_one_byte_tokens: bool = False) -> dict[bytes, int]:
+    rank_to_byte = data_gym_byte_order()
+    n_printable = sum(1 for b in range(256) if chr(b).isprintable() and chr(b) != " ")
+    char_to_byte = {chr(b): b for b in rank_to_byte[:n_printable]}
+    for i, b in enumerate(rank_to_byte[n_printable:]):
+        char_to_byte[chr(256 + i)] = b
+
+    def to_bytes(s: str) -> bytes:
+        return bytes(char_to_byte[ch] for ch in s)
+
+    merges_text = fetch(vocab_bpe_file, vocab_bpe_hash).decode()
+    merges = [tuple(line.split()) for line in merges_text.split("\n")[1:-1]]
+    ranks = {bytes([b]): i for i, b in enumerate(rank_to_byte)}
+    for first, second in merges:
+        ranks[to_bytes(first) + to_bytes(second)] = len(ranks)
+    encoder = {to_bytes(k): v for k, v in json.loads(fetch(encoder_json_file, encoder_json_hash)).items()}
+    encoder.pop(b"<|endoftext|>", None)
+    encoder.pop(b"<|startoftext|>", None)
+    if clobber_one_byte_tokens:
+        for k, v in encoder.items():
+            if len(k) == 1:
+                ranks[k] = v
+    assert ranks == encoder  # merge order must equal token index order
+    return ranks

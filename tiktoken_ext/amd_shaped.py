@@ -7,7 +7,7 @@ import gzip
 import os
 
 import tiktoken_amd
-from tiktoken_amd.load import parse_tiktoken_bpe
+from tiktoken_amd.vocab_io import parse_tiktoken_bpe
 
 from . import openai_public as _pub
 

@@ -1,9 +1,9 @@
 """Stock OpenAI encodings (same names, patterns, special-token ids and pinned vocabulary files as the
 reference's tiktoken_ext/openai_public.py).  The vocabulary files are fetched -- or read from
-$TIKTOKEN_CACHE_DIR -- by tiktoken_amd.load exactly as the reference does; only the three distinct
+$TIKTOKEN_CACHE_DIR -- by tiktoken_amd.vocab_io exactly as the reference does; only the three distinct
 `pat_str`s below have compiled GPU scanners, which covers every stock encoding.
 """
-from tiktoken_amd.load import data_gym_to_mergeable_bpe_ranks, load_tiktoken_bpe
+from tiktoken_amd.vocab_io import data_gym_to_mergeable_bpe_ranks, load_tiktoken_bpe
 
 ENDOFTEXT = "<|endoftext|>"
 FIM_PREFIX = "<|fim_prefix|>"

@@ -7,7 +7,7 @@
       special per ~2 KiB plus decoys
 
 Each config is encoded from HBM-resident inputs (tk_encode_batch_device), timed over a few steps, and the
-first documents are compared token-for-token with the CPU oracle.  Prints one JSON object per config.
+whole result is compared token-for-token with the CPU oracle.  Prints one JSON object per config.
 """
 import json
 import os
@@ -45,47 +45,22 @@ def main():
             dt, nt, do = core.encode_batch_device(d_text.data_ptr(), n, d_off.data_ptr(), off, nd, allowed)
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / steps
-        # parity on the first <= 16 MiB of documents
+        # parity: every document, every token
         pat_id = {"gpt2_shaped": 0, "cl100k_shaped": 1, "o200k_shaped": 2, "o200k_custom8": 2}[enc_name]
         C = h.c_oracle.COracle(pat_id, spec["mergeable_ranks"], spec["special_tokens"])
-        nd_s = max(1, int(np.searchsorted(off, min(n, 16 << 20), side="right")) - 1)
+        nd_s = nd
         sb = int(off[nd_s])
         rt, ro = C.encode_batch(blob[:sb], off[: nd_s + 1], allowed, os.cpu_count() or 8)
         g_off = torch.as_tensor(DevArray(do, nd + 1, "<i8"), device="cuda")[: nd_s + 1].cpu().numpy().astype(np.uint64)
         g_tok = torch.as_tensor(DevArray(dt, max(nt, 1), "<i4"), device="cuda")[: int(g_off[-1])].cpu().numpy().view(np.uint32)
         ok = bool(np.array_equal(g_off, ro) and np.array_equal(g_tok, rt))
         print(json.dumps({"config": name, "encoding": enc_name, "bytes": n, "docs": nd, "tokens": nt, "ms_per_step": round(el * 1e3, 3),
-                          "GBps": round(n / el / 1e9, 3), "parity_first_16MiB": ok}), flush=True)
+                          "GBps": round(n / el / 1e9, 3), "parity_all_tokens": ok}), flush=True)
 
-    lorem = np.frombuffer(h.lorem(1 << 20), np.uint8)
-    run("C1 gpt2 1MiB lorem, 1 doc", "gpt2_shaped", lorem, np.array([0, len(lorem)], np.uint64), None, steps=10)
-    blob, off = h.gen_corpus(0x5EED0002, 0, 64 << 20, threads=16)
-    run("C2 cl100k 64MiB mixed UTF-8", "cl100k_shaped", blob, off, None)
-    # C5: insert specials / decoys into documents
-    blob, off = h.gen_corpus(0x5EED0005, 1, 256 << 20, threads=16)
-    bb = blob.tobytes()
-    rng = np.random.default_rng(5)
-    decoys = [b"<|custom_9|>", b"<|endoftext", b"<|custom_3|", b"<|", b"|>"]
-    parts, lens = [], []
-    for d in range(len(off) - 1):
-        t = bb[int(off[d]):int(off[d + 1])]
-        out, pos = [], 0
-        while pos < len(t):
-            step = int(rng.integers(512, 3584))
-            cut = min(len(t), pos + step)
-            while cut < len(t) and (t[cut] & 0xC0) == 0x80:
-                cut += 1
-            out.append(t[pos:cut])
-            if cut < len(t):
-                out.append(b"<|custom_%d|>" % rng.integers(0, 8) if rng.random() < 0.8 else decoys[int(rng.integers(0, len(decoys)))])
-            pos = cut
-        doc = b"".join(out)
-        parts.append(doc)
-        lens.append(len(doc))
-    blob5 = np.frombuffer(b"".join(parts), np.uint8)
-    off5 = np.zeros(len(lens) + 1, np.uint64)
-    off5[1:] = np.cumsum(lens)
-    run("C5 o200k+8 specials 256MiB, allowed_special=all", "o200k_custom8", blob5, off5, "all")
+    for cfg, title, enc_name, steps in (("C1", "C1 gpt2 1MiB lorem, 1 doc", "gpt2_shaped", 10), ("C2", "C2 cl100k 64MiB mixed UTF-8", "cl100k_shaped", 3),
+                                       ("C5", "C5 o200k+8 specials 256MiB, allowed_special=all", "o200k_custom8", 3)):
+        _, _, _, blob, off, allowed = h.baseline_config(cfg)
+        run(title, enc_name, blob, off, allowed, steps=steps)
 
 
 if __name__ == "__main__":

@@ -18,7 +18,8 @@
         for (int i = 0; i < ITER; ++i) {                                                            \
             asm volatile(ASM8 ASM8 ASM8 ASM8                                                        \
                          : "+v"(a0), "+v"(a1), "+v"(a2), "+v"(a3), "+v"(a4), "+v"(a5), "+v"(a6), "+v"(a7) \
-                         : "v"(b), "v"(c));                                                         \
+                         : "v"(b), "v"(c)                                                           \
+                         : "s10", "s11", "s12", "s13", "vcc", "scc");                                      \
         }                                                                                           \
         out[blockIdx.x * 256 + threadIdx.x] = a0 ^ a1 ^ a2 ^ a3 ^ a4 ^ a5 ^ a6 ^ a7;               \
     }
@@ -230,6 +231,7 @@ typedef void (*kern_t)(uint32_t*, uint32_t);
 struct Ent { const char* name; kern_t k; int instr_per_iter; };
 
 int main() {
+    setvbuf(stdout, NULL, _IONBF, 0);
     hipDeviceProp_t p;
     CHK(hipGetDeviceProperties(&p, 0));
     const int cus = p.multiProcessorCount;
