@@ -174,9 +174,9 @@ def sim_lib():
         d = os.path.join(ROOT, "tests", "hostsim")
         so = os.path.join(d, "libtk_hostsim.so")
         srcs = [os.path.join(d, "tk_hostsim.cpp")] + [os.path.join(ROOT, "tiktoken_amd", "csrc", f)
-                                                       for f in ("tk_tables.cpp", "tk_device.h", "tk_common.h", "tk_tables.h")]
+                                                       for f in ("tk_tables.cpp", "tk_device.h", "tk_common.h", "tk_tables.h", "tk_chunk.h")]
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", srcs[0], srcs[1], "-o", so])
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", srcs[0], srcs[1], "-o", so])
         L = ctypes.CDLL(so)
         vp, u64 = ctypes.c_void_p, ctypes.c_uint64
         L.tks_create.restype = vp
@@ -190,6 +190,8 @@ def sim_lib():
         L.tks_pretok_bits.argtypes = [vp, vp, u64, vp, u64, vp]
         L.tks_pretok_tiles.restype = u64
         L.tks_pretok_tiles.argtypes = [vp, vp, u64, vp, u64, vp, ctypes.c_uint32, ctypes.c_uint32]
+        L.tks_chunk_check.restype = u64
+        L.tks_chunk_check.argtypes = [vp, vp, u64, vp, u64, vp, vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
         L.tks_encode_piece.restype = ctypes.c_int64
         L.tks_encode_piece.argtypes = [vp, vp, ctypes.c_uint32, vp]
         _sim_lib = L
@@ -229,6 +231,16 @@ class HostSim:
         nw = sim_lib().tks_pretok_tiles(self._h, b.ctypes.data, n, doc_off.ctypes.data, len(doc_off) - 1, starts.ctypes.data, tile, left)
         idx = np.flatnonzero(starts[:n])
         return (np.concatenate([idx[1:], [n]]).astype(np.uint64) if n else np.zeros(0, np.uint64)), nw
+
+    def chunk_check(self, blob: np.ndarray, doc_off: np.ndarray, ss=None, si=None, tile: int = 3840, left: int = 64, win: int = 4096):
+        """Phases A-C of tk_k_front (16 bytes per lane, tk_chunk.h) against the per-byte reference: (mismatches, first position, code)."""
+        n = len(blob)
+        b = np.ascontiguousarray(blob) if n else np.zeros(1, np.uint8)
+        fb, what = ctypes.c_uint64(), ctypes.c_uint32()
+        bad = sim_lib().tks_chunk_check(self._h, b.ctypes.data, n, doc_off.ctypes.data, len(doc_off) - 1,
+                                        ss.ctypes.data if ss is not None else None, si.ctypes.data if si is not None else None,
+                                        tile, left, win, ctypes.byref(fb), ctypes.byref(what))
+        return bad, fb.value, what.value
 
     def encode_piece(self, piece: bytes) -> list[int]:
         out = np.empty(max(len(piece), 1), np.uint32)

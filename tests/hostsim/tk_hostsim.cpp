@@ -11,6 +11,7 @@
 #include <string>
 #include <vector>
 
+#include "../../tiktoken_amd/csrc/tk_chunk.h"
 #include "../../tiktoken_amd/csrc/tk_device.h"
 #include "../../tiktoken_amd/csrc/tk_tables.h"
 #include "../../tiktoken_amd/csrc/tk_unicode_tables.inc"
@@ -45,6 +46,9 @@ void* tks_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uin
     TkTables& D = s->T;
     D.uc_stage1 = tk_uc_stage1;
     D.uc_stage2 = tk_uc_stage2;
+    static uint32_t byte_tab[256 * 2];
+    tk_build_byte_table(tk_uc_stage1, tk_uc_stage2, byte_tab);
+    D.byte_tab = byte_tab;
     D.piece = H.piece.data();
     D.piece_off = H.piece_off.data();
     D.piece_mask = H.piece_mask;
@@ -328,6 +332,144 @@ uint64_t tks_pretok_tiles(void* pv, const uint8_t* text_in, uint64_t n, const ui
             }
     }
     return n_walkback;
+}
+
+
+// Mirror of phases A-C of tk_k_front: the text is classified 16 bytes per "lane" with the functions of tk_chunk.h (table pass,
+// decode pass, final masks, set algebra, certain starts) over every tile's 4096-byte window, and compared position by position
+// with the per-byte reference (tk_class_byte + propagation, tk_certain_start).  ss / si (may be null): special-token bitmaps.
+// Returns the number of mismatching positions; *first_bad gets the first one (text offset), *what a code (1 class, 2 cont,
+// 3 hard, 4 certain).
+uint64_t tks_chunk_check(void* pv, const uint8_t* text_in, uint64_t n, const uint64_t* doc_off, uint64_t n_docs, const uint32_t* ss,
+                         const uint32_t* si, uint32_t tile, uint32_t left, uint32_t win, uint64_t* first_bad, uint32_t* what) {
+    Sim* s = (Sim*)pv;
+    const TkTables& T = s->T;
+    std::vector<uint8_t> text(text_in, text_in + n);
+    text.resize(n + 64, 0xA5);  // (garbage after the end, as a device buffer may hold: the kernel must mask it)
+    std::vector<uint32_t> brk((n + 31) / 32 + 2, 0);
+    for (uint64_t d = 0; d < n_docs; ++d)
+        if (doc_off[d] < n) brk[doc_off[d] >> 5] |= 1u << (doc_off[d] & 31);
+    if (ss)
+        for (uint64_t i = 0; i < n; ++i)
+            if (tk_bit(ss, i)) {
+                brk[i >> 5] |= 1u << (i & 31);
+                uint64_t e = i + 1;
+                while (e < n && tk_bit(si, e)) ++e;
+                if (e < n) brk[e >> 5] |= 1u << (e & 31);
+            }
+    // reference: class byte per position (continuation bytes carry their char's class | 0x40; 0x80 = hard)
+    std::vector<uint8_t> ref(n + 80, TK_C_END | 0x80);
+    uint8_t last = TK_C_OT;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t c = tk_class_byte(T, text.data(), i, n, brk.data(), ss, si);
+        if ((c & 15u) == TK_C_CONT) ref[i] = (uint8_t)(last | 0x40);
+        else {
+            ref[i] = (uint8_t)c;
+            last = (uint8_t)(c & 15u);
+        }
+    }
+    const int pat = T.pattern;
+    auto certain_ref = [&](uint64_t i, bool prev_known) -> bool {
+        uint32_t c = ref[i];
+        if (c & 0x40u) return false;
+        if (c & 0x80u) return true;
+        if (i == 0 || !prev_known) return false;
+        return tk_certain_start(pat, ref[i - 1] & 15u, c & 15u);
+    };
+    uint64_t bad = 0;
+    auto report = [&](uint64_t pos, uint32_t code) {
+        if (!bad) {
+            *first_bad = pos;
+            *what = code;
+        }
+        ++bad;
+    };
+    const uint32_t nlanes = win / 16;
+    for (uint64_t t0 = 0; t0 < n || t0 == 0; t0 += tile) {
+        const int64_t base = (int64_t)t0 - left;
+        std::vector<uint8_t> raw(win + 16, 0);
+        std::vector<uint32_t> lastc(nlanes, 0);
+        std::vector<TkChunkMasks> masks(nlanes);
+        std::vector<TkSets> sets(nlanes);
+        std::vector<uint32_t> valids(nlanes, 0);
+        // pass 1: the window copy ("LDS")
+        for (uint32_t t = 0; t < nlanes; ++t) {
+            const int64_t gp = base + (int64_t)t * 16;
+            for (int j = 0; j < 16; ++j) {
+                const int64_t g = gp + j;
+                raw[t * 16 + j] = (g >= 0 && (uint64_t)g < n) ? text[g] : 0;
+            }
+        }
+        for (int j = 0; j < 16; ++j) {  // the 16 bytes behind the window, unmasked as in the kernel
+            const int64_t g = base + win + j;
+            raw[win + j] = (g >= 0 && (uint64_t)(base + win) < n && (uint64_t)g < n + 64) ? text[g] : 0;
+        }
+        for (uint32_t t = 0; t < nlanes; ++t) {
+            const int64_t gp = base + (int64_t)t * 16;
+            uint32_t w[4], valid = 0, past = 0;
+            memcpy(w, &raw[t * 16], 16);
+            for (int j = 0; j < 16; ++j) {
+                const int64_t g = gp + j;
+                if (g >= 0 && (uint64_t)g < n) valid |= 1u << j;
+                if (g >= 0 && (uint64_t)g >= n) past |= 1u << j;
+            }
+            TkChunk ch;
+            auto tab = [&](uint32_t b, uint32_t& x, uint32_t& y) {
+                x = T.byte_tab[2 * b];
+                y = T.byte_tab[2 * b + 1];
+            };
+            tk_chunk_table_pass(w, tab, ch);
+            auto get4 = [&](int k) -> uint32_t {
+                uint32_t v;
+                memcpy(&v, &raw[(int64_t)t * 16 + k], 4);
+                return v;
+            };
+            auto cls_of = [&](uint32_t cp) -> uint32_t { return tk_class_of_cp(T, cp > 0x10FFFFu ? 0xFFFFu : cp); };
+            uint32_t prev = 0;
+            if (t) memcpy(&prev, &raw[t * 16 - 4], 4);
+            tk_chunk_decode(ch, prev, t > 0, get4, cls_of);
+            uint32_t brk16 = 0, ss16 = 0, si16 = 0;
+            for (int j = 0; j < 16; ++j) {
+                const int64_t g = gp + j;
+                if (g < 0 || (uint64_t)g >= n) continue;
+                if (tk_bit(brk.data(), (uint64_t)g)) brk16 |= 1u << j;
+                if (ss && tk_bit(ss, (uint64_t)g)) ss16 |= 1u << j;
+                if (si && tk_bit(si, (uint64_t)g)) si16 |= 1u << j;
+            }
+            tk_chunk_finalize(ch, valid, past, brk16, ss16, si16, masks[t]);
+            tk_sets_from_planes(masks[t].p[0], masks[t].p[1], masks[t].p[2], masks[t].p[3], sets[t]);
+            lastc[t] = tk_class_from_planes(masks[t].p, 15);
+            valids[t] = valid;
+        }
+        for (uint32_t t = 0; t < nlanes; ++t) {
+            const int64_t gp = base + (int64_t)t * 16;
+            const TkChunkMasks& m = masks[t];
+            const uint32_t prevc = t ? lastc[t - 1] : 0u;
+            const uint32_t cert = tk_chunk_certain(pat, sets[t], m.text, m.hard & m.text, prevc);
+            // (the window may begin inside a char: its bytes there have no known class, and the first char start of the window no
+            // known predecessor -- the kernel treats both as "unknown, never certain")
+            int first = 0;
+            if (t == 0)
+                while (first < 16 && gp + first >= 0 && (uint64_t)(gp + first) < n && !((m.start >> first) & 1u)) ++first;
+            for (int j = 0; j < 16; ++j) {
+                const int64_t g = gp + j;
+                if (g < 0 || (t == 0 && j < first)) continue;
+                const uint32_t cls = tk_class_from_planes(m.p, (uint32_t)j);
+                const bool start = (m.start >> j) & 1u, hard = (m.hard >> j) & 1u;
+                if ((uint64_t)g >= n) {  // past the end: END, a char start, hard
+                    if (cls != TK_C_END || !start || !hard || ((cert >> j) & 1u)) report((uint64_t)g, 5);
+                    continue;
+                }
+                const uint32_t r = ref[g];
+                if (cls != (r & 15u)) report((uint64_t)g, 1);
+                else if (start != !(r & 0x40u)) report((uint64_t)g, 2);
+                else if (hard != (bool)(r & 0x80u)) report((uint64_t)g, 3);
+                else if ((bool)((cert >> j) & 1u) != certain_ref((uint64_t)g, !(t == 0 && j == first))) report((uint64_t)g, 4);
+            }
+        }
+        if (n == 0) break;
+    }
+    return bad;
 }
 
 // Mirror of the per-piece work (whole-piece probe, lane merge) for pieces of <= 16 bytes; longer pieces use the

@@ -177,3 +177,55 @@ def test_two_special_strings_may_share_an_id():
     h.HostSim(h.PAT_STR[2], ranks, specials)  # builds
     with pytest.raises(ValueError):  # (the same STRING twice cannot be expressed in a dict; two spellings that collide can)
         h.HostSim(h.PAT_STR[2], ranks, {"<|a|>": 1000, "": 1001})
+
+
+# ---------------------------------------------------------------- 16-bytes-per-lane classification (tk_chunk.h)
+def _spec_bitmaps(data: bytes, specials):
+    """(ss, si) bitmaps of the non-overlapping occurrences of the given special strings, leftmost first."""
+    n = len(data)
+    ss = np.zeros(n // 32 + 2, np.uint32)
+    si = np.zeros(n // 32 + 2, np.uint32)
+    pos = 0
+    while True:
+        hits = [(data.find(s.encode(), pos), s) for s in specials]
+        hits = [(i, s) for i, s in hits if i >= 0]
+        if not hits:
+            break
+        i, s = min(hits)
+        ss[i >> 5] |= np.uint32(1 << (i & 31))
+        for j in range(i + 1, i + len(s.encode())):
+            si[j >> 5] |= np.uint32(1 << (j & 31))
+        pos = i + len(s.encode())
+    return ss, si
+
+
+@pytest.mark.parametrize("name", h.ENCODING_NAMES)
+def test_chunk_classification_equals_per_byte_reference(name):
+    """Phases A-C of tk_k_front -- classes, char starts, hard starts and certain starts computed 16 bytes per lane from bit planes
+    (tk_chunk.h) -- against tk_class_byte / tk_certain_start position by position, on corpora, on adversarial strings, with
+    documents and the text ending at every offset of a chunk, with tiny windows (many window edges) and with special tokens."""
+    sim = h.HostSim(h.PAT_STR[h.PATTERN_OF[name]], h.load_vocab(name), h.SPECIALS[name])
+    for mix in (0, 1):
+        blob, off = h.gen_corpus(0xC0FFEE + mix, mix, 1 << 19)
+        assert sim.chunk_check(blob, off) == (0, 0, 0)
+        assert sim.chunk_check(blob, off, tile=160, left=32, win=256) == (0, 0, 0)
+        assert sim.chunk_check(blob, off, tile=64, left=16, win=128) == (0, 0, 0)
+    rng = np.random.default_rng(7)
+    docs = ["".join(rng.choice(h.ADV, size=int(rng.integers(0, 40)))).encode() for _ in range(3000)]
+    blob, off = h.pack(docs)
+    assert sim.chunk_check(blob, off) == (0, 0, 0)
+    assert sim.chunk_check(blob, off, tile=64, left=16, win=128) == (0, 0, 0)
+    for cut in range(1, 40):  # the text ends at every position of a chunk; 4-byte chars at every alignment
+        data = ("😀é中a" * 12).encode()[:cut]
+        try:
+            data.decode()
+        except UnicodeDecodeError:
+            continue
+        blob, off = h.pack([data])
+        assert sim.chunk_check(blob, off) == (0, 0, 0), cut
+    # special tokens: first / interior bytes come from the marking kernels as bitmaps
+    text = ("hello <|endoftext|> wörld<|endoftext|><|endoftext|>\n 中<|endoftext|>" * 40).encode()
+    ss, si = _spec_bitmaps(text, ["<|endoftext|>"])
+    blob, off = h.pack([text])
+    assert sim.chunk_check(blob, off, ss, si) == (0, 0, 0)
+    assert sim.chunk_check(blob, off, ss, si, tile=64, left=16, win=128) == (0, 0, 0)

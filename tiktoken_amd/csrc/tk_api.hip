@@ -63,7 +63,7 @@ struct tk_core {
     uint32_t* h_counters = nullptr;  // pinned
     TkHostTables H;
     TkTables D;  // device view
-    Buf t_stage1, t_stage2, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_spec_bytes, t_spec_off, t_spec_id;
+    Buf t_stage1, t_stage2, t_byte_tab, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_spec_bytes, t_spec_off, t_spec_id;
     uint32_t spec_max_len = 0;
     std::mutex mu;
     // workspace
@@ -173,6 +173,11 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     int rc;
     if ((rc = upload(c->t_stage1, tk_uc_stage1, sizeof tk_uc_stage1))) return bail(rc);
     if ((rc = upload(c->t_stage2, tk_uc_stage2, sizeof tk_uc_stage2))) return bail(rc);
+    {
+        uint32_t bt[256 * 2];
+        tk_build_byte_table(tk_uc_stage1, tk_uc_stage2, bt);
+        if ((rc = upload(c->t_byte_tab, bt, sizeof bt))) return bail(rc);
+    }
     if ((rc = upload(c->t_piece, H.piece.data(), H.piece.size() * sizeof(TkPieceSlot)))) return bail(rc);
     if ((rc = upload(c->t_piece_off, H.piece_off.data(), H.piece_off.size() * 4))) return bail(rc);
     if ((rc = upload(c->t_tok_bytes, H.tok_bytes.data(), H.tok_bytes.size()))) return bail(rc);
@@ -186,6 +191,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     TkTables& D = c->D;
     D.uc_stage1 = c->t_stage1.as<uint8_t>();
     D.uc_stage2 = c->t_stage2.as<uint8_t>();
+    D.byte_tab = c->t_byte_tab.as<uint32_t>();
     D.piece = c->t_piece.as<TkPieceSlot>();
     D.piece_off = c->t_piece_off.as<uint32_t>();
     D.piece_mask = H.piece_mask;
@@ -214,7 +220,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
 extern "C" void tk_destroy(tk_core* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_piece, &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2,
+    for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_piece, &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2,
                    &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off, &c->brk, &c->docb,
                    &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->tok1, &c->cnt, &c->staging, &c->listB,
                    &c->listC, &c->counters, &c->total, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv, &c->out_tokens,

@@ -1,0 +1,206 @@
+// Classification of the text 16 bytes per lane (host-compilable; the front kernel in tk_fused.h is the product caller,
+// tests/hostsim drives the same functions on the CPU).
+//
+// The regex classes of reference src/lib.rs:365 (\p{L} \p{N} \p{M} \s ... of the stock patterns) are a 4-bit class per
+// character (tk_common.h).  Instead of one byte per lane + one ballot per class set, every lane keeps its OWN 16 text bytes
+// and builds 16-bit masks (bit j = byte j of the chunk) directly in registers:
+//
+//   1. table pass     one LDS table lookup per byte (256 entries x {class planes, flag planes}) and two shift-or
+//                     accumulations: ASCII bytes are classified, lead / continuation bytes are flagged;
+//   2. decode pass    per lead byte of the chunk (and for the char that straddles in from the left): code point ->
+//                     two-stage Unicode class table -> the class is OR-ed into the planes of all bytes of the char;
+//   3. set algebra    class-set masks (letters, white space, ...) and the certain-start mask are boolean functions of the
+//                     four planes, evaluated on 16-bit masks with full-rate VALU instructions.
+//
+// The measured motivation is in profiles/r02_front_phases_before.csv: the one-byte-per-lane form cost 158 vector
+// instructions per 64 text bytes for these steps; this form needs about 25.
+#pragma once
+#include "tk_common.h"
+
+// ---- byte table -----------------------------------------------------------------------------------------------------
+// entry[b] = {planes, flags}
+//   planes: bit 8p = bit p of the class nibble (ASCII bytes; 0 for bytes >= 0x80)
+//   flags : bit 0 continuation byte (0x80..0xBF), bit 8 / 16 / 24 lead byte of a 2 / 3 / 4-byte char
+inline void tk_build_byte_table(const uint8_t* stage1, const uint8_t* stage2, uint32_t* out /* [256 * 2] */) {
+    for (uint32_t b = 0; b < 256; ++b) {
+        uint32_t planes = 0, flags = 0;
+        if (b < 0x80u) {
+            const uint32_t c = stage2[(uint32_t)stage1[0] * 256u + b];
+            for (uint32_t p = 0; p < 4; ++p) planes |= ((c >> p) & 1u) << (8u * p);
+        } else if (b < 0xC0u) {
+            flags = 1u;
+        } else if (b < 0xE0u) {
+            flags = 1u << 8;
+        } else if (b < 0xF0u) {
+            flags = 1u << 16;
+        } else {
+            flags = 1u << 24;
+        }
+        out[2 * b] = planes;
+        out[2 * b + 1] = flags;
+    }
+}
+
+struct TkChunk {
+    uint32_t acc0, acc1;  // class planes of positions 0..7 / 8..15: byte p of the word = plane p, bit j = position
+    uint32_t f0, f1;      // flag planes, same layout: plane 0 continuation, planes 1..3 lead byte of a 2/3/4-byte char
+};
+
+// plane p (16 bits) out of the two accumulators
+TK_HD uint32_t tk_plane16(uint32_t a0, uint32_t a1, uint32_t p) { return ((a0 >> (8u * p)) & 0xFFu) | (((a1 >> (8u * p)) & 0xFFu) << 8); }
+
+// 1. table pass.  tab(b, x, y) -> entry of byte b
+template <class Tab>
+TK_HD void tk_chunk_table_pass(const uint32_t w[4], Tab& tab, TkChunk& c) {
+    c.acc0 = c.acc1 = c.f0 = c.f1 = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+#pragma unroll
+#endif
+    for (int k = 0; k < 16; ++k) {
+        const uint32_t b = (w[k >> 2] >> (8 * (k & 3))) & 0xFFu;
+        uint32_t x, y;
+        tab(b, x, y);
+        if (k < 8) {
+            c.acc0 |= x << k;
+            c.f0 |= y << k;
+        } else {
+            c.acc1 |= x << (k - 8);
+            c.f1 |= y << (k - 8);
+        }
+    }
+}
+
+// code point of the UTF-8 sequence whose bytes are `four` (little-endian: lead byte in bits 0..7); valid UTF-8 assumed
+TK_HD uint32_t tk_utf8_cp(uint32_t four, uint32_t* len_out) {
+    const uint32_t b0 = four & 0xFFu;
+    const uint32_t len = 2u + (uint32_t)(b0 >= 0xE0u) + (uint32_t)(b0 >= 0xF0u);
+    const uint32_t x = ((b0 & 0x3Fu) << 18) | (((four >> 8) & 0x3Fu) << 12) | (((four >> 16) & 0x3Fu) << 6) | ((four >> 24) & 0x3Fu);
+    const uint32_t mask = len == 2u ? 0x7FFu : (len == 3u ? 0xFFFFu : 0x1FFFFFu);
+    *len_out = len;
+    return (x >> (6u * (4u - len))) & mask;
+}
+
+// class c OR-ed into the planes of positions [k, k + len) that fall inside the chunk (k may be negative)
+TK_HD void tk_chunk_apply(TkChunk& c, int k, uint32_t len, uint32_t cls) {
+    const uint32_t ones = (1u << len) - 1u;
+    const uint32_t m = (k >= 0 ? ones << k : ones >> (uint32_t)(-k)) & 0xFFFFu;
+    const uint32_t pl = ((cls * 0x00204081u) & 0x01010101u) * 0xFFu;  // byte p = 0xFF iff bit p of the class
+    c.acc0 |= pl & ((m & 0xFFu) * 0x01010101u);
+    c.acc1 |= pl & ((m >> 8) * 0x01010101u);
+}
+
+// 2. decode pass.  get4(k) -> the four text bytes at chunk-relative offset k (-3 <= k <= 15), cls_of(cp) -> class nibble.
+// prev: the four bytes before the chunk (byte 3 of `prev` = position -1) locate the lead of a char that straddles in from the
+// previous chunk (has_prev: those bytes exist).
+template <class Get4, class ClsOf>
+TK_HD void tk_chunk_decode(TkChunk& c, uint32_t prev, bool has_prev, Get4& get4, ClsOf& cls_of) {
+    const uint32_t cont = tk_plane16(c.f0, c.f1, 0);
+    uint32_t leads = tk_plane16(c.f0, c.f1, 1) | tk_plane16(c.f0, c.f1, 2) | tk_plane16(c.f0, c.f1, 3);
+    if ((cont & 1u) && has_prev) {
+        const int k = (prev >> 24) >= 0xC0u ? -1 : (((prev >> 16) & 0xFFu) >= 0xC0u ? -2 : -3);
+        uint32_t len;
+        const uint32_t cp = tk_utf8_cp(get4(k), &len);
+        tk_chunk_apply(c, k, len, cls_of(cp));
+    }
+    while (leads) {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const int k = __ffs((int)leads) - 1;
+#else
+        const int k = __builtin_ctz(leads);
+#endif
+        leads &= leads - 1;
+        uint32_t len;
+        const uint32_t cp = tk_utf8_cp(get4(k), &len);
+        tk_chunk_apply(c, k, len, cls_of(cp));
+    }
+}
+
+// Final masks of a chunk.  valid / past: positions inside the text / at or after its end; brk: break bitmap bits (document
+// starts, special-token edges); ss / si: first / interior bytes of allowed special-token occurrences (0 without specials).
+struct TkChunkMasks {
+    uint32_t p[4];               // class planes (continuation bytes carry their char's class)
+    uint32_t start, hard, text;  // char starts; hard starts (look-ahead sees end-of-text there); char starts of real text
+};
+TK_HD void tk_chunk_finalize(const TkChunk& c, uint32_t valid, uint32_t past, uint32_t brk, uint32_t ss, uint32_t si, TkChunkMasks& m) {
+    const uint32_t inv = ~valid & 0xFFFFu;
+    uint32_t cont = tk_plane16(c.f0, c.f1, 0) & valid;
+    // positions outside the text are class END (1100b); special-token bytes are class SPEC (1101b), their interior is "continuation"
+    const uint32_t sm = (ss | si) & valid;
+    m.p[0] = (tk_plane16(c.acc0, c.acc1, 0) & valid) | sm;
+    m.p[1] = tk_plane16(c.acc0, c.acc1, 1) & valid & ~sm;
+    m.p[2] = tk_plane16(c.acc0, c.acc1, 2) | inv | sm;
+    m.p[3] = tk_plane16(c.acc0, c.acc1, 3) | inv | sm;
+    cont = (cont & ~ss) | (si & valid);
+    m.start = ~cont & 0xFFFFu;
+    m.text = m.start & valid;
+    m.hard = (brk & m.text) | (past & 0xFFFFu) | (ss & ~si & valid);
+}
+
+// class nibble of position j from the four planes
+TK_HD uint32_t tk_class_from_planes(const uint32_t p[4], uint32_t j) {
+    return ((p[0] >> j) & 1u) | (((p[1] >> j) & 1u) << 1) | (((p[2] >> j) & 1u) << 2) | (((p[3] >> j) & 1u) << 3);
+}
+
+// 3. set algebra on 16-bit masks.  P[p] = plane p; classes are tk_common.h's TK_C_* codes.
+struct TkSets {
+    uint32_t ws, nl, sp, wso, l, lu, ll, lc, mk, nu, ap, sl, ot, oth, word, up, low, cas, nlsl, end, spec;
+};
+TK_HD void tk_sets_from_planes(uint32_t p0, uint32_t p1, uint32_t p2, uint32_t p3, TkSets& s) {
+    const uint32_t m = 0xFFFFu;
+    const uint32_t n0 = ~p0 & m, n1 = ~p1 & m, n2 = ~p2 & m, n3 = ~p3 & m;
+    const uint32_t q00 = n3 & n2, q01 = n3 & p2, q10 = p3 & n2, q11 = p3 & p2;  // class >> 2
+    const uint32_t r00 = n1 & n0, r01 = n1 & p0, r10 = p1 & n0, r11 = p1 & p0;  // class & 3
+    s.nl = q00 & r01;
+    s.sp = q00 & r10;
+    s.wso = q00 & r11;
+    s.ws = q00 & ~r00;
+    s.lu = q01 & r00;
+    s.ll = q01 & r01;
+    s.lc = q01 & r10;
+    s.mk = q01 & r11;
+    s.l = q01 & ~r11;
+    s.word = q01;                 // L | MK
+    s.up = q01 & ~r01;            // LU LC MK
+    s.low = q01 & ~r00;           // LL LC MK
+    s.cas = q01 & p1;             // LC MK
+    s.nu = q10 & r00;
+    s.ap = q10 & r01;
+    s.sl = q10 & r10;
+    s.ot = q10 & r11;
+    s.oth = s.mk | (q10 & ~r00);  // MK AP SL OT
+    s.nlsl = s.nl | s.sl;
+    s.end = q11 & r00;
+    s.spec = q11 & r01;
+}
+
+// `set` of the PREVIOUS byte: shifted by one position, bit 0 taken from the class of the byte before the chunk
+TK_HD uint32_t tk_prev_set(uint32_t set, uint32_t class_mask, uint32_t prevc) { return ((set << 1) & 0xFFFFu) | ((class_mask >> prevc) & 1u); }
+
+// Certain piece starts of the chunk: char starts where a boundary is certain whatever the left context (tk_device.h
+// tk_certain_mask restated on masks).  prevc = class nibble of the byte before the chunk (0 when unknown: never certain).
+TK_HD uint32_t tk_chunk_certain(int pat, const TkSets& s, uint32_t start, uint32_t hard, uint32_t prevc) {
+    const uint32_t L3 = TK_M_L, O4 = TK_M_OTHER, NU = TK_CB(TK_C_NU);
+    uint32_t cert = hard;
+    if (pat == TK_PAT_R50K) {
+        cert |= tk_prev_set(s.nl | s.wso, TK_CB(TK_C_NL) | TK_CB(TK_C_WSO), prevc) & (s.l | s.oth | s.nu);
+        cert |= tk_prev_set(s.l, L3, prevc) & (s.ws | s.oth | s.nu);
+        cert |= tk_prev_set(s.mk | s.sl | s.ot, TK_CB(TK_C_MK) | TK_CB(TK_C_SL) | TK_CB(TK_C_OT), prevc) & (s.ws | s.l | s.nu);
+        cert |= tk_prev_set(s.ap, TK_CB(TK_C_AP), prevc) & (s.ws | s.lu | s.lc | s.nu);
+        cert |= tk_prev_set(s.nu, NU, prevc) & (s.ws | s.l | s.oth);
+    } else if (pat == TK_PAT_CL100K) {
+        cert |= tk_prev_set(s.nl, TK_CB(TK_C_NL), prevc) & (s.l | s.oth | s.nu);
+        cert |= tk_prev_set(s.sp, TK_CB(TK_C_SP), prevc) & s.nu;
+        cert |= tk_prev_set(s.wso, TK_CB(TK_C_WSO), prevc) & (s.oth | s.nu);
+        cert |= tk_prev_set(s.l, L3, prevc) & (s.ws | s.oth | s.nu);
+        cert |= tk_prev_set(s.oth, O4, prevc) & (s.sp | s.wso | s.nu);
+        cert |= tk_prev_set(s.nu, NU, prevc) & (s.ws | s.l | s.oth);
+    } else {
+        cert |= tk_prev_set(s.nl, TK_CB(TK_C_NL), prevc) & (s.l | s.mk | s.nu | s.ap | s.ot);
+        cert |= tk_prev_set(s.sp, TK_CB(TK_C_SP), prevc) & s.nu;
+        cert |= tk_prev_set(s.wso, TK_CB(TK_C_WSO), prevc) & (s.nu | s.ap | s.sl | s.ot);
+        cert |= tk_prev_set(s.l, L3, prevc) & (s.ws | s.nu | s.sl | s.ot);
+        cert |= tk_prev_set(s.oth, O4, prevc) & (s.sp | s.wso | s.nu);
+        cert |= tk_prev_set(s.nu, NU, prevc) & (s.ws | s.l | s.oth);
+    }
+    return cert & start;  // (pass the char starts of REAL text: positions past the end are hard but never pieces)
+}

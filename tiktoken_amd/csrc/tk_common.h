@@ -75,6 +75,7 @@ struct TkPairSlot {  // 16 bytes
 struct TkTables {
     const uint8_t* uc_stage1;   // [0x1100]
     const uint8_t* uc_stage2;   // [nblocks*256]
+    const uint32_t* byte_tab;   // [256 * 2] per-byte {class planes, flag planes} of the 16-bytes-per-lane classifier (tk_chunk.h)
     const TkPieceSlot* piece;   // [piece_mask+1]
     const uint32_t* piece_off;  // [piece_mask+1] offset of the slot's key bytes in tok_bytes
     uint64_t piece_mask;

@@ -28,6 +28,7 @@
 // with integer flags instead of short-circuit control flow; and same-address returning atomics run at only
 // 25..130 M/s on this multi-XCD part, so nothing on the path allocates through a global counter.
 #pragma once
+#include "tk_chunk.h"
 #include "tk_kernels.h"
 
 #define TKF_NONE 0xFFFFFFFFu
@@ -136,7 +137,6 @@ struct TkWinLds32 {  // 32 positions from window offset r (the bitmaps seen as 3
     }
 };
 
-#define TKF_CLW (TK2_CLIST / 4)  // certain-start list entries per wave
 // exact compare of the piece at LDS offset o with text[pos .. pos+len) in HBM
 __device__ __forceinline__ bool tk_equal_lds_text(const uint8_t* raw, uint32_t o, const uint8_t* text, uint64_t pos, uint32_t len) {
     uint32_t i = 0;
@@ -156,17 +156,20 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
                                                   const uint64_t* __restrict__ doc_off, uint64_t n_docs, TkFrontOut out,
                                                   TkMissSlot* __restrict__ mt, uint32_t mt_mask, int dbg) {
     constexpr int pat = PAT;
-    constexpr int BM_BYTES = TKB_KINDS * (TK2_NSEG + 2) * 8;
+    constexpr int NW = TK2_NSEG + 2;            // 64-bit words per bitmap (two sentinel words beyond the window)
+    constexpr int BM_BYTES = TKB_KINDS * NW * 8;
     __shared__ __attribute__((aligned(16))) uint8_t raw[TK2_WIN + 16];
-    __shared__ uint8_t cls2[TK2_WIN];
     __shared__ __attribute__((aligned(16))) uint8_t pool[BM_BYTES + TK2_CLIST * 2];  // bitmaps + certain list; later the piece list
+    __shared__ __attribute__((aligned(8))) uint64_t planes[4][NW];                   // class planes (bit = text byte)
+    __shared__ __attribute__((aligned(8))) uint32_t btab[256 * 2];                   // byte table (tk_chunk.h)
+    __shared__ uint32_t certw[TK2_WIN / 32];                                         // certain starts (hard starts included)
     __shared__ uint32_t bits[TK_TILE / 32];
     __shared__ uint32_t woff[TK_TILE / 32 + 1];
-    __shared__ uint32_t cnw[8], np_sh, nmiss_sh, need_walk, last_end_sh;
-    __shared__ uint32_t certm[16];
+    __shared__ uint8_t lastc[256];
+    __shared__ uint32_t ncl_sh[2], np_sh, nmiss_sh, need_walk, last_end_sh;
     __shared__ uint32_t brkw[TK2_WIN / 32 + 1], ssw[TK2_WIN / 32 + 1], siw[TK2_WIN / 32 + 1], docw[TK2_WIN / 32 + 1];
     __shared__ uint32_t scan_sh[8];
-    uint64_t(*bm)[TK2_NSEG + 2] = (uint64_t(*)[TK2_NSEG + 2])pool;
+    uint64_t(*bm)[NW] = (uint64_t(*)[NW])pool;
     uint16_t* clist = (uint16_t*)(pool + BM_BYTES);
     uint16_t* plist = (uint16_t*)pool;  // valid after the scanners are done
     const uint32_t tid = threadIdx.x;
@@ -175,13 +178,34 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
     const uint64_t tile_start = tile * TK_TILE;
     const uint64_t tile_end = tile_start + TK_TILE < n ? tile_start + TK_TILE : n;
     const int64_t base = (int64_t)tile_start - TK2_LEFT;
-    // ---- A: window -> LDS
-    for (uint32_t v = tid; v < (TK2_WIN + 16) / 16; v += 256) {
-        int64_t gp = base + (int64_t)v * 16;
-        uint4 x = make_uint4(0, 0, 0, 0);
-        if (gp >= 0 && (uint64_t)gp < n) x = *(const uint4*)(text + gp);  // text is readable 64 bytes past n
-        *(uint4*)(raw + v * 16) = x;
+    // ---- A: every lane owns 16 bytes of the window (kept in registers and copied to LDS)
+    const int64_t gp = base + (int64_t)tid * 16;
+    uint32_t w[4] = {0, 0, 0, 0};
+    uint32_t valid = 0, past = 0;  // 16-bit masks: byte is text / byte lies at or after the end of the text
+    if (gp + 16 > 0 && (uint64_t)(gp < 0 ? 0 : gp) < n) {
+        const uint4 x = *(const uint4*)(text + gp);  // (a window never starts before -64: gp >= 0 here except on tile 0, where gp + 16 > 0 => gp >= 0)
+        w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w;
+        const uint64_t left = n - (uint64_t)gp;       // text bytes from gp on
+        valid = left >= 16 ? 0xFFFFu : ((1u << (uint32_t)left) - 1u);
+        if (left < 16) {                              // the text ends inside the chunk: bytes after it read as zero
+            const uint32_t nb = (uint32_t)left;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int lo = 4 * d;
+                const uint32_t keep = nb >= (uint32_t)lo + 4u ? 0xFFFFFFFFu : (nb <= (uint32_t)lo ? 0u : ((1u << (8u * (nb - lo))) - 1u));
+                w[d] &= keep;
+            }
+        }
     }
+    if (gp >= 0) past = ~valid & 0xFFFFu;  // (positions before the text, tile 0 only, are neither text nor "past")
+    *(uint4*)(raw + tid * 16) = make_uint4(w[0], w[1], w[2], w[3]);
+    if (tid == 0) {  // 16 more bytes behind the window: a char that starts in its last bytes is decoded whole
+        const int64_t ge = base + TK2_WIN;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if ((uint64_t)ge < n) x = *(const uint4*)(text + ge);  // (bytes past n only follow a complete char: never decoded)
+        *(uint4*)(raw + TK2_WIN) = x;
+    }
+    *(uint2*)&btab[tid * 2] = *(const uint2*)&T.byte_tab[tid * 2];
     if (tid < TK2_WIN / 32) {  // break / special bitmaps of the window (the window base is 32-aligned)
         int64_t wgp = base + (int64_t)tid * 32;
         bool in = wgp >= 0 && (uint64_t)wgp < n;
@@ -190,189 +214,148 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
         ssw[tid] = (SPEC && in) ? ss[wgp >> 5] : 0u;
         siw[tid] = (SPEC && in) ? si[wgp >> 5] : 0u;
     }
-    if (tid < 16) certm[tid] = tk_certain_mask(PAT, tid);
     if (tid == 0) {
         nmiss_sh = 0;
         need_walk = 0;
+        ncl_sh[0] = ncl_sh[1] = 0;
         last_end_sh = (uint32_t)(tile_end - tile_start) + TK2_LEFT;
     }
     if (tid < TKB_KINDS) {
         bm[tid][TK2_NSEG] = tid <= TKB_HARD ? ~0ull : 0ull;  // beyond the window: unknown -> "stop"
         bm[tid][TK2_NSEG + 1] = tid <= TKB_HARD ? ~0ull : 0ull;
     }
+    if (tid < 4) planes[tid][TK2_NSEG] = planes[tid][TK2_NSEG + 1] = tid >= 2 ? ~0ull : 0ull;  // (class END)
     __syncthreads();
     if (dbg & 0x1000) {  // (perf experiments: stop after this phase)
         if (tid == 0) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
         return;
     }
-    // ---- B1: class of every byte (branch-free): every lane finds the lead byte of ITS char (0..3 bytes back),
-    // decodes the code point from the LDS copy of the text and issues the two table loads -- so continuation
-    // bytes get their char's class without any cross-lane step.  The loads of all 17 segments of the wave are in
-    // flight together.  (An all-ASCII fast path was tried: 97.6 % of the bench corpus' segments hold a non-ASCII byte.)
-    constexpr int NS = TK2_NSEG / 4;  // 17 segments per wave, contiguous
-    uint32_t creg[NS];
-    auto class_at = [&](uint32_t pl) -> uint32_t {
+    // ---- B: classes of the lane's 16 bytes as 16-bit masks (tk_chunk.h): table pass, decode pass for non-ASCII chars
+    TkChunk ch;
+    {
+        auto tab = [&](uint32_t b, uint32_t& x, uint32_t& y) {
+            const uint2 e = *(const uint2*)&btab[b * 2];
+            x = e.x;
+            y = e.y;
+        };
+        tk_chunk_table_pass(w, tab, ch);
         const uint32_t* dw = (const uint32_t*)raw;
-        const uint32_t wi = pl >> 2, sft = pl & 3u;
-        const uint32_t d0 = dw[wi ? wi - 1 : 0], d1 = dw[wi], d2 = dw[wi + 1];
-        const uint32_t fwd = __builtin_amdgcn_alignbyte(d2, d1, sft);
-        const uint32_t back = sft == 3u ? d1 : __builtin_amdgcn_alignbyte(d1, d0, sft + 1u);
-        const uint32_t b = fwd & 0xFFu;
-        uint32_t k = 0;
-        if ((b & 0xC0u) == 0x80u) k = ((back >> 16) & 0xC0u) != 0x80u ? 1u : (((back >> 8) & 0xC0u) != 0x80u ? 2u : 3u);
-        const uint64_t seven = ((uint64_t)fwd << 24) | (uint64_t)(back & 0xFFFFFFu);
-        const uint32_t ch = (uint32_t)(seven >> (8u * (3u - k)));
-        const uint32_t l = ch & 0xFFu, c1b = (ch >> 8) & 0x3Fu, c2b = (ch >> 16) & 0x3Fu, c3b = (ch >> 24) & 0x3Fu;
-        uint32_t cp = l;
-        if (l >= 0xF0u) cp = ((l & 7u) << 18) | (c1b << 12) | (c2b << 6) | c3b;
-        else if (l >= 0xE0u) cp = ((l & 15u) << 12) | (c1b << 6) | c2b;
-        else if (l >= 0xC0u) cp = ((l & 31u) << 6) | c1b;
-        if (cp > 0x10FFFFu) cp = 0xFFFFu;
-        return T.uc_stage2[(uint32_t)T.uc_stage1[cp >> 8] * 256u + (cp & 255u)];
-    };
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        creg[i] = class_at((uint32_t)(wid * NS + i) * 64u + lane);
+        auto get4 = [&](int k) -> uint32_t {  // four window bytes at chunk-relative offset k (tid > 0 whenever k < 0)
+            const uint32_t o = tid * 16u + (uint32_t)k;
+            return __builtin_amdgcn_alignbyte(dw[(o >> 2) + 1], dw[o >> 2], o & 3u);
+        };
+        auto cls_of = [&](uint32_t cp) -> uint32_t {
+            if (cp > 0x10FFFFu) cp = 0xFFFFu;
+            return T.uc_stage2[(uint32_t)T.uc_stage1[cp >> 8] * 256u + (cp & 255u)];
+        };
+        const uint32_t prev = tid ? dw[tid * 4u - 1u] : 0u;
+        tk_chunk_decode(ch, prev, tid > 0, get4, cls_of);
     }
-    if (dbg & 0x2000) {  // (perf experiments: stop after the classification; the loads are waited for)
-        uint32_t x = 0;
-#pragma unroll
-        for (int i = 0; i < NS; ++i) x ^= creg[i];
-        if (tid == 0 || x == 0xFFFFFFFFu) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
+    if (dbg & 0x2000) {  // (perf experiments: stop after the classification)
+        if (tid == 0 || (ch.acc0 ^ ch.acc1) == 0xFFFFFFF1u) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
         return;
     }
-    // ---- B2: flags, class bytes, bitmaps, certain starts (previous class = lane - 1, carried across segments).
-    // Each wave keeps its own list of certain starts (no LDS atomics): starts that will scan a word from the front
-    // of its array, the rest from the back, so that the scanners of a wavefront mostly follow the same branch.
-    uint32_t carry = TK_C_END;
-    if (wid > 0) {
-        const uint32_t pl = (uint32_t)(wid * NS) * 64u - 1u;
-        carry = class_at(pl);
-        const int64_t gpp = base + pl;
-        if (gpp < 0 || (uint64_t)gpp >= n) carry = TK_C_END;
-        else if (SPEC && (((ssw[pl >> 5] >> (pl & 31u)) & 1u) || ((siw[pl >> 5] >> (pl & 31u)) & 1u))) carry = TK_C_SPEC;
+    // ---- C: masks of the chunk -> bitmaps in LDS; certain starts; the list of scan starts
+    TkChunkMasks mk;
+    {
+        const uint32_t sh16 = (tid & 1u) * 16u;
+        const uint32_t brk16 = (brkw[tid >> 1] >> sh16) & 0xFFFFu;
+        const uint32_t ss16 = SPEC ? (ssw[tid >> 1] >> sh16) & 0xFFFFu : 0u, si16 = SPEC ? (siw[tid >> 1] >> sh16) & 0xFFFFu : 0u;
+        tk_chunk_finalize(ch, valid, past, brk16, ss16, si16, mk);
     }
-    uint32_t spill_mask = 0, extra_back = 0;
-    uint32_t cw_front = 0, cw_back = 0;  // wave-uniform
-    uint64_t left_certw = 0;             // wave 0: certain starts inside the left context segment
-    uint16_t* clw = clist + wid * TKF_CLW;
-    // window positions [lo_valid, hi_valid) are text; flags below are 0/1 integers (no short-circuit control flow)
-    const uint32_t lo_valid = base < 0 ? (uint32_t)(-base) : 0u;
-    const uint32_t hi_valid = (int64_t)n - base < (int64_t)TK2_WIN ? (uint32_t)((int64_t)n - base) : (uint32_t)TK2_WIN;
-#pragma unroll
-    for (int i = 0; i < NS; ++i) {
-        const int g = wid * NS + i;
-        const uint32_t pl = (uint32_t)g * 64u + lane;
-        const uint32_t past = pl >= hi_valid, valid = (uint32_t)(pl >= lo_valid) & (past ^ 1u);
-        const uint32_t b = raw[pl];
-        uint32_t cont = valid & (uint32_t)((b & 0xC0u) == 0x80u);
-        uint32_t c = valid ? creg[i] : (uint32_t)TK_C_END;
-        uint32_t hard = past;  // positions after the end of the text stop every look-ahead
-        if constexpr (SPEC) {
-            const uint32_t spec_s = valid & (ssw[pl >> 5] >> (pl & 31u)) & 1u, spec_i = valid & (siw[pl >> 5] >> (pl & 31u)) & 1u;
-            if (spec_i | spec_s) c = TK_C_SPEC;
-            cont = spec_i | (cont & (spec_s ^ 1u));
-            hard |= spec_s & (spec_i ^ 1u);
-        }
-        hard |= valid & (cont ^ 1u) & (brkw[pl >> 5] >> (pl & 31u)) & 1u;
-        cls2[pl] = (uint8_t)(c | (cont << 6) | (hard << 7));
+    TkSets st;
+    tk_sets_from_planes(mk.p[0], mk.p[1], mk.p[2], mk.p[3], st);
+    {
         constexpr bool O2 = PAT == TK_PAT_O200K, R5 = PAT == TK_PAT_R50K;
-        const uint64_t w_start = __ballot(cont == 0u), w_hard = __ballot(hard != 0u);
-        uint32_t prevc = __shfl_up(c, 1, 64);
-        if (lane == 0) prevc = carry;
-        carry = __shfl(c, 63, 64);
-        const bool in_tile = g >= 1 && g <= TK_TILE / 64;
-        // (lane 0 of the context segment has no known predecessor: never certain unless hard)
-        const uint32_t has_prev = g > 0 ? 1u : (uint32_t)(lane > 0);
-        const uint32_t cert = valid & (cont ^ 1u) & (hard | (has_prev & (certm[prevc] >> c))) & 1u;
-        const uint64_t certw = __ballot(cert != 0u);
-        if (g == 0) left_certw = certw;
-        if (in_tile && certw) {
-            // kind of scan this start will run (a guess from the class of the next byte: only the grouping depends on it)
-            const uint32_t nc = __shfl_down(c, 1, 64);
-            constexpr uint32_t PREFIX_OK = ~(TK_CB(TK_C_NL) | TK_CB(TK_C_NU));
-            const uint32_t wordish = ((TK_M_WORD >> c) | ((PREFIX_OK >> c) & (TK_M_WORD >> nc) & (uint32_t)(lane < 63))) & 1u;
-            const uint64_t mw = __ballot((cert & wordish) != 0u), mr = certw & ~mw;
-            const uint32_t nw = (uint32_t)__popcll(mw), nr = (uint32_t)__popcll(mr);
-            if (cw_front + cw_back + nw + nr <= TKF_CLW) {
-                const uint64_t below = (1ull << lane) - 1ull;
-                const uint32_t at_w = cw_front + (uint32_t)__popcll(mw & below), at_r = TKF_CLW - 1u - cw_back - (uint32_t)__popcll(mr & below);
-                if (cert) clw[wordish ? at_w : at_r] = (uint16_t)pl;
-                cw_front += nw;
-                cw_back += nr;
-            } else if (cert) {
-                spill_mask |= 1u << i;  // list full: these lanes scan from their own positions
-            }
-        }
-        const uint64_t w_oth = __ballot((TK_M_OTHER >> c) & 1u), w_ws = __ballot((TK_M_WS >> c) & 1u), w_nu = __ballot(c == TK_C_NU);
-        uint64_t w_L = 0, w_up = 0, w_low = 0, w_cas = 0, w_nl = 0, w_nlsl = 0;
-        if constexpr (!O2) w_L = __ballot((TK_M_L >> c) & 1u);
+        uint16_t* b16 = (uint16_t*)pool;  // halfword tid of bitmap `kind` = positions [16 tid, 16 tid + 16)
+        constexpr int HW = NW * 4;         // halfwords per bitmap
+        b16[TKB_START * HW + tid] = (uint16_t)mk.start;
+        b16[TKB_HARD * HW + tid] = (uint16_t)mk.hard;
+        b16[TKB_OTH * HW + tid] = (uint16_t)st.oth;
+        b16[TKB_WS * HW + tid] = (uint16_t)st.ws;
+        b16[TKB_NU * HW + tid] = (uint16_t)st.nu;
+        if constexpr (!O2) b16[TKB_L * HW + tid] = (uint16_t)st.l;
         if constexpr (O2) {
-            w_up = __ballot((TK_M_UPPERISH >> c) & 1u);
-            w_low = __ballot((TK_M_LOWERISH >> c) & 1u);
-            w_cas = __ballot(c == TK_C_LC || c == TK_C_MK);
-            w_nlsl = __ballot(c == TK_C_NL || c == TK_C_SL);
+            b16[TKB_UP * HW + tid] = (uint16_t)st.up;
+            b16[TKB_LOW * HW + tid] = (uint16_t)st.low;
+            b16[TKB_CAS * HW + tid] = (uint16_t)st.cas;
+            b16[TKB_NLSL * HW + tid] = (uint16_t)st.nlsl;
         }
-        if constexpr (!R5) w_nl = __ballot(c == TK_C_NL);
-        if (lane == 0) {
-            if (in_tile) {
-                bits[(g - 1) * 2] = (uint32_t)certw;
-                bits[(g - 1) * 2 + 1] = (uint32_t)(certw >> 32);
-            }
-            if (g == 1 && tile_start > 0) {
-                // is the first char of the tile a certain start?  If not, the piece that crosses in from the left
-                // must be re-scanned from ITS start: the last certain start in the left context, or further back
-                const bool first_cert = w_start && ((certw >> (__ffsll((unsigned long long)w_start) - 1)) & 1ull);
-                if (!first_cert) {
-                    if (left_certw && cw_front + cw_back < TKF_CLW) {
-                        clw[TKF_CLW - 1u - cw_back] = (uint16_t)(63 - __clzll((long long)left_certw));
-                        extra_back = 1;
-                    } else {
-                        need_walk = 1;
-                    }
-                }
-            }
-            bm[TKB_START][g] = w_start;
-            bm[TKB_HARD][g] = w_hard;
-            bm[TKB_OTH][g] = w_oth;
-            bm[TKB_WS][g] = w_ws;
-            bm[TKB_NU][g] = w_nu;
-            if constexpr (!O2) bm[TKB_L][g] = w_L;
-            if constexpr (O2) {
-                bm[TKB_UP][g] = w_up;
-                bm[TKB_LOW][g] = w_low;
-                bm[TKB_CAS][g] = w_cas;
-                bm[TKB_NLSL][g] = w_nlsl;
-            }
-            if constexpr (!R5) bm[TKB_NL][g] = w_nl;
-        }
-        if (g == 1) cw_back += __shfl(extra_back, 0, 64);  // (the entry lane 0 may have added above)
+        if constexpr (!R5) b16[TKB_NL * HW + tid] = (uint16_t)st.nl;
+        uint16_t* p16 = (uint16_t*)planes;
+#pragma unroll
+        for (int p = 0; p < 4; ++p) p16[p * HW + tid] = (uint16_t)mk.p[p];
+        lastc[tid] = (uint8_t)tk_class_from_planes(mk.p, 15);
     }
-    if (lane == 0) {
-        cnw[wid] = cw_front;
-        cnw[4 + wid] = cw_back;
+    __syncthreads();
+    // the class before the chunk: never known for the first chunk of the window (nothing there is certain unless hard)
+    const uint32_t prevc = tid ? (uint32_t)lastc[tid - 1] : 0u;
+    const uint32_t cert = tk_chunk_certain(PAT, st, mk.text, mk.hard & mk.text, prevc);
+    ((uint16_t*)certw)[tid] = (uint16_t)cert;
+    constexpr uint32_t T0 = TK2_LEFT / 16, T1 = (TK2_LEFT + TK_TILE) / 16;  // chunks [T0, T1) are the tile
+    const bool in_tile = tid >= T0 && tid < T1;
+    if (in_tile) ((uint16_t*)bits)[tid - T0] = (uint16_t)cert;
+    // scan starts of this lane: its certain starts inside the tile; plus, for the first chunk of the tile, the start of the piece
+    // that crosses in from the left when the first char of the tile is not certain itself: the last certain start of the left
+    // context, else a walk back through HBM
+    uint32_t mine = in_tile ? cert : 0u;
+    uint32_t extra = TKF_NONE;
+    if (wid == 0) {
+        uint64_t leftc = 0;  // certain starts of the 64-byte left context (lanes 0..3)
+#pragma unroll
+        for (int q = 0; q < (int)T0; ++q) leftc |= (uint64_t)(uint32_t)__shfl((int)cert, q, 64) << (16 * q);
+        if (tid == T0 && tile_start > 0 && tile_start < n) {
+            const bool first_cert = mk.text && ((cert >> (__ffs((int)mk.text) - 1)) & 1u);
+            if (!first_cert) {
+                if (leftc) extra = 63u - (uint32_t)__clzll((long long)leftc);
+                else need_walk = 1;
+            }
+        }
+    }
+    // kind of scan a start will run (a guess from the class of the next byte: only the grouping depends on it), so that the
+    // scanners of a wavefront mostly follow the same branch: word-like starts fill the list from the front, the rest from the back
+    constexpr uint32_t PREFIX_OK = ~(TK_CB(TK_C_NL) | TK_CB(TK_C_NU));
+    const uint32_t prefix_ok = (st.sp | st.wso | st.ap | st.sl | st.ot | st.mk | st.l) & 0xFFFFu;  // classes of PREFIX_OK that occur in text
+    (void)PREFIX_OK;
+    const uint32_t wordish = mine & (st.word | (prefix_ok & (st.word >> 1)));
+    const uint32_t nw = (uint32_t)__popc(wordish), nr = (uint32_t)__popc(mine & ~wordish) + (extra != TKF_NONE ? 1u : 0u);
+    uint32_t tot2;
+    const uint32_t ex2 = tk_block_exscan_256(nw | (nr << 16), &tot2, scan_sh);
+    const uint32_t n_front = tot2 & 0xFFFFu, n_back = tot2 >> 16;
+    const bool listed = n_front + n_back <= TK2_CLIST;
+    if (listed) {
+        uint32_t at_w = ex2 & 0xFFFFu, at_r = TK2_CLIST - 1u - (ex2 >> 16);
+        if (extra != TKF_NONE) clist[at_r--] = (uint16_t)extra;
+        for (uint32_t m = mine; m; m &= m - 1) {
+            const uint32_t j = (uint32_t)__ffs((int)m) - 1u;
+            const uint16_t pos = (uint16_t)(tid * 16u + j);
+            if ((wordish >> j) & 1u) clist[at_w++] = pos;
+            else clist[at_r--] = pos;
+        }
     }
     __syncthreads();
     if (dbg & 0x4000) {  // (perf experiments: stop after this phase)
         if (tid == 0) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
         return;
     }
-    // ---- D: one lane per certain start; only boundaries inside the tile are recorded
-    TkWin2Acc acc{cls2, raw, base, &T, text, n, brk, ss, si};
+    // ---- D: one lane per scan start; only boundaries inside the tile are recorded
+    const uint32_t* planes32 = (const uint32_t*)planes;
+    TkWin2Acc acc{planes32, (const uint32_t*)bm[TKB_START], (const uint32_t*)bm[TKB_HARD], raw, base, &T, text, n, brk, ss, si};
     auto scan_from = [&](uint64_t p) {
         for (;;) {
             const int64_t r = (int64_t)p - base;
             uint32_t len = 0;
             if (r >= 0 && r + 64 <= TK2_WIN) {
                 const uint32_t wi = (uint32_t)r >> 6, sh = (uint32_t)r & 63u;
+                const uint32_t c = tk_class_at_lds(planes32, (uint32_t)r);
                 {  // most pieces are short: 32-position windows first (a third of the vector-ALU work of the 64-bit form)
-                    const TkWinLds32 w32((const uint32_t(*)[2 * (TK2_NSEG + 2)])bm, (uint32_t)r);
-                    len = tk_piece_len_bits32(w32, acc, p, cls2[r] & 15u, pat);
+                    const TkWinLds32 w32((const uint32_t(*)[2 * NW])bm, (uint32_t)r);
+                    len = tk_piece_len_bits32(w32, acc, p, c, pat);
                 }
                 if (len == 0) {
-                const TkWinLds w(bm, wi, sh);
-                TkBmExt ext{bm, wi, sh, (uint32_t)(TK2_WIN - r)};
-                len = tk_piece_len_bits(w, acc, ext, p, cls2[r] & 15u, pat);
+                    const TkWinLds wl(bm, wi, sh);
+                    TkBmExt ext{bm, wi, sh, (uint32_t)(TK2_WIN - r)};
+                    len = tk_piece_len_bits(wl, acc, ext, p, c, pat);
                 }
             }
             uint64_t e = len ? p + len : tk_piece_end_slow(&acc, p, pat);
@@ -385,46 +368,21 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
                 break;
             }
             if (e >= tile_start) {
-                const int64_t re = (int64_t)e - base;  // inside the window (e < tile_end)
-                const uint32_t ce = cls2[re];
-                if (ce & 0x80u) break;
-                if ((certm[cls2[re - 1] & 15u] >> (ce & 15u)) & 1u) break;
+                const uint32_t re = (uint32_t)((int64_t)e - base);  // inside the window (e < tile_end)
+                if ((certw[re >> 5] >> (re & 31u)) & 1u) break;    // a certain start: another lane scans from there
                 atomicOr(&bits[(uint32_t)(e - tile_start) >> 5], 1u << ((uint32_t)(e - tile_start) & 31));
             }
             p = e;
         }
     };
-    {
-        // work items: the four word lists, then the four other lists, then spilled lanes, then the walk-back start
-        uint32_t pre[9];
-        pre[0] = 0;
-#pragma unroll
-        for (int q = 0; q < 8; ++q) pre[q + 1] = pre[q] + cnw[q];
-        uint32_t i = tid;
-        bool walk = tid == 0 && need_walk;
-        for (;;) {
-            uint64_t p;
-            if (i < pre[8]) {
-                uint32_t q = 0;
-#pragma unroll
-                for (int t = 1; t < 8; ++t) q += i >= pre[t];
-                const uint32_t off = i - pre[q];
-                const uint16_t* lw = clist + (q & 3u) * TKF_CLW;
-                p = (uint64_t)(base + (q < 4u ? lw[off] : lw[TKF_CLW - 1u - off]));
-                i += 256;
-            } else if (spill_mask) {
-                const int k = __ffs((int)spill_mask) - 1;
-                spill_mask &= spill_mask - 1;
-                p = (uint64_t)(base + (int64_t)((uint32_t)(wid * NS + k) * 64u + lane));
-            } else if (walk) {
-                walk = false;
-                p = tk_certain_before(&T, text, n, brk, ss, si, tile_start - 1, pat);
-            } else {
-                break;
-            }
-            scan_from(p);
-        }
+    if (listed) {
+        for (uint32_t i = tid; i < n_front + n_back; i += 256)
+            scan_from((uint64_t)(base + (i < n_front ? clist[i] : clist[TK2_CLIST - 1u - (i - n_front)])));
+    } else {  // more starts than the list holds (a start every other byte): every lane walks its own
+        if (extra != TKF_NONE) scan_from((uint64_t)(base + extra));
+        for (uint32_t m = mine; m; m &= m - 1) scan_from((uint64_t)(base + (int64_t)(tid * 16u + (uint32_t)__ffs((int)m) - 1u)));
     }
+    if (tid == 0 && need_walk) scan_from(tk_certain_before(&T, text, n, brk, ss, si, tile_start - 1, pat));
     __syncthreads();
     if (dbg & 0x8000) {  // (perf experiments: stop after this phase)
         if (tid == 0) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
@@ -469,7 +427,6 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
             const uint32_t e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
             len = e_loc - s_loc;
             gs = (uint64_t)(base + s_loc);
-            const uint32_t cb = cls2[s_loc];
             // documents that start at this piece
             if ((docw[s_loc >> 5] >> (s_loc & 31u)) & 1u) {
                 const uint64_t want = gs + chunk_base;
@@ -481,7 +438,7 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
                 }
                 for (; lo < n_docs && doc_off[lo] == want; ++lo) out.doc_pid[lo] = pid;
             }
-            if ((cb & 15u) == TK_C_SPEC) {
+            if (SPEC && ((ssw[s_loc >> 5] >> (s_loc & 31u)) & 1u)) {
                 out.tok1[pid] = tk_special_id(T, text, gs, len);
                 out.cnt[pid] = 1;
             } else {

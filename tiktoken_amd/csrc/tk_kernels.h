@@ -11,7 +11,7 @@
 
 #include "tk_device.h"
 
-#define TK_TILE 4096
+#define TK_TILE 3840  // text bytes per tile: with 64 bytes of left context and 192 of look-ahead the LDS window is 4096 = 256 lanes x 16
 
 // Deferred pieces are binned by length so that the 64 lanes of a wave run similar trip counts.
 #define TK_NBIN 9
@@ -223,13 +223,13 @@ __device__ __forceinline__ uint32_t tk_special_id(const TkTables& T, const uint8
 
 // ------------------------------------------------------------------------------------------
 // pre-tokenisation: tile geometry and the scanner's accessors (the kernel is tk_k_front in tk_fused.h)
-// A tile is 4096 bytes; its LDS window adds 64 bytes of left context and 192 of look-ahead.
+// A tile is 3840 bytes; its LDS window adds 64 bytes of left context and 192 of look-ahead: 4096 bytes = 16 per lane.
 // ------------------------------------------------------------------------------------------
 #define TK2_LEFT 64
 #define TK2_RIGHT 192
-#define TK2_WIN (TK2_LEFT + TK_TILE + TK2_RIGHT)  // 4352
-#define TK2_NSEG (TK2_WIN / 64)                   // 68
-#define TK2_CLIST 1536
+#define TK2_WIN (TK2_LEFT + TK_TILE + TK2_RIGHT)  // 4096
+#define TK2_NSEG (TK2_WIN / 64)                   // 64
+#define TK2_CLIST 2048                            // certain-start list entries per tile (more: every lane scans from its own starts)
 
 // Out-of-line slow paths: they are rare, and inlining them at every call site of the scanner made the
 // kernel ~30k instructions (instruction-cache thrash).
@@ -238,8 +238,18 @@ __device__ __noinline__ uint32_t tk_class_byte_slow(const TkTables* T, const uin
     return tk_class_byte(*T, text, pos, n, brk, ss, si);
 }
 
-struct TkWin2Acc {  // byte-walking fallback: propagated classes inside the window, HBM outside
-    const uint8_t* cls2;
+// class nibble of window position r from the four plane bitmaps in LDS (32-bit view: plane p starts at word p * PLW)
+#define TK2_PLW (2 * (TK2_NSEG + 2))
+__device__ __forceinline__ uint32_t tk_class_at_lds(const uint32_t* planes32, uint32_t r) {
+    const uint32_t wi = r >> 5, b = r & 31u;
+    return ((planes32[wi] >> b) & 1u) | (((planes32[TK2_PLW + wi] >> b) & 1u) << 1) | (((planes32[2 * TK2_PLW + wi] >> b) & 1u) << 2) |
+           (((planes32[3 * TK2_PLW + wi] >> b) & 1u) << 3);
+}
+
+struct TkWin2Acc {  // byte-walking fallback: the window's bitmaps inside the window, HBM outside
+    const uint32_t* planes32;  // [4][TK2_PLW]
+    const uint32_t* start32;   // char-start bitmap
+    const uint32_t* hard32;    // hard-start bitmap
     const uint8_t* raw;
     int64_t base;
     const TkTables* T;
@@ -250,8 +260,9 @@ struct TkWin2Acc {  // byte-walking fallback: propagated classes inside the wind
         if (pos >= n) return TK_C_END;
         int64_t r = (int64_t)pos - base;
         if (r >= 0 && r < TK2_WIN) {
-            uint32_t c = cls2[r];
-            return (c & 0x40u) ? (uint32_t)TK_C_CONT : (c & 0x8Fu);
+            const uint32_t wi = (uint32_t)r >> 5, b = (uint32_t)r & 31u;
+            if (!((start32[wi] >> b) & 1u)) return (uint32_t)TK_C_CONT;
+            return tk_class_at_lds(planes32, (uint32_t)r) | (((hard32[wi] >> b) & 1u) << 7);
         }
         return tk_class_byte_slow(T, text, pos, n, brk, ss, si);
     }
@@ -278,14 +289,6 @@ __device__ __forceinline__ uint64_t tk_piece_end_slow(TkWin2Acc* acc, uint64_t p
     if (e <= p) e = tk_next_char(*acc, p);
     return e;
 }
-// class byte of e (flags included) and class of the char before e, for positions outside the LDS window
-__device__ __forceinline__ uint32_t tk_boundary_classes_slow(const TkWin2Acc* acc, uint64_t e) {
-    uint32_t ce = acc->cls(e);
-    uint64_t j = e - 1;
-    while (acc->cls(j) == TK_C_CONT) --j;
-    return (ce & 0xFFu) | ((acc->cls(j) & 15u) << 8);
-}
-
 // ------------------------------------------------------------------------------------------
 // bitmap -> piece offsets
 // ------------------------------------------------------------------------------------------
