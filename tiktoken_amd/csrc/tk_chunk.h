@@ -1,5 +1,5 @@
-// Classification of the text 16 bytes per lane (host-compilable; the front kernel in tk_fused.h is the product caller,
-// tests/hostsim drives the same functions on the CPU).
+// Classification of the text 16 bytes per lane (host-compilable, like tk_device.h: the front kernel in tk_fused.h is the only
+// product caller; the CPU-side unit tests drive the same functions sequentially).
 //
 // The regex classes of reference src/lib.rs:365 (\p{L} \p{N} \p{M} \s ... of the stock patterns) are a 4-bit class per
 // character (tk_common.h).  Instead of one byte per lane + one ballot per class set, every lane keeps its OWN 16 text bytes
