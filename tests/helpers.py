@@ -190,6 +190,9 @@ def sim_lib():
         L.tks_pretok_bits.argtypes = [vp, vp, u64, vp, u64, vp]
         L.tks_pretok_tiles.restype = u64
         L.tks_pretok_tiles.argtypes = [vp, vp, u64, vp, u64, vp, ctypes.c_uint32, ctypes.c_uint32]
+        L.tks_table_stats.argtypes = [vp, vp, vp]
+        L.tks_lookup.restype = ctypes.c_uint32
+        L.tks_lookup.argtypes = [vp, vp, ctypes.c_uint32]
         L.tks_chunk_check.restype = u64
         L.tks_chunk_check.argtypes = [vp, vp, u64, vp, u64, vp, vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
         L.tks_encode_piece.restype = ctypes.c_int64
@@ -210,6 +213,15 @@ class HostSim:
 
     def n_pairs(self):
         return sim_lib().tks_n_pairs(self._h)
+
+    def table_stats(self):
+        probes, slots = (ctypes.c_double * 3)(), (ctypes.c_uint64 * 3)()
+        sim_lib().tks_table_stats(self._h, probes, slots)
+        return list(probes), list(slots)
+
+    def lookup(self, piece: bytes) -> int:
+        b = np.frombuffer(piece, np.uint8) if piece else np.zeros(1, np.uint8)
+        return sim_lib().tks_lookup(self._h, b.ctypes.data, len(piece))
 
     def piece_ends(self, blob: np.ndarray, doc_off: np.ndarray, bits: bool = False):
         """Piece end offsets from the simulated pre-tokeniser; bits=True mirrors the bit-parallel kernel

@@ -49,6 +49,12 @@ void* tks_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uin
     static uint32_t byte_tab[256 * 2];
     tk_build_byte_table(tk_uc_stage1, tk_uc_stage2, byte_tab);
     D.byte_tab = byte_tab;
+    D.short_tab = H.short_tab.empty() ? nullptr : H.short_tab.data();
+    D.short_mask = H.short_mask;
+    D.short_shift = H.short_shift;
+    D.mid_tab = H.mid_tab.data();
+    D.mid_mask = H.mid_mask;
+    D.mid_shift = H.mid_shift;
     D.piece = H.piece.data();
     D.piece_off = H.piece_off.data();
     D.piece_mask = H.piece_mask;
@@ -68,6 +74,19 @@ void* tks_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uin
 }
 void tks_destroy(void* p) { delete (Sim*)p; }
 uint64_t tks_n_pairs(void* p) { return ((Sim*)p)->H.n_pairs; }
+// table build statistics: average slots inspected per stored token {short, mid, long}, table sizes in slots
+void tks_table_stats(void* p, double* probes, uint64_t* slots) {
+    const TkHostTables& H = ((Sim*)p)->H;
+    probes[0] = H.probes_short; probes[1] = H.probes_mid; probes[2] = H.probes_long;
+    slots[0] = H.short_tab.size(); slots[1] = H.mid_tab.size(); slots[2] = H.piece.size();
+}
+// whole-piece lookup through the device probe functions (TK_RANK_MAX = absent)
+uint32_t tks_lookup(void* p, const uint8_t* piece, uint32_t len) {
+    Sim* s = (Sim*)p;
+    std::vector<uint8_t> text(piece, piece + len);
+    text.resize(len + 64, 0);
+    return tk_lookup_text_piece(s->T, text.data(), 0, len);
+}
 
 // Mirror of the byte-walking scanner (the fallback of tk_k_front): class bytes, certain starts, scanner from each certain start.
 // doc_off marks hard starts.  Writes a byte per position: 1 = piece start.  Returns the number of

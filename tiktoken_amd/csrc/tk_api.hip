@@ -63,12 +63,12 @@ struct tk_core {
     uint32_t* h_counters = nullptr;  // pinned
     TkHostTables H;
     TkTables D;  // device view
-    Buf t_stage1, t_stage2, t_byte_tab, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_spec_bytes, t_spec_off, t_spec_id;
+    Buf t_stage1, t_stage2, t_byte_tab, t_short, t_mid, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_spec_bytes, t_spec_off, t_spec_id;
     uint32_t spec_max_len = 0;
     std::mutex mu;
     // workspace
-    Buf text, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, tok1, cnt, staging, listB, listC, counters, total, g_id, g_rk, g_nx,
-        g_pv, g_lv, out_tokens, out_tok_off, allowed, tile_np, tile_nt, tile_nmiss, doc_pid, mt_slots, wbin, wave_pieces;
+    Buf text, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, res, rflag, staging, listB, listC, counters, total, g_id, g_rk, g_nx,
+        g_pv, g_lv, out_tokens, out_tok_off, allowed, tile_np, tile_nt, tile_nmiss, mt_slots, wbin, wave_pieces;
     uint64_t chunk_bytes = 1ull << 30;
     int dbg = 0;
     std::vector<uint8_t> sorted_blob;  // token_byte_values(), packed (built on first use)
@@ -178,6 +178,8 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
         tk_build_byte_table(tk_uc_stage1, tk_uc_stage2, bt);
         if ((rc = upload(c->t_byte_tab, bt, sizeof bt))) return bail(rc);
     }
+    if ((rc = upload(c->t_short, H.short_tab.data(), H.short_tab.size() * sizeof(TkShortSlot)))) return bail(rc);
+    if ((rc = upload(c->t_mid, H.mid_tab.data(), H.mid_tab.size() * sizeof(TkPieceSlot)))) return bail(rc);
     if ((rc = upload(c->t_piece, H.piece.data(), H.piece.size() * sizeof(TkPieceSlot)))) return bail(rc);
     if ((rc = upload(c->t_piece_off, H.piece_off.data(), H.piece_off.size() * 4))) return bail(rc);
     if ((rc = upload(c->t_tok_bytes, H.tok_bytes.data(), H.tok_bytes.size()))) return bail(rc);
@@ -192,6 +194,12 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     D.uc_stage1 = c->t_stage1.as<uint8_t>();
     D.uc_stage2 = c->t_stage2.as<uint8_t>();
     D.byte_tab = c->t_byte_tab.as<uint32_t>();
+    D.short_tab = H.short_tab.empty() ? nullptr : c->t_short.as<TkShortSlot>();
+    D.short_mask = H.short_mask;
+    D.short_shift = H.short_shift;
+    D.mid_tab = c->t_mid.as<TkPieceSlot>();
+    D.mid_mask = H.mid_mask;
+    D.mid_shift = H.mid_shift;
     D.piece = c->t_piece.as<TkPieceSlot>();
     D.piece_off = c->t_piece_off.as<uint32_t>();
     D.piece_mask = H.piece_mask;
@@ -220,11 +228,11 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
 extern "C" void tk_destroy(tk_core* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_piece, &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2,
+    for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_piece, &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2,
                    &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off, &c->brk, &c->docb,
-                   &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->tok1, &c->cnt, &c->staging, &c->listB,
+                   &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->res, &c->rflag, &c->staging, &c->listB,
                    &c->listC, &c->counters, &c->total, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv, &c->out_tokens,
-                   &c->out_tok_off, &c->allowed, &c->tile_np, &c->tile_nt, &c->tile_nmiss, &c->doc_pid, &c->mt_slots, &c->wbin,
+                   &c->out_tok_off, &c->allowed, &c->tile_np, &c->tile_nt, &c->tile_nmiss, &c->mt_slots, &c->wbin,
                    &c->wave_pieces})
         release(*b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -284,13 +292,12 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
     TRY(ensure(c->tile_np, (ntiles + 2) * 4));
     TRY(ensure(c->tile_nt, (ntiles + 2) * 4));
     TRY(ensure(c->tile_nmiss, (ntiles + 2) * 4));
-    TRY(ensure(c->doc_pid, (n_docs + 2) * 4));
     TRY(ensure(c->wbin, (TK_NBIN * TKD_WAVES + 2) * 4));
     TRY(ensure(c->wave_pieces, 16384 * 4));
     const uint64_t pid_cap = tk_pid_cap(n);
-    TRY(ensure(c->tok1, pid_cap * 4));
-    TRY(ensure(c->cnt, pid_cap * 4));
-    TRY(ensure(c->staging, pid_cap * 4));
+    TRY(ensure(c->res, pid_cap * 4));
+    TRY(ensure(c->rflag, (ntiles + 1) * TKF_MISS_CAP * 8));
+    TRY(ensure(c->staging, (n + 64) * 4));
     if (pretok_only) {
         TRY(ensure(c->out_tokens, pid_cap * 4));
         d_out = c->out_tokens.as<uint32_t>();
@@ -306,16 +313,16 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
     HIPCHK(hipMemsetAsync(c->brk.p, 0, (nwords + 2) * 4, s));
     HIPCHK(hipMemsetAsync(c->counters.p, 0, TK_CNT_N * 4, s));
     HIPCHK(hipMemsetAsync(c->total.p, 0, 16, s));
-    HIPCHK(hipMemsetAsync(c->doc_pid.p, 0xFF, (n_docs + 2) * 4, s));
     uint32_t *brk = c->brk.as<uint32_t>(), *starts = c->starts.as<uint32_t>();
     uint32_t *ss = nullptr, *si = nullptr, *docb = nullptr;
     uint32_t* counters = c->counters.as<uint32_t>();
-    uint32_t *tok1 = c->tok1.as<uint32_t>(), *cnt = c->cnt.as<uint32_t>(), *stg = c->staging.as<uint32_t>();
+    uint32_t *res = c->res.as<uint32_t>(), *stg = c->staging.as<uint32_t>();
+    uint2* rflag = c->rflag.as<uint2>();
     uint32_t *tile_np = c->tile_np.as<uint32_t>(), *tile_nt = c->tile_nt.as<uint32_t>();
-    // The per-tile miss lists (TKF_MISS_CAP entries per tile: start, index | length) live in memory that is not needed
-    // until the back kernel writes it: the two halves of the output region.
-    TkFrontOut fo{starts, tile_np, tok1, cnt, c->tile_nmiss.as<uint32_t>(), d_out, d_out ? d_out + ntiles * TKF_MISS_CAP : nullptr,
-                  c->listC.as<uint32_t>(), counters, c->doc_pid.as<uint32_t>()};
+    // The per-tile miss lists (TKF_MISS_CAP entries of 8 bytes per tile) live in memory that is not needed until the back
+    // kernel writes it: the output region (8-byte aligned inside it).
+    uint2* miss = d_out ? (uint2*)(((uintptr_t)d_out + 7) & ~(uintptr_t)7) : nullptr;
+    TkFrontOut fo{starts, tile_np, res, c->tile_nmiss.as<uint32_t>(), miss, c->listC.as<uint32_t>(), counters};
     TkMissSlot* mt = nullptr;
     uint32_t mt_bits = 14;
     uint64_t nB = 0, nC = 0;
@@ -352,7 +359,7 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         }
         TRY(timed(c, s, "tk_k_front", [&] {
             const dim3 grid((uint32_t)ntiles);
-            launch_front(T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, d_doc_off, n_docs, fo,
+            launch_front(T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, fo,
                          (c->dbg & 256) ? (TkMissSlot*)nullptr : mt, (1u << mt_bits) - 1u, c->dbg);
         }));
     } else if (n > 0) {
@@ -390,14 +397,13 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         const uint32_t tpg = ntiles > 16384 ? TKD_GROUP : 1;
         const uint32_t dd_blocks = grid_for(ntiles, 4 * tpg, TKD_WAVES / 4), tf_blocks = grid_for(ntiles, 4, 4096);
         TRY(timed(c, s, "tk_k_bincount", [&] {
-            hipLaunchKernelGGL(tk_k_bincount, dim3(dd_blocks), dim3(256), 0, s, ntiles, fo.tile_nmiss, fo.miss_kl, wbin, tpg);
+            hipLaunchKernelGGL(tk_k_bincount, dim3(dd_blocks), dim3(256), 0, s, ntiles, fo.tile_nmiss, miss, wbin, tpg);
         }));
         TRY(timed(c, s, "tk_k_scan_small", [&] {
             hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, wbin, (uint64_t)TK_NBIN * dd_blocks * 4 + 1, c->total.as<uint64_t>());
         }));
         TRY(timed(c, s, "tk_k_binfill", [&] {
-            hipLaunchKernelGGL(tk_k_binfill, dim3(dd_blocks), dim3(256), 0, s, ntiles, fo.tile_nmiss, fo.miss_s, fo.miss_kl, wbin, c->listB.as<uint32_t>(), bins,
-                               counters, tpg);
+            hipLaunchKernelGGL(tk_k_binfill, dim3(dd_blocks), dim3(256), 0, s, ntiles, fo.tile_nmiss, miss, wbin, c->listB.as<uint32_t>(), bins, counters, tpg);
         }));
         {
             // The bins are independent: spread them over the side streams, longest-tailed kernels first.  List lengths are
@@ -423,15 +429,15 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
                 hipStream_t sa = c->aux[slot++ & 3];
                 TRY(timed(c, sa, names[b], [&] {
                     switch (b) {
-                        case 0: hipLaunchKernelGGL((tk_k_merge_llane<16, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
-                        case 1: hipLaunchKernelGGL((tk_k_merge_llane<24, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
-                        case 2: hipLaunchKernelGGL((tk_k_merge_llane<32, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
-                        case 3: hipLaunchKernelGGL((tk_k_merge_llane<48, 128>), dim3(grid_for(most, 128, 8192)), dim3(128), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
-                        case 4: hipLaunchKernelGGL((tk_k_merge_llane<64, 128>), dim3(grid_for(most, 128, 8192)), dim3(128), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
-                        case 5: hipLaunchKernelGGL((tk_k_merge_group<8>), dim3(grid_for(most, 32, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
-                        case 6: hipLaunchKernelGGL((tk_k_merge_group<16>), dim3(grid_for(most, 16, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
-                        case 7: hipLaunchKernelGGL((tk_k_merge_group<32>), dim3(grid_for(most, 8, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
-                        default: hipLaunchKernelGGL((tk_k_merge_group<64>), dim3(grid_for(most, 4, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, tok1, cnt, stg); break;
+                        case 0: hipLaunchKernelGGL((tk_k_merge_llane<16, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, miss, stg); break;
+                        case 1: hipLaunchKernelGGL((tk_k_merge_llane<24, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, miss, stg); break;
+                        case 2: hipLaunchKernelGGL((tk_k_merge_llane<32, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, miss, stg); break;
+                        case 3: hipLaunchKernelGGL((tk_k_merge_llane<48, 128>), dim3(grid_for(most, 128, 8192)), dim3(128), 0, sa, T, d_text, lst, cp, miss, stg); break;
+                        case 4: hipLaunchKernelGGL((tk_k_merge_llane<64, 128>), dim3(grid_for(most, 128, 8192)), dim3(128), 0, sa, T, d_text, lst, cp, miss, stg); break;
+                        case 5: hipLaunchKernelGGL((tk_k_merge_group<8>), dim3(grid_for(most, 32, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, miss, stg); break;
+                        case 6: hipLaunchKernelGGL((tk_k_merge_group<16>), dim3(grid_for(most, 16, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, miss, stg); break;
+                        case 7: hipLaunchKernelGGL((tk_k_merge_group<32>), dim3(grid_for(most, 8, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, miss, stg); break;
+                        default: hipLaunchKernelGGL((tk_k_merge_group<64>), dim3(grid_for(most, 4, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, miss, stg); break;
                     }
                 }));
             }
@@ -455,26 +461,26 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
             TRY(timed(c, s, "tk_k_merge_long", [&] {
                 hipLaunchKernelGGL(tk_k_merge_long, dim3(grid_for(nC, 4, 8192)), dim3(256), 0, s, T, d_text, c->listC.as<uint32_t>(), (uint32_t)nC,
                                    c->g_id.as<uint32_t>(), c->g_rk.as<uint32_t>(), c->g_nx.as<uint32_t>(), c->g_pv.as<uint32_t>(),
-                                   c->g_lv.as<uint64_t>(), tok1, cnt, stg);
+                                   c->g_lv.as<uint64_t>(), miss, stg);
             }));
         }
         if (mt) {
-            TRY(timed(c, s, "tk_k_dup_publish", [&] { hipLaunchKernelGGL(tk_k_dup_publish, dim3(grid_for(1ull << mt_bits, 256, 4096)), dim3(256), 0, s, mt, 1u << mt_bits, tok1, cnt); }));
+            TRY(timed(c, s, "tk_k_dup_publish", [&] { hipLaunchKernelGGL(tk_k_dup_publish, dim3(grid_for(1ull << mt_bits, 256, 4096)), dim3(256), 0, s, mt, 1u << mt_bits, miss); }));
         }
         TRY(timed(c, s, "tk_k_tile_finish", [&] {
-            hipLaunchKernelGGL(tk_k_tile_finish, dim3(tf_blocks), dim3(256), 0, s, ntiles, tile_np, mt, tok1, cnt, tile_nt, c->wave_pieces.as<uint32_t>());
+            hipLaunchKernelGGL(tk_k_tile_finish, dim3(tf_blocks), dim3(256), 0, s, ntiles, tile_np, mt, res, miss, rflag, tile_nt, c->wave_pieces.as<uint32_t>());
         }));
         hipLaunchKernelGGL(tk_k_sum_pieces, dim3(1), dim3(1024), 0, s, c->wave_pieces.as<uint32_t>(), tf_blocks * 4u, c->total.as<unsigned long long>() + 1);
         TRY(timed(c, s, "tk_k_scan_small", [&] {
             hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, tile_nt, ntiles, c->total.as<uint64_t>());
         }));
         TRY(timed(c, s, "tk_k_back", [&] {
-            hipLaunchKernelGGL(tk_k_back, dim3(grid_for(ntiles, 4, 16384)), dim3(256), 0, s, ntiles, tile_np, tile_nt, tok1, cnt, stg, d_out);
+            hipLaunchKernelGGL(tk_k_back, dim3(grid_for(ntiles, 4, 16384)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, rflag, stg, d_out);
         }));
     }
     if (d_tok_off) {
         TRY(timed(c, s, "tk_k_docoff", [&] {
-            hipLaunchKernelGGL(tk_k_docoff, dim3(grid_for(n_docs + 1, 4, 8192)), dim3(256), 0, s, n_docs, c->doc_pid.as<uint32_t>(), tile_nt, cnt, c->total.as<uint64_t>(), tok_base_global, d_tok_off);
+            hipLaunchKernelGGL(tk_k_docoff, dim3(grid_for(n_docs + 1, 4, 8192)), dim3(256), 0, s, n_docs, d_doc_off, base, n, starts, tile_nt, res, rflag, c->total.as<uint64_t>(), tok_base_global, d_tok_off);
         }));
     }
     uint64_t tp[2] = {0, 0};  // tokens, pieces

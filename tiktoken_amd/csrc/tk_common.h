@@ -2,11 +2,12 @@
 //
 // Table layouts live in HBM and are read-only after tk_create(); they replace the reference's
 // `encoder: FxHashMap<Vec<u8>, Rank>` (src/lib.rs:321) with three exact structures:
-//   * piece table  : open-addressed {key64, rank, len} keyed by the piece's BYTES.  Keys of <= 8
-//                    bytes are stored inline (little-endian packed) and compared exactly; longer
-//                    keys store a 64-bit hash and are verified against the token-bytes blob, so a
-//                    hit is always an exact byte match (never a fingerprint alone).  This is the
-//                    whole-piece probe of src/lib.rs:367-368.
+//   * piece tables : the whole-piece probe of src/lib.rs:367-368, keyed by the piece's BYTES and split by length so that each
+//                    length class runs its own short code path on tables that fit the L2:
+//                      short (1..4 bytes): 8-byte slots {key32, rank | (len-1) << 30}, the bytes packed little-endian;
+//                      mid   (5..8 bytes): 16-byte slots {key64, rank, len}, the bytes packed little-endian;
+//                      long  (> 8 bytes) : 16-byte slots {hash64, rank, len}, verified against the token-bytes blob,
+//                    so a hit is always an exact byte match (never a fingerprint alone).
 //   * pair table   : open-addressed {(id_left << 32) | id_right -> id_merged} for every vocabulary
 //                    token T and every split T = A || B with A and B both vocabulary tokens.  Every
 //                    part that ever exists during _byte_pair_merge (src/lib.rs:140-196) is itself
@@ -64,6 +65,12 @@ struct TkPieceSlot {  // 16 bytes
     uint32_t rank;
     uint32_t len;
 };
+struct TkShortSlot {  // 8 bytes
+    uint32_t key;      // packed bytes (len <= 4)
+    uint32_t val;      // rank | (len - 1) << 30; 0xFFFFFFFF = empty
+};
+#define TK_SHORT_EMPTY 0xFFFFFFFFu
+#define TK_SHORT_MAX_RANK 0x3FFFFFFFu  // larger ranks: no short table, pieces of <= 4 bytes live in the mid table
 struct TkPairSlot {  // 16 bytes
     uint64_t key;    // (id_left << 32) | id_right; ~0 = empty
     uint32_t rank;
@@ -76,7 +83,11 @@ struct TkTables {
     const uint8_t* uc_stage1;   // [0x1100]
     const uint8_t* uc_stage2;   // [nblocks*256]
     const uint32_t* byte_tab;   // [256 * 2] per-byte {class planes, flag planes} of the 16-bytes-per-lane classifier (tk_chunk.h)
-    const TkPieceSlot* piece;   // [piece_mask+1]
+    const TkShortSlot* short_tab;  // [short_mask+1] tokens of 1..4 bytes (null when some rank exceeds TK_SHORT_MAX_RANK)
+    uint32_t short_mask, short_shift;  // slot = (key32 * K) >> short_shift
+    const TkPieceSlot* mid_tab;    // [mid_mask+1] tokens of 5..8 bytes (1..8 without a short table)
+    uint32_t mid_mask, mid_shift;
+    const TkPieceSlot* piece;   // [piece_mask+1] tokens of more than 8 bytes
     const uint32_t* piece_off;  // [piece_mask+1] offset of the slot's key bytes in tok_bytes
     uint64_t piece_mask;
     const uint8_t* tok_bytes;   // all token byte strings, concatenated
@@ -114,6 +125,13 @@ TK_HD uint64_t tk_piece_slot_hash(uint64_t key, uint32_t len) {
     x *= 0x27D4EB2Fu;
     x ^= x >> 16;
     return x;
+}
+// slots of the short / mid tables: multiplicative hashing, top bits (two or six vector instructions)
+TK_HD uint32_t tk_short_slot(uint32_t key, uint32_t shift) { return (key * 0x9E3779B1u) >> shift; }
+TK_HD uint32_t tk_mid_slot(uint64_t key, uint32_t shift) {
+    uint32_t x = (uint32_t)key * 0x9E3779B1u + (uint32_t)(key >> 32) * 0x85EBCA77u;
+    x ^= x >> 15;
+    return (x * 0xC2B2AE3Du) >> shift;
 }
 TK_HD uint64_t tk_pair_slot_hash(uint64_t key) { return tk_mix64(key * 0x9FB21C651E98DF25ull + 0x2545F4914F6CDD1Dull); }
 

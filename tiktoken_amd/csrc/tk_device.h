@@ -615,17 +615,34 @@ TK_HD uint32_t tk_piece_len_bits32(const W32& w, A& a, uint64_t p, uint32_t c, i
 // ------------------------------------------------------------------------------------------
 // table probes
 // ------------------------------------------------------------------------------------------
-// Exact bytes -> rank probe.  `key` = packed bytes (len <= 8) or tk hash (len > 8); for len > 8
-// the candidate is verified byte for byte against the token blob through `cmp(off)`.
+// Exact bytes -> rank probes, one per length class (tk_common.h).  Short: key = the 1..4 bytes packed little-endian.
+TK_HD uint32_t tk_probe_short(const TkTables& T, uint32_t key, uint32_t len) {
+    uint32_t i = tk_short_slot(key, T.short_shift);
+    for (;;) {
+        const TkShortSlot s = T.short_tab[i];
+        if (s.key == key && (s.val >> 30) == len - 1u && s.val != TK_SHORT_EMPTY) return s.val & TK_SHORT_MAX_RANK;
+        if (s.val == TK_SHORT_EMPTY) return TK_RANK_MAX;
+        i = (i + 1u) & T.short_mask;
+    }
+}
+// Mid: key = the bytes (<= 8) packed little-endian.
+TK_HD uint32_t tk_probe_mid(const TkTables& T, uint64_t key, uint32_t len) {
+    uint32_t i = tk_mid_slot(key, T.mid_shift);
+    for (;;) {
+        const TkPieceSlot s = T.mid_tab[i];
+        if (s.key == key && s.len == len) return s.rank;
+        if (s.len == 0u) return TK_RANK_MAX;
+        i = (i + 1u) & T.mid_mask;
+    }
+}
+// Long (> 8 bytes): key = tk hash of the bytes; the candidate is verified byte for byte against the token blob through `verify(off)`.
 template <class Verify>
 TK_HD uint32_t tk_probe_piece(const TkTables& T, uint64_t key, uint32_t len, Verify verify) {
     uint64_t i = tk_piece_slot_hash(key, len) & T.piece_mask;
     for (;;) {
         TkPieceSlot s = T.piece[i];
         if (s.key == TK_EMPTY_KEY && s.len == 0u) return TK_RANK_MAX;
-        if (s.key == key && s.len == len) {
-            if (len <= 8u || verify(T.piece_off[i])) return s.rank;
-        }
+        if (s.key == key && s.len == len && verify(T.piece_off[i])) return s.rank;
         i = (i + 1) & T.piece_mask;
     }
 }
@@ -704,6 +721,11 @@ TK_HD bool tk_equal_bytes(const uint8_t* text, uint64_t pos, const uint8_t* blob
 
 // Whole-piece probe of text[pos..pos+len)  (src/lib.rs:367)
 TK_HD uint32_t tk_lookup_text_piece(const TkTables& T, const uint8_t* __restrict__ text, uint64_t pos, uint32_t len) {
+    if (len <= 8u) {
+        const uint64_t key = tk_mask_low_bytes(tk_load8(text, pos), len);
+        if (len <= 4u && T.short_tab) return tk_probe_short(T, (uint32_t)key, len);
+        return tk_probe_mid(T, key, len);
+    }
     uint64_t key = tk_key_of_text(text, pos, len);
     return tk_probe_piece(T, key, len, [&](uint32_t off) { return tk_equal_bytes(text, pos, T.tok_bytes, off, len); });
 }

@@ -33,26 +33,28 @@
 
 #define TKF_NONE 0xFFFFFFFFu
 #define TKF_MISS_CAP 2048  // missed pieces per tile: each is at least two bytes long
+#define TKF_BATCH 960  // pieces per probe batch of the front kernel (the class lists hold 1024 entries, their packed counter 1023)
 #define TKF_CAP 4096  // piece ids per tile: pid = tile * TKF_CAP + k (a 4096-byte tile starts at most 4096 pieces)
 
+// Per-piece result word res[piece id]: a token id (the piece is a vocabulary token, src/lib.rs:367), or a reference to where its
+// tokens will be once the merge kernels have run.
+#define TK_RES_FLAG 0x80000000u  // not a single token: TK_RES_FLAG | j = entry j of the tile's miss list (its result replaces the entry)
+#define TK_RES_DUP 0xC0000000u   // TK_RES_DUP | slot = duplicate of the piece that claimed this slot of the in-call miss table
 struct TkFrontOut {
-    uint32_t* starts;     // piece-start bitmap (n/32 words; each tile stores its own 128 words)
+    uint32_t* starts;     // piece-start bitmap (n/32 words; each tile stores its own 120 words)
     uint32_t* tile_np;    // pieces per tile
-    uint32_t* tok1;       // [piece id] token (count 1) or staging position of the tokens (count > 1)
-    uint32_t* cnt;        // [piece id] token count, or TK_DUP_FLAG | slot
-    uint32_t* tile_nmiss; // pieces of the tile that have to be merged: not a token, not a duplicate, at most TK_GLANE_MAX bytes
-    uint32_t* miss_s;     // [tile * TKF_MISS_CAP + j] their start ...
-    uint32_t* miss_kl;    // ... and (index in the run) | (length - 1) << 12; consumed by tk_k_bincount / tk_k_binfill
-    uint32_t* listC;      // {pid, start, len, scratch bytes before, tree levels before} for > 1 KiB pieces
+    uint32_t* res;        // [piece id] see above
+    uint32_t* tile_nmiss; // entries on the tile's miss list: pieces that have to be merged (not a token, not a duplicate)
+    uint2* miss;          // [tile * TKF_MISS_CAP + j] {start, length}; the merge kernels replace it by {token count, token | staging position}
+    uint32_t* listC;      // {miss index, start, len, scratch bytes before, tree levels before} for > 1 KiB pieces
     uint32_t* counters;
-    uint32_t* doc_pid;    // [n_docs] piece id at which each document starts (TKF_NONE: no piece)
 };
 // In-call de-duplication of missed pieces: open-addressed, one 32-byte slot per distinct piece.
 struct TkMissSlot {
     unsigned long long key;  // ~0 = empty
     unsigned long long aux;  // identity of the claimant, ~0 until it has written it: pieces of <= 7 bytes: the bytes themselves
                              // | length << 56; longer ones: 1 << 63 | length << 32 | start (compared in the text)
-    uint32_t pid;            // claimant piece id
+    uint32_t mi;             // claimant's miss-list entry (tile * TKF_MISS_CAP + j)
     uint32_t res_cnt;        // claimant's result, published after the merges
     uint32_t res_tok;
     uint32_t pad;
@@ -99,7 +101,7 @@ __device__ __forceinline__ uint64_t tk_key_of_lds(const uint8_t* raw, uint32_t o
 }
 
 // a piece for the tree kernel: reserve its scratch (4 uint32 per byte + the 64-ary min-tree levels)
-__device__ __forceinline__ void tk_append_tree(uint32_t* listC, uint32_t* counters, uint32_t pid, uint32_t s, uint32_t len) {
+__device__ __forceinline__ void tk_append_tree(uint32_t* listC, uint32_t* counters, uint32_t mi, uint32_t s, uint32_t len) {
     uint32_t lv = 0, c = len;
     do {
         c = (c + 63) >> 6;
@@ -107,7 +109,7 @@ __device__ __forceinline__ void tk_append_tree(uint32_t* listC, uint32_t* counte
     } while (c > 64);
     const uint32_t gi = atomicAdd(&counters[TK_CNT_C], 1u);
     uint32_t* e = listC + 5 * (uint64_t)gi;
-    e[0] = pid;
+    e[0] = mi;
     e[1] = s;
     e[2] = len;
     e[3] = atomicAdd(&counters[TK_CNT_CBYTES], len);
@@ -152,8 +154,7 @@ __device__ __forceinline__ bool tk_equal_lds_text(const uint8_t* raw, uint32_t o
 template <int PAT, bool SPEC>
 __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
                                                   const uint32_t* __restrict__ brk, const uint32_t* __restrict__ docb,
-                                                  const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si,
-                                                  const uint64_t* __restrict__ doc_off, uint64_t n_docs, TkFrontOut out,
+                                                  const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, TkFrontOut out,
                                                   TkMissSlot* __restrict__ mt, uint32_t mt_mask, int dbg) {
     constexpr int pat = PAT;
     constexpr int NW = TK2_NSEG + 2;            // 64-bit words per bitmap (two sentinel words beyond the window)
@@ -166,8 +167,8 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
     __shared__ uint32_t bits[TK_TILE / 32];
     __shared__ uint32_t woff[TK_TILE / 32 + 1];
     __shared__ uint8_t lastc[256];
-    __shared__ uint32_t ncl_sh[2], np_sh, nmiss_sh, need_walk, last_end_sh;
-    __shared__ uint32_t brkw[TK2_WIN / 32 + 1], ssw[TK2_WIN / 32 + 1], siw[TK2_WIN / 32 + 1], docw[TK2_WIN / 32 + 1];
+    __shared__ uint32_t np_sh, nmiss_sh, need_walk, last_end_sh, ncls_sh, nx_sh;
+    __shared__ uint32_t brkw[TK2_WIN / 32 + 1], ssw[TK2_WIN / 32 + 1], siw[TK2_WIN / 32 + 1];
     __shared__ uint32_t scan_sh[8];
     uint64_t(*bm)[NW] = (uint64_t(*)[NW])pool;
     uint16_t* clist = (uint16_t*)(pool + BM_BYTES);
@@ -210,14 +211,12 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
         int64_t wgp = base + (int64_t)tid * 32;
         bool in = wgp >= 0 && (uint64_t)wgp < n;
         brkw[tid] = in ? brk[wgp >> 5] : 0u;
-        docw[tid] = in ? (docb ? docb[wgp >> 5] : brkw[tid]) : 0u;
         ssw[tid] = (SPEC && in) ? ss[wgp >> 5] : 0u;
         siw[tid] = (SPEC && in) ? si[wgp >> 5] : 0u;
     }
     if (tid == 0) {
         nmiss_sh = 0;
         need_walk = 0;
-        ncl_sh[0] = ncl_sh[1] = 0;
         last_end_sh = (uint32_t)(tile_end - tile_start) + TK2_LEFT;
     }
     if (tid < TKB_KINDS) {
@@ -415,100 +414,188 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
         if (tid == 0) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
         return;
     }
-    // ---- F: whole-piece probe, one lane per piece
+    // ---- F: whole-piece probe (src/lib.rs:367).  Pieces are first sorted by length class into LDS lists -- short (<= 4 bytes),
+    // mid (5..8), long -- so that every wavefront runs ONE probe path with all lanes busy; pieces that are not tokens go to a
+    // fourth list and get their de-duplication pass the same way.  Batches of 1024 pieces bound the lists.
     const uint32_t last_end = last_end_sh;
-    for (uint32_t k0 = 0; k0 < np; k0 += 256) {
-        const uint32_t k = k0 + tid;
-        uint32_t cat = 0, len = 0;  // cat 1: not a token (-> miss list), 2: longer than the lane-group kernels take (-> tree list)
-        uint64_t gs = 0;
-        const uint32_t pid = run_base + k;
-        if (k < np) {
-            const uint32_t s_loc = plist[k];
-            const uint32_t e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
-            len = e_loc - s_loc;
-            gs = (uint64_t)(base + s_loc);
-            // documents that start at this piece
-            if ((docw[s_loc >> 5] >> (s_loc & 31u)) & 1u) {
-                const uint64_t want = gs + chunk_base;
-                uint64_t lo = 0, hi = n_docs;  // first d with doc_off[d] >= want
-                while (lo < hi) {
-                    uint64_t mid = (lo + hi) >> 1;
-                    if (doc_off[mid] < want) lo = mid + 1;
-                    else hi = mid;
+    uint16_t* ord_sl = (uint16_t*)btab;        // [1024] short pieces from the front, long ones from the back (the byte table is dead)
+    uint16_t* ord_m = (uint16_t*)planes;       // [1024] mid pieces (the planes are dead)
+    uint16_t* ord_x = (uint16_t*)(pool + TK_TILE * 2);  // [1024] pieces that are not tokens (behind the piece list)
+    const uint32_t* dwr = (const uint32_t*)raw;
+    const bool short_tab = T.short_tab != nullptr;
+    for (uint32_t kb = 0; kb < np; kb += TKF_BATCH) {
+        const uint32_t nb = np - kb < TKF_BATCH ? np - kb : (uint32_t)TKF_BATCH;
+        if (tid == 0) {
+            ncls_sh = 0;
+            nx_sh = 0;
+        }
+        __syncthreads();
+        // F0: length class of every piece of the batch -> lists (one packed LDS counter: short | mid << 11 | long << 22)
+        for (uint32_t i0 = 0; i0 < nb; i0 += 256) {
+            const uint32_t i = i0 + tid;
+            uint32_t cls = 3;  // 0 short, 1 mid, 2 long, 3 none
+            if (i < nb) {
+                const uint32_t k = kb + i;
+                const uint32_t s_loc = plist[k], e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
+                const uint32_t len = e_loc - s_loc;
+                cls = len <= 4u ? 0u : (len <= 8u ? 1u : 2u);
+                if (SPEC && ((ssw[s_loc >> 5] >> (s_loc & 31u)) & 1u)) {  // a special token: its id (src/lib.rs:426-434)
+                    out.res[run_base + k] = tk_special_id(T, text, (uint64_t)(base + s_loc), len);
+                    cls = 3;
                 }
-                for (; lo < n_docs && doc_off[lo] == want; ++lo) out.doc_pid[lo] = pid;
             }
-            if (SPEC && ((ssw[s_loc >> 5] >> (s_loc & 31u)) & 1u)) {
-                out.tok1[pid] = tk_special_id(T, text, gs, len);
-                out.cnt[pid] = 1;
-            } else {
+            const uint64_t m0 = __ballot(cls == 0u), m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u);
+            const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2);
+            uint32_t at = 0;
+            if (lane == 0) at = atomicAdd(&ncls_sh, c0 | (c1 << 11) | (c2 << 22));
+            at = (uint32_t)__shfl((int)at, 0, 64);
+            const uint64_t below = (1ull << lane) - 1ull;
+            if (cls == 0u) ord_sl[(at & 2047u) + (uint32_t)__popcll(m0 & below)] = (uint16_t)i;
+            else if (cls == 1u) ord_m[((at >> 11) & 2047u) + (uint32_t)__popcll(m1 & below)] = (uint16_t)i;
+            else if (cls == 2u) ord_sl[1023u - (at >> 22) - (uint32_t)__popcll(m2 & below)] = (uint16_t)i;
+        }
+        __syncthreads();
+        const uint32_t n_s = ncls_sh & 2047u, n_m = (ncls_sh >> 11) & 2047u, n_l = ncls_sh >> 22;
+        // a piece that is not a token: remembered for the de-duplication pass
+        auto not_a_token = [&](bool miss, uint32_t i) {
+            const uint64_t m = __ballot(miss);
+            if (m) {
+                uint32_t at = 0;
+                const int leader = __ffsll((unsigned long long)m) - 1;
+                if (lane == leader) at = atomicAdd(&nx_sh, (uint32_t)__popcll(m));
+                at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (miss) ord_x[at] = (uint16_t)i;
+            }
+        };
+        // F1: short pieces: the bytes are the key (one unaligned LDS dword), 8-byte slots
+        for (uint32_t q0 = 0; q0 < n_s; q0 += 256) {
+            const uint32_t q = q0 + tid;
+            bool miss = false;
+            uint32_t i = 0;
+            if (q < n_s) {
+                i = ord_sl[q];
+                const uint32_t k = kb + i, s_loc = plist[k], e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
+                const uint32_t len = e_loc - s_loc;
+                const uint32_t v = __builtin_amdgcn_alignbyte(dwr[(s_loc >> 2) + 1], dwr[s_loc >> 2], s_loc & 3u);
+                const uint32_t key = v & (0xFFFFFFFFu >> (32u - 8u * len));
+                const uint32_t r = (dbg & 2) ? len : (short_tab ? tk_probe_short(T, key, len) : tk_probe_mid(T, (uint64_t)key, len));
+                if (r != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k] = r == TK_RANK_MAX ? 0u : r;
+                else miss = true;
+            }
+            not_a_token(miss, i);
+        }
+        // F2: mid pieces: 64-bit key, 16-byte slots
+        for (uint32_t q0 = 0; q0 < n_m; q0 += 256) {
+            const uint32_t q = q0 + tid;
+            bool miss = false;
+            uint32_t i = 0;
+            if (q < n_m) {
+                i = ord_m[q];
+                const uint32_t k = kb + i, s_loc = plist[k], e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
+                const uint32_t len = e_loc - s_loc;
+                const uint64_t key = tk_mask_low_bytes(tk_lds_load8(raw, s_loc), len);
+                const uint32_t r = (dbg & 2) ? len : tk_probe_mid(T, key, len);
+                if (r != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k] = r == TK_RANK_MAX ? 0u : r;
+                else miss = true;
+            }
+            not_a_token(miss, i);
+        }
+        // F3: long pieces: hash of the bytes, candidates verified against the token blob
+        for (uint32_t q0 = 0; q0 < n_l; q0 += 256) {
+            const uint32_t q = q0 + tid;
+            bool miss = false;
+            uint32_t i = 0;
+            if (q < n_l) {
+                i = ord_sl[1023u - q];
+                const uint32_t k = kb + i, s_loc = plist[k], e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
+                const uint32_t len = e_loc - s_loc;
+                const uint64_t gs = (uint64_t)(base + s_loc);
                 const bool in_lds = e_loc + 8u <= (uint32_t)TK2_WIN;
                 const uint64_t key = in_lds ? tk_key_of_lds(raw, s_loc, len) : tk_key_of_text(text, gs, len);
-                uint32_t r = (dbg & 2) ? len : tk_probe_piece(T, key, len, [&](uint32_t off) {
+                const uint32_t r = (dbg & 2) ? len : tk_probe_piece(T, key, len, [&](uint32_t off) {
                     return in_lds ? tk_equal_lds_text(raw, s_loc, T.tok_bytes, off, len) : tk_equal_bytes(text, gs, T.tok_bytes, off, len);
                 });
-                if ((dbg & 8) && r == TK_RANK_MAX) r = 0;  // (perf experiments: 2 = no probe, 8 = no deferred pieces)
-                if (r != TK_RANK_MAX) {
-                    out.tok1[pid] = r;
-                    out.cnt[pid] = 1;
-                } else if (len > TK_GLANE_MAX) {
-                    cat = 2u;
-                } else {
-                    cat = 1u;
-                    // In-call de-duplication: claim a slot of the miss table (first occurrence: stays on the miss list and gets
-                    // merged) or find it claimed by IDENTICAL bytes -- pieces of <= 7 bytes carry their bytes in the slot, longer
-                    // ones are compared with the claimant's text -- and only record the slot (resolved by tk_k_tile_finish).
-                    // Slots are written once, so a cached load can only be stale towards "empty", where the atomic decides.
-                    if (mt) {
-                        const unsigned long long ident = len <= 7u ? (key | ((unsigned long long)len << 56))
-                                                                   : ((1ull << 63) | ((unsigned long long)len << 32) | (uint32_t)gs);
-                        unsigned long long kk = tk_mix64(key ^ ((uint64_t)len * 0xA24BAED4963EE407ull));
-                        if (dbg & 512) kk &= 0xFFFull;  // test hook: force collisions between different pieces
-                        if (kk == TK_EMPTY_KEY) kk = 0;
-                        uint32_t i = (uint32_t)(kk >> 7) & mt_mask;
-                        for (int p = 0; p < TK_MT_PROBES; ++p) {
-                            const ulonglong2 ka = *(const ulonglong2*)&mt[i].key;
-                            unsigned long long cur = ka.x;
-                            if (cur == TK_EMPTY_KEY) cur = atomicCAS(&mt[i].key, TK_EMPTY_KEY, kk);
-                            if (cur == TK_EMPTY_KEY) {
-                                mt[i].pid = pid;
-                                __hip_atomic_store(&mt[i].aux, ident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                if (r != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k] = r == TK_RANK_MAX ? 0u : r;
+                else miss = true;
+            }
+            not_a_token(miss, i);
+        }
+        __syncthreads();
+        // F4: pieces that are not tokens.  In-call de-duplication: claim a slot of the miss table (first occurrence: goes on the
+        // tile's miss list and gets merged) or find it claimed by IDENTICAL bytes -- pieces of <= 7 bytes carry their bytes in the
+        // slot, longer ones are compared with the claimant's text -- and only record the slot (resolved by tk_k_tile_finish).
+        // Slots are written once, so a cached load can only be stale towards "empty", where the atomic decides.
+        const uint32_t n_x = nx_sh;
+        for (uint32_t q0 = 0; q0 < n_x; q0 += 256) {
+            const uint32_t q = q0 + tid;
+            bool listed = false;
+            uint32_t k = 0, len = 0, slot = TKF_NONE;
+            uint64_t gs = 0;
+            if (q < n_x) {
+                k = kb + ord_x[q];
+                const uint32_t s_loc = plist[k], e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
+                len = e_loc - s_loc;
+                gs = (uint64_t)(base + s_loc);
+                listed = true;
+                if (mt && len <= TK_GLANE_MAX) {
+                    const bool in_lds = e_loc + 8u <= (uint32_t)TK2_WIN;
+                    const uint64_t key = in_lds ? tk_key_of_lds(raw, s_loc, len) : tk_key_of_text(text, gs, len);
+                    const unsigned long long ident = len <= 7u ? (key | ((unsigned long long)len << 56))
+                                                               : ((1ull << 63) | ((unsigned long long)len << 32) | (uint32_t)gs);
+                    // slot key: two independent 32-bit hashes of (bytes, length) -- equal bytes are verified anyway
+                    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
+                    uint32_t h1 = klo * 0x9E3779B1u + khi * 0x85EBCA77u + len * 0xC2B2AE3Du;
+                    h1 ^= h1 >> 15;
+                    h1 *= 0x27D4EB2Fu;
+                    uint32_t h2 = (klo ^ 0x5BD1E995u) * 0x165667B1u + (khi + len) * 0xD3A2646Du;
+                    h2 ^= h2 >> 13;
+                    unsigned long long kk = ((unsigned long long)h2 << 32) | h1;
+                    if (dbg & 512) kk &= 0xFFFull;  // test hook: force collisions between different pieces
+                    if (kk == TK_EMPTY_KEY) kk = 0;
+                    uint32_t i = ((uint32_t)kk ^ (uint32_t)(kk >> 40)) & mt_mask;
+                    for (int p = 0; p < TK_MT_PROBES; ++p) {
+                        const ulonglong2 ka = *(const ulonglong2*)&mt[i].key;
+                        unsigned long long cur = ka.x;
+                        if (cur == TK_EMPTY_KEY) cur = atomicCAS(&mt[i].key, TK_EMPTY_KEY, kk);
+                        if (cur == TK_EMPTY_KEY) {
+                            slot = i;  // claimed: the miss entry is recorded below
+                            __hip_atomic_store(&mt[i].aux, ident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            break;
+                        }
+                        if (cur == kk) {
+                            unsigned long long a = ka.y;
+                            if (a == TK_EMPTY_KEY) a = __hip_atomic_load(&mt[i].aux, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            const bool same = len <= 7u ? a == ident
+                                                        : ((a >> 32) == (ident >> 32) &&
+                                                           (in_lds ? tk_equal_lds_text(raw, s_loc, text, (uint32_t)a, len)
+                                                                   : tk_equal_bytes(text, gs, text, (uint32_t)a, len)));
+                            if (a != TK_EMPTY_KEY && same) {
+                                out.res[run_base + k] = TK_RES_DUP | i;
+                                listed = false;
                                 break;
                             }
-                            if (cur == kk) {
-                                unsigned long long a = ka.y;
-                                if (a == TK_EMPTY_KEY) a = __hip_atomic_load(&mt[i].aux, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                                const bool same = len <= 7u ? a == ident
-                                                            : ((a >> 32) == (ident >> 32) &&
-                                                               (in_lds ? tk_equal_lds_text(raw, s_loc, text, (uint32_t)a, len)
-                                                                       : tk_equal_bytes(text, gs, text, (uint32_t)a, len)));
-                                if (a != TK_EMPTY_KEY && same) {
-                                    out.cnt[pid] = TK_DUP_FLAG | i;
-                                    cat = 0;
-                                    break;
-                                }
-                            }
-                            i = (i + 1) & mt_mask;
                         }
+                        i = (i + 1) & mt_mask;
                     }
                 }
             }
-        }
-        const uint64_t m = __ballot(cat == 1u);
-        if (m) {  // the tile's own miss list (no global atomics)
-            const int leader = __ffsll((unsigned long long)m) - 1;
-            uint32_t at = 0;
-            if (lane == leader) at = atomicAdd(&nmiss_sh, (uint32_t)__popcll(m));
-            at = __shfl(at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (cat == 1u) {
-                const uint64_t mi = tile * TKF_MISS_CAP + at;
-                out.miss_s[mi] = (uint32_t)gs;
-                out.miss_kl[mi] = k | ((len - 1u) << 12);
+            const uint64_t m = __ballot(listed);
+            if (m) {  // the tile's own miss list (no global atomics)
+                const int leader = __ffsll((unsigned long long)m) - 1;
+                uint32_t at = 0;
+                if (lane == leader) at = atomicAdd(&nmiss_sh, (uint32_t)__popcll(m));
+                at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                if (listed) {
+                    const uint32_t mi = (uint32_t)tile * TKF_MISS_CAP + at;
+                    out.miss[mi] = make_uint2((uint32_t)gs, len);
+                    out.res[run_base + k] = TK_RES_FLAG | at;
+                    if (slot != TKF_NONE) mt[slot].mi = mi;
+                    if (len > TK_GLANE_MAX) tk_append_tree(out.listC, out.counters, mi, (uint32_t)gs, len);
+                }
             }
         }
-        if (cat == 2u) tk_append_tree(out.listC, out.counters, pid, (uint32_t)gs, len);
+        __syncthreads();  // (the lists are reused by the next batch)
     }
-    __syncthreads();
     if (tid == 0) out.tile_nmiss[tile] = nmiss_sh;
 }
 
@@ -531,17 +618,16 @@ struct TkMissGroup {  // the miss lists of TKD_GROUP consecutive tiles, flattene
         for (int q = 0; q < TKD_GROUP; ++q) pre[q + 1] = pre[q] + __shfl(nm_l, q, 64);
     }
     __device__ __forceinline__ uint32_t total() const { return pre[TKD_GROUP]; }
-    // flat index -> position in the miss arrays; *run_base gets the first piece id of that tile
-    __device__ __forceinline__ uint32_t locate(uint32_t f, uint64_t t0, uint32_t* run_base) const {
+    // flat index -> miss-list entry
+    __device__ __forceinline__ uint32_t locate(uint32_t f, uint64_t t0) const {
         uint32_t q = 0;
 #pragma unroll
         for (int i = 1; i < TKD_GROUP; ++i) q += f >= pre[i];
-        *run_base = (uint32_t)(t0 + q) * TKF_CAP;
         return (uint32_t)(t0 + q) * TKF_MISS_CAP + (f - pre[q]);
     }
 };
 
-__global__ __launch_bounds__(256) void tk_k_bincount(uint64_t ntiles, const uint32_t* __restrict__ tile_nmiss, const uint32_t* __restrict__ miss_kl,
+__global__ __launch_bounds__(256) void tk_k_bincount(uint64_t ntiles, const uint32_t* __restrict__ tile_nmiss, const uint2* __restrict__ miss,
                                                      uint32_t* __restrict__ wbin, uint32_t tpg) {
     const uint32_t nwaves = gridDim.x * 4u;  // tk_k_binfill runs with the same grid: identical wave -> tile-group mapping
     const int lane = threadIdx.x & 63;
@@ -556,11 +642,10 @@ __global__ __launch_bounds__(256) void tk_k_bincount(uint64_t ntiles, const uint
         grp.load(tile_nmiss, t0, ntiles, lane, tpg);
         for (uint32_t j0 = 0; j0 < grp.total(); j0 += 64) {
             const uint32_t f = j0 + lane;
-            uint32_t bin = TK_NBIN;
+            uint32_t bin = TK_NBIN;  // (pieces over TK_GLANE_MAX bytes are on the tree list: no bin)
             if (f < grp.total()) {
-                uint32_t rb;
-                const uint32_t kl = miss_kl[grp.locate(f, t0, &rb)];
-                bin = (uint32_t)tk_bin_of(((kl >> 12) & 1023u) + 1u);
+                const uint32_t len = miss[grp.locate(f, t0)].y;
+                if (len <= TK_GLANE_MAX) bin = (uint32_t)tk_bin_of(len);
             }
 #pragma unroll
             for (int b = 0; b < TK_NBIN; ++b) nb[b] += (uint32_t)__popcll(__ballot(bin == (uint32_t)b));
@@ -573,9 +658,9 @@ __global__ __launch_bounds__(256) void tk_k_bincount(uint64_t ntiles, const uint
 }
 
 // pass 2: wscan = exclusive scan of wbin (TK_NBIN * nwaves + 1 entries; the last one is the grand total)
-__global__ __launch_bounds__(256) void tk_k_binfill(uint64_t ntiles, const uint32_t* __restrict__ tile_nmiss, const uint32_t* __restrict__ miss_s,
-                                                    const uint32_t* __restrict__ miss_kl, const uint32_t* __restrict__ wscan,
-                                                    uint32_t* __restrict__ listM, TkBins bins, uint32_t* __restrict__ counters, uint32_t tpg) {
+__global__ __launch_bounds__(256) void tk_k_binfill(uint64_t ntiles, const uint32_t* __restrict__ tile_nmiss, const uint2* __restrict__ miss,
+                                                    const uint32_t* __restrict__ wscan, uint32_t* __restrict__ listM, TkBins bins,
+                                                    uint32_t* __restrict__ counters, uint32_t tpg) {
     const int lane = threadIdx.x & 63;
     const uint64_t ngroups = (ntiles + tpg - 1) / tpg;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
@@ -590,24 +675,20 @@ __global__ __launch_bounds__(256) void tk_k_binfill(uint64_t ntiles, const uint3
         grp.load(tile_nmiss, t0, ntiles, lane, tpg);
         for (uint32_t j0 = 0; j0 < grp.total(); j0 += 64) {
             const uint32_t f = j0 + lane;
-            uint32_t bin = TK_NBIN, pid = 0, s = 0, len = 0;
+            uint32_t bin = TK_NBIN, mi = 0, s = 0, len = 0;
             if (f < grp.total()) {
-                uint32_t rb;
-                const uint32_t mi = grp.locate(f, t0, &rb);
-                const uint32_t kl = miss_kl[mi];
-                {
-                    pid = rb + (kl & 4095u);
-                    s = miss_s[mi];
-                    len = ((kl >> 12) & 1023u) + 1u;
-                    bin = (uint32_t)tk_bin_of(len);
-                }
+                mi = grp.locate(f, t0);
+                const uint2 e = miss[mi];
+                s = e.x;
+                len = e.y;
+                if (len <= TK_GLANE_MAX) bin = (uint32_t)tk_bin_of(len);
             }
 #pragma unroll
             for (int b = 0; b < TK_NBIN; ++b) {
                 const uint64_t m = __ballot(bin == (uint32_t)b);
                 if (bin == (uint32_t)b) {
                     uint32_t* q = listM + 3 * (uint64_t)(at[b] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
-                    q[0] = pid;
+                    q[0] = mi;
                     q[1] = s;
                     q[2] = len;
                 }
@@ -618,30 +699,29 @@ __global__ __launch_bounds__(256) void tk_k_binfill(uint64_t ntiles, const uint3
 }
 
 // ------------------------------------------------------------------------------------------
-// merges on {pid, start, len} entries (same algorithms as tk_k_merge_llane / tk_k_merge_group / tk_k_merge_long)
-// result: cnt[pid] = token count; tok1[pid] = the token (count 1) or the staging position of the tokens
+// merges on {miss index, start, len} entries: byte_pair_merge (src/lib.rs:140-196) of the piece text[start .. start + len)
+// result: miss[mi] = {token count, the token (count 1) | the staging position of the tokens}
 // ------------------------------------------------------------------------------------------
 template <int NMAX, int THREADS>
 __global__ __launch_bounds__(THREADS) void tk_k_merge_llane(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ list,
-                                                             const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ tok1,
-                                                             uint32_t* __restrict__ cnt, uint32_t* __restrict__ staging) {
+                                                             const uint32_t* __restrict__ count_ptr, uint2* __restrict__ miss,
+                                                             uint32_t* __restrict__ staging) {
     const uint32_t count = *count_ptr;  // list length produced on the device (tk_k_binfill): no host round trip before the merges
     __shared__ uint32_t s_id[NMAX * THREADS];
     __shared__ uint32_t s_rk[NMAX * THREADS];
     uint32_t* id = s_id + threadIdx.x;
     uint32_t* rk = s_rk + threadIdx.x;
     for (uint32_t it = blockIdx.x * THREADS + threadIdx.x; it < count; it += gridDim.x * THREADS) {
-        const uint32_t pid = list[3 * (uint64_t)it], s = list[3 * (uint64_t)it + 1], n = list[3 * (uint64_t)it + 2];
+        const uint32_t mi = list[3 * (uint64_t)it], s = list[3 * (uint64_t)it + 1], n = list[3 * (uint64_t)it + 2];
         const uint32_t t = tk_lane_merge<THREADS>(T, text, s, n, id, rk, staging + s);
-        cnt[pid] = t;
-        tok1[pid] = t == 1 ? id[0] : s;
+        miss[mi] = make_uint2(t, t == 1 ? id[0] : s);
     }
 }
 
 template <int G>
 __global__ __launch_bounds__(256) void tk_k_merge_group(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ list,
-                                                         const uint32_t* __restrict__ count_ptr, uint32_t* __restrict__ tok1,
-                                                         uint32_t* __restrict__ cnt, uint32_t* __restrict__ staging) {
+                                                         const uint32_t* __restrict__ count_ptr, uint2* __restrict__ miss,
+                                                         uint32_t* __restrict__ staging) {
     const uint32_t count = *count_ptr;
     constexpr int C = 16, NMAX = G * C, PPW = 64 / G;
     constexpr uint32_t NONE = 0xFFFFu;
@@ -671,9 +751,9 @@ __global__ __launch_bounds__(256) void tk_k_merge_group(TkTables T, const uint8_
     for (uint32_t e0 = wave * PPW; e0 < count; e0 += nwaves * PPW) {
         const uint32_t e = e0 + grp;
         const bool valid = e < count;
-        uint32_t pid = 0, s = 0, n = 0;
+        uint32_t mi = 0, s = 0, n = 0;
         if (valid) {
-            pid = list[3 * (uint64_t)e];
+            mi = list[3 * (uint64_t)e];
             s = list[3 * (uint64_t)e + 1];
             n = list[3 * (uint64_t)e + 2];
         }
@@ -777,10 +857,7 @@ __global__ __launch_bounds__(256) void tk_k_merge_group(TkTables T, const uint8_
                 mm &= mm - 1;
                 staging[s + t++] = id[g * C + c];
             }
-            if (g == 0) {
-                cnt[pid] = total;
-                tok1[pid] = total == 1 ? id[0] : s;
-            }
+            if (g == 0) miss[mi] = make_uint2(total, total == 1 ? id[0] : s);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -789,12 +866,12 @@ __global__ __launch_bounds__(256) void tk_k_merge_group(TkTables T, const uint8_
 __global__ __launch_bounds__(256) void tk_k_merge_long(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listC,
                                                         uint32_t nC, uint32_t* __restrict__ g_id, uint32_t* __restrict__ g_rk,
                                                         uint32_t* __restrict__ g_nx, uint32_t* __restrict__ g_pv, uint64_t* __restrict__ g_lv,
-                                                        uint32_t* __restrict__ tok1, uint32_t* __restrict__ cnt, uint32_t* __restrict__ staging) {
+                                                        uint2* __restrict__ miss, uint32_t* __restrict__ staging) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
     for (uint32_t w = wave; w < nC; w += nwaves) {
         const uint32_t* ent = listC + 5 * (uint64_t)w;
-        const uint32_t pid = ent[0], s = ent[1], n = ent[2];
+        const uint32_t mi = ent[0], s = ent[1], n = ent[2];
         uint32_t* id = g_id + ent[3];
         uint32_t* rk = g_rk + ent[3];
         uint32_t* nx = g_nx + ent[3];
@@ -881,59 +958,59 @@ __global__ __launch_bounds__(256) void tk_k_merge_long(TkTables T, const uint8_t
             if (v != TK_RANK_MAX) staging[s + t + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = v;
             t += (uint32_t)__popcll(m);
         }
-        if (lane == 0) {
-            cnt[pid] = t;
-            tok1[pid] = t == 1 ? id[0] : s;  // (the leftmost part always survives)
-        }
+        if (lane == 0) miss[mi] = make_uint2(t, t == 1 ? id[0] : s);  // (the leftmost part always survives)
     }
 }
 
 // ------------------------------------------------------------------------------------------
 // back end
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tk_k_dup_publish(TkMissSlot* __restrict__ mt, uint32_t mt_slots, const uint32_t* __restrict__ tok1,
-                                                         const uint32_t* __restrict__ cnt) {
+__global__ __launch_bounds__(256) void tk_k_dup_publish(TkMissSlot* __restrict__ mt, uint32_t mt_slots, const uint2* __restrict__ miss) {
     for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < mt_slots; i += gridDim.x * 256u) {
         if (mt[i].key == TK_EMPTY_KEY) continue;
-        const uint32_t rep = mt[i].pid;
-        mt[i].res_cnt = cnt[rep];
-        mt[i].res_tok = tok1[rep];
+        const uint2 r = miss[mt[i].mi];
+        mt[i].res_cnt = r.x;
+        mt[i].res_tok = r.y;
     }
 }
 
-// one wavefront per tile, four consecutive pieces per lane (16-byte loads; runs start 16-byte aligned):
-// duplicates take their claimant's published result; token count of the tile
+// one wavefront per tile, four consecutive pieces per lane (16-byte loads; runs start 16-byte aligned): the pieces that are not single
+// tokens get their result {count, token | staging position} -- from the tile's miss list or, for duplicates, from the claimant's slot --
+// appended IN PIECE ORDER to rflag[tile * TKF_MISS_CAP ...], so that the passes after this one read it sequentially; token count of the tile
 __global__ __launch_bounds__(256) void tk_k_tile_finish(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const TkMissSlot* __restrict__ mt,
-                                                        uint32_t* __restrict__ tok1, uint32_t* __restrict__ cnt, uint32_t* __restrict__ tile_nt,
-                                                        uint32_t* __restrict__ wave_pieces) {
+                                                        const uint32_t* __restrict__ res, const uint2* __restrict__ miss, uint2* __restrict__ rflag,
+                                                        uint32_t* __restrict__ tile_nt, uint32_t* __restrict__ wave_pieces) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
     uint32_t pieces = 0;
     for (uint64_t t = wave; t < ntiles; t += nwaves) {
-        const uint32_t np = tile_np[t], rb = (uint32_t)t * TKF_CAP;
+        const uint32_t np = tile_np[t], rb = (uint32_t)t * TKF_CAP, mb = (uint32_t)t * TKF_MISS_CAP;
         pieces += np;
-        uint32_t sum = 0;
-        for (uint32_t k = lane * 4; k < np; k += 256) {
-            const uint32_t pid = rb + k;
-            const uint4 c4 = *(const uint4*)(cnt + pid);
-            uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
-            uint2 res[4];
-            bool dup[4];
+        uint32_t sum = 0, fbase = 0;
+        for (uint32_t k = lane * 4; k - lane * 4 < np; k += 256) {  // (uniform trip count: the scan below needs every lane)
+            uint4 r4 = make_uint4(0, 0, 0, 0);
+            if (k < np) r4 = *(const uint4*)(res + rb + k);
+            const uint32_t r[4] = {r4.x, r4.y, r4.z, r4.w};
+            uint2 v[4];
+            uint32_t nf = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) {  // all four slot loads in flight together
-                dup[j] = k + j < np && (c[j] & TK_DUP_FLAG);
-                if (k + j >= np) c[j] = 0;
-                if (dup[j]) res[j] = *(const uint2*)&mt[c[j] & ~TK_DUP_FLAG].res_cnt;
+            for (int j = 0; j < 4; ++j) {  // all four loads in flight together
+                const bool live = k + j < np, flagged = live && (r[j] & TK_RES_FLAG);
+                v[j] = make_uint2(live ? 1u : 0u, 0u);
+                if (flagged) {
+                    if ((r[j] & TK_RES_DUP) == TK_RES_DUP) v[j] = *(const uint2*)&mt[r[j] & ~TK_RES_DUP].res_cnt;
+                    else v[j] = miss[mb + (r[j] & ~TK_RES_FLAG)];
+                    ++nf;
+                }
             }
+            const uint32_t inc = tk_wave_scan_u32(nf, lane);
+            uint32_t at = mb + fbase + inc - nf;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                if (dup[j]) {
-                    c[j] = res[j].x;
-                    tok1[pid + j] = res[j].y;
-                    cnt[pid + j] = c[j];
-                }
-                sum += c[j];
+                if (k + j < np && (r[j] & TK_RES_FLAG)) rflag[at++] = v[j];
+                sum += v[j].x;
             }
+            fbase += (uint32_t)__shfl((int)inc, 63, 64);
         }
         sum = tk_wave_sum_u32(sum);
         if (lane == 0) tile_nt[t] = sum;
@@ -941,37 +1018,49 @@ __global__ __launch_bounds__(256) void tk_k_tile_finish(uint64_t ntiles, const u
     if (lane == 0) wave_pieces[wave] = pieces;  // (summed by tk_k_sum_pieces: no same-address atomics)
 }
 
-// one wavefront per tile, four consecutive pieces per lane: local scan of the piece counts, tokens to their final
-// positions.  Single tokens go out as one 16-byte store per lane; the tokens of a multi-token piece are copied
-// from the staging area by the whole wavefront.
-__global__ __launch_bounds__(256) void tk_k_back(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_tb, const uint32_t* __restrict__ tok1,
-                                                 const uint32_t* __restrict__ cnt, const uint32_t* __restrict__ staging, uint32_t* __restrict__ out) {
+// one wavefront per tile, four consecutive pieces per lane: local scan of the piece counts, tokens to their final positions.
+// Single tokens go out as one 16-byte store per lane; the tokens of a multi-token piece are copied from the staging area by
+// eight lanes per piece.
+__global__ __launch_bounds__(256) void tk_k_back(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_tb,
+                                                 const uint32_t* __restrict__ res, const uint2* __restrict__ rflag, const uint32_t* __restrict__ staging,
+                                                 uint32_t* __restrict__ out) {
     __shared__ uint32_t mlist_sh[4][256 * 3];
     const int lane = threadIdx.x & 63;
     uint32_t* mlist = mlist_sh[threadIdx.x >> 6];
     const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
     for (uint64_t t = wave; t < ntiles; t += nwaves) {
-        const uint32_t np = tile_np[t], rb = (uint32_t)t * TKF_CAP;
-        uint32_t run = tile_tb[t];
+        const uint32_t np = tile_np[t], rb = (uint32_t)t * TKF_CAP, mb = (uint32_t)t * TKF_MISS_CAP;
+        uint32_t run = tile_tb[t], fbase = 0;
         for (uint32_t k0 = 0; k0 < np; k0 += 256) {
             const uint32_t k = k0 + lane * 4;
-            const uint32_t pid = rb + k;
-            uint4 c4 = make_uint4(0, 0, 0, 0), t4 = make_uint4(0, 0, 0, 0);
-            if (k < np) {
-                c4 = *(const uint4*)(cnt + pid);
-                t4 = *(const uint4*)(tok1 + pid);
-            }
-            uint32_t c[4] = {c4.x, c4.y, c4.z, c4.w};
-            const uint32_t tk[4] = {t4.x, t4.y, t4.z, t4.w};
+            uint4 t4 = make_uint4(0, 0, 0, 0);
+            if (k < np) t4 = *(const uint4*)(res + rb + k);
+            uint32_t tk[4] = {t4.x, t4.y, t4.z, t4.w};
+            uint32_t c[4];
+            uint32_t nf = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                if (k + j >= np) c[j] = 0;
+            for (int j = 0; j < 4; ++j) {
+                c[j] = k + j < np ? 1u : 0u;
+                nf += (c[j] && (tk[j] & TK_RES_FLAG)) ? 1u : 0u;
+            }
+            const uint32_t finc = tk_wave_scan_u32(nf, lane);
+            if (nf) {  // results of the flagged pieces: sequential in rflag
+                uint32_t at = mb + fbase + finc - nf;
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+                    if (c[j] && (tk[j] & TK_RES_FLAG)) {
+                        const uint2 v = rflag[at++];
+                        c[j] = v.x;
+                        tk[j] = v.y;
+                    }
+            }
+            fbase += (uint32_t)__shfl((int)finc, 63, 64);
             const uint32_t mine = c[0] + c[1] + c[2] + c[3];
             const uint32_t inc = tk_wave_scan_u32(mine, lane);
             const uint32_t o = run + inc - mine;
             const bool four = c[0] == 1u && c[1] == 1u && c[2] == 1u && c[3] == 1u;
             if (four) {
-                *(uint4*)(out + o) = t4;  // (4-byte aligned 16-byte store)
+                *(uint4*)(out + o) = make_uint4(tk[0], tk[1], tk[2], tk[3]);  // (4-byte aligned 16-byte store)
             } else {
                 uint32_t oo = o;
 #pragma unroll
@@ -1026,21 +1115,41 @@ __global__ __launch_bounds__(1024) void tk_k_sum_pieces(const uint32_t* __restri
     }
 }
 
-// tok_off[d] = tokens before the piece at which document d starts (one wavefront per document)
-__global__ __launch_bounds__(256) void tk_k_docoff(uint64_t n_docs, const uint32_t* __restrict__ doc_pid, const uint32_t* __restrict__ tile_tb,
-                                                    const uint32_t* __restrict__ cnt, const uint64_t* __restrict__ total,
-                                                    uint64_t tok_base_global, uint64_t* __restrict__ tok_off) {
+// tok_off[d] = tokens before the piece at which document d starts (one wavefront per document).  The piece is found in the piece-start
+// bitmap of the document's tile (a document start is a hard piece start); its token offset is the tile's base plus the counts of the
+// tile's pieces before it -- single tokens count one, the others are read from rflag in order.
+__global__ __launch_bounds__(256) void tk_k_docoff(uint64_t n_docs, const uint64_t* __restrict__ doc_off, uint64_t chunk_base, uint64_t n,
+                                                    const uint32_t* __restrict__ starts, const uint32_t* __restrict__ tile_tb,
+                                                    const uint32_t* __restrict__ res, const uint2* __restrict__ rflag,
+                                                    const uint64_t* __restrict__ total, uint64_t tok_base_global, uint64_t* __restrict__ tok_off) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
     for (uint64_t d = wave; d <= n_docs; d += nwaves) {
-        const uint32_t pid = d < n_docs ? doc_pid[d] : TKF_NONE;
+        const uint64_t pos = d < n_docs ? doc_off[d] - chunk_base : n;
         uint64_t v;
-        if (pid == TKF_NONE) {
+        if (pos >= n) {
             v = total[0];  // empty documents at the end of the chunk, and the closing offset
         } else {
-            const uint32_t t = pid / TKF_CAP, rb = t * TKF_CAP;
-            uint32_t sum = 0;
-            for (uint32_t j = rb + lane; j < pid; j += 64) sum += cnt[j];
+            const uint32_t t = (uint32_t)(pos / TK_TILE), in_tile = (uint32_t)(pos - (uint64_t)t * TK_TILE);
+            // pieces of the tile that start before pos
+            uint32_t kp = 0;
+            const uint32_t* sw = starts + (uint64_t)t * (TK_TILE / 32);
+            for (uint32_t w = lane; w * 32 < in_tile; w += 64) {
+                const uint32_t bits = sw[w], rem = in_tile - w * 32;
+                kp += (uint32_t)__popc(rem >= 32u ? bits : (bits & ((1u << rem) - 1u)));
+            }
+            kp = tk_wave_sum_u32(kp);
+            const uint32_t rb = t * TKF_CAP, mb = t * TKF_MISS_CAP;
+            uint32_t sum = 0, fbase = 0;
+            for (uint32_t k0 = 0; k0 < kp; k0 += 64) {
+                const uint32_t k = k0 + lane;
+                const bool flagged = k < kp && (res[rb + k] & TK_RES_FLAG);
+                const uint64_t fm = __ballot(flagged);
+                uint32_t c = k < kp ? 1u : 0u;
+                if (flagged) c = rflag[mb + fbase + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))].x;
+                fbase += (uint32_t)__popcll(fm);
+                sum += c;
+            }
             v = (uint64_t)tile_tb[t] + tk_wave_sum_u32(sum);
         }
         if (lane == 0) tok_off[d] = tok_base_global + v;
@@ -1055,13 +1164,11 @@ __global__ void tk_k_single_front(TkTables T, const uint8_t* __restrict__ text, 
     uint32_t nm = 0;
     const uint32_t r = (no_lookup && n > 1u) ? TK_RANK_MAX : tk_lookup_text_piece(T, text, 0, n);
     if (r != TK_RANK_MAX) {
-        out.tok1[0] = r;
-        out.cnt[0] = 1;
-    } else if (n > TK_GLANE_MAX) {
-        tk_append_tree(out.listC, out.counters, 0, 0, n);
+        out.res[0] = r;
     } else {
-        out.miss_s[0] = 0;
-        out.miss_kl[0] = (n - 1u) << 12;
+        out.res[0] = TK_RES_FLAG | 0u;
+        out.miss[0] = make_uint2(0u, n);
+        if (n > TK_GLANE_MAX) tk_append_tree(out.listC, out.counters, 0, 0, n);
         nm = 1;
     }
     out.tile_nmiss[0] = nm;

@@ -49,13 +49,35 @@ uint64_t tk_key_of_bytes(const uint8_t* p, uint32_t len) {
 
 uint32_t TkHostTables::lookup_piece(const uint8_t* p, uint32_t len) const {
     if (len == 0) return TK_RANK_MAX;
+    if (len <= 8) {
+        uint64_t key = 0;
+        memcpy(&key, p, len);
+        if (len <= 4 && !short_tab.empty()) {
+            uint32_t i = tk_short_slot((uint32_t)key, short_shift);
+            for (;;) {
+                const TkShortSlot& s = short_tab[i];
+                if (s.val == TK_SHORT_EMPTY) return TK_RANK_MAX;
+                if (s.key == (uint32_t)key && (s.val >> 30) == len - 1) return s.val & TK_SHORT_MAX_RANK;
+                i = (i + 1) & short_mask;
+            }
+        }
+        if (mid_tab.empty()) return TK_RANK_MAX;
+        uint32_t i = tk_mid_slot(key, mid_shift);
+        for (;;) {
+            const TkPieceSlot& s = mid_tab[i];
+            if (s.len == 0) return TK_RANK_MAX;
+            if (s.key == key && s.len == len) return s.rank;
+            i = (i + 1) & mid_mask;
+        }
+    }
+    if (piece.empty()) return TK_RANK_MAX;
     uint64_t key = tk_key_of_bytes(p, len);
     uint64_t i = tk_piece_slot_hash(key, len) & piece_mask;
     for (;;) {
         const TkPieceSlot& s = piece[i];
         if (s.key == TK_EMPTY_KEY && s.len == 0) return TK_RANK_MAX;
         if (s.key == key && s.len == len) {
-            if (len <= 8 || memcmp(tok_bytes.data() + piece_off[i], p, len) == 0) return s.rank;
+            if (memcmp(tok_bytes.data() + piece_off[i], p, len) == 0) return s.rank;
         }
         i = (i + 1) & piece_mask;
     }
@@ -99,15 +121,41 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
     T.tok_bytes.assign(ranks_blob, ranks_blob + ranks_off[n_ranks]);
     T.tok_bytes.resize(T.tok_bytes.size() + 16, 0);  // device verification reads whole 8-byte words
 
-    // piece table (bytes -> rank)
+    // piece tables (bytes -> rank), split by length
+    uint32_t max_rank = 0;
+    uint64_t n_short = 0, n_mid = 0, n_long = 0;
+    for (uint64_t k = 0; k < n_ranks; ++k) {
+        max_rank = std::max(max_rank, ranks_ids[k] == TK_RANK_MAX ? 0u : ranks_ids[k]);
+        const uint64_t len = ranks_off[k + 1] - ranks_off[k];
+        (len <= 4 ? n_short : (len <= 8 ? n_mid : n_long)) += 1;
+    }
+    for (uint64_t k = 0; k < n_spec; ++k) max_rank = std::max(max_rank, spec_ids[k]);
+    if (max_rank >= 0x80000000u)
+        return "token ids of 2^31 and above are not supported (the per-piece result word keeps its top bit for pieces that are not a "
+               "single token)";
+    const bool use_short = max_rank <= TK_SHORT_MAX_RANK;
+    if (!use_short) {
+        n_mid += n_short;
+        n_short = 0;
+    }
+    auto pow2_for = [](uint64_t items, uint32_t* mask, uint32_t* shift) {  // load factor <= 0.5
+        uint32_t bits = 6;
+        while ((1ull << bits) < 2 * items + 2) ++bits;
+        *mask = (uint32_t)((1ull << bits) - 1);
+        *shift = 32 - bits;
+        return (uint64_t)1 << bits;
+    };
+    if (use_short) T.short_tab.assign(pow2_for(n_short, &T.short_mask, &T.short_shift), TkShortSlot{0xFFFFFFFFu, TK_SHORT_EMPTY});
+    T.mid_tab.assign(pow2_for(n_mid, &T.mid_mask, &T.mid_shift), TkPieceSlot{TK_EMPTY_KEY, TK_RANK_MAX, 0});
     uint64_t cap = 64;
-    while (cap < 2 * n_ranks + 2) cap <<= 1;
+    while (cap < 2 * n_long + 2) cap <<= 1;
     T.piece_mask = cap - 1;
     T.piece.assign(cap, TkPieceSlot{TK_EMPTY_KEY, TK_RANK_MAX, 0});
     T.piece_off.assign(cap, 0);
     for (int b = 0; b < 256; ++b) T.byte_rank[b] = TK_RANK_MAX;
     T.pair2.assign(65536, TK_RANK_MAX);
     T.decoder.reserve(n_ranks * 2);
+    uint64_t pr_short = 0, pr_mid = 0, pr_long = 0;
     for (uint64_t k = 0; k < n_ranks; ++k) {
         uint64_t o = ranks_off[k], len64 = ranks_off[k + 1] - o;
         if (len64 == 0) return "mergeable_ranks contains an empty key";
@@ -118,15 +166,44 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
         if (!T.decoder.emplace(rank, std::make_pair((uint32_t)o, len)).second)
             return "Encoder and decoder must be of equal length. Maybe you had duplicate token indices in your "
                    "encoder?";  // src/lib.rs:636-641
-        uint64_t key = tk_key_of_bytes(p, len);
-        uint64_t i = tk_piece_slot_hash(key, len) & T.piece_mask;
-        while (!(T.piece[i].key == TK_EMPTY_KEY && T.piece[i].len == 0)) i = (i + 1) & T.piece_mask;
-        T.piece[i] = TkPieceSlot{key, rank, len};
-        T.piece_off[i] = (uint32_t)o;
+        if (len <= 8) {
+            uint64_t key = 0;
+            memcpy(&key, p, len);
+            if (len <= 4 && use_short) {
+                uint32_t i = tk_short_slot((uint32_t)key, T.short_shift);
+                ++pr_short;
+                while (T.short_tab[i].val != TK_SHORT_EMPTY) {
+                    i = (i + 1) & T.short_mask;
+                    ++pr_short;
+                }
+                T.short_tab[i] = TkShortSlot{(uint32_t)key, rank | ((len - 1) << 30)};
+            } else {
+                uint32_t i = tk_mid_slot(key, T.mid_shift);
+                ++pr_mid;
+                while (T.mid_tab[i].len != 0) {
+                    i = (i + 1) & T.mid_mask;
+                    ++pr_mid;
+                }
+                T.mid_tab[i] = TkPieceSlot{key, rank, len};
+            }
+        } else {
+            uint64_t key = tk_key_of_bytes(p, len);
+            uint64_t i = tk_piece_slot_hash(key, len) & T.piece_mask;
+            ++pr_long;
+            while (!(T.piece[i].key == TK_EMPTY_KEY && T.piece[i].len == 0)) {
+                i = (i + 1) & T.piece_mask;
+                ++pr_long;
+            }
+            T.piece[i] = TkPieceSlot{key, rank, len};
+            T.piece_off[i] = (uint32_t)o;
+        }
         if (len == 1) T.byte_rank[p[0]] = rank;
         if (len == 2) T.pair2[((uint32_t)p[0] << 8) | p[1]] = rank;
         if (len > T.max_token_len) T.max_token_len = len;
     }
+    T.probes_short = n_short ? (double)pr_short / (double)n_short : 0;
+    T.probes_mid = n_mid ? (double)pr_mid / (double)n_mid : 0;
+    T.probes_long = n_long ? (double)pr_long / (double)n_long : 0;
     for (int b = 0; b < 256; ++b)
         if (T.byte_rank[b] == TK_RANK_MAX)
             return "every single byte must be a key of mergeable_ranks (byte_pair_encode indexes ranks[piece] for "

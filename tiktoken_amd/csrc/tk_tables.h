@@ -12,9 +12,14 @@
 struct TkHostTables {
     int pattern = -1;
     std::vector<uint8_t> tok_bytes;
-    std::vector<TkPieceSlot> piece;
+    std::vector<TkShortSlot> short_tab;  // tokens of 1..4 bytes (empty when a rank exceeds TK_SHORT_MAX_RANK)
+    uint32_t short_mask = 0, short_shift = 0;
+    std::vector<TkPieceSlot> mid_tab;    // tokens of 5..8 bytes (1..8 without a short table)
+    uint32_t mid_mask = 0, mid_shift = 0;
+    std::vector<TkPieceSlot> piece;      // tokens of more than 8 bytes
     std::vector<uint32_t> piece_off;
     uint64_t piece_mask = 0;
+    double probes_short = 0, probes_mid = 0, probes_long = 0;  // average slots inspected per stored token (build statistics)
     std::vector<TkPairSlot> pair;   // wide format (empty when packed)
     std::vector<uint64_t> pair8;    // packed format (empty when wide)
     uint64_t pair_mask = 0;
