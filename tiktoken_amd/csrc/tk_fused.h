@@ -33,6 +33,8 @@
 
 #define TKF_NONE 0xFFFFFFFFu
 #define TKF_MISS_CAP 2048  // missed pieces per tile: each is at least two bytes long
+#define TKF_CHAIN_END 0xFFFFFFFFFFFFFFFFull
+#define TKF_CONT_CAP 256  // continuation list of the scanners
 #define TKF_BATCH 960  // pieces per probe batch of the front kernel (the class lists hold 1024 entries, their packed counter 1023)
 #define TKF_CAP 4096  // piece ids per tile: pid = tile * TKF_CAP + k (a 4096-byte tile starts at most 4096 pieces)
 
@@ -167,7 +169,8 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
     __shared__ uint32_t bits[TK_TILE / 32];
     __shared__ uint32_t woff[TK_TILE / 32 + 1];
     __shared__ uint8_t lastc[256];
-    __shared__ uint32_t np_sh, nmiss_sh, need_walk, last_end_sh, ncls_sh, nx_sh;
+    __shared__ uint32_t np_sh, nmiss_sh, need_walk, last_end_sh, ncls_sh, nx_sh, ncont_sh;
+    __shared__ uint16_t contl[TKF_CONT_CAP];  // scan chains that continue after their first piece (window positions)
     __shared__ uint32_t brkw[TK2_WIN / 32 + 1], ssw[TK2_WIN / 32 + 1], siw[TK2_WIN / 32 + 1];
     __shared__ uint32_t scan_sh[8];
     uint64_t(*bm)[NW] = (uint64_t(*)[NW])pool;
@@ -217,6 +220,7 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
     if (tid == 0) {
         nmiss_sh = 0;
         need_walk = 0;
+        ncont_sh = 0;
         last_end_sh = (uint32_t)(tile_end - tile_start) + TK2_LEFT;
     }
     if (tid < TKB_KINDS) {
@@ -340,48 +344,82 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
     // ---- D: one lane per scan start; only boundaries inside the tile are recorded
     const uint32_t* planes32 = (const uint32_t*)planes;
     TkWin2Acc acc{planes32, (const uint32_t*)bm[TKB_START], (const uint32_t*)bm[TKB_HARD], raw, base, &T, text, n, brk, ss, si};
+    // One evaluation: the piece that starts at p.  Returns its end when the scan has to go on from there (an uncertain boundary,
+    // recorded here when it lies inside the tile), or TKF_CHAIN_END when the chain ends (tile end, or a certain start that has its
+    // own scanner).
+    auto piece_from = [&](uint64_t p) -> uint64_t {
+        const int64_t r = (int64_t)p - base;
+        uint32_t len = 0;
+        if (r >= 0 && r + 64 <= TK2_WIN) {
+            const uint32_t wi = (uint32_t)r >> 6, sh = (uint32_t)r & 63u;
+            const uint32_t c = tk_class_at_lds(planes32, (uint32_t)r);
+            {  // most pieces are short: 32-position windows first (a third of the vector-ALU work of the 64-bit form)
+                const TkWinLds32 w32((const uint32_t(*)[2 * NW])bm, (uint32_t)r);
+                len = tk_piece_len_bits32(w32, acc, p, c, pat);
+            }
+            if (len == 0) {
+                const TkWinLds wl(bm, wi, sh);
+                TkBmExt ext{bm, wi, sh, (uint32_t)(TK2_WIN - r)};
+                len = tk_piece_len_bits(wl, acc, ext, p, c, pat);
+            }
+        }
+        uint64_t e = len ? p + len : tk_piece_end_slow(&acc, p, pat);
+        if (e > n) e = n;
+        if (e >= tile_end) {  // the piece that reaches the tile end: remember where it ends (clamped to the 32-bit window offset)
+            if (p < tile_end) {
+                uint64_t rel = e - (uint64_t)base;
+                last_end_sh = rel > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)rel;
+            }
+            return TKF_CHAIN_END;
+        }
+        if (e >= tile_start) {
+            const uint32_t re = (uint32_t)((int64_t)e - base);  // inside the window (e < tile_end)
+            if ((certw[re >> 5] >> (re & 31u)) & 1u) return TKF_CHAIN_END;  // a certain start: another lane scans from there
+            atomicOr(&bits[(uint32_t)(e - tile_start) >> 5], 1u << ((uint32_t)(e - tile_start) & 31));
+        }
+        return e;
+    };
     auto scan_from = [&](uint64_t p) {
-        for (;;) {
-            const int64_t r = (int64_t)p - base;
-            uint32_t len = 0;
-            if (r >= 0 && r + 64 <= TK2_WIN) {
-                const uint32_t wi = (uint32_t)r >> 6, sh = (uint32_t)r & 63u;
-                const uint32_t c = tk_class_at_lds(planes32, (uint32_t)r);
-                {  // most pieces are short: 32-position windows first (a third of the vector-ALU work of the 64-bit form)
-                    const TkWinLds32 w32((const uint32_t(*)[2 * NW])bm, (uint32_t)r);
-                    len = tk_piece_len_bits32(w32, acc, p, c, pat);
-                }
-                if (len == 0) {
-                    const TkWinLds wl(bm, wi, sh);
-                    TkBmExt ext{bm, wi, sh, (uint32_t)(TK2_WIN - r)};
-                    len = tk_piece_len_bits(wl, acc, ext, p, c, pat);
-                }
+        while (p != TKF_CHAIN_END) p = piece_from(p);
+    };
+    // Round 1: ONE piece per scan start, all lanes busy.  94..98 % of the pieces end at a certain start; the few chains that go on
+    // (an uncertain boundary) are collected and walked in round 2 by a handful of lanes -- a wavefront does not repeat the whole
+    // evaluation for its slowest lane.
+    auto round1 = [&](uint64_t p, bool active) {
+        const uint64_t e = active ? piece_from(p) : TKF_CHAIN_END;
+        const bool go_on = e != TKF_CHAIN_END;
+        const uint64_t m = __ballot(go_on);
+        if (m) {
+            uint32_t at = 0;
+            const int leader = __ffsll((unsigned long long)m) - 1;
+            if (lane == leader) at = atomicAdd(&ncont_sh, (uint32_t)__popcll(m));
+            at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (go_on) {
+                // (a chain that goes on is still left of the tile end; left of the window only on the walk-back path, never here)
+                if (at < TKF_CONT_CAP && (int64_t)e >= base) contl[at] = (uint16_t)(e - (uint64_t)base);
+                else scan_from(e);  // list full: walk the chain right here
             }
-            uint64_t e = len ? p + len : tk_piece_end_slow(&acc, p, pat);
-            if (e > n) e = n;
-            if (e >= tile_end) {  // the piece that reaches the tile end: remember where it ends (clamped to the 32-bit window offset)
-                if (p < tile_end) {
-                    uint64_t rel = e - (uint64_t)base;
-                    last_end_sh = rel > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)rel;
-                }
-                break;
-            }
-            if (e >= tile_start) {
-                const uint32_t re = (uint32_t)((int64_t)e - base);  // inside the window (e < tile_end)
-                if ((certw[re >> 5] >> (re & 31u)) & 1u) break;    // a certain start: another lane scans from there
-                atomicOr(&bits[(uint32_t)(e - tile_start) >> 5], 1u << ((uint32_t)(e - tile_start) & 31));
-            }
-            p = e;
         }
     };
     if (listed) {
-        for (uint32_t i = tid; i < n_front + n_back; i += 256)
-            scan_from((uint64_t)(base + (i < n_front ? clist[i] : clist[TK2_CLIST - 1u - (i - n_front)])));
+        const uint32_t total = n_front + n_back;
+        for (uint32_t i0 = 0; i0 < total; i0 += 256) {
+            const uint32_t i = i0 + tid;
+            const bool active = i < total;
+            round1(active ? (uint64_t)(base + (i < n_front ? clist[i] : clist[TK2_CLIST - 1u - (i - n_front)])) : 0, active);
+        }
     } else {  // more starts than the list holds (a start every other byte): every lane walks its own
         if (extra != TKF_NONE) scan_from((uint64_t)(base + extra));
         for (uint32_t m = mine; m; m &= m - 1) scan_from((uint64_t)(base + (int64_t)(tid * 16u + (uint32_t)__ffs((int)m) - 1u)));
     }
-    if (tid == 0 && need_walk) scan_from(tk_certain_before(&T, text, n, brk, ss, si, tile_start - 1, pat));
+    if (tid == 0 && need_walk) {
+        scan_from(tk_certain_before(&T, text, n, brk, ss, si, tile_start - 1, pat));
+    }
+    __syncthreads();
+    {  // round 2: the chains that go on
+        const uint32_t nc = ncont_sh < TKF_CONT_CAP ? ncont_sh : (uint32_t)TKF_CONT_CAP;
+        for (uint32_t i = tid; i < nc; i += 256) scan_from((uint64_t)(base + contl[i]));
+    }
     __syncthreads();
     if (dbg & 0x8000) {  // (perf experiments: stop after this phase)
         if (tid == 0) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
