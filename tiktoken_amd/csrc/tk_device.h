@@ -615,36 +615,48 @@ TK_HD uint32_t tk_piece_len_bits32(const W32& w, A& a, uint64_t p, uint32_t c, i
 // ------------------------------------------------------------------------------------------
 // table probes
 // ------------------------------------------------------------------------------------------
-// Exact bytes -> rank probes, one per length class (tk_common.h).  Short: key = the 1..4 bytes packed little-endian.
-TK_HD uint32_t tk_probe_short(const TkTables& T, uint32_t key, uint32_t len) {
-    uint32_t i = tk_short_slot(key, T.short_shift);
+// Exact bytes -> rank probes, one per length class (tk_common.h).  The `_from` forms continue from a slot the caller has already
+// loaded (so that the first loads of several independent probes can be in flight together).
+// Short: key = the 1..4 bytes packed little-endian.
+TK_HD uint32_t tk_probe_short_from(const TkTables& T, uint32_t key, uint32_t len, uint32_t i, TkShortSlot s) {
     for (;;) {
-        const TkShortSlot s = T.short_tab[i];
         if (s.key == key && (s.val >> 30) == len - 1u && s.val != TK_SHORT_EMPTY) return s.val & TK_SHORT_MAX_RANK;
         if (s.val == TK_SHORT_EMPTY) return TK_RANK_MAX;
         i = (i + 1u) & T.short_mask;
+        s = T.short_tab[i];
     }
 }
+TK_HD uint32_t tk_probe_short(const TkTables& T, uint32_t key, uint32_t len) {
+    const uint32_t i = tk_short_slot(key, T.short_shift);
+    return tk_probe_short_from(T, key, len, i, T.short_tab[i]);
+}
 // Mid: key = the bytes (<= 8) packed little-endian.
-TK_HD uint32_t tk_probe_mid(const TkTables& T, uint64_t key, uint32_t len) {
-    uint32_t i = tk_mid_slot(key, T.mid_shift);
+TK_HD uint32_t tk_probe_mid_from(const TkTables& T, uint64_t key, uint32_t len, uint32_t i, TkPieceSlot s) {
     for (;;) {
-        const TkPieceSlot s = T.mid_tab[i];
         if (s.key == key && s.len == len) return s.rank;
         if (s.len == 0u) return TK_RANK_MAX;
         i = (i + 1u) & T.mid_mask;
+        s = T.mid_tab[i];
     }
+}
+TK_HD uint32_t tk_probe_mid(const TkTables& T, uint64_t key, uint32_t len) {
+    const uint32_t i = tk_mid_slot(key, T.mid_shift);
+    return tk_probe_mid_from(T, key, len, i, T.mid_tab[i]);
 }
 // Long (> 8 bytes): key = tk hash of the bytes; the candidate is verified byte for byte against the token blob through `verify(off)`.
 template <class Verify>
-TK_HD uint32_t tk_probe_piece(const TkTables& T, uint64_t key, uint32_t len, Verify verify) {
-    uint64_t i = tk_piece_slot_hash(key, len) & T.piece_mask;
+TK_HD uint32_t tk_probe_piece_from(const TkTables& T, uint64_t key, uint32_t len, uint64_t i, TkPieceSlot s, Verify verify) {
     for (;;) {
-        TkPieceSlot s = T.piece[i];
         if (s.key == TK_EMPTY_KEY && s.len == 0u) return TK_RANK_MAX;
         if (s.key == key && s.len == len && verify(T.piece_off[i])) return s.rank;
         i = (i + 1) & T.piece_mask;
+        s = T.piece[i];
     }
+}
+template <class Verify>
+TK_HD uint32_t tk_probe_piece(const TkTables& T, uint64_t key, uint32_t len, Verify verify) {
+    const uint64_t i = tk_piece_slot_hash(key, len) & T.piece_mask;
+    return tk_probe_piece_from(T, key, len, i, T.piece[i], verify);
 }
 
 // Pair probe.  Packed format: 4-slot (32-byte, 32-byte-aligned) buckets; a bucket is fetched with two

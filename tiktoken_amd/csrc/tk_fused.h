@@ -379,48 +379,56 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
         }
         return e;
     };
-    auto scan_from = [&](uint64_t p) {
-        while (p != TKF_CHAIN_END) p = piece_from(p);
-    };
-    // Round 1: ONE piece per scan start, all lanes busy.  94..98 % of the pieces end at a certain start; the few chains that go on
-    // (an uncertain boundary) are collected and walked in round 2 by a handful of lanes -- a wavefront does not repeat the whole
-    // evaluation for its slowest lane.
-    auto round1 = [&](uint64_t p, bool active) {
-        const uint64_t e = active ? piece_from(p) : TKF_CHAIN_END;
-        const bool go_on = e != TKF_CHAIN_END;
-        const uint64_t m = __ballot(go_on);
-        if (m) {
-            uint32_t at = 0;
-            const int leader = __ffsll((unsigned long long)m) - 1;
-            if (lane == leader) at = atomicAdd(&ncont_sh, (uint32_t)__popcll(m));
-            at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (go_on) {
-                // (a chain that goes on is still left of the tile end; left of the window only on the walk-back path, never here)
-                if (at < TKF_CONT_CAP && (int64_t)e >= base) contl[at] = (uint16_t)(e - (uint64_t)base);
-                else scan_from(e);  // list full: walk the chain right here
+    // Two rounds around ONE instance of the evaluation (the scanner is big: a second inlined copy spills registers).
+    //   round 0: one piece per scan start, all lanes busy.  94..98 % of the pieces end at a certain start; a chain that goes on (an
+    //            uncertain boundary) is put on the continuation list -- a wavefront does not repeat the evaluation for its slowest lane;
+    //   round 1: the listed chains, the walk-back start and (when the start list overflowed) every lane's own starts, walked to their ends.
+    uint32_t own = listed ? 0u : mine;
+    bool own_extra = !listed && extra != TKF_NONE, walk = tid == 0;
+    for (int round = 0; round < 2; ++round) {
+        const uint32_t cnt = round == 0 ? (listed ? n_front + n_back : 0u) : (ncont_sh < TKF_CONT_CAP ? ncont_sh : (uint32_t)TKF_CONT_CAP);
+        uint32_t i = tid;
+        for (;;) {
+            uint64_t p = TKF_CHAIN_END;
+            if (i < cnt) {
+                p = (uint64_t)(base + (round == 0 ? (i < n_front ? clist[i] : clist[TK2_CLIST - 1u - (i - n_front)]) : contl[i]));
+                i += 256;
+            } else if (round == 1) {
+                if (own_extra) {
+                    own_extra = false;
+                    p = (uint64_t)(base + extra);
+                } else if (own) {
+                    p = (uint64_t)(base + (int64_t)(tid * 16u + (uint32_t)__ffs((int)own) - 1u));
+                    own &= own - 1;
+                } else if (walk) {
+                    walk = false;
+                    if (need_walk) p = tk_certain_before(&T, text, n, brk, ss, si, tile_start - 1, pat);
+                }
+            }
+            if (!__any(p != TKF_CHAIN_END)) break;
+            for (;;) {  // (round 0: one pass, unless the continuation list is full)
+                const uint64_t e = p != TKF_CHAIN_END ? piece_from(p) : TKF_CHAIN_END;
+                bool go_on = e != TKF_CHAIN_END;
+                if (round == 0) {
+                    const uint64_t m = __ballot(go_on);
+                    if (m) {
+                        uint32_t at = 0;
+                        const int leader = __ffsll((unsigned long long)m) - 1;
+                        if (lane == leader) at = atomicAdd(&ncont_sh, (uint32_t)__popcll(m));
+                        at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                        // (a chain that goes on is left of the tile end and, in round 0, inside the window)
+                        if (go_on && at < TKF_CONT_CAP) {
+                            contl[at] = (uint16_t)(e - (uint64_t)base);
+                            go_on = false;
+                        }
+                    }
+                }
+                p = go_on ? e : TKF_CHAIN_END;
+                if (!__any(p != TKF_CHAIN_END)) break;
             }
         }
-    };
-    if (listed) {
-        const uint32_t total = n_front + n_back;
-        for (uint32_t i0 = 0; i0 < total; i0 += 256) {
-            const uint32_t i = i0 + tid;
-            const bool active = i < total;
-            round1(active ? (uint64_t)(base + (i < n_front ? clist[i] : clist[TK2_CLIST - 1u - (i - n_front)])) : 0, active);
-        }
-    } else {  // more starts than the list holds (a start every other byte): every lane walks its own
-        if (extra != TKF_NONE) scan_from((uint64_t)(base + extra));
-        for (uint32_t m = mine; m; m &= m - 1) scan_from((uint64_t)(base + (int64_t)(tid * 16u + (uint32_t)__ffs((int)m) - 1u)));
+        __syncthreads();
     }
-    if (tid == 0 && need_walk) {
-        scan_from(tk_certain_before(&T, text, n, brk, ss, si, tile_start - 1, pat));
-    }
-    __syncthreads();
-    {  // round 2: the chains that go on
-        const uint32_t nc = ncont_sh < TKF_CONT_CAP ? ncont_sh : (uint32_t)TKF_CONT_CAP;
-        for (uint32_t i = tid; i < nc; i += 256) scan_from((uint64_t)(base + contl[i]));
-    }
-    __syncthreads();
     if (dbg & 0x8000) {  // (perf experiments: stop after this phase)
         if (tid == 0) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
         return;
@@ -505,58 +513,82 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
                 if (miss) ord_x[at] = (uint16_t)i;
             }
         };
-        // F1: short pieces: the bytes are the key (one unaligned LDS dword), 8-byte slots
-        for (uint32_t q0 = 0; q0 < n_s; q0 += 256) {
+        // F1..F3 in one loop: a lane takes the q-th short, mid and long piece together, so that the first table loads of the three
+        // independent probes are in flight at the same time (the probes are latency-bound: profiles/r02_front_phases_*.csv).
+        //   short: the bytes are the key (one unaligned LDS dword), 8-byte slots
+        //   mid  : 64-bit key, 16-byte slots
+        //   long : hash of the bytes, candidates verified against the token blob
+        const uint32_t n_max = n_s > n_m ? (n_s > n_l ? n_s : n_l) : (n_m > n_l ? n_m : n_l);
+        for (uint32_t q0 = 0; q0 < n_max; q0 += 256) {
             const uint32_t q = q0 + tid;
-            bool miss = false;
-            uint32_t i = 0;
-            if (q < n_s) {
-                i = ord_sl[q];
-                const uint32_t k = kb + i, s_loc = plist[k], e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
-                const uint32_t len = e_loc - s_loc;
+            const bool has_s = q < n_s, has_m = q < n_m, has_l = q < n_l;
+            uint32_t i_s = 0, i_m = 0, i_l = 0;
+            // short: key and first slot
+            uint32_t k_s = 0, len_s = 1, key_s = 0, at_s = 0;
+            if (has_s) {
+                i_s = ord_sl[q];
+                k_s = kb + i_s;
+                const uint32_t s_loc = plist[k_s], e_loc = k_s + 1 < np ? (uint32_t)plist[k_s + 1] : last_end;
+                len_s = e_loc - s_loc;
                 const uint32_t v = __builtin_amdgcn_alignbyte(dwr[(s_loc >> 2) + 1], dwr[s_loc >> 2], s_loc & 3u);
-                const uint32_t key = v & (0xFFFFFFFFu >> (32u - 8u * len));
-                const uint32_t r = (dbg & 2) ? len : (short_tab ? tk_probe_short(T, key, len) : tk_probe_mid(T, (uint64_t)key, len));
-                if (r != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k] = r == TK_RANK_MAX ? 0u : r;
-                else miss = true;
+                key_s = v & (0xFFFFFFFFu >> (32u - 8u * len_s));
+                at_s = short_tab ? tk_short_slot(key_s, T.short_shift) : tk_mid_slot((uint64_t)key_s, T.mid_shift);
             }
-            not_a_token(miss, i);
-        }
-        // F2: mid pieces: 64-bit key, 16-byte slots
-        for (uint32_t q0 = 0; q0 < n_m; q0 += 256) {
-            const uint32_t q = q0 + tid;
-            bool miss = false;
-            uint32_t i = 0;
-            if (q < n_m) {
-                i = ord_m[q];
-                const uint32_t k = kb + i, s_loc = plist[k], e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
-                const uint32_t len = e_loc - s_loc;
-                const uint64_t key = tk_mask_low_bytes(tk_lds_load8(raw, s_loc), len);
-                const uint32_t r = (dbg & 2) ? len : tk_probe_mid(T, key, len);
-                if (r != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k] = r == TK_RANK_MAX ? 0u : r;
-                else miss = true;
+            TkShortSlot slot_s{0, 0};
+            TkPieceSlot slot_sm{0, 0, 0};
+            if (short_tab) slot_s = T.short_tab[at_s];
+            else slot_sm = T.mid_tab[at_s];
+            // mid: key and first slot
+            uint32_t k_m = 0, len_m = 5, at_m = 0;
+            uint64_t key_m = 0;
+            if (has_m) {
+                i_m = ord_m[q];
+                k_m = kb + i_m;
+                const uint32_t s_loc = plist[k_m], e_loc = k_m + 1 < np ? (uint32_t)plist[k_m + 1] : last_end;
+                len_m = e_loc - s_loc;
+                key_m = tk_mask_low_bytes(tk_lds_load8(raw, s_loc), len_m);
+                at_m = tk_mid_slot(key_m, T.mid_shift);
             }
-            not_a_token(miss, i);
-        }
-        // F3: long pieces: hash of the bytes, candidates verified against the token blob
-        for (uint32_t q0 = 0; q0 < n_l; q0 += 256) {
-            const uint32_t q = q0 + tid;
-            bool miss = false;
-            uint32_t i = 0;
-            if (q < n_l) {
-                i = ord_sl[1023u - q];
-                const uint32_t k = kb + i, s_loc = plist[k], e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
-                const uint32_t len = e_loc - s_loc;
-                const uint64_t gs = (uint64_t)(base + s_loc);
-                const bool in_lds = e_loc + 8u <= (uint32_t)TK2_WIN;
-                const uint64_t key = in_lds ? tk_key_of_lds(raw, s_loc, len) : tk_key_of_text(text, gs, len);
-                const uint32_t r = (dbg & 2) ? len : tk_probe_piece(T, key, len, [&](uint32_t off) {
-                    return in_lds ? tk_equal_lds_text(raw, s_loc, T.tok_bytes, off, len) : tk_equal_bytes(text, gs, T.tok_bytes, off, len);
+            const TkPieceSlot slot_m = T.mid_tab[at_m];
+            // long: hash and first slot
+            uint32_t k_l = 0, len_l = 9, sloc_l = 0;
+            uint64_t key_l = 0, at_l = 0, gs_l = 0;
+            bool in_lds = true;
+            if (has_l) {
+                i_l = ord_sl[1023u - q];
+                k_l = kb + i_l;
+                sloc_l = plist[k_l];
+                const uint32_t e_loc = k_l + 1 < np ? (uint32_t)plist[k_l + 1] : last_end;
+                len_l = e_loc - sloc_l;
+                gs_l = (uint64_t)(base + sloc_l);
+                in_lds = e_loc + 8u <= (uint32_t)TK2_WIN;
+                key_l = in_lds ? tk_key_of_lds(raw, sloc_l, len_l) : tk_key_of_text(text, gs_l, len_l);
+                at_l = tk_piece_slot_hash(key_l, len_l) & T.piece_mask;
+            }
+            const TkPieceSlot slot_l = T.piece[at_l];
+            // resolve
+            bool miss_s = false, miss_m = false, miss_l = false;
+            if (has_s) {
+                const uint32_t r = (dbg & 2) ? len_s : (short_tab ? tk_probe_short_from(T, key_s, len_s, at_s, slot_s)
+                                                                  : tk_probe_mid_from(T, (uint64_t)key_s, len_s, at_s, slot_sm));
+                if (r != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k_s] = r == TK_RANK_MAX ? 0u : r;
+                else miss_s = true;
+            }
+            if (has_m) {
+                const uint32_t r = (dbg & 2) ? len_m : tk_probe_mid_from(T, key_m, len_m, at_m, slot_m);
+                if (r != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k_m] = r == TK_RANK_MAX ? 0u : r;
+                else miss_m = true;
+            }
+            if (has_l) {
+                const uint32_t r = (dbg & 2) ? len_l : tk_probe_piece_from(T, key_l, len_l, at_l, slot_l, [&](uint32_t off) {
+                    return in_lds ? tk_equal_lds_text(raw, sloc_l, T.tok_bytes, off, len_l) : tk_equal_bytes(text, gs_l, T.tok_bytes, off, len_l);
                 });
-                if (r != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k] = r == TK_RANK_MAX ? 0u : r;
-                else miss = true;
+                if (r != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k_l] = r == TK_RANK_MAX ? 0u : r;
+                else miss_l = true;
             }
-            not_a_token(miss, i);
+            not_a_token(miss_s, i_s);
+            not_a_token(miss_m, i_m);
+            not_a_token(miss_l, i_l);
         }
         __syncthreads();
         // F4: pieces that are not tokens.  In-call de-duplication: claim a slot of the miss table (first occurrence: goes on the
