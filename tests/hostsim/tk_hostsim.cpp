@@ -29,7 +29,10 @@ struct FlatAcc {
     uint32_t byte(uint64_t pos) const { return text[pos]; }
 };
 
+static uint64_t g_flat_mismatch = 0;
+
 extern "C" {
+uint64_t tks_flat_mismatches() { return g_flat_mismatch; }
 
 void* tks_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uint32_t* ranks_ids, uint64_t n_ranks,
                  const uint8_t* spec_blob, const uint64_t* spec_off, const uint32_t* spec_ids, uint64_t n_spec,
@@ -252,6 +255,7 @@ uint64_t tks_pretok_bits(void* pv, const uint8_t* text_in, uint64_t n, const uin
                 uint32_t get(int kind) const { return (uint32_t)w->get(kind); }
             } w32{&w, (uint32_t)w.start, (uint32_t)w.stop};
             uint32_t len = tk_piece_len_bits32(w32, acc, q, cls2[q] & 15u, pat);
+            if (tk_piece_len_flat32(w32, acc, q, cls2[q] & 15u, pat) != len) ++g_flat_mismatch;  // the kernel's branch-free form
             if (len) ++n_fast32;
             else len = tk_piece_len_bits(w, acc, ext, q, cls2[q] & 15u, pat);
             uint64_t e;
