@@ -27,12 +27,26 @@ struct FlatAcc {
     uint64_t n;
     uint32_t cls(uint64_t pos) const { return pos >= n ? (uint32_t)TK_C_END : cls_[pos]; }
     uint32_t byte(uint64_t pos) const { return text[pos]; }
+    // run queries of tk_piece_end_runs, answered by plain loops (the kernel answers them with the whole workgroup)
+    uint64_t run_end(uint64_t from, uint32_t mask) const {
+        uint64_t s = from;
+        while ((mask >> tk_la(*this, s)) & 1u) s = tk_next_char(*this, s);
+        return s;
+    }
+    uint64_t last_in(uint64_t from, uint64_t to, uint32_t mask) const {
+        uint64_t best = TK_NO_POS;
+        for (uint64_t i = from; i < to && i < n; ++i) {
+            const uint32_t c = cls_[i] & 15u;
+            if (c != TK_C_CONT && ((mask >> c) & 1u)) best = i;
+        }
+        return best;
+    }
 };
 
-static uint64_t g_flat_mismatch = 0;
+static uint64_t g_runs_mismatch = 0;
 
 extern "C" {
-uint64_t tks_flat_mismatches() { return g_flat_mismatch; }
+uint64_t tks_runs_mismatches() { return g_runs_mismatch; }
 
 void* tks_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uint32_t* ranks_ids, uint64_t n_ranks,
                  const uint8_t* spec_blob, const uint64_t* spec_off, const uint32_t* spec_ids, uint64_t n_spec,
@@ -123,6 +137,7 @@ uint64_t tks_pretok(void* p, const uint8_t* text_in, uint64_t n, const uint64_t*
         uint64_t q = i;
         for (;;) {
             uint64_t e = tk_piece_end(acc, q, pat);
+            if (tk_piece_end_runs(acc, q, pat) != e) ++g_runs_mismatch;  // the run-query form must agree everywhere
             if (e <= q) e = tk_next_char(acc, q);
             if (e >= n) break;
             uint32_t ce = acc.cls(e);
@@ -255,7 +270,6 @@ uint64_t tks_pretok_bits(void* pv, const uint8_t* text_in, uint64_t n, const uin
                 uint32_t get(int kind) const { return (uint32_t)w->get(kind); }
             } w32{&w, (uint32_t)w.start, (uint32_t)w.stop};
             uint32_t len = tk_piece_len_bits32(w32, acc, q, cls2[q] & 15u, pat);
-            if (tk_piece_len_flat32(w32, acc, q, cls2[q] & 15u, pat) != len) ++g_flat_mismatch;  // the kernel's branch-free form
             if (len) ++n_fast32;
             else len = tk_piece_len_bits(w, acc, ext, q, cls2[q] & 15u, pat);
             uint64_t e;

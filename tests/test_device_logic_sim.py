@@ -231,18 +231,18 @@ def test_chunk_classification_equals_per_byte_reference(name):
     assert sim.chunk_check(blob, off, ss, si, tile=64, left=16, win=128) == (0, 0, 0)
 
 
-def test_branch_free_scanner_equals_the_branching_one():
-    """tk_piece_len_flat32 (what tk_k_front runs) against tk_piece_len_bits32 on every piece start of corpora and adversarial
-    documents, all three patterns: same length or the same "not decided in the window" answer."""
+def test_run_query_scanner_equals_the_byte_walking_one():
+    """tk_piece_end_runs (the scanner over run queries that the front kernel uses for pieces that leave a tile's window) against
+    tk_piece_end at every piece start of corpora and adversarial documents, all three patterns."""
     rng = np.random.default_rng(11)
-    before = h.sim_lib().tks_flat_mismatches()
+    before = h.sim_lib().tks_runs_mismatches()
     for name in h.ENCODING_NAMES:
         sim = h.HostSim(h.PAT_STR[h.PATTERN_OF[name]], h.load_vocab(name), h.SPECIALS[name])
         for mix in (0, 1):
             blob, off = h.gen_corpus(0xF1A7 + mix, mix, 1 << 19)
-            ends, _ = sim.piece_ends(blob, off, bits=True)
-            want, _ = sim.piece_ends(blob, off)
-            assert np.array_equal(ends, want)
+            sim.piece_ends(blob, off)
         docs = ["".join(rng.choice(h.ADV, size=int(rng.integers(0, 40)))).encode() for _ in range(5000)]
-        sim.piece_ends(*h.pack(docs), bits=True)
-    assert h.sim_lib().tks_flat_mismatches() == before
+        sim.piece_ends(*h.pack(docs))
+        for rep in ("x", " ", "中", "1", "\n", "!", "a\u0301", "Aa", " \n"):
+            sim.piece_ends(*h.pack([(rep * 700).encode(), ("z" + rep * 300 + "'ll").encode()]))
+    assert h.sim_lib().tks_runs_mismatches() == before

@@ -275,6 +275,94 @@ TK_HD uint64_t tk_piece_end(A& a, uint64_t p, int pat) {
 }
 
 // ------------------------------------------------------------------------------------------
+// The same scanner written over RUN QUERIES instead of a byte walk: for pieces that leave a tile's LDS window (a run of a million
+// letters, spaces or CJK chars is one piece: reference tests/test_encoding.py:52-57,113-124) the front kernel answers each query
+// with the whole workgroup, 4 KiB per step, so that such a piece costs microseconds per KiB instead of microseconds per byte.
+// R provides  cls(pos), byte(pos)                  as the accessors above (single positions)
+//             run_end(from, mask)                  = tk_run_end: first char start s >= from whose look-ahead class is not in mask
+//             last_in(from, to, mask)              start of the last char of [from, to) whose class nibble is in mask, or ~0
+// Must return exactly what tk_piece_end returns (checked on the CPU for every piece of the test corpora).
+// ------------------------------------------------------------------------------------------
+#define TK_NO_POS 0xFFFFFFFFFFFFFFFFull
+template <class R>
+TK_HD uint64_t tk_ws_tail_runs(R& r, uint64_t p, int pat) {
+    const uint32_t c0 = r.cls(p) & 15u;
+    if (!((TK_M_WS >> c0) & 1u)) return p;
+    const uint64_t p1 = tk_next_char(r, p);
+    const uint64_t q = r.run_end(p1, TK_M_WS);
+    const bool at_end = tk_la(r, q) == TK_C_END;
+    if (pat != TK_PAT_O200K && at_end) return q;
+    if (pat != TK_PAT_R50K) {
+        const uint64_t nlp = r.last_in(p, q, TK_CB(TK_C_NL));
+        if (nlp != TK_NO_POS) return nlp + 1;  // (\r and \n are single bytes)
+    }
+    if (at_end) return q;
+    if (q > p1) return r.last_in(p, q, TK_M_WS);  // two or more chars: back off one
+    return q;
+}
+template <class R>
+TK_HD uint64_t tk_o200k_word_runs(R& r, uint64_t s, uint32_t c_first) {
+    uint64_t r_end = s;
+    if ((TK_M_UPPERISH >> c_first) & 1u) r_end = r.run_end(tk_next_char(r, s), TK_M_UPPERISH);
+    uint32_t c = r_end == s ? c_first : tk_la(r, r_end);
+    uint64_t t_end = r_end;
+    if ((TK_M_LOWERISH >> c) & 1u) {
+        t_end = r.run_end(tk_next_char(r, r_end), TK_M_LOWERISH);
+        c = tk_la(r, t_end);
+    }
+    uint64_t e;
+    if (t_end > r_end) {
+        e = t_end;
+    } else {
+        const uint64_t lc = r_end > s ? r.last_in(s, r_end, TK_CB(TK_C_LC) | TK_CB(TK_C_MK)) : TK_NO_POS;
+        if (lc != TK_NO_POS) {
+            e = tk_next_char(r, lc);
+            c = tk_la(r, e);
+        } else {
+            e = r_end;
+        }
+    }
+    if (c == TK_C_AP) e += tk_contraction_len(r, e, true);
+    return e;
+}
+template <class R>
+TK_HD uint64_t tk_piece_end_runs(R& r, uint64_t p, int pat) {
+    const uint32_t c = r.cls(p) & 15u;
+    const uint64_t p1 = tk_next_char(r, p);
+    if (c == TK_C_SPEC) return p1;
+    const uint32_t nxt = tk_la(r, p1);
+    if (pat == TK_PAT_O200K) {
+        if ((TK_M_WORD >> c) & 1u) return tk_o200k_word_runs(r, p, c);
+        if (c != TK_C_NL && c != TK_C_NU && ((TK_M_WORD >> nxt) & 1u)) return tk_o200k_word_runs(r, p1, nxt);
+        if (c == TK_C_NU) return tk_digits3(r, p);
+    } else {
+        if (c == TK_C_AP) {
+            const uint32_t k = tk_contraction_len(r, p, pat == TK_PAT_CL100K);
+            if (k) return p + k;
+        }
+        if (pat == TK_PAT_CL100K) {
+            if (((TK_M_L >> c) & 1u) || (c != TK_C_NL && c != TK_C_NU && ((TK_M_L >> nxt) & 1u))) return r.run_end(p1, TK_M_L);
+            if (c == TK_C_NU) return tk_digits3(r, p);
+        }
+    }
+    uint64_t s = p;
+    uint32_t k = c;
+    if (c == TK_C_SP && nxt != TK_C_END) {
+        s = p1;
+        k = nxt;
+    }
+    if (pat == TK_PAT_R50K) {
+        if ((TK_M_L >> k) & 1u) return r.run_end(tk_next_char(r, s), TK_M_L);
+        if (k == TK_C_NU) return r.run_end(tk_next_char(r, s), TK_CB(TK_C_NU));
+        if ((TK_M_OTHER >> k) & 1u) return r.run_end(tk_next_char(r, s), TK_M_OTHER);
+    } else if ((TK_M_OTHER >> k) & 1u) {
+        const uint64_t e = r.run_end(tk_next_char(r, s), TK_M_OTHER);
+        return r.run_end(e, pat == TK_PAT_O200K ? (TK_CB(TK_C_NL) | TK_CB(TK_C_SL)) : TK_CB(TK_C_NL));
+    }
+    return tk_ws_tail_runs(r, p, pat);
+}
+
+// ------------------------------------------------------------------------------------------
 // Bit-parallel form of the scanner.  The pre-tokeniser kernel keeps, per tile, one bitmap per class
 // set (bit = text byte; continuation bytes carry the class of their char).  At a piece start p it
 // extracts 64-bit windows (bit k <-> position p + k); run ends are then `ctz` of a masked window
@@ -610,108 +698,6 @@ TK_HD uint32_t tk_piece_len_bits32(const W32& w, A& a, uint64_t p, uint32_t c, i
     if (at_end) return q;
     if (tk_w32_popc(st) >= 2u) return 31u - tk_w32_clz(st);
     return q;
-}
-
-// ------------------------------------------------------------------------------------------
-// Branch-free form of the 32-bit fast path.  Same rules and the same "0 = not decided inside the window" contract as
-// tk_piece_len_bits32, but every alternative of the pattern is evaluated on the windows and the result is SELECTED, so that the
-// lanes of a wavefront -- which start at pieces of different kinds -- do not serialise one another's branches (measured on the
-// round-2 kernel: 380 vector + 230 scalar instructions per wavefront evaluation with branches).  Only the contraction check,
-// which has to read text bytes, stays conditional.
-// ------------------------------------------------------------------------------------------
-TK_HD uint32_t tk_run32c(uint32_t bits, uint32_t stop, uint32_t from) {  // as tk_run32, for any `from` (>= 32: 0)
-    const uint32_t f = from > 31u ? 31u : from;
-    const uint32_t r = tk_w32_ctz(~((bits & ~stop) >> f));
-    return from > 31u ? 0u : r;
-}
-template <class W32, class A>
-TK_HD uint32_t tk_piece_len_flat32(const W32& w, A& a, uint64_t p, uint32_t c, int pat) {
-    const uint32_t stop = w.stop;
-    const uint32_t k1 = 1u + tk_w32_ctz((w.start | stop) >> 1);
-    if (k1 > 4u || c == TK_C_SPEC) return 0;
-    const uint32_t nxt_end = (stop >> k1) & 1u;
-    const uint32_t S = TK_WIN32_SAFE;
-    const uint32_t ws = w.get(TKB_WS), nu = w.get(TKB_NU), oth = w.get(TKB_OTH);
-    uint32_t len = 0, bad = 0;  // bad: some run involved in the selected alternative leaves the safe part of the window
-    if (pat == TK_PAT_O200K) {
-        const uint32_t up = w.get(TKB_UP), low = w.get(TKB_LOW), cas = w.get(TKB_CAS), nlsl = w.get(TKB_NLSL), nl = w.get(TKB_NL);
-        // word alternatives (an optional prefix char, then [upper-ish]*[lower-ish]+ or [upper-ish]+[lower-ish]*)
-        const uint32_t wordc = (TK_M_WORD >> c) & 1u;
-        const uint32_t pre = (uint32_t)(c != TK_C_NL) & (uint32_t)(c != TK_C_NU) & (nxt_end ^ 1u) & (((up | low) >> k1) & 1u);
-        const uint32_t is_word = wordc | pre;
-        const uint32_t ks = wordc ? 0u : k1;
-        const uint32_t re = ks + tk_run32c(up, stop, ks);
-        const uint32_t te = re + tk_run32c(low, stop, re);
-        const uint32_t xx = cas & ~stop & tk_below32(re) & ~tk_below32(ks);
-        const uint32_t e_w = te > re ? te : (xx ? 32u - tk_w32_clz(xx) : re);
-        const uint32_t bad_w = (uint32_t)(re > S) | (uint32_t)(te > S);
-        // digits: up to three
-        const uint32_t rn = tk_run32c(nu, stop, 0);
-        uint32_t sx = w.start & tk_below32(rn);
-        sx &= sx - 1;
-        sx &= sx - 1;
-        sx &= sx - 1;
-        const uint32_t e_n = sx ? tk_w32_ctz(sx) : rn;
-        const uint32_t bad_n = e_n > S;
-        // optional space, other-run, then newlines / slashes
-        const uint32_t s0 = (c == TK_C_SP && !nxt_end) ? k1 : 0u;
-        const uint32_t is_oth = (oth >> s0) & 1u;
-        const uint32_t e1 = s0 + tk_run32c(oth, stop, s0);
-        const uint32_t e2 = e1 + tk_run32c(nlsl, stop, e1);
-        const uint32_t bad_o = (uint32_t)(e1 > S) | (uint32_t)(e2 > S);
-        // white space
-        const uint32_t q = tk_run32c(ws, stop, 0);
-        const uint32_t rng = tk_below32(q), at_end = (stop >> (q > 31u ? 31u : q)) & 1u, nlr = nl & rng, st = w.start & rng;
-        const uint32_t e_s = nlr ? 32u - tk_w32_clz(nlr) : (at_end ? q : (tk_w32_popc(st) >= 2u ? 31u - tk_w32_clz(st) : q));
-        const uint32_t bad_s = q > S;
-        const uint32_t is_nu = c == TK_C_NU;
-        len = is_word ? e_w : (is_nu ? e_n : (is_oth ? e2 : e_s));
-        bad = is_word ? bad_w : (is_nu ? bad_n : (is_oth ? bad_o : bad_s));
-        if (bad) return 0;
-        if (is_word && !((stop >> len) & 1u) && a.byte(p + len) == '\'') len += tk_contraction_bits(w, a, p, len, true);
-        return len;
-    }
-    const uint32_t L = w.get(TKB_L);
-    if (c == TK_C_AP) {  // (rare: a piece that starts with an apostrophe)
-        const uint32_t k = tk_contraction_bits(w, a, p, 0, pat == TK_PAT_CL100K);
-        if (k) return k;
-    }
-    const uint32_t s0 = (c == TK_C_SP && !nxt_end) ? k1 : 0u;
-    const uint32_t q = tk_run32c(ws, stop, 0);
-    const uint32_t rng = tk_below32(q), at_end = (stop >> (q > 31u ? 31u : q)) & 1u, st = w.start & rng;
-    if (pat == TK_PAT_CL100K) {
-        const uint32_t nl = w.get(TKB_NL);
-        // letters, with an optional single prefix char that is not a letter, digit or newline
-        const uint32_t letc = (TK_M_L >> c) & 1u;
-        const uint32_t pre = (uint32_t)(c != TK_C_NL) & (uint32_t)(c != TK_C_NU) & (nxt_end ^ 1u) & ((L >> k1) & 1u);
-        const uint32_t is_word = letc | pre;
-        const uint32_t ks = letc ? 0u : k1;
-        const uint32_t e_w = ks + tk_run32c(L, stop, ks);
-        const uint32_t rn = tk_run32c(nu, stop, 0);
-        uint32_t sx = w.start & tk_below32(rn);
-        sx &= sx - 1;
-        sx &= sx - 1;
-        sx &= sx - 1;
-        const uint32_t e_n = sx ? tk_w32_ctz(sx) : rn;
-        const uint32_t is_oth = (oth >> s0) & 1u;
-        const uint32_t e1 = s0 + tk_run32c(oth, stop, s0);
-        const uint32_t e2 = e1 + tk_run32c(nl, stop, e1);
-        const uint32_t nlr = nl & rng;
-        const uint32_t e_s = at_end ? q : (nlr ? 32u - tk_w32_clz(nlr) : (tk_w32_popc(st) >= 2u ? 31u - tk_w32_clz(st) : q));
-        const uint32_t is_nu = c == TK_C_NU;
-        len = is_word ? e_w : (is_nu ? e_n : (is_oth ? e2 : e_s));
-        bad = is_word ? (uint32_t)(e_w > S) : (is_nu ? (uint32_t)(e_n > S) : (is_oth ? ((uint32_t)(e1 > S) | (uint32_t)(e2 > S)) : (uint32_t)(q > S)));
-        return bad ? 0u : len;
-    }
-    // r50k: optional space, then a run of letters / digits / other; else white space
-    const uint32_t kl = (L >> s0) & 1u, kn = (nu >> s0) & 1u, ko = (oth >> s0) & 1u;
-    const uint32_t rb = kl ? L : (kn ? nu : oth);
-    const uint32_t e_r = s0 + tk_run32c(rb, stop, s0);
-    const uint32_t e_s = at_end ? q : (tk_w32_popc(st) >= 2u ? 31u - tk_w32_clz(st) : q);
-    const uint32_t is_run = kl | kn | ko;
-    len = is_run ? e_r : e_s;
-    bad = is_run ? (uint32_t)(e_r > S) : (uint32_t)(q > S);
-    return bad ? 0u : len;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -355,7 +355,7 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
             const uint32_t c = tk_class_at_lds(planes32, (uint32_t)r);
             {  // most pieces are short: 32-position windows first (a third of the vector-ALU work of the 64-bit form)
                 const TkWinLds32 w32((const uint32_t(*)[2 * NW])bm, (uint32_t)r);
-                len = tk_piece_len_flat32(w32, acc, p, c, pat);
+                len = tk_piece_len_bits32(w32, acc, p, c, pat);
             }
             if (len == 0) {
                 const TkWinLds wl(bm, wi, sh);
