@@ -68,7 +68,7 @@ struct tk_core {
     std::mutex mu;
     // workspace
     Buf text, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, res, rflag, staging, listB, listC, counters, total, g_id, g_rk, g_nx,
-        g_pv, g_lv, out_tokens, out_tok_off, allowed, tile_np, tile_nt, tile_nmiss, mt_slots, wbin, wave_pieces;
+        g_pv, g_lv, out_tokens, out_tok_off, allowed, tile_np, tile_nt, tile_nmiss, mt_slots, wbin, wave_pieces, deferred;
     uint64_t chunk_bytes = 1ull << 30;
     int dbg = 0;
     std::vector<uint8_t> sorted_blob;  // token_byte_values(), packed (built on first use)
@@ -232,7 +232,7 @@ extern "C" void tk_destroy(tk_core* c) {
                    &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off, &c->brk, &c->docb,
                    &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->res, &c->rflag, &c->staging, &c->listB,
                    &c->listC, &c->counters, &c->total, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv, &c->out_tokens,
-                   &c->out_tok_off, &c->allowed, &c->tile_np, &c->tile_nt, &c->tile_nmiss, &c->mt_slots, &c->wbin,
+                   &c->out_tok_off, &c->allowed, &c->tile_np, &c->tile_nt, &c->tile_nmiss, &c->mt_slots, &c->wbin, &c->deferred,
                    &c->wave_pieces})
         release(*b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -260,17 +260,17 @@ static uint32_t grid_for(uint64_t items, uint32_t per_block, uint32_t cap) {
 //   d_text: chunk text (readable 64 bytes past n); d_doc_off: uint64 offsets of the chunk's
 //   documents (n_docs+1 entries, absolute; `base` is subtracted); single_piece: the whole buffer
 //   is one piece (encode_single_piece), no pre-tokenisation.
-template <class... A>
+template <bool SLOW, class... A>
 static void launch_front(int pattern, bool spec, dim3 grid, hipStream_t s, A... a) {
     if (pattern == TK_PAT_R50K) {
-        if (spec) hipLaunchKernelGGL((tk_k_front<TK_PAT_R50K, true>), grid, dim3(256), 0, s, a...);
-        else hipLaunchKernelGGL((tk_k_front<TK_PAT_R50K, false>), grid, dim3(256), 0, s, a...);
+        if (spec) hipLaunchKernelGGL((tk_k_front<TK_PAT_R50K, true, SLOW>), grid, dim3(256), 0, s, a...);
+        else hipLaunchKernelGGL((tk_k_front<TK_PAT_R50K, false, SLOW>), grid, dim3(256), 0, s, a...);
     } else if (pattern == TK_PAT_CL100K) {
-        if (spec) hipLaunchKernelGGL((tk_k_front<TK_PAT_CL100K, true>), grid, dim3(256), 0, s, a...);
-        else hipLaunchKernelGGL((tk_k_front<TK_PAT_CL100K, false>), grid, dim3(256), 0, s, a...);
+        if (spec) hipLaunchKernelGGL((tk_k_front<TK_PAT_CL100K, true, SLOW>), grid, dim3(256), 0, s, a...);
+        else hipLaunchKernelGGL((tk_k_front<TK_PAT_CL100K, false, SLOW>), grid, dim3(256), 0, s, a...);
     } else {
-        if (spec) hipLaunchKernelGGL((tk_k_front<TK_PAT_O200K, true>), grid, dim3(256), 0, s, a...);
-        else hipLaunchKernelGGL((tk_k_front<TK_PAT_O200K, false>), grid, dim3(256), 0, s, a...);
+        if (spec) hipLaunchKernelGGL((tk_k_front<TK_PAT_O200K, true, SLOW>), grid, dim3(256), 0, s, a...);
+        else hipLaunchKernelGGL((tk_k_front<TK_PAT_O200K, false, SLOW>), grid, dim3(256), 0, s, a...);
     }
 }
 
@@ -357,10 +357,18 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
             HIPCHK(hipMemsetAsync(c->mt_slots.p, 0xFF, sizeof(TkMissSlot) << mt_bits, s));
             mt = c->mt_slots.as<TkMissSlot>();
         }
+        TRY(ensure(c->deferred, (ntiles + 2) * 4));
+        uint32_t* deferred = c->deferred.as<uint32_t>();
         TRY(timed(c, s, "tk_k_front", [&] {
             const dim3 grid((uint32_t)ntiles);
-            launch_front(T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, fo,
-                         (c->dbg & 256) ? (TkMissSlot*)nullptr : mt, (1u << mt_bits) - 1u, c->dbg);
+            launch_front<false>(T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, fo,
+                                (c->dbg & 256) ? (TkMissSlot*)nullptr : mt, (1u << mt_bits) - 1u, deferred, c->dbg);
+        }));
+        // the tiles that need the workgroup-wide scanner (long pieces, far-away piece starts); their number stays on the device
+        TRY(timed(c, s, "tk_k_front_slow", [&] {
+            const dim3 grid((uint32_t)(ntiles < 1024 ? ntiles : 1024));
+            launch_front<true>(T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, fo,
+                               (c->dbg & 256) ? (TkMissSlot*)nullptr : mt, (1u << mt_bits) - 1u, deferred, c->dbg);
         }));
     } else if (n > 0) {
         TRY(timed(c, s, "tk_k_single_front", [&] { hipLaunchKernelGGL(tk_k_single_front, dim3(1), dim3(64), 0, s, T, d_text, (uint32_t)n, fo, no_lookup ? 1 : 0); }));

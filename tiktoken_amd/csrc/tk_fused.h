@@ -35,6 +35,7 @@
 #define TKF_MISS_CAP 2048  // missed pieces per tile: each is at least two bytes long
 #define TKF_CHAIN_END 0xFFFFFFFFFFFFFFFFull
 #define TKF_CONT_CAP 256  // continuation list of the scanners
+#define TKF_SLOW_CAP 8    // pieces of one tile that leave its window
 #define TKF_BATCH 960  // pieces per probe batch of the front kernel (the class lists hold 1024 entries, their packed counter 1023)
 #define TKF_CAP 4096  // piece ids per tile: pid = tile * TKF_CAP + k (a 4096-byte tile starts at most 4096 pieces)
 
@@ -62,26 +63,200 @@ struct TkMissSlot {
     uint32_t pad;
 };
 
-// last certain piece start at or before `pos` (exists: position 0 and document starts are hard starts)
-__device__ __noinline__ uint64_t tk_certain_before(const TkTables* T, const uint8_t* text, uint64_t n, const uint32_t* brk,
-                                                   const uint32_t* ss, const uint32_t* si, uint64_t pos, int pat) {
-    uint32_t c = tk_class_byte_slow(T, text, pos, n, brk, ss, si);
-    for (;;) {
-        while ((c & 15u) == TK_C_CONT && pos > 0) {
-            --pos;
-            c = tk_class_byte_slow(T, text, pos, n, brk, ss, si);
+// ------------------------------------------------------------------------------------------
+// Workgroup-wide scanning straight from global memory, for the rare places where a tile's LDS window is not enough: a piece that
+// leaves the window (a run of a million letters is ONE piece), and the search for the last certain piece start before a tile whose
+// left context has none.  All 256 threads take part (uniform control flow): every lane classifies 16 bytes (tk_chunk.h), a query
+// advances 4 KiB per step.  The scanner itself is tk_piece_end_runs (tk_device.h) over these run queries.
+// ------------------------------------------------------------------------------------------
+struct TkCoop {
+    const TkTables* T;
+    const uint8_t* text;
+    uint64_t n;
+    const uint32_t *brk, *ss, *si;
+    const uint32_t* btab;  // LDS: byte table
+    uint32_t* red;         // LDS [8]
+    uint8_t* lastc;        // LDS [256]
+    int pat;
+};
+
+// masks of the 16 text bytes at g (a multiple of 16, may be negative or beyond the text)
+__device__ __forceinline__ void tk_coop_chunk(const TkCoop& C, int64_t g, TkChunkMasks& mk) {
+    uint32_t w[4] = {0, 0, 0, 0};
+    uint32_t valid = 0, past = 0;
+    if (g >= 0 && (uint64_t)g < C.n) {
+        const uint4 x = *(const uint4*)(C.text + g);
+        w[0] = x.x; w[1] = x.y; w[2] = x.z; w[3] = x.w;
+        const uint64_t left = C.n - (uint64_t)g;
+        valid = left >= 16 ? 0xFFFFu : ((1u << (uint32_t)left) - 1u);
+        if (left < 16) {
+            const uint32_t nb = (uint32_t)left;
+#pragma unroll
+            for (int d = 0; d < 4; ++d) {
+                const int lo = 4 * d;
+                w[d] &= nb >= (uint32_t)lo + 4u ? 0xFFFFFFFFu : (nb <= (uint32_t)lo ? 0u : ((1u << (8u * (nb - lo))) - 1u));
+            }
         }
-        if ((c & TK_F_HARD) || pos == 0) return pos;
-        uint64_t j = pos - 1;
-        uint32_t pc = tk_class_byte_slow(T, text, j, n, brk, ss, si);
-        while ((pc & 15u) == TK_C_CONT && j > 0) {
-            --j;
-            pc = tk_class_byte_slow(T, text, j, n, brk, ss, si);
-        }
-        if (tk_certain_start(pat, pc & 15u, c & 15u)) return pos;
-        pos = j;
-        c = pc;
     }
+    if (g >= 0) past = ~valid & 0xFFFFu;
+    TkChunk ch;
+    auto tab = [&](uint32_t b, uint32_t& x, uint32_t& y) {
+        const uint2 e = *(const uint2*)&C.btab[b * 2];
+        x = e.x;
+        y = e.y;
+    };
+    tk_chunk_table_pass(w, tab, ch);
+    auto get4 = [&](int k) -> uint32_t {  // (only asked for chars that have bytes inside the text)
+        const uint64_t a = (uint64_t)(g + k);
+        const uint32_t* q = (const uint32_t*)(C.text + (a & ~3ull));
+        return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)a & 3u);
+    };
+    auto cls_of = [&](uint32_t cp) -> uint32_t {
+        if (cp > 0x10FFFFu) cp = 0xFFFFu;
+        return C.T->uc_stage2[(uint32_t)C.T->uc_stage1[cp >> 8] * 256u + (cp & 255u)];
+    };
+    const bool has_prev = g >= 16 && valid;
+    const uint32_t prev = has_prev ? *(const uint32_t*)(C.text + g - 4) : 0u;
+    if (valid) tk_chunk_decode(ch, prev, has_prev, get4, cls_of);
+    uint32_t brk16 = 0, ss16 = 0, si16 = 0;
+    if (valid) {
+        const uint32_t sh = (uint32_t)g & 16u;
+        brk16 = (C.brk[g >> 5] >> sh) & 0xFFFFu;
+        if (C.ss) {
+            ss16 = (C.ss[g >> 5] >> sh) & 0xFFFFu;
+            si16 = (C.si[g >> 5] >> sh) & 0xFFFFu;
+        }
+    }
+    tk_chunk_finalize(ch, valid, past, brk16, ss16, si16, mk);
+}
+// bytes of the chunk whose class nibble is in the class mask cm
+__device__ __forceinline__ uint32_t tk_member16(const uint32_t p[4], uint32_t cm) {
+    const uint32_t n0 = ~p[0], n1 = ~p[1], n2 = ~p[2], n3 = ~p[3];
+    const uint32_t q[4] = {n3 & n2, n3 & p[2], p[3] & n2, p[3] & p[2]}, r[4] = {n1 & n0, n1 & p[0], p[1] & n0, p[1] & p[0]};
+    uint32_t m = 0;
+#pragma unroll
+    for (int c = 0; c < 16; ++c) m |= ((cm >> c) & 1u) ? (q[c >> 2] & r[c & 3]) : 0u;
+    return m & 0xFFFFu;
+}
+// first / last lane's value over the workgroup (v = TKF_NONE where a lane has none; lanes are in position order)
+__device__ __forceinline__ uint32_t tk_coop_first(const TkCoop& C, uint32_t v, bool last) {
+    const uint64_t m = __ballot(v != TKF_NONE);
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t wv = TKF_NONE;
+    if (m) wv = (uint32_t)__shfl((int)v, last ? 63 - __clzll((long long)m) : __ffsll((unsigned long long)m) - 1, 64);
+    if (lane == 0) C.red[wid] = wv;
+    __syncthreads();
+    uint32_t res = TKF_NONE;
+    if (last) {
+        for (int q = 0; q < 4; ++q)
+            if (C.red[q] != TKF_NONE) res = C.red[q];
+    } else {
+        for (int q = 3; q >= 0; --q)
+            if (C.red[q] != TKF_NONE) res = C.red[q];
+    }
+    __syncthreads();
+    return res;
+}
+// run_end of tk_piece_end_runs: first char start s >= from whose look-ahead class (END at hard starts and past the text) is not in cm
+__device__ __forceinline__ uint64_t tk_coop_run_end(const TkCoop& C, uint64_t from, uint32_t cm) {
+    for (uint64_t wb = from & ~15ull;; wb += 4096) {
+        const uint64_t g = wb + 16ull * threadIdx.x;
+        TkChunkMasks mk;
+        tk_coop_chunk(C, (int64_t)g, mk);
+        uint32_t stopm = (~tk_member16(mk.p, cm) | mk.hard) & 0xFFFFu;
+        if (g + 16 <= from) stopm = 0;
+        else if (g < from) stopm &= ~((1u << (uint32_t)(from - g)) - 1u);
+        const uint32_t first = stopm ? (uint32_t)(g - wb) + (uint32_t)__ffs((int)stopm) - 1u : TKF_NONE;
+        const uint32_t res = tk_coop_first(C, first, false);
+        if (res != TKF_NONE) return wb + res;
+    }
+}
+// last_in of tk_piece_end_runs: start of the last char of [from, to) whose class is in cm, or TK_NO_POS
+__device__ __forceinline__ uint64_t tk_coop_last_in(const TkCoop& C, uint64_t from, uint64_t to, uint32_t cm) {
+    if (to <= from) return TK_NO_POS;
+    for (int64_t wb = (int64_t)((to - 1) & ~15ull) - 4080;; wb -= 4096) {
+        const int64_t g = wb + 16ll * threadIdx.x;
+        TkChunkMasks mk;
+        tk_coop_chunk(C, g, mk);
+        uint32_t cand = tk_member16(mk.p, cm) & mk.text;
+        if (g >= (int64_t)to || g + 16 <= (int64_t)from) cand = 0;
+        else {
+            if (g + 16 > (int64_t)to) cand &= (1u << (uint32_t)((int64_t)to - g)) - 1u;
+            if (g < (int64_t)from) cand &= ~((1u << (uint32_t)((int64_t)from - g)) - 1u);
+        }
+        const uint32_t last = cand ? (uint32_t)(g - wb) + 31u - (uint32_t)__clz((int)cand) : TKF_NONE;
+        const uint32_t res = tk_coop_first(C, last, true);
+        if (res != TKF_NONE) return (uint64_t)(wb + res);
+        if (wb <= (int64_t)from) return TK_NO_POS;
+    }
+}
+// last certain piece start at or before `pos` (exists: position 0 and document starts are hard starts)
+__device__ __noinline__ uint64_t tk_coop_certain_before(const TkCoop* Cp, uint64_t pos) {
+    const TkCoop& C = *Cp;
+    for (int64_t wb = (int64_t)(pos & ~15ull) - 4080;; wb -= 4080) {  // (16 bytes of overlap: the first chunk of a span has no known
+        const int64_t g = wb + 16ll * threadIdx.x;                    //  predecessor; the next span sees it as its last chunk)
+        TkChunkMasks mk;
+        tk_coop_chunk(C, g, mk);
+        TkSets st;
+        tk_sets_from_planes(mk.p[0], mk.p[1], mk.p[2], mk.p[3], st);
+        C.lastc[threadIdx.x] = (uint8_t)tk_class_from_planes(mk.p, 15);
+        __syncthreads();
+        const uint32_t prevc = threadIdx.x ? (uint32_t)C.lastc[threadIdx.x - 1] : 0u;
+        uint32_t cert = tk_chunk_certain(C.pat, st, mk.text, mk.hard & mk.text, prevc);
+        if (g > (int64_t)pos) cert = 0;
+        else if (g + 16 > (int64_t)pos + 1) cert &= (2u << (uint32_t)((int64_t)pos - g)) - 1u;
+        const uint32_t last = cert ? (uint32_t)(g - wb) + 31u - (uint32_t)__clz((int)cert) : TKF_NONE;
+        const uint32_t res = tk_coop_first(C, last, true);  // (its barriers also protect lastc)
+        if (res != TKF_NONE) return (uint64_t)(wb + res);
+    }
+}
+struct TkCoopAcc {  // provider of tk_piece_end_runs: single positions straight from global memory (uniform loads), runs by the workgroup
+    const TkCoop& C;
+    __device__ __forceinline__ uint32_t cls(uint64_t pos) const { return pos >= C.n ? (uint32_t)TK_C_END : tk_class_byte_slow(C.T, C.text, pos, C.n, C.brk, C.ss, C.si); }
+    __device__ __forceinline__ uint32_t byte(uint64_t pos) const { return C.text[pos]; }
+    __device__ __forceinline__ uint64_t run_end(uint64_t from, uint32_t cm) const { return tk_coop_run_end(C, from, cm); }
+    __device__ __forceinline__ uint64_t last_in(uint64_t from, uint64_t to, uint32_t cm) const { return tk_coop_last_in(C, from, to, cm); }
+};
+// end of the piece that starts at p (any length), by the whole workgroup
+__device__ __noinline__ uint64_t tk_coop_piece_end(const TkCoop* Cp, uint64_t p) {
+    TkCoopAcc acc{*Cp};
+    uint64_t e = tk_piece_end_runs(acc, p, Cp->pat);
+    if (e <= p) e = tk_next_char(acc, p);
+    return e > Cp->n ? Cp->n : e;
+}
+// In a run of ASCII digits the pieces of the cl100k / o200k patterns are groups of three from the start of the run (\p{N}{1,3}): a chain
+// that walks such a run towards `target` can jump over the whole groups (a megabyte of digits would otherwise be 350 000 evaluations).
+__device__ __noinline__ uint64_t tk_coop_skip_digit_groups(const TkCoop* Cp, uint64_t p, uint64_t target) {
+    const TkCoop& C = *Cp;
+    uint64_t r2 = 0;
+    for (uint64_t wb = p & ~15ull;; wb += 4096) {  // end of the run of ASCII digits that are not hard starts
+        const uint64_t g = wb + 16ull * threadIdx.x;
+        TkChunkMasks mk;
+        tk_coop_chunk(C, (int64_t)g, mk);
+        uint32_t ascii = 0;
+        if (g < C.n) {
+            const uint4 x = *(const uint4*)(C.text + g);
+            const uint32_t w[4] = {x.x, x.y, x.z, x.w};
+#pragma unroll
+            for (int k = 0; k < 16; ++k) ascii |= (((w[k >> 2] >> (8 * (k & 3) + 7)) & 1u) ^ 1u) << k;
+        }
+        uint32_t stopm = (~(tk_member16(mk.p, TK_CB(TK_C_NU)) & ascii) | mk.hard) & 0xFFFFu;
+        if (g + 16 <= p) stopm = 0;
+        else if (g < p) stopm &= ~((2u << (uint32_t)(p - g)) - 1u);  // (p itself starts a piece: its own hard flag does not stop the run)
+        else if (g == p) stopm &= ~1u;
+        const uint32_t first = stopm ? (uint32_t)(g - wb) + (uint32_t)__ffs((int)stopm) - 1u : TKF_NONE;
+        const uint32_t res = tk_coop_first(C, first, false);
+        if (res != TKF_NONE) {
+            r2 = wb + res;
+            break;
+        }
+        if (wb + 4096 >= target + 4096) {  // far enough: the run reaches beyond the target
+            r2 = wb + 4096;
+            break;
+        }
+    }
+    const uint64_t lim = r2 < target ? r2 : target;
+    return lim > p ? p + 3 * ((lim - p) / 3) : p;
 }
 
 // 8 bytes of the LDS text copy starting at byte offset o (three aligned dword reads)
@@ -153,11 +328,15 @@ __device__ __forceinline__ bool tk_equal_lds_text(const uint8_t* raw, uint32_t o
     return true;
 }
 
-template <int PAT, bool SPEC>
-__global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
+// SLOW = false: one workgroup per tile.  A tile that needs the workgroup-wide scanner (tk_coop_*: no certain start in its left context, or
+// a piece that leaves its window -- about 3 % of the tiles of ordinary text) is not finished here: it goes on the `deferred` list.
+// SLOW = true: the same kernel with that scanner compiled in (its calls cost registers: kept out of the common path), launched over the
+// deferred tiles with a fixed grid.
+template <int PAT, bool SPEC, bool SLOW>
+__global__ __launch_bounds__(256, SLOW ? 2 : 8) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
                                                   const uint32_t* __restrict__ brk, const uint32_t* __restrict__ docb,
                                                   const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, TkFrontOut out,
-                                                  TkMissSlot* __restrict__ mt, uint32_t mt_mask, int dbg) {
+                                                  TkMissSlot* __restrict__ mt, uint32_t mt_mask, uint32_t* __restrict__ deferred, int dbg) {
     constexpr int pat = PAT;
     constexpr int NW = TK2_NSEG + 2;            // 64-bit words per bitmap (two sentinel words beyond the window)
     constexpr int BM_BYTES = TKB_KINDS * NW * 8;
@@ -167,18 +346,28 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
     __shared__ __attribute__((aligned(8))) uint32_t btab[256 * 2];                   // byte table (tk_chunk.h)
     __shared__ uint32_t certw[TK2_WIN / 32];                                         // certain starts (hard starts included)
     __shared__ uint32_t bits[TK_TILE / 32];
-    __shared__ uint32_t woff[TK_TILE / 32 + 1];
-    __shared__ uint8_t lastc[256];
+    __shared__ uint8_t lastc_own[SLOW ? 256 : 4];
     __shared__ uint32_t np_sh, nmiss_sh, need_walk, last_end_sh, ncls_sh, nx_sh, ncont_sh;
     __shared__ uint16_t contl[TKF_CONT_CAP];  // scan chains that continue after their first piece (window positions)
-    __shared__ uint32_t brkw[TK2_WIN / 32 + 1], ssw[TK2_WIN / 32 + 1], siw[TK2_WIN / 32 + 1];
+    __shared__ uint16_t slowl[TKF_SLOW_CAP];  // pieces that leave the window (window positions of their starts)
+    __shared__ uint32_t nslow_sh;
+    __shared__ uint32_t brkw[TK2_WIN / 32 + 1], ssw[SPEC ? TK2_WIN / 32 + 1 : 1], siw[SPEC ? TK2_WIN / 32 + 1 : 1];
     __shared__ uint32_t scan_sh[8];
     uint64_t(*bm)[NW] = (uint64_t(*)[NW])pool;
     uint16_t* clist = (uint16_t*)(pool + BM_BYTES);
     uint16_t* plist = (uint16_t*)pool;  // valid after the scanners are done
+    uint32_t* woff = certw;             // (phase E; the certain-start bitmap is dead by then)
+    uint8_t* lastc = SLOW ? lastc_own : (uint8_t*)contl;  // (phase C; the continuation list is used from phase D on)
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
-    const uint64_t tile = blockIdx.x;
+    uint32_t item = blockIdx.x;
+    if (SLOW && item >= out.counters[TK_CNT_DEFER]) return;
+    do {  // (SLOW: a fixed grid walks the deferred list; otherwise one tile per workgroup)
+    if (SLOW && item != blockIdx.x) __syncthreads();  // (the shared arrays are reused by the next tile)
+    const uint64_t tile = SLOW ? (uint64_t)deferred[item] : (uint64_t)item;
+    auto defer_tile = [&]() {
+        if (tid == 0) deferred[atomicAdd(&out.counters[TK_CNT_DEFER], 1u)] = (uint32_t)tile;
+    };
     const uint64_t tile_start = tile * TK_TILE;
     const uint64_t tile_end = tile_start + TK_TILE < n ? tile_start + TK_TILE : n;
     const int64_t base = (int64_t)tile_start - TK2_LEFT;
@@ -214,13 +403,16 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
         int64_t wgp = base + (int64_t)tid * 32;
         bool in = wgp >= 0 && (uint64_t)wgp < n;
         brkw[tid] = in ? brk[wgp >> 5] : 0u;
-        ssw[tid] = (SPEC && in) ? ss[wgp >> 5] : 0u;
-        siw[tid] = (SPEC && in) ? si[wgp >> 5] : 0u;
+        if constexpr (SPEC) {
+            ssw[tid] = in ? ss[wgp >> 5] : 0u;
+            siw[tid] = in ? si[wgp >> 5] : 0u;
+        }
     }
     if (tid == 0) {
         nmiss_sh = 0;
         need_walk = 0;
         ncont_sh = 0;
+        nslow_sh = 0;
         last_end_sh = (uint32_t)(tile_end - tile_start) + TK2_LEFT;
     }
     if (tid < TKB_KINDS) {
@@ -231,7 +423,7 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
     __syncthreads();
     if (dbg & 0x1000) {  // (perf experiments: stop after this phase)
         if (tid == 0) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
-        return;
+        continue;
     }
     // ---- B: classes of the lane's 16 bytes as 16-bit masks (tk_chunk.h): table pass, decode pass for non-ASCII chars
     TkChunk ch;
@@ -256,7 +448,7 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
     }
     if (dbg & 0x2000) {  // (perf experiments: stop after the classification)
         if (tid == 0 || (ch.acc0 ^ ch.acc1) == 0xFFFFFFF1u) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
-        return;
+        continue;
     }
     // ---- C: masks of the chunk -> bitmaps in LDS; certain starts; the list of scan starts
     TkChunkMasks mk;
@@ -337,35 +529,23 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
         }
     }
     __syncthreads();
+    if (!SLOW && need_walk) {  // no certain start in the left context: a tile for the workgroup-wide scanner
+        defer_tile();
+        continue;
+    }
     if (dbg & 0x4000) {  // (perf experiments: stop after this phase)
         if (tid == 0) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
-        return;
+        continue;
     }
     // ---- D: one lane per scan start; only boundaries inside the tile are recorded
     const uint32_t* planes32 = (const uint32_t*)planes;
-    TkWin2Acc acc{planes32, (const uint32_t*)bm[TKB_START], (const uint32_t*)bm[TKB_HARD], raw, base, &T, text, n, brk, ss, si};
-    // One evaluation: the piece that starts at p.  Returns its end when the scan has to go on from there (an uncertain boundary,
-    // recorded here when it lies inside the tile), or TKF_CHAIN_END when the chain ends (tile end, or a certain start that has its
-    // own scanner).
-    auto piece_from = [&](uint64_t p) -> uint64_t {
-        const int64_t r = (int64_t)p - base;
-        uint32_t len = 0;
-        if (r >= 0 && r + 64 <= TK2_WIN) {
-            const uint32_t wi = (uint32_t)r >> 6, sh = (uint32_t)r & 63u;
-            const uint32_t c = tk_class_at_lds(planes32, (uint32_t)r);
-            {  // most pieces are short: 32-position windows first (a third of the vector-ALU work of the 64-bit form)
-                const TkWinLds32 w32((const uint32_t(*)[2 * NW])bm, (uint32_t)r);
-                len = tk_piece_len_bits32(w32, acc, p, c, pat);
-            }
-            if (len == 0) {
-                const TkWinLds wl(bm, wi, sh);
-                TkBmExt ext{bm, wi, sh, (uint32_t)(TK2_WIN - r)};
-                len = tk_piece_len_bits(wl, acc, ext, p, c, pat);
-            }
-        }
-        uint64_t e = len ? p + len : tk_piece_end_slow(&acc, p, pat);
-        if (e > n) e = n;
-        if (e >= tile_end) {  // the piece that reaches the tile end: remember where it ends (clamped to the 32-bit window offset)
+    TkWin2Acc acc{planes32, (const uint32_t*)bm[TKB_START], (const uint32_t*)bm[TKB_HARD], raw, base, n, false};
+    const TkCoop coop{&T, text, n, brk, SPEC ? ss : nullptr, SPEC ? si : nullptr, btab, scan_sh, lastc, PAT};  // (used when SLOW)
+    // what the end e of the piece that starts at p means for this tile: TKF_CHAIN_END when the chain ends here (the piece reaches the tile
+    // end -- its end is remembered for the probe -- or e is a certain start, which has its own scanner), else e: the scan goes on from
+    // there (an uncertain boundary, recorded when it lies inside the tile)
+    auto chain_step = [&](uint64_t p, uint64_t e) -> uint64_t {
+        if (e >= tile_end) {  // (clamped to the 32-bit window offset)
             if (p < tile_end) {
                 uint64_t rel = e - (uint64_t)base;
                 last_end_sh = rel > 0xFFFFFFF0ull ? 0xFFFFFFF0u : (uint32_t)rel;
@@ -374,23 +554,94 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
         }
         if (e >= tile_start) {
             const uint32_t re = (uint32_t)((int64_t)e - base);  // inside the window (e < tile_end)
-            if ((certw[re >> 5] >> (re & 31u)) & 1u) return TKF_CHAIN_END;  // a certain start: another lane scans from there
+            if ((certw[re >> 5] >> (re & 31u)) & 1u) return TKF_CHAIN_END;
             atomicOr(&bits[(uint32_t)(e - tile_start) >> 5], 1u << ((uint32_t)(e - tile_start) & 31));
         }
         return e;
     };
-    // Two rounds around ONE instance of the evaluation (the scanner is big: a second inlined copy spills registers).
+    // One evaluation by one lane: the piece that starts at window position p - base.  A piece that leaves the window goes on the slow list
+    // (answered by the whole workgroup below).
+    auto piece_from = [&](uint64_t p) -> uint64_t {
+        const uint32_t r = (uint32_t)((int64_t)p - base);
+        uint32_t len = 0;
+        if (r + 64u <= (uint32_t)TK2_WIN) {
+            const uint32_t wi = r >> 6, sh = r & 63u;
+            const uint32_t c = tk_class_at_lds(planes32, r);
+            {  // most pieces are short: 32-position windows first (a third of the vector-ALU work of the 64-bit form)
+                const TkWinLds32 w32((const uint32_t(*)[2 * NW])bm, r);
+                len = tk_piece_len_bits32(w32, acc, p, c, pat);
+            }
+            if (len == 0) {
+                const TkWinLds wl(bm, wi, sh);
+                TkBmExt ext{bm, wi, sh, (uint32_t)TK2_WIN - r};
+                len = tk_piece_len_bits(wl, acc, ext, p, c, pat);
+            }
+        }
+        uint64_t e = p + len;
+        if (len == 0) {
+            acc.left = false;
+            e = tk_piece_end_slow(&acc, p, pat);  // byte walk inside the window
+            if (acc.left) {
+                const uint32_t at = atomicAdd(&nslow_sh, 1u);
+                if (SLOW) {
+                    if (at < TKF_SLOW_CAP) slowl[at] = (uint16_t)r;
+                    else atomicOr(&out.counters[TK_CNT_ERR], 1u);  // (cannot happen: at most two pieces of a tile can leave its window)
+                }
+                return TKF_CHAIN_END;
+            }
+        }
+        if (e > n) e = n;
+        return chain_step(p, e);
+    };
+    // The same for a piece of any length, anywhere, by the whole workgroup (uniform control flow): walks the chain from p until it ends
+    // or re-enters the tile, where the lanes' scanners take over through the continuation list.
+    auto coop_chain = [&](uint64_t p) {
+        if constexpr (SLOW) {
+            for (;;) {
+                uint64_t e = p;
+                if (PAT != TK_PAT_R50K && p < tile_start && (tk_class_byte_slow(&T, text, p, n, brk, coop.ss, coop.si) & 15u) == TK_C_NU)
+                    e = tk_coop_skip_digit_groups(&coop, p, tile_start);  // whole three-digit groups left of the tile
+                if (e == p) e = tk_coop_piece_end(&coop, p);
+                const uint64_t nx = chain_step(p, e);  // (all threads compute the same; the bit and last_end updates are idempotent)
+                if (nx == TKF_CHAIN_END) return;
+                if (nx >= tile_start) {  // inside the tile (and the window) again
+                    __syncthreads();
+                    if (tid == 0) {
+                        const uint32_t at = ncont_sh;
+                        if (at < TKF_CONT_CAP) {
+                            contl[at] = (uint16_t)(nx - (uint64_t)base);
+                            ncont_sh = at + 1;
+                        } else {
+                            atomicOr(&out.counters[TK_CNT_ERR], 2u);
+                        }
+                    }
+                    __syncthreads();
+                    return;
+                }
+                p = nx;
+            }
+        }
+    };
+    // The tile starts inside a piece and its left context holds no certain start: find the last one before it and walk from there.
+    if constexpr (SLOW) {
+        if (need_walk) coop_chain(tk_coop_certain_before(&coop, tile_start - 1));
+    }
+    // Rounds around ONE instance of the lanes' evaluation (the scanner is big: a second inlined copy spills registers).
     //   round 0: one piece per scan start, all lanes busy.  94..98 % of the pieces end at a certain start; a chain that goes on (an
     //            uncertain boundary) is put on the continuation list -- a wavefront does not repeat the evaluation for its slowest lane;
-    //   round 1: the listed chains, the walk-back start and (when the start list overflowed) every lane's own starts, walked to their ends.
+    //   round 1+: the listed chains (and, when the start list overflowed, every lane's own starts), walked to their ends.
+    // After each round the workgroup answers the pieces that left the window; those can add continuations for one more round.
     uint32_t own = listed ? 0u : mine;
-    bool own_extra = !listed && extra != TKF_NONE, walk = tid == 0;
-    for (int round = 0; round < 2; ++round) {
-        const uint32_t cnt = round == 0 ? (listed ? n_front + n_back : 0u) : (ncont_sh < TKF_CONT_CAP ? ncont_sh : (uint32_t)TKF_CONT_CAP);
-        uint32_t i = tid;
+    bool own_extra = !listed && extra != TKF_NONE;
+    uint32_t cont_done = 0, slow_done = 0;
+    for (int round = 0;; ++round) {
+        const uint32_t cont_n = ncont_sh < TKF_CONT_CAP ? ncont_sh : (uint32_t)TKF_CONT_CAP;
+        const uint32_t lo = round == 0 ? 0u : cont_done, hi = round == 0 ? (listed ? n_front + n_back : 0u) : cont_n;
+        if (round) cont_done = cont_n;
+        uint32_t i = lo + tid;
         for (;;) {
             uint64_t p = TKF_CHAIN_END;
-            if (i < cnt) {
+            if (i < hi) {
                 p = (uint64_t)(base + (round == 0 ? (i < n_front ? clist[i] : clist[TK2_CLIST - 1u - (i - n_front)]) : contl[i]));
                 i += 256;
             } else if (round == 1) {
@@ -400,9 +651,6 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
                 } else if (own) {
                     p = (uint64_t)(base + (int64_t)(tid * 16u + (uint32_t)__ffs((int)own) - 1u));
                     own &= own - 1;
-                } else if (walk) {
-                    walk = false;
-                    if (need_walk) p = tk_certain_before(&T, text, n, brk, ss, si, tile_start - 1, pat);
                 }
             }
             if (!__any(p != TKF_CHAIN_END)) break;
@@ -416,7 +664,7 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
                         const int leader = __ffsll((unsigned long long)m) - 1;
                         if (lane == leader) at = atomicAdd(&ncont_sh, (uint32_t)__popcll(m));
                         at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                        // (a chain that goes on is left of the tile end and, in round 0, inside the window)
+                        // (a chain that goes on is left of the tile end and inside the window)
                         if (go_on && at < TKF_CONT_CAP) {
                             contl[at] = (uint16_t)(e - (uint64_t)base);
                             go_on = false;
@@ -428,10 +676,21 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
             }
         }
         __syncthreads();
+        if (!SLOW && nslow_sh) break;  // a piece leaves the window: the tile is deferred (below)
+        const uint32_t slow_n = nslow_sh < TKF_SLOW_CAP ? nslow_sh : (uint32_t)TKF_SLOW_CAP;
+        for (uint32_t q = slow_done; q < slow_n; ++q) coop_chain((uint64_t)(base + slowl[q]));
+        slow_done = slow_n;
+        __syncthreads();
+        const uint32_t cont_now = ncont_sh < TKF_CONT_CAP ? ncont_sh : (uint32_t)TKF_CONT_CAP;
+        if (round >= 1 && cont_now == cont_done) break;
+    }
+    if (!SLOW && nslow_sh) {
+        defer_tile();
+        continue;
     }
     if (dbg & 0x8000) {  // (perf experiments: stop after this phase)
         if (tid == 0) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
-        return;
+        continue;
     }
     // ---- E: enumerate the pieces of the tile (set bits of `bits`, in order) -> plist (aliases the bitmaps)
     {
@@ -458,7 +717,7 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
     __syncthreads();
     if (dbg & 0x10000) {  // (perf experiments: stop after this phase)
         if (tid == 0) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
-        return;
+        continue;
     }
     // ---- F: whole-piece probe (src/lib.rs:367).  Pieces are first sorted by length class into LDS lists -- short (<= 4 bytes),
     // mid (5..8), long -- so that every wavefront runs ONE probe path with all lanes busy; pieces that are not tokens go to a
@@ -667,6 +926,7 @@ __global__ __launch_bounds__(256, 7) void tk_k_front(TkTables T, const uint8_t* 
         __syncthreads();  // (the lists are reused by the next batch)
     }
     if (tid == 0) out.tile_nmiss[tile] = nmiss_sh;
+    } while (SLOW && (item += gridDim.x) < out.counters[TK_CNT_DEFER]);
 }
 
 // The pieces on the tiles' miss lists (first occurrences: duplicates were resolved by the front kernel) have to be

@@ -32,7 +32,7 @@ struct TkBins {
 };
 
 // counters (device uint32 array)
-enum { TK_CNT_B = 0, TK_CNT_C = 1, TK_CNT_CBYTES = 2, TK_CNT_CLEVELS = 3, TK_CNT_DUP = 4, TK_CNT_COLL = 5, TK_CNT_BIN0 = 8, TK_CNT_N = 8 + TK_NBIN + 1 };
+enum { TK_CNT_B = 0, TK_CNT_C = 1, TK_CNT_CBYTES = 2, TK_CNT_CLEVELS = 3, TK_CNT_DUP = 4, TK_CNT_COLL = 5, TK_CNT_ERR = 6, TK_CNT_DEFER = 7, TK_CNT_BIN0 = 8, TK_CNT_N = 8 + TK_NBIN + 1 };
 
 #define TK_MT_BITS 22   // most slots of the in-call miss table (tk_fused.h); sized by the chunk
 #define TK_MT_PROBES 8
@@ -246,17 +246,17 @@ __device__ __forceinline__ uint32_t tk_class_at_lds(const uint32_t* planes32, ui
            (((planes32[3 * TK2_PLW + wi] >> b) & 1u) << 3);
 }
 
-struct TkWin2Acc {  // byte-walking fallback: the window's bitmaps inside the window, HBM outside
+struct TkWin2Acc {  // byte-walking fallback inside the window (for the pieces the bit-parallel scanners decline).  It never leaves
+                    // the window: a look outside sets `left` and reads as end-of-text -- the caller then hands the piece to the
+                    // workgroup-wide scanner (tk_coop_*), which answers run queries at 4 KiB per step.
     const uint32_t* planes32;  // [4][TK2_PLW]
     const uint32_t* start32;   // char-start bitmap
     const uint32_t* hard32;    // hard-start bitmap
     const uint8_t* raw;
     int64_t base;
-    const TkTables* T;
-    const uint8_t* text;
     uint64_t n;
-    const uint32_t *brk, *ss, *si;
-    __device__ __forceinline__ uint32_t cls(uint64_t pos) const {
+    bool left;
+    __device__ __forceinline__ uint32_t cls(uint64_t pos) {
         if (pos >= n) return TK_C_END;
         int64_t r = (int64_t)pos - base;
         if (r >= 0 && r < TK2_WIN) {
@@ -264,12 +264,14 @@ struct TkWin2Acc {  // byte-walking fallback: the window's bitmaps inside the wi
             if (!((start32[wi] >> b) & 1u)) return (uint32_t)TK_C_CONT;
             return tk_class_at_lds(planes32, (uint32_t)r) | (((hard32[wi] >> b) & 1u) << 7);
         }
-        return tk_class_byte_slow(T, text, pos, n, brk, ss, si);
+        left = true;
+        return TK_C_END;
     }
-    __device__ __forceinline__ uint32_t byte(uint64_t pos) const {
+    __device__ __forceinline__ uint32_t byte(uint64_t pos) {
         int64_t r = (int64_t)pos - base;
         if (r >= 0 && r < TK2_WIN) return raw[r];
-        return text[pos];
+        left = true;
+        return 0;
     }
 };
 

@@ -1,12 +1,26 @@
-import sys, time
-sys.path.insert(0, '/root/repo'); sys.path.insert(0, '/root/repo/tests')
+#!/usr/bin/env python3
+"""Timing + parity of the reference's pathological inputs (tests/test_encoding.py:52-57,113-124 and CHANGELOG v0.13.0): long runs of one
+character or of a short unit.  Prints per input: wall time of Encoding.encode_ordinary (second call), the library's per-kernel times of
+that call, token count, parity with the C oracle."""
+import sys, time, os
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np, helpers as h
 import tiktoken_amd
-enc = tiktoken_amd.get_encoding("o200k_shaped")
-C = h.c_oracle_for("o200k_shaped")
-for ch in ["x", "0", "^", " ", "\n", "a1", "Ab", "中"]:
-    for n in (100_000, 1_000_000):
-        s = ch * (n // len(ch))
-        t0 = time.perf_counter(); toks = enc.encode_ordinary(s); dt = time.perf_counter() - t0
-        ok = np.array_equal(np.asarray(toks, np.uint32), C.encode_ordinary(s.encode())) if n <= 100_000 or ch in "x0" else None
-        print(f"{ch!r:6} x {n:>9}: {dt*1e3:9.1f} ms  tokens {len(toks):>8}  parity {ok}", flush=True)
+
+names = sys.argv[1:] or ["o200k_shaped"]
+KERN = ["tk_k_front", "tk_k_front_slow", "tk_k_merge_long", "tk_k_back"]
+for name in names:
+    enc = tiktoken_amd.get_encoding(name)
+    C = h.c_oracle_for(name)
+    core = enc._core_bpe
+    for unit in ["x", "0", "^", " ", "\n", "a1", "Ab", "中", "1", "é", " \n", "x'll"]:
+        for n in (100_000, 1_000_000):
+            s = unit * (n // len(unit))
+            enc.encode_ordinary(s)
+            core.set_profiling(True); core.reset_kernel_ms()
+            t0 = time.perf_counter(); toks = enc.encode_ordinary(s); dt = time.perf_counter() - t0
+            core.set_profiling(False)
+            km = {k: round(core.kernel_ms(k)[0], 2) for k in KERN}
+            ok = bool(np.array_equal(np.asarray(toks, np.uint32), C.encode_ordinary(s.encode())))
+            print(f"{name} {unit!r:7} x {n:>9}: {dt*1e3:9.1f} ms  tokens {len(toks):>8}  parity {ok}  kernels {km}", flush=True)
