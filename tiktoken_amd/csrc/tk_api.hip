@@ -68,7 +68,7 @@ struct tk_core {
     std::mutex mu;
     // workspace
     Buf text, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, res, rflag, staging, listB, listC, counters, total, g_id, g_rk, g_nx,
-        g_pv, g_lv, out_tokens, out_tok_off, allowed, tile_np, tile_nt, tile_nmiss, mt_slots, wbin, wave_pieces, deferred;
+        g_pv, g_lv, out_tokens, out_tok_off, allowed, tile_np, tile_nt, tile_nmiss, mt_slots, wbin, wave_pieces, deferred, big;
     uint64_t chunk_bytes = 1ull << 30;
     int dbg = 0;
     std::vector<uint8_t> sorted_blob;  // token_byte_values(), packed (built on first use)
@@ -232,7 +232,7 @@ extern "C" void tk_destroy(tk_core* c) {
                    &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off, &c->brk, &c->docb,
                    &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->res, &c->rflag, &c->staging, &c->listB,
                    &c->listC, &c->counters, &c->total, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv, &c->out_tokens,
-                   &c->out_tok_off, &c->allowed, &c->tile_np, &c->tile_nt, &c->tile_nmiss, &c->mt_slots, &c->wbin, &c->deferred,
+                   &c->out_tok_off, &c->allowed, &c->tile_np, &c->tile_nt, &c->tile_nmiss, &c->mt_slots, &c->wbin, &c->deferred, &c->big,
                    &c->wave_pieces})
         release(*b);
     if (c->stream) (void)hipStreamDestroy(c->stream);
@@ -312,6 +312,8 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
     TRY(ensure(c->listC, (n / 1025 + 64) * 20));
     HIPCHK(hipMemsetAsync(c->brk.p, 0, (nwords + 2) * 4, s));
     HIPCHK(hipMemsetAsync(c->counters.p, 0, TK_CNT_N * 4, s));
+    TRY(ensure(c->big, (1 + 3 * TK_BIGCOPY_CAP) * 4));
+    HIPCHK(hipMemsetAsync(c->big.p, 0, 4, s));
     HIPCHK(hipMemsetAsync(c->total.p, 0, 16, s));
     uint32_t *brk = c->brk.as<uint32_t>(), *starts = c->starts.as<uint32_t>();
     uint32_t *ss = nullptr, *si = nullptr, *docb = nullptr;
@@ -466,11 +468,19 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
             TRY(ensure(c->g_nx, (lb + 64) * 4));
             TRY(ensure(c->g_pv, (lb + 64) * 4));
             TRY(ensure(c->g_lv, (lvls + 64) * 8));
-            TRY(timed(c, s, "tk_k_merge_long", [&] {
-                hipLaunchKernelGGL(tk_k_merge_long, dim3(grid_for(nC, 4, 8192)), dim3(256), 0, s, T, d_text, c->listC.as<uint32_t>(), (uint32_t)nC,
-                                   c->g_id.as<uint32_t>(), c->g_rk.as<uint32_t>(), c->g_nx.as<uint32_t>(), c->g_pv.as<uint32_t>(),
-                                   c->g_lv.as<uint64_t>(), miss, stg);
-            }));
+            if (c->H.monotone && !(c->dbg & 1024)) {  // (debug bit 1024: force the one-merge-at-a-time kernel)
+                TRY(timed(c, s, "tk_k_merge_long", [&] {
+                    hipLaunchKernelGGL(tk_k_merge_rounds, dim3(grid_for(nC, 1, 1024)), dim3(TKB_THREADS), 0, s, T, d_text, c->listC.as<uint32_t>(),
+                                       (uint32_t)nC, c->g_id.as<uint32_t>(), c->g_rk.as<uint32_t>(), c->g_nx.as<uint32_t>(), c->g_pv.as<uint32_t>(),
+                                       miss, stg);
+                }));
+            } else {
+                TRY(timed(c, s, "tk_k_merge_long", [&] {
+                    hipLaunchKernelGGL(tk_k_merge_long, dim3(grid_for(nC, 4, 8192)), dim3(256), 0, s, T, d_text, c->listC.as<uint32_t>(), (uint32_t)nC,
+                                       c->g_id.as<uint32_t>(), c->g_rk.as<uint32_t>(), c->g_nx.as<uint32_t>(), c->g_pv.as<uint32_t>(),
+                                       c->g_lv.as<uint64_t>(), miss, stg);
+                }));
+            }
         }
         if (mt) {
             TRY(timed(c, s, "tk_k_dup_publish", [&] { hipLaunchKernelGGL(tk_k_dup_publish, dim3(grid_for(1ull << mt_bits, 256, 4096)), dim3(256), 0, s, mt, 1u << mt_bits, miss); }));
@@ -483,8 +493,10 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
             hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, tile_nt, ntiles, c->total.as<uint64_t>());
         }));
         TRY(timed(c, s, "tk_k_back", [&] {
-            hipLaunchKernelGGL(tk_k_back, dim3(grid_for(ntiles, 4, 16384)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, rflag, stg, d_out);
+            hipLaunchKernelGGL(tk_k_back, dim3(grid_for(ntiles, 4, 16384)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, rflag, stg, d_out, c->big.as<uint32_t>());
         }));
+        if (n > TK_BIGCOPY)  // (a token run of TK_BIGCOPY tokens needs at least as many bytes)
+            hipLaunchKernelGGL(tk_k_bigcopy, dim3(1024), dim3(256), 0, s, c->big.as<uint32_t>(), stg, d_out);
     }
     if (d_tok_off) {
         TRY(timed(c, s, "tk_k_docoff", [&] {
@@ -500,6 +512,7 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         nB += hb[TK_CNT_BIN0 + b];
         if ((c->dbg & 64) && hb[TK_CNT_BIN0 + b]) fprintf(stderr, "bin %d (%u..%u bytes): %u pieces\n", b, tk_bin_lo(b), tk_bin_hi(b), hb[TK_CNT_BIN0 + b]);
     }
+    if (hb[TK_CNT_ERR]) return fail(TK_RUNTIME_ERROR, "internal error in the front kernel (scanner list overflow, code " + std::to_string(hb[TK_CNT_ERR]) + ")");
     const uint64_t T_total = tp[0];
     c->st_bytes += n;
     c->st_pieces += tp[1];

@@ -33,6 +33,8 @@
 
 #define TKF_NONE 0xFFFFFFFFu
 #define TKF_MISS_CAP 2048  // missed pieces per tile: each is at least two bytes long
+#define TK_BIGCOPY 4096      // token runs from this length on are copied by tk_k_bigcopy
+#define TK_BIGCOPY_CAP 1024  // entries of its list
 #define TKF_CHAIN_END 0xFFFFFFFFFFFFFFFFull
 #define TKF_CONT_CAP 256  // continuation list of the scanners
 #define TKF_SLOW_CAP 8    // pieces of one tile that leave its window
@@ -81,7 +83,8 @@ struct TkCoop {
 };
 
 // masks of the 16 text bytes at g (a multiple of 16, may be negative or beyond the text)
-__device__ __forceinline__ void tk_coop_chunk(const TkCoop& C, int64_t g, TkChunkMasks& mk) {
+// (one copy: the callers are inlined into the scanner at several places and the instruction cache is small)
+__device__ __noinline__ void tk_coop_chunk(const TkCoop& C, int64_t g, TkChunkMasks& mk) {
     uint32_t w[4] = {0, 0, 0, 0};
     uint32_t valid = 0, past = 0;
     if (g >= 0 && (uint64_t)g < C.n) {
@@ -158,7 +161,7 @@ __device__ __forceinline__ uint32_t tk_coop_first(const TkCoop& C, uint32_t v, b
     return res;
 }
 // run_end of tk_piece_end_runs: first char start s >= from whose look-ahead class (END at hard starts and past the text) is not in cm
-__device__ __forceinline__ uint64_t tk_coop_run_end(const TkCoop& C, uint64_t from, uint32_t cm) {
+__device__ __noinline__ uint64_t tk_coop_run_end(const TkCoop& C, uint64_t from, uint32_t cm) {
     for (uint64_t wb = from & ~15ull;; wb += 4096) {
         const uint64_t g = wb + 16ull * threadIdx.x;
         TkChunkMasks mk;
@@ -172,7 +175,7 @@ __device__ __forceinline__ uint64_t tk_coop_run_end(const TkCoop& C, uint64_t fr
     }
 }
 // last_in of tk_piece_end_runs: start of the last char of [from, to) whose class is in cm, or TK_NO_POS
-__device__ __forceinline__ uint64_t tk_coop_last_in(const TkCoop& C, uint64_t from, uint64_t to, uint32_t cm) {
+__device__ __noinline__ uint64_t tk_coop_last_in(const TkCoop& C, uint64_t from, uint64_t to, uint32_t cm) {
     if (to <= from) return TK_NO_POS;
     for (int64_t wb = (int64_t)((to - 1) & ~15ull) - 4080;; wb -= 4096) {
         const int64_t g = wb + 16ll * threadIdx.x;
@@ -1293,6 +1296,123 @@ __global__ __launch_bounds__(256) void tk_k_merge_long(TkTables T, const uint8_t
 }
 
 // ------------------------------------------------------------------------------------------
+// Long pieces, in rounds (one workgroup per piece).  byte_pair_merge (src/lib.rs:140-196) always merges the leftmost pair of the lowest
+// rank m.  When the vocabulary is MONOTONE -- every token that has a split into two tokens ranks above both of them, which holds for any
+// vocabulary produced by BPE training and is checked for the whole pair table at tk_create -- a merge of rank m only creates pairs that
+// rank above m, so the reference's next picks are exactly the other rank-m pairs, left to right, skipping the ones a pick has consumed.
+// One round therefore applies ALL of them at once: within a run of overlapping rank-m pairs the even ones.  The number of rounds is bounded
+// by the number of distinct ranks that get merged, not by the length: a megabyte of one character takes a few dozen rounds.
+// (Pieces of a non-monotone vocabulary go through tk_k_merge_long, one merge at a time.)
+//   P0/R0 and P1/R1: the parts (token ids) and the rank of each part's pair with its right neighbour, double-buffered and compacted every round.
+// ------------------------------------------------------------------------------------------
+#define TKB_THREADS 1024
+struct TkRunState {  // segment summary for the run-parity scan: is the segment all rank-m pairs, parity of its trailing run of them
+    uint32_t all, par;
+};
+__device__ __forceinline__ TkRunState tk_run_combine(TkRunState a, TkRunState b) { return TkRunState{a.all & b.all, b.all ? (a.par ^ b.par) : b.par}; }
+
+__global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listC,
+                                                                  uint32_t nC, uint32_t* __restrict__ g_p0, uint32_t* __restrict__ g_r0,
+                                                                  uint32_t* __restrict__ g_p1, uint32_t* __restrict__ g_r1,
+                                                                  uint2* __restrict__ miss, uint32_t* __restrict__ staging) {
+    __shared__ uint32_t red[TKB_THREADS / 64];
+    __shared__ uint32_t sc_all[TKB_THREADS / 64], sc_par[TKB_THREADS / 64], sc_cnt[TKB_THREADS / 64];
+    __shared__ uint32_t bcast;
+    const uint32_t tid = threadIdx.x;
+    const int lane = tid & 63, wid = tid >> 6;
+    constexpr uint32_t MARK = 0x80000000u;  // (token ids stay below 2^31: checked at tk_create)
+    for (uint32_t w = blockIdx.x; w < nC; w += gridDim.x) {
+        const uint32_t* ent = listC + 5 * (uint64_t)w;
+        const uint32_t mi = ent[0], s = ent[1], n = ent[2];
+        uint32_t *P0 = g_p0 + ent[3], *R0 = g_r0 + ent[3], *P1 = g_p1 + ent[3], *R1 = g_r1 + ent[3];
+        for (uint32_t k = tid; k < n; k += TKB_THREADS) {
+            const uint32_t b0 = text[s + k];
+            P0[k] = T.byte_rank[b0];
+            R0[k] = k + 1 < n ? T.pair2[(b0 << 8) | text[s + k + 1]] : TK_RANK_MAX;
+        }
+        __syncthreads();
+        uint32_t cnt = n;
+        for (;;) {
+            const uint32_t per = (cnt + TKB_THREADS - 1) / TKB_THREADS;
+            const uint32_t lo = tid * per < cnt ? tid * per : cnt, hi = lo + per < cnt ? lo + per : cnt;
+            // a. the lowest rank
+            uint32_t m = TK_RANK_MAX;
+            for (uint32_t i = lo; i < hi; ++i) m = R0[i] < m ? R0[i] : m;
+            m = tk_wave_min_u32(m);
+            if (lane == 0) red[wid] = m;
+            __syncthreads();
+            m = red[lane & (TKB_THREADS / 64 - 1)];
+            m = tk_wave_min_u32(m);
+            __syncthreads();
+            if (m == TK_RANK_MAX) break;
+            // b. for every part: c = parity of the run of rank-m pairs right before it.  Thread summaries, then a workgroup scan.
+            TkRunState mine{1u, 0u};
+            for (uint32_t i = lo; i < hi; ++i) {
+                const uint32_t f = R0[i] == m;
+                mine = tk_run_combine(mine, TkRunState{f, f});
+            }
+            TkRunState inc = mine;  // inclusive scan over the wave, then over the waves
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                TkRunState up{(uint32_t)__shfl_up((int)inc.all, o, 64), (uint32_t)__shfl_up((int)inc.par, o, 64)};
+                if (lane >= o) inc = tk_run_combine(up, inc);
+            }
+            if (lane == 63) {
+                sc_all[wid] = inc.all;
+                sc_par[wid] = inc.par;
+            }
+            __syncthreads();
+            TkRunState before{1u, 0u};  // everything left of this thread's range
+            for (int q = 0; q < wid; ++q) before = tk_run_combine(before, TkRunState{sc_all[q], sc_par[q]});
+            {
+                TkRunState ex{(uint32_t)__shfl_up((int)inc.all, 1, 64), (uint32_t)__shfl_up((int)inc.par, 1, 64)};
+                if (lane > 0) before = tk_run_combine(before, ex);
+            }
+            // c. parts that survive (a part right of an even pair of a run is absorbed): count, scan, write
+            uint32_t par = before.par, keep = 0;
+            for (uint32_t i = lo; i < hi; ++i) {
+                keep += par ^ 1u;  // (the pair before an absorbed part was selected: odd count of rank-m pairs before it)
+                par = R0[i] == m ? (par ^ 1u) : 0u;
+            }
+            const uint32_t kinc = tk_wave_scan_u32(keep, lane);
+            if (lane == 63) sc_cnt[wid] = kinc;
+            __syncthreads();
+            uint32_t at = kinc - keep, total = 0;
+            for (int q = 0; q < TKB_THREADS / 64; ++q) {
+                if (q < wid) at += sc_cnt[q];
+                total += sc_cnt[q];
+            }
+            par = before.par;
+            for (uint32_t i = lo; i < hi; ++i) {
+                const uint32_t f = R0[i] == m;
+                if (!par) {                       // kept; selected when its own pair has rank m
+                    P1[at] = f ? (m | MARK) : (P0[i] & ~MARK);
+                    R1[at] = R0[i];                // (still right when neither this part nor the next one changes)
+                    ++at;
+                }
+                par = f ? (par ^ 1u) : 0u;
+            }
+            __syncthreads();
+            // d. ranks of the pairs that a merge has touched
+            const uint32_t per2 = (total + TKB_THREADS - 1) / TKB_THREADS;
+            for (uint32_t j = tid * per2; j < total && j < (tid + 1) * per2; ++j) {
+                const uint32_t a = P1[j], b = j + 1 < total ? P1[j + 1] : 0u;
+                if (j + 1 >= total) R1[j] = TK_RANK_MAX;
+                else if ((a | b) & MARK) R1[j] = tk_probe_pair(T, a & ~MARK, b & ~MARK);
+            }
+            __syncthreads();
+            uint32_t* t0 = P0; P0 = P1; P1 = t0;
+            t0 = R0; R0 = R1; R1 = t0;
+            cnt = total;
+        }
+        for (uint32_t k = tid; k < cnt; k += TKB_THREADS) staging[s + k] = P0[k] & ~MARK;
+        if (tid == 0) miss[mi] = make_uint2(cnt, cnt == 1 ? (P0[0] & ~MARK) : s);
+        __syncthreads();
+    }
+    (void)bcast;
+}
+
+// ------------------------------------------------------------------------------------------
 // back end
 // ------------------------------------------------------------------------------------------
 __global__ __launch_bounds__(256) void tk_k_dup_publish(TkMissSlot* __restrict__ mt, uint32_t mt_slots, const uint2* __restrict__ miss) {
@@ -1353,7 +1473,7 @@ __global__ __launch_bounds__(256) void tk_k_tile_finish(uint64_t ntiles, const u
 // eight lanes per piece.
 __global__ __launch_bounds__(256) void tk_k_back(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_tb,
                                                  const uint32_t* __restrict__ res, const uint2* __restrict__ rflag, const uint32_t* __restrict__ staging,
-                                                 uint32_t* __restrict__ out) {
+                                                 uint32_t* __restrict__ out, uint32_t* __restrict__ big) {
     __shared__ uint32_t mlist_sh[4][256 * 3];
     const int lane = threadIdx.x & 63;
     uint32_t* mlist = mlist_sh[threadIdx.x >> 6];
@@ -1420,13 +1540,34 @@ __global__ __launch_bounds__(256) void tk_k_back(uint64_t ntiles, const uint32_t
                     const uint32_t e = e0 + (lane >> 3);
                     if (e < ntot) {
                         const uint32_t src = mlist[e * 3], cc = mlist[e * 3 + 1], dst = mlist[e * 3 + 2];
-                        for (uint32_t i = lane & 7; i < cc; i += 8) out[dst + i] = staging[src + i];
+                        if (cc < TK_BIGCOPY) {
+                            for (uint32_t i = lane & 7; i < cc; i += 8) out[dst + i] = staging[src + i];
+                        } else if ((lane & 7) == 0) {  // thousands of tokens of one piece: copied by tk_k_bigcopy with the whole device
+                            const uint32_t at = atomicAdd(&big[0], 1u);
+                            if (at < TK_BIGCOPY_CAP) {
+                                big[1 + 3 * at] = src;
+                                big[2 + 3 * at] = dst;
+                                big[3 + 3 * at] = cc;
+                            } else {
+                                for (uint32_t i = 0; i < cc; ++i) out[dst + i] = staging[src + i];
+                            }
+                        }
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
             }
             run += __shfl(inc, 63, 64);
         }
+    }
+}
+
+// the token runs of very long pieces (big[0] entries {staging position, output position, count} recorded by tk_k_back): every entry is
+// copied by the whole grid
+__global__ __launch_bounds__(256) void tk_k_bigcopy(const uint32_t* __restrict__ big, const uint32_t* __restrict__ staging, uint32_t* __restrict__ out) {
+    const uint32_t nb = big[0] < TK_BIGCOPY_CAP ? big[0] : (uint32_t)TK_BIGCOPY_CAP;
+    for (uint32_t e = 0; e < nb; ++e) {
+        const uint32_t src = big[1 + 3 * e], dst = big[2 + 3 * e], cc = big[3 + 3 * e];
+        for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < cc; i += gridDim.x * 256u) out[dst + i] = staging[src + i];
     }
 }
 
