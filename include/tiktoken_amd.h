@@ -85,6 +85,12 @@ int tk_byte_pair_encode(tk_core* core, const uint8_t* piece, uint64_t len, uint3
 int tk_encode_single_token(tk_core* core, const uint8_t* piece, uint64_t len, uint32_t* token_out);
 /* CoreBPE.decode_bytes(tokens)         TK_KEY_ERROR "Invalid token for decoding: N"  src/py.rs:156-162, lib.rs:345-358 */
 int tk_decode_bytes(tk_core* core, const uint32_t* tokens, uint64_t n, uint8_t** bytes_out, uint64_t* len_out);
+/* The same for a packed batch, on the device: tokens of all documents back to back, tok_off[n_docs + 1] token offsets.  One call
+ * replaces the per-document thread pool of Encoding.decode_bytes_batch / decode_batch (tiktoken/core.py:331-350).  *bytes_out:
+ * library-owned (tk_free), byte_off_out (may be null): n_docs + 1 byte offsets.  TK_KEY_ERROR as tk_decode_bytes; TK_UNSUPPORTED
+ * when the ids are too sparse for a direct table (>= 2^26). */
+int tk_decode_batch(tk_core* core, const uint32_t* tokens, const uint64_t* tok_off, uint64_t n_docs, uint8_t** bytes_out,
+                    uint64_t* n_bytes_out, uint64_t* byte_off_out);
 /* CoreBPE.decode_single_token_bytes(token)  (pointer into the core; do not free)  src/py.rs:164-172 */
 int tk_decode_single_token_bytes(tk_core* core, uint32_t token, const uint8_t** bytes_out, uint64_t* len_out);
 /* CoreBPE.token_byte_values(): tokens in lexicographic byte order                  src/py.rs:178-183, lib.rs:648-650 */

@@ -39,6 +39,7 @@ def lib():
         L.tko_encode_ordinary.argtypes = [vp, vp, u64, vp, u64]
         L.tko_encode.restype = ctypes.c_int64
         L.tko_encode.argtypes = [vp, vp, u64, vp, u64, vp, u64]
+        L.tko_last_encode_seconds.restype = ctypes.c_double
         L.tko_encode_batch.restype = i32
         L.tko_encode_batch.argtypes = [vp, vp, vp, u64, i32, vp, u64, i32, vp, vp]
         _LIB = L
@@ -131,3 +132,8 @@ class COracle:
                                     n_threads, tokens.ctypes.data, tok_off.ctypes.data)
         assert rc == 0
         return tokens[: int(tok_off[-1])], tok_off
+
+
+def last_encode_seconds() -> float:
+    """Wall time of the parallel per-document phase of the last COracle.encode_batch call (its packing pass excluded)."""
+    return float(lib().tko_last_encode_seconds())

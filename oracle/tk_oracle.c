@@ -5,6 +5,7 @@
 #include <pthread.h>
 #include <stdlib.h>
 #include <string.h>
+#include <time.h>
 
 #include "tk_unicode_tables.inc"
 
@@ -554,9 +555,20 @@ static void* worker(void* arg) {
     return 0;
 }
 
+static double g_last_encode_seconds = 0.0;
+/* wall time of the parallel per-document encode of the last tko_encode_batch call (what the reference's thread pool does,
+ * core.py:175); the packing of the results into one buffer that follows is this oracle's own addition and is excluded */
+double tko_last_encode_seconds(void) { return g_last_encode_seconds; }
+static double now_seconds(void) {
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1e-9 * (double)ts.tv_nsec;
+}
+
 int tko_encode_batch(const tko_vocab* v, const uint8_t* blob, const uint64_t* doc_off, uint64_t n_docs, int mode,
                      const uint32_t* allowed_ids, uint64_t n_allowed, int n_threads, uint32_t* tokens_out,
                      uint64_t* tok_off_out) {
+    const double t_start = now_seconds();
     if (n_threads < 1) n_threads = 1;
     if (n_threads > 256) n_threads = 256;
     uint64_t* counts = (uint64_t*)calloc(n_docs ? n_docs : 1, sizeof(uint64_t));
@@ -571,6 +583,7 @@ int tko_encode_batch(const tko_vocab* v, const uint8_t* blob, const uint64_t* do
         worker(&jobs[0]);
     else
         for (int t = 0; t < n_threads; ++t) pthread_join(th[t], 0);
+    g_last_encode_seconds = now_seconds() - t_start;
     /* tokens of document d sit at index doc_off[d]; compact them forward (dest <= src always) */
     uint64_t w = 0;
     for (uint64_t d = 0; d < n_docs; ++d) {

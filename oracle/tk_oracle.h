@@ -62,7 +62,11 @@ int tko_encode_batch(const tko_vocab* v, const uint8_t* blob, const uint64_t* do
                      int mode, const uint32_t* allowed_ids, uint64_t n_allowed, int n_threads,
                      uint32_t* tokens_out, uint64_t* tok_off_out);
 
+/* seconds spent in the parallel per-document encode of the last tko_encode_batch call (the packing pass that follows is excluded) */
+double tko_last_encode_seconds(void);
+
 #ifdef __cplusplus
 }
 #endif
+
 #endif

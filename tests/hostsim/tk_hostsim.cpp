@@ -75,6 +75,7 @@ void* tks_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uin
     D.piece = H.piece.data();
     D.piece_off = H.piece_off.data();
     D.piece_mask = H.piece_mask;
+    D.max_token_len = H.max_token_len;
     D.tok_bytes = H.tok_bytes.data();
     D.pair = H.pair8.empty() ? H.pair.data() : nullptr;
     D.pair8 = H.pair8.empty() ? nullptr : H.pair8.data();

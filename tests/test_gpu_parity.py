@@ -243,3 +243,95 @@ def test_baseline_configs_at_full_size(cfg):
         raise AssertionError((cfg, "first differing token", i, "document", d, blob[int(off[d]):int(off[d + 1])].tobytes()[:200]))
     if allowed:
         assert np.isin(toks, np.array(sorted(specials.values()), np.uint32)).sum() > 0  # (specials were really exercised)
+
+
+# ---------------------------------------------------------------- long pieces (reference tests/test_encoding.py:52-57, CHANGELOG v0.13.0)
+@pytest.mark.parametrize("unit", ["x", " ", "中"])
+def test_megabyte_runs_are_fast(cores, unit):
+    """A million repetitions of one character is ONE piece (or two): pre-tokenised by the workgroup-wide scanner, merged in rounds.
+    Bit-exact, and under 20 ms per call -- the reference added _byte_pair_merge_large precisely so that such inputs are cheap."""
+    import time
+
+    core, C = cores["o200k_shaped"], h.c_oracle_for("o200k_shaped")
+    data = (unit * 1_000_000).encode()
+    want = C.encode_ordinary(data)
+    assert np.array_equal(core._encode_np(data, None), want)
+    best = 1e9
+    for _ in range(3):
+        t0 = time.perf_counter()
+        got = core._encode_np(data, None)
+        best = min(best, time.perf_counter() - t0)
+    assert np.array_equal(got, want)
+    assert best < 0.020, f"{unit!r} * 1e6 took {best * 1e3:.1f} ms"
+
+
+@pytest.mark.parametrize("name", h.ENCODING_NAMES)
+def test_long_runs_of_every_kind(cores, name):
+    """Documents made of long runs (2..40 KiB) of letters, digits, white space with and without newlines, punctuation, CJK, accented
+    letters, alternating case, contractions -- every path of the scanner over run queries, the digit-group jumps, the far-away
+    piece starts and the merges in rounds -- against the oracle, every token."""
+    core, C = cores[name], h.c_oracle_for(name)
+    rng = np.random.default_rng(0xA11)
+    units = ["x", "Q", "é", "中", "ก", "1", "٣", " ", "\t", "\n", " \n", "\r\n", "!", "/", "!/\n", "'", "x'll", "Ab", "aB1", "　", "é", "a ", " a", "0 ", "--"]
+    docs = []
+    for _ in range(60):
+        parts = []
+        for _ in range(int(rng.integers(1, 5))):
+            u = units[int(rng.integers(0, len(units)))]
+            parts.append(u * int(rng.integers(2_000, 40_000) // len(u.encode())))
+            if rng.random() < 0.5:
+                parts.append("".join(rng.choice(h.ADV, size=int(rng.integers(0, 6)))))
+        docs.append("".join(parts).encode())
+    blob, off = h.pack(docs)
+    toks, toff = core.encode_batch_packed(blob, off)
+    rt, ro = C.encode_batch(blob, off, None, 8)
+    assert np.array_equal(toff, ro), int(np.flatnonzero(toff != ro)[0]) - 1
+    assert np.array_equal(toks, rt)
+    starts = core.pretokenize_packed(blob, off)
+    bb = blob.tobytes()
+    ref = []
+    for d in range(len(off) - 1):
+        a, b = int(off[d]), int(off[d + 1])
+        ref += [a] + [a + e for e in C.split(bb[a:b])[:-1]] if b > a else []
+    ref.append(len(bb))
+    assert starts.tolist() == ref
+
+
+def test_rounds_and_one_at_a_time_merges_agree(monkeypatch):
+    """Long pieces go through tk_k_merge_rounds (all pairs of the lowest rank per round, its assumption checked round by round);
+    debug bit 1024 forces tk_k_merge_long (the reference's order literally) for the same pieces."""
+    from tiktoken_amd import CoreBPE
+
+    g = h.load_golden("cl100k_shaped")
+    rng = np.random.default_rng(5)
+    pieces = [("ab" * 3000).encode(), bytes(rng.integers(97, 123, size=5000, dtype=np.uint8)), ("the quick brown fox " * 400).replace(" ", "").encode(),
+              ("中文字" * 1500).encode(), bytes(rng.integers(0, 256, size=3000, dtype=np.uint8))]
+    a = CoreBPE(h.golden_vocab("cl100k_shaped"), g["special_tokens"], g["pat_str"])
+    monkeypatch.setenv("TIKTOKEN_AMD_DEBUG", "1024")
+    b = CoreBPE(h.golden_vocab("cl100k_shaped"), g["special_tokens"], g["pat_str"])
+    monkeypatch.delenv("TIKTOKEN_AMD_DEBUG")
+    C = h.c_oracle_for("cl100k_shaped")
+    for p in pieces:
+        want = C.encode_piece(p)
+        assert a.encode_single_piece(p) == want
+        assert b.encode_single_piece(p) == want
+
+
+# ---------------------------------------------------------------- decode on the device (src/lib.rs:345-358)
+def test_decode_batch_on_device(cores):
+    core = cores["o200k_shaped"]
+    blob, off = h.gen_corpus(0xDEC0DE, 1, 4 << 20)
+    toks, toff = core.encode_batch_packed(blob, off)
+    data, boff = core.decode_batch_packed(toks, toff)
+    assert data == blob.tobytes() and np.array_equal(boff, off)
+    # one long document through tk_decode_bytes (device path), a short one on the host, special tokens, an unknown id
+    assert core.decode_bytes(toks[: int(toff[40])].tolist()) == blob[: int(off[40])].tobytes()
+    assert core.decode_bytes(toks[:7].tolist()) == b"".join(core.decode_single_token_bytes(int(t)) for t in toks[:7])
+    sp = np.array([199999, 200018] * 5000, np.uint32)
+    assert core.decode_batch_packed(sp, np.array([0, len(sp)], np.uint64))[0] == b"<|endoftext|><|endofprompt|>" * 5000
+    bad = toks[:20000].copy()
+    bad[12345] = 199_998_0
+    with pytest.raises(KeyError, match="Invalid token for decoding: 1999980"):
+        core.decode_batch_packed(bad, np.array([0, len(bad)], np.uint64))
+    data, boff = core.decode_batch_packed(np.zeros(0, np.uint32), np.zeros(3, np.uint64))
+    assert data == b"" and boff.tolist() == [0, 0, 0]

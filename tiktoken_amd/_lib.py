@@ -66,6 +66,8 @@ def lib() -> ctypes.CDLL:
         L.tk_encode_single_token.argtypes = [vp, vp, u64, P(u32)]
         L.tk_decode_bytes.restype = i32
         L.tk_decode_bytes.argtypes = [vp, vp, u64, P(vp), P(u64)]
+        L.tk_decode_batch.restype = i32
+        L.tk_decode_batch.argtypes = [vp, vp, vp, u64, P(vp), P(u64), vp]
         L.tk_decode_single_token_bytes.restype = i32
         L.tk_decode_single_token_bytes.argtypes = [vp, u32, P(vp), P(u64)]
         L.tk_n_tokens.restype = u64

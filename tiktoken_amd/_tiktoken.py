@@ -302,6 +302,22 @@ class CoreBPE:
         self._L.tk_free(out)
         return data
 
+    def decode_batch_packed(self, tokens: np.ndarray, tok_off: np.ndarray) -> tuple[bytes, np.ndarray]:
+        """One GPU call for a packed batch: (all bytes back to back, byte_off uint64[n_docs + 1])  -- tk_decode_batch."""
+        tokens = np.ascontiguousarray(tokens, dtype=np.uint32)
+        tok_off = np.ascontiguousarray(tok_off, dtype=np.uint64)
+        if tok_off.ndim != 1 or len(tok_off) < 1 or int(tok_off[-1]) != len(tokens):
+            raise ValueError("tok_off must hold n_docs + 1 offsets ending at len(tokens)")
+        byte_off = np.empty(len(tok_off), dtype=np.uint64)
+        out, n = ctypes.c_void_p(), ctypes.c_uint64()
+        src = tokens if len(tokens) else np.zeros(1, dtype=np.uint32)
+        rc = self._L.tk_decode_batch(self._h, src.ctypes.data, tok_off.ctypes.data, len(tok_off) - 1, ctypes.byref(out), ctypes.byref(n),
+                                     byte_off.ctypes.data)
+        _lib.raise_for(rc)
+        data = ctypes.string_at(out, n.value)
+        self._L.tk_free(out)
+        return data, byte_off
+
     def decode_single_token_bytes(self, token: int) -> bytes:
         if not 0 <= token <= 0xFFFFFFFF:
             raise KeyError(str(token))

@@ -192,14 +192,24 @@ class Encoding:
         return b"".join(pieces).decode("utf-8", errors="strict"), offsets
 
     def decode_batch(self, batch: Sequence[Sequence[int]], *, errors: str = "replace", num_threads: int = 8) -> list[str]:
-        with ThreadPoolExecutor(num_threads) as pool:
-            return list(pool.map(functools.partial(self.decode, errors=errors), batch))
+        """Decode a batch; the whole batch goes to the GPU in one call (`num_threads` is accepted for compatibility)."""
+        return [b.decode("utf-8", errors=errors) for b in self.decode_bytes_batch(batch)]
 
     def decode_bytes_batch(self, batch: Sequence[Sequence[int]], *, num_threads: int = 8) -> list[bytes]:
-        with ThreadPoolExecutor(num_threads) as pool:
-            return list(pool.map(self.decode_bytes, batch))
+        """One GPU call for the whole batch (tk_decode_batch) instead of one pool task per document."""
+        import numpy as np
 
-    # ------------------------------------------------------------------ misc
+        lens = np.fromiter((len(t) for t in batch), dtype=np.uint64, count=len(batch))
+        tok_off = np.zeros(len(batch) + 1, dtype=np.uint64)
+        np.cumsum(lens, out=tok_off[1:])
+        flat = np.fromiter((t for doc in batch for t in doc), dtype=np.uint32, count=int(tok_off[-1]))
+        try:
+            data, byte_off = self._core_bpe.decode_batch_packed(flat, tok_off)
+        except ValueError:  # (ids too sparse for the device table)
+            return [self.decode_bytes(t) for t in batch]
+        bounds = byte_off.tolist()
+        return [data[a:b] for a, b in zip(bounds[:-1], bounds[1:])]
+
     def token_byte_values(self) -> list[bytes]:
         return self._core_bpe.token_byte_values()
 

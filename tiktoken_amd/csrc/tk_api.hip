@@ -12,6 +12,7 @@
 #include <vector>
 
 #include "../../include/tiktoken_amd.h"
+#include "tk_decode.h"
 #include "tk_fused.h"
 #include "tk_tables.h"
 #include "tk_unicode_tables.inc"
@@ -63,7 +64,7 @@ struct tk_core {
     uint32_t* h_counters = nullptr;  // pinned
     TkHostTables H;
     TkTables D;  // device view
-    Buf t_stage1, t_stage2, t_byte_tab, t_short, t_mid, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_spec_bytes, t_spec_off, t_spec_id;
+    Buf t_stage1, t_stage2, t_byte_tab, t_short, t_mid, t_dec, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_spec_bytes, t_spec_off, t_spec_id;
     uint32_t spec_max_len = 0;
     std::mutex mu;
     // workspace
@@ -71,6 +72,8 @@ struct tk_core {
         g_pv, g_lv, out_tokens, out_tok_off, allowed, tile_np, tile_nt, tile_nmiss, mt_slots, wbin, wave_pieces, deferred, big;
     uint64_t chunk_bytes = 1ull << 30;
     int dbg = 0;
+    uint32_t n_dec = 0;  // entries of the device decode table (0: ids too sparse for a direct table -- decode stays on the host)
+    Buf d_tok, d_lens, d_bsum, d_tboff, d_bytes, d_boff;  // decode workspace
     std::vector<uint8_t> sorted_blob;  // token_byte_values(), packed (built on first use)
     std::vector<uint64_t> sorted_off;
     // instrumentation
@@ -203,6 +206,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     D.piece = c->t_piece.as<TkPieceSlot>();
     D.piece_off = c->t_piece_off.as<uint32_t>();
     D.piece_mask = H.piece_mask;
+    D.max_token_len = H.max_token_len;
     D.tok_bytes = c->t_tok_bytes.as<uint8_t>();
     D.pair = H.pair8.empty() ? c->t_pair.as<TkPairSlot>() : nullptr;
     D.pair8 = H.pair8.empty() ? nullptr : c->t_pair.as<uint64_t>();
@@ -216,6 +220,18 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     memcpy(D.spec_first, H.spec_first, sizeof D.spec_first);
     D.pattern = H.pattern;
     for (size_t k = 0; k + 1 < H.spec_off.size(); ++k) c->spec_max_len = std::max(c->spec_max_len, H.spec_off[k + 1] - H.spec_off[k]);
+    {  // decode table: id -> {offset into the token / special blob, length}
+        uint32_t max_id = 0;
+        for (const auto& kv : H.decoder) max_id = std::max(max_id, kv.first);
+        for (const auto& kv : H.spec_decoder) max_id = std::max(max_id, kv.first);
+        if (max_id < (1u << 26)) {
+            std::vector<uint2> dec((size_t)max_id + 1, make_uint2(0, 0));
+            for (const auto& kv : H.spec_decoder) dec[kv.first] = make_uint2(kv.second.first | TK_DEC_SPEC, kv.second.second);
+            for (const auto& kv : H.decoder) dec[kv.first] = make_uint2(kv.second.first, kv.second.second);  // (lib.rs:347-351: decoder first)
+            if ((rc = upload(c->t_dec, dec.data(), dec.size() * sizeof(uint2)))) return bail(rc);
+            c->n_dec = max_id + 1;
+        }
+    }
     if (const char* e = getenv("TIKTOKEN_AMD_CHUNK_BYTES")) {
         uint64_t v = strtoull(e, nullptr, 10);
         if (v >= 4096 && v <= (3ull << 30)) c->chunk_bytes = v;
@@ -228,7 +244,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
 extern "C" void tk_destroy(tk_core* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_piece, &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2,
+    for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_dec, &c->d_tok, &c->d_lens, &c->d_bsum, &c->d_tboff, &c->d_bytes, &c->d_boff, &c->t_piece, &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2,
                    &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off, &c->brk, &c->docb,
                    &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->res, &c->rflag, &c->staging, &c->listB,
                    &c->listC, &c->counters, &c->total, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv, &c->out_tokens,
@@ -468,19 +484,19 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
             TRY(ensure(c->g_nx, (lb + 64) * 4));
             TRY(ensure(c->g_pv, (lb + 64) * 4));
             TRY(ensure(c->g_lv, (lvls + 64) * 8));
-            if (c->H.monotone && !(c->dbg & 1024)) {  // (debug bit 1024: force the one-merge-at-a-time kernel)
-                TRY(timed(c, s, "tk_k_merge_long", [&] {
+            const bool rounds = !(c->dbg & 1024);  // (debug bit 1024: one merge at a time for every long piece)
+            if (rounds) {
+                TRY(timed(c, s, "tk_k_merge_rounds", [&] {
                     hipLaunchKernelGGL(tk_k_merge_rounds, dim3(grid_for(nC, 1, 1024)), dim3(TKB_THREADS), 0, s, T, d_text, c->listC.as<uint32_t>(),
                                        (uint32_t)nC, c->g_id.as<uint32_t>(), c->g_rk.as<uint32_t>(), c->g_nx.as<uint32_t>(), c->g_pv.as<uint32_t>(),
                                        miss, stg);
                 }));
-            } else {
-                TRY(timed(c, s, "tk_k_merge_long", [&] {
-                    hipLaunchKernelGGL(tk_k_merge_long, dim3(grid_for(nC, 4, 8192)), dim3(256), 0, s, T, d_text, c->listC.as<uint32_t>(), (uint32_t)nC,
-                                       c->g_id.as<uint32_t>(), c->g_rk.as<uint32_t>(), c->g_nx.as<uint32_t>(), c->g_pv.as<uint32_t>(),
-                                       c->g_lv.as<uint64_t>(), miss, stg);
-                }));
             }
+            TRY(timed(c, s, "tk_k_merge_long", [&] {
+                hipLaunchKernelGGL(tk_k_merge_long, dim3(grid_for(nC, 4, 8192)), dim3(256), 0, s, T, d_text, c->listC.as<uint32_t>(), (uint32_t)nC,
+                                   c->g_id.as<uint32_t>(), c->g_rk.as<uint32_t>(), c->g_nx.as<uint32_t>(), c->g_pv.as<uint32_t>(),
+                                   c->g_lv.as<uint64_t>(), miss, stg, rounds ? 1 : 0);
+            }));
         }
         if (mt) {
             TRY(timed(c, s, "tk_k_dup_publish", [&] { hipLaunchKernelGGL(tk_k_dup_publish, dim3(grid_for(1ull << mt_bits, 256, 4096)), dim3(256), 0, s, mt, 1u << mt_bits, miss); }));
@@ -741,6 +757,10 @@ extern "C" int tk_decode_single_token_bytes(tk_core* c, uint32_t token, const ui
 
 extern "C" int tk_decode_bytes(tk_core* c, const uint32_t* tokens, uint64_t n, uint8_t** bytes_out, uint64_t* len_out) {
     if (!c) return fail(TK_VALUE_ERROR, "core is null");
+    if (n >= 8192 && c->n_dec) {  // long inputs: on the device (short ones are quicker on the host than a launch)
+        const uint64_t off[2] = {0, n};
+        return tk_decode_batch(c, tokens, off, 1, bytes_out, len_out, nullptr);
+    }
     std::string acc;
     acc.reserve(n * 4);
     for (uint64_t i = 0; i < n; ++i) {
@@ -754,6 +774,69 @@ extern "C" int tk_decode_bytes(tk_core* c, const uint32_t* tokens, uint64_t n, u
     memcpy(host, acc.data(), acc.size());
     *bytes_out = host;
     *len_out = acc.size();
+    return TK_OK;
+}
+
+// CoreBPE.decode_bytes over a packed batch (Encoding.decode_bytes_batch / decode_batch, tiktoken/core.py:331-350), on the device.
+extern "C" int tk_decode_batch(tk_core* c, const uint32_t* tokens, const uint64_t* tok_off, uint64_t n_docs, uint8_t** bytes_out,
+                               uint64_t* n_bytes_out, uint64_t* byte_off_out) {
+    if (!c) return fail(TK_VALUE_ERROR, "core is null");
+    if (!tok_off || !bytes_out || !n_bytes_out) return fail(TK_VALUE_ERROR, "null argument");
+    if (tok_off[0] != 0) return fail(TK_VALUE_ERROR, "tok_off[0] must be 0");
+    for (uint64_t d = 0; d < n_docs; ++d)
+        if (tok_off[d + 1] < tok_off[d]) return fail(TK_VALUE_ERROR, "tok_off must be non-decreasing");
+    if (!c->n_dec) return fail(TK_UNSUPPORTED, "token ids are too sparse for the device decode table");
+    const uint64_t n = tok_off[n_docs];
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
+    const uint64_t nb = (n + TK_DEC_BLOCK - 1) / TK_DEC_BLOCK;
+    TRY(ensure(c->d_tok, (n + 1) * 4));
+    TRY(ensure(c->d_lens, (n + 1) * 4));
+    TRY(ensure(c->d_bsum, (nb + 4) * 8));
+    TRY(ensure(c->d_tboff, (n + 1) * 8));
+    TRY(ensure(c->d_boff, (n_docs + 2) * 8 * 2));
+    unsigned long long* total = c->d_bsum.as<unsigned long long>() + nb + 1;  // [0] total bytes, [1] first invalid position
+    unsigned long long h_tot[2] = {0, ~0ull};
+    HIPCHK(hipMemcpyAsync(total, h_tot, 16, hipMemcpyHostToDevice, s));
+    if (n) {
+        HIPCHK(hipMemcpyAsync(c->d_tok.p, tokens, n * 4, hipMemcpyHostToDevice, s));
+        hipLaunchKernelGGL(tk_k_dec_len, dim3((uint32_t)nb), dim3(256), 0, s, c->d_tok.as<uint32_t>(), n, c->t_dec.as<uint2>(), c->n_dec,
+                           c->d_lens.as<uint32_t>(), c->d_bsum.as<unsigned long long>(), total + 1);
+        hipLaunchKernelGGL(tk_k_dec_scan64, dim3(1), dim3(1024), 0, s, c->d_bsum.as<unsigned long long>(), nb, total);
+    }
+    HIPCHK(hipMemcpyAsync(h_tot, total, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (h_tot[1] != ~0ull) return fail(TK_KEY_ERROR, "Invalid token for decoding: " + std::to_string(tokens[h_tot[1]]));
+    const uint64_t nbytes = h_tot[0];
+    TRY(ensure(c->d_bytes, nbytes + 16));
+    uint64_t* d_tok_off = c->d_boff.as<uint64_t>();
+    uint64_t* d_byte_off = d_tok_off + n_docs + 1;
+    if (n) {
+        hipLaunchKernelGGL(tk_k_dec_copy, dim3((uint32_t)nb), dim3(256), 0, s, c->d_tok.as<uint32_t>(), n, c->t_dec.as<uint2>(), c->d_lens.as<uint32_t>(),
+                           c->d_bsum.as<unsigned long long>(), c->D.tok_bytes, c->D.spec_bytes, c->d_bytes.as<uint8_t>(),
+                           c->d_tboff.as<unsigned long long>());
+    }
+    uint8_t* host = (uint8_t*)malloc(nbytes ? nbytes : 1);
+    if (!host) return fail(TK_RUNTIME_ERROR, "out of host memory");
+    hipError_t e = hipSuccess;
+    if (byte_off_out) {
+        e = hipMemcpyAsync(d_tok_off, tok_off, (n_docs + 1) * 8, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) {
+            hipLaunchKernelGGL(tk_k_dec_docoff, dim3(grid_for(n_docs + 1, 256, 4096)), dim3(256), 0, s, d_tok_off, n_docs, n,
+                               c->d_tboff.as<unsigned long long>(), total, d_byte_off);
+            e = hipMemcpyAsync(byte_off_out, d_byte_off, (n_docs + 1) * 8, hipMemcpyDeviceToHost, s);
+        }
+    }
+    if (e == hipSuccess && nbytes) e = hipMemcpyAsync(host, c->d_bytes.p, nbytes, hipMemcpyDeviceToHost, s);
+    if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipGetLastError();
+    if (e != hipSuccess) {
+        free(host);
+        return fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e));
+    }
+    *bytes_out = host;
+    *n_bytes_out = nbytes;
     return TK_OK;
 }
 

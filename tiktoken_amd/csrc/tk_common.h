@@ -90,6 +90,7 @@ struct TkTables {
     const TkPieceSlot* piece;   // [piece_mask+1] tokens of more than 8 bytes
     const uint32_t* piece_off;  // [piece_mask+1] offset of the slot's key bytes in tok_bytes
     uint64_t piece_mask;
+    uint32_t max_token_len;     // longest vocabulary token in bytes: a longer piece cannot be a token (no probe, no hash of its bytes)
     const uint8_t* tok_bytes;   // all token byte strings, concatenated
     const TkPairSlot* pair;     // [pair_mask+1] wide 16-byte slots (only when some id needs more than 21 bits)
     const uint64_t* pair8;      // [(pair_mask+1)*4] packed 8-byte slots in 4-slot buckets: (id_left:21 | id_right:21 | id_merged:22), ~0 = empty

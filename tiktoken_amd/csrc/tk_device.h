@@ -826,6 +826,7 @@ TK_HD uint32_t tk_lookup_text_piece(const TkTables& T, const uint8_t* __restrict
         if (len <= 4u && T.short_tab) return tk_probe_short(T, (uint32_t)key, len);
         return tk_probe_mid(T, key, len);
     }
+    if (len > T.max_token_len) return TK_RANK_MAX;  // longer than every token
     uint64_t key = tk_key_of_text(text, pos, len);
     return tk_probe_piece(T, key, len, [&](uint32_t off) { return tk_equal_bytes(text, pos, T.tok_bytes, off, len); });
 }

@@ -33,6 +33,7 @@
 
 #define TKF_NONE 0xFFFFFFFFu
 #define TKF_MISS_CAP 2048  // missed pieces per tile: each is at least two bytes long
+#define TK_MERGE_REDO 0xFFFFFFFFu  // miss[mi].x after tk_k_merge_rounds: the piece has to go through tk_k_merge_long
 #define TK_BIGCOPY 4096      // token runs from this length on are copied by tk_k_bigcopy
 #define TK_BIGCOPY_CAP 1024  // entries of its list
 #define TKF_CHAIN_END 0xFFFFFFFFFFFFFFFFull
@@ -815,7 +816,7 @@ __global__ __launch_bounds__(256, SLOW ? 2 : 8) void tk_k_front(TkTables T, cons
             // long: hash and first slot
             uint32_t k_l = 0, len_l = 9, sloc_l = 0;
             uint64_t key_l = 0, at_l = 0, gs_l = 0;
-            bool in_lds = true;
+            bool in_lds = true, too_long = false;
             if (has_l) {
                 i_l = ord_sl[1023u - q];
                 k_l = kb + i_l;
@@ -824,8 +825,11 @@ __global__ __launch_bounds__(256, SLOW ? 2 : 8) void tk_k_front(TkTables T, cons
                 len_l = e_loc - sloc_l;
                 gs_l = (uint64_t)(base + sloc_l);
                 in_lds = e_loc + 8u <= (uint32_t)TK2_WIN;
-                key_l = in_lds ? tk_key_of_lds(raw, sloc_l, len_l) : tk_key_of_text(text, gs_l, len_l);
-                at_l = tk_piece_slot_hash(key_l, len_l) & T.piece_mask;
+                too_long = len_l > T.max_token_len;  // (longer than every token: not a token, and no reason to hash a megabyte)
+                if (!too_long) {
+                    key_l = in_lds ? tk_key_of_lds(raw, sloc_l, len_l) : tk_key_of_text(text, gs_l, len_l);
+                    at_l = tk_piece_slot_hash(key_l, len_l) & T.piece_mask;
+                }
             }
             const TkPieceSlot slot_l = T.piece[at_l];
             // resolve
@@ -842,7 +846,7 @@ __global__ __launch_bounds__(256, SLOW ? 2 : 8) void tk_k_front(TkTables T, cons
                 else miss_m = true;
             }
             if (has_l) {
-                const uint32_t r = (dbg & 2) ? len_l : tk_probe_piece_from(T, key_l, len_l, at_l, slot_l, [&](uint32_t off) {
+                const uint32_t r = (dbg & 2) ? len_l : too_long ? TK_RANK_MAX : tk_probe_piece_from(T, key_l, len_l, at_l, slot_l, [&](uint32_t off) {
                     return in_lds ? tk_equal_lds_text(raw, sloc_l, T.tok_bytes, off, len_l) : tk_equal_bytes(text, gs_l, T.tok_bytes, off, len_l);
                 });
                 if (r != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k_l] = r == TK_RANK_MAX ? 0u : r;
@@ -1196,15 +1200,17 @@ __global__ __launch_bounds__(256) void tk_k_merge_group(TkTables T, const uint8_
     }
 }
 
+// (redo_only: after tk_k_merge_rounds -- only the pieces it has marked TK_MERGE_REDO)
 __global__ __launch_bounds__(256) void tk_k_merge_long(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listC,
                                                         uint32_t nC, uint32_t* __restrict__ g_id, uint32_t* __restrict__ g_rk,
                                                         uint32_t* __restrict__ g_nx, uint32_t* __restrict__ g_pv, uint64_t* __restrict__ g_lv,
-                                                        uint2* __restrict__ miss, uint32_t* __restrict__ staging) {
+                                                        uint2* __restrict__ miss, uint32_t* __restrict__ staging, int redo_only) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
     for (uint32_t w = wave; w < nC; w += nwaves) {
         const uint32_t* ent = listC + 5 * (uint64_t)w;
         const uint32_t mi = ent[0], s = ent[1], n = ent[2];
+        if (redo_only && miss[mi].x != TK_MERGE_REDO) continue;
         uint32_t* id = g_id + ent[3];
         uint32_t* rk = g_rk + ent[3];
         uint32_t* nx = g_nx + ent[3];
@@ -1297,12 +1303,13 @@ __global__ __launch_bounds__(256) void tk_k_merge_long(TkTables T, const uint8_t
 
 // ------------------------------------------------------------------------------------------
 // Long pieces, in rounds (one workgroup per piece).  byte_pair_merge (src/lib.rs:140-196) always merges the leftmost pair of the lowest
-// rank m.  When the vocabulary is MONOTONE -- every token that has a split into two tokens ranks above both of them, which holds for any
-// vocabulary produced by BPE training and is checked for the whole pair table at tk_create -- a merge of rank m only creates pairs that
-// rank above m, so the reference's next picks are exactly the other rank-m pairs, left to right, skipping the ones a pick has consumed.
-// One round therefore applies ALL of them at once: within a run of overlapping rank-m pairs the even ones.  The number of rounds is bounded
-// by the number of distinct ranks that get merged, not by the length: a megabyte of one character takes a few dozen rounds.
-// (Pieces of a non-monotone vocabulary go through tk_k_merge_long, one merge at a time.)
+// rank m.  As long as every pair that such a merge creates ranks ABOVE m -- the normal case: a longer token is learnt after its parts --
+// the reference's next picks are exactly the other rank-m pairs, left to right, skipping the ones a pick has consumed.  One round therefore
+// applies ALL of them at once: within a run of overlapping rank-m pairs the even ones.  The number of rounds is bounded by the number of
+// distinct ranks that get merged, not by the length: a megabyte of one character takes a few dozen rounds.
+// The condition is CHECKED, round by round, on every pair a merge creates -- the lasting ones and the ones that exist only between two
+// picks of the same round (merged part, not-yet-merged right neighbour).  A piece that violates it is handed to tk_k_merge_long (one merge
+// at a time, the reference's order literally), so the result never depends on the assumption.
 //   P0/R0 and P1/R1: the parts (token ids) and the rank of each part's pair with its right neighbour, double-buffered and compacted every round.
 // ------------------------------------------------------------------------------------------
 #define TKB_THREADS 1024
@@ -1317,7 +1324,7 @@ __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds(TkTables T, con
                                                                   uint2* __restrict__ miss, uint32_t* __restrict__ staging) {
     __shared__ uint32_t red[TKB_THREADS / 64];
     __shared__ uint32_t sc_all[TKB_THREADS / 64], sc_par[TKB_THREADS / 64], sc_cnt[TKB_THREADS / 64];
-    __shared__ uint32_t bcast;
+    __shared__ uint32_t viol_sh;
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     constexpr uint32_t MARK = 0x80000000u;  // (token ids stay below 2^31: checked at tk_create)
@@ -1330,8 +1337,10 @@ __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds(TkTables T, con
             P0[k] = T.byte_rank[b0];
             R0[k] = k + 1 < n ? T.pair2[(b0 << 8) | text[s + k + 1]] : TK_RANK_MAX;
         }
+        if (tid == 0) viol_sh = 0;
         __syncthreads();
         uint32_t cnt = n;
+        bool redo = false;
         for (;;) {
             const uint32_t per = (cnt + TKB_THREADS - 1) / TKB_THREADS;
             const uint32_t lo = tid * per < cnt ? tid * per : cnt, hi = lo + per < cnt ? lo + per : cnt;
@@ -1389,6 +1398,9 @@ __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds(TkTables T, con
                     P1[at] = f ? (m | MARK) : (P0[i] & ~MARK);
                     R1[at] = R0[i];                // (still right when neither this part nor the next one changes)
                     ++at;
+                    // the next pick of this round is the pair right after this one: between the two picks the pair (merged part,
+                    // its still unmerged right neighbour) exists and must not rank below m either
+                    if (f && i + 2 < cnt && R0[i + 2] == m && tk_probe_pair(T, m, P0[i + 2] & ~MARK) < m) viol_sh = 1;
                 }
                 par = f ? (par ^ 1u) : 0u;
             }
@@ -1398,18 +1410,29 @@ __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds(TkTables T, con
             for (uint32_t j = tid * per2; j < total && j < (tid + 1) * per2; ++j) {
                 const uint32_t a = P1[j], b = j + 1 < total ? P1[j + 1] : 0u;
                 if (j + 1 >= total) R1[j] = TK_RANK_MAX;
-                else if ((a | b) & MARK) R1[j] = tk_probe_pair(T, a & ~MARK, b & ~MARK);
+                else if ((a | b) & MARK) {
+                    const uint32_t r = tk_probe_pair(T, a & ~MARK, b & ~MARK);
+                    R1[j] = r;
+                    if (r < m) viol_sh = 1;  // a merge created a pair that the reference would have picked before the rest of this round
+                }
             }
             __syncthreads();
+            if (viol_sh) {
+                redo = true;
+                break;
+            }
             uint32_t* t0 = P0; P0 = P1; P1 = t0;
             t0 = R0; R0 = R1; R1 = t0;
             cnt = total;
         }
-        for (uint32_t k = tid; k < cnt; k += TKB_THREADS) staging[s + k] = P0[k] & ~MARK;
-        if (tid == 0) miss[mi] = make_uint2(cnt, cnt == 1 ? (P0[0] & ~MARK) : s);
+        if (redo) {
+            if (tid == 0) miss[mi] = make_uint2(TK_MERGE_REDO, 0u);
+        } else {
+            for (uint32_t k = tid; k < cnt; k += TKB_THREADS) staging[s + k] = P0[k] & ~MARK;
+            if (tid == 0) miss[mi] = make_uint2(cnt, cnt == 1 ? (P0[0] & ~MARK) : s);
+        }
         __syncthreads();
     }
-    (void)bcast;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -243,9 +243,7 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
         for (auto& e : part) entries.insert(entries.end(), e.begin(), e.end());  // (token order, as a single thread would produce)
     }
     T.n_pairs = entries.size();
-    T.monotone = true;
-    for (const TkPairSlot& e : entries)
-        if (e.rank <= (uint32_t)(e.key >> 32) || e.rank <= (uint32_t)e.key) T.monotone = false;
+
     uint32_t max_id = 0;
     for (uint64_t k = 0; k < n_ranks; ++k) max_id = std::max(max_id, ranks_ids[k]);
     if (max_id <= TK_PAIR8_MAX_ID) {

@@ -32,8 +32,6 @@ struct TkHostTables {
     // decoder side (src/lib.rs:323-324): rank -> (offset into tok_bytes / spec_bytes, length)
     std::unordered_map<uint32_t, std::pair<uint32_t, uint32_t>> decoder, spec_decoder;
     std::vector<uint32_t> sorted_ranks;  // ranks ordered by token bytes (lib.rs:648-650)
-    bool monotone = true;  // every token that splits into two tokens ranks above both (true for any BPE-trained vocabulary):
-                           // long pieces are then merged in rounds (tk_k_merge_rounds)
     uint32_t max_token_len = 0;
     uint64_t n_ranks = 0;
 
