@@ -99,6 +99,23 @@ int tk_sorted_token(tk_core* core, uint64_t i, const uint8_t** bytes_out, uint64
 /* The same list in one call: packed bytes + n+1 offsets, owned by the core (valid until tk_destroy). */
 int tk_sorted_tokens_packed(tk_core* core, const uint8_t** blob_out, const uint64_t** off_out, uint64_t* n_out);
 
+/* Several GPUs of one node in one process: the batch is split by documents into contiguous ranges of about equal byte counts, every
+ * core (one per device; created with tk_create) encodes its range from its own host thread, the token ids come back in document
+ * order.  Replaces nothing in the reference (its scaling knob is the thread pool of tiktoken/core.py:175); BASELINE north_star:
+ * "inputs shard by document across the GPUs of one node".  The group does not own the cores. */
+typedef struct tk_group tk_group;
+int tk_group_create(tk_core** cores, uint32_t n, tk_group** out);
+void tk_group_destroy(tk_group* group);
+uint32_t tk_group_size(tk_group* group);
+/* same contract as tk_encode_batch */
+int tk_group_encode_batch(tk_group* group, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special,
+                          const uint32_t* allowed_ids, uint64_t n_allowed, uint32_t** tokens_out, uint64_t* n_tokens_out,
+                          uint64_t* tok_off_out);
+/* results gathered on the first core's device with one peer copy per other core (xGMI); the pointers are owned by the group */
+int tk_group_encode_batch_device(tk_group* group, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special,
+                                 const uint32_t* allowed_ids, uint64_t n_allowed, const uint32_t** d_tokens_out, uint64_t* n_tokens_out,
+                                 const uint64_t** d_tok_off_out);
+
 /* Vocabulary wire format: the text of a `.tiktoken` file (`base64(token) SP rank` per line) -> the packed arrays tk_create takes.
  * Replaces the per-line Python loop of tiktoken/load.py:159-171.  Release the three arrays with tk_free.  TK_VALUE_ERROR with
  * "Error parsing line N ..." on malformed input. */

@@ -76,6 +76,15 @@ def lib() -> ctypes.CDLL:
         L.tk_sorted_token.argtypes = [vp, u64, P(vp), P(u64), P(u32)]
         L.tk_sorted_tokens_packed.restype = i32
         L.tk_sorted_tokens_packed.argtypes = [vp, P(vp), P(vp), P(u64)]
+        L.tk_group_create.restype = i32
+        L.tk_group_create.argtypes = [vp, u32, P(vp)]
+        L.tk_group_destroy.argtypes = [vp]
+        L.tk_group_size.restype = u32
+        L.tk_group_size.argtypes = [vp]
+        L.tk_group_encode_batch.restype = i32
+        L.tk_group_encode_batch.argtypes = [vp, vp, vp, u64, i32, vp, u64, P(vp), P(u64), vp]
+        L.tk_group_encode_batch_device.restype = i32
+        L.tk_group_encode_batch_device.argtypes = [vp, vp, vp, u64, i32, vp, u64, P(vp), P(u64), P(vp)]
         L.tk_parse_tiktoken_bpe.restype = i32
         L.tk_parse_tiktoken_bpe.argtypes = [vp, u64, P(vp), P(vp), P(vp), P(u64)]
         L.tk_free.argtypes = [vp]

@@ -48,10 +48,30 @@ def _check_packed(blob: np.ndarray, doc_off: np.ndarray) -> None:
         raise ValueError("doc_off must be non-decreasing")
 
 
+def default_devices() -> list[int]:
+    """Devices a CoreBPE uses when none are named: $TIKTOKEN_AMD_DEVICES (comma-separated ordinals, or "all"), else device 0."""
+    import os
+
+    v = os.environ.get("TIKTOKEN_AMD_DEVICES", "").strip()
+    if not v:
+        return [0]
+    if v == "all":
+        return list(range(max(_lib.device_count(), 1)))
+    return [int(x) for x in v.split(",") if x.strip()]
+
+
 class CoreBPE:
     def __init__(self, encoder: dict[bytes, int], special_tokens_encoder: dict[str, int], pattern: str, *,
-                 device: int = 0):
+                 device: int | None = None, devices: Sequence[int] | None = None):
+        """`devices`: several GPUs of this node (one replica of the tables per device; batches are split by documents into
+        contiguous ranges of about equal byte counts -- tk_group_encode_batch).  A device may be named twice (virtual ranks)."""
         L = _lib.lib()
+        if devices is None:
+            devices = [device] if device is not None else default_devices()
+        devices = list(devices)
+        device = devices[0]
+        self._replicas: list[CoreBPE] = []
+        self._group = None
         for v in encoder.values():
             if not 0 <= v <= 0xFFFFFFFF:
                 raise OverflowError("rank does not fit in u32")  # PyO3 would refuse the conversion too
@@ -66,8 +86,21 @@ class CoreBPE:
         self._h = h
         self._L = L
         self.device = device
+        self.devices = devices
+        if len(devices) > 1:
+            self._replicas = [CoreBPE(encoder, special_tokens_encoder, pattern, devices=[d]) for d in devices[1:]]
+            handles = (ctypes.c_void_p * len(devices))(h, *[r._h for r in self._replicas])
+            grp = ctypes.c_void_p()
+            _lib.raise_for(L.tk_group_create(handles, len(devices), ctypes.byref(grp)))
+            self._group = grp
 
     def __del__(self):
+        g, self._group = getattr(self, "_group", None), None
+        if g:
+            try:
+                self._L.tk_group_destroy(g)
+            except Exception:
+                pass
         h, self._h = getattr(self, "_h", None), None
         if h:
             try:
@@ -129,10 +162,34 @@ class CoreBPE:
         else:
             ids, k = self._allowed_ids(allowed_special)
             mode = 1
-        rc = self._L.tk_encode_batch(self._h, src.ctypes.data, doc_off.ctypes.data, n_docs, mode, ids.ctypes.data, k,
-                                     ctypes.byref(out), ctypes.byref(n), tok_off.ctypes.data)
+        if self._group is not None and n_docs > 1:
+            rc = self._L.tk_group_encode_batch(self._group, src.ctypes.data, doc_off.ctypes.data, n_docs, mode, ids.ctypes.data, k,
+                                               ctypes.byref(out), ctypes.byref(n), tok_off.ctypes.data)
+        else:
+            rc = self._L.tk_encode_batch(self._h, src.ctypes.data, doc_off.ctypes.data, n_docs, mode, ids.ctypes.data, k,
+                                         ctypes.byref(out), ctypes.byref(n), tok_off.ctypes.data)
         _lib.raise_for(rc)
         return _take_u32(out, n.value), tok_off
+
+    def encode_batch_gathered(self, blob: np.ndarray, doc_off: np.ndarray, allowed_special: AbstractSet[str] | None = None):
+        """Multi-GPU batch with the token ids gathered on the FIRST device (peer copies over xGMI): returns
+        (d_tokens_ptr, n_tokens, d_tok_off_ptr), device pointers owned by this CoreBPE and valid until its next call."""
+        if self._group is None:
+            raise ValueError("encode_batch_gathered needs a CoreBPE built with several devices")
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        doc_off = np.ascontiguousarray(doc_off, dtype=np.uint64)
+        _check_packed(blob, doc_off)
+        if allowed_special is None:
+            ids, k, mode = np.zeros(1, dtype=np.uint32), 0, 0
+        else:
+            ids, k = self._allowed_ids(allowed_special)
+            mode = 1
+        src = blob if len(blob) else np.zeros(1, dtype=np.uint8)
+        dt, dn, do = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_void_p()
+        rc = self._L.tk_group_encode_batch_device(self._group, src.ctypes.data, doc_off.ctypes.data, len(doc_off) - 1, mode, ids.ctypes.data, k,
+                                                  ctypes.byref(dt), ctypes.byref(dn), ctypes.byref(do))
+        _lib.raise_for(rc)
+        return dt.value, dn.value, do.value
 
     def encode_batch_device(self, d_text_ptr: int, n_bytes: int, d_doc_off_ptr: int, h_doc_off: np.ndarray | None,
                             n_docs: int, allowed_special: AbstractSet[str] | None = None, stream: int = 0):

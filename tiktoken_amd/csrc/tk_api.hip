@@ -9,6 +9,7 @@
 #include <map>
 #include <mutex>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/tiktoken_amd.h"
@@ -837,6 +838,161 @@ extern "C" int tk_decode_batch(tk_core* c, const uint32_t* tokens, const uint64_
     }
     *bytes_out = host;
     *n_bytes_out = nbytes;
+    return TK_OK;
+}
+
+// ------------------------------------------------------------------------------------------
+// Several GPUs of one node, one process: the documents of a batch are split into contiguous ranges of about equal
+// byte counts (documents never interact: tiktoken/core.py:174-176 maps a pure function), every core encodes its range on its own
+// device from its own host thread, and the token ids are gathered in document order -- on the host, or on the first core's device
+// through peer copies over xGMI.  No collective on the data path.
+// ------------------------------------------------------------------------------------------
+struct tk_group {
+    std::vector<tk_core*> cores;
+    Buf root_tokens, root_off;  // gathered results on cores[0]'s device (tk_group_encode_batch_device)
+};
+
+extern "C" int tk_group_create(tk_core** cores, uint32_t n, tk_group** out) {
+    if (!cores || !out || n == 0) return fail(TK_VALUE_ERROR, "tk_group_create needs at least one core");
+    for (uint32_t i = 0; i < n; ++i)
+        if (!cores[i]) return fail(TK_VALUE_ERROR, "null core");
+    tk_group* g = new tk_group();
+    g->cores.assign(cores, cores + n);
+    *out = g;
+    return TK_OK;
+}
+extern "C" void tk_group_destroy(tk_group* g) {
+    if (!g) return;
+    if (!g->cores.empty()) (void)hipSetDevice(g->cores[0]->device);
+    release(g->root_tokens);
+    release(g->root_off);
+    delete g;
+}
+extern "C" uint32_t tk_group_size(tk_group* g) { return g ? (uint32_t)g->cores.size() : 0; }
+
+// document ranges [first[r], first[r + 1]) of about equal byte counts (contiguous: the order of the results is the order of the input)
+static std::vector<uint64_t> partition_by_bytes(const uint64_t* doc_off, uint64_t n_docs, uint32_t parts) {
+    std::vector<uint64_t> first(parts + 1, n_docs);
+    first[0] = 0;
+    const uint64_t total = doc_off[n_docs];
+    uint64_t d = 0;
+    for (uint32_t r = 1; r < parts; ++r) {
+        const uint64_t want = total / parts * r + (total % parts) * r / parts;
+        while (d < n_docs && doc_off[d] < want) ++d;
+        first[r] = d;
+    }
+    return first;
+}
+
+struct ShardResult {
+    int rc = TK_OK;
+    std::string err;
+    uint32_t* tokens = nullptr;
+    uint64_t n_tokens = 0;
+    std::vector<uint64_t> tok_off;
+};
+
+static int group_encode(tk_group* g, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special, const uint32_t* allowed_ids,
+                        uint64_t n_allowed, std::vector<ShardResult>& res, std::vector<uint64_t>& first) {
+    if (!g) return fail(TK_VALUE_ERROR, "group is null");
+    if (!doc_off) return fail(TK_VALUE_ERROR, "null argument");
+    if (doc_off[0] != 0) return fail(TK_VALUE_ERROR, "doc_off[0] must be 0");
+    for (uint64_t d = 0; d < n_docs; ++d)
+        if (doc_off[d + 1] < doc_off[d]) return fail(TK_VALUE_ERROR, "doc_off must be non-decreasing");
+    const uint32_t R = (uint32_t)g->cores.size();
+    first = partition_by_bytes(doc_off, n_docs, R);
+    res.assign(R, ShardResult());
+    std::vector<std::thread> th;
+    for (uint32_t r = 0; r < R; ++r) {
+        th.emplace_back([&, r]() {
+            const uint64_t d0 = first[r], nd = first[r + 1] - d0;
+            std::vector<uint64_t> off(nd + 1);
+            for (uint64_t k = 0; k <= nd; ++k) off[k] = doc_off[d0 + k] - doc_off[d0];
+            ShardResult& o = res[r];
+            o.tok_off.assign(nd + 1, 0);
+            o.rc = tk_encode_batch(g->cores[r], utf8 + doc_off[d0], off.data(), nd, use_special, allowed_ids, n_allowed, &o.tokens, &o.n_tokens,
+                                   o.tok_off.data());
+            if (o.rc != TK_OK) o.err = tk_last_error();  // (thread-local message of this worker)
+        });
+    }
+    for (auto& t : th) t.join();
+    for (uint32_t r = 0; r < R; ++r)
+        if (res[r].rc != TK_OK) {
+            const int rc = res[r].rc;
+            const std::string msg = "device " + std::to_string(g->cores[r]->device) + ": " + res[r].err;
+            for (auto& o : res) free(o.tokens);
+            return fail(rc, msg);
+        }
+    return TK_OK;
+}
+
+// Encoding.encode_ordinary_batch / encode_batch over several GPUs; same contract as tk_encode_batch.
+extern "C" int tk_group_encode_batch(tk_group* g, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special,
+                                     const uint32_t* allowed_ids, uint64_t n_allowed, uint32_t** tokens_out, uint64_t* n_tokens_out,
+                                     uint64_t* tok_off_out) {
+    if (!tokens_out || !n_tokens_out) return fail(TK_VALUE_ERROR, "null argument");
+    std::vector<ShardResult> res;
+    std::vector<uint64_t> first;
+    TRY(group_encode(g, utf8, doc_off, n_docs, use_special, allowed_ids, n_allowed, res, first));
+    uint64_t total = 0;
+    std::vector<uint64_t> base(res.size() + 1, 0);
+    for (size_t r = 0; r < res.size(); ++r) {
+        base[r] = total;
+        total += res[r].n_tokens;
+    }
+    uint32_t* host = (uint32_t*)malloc((total ? total : 1) * 4);
+    if (!host) {
+        for (auto& o : res) free(o.tokens);
+        return fail(TK_RUNTIME_ERROR, "out of host memory");
+    }
+    std::vector<std::thread> th;
+    for (size_t r = 0; r < res.size(); ++r)
+        th.emplace_back([&, r]() {
+            if (res[r].n_tokens) memcpy(host + base[r], res[r].tokens, res[r].n_tokens * 4);
+            if (tok_off_out)
+                for (uint64_t k = 0; k + 1 < res[r].tok_off.size() || (r + 1 == res.size() && k < res[r].tok_off.size()); ++k)
+                    tok_off_out[first[r] + k] = base[r] + res[r].tok_off[k];
+            free(res[r].tokens);
+        });
+    for (auto& t : th) t.join();
+    *tokens_out = host;
+    *n_tokens_out = total;
+    return TK_OK;
+}
+
+// The same with the results gathered on the FIRST core's device: every other core's token ids travel there with one peer copy
+// (hipMemcpyPeer: xGMI between the GPUs of a node).  *d_tokens_out / *d_tok_off_out are owned by the group (valid until its next call).
+extern "C" int tk_group_encode_batch_device(tk_group* g, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special,
+                                            const uint32_t* allowed_ids, uint64_t n_allowed, const uint32_t** d_tokens_out,
+                                            uint64_t* n_tokens_out, const uint64_t** d_tok_off_out) {
+    if (!d_tokens_out || !n_tokens_out) return fail(TK_VALUE_ERROR, "null argument");
+    // (the shards' encodes leave their ids in each core's out_tokens buffer; the host copies made by tk_encode_batch are dropped)
+    std::vector<ShardResult> res;
+    std::vector<uint64_t> first;
+    TRY(group_encode(g, utf8, doc_off, n_docs, use_special, allowed_ids, n_allowed, res, first));
+    uint64_t total = 0;
+    std::vector<uint64_t> base(res.size() + 1, 0);
+    for (size_t r = 0; r < res.size(); ++r) {
+        base[r] = total;
+        total += res[r].n_tokens;
+        free(res[r].tokens);
+    }
+    tk_core* root = g->cores[0];
+    HIPCHK(hipSetDevice(root->device));
+    TRY(ensure(g->root_tokens, (total + 1) * 4));
+    TRY(ensure(g->root_off, (n_docs + 2) * 8));
+    std::vector<uint64_t> off(n_docs + 1, 0);
+    for (size_t r = 0; r < res.size(); ++r) {
+        tk_core* c = g->cores[r];
+        if (res[r].n_tokens)
+            HIPCHK(hipMemcpyPeer((uint32_t*)g->root_tokens.p + base[r], root->device, c->out_tokens.p, c->device, res[r].n_tokens * 4));
+        for (uint64_t k = 0; k + 1 < res[r].tok_off.size(); ++k) off[first[r] + k] = base[r] + res[r].tok_off[k];
+    }
+    off[n_docs] = total;
+    HIPCHK(hipMemcpy(g->root_off.p, off.data(), (n_docs + 1) * 8, hipMemcpyHostToDevice));
+    *d_tokens_out = g->root_tokens.as<uint32_t>();
+    if (d_tok_off_out) *d_tok_off_out = g->root_off.as<uint64_t>();
+    *n_tokens_out = total;
     return TK_OK;
 }
 

@@ -194,9 +194,13 @@ __device__ __noinline__ uint64_t tk_coop_last_in(const TkCoop& C, uint64_t from,
         if (wb <= (int64_t)from) return TK_NO_POS;
     }
 }
-// last certain piece start at or before `pos` (exists: position 0 and document starts are hard starts)
-__device__ __noinline__ uint64_t tk_coop_certain_before(const TkCoop* Cp, uint64_t pos) {
+// last certain piece start at or before `pos` (exists: position 0 and document starts are hard starts).  *last_other gets the highest
+// position in (result, pos] whose class differs from the class of the byte at `pos` (TK_NO_POS: none): when there is none behind the
+// first char, everything between the returned start and `pos` is one run of a single class.
+__device__ __noinline__ uint64_t tk_coop_certain_before(const TkCoop* Cp, uint64_t pos, uint64_t* last_other, uint32_t* cls_at_pos) {
     const TkCoop& C = *Cp;
+    uint64_t other = TK_NO_POS;
+    uint32_t cref = 16;  // (set in the first span: the lane that covers `pos`)
     for (int64_t wb = (int64_t)(pos & ~15ull) - 4080;; wb -= 4080) {  // (16 bytes of overlap: the first chunk of a span has no known
         const int64_t g = wb + 16ll * threadIdx.x;                    //  predecessor; the next span sees it as its last chunk)
         TkChunkMasks mk;
@@ -204,14 +208,31 @@ __device__ __noinline__ uint64_t tk_coop_certain_before(const TkCoop* Cp, uint64
         TkSets st;
         tk_sets_from_planes(mk.p[0], mk.p[1], mk.p[2], mk.p[3], st);
         C.lastc[threadIdx.x] = (uint8_t)tk_class_from_planes(mk.p, 15);
+        if (cref == 16 && g <= (int64_t)pos && (int64_t)pos < g + 16) C.red[4] = tk_class_from_planes(mk.p, (uint32_t)((int64_t)pos - g));
         __syncthreads();
+        if (cref == 16) cref = C.red[4];
         const uint32_t prevc = threadIdx.x ? (uint32_t)C.lastc[threadIdx.x - 1] : 0u;
         uint32_t cert = tk_chunk_certain(C.pat, st, mk.text, mk.hard & mk.text, prevc);
-        if (g > (int64_t)pos) cert = 0;
-        else if (g + 16 > (int64_t)pos + 1) cert &= (2u << (uint32_t)((int64_t)pos - g)) - 1u;
+        uint32_t oth = ~tk_member16(mk.p, 1u << cref) & 0xFFFFu;  // bytes of another class
+        if (g > (int64_t)pos) cert = oth = 0;
+        else if (g + 16 > (int64_t)pos + 1) {
+            cert &= (2u << (uint32_t)((int64_t)pos - g)) - 1u;
+            oth &= (2u << (uint32_t)((int64_t)pos - g)) - 1u;
+        }
+        if (g < 0) oth = 0;
         const uint32_t last = cert ? (uint32_t)(g - wb) + 31u - (uint32_t)__clz((int)cert) : TKF_NONE;
-        const uint32_t res = tk_coop_first(C, last, true);  // (its barriers also protect lastc)
-        if (res != TKF_NONE) return (uint64_t)(wb + res);
+        const uint32_t res = tk_coop_first(C, last, true);  // (its barriers also protect lastc and red[4])
+        if (other == TK_NO_POS) {
+            const uint32_t lo = oth ? (uint32_t)(g - wb) + 31u - (uint32_t)__clz((int)oth) : TKF_NONE;
+            const uint32_t ro = tk_coop_first(C, lo, true);
+            if (ro != TKF_NONE) other = (uint64_t)(wb + ro);
+        }
+        if (res != TKF_NONE) {
+            const uint64_t p0 = (uint64_t)(wb + res);
+            *last_other = (other != TK_NO_POS && other > p0) ? other : TK_NO_POS;
+            *cls_at_pos = cref;
+            return p0;
+        }
     }
 }
 struct TkCoopAcc {  // provider of tk_piece_end_runs: single positions straight from global memory (uniform loads), runs by the workgroup
@@ -628,7 +649,20 @@ __global__ __launch_bounds__(256, SLOW ? 2 : 8) void tk_k_front(TkTables T, cons
     };
     // The tile starts inside a piece and its left context holds no certain start: find the last one before it and walk from there.
     if constexpr (SLOW) {
-        if (need_walk) coop_chain(tk_coop_certain_before(&coop, tile_start - 1));
+        if (need_walk) {
+            uint64_t other;
+            uint32_t crun;
+            const uint64_t p0 = tk_coop_certain_before(&coop, tile_start - 1, &other, &crun);
+            // A tile deep inside a long run of one class: everything from the first char after p0 up to the end of this window is that
+            // class (and no hard start) -- the piece that covers the tile start began at p0 (or within a contraction's length of it) and
+            // reaches beyond the window: there is no piece start in this tile.  Only the tile in which the run ends evaluates the piece.
+            TkCoopAcc ca{coop};
+            const bool stretch_uniform = other == TK_NO_POS || other < tk_next_char(ca, p0);
+            const bool class_ok = crun >= (uint32_t)TK_C_NL && crun <= (uint32_t)TK_C_OT && (crun != TK_C_NU || PAT == TK_PAT_R50K);
+            const uint32_t here = tid >= T0 ? (uint32_t)((tk_member16(mk.p, 1u << (crun & 15u)) == 0xFFFFu) & (mk.hard == 0u)) : 1u;
+            const bool covered = stretch_uniform && class_ok && __syncthreads_and((int)here);
+            if (!covered) coop_chain(p0);
+        }
     }
     // Rounds around ONE instance of the lanes' evaluation (the scanner is big: a second inlined copy spills registers).
     //   round 0: one piece per scan start, all lanes busy.  94..98 % of the pieces end at a certain start; a chain that goes on (an
@@ -1318,12 +1352,23 @@ struct TkRunState {  // segment summary for the run-parity scan: is the segment 
 };
 __device__ __forceinline__ TkRunState tk_run_combine(TkRunState a, TkRunState b) { return TkRunState{a.all & b.all, b.all ? (a.par ^ b.par) : b.par}; }
 
+// inclusive scan of run states over a wavefront (lane order = element order)
+__device__ __forceinline__ TkRunState tk_run_scan_wave(TkRunState v, int lane) {
+#pragma unroll
+    for (int o = 1; o < 64; o <<= 1) {
+        const TkRunState up{(uint32_t)__shfl_up((int)v.all, o, 64), (uint32_t)__shfl_up((int)v.par, o, 64)};
+        if (lane >= o) v = tk_run_combine(up, v);
+    }
+    return v;
+}
+
 __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listC,
                                                                   uint32_t nC, uint32_t* __restrict__ g_p0, uint32_t* __restrict__ g_r0,
                                                                   uint32_t* __restrict__ g_p1, uint32_t* __restrict__ g_r1,
                                                                   uint2* __restrict__ miss, uint32_t* __restrict__ staging) {
-    __shared__ uint32_t red[TKB_THREADS / 64];
-    __shared__ uint32_t sc_all[TKB_THREADS / 64], sc_par[TKB_THREADS / 64], sc_cnt[TKB_THREADS / 64];
+    constexpr int NWV = TKB_THREADS / 64;
+    __shared__ uint32_t red[NWV];
+    __shared__ uint32_t sc_all[NWV], sc_par[NWV], sc_cnt[NWV];
     __shared__ uint32_t viol_sh;
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
@@ -1342,72 +1387,88 @@ __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds(TkTables T, con
         uint32_t cnt = n;
         bool redo = false;
         for (;;) {
-            const uint32_t per = (cnt + TKB_THREADS - 1) / TKB_THREADS;
-            const uint32_t lo = tid * per < cnt ? tid * per : cnt, hi = lo + per < cnt ? lo + per : cnt;
             // a. the lowest rank
             uint32_t m = TK_RANK_MAX;
-            for (uint32_t i = lo; i < hi; ++i) m = R0[i] < m ? R0[i] : m;
+            for (uint32_t i = tid; i < cnt; i += TKB_THREADS) m = R0[i] < m ? R0[i] : m;
             m = tk_wave_min_u32(m);
             if (lane == 0) red[wid] = m;
             __syncthreads();
-            m = red[lane & (TKB_THREADS / 64 - 1)];
+            m = red[lane & (NWV - 1)];
             m = tk_wave_min_u32(m);
             __syncthreads();
             if (m == TK_RANK_MAX) break;
-            // b. for every part: c = parity of the run of rank-m pairs right before it.  Thread summaries, then a workgroup scan.
-            TkRunState mine{1u, 0u};
-            for (uint32_t i = lo; i < hi; ++i) {
-                const uint32_t f = R0[i] == m;
-                mine = tk_run_combine(mine, TkRunState{f, f});
+            // Every wavefront owns a contiguous range of the parts and walks it in rows of 64 (coalesced); the state that crosses rows
+            // and wavefronts is the parity of the run of rank-m pairs that ends right before an element.
+            const uint32_t per = ((cnt + NWV - 1) / NWV + 63u) & ~63u;
+            const uint32_t wlo = (uint32_t)wid * per < cnt ? (uint32_t)wid * per : cnt, whi = wlo + per < cnt ? wlo + per : cnt;
+            // b. run state of each wavefront's range, then of everything before it
+            TkRunState acc{1u, 0u};
+            for (uint32_t r0 = wlo; r0 < whi; r0 += 64) {
+                const uint32_t i = r0 + lane;
+                const uint32_t f = i < whi ? (uint32_t)(R0[i] == m) : 0u;
+                TkRunState v{i < whi ? f : 1u, i < whi ? f : 0u};  // (padding lanes: the neutral element)
+                v = tk_run_scan_wave(v, lane);
+                const TkRunState row{(uint32_t)__shfl((int)v.all, 63, 64), (uint32_t)__shfl((int)v.par, 63, 64)};
+                acc = tk_run_combine(acc, row);
             }
-            TkRunState inc = mine;  // inclusive scan over the wave, then over the waves
-#pragma unroll
-            for (int o = 1; o < 64; o <<= 1) {
-                TkRunState up{(uint32_t)__shfl_up((int)inc.all, o, 64), (uint32_t)__shfl_up((int)inc.par, o, 64)};
-                if (lane >= o) inc = tk_run_combine(up, inc);
-            }
-            if (lane == 63) {
-                sc_all[wid] = inc.all;
-                sc_par[wid] = inc.par;
+            if (lane == 0) {
+                sc_all[wid] = acc.all;
+                sc_par[wid] = acc.par;
             }
             __syncthreads();
-            TkRunState before{1u, 0u};  // everything left of this thread's range
+            TkRunState before{1u, 0u};
             for (int q = 0; q < wid; ++q) before = tk_run_combine(before, TkRunState{sc_all[q], sc_par[q]});
+            // c. parts that survive in this range (a part right after an odd count of rank-m pairs is absorbed)
+            uint32_t keep = 0;
             {
-                TkRunState ex{(uint32_t)__shfl_up((int)inc.all, 1, 64), (uint32_t)__shfl_up((int)inc.par, 1, 64)};
-                if (lane > 0) before = tk_run_combine(before, ex);
+                TkRunState carry = before;
+                for (uint32_t r0 = wlo; r0 < whi; r0 += 64) {
+                    const uint32_t i = r0 + lane;
+                    const bool in = i < whi;
+                    const uint32_t f = in ? (uint32_t)(R0[i] == m) : 0u;
+                    TkRunState v = tk_run_scan_wave(TkRunState{in ? f : 1u, in ? f : 0u}, lane);
+                    TkRunState ex{(uint32_t)__shfl_up((int)v.all, 1, 64), (uint32_t)__shfl_up((int)v.par, 1, 64)};
+                    if (lane == 0) ex = TkRunState{1u, 0u};
+                    const uint32_t c = tk_run_combine(carry, ex).par;  // parity of the run of rank-m pairs right before element i
+                    keep += (uint32_t)__popcll(__ballot(in && c == 0u));
+                    carry = tk_run_combine(carry, TkRunState{(uint32_t)__shfl((int)v.all, 63, 64), (uint32_t)__shfl((int)v.par, 63, 64)});
+                }
             }
-            // c. parts that survive (a part right of an even pair of a run is absorbed): count, scan, write
-            uint32_t par = before.par, keep = 0;
-            for (uint32_t i = lo; i < hi; ++i) {
-                keep += par ^ 1u;  // (the pair before an absorbed part was selected: odd count of rank-m pairs before it)
-                par = R0[i] == m ? (par ^ 1u) : 0u;
-            }
-            const uint32_t kinc = tk_wave_scan_u32(keep, lane);
-            if (lane == 63) sc_cnt[wid] = kinc;
+            if (lane == 0) sc_cnt[wid] = keep;
             __syncthreads();
-            uint32_t at = kinc - keep, total = 0;
-            for (int q = 0; q < TKB_THREADS / 64; ++q) {
+            uint32_t at = 0, total = 0;
+            for (int q = 0; q < NWV; ++q) {
                 if (q < wid) at += sc_cnt[q];
                 total += sc_cnt[q];
             }
-            par = before.par;
-            for (uint32_t i = lo; i < hi; ++i) {
-                const uint32_t f = R0[i] == m;
-                if (!par) {                       // kept; selected when its own pair has rank m
-                    P1[at] = f ? (m | MARK) : (P0[i] & ~MARK);
-                    R1[at] = R0[i];                // (still right when neither this part nor the next one changes)
-                    ++at;
-                    // the next pick of this round is the pair right after this one: between the two picks the pair (merged part,
-                    // its still unmerged right neighbour) exists and must not rank below m either
-                    if (f && i + 2 < cnt && R0[i + 2] == m && tk_probe_pair(T, m, P0[i + 2] & ~MARK) < m) viol_sh = 1;
+            {
+                TkRunState carry = before;
+                for (uint32_t r0 = wlo; r0 < whi; r0 += 64) {
+                    const uint32_t i = r0 + lane;
+                    const bool in = i < whi;
+                    const uint32_t rk = in ? R0[i] : 0u;
+                    const uint32_t f = in ? (uint32_t)(rk == m) : 0u;
+                    TkRunState v = tk_run_scan_wave(TkRunState{in ? f : 1u, in ? f : 0u}, lane);
+                    TkRunState ex{(uint32_t)__shfl_up((int)v.all, 1, 64), (uint32_t)__shfl_up((int)v.par, 1, 64)};
+                    if (lane == 0) ex = TkRunState{1u, 0u};
+                    const uint32_t c = tk_run_combine(carry, ex).par;
+                    const bool kept = in && c == 0u;
+                    const uint64_t km = __ballot(kept);
+                    if (kept) {  // selected when its own pair has rank m
+                        const uint32_t o = at + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
+                        P1[o] = f ? (m | MARK) : (P0[i] & ~MARK);
+                        R1[o] = rk;  // (still right when neither this part nor the next one changes)
+                        // the next pick of this round is the pair right after this one: between the two picks the pair (merged part,
+                        // its still unmerged right neighbour) exists and must not rank below m either
+                        if (f && i + 2 < cnt && R0[i + 2] == m && tk_probe_pair(T, m, P0[i + 2] & ~MARK) < m) viol_sh = 1;
+                    }
+                    at += (uint32_t)__popcll(km);
+                    carry = tk_run_combine(carry, TkRunState{(uint32_t)__shfl((int)v.all, 63, 64), (uint32_t)__shfl((int)v.par, 63, 64)});
                 }
-                par = f ? (par ^ 1u) : 0u;
             }
             __syncthreads();
             // d. ranks of the pairs that a merge has touched
-            const uint32_t per2 = (total + TKB_THREADS - 1) / TKB_THREADS;
-            for (uint32_t j = tid * per2; j < total && j < (tid + 1) * per2; ++j) {
+            for (uint32_t j = tid; j < total; j += TKB_THREADS) {
                 const uint32_t a = P1[j], b = j + 1 < total ? P1[j + 1] : 0u;
                 if (j + 1 >= total) R1[j] = TK_RANK_MAX;
                 else if ((a | b) & MARK) {
