@@ -335,3 +335,36 @@ def test_decode_batch_on_device(cores):
         core.decode_batch_packed(bad, np.array([0, len(bad)], np.uint64))
     data, boff = core.decode_batch_packed(np.zeros(0, np.uint32), np.zeros(3, np.uint64))
     assert data == b"" and boff.tolist() == [0, 0, 0]
+
+
+# ---------------------------------------------------------------- several devices in one process (virtual ranks on one GPU here)
+def test_multi_device_group_equals_single_device():
+    """CoreBPE(devices=[...]): documents split into contiguous ranges of about equal bytes, one replica per device (tk_group_encode_batch);
+    on the one-GPU test box two and three replicas share device 0.  Same tokens and offsets as the oracle, ordinary and with specials;
+    the variant that gathers the ids on the first device (peer copies) returns the same."""
+    import torch
+
+    from bench import DevArray
+    from tiktoken_amd import CoreBPE
+
+    g = h.load_golden("cl100k_shaped")
+    C = h.c_oracle_for("cl100k_shaped")
+    blob, off = h.gen_corpus(0x6A7, 0, 6 << 20)
+    rt, ro = C.encode_batch(blob, off, None, 8)
+    for devices in ([0, 0], [0, 0, 0]):
+        core = CoreBPE(h.golden_vocab("cl100k_shaped"), g["special_tokens"], g["pat_str"], devices=devices)
+        toks, toff = core.encode_batch_packed(blob, off)
+        assert np.array_equal(toff, ro) and np.array_equal(toks, rt)
+        dt, nt, do = core.encode_batch_gathered(blob, off)
+        assert nt == len(rt)
+        assert np.array_equal(torch.as_tensor(DevArray(dt, nt, "<i4"), device="cuda").cpu().numpy().view(np.uint32), rt)
+        assert np.array_equal(torch.as_tensor(DevArray(do, len(off), "<i8"), device="cuda").cpu().numpy().astype(np.uint64), ro)
+    st, so = C.encode_batch(blob, off, {"<|endoftext|>"}, 8)
+    toks, toff = core.encode_batch_packed(blob, off, {"<|endoftext|>"})
+    assert np.array_equal(toff, so) and np.array_equal(toks, st)
+    # ragged: fewer documents than replicas, empty documents, an empty batch
+    for docs in ([b"one"], [b"", b""], [], [b"a", b"", b"bb " * 1000, b""]):
+        b2, o2 = h.pack(docs)
+        t2, f2 = core.encode_batch_packed(b2, o2)
+        w2, x2 = C.encode_batch(b2, o2, None, 1) if docs else (np.zeros(0, np.uint32), np.zeros(1, np.uint64))
+        assert np.array_equal(t2, w2) and np.array_equal(f2, x2), docs

@@ -358,7 +358,7 @@ __device__ __forceinline__ bool tk_equal_lds_text(const uint8_t* raw, uint32_t o
 // SLOW = true: the same kernel with that scanner compiled in (its calls cost registers: kept out of the common path), launched over the
 // deferred tiles with a fixed grid.
 template <int PAT, bool SPEC, bool SLOW>
-__global__ __launch_bounds__(256, SLOW ? 2 : 8) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
+__global__ __launch_bounds__(256, SLOW ? 3 : 8) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
                                                   const uint32_t* __restrict__ brk, const uint32_t* __restrict__ docb,
                                                   const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, TkFrontOut out,
                                                   TkMissSlot* __restrict__ mt, uint32_t mt_mask, uint32_t* __restrict__ deferred, int dbg) {
@@ -521,13 +521,14 @@ __global__ __launch_bounds__(256, SLOW ? 2 : 8) void tk_k_front(TkTables T, cons
     uint32_t mine = in_tile ? cert : 0u;
     uint32_t extra = TKF_NONE;
     if (wid == 0) {
-        uint64_t leftc = 0;  // certain starts of the 64-byte left context (lanes 0..3)
-#pragma unroll
-        for (int q = 0; q < (int)T0; ++q) leftc |= (uint64_t)(uint32_t)__shfl((int)cert, q, 64) << (16 * q);
+        // the last certain start of the left context (lanes 0 .. T0 - 1)
+        const uint64_t lm = __ballot(cert != 0u) & ((1ull << T0) - 1ull);
+        const int ll = lm ? 63 - __clzll((long long)lm) : 0;
+        const uint32_t lc = (uint32_t)__shfl((int)cert, ll, 64);
         if (tid == T0 && tile_start > 0 && tile_start < n) {
             const bool first_cert = mk.text && ((cert >> (__ffs((int)mk.text) - 1)) & 1u);
             if (!first_cert) {
-                if (leftc) extra = 63u - (uint32_t)__clzll((long long)leftc);
+                if (lm) extra = (uint32_t)ll * 16u + 31u - (uint32_t)__clz((int)lc);
                 else need_walk = 1;
             }
         }
@@ -1397,19 +1398,30 @@ __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds(TkTables T, con
             m = tk_wave_min_u32(m);
             __syncthreads();
             if (m == TK_RANK_MAX) break;
-            // Every wavefront owns a contiguous range of the parts and walks it in rows of 64 (coalesced); the state that crosses rows
-            // and wavefronts is the parity of the run of rank-m pairs that ends right before an element.
-            const uint32_t per = ((cnt + NWV - 1) / NWV + 63u) & ~63u;
+            // Every wavefront owns a contiguous range of the parts and walks it in rows of 256 (four consecutive parts per lane: coalesced,
+            // and one wave scan per 256 parts); the state that crosses lanes, rows and wavefronts is the parity of the run of rank-m pairs
+            // that ends right before a part.
+            constexpr uint32_t ROW = 256;
+            const uint32_t per = ((cnt + NWV - 1) / NWV + ROW - 1u) / ROW * ROW;
             const uint32_t wlo = (uint32_t)wid * per < cnt ? (uint32_t)wid * per : cnt, whi = wlo + per < cnt ? wlo + per : cnt;
+            // four parts of a lane: their rank-m flags (parts beyond the range: neutral) and the lane's run state
+            auto lane_state = [&](uint32_t i0, uint32_t rk[4], uint32_t f[4]) -> TkRunState {
+                TkRunState v{1u, 0u};
+#pragma unroll
+                for (int q = 0; q < 4; ++q) {
+                    const bool in = i0 + q < whi;
+                    rk[q] = in ? R0[i0 + q] : 0u;
+                    f[q] = in ? (uint32_t)(rk[q] == m) : 0u;
+                    if (in) v = tk_run_combine(v, TkRunState{f[q], f[q]});
+                }
+                return v;
+            };
             // b. run state of each wavefront's range, then of everything before it
             TkRunState acc{1u, 0u};
-            for (uint32_t r0 = wlo; r0 < whi; r0 += 64) {
-                const uint32_t i = r0 + lane;
-                const uint32_t f = i < whi ? (uint32_t)(R0[i] == m) : 0u;
-                TkRunState v{i < whi ? f : 1u, i < whi ? f : 0u};  // (padding lanes: the neutral element)
-                v = tk_run_scan_wave(v, lane);
-                const TkRunState row{(uint32_t)__shfl((int)v.all, 63, 64), (uint32_t)__shfl((int)v.par, 63, 64)};
-                acc = tk_run_combine(acc, row);
+            for (uint32_t r0 = wlo; r0 < whi; r0 += ROW) {
+                uint32_t rk[4], f[4];
+                TkRunState v = tk_run_scan_wave(lane_state(r0 + 4u * lane, rk, f), lane);
+                acc = tk_run_combine(acc, TkRunState{(uint32_t)__shfl((int)v.all, 63, 64), (uint32_t)__shfl((int)v.par, 63, 64)});
             }
             if (lane == 0) {
                 sc_all[wid] = acc.all;
@@ -1422,15 +1434,19 @@ __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds(TkTables T, con
             uint32_t keep = 0;
             {
                 TkRunState carry = before;
-                for (uint32_t r0 = wlo; r0 < whi; r0 += 64) {
-                    const uint32_t i = r0 + lane;
-                    const bool in = i < whi;
-                    const uint32_t f = in ? (uint32_t)(R0[i] == m) : 0u;
-                    TkRunState v = tk_run_scan_wave(TkRunState{in ? f : 1u, in ? f : 0u}, lane);
+                for (uint32_t r0 = wlo; r0 < whi; r0 += ROW) {
+                    const uint32_t i0 = r0 + 4u * lane;
+                    uint32_t rk[4], f[4];
+                    TkRunState v = tk_run_scan_wave(lane_state(i0, rk, f), lane);
                     TkRunState ex{(uint32_t)__shfl_up((int)v.all, 1, 64), (uint32_t)__shfl_up((int)v.par, 1, 64)};
                     if (lane == 0) ex = TkRunState{1u, 0u};
-                    const uint32_t c = tk_run_combine(carry, ex).par;  // parity of the run of rank-m pairs right before element i
-                    keep += (uint32_t)__popcll(__ballot(in && c == 0u));
+                    uint32_t c = tk_run_combine(carry, ex).par, kl = 0;  // parity of the run of rank-m pairs right before the lane's first part
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        kl += (uint32_t)(i0 + q < whi) & (c ^ 1u);
+                        c = f[q] ? (c ^ 1u) : 0u;
+                    }
+                    keep += tk_wave_sum_u32(kl);
                     carry = tk_run_combine(carry, TkRunState{(uint32_t)__shfl((int)v.all, 63, 64), (uint32_t)__shfl((int)v.par, 63, 64)});
                 }
             }
@@ -1443,26 +1459,35 @@ __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds(TkTables T, con
             }
             {
                 TkRunState carry = before;
-                for (uint32_t r0 = wlo; r0 < whi; r0 += 64) {
-                    const uint32_t i = r0 + lane;
-                    const bool in = i < whi;
-                    const uint32_t rk = in ? R0[i] : 0u;
-                    const uint32_t f = in ? (uint32_t)(rk == m) : 0u;
-                    TkRunState v = tk_run_scan_wave(TkRunState{in ? f : 1u, in ? f : 0u}, lane);
+                for (uint32_t r0 = wlo; r0 < whi; r0 += ROW) {
+                    const uint32_t i0 = r0 + 4u * lane;
+                    uint32_t rk[4], f[4];
+                    TkRunState v = tk_run_scan_wave(lane_state(i0, rk, f), lane);
                     TkRunState ex{(uint32_t)__shfl_up((int)v.all, 1, 64), (uint32_t)__shfl_up((int)v.par, 1, 64)};
                     if (lane == 0) ex = TkRunState{1u, 0u};
-                    const uint32_t c = tk_run_combine(carry, ex).par;
-                    const bool kept = in && c == 0u;
-                    const uint64_t km = __ballot(kept);
-                    if (kept) {  // selected when its own pair has rank m
-                        const uint32_t o = at + (uint32_t)__popcll(km & ((1ull << lane) - 1ull));
-                        P1[o] = f ? (m | MARK) : (P0[i] & ~MARK);
-                        R1[o] = rk;  // (still right when neither this part nor the next one changes)
-                        // the next pick of this round is the pair right after this one: between the two picks the pair (merged part,
-                        // its still unmerged right neighbour) exists and must not rank below m either
-                        if (f && i + 2 < cnt && R0[i + 2] == m && tk_probe_pair(T, m, P0[i + 2] & ~MARK) < m) viol_sh = 1;
+                    uint32_t c = tk_run_combine(carry, ex).par, kl = 0, keepm = 0;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        const uint32_t k = (uint32_t)(i0 + q < whi) & (c ^ 1u);
+                        keepm |= k << q;
+                        kl += k;
+                        c = f[q] ? (c ^ 1u) : 0u;
                     }
-                    at += (uint32_t)__popcll(km);
+                    const uint32_t inc = tk_wave_scan_u32(kl, lane);
+                    uint32_t o = at + inc - kl;
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        if ((keepm >> q) & 1u) {  // kept; selected when its own pair has rank m
+                            const uint32_t i = i0 + q;
+                            P1[o] = f[q] ? (m | MARK) : (P0[i] & ~MARK);
+                            R1[o] = rk[q];  // (still right when neither this part nor the next one changes)
+                            ++o;
+                            // the next pick of this round is the pair right after this one: between the two picks the pair (merged part,
+                            // its still unmerged right neighbour) exists and must not rank below m either
+                            if (f[q] && i + 2 < cnt && R0[i + 2] == m && tk_probe_pair(T, m, P0[i + 2] & ~MARK) < m) viol_sh = 1;
+                        }
+                    }
+                    at += (uint32_t)__shfl((int)inc, 63, 64);
                     carry = tk_run_combine(carry, TkRunState{(uint32_t)__shfl((int)v.all, 63, 64), (uint32_t)__shfl((int)v.par, 63, 64)});
                 }
             }

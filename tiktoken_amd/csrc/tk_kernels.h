@@ -11,7 +11,7 @@
 
 #include "tk_device.h"
 
-#define TK_TILE 3840  // text bytes per tile: with 64 bytes of left context and 192 of look-ahead the LDS window is 4096 = 256 lanes x 16
+#define TK_TILE 3840  // text bytes per tile: with 128 bytes of left context and 128 of look-ahead the LDS window is 4096 = 256 lanes x 16
 
 // Deferred pieces are binned by length so that the 64 lanes of a wave run similar trip counts.
 #define TK_NBIN 9
@@ -223,10 +223,12 @@ __device__ __forceinline__ uint32_t tk_special_id(const TkTables& T, const uint8
 
 // ------------------------------------------------------------------------------------------
 // pre-tokenisation: tile geometry and the scanner's accessors (the kernel is tk_k_front in tk_fused.h)
-// A tile is 3840 bytes; its LDS window adds 64 bytes of left context and 192 of look-ahead: 4096 bytes = 16 per lane.
+// A tile is 3840 bytes; its LDS window adds 128 bytes of left context and 128 of look-ahead: 4096 bytes = 16 per lane.  (Left context:
+// where the last certain start before the tile is looked for -- 2.0 % of the tiles of the bench corpus have none within 64 bytes, 0.8 %
+// none within 128; look-ahead: a piece that reaches further beyond the tile end is finished by the workgroup-wide scanner.)
 // ------------------------------------------------------------------------------------------
-#define TK2_LEFT 64
-#define TK2_RIGHT 192
+#define TK2_LEFT 128
+#define TK2_RIGHT 128
 #define TK2_WIN (TK2_LEFT + TK_TILE + TK2_RIGHT)  // 4096
 #define TK2_NSEG (TK2_WIN / 64)                   // 64
 #define TK2_CLIST 2048                            // certain-start list entries per tile (more: every lane scans from its own starts)
