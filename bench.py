@@ -68,6 +68,8 @@ def main():
     ap.add_argument("--encoding", default="o200k_shaped")
     ap.add_argument("--cpu-sample-mib", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-host-path", action="store_true", help="skip the T2 / T3 host-boundary timings")
+    ap.add_argument("--t3-sample-mib", type=int, default=64)
     args = ap.parse_args()
 
     import torch
@@ -191,6 +193,39 @@ def main():
                     "pipeline_achieved": round(b_alg / (sum_ms * 1e-3) / 1e9, 2),
                     "kernels_ms_avg": {k: round(v["ms_avg"], 4) for k, v in kern.items()}}
 
+    # ---- host-boundary rates (rank 0, N = 1; never `value`): T2 = tk_encode_batch, host buffers in, host token ids out (pinned staging,
+    # PCIe both ways inside the call); T3 = Encoding.encode_ordinary_batch on a bounded sample, Python list[str] -> list[list[int]]
+    host_path = None
+    if rank == 0 and world == 1 and not args.no_host_path:
+        host_path = {}
+        hb = blob[:nbytes]
+        core.encode_batch_packed(hb, doc_off)
+        best2 = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            h_tok, h_off = core.encode_batch_packed(hb, doc_off)
+            dt2 = time.perf_counter() - t0
+            best2 = dt2 if best2 is None else min(best2, dt2)
+        host_path["t2_gbps"] = round(nbytes / best2 / 1e9, 3)
+        host_path["t2_ms"] = round(best2 * 1e3, 2)
+        host_path["t2_what"] = "tk_encode_batch: pageable host text + offsets in, token ids + offsets out in host memory (PCIe inclusive), best of 2"
+        host_path["t2_tokens"] = int(len(h_tok))
+        del h_tok, h_off
+        nd3 = max(int(np.searchsorted(doc_off, min(nbytes, args.t3_sample_mib << 20), side="right")) - 1, 1)
+        sb3 = int(doc_off[nd3])
+        raw = blob[:sb3].tobytes()
+        docs = [raw[int(doc_off[i]):int(doc_off[i + 1])].decode("utf-8") for i in range(nd3)]
+        enc = tiktoken_amd.Encoding(args.encoding, pat_str=spec["pat_str"], mergeable_ranks=spec["mergeable_ranks"],
+                                    special_tokens=spec["special_tokens"])
+        enc.encode_ordinary_batch(docs[:64])
+        t0 = time.perf_counter()
+        lists = enc.encode_ordinary_batch(docs)
+        dt3 = time.perf_counter() - t0
+        host_path["t3_gbps"] = round(sb3 / dt3 / 1e9, 4)
+        host_path["t3_ms"] = round(dt3 * 1e3, 1)
+        host_path["t3_what"] = f"Encoding.encode_ordinary_batch(list[str]) -> list[list[int]] on the first {nd3} documents ({sb3} bytes), one run"
+        del lists, docs, enc
+
     # ---- parity of the WHOLE result + CPU baseline (rank 0, N = 1 only)
     cpu = None
     parity = None
@@ -242,7 +277,7 @@ def main():
                        "encoding": args.encoding, "bytes_per_gpu": nbytes, "docs_rank0": n_docs,
                        "tokens_total": total_tokens, "pieces_rank0": stats["pieces"],
                        "parallelism": f"doc-sharded x{world}" + (" + RCCL gather of token ids to rank 0" if world > 1 else "")},
-            "roofline": roofline, "cpu_baseline": cpu, "parity_all_tokens_vs_oracle": parity,
+            "roofline": roofline, "cpu_baseline": cpu, "parity_all_tokens_vs_oracle": parity, "host_path": host_path,
             "host": {"cpus": ncpu, "corpus_gen_s": round(t_gen, 2)},
         }
         print(json.dumps(line), flush=True)

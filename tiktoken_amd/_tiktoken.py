@@ -28,12 +28,32 @@ def _pack_pairs(items: Sequence[tuple[bytes, int]]):
     return data, off, ids if len(items) else np.zeros(1, dtype=np.uint32)
 
 
+class _OwnedBuffer:
+    """A library-owned result buffer (page-locked host memory for large results) seen through the array interface: numpy views it in
+    place, and it goes back to the library (tk_free) when the last view is gone.  The counterpart of the reference's TiktokenBuffer
+    (src/py.rs:186-249)."""
+
+    def __init__(self, ptr: int, n: int):
+        self._ptr = ptr
+        self.__array_interface__ = {"shape": (n,), "typestr": "<u4", "data": (ptr, True), "version": 3}
+
+    def __del__(self):
+        ptr, self._ptr = getattr(self, "_ptr", None), None
+        if ptr:
+            try:
+                _lib.lib().tk_free(ptr)
+            except Exception:
+                pass
+
+
 def _take_u32(ptr: ctypes.c_void_p, n: int) -> np.ndarray:
-    """Copy a library-owned uint32 buffer into a numpy array and release it."""
-    if n:
-        out = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint32)), shape=(n,)).copy()
-    else:
-        out = np.zeros(0, dtype=np.uint32)
+    """numpy array of a library-owned uint32 result: large ones in place (no second copy), small ones copied and released."""
+    if not n:
+        _lib.lib().tk_free(ptr)
+        return np.zeros(0, dtype=np.uint32)
+    if n >= (1 << 16):
+        return np.asarray(_OwnedBuffer(ptr.value, n))
+    out = np.ctypeslib.as_array(ctypes.cast(ptr, ctypes.POINTER(ctypes.c_uint32)), shape=(n,)).copy()
     _lib.lib().tk_free(ptr)
     return out
 

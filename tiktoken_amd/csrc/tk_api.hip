@@ -6,6 +6,8 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <functional>
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <string>
@@ -62,6 +64,9 @@ struct tk_core {
     hipStream_t stream = nullptr;
     hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};  // side streams: the merge kernels are independent of each other
     hipEvent_t ev_fork = nullptr, ev_cnt = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t cs_h2d = nullptr, cs_d2h = nullptr;  // copy streams of the host-buffer entry point (created on first use)
+    void* stage[2] = {nullptr, nullptr};             // page-locked staging buffers
+    hipEvent_t ev_stage[2] = {nullptr, nullptr};
     uint32_t* h_counters = nullptr;  // pinned
     TkHostTables H;
     TkTables D;  // device view
@@ -83,6 +88,54 @@ struct tk_core {
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
     uint64_t st_bytes = 0, st_pieces = 0, st_tokens = 0, st_docs = 0, st_medium = 0, st_long = 0;
 };
+
+// ------------------------------------------------------------------------------------------
+// Pinned host memory, pooled.  Results of the host-buffer entry points are returned in page-locked buffers (the D2H copy runs at PCIe
+// speed and the caller reads them in place: no second copy); pinning a gigabyte costs far more than filling it, so released buffers are
+// kept for the next call.  tk_free() recognises them.
+// ------------------------------------------------------------------------------------------
+struct PinnedBuf {
+    void* p;
+    size_t cap;
+    bool used;
+};
+static std::mutex g_pin_mu;
+static std::vector<PinnedBuf> g_pin;
+static void* pinned_get(size_t bytes) {
+    if (bytes < 64) bytes = 64;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    PinnedBuf* best = nullptr;
+    for (auto& b : g_pin)
+        if (!b.used && b.cap >= bytes && (!best || b.cap < best->cap)) best = &b;
+    if (best && best->cap <= 4 * bytes + (64u << 20)) {
+        best->used = true;
+        return best->p;
+    }
+    void* p = nullptr;
+    const size_t cap = bytes + bytes / 4 + 4096;
+    if (hipHostMalloc(&p, cap, hipHostMallocPortable) != hipSuccess) return nullptr;
+    size_t free_bytes = 0;  // keep the pool bounded: drop idle buffers beyond 8 GiB
+    for (size_t i = 0; i < g_pin.size();) {
+        if (!g_pin[i].used && (free_bytes += g_pin[i].cap) > (8ull << 30)) {
+            (void)hipHostFree(g_pin[i].p);
+            g_pin.erase(g_pin.begin() + i);
+        } else {
+            ++i;
+        }
+    }
+    g_pin.push_back(PinnedBuf{p, cap, true});
+    return p;
+}
+static bool pinned_release(void* p) {
+    if (!p) return false;
+    std::lock_guard<std::mutex> lk(g_pin_mu);
+    for (auto& b : g_pin)
+        if (b.p == p) {
+            b.used = false;
+            return true;
+        }
+    return false;
+}
 
 template <class F>
 static int timed(tk_core* c, hipStream_t s, const char* name, F&& f) {
@@ -134,6 +187,7 @@ static int upload(Buf& b, const void* src, size_t bytes) {
     return TK_OK;
 }
 
+extern "C" void tk_free(void* p);
 extern "C" const char* tk_last_error(void) { return g_err.c_str(); }
 
 extern "C" int tk_device_count(void) {
@@ -256,6 +310,12 @@ extern "C" void tk_destroy(tk_core* c) {
     for (int i = 0; i < 4; ++i) {
         if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
+    }
+    if (c->cs_h2d) (void)hipStreamDestroy(c->cs_h2d);
+    if (c->cs_d2h) (void)hipStreamDestroy(c->cs_d2h);
+    for (int i = 0; i < 2; ++i) {
+        if (c->stage[i]) (void)hipHostFree(c->stage[i]);
+        if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]);
     }
     if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
     if (c->ev_cnt) (void)hipEventDestroy(c->ev_cnt);
@@ -479,7 +539,7 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         const uint32_t* hc = c->h_counters;
         nC = hc[TK_CNT_C];
         if (nC) {
-            const uint64_t lb = hc[TK_CNT_CBYTES], lvls = hc[TK_CNT_CLEVELS];
+            const uint64_t lb = (uint64_t)hc[TK_CNT_CBYTES] + 4 * nC, lvls = hc[TK_CNT_CLEVELS];
             TRY(ensure(c->g_id, (lb + 64) * 4));
             TRY(ensure(c->g_rk, (lb + 64) * 4));
             TRY(ensure(c->g_nx, (lb + 64) * 4));
@@ -556,9 +616,18 @@ static int prepare_allowed(tk_core* c, hipStream_t s, const uint32_t* allowed_id
     return TK_OK;
 }
 
+// Hooks of the host-buffer entry point: the text of a chunk must have arrived before its kernels start, and its tokens can start
+// their way back while the next chunk is being encoded.
+struct ChunkHooks {
+    std::function<int(uint64_t /*byte_end*/)> before;                                   // text [0, byte_end) has to be on the device
+    std::function<int(uint64_t /*tok_begin*/, uint64_t /*n_tok*/, bool /*last*/)> after;  // a chunk's tokens are final (stream idle)
+};
+
 // Device-resident batch: chunk by documents, run the pipeline per chunk.
 static int encode_device_locked(tk_core* c, hipStream_t s, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
-                                const uint64_t* h_doc_off, uint64_t n_docs, bool use_special, uint64_t* n_tokens_out) {
+                                const uint64_t* h_doc_off, uint64_t n_docs, bool use_special, uint64_t* n_tokens_out,
+                                uint64_t chunk_bytes = 0, const ChunkHooks* hooks = nullptr) {
+    if (!chunk_bytes) chunk_bytes = c->chunk_bytes;
     c->st_bytes = c->st_pieces = c->st_tokens = c->st_medium = c->st_long = 0;
     c->st_docs = n_docs;
     TRY(ensure(c->out_tokens, tk_pid_cap(n_bytes) * 4));  // (the front kernel parks its miss lists here: tk_pid_cap entries)
@@ -566,18 +635,22 @@ static int encode_device_locked(tk_core* c, hipStream_t s, const uint8_t* d_utf8
     uint32_t* d_out = c->out_tokens.as<uint32_t>();
     uint64_t* d_tok_off = c->out_tok_off.as<uint64_t>();
     uint64_t total = 0;
-    if (n_bytes <= c->chunk_bytes) {
+    if (n_bytes <= chunk_bytes) {
+        if (hooks && hooks->before) TRY(hooks->before(n_bytes));
         TRY(run_chunk(c, s, d_utf8, n_bytes, d_doc_off, n_docs, 0, use_special, false, d_out, 0, d_tok_off, &total));
+        if (hooks && hooks->after) TRY(hooks->after(0, total, true));
     } else {
         if (!h_doc_off) return fail(TK_VALUE_ERROR, "h_doc_off is required when n_bytes exceeds the chunk size");
         uint64_t d0 = 0;
         while (d0 < n_docs) {
             uint64_t d1 = d0 + 1;
-            while (d1 < n_docs && h_doc_off[d1 + 1] - h_doc_off[d0] <= c->chunk_bytes) ++d1;
+            while (d1 < n_docs && h_doc_off[d1 + 1] - h_doc_off[d0] <= chunk_bytes) ++d1;
             uint64_t b = h_doc_off[d0], nn = h_doc_off[d1] - b;
             if (nn >= (4ull << 30) - 65536) return fail(TK_VALUE_ERROR, "a single document of 4 GiB or more is not supported");
             uint64_t t = 0;
+            if (hooks && hooks->before) TRY(hooks->before(b + nn));
             TRY(run_chunk(c, s, d_utf8 + b, nn, d_doc_off + d0, d1 - d0, b, use_special, false, d_out + total, total, d_tok_off + d0, &t));
+            if (hooks && hooks->after) TRY(hooks->after(total, t, d1 == n_docs));
             total += t;
             d0 = d1;
         }
@@ -606,6 +679,28 @@ extern "C" int tk_encode_batch_device(tk_core* c, const void* d_utf8, uint64_t n
     return TK_OK;
 }
 
+// Host-buffer batches: the text goes to the device through two page-locked staging buffers (filled by a few host threads, sent by DMA on
+// a copy stream) while earlier chunks are being encoded, and every chunk's tokens start their way back to a page-locked result buffer on a
+// second copy stream while the next chunk is being encoded.  PCIe is the ceiling of this path (about 50 GB/s per direction).
+#define TK_STAGE_BYTES (64ull << 20)
+#define TK_HOST_CHUNK (128ull << 20)
+
+static void parallel_memcpy(void* dst, const void* src, size_t n, unsigned nth) {
+    if (n < (8u << 20) || nth <= 1) {
+        memcpy(dst, src, n);
+        return;
+    }
+    std::vector<std::thread> th;
+    const size_t per = ((n + nth - 1) / nth + 4095) & ~(size_t)4095;
+    for (unsigned t = 0; t < nth; ++t) {
+        const size_t a = (size_t)t * per;
+        if (a >= n) break;
+        const size_t len = a + per < n ? per : n - a;
+        th.emplace_back([=]() { memcpy((uint8_t*)dst + a, (const uint8_t*)src + a, len); });
+    }
+    for (auto& t : th) t.join();
+}
+
 extern "C" int tk_encode_batch(tk_core* c, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special,
                                const uint32_t* allowed_ids, uint64_t n_allowed, uint32_t** tokens_out, uint64_t* n_tokens_out,
                                uint64_t* tok_off_out) {
@@ -620,17 +715,109 @@ extern "C" int tk_encode_batch(tk_core* c, const uint8_t* utf8, const uint64_t* 
     const uint64_t n_bytes = doc_off[n_docs];
     TRY(ensure(c->text, n_bytes + 256));
     TRY(ensure(c->doc_off, (n_docs + 2) * 8));
-    if (n_bytes) HIPCHK(hipMemcpyAsync(c->text.p, utf8, n_bytes, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync((uint8_t*)c->text.p + n_bytes, 0, 128, s));
     HIPCHK(hipMemcpyAsync(c->doc_off.p, doc_off, (n_docs + 1) * 8, hipMemcpyHostToDevice, s));
     bool any = false;
     if (use_special) TRY(prepare_allowed(c, s, allowed_ids, n_allowed, &any));
     uint64_t total = 0;
-    TRY(encode_device_locked(c, s, c->text.as<uint8_t>(), n_bytes, c->doc_off.as<uint64_t>(), doc_off, n_docs, use_special && any, &total));
-    uint32_t* host = (uint32_t*)malloc((total ? total : 1) * 4);
-    if (!host) return fail(TK_RUNTIME_ERROR, "out of host memory");
-    if (total) HIPCHK(hipMemcpy(host, c->out_tokens.p, total * 4, hipMemcpyDeviceToHost));
-    if (tok_off_out) HIPCHK(hipMemcpy(tok_off_out, c->out_tok_off.p, (n_docs + 1) * 8, hipMemcpyDeviceToHost));
+    if (n_bytes < 2 * TK_STAGE_BYTES) {
+        // small batches: one copy each way (latency matters more than overlap)
+        if (n_bytes) HIPCHK(hipMemcpyAsync(c->text.p, utf8, n_bytes, hipMemcpyHostToDevice, s));
+        TRY(encode_device_locked(c, s, c->text.as<uint8_t>(), n_bytes, c->doc_off.as<uint64_t>(), doc_off, n_docs, use_special && any, &total));
+        uint32_t* host = (uint32_t*)(total * 4 >= (1u << 20) ? pinned_get((total ? total : 1) * 4) : malloc((total ? total : 1) * 4));
+        if (!host) return fail(TK_RUNTIME_ERROR, "out of host memory");
+        hipError_t e = hipSuccess;
+        if (total) e = hipMemcpy(host, c->out_tokens.p, total * 4, hipMemcpyDeviceToHost);
+        if (e == hipSuccess && tok_off_out) e = hipMemcpy(tok_off_out, c->out_tok_off.p, (n_docs + 1) * 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) {
+            tk_free(host);
+            return fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e));
+        }
+        *tokens_out = host;
+        *n_tokens_out = total;
+        return TK_OK;
+    }
+    // ---- pipelined
+    if (!c->cs_h2d) {
+        HIPCHK(hipStreamCreateWithFlags(&c->cs_h2d, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&c->cs_d2h, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(hipHostMalloc(&c->stage[i], TK_STAGE_BYTES, hipHostMallocPortable));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming));
+        }
+    }
+    const uint64_t n_blocks = (n_bytes + TK_STAGE_BYTES - 1) / TK_STAGE_BYTES;
+    std::vector<hipEvent_t> ev_block(n_blocks, nullptr);
+    for (auto& e : ev_block) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    auto drop_events = [&]() {
+        for (auto e : ev_block)
+            if (e) (void)hipEventDestroy(e);
+    };
+    // producer: stage + send the text, block by block
+    std::atomic<int> h2d_rc{TK_OK};
+    std::atomic<uint64_t> blocks_sent{0};
+    const int dev = c->device;
+    unsigned nth = std::thread::hardware_concurrency();
+    nth = nth == 0 ? 4 : (nth > 8 ? 8 : nth);
+    std::thread producer([&]() {
+        (void)hipSetDevice(dev);
+        for (uint64_t b = 0; b < n_blocks; ++b) {
+            const int slot = (int)(b & 1);
+            const uint64_t a = b * TK_STAGE_BYTES, len = a + TK_STAGE_BYTES < n_bytes ? TK_STAGE_BYTES : n_bytes - a;
+            if (b >= 2 && hipEventSynchronize(c->ev_stage[slot]) != hipSuccess) h2d_rc = TK_RUNTIME_ERROR;  // the slot's previous DMA is done
+            parallel_memcpy(c->stage[slot], utf8 + a, len, nth);
+            if (hipMemcpyAsync((uint8_t*)c->text.p + a, c->stage[slot], len, hipMemcpyHostToDevice, c->cs_h2d) != hipSuccess) h2d_rc = TK_RUNTIME_ERROR;
+            (void)hipEventRecord(c->ev_stage[slot], c->cs_h2d);
+            (void)hipEventRecord(ev_block[b], c->cs_h2d);
+            blocks_sent.store(b + 1, std::memory_order_release);
+        }
+    });
+    // consumer side
+    uint32_t* host = nullptr;
+    uint64_t host_cap = 0;  // tokens
+    ChunkHooks hooks;
+    hooks.before = [&](uint64_t byte_end) -> int {
+        const uint64_t need = (byte_end + TK_STAGE_BYTES - 1) / TK_STAGE_BYTES;  // blocks [0, need) must have been sent
+        while (blocks_sent.load(std::memory_order_acquire) < need) std::this_thread::yield();
+        if (need) HIPCHK(hipStreamWaitEvent(s, ev_block[need - 1], 0));
+        return h2d_rc.load() == TK_OK ? TK_OK : fail(TK_RUNTIME_ERROR, "host-to-device copy failed");
+    };
+    uint64_t bytes_done = 0;
+    hooks.after = [&](uint64_t tok_begin, uint64_t n_tok, bool last) -> int {
+        bytes_done = c->st_bytes;  // (bytes encoded so far: the density of the chunks seen sizes the result buffer)
+        const uint64_t need = tok_begin + n_tok;
+        if (need > host_cap || !host) {
+            uint64_t est = last ? need : (uint64_t)((double)need / (double)(bytes_done ? bytes_done : 1) * (double)n_bytes * 1.08) + 4096;
+            if (est < need) est = need;
+            uint32_t* nh = (uint32_t*)pinned_get((est ? est : 1) * 4);
+            if (!nh) return fail(TK_RUNTIME_ERROR, "out of page-locked host memory");
+            if (host) {
+                HIPCHK(hipStreamSynchronize(c->cs_d2h));
+                if (tok_begin) parallel_memcpy(nh, host, tok_begin * 4, nth);
+                tk_free(host);
+            }
+            host = nh;
+            host_cap = est;
+        }
+        if (n_tok) HIPCHK(hipMemcpyAsync(host + tok_begin, c->out_tokens.as<uint32_t>() + tok_begin, n_tok * 4, hipMemcpyDeviceToHost, c->cs_d2h));
+        return TK_OK;
+    };
+    int rc = encode_device_locked(c, s, c->text.as<uint8_t>(), n_bytes, c->doc_off.as<uint64_t>(), doc_off, n_docs, use_special && any, &total,
+                                  TK_HOST_CHUNK, &hooks);
+    producer.join();
+    hipError_t e = hipStreamSynchronize(c->cs_h2d);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->cs_d2h);
+    drop_events();
+    if (rc == TK_OK && e != hipSuccess) rc = fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e));
+    if (rc == TK_OK && tok_off_out) {
+        e = hipMemcpy(tok_off_out, c->out_tok_off.p, (n_docs + 1) * 8, hipMemcpyDeviceToHost);
+        if (e != hipSuccess) rc = fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e));
+    }
+    if (rc != TK_OK) {
+        tk_free(host);
+        return rc;
+    }
+    if (!host) host = (uint32_t*)pinned_get(64);
     *tokens_out = host;
     *n_tokens_out = total;
     return TK_OK;
@@ -920,7 +1107,7 @@ static int group_encode(tk_group* g, const uint8_t* utf8, const uint64_t* doc_of
         if (res[r].rc != TK_OK) {
             const int rc = res[r].rc;
             const std::string msg = "device " + std::to_string(g->cores[r]->device) + ": " + res[r].err;
-            for (auto& o : res) free(o.tokens);
+            for (auto& o : res) tk_free(o.tokens);
             return fail(rc, msg);
         }
     return TK_OK;
@@ -942,7 +1129,7 @@ extern "C" int tk_group_encode_batch(tk_group* g, const uint8_t* utf8, const uin
     }
     uint32_t* host = (uint32_t*)malloc((total ? total : 1) * 4);
     if (!host) {
-        for (auto& o : res) free(o.tokens);
+        for (auto& o : res) tk_free(o.tokens);
         return fail(TK_RUNTIME_ERROR, "out of host memory");
     }
     std::vector<std::thread> th;
@@ -952,7 +1139,7 @@ extern "C" int tk_group_encode_batch(tk_group* g, const uint8_t* utf8, const uin
             if (tok_off_out)
                 for (uint64_t k = 0; k + 1 < res[r].tok_off.size() || (r + 1 == res.size() && k < res[r].tok_off.size()); ++k)
                     tok_off_out[first[r] + k] = base[r] + res[r].tok_off[k];
-            free(res[r].tokens);
+            tk_free(res[r].tokens);
         });
     for (auto& t : th) t.join();
     *tokens_out = host;
@@ -975,7 +1162,7 @@ extern "C" int tk_group_encode_batch_device(tk_group* g, const uint8_t* utf8, co
     for (size_t r = 0; r < res.size(); ++r) {
         base[r] = total;
         total += res[r].n_tokens;
-        free(res[r].tokens);
+        tk_free(res[r].tokens);
     }
     tk_core* root = g->cores[0];
     HIPCHK(hipSetDevice(root->device));
@@ -1055,7 +1242,9 @@ extern "C" int tk_parse_tiktoken_bpe(const uint8_t* text, uint64_t len, uint8_t*
     return TK_OK;
 }
 
-extern "C" void tk_free(void* p) { free(p); }
+extern "C" void tk_free(void* p) {
+    if (!pinned_release(p)) free(p);
+}
 
 extern "C" void tk_set_profiling(tk_core* c, int enabled) {
     if (c) c->profiling = enabled != 0;

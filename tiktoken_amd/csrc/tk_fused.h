@@ -110,18 +110,43 @@ __device__ __noinline__ void tk_coop_chunk(const TkCoop& C, int64_t g, TkChunkMa
         y = e.y;
     };
     tk_chunk_table_pass(w, tab, ch);
-    auto get4 = [&](int k) -> uint32_t {  // (only asked for chars that have bytes inside the text)
-        const uint64_t a = (uint64_t)(g + k);
-        const uint32_t* q = (const uint32_t*)(C.text + (a & ~3ull));
-        return __builtin_amdgcn_alignbyte(q[1], q[0], (uint32_t)a & 3u);
-    };
-    auto cls_of = [&](uint32_t cp) -> uint32_t {
-        if (cp > 0x10FFFFu) cp = 0xFFFFu;
-        return C.T->uc_stage2[(uint32_t)C.T->uc_stage1[cp >> 8] * 256u + (cp & 255u)];
-    };
+    // Non-ASCII chars: code point -> class through the two-stage table.  One workgroup walks here step by step, so the latency of a step
+    // is what counts: the (at most eight) lead bytes of the chunk are decoded from registers and their table loads are issued together,
+    // two dependent loads per chunk instead of two per char.
     const bool has_prev = g >= 16 && valid;
     const uint32_t prev = has_prev ? *(const uint32_t*)(C.text + g - 4) : 0u;
-    if (valid) tk_chunk_decode(ch, prev, has_prev, get4, cls_of);
+    const uint32_t w4 = (valid && (uint64_t)g + 16 < C.n) ? *(const uint32_t*)(C.text + g + 16) : 0u;
+    if (valid && ((w[0] | w[1] | w[2] | w[3]) & 0x80808080u)) {
+        auto cls_idx = [&](uint32_t cp) -> uint32_t { return cp > 0x10FFFFu ? 0xFFFFu : cp; };
+        const uint32_t cont = tk_plane16(ch.f0, ch.f1, 0);
+        uint32_t leads = tk_plane16(ch.f0, ch.f1, 1) | tk_plane16(ch.f0, ch.f1, 2) | tk_plane16(ch.f0, ch.f1, 3);
+        int kk[9];
+        uint32_t cp[9], ln[9], s1[9], act = 0;
+        {  // a char that straddles in from the previous chunk
+            const bool on = (cont & 1u) && has_prev;
+            const int k = (prev >> 24) >= 0xC0u ? -1 : (((prev >> 16) & 0xFFu) >= 0xC0u ? -2 : -3);
+            kk[8] = k;
+            cp[8] = cls_idx(tk_utf8_cp(__builtin_amdgcn_alignbyte(w[0], prev, (uint32_t)(4 + k)), &ln[8]));
+            act |= on ? 256u : 0u;
+        }
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+            const int k = leads ? __ffs((int)leads) - 1 : 0;
+            act |= leads ? (1u << q) : 0u;
+            leads &= leads - 1;
+            kk[q] = k;
+            const int d = k >> 2;
+            const uint32_t lo = d == 0 ? w[0] : (d == 1 ? w[1] : (d == 2 ? w[2] : w[3])), hi = d == 0 ? w[1] : (d == 1 ? w[2] : (d == 2 ? w[3] : w4));
+            cp[q] = cls_idx(tk_utf8_cp(__builtin_amdgcn_alignbyte(hi, lo, (uint32_t)k & 3u), &ln[q]));
+        }
+#pragma unroll
+        for (int q = 0; q < 9; ++q) s1[q] = C.T->uc_stage1[cp[q] >> 8];
+#pragma unroll
+        for (int q = 0; q < 9; ++q) s1[q] = C.T->uc_stage2[s1[q] * 256u + (cp[q] & 255u)];
+#pragma unroll
+        for (int q = 0; q < 9; ++q)
+            if ((act >> q) & 1u) tk_chunk_apply(ch, kk[q], ln[q], s1[q]);
+    }
     uint32_t brk16 = 0, ss16 = 0, si16 = 0;
     if (valid) {
         const uint32_t sh = (uint32_t)g & 16u;
@@ -314,7 +339,7 @@ __device__ __forceinline__ void tk_append_tree(uint32_t* listC, uint32_t* counte
     e[0] = mi;
     e[1] = s;
     e[2] = len;
-    e[3] = atomicAdd(&counters[TK_CNT_CBYTES], len);
+    e[3] = atomicAdd(&counters[TK_CNT_CBYTES], (len + 3u) & ~3u);  // (scratch offsets stay multiples of four entries: 16-byte loads)
     e[4] = atomicAdd(&counters[TK_CNT_CLEVELS], lv);
 }
 
@@ -1401,26 +1426,38 @@ __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds(TkTables T, con
             // Every wavefront owns a contiguous range of the parts and walks it in rows of 256 (four consecutive parts per lane: coalesced,
             // and one wave scan per 256 parts); the state that crosses lanes, rows and wavefronts is the parity of the run of rank-m pairs
             // that ends right before a part.
-            constexpr uint32_t ROW = 256;
+            constexpr int EPL = 8;  // parts per lane and row: eight loads in flight per lane hide the memory latency of this one-CU kernel
+            constexpr uint32_t ROW = 64 * EPL;
             const uint32_t per = ((cnt + NWV - 1) / NWV + ROW - 1u) / ROW * ROW;
             const uint32_t wlo = (uint32_t)wid * per < cnt ? (uint32_t)wid * per : cnt, whi = wlo + per < cnt ? wlo + per : cnt;
-            // four parts of a lane: their rank-m flags (parts beyond the range: neutral) and the lane's run state
-            auto lane_state = [&](uint32_t i0, uint32_t rk[4], uint32_t f[4]) -> TkRunState {
-                TkRunState v{1u, 0u};
+            // the parts of a lane: their ranks, rank-m flags (parts beyond the range: neutral) and the lane's run state
+            auto lane_state = [&](uint32_t i0, uint32_t rk[EPL], uint32_t& fm) -> TkRunState {
+                if (i0 + EPL <= whi) {  // (ranges and scratch offsets are multiples of four parts: 16-byte loads)
 #pragma unroll
-                for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < EPL; q += 4) {
+                        const uint4 x = *(const uint4*)(R0 + i0 + q);
+                        rk[q] = x.x; rk[q + 1] = x.y; rk[q + 2] = x.z; rk[q + 3] = x.w;
+                    }
+                } else {
+#pragma unroll
+                    for (int q = 0; q < EPL; ++q) rk[q] = i0 + q < whi ? R0[i0 + q] : 0u;
+                }
+                TkRunState v{1u, 0u};
+                fm = 0;
+#pragma unroll
+                for (int q = 0; q < EPL; ++q) {
                     const bool in = i0 + q < whi;
-                    rk[q] = in ? R0[i0 + q] : 0u;
-                    f[q] = in ? (uint32_t)(rk[q] == m) : 0u;
-                    if (in) v = tk_run_combine(v, TkRunState{f[q], f[q]});
+                    const uint32_t f = in ? (uint32_t)(rk[q] == m) : 0u;
+                    fm |= f << q;
+                    if (in) v = tk_run_combine(v, TkRunState{f, f});
                 }
                 return v;
             };
             // b. run state of each wavefront's range, then of everything before it
             TkRunState acc{1u, 0u};
             for (uint32_t r0 = wlo; r0 < whi; r0 += ROW) {
-                uint32_t rk[4], f[4];
-                TkRunState v = tk_run_scan_wave(lane_state(r0 + 4u * lane, rk, f), lane);
+                uint32_t rk[EPL], fm;
+                TkRunState v = tk_run_scan_wave(lane_state(r0 + (uint32_t)EPL * lane, rk, fm), lane);
                 acc = tk_run_combine(acc, TkRunState{(uint32_t)__shfl((int)v.all, 63, 64), (uint32_t)__shfl((int)v.par, 63, 64)});
             }
             if (lane == 0) {
@@ -1435,16 +1472,16 @@ __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds(TkTables T, con
             {
                 TkRunState carry = before;
                 for (uint32_t r0 = wlo; r0 < whi; r0 += ROW) {
-                    const uint32_t i0 = r0 + 4u * lane;
-                    uint32_t rk[4], f[4];
-                    TkRunState v = tk_run_scan_wave(lane_state(i0, rk, f), lane);
+                    const uint32_t i0 = r0 + (uint32_t)EPL * lane;
+                    uint32_t rk[EPL], fm;
+                    TkRunState v = tk_run_scan_wave(lane_state(i0, rk, fm), lane);
                     TkRunState ex{(uint32_t)__shfl_up((int)v.all, 1, 64), (uint32_t)__shfl_up((int)v.par, 1, 64)};
                     if (lane == 0) ex = TkRunState{1u, 0u};
                     uint32_t c = tk_run_combine(carry, ex).par, kl = 0;  // parity of the run of rank-m pairs right before the lane's first part
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < EPL; ++q) {
                         kl += (uint32_t)(i0 + q < whi) & (c ^ 1u);
-                        c = f[q] ? (c ^ 1u) : 0u;
+                        c = ((fm >> q) & 1u) ? (c ^ 1u) : 0u;
                     }
                     keep += tk_wave_sum_u32(kl);
                     carry = tk_run_combine(carry, TkRunState{(uint32_t)__shfl((int)v.all, 63, 64), (uint32_t)__shfl((int)v.par, 63, 64)});
@@ -1460,31 +1497,31 @@ __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds(TkTables T, con
             {
                 TkRunState carry = before;
                 for (uint32_t r0 = wlo; r0 < whi; r0 += ROW) {
-                    const uint32_t i0 = r0 + 4u * lane;
-                    uint32_t rk[4], f[4];
-                    TkRunState v = tk_run_scan_wave(lane_state(i0, rk, f), lane);
+                    const uint32_t i0 = r0 + (uint32_t)EPL * lane;
+                    uint32_t rk[EPL], fm;
+                    TkRunState v = tk_run_scan_wave(lane_state(i0, rk, fm), lane);
                     TkRunState ex{(uint32_t)__shfl_up((int)v.all, 1, 64), (uint32_t)__shfl_up((int)v.par, 1, 64)};
                     if (lane == 0) ex = TkRunState{1u, 0u};
                     uint32_t c = tk_run_combine(carry, ex).par, kl = 0, keepm = 0;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < EPL; ++q) {
                         const uint32_t k = (uint32_t)(i0 + q < whi) & (c ^ 1u);
                         keepm |= k << q;
                         kl += k;
-                        c = f[q] ? (c ^ 1u) : 0u;
+                        c = ((fm >> q) & 1u) ? (c ^ 1u) : 0u;
                     }
                     const uint32_t inc = tk_wave_scan_u32(kl, lane);
                     uint32_t o = at + inc - kl;
 #pragma unroll
-                    for (int q = 0; q < 4; ++q) {
+                    for (int q = 0; q < EPL; ++q) {
                         if ((keepm >> q) & 1u) {  // kept; selected when its own pair has rank m
-                            const uint32_t i = i0 + q;
-                            P1[o] = f[q] ? (m | MARK) : (P0[i] & ~MARK);
+                            const uint32_t i = i0 + q, f = (fm >> q) & 1u;
+                            P1[o] = f ? (m | MARK) : (P0[i] & ~MARK);
                             R1[o] = rk[q];  // (still right when neither this part nor the next one changes)
                             ++o;
                             // the next pick of this round is the pair right after this one: between the two picks the pair (merged part,
                             // its still unmerged right neighbour) exists and must not rank below m either
-                            if (f[q] && i + 2 < cnt && R0[i + 2] == m && tk_probe_pair(T, m, P0[i + 2] & ~MARK) < m) viol_sh = 1;
+                            if (f && i + 2 < cnt && R0[i + 2] == m && tk_probe_pair(T, m, P0[i + 2] & ~MARK) < m) viol_sh = 1;
                         }
                     }
                     at += (uint32_t)__shfl((int)inc, 63, 64);
