@@ -193,39 +193,6 @@ def main():
                     "pipeline_achieved": round(b_alg / (sum_ms * 1e-3) / 1e9, 2),
                     "kernels_ms_avg": {k: round(v["ms_avg"], 4) for k, v in kern.items()}}
 
-    # ---- host-boundary rates (rank 0, N = 1; never `value`): T2 = tk_encode_batch, host buffers in, host token ids out (pinned staging,
-    # PCIe both ways inside the call); T3 = Encoding.encode_ordinary_batch on a bounded sample, Python list[str] -> list[list[int]]
-    host_path = None
-    if rank == 0 and world == 1 and not args.no_host_path:
-        host_path = {}
-        hb = blob[:nbytes]
-        core.encode_batch_packed(hb, doc_off)
-        best2 = None
-        for _ in range(2):
-            t0 = time.perf_counter()
-            h_tok, h_off = core.encode_batch_packed(hb, doc_off)
-            dt2 = time.perf_counter() - t0
-            best2 = dt2 if best2 is None else min(best2, dt2)
-        host_path["t2_gbps"] = round(nbytes / best2 / 1e9, 3)
-        host_path["t2_ms"] = round(best2 * 1e3, 2)
-        host_path["t2_what"] = "tk_encode_batch: pageable host text + offsets in, token ids + offsets out in host memory (PCIe inclusive), best of 2"
-        host_path["t2_tokens"] = int(len(h_tok))
-        del h_tok, h_off
-        nd3 = max(int(np.searchsorted(doc_off, min(nbytes, args.t3_sample_mib << 20), side="right")) - 1, 1)
-        sb3 = int(doc_off[nd3])
-        raw = blob[:sb3].tobytes()
-        docs = [raw[int(doc_off[i]):int(doc_off[i + 1])].decode("utf-8") for i in range(nd3)]
-        enc = tiktoken_amd.Encoding(args.encoding, pat_str=spec["pat_str"], mergeable_ranks=spec["mergeable_ranks"],
-                                    special_tokens=spec["special_tokens"])
-        enc.encode_ordinary_batch(docs[:64])
-        t0 = time.perf_counter()
-        lists = enc.encode_ordinary_batch(docs)
-        dt3 = time.perf_counter() - t0
-        host_path["t3_gbps"] = round(sb3 / dt3 / 1e9, 4)
-        host_path["t3_ms"] = round(dt3 * 1e3, 1)
-        host_path["t3_what"] = f"Encoding.encode_ordinary_batch(list[str]) -> list[list[int]] on the first {nd3} documents ({sb3} bytes), one run"
-        del lists, docs, enc
-
     # ---- parity of the WHOLE result + CPU baseline (rank 0, N = 1 only)
     cpu = None
     parity = None
@@ -264,6 +231,41 @@ def main():
                "single_thread_value": round(sb1 / t1 / 1e9, 5),
                "sample": f"first {nd_s} documents ({sb} bytes) of the same corpus, C restatement of CoreBPE (oracle/tk_oracle.c), {ncpu} threads over "
                          f"documents, per-document encode phase only (timed in C), best of 3; single thread: first {sb1} bytes"}
+
+    # ---- host-boundary rates (rank 0, N = 1; never `value`): T2 = tk_encode_batch, host buffers in, host token ids out (pinned staging,
+    # PCIe both ways inside the call); T3 = Encoding.encode_ordinary_batch on a bounded sample, Python list[str] -> list[list[int]]
+    host_path = None
+    if rank == 0 and world == 1 and not args.no_host_path:
+        host_path = {}
+        hb = blob[:nbytes]
+        core.encode_batch_packed(hb, doc_off)
+        best2 = None
+        for _ in range(2):
+            t0 = time.perf_counter()
+            h_tok, h_off = core.encode_batch_packed(hb, doc_off)
+            dt2 = time.perf_counter() - t0
+            best2 = dt2 if best2 is None else min(best2, dt2)
+        host_path["t2_gbps"] = round(nbytes / best2 / 1e9, 3)
+        host_path["t2_ms"] = round(best2 * 1e3, 2)
+        host_path["t2_what"] = "tk_encode_batch: pageable host text + offsets in, token ids + offsets out in host memory (PCIe inclusive), best of 2"
+        host_path["t2_tokens"] = int(len(h_tok))
+        if parity is not None:  # (g_toks / g_tok_off: the device-resident result that was compared with the oracle above)
+            host_path["t2_identical_to_checked_result"] = bool(np.array_equal(h_off, g_tok_off) and np.array_equal(h_tok, g_toks))
+        del h_tok, h_off
+        nd3 = max(int(np.searchsorted(doc_off, min(nbytes, args.t3_sample_mib << 20), side="right")) - 1, 1)
+        sb3 = int(doc_off[nd3])
+        raw = blob[:sb3].tobytes()
+        docs = [raw[int(doc_off[i]):int(doc_off[i + 1])].decode("utf-8") for i in range(nd3)]
+        enc = tiktoken_amd.Encoding(args.encoding, pat_str=spec["pat_str"], mergeable_ranks=spec["mergeable_ranks"],
+                                    special_tokens=spec["special_tokens"])
+        enc.encode_ordinary_batch(docs[:64])
+        t0 = time.perf_counter()
+        lists = enc.encode_ordinary_batch(docs)
+        dt3 = time.perf_counter() - t0
+        host_path["t3_gbps"] = round(sb3 / dt3 / 1e9, 4)
+        host_path["t3_ms"] = round(dt3 * 1e3, 1)
+        host_path["t3_what"] = f"Encoding.encode_ordinary_batch(list[str]) -> list[list[int]] on the first {nd3} documents ({sb3} bytes), one run"
+        del lists, docs, enc
 
     if rank == 0:
         line = {

@@ -260,3 +260,24 @@ class HostSim:
         b = np.frombuffer(piece, np.uint8)
         n = sim_lib().tks_encode_piece(self._h, b.ctypes.data, len(piece), out.ctypes.data)
         return out[:n].tolist()
+
+
+class _DevArray:
+    """A device buffer of the library seen through __cuda_array_interface__ (torch.as_tensor reads it in place)."""
+
+    def __init__(self, ptr: int, n: int, typestr: str):
+        self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
+
+
+def dev_u32(ptr: int, n: int) -> np.ndarray:
+    import torch
+
+    if not n:
+        return np.zeros(0, np.uint32)
+    return torch.as_tensor(_DevArray(ptr, n, "<i4"), device="cuda").cpu().numpy().view(np.uint32)
+
+
+def dev_u64(ptr: int, n: int) -> np.ndarray:
+    import torch
+
+    return torch.as_tensor(_DevArray(ptr, n, "<i8"), device="cuda").cpu().numpy().astype(np.uint64)

@@ -179,6 +179,33 @@ def test_dedup_collision_and_disabled_paths(dbg, monkeypatch):
     assert np.array_equal(toff, ro) and np.array_equal(toks, rt)
 
 
+def test_text_at_any_device_address():
+    """tk_encode_batch_device takes the text where the caller has it: a buffer that starts at an odd address (a slice of a tensor)
+    gives the same tokens, also for the inputs that go through the workgroup-wide scanner (long runs)."""
+    import torch
+    from tiktoken_amd import CoreBPE
+
+    g = h.load_golden("o200k_shaped")
+    core = CoreBPE(h.golden_vocab("o200k_shaped"), g["special_tokens"], g["pat_str"])
+    C = h.c_oracle_for("o200k_shaped")
+    blob, off = h.gen_corpus(0xA11E, 1, 2 << 20)
+    docs = [blob[int(off[i]):int(off[i + 1])].tobytes() for i in range(len(off) - 1)]
+    docs[3:3] = [("x" * 20000).encode(), ("\u4e2d" * 9000).encode(), (" " * 15000 + "a").encode(), ("Ab" * 3000).encode(), ("\u00e9" * 7000 + "\n\n").encode()]
+    blob = np.frombuffer(b"".join(docs), np.uint8)
+    off = np.zeros(len(docs) + 1, np.uint64)
+    off[1:] = np.cumsum([len(d) for d in docs])
+    rt, ro = C.encode_batch(blob, off, None, 8)
+    d_off = torch.from_numpy(off.view(np.int64)).cuda()
+    for shift in (1, 2, 7, 13):
+        host = np.zeros(len(blob) + shift + 64, np.uint8)
+        host[shift:shift + len(blob)] = blob
+        d = torch.from_numpy(host).cuda()
+        dt, nt, do = core.encode_batch_device(d.data_ptr() + shift, len(blob), d_off.data_ptr(), off, len(docs))
+        toks = h.dev_u32(dt, nt)
+        toff = h.dev_u64(do, len(docs) + 1)
+        assert np.array_equal(toff, ro) and np.array_equal(toks, rt), shift
+
+
 def test_multi_chunk_batches(monkeypatch):
     """Batches larger than the per-launch chunk are cut at document boundaries (tk_api.hip); force a tiny
     chunk so that a 3 MiB batch needs many launches, incl. documents larger than the chunk itself."""

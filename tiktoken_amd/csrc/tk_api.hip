@@ -74,7 +74,7 @@ struct tk_core {
     uint32_t spec_max_len = 0;
     std::mutex mu;
     // workspace
-    Buf text, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, res, rflag, staging, listB, listC, counters, total, g_id, g_rk, g_nx,
+    Buf text, text_al, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, res, rflag, staging, listB, listC, counters, total, g_id, g_rk, g_nx,
         g_pv, g_lv, out_tokens, out_tok_off, allowed, tile_np, tile_nt, tile_nmiss, mt_slots, wbin, wave_pieces, deferred, big;
     uint64_t chunk_bytes = 1ull << 30;
     int dbg = 0;
@@ -300,7 +300,7 @@ extern "C" void tk_destroy(tk_core* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_dec, &c->d_tok, &c->d_lens, &c->d_bsum, &c->d_tboff, &c->d_bytes, &c->d_boff, &c->t_piece, &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2,
-                   &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off, &c->brk, &c->docb,
+                   &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->text_al, &c->doc_off, &c->brk, &c->docb,
                    &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->res, &c->rflag, &c->staging, &c->listB,
                    &c->listC, &c->counters, &c->total, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv, &c->out_tokens,
                    &c->out_tok_off, &c->allowed, &c->tile_np, &c->tile_nt, &c->tile_nmiss, &c->mt_slots, &c->wbin, &c->deferred, &c->big,
@@ -635,9 +635,23 @@ static int encode_device_locked(tk_core* c, hipStream_t s, const uint8_t* d_utf8
     uint32_t* d_out = c->out_tokens.as<uint32_t>();
     uint64_t* d_tok_off = c->out_tok_off.as<uint64_t>();
     uint64_t total = 0;
+    // The kernels read the text with aligned 4- and 16-byte loads (some of them through the scalar unit, which ignores the low address
+    // bits): a chunk whose first byte is not 16-byte aligned is copied to an aligned buffer first (a device-to-device copy, ~0.1 ms per
+    // 128 MiB).  Chunk cuts prefer documents that start at an aligned address.
+    auto aligned_text = [&](const uint8_t* p, uint64_t nn, const uint8_t** out) -> int {
+        *out = p;
+        if (((uintptr_t)p & 15u) == 0 || !nn) return TK_OK;
+        TRY(ensure(c->text_al, nn + 256));
+        HIPCHK(hipMemcpyAsync(c->text_al.p, p, nn, hipMemcpyDeviceToDevice, s));
+        HIPCHK(hipMemsetAsync((uint8_t*)c->text_al.p + nn, 0, 128, s));
+        *out = c->text_al.as<uint8_t>();
+        return TK_OK;
+    };
     if (n_bytes <= chunk_bytes) {
         if (hooks && hooks->before) TRY(hooks->before(n_bytes));
-        TRY(run_chunk(c, s, d_utf8, n_bytes, d_doc_off, n_docs, 0, use_special, false, d_out, 0, d_tok_off, &total));
+        const uint8_t* tx;
+        TRY(aligned_text(d_utf8, n_bytes, &tx));
+        TRY(run_chunk(c, s, tx, n_bytes, d_doc_off, n_docs, 0, use_special, false, d_out, 0, d_tok_off, &total));
         if (hooks && hooks->after) TRY(hooks->after(0, total, true));
     } else {
         if (!h_doc_off) return fail(TK_VALUE_ERROR, "h_doc_off is required when n_bytes exceeds the chunk size");
@@ -645,11 +659,19 @@ static int encode_device_locked(tk_core* c, hipStream_t s, const uint8_t* d_utf8
         while (d0 < n_docs) {
             uint64_t d1 = d0 + 1;
             while (d1 < n_docs && h_doc_off[d1 + 1] - h_doc_off[d0] <= chunk_bytes) ++d1;
+            if (d1 < n_docs)  // an aligned cut a little earlier saves the next chunk its copy
+                for (uint64_t q = d1; q > d0 + 1 && d1 - q < 256; --q)
+                    if ((((uintptr_t)d_utf8 + h_doc_off[q]) & 15u) == 0) {
+                        d1 = q;
+                        break;
+                    }
             uint64_t b = h_doc_off[d0], nn = h_doc_off[d1] - b;
             if (nn >= (4ull << 30) - 65536) return fail(TK_VALUE_ERROR, "a single document of 4 GiB or more is not supported");
             uint64_t t = 0;
             if (hooks && hooks->before) TRY(hooks->before(b + nn));
-            TRY(run_chunk(c, s, d_utf8 + b, nn, d_doc_off + d0, d1 - d0, b, use_special, false, d_out + total, total, d_tok_off + d0, &t));
+            const uint8_t* tx;
+            TRY(aligned_text(d_utf8 + b, nn, &tx));
+            TRY(run_chunk(c, s, tx, nn, d_doc_off + d0, d1 - d0, b, use_special, false, d_out + total, total, d_tok_off + d0, &t));
             if (hooks && hooks->after) TRY(hooks->after(total, t, d1 == n_docs));
             total += t;
             d0 = d1;
