@@ -342,6 +342,16 @@ def test_rounds_and_one_at_a_time_merges_agree(monkeypatch):
         want = C.encode_piece(p)
         assert a.encode_single_piece(p) == want
         assert b.encode_single_piece(p) == want
+    # pieces of 128 KiB and more: all the workgroups of tk_k_merge_rounds_wide on one piece (several such pieces in one call, with
+    # short ones between them; lowercase letters only, so that every document is one piece of the pattern)
+    big = [bytes(rng.integers(97, 123, size=300_000, dtype=np.uint8)), ("ab" * 100_000).encode(), ("the quick brown fox " * 9000).replace(" ", "").encode(),
+           bytes(rng.integers(97, 101, size=150_001, dtype=np.uint8)), b"hello", ("abc" * 50_000).encode()]
+    blob = np.frombuffer(b"".join(big), np.uint8)
+    off = np.zeros(len(big) + 1, np.uint64)
+    off[1:] = np.cumsum([len(x) for x in big])
+    toks, toff = a.encode_batch_packed(blob, off)
+    rt, ro = C.encode_batch(blob, off, None, 8)
+    assert np.array_equal(toff, ro) and np.array_equal(toks, rt)
 
 
 # ---------------------------------------------------------------- decode on the device (src/lib.rs:345-358)

@@ -74,7 +74,7 @@ struct tk_core {
     uint32_t spec_max_len = 0;
     std::mutex mu;
     // workspace
-    Buf text, text_al, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, res, rflag, staging, listB, listC, counters, total, g_id, g_rk, g_nx,
+    Buf text, text_al, tile_sum, wide_ws, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, res, rflag, staging, listB, listC, counters, total, g_id, g_rk, g_nx,
         g_pv, g_lv, out_tokens, out_tok_off, allowed, tile_np, tile_nt, tile_nmiss, mt_slots, wbin, wave_pieces, deferred, big;
     uint64_t chunk_bytes = 1ull << 30;
     int dbg = 0;
@@ -300,7 +300,7 @@ extern "C" void tk_destroy(tk_core* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_dec, &c->d_tok, &c->d_lens, &c->d_bsum, &c->d_tboff, &c->d_bytes, &c->d_boff, &c->t_piece, &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2,
-                   &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->text_al, &c->doc_off, &c->brk, &c->docb,
+                   &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->text_al, &c->tile_sum, &c->wide_ws, &c->doc_off, &c->brk, &c->docb,
                    &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->res, &c->rflag, &c->staging, &c->listB,
                    &c->listC, &c->counters, &c->total, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv, &c->out_tokens,
                    &c->out_tok_off, &c->allowed, &c->tile_np, &c->tile_nt, &c->tile_nmiss, &c->mt_slots, &c->wbin, &c->deferred, &c->big,
@@ -401,7 +401,9 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
     // The per-tile miss lists (TKF_MISS_CAP entries of 8 bytes per tile) live in memory that is not needed until the back
     // kernel writes it: the output region (8-byte aligned inside it).
     uint2* miss = d_out ? (uint2*)(((uintptr_t)d_out + 7) & ~(uintptr_t)7) : nullptr;
-    TkFrontOut fo{starts, tile_np, res, c->tile_nmiss.as<uint32_t>(), miss, c->listC.as<uint32_t>(), counters};
+    TRY(ensure(c->tile_sum, ntiles + 16));
+    HIPCHK(hipMemsetAsync(c->tile_sum.p, 0xFF, ntiles + 16, s));
+    TkFrontOut fo{starts, tile_np, res, c->tile_nmiss.as<uint32_t>(), c->tile_sum.as<uint8_t>(), miss, c->listC.as<uint32_t>(), counters};
     TkMissSlot* mt = nullptr;
     uint32_t mt_bits = 14;
     uint64_t nB = 0, nC = 0;
@@ -551,6 +553,15 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
                     hipLaunchKernelGGL(tk_k_merge_rounds, dim3(grid_for(nC, 1, 1024)), dim3(TKB_THREADS), 0, s, T, d_text, c->listC.as<uint32_t>(),
                                        (uint32_t)nC, c->g_id.as<uint32_t>(), c->g_rk.as<uint32_t>(), c->g_nx.as<uint32_t>(), c->g_pv.as<uint32_t>(),
                                        miss, stg);
+                }));
+            }
+            if (rounds && n >= TK_WIDE_MIN) {  // (pieces of TK_WIDE_MIN bytes and more, if there are any: the whole grid on each)
+                TRY(ensure(c->wide_ws, sizeof(TkWideWs)));
+                HIPCHK(hipMemsetAsync(c->wide_ws.p, 0, sizeof(TkWideWs), s));
+                TRY(timed(c, s, "tk_k_merge_rounds_wide", [&] {
+                    hipLaunchKernelGGL(tk_k_merge_rounds_wide, dim3(TK_WIDE_BLOCKS), dim3(TKB_THREADS), 0, s, T, d_text, c->listC.as<uint32_t>(),
+                                       (uint32_t)nC, c->g_id.as<uint32_t>(), c->g_rk.as<uint32_t>(), c->g_nx.as<uint32_t>(), c->g_pv.as<uint32_t>(),
+                                       miss, stg, c->wide_ws.as<TkWideWs>());
                 }));
             }
             TRY(timed(c, s, "tk_k_merge_long", [&] {

@@ -51,6 +51,8 @@ struct TkFrontOut {
     uint32_t* tile_np;    // pieces per tile
     uint32_t* res;        // [piece id] see above
     uint32_t* tile_nmiss; // entries on the tile's miss list: pieces that have to be merged (not a token, not a duplicate)
+    uint8_t* tile_sum;    // per tile, written when a tile is deferred for a walk back: its class if the whole tile is one run of that
+                          // class without a certain start (later tiles jump over it), 16 if not; 0xFF: not written
     uint2* miss;          // [tile * TKF_MISS_CAP + j] {start, length}; the merge kernels replace it by {token count, token | staging position}
     uint32_t* listC;      // {miss index, start, len, scratch bytes before, tree levels before} for > 1 KiB pieces
     uint32_t* counters;
@@ -222,10 +224,11 @@ __device__ __noinline__ uint64_t tk_coop_last_in(const TkCoop& C, uint64_t from,
 // last certain piece start at or before `pos` (exists: position 0 and document starts are hard starts).  *last_other gets the highest
 // position in (result, pos] whose class differs from the class of the byte at `pos` (TK_NO_POS: none): when there is none behind the
 // first char, everything between the returned start and `pos` is one run of a single class.
-__device__ __noinline__ uint64_t tk_coop_certain_before(const TkCoop* Cp, uint64_t pos, uint64_t* last_other, uint32_t* cls_at_pos) {
+// cref_in < 16: the class to compare with instead of the class at `pos` (the caller has skipped a stretch of that class).
+__device__ __noinline__ uint64_t tk_coop_certain_before(const TkCoop* Cp, uint64_t pos, uint32_t cref_in, uint64_t* last_other, uint32_t* cls_at_pos) {
     const TkCoop& C = *Cp;
     uint64_t other = TK_NO_POS;
-    uint32_t cref = 16;  // (set in the first span: the lane that covers `pos`)
+    uint32_t cref = cref_in;  // (16: set in the first span by the lane that covers `pos`)
     for (int64_t wb = (int64_t)(pos & ~15ull) - 4080;; wb -= 4080) {  // (16 bytes of overlap: the first chunk of a span has no known
         const int64_t g = wb + 16ll * threadIdx.x;                    //  predecessor; the next span sees it as its last chunk)
         TkChunkMasks mk;
@@ -581,6 +584,17 @@ __global__ __launch_bounds__(256, SLOW ? 3 : 8) void tk_k_front(TkTables T, cons
     }
     __syncthreads();
     if (!SLOW && need_walk) {  // no certain start in the left context: a tile for the workgroup-wide scanner
+        // (and a note for the walk-backs of later tiles: is this tile one run of a single class without a certain start?)
+        if (tid == T0) scan_sh[0] = tk_class_from_planes(mk.p, 0);
+        __syncthreads();
+        const uint32_t c0 = scan_sh[0];
+        bool same = cert == 0u && valid == 0xFFFFu;
+#pragma unroll
+        for (int b = 0; b < 4; ++b) same = same && (mk.p[b] & 0xFFFFu) == (((c0 >> b) & 1u) ? 0xFFFFu : 0u);
+        const bool wave_ok = __ballot(in_tile && !same) == 0ull;
+        if (lane == 0) scan_sh[1 + wid] = wave_ok ? 1u : 0u;
+        __syncthreads();
+        if (tid == 0) out.tile_sum[tile] = (scan_sh[1] & scan_sh[2] & scan_sh[3] & scan_sh[4]) ? (uint8_t)c0 : (uint8_t)16;
         defer_tile();
         continue;
     }
@@ -678,7 +692,22 @@ __global__ __launch_bounds__(256, SLOW ? 3 : 8) void tk_k_front(TkTables T, cons
         if (need_walk) {
             uint64_t other;
             uint32_t crun;
-            const uint64_t p0 = tk_coop_certain_before(&coop, tile_start - 1, &other, &crun);
+            // Tiles before this one that are whole runs of the class of the byte before this tile, without a certain start (they were
+            // deferred like this one and have said so in tile_sum), are jumped over, 256 tiles per step.
+            const uint32_t cprev = (uint32_t)lastc[T0 - 1];
+            uint64_t skipped = 0;
+            for (;;) {
+                const int64_t q = (int64_t)tile - 1 - (int64_t)skipped - (int64_t)tid;
+                const bool match = q >= 0 && (uint32_t)out.tile_sum[q] == cprev;
+                const uint32_t first = tk_coop_first(coop, match ? TKF_NONE : tid, false);
+                if (first == TKF_NONE) {
+                    skipped += 256;
+                    continue;
+                }
+                skipped += first;
+                break;
+            }
+            const uint64_t p0 = tk_coop_certain_before(&coop, tile_start - skipped * TK_TILE - 1, skipped ? cprev : 16u, &other, &crun);
             // A tile deep inside a long run of one class: everything from the first char after p0 up to the end of this window is that
             // class (and no hard start) -- the piece that covers the tile start began at p0 (or within a contraction's length of it) and
             // reaches beyond the window: there is no piece start in this tile.  Only the tile in which the run ends evaluates the piece.
@@ -1388,173 +1417,313 @@ __device__ __forceinline__ TkRunState tk_run_scan_wave(TkRunState v, int lane) {
     return v;
 }
 
+// The rounds of ONE piece, by one workgroup (WIDE = false) or by all the workgroups of the launch together (WIDE = true: pieces of
+// TK_WIDE_MIN bytes and more -- a megabyte run is a single piece, and one CU walks it at the latency of its 16 wavefronts).  The wide form
+// is the same algorithm with "wavefront of the workgroup" read as "wavefront of the grid": the per-wavefront summaries and the round's
+// minimum go through global memory, and the workgroup barriers become grid barriers (a counter in global memory; every workgroup of
+// the launch is resident: the grid is far smaller than the chip).
+#define TK_WIDE_MIN (1u << 17)
+#define TK_WIDE_BLOCKS 64
+struct TkWideWs {  // workspace of the wide launch (zeroed before it)
+    uint32_t bar;      // barrier arrivals (monotonic)
+    uint32_t viol;     // a round was not valid: the piece is redone one merge at a time
+    uint32_t gmin[2];  // lowest rank of the next round (alternating slots)
+    uint32_t sc[4][TK_WIDE_BLOCKS * (TKB_THREADS / 64)];  // per wavefront: run state (all, parity), survivors, odd leading stretch
+};
+__device__ __forceinline__ uint32_t tk_ld_agent(const uint32_t* p) { return __hip_atomic_load(p, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+__device__ __forceinline__ void tk_st_agent(uint32_t* p, uint32_t v) { __hip_atomic_store(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT); }
+// all workgroups of the launch: everything written before is visible to everyone after
+__device__ __forceinline__ void tk_grid_barrier(uint32_t* bar, uint32_t& epoch) {
+    __threadfence();
+    __syncthreads();
+    epoch += gridDim.x;
+    if (threadIdx.x == 0) {
+        __hip_atomic_fetch_add(bar, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+        while (__hip_atomic_load(bar, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_AGENT) < epoch) __builtin_amdgcn_s_sleep(2);
+    }
+    __syncthreads();
+    __threadfence();
+}
+
+template <bool WIDE>
+__device__ __forceinline__ void tk_rounds_piece(const TkTables& T, const uint8_t* __restrict__ text, const uint32_t* ent, uint32_t* g_p0, uint32_t* g_r0,
+                                                uint32_t* g_p1, uint32_t* g_r1, uint2* __restrict__ miss, uint32_t* __restrict__ staging,
+                                                TkWideWs* ws, uint32_t& epoch, uint32_t* red, uint32_t (*sc_lds)[TKB_THREADS / 64], uint32_t* viol_lds) {
+    constexpr int NWB = TKB_THREADS / 64;                               // wavefronts per workgroup
+    const uint32_t NWV = WIDE ? (uint32_t)NWB * gridDim.x : (uint32_t)NWB;  // wavefronts that share the piece
+    const uint32_t tid = threadIdx.x;
+    const int lane = tid & 63;
+    const uint32_t wib = tid >> 6, wid = WIDE ? blockIdx.x * NWB + wib : wib;
+    const uint32_t gtid = WIDE ? blockIdx.x * TKB_THREADS + tid : tid, gthreads = WIDE ? gridDim.x * TKB_THREADS : (uint32_t)TKB_THREADS;
+    constexpr uint32_t MARK = 0x80000000u;  // (token ids stay below 2^31: checked at tk_create)
+    auto sync = [&]() {
+        if constexpr (WIDE) tk_grid_barrier(&ws->bar, epoch);
+        else __syncthreads();
+    };
+    auto sc_put = [&](int k, uint32_t v) {
+        if constexpr (WIDE) tk_st_agent(&ws->sc[k][wid], v);
+        else sc_lds[k][wid] = v;
+    };
+    auto sc_get = [&](int k, uint32_t q) -> uint32_t {
+        if constexpr (WIDE) return tk_ld_agent(&ws->sc[k][q]);
+        else return sc_lds[k][q];
+    };
+    auto set_viol = [&]() {
+        if constexpr (WIDE) tk_st_agent(&ws->viol, 1u);
+        else *viol_lds = 1;
+    };
+    // minimum over everyone who shares the piece (round = which of the two global slots; ends with a barrier)
+    auto all_min = [&](uint32_t v, uint32_t round) -> uint32_t {
+        v = tk_wave_min_u32(v);
+        if (lane == 0) red[wib] = v;
+        __syncthreads();
+        v = tk_wave_min_u32(red[lane & (NWB - 1)]);
+        if constexpr (WIDE) {
+            if (tid == 0) __hip_atomic_fetch_min(&ws->gmin[round & 1u], v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            tk_grid_barrier(&ws->bar, epoch);
+            v = tk_ld_agent(&ws->gmin[round & 1u]);
+        } else
+            __syncthreads();
+        return v;
+    };
+    const uint32_t mi = ent[0], s = ent[1], n = ent[2];
+    uint32_t *P0 = g_p0 + ent[3], *R0 = g_r0 + ent[3], *P1 = g_p1 + ent[3], *R1 = g_r1 + ent[3];
+    if constexpr (WIDE) {  // (the slots were left by the previous piece; nobody uses them before the barrier below)
+        if (gtid == 0) {
+            tk_st_agent(&ws->viol, 0u);
+            tk_st_agent(&ws->gmin[0], TK_RANK_MAX);
+            tk_st_agent(&ws->gmin[1], TK_RANK_MAX);
+        }
+        tk_grid_barrier(&ws->bar, epoch);
+    } else {
+        if (tid == 0) *viol_lds = 0;
+    }
+    uint32_t m = TK_RANK_MAX;  // the lowest rank among the pairs: found while the ranks are written (no pass of its own)
+    for (uint32_t k = gtid; k < n; k += gthreads) {
+        const uint32_t b0 = text[s + k];
+        P0[k] = T.byte_rank[b0];
+        const uint32_t r = k + 1 < n ? T.pair2[(b0 << 8) | text[s + k + 1]] : TK_RANK_MAX;
+        R0[k] = r;
+        m = r < m ? r : m;
+    }
+    uint32_t round = 0;
+    m = all_min(m, round);
+    uint32_t cnt = n;
+    bool redo = false;
+    for (;;) {
+        if (m == TK_RANK_MAX) break;
+        // Every wavefront owns a contiguous range of the parts and walks it in rows of 512 (eight consecutive parts per lane: coalesced,
+        // and one wave scan per row); the state that crosses lanes, rows and wavefronts is the parity of the run of rank-m pairs that
+        // ends right before a part.
+        constexpr int EPL = 8;
+        constexpr uint32_t ROW = 64 * EPL;
+        const uint32_t per = ((cnt + NWV - 1) / NWV + ROW - 1u) / ROW * ROW;
+        const uint32_t wlo = wid * per < cnt ? wid * per : cnt, whi = wlo + per < cnt ? wlo + per : cnt;
+        // the parts of a lane: their ranks, rank-m flags (parts beyond the range: none) and the lane's run state
+        auto lane_state = [&](uint32_t i0, uint32_t rk[EPL], uint32_t& fm) -> TkRunState {
+            if (i0 + EPL <= whi) {  // (ranges and scratch offsets are multiples of four parts: 16-byte loads)
+#pragma unroll
+                for (int q = 0; q < EPL; q += 4) {
+                    const uint4 x = *(const uint4*)(R0 + i0 + q);
+                    rk[q] = x.x; rk[q + 1] = x.y; rk[q + 2] = x.z; rk[q + 3] = x.w;
+                }
+            } else {
+#pragma unroll
+                for (int q = 0; q < EPL; ++q) rk[q] = i0 + q < whi ? R0[i0 + q] : 0u;
+            }
+            TkRunState v{1u, 0u};
+            fm = 0;
+#pragma unroll
+            for (int q = 0; q < EPL; ++q) {
+                const bool in = i0 + q < whi;
+                const uint32_t f = in ? (uint32_t)(rk[q] == m) : 0u;
+                fm |= f << q;
+                if (in) v = tk_run_combine(v, TkRunState{f, f});
+            }
+            return v;
+        };
+        // b. one pass gives, per wavefront range: its run state, the number of parts that survive (a part right after an odd count of
+        // rank-m pairs is absorbed) if no run enters the range, and the length of the run of rank-m pairs the range starts with -- a run
+        // of odd length that enters flips the fate of exactly those parts and the one after them
+        uint32_t keep0 = 0, lead = 0;
+        TkRunState acc{1u, 0u};
+        {
+            bool open = true;
+            for (uint32_t r0 = wlo; r0 < whi; r0 += ROW) {
+                const uint32_t i0 = r0 + (uint32_t)EPL * lane;
+                uint32_t rk[EPL], fm;
+                TkRunState v = tk_run_scan_wave(lane_state(i0, rk, fm), lane);
+                TkRunState ex{(uint32_t)__shfl_up((int)v.all, 1, 64), (uint32_t)__shfl_up((int)v.par, 1, 64)};
+                if (lane == 0) ex = TkRunState{1u, 0u};
+                uint32_t c = tk_run_combine(acc, ex).par, kl = 0;  // parity of the run of rank-m pairs right before the lane's first part
+#pragma unroll
+                for (int q = 0; q < EPL; ++q) {
+                    kl += (uint32_t)(i0 + q < whi) & (c ^ 1u);
+                    c = ((fm >> q) & 1u) ? (c ^ 1u) : 0u;
+                }
+                keep0 += tk_wave_sum_u32(kl);
+                if (open) {  // (parts beyond the range have no flag: the leading run ends there at the latest)
+                    const uint64_t stop = __ballot(fm != (1u << EPL) - 1u);
+                    if (stop) {
+                        const int l0 = __ffsll((unsigned long long)stop) - 1;
+                        const uint32_t f0 = (uint32_t)__shfl((int)fm, l0, 64);
+                        lead += (uint32_t)l0 * EPL + (uint32_t)__ffs((int)~f0) - 1u;
+                        open = false;
+                    } else
+                        lead += ROW;
+                }
+                acc = tk_run_combine(acc, TkRunState{(uint32_t)__shfl((int)v.all, 63, 64), (uint32_t)__shfl((int)v.par, 63, 64)});
+            }
+        }
+        if (lane == 0) {
+            const uint32_t len = whi - wlo, aff = lead + 1u < len ? lead + 1u : len;
+            sc_put(0, acc.all);
+            sc_put(1, acc.par);
+            sc_put(2, keep0);
+            sc_put(3, aff & 1u);
+        }
+        if constexpr (WIDE) {
+            if (gtid == 0) tk_st_agent(&ws->gmin[(round + 1u) & 1u], TK_RANK_MAX);  // (last read a round ago, next written after the barrier below)
+        }
+        sync();
+        TkRunState before{1u, 0u};
+        uint32_t at = 0, total = 0;
+        if constexpr (WIDE) {
+            // prefix over the wavefronts of the grid: 64 lanes take a block of summaries each, then one wave scan
+            const uint32_t blk = (NWV + 63u) / 64u;
+            TkRunState mine{1u, 0u};
+            uint32_t k0 = 0, k1 = 0;  // survivors of my summaries if the state that enters my block has parity 0 / 1 (they differ only
+                                      // while the block so far is all rank-m pairs)
+            for (uint32_t j = 0; j < blk; ++j) {
+                const uint32_t q = (uint32_t)lane * blk + j;
+                if (q < NWV) {
+                    const uint32_t a = sc_get(0, q), pr = sc_get(1, q), kp = sc_get(2, q), od = sc_get(3, q);
+                    k0 += kp - (mine.par & od);
+                    k1 += kp - ((mine.all ? (mine.par ^ 1u) : mine.par) & od);
+                    mine = tk_run_combine(mine, TkRunState{a, pr});
+                }
+            }
+            // exclusive scan of the lanes' states
+            TkRunState inc = tk_run_scan_wave(mine, lane);
+            TkRunState ex{(uint32_t)__shfl_up((int)inc.all, 1, 64), (uint32_t)__shfl_up((int)inc.par, 1, 64)};
+            if (lane == 0) ex = TkRunState{1u, 0u};
+            const uint32_t kl = ex.par ? k1 : k0;  // survivors of my block given what enters it
+            const uint32_t kinc = tk_wave_scan_u32(kl, lane);
+            total = (uint32_t)__shfl((int)kinc, 63, 64);
+            // my own wavefront's place: the lane that holds summary `wid`, then the summaries of its block before it
+            const int owner = (int)(wid / blk);
+            TkRunState st{(uint32_t)__shfl((int)ex.all, owner, 64), (uint32_t)__shfl((int)ex.par, owner, 64)};
+            at = (uint32_t)__shfl((int)(kinc - kl), owner, 64);
+            for (uint32_t q = (uint32_t)owner * blk; q < wid; ++q) {
+                at += sc_get(2, q) - (st.par & sc_get(3, q));
+                st = tk_run_combine(st, TkRunState{sc_get(0, q), sc_get(1, q)});
+            }
+            before = st;
+        } else {
+            TkRunState st{1u, 0u};
+            for (uint32_t q = 0; q < NWV; ++q) {
+                if (q == wid) before = st;
+                const uint32_t k = sc_get(2, q) - (st.par & sc_get(3, q));
+                if (q < wid) at += k;
+                total += k;
+                st = tk_run_combine(st, TkRunState{sc_get(0, q), sc_get(1, q)});
+            }
+        }
+        // c. the survivors move to their places
+        {
+            TkRunState carry = before;
+            for (uint32_t r0 = wlo; r0 < whi; r0 += ROW) {
+                const uint32_t i0 = r0 + (uint32_t)EPL * lane;
+                uint32_t rk[EPL], fm;
+                TkRunState v = tk_run_scan_wave(lane_state(i0, rk, fm), lane);
+                TkRunState ex{(uint32_t)__shfl_up((int)v.all, 1, 64), (uint32_t)__shfl_up((int)v.par, 1, 64)};
+                if (lane == 0) ex = TkRunState{1u, 0u};
+                uint32_t c = tk_run_combine(carry, ex).par, kl = 0, keepm = 0;
+#pragma unroll
+                for (int q = 0; q < EPL; ++q) {
+                    const uint32_t k = (uint32_t)(i0 + q < whi) & (c ^ 1u);
+                    keepm |= k << q;
+                    kl += k;
+                    c = ((fm >> q) & 1u) ? (c ^ 1u) : 0u;
+                }
+                const uint32_t inc = tk_wave_scan_u32(kl, lane);
+                uint32_t o = at + inc - kl;
+#pragma unroll
+                for (int q = 0; q < EPL; ++q) {
+                    if ((keepm >> q) & 1u) {  // kept; selected when its own pair has rank m
+                        const uint32_t i = i0 + q, f = (fm >> q) & 1u;
+                        P1[o] = f ? (m | MARK) : (P0[i] & ~MARK);
+                        R1[o] = rk[q];  // (still right when neither this part nor the next one changes)
+                        ++o;
+                        // the next pick of this round is the pair right after this one: between the two picks the pair (merged part,
+                        // its still unmerged right neighbour) exists and must not rank below m either
+                        if (f && i + 2 < cnt && R0[i + 2] == m && tk_probe_pair(T, m, P0[i + 2] & ~MARK) < m) set_viol();
+                    }
+                }
+                at += (uint32_t)__shfl((int)inc, 63, 64);
+                carry = tk_run_combine(carry, TkRunState{(uint32_t)__shfl((int)v.all, 63, 64), (uint32_t)__shfl((int)v.par, 63, 64)});
+            }
+        }
+        sync();
+        // d. ranks of the pairs that a merge has touched; the lowest rank of the next round on the way
+        uint32_t mn = TK_RANK_MAX;
+        for (uint32_t j = gtid; j < total; j += gthreads) {
+            const uint32_t a = P1[j], b = j + 1 < total ? P1[j + 1] : 0u;
+            uint32_t r;
+            if (j + 1 >= total) R1[j] = r = TK_RANK_MAX;
+            else if ((a | b) & MARK) {
+                r = tk_probe_pair(T, a & ~MARK, b & ~MARK);
+                R1[j] = r;
+                if (r < m) set_viol();  // a merge created a pair that the reference would have picked before the rest of this round
+            } else
+                r = R1[j];
+            mn = r < mn ? r : mn;
+        }
+        ++round;
+        m = all_min(mn, round);  // (its barrier also publishes the violation flag and this round's writes)
+        if (WIDE ? tk_ld_agent(&ws->viol) : *viol_lds) {
+            redo = true;
+            break;
+        }
+        uint32_t* t0 = P0; P0 = P1; P1 = t0;
+        t0 = R0; R0 = R1; R1 = t0;
+        cnt = total;
+    }
+    if (redo) {
+        if (gtid == 0) miss[mi] = make_uint2(TK_MERGE_REDO, 0u);
+    } else {
+        for (uint32_t k = gtid; k < cnt; k += gthreads) staging[s + k] = P0[k] & ~MARK;
+        if (gtid == 0) miss[mi] = make_uint2(cnt, cnt == 1 ? (P0[0] & ~MARK) : s);
+    }
+    sync();
+}
+
+// one workgroup per piece (pieces of TK_WIDE_MIN bytes and more are left to tk_k_merge_rounds_wide)
 __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listC,
                                                                   uint32_t nC, uint32_t* __restrict__ g_p0, uint32_t* __restrict__ g_r0,
                                                                   uint32_t* __restrict__ g_p1, uint32_t* __restrict__ g_r1,
                                                                   uint2* __restrict__ miss, uint32_t* __restrict__ staging) {
-    constexpr int NWV = TKB_THREADS / 64;
-    __shared__ uint32_t red[NWV];
-    __shared__ uint32_t sc_all[NWV], sc_par[NWV], sc_cnt[NWV];
+    __shared__ uint32_t red[TKB_THREADS / 64];
+    __shared__ uint32_t sc[4][TKB_THREADS / 64];
     __shared__ uint32_t viol_sh;
-    const uint32_t tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
-    constexpr uint32_t MARK = 0x80000000u;  // (token ids stay below 2^31: checked at tk_create)
+    uint32_t epoch = 0;
     for (uint32_t w = blockIdx.x; w < nC; w += gridDim.x) {
         const uint32_t* ent = listC + 5 * (uint64_t)w;
-        const uint32_t mi = ent[0], s = ent[1], n = ent[2];
-        uint32_t *P0 = g_p0 + ent[3], *R0 = g_r0 + ent[3], *P1 = g_p1 + ent[3], *R1 = g_r1 + ent[3];
-        for (uint32_t k = tid; k < n; k += TKB_THREADS) {
-            const uint32_t b0 = text[s + k];
-            P0[k] = T.byte_rank[b0];
-            R0[k] = k + 1 < n ? T.pair2[(b0 << 8) | text[s + k + 1]] : TK_RANK_MAX;
-        }
-        if (tid == 0) viol_sh = 0;
-        __syncthreads();
-        uint32_t cnt = n;
-        bool redo = false;
-        for (;;) {
-            // a. the lowest rank
-            uint32_t m = TK_RANK_MAX;
-            for (uint32_t i = tid; i < cnt; i += TKB_THREADS) m = R0[i] < m ? R0[i] : m;
-            m = tk_wave_min_u32(m);
-            if (lane == 0) red[wid] = m;
-            __syncthreads();
-            m = red[lane & (NWV - 1)];
-            m = tk_wave_min_u32(m);
-            __syncthreads();
-            if (m == TK_RANK_MAX) break;
-            // Every wavefront owns a contiguous range of the parts and walks it in rows of 256 (four consecutive parts per lane: coalesced,
-            // and one wave scan per 256 parts); the state that crosses lanes, rows and wavefronts is the parity of the run of rank-m pairs
-            // that ends right before a part.
-            constexpr int EPL = 8;  // parts per lane and row: eight loads in flight per lane hide the memory latency of this one-CU kernel
-            constexpr uint32_t ROW = 64 * EPL;
-            const uint32_t per = ((cnt + NWV - 1) / NWV + ROW - 1u) / ROW * ROW;
-            const uint32_t wlo = (uint32_t)wid * per < cnt ? (uint32_t)wid * per : cnt, whi = wlo + per < cnt ? wlo + per : cnt;
-            // the parts of a lane: their ranks, rank-m flags (parts beyond the range: neutral) and the lane's run state
-            auto lane_state = [&](uint32_t i0, uint32_t rk[EPL], uint32_t& fm) -> TkRunState {
-                if (i0 + EPL <= whi) {  // (ranges and scratch offsets are multiples of four parts: 16-byte loads)
-#pragma unroll
-                    for (int q = 0; q < EPL; q += 4) {
-                        const uint4 x = *(const uint4*)(R0 + i0 + q);
-                        rk[q] = x.x; rk[q + 1] = x.y; rk[q + 2] = x.z; rk[q + 3] = x.w;
-                    }
-                } else {
-#pragma unroll
-                    for (int q = 0; q < EPL; ++q) rk[q] = i0 + q < whi ? R0[i0 + q] : 0u;
-                }
-                TkRunState v{1u, 0u};
-                fm = 0;
-#pragma unroll
-                for (int q = 0; q < EPL; ++q) {
-                    const bool in = i0 + q < whi;
-                    const uint32_t f = in ? (uint32_t)(rk[q] == m) : 0u;
-                    fm |= f << q;
-                    if (in) v = tk_run_combine(v, TkRunState{f, f});
-                }
-                return v;
-            };
-            // b. run state of each wavefront's range, then of everything before it
-            TkRunState acc{1u, 0u};
-            for (uint32_t r0 = wlo; r0 < whi; r0 += ROW) {
-                uint32_t rk[EPL], fm;
-                TkRunState v = tk_run_scan_wave(lane_state(r0 + (uint32_t)EPL * lane, rk, fm), lane);
-                acc = tk_run_combine(acc, TkRunState{(uint32_t)__shfl((int)v.all, 63, 64), (uint32_t)__shfl((int)v.par, 63, 64)});
-            }
-            if (lane == 0) {
-                sc_all[wid] = acc.all;
-                sc_par[wid] = acc.par;
-            }
-            __syncthreads();
-            TkRunState before{1u, 0u};
-            for (int q = 0; q < wid; ++q) before = tk_run_combine(before, TkRunState{sc_all[q], sc_par[q]});
-            // c. parts that survive in this range (a part right after an odd count of rank-m pairs is absorbed)
-            uint32_t keep = 0;
-            {
-                TkRunState carry = before;
-                for (uint32_t r0 = wlo; r0 < whi; r0 += ROW) {
-                    const uint32_t i0 = r0 + (uint32_t)EPL * lane;
-                    uint32_t rk[EPL], fm;
-                    TkRunState v = tk_run_scan_wave(lane_state(i0, rk, fm), lane);
-                    TkRunState ex{(uint32_t)__shfl_up((int)v.all, 1, 64), (uint32_t)__shfl_up((int)v.par, 1, 64)};
-                    if (lane == 0) ex = TkRunState{1u, 0u};
-                    uint32_t c = tk_run_combine(carry, ex).par, kl = 0;  // parity of the run of rank-m pairs right before the lane's first part
-#pragma unroll
-                    for (int q = 0; q < EPL; ++q) {
-                        kl += (uint32_t)(i0 + q < whi) & (c ^ 1u);
-                        c = ((fm >> q) & 1u) ? (c ^ 1u) : 0u;
-                    }
-                    keep += tk_wave_sum_u32(kl);
-                    carry = tk_run_combine(carry, TkRunState{(uint32_t)__shfl((int)v.all, 63, 64), (uint32_t)__shfl((int)v.par, 63, 64)});
-                }
-            }
-            if (lane == 0) sc_cnt[wid] = keep;
-            __syncthreads();
-            uint32_t at = 0, total = 0;
-            for (int q = 0; q < NWV; ++q) {
-                if (q < wid) at += sc_cnt[q];
-                total += sc_cnt[q];
-            }
-            {
-                TkRunState carry = before;
-                for (uint32_t r0 = wlo; r0 < whi; r0 += ROW) {
-                    const uint32_t i0 = r0 + (uint32_t)EPL * lane;
-                    uint32_t rk[EPL], fm;
-                    TkRunState v = tk_run_scan_wave(lane_state(i0, rk, fm), lane);
-                    TkRunState ex{(uint32_t)__shfl_up((int)v.all, 1, 64), (uint32_t)__shfl_up((int)v.par, 1, 64)};
-                    if (lane == 0) ex = TkRunState{1u, 0u};
-                    uint32_t c = tk_run_combine(carry, ex).par, kl = 0, keepm = 0;
-#pragma unroll
-                    for (int q = 0; q < EPL; ++q) {
-                        const uint32_t k = (uint32_t)(i0 + q < whi) & (c ^ 1u);
-                        keepm |= k << q;
-                        kl += k;
-                        c = ((fm >> q) & 1u) ? (c ^ 1u) : 0u;
-                    }
-                    const uint32_t inc = tk_wave_scan_u32(kl, lane);
-                    uint32_t o = at + inc - kl;
-#pragma unroll
-                    for (int q = 0; q < EPL; ++q) {
-                        if ((keepm >> q) & 1u) {  // kept; selected when its own pair has rank m
-                            const uint32_t i = i0 + q, f = (fm >> q) & 1u;
-                            P1[o] = f ? (m | MARK) : (P0[i] & ~MARK);
-                            R1[o] = rk[q];  // (still right when neither this part nor the next one changes)
-                            ++o;
-                            // the next pick of this round is the pair right after this one: between the two picks the pair (merged part,
-                            // its still unmerged right neighbour) exists and must not rank below m either
-                            if (f && i + 2 < cnt && R0[i + 2] == m && tk_probe_pair(T, m, P0[i + 2] & ~MARK) < m) viol_sh = 1;
-                        }
-                    }
-                    at += (uint32_t)__shfl((int)inc, 63, 64);
-                    carry = tk_run_combine(carry, TkRunState{(uint32_t)__shfl((int)v.all, 63, 64), (uint32_t)__shfl((int)v.par, 63, 64)});
-                }
-            }
-            __syncthreads();
-            // d. ranks of the pairs that a merge has touched
-            for (uint32_t j = tid; j < total; j += TKB_THREADS) {
-                const uint32_t a = P1[j], b = j + 1 < total ? P1[j + 1] : 0u;
-                if (j + 1 >= total) R1[j] = TK_RANK_MAX;
-                else if ((a | b) & MARK) {
-                    const uint32_t r = tk_probe_pair(T, a & ~MARK, b & ~MARK);
-                    R1[j] = r;
-                    if (r < m) viol_sh = 1;  // a merge created a pair that the reference would have picked before the rest of this round
-                }
-            }
-            __syncthreads();
-            if (viol_sh) {
-                redo = true;
-                break;
-            }
-            uint32_t* t0 = P0; P0 = P1; P1 = t0;
-            t0 = R0; R0 = R1; R1 = t0;
-            cnt = total;
-        }
-        if (redo) {
-            if (tid == 0) miss[mi] = make_uint2(TK_MERGE_REDO, 0u);
-        } else {
-            for (uint32_t k = tid; k < cnt; k += TKB_THREADS) staging[s + k] = P0[k] & ~MARK;
-            if (tid == 0) miss[mi] = make_uint2(cnt, cnt == 1 ? (P0[0] & ~MARK) : s);
-        }
-        __syncthreads();
+        if (ent[2] >= TK_WIDE_MIN) continue;
+        tk_rounds_piece<false>(T, text, ent, g_p0, g_r0, g_p1, g_r1, miss, staging, nullptr, epoch, red, sc, &viol_sh);
+    }
+}
+// all workgroups of the launch (TK_WIDE_BLOCKS of them) on one piece after the other
+__global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds_wide(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listC,
+                                                                       uint32_t nC, uint32_t* __restrict__ g_p0, uint32_t* __restrict__ g_r0,
+                                                                       uint32_t* __restrict__ g_p1, uint32_t* __restrict__ g_r1,
+                                                                       uint2* __restrict__ miss, uint32_t* __restrict__ staging, TkWideWs* __restrict__ ws) {
+    __shared__ uint32_t red[TKB_THREADS / 64];
+    uint32_t epoch = 0;
+    for (uint32_t w = 0; w < nC; ++w) {
+        const uint32_t* ent = listC + 5 * (uint64_t)w;
+        if (ent[2] < TK_WIDE_MIN) continue;
+        tk_rounds_piece<true>(T, text, ent, g_p0, g_r0, g_p1, g_r1, miss, staging, ws, epoch, red, nullptr, nullptr);
     }
 }
 
