@@ -405,3 +405,57 @@ def test_multi_device_group_equals_single_device():
         t2, f2 = core.encode_batch_packed(b2, o2)
         w2, x2 = C.encode_batch(b2, o2, None, 1) if docs else (np.zeros(0, np.uint32), np.zeros(1, np.uint64))
         assert np.array_equal(t2, w2) and np.array_equal(f2, x2), docs
+
+
+# ---------------------------------------------------------------- small calls: one launch (tk_k_small)
+def test_small_calls_one_launch_same_tokens(monkeypatch):
+    """A single document of up to 2 KiB without special tokens is encoded by ONE workgroup in ONE launch (tk_k_small); the result is
+    the oracle's, and the general pipeline's (debug bit 2048 switches the short cut off).  Pieces that are not tokens and longer than
+    24 bytes send the call to the general path."""
+    from tiktoken_amd import CoreBPE
+
+    rng = np.random.default_rng(11)
+    alphabet = list("abcdefghijklmnopqrstuvwxyzABCDEFGHIJKLMNOPQRSTUVWXYZ0123456789   \n\t.,;:!?'\"()-_/\u00e9\u00fc\u00df\u4e2d\u6587\u0416\u0434\U0001F600\u200b\u3000\r")
+    texts = ["hello world", "a", " ", "\n", "Hello, World! It's 12345 o'clock.\n\n  def f(x):\n\treturn x's", "x" * 2048, " " * 2048, "ab" * 1000,
+             "\u4e2d" * 682, "don't DON'T I'LL we've", "supercalifragilisticexpialidociousantidisestablishmentarianism" * 3, "1234567890" * 20]
+    for _ in range(300):
+        k = int(rng.integers(1, 400))
+        texts.append("".join(alphabet[int(j)] for j in rng.integers(0, len(alphabet), size=k)))
+    texts = [t for t in texts if len(t.encode()) <= 2048]
+    for name in ("gpt2_shaped", "cl100k_shaped", "o200k_shaped"):
+        g = h.load_golden(name)
+        a = CoreBPE(h.golden_vocab(name), g["special_tokens"], g["pat_str"])
+        monkeypatch.setenv("TIKTOKEN_AMD_DEBUG", "2048")
+        b = CoreBPE(h.golden_vocab(name), g["special_tokens"], g["pat_str"])
+        monkeypatch.delenv("TIKTOKEN_AMD_DEBUG")
+        C = h.c_oracle_for(name)
+        a.set_profiling(True)
+        a.reset_kernel_ms()
+        for t in texts:
+            want = C.encode_ordinary(t.encode()).tolist()
+            assert a.encode_ordinary(t) == want, (name, t)
+            assert b.encode_ordinary(t) == want, (name, t)
+        assert a.kernel_ms("tk_k_small")[1] >= len(texts)
+        assert a.kernel_ms("tk_k_front")[1] < len(texts) // 4  # (only the few calls with long non-token pieces)
+        a.set_profiling(False)
+
+
+def test_hello_world_latency():
+    """The reference's commonest call, end to end through the Python layer (Encoding.encode: special-token check, str -> UTF-8, C ABI,
+    one launch, list of ints).  Measured 27 us on MI355X (tools/small_call.py); the bounds leave room for a busy host."""
+    import time
+
+    import tiktoken_amd
+
+    enc = tiktoken_amd.get_encoding("o200k_shaped")
+    for _ in range(300):
+        enc.encode("hello world")
+    ts = []
+    for _ in range(3000):
+        t0 = time.perf_counter_ns()
+        enc.encode("hello world")
+        ts.append(time.perf_counter_ns() - t0)
+    ts.sort()
+    p10, med = ts[len(ts) // 10] / 1e3, ts[len(ts) // 2] / 1e3
+    print(f"Encoding.encode('hello world'): p10 {p10:.1f} us, median {med:.1f} us")
+    assert p10 <= 30.0 and med <= 45.0, (p10, med)

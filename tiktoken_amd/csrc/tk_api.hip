@@ -6,6 +6,7 @@
 #include <stdlib.h>
 #include <string.h>
 
+#include <chrono>
 #include <functional>
 #include <atomic>
 #include <map>
@@ -80,6 +81,10 @@ struct tk_core {
     int dbg = 0;
     uint32_t n_dec = 0;  // entries of the device decode table (0: ids too sparse for a direct table -- decode stays on the host)
     Buf d_tok, d_lens, d_bsum, d_tboff, d_bytes, d_boff;  // decode workspace
+    uint8_t* small_in = nullptr;    // page-locked, device-visible: text of a small call (tk_k_small)
+    uint32_t* small_out = nullptr;  // page-locked, device-visible: its result
+    uint32_t small_seq = 0;
+    Buf small_ws;
     std::vector<uint8_t> sorted_blob;  // token_byte_values(), packed (built on first use)
     std::vector<uint64_t> sorted_off;
     // instrumentation
@@ -304,8 +309,10 @@ extern "C" void tk_destroy(tk_core* c) {
                    &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->res, &c->rflag, &c->staging, &c->listB,
                    &c->listC, &c->counters, &c->total, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv, &c->out_tokens,
                    &c->out_tok_off, &c->allowed, &c->tile_np, &c->tile_nt, &c->tile_nmiss, &c->mt_slots, &c->wbin, &c->deferred, &c->big,
-                   &c->wave_pieces})
+                   &c->wave_pieces, &c->small_ws})
         release(*b);
+    if (c->small_in) (void)hipHostFree(c->small_in);
+    if (c->small_out) (void)hipHostFree(c->small_out);
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (int i = 0; i < 4; ++i) {
         if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
@@ -734,6 +741,59 @@ static void parallel_memcpy(void* dst, const void* src, size_t n, unsigned nth) 
     for (auto& t : th) t.join();
 }
 
+// One short document without special tokens: one launch, no copies, no stream synchronisation (tk_k_small, tk_fused.h).
+// Returns TK_OK with *handled = false when the call has to take the general path.
+static int encode_small(tk_core* c, const uint8_t* utf8, uint32_t n, uint32_t** tokens_out, uint64_t* n_tokens_out, bool* handled) {
+    *handled = false;
+    if (!c->small_in) {
+        HIPCHK(hipHostMalloc((void**)&c->small_in, TK_SMALL_MAX + 64, hipHostMallocCoherent | hipHostMallocMapped));
+        HIPCHK(hipHostMalloc((void**)&c->small_out, (TK_SMALL_HDR + TK_SMALL_MAX + 16) * 4, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(c->small_in, 0, TK_SMALL_MAX + 64);
+        memset(c->small_out, 0, (TK_SMALL_HDR + TK_SMALL_MAX + 16) * 4);
+        TRY(ensure(c->small_ws, 256 * TK_SMALL_PIECE * 4));
+    }
+    memcpy(c->small_in, utf8, n);
+    memset(c->small_in + n, 0, 8);
+    void *d_in = nullptr, *d_out = nullptr;
+    HIPCHK(hipHostGetDevicePointer(&d_in, c->small_in, 0));
+    HIPCHK(hipHostGetDevicePointer(&d_out, c->small_out, 0));
+    const uint32_t seq = ++c->small_seq ? c->small_seq : ++c->small_seq;  // (never 0: the buffer starts zeroed)
+    hipStream_t s = c->stream;
+    TRY(timed(c, s, "tk_k_small", [&] {
+        hipLaunchKernelGGL(tk_k_small, dim3(1), dim3(256), 0, s, c->D, (const uint8_t*)d_in, n, seq, (uint32_t*)d_out, c->small_ws.as<uint32_t>());
+    }));
+    // the kernel's last store is the sequence number (system scope): watch for it instead of waiting on the stream
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t spins = 0;
+    while (__atomic_load_n(&c->small_out[2], __ATOMIC_ACQUIRE) != seq) {
+        if ((++spins & 0xFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            HIPCHK(hipStreamSynchronize(s));
+            if (__atomic_load_n(&c->small_out[2], __ATOMIC_ACQUIRE) != seq) return fail(TK_RUNTIME_ERROR, "the small-call kernel did not complete");
+            break;
+        }
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    if (c->profiling) {
+        HIPCHK(hipStreamSynchronize(s));
+        TRY(drain_events(c));
+    }
+    if (c->small_out[0] != 1u) return TK_OK;  // a long piece that is not a token: general path
+    const uint64_t nt = c->small_out[1];
+    uint32_t* host = (uint32_t*)malloc((nt ? nt : 1) * 4);
+    if (!host) return fail(TK_RUNTIME_ERROR, "out of host memory");
+    memcpy(host, c->small_out + TK_SMALL_HDR, nt * 4);
+    c->st_bytes = n;
+    c->st_tokens = nt;
+    c->st_docs = 1;
+    c->st_pieces = c->st_medium = c->st_long = 0;
+    *tokens_out = host;
+    *n_tokens_out = nt;
+    *handled = true;
+    return TK_OK;
+}
+
 extern "C" int tk_encode_batch(tk_core* c, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special,
                                const uint32_t* allowed_ids, uint64_t n_allowed, uint32_t** tokens_out, uint64_t* n_tokens_out,
                                uint64_t* tok_off_out) {
@@ -746,6 +806,17 @@ extern "C" int tk_encode_batch(tk_core* c, const uint8_t* utf8, const uint64_t* 
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const uint64_t n_bytes = doc_off[n_docs];
+    if (n_docs == 1 && n_bytes > 0 && n_bytes <= TK_SMALL_MAX && !(use_special && n_allowed) && !(c->dbg & 2048)) {
+        bool handled = false;
+        TRY(encode_small(c, utf8, (uint32_t)n_bytes, tokens_out, n_tokens_out, &handled));
+        if (handled) {
+            if (tok_off_out) {
+                tok_off_out[0] = 0;
+                tok_off_out[1] = *n_tokens_out;
+            }
+            return TK_OK;
+        }
+    }
     TRY(ensure(c->text, n_bytes + 256));
     TRY(ensure(c->doc_off, (n_docs + 2) * 8));
     HIPCHK(hipMemsetAsync((uint8_t*)c->text.p + n_bytes, 0, 128, s));

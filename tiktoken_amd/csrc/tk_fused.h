@@ -1959,3 +1959,96 @@ __global__ void tk_k_single_front(TkTables T, const uint8_t* __restrict__ text, 
     }
     out.tile_nmiss[0] = nm;
 }
+
+// ------------------------------------------------------------------------------------------
+// Small calls.  Encoding.encode("hello world") is the reference's most common call (tiktoken/core.py:84-139 on one short string): a
+// pipeline of twenty launches costs a hundred times what the work does.  One workgroup does the whole job for a single document of up
+// to TK_SMALL_MAX bytes without special tokens: text from page-locked host memory straight into LDS, a class per byte, the end of the
+// piece that would start at every char (tk_piece_end: the byte-walk scanner, all positions in parallel), one lane follows the chain of
+// true piece starts, then one lane per piece: vocabulary probe, else byte_pair_merge in LDS (pieces of up to TK_SMALL_PIECE bytes;
+// anything longer that is not a token sends the call to the general path: status 2).  Tokens, their count and the completion word go
+// straight to page-locked host memory, so the host needs neither a copy nor a stream synchronisation: it watches the completion word.
+// ------------------------------------------------------------------------------------------
+#define TK_SMALL_MAX 2048
+#define TK_SMALL_PIECE 24
+#define TK_SMALL_HDR 4  // result words before the tokens: status (1 done, 2 not handled), token count, completion sequence number, 0
+struct TkSmallAcc {
+    const uint8_t *c, *raw;
+    uint32_t n;
+    __device__ __forceinline__ uint32_t cls(uint64_t pos) const { return pos < n ? (uint32_t)c[pos] : (uint32_t)TK_C_END; }
+    __device__ __forceinline__ uint32_t byte(uint64_t pos) const { return pos < n ? (uint32_t)raw[pos] : 0u; }
+};
+__global__ __launch_bounds__(256) void tk_k_small(TkTables T, const uint8_t* __restrict__ text, uint32_t n, uint32_t seq, uint32_t* __restrict__ out,
+                                                   uint32_t* __restrict__ ws /* [256][TK_SMALL_PIECE] */) {
+    __shared__ __attribute__((aligned(16))) uint8_t raw[TK_SMALL_MAX + 16];
+    __shared__ uint8_t cls[TK_SMALL_MAX + 16];
+    __shared__ uint16_t nxt[TK_SMALL_MAX];
+    __shared__ uint16_t plist[TK_SMALL_MAX + 1];
+    __shared__ uint32_t idb[TK_SMALL_PIECE * 256], rkb[TK_SMALL_PIECE * 256];
+    __shared__ uint32_t np_sh, bail_sh, scan_sh[8];
+    const uint32_t tid = threadIdx.x;
+    const int pat = T.pattern;
+    for (uint32_t i = tid * 4u; i < TK_SMALL_MAX + 16u; i += 1024u) *(uint32_t*)(raw + i) = i < n ? *(const uint32_t*)(text + i) : 0u;  // (input buffer is padded)
+    if (tid == 0) bail_sh = 0;
+    __syncthreads();
+    if (tid < 16u && n + tid < TK_SMALL_MAX + 16u) raw[n + tid] = 0;  // (bytes of the last word beyond the text)
+    __syncthreads();
+    for (uint32_t i = tid; i < n; i += 256u) {
+        uint32_t c = tk_classify_text(T, raw, i, n);
+        if (i == 0) c |= TK_F_HARD;
+        cls[i] = (uint8_t)c;
+    }
+    __syncthreads();
+    TkSmallAcc acc{cls, raw, n};
+    for (uint32_t i = tid; i < n; i += 256u) {
+        uint32_t e = i + 1u;
+        if (cls[i] != TK_C_CONT) {
+            const uint64_t e64 = tk_piece_end(acc, (uint64_t)i, pat);
+            const uint64_t nc = tk_next_char(acc, (uint64_t)i);
+            e = (uint32_t)(e64 > nc ? e64 : nc);
+            if (e > n) e = n;
+        }
+        nxt[i] = (uint16_t)e;
+    }
+    __syncthreads();
+    if (tid == 0) {
+        uint32_t np = 0, p = 0;
+        while (p < n) {
+            plist[np++] = (uint16_t)p;
+            p = nxt[p];
+        }
+        plist[np] = (uint16_t)n;
+        np_sh = np;
+    }
+    __syncthreads();
+    const uint32_t np = np_sh;
+    uint32_t base = 0;
+    for (uint32_t r0 = 0; r0 < np; r0 += 256u) {
+        const uint32_t i = r0 + tid;
+        uint32_t cnt = 0, tok = 0;
+        if (i < np) {
+            const uint32_t s0 = plist[i], len = (uint32_t)plist[i + 1] - s0;
+            tok = tk_lookup_text_piece(T, raw, s0, len);
+            if (tok != TK_RANK_MAX) cnt = 1;
+            else if (len <= TK_SMALL_PIECE) cnt = tk_lane_merge<256>(T, raw, s0, len, idb + tid, rkb + tid, ws + tid * TK_SMALL_PIECE);
+            else bail_sh = 1;
+        }
+        uint32_t tot;
+        const uint32_t ex = tk_block_exscan_256(cnt, &tot, scan_sh);
+        if (i < np && !bail_sh) {
+            uint32_t* o = out + TK_SMALL_HDR + base + ex;
+            if (tok != TK_RANK_MAX) o[0] = tok;
+            else
+                for (uint32_t j = 0; j < cnt; ++j) o[j] = ws[tid * TK_SMALL_PIECE + j];
+        }
+        base += tot;
+    }
+    __threadfence_system();
+    __syncthreads();
+    if (tid == 0) {
+        out[0] = bail_sh ? 2u : 1u;
+        out[1] = base;
+        __threadfence_system();
+        __hip_atomic_store(&out[2], seq, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    }
+}

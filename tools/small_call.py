@@ -1,0 +1,39 @@
+#!/usr/bin/env python3
+"""Latency of small calls (the reference's most common use): microseconds per call, median of many."""
+import os, sys, time, ctypes
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import tiktoken_amd
+
+def med(f, n=2000, warm=200):
+    for _ in range(warm): f()
+    ts = []
+    for _ in range(n):
+        t0 = time.perf_counter_ns(); f(); ts.append(time.perf_counter_ns() - t0)
+    ts.sort()
+    return ts[len(ts) // 2] / 1e3, ts[len(ts) // 10] / 1e3, ts[(len(ts) * 9) // 10] / 1e3
+
+enc = tiktoken_amd.get_encoding(sys.argv[1] if len(sys.argv) > 1 else "o200k_shaped")
+core = enc._core_bpe
+for text in ["hello world", "The quick brown fox jumps over the lazy dog. " * 4, "lorem ipsum dolor sit amet " * 70]:
+    b = text.encode()
+    buf = np.frombuffer(b, np.uint8)
+    off = (ctypes.c_uint64 * 2)(0, len(b))
+    L = core._L
+    def raw():
+        out, n = ctypes.c_void_p(), ctypes.c_uint64()
+        L.tk_encode_ordinary(core._h, buf.ctypes.data, len(b), ctypes.byref(out), ctypes.byref(n))
+        L.tk_free(out)
+    r = {"Encoding.encode": med(lambda: enc.encode(text)), "Encoding.encode_ordinary": med(lambda: enc.encode_ordinary(text)),
+         "CoreBPE.encode_ordinary": med(lambda: core.encode_ordinary(text)), "C ABI tk_encode_ordinary (ctypes)": med(raw)}
+    print(f"{len(b)} bytes, {len(enc.encode(text))} tokens:")
+    for k, (m, lo, hi) in r.items():
+        print(f"   {k:36} median {m:8.1f} us   p10 {lo:8.1f}   p90 {hi:8.1f}")
+# C1: 1 MiB lorem, one document (general pipeline)
+import helpers as h
+_, _, _, blob, off, _ = h.baseline_config("C1")
+g = tiktoken_amd.get_encoding("gpt2_shaped")
+s = blob.tobytes().decode()
+print("C1 (1 MiB, gpt2_shaped) Encoding.encode_ordinary:", med(lambda: g.encode_ordinary(s), n=30, warm=3))
+print("C1 CoreBPE._encode_np:", med(lambda: g._core_bpe._encode_np(blob.tobytes(), None), n=30, warm=3))
