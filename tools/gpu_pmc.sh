@@ -5,7 +5,7 @@ rocprofv3 -L 2>/dev/null | grep -oE "\b(SQ_[A-Z_0-9]+|GRBM_[A-Z_]+|TCP_[A-Z_0-9]
 wc -l $R/gpurun_out/pmc2/counters.txt
 for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
   T=$(echo $SET | cut -d' ' -f1)
-  rocprofv3 --pmc $SET --output-format csv -d $R/gpurun_out/pmc2/$T -o p -- python $R/bench.py --gpus 1 --steps 1 --warmup 0 --mib 1024 --no-cpu-baseline > $R/gpurun_out/pmc2/$T.log 2>&1
+  rocprofv3 --pmc $SET --output-format csv -d $R/gpurun_out/pmc2/$T -o p -- python $R/bench.py --gpus 1 --steps 1 --warmup 0 --mib 1024 --no-cpu-baseline --no-host-path > $R/gpurun_out/pmc2/$T.log 2>&1
 done
 cd $R; python - <<'PY'
 import csv, glob, collections
@@ -15,7 +15,7 @@ for f in glob.glob("gpurun_out/pmc2/*/p_counter_collection.csv"):
         k = r["Kernel_Name"].split("(")[0]
         if k.startswith("void "):
             k = k[5:]
-        k = k.split("<")[0]
+        k = "tk_k_front_slow" if k.startswith("tk_k_front<") and k.split(">")[0].replace(" ", "").endswith(("true", ",1")) else k.split("<")[0]
         if k.startswith("tk_k_"):
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():
