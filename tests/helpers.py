@@ -174,9 +174,9 @@ def sim_lib():
         d = os.path.join(ROOT, "tests", "hostsim")
         so = os.path.join(d, "libtk_hostsim.so")
         srcs = [os.path.join(d, "tk_hostsim.cpp")] + [os.path.join(ROOT, "tiktoken_amd", "csrc", f)
-                                                       for f in ("tk_tables.cpp", "tk_device.h", "tk_common.h", "tk_tables.h", "tk_chunk.h")]
+                                                       for f in ("tk_tables.cpp", "tk_pattern.cpp", "tk_device.h", "tk_common.h", "tk_tables.h", "tk_chunk.h")]
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", srcs[0], srcs[1], "-o", so])
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", srcs[0], srcs[1], srcs[2], "-o", so])
         L = ctypes.CDLL(so)
         vp, u64 = ctypes.c_void_p, ctypes.c_uint64
         L.tks_create.restype = vp

@@ -45,6 +45,9 @@ struct FlatAcc {
 
 static uint64_t g_runs_mismatch = 0;
 
+// certain piece starts from the table that travels with the pattern (TkTables::cert: the family's static table for stock patterns)
+static inline bool tk_certain_rt(const uint16_t* cert, uint32_t a, uint32_t b) { return (cert[a & 15u] >> b) & 1u; }
+
 extern "C" {
 uint64_t tks_runs_mismatches() { return g_runs_mismatch; }
 
@@ -88,6 +91,8 @@ void* tks_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uin
     D.n_spec = (uint32_t)H.spec_id.size();
     memcpy(D.spec_first, H.spec_first, sizeof D.spec_first);
     D.pattern = H.pattern;
+    D.pat = H.pat;
+    memcpy(D.cert, H.cert, sizeof D.cert);
     return s;
 }
 void tks_destroy(void* p) { delete (Sim*)p; }
@@ -121,6 +126,10 @@ uint64_t tks_pretok(void* p, const uint8_t* text_in, uint64_t n, const uint64_t*
     memset(starts, 0, n);
     FlatAcc acc{cls.data(), text.data(), n};
     const int pat = s->T.pattern;
+    const uint16_t* s_cert = s->T.cert;
+    (void)pat;
+    const TkPat patx = s->T.pat;
+    (void)patx;
     uint64_t n_certain = 0;
     for (uint64_t i = 0; i < n; ++i) {
         uint32_t c = cls[i];
@@ -130,22 +139,22 @@ uint64_t tks_pretok(void* p, const uint8_t* text_in, uint64_t n, const uint64_t*
             if (i == 0) continue;  // the kernel sees TK_C_END to the left of position 0
             uint64_t j = i - 1;
             while (j > 0 && cls[j] == TK_C_CONT) --j;
-            certain = tk_certain_start(pat, cls[j] & 15u, c & 15u);
+            certain = tk_certain_rt(s_cert, cls[j] & 15u, c & 15u);
         }
         if (!certain) continue;
         ++n_certain;
         starts[i] = 1;
         uint64_t q = i;
         for (;;) {
-            uint64_t e = tk_piece_end(acc, q, pat);
-            if (tk_piece_end_runs(acc, q, pat) != e) ++g_runs_mismatch;  // the run-query form must agree everywhere
+            uint64_t e = tk_piece_end(acc, q, patx);
+            if (tk_piece_end_runs(acc, q, patx) != e) ++g_runs_mismatch;  // the run-query form must agree everywhere
             if (e <= q) e = tk_next_char(acc, q);
             if (e >= n) break;
             uint32_t ce = acc.cls(e);
             if (ce & TK_F_HARD) break;
             uint64_t j = e - 1;
             while (acc.cls(j) == TK_C_CONT) --j;
-            if (tk_certain_start(pat, acc.cls(j) & 15u, ce & 15u)) break;
+            if (tk_certain_rt(s_cert, acc.cls(j) & 15u, ce & 15u)) break;
             starts[e] = 1;
             q = e;
         }
@@ -209,6 +218,7 @@ uint64_t tks_pretok_bits(void* pv, const uint8_t* text_in, uint64_t n, const uin
         }
     }
     // bitmaps (one byte per bit here; the kernel packs them with __ballot)
+    const TkPat patx = s->T.pat;
     const size_t m = n + 80;
     std::vector<uint8_t> b_start(m, 0), b_hard(m, 0), b_L(m, 0), b_up(m, 0), b_low(m, 0), b_cas(m, 0), b_oth(m, 0), b_ws(m, 0),
         b_nl(m, 0), b_nu(m, 0), b_nlsl(m, 0);
@@ -229,11 +239,14 @@ uint64_t tks_pretok_bits(void* pv, const uint8_t* text_in, uint64_t n, const uin
         b_ws[i] = (TK_M_WS >> k) & 1u;
         b_nl[i] = k == TK_C_NL;
         b_nu[i] = k == TK_C_NU;
-        b_nlsl[i] = k == TK_C_NL || k == TK_C_SL;
+        // (generic patterns keep their suffix set in this bitmap, as the front kernel does)
+        b_nlsl[i] = patx.generic() ? (((patx.suffix() & 1u) && k == TK_C_NL) || ((patx.suffix() & 2u) && k == TK_C_SL)) : (k == TK_C_NL || k == TK_C_SL);
     }
     memset(starts, 0, n);
     PropAcc acc{cls2.data(), text.data(), n};
     const int pat = s->T.pattern;
+    const uint16_t* s_cert = s->T.cert;
+    (void)pat;
     uint64_t n_fallback = 0, n_fast32 = 0;
     (void)n_fast32;
     for (uint64_t i = 0; i < n; ++i) {
@@ -242,7 +255,7 @@ uint64_t tks_pretok_bits(void* pv, const uint8_t* text_in, uint64_t n, const uin
         bool certain = (c & 0x80u) != 0;
         if (!certain) {
             if (i == 0) continue;
-            certain = tk_certain_start(pat, cls2[i - 1] & 15u, c & 15u);  // propagated class: no walking back
+            certain = tk_certain_rt(s_cert, cls2[i - 1] & 15u, c & 15u);  // propagated class: no walking back
         }
         if (!certain) continue;
         starts[i] = 1;
@@ -270,21 +283,21 @@ uint64_t tks_pretok_bits(void* pv, const uint8_t* text_in, uint64_t n, const uin
                 uint32_t start, stop;
                 uint32_t get(int kind) const { return (uint32_t)w->get(kind); }
             } w32{&w, (uint32_t)w.start, (uint32_t)w.stop};
-            uint32_t len = tk_piece_len_bits32(w32, acc, q, cls2[q] & 15u, pat);
+            uint32_t len = tk_piece_len_bits32(w32, acc, q, cls2[q] & 15u, patx);
             if (len) ++n_fast32;
-            else len = tk_piece_len_bits(w, acc, ext, q, cls2[q] & 15u, pat);
+            else len = tk_piece_len_bits(w, acc, ext, q, cls2[q] & 15u, patx);
             uint64_t e;
             if (len) {
                 e = q + len;
             } else {
                 ++n_fallback;
-                e = tk_piece_end(acc, q, pat);
+                e = tk_piece_end(acc, q, patx);
             }
             if (e <= q) e = tk_next_char(acc, q);
             if (e >= n) break;
             uint32_t ce = cls2[e];
             if (ce & 0x80u) break;
-            if (tk_certain_start(pat, cls2[e - 1] & 15u, ce & 15u)) break;
+            if (tk_certain_rt(s_cert, cls2[e - 1] & 15u, ce & 15u)) break;
             starts[e] = 1;
             q = e;
         }
@@ -317,25 +330,29 @@ uint64_t tks_pretok_tiles(void* pv, const uint8_t* text_in, uint64_t n, const ui
     memset(starts, 0, n);
     PropAcc acc{cls2.data(), text.data(), n};
     const int pat = s->T.pattern;
+    const uint16_t* s_cert = s->T.cert;
+    (void)pat;
+    const TkPat patx = s->T.pat;
+    (void)patx;
     auto certain_at = [&](uint64_t i) -> bool {
         uint32_t c = cls2[i];
         if (c & 0x40u) return false;
         if (c & 0x80u) return true;
         if (i == 0) return false;
-        return tk_certain_start(pat, cls2[i - 1] & 15u, c & 15u);
+        return tk_certain_rt(s_cert, cls2[i - 1] & 15u, c & 15u);
     };
     uint64_t n_walkback = 0;
     for (uint64_t t0 = 0; t0 < n; t0 += tile) {
         const uint64_t t1 = t0 + tile < n ? t0 + tile : n;
         auto scan_from = [&](uint64_t q) {
             for (;;) {
-                uint64_t e = tk_piece_end(acc, q, pat);
+                uint64_t e = tk_piece_end(acc, q, patx);
                 if (e <= q) e = tk_next_char(acc, q);
                 if (e >= t1) break;                // the next piece start belongs to a later tile
                 uint32_t ce = cls2[e];
                 if (e >= t0) {
                     if (ce & 0x80u) break;
-                    if (tk_certain_start(pat, cls2[e - 1] & 15u, ce & 15u)) break;  // a scanner of this tile starts there
+                    if (tk_certain_rt(s_cert, cls2[e - 1] & 15u, ce & 15u)) break;  // a scanner of this tile starts there
                     starts[e] = 1;
                 } else if (certain_at(e)) {
                     break;                            // cannot happen: q was the LAST certain start before the tile
@@ -407,12 +424,16 @@ uint64_t tks_chunk_check(void* pv, const uint8_t* text_in, uint64_t n, const uin
         }
     }
     const int pat = T.pattern;
+    const uint16_t* s_cert = T.cert;
+    (void)pat;
+    const TkPat patx = T.pat;
+    (void)patx;
     auto certain_ref = [&](uint64_t i, bool prev_known) -> bool {
         uint32_t c = ref[i];
         if (c & 0x40u) return false;
         if (c & 0x80u) return true;
         if (i == 0 || !prev_known) return false;
-        return tk_certain_start(pat, ref[i - 1] & 15u, c & 15u);
+        return tk_certain_rt(s_cert, ref[i - 1] & 15u, c & 15u);
     };
     uint64_t bad = 0;
     auto report = [&](uint64_t pos, uint32_t code) {
@@ -483,7 +504,8 @@ uint64_t tks_chunk_check(void* pv, const uint8_t* text_in, uint64_t n, const uin
             const int64_t gp = base + (int64_t)t * 16;
             const TkChunkMasks& m = masks[t];
             const uint32_t prevc = t ? lastc[t - 1] : 0u;
-            const uint32_t cert = tk_chunk_certain(pat, sets[t], m.text, m.hard & m.text, prevc);
+            const uint32_t cert = T.pat.generic() ? tk_chunk_certain_rt(T.cert, sets[t], m.text, m.hard & m.text, prevc)
+                                                   : tk_chunk_certain(pat, sets[t], m.text, m.hard & m.text, prevc);
             // (the window may begin inside a char: its bytes there have no known class, and the first char start of the window no
             // known predecessor -- the kernel treats both as "unknown, never certain")
             int first = 0;

@@ -1,0 +1,171 @@
+"""pat_str handling (reference: the pattern is compiled once per Encoding, src/lib.rs:623): the parser of the supported family
+(tiktoken_amd/csrc/tk_pattern.cpp) and the scanners parametrised by it, against Python `regex` -- the engine the reference's own
+educational implementation uses for the same patterns (tiktoken/_educational.py).
+
+CPU part: the device headers compiled for the host (tests/hostsim) run the byte-walking scanner, the run-query scanner, the
+bit-parallel scanners and the tile rule on generated texts for every variation; `regex.findall` is the expected split.
+GPU part (-m gpu): the same through tk_pretokenize_batch and a whole encode through the Python oracle's regex path."""
+import random
+
+import numpy as np
+import pytest
+import regex
+
+import helpers as h
+
+R50K, CL100K, O200K = (h.PAT_STR[i] for i in range(3))
+CL100K_PLAIN = r"""'(?i:[sdmt]|ll|ve|re)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s+$|\s*[\r\n]|\s+(?!\S)|\s"""  # no possessive markers
+QWEN2 = r"""(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+"""
+
+# variations inside the family: (name, pattern)
+VARIANTS = [
+    ("qwen2 (cl100k with single digits)", QWEN2),
+    ("cl100k, groups of two digits", CL100K.replace("{1,3}", "{1,2}")),
+    ("cl100k, unbounded digits", CL100K.replace(r"\p{N}{1,3}+", r"\p{N}+")),
+    ("cl100k without possessive markers, seven digits", CL100K_PLAIN.replace("{1,3}", "{1,7}")),
+    ("cl100k, other contractions", CL100K.replace("[sdmt]|ll|ve|re", "[sdm]|ll|re|nt")),
+    ("cl100k, case-sensitive contractions", CL100K.replace("(?i:", "(?:")),
+    ("cl100k, no contractions suffix set with slash", CL100K.replace(r"[\r\n]*+", r"[\r\n/]*")),
+    ("cl100k, no suffix set", CL100K.replace(r"[\r\n]*+", "")),
+    ("cl100k without the end-of-text rule", CL100K.replace(r"\s++$|", "")),
+    ("cl100k without the newline rule", CL100K.replace(r"\s*[\r\n]|", "")),
+    ("o200k, single digits", O200K.replace("{1,3}", "{1,1}")),
+    ("o200k, groups of four digits", O200K.replace("{1,3}", "{1,4}")),
+    ("o200k, unbounded digits", O200K.replace(r"\p{N}{1,3}", r"\p{N}+")),
+    ("o200k, fewer contractions", O200K.replace("'s|'t|'re|'ve|'m|'ll|'d", "'s|'t|'ll")),
+    ("o200k, no contractions", O200K.replace("(?i:'s|'t|'re|'ve|'m|'ll|'d)?", "")),
+    ("o200k, case-sensitive contractions", O200K.replace("(?i:'s", "(?:'s")),
+    ("o200k, newline-only suffix set", O200K.replace(r"[\r\n/]*", r"[\r\n]*")),
+    ("o200k, slash-only suffix set", O200K.replace(r"[\r\n/]*", r"/*")),
+    ("o200k with the end-of-text rule", O200K.replace(r"|\s*[\r\n]+", r"|\s+$|\s*[\r\n]+")),
+    ("r50k, other contractions", R50K.replace("[sdmt]|ll|ve|re", "[st]|ve|nt|em")),
+    ("r50k, case-insensitive contractions", R50K.replace("'(?:", "'(?i:")),
+    ("r50k, no contractions", R50K.replace("'(?:[sdmt]|ll|ve|re)|", "")),
+]
+
+ALPHABET = list("abcdeflmnrstvxABDELMNRSTVX") + list("0123456789") * 2 + [" "] * 8 + ["\n", "\r", "\t", " ", "　", "'", "'", "'", "/", "/", "!", ".",
+            "-", "€", "é", "É", "中", "́", "ǅ", "ʰ", "²", "٣", "ſ", "K", "\U0001F600"]
+
+
+def _texts(seed, n, lo=0, hi=40):
+    rng = random.Random(seed)
+    out = []
+    for _ in range(n):
+        k = rng.randint(lo, hi)
+        s = []
+        while len(s) < k:
+            r = rng.random()
+            if r < 0.15:
+                s.extend(rng.choice(["'s", "'S", "'ll", "'LL", "'nt", "'Ve", "'re", "'em", "'d", "'m", "'t", "'ſ"]))
+            elif r < 0.25:
+                s.extend(rng.choice(ALPHABET) * rng.randint(2, 6))
+            else:
+                s.append(rng.choice(ALPHABET))
+        out.append("".join(s))
+    return out
+
+
+def _ends_regex(pat, docs, off):
+    ref = []
+    for d, t in enumerate(docs):
+        pos = 0
+        for piece in regex.findall(pat, t):
+            pos += len(piece.encode())
+            ref.append(int(off[d]) + pos)
+        assert pos == len(t.encode()), (pat, t)
+    return ref
+
+
+TINY = {bytes([b]): b for b in range(256)}
+
+
+def test_stock_spellings_map_to_the_stock_scanners():
+    from tiktoken_amd import _lib
+    from oracle import py_oracle as po
+
+    L = _lib.lib()
+    for fam, p in ((0, R50K), (0, po.GPT2_ORIG_PAT), (1, CL100K), (2, O200K)):
+        assert L.tk_pattern_id(p.encode()) == fam
+    # spelled without possessive markers, with the other forms of the contraction list and of the white-space tail
+    assert L.tk_pattern_id(CL100K_PLAIN.encode()) == 1
+    assert L.tk_pattern_id(CL100K.replace("'(?i:[sdmt]|ll|ve|re)", "(?i:'s|'t|'re|'ve|'m|'ll|'d)").encode()) == 1
+    assert L.tk_pattern_id(O200K.replace(r"\s*[\r\n]+", r"\s*[\r\n]").encode()) == 2
+    for _, p in VARIANTS:
+        assert L.tk_pattern_id(p.encode()) in (0, 1, 2), p
+
+
+@pytest.mark.parametrize("bad,why", [
+    (r"\w+|\s+", "not the letter alternative"),
+    (CL100K.replace("[sdmt]|ll|ve|re", "[sdmt]|ll|ve|re|ing"), "one or two letters"),
+    (CL100K.replace("[sdmt]|ll|ve|re", "[sdmt]|ll|ve|re|st"), "beginning of a two-letter one"),
+    (CL100K.replace("[sdmt]", "[sdmtk]"), "U+212A"),
+    (CL100K.replace("{1,3}", "{2,3}"), "digit group"),
+    (CL100K.replace(r"[\r\n]*+", r"[\r\n\\]*"), "suffix set"),
+    (CL100K + r"|x", "unexpected alternative"),
+    (O200K.replace(r"\p{N}{1,3}|", ""), "digit group"),
+    (R50K.replace(r"| ?\p{N}++", ""), r"\p{N}+"),
+    (CL100K.replace(r"\p{L}++", r"[\p{L}\p{M}]+"), "letter alternative"),
+])
+def test_unsupported_patterns_are_refused_with_the_reason(bad, why):
+    with pytest.raises(ValueError, match=regex.escape(why)):
+        h.HostSim(bad, TINY, {})
+
+
+@pytest.mark.parametrize("name,pat", VARIANTS, ids=[v[0] for v in VARIANTS])
+def test_scanners_of_a_variation_equal_regex(name, pat):
+    sim = h.HostSim(pat, TINY, {})
+    before = h.sim_lib().tks_runs_mismatches()
+    texts = _texts(hash(name) & 0xFFFF, 1500) + ["", "a", "'", " ", "\n", "1", "12345678901234567890", "x'll'LL'll", "  \n  \n  ", "a  \n\n  b", "   ", "a/\n//\nb",
+                                               "!!\r\n/x", "Don't DON'T don'T", "I'ſ 'ſx", "'K", "1 22 333 4444 55555", "٣٣٣٣٣٣٣", "²²²²²"]
+    for i in range(0, len(texts), 7):
+        docs = texts[i:i + 7]
+        blob, off = h.pack([d.encode() for d in docs])
+        ref = _ends_regex(pat, docs, off)
+        assert sim.piece_ends(blob, off)[0].tolist() == ref, (name, docs)             # byte-walking scanner from certain starts
+        assert sim.piece_ends(blob, off, bits=True)[0].tolist() == ref, (name, docs)  # bit-parallel scanners
+    assert h.sim_lib().tks_runs_mismatches() == before                                 # run-query scanner agreed at every piece
+    # the tile rule of the front kernel (tiny tiles, so that pieces and contexts cross tile edges all the time) and long runs
+    long_texts = _texts(hash(name) & 0xFFF, 60, 200, 1200) + ["7" * 700 + "x" * 300 + " " * 400 + "\n" * 90 + "/" * 50 + "!" * 333 + "中" * 200 + "'ll" * 100]
+    for t in long_texts:
+        blob, off = h.pack([t.encode()])
+        ref = _ends_regex(pat, [t], off)
+        for tile, left in ((16, 16), (64, 32), (256, 64)):
+            assert sim.piece_ends_tiled(blob, off, tile, left)[0].tolist() == ref, (name, tile, t[:80])
+        assert sim.piece_ends(blob, off, bits=True)[0].tolist() == ref
+
+
+# ---------------------------------------------------------------- on the device
+@pytest.mark.gpu
+@pytest.mark.parametrize("name,pat", VARIANTS, ids=[v[0] for v in VARIANTS])
+def test_gpu_split_of_a_variation_equals_regex(name, pat):
+    from tiktoken_amd import CoreBPE
+
+    core = CoreBPE(TINY, {}, pat)
+    texts = _texts(hash(name) & 0xFFFF, 4000, 0, 120) + _texts(7, 40, 3000, 9000) + ["x" * 20000 + "7" * 9001 + " " * 7000 + "\n" * 300 + "ab'll" * 900]
+    blob, off = h.pack([t.encode() for t in texts])
+    ref = _ends_regex(pat, texts, off)
+    starts = core.pretokenize_packed(blob, off)
+    assert starts[1:].tolist() == ref
+    # a whole encode of short calls (the one-launch path scans with the same pattern)
+    for t in texts[:300]:
+        if t:
+            assert core.encode_ordinary(t) == list(t.encode())  # (byte vocabulary: one token per byte, in piece order)
+
+
+@pytest.mark.gpu
+def test_gpu_encode_with_a_variation_equals_the_python_restatement():
+    """A real (shaped) vocabulary under Qwen2's pattern: token ids against the Python restatement of the reference's encode loop with
+    `regex` doing the split (what tiktoken/_educational.py does)."""
+    from oracle import py_oracle as po
+    from tiktoken_amd import CoreBPE
+
+    ranks = h.load_vocab("cl100k_shaped")
+    core = CoreBPE(ranks, {}, QWEN2)
+    texts = _texts(3, 400, 0, 200)
+    got = core.encode_batch_packed(*h.pack([t.encode() for t in texts]))
+    toks, toff = got
+    for i, t in enumerate(texts):
+        want = []
+        for piece in regex.findall(QWEN2, t):
+            want += po.byte_pair_encode(piece.encode(), ranks)
+        assert toks[int(toff[i]):int(toff[i + 1])].tolist() == want, t

@@ -206,9 +206,11 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
                          const char* pat_str, int device, tk_core** out) {
     if (!out) return fail(TK_VALUE_ERROR, "out is null");
     *out = nullptr;
-    if (tk_pattern_id(pat_str) < 0)
-        return fail(TK_UNSUPPORTED, std::string("unsupported pat_str (only the stock r50k/gpt2, cl100k and o200k patterns "
-                                                "have compiled scanners): ") + (pat_str ? pat_str : "(null)"));
+    {
+        TkPat pp;
+        const std::string perr = tk_parse_pattern(pat_str, &pp);
+        if (!perr.empty()) return fail(TK_UNSUPPORTED, perr);
+    }
     int ndev = 0;
     if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0)
         return fail(TK_RUNTIME_ERROR, "no HIP device available: tiktoken_amd has no CPU path");
@@ -279,6 +281,8 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     D.n_spec = (uint32_t)H.spec_id.size();
     memcpy(D.spec_first, H.spec_first, sizeof D.spec_first);
     D.pattern = H.pattern;
+    D.pat = H.pat;
+    memcpy(D.cert, H.cert, sizeof D.cert);
     for (size_t k = 0; k + 1 < H.spec_off.size(); ++k) c->spec_max_len = std::max(c->spec_max_len, H.spec_off[k + 1] - H.spec_off[k]);
     {  // decode table: id -> {offset into the token / special blob, length}
         uint32_t max_id = 0;
@@ -352,9 +356,12 @@ static void launch_front(int pattern, bool spec, dim3 grid, hipStream_t s, A... 
     } else if (pattern == TK_PAT_CL100K) {
         if (spec) hipLaunchKernelGGL((tk_k_front<TK_PAT_CL100K, true, SLOW>), grid, dim3(256), 0, s, a...);
         else hipLaunchKernelGGL((tk_k_front<TK_PAT_CL100K, false, SLOW>), grid, dim3(256), 0, s, a...);
-    } else {
+    } else if (pattern == TK_PAT_O200K) {
         if (spec) hipLaunchKernelGGL((tk_k_front<TK_PAT_O200K, true, SLOW>), grid, dim3(256), 0, s, a...);
         else hipLaunchKernelGGL((tk_k_front<TK_PAT_O200K, false, SLOW>), grid, dim3(256), 0, s, a...);
+    } else {  // a pattern of the family that is not one of the stock three: family and parameters are run-time values
+        if (spec) hipLaunchKernelGGL((tk_k_front<TK_PAT_GENERIC, true, SLOW>), grid, dim3(256), 0, s, a...);
+        else hipLaunchKernelGGL((tk_k_front<TK_PAT_GENERIC, false, SLOW>), grid, dim3(256), 0, s, a...);
     }
 }
 
@@ -449,13 +456,13 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         uint32_t* deferred = c->deferred.as<uint32_t>();
         TRY(timed(c, s, "tk_k_front", [&] {
             const dim3 grid((uint32_t)ntiles);
-            launch_front<false>(T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, fo,
+            launch_front<false>(T.pat.generic() ? TK_PAT_GENERIC : T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, fo,
                                 (c->dbg & 256) ? (TkMissSlot*)nullptr : mt, (1u << mt_bits) - 1u, deferred, c->dbg);
         }));
         // the tiles that need the workgroup-wide scanner (long pieces, far-away piece starts); their number stays on the device
         TRY(timed(c, s, "tk_k_front_slow", [&] {
             const dim3 grid((uint32_t)(ntiles < 1024 ? ntiles : 1024));
-            launch_front<true>(T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, fo,
+            launch_front<true>(T.pat.generic() ? TK_PAT_GENERIC : T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, fo,
                                (c->dbg & 256) ? (TkMissSlot*)nullptr : mt, (1u << mt_bits) - 1u, deferred, c->dbg);
         }));
     } else if (n > 0) {

@@ -204,3 +204,16 @@ TK_HD uint32_t tk_chunk_certain(int pat, const TkSets& s, uint32_t start, uint32
     }
     return cert & start;  // (pass the char starts of REAL text: positions past the end are hard but never pieces)
 }
+
+// The same from a table given at run time (generic patterns: cert[a] = class mask, TkTables::cert)
+TK_HD uint32_t tk_chunk_certain_rt(const uint16_t* cm, const TkSets& s, uint32_t start, uint32_t hard, uint32_t prevc) {
+    const uint32_t set_of[12] = {0u, s.nl, s.sp, s.wso, s.lu, s.ll, s.lc, s.mk, s.nu, s.ap, s.sl, s.ot};
+    uint32_t cert = hard;
+    for (uint32_t a = TK_C_NL; a <= (uint32_t)TK_C_OT; ++a) {
+        const uint32_t m = cm[a];
+        uint32_t follow = 0;
+        for (uint32_t b = TK_C_NL; b <= (uint32_t)TK_C_OT; ++b) follow |= ((m >> b) & 1u) ? set_of[b] : 0u;
+        cert |= tk_prev_set(set_of[a], 1u << a, prevc) & follow;
+    }
+    return cert & start;
+}

@@ -78,6 +78,38 @@ struct TkPairSlot {  // 16 bytes
 };
 #define TK_EMPTY_KEY 0xFFFFFFFFFFFFFFFFull
 
+// A split pattern of the supported family (reference: pat_str, compiled once per Encoding, src/lib.rs:623).  The three stock patterns
+// differ in their alternatives (the `family`); within a family a pattern may vary the contraction list after the apostrophe, its case
+// sensitivity, the longest digit group (\p{N}{1,k}; \p{N}+ = unbounded) and the suffix set behind a run of "other" chars
+// ([\r\n]*, [\r\n/]*, [/]* or none).  The scanners take a TkPat by value: for the stock patterns it is a compile-time constant.
+struct TkPat {
+    uint32_t w0;     // family (2 bits) | case-insensitive contractions << 2 | suffix set << 3 (1 = \r\n, 2 = '/') | generic << 5 |
+                     // \s+$ before the newline rule << 6 | newline rule \s*[\r\n]+ << 7 | longest digit group << 8 (0 = unbounded) |
+                     // number of two-letter contractions << 16
+    uint32_t c1;     // one-letter contractions ('s 't ...): bit = letter - 'a'
+    uint32_t c2[2];  // two-letter contractions, 16 bits each (first << 8 | second), at most four
+    TK_HD constexpr int fam() const { return (int)(w0 & 3u); }
+    TK_HD constexpr bool ci() const { return (w0 >> 2) & 1u; }
+    TK_HD constexpr uint32_t suffix() const { return (w0 >> 3) & 3u; }
+    TK_HD constexpr bool generic() const { return (w0 >> 5) & 1u; }
+    TK_HD constexpr bool ws_dollar() const { return (w0 >> 6) & 1u; }
+    TK_HD constexpr bool nl_rule() const { return (w0 >> 7) & 1u; }
+    TK_HD constexpr uint32_t digits() const { return (w0 >> 8) & 0xFFu; }
+    TK_HD constexpr uint32_t n2() const { return (w0 >> 16) & 7u; }
+    TK_HD constexpr uint32_t two(uint32_t i) const { return (c2[i >> 1] >> (16u * (i & 1u))) & 0xFFFFu; }
+    // class mask of the suffix set
+    TK_HD constexpr uint32_t suffix_mask() const { return ((suffix() & 1u) ? TK_CB(TK_C_NL) : 0u) | ((suffix() & 2u) ? TK_CB(TK_C_SL) : 0u); }
+    TK_HD constexpr bool same_as(const TkPat& o) const { return ((w0 ^ o.w0) & ~32u) == 0u && c1 == o.c1 && c2[0] == o.c2[0] && c2[1] == o.c2[1]; }
+};
+#define TK_PAT_GENERIC 3  // kernel template argument: family and parameters are read from TkTables::pat at run time
+// the stock pattern of a family: 's 't 'm 'd, 'll 've 're; r50k: case-sensitive, \p{N}+, no suffix; cl100k / o200k: (?i), \p{N}{1,3}
+TK_HD constexpr TkPat tk_stock_pat(int fam) {
+    return TkPat{(uint32_t)fam | (fam != TK_PAT_R50K ? 4u : 0u) | (fam == TK_PAT_CL100K ? 8u : (fam == TK_PAT_O200K ? 24u : 0u)) |
+                     (fam != TK_PAT_O200K ? 64u : 0u) | (fam != TK_PAT_R50K ? 128u : 0u) | (fam != TK_PAT_R50K ? (3u << 8) : 0u) | (3u << 16),
+                 (1u << ('s' - 'a')) | (1u << ('t' - 'a')) | (1u << ('m' - 'a')) | (1u << ('d' - 'a')),
+                 {((uint32_t)'l' << 8 | 'l') | (((uint32_t)'v' << 8 | 'e') << 16), ((uint32_t)'r' << 8 | 'e')}};
+}
+
 // Device-resident view of one encoding's tables.
 struct TkTables {
     const uint8_t* uc_stage1;   // [0x1100]
@@ -103,7 +135,10 @@ struct TkTables {
     const uint32_t* spec_id;   // [n_spec]
     uint32_t n_spec;
     uint32_t spec_first[8];  // 256-bit set of first bytes
-    int pattern;
+    int pattern;             // family of the split pattern (TK_PAT_*)
+    TkPat pat;               // the pattern itself
+    uint16_t cert[16];       // certain piece starts: cert[a] = classes that always start a piece after a char of class a
+                             // (the family's table for the stock patterns; derived per pattern otherwise: tk_pattern.cpp)
 };
 
 TK_HD uint64_t tk_mix64(uint64_t x) {

@@ -121,33 +121,29 @@ TK_HD uint64_t tk_run_end(A& a, uint64_t s, uint32_t mask) {
     return s;
 }
 
-// byte length of a contraction whose apostrophe is at p, or 0 (case-insensitive forms fold
-// U+017F to 's', as Unicode simple case folding does in both regex engines)
+// byte length of a contraction whose apostrophe is at p, or 0.  The list comes with the pattern (TkPat); case-insensitive forms fold
+// U+017F to 's', as Unicode simple case folding does in both regex engines (no other char folds to a letter the parser admits).
 template <class A>
-TK_HD uint32_t tk_contraction_len(A& a, uint64_t p, bool ci) {
+TK_HD uint32_t tk_contraction_len(A& a, uint64_t p, TkPat pat) {
     if (tk_la(a, p + 1) == TK_C_END) return 0;
-    uint32_t b1 = a.byte(p + 1);
-    if (ci) {
-        if (b1 == 0xC5u) return (a.cls(p + 2) == TK_C_CONT && a.byte(p + 2) == 0xBFu) ? 3u : 0u;
-        uint32_t al = b1 | 0x20u;
-        if (b1 >= 0x80u || al < 'a' || al > 'z') return 0;
-        if (al == 's' || al == 'd' || al == 'm' || al == 't') return 2;
-        if (tk_la(a, p + 2) == TK_C_END) return 0;
-        uint32_t b2 = a.byte(p + 2), bl = b2 | 0x20u;
-        if (b2 >= 0x80u) return 0;
-        if ((al == 'l' && bl == 'l') || (al == 'v' && bl == 'e') || (al == 'r' && bl == 'e')) return 3;
-        return 0;
-    }
-    if (b1 == 's' || b1 == 'd' || b1 == 'm' || b1 == 't') return 2;
-    if (tk_la(a, p + 2) == TK_C_END) return 0;
-    uint32_t b2 = a.byte(p + 2);
-    if ((b1 == 'l' && b2 == 'l') || (b1 == 'v' && b2 == 'e') || (b1 == 'r' && b2 == 'e')) return 3;
+    const uint32_t b1 = a.byte(p + 1);
+    const bool ci = pat.ci();
+    if (ci && b1 == 0xC5u) return (((pat.c1 >> ('s' - 'a')) & 1u) && a.cls(p + 2) == TK_C_CONT && a.byte(p + 2) == 0xBFu) ? 3u : 0u;
+    const uint32_t al = ci ? (b1 | 0x20u) : b1;
+    if (b1 >= 0x80u || al < 'a' || al > 'z') return 0;
+    if ((pat.c1 >> (al - 'a')) & 1u) return 2;
+    if (!pat.n2() || tk_la(a, p + 2) == TK_C_END) return 0;
+    const uint32_t b2 = a.byte(p + 2), bl = ci ? (b2 | 0x20u) : b2;
+    if (b2 >= 0x80u) return 0;
+    const uint32_t key = (al << 8) | bl;
+    for (uint32_t i = 0; i < pat.n2(); ++i)
+        if (pat.two(i) == key) return 3;
     return 0;
 }
 
 // \s++$ | \s*[\r\n]+? | \s+(?!\S) | \s  -- p is a white-space char
 template <class A>
-TK_HD uint64_t tk_ws_tail(A& a, uint64_t p, int pat) {
+TK_HD uint64_t tk_ws_tail(A& a, uint64_t p, TkPat pat) {
     uint64_t q = p, last_start = p, after_last_nl = 0;
     uint32_t nchars = 0;
     bool has_nl = false;
@@ -164,8 +160,8 @@ TK_HD uint64_t tk_ws_tail(A& a, uint64_t p, int pat) {
         c = tk_la(a, q);
     }
     bool at_end = (c == TK_C_END);
-    if (pat != TK_PAT_O200K && at_end) return q;
-    if (pat != TK_PAT_R50K && has_nl) return after_last_nl;
+    if (pat.ws_dollar() && at_end) return q;
+    if (pat.nl_rule() && has_nl) return after_last_nl;
     if (at_end) return q;
     if (nchars >= 2) return last_start;
     return q;
@@ -174,7 +170,7 @@ TK_HD uint64_t tk_ws_tail(A& a, uint64_t p, int pat) {
 // o200k letter alternatives from s (s is the first letter-ish char; its flags were already
 // handled by the caller)
 template <class A>
-TK_HD uint64_t tk_o200k_word(A& a, uint64_t s, uint32_t c_first) {
+TK_HD uint64_t tk_o200k_word(A& a, uint64_t s, uint32_t c_first, TkPat pat) {
     uint64_t r_end = s, after_last_c = 0;
     bool has_c = false;
     uint32_t c = c_first;
@@ -200,14 +196,15 @@ TK_HD uint64_t tk_o200k_word(A& a, uint64_t s, uint32_t c_first) {
     } else {
         e = r_end;
     }
-    if (c == TK_C_AP) e += tk_contraction_len(a, e, true);
+    if (c == TK_C_AP) e += tk_contraction_len(a, e, pat);
     return e;
 }
 
+// \p{N}{1,k} from p (k = 0: \p{N}+)
 template <class A>
-TK_HD uint64_t tk_digits3(A& a, uint64_t p) {
+TK_HD uint64_t tk_digits(A& a, uint64_t p, uint32_t k) {
     uint64_t e = tk_next_char(a, p);
-    for (int i = 0; i < 2; ++i) {
+    for (uint32_t i = 1; k == 0u || i < k; ++i) {
         if (tk_la(a, e) != TK_C_NU) break;
         e = tk_next_char(a, e);
     }
@@ -216,14 +213,14 @@ TK_HD uint64_t tk_digits3(A& a, uint64_t p) {
 
 // End (exclusive) of the piece that starts at p.  p must be a true piece start.
 template <class A>
-TK_HD uint64_t tk_piece_end(A& a, uint64_t p, int pat) {
+TK_HD uint64_t tk_piece_end(A& a, uint64_t p, TkPat pat) {
     uint32_t c = a.cls(p) & 15u;
     uint64_t p1 = tk_next_char(a, p);
     if (c == TK_C_SPEC) return p1;  // a whole special token (its interior bytes are TK_C_CONT)
     uint32_t nxt = tk_la(a, p1);
-    if (pat == TK_PAT_R50K) {
+    if (pat.fam() == TK_PAT_R50K) {
         if (c == TK_C_AP) {
-            uint32_t k = tk_contraction_len(a, p, false);
+            uint32_t k = tk_contraction_len(a, p, pat);
             if (k) return p + k;
         }
         uint64_t s = p;
@@ -237,14 +234,14 @@ TK_HD uint64_t tk_piece_end(A& a, uint64_t p, int pat) {
         if ((TK_M_OTHER >> k) & 1u) return tk_run_end(a, tk_next_char(a, s), TK_M_OTHER);
         return tk_ws_tail(a, p, pat);
     }
-    if (pat == TK_PAT_CL100K) {
+    if (pat.fam() == TK_PAT_CL100K) {
         if (c == TK_C_AP) {
-            uint32_t k = tk_contraction_len(a, p, true);
+            uint32_t k = tk_contraction_len(a, p, pat);
             if (k) return p + k;
         }
         if (((TK_M_L >> c) & 1u) || (c != TK_C_NL && c != TK_C_NU && ((TK_M_L >> nxt) & 1u)))
             return tk_run_end(a, p1, TK_M_L);
-        if (c == TK_C_NU) return tk_digits3(a, p);
+        if (c == TK_C_NU) return tk_digits(a, p, pat.digits());
         uint64_t s = p;
         uint32_t k = c;
         if (c == TK_C_SP && nxt != TK_C_END) {
@@ -253,14 +250,14 @@ TK_HD uint64_t tk_piece_end(A& a, uint64_t p, int pat) {
         }
         if ((TK_M_OTHER >> k) & 1u) {
             uint64_t e = tk_run_end(a, tk_next_char(a, s), TK_M_OTHER);
-            return tk_run_end(a, e, TK_CB(TK_C_NL));
+            return tk_run_end(a, e, pat.suffix_mask());
         }
         return tk_ws_tail(a, p, pat);
     }
     // o200k
-    if ((TK_M_WORD >> c) & 1u) return tk_o200k_word(a, p, c);
-    if (c != TK_C_NL && c != TK_C_NU && ((TK_M_WORD >> nxt) & 1u)) return tk_o200k_word(a, p1, nxt);
-    if (c == TK_C_NU) return tk_digits3(a, p);
+    if ((TK_M_WORD >> c) & 1u) return tk_o200k_word(a, p, c, pat);
+    if (c != TK_C_NL && c != TK_C_NU && ((TK_M_WORD >> nxt) & 1u)) return tk_o200k_word(a, p1, nxt, pat);
+    if (c == TK_C_NU) return tk_digits(a, p, pat.digits());
     uint64_t s = p;
     uint32_t k = c;
     if (c == TK_C_SP && nxt != TK_C_END) {
@@ -269,7 +266,7 @@ TK_HD uint64_t tk_piece_end(A& a, uint64_t p, int pat) {
     }
     if ((TK_M_OTHER >> k) & 1u) {
         uint64_t e = tk_run_end(a, tk_next_char(a, s), TK_M_OTHER);
-        return tk_run_end(a, e, TK_CB(TK_C_NL) | TK_CB(TK_C_SL));
+        return tk_run_end(a, e, pat.suffix_mask());
     }
     return tk_ws_tail(a, p, pat);
 }
@@ -285,14 +282,14 @@ TK_HD uint64_t tk_piece_end(A& a, uint64_t p, int pat) {
 // ------------------------------------------------------------------------------------------
 #define TK_NO_POS 0xFFFFFFFFFFFFFFFFull
 template <class R>
-TK_HD uint64_t tk_ws_tail_runs(R& r, uint64_t p, int pat) {
+TK_HD uint64_t tk_ws_tail_runs(R& r, uint64_t p, TkPat pat) {
     const uint32_t c0 = r.cls(p) & 15u;
     if (!((TK_M_WS >> c0) & 1u)) return p;
     const uint64_t p1 = tk_next_char(r, p);
     const uint64_t q = r.run_end(p1, TK_M_WS);
     const bool at_end = tk_la(r, q) == TK_C_END;
-    if (pat != TK_PAT_O200K && at_end) return q;
-    if (pat != TK_PAT_R50K) {
+    if (pat.ws_dollar() && at_end) return q;
+    if (pat.nl_rule()) {
         const uint64_t nlp = r.last_in(p, q, TK_CB(TK_C_NL));
         if (nlp != TK_NO_POS) return nlp + 1;  // (\r and \n are single bytes)
     }
@@ -301,7 +298,7 @@ TK_HD uint64_t tk_ws_tail_runs(R& r, uint64_t p, int pat) {
     return q;
 }
 template <class R>
-TK_HD uint64_t tk_o200k_word_runs(R& r, uint64_t s, uint32_t c_first) {
+TK_HD uint64_t tk_o200k_word_runs(R& r, uint64_t s, uint32_t c_first, TkPat pat) {
     uint64_t r_end = s;
     if ((TK_M_UPPERISH >> c_first) & 1u) r_end = r.run_end(tk_next_char(r, s), TK_M_UPPERISH);
     uint32_t c = r_end == s ? c_first : tk_la(r, r_end);
@@ -322,27 +319,27 @@ TK_HD uint64_t tk_o200k_word_runs(R& r, uint64_t s, uint32_t c_first) {
             e = r_end;
         }
     }
-    if (c == TK_C_AP) e += tk_contraction_len(r, e, true);
+    if (c == TK_C_AP) e += tk_contraction_len(r, e, pat);
     return e;
 }
 template <class R>
-TK_HD uint64_t tk_piece_end_runs(R& r, uint64_t p, int pat) {
+TK_HD uint64_t tk_piece_end_runs(R& r, uint64_t p, TkPat pat) {
     const uint32_t c = r.cls(p) & 15u;
     const uint64_t p1 = tk_next_char(r, p);
     if (c == TK_C_SPEC) return p1;
     const uint32_t nxt = tk_la(r, p1);
-    if (pat == TK_PAT_O200K) {
-        if ((TK_M_WORD >> c) & 1u) return tk_o200k_word_runs(r, p, c);
-        if (c != TK_C_NL && c != TK_C_NU && ((TK_M_WORD >> nxt) & 1u)) return tk_o200k_word_runs(r, p1, nxt);
-        if (c == TK_C_NU) return tk_digits3(r, p);
+    if (pat.fam() == TK_PAT_O200K) {
+        if ((TK_M_WORD >> c) & 1u) return tk_o200k_word_runs(r, p, c, pat);
+        if (c != TK_C_NL && c != TK_C_NU && ((TK_M_WORD >> nxt) & 1u)) return tk_o200k_word_runs(r, p1, nxt, pat);
+        if (c == TK_C_NU) return tk_digits(r, p, pat.digits());
     } else {
         if (c == TK_C_AP) {
-            const uint32_t k = tk_contraction_len(r, p, pat == TK_PAT_CL100K);
+            const uint32_t k = tk_contraction_len(r, p, pat);
             if (k) return p + k;
         }
-        if (pat == TK_PAT_CL100K) {
+        if (pat.fam() == TK_PAT_CL100K) {
             if (((TK_M_L >> c) & 1u) || (c != TK_C_NL && c != TK_C_NU && ((TK_M_L >> nxt) & 1u))) return r.run_end(p1, TK_M_L);
-            if (c == TK_C_NU) return tk_digits3(r, p);
+            if (c == TK_C_NU) return tk_digits(r, p, pat.digits());
         }
     }
     uint64_t s = p;
@@ -351,13 +348,13 @@ TK_HD uint64_t tk_piece_end_runs(R& r, uint64_t p, int pat) {
         s = p1;
         k = nxt;
     }
-    if (pat == TK_PAT_R50K) {
+    if (pat.fam() == TK_PAT_R50K) {
         if ((TK_M_L >> k) & 1u) return r.run_end(tk_next_char(r, s), TK_M_L);
         if (k == TK_C_NU) return r.run_end(tk_next_char(r, s), TK_CB(TK_C_NU));
         if ((TK_M_OTHER >> k) & 1u) return r.run_end(tk_next_char(r, s), TK_M_OTHER);
     } else if ((TK_M_OTHER >> k) & 1u) {
         const uint64_t e = r.run_end(tk_next_char(r, s), TK_M_OTHER);
-        return r.run_end(e, pat == TK_PAT_O200K ? (TK_CB(TK_C_NL) | TK_CB(TK_C_SL)) : TK_CB(TK_C_NL));
+        return r.run_end(e, pat.suffix_mask());
     }
     return tk_ws_tail_runs(r, p, pat);
 }
@@ -454,30 +451,27 @@ TK_HD bool tk_bitx(uint64_t bits0, X& x, int kind, uint32_t k) {
 }
 
 template <class W, class A>
-TK_HD uint32_t tk_contraction_bits(const W& w, A& a, uint64_t p, uint32_t e, bool ci) {
+TK_HD uint32_t tk_contraction_bits(const W& w, A& a, uint64_t p, uint32_t e, TkPat pat) {
     if ((w.stop >> (e + 1)) & 1ull) return 0;
-    uint32_t b1 = a.byte(p + e + 1);
-    if (ci) {
-        if (b1 == 0xC5u) return (!((w.start >> (e + 2)) & 1ull) && !((w.stop >> (e + 2)) & 1ull) && a.byte(p + e + 2) == 0xBFu) ? 3u : 0u;
-        uint32_t al = b1 | 0x20u;
-        if (b1 >= 0x80u || al < 'a' || al > 'z') return 0;
-        if (al == 's' || al == 'd' || al == 'm' || al == 't') return 2;
-        if ((w.stop >> (e + 2)) & 1ull) return 0;
-        uint32_t b2 = a.byte(p + e + 2), bl = b2 | 0x20u;
-        if (b2 >= 0x80u) return 0;
-        if ((al == 'l' && bl == 'l') || (al == 'v' && bl == 'e') || (al == 'r' && bl == 'e')) return 3;
-        return 0;
-    }
-    if (b1 == 's' || b1 == 'd' || b1 == 'm' || b1 == 't') return 2;
-    if ((w.stop >> (e + 2)) & 1ull) return 0;
-    uint32_t b2 = a.byte(p + e + 2);
-    if ((b1 == 'l' && b2 == 'l') || (b1 == 'v' && b2 == 'e') || (b1 == 'r' && b2 == 'e')) return 3;
+    const uint32_t b1 = a.byte(p + e + 1);
+    const bool ci = pat.ci();
+    if (ci && b1 == 0xC5u)
+        return (((pat.c1 >> ('s' - 'a')) & 1u) && !((w.start >> (e + 2)) & 1ull) && !((w.stop >> (e + 2)) & 1ull) && a.byte(p + e + 2) == 0xBFu) ? 3u : 0u;
+    const uint32_t al = ci ? (b1 | 0x20u) : b1;
+    if (b1 >= 0x80u || al < 'a' || al > 'z') return 0;
+    if ((pat.c1 >> (al - 'a')) & 1u) return 2;
+    if (!pat.n2() || ((w.stop >> (e + 2)) & 1ull)) return 0;
+    const uint32_t b2 = a.byte(p + e + 2), bl = ci ? (b2 | 0x20u) : b2;
+    if (b2 >= 0x80u) return 0;
+    const uint32_t key = (al << 8) | bl;
+    for (uint32_t i = 0; i < pat.n2(); ++i)
+        if (pat.two(i) == key) return 3;
     return 0;
 }
 
 // c = class nibble of the char at p.  Returns the piece length, or 0 if unresolved.
 template <class W, class A, class X>
-TK_HD uint32_t tk_piece_len_bits(const W& w, A& a, X& x, uint64_t p, uint32_t c, int pat) {
+TK_HD uint32_t tk_piece_len_bits(const W& w, A& a, X& x, uint64_t p, uint32_t c, TkPat pat) {
     const uint64_t stop = w.stop;
     // length of the first char: next char start or stop after position 0
     const uint32_t k1 = 1u + tk_ctz64((w.start | stop) >> 1);
@@ -485,7 +479,7 @@ TK_HD uint32_t tk_piece_len_bits(const W& w, A& a, X& x, uint64_t p, uint32_t c,
     if (c == TK_C_SPEC) return 0;
     const bool nxt_end = (stop >> k1) & 1ull;
     uint32_t e = 0;
-    if (pat == TK_PAT_O200K) {
+    if (pat.fam() == TK_PAT_O200K) {
         const uint64_t word = w.get(TKB_UP) | w.get(TKB_LOW);
         uint32_t ks = 64;
         if ((TK_M_WORD >> c) & 1u) ks = 0;
@@ -507,17 +501,17 @@ TK_HD uint32_t tk_piece_len_bits(const W& w, A& a, X& x, uint64_t p, uint32_t c,
                 e = lc >= 0 ? (uint32_t)lc + 1u : re;
             }
             if (e <= TK_WIN_SAFE) {
-                if (!((stop >> e) & 1ull) && a.byte(p + e) == '\'') e += tk_contraction_bits(w, a, p, e, true);
+                if (!((stop >> e) & 1ull) && a.byte(p + e) == '\'') e += tk_contraction_bits(w, a, p, e, pat);
             } else if (e + 4u <= x.limit()) {
-                if (!tk_bitx(w.stop, x, TKB_HARD, e) && a.byte(p + e) == '\'') e += tk_contraction_len(a, p + e, true);
+                if (!tk_bitx(w.stop, x, TKB_HARD, e) && a.byte(p + e) == '\'') e += tk_contraction_len(a, p + e, pat);
             } else {
                 return 0;
             }
             return e;
         }
-    } else if (pat == TK_PAT_CL100K) {
+    } else if (pat.fam() == TK_PAT_CL100K) {
         if (c == TK_C_AP) {
-            uint32_t k = tk_contraction_bits(w, a, p, 0, true);
+            uint32_t k = tk_contraction_bits(w, a, p, 0, pat);
             if (k) return k;
         }
         if ((TK_M_L >> c) & 1u) {
@@ -530,16 +524,17 @@ TK_HD uint32_t tk_piece_len_bits(const W& w, A& a, X& x, uint64_t p, uint32_t c,
         }
     } else {
         if (c == TK_C_AP) {
-            uint32_t k = tk_contraction_bits(w, a, p, 0, false);
+            uint32_t k = tk_contraction_bits(w, a, p, 0, pat);
             if (k) return k;
         }
     }
-    if (pat != TK_PAT_R50K && c == TK_C_NU) {
+    if (pat.fam() != TK_PAT_R50K && c == TK_C_NU) {
         uint32_t r = tk_run(w.get(TKB_NU), stop, 0);
-        uint64_t sx = w.start & tk_below(r);
-        sx &= sx - 1;
-        sx &= sx - 1;
-        sx &= sx - 1;
+        uint64_t sx = pat.digits() ? (w.start & tk_below(r)) : 0ull;  // start bits of the run's chars: the (k+1)-th one ends the group
+        for (uint32_t i = 0; i < pat.digits(); ++i) {
+            if (pat.generic() && !sx) break;
+            sx &= sx - 1;
+        }
         e = sx ? tk_ctz64(sx) : r;
         return e > TK_WIN_SAFE ? 0 : e;
     }
@@ -547,7 +542,7 @@ TK_HD uint32_t tk_piece_len_bits(const W& w, A& a, X& x, uint64_t p, uint32_t c,
     uint32_t s = 0;
     bool s_ok = true;
     if (c == TK_C_SP && !nxt_end) s = k1;
-    if (pat == TK_PAT_R50K) {
+    if (pat.fam() == TK_PAT_R50K) {
         int kind = -1;
         uint64_t b0 = 0;
         if ((w.get(TKB_L) >> s) & 1ull) { kind = TKB_L; b0 = w.get(TKB_L); }
@@ -562,7 +557,8 @@ TK_HD uint32_t tk_piece_len_bits(const W& w, A& a, X& x, uint64_t p, uint32_t c,
         uint32_t r = tk_runx(w.get(TKB_OTH), stop, x, TKB_OTH, s);
         if (r == TK_UNRES) return 0;
         const uint32_t e1 = s + r;
-        uint32_t r2 = pat == TK_PAT_O200K ? tk_runx(w.get(TKB_NLSL), stop, x, TKB_NLSL, e1) : tk_runx(w.get(TKB_NL), stop, x, TKB_NL, e1);
+        // (the suffix set behind the run: its own bitmap for o200k and for generic patterns, the newline bitmap for cl100k)
+        uint32_t r2 = (pat.fam() == TK_PAT_O200K || pat.generic()) ? tk_runx(w.get(TKB_NLSL), stop, x, TKB_NLSL, e1) : tk_runx(w.get(TKB_NL), stop, x, TKB_NL, e1);
         return r2 == TK_UNRES ? 0 : e1 + r2;
     } else {
         s_ok = false;
@@ -576,16 +572,16 @@ TK_HD uint32_t tk_piece_len_bits(const W& w, A& a, X& x, uint64_t p, uint32_t c,
             uint64_t rng = tk_below(q);
             bool at_end = (stop >> q) & 1ull;
             uint64_t nlr = w.get(TKB_NL) & rng, st = w.start & rng;
-            if (pat != TK_PAT_O200K && at_end) return q;
-            if (pat != TK_PAT_R50K && nlr) return 64u - tk_clz64(nlr);
+            if (pat.ws_dollar() && at_end) return q;
+            if (pat.nl_rule() && nlr) return 64u - tk_clz64(nlr);
             if (at_end) return q;
             if (tk_popc64(st) >= 2u) return 63u - tk_clz64(st);
             return q;
         }
         if (q + 1u > x.limit()) return 0;
         const bool at_end = tk_bitx(w.stop, x, TKB_HARD, q);
-        if (pat != TK_PAT_O200K && at_end) return q;
-        if (pat != TK_PAT_R50K) {
+        if (pat.ws_dollar() && at_end) return q;
+        if (pat.nl_rule()) {
             int ln = tk_last_setx(w.get(TKB_NL), x, TKB_NL, 0, q);
             if (ln >= 0) return (uint32_t)ln + 1u;
         }
@@ -617,13 +613,13 @@ TK_HD uint32_t tk_run32(uint32_t bits, uint32_t stop, uint32_t from) {          
 }
 
 template <class W32, class A>
-TK_HD uint32_t tk_piece_len_bits32(const W32& w, A& a, uint64_t p, uint32_t c, int pat) {
+TK_HD uint32_t tk_piece_len_bits32(const W32& w, A& a, uint64_t p, uint32_t c, TkPat pat) {
     const uint32_t stop = w.stop;
     const uint32_t k1 = 1u + tk_w32_ctz((w.start | stop) >> 1);
     if (k1 > 4u || c == TK_C_SPEC) return 0;
     const bool nxt_end = (stop >> k1) & 1u;
     uint32_t e = 0;
-    if (pat == TK_PAT_O200K) {
+    if (pat.fam() == TK_PAT_O200K) {
         uint32_t ks = 64;
         if ((TK_M_WORD >> c) & 1u) ks = 0;
         else if (c != TK_C_NL && c != TK_C_NU && !nxt_end && (((w.get(TKB_UP) | w.get(TKB_LOW)) >> k1) & 1u)) ks = k1;
@@ -638,12 +634,12 @@ TK_HD uint32_t tk_piece_len_bits32(const W32& w, A& a, uint64_t p, uint32_t c, i
                 const uint32_t xx = w.get(TKB_CAS) & ~stop & tk_below32(re) & ~tk_below32(ks);
                 e = xx ? 32u - tk_w32_clz(xx) : re;
             }
-            if (!((stop >> e) & 1u) && a.byte(p + e) == '\'') e += tk_contraction_bits(w, a, p, e, true);
+            if (!((stop >> e) & 1u) && a.byte(p + e) == '\'') e += tk_contraction_bits(w, a, p, e, pat);
             return e;
         }
-    } else if (pat == TK_PAT_CL100K) {
+    } else if (pat.fam() == TK_PAT_CL100K) {
         if (c == TK_C_AP) {
-            const uint32_t k = tk_contraction_bits(w, a, p, 0, true);
+            const uint32_t k = tk_contraction_bits(w, a, p, 0, pat);
             if (k) return k;
         }
         if ((TK_M_L >> c) & 1u) {
@@ -656,23 +652,24 @@ TK_HD uint32_t tk_piece_len_bits32(const W32& w, A& a, uint64_t p, uint32_t c, i
         }
     } else {
         if (c == TK_C_AP) {
-            const uint32_t k = tk_contraction_bits(w, a, p, 0, false);
+            const uint32_t k = tk_contraction_bits(w, a, p, 0, pat);
             if (k) return k;
         }
     }
-    if (pat != TK_PAT_R50K && c == TK_C_NU) {
+    if (pat.fam() != TK_PAT_R50K && c == TK_C_NU) {
         const uint32_t r = tk_run32(w.get(TKB_NU), stop, 0);
-        uint32_t sx = w.start & tk_below32(r);
-        sx &= sx - 1;
-        sx &= sx - 1;
-        sx &= sx - 1;
+        uint32_t sx = pat.digits() ? (w.start & tk_below32(r)) : 0u;
+        for (uint32_t i = 0; i < pat.digits(); ++i) {
+            if (pat.generic() && !sx) break;
+            sx &= sx - 1;
+        }
         e = sx ? tk_w32_ctz(sx) : r;
         return e > TK_WIN32_SAFE ? 0 : e;
     }
     // optional single space, then a run of one kind (r50k: letters / digits / other; others: other only)
     uint32_t s = 0;
     if (c == TK_C_SP && !nxt_end) s = k1;
-    if (pat == TK_PAT_R50K) {
+    if (pat.fam() == TK_PAT_R50K) {
         int kind = -1;
         if ((w.get(TKB_L) >> s) & 1u) kind = TKB_L;
         else if ((w.get(TKB_NU) >> s) & 1u) kind = TKB_NU;
@@ -684,7 +681,7 @@ TK_HD uint32_t tk_piece_len_bits32(const W32& w, A& a, uint64_t p, uint32_t c, i
     } else if ((w.get(TKB_OTH) >> s) & 1u) {
         const uint32_t e1 = s + tk_run32(w.get(TKB_OTH), stop, s);
         if (e1 > TK_WIN32_SAFE) return 0;
-        const uint32_t e2 = e1 + tk_run32(pat == TK_PAT_O200K ? w.get(TKB_NLSL) : w.get(TKB_NL), stop, e1);
+        const uint32_t e2 = e1 + tk_run32((pat.fam() == TK_PAT_O200K || pat.generic()) ? w.get(TKB_NLSL) : w.get(TKB_NL), stop, e1);
         return e2 > TK_WIN32_SAFE ? 0 : e2;
     }
     // white space
@@ -693,8 +690,8 @@ TK_HD uint32_t tk_piece_len_bits32(const W32& w, A& a, uint64_t p, uint32_t c, i
     const uint32_t rng = tk_below32(q);
     const bool at_end = (stop >> q) & 1u;
     const uint32_t nlr = w.get(TKB_NL) & rng, st = w.start & rng;
-    if (pat != TK_PAT_O200K && at_end) return q;
-    if (pat != TK_PAT_R50K && nlr) return 32u - tk_w32_clz(nlr);
+    if (pat.ws_dollar() && at_end) return q;
+    if (pat.nl_rule() && nlr) return 32u - tk_w32_clz(nlr);
     if (at_end) return q;
     if (tk_w32_popc(st) >= 2u) return 31u - tk_w32_clz(st);
     return q;

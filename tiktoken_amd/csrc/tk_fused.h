@@ -82,7 +82,7 @@ struct TkCoop {
     const uint32_t* btab;  // LDS: byte table
     uint32_t* red;         // LDS [8]
     uint8_t* lastc;        // LDS [256]
-    int pat;
+    TkPat pat;
 };
 
 // masks of the 16 text bytes at g (a multiple of 16, may be negative or beyond the text)
@@ -240,7 +240,8 @@ __device__ __noinline__ uint64_t tk_coop_certain_before(const TkCoop* Cp, uint64
         __syncthreads();
         if (cref == 16) cref = C.red[4];
         const uint32_t prevc = threadIdx.x ? (uint32_t)C.lastc[threadIdx.x - 1] : 0u;
-        uint32_t cert = tk_chunk_certain(C.pat, st, mk.text, mk.hard & mk.text, prevc);
+        uint32_t cert = C.pat.generic() ? tk_chunk_certain_rt(C.T->cert, st, mk.text, mk.hard & mk.text, prevc)
+                                        : tk_chunk_certain(C.pat.fam(), st, mk.text, mk.hard & mk.text, prevc);
         uint32_t oth = ~tk_member16(mk.p, 1u << cref) & 0xFFFFu;  // bytes of another class
         if (g > (int64_t)pos) cert = oth = 0;
         else if (g + 16 > (int64_t)pos + 1) {
@@ -309,7 +310,8 @@ __device__ __noinline__ uint64_t tk_coop_skip_digit_groups(const TkCoop* Cp, uin
         }
     }
     const uint64_t lim = r2 < target ? r2 : target;
-    return lim > p ? p + 3 * ((lim - p) / 3) : p;
+    const uint64_t k = C.pat.digits();  // (the caller asks only for patterns with bounded digit groups)
+    return lim > p ? p + k * ((lim - p) / k) : p;
 }
 
 // 8 bytes of the LDS text copy starting at byte offset o (three aligned dword reads)
@@ -390,7 +392,10 @@ __global__ __launch_bounds__(256, SLOW ? 3 : 8) void tk_k_front(TkTables T, cons
                                                   const uint32_t* __restrict__ brk, const uint32_t* __restrict__ docb,
                                                   const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, TkFrontOut out,
                                                   TkMissSlot* __restrict__ mt, uint32_t mt_mask, uint32_t* __restrict__ deferred, int dbg) {
-    constexpr int pat = PAT;
+    // the pattern: a compile-time constant for the three stock patterns; PAT = TK_PAT_GENERIC reads family and parameters from the tables
+    constexpr bool GEN = PAT == TK_PAT_GENERIC;
+    const TkPat pat = GEN ? T.pat : tk_stock_pat(PAT);
+    const int fam = GEN ? T.pat.fam() : PAT;
     constexpr int NW = TK2_NSEG + 2;            // 64-bit words per bitmap (two sentinel words beyond the window)
     constexpr int BM_BYTES = TKB_KINDS * NW * 8;
     __shared__ __attribute__((aligned(16))) uint8_t raw[TK2_WIN + 16];
@@ -514,7 +519,7 @@ __global__ __launch_bounds__(256, SLOW ? 3 : 8) void tk_k_front(TkTables T, cons
     TkSets st;
     tk_sets_from_planes(mk.p[0], mk.p[1], mk.p[2], mk.p[3], st);
     {
-        constexpr bool O2 = PAT == TK_PAT_O200K, R5 = PAT == TK_PAT_R50K;
+        const bool O2 = fam == TK_PAT_O200K, R5 = fam == TK_PAT_R50K;  // (constants unless GEN)
         uint16_t* b16 = (uint16_t*)pool;  // halfword tid of bitmap `kind` = positions [16 tid, 16 tid + 16)
         constexpr int HW = NW * 4;         // halfwords per bitmap
         b16[TKB_START * HW + tid] = (uint16_t)mk.start;
@@ -522,14 +527,15 @@ __global__ __launch_bounds__(256, SLOW ? 3 : 8) void tk_k_front(TkTables T, cons
         b16[TKB_OTH * HW + tid] = (uint16_t)st.oth;
         b16[TKB_WS * HW + tid] = (uint16_t)st.ws;
         b16[TKB_NU * HW + tid] = (uint16_t)st.nu;
-        if constexpr (!O2) b16[TKB_L * HW + tid] = (uint16_t)st.l;
-        if constexpr (O2) {
+        if (!O2 || GEN) b16[TKB_L * HW + tid] = (uint16_t)st.l;
+        if (O2 || GEN) {
             b16[TKB_UP * HW + tid] = (uint16_t)st.up;
             b16[TKB_LOW * HW + tid] = (uint16_t)st.low;
             b16[TKB_CAS * HW + tid] = (uint16_t)st.cas;
-            b16[TKB_NLSL * HW + tid] = (uint16_t)st.nlsl;
+            // (generic patterns: the suffix set behind a run of "other" chars, whatever the family)
+            b16[TKB_NLSL * HW + tid] = (uint16_t)(GEN ? (((pat.suffix() & 1u) ? st.nl : 0u) | ((pat.suffix() & 2u) ? st.sl : 0u)) : st.nlsl);
         }
-        if constexpr (!R5) b16[TKB_NL * HW + tid] = (uint16_t)st.nl;
+        if (!R5 || GEN) b16[TKB_NL * HW + tid] = (uint16_t)st.nl;
         uint16_t* p16 = (uint16_t*)planes;
 #pragma unroll
         for (int p = 0; p < 4; ++p) p16[p * HW + tid] = (uint16_t)mk.p[p];
@@ -538,7 +544,7 @@ __global__ __launch_bounds__(256, SLOW ? 3 : 8) void tk_k_front(TkTables T, cons
     __syncthreads();
     // the class before the chunk: never known for the first chunk of the window (nothing there is certain unless hard)
     const uint32_t prevc = tid ? (uint32_t)lastc[tid - 1] : 0u;
-    const uint32_t cert = tk_chunk_certain(PAT, st, mk.text, mk.hard & mk.text, prevc);
+    const uint32_t cert = GEN ? tk_chunk_certain_rt(T.cert, st, mk.text, mk.hard & mk.text, prevc) : tk_chunk_certain(fam, st, mk.text, mk.hard & mk.text, prevc);
     ((uint16_t*)certw)[tid] = (uint16_t)cert;
     constexpr uint32_t T0 = TK2_LEFT / 16, T1 = (TK2_LEFT + TK_TILE) / 16;  // chunks [T0, T1) are the tile
     const bool in_tile = tid >= T0 && tid < T1;
@@ -605,7 +611,7 @@ __global__ __launch_bounds__(256, SLOW ? 3 : 8) void tk_k_front(TkTables T, cons
     // ---- D: one lane per scan start; only boundaries inside the tile are recorded
     const uint32_t* planes32 = (const uint32_t*)planes;
     TkWin2Acc acc{planes32, (const uint32_t*)bm[TKB_START], (const uint32_t*)bm[TKB_HARD], raw, base, n, false};
-    const TkCoop coop{&T, text, n, brk, SPEC ? ss : nullptr, SPEC ? si : nullptr, btab, scan_sh, lastc, PAT};  // (used when SLOW)
+    const TkCoop coop{&T, text, n, brk, SPEC ? ss : nullptr, SPEC ? si : nullptr, btab, scan_sh, lastc, pat};  // (used when SLOW)
     // what the end e of the piece that starts at p means for this tile: TKF_CHAIN_END when the chain ends here (the piece reaches the tile
     // end -- its end is remembered for the probe -- or e is a certain start, which has its own scanner), else e: the scan goes on from
     // there (an uncertain boundary, recorded when it lies inside the tile)
@@ -664,7 +670,7 @@ __global__ __launch_bounds__(256, SLOW ? 3 : 8) void tk_k_front(TkTables T, cons
         if constexpr (SLOW) {
             for (;;) {
                 uint64_t e = p;
-                if (PAT != TK_PAT_R50K && p < tile_start && (tk_class_byte_slow(&T, text, p, n, brk, coop.ss, coop.si) & 15u) == TK_C_NU)
+                if (fam != TK_PAT_R50K && pat.digits() && p < tile_start && (tk_class_byte_slow(&T, text, p, n, brk, coop.ss, coop.si) & 15u) == TK_C_NU)
                     e = tk_coop_skip_digit_groups(&coop, p, tile_start);  // whole three-digit groups left of the tile
                 if (e == p) e = tk_coop_piece_end(&coop, p);
                 const uint64_t nx = chain_step(p, e);  // (all threads compute the same; the bit and last_end updates are idempotent)
@@ -713,7 +719,7 @@ __global__ __launch_bounds__(256, SLOW ? 3 : 8) void tk_k_front(TkTables T, cons
             // reaches beyond the window: there is no piece start in this tile.  Only the tile in which the run ends evaluates the piece.
             TkCoopAcc ca{coop};
             const bool stretch_uniform = other == TK_NO_POS || other < tk_next_char(ca, p0);
-            const bool class_ok = crun >= (uint32_t)TK_C_NL && crun <= (uint32_t)TK_C_OT && (crun != TK_C_NU || PAT == TK_PAT_R50K);
+            const bool class_ok = crun >= (uint32_t)TK_C_NL && crun <= (uint32_t)TK_C_OT && (crun != TK_C_NU || fam == TK_PAT_R50K || pat.digits() == 0u);
             const uint32_t here = tid >= T0 ? (uint32_t)((tk_member16(mk.p, 1u << (crun & 15u)) == 0xFFFFu) & (mk.hard == 0u)) : 1u;
             const bool covered = stretch_uniform && class_ok && __syncthreads_and((int)here);
             if (!covered) coop_chain(p0);
@@ -1987,7 +1993,7 @@ __global__ __launch_bounds__(256) void tk_k_small(TkTables T, const uint8_t* __r
     __shared__ uint32_t idb[TK_SMALL_PIECE * 256], rkb[TK_SMALL_PIECE * 256];
     __shared__ uint32_t np_sh, bail_sh, scan_sh[8];
     const uint32_t tid = threadIdx.x;
-    const int pat = T.pattern;
+    const TkPat pat = T.pat;
     for (uint32_t i = tid * 4u; i < TK_SMALL_MAX + 16u; i += 1024u) *(uint32_t*)(raw + i) = i < n ? *(const uint32_t*)(text + i) : 0u;  // (input buffer is padded)
     if (tid == 0) bail_sh = 0;
     __syncthreads();

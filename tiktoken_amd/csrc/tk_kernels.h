@@ -288,7 +288,7 @@ struct TkBmExt {  // extension windows for runs longer than the first 64-bit win
     __device__ __forceinline__ uint32_t limit() const { return lim; }
 };
 
-__device__ __forceinline__ uint64_t tk_piece_end_slow(TkWin2Acc* acc, uint64_t p, int pat) {
+__device__ __forceinline__ uint64_t tk_piece_end_slow(TkWin2Acc* acc, uint64_t p, TkPat pat) {
     uint64_t e = tk_piece_end(*acc, p, pat);
     if (e <= p) e = tk_next_char(*acc, p);
     return e;

@@ -6,23 +6,9 @@
 #include <numeric>
 #include <thread>
 
-static const char* const PAT_R50K =
-    R"('(?:[sdmt]|ll|ve|re)| ?\p{L}++| ?\p{N}++| ?[^\s\p{L}\p{N}]++|\s++$|\s+(?!\S)|\s)";
-static const char* const PAT_GPT2_ORIG =
-    R"('s|'t|'re|'ve|'m|'ll|'d| ?[\p{L}]+| ?[\p{N}]+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+)";
-static const char* const PAT_CL100K =
-    R"('(?i:[sdmt]|ll|ve|re)|[^\r\n\p{L}\p{N}]?+\p{L}++|\p{N}{1,3}+| ?[^\s\p{L}\p{N}]++[\r\n]*+|\s++$|\s*[\r\n]|\s+(?!\S)|\s)";
-static const char* const PAT_O200K =
-    R"([^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]*[\p{Ll}\p{Lm}\p{Lo}\p{M}]+(?i:'s|'t|'re|'ve|'m|'ll|'d)?|)"
-    R"([^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]+[\p{Ll}\p{Lm}\p{Lo}\p{M}]*(?i:'s|'t|'re|'ve|'m|'ll|'d)?|)"
-    R"(\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n/]*|\s*[\r\n]+|\s+(?!\S)|\s+)";
-
 int tk_pattern_id(const char* pat_str) {
-    if (!pat_str) return -1;
-    if (!strcmp(pat_str, PAT_R50K) || !strcmp(pat_str, PAT_GPT2_ORIG)) return TK_PAT_R50K;
-    if (!strcmp(pat_str, PAT_CL100K)) return TK_PAT_CL100K;
-    if (!strcmp(pat_str, PAT_O200K)) return TK_PAT_O200K;
-    return -1;
+    TkPat p;
+    return tk_parse_pattern(pat_str, &p).empty() ? p.fam() : -1;
 }
 
 uint64_t tk_key_of_bytes(const uint8_t* p, uint32_t len) {
@@ -110,11 +96,11 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
                             uint64_t n_ranks, const uint8_t* spec_blob, const uint64_t* spec_off,
                             const uint32_t* spec_ids, uint64_t n_spec, const char* pat_str, TkHostTables* out) {
     TkHostTables& T = *out;
-    T.pattern = tk_pattern_id(pat_str);
-    if (T.pattern < 0)
-        return std::string("unsupported pat_str: this build carries hand-compiled scanners for the stock patterns of "
-                           "tiktoken_ext/openai_public.py (r50k/gpt2, cl100k, o200k) only; got: ") +
-               (pat_str ? pat_str : "(null)");
+    {
+        const std::string perr = tk_parse_pattern(pat_str, &T.pat, T.cert);
+        if (!perr.empty()) return perr;
+        T.pattern = T.pat.fam();
+    }
     if (n_ranks == 0) return "mergeable_ranks is empty";
     if (ranks_off[n_ranks] >= 0xFFFFFFFFull) return "vocabulary byte blob too large";
     T.n_ranks = n_ranks;

@@ -10,7 +10,9 @@
 #include "tk_common.h"
 
 struct TkHostTables {
-    int pattern = -1;
+    int pattern = -1;  // family of the split pattern
+    TkPat pat{};       // the pattern (tk_pattern.cpp)
+    uint16_t cert[16] = {0};  // its certain piece starts
     std::vector<uint8_t> tok_bytes;
     std::vector<TkShortSlot> short_tab;  // tokens of 1..4 bytes (empty when a rank exceeds TK_SHORT_MAX_RANK)
     uint32_t short_mask = 0, short_shift = 0;
@@ -49,8 +51,13 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
                             uint64_t n_ranks, const uint8_t* spec_blob, const uint64_t* spec_off,
                             const uint32_t* spec_ids, uint64_t n_spec, const char* pat_str, TkHostTables* out);
 
-// pattern id for a pat_str, or -1 (exported through the C ABI, include/tiktoken_amd.h)
+// family of a pat_str (TK_PAT_*), or -1 when the library has no scanner for it (exported through the C ABI, include/tiktoken_amd.h)
 extern "C" int tk_pattern_id(const char* pat_str);
+// pat_str -> TkPat (tk_pattern.cpp): "" or the reason why the pattern is not supported
+// cert_out (may be null): the table of certain piece starts, [16] class masks -- the family's for a stock pattern, else the family's
+// minus every pair for which a counter-example exists among all short strings over class representatives and random longer ones
+std::string tk_parse_pattern(const char* pat_str, TkPat* out, uint16_t* cert_out = nullptr);
+void tk_derive_certain(const TkPat& pat, uint16_t* cert);
 
 // `.tiktoken` text -> packed token bytes + offsets + ranks (reference tiktoken/load.py:159-171).  "" or an error message.
 std::string tk_parse_tiktoken(const uint8_t* text, uint64_t len, std::vector<uint8_t>* blob, std::vector<uint64_t>* off,
