@@ -39,7 +39,9 @@ int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uint32
               const char* pat_str, int device, tk_core** out);
 void tk_destroy(tk_core* core);
 
-/* Pattern id (0 r50k/gpt2, 1 cl100k, 2 o200k) for a pat_str, or -1 if it is not a stock pattern. */
+/* Family (0 r50k/gpt2, 1 cl100k, 2 o200k) of a pat_str the library has scanners for -- the stock patterns, their other spellings,
+ * and variations of the contraction list, digit group, suffix set and white-space rules (tk_pattern.cpp) -- or -1.  Reference: the
+ * regex compiled once per Encoding, src/lib.rs:623. */
 int tk_pattern_id(const char* pat_str);
 
 /* Encoding.encode_ordinary_batch / encode_batch                        tiktoken/core.py:164-206
