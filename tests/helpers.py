@@ -191,6 +191,7 @@ def sim_lib():
         L.tks_pretok_tiles.restype = u64
         L.tks_pretok_tiles.argtypes = [vp, vp, u64, vp, u64, vp, ctypes.c_uint32, ctypes.c_uint32]
         L.tks_runs_mismatches.restype = u64
+        L.tks_never_violations.restype = u64
         L.tks_table_stats.argtypes = [vp, vp, vp]
         L.tks_lookup.restype = ctypes.c_uint32
         L.tks_lookup.argtypes = [vp, vp, ctypes.c_uint32]

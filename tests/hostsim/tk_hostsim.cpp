@@ -43,13 +43,15 @@ struct FlatAcc {
     }
 };
 
-static uint64_t g_runs_mismatch = 0;
+static uint64_t g_runs_mismatch = 0, g_never_viol = 0;
 
 // certain piece starts from the table that travels with the pattern (TkTables::cert: the family's static table for stock patterns)
 static inline bool tk_certain_rt(const uint16_t* cert, uint32_t a, uint32_t b) { return (cert[a & 15u] >> b) & 1u; }
 
 extern "C" {
 uint64_t tks_runs_mismatches() { return g_runs_mismatch; }
+// piece starts found at a class pair that tk_never_mask calls impossible (stock patterns)
+uint64_t tks_never_violations() { return g_never_viol; }
 
 void* tks_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uint32_t* ranks_ids, uint64_t n_ranks,
                  const uint8_t* spec_blob, const uint64_t* spec_off, const uint32_t* spec_ids, uint64_t n_spec,
@@ -159,6 +161,14 @@ uint64_t tks_pretok(void* p, const uint8_t* text_in, uint64_t n, const uint64_t*
             q = e;
         }
     }
+    if (!patx.generic())  // every piece start against the table of impossible boundaries
+        for (uint64_t i = 1; i < n; ++i) {
+            if (!starts[i] || (cls[i] & TK_F_HARD)) continue;
+            uint64_t j = i - 1;
+            while (j > 0 && cls[j] == TK_C_CONT) --j;
+            const bool near = (i >= 2 && text[i - 2] == '\'') || (i >= 3 && text[i - 3] == '\'');
+            if (!near && ((tk_never_mask(pat, cls[j] & 15u) >> (cls[i] & 15u)) & 1u)) ++g_never_viol;
+        }
     return n_certain;
 }
 
@@ -511,9 +521,28 @@ uint64_t tks_chunk_check(void* pv, const uint8_t* text_in, uint64_t n, const uin
             int first = 0;
             if (t == 0)
                 while (first < 16 && gp + first >= 0 && (uint64_t)(gp + first) < n && !((m.start >> first) & 1u)) ++first;
+            uint32_t nev = 0;
+            if (!T.pat.generic()) {
+                uint32_t ap_before = t ? 0u : 7u;  // (the first chunk of a window cannot see what stands before it: as if apostrophes did)
+                for (int b = 1; b <= 3; ++b)
+                    if (t > 0 && raw[(int64_t)t * 16 - b] == '\'') ap_before |= 1u << (3 - b);
+                nev = tk_chunk_never(pat, sets[t], prevc, ap_before);
+            }
             for (int j = 0; j < 16; ++j) {
                 const int64_t g = gp + j;
                 if (g < 0 || (t == 0 && j < first)) continue;
+                if (!T.pat.generic() && (uint64_t)g < n && !(t == 0 && j <= first)) {  // the set-algebra form against the table
+                    bool want = false;
+                    if ((m.start >> j) & 1u) {
+                        int64_t q = g - 1;
+                        while (q > 0 && (ref[q] & 0x40u)) --q;
+                        want = q >= 0 && ((tk_never_mask(pat, ref[q] & 15u) >> (ref[g] & 15u)) & 1u);
+                    }
+                    const bool near = (g >= 2 && text_in[g - 2] == '\'') || (g >= 3 && text_in[g - 3] == '\'');
+                    const bool got = (nev >> j) & 1u & ((m.start >> j) & 1u);
+                    // claiming "never" where the table does not is an error; the other way round only without an apostrophe nearby
+                    if ((got && (!want || near)) || (!got && want && !near && (t > 0 || j > 2))) report((uint64_t)g, 6);
+                }
                 const uint32_t cls = tk_class_from_planes(m.p, (uint32_t)j);
                 const bool start = (m.start >> j) & 1u, hard = (m.hard >> j) & 1u;
                 if ((uint64_t)g >= n) {  // past the end: END, a char start, hard

@@ -236,6 +236,7 @@ def test_run_query_scanner_equals_the_byte_walking_one():
     tk_piece_end at every piece start of corpora and adversarial documents, all three patterns."""
     rng = np.random.default_rng(11)
     before = h.sim_lib().tks_runs_mismatches()
+    never_before = h.sim_lib().tks_never_violations()
     for name in h.ENCODING_NAMES:
         sim = h.HostSim(h.PAT_STR[h.PATTERN_OF[name]], h.load_vocab(name), h.SPECIALS[name])
         for mix in (0, 1):
@@ -245,4 +246,9 @@ def test_run_query_scanner_equals_the_byte_walking_one():
         sim.piece_ends(*h.pack(docs))
         for rep in ("x", " ", "中", "1", "\n", "!", "a\u0301", "Aa", " \n"):
             sim.piece_ends(*h.pack([(rep * 700).encode(), ("z" + rep * 300 + "'ll").encode()]))
+        # the table of impossible boundaries (tk_never_mask: the front kernel skips the scanner on its word) on contraction-heavy text
+        apo = list("abdelmrstvxABDELMRSTVX") + ["'"] * 8 + [" ", " ", "\n", "1", "!", "/", "\u017f", "\u0301", "\u4e2d", "\t", "\u01c5"]
+        docs = ["".join(rng.choice(apo, size=int(rng.integers(0, 30)))).encode() for _ in range(20000)]
+        sim.piece_ends(*h.pack(docs))
     assert h.sim_lib().tks_runs_mismatches() == before
+    assert h.sim_lib().tks_never_violations() == never_before

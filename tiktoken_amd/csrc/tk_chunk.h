@@ -205,6 +205,38 @@ TK_HD uint32_t tk_chunk_certain(int pat, const TkSets& s, uint32_t start, uint32
     return cert & start;  // (pass the char starts of REAL text: positions past the end are hard but never pieces)
 }
 
+// Char starts of the chunk at which NO piece of the stock pattern `pat` can start: the class pair (previous char, this char) is in
+// tk_never_mask (tk_device.h) and no apostrophe stands two or three bytes before (ap_before: bits 0..2 = apostrophe at byte -3, -2, -1
+// before the chunk).  The rows are written out as set algebra; the unit tests check them against the table.
+TK_HD uint32_t tk_chunk_never(int pat, const TkSets& s, uint32_t prevc, uint32_t ap_before) {
+    const uint32_t L3 = TK_M_L, O4 = TK_M_OTHER;
+    uint32_t nev = 0;
+    if (pat == TK_PAT_R50K) {
+        nev |= tk_prev_set(s.sp, TK_CB(TK_C_SP), prevc) & (s.l | s.oth | s.nu);
+        nev |= tk_prev_set(s.l, L3, prevc) & s.l;
+        nev |= tk_prev_set(s.nu, TK_CB(TK_C_NU), prevc) & s.nu;
+        nev |= tk_prev_set(s.oth, O4, prevc) & s.oth;
+    } else if (pat == TK_PAT_CL100K) {
+        nev |= tk_prev_set(s.nl, TK_CB(TK_C_NL), prevc) & s.nl;
+        nev |= tk_prev_set(s.sp, TK_CB(TK_C_SP), prevc) & (s.nl | s.l | s.oth);
+        nev |= tk_prev_set(s.wso, TK_CB(TK_C_WSO), prevc) & (s.nl | s.l);
+        nev |= tk_prev_set(s.l, L3, prevc) & s.l;
+        nev |= tk_prev_set(s.oth, O4, prevc) & (s.nl | s.oth);
+    } else {
+        nev |= tk_prev_set(s.nl, TK_CB(TK_C_NL), prevc) & s.nl;
+        nev |= tk_prev_set(s.sp, TK_CB(TK_C_SP), prevc) & (s.nl | s.l | s.oth);
+        nev |= tk_prev_set(s.wso, TK_CB(TK_C_WSO), prevc) & (s.nl | s.l | s.mk);
+        nev |= tk_prev_set(s.lu, TK_CB(TK_C_LU), prevc) & (s.l | s.mk);
+        nev |= tk_prev_set(s.ll | s.lc, TK_CB(TK_C_LL) | TK_CB(TK_C_LC), prevc) & (s.ll | s.lc | s.mk);
+        nev |= tk_prev_set(s.mk, TK_CB(TK_C_MK), prevc) & s.mk;
+        nev |= tk_prev_set(s.ap | s.ot, TK_CB(TK_C_AP) | TK_CB(TK_C_OT), prevc) & (s.nl | s.oth);
+        nev |= tk_prev_set(s.sl, TK_CB(TK_C_SL), prevc) & (s.nl | s.sl);
+    }
+    // the end of a contraction ('s: apostrophe + 2 bytes; 'll, 'ſ: + 3) is a boundary whatever the classes say
+    const uint32_t near = ((s.ap << 2) | (s.ap << 3) | ((ap_before & 1u) ? 1u : 0u) | ((ap_before & 2u) ? 3u : 0u) | ((ap_before & 4u) ? 6u : 0u)) & 0xFFFFu;
+    return nev & ~near;
+}
+
 // The same from a table given at run time (generic patterns: cert[a] = class mask, TkTables::cert)
 TK_HD uint32_t tk_chunk_certain_rt(const uint16_t* cm, const TkSets& s, uint32_t start, uint32_t hard, uint32_t prevc) {
     const uint32_t set_of[12] = {0u, s.nl, s.sp, s.wso, s.lu, s.ll, s.lc, s.mk, s.nu, s.ap, s.sl, s.ot};

@@ -98,6 +98,45 @@ TK_HD uint32_t tk_certain_mask(int pat, uint32_t a) {
 }
 TK_HD bool tk_certain_start(int pat, uint32_t a, uint32_t b) { return (tk_certain_mask(pat, a) >> b) & 1u; }
 
+// The opposite table: NEVER[pat][a] = classes b such that NO piece of the stock pattern starts at a char of class b that follows a char
+// of class a -- unless an apostrophe stands two or three bytes before it (the end of a contraction is a boundary inside a run of
+// letters).  Derived by brute force against Python `regex` like the table above; the front kernel uses it to take the common case
+// "the piece ends at the next certain start" without running the scanner (tk_chunk_never, tk_chunk.h), and the CPU simulation checks
+// every piece start of the test corpora against it.
+TK_HD uint32_t tk_never_mask(int pat, uint32_t a) {
+    const uint32_t L3 = TK_M_L, MK = TK_CB(TK_C_MK), NL = TK_CB(TK_C_NL), O4 = TK_M_OTHER;
+    if (pat == TK_PAT_R50K) {
+        switch (a) {
+            case TK_C_SP: return L3 | O4 | TK_CB(TK_C_NU);
+            case TK_C_LU: case TK_C_LL: case TK_C_LC: return L3;
+            case TK_C_NU: return TK_CB(TK_C_NU);
+            case TK_C_MK: case TK_C_AP: case TK_C_SL: case TK_C_OT: return O4;
+            default: return 0;
+        }
+    } else if (pat == TK_PAT_CL100K) {
+        switch (a) {
+            case TK_C_NL: return NL;
+            case TK_C_SP: return NL | L3 | O4;
+            case TK_C_WSO: return NL | L3;
+            case TK_C_LU: case TK_C_LL: case TK_C_LC: return L3;
+            case TK_C_MK: case TK_C_AP: case TK_C_SL: case TK_C_OT: return NL | O4;
+            default: return 0;
+        }
+    } else {
+        switch (a) {
+            case TK_C_NL: return NL;
+            case TK_C_SP: return NL | L3 | O4;
+            case TK_C_WSO: return NL | L3 | MK;
+            case TK_C_LU: return L3 | MK;
+            case TK_C_LL: case TK_C_LC: return TK_CB(TK_C_LL) | TK_CB(TK_C_LC) | MK;  // (an upper-case letter may start the next word)
+            case TK_C_MK: return MK;
+            case TK_C_AP: case TK_C_OT: return NL | O4;
+            case TK_C_SL: return NL | TK_CB(TK_C_SL);
+            default: return 0;
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------
 // The scanner.  `A` is an accessor: A::cls(pos) -> class byte of position pos (TK_C_END at and
 // beyond the end of the buffer), A::byte(pos) -> raw text byte.

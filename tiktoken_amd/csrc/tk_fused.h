@@ -37,7 +37,8 @@
 #define TK_BIGCOPY 4096      // token runs from this length on are copied by tk_k_bigcopy
 #define TK_BIGCOPY_CAP 1024  // entries of its list
 #define TKF_CHAIN_END 0xFFFFFFFFFFFFFFFFull
-#define TKF_CONT_CAP 256  // continuation list of the scanners
+#define TKF_CONT_CAP 256       // continuation list of the scanners: deferred-tile variant (own array)
+#define TKF_CONT_CAP_FAST 768  // ... one-workgroup-per-tile variant (the list lives in the byte table's LDS, dead after phase B)
 #define TKF_SLOW_CAP 8    // pieces of one tile that leave its window
 #define TKF_BATCH 960  // pieces per probe batch of the front kernel (the class lists hold 1024 entries, their packed counter 1023)
 #define TKF_CAP 4096  // piece ids per tile: pid = tile * TKF_CAP + k (a 4096-byte tile starts at most 4096 pieces)
@@ -404,9 +405,9 @@ __global__ __launch_bounds__(256, SLOW ? 3 : 8) void tk_k_front(TkTables T, cons
     __shared__ __attribute__((aligned(8))) uint32_t btab[256 * 2];                   // byte table (tk_chunk.h)
     __shared__ uint32_t certw[TK2_WIN / 32];                                         // certain starts (hard starts included)
     __shared__ uint32_t bits[TK_TILE / 32];
-    __shared__ uint8_t lastc_own[SLOW ? 256 : 4];
+    __shared__ uint8_t lastc_own[256];
     __shared__ uint32_t np_sh, nmiss_sh, need_walk, last_end_sh, ncls_sh, nx_sh, ncont_sh;
-    __shared__ uint16_t contl[TKF_CONT_CAP];  // scan chains that continue after their first piece (window positions)
+    __shared__ uint16_t contl_own[SLOW ? TKF_CONT_CAP : 1], stop_own[SLOW ? 256 : 2];
     __shared__ uint16_t slowl[TKF_SLOW_CAP];  // pieces that leave the window (window positions of their starts)
     __shared__ uint32_t nslow_sh;
     __shared__ uint32_t brkw[TK2_WIN / 32 + 1], ssw[SPEC ? TK2_WIN / 32 + 1 : 1], siw[SPEC ? TK2_WIN / 32 + 1 : 1];
@@ -415,7 +416,12 @@ __global__ __launch_bounds__(256, SLOW ? 3 : 8) void tk_k_front(TkTables T, cons
     uint16_t* clist = (uint16_t*)(pool + BM_BYTES);
     uint16_t* plist = (uint16_t*)pool;  // valid after the scanners are done
     uint32_t* woff = certw;             // (phase E; the certain-start bitmap is dead by then)
-    uint8_t* lastc = SLOW ? lastc_own : (uint8_t*)contl;  // (phase C; the continuation list is used from phase D on)
+    uint8_t* lastc = lastc_own;
+    // From phase C on the byte table is dead in the one-tile-per-workgroup variant: its 2 KiB hold the "stop" bitmap of the scanners'
+    // short cut (256 halfwords) and the continuation list; the deferred-tile variant still classifies text with it (tk_coop_chunk).
+    constexpr uint32_t CONT_CAP = SLOW ? (uint32_t)TKF_CONT_CAP : (uint32_t)TKF_CONT_CAP_FAST;
+    uint16_t* stop16 = SLOW ? stop_own : (uint16_t*)btab;          // [256] char starts at which a piece may start (16 per lane)
+    uint16_t* contl = SLOW ? contl_own : (uint16_t*)btab + 256;    // [CONT_CAP] scan chains still to be walked (window positions)
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     uint32_t item = blockIdx.x;
@@ -546,6 +552,20 @@ __global__ __launch_bounds__(256, SLOW ? 3 : 8) void tk_k_front(TkTables T, cons
     const uint32_t prevc = tid ? (uint32_t)lastc[tid - 1] : 0u;
     const uint32_t cert = GEN ? tk_chunk_certain_rt(T.cert, st, mk.text, mk.hard & mk.text, prevc) : tk_chunk_certain(fam, st, mk.text, mk.hard & mk.text, prevc);
     ((uint16_t*)certw)[tid] = (uint16_t)cert;
+    // The scanners' short cut: between a piece start and the next position at which a piece MAY start there is no boundary.  "May
+    // start" = every char start except those whose class pair never has one (tk_chunk_never; generic patterns: every char start).
+    {
+        uint32_t stopm = mk.start;
+        if (!GEN) {
+            uint32_t apb = 7u;  // apostrophes in the three bytes before the chunk (the first chunk of the window cannot know)
+            if (tid) {
+                const uint32_t pv = ((const uint32_t*)raw)[tid * 4u - 1u];
+                apb = (uint32_t)(((pv >> 8) & 0xFFu) == 0x27u) | ((uint32_t)(((pv >> 16) & 0xFFu) == 0x27u) << 1) | ((uint32_t)((pv >> 24) == 0x27u) << 2);
+            }
+            stopm &= ~tk_chunk_never(fam, st, prevc, apb);
+        }
+        stop16[tid] = (uint16_t)(stopm | cert);  // (a hard start -- a document begins -- is a start whatever the classes on its two sides)
+    }
     constexpr uint32_t T0 = TK2_LEFT / 16, T1 = (TK2_LEFT + TK_TILE) / 16;  // chunks [T0, T1) are the tile
     const bool in_tile = tid >= T0 && tid < T1;
     if (in_tile) ((uint16_t*)bits)[tid - T0] = (uint16_t)cert;
@@ -679,7 +699,7 @@ __global__ __launch_bounds__(256, SLOW ? 3 : 8) void tk_k_front(TkTables T, cons
                     __syncthreads();
                     if (tid == 0) {
                         const uint32_t at = ncont_sh;
-                        if (at < TKF_CONT_CAP) {
+                        if (at < CONT_CAP) {
                             contl[at] = (uint16_t)(nx - (uint64_t)base);
                             ncont_sh = at + 1;
                         } else {
@@ -734,7 +754,7 @@ __global__ __launch_bounds__(256, SLOW ? 3 : 8) void tk_k_front(TkTables T, cons
     bool own_extra = !listed && extra != TKF_NONE;
     uint32_t cont_done = 0, slow_done = 0;
     for (int round = 0;; ++round) {
-        const uint32_t cont_n = ncont_sh < TKF_CONT_CAP ? ncont_sh : (uint32_t)TKF_CONT_CAP;
+        const uint32_t cont_n = ncont_sh < CONT_CAP ? ncont_sh : CONT_CAP;
         const uint32_t lo = round == 0 ? 0u : cont_done, hi = round == 0 ? (listed ? n_front + n_back : 0u) : cont_n;
         if (round) cont_done = cont_n;
         uint32_t i = lo + tid;
@@ -753,7 +773,38 @@ __global__ __launch_bounds__(256, SLOW ? 3 : 8) void tk_k_front(TkTables T, cons
                 }
             }
             if (!__any(p != TKF_CHAIN_END)) break;
-            for (;;) {  // (round 0: one pass, unless the continuation list is full)
+            if (round == 0) {
+                // Short cut: the first position after p at which a piece may start.  If it is a certain start, the piece ends there
+                // and nothing else has to be found out (85 % of the pieces).  The others go on the continuation list, so that the
+                // scanner below runs in round 1 with all lanes of a wavefront busy instead of here for a few lanes of each.
+                bool need = p != TKF_CHAIN_END;
+                const uint32_t r = need ? (uint32_t)((int64_t)p - base) : 0u;
+                if (need && r + 32u < (uint32_t)TK2_WIN) {
+                    const uint32_t* sw = (const uint32_t*)stop16;
+                    const uint32_t w = __builtin_amdgcn_alignbit(sw[(r >> 5) + 1u], sw[r >> 5], r & 31u) & ~1u;
+                    if (w) {
+                        const uint32_t re = r + (uint32_t)__ffs((int)w) - 1u;
+                        if ((certw[re >> 5] >> (re & 31u)) & 1u) {
+                            chain_step(p, (uint64_t)(base + (int64_t)re));  // (a certain start: the chain ends; the tile's last end is noted)
+                            need = false;
+                        }
+                    }
+                }
+                const uint64_t m = __ballot(need);
+                if (m) {
+                    uint32_t at = 0;
+                    const int leader = __ffsll((unsigned long long)m) - 1;
+                    if (lane == leader) at = atomicAdd(&ncont_sh, (uint32_t)__popcll(m));
+                    at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                    if (need && at < CONT_CAP) {
+                        contl[at] = (uint16_t)r;
+                        need = false;
+                    }
+                }
+                p = need ? p : TKF_CHAIN_END;
+                if (!__any(p != TKF_CHAIN_END)) continue;
+            }
+            for (;;) {  // (round 0: only when the continuation list is full)
                 const uint64_t e = p != TKF_CHAIN_END ? piece_from(p) : TKF_CHAIN_END;
                 bool go_on = e != TKF_CHAIN_END;
                 if (round == 0) {
@@ -764,7 +815,7 @@ __global__ __launch_bounds__(256, SLOW ? 3 : 8) void tk_k_front(TkTables T, cons
                         if (lane == leader) at = atomicAdd(&ncont_sh, (uint32_t)__popcll(m));
                         at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
                         // (a chain that goes on is left of the tile end and inside the window)
-                        if (go_on && at < TKF_CONT_CAP) {
+                        if (go_on && at < CONT_CAP) {
                             contl[at] = (uint16_t)(e - (uint64_t)base);
                             go_on = false;
                         }
@@ -780,7 +831,7 @@ __global__ __launch_bounds__(256, SLOW ? 3 : 8) void tk_k_front(TkTables T, cons
         for (uint32_t q = slow_done; q < slow_n; ++q) coop_chain((uint64_t)(base + slowl[q]));
         slow_done = slow_n;
         __syncthreads();
-        const uint32_t cont_now = ncont_sh < TKF_CONT_CAP ? ncont_sh : (uint32_t)TKF_CONT_CAP;
+        const uint32_t cont_now = ncont_sh < CONT_CAP ? ncont_sh : CONT_CAP;
         if (round >= 1 && cont_now == cont_done) break;
     }
     if (!SLOW && nslow_sh) {

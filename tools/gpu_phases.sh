@@ -6,11 +6,11 @@ R=$GRAFT_REPO_ROOT; O=$R/gpurun_out/phases_$TAG; mkdir -p $O
 cd /tmp && export TMPDIR=/tmp
 for V in 0 0x1000 0x2000 0x4000 0x8000 0x10000 2 8 256; do
   D=$((V))
-  TIKTOKEN_AMD_DEBUG=$D timeout 90 python $R/bench.py --gpus 1 --steps 3 --warmup 1 --mib 1024 --no-cpu-baseline > $O/bench_$V.json 2> $O/bench_$V.err
+  TIKTOKEN_AMD_DEBUG=$D timeout 90 python $R/bench.py --gpus 1 --steps 3 --warmup 1 --mib 1024 --no-cpu-baseline --no-host-path > $O/bench_$V.json 2> $O/bench_$V.err
 done
 for V in ${PMC_VARIANTS:-0 0x2000 0x4000 0x8000 0x10000}; do
   D=$((V))
-  TIKTOKEN_AMD_DEBUG=$D timeout 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_$V -o p -- python $R/bench.py --gpus 1 --steps 1 --warmup 0 --mib 1024 --no-cpu-baseline > $O/pmc_$V.log 2>&1
+  TIKTOKEN_AMD_DEBUG=$D timeout 150 rocprofv3 --pmc SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_VALU --output-format csv -d $O/pmc_$V -o p -- python $R/bench.py --gpus 1 --steps 1 --warmup 0 --mib 1024 --no-cpu-baseline --no-host-path > $O/pmc_$V.log 2>&1
 done
 cd $R; python - "$O" <<'PY'
 import csv, glob, json, os, sys, collections
