@@ -47,6 +47,13 @@ static uint64_t g_runs_mismatch = 0, g_never_viol = 0;
 
 // certain piece starts from the table that travels with the pattern (TkTables::cert: the family's static table for stock patterns)
 static inline bool tk_certain_rt(const uint16_t* cert, uint32_t a, uint32_t b) { return (cert[a & 15u] >> b) & 1u; }
+// ... plus the one rule with context: in the stock o200k pattern a lower-case letter followed by an upper-case one is a boundary unless an
+// apostrophe stands two or three bytes before the upper-case letter ("'lL" is a contraction) -- tk_chunk_certain's `near` term
+static inline bool tk_certain_ctx(const TkTables& T, uint32_t a, uint32_t b, const uint8_t* text, uint64_t i) {
+    if ((T.cert[a & 15u] >> b) & 1u) return true;
+    if (T.pat.generic() || T.pattern != TK_PAT_O200K || a != TK_C_LL || b != TK_C_LU) return false;
+    return !((i >= 2 && text[i - 2] == '\'') || (i >= 3 && text[i - 3] == '\''));
+}
 
 extern "C" {
 uint64_t tks_runs_mismatches() { return g_runs_mismatch; }
@@ -141,7 +148,7 @@ uint64_t tks_pretok(void* p, const uint8_t* text_in, uint64_t n, const uint64_t*
             if (i == 0) continue;  // the kernel sees TK_C_END to the left of position 0
             uint64_t j = i - 1;
             while (j > 0 && cls[j] == TK_C_CONT) --j;
-            certain = tk_certain_rt(s_cert, cls[j] & 15u, c & 15u);
+            certain = tk_certain_ctx(s->T, cls[j] & 15u, c & 15u, text.data(), i);
         }
         if (!certain) continue;
         ++n_certain;
@@ -156,7 +163,7 @@ uint64_t tks_pretok(void* p, const uint8_t* text_in, uint64_t n, const uint64_t*
             if (ce & TK_F_HARD) break;
             uint64_t j = e - 1;
             while (acc.cls(j) == TK_C_CONT) --j;
-            if (tk_certain_rt(s_cert, acc.cls(j) & 15u, ce & 15u)) break;
+            if (tk_certain_ctx(s->T, acc.cls(j) & 15u, ce & 15u, text.data(), e)) break;
             starts[e] = 1;
             q = e;
         }
@@ -265,7 +272,7 @@ uint64_t tks_pretok_bits(void* pv, const uint8_t* text_in, uint64_t n, const uin
         bool certain = (c & 0x80u) != 0;
         if (!certain) {
             if (i == 0) continue;
-            certain = tk_certain_rt(s_cert, cls2[i - 1] & 15u, c & 15u);  // propagated class: no walking back
+            certain = tk_certain_ctx(s->T, cls2[i - 1] & 15u, c & 15u, text.data(), i);  // propagated class: no walking back
         }
         if (!certain) continue;
         starts[i] = 1;
@@ -307,7 +314,7 @@ uint64_t tks_pretok_bits(void* pv, const uint8_t* text_in, uint64_t n, const uin
             if (e >= n) break;
             uint32_t ce = cls2[e];
             if (ce & 0x80u) break;
-            if (tk_certain_rt(s_cert, cls2[e - 1] & 15u, ce & 15u)) break;
+            if (tk_certain_ctx(s->T, cls2[e - 1] & 15u, ce & 15u, text.data(), e)) break;
             starts[e] = 1;
             q = e;
         }
@@ -349,7 +356,7 @@ uint64_t tks_pretok_tiles(void* pv, const uint8_t* text_in, uint64_t n, const ui
         if (c & 0x40u) return false;
         if (c & 0x80u) return true;
         if (i == 0) return false;
-        return tk_certain_rt(s_cert, cls2[i - 1] & 15u, c & 15u);
+        return tk_certain_ctx(s->T, cls2[i - 1] & 15u, c & 15u, text.data(), i);
     };
     uint64_t n_walkback = 0;
     for (uint64_t t0 = 0; t0 < n; t0 += tile) {
@@ -362,7 +369,7 @@ uint64_t tks_pretok_tiles(void* pv, const uint8_t* text_in, uint64_t n, const ui
                 uint32_t ce = cls2[e];
                 if (e >= t0) {
                     if (ce & 0x80u) break;
-                    if (tk_certain_rt(s_cert, cls2[e - 1] & 15u, ce & 15u)) break;  // a scanner of this tile starts there
+                    if (tk_certain_ctx(s->T, cls2[e - 1] & 15u, ce & 15u, text.data(), e)) break;  // a scanner of this tile starts there
                     starts[e] = 1;
                 } else if (certain_at(e)) {
                     break;                            // cannot happen: q was the LAST certain start before the tile
@@ -438,12 +445,13 @@ uint64_t tks_chunk_check(void* pv, const uint8_t* text_in, uint64_t n, const uin
     (void)pat;
     const TkPat patx = T.pat;
     (void)patx;
-    auto certain_ref = [&](uint64_t i, bool prev_known) -> bool {
+    auto certain_ref = [&](uint64_t i, bool prev_known, bool ctx_known) -> bool {
         uint32_t c = ref[i];
         if (c & 0x40u) return false;
         if (c & 0x80u) return true;
         if (i == 0 || !prev_known) return false;
-        return tk_certain_rt(s_cert, ref[i - 1] & 15u, c & 15u);
+        // (the first three bytes of a window cannot see an apostrophe before it: only the table counts there)
+        return ctx_known ? tk_certain_ctx(T, ref[i - 1] & 15u, c & 15u, text.data(), i) : tk_certain_rt(s_cert, ref[i - 1] & 15u, c & 15u);
     };
     uint64_t bad = 0;
     auto report = [&](uint64_t pos, uint32_t code) {
@@ -514,8 +522,12 @@ uint64_t tks_chunk_check(void* pv, const uint8_t* text_in, uint64_t n, const uin
             const int64_t gp = base + (int64_t)t * 16;
             const TkChunkMasks& m = masks[t];
             const uint32_t prevc = t ? lastc[t - 1] : 0u;
+            uint32_t ap_before = t ? 0u : 7u;  // (the first chunk of a window cannot see what stands before it: as if apostrophes did)
+            for (int b = 1; b <= 3; ++b)
+                if (t > 0 && raw[(int64_t)t * 16 - b] == '\'') ap_before |= 1u << (3 - b);
+            const uint32_t near16 = tk_chunk_near(sets[t].ap, ap_before);
             const uint32_t cert = T.pat.generic() ? tk_chunk_certain_rt(T.cert, sets[t], m.text, m.hard & m.text, prevc)
-                                                   : tk_chunk_certain(pat, sets[t], m.text, m.hard & m.text, prevc);
+                                                   : tk_chunk_certain(pat, sets[t], m.text, m.hard & m.text, prevc, near16);
             // (the window may begin inside a char: its bytes there have no known class, and the first char start of the window no
             // known predecessor -- the kernel treats both as "unknown, never certain")
             int first = 0;
@@ -523,10 +535,7 @@ uint64_t tks_chunk_check(void* pv, const uint8_t* text_in, uint64_t n, const uin
                 while (first < 16 && gp + first >= 0 && (uint64_t)(gp + first) < n && !((m.start >> first) & 1u)) ++first;
             uint32_t nev = 0;
             if (!T.pat.generic()) {
-                uint32_t ap_before = t ? 0u : 7u;  // (the first chunk of a window cannot see what stands before it: as if apostrophes did)
-                for (int b = 1; b <= 3; ++b)
-                    if (t > 0 && raw[(int64_t)t * 16 - b] == '\'') ap_before |= 1u << (3 - b);
-                nev = tk_chunk_never(pat, sets[t], prevc, ap_before);
+                nev = tk_chunk_never(pat, sets[t], prevc, near16);
             }
             for (int j = 0; j < 16; ++j) {
                 const int64_t g = gp + j;
@@ -553,7 +562,7 @@ uint64_t tks_chunk_check(void* pv, const uint8_t* text_in, uint64_t n, const uin
                 if (cls != (r & 15u)) report((uint64_t)g, 1);
                 else if (start != !(r & 0x40u)) report((uint64_t)g, 2);
                 else if (hard != (bool)(r & 0x80u)) report((uint64_t)g, 3);
-                else if ((bool)((cert >> j) & 1u) != certain_ref((uint64_t)g, !(t == 0 && j == first))) report((uint64_t)g, 4);
+                else if ((bool)((cert >> j) & 1u) != certain_ref((uint64_t)g, !(t == 0 && j == first), !(t == 0 && j < 3))) report((uint64_t)g, 4);
             }
         }
         if (n == 0) break;

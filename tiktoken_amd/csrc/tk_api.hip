@@ -594,23 +594,13 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         TRY(timed(c, s, "tk_k_scan_small", [&] {
             hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, tile_nt, ntiles, c->total.as<uint64_t>());
         }));
-        // the document offsets need what the token copy needs (tile bases, per-piece counts) and write elsewhere: side by side
-        const bool docoff_aside = d_tok_off != nullptr;
-        if (docoff_aside) {
-            HIPCHK(hipEventRecord(c->ev_fork, s));
-            HIPCHK(hipStreamWaitEvent(c->aux[0], c->ev_fork, 0));
-            TRY(timed(c, c->aux[0], "tk_k_docoff", [&] {
-                hipLaunchKernelGGL(tk_k_docoff, dim3(grid_for(n_docs + 1, 4, 8192)), dim3(256), 0, c->aux[0], n_docs, d_doc_off, base, n, starts, tile_nt, res, rflag, c->total.as<uint64_t>(), tok_base_global, d_tok_off);
-            }));
-            HIPCHK(hipEventRecord(c->ev_join[0], c->aux[0]));
-        }
         TRY(timed(c, s, "tk_k_back", [&] {
             hipLaunchKernelGGL(tk_k_back, dim3(grid_for(ntiles, 4, 16384)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, rflag, stg, d_out, c->big.as<uint32_t>());
         }));
         if (n > TK_BIGCOPY)  // (a token run of TK_BIGCOPY tokens needs at least as many bytes)
             hipLaunchKernelGGL(tk_k_bigcopy, dim3(1024), dim3(256), 0, s, c->big.as<uint32_t>(), stg, d_out);
-        if (docoff_aside) HIPCHK(hipStreamWaitEvent(s, c->ev_join[0], 0));
-    } else if (d_tok_off) {
+    }
+    if (d_tok_off) {  // (beside the token copy on a second stream it takes as long as behind it: both wait for the same memory system)
         TRY(timed(c, s, "tk_k_docoff", [&] {
             hipLaunchKernelGGL(tk_k_docoff, dim3(grid_for(n_docs + 1, 4, 8192)), dim3(256), 0, s, n_docs, d_doc_off, base, n, starts, tile_nt, res, rflag, c->total.as<uint64_t>(), tok_base_global, d_tok_off);
         }));

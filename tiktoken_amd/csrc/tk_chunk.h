@@ -178,7 +178,9 @@ TK_HD uint32_t tk_prev_set(uint32_t set, uint32_t class_mask, uint32_t prevc) { 
 
 // Certain piece starts of the chunk: char starts where a boundary is certain whatever the left context (tk_device.h
 // tk_certain_mask restated on masks).  prevc = class nibble of the byte before the chunk (0 when unknown: never certain).
-TK_HD uint32_t tk_chunk_certain(int pat, const TkSets& s, uint32_t start, uint32_t hard, uint32_t prevc) {
+// near: positions with an apostrophe two or three bytes before them (tk_chunk_near) -- there a lower-case letter followed by an upper-case
+// one may be the inside of a contraction ("'lL"); everywhere else it is a boundary of the o200k pattern ("camelCase").
+TK_HD uint32_t tk_chunk_certain(int pat, const TkSets& s, uint32_t start, uint32_t hard, uint32_t prevc, uint32_t near) {
     const uint32_t L3 = TK_M_L, O4 = TK_M_OTHER, NU = TK_CB(TK_C_NU);
     uint32_t cert = hard;
     if (pat == TK_PAT_R50K) {
@@ -199,16 +201,23 @@ TK_HD uint32_t tk_chunk_certain(int pat, const TkSets& s, uint32_t start, uint32
         cert |= tk_prev_set(s.sp, TK_CB(TK_C_SP), prevc) & s.nu;
         cert |= tk_prev_set(s.wso, TK_CB(TK_C_WSO), prevc) & (s.nu | s.ap | s.sl | s.ot);
         cert |= tk_prev_set(s.l, L3, prevc) & (s.ws | s.nu | s.sl | s.ot);
+        cert |= tk_prev_set(s.ll, TK_CB(TK_C_LL), prevc) & s.lu & ~near;
         cert |= tk_prev_set(s.oth, O4, prevc) & (s.sp | s.wso | s.nu);
         cert |= tk_prev_set(s.nu, NU, prevc) & (s.ws | s.l | s.oth);
     }
     return cert & start;  // (pass the char starts of REAL text: positions past the end are hard but never pieces)
 }
 
+// Positions of the chunk with an apostrophe two or three bytes before them: the end of a contraction ('s: apostrophe + 2 bytes; 'll,
+// 'ſ: + 3).  ap = the chunk's apostrophe bytes; ap_before: bits 0..2 = apostrophe at byte -3, -2, -1 before the chunk (7 when unknown).
+TK_HD uint32_t tk_chunk_near(uint32_t ap, uint32_t ap_before) {
+    return ((ap << 2) | (ap << 3) | ((ap_before & 1u) ? 1u : 0u) | ((ap_before & 2u) ? 3u : 0u) | ((ap_before & 4u) ? 6u : 0u)) & 0xFFFFu;
+}
+
 // Char starts of the chunk at which NO piece of the stock pattern `pat` can start: the class pair (previous char, this char) is in
-// tk_never_mask (tk_device.h) and no apostrophe stands two or three bytes before (ap_before: bits 0..2 = apostrophe at byte -3, -2, -1
-// before the chunk).  The rows are written out as set algebra; the unit tests check them against the table.
-TK_HD uint32_t tk_chunk_never(int pat, const TkSets& s, uint32_t prevc, uint32_t ap_before) {
+// tk_never_mask (tk_device.h) and the position is not `near` an apostrophe (tk_chunk_near).  The rows are written out as set algebra;
+// the unit tests check them against the table.
+TK_HD uint32_t tk_chunk_never(int pat, const TkSets& s, uint32_t prevc, uint32_t near) {
     const uint32_t L3 = TK_M_L, O4 = TK_M_OTHER;
     uint32_t nev = 0;
     if (pat == TK_PAT_R50K) {
@@ -232,9 +241,7 @@ TK_HD uint32_t tk_chunk_never(int pat, const TkSets& s, uint32_t prevc, uint32_t
         nev |= tk_prev_set(s.ap | s.ot, TK_CB(TK_C_AP) | TK_CB(TK_C_OT), prevc) & (s.nl | s.oth);
         nev |= tk_prev_set(s.sl, TK_CB(TK_C_SL), prevc) & (s.nl | s.sl);
     }
-    // the end of a contraction ('s: apostrophe + 2 bytes; 'll, 'ſ: + 3) is a boundary whatever the classes say
-    const uint32_t near = ((s.ap << 2) | (s.ap << 3) | ((ap_before & 1u) ? 1u : 0u) | ((ap_before & 2u) ? 3u : 0u) | ((ap_before & 4u) ? 6u : 0u)) & 0xFFFFu;
-    return nev & ~near;
+    return nev & ~near;  // (the end of a contraction is a boundary whatever the classes say)
 }
 
 // The same from a table given at run time (generic patterns: cert[a] = class mask, TkTables::cert)

@@ -241,8 +241,13 @@ __device__ __noinline__ uint64_t tk_coop_certain_before(const TkCoop* Cp, uint64
         __syncthreads();
         if (cref == 16) cref = C.red[4];
         const uint32_t prevc = threadIdx.x ? (uint32_t)C.lastc[threadIdx.x - 1] : 0u;
+        uint32_t apb = 7u;  // apostrophes in the three bytes before the chunk
+        if (g >= 4 && (uint64_t)g < C.n) {
+            const uint32_t pv = *(const uint32_t*)(C.text + g - 4);
+            apb = (uint32_t)(((pv >> 8) & 0xFFu) == 0x27u) | ((uint32_t)(((pv >> 16) & 0xFFu) == 0x27u) << 1) | ((uint32_t)((pv >> 24) == 0x27u) << 2);
+        }
         uint32_t cert = C.pat.generic() ? tk_chunk_certain_rt(C.T->cert, st, mk.text, mk.hard & mk.text, prevc)
-                                        : tk_chunk_certain(C.pat.fam(), st, mk.text, mk.hard & mk.text, prevc);
+                                        : tk_chunk_certain(C.pat.fam(), st, mk.text, mk.hard & mk.text, prevc, tk_chunk_near(st.ap, apb));
         uint32_t oth = ~tk_member16(mk.p, 1u << cref) & 0xFFFFu;  // bytes of another class
         if (g > (int64_t)pos) cert = oth = 0;
         else if (g + 16 > (int64_t)pos + 1) {
@@ -550,20 +555,22 @@ __global__ __launch_bounds__(256, SLOW ? 3 : 8) void tk_k_front(TkTables T, cons
     __syncthreads();
     // the class before the chunk: never known for the first chunk of the window (nothing there is certain unless hard)
     const uint32_t prevc = tid ? (uint32_t)lastc[tid - 1] : 0u;
-    const uint32_t cert = GEN ? tk_chunk_certain_rt(T.cert, st, mk.text, mk.hard & mk.text, prevc) : tk_chunk_certain(fam, st, mk.text, mk.hard & mk.text, prevc);
+    uint32_t near = 0xFFFFu;  // positions with an apostrophe two or three bytes before (the first chunk of the window cannot know: all)
+    {
+        uint32_t apb = 7u;
+        if (tid) {
+            const uint32_t pv = ((const uint32_t*)raw)[tid * 4u - 1u];
+            apb = (uint32_t)(((pv >> 8) & 0xFFu) == 0x27u) | ((uint32_t)(((pv >> 16) & 0xFFu) == 0x27u) << 1) | ((uint32_t)((pv >> 24) == 0x27u) << 2);
+        }
+        near = tk_chunk_near(st.ap, apb);
+    }
+    const uint32_t cert = GEN ? tk_chunk_certain_rt(T.cert, st, mk.text, mk.hard & mk.text, prevc) : tk_chunk_certain(fam, st, mk.text, mk.hard & mk.text, prevc, near);
     ((uint16_t*)certw)[tid] = (uint16_t)cert;
     // The scanners' short cut: between a piece start and the next position at which a piece MAY start there is no boundary.  "May
     // start" = every char start except those whose class pair never has one (tk_chunk_never; generic patterns: every char start).
     {
         uint32_t stopm = mk.start;
-        if (!GEN) {
-            uint32_t apb = 7u;  // apostrophes in the three bytes before the chunk (the first chunk of the window cannot know)
-            if (tid) {
-                const uint32_t pv = ((const uint32_t*)raw)[tid * 4u - 1u];
-                apb = (uint32_t)(((pv >> 8) & 0xFFu) == 0x27u) | ((uint32_t)(((pv >> 16) & 0xFFu) == 0x27u) << 1) | ((uint32_t)((pv >> 24) == 0x27u) << 2);
-            }
-            stopm &= ~tk_chunk_never(fam, st, prevc, apb);
-        }
+        if (!GEN) stopm &= ~tk_chunk_never(fam, st, prevc, near);
         stop16[tid] = (uint16_t)(stopm | cert);  // (a hard start -- a document begins -- is a start whatever the classes on its two sides)
     }
     constexpr uint32_t T0 = TK2_LEFT / 16, T1 = (TK2_LEFT + TK_TILE) / 16;  // chunks [T0, T1) are the tile
