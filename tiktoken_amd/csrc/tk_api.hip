@@ -75,7 +75,7 @@ struct tk_core {
     uint32_t spec_max_len = 0;
     std::mutex mu;
     // workspace
-    Buf text, text_al, tile_sum, wide_ws, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, res, rflag, staging, listB, listC, counters, total, g_id, g_rk, g_nx,
+    Buf text, text_al, tile_sum, wide_ws, scan_sums, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, res, rflag, staging, listB, listC, counters, total, g_id, g_rk, g_nx,
         g_pv, g_lv, out_tokens, out_tok_off, allowed, tile_np, tile_nt, tile_nmiss, mt_slots, wbin, wave_pieces, deferred, big;
     uint64_t chunk_bytes = 1ull << 30;
     int dbg = 0;
@@ -309,7 +309,7 @@ extern "C" void tk_destroy(tk_core* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_dec, &c->d_tok, &c->d_lens, &c->d_bsum, &c->d_tboff, &c->d_bytes, &c->d_boff, &c->t_piece, &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2,
-                   &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->text_al, &c->tile_sum, &c->wide_ws, &c->doc_off, &c->brk, &c->docb,
+                   &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->text_al, &c->tile_sum, &c->wide_ws, &c->scan_sums, &c->doc_off, &c->brk, &c->docb,
                    &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->res, &c->rflag, &c->staging, &c->listB,
                    &c->listC, &c->counters, &c->total, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv, &c->out_tokens,
                    &c->out_tok_off, &c->allowed, &c->tile_np, &c->tile_nt, &c->tile_nmiss, &c->mt_slots, &c->wbin, &c->deferred, &c->big,
@@ -368,6 +368,21 @@ static void launch_front(int pattern, bool spec, dim3 grid, hipStream_t s, A... 
 // The production pipeline (kernels of tk_fused.h).  One host synchronisation in the middle (the sizes of the
 // deferred-piece lists decide the merge launches) and none after it: the token total is read by the caller's
 // final synchronisation.
+// exclusive prefix sum of a uint32 array in place, total -> total_out[0]
+static int scan_u32(tk_core* c, hipStream_t s, uint32_t* a, uint64_t n, uint64_t* total_out) {
+    if (n <= 4 * (uint64_t)TK_SCAN_BLOCK) {
+        TRY(timed(c, s, "tk_k_scan_small", [&] { hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, a, n, total_out); }));
+        return TK_OK;
+    }
+    const uint64_t nb = (n + TK_SCAN_BLOCK - 1) / TK_SCAN_BLOCK;
+    TRY(ensure(c->scan_sums, (nb + 2) * 4));
+    uint32_t* sums = c->scan_sums.as<uint32_t>();
+    TRY(timed(c, s, "tk_k_scan_sums", [&] { hipLaunchKernelGGL(tk_k_scan_sums, dim3((uint32_t)nb), dim3(1024), 0, s, a, n, sums); }));
+    TRY(timed(c, s, "tk_k_scan_small", [&] { hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, sums, nb, total_out); }));
+    TRY(timed(c, s, "tk_k_scan_apply", [&] { hipLaunchKernelGGL(tk_k_scan_apply, dim3((uint32_t)nb), dim3(1024), 0, s, a, n, sums); }));
+    return TK_OK;
+}
+
 static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t n, const uint64_t* d_doc_off, uint64_t n_docs,
                      uint64_t base, bool use_special, bool single_piece, uint32_t* d_out, uint64_t tok_base_global,
                      uint64_t* d_tok_off, uint64_t* n_tokens_out, bool pretok_only = false, bool no_lookup = false) {
@@ -502,9 +517,7 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         TRY(timed(c, s, "tk_k_bincount", [&] {
             hipLaunchKernelGGL(tk_k_bincount, dim3(dd_blocks), dim3(256), 0, s, ntiles, fo.tile_nmiss, miss, wbin, tpg);
         }));
-        TRY(timed(c, s, "tk_k_scan_small", [&] {
-            hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, wbin, (uint64_t)TK_NBIN * dd_blocks * 4 + 1, c->total.as<uint64_t>());
-        }));
+        TRY(scan_u32(c, s, wbin, (uint64_t)TK_NBIN * dd_blocks * 4 + 1, c->total.as<uint64_t>()));
         TRY(timed(c, s, "tk_k_binfill", [&] {
             hipLaunchKernelGGL(tk_k_binfill, dim3(dd_blocks), dim3(256), 0, s, ntiles, fo.tile_nmiss, miss, wbin, c->listB.as<uint32_t>(), bins, counters, tpg);
         }));
@@ -591,9 +604,7 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
             hipLaunchKernelGGL(tk_k_tile_finish, dim3(tf_blocks), dim3(256), 0, s, ntiles, tile_np, mt, res, miss, rflag, tile_nt, c->wave_pieces.as<uint32_t>());
         }));
         hipLaunchKernelGGL(tk_k_sum_pieces, dim3(1), dim3(1024), 0, s, c->wave_pieces.as<uint32_t>(), tf_blocks * 4u, c->total.as<unsigned long long>() + 1);
-        TRY(timed(c, s, "tk_k_scan_small", [&] {
-            hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, tile_nt, ntiles, c->total.as<uint64_t>());
-        }));
+        TRY(scan_u32(c, s, tile_nt, ntiles, c->total.as<uint64_t>()));
         TRY(timed(c, s, "tk_k_back", [&] {
             hipLaunchKernelGGL(tk_k_back, dim3(grid_for(ntiles, 4, 16384)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, rflag, stg, d_out, c->big.as<uint32_t>());
         }));

@@ -344,6 +344,47 @@ __global__ __launch_bounds__(1024) void tk_k_scan_small(uint32_t* __restrict__ a
     if (threadIdx.x == 0) total_out[0] = carry_sh;
 }
 
+// Larger arrays: reduce, scan the sums, scan again with the bases (three short launches instead of one workgroup walking everything).
+#define TK_SCAN_BLOCK 8192  // elements per workgroup of the two wide passes (1024 threads x 8)
+__global__ __launch_bounds__(1024) void tk_k_scan_sums(const uint32_t* __restrict__ a, uint64_t n, uint32_t* __restrict__ sums) {
+    __shared__ uint32_t wsum[16];
+    const uint64_t i0 = (uint64_t)blockIdx.x * TK_SCAN_BLOCK + (uint64_t)threadIdx.x * 8;
+    uint32_t mine = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) mine += i0 + j < n ? a[i0 + j] : 0u;
+    mine = tk_wave_sum_u32(mine);
+    if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        uint32_t t = 0;
+        for (int w = 0; w < 16; ++w) t += wsum[w];
+        sums[blockIdx.x] = t;
+    }
+}
+// bases[b] = exclusive prefix of the sums (tk_k_scan_small over them); a <- exclusive prefix of a, in place
+__global__ __launch_bounds__(1024) void tk_k_scan_apply(uint32_t* __restrict__ a, uint64_t n, const uint32_t* __restrict__ bases) {
+    __shared__ uint32_t wsum[16];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    const uint64_t i0 = (uint64_t)blockIdx.x * TK_SCAN_BLOCK + (uint64_t)threadIdx.x * 8;
+    uint32_t v[8], mine = 0;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        v[j] = i0 + j < n ? a[i0 + j] : 0u;
+        mine += v[j];
+    }
+    const uint32_t inc = tk_wave_scan_u32(mine, lane);
+    if (lane == 63) wsum[wid] = inc;
+    __syncthreads();
+    uint32_t wbase = 0;
+    for (int w = 0; w < wid; ++w) wbase += wsum[w];
+    uint32_t run = bases[blockIdx.x] + wbase + inc - mine;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+        if (i0 + j < n) a[i0 + j] = run;
+        run += v[j];
+    }
+}
+
 __global__ __launch_bounds__(256) void tk_k_emit(const uint32_t* __restrict__ starts, uint64_t nwords, const uint32_t* __restrict__ blockpre,
                                                  uint32_t* __restrict__ pstart, uint64_t P, uint64_t n) {
     __shared__ uint32_t sh[8];
