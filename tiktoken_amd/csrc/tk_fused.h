@@ -394,7 +394,7 @@ __device__ __forceinline__ bool tk_equal_lds_text(const uint8_t* raw, uint32_t o
 // SLOW = true: the same kernel with that scanner compiled in (its calls cost registers: kept out of the common path), launched over the
 // deferred tiles with a fixed grid.
 template <int PAT, bool SPEC, bool SLOW>
-__global__ __launch_bounds__(256, SLOW ? 3 : 8) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
+__global__ __launch_bounds__(256, SLOW ? 4 : 8) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
                                                   const uint32_t* __restrict__ brk, const uint32_t* __restrict__ docb,
                                                   const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, TkFrontOut out,
                                                   TkMissSlot* __restrict__ mt, uint32_t mt_mask, uint32_t* __restrict__ deferred, int dbg) {
