@@ -60,11 +60,12 @@ struct KernelStat {
     uint64_t launches = 0;
 };
 
+#define TK_NAUX 6  // side streams of the merge kernels
 struct tk_core {
     int device = 0;
     hipStream_t stream = nullptr;
-    hipStream_t aux[4] = {nullptr, nullptr, nullptr, nullptr};  // side streams: the merge kernels are independent of each other
-    hipEvent_t ev_fork = nullptr, ev_cnt = nullptr, ev_join[4] = {nullptr, nullptr, nullptr, nullptr};
+    hipStream_t aux[TK_NAUX] = {};  // side streams: the merge kernels are independent of each other
+    hipEvent_t ev_fork = nullptr, ev_cnt = nullptr, ev_join[TK_NAUX] = {};
     hipStream_t cs_h2d = nullptr, cs_d2h = nullptr;  // copy streams of the host-buffer entry point (created on first use)
     void* stage[2] = {nullptr, nullptr};             // page-locked staging buffers
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
@@ -75,7 +76,7 @@ struct tk_core {
     uint32_t spec_max_len = 0;
     std::mutex mu;
     // workspace
-    Buf text, text_al, tile_sum, wide_ws, scan_sums, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, res, rflag, staging, listB, listC, counters, total, g_id, g_rk, g_nx,
+    Buf text, text_al, tile_sum, wide_ws, scan_sums, row_base, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, res, rflag, staging, listB, listC, counters, total, g_id, g_rk, g_nx,
         g_pv, g_lv, out_tokens, out_tok_off, allowed, tile_np, tile_nt, tile_nmiss, mt_slots, wbin, wave_pieces, deferred, big;
     uint64_t chunk_bytes = 1ull << 30;
     int dbg = 0;
@@ -228,7 +229,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     };
     if (hipSetDevice(device) != hipSuccess) return bail(fail(TK_RUNTIME_ERROR, "hipSetDevice failed"));
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(TK_RUNTIME_ERROR, "hipStreamCreate failed"));
-    for (int i = 0; i < 4; ++i)
+    for (int i = 0; i < TK_NAUX; ++i)
         if (hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess)
             return bail(fail(TK_RUNTIME_ERROR, "hipStreamCreate failed"));
     if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_cnt, hipEventDisableTiming) != hipSuccess)
@@ -309,7 +310,7 @@ extern "C" void tk_destroy(tk_core* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_dec, &c->d_tok, &c->d_lens, &c->d_bsum, &c->d_tboff, &c->d_bytes, &c->d_boff, &c->t_piece, &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2,
-                   &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->text_al, &c->tile_sum, &c->wide_ws, &c->scan_sums, &c->doc_off, &c->brk, &c->docb,
+                   &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->text_al, &c->tile_sum, &c->wide_ws, &c->scan_sums, &c->row_base, &c->doc_off, &c->brk, &c->docb,
                    &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->res, &c->rflag, &c->staging, &c->listB,
                    &c->listC, &c->counters, &c->total, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv, &c->out_tokens,
                    &c->out_tok_off, &c->allowed, &c->tile_np, &c->tile_nt, &c->tile_nmiss, &c->mt_slots, &c->wbin, &c->deferred, &c->big,
@@ -318,7 +319,7 @@ extern "C" void tk_destroy(tk_core* c) {
     if (c->small_in) (void)hipHostFree(c->small_in);
     if (c->small_out) (void)hipHostFree(c->small_out);
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    for (int i = 0; i < 4; ++i) {
+    for (int i = 0; i < TK_NAUX; ++i) {
         if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
         if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
     }
@@ -431,6 +432,7 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
     // kernel writes it: the output region (8-byte aligned inside it).
     uint2* miss = d_out ? (uint2*)(((uintptr_t)d_out + 7) & ~(uintptr_t)7) : nullptr;
     TRY(ensure(c->tile_sum, ntiles + 16));
+    TRY(ensure(c->row_base, (ntiles + 1) * (TKF_CAP / 256) * 8));
     HIPCHK(hipMemsetAsync(c->tile_sum.p, 0xFF, ntiles + 16, s));
     TkFrontOut fo{starts, tile_np, res, c->tile_nmiss.as<uint32_t>(), c->tile_sum.as<uint8_t>(), miss, c->listC.as<uint32_t>(), counters};
     TkMissSlot* mt = nullptr;
@@ -533,16 +535,18 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
                 HIPCHK(hipStreamSynchronize(s));
             }
             HIPCHK(hipEventRecord(c->ev_fork, s));
-            for (int i = 0; i < 4; ++i) HIPCHK(hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
-            static const int order[TK_NBIN] = {8, 7, 6, 5, 0, 1, 4, 3, 2};
-            int slot = 0;
+            for (int i = 0; i < TK_NAUX; ++i) HIPCHK(hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
+            // (longest first; the four lane-group kernels have a stream each -- their run time is the longest piece's chain of
+            // merges --, the five lane-per-piece kernels share two)
+            static const int order[TK_NBIN] = {6, 8, 7, 5, 2, 4, 1, 3, 0};
+            static const int stream_of[TK_NBIN] = {5, 5, 4, 4, 5, 3, 0, 2, 1};
             for (int oi = 0; oi < TK_NBIN; ++oi) {
                 const int b = order[oi];
                 if (n < tk_bin_lo(b) || (small && !small_counts[TK_CNT_BIN0 + b])) continue;
                 const uint64_t most = n / tk_bin_lo(b);
                 const uint32_t* lst = c->listB.as<uint32_t>() + 3 * (uint64_t)bins.off[b];
                 const uint32_t* cp = counters + TK_CNT_BIN0 + b;
-                hipStream_t sa = c->aux[slot++ & 3];
+                hipStream_t sa = c->aux[stream_of[b]];
                 TRY(timed(c, sa, names[b], [&] {
                     switch (b) {
                         case 0: hipLaunchKernelGGL((tk_k_merge_llane<16, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, miss, stg); break;
@@ -557,7 +561,7 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
                     }
                 }));
             }
-            for (int i = 0; i < 4; ++i) {
+            for (int i = 0; i < TK_NAUX; ++i) {
                 HIPCHK(hipEventRecord(c->ev_join[i], c->aux[i]));
                 HIPCHK(hipStreamWaitEvent(s, c->ev_join[i], 0));
             }
@@ -606,14 +610,14 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         hipLaunchKernelGGL(tk_k_sum_pieces, dim3(1), dim3(1024), 0, s, c->wave_pieces.as<uint32_t>(), tf_blocks * 4u, c->total.as<unsigned long long>() + 1);
         TRY(scan_u32(c, s, tile_nt, ntiles, c->total.as<uint64_t>()));
         TRY(timed(c, s, "tk_k_back", [&] {
-            hipLaunchKernelGGL(tk_k_back, dim3(grid_for(ntiles, 4, 16384)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, rflag, stg, d_out, c->big.as<uint32_t>());
+            hipLaunchKernelGGL(tk_k_back, dim3(grid_for(ntiles, 4, 16384)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, rflag, stg, d_out, c->big.as<uint32_t>(), c->row_base.as<uint2>());
         }));
         if (n > TK_BIGCOPY)  // (a token run of TK_BIGCOPY tokens needs at least as many bytes)
             hipLaunchKernelGGL(tk_k_bigcopy, dim3(1024), dim3(256), 0, s, c->big.as<uint32_t>(), stg, d_out);
     }
     if (d_tok_off) {  // (beside the token copy on a second stream it takes as long as behind it: both wait for the same memory system)
         TRY(timed(c, s, "tk_k_docoff", [&] {
-            hipLaunchKernelGGL(tk_k_docoff, dim3(grid_for(n_docs + 1, 4, 8192)), dim3(256), 0, s, n_docs, d_doc_off, base, n, starts, tile_nt, res, rflag, c->total.as<uint64_t>(), tok_base_global, d_tok_off);
+            hipLaunchKernelGGL(tk_k_docoff, dim3(grid_for(n_docs + 1, 4, 8192)), dim3(256), 0, s, n_docs, d_doc_off, base, n, starts, tile_nt, res, rflag, (n > 0 && !single_piece && d_out) ? c->row_base.as<uint2>() : (const uint2*)nullptr, c->total.as<uint64_t>(), tok_base_global, d_tok_off);
         }));
     }
     uint64_t tp[2] = {0, 0};  // tokens, pieces

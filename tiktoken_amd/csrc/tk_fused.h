@@ -1852,7 +1852,7 @@ __global__ __launch_bounds__(256) void tk_k_tile_finish(uint64_t ntiles, const u
 // eight lanes per piece.
 __global__ __launch_bounds__(256) void tk_k_back(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_tb,
                                                  const uint32_t* __restrict__ res, const uint2* __restrict__ rflag, const uint32_t* __restrict__ staging,
-                                                 uint32_t* __restrict__ out, uint32_t* __restrict__ big) {
+                                                 uint32_t* __restrict__ out, uint32_t* __restrict__ big, uint2* __restrict__ row_base) {
     __shared__ uint32_t mlist_sh[4][256 * 3];
     const int lane = threadIdx.x & 63;
     uint32_t* mlist = mlist_sh[threadIdx.x >> 6];
@@ -1862,6 +1862,8 @@ __global__ __launch_bounds__(256) void tk_k_back(uint64_t ntiles, const uint32_t
         uint32_t run = tile_tb[t], fbase = 0;
         for (uint32_t k0 = 0; k0 < np; k0 += 256) {
             const uint32_t k = k0 + lane * 4;
+            // (token offset and rflag position at which this row of 256 pieces starts: tk_k_docoff continues from there)
+            if (lane == 0) row_base[t * (TKF_CAP / 256) + (k0 >> 8)] = make_uint2(run, fbase);
             uint4 t4 = make_uint4(0, 0, 0, 0);
             if (k < np) t4 = *(const uint4*)(res + rb + k);
             uint32_t tk[4] = {t4.x, t4.y, t4.z, t4.w};
@@ -1970,7 +1972,7 @@ __global__ __launch_bounds__(1024) void tk_k_sum_pieces(const uint32_t* __restri
 // tile's pieces before it -- single tokens count one, the others are read from rflag in order.
 __global__ __launch_bounds__(256) void tk_k_docoff(uint64_t n_docs, const uint64_t* __restrict__ doc_off, uint64_t chunk_base, uint64_t n,
                                                     const uint32_t* __restrict__ starts, const uint32_t* __restrict__ tile_tb,
-                                                    const uint32_t* __restrict__ res, const uint2* __restrict__ rflag,
+                                                    const uint32_t* __restrict__ res, const uint2* __restrict__ rflag, const uint2* __restrict__ row_base,
                                                     const uint64_t* __restrict__ total, uint64_t tok_base_global, uint64_t* __restrict__ tok_off) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
@@ -1990,8 +1992,16 @@ __global__ __launch_bounds__(256) void tk_k_docoff(uint64_t n_docs, const uint64
             }
             kp = tk_wave_sum_u32(kp);
             const uint32_t rb = t * TKF_CAP, mb = t * TKF_MISS_CAP;
-            uint32_t sum = 0, fbase = 0;
-            for (uint32_t k0 = 0; k0 < kp; k0 += 64) {
+            // the back kernel has left the token offset and the rflag position of every row of 256 pieces: count on from the row of kp
+            uint64_t row_run = tile_tb[t];
+            uint32_t sum = 0, fbase = 0, kstart = 0;
+            if (row_base && kp >= 256u) {
+                const uint2 rbv = row_base[(uint64_t)t * (TKF_CAP / 256) + (kp >> 8)];
+                row_run = rbv.x;
+                fbase = rbv.y;
+                kstart = kp & ~255u;
+            }
+            for (uint32_t k0 = kstart; k0 < kp; k0 += 64) {
                 const uint32_t k = k0 + lane;
                 const bool flagged = k < kp && (res[rb + k] & TK_RES_FLAG);
                 const uint64_t fm = __ballot(flagged);
@@ -2000,7 +2010,7 @@ __global__ __launch_bounds__(256) void tk_k_docoff(uint64_t n_docs, const uint64
                 fbase += (uint32_t)__popcll(fm);
                 sum += c;
             }
-            v = (uint64_t)tile_tb[t] + tk_wave_sum_u32(sum);
+            v = row_run + tk_wave_sum_u32(sum);
         }
         if (lane == 0) tok_off[d] = tok_base_global + v;
     }
