@@ -1222,20 +1222,23 @@ __global__ __launch_bounds__(256) void tk_k_merge_group(TkTables T, const uint8_
     uint32_t* id = s_id[wid] + grp * NMAX;
     uint32_t* rk = s_rk[wid] + grp * NMAX;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
-    auto local_min = [&]() -> uint64_t {
-        uint64_t m = ~0ull;
+    // lowest rank of the lane's 16 positions and the leftmost position that has it (32-bit compares: a 64-bit (rank, position) key
+    // costs three vector instructions per compare, and this runs after every merge)
+    auto local_min = [&](uint32_t& pos_out) -> uint32_t {
         const uint4* q = (const uint4*)(rk + g * C);
+        uint32_t r[C];
 #pragma unroll
         for (int v = 0; v < C / 4; ++v) {
-            uint4 x = q[v];
-            uint32_t k0 = g * C + v * 4;
-            uint64_t a = ((uint64_t)x.x << 32) | k0, b = ((uint64_t)x.y << 32) | (k0 + 1), c = ((uint64_t)x.z << 32) | (k0 + 2),
-                     d = ((uint64_t)x.w << 32) | (k0 + 3);
-            a = a < b ? a : b;
-            c = c < d ? c : d;
-            a = a < c ? a : c;
-            m = m < a ? m : a;
+            const uint4 x = q[v];
+            r[4 * v] = x.x; r[4 * v + 1] = x.y; r[4 * v + 2] = x.z; r[4 * v + 3] = x.w;
         }
+        uint32_t m = r[0];
+#pragma unroll
+        for (int c = 1; c < C; ++c) m = r[c] < m ? r[c] : m;
+        uint32_t eq = 0;
+#pragma unroll
+        for (int c = 0; c < C; ++c) eq |= (uint32_t)(r[c] == m) << c;
+        pos_out = (uint32_t)(g * C) + (uint32_t)__ffs((int)eq) - 1u;
         return m;
     };
     for (uint32_t e0 = wave * PPW; e0 < count; e0 += nwaves * PPW) {
@@ -1261,18 +1264,24 @@ __global__ __launch_bounds__(256) void tk_k_merge_group(TkTables T, const uint8_
             rk[k] = r;
         }
         __builtin_amdgcn_wave_barrier();
-        uint64_t lk = local_min();
+        uint32_t lpos = 0, lrank = local_min(lpos);
         for (;;) {
-            uint64_t m = lk;
+            // the group's lowest rank, then the leftmost position among the lanes that hold it (leftmost lowest: lib.rs:151,190)
+            uint32_t best = lrank;
 #pragma unroll
             for (int o = G / 2; o > 0; o >>= 1) {
-                uint64_t w = __shfl_xor(m, o, 64);
-                m = w < m ? w : m;
+                const uint32_t w = (uint32_t)__shfl_xor((int)best, o, 64);
+                best = w < best ? w : best;
             }
-            const uint32_t best = (uint32_t)(m >> 32);
             const bool fin = best == TK_RANK_MAX;
             if (__all(fin)) break;
-            const uint32_t bi = (uint32_t)m & (NMAX - 1), ob = bi / C, bl = bi % C;
+            uint32_t bpos = lrank == best ? lpos : 0xFFFFFFFFu;
+#pragma unroll
+            for (int o = G / 2; o > 0; o >>= 1) {
+                const uint32_t w = (uint32_t)__shfl_xor((int)bpos, o, 64);
+                bpos = w < bpos ? w : bpos;
+            }
+            const uint32_t bi = bpos & (NMAX - 1), ob = bi / C, bl = bi % C;
             const uint64_t nbw = __ballot(mask != 0);
             const uint64_t nb = G == 64 ? nbw : ((nbw >> gbase) & ((1ull << (G & 63)) - 1ull));
             const uint32_t my_first = mask ? (uint32_t)(g * C + __ffs((int)mask) - 1) : NONE;
@@ -1330,7 +1339,7 @@ __global__ __launch_bounds__(256) void tk_k_merge_group(TkTables T, const uint8_
                 }
             }
             __builtin_amdgcn_wave_barrier();
-            if (touched) lk = local_min();
+            if (touched) lrank = local_min(lpos);
         }
         const uint32_t mine = __popc(mask);
         uint32_t inc = mine;
