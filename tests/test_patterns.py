@@ -134,6 +134,67 @@ def test_scanners_of_a_variation_equal_regex(name, pat):
         assert sim.piece_ends(blob, off, bits=True)[0].tolist() == ref
 
 
+def _pattern_from(family, contr, ci, digits, suffix, dollar, nl_rule, spell):
+    """A pattern string of the supported family from its parameters (spell: which of the equivalent spellings to use)."""
+    items = sorted(contr)
+    flag = "i" if ci else ""
+    if spell % 3 == 0:
+        singles = "".join(c for c in items if len(c) == 1)
+        alts = ([f"[{singles}]"] if singles else []) + [c for c in items if len(c) == 2]
+        clist = f"'(?{flag}:{'|'.join(alts)})" if alts else ""
+    elif spell % 3 == 1:
+        clist = f"(?{flag}:{'|'.join(chr(39) + c for c in items)})" if items else ""
+    else:
+        clist = "|".join("'" + c for c in items) if not ci else (f"(?i:{'|'.join(chr(39) + c for c in items)})" if items else "")
+    poss = "+" if spell & 4 else ""
+    dig = r"\p{N}+" if digits == 0 else (r"\p{N}" if digits == 1 and spell & 8 else r"\p{N}{1,%d}" % digits)
+    suf = {0: "", 1: r"[\r\n]*", 2: "/*", 3: r"[\r\n/]*"}[suffix]
+    tail = ([r"\s+" + poss + "$"] if dollar else []) + ([r"\s*[\r\n]" + ("+" if spell & 16 else "")] if nl_rule else []) + [r"\s+(?!\S)", r"\s+" if spell & 32 else r"\s"]
+    if family == 0:
+        alts = ([clist] if clist else []) + [r" ?\p{L}+" + poss, r" ?\p{N}+" + poss, r" ?[^\s\p{L}\p{N}]+" + poss] + [t for t in tail if "[\\r\\n]" not in t]
+    elif family == 1:
+        alts = ([clist] if clist else []) + [r"[^\r\n\p{L}\p{N}]?" + poss + r"\p{L}+" + poss, dig, r" ?[^\s\p{L}\p{N}]+" + poss + suf] + tail
+    else:
+        csuf = (f"(?{flag}:{'|'.join(chr(39) + c for c in items)})?" if items else "")
+        w1 = r"[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]*[\p{Ll}\p{Lm}\p{Lo}\p{M}]+" + csuf
+        w2 = r"[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]+[\p{Ll}\p{Lm}\p{Lo}\p{M}]*" + csuf
+        alts = [w1, w2, dig, r" ?[^\s\p{L}\p{N}]+" + suf] + tail
+    return "|".join(alts)
+
+
+def test_generated_patterns_equal_regex():
+    """Patterns generated from random parameters (contraction list, case sensitivity, digit group, suffix set, white-space rules, and the
+    equivalent spellings of each part): whatever the parser accepts must split exactly as Python `regex` does; what it refuses must say
+    why.  (The parser refuses e.g. a one-letter contraction that begins a two-letter one.)"""
+    rng = random.Random(20260921)
+    letters1, letters2 = list("sdmtnxe"), ["ll", "ve", "re", "nt", "em", "dx", "ar"]
+    accepted = refused = 0
+    texts = _texts(99, 500, 0, 60) + ["x'll'LL'nt'em y'S z'T 12345 6 78/\n/ a  \n\n  b   ", "I'ſ 'ſx 'K DON'T don'T He'Ll"]
+    for it in range(60):
+        family = rng.randrange(3)
+        contr = set(rng.sample(letters1, rng.randrange(0, 5))) | set(rng.sample(letters2, rng.randrange(0, 5)))
+        pat = _pattern_from(family, contr, rng.random() < 0.6, rng.choice([0, 1, 1, 2, 3, 3, 5, 12]), rng.choice([0, 1, 1, 2, 3, 3]),
+                            rng.random() < 0.5, rng.random() < 0.75, rng.randrange(64))
+        regex.compile(pat)  # (a well-formed pattern whatever the parser thinks of it)
+        try:
+            sim = h.HostSim(pat, TINY, {})
+        except ValueError as e:
+            refused += 1
+            assert str(e).startswith("unsupported pat_str: ")
+            continue
+        accepted += 1
+        for i in range(0, len(texts), 9):
+            docs = texts[i:i + 9]
+            blob, off = h.pack([d.encode() for d in docs])
+            ref = _ends_regex(pat, docs, off)
+            assert sim.piece_ends(blob, off)[0].tolist() == ref, (pat, docs)
+            assert sim.piece_ends(blob, off, bits=True)[0].tolist() == ref, (pat, docs)
+        t = "".join(texts[:120])
+        blob, off = h.pack([t.encode()])
+        assert sim.piece_ends_tiled(blob, off, 32, 16)[0].tolist() == _ends_regex(pat, [t], off), pat
+    assert accepted >= 25, (accepted, refused)
+
+
 # ---------------------------------------------------------------- on the device
 @pytest.mark.gpu
 @pytest.mark.parametrize("name,pat", VARIANTS, ids=[v[0] for v in VARIANTS])
