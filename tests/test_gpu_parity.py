@@ -292,6 +292,25 @@ def test_megabyte_runs_are_fast(cores, unit):
     assert best < 0.020, f"{unit!r} * 1e6 took {best * 1e3:.1f} ms"
 
 
+@pytest.mark.parametrize("unit,name", [("Ab", "o200k_shaped"), ("x'll", "o200k_shaped"), ("x'll", "cl100k_shaped"), ("a'S b'Ll", "gpt2_shaped"),
+                                        ("x'll\u4e2d'd", "o200k_shaped"), ("1a", "cl100k_shaped")])
+def test_chains_of_uncertain_boundaries_do_not_take_seconds(cores, unit, name):
+    """A megabyte of short pieces without a single certain piece start ("camelCase" chains; contraction chains, where whether 'll ends a
+    piece depends on unbounded left context).  The first kind has certain starts by a rule with context (lower -> upper without an
+    apostrophe near), the second is walked a 4 KiB window at a time (tk_coop_window_walk): 4 ms and 20 ms here; round 1: 6.5 s and 3 s."""
+    import time
+
+    core, C = cores[name], h.c_oracle_for(name)
+    data = (unit * (1_000_000 // len(unit))).encode()
+    want = C.encode_ordinary(data)
+    assert np.array_equal(core._encode_np(data, None), want)
+    t0 = time.perf_counter()
+    got = core._encode_np(data, None)
+    dt = time.perf_counter() - t0
+    assert np.array_equal(got, want)
+    assert dt < 0.15, f"{unit!r}: {dt * 1e3:.1f} ms"
+
+
 @pytest.mark.parametrize("name", h.ENCODING_NAMES)
 def test_long_runs_of_every_kind(cores, name):
     """Documents made of long runs (2..40 KiB) of letters, digits, white space with and without newlines, punctuation, CJK, accented

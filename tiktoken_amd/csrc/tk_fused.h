@@ -284,6 +284,94 @@ __device__ __noinline__ uint64_t tk_coop_piece_end(const TkCoop* Cp, uint64_t p)
     if (e <= p) e = tk_next_char(acc, p);
     return e > Cp->n ? Cp->n : e;
 }
+// A chain of SHORT pieces with uncertain boundaries ("x'llx'll...": whether 'll ends a piece depends on what stands before it, as far
+// back as one cares to look) cannot be cut by any local rule; a tile in such a stretch walks from the last certain start, and piece by
+// piece with the whole workgroup that is 12 us per piece.  This walks a 4 KiB window at a time instead: classes of the window (16 bytes
+// per lane, as everywhere), then every lane evaluates the piece that WOULD start at each of its char starts (tk_piece_end on the LDS
+// copy), then pointer doubling follows the chain from p in twelve steps.  Returns the last position of the chain from p whose piece ends
+// inside the window and before `target` (p itself if its piece does not: the caller evaluates that one by the run queries).
+struct TkWalkLds {
+    uint8_t* raw;       // [TK2_WIN + 16]
+    uint32_t* planes;   // [4 * TK2_PLW]
+    uint32_t* start;    // [TK2_WIN / 32 + 4]
+    uint32_t* hard;     // [TK2_WIN / 32 + 4]
+    uint16_t* jump;     // [TK2_WIN]
+};
+struct TkWalkAcc {  // accessor over the walk's window for ONE evaluation: looking past `lim` (window offset) sets `left` -- the evaluation is
+                    // then dropped, which also bounds its cost (a window of one letter would otherwise be walked to its end from every byte)
+    const uint32_t *planes32, *start32, *hard32;
+    const uint8_t* raw;
+    int64_t base;
+    uint64_t n;
+    uint32_t lim;
+    bool left;
+    __device__ __forceinline__ uint32_t cls(uint64_t pos) {
+        if (pos >= n) return TK_C_END;
+        const int64_t r = (int64_t)pos - base;
+        if (r >= 0 && r < (int64_t)lim) {
+            const uint32_t wi = (uint32_t)r >> 5, b = (uint32_t)r & 31u;
+            if (!((start32[wi] >> b) & 1u)) return (uint32_t)TK_C_CONT;
+            return tk_class_at_lds(planes32, (uint32_t)r) | (((hard32[wi] >> b) & 1u) << 7);
+        }
+        left = true;
+        return TK_C_END;
+    }
+    __device__ __forceinline__ uint32_t byte(uint64_t pos) {
+        const int64_t r = (int64_t)pos - base;
+        if (r >= 0 && r < (int64_t)lim) return raw[r];
+        left = true;
+        return 0;
+    }
+};
+#define TK_WALK_PIECE 256u  // longest piece the window walk follows (longer ones are the business of the run queries)
+__device__ __noinline__ uint64_t tk_coop_window_walk(const TkCoop* Cp, const TkWalkLds* Lp, uint64_t p, uint64_t target) {
+    const TkCoop& C = *Cp;
+    const TkWalkLds& L = *Lp;
+    const uint32_t tid = threadIdx.x;
+    const uint64_t wb = p & ~15ull;
+    const uint64_t g = wb + 16ull * tid;
+    TkChunkMasks mk;
+    tk_coop_chunk(C, (int64_t)g, mk);
+    {
+        constexpr uint32_t HW = TK2_PLW * 2u;  // halfwords per plane
+        uint16_t* p16 = (uint16_t*)L.planes;
+#pragma unroll
+        for (int pl = 0; pl < 4; ++pl) p16[pl * HW + tid] = (uint16_t)mk.p[pl];
+        ((uint16_t*)L.start)[tid] = (uint16_t)mk.start;
+        ((uint16_t*)L.hard)[tid] = (uint16_t)mk.hard;
+        uint4 x = make_uint4(0, 0, 0, 0);
+        if (g < C.n) x = *(const uint4*)(C.text + g);  // (the text is readable 64 bytes past its end)
+        *(uint4*)(L.raw + 16u * tid) = x;
+    }
+    __syncthreads();
+    TkWalkAcc acc{L.planes, L.start, L.hard, L.raw, (int64_t)wb, C.n, (uint32_t)TK2_WIN, false};
+    for (uint32_t j = 0; j < 16u; ++j) {
+        const uint64_t q = g + j;
+        uint32_t v = 16u * tid + j;  // a position the chain cannot leave: no piece start, outside [p, target), or unresolved in this window
+        if (((mk.start >> j) & 1u) && q >= p && q < target && q < C.n) {
+            acc.left = false;
+            acc.lim = v + TK_WALK_PIECE < (uint32_t)TK2_WIN ? v + TK_WALK_PIECE : (uint32_t)TK2_WIN;
+            uint64_t e = tk_piece_end(acc, q, C.pat);
+            if (e <= q) e = tk_next_char(acc, q);
+            if (!acc.left && e < target && e - wb < (uint64_t)TK2_WIN) v = (uint32_t)(e - wb);
+        }
+        L.jump[16u * tid + j] = (uint16_t)v;
+    }
+    __syncthreads();
+    for (int it = 0; it < 12; ++it) {  // jump <- jump o jump
+        uint16_t nv[16];
+#pragma unroll
+        for (int j = 0; j < 16; ++j) nv[j] = L.jump[L.jump[16u * tid + j]];
+        __syncthreads();
+#pragma unroll
+        for (int j = 0; j < 16; ++j) L.jump[16u * tid + j] = nv[j];
+        __syncthreads();
+    }
+    const uint32_t t = L.jump[(uint32_t)(p - wb)];
+    __syncthreads();
+    return wb + t;
+}
+
 // In a run of ASCII digits the pieces of the cl100k / o200k patterns are groups of three from the start of the run (\p{N}{1,3}): a chain
 // that walks such a run towards `target` can jump over the whole groups (a megabyte of digits would otherwise be 350 000 evaluations).
 __device__ __noinline__ uint64_t tk_coop_skip_digit_groups(const TkCoop* Cp, uint64_t p, uint64_t target) {
@@ -413,6 +501,10 @@ __global__ __launch_bounds__(256, SLOW ? 4 : 8) void tk_k_front(TkTables T, cons
     __shared__ uint8_t lastc_own[256];
     __shared__ uint32_t np_sh, nmiss_sh, need_walk, last_end_sh, ncls_sh, nx_sh, ncont_sh;
     __shared__ uint16_t contl_own[SLOW ? TKF_CONT_CAP : 1], stop_own[SLOW ? 256 : 2];
+    // second window of the deferred-tile variant: a stretch of text left of the tile, walked by tk_coop_window_walk
+    __shared__ __attribute__((aligned(16))) uint8_t w2_raw[SLOW ? TK2_WIN + 16 : 16];
+    __shared__ uint32_t w2_planes[SLOW ? 4 * TK2_PLW : 1], w2_start[SLOW ? TK2_WIN / 32 + 4 : 1], w2_hard[SLOW ? TK2_WIN / 32 + 4 : 1];
+    __shared__ uint16_t w2_jump[SLOW ? TK2_WIN : 2];
     __shared__ uint16_t slowl[TKF_SLOW_CAP];  // pieces that leave the window (window positions of their starts)
     __shared__ uint32_t nslow_sh;
     __shared__ uint32_t brkw[TK2_WIN / 32 + 1], ssw[SPEC ? TK2_WIN / 32 + 1 : 1], siw[SPEC ? TK2_WIN / 32 + 1 : 1];
@@ -695,10 +787,18 @@ __global__ __launch_bounds__(256, SLOW ? 4 : 8) void tk_k_front(TkTables T, cons
     // or re-enters the tile, where the lanes' scanners take over through the continuation list.
     auto coop_chain = [&](uint64_t p) {
         if constexpr (SLOW) {
+            const TkWalkLds walk{w2_raw, w2_planes, w2_start, w2_hard, w2_jump};
             for (;;) {
                 uint64_t e = p;
                 if (fam != TK_PAT_R50K && pat.digits() && p < tile_start && (tk_class_byte_slow(&T, text, p, n, brk, coop.ss, coop.si) & 15u) == TK_C_NU)
                     e = tk_coop_skip_digit_groups(&coop, p, tile_start);  // whole three-digit groups left of the tile
+                if (e == p && p + 1024u < tile_start) {  // far left of the tile: a window of pieces per step (nothing of them lies in this tile)
+                    const uint64_t t = tk_coop_window_walk(&coop, &walk, p, tile_start);
+                    if (t != p) {
+                        p = t;
+                        continue;
+                    }
+                }
                 if (e == p) e = tk_coop_piece_end(&coop, p);
                 const uint64_t nx = chain_step(p, e);  // (all threads compute the same; the bit and last_end updates are idempotent)
                 if (nx == TKF_CHAIN_END) return;
