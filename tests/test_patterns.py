@@ -230,3 +230,45 @@ def test_gpu_encode_with_a_variation_equals_the_python_restatement():
         for piece in regex.findall(QWEN2, t):
             want += po.byte_pair_encode(piece.encode(), ranks)
         assert toks[int(toff[i]):int(toff[i + 1])].tolist() == want, t
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("pat", [QWEN2, O200K.replace("{1,3}", "{1,2}"), R50K.replace("[sdmt]|ll|ve|re", "[st]|ve|nt|em")], ids=["qwen2", "o200k-2-digits", "r50k-contractions"])
+def test_gpu_variation_with_special_tokens(pat):
+    """A pattern outside the stock three together with special tokens (the generic kernels' special-token instance): the text is cut at
+    the allowed specials (each a piece of its own, lib.rs:375-442), `regex` splits the stretches between them, and the ids are the
+    specials' ids or, with a byte vocabulary, the bytes."""
+    from tiktoken_amd import CoreBPE
+
+    specials = {"<|endoftext|>": 300, "<|im_start|>": 301, "<|im_end|>": 302}
+    core = CoreBPE(TINY, specials, pat)
+    rng = random.Random(8)
+    texts = []
+    for t in _texts(21, 600, 0, 80):
+        parts = []
+        for ch in t:
+            parts.append(ch)
+            if rng.random() < 0.04:
+                parts.append(rng.choice(list(specials) + ["<|endoftext", "<|im_"]))
+        texts.append("".join(parts))
+    allowed = {"<|endoftext|>", "<|im_start|>"}  # (<|im_end|> stays ordinary text)
+    sp = regex.compile("|".join(regex.escape(x) for x in sorted(allowed, key=len, reverse=True)))
+    blob, off = h.pack([t.encode() for t in texts])
+    want_ends, want_tokens = [], []
+    for d, t in enumerate(texts):
+        pos, byte_pos = 0, int(off[d])
+        for m in list(sp.finditer(t)) + [None]:
+            seg = t[pos:m.start()] if m else t[pos:]
+            for piece in regex.findall(pat, seg):
+                byte_pos += len(piece.encode())
+                want_ends.append(byte_pos)
+                want_tokens += list(piece.encode())
+            if m:
+                byte_pos += len(m.group().encode())
+                want_ends.append(byte_pos)
+                want_tokens.append(specials[m.group()])
+                pos = m.end()
+    starts = core.pretokenize_packed(blob, off, allowed)
+    assert starts[1:].tolist() == want_ends
+    toks, _ = core.encode_batch_packed(blob, off, allowed)
+    assert toks.tolist() == want_tokens
