@@ -156,6 +156,46 @@ ADV = list("aAsStTlLvVeErRdDmMxZ") + ["ſ", "中", "́", "ʰ", "ǅ", "1", "2", "
                                         " world", "ing", "tion", "<|", "|>", "<|endoftext|>"]
 
 
+# Units of the fuzzed documents (tools/gpu_fuzz.py, test_fuzzed_awkward_documents): runs of one class, chains of uncertain boundaries,
+# contractions in every case, digits, white space with and without newlines, CJK, combining marks, special tokens, near-specials.
+FUZZ_UNITS = ["x", "X", "Ab", "aB", "x'll", "X'LL", "y's", "'t", "'", "''", "1", "12", "1234567", " ", "  ", "\n", "\r\n", " \n", "\t", "\u00a0",
+              "\u3000", "\u4e2d", "\u4e2d\u6587", "\u00e9", "\u00c9", "\u0301", "a\u0301", "\u01c5", "\u02b0", "!", "...", "/", "//", "!/\n", "-", "=",
+              "\U0001F600", "\u017f", "\u212a", "hello", "World", " the", " of", ",", ".", "https://example.com/a/b?c=d", "foo_bar",
+              "camelCaseWord", "x'sS", "don't", "DON'T", "I'll", " a's", "<|endoftext|>", "<|endofprompt|>", "<|endoftext", "\u0661\u0662\u0663",
+              "\u00b2", "\x7f", "\u200b", "\u2028", "\u1680"]
+
+
+def fuzz_doc(rng) -> str:
+    """One awkward document (rng: random.Random)."""
+    r = rng.random()
+    if r < 0.05:
+        return ""
+    if r < 0.15:
+        return rng.choice(FUZZ_UNITS)
+    parts, size, target = [], 0, int(rng.lognormvariate(8.5, 1.6))
+    while size < target:
+        u = rng.choice(FUZZ_UNITS)
+        k = rng.choice([1, 1, 1, 2, 3, 5, 17, 64, 300, 2000, 20000]) if rng.random() < 0.3 else 1
+        seg = u * k
+        parts.append(seg)
+        size += len(seg)
+        if rng.random() < 0.5:
+            parts.append(rng.choice([" ", "", "", "\n"]))
+    return "".join(parts)
+
+
+def fuzz_batch(seed: int, nbytes: int) -> list[bytes]:
+    import random
+
+    rng = random.Random(seed)
+    docs, total = [], 0
+    while total < nbytes:
+        d = fuzz_doc(rng).encode()
+        docs.append(d)
+        total += len(d)
+    return docs
+
+
 def pack(docs: list[bytes]):
     blob = np.frombuffer(b"".join(docs) + b"\0" * 64, np.uint8)
     off = np.zeros(len(docs) + 1, np.uint64)

@@ -479,3 +479,36 @@ def test_hello_world_latency():
     p10, med = ts[len(ts) // 10] / 1e3, ts[len(ts) // 2] / 1e3
     print(f"Encoding.encode('hello world'): p10 {p10:.1f} us, median {med:.1f} us")
     assert p10 <= 33.0 and med <= 48.0, (p10, med)
+
+
+@pytest.mark.parametrize("name", h.ENCODING_NAMES)
+def test_fuzzed_awkward_documents(cores, name):
+    """Random batches of awkward documents (helpers.fuzz_batch; tools/gpu_fuzz.py runs many more seeds), with and without special tokens,
+    every token against the oracle."""
+    import zlib
+
+    core, C = cores[name], h.c_oracle_for(name)
+    for seed in (1, 2):
+        blob, off = h.pack(h.fuzz_batch(zlib.crc32(name.encode()) + seed, 6 << 20))
+        for allowed in (None, "all"):
+            toks, toff = core.encode_batch_packed(blob, off, allowed)
+            rt, ro = C.encode_batch(blob, off, allowed, 8)
+            assert np.array_equal(toff, ro), (seed, allowed)
+            assert np.array_equal(toks, rt), (seed, allowed)
+
+
+@pytest.mark.parametrize("name,word", [("o200k_shaped", " a's"), ("cl100k_shaped", " a's"), ("gpt2_shaped", " a's"), ("o200k_shaped", " I'll")])
+def test_full_continuation_list_and_a_piece_that_leaves_the_window(cores, name, word):
+    """A tile with more scan chains that go on after an uncertain boundary (" a's": whether 's ends the piece is not known from the class
+    pair) than the continuation list holds, in which a white-space piece needs text beyond the window ("\\n" + 6000 spaces: `\\s*[\\r\\n]+`
+    ends at the last newline of the run, which only the workgroup-wide scanner can know) and ends inside the tile again.  Found by
+    tools/gpu_fuzz.py: the chain's re-entry had no room on the list ("scanner list overflow"); now the workgroup walks on itself."""
+    core, C = cores[name], h.c_oracle_for(name)
+    docs = []
+    for k in range(0, 1100, 37):
+        docs.append((word * k + "\n" + " " * 6000 + "x" + word * 900 + " \n" + "\t" * 5000 + "\n!").encode())
+    blob, off = h.pack(docs)
+    toks, toff = core.encode_batch_packed(blob, off)
+    rt, ro = C.encode_batch(blob, off, None, 8)
+    assert np.array_equal(toff, ro)
+    assert np.array_equal(toks, rt)

@@ -37,7 +37,7 @@
 #define TK_BIGCOPY 4096      // token runs from this length on are copied by tk_k_bigcopy
 #define TK_BIGCOPY_CAP 1024  // entries of its list
 #define TKF_CHAIN_END 0xFFFFFFFFFFFFFFFFull
-#define TKF_CONT_CAP 256       // continuation list of the scanners: deferred-tile variant (own array)
+#define TKF_CONT_CAP 768       // continuation list of the scanners: deferred-tile variant (own array)
 #define TKF_CONT_CAP_FAST 768  // ... one-workgroup-per-tile variant (the list lives in the byte table's LDS, dead after phase B)
 #define TKF_SLOW_CAP 8    // pieces of one tile that leave its window
 #define TKF_BATCH 960  // pieces per probe batch of the front kernel (the class lists hold 1024 entries, their packed counter 1023)
@@ -802,19 +802,20 @@ __global__ __launch_bounds__(256, SLOW ? 4 : 8) void tk_k_front(TkTables T, cons
                 if (e == p) e = tk_coop_piece_end(&coop, p);
                 const uint64_t nx = chain_step(p, e);  // (all threads compute the same; the bit and last_end updates are idempotent)
                 if (nx == TKF_CHAIN_END) return;
-                if (nx >= tile_start) {  // inside the tile (and the window) again
+                if (nx >= tile_start) {  // inside the tile (and the window) again: the lanes' scanners take over from the continuation list
                     __syncthreads();
-                    if (tid == 0) {
-                        const uint32_t at = ncont_sh;
-                        if (at < CONT_CAP) {
-                            contl[at] = (uint16_t)(nx - (uint64_t)base);
-                            ncont_sh = at + 1;
-                        } else {
-                            atomicOr(&out.counters[TK_CNT_ERR], 2u);
+                    const bool room = ncont_sh < CONT_CAP;
+                    __syncthreads();
+                    if (room) {
+                        if (tid == 0) {
+                            contl[ncont_sh] = (uint16_t)(nx - (uint64_t)base);
+                            ncont_sh = ncont_sh + 1;
                         }
+                        __syncthreads();
+                        return;
                     }
-                    __syncthreads();
-                    return;
+                    // (the list is full -- a tile of nothing but uncertain boundaries: the workgroup walks on itself; chain_step records
+                    // the boundaries and ends the chain at the next certain start or at the end of the tile)
                 }
                 p = nx;
             }
