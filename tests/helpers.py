@@ -214,9 +214,10 @@ def sim_lib():
         d = os.path.join(ROOT, "tests", "hostsim")
         so = os.path.join(d, "libtk_hostsim.so")
         srcs = [os.path.join(d, "tk_hostsim.cpp")] + [os.path.join(ROOT, "tiktoken_amd", "csrc", f)
-                                                       for f in ("tk_tables.cpp", "tk_pattern.cpp", "tk_device.h", "tk_common.h", "tk_tables.h", "tk_chunk.h")]
+                                                       for f in ("tk_tables.cpp", "tk_pattern.cpp", "tk_regex.cpp", "tk_device.h", "tk_common.h", "tk_tables.h", "tk_chunk.h", "tk_regex.h",
+                                                                 "tk_regex_split.h", "tk_regex_host.h")]
         if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", srcs[0], srcs[1], srcs[2], "-o", so])
+            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", srcs[0], srcs[1], srcs[2], srcs[3], "-o", so])
         L = ctypes.CDLL(so)
         vp, u64 = ctypes.c_void_p, ctypes.c_uint64
         L.tks_create.restype = vp
@@ -239,6 +240,13 @@ def sim_lib():
         L.tks_chunk_check.argtypes = [vp, vp, u64, vp, u64, vp, vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
         L.tks_encode_piece.restype = ctypes.c_int64
         L.tks_encode_piece.argtypes = [vp, vp, ctypes.c_uint32, vp]
+        L.tks_rx_compile.restype = vp
+        L.tks_rx_compile.argtypes = [ctypes.c_char_p, ctypes.c_char_p, u64]
+        L.tks_rx_free.argtypes = [vp]
+        L.tks_rx_size.restype = u64
+        L.tks_rx_size.argtypes = [vp]
+        L.tks_rx_split.restype = u64
+        L.tks_rx_split.argtypes = [vp, vp, u64, vp, u64, vp, vp, u64, ctypes.c_int, vp, vp]
         _sim_lib = L
     return _sim_lib
 
@@ -322,3 +330,38 @@ def dev_u64(ptr: int, n: int) -> np.ndarray:
     import torch
 
     return torch.as_tensor(_DevArray(ptr, n, "<i8"), device="cuda").cpu().numpy().astype(np.uint64)
+
+
+class RxSim:
+    """The generic pat_str engine on the CPU (tests/hostsim): the compiler of tk_regex.cpp and the lanes of the two split kernels."""
+
+    def __init__(self, pat_str: str):
+        L = sim_lib()
+        err = ctypes.create_string_buffer(512)
+        self._h = L.tks_rx_compile(pat_str.encode(), err, 512)
+        if not self._h:
+            raise ValueError(err.value.decode())
+        self._L = L
+        self.size = int(L.tks_rx_size(self._h))
+        self.stats = (0, 0)
+
+    def __del__(self):
+        if getattr(self, "_h", None):
+            self._L.tks_rx_free(self._h)
+            self._h = None
+
+    def split(self, docs: list[bytes], specials: list[tuple[int, int]] = (), speculate: bool = True) -> list[int]:
+        """Piece starts (byte offsets into the packed batch) of the documents; specials: (offset, length) of allowed special tokens."""
+        blob, off = pack(docs)
+        n = len(blob)
+        starts = np.zeros(n + 1, np.uint8)
+        sa = np.array([a for a, _ in specials], np.uint64)
+        sl = np.array([b for _, b in specials], np.uint64)
+        stats = np.zeros(2, np.uint64)
+        buf = np.ascontiguousarray(blob) if n else np.zeros(1, np.uint8)
+        rc = self._L.tks_rx_split(self._h, buf.ctypes.data, n, off.ctypes.data, len(off) - 1, sa.ctypes.data if len(sa) else None,
+                                  sl.ctypes.data if len(sl) else None, len(sa), 1 if speculate else 0, starts.ctypes.data, stats.ctypes.data)
+        self.stats = (int(stats[0]), int(stats[1]))
+        if rc:
+            raise RuntimeError(f"split error {rc & 255} at byte {rc >> 8}")
+        return np.flatnonzero(starts[:n]).tolist()

@@ -11,7 +11,11 @@
 #include <string>
 #include <vector>
 
+static uint64_t g_rx_matches = 0;
+#define TK_RX_ON_MATCH() (++g_rx_matches)
 #include "../../tiktoken_amd/csrc/tk_chunk.h"
+#include "../../tiktoken_amd/csrc/tk_regex_host.h"
+#include "../../tiktoken_amd/csrc/tk_regex_split.h"
 #include "../../tiktoken_amd/csrc/tk_device.h"
 #include "../../tiktoken_amd/csrc/tk_tables.h"
 #include "../../tiktoken_amd/csrc/tk_unicode_tables.inc"
@@ -608,6 +612,60 @@ int64_t tks_encode_piece(void* p, const uint8_t* piece, uint32_t len, uint32_t* 
     }
     for (size_t k = 0; k < ids.size(); ++k) out[k] = ids[k];
     return (int64_t)ids.size();
+}
+
+// ---- the generic pat_str engine (tk_regex.cpp, tk_regex_split.h): compile, then the two kernels' lanes one after the other
+void* tks_rx_compile(const char* pat_str, char* err, uint64_t errcap) {
+    TkRxCompiled* c = new TkRxCompiled();
+    const std::string e = tk_rx_compile(pat_str, c);
+    if (!e.empty()) {
+        strncpy(err, e.c_str(), errcap - 1);
+        err[errcap - 1] = 0;
+        delete c;
+        return nullptr;
+    }
+    return c;
+}
+void tks_rx_free(void* p) { delete (TkRxCompiled*)p; }
+uint64_t tks_rx_size(void* p) { return ((TkRxCompiled*)p)->ins.size(); }
+// Piece starts of a packed batch: a byte per position (1 = start).  spec_at / spec_len: occurrences of allowed special tokens (sorted).
+// speculate = 0: every document walked by the matcher alone.  stats[0] = matcher runs of the speculative pass, [1] = of the resolving pass.
+// Returns 0, or error bits | position << 8.
+uint64_t tks_rx_split(void* p, const uint8_t* text_in, uint64_t n, const uint64_t* doc_off, uint64_t n_docs, const uint64_t* spec_at,
+                      const uint64_t* spec_len, uint64_t n_spec, int speculate, uint8_t* starts, uint64_t* stats) {
+    const TkRxCompiled* c = (const TkRxCompiled*)p;
+    const TkRxProg P = c->view();
+    std::vector<uint8_t> text(text_in, text_in + n);
+    text.resize(n + 64, 0);
+    const uint64_t nw = (n + 31) / 32 + 2;
+    std::vector<uint32_t> brk(nw, 0), ss(nw, 0), si(nw, 0), spec(nw, 0), gst(nw, 0);
+    auto setb = [](std::vector<uint32_t>& v, uint64_t q) { v[q >> 5] |= 1u << (q & 31); };
+    for (uint64_t d = 0; d < n_docs; ++d)
+        if (doc_off[d] < n) setb(brk, doc_off[d]);
+    for (uint64_t k = 0; k < n_spec; ++k) {
+        setb(ss, spec_at[k]);
+        setb(brk, spec_at[k]);
+        for (uint64_t j = spec_at[k] + 1; j < spec_at[k] + spec_len[k]; ++j) setb(si, j);
+        if (spec_at[k] + spec_len[k] < n) setb(brk, spec_at[k] + spec_len[k]);
+    }
+    TkRxText t{text.data(), (uint32_t)n, brk.data(), n_spec ? ss.data() : nullptr, n_spec ? si.data() : nullptr, 0xFFFFFFFFu, false};
+    const uint32_t nseg = (uint32_t)((n + TK_RX_SEG - 1) / TK_RX_SEG);
+    std::vector<uint32_t> xexit(nseg + 1, TK_RX_UNKNOWN);
+    g_rx_matches = 0;
+    if (speculate)
+        for (uint32_t k = 0; k < nseg; ++k) tk_rx_speculate_lane(P, t, k, spec.data(), xexit.data());
+    stats[0] = g_rx_matches;
+    g_rx_matches = 0;
+    uint64_t rc = 0;
+    for (uint64_t d = 0; d < n_docs && !rc; ++d) {
+        uint32_t err_pos = 0;
+        const uint32_t e = tk_rx_resolve_lane(P, t, (uint32_t)doc_off[d], (uint32_t)doc_off[d + 1], speculate ? spec.data() : nullptr, xexit.data(),
+                                              [&](uint32_t w, uint32_t bits) { gst[w] |= bits; }, &err_pos);
+        if (e) rc = e | ((uint64_t)err_pos << 8);
+    }
+    stats[1] = g_rx_matches;
+    for (uint64_t i = 0; i < n; ++i) starts[i] = (gst[i >> 5] >> (i & 31)) & 1u;
+    return rc;
 }
 
 }  // extern "C"

@@ -1,0 +1,137 @@
+"""The generic pat_str engine (tiktoken_amd/csrc/tk_regex.cpp, tk_regex.h, tk_regex_split.h) on the CPU: the compiler and the very code
+the two split kernels run per lane (tests/hostsim), against Python `regex` -- the engine the golden fixtures were made with
+(tools/gen_golden.py; reference tiktoken/core.py:395-404 splits with it too).  The GPU side is tests/test_gpu_regex.py."""
+import random
+
+import pytest
+import regex
+
+import helpers as h
+
+# (pattern for the engine, the same for Python `regex` where the dialects differ: `$` is end-of-text only in fancy-regex / Rust)
+PATTERNS = [
+    (h.PAT_STR[0], None),
+    (h.PAT_STR[1], None),
+    (h.PAT_STR[2], None),
+    # GPT-2's original spelling, Llama-3 / Qwen2 style variations
+    (r"'s|'t|'re|'ve|'m|'ll|'d| ?[\p{L}]+| ?[\p{N}]+| ?[^\s\p{L}\p{N}]+|\s+(?!\S)|\s+", None),
+    (r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+", None),
+    # outside the three scanner families
+    (r"\w+|[^\w\s]+|\s+", None),
+    (r"\p{Lu}?\p{Ll}+|\p{Lu}+(?!\p{Ll})|\d{1,3}|[^\s\p{L}\d]+|\s+|.", r"\p{Lu}?\p{Ll}+|\p{Lu}+(?!\p{Ll})|\d{1,3}|[^\s\p{L}\d]+|\s+|(?s:.)"),
+    (r"[A-Za-z]+|[0-9]{2}|[0-9]|\s+?|[^A-Za-z0-9\s]++|.", r"[A-Za-z]+|[0-9]{2}|[0-9]|\s+?|[^A-Za-z0-9\s]++|(?s:.)"),
+    (r"(?:ab)+|a|b|(?>x+)y|x|[^abx]+", None),
+    (r" ?\p{L}+(?='s)|'s|(?i)don't|[一-鿿]{1,2}|\P{L}", None),
+    (r"\s+$|\s*\n|[^\S\n]+(?=\S)|\S{1,5}?(?=\s|$)|\S{1,5}", r"\s+\Z|\s*\n|[^\S\n]+(?=\S)|\S{1,5}?(?=\s|\Z)|\S{1,5}"),
+    (r"(?s).{1,7}", None),
+    (r"^\p{L}|\p{L}{2,}|(?i:k+|s+)|\pN+|[\s\S]", r"\A\p{L}|\p{L}{2,}|(?i:k+|s+)|\pN+|[\s\S]"),
+    (r"(?:\p{L}\p{M}*)+|\p{Nd}+(?:[.,]\p{Nd}+)*|[^\p{L}\p{M}\p{Nd}]", None),
+]
+
+
+def py_starts(pat: str, text: str) -> list[int]:
+    """Byte offsets of the pieces of `text`; raises if they do not cover it."""
+    out, at, b = [], 0, 0
+    for m in regex.finditer(pat, text):
+        if m.start() != at or m.end() == m.start():
+            raise LookupError(at)
+        out.append(b)
+        b += len(m.group().encode())
+        at = m.end()
+    if at != len(text):
+        raise LookupError(at)
+    return out
+
+
+def random_text(rng: random.Random, n: int) -> str:
+    alpha = h.ADV + ["k", "K", "s", "S", "K", "ſ", "ab", "x", "y", "don't", "DON'T", "中", "文", ".", ",", "3.14", "'s", "_", "\n\n", "  "]
+    return "".join(rng.choice(alpha) for _ in range(n))
+
+
+@pytest.mark.parametrize("idx", range(len(PATTERNS)))
+def test_split_equals_python_regex(idx):
+    pat, py = PATTERNS[idx]
+    py = py or pat
+    rx = h.RxSim(pat)
+    rng = random.Random(idx)
+    docs = [random_text(rng, rng.choice([0, 1, 2, 5, 30, 300, 3000])) for _ in range(150)]
+    docs += [h.fuzz_doc(rng)[:20000] for _ in range(40)]
+    want, base, ok_docs = [], 0, []
+    for d in docs:
+        try:
+            st = py_starts(py, d)
+        except LookupError:
+            continue  # (a text this pattern does not cover: below)
+        ok_docs.append(d.encode())
+        want += [base + s for s in st]
+        base += len(ok_docs[-1])
+    assert len(ok_docs) > 20
+    assert rx.split(ok_docs, speculate=False) == want
+    assert rx.split(ok_docs, speculate=True) == want
+
+
+def test_long_runs_and_speculation_work():
+    """Megabyte-scale documents: the speculative pass does the matching (the resolving lane runs the matcher a handful of times), a run
+    that is one piece costs one scan, and the result is the sequential one."""
+    rx = h.RxSim(PATTERNS[6][0])
+    rng = random.Random(7)
+    doc = "".join(rng.choice(["hello ", "World", " 12345", "\n", "x" * 3000, " " * 700, "中文", "é", "...", "CamelCase"]) for _ in range(60000))
+    want = py_starts(PATTERNS[6][1], doc)
+    got = rx.split([doc.encode()], speculate=True)
+    assert got == want
+    spec_runs, resolve_runs = rx.stats
+    assert resolve_runs < len(want) // 50, (resolve_runs, len(want))
+    assert rx.split([doc.encode()], speculate=False) == want
+    one = ("y" * 3_000_000).encode()
+    assert rx.split([one, one[:5000]]) == [0, 3_000_000]
+    assert rx.stats[0] < 3 * 3_000_000 // 1024 + 10  # (lanes inside the run give up at once)
+
+
+def test_special_tokens_cut_the_haystack():
+    pat = PATTERNS[2][0]
+    rx = h.RxSim(pat)
+    sp = "<|endoftext|>"
+    parts = ["Hello  ", sp, "world \n ", sp, sp, " x  "]
+    text = "".join(parts)
+    want, specials, at = [], [], 0
+    for part in parts:
+        if part == sp:
+            want.append(at)
+            specials.append((at, len(sp)))
+        else:
+            want += [at + s for s in py_starts(pat, part)]
+        at += len(part.encode())
+    for spec in (False, True):
+        assert rx.split([text.encode()], specials, speculate=spec) == want
+    big = ("lorem ipsum " * 300 + sp) * 20
+    specials = [(m.start(), len(sp)) for m in regex.finditer(regex.escape(sp), big)]
+    want, at = [], 0
+    for part in regex.split("(" + regex.escape(sp) + ")", big):
+        if part == sp:
+            want.append(at)
+        elif part:
+            want += [at + s for s in py_starts(pat, part)]
+        at += len(part)
+    assert rx.split([big.encode()], specials) == want
+
+
+def test_gaps_and_errors_are_loud():
+    rx = h.RxSim(r"\w+|\s+")
+    assert rx.split([b"hello world"]) == [0, 5, 6]
+    with pytest.raises(RuntimeError, match="error 4 at byte 5"):
+        rx.split([b"hello, world"])
+    rx = h.RxSim(r"(?:ab)*c|a|b")  # a repeated group needs a frame per repetition: bounded stack, loud failure
+    assert rx.split([b"ababc" * 3]) == [0, 5, 10]
+    with pytest.raises(RuntimeError, match="error 8"):
+        rx.split([b"ab" * 200])
+
+
+@pytest.mark.parametrize("pat,why", [
+    (r"(?<=a)b|.", "look-behind"), (r"\bfoo|.", "look-behind"), (r"(a)\1|.", "back-references"), (r"a*", "empty string"),
+    (r"(?:a*)+|.", "empty string"), (r"\p{Han}+|.", "General_Category"), (r"[a-z&&[^b]]|.", "set operations"), (r"(?m)^a|.", "(?m)"),
+    (r"(?i)é|.", "non-ASCII cased"), (r"[[:alpha:]]|.", "POSIX"), (r"(a|b", "unterminated group"), (r"a)|b", "unbalanced"),
+    (r"x{3,2}|.", "out of order"), (r"a**|.", "quantifier behind"), (r"[z-a]|.", "out of order"), (r"(?=a)|.", "empty string"),
+])
+def test_unsupported_patterns_say_why(pat, why):
+    with pytest.raises(ValueError, match=regex.escape(why)):
+        h.RxSim(pat)

@@ -1,0 +1,689 @@
+// pat_str -> program of the generic engine (tk_regex.h).  Reference: Regex::new(pattern) of fancy-regex, src/lib.rs:623 -- a pattern
+// outside the three scanner families of tk_pattern.cpp is no longer refused: it is parsed here (the syntax fancy-regex and the Rust
+// `regex` crate share with Python `regex`), compiled to a backtracking program and run on the GPU.
+//
+// Supported: literals, `.`, classes [...] with ranges / escapes / negation, \d \s \w \D \S \W, \p{..} \P{..} for General_Category values,
+// the escapes \n \r \t \f \v \xHH \x{H..} \uHHHH \u{H..} \UHHHHHHHH, alternation, groups (capturing ones are plain groups: a split pattern
+// has no use for captures), (?: ) (?i: ) (?s: ) (?i) (?s) (?-i), atomic groups (?> ), look-ahead (?= ) (?! ), the quantifiers ? * + {m} {m,}
+// {m,n} in their greedy, lazy (?) and possessive (+) forms, ^ \A $ \z.  Refused, with the reason: look-behind, \b \B, back-references,
+// (?m) (?x), class set operations (&& --), POSIX classes, script / binary properties other than the above, case-insensitive matching of
+// non-ASCII cased letters, a pattern (or a repeated group) that can match the empty string.
+#include "tk_regex.h"
+
+#include <string.h>
+
+#include <string>
+#include <utility>
+#include <vector>
+
+#include "tk_regex_host.h"
+#include "tk_regex_props.inc"
+
+namespace {
+
+const char* const GC_NAMES[30] = {"Lu", "Ll", "Lt", "Lm", "Lo", "Mn", "Mc", "Me", "Nd", "Nl", "No", "Pc", "Pd", "Ps", "Pe",
+                                  "Pi", "Pf", "Po", "Sm", "Sc", "Sk", "So", "Zs", "Zl", "Zp", "Cc", "Cf", "Cs", "Co", "Cn"};
+
+uint32_t prop_of(uint32_t cp) { return tk_rx_stage2[(uint32_t)tk_rx_stage1[cp >> 8] * 256u + (cp & 255u)]; }
+
+struct CharSet {
+    bool neg = false;
+    uint32_t gcmask = 0, flags = 0;  // flags: 0x20 \s, 0x40 \w
+    bool comp = false;               // one complemented term: \S \D \W \P{..} inside a class
+    uint32_t cgcmask = 0, cflags = 0;
+    std::vector<std::pair<uint32_t, uint32_t>> ranges;
+    bool member(uint32_t cp) const {
+        const uint32_t pr = prop_of(cp);
+        bool in = ((gcmask >> (pr & 31u)) & 1u) || (pr & flags & 0x60u);
+        if (!in && comp) in = !(((cgcmask >> (pr & 31u)) & 1u) || (pr & cflags & 0x60u));
+        for (size_t i = 0; i < ranges.size() && !in; ++i) in = cp >= ranges[i].first && cp <= ranges[i].second;
+        return in != neg;
+    }
+};
+
+struct Node {
+    enum Kind { EMPTY, SET, CAT, ALT, REPEAT, ATOMIC, LOOK, START, END } kind = EMPTY;
+    int set = -1;
+    std::vector<int> kids;
+    uint32_t mn = 0, mx = 0;
+    int mode = TK_RX_GREEDY;
+    bool neg = false;
+};
+
+struct Flags {
+    bool ci = false, dotall = false;
+};
+
+struct Parser {
+    std::vector<uint32_t> s;  // the pattern as code points
+    size_t i = 0;
+    std::vector<Node> nodes;
+    std::vector<CharSet> sets;
+    std::string err;
+
+    bool fail(const std::string& m) {
+        if (err.empty()) err = m + " (at offset " + std::to_string(i) + " of the pattern)";
+        return false;
+    }
+    bool more() const { return i < s.size(); }
+    uint32_t peek(size_t k = 0) const { return i + k < s.size() ? s[i + k] : 0u; }
+    int add(const Node& n) {
+        nodes.push_back(n);
+        return (int)nodes.size() - 1;
+    }
+    int add_set(const CharSet& c) {
+        sets.push_back(c);
+        Node n;
+        n.kind = Node::SET;
+        n.set = (int)sets.size() - 1;
+        return add(n);
+    }
+
+    // ---- sets
+    bool add_char(CharSet& c, uint32_t cp, bool ci) {
+        c.ranges.push_back({cp, cp});
+        if (!ci) return true;
+        if (cp < 128u) {
+            if ((cp >= 'a' && cp <= 'z') || (cp >= 'A' && cp <= 'Z')) c.ranges.push_back({cp ^ 0x20u, cp ^ 0x20u});
+            // simple case folding reaches two letters beyond ASCII: U+017F (long s) folds to s, U+212A (Kelvin sign) to k
+            if ((cp | 0x20u) == 's') c.ranges.push_back({0x17Fu, 0x17Fu});
+            if ((cp | 0x20u) == 'k') c.ranges.push_back({0x212Au, 0x212Au});
+            return true;
+        }
+        if (cp == 0x17Fu) {
+            c.ranges.push_back({'s', 's'});
+            c.ranges.push_back({'S', 'S'});
+            return true;
+        }
+        if (cp == 0x212Au) {
+            c.ranges.push_back({'k', 'k'});
+            c.ranges.push_back({'K', 'K'});
+            return true;
+        }
+        const uint32_t gc = prop_of(cp) & 31u;
+        if (gc <= 2u) return fail("case-insensitive matching of a non-ASCII cased letter is not supported");
+        return true;
+    }
+    bool add_range(CharSet& c, uint32_t lo, uint32_t hi, bool ci) {
+        if (lo > hi) return fail("class range out of order");
+        if (!ci) {
+            c.ranges.push_back({lo, hi});
+            return true;
+        }
+        // the ASCII part is folded char by char; beyond ASCII a range is taken as it is when it holds no cased letter
+        for (uint32_t cp = lo; cp <= hi && cp < 128u; ++cp)
+            if (!add_char(c, cp, true)) return false;
+        if (hi >= 128u) {
+            if (hi > 0x10FFFFu) return fail("class range beyond U+10FFFF");
+            const uint32_t from = lo < 128u ? 128u : lo;
+            for (uint32_t cp = from; cp <= hi; ++cp)
+                if ((prop_of(cp) & 31u) <= 2u && cp != 0x17Fu && cp != 0x212Au)
+                    return fail("case-insensitive class range with non-ASCII cased letters is not supported");
+            c.ranges.push_back({from, hi});
+            if (from <= 0x17Fu && hi >= 0x17Fu) add_char(c, 0x17Fu, true);
+            if (from <= 0x212Au && hi >= 0x212Au) add_char(c, 0x212Au, true);
+        }
+        return true;
+    }
+    bool hexval(uint32_t ch, uint32_t* v) {
+        if (ch >= '0' && ch <= '9') *v = ch - '0';
+        else if (ch >= 'a' && ch <= 'f') *v = ch - 'a' + 10;
+        else if (ch >= 'A' && ch <= 'F') *v = ch - 'A' + 10;
+        else return false;
+        return true;
+    }
+    bool hex_fixed(int digits, uint32_t* cp) {
+        uint32_t v = 0, d;
+        for (int k = 0; k < digits; ++k) {
+            if (!more() || !hexval(peek(), &d)) return fail("bad hexadecimal escape");
+            v = v * 16 + d;
+            ++i;
+        }
+        *cp = v;
+        return true;
+    }
+    bool hex_braced(uint32_t* cp) {  // {H..}
+        ++i;
+        uint32_t v = 0, d;
+        int k = 0;
+        while (more() && peek() != '}') {
+            if (!hexval(peek(), &d) || ++k > 6) return fail("bad hexadecimal escape");
+            v = v * 16 + d;
+            ++i;
+        }
+        if (!more() || !k) return fail("bad hexadecimal escape");
+        ++i;
+        *cp = v;
+        return true;
+    }
+    // \p{..} / \P{..}: General_Category values
+    bool property(CharSet& c, bool ci, bool* negated) {
+        const bool neg = peek() == 'P';
+        ++i;
+        std::string name;
+        if (peek() == '{') {
+            ++i;
+            while (more() && peek() != '}') name += (char)(peek() < 128 ? peek() : '?'), ++i;
+            if (!more()) return fail("unterminated \\p{");
+            ++i;
+        } else if (more()) {
+            name += (char)peek();
+            ++i;
+        }
+        bool inner_neg = false;
+        if (!name.empty() && name[0] == '^') {
+            inner_neg = true;
+            name.erase(0, 1);
+        }
+        for (const char* pre : {"gc=", "General_Category=", "general_category="})
+            if (name.rfind(pre, 0) == 0) name.erase(0, strlen(pre));
+        static const struct { const char* a; const char* b; } alias[] = {
+            {"Letter", "L"}, {"Mark", "M"}, {"Number", "N"}, {"Punctuation", "P"}, {"Symbol", "S"}, {"Separator", "Z"}, {"Other", "C"},
+            {"Uppercase_Letter", "Lu"}, {"Lowercase_Letter", "Ll"}, {"Titlecase_Letter", "Lt"}, {"Modifier_Letter", "Lm"}, {"Other_Letter", "Lo"},
+            {"Decimal_Number", "Nd"}, {"Letter_Number", "Nl"}, {"Other_Number", "No"}, {"Nonspacing_Mark", "Mn"}, {"Spacing_Mark", "Mc"},
+            {"Enclosing_Mark", "Me"}, {"Control", "Cc"}, {"Format", "Cf"}, {"Unassigned", "Cn"}, {"Private_Use", "Co"}, {"Space_Separator", "Zs"}};
+        for (const auto& a : alias)
+            if (name == a.a) name = a.b;
+        uint32_t m = 0;
+        if (name == "LC") m = 7u;
+        else
+            for (int g = 0; g < 30; ++g)
+                if (name == GC_NAMES[g] || (name.size() == 1 && GC_NAMES[g][0] == name[0])) m |= 1u << g;
+        if (!m) return fail("\\p{" + name + "}: only General_Category values are supported (write other properties as ranges)");
+        if (ci && (m & 7u) && (m & 7u) != 7u) return fail("\\p{" + name + "} under (?i) is not supported");
+        c.gcmask |= m;
+        *negated = neg != inner_neg;
+        return true;
+    }
+    // an escape that stands for a set: fills `c`, *negated = the set is the complement
+    bool class_escape(uint32_t e, CharSet& c, bool ci, bool* negated) {
+        *negated = false;
+        switch (e) {
+            case 'd': c.gcmask |= 1u << 8; ++i; return true;
+            case 'D': c.gcmask |= 1u << 8; *negated = true; ++i; return true;
+            case 's': c.flags |= 0x20u; ++i; return true;
+            case 'S': c.flags |= 0x20u; *negated = true; ++i; return true;
+            case 'w': c.flags |= 0x40u; ++i; return true;
+            case 'W': c.flags |= 0x40u; *negated = true; ++i; return true;
+            default: return property(c, ci, negated);
+        }
+    }
+    static bool is_class_escape(uint32_t e) { return e == 'd' || e == 'D' || e == 's' || e == 'S' || e == 'w' || e == 'W' || e == 'p' || e == 'P'; }
+    // a literal escape behind the backslash (i at the escape letter): one code point
+    bool literal_escape(uint32_t* cp) {
+        const uint32_t e = peek();
+        ++i;
+        switch (e) {
+            case 'n': *cp = '\n'; return true;
+            case 'r': *cp = '\r'; return true;
+            case 't': *cp = '\t'; return true;
+            case 'f': *cp = '\f'; return true;
+            case 'v': *cp = '\v'; return true;
+            case 'a': *cp = 7; return true;
+            case 'e': *cp = 27; return true;
+            case '0': *cp = 0; return true;
+            case 'x': return peek() == '{' ? hex_braced(cp) : hex_fixed(2, cp);
+            case 'u': return peek() == '{' ? hex_braced(cp) : hex_fixed(4, cp);
+            case 'U': return hex_fixed(8, cp);
+            default: break;
+        }
+        if (e >= '1' && e <= '9') return fail("back-references are not supported");
+        if (e == 'b' || e == 'B') return fail("\\b and \\B look at the char before the position (look-behind): not supported");
+        if (e == 'G' || e == 'K' || e == 'Z' || e == 'k' || e == 'g' || e == 'X' || e == 'R' || e == 'h' || e == 'H' || e == 'N')
+            return fail(std::string("the escape \\") + (char)e + " is not supported");
+        if ((e >= 'a' && e <= 'z') || (e >= 'A' && e <= 'Z')) return fail(std::string("unknown escape \\") + (char)e);
+        *cp = e;  // escaped punctuation
+        return true;
+    }
+    int parse_class(const Flags& f) {  // i at '['
+        ++i;
+        CharSet c;
+        if (peek() == '^') {
+            c.neg = true;
+            ++i;
+        }
+        bool first = true;
+        while (more() && (peek() != ']' || first)) {
+            first = false;
+            uint32_t lo;
+            if (peek() == '[') {
+                if (peek(1) == ':') return fail("POSIX classes are not supported"), -1;
+                return fail("nested classes are not supported"), -1;
+            }
+            if ((peek() == '&' && peek(1) == '&') || (peek() == '-' && peek(1) == '-') || (peek() == '~' && peek(1) == '~'))
+                return fail("class set operations are not supported"), -1;
+            if (peek() == '\\') {
+                ++i;
+                if (!more()) return fail("pattern ends in a backslash"), -1;
+                if (is_class_escape(peek())) {
+                    bool negated;
+                    CharSet sub;
+                    if (!class_escape(peek(), sub, f.ci, &negated)) return -1;
+                    if (negated) {  // a complement inside a union: one per class ([^\S\n], [\S\d])
+                        if (c.comp) return fail("more than one negated escape inside a class is not supported"), -1;
+                        c.comp = true;
+                        c.cgcmask = sub.gcmask;
+                        c.cflags = sub.flags;
+                    } else {
+                        c.gcmask |= sub.gcmask;
+                        c.flags |= sub.flags;
+                    }
+                    continue;
+                }
+                if (!literal_escape(&lo)) return -1;
+            } else {
+                lo = peek();
+                ++i;
+            }
+            if (peek() == '-' && peek(1) != ']' && i + 1 < s.size()) {  // range
+                ++i;
+                uint32_t hi;
+                if (peek() == '\\') {
+                    ++i;
+                    if (!more() || is_class_escape(peek())) return fail("bad class range"), -1;
+                    if (!literal_escape(&hi)) return -1;
+                } else {
+                    hi = peek();
+                    ++i;
+                }
+                if (!add_range(c, lo, hi, f.ci)) return -1;
+            } else if (!add_char(c, lo, f.ci)) {
+                return -1;
+            }
+        }
+        if (!more()) return fail("unterminated class"), -1;
+        ++i;  // ]
+        return add_set(c);
+    }
+
+    // ---- expressions
+    int parse_alt(Flags f, int depth) {
+        if (depth > 40) return fail("pattern nested too deeply"), -1;
+        std::vector<int> alts;
+        for (;;) {
+            const int c = parse_cat(f, depth);
+            if (c < 0) return -1;
+            alts.push_back(c);
+            if (peek() == '|' && more()) {
+                ++i;
+                continue;
+            }
+            break;
+        }
+        if (alts.size() == 1) return alts[0];
+        Node n;
+        n.kind = Node::ALT;
+        n.kids = alts;
+        return add(n);
+    }
+    int parse_cat(Flags& f, int depth) {  // (inline flags (?i) change f for the rest of the enclosing group)
+        Node cat;
+        cat.kind = Node::CAT;
+        while (more() && peek() != '|' && peek() != ')') {
+            int a = parse_atom(f, depth);
+            if (a == -2) continue;  // inline flags
+            if (a < 0) return -1;
+            a = parse_quant(a);
+            if (a < 0) return -1;
+            cat.kids.push_back(a);
+        }
+        if (cat.kids.size() == 1) return cat.kids[0];
+        if (cat.kids.empty()) cat.kind = Node::EMPTY;
+        return add(cat);
+    }
+    int parse_quant(int a) {
+        for (;;) {
+            uint32_t mn, mx;
+            const uint32_t q = peek();
+            if (!more()) return a;
+            if (q == '?') mn = 0, mx = 1, ++i;
+            else if (q == '*') mn = 0, mx = TK_RX_INF, ++i;
+            else if (q == '+') mn = 1, mx = TK_RX_INF, ++i;
+            else if (q == '{') {
+                size_t j = i + 1;
+                uint64_t v = 0;
+                int nd = 0;
+                while (j < s.size() && s[j] >= '0' && s[j] <= '9' && nd < 6) v = v * 10 + (s[j] - '0'), ++j, ++nd;
+                if (!nd) return fail("bad quantifier"), -1;
+                mn = mx = (uint32_t)v;
+                if (j < s.size() && s[j] == ',') {
+                    ++j;
+                    v = 0, nd = 0;
+                    while (j < s.size() && s[j] >= '0' && s[j] <= '9' && nd < 6) v = v * 10 + (s[j] - '0'), ++j, ++nd;
+                    mx = nd ? (uint32_t)v : TK_RX_INF;
+                }
+                if (j >= s.size() || s[j] != '}') return fail("bad quantifier"), -1;
+                if (mx < mn) return fail("quantifier range out of order"), -1;
+                i = j + 1;
+            } else {
+                return a;
+            }
+            const Node::Kind k = nodes[a].kind;
+            if (k == Node::START || k == Node::END || k == Node::LOOK || k == Node::EMPTY) return fail("nothing to repeat"), -1;
+            Node r;
+            r.kind = Node::REPEAT;
+            r.kids = {a};
+            r.mn = mn;
+            r.mx = mx;
+            if (peek() == '?' && more()) r.mode = TK_RX_LAZY, ++i;
+            else if (peek() == '+' && more()) r.mode = TK_RX_POSSESSIVE, ++i;
+            a = add(r);
+            if (more() && (peek() == '*' || peek() == '+' || peek() == '?' || peek() == '{')) return fail("a quantifier behind a quantifier"), -1;
+        }
+    }
+    int parse_atom(Flags& f, int depth) {
+        const uint32_t c = peek();
+        if (c == '(') {
+            ++i;
+            Flags g = f;
+            Node::Kind wrap = Node::EMPTY;
+            bool neg = false;
+            if (peek() == '?') {
+                ++i;
+                const uint32_t k = peek();
+                if (k == ':') ++i;
+                else if (k == '>') wrap = Node::ATOMIC, ++i;
+                else if (k == '=') wrap = Node::LOOK, ++i;
+                else if (k == '!') wrap = Node::LOOK, neg = true, ++i;
+                else if (k == '<' && (peek(1) == '=' || peek(1) == '!')) return fail("look-behind is not supported: a piece must not depend on the text before it"), -1;
+                else if (k == 'P' || k == '<' || k == '\'') {  // named group: a plain group
+                    const uint32_t close = k == '\'' ? '\'' : '>';
+                    if (k == 'P') ++i;
+                    if (peek() == '=' || peek() == '>') return fail("named back-references are not supported"), -1;
+                    ++i;
+                    while (more() && peek() != close) ++i;
+                    if (!more()) return fail("unterminated group name"), -1;
+                    ++i;
+                } else {  // flags: (?i) (?s) (?is:...) (?-i)
+                    bool on = true, any = false;
+                    for (;; ++i) {
+                        const uint32_t fl = peek();
+                        if (fl == '-') on = false;
+                        else if (fl == 'i') g.ci = on, any = true;
+                        else if (fl == 's') g.dotall = on, any = true;
+                        else if (fl == 'u') any = true;
+                        else if (fl == 'm' || fl == 'x' || fl == 'U' || fl == 'R') return fail(std::string("the flag (?") + (char)fl + ") is not supported"), -1;
+                        else break;
+                    }
+                    if (!any) return fail("unknown group syntax"), -1;
+                    if (peek() == ')') {  // inline: for the rest of the enclosing group
+                        ++i;
+                        f = g;
+                        return -2;
+                    }
+                    if (peek() != ':') return fail("unknown group syntax"), -1;
+                    ++i;
+                }
+            }
+            int body = parse_alt(g, depth + 1);
+            if (body < 0) return -1;
+            if (peek() != ')' || !more()) return fail("unterminated group"), -1;
+            ++i;
+            if (wrap == Node::EMPTY) return body;
+            Node n;
+            n.kind = wrap;
+            n.kids = {body};
+            n.neg = neg;
+            return add(n);
+        }
+        if (c == '[') return parse_class(f);
+        if (c == '.') {
+            ++i;
+            CharSet cs;
+            cs.neg = true;
+            if (!f.dotall) cs.ranges.push_back({'\n', '\n'});
+            return add_set(cs);
+        }
+        if (c == '^' || c == '$') {
+            ++i;
+            Node n;
+            n.kind = c == '^' ? Node::START : Node::END;
+            return add(n);
+        }
+        if (c == '*' || c == '+' || c == '?') return fail("nothing to repeat"), -1;
+        if (c == '{' || c == '}' || c == ']') return fail(std::string("unescaped '") + (char)c + "'"), -1;
+        if (c == '\\') {
+            ++i;
+            if (!more()) return fail("pattern ends in a backslash"), -1;
+            const uint32_t e = peek();
+            if (e == 'A' || e == 'z') {
+                ++i;
+                Node n;
+                n.kind = e == 'A' ? Node::START : Node::END;
+                return add(n);
+            }
+            if (is_class_escape(e)) {
+                CharSet cs;
+                bool negated;
+                if (!class_escape(e, cs, f.ci, &negated)) return -1;
+                cs.neg = negated;
+                return add_set(cs);
+            }
+            uint32_t cp;
+            if (!literal_escape(&cp)) return -1;
+            CharSet cs;
+            if (!add_char(cs, cp, f.ci)) return -1;
+            return add_set(cs);
+        }
+        ++i;
+        CharSet cs;
+        if (!add_char(cs, c, f.ci)) return -1;
+        return add_set(cs);
+    }
+};
+
+struct Emitter {
+    const Parser& P;
+    std::vector<TkRxIns> code;
+    std::string err;
+    explicit Emitter(const Parser& p) : P(p) {}
+
+    uint32_t minlen(int n) const {
+        const Node& N = P.nodes[n];
+        switch (N.kind) {
+            case Node::SET: return 1;
+            case Node::CAT: {
+                uint64_t t = 0;
+                for (int k : N.kids) t += minlen(k);
+                return t > 0xFFFFFF ? 0xFFFFFFu : (uint32_t)t;
+            }
+            case Node::ALT: {
+                uint32_t m = 0xFFFFFFFFu;
+                for (int k : N.kids) m = m < minlen(k) ? m : minlen(k);
+                return m;
+            }
+            case Node::REPEAT: {
+                const uint64_t t = (uint64_t)minlen(N.kids[0]) * N.mn;
+                return t > 0xFFFFFF ? 0xFFFFFFu : (uint32_t)t;
+            }
+            case Node::ATOMIC: return minlen(N.kids[0]);
+            default: return 0;
+        }
+    }
+    uint32_t here() const { return (uint32_t)code.size(); }
+    uint32_t put(uint32_t op, uint32_t a = 0, uint32_t b = 0, uint32_t c = 0) {
+        code.push_back(TkRxIns{op, a, b, c});
+        return here() - 1;
+    }
+    // tail: nothing that can fail follows this node inside its alternative (a repeated group then needs no way back into it)
+    bool emit(int n, bool tail) {
+        if (code.size() > 4096) {
+            if (err.empty()) err = "the pattern is too large";
+            return false;
+        }
+        const Node& N = P.nodes[n];
+        switch (N.kind) {
+            case Node::EMPTY: return true;
+            case Node::SET: put(TK_RX_SET, (uint32_t)N.set); return true;
+            case Node::START: put(TK_RX_START); return true;
+            case Node::END: put(TK_RX_END); return true;
+            case Node::CAT:
+                for (size_t k = 0; k < N.kids.size(); ++k)
+                    if (!emit(N.kids[k], tail && k + 1 == N.kids.size())) return false;
+                return true;
+            case Node::ALT: {
+                std::vector<uint32_t> jumps;
+                for (size_t k = 0; k < N.kids.size(); ++k) {
+                    uint32_t split = 0;
+                    const bool last = k + 1 == N.kids.size();
+                    if (!last) split = put(TK_RX_SPLIT);
+                    if (!last) code[split].a = here();
+                    if (!emit(N.kids[k], tail)) return false;
+                    if (!last) {
+                        jumps.push_back(put(TK_RX_JMP));
+                        code[split].b = here();
+                    }
+                }
+                for (uint32_t j : jumps) code[j].a = here();
+                return true;
+            }
+            case Node::ATOMIC: {
+                put(TK_RX_ATOM_BEGIN);
+                if (!emit(N.kids[0], true)) return false;
+                put(TK_RX_ATOM_END);
+                return true;
+            }
+            case Node::LOOK: {
+                const uint32_t b = put(TK_RX_LOOK_BEGIN, N.neg ? 1u : 0u);
+                if (!emit(N.kids[0], true)) return false;
+                put(TK_RX_LOOK_END);
+                code[b].b = here();
+                return true;
+            }
+            case Node::REPEAT: return emit_repeat(N, tail);
+        }
+        return true;
+    }
+    bool emit_repeat(const Node& N, bool tail) {
+        const int body = N.kids[0];
+        const Node& B = P.nodes[body];
+        if (N.mx == 0) return true;  // x{0}
+        if (B.kind == Node::SET) {    // one instruction, one backtrack frame
+            put(TK_RX_REP | ((uint32_t)N.mode << 8), (uint32_t)B.set, N.mn, N.mx);
+            return true;
+        }
+        if (N.mx == TK_RX_INF && minlen(body) == 0) {
+            err = "a repeated group that can match the empty string is not supported";
+            return false;
+        }
+        if (N.mn > 64 || (N.mx != TK_RX_INF && N.mx > 64)) {
+            err = "a group repeated more than 64 times is not supported";
+            return false;
+        }
+        const bool lazy = N.mode == TK_RX_LAZY;
+        if (N.mx == TK_RX_INF && !lazy && (N.mode == TK_RX_POSSESSIVE || tail)) {
+            // No way back into the loop is ever taken (possessive; or greedy where nothing can fail behind it): every repetition is atomic and
+            // forgets the previous one's way out -- a constant number of frames however often the group repeats.
+            for (uint32_t k = 0; k < N.mn; ++k) {
+                put(TK_RX_ATOM_BEGIN);
+                if (!emit(body, true)) return false;
+                put(TK_RX_ATOM_END);
+            }
+            const uint32_t sp = put(TK_RX_SPLIT);
+            code[sp].a = here();
+            put(TK_RX_ATOM_BEGIN);
+            if (!emit(body, true)) return false;
+            put(TK_RX_ATOM_END);
+            put(TK_RX_POP);
+            put(TK_RX_JMP, sp);
+            code[sp].b = here();
+            return true;
+        }
+        const bool poss = N.mode == TK_RX_POSSESSIVE;
+        if (poss) put(TK_RX_ATOM_BEGIN);
+        for (uint32_t k = 0; k < N.mn; ++k)
+            if (!emit(body, false)) return false;
+        // a split that prefers `go` (greedy) or `skip` (lazy)
+        auto split = [&](uint32_t* go_field_owner) { *go_field_owner = put(TK_RX_SPLIT); };
+        if (N.mx == TK_RX_INF) {  // L: split(body, out); body; jmp L
+            uint32_t sp;
+            split(&sp);
+            const uint32_t body_at = here();
+            if (!emit(body, false)) return false;
+            put(TK_RX_JMP, sp);
+            const uint32_t out = here();
+            code[sp].a = lazy ? out : body_at;
+            code[sp].b = lazy ? body_at : out;
+        } else {  // (body (body (body)?)?)?: every split leaves for the common end
+            std::vector<uint32_t> splits;
+            for (uint32_t k = N.mn; k < N.mx; ++k) {
+                uint32_t sp;
+                split(&sp);
+                splits.push_back(sp);
+                code[sp].a = here();  // (patched below for lazy)
+                if (!emit(body, false)) return false;
+            }
+            const uint32_t out = here();
+            for (uint32_t sp : splits) {
+                const uint32_t body_at = code[sp].a;
+                code[sp].a = lazy ? out : body_at;
+                code[sp].b = lazy ? body_at : out;
+            }
+        }
+        if (poss) put(TK_RX_ATOM_END);
+        return true;
+    }
+};
+
+bool utf8_to_cps(const char* p, std::vector<uint32_t>* out) {
+    const uint8_t* s = (const uint8_t*)p;
+    while (*s) {
+        uint32_t b0 = *s, need = b0 < 0x80 ? 1 : (b0 >= 0xF0 ? 4 : (b0 >= 0xE0 ? 3 : (b0 >= 0xC0 ? 2 : 0)));
+        if (!need) return false;
+        uint32_t cp = need == 1 ? b0 : (b0 & (0x7Fu >> need));
+        for (uint32_t k = 1; k < need; ++k) {
+            if ((s[k] & 0xC0u) != 0x80u) return false;
+            cp = (cp << 6) | (s[k] & 0x3Fu);
+        }
+        out->push_back(cp);
+        s += need;
+    }
+    return true;
+}
+
+}  // namespace
+
+const uint8_t* tk_rx_props_stage1() { return tk_rx_stage1; }
+const uint8_t* tk_rx_props_stage2() { return tk_rx_stage2; }
+uint32_t tk_rx_props_blocks() { return TK_RX_NBLOCKS; }
+
+std::string tk_rx_compile(const char* pat_str, TkRxCompiled* out) {
+    Parser P;
+    if (!utf8_to_cps(pat_str, &P.s)) return "the pattern is not valid UTF-8";
+    Flags f;
+    const int root = P.parse_alt(f, 0);
+    if (root < 0) return P.err.empty() ? "cannot parse the pattern" : P.err;
+    if (P.more()) return P.peek() == ')' ? "unbalanced ')'" : "cannot parse the pattern";
+    Emitter E(P);
+    if (E.minlen(root) == 0) return "the pattern can match the empty string (a piece must hold at least one char)";
+    if (!E.emit(root, true)) return E.err;
+    E.put(TK_RX_MATCH);
+    if (E.code.size() > TK_RX_MAX_INS) return "the pattern is too large (more than " + std::to_string(TK_RX_MAX_INS) + " instructions)";
+    if (P.sets.size() > TK_RX_MAX_SETS) return "the pattern has too many classes";
+    out->ins = E.code;
+    out->sets.clear();
+    out->ranges.clear();
+    for (const CharSet& c : P.sets) {
+        TkRxSet S{};
+        for (uint32_t cp = 0; cp < 128; ++cp)
+            if (c.member(cp)) S.ascii[cp >> 5] |= 1u << (cp & 31u);
+        S.gcmask = c.gcmask;
+        S.cgcmask = c.cgcmask;
+        S.flags = (c.flags & 0x60u) | (c.neg ? 1u : 0u) | (c.comp ? 2u : 0u) | ((c.cflags & 0x60u) << 8);
+        const uint32_t roff = (uint32_t)out->ranges.size() / 2;
+        for (const auto& r : c.ranges)
+            if (r.second >= 128u) {  // (the ASCII part lives in the bitmap)
+                out->ranges.push_back(r.first < 128u ? 128u : r.first);
+                out->ranges.push_back(r.second);
+            }
+        S.rr = roff << 16 | ((uint32_t)out->ranges.size() / 2 - roff);
+        out->sets.push_back(S);
+    }
+    if (out->ranges.size() / 2 > TK_RX_MAX_RANGES) return "the pattern has too many class ranges";
+    return "";
+}
+
+TkRxProg TkRxCompiled::view() const {
+    return TkRxProg{ins.data(), sets.data(), ranges.data(), tk_rx_stage1, tk_rx_stage2, (uint32_t)ins.size(), (uint32_t)sets.size(),
+                    (uint32_t)ranges.size() / 2};
+}

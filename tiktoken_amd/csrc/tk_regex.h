@@ -1,0 +1,236 @@
+// The generic pat_str engine: any split pattern outside the three hand-written scanner families (tk_pattern.cpp) is compiled once per
+// Encoding (reference: Regex::new(pattern), src/lib.rs:623) into a small backtracking program that the GPU runs itself
+// (tk_regex_kernels.h).  This header holds what host and device share: the program layout, the property lookup and the matcher.
+//
+// Semantics are those of fancy-regex / Python `regex` for the supported syntax (tk_regex.cpp): leftmost, alternatives in order,
+// greedy / lazy / possessive quantifiers, atomic groups, look-ahead, case-insensitive literals; no look-behind, no back-references.
+// Without look-behind the end of the piece that starts at p depends only on the text from p on (and on where its haystack ends), which is
+// what lets the kernels evaluate piece starts speculatively in parallel and prove them afterwards (tk_regex_kernels.h).
+//
+// A program is an array of 16-byte instructions over "sets" (sets of code points).  Repeats of a single set -- \s+, \p{L}*, [^\r\n]+? --
+// are ONE instruction with ONE backtrack frame however long the run is (a frame holds a range of positions), and a repeated GROUP that is
+// possessive, or stands where nothing can fail behind it (the tail of an alternative, of a look-ahead, of an atomic group), forgets each
+// repetition's alternatives as it goes: the backtrack stack is bounded by the nesting of the pattern, not by the text, for everything but
+// a backtracking repeated group in the middle of an alternative ((?:ab)*c), which is good for TK_RX_STACK / 2 repetitions.
+#pragma once
+#include <stdint.h>
+
+#include "tk_common.h"
+
+enum {
+    TK_RX_SET = 0,     // a: set -- one char of the set
+    TK_RX_REP,         // a: set, b: min, c: max (0xFFFFFFFF = unbounded); mode = (op >> 8) & 3
+    TK_RX_SPLIT,       // a: first choice, b: second choice
+    TK_RX_JMP,         // a: target
+    TK_RX_MATCH,
+    TK_RX_END,         // end of the haystack ($, \z)
+    TK_RX_START,       // start of the haystack (^, \A)
+    TK_RX_ATOM_BEGIN,  // (?>...), possessive quantifiers of groups
+    TK_RX_ATOM_END,
+    TK_RX_LOOK_BEGIN,  // a: 1 = negative, b: instruction behind the look-ahead
+    TK_RX_LOOK_END,
+    TK_RX_FAIL,
+    TK_RX_POP,  // forget the newest alternative (possessive loops of groups: the way out of the previous repetition)
+};
+enum { TK_RX_GREEDY = 0, TK_RX_LAZY = 1, TK_RX_POSSESSIVE = 2 };
+#define TK_RX_INF 0xFFFFFFFFu
+
+struct TkRxIns {  // 16 bytes
+    uint32_t op, a, b, c;
+};
+// A set of code points: ASCII members as a bitmap (everything below already applied); beyond ASCII the union of General_Category members
+// (gcmask, bit = index in tools/gen_regex_props.py's order), \s / \w members (flags bits 5 / 6, the bits of the property byte), explicit
+// ranges and -- flags bit 1 -- the COMPLEMENT of one more such term (cgcmask, flags bits 13 / 14: the \S of [^\S\n]); flags bit 0 negates
+// the whole.
+struct TkRxSet {  // 32 bytes
+    uint32_t ascii[4];
+    uint32_t gcmask, cgcmask;
+    uint32_t flags;
+    uint32_t rr;  // ranges[roff .. roff + rcnt): pairs (lo, hi), inclusive; roff << 16 | rcnt
+};
+struct TkRxProg {
+    const TkRxIns* ins;
+    const TkRxSet* sets;
+    const uint32_t* ranges;
+    const uint8_t* stage1;  // [0x1100] property table (tk_regex_props.inc)
+    const uint8_t* stage2;
+    uint32_t n_ins, n_sets, n_ranges;
+};
+
+#define TK_RX_FAILED 0xFFFFFFFFu    // no match at this position
+#define TK_RX_OVERFLOW 0xFFFFFFFEu  // backtrack stack exhausted (a repeated group on a long text)
+#define TK_RX_STACK 64
+
+TK_HD uint32_t tk_rx_prop(const TkRxProg& P, uint32_t cp) {
+    if (cp > 0x10FFFFu) cp = 0xFFFDu;
+    return P.stage2[(uint32_t)P.stage1[cp >> 8] * 256u + (cp & 255u)];
+}
+
+TK_HD bool tk_rx_in_set(const TkRxProg& P, uint32_t s, uint32_t cp) {
+    const TkRxSet& S = P.sets[s];
+    if (cp < 128u) return (S.ascii[cp >> 5] >> (cp & 31u)) & 1u;
+    const uint32_t pr = tk_rx_prop(P, cp);
+    bool in = ((S.gcmask >> (pr & 31u)) & 1u) || (pr & S.flags & 0x60u);
+    if (!in && (S.flags & 2u)) in = !(((S.cgcmask >> (pr & 31u)) & 1u) || (pr & (S.flags >> 8) & 0x60u));
+    const uint32_t roff = S.rr >> 16, rcnt = S.rr & 0xFFFFu;
+    for (uint32_t i = 0; i < rcnt && !in; ++i) in = cp >= P.ranges[2 * (roff + i)] && cp <= P.ranges[2 * (roff + i) + 1];
+    return in != (bool)(S.flags & 1u);
+}
+
+// The char at pos (pos < t.n): code point and length.  Malformed UTF-8 reads as U+FFFD, one byte long (the boundary's contract is valid
+// UTF-8; this only keeps the walk inside the text).
+template <class A>
+TK_HD uint32_t tk_rx_decode(A& t, uint32_t pos, uint32_t* len) {
+    const uint32_t b0 = t.byte(pos);
+    *len = 1;
+    if (b0 < 0x80u) return b0;
+    const uint32_t need = b0 >= 0xF0u ? 4u : (b0 >= 0xE0u ? 3u : (b0 >= 0xC0u ? 2u : 0u));
+    if (!need || (uint64_t)pos + need > t.n) return 0xFFFDu;
+    uint32_t cp = b0 & (0x7Fu >> need);
+    for (uint32_t i = 1; i < need; ++i) {
+        const uint32_t b = t.byte(pos + i);
+        if ((b & 0xC0u) != 0x80u) return 0xFFFDu;
+        cp = (cp << 6) | (b & 0x3Fu);
+    }
+    *len = need;
+    return cp;
+}
+
+// End of the match of P that starts at `start`, TK_RX_FAILED or TK_RX_OVERFLOW.  `t` gives the text: byte(pos), n, hard(pos) -- a
+// position where a new haystack begins (document start, special-token edge): the match sees end-of-text there, exactly like the slice of
+// src/lib.rs:405.  Positions are 32-bit (a chunk is < 3 GiB).
+template <class A>
+TK_HD uint32_t tk_rx_match(const TkRxProg& P, A& t, uint32_t start) {
+    enum { F_ALT = 0, F_RANGE = 1, F_LAZY = 2, F_ATOM = 3, F_LOOK = 4 };
+    uint32_t fk[TK_RX_STACK], fp[TK_RX_STACK], fa[TK_RX_STACK];  // frames: kind << 24 | pc, position, aux
+    int sp = 0;
+    uint32_t pc = 0, pos = start;
+    auto at_end = [&](uint32_t p) -> bool { return p >= t.n || (p > start && t.hard(p)); };
+    for (;;) {
+        const TkRxIns I = P.ins[pc];
+        bool fail = false;
+        switch (I.op & 0xFFu) {
+            case TK_RX_SET: {
+                uint32_t len;
+                if (!at_end(pos) && tk_rx_in_set(P, I.a, tk_rx_decode(t, pos, &len))) {
+                    pos += len;
+                    ++pc;
+                } else {
+                    fail = true;
+                }
+            } break;
+            case TK_RX_REP: {
+                const uint32_t mode = (I.op >> 8) & 3u, mn = I.b, mx = I.c;
+                const uint32_t want = mode == TK_RX_LAZY ? mn : mx;
+                uint32_t c = 0, pmin = pos;
+                while (c < want && !at_end(pos)) {
+                    uint32_t len;
+                    if (!tk_rx_in_set(P, I.a, tk_rx_decode(t, pos, &len))) break;
+                    pos += len;
+                    if (++c == mn) pmin = pos;
+                }
+                if (c < mn) {
+                    fail = true;
+                    break;
+                }
+                if ((mode == TK_RX_GREEDY && pos > pmin) || (mode == TK_RX_LAZY && c < mx)) {
+                    if (sp == TK_RX_STACK) return TK_RX_OVERFLOW;
+                    fk[sp] = mode == TK_RX_GREEDY ? ((uint32_t)F_RANGE << 24 | (pc + 1)) : ((uint32_t)F_LAZY << 24 | pc);
+                    fp[sp] = mode == TK_RX_GREEDY ? pmin : pos;
+                    fa[sp] = mode == TK_RX_GREEDY ? pos : c;
+                    ++sp;
+                }
+                ++pc;
+            } break;
+            case TK_RX_SPLIT:
+                if (sp == TK_RX_STACK) return TK_RX_OVERFLOW;
+                fk[sp] = (uint32_t)F_ALT << 24 | I.b;
+                fp[sp] = pos;
+                fa[sp] = 0;
+                ++sp;
+                pc = I.a;
+                break;
+            case TK_RX_JMP: pc = I.a; break;
+            case TK_RX_MATCH: return pos;
+            case TK_RX_END:
+                if (at_end(pos)) ++pc;
+                else fail = true;
+                break;
+            case TK_RX_START:
+                if (pos == start && (pos == 0 || t.hard(pos))) ++pc;
+                else fail = true;
+                break;
+            case TK_RX_ATOM_BEGIN:
+                if (sp == TK_RX_STACK) return TK_RX_OVERFLOW;
+                fk[sp] = (uint32_t)F_ATOM << 24;
+                fp[sp] = fa[sp] = 0;
+                ++sp;
+                ++pc;
+                break;
+            case TK_RX_ATOM_END:  // the group matched: its alternatives are forgotten
+                while (sp > 0 && (fk[--sp] >> 24) != F_ATOM) {}
+                ++pc;
+                break;
+            case TK_RX_LOOK_BEGIN:
+                if (sp == TK_RX_STACK) return TK_RX_OVERFLOW;
+                fk[sp] = (uint32_t)F_LOOK << 24 | I.b;
+                fp[sp] = pos;
+                fa[sp] = I.a;
+                ++sp;
+                ++pc;
+                break;
+            case TK_RX_LOOK_END: {  // the look-ahead's body matched
+                while (sp > 0 && (fk[--sp] >> 24) != F_LOOK) {}
+                pos = fp[sp];
+                if (fa[sp]) fail = true;  // negative look-ahead
+                else ++pc;
+            } break;
+            case TK_RX_POP:
+                if (sp > 0) --sp;
+                ++pc;
+                break;
+            default: fail = true; break;
+        }
+        while (fail) {  // backtrack
+            if (sp == 0) return TK_RX_FAILED;
+            --sp;
+            const uint32_t kind = fk[sp] >> 24, tgt = fk[sp] & 0xFFFFFFu;
+            if (kind == F_ALT) {
+                pc = tgt;
+                pos = fp[sp];
+                fail = false;
+            } else if (kind == F_RANGE) {  // give back one char of a greedy run: [fp, fa] is the range of possible ends
+                uint32_t cur = fa[sp] - 1;
+                while (cur > fp[sp] && (t.byte(cur) & 0xC0u) == 0x80u) --cur;
+                if (cur > fp[sp]) {
+                    fa[sp] = cur;
+                    ++sp;
+                }
+                pos = cur;
+                pc = tgt;
+                fail = false;
+            } else if (kind == F_LAZY) {  // take one more char of a lazy run
+                const TkRxIns R = P.ins[tgt];
+                uint32_t p = fp[sp], c = fa[sp], len;
+                if (c < R.c && !at_end(p) && tk_rx_in_set(P, R.a, tk_rx_decode(t, p, &len))) {
+                    p += len;
+                    ++c;
+                    if (c < R.c) {
+                        fp[sp] = p;
+                        fa[sp] = c;
+                        ++sp;
+                    }
+                    pos = p;
+                    pc = tgt + 1;
+                    fail = false;
+                }
+            } else if (kind == F_LOOK) {  // the look-ahead's body cannot match
+                if (fa[sp]) {             // ... which is what a negative one asks for
+                    pos = fp[sp];
+                    pc = tgt;
+                    fail = false;
+                }
+            }  // F_ATOM: the group failed as a whole
+        }
+    }
+}

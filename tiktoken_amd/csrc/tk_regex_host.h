@@ -1,0 +1,27 @@
+// Host side of the generic pat_str engine: the compiled program as vectors (tk_regex.cpp), uploaded once per Encoding by tk_create.
+#pragma once
+#include <stdint.h>
+
+#include <string>
+#include <vector>
+
+#include "tk_regex.h"
+
+#define TK_RX_MAX_INS 448     // the kernels keep the program in LDS: 448 x 16 + 64 x 32 + 192 x 8 bytes = 10.5 KiB
+#define TK_RX_MAX_SETS 64
+#define TK_RX_MAX_RANGES 192  // pairs
+
+struct TkRxCompiled {
+    std::vector<TkRxIns> ins;
+    std::vector<TkRxSet> sets;
+    std::vector<uint32_t> ranges;  // pairs (lo, hi)
+    bool empty() const { return ins.empty(); }
+    // a view over the vectors and the built-in property table (host-side matching: tests/hostsim, tk_create's self-check)
+    TkRxProg view() const;
+};
+
+// pat_str -> program; "" or the reason why the pattern is not supported
+std::string tk_rx_compile(const char* pat_str, TkRxCompiled* out);
+const uint8_t* tk_rx_props_stage1();  // [0x1100]
+const uint8_t* tk_rx_props_stage2();  // [tk_rx_props_blocks() * 256]
+uint32_t tk_rx_props_blocks();
