@@ -350,8 +350,9 @@ class RxSim:
             self._L.tks_rx_free(self._h)
             self._h = None
 
-    def split(self, docs: list[bytes], specials: list[tuple[int, int]] = (), speculate: bool = True) -> list[int]:
-        """Piece starts (byte offsets into the packed batch) of the documents; specials: (offset, length) of allowed special tokens."""
+    def split(self, docs: list[bytes], specials: list[tuple[int, int]] = (), speculate: int | bool = True) -> list[int]:
+        """Piece starts (byte offsets into the packed batch) of the documents; specials: (offset, length) of allowed special tokens.
+        speculate: False = the matcher alone walks every document; True / 1 = with the speculative pass over 256-byte segments; 2 = 1 KiB."""
         blob, off = pack(docs)
         n = len(blob)
         starts = np.zeros(n + 1, np.uint8)
@@ -360,7 +361,7 @@ class RxSim:
         stats = np.zeros(2, np.uint64)
         buf = np.ascontiguousarray(blob) if n else np.zeros(1, np.uint8)
         rc = self._L.tks_rx_split(self._h, buf.ctypes.data, n, off.ctypes.data, len(off) - 1, sa.ctypes.data if len(sa) else None,
-                                  sl.ctypes.data if len(sl) else None, len(sa), 1 if speculate else 0, starts.ctypes.data, stats.ctypes.data)
+                                  sl.ctypes.data if len(sl) else None, len(sa), int(speculate), starts.ctypes.data, stats.ctypes.data)
         self.stats = (int(stats[0]), int(stats[1]))
         if rc:
             raise RuntimeError(f"split error {rc & 255} at byte {rc >> 8}")

@@ -23,6 +23,7 @@ static uint64_t g_rx_matches = 0;
 struct Sim {
     TkHostTables H;
     TkTables T;
+    std::vector<uint32_t> byte_tab;
 };
 
 struct FlatAcc {
@@ -77,11 +78,14 @@ void* tks_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uin
     }
     TkHostTables& H = s->H;
     TkTables& D = s->T;
-    D.uc_stage1 = tk_uc_stage1;
-    D.uc_stage2 = tk_uc_stage2;
-    static uint32_t byte_tab[256 * 2];
-    tk_build_byte_table(tk_uc_stage1, tk_uc_stage2, byte_tab);
-    D.byte_tab = byte_tab;
+    // (a pat_str of the generic engine: every char a letter, as tk_create sets it up -- the split is tks_rx_split's)
+    static const std::vector<uint8_t> ll_stage1(0x1100, 0), ll_stage2(256, (uint8_t)TK_C_LL);
+    const bool gen = !H.rx.empty();
+    D.uc_stage1 = gen ? ll_stage1.data() : tk_uc_stage1;
+    D.uc_stage2 = gen ? ll_stage2.data() : tk_uc_stage2;
+    s->byte_tab.resize(256 * 2);
+    tk_build_byte_table(D.uc_stage1, D.uc_stage2, s->byte_tab.data());
+    D.byte_tab = s->byte_tab.data();
     D.short_tab = H.short_tab.empty() ? nullptr : H.short_tab.data();
     D.short_mask = H.short_mask;
     D.short_shift = H.short_shift;
@@ -633,6 +637,7 @@ uint64_t tks_rx_size(void* p) { return ((TkRxCompiled*)p)->ins.size(); }
 // Returns 0, or error bits | position << 8.
 uint64_t tks_rx_split(void* p, const uint8_t* text_in, uint64_t n, const uint64_t* doc_off, uint64_t n_docs, const uint64_t* spec_at,
                       const uint64_t* spec_len, uint64_t n_spec, int speculate, uint8_t* starts, uint64_t* stats) {
+    const uint32_t seg_shift = speculate == 2 ? TK_RX_SEG_SHIFT_LARGE : TK_RX_SEG_SHIFT_SMALL;  // (speculate: 1 = 256-byte segments, 2 = 1 KiB)
     const TkRxCompiled* c = (const TkRxCompiled*)p;
     const TkRxProg P = c->view();
     std::vector<uint8_t> text(text_in, text_in + n);
@@ -649,17 +654,17 @@ uint64_t tks_rx_split(void* p, const uint8_t* text_in, uint64_t n, const uint64_
         if (spec_at[k] + spec_len[k] < n) setb(brk, spec_at[k] + spec_len[k]);
     }
     TkRxText t{text.data(), (uint32_t)n, brk.data(), n_spec ? ss.data() : nullptr, n_spec ? si.data() : nullptr, 0xFFFFFFFFu, false};
-    const uint32_t nseg = (uint32_t)((n + TK_RX_SEG - 1) / TK_RX_SEG);
+    const uint32_t nseg = (uint32_t)((n + (1u << seg_shift) - 1) >> seg_shift);
     std::vector<uint32_t> xexit(nseg + 1, TK_RX_UNKNOWN);
     g_rx_matches = 0;
     if (speculate)
-        for (uint32_t k = 0; k < nseg; ++k) tk_rx_speculate_lane(P, t, k, spec.data(), xexit.data());
+        for (uint32_t k = 0; k < nseg; ++k) tk_rx_speculate_lane(P, t, k, seg_shift, spec.data(), xexit.data());
     stats[0] = g_rx_matches;
     g_rx_matches = 0;
     uint64_t rc = 0;
     for (uint64_t d = 0; d < n_docs && !rc; ++d) {
         uint32_t err_pos = 0;
-        const uint32_t e = tk_rx_resolve_lane(P, t, (uint32_t)doc_off[d], (uint32_t)doc_off[d + 1], speculate ? spec.data() : nullptr, xexit.data(),
+        const uint32_t e = tk_rx_resolve_lane(P, t, (uint32_t)doc_off[d], (uint32_t)doc_off[d + 1], seg_shift, speculate ? spec.data() : nullptr, xexit.data(),
                                               [&](uint32_t w, uint32_t bits) { gst[w] |= bits; }, &err_pos);
         if (e) rc = e | ((uint64_t)err_pos << 8);
     }

@@ -1,0 +1,152 @@
+"""GPU tests of the generic pat_str engine (tk_regex_kernels.h): a pat_str outside the three scanner families, split and encoded on the
+device through the C ABI, against Python `regex` (the split) + the C oracle's byte_pair_encode (the tokens).  Bit-exact."""
+import random
+
+import numpy as np
+import pytest
+import regex
+
+import helpers as h
+from test_regex_engine import PATTERNS, py_starts, random_text
+
+pytestmark = pytest.mark.gpu
+NAME = "o200k_shaped"
+
+
+def make_core(pat, specials=None):
+    from tiktoken_amd import CoreBPE
+
+    return CoreBPE(h.golden_vocab(NAME), specials if specials is not None else h.load_golden(NAME)["special_tokens"], pat)
+
+
+def make_docs(rng, count, big=0):
+    """Documents for patterns that cover every text (no gaps): short adversarial strings, awkward documents, `big` long ones with runs."""
+    docs = [random_text(rng, rng.choice([0, 1, 3, 30, 300, 3000])) if rng.random() < 0.75 else h.fuzz_doc(rng)[:20000] for _ in range(count)]
+    for _ in range(big):
+        parts = []
+        while sum(map(len, parts)) < 1_500_000:
+            parts.append(rng.choice(["hello ", "World", " 12345", "\n", "x" * 5000, " " * 900, "中文", "é", "...", "CamelCase", " don't", "\r\n\r\n", "3.14"]))
+        docs.append("".join(parts))
+    return docs
+
+
+def oracle_tokens(py_pat, docs, C, cache):
+    toks, off = [], [0]
+    for d in docs:
+        for m in regex.finditer(py_pat, d):
+            p = m.group().encode()
+            t = cache.get(p)
+            if t is None:
+                t = cache[p] = C.encode_piece(p)
+            toks += t
+        off.append(len(toks))
+    return np.array(toks, np.uint32), np.array(off, np.uint64)
+
+
+# (patterns 9 and 13 leave gaps on most texts: their split is covered by the CPU tests, which run the kernels' lanes one by one)
+@pytest.mark.parametrize("idx", [5, 6, 7, 8, 10, 11, 12])
+def test_split_and_tokens_equal_python_regex_plus_oracle(idx):
+    pat, py = PATTERNS[idx]
+    py = py or pat
+    core, C = make_core(pat), h.c_oracle_for(NAME)
+    rng = random.Random(1000 + idx)
+    docs = make_docs(rng, 200, big=1 if idx in (5, 6) else 0)
+    enc = [d.encode() for d in docs]
+    blob, off = h.pack(enc)
+    want_starts, base = [], 0
+    for d, e in zip(docs, enc):
+        want_starts += [base + s for s in py_starts(py, d)]
+        base += len(e)
+    got = core.pretokenize_packed(blob, off)
+    assert got.tolist() == want_starts + [len(blob)]
+    rt, ro = oracle_tokens(py, docs, C, {})
+    toks, toff = core.encode_batch_packed(blob, off)
+    assert np.array_equal(toff, ro)
+    assert np.array_equal(toks, rt)
+
+
+def test_encoding_api_with_a_pattern_of_its_own():
+    """The reference's "Extending tiktoken" recipe (README.md:83-94) with a pat_str the library has no hand-written scanner for."""
+    from tiktoken_amd import Encoding
+
+    pat = r"\p{Lu}?\p{Ll}+|\p{Lu}+(?!\p{Ll})|\d{1,3}|[^\s\p{L}\d]+|\s+|."
+    specials = {"<|endoftext|>": 199999, "<|sep|>": 200000}
+    enc = Encoding("camel", pat_str=pat, mergeable_ranks=h.golden_vocab(NAME), special_tokens=specials)
+    C = h.c_oracle_for(NAME)
+    text = "parseHTTPRequest42 isDone\n\n  fooBar_baz 1234567"
+    want = [t for m in regex.finditer(r"\p{Lu}?\p{Ll}+|\p{Lu}+(?!\p{Ll})|\d{1,3}|[^\s\p{L}\d]+|\s+|(?s:.)", text) for t in C.encode_piece(m.group().encode())]
+    assert enc.encode_ordinary(text) == want
+    assert enc.encode(text) == want
+    assert enc.decode(want) == text
+    both = text + "<|sep|>" + text + "<|endoftext|>"
+    assert enc.encode(both, allowed_special="all") == want + [200000] + want + [199999]
+    assert enc.encode_batch([both, "", text], allowed_special={"<|sep|>"}, disallowed_special=()) == [
+        want + [200000] + want + enc.encode_ordinary("<|endoftext|>"), [], want]
+    with pytest.raises(ValueError):
+        enc.encode(both)  # disallowed special, as in the reference (core.py:120-124)
+    assert enc.encode_ordinary("hello world") == [t for p in (b"hello", b" ", b"world") for t in C.encode_piece(p)]
+
+
+def test_special_tokens_batch():
+    pat, py = PATTERNS[6]
+    g = h.load_golden(NAME)
+    core, C = make_core(pat), h.c_oracle_for(NAME)
+    rng = random.Random(77)
+    sp = list(g["special_tokens"])
+    docs = []
+    for _ in range(200):
+        parts = []
+        for _ in range(rng.randrange(0, 12)):
+            parts.append(rng.choice(sp) if rng.random() < 0.3 else random_text(rng, rng.choice([0, 1, 5, 80, 700])))
+        docs.append("".join(parts))
+    alt = "(" + "|".join(regex.escape(s) for s in sorted(sp, key=len, reverse=True)) + ")"
+    toks, off, cache = [], [0], {}
+    for d in docs:
+        for part in regex.split(alt, d):
+            if part in g["special_tokens"]:
+                toks.append(g["special_tokens"][part])
+            else:
+                t, _ = oracle_tokens(py, [part], C, cache)
+                toks += t.tolist()
+        off.append(len(toks))
+    blob, doff = h.pack([d.encode() for d in docs])
+    got, goff = core.encode_batch_packed(blob, doff, "all")
+    assert np.array_equal(goff, np.array(off, np.uint64))
+    assert np.array_equal(got, np.array(toks, np.uint32))
+
+
+def test_gaps_and_deep_backtracking_are_refused_loudly():
+    core = make_core(r"\w+|\s+")
+    blob, off = h.pack([b"fine words only", b"hello, world"])
+    with pytest.raises(ValueError, match="does not match at byte 20"):
+        core.encode_batch_packed(blob, off)
+    assert core.encode_ordinary("fine words only") == make_core(r"\w+|\s+|[^\w\s]+").encode_ordinary("fine words only")
+    core = make_core(r"(?:ab)*c|a|b")
+    with pytest.raises(ValueError, match="possessive"):
+        core.encode_ordinary("ab" * 500)
+    from tiktoken_amd import CoreBPE
+
+    with pytest.raises(ValueError, match="look-behind"):
+        CoreBPE(h.golden_vocab(NAME), {}, r"(?<=a)b|.")
+
+
+def test_one_large_document_and_multi_chunk(monkeypatch):
+    """A single 6 MiB document (the resolving pass is one lane: it must live off the speculative pass) and the same batch cut into chunks."""
+    pat, py = PATTERNS[5]
+    rng = random.Random(5)
+    words = ["alpha", "Beta", " ", "  ", "\n", "42", "...", "中文", "don't", "é", "_", "x" * 300]
+    doc = "".join(rng.choice(words) for _ in range(1_200_000))
+    docs = [doc, "tail doc", ""]
+    C = h.c_oracle_for(NAME)
+    rt, ro = oracle_tokens(py or pat, docs, C, {})
+    blob, off = h.pack([d.encode() for d in docs])
+    core = make_core(pat)
+    toks, toff = core.encode_batch_packed(blob, off)
+    assert np.array_equal(toff, ro) and np.array_equal(toks, rt)
+    many = make_docs(rng, 300)
+    rt, ro = oracle_tokens(py or pat, many, C, {})
+    blob, off = h.pack([d.encode() for d in many])
+    monkeypatch.setenv("TIKTOKEN_AMD_CHUNK_BYTES", "65536")
+    small_chunks = make_core(pat)
+    toks, toff = small_chunks.encode_batch_packed(blob, off)
+    assert np.array_equal(toff, ro) and np.array_equal(toks, rt)

@@ -106,9 +106,28 @@ def test_stock_spellings_map_to_the_stock_scanners():
     (R50K.replace(r"| ?\p{N}++", ""), r"\p{N}+"),
     (CL100K.replace(r"\p{L}++", r"[\p{L}\p{M}]+"), "letter alternative"),
 ])
-def test_unsupported_patterns_are_refused_with_the_reason(bad, why):
-    with pytest.raises(ValueError, match=regex.escape(why)):
-        h.HostSim(bad, TINY, {})
+def test_patterns_outside_the_families_run_on_the_generic_engine(bad, why):
+    """What the hand-written scanners do not cover (`why`: the family parser's reason) is compiled for the generic engine (tk_regex.cpp)
+    instead of being refused; its split is Python `regex`'s."""
+    from tiktoken_amd import _lib
+
+    assert _lib.lib().tk_pattern_id(bad.encode()) == 3
+    rx = h.RxSim(bad)
+    texts = [t for t in _texts(len(why), 400) + ["x'ing y'st z'k 'K", "12 345 6789", "a\\\n\\b", "don't stop"] if _covers(bad, t)]
+    assert len(texts) > 40
+    blob, off = h.pack([d.encode() for d in texts])
+    ref = _ends_regex(bad, texts, off)
+    starts = rx.split([d.encode() for d in texts])
+    assert starts[1:] + [len(blob)] == ref
+
+
+def _covers(pat, text):
+    at = 0
+    for m in regex.finditer(pat, text):
+        if m.start() != at:
+            return False
+        at = m.end()
+    return at == len(text)
 
 
 @pytest.mark.parametrize("name,pat", VARIANTS, ids=[v[0] for v in VARIANTS])
@@ -164,8 +183,11 @@ def _pattern_from(family, contr, ci, digits, suffix, dollar, nl_rule, spell):
 
 def test_generated_patterns_equal_regex():
     """Patterns generated from random parameters (contraction list, case sensitivity, digit group, suffix set, white-space rules, and the
-    equivalent spellings of each part): whatever the parser accepts must split exactly as Python `regex` does; what it refuses must say
-    why.  (The parser refuses e.g. a one-letter contraction that begins a two-letter one.)"""
+    equivalent spellings of each part): whatever the family parser accepts must split exactly as Python `regex` does under the
+    hand-written scanners; what it refuses (e.g. a one-letter contraction that begins a two-letter one) runs on the generic engine, with
+    the same split."""
+    from tiktoken_amd import _lib
+
     rng = random.Random(20260921)
     letters1, letters2 = list("sdmtnxe"), ["ll", "ve", "re", "nt", "em", "dx", "ar"]
     accepted = refused = 0
@@ -176,12 +198,13 @@ def test_generated_patterns_equal_regex():
         pat = _pattern_from(family, contr, rng.random() < 0.6, rng.choice([0, 1, 1, 2, 3, 3, 5, 12]), rng.choice([0, 1, 1, 2, 3, 3]),
                             rng.random() < 0.5, rng.random() < 0.75, rng.randrange(64))
         regex.compile(pat)  # (a well-formed pattern whatever the parser thinks of it)
-        try:
-            sim = h.HostSim(pat, TINY, {})
-        except ValueError as e:
+        if _lib.lib().tk_pattern_id(pat.encode()) == 3:  # not a member of the scanner families: the generic engine (tk_regex.cpp) takes it
             refused += 1
-            assert str(e).startswith("unsupported pat_str: ")
+            rx = h.RxSim(pat)
+            blob, off = h.pack([d.encode() for d in texts])
+            assert rx.split([d.encode() for d in texts])[1:] + [len(blob)] == _ends_regex(pat, texts, off), pat
             continue
+        sim = h.HostSim(pat, TINY, {})
         accepted += 1
         for i in range(0, len(texts), 9):
             docs = texts[i:i + 9]

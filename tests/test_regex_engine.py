@@ -3,6 +3,7 @@ the two split kernels run per lane (tests/hostsim), against Python `regex` -- th
 (tools/gen_golden.py; reference tiktoken/core.py:395-404 splits with it too).  The GPU side is tests/test_gpu_regex.py."""
 import random
 
+import numpy as np
 import pytest
 import regex
 
@@ -66,8 +67,8 @@ def test_split_equals_python_regex(idx):
         want += [base + s for s in st]
         base += len(ok_docs[-1])
     assert len(ok_docs) > 20
-    assert rx.split(ok_docs, speculate=False) == want
-    assert rx.split(ok_docs, speculate=True) == want
+    for speculate in (0, 1, 2):
+        assert rx.split(ok_docs, speculate=speculate) == want, speculate
 
 
 def test_long_runs_and_speculation_work():
@@ -77,14 +78,15 @@ def test_long_runs_and_speculation_work():
     rng = random.Random(7)
     doc = "".join(rng.choice(["hello ", "World", " 12345", "\n", "x" * 3000, " " * 700, "中文", "é", "...", "CamelCase"]) for _ in range(60000))
     want = py_starts(PATTERNS[6][1], doc)
-    got = rx.split([doc.encode()], speculate=True)
+    got = rx.split([doc.encode()], speculate=2)
     assert got == want
+    assert rx.split([doc.encode()], speculate=1) == want
     spec_runs, resolve_runs = rx.stats
     assert resolve_runs < len(want) // 50, (resolve_runs, len(want))
     assert rx.split([doc.encode()], speculate=False) == want
     one = ("y" * 3_000_000).encode()
-    assert rx.split([one, one[:5000]]) == [0, 3_000_000]
-    assert rx.stats[0] < 3 * 3_000_000 // 1024 + 10  # (lanes inside the run give up at once)
+    assert rx.split([one, one[:5000]], speculate=2) == [0, 3_000_000]
+    assert rx.stats[0] < 3 * 3_000_000 // 1024 + 10  # (lanes inside the run give up after one look)
 
 
 def test_special_tokens_cut_the_haystack():
@@ -101,7 +103,7 @@ def test_special_tokens_cut_the_haystack():
         else:
             want += [at + s for s in py_starts(pat, part)]
         at += len(part.encode())
-    for spec in (False, True):
+    for spec in (0, 1, 2):
         assert rx.split([text.encode()], specials, speculate=spec) == want
     big = ("lorem ipsum " * 300 + sp) * 20
     specials = [(m.start(), len(sp)) for m in regex.finditer(regex.escape(sp), big)]
@@ -135,3 +137,31 @@ def test_gaps_and_errors_are_loud():
 def test_unsupported_patterns_say_why(pat, why):
     with pytest.raises(ValueError, match=regex.escape(why)):
         h.RxSim(pat)
+
+
+@pytest.mark.parametrize("idx", [5, 6, 9, 13])
+def test_front_kernel_scanners_cut_at_hard_starts_only(idx):
+    """What the front kernel does with a pat_str of the generic engine: tk_create gives it a class table in which every char is a letter and
+    the "no split" member of the r50k family, and the engine's piece starts arrive as hard starts.  Every scanner form of the device headers
+    (byte walk, bit-parallel, the per-tile rule, the 16-bytes-per-lane classification) must then reproduce exactly those starts."""
+    pat, py = PATTERNS[idx]
+    rng = random.Random(100 + idx)
+    docs = []
+    while len(docs) < 60:
+        d = random_text(rng, rng.choice([1, 5, 50, 800])) if rng.random() < 0.7 else h.fuzz_doc(rng)[:30000]
+        try:
+            py_starts(py or pat, d)
+        except LookupError:
+            continue
+        docs.append(d.encode())
+    starts = h.RxSim(pat).split(docs)
+    blob, _ = h.pack(docs)
+    n = len(blob)
+    pieces = np.array(starts + [n], np.uint64)  # every piece a "document": its start is a hard start
+    sim = h.HostSim(pat, {bytes([b]): b for b in range(256)}, {})
+    want = pieces[1:]
+    for ends, _ in (sim.piece_ends(blob, pieces), sim.piece_ends(blob, pieces, bits=True), sim.piece_ends_tiled(blob, pieces),
+                    sim.piece_ends_tiled(blob, pieces, tile=64, left=16)):
+        assert np.array_equal(ends, want)
+    bad, pos, code = sim.chunk_check(blob, pieces)
+    assert bad == 0, (pos, code)

@@ -20,6 +20,7 @@
 #include "tk_fused.h"
 #include "tk_tables.h"
 #include "tk_unicode_tables.inc"
+#include "tk_regex_kernels.h"
 
 static thread_local std::string g_err;
 static int fail(int code, const std::string& msg) {
@@ -74,6 +75,9 @@ struct tk_core {
     TkTables D;  // device view
     Buf t_stage1, t_stage2, t_byte_tab, t_short, t_mid, t_dec, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_spec_bytes, t_spec_off, t_spec_id;
     uint32_t spec_max_len = 0;
+    bool has_rx = false;  // the pat_str runs on the generic engine (tk_regex_kernels.h)
+    TkRxDev rx{};
+    Buf t_rx_ins, t_rx_sets, t_rx_ranges, t_rx_s1, t_rx_s2, rx_spec, rx_gst, rx_exit;
     std::mutex mu;
     // workspace
     Buf text, text_al, tile_sum, wide_ws, scan_sums, row_base, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, res, rflag, staging, listB, listC, counters, total, g_id, g_rk, g_nx,
@@ -209,7 +213,8 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     *out = nullptr;
     {
         TkPat pp;
-        const std::string perr = tk_parse_pattern(pat_str, &pp);
+        TkRxCompiled prx;
+        const std::string perr = tk_compile_pattern(pat_str, &pp, nullptr, &prx);
         if (!perr.empty()) return fail(TK_UNSUPPORTED, perr);
     }
     int ndev = 0;
@@ -237,12 +242,29 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     if (hipHostMalloc((void**)&c->h_counters, 256, hipHostMallocDefault) != hipSuccess) return bail(fail(TK_RUNTIME_ERROR, "hipHostMalloc failed"));
     const TkHostTables& H = c->H;
     int rc;
-    if ((rc = upload(c->t_stage1, tk_uc_stage1, sizeof tk_uc_stage1))) return bail(rc);
-    if ((rc = upload(c->t_stage2, tk_uc_stage2, sizeof tk_uc_stage2))) return bail(rc);
-    {
+    if (H.rx.empty()) {
+        if ((rc = upload(c->t_stage1, tk_uc_stage1, sizeof tk_uc_stage1))) return bail(rc);
+        if ((rc = upload(c->t_stage2, tk_uc_stage2, sizeof tk_uc_stage2))) return bail(rc);
         uint32_t bt[256 * 2];
         tk_build_byte_table(tk_uc_stage1, tk_uc_stage2, bt);
         if ((rc = upload(c->t_byte_tab, bt, sizeof bt))) return bail(rc);
+    } else {
+        // The generic engine splits (tk_regex_kernels.h) and hands every piece start to the front kernel as a hard start; the scanners
+        // then run over a class table in which every char is a lower-case letter: a piece is a run of letters up to the next hard start.
+        std::vector<uint8_t> s1(0x1100, 0), s2(256, (uint8_t)TK_C_LL);
+        if ((rc = upload(c->t_stage1, s1.data(), s1.size()))) return bail(rc);
+        if ((rc = upload(c->t_stage2, s2.data(), s2.size()))) return bail(rc);
+        uint32_t bt[256 * 2];
+        tk_build_byte_table(s1.data(), s2.data(), bt);
+        if ((rc = upload(c->t_byte_tab, bt, sizeof bt))) return bail(rc);
+        if ((rc = upload(c->t_rx_ins, H.rx.ins.data(), H.rx.ins.size() * sizeof(TkRxIns)))) return bail(rc);
+        if ((rc = upload(c->t_rx_sets, H.rx.sets.data(), H.rx.sets.size() * sizeof(TkRxSet)))) return bail(rc);
+        if ((rc = upload(c->t_rx_ranges, H.rx.ranges.data(), H.rx.ranges.size() * 4))) return bail(rc);
+        if ((rc = upload(c->t_rx_s1, tk_rx_props_stage1(), 0x1100))) return bail(rc);
+        if ((rc = upload(c->t_rx_s2, tk_rx_props_stage2(), (size_t)tk_rx_props_blocks() * 256))) return bail(rc);
+        c->rx = TkRxDev{c->t_rx_ins.as<TkRxIns>(), c->t_rx_sets.as<TkRxSet>(), c->t_rx_ranges.as<uint32_t>(), c->t_rx_s1.as<uint8_t>(),
+                        c->t_rx_s2.as<uint8_t>(), (uint32_t)H.rx.ins.size(), (uint32_t)H.rx.sets.size(), (uint32_t)H.rx.ranges.size() / 2};
+        c->has_rx = true;
     }
     if ((rc = upload(c->t_short, H.short_tab.data(), H.short_tab.size() * sizeof(TkShortSlot)))) return bail(rc);
     if ((rc = upload(c->t_mid, H.mid_tab.data(), H.mid_tab.size() * sizeof(TkPieceSlot)))) return bail(rc);
@@ -309,6 +331,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
 extern "C" void tk_destroy(tk_core* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
+    for (Buf* b : {&c->t_rx_ins, &c->t_rx_sets, &c->t_rx_ranges, &c->t_rx_s1, &c->t_rx_s2, &c->rx_spec, &c->rx_gst, &c->rx_exit}) release(*b);
     for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_dec, &c->d_tok, &c->d_lens, &c->d_bsum, &c->d_tboff, &c->d_bytes, &c->d_boff, &c->t_piece, &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2,
                    &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->text_al, &c->tile_sum, &c->wide_ws, &c->scan_sums, &c->row_base, &c->doc_off, &c->brk, &c->docb,
                    &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->res, &c->rflag, &c->staging, &c->listB,
@@ -462,6 +485,24 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
                 hipLaunchKernelGGL(tk_k_spec_resolve, dim3(grid_for(nwords, 256, 65536)), dim3(256), 0, s, T, d_text, n, allowed, docb, cand,
                                    c->spec_max_len, ss, si, brk);
             }));
+        }
+        if (c->has_rx) {  // the generic engine finds the piece starts; they join the hard starts in `brk`
+            const uint32_t seg_shift = n < TK_RX_SEG_SMALL_BELOW ? TK_RX_SEG_SHIFT_SMALL : TK_RX_SEG_SHIFT_LARGE;
+            const uint64_t nseg = (n + (1ull << seg_shift) - 1) >> seg_shift;
+            TRY(ensure(c->rx_spec, (nwords + 2) * 4));
+            TRY(ensure(c->rx_gst, (nwords + 2) * 4));
+            TRY(ensure(c->rx_exit, (nseg + 2) * 4));
+            HIPCHK(hipMemsetAsync(c->rx_spec.p, 0, (nwords + 2) * 4, s));
+            HIPCHK(hipMemsetAsync(c->rx_gst.p, 0, (nwords + 2) * 4, s));
+            uint32_t *spec = c->rx_spec.as<uint32_t>(), *gst = c->rx_gst.as<uint32_t>(), *xexit = c->rx_exit.as<uint32_t>();
+            TRY(timed(c, s, "tk_k_rx_speculate", [&] {
+                hipLaunchKernelGGL(tk_k_rx_speculate, dim3(grid_for(nseg, 256, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, seg_shift, spec, xexit);
+            }));
+            TRY(timed(c, s, "tk_k_rx_resolve", [&] {
+                hipLaunchKernelGGL(tk_k_rx_resolve, dim3(grid_for(n_docs, 256, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, d_doc_off, n_docs,
+                                   base, seg_shift, spec, xexit, gst, counters);
+            }));
+            TRY(timed(c, s, "tk_k_rx_merge", [&] { hipLaunchKernelGGL(tk_k_rx_merge, dim3(grid_for(nwords, 256, 4096)), dim3(256), 0, s, brk, gst, nwords); }));
         }
         if (n > 32768 && !pretok_only) {  // in-call de-duplication of missed pieces pays for its table reset only on real batches
             while (mt_bits < TK_MT_BITS && (1ull << mt_bits) < n / 128) ++mt_bits;  // 4 Mi slots from 512 MiB up
@@ -629,6 +670,12 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         nB += hb[TK_CNT_BIN0 + b];
         if ((c->dbg & 64) && hb[TK_CNT_BIN0 + b]) fprintf(stderr, "bin %d (%u..%u bytes): %u pieces\n", b, tk_bin_lo(b), tk_bin_hi(b), hb[TK_CNT_BIN0 + b]);
     }
+    if (hb[TK_CNT_ERR] & TK_RX_ERR_GAP)
+        return fail(TK_VALUE_ERROR, "pat_str does not match at byte " + std::to_string(base + (uint64_t)(~hb[TK_CNT_RXPOS])) +
+                                        " of the batch: the reference would drop the text up to the next match; this library refuses patterns that leave gaps");
+    if (hb[TK_CNT_ERR] & TK_RX_ERR_STACK)
+        return fail(TK_VALUE_ERROR, "pat_str: a repeated group needs more backtracking state than the matcher keeps (piece at byte " +
+                                        std::to_string(base + (uint64_t)(~hb[TK_CNT_RXPOS])) + " of the batch); make the group possessive, e.g. (?:...)++");
     if (hb[TK_CNT_ERR]) return fail(TK_RUNTIME_ERROR, "internal error in the front kernel (scanner list overflow, code " + std::to_string(hb[TK_CNT_ERR]) + ")");
     const uint64_t T_total = tp[0];
     c->st_bytes += n;
@@ -828,7 +875,7 @@ extern "C" int tk_encode_batch(tk_core* c, const uint8_t* utf8, const uint64_t* 
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const uint64_t n_bytes = doc_off[n_docs];
-    if (n_docs == 1 && n_bytes > 0 && n_bytes <= TK_SMALL_MAX && !(use_special && n_allowed) && !(c->dbg & 2048)) {
+    if (n_docs == 1 && n_bytes > 0 && n_bytes <= TK_SMALL_MAX && !(use_special && n_allowed) && !(c->dbg & 2048) && !c->has_rx) {
         bool handled = false;
         TRY(encode_small(c, utf8, (uint32_t)n_bytes, tokens_out, n_tokens_out, &handled));
         if (handled) {

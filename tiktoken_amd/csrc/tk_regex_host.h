@@ -16,7 +16,7 @@ struct TkRxCompiled {
     std::vector<TkRxSet> sets;
     std::vector<uint32_t> ranges;  // pairs (lo, hi)
     bool empty() const { return ins.empty(); }
-    // a view over the vectors and the built-in property table (host-side matching: tests/hostsim, tk_create's self-check)
+    // a view over the vectors and the built-in property table (host-side matching by the CPU tests)
     TkRxProg view() const;
 };
 

@@ -1,9 +1,9 @@
 // Piece starts of a chunk under a compiled pat_str (tk_regex.h), found in parallel and then proven -- the work of one lane of each of the
-// two kernels of tk_regex_kernels.h, written for host and device so that tests/hostsim can run the very same code lane by lane.
+// two kernels of tk_regex_kernels.h, written for host and device so that the CPU tests can run the very same code lane by lane.
 //
 // The chain of piece starts of a document is sequential: the next start is where the match that begins at this one ends (reference:
 // find_iter, src/lib.rs:365).  But the end of the match that starts at p depends only on the text from p on (no look-behind), so:
-//   1. tk_rx_speculate_lane: the text is cut into segments of TK_RX_SEG bytes; lane k starts at the first char of segment k AS IF it
+//   1. tk_rx_speculate_lane: the text is cut into segments of 256 or 1024 bytes; lane k starts at the first char of segment k AS IF it
 //      were a piece start and follows the chain to the end of its segment, noting every start in the bitmap `spec` and the position at which
 //      it leaves the segment in `xexit[k]`.  Chains that start at different places run together after a few pieces, so most of these
 //      guesses are right from some point on -- but nothing here is trusted yet.
@@ -20,13 +20,17 @@
 #pragma once
 #include "tk_regex.h"
 
-#define TK_RX_SEG 1024u     // bytes per speculative segment (a multiple of 32: a segment owns its words of the bitmap)
-#define TK_RX_AHEAD 4096u   // bytes a speculative match may look beyond its segment
+// bytes per speculative segment = 1 << seg_shift (a multiple of 32: a segment owns its words of the bitmap): 256 for chunks that would
+// not fill the GPU with 1 KiB segments, 1024 otherwise (fewer, longer chains: less is matched twice around the segment boundaries)
+#define TK_RX_SEG_SHIFT_SMALL 8u
+#define TK_RX_SEG_SHIFT_LARGE 10u
+#define TK_RX_SEG_SMALL_BELOW (256ull << 20)  // chunk bytes
+#define TK_RX_AHEAD 16384u  // bytes a speculative match may look beyond its segment
 #define TK_RX_UNKNOWN 0xFFFFFFFFu
 #define TK_RX_ERR_GAP 4u       // bits of the chunk's error word
 #define TK_RX_ERR_STACK 8u
 #ifndef TK_RX_ON_MATCH
-#define TK_RX_ON_MATCH()  // (tests/hostsim counts the matcher's runs here)
+#define TK_RX_ON_MATCH()  // (the CPU tests count the matcher's runs here)
 #endif
 
 struct TkRxText {
@@ -37,13 +41,31 @@ struct TkRxText {
     const uint32_t* si;   // special-token interiors
     uint32_t limit;       // a speculative match sees the end of the text here ...
     bool hit;             // ... and says so
-    TK_HD uint32_t byte(uint32_t p) const { return text[p]; }
+    // the text word and the bitmap word read last: a lane walks its text byte by byte, one load per four bytes / thirty-two positions
+    uint32_t tw_at = 0xFFFFFFFFu, tw = 0, bw_at = 0xFFFFFFFFu, bw = 0;
+    TK_HD uint32_t byte(uint32_t p) {
+        const uint32_t i = p >> 2;
+        if (i != tw_at) {
+            tw_at = i;
+#if defined(__HIP_DEVICE_COMPILE__)
+            tw = *(const uint32_t*)(text + 4u * (size_t)i);  // (the chunk's text is 16-byte aligned and readable 64 bytes past n)
+#else
+            __builtin_memcpy(&tw, text + 4u * (size_t)i, 4);
+#endif
+        }
+        return (tw >> (8u * (p & 3u))) & 0xFFu;
+    }
     TK_HD bool hard(uint32_t p) {
         if (p >= limit) {
             hit = true;
             return true;
         }
-        return (brk[p >> 5] >> (p & 31u)) & 1u;
+        const uint32_t i = p >> 5;
+        if (i != bw_at) {
+            bw_at = i;
+            bw = brk[i];
+        }
+        return (bw >> (p & 31u)) & 1u;
     }
     TK_HD bool special(uint32_t p) const { return ss && ((ss[p >> 5] >> (p & 31u)) & 1u); }
     TK_HD bool inside_special(uint32_t p) const { return si && ((si[p >> 5] >> (p & 31u)) & 1u); }
@@ -60,10 +82,11 @@ TK_HD uint32_t tk_rx_next(const TkRxProg& P, TkRxText& t, uint32_t p) {
     return tk_rx_match(P, t, p);
 }
 
-TK_HD void tk_rx_speculate_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint32_t* spec, uint32_t* xexit) {
-    const uint64_t a64 = (uint64_t)k * TK_RX_SEG;
+TK_HD void tk_rx_speculate_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint32_t seg_shift, uint32_t* spec, uint32_t* xexit) {
+    const uint64_t a64 = (uint64_t)k << seg_shift;
     if (a64 >= t.n) return;
-    const uint32_t a = (uint32_t)a64, end = t.n - a > TK_RX_SEG ? a + TK_RX_SEG : t.n;
+    const uint32_t seg = 1u << seg_shift;
+    const uint32_t a = (uint32_t)a64, end = t.n - a > seg ? a + seg : t.n;
     t.limit = t.n - end > TK_RX_AHEAD ? end + TK_RX_AHEAD : t.n;
     t.hit = false;
     uint32_t p = a;
@@ -87,16 +110,16 @@ TK_HD void tk_rx_speculate_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint3
 // One document [b, e) of the chunk.  `orbits(word index, bits)` ORs into the bitmap of true starts (shared words: atomic on the device).
 // Returns 0 or the error bits.
 template <class Or>
-TK_HD uint32_t tk_rx_resolve_lane(const TkRxProg& P, TkRxText t, uint32_t b, uint32_t e, const uint32_t* spec, const uint32_t* xexit, Or&& orbits,
-                                  uint32_t* err_pos) {
+TK_HD uint32_t tk_rx_resolve_lane(const TkRxProg& P, TkRxText t, uint32_t b, uint32_t e, uint32_t seg_shift, const uint32_t* spec, const uint32_t* xexit,
+                                  Or&& orbits, uint32_t* err_pos) {
     t.limit = 0xFFFFFFFFu;
     t.hit = false;
     uint32_t p = b;
     while (p < e) {
         bool run = true;
         if (spec && ((spec[p >> 5] >> (p & 31u)) & 1u)) {  // on segment k's chain: its bits from p on are true starts
-            const uint32_t k = p / TK_RX_SEG;
-            const uint64_t se64 = ((uint64_t)k + 1u) * TK_RX_SEG;
+            const uint32_t k = p >> seg_shift;
+            const uint64_t se64 = ((uint64_t)k + 1u) << seg_shift;
             const uint32_t seg_end = se64 < e ? (uint32_t)se64 : e;
             uint32_t last = p;
             for (uint32_t w = p >> 5; w <= (seg_end - 1u) >> 5; ++w) {

@@ -8,7 +8,26 @@
 
 int tk_pattern_id(const char* pat_str) {
     TkPat p;
-    return tk_parse_pattern(pat_str, &p).empty() ? p.fam() : -1;
+    TkRxCompiled rx;
+    if (!tk_compile_pattern(pat_str, &p, nullptr, &rx).empty()) return -1;
+    return rx.empty() ? p.fam() : 3;
+}
+
+// r50k family, generic kernels, no contractions: with every char classed as a letter its only alternative that ever matches is \p{L}+,
+// which runs from one hard start to the next
+TkPat tk_nosplit_pat() { return TkPat{(uint32_t)TK_PAT_R50K | 32u, 0u, {0u, 0u}}; }
+
+std::string tk_compile_pattern(const char* pat_str, TkPat* pat, uint16_t* cert, TkRxCompiled* rx) {
+    const std::string perr = tk_parse_pattern(pat_str, pat, cert);
+    if (perr.empty()) return "";
+    const std::string rerr = tk_rx_compile(pat_str, rx);
+    if (!rerr.empty()) {
+        rx->ins.clear();
+        return "pat_str is not supported: " + rerr + " [and it is not one of the hand-written scanner families: " + perr + "]";
+    }
+    *pat = tk_nosplit_pat();
+    if (cert) memset(cert, 0, 16 * sizeof(uint16_t));  // no certain starts but the hard ones
+    return "";
 }
 
 uint64_t tk_key_of_bytes(const uint8_t* p, uint32_t len) {
@@ -97,7 +116,7 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
                             const uint32_t* spec_ids, uint64_t n_spec, const char* pat_str, TkHostTables* out) {
     TkHostTables& T = *out;
     {
-        const std::string perr = tk_parse_pattern(pat_str, &T.pat, T.cert);
+        const std::string perr = tk_compile_pattern(pat_str, &T.pat, T.cert, &T.rx);
         if (!perr.empty()) return perr;
         T.pattern = T.pat.fam();
     }

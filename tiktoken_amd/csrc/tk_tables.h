@@ -8,11 +8,14 @@
 #include <vector>
 
 #include "tk_common.h"
+#include "tk_regex_host.h"
 
 struct TkHostTables {
     int pattern = -1;  // family of the split pattern
     TkPat pat{};       // the pattern (tk_pattern.cpp)
     uint16_t cert[16] = {0};  // its certain piece starts
+    TkRxCompiled rx;          // a pat_str outside the scanner families: its program for the generic engine (tk_regex.cpp); pat is then
+                              // the "no split" member of the r50k family, run over a class table in which every char is a letter
     std::vector<uint8_t> tok_bytes;
     std::vector<TkShortSlot> short_tab;  // tokens of 1..4 bytes (empty when a rank exceeds TK_SHORT_MAX_RANK)
     uint32_t short_mask = 0, short_shift = 0;
@@ -45,14 +48,19 @@ struct TkHostTables {
 // key of a byte string as stored in the piece table
 uint64_t tk_key_of_bytes(const uint8_t* p, uint32_t len);
 
-// Returns "" on success or an error message.  pat_str must be one of the stock patterns of
-// reference tiktoken_ext/openai_public.py:12-14,89,104-114 (or the GPT-2 spelling at :9-11).
+// Returns "" on success or an error message.  pat_str: a member of the three scanner families (tk_pattern.cpp) or anything the generic
+// engine compiles (tk_regex.cpp).
 std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uint32_t* ranks_ids,
                             uint64_t n_ranks, const uint8_t* spec_blob, const uint64_t* spec_off,
                             const uint32_t* spec_ids, uint64_t n_spec, const char* pat_str, TkHostTables* out);
 
-// family of a pat_str (TK_PAT_*), or -1 when the library has no scanner for it (exported through the C ABI, include/tiktoken_amd.h)
+// family of a pat_str (TK_PAT_*), 3 when it runs on the generic engine, or -1 when it is not supported at all (exported through the
+// C ABI, include/tiktoken_amd.h)
 extern "C" int tk_pattern_id(const char* pat_str);
+// pat_str -> scanner family + parameters, or the generic engine's program: "" or why neither understands the pattern
+std::string tk_compile_pattern(const char* pat_str, TkPat* pat, uint16_t* cert, TkRxCompiled* rx);
+// the pattern the front kernel runs when the generic engine has done the split: pieces end at hard starts and nowhere else
+TkPat tk_nosplit_pat();
 // pat_str -> TkPat (tk_pattern.cpp): "" or the reason why the pattern is not supported
 // cert_out (may be null): the table of certain piece starts, [16] class masks -- the family's for a stock pattern, else the family's
 // minus every pair for which a counter-example exists among all short strings over class representatives and random longer ones
