@@ -150,3 +150,27 @@ def test_one_large_document_and_multi_chunk(monkeypatch):
     small_chunks = make_core(pat)
     toks, toff = small_chunks.encode_batch_packed(blob, off)
     assert np.array_equal(toff, ro) and np.array_equal(toks, rt)
+
+
+@pytest.mark.parametrize("name,mix,nbytes", [("gpt2_shaped", 2, 4 << 20), ("cl100k_shaped", 0, 8 << 20), ("o200k_shaped", 1, 16 << 20)])
+def test_stock_patterns_through_the_generic_engine_equal_the_scanners(name, mix, nbytes, monkeypatch):
+    """The stock pat_str compiled for the generic engine (TIKTOKEN_AMD_DEBUG=1048576) against the hand-written scanners of its family on
+    the bench corpora, with and without special tokens: two independent implementations of the split, every token equal (and equal to the
+    oracle: test_gpu_parity.py holds the scanners to it on the same corpora)."""
+    from tiktoken_amd import CoreBPE
+
+    g = h.load_golden(name)
+    blob, off = h.gen_corpus(0x5EED0100 + mix, mix, nbytes)
+    blob, off = h.insert_specials(blob, off)
+    top = max(max(g["special_tokens"].values()), max(h.golden_vocab(name).values()))
+    specials = {**g["special_tokens"], **{f"<|custom_{i}|>": top + 1 + i for i in range(8)}}
+    scanners = CoreBPE(h.golden_vocab(name), specials, g["pat_str"])
+    monkeypatch.setenv("TIKTOKEN_AMD_DEBUG", "1048576")
+    generic = CoreBPE(h.golden_vocab(name), specials, g["pat_str"])
+    monkeypatch.delenv("TIKTOKEN_AMD_DEBUG")
+    for allowed in (None, "all"):
+        t1, o1 = scanners.encode_batch_packed(blob, off, allowed)
+        t2, o2 = generic.encode_batch_packed(blob, off, allowed)
+        assert np.array_equal(o1, o2), allowed
+        assert np.array_equal(t1, t2), allowed
+        assert np.array_equal(scanners.pretokenize_packed(blob, off, allowed), generic.pretokenize_packed(blob, off, allowed))

@@ -165,3 +165,22 @@ def test_front_kernel_scanners_cut_at_hard_starts_only(idx):
         assert np.array_equal(ends, want)
     bad, pos, code = sim.chunk_check(blob, pieces)
     assert bad == 0, (pos, code)
+
+
+@pytest.mark.parametrize("name,mix,nbytes", [("gpt2_shaped", 2, 2 << 20), ("cl100k_shaped", 0, 6 << 20), ("o200k_shaped", 1, 6 << 20)])
+def test_stock_patterns_through_the_generic_engine_equal_the_oracle_split(name, mix, nbytes):
+    """The three stock pat_str compiled for the generic engine, on the bench corpora, against the oracle's sequential scanner (itself pinned to
+    Python `regex`): the engine could replace the hand-written scanners, it is only slower."""
+    pat = h.load_golden(name)["pat_str"]
+    rx, C = h.RxSim(pat), h.c_oracle_for(name)
+    blob, off = h.gen_corpus(0x5EED0200 + mix, mix, nbytes)
+    bb = blob.tobytes()
+    docs = [bb[int(off[d]):int(off[d + 1])] for d in range(len(off) - 1)]
+    want = []
+    for d, doc in enumerate(docs):
+        if doc:
+            want += [int(off[d])] + [int(off[d]) + e for e in C.split(doc)[:-1]]
+    for speculate in (1, 2):
+        assert rx.split(docs, speculate=speculate) == want
+        spec_runs, resolve_runs = rx.stats
+        assert resolve_runs < len(want) // 5, (resolve_runs, len(want))  # (most of the matching is done by the speculative lanes)
