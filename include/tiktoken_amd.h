@@ -31,17 +31,24 @@ int tk_device_count(void);
 
 /* CoreBPE.__new__(encoder, special_tokens_encoder, pattern)            src/py.rs:15-23, src/lib.rs:618-663
  * ranks: n_ranks byte strings ranks_blob[ranks_off[i]..ranks_off[i+1]) with ids ranks_ids[i];
- * specials likewise (UTF-8).  pat_str must be one of the stock patterns of
- * tiktoken_ext/openai_public.py:12-14,89,104-114 (TK_UNSUPPORTED otherwise).  Duplicate ranks ->
- * TK_VALUE_ERROR (the reference panics, src/lib.rs:636-641).  device = HIP device ordinal. */
+ * specials likewise (UTF-8).  pat_str: the split regex, compiled once here (Regex::new, src/lib.rs:623).  The three families of
+ * tiktoken_ext/openai_public.py:12-14,89,104-114 (stock strings, their other spellings, variations of the contraction list, digit
+ * group, suffix set and white-space rules) run on hand-written scanners; any other pattern in the syntax fancy-regex shares with
+ * Python `regex` -- classes, \p{General_Category}, alternation, groups, (?i: ), greedy / lazy / possessive quantifiers, atomic groups,
+ * look-ahead, ^ $ -- is compiled to a program for the generic GPU engine (tk_regex.cpp).  Refused with TK_UNSUPPORTED and the
+ * reason: look-behind, \b, back-references, script properties, a pattern that can match the empty string.  A pattern that leaves
+ * text unmatched (the reference drops such text silently) makes the encode call fail with TK_VALUE_ERROR and the byte offset.
+ * Text must be valid UTF-8 (the reference's boundary is &str); other bytes never crash but their split is unspecified.
+ * Duplicate ranks -> TK_VALUE_ERROR (the reference panics, src/lib.rs:636-641).  device = HIP device ordinal. */
 int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uint32_t* ranks_ids, uint64_t n_ranks,
               const uint8_t* spec_blob, const uint64_t* spec_off, const uint32_t* spec_ids, uint64_t n_spec,
               const char* pat_str, int device, tk_core** out);
 void tk_destroy(tk_core* core);
 
-/* Family (0 r50k/gpt2, 1 cl100k, 2 o200k) of a pat_str the library has scanners for -- the stock patterns, their other spellings,
- * and variations of the contraction list, digit group, suffix set and white-space rules (tk_pattern.cpp) -- or -1.  Reference: the
- * regex compiled once per Encoding, src/lib.rs:623. */
+/* How a pat_str would run: 0 r50k/gpt2, 1 cl100k, 2 o200k -- a family the library has hand-written scanners for (the stock patterns,
+ * their other spellings, and variations of the contraction list, digit group, suffix set and white-space rules: tk_pattern.cpp);
+ * 3 -- the generic engine (tk_regex.cpp); -1 -- not supported (tk_create would say why).  Reference: the regex compiled once per
+ * Encoding, src/lib.rs:623. */
 int tk_pattern_id(const char* pat_str);
 
 /* Encoding.encode_ordinary_batch / encode_batch                        tiktoken/core.py:164-206

@@ -174,3 +174,13 @@ def test_stock_patterns_through_the_generic_engine_equal_the_scanners(name, mix,
         assert np.array_equal(o1, o2), allowed
         assert np.array_equal(t1, t2), allowed
         assert np.array_equal(scanners.pretokenize_packed(blob, off, allowed), generic.pretokenize_packed(blob, off, allowed))
+
+
+def test_exploding_backtracking_is_stopped():
+    """Nested quantifiers on a text that makes them explode ((?:a+)+b on a run of a's): fancy-regex gives up after 1 000 000 backtracks
+    (Error::BacktrackLimitExceeded -- a panic in the reference, src/lib.rs:365); the GPU matcher has the same kind of budget, so the call
+    fails instead of hanging the device."""
+    core = make_core(r"(?:a+)+b|[\s\S]")
+    assert core.encode_ordinary("aaab aab") == make_core(r"a+b|[\s\S]").encode_ordinary("aaab aab")
+    with pytest.raises(ValueError, match="backtrack limit"):
+        core.encode_ordinary("a" * 26)

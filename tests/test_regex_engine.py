@@ -30,10 +30,11 @@ PATTERNS = [
 ]
 
 
-def py_starts(pat: str, text: str) -> list[int]:
-    """Byte offsets of the pieces of `text`; raises if they do not cover it."""
+def py_starts(pat, text: str, timeout=None) -> list[int]:
+    """Byte offsets of the pieces of `text` (pat: a pattern string or a compiled pattern); raises LookupError if they do not cover it
+    (TimeoutError if `regex` needs longer than `timeout` seconds: exploding backtracking)."""
     out, at, b = [], 0, 0
-    for m in regex.finditer(pat, text):
+    for m in (regex.finditer(pat, text, timeout=timeout) if isinstance(pat, str) else pat.finditer(text, timeout=timeout)):
         if m.start() != at or m.end() == m.start():
             raise LookupError(at)
         out.append(b)
@@ -184,3 +185,93 @@ def test_stock_patterns_through_the_generic_engine_equal_the_oracle_split(name, 
         assert rx.split(docs, speculate=speculate) == want
         spec_runs, resolve_runs = rx.stats
         assert resolve_runs < len(want) // 5, (resolve_runs, len(want))  # (most of the matching is done by the speculative lanes)
+
+
+def _gen_pattern(rng: random.Random):
+    """A random pattern of the supported syntax, as (engine pattern, Python pattern): the two differ in how they spell end / start of text."""
+    lits = ["a", "b", "c", "x", "1", " ", r"\n", "'", r"\.", "s", "k", "é", "中"]
+    sets = [r"[a-c]", r"[^a\s]", r"\s", r"\S", r"\d", r"\w", r"\p{L}", r"\p{Lu}", r"\P{N}", r"[\s\S]", r"[^\S\n]", r"[x1\p{Ll}]", r"\p{Nd}", r"[^\r\n\p{L}\p{N}]",
+            r"[a\-c]", r"[\]x]", r"\pL", r"\x61", r"\u4e2d", r"[\x61-\x63]"]
+    quants = ["", "", "", "?", "*", "+", "{1,3}", "{2}", "{2,}", "??", "*?", "+?", "?+", "*+", "++", "{1,2}?", "{0,2}+"]
+
+    def atom(depth, ci):
+        r = rng.random()
+        if r < 0.35:
+            return rng.choice(lits)
+        if r < 0.75 or depth > 2:
+            s = rng.choice(sets)
+            return rng.choice(lits) if ci and ("Lu" in s or "Ll" in s) else s
+        if r < 0.8:
+            return "."
+        kind = rng.choice(["(?:", "(?:", "(", "(?>", "(?i:", "(?s:"])
+        if kind == "(?i:":
+            return kind + "|".join(rng.choice(["s", "k", "ab", "x1", "'s", "a b"]) for _ in range(rng.randint(1, 3))) + ")"
+        return kind + alt(depth + 1, ci, rng.randint(1, 3)) + ")"
+
+    def concat(depth, ci):
+        parts = [atom(depth, ci) + rng.choice(quants) for _ in range(rng.randint(0, 3))]
+        parts.insert(rng.randint(0, len(parts)), atom(depth, ci) + rng.choice(["", "", "+", "{2}", "{1,3}", "+?", "++"]))  # (at least one char)
+        if rng.random() < 0.2:
+            parts.append(rng.choice(["(?=", "(?!"]) + atom(depth + 1, ci) + ")")
+        return "".join(parts)
+
+    def alt(depth, ci, n):
+        return "|".join(concat(depth, ci) for _ in range(n))
+
+    body = alt(0, False, rng.randint(1, 5))
+    eng = py = body
+    if rng.random() < 0.25:
+        eng, py = eng + r"|\s+$", py + r"|\s+\Z"
+    if rng.random() < 0.15:
+        eng, py = r"^\w|" + eng, r"\A\w|" + py
+    if rng.random() < 0.75:
+        eng, py = eng + r"|[\s\S]", py + r"|[\s\S]"
+    return eng, py
+
+
+def test_generated_patterns_equal_python_regex():
+    """Random patterns over the whole supported syntax (classes, properties, escapes, the three kinds of quantifier, groups, atomic groups,
+    case-insensitive groups, look-ahead, anchors): whatever the compiler accepts must split every text as Python `regex` does, gaps included;
+    what it refuses must be refused for a stated reason."""
+    rng = random.Random(20260922)
+    alphabet = list("abcxABCX12 \n\t'.,sSkK") + ["ſ", "K", "é", "中", "É", "٣", "\r\n", "  ", "ab", "'s"]
+    texts = ["".join(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 2, 4, 8, 20, 60]))) for _ in range(120)]
+    texts += ["a" * 300, " " * 200 + "x", "ab" * 20, "x1" * 25 + "\n", "'s" * 12]
+    compiled = refused = deep = exploded = 0
+    for it in range(1000):
+        eng, py = _gen_pattern(rng)
+        pyc = regex.compile(py)
+        try:
+            rx = h.RxSim(eng)
+        except ValueError as e:
+            refused += 1
+            assert any(w in str(e) for w in ("empty string", "too large", "too many")), (eng, str(e))
+            continue
+        compiled += 1
+        good, want, base = [], [], 0
+        for t in texts:
+            try:
+                st = py_starts(pyc, t, timeout=0.25)
+            except TimeoutError:  # nested quantifiers that explode: the engine must give up as well (fancy-regex: BacktrackLimitExceeded) or be right
+                exploded += 1
+                try:
+                    rx.split([t.encode()])
+                except RuntimeError as e:
+                    assert "error 16" in str(e) or "error 8" in str(e) or "error 4" in str(e), (eng, str(e))
+                continue
+            except LookupError:
+                with pytest.raises(RuntimeError, match="error (4|8|16) at"):  # a gap (or, rarely, too deep / too much backtracking) is reported, never guessed
+                    rx.split([t.encode()])
+                continue
+            good.append(t.encode())
+            want += [base + s for s in st]
+            base += len(good[-1])
+        try:
+            got = rx.split(good, speculate=1 + (it & 1))
+        except RuntimeError as e:
+            # a backtracking repeated group in the middle of an alternative on a long text (8), or more backtracking than the budget (16)
+            assert "error 8" in str(e) or "error 16" in str(e), (eng, str(e))
+            deep += 1
+            continue
+        assert got == want, (eng, py)
+    assert compiled > 800 and deep < compiled // 15, (compiled, refused, deep, exploded)

@@ -676,6 +676,9 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
     if (hb[TK_CNT_ERR] & TK_RX_ERR_STACK)
         return fail(TK_VALUE_ERROR, "pat_str: a repeated group needs more backtracking state than the matcher keeps (piece at byte " +
                                         std::to_string(base + (uint64_t)(~hb[TK_CNT_RXPOS])) + " of the batch); make the group possessive, e.g. (?:...)++");
+    if (hb[TK_CNT_ERR] & TK_RX_ERR_LIMIT)
+        return fail(TK_VALUE_ERROR, "pat_str: backtrack limit exceeded at byte " + std::to_string(base + (uint64_t)(~hb[TK_CNT_RXPOS])) +
+                                        " of the batch (nested quantifiers; the reference's fancy-regex gives up after 1 000 000 backtracks as well)");
     if (hb[TK_CNT_ERR]) return fail(TK_RUNTIME_ERROR, "internal error in the front kernel (scanner list overflow, code " + std::to_string(hb[TK_CNT_ERR]) + ")");
     const uint64_t T_total = tp[0];
     c->st_bytes += n;

@@ -572,13 +572,14 @@ struct Emitter {
         }
         const bool lazy = N.mode == TK_RX_LAZY;
         if (N.mx == TK_RX_INF && !lazy && (N.mode == TK_RX_POSSESSIVE || tail)) {
-            // No way back into the loop is ever taken (possessive; or greedy where nothing can fail behind it): every repetition is atomic and
-            // forgets the previous one's way out -- a constant number of frames however often the group repeats.
-            for (uint32_t k = 0; k < N.mn; ++k) {
-                put(TK_RX_ATOM_BEGIN);
-                if (!emit(body, true)) return false;
-                put(TK_RX_ATOM_END);
-            }
+            // No way back into a finished repetition is ever taken once the minimum is reached (possessive; or greedy where nothing can
+            // fail behind the loop: the way out of the last repetition leads to a match): every further repetition is atomic and forgets
+            // the previous one's way out -- a constant number of frames however often the group repeats.  The first `mn` repetitions keep
+            // their alternatives (x{2,}: if the second cannot match, the first may have to give something back).
+            const bool poss = N.mode == TK_RX_POSSESSIVE;
+            if (poss) put(TK_RX_ATOM_BEGIN);
+            for (uint32_t k = 0; k < N.mn; ++k)
+                if (!emit(body, false)) return false;
             const uint32_t sp = put(TK_RX_SPLIT);
             code[sp].a = here();
             put(TK_RX_ATOM_BEGIN);
@@ -587,6 +588,7 @@ struct Emitter {
             put(TK_RX_POP);
             put(TK_RX_JMP, sp);
             code[sp].b = here();
+            if (poss) put(TK_RX_ATOM_END);
             return true;
         }
         const bool poss = N.mode == TK_RX_POSSESSIVE;

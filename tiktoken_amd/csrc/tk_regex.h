@@ -59,6 +59,13 @@ struct TkRxProg {
 
 #define TK_RX_FAILED 0xFFFFFFFFu    // no match at this position
 #define TK_RX_OVERFLOW 0xFFFFFFFEu  // backtrack stack exhausted (a repeated group on a long text)
+#define TK_RX_LIMIT 0xFFFFFFFDu     // backtrack budget exhausted (nested quantifiers that explode: the reference's fancy-regex gives up too)
+#define TK_RX_IS_ERROR(q) ((q) >= TK_RX_LIMIT)
+// Work one match may do, in steps (an instruction, a char of a repeat, a backtrack): fancy-regex's default limit of 1 000 000 backtracks
+// (Error::BacktrackLimitExceeded, which the reference turns into a panic) plus what linear walks over the text itself need (\s*[\r\n]+ on
+// a megabyte of blanks runs forward once and steps back a char at a time).
+#define TK_RX_BUDGET_BASE 1000000u
+#define TK_RX_BUDGET_PER_BYTE 8u
 #define TK_RX_STACK 64
 
 TK_HD uint32_t tk_rx_prop(const TkRxProg& P, uint32_t cp) {
@@ -105,10 +112,18 @@ TK_HD uint32_t tk_rx_match(const TkRxProg& P, A& t, uint32_t start) {
     uint32_t fk[TK_RX_STACK], fp[TK_RX_STACK], fa[TK_RX_STACK];  // frames: kind << 24 | pc, position, aux
     int sp = 0;
     uint32_t pc = 0, pos = start;
+    uint32_t steps = 0, far = start;  // work done; the farthest position looked at
+    auto spent = [&]() -> bool {
+        const uint32_t span = far - start < (1u << 28) ? far - start : (1u << 28);
+        return steps > TK_RX_BUDGET_BASE + TK_RX_BUDGET_PER_BYTE * span;
+    };
     auto at_end = [&](uint32_t p) -> bool { return p >= t.n || (p > start && t.hard(p)); };
     for (;;) {
         const TkRxIns I = P.ins[pc];
         bool fail = false;
+        if (pos > far) far = pos;
+        ++steps;
+        if (spent()) return TK_RX_LIMIT;
         switch (I.op & 0xFFu) {
             case TK_RX_SET: {
                 uint32_t len;
@@ -129,6 +144,8 @@ TK_HD uint32_t tk_rx_match(const TkRxProg& P, A& t, uint32_t start) {
                     pos += len;
                     if (++c == mn) pmin = pos;
                 }
+                steps += c;
+                if (pos > far) far = pos;
                 if (c < mn) {
                     fail = true;
                     break;
@@ -193,6 +210,7 @@ TK_HD uint32_t tk_rx_match(const TkRxProg& P, A& t, uint32_t start) {
         }
         while (fail) {  // backtrack
             if (sp == 0) return TK_RX_FAILED;
+            if (++steps > (3u << 30)) return TK_RX_LIMIT;  // (a pop is a step; the check proper is at the next instruction)
             --sp;
             const uint32_t kind = fk[sp] >> 24, tgt = fk[sp] & 0xFFFFFFu;
             if (kind == F_ALT) {

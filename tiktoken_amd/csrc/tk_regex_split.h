@@ -29,6 +29,7 @@
 #define TK_RX_UNKNOWN 0xFFFFFFFFu
 #define TK_RX_ERR_GAP 4u       // bits of the chunk's error word
 #define TK_RX_ERR_STACK 8u
+#define TK_RX_ERR_LIMIT 16u
 #ifndef TK_RX_ON_MATCH
 #define TK_RX_ON_MATCH()  // (the CPU tests count the matcher's runs here)
 #endif
@@ -71,7 +72,7 @@ struct TkRxText {
     TK_HD bool inside_special(uint32_t p) const { return si && ((si[p >> 5] >> (p & 31u)) & 1u); }
 };
 
-// the start that follows the piece (or special token) that starts at p; TK_RX_FAILED / TK_RX_OVERFLOW
+// the start that follows the piece (or special token) that starts at p; or an error code (TK_RX_IS_ERROR)
 TK_HD uint32_t tk_rx_next(const TkRxProg& P, TkRxText& t, uint32_t p) {
     if (t.special(p)) {
         uint32_t q = p + 1;
@@ -96,7 +97,7 @@ TK_HD void tk_rx_speculate_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint3
         for (;;) {
             spec[p >> 5] |= 1u << (p & 31u);  // (the words of a segment belong to its lane)
             const uint32_t q = tk_rx_next(P, t, p);
-            if (q >= TK_RX_OVERFLOW || t.hit) break;
+            if (TK_RX_IS_ERROR(q) || t.hit) break;
             if (q >= end) {
                 x = q;
                 break;
@@ -143,9 +144,9 @@ TK_HD uint32_t tk_rx_resolve_lane(const TkRxProg& P, TkRxText t, uint32_t b, uin
         }
         if (run) {
             const uint32_t q = tk_rx_next(P, t, p);
-            if (q >= TK_RX_OVERFLOW) {
+            if (TK_RX_IS_ERROR(q)) {
                 *err_pos = p;
-                return q == TK_RX_FAILED ? TK_RX_ERR_GAP : TK_RX_ERR_STACK;
+                return q == TK_RX_FAILED ? TK_RX_ERR_GAP : (q == TK_RX_OVERFLOW ? TK_RX_ERR_STACK : TK_RX_ERR_LIMIT);
             }
             p = q;
         }
