@@ -24,7 +24,10 @@ namespace {
 const char* const GC_NAMES[30] = {"Lu", "Ll", "Lt", "Lm", "Lo", "Mn", "Mc", "Me", "Nd", "Nl", "No", "Pc", "Pd", "Ps", "Pe",
                                   "Pi", "Pf", "Po", "Sm", "Sc", "Sk", "So", "Zs", "Zl", "Zp", "Cc", "Cf", "Cs", "Co", "Cn"};
 
-uint32_t prop_of(uint32_t cp) { return tk_rx_stage2[(uint32_t)tk_rx_stage1[cp >> 8] * 256u + (cp & 255u)]; }
+uint32_t prop_of(uint32_t cp) {
+    if (cp > 0x10FFFFu) cp = 0xFFFDu;
+    return tk_rx_stage2[(uint32_t)tk_rx_stage1[cp >> 8] * 256u + (cp & 255u)];
+}
 
 struct CharSet {
     bool neg = false;
@@ -209,6 +212,10 @@ struct Parser {
         }
     }
     static bool is_class_escape(uint32_t e) { return e == 'd' || e == 'D' || e == 's' || e == 'S' || e == 'w' || e == 'W' || e == 'p' || e == 'P'; }
+    bool scalar(uint32_t cp) {
+        if (cp > 0x10FFFFu || (cp >= 0xD800u && cp <= 0xDFFFu)) return fail("escape is not a Unicode scalar value");
+        return true;
+    }
     // a literal escape behind the backslash (i at the escape letter): one code point
     bool literal_escape(uint32_t* cp) {
         const uint32_t e = peek();
@@ -222,9 +229,9 @@ struct Parser {
             case 'a': *cp = 7; return true;
             case 'e': *cp = 27; return true;
             case '0': *cp = 0; return true;
-            case 'x': return peek() == '{' ? hex_braced(cp) : hex_fixed(2, cp);
-            case 'u': return peek() == '{' ? hex_braced(cp) : hex_fixed(4, cp);
-            case 'U': return hex_fixed(8, cp);
+            case 'x': return (peek() == '{' ? hex_braced(cp) : hex_fixed(2, cp)) && scalar(*cp);
+            case 'u': return (peek() == '{' ? hex_braced(cp) : hex_fixed(4, cp)) && scalar(*cp);
+            case 'U': return hex_fixed(8, cp) && scalar(*cp);
             default: break;
         }
         if (e >= '1' && e <= '9') return fail("back-references are not supported");
