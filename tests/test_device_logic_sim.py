@@ -252,3 +252,26 @@ def test_run_query_scanner_equals_the_byte_walking_one():
         sim.piece_ends(*h.pack(docs))
     assert h.sim_lib().tks_runs_mismatches() == before
     assert h.sim_lib().tks_never_violations() == never_before
+
+
+def test_scanners_under_the_sanitizers(tmp_path):
+    """tests/hostsim/scan_sanitize.cpp: every scanner form of the device headers and the 16-bytes-per-lane classification on random text
+    (valid UTF-8, truncated chars, stray continuation bytes, NULs, long runs, random document starts) in buffers sized as on the device,
+    built with AddressSanitizer and UBSan -- an out-of-bounds read that the GPU would answer with garbage ends the run here.
+    (3000 rounds per pattern ran clean as well: 60 000 calls.)"""
+    import os
+    import subprocess
+
+    exe = str(tmp_path / "scan_sanitize")
+    d = os.path.join(h.ROOT, "tests", "hostsim")
+    csrc = os.path.join(h.ROOT, "tiktoken_amd", "csrc")
+    cc = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-D_GLIBCXX_SANITIZE_VECTOR", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                         "-Wno-unused-function", os.path.join(d, "scan_sanitize.cpp"), os.path.join(csrc, "tk_tables.cpp"), os.path.join(csrc, "tk_pattern.cpp"),
+                         os.path.join(csrc, "tk_regex.cpp"), "-pthread", "-o", exe], capture_output=True, text=True)
+    if cc.returncode != 0 and "sanitize" in cc.stderr:
+        pytest.skip("this g++ has no sanitizer runtime")
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    qwen2 = h.PAT_STR[1].replace(r"\p{N}{1,3}", r"\p{N}")
+    run = subprocess.run([exe, h.PAT_STR[0], h.PAT_STR[1], h.PAT_STR[2], qwen2], capture_output=True, text=True, timeout=900,
+                         env={**os.environ, "TK_SAN_ROUNDS": "300"})
+    assert run.returncode == 0 and run.stdout.startswith("ok "), (run.stdout[-500:], run.stderr[-3000:])
