@@ -11,8 +11,9 @@
 #include <string>
 #include <vector>
 
-static uint64_t g_rx_matches = 0;
+static uint64_t g_rx_matches = 0, g_rx_steps = 0;
 #define TK_RX_ON_MATCH() (++g_rx_matches)
+#define TK_RX_ON_DONE(steps) (g_rx_steps += (steps))
 #include "../../tiktoken_amd/csrc/tk_chunk.h"
 #include "../../tiktoken_amd/csrc/tk_regex_host.h"
 #include "../../tiktoken_amd/csrc/tk_regex_split.h"
@@ -632,6 +633,7 @@ void* tks_rx_compile(const char* pat_str, char* err, uint64_t errcap) {
 }
 void tks_rx_free(void* p) { delete (TkRxCompiled*)p; }
 uint64_t tks_rx_size(void* p) { return ((TkRxCompiled*)p)->ins.size(); }
+uint64_t tks_rx_steps() { return g_rx_steps; }  // matcher steps so far (instructions + chars of repeats + backtracks)
 // Piece starts of a packed batch: a byte per position (1 = start).  spec_at / spec_len: occurrences of allowed special tokens (sorted).
 // speculate = 0: every document walked by the matcher alone.  stats[0] = matcher runs of the speculative pass, [1] = of the resolving pass.
 // Returns 0, or error bits | position << 8.

@@ -1,6 +1,7 @@
 """The generic pat_str engine (tiktoken_amd/csrc/tk_regex.cpp, tk_regex.h, tk_regex_split.h) on the CPU: the compiler and the very code
 the two split kernels run per lane (tests/hostsim), against Python `regex` -- the engine the golden fixtures were made with
 (tools/gen_golden.py; reference tiktoken/core.py:395-404 splits with it too).  The GPU side is tests/test_gpu_regex.py."""
+import ctypes
 import random
 
 import numpy as np
@@ -123,10 +124,13 @@ def test_gaps_and_errors_are_loud():
     assert rx.split([b"hello world"]) == [0, 5, 6]
     with pytest.raises(RuntimeError, match="error 4 at byte 5"):
         rx.split([b"hello, world"])
-    rx = h.RxSim(r"(?:ab)*c|a|b")  # a repeated group needs a frame per repetition: bounded stack, loud failure
-    assert rx.split([b"ababc" * 3]) == [0, 5, 10]
+    # a backtracking repeated group in the middle of an alternative needs a frame per repetition wherever both going on and leaving
+    # can begin with the next byte: bounded stack, loud failure
+    rx = h.RxSim(r"(?:\w\w)*\w!|\w|!")
+    assert rx.split([b"abc!" * 3]) == [0, 4, 8]
     with pytest.raises(RuntimeError, match="error 8"):
         rx.split([b"ab" * 200])
+    assert h.RxSim(r"(?:ab)*c|a|b").split([b"ab" * 200]) == list(range(400))  # (here the way out needs a 'c': no frame is kept)
 
 
 @pytest.mark.parametrize("pat,why", [
@@ -293,3 +297,39 @@ def test_compiler_and_lanes_under_the_sanitizers(tmp_path):
     assert cc.returncode == 0, cc.stderr[-2000:]
     run = subprocess.run([exe, "40"], capture_output=True, text=True, timeout=600)
     assert run.returncode == 0 and run.stdout.startswith("ok "), (run.stdout[-500:], run.stderr[-3000:])
+
+
+def test_first_byte_pruning_is_exact(monkeypatch):
+    """A SPLIT carries the bytes each of its choices can begin with, and the matcher skips a choice that cannot begin with the byte at the
+    position.  Regressions found by the generated-pattern test while this was written: the pruning looked across the end of an atomic group
+    (failing inside the group may still use its alternatives, failing behind it may not), and dropped the frame that a possessive loop's POP
+    expects.  Every pattern here must split the same way with and without the bitmaps, and as Python `regex` does."""
+    cases = [
+        (r"\P{N}+?(?>\s?( +\S{2}){1,3}){2}|[\s\S]", "'s   ,٣  KCKabaAx''sſ"),
+        (r"a+(?=((?:a(?!\p{Lu})|\p{Nd}+x{1,3})|.\p{L}{0,2}+))|s??\s((?>\P{N}+?|\s?+.+\s?)+(?! )|[\s\S]+?(?=b))*+\d++|[\s\S]", "K中\nx'ssascSſ中sbc中KK.K 12 aab"),
+        (r"(?:ab|a)*+c|(?>a+|b)+d|[\s\S]", "ababac abd aabbd ab"),
+        (h.PAT_STR[2], "Hello World's  DON'T\n\n 123456 x'll y'LL  "),
+    ]
+    for pat, text in cases:
+        want = py_starts(pat, text)
+        monkeypatch.delenv("TIKTOKEN_AMD_RX_NO_PRUNING", raising=False)
+        pruned = h.RxSim(pat)
+        monkeypatch.setenv("TIKTOKEN_AMD_RX_NO_PRUNING", "1")
+        plain = h.RxSim(pat)
+        monkeypatch.delenv("TIKTOKEN_AMD_RX_NO_PRUNING")
+        assert pruned.split([text.encode()]) == want, pat
+        assert plain.split([text.encode()]) == want, pat
+    L = h.sim_lib()
+    L.tks_rx_steps.restype = ctypes.c_uint64
+    blob, off = h.gen_corpus(0x5EED0200 + 1, 1, 1 << 20)
+    bb = blob.tobytes()
+    docs = [bb[int(off[d]):int(off[d + 1])] for d in range(len(off) - 1)]
+    work = []
+    for prune in (True, False):
+        if not prune:
+            monkeypatch.setenv("TIKTOKEN_AMD_RX_NO_PRUNING", "1")
+        rx = h.RxSim(h.PAT_STR[2])
+        s0 = L.tks_rx_steps()
+        work.append((rx.split(docs, speculate=0), L.tks_rx_steps() - s0))
+    assert work[0][0] == work[1][0]
+    assert work[0][1] < 0.65 * work[1][1], (work[0][1], work[1][1])  # (o200k on web text: 17 steps per piece instead of 32)

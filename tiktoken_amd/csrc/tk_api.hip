@@ -77,7 +77,7 @@ struct tk_core {
     uint32_t spec_max_len = 0;
     bool has_rx = false;  // the pat_str runs on the generic engine (tk_regex_kernels.h)
     TkRxDev rx{};
-    Buf t_rx_ins, t_rx_sets, t_rx_ranges, t_rx_s1, t_rx_s2, rx_spec, rx_gst, rx_exit;
+    Buf t_rx_ins, t_rx_sets, t_rx_ranges, t_rx_first, t_rx_s1, t_rx_s2, rx_spec, rx_gst, rx_exit;
     std::mutex mu;
     // workspace
     Buf text, text_al, tile_sum, wide_ws, scan_sums, row_base, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, res, rflag, staging, listB, listC, counters, total, g_id, g_rk, g_nx,
@@ -260,10 +260,12 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
         if ((rc = upload(c->t_rx_ins, H.rx.ins.data(), H.rx.ins.size() * sizeof(TkRxIns)))) return bail(rc);
         if ((rc = upload(c->t_rx_sets, H.rx.sets.data(), H.rx.sets.size() * sizeof(TkRxSet)))) return bail(rc);
         if ((rc = upload(c->t_rx_ranges, H.rx.ranges.data(), H.rx.ranges.size() * 4))) return bail(rc);
+        if ((rc = upload(c->t_rx_first, H.rx.first.data(), H.rx.first.size() * 4))) return bail(rc);
         if ((rc = upload(c->t_rx_s1, tk_rx_props_stage1(), 0x1100))) return bail(rc);
         if ((rc = upload(c->t_rx_s2, tk_rx_props_stage2(), (size_t)tk_rx_props_blocks() * 256))) return bail(rc);
         c->rx = TkRxDev{c->t_rx_ins.as<TkRxIns>(), c->t_rx_sets.as<TkRxSet>(), c->t_rx_ranges.as<uint32_t>(), c->t_rx_s1.as<uint8_t>(),
-                        c->t_rx_s2.as<uint8_t>(), (uint32_t)H.rx.ins.size(), (uint32_t)H.rx.sets.size(), (uint32_t)H.rx.ranges.size() / 2};
+                        c->t_rx_s2.as<uint8_t>(), (uint32_t)H.rx.ins.size(), (uint32_t)H.rx.sets.size(), (uint32_t)H.rx.ranges.size() / 2,
+                        c->t_rx_first.as<uint32_t>(), (uint32_t)H.rx.first.size() / 8};
         c->has_rx = true;
     }
     if ((rc = upload(c->t_short, H.short_tab.data(), H.short_tab.size() * sizeof(TkShortSlot)))) return bail(rc);
@@ -331,7 +333,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
 extern "C" void tk_destroy(tk_core* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (Buf* b : {&c->t_rx_ins, &c->t_rx_sets, &c->t_rx_ranges, &c->t_rx_s1, &c->t_rx_s2, &c->rx_spec, &c->rx_gst, &c->rx_exit}) release(*b);
+    for (Buf* b : {&c->t_rx_ins, &c->t_rx_sets, &c->t_rx_ranges, &c->t_rx_first, &c->t_rx_s1, &c->t_rx_s2, &c->rx_spec, &c->rx_gst, &c->rx_exit}) release(*b);
     for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_dec, &c->d_tok, &c->d_lens, &c->d_bsum, &c->d_tboff, &c->d_bytes, &c->d_boff, &c->t_piece, &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2,
                    &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->text_al, &c->tile_sum, &c->wide_ws, &c->scan_sums, &c->row_base, &c->doc_off, &c->brk, &c->docb,
                    &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->res, &c->rflag, &c->staging, &c->listB,

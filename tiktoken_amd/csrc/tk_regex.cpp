@@ -10,6 +10,7 @@
 // non-ASCII cased letters, a pattern (or a repeated group) that can match the empty string.
 #include "tk_regex.h"
 
+#include <stdlib.h>
 #include <string.h>
 
 #include <string>
@@ -479,6 +480,9 @@ struct Parser {
     }
 };
 
+// emit-time mark on a SPLIT whose frame a later POP removes: first-byte pruning may skip its first choice but must not drop the frame
+const uint32_t SPLIT_KEEPS_FRAME = 0x80000000u;
+
 struct Emitter {
     const Parser& P;
     std::vector<TkRxIns> code;
@@ -587,7 +591,7 @@ struct Emitter {
             if (poss) put(TK_RX_ATOM_BEGIN);
             for (uint32_t k = 0; k < N.mn; ++k)
                 if (!emit(body, false)) return false;
-            const uint32_t sp = put(TK_RX_SPLIT);
+            const uint32_t sp = put(TK_RX_SPLIT | SPLIT_KEEPS_FRAME);  // (the POP below takes this split's frame: it has to be there)
             code[sp].a = here();
             put(TK_RX_ATOM_BEGIN);
             if (!emit(body, true)) return false;
@@ -650,6 +654,111 @@ bool utf8_to_cps(const char* p, std::vector<uint32_t>* out) {
     return true;
 }
 
+// ---- first-byte bitmaps.  first(i) = the bytes a match of the program from instruction i can begin with (before any byte is consumed),
+// as the least fixpoint of the obvious equations; whatever cannot be known is "every byte" (reaching MATCH or the end of a look-ahead
+// succeeds whatever follows, and so -- for this purpose -- does reaching the end of an atomic group; a look-ahead in front is ignored:
+// it only restricts).  A SPLIT then carries the bitmaps of its two targets:
+// the matcher does not take -- and does not keep as a way back -- a choice that cannot begin with the byte at the position, which it would
+// find out by failing a few instructions later.  (Not consulted at the end of the haystack, where `$` and empty tails decide.)
+struct Bits256 {
+    uint32_t w[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    bool merge(const Bits256& o) {
+        bool ch = false;
+        for (int k = 0; k < 8; ++k) {
+            const uint32_t v = w[k] | o.w[k];
+            ch |= v != w[k];
+            w[k] = v;
+        }
+        return ch;
+    }
+    void set(uint32_t b) { w[b >> 5] |= 1u << (b & 31u); }
+    void all() {
+        for (uint32_t& x : w) x = 0xFFFFFFFFu;
+    }
+    bool operator==(const Bits256& o) const { return !memcmp(w, o.w, sizeof w); }
+};
+
+uint32_t utf8_lead(uint32_t cp) { return cp < 0x80u ? cp : (cp < 0x800u ? 0xC0u | (cp >> 6) : (cp < 0x10000u ? 0xE0u | (cp >> 12) : 0xF0u | (cp >> 18))); }
+
+Bits256 first_bytes_of_set(const TkRxSet& S, const std::vector<uint32_t>& ranges) {
+    Bits256 b;
+    for (uint32_t c = 0; c < 128; ++c)
+        if ((S.ascii[c >> 5] >> (c & 31u)) & 1u) b.set(c);
+    const uint32_t roff = S.rr >> 16, rcnt = S.rr & 0xFFFFu;
+    if ((S.flags & 3u) || S.gcmask || (S.flags & 0x60u)) {  // negated / complemented / property members: any byte from 0x80 on
+        for (uint32_t c = 128; c < 256; ++c) b.set(c);       // (malformed bytes read as U+FFFD, which such a set may hold)
+        return b;
+    }
+    for (uint32_t i = 0; i < rcnt; ++i) {
+        const uint32_t lo = ranges[2 * (roff + i)], hi = ranges[2 * (roff + i) + 1];
+        for (uint32_t c = utf8_lead(lo); c <= utf8_lead(hi > 0x10FFFFu ? 0x10FFFFu : hi); ++c) b.set(c);
+        if (lo <= 0xFFFDu && hi >= 0xFFFDu)
+            for (uint32_t c = 128; c < 256; ++c) b.set(c);
+    }
+    return b;
+}
+
+void annotate_first_bytes(TkRxCompiled* out) {
+    std::vector<TkRxIns>& code = out->ins;
+    if (getenv("TIKTOKEN_AMD_RX_NO_PRUNING")) {  // (tests: the same program without the bitmaps must split the same way)
+        for (TkRxIns& I : code)
+            if ((I.op & 0xFFu) == TK_RX_SPLIT) I.op = TK_RX_SPLIT;
+        out->first.assign(8, 0xFFFFFFFFu);
+        return;
+    }
+    const size_t n = code.size();
+    std::vector<Bits256> first(n), of_set(out->sets.size());
+    for (size_t s = 0; s < out->sets.size(); ++s) of_set[s] = first_bytes_of_set(out->sets[s], out->ranges);
+    Bits256 every;
+    every.all();
+    for (bool changed = true; changed;) {
+        changed = false;
+        for (size_t i = n; i-- > 0;) {
+            const TkRxIns& I = code[i];
+            Bits256 f;
+            auto at = [&](uint32_t j) -> const Bits256& { return j < n ? first[j] : every; };
+            switch (I.op & 0xFFu) {
+                case TK_RX_SET: f = of_set[I.a]; break;
+                case TK_RX_REP:
+                    f = of_set[I.a];
+                    if (I.b == 0) f.merge(at((uint32_t)i + 1));
+                    break;
+                case TK_RX_SPLIT:
+                    f = at(I.a);
+                    f.merge(at(I.b));
+                    break;
+                case TK_RX_JMP: f = at(I.a); break;
+                case TK_RX_MATCH:
+                case TK_RX_LOOK_END:
+                case TK_RX_ATOM_END:  // (a commit point: failing before it may still use the group's alternatives, failing behind it may not --
+                case TK_RX_POP:       //  pruning must not look across)
+                    f = every;
+                    break;
+                case TK_RX_END:
+                case TK_RX_FAIL: break;  // (nothing: `$` fails unless the haystack ends here, and there the bitmaps are not consulted)
+                case TK_RX_LOOK_BEGIN: f = at(I.b); break;
+                default: f = at((uint32_t)i + 1); break;  // START, ATOM_BEGIN: on to the next instruction
+            }
+            changed |= first[i].merge(f);
+        }
+    }
+    std::vector<Bits256> uniq;
+    auto id_of = [&](uint32_t target) -> uint32_t {  // 1 + index, 0 = no bitmap (every byte, or the table is full)
+        const Bits256& f = target < n ? first[target] : every;
+        if (f == every) return 0;
+        for (size_t k = 0; k < uniq.size(); ++k)
+            if (uniq[k] == f) return (uint32_t)k + 1;
+        if (uniq.size() >= TK_RX_MAX_FIRST) return 0;
+        uniq.push_back(f);
+        return (uint32_t)uniq.size();
+    };
+    for (TkRxIns& I : code)
+        if ((I.op & 0xFFu) == TK_RX_SPLIT) I.op = TK_RX_SPLIT | id_of(I.a) << 8 | ((I.op & SPLIT_KEEPS_FRAME) ? 0u : id_of(I.b) << 16);
+    out->first.clear();
+    for (const Bits256& f : uniq) out->first.insert(out->first.end(), f.w, f.w + 8);
+    if (out->first.empty()) out->first.assign(8, 0xFFFFFFFFu);  // (never indexed; keeps the upload simple)
+}
+
 }  // namespace
 
 const uint8_t* tk_rx_props_stage1() { return tk_rx_stage1; }
@@ -689,10 +798,11 @@ std::string tk_rx_compile(const char* pat_str, TkRxCompiled* out) {
         out->sets.push_back(S);
     }
     if (out->ranges.size() / 2 > TK_RX_MAX_RANGES) return "the pattern has too many class ranges";
+    annotate_first_bytes(out);
     return "";
 }
 
 TkRxProg TkRxCompiled::view() const {
     return TkRxProg{ins.data(), sets.data(), ranges.data(), tk_rx_stage1, tk_rx_stage2, (uint32_t)ins.size(), (uint32_t)sets.size(),
-                    (uint32_t)ranges.size() / 2};
+                    (uint32_t)ranges.size() / 2, first.data(), (uint32_t)first.size() / 8};
 }

@@ -20,7 +20,8 @@
 enum {
     TK_RX_SET = 0,     // a: set -- one char of the set
     TK_RX_REP,         // a: set, b: min, c: max (0xFFFFFFFF = unbounded); mode = (op >> 8) & 3
-    TK_RX_SPLIT,       // a: first choice, b: second choice
+    TK_RX_SPLIT,       // a: first choice, b: second choice; (op >> 8) & 127 and (op >> 16) & 127: 1 + index of the first-byte bitmap of
+                       // each choice (0: none) -- a choice whose bitmap lacks the byte at the position is not taken, nor kept as a way back
     TK_RX_JMP,         // a: target
     TK_RX_MATCH,
     TK_RX_END,         // end of the haystack ($, \z)
@@ -55,6 +56,8 @@ struct TkRxProg {
     const uint8_t* stage1;  // [0x1100] property table (tk_regex_props.inc)
     const uint8_t* stage2;
     uint32_t n_ins, n_sets, n_ranges;
+    const uint32_t* first;  // first-byte bitmaps, 8 words each: the bytes with which a match of the rest of the program from some
+    uint32_t n_first;       // instruction can begin (tk_regex.cpp: a fixpoint over the program; conservative, so skipping is exact)
 };
 
 #define TK_RX_FAILED 0xFFFFFFFFu    // no match at this position
@@ -67,6 +70,9 @@ struct TkRxProg {
 #define TK_RX_BUDGET_BASE 1000000u
 #define TK_RX_BUDGET_PER_BYTE 8u
 #define TK_RX_STACK 64
+#ifndef TK_RX_ON_DONE
+#define TK_RX_ON_DONE(steps)  // (the CPU tests add up the matcher's work here)
+#endif
 
 TK_HD uint32_t tk_rx_prop(const TkRxProg& P, uint32_t cp) {
     if (cp > 0x10FFFFu) cp = 0xFFFDu;
@@ -109,7 +115,7 @@ TK_HD uint32_t tk_rx_decode(A& t, uint32_t pos, uint32_t* len) {
 template <class A>
 TK_HD uint32_t tk_rx_match(const TkRxProg& P, A& t, uint32_t start) {
     enum { F_ALT = 0, F_RANGE = 1, F_LAZY = 2, F_ATOM = 3, F_LOOK = 4 };
-    uint32_t fk[TK_RX_STACK], fp[TK_RX_STACK], fa[TK_RX_STACK];  // frames: kind << 24 | pc, position, aux
+    uint32_t fk[TK_RX_STACK], fp[TK_RX_STACK], fa_[TK_RX_STACK];  // frames: kind << 24 | pc, position, aux
     int sp = 0;
     uint32_t pc = 0, pos = start;
     uint32_t steps = 0, far = start;  // work done; the farthest position looked at
@@ -154,21 +160,34 @@ TK_HD uint32_t tk_rx_match(const TkRxProg& P, A& t, uint32_t start) {
                     if (sp == TK_RX_STACK) return TK_RX_OVERFLOW;
                     fk[sp] = mode == TK_RX_GREEDY ? ((uint32_t)F_RANGE << 24 | (pc + 1)) : ((uint32_t)F_LAZY << 24 | pc);
                     fp[sp] = mode == TK_RX_GREEDY ? pmin : pos;
-                    fa[sp] = mode == TK_RX_GREEDY ? pos : c;
+                    fa_[sp] = mode == TK_RX_GREEDY ? pos : c;
                     ++sp;
                 }
                 ++pc;
             } break;
-            case TK_RX_SPLIT:
-                if (sp == TK_RX_STACK) return TK_RX_OVERFLOW;
-                fk[sp] = (uint32_t)F_ALT << 24 | I.b;
-                fp[sp] = pos;
-                fa[sp] = 0;
-                ++sp;
-                pc = I.a;
-                break;
+            case TK_RX_SPLIT: {
+                uint32_t go = 3u;  // bit 0: the first choice can begin with the byte here, bit 1: the second can
+                const uint32_t fa = (I.op >> 8) & 127u, fb = (I.op >> 16) & 127u;
+                if ((fa | fb) && !at_end(pos)) {
+                    const uint32_t b = t.byte(pos);
+                    if (fa && !((P.first[(fa - 1u) * 8u + (b >> 5)] >> (b & 31u)) & 1u)) go &= ~1u;
+                    if (fb && !((P.first[(fb - 1u) * 8u + (b >> 5)] >> (b & 31u)) & 1u)) go &= ~2u;
+                }
+                if (go == 3u) {
+                    if (sp == TK_RX_STACK) return TK_RX_OVERFLOW;
+                    fk[sp] = (uint32_t)F_ALT << 24 | I.b;
+                    fp[sp] = pos;
+                    fa_[sp] = 0;
+                    ++sp;
+                    pc = I.a;
+                } else if (go) {
+                    pc = go == 1u ? I.a : I.b;
+                } else {
+                    fail = true;
+                }
+            } break;
             case TK_RX_JMP: pc = I.a; break;
-            case TK_RX_MATCH: return pos;
+            case TK_RX_MATCH: TK_RX_ON_DONE(steps); return pos;
             case TK_RX_END:
                 if (at_end(pos)) ++pc;
                 else fail = true;
@@ -180,7 +199,7 @@ TK_HD uint32_t tk_rx_match(const TkRxProg& P, A& t, uint32_t start) {
             case TK_RX_ATOM_BEGIN:
                 if (sp == TK_RX_STACK) return TK_RX_OVERFLOW;
                 fk[sp] = (uint32_t)F_ATOM << 24;
-                fp[sp] = fa[sp] = 0;
+                fp[sp] = fa_[sp] = 0;
                 ++sp;
                 ++pc;
                 break;
@@ -192,14 +211,14 @@ TK_HD uint32_t tk_rx_match(const TkRxProg& P, A& t, uint32_t start) {
                 if (sp == TK_RX_STACK) return TK_RX_OVERFLOW;
                 fk[sp] = (uint32_t)F_LOOK << 24 | I.b;
                 fp[sp] = pos;
-                fa[sp] = I.a;
+                fa_[sp] = I.a;
                 ++sp;
                 ++pc;
                 break;
             case TK_RX_LOOK_END: {  // the look-ahead's body matched
                 while (sp > 0 && (fk[--sp] >> 24) != F_LOOK) {}
                 pos = fp[sp];
-                if (fa[sp]) fail = true;  // negative look-ahead
+                if (fa_[sp]) fail = true;  // negative look-ahead
                 else ++pc;
             } break;
             case TK_RX_POP:
@@ -209,7 +228,10 @@ TK_HD uint32_t tk_rx_match(const TkRxProg& P, A& t, uint32_t start) {
             default: fail = true; break;
         }
         while (fail) {  // backtrack
-            if (sp == 0) return TK_RX_FAILED;
+            if (sp == 0) {
+                TK_RX_ON_DONE(steps);
+                return TK_RX_FAILED;
+            }
             if (++steps > (3u << 30)) return TK_RX_LIMIT;  // (a pop is a step; the check proper is at the next instruction)
             --sp;
             const uint32_t kind = fk[sp] >> 24, tgt = fk[sp] & 0xFFFFFFu;
@@ -218,10 +240,10 @@ TK_HD uint32_t tk_rx_match(const TkRxProg& P, A& t, uint32_t start) {
                 pos = fp[sp];
                 fail = false;
             } else if (kind == F_RANGE) {  // give back one char of a greedy run: [fp, fa] is the range of possible ends
-                uint32_t cur = fa[sp] - 1;
+                uint32_t cur = fa_[sp] - 1;
                 while (cur > fp[sp] && (t.byte(cur) & 0xC0u) == 0x80u) --cur;
                 if (cur > fp[sp]) {
-                    fa[sp] = cur;
+                    fa_[sp] = cur;
                     ++sp;
                 }
                 pos = cur;
@@ -229,13 +251,13 @@ TK_HD uint32_t tk_rx_match(const TkRxProg& P, A& t, uint32_t start) {
                 fail = false;
             } else if (kind == F_LAZY) {  // take one more char of a lazy run
                 const TkRxIns R = P.ins[tgt];
-                uint32_t p = fp[sp], c = fa[sp], len;
+                uint32_t p = fp[sp], c = fa_[sp], len;
                 if (c < R.c && !at_end(p) && tk_rx_in_set(P, R.a, tk_rx_decode(t, p, &len))) {
                     p += len;
                     ++c;
                     if (c < R.c) {
                         fp[sp] = p;
-                        fa[sp] = c;
+                        fa_[sp] = c;
                         ++sp;
                     }
                     pos = p;
@@ -243,7 +265,7 @@ TK_HD uint32_t tk_rx_match(const TkRxProg& P, A& t, uint32_t start) {
                     fail = false;
                 }
             } else if (kind == F_LOOK) {  // the look-ahead's body cannot match
-                if (fa[sp]) {             // ... which is what a negative one asks for
+                if (fa_[sp]) {             // ... which is what a negative one asks for
                     pos = fp[sp];
                     pc = tgt;
                     fail = false;

@@ -7,14 +7,16 @@
 
 #include "tk_regex.h"
 
-#define TK_RX_MAX_INS 448     // the kernels keep the program in LDS: 448 x 16 + 64 x 32 + 192 x 8 bytes = 10.5 KiB
+#define TK_RX_MAX_INS 448     // the kernels keep the program in LDS: 448 x 16 + 64 x 32 + 192 x 8 + 64 x 32 bytes = 12.5 KiB
 #define TK_RX_MAX_SETS 64
 #define TK_RX_MAX_RANGES 192  // pairs
+#define TK_RX_MAX_FIRST 64    // first-byte bitmaps (32 bytes each)
 
 struct TkRxCompiled {
     std::vector<TkRxIns> ins;
     std::vector<TkRxSet> sets;
     std::vector<uint32_t> ranges;  // pairs (lo, hi)
+    std::vector<uint32_t> first;   // first-byte bitmaps, 8 words each (TkRxProg::first)
     bool empty() const { return ins.empty(); }
     // a view over the vectors and the built-in property table (host-side matching by the CPU tests)
     TkRxProg view() const;

@@ -8,7 +8,7 @@
 //                       in which every char is a letter: its scanners then cut at hard starts and nowhere else, and everything behind the
 //                       split -- whole-piece probe, de-duplication, merges, long pieces, token copy -- is the pipeline of the stock patterns.
 //
-// The program (<= 10.5 KiB) is copied to LDS by every workgroup; the property table (42 KiB) stays in global memory (L2).  Integer work,
+// The program (<= 12.5 KiB) is copied to LDS by every workgroup; the property table (42 KiB) stays in global memory (L2).  Integer work,
 // data-dependent branches, one lane per unit: this path is bound by divergence and latency, not by HBM -- it exists so that no pat_str
 // is refused, the three stock families keep their hand-written scanners.
 #pragma once
@@ -22,12 +22,15 @@ struct TkRxDev {  // the compiled program in device memory
     const uint8_t* stage1;
     const uint8_t* stage2;
     uint32_t n_ins, n_sets, n_ranges;
+    const uint32_t* first;
+    uint32_t n_first;
 };
 
 struct TkRxLds {
     TkRxIns ins[TK_RX_MAX_INS];
     TkRxSet sets[TK_RX_MAX_SETS];
     uint32_t ranges[2 * TK_RX_MAX_RANGES];
+    uint32_t first[8 * TK_RX_MAX_FIRST];
 };
 
 __device__ __forceinline__ TkRxProg tk_rx_stage_program(const TkRxDev& R, TkRxLds* L) {
@@ -38,8 +41,9 @@ __device__ __forceinline__ TkRxProg tk_rx_stage_program(const TkRxDev& R, TkRxLd
     uint32_t* ds = (uint32_t*)L->sets;
     for (uint32_t i = threadIdx.x; i < R.n_sets * 8u; i += blockDim.x) ds[i] = ss[i];
     for (uint32_t i = threadIdx.x; i < R.n_ranges * 2u; i += blockDim.x) L->ranges[i] = R.ranges[i];
+    for (uint32_t i = threadIdx.x; i < R.n_first * 8u; i += blockDim.x) L->first[i] = R.first[i];
     __syncthreads();
-    return TkRxProg{L->ins, L->sets, L->ranges, R.stage1, R.stage2, R.n_ins, R.n_sets, R.n_ranges};
+    return TkRxProg{L->ins, L->sets, L->ranges, R.stage1, R.stage2, R.n_ins, R.n_sets, R.n_ranges, L->first, R.n_first};
 }
 
 __global__ __launch_bounds__(256) void tk_k_rx_speculate(TkRxDev R, const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ brk,
