@@ -1,6 +1,7 @@
 #!/bin/bash
 # usage: bash tools/gpu_round_end.sh TAG  -- everything the committed artefacts under profiles/ are made from:
-# GPU tests, smoke, bench (1 GiB), kernel-trace stats + HBM traffic counters, SQ counters, the other configs, small calls, long runs.
+# GPU tests, smoke, bench (1 GiB), kernel-trace stats + HBM traffic counters, SQ counters, the other configs, small calls, long runs,
+# the generic pat_str engine beside the scanners, fuzzed batches.
 TAG=${1:-r02}
 mkdir -p gpurun_out
 timeout 900 python -m pytest tests -m gpu -q 2>&1 | tail -3 > gpurun_out/${TAG}_pytest_gpu.log; cat gpurun_out/${TAG}_pytest_gpu.log
@@ -11,3 +12,6 @@ timeout 600 python bench.py > gpurun_out/${TAG}_bench_1gpu.json 2> gpurun_out/${
 timeout 600 python tools/bench_configs.py > gpurun_out/${TAG}_configs.jsonl 2> gpurun_out/${TAG}_configs.err; cat gpurun_out/${TAG}_configs.jsonl | cut -c1-300
 timeout 300 python tools/small_call.py > gpurun_out/${TAG}_small_calls.txt 2>&1; cat gpurun_out/${TAG}_small_calls.txt
 timeout 300 python tools/stress_repeats.py o200k_shaped > gpurun_out/${TAG}_long_runs.txt 2>&1; cat gpurun_out/${TAG}_long_runs.txt
+timeout 300 python tools/generic_vs_scanners.py 256 > gpurun_out/${TAG}_generic_vs_scanners.txt 2>&1; cut -c1-400 gpurun_out/${TAG}_generic_vs_scanners.txt
+timeout 120 python tools/rx_diag.py > gpurun_out/${TAG}_generic_pat_small_batches.txt 2>&1; tail -3 gpurun_out/${TAG}_generic_pat_small_batches.txt | cut -c1-300
+timeout 300 python tools/gpu_fuzz.py 4 24 100 > gpurun_out/${TAG}_fuzz.txt 2>&1; tail -1 gpurun_out/${TAG}_fuzz.txt
