@@ -28,6 +28,9 @@ PATTERNS = [
     (r"(?s).{1,7}", None),
     (r"^\p{L}|\p{L}{2,}|(?i:k+|s+)|\pN+|[\s\S]", r"\A\p{L}|\p{L}{2,}|(?i:k+|s+)|\pN+|[\s\S]"),
     (r"(?:\p{L}\p{M}*)+|\p{Nd}+(?:[.,]\p{Nd}+)*|[^\p{L}\p{M}\p{Nd}]", None),
+    # scripts (expanded into ranges at compile time): a Kimi-style CJK alternative in front of an o200k-like tail
+    (r"[\p{Han}\p{Hiragana}\p{Katakana}]+|\p{Latin}+|\p{Script=Greek}+|\p{sc=Cyrl}+|\p{Thai}+|[^\p{Han}\s]|\s+", None),
+    (r"\P{Latin}+?(?=\p{Latin}|$)|(?i:\p{Latin}{1,4})", r"\P{Latin}+?(?=\p{Latin}|\Z)|(?i:\p{Latin}{1,4})"),
 ]
 
 
@@ -135,7 +138,8 @@ def test_gaps_and_errors_are_loud():
 
 @pytest.mark.parametrize("pat,why", [
     (r"(?<=a)b|.", "look-behind"), (r"\bfoo|.", "look-behind"), (r"(a)\1|.", "back-references"), (r"a*", "empty string"),
-    (r"(?:a*)+|.", "empty string"), (r"\p{Han}+|.", "General_Category"), (r"[a-z&&[^b]]|.", "set operations"), (r"(?m)^a|.", "(?m)"),
+    (r"(?:a*)+|.", "empty string"), (r"\p{Alphabetic}+|.", "General_Category value or a script"), (r"[\P{Han}x]|.", "negated script"),
+    (r"\p{scx=Han}|.", "General_Category value or a script"), (r"[a-z&&[^b]]|.", "set operations"), (r"(?m)^a|.", "(?m)"),
     (r"(?i)é|.", "non-ASCII cased"), (r"[[:alpha:]]|.", "POSIX"), (r"(a|b", "unterminated group"), (r"a)|b", "unbalanced"),
     (r"x{3,2}|.", "out of order"), (r"a**|.", "quantifier behind"), (r"[z-a]|.", "out of order"), (r"(?=a)|.", "empty string"),
 ])

@@ -2,23 +2,25 @@
 // outside the three scanner families of tk_pattern.cpp is no longer refused: it is parsed here (the syntax fancy-regex and the Rust
 // `regex` crate share with Python `regex`), compiled to a backtracking program and run on the GPU.
 //
-// Supported: literals, `.`, classes [...] with ranges / escapes / negation, \d \s \w \D \S \W, \p{..} \P{..} for General_Category values,
+// Supported: literals, `.`, classes [...] with ranges / escapes / negation, \d \s \w \D \S \W, \p{..} \P{..} for General_Category values and scripts (\p{Han}, \p{Script=Greek}),
 // the escapes \n \r \t \f \v \xHH \x{H..} \uHHHH \u{H..} \UHHHHHHHH, alternation, groups (capturing ones are plain groups: a split pattern
 // has no use for captures), (?: ) (?i: ) (?s: ) (?i) (?s) (?-i), atomic groups (?> ), look-ahead (?= ) (?! ), the quantifiers ? * + {m} {m,}
 // {m,n} in their greedy, lazy (?) and possessive (+) forms, ^ \A $ \z.  Refused, with the reason: look-behind, \b \B, back-references,
-// (?m) (?x), class set operations (&& --), POSIX classes, script / binary properties other than the above, case-insensitive matching of
+// (?m) (?x), class set operations (&& --), POSIX classes, binary properties (\\p{Alphabetic} ...), script extensions, case-insensitive matching of
 // non-ASCII cased letters, a pattern (or a repeated group) that can match the empty string.
 #include "tk_regex.h"
 
 #include <stdlib.h>
 #include <string.h>
 
+#include <algorithm>
 #include <string>
 #include <utility>
 #include <vector>
 
 #include "tk_regex_host.h"
 #include "tk_regex_props.inc"
+#include "tk_regex_scripts.inc"
 
 namespace {
 
@@ -193,7 +195,31 @@ struct Parser {
         else
             for (int g = 0; g < 30; ++g)
                 if (name == GC_NAMES[g] || (name.size() == 1 && GC_NAMES[g][0] == name[0])) m |= 1u << g;
-        if (!m) return fail("\\p{" + name + "}: only General_Category values are supported (write other properties as ranges)");
+        if (!m) {  // a script?  Its ranges join the class (tk_regex_scripts.inc)
+            std::string key;
+            for (const char* pre : {"Script=", "script=", "sc=", "Is"})
+                if (name.rfind(pre, 0) == 0 && name.size() > strlen(pre)) {
+                    name.erase(0, strlen(pre));
+                    break;
+                }
+            for (char ch : name)
+                if (ch != '_' && ch != ' ' && ch != '-') key += (char)((ch >= 'A' && ch <= 'Z') ? ch + 32 : ch);
+            for (const TkRxScript& sc : tk_rx_scripts) {
+                const char* q = sc.names;
+                while (*q) {
+                    const char* e = strchr(q, '|');
+                    const size_t len = e ? (size_t)(e - q) : strlen(q);
+                    if (len == key.size() && !memcmp(q, key.data(), len)) {
+                        for (unsigned k = 0; k < sc.cnt; ++k)
+                            c.ranges.push_back({tk_rx_script_ranges[2 * (sc.off + k)], tk_rx_script_ranges[2 * (sc.off + k) + 1]});
+                        *negated = neg != inner_neg;
+                        return true;
+                    }
+                    q += len + (e ? 1 : 0);
+                }
+            }
+            return fail("\\p{" + name + "}: not a General_Category value or a script (write other properties as ranges)");
+        }
         if (ci && (m & 7u) && (m & 7u) != 7u) return fail("\\p{" + name + "} under (?i) is not supported");
         c.gcmask |= m;
         *negated = neg != inner_neg;
@@ -269,12 +295,14 @@ struct Parser {
                     if (!class_escape(peek(), sub, f.ci, &negated)) return -1;
                     if (negated) {  // a complement inside a union: one per class ([^\S\n], [\S\d])
                         if (c.comp) return fail("more than one negated escape inside a class is not supported"), -1;
+                        if (!sub.ranges.empty()) return fail("a negated script inside a class is not supported (negate the class: [^\\p{..}])"), -1;
                         c.comp = true;
                         c.cgcmask = sub.gcmask;
                         c.cflags = sub.flags;
                     } else {
                         c.gcmask |= sub.gcmask;
                         c.flags |= sub.flags;
+                        c.ranges.insert(c.ranges.end(), sub.ranges.begin(), sub.ranges.end());
                     }
                     continue;
                 }
@@ -789,11 +817,19 @@ std::string tk_rx_compile(const char* pat_str, TkRxCompiled* out) {
         S.cgcmask = c.cgcmask;
         S.flags = (c.flags & 0x60u) | (c.neg ? 1u : 0u) | (c.comp ? 2u : 0u) | ((c.cflags & 0x60u) << 8);
         const uint32_t roff = (uint32_t)out->ranges.size() / 2;
-        for (const auto& r : c.ranges)
-            if (r.second >= 128u) {  // (the ASCII part lives in the bitmap)
-                out->ranges.push_back(r.first < 128u ? 128u : r.first);
+        std::vector<std::pair<uint32_t, uint32_t>> rs;  // beyond ASCII (the ASCII part lives in the bitmap), sorted and merged: the matcher
+        for (const auto& r : c.ranges)                   // looks a code point up by bisection
+            if (r.second >= 128u) rs.push_back({r.first < 128u ? 128u : r.first, r.second});
+        std::sort(rs.begin(), rs.end());
+        for (const auto& r : rs) {
+            const size_t k = out->ranges.size();
+            if (k > 2 * (size_t)roff && r.first <= out->ranges[k - 1] + 1u) {
+                if (r.second > out->ranges[k - 1]) out->ranges[k - 1] = r.second;
+            } else {
+                out->ranges.push_back(r.first);
                 out->ranges.push_back(r.second);
             }
+        }
         S.rr = roff << 16 | ((uint32_t)out->ranges.size() / 2 - roff);
         out->sets.push_back(S);
     }

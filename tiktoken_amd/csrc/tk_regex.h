@@ -85,8 +85,16 @@ TK_HD bool tk_rx_in_set(const TkRxProg& P, uint32_t s, uint32_t cp) {
     const uint32_t pr = tk_rx_prop(P, cp);
     bool in = ((S.gcmask >> (pr & 31u)) & 1u) || (pr & S.flags & 0x60u);
     if (!in && (S.flags & 2u)) in = !(((S.cgcmask >> (pr & 31u)) & 1u) || (pr & (S.flags >> 8) & 0x60u));
-    const uint32_t roff = S.rr >> 16, rcnt = S.rr & 0xFFFFu;
-    for (uint32_t i = 0; i < rcnt && !in; ++i) in = cp >= P.ranges[2 * (roff + i)] && cp <= P.ranges[2 * (roff + i) + 1];
+    if (!in && (S.rr & 0xFFFFu)) {  // the ranges of a set are sorted and disjoint (tk_regex.cpp): first range that ends at or behind cp
+        const uint32_t roff = S.rr >> 16;
+        uint32_t lo = 0, hi = S.rr & 0xFFFFu;
+        while (lo < hi) {
+            const uint32_t mid = (lo + hi) >> 1;
+            if (cp > P.ranges[2 * (roff + mid) + 1]) lo = mid + 1;
+            else hi = mid;
+        }
+        in = lo < (S.rr & 0xFFFFu) && cp >= P.ranges[2 * (roff + lo)];
+    }
     return in != (bool)(S.flags & 1u);
 }
 

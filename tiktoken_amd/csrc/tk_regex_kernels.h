@@ -8,7 +8,7 @@
 //                       in which every char is a letter: its scanners then cut at hard starts and nowhere else, and everything behind the
 //                       split -- whole-piece probe, de-duplication, merges, long pieces, token copy -- is the pipeline of the stock patterns.
 //
-// The program (<= 12.5 KiB) is copied to LDS by every workgroup; the property table (42 KiB) stays in global memory (L2).  Integer work,
+// The program (<= 15 KiB) is copied to LDS by every workgroup; the property table (42 KiB) stays in global memory (L2).  Integer work,
 // data-dependent branches, one lane per unit: this path is bound by divergence and latency, not by HBM -- it exists so that no pat_str
 // is refused, the three stock families keep their hand-written scanners.
 #pragma once
