@@ -337,3 +337,35 @@ def test_first_byte_pruning_is_exact(monkeypatch):
         work.append((rx.split(docs, speculate=0), L.tks_rx_steps() - s0))
     assert work[0][0] == work[1][0]
     assert work[0][1] < 0.65 * work[1][1], (work[0][1], work[1][1])  # (o200k on web text: 17 steps per piece instead of 32)
+
+
+@pytest.mark.parametrize("idx", [2, 5, 7, 12])
+def test_special_tokens_at_random_places(idx):
+    """Special tokens of several lengths at random char boundaries -- next to each other, at document edges, across the segment boundaries of
+    the speculative pass, with a speculative start falling inside one: the haystack ends at a special and begins anew behind it."""
+    pat, py = PATTERNS[idx]
+    py = py or pat
+    rx = h.RxSim(pat)
+    rng = random.Random(500 + idx)
+    sp = ["<|endoftext|>", "<|x|>", "<|a-very-long-special-token-that-spans-more-than-one-word-and-then-some|>"]
+    docs, specials, want, base = [], [], [], 0
+    for _ in range(120):
+        parts = []
+        for _ in range(rng.randrange(0, 14)):
+            part = rng.choice(sp) if rng.random() < 0.35 else random_text(rng, rng.choice([0, 1, 4, 40, 250, 700]))
+            if parts and part not in sp and parts[-1] not in sp:
+                parts[-1] += part  # (text next to text is one haystack)
+            else:
+                parts.append(part)
+        at = base
+        for part in parts:
+            if part in sp:
+                want.append(at)
+                specials.append((at, len(part)))
+            else:
+                want += [at + s for s in py_starts(py, part)]
+            at += len(part.encode())
+        docs.append("".join(parts).encode())
+        base = at
+    for speculate in (0, 1, 2):
+        assert rx.split(docs, specials, speculate=speculate) == want, speculate
