@@ -44,7 +44,7 @@ def oracle_tokens(py_pat, docs, C, cache):
 
 
 # (patterns 9 and 13 leave gaps on most texts: their split is covered by the CPU tests, which run the kernels' lanes one by one)
-@pytest.mark.parametrize("idx", [5, 6, 7, 8, 10, 11, 12, 14])
+@pytest.mark.parametrize("idx", [5, 6, 7, 8, 10, 11, 12, 14, 16])
 def test_split_and_tokens_equal_python_regex_plus_oracle(idx):
     pat, py = PATTERNS[idx]
     py = py or pat

@@ -10,6 +10,12 @@ import regex
 
 import helpers as h
 
+KIMI = "|".join([
+    r"[\p{Han}]+",
+    r"[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}&&[^\p{Han}]]*[\p{Ll}\p{Lm}\p{Lo}\p{M}&&[^\p{Han}]]+(?i:'s|'t|'re|'ve|'m|'ll|'d)?",
+    r"[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}&&[^\p{Han}]]+[\p{Ll}\p{Lm}\p{Lo}\p{M}&&[^\p{Han}]]*(?i:'s|'t|'re|'ve|'m|'ll|'d)?",
+    r"\p{N}{1,3}", r" ?[^\s\p{L}\p{N}]+[\r\n]*", r"\s*[\r\n]+", r"\s+(?!\S)", r"\s+"])
+
 # (pattern for the engine, the same for Python `regex` where the dialects differ: `$` is end-of-text only in fancy-regex / Rust)
 PATTERNS = [
     (h.PAT_STR[0], None),
@@ -31,6 +37,9 @@ PATTERNS = [
     # scripts (expanded into ranges at compile time): a Kimi-style CJK alternative in front of an o200k-like tail
     (r"[\p{Han}\p{Hiragana}\p{Katakana}]+|\p{Latin}+|\p{Script=Greek}+|\p{sc=Cyrl}+|\p{Thai}+|[^\p{Han}\s]|\s+", None),
     (r"\P{Latin}+?(?=\p{Latin}|$)|(?i:\p{Latin}{1,4})", r"\P{Latin}+?(?=\p{Latin}|\Z)|(?i:\p{Latin}{1,4})"),
+    # class set operations (Python `regex` needs its V1 syntax for them): Kimi-K2's pat_str -- o200k's with Han split off
+    (KIMI, "(?V1)" + KIMI),
+    (r"[\p{L}&&[^a-cé]]+|[\w--\d]|[^\s&&\P{N}--[1-3]]+|\s+|[\s\S]", r"(?V1)[\p{L}&&[^a-cé]]+|[\w--\d]|[^\s&&\P{N}--[1-3]]+|\s+|[\s\S]"),
 ]
 
 
@@ -139,7 +148,7 @@ def test_gaps_and_errors_are_loud():
 @pytest.mark.parametrize("pat,why", [
     (r"(?<=a)b|.", "look-behind"), (r"\bfoo|.", "look-behind"), (r"(a)\1|.", "back-references"), (r"a*", "empty string"),
     (r"(?:a*)+|.", "empty string"), (r"\p{Alphabetic}+|.", "General_Category value or a script"), (r"[\P{Han}x]|.", "negated script"),
-    (r"\p{scx=Han}|.", "General_Category value or a script"), (r"[a-z&&[^b]]|.", "set operations"), (r"(?m)^a|.", "(?m)"),
+    (r"\p{scx=Han}|.", "General_Category value or a script"), (r"[a-z~~[b]]|.", "~~"), (r"[a-z&&[b&&[c]]]|.", "inside the operand"), (r"[a&&b]|.", "right side"), (r"(?m)^a|.", "(?m)"),
     (r"(?i)é|.", "non-ASCII cased"), (r"[[:alpha:]]|.", "POSIX"), (r"(a|b", "unterminated group"), (r"a)|b", "unbalanced"),
     (r"x{3,2}|.", "out of order"), (r"a**|.", "quantifier behind"), (r"[z-a]|.", "out of order"), (r"(?=a)|.", "empty string"),
 ])

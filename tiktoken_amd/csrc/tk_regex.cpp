@@ -2,11 +2,11 @@
 // outside the three scanner families of tk_pattern.cpp is no longer refused: it is parsed here (the syntax fancy-regex and the Rust
 // `regex` crate share with Python `regex`), compiled to a backtracking program and run on the GPU.
 //
-// Supported: literals, `.`, classes [...] with ranges / escapes / negation, \d \s \w \D \S \W, \p{..} \P{..} for General_Category values and scripts (\p{Han}, \p{Script=Greek}),
+// Supported: literals, `.`, classes [...] with ranges / escapes / negation / intersection [A&&[^B]] / difference [A--B], \d \s \w \D \S \W, \p{..} \P{..} for General_Category values and scripts (\p{Han}, \p{Script=Greek}),
 // the escapes \n \r \t \f \v \xHH \x{H..} \uHHHH \u{H..} \UHHHHHHHH, alternation, groups (capturing ones are plain groups: a split pattern
 // has no use for captures), (?: ) (?i: ) (?s: ) (?i) (?s) (?-i), atomic groups (?> ), look-ahead (?= ) (?! ), the quantifiers ? * + {m} {m,}
 // {m,n} in their greedy, lazy (?) and possessive (+) forms, ^ \A $ \z.  Refused, with the reason: look-behind, \b \B, back-references,
-// (?m) (?x), class set operations (&& --), POSIX classes, binary properties (\\p{Alphabetic} ...), script extensions, case-insensitive matching of
+// (?m) (?x), the class set operation ~~ and set operations nested in operands, POSIX classes, binary properties (\\p{Alphabetic} ...), script extensions, case-insensitive matching of
 // non-ASCII cased letters, a pattern (or a repeated group) that can match the empty string.
 #include "tk_regex.h"
 
@@ -38,12 +38,13 @@ struct CharSet {
     bool comp = false;               // one complemented term: \S \D \W \P{..} inside a class
     uint32_t cgcmask = 0, cflags = 0;
     std::vector<std::pair<uint32_t, uint32_t>> ranges;
-    bool member(uint32_t cp) const {
+    int and_set = -1;  // [A&&B], [A--B]: the set the members also have to be in (an operand of its own in Parser::sets; chains on)
+    bool raw(uint32_t cp) const {  // membership before negation and intersection
         const uint32_t pr = prop_of(cp);
         bool in = ((gcmask >> (pr & 31u)) & 1u) || (pr & flags & 0x60u);
         if (!in && comp) in = !(((cgcmask >> (pr & 31u)) & 1u) || (pr & cflags & 0x60u));
         for (size_t i = 0; i < ranges.size() && !in; ++i) in = cp >= ranges[i].first && cp <= ranges[i].second;
-        return in != neg;
+        return in;
     }
 };
 
@@ -86,6 +87,11 @@ struct Parser {
     }
 
     // ---- sets
+    bool member(const CharSet& c, uint32_t cp) const {
+        bool in = c.raw(cp);
+        for (int k = c.and_set; in && k >= 0; k = sets[k].and_set) in = sets[k].raw(cp) != sets[k].neg;
+        return in != c.neg;
+    }
     bool add_char(CharSet& c, uint32_t cp, bool ci) {
         c.ranges.push_back({cp, cp});
         if (!ci) return true;
@@ -270,6 +276,12 @@ struct Parser {
         return true;
     }
     int parse_class(const Flags& f) {  // i at '['
+        CharSet c;
+        if (!parse_class_body(f, &c, true)) return -1;
+        return add_set(c);
+    }
+    // [ ... ] -> *out.  Set operations (top level of a class only): [A&&B] intersection, [A--B] difference, B a class or an escape; chains.
+    bool parse_class_body(const Flags& f, CharSet* out, bool allow_ops) {
         ++i;
         CharSet c;
         if (peek() == '^') {
@@ -277,25 +289,50 @@ struct Parser {
             ++i;
         }
         bool first = true;
+        int tail = -1;  // last operand of a chain of set operations (index into sets), -1: still the left side
         while (more() && (peek() != ']' || first)) {
             first = false;
             uint32_t lo;
-            if (peek() == '[') {
-                if (peek(1) == ':') return fail("POSIX classes are not supported"), -1;
-                return fail("nested classes are not supported"), -1;
+            const bool op_and = peek() == '&' && peek(1) == '&', op_diff = peek() == '-' && peek(1) == '-';
+            if (op_and || op_diff) {
+                if (!allow_ops) return fail("a set operation inside the operand of a set operation is not supported");
+                i += 2;
+                CharSet operand;
+                if (peek() == '[') {
+                    if (!parse_class_body(f, &operand, false)) return false;
+                } else if (peek() == '\\' && is_class_escape(peek(1))) {
+                    ++i;
+                    bool negated;
+                    if (!class_escape(peek(), operand, f.ci, &negated)) return false;
+                    operand.neg = negated;
+                } else {
+                    return fail("the right side of a class set operation has to be a class or an escape like \\p{..}");
+                }
+                if (op_diff) operand.neg = !operand.neg;
+                sets.push_back(operand);
+                const int idx = (int)sets.size() - 1;
+                if (tail < 0) c.and_set = idx;
+                else sets[tail].and_set = idx;
+                tail = idx;
+                if (peek() != ']' && !(peek() == '&' && peek(1) == '&') && !(peek() == '-' && peek(1) == '-'))
+                    return fail("only ']' or another set operation may follow the operand of a set operation");
+                continue;
             }
-            if ((peek() == '&' && peek(1) == '&') || (peek() == '-' && peek(1) == '-') || (peek() == '~' && peek(1) == '~'))
-                return fail("class set operations are not supported"), -1;
+            if (peek() == '[') {
+                if (peek(1) == ':') return fail("POSIX classes are not supported");
+                return fail("nested classes are only supported as operands of && and --");
+            }
+            if (peek() == '~' && peek(1) == '~') return fail("the class set operation ~~ is not supported");
             if (peek() == '\\') {
                 ++i;
-                if (!more()) return fail("pattern ends in a backslash"), -1;
+                if (!more()) return fail("pattern ends in a backslash");
                 if (is_class_escape(peek())) {
                     bool negated;
                     CharSet sub;
-                    if (!class_escape(peek(), sub, f.ci, &negated)) return -1;
+                    if (!class_escape(peek(), sub, f.ci, &negated)) return false;
                     if (negated) {  // a complement inside a union: one per class ([^\S\n], [\S\d])
-                        if (c.comp) return fail("more than one negated escape inside a class is not supported"), -1;
-                        if (!sub.ranges.empty()) return fail("a negated script inside a class is not supported (negate the class: [^\\p{..}])"), -1;
+                        if (c.comp) return fail("more than one negated escape inside a class is not supported");
+                        if (!sub.ranges.empty()) return fail("a negated script inside a class is not supported (negate the class: [^\\p{..}])");
                         c.comp = true;
                         c.cgcmask = sub.gcmask;
                         c.cflags = sub.flags;
@@ -306,30 +343,31 @@ struct Parser {
                     }
                     continue;
                 }
-                if (!literal_escape(&lo)) return -1;
+                if (!literal_escape(&lo)) return false;
             } else {
                 lo = peek();
                 ++i;
             }
-            if (peek() == '-' && peek(1) != ']' && i + 1 < s.size()) {  // range
+            if (peek() == '-' && peek(1) != ']' && peek(1) != '-' && i + 1 < s.size()) {  // range
                 ++i;
                 uint32_t hi;
                 if (peek() == '\\') {
                     ++i;
-                    if (!more() || is_class_escape(peek())) return fail("bad class range"), -1;
-                    if (!literal_escape(&hi)) return -1;
+                    if (!more() || is_class_escape(peek())) return fail("bad class range");
+                    if (!literal_escape(&hi)) return false;
                 } else {
                     hi = peek();
                     ++i;
                 }
-                if (!add_range(c, lo, hi, f.ci)) return -1;
+                if (!add_range(c, lo, hi, f.ci)) return false;
             } else if (!add_char(c, lo, f.ci)) {
-                return -1;
+                return false;
             }
         }
-        if (!more()) return fail("unterminated class"), -1;
+        if (!more()) return fail("unterminated class");
         ++i;  // ]
-        return add_set(c);
+        *out = c;
+        return true;
     }
 
     // ---- expressions
@@ -812,10 +850,10 @@ std::string tk_rx_compile(const char* pat_str, TkRxCompiled* out) {
     for (const CharSet& c : P.sets) {
         TkRxSet S{};
         for (uint32_t cp = 0; cp < 128; ++cp)
-            if (c.member(cp)) S.ascii[cp >> 5] |= 1u << (cp & 31u);
+            if (P.member(c, cp)) S.ascii[cp >> 5] |= 1u << (cp & 31u);
         S.gcmask = c.gcmask;
         S.cgcmask = c.cgcmask;
-        S.flags = (c.flags & 0x60u) | (c.neg ? 1u : 0u) | (c.comp ? 2u : 0u) | ((c.cflags & 0x60u) << 8);
+        S.flags = (c.flags & 0x60u) | (c.neg ? 1u : 0u) | (c.comp ? 2u : 0u) | ((c.cflags & 0x60u) << 8) | ((uint32_t)(c.and_set + 1) << 16);
         const uint32_t roff = (uint32_t)out->ranges.size() / 2;
         std::vector<std::pair<uint32_t, uint32_t>> rs;  // beyond ASCII (the ASCII part lives in the bitmap), sorted and merged: the matcher
         for (const auto& r : c.ranges)                   // looks a code point up by bisection

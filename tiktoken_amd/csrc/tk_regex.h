@@ -41,8 +41,8 @@ struct TkRxIns {  // 16 bytes
 };
 // A set of code points: ASCII members as a bitmap (everything below already applied); beyond ASCII the union of General_Category members
 // (gcmask, bit = index in tools/gen_regex_props.py's order), \s / \w members (flags bits 5 / 6, the bits of the property byte), explicit
-// ranges and -- flags bit 1 -- the COMPLEMENT of one more such term (cgcmask, flags bits 13 / 14: the \S of [^\S\n]); flags bit 0 negates
-// the whole.
+// ranges and -- flags bit 1 -- the COMPLEMENT of one more such term (cgcmask, flags bits 13 / 14: the \S of [^\S\n]); flags bits 16..22:
+// 1 + the set the members must ALSO be in ([A&&B], [A--B]; 0 = none; that set chains on the same way); flags bit 0 negates the whole.
 struct TkRxSet {  // 32 bytes
     uint32_t ascii[4];
     uint32_t gcmask, cgcmask;
@@ -79,10 +79,8 @@ TK_HD uint32_t tk_rx_prop(const TkRxProg& P, uint32_t cp) {
     return P.stage2[(uint32_t)P.stage1[cp >> 8] * 256u + (cp & 255u)];
 }
 
-TK_HD bool tk_rx_in_set(const TkRxProg& P, uint32_t s, uint32_t cp) {
-    const TkRxSet& S = P.sets[s];
-    if (cp < 128u) return (S.ascii[cp >> 5] >> (cp & 31u)) & 1u;
-    const uint32_t pr = tk_rx_prop(P, cp);
+// membership of a non-ASCII code point before negation and intersection (pr: its property byte)
+TK_HD bool tk_rx_raw_member(const TkRxProg& P, const TkRxSet& S, uint32_t cp, uint32_t pr) {
     bool in = ((S.gcmask >> (pr & 31u)) & 1u) || (pr & S.flags & 0x60u);
     if (!in && (S.flags & 2u)) in = !(((S.cgcmask >> (pr & 31u)) & 1u) || (pr & (S.flags >> 8) & 0x60u));
     if (!in && (S.rr & 0xFFFFu)) {  // the ranges of a set are sorted and disjoint (tk_regex.cpp): first range that ends at or behind cp
@@ -94,6 +92,19 @@ TK_HD bool tk_rx_in_set(const TkRxProg& P, uint32_t s, uint32_t cp) {
             else hi = mid;
         }
         in = lo < (S.rr & 0xFFFFu) && cp >= P.ranges[2 * (roff + lo)];
+    }
+    return in;
+}
+
+TK_HD bool tk_rx_in_set(const TkRxProg& P, uint32_t s, uint32_t cp) {
+    const TkRxSet& S = P.sets[s];
+    if (cp < 128u) return (S.ascii[cp >> 5] >> (cp & 31u)) & 1u;
+    const uint32_t pr = tk_rx_prop(P, cp);
+    bool in = tk_rx_raw_member(P, S, cp, pr);
+    for (uint32_t nx = (S.flags >> 16) & 127u; in && nx;) {  // [A&&B], [A--B]: the operands, each a set of its own (negated for --)
+        const TkRxSet& B = P.sets[nx - 1u];
+        in = tk_rx_raw_member(P, B, cp, pr) != (bool)(B.flags & 1u);
+        nx = (B.flags >> 16) & 127u;
     }
     return in != (bool)(S.flags & 1u);
 }
