@@ -378,3 +378,33 @@ def test_special_tokens_at_random_places(idx):
         base = at
     for speculate in (0, 1, 2):
         assert rx.split(docs, specials, speculate=speculate) == want, speculate
+
+
+def test_known_tokenizer_patterns_are_accepted():
+    """pat_str of tiktoken-style tokenizers in the wild: each runs either on a hand-written scanner family or on the generic engine, and
+    either way splits a mixed sample as Python `regex` does."""
+    from tiktoken_amd import _lib
+
+    word = r"[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]*[\p{Ll}\p{Lm}\p{Lo}\p{M}]+|[^\r\n\p{L}\p{N}]?[\p{Lu}\p{Lt}\p{Lm}\p{Lo}\p{M}]+[\p{Ll}\p{Lm}\p{Lo}\p{M}]*"
+    known = {
+        "gpt2 / r50k / p50k": (h.PAT_STR[0], None),
+        "cl100k": (h.PAT_STR[1], None),
+        "o200k / o200k_harmony": (h.PAT_STR[2], None),
+        "llama-3": (r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}{1,3}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+", None),
+        "qwen2": (r"(?i:'s|'t|'re|'ve|'m|'ll|'d)|[^\r\n\p{L}\p{N}]?\p{L}+|\p{N}| ?[^\s\p{L}\p{N}]+[\r\n]*|\s*[\r\n]+|\s+(?!\S)|\s+", None),
+        "mistral tekken": (word + r"|\p{N}| ?[^\s\p{L}\p{N}]+[\r\n/]*|\s*[\r\n]+|\s+(?!\S)|\s+", None),
+        "kimi-k2": (KIMI, "(?V1)" + KIMI),
+    }
+    rng = random.Random(99)
+    sample = [random_text(rng, 400) for _ in range(40)] + ["Hello, World! It's 2024-01-02T03:04:05Z; naïve café — 你好世界 こんにちは 안녕하세요 привет\n\n\tdef f(x):\n        return x**2  # 12345678\r\n"]
+    ran_on = {}
+    for name, (pat, py) in known.items():
+        how = _lib.lib().tk_pattern_id(pat.encode())
+        assert how in (0, 1, 2, 3), name
+        ran_on[name] = how
+        want, base = [], 0
+        for t in sample:
+            want += [base + s for s in py_starts(py or pat, t)]
+            base += len(t.encode())
+        assert h.RxSim(pat).split([t.encode() for t in sample]) == want, name  # (the generic engine takes the family patterns as well)
+    assert ran_on["kimi-k2"] == 3 and ran_on["llama-3"] == 1 and ran_on["qwen2"] == 1 and ran_on["o200k / o200k_harmony"] == 2, ran_on
