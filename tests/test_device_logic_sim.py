@@ -275,3 +275,23 @@ def test_scanners_under_the_sanitizers(tmp_path):
     run = subprocess.run([exe, h.PAT_STR[0], h.PAT_STR[1], h.PAT_STR[2], qwen2], capture_output=True, text=True, timeout=900,
                          env={**os.environ, "TK_SAN_ROUNDS": "300"})
     assert run.returncode == 0 and run.stdout.startswith("ok "), (run.stdout[-500:], run.stderr[-3000:])
+
+
+@pytest.mark.parametrize("name", h.ENCODING_NAMES)
+def test_scanner_forms_on_fuzzed_documents(name):
+    """The awkward documents of the GPU fuzzer (helpers.fuzz_batch: runs of 20 000 units, chains of uncertain boundaries, near-specials) through
+    every scanner form of the device headers on the CPU, against the oracle's split."""
+    import zlib
+
+    sim, C = h.HostSim(h.load_golden(name)["pat_str"], {bytes([b]): b for b in range(256)}, {}), h.c_oracle_for(name)
+    for seed in range(2):
+        blob, off = h.pack(h.fuzz_batch(zlib.crc32(name.encode()) + 100 + seed, 2 << 20))
+        bb, ref = blob.tobytes(), []
+        for d in range(len(off) - 1):
+            a, b = int(off[d]), int(off[d + 1])
+            if b > a:
+                ref += [a + e for e in C.split(bb[a:b])]
+        assert sim.piece_ends_tiled(blob, off, 3840, 128)[0].tolist() == ref
+        assert sim.piece_ends(blob, off, bits=True)[0].tolist() == ref
+        assert sim.piece_ends(blob, off)[0].tolist() == ref
+        assert sim.chunk_check(blob, off)[0] == 0
