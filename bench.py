@@ -36,7 +36,8 @@ sys.path.insert(0, ROOT)
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
 KERNELS = ["tk_k_mark_docs", "tk_k_front", "tk_k_front_slow", "tk_k_single_front", "tk_k_bincount", "tk_k_binfill", *[f"tk_k_merge_llane_{i}" for i in (16, 24, 32, 48, 64)],
            *[f"tk_k_merge_group_{i}" for i in (8, 16, 32, 64)], "tk_k_merge_rounds", "tk_k_merge_rounds_wide", "tk_k_merge_long", "tk_k_dup_publish", "tk_k_tile_finish",
-           "tk_k_scan_small", "tk_k_scan_sums", "tk_k_scan_apply", "tk_k_back", "tk_k_docoff"]
+           "tk_k_scan_small", "tk_k_scan_sums", "tk_k_scan_apply", "tk_k_back", "tk_k_docoff",
+           "tk_k_rx_speculate", "tk_k_rx_resolve", "tk_k_rx_merge"]  # (the last three only run for a pat_str on the generic engine)
 
 
 def gen_corpus(seed: int, mix: int, nbytes: int, threads: int):
@@ -70,6 +71,8 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the T2 / T3 host-boundary timings")
     ap.add_argument("--t3-sample-mib", type=int, default=64)
+    ap.add_argument("--generic-engine", action="store_true",
+                    help="NOT the headline: run the encoding's pat_str on the generic regex engine instead of the hand-written scanners")
     args = ap.parse_args()
 
     import torch
@@ -105,6 +108,8 @@ def main():
     from tiktoken_ext import amd_shaped
 
     spec = amd_shaped.ENCODING_CONSTRUCTORS[args.encoding]()
+    if args.generic_engine:  # (read once, when the pattern is compiled)
+        os.environ["TIKTOKEN_AMD_DEBUG"] = str(int(os.environ.get("TIKTOKEN_AMD_DEBUG", "0")) | 0x100000)
     core = CoreBPE(spec["mergeable_ranks"], spec["special_tokens"], spec["pat_str"], device=local_rank)
 
     d_text = torch.from_numpy(blob).cuda()          # nbytes + 64 readable bytes, resident in HBM
@@ -276,7 +281,8 @@ def main():
             "config": {"workload": f"{args.encoding} encode_ordinary_batch, {args.mib} MiB synthetic web-text per GPU "
                                    f"(tkc_generate mix=1, seed {'0x5EED0003' if world == 1 else '0x5EED0004+rank'}), "
                                    f"{n_docs} docs on rank 0, inputs resident in HBM, packed u32 output",
-                       "encoding": args.encoding, "bytes_per_gpu": nbytes, "docs_rank0": n_docs,
+                       "encoding": args.encoding, "pat_str_runs_on": "generic regex engine (--generic-engine)" if args.generic_engine else "hand-written scanners",
+                       "bytes_per_gpu": nbytes, "docs_rank0": n_docs,
                        "tokens_total": total_tokens, "pieces_rank0": stats["pieces"],
                        "parallelism": f"doc-sharded x{world}" + (" + RCCL gather of token ids to rank 0" if world > 1 else "")},
             "roofline": roofline, "cpu_baseline": cpu, "parity_all_tokens_vs_oracle": parity, "host_path": host_path,
