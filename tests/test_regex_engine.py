@@ -39,6 +39,9 @@ PATTERNS = [
     (r"\P{Latin}+?(?=\p{Latin}|$)|(?i:\p{Latin}{1,4})", r"\P{Latin}+?(?=\p{Latin}|\Z)|(?i:\p{Latin}{1,4})"),
     # class set operations (Python `regex` needs its V1 syntax for them): Kimi-K2's pat_str -- o200k's with Han split off
     (KIMI, "(?V1)" + KIMI),
+    # word boundaries and one-char look-behind: the char before a position is text too
+    (r"\b\w+\b|\s+|\B[^\w\s]+|[^\w\s]", None),
+    (r"(?<=\s)\p{L}+|(?<![a-zé])\d{1,2}|(?<!\S)'s|(?<=a|b|[x-z])!|\p{L}+?(?=\p{Lu}|\b)|[\s\S]", None),
     (r"[\p{L}&&[^a-cé]]+|[\w--\d]|[^\s&&\P{N}--[1-3]]+|\s+|[\s\S]", r"(?V1)[\p{L}&&[^a-cé]]+|[\w--\d]|[^\s&&\P{N}--[1-3]]+|\s+|[\s\S]"),
 ]
 
@@ -146,7 +149,7 @@ def test_gaps_and_errors_are_loud():
 
 
 @pytest.mark.parametrize("pat,why", [
-    (r"(?<=a)b|.", "look-behind"), (r"\bfoo|.", "look-behind"), (r"(a)\1|.", "back-references"), (r"a*", "empty string"),
+    (r"(?<=ab)c|.", "look-behind is supported for one char only"), (r"[\b]|.", "inside a class"), (r"(?<=a*)c|.", "one char only"), (r"(a)\1|.", "back-references"), (r"a*", "empty string"),
     (r"(?:a*)+|.", "empty string"), (r"\p{Alphabetic}+|.", "General_Category value or a script"), (r"[\P{Han}x]|.", "negated script"),
     (r"\p{scx=Han}|.", "General_Category value or a script"), (r"[a-z~~[b]]|.", "~~"), (r"[a-z&&[b&&[c]]]|.", "inside the operand"), (r"[a&&b]|.", "right side"), (r"(?m)^a|.", "(?m)"),
     (r"(?i)é|.", "non-ASCII cased"), (r"[[:alpha:]]|.", "POSIX"), (r"(a|b", "unterminated group"), (r"a)|b", "unbalanced"),
@@ -230,6 +233,8 @@ def _gen_pattern(rng: random.Random):
         parts.insert(rng.randint(0, len(parts)), atom(depth, ci) + rng.choice(["", "", "+", "{2}", "{1,3}", "+?", "++"]))  # (at least one char)
         if rng.random() < 0.2:
             parts.append(rng.choice(["(?=", "(?!"]) + atom(depth + 1, ci) + ")")
+        if rng.random() < 0.2:  # word boundaries, one-char look-behind: anywhere between the atoms
+            parts.insert(rng.randint(0, len(parts)), rng.choice([r"\b", r"\B", r"(?<=\s)", r"(?<!\S)", r"(?<![a-c])", r"(?<=a|\p{Lu})", r"(?<!\w)"]))
         return "".join(parts)
 
     def alt(depth, ci, n):
@@ -257,6 +262,10 @@ def test_generated_patterns_equal_python_regex():
     compiled = refused = deep = exploded = 0
     for it in range(1000):
         eng, py = _gen_pattern(rng)
+        if "(?i:" in eng and r"[^a\s]" in eng:
+            # `regex` 2026.7.19 lets a scoped (?i: ) leak into a negated class that holds a class escape, anywhere in the pattern:
+            # regex.findall(r"(?i:k)|[^a\s]", "A") == [] (but ["A"] for [^a], or with (?:k)) -- not how fancy-regex scopes flags
+            continue
         pyc = regex.compile(py)
         try:
             rx = h.RxSim(eng)
@@ -291,7 +300,7 @@ def test_generated_patterns_equal_python_regex():
             deep += 1
             continue
         assert got == want, (eng, py)
-    assert compiled > 800 and deep < compiled // 15, (compiled, refused, deep, exploded)
+    assert compiled > 750 and deep < compiled // 15, (compiled, refused, deep, exploded)
 
 
 def test_compiler_and_lanes_under_the_sanitizers(tmp_path):

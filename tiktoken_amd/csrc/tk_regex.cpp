@@ -5,7 +5,8 @@
 // Supported: literals, `.`, classes [...] with ranges / escapes / negation / intersection [A&&[^B]] / difference [A--B], \d \s \w \D \S \W, \p{..} \P{..} for General_Category values and scripts (\p{Han}, \p{Script=Greek}),
 // the escapes \n \r \t \f \v \xHH \x{H..} \uHHHH \u{H..} \UHHHHHHHH, alternation, groups (capturing ones are plain groups: a split pattern
 // has no use for captures), (?: ) (?i: ) (?s: ) (?i) (?s) (?-i), atomic groups (?> ), look-ahead (?= ) (?! ), the quantifiers ? * + {m} {m,}
-// {m,n} in their greedy, lazy (?) and possessive (+) forms, ^ \A $ \z.  Refused, with the reason: look-behind, \b \B, back-references,
+// {m,n} in their greedy, lazy (?) and possessive (+) forms, ^ \A $ \z, \b \B, one-char look-behind (?<=X) (?<!X).  Refused, with the reason:
+// look-behind of more than one char, back-references,
 // (?m) (?x), the class set operation ~~ and set operations nested in operands, POSIX classes, binary properties (\\p{Alphabetic} ...), script extensions, case-insensitive matching of
 // non-ASCII cased letters, a pattern (or a repeated group) that can match the empty string.
 #include "tk_regex.h"
@@ -49,7 +50,7 @@ struct CharSet {
 };
 
 struct Node {
-    enum Kind { EMPTY, SET, CAT, ALT, REPEAT, ATOMIC, LOOK, START, END } kind = EMPTY;
+    enum Kind { EMPTY, SET, CAT, ALT, REPEAT, ATOMIC, LOOK, START, END, WORDB, PREV } kind = EMPTY;
     int set = -1;
     std::vector<int> kids;
     uint32_t mn = 0, mx = 0;
@@ -268,7 +269,7 @@ struct Parser {
             default: break;
         }
         if (e >= '1' && e <= '9') return fail("back-references are not supported");
-        if (e == 'b' || e == 'B') return fail("\\b and \\B look at the char before the position (look-behind): not supported");
+        if (e == 'b' || e == 'B') return fail("\\b inside a class is not supported");
         if (e == 'G' || e == 'K' || e == 'Z' || e == 'k' || e == 'g' || e == 'X' || e == 'R' || e == 'h' || e == 'H' || e == 'N')
             return fail(std::string("the escape \\") + (char)e + " is not supported");
         if ((e >= 'a' && e <= 'z') || (e >= 'A' && e <= 'Z')) return fail(std::string("unknown escape \\") + (char)e);
@@ -370,6 +371,30 @@ struct Parser {
         return true;
     }
 
+    // the node matches exactly one char from a set that can be written as one CharSet: a set, or an alternation of such
+    bool one_char_set(int n, CharSet* u) const {
+        const Node& N = nodes[n];
+        if (N.kind == Node::SET) {
+            const CharSet& c = sets[N.set];
+            if (c.and_set >= 0) return false;
+            if (u->gcmask == 0 && u->flags == 0 && !u->comp && u->ranges.empty() && !u->neg) {
+                *u = c;
+                return true;
+            }
+            if (c.neg || c.comp || u->neg || u->comp) return false;  // (a union with a negated member: write it as one class)
+            u->gcmask |= c.gcmask;
+            u->flags |= c.flags;
+            u->ranges.insert(u->ranges.end(), c.ranges.begin(), c.ranges.end());
+            return true;
+        }
+        if (N.kind == Node::ALT) {
+            for (int k : N.kids)
+                if (!one_char_set(k, u)) return false;
+            return true;
+        }
+        return false;
+    }
+
     // ---- expressions
     int parse_alt(Flags f, int depth) {
         if (depth > 40) return fail("pattern nested too deeply"), -1;
@@ -433,7 +458,7 @@ struct Parser {
                 return a;
             }
             const Node::Kind k = nodes[a].kind;
-            if (k == Node::START || k == Node::END || k == Node::LOOK || k == Node::EMPTY) return fail("nothing to repeat"), -1;
+            if (k == Node::START || k == Node::END || k == Node::LOOK || k == Node::EMPTY || k == Node::WORDB || k == Node::PREV) return fail("nothing to repeat"), -1;
             Node r;
             r.kind = Node::REPEAT;
             r.kids = {a};
@@ -459,7 +484,22 @@ struct Parser {
                 else if (k == '>') wrap = Node::ATOMIC, ++i;
                 else if (k == '=') wrap = Node::LOOK, ++i;
                 else if (k == '!') wrap = Node::LOOK, neg = true, ++i;
-                else if (k == '<' && (peek(1) == '=' || peek(1) == '!')) return fail("look-behind is not supported: a piece must not depend on the text before it"), -1;
+                else if (k == '<' && (peek(1) == '=' || peek(1) == '!')) {  // look-behind: one char (a class, a literal, an alternation of them)
+                    const bool negative = peek(1) == '!';
+                    i += 2;
+                    const int body = parse_alt(g, depth + 1);
+                    if (body < 0) return -1;
+                    if (peek() != ')' || !more()) return fail("unterminated group"), -1;
+                    ++i;
+                    CharSet u;
+                    if (!one_char_set(body, &u)) return fail("look-behind is supported for one char only: (?<=\\s), (?<![a-z]), (?<!a|b)"), -1;
+                    sets.push_back(u);
+                    Node n;
+                    n.kind = Node::PREV;
+                    n.set = (int)sets.size() - 1;
+                    n.neg = negative;
+                    return add(n);
+                }
                 else if (k == 'P' || k == '<' || k == '\'') {  // named group: a plain group
                     const uint32_t close = k == '\'' ? '\'' : '>';
                     if (k == 'P') ++i;
@@ -524,6 +564,13 @@ struct Parser {
                 ++i;
                 Node n;
                 n.kind = e == 'A' ? Node::START : Node::END;
+                return add(n);
+            }
+            if (e == 'b' || e == 'B') {
+                ++i;
+                Node n;
+                n.kind = Node::WORDB;
+                n.neg = e == 'B';
                 return add(n);
             }
             if (is_class_escape(e)) {
@@ -593,6 +640,8 @@ struct Emitter {
             case Node::EMPTY: return true;
             case Node::SET: put(TK_RX_SET, (uint32_t)N.set); return true;
             case Node::START: put(TK_RX_START); return true;
+            case Node::WORDB: put(TK_RX_WORDB, N.neg ? 1u : 0u); return true;
+            case Node::PREV: put(TK_RX_PREV, (uint32_t)N.set, N.neg ? 1u : 0u); return true;
             case Node::END: put(TK_RX_END); return true;
             case Node::CAT:
                 for (size_t k = 0; k < N.kids.size(); ++k)

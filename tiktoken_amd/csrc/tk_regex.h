@@ -3,9 +3,10 @@
 // (tk_regex_kernels.h).  This header holds what host and device share: the program layout, the property lookup and the matcher.
 //
 // Semantics are those of fancy-regex / Python `regex` for the supported syntax (tk_regex.cpp): leftmost, alternatives in order,
-// greedy / lazy / possessive quantifiers, atomic groups, look-ahead, case-insensitive literals; no look-behind, no back-references.
-// Without look-behind the end of the piece that starts at p depends only on the text from p on (and on where its haystack ends), which is
-// what lets the kernels evaluate piece starts speculatively in parallel and prove them afterwards (tk_regex_kernels.h).
+// greedy / lazy / possessive quantifiers, atomic groups, look-ahead, case-insensitive literals, \b and one-char look-behind; no
+// back-references.  The end of the piece that starts at p depends only on the TEXT around p -- from p on, plus the one char before a
+// position for \b and (?<=X) -- and on where its haystack begins and ends, never on where earlier pieces began: that is what lets the
+// kernels evaluate piece starts speculatively in parallel and prove them afterwards (tk_regex_kernels.h).
 //
 // A program is an array of 16-byte instructions over "sets" (sets of code points).  Repeats of a single set -- \s+, \p{L}*, [^\r\n]+? --
 // are ONE instruction with ONE backtrack frame however long the run is (a frame holds a range of positions), and a repeated GROUP that is
@@ -32,6 +33,8 @@ enum {
     TK_RX_LOOK_END,
     TK_RX_FAIL,
     TK_RX_POP,  // forget the newest alternative (possessive loops of groups: the way out of the previous repetition)
+    TK_RX_WORDB,  // a: 0 = \b, 1 = \B -- word boundary between the char before the position and the char at it
+    TK_RX_PREV,   // a: set, b: 1 = negative -- one-char look-behind (?<=X) / (?<!X): the char before the position is (not) in the set
 };
 enum { TK_RX_GREEDY = 0, TK_RX_LAZY = 1, TK_RX_POSSESSIVE = 2 };
 #define TK_RX_INF 0xFFFFFFFFu
@@ -78,6 +81,9 @@ TK_HD uint32_t tk_rx_prop(const TkRxProg& P, uint32_t cp) {
     if (cp > 0x10FFFFu) cp = 0xFFFDu;
     return P.stage2[(uint32_t)P.stage1[cp >> 8] * 256u + (cp & 255u)];
 }
+
+// \w: Alphabetic | M | Nd | Pc | Join_Control (bit 6 of the property byte)
+TK_HD bool tk_rx_is_word(const TkRxProg& P, uint32_t cp) { return (tk_rx_prop(P, cp) & 0x40u) != 0u; }
 
 // membership of a non-ASCII code point before negation and intersection (pr: its property byte)
 TK_HD bool tk_rx_raw_member(const TkRxProg& P, const TkRxSet& S, uint32_t cp, uint32_t pr) {
@@ -244,6 +250,28 @@ TK_HD uint32_t tk_rx_match(const TkRxProg& P, A& t, uint32_t start) {
                 if (sp > 0) --sp;
                 ++pc;
                 break;
+            case TK_RX_WORDB:
+            case TK_RX_PREV: {
+                // the char before the position, if the haystack has one (it begins at a hard start; the match itself may have begun later)
+                const bool has_prev = pos > start || (pos > 0 && !t.hard(pos));
+                uint32_t prev = 0;
+                if (has_prev) {
+                    uint32_t q = pos - 1, len;
+                    for (int k = 0; k < 3 && q > 0 && (t.byte(q) & 0xC0u) == 0x80u && !(q <= start && t.hard(q)); ++k) --q;
+                    prev = tk_rx_decode(t, q, &len);
+                    if (q + len != pos) prev = 0xFFFDu;  // (malformed UTF-8: the byte before stands for itself)
+                }
+                bool ok;
+                if ((I.op & 0xFFu) == TK_RX_PREV) {
+                    ok = (has_prev && tk_rx_in_set(P, I.a, prev)) != (bool)I.b;
+                } else {
+                    uint32_t len;
+                    const bool wb = has_prev && tk_rx_is_word(P, prev), wa = !at_end(pos) && tk_rx_is_word(P, tk_rx_decode(t, pos, &len));
+                    ok = (wb != wa) != (bool)I.a;
+                }
+                if (ok) ++pc;
+                else fail = true;
+            } break;
             default: fail = true; break;
         }
         while (fail) {  // backtrack
