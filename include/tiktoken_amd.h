@@ -35,8 +35,8 @@ int tk_device_count(void);
  * tiktoken_ext/openai_public.py:12-14,89,104-114 (stock strings, their other spellings, variations of the contraction list, digit
  * group, suffix set and white-space rules) run on hand-written scanners; any other pattern in the syntax fancy-regex shares with
  * Python `regex` -- classes (with && and --), \p{General_Category}, \p{Script}, alternation, groups, (?i: ), greedy / lazy / possessive quantifiers, atomic groups,
- * look-ahead, one-char look-behind, \b, ^ $ -- is compiled to a program for the generic GPU engine (tk_regex.cpp).  Refused with
- * TK_UNSUPPORTED and the reason: longer look-behind, back-references, binary properties, a pattern that can match the empty string.  A pattern that leaves
+ * look-ahead, look-behind of fixed length, \b, ^ $ -- is compiled to a program for the generic GPU engine (tk_regex.cpp).  Refused with
+ * TK_UNSUPPORTED and the reason: look-behind of variable length, back-references, binary properties, a pattern that can match the empty string.  A pattern that leaves
  * text unmatched (the reference drops such text silently) makes the encode call fail with TK_VALUE_ERROR and the byte offset.
  * Text must be valid UTF-8 (the reference's boundary is &str); other bytes never crash but their split is unspecified.
  * Duplicate ranks -> TK_VALUE_ERROR (the reference panics, src/lib.rs:636-641).  device = HIP device ordinal. */

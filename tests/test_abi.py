@@ -46,7 +46,7 @@ def test_pattern_ids():
     assert L.tk_pattern_id(pub.cl100k_pat_str.encode()) == 1
     assert L.tk_pattern_id(pub.o200k_pat_str.encode()) == 2
     assert L.tk_pattern_id(b"\\w+") == 3  # the generic engine (tk_regex.cpp)
-    assert L.tk_pattern_id(b"(?<=ab)c") == -1  # (look-behind of more than one char)
+    assert L.tk_pattern_id(b"(?<=a+)c") == -1  # (look-behind of variable length)
     # the plugin module spells the same patterns as the reference (compared via the oracle's copies)
     assert (pub.r50k_pat_str, pub.cl100k_pat_str, pub.o200k_pat_str) == (po.R50K_PAT, po.CL100K_PAT, po.O200K_PAT)
 
@@ -59,7 +59,7 @@ def test_fails_loudly_without_a_device():
     with pytest.raises(RuntimeError, match="no HIP device"):
         CoreBPE({bytes([b]): b for b in range(256)}, {}, h.PAT_STR[0])
     with pytest.raises(ValueError):  # argument errors are still reported as ValueError (src/py.rs:21-22)
-        CoreBPE({bytes([b]): b for b in range(256)}, {}, r"(?<=ab)\w+")
+        CoreBPE({bytes([b]): b for b in range(256)}, {}, r"(?<=a+)\w+")
 
 
 def test_product_never_imports_the_oracle():

@@ -166,7 +166,7 @@ def test_rejects_bad_vocabularies():
     with pytest.raises(ValueError):  # a missing single byte (src/lib.rs:201-203 would panic at encode time)
         h.HostSim(h.PAT_STR[0], {bytes([b]): b for b in range(255)}, {})
     with pytest.raises(ValueError, match="look-behind"):  # a pattern neither the scanner families nor the generic engine take
-        h.HostSim(r"(?<!ab)\w+|\s+", {bytes([b]): b for b in range(256)}, {})
+        h.HostSim(r"(?<!a*b)\w+|\s+", {bytes([b]): b for b in range(256)}, {})
 
 
 def test_two_special_strings_may_share_an_id():

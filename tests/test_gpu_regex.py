@@ -44,7 +44,7 @@ def oracle_tokens(py_pat, docs, C, cache):
 
 
 # (patterns 9 and 13 leave gaps on most texts: their split is covered by the CPU tests, which run the kernels' lanes one by one)
-@pytest.mark.parametrize("idx", [5, 6, 7, 8, 10, 11, 12, 14, 16, 17, 18])
+@pytest.mark.parametrize("idx", [5, 6, 7, 8, 10, 11, 12, 14, 16, 17, 18, 19])
 def test_split_and_tokens_equal_python_regex_plus_oracle(idx):
     pat, py = PATTERNS[idx]
     py = py or pat
@@ -128,7 +128,7 @@ def test_gaps_and_deep_backtracking_are_refused_loudly():
     from tiktoken_amd import CoreBPE
 
     with pytest.raises(ValueError, match="look-behind"):
-        CoreBPE(h.golden_vocab(NAME), {}, r"(?<=ab)c|.")
+        CoreBPE(h.golden_vocab(NAME), {}, r"(?<=a+b)c|.")
 
 
 def test_one_large_document_and_multi_chunk(monkeypatch):

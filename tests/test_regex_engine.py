@@ -42,6 +42,7 @@ PATTERNS = [
     # word boundaries and one-char look-behind: the char before a position is text too
     (r"\b\w+\b|\s+|\B[^\w\s]+|[^\w\s]", None),
     (r"(?<=\s)\p{L}+|(?<![a-zé])\d{1,2}|(?<!\S)'s|(?<=a|b|[x-z])!|\p{L}+?(?=\p{Lu}|\b)|[\s\S]", None),
+    (r"(?<=\r\n|\n\n)\S+|(?<!ab|\p{Lu}{2}|[.,] )\p{Ll}{1,3}|(?<=中.)\w|(?<!\s{3})\s|[\s\S]", None),
     (r"[\p{L}&&[^a-cé]]+|[\w--\d]|[^\s&&\P{N}--[1-3]]+|\s+|[\s\S]", r"(?V1)[\p{L}&&[^a-cé]]+|[\w--\d]|[^\s&&\P{N}--[1-3]]+|\s+|[\s\S]"),
 ]
 
@@ -149,7 +150,7 @@ def test_gaps_and_errors_are_loud():
 
 
 @pytest.mark.parametrize("pat,why", [
-    (r"(?<=ab)c|.", "look-behind is supported for one char only"), (r"[\b]|.", "inside a class"), (r"(?<=a*)c|.", "one char only"), (r"(a)\1|.", "back-references"), (r"a*", "empty string"),
+    (r"(?<=a+b)c|.", "look-behind has to be"), (r"[\b]|.", "inside a class"), (r"(?<=a*)c|.", "fixed-length"), (r"(?<=a(?=b))c|.", "fixed-length"), (r"(a)\1|.", "back-references"), (r"a*", "empty string"),
     (r"(?:a*)+|.", "empty string"), (r"\p{Alphabetic}+|.", "General_Category value or a script"), (r"[\P{Han}x]|.", "negated script"),
     (r"\p{scx=Han}|.", "General_Category value or a script"), (r"[a-z~~[b]]|.", "~~"), (r"[a-z&&[b&&[c]]]|.", "inside the operand"), (r"[a&&b]|.", "right side"), (r"(?m)^a|.", "(?m)"),
     (r"(?i)é|.", "non-ASCII cased"), (r"[[:alpha:]]|.", "POSIX"), (r"(a|b", "unterminated group"), (r"a)|b", "unbalanced"),
@@ -234,7 +235,7 @@ def _gen_pattern(rng: random.Random):
         if rng.random() < 0.2:
             parts.append(rng.choice(["(?=", "(?!"]) + atom(depth + 1, ci) + ")")
         if rng.random() < 0.2:  # word boundaries, one-char look-behind: anywhere between the atoms
-            parts.insert(rng.randint(0, len(parts)), rng.choice([r"\b", r"\B", r"(?<=\s)", r"(?<!\S)", r"(?<![a-c])", r"(?<=a|\p{Lu})", r"(?<!\w)"]))
+            parts.insert(rng.randint(0, len(parts)), rng.choice([r"\b", r"\B", r"(?<=\s)", r"(?<!\S)", r"(?<![a-c])", r"(?<=a|\p{Lu})", r"(?<!\w)", r"(?<=ab|\s)", r"(?<!\S{2})", r"(?<=[a-c]\p{L}|1)", r"(?<!\n\n)"]))
         return "".join(parts)
 
     def alt(depth, ci, n):

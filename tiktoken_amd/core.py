@@ -48,8 +48,8 @@ class Encoding:
             o200k patterns -- in any of their spellings, with variations of the contraction list, the digit group length, the suffix set
             after punctuation and the white-space rules, e.g. Qwen2's or Llama-3's -- run on hand-written GPU scanners; any other
             pattern runs on the generic GPU regex engine (classes, \\p{..} General_Category values and scripts, groups, (?i: ), greedy / lazy /
-            possessive quantifiers, atomic groups, look-ahead, \\b, one-char look-behind).  ValueError with the reason for what neither takes:
-            longer look-behind, back-references, binary properties, patterns that can match the empty string.  There is no CPU regex fallback.
+            possessive quantifiers, atomic groups, look-ahead, \\b, look-behind of fixed length).  ValueError with the reason for what neither takes:
+            look-behind of variable length, back-references, binary properties, patterns that can match the empty string.  There is no CPU regex fallback.
         mergeable_ranks: token bytes -> rank; ranks are merge priorities.
         special_tokens: special token string -> id.
         explicit_n_vocab: if given, checked against the number of tokens and the largest id.

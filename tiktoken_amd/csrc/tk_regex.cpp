@@ -5,8 +5,8 @@
 // Supported: literals, `.`, classes [...] with ranges / escapes / negation / intersection [A&&[^B]] / difference [A--B], \d \s \w \D \S \W, \p{..} \P{..} for General_Category values and scripts (\p{Han}, \p{Script=Greek}),
 // the escapes \n \r \t \f \v \xHH \x{H..} \uHHHH \u{H..} \UHHHHHHHH, alternation, groups (capturing ones are plain groups: a split pattern
 // has no use for captures), (?: ) (?i: ) (?s: ) (?i) (?s) (?-i), atomic groups (?> ), look-ahead (?= ) (?! ), the quantifiers ? * + {m} {m,}
-// {m,n} in their greedy, lazy (?) and possessive (+) forms, ^ \A $ \z, \b \B, one-char look-behind (?<=X) (?<!X).  Refused, with the reason:
-// look-behind of more than one char, back-references,
+// {m,n} in their greedy, lazy (?) and possessive (+) forms, ^ \A $ \z, \b \B, look-behind of fixed length (?<=ab|c) (?<!\S).  Refused, with the reason:
+// look-behind of variable length, back-references,
 // (?m) (?x), the class set operation ~~ and set operations nested in operands, POSIX classes, binary properties (\\p{Alphabetic} ...), script extensions, case-insensitive matching of
 // non-ASCII cased letters, a pattern (or a repeated group) that can match the empty string.
 #include "tk_regex.h"
@@ -50,7 +50,7 @@ struct CharSet {
 };
 
 struct Node {
-    enum Kind { EMPTY, SET, CAT, ALT, REPEAT, ATOMIC, LOOK, START, END, WORDB, PREV } kind = EMPTY;
+    enum Kind { EMPTY, SET, CAT, ALT, REPEAT, ATOMIC, LOOK, START, END, WORDB, BEHIND } kind = EMPTY;
     int set = -1;
     std::vector<int> kids;
     uint32_t mn = 0, mx = 0;
@@ -371,25 +371,21 @@ struct Parser {
         return true;
     }
 
-    // the node matches exactly one char from a set that can be written as one CharSet: a set, or an alternation of such
-    bool one_char_set(int n, CharSet* u) const {
+    // the node as a fixed-length sequence of sets (set indices appended to *seq): sets, concatenations, x{m} of such; false otherwise
+    bool behind_sequence(int n, std::vector<int>* seq) const {
         const Node& N = nodes[n];
         if (N.kind == Node::SET) {
-            const CharSet& c = sets[N.set];
-            if (c.and_set >= 0) return false;
-            if (u->gcmask == 0 && u->flags == 0 && !u->comp && u->ranges.empty() && !u->neg) {
-                *u = c;
-                return true;
-            }
-            if (c.neg || c.comp || u->neg || u->comp) return false;  // (a union with a negated member: write it as one class)
-            u->gcmask |= c.gcmask;
-            u->flags |= c.flags;
-            u->ranges.insert(u->ranges.end(), c.ranges.begin(), c.ranges.end());
+            seq->push_back(N.set);
             return true;
         }
-        if (N.kind == Node::ALT) {
+        if (N.kind == Node::CAT) {
             for (int k : N.kids)
-                if (!one_char_set(k, u)) return false;
+                if (!behind_sequence(k, seq)) return false;
+            return true;
+        }
+        if (N.kind == Node::REPEAT && N.mn == N.mx && N.mn <= 16) {
+            for (uint32_t k = 0; k < N.mn; ++k)
+                if (!behind_sequence(N.kids[0], seq) || seq->size() > 16) return false;
             return true;
         }
         return false;
@@ -458,7 +454,7 @@ struct Parser {
                 return a;
             }
             const Node::Kind k = nodes[a].kind;
-            if (k == Node::START || k == Node::END || k == Node::LOOK || k == Node::EMPTY || k == Node::WORDB || k == Node::PREV) return fail("nothing to repeat"), -1;
+            if (k == Node::START || k == Node::END || k == Node::LOOK || k == Node::EMPTY || k == Node::WORDB || k == Node::BEHIND) return fail("nothing to repeat"), -1;
             Node r;
             r.kind = Node::REPEAT;
             r.kids = {a};
@@ -484,19 +480,24 @@ struct Parser {
                 else if (k == '>') wrap = Node::ATOMIC, ++i;
                 else if (k == '=') wrap = Node::LOOK, ++i;
                 else if (k == '!') wrap = Node::LOOK, neg = true, ++i;
-                else if (k == '<' && (peek(1) == '=' || peek(1) == '!')) {  // look-behind: one char (a class, a literal, an alternation of them)
+                else if (k == '<' && (peek(1) == '=' || peek(1) == '!')) {  // look-behind: fixed-length sequences of single chars
                     const bool negative = peek(1) == '!';
                     i += 2;
                     const int body = parse_alt(g, depth + 1);
                     if (body < 0) return -1;
                     if (peek() != ')' || !more()) return fail("unterminated group"), -1;
                     ++i;
-                    CharSet u;
-                    if (!one_char_set(body, &u)) return fail("look-behind is supported for one char only: (?<=\\s), (?<![a-z]), (?<!a|b)"), -1;
-                    sets.push_back(u);
+                    std::vector<int> seq;
+                    const Node& B = nodes[body];
+                    const std::vector<int> alts = B.kind == Node::ALT ? B.kids : std::vector<int>{body};
+                    for (int a : alts) {
+                        seq.clear();
+                        if (!behind_sequence(a, &seq) || seq.empty() || seq.size() > 16)
+                            return fail("look-behind has to be an alternation of fixed-length sequences (at most 16 chars) of single chars or classes"), -1;
+                    }
                     Node n;
-                    n.kind = Node::PREV;
-                    n.set = (int)sets.size() - 1;
+                    n.kind = Node::BEHIND;
+                    n.kids = {body};
                     n.neg = negative;
                     return add(n);
                 }
@@ -641,7 +642,6 @@ struct Emitter {
             case Node::SET: put(TK_RX_SET, (uint32_t)N.set); return true;
             case Node::START: put(TK_RX_START); return true;
             case Node::WORDB: put(TK_RX_WORDB, N.neg ? 1u : 0u); return true;
-            case Node::PREV: put(TK_RX_PREV, (uint32_t)N.set, N.neg ? 1u : 0u); return true;
             case Node::END: put(TK_RX_END); return true;
             case Node::CAT:
                 for (size_t k = 0; k < N.kids.size(); ++k)
@@ -672,6 +672,31 @@ struct Emitter {
             case Node::LOOK: {
                 const uint32_t b = put(TK_RX_LOOK_BEGIN, N.neg ? 1u : 0u);
                 if (!emit(N.kids[0], true)) return false;
+                put(TK_RX_LOOK_END);
+                code[b].b = here();
+                return true;
+            }
+            case Node::BEHIND: {  // a zero-width group like a look-ahead; each alternative: its chars, the nearest last, as PREV tests
+                const uint32_t b = put(TK_RX_LOOK_BEGIN, N.neg ? 1u : 0u);
+                const Node& B = P.nodes[N.kids[0]];
+                const std::vector<int> alts = B.kind == Node::ALT ? B.kids : std::vector<int>{N.kids[0]};
+                std::vector<uint32_t> jumps;
+                for (size_t k = 0; k < alts.size(); ++k) {
+                    const bool last = k + 1 == alts.size();
+                    uint32_t split = 0;
+                    if (!last) {
+                        split = put(TK_RX_SPLIT);
+                        code[split].a = here();
+                    }
+                    std::vector<int> seq;
+                    P.behind_sequence(alts[k], &seq);
+                    for (size_t j = 0; j < seq.size(); ++j) put(TK_RX_PREV, (uint32_t)seq[j], 0u, (uint32_t)(seq.size() - j));
+                    if (!last) {
+                        jumps.push_back(put(TK_RX_JMP));
+                        code[split].b = here();
+                    }
+                }
+                for (uint32_t j : jumps) code[j].a = here();
                 put(TK_RX_LOOK_END);
                 code[b].b = here();
                 return true;

@@ -3,8 +3,8 @@
 // (tk_regex_kernels.h).  This header holds what host and device share: the program layout, the property lookup and the matcher.
 //
 // Semantics are those of fancy-regex / Python `regex` for the supported syntax (tk_regex.cpp): leftmost, alternatives in order,
-// greedy / lazy / possessive quantifiers, atomic groups, look-ahead, case-insensitive literals, \b and one-char look-behind; no
-// back-references.  The end of the piece that starts at p depends only on the TEXT around p -- from p on, plus the one char before a
+// greedy / lazy / possessive quantifiers, atomic groups, look-ahead, case-insensitive literals, \b and look-behind of fixed length; no
+// back-references.  The end of the piece that starts at p depends only on the TEXT around p -- from p on, plus a few chars before a
 // position for \b and (?<=X) -- and on where its haystack begins and ends, never on where earlier pieces began: that is what lets the
 // kernels evaluate piece starts speculatively in parallel and prove them afterwards (tk_regex_kernels.h).
 //
@@ -34,7 +34,7 @@ enum {
     TK_RX_FAIL,
     TK_RX_POP,  // forget the newest alternative (possessive loops of groups: the way out of the previous repetition)
     TK_RX_WORDB,  // a: 0 = \b, 1 = \B -- word boundary between the char before the position and the char at it
-    TK_RX_PREV,   // a: set, b: 1 = negative -- one-char look-behind (?<=X) / (?<!X): the char before the position is (not) in the set
+    TK_RX_PREV,   // a: set, c: distance d >= 1 -- look-behind: the d-th char before the position exists (in this haystack) and is in the set
 };
 enum { TK_RX_GREEDY = 0, TK_RX_LAZY = 1, TK_RX_POSSESSIVE = 2 };
 #define TK_RX_INF 0xFFFFFFFFu
@@ -252,18 +252,25 @@ TK_HD uint32_t tk_rx_match(const TkRxProg& P, A& t, uint32_t start) {
                 break;
             case TK_RX_WORDB:
             case TK_RX_PREV: {
-                // the char before the position, if the haystack has one (it begins at a hard start; the match itself may have begun later)
-                const bool has_prev = pos > start || (pos > 0 && !t.hard(pos));
-                uint32_t prev = 0;
-                if (has_prev) {
-                    uint32_t q = pos - 1, len;
-                    for (int k = 0; k < 3 && q > 0 && (t.byte(q) & 0xC0u) == 0x80u && !(q <= start && t.hard(q)); ++k) --q;
-                    prev = tk_rx_decode(t, q, &len);
-                    if (q + len != pos) prev = 0xFFFDu;  // (malformed UTF-8: the byte before stands for itself)
+                // the d-th char before the position, if the haystack has one (it begins at a hard start; the match itself may have begun later)
+                const uint32_t dist = (I.op & 0xFFu) == TK_RX_PREV ? I.c : 1u;
+                uint32_t q = pos, prev = 0;
+                bool has_prev = true;
+                for (uint32_t d = 0; d < dist && has_prev; ++d) {
+                    has_prev = q > 0 && !(q <= start && t.hard(q));  // (a hard position at or before the match's start is where the haystack begins)
+                    if (!has_prev) break;
+                    uint32_t r = q - 1, len;
+                    for (int k = 0; k < 3 && r > 0 && (t.byte(r) & 0xC0u) == 0x80u && !(r <= start && t.hard(r)); ++k) --r;
+                    prev = tk_rx_decode(t, r, &len);
+                    if (r + len != q) {  // (malformed UTF-8: the byte before stands for itself)
+                        prev = 0xFFFDu;
+                        r = q - 1;
+                    }
+                    q = r;
                 }
                 bool ok;
                 if ((I.op & 0xFFu) == TK_RX_PREV) {
-                    ok = (has_prev && tk_rx_in_set(P, I.a, prev)) != (bool)I.b;
+                    ok = has_prev && tk_rx_in_set(P, I.a, prev);
                 } else {
                     uint32_t len;
                     const bool wb = has_prev && tk_rx_is_word(P, prev), wa = !at_end(pos) && tk_rx_is_word(P, tk_rx_decode(t, pos, &len));
