@@ -4,10 +4,10 @@
 //
 // Supported: literals, `.`, classes [...] with ranges / escapes / negation / intersection [A&&[^B]] / difference [A--B], \d \s \w \D \S \W, \p{..} \P{..} for General_Category values and scripts (\p{Han}, \p{Script=Greek}),
 // the escapes \n \r \t \f \v \xHH \x{H..} \uHHHH \u{H..} \UHHHHHHHH, alternation, groups (capturing ones are plain groups: a split pattern
-// has no use for captures), (?: ) (?i: ) (?s: ) (?i) (?s) (?-i), atomic groups (?> ), look-ahead (?= ) (?! ), the quantifiers ? * + {m} {m,}
+// has no use for captures), (?: ) (?i: ) (?s: ) (?m: ) (?i) (?s) (?m) (?-i), atomic groups (?> ), look-ahead (?= ) (?! ), the quantifiers ? * + {m} {m,}
 // {m,n} in their greedy, lazy (?) and possessive (+) forms, ^ \A $ \z, \b \B, look-behind of fixed length (?<=ab|c) (?<!\S).  Refused, with the reason:
 // look-behind of variable length, back-references,
-// (?m) (?x), the class set operation ~~ and set operations nested in operands, POSIX classes, binary properties (\\p{Alphabetic} ...), script extensions, case-insensitive matching of
+// (?x), the class set operation ~~ and set operations nested in operands, POSIX classes, binary properties (\\p{Alphabetic} ...), script extensions, case-insensitive matching of
 // non-ASCII cased letters, a pattern (or a repeated group) that can match the empty string.
 #include "tk_regex.h"
 
@@ -59,7 +59,7 @@ struct Node {
 };
 
 struct Flags {
-    bool ci = false, dotall = false;
+    bool ci = false, dotall = false, multiline = false;
 };
 
 struct Parser {
@@ -197,6 +197,11 @@ struct Parser {
             {"Enclosing_Mark", "Me"}, {"Control", "Cc"}, {"Format", "Cf"}, {"Unassigned", "Cn"}, {"Private_Use", "Co"}, {"Space_Separator", "Zs"}};
         for (const auto& a : alias)
             if (name == a.a) name = a.b;
+        if (name == "White_Space" || name == "WhiteSpace" || name == "space" || name == "Space" || name == "WSpace") {  // == \s
+            c.flags |= 0x20u;
+            *negated = neg != inner_neg;
+            return true;
+        }
         uint32_t m = 0;
         if (name == "LC") m = 7u;
         else
@@ -516,8 +521,9 @@ struct Parser {
                         if (fl == '-') on = false;
                         else if (fl == 'i') g.ci = on, any = true;
                         else if (fl == 's') g.dotall = on, any = true;
+                        else if (fl == 'm') g.multiline = on, any = true;
                         else if (fl == 'u') any = true;
-                        else if (fl == 'm' || fl == 'x' || fl == 'U' || fl == 'R') return fail(std::string("the flag (?") + (char)fl + ") is not supported"), -1;
+                        else if (fl == 'x' || fl == 'U' || fl == 'R') return fail(std::string("the flag (?") + (char)fl + ") is not supported"), -1;
                         else break;
                     }
                     if (!any) return fail("unknown group syntax"), -1;
@@ -553,7 +559,20 @@ struct Parser {
             ++i;
             Node n;
             n.kind = c == '^' ? Node::START : Node::END;
-            return add(n);
+            const int anchor = add(n);
+            if (!f.multiline) return anchor;
+            // (?m): ^ also behind a newline, $ also in front of one -- (?:\A|(?<=\n)), (?:\z|(?=\n))
+            CharSet nl;
+            nl.ranges.push_back({'\n', '\n'});
+            const int set_node = add_set(nl);
+            Node look;
+            look.kind = c == '^' ? Node::BEHIND : Node::LOOK;
+            look.kids = {set_node};
+            const int look_node = add(look);
+            Node alt;
+            alt.kind = Node::ALT;
+            alt.kids = {anchor, look_node};
+            return add(alt);
         }
         if (c == '*' || c == '+' || c == '?') return fail("nothing to repeat"), -1;
         if (c == '{' || c == '}' || c == ']') return fail(std::string("unescaped '") + (char)c + "'"), -1;
