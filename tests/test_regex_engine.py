@@ -420,3 +420,18 @@ def test_known_tokenizer_patterns_are_accepted():
             base += len(t.encode())
         assert h.RxSim(pat).split([t.encode() for t in sample]) == want, name  # (the generic engine takes the family patterns as well)
     assert ran_on["kimi-k2"] == 3 and ran_on["llama-3"] == 1 and ran_on["qwen2"] == 1 and ran_on["o200k / o200k_harmony"] == 2, ran_on
+
+
+@pytest.mark.parametrize("unit,name", [("x'll", "o200k_shaped"), ("Ab", "o200k_shaped"), ("x'll", "cl100k_shaped"), ("a'S b'Ll", "gpt2_shaped"),
+                                        ("x'll中'd", "o200k_shaped"), ("1a", "cl100k_shaped")])
+def test_chains_of_uncertain_boundaries_are_linear_for_the_generic_split(unit, name):
+    """The inputs on which the scanner families still work quadratically (a megabyte without a certain piece start: every deferred tile walks
+    from the start of the stretch; tests/test_gpu_parity.py::test_chains_of_uncertain_boundaries_do_not_take_seconds) are easy for the
+    speculative split: pieces are short, every segment's guess is accepted, the resolving lane hardly ever runs the matcher.  DESIGN section 7
+    plans to route such chunks through it."""
+    rx, C = h.RxSim(h.load_golden(name)["pat_str"]), h.c_oracle_for(name)
+    data = (unit * (1_000_000 // len(unit))).encode()
+    want = [0] + C.split(data)[:-1]
+    assert rx.split([data], speculate=1) == want
+    spec_runs, resolve_runs = rx.stats
+    assert spec_runs < 1.02 * len(want) and resolve_runs < len(want) // 50, (spec_runs, resolve_runs, len(want))
