@@ -50,7 +50,8 @@ static std::string good_alt(int depth, int n) {
 }
 static std::string good_atom(int depth) {
     static const char* const a[] = {"a", "b", " ", "\\n", "'", "s", "k", "é", "中", "[a-c]", "[^a\\s]", "\\s", "\\S", "\\d", "\\w", "\\p{L}", "\\p{Lu}", "\\P{N}", "[\\s\\S]",
-                                    "[^\\S\\n]", "[x1\\p{Ll}]", "[^\\r\\n\\p{L}\\p{N}]", ".", "\\x61", "[\\x{4e00}-\\x{9fff}]", "\\p{M}", "\\p{Nd}"};
+                                    "[^\\S\\n]", "[x1\\p{Ll}]", "[^\\r\\n\\p{L}\\p{N}]", ".", "\\x61", "[\\x{4e00}-\\x{9fff}]", "\\p{M}", "\\p{Nd}",
+                                    "\\p{Han}", "[\\p{L}&&[^a-c\\p{Han}]]", "[\\w--\\d]", "a\\b", "\\B.", "(?<=\\s)a", "(?<!ab|\\p{Lu})\\w", "(?m:^a|b$)"};
     if (depth > 2 || rnd() % 4) return a[rnd() % (sizeof a / sizeof a[0])];
     static const char* const open[] = {"(?:", "(?:", "(", "(?>", "(?s:", "(?i:"};
     const char* o = open[rnd() % 6];
@@ -100,12 +101,25 @@ int main(int argc, char** argv) {
             }
             for (uint32_t d : doc)
                 if (d < n) brk[d >> 5] |= 1u << (d & 31);
+            // special tokens at random places (every second text): start bit, interior bits, hard edges -- as tk_k_spec_resolve leaves them
+            uint32_t *ss = (uint32_t*)calloc(nw, 4), *si = (uint32_t*)calloc(nw, 4);
+            const bool with_specials = (k & 1) && n > 8;
+            if (with_specials)
+                for (uint32_t at = rnd() % 40; at + 1 < n; at += 1 + rnd() % 700) {
+                    uint32_t len = 1 + rnd() % 90;
+                    if (at + len > n) len = n - at;
+                    ss[at >> 5] |= 1u << (at & 31);
+                    brk[at >> 5] |= 1u << (at & 31);
+                    for (uint32_t j = at + 1; j < at + len; ++j) si[j >> 5] |= 1u << (j & 31);
+                    if (at + len < n) brk[(at + len) >> 5] |= 1u << ((at + len) & 31);
+                    at += len;
+                }
             for (uint32_t shift : {TK_RX_SEG_SHIFT_SMALL, TK_RX_SEG_SHIFT_LARGE}) {
                 const uint32_t nseg = (uint32_t)(((uint64_t)n + (1u << shift) - 1) >> shift);
                 uint32_t* xexit = (uint32_t*)malloc((nseg + 2) * 4);
                 memset(spec, 0, nw * 4);
                 memset(gst, 0, nw * 4);
-                TkRxText t{text, n, brk, nullptr, nullptr, 0xFFFFFFFFu, false};
+                TkRxText t{text, n, brk, with_specials ? ss : nullptr, with_specials ? si : nullptr, 0xFFFFFFFFu, false};
                 for (uint32_t s = 0; s < nseg; ++s) tk_rx_speculate_lane(P, t, s, shift, spec, xexit);
                 for (size_t d = 0; d + 1 < doc.size(); ++d) {
                     uint32_t err_pos = 0;
@@ -121,6 +135,8 @@ int main(int argc, char** argv) {
             free(brk);
             free(spec);
             free(gst);
+            free(ss);
+            free(si);
         }
     }
     printf("ok %llu %llu\n", (unsigned long long)compiled, (unsigned long long)splits);
