@@ -120,6 +120,8 @@ def test_gaps_and_deep_backtracking_are_refused_loudly():
     blob, off = h.pack([b"fine words only", b"hello, world"])
     with pytest.raises(ValueError, match="does not match at byte 20"):
         core.encode_batch_packed(blob, off)
+    with pytest.raises(ValueError, match="does not match at byte 20"):
+        core.pretokenize_packed(blob, off)
     assert core.encode_ordinary("fine words only") == make_core(r"\w+|\s+|[^\w\s]+").encode_ordinary("fine words only")
     core = make_core(r"(?:\w\w)*\w!|\w|!")
     assert core.encode_ordinary("abc!abc!") == make_core(r"\w\w\w!").encode_ordinary("abc!abc!")

@@ -409,6 +409,19 @@ static int scan_u32(tk_core* c, hipStream_t s, uint32_t* a, uint64_t n, uint64_t
     return TK_OK;
 }
 
+// the generic pat_str engine gave up on a piece (tk_regex_split.h): which way, and where
+static int rx_failure(const uint32_t* counters, uint64_t base) {
+    const std::string at = std::to_string(base + (uint64_t)(~counters[TK_CNT_RXPOS]));
+    if (counters[TK_CNT_ERR] & TK_RX_ERR_GAP)
+        return fail(TK_VALUE_ERROR, "pat_str does not match at byte " + at +
+                                        " of the batch: the reference would drop the text up to the next match; this library refuses patterns that leave gaps");
+    if (counters[TK_CNT_ERR] & TK_RX_ERR_STACK)
+        return fail(TK_VALUE_ERROR, "pat_str: a repeated group needs more backtracking state than the matcher keeps (piece at byte " + at +
+                                        " of the batch); make the group possessive, e.g. (?:...)++");
+    return fail(TK_VALUE_ERROR, "pat_str: backtrack limit exceeded at byte " + at +
+                                    " of the batch (nested quantifiers; the reference's fancy-regex gives up after 1 000 000 backtracks as well)");
+}
+
 static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t n, const uint64_t* d_doc_off, uint64_t n_docs,
                      uint64_t base, bool use_special, bool single_piece, uint32_t* d_out, uint64_t tok_base_global,
                      uint64_t* d_tok_off, uint64_t* n_tokens_out, bool pretok_only = false, bool no_lookup = false) {
@@ -543,6 +556,7 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
             }));
             HIPCHK(hipMemcpyAsync(&P, c->total.p, 8, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
+            if (c->h_counters[TK_CNT_ERR] & (TK_RX_ERR_GAP | TK_RX_ERR_STACK | TK_RX_ERR_LIMIT)) return rx_failure(c->h_counters, base);
             TRY(ensure(c->pstart, (P + 2) * 4));
             TRY(timed(c, s, "tk_k_emit", [&] {
                 hipLaunchKernelGGL(tk_k_emit, dim3((uint32_t)nblk), dim3(256), 0, s, starts, nwords, c->blockcnt.as<uint32_t>(),
@@ -672,15 +686,7 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         nB += hb[TK_CNT_BIN0 + b];
         if ((c->dbg & 64) && hb[TK_CNT_BIN0 + b]) fprintf(stderr, "bin %d (%u..%u bytes): %u pieces\n", b, tk_bin_lo(b), tk_bin_hi(b), hb[TK_CNT_BIN0 + b]);
     }
-    if (hb[TK_CNT_ERR] & TK_RX_ERR_GAP)
-        return fail(TK_VALUE_ERROR, "pat_str does not match at byte " + std::to_string(base + (uint64_t)(~hb[TK_CNT_RXPOS])) +
-                                        " of the batch: the reference would drop the text up to the next match; this library refuses patterns that leave gaps");
-    if (hb[TK_CNT_ERR] & TK_RX_ERR_STACK)
-        return fail(TK_VALUE_ERROR, "pat_str: a repeated group needs more backtracking state than the matcher keeps (piece at byte " +
-                                        std::to_string(base + (uint64_t)(~hb[TK_CNT_RXPOS])) + " of the batch); make the group possessive, e.g. (?:...)++");
-    if (hb[TK_CNT_ERR] & TK_RX_ERR_LIMIT)
-        return fail(TK_VALUE_ERROR, "pat_str: backtrack limit exceeded at byte " + std::to_string(base + (uint64_t)(~hb[TK_CNT_RXPOS])) +
-                                        " of the batch (nested quantifiers; the reference's fancy-regex gives up after 1 000 000 backtracks as well)");
+    if (hb[TK_CNT_ERR] & (TK_RX_ERR_GAP | TK_RX_ERR_STACK | TK_RX_ERR_LIMIT)) return rx_failure(hb, base);
     if (hb[TK_CNT_ERR]) return fail(TK_RUNTIME_ERROR, "internal error in the front kernel (scanner list overflow, code " + std::to_string(hb[TK_CNT_ERR]) + ")");
     const uint64_t T_total = tp[0];
     c->st_bytes += n;
