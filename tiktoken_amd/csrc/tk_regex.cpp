@@ -765,11 +765,9 @@ struct Emitter {
         if (poss) put(TK_RX_ATOM_BEGIN);
         for (uint32_t k = 0; k < N.mn; ++k)
             if (!emit(body, false)) return false;
-        // a split that prefers `go` (greedy) or `skip` (lazy)
-        auto split = [&](uint32_t* go_field_owner) { *go_field_owner = put(TK_RX_SPLIT); };
+        // every split prefers the body (greedy) or the way out (lazy)
         if (N.mx == TK_RX_INF) {  // L: split(body, out); body; jmp L
-            uint32_t sp;
-            split(&sp);
+            const uint32_t sp = put(TK_RX_SPLIT);
             const uint32_t body_at = here();
             if (!emit(body, false)) return false;
             put(TK_RX_JMP, sp);
@@ -779,8 +777,7 @@ struct Emitter {
         } else {  // (body (body (body)?)?)?: every split leaves for the common end
             std::vector<uint32_t> splits;
             for (uint32_t k = N.mn; k < N.mx; ++k) {
-                uint32_t sp;
-                split(&sp);
+                const uint32_t sp = put(TK_RX_SPLIT);
                 splits.push_back(sp);
                 code[sp].a = here();  // (patched below for lazy)
                 if (!emit(body, false)) return false;
