@@ -44,6 +44,11 @@ PATTERNS = [
     (r"(?<=\s)\p{L}+|(?<![a-zé])\d{1,2}|(?<!\S)'s|(?<=a|b|[x-z])!|\p{L}+?(?=\p{Lu}|\b)|[\s\S]", None),
     (r"(?<=\r\n|\n\n)\S+|(?<!ab|\p{Lu}{2}|[.,] )\p{Ll}{1,3}|(?<=中.)\w|(?<!\s{3})\s|[\s\S]", None),
     (r"[\p{L}&&[^a-cé]]+|[\w--\d]|[^\s&&\P{N}--[1-3]]+|\s+|[\s\S]", r"(?V1)[\p{L}&&[^a-cé]]+|[\w--\d]|[^\s&&\P{N}--[1-3]]+|\s+|[\s\S]"),
+    # (?x): the pattern may be laid out with white space and comments
+    ("""(?x) \\p{L}+ (?: 's | 't )?   # words, with a contraction
+             | \\p{N}{1,3}             # digits in groups
+             | [ ]? [^\\s\\p{L}\\p{N}]+  # punctuation: the blank in the class is a blank
+             | \\s+ (?! \\S ) | \\s+""", None),
     # (?m): ^ also behind a newline, $ also in front of one
     (r"(?m)^\p{L}+$|^[ \t]+|\p{White_Space}+$|(?-m:^.)|[^\n]+?(?=\s|$)|\s", r"(?m)^\p{L}+$|^[ \t]+|\p{White_Space}+$|(?-m:\A.)|[^\n]+?(?=\s|$)|\s"),
 ]
@@ -154,7 +159,7 @@ def test_gaps_and_errors_are_loud():
 @pytest.mark.parametrize("pat,why", [
     (r"(?<=a+b)c|.", "look-behind has to be"), (r"[\b]|.", "inside a class"), (r"(?<=a*)c|.", "fixed-length"), (r"(?<=a(?=b))c|.", "fixed-length"), (r"(a)\1|.", "back-references"), (r"a*", "empty string"),
     (r"(?:a*)+|.", "empty string"), (r"\p{Alphabetic}+|.", "General_Category value or a script"), (r"[\P{Han}x]|.", "negated script"),
-    (r"\p{scx=Han}|.", "General_Category value or a script"), (r"[a-z~~[b]]|.", "~~"), (r"[a-z&&[b&&[c]]]|.", "inside the operand"), (r"[a&&b]|.", "right side"), (r"(?x) a | .", "(?x)"),
+    (r"\p{scx=Han}|.", "General_Category value or a script"), (r"[a-z~~[b]]|.", "~~"), (r"[a-z&&[b&&[c]]]|.", "inside the operand"), (r"[a&&b]|.", "right side"), (r"(?U)a|.", "(?U)"),
     (r"(?i)é|.", "non-ASCII cased"), (r"[[:alpha:]]|.", "POSIX"), (r"(a|b", "unterminated group"), (r"a)|b", "unbalanced"),
     (r"x{3,2}|.", "out of order"), (r"a**|.", "quantifier behind"), (r"[z-a]|.", "out of order"), (r"(?=a)|.", "empty string"),
 ])

@@ -4,10 +4,10 @@
 //
 // Supported: literals, `.`, classes [...] with ranges / escapes / negation / intersection [A&&[^B]] / difference [A--B], \d \s \w \D \S \W, \p{..} \P{..} for General_Category values and scripts (\p{Han}, \p{Script=Greek}),
 // the escapes \n \r \t \f \v \xHH \x{H..} \uHHHH \u{H..} \UHHHHHHHH, alternation, groups (capturing ones are plain groups: a split pattern
-// has no use for captures), (?: ) (?i: ) (?s: ) (?m: ) (?i) (?s) (?m) (?-i), atomic groups (?> ), look-ahead (?= ) (?! ), the quantifiers ? * + {m} {m,}
+// has no use for captures), (?: ) (?i: ) (?s: ) (?m: ) (?x: ) (?i) (?s) (?m) (?x) (?-i), atomic groups (?> ), look-ahead (?= ) (?! ), the quantifiers ? * + {m} {m,}
 // {m,n} in their greedy, lazy (?) and possessive (+) forms, ^ \A $ \z, \b \B, look-behind of fixed length (?<=ab|c) (?<!\S).  Refused, with the reason:
 // look-behind of variable length, back-references,
-// (?x), the class set operation ~~ and set operations nested in operands, POSIX classes, binary properties (\\p{Alphabetic} ...), script extensions, case-insensitive matching of
+// the class set operation ~~ and set operations nested in operands, POSIX classes, binary properties (\\p{Alphabetic} ...), script extensions, case-insensitive matching of
 // non-ASCII cased letters, a pattern (or a repeated group) that can match the empty string.
 #include "tk_regex.h"
 
@@ -59,7 +59,7 @@ struct Node {
 };
 
 struct Flags {
-    bool ci = false, dotall = false, multiline = false;
+    bool ci = false, dotall = false, multiline = false, verbose = false;
 };
 
 struct Parser {
@@ -419,10 +419,13 @@ struct Parser {
     int parse_cat(Flags& f, int depth) {  // (inline flags (?i) change f for the rest of the enclosing group)
         Node cat;
         cat.kind = Node::CAT;
-        while (more() && peek() != '|' && peek() != ')') {
+        for (;;) {
+            skip_verbose(f);
+            if (!more() || peek() == '|' || peek() == ')') break;
             int a = parse_atom(f, depth);
             if (a == -2) continue;  // inline flags
             if (a < 0) return -1;
+            skip_verbose(f);
             a = parse_quant(a);
             if (a < 0) return -1;
             cat.kids.push_back(a);
@@ -430,6 +433,19 @@ struct Parser {
         if (cat.kids.size() == 1) return cat.kids[0];
         if (cat.kids.empty()) cat.kind = Node::EMPTY;
         return add(cat);
+    }
+    // (?x): white space and #-comments between the tokens of the pattern mean nothing (inside a class they stay literal)
+    void skip_verbose(const Flags& f) {
+        while (f.verbose && more()) {
+            const uint32_t c = peek();
+            if (c == ' ' || c == '\t' || c == '\n' || c == '\r' || c == '\f' || c == '\v') {
+                ++i;
+            } else if (c == '#') {
+                while (more() && peek() != '\n') ++i;
+            } else {
+                break;
+            }
+        }
     }
     int parse_quant(int a) {
         for (;;) {
@@ -522,8 +538,9 @@ struct Parser {
                         else if (fl == 'i') g.ci = on, any = true;
                         else if (fl == 's') g.dotall = on, any = true;
                         else if (fl == 'm') g.multiline = on, any = true;
+                        else if (fl == 'x') g.verbose = on, any = true;
                         else if (fl == 'u') any = true;
-                        else if (fl == 'x' || fl == 'U' || fl == 'R') return fail(std::string("the flag (?") + (char)fl + ") is not supported"), -1;
+                        else if (fl == 'U' || fl == 'R') return fail(std::string("the flag (?") + (char)fl + ") is not supported"), -1;
                         else break;
                     }
                     if (!any) return fail("unknown group syntax"), -1;
