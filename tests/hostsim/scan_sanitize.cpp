@@ -67,6 +67,52 @@ int main(int argc, char** argv) {
         }
         tks_destroy(sim);
     }
+    // With a real vocabulary (TK_SAN_VOCAB: a .tiktoken text file): the whole-piece probes of the three tables and the per-lane merge on
+    // random pieces -- vocabulary tokens, their prefixes, concatenations, random bytes -- placed at the end of an n + 64 byte buffer.
+    if (const char* vp = getenv("TK_SAN_VOCAB")) {
+        FILE* f = fopen(vp, "rb");
+        if (!f) {
+            fprintf(stderr, "cannot open %s\n", vp);
+            return 2;
+        }
+        std::vector<uint8_t> raw;
+        uint8_t buf[65536];
+        for (size_t k; (k = fread(buf, 1, sizeof buf, f)) > 0;) raw.insert(raw.end(), buf, buf + k);
+        fclose(f);
+        std::vector<uint8_t> vb;
+        std::vector<uint64_t> vo;
+        std::vector<uint32_t> vi;
+        const std::string e = tk_parse_tiktoken(raw.data(), raw.size(), &vb, &vo, &vi);
+        if (!e.empty()) {
+            fprintf(stderr, "vocab: %s\n", e.c_str());
+            return 2;
+        }
+        char err[256];
+        uint64_t soff = 0;
+        void* sim = tks_create(vb.data(), vo.data(), vi.data(), vi.size(), vb.data(), &soff, vi.data(), 0, argv[argc - 1], err, sizeof err);
+        if (!sim) {
+            fprintf(stderr, "tks_create: %s\n", err);
+            return 2;
+        }
+        std::vector<uint32_t> out(4096);
+        for (int r = 0; r < rounds * 50; ++r) {
+            std::vector<uint8_t> piece;
+            const int parts = 1 + rnd() % 4;
+            for (int k = 0; k < parts; ++k) {
+                const uint32_t t = rnd() % vi.size();
+                uint64_t a = vo[t], b = vo[t + 1];
+                if (rnd() % 4 == 0 && b - a > 1) b = a + 1 + rnd() % (b - a - 1);  // a prefix
+                piece.insert(piece.end(), vb.begin() + a, vb.begin() + b);
+                if (rnd() % 8 == 0) piece.push_back((uint8_t)rnd());
+            }
+            if (piece.size() > 1000) piece.resize(1000);
+            piece.shrink_to_fit();
+            tks_lookup(sim, piece.data(), (uint32_t)piece.size());
+            tks_encode_piece(sim, piece.data(), (uint32_t)piece.size(), out.data());
+            runs += 2;
+        }
+        tks_destroy(sim);
+    }
     printf("ok %llu\n", (unsigned long long)runs);
     return 0;
 }

@@ -272,8 +272,12 @@ def test_scanners_under_the_sanitizers(tmp_path):
         pytest.skip("this g++ has no sanitizer runtime")
     assert cc.returncode == 0, cc.stderr[-2000:]
     qwen2 = h.PAT_STR[1].replace(r"\p{N}{1,3}", r"\p{N}")
-    run = subprocess.run([exe, h.PAT_STR[0], h.PAT_STR[1], h.PAT_STR[2], qwen2], capture_output=True, text=True, timeout=900,
-                         env={**os.environ, "TK_SAN_ROUNDS": "300"})
+    import gzip
+
+    vocab = tmp_path / "o200k_shaped.tiktoken"  # (with it: the whole-piece probes and the per-lane merge on random pieces, 15 000 of them)
+    vocab.write_bytes(gzip.open(os.path.join(h.ROOT, "tiktoken_amd", "vocab", "o200k_shaped.tiktoken.gz")).read())
+    run = subprocess.run([exe, h.PAT_STR[0], h.PAT_STR[1], qwen2, h.PAT_STR[2]], capture_output=True, text=True, timeout=900,
+                         env={**os.environ, "TK_SAN_ROUNDS": "300", "TK_SAN_VOCAB": str(vocab)})
     assert run.returncode == 0 and run.stdout.startswith("ok "), (run.stdout[-500:], run.stderr[-3000:])
 
 
