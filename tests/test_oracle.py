@@ -1,7 +1,6 @@
 """The CPU oracle pinned against (a) the golden fixtures produced by the reference's own Python code
 (tools/gen_golden.py: tiktoken/_educational.py bpe_encode + regex.findall), (b) Python `regex` directly,
 (c) the vocabulary-free vectors of the reference's Rust unit tests."""
-import itertools
 import random
 
 import numpy as np

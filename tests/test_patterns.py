@@ -7,7 +7,6 @@ bit-parallel scanners and the tile rule on generated texts for every variation; 
 GPU part (-m gpu): the same through tk_pretokenize_batch and a whole encode through the Python oracle's regex path."""
 import random
 
-import numpy as np
 import pytest
 import regex
 

@@ -11,7 +11,6 @@ Differences that matter for speed, none for results:
 from __future__ import annotations
 
 import functools
-from concurrent.futures import ThreadPoolExecutor
 from typing import TYPE_CHECKING, AbstractSet, Collection, Literal, NoReturn, Sequence
 
 import numpy as np

@@ -3,7 +3,6 @@
 import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
-import numpy as np
 import helpers as h
 import tiktoken_amd
 from bench import KERNELS

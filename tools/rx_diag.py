@@ -6,7 +6,6 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 T0 = time.perf_counter()
 def say(*a):
     print("[%6.2f]" % (time.perf_counter() - T0), *a, flush=True)
-import numpy as np
 import helpers as h
 from tiktoken_amd import CoreBPE
 say("imports done")
