@@ -187,3 +187,25 @@ def test_exploding_backtracking_is_stopped():
     assert core.encode_ordinary("aaab aab") == make_core(r"a+b|[\s\S]").encode_ordinary("aaab aab")
     with pytest.raises(ValueError, match="backtrack limit"):
         core.encode_ordinary("a" * 26)
+
+
+def test_golden_vectors_of_generic_patterns():
+    """tests/golden/generic_patterns.json.gz: ten pat_str outside the scanner families, encoded by the reference's own Python code
+    (tiktoken/_educational.py SimpleBytePairEncoding: regex.findall + bpe_encode) with the vocabulary its own bpe_train produced
+    (tools/gen_golden_generic.py).  The GPU path has to give the same token ids."""
+    from tiktoken_amd import CoreBPE
+    from test_regex_engine import _generic_golden
+
+    ranks = h.golden_vocab("edu600")
+    n = 0
+    for p in _generic_golden():
+        core = CoreBPE(ranks, {}, p["pat_str"])
+        blob, off = h.pack([c["text"] for c in p["cases"]])
+        toks, toff = core.encode_batch_packed(blob, off)
+        want = [t for c in p["cases"] for t in c["tokens"]]
+        assert toff.tolist() == np.cumsum([0] + [len(c["tokens"]) for c in p["cases"]]).tolist(), p["pat_str"]
+        assert toks.tolist() == want, p["pat_str"]
+        for c in p["cases"][:12]:  # (and one by one: the single-document entry)
+            assert core.encode_ordinary(c["text"].decode()) == c["tokens"], (p["pat_str"], c["text"])
+        n += len(want)
+    assert n > 100_000

@@ -440,3 +440,44 @@ def test_chains_of_uncertain_boundaries_are_linear_for_the_generic_split(unit, n
     assert rx.split([data], speculate=1) == want
     spec_runs, resolve_runs = rx.stats
     assert spec_runs < 1.02 * len(want) and resolve_runs < len(want) // 50, (spec_runs, resolve_runs, len(want))
+
+
+def _generic_golden():
+    import base64
+    import gzip
+    import json
+    import os
+
+    with gzip.open(os.path.join(h.ROOT, "tests", "golden", "generic_patterns.json.gz")) as f:
+        g = json.loads(f.read())
+    for p in g["patterns"]:
+        for c in p["cases"]:
+            c["text"] = base64.b64decode(c["text"])
+    return g["patterns"]
+
+
+def test_generic_patterns_against_the_references_own_python_code():
+    """tests/golden/generic_patterns.json.gz (tools/gen_golden_generic.py): ten pat_str outside the scanner families, encoded by the
+    reference's tiktoken/_educational.py (SimpleBytePairEncoding: regex.findall + bpe_encode) with the vocabulary its own bpe_train
+    produced.  Here the CPU side of the product path: the compiler, the split lanes, then the device headers' probe + per-lane merge per piece."""
+    ranks = h.golden_vocab("edu600")
+    n = 0
+    for p in _generic_golden():
+        rx, sim = h.RxSim(p["pat_str"]), h.HostSim(p["pat_str"], ranks, {})
+        docs = [c["text"] for c in p["cases"]]
+        starts = rx.split(docs)
+        blob, off = h.pack(docs)
+        bb, bounds = blob.tobytes(), starts + [len(blob)]
+        pieces = [bb[a:b] for a, b in zip(bounds[:-1], bounds[1:])]
+        cache, k = {}, 0
+        for c, a, b in zip(p["cases"], off[:-1].tolist(), off[1:].tolist()):
+            got = []
+            while k < len(starts) and starts[k] < b:
+                piece = pieces[k]
+                if piece not in cache:
+                    cache[piece] = sim.encode_piece(piece)
+                got += cache[piece]
+                k += 1
+            assert got == c["tokens"], (p["pat_str"], c["text"][:80])
+            n += len(got)
+    assert n > 100_000
