@@ -481,3 +481,31 @@ def test_generic_patterns_against_the_references_own_python_code():
             assert got == c["tokens"], (p["pat_str"], c["text"][:80])
             n += len(got)
     assert n > 100_000
+
+
+@pytest.mark.parametrize("idx", [0, 2, 3, 4, 6, 7, 8, 16, 19, 21])
+def test_split_equals_oniguruma_where_the_dialects_agree(idx):
+    """A second, independent engine: Oniguruma through HF `tokenizers` (Split(Regex(pat), "isolated")), for the patterns whose syntax means
+    the same there (no \\w \\s \\d on exotic chars, no `$`, no (?i) on non-ASCII, no (?m): Oniguruma defines those differently) -- among
+    them Kimi-K2's class intersections and the fixed-length look-behinds.  It also settles the one case where Python `regex` is the odd
+    one out: a scoped (?i: ) does not reach a later negated class."""
+    tokenizers = pytest.importorskip("tokenizers")
+    pat = PATTERNS[idx][0]
+    split = tokenizers.pre_tokenizers.Split(tokenizers.Regex(pat), behavior="isolated")
+    rx = h.RxSim(pat)
+    rng = random.Random(7000 + idx)
+    texts = [random_text(rng, rng.choice([1, 5, 30, 200])) for _ in range(120)] + [h.fuzz_doc(rng)[:2000] for _ in range(8)]
+    compared = 0
+    for t in texts:
+        if not t:
+            continue
+        try:
+            got = rx.split([t.encode()])
+        except RuntimeError:
+            continue  # (a text the pattern does not cover)
+        assert got == [len(t[:a].encode()) for _, (a, _b) in split.pre_tokenize_str(t)], (pat, t)
+        compared += 1
+    assert compared > (15 if idx == 9 else 80)
+    quirk = r"(?i:k)|[^a\s]"
+    onig = tokenizers.pre_tokenizers.Split(tokenizers.Regex(quirk), behavior="isolated")
+    assert [a for _, (a, _b) in onig.pre_tokenize_str("AkK")] == h.RxSim(quirk).split([b"AkK"]) == [0, 1, 2]
