@@ -1,6 +1,7 @@
 """The CPU oracle pinned against (a) the golden fixtures produced by the reference's own Python code
 (tools/gen_golden.py: tiktoken/_educational.py bpe_encode + regex.findall), (b) Python `regex` directly,
-(c) the vocabulary-free vectors of the reference's Rust unit tests."""
+(c) the vocabulary-free vectors of the reference's Rust unit tests, (d) a third-party implementation: HF `tokenizers` built from the same
+vocabulary files."""
 import random
 
 import numpy as np
@@ -122,3 +123,49 @@ def test_special_token_slices_are_independent_haystacks():
     a = C.encode(b"x  <|endoftext|>", {"<|endoftext|>"}).tolist()
     assert a == C.encode_ordinary(b"x  ").tolist() + [100257]
     assert C.encode(b"x  <|endoftext|>", set()).tolist() == C.encode_ordinary(b"x  <|endoftext|>").tolist()
+
+
+@pytest.mark.parametrize("name,mix", [("gpt2_shaped", 2), ("cl100k_shaped", 0), ("o200k_shaped", 1)])
+def test_oracle_equals_hf_tokenizers(name, mix, tmp_path, monkeypatch):
+    """A third-party implementation as a witness: HF `tokenizers` (its own Rust BPE, Oniguruma for the split), built from the same
+    `.tiktoken` vocabulary by transformers' TikTokenConverter (which reconstructs the merge list from the ranks), must give the ids the C
+    oracle gives -- on corpus documents and on the fuzzer's awkward ones.  (SURVEY 8(d) lists HF tokenizers as context for the baseline;
+    here it pins the oracle, for o200k too, where the reference's own tests hold no known answers.)  The pattern is handed to Oniguruma in
+    a spelling that means the same there: no possessive marker behind a counted repeat ({1,3}+ repeats the repeat in Ruby syntax), \\z for
+    the end of the text ($ is end-of-line there)."""
+    import base64
+    import gzip
+    import os
+    import random
+    import sys
+    import types
+
+    pytest.importorskip("tokenizers")
+    convert = pytest.importorskip("transformers.convert_slow_tokenizer")
+    from test_patterns import CL100K_PLAIN
+
+    def load_tiktoken_bpe(path, expected_hash=None):  # the .tiktoken text format (reference tiktoken/load.py:159-171); the converter asks for it
+        return {base64.b64decode(t): int(r) for t, r in (line.split() for line in open(path, "rb").read().splitlines() if line)}
+
+    shim, shim_load = types.ModuleType("tiktoken"), types.ModuleType("tiktoken.load")
+    shim_load.load_tiktoken_bpe = load_tiktoken_bpe
+    shim.load = shim_load
+    monkeypatch.setitem(sys.modules, "tiktoken", shim)
+    monkeypatch.setitem(sys.modules, "tiktoken.load", shim_load)
+    vocab = tmp_path / (name + ".tiktoken")
+    vocab.write_bytes(gzip.open(os.path.join(h.ROOT, "tiktoken_amd", "vocab", name + ".tiktoken.gz")).read())
+    pat = CL100K_PLAIN.replace("$", r"\z") if name == "cl100k_shaped" else h.load_golden(name)["pat_str"]
+    hf = convert.TikTokenConverter(vocab_file=str(vocab), pattern=pat, add_prefix_space=False).converted()
+    C = h.c_oracle_for(name)
+    rng = random.Random(1)
+    texts = ["hello world", "The quick brown fox's 12345 jumps\n\n  over\tthe lazy dog. 中文 😀", "DON'T stop", "x \n ", "a  \n\n  b  "]
+    texts += [h.fuzz_doc(rng)[:3000] for _ in range(40)]
+    blob, off = h.gen_corpus(0x5EED0300 + mix, mix, 1 << 20)
+    bb = blob.tobytes()
+    texts += [bb[int(off[d]):int(off[d + 1])].decode() for d in range(min(200, len(off) - 1))]
+    n = 0
+    for text in texts:
+        want = C.encode_ordinary(text.encode()).tolist()
+        assert hf.encode(text, add_special_tokens=False).ids == want, text[:80]
+        n += len(want)
+    assert n > 150_000
