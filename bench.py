@@ -53,6 +53,50 @@ def gen_corpus(seed: int, mix: int, nbytes: int, threads: int):
     return out, off[: nd.value + 1].copy()
 
 
+def hf_tokenizers_rate(encoding, spec, blob, doc_off, nbytes, ctoks, coff, sample_mib=32):
+    """Context for `cpu_baseline`: the reference's Rust core cannot be built here, so beside the C restatement stands a
+    Rust tokenizer that can run -- HF `tokenizers`, built from the same vocabulary by transformers' TikTokenConverter (the merge list
+    reconstructed from the ranks), `encode_batch` over all host threads on the first `sample_mib` MiB.  Its ids must be the oracle's.
+    Never the baseline itself; None with the reason when the packages are missing."""
+    try:
+        import base64
+        import tempfile
+        import types
+
+        def load_tiktoken_bpe(path, expected_hash=None):  # (the converter reads the vocabulary through `tiktoken.load`)
+            return {base64.b64decode(t): int(r) for t, r in (line.split() for line in open(path, "rb").read().splitlines() if line)}
+
+        if "tiktoken" not in sys.modules:
+            shim, shim_load = types.ModuleType("tiktoken"), types.ModuleType("tiktoken.load")
+            shim_load.load_tiktoken_bpe = load_tiktoken_bpe
+            shim.load = shim_load
+            sys.modules["tiktoken"], sys.modules["tiktoken.load"] = shim, shim_load
+        import tokenizers
+        from transformers.convert_slow_tokenizer import TikTokenConverter
+
+        pat = spec["pat_str"]
+        if "{1,3}+" in pat:  # Oniguruma reads {1,3}+ as a repeated repeat and $ as end of line: the same pattern in its dialect
+            pat = (pat.replace("?+", "?").replace("++", "+").replace("*+", "*").replace("{1,3}+", "{1,3}").replace("$", "\\z"))
+        with tempfile.NamedTemporaryFile("wb", suffix=".tiktoken", delete=False) as f:
+            for tok, rank in sorted(spec["mergeable_ranks"].items(), key=lambda kv: kv[1]):
+                f.write(base64.b64encode(tok) + b" " + str(rank).encode() + b"\n")
+            path = f.name
+        hf = TikTokenConverter(vocab_file=path, pattern=pat, add_prefix_space=False).converted()
+        os.unlink(path)
+        nd = max(int(np.searchsorted(doc_off, min(nbytes, sample_mib << 20), side="right")) - 1, 1)
+        sb = int(doc_off[nd])
+        raw = blob[:sb].tobytes()
+        texts = [raw[int(doc_off[d]):int(doc_off[d + 1])].decode() for d in range(nd)]
+        t0 = time.perf_counter()
+        enc = hf.encode_batch(texts, add_special_tokens=False)
+        dt = time.perf_counter() - t0
+        same = all(e.ids == ctoks[int(coff[d]):int(coff[d + 1])].tolist() for d, e in list(enumerate(enc))[:: max(1, nd // 2000)])
+        return {"value": round(sb / dt / 1e9, 4), "unit": "GB/s", "what": f"HF tokenizers {tokenizers.__version__} (Rust BPE + Oniguruma) encode_batch, "
+                f"first {nd} documents ({sb} bytes), all host threads, one run", "same_ids_as_oracle_on_a_sample_of_documents": bool(same)}
+    except Exception as e:  # (context only: never fails the bench)
+        return {"value": None, "why": f"{type(e).__name__}: {e}"[:200]}
+
+
 class DevArray:
     """Zero-copy view of library-owned device memory for torch (via __cuda_array_interface__)."""
 
@@ -71,6 +115,7 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-host-path", action="store_true", help="skip the T2 / T3 host-boundary timings")
     ap.add_argument("--t3-sample-mib", type=int, default=64)
+    ap.add_argument("--no-hf", action="store_true", help="skip the HF tokenizers context figure of the CPU baseline")
     ap.add_argument("--generic-engine", action="store_true",
                     help="NOT the headline: run the encoding's pat_str on the generic regex engine instead of the hand-written scanners")
     args = ap.parse_args()
@@ -236,6 +281,9 @@ def main():
                "single_thread_value": round(sb1 / t1 / 1e9, 5),
                "sample": f"first {nd_s} documents ({sb} bytes) of the same corpus, C restatement of CoreBPE (oracle/tk_oracle.c), {ncpu} threads over "
                          f"documents, per-document encode phase only (timed in C), best of 3; single thread: first {sb1} bytes"}
+
+        if not args.no_hf:
+            cpu["rust_cpu_tokenizer_for_context"] = hf_tokenizers_rate(args.encoding, spec, blob, doc_off, nbytes, ctoks, coff)
 
     # ---- host-boundary rates (rank 0, N = 1; never `value`): T2 = tk_encode_batch, host buffers in, host token ids out (pinned staging,
     # PCIe both ways inside the call); T3 = Encoding.encode_ordinary_batch on a bounded sample, Python list[str] -> list[list[int]]
