@@ -140,7 +140,7 @@ def test_oracle_equals_hf_tokenizers(name, mix, tmp_path, monkeypatch):
     import sys
     import types
 
-    pytest.importorskip("tokenizers")
+    tokenizers = pytest.importorskip("tokenizers")
     convert = pytest.importorskip("transformers.convert_slow_tokenizer")
     from test_patterns import CL100K_PLAIN
 
@@ -169,3 +169,11 @@ def test_oracle_equals_hf_tokenizers(name, mix, tmp_path, monkeypatch):
         assert hf.encode(text, add_special_tokens=False).ids == want, text[:80]
         n += len(want)
     assert n > 150_000
+    # special tokens: registered with HF as added tokens (its own ids for them: mapped back), against encode(..., allowed_special="all")
+    specials = h.load_golden(name)["special_tokens"]
+    hf.add_special_tokens([tokenizers.AddedToken(s, normalized=False, special=True) for s in specials])
+    back = {hf.token_to_id(s): i for s, i in specials.items()}
+    sp = list(specials)
+    for _ in range(300):
+        text = "".join(rng.choice(h.ADV + sp + sp + ["<|endoftext", "|>", "<|"]) for _ in range(rng.randint(1, 30)))
+        assert [back.get(i, i) for i in hf.encode(text, add_special_tokens=False).ids] == C.encode(text.encode(), "all").tolist(), text
