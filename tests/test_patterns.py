@@ -294,3 +294,22 @@ def test_gpu_variation_with_special_tokens(pat):
     assert starts[1:].tolist() == want_ends
     toks, _ = core.encode_batch_packed(blob, off, allowed)
     assert toks.tolist() == want_tokens
+
+
+def test_pattern_parsers_under_the_sanitizers(tmp_path):
+    """tests/hostsim/pat_sanitize.cpp: tk_compile_pattern -- the family parser, then the generic compiler -- on random, mostly ill-formed
+    strings and on mutations of the stock patterns, built with AddressSanitizer and UBSan: whatever a caller hands to tk_create is refused
+    or compiled, never a crash.  (20 000 strings ran clean; 8 000 here.)"""
+    import os
+    import subprocess
+
+    exe = str(tmp_path / "pat_sanitize")
+    d, csrc = os.path.join(h.ROOT, "tests", "hostsim"), os.path.join(h.ROOT, "tiktoken_amd", "csrc")
+    cc = subprocess.run(["g++", "-O1", "-g", "-std=c++17", "-D_GLIBCXX_SANITIZE_VECTOR", "-fsanitize=address,undefined", "-fno-sanitize-recover=all",
+                         "-Wno-unused-function", os.path.join(d, "pat_sanitize.cpp"), os.path.join(csrc, "tk_tables.cpp"), os.path.join(csrc, "tk_pattern.cpp"),
+                         os.path.join(csrc, "tk_regex.cpp"), "-pthread", "-o", exe], capture_output=True, text=True)
+    if cc.returncode != 0 and "sanitize" in cc.stderr:
+        pytest.skip("this g++ has no sanitizer runtime")
+    assert cc.returncode == 0, cc.stderr[-2000:]
+    run = subprocess.run([exe, R50K, CL100K, O200K], capture_output=True, text=True, timeout=900, env={**os.environ, "TK_SAN_ROUNDS": "8000"})
+    assert run.returncode == 0 and run.stdout.startswith("ok 8000 "), (run.stdout[-300:], run.stderr[-3000:])
