@@ -299,7 +299,8 @@ def test_gpu_variation_with_special_tokens(pat):
 def test_pattern_parsers_under_the_sanitizers(tmp_path):
     """tests/hostsim/pat_sanitize.cpp: tk_compile_pattern -- the family parser, then the generic compiler -- on random, mostly ill-formed
     strings and on mutations of the stock patterns, built with AddressSanitizer and UBSan: whatever a caller hands to tk_create is refused
-    or compiled, never a crash.  (20 000 strings ran clean; 8 000 here.)"""
+    or compiled, never a crash (20 000 strings ran clean; 8 000 here); then the `.tiktoken` parser on damaged files and the table builder on
+    vocabularies it has to refuse (missing byte, duplicate or oversized ranks) or accept (sparse ranks)."""
     import os
     import subprocess
 
