@@ -537,13 +537,16 @@ typedef struct {
     uint32_t* tokens;
     uint64_t* counts;
     int tid, nth;
+    uint64_t* next; /* shared: the next block of documents nobody has taken yet */
 } job_t;
 
 static void* worker(void* arg) {
     job_t* j = (job_t*)arg;
-    /* contiguous blocks of 64 documents, round-robin over threads */
-    for (uint64_t base = (uint64_t)j->tid * 64; base < j->n_docs; base += (uint64_t)j->nth * 64) {
-        uint64_t hi = base + 64 < j->n_docs ? base + 64 : j->n_docs;
+    /* contiguous blocks of 16 documents, handed out as threads become free (a thread pool over documents, core.py:175) */
+    for (;;) {
+        uint64_t base = __atomic_fetch_add(j->next, 1, __ATOMIC_RELAXED) * 16;
+        if (base >= j->n_docs) break;
+        uint64_t hi = base + 16 < j->n_docs ? base + 16 : j->n_docs;
         for (uint64_t d = base; d < hi; ++d) {
             uint64_t a = j->doc_off[d], b = j->doc_off[d + 1];
             int64_t n = j->mode == 0
@@ -574,8 +577,9 @@ int tko_encode_batch(const tko_vocab* v, const uint8_t* blob, const uint64_t* do
     uint64_t* counts = (uint64_t*)calloc(n_docs ? n_docs : 1, sizeof(uint64_t));
     pthread_t th[256];
     job_t jobs[256];
+    uint64_t next = 0;
     for (int t = 0; t < n_threads; ++t) {
-        job_t j = {v, blob, doc_off, n_docs, mode, allowed_ids, n_allowed, tokens_out, counts, t, n_threads};
+        job_t j = {v, blob, doc_off, n_docs, mode, allowed_ids, n_allowed, tokens_out, counts, t, n_threads, &next};
         jobs[t] = j;
         if (n_threads > 1) pthread_create(&th[t], 0, worker, &jobs[t]);
     }

@@ -12,7 +12,8 @@ import subprocess
 import threading
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "csrc", "libtiktoken_amd.so")
+# ($TIKTOKEN_AMD_LIB: another build of the same library -- kernel experiments with other compile-time parameters, tools/build_variant.sh)
+_SO = os.environ.get("TIKTOKEN_AMD_LIB") or os.path.join(_HERE, "csrc", "libtiktoken_amd.so")
 _lock = threading.Lock()
 _lib = None
 
@@ -93,6 +94,9 @@ def lib() -> ctypes.CDLL:
         L.tk_get_kernel_ms.restype = i32
         L.tk_get_kernel_ms.argtypes = [vp, ctypes.c_char_p, P(ctypes.c_double), P(u64)]
         L.tk_last_stats.argtypes = [vp, P(u64), P(u64), P(u64), P(u64), P(u64), P(u64)]
+        if hasattr(L, "tk_stat"):  # (absent from older builds selected through $TIKTOKEN_AMD_LIB)
+            L.tk_stat.restype = u64
+            L.tk_stat.argtypes = [vp, ctypes.c_char_p]
         _lib = L
     return _lib
 

@@ -434,3 +434,7 @@ class CoreBPE:
         v = [ctypes.c_uint64() for _ in range(6)]
         self._L.tk_last_stats(self._h, *[ctypes.byref(x) for x in v])
         return dict(zip(("bytes", "pieces", "tokens", "docs", "medium_pieces", "long_pieces"), (x.value for x in v)))
+
+    def stat(self, name: str) -> int:
+        """One named figure of the last encode call (tk_stat): "hot_probes", "hot_hits", "hot_slots", "hot_seed", ..."""
+        return int(self._L.tk_stat(self._h, name.encode())) if hasattr(self._L, "tk_stat") else 0

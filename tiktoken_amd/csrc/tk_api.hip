@@ -23,6 +23,7 @@
 #include "tk_regex_kernels.h"
 
 static thread_local std::string g_err;
+static double now_us() { return std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now().time_since_epoch()).count(); }
 static int fail(int code, const std::string& msg) {
     g_err = msg;
     return code;
@@ -62,28 +63,63 @@ struct KernelStat {
 };
 
 #define TK_NAUX 6  // side streams of the merge kernels
+#define TK_NSET 4  // chunks in flight (work sets): the front kernel of chunk k + 1 runs while chunk k is merged and its tokens are placed
+
+// Work buffers of ONE chunk in flight.
+struct WorkSet {
+    Buf text_al, tile_sum, wide_ws, scan_sums, row_base, brk, docb, cand, ss, si, starts, blockcnt, pstart, res, rflag, miss, staging, listB, listC, counters, total, g_id, g_rk,
+        g_nx, g_pv, g_lv, tile_np, tile_nt, tile_nmiss, mt_slots, wbin, wave_pieces, deferred, big, rx_spec, rx_gst, rx_exit;
+    hipStream_t sb = nullptr;        // the set's back stage in a multi-chunk batch: back stages of different chunks overlap each other too
+                                     // (they are chains of short latency-bound kernels, ~2 ms however small the chunk)
+    hipEvent_t ev_front = nullptr;   // the front kernel is done
+    hipEvent_t ev_cnt = nullptr;     // ... and the deferred tiles: the counters are in h_counters
+    hipEvent_t ev_tot = nullptr;     // the chunk's token base and total are known (tok_bases[k + 1] written)
+    hipEvent_t ev_done = nullptr;    // the back stage is done: totals and counters are in h_total / h_counters + TK_CNT_N, the buffers are free
+    hipEvent_t ev_fork = nullptr, ev_join[TK_NAUX] = {};  // fork / join of the merge kernels on the side streams
+    uint32_t* h_counters = nullptr;  // pinned [2][TK_CNT_N]
+    uint64_t* h_total = nullptr;     // pinned [2]: tokens, pieces of the chunk
+    std::vector<Buf*> all() {
+        return {&text_al, &tile_sum, &wide_ws, &scan_sums, &row_base, &brk, &docb, &cand, &ss, &si, &starts, &blockcnt, &pstart, &res, &rflag, &miss, &staging, &listB,
+                &listC, &counters, &total, &g_id, &g_rk, &g_nx, &g_pv, &g_lv, &tile_np, &tile_nt, &tile_nmiss, &mt_slots, &wbin, &wave_pieces, &deferred, &big, &rx_spec,
+                &rx_gst, &rx_exit};
+    }
+};
+// What the front stage of a chunk leaves for its back stage.
+struct ChunkJob {
+    const uint8_t* d_text = nullptr;
+    uint64_t n = 0, n_docs = 0, base = 0, ntiles = 0;
+    const uint64_t* d_doc_off = nullptr;
+    uint64_t* d_tok_off = nullptr;
+    bool single_piece = false, spec = false;
+    uint32_t index = 0;  // position of the chunk in its batch
+    uint32_t mt_bits = 14;
+    TkMissSlot* mt = nullptr;
+    TkBins bins{};
+};
+
 struct tk_core {
     int device = 0;
     hipStream_t stream = nullptr;
     hipStream_t aux[TK_NAUX] = {};  // side streams: the merge kernels are independent of each other
-    hipEvent_t ev_fork = nullptr, ev_cnt = nullptr, ev_join[TK_NAUX] = {};
+    hipEvent_t ev_start = nullptr;
     hipStream_t cs_h2d = nullptr, cs_d2h = nullptr;  // copy streams of the host-buffer entry point (created on first use)
     void* stage[2] = {nullptr, nullptr};             // page-locked staging buffers
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
-    uint32_t* h_counters = nullptr;  // pinned
     TkHostTables H;
     TkTables D;  // device view
-    Buf t_stage1, t_stage2, t_byte_tab, t_short, t_mid, t_dec, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_spec_bytes, t_spec_off, t_spec_id;
+    Buf t_stage1, t_stage2, t_byte_tab, t_short, t_mid, t_dec, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_hot, t_spec_bytes, t_spec_off, t_spec_id;
     uint32_t spec_max_len = 0;
     bool has_rx = false;  // the pat_str runs on the generic engine (tk_regex_kernels.h)
     TkRxDev rx{};
-    Buf t_rx_ins, t_rx_sets, t_rx_ranges, t_rx_first, t_rx_s1, t_rx_s2, rx_spec, rx_gst, rx_exit;
+    Buf t_rx_ins, t_rx_sets, t_rx_ranges, t_rx_first, t_rx_s1, t_rx_s2;
     std::mutex mu;
-    // workspace
-    Buf text, text_al, tile_sum, wide_ws, scan_sums, row_base, doc_off, brk, docb, cand, ss, si, starts, blockcnt, pstart, res, rflag, staging, listB, listC, counters, total, g_id, g_rk, g_nx,
-        g_pv, g_lv, out_tokens, out_tok_off, allowed, tile_np, tile_nt, tile_nmiss, mt_slots, wbin, wave_pieces, deferred, big;
-    uint64_t chunk_bytes = 1ull << 30;
+    // workspace: per chunk in flight, and what a whole call shares
+    WorkSet ws[TK_NSET];
+    Buf text, doc_off, out_tokens, out_tok_off, allowed, tok_bases;  // tok_bases[k]: tokens of the chunks before chunk k (on the device)
+    uint64_t chunk_bytes = 1ull << 30;  // one chunk per GiB: smaller chunks pipeline (stage_front / stage_back) but pay the merge kernels' fixed latency per chunk
     int dbg = 0;
+    uint32_t n_cu = 256;             // compute units of the device
+    uint32_t front_wgs = TKF_OCC;    // workgroups per CU of the persistent front kernel ($TIKTOKEN_AMD_FRONT_WGS)
     uint32_t n_dec = 0;  // entries of the device decode table (0: ids too sparse for a direct table -- decode stays on the host)
     Buf d_tok, d_lens, d_bsum, d_tboff, d_bytes, d_boff;  // decode workspace
     uint8_t* small_in = nullptr;    // page-locked, device-visible: text of a small call (tk_k_small)
@@ -97,6 +133,8 @@ struct tk_core {
     std::map<std::string, KernelStat> stats;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
     uint64_t st_bytes = 0, st_pieces = 0, st_tokens = 0, st_docs = 0, st_medium = 0, st_long = 0;
+    uint64_t st_hot_probes = 0, st_hot_hits = 0, st_chunks = 0;
+    double host_us[6] = {0, 0, 0, 0, 0, 0};  // host time of the last call: front stages, back stages (of which: waiting for the front kernel), finish waits, total
 };
 
 // ------------------------------------------------------------------------------------------
@@ -234,12 +272,25 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     };
     if (hipSetDevice(device) != hipSuccess) return bail(fail(TK_RUNTIME_ERROR, "hipSetDevice failed"));
     if (hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking) != hipSuccess) return bail(fail(TK_RUNTIME_ERROR, "hipStreamCreate failed"));
+    // All streams at the default priority.  (Measured, profiles/r03_stream_priority.txt: the mere existence of high-priority streams
+    // in the process slows the front kernel from 5.76 to 6.28 ms per GiB even while nothing runs on them.  $TIKTOKEN_AMD_PRIO=1 gives the
+    // back stages' streams the highest priority for experiments.)
+    int prio_lo = 0, prio_hi = 0;
+    (void)hipDeviceGetStreamPriorityRange(&prio_lo, &prio_hi);
+    if (!getenv("TIKTOKEN_AMD_PRIO")) prio_hi = 0;
     for (int i = 0; i < TK_NAUX; ++i)
-        if (hipStreamCreateWithFlags(&c->aux[i], hipStreamNonBlocking) != hipSuccess || hipEventCreateWithFlags(&c->ev_join[i], hipEventDisableTiming) != hipSuccess)
-            return bail(fail(TK_RUNTIME_ERROR, "hipStreamCreate failed"));
-    if (hipEventCreateWithFlags(&c->ev_fork, hipEventDisableTiming) != hipSuccess || hipEventCreateWithFlags(&c->ev_cnt, hipEventDisableTiming) != hipSuccess)
-        return bail(fail(TK_RUNTIME_ERROR, "hipEventCreate failed"));
-    if (hipHostMalloc((void**)&c->h_counters, 256, hipHostMallocDefault) != hipSuccess) return bail(fail(TK_RUNTIME_ERROR, "hipHostMalloc failed"));
+        if (hipStreamCreateWithPriority(&c->aux[i], hipStreamNonBlocking, prio_hi) != hipSuccess) return bail(fail(TK_RUNTIME_ERROR, "hipStreamCreate failed"));
+    if (hipEventCreateWithFlags(&c->ev_start, hipEventDisableTiming) != hipSuccess) return bail(fail(TK_RUNTIME_ERROR, "hipEventCreate failed"));
+    for (WorkSet& w : c->ws) {
+        if (hipStreamCreateWithPriority(&w.sb, hipStreamNonBlocking, prio_hi) != hipSuccess) return bail(fail(TK_RUNTIME_ERROR, "hipStreamCreate failed"));
+        for (hipEvent_t* e : {&w.ev_front, &w.ev_cnt, &w.ev_tot, &w.ev_done, &w.ev_fork})
+            if (hipEventCreateWithFlags(e, hipEventDisableTiming) != hipSuccess) return bail(fail(TK_RUNTIME_ERROR, "hipEventCreate failed"));
+        for (int i = 0; i < TK_NAUX; ++i)
+            if (hipEventCreateWithFlags(&w.ev_join[i], hipEventDisableTiming) != hipSuccess) return bail(fail(TK_RUNTIME_ERROR, "hipEventCreate failed"));
+        if (hipHostMalloc((void**)&w.h_counters, 2 * TK_CNT_N * 4 + 64, hipHostMallocDefault) != hipSuccess ||
+            hipHostMalloc((void**)&w.h_total, 64, hipHostMallocDefault) != hipSuccess)
+            return bail(fail(TK_RUNTIME_ERROR, "hipHostMalloc failed"));
+    }
     const TkHostTables& H = c->H;
     int rc;
     if (H.rx.empty()) {
@@ -277,6 +328,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
                      H.pair8.empty() ? H.pair.size() * sizeof(TkPairSlot) : H.pair8.size() * 8))) return bail(rc);
     if ((rc = upload(c->t_pair2, H.pair2.data(), H.pair2.size() * 4))) return bail(rc);
     if ((rc = upload(c->t_byte_rank, H.byte_rank, sizeof H.byte_rank))) return bail(rc);
+    if (!H.hot.empty() && (rc = upload(c->t_hot, H.hot.data(), H.hot.size() * 4))) return bail(rc);
     if ((rc = upload(c->t_spec_bytes, H.spec_bytes.data(), H.spec_bytes.size()))) return bail(rc);
     if ((rc = upload(c->t_spec_off, H.spec_off.data(), H.spec_off.size() * 4))) return bail(rc);
     if ((rc = upload(c->t_spec_id, H.spec_id.data(), H.spec_id.size() * 4))) return bail(rc);
@@ -300,6 +352,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     D.pair_mask = H.pair_mask;
     D.pair2 = c->t_pair2.as<uint32_t>();
     D.byte_rank = c->t_byte_rank.as<uint32_t>();
+    D.hot = H.hot.empty() ? nullptr : c->t_hot.as<uint32_t>();
     D.spec_bytes = c->t_spec_bytes.as<uint8_t>();
     D.spec_off = c->t_spec_off.as<uint32_t>();
     D.spec_id = c->t_spec_id.as<uint32_t>();
@@ -326,6 +379,14 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
         if (v >= 4096 && v <= (3ull << 30)) c->chunk_bytes = v;
     }
     if (const char* e = getenv("TIKTOKEN_AMD_DEBUG")) c->dbg = atoi(e);
+    {
+        int cu = 0;
+        if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) c->n_cu = (uint32_t)cu;
+        if (const char* e = getenv("TIKTOKEN_AMD_FRONT_WGS")) {
+            const int v = atoi(e);
+            if (v >= 1 && v <= 8) c->front_wgs = (uint32_t)v;
+        }
+    }
     *out = c;
     return TK_OK;
 }
@@ -333,30 +394,33 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
 extern "C" void tk_destroy(tk_core* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (Buf* b : {&c->t_rx_ins, &c->t_rx_sets, &c->t_rx_ranges, &c->t_rx_first, &c->t_rx_s1, &c->t_rx_s2, &c->rx_spec, &c->rx_gst, &c->rx_exit}) release(*b);
-    for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_dec, &c->d_tok, &c->d_lens, &c->d_bsum, &c->d_tboff, &c->d_bytes, &c->d_boff, &c->t_piece, &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2,
-                   &c->t_byte_rank, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->text_al, &c->tile_sum, &c->wide_ws, &c->scan_sums, &c->row_base, &c->doc_off, &c->brk, &c->docb,
-                   &c->cand, &c->ss, &c->si, &c->starts, &c->blockcnt, &c->pstart, &c->res, &c->rflag, &c->staging, &c->listB,
-                   &c->listC, &c->counters, &c->total, &c->g_id, &c->g_rk, &c->g_nx, &c->g_pv, &c->g_lv, &c->out_tokens,
-                   &c->out_tok_off, &c->allowed, &c->tile_np, &c->tile_nt, &c->tile_nmiss, &c->mt_slots, &c->wbin, &c->deferred, &c->big,
-                   &c->wave_pieces, &c->small_ws})
+    for (Buf* b : {&c->t_rx_ins, &c->t_rx_sets, &c->t_rx_ranges, &c->t_rx_first, &c->t_rx_s1, &c->t_rx_s2}) release(*b);
+    for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_dec, &c->d_tok, &c->d_lens, &c->d_bsum, &c->d_tboff, &c->d_bytes, &c->d_boff, &c->t_piece,
+                   &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2, &c->t_byte_rank, &c->t_hot, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off,
+                   &c->out_tokens, &c->out_tok_off, &c->allowed, &c->tok_bases, &c->small_ws})
         release(*b);
+    for (WorkSet& w : c->ws) {
+        for (Buf* b : w.all()) release(*b);
+        for (hipEvent_t e : {w.ev_front, w.ev_cnt, w.ev_tot, w.ev_done, w.ev_fork})
+            if (e) (void)hipEventDestroy(e);
+        for (int i = 0; i < TK_NAUX; ++i)
+            if (w.ev_join[i]) (void)hipEventDestroy(w.ev_join[i]);
+        if (w.sb) (void)hipStreamDestroy(w.sb);
+        if (w.h_counters) (void)hipHostFree(w.h_counters);
+        if (w.h_total) (void)hipHostFree(w.h_total);
+    }
     if (c->small_in) (void)hipHostFree(c->small_in);
     if (c->small_out) (void)hipHostFree(c->small_out);
     if (c->stream) (void)hipStreamDestroy(c->stream);
-    for (int i = 0; i < TK_NAUX; ++i) {
+    for (int i = 0; i < TK_NAUX; ++i)
         if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
-        if (c->ev_join[i]) (void)hipEventDestroy(c->ev_join[i]);
-    }
     if (c->cs_h2d) (void)hipStreamDestroy(c->cs_h2d);
     if (c->cs_d2h) (void)hipStreamDestroy(c->cs_d2h);
     for (int i = 0; i < 2; ++i) {
         if (c->stage[i]) (void)hipHostFree(c->stage[i]);
         if (c->ev_stage[i]) (void)hipEventDestroy(c->ev_stage[i]);
     }
-    if (c->ev_fork) (void)hipEventDestroy(c->ev_fork);
-    if (c->ev_cnt) (void)hipEventDestroy(c->ev_cnt);
-    if (c->h_counters) (void)hipHostFree(c->h_counters);
+    if (c->ev_start) (void)hipEventDestroy(c->ev_start);
     delete c;
 }
 
@@ -370,10 +434,6 @@ static uint32_t grid_for(uint64_t items, uint32_t per_block, uint32_t cap) {
     return (uint32_t)g;
 }
 
-// One chunk (n < 4 GiB bytes) of packed documents, everything device resident.
-//   d_text: chunk text (readable 64 bytes past n); d_doc_off: uint64 offsets of the chunk's
-//   documents (n_docs+1 entries, absolute; `base` is subtracted); single_piece: the whole buffer
-//   is one piece (encode_single_piece), no pre-tokenisation.
 template <bool SLOW, class... A>
 static void launch_front(int pattern, bool spec, dim3 grid, hipStream_t s, A... a) {
     if (pattern == TK_PAT_R50K) {
@@ -391,18 +451,15 @@ static void launch_front(int pattern, bool spec, dim3 grid, hipStream_t s, A... 
     }
 }
 
-// The production pipeline (kernels of tk_fused.h).  One host synchronisation in the middle (the sizes of the
-// deferred-piece lists decide the merge launches) and none after it: the token total is read by the caller's
-// final synchronisation.
 // exclusive prefix sum of a uint32 array in place, total -> total_out[0]
-static int scan_u32(tk_core* c, hipStream_t s, uint32_t* a, uint64_t n, uint64_t* total_out) {
-    if (n <= 4 * (uint64_t)TK_SCAN_BLOCK) {
+static int scan_u32(tk_core* c, WorkSet& w, hipStream_t s, uint32_t* a, uint64_t n, uint64_t* total_out) {
+    if (n <= 16 * (uint64_t)TK_SCAN_BLOCK) {  // (one workgroup walks up to 128 Ki values in ~20 us: cheaper than three launches)
         TRY(timed(c, s, "tk_k_scan_small", [&] { hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, a, n, total_out); }));
         return TK_OK;
     }
     const uint64_t nb = (n + TK_SCAN_BLOCK - 1) / TK_SCAN_BLOCK;
-    TRY(ensure(c->scan_sums, (nb + 2) * 4));
-    uint32_t* sums = c->scan_sums.as<uint32_t>();
+    TRY(ensure(w.scan_sums, (nb + 2) * 4));
+    uint32_t* sums = w.scan_sums.as<uint32_t>();
     TRY(timed(c, s, "tk_k_scan_sums", [&] { hipLaunchKernelGGL(tk_k_scan_sums, dim3((uint32_t)nb), dim3(1024), 0, s, a, n, sums); }));
     TRY(timed(c, s, "tk_k_scan_small", [&] { hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, sums, nb, total_out); }));
     TRY(timed(c, s, "tk_k_scan_apply", [&] { hipLaunchKernelGGL(tk_k_scan_apply, dim3((uint32_t)nb), dim3(1024), 0, s, a, n, sums); }));
@@ -422,77 +479,125 @@ static int rx_failure(const uint32_t* counters, uint64_t base) {
                                     " of the batch (nested quantifiers; the reference's fancy-regex gives up after 1 000 000 backtracks as well)");
 }
 
-static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t n, const uint64_t* d_doc_off, uint64_t n_docs,
-                     uint64_t base, bool use_special, bool single_piece, uint32_t* d_out, uint64_t tok_base_global,
-                     uint64_t* d_tok_off, uint64_t* n_tokens_out, bool pretok_only = false, bool no_lookup = false) {
+// ------------------------------------------------------------------------------------------
+// The production pipeline (kernels of tk_fused.h) on one chunk (n < 4 GiB bytes) of packed documents, everything device resident, in two
+// stages so that chunks can overlap: while chunk k is merged and its tokens are placed (stage_back: latency- and memory-bound kernels,
+// on their own stream), the front kernel of chunk k + 1 (bound by the vector ALU) already runs on the caller's stream.  Each chunk in
+// flight has its own WorkSet.  The host never needs a chunk's token count to queue the next one: the running total stays on the device
+// (c->tok_bases[k]: written by chunk k - 1's back stage as soon as it knows its token count).
+//   d_text: chunk text (readable 64 bytes past n); d_doc_off: uint64 offsets of the chunk's documents (n_docs + 1 entries, absolute;
+//   `base` is subtracted); single_piece: the whole buffer is one piece (encode_single_piece), no pre-tokenisation.
+// ------------------------------------------------------------------------------------------
+// The tiles the front kernel has deferred (they need the workgroup-wide scanner: long pieces, far-away piece starts; their number stays
+// on the device), then the counters of both kernels -- pieces for the tree kernel, errors of the generic engine -- on their way to the host.
+// A kernel of a few hundred workgroups that each take ~0.3 ms: it belongs to the back stage, beside the next chunk's front kernel.
+static int stage_deferred(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s) {
+    const TkTables& T = c->D;
+    if (job.n > 0 && !job.single_piece) {
+        TkFrontOut fo{w.starts.as<uint32_t>(), w.tile_np.as<uint32_t>(), w.res.as<uint32_t>(), w.tile_nmiss.as<uint32_t>(), w.tile_sum.as<uint8_t>(), w.miss.as<uint2>(),
+                      w.listC.as<uint32_t>(), w.counters.as<uint32_t>()};
+        uint32_t *ss = job.spec ? w.ss.as<uint32_t>() : nullptr, *si = job.spec ? w.si.as<uint32_t>() : nullptr, *docb = job.spec ? w.docb.as<uint32_t>() : nullptr;
+        TRY(timed(c, s, "tk_k_front_slow", [&] {
+            const dim3 grid((uint32_t)(job.ntiles < 1024 ? job.ntiles : 1024));
+            launch_front<true>(T.pat.generic() ? TK_PAT_GENERIC : T.pattern, job.spec, grid, s, T, job.d_text, job.n, job.base, w.brk.as<uint32_t>(), docb, ss, si, fo,
+                               (c->dbg & 256) ? (TkMissSlot*)nullptr : job.mt, (1u << job.mt_bits) - 1u, w.deferred.as<uint32_t>(), c->dbg);
+        }));
+    }
+    HIPCHK(hipMemcpyAsync(w.h_counters, w.counters.p, TK_CNT_N * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(w.ev_cnt, s));
+    return TK_OK;
+}
+
+static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, const uint8_t* d_text, uint64_t n, const uint64_t* d_doc_off, uint64_t n_docs,
+                       uint64_t base, bool use_special, bool single_piece, uint64_t* d_tok_off, bool pretok_only, bool no_lookup,
+                       uint64_t* pretok_count_out) {
     const TkTables& T = c->D;
     const uint64_t nwords = (n + 31) / 32;
     const uint64_t nblk = (nwords + 255) / 256;
     const uint64_t ntiles = (n && !single_piece) ? (n + TK_TILE - 1) / TK_TILE : 1;  // (single piece: one run of one piece)
-    TRY(ensure(c->brk, (nwords + 2) * 4));
-    TRY(ensure(c->starts, (nwords + 2) * 4));
-    TRY(ensure(c->blockcnt, (nblk + 2) * 4));
-    TRY(ensure(c->counters, TK_CNT_N * 4));
-    TRY(ensure(c->total, 16));
-    TRY(ensure(c->tile_np, (ntiles + 2) * 4));
-    TRY(ensure(c->tile_nt, (ntiles + 2) * 4));
-    TRY(ensure(c->tile_nmiss, (ntiles + 2) * 4));
-    TRY(ensure(c->wbin, (TK_NBIN * TKD_WAVES + 2) * 4));
-    TRY(ensure(c->wave_pieces, 16384 * 4));
+    job = ChunkJob();
+    job.d_text = d_text;
+    job.n = n;
+    job.n_docs = n_docs;
+    job.base = base;
+    job.ntiles = ntiles;
+    job.d_doc_off = d_doc_off;
+    job.d_tok_off = d_tok_off;
+    job.single_piece = single_piece;
+    TRY(ensure(w.brk, (nwords + 2) * 4));
+    TRY(ensure(w.starts, (nwords + 2) * 4));
+    TRY(ensure(w.blockcnt, (nblk + 2) * 4));
+    TRY(ensure(w.counters, TK_CNT_N * 4));
+    TRY(ensure(w.total, 16));
+    TRY(ensure(w.tile_np, (ntiles + 2) * 4));
+    TRY(ensure(w.tile_nt, (ntiles + 2) * 4));
+    TRY(ensure(w.tile_nmiss, (ntiles + 2) * 4));
+    TRY(ensure(w.wbin, (TK_NBIN * TKD_WAVES + 2) * 4));
+    TRY(ensure(w.wave_pieces, 16384 * 4));
     const uint64_t pid_cap = tk_pid_cap(n);
-    TRY(ensure(c->res, pid_cap * 4));
-    TRY(ensure(c->rflag, (ntiles + 1) * TKF_MISS_CAP * 8));
-    TRY(ensure(c->staging, (n + 64) * 4));
-    if (pretok_only) {
-        TRY(ensure(c->out_tokens, pid_cap * 4));
-        d_out = c->out_tokens.as<uint32_t>();
-    }
-    TkBins bins;
+    TRY(ensure(w.res, pid_cap * 4));
+    TRY(ensure(w.rflag, (ntiles + 1) * TKF_MISS_CAP * 8));
+    TRY(ensure(w.miss, (ntiles + 1) * TKF_MISS_CAP * 8 + 64));
+    TRY(ensure(w.staging, (n + 64) * 4));
     uint64_t pool = 0;
     for (int b = 0; b < TK_NBIN; ++b) {
-        bins.off[b] = (uint32_t)pool;
+        job.bins.off[b] = (uint32_t)pool;
         pool += n / tk_bin_lo(b) + 64;
     }
-    TRY(ensure(c->listB, pool * 12));
-    TRY(ensure(c->listC, (n / 1025 + 64) * 20));
-    HIPCHK(hipMemsetAsync(c->brk.p, 0, (nwords + 2) * 4, s));
-    HIPCHK(hipMemsetAsync(c->counters.p, 0, TK_CNT_N * 4, s));
-    TRY(ensure(c->big, (1 + 3 * TK_BIGCOPY_CAP) * 4));
-    HIPCHK(hipMemsetAsync(c->big.p, 0, 4, s));
-    HIPCHK(hipMemsetAsync(c->total.p, 0, 16, s));
-    uint32_t *brk = c->brk.as<uint32_t>(), *starts = c->starts.as<uint32_t>();
+    TRY(ensure(w.listB, pool * 12));
+    TRY(ensure(w.listC, (n / 1025 + 64) * 20));
+    TRY(ensure(w.big, (1 + 3 * TK_BIGCOPY_CAP) * 4));
+    TkClearArgs clr;
+    clr.n = 0;
+    auto clear = [&](Buf& b, uint64_t bytes, uint32_t v) {  // (every Buf has at least 256 bytes of slack behind what was asked for)
+        clr.p[clr.n] = b.as<uint4>();
+        clr.n16[clr.n] = (bytes + 15) / 16;
+        clr.v[clr.n] = v;
+        ++clr.n;
+    };
+    clear(w.brk, (nwords + 2) * 4, 0u);
+    clear(w.counters, TK_CNT_N * 4, 0u);
+    clear(w.big, 4, 0u);
+    clear(w.total, 16, 0u);
+    uint32_t *brk = w.brk.as<uint32_t>(), *starts = w.starts.as<uint32_t>();
     uint32_t *ss = nullptr, *si = nullptr, *docb = nullptr;
-    uint32_t* counters = c->counters.as<uint32_t>();
-    uint32_t *res = c->res.as<uint32_t>(), *stg = c->staging.as<uint32_t>();
-    uint2* rflag = c->rflag.as<uint2>();
-    uint32_t *tile_np = c->tile_np.as<uint32_t>(), *tile_nt = c->tile_nt.as<uint32_t>();
-    // The per-tile miss lists (TKF_MISS_CAP entries of 8 bytes per tile) live in memory that is not needed until the back
-    // kernel writes it: the output region (8-byte aligned inside it).
-    uint2* miss = d_out ? (uint2*)(((uintptr_t)d_out + 7) & ~(uintptr_t)7) : nullptr;
-    TRY(ensure(c->tile_sum, ntiles + 16));
-    TRY(ensure(c->row_base, (ntiles + 1) * (TKF_CAP / 256) * 8));
-    HIPCHK(hipMemsetAsync(c->tile_sum.p, 0xFF, ntiles + 16, s));
-    TkFrontOut fo{starts, tile_np, res, c->tile_nmiss.as<uint32_t>(), c->tile_sum.as<uint8_t>(), miss, c->listC.as<uint32_t>(), counters};
-    TkMissSlot* mt = nullptr;
-    uint32_t mt_bits = 14;
-    uint64_t nB = 0, nC = 0;
+    uint32_t* counters = w.counters.as<uint32_t>();
+    uint2* miss = w.miss.as<uint2>();  // per tile TKF_MISS_CAP entries of 8 bytes
+    TRY(ensure(w.tile_sum, ntiles + 16));
+    TRY(ensure(w.row_base, (ntiles + 1) * (TKF_CAP / 256) * 8));
+    clear(w.tile_sum, ntiles + 16, 0xFFFFFFFFu);
+    TkFrontOut fo{starts, w.tile_np.as<uint32_t>(), w.res.as<uint32_t>(), w.tile_nmiss.as<uint32_t>(), w.tile_sum.as<uint8_t>(), miss, w.listC.as<uint32_t>(), counters};
     if (n > 0 && !single_piece) {
         if (use_special) {
-            TRY(ensure(c->docb, (nwords + 2) * 4));
-            TRY(ensure(c->cand, (nwords + 2) * 4));
-            TRY(ensure(c->ss, (nwords + 2) * 4));
-            TRY(ensure(c->si, (nwords + 2) * 4));
-            for (Buf* b : {&c->docb, &c->cand, &c->ss, &c->si}) HIPCHK(hipMemsetAsync(b->p, 0, (nwords + 2) * 4, s));
-            docb = c->docb.as<uint32_t>();
-            ss = c->ss.as<uint32_t>();
-            si = c->si.as<uint32_t>();
+            TRY(ensure(w.docb, (nwords + 2) * 4));
+            TRY(ensure(w.cand, (nwords + 2) * 4));
+            TRY(ensure(w.ss, (nwords + 2) * 4));
+            TRY(ensure(w.si, (nwords + 2) * 4));
+            for (Buf* b : {&w.docb, &w.cand, &w.ss, &w.si}) clear(*b, (nwords + 2) * 4, 0u);
+            docb = w.docb.as<uint32_t>();
+            ss = w.ss.as<uint32_t>();
+            si = w.si.as<uint32_t>();
         }
+        if (c->has_rx) {
+            TRY(ensure(w.rx_spec, (nwords + 2) * 4));
+            TRY(ensure(w.rx_gst, (nwords + 2) * 4));
+            clear(w.rx_spec, (nwords + 2) * 4, 0u);
+            clear(w.rx_gst, (nwords + 2) * 4, 0u);
+        }
+        if (n > 32768 && !pretok_only) {  // in-call de-duplication of missed pieces pays for its table reset only on real batches
+            while (job.mt_bits < TK_MT_BITS && (1ull << job.mt_bits) < n / 128) ++job.mt_bits;  // 4 Mi slots from 512 MiB up
+            TRY(ensure(w.mt_slots, sizeof(TkMissSlot) << job.mt_bits));
+            clear(w.mt_slots, sizeof(TkMissSlot) << job.mt_bits, 0xFFFFFFFFu);
+            job.mt = w.mt_slots.as<TkMissSlot>();
+        }
+        hipLaunchKernelGGL(tk_k_chunk_clear, dim3(grid_for(n / 64 + 1, 256, 2048)), dim3(256), 0, s, clr);
+        clr.n = 0;
         TRY(timed(c, s, "tk_k_mark_docs", [&] {
             hipLaunchKernelGGL(tk_k_mark_docs, dim3(grid_for(n_docs, 256, 4096)), dim3(256), 0, s, d_doc_off, n_docs, base, n, brk, docb);
         }));
         if (use_special) {
             const uint8_t* allowed = c->allowed.as<uint8_t>();
-            uint32_t* cand = c->cand.as<uint32_t>();
+            uint32_t* cand = w.cand.as<uint32_t>();
             TRY(timed(c, s, "tk_k_spec_cand", [&] {
                 hipLaunchKernelGGL(tk_k_spec_cand, dim3(grid_for(n / 16 + 1, 256, 65536)), dim3(256), 0, s, T, d_text, n, allowed, docb, cand);
             }));
@@ -504,12 +609,8 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
         if (c->has_rx) {  // the generic engine finds the piece starts; they join the hard starts in `brk`
             const uint32_t seg_shift = n < TK_RX_SEG_SMALL_BELOW ? TK_RX_SEG_SHIFT_SMALL : TK_RX_SEG_SHIFT_LARGE;
             const uint64_t nseg = (n + (1ull << seg_shift) - 1) >> seg_shift;
-            TRY(ensure(c->rx_spec, (nwords + 2) * 4));
-            TRY(ensure(c->rx_gst, (nwords + 2) * 4));
-            TRY(ensure(c->rx_exit, (nseg + 2) * 4));
-            HIPCHK(hipMemsetAsync(c->rx_spec.p, 0, (nwords + 2) * 4, s));
-            HIPCHK(hipMemsetAsync(c->rx_gst.p, 0, (nwords + 2) * 4, s));
-            uint32_t *spec = c->rx_spec.as<uint32_t>(), *gst = c->rx_gst.as<uint32_t>(), *xexit = c->rx_exit.as<uint32_t>();
+            TRY(ensure(w.rx_exit, (nseg + 2) * 4));
+            uint32_t *spec = w.rx_spec.as<uint32_t>(), *gst = w.rx_gst.as<uint32_t>(), *xexit = w.rx_exit.as<uint32_t>();
             TRY(timed(c, s, "tk_k_rx_speculate", [&] {
                 hipLaunchKernelGGL(tk_k_rx_speculate, dim3(grid_for(nseg, 256, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, seg_shift, spec, xexit);
             }));
@@ -519,66 +620,76 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
             }));
             TRY(timed(c, s, "tk_k_rx_merge", [&] { hipLaunchKernelGGL(tk_k_rx_merge, dim3(grid_for(nwords, 256, 4096)), dim3(256), 0, s, brk, gst, nwords); }));
         }
-        if (n > 32768 && !pretok_only) {  // in-call de-duplication of missed pieces pays for its table reset only on real batches
-            while (mt_bits < TK_MT_BITS && (1ull << mt_bits) < n / 128) ++mt_bits;  // 4 Mi slots from 512 MiB up
-            TRY(ensure(c->mt_slots, sizeof(TkMissSlot) << mt_bits));
-            HIPCHK(hipMemsetAsync(c->mt_slots.p, 0xFF, sizeof(TkMissSlot) << mt_bits, s));
-            mt = c->mt_slots.as<TkMissSlot>();
-        }
-        TRY(ensure(c->deferred, (ntiles + 2) * 4));
-        uint32_t* deferred = c->deferred.as<uint32_t>();
+        TRY(ensure(w.deferred, (ntiles + 2) * 4));
+        uint32_t* deferred = w.deferred.as<uint32_t>();
+        TkMissSlot* mt_arg = (c->dbg & 256) ? (TkMissSlot*)nullptr : job.mt;
         TRY(timed(c, s, "tk_k_front", [&] {
-            const dim3 grid((uint32_t)ntiles);
+            // (only the variant with the LDS piece cache, TKF_HOT_BITS > 0, which keeps the cache over all the tiles a workgroup walks)
+            const uint64_t resident = TKF_HOT_BITS ? (uint64_t)c->n_cu * c->front_wgs : ntiles;
+            const dim3 grid((uint32_t)(ntiles < resident ? ntiles : resident));
             launch_front<false>(T.pat.generic() ? TK_PAT_GENERIC : T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, fo,
-                                (c->dbg & 256) ? (TkMissSlot*)nullptr : mt, (1u << mt_bits) - 1u, deferred, c->dbg);
-        }));
-        // the tiles that need the workgroup-wide scanner (long pieces, far-away piece starts); their number stays on the device
-        TRY(timed(c, s, "tk_k_front_slow", [&] {
-            const dim3 grid((uint32_t)(ntiles < 1024 ? ntiles : 1024));
-            launch_front<true>(T.pat.generic() ? TK_PAT_GENERIC : T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, fo,
-                               (c->dbg & 256) ? (TkMissSlot*)nullptr : mt, (1u << mt_bits) - 1u, deferred, c->dbg);
+                                mt_arg, (1u << job.mt_bits) - 1u, deferred, c->dbg);
         }));
     } else if (n > 0) {
+        hipLaunchKernelGGL(tk_k_chunk_clear, dim3(1), dim3(256), 0, s, clr);
+        clr.n = 0;
         TRY(timed(c, s, "tk_k_single_front", [&] { hipLaunchKernelGGL(tk_k_single_front, dim3(1), dim3(64), 0, s, T, d_text, (uint32_t)n, fo, no_lookup ? 1 : 0); }));
     }
-    // the front kernel's counters (pieces for the tree kernel) go back to the host while the next kernels run
-    HIPCHK(hipMemcpyAsync(c->h_counters, counters, TK_CNT_N * 4, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipEventRecord(c->ev_cnt, s));
+    if (clr.n) hipLaunchKernelGGL(tk_k_chunk_clear, dim3(1), dim3(256), 0, s, clr);  // (an empty chunk)
+    job.spec = ss != nullptr;
+    HIPCHK(hipEventRecord(w.ev_front, s));
     if (pretok_only) {  // debugging / test entry: piece offsets only
+        TRY(stage_deferred(c, w, job, s));
         uint64_t P = 0;
-        TRY(ensure(c->pstart, 16));
+        TRY(ensure(w.pstart, 16));
         if (n > 0) {
             TRY(timed(c, s, "tk_k_count", [&] {
-                hipLaunchKernelGGL(tk_k_count, dim3((uint32_t)nblk), dim3(256), 0, s, starts, nwords, c->blockcnt.as<uint32_t>());
+                hipLaunchKernelGGL(tk_k_count, dim3((uint32_t)nblk), dim3(256), 0, s, starts, nwords, w.blockcnt.as<uint32_t>());
             }));
             TRY(timed(c, s, "tk_k_scan_small", [&] {
-                hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, c->blockcnt.as<uint32_t>(), nblk, c->total.as<uint64_t>());
+                hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, w.blockcnt.as<uint32_t>(), nblk, w.total.as<uint64_t>());
             }));
-            HIPCHK(hipMemcpyAsync(&P, c->total.p, 8, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipMemcpyAsync(&P, w.total.p, 8, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
-            if (c->h_counters[TK_CNT_ERR] & (TK_RX_ERR_GAP | TK_RX_ERR_STACK | TK_RX_ERR_LIMIT)) return rx_failure(c->h_counters, base);
-            TRY(ensure(c->pstart, (P + 2) * 4));
+            if (w.h_counters[TK_CNT_ERR] & (TK_RX_ERR_GAP | TK_RX_ERR_STACK | TK_RX_ERR_LIMIT)) return rx_failure(w.h_counters, base);
+            TRY(ensure(w.pstart, (P + 2) * 4));
             TRY(timed(c, s, "tk_k_emit", [&] {
-                hipLaunchKernelGGL(tk_k_emit, dim3((uint32_t)nblk), dim3(256), 0, s, starts, nwords, c->blockcnt.as<uint32_t>(),
-                                   c->pstart.as<uint32_t>(), P, n);
+                hipLaunchKernelGGL(tk_k_emit, dim3((uint32_t)nblk), dim3(256), 0, s, starts, nwords, w.blockcnt.as<uint32_t>(),
+                                   w.pstart.as<uint32_t>(), P, n);
             }));
         } else {
-            HIPCHK(hipMemsetAsync(c->pstart.p, 0, 4, s));
+            HIPCHK(hipMemsetAsync(w.pstart.p, 0, 4, s));
         }
-        *n_tokens_out = P;
-        return TK_OK;
+        *pretok_count_out = P;
     }
+    return TK_OK;
+}
+
+// Second stage of a chunk, on stream s (the front stage's stream for a single chunk, the set's own otherwise; the caller has made it wait
+// for w.ev_front).  d_out: the batch's token buffer; the chunk's tokens go behind tok_bases[job.index] of them, which the previous chunk's
+// back stage writes (prev_tot: the event to wait for, null for the first chunk or on a single stream).
+static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s, uint32_t* d_out, hipEvent_t prev_tot) {
+    const TkTables& T = c->D;
+    const uint64_t n = job.n, ntiles = job.ntiles;
+    const uint8_t* d_text = job.d_text;
+    uint32_t* counters = w.counters.as<uint32_t>();
+    uint32_t *res = w.res.as<uint32_t>(), *stg = w.staging.as<uint32_t>();
+    uint2 *rflag = w.rflag.as<uint2>(), *miss = w.miss.as<uint2>();
+    uint32_t *tile_np = w.tile_np.as<uint32_t>(), *tile_nt = w.tile_nt.as<uint32_t>(), *tile_nmiss = w.tile_nmiss.as<uint32_t>();
+    const unsigned long long* tok_base = c->tok_bases.as<unsigned long long>() + job.index;
+    uint64_t nC = 0;
+    TRY(stage_deferred(c, w, job, s));
     if (n > 0) {
-        uint32_t* wbin = c->wbin.as<uint32_t>();
+        uint32_t* wbin = w.wbin.as<uint32_t>();
         // the two list passes and the tile passes: as many workgroups as the chunk has work for (small calls are latency-bound)
         const uint32_t tpg = ntiles > 16384 ? TKD_GROUP : 1;
         const uint32_t dd_blocks = grid_for(ntiles, 4 * tpg, TKD_WAVES / 4), tf_blocks = grid_for(ntiles, 4, 4096);
         TRY(timed(c, s, "tk_k_bincount", [&] {
-            hipLaunchKernelGGL(tk_k_bincount, dim3(dd_blocks), dim3(256), 0, s, ntiles, fo.tile_nmiss, miss, wbin, tpg);
+            hipLaunchKernelGGL(tk_k_bincount, dim3(dd_blocks), dim3(256), 0, s, ntiles, tile_nmiss, miss, wbin, tpg);
         }));
-        TRY(scan_u32(c, s, wbin, (uint64_t)TK_NBIN * dd_blocks * 4 + 1, c->total.as<uint64_t>()));
+        TRY(scan_u32(c, w, s, wbin, (uint64_t)TK_NBIN * dd_blocks * 4 + 1, w.total.as<uint64_t>()));
         TRY(timed(c, s, "tk_k_binfill", [&] {
-            hipLaunchKernelGGL(tk_k_binfill, dim3(dd_blocks), dim3(256), 0, s, ntiles, fo.tile_nmiss, miss, wbin, c->listB.as<uint32_t>(), bins, counters, tpg);
+            hipLaunchKernelGGL(tk_k_binfill, dim3(dd_blocks), dim3(256), 0, s, ntiles, tile_nmiss, miss, wbin, w.listB.as<uint32_t>(), job.bins, counters, tpg);
         }));
         {
             // The bins are independent: spread them over the side streams, longest-tailed kernels first.  List lengths are
@@ -591,8 +702,8 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
                 HIPCHK(hipMemcpyAsync(small_counts, counters, sizeof small_counts, hipMemcpyDeviceToHost, s));
                 HIPCHK(hipStreamSynchronize(s));
             }
-            HIPCHK(hipEventRecord(c->ev_fork, s));
-            for (int i = 0; i < TK_NAUX; ++i) HIPCHK(hipStreamWaitEvent(c->aux[i], c->ev_fork, 0));
+            HIPCHK(hipEventRecord(w.ev_fork, s));
+            for (int i = 0; i < TK_NAUX; ++i) HIPCHK(hipStreamWaitEvent(c->aux[i], w.ev_fork, 0));
             // (longest first; the four lane-group kernels have a stream each -- their run time is the longest piece's chain of
             // merges --, the five lane-per-piece kernels share two)
             static const int order[TK_NBIN] = {6, 8, 7, 5, 2, 4, 1, 3, 0};
@@ -601,7 +712,7 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
                 const int b = order[oi];
                 if (n < tk_bin_lo(b) || (small && !small_counts[TK_CNT_BIN0 + b])) continue;
                 const uint64_t most = n / tk_bin_lo(b);
-                const uint32_t* lst = c->listB.as<uint32_t>() + 3 * (uint64_t)bins.off[b];
+                const uint32_t* lst = w.listB.as<uint32_t>() + 3 * (uint64_t)job.bins.off[b];
                 const uint32_t* cp = counters + TK_CNT_BIN0 + b;
                 hipStream_t sa = c->aux[stream_of[b]];
                 TRY(timed(c, sa, names[b], [&] {
@@ -619,83 +730,115 @@ static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t 
                 }));
             }
             for (int i = 0; i < TK_NAUX; ++i) {
-                HIPCHK(hipEventRecord(c->ev_join[i], c->aux[i]));
-                HIPCHK(hipStreamWaitEvent(s, c->ev_join[i], 0));
+                HIPCHK(hipEventRecord(w.ev_join[i], c->aux[i]));
+                HIPCHK(hipStreamWaitEvent(s, w.ev_join[i], 0));
             }
         }
         // pieces longer than TK_GLANE_MAX were listed by the front kernel: their scratch is sized from its counters,
         // which were copied back while the kernels above were being queued
-        HIPCHK(hipEventSynchronize(c->ev_cnt));
-        const uint32_t* hc = c->h_counters;
+        {
+            const double t0 = now_us();
+            HIPCHK(hipEventSynchronize(w.ev_cnt));
+            c->host_us[2] += now_us() - t0;
+        }
+        const uint32_t* hc = w.h_counters;
         nC = hc[TK_CNT_C];
         if (nC) {
             const uint64_t lb = (uint64_t)hc[TK_CNT_CBYTES] + 4 * nC, lvls = hc[TK_CNT_CLEVELS];
-            TRY(ensure(c->g_id, (lb + 64) * 4));
-            TRY(ensure(c->g_rk, (lb + 64) * 4));
-            TRY(ensure(c->g_nx, (lb + 64) * 4));
-            TRY(ensure(c->g_pv, (lb + 64) * 4));
-            TRY(ensure(c->g_lv, (lvls + 64) * 8));
+            TRY(ensure(w.g_id, (lb + 64) * 4));
+            TRY(ensure(w.g_rk, (lb + 64) * 4));
+            TRY(ensure(w.g_nx, (lb + 64) * 4));
+            TRY(ensure(w.g_pv, (lb + 64) * 4));
+            TRY(ensure(w.g_lv, (lvls + 64) * 8));
             const bool rounds = !(c->dbg & 1024);  // (debug bit 1024: one merge at a time for every long piece)
             if (rounds) {
                 TRY(timed(c, s, "tk_k_merge_rounds", [&] {
-                    hipLaunchKernelGGL(tk_k_merge_rounds, dim3(grid_for(nC, 1, 1024)), dim3(TKB_THREADS), 0, s, T, d_text, c->listC.as<uint32_t>(),
-                                       (uint32_t)nC, c->g_id.as<uint32_t>(), c->g_rk.as<uint32_t>(), c->g_nx.as<uint32_t>(), c->g_pv.as<uint32_t>(),
+                    hipLaunchKernelGGL(tk_k_merge_rounds, dim3(grid_for(nC, 1, 1024)), dim3(TKB_THREADS), 0, s, T, d_text, w.listC.as<uint32_t>(),
+                                       (uint32_t)nC, w.g_id.as<uint32_t>(), w.g_rk.as<uint32_t>(), w.g_nx.as<uint32_t>(), w.g_pv.as<uint32_t>(),
                                        miss, stg);
                 }));
             }
             if (rounds && n >= TK_WIDE_MIN) {  // (pieces of TK_WIDE_MIN bytes and more, if there are any: the whole grid on each)
-                TRY(ensure(c->wide_ws, sizeof(TkWideWs)));
-                HIPCHK(hipMemsetAsync(c->wide_ws.p, 0, sizeof(TkWideWs), s));
+                TRY(ensure(w.wide_ws, sizeof(TkWideWs)));
+                HIPCHK(hipMemsetAsync(w.wide_ws.p, 0, sizeof(TkWideWs), s));
                 TRY(timed(c, s, "tk_k_merge_rounds_wide", [&] {
-                    hipLaunchKernelGGL(tk_k_merge_rounds_wide, dim3(TK_WIDE_BLOCKS), dim3(TKB_THREADS), 0, s, T, d_text, c->listC.as<uint32_t>(),
-                                       (uint32_t)nC, c->g_id.as<uint32_t>(), c->g_rk.as<uint32_t>(), c->g_nx.as<uint32_t>(), c->g_pv.as<uint32_t>(),
-                                       miss, stg, c->wide_ws.as<TkWideWs>());
+                    hipLaunchKernelGGL(tk_k_merge_rounds_wide, dim3(TK_WIDE_BLOCKS), dim3(TKB_THREADS), 0, s, T, d_text, w.listC.as<uint32_t>(),
+                                       (uint32_t)nC, w.g_id.as<uint32_t>(), w.g_rk.as<uint32_t>(), w.g_nx.as<uint32_t>(), w.g_pv.as<uint32_t>(),
+                                       miss, stg, w.wide_ws.as<TkWideWs>());
                 }));
             }
             TRY(timed(c, s, "tk_k_merge_long", [&] {
-                hipLaunchKernelGGL(tk_k_merge_long, dim3(grid_for(nC, 4, 8192)), dim3(256), 0, s, T, d_text, c->listC.as<uint32_t>(), (uint32_t)nC,
-                                   c->g_id.as<uint32_t>(), c->g_rk.as<uint32_t>(), c->g_nx.as<uint32_t>(), c->g_pv.as<uint32_t>(),
-                                   c->g_lv.as<uint64_t>(), miss, stg, rounds ? 1 : 0);
+                hipLaunchKernelGGL(tk_k_merge_long, dim3(grid_for(nC, 4, 8192)), dim3(256), 0, s, T, d_text, w.listC.as<uint32_t>(), (uint32_t)nC,
+                                   w.g_id.as<uint32_t>(), w.g_rk.as<uint32_t>(), w.g_nx.as<uint32_t>(), w.g_pv.as<uint32_t>(),
+                                   w.g_lv.as<uint64_t>(), miss, stg, rounds ? 1 : 0);
             }));
         }
-        if (mt) {
-            TRY(timed(c, s, "tk_k_dup_publish", [&] { hipLaunchKernelGGL(tk_k_dup_publish, dim3(grid_for(1ull << mt_bits, 256, 4096)), dim3(256), 0, s, mt, 1u << mt_bits, miss); }));
+        if (job.mt) {
+            TRY(timed(c, s, "tk_k_dup_publish", [&] { hipLaunchKernelGGL(tk_k_dup_publish, dim3(grid_for(1ull << job.mt_bits, 256, 4096)), dim3(256), 0, s, job.mt, 1u << job.mt_bits, miss); }));
         }
         TRY(timed(c, s, "tk_k_tile_finish", [&] {
-            hipLaunchKernelGGL(tk_k_tile_finish, dim3(tf_blocks), dim3(256), 0, s, ntiles, tile_np, mt, res, miss, rflag, tile_nt, c->wave_pieces.as<uint32_t>());
+            hipLaunchKernelGGL(tk_k_tile_finish, dim3(tf_blocks), dim3(256), 0, s, ntiles, tile_np, job.mt, res, miss, rflag, tile_nt, w.wave_pieces.as<uint32_t>());
         }));
-        hipLaunchKernelGGL(tk_k_sum_pieces, dim3(1), dim3(1024), 0, s, c->wave_pieces.as<uint32_t>(), tf_blocks * 4u, c->total.as<unsigned long long>() + 1);
-        TRY(scan_u32(c, s, tile_nt, ntiles, c->total.as<uint64_t>()));
+        hipLaunchKernelGGL(tk_k_sum_pieces, dim3(1), dim3(1024), 0, s, w.wave_pieces.as<uint32_t>(), tf_blocks * 4u, w.total.as<unsigned long long>() + 1);
+        TRY(scan_u32(c, w, s, tile_nt, ntiles, w.total.as<uint64_t>()));
+    }
+    // the chunk's token count is known: the next chunk's base (its back stage may be running beside this one)
+    if (prev_tot) HIPCHK(hipStreamWaitEvent(s, prev_tot, 0));
+    hipLaunchKernelGGL(tk_k_advance, dim3(1), dim3(64), 0, s, c->tok_bases.as<unsigned long long>(), job.index, w.total.as<uint64_t>());
+    HIPCHK(hipEventRecord(w.ev_tot, s));
+    if (n > 0) {
         TRY(timed(c, s, "tk_k_back", [&] {
-            hipLaunchKernelGGL(tk_k_back, dim3(grid_for(ntiles, 4, 16384)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, rflag, stg, d_out, c->big.as<uint32_t>(), c->row_base.as<uint2>());
+            hipLaunchKernelGGL(tk_k_back, dim3(grid_for(ntiles, 4, 16384)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, rflag, stg, d_out, tok_base, w.big.as<uint32_t>(), w.row_base.as<uint2>());
         }));
         if (n > TK_BIGCOPY)  // (a token run of TK_BIGCOPY tokens needs at least as many bytes)
-            hipLaunchKernelGGL(tk_k_bigcopy, dim3(1024), dim3(256), 0, s, c->big.as<uint32_t>(), stg, d_out);
+            hipLaunchKernelGGL(tk_k_bigcopy, dim3(1024), dim3(256), 0, s, w.big.as<uint32_t>(), stg, d_out, tok_base);
     }
-    if (d_tok_off) {  // (beside the token copy on a second stream it takes as long as behind it: both wait for the same memory system)
+    if (job.d_tok_off) {  // (beside the token copy on a second stream it takes as long as behind it: both wait for the same memory system)
         TRY(timed(c, s, "tk_k_docoff", [&] {
-            hipLaunchKernelGGL(tk_k_docoff, dim3(grid_for(n_docs + 1, 4, 8192)), dim3(256), 0, s, n_docs, d_doc_off, base, n, starts, tile_nt, res, rflag, (n > 0 && !single_piece && d_out) ? c->row_base.as<uint2>() : (const uint2*)nullptr, c->total.as<uint64_t>(), tok_base_global, d_tok_off);
+            hipLaunchKernelGGL(tk_k_docoff, dim3(grid_for(job.n_docs + 1, 4, 8192)), dim3(256), 0, s, job.n_docs, job.d_doc_off, job.base, n, w.starts.as<uint32_t>(), tile_nt, res, rflag, (n > 0 && !job.single_piece) ? w.row_base.as<uint2>() : (const uint2*)nullptr, w.total.as<uint64_t>(), tok_base, job.d_tok_off);
         }));
     }
-    uint64_t tp[2] = {0, 0};  // tokens, pieces
-    uint32_t hb[TK_CNT_N] = {0};
-    HIPCHK(hipMemcpyAsync(tp, c->total.p, 16, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipMemcpyAsync(hb, counters, sizeof hb, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipMemcpyAsync(w.h_total, w.total.p, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipMemcpyAsync(w.h_counters + TK_CNT_N, counters, TK_CNT_N * 4, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipEventRecord(w.ev_done, s));
+    c->st_long += nC;
+    return TK_OK;
+}
+
+// the chunk of `w` is complete: its totals, statistics and error flags (waits for its back stage)
+static int chunk_finish(tk_core* c, WorkSet& w, const ChunkJob& job, uint64_t* n_tokens_out) {
+    HIPCHK(hipEventSynchronize(w.ev_done));
+    const uint32_t* hb = w.h_counters + TK_CNT_N;
+    uint64_t nB = 0;
     for (int b = 0; b < TK_NBIN; ++b) {
         nB += hb[TK_CNT_BIN0 + b];
         if ((c->dbg & 64) && hb[TK_CNT_BIN0 + b]) fprintf(stderr, "bin %d (%u..%u bytes): %u pieces\n", b, tk_bin_lo(b), tk_bin_hi(b), hb[TK_CNT_BIN0 + b]);
     }
-    if (hb[TK_CNT_ERR] & (TK_RX_ERR_GAP | TK_RX_ERR_STACK | TK_RX_ERR_LIMIT)) return rx_failure(hb, base);
+    if (hb[TK_CNT_ERR] & (TK_RX_ERR_GAP | TK_RX_ERR_STACK | TK_RX_ERR_LIMIT)) return rx_failure(hb, job.base);
     if (hb[TK_CNT_ERR]) return fail(TK_RUNTIME_ERROR, "internal error in the front kernel (scanner list overflow, code " + std::to_string(hb[TK_CNT_ERR]) + ")");
-    const uint64_t T_total = tp[0];
-    c->st_bytes += n;
-    c->st_pieces += tp[1];
-    c->st_tokens += T_total;
+    c->st_bytes += job.n;
+    c->st_pieces += w.h_total[1];
+    c->st_tokens += w.h_total[0];
     c->st_medium += nB;
-    c->st_long += nC;
-    *n_tokens_out = T_total;
+    c->st_hot_probes += hb[TK_CNT_HOT_PROBE];
+    c->st_hot_hits += hb[TK_CNT_HOT_HIT];
+    c->st_chunks += 1;
+    *n_tokens_out = w.h_total[0];
     return TK_OK;
+}
+
+// one chunk, both stages on one stream, waited for: the single-chunk entries (pre-tokenise only, single piece)
+static int run_chunk(tk_core* c, hipStream_t s, const uint8_t* d_text, uint64_t n, const uint64_t* d_doc_off, uint64_t n_docs,
+                     uint64_t base, bool use_special, bool single_piece, uint32_t* d_out, uint64_t* d_tok_off, uint64_t* n_tokens_out,
+                     bool pretok_only = false, bool no_lookup = false) {
+    WorkSet& w = c->ws[0];
+    ChunkJob job;
+    TRY(ensure(c->tok_bases, 64));
+    HIPCHK(hipMemsetAsync(c->tok_bases.p, 0, 16, s));
+    TRY(stage_front(c, w, job, s, d_text, n, d_doc_off, n_docs, base, use_special, single_piece, d_tok_off, pretok_only, no_lookup, n_tokens_out));
+    if (pretok_only) return TK_OK;
+    TRY(stage_back(c, w, job, s, d_out, nullptr));
+    return chunk_finish(c, w, job, n_tokens_out);
 }
 
 static int prepare_allowed(tk_core* c, hipStream_t s, const uint32_t* allowed_ids, uint64_t n_allowed, bool* any) {
@@ -721,38 +864,29 @@ struct ChunkHooks {
     std::function<int(uint64_t /*tok_begin*/, uint64_t /*n_tok*/, bool /*last*/)> after;  // a chunk's tokens are final (stream idle)
 };
 
-// Device-resident batch: chunk by documents, run the pipeline per chunk.
+// Device-resident batch: cut into chunks at document boundaries and pipelined -- the front stage of chunk k + 1 is queued (on the
+// caller's stream) before the back stage of chunk k (on the back-stage stream), so the two overlap on the device; TK_NSET work sets.
 static int encode_device_locked(tk_core* c, hipStream_t s, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
                                 const uint64_t* h_doc_off, uint64_t n_docs, bool use_special, uint64_t* n_tokens_out,
                                 uint64_t chunk_bytes = 0, const ChunkHooks* hooks = nullptr) {
     if (!chunk_bytes) chunk_bytes = c->chunk_bytes;
-    c->st_bytes = c->st_pieces = c->st_tokens = c->st_medium = c->st_long = 0;
+    c->st_bytes = c->st_pieces = c->st_tokens = c->st_medium = c->st_long = c->st_hot_probes = c->st_hot_hits = c->st_chunks = 0;
     c->st_docs = n_docs;
-    TRY(ensure(c->out_tokens, tk_pid_cap(n_bytes) * 4));  // (the front kernel parks its miss lists here: tk_pid_cap entries)
+    TRY(ensure(c->out_tokens, (n_bytes + 64) * 4));  // (a token is at least one byte of text)
     TRY(ensure(c->out_tok_off, (n_docs + 2) * 8));
     uint32_t* d_out = c->out_tokens.as<uint32_t>();
     uint64_t* d_tok_off = c->out_tok_off.as<uint64_t>();
-    uint64_t total = 0;
-    // The kernels read the text with aligned 4- and 16-byte loads (some of them through the scalar unit, which ignores the low address
-    // bits): a chunk whose first byte is not 16-byte aligned is copied to an aligned buffer first (a device-to-device copy, ~0.1 ms per
-    // 128 MiB).  Chunk cuts prefer documents that start at an aligned address.
-    auto aligned_text = [&](const uint8_t* p, uint64_t nn, const uint8_t** out) -> int {
-        *out = p;
-        if (((uintptr_t)p & 15u) == 0 || !nn) return TK_OK;
-        TRY(ensure(c->text_al, nn + 256));
-        HIPCHK(hipMemcpyAsync(c->text_al.p, p, nn, hipMemcpyDeviceToDevice, s));
-        HIPCHK(hipMemsetAsync((uint8_t*)c->text_al.p + nn, 0, 128, s));
-        *out = c->text_al.as<uint8_t>();
-        return TK_OK;
+    // chunks: document ranges [d0, d1) of at most chunk_bytes (a longer document is a chunk of its own); cuts prefer documents that
+    // start at a 16-byte aligned address (the kernels read the text with aligned 4- and 16-byte loads, some of them through the scalar
+    // unit, which ignores the low address bits: any other chunk is first copied to an aligned buffer, ~0.1 ms per 128 MiB)
+    struct Cut {
+        uint64_t d0, d1, b, nn;
     };
-    if (n_bytes <= chunk_bytes) {
-        if (hooks && hooks->before) TRY(hooks->before(n_bytes));
-        const uint8_t* tx;
-        TRY(aligned_text(d_utf8, n_bytes, &tx));
-        TRY(run_chunk(c, s, tx, n_bytes, d_doc_off, n_docs, 0, use_special, false, d_out, 0, d_tok_off, &total));
-        if (hooks && hooks->after) TRY(hooks->after(0, total, true));
+    std::vector<Cut> cuts;
+    if (n_bytes <= chunk_bytes || !h_doc_off) {
+        if (n_bytes > chunk_bytes && n_bytes >= (3ull << 30)) return fail(TK_VALUE_ERROR, "h_doc_off is required when n_bytes exceeds the chunk size");
+        cuts.push_back(Cut{0, n_docs, 0, n_bytes});
     } else {
-        if (!h_doc_off) return fail(TK_VALUE_ERROR, "h_doc_off is required when n_bytes exceeds the chunk size");
         uint64_t d0 = 0;
         while (d0 < n_docs) {
             uint64_t d1 = d0 + 1;
@@ -763,19 +897,66 @@ static int encode_device_locked(tk_core* c, hipStream_t s, const uint8_t* d_utf8
                         d1 = q;
                         break;
                     }
-            uint64_t b = h_doc_off[d0], nn = h_doc_off[d1] - b;
+            const uint64_t b = h_doc_off[d0], nn = h_doc_off[d1] - b;
             if (nn >= (4ull << 30) - 65536) return fail(TK_VALUE_ERROR, "a single document of 4 GiB or more is not supported");
-            uint64_t t = 0;
-            if (hooks && hooks->before) TRY(hooks->before(b + nn));
-            const uint8_t* tx;
-            TRY(aligned_text(d_utf8 + b, nn, &tx));
-            TRY(run_chunk(c, s, tx, nn, d_doc_off + d0, d1 - d0, b, use_special, false, d_out + total, total, d_tok_off + d0, &t));
-            if (hooks && hooks->after) TRY(hooks->after(total, t, d1 == n_docs));
-            total += t;
+            cuts.push_back(Cut{d0, d1, b, nn});
             d0 = d1;
         }
+        if (cuts.empty()) cuts.push_back(Cut{0, 0, 0, 0});
     }
+    const size_t N = cuts.size();
+    TRY(ensure(c->tok_bases, (N + 2) * 8));
+    HIPCHK(hipMemsetAsync(c->tok_bases.p, 0, 8, s));  // (before the first front stage on the same stream, which every back stage waits for)
+    ChunkJob jobs[TK_NSET];
+    auto front = [&](size_t k) -> int {
+        WorkSet& w = c->ws[k % TK_NSET];
+        const Cut& q = cuts[k];
+        if (k >= TK_NSET) HIPCHK(hipStreamWaitEvent(s, w.ev_done, 0));  // the set's previous chunk has left its buffers
+        if (hooks && hooks->before) TRY(hooks->before(q.b + q.nn));
+        const uint8_t* tx = d_utf8 + q.b;
+        if (((uintptr_t)tx & 15u) != 0 && q.nn) {
+            TRY(ensure(w.text_al, q.nn + 256));
+            HIPCHK(hipMemcpyAsync(w.text_al.p, tx, q.nn, hipMemcpyDeviceToDevice, s));
+            HIPCHK(hipMemsetAsync((uint8_t*)w.text_al.p + q.nn, 0, 128, s));
+            tx = w.text_al.as<uint8_t>();
+        }
+        TRY(stage_front(c, w, jobs[k % TK_NSET], s, tx, q.nn, d_doc_off + q.d0, q.d1 - q.d0, q.b, use_special, false, d_tok_off + q.d0, false, false, nullptr));
+        jobs[k % TK_NSET].index = (uint32_t)k;
+        return TK_OK;
+    };
+    uint64_t total = 0;
+    auto finish = [&](size_t k) -> int {
+        uint64_t t = 0;
+        TRY(chunk_finish(c, c->ws[k % TK_NSET], jobs[k % TK_NSET], &t));
+        if (hooks && hooks->after) TRY(hooks->after(total, t, k + 1 == N));
+        total += t;
+        return TK_OK;
+    };
+    for (double& x : c->host_us) x = 0;
+    const double t_call = now_us();
+    TRY(front(0));
+    for (size_t k = 0; k < N; ++k) {
+        if (k + 1 < N) {
+            double t0 = now_us();
+            if (k + 1 >= TK_NSET) TRY(finish(k + 1 - TK_NSET));  // (its totals are read before the set is handed to chunk k + 1)
+            c->host_us[3] += now_us() - t0;
+            t0 = now_us();
+            TRY(front(k + 1));
+            c->host_us[0] += now_us() - t0;
+        }
+        const double tb0 = now_us();
+        // a single chunk keeps both stages on the caller's stream; otherwise every set's back stage has a stream of its own
+        WorkSet& w = c->ws[k % TK_NSET];
+        hipStream_t sb = N > 1 ? w.sb : s;
+        if (N > 1) HIPCHK(hipStreamWaitEvent(sb, w.ev_front, 0));
+        TRY(stage_back(c, w, jobs[k % TK_NSET], sb, d_out, (N > 1 && k > 0) ? c->ws[(k - 1) % TK_NSET].ev_tot : (hipEvent_t) nullptr));
+        c->host_us[1] += now_us() - tb0;
+    }
+    const double t_tail = now_us();
+    for (size_t k = N > TK_NSET ? N - TK_NSET : 0; k < N; ++k) TRY(finish(k));
     HIPCHK(hipStreamSynchronize(s));
+    c->host_us[4] = now_us() - t_tail;
+    c->host_us[5] = now_us() - t_call;
     TRY(drain_events(c));
     *n_tokens_out = total;
     return TK_OK;
@@ -1030,14 +1211,13 @@ extern "C" int tk_pretokenize_batch(tk_core* c, const uint8_t* utf8, const uint6
     bool any = false;
     if (use_special) TRY(prepare_allowed(c, s, allowed_ids, n_allowed, &any));
     uint64_t P = 0;
-    TRY(run_chunk(c, s, c->text.as<uint8_t>(), n_bytes, c->doc_off.as<uint64_t>(), n_docs, 0, use_special && any, false, nullptr, 0,
-                  nullptr, &P, true));
+    TRY(run_chunk(c, s, c->text.as<uint8_t>(), n_bytes, c->doc_off.as<uint64_t>(), n_docs, 0, use_special && any, false, nullptr, nullptr, &P, true));
     HIPCHK(hipStreamSynchronize(s));
     TRY(drain_events(c));
     uint32_t* host = (uint32_t*)malloc((P + 1) * 4);
     if (!host) return fail(TK_RUNTIME_ERROR, "out of host memory");
     {
-        hipError_t e = hipMemcpy(host, c->pstart.p, (P + 1) * 4, hipMemcpyDeviceToHost);
+        hipError_t e = hipMemcpy(host, c->ws[0].pstart.p, (P + 1) * 4, hipMemcpyDeviceToHost);
         if (e != hipSuccess) {
             free(host);
             return fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e));
@@ -1066,13 +1246,13 @@ static int single_piece(tk_core* c, const uint8_t* piece, uint64_t len, bool no_
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
-    c->st_bytes = c->st_pieces = c->st_tokens = c->st_medium = c->st_long = 0;
+    c->st_bytes = c->st_pieces = c->st_tokens = c->st_medium = c->st_long = c->st_chunks = 0;
     TRY(ensure(c->text, len + 256));
     if (len) HIPCHK(hipMemcpyAsync(c->text.p, piece, len, hipMemcpyHostToDevice, s));
     HIPCHK(hipMemsetAsync((uint8_t*)c->text.p + len, 0, 128, s));
-    TRY(ensure(c->out_tokens, tk_pid_cap(len) * 4));
+    TRY(ensure(c->out_tokens, (len + 64) * 4));
     uint64_t total = 0;
-    TRY(run_chunk(c, s, c->text.as<uint8_t>(), len, nullptr, 0, 0, false, true, c->out_tokens.as<uint32_t>(), 0, nullptr, &total, false, no_lookup));
+    TRY(run_chunk(c, s, c->text.as<uint8_t>(), len, nullptr, 0, 0, false, true, c->out_tokens.as<uint32_t>(), nullptr, &total, false, no_lookup));
     HIPCHK(hipStreamSynchronize(s));
     TRY(drain_events(c));
     uint32_t* host = (uint32_t*)malloc((total ? total : 1) * 4);
@@ -1457,4 +1637,23 @@ extern "C" void tk_last_stats(tk_core* c, uint64_t* n_bytes, uint64_t* n_pieces,
     if (n_docs) *n_docs = c->st_docs;
     if (n_medium) *n_medium = c->st_medium;
     if (n_long) *n_long = c->st_long;
+}
+extern "C" uint64_t tk_stat(tk_core* c, const char* name) {
+    if (!c || !name) return 0;
+    const std::string k(name);
+    if (k == "hot_probes") return c->st_hot_probes;
+    if (k == "hot_hits") return c->st_hot_hits;
+    if (k == "hot_slots") return TKF_HOT_BITS ? TKF_HOT_SLOTS : 0;
+    if (k == "hot_seed") return c->H.n_hot;
+    if (k == "front_wgs_per_cu") return c->front_wgs;
+    if (k == "compute_units") return c->n_cu;
+    if (k == "chunks") return c->st_chunks;
+    if (k == "host_front_us") return (uint64_t)c->host_us[0];
+    if (k == "host_back_us") return (uint64_t)c->host_us[1];
+    if (k == "host_back_wait_us") return (uint64_t)c->host_us[2];
+    if (k == "host_finish_us") return (uint64_t)c->host_us[3];
+    if (k == "host_tail_us") return (uint64_t)c->host_us[4];
+    if (k == "host_total_us") return (uint64_t)c->host_us[5];
+    if (k == "chunk_bytes") return c->chunk_bytes;
+    return 0;
 }

@@ -139,7 +139,36 @@ struct TkTables {
     TkPat pat;               // the pattern itself
     uint16_t cert[16];       // certain piece starts: cert[a] = classes that always start a piece after a char of class a
                              // (the family's table for the stock patterns; derived per pattern otherwise: tk_pattern.cpp)
+    const uint32_t* hot;     // [TKF_HOT_SLOTS * 4] seed of the front kernel's LDS piece cache (below); null: the cache starts empty
 };
+
+// ------------------------------------------------------------------------------------------
+// The LDS-resident piece cache of the front kernel: an open-addressed (direct-mapped) hash bytes -> rank in the workgroup's LDS, the
+// device form of the reference's "encoder map as a cache" (src/lib.rs:245-260, 367-368).  A workgroup is persistent (it walks over
+// a few hundred tiles), loads the seed -- the lowest-ranked tokens of up to TK_HOT_MAXLEN bytes, placed at tk_create -- once, and
+// then keeps the table current with the pieces its text actually uses: every piece that had to go to the vocabulary tables in HBM
+// replaces the entry of its slot, and so does a piece that is NOT a token once it has its slot of the in-call miss table (its later
+// occurrences in the workgroup's tiles are then duplicates without a probe).  Keys are the piece's bytes, zero padded, plus its
+// length: a hit is an exact match, never a fingerprint.
+//   entry (16 bytes): k0 k1 k2 = the bytes, little-endian; w = len << 28 | payload:
+//     payload bit 27 clear: the token id (ids of 2^27 and above are not cached);
+//     payload bit 27 set  : TK_RES_DUP reference to miss-table slot payload & 0x7FFFFFF (valid for this launch only: the cache dies with it);
+//     len 0 = empty, len 15 = entry being replaced (never equal to a piece's length).
+// ------------------------------------------------------------------------------------------
+#ifndef TKF_HOT_BITS
+#define TKF_HOT_BITS 0  // log2 of the slots per workgroup (10: 16 KiB of LDS); 0 compiles the cache out -- the default, see tk_fused.h
+#endif
+#define TKF_HOT_SLOTS (1u << TKF_HOT_BITS)
+#define TK_HOT_MAXLEN 12u
+#define TK_HOT_DUP (1u << 27)
+#define TK_HOT_PAYLOAD 0x0FFFFFFFu
+#define TK_HOT_LOCK 0xF0000000u
+TK_HD uint32_t tk_hot_slot(uint32_t k0, uint32_t k1, uint32_t k2) {
+    uint32_t h = k0 * 0x9E3779B1u + k1 * 0x85EBCA77u + k2 * 0xC2B2AE3Du;
+    h ^= h >> 15;
+    h *= 0x27D4EB2Fu;
+    return TKF_HOT_BITS ? h >> (32 - (TKF_HOT_BITS ? TKF_HOT_BITS : 1)) : 0u;
+}
 
 TK_HD uint64_t tk_mix64(uint64_t x) {
     x ^= x >> 32;
@@ -169,7 +198,17 @@ TK_HD uint32_t tk_mid_slot(uint64_t key, uint32_t shift) {
     x ^= x >> 15;
     return (x * 0xC2B2AE3Du) >> shift;
 }
-TK_HD uint64_t tk_pair_slot_hash(uint64_t key) { return tk_mix64(key * 0x9FB21C651E98DF25ull + 0x2545F4914F6CDD1Dull); }
+// Bucket of a pair key: 32-bit multiplies only (this sits on the dependent chain of every merge -- two probes per merge, one merge
+// after the other; a 64-bit mixer is three 64-bit multiplies = a dozen quarter-rate instructions in a row).
+TK_HD uint64_t tk_pair_slot_hash(uint64_t key) {
+    uint32_t x = (uint32_t)key * 0x9E3779B1u + (uint32_t)(key >> 32) * 0x85EBCA77u;
+    x ^= x >> 15;
+    x *= 0x2C1B3C6Du;
+    x ^= x >> 12;
+    x *= 0x297A2D39u;
+    x ^= x >> 15;
+    return x;
+}
 
 // streaming hash for keys longer than 8 bytes: fold 8-byte little-endian words (last one zero padded)
 TK_HD uint64_t tk_hash_step(uint64_t h, uint64_t w) {

@@ -481,8 +481,18 @@ __device__ __forceinline__ bool tk_equal_lds_text(const uint8_t* raw, uint32_t o
 // a piece that leaves its window -- about 3 % of the tiles of ordinary text) is not finished here: it goes on the `deferred` list.
 // SLOW = true: the same kernel with that scanner compiled in (its calls cost registers: kept out of the common path), launched over the
 // deferred tiles with a fixed grid.
+// Workgroups per CU.  20 KiB of LDS per tile x 8 = the CU's 160 KiB, and 8 x 4 wavefronts = its 32 wavefront slots: the kernel needs all
+// of them (measured, profiles/r03_lds_cache_experiment.jsonl: a workgroup takes ~39 us per tile however many share the CU, so the rate
+// is proportional to the workgroups in flight -- 5.9 ms per GiB with 8 per CU, 10.6 with 4, 13.6 with 3).  That is why the LDS piece
+// cache below is compiled out by default (TKF_HOT_BITS = 0): its 16-32 KiB per workgroup cost more in occupancy than its hits save.
+#ifndef TKF_OCC
+#define TKF_OCC 8
+#endif
+#ifndef TKF_ROWS
+#define TKF_ROWS 1  // phase F: one length class per row of 64 pieces (0: the three classes side by side in every lane)
+#endif
 template <int PAT, bool SPEC, bool SLOW>
-__global__ __launch_bounds__(256, SLOW ? 4 : 8) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
+__global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
                                                   const uint32_t* __restrict__ brk, const uint32_t* __restrict__ docb,
                                                   const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, TkFrontOut out,
                                                   TkMissSlot* __restrict__ mt, uint32_t mt_mask, uint32_t* __restrict__ deferred, int dbg) {
@@ -509,6 +519,10 @@ __global__ __launch_bounds__(256, SLOW ? 4 : 8) void tk_k_front(TkTables T, cons
     __shared__ uint32_t nslow_sh;
     __shared__ uint32_t brkw[TK2_WIN / 32 + 1], ssw[SPEC ? TK2_WIN / 32 + 1 : 1], siw[SPEC ? TK2_WIN / 32 + 1 : 1];
     __shared__ uint32_t scan_sh[8];
+    // the LDS piece cache (tk_common.h): lives as long as the workgroup, i.e. over all the tiles it walks
+    constexpr bool HOT = !SLOW && TKF_HOT_BITS > 0;
+    __shared__ __attribute__((aligned(16))) uint32_t hot[HOT ? TKF_HOT_SLOTS * 4 : 4];
+    __shared__ __attribute__((aligned(16))) uint32_t hot_mask[HOT ? 16 * 4 : 4];  // [len] -> byte masks of the three key words
     uint64_t(*bm)[NW] = (uint64_t(*)[NW])pool;
     uint16_t* clist = (uint16_t*)(pool + BM_BYTES);
     uint16_t* plist = (uint16_t*)pool;  // valid after the scanners are done
@@ -522,9 +536,25 @@ __global__ __launch_bounds__(256, SLOW ? 4 : 8) void tk_k_front(TkTables T, cons
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     uint32_t item = blockIdx.x;
-    if (SLOW && item >= out.counters[TK_CNT_DEFER]) return;
-    do {  // (SLOW: a fixed grid walks the deferred list; otherwise one tile per workgroup)
-    if (SLOW && item != blockIdx.x) __syncthreads();  // (the shared arrays are reused by the next tile)
+    // SLOW, and the variant with the piece cache: persistent, a fixed grid walks the deferred list / the tiles with the stride of the
+    // grid.  Otherwise one tile per workgroup (the loop's state would cost registers the kernel does not have at eight workgroups per CU).
+    constexpr bool PERSIST = SLOW || HOT;
+    const uint32_t n_items = SLOW ? out.counters[TK_CNT_DEFER] : (PERSIST ? (uint32_t)((n + TK_TILE - 1) / TK_TILE) : gridDim.x);
+    if (PERSIST && item >= n_items) return;
+    const bool use_hot = HOT && !(dbg & 0x200000);  // (debug bit 0x200000: the piece cache is never consulted)
+    uint32_t hot_probes = 0, hot_hits = 0;         // per lane; summed into the counters when the workgroup is done
+    if constexpr (HOT) {
+        for (uint32_t i = tid; i < TKF_HOT_SLOTS; i += 256)
+            *(uint4*)&hot[i * 4] = (T.hot && use_hot) ? *(const uint4*)&T.hot[i * 4] : make_uint4(0, 0, 0, 0);
+        if (tid < 16) {
+            uint32_t m[3];
+#pragma unroll
+            for (int j = 0; j < 3; ++j) m[j] = tid >= 4u * j + 4u ? 0xFFFFFFFFu : (tid <= 4u * j ? 0u : ((1u << (8u * (tid - 4u * j))) - 1u));
+            *(uint4*)&hot_mask[tid * 4] = make_uint4(m[0], m[1], m[2], 0u);
+        }
+    }
+    do {
+    if (PERSIST && item != blockIdx.x) __syncthreads();  // (the shared arrays are reused by the next tile)
     const uint64_t tile = SLOW ? (uint64_t)deferred[item] : (uint64_t)item;
     auto defer_tile = [&]() {
         if (tid == 0) deferred[atomicAdd(&out.counters[TK_CNT_DEFER], 1u)] = (uint32_t)tile;
@@ -986,6 +1016,30 @@ __global__ __launch_bounds__(256, SLOW ? 4 : 8) void tk_k_front(TkTables T, cons
     uint16_t* ord_x = (uint16_t*)(pool + TK_TILE * 2);  // [1024] pieces that are not tokens (behind the piece list)
     const uint32_t* dwr = (const uint32_t*)raw;
     const bool short_tab = T.short_tab != nullptr;
+    // key of the piece cache: the (at most twelve) bytes at window offset s_loc, zero padded
+    auto hot_key = [&](uint32_t s_loc, uint32_t len, uint32_t& k0, uint32_t& k1, uint32_t& k2) {
+        const uint32_t wi = s_loc >> 2, sft = s_loc & 3u;
+        const uint32_t d0 = dwr[wi], d1 = dwr[wi + 1], d2 = dwr[wi + 2], d3 = dwr[wi + 3];
+        const uint4 m = *(const uint4*)&hot_mask[len * 4];
+        k0 = __builtin_amdgcn_alignbyte(d1, d0, sft) & m.x;
+        k1 = __builtin_amdgcn_alignbyte(d2, d1, sft) & m.y;
+        k2 = __builtin_amdgcn_alignbyte(d3, d2, sft) & m.z;
+    };
+    // A piece that went to the tables in HBM replaces the entry of its slot.  Lanes of any wavefront may do this at the same time (never
+    // while anyone probes: barriers separate the phases): the exchange of the entry's last word makes ONE of them the writer -- whoever
+    // finds the "being replaced" mark backs off, and the writer's final store of that word (after the key words) lifts the mark.
+    auto hot_insert = [&](uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, uint32_t payload) {
+        if constexpr (HOT) {
+            uint32_t* e = &hot[tk_hot_slot(k0, k1, k2) * 4];
+            const uint32_t old = __hip_atomic_exchange(&e[3], TK_HOT_LOCK, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            if ((old >> 28) != 15u) {
+                e[0] = k0;
+                e[1] = k1;
+                e[2] = k2;
+                __hip_atomic_store(&e[3], (len << 28) | payload, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+            }
+        }
+    };
     for (uint32_t kb = 0; kb < np; kb += TKF_BATCH) {
         const uint32_t nb = np - kb < TKF_BATCH ? np - kb : (uint32_t)TKF_BATCH;
         if (tid == 0) {
@@ -1005,6 +1059,16 @@ __global__ __launch_bounds__(256, SLOW ? 4 : 8) void tk_k_front(TkTables T, cons
                 if (SPEC && ((ssw[s_loc >> 5] >> (s_loc & 31u)) & 1u)) {  // a special token: its id (src/lib.rs:426-434)
                     out.res[run_base + k] = tk_special_id(T, text, (uint64_t)(base + s_loc), len);
                     cls = 3;
+                } else if (HOT && use_hot && len <= TK_HOT_MAXLEN) {  // the piece cache in LDS first; the tables in HBM only on a miss
+                    uint32_t k0, k1, k2;
+                    hot_key(s_loc, len, k0, k1, k2);
+                    const uint4 e = *(const uint4*)&hot[tk_hot_slot(k0, k1, k2) * 4];
+                    ++hot_probes;
+                    if (e.x == k0 && e.y == k1 && e.z == k2 && (e.w >> 28) == len) {
+                        out.res[run_base + k] = (e.w & TK_HOT_DUP) ? (TK_RES_DUP | (e.w & (TK_HOT_DUP - 1u))) : (e.w & TK_HOT_PAYLOAD);
+                        ++hot_hits;
+                        cls = 3;
+                    }
                 }
             }
             const uint64_t m0 = __ballot(cls == 0u), m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u);
@@ -1030,6 +1094,75 @@ __global__ __launch_bounds__(256, SLOW ? 4 : 8) void tk_k_front(TkTables T, cons
                 if (miss) ord_x[at] = (uint16_t)i;
             }
         };
+#if TKF_ROWS
+        // F1..F3 by rows of 64 pieces of ONE length class: a wavefront takes every fourth row (long pieces first: the dearest rows are
+        // spread evenly) and runs that class's probe only -- a third of the instructions of the earlier form, in which every lane ran
+        // the short, the mid and the long path in every round however few pieces of a class were left (the kernel is bound by the
+        // vector ALU's issue rate; the eight wavefronts per SIMD keep enough probes in flight).
+        //   short: the bytes are the key (one unaligned LDS dword), 8-byte slots
+        //   mid  : 64-bit key, 16-byte slots
+        //   long : hash of the bytes, candidates verified against the token blob
+        const uint32_t rows_l = (n_l + 63u) >> 6, rows_m = (n_m + 63u) >> 6, rows_s = (n_s + 63u) >> 6;
+        for (uint32_t r = (uint32_t)wid; r < rows_l + rows_m + rows_s; r += 4u) {
+            bool miss = false;
+            uint32_t i_p = 0;
+            if (r < rows_l) {
+                const uint32_t q = r * 64u + (uint32_t)lane;
+                if (q < n_l) {
+                    i_p = ord_sl[1023u - q];
+                    const uint32_t k_l = kb + i_p, sloc_l = plist[k_l];
+                    const uint32_t e_loc = k_l + 1 < np ? (uint32_t)plist[k_l + 1] : last_end;
+                    const uint32_t len_l = e_loc - sloc_l;
+                    const uint64_t gs_l = (uint64_t)(base + sloc_l);
+                    const bool in_lds = e_loc + 8u <= (uint32_t)TK2_WIN;
+                    uint32_t rk = TK_RANK_MAX;
+                    if (dbg & 2) rk = len_l;
+                    else if (len_l <= T.max_token_len) {  // (longer than every token: not a token, and no reason to hash a megabyte)
+                        const uint64_t key_l = in_lds ? tk_key_of_lds(raw, sloc_l, len_l) : tk_key_of_text(text, gs_l, len_l);
+                        const uint64_t at_l = tk_piece_slot_hash(key_l, len_l) & T.piece_mask;
+                        rk = tk_probe_piece_from(T, key_l, len_l, at_l, T.piece[at_l], [&](uint32_t off) {
+                            return in_lds ? tk_equal_lds_text(raw, sloc_l, T.tok_bytes, off, len_l) : tk_equal_bytes(text, gs_l, T.tok_bytes, off, len_l);
+                        });
+                    }
+                    if (rk != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k_l] = rk == TK_RANK_MAX ? 0u : rk;
+                    else miss = true;
+                    if (use_hot && rk < TK_HOT_DUP && len_l <= TK_HOT_MAXLEN) {
+                        uint32_t k0, k1, k2;
+                        hot_key(sloc_l, len_l, k0, k1, k2);
+                        hot_insert(k0, k1, k2, len_l, rk);
+                    }
+                }
+            } else if (r < rows_l + rows_m) {
+                const uint32_t q = (r - rows_l) * 64u + (uint32_t)lane;
+                if (q < n_m) {
+                    i_p = ord_m[q];
+                    const uint32_t k_m = kb + i_p;
+                    const uint32_t s_loc = plist[k_m], e_loc = k_m + 1 < np ? (uint32_t)plist[k_m + 1] : last_end;
+                    const uint32_t len_m = e_loc - s_loc;
+                    const uint64_t key_m = tk_mask_low_bytes(tk_lds_load8(raw, s_loc), len_m);
+                    const uint32_t rk = (dbg & 2) ? len_m : tk_probe_mid(T, key_m, len_m);
+                    if (rk != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k_m] = rk == TK_RANK_MAX ? 0u : rk;
+                    else miss = true;
+                    if (use_hot && rk < TK_HOT_DUP) hot_insert((uint32_t)key_m, (uint32_t)(key_m >> 32), 0u, len_m, rk);
+                }
+            } else {
+                const uint32_t q = (r - rows_l - rows_m) * 64u + (uint32_t)lane;
+                if (q < n_s) {
+                    i_p = ord_sl[q];
+                    const uint32_t k_s = kb + i_p;
+                    const uint32_t s_loc = plist[k_s], e_loc = k_s + 1 < np ? (uint32_t)plist[k_s + 1] : last_end;
+                    const uint32_t len_s = e_loc - s_loc;
+                    const uint32_t v = __builtin_amdgcn_alignbyte(dwr[(s_loc >> 2) + 1], dwr[s_loc >> 2], s_loc & 3u);
+                    const uint32_t key_s = v & (0xFFFFFFFFu >> (32u - 8u * len_s));
+                    const uint32_t rk = (dbg & 2) ? len_s : (short_tab ? tk_probe_short(T, key_s, len_s) : tk_probe_mid(T, (uint64_t)key_s, len_s));
+                    if (rk != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k_s] = rk == TK_RANK_MAX ? 0u : rk;
+                    else miss = true;
+                    if (use_hot && rk < TK_HOT_DUP) hot_insert(key_s, 0u, 0u, len_s, rk);
+                }
+            }
+            not_a_token(miss, i_p);
+        }
+#else
         // F1..F3 in one loop: a lane takes the q-th short, mid and long piece together, so that the first table loads of the three
         // independent probes are in flight at the same time (the probes are latency-bound: profiles/r02_front_phases_*.csv).
         //   short: the bytes are the key (one unaligned LDS dword), 8-byte slots
@@ -1093,11 +1226,13 @@ __global__ __launch_bounds__(256, SLOW ? 4 : 8) void tk_k_front(TkTables T, cons
                                                                   : tk_probe_mid_from(T, (uint64_t)key_s, len_s, at_s, slot_sm));
                 if (r != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k_s] = r == TK_RANK_MAX ? 0u : r;
                 else miss_s = true;
+                if (use_hot && r < TK_HOT_DUP) hot_insert(key_s, 0u, 0u, len_s, r);
             }
             if (has_m) {
                 const uint32_t r = (dbg & 2) ? len_m : tk_probe_mid_from(T, key_m, len_m, at_m, slot_m);
                 if (r != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k_m] = r == TK_RANK_MAX ? 0u : r;
                 else miss_m = true;
+                if (use_hot && r < TK_HOT_DUP) hot_insert((uint32_t)key_m, (uint32_t)(key_m >> 32), 0u, len_m, r);
             }
             if (has_l) {
                 const uint32_t r = (dbg & 2) ? len_l : too_long ? TK_RANK_MAX : tk_probe_piece_from(T, key_l, len_l, at_l, slot_l, [&](uint32_t off) {
@@ -1105,25 +1240,37 @@ __global__ __launch_bounds__(256, SLOW ? 4 : 8) void tk_k_front(TkTables T, cons
                 });
                 if (r != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k_l] = r == TK_RANK_MAX ? 0u : r;
                 else miss_l = true;
+                if (use_hot && r < TK_HOT_DUP && len_l <= TK_HOT_MAXLEN) {
+                    uint32_t k0, k1, k2;
+                    hot_key(sloc_l, len_l, k0, k1, k2);
+                    hot_insert(k0, k1, k2, len_l, r);
+                }
             }
             not_a_token(miss_s, i_s);
             not_a_token(miss_m, i_m);
             not_a_token(miss_l, i_l);
         }
+#endif
         __syncthreads();
         // F4: pieces that are not tokens.  In-call de-duplication: claim a slot of the miss table (first occurrence: goes on the
         // tile's miss list and gets merged) or find it claimed by IDENTICAL bytes -- pieces of <= 7 bytes carry their bytes in the
         // slot, longer ones are compared with the claimant's text -- and only record the slot (resolved by tk_k_tile_finish).
         // Slots are written once, so a cached load can only be stale towards "empty", where the atomic decides.
         const uint32_t n_x = nx_sh;
+#if TKF_ROWS
+        for (uint32_t q0 = (uint32_t)wid * 64u; q0 < n_x; q0 += 256u) {  // (rows of 64: a wavefront without pieces does not run the body)
+            const uint32_t q = q0 + (uint32_t)lane;
+#else
         for (uint32_t q0 = 0; q0 < n_x; q0 += 256) {
             const uint32_t q = q0 + tid;
+#endif
             bool listed = false;
-            uint32_t k = 0, len = 0, slot = TKF_NONE;
+            uint32_t k = 0, len = 0, slot = TKF_NONE, dup_slot = TKF_NONE, s_loc = 0;
             uint64_t gs = 0;
             if (q < n_x) {
                 k = kb + ord_x[q];
-                const uint32_t s_loc = plist[k], e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
+                s_loc = plist[k];
+                const uint32_t e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
                 len = e_loc - s_loc;
                 gs = (uint64_t)(base + s_loc);
                 listed = true;
@@ -1162,6 +1309,7 @@ __global__ __launch_bounds__(256, SLOW ? 4 : 8) void tk_k_front(TkTables T, cons
                             if (a != TK_EMPTY_KEY && same) {
                                 out.res[run_base + k] = TK_RES_DUP | i;
                                 listed = false;
+                                dup_slot = i;
                                 break;
                             }
                         }
@@ -1183,11 +1331,28 @@ __global__ __launch_bounds__(256, SLOW ? 4 : 8) void tk_k_front(TkTables T, cons
                     if (len > TK_GLANE_MAX) tk_append_tree(out.listC, out.counters, mi, (uint32_t)gs, len);
                 }
             }
+            // its later occurrences in this workgroup's tiles are duplicates without a probe: the slot goes into the piece cache
+            if (use_hot && q < n_x && len <= TK_HOT_MAXLEN) {
+                const uint32_t sl = listed ? slot : dup_slot;
+                if (sl != TKF_NONE) {
+                    uint32_t k0, k1, k2;
+                    hot_key(s_loc, len, k0, k1, k2);
+                    hot_insert(k0, k1, k2, len, TK_HOT_DUP | sl);
+                }
+            }
         }
         __syncthreads();  // (the lists are reused by the next batch)
     }
     if (tid == 0) out.tile_nmiss[tile] = nmiss_sh;
-    } while (SLOW && (item += gridDim.x) < out.counters[TK_CNT_DEFER]);
+    } while (PERSIST && (item += gridDim.x) < n_items);
+    if constexpr (HOT) {  // statistics of the piece cache (two fire-and-forget atomics per wavefront)
+        hot_probes = tk_wave_sum_u32(hot_probes);
+        hot_hits = tk_wave_sum_u32(hot_hits);
+        if (lane == 0 && hot_probes) {
+            __hip_atomic_fetch_add(&out.counters[TK_CNT_HOT_PROBE], hot_probes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+            __hip_atomic_fetch_add(&out.counters[TK_CNT_HOT_HIT], hot_hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        }
+    }
 }
 
 // The pieces on the tiles' miss lists (first occurrences: duplicates were resolved by the front kernel) have to be
@@ -1962,8 +2127,12 @@ __global__ __launch_bounds__(256) void tk_k_tile_finish(uint64_t ntiles, const u
 // eight lanes per piece.
 __global__ __launch_bounds__(256) void tk_k_back(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_tb,
                                                  const uint32_t* __restrict__ res, const uint2* __restrict__ rflag, const uint32_t* __restrict__ staging,
-                                                 uint32_t* __restrict__ out, uint32_t* __restrict__ big, uint2* __restrict__ row_base) {
+                                                 uint32_t* __restrict__ out_all, const unsigned long long* __restrict__ tok_base, uint32_t* __restrict__ big,
+                                                 uint2* __restrict__ row_base) {
     __shared__ uint32_t mlist_sh[4][256 * 3];
+    // the chunk's tokens follow those of the chunks before it: their number stays on the device (chunks are pipelined, the host does
+    // not know it when it queues this kernel)
+    uint32_t* __restrict__ out = out_all + tok_base[0];
     const int lane = threadIdx.x & 63;
     uint32_t* mlist = mlist_sh[threadIdx.x >> 6];
     const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
@@ -2054,7 +2223,9 @@ __global__ __launch_bounds__(256) void tk_k_back(uint64_t ntiles, const uint32_t
 
 // the token runs of very long pieces (big[0] entries {staging position, output position, count} recorded by tk_k_back): every entry is
 // copied by the whole grid
-__global__ __launch_bounds__(256) void tk_k_bigcopy(const uint32_t* __restrict__ big, const uint32_t* __restrict__ staging, uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void tk_k_bigcopy(const uint32_t* __restrict__ big, const uint32_t* __restrict__ staging, uint32_t* __restrict__ out_all,
+                                                    const unsigned long long* __restrict__ tok_base) {
+    uint32_t* __restrict__ out = out_all + tok_base[0];
     const uint32_t nb = big[0] < TK_BIGCOPY_CAP ? big[0] : (uint32_t)TK_BIGCOPY_CAP;
     for (uint32_t e = 0; e < nb; ++e) {
         const uint32_t src = big[1 + 3 * e], dst = big[2 + 3 * e], cc = big[3 + 3 * e];
@@ -2083,7 +2254,8 @@ __global__ __launch_bounds__(1024) void tk_k_sum_pieces(const uint32_t* __restri
 __global__ __launch_bounds__(256) void tk_k_docoff(uint64_t n_docs, const uint64_t* __restrict__ doc_off, uint64_t chunk_base, uint64_t n,
                                                     const uint32_t* __restrict__ starts, const uint32_t* __restrict__ tile_tb,
                                                     const uint32_t* __restrict__ res, const uint2* __restrict__ rflag, const uint2* __restrict__ row_base,
-                                                    const uint64_t* __restrict__ total, uint64_t tok_base_global, uint64_t* __restrict__ tok_off) {
+                                                    const uint64_t* __restrict__ total, const unsigned long long* __restrict__ tok_base, uint64_t* __restrict__ tok_off) {
+    const uint64_t tok_base_global = tok_base[0];  // tokens of the chunks before this one
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
     for (uint64_t d = wave; d <= n_docs; d += nwaves) {
@@ -2124,6 +2296,11 @@ __global__ __launch_bounds__(256) void tk_k_docoff(uint64_t n_docs, const uint64
         }
         if (lane == 0) tok_off[d] = tok_base_global + v;
     }
+}
+
+// chunk k knows its token count: the next chunk's tokens start behind them (tok_bases[0] = 0)
+__global__ void tk_k_advance(unsigned long long* __restrict__ tok_bases, uint32_t k, const uint64_t* __restrict__ total) {
+    if (blockIdx.x == 0 && threadIdx.x == 0) tok_bases[k + 1] = tok_bases[k] + total[0];
 }
 
 // encode_single_piece (src/py.rs:145-150): the whole buffer is one piece, no pre-tokenisation

@@ -32,7 +32,7 @@ struct TkBins {
 };
 
 // counters (device uint32 array)
-enum { TK_CNT_B = 0, TK_CNT_C = 1, TK_CNT_CBYTES = 2, TK_CNT_CLEVELS = 3, TK_CNT_DUP = 4, TK_CNT_COLL = 5, TK_CNT_ERR = 6, TK_CNT_DEFER = 7, TK_CNT_BIN0 = 8, TK_CNT_RXPOS = 8 + TK_NBIN + 1, TK_CNT_N = 8 + TK_NBIN + 2 };
+enum { TK_CNT_B = 0, TK_CNT_C = 1, TK_CNT_CBYTES = 2, TK_CNT_CLEVELS = 3, TK_CNT_DUP = 4, TK_CNT_COLL = 5, TK_CNT_ERR = 6, TK_CNT_DEFER = 7, TK_CNT_BIN0 = 8, TK_CNT_RXPOS = 8 + TK_NBIN + 1, TK_CNT_HOT_PROBE = 8 + TK_NBIN + 2, TK_CNT_HOT_HIT = 8 + TK_NBIN + 3, TK_CNT_N = 8 + TK_NBIN + 4 };
 // (TK_CNT_ERR: bits 1, 2 scanner lists of the front kernel; bits 4, 8 the generic pat_str engine -- tk_regex_split.h; TK_CNT_RXPOS: ~position of its first error)
 
 #define TK_MT_BITS 22   // most slots of the in-call miss table (tk_fused.h); sized by the chunk
@@ -100,6 +100,25 @@ __device__ __forceinline__ uint32_t tk_wave_append(bool want, uint32_t* counter,
     if (lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
     base = __shfl(base, leader, 64);
     return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+
+// ------------------------------------------------------------------------------------------
+// Start of a chunk: every buffer that has to be zero (or all ones) before the kernels run, in ONE launch (a hipMemsetAsync per buffer
+// costs the host 30-60 us each, and with pipelined chunks the host's time per chunk is what bounds the pipeline).
+// ------------------------------------------------------------------------------------------
+#define TK_CLEAR_MAX 14
+struct TkClearArgs {
+    uint4* p[TK_CLEAR_MAX];
+    uint64_t n16[TK_CLEAR_MAX];  // 16-byte units
+    uint32_t v[TK_CLEAR_MAX];    // fill word
+    int n;
+};
+__global__ __launch_bounds__(256) void tk_k_chunk_clear(TkClearArgs a) {
+    const uint64_t gtid = blockIdx.x * 256ull + threadIdx.x, gthreads = (uint64_t)gridDim.x * 256;
+    for (int r = 0; r < a.n; ++r) {
+        const uint4 x = make_uint4(a.v[r], a.v[r], a.v[r], a.v[r]);
+        for (uint64_t i = gtid; i < a.n16[r]; i += gthreads) a.p[r][i] = x;
+    }
 }
 
 // ------------------------------------------------------------------------------------------

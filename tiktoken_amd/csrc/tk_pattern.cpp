@@ -27,10 +27,16 @@
 
 namespace {
 
-// the pattern without possessive markers: a '+' right behind a quantifier (?, *, +, {m,n}) -- same matches for these patterns
-std::string strip_possessive(const std::string& s) {
-    std::string o;
+// The pattern without possessive markers (a '+' right behind a quantifier: ?, *, +, {m,n}).  A marker is dropped only where it cannot
+// change a match: the quantified atom is one of the families' atoms whose class is disjoint from everything that may follow it in a
+// member of the family (a give-back never helps there), or it is \s with nothing behind it but `$` or the end of the alternative.
+// Anywhere else -- `\s++(?!\S)` matches at the end of the text only, `\s*+[\r\n]+` never, `[\p{Lu}..\p{Lo}]*+[\p{Ll}..\p{Lo}]+` fails
+// on a run of \p{Lo} -- *unsafe is set and the caller leaves the pattern to the generic engine, which implements possessive repeats.
+std::string strip_possessive(const std::string& s, bool* unsafe) {
+    std::string o, atom;
     bool in_class = false, prev_quant = false, prev_open = false;
+    *unsafe = false;
+    size_t class_from = 0;
     for (size_t i = 0; i < s.size(); ++i) {
         const char c = s[i];
         if (c == '\\' && i + 1 < s.size()) {  // an escape is one token: \s, \p{L}
@@ -40,18 +46,23 @@ std::string strip_possessive(const std::string& s) {
                 ++j;
             }
             o.append(s, i, j - i);
+            if (!in_class) atom.assign(s, i, j - i);
             i = j - 1;
             prev_quant = prev_open = false;
             continue;
         }
         if (in_class) {
-            if (c == ']') in_class = false;
+            if (c == ']') {
+                in_class = false;
+                atom.assign(s, class_from, i - class_from + 1);
+            }
             o += c;
             prev_quant = prev_open = false;
             continue;
         }
         if (c == '[') {
             in_class = true;
+            class_from = i;
             o += c;
             prev_quant = prev_open = false;
             continue;
@@ -67,9 +78,16 @@ std::string strip_possessive(const std::string& s) {
         }
         if (c == '+' && prev_quant) {  // possessive marker
             prev_quant = false;
+            static const char* const SAFE[] = {" ", "[^\\r\\n\\p{L}\\p{N}]", "\\p{L}", "[\\p{L}]", "\\p{N}", "[\\p{N}]", "[^\\s\\p{L}\\p{N}]", "[\\r\\n]", "[\\n\\r]",
+                                               "[\\r\\n/]", "[/\\r\\n]", "[\\n\\r/]", "/", "[/]"};
+            bool ok = false;
+            for (const char* a : SAFE) ok = ok || atom == a;
+            if (atom == "\\s") ok = i + 1 >= s.size() || s[i + 1] == '$' || s[i + 1] == '|';
+            if (!ok) *unsafe = true;
             continue;
         }
         const bool quant = (c == '?' && !prev_open) || c == '*' || c == '+';
+        if (!quant) atom.assign(1, c);
         o += c;
         prev_open = c == '(';
         prev_quant = quant;
@@ -276,7 +294,11 @@ void tk_derive_certain(const TkPat& pat, uint16_t* cert) {
 
 std::string tk_parse_pattern(const char* pat_str, TkPat* out, uint16_t* cert_out) {
     if (!pat_str) return "pat_str is null";
-    std::string s = strip_possessive(pat_str);
+    bool possessive_matters = false;
+    std::string s = strip_possessive(pat_str, &possessive_matters);
+    if (possessive_matters)
+        return std::string("unsupported pat_str: a possessive quantifier at a place where it changes the matches (the scanner families "
+                           "are written for the backtracking forms); pattern: ") + pat_str;
     replace_all(s, "[\\p{L}]", "\\p{L}");
     replace_all(s, "[\\p{N}]", "\\p{N}");
     std::vector<std::string> alts = split_top(s);

@@ -218,6 +218,29 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
             return "every single byte must be a key of mergeable_ranks (byte_pair_encode indexes ranks[piece] for "
                    "1-byte pieces, src/lib.rs:201-203)";
 
+    // Seed of the LDS piece cache (tk_common.h): tokens of up to TK_HOT_MAXLEN bytes in rank order -- a low rank is a frequent
+    // string of the training text -- each into the slot of its bytes while that slot is free.  The kernel replaces entries with
+    // the pieces its text really uses, so the seed only has to be a fair first guess.
+    if (TKF_HOT_BITS) {
+        T.hot.assign((size_t)TKF_HOT_SLOTS * 4, 0u);
+        std::vector<uint64_t> by_rank(n_ranks);
+        std::iota(by_rank.begin(), by_rank.end(), 0);
+        std::sort(by_rank.begin(), by_rank.end(), [&](uint64_t a, uint64_t b) { return ranks_ids[a] < ranks_ids[b]; });
+        for (uint64_t k : by_rank) {
+            const uint32_t len = (uint32_t)(ranks_off[k + 1] - ranks_off[k]), rank = ranks_ids[k];
+            if (len > TK_HOT_MAXLEN || rank >= TK_HOT_DUP) continue;
+            uint32_t kw[3] = {0, 0, 0};
+            memcpy(kw, ranks_blob + ranks_off[k], len);
+            uint32_t* e = &T.hot[(size_t)tk_hot_slot(kw[0], kw[1], kw[2]) * 4];
+            if (e[3]) continue;
+            e[0] = kw[0];
+            e[1] = kw[1];
+            e[2] = kw[2];
+            e[3] = (len << 28) | rank;
+            if (++T.n_hot == TKF_HOT_SLOTS) break;
+        }
+    }
+
     // pair table: all splits of all tokens into two vocabulary tokens (read-only lookups: split over host threads)
     std::vector<TkPairSlot> entries;
     {

@@ -31,6 +31,8 @@ struct TkHostTables {
     uint64_t n_pairs = 0;
     std::vector<uint32_t> pair2;
     uint32_t byte_rank[256];
+    std::vector<uint32_t> hot;  // seed of the front kernel's LDS piece cache: TKF_HOT_SLOTS entries of four words (tk_common.h)
+    uint32_t n_hot = 0;         // tokens placed in it
     std::vector<uint8_t> spec_bytes;
     std::vector<uint32_t> spec_off, spec_id;
     uint32_t spec_first[8];
