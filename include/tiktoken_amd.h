@@ -120,10 +120,15 @@ uint32_t tk_group_size(tk_group* group);
 int tk_group_encode_batch(tk_group* group, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special,
                           const uint32_t* allowed_ids, uint64_t n_allowed, uint32_t** tokens_out, uint64_t* n_tokens_out,
                           uint64_t* tok_off_out);
-/* results gathered on the first core's device with one peer copy per other core (xGMI); the pointers are owned by the group */
+/* Results gathered on the first core's device; only the text crosses PCIe (every shard's ids stay on its device until the gather).
+ * The gather is ONE exchange over xGMI: grouped ncclSend / ncclRecv through RCCL (rccl.h:700-722, loaded on first use) when the
+ * group's devices are pairwise distinct, concurrent peer copies (one stream per source device) when a device is named twice or
+ * RCCL cannot be loaded ($TIKTOKEN_AMD_NO_RCCL forces the latter).  The pointers are owned by the group (valid until its next call). */
 int tk_group_encode_batch_device(tk_group* group, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special,
                                  const uint32_t* allowed_ids, uint64_t n_allowed, const uint32_t** d_tokens_out, uint64_t* n_tokens_out,
                                  const uint64_t** d_tok_off_out);
+/* "gathers_rccl" / "gathers_peer": how many device gathers of this group ran on RCCL / on peer copies */
+uint64_t tk_group_stat(tk_group* group, const char* name);
 
 /* Vocabulary wire format: the text of a `.tiktoken` file (`base64(token) SP rank` per line) -> the packed arrays tk_create takes.
  * Replaces the per-line Python loop of tiktoken/load.py:159-171.  Release the three arrays with tk_free.  TK_VALUE_ERROR with

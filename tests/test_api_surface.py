@@ -120,3 +120,15 @@ def test_shaped_vocab_files_parse_like_reference_format():
     assert sorted(ranks.values()) == list(range(50256))
     order = vocab_io.data_gym_byte_order()
     assert [ranks[bytes([b])] for b in order] == list(range(256))
+
+
+def test_model_table():
+    """reference tiktoken/model.py:88-105 and tests/test_misc.py: exact names, dated versions through prefixes, the longest prefix decides."""
+    f = tiktoken_amd.encoding_name_for_model
+    assert f("gpt2") == "gpt2" and f("text-davinci-003") == "p50k_base" and f("text-davinci-edit-001") == "p50k_edit"
+    assert f("gpt-3.5-turbo-0301") == "cl100k_base" and f("gpt-4") == "cl100k_base" and f("gpt-4-32k") == "cl100k_base"
+    assert f("gpt-4o") == "o200k_base" and f("gpt-4o-2024-05-13") == "o200k_base" and f("gpt-oss-120b") == "o200k_harmony"
+    assert f("ft:gpt-4o:org") == "o200k_base" and f("ft:gpt-4:org") == "cl100k_base" and f("gpt-5-mini") == "o200k_base"
+    with pytest.raises(KeyError, match="Could not automatically map"):
+        f("llama-3")
+    assert callable(tiktoken_amd.encoding_for_model)

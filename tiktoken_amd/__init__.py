@@ -9,4 +9,4 @@ __version__ = "0.1.0"
 
 from ._tiktoken import CoreBPE  # noqa: F401
 from .core import Encoding  # noqa: F401
-from .plugins import get_encoding, list_encoding_names  # noqa: F401
+from .plugins import encoding_for_model, encoding_name_for_model, get_encoding, list_encoding_names  # noqa: F401

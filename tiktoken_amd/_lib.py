@@ -86,6 +86,8 @@ def lib() -> ctypes.CDLL:
         L.tk_group_encode_batch.argtypes = [vp, vp, vp, u64, i32, vp, u64, P(vp), P(u64), vp]
         L.tk_group_encode_batch_device.restype = i32
         L.tk_group_encode_batch_device.argtypes = [vp, vp, vp, u64, i32, vp, u64, P(vp), P(u64), P(vp)]
+        L.tk_group_stat.restype = u64
+        L.tk_group_stat.argtypes = [vp, ctypes.c_char_p]
         L.tk_parse_tiktoken_bpe.restype = i32
         L.tk_parse_tiktoken_bpe.argtypes = [vp, u64, P(vp), P(vp), P(vp), P(u64)]
         L.tk_free.argtypes = [vp]

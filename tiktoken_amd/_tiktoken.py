@@ -89,6 +89,8 @@ class CoreBPE:
         if devices is None:
             devices = [device] if device is not None else default_devices()
         devices = list(devices)
+        if not devices:
+            raise ValueError("devices must name at least one GPU")
         device = devices[0]
         self._replicas: list[CoreBPE] = []
         self._group = None
@@ -210,6 +212,9 @@ class CoreBPE:
                                                   ctypes.byref(dt), ctypes.byref(dn), ctypes.byref(do))
         _lib.raise_for(rc)
         return dt.value, dn.value, do.value
+
+    def group_stat(self, name: str) -> int:
+        return int(self._L.tk_group_stat(self._group, name.encode())) if self._group is not None else 0
 
     def encode_batch_device(self, d_text_ptr: int, n_bytes: int, d_doc_off_ptr: int, h_doc_off: np.ndarray | None,
                             n_docs: int, allowed_special: AbstractSet[str] | None = None, stream: int = 0):

@@ -2,6 +2,8 @@
 // Host code here only builds tables, moves buffers and launches kernels; every byte of
 // pre-tokenisation and merging is done by the kernels in tk_fused.h / tk_kernels.h.  There is no CPU path.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
+#include <rccl/rccl.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -1055,11 +1057,14 @@ static int encode_small(tk_core* c, const uint8_t* utf8, uint32_t n, uint32_t** 
     return TK_OK;
 }
 
-extern "C" int tk_encode_batch(tk_core* c, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special,
-                               const uint32_t* allowed_ids, uint64_t n_allowed, uint32_t** tokens_out, uint64_t* n_tokens_out,
-                               uint64_t* tok_off_out) {
+// Host text in.  device_result = false: the contract of tk_encode_batch (ids in a host buffer the caller frees).  device_result = true: the ids
+// stay on the device (c->out_tokens, c->out_tok_off: valid until the core's next call) and only the text crosses PCIe -- what the
+// several-GPU gather needs; the one-launch small path (which writes straight to host memory) is not taken then.
+static int encode_batch_impl(tk_core* c, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special,
+                             const uint32_t* allowed_ids, uint64_t n_allowed, uint32_t** tokens_out, uint64_t* n_tokens_out,
+                             uint64_t* tok_off_out, bool device_result) {
     if (!c) return fail(TK_VALUE_ERROR, "core is null");
-    if (!doc_off || !tokens_out || !n_tokens_out) return fail(TK_VALUE_ERROR, "null argument");
+    if (!doc_off || (!device_result && !tokens_out) || !n_tokens_out) return fail(TK_VALUE_ERROR, "null argument");
     if (doc_off[0] != 0) return fail(TK_VALUE_ERROR, "doc_off[0] must be 0");
     for (uint64_t d = 0; d < n_docs; ++d)
         if (doc_off[d + 1] < doc_off[d]) return fail(TK_VALUE_ERROR, "doc_off must be non-decreasing");
@@ -1067,7 +1072,7 @@ extern "C" int tk_encode_batch(tk_core* c, const uint8_t* utf8, const uint64_t* 
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const uint64_t n_bytes = doc_off[n_docs];
-    if (n_docs == 1 && n_bytes > 0 && n_bytes <= TK_SMALL_MAX && !(use_special && n_allowed) && !(c->dbg & 2048) && !c->has_rx) {
+    if (!device_result && n_docs == 1 && n_bytes > 0 && n_bytes <= TK_SMALL_MAX && !(use_special && n_allowed) && !(c->dbg & 2048) && !c->has_rx) {
         bool handled = false;
         TRY(encode_small(c, utf8, (uint32_t)n_bytes, tokens_out, n_tokens_out, &handled));
         if (handled) {
@@ -1089,6 +1094,10 @@ extern "C" int tk_encode_batch(tk_core* c, const uint8_t* utf8, const uint64_t* 
         // small batches: one copy each way (latency matters more than overlap)
         if (n_bytes) HIPCHK(hipMemcpyAsync(c->text.p, utf8, n_bytes, hipMemcpyHostToDevice, s));
         TRY(encode_device_locked(c, s, c->text.as<uint8_t>(), n_bytes, c->doc_off.as<uint64_t>(), doc_off, n_docs, use_special && any, &total));
+        if (device_result) {
+            *n_tokens_out = total;
+            return TK_OK;
+        }
         uint32_t* host = (uint32_t*)(total * 4 >= (1u << 20) ? pinned_get((total ? total : 1) * 4) : malloc((total ? total : 1) * 4));
         if (!host) return fail(TK_RUNTIME_ERROR, "out of host memory");
         hipError_t e = hipSuccess;
@@ -1148,7 +1157,7 @@ extern "C" int tk_encode_batch(tk_core* c, const uint8_t* utf8, const uint64_t* 
         return h2d_rc.load() == TK_OK ? TK_OK : fail(TK_RUNTIME_ERROR, "host-to-device copy failed");
     };
     uint64_t bytes_done = 0;
-    hooks.after = [&](uint64_t tok_begin, uint64_t n_tok, bool last) -> int {
+    if (!device_result) hooks.after = [&](uint64_t tok_begin, uint64_t n_tok, bool last) -> int {
         bytes_done = c->st_bytes;  // (bytes encoded so far: the density of the chunks seen sizes the result buffer)
         const uint64_t need = tok_begin + n_tok;
         if (need > host_cap || !host) {
@@ -1174,7 +1183,7 @@ extern "C" int tk_encode_batch(tk_core* c, const uint8_t* utf8, const uint64_t* 
     if (e == hipSuccess) e = hipStreamSynchronize(c->cs_d2h);
     drop_events();
     if (rc == TK_OK && e != hipSuccess) rc = fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e));
-    if (rc == TK_OK && tok_off_out) {
+    if (rc == TK_OK && tok_off_out && !device_result) {
         e = hipMemcpy(tok_off_out, c->out_tok_off.p, (n_docs + 1) * 8, hipMemcpyDeviceToHost);
         if (e != hipSuccess) rc = fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e));
     }
@@ -1182,10 +1191,17 @@ extern "C" int tk_encode_batch(tk_core* c, const uint8_t* utf8, const uint64_t* 
         tk_free(host);
         return rc;
     }
+    *n_tokens_out = total;
+    if (device_result) return TK_OK;
     if (!host) host = (uint32_t*)pinned_get(64);
     *tokens_out = host;
-    *n_tokens_out = total;
     return TK_OK;
+}
+
+extern "C" int tk_encode_batch(tk_core* c, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special,
+                               const uint32_t* allowed_ids, uint64_t n_allowed, uint32_t** tokens_out, uint64_t* n_tokens_out,
+                               uint64_t* tok_off_out) {
+    return encode_batch_impl(c, utf8, doc_off, n_docs, use_special, allowed_ids, n_allowed, tokens_out, n_tokens_out, tok_off_out, false);
 }
 
 // Debug / test entry: the piece-start offsets the GPU pre-tokeniser produces for a packed batch
@@ -1398,9 +1414,47 @@ extern "C" int tk_decode_batch(tk_core* c, const uint32_t* tokens, const uint64_
 // device from its own host thread, and the token ids are gathered in document order -- on the host, or on the first core's device
 // through peer copies over xGMI.  No collective on the data path.
 // ------------------------------------------------------------------------------------------
+// RCCL, loaded on demand (a 570 MB library nobody pays for who uses one GPU): the gather of the several-GPU entry runs on it when the
+// group's devices are pairwise distinct -- grouped ncclSend / ncclRecv of the shards' id buffers to the first core's device
+// (rccl.h:700-722; a gather with per-rank counts).  Virtual ranks (a device named twice) and a missing library use peer copies.
+struct TkRccl {
+    void* lib = nullptr;
+    ncclResult_t (*CommInitAll)(ncclComm_t*, int, const int*) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    const char* (*GetErrorString)(ncclResult_t) = nullptr;
+    bool load() {
+        if (lib) return true;
+        for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+            lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
+            if (lib) break;
+        }
+        if (!lib) return false;
+        CommInitAll = (decltype(CommInitAll))dlsym(lib, "ncclCommInitAll");
+        CommDestroy = (decltype(CommDestroy))dlsym(lib, "ncclCommDestroy");
+        GroupStart = (decltype(GroupStart))dlsym(lib, "ncclGroupStart");
+        GroupEnd = (decltype(GroupEnd))dlsym(lib, "ncclGroupEnd");
+        Send = (decltype(Send))dlsym(lib, "ncclSend");
+        Recv = (decltype(Recv))dlsym(lib, "ncclRecv");
+        GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
+        return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv;
+    }
+};
+static TkRccl g_rccl;
+static std::mutex g_rccl_mu;
+
 struct tk_group {
     std::vector<tk_core*> cores;
-    Buf root_tokens, root_off;  // gathered results on cores[0]'s device (tk_group_encode_batch_device)
+    std::mutex mu;
+    Buf root_tokens, root_off, root_raw;  // gathered results on cores[0]'s device; root_raw: the shards' own offsets before rebasing
+    std::vector<hipStream_t> gs;          // one copy stream per core, on the core's device
+    std::vector<hipEvent_t> ge;
+    std::vector<ncclComm_t> comms;        // RCCL communicators (one per core), empty: peer copies
+    bool rccl_tried = false;
+    uint64_t gathers_rccl = 0, gathers_peer = 0;
 };
 
 extern "C" int tk_group_create(tk_core** cores, uint32_t n, tk_group** out) {
@@ -1414,12 +1468,27 @@ extern "C" int tk_group_create(tk_core** cores, uint32_t n, tk_group** out) {
 }
 extern "C" void tk_group_destroy(tk_group* g) {
     if (!g) return;
+    for (size_t r = 0; r < g->gs.size(); ++r) {
+        (void)hipSetDevice(g->cores[r]->device);
+        if (g->gs[r]) (void)hipStreamDestroy(g->gs[r]);
+        if (g->ge[r]) (void)hipEventDestroy(g->ge[r]);
+    }
+    for (ncclComm_t cm : g->comms)
+        if (cm) (void)g_rccl.CommDestroy(cm);
     if (!g->cores.empty()) (void)hipSetDevice(g->cores[0]->device);
     release(g->root_tokens);
     release(g->root_off);
+    release(g->root_raw);
     delete g;
 }
 extern "C" uint32_t tk_group_size(tk_group* g) { return g ? (uint32_t)g->cores.size() : 0; }
+// 1: the device gather of the last tk_group_encode_batch_device ran on RCCL, 0: on peer copies
+extern "C" uint64_t tk_group_stat(tk_group* g, const char* name) {
+    if (!g || !name) return 0;
+    if (!strcmp(name, "gathers_rccl")) return g->gathers_rccl;
+    if (!strcmp(name, "gathers_peer")) return g->gathers_peer;
+    return 0;
+}
 
 // document ranges [first[r], first[r + 1]) of about equal byte counts (contiguous: the order of the results is the order of the input)
 static std::vector<uint64_t> partition_by_bytes(const uint64_t* doc_off, uint64_t n_docs, uint32_t parts) {
@@ -1443,8 +1512,9 @@ struct ShardResult {
     std::vector<uint64_t> tok_off;
 };
 
+// every core encodes its document range from its own host thread; on_device: the ids stay in each core's out_tokens / out_tok_off
 static int group_encode(tk_group* g, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special, const uint32_t* allowed_ids,
-                        uint64_t n_allowed, std::vector<ShardResult>& res, std::vector<uint64_t>& first) {
+                        uint64_t n_allowed, std::vector<ShardResult>& res, std::vector<uint64_t>& first, bool on_device) {
     if (!g) return fail(TK_VALUE_ERROR, "group is null");
     if (!doc_off) return fail(TK_VALUE_ERROR, "null argument");
     if (doc_off[0] != 0) return fail(TK_VALUE_ERROR, "doc_off[0] must be 0");
@@ -1460,9 +1530,9 @@ static int group_encode(tk_group* g, const uint8_t* utf8, const uint64_t* doc_of
             std::vector<uint64_t> off(nd + 1);
             for (uint64_t k = 0; k <= nd; ++k) off[k] = doc_off[d0 + k] - doc_off[d0];
             ShardResult& o = res[r];
-            o.tok_off.assign(nd + 1, 0);
-            o.rc = tk_encode_batch(g->cores[r], utf8 + doc_off[d0], off.data(), nd, use_special, allowed_ids, n_allowed, &o.tokens, &o.n_tokens,
-                                   o.tok_off.data());
+            if (!on_device) o.tok_off.assign(nd + 1, 0);
+            o.rc = encode_batch_impl(g->cores[r], utf8 + doc_off[d0], off.data(), nd, use_special, allowed_ids, n_allowed, &o.tokens, &o.n_tokens,
+                                     on_device ? nullptr : o.tok_off.data(), on_device);
             if (o.rc != TK_OK) o.err = tk_last_error();  // (thread-local message of this worker)
         });
     }
@@ -1482,9 +1552,11 @@ extern "C" int tk_group_encode_batch(tk_group* g, const uint8_t* utf8, const uin
                                      const uint32_t* allowed_ids, uint64_t n_allowed, uint32_t** tokens_out, uint64_t* n_tokens_out,
                                      uint64_t* tok_off_out) {
     if (!tokens_out || !n_tokens_out) return fail(TK_VALUE_ERROR, "null argument");
+    if (!g) return fail(TK_VALUE_ERROR, "group is null");
+    std::lock_guard<std::mutex> lk(g->mu);
     std::vector<ShardResult> res;
     std::vector<uint64_t> first;
-    TRY(group_encode(g, utf8, doc_off, n_docs, use_special, allowed_ids, n_allowed, res, first));
+    TRY(group_encode(g, utf8, doc_off, n_docs, use_special, allowed_ids, n_allowed, res, first, false));
     uint64_t total = 0;
     std::vector<uint64_t> base(res.size() + 1, 0);
     for (size_t r = 0; r < res.size(); ++r) {
@@ -1511,37 +1583,103 @@ extern "C" int tk_group_encode_batch(tk_group* g, const uint8_t* utf8, const uin
     return TK_OK;
 }
 
-// The same with the results gathered on the FIRST core's device: every other core's token ids travel there with one peer copy
-// (hipMemcpyPeer: xGMI between the GPUs of a node).  *d_tokens_out / *d_tok_off_out are owned by the group (valid until its next call).
+// raw[0 .. n]: a shard's own token offsets; out[k] = raw[k] + base for its documents (k < n), and out[n] as well when `last`
+__global__ __launch_bounds__(256) void tk_k_group_rebase(const uint64_t* __restrict__ raw, uint64_t n, uint64_t base, uint64_t* __restrict__ out, int last) {
+    const uint64_t k = (uint64_t)blockIdx.x * 256u + threadIdx.x;
+    if (k < n || (last && k == n)) out[k] = raw[k] + base;
+}
+
+// The same with the results gathered on the FIRST core's device and nothing but the text crossing PCIe: every core encodes its shard with
+// the ids left on its own device, then all shards travel to the first device at the same time -- RCCL send / recv over xGMI when the
+// devices are distinct, concurrent peer copies (one stream per source device) otherwise -- and their document offsets are rebased
+// there.  *d_tokens_out / *d_tok_off_out are owned by the group (valid until its next call).
 extern "C" int tk_group_encode_batch_device(tk_group* g, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special,
                                             const uint32_t* allowed_ids, uint64_t n_allowed, const uint32_t** d_tokens_out,
                                             uint64_t* n_tokens_out, const uint64_t** d_tok_off_out) {
     if (!d_tokens_out || !n_tokens_out) return fail(TK_VALUE_ERROR, "null argument");
-    // (the shards' encodes leave their ids in each core's out_tokens buffer; the host copies made by tk_encode_batch are dropped)
+    if (!g) return fail(TK_VALUE_ERROR, "group is null");
+    std::lock_guard<std::mutex> lk(g->mu);
     std::vector<ShardResult> res;
     std::vector<uint64_t> first;
-    TRY(group_encode(g, utf8, doc_off, n_docs, use_special, allowed_ids, n_allowed, res, first));
+    TRY(group_encode(g, utf8, doc_off, n_docs, use_special, allowed_ids, n_allowed, res, first, true));
+    const size_t R = res.size();
     uint64_t total = 0;
-    std::vector<uint64_t> base(res.size() + 1, 0);
-    for (size_t r = 0; r < res.size(); ++r) {
+    std::vector<uint64_t> base(R + 1, 0);
+    for (size_t r = 0; r < R; ++r) {
         base[r] = total;
         total += res[r].n_tokens;
-        tk_free(res[r].tokens);
     }
     tk_core* root = g->cores[0];
+    if (g->gs.empty()) {
+        g->gs.assign(R, nullptr);
+        g->ge.assign(R, nullptr);
+        for (size_t r = 0; r < R; ++r) {
+            HIPCHK(hipSetDevice(g->cores[r]->device));
+            HIPCHK(hipStreamCreateWithFlags(&g->gs[r], hipStreamNonBlocking));
+            HIPCHK(hipEventCreateWithFlags(&g->ge[r], hipEventDisableTiming));
+        }
+    }
+    if (!g->rccl_tried) {  // communicators once per group, when no device is named twice
+        g->rccl_tried = true;
+        std::vector<int> devs;
+        bool distinct = R > 1 && !getenv("TIKTOKEN_AMD_NO_RCCL");
+        for (size_t r = 0; r < R; ++r) {
+            for (int d : devs) distinct = distinct && d != g->cores[r]->device;
+            devs.push_back(g->cores[r]->device);
+        }
+        if (distinct) {
+            std::lock_guard<std::mutex> lr(g_rccl_mu);
+            if (g_rccl.load()) {
+                g->comms.assign(R, nullptr);
+                if (g_rccl.CommInitAll(g->comms.data(), (int)R, devs.data()) != ncclSuccess) g->comms.clear();
+            }
+        }
+    }
     HIPCHK(hipSetDevice(root->device));
     TRY(ensure(g->root_tokens, (total + 1) * 4));
     TRY(ensure(g->root_off, (n_docs + 2) * 8));
-    std::vector<uint64_t> off(n_docs + 1, 0);
-    for (size_t r = 0; r < res.size(); ++r) {
-        tk_core* c = g->cores[r];
-        if (res[r].n_tokens)
-            HIPCHK(hipMemcpyPeer((uint32_t*)g->root_tokens.p + base[r], root->device, c->out_tokens.p, c->device, res[r].n_tokens * 4));
-        for (uint64_t k = 0; k + 1 < res[r].tok_off.size(); ++k) off[first[r] + k] = base[r] + res[r].tok_off[k];
+    TRY(ensure(g->root_raw, (n_docs + R + 2) * 8));
+    uint32_t* rt = g->root_tokens.as<uint32_t>();
+    uint64_t* raw = g->root_raw.as<uint64_t>();
+    bool by_rccl = !g->comms.empty();
+    if (by_rccl) {
+        ncclResult_t nr = g_rccl.GroupStart();
+        for (size_t r = 1; r < R && nr == ncclSuccess; ++r) {
+            if (!res[r].n_tokens) continue;
+            (void)hipSetDevice(g->cores[r]->device);
+            nr = g_rccl.Send(g->cores[r]->out_tokens.p, res[r].n_tokens, ncclUint32, 0, g->comms[r], g->gs[r]);
+            (void)hipSetDevice(root->device);
+            if (nr == ncclSuccess) nr = g_rccl.Recv(rt + base[r], res[r].n_tokens, ncclUint32, (int)r, g->comms[0], g->gs[0]);
+        }
+        const ncclResult_t ne = g_rccl.GroupEnd();
+        if (nr == ncclSuccess) nr = ne;
+        if (nr != ncclSuccess)
+            return fail(TK_RUNTIME_ERROR, std::string("RCCL gather failed: ") + (g_rccl.GetErrorString ? g_rccl.GetErrorString(nr) : "?"));
+        HIPCHK(hipSetDevice(root->device));
+        if (res[0].n_tokens) HIPCHK(hipMemcpyAsync(rt, root->out_tokens.p, res[0].n_tokens * 4, hipMemcpyDeviceToDevice, g->gs[0]));
+        ++g->gathers_rccl;
     }
-    off[n_docs] = total;
-    HIPCHK(hipMemcpy(g->root_off.p, off.data(), (n_docs + 1) * 8, hipMemcpyHostToDevice));
-    *d_tokens_out = g->root_tokens.as<uint32_t>();
+    for (size_t r = 0; r < R; ++r) {  // offsets (and, without RCCL, the ids): one peer copy per shard, each on its source device's stream
+        tk_core* c = g->cores[r];
+        const uint64_t nd = first[r + 1] - first[r];
+        HIPCHK(hipSetDevice(c->device));
+        if (!by_rccl && res[r].n_tokens)
+            HIPCHK(hipMemcpyPeerAsync(rt + base[r], root->device, c->out_tokens.p, c->device, res[r].n_tokens * 4, g->gs[r]));
+        HIPCHK(hipMemcpyPeerAsync(raw + first[r] + r, root->device, c->out_tok_off.p, c->device, (nd + 1) * 8, g->gs[r]));
+        HIPCHK(hipEventRecord(g->ge[r], g->gs[r]));
+    }
+    if (!by_rccl) ++g->gathers_peer;
+    HIPCHK(hipSetDevice(root->device));
+    hipStream_t s0 = g->gs[0];
+    for (size_t r = 1; r < R; ++r) HIPCHK(hipStreamWaitEvent(s0, g->ge[r], 0));
+    for (size_t r = 0; r < R; ++r) {
+        const uint64_t nd = first[r + 1] - first[r];
+        hipLaunchKernelGGL(tk_k_group_rebase, dim3((uint32_t)((nd + 1 + 255) / 256)), dim3(256), 0, s0, raw + first[r] + r, nd, base[r],
+                           g->root_off.as<uint64_t>() + first[r], r + 1 == R ? 1 : 0);
+    }
+    HIPCHK(hipGetLastError());
+    HIPCHK(hipStreamSynchronize(s0));
+    *d_tokens_out = rt;
     if (d_tok_off_out) *d_tok_off_out = g->root_off.as<uint64_t>();
     *n_tokens_out = total;
     return TK_OK;

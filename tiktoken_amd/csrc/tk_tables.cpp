@@ -4,6 +4,7 @@
 #include <string.h>
 
 #include <algorithm>
+#include <array>
 #include <numeric>
 #include <thread>
 
@@ -355,14 +356,14 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
 // ------------------------------------------------------------------------------------------
 std::string tk_parse_tiktoken(const uint8_t* text, uint64_t len, std::vector<uint8_t>* blob, std::vector<uint64_t>* off,
                               std::vector<uint32_t>* ids) {
-    static int8_t dec[256];
-    static bool init = false;
-    if (!init) {
-        for (int i = 0; i < 256; ++i) dec[i] = -1;
+    // (built once, thread-safe: initialisation of a function-local static)
+    static const std::array<int8_t, 256> dec = [] {
+        std::array<int8_t, 256> d;
+        d.fill(-1);
         const char* al = "ABCDEFGHIJKLMNOPQRSTUVWXYZabcdefghijklmnopqrstuvwxyz0123456789+/";
-        for (int i = 0; i < 64; ++i) dec[(unsigned char)al[i]] = (int8_t)i;
-        init = true;
-    }
+        for (int i = 0; i < 64; ++i) d[(unsigned char)al[i]] = (int8_t)i;
+        return d;
+    }();
     blob->clear();
     off->assign(1, 0);
     ids->clear();

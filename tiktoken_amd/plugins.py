@@ -65,3 +65,44 @@ def get_encoding(encoding_name: str):
 
 def list_encoding_names() -> list[str]:
     return list(_CATALOGUE.makers())
+
+
+# Model name -> encoding name (reference tiktoken/model.py:7-86; public API `encoding_for_model`).  Kept by encoding: exact names and,
+# after "|", name prefixes ("gpt-4o-2024-05-13"); of several matching prefixes the longest one decides ("ft:gpt-4o" over "ft:gpt-4").
+_MODELS_BY_ENCODING = {
+    "o200k_base": "o1 o3 o4-mini gpt-5 gpt-4.1 gpt-4o | o1- o3- o4-mini- gpt-5 gpt-4.5- gpt-4.1- chatgpt-4o- gpt-4o- ft:gpt-4o",
+    "o200k_harmony": "| gpt-oss-",
+    "cl100k_base": "gpt-4 gpt-3.5-turbo gpt-3.5 gpt-35-turbo davinci-002 babbage-002 text-embedding-ada-002 text-embedding-3-small "
+                   "text-embedding-3-large | gpt-4- gpt-3.5-turbo- gpt-35-turbo- ft:gpt-4 ft:gpt-3.5-turbo ft:davinci-002 ft:babbage-002",
+    "p50k_base": "text-davinci-003 text-davinci-002 code-davinci-002 code-davinci-001 code-cushman-002 code-cushman-001 davinci-codex "
+                 "cushman-codex |",
+    "p50k_edit": "text-davinci-edit-001 code-davinci-edit-001 |",
+    "r50k_base": "text-davinci-001 text-curie-001 text-babbage-001 text-ada-001 davinci curie babbage ada text-similarity-davinci-001 "
+                 "text-similarity-curie-001 text-similarity-babbage-001 text-similarity-ada-001 text-search-davinci-doc-001 "
+                 "text-search-curie-doc-001 text-search-babbage-doc-001 text-search-ada-doc-001 code-search-babbage-code-001 "
+                 "code-search-ada-code-001 |",
+    "gpt2": "gpt2 gpt-2 |",
+}
+_EXACT, _PREFIXES = {}, []
+for _enc, _spec in _MODELS_BY_ENCODING.items():
+    _names, _, _pre = _spec.partition("|")
+    _EXACT.update((m, _enc) for m in _names.split())
+    _PREFIXES.extend((p, _enc) for p in _pre.split())
+_PREFIXES.sort(key=lambda pe: -len(pe[0]))
+
+
+def encoding_name_for_model(model_name: str) -> str:
+    """Name of the encoding a model uses; KeyError for a model nobody has listed."""
+    hit = _EXACT.get(model_name)
+    if hit is None:
+        hit = next((enc for pre, enc in _PREFIXES if model_name.startswith(pre)), None)
+    if hit is None:
+        raise KeyError(
+            f"Could not automatically map {model_name} to a tokeniser. "
+            "Please use `tiktoken.get_encoding` to explicitly get the tokeniser you expect."
+        ) from None
+    return hit
+
+
+def encoding_for_model(model_name: str):
+    return get_encoding(encoding_name_for_model(model_name))
