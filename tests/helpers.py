@@ -225,6 +225,8 @@ def sim_lib():
         L.tks_destroy.argtypes = [vp]
         L.tks_n_pairs.restype = u64
         L.tks_n_pairs.argtypes = [vp]
+        L.tks_tables_digest.restype = u64
+        L.tks_tables_digest.argtypes = [vp]
         L.tks_pretok.restype = u64
         L.tks_pretok.argtypes = [vp, vp, u64, vp, u64, vp]
         L.tks_pretok_bits.restype = u64

@@ -115,6 +115,27 @@ void* tks_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uin
 }
 void tks_destroy(void* p) { delete (Sim*)p; }
 uint64_t tks_n_pairs(void* p) { return ((Sim*)p)->H.n_pairs; }
+// FNV-1a over every table the device gets (the build must not depend on the number of host threads)
+uint64_t tks_tables_digest(void* p) {
+    const TkHostTables& H = ((Sim*)p)->H;
+    uint64_t h = 0xCBF29CE484222325ull;
+    auto mix = [&](const void* d, size_t n) {
+        const uint8_t* b = (const uint8_t*)d;
+        for (size_t i = 0; i < n; ++i) h = (h ^ b[i]) * 0x100000001B3ull;
+    };
+    mix(H.short_tab.data(), H.short_tab.size() * sizeof(TkShortSlot));
+    for (const TkPieceSlot& e : H.mid_tab) { mix(&e.key, 8); mix(&e.rank, 4); mix(&e.len, 4); }
+    for (const TkPieceSlot& e : H.piece) { mix(&e.key, 8); mix(&e.rank, 4); mix(&e.len, 4); }
+    mix(H.piece_off.data(), H.piece_off.size() * 4);
+    mix(H.pair8.data(), H.pair8.size() * 8);
+    for (const TkPairSlot& e : H.pair) { mix(&e.key, 8); mix(&e.rank, 4); }
+    mix(H.pair2.data(), H.pair2.size() * 4);
+    mix(H.byte_rank, sizeof H.byte_rank);
+    mix(H.tok_bytes.data(), H.tok_bytes.size());
+    const std::vector<uint32_t>& sr = H.sorted_ranks();
+    mix(sr.data(), sr.size() * 4);
+    return h;
+}
 // table build statistics: average slots inspected per stored token {short, mid, long}, table sizes in slots
 void tks_table_stats(void* p, double* probes, uint64_t* slots) {
     const TkHostTables& H = ((Sim*)p)->H;

@@ -132,3 +132,27 @@ def test_model_table():
     with pytest.raises(KeyError, match="Could not automatically map"):
         f("llama-3")
     assert callable(tiktoken_amd.encoding_for_model)
+
+
+def test_rank_table_fills_itself_on_first_use():
+    """vocab_io.RankTable: the parsed file stays in packed arrays (what tk_create takes) until somebody reads the dict."""
+    src = {bytes([i]): i for i in range(256)}
+    src.update({b"ab": 256, b"abc": 257, b"\xe4\xb8\xad": 258})
+    text = b"".join(base64.b64encode(k) + b" %d\n" % v for k, v in src.items())
+    t = vocab_io.parse_tiktoken_bpe(text)
+    assert t._pending is not None and t.max_rank() == 258 and t._pending is not None  # nothing walked the dict
+    assert t.packed is not None and len(t.packed[2]) == len(src)
+    assert len(t) == len(src) and t._pending is None  # the first use filled it
+    assert t == src and src == t and dict(t) == src and t[b"abc"] == 257 and b"zz" not in t and t.get(b"zz", 7) == 7
+    for fresh_use in (lambda x: x[b"ab"], lambda x: b"ab" in x, lambda x: list(x)[0], lambda x: {**x}, lambda x: x.items(), lambda x: repr(x), lambda x: x.copy()):
+        u = vocab_io.parse_tiktoken_bpe(text)
+        fresh_use(u)
+        assert u._pending is None and dict.__len__(u) == len(src)
+    u = vocab_io.parse_tiktoken_bpe(text)
+    u[b"new"] = 300
+    assert u.packed is None and len(u) == len(src) + 1 and u.max_rank() == 300
+    import pickle
+
+    assert pickle.loads(pickle.dumps(vocab_io.parse_tiktoken_bpe(text))) == src
+    dup = vocab_io.parse_tiktoken_bpe(b"YQ== 0\nYg== 1\nYQ== 2\n")  # a token listed twice: the dict keeps the later rank
+    assert dict(dup) == {b"a": 2, b"b": 1} and dup.packed is None

@@ -299,3 +299,16 @@ def test_scanner_forms_on_fuzzed_documents(name):
         assert sim.piece_ends(blob, off, bits=True)[0].tolist() == ref
         assert sim.piece_ends(blob, off)[0].tolist() == ref
         assert sim.chunk_check(blob, off)[0] == 0
+
+
+def test_tables_do_not_depend_on_the_thread_count(monkeypatch):
+    """the pair table is built by several host threads (tk_tables.cpp); every table the device gets -- and the sorted token
+    list -- must be byte for byte what one thread builds."""
+    g = h.load_golden("o200k_shaped")
+    ranks = h.golden_vocab("o200k_shaped")
+    digests = []
+    for nth in ("1", "3", "8", "32"):
+        monkeypatch.setenv("TIKTOKEN_AMD_BUILD_THREADS", nth)
+        sim = h.HostSim(g["pat_str"], ranks, g["special_tokens"])
+        digests.append((sim.n_pairs(), h.sim_lib().tks_tables_digest(sim._h)))
+    assert len(set(digests)) == 1, digests

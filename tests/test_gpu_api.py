@@ -274,3 +274,25 @@ def test_byte_pair_encode_has_no_whole_piece_shortcut():
     assert core.encode_single_piece(b"abc") == [256] == po.encode_single_piece(b"abc", ranks)
     assert core._byte_pair_encode(b"abc") == [97, 98, 99] == po.byte_pair_encode(b"abc", ranks)
     assert core._byte_pair_encode(b"a") == [97]
+
+
+def test_encoding_from_a_parsed_file_never_walks_the_dict():
+    """vocab_io.RankTable hands tk_create the parser's arrays; a file that lists a token twice falls back to the dict (the later rank wins,
+    as in the reference's dict comprehension, load.py:159-171)."""
+    import base64
+
+    from tiktoken_amd import vocab_io
+
+    g = h.load_golden("cl100k_shaped")
+    ranks = h.golden_vocab("cl100k_shaped")
+    text = b"".join(base64.b64encode(k) + b" %d\n" % v for k, v in ranks.items())
+    table = vocab_io.parse_tiktoken_bpe(text)
+    enc = tiktoken.Encoding("t1", pat_str=g["pat_str"], mergeable_ranks=table, special_tokens=g["special_tokens"])
+    assert table._pending is not None  # still packed: nobody needed the dict
+    ref = tiktoken.Encoding("t2", pat_str=g["pat_str"], mergeable_ranks=dict(ranks), special_tokens=g["special_tokens"])
+    s = "The quick brown fox's 12345 jumps\n\n over the lazy dog. 中文 \U0001F600"
+    assert enc.encode_ordinary(s) == ref.encode_ordinary(s)
+    some = next(k for k in ranks if len(k) == 3)
+    dup = vocab_io.parse_tiktoken_bpe(text + base64.b64encode(some) + b" %d\n" % (max(ranks.values()) + 1))
+    enc2 = tiktoken.Encoding("t3", pat_str=g["pat_str"], mergeable_ranks=dup, special_tokens={})
+    assert enc2.encode_single_token(some) == max(ranks.values()) + 1

@@ -94,16 +94,28 @@ class CoreBPE:
         device = devices[0]
         self._replicas: list[CoreBPE] = []
         self._group = None
-        for v in encoder.values():
-            if not 0 <= v <= 0xFFFFFFFF:
-                raise OverflowError("rank does not fit in u32")  # PyO3 would refuse the conversion too
         self._specials = dict(special_tokens_encoder)
-        packed = getattr(encoder, "packed", None)  # vocab_io.RankTable: arrays straight from the native parser
-        rb, ro, ri = packed if packed is not None and len(packed[2]) == len(encoder) else _pack_pairs(list(encoder.items()))
         sb, so, si = _pack_pairs([(k.encode("utf-8"), v) for k, v in self._specials.items()])
+        # vocab_io.RankTable: the arrays straight from the native parser (its dict may not even be filled yet: nothing here walks it)
+        packed = getattr(encoder, "packed", None)
+        fresh = packed is not None and getattr(encoder, "_pending", None) is not None
         h = ctypes.c_void_p()
-        rc = L.tk_create(rb.ctypes.data, ro.ctypes.data, ri.ctypes.data, len(encoder), sb.ctypes.data, so.ctypes.data,
-                         si.ctypes.data, len(self._specials), pattern.encode("utf-8"), device, ctypes.byref(h))
+        for attempt in (0, 1):
+            if packed is not None and (fresh or len(packed[2]) == len(encoder)):
+                rb, ro, ri = packed
+            else:
+                for v in encoder.values():
+                    if not 0 <= v <= 0xFFFFFFFF:
+                        raise OverflowError("rank does not fit in u32")  # PyO3 would refuse the conversion too
+                rb, ro, ri = _pack_pairs(list(encoder.items()))
+            rc = L.tk_create(rb.ctypes.data, ro.ctypes.data, ri.ctypes.data, len(ro) - 1, sb.ctypes.data, so.ctypes.data,
+                             si.ctypes.data, len(self._specials), pattern.encode("utf-8"), device, ctypes.byref(h))
+            if rc != _lib.TK_OK and fresh and attempt == 0 and "duplicate key" in _lib.last_error():
+                # a file that lists a token twice: the dict keeps the later rank (as the reference's does) -- build from the dict
+                encoder.materialize()
+                packed, fresh = encoder.packed, False
+                continue
+            break
         _lib.raise_for(rc)
         self._h = h
         self._L = L

@@ -57,7 +57,8 @@ class Encoding:
         self._pat_str = pat_str
         self._mergeable_ranks = mergeable_ranks
         self._special_tokens = special_tokens
-        self.max_token_value = max(max(mergeable_ranks.values()), max(special_tokens.values(), default=0))
+        top = mergeable_ranks.max_rank() if hasattr(mergeable_ranks, "max_rank") else max(mergeable_ranks.values())  # (vocab_io.RankTable: no dict walk)
+        self.max_token_value = max(top, max(special_tokens.values(), default=0))
         if explicit_n_vocab:
             assert len(mergeable_ranks) + len(special_tokens) == explicit_n_vocab
             assert self.max_token_value == explicit_n_vocab - 1

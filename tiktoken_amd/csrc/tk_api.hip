@@ -366,12 +366,12 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     for (size_t k = 0; k + 1 < H.spec_off.size(); ++k) c->spec_max_len = std::max(c->spec_max_len, H.spec_off[k + 1] - H.spec_off[k]);
     {  // decode table: id -> {offset into the token / special blob, length}
         uint32_t max_id = 0;
-        for (const auto& kv : H.decoder) max_id = std::max(max_id, kv.first);
+        max_id = H.max_rank;
         for (const auto& kv : H.spec_decoder) max_id = std::max(max_id, kv.first);
         if (max_id < (1u << 26)) {
             std::vector<uint2> dec((size_t)max_id + 1, make_uint2(0, 0));
             for (const auto& kv : H.spec_decoder) dec[kv.first] = make_uint2(kv.second.first | TK_DEC_SPEC, kv.second.second);
-            for (const auto& kv : H.decoder) dec[kv.first] = make_uint2(kv.second.first, kv.second.second);  // (lib.rs:347-351: decoder first)
+            H.for_each_token([&](uint32_t r, uint32_t o, uint32_t l) { dec[r] = make_uint2(o, l); });  // (lib.rs:347-351: decoder first)
             if ((rc = upload(c->t_dec, dec.data(), dec.size() * sizeof(uint2)))) return bail(rc);
             c->n_dec = max_id + 1;
         }
@@ -1308,13 +1308,12 @@ extern "C" int tk_encode_single_token(tk_core* c, const uint8_t* piece, uint64_t
 
 extern "C" int tk_decode_single_token_bytes(tk_core* c, uint32_t token, const uint8_t** bytes_out, uint64_t* len_out) {
     if (!c) return fail(TK_VALUE_ERROR, "core is null");
-    auto it = c->H.decoder.find(token);
-    if (it != c->H.decoder.end()) {
-        *bytes_out = c->H.tok_bytes.data() + it->second.first;
-        *len_out = it->second.second;
+    if (const auto* e = c->H.find_token(token)) {
+        *bytes_out = c->H.tok_bytes.data() + e->first;
+        *len_out = e->second;
         return TK_OK;
     }
-    it = c->H.spec_decoder.find(token);
+    auto it = c->H.spec_decoder.find(token);
     if (it != c->H.spec_decoder.end()) {
         *bytes_out = c->H.spec_bytes.data() + it->second.first;
         *len_out = it->second.second;
@@ -1688,8 +1687,8 @@ extern "C" int tk_group_encode_batch_device(tk_group* g, const uint8_t* utf8, co
 extern "C" uint64_t tk_n_tokens(tk_core* c) { return c ? c->H.n_ranks : 0; }
 
 extern "C" int tk_sorted_token(tk_core* c, uint64_t i, const uint8_t** bytes_out, uint64_t* len_out, uint32_t* rank_out) {
-    if (!c || i >= c->H.sorted_ranks.size()) return fail(TK_VALUE_ERROR, "index out of range");
-    uint32_t r = c->H.sorted_ranks[i];
+    if (!c || i >= c->H.sorted_ranks().size()) return fail(TK_VALUE_ERROR, "index out of range");
+    uint32_t r = c->H.sorted_ranks()[i];
     if (rank_out) *rank_out = r;
     return tk_decode_single_token_bytes(c, r, bytes_out, len_out);
 }
@@ -1701,10 +1700,10 @@ extern "C" int tk_sorted_tokens_packed(tk_core* c, const uint8_t** blob_out, con
     std::lock_guard<std::mutex> lk(c->mu);
     if (c->sorted_off.empty()) {
         const TkHostTables& H = c->H;
-        c->sorted_off.reserve(H.sorted_ranks.size() + 1);
+        c->sorted_off.reserve(H.sorted_ranks().size() + 1);
         c->sorted_off.push_back(0);
-        for (uint32_t r : H.sorted_ranks) {
-            const auto& e = H.decoder.at(r);
+        for (uint32_t r : H.sorted_ranks()) {
+            const auto& e = *H.find_token(r);
             c->sorted_blob.insert(c->sorted_blob.end(), H.tok_bytes.begin() + e.first, H.tok_bytes.begin() + e.first + e.second);
             c->sorted_off.push_back(c->sorted_blob.size());
         }

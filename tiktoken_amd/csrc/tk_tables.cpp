@@ -1,10 +1,12 @@
 #include "tk_tables.h"
 
+#include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
 
 #include <algorithm>
 #include <array>
+#include <chrono>
 #include <numeric>
 #include <thread>
 
@@ -120,11 +122,19 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
                             uint64_t n_ranks, const uint8_t* spec_blob, const uint64_t* spec_off,
                             const uint32_t* spec_ids, uint64_t n_spec, const char* pat_str, TkHostTables* out) {
     TkHostTables& T = *out;
+    const bool timing = getenv("TIKTOKEN_AMD_TIMING") != nullptr;
+    auto t_prev = std::chrono::steady_clock::now();
+    auto lap = [&](const char* what) {
+        const auto now = std::chrono::steady_clock::now();
+        if (timing) fprintf(stderr, "tk_build_tables: %-28s %7.1f ms\n", what, std::chrono::duration<double, std::milli>(now - t_prev).count());
+        t_prev = now;
+    };
     {
         const std::string perr = tk_compile_pattern(pat_str, &T.pat, T.cert, &T.rx);
         if (!perr.empty()) return perr;
         T.pattern = T.pat.fam();
     }
+    lap("pattern");
     if (n_ranks == 0) return "mergeable_ranks is empty";
     if (ranks_off[n_ranks] >= 0xFFFFFFFFull) return "vocabulary byte blob too large";
     T.n_ranks = n_ranks;
@@ -164,7 +174,14 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
     T.piece_off.assign(cap, 0);
     for (int b = 0; b < 256; ++b) T.byte_rank[b] = TK_RANK_MAX;
     T.pair2.assign(65536, TK_RANK_MAX);
-    T.decoder.reserve(n_ranks * 2);
+    {
+        uint32_t mr = 0;
+        for (uint64_t k = 0; k < n_ranks; ++k) mr = std::max(mr, ranks_ids[k] == TK_RANK_MAX ? 0u : ranks_ids[k]);
+        T.max_rank = mr;
+        T.dec_is_dense = (uint64_t)mr < 4 * n_ranks + 65536;
+        if (T.dec_is_dense) T.dec_dense.assign((size_t)mr + 1, std::make_pair(0u, 0u));
+        else T.dec_sparse.reserve(n_ranks * 2);
+    }
     uint64_t pr_short = 0, pr_mid = 0, pr_long = 0;
     for (uint64_t k = 0; k < n_ranks; ++k) {
         uint64_t o = ranks_off[k], len64 = ranks_off[k + 1] - o;
@@ -173,7 +190,14 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
         if (rank == TK_RANK_MAX) return "rank 0xFFFFFFFF is reserved (Rank::MAX sentinel, src/lib.rs:53)";
         const uint8_t* p = ranks_blob + o;
         if (T.lookup_piece(p, len) != TK_RANK_MAX) return "duplicate key in mergeable_ranks";
-        if (!T.decoder.emplace(rank, std::make_pair((uint32_t)o, len)).second)
+        bool fresh;
+        if (T.dec_is_dense) {
+            fresh = T.dec_dense[rank].second == 0;
+            T.dec_dense[rank] = std::make_pair((uint32_t)o, len);
+        } else {
+            fresh = T.dec_sparse.emplace(rank, std::make_pair((uint32_t)o, len)).second;
+        }
+        if (!fresh)
             return "Encoder and decoder must be of equal length. Maybe you had duplicate token indices in your "
                    "encoder?";  // src/lib.rs:636-641
         if (len <= 8) {
@@ -219,6 +243,7 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
             return "every single byte must be a key of mergeable_ranks (byte_pair_encode indexes ranks[piece] for "
                    "1-byte pieces, src/lib.rs:201-203)";
 
+    lap("piece tables + decoder");
     // Seed of the LDS piece cache (tk_common.h): tokens of up to TK_HOT_MAXLEN bytes in rank order -- a low rank is a frequent
     // string of the training text -- each into the slot of its bytes while that slot is free.  The kernel replaces entries with
     // the pieces its text really uses, so the seed only has to be a fair first guess.
@@ -246,23 +271,27 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
     std::vector<TkPairSlot> entries;
     {
         unsigned nth = std::thread::hardware_concurrency();
-        nth = nth == 0 ? 1 : (nth > 16 ? 16 : nth);
+        nth = nth == 0 ? 1 : (nth > 32 ? 32 : nth);
+        if (const char* e = getenv("TIKTOKEN_AMD_BUILD_THREADS")) nth = (unsigned)std::max(1, atoi(e));
         if (n_ranks < 4096) nth = 1;
-        std::vector<std::vector<TkPairSlot>> part(nth);
+        // blocks of 256 tokens, dealt round-robin (the file is in rank order: its tail holds the long tokens -- most of the work); the
+        // entries are put together in block order, so the table's layout does not depend on the number of threads
+        const uint64_t nblocks = (n_ranks + 255) / 256;
+        std::vector<std::vector<TkPairSlot>> part(nblocks);
         auto work = [&](unsigned t) {
-            std::vector<TkPairSlot>& e = part[t];
-            e.reserve(n_ranks * 3 / nth + 16);
-            const uint64_t k0 = n_ranks * t / nth, k1 = n_ranks * (t + 1) / nth;
-            for (uint64_t k = k0; k < k1; ++k) {
-                uint64_t o = ranks_off[k];
-                uint32_t len = (uint32_t)(ranks_off[k + 1] - o), rank = ranks_ids[k];
-                const uint8_t* p = ranks_blob + o;
-                for (uint32_t s = 1; s < len; ++s) {
-                    uint32_t a = T.lookup_piece(p, s);
-                    if (a == TK_RANK_MAX) continue;
-                    uint32_t b = T.lookup_piece(p + s, len - s);
-                    if (b == TK_RANK_MAX) continue;
-                    e.push_back(TkPairSlot{((uint64_t)a << 32) | b, rank, 0});
+            for (uint64_t b = t; b < nblocks; b += nth) {
+                std::vector<TkPairSlot>& e = part[b];
+                for (uint64_t k = b * 256; k < b * 256 + 256 && k < n_ranks; ++k) {
+                    uint64_t o = ranks_off[k];
+                    uint32_t len = (uint32_t)(ranks_off[k + 1] - o), rank = ranks_ids[k];
+                    const uint8_t* p = ranks_blob + o;
+                    for (uint32_t s = 1; s < len; ++s) {
+                        uint32_t a = T.lookup_piece(p, s);
+                        if (a == TK_RANK_MAX) continue;
+                        uint32_t b2 = T.lookup_piece(p + s, len - s);
+                        if (b2 == TK_RANK_MAX) continue;
+                        e.push_back(TkPairSlot{((uint64_t)a << 32) | b2, rank, 0});
+                    }
                 }
             }
         };
@@ -273,9 +302,10 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
         size_t tot = 0;
         for (auto& e : part) tot += e.size();
         entries.reserve(tot);
-        for (auto& e : part) entries.insert(entries.end(), e.begin(), e.end());  // (token order, as a single thread would produce)
+        for (auto& e : part) entries.insert(entries.end(), e.begin(), e.end());
     }
     T.n_pairs = entries.size();
+    lap("pair entries");
 
     uint32_t max_id = 0;
     for (uint64_t k = 0; k < n_ranks; ++k) max_id = std::max(max_id, ranks_ids[k]);
@@ -311,6 +341,7 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
         }
     }
 
+    lap("pair table");
     // special tokens, sorted by bytes (deterministic order; the reference's alternation order is
     // hash-map order, src/lib.rs:625-631)
     std::vector<uint64_t> order(n_spec);
@@ -336,17 +367,28 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
         if (sbytes(order[i]) == sbytes(order[i - 1])) return "duplicate special token string";
     T.spec_bytes.resize(T.spec_bytes.size() + 16, 0);
 
-    // sorted token bytes (token_byte_values, src/lib.rs:648-650, src/py.rs:178-183)
-    std::vector<uint64_t> idx(n_ranks);
-    std::iota(idx.begin(), idx.end(), 0);
-    std::sort(idx.begin(), idx.end(), [&](uint64_t a, uint64_t b) {
-        uint64_t la = ranks_off[a + 1] - ranks_off[a], lb = ranks_off[b + 1] - ranks_off[b];
-        int c = memcmp(ranks_blob + ranks_off[a], ranks_blob + ranks_off[b], la < lb ? la : lb);
-        return c < 0 || (c == 0 && la < lb);
-    });
-    T.sorted_ranks.resize(n_ranks);
-    for (uint64_t i = 0; i < n_ranks; ++i) T.sorted_ranks[i] = ranks_ids[idx[i]];
+    lap("special tokens");
     return "";
+}
+
+// sorted token bytes (token_byte_values, src/lib.rs:648-650, src/py.rs:178-183)
+const std::vector<uint32_t>& TkHostTables::sorted_ranks() const {
+    std::call_once(sorted_once_, [this] {
+        struct E {
+            uint32_t rank, off, len;
+        };
+        std::vector<E> v;
+        v.reserve(n_ranks);
+        for_each_token([&](uint32_t r, uint32_t o, uint32_t l) { v.push_back(E{r, o, l}); });
+        const uint8_t* b = tok_bytes.data();
+        std::sort(v.begin(), v.end(), [b](const E& x, const E& y) {
+            const int c = memcmp(b + x.off, b + y.off, x.len < y.len ? x.len : y.len);
+            return c < 0 || (c == 0 && x.len < y.len);
+        });
+        sorted_ranks_.resize(v.size());
+        for (size_t i = 0; i < v.size(); ++i) sorted_ranks_[i] = v[i].rank;
+    });
+    return sorted_ranks_;
 }
 
 

@@ -3,6 +3,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <mutex>
 #include <string>
 #include <unordered_map>
 #include <vector>
@@ -36,9 +37,30 @@ struct TkHostTables {
     std::vector<uint8_t> spec_bytes;
     std::vector<uint32_t> spec_off, spec_id;
     uint32_t spec_first[8];
-    // decoder side (src/lib.rs:323-324): rank -> (offset into tok_bytes / spec_bytes, length)
-    std::unordered_map<uint32_t, std::pair<uint32_t, uint32_t>> decoder, spec_decoder;
-    std::vector<uint32_t> sorted_ranks;  // ranks ordered by token bytes (lib.rs:648-650)
+    // decoder side (src/lib.rs:323-324): rank -> (offset into tok_bytes / spec_bytes, length).  Ranks are dense in every real vocabulary
+    // (0 .. n-1 with a few holes): a direct table `dec_dense[rank]` then; a hash map only when the largest rank is far above the count.
+    std::vector<std::pair<uint32_t, uint32_t>> dec_dense;  // length 0 = no such rank
+    std::unordered_map<uint32_t, std::pair<uint32_t, uint32_t>> dec_sparse, spec_decoder;
+    bool dec_is_dense = true;
+    uint32_t max_rank = 0;
+    const std::pair<uint32_t, uint32_t>* find_token(uint32_t rank) const {
+        if (dec_is_dense) return rank < dec_dense.size() && dec_dense[rank].second ? &dec_dense[rank] : nullptr;
+        const auto it = dec_sparse.find(rank);
+        return it == dec_sparse.end() ? nullptr : &it->second;
+    }
+    template <class F>
+    void for_each_token(F&& f) const {  // f(rank, offset, length)
+        if (dec_is_dense) {
+            for (size_t r = 0; r < dec_dense.size(); ++r)
+                if (dec_dense[r].second) f((uint32_t)r, dec_dense[r].first, dec_dense[r].second);
+        } else {
+            for (const auto& kv : dec_sparse) f(kv.first, kv.second.first, kv.second.second);
+        }
+    }
+    // ranks ordered by token bytes (token_byte_values, lib.rs:648-650): needed by one API call only, so sorted on first use
+    const std::vector<uint32_t>& sorted_ranks() const;
+    mutable std::vector<uint32_t> sorted_ranks_;
+    mutable std::once_flag sorted_once_;
     uint32_t max_token_len = 0;
     uint64_t n_ranks = 0;
 

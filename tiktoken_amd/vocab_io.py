@@ -22,22 +22,64 @@ from . import _lib
 
 
 class RankTable(dict):
-    """`dict[bytes, int]` that also carries the packed (blob, offsets, ranks) arrays it was parsed from; any mutation
-    drops them, so a CoreBPE built from the table always sees the dict's current contents."""
+    """`dict[bytes, int]` as parsed from a `.tiktoken` file.  It carries the packed (blob, offsets, ranks) arrays it was parsed from
+    -- what `tk_create` takes, so building an Encoding never walks 200 000 Python objects -- and fills the dict itself from them on
+    first use (a fifth of a second for the o200k file; an `Encoding` needs only the count and the largest rank).  Any mutation drops
+    the arrays, so a CoreBPE built from the table always sees the dict's current contents.  C code that reads a dict's storage
+    directly (`PyDict_Next`) must be handed `table.materialize()`; everything at Python level fills the dict by itself."""
 
-    packed = None
+    packed = None  # (blob uint8[], off uint64[n+1], ranks uint32[n]) while they describe the dict exactly
+    _pending = None  # the same arrays until the dict has been filled from them
+
+    @classmethod
+    def from_packed(cls, blob: bytes, off: np.ndarray, ids: np.ndarray) -> "RankTable":
+        t = cls()
+        t._pending = (blob, off, ids)
+        t.packed = (np.frombuffer(blob, np.uint8) if blob else np.zeros(1, np.uint8), off, ids)
+        return t
+
+    def materialize(self) -> "RankTable":
+        pend, self._pending = self._pending, None
+        if pend is not None:
+            blob, off, ids = pend
+            bounds = off.tolist()
+            dict.update(self, zip((blob[a:b] for a, b in zip(bounds[:-1], bounds[1:])), ids.tolist()))
+            if dict.__len__(self) != len(ids):  # (duplicate keys collapse in the dict: then the packed form no longer matches it)
+                self.packed = None
+        return self
+
+    # (what an Encoding asks for without needing the dict)
+    def max_rank(self) -> int:
+        if self.packed is not None:
+            return int(self.packed[2].max()) if len(self.packed[2]) else 0
+        return max(self.values())
+
+    def _reading(name):  # noqa: N805
+        def method(self, *a, **k):
+            return getattr(dict, name)(self.materialize(), *a, **k)
+
+        method.__name__ = name
+        return method
 
     def _mutating(name):  # noqa: N805
         def method(self, *a, **k):
+            self.materialize()
             self.packed = None
             return getattr(dict, name)(self, *a, **k)
 
         method.__name__ = name
         return method
 
+    for _n in ("__len__", "__getitem__", "__contains__", "__iter__", "__reversed__", "__eq__", "__ne__", "__repr__", "__or__", "__ror__", "keys", "values", "items", "get",
+               "copy", "__sizeof__"):
+        locals()[_n] = _reading(_n)
     for _n in ("__setitem__", "__delitem__", "pop", "popitem", "clear", "update", "setdefault", "__ior__"):
         locals()[_n] = _mutating(_n)
-    del _n, _mutating
+    del _n, _mutating, _reading
+    __hash__ = None
+
+    def __reduce__(self):
+        return (dict, (dict(self.materialize()),))
 
 
 def parse_tiktoken_bpe(contents: bytes, source: str = "<bytes>") -> RankTable:
@@ -55,11 +97,7 @@ def parse_tiktoken_bpe(contents: bytes, source: str = "<bytes>") -> RankTable:
     finally:
         for p in (pb, po, pi):
             L.tk_free(p)
-    bounds = off.tolist()
-    table = RankTable(zip((blob[a:b] for a, b in zip(bounds[:-1], bounds[1:])), ids.tolist()))
-    if len(table) == cnt:  # (duplicate keys collapse in the dict: then the packed form no longer matches it)
-        table.packed = (np.frombuffer(blob, np.uint8) if blob else np.zeros(1, np.uint8), off, ids)
-    return table
+    return RankTable.from_packed(blob, off, ids)
 
 
 def dump_tiktoken_bpe(bpe_ranks: dict[bytes, int], tiktoken_bpe_file: str) -> None:
