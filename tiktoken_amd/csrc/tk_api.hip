@@ -70,7 +70,7 @@ struct KernelStat {
 // Work buffers of ONE chunk in flight.
 struct WorkSet {
     Buf text_al, tile_sum, wide_ws, scan_sums, row_base, brk, docb, cand, ss, si, starts, blockcnt, pstart, res, rflag, miss, staging, listB, listC, counters, total, g_id, g_rk,
-        g_nx, g_pv, g_lv, tile_np, tile_nt, tile_nmiss, mt_slots, wbin, wave_pieces, deferred, big, rx_spec, rx_gst, rx_exit;
+        g_nx, g_pv, g_lv, tile_np, tile_nt, tile_nmiss, mt_slots, wbin, wave_pieces, deferred, big, rx_spec, rx_gst, rx_exit, merge_work;
     hipStream_t sb = nullptr;        // the set's back stage in a multi-chunk batch: back stages of different chunks overlap each other too
                                      // (they are chains of short latency-bound kernels, ~2 ms however small the chunk)
     hipEvent_t ev_front = nullptr;   // the front kernel is done
@@ -83,7 +83,7 @@ struct WorkSet {
     std::vector<Buf*> all() {
         return {&text_al, &tile_sum, &wide_ws, &scan_sums, &row_base, &brk, &docb, &cand, &ss, &si, &starts, &blockcnt, &pstart, &res, &rflag, &miss, &staging, &listB,
                 &listC, &counters, &total, &g_id, &g_rk, &g_nx, &g_pv, &g_lv, &tile_np, &tile_nt, &tile_nmiss, &mt_slots, &wbin, &wave_pieces, &deferred, &big, &rx_spec,
-                &rx_gst, &rx_exit};
+                &rx_gst, &rx_exit, &merge_work};
     }
 };
 // What the front stage of a chunk leaves for its back stage.
@@ -560,6 +560,8 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
     clear(w.brk, (nwords + 2) * 4, 0u);
     clear(w.counters, TK_CNT_N * 4, 0u);
     clear(w.big, 4, 0u);
+    TRY(ensure(w.merge_work, 16 * TKM_WORK_STRIDE * 4));
+    clear(w.merge_work, 16 * TKM_WORK_STRIDE * 4, 0u);
     clear(w.total, 16, 0u);
     uint32_t *brk = w.brk.as<uint32_t>(), *starts = w.starts.as<uint32_t>();
     uint32_t *ss = nullptr, *si = nullptr, *docb = nullptr;
@@ -693,6 +695,17 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
         TRY(timed(c, s, "tk_k_binfill", [&] {
             hipLaunchKernelGGL(tk_k_binfill, dim3(dd_blocks), dim3(256), 0, s, ntiles, tile_nmiss, miss, wbin, w.listB.as<uint32_t>(), job.bins, counters, tpg);
         }));
+        if (T.pair8 && !(c->dbg & 0x800000)) {
+            // every bin in one launch (tk_k_merge_all); debug bit 0x800000: the kernel-per-bin form below
+            uint64_t most_units = 0;
+            for (int b = 0; b < TK_NBIN; ++b)
+                if (n >= tk_bin_lo(b)) most_units += (n / tk_bin_lo(b)) / (64u >> (b == 0 ? 0 : (b <= 2 ? 1 : (b <= 4 ? 2 : b - 2)))) + 1;
+            uint32_t wgs = (uint32_t)std::min<uint64_t>((most_units + 3) / 4, (uint64_t)c->n_cu * TKM_WGS_PER_CU);
+            wgs = std::max(4u, (wgs + 3u) & ~3u);  // (wavefronts: a multiple of 16, tk_k_merge_all's work counters rely on it)
+            TRY(timed(c, s, "tk_k_merge_all", [&] {
+                hipLaunchKernelGGL(tk_k_merge_all, dim3(wgs), dim3(256), 0, s, T, d_text, w.listB.as<uint32_t>(), job.bins, counters, miss, stg, w.merge_work.as<uint32_t>(), c->dbg);
+            }));
+        } else
         {
             // The bins are independent: spread them over the side streams, longest-tailed kernels first.  List lengths are
             // read on the device, so nothing waits for the host here; grids are sized by the most a bin can hold.

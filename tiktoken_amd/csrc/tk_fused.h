@@ -1628,6 +1628,273 @@ __global__ __launch_bounds__(256) void tk_k_merge_group(TkTables T, const uint8_
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// All the binned pieces (2 .. TK_GLANE_MAX bytes) in ONE launch.  The nine kernels above -- one per length bin, on side streams -- ran
+// as three chains on the device's hardware queues, each kernel as long as its slowest wavefront: 1.9 ms per GiB, of which the three
+// one-lane-per-piece kernels for 25..64-byte pieces took 0.25..0.73 ms each (a wavefront alone on its SIMD, a rank scan of up to 63 LDS
+// reads per merge).  Here a wavefront works on `units`: 64 / G pieces of one bin, G = 1 .. 64 lanes per piece, 16 part positions per
+// lane (the scheme of tk_k_merge_group with G a run-time value of the unit), taken longest bin first -- the first unit by the
+// wavefront's index, the next ones through sixteen work counters -- so the long chains of merges start at once and the short
+// pieces fill in behind them.
+//   * a position's LDS word is the KEY rank << 10 | position (packed pair table: ranks < 2^22), TKM_NOKEY for "no pair starts here":
+//     the lowest key is the leftmost lowest rank (lib.rs:151,190) -- one min-reduction per merge instead of two, and a lane's minimum over
+//     its 16 positions is four 16-byte LDS reads and fifteen v_min;
+//   * G = 1 (pieces of <= 16 bytes): no cross-lane step at all; the lane issues the first buckets of its two probes together.
+// Needs the packed pair table (every id <= TK_PAIR8_MAX_ID); vocabularies with larger ids keep the kernels above.
+// ------------------------------------------------------------------------------------------
+#define TKM_NOKEY 0xFFFFFFFFu
+__device__ __forceinline__ uint32_t tkm_key(uint32_t rank, uint32_t pos) { return rank == TK_RANK_MAX ? TKM_NOKEY : ((rank << 10) | pos); }
+__device__ __forceinline__ int tkm_lg_of_bin(int b) {  // log2 of the lanes per piece: 16 positions per lane
+    return b == 0 ? 0 : (b <= 2 ? 1 : (b <= 4 ? 2 : b - 2));  // bins <= 16, 24, 32, 48, 64, 128, 256, 512, 1024 bytes
+}
+// minimum over the aligned group of 1 << lg lanes, in every lane of it: DPP steps inside a row of 16 lanes (a few cycles each; a
+// bpermute goes through the LDS crossbar and this sits on the dependent chain of every merge), bpermutes only for 32 and 64 lanes
+__device__ __forceinline__ uint32_t tkm_group_min(uint32_t v, int lg) {
+    if (lg >= 1) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0xB1, 0xF, 0xF, false));   // quad_perm [1,0,3,2]: lane ^ 1
+    if (lg >= 2) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]: lane ^ 2
+    if (lg >= 3) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));  // row_half_mirror: the other quad of 8
+    if (lg >= 4) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));  // row_mirror: the other half of 16
+    if (lg >= 5) v = min(v, (uint32_t)__shfl_xor((int)v, 16, 64));
+    if (lg >= 6) v = min(v, (uint32_t)__shfl_xor((int)v, 32, 64));
+    return v;
+}
+// both probes of a merge by one lane: the first buckets of the two in flight together (packed table)
+__device__ __forceinline__ void tkm_probe2(const TkTables& T, uint32_t a0, uint32_t b0, bool on0, uint32_t a1, uint32_t b1, bool on1, uint32_t& r0, uint32_t& r1) {
+    r0 = r1 = TK_RANK_MAX;
+    const uint64_t k0 = ((uint64_t)a0 << TK_PAIR8_ID_BITS) | b0, k1 = ((uint64_t)a1 << TK_PAIR8_ID_BITS) | b1;
+    uint64_t bk0 = tk_pair_slot_hash(k0) & T.pair_mask, bk1 = tk_pair_slot_hash(k1) & T.pair_mask;
+    while (on0 || on1) {
+        ulonglong2 x0 = {0, 0}, x1 = {0, 0}, y0 = {0, 0}, y1 = {0, 0};
+        if (on0) {
+            x0 = *(const ulonglong2*)(T.pair8 + bk0 * 4);
+            x1 = *(const ulonglong2*)(T.pair8 + bk0 * 4 + 2);
+        }
+        if (on1) {
+            y0 = *(const ulonglong2*)(T.pair8 + bk1 * 4);
+            y1 = *(const ulonglong2*)(T.pair8 + bk1 * 4 + 2);
+        }
+        if (on0) {
+            const uint64_t s[4] = {x0.x, x0.y, x1.x, x1.y};
+            on0 = s[3] != TK_EMPTY_KEY;  // (a bucket with a free slot ends the search)
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((s[q] >> 22) == k0) {
+                    r0 = (uint32_t)(s[q] & 0x3FFFFFu);
+                    on0 = false;
+                }
+            bk0 = (bk0 + 1) & T.pair_mask;
+        }
+        if (on1) {
+            const uint64_t s[4] = {y0.x, y0.y, y1.x, y1.y};
+            on1 = s[3] != TK_EMPTY_KEY;
+#pragma unroll
+            for (int q = 0; q < 4; ++q)
+                if ((s[q] >> 22) == k1) {
+                    r1 = (uint32_t)(s[q] & 0x3FFFFFu);
+                    on1 = false;
+                }
+            bk1 = (bk1 + 1) & T.pair_mask;
+        }
+    }
+}
+#define TKM_WGS_PER_CU 5  // 32 KiB of LDS per workgroup
+#define TKM_WORK_STRIDE 64  // words between two work counters (256 bytes)
+__global__ __launch_bounds__(256, TKM_WGS_PER_CU) void tk_k_merge_all(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listB, TkBins bins,
+                                                                      uint32_t* __restrict__ counters, uint2* __restrict__ miss, uint32_t* __restrict__ staging,
+                                                                      uint32_t* __restrict__ work /* 16 counters, TKM_WORK_STRIDE words apart, zero */, int dbg) {
+    constexpr int C = 16;
+    constexpr uint32_t NONE = 0xFFFFu;
+    __shared__ __attribute__((aligned(16))) uint32_t s_id[4][1024];
+    __shared__ __attribute__((aligned(16))) uint32_t s_key[4][1024];
+    const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
+    uint32_t* id = s_id[wid] + lane * C;   // the lane's 16 positions (a piece's G lanes are neighbours: its positions are contiguous)
+    uint32_t* key = s_key[wid] + lane * C;
+    const uint32_t* idw = s_id[wid];
+    uint32_t* keyw = s_key[wid];
+    const uint32_t nwaves = gridDim.x * 4u;  // (a multiple of 16: see the work counters)
+    // units, longest bin first (wave-uniform; the counts were left by tk_k_binfill)
+    uint32_t ustart[TK_NBIN + 1];  // ustart[q]: first unit of the q-th bin in processing order (bin TK_NBIN - 1 - q)
+    ustart[0] = 0;
+#pragma unroll
+    for (int q = 0; q < TK_NBIN; ++q) {
+        const int b = TK_NBIN - 1 - q;
+        const uint32_t cnt = counters[TK_CNT_BIN0 + b], sh = 6u - (uint32_t)tkm_lg_of_bin(b);
+        ustart[q + 1] = ustart[q] + ((cnt + (1u << sh) - 1u) >> sh);
+    }
+    const uint32_t total_units = ustart[TK_NBIN];
+    uint32_t u = blockIdx.x * 4u + (uint32_t)wid;
+    auto local_min = [&]() -> uint32_t {
+        const uint4* q = (const uint4*)key;
+        const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
+        const uint32_t m0 = min(min(a.x, a.y), min(a.z, a.w)), m1 = min(min(b.x, b.y), min(b.z, b.w));
+        const uint32_t m2 = min(min(c.x, c.y), min(c.z, c.w)), m3 = min(min(d.x, d.y), min(d.z, d.w));
+        return min(min(m0, m1), min(m2, m3));
+    };
+    while (u < total_units) {
+        int q = 0;
+        uint32_t ubase = 0;  // = ustart[q] (no indexing by a run-time value: the table stays in scalar registers)
+#pragma unroll
+        for (int i = 1; i < TK_NBIN; ++i)
+            if (u >= ustart[i]) {
+                q = i;
+                ubase = ustart[i];
+            }
+        const int b = TK_NBIN - 1 - q;
+        const int lg = tkm_lg_of_bin(b);
+        const uint32_t G = 1u << lg, NMAX = G * C, ppw = 64u >> lg;
+        const uint32_t g = (uint32_t)lane & (G - 1u), grp = (uint32_t)lane >> lg, gbase = grp << lg;
+        // Long pieces are the kernel's critical path (a 1 KiB piece is ~700 merges, one after the other): their wavefronts get the SIMD's
+        // issue slots first, the short pieces' wavefronts fill the gaps
+        if (b >= 7) __builtin_amdgcn_s_setprio(3);
+        else if (b >= 5) __builtin_amdgcn_s_setprio(2);
+        else if (b >= 3) __builtin_amdgcn_s_setprio(1);
+        else __builtin_amdgcn_s_setprio(0);
+        const uint32_t count = counters[TK_CNT_BIN0 + b];
+        const uint32_t e = (u - ubase) * ppw + grp;
+        const bool valid = e < count;
+        uint32_t mi = 0, s = 0, n = 0;
+        if (valid) {
+            const uint32_t* le = listB + 3 * ((uint64_t)bins.off[b] + e);
+            mi = le[0];
+            s = le[1];
+            n = le[2];
+        }
+        // the lane's 16 parts: ids of the single bytes, keys of the 2-byte pairs (17 text bytes: three aligned words)
+        uint32_t mask = 0;
+        {
+            const uint32_t k0 = g * C;
+            uint64_t w0 = 0, w1 = 0, w2 = 0;
+            if (k0 < n) {
+                w0 = tk_load8(text, (uint64_t)s + k0);
+                w1 = tk_load8(text, (uint64_t)s + k0 + 8);
+                w2 = tk_load8(text, (uint64_t)s + k0 + 16);
+            }
+            uint32_t rr[C];
+#pragma unroll
+            for (int c = 0; c < C; ++c) {
+                const uint32_t k = k0 + c;
+                const uint32_t b0 = (uint32_t)((c < 8 ? w0 >> (8 * c) : w1 >> (8 * (c - 8))) & 0xFFu);
+                const uint32_t b1 = (uint32_t)((c < 7 ? w0 >> (8 * (c + 1)) : (c < 15 ? w1 >> (8 * (c - 7)) : w2)) & 0xFFu);
+                rr[c] = TK_RANK_MAX;
+                if (k < n) {
+                    id[c] = T.byte_rank[b0];
+                    if (k + 1 < n) rr[c] = T.pair2[(b0 << 8) | b1];
+                    mask |= 1u << c;
+                }
+            }
+#pragma unroll
+            for (int c = 0; c < C; ++c) key[c] = tkm_key(rr[c], k0 + c);
+        }
+        __builtin_amdgcn_wave_barrier();
+        uint32_t lkey = local_min();
+        // (perf experiments, debug bits 25..28 = bin + 1: only that bin is merged, the pieces of the others come out as their single bytes)
+        if (((dbg >> 25) & 15) && ((dbg >> 25) & 15) - 1 != b) lkey = TKM_NOKEY;
+        for (;;) {
+            // the piece's lowest key: leftmost lowest rank
+            const uint32_t best = tkm_group_min(lkey, lg);
+            const bool fin = best == TKM_NOKEY;
+            if (__all(fin)) break;
+            const uint32_t bi = best & (NMAX - 1u), brank = best >> 10, ob = bi / C, bl = bi % C;
+            // neighbours through the lanes' alive masks: j = the part being absorbed, nn = the part after it, pp = the part before bi
+            const uint64_t nbw = __ballot(mask != 0);
+            const uint64_t nb = lg == 6 ? nbw : ((nbw >> gbase) & ((1ull << G) - 1ull));
+            const uint32_t my_first = mask ? (uint32_t)(g * C + __ffs((int)mask) - 1) : NONE;
+            const uint32_t my_last = mask ? (uint32_t)(g * C + 31 - __clz((int)mask)) : NONE;
+            const uint32_t om = __shfl(mask, gbase + (int)ob, 64);
+            uint32_t j;
+            {
+                const uint32_t hi = om & ~((2u << bl) - 1u);
+                const uint64_t la = nb & ~((2ull << ob) - 1ull);
+                const int lj = la ? __ffsll((unsigned long long)la) - 1 : 0;
+                const uint32_t fj = __shfl(my_first, gbase + lj, 64);
+                j = hi ? ob * C + (uint32_t)__ffs((int)hi) - 1u : fj;
+            }
+            j &= (NMAX - 1u);
+            const uint32_t oj = j / C, jl = j % C;
+            uint32_t nn;
+            {
+                const uint32_t ojm = __shfl(mask, gbase + (int)oj, 64);
+                const uint32_t hi = ojm & ~((2u << jl) - 1u);
+                const uint64_t la = nb & ~((2ull << oj) - 1ull);
+                const int ln = la ? __ffsll((unsigned long long)la) - 1 : 0;
+                const uint32_t fn = __shfl(my_first, gbase + ln, 64);
+                nn = hi ? oj * C + (uint32_t)__ffs((int)hi) - 1u : (la ? fn : NONE);
+            }
+            uint32_t pp;
+            {
+                const uint32_t lo = om & ((1u << bl) - 1u);
+                const uint64_t lb = nb & ((1ull << ob) - 1ull);
+                const int lp = lb ? 63 - __clzll((long long)lb) : 0;
+                const uint32_t fl = __shfl(my_last, gbase + lp, 64);
+                pp = lo ? ob * C + 31u - (uint32_t)__clz((int)lo) : (lb ? fl : NONE);
+            }
+            // the two new pairs: (merged, next) and (previous, merged)
+            const uint32_t* pid = idw + gbase * C;  // the piece's positions
+            uint32_t newr_i = TK_RANK_MAX, newr_p = TK_RANK_MAX;
+            if (dbg & 0x1000000) {  // (perf experiments: no probes -- wrong tokens, the cost of everything else)
+            } else if (lg == 0) {
+                if (!fin) tkm_probe2(T, brank, nn != NONE ? pid[nn & (NMAX - 1u)] : 0u, nn != NONE, pp != NONE ? pid[pp & (NMAX - 1u)] : 0u, brank, pp != NONE, newr_i, newr_p);
+            } else {
+                uint32_t newr = TK_RANK_MAX;
+                if (!fin) {
+                    if (g == 0 && nn != NONE) newr = tk_probe_pair(T, brank, pid[nn]);
+                    if (g == 1 && pp != NONE) newr = tk_probe_pair(T, pid[pp], brank);
+                }
+                newr_i = __shfl(newr, gbase, 64);
+                newr_p = __shfl(newr, gbase + 1, 64);
+            }
+            __builtin_amdgcn_wave_barrier();
+            bool touched = false;
+            uint32_t* pkey = keyw + gbase * C;
+            if (!fin) {
+                if (g == ob) {
+                    id[bl] = brank;
+                    key[bl] = tkm_key(newr_i, bi);
+                    touched = true;
+                }
+                if (g == oj) {
+                    mask &= ~(1u << jl);
+                    key[jl] = TKM_NOKEY;
+                    touched = true;
+                }
+                if (pp != NONE && g == pp / C) {
+                    pkey[pp] = tkm_key(newr_p, pp);
+                    touched = true;
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+            if (touched) lkey = local_min();
+        }
+        // the piece's tokens, in order, to the staging area at its text position
+        const uint32_t mine = __popc(mask);
+        uint32_t inc = mine;
+        for (uint32_t o = 1; o < G; o <<= 1) {
+            const uint32_t w = __shfl_up(inc, o, 64);
+            if (g >= o) inc += w;
+        }
+        const uint32_t total = __shfl(inc, gbase + G - 1, 64);
+        if (valid) {
+            uint32_t t = inc - mine, mm = mask;
+            while (mm) {
+                const int c = __ffs((int)mm) - 1;
+                mm &= mm - 1;
+                staging[s + t++] = id[c];
+            }
+            if (g == 0) miss[mi] = make_uint2(total, total == 1 ? id[0] : s);
+        }
+        __builtin_amdgcn_wave_barrier();
+        // The next unit: sixteen counters share the requests, each in a cache line of its own -- atomics on one LINE are served one after
+        // the other at the memory side (with the sixteen in one line, 34 000 requests cost 1.1 ms: half the kernel).  Counter c hands out the
+        // units nwaves + c, nwaves + c + 16, ...
+        uint32_t nu = 0;
+        {
+            const uint32_t cidx = (blockIdx.x * 4u + (uint32_t)wid) & 15u;
+            if (lane == 0) nu = nwaves + cidx + 16u * atomicAdd(&work[cidx * TKM_WORK_STRIDE], 1u);
+        }
+        u = (uint32_t)__shfl((int)nu, 0, 64);
+    }
+}
+
 // (redo_only: after tk_k_merge_rounds -- only the pieces it has marked TK_MERGE_REDO)
 __global__ __launch_bounds__(256) void tk_k_merge_long(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listC,
                                                         uint32_t nC, uint32_t* __restrict__ g_id, uint32_t* __restrict__ g_rk,
