@@ -111,6 +111,41 @@ class DevArray:
         self.__cuda_array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, False), "version": 2}
 
 
+def one_process(args, torch):
+    """bench.py --gpus N --one-process: the product's own several-GPU path.  N document shards of --mib MiB each, host text in (the group's
+    contract), every shard encoded on its device, ids gathered on the first device; value = PCIe-inclusive aggregate rate."""
+    import tiktoken_amd  # noqa: F401
+    from tiktoken_amd._tiktoken import CoreBPE
+    from tiktoken_ext import amd_shaped
+
+    n = args.gpus
+    have = torch.cuda.device_count()
+    devices = list(range(n)) if have >= n else [i % max(have, 1) for i in range(n)]
+    ncpu = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    parts, offs, base = [], [np.zeros(1, np.uint64)], 0
+    for r in range(n):
+        b, o = gen_corpus(0x5EED0004 + r, 1, args.mib << 20, min(ncpu, 32))
+        parts.append(b[: int(o[-1])])
+        offs.append(o[1:] + np.uint64(base))
+        base += int(o[-1])
+    blob = np.concatenate(parts + [np.zeros(64, np.uint8)])[:base]
+    doc_off = np.concatenate(offs)
+    spec = amd_shaped.ENCODING_CONSTRUCTORS[args.encoding]()
+    core = CoreBPE(spec["mergeable_ranks"], spec["special_tokens"], spec["pat_str"], devices=devices)
+    for _ in range(args.warmup):
+        core.encode_batch_gathered(blob, doc_off)
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        dt, nt, do = core.encode_batch_gathered(blob, doc_off)
+    el = time.perf_counter() - t0
+    print(json.dumps({"metric": "GB/s text encoded, one process driving N devices (host text in, ids gathered on device 0): PCIe-inclusive",
+                      "value": round(base * args.steps / el / 1e9, 3), "unit": "GB/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
+                      "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
+                      "data": "synthetic", "config": {"workload": f"{args.encoding}, {n} shards of {args.mib} MiB, tk_group_encode_batch_device",
+                                                      "devices": devices, "tokens_total": int(nt),
+                                                      "gather": "rccl" if core.group_stat("gathers_rccl") else "peer copies"}}), flush=True)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,12 +158,17 @@ def main():
     ap.add_argument("--no-host-path", action="store_true", help="skip the T2 / T3 host-boundary timings")
     ap.add_argument("--t3-sample-mib", type=int, default=64)
     ap.add_argument("--no-hf", action="store_true", help="skip the HF tokenizers context figure of the CPU baseline")
+    ap.add_argument("--one-process", action="store_true",
+                    help="NOT the driver's mode: drive the product's several-GPU entry (CoreBPE(devices=...), tk_group_encode_batch_device: host text in, "
+                         "ids gathered on device 0 over xGMI) from this one process; a device is named several times when the box has fewer GPUs")
     ap.add_argument("--generic-engine", action="store_true",
                     help="NOT the headline: run the encoding's pat_str on the generic regex engine instead of the hand-written scanners")
     args = ap.parse_args()
 
     import torch
 
+    if args.one_process:
+        return one_process(args, torch)
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))

@@ -353,7 +353,8 @@ class RxSim:
             self._h = None
 
     def split(self, docs: list[bytes], specials: list[tuple[int, int]] = (), speculate: int | bool = True) -> list[int]:
-        """Piece starts (byte offsets into the packed batch) of the documents; specials: (offset, length) of allowed special tokens.
+        """Piece starts (byte offsets into the packed batch) of the documents -- gap chars included, listed in self.gaps as well;
+        specials: (offset, length) of allowed special tokens.
         speculate: False = the matcher alone walks every document; True / 1 = with the speculative pass over 256-byte segments; 2 = 1 KiB."""
         blob, off = pack(docs)
         n = len(blob)
@@ -367,4 +368,5 @@ class RxSim:
         self.stats = (int(stats[0]), int(stats[1]))
         if rc:
             raise RuntimeError(f"split error {rc & 255} at byte {rc >> 8}")
+        self.gaps = np.flatnonzero(starts[:n] & 2).tolist()  # the starts that are gap chars (the pattern matches nothing there)
         return np.flatnonzero(starts[:n]).tolist()

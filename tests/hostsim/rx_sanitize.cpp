@@ -119,17 +119,19 @@ int main(int argc, char** argv) {
                 uint32_t* xexit = (uint32_t*)malloc((nseg + 2) * 4);
                 memset(spec, 0, nw * 4);
                 memset(gst, 0, nw * 4);
+                uint32_t* sgap = (uint32_t*)calloc(nw, 4);
                 TkRxText t{text, n, brk, with_specials ? ss : nullptr, with_specials ? si : nullptr, 0xFFFFFFFFu, false};
-                for (uint32_t s = 0; s < nseg; ++s) tk_rx_speculate_lane(P, t, s, shift, spec, xexit);
+                for (uint32_t s = 0; s < nseg; ++s) tk_rx_speculate_lane(P, t, s, shift, spec, sgap, xexit);
                 for (size_t d = 0; d + 1 < doc.size(); ++d) {
                     uint32_t err_pos = 0;
-                    (void)tk_rx_resolve_lane(P, t, doc[d], doc[d + 1], shift, spec, xexit, [&](uint32_t w, uint32_t bits) {
-                        if (w >= nw) abort();
+                    (void)tk_rx_resolve_lane(P, t, doc[d], doc[d + 1], shift, spec, sgap, xexit, [&](uint32_t w, uint32_t bits, uint32_t gaps) {
+                        if (w >= nw || (gaps & ~(gst[w] | bits))) abort();  // (a gap char is a start)
                         gst[w] |= bits;
                     }, &err_pos);
                 }
                 ++splits;
                 free(xexit);
+                free(sgap);
             }
             free(text);
             free(brk);

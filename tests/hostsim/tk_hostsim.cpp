@@ -666,7 +666,7 @@ uint64_t tks_rx_split(void* p, const uint8_t* text_in, uint64_t n, const uint64_
     std::vector<uint8_t> text(text_in, text_in + n);
     text.resize(n + 64, 0);
     const uint64_t nw = (n + 31) / 32 + 2;
-    std::vector<uint32_t> brk(nw, 0), ss(nw, 0), si(nw, 0), spec(nw, 0), gst(nw, 0);
+    std::vector<uint32_t> brk(nw, 0), ss(nw, 0), si(nw, 0), spec(nw, 0), sgap(nw, 0), gst(nw, 0), ggap(nw, 0);
     auto setb = [](std::vector<uint32_t>& v, uint64_t q) { v[q >> 5] |= 1u << (q & 31); };
     for (uint64_t d = 0; d < n_docs; ++d)
         if (doc_off[d] < n) setb(brk, doc_off[d]);
@@ -681,18 +681,22 @@ uint64_t tks_rx_split(void* p, const uint8_t* text_in, uint64_t n, const uint64_
     std::vector<uint32_t> xexit(nseg + 1, TK_RX_UNKNOWN);
     g_rx_matches = 0;
     if (speculate)
-        for (uint32_t k = 0; k < nseg; ++k) tk_rx_speculate_lane(P, t, k, seg_shift, spec.data(), xexit.data());
+        for (uint32_t k = 0; k < nseg; ++k) tk_rx_speculate_lane(P, t, k, seg_shift, spec.data(), sgap.data(), xexit.data());
     stats[0] = g_rx_matches;
     g_rx_matches = 0;
     uint64_t rc = 0;
     for (uint64_t d = 0; d < n_docs && !rc; ++d) {
         uint32_t err_pos = 0;
-        const uint32_t e = tk_rx_resolve_lane(P, t, (uint32_t)doc_off[d], (uint32_t)doc_off[d + 1], seg_shift, speculate ? spec.data() : nullptr, xexit.data(),
-                                              [&](uint32_t w, uint32_t bits) { gst[w] |= bits; }, &err_pos);
+        const uint32_t e = tk_rx_resolve_lane(P, t, (uint32_t)doc_off[d], (uint32_t)doc_off[d + 1], seg_shift, speculate ? spec.data() : nullptr, sgap.data(), xexit.data(),
+                                              [&](uint32_t w, uint32_t bits, uint32_t gaps) {
+                                                  gst[w] |= bits;
+                                                  ggap[w] |= gaps;
+                                              },
+                                              &err_pos);
         if (e) rc = e | ((uint64_t)err_pos << 8);
     }
     stats[1] = g_rx_matches;
-    for (uint64_t i = 0; i < n; ++i) starts[i] = (gst[i >> 5] >> (i & 31)) & 1u;
+    for (uint64_t i = 0; i < n; ++i) starts[i] = ((gst[i >> 5] >> (i & 31)) & 1u) | (((ggap[i >> 5] >> (i & 31)) & 1u) << 1);  // bit 1: a gap char
     return rc;
 }
 

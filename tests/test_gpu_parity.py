@@ -418,12 +418,19 @@ def test_multi_device_group_equals_single_device():
     st, so = C.encode_batch(blob, off, {"<|endoftext|>"}, 8)
     toks, toff = core.encode_batch_packed(blob, off, {"<|endoftext|>"})
     assert np.array_equal(toff, so) and np.array_equal(toks, st)
-    # ragged: fewer documents than replicas, empty documents, an empty batch
-    for docs in ([b"one"], [b"", b""], [], [b"a", b"", b"bb " * 1000, b""]):
+    # ragged: fewer documents than replicas, empty documents, an empty batch -- through the host gather and through the device gather
+    # (whose shards never take the one-launch small path: that one writes to host memory only)
+    for docs in ([b"one"], [b"a", b"b"], [b"", b""], [], [b"a", b"", b"bb " * 1000, b""], [b"x" * 5000, b"", b"", b"tail"]):
         b2, o2 = h.pack(docs)
         t2, f2 = core.encode_batch_packed(b2, o2)
         w2, x2 = C.encode_batch(b2, o2, None, 1) if docs else (np.zeros(0, np.uint32), np.zeros(1, np.uint64))
         assert np.array_equal(t2, w2) and np.array_equal(f2, x2), docs
+        dt, nt, do = core.encode_batch_gathered(b2, o2)
+        assert nt == len(w2), docs
+        if nt:
+            assert np.array_equal(torch.as_tensor(DevArray(dt, nt, "<i4"), device="cuda").cpu().numpy().view(np.uint32), w2), docs
+        assert np.array_equal(torch.as_tensor(DevArray(do, len(o2), "<i8"), device="cuda").cpu().numpy().astype(np.uint64), x2), docs
+    assert core.group_stat("gathers_peer") > 0 and core.group_stat("gathers_rccl") == 0  # (virtual ranks share a device: no RCCL here)
 
 
 # ---------------------------------------------------------------- small calls: one launch (tk_k_small)

@@ -7,7 +7,7 @@ import pytest
 import regex
 
 import helpers as h
-from test_regex_engine import PATTERNS, py_starts, random_text
+from test_regex_engine import PATTERNS, py_starts, py_starts_gaps, random_text
 
 pytestmark = pytest.mark.gpu
 NAME = "o200k_shaped"
@@ -19,9 +19,9 @@ def make_core(pat, specials=None):
     return CoreBPE(h.golden_vocab(NAME), specials if specials is not None else h.load_golden(NAME)["special_tokens"], pat)
 
 
-def make_docs(rng, count, big=0):
-    """Documents for patterns that cover every text (no gaps): short adversarial strings, awkward documents, `big` long ones with runs."""
-    docs = [random_text(rng, rng.choice([0, 1, 3, 30, 300, 3000])) if rng.random() < 0.75 else h.fuzz_doc(rng)[:20000] for _ in range(count)]
+def make_docs(rng, count, big=0, cap=20000):
+    """Short adversarial strings, awkward documents (cut at `cap` chars), `big` long ones with runs."""
+    docs = [random_text(rng, rng.choice([0, 1, 3, 30, 300, 3000])) if rng.random() < 0.75 else h.fuzz_doc(rng)[:cap] for _ in range(count)]
     for _ in range(big):
         parts = []
         while sum(map(len, parts)) < 1_500_000:
@@ -43,7 +43,7 @@ def oracle_tokens(py_pat, docs, C, cache):
     return np.array(toks, np.uint32), np.array(off, np.uint64)
 
 
-# (patterns 9 and 13 leave gaps on most texts: their split is covered by the CPU tests, which run the kernels' lanes one by one)
+# (patterns 9 and 13 leave gaps on most texts: test_text_the_pattern_does_not_match_yields_no_tokens)
 @pytest.mark.parametrize("idx", [5, 6, 7, 8, 10, 11, 12, 14, 16, 17, 18, 19])
 def test_split_and_tokens_equal_python_regex_plus_oracle(idx):
     pat, py = PATTERNS[idx]
@@ -115,14 +115,41 @@ def test_special_tokens_batch():
     assert np.array_equal(got, np.array(toks, np.uint32))
 
 
-def test_gaps_and_deep_backtracking_are_refused_loudly():
+def test_text_the_pattern_does_not_match_yields_no_tokens():
+    """find_iter (src/lib.rs:365,405) goes on behind text the pattern does not match: the reference drops it.  Split and tokens against
+    Python `regex.finditer` + the oracle's byte_pair_encode, for patterns that leave gaps on most texts."""
+    C = h.c_oracle_for(NAME)
     core = make_core(r"\w+|\s+")
-    blob, off = h.pack([b"fine words only", b"hello, world"])
-    with pytest.raises(ValueError, match="does not match at byte 20"):
-        core.encode_batch_packed(blob, off)
-    with pytest.raises(ValueError, match="does not match at byte 20"):
-        core.pretokenize_packed(blob, off)
+    blob, off = h.pack([b"fine words only", b"hello, world", "¡hola! ¿qué?".encode(), b"", b"!!", b"..."])
+    toks, toff = core.encode_batch_packed(blob, off)
+    rt, ro = oracle_tokens(r"\w+|\s+", ["fine words only", "hello, world", "¡hola! ¿qué?", "", "!!", "..."], C, {})
+    assert np.array_equal(toff, ro) and np.array_equal(toks, rt)
+    assert core.pretokenize_packed(blob, off).tolist()[:8] == [0, 4, 5, 10, 11, 15, 20, 21] and 20 in core.last_gaps.tolist()
     assert core.encode_ordinary("fine words only") == make_core(r"\w+|\s+|[^\w\s]+").encode_ordinary("fine words only")
+    assert core.encode_ordinary("?!") == []
+    for idx, pat in ((9, None), (13, None), (-1, r"\p{L}+|\d"), (-2, r"[a-m]+(?=[n-z])|\s")):
+        pat, py = (PATTERNS[idx][0], PATTERNS[idx][1] or PATTERNS[idx][0]) if idx >= 0 else (pat, pat)
+        core = make_core(pat)
+        rng = random.Random(4000 + idx)
+        # (documents cut at 1000 chars: a pattern like ` ?\p{L}+(?='s)` fails at every char of a run of letters after scanning it to its end --
+        #  quadratic in the run for any backtracking matcher, the reference's included, and a GPU lane is a slow place for that)
+        docs = make_docs(rng, 150, big=1 if idx == -1 else 0, cap=1000)
+        blob, off = h.pack([d.encode() for d in docs])
+        want, wgap, base = [], [], 0
+        for d in docs:
+            st, gp = py_starts_gaps(py, d)
+            want += [base + v for v in st]
+            wgap += [base + v for v in gp]
+            base += len(d.encode())
+        assert len(wgap) > 100
+        got = core.pretokenize_packed(blob, off)
+        assert got.tolist() == want + [len(blob)] and core.last_gaps.tolist() == wgap, pat
+        rt, ro = oracle_tokens(py, docs, C, {})
+        toks, toff = core.encode_batch_packed(blob, off)
+        assert np.array_equal(toff, ro) and np.array_equal(toks, rt), pat
+
+
+def test_deep_backtracking_is_refused_loudly():
     core = make_core(r"(?:\w\w)*\w!|\w|!")
     assert core.encode_ordinary("abc!abc!") == make_core(r"\w\w\w!").encode_ordinary("abc!abc!")
     with pytest.raises(ValueError, match="possessive"):

@@ -250,7 +250,8 @@ class CoreBPE:
 
     def pretokenize_packed(self, blob: np.ndarray, doc_off: np.ndarray, allowed_special: AbstractSet[str] | None = None) -> np.ndarray:
         """Piece start offsets (uint32, ascending, plus a final sentinel = total bytes) of a packed batch --
-        what `regex.find_iter` yields at src/lib.rs:365/405, computed by the GPU pre-tokeniser."""
+        what `regex.find_iter` yields at src/lib.rs:365/405, computed by the GPU pre-tokeniser.  Chars the pattern does not match
+        (generic engine only) are steps of their own; their offsets are also left in `self.last_gaps`."""
         blob = np.ascontiguousarray(blob, dtype=np.uint8)
         doc_off = np.ascontiguousarray(doc_off, dtype=np.uint64)
         _check_packed(blob, doc_off)
@@ -264,7 +265,10 @@ class CoreBPE:
         rc = self._L.tk_pretokenize_batch(self._h, src.ctypes.data, doc_off.ctypes.data, len(doc_off) - 1, mode,
                                           ids.ctypes.data, k, ctypes.byref(out), ctypes.byref(n))
         _lib.raise_for(rc)
-        return _take_u32(out, n.value)
+        starts = _take_u32(out, n.value)
+        # bit 31: a char at which a pat_str of the generic engine matches nothing (find_iter skips it: no token) -- kept in self.last_gaps
+        self.last_gaps = (starts[starts >= 0x80000000] & 0x7FFFFFFF).astype(np.uint32)
+        return starts & np.uint32(0x7FFFFFFF) if len(self.last_gaps) else starts
 
     def encode_single_token(self, piece: bytes) -> int:
         tok = ctypes.c_uint32()

@@ -471,9 +471,6 @@ static int scan_u32(tk_core* c, WorkSet& w, hipStream_t s, uint32_t* a, uint64_t
 // the generic pat_str engine gave up on a piece (tk_regex_split.h): which way, and where
 static int rx_failure(const uint32_t* counters, uint64_t base) {
     const std::string at = std::to_string(base + (uint64_t)(~counters[TK_CNT_RXPOS]));
-    if (counters[TK_CNT_ERR] & TK_RX_ERR_GAP)
-        return fail(TK_VALUE_ERROR, "pat_str does not match at byte " + at +
-                                        " of the batch: the reference would drop the text up to the next match; this library refuses patterns that leave gaps");
     if (counters[TK_CNT_ERR] & TK_RX_ERR_STACK)
         return fail(TK_VALUE_ERROR, "pat_str: a repeated group needs more backtracking state than the matcher keeps (piece at byte " + at +
                                         " of the batch); make the group possessive, e.g. (?:...)++");
@@ -502,7 +499,8 @@ static int stage_deferred(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream
         TRY(timed(c, s, "tk_k_front_slow", [&] {
             const dim3 grid((uint32_t)(job.ntiles < 1024 ? job.ntiles : 1024));
             launch_front<true>(T.pat.generic() ? TK_PAT_GENERIC : T.pattern, job.spec, grid, s, T, job.d_text, job.n, job.base, w.brk.as<uint32_t>(), docb, ss, si, fo,
-                               (c->dbg & 256) ? (TkMissSlot*)nullptr : job.mt, (1u << job.mt_bits) - 1u, w.deferred.as<uint32_t>(), c->dbg);
+                               (c->dbg & 256) ? (TkMissSlot*)nullptr : job.mt, (1u << job.mt_bits) - 1u, w.deferred.as<uint32_t>(),
+                               c->has_rx ? w.rx_gst.as<uint32_t>() + (job.n + 31) / 32 + 2 : (const uint32_t*)nullptr, c->dbg);
         }));
     }
     HIPCHK(hipMemcpyAsync(w.h_counters, w.counters.p, TK_CNT_N * 4, hipMemcpyDeviceToHost, s));
@@ -583,10 +581,11 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
             si = w.si.as<uint32_t>();
         }
         if (c->has_rx) {
-            TRY(ensure(w.rx_spec, (nwords + 2) * 4));
-            TRY(ensure(w.rx_gst, (nwords + 2) * 4));
-            clear(w.rx_spec, (nwords + 2) * 4, 0u);
-            clear(w.rx_gst, (nwords + 2) * 4, 0u);
+            // (two bitmaps each: the starts, and behind them the gap chars among the starts)
+            TRY(ensure(w.rx_spec, 2 * (nwords + 2) * 4));
+            TRY(ensure(w.rx_gst, 2 * (nwords + 2) * 4));
+            clear(w.rx_spec, 2 * (nwords + 2) * 4, 0u);
+            clear(w.rx_gst, 2 * (nwords + 2) * 4, 0u);
         }
         if (n > 32768 && !pretok_only) {  // in-call de-duplication of missed pieces pays for its table reset only on real batches
             while (job.mt_bits < TK_MT_BITS && (1ull << job.mt_bits) < n / 128) ++job.mt_bits;  // 4 Mi slots from 512 MiB up
@@ -616,11 +615,11 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
             TRY(ensure(w.rx_exit, (nseg + 2) * 4));
             uint32_t *spec = w.rx_spec.as<uint32_t>(), *gst = w.rx_gst.as<uint32_t>(), *xexit = w.rx_exit.as<uint32_t>();
             TRY(timed(c, s, "tk_k_rx_speculate", [&] {
-                hipLaunchKernelGGL(tk_k_rx_speculate, dim3(grid_for(nseg, 256, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, seg_shift, spec, xexit);
+                hipLaunchKernelGGL(tk_k_rx_speculate, dim3(grid_for(nseg, 256, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, seg_shift, spec, spec + nwords + 2, xexit);
             }));
             TRY(timed(c, s, "tk_k_rx_resolve", [&] {
                 hipLaunchKernelGGL(tk_k_rx_resolve, dim3(grid_for(n_docs, 256, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, d_doc_off, n_docs,
-                                   base, seg_shift, spec, xexit, gst, counters);
+                                   base, seg_shift, spec, spec + nwords + 2, xexit, gst, gst + nwords + 2, counters);
             }));
             TRY(timed(c, s, "tk_k_rx_merge", [&] { hipLaunchKernelGGL(tk_k_rx_merge, dim3(grid_for(nwords, 256, 4096)), dim3(256), 0, s, brk, gst, nwords); }));
         }
@@ -632,7 +631,7 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
             const uint64_t resident = TKF_HOT_BITS ? (uint64_t)c->n_cu * c->front_wgs : ntiles;
             const dim3 grid((uint32_t)(ntiles < resident ? ntiles : resident));
             launch_front<false>(T.pat.generic() ? TK_PAT_GENERIC : T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, fo,
-                                mt_arg, (1u << job.mt_bits) - 1u, deferred, c->dbg);
+                                mt_arg, (1u << job.mt_bits) - 1u, deferred, c->has_rx ? w.rx_gst.as<uint32_t>() + nwords + 2 : (const uint32_t*)nullptr, c->dbg);
         }));
     } else if (n > 0) {
         hipLaunchKernelGGL(tk_k_chunk_clear, dim3(1), dim3(256), 0, s, clr);
@@ -659,7 +658,7 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
             TRY(ensure(w.pstart, (P + 2) * 4));
             TRY(timed(c, s, "tk_k_emit", [&] {
                 hipLaunchKernelGGL(tk_k_emit, dim3((uint32_t)nblk), dim3(256), 0, s, starts, nwords, w.blockcnt.as<uint32_t>(),
-                                   w.pstart.as<uint32_t>(), P, n);
+                                   w.pstart.as<uint32_t>(), P, n, c->has_rx ? w.rx_gst.as<uint32_t>() + nwords + 2 : (const uint32_t*)nullptr);
             }));
         } else {
             HIPCHK(hipMemsetAsync(w.pstart.p, 0, 4, s));

@@ -47,6 +47,7 @@
 // tokens will be once the merge kernels have run.
 #define TK_RES_FLAG 0x80000000u  // not a single token: TK_RES_FLAG | j = entry j of the tile's miss list (its result replaces the entry)
 #define TK_RES_DUP 0xC0000000u   // TK_RES_DUP | slot = duplicate of the piece that claimed this slot of the in-call miss table
+#define TK_RES_GAP 0x7FFFFFFFu   // no token at all: a char at which a pat_str of the generic engine matches nothing (find_iter skips it, src/lib.rs:365)
 struct TkFrontOut {
     uint32_t* starts;     // piece-start bitmap (n/32 words; each tile stores its own 120 words)
     uint32_t* tile_np;    // pieces per tile
@@ -495,7 +496,8 @@ template <int PAT, bool SPEC, bool SLOW>
 __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
                                                   const uint32_t* __restrict__ brk, const uint32_t* __restrict__ docb,
                                                   const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, TkFrontOut out,
-                                                  TkMissSlot* __restrict__ mt, uint32_t mt_mask, uint32_t* __restrict__ deferred, int dbg) {
+                                                  TkMissSlot* __restrict__ mt, uint32_t mt_mask, uint32_t* __restrict__ deferred,
+                                                  const uint32_t* __restrict__ gapb /* gap chars of the generic engine's split, or null */, int dbg) {
     // the pattern: a compile-time constant for the three stock patterns; PAT = TK_PAT_GENERIC reads family and parameters from the tables
     constexpr bool GEN = PAT == TK_PAT_GENERIC;
     const TkPat pat = GEN ? T.pat : tk_stock_pat(PAT);
@@ -1058,6 +1060,10 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
                 cls = len <= 4u ? 0u : (len <= 8u ? 1u : 2u);
                 if (SPEC && ((ssw[s_loc >> 5] >> (s_loc & 31u)) & 1u)) {  // a special token: its id (src/lib.rs:426-434)
                     out.res[run_base + k] = tk_special_id(T, text, (uint64_t)(base + s_loc), len);
+                    cls = 3;
+                } else if (GEN && gapb && ((gapb[(uint64_t)(base + s_loc) >> 5] >> ((uint32_t)(base + s_loc) & 31u)) & 1u)) {  // a gap char: no token
+                    // (read from global memory per piece: only a pat_str of the generic engine has the bitmap, and LDS is what this kernel lacks)
+                    out.res[run_base + k] = TK_RES_GAP;
                     cls = 3;
                 } else if (HOT && use_hot && len <= TK_HOT_MAXLEN) {  // the piece cache in LDS first; the tables in HBM only on a miss
                     uint32_t k0, k1, k2;
@@ -2367,7 +2373,7 @@ __global__ __launch_bounds__(256) void tk_k_tile_finish(uint64_t ntiles, const u
 #pragma unroll
             for (int j = 0; j < 4; ++j) {  // all four loads in flight together
                 const bool live = k + j < np, flagged = live && (r[j] & TK_RES_FLAG);
-                v[j] = make_uint2(live ? 1u : 0u, 0u);
+                v[j] = make_uint2(live && r[j] != TK_RES_GAP ? 1u : 0u, 0u);
                 if (flagged) {
                     if ((r[j] & TK_RES_DUP) == TK_RES_DUP) v[j] = *(const uint2*)&mt[r[j] & ~TK_RES_DUP].res_cnt;
                     else v[j] = miss[mb + (r[j] & ~TK_RES_FLAG)];
@@ -2417,7 +2423,7 @@ __global__ __launch_bounds__(256) void tk_k_back(uint64_t ntiles, const uint32_t
             uint32_t nf = 0;
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
-                c[j] = k + j < np ? 1u : 0u;
+                c[j] = (k + j < np && tk[j] != TK_RES_GAP) ? 1u : 0u;
                 nf += (c[j] && (tk[j] & TK_RES_FLAG)) ? 1u : 0u;
             }
             const uint32_t finc = tk_wave_scan_u32(nf, lane);
@@ -2552,9 +2558,10 @@ __global__ __launch_bounds__(256) void tk_k_docoff(uint64_t n_docs, const uint64
             }
             for (uint32_t k0 = kstart; k0 < kp; k0 += 64) {
                 const uint32_t k = k0 + lane;
-                const bool flagged = k < kp && (res[rb + k] & TK_RES_FLAG);
+                const uint32_t rv = k < kp ? res[rb + k] : 0u;
+                const bool flagged = k < kp && (rv & TK_RES_FLAG);
                 const uint64_t fm = __ballot(flagged);
-                uint32_t c = k < kp ? 1u : 0u;
+                uint32_t c = (k < kp && rv != TK_RES_GAP) ? 1u : 0u;
                 if (flagged) c = rflag[mb + fbase + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))].x;
                 fbase += (uint32_t)__popcll(fm);
                 sum += c;

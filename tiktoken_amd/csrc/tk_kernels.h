@@ -406,7 +406,7 @@ __global__ __launch_bounds__(1024) void tk_k_scan_apply(uint32_t* __restrict__ a
 }
 
 __global__ __launch_bounds__(256) void tk_k_emit(const uint32_t* __restrict__ starts, uint64_t nwords, const uint32_t* __restrict__ blockpre,
-                                                 uint32_t* __restrict__ pstart, uint64_t P, uint64_t n) {
+                                                 uint32_t* __restrict__ pstart, uint64_t P, uint64_t n, const uint32_t* __restrict__ gapb) {
     __shared__ uint32_t sh[8];
     uint64_t w = blockIdx.x * 256ull + threadIdx.x;
     uint32_t v = w < nwords ? starts[w] : 0;
@@ -416,7 +416,8 @@ __global__ __launch_bounds__(256) void tk_k_emit(const uint32_t* __restrict__ st
     while (v) {
         uint32_t b = __ffs(v) - 1;
         v &= v - 1;
-        pstart[o++] = (uint32_t)(w * 32 + b);
+        // (bit 31: a gap char of the generic engine's split -- tk_pretokenize_batch handles one chunk, positions stay below 2^30)
+        pstart[o++] = (uint32_t)(w * 32 + b) | ((gapb && ((gapb[w] >> b) & 1u)) ? 0x80000000u : 0u);
     }
     if (blockIdx.x == 0 && threadIdx.x == 0) pstart[P] = (uint32_t)n;
 }

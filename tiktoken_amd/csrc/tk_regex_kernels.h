@@ -4,6 +4,8 @@
 //                       were a piece start (bitmap `spec`, exit position per segment);
 //   tk_k_rx_resolve   : one lane per document walks the true chain, taking whole segments from `spec` wherever it lands on a speculative
 //                       chain (exact: a match depends only on the text to its right) -> bitmap `gst` of true piece starts;
+//   (gap chars -- positions at which the pattern matches nothing: find_iter skips them -- are pieces of their own, marked in `sgap` / `ggap`:
+//    the front kernel gives them no token)
 //   tk_k_rx_merge     : brk |= gst.  From here on every piece start is a "hard" start for the front kernel, which runs with a class table
 //                       in which every char is a letter: its scanners then cut at hard starts and nowhere else, and everything behind the
 //                       split -- whole-piece probe, de-duplication, merges, long pieces, token copy -- is the pipeline of the stock patterns.
@@ -48,19 +50,19 @@ __device__ __forceinline__ TkRxProg tk_rx_stage_program(const TkRxDev& R, TkRxLd
 
 __global__ __launch_bounds__(256) void tk_k_rx_speculate(TkRxDev R, const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ brk,
                                                          const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, uint32_t seg_shift,
-                                                         uint32_t* __restrict__ spec, uint32_t* __restrict__ xexit) {
+                                                         uint32_t* __restrict__ spec, uint32_t* __restrict__ sgap, uint32_t* __restrict__ xexit) {
     __shared__ TkRxLds L;
     const TkRxProg P = tk_rx_stage_program(R, &L);
     const uint32_t nseg = (uint32_t)(((uint64_t)n + (1u << seg_shift) - 1u) >> seg_shift);
     const TkRxText t{text, n, brk, ss, si, 0xFFFFFFFFu, false};
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += gridDim.x * blockDim.x) tk_rx_speculate_lane(P, t, k, seg_shift, spec, xexit);
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += gridDim.x * blockDim.x) tk_rx_speculate_lane(P, t, k, seg_shift, spec, sgap, xexit);
 }
 
 __global__ __launch_bounds__(256) void tk_k_rx_resolve(TkRxDev R, const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ brk,
                                                        const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si,
                                                        const uint64_t* __restrict__ doc_off, uint64_t n_docs, uint64_t base, uint32_t seg_shift,
-                                                       const uint32_t* __restrict__ spec, const uint32_t* __restrict__ xexit, uint32_t* __restrict__ gst,
-                                                       uint32_t* __restrict__ counters) {
+                                                       const uint32_t* __restrict__ spec, const uint32_t* __restrict__ sgap, const uint32_t* __restrict__ xexit,
+                                                       uint32_t* __restrict__ gst, uint32_t* __restrict__ ggap, uint32_t* __restrict__ counters) {
     __shared__ TkRxLds L;
     const TkRxProg P = tk_rx_stage_program(R, &L);
     const TkRxText t{text, n, brk, ss, si, 0xFFFFFFFFu, false};
@@ -68,7 +70,12 @@ __global__ __launch_bounds__(256) void tk_k_rx_resolve(TkRxDev R, const uint8_t*
         const uint64_t b = doc_off[d] - base, e = doc_off[d + 1] - base;
         if (b >= e || e > n) continue;
         uint32_t err_pos = 0;
-        const uint32_t err = tk_rx_resolve_lane(P, t, (uint32_t)b, (uint32_t)e, seg_shift, spec, xexit, [&](uint32_t w, uint32_t bits) { atomicOr(&gst[w], bits); }, &err_pos);
+        const uint32_t err = tk_rx_resolve_lane(P, t, (uint32_t)b, (uint32_t)e, seg_shift, spec, sgap, xexit,
+                                                [&](uint32_t w, uint32_t bits, uint32_t gaps) {
+                                                    if (bits) atomicOr(&gst[w], bits);
+                                                    if (gaps) atomicOr(&ggap[w], gaps);
+                                                },
+                                                &err_pos);
         if (err) {
             atomicOr(&counters[TK_CNT_ERR], err);
             atomicMax(&counters[TK_CNT_RXPOS], ~err_pos);  // (the counters start at zero: the smallest position wins)

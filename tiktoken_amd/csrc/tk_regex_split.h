@@ -15,8 +15,10 @@
 // it would scan to its end); a lane that would have to stops, and the resolving lane -- which really is at a piece start -- goes on.
 //
 // Special tokens (encode() with allowed_special): a haystack ends where a special token starts (`hard` bit, as at a document start);
-// the token itself is one step of the chain.  A position where the pattern does not match leaves a gap in the reference (the bytes up to
-// the next match are dropped); this engine refuses such a text (TK_RX_ERR_GAP) instead of guessing what the caller wanted.
+// the token itself is one step of the chain.  A position where the pattern does not match: the reference's find_iter goes on to the next
+// match and the text in between yields no token (src/lib.rs:365,405).  Here such a char is a step of the chain as well -- a GAP piece of
+// one char, marked in a second bitmap (`sgap` beside `spec`, `ggap` beside the true starts) -- and the pipeline behind the split gives a
+// gap piece no token (TK_RES_GAP, tk_fused.h).
 #pragma once
 #include "tk_regex.h"
 
@@ -72,18 +74,25 @@ struct TkRxText {
     TK_HD bool inside_special(uint32_t p) const { return si && ((si[p >> 5] >> (p & 31u)) & 1u); }
 };
 
-// the start that follows the piece (or special token) that starts at p; or an error code (TK_RX_IS_ERROR)
-TK_HD uint32_t tk_rx_next(const TkRxProg& P, TkRxText& t, uint32_t p) {
+// the start that follows the piece (or special token, or gap char) that starts at p; or an error code (TK_RX_IS_ERROR: stack, budget)
+TK_HD uint32_t tk_rx_next(const TkRxProg& P, TkRxText& t, uint32_t p, bool* gap) {
+    *gap = false;
     if (t.special(p)) {
         uint32_t q = p + 1;
         while (q < t.n && !t.hard(q)) ++q;
         return q;
     }
     TK_RX_ON_MATCH();
-    return tk_rx_match(P, t, p);
+    const uint32_t e = tk_rx_match(P, t, p);
+    if (e != TK_RX_FAILED) return e;
+    // no match starts here: the char is skipped (find_iter tries the next position)
+    *gap = true;
+    uint32_t q = p + 1;
+    while (q < t.n && !t.hard(q) && (t.byte(q) & 0xC0u) == 0x80u) ++q;
+    return q;
 }
 
-TK_HD void tk_rx_speculate_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint32_t seg_shift, uint32_t* spec, uint32_t* xexit) {
+TK_HD void tk_rx_speculate_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint32_t seg_shift, uint32_t* spec, uint32_t* sgap, uint32_t* xexit) {
     const uint64_t a64 = (uint64_t)k << seg_shift;
     if (a64 >= t.n) return;
     const uint32_t seg = 1u << seg_shift;
@@ -96,8 +105,10 @@ TK_HD void tk_rx_speculate_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint3
     if (p < end) {
         for (;;) {
             spec[p >> 5] |= 1u << (p & 31u);  // (the words of a segment belong to its lane)
-            const uint32_t q = tk_rx_next(P, t, p);
+            bool gap;
+            const uint32_t q = tk_rx_next(P, t, p, &gap);
             if (TK_RX_IS_ERROR(q) || t.hit) break;
+            if (gap) sgap[p >> 5] |= 1u << (p & 31u);
             if (q >= end) {
                 x = q;
                 break;
@@ -108,11 +119,11 @@ TK_HD void tk_rx_speculate_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint3
     xexit[k] = x;
 }
 
-// One document [b, e) of the chunk.  `orbits(word index, bits)` ORs into the bitmap of true starts (shared words: atomic on the device).
-// Returns 0 or the error bits.
+// One document [b, e) of the chunk.  `orbits(word index, start bits, gap bits)` ORs into the bitmaps of true starts and of the gap chars
+// among them (shared words: atomic on the device).  Returns 0 or the error bits.
 template <class Or>
-TK_HD uint32_t tk_rx_resolve_lane(const TkRxProg& P, TkRxText t, uint32_t b, uint32_t e, uint32_t seg_shift, const uint32_t* spec, const uint32_t* xexit,
-                                  Or&& orbits, uint32_t* err_pos) {
+TK_HD uint32_t tk_rx_resolve_lane(const TkRxProg& P, TkRxText t, uint32_t b, uint32_t e, uint32_t seg_shift, const uint32_t* spec, const uint32_t* sgap,
+                                  const uint32_t* xexit, Or&& orbits, uint32_t* err_pos) {
     t.limit = 0xFFFFFFFFu;
     t.hit = false;
     uint32_t p = b;
@@ -128,8 +139,8 @@ TK_HD uint32_t tk_rx_resolve_lane(const TkRxProg& P, TkRxText t, uint32_t b, uin
                 if (w == (p >> 5)) bits &= ~0u << (p & 31u);
                 if (w == ((seg_end - 1u) >> 5) && (seg_end & 31u)) bits &= (1u << (seg_end & 31u)) - 1u;
                 if (bits) {
-                    orbits(w, bits);
                     last = w * 32u + 31u - (uint32_t)__builtin_clz(bits);
+                    orbits(w, bits, sgap[w] & bits);  // (a start whose evaluation the guess broke off has no gap bit: it is matched again below)
                 }
             }
             const uint32_t x = xexit[k];
@@ -140,14 +151,16 @@ TK_HD uint32_t tk_rx_resolve_lane(const TkRxProg& P, TkRxText t, uint32_t b, uin
                 p = last;  // the guess stopped here (it would have had to look too far ahead): go on from its last start
             }
         } else {
-            orbits(p >> 5, 1u << (p & 31u));
+            orbits(p >> 5, 1u << (p & 31u), 0u);
         }
         if (run) {
-            const uint32_t q = tk_rx_next(P, t, p);
+            bool gap;
+            const uint32_t q = tk_rx_next(P, t, p, &gap);
             if (TK_RX_IS_ERROR(q)) {
                 *err_pos = p;
-                return q == TK_RX_FAILED ? TK_RX_ERR_GAP : (q == TK_RX_OVERFLOW ? TK_RX_ERR_STACK : TK_RX_ERR_LIMIT);
+                return q == TK_RX_OVERFLOW ? TK_RX_ERR_STACK : TK_RX_ERR_LIMIT;
             }
+            if (gap) orbits(p >> 5, 0u, 1u << (p & 31u));
             p = q;
         }
     }

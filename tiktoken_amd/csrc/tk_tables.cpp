@@ -150,9 +150,9 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
         (len <= 4 ? n_short : (len <= 8 ? n_mid : n_long)) += 1;
     }
     for (uint64_t k = 0; k < n_spec; ++k) max_rank = std::max(max_rank, spec_ids[k]);
-    if (max_rank >= 0x80000000u)
-        return "token ids of 2^31 and above are not supported (the per-piece result word keeps its top bit for pieces that are not a "
-               "single token)";
+    if (max_rank >= 0x7FFFFFFFu)
+        return "token ids of 2^31 - 1 and above are not supported (the per-piece result word keeps its top bit for pieces that are not a "
+               "single token, and one value for text that yields no token)";
     const bool use_short = max_rank <= TK_SHORT_MAX_RANK;
     if (!use_short) {
         n_mid += n_short;
