@@ -51,6 +51,12 @@ PATTERNS = [
              | \\s+ (?! \\S ) | \\s+""", None),
     # (?m): ^ also behind a newline, $ also in front of one
     (r"(?m)^\p{L}+$|^[ \t]+|\p{White_Space}+$|(?-m:^.)|[^\n]+?(?=\s|$)|\s", r"(?m)^\p{L}+$|^[ \t]+|\p{White_Space}+$|(?-m:\A.)|[^\n]+?(?=\s|$)|\s"),
+    # binary properties of the UCD (the Rust `regex` crate has them; a category mask plus ranges here)
+    (r"\p{Alphabetic}+|\p{Emoji_Presentation}|[\p{Math}\p{Dash}]+| ?\p{Ideographic}|\P{Alpha}", None),
+    (r"\p{Uppercase}\p{Lowercase}*|\p{Lower}+|[\p{XID_Continue}&&\P{Alphabetic}]+|\p{Extended_Pictographic}\p{Emoji_Modifier}?|[^\p{Cased}]",
+     r"(?V1)\p{Uppercase}\p{Lowercase}*|\p{Lower}+|[\p{XID_Continue}&&\P{Alphabetic}]+|\p{Extended_Pictographic}\p{Emoji_Modifier}?|[^\p{Cased}]"),
+    # POSIX classes are ASCII in the Rust `regex` crate (Python `regex` makes them Unicode: spelled out for it)
+    (r"[[:alpha:]]+|[[:digit:][:punct:]]+|[[:^alnum:][:space:]]|[[:word:]]", r"[A-Za-z]+|[0-9!-/:-@\[-`{-~]+|[^0-9A-Za-z]|[0-9A-Za-z_]"),
 ]
 
 
@@ -185,11 +191,30 @@ def test_gaps_are_skipped_and_errors_are_loud():
     assert h.RxSim(r"(?:ab)*c|a|b").split([b"ab" * 200]) == list(range(400))  # (here the way out needs a 'c': no frame is kept)
 
 
+def test_binary_properties_equal_python_regex():
+    """Every binary property of tk_regex_binprops.inc (and the aliases Python `regex` knows): the split under \\p{X}+|\\P{X}+ of a text
+    that holds code points of all planes says where membership changes."""
+    import sys, os
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    from gen_regex_props import BINARY
+
+    rng = random.Random(59)
+    cps = [cp for cp in range(0x250)] + rng.sample(range(0x250, 0x3400), 3000) + rng.sample(range(0xA000, 0xD800), 800) + \
+          rng.sample(range(0xE000, 0x10000), 1500) + rng.sample(range(0x10000, 0x20000), 6000) + rng.sample(range(0x2F000, 0x32000), 100) + \
+          rng.sample(range(0xE0000, 0xE0200), 100) + [0x3400, 0x4E00, 0x9FFF, 0x20000, 0x2A6DF, 0x10FFFF, 0xFFFE, 0xFDD0, 0x1F1E6, 0x1F3FB, 0x200D, 0x200C]
+    rng.shuffle(cps)
+    text = "".join(map(chr, cps))
+    for name in BINARY + ["Alpha", "Lower", "Upper", "XIDS", "XIDC", "IDS", "Ideo", "Dia", "Ext", "ASCII", "Any", "Assigned", "alphabetic", "WHITE_SPACE"]:
+        pat = r"\p{%s}+|\P{%s}+" % (name, name)
+        assert h.RxSim(pat).split([text.encode()]) == py_starts(pat, text), name
+    assert h.RxSim(r"(?i)\p{Alphabetic}+|.").split([b"aB1"]) == [0, 2]
+
+
 @pytest.mark.parametrize("pat,why", [
     (r"(?<=a+b)c|.", "look-behind has to be"), (r"[\b]|.", "inside a class"), (r"(?<=a*)c|.", "fixed-length"), (r"(?<=a(?=b))c|.", "fixed-length"), (r"(a)\1|.", "back-references"), (r"a*", "empty string"),
-    (r"(?:a*)+|.", "empty string"), (r"\p{Alphabetic}+|.", "General_Category value or a script"), (r"[\P{Han}x]|.", "negated script"),
-    (r"\p{scx=Han}|.", "General_Category value or a script"), (r"[a-z~~[b]]|.", "~~"), (r"[a-z&&[b&&[c]]]|.", "inside the operand"), (r"[a&&b]|.", "right side"), (r"(?U)a|.", "(?U)"),
-    (r"(?i)é|.", "non-ASCII cased"), (r"[[:alpha:]]|.", "POSIX"), (r"(a|b", "unterminated group"), (r"a)|b", "unbalanced"),
+    (r"(?:a*)+|.", "empty string"), (r"\p{Alphabetical}+|.", "a script or a binary property"), (r"[\P{Han}x]|.", "negated script"),
+    (r"\p{scx=Han}|.", "a script or a binary property"), (r"(?i)\p{Lowercase}|.", "under (?i)"), (r"[[:alfa:]]|.", "unknown POSIX class"), (r"[a-z~~[b]]|.", "~~"), (r"[a-z&&[b&&[c]]]|.", "inside the operand"), (r"[a&&b]|.", "right side"), (r"(?U)a|.", "(?U)"),
+    (r"(?i)é|.", "non-ASCII cased"), (r"[[:alpha]]|.", "malformed POSIX"), (r"(a|b", "unterminated group"), (r"a)|b", "unbalanced"),
     (r"x{3,2}|.", "out of order"), (r"a**|.", "quantifier behind"), (r"[z-a]|.", "out of order"), (r"(?=a)|.", "empty string"),
 ])
 def test_unsupported_patterns_say_why(pat, why):

@@ -2,12 +2,14 @@
 // outside the three scanner families of tk_pattern.cpp is no longer refused: it is parsed here (the syntax fancy-regex and the Rust
 // `regex` crate share with Python `regex`), compiled to a backtracking program and run on the GPU.
 //
-// Supported: literals, `.`, classes [...] with ranges / escapes / negation / intersection [A&&[^B]] / difference [A--B], \d \s \w \D \S \W, \p{..} \P{..} for General_Category values and scripts (\p{Han}, \p{Script=Greek}),
+// Supported: literals, `.`, classes [...] with ranges / escapes / negation / intersection [A&&[^B]] / difference [A--B], \d \s \w \D \S \W, \p{..} \P{..} for General_Category values,
+// scripts (\p{Han}, \p{Script=Greek}) and the binary properties of the UCD (\p{Alphabetic}, \p{Emoji}, ...: tk_regex_binprops.inc), the POSIX classes
+// [[:alpha:]] [[:^digit:]] (ASCII, as in the Rust `regex` crate),
 // the escapes \n \r \t \f \v \xHH \x{H..} \uHHHH \u{H..} \UHHHHHHHH, alternation, groups (capturing ones are plain groups: a split pattern
 // has no use for captures), (?: ) (?i: ) (?s: ) (?m: ) (?x: ) (?i) (?s) (?m) (?x) (?-i), atomic groups (?> ), look-ahead (?= ) (?! ), the quantifiers ? * + {m} {m,}
 // {m,n} in their greedy, lazy (?) and possessive (+) forms, ^ \A $ \z, \b \B, look-behind of fixed length (?<=ab|c) (?<!\S).  Refused, with the reason:
 // look-behind of variable length, back-references,
-// the class set operation ~~ and set operations nested in operands, POSIX classes, binary properties (\\p{Alphabetic} ...), script extensions, case-insensitive matching of
+// the class set operation ~~ and set operations nested in operands, script extensions, case-insensitive matching of
 // non-ASCII cased letters, a pattern (or a repeated group) that can match the empty string.
 #include "tk_regex.h"
 
@@ -22,6 +24,7 @@
 #include "tk_regex_host.h"
 #include "tk_regex_props.inc"
 #include "tk_regex_scripts.inc"
+#include "tk_regex_binprops.inc"
 
 namespace {
 
@@ -197,7 +200,18 @@ struct Parser {
             {"Enclosing_Mark", "Me"}, {"Control", "Cc"}, {"Format", "Cf"}, {"Unassigned", "Cn"}, {"Private_Use", "Co"}, {"Space_Separator", "Zs"}};
         for (const auto& a : alias)
             if (name == a.a) name = a.b;
-        if (name == "White_Space" || name == "WhiteSpace" || name == "space" || name == "Space" || name == "WSpace") {  // == \s
+        // (names are matched loosely, UTS #18: case, '_', '-' and blanks do not count -- \p{white_space}, \p{WHITE-SPACE})
+        auto loose = [](const std::string& v) {
+            std::string k;
+            for (char ch : v)
+                if (ch != '_' && ch != ' ' && ch != '-') k += (char)((ch >= 'A' && ch <= 'Z') ? ch + 32 : ch);
+            return k;
+        };
+        const std::string lname = loose(name);
+        if (name.size() > 2)  // (one- and two-letter names are General_Category values as they are spelled: \p{L}, \p{Lu}; "LC" below)
+            for (const auto& a : alias)
+                if (lname == loose(a.a)) name = a.b;
+        if (lname == "whitespace" || lname == "space" || lname == "wspace") {  // == \s
             c.flags |= 0x20u;
             *negated = neg != inner_neg;
             return true;
@@ -230,7 +244,41 @@ struct Parser {
                     q += len + (e ? 1 : 0);
                 }
             }
-            return fail("\\p{" + name + "}: not a General_Category value or a script (write other properties as ranges)");
+            // a binary property (tk_regex_binprops.inc): categories that lie in it entirely + the ranges they leave out
+            if (key == "any") {
+                c.ranges.push_back({0u, 0x10FFFFu});
+                *negated = neg != inner_neg;
+                return true;
+            }
+            if (key == "ascii") {
+                c.ranges.push_back({0u, 127u});
+                *negated = neg != inner_neg;
+                return true;
+            }
+            if (key == "assigned") {  // everything but Cn
+                c.gcmask |= 0x3FFFFFFFu & ~(1u << 29);
+                *negated = neg != inner_neg;
+                return true;
+            }
+            for (const TkRxBinProp& bp : tk_rx_binprops) {
+                const char* q = bp.names;
+                while (*q) {
+                    const char* e = strchr(q, '|');
+                    const size_t len = e ? (size_t)(e - q) : strlen(q);
+                    if (len == key.size() && !memcmp(q, key.data(), len)) {
+                        if (ci && bp.case_sensitive) return fail("\\p{" + name + "} under (?i) is not supported");
+                        c.gcmask |= bp.gcmask;
+                        for (uint32_t cp = 0; cp < 128u; ++cp)
+                            if ((bp.ascii[cp >> 5] >> (cp & 31u)) & 1u) c.ranges.push_back({cp, cp});
+                        for (unsigned k = 0; k < bp.cnt; ++k)
+                            c.ranges.push_back({tk_rx_binprop_ranges[2 * (bp.off + k)], tk_rx_binprop_ranges[2 * (bp.off + k) + 1]});
+                        *negated = neg != inner_neg;
+                        return true;
+                    }
+                    q += len + (e ? 1 : 0);
+                }
+            }
+            return fail("\\p{" + name + "}: not a General_Category value, a script or a binary property of the UCD");
         }
         if (ci && (m & 7u) && (m & 7u) != 7u) return fail("\\p{" + name + "} under (?i) is not supported");
         c.gcmask |= m;
@@ -281,6 +329,40 @@ struct Parser {
         *cp = e;  // escaped punctuation
         return true;
     }
+    // [:name:] / [:^name:] inside a class (i at '['): the ASCII classes of the Rust `regex` crate
+    bool posix_class(CharSet& c, bool ci) {
+        size_t j = i + 2;
+        bool neg = false;
+        if (j < s.size() && s[j] == '^') {
+            neg = true;
+            ++j;
+        }
+        std::string name;
+        while (j < s.size() && s[j] >= 'a' && s[j] <= 'z') name += (char)s[j++];
+        if (j + 1 >= s.size() || s[j] != ':' || s[j + 1] != ']') return fail("malformed POSIX class (expected [:name:])");
+        static const struct { const char* name; const char* set; } posix[] = {  // pairs lo, hi
+            {"alnum", "09AZaz"}, {"alpha", "AZaz"}, {"ascii", "\x01\x7f"}, {"blank", "\t\t  "}, {"cntrl", "\x01\x1f\x7f\x7f"}, {"digit", "09"},
+            {"graph", "!~"}, {"lower", "az"}, {"print", " ~"}, {"punct", "!/:@[`{~"}, {"space", "\t\r  "}, {"upper", "AZ"},
+            {"word", "09AZaz__"}, {"xdigit", "09AFaf"}};
+        for (const auto& pc : posix) {
+            if (name != pc.name) continue;
+            bool in[128] = {false};
+            for (const char* q = pc.set; *q; q += 2)
+                for (int cp = q[0]; cp <= q[1]; ++cp) in[cp] = true;
+            if (name == "ascii" || name == "cntrl") in[0] = true;  // (NUL cannot stand in the string above)
+            if (!neg) {
+                for (uint32_t cp = 0; cp < 128u; ++cp)
+                    if (in[cp] && !add_char(c, cp, ci)) return false;
+            } else {
+                for (uint32_t cp = 0; cp < 128u; ++cp)
+                    if (!in[cp] && !add_char(c, cp, ci)) return false;
+                c.ranges.push_back({128u, 0x10FFFFu});
+            }
+            i = j + 2;
+            return true;
+        }
+        return fail("unknown POSIX class [:" + name + ":]");
+    }
     int parse_class(const Flags& f) {  // i at '['
         CharSet c;
         if (!parse_class_body(f, &c, true)) return -1;
@@ -325,7 +407,10 @@ struct Parser {
                 continue;
             }
             if (peek() == '[') {
-                if (peek(1) == ':') return fail("POSIX classes are not supported");
+                if (peek(1) == ':') {  // [:alpha:] / [:^alpha:] -- ASCII, as in the Rust `regex` crate
+                    if (!posix_class(c, f.ci)) return false;
+                    continue;
+                }
                 return fail("nested classes are only supported as operands of && and --");
             }
             if (peek() == '~' && peek(1) == '~') return fail("the class set operation ~~ is not supported");
@@ -976,6 +1061,15 @@ std::string tk_rx_compile(const char* pat_str, TkRxCompiled* out) {
             }
         }
         S.rr = roff << 16 | ((uint32_t)out->ranges.size() / 2 - roff);
+        // \p{X}+|\P{X}+ : two sets, one list of ranges (a binary property can be several hundred of them)
+        for (const TkRxSet& Q : out->sets) {
+            const uint32_t qo = Q.rr >> 16, qc = Q.rr & 0xFFFFu, cnt = S.rr & 0xFFFFu;
+            if (cnt && qc == cnt && qo != roff && std::equal(out->ranges.begin() + 2 * qo, out->ranges.begin() + 2 * (qo + qc), out->ranges.begin() + 2 * roff)) {
+                out->ranges.resize(2 * (size_t)roff);
+                S.rr = qo << 16 | qc;
+                break;
+            }
+        }
         out->sets.push_back(S);
     }
     if (out->ranges.size() / 2 > TK_RX_MAX_RANGES) return "the pattern has too many class ranges";

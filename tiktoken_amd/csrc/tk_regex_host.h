@@ -7,9 +7,9 @@
 
 #include "tk_regex.h"
 
-#define TK_RX_MAX_INS 448     // the kernels keep the program in LDS: 448 x 16 + 64 x 32 + 512 x 8 + 64 x 32 bytes = 15 KiB
+#define TK_RX_MAX_INS 448     // the kernels keep the program in LDS: 448 x 16 + 64 x 32 + 1024 x 8 + 64 x 32 bytes = 19 KiB
 #define TK_RX_MAX_SETS 64
-#define TK_RX_MAX_RANGES 512  // pairs (a script is up to 176 of them)
+#define TK_RX_MAX_RANGES 1024  // pairs (a script is up to 176 of them, a binary property up to 632: tk_regex_binprops.inc)
 #define TK_RX_MAX_FIRST 64    // first-byte bitmaps (32 bytes each)
 
 struct TkRxCompiled {
