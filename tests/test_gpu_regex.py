@@ -44,7 +44,7 @@ def oracle_tokens(py_pat, docs, C, cache):
 
 
 # (patterns 9 and 13 leave gaps on most texts: test_text_the_pattern_does_not_match_yields_no_tokens)
-@pytest.mark.parametrize("idx", [5, 6, 7, 8, 10, 11, 12, 14, 16, 17, 18, 19])
+@pytest.mark.parametrize("idx", [5, 6, 7, 8, 10, 11, 12, 14, 16, 17, 18, 19, 23, 25])  # (23: binary properties, 25: POSIX classes)
 def test_split_and_tokens_equal_python_regex_plus_oracle(idx):
     pat, py = PATTERNS[idx]
     py = py or pat
@@ -127,7 +127,7 @@ def test_text_the_pattern_does_not_match_yields_no_tokens():
     assert core.pretokenize_packed(blob, off).tolist()[:8] == [0, 4, 5, 10, 11, 15, 20, 21] and 20 in core.last_gaps.tolist()
     assert core.encode_ordinary("fine words only") == make_core(r"\w+|\s+|[^\w\s]+").encode_ordinary("fine words only")
     assert core.encode_ordinary("?!") == []
-    for idx, pat in ((9, None), (13, None), (-1, r"\p{L}+|\d"), (-2, r"[a-m]+(?=[n-z])|\s")):
+    for idx, pat in ((9, None), (13, None), (24, None), (-1, r"\p{L}+|\d"), (-2, r"[a-m]+(?=[n-z])|\s")):  # (24: binary properties, titlecase letters are gaps)
         pat, py = (PATTERNS[idx][0], PATTERNS[idx][1] or PATTERNS[idx][0]) if idx >= 0 else (pat, pat)
         core = make_core(pat)
         rng = random.Random(4000 + idx)
