@@ -355,7 +355,8 @@ class RxSim:
     def split(self, docs: list[bytes], specials: list[tuple[int, int]] = (), speculate: int | bool = True) -> list[int]:
         """Piece starts (byte offsets into the packed batch) of the documents -- gap chars included, listed in self.gaps as well;
         specials: (offset, length) of allowed special tokens.
-        speculate: False = the matcher alone walks every document; True / 1 = with the speculative pass over 256-byte segments; 2 = 1 KiB."""
+        speculate: False = the matcher alone walks every document; True / 1 = with the speculative pass over 256-byte segments; 2 = 1 KiB;
+        + 4: with the link pass (what the device runs); + 8: documents resolved by groups of 64 lanes (the device's wavefront)."""
         blob, off = pack(docs)
         n = len(blob)
         starts = np.zeros(n + 1, np.uint8)

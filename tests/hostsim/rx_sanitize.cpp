@@ -117,18 +117,32 @@ int main(int argc, char** argv) {
             for (uint32_t shift : {TK_RX_SEG_SHIFT_SMALL, TK_RX_SEG_SHIFT_LARGE}) {
                 const uint32_t nseg = (uint32_t)(((uint64_t)n + (1u << shift) - 1) >> shift);
                 uint32_t* xexit = (uint32_t*)malloc((nseg + 2) * 4);
+                uint32_t* lmerge = (uint32_t*)malloc((nseg + 2) * 4);
+                uint32_t* lexit = (uint32_t*)malloc((nseg + 2) * 4);
                 memset(spec, 0, nw * 4);
-                memset(gst, 0, nw * 4);
                 uint32_t* sgap = (uint32_t*)calloc(nw, 4);
+                uint32_t* lnk = (uint32_t*)calloc(nw, 4);
+                uint32_t* lgap = (uint32_t*)calloc(nw, 4);
                 TkRxText t{text, n, brk, with_specials ? ss : nullptr, with_specials ? si : nullptr, 0xFFFFFFFFu, false};
                 for (uint32_t s = 0; s < nseg; ++s) tk_rx_speculate_lane(P, t, s, shift, spec, sgap, xexit);
-                for (size_t d = 0; d + 1 < doc.size(); ++d) {
-                    uint32_t err_pos = 0;
-                    (void)tk_rx_resolve_lane(P, t, doc[d], doc[d + 1], shift, spec, sgap, xexit, [&](uint32_t w, uint32_t bits, uint32_t gaps) {
-                        if (w >= nw || (gaps & ~(gst[w] | bits))) abort();  // (a gap char is a start)
-                        gst[w] |= bits;
-                    }, &err_pos);
+                for (uint32_t s = 0; s < nseg; ++s) tk_rx_link_lane(P, t, s, shift, spec, xexit, lnk, lgap, lmerge, lexit);
+                const TkRxMaps M{spec, sgap, xexit, lnk, lgap, lmerge, lexit, shift};
+                for (int by_group = 0; by_group < 2; ++by_group) {  // (one lane per document; a group of lanes per document)
+                    memset(gst, 0, nw * 4);
+                    for (size_t d = 0; d + 1 < doc.size(); ++d) {
+                        uint32_t err_pos = 0;
+                        auto orb = [&](uint32_t w, uint32_t bits, uint32_t gaps) {
+                            if (w >= nw || (gaps & ~(gst[w] | bits))) abort();  // (a gap char is a start)
+                            gst[w] |= bits;
+                        };
+                        if (by_group) (void)tk_rx_resolve_group_host(P, t, M, doc[d], doc[d + 1], orb, &err_pos);
+                        else (void)tk_rx_resolve_lane(P, t, M, doc[d], doc[d + 1], orb, &err_pos);
+                    }
                 }
+                free(lmerge);
+                free(lexit);
+                free(lnk);
+                free(lgap);
                 ++splits;
                 free(xexit);
                 free(sgap);

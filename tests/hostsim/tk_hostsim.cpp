@@ -656,17 +656,19 @@ void tks_rx_free(void* p) { delete (TkRxCompiled*)p; }
 uint64_t tks_rx_size(void* p) { return ((TkRxCompiled*)p)->ins.size(); }
 uint64_t tks_rx_steps() { return g_rx_steps; }  // matcher steps so far (instructions + chars of repeats + backtracks)
 // Piece starts of a packed batch: a byte per position (1 = start).  spec_at / spec_len: occurrences of allowed special tokens (sorted).
-// speculate = 0: every document walked by the matcher alone.  stats[0] = matcher runs of the speculative pass, [1] = of the resolving pass.
-// Returns 0, or error bits | position << 8.
+// speculate = 0: every document walked by the matcher alone; bits 0..1: 1 = speculative pass over 256-byte segments, 2 = over 1 KiB; bit 2: with
+// the link pass; bit 3: documents resolved by groups of 64 lanes (the host form of the device's wavefront).
+// stats[0] = matcher runs of the speculative (+ link) pass, [1] = of the resolving pass.  Returns 0, or error bits | position << 8.
 uint64_t tks_rx_split(void* p, const uint8_t* text_in, uint64_t n, const uint64_t* doc_off, uint64_t n_docs, const uint64_t* spec_at,
                       const uint64_t* spec_len, uint64_t n_spec, int speculate, uint8_t* starts, uint64_t* stats) {
-    const uint32_t seg_shift = speculate == 2 ? TK_RX_SEG_SHIFT_LARGE : TK_RX_SEG_SHIFT_SMALL;  // (speculate: 1 = 256-byte segments, 2 = 1 KiB)
+    const uint32_t seg_shift = (speculate & 3) == 2 ? TK_RX_SEG_SHIFT_LARGE : TK_RX_SEG_SHIFT_SMALL;
+    const bool with_links = (speculate & 3) && (speculate & 4), by_group = (speculate & 8) != 0;
     const TkRxCompiled* c = (const TkRxCompiled*)p;
     const TkRxProg P = c->view();
     std::vector<uint8_t> text(text_in, text_in + n);
     text.resize(n + 64, 0);
     const uint64_t nw = (n + 31) / 32 + 2;
-    std::vector<uint32_t> brk(nw, 0), ss(nw, 0), si(nw, 0), spec(nw, 0), sgap(nw, 0), gst(nw, 0), ggap(nw, 0);
+    std::vector<uint32_t> brk(nw, 0), ss(nw, 0), si(nw, 0), spec(nw, 0), sgap(nw, 0), gst(nw, 0), ggap(nw, 0), lnk(nw, 0), lgap(nw, 0);
     auto setb = [](std::vector<uint32_t>& v, uint64_t q) { v[q >> 5] |= 1u << (q & 31); };
     for (uint64_t d = 0; d < n_docs; ++d)
         if (doc_off[d] < n) setb(brk, doc_off[d]);
@@ -678,21 +680,24 @@ uint64_t tks_rx_split(void* p, const uint8_t* text_in, uint64_t n, const uint64_
     }
     TkRxText t{text.data(), (uint32_t)n, brk.data(), n_spec ? ss.data() : nullptr, n_spec ? si.data() : nullptr, 0xFFFFFFFFu, false};
     const uint32_t nseg = (uint32_t)((n + (1u << seg_shift) - 1) >> seg_shift);
-    std::vector<uint32_t> xexit(nseg + 1, TK_RX_UNKNOWN);
+    std::vector<uint32_t> xexit(nseg + 1, TK_RX_UNKNOWN), lmerge(nseg + 1, TK_RX_NOLINK), lexit(nseg + 1, TK_RX_UNKNOWN);
     g_rx_matches = 0;
-    if (speculate)
+    if (speculate & 3)
         for (uint32_t k = 0; k < nseg; ++k) tk_rx_speculate_lane(P, t, k, seg_shift, spec.data(), sgap.data(), xexit.data());
+    if (with_links)
+        for (uint32_t k = 0; k < nseg; ++k) tk_rx_link_lane(P, t, k, seg_shift, spec.data(), xexit.data(), lnk.data(), lgap.data(), lmerge.data(), lexit.data());
     stats[0] = g_rx_matches;
     g_rx_matches = 0;
+    const TkRxMaps M{(speculate & 3) ? spec.data() : nullptr, sgap.data(), xexit.data(), with_links ? lnk.data() : nullptr, lgap.data(), lmerge.data(), lexit.data(), seg_shift};
     uint64_t rc = 0;
     for (uint64_t d = 0; d < n_docs && !rc; ++d) {
         uint32_t err_pos = 0;
-        const uint32_t e = tk_rx_resolve_lane(P, t, (uint32_t)doc_off[d], (uint32_t)doc_off[d + 1], seg_shift, speculate ? spec.data() : nullptr, sgap.data(), xexit.data(),
-                                              [&](uint32_t w, uint32_t bits, uint32_t gaps) {
-                                                  gst[w] |= bits;
-                                                  ggap[w] |= gaps;
-                                              },
-                                              &err_pos);
+        auto orb = [&](uint32_t w, uint32_t bits, uint32_t gaps) {
+            gst[w] |= bits;
+            ggap[w] |= gaps;
+        };
+        const uint32_t e = by_group ? tk_rx_resolve_group_host(P, t, M, (uint32_t)doc_off[d], (uint32_t)doc_off[d + 1], orb, &err_pos)
+                                    : tk_rx_resolve_lane(P, t, M, (uint32_t)doc_off[d], (uint32_t)doc_off[d + 1], orb, &err_pos);
         if (e) rc = e | ((uint64_t)err_pos << 8);
     }
     stats[1] = g_rx_matches;

@@ -188,7 +188,7 @@ def test_encode_with_unstable_contract():
 
 
 def test_threads_share_one_encoding():
-    """The reference object is frozen and entered from many Python threads (core.py:175); ours serialises calls."""
+    """The reference object is frozen and entered from many Python threads (core.py:175)."""
     from concurrent.futures import ThreadPoolExecutor
 
     enc = tiktoken.get_encoding("cl100k_shaped")
@@ -196,6 +196,71 @@ def test_threads_share_one_encoding():
     with ThreadPoolExecutor(8) as ex:
         got = list(ex.map(enc.encode_ordinary, texts))
     assert got == [oracle_encode("cl100k_shaped", t) for t in texts]
+
+
+def test_small_calls_of_several_threads_overlap():
+    """core.py:175 -- a pool of threads on one Encoding is the reference's normal use (it keeps a regex per thread for it, lib.rs:232-238).
+    Small calls take no lock here: each runs on a slot of its own.  Correct under load, and 8 threads finish a fixed number of calls faster
+    than one (the C entry directly: ctypes releases the GIL around it; measured numbers in profiles/r03_small_calls_threads.txt)."""
+    import threading
+    import time
+
+    enc = tiktoken.get_encoding("o200k_shaped")
+    core = enc._core_bpe
+    texts = [(f"worker {i}: " + "The quick brown fox jumps over the lazy dog; 3.14159 and so on, ünïcödé too. " * 2)[:180] for i in range(16)]
+    datas = [t.encode() for t in texts]
+    want = [oracle_encode("o200k_shaped", t) for t in texts]
+    for d, w in zip(datas, want):
+        assert core._encode_np(d, None).tolist() == w
+
+    def run(n_threads, calls_per_thread):
+        bad = []
+
+        def work(k):
+            for j in range(calls_per_thread):
+                i = (k + j) % len(datas)
+                if core._encode_np(datas[i], None).tolist() != want[i]:
+                    bad.append((k, j))
+
+        th = [threading.Thread(target=work, args=(k,)) for k in range(n_threads)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        assert not bad, bad[:3]
+        return time.perf_counter() - t0
+
+    run(8, 200)  # (every slot used, results compared under load)
+
+    # the rate through the C entry itself (ctypes releases the GIL around the call; the Python work around it does not overlap)
+    import ctypes
+
+    L, hnd = core._L, core._h
+    bufs = [np.frombuffer(d, np.uint8) for d in datas]
+
+    def raw(n_threads, calls_per_thread):
+        def work(k):
+            out, n = ctypes.c_void_p(), ctypes.c_uint64()
+            b = bufs[k % len(bufs)]
+            for _ in range(calls_per_thread):
+                L.tk_encode_ordinary(hnd, b.ctypes.data, len(b), ctypes.byref(out), ctypes.byref(n))
+                L.tk_free(out)
+
+        th = [threading.Thread(target=work, args=(k,)) for k in range(n_threads)]
+        t0 = time.perf_counter()
+        for t in th:
+            t.start()
+        for t in th:
+            t.join()
+        return time.perf_counter() - t0
+
+    raw(8, 100)
+    total = 16000
+    t1 = min(raw(1, total) for _ in range(2))
+    t8 = min(raw(8, total // 8) for _ in range(2))
+    print(f"{total} calls of 180 bytes through the C ABI: one thread {t1 * 1e6 / total:.1f} us per call, eight threads {t8 * 1e6 / total:.1f} us per call ({t1 / t8:.2f}x)")
+    assert t8 < t1 / 1.4, (t1, t8)  # (measured 2.2-2.8x: profiles/r03_small_calls.txt; the launch path of the HIP runtime is the shared part)
 
 
 def test_real_vocab_known_answers_if_available():

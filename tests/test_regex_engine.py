@@ -116,7 +116,7 @@ def test_split_equals_python_regex(idx):
         want += [base + s for s in st]
         base += len(ok_docs[-1])
     assert len(ok_docs) > 20
-    for speculate in (0, 1, 2):
+    for speculate in (0, 1, 2, 5, 6, 13, 14):  # (+4: the link pass, +8: a group of lanes per document)
         assert rx.split(ok_docs, speculate=speculate) == want, speculate
 
 
@@ -133,6 +133,10 @@ def test_long_runs_and_speculation_work():
     spec_runs, resolve_runs = rx.stats
     assert resolve_runs < len(want) // 50, (resolve_runs, len(want))
     assert rx.split([doc.encode()], speculate=False) == want
+    # with the link pass the resolving lane runs the matcher only where a guess broke off (here: never but for the long runs' pieces)
+    for mode in (5, 6, 13, 14):
+        assert rx.split([doc.encode()], speculate=mode) == want, mode
+        assert rx.stats[1] < resolve_runs // 4 + 10, (mode, rx.stats, resolve_runs)
     one = ("y" * 3_000_000).encode()
     assert rx.split([one, one[:5000]], speculate=2) == [0, 3_000_000]
     assert rx.stats[0] < 3 * 3_000_000 // 1024 + 10  # (lanes inside the run give up after one look)
@@ -152,7 +156,7 @@ def test_special_tokens_cut_the_haystack():
         else:
             want += [at + s for s in py_starts(pat, part)]
         at += len(part.encode())
-    for spec in (0, 1, 2):
+    for spec in (0, 1, 2, 5, 6, 13, 14):
         assert rx.split([text.encode()], specials, speculate=spec) == want
     big = ("lorem ipsum " * 300 + sp) * 20
     specials = [(m.start(), len(sp)) for m in regex.finditer(regex.escape(sp), big)]
@@ -170,7 +174,7 @@ def test_gaps_are_skipped_and_errors_are_loud():
     rx = h.RxSim(r"\w+|\s+")
     assert rx.split([b"hello world"]) == [0, 5, 6] and rx.gaps == []
     # text the pattern does not match: find_iter goes on behind it (src/lib.rs:365) -- every such char is a step of its own, marked as a gap
-    for speculate in (0, 1, 2):
+    for speculate in (0, 1, 2, 5, 6, 13, 14):  # (+4: the link pass, +8: a group of lanes per document)
         assert rx.split([b"hello, world"], speculate=speculate) == [0, 5, 6, 7] and rx.gaps == [5]
         assert rx.split(["¡hola! ¿qué?".encode(), b"", b"!!"], speculate=speculate) == [0, 2, 6, 7, 8, 10, 14, 15, 16] and rx.gaps == [0, 6, 8, 14, 15, 16]
     docs = ["x, y; z" * 300, "...", "a" * 2000 + "!" * 50 + "b"]
@@ -180,7 +184,7 @@ def test_gaps_are_skipped_and_errors_are_loud():
         st += [base + v for v in a]
         gp += [base + v for v in g]
         base += len(d.encode())
-    for speculate in (0, 1, 2):
+    for speculate in (0, 1, 2, 5, 6, 13, 14):  # (+4: the link pass, +8: a group of lanes per document)
         assert rx.split([d.encode() for d in docs], speculate=speculate) == st and rx.gaps == gp
     # a backtracking repeated group in the middle of an alternative needs a frame per repetition wherever both going on and leaving
     # can begin with the next byte: bounded stack, loud failure
@@ -257,7 +261,7 @@ def test_stock_patterns_through_the_generic_engine_equal_the_oracle_split(name, 
     for d, doc in enumerate(docs):
         if doc:
             want += [int(off[d])] + [int(off[d]) + e for e in C.split(doc)[:-1]]
-    for speculate in (1, 2):
+    for speculate in (1, 2, 5, 14):
         assert rx.split(docs, speculate=speculate) == want
         spec_runs, resolve_runs = rx.stats
         assert resolve_runs < len(want) // 5, (resolve_runs, len(want))  # (most of the matching is done by the speculative lanes)
@@ -348,7 +352,7 @@ def test_generated_patterns_equal_python_regex():
             wgap += [base + s for s in gp]
             base += len(good[-1])
         try:
-            got = rx.split(good, speculate=1 + (it & 1))
+            got = rx.split(good, speculate=(1 + (it & 1)) | (4 if it & 2 else 0) | (8 if it & 4 else 0))
         except RuntimeError as e:
             # a backtracking repeated group in the middle of an alternative on a long text (8), or more backtracking than the budget (16)
             assert "error 8" in str(e) or "error 16" in str(e), (eng, str(e))
@@ -440,7 +444,7 @@ def test_special_tokens_at_random_places(idx):
             at += len(part.encode())
         docs.append("".join(parts).encode())
         base = at
-    for speculate in (0, 1, 2):
+    for speculate in (0, 1, 2, 5, 6, 13, 14):  # (+4: the link pass, +8: a group of lanes per document)
         assert rx.split(docs, specials, speculate=speculate) == want, speculate
 
 

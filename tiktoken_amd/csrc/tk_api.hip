@@ -65,12 +65,13 @@ struct KernelStat {
 };
 
 #define TK_NAUX 6  // side streams of the merge kernels
+#define TK_SMALL_SLOTS 8  // small calls in flight at the same time (tk_core::SmallSlot)
 #define TK_NSET 4  // chunks in flight (work sets): the front kernel of chunk k + 1 runs while chunk k is merged and its tokens are placed
 
 // Work buffers of ONE chunk in flight.
 struct WorkSet {
     Buf text_al, tile_sum, wide_ws, scan_sums, row_base, brk, docb, cand, ss, si, starts, blockcnt, pstart, res, rflag, miss, staging, listB, listC, counters, total, g_id, g_rk,
-        g_nx, g_pv, g_lv, tile_np, tile_nt, tile_nmiss, mt_slots, wbin, wave_pieces, deferred, big, rx_spec, rx_gst, rx_exit, merge_work;
+        g_nx, g_pv, g_lv, tile_np, tile_nt, tile_nmiss, mt_slots, wbin, wave_pieces, deferred, big, rx_spec, rx_gst, rx_lnk, rx_exit, merge_work;
     hipStream_t sb = nullptr;        // the set's back stage in a multi-chunk batch: back stages of different chunks overlap each other too
                                      // (they are chains of short latency-bound kernels, ~2 ms however small the chunk)
     hipEvent_t ev_front = nullptr;   // the front kernel is done
@@ -83,7 +84,7 @@ struct WorkSet {
     std::vector<Buf*> all() {
         return {&text_al, &tile_sum, &wide_ws, &scan_sums, &row_base, &brk, &docb, &cand, &ss, &si, &starts, &blockcnt, &pstart, &res, &rflag, &miss, &staging, &listB,
                 &listC, &counters, &total, &g_id, &g_rk, &g_nx, &g_pv, &g_lv, &tile_np, &tile_nt, &tile_nmiss, &mt_slots, &wbin, &wave_pieces, &deferred, &big, &rx_spec,
-                &rx_gst, &rx_exit, &merge_work};
+                &rx_gst, &rx_lnk, &rx_exit, &merge_work};
     }
 };
 // What the front stage of a chunk leaves for its back stage.
@@ -121,13 +122,24 @@ struct tk_core {
     uint64_t chunk_bytes = 1ull << 30;  // one chunk per GiB: smaller chunks pipeline (stage_front / stage_back) but pay the merge kernels' fixed latency per chunk
     int dbg = 0;
     uint32_t n_cu = 256;             // compute units of the device
+    uint32_t rx_seg_shift = 0;       // 0: by chunk size (tk_regex_split.h)
     uint32_t front_wgs = TKF_OCC;    // workgroups per CU of the persistent front kernel ($TIKTOKEN_AMD_FRONT_WGS)
     uint32_t n_dec = 0;  // entries of the device decode table (0: ids too sparse for a direct table -- decode stays on the host)
     Buf d_tok, d_lens, d_bsum, d_tboff, d_bytes, d_boff;  // decode workspace
-    uint8_t* small_in = nullptr;    // page-locked, device-visible: text of a small call (tk_k_small)
-    uint32_t* small_out = nullptr;  // page-locked, device-visible: its result
-    uint32_t small_seq = 0;
-    Buf small_ws;
+    // Small calls (tk_k_small) do not take `mu`: the reference's normal use is several threads on one Encoding (core.py:175, a thread pool
+    // over encode; lib.rs:232-238 keeps a regex per thread for it), and a small call needs nothing of the shared workspace -- a slot of its
+    // own (page-locked text and result buffers the kernel reads and writes directly, merge scratch, a stream) is all.  A caller takes a
+    // free slot (one atomic exchange), launches, watches the slot's completion word.
+    struct SmallSlot {
+        std::atomic<int> busy{0};
+        uint8_t* in = nullptr;    // page-locked, device-visible: text of the call
+        uint32_t* out = nullptr;  // page-locked, device-visible: its result
+        void *d_in = nullptr, *d_out = nullptr;
+        uint32_t seq = 0;
+        Buf ws;
+        hipStream_t s = nullptr;
+    };
+    SmallSlot small[TK_SMALL_SLOTS];
     std::vector<uint8_t> sorted_blob;  // token_byte_values(), packed (built on first use)
     std::vector<uint64_t> sorted_off;
     // instrumentation
@@ -381,6 +393,10 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
         if (v >= 4096 && v <= (3ull << 30)) c->chunk_bytes = v;
     }
     if (const char* e = getenv("TIKTOKEN_AMD_DEBUG")) c->dbg = atoi(e);
+    if (const char* e = getenv("TIKTOKEN_AMD_RX_SEG_SHIFT")) {  // (experiments: segment size of the generic engine's speculative pass, 2^k bytes)
+        const int k = atoi(e);
+        if (k >= 5 && k <= 14) c->rx_seg_shift = (uint32_t)k;
+    }
     {
         int cu = 0;
         if (hipDeviceGetAttribute(&cu, hipDeviceAttributeMultiprocessorCount, device) == hipSuccess && cu > 0) c->n_cu = (uint32_t)cu;
@@ -399,7 +415,7 @@ extern "C" void tk_destroy(tk_core* c) {
     for (Buf* b : {&c->t_rx_ins, &c->t_rx_sets, &c->t_rx_ranges, &c->t_rx_first, &c->t_rx_s1, &c->t_rx_s2}) release(*b);
     for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_dec, &c->d_tok, &c->d_lens, &c->d_bsum, &c->d_tboff, &c->d_bytes, &c->d_boff, &c->t_piece,
                    &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2, &c->t_byte_rank, &c->t_hot, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off,
-                   &c->out_tokens, &c->out_tok_off, &c->allowed, &c->tok_bases, &c->small_ws})
+                   &c->out_tokens, &c->out_tok_off, &c->allowed, &c->tok_bases})
         release(*b);
     for (WorkSet& w : c->ws) {
         for (Buf* b : w.all()) release(*b);
@@ -411,8 +427,12 @@ extern "C" void tk_destroy(tk_core* c) {
         if (w.h_counters) (void)hipHostFree(w.h_counters);
         if (w.h_total) (void)hipHostFree(w.h_total);
     }
-    if (c->small_in) (void)hipHostFree(c->small_in);
-    if (c->small_out) (void)hipHostFree(c->small_out);
+    for (auto& sl : c->small) {
+        if (sl.in) (void)hipHostFree(sl.in);
+        if (sl.out) (void)hipHostFree(sl.out);
+        if (sl.ws.p) (void)hipFree(sl.ws.p);
+        if (sl.s) (void)hipStreamDestroy(sl.s);
+    }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (int i = 0; i < TK_NAUX; ++i)
         if (c->aux[i]) (void)hipStreamDestroy(c->aux[i]);
@@ -584,8 +604,10 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
             // (two bitmaps each: the starts, and behind them the gap chars among the starts)
             TRY(ensure(w.rx_spec, 2 * (nwords + 2) * 4));
             TRY(ensure(w.rx_gst, 2 * (nwords + 2) * 4));
+            TRY(ensure(w.rx_lnk, 2 * (nwords + 2) * 4));
             clear(w.rx_spec, 2 * (nwords + 2) * 4, 0u);
             clear(w.rx_gst, 2 * (nwords + 2) * 4, 0u);
+            clear(w.rx_lnk, 2 * (nwords + 2) * 4, 0u);
         }
         if (n > 32768 && !pretok_only) {  // in-call de-duplication of missed pieces pays for its table reset only on real batches
             while (job.mt_bits < TK_MT_BITS && (1ull << job.mt_bits) < n / 128) ++job.mt_bits;  // 4 Mi slots from 512 MiB up
@@ -610,16 +632,29 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
             }));
         }
         if (c->has_rx) {  // the generic engine finds the piece starts; they join the hard starts in `brk`
-            const uint32_t seg_shift = n < TK_RX_SEG_SMALL_BELOW ? TK_RX_SEG_SHIFT_SMALL : TK_RX_SEG_SHIFT_LARGE;
+            const uint32_t seg_shift = c->rx_seg_shift ? c->rx_seg_shift : (n < TK_RX_SEG_SMALL_BELOW ? TK_RX_SEG_SHIFT_SMALL : TK_RX_SEG_SHIFT_LARGE);
             const uint64_t nseg = (n + (1ull << seg_shift) - 1) >> seg_shift;
-            TRY(ensure(w.rx_exit, (nseg + 2) * 4));
+            TRY(ensure(w.rx_exit, 3 * (nseg + 2) * 4));  // exit of every segment's chain; where the link met it; where the link left the segment
             uint32_t *spec = w.rx_spec.as<uint32_t>(), *gst = w.rx_gst.as<uint32_t>(), *xexit = w.rx_exit.as<uint32_t>();
+            uint32_t *lnk = w.rx_lnk.as<uint32_t>(), *lmerge = xexit + nseg + 2, *lexit = xexit + 2 * (nseg + 2);
             TRY(timed(c, s, "tk_k_rx_speculate", [&] {
                 hipLaunchKernelGGL(tk_k_rx_speculate, dim3(grid_for(nseg, 256, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, seg_shift, spec, spec + nwords + 2, xexit);
             }));
+            const bool links = !(c->dbg & 0x2000000);  // (debug bit 0x2000000: no link pass -- the resolving pass matches its way from one chain to the next)
+            if (links) {
+                TRY(timed(c, s, "tk_k_rx_link", [&] {
+                    hipLaunchKernelGGL(tk_k_rx_link, dim3(grid_for(nseg, 256, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, seg_shift, spec, xexit,
+                                       lnk, lnk + nwords + 2, lmerge, lexit);
+                }));
+            }
+            const TkRxMaps maps{spec, spec + nwords + 2, xexit, links ? lnk : (const uint32_t*)nullptr, lnk + nwords + 2, lmerge, lexit, seg_shift};
             TRY(timed(c, s, "tk_k_rx_resolve", [&] {
-                hipLaunchKernelGGL(tk_k_rx_resolve, dim3(grid_for(n_docs, 256, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, d_doc_off, n_docs,
-                                   base, seg_shift, spec, spec + nwords + 2, xexit, gst, gst + nwords + 2, counters);
+                if (c->dbg & 0x4000000)  // (debug bit 0x4000000: one lane per document instead of one wavefront)
+                    hipLaunchKernelGGL(tk_k_rx_resolve, dim3(grid_for(n_docs, 256, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, d_doc_off, n_docs,
+                                       base, maps, gst, gst + nwords + 2, counters);
+                else
+                    hipLaunchKernelGGL(tk_k_rx_resolve_wave, dim3(grid_for(n_docs, 4, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, d_doc_off, n_docs,
+                                       base, maps, gst, gst + nwords + 2, counters);
             }));
             TRY(timed(c, s, "tk_k_rx_merge", [&] { hipLaunchKernelGGL(tk_k_rx_merge, dim3(grid_for(nwords, 256, 4096)), dim3(256), 0, s, brk, gst, nwords); }));
         }
@@ -1016,53 +1051,83 @@ static void parallel_memcpy(void* dst, const void* src, size_t n, unsigned nth) 
     for (auto& t : th) t.join();
 }
 
-// One short document without special tokens: one launch, no copies, no stream synchronisation (tk_k_small, tk_fused.h).
+// One short document without special tokens: one launch, no copies, no stream synchronisation (tk_k_small, tk_fused.h), and no lock: the
+// call runs on a slot of its own (tk_core::SmallSlot), so the threads of a caller's pool overlap (core.py:175).
 // Returns TK_OK with *handled = false when the call has to take the general path.
 static int encode_small(tk_core* c, const uint8_t* utf8, uint32_t n, uint32_t** tokens_out, uint64_t* n_tokens_out, bool* handled) {
     *handled = false;
-    if (!c->small_in) {
-        HIPCHK(hipHostMalloc((void**)&c->small_in, TK_SMALL_MAX + 64, hipHostMallocCoherent | hipHostMallocMapped));
-        HIPCHK(hipHostMalloc((void**)&c->small_out, (TK_SMALL_HDR + TK_SMALL_MAX + 16) * 4, hipHostMallocCoherent | hipHostMallocMapped));
-        memset(c->small_in, 0, TK_SMALL_MAX + 64);
-        memset(c->small_out, 0, (TK_SMALL_HDR + TK_SMALL_MAX + 16) * 4);
-        TRY(ensure(c->small_ws, 256 * TK_SMALL_PIECE * 4));
+    // a free slot: start at a place of this thread's own, so that a pool of callers does not fight over slot 0
+    static std::atomic<uint32_t> next_thread{0};
+    static thread_local uint32_t home = next_thread.fetch_add(1, std::memory_order_relaxed);
+    tk_core::SmallSlot* sl = nullptr;
+    for (uint32_t spins = 0; !sl; ++spins) {
+        for (uint32_t k = 0; k < TK_SMALL_SLOTS && !sl; ++k) {
+            tk_core::SmallSlot& cand = c->small[(home + k) % TK_SMALL_SLOTS];
+            if (!cand.busy.load(std::memory_order_relaxed) && !cand.busy.exchange(1, std::memory_order_acquire)) sl = &cand;
+        }
+        if (!sl) {
+            if (spins > 64) std::this_thread::yield();  // (more callers than slots: a slot is held for some tens of microseconds)
+#if defined(__x86_64__)
+            else __builtin_ia32_pause();
+#endif
+        }
     }
-    memcpy(c->small_in, utf8, n);
-    memset(c->small_in + n, 0, 8);
-    void *d_in = nullptr, *d_out = nullptr;
-    HIPCHK(hipHostGetDevicePointer(&d_in, c->small_in, 0));
-    HIPCHK(hipHostGetDevicePointer(&d_out, c->small_out, 0));
-    const uint32_t seq = ++c->small_seq ? c->small_seq : ++c->small_seq;  // (never 0: the buffer starts zeroed)
-    hipStream_t s = c->stream;
-    TRY(timed(c, s, "tk_k_small", [&] {
-        hipLaunchKernelGGL(tk_k_small, dim3(1), dim3(256), 0, s, c->D, (const uint8_t*)d_in, n, seq, (uint32_t*)d_out, c->small_ws.as<uint32_t>());
-    }));
+    struct Release {
+        tk_core::SmallSlot* s;
+        ~Release() { s->busy.store(0, std::memory_order_release); }
+    } release_slot{sl};
+    HIPCHK(hipSetDevice(c->device));
+    if (!sl->in) {  // first use of the slot
+        HIPCHK(hipHostMalloc((void**)&sl->in, TK_SMALL_MAX + 64, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(sl->in, 0, TK_SMALL_MAX + 64);
+        HIPCHK(hipHostMalloc((void**)&sl->out, (TK_SMALL_HDR + TK_SMALL_MAX + 16) * 4, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(sl->out, 0, (TK_SMALL_HDR + TK_SMALL_MAX + 16) * 4);
+        TRY(ensure(sl->ws, 256 * TK_SMALL_PIECE * 4));
+        HIPCHK(hipHostGetDevicePointer(&sl->d_in, sl->in, 0));
+        HIPCHK(hipHostGetDevicePointer(&sl->d_out, sl->out, 0));
+        HIPCHK(hipStreamCreateWithFlags(&sl->s, hipStreamNonBlocking));
+    }
+    memcpy(sl->in, utf8, n);
+    memset(sl->in + n, 0, 8);
+    const uint32_t seq = ++sl->seq ? sl->seq : ++sl->seq;  // (never 0: the buffer starts zeroed)
+    hipStream_t s = sl->s;
+    if (c->profiling) {  // (kernel times are collected in the core's shared list: one caller at a time then)
+        std::lock_guard<std::mutex> lk(c->mu);
+        TRY(timed(c, s, "tk_k_small", [&] {
+            hipLaunchKernelGGL(tk_k_small, dim3(1), dim3(256), 0, s, c->D, (const uint8_t*)sl->d_in, n, seq, (uint32_t*)sl->d_out, sl->ws.as<uint32_t>());
+        }));
+        HIPCHK(hipStreamSynchronize(s));
+        TRY(drain_events(c));
+    } else {
+        hipLaunchKernelGGL(tk_k_small, dim3(1), dim3(256), 0, s, c->D, (const uint8_t*)sl->d_in, n, seq, (uint32_t*)sl->d_out, sl->ws.as<uint32_t>());
+        const hipError_t le = hipGetLastError();
+        if (le != hipSuccess) return fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(le) + " in tk_k_small");
+    }
     // the kernel's last store is the sequence number (system scope): watch for it instead of waiting on the stream
     const auto t0 = std::chrono::steady_clock::now();
     uint32_t spins = 0;
-    while (__atomic_load_n(&c->small_out[2], __ATOMIC_ACQUIRE) != seq) {
+    while (__atomic_load_n(&sl->out[2], __ATOMIC_ACQUIRE) != seq) {
         if ((++spins & 0xFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
             HIPCHK(hipStreamSynchronize(s));
-            if (__atomic_load_n(&c->small_out[2], __ATOMIC_ACQUIRE) != seq) return fail(TK_RUNTIME_ERROR, "the small-call kernel did not complete");
+            if (__atomic_load_n(&sl->out[2], __ATOMIC_ACQUIRE) != seq) return fail(TK_RUNTIME_ERROR, "the small-call kernel did not complete");
             break;
         }
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
     }
-    if (c->profiling) {
-        HIPCHK(hipStreamSynchronize(s));
-        TRY(drain_events(c));
-    }
-    if (c->small_out[0] != 1u) return TK_OK;  // a long piece that is not a token: general path
-    const uint64_t nt = c->small_out[1];
+    if (sl->out[0] != 1u) return TK_OK;  // a long piece that is not a token: general path
+    const uint64_t nt = sl->out[1];
     uint32_t* host = (uint32_t*)malloc((nt ? nt : 1) * 4);
     if (!host) return fail(TK_RUNTIME_ERROR, "out of host memory");
-    memcpy(host, c->small_out + TK_SMALL_HDR, nt * 4);
-    c->st_bytes = n;
-    c->st_tokens = nt;
-    c->st_docs = 1;
-    c->st_pieces = c->st_medium = c->st_long = 0;
+    memcpy(host, sl->out + TK_SMALL_HDR, nt * 4);
+    // (statistics of the last call: plain words, written without the lock -- with several callers "the last call" is whoever came last)
+    __atomic_store_n(&c->st_bytes, (uint64_t)n, __ATOMIC_RELAXED);
+    __atomic_store_n(&c->st_tokens, nt, __ATOMIC_RELAXED);
+    __atomic_store_n(&c->st_docs, (uint64_t)1, __ATOMIC_RELAXED);
+    __atomic_store_n(&c->st_pieces, (uint64_t)0, __ATOMIC_RELAXED);
+    __atomic_store_n(&c->st_medium, (uint64_t)0, __ATOMIC_RELAXED);
+    __atomic_store_n(&c->st_long, (uint64_t)0, __ATOMIC_RELAXED);
     *tokens_out = host;
     *n_tokens_out = nt;
     *handled = true;
@@ -1080,12 +1145,9 @@ static int encode_batch_impl(tk_core* c, const uint8_t* utf8, const uint64_t* do
     if (doc_off[0] != 0) return fail(TK_VALUE_ERROR, "doc_off[0] must be 0");
     for (uint64_t d = 0; d < n_docs; ++d)
         if (doc_off[d + 1] < doc_off[d]) return fail(TK_VALUE_ERROR, "doc_off must be non-decreasing");
-    std::lock_guard<std::mutex> lk(c->mu);
-    HIPCHK(hipSetDevice(c->device));
-    hipStream_t s = c->stream;
     const uint64_t n_bytes = doc_off[n_docs];
     if (!device_result && n_docs == 1 && n_bytes > 0 && n_bytes <= TK_SMALL_MAX && !(use_special && n_allowed) && !(c->dbg & 2048) && !c->has_rx) {
-        bool handled = false;
+        bool handled = false;  // (before the lock: small calls of several threads run side by side)
         TRY(encode_small(c, utf8, (uint32_t)n_bytes, tokens_out, n_tokens_out, &handled));
         if (handled) {
             if (tok_off_out) {
@@ -1095,6 +1157,9 @@ static int encode_batch_impl(tk_core* c, const uint8_t* utf8, const uint64_t* do
             return TK_OK;
         }
     }
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = c->stream;
     TRY(ensure(c->text, n_bytes + 256));
     TRY(ensure(c->doc_off, (n_docs + 2) * 8));
     HIPCHK(hipMemsetAsync((uint8_t*)c->text.p + n_bytes, 0, 128, s));

@@ -106,7 +106,7 @@ __device__ __forceinline__ uint32_t tk_wave_append(bool want, uint32_t* counter,
 // Start of a chunk: every buffer that has to be zero (or all ones) before the kernels run, in ONE launch (a hipMemsetAsync per buffer
 // costs the host 30-60 us each, and with pipelined chunks the host's time per chunk is what bounds the pipeline).
 // ------------------------------------------------------------------------------------------
-#define TK_CLEAR_MAX 14
+#define TK_CLEAR_MAX 16
 struct TkClearArgs {
     uint4* p[TK_CLEAR_MAX];
     uint64_t n16[TK_CLEAR_MAX];  // 16-byte units

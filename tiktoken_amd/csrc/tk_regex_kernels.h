@@ -2,8 +2,11 @@
 //
 //   tk_k_rx_speculate : one lane per segment (256 bytes or 1 KiB) of the chunk follows the chain of piece starts from the segment's first char as if it
 //                       were a piece start (bitmap `spec`, exit position per segment);
-//   tk_k_rx_resolve   : one lane per document walks the true chain, taking whole segments from `spec` wherever it lands on a speculative
-//                       chain (exact: a match depends only on the text to its right) -> bitmap `gst` of true piece starts;
+//   tk_k_rx_link      : one lane per segment walks from where the segment before it was left (as guessed) until it meets its own segment's
+//                       chain: with these links a segment is taken whole wherever the guesses were right;
+//   tk_k_rx_resolve_wave : one wavefront per document walks the true chain, 64 segments per step wherever the plans of its lanes hold, one
+//                       match where they do not (exact: a match depends only on the text around it) -> bitmap `gst` of true piece starts
+//                       (tk_k_rx_resolve: the same by one lane per document);
 //   (gap chars -- positions at which the pattern matches nothing: find_iter skips them -- are pieces of their own, marked in `sgap` / `ggap`:
 //    the front kernel gives them no token)
 //   tk_k_rx_merge     : brk |= gst.  From here on every piece start is a "hard" start for the front kernel, which runs with a class table
@@ -58,10 +61,22 @@ __global__ __launch_bounds__(256) void tk_k_rx_speculate(TkRxDev R, const uint8_
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += gridDim.x * blockDim.x) tk_rx_speculate_lane(P, t, k, seg_shift, spec, sgap, xexit);
 }
 
+__global__ __launch_bounds__(256) void tk_k_rx_link(TkRxDev R, const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ brk,
+                                                    const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, uint32_t seg_shift,
+                                                    const uint32_t* __restrict__ spec, const uint32_t* __restrict__ xexit, uint32_t* __restrict__ lnk,
+                                                    uint32_t* __restrict__ lgap, uint32_t* __restrict__ lmerge, uint32_t* __restrict__ lexit) {
+    __shared__ TkRxLds L;
+    const TkRxProg P = tk_rx_stage_program(R, &L);
+    const uint32_t nseg = (uint32_t)(((uint64_t)n + (1u << seg_shift) - 1u) >> seg_shift);
+    const TkRxText t{text, n, brk, ss, si, 0xFFFFFFFFu, false};
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += gridDim.x * blockDim.x)
+        tk_rx_link_lane(P, t, k, seg_shift, spec, xexit, lnk, lgap, lmerge, lexit);
+}
+
+// one lane per document (debug bit 0x4000000; the CPU tests run this form lane by lane)
 __global__ __launch_bounds__(256) void tk_k_rx_resolve(TkRxDev R, const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ brk,
                                                        const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si,
-                                                       const uint64_t* __restrict__ doc_off, uint64_t n_docs, uint64_t base, uint32_t seg_shift,
-                                                       const uint32_t* __restrict__ spec, const uint32_t* __restrict__ sgap, const uint32_t* __restrict__ xexit,
+                                                       const uint64_t* __restrict__ doc_off, uint64_t n_docs, uint64_t base, TkRxMaps M,
                                                        uint32_t* __restrict__ gst, uint32_t* __restrict__ ggap, uint32_t* __restrict__ counters) {
     __shared__ TkRxLds L;
     const TkRxProg P = tk_rx_stage_program(R, &L);
@@ -70,7 +85,7 @@ __global__ __launch_bounds__(256) void tk_k_rx_resolve(TkRxDev R, const uint8_t*
         const uint64_t b = doc_off[d] - base, e = doc_off[d + 1] - base;
         if (b >= e || e > n) continue;
         uint32_t err_pos = 0;
-        const uint32_t err = tk_rx_resolve_lane(P, t, (uint32_t)b, (uint32_t)e, seg_shift, spec, sgap, xexit,
+        const uint32_t err = tk_rx_resolve_lane(P, t, M, (uint32_t)b, (uint32_t)e,
                                                 [&](uint32_t w, uint32_t bits, uint32_t gaps) {
                                                     if (bits) atomicOr(&gst[w], bits);
                                                     if (gaps) atomicOr(&ggap[w], gaps);
@@ -79,6 +94,59 @@ __global__ __launch_bounds__(256) void tk_k_rx_resolve(TkRxDev R, const uint8_t*
         if (err) {
             atomicOr(&counters[TK_CNT_ERR], err);
             atomicMax(&counters[TK_CNT_RXPOS], ~err_pos);  // (the counters start at zero: the smallest position wins)
+        }
+    }
+}
+
+// One WAVEFRONT per document (tk_rx_resolve_group_host is the same, lane after lane): lane j plans segment k0 + j as if the chain entered
+// it where the guess for the segment before it ended; the longest prefix of lanes whose plans hold -- every exit known and equal to the next
+// lane's entry -- is taken at once, 64 segments per step.  Where lane 0 has no plan the wavefront takes one step of the serial form (all
+// lanes run it on the same arguments: uniform control flow, lane 0 writes).  A single document of many megabytes is resolved by its
+// wavefront at the rate of its memory operations, not of one lane's matcher.
+__global__ __launch_bounds__(256) void tk_k_rx_resolve_wave(TkRxDev R, const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ brk,
+                                                            const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si,
+                                                            const uint64_t* __restrict__ doc_off, uint64_t n_docs, uint64_t base, TkRxMaps M,
+                                                            uint32_t* __restrict__ gst, uint32_t* __restrict__ ggap, uint32_t* __restrict__ counters) {
+    __shared__ TkRxLds L;
+    const TkRxProg P = tk_rx_stage_program(R, &L);
+    const uint32_t lane = threadIdx.x & 63u;
+    const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
+    auto orb_all = [&](uint32_t w, uint32_t bits, uint32_t gaps) {
+        if (bits) atomicOr(&gst[w], bits);
+        if (gaps) atomicOr(&ggap[w], gaps);
+    };
+    auto orb_lane0 = [&](uint32_t w, uint32_t bits, uint32_t gaps) {
+        if (lane == 0u) orb_all(w, bits, gaps);
+    };
+    for (uint64_t d = wave; d < n_docs; d += nwaves) {
+        const uint64_t b64 = doc_off[d] - base, e64 = doc_off[d + 1] - base;
+        if (b64 >= e64 || e64 > n) continue;
+        const uint32_t e = (uint32_t)e64;
+        TkRxText t{text, n, brk, ss, si, 0xFFFFFFFFu, false};
+        uint32_t p = (uint32_t)b64, err = 0;
+        while (p < e) {
+            const uint32_t k = (p >> M.seg_shift) + lane;
+            uint32_t entry = p;
+            if (lane) entry = ((uint64_t)k << M.seg_shift) < n ? M.xexit[k - 1u] : TK_RX_UNKNOWN;
+            TkRxPlan plan{false, false, 0, 0, TK_RX_UNKNOWN};
+            if (entry != TK_RX_UNKNOWN) plan = tk_rx_plan(M, n, k, entry, e);
+            // lanes 0 .. len - 1: every plan holds, every exit but the last is known and is the next lane's entry
+            const uint32_t prev_exit = (uint32_t)__shfl_up((int)plan.exit, 1, 64);
+            const bool chained = plan.ok && (lane == 0u || (prev_exit != TK_RX_UNKNOWN && prev_exit == entry));
+            const uint64_t bad = ~__ballot(chained);
+            uint32_t len = bad ? (uint32_t)__ffsll((unsigned long long)bad) - 1u : 64u;
+            if (len && (uint32_t)__shfl((int)plan.exit, (int)len - 1, 64) == TK_RX_UNKNOWN) --len;  // (that segment's guess broke off: the serial step's)
+            if (len == 0u) {
+                p = tk_rx_resolve_step(P, t, M, p, e, orb_lane0, &err);
+                if (err) break;
+                continue;
+            }
+            if (lane < len) (void)tk_rx_emit(M, plan, entry, orb_all);
+            p = (uint32_t)__shfl((int)plan.exit, (int)len - 1, 64);
+        }
+        if (err && lane == 0u) {
+            atomicOr(&counters[TK_CNT_ERR], err);
+            atomicMax(&counters[TK_CNT_RXPOS], ~p);  // (the counters start at zero: the smallest position wins)
         }
     }
 }

@@ -11,8 +11,13 @@
 //      is on segment k's speculative chain (its bit is set in `spec`), everything that chain found from p on is true as well: the lane takes
 //      the rest of the segment's bits and jumps to xexit[k] -- a few memory operations per KiB instead of a match per piece.  Where p
 //      is not on the chain it runs the matcher itself until the chains meet.  The result is exact whatever the guesses were.
+//   1b. tk_rx_link_lane: lane k walks from xexit[k - 1] -- where the true chain enters segment k if the guess for k - 1 was right -- until
+//      it meets segment k's chain; with these links the resolving pass runs the matcher only where a guess was wrong, and a group of
+//      lanes can prove 64 consecutive segments of one document at once (tk_rx_plan / tk_rx_emit).
 // A speculative match never reads more than TK_RX_AHEAD bytes beyond its segment (a megabyte of one letter is one piece: every lane inside
-// it would scan to its end); a lane that would have to stops, and the resolving lane -- which really is at a piece start -- goes on.
+// it would scan to its end); a lane that would have to at its FIRST evaluation stops (it is probably inside that piece), one that meets
+// such a piece later along its chain evaluates it in full -- once, in parallel with everybody else -- and the resolving lane, which really
+// is at a piece start, evaluates whatever is left.
 //
 // Special tokens (encode() with allowed_special): a haystack ends where a special token starts (`hard` bit, as at a document start);
 // the token itself is one step of the chain.  A position where the pattern does not match: the reference's find_iter goes on to the next
@@ -26,7 +31,7 @@
 // not fill the GPU with 1 KiB segments, 1024 otherwise (fewer, longer chains: less is matched twice around the segment boundaries)
 #define TK_RX_SEG_SHIFT_SMALL 8u
 #define TK_RX_SEG_SHIFT_LARGE 10u
-#define TK_RX_SEG_SMALL_BELOW (256ull << 20)  // chunk bytes
+#define TK_RX_SEG_SMALL_BELOW (4ull << 30)  // chunk bytes: every chunk (measured at 256 MiB, o200k pat_str: 17.8 ms with 256-byte segments, 24.2 with 1 KiB -- four times the lanes beat the pieces matched twice)
 #define TK_RX_AHEAD 16384u  // bytes a speculative match may look beyond its segment
 #define TK_RX_UNKNOWN 0xFFFFFFFFu
 #define TK_RX_ERR_GAP 4u       // bits of the chunk's error word
@@ -92,21 +97,35 @@ TK_HD uint32_t tk_rx_next(const TkRxProg& P, TkRxText& t, uint32_t p, bool* gap)
     return q;
 }
 
+// bit p of a bitmap
+TK_HD bool tk_rx_bit(const uint32_t* bm, uint32_t p) { return (bm[p >> 5] >> (p & 31u)) & 1u; }
+
 TK_HD void tk_rx_speculate_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint32_t seg_shift, uint32_t* spec, uint32_t* sgap, uint32_t* xexit) {
     const uint64_t a64 = (uint64_t)k << seg_shift;
     if (a64 >= t.n) return;
     const uint32_t seg = 1u << seg_shift;
     const uint32_t a = (uint32_t)a64, end = t.n - a > seg ? a + seg : t.n;
-    t.limit = t.n - end > TK_RX_AHEAD ? end + TK_RX_AHEAD : t.n;
+    const uint32_t limit = t.n - end > TK_RX_AHEAD ? end + TK_RX_AHEAD : t.n;
+    t.limit = limit;
     t.hit = false;
     uint32_t p = a;
     while (p < end && ((t.byte(p) & 0xC0u) == 0x80u || t.inside_special(p))) ++p;
+    const uint32_t first = p;
     uint32_t x = TK_RX_UNKNOWN;
     if (p < end) {
         for (;;) {
             spec[p >> 5] |= 1u << (p & 31u);  // (the words of a segment belong to its lane)
             bool gap;
-            const uint32_t q = tk_rx_next(P, t, p, &gap);
+            uint32_t q = tk_rx_next(P, t, p, &gap);
+            if (t.hit && p != first && !TK_RX_IS_ERROR(q)) {
+                // A long piece (it reaches TK_RX_AHEAD bytes beyond the segment) that this lane has come to along its chain: very likely a
+                // true start, and nobody else will evaluate it in parallel -- the lanes of the segments inside the piece stop at their FIRST
+                // evaluation (below), so the text of a long piece is scanned once here instead of once by the resolving lane of its document.
+                t.limit = 0xFFFFFFFFu;
+                t.hit = false;
+                q = tk_rx_next(P, t, p, &gap);
+                t.limit = limit;
+            }
             if (TK_RX_IS_ERROR(q) || t.hit) break;
             if (gap) sgap[p >> 5] |= 1u << (p & 31u);
             if (q >= end) {
@@ -119,50 +138,183 @@ TK_HD void tk_rx_speculate_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint3
     xexit[k] = x;
 }
 
-// One document [b, e) of the chunk.  `orbits(word index, start bits, gap bits)` ORs into the bitmaps of true starts and of the gap chars
-// among them (shared words: atomic on the device).  Returns 0 or the error bits.
+// Links between consecutive segments.  The true chain enters segment k where segment k - 1 was left -- at xexit[k - 1], if that guess was
+// right -- and that position is usually NOT on segment k's own speculative chain (which started at the segment's first char): the chains
+// meet a few pieces later.  Lane k walks from xexit[k - 1] until it stands on a start of segment k's chain, noting its steps in `lnk`
+// (gap chars in `lgap`; both in the segment's own words) and the meeting point in lmerge[k]; or it leaves the segment without meeting the
+// chain (lmerge[k] = end of the segment, lexit[k] = where to).  With the links the resolving pass runs the matcher only where a guess was
+// wrong: entering segment k at xexit[k - 1] it takes the link's steps, then the chain's from the meeting point on, and jumps to xexit[k].
+#define TK_RX_NOLINK 0xFFFFFFFFu
+TK_HD void tk_rx_link_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint32_t seg_shift, const uint32_t* spec, const uint32_t* xexit,
+                           uint32_t* lnk, uint32_t* lgap, uint32_t* lmerge, uint32_t* lexit) {
+    const uint64_t a64 = (uint64_t)k << seg_shift;
+    if (a64 >= t.n) return;
+    const uint32_t seg = 1u << seg_shift;
+    const uint32_t a = (uint32_t)a64, end = t.n - a > seg ? a + seg : t.n;
+    uint32_t m = TK_RX_NOLINK, x = TK_RX_UNKNOWN;
+    const uint32_t e = k ? xexit[k - 1] : TK_RX_UNKNOWN;
+    if (e != TK_RX_UNKNOWN && e >= a && e < end) {
+        if (tk_rx_bit(spec, e)) {
+            m = e;  // on the chain as it is
+        } else {
+            t.limit = t.n - end > TK_RX_AHEAD ? end + TK_RX_AHEAD : t.n;
+            t.hit = false;
+            uint32_t p = e;
+            for (;;) {
+                lnk[p >> 5] |= 1u << (p & 31u);
+                bool gap;
+                const uint32_t q = tk_rx_next(P, t, p, &gap);
+                if (TK_RX_IS_ERROR(q) || t.hit) break;  // (no link: the resolving lane evaluates this stretch itself)
+                if (gap) lgap[p >> 5] |= 1u << (p & 31u);
+                if (q >= end) {
+                    m = end;
+                    x = q;
+                    break;
+                }
+                if (tk_rx_bit(spec, q)) {
+                    m = q;
+                    break;
+                }
+                p = q;
+            }
+        }
+    }
+    lmerge[k] = m;
+    lexit[k] = x;
+}
+
+struct TkRxMaps {  // what the speculative pass and the link pass have left (lnk == nullptr: no link pass; spec == nullptr: no speculation)
+    const uint32_t *spec, *sgap, *xexit, *lnk, *lgap, *lmerge, *lexit;
+    uint32_t seg_shift;
+};
+
+// the set bits of bm (gaps: gm) in [from, to), through `orbits`; returns the last position taken, or `none`
 template <class Or>
-TK_HD uint32_t tk_rx_resolve_lane(const TkRxProg& P, TkRxText t, uint32_t b, uint32_t e, uint32_t seg_shift, const uint32_t* spec, const uint32_t* sgap,
-                                  const uint32_t* xexit, Or&& orbits, uint32_t* err_pos) {
+TK_HD uint32_t tk_rx_take(const uint32_t* bm, const uint32_t* gm, uint32_t from, uint32_t to, uint32_t none, Or&& orbits) {
+    uint32_t last = none;
+    if (from >= to) return last;
+    for (uint32_t w = from >> 5; w <= (to - 1u) >> 5; ++w) {
+        uint32_t bits = bm[w];
+        if (w == (from >> 5)) bits &= ~0u << (from & 31u);
+        if (w == ((to - 1u) >> 5) && (to & 31u)) bits &= (1u << (to & 31u)) - 1u;
+        if (bits) {
+            last = w * 32u + 31u - (uint32_t)__builtin_clz(bits);
+            orbits(w, bits, gm[w] & bits);  // (a start whose evaluation a guess broke off has no gap bit: it is matched again)
+        }
+    }
+    return last;
+}
+
+// What segment k holds for a chain that enters it at `entry` (a true start, or assumed to be one), for the document that ends at e:
+//   ok    : the maps answer -- entry is on the segment's chain, or it is xexit[k - 1] and the link pass has walked from there;
+//   m     : from where on the segment's own chain is taken (>= seg_end: nowhere), link: the steps of `lnk` before it are taken too;
+//   exit  : the first start behind the segment (>= e: the document is finished); TK_RX_UNKNOWN: the chain's guess broke off (a piece that
+//           looks too far ahead) -- the caller goes on from the last start taken.
+struct TkRxPlan {
+    bool ok, link;
+    uint32_t m, seg_end, exit;
+};
+TK_HD TkRxPlan tk_rx_plan(const TkRxMaps& M, uint32_t n, uint32_t k, uint32_t entry, uint32_t e) {
+    TkRxPlan R{false, false, 0, 0, TK_RX_UNKNOWN};
+    const uint64_t a64 = (uint64_t)k << M.seg_shift, end64 = a64 + (1ull << M.seg_shift);
+    if (!M.spec || a64 >= n) return R;
+    const uint32_t a = (uint32_t)a64, end = end64 < n ? (uint32_t)end64 : n;
+    R.seg_end = end < e ? end : e;
+    if (entry < a || entry >= R.seg_end) return R;
+    if (tk_rx_bit(M.spec, entry)) {
+        R.m = entry;
+    } else if (M.lnk && k && M.xexit[k - 1] == entry && M.lmerge[k] != TK_RX_NOLINK) {
+        R.m = M.lmerge[k];
+        R.link = true;
+    } else {
+        return R;
+    }
+    R.ok = true;
+    if (R.m >= R.seg_end) R.exit = (R.link && R.m == end) ? M.lexit[k] : R.m;  // (left without meeting the chain; or met it behind the document's end)
+    else R.exit = M.xexit[k];
+    return R;
+}
+// the starts of the plan, through `orbits`; returns the last start taken
+template <class Or>
+TK_HD uint32_t tk_rx_emit(const TkRxMaps& M, const TkRxPlan& R, uint32_t entry, Or&& orbits) {
+    uint32_t last = entry;
+    if (R.link) last = tk_rx_take(M.lnk, M.lgap, entry, R.m < R.seg_end ? R.m : R.seg_end, last, orbits);
+    if (R.m < R.seg_end) last = tk_rx_take(M.spec, M.sgap, R.m, R.seg_end, last, orbits);
+    return last;
+}
+
+// One step of the true chain of the document [.., e) from the true start p: the whole rest of p's segment when the maps answer, one
+// match otherwise.  Returns the next true start (>= e: done) or, with *err set, the position of the failure.
+template <class Or>
+TK_HD uint32_t tk_rx_resolve_step(const TkRxProg& P, TkRxText& t, const TkRxMaps& M, uint32_t p, uint32_t e, Or&& orbits, uint32_t* err) {
+    const TkRxPlan R = tk_rx_plan(M, t.n, p >> M.seg_shift, p, e);
+    if (R.ok) {
+        const uint32_t last = tk_rx_emit(M, R, p, orbits);
+        if (R.exit != TK_RX_UNKNOWN) return R.exit;
+        p = last;  // the guess stopped here (it would have had to look too far ahead): go on from its last start
+    } else {
+        orbits(p >> 5, 1u << (p & 31u), 0u);
+    }
+    bool gap;
+    const uint32_t q = tk_rx_next(P, t, p, &gap);
+    if (TK_RX_IS_ERROR(q)) {
+        *err = q == TK_RX_OVERFLOW ? TK_RX_ERR_STACK : TK_RX_ERR_LIMIT;
+        return p;
+    }
+    if (gap) orbits(p >> 5, 0u, 1u << (p & 31u));
+    return q;
+}
+
+// One document [b, e) of the chunk by one lane.  `orbits(word index, start bits, gap bits)` ORs into the bitmaps of true starts and of the
+// gap chars among them (shared words: atomic on the device).  Returns 0 or the error bits.
+template <class Or>
+TK_HD uint32_t tk_rx_resolve_lane(const TkRxProg& P, TkRxText t, const TkRxMaps& M, uint32_t b, uint32_t e, Or&& orbits, uint32_t* err_pos) {
     t.limit = 0xFFFFFFFFu;
     t.hit = false;
-    uint32_t p = b;
+    uint32_t p = b, err = 0;
     while (p < e) {
-        bool run = true;
-        if (spec && ((spec[p >> 5] >> (p & 31u)) & 1u)) {  // on segment k's chain: its bits from p on are true starts
-            const uint32_t k = p >> seg_shift;
-            const uint64_t se64 = ((uint64_t)k + 1u) << seg_shift;
-            const uint32_t seg_end = se64 < e ? (uint32_t)se64 : e;
-            uint32_t last = p;
-            for (uint32_t w = p >> 5; w <= (seg_end - 1u) >> 5; ++w) {
-                uint32_t bits = spec[w];
-                if (w == (p >> 5)) bits &= ~0u << (p & 31u);
-                if (w == ((seg_end - 1u) >> 5) && (seg_end & 31u)) bits &= (1u << (seg_end & 31u)) - 1u;
-                if (bits) {
-                    last = w * 32u + 31u - (uint32_t)__builtin_clz(bits);
-                    orbits(w, bits, sgap[w] & bits);  // (a start whose evaluation the guess broke off has no gap bit: it is matched again below)
-                }
-            }
-            const uint32_t x = xexit[k];
-            if (x != TK_RX_UNKNOWN) {
-                p = x;
-                run = false;
-            } else {
-                p = last;  // the guess stopped here (it would have had to look too far ahead): go on from its last start
-            }
-        } else {
-            orbits(p >> 5, 1u << (p & 31u), 0u);
+        p = tk_rx_resolve_step(P, t, M, p, e, orbits, &err);
+        if (err) {
+            *err_pos = p;
+            return err;
         }
-        if (run) {
-            bool gap;
-            const uint32_t q = tk_rx_next(P, t, p, &gap);
-            if (TK_RX_IS_ERROR(q)) {
+    }
+    return 0;
+}
+
+// The same by a group of TK_RX_WAVE lanes that look at consecutive segments at once: lane j plans segment k0 + j as if the chain entered
+// it at xexit[k0 + j - 1] (lane 0: at p); the longest prefix of lanes whose plans hold and whose exits are what the next lane assumed is
+// taken in one go, and the chain continues behind it.  Where lane 0 has no plan the group takes one step of the serial form.  The host
+// form runs the lanes one after the other (tests/hostsim); the device form (tk_regex_kernels.h) ballots.
+#define TK_RX_WAVE 64u
+template <class Or>
+TK_HD uint32_t tk_rx_resolve_group_host(const TkRxProg& P, TkRxText t, const TkRxMaps& M, uint32_t b, uint32_t e, Or&& orbits, uint32_t* err_pos) {
+    t.limit = 0xFFFFFFFFu;
+    t.hit = false;
+    uint32_t p = b, err = 0;
+    while (p < e) {
+        const uint32_t k0 = p >> M.seg_shift;
+        TkRxPlan plan[TK_RX_WAVE];
+        uint32_t entry[TK_RX_WAVE], L = 0;
+        for (uint32_t j = 0; j < TK_RX_WAVE; ++j) {
+            entry[j] = j ? (M.spec && ((uint64_t)(k0 + j) << M.seg_shift) < t.n ? M.xexit[k0 + j - 1] : TK_RX_UNKNOWN) : p;
+            plan[j] = entry[j] == TK_RX_UNKNOWN ? TkRxPlan{false, false, 0, 0, TK_RX_UNKNOWN} : tk_rx_plan(M, t.n, k0 + j, entry[j], e);
+        }
+        // lanes 0 .. L - 1: every plan holds, every exit but the last is known and is the next lane's entry
+        while (L < TK_RX_WAVE && plan[L].ok && (L == 0 || (plan[L - 1].exit != TK_RX_UNKNOWN && plan[L - 1].exit == entry[L]))) ++L;
+        if (L && plan[L - 1].exit == TK_RX_UNKNOWN) {  // (the last plan's chain broke off: its segment is left to the serial step)
+            --L;
+        }
+        if (L == 0) {
+            p = tk_rx_resolve_step(P, t, M, p, e, orbits, &err);
+            if (err) {
                 *err_pos = p;
-                return q == TK_RX_OVERFLOW ? TK_RX_ERR_STACK : TK_RX_ERR_LIMIT;
+                return err;
             }
-            if (gap) orbits(p >> 5, 0u, 1u << (p & 31u));
-            p = q;
+            continue;
         }
+        for (uint32_t j = 0; j < L; ++j) (void)tk_rx_emit(M, plan[j], entry[j], orbits);
+        p = plan[L - 1].exit;
     }
     return 0;
 }

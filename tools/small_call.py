@@ -37,3 +37,28 @@ g = tiktoken_amd.get_encoding("gpt2_shaped")
 s = blob.tobytes().decode()
 print("C1 (1 MiB, gpt2_shaped) Encoding.encode_ordinary:", med(lambda: g.encode_ordinary(s), n=30, warm=3))
 print("C1 CoreBPE._encode_np:", med(lambda: g._core_bpe._encode_np(blob.tobytes(), None), n=30, warm=3))
+
+# several threads on one Encoding (core.py:175): small calls take no lock (a slot each); calls per second through the C ABI and through
+# Encoding.encode_ordinary (the latter holds the GIL for its Python part)
+import threading
+text = ("The quick brown fox jumps over the lazy dog; 3.14159 and so on, ünïcödé too. " * 3)[:180]
+b = text.encode(); buf = np.frombuffer(b, np.uint8); L = core._L
+def raw_call():
+    out, n = ctypes.c_void_p(), ctypes.c_uint64()
+    L.tk_encode_ordinary(core._h, buf.ctypes.data, len(b), ctypes.byref(out), ctypes.byref(n))
+    L.tk_free(out)
+def rate(f, nth, total=24000):
+    def work():
+        for _ in range(total // nth): f()
+    for _ in range(200): f()
+    th = [threading.Thread(target=work) for _ in range(nth)]
+    t0 = time.perf_counter()
+    for t in th: t.start()
+    for t in th: t.join()
+    return total / (time.perf_counter() - t0)
+print(f"threads on one Encoding, {len(b)}-byte calls (calls per second):")
+base_raw = base_py = None
+for nth in (1, 2, 4, 8, 16):
+    r_raw, r_py = rate(raw_call, nth), rate(lambda: enc.encode_ordinary(text), nth)
+    base_raw = base_raw or r_raw; base_py = base_py or r_py
+    print(f"   {nth:2d} threads: C ABI {r_raw:9.0f}/s ({r_raw / base_raw:4.2f}x)   Encoding.encode_ordinary {r_py:9.0f}/s ({r_py / base_py:4.2f}x)")
