@@ -311,6 +311,58 @@ def test_chains_of_uncertain_boundaries_do_not_take_seconds(cores, unit, name):
     assert dt < 0.15, f"{unit!r}: {dt * 1e3:.1f} ms"
 
 
+def test_ten_megabytes_without_a_certain_start_take_the_generic_way():
+    """A stretch of short pieces without certain starts used to be quadratic (every deferred tile walked from its start: 23 ms for 1 MB,
+    seconds for 10 MB).  Now a tile gives up after TKF_WALK_BUDGET windows, the generic engine splits the chunk under the same pat_str
+    (linear on such text), and the tiles that gave up run again with every piece start a hard start (tk_api.hip, stage_deferred)."""
+    import time
+
+    import tiktoken_amd
+
+    name = "o200k_shaped"
+    core, C = tiktoken_amd.get_encoding(name)._core_bpe, h.c_oracle_for(name)
+    data = ("x'll" * 2_500_000).encode()
+    want = C.encode_ordinary(data)
+    before = core.stat("fallbacks")
+    assert np.array_equal(core._encode_np(data, None), want)
+    assert core.stat("fallbacks") == before + 1
+    ts = []
+    for _ in range(3):
+        t0 = time.perf_counter()
+        got = core._encode_np(data, None)
+        ts.append(time.perf_counter() - t0)
+    assert np.array_equal(got, want)
+    print(f"10 MB of x'll: {min(ts) * 1e3:.1f} ms")
+    assert min(ts) < 0.12, ts
+    # documents around it, special tokens inside it, and a second stretch in a later document
+    docs = [b"plain text before. ", ("x'll" * 300_000).encode(), b"", ("y'd" * 200_000 + "<|endoftext|>" + "z'Re" * 100_000).encode(), b"and after"]
+    blob, off = h.pack(docs)
+    for allowed in (None, "all"):
+        toks, toff = core.encode_batch_packed(blob, off, allowed)
+        rt, ro = C.encode_batch(blob, off, None if allowed is None else set(h.load_golden(name)["special_tokens"]), 4)
+        assert np.array_equal(toff, ro) and np.array_equal(toks, rt), allowed
+
+
+@pytest.mark.parametrize("name", h.ENCODING_NAMES)
+def test_ordinary_text_through_the_give_up_path(monkeypatch, name):
+    """TIKTOKEN_AMD_DEBUG bit 0x20000000: a walk budget of zero windows -- every deferred tile that would walk a window gives up, and the
+    chunk goes the generic way of the test above.  Same tokens as the oracle on corpus text with special tokens."""
+    from tiktoken_amd import CoreBPE
+
+    monkeypatch.setenv("TIKTOKEN_AMD_DEBUG", str(0x20000000))
+    g = h.load_golden(name)
+    core, C = CoreBPE(h.golden_vocab(name), g["special_tokens"], h.PAT_STR[h.ENCODING_NAMES.index(name)]), h.c_oracle_for(name)
+    blob, off = h.gen_corpus(0xFA11 + h.ENCODING_NAMES.index(name), 1, 8 << 20)
+    docs = [blob[int(off[i]):int(off[i + 1])].tobytes() for i in range(len(off) - 1)]
+    docs[3] = docs[3] + ("x'll" * 100_000).encode() + b"<|endoftext|>" + ("Ab" * 5000 + "q're" * 60_000).encode()
+    blob, off = h.pack(docs)
+    for allowed in (None, "all"):
+        toks, toff = core.encode_batch_packed(blob, off, allowed)
+        rt, ro = C.encode_batch(blob, off, None if allowed is None else set(g["special_tokens"]), 8)
+        assert np.array_equal(toff, ro) and np.array_equal(toks, rt), allowed
+    assert core.stat("fallbacks") >= 2
+
+
 @pytest.mark.parametrize("name", h.ENCODING_NAMES)
 def test_long_runs_of_every_kind(cores, name):
     """Documents made of long runs (2..40 KiB) of letters, digits, white space with and without newlines, punctuation, CJK, accented

@@ -483,14 +483,17 @@ def test_known_tokenizer_patterns_are_accepted():
 def test_chains_of_uncertain_boundaries_are_linear_for_the_generic_split(unit, name):
     """The inputs on which the scanner families still work quadratically (a megabyte without a certain piece start: every deferred tile walks
     from the start of the stretch; tests/test_gpu_parity.py::test_chains_of_uncertain_boundaries_do_not_take_seconds) are easy for the
-    speculative split: pieces are short, every segment's guess is accepted, the resolving lane hardly ever runs the matcher.  DESIGN section 7
-    plans to route such chunks through it."""
+    speculative split: pieces are short, every segment's guess is accepted, the resolving lane hardly ever runs the matcher.  The library
+    routes such chunks through it (tk_api.hip, stage_deferred)."""
     rx, C = h.RxSim(h.load_golden(name)["pat_str"]), h.c_oracle_for(name)
     data = (unit * (1_000_000 // len(unit))).encode()
     want = [0] + C.split(data)[:-1]
     assert rx.split([data], speculate=1) == want
     spec_runs, resolve_runs = rx.stats
-    assert spec_runs < 1.02 * len(want) and resolve_runs < len(want) // 50, (spec_runs, resolve_runs, len(want))
+    # (128-byte segments: a lane's first piece or two are matched again by its neighbour)
+    assert spec_runs < 1.15 * len(want) and resolve_runs < len(want) // 25, (spec_runs, resolve_runs, len(want))
+    assert rx.split([data], speculate=13) == want  # with the link pass, a group of lanes per document: the matcher never runs in the resolving pass
+    assert rx.stats[1] <= 2, rx.stats
 
 
 def _generic_golden():

@@ -113,6 +113,9 @@ struct tk_core {
     Buf t_stage1, t_stage2, t_byte_tab, t_short, t_mid, t_dec, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_hot, t_spec_bytes, t_spec_off, t_spec_id;
     uint32_t spec_max_len = 0;
     bool has_rx = false;  // the pat_str runs on the generic engine (tk_regex_kernels.h)
+    bool has_rx_fb = false;  // a pat_str of the scanner families, compiled for the generic engine as well: the way out of stretches without certain starts (stage_deferred)
+    TkRxCompiled rx_fb;
+    uint64_t st_fallbacks = 0;  // chunks that took that way
     TkRxDev rx{};
     Buf t_rx_ins, t_rx_sets, t_rx_ranges, t_rx_first, t_rx_s1, t_rx_s2;
     std::mutex mu;
@@ -307,7 +310,25 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     }
     const TkHostTables& H = c->H;
     int rc;
+    auto upload_rx = [&](const TkRxCompiled& X) -> int {  // the program of the generic engine
+        TRY(upload(c->t_rx_ins, X.ins.data(), X.ins.size() * sizeof(TkRxIns)));
+        TRY(upload(c->t_rx_sets, X.sets.data(), X.sets.size() * sizeof(TkRxSet)));
+        TRY(upload(c->t_rx_ranges, X.ranges.data(), X.ranges.size() * 4));
+        TRY(upload(c->t_rx_first, X.first.data(), X.first.size() * 4));
+        TRY(upload(c->t_rx_s1, tk_rx_props_stage1(), 0x1100));
+        TRY(upload(c->t_rx_s2, tk_rx_props_stage2(), (size_t)tk_rx_props_blocks() * 256));
+        c->rx = TkRxDev{c->t_rx_ins.as<TkRxIns>(), c->t_rx_sets.as<TkRxSet>(), c->t_rx_ranges.as<uint32_t>(), c->t_rx_s1.as<uint8_t>(),
+                        c->t_rx_s2.as<uint8_t>(), (uint32_t)X.ins.size(), (uint32_t)X.sets.size(), (uint32_t)X.ranges.size() / 2,
+                        c->t_rx_first.as<uint32_t>(), (uint32_t)X.first.size() / 8};
+        return TK_OK;
+    };
     if (H.rx.empty()) {
+        // a pattern of the scanner families: compiled for the generic engine as well, for stretches of text without certain starts
+        // (stage_deferred); a family member the generic compiler cannot take keeps its scanners alone
+        if (tk_rx_compile(pat_str, &c->rx_fb).empty()) {
+            if ((rc = upload_rx(c->rx_fb))) return bail(rc);
+            c->has_rx_fb = true;
+        }
         if ((rc = upload(c->t_stage1, tk_uc_stage1, sizeof tk_uc_stage1))) return bail(rc);
         if ((rc = upload(c->t_stage2, tk_uc_stage2, sizeof tk_uc_stage2))) return bail(rc);
         uint32_t bt[256 * 2];
@@ -322,15 +343,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
         uint32_t bt[256 * 2];
         tk_build_byte_table(s1.data(), s2.data(), bt);
         if ((rc = upload(c->t_byte_tab, bt, sizeof bt))) return bail(rc);
-        if ((rc = upload(c->t_rx_ins, H.rx.ins.data(), H.rx.ins.size() * sizeof(TkRxIns)))) return bail(rc);
-        if ((rc = upload(c->t_rx_sets, H.rx.sets.data(), H.rx.sets.size() * sizeof(TkRxSet)))) return bail(rc);
-        if ((rc = upload(c->t_rx_ranges, H.rx.ranges.data(), H.rx.ranges.size() * 4))) return bail(rc);
-        if ((rc = upload(c->t_rx_first, H.rx.first.data(), H.rx.first.size() * 4))) return bail(rc);
-        if ((rc = upload(c->t_rx_s1, tk_rx_props_stage1(), 0x1100))) return bail(rc);
-        if ((rc = upload(c->t_rx_s2, tk_rx_props_stage2(), (size_t)tk_rx_props_blocks() * 256))) return bail(rc);
-        c->rx = TkRxDev{c->t_rx_ins.as<TkRxIns>(), c->t_rx_sets.as<TkRxSet>(), c->t_rx_ranges.as<uint32_t>(), c->t_rx_s1.as<uint8_t>(),
-                        c->t_rx_s2.as<uint8_t>(), (uint32_t)H.rx.ins.size(), (uint32_t)H.rx.sets.size(), (uint32_t)H.rx.ranges.size() / 2,
-                        c->t_rx_first.as<uint32_t>(), (uint32_t)H.rx.first.size() / 8};
+        if ((rc = upload_rx(H.rx))) return bail(rc);
         c->has_rx = true;
     }
     if ((rc = upload(c->t_short, H.short_tab.data(), H.short_tab.size() * sizeof(TkShortSlot)))) return bail(rc);
@@ -498,6 +511,40 @@ static int rx_failure(const uint32_t* counters, uint64_t base) {
                                     " of the batch (nested quantifiers; the reference's fancy-regex gives up after 1 000 000 backtracks as well)");
 }
 
+// The generic engine's split of a chunk (tk_regex_kernels.h): speculate, link, resolve, then brk |= the true piece starts.  The three
+// pairs of bitmaps (rx_spec, rx_lnk, rx_gst: starts and gap chars) are zero on entry.
+static int rx_split(tk_core* c, WorkSet& w, hipStream_t s, const uint8_t* d_text, uint64_t n, uint32_t* brk, const uint32_t* ss, const uint32_t* si,
+                    const uint64_t* d_doc_off, uint64_t n_docs, uint64_t base) {
+    const uint64_t nwords = (n + 31) / 32;
+    uint32_t* counters = w.counters.as<uint32_t>();
+    const uint32_t seg_shift = c->rx_seg_shift ? c->rx_seg_shift : (n < TK_RX_SEG_SMALL_BELOW ? TK_RX_SEG_SHIFT_SMALL : TK_RX_SEG_SHIFT_LARGE);
+    const uint64_t nseg = (n + (1ull << seg_shift) - 1) >> seg_shift;
+    TRY(ensure(w.rx_exit, 3 * (nseg + 2) * 4));  // exit of every segment's chain; where the link met it; where the link left the segment
+    uint32_t *spec = w.rx_spec.as<uint32_t>(), *gst = w.rx_gst.as<uint32_t>(), *xexit = w.rx_exit.as<uint32_t>();
+    uint32_t *lnk = w.rx_lnk.as<uint32_t>(), *lmerge = xexit + nseg + 2, *lexit = xexit + 2 * (nseg + 2);
+    TRY(timed(c, s, "tk_k_rx_speculate", [&] {
+        hipLaunchKernelGGL(tk_k_rx_speculate, dim3(grid_for(nseg, 256, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, seg_shift, spec, spec + nwords + 2, xexit);
+    }));
+    const bool links = !(c->dbg & 0x20000);  // (debug bit 0x20000: no link pass -- the resolving pass matches its way from one chain to the next)
+    if (links) {
+        TRY(timed(c, s, "tk_k_rx_link", [&] {
+            hipLaunchKernelGGL(tk_k_rx_link, dim3(grid_for(nseg, 256, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, seg_shift, spec, xexit,
+                               lnk, lnk + nwords + 2, lmerge, lexit);
+        }));
+    }
+    const TkRxMaps maps{spec, spec + nwords + 2, xexit, links ? lnk : (const uint32_t*)nullptr, lnk + nwords + 2, lmerge, lexit, seg_shift};
+    TRY(timed(c, s, "tk_k_rx_resolve", [&] {
+        if (c->dbg & 0x40000)  // (debug bit 0x40000: one lane per document instead of one wavefront)
+            hipLaunchKernelGGL(tk_k_rx_resolve, dim3(grid_for(n_docs, 256, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, d_doc_off, n_docs,
+                               base, maps, gst, gst + nwords + 2, counters);
+        else
+            hipLaunchKernelGGL(tk_k_rx_resolve_wave, dim3(grid_for(n_docs, 4, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, d_doc_off, n_docs,
+                               base, maps, gst, gst + nwords + 2, counters);
+    }));
+    TRY(timed(c, s, "tk_k_rx_merge", [&] { hipLaunchKernelGGL(tk_k_rx_merge, dim3(grid_for(nwords, 256, 4096)), dim3(256), 0, s, brk, gst, nwords); }));
+    return TK_OK;
+}
+
 // ------------------------------------------------------------------------------------------
 // The production pipeline (kernels of tk_fused.h) on one chunk (n < 4 GiB bytes) of packed documents, everything device resident, in two
 // stages so that chunks can overlap: while chunk k is merged and its tokens are placed (stage_back: latency- and memory-bound kernels,
@@ -512,16 +559,43 @@ static int rx_failure(const uint32_t* counters, uint64_t base) {
 // A kernel of a few hundred workgroups that each take ~0.3 ms: it belongs to the back stage, beside the next chunk's front kernel.
 static int stage_deferred(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s) {
     const TkTables& T = c->D;
+    // A stretch without certain starts ("x'llx'll...": whether 'll ends a piece depends on everything before it) makes every deferred tile
+    // inside it walk from the stretch's start -- quadratic in its length, seconds for 10 MB.  A tile whose walk exceeds TKF_WALK_BUDGET
+    // windows gives up instead (second list); if any did, the generic engine -- linear on exactly such text: the pieces are short, every
+    // segment's guess is taken -- splits the chunk under the same pat_str, its piece starts become hard starts, and the tiles that gave up
+    // run again: every piece start is certain now.  (Pieces that are already final are what they were: a hard start at the start of a
+    // piece changes nothing, and the stock patterns match a piece the same way when the text ends behind it.)
+    const bool can_fall_back = c->has_rx_fb && job.n >= (256u << 10) && !(c->dbg & 0x400000);  // (debug bit 0x40000000: never)
     if (job.n > 0 && !job.single_piece) {
         TkFrontOut fo{w.starts.as<uint32_t>(), w.tile_np.as<uint32_t>(), w.res.as<uint32_t>(), w.tile_nmiss.as<uint32_t>(), w.tile_sum.as<uint8_t>(), w.miss.as<uint2>(),
                       w.listC.as<uint32_t>(), w.counters.as<uint32_t>()};
         uint32_t *ss = job.spec ? w.ss.as<uint32_t>() : nullptr, *si = job.spec ? w.si.as<uint32_t>() : nullptr, *docb = job.spec ? w.docb.as<uint32_t>() : nullptr;
+        const dim3 grid((uint32_t)(job.ntiles < 1024 ? job.ntiles : 1024));
+        const int pat_id = T.pat.generic() ? TK_PAT_GENERIC : T.pattern;
+        TkMissSlot* mt_arg = (c->dbg & 256) ? (TkMissSlot*)nullptr : job.mt;
+        const uint32_t* gapb = c->has_rx ? w.rx_gst.as<uint32_t>() + (job.n + 31) / 32 + 2 : (const uint32_t*)nullptr;
         TRY(timed(c, s, "tk_k_front_slow", [&] {
-            const dim3 grid((uint32_t)(job.ntiles < 1024 ? job.ntiles : 1024));
-            launch_front<true>(T.pat.generic() ? TK_PAT_GENERIC : T.pattern, job.spec, grid, s, T, job.d_text, job.n, job.base, w.brk.as<uint32_t>(), docb, ss, si, fo,
-                               (c->dbg & 256) ? (TkMissSlot*)nullptr : job.mt, (1u << job.mt_bits) - 1u, w.deferred.as<uint32_t>(),
-                               c->has_rx ? w.rx_gst.as<uint32_t>() + (job.n + 31) / 32 + 2 : (const uint32_t*)nullptr, c->dbg);
+            launch_front<true>(pat_id, job.spec, grid, s, T, job.d_text, job.n, job.base, w.brk.as<uint32_t>(), docb, ss, si, fo, mt_arg, (1u << job.mt_bits) - 1u,
+                               w.deferred.as<uint32_t>(), gapb, (c->dbg & ~TKF_DBG_SECOND) | (can_fall_back ? TKF_DBG_MAY_GIVE_UP : 0));
         }));
+        if (can_fall_back) {
+            HIPCHK(hipMemcpyAsync(w.h_counters, w.counters.p, TK_CNT_N * 4, hipMemcpyDeviceToHost, s));
+            HIPCHK(hipEventRecord(w.ev_cnt, s));
+            HIPCHK(hipEventSynchronize(w.ev_cnt));
+            if (w.h_counters[TK_CNT_DEFER2]) {
+                const uint64_t nwords = (job.n + 31) / 32;
+                for (Buf* b : {&w.rx_spec, &w.rx_gst, &w.rx_lnk}) {
+                    TRY(ensure(*b, 2 * (nwords + 2) * 4));
+                    HIPCHK(hipMemsetAsync(b->p, 0, 2 * (nwords + 2) * 4, s));
+                }
+                TRY(rx_split(c, w, s, job.d_text, job.n, w.brk.as<uint32_t>(), ss, si, job.d_doc_off, job.n_docs, job.base));
+                TRY(timed(c, s, "tk_k_front_slow", [&] {
+                    launch_front<true>(pat_id, job.spec, grid, s, T, job.d_text, job.n, job.base, w.brk.as<uint32_t>(), docb, ss, si, fo, mt_arg, (1u << job.mt_bits) - 1u,
+                                       w.deferred.as<uint32_t>() + job.ntiles + 2, gapb, (c->dbg & ~TKF_DBG_MAY_GIVE_UP) | TKF_DBG_SECOND);
+                }));
+                c->st_fallbacks += 1;
+            }
+        }
     }
     HIPCHK(hipMemcpyAsync(w.h_counters, w.counters.p, TK_CNT_N * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(w.ev_cnt, s));
@@ -631,34 +705,8 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
                                    c->spec_max_len, ss, si, brk);
             }));
         }
-        if (c->has_rx) {  // the generic engine finds the piece starts; they join the hard starts in `brk`
-            const uint32_t seg_shift = c->rx_seg_shift ? c->rx_seg_shift : (n < TK_RX_SEG_SMALL_BELOW ? TK_RX_SEG_SHIFT_SMALL : TK_RX_SEG_SHIFT_LARGE);
-            const uint64_t nseg = (n + (1ull << seg_shift) - 1) >> seg_shift;
-            TRY(ensure(w.rx_exit, 3 * (nseg + 2) * 4));  // exit of every segment's chain; where the link met it; where the link left the segment
-            uint32_t *spec = w.rx_spec.as<uint32_t>(), *gst = w.rx_gst.as<uint32_t>(), *xexit = w.rx_exit.as<uint32_t>();
-            uint32_t *lnk = w.rx_lnk.as<uint32_t>(), *lmerge = xexit + nseg + 2, *lexit = xexit + 2 * (nseg + 2);
-            TRY(timed(c, s, "tk_k_rx_speculate", [&] {
-                hipLaunchKernelGGL(tk_k_rx_speculate, dim3(grid_for(nseg, 256, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, seg_shift, spec, spec + nwords + 2, xexit);
-            }));
-            const bool links = !(c->dbg & 0x2000000);  // (debug bit 0x2000000: no link pass -- the resolving pass matches its way from one chain to the next)
-            if (links) {
-                TRY(timed(c, s, "tk_k_rx_link", [&] {
-                    hipLaunchKernelGGL(tk_k_rx_link, dim3(grid_for(nseg, 256, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, seg_shift, spec, xexit,
-                                       lnk, lnk + nwords + 2, lmerge, lexit);
-                }));
-            }
-            const TkRxMaps maps{spec, spec + nwords + 2, xexit, links ? lnk : (const uint32_t*)nullptr, lnk + nwords + 2, lmerge, lexit, seg_shift};
-            TRY(timed(c, s, "tk_k_rx_resolve", [&] {
-                if (c->dbg & 0x4000000)  // (debug bit 0x4000000: one lane per document instead of one wavefront)
-                    hipLaunchKernelGGL(tk_k_rx_resolve, dim3(grid_for(n_docs, 256, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, d_doc_off, n_docs,
-                                       base, maps, gst, gst + nwords + 2, counters);
-                else
-                    hipLaunchKernelGGL(tk_k_rx_resolve_wave, dim3(grid_for(n_docs, 4, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, d_doc_off, n_docs,
-                                       base, maps, gst, gst + nwords + 2, counters);
-            }));
-            TRY(timed(c, s, "tk_k_rx_merge", [&] { hipLaunchKernelGGL(tk_k_rx_merge, dim3(grid_for(nwords, 256, 4096)), dim3(256), 0, s, brk, gst, nwords); }));
-        }
-        TRY(ensure(w.deferred, (ntiles + 2) * 4));
+        if (c->has_rx) TRY(rx_split(c, w, s, d_text, n, brk, ss, si, d_doc_off, n_docs, base));  // the generic engine finds the piece starts; they join the hard starts in `brk`
+        TRY(ensure(w.deferred, 2 * (ntiles + 2) * 4));  // (behind the list of deferred tiles: those that gave up their walk, stage_deferred)
         uint32_t* deferred = w.deferred.as<uint32_t>();
         TkMissSlot* mt_arg = (c->dbg & 256) ? (TkMissSlot*)nullptr : job.mt;
         TRY(timed(c, s, "tk_k_front", [&] {
@@ -1862,6 +1910,7 @@ extern "C" uint64_t tk_stat(tk_core* c, const char* name) {
     if (k == "front_wgs_per_cu") return c->front_wgs;
     if (k == "compute_units") return c->n_cu;
     if (k == "chunks") return c->st_chunks;
+    if (k == "fallbacks") return c->st_fallbacks;  // chunks re-split by the generic engine since the core was made (stage_deferred)
     if (k == "host_front_us") return (uint64_t)c->host_us[0];
     if (k == "host_back_us") return (uint64_t)c->host_us[1];
     if (k == "host_back_wait_us") return (uint64_t)c->host_us[2];

@@ -40,6 +40,15 @@
 #define TKF_CONT_CAP 768       // continuation list of the scanners: deferred-tile variant (own array)
 #define TKF_CONT_CAP_FAST 768  // ... one-workgroup-per-tile variant (the list lives in the byte table's LDS, dead after phase B)
 #define TKF_SLOW_CAP 8    // pieces of one tile that leave its window
+// A deferred tile in a stretch without certain starts walks towards itself from the stretch's start, a 4 KiB window per step; every tile
+// of the stretch does: quadratic.  With TKF_DBG_MAY_GIVE_UP in `dbg` a tile gives up after TKF_WALK_BUDGET windows and goes on a second
+// list (behind the first, count in TK_CNT_DEFER2); the host then lets the generic engine split the chunk -- every piece start becomes a
+// hard start -- and runs the kernel again over that list (TKF_DBG_SECOND).  TIKTOKEN_AMD_DEBUG bit 0x20000000: a budget of zero windows
+// (tests: ordinary corpora through this path).
+#define TKF_WALK_BUDGET 32u
+#define TKF_DBG_MAY_GIVE_UP 0x8000000
+#define TKF_DBG_SECOND 0x10000000
+#define TKF_DBG_NO_BUDGET 0x20000000
 #define TKF_BATCH 960  // pieces per probe batch of the front kernel (the class lists hold 1024 entries, their packed counter 1023)
 #define TKF_CAP 4096  // piece ids per tile: pid = tile * TKF_CAP + k (a 4096-byte tile starts at most 4096 pieces)
 
@@ -541,7 +550,7 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
     // SLOW, and the variant with the piece cache: persistent, a fixed grid walks the deferred list / the tiles with the stride of the
     // grid.  Otherwise one tile per workgroup (the loop's state would cost registers the kernel does not have at eight workgroups per CU).
     constexpr bool PERSIST = SLOW || HOT;
-    const uint32_t n_items = SLOW ? out.counters[TK_CNT_DEFER] : (PERSIST ? (uint32_t)((n + TK_TILE - 1) / TK_TILE) : gridDim.x);
+    const uint32_t n_items = SLOW ? out.counters[(dbg & TKF_DBG_SECOND) ? TK_CNT_DEFER2 : TK_CNT_DEFER] : (PERSIST ? (uint32_t)((n + TK_TILE - 1) / TK_TILE) : gridDim.x);
     if (PERSIST && item >= n_items) return;
     const bool use_hot = HOT && !(dbg & 0x200000);  // (debug bit 0x200000: the piece cache is never consulted)
     uint32_t hot_probes = 0, hot_hits = 0;         // per lane; summed into the counters when the workgroup is done
@@ -817,14 +826,20 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
     };
     // The same for a piece of any length, anywhere, by the whole workgroup (uniform control flow): walks the chain from p until it ends
     // or re-enters the tile, where the lanes' scanners take over through the continuation list.
+    bool gave_up = false;  // (SLOW: the walk towards the tile was longer than TKF_WALK_BUDGET windows)
     auto coop_chain = [&](uint64_t p) {
         if constexpr (SLOW) {
             const TkWalkLds walk{w2_raw, w2_planes, w2_start, w2_hard, w2_jump};
+            uint32_t windows = 0;
             for (;;) {
                 uint64_t e = p;
                 if (fam != TK_PAT_R50K && pat.digits() && p < tile_start && (tk_class_byte_slow(&T, text, p, n, brk, coop.ss, coop.si) & 15u) == TK_C_NU)
                     e = tk_coop_skip_digit_groups(&coop, p, tile_start);  // whole three-digit groups left of the tile
                 if (e == p && p + 1024u < tile_start) {  // far left of the tile: a window of pieces per step (nothing of them lies in this tile)
+                    if ((dbg & TKF_DBG_MAY_GIVE_UP) && windows++ >= ((dbg & TKF_DBG_NO_BUDGET) ? 0u : TKF_WALK_BUDGET)) {  // (uniform: every lane counts the same)
+                        gave_up = true;
+                        return;
+                    }
                     const uint64_t t = tk_coop_window_walk(&coop, &walk, p, tile_start);
                     if (t != p) {
                         p = t;
@@ -884,6 +899,10 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
             const bool covered = stretch_uniform && class_ok && __syncthreads_and((int)here);
             if (!covered) coop_chain(p0);
         }
+    }
+    if (SLOW && gave_up) {  // on the second list: the tile runs again when the generic engine has split the chunk (tk_api.hip, stage_deferred)
+        if (tid == 0) deferred[(n + TK_TILE - 1) / TK_TILE + 2 + atomicAdd(&out.counters[TK_CNT_DEFER2], 1u)] = (uint32_t)tile;
+        continue;
     }
     // Rounds around ONE instance of the lanes' evaluation (the scanner is big: a second inlined copy spills registers).
     //   round 0: one piece per scan start, all lanes busy.  94..98 % of the pieces end at a certain start; a chain that goes on (an

@@ -32,8 +32,9 @@ struct TkBins {
 };
 
 // counters (device uint32 array)
-enum { TK_CNT_B = 0, TK_CNT_C = 1, TK_CNT_CBYTES = 2, TK_CNT_CLEVELS = 3, TK_CNT_DUP = 4, TK_CNT_COLL = 5, TK_CNT_ERR = 6, TK_CNT_DEFER = 7, TK_CNT_BIN0 = 8, TK_CNT_RXPOS = 8 + TK_NBIN + 1, TK_CNT_HOT_PROBE = 8 + TK_NBIN + 2, TK_CNT_HOT_HIT = 8 + TK_NBIN + 3, TK_CNT_N = 8 + TK_NBIN + 4 };
-// (TK_CNT_ERR: bits 1, 2 scanner lists of the front kernel; bits 4, 8 the generic pat_str engine -- tk_regex_split.h; TK_CNT_RXPOS: ~position of its first error)
+enum { TK_CNT_B = 0, TK_CNT_C = 1, TK_CNT_CBYTES = 2, TK_CNT_CLEVELS = 3, TK_CNT_DUP = 4, TK_CNT_COLL = 5, TK_CNT_ERR = 6, TK_CNT_DEFER = 7, TK_CNT_BIN0 = 8, TK_CNT_RXPOS = 8 + TK_NBIN + 1, TK_CNT_HOT_PROBE = 8 + TK_NBIN + 2, TK_CNT_HOT_HIT = 8 + TK_NBIN + 3, TK_CNT_DEFER2 = 8 + TK_NBIN + 4, TK_CNT_N = 8 + TK_NBIN + 5 };
+// (TK_CNT_DEFER2: deferred tiles that gave up their walk -- tk_fused.h, TKF_WALK_BUDGET;
+//  TK_CNT_ERR: bits 1, 2 scanner lists of the front kernel; bits 4, 8 the generic pat_str engine -- tk_regex_split.h; TK_CNT_RXPOS: ~position of its first error)
 
 #define TK_MT_BITS 22   // most slots of the in-call miss table (tk_fused.h); sized by the chunk
 #define TK_MT_PROBES 8

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void tk_k_rx_link(TkRxDev R, const uint8_t* __
         tk_rx_link_lane(P, t, k, seg_shift, spec, xexit, lnk, lgap, lmerge, lexit);
 }
 
-// one lane per document (debug bit 0x4000000; the CPU tests run this form lane by lane)
+// one lane per document (debug bit 0x40000; the CPU tests run this form lane by lane)
 __global__ __launch_bounds__(256) void tk_k_rx_resolve(TkRxDev R, const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ brk,
                                                        const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si,
                                                        const uint64_t* __restrict__ doc_off, uint64_t n_docs, uint64_t base, TkRxMaps M,

@@ -27,11 +27,13 @@
 #pragma once
 #include "tk_regex.h"
 
-// bytes per speculative segment = 1 << seg_shift (a multiple of 32: a segment owns its words of the bitmap): 256 for chunks that would
-// not fill the GPU with 1 KiB segments, 1024 otherwise (fewer, longer chains: less is matched twice around the segment boundaries)
-#define TK_RX_SEG_SHIFT_SMALL 8u
+// bytes per speculative segment = 1 << seg_shift (a multiple of 32: a segment owns its words of the bitmap).  Measured with the o200k
+// pat_str on 256 MiB of the bench corpus (profiles/r03_generic_engine.txt), speculative pass: 1 KiB segments 24.2 ms, 512 B 20.8, 256 B
+// 17.8 / 14.9 (with the link pass), 128 B 13.6, 64 B 13.5 -- more lanes beat the pieces that are matched twice around the segment
+// boundaries; 128 bytes for every chunk (the CPU tests also run the LARGE form).
+#define TK_RX_SEG_SHIFT_SMALL 7u
 #define TK_RX_SEG_SHIFT_LARGE 10u
-#define TK_RX_SEG_SMALL_BELOW (4ull << 30)  // chunk bytes: every chunk (measured at 256 MiB, o200k pat_str: 17.8 ms with 256-byte segments, 24.2 with 1 KiB -- four times the lanes beat the pieces matched twice)
+#define TK_RX_SEG_SMALL_BELOW (4ull << 30)  // chunk bytes below which the SMALL segments are used: always
 #define TK_RX_AHEAD 16384u  // bytes a speculative match may look beyond its segment
 #define TK_RX_UNKNOWN 0xFFFFFFFFu
 #define TK_RX_ERR_GAP 4u       // bits of the chunk's error word
@@ -285,7 +287,7 @@ TK_HD uint32_t tk_rx_resolve_lane(const TkRxProg& P, TkRxText t, const TkRxMaps&
 // The same by a group of TK_RX_WAVE lanes that look at consecutive segments at once: lane j plans segment k0 + j as if the chain entered
 // it at xexit[k0 + j - 1] (lane 0: at p); the longest prefix of lanes whose plans hold and whose exits are what the next lane assumed is
 // taken in one go, and the chain continues behind it.  Where lane 0 has no plan the group takes one step of the serial form.  The host
-// form runs the lanes one after the other (tests/hostsim); the device form (tk_regex_kernels.h) ballots.
+// form runs the lanes one after the other (the CPU tests); the device form (tk_regex_kernels.h) ballots.
 #define TK_RX_WAVE 64u
 template <class Or>
 TK_HD uint32_t tk_rx_resolve_group_host(const TkRxProg& P, TkRxText t, const TkRxMaps& M, uint32_t b, uint32_t e, Or&& orbits, uint32_t* err_pos) {
