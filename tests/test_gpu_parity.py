@@ -333,7 +333,7 @@ def test_ten_megabytes_without_a_certain_start_take_the_generic_way():
         ts.append(time.perf_counter() - t0)
     assert np.array_equal(got, want)
     print(f"10 MB of x'll: {min(ts) * 1e3:.1f} ms")
-    assert min(ts) < 0.12, ts
+    assert min(ts) < 0.06, ts  # (measured 45 ms: profiles/r03_long_runs.txt has the 1 MB cases)
     # documents around it, special tokens inside it, and a second stretch in a later document
     docs = [b"plain text before. ", ("x'll" * 300_000).encode(), b"", ("y'd" * 200_000 + "<|endoftext|>" + "z'Re" * 100_000).encode(), b"and after"]
     blob, off = h.pack(docs)

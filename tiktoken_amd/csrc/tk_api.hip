@@ -1493,8 +1493,10 @@ extern "C" int tk_decode_batch(tk_core* c, const uint32_t* tokens, const uint64_
     HIPCHK(hipMemcpyAsync(total, h_tot, 16, hipMemcpyHostToDevice, s));
     if (n) {
         HIPCHK(hipMemcpyAsync(c->d_tok.p, tokens, n * 4, hipMemcpyHostToDevice, s));
-        hipLaunchKernelGGL(tk_k_dec_len, dim3((uint32_t)nb), dim3(256), 0, s, c->d_tok.as<uint32_t>(), n, c->t_dec.as<uint2>(), c->n_dec,
-                           c->d_lens.as<uint32_t>(), c->d_bsum.as<unsigned long long>(), total + 1);
+        TRY(timed(c, s, "tk_k_dec_len", [&] {
+            hipLaunchKernelGGL(tk_k_dec_len, dim3((uint32_t)nb), dim3(256), 0, s, c->d_tok.as<uint32_t>(), n, c->t_dec.as<uint2>(), c->n_dec,
+                               c->d_lens.as<uint32_t>(), c->d_bsum.as<unsigned long long>(), total + 1);
+        }));
         hipLaunchKernelGGL(tk_k_dec_scan64, dim3(1), dim3(1024), 0, s, c->d_bsum.as<unsigned long long>(), nb, total);
     }
     HIPCHK(hipMemcpyAsync(h_tot, total, 16, hipMemcpyDeviceToHost, s));
@@ -1505,9 +1507,11 @@ extern "C" int tk_decode_batch(tk_core* c, const uint32_t* tokens, const uint64_
     uint64_t* d_tok_off = c->d_boff.as<uint64_t>();
     uint64_t* d_byte_off = d_tok_off + n_docs + 1;
     if (n) {
-        hipLaunchKernelGGL(tk_k_dec_copy, dim3((uint32_t)nb), dim3(256), 0, s, c->d_tok.as<uint32_t>(), n, c->t_dec.as<uint2>(), c->d_lens.as<uint32_t>(),
-                           c->d_bsum.as<unsigned long long>(), c->D.tok_bytes, c->D.spec_bytes, c->d_bytes.as<uint8_t>(),
-                           c->d_tboff.as<unsigned long long>());
+        TRY(timed(c, s, "tk_k_dec_copy", [&] {
+            hipLaunchKernelGGL(tk_k_dec_copy, dim3((uint32_t)nb), dim3(256), 0, s, c->d_tok.as<uint32_t>(), n, c->t_dec.as<uint2>(), c->d_lens.as<uint32_t>(),
+                               c->d_bsum.as<unsigned long long>(), c->D.tok_bytes, c->D.spec_bytes, c->d_bytes.as<uint8_t>(),
+                               c->d_tboff.as<unsigned long long>());
+        }));
     }
     uint8_t* host = (uint8_t*)malloc(nbytes ? nbytes : 1);
     if (!host) return fail(TK_RUNTIME_ERROR, "out of host memory");
@@ -1529,7 +1533,7 @@ extern "C" int tk_decode_batch(tk_core* c, const uint32_t* tokens, const uint64_
     }
     *bytes_out = host;
     *n_bytes_out = nbytes;
-    return TK_OK;
+    return drain_events(c);
 }
 
 // ------------------------------------------------------------------------------------------

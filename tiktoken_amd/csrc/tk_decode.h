@@ -8,6 +8,7 @@
 // Included by tk_api.hip only.
 #pragma once
 #include "tk_kernels.h"
+#include "tk_device.h"
 
 #define TK_DEC_SPEC 0x80000000u  // entry.x bit: the bytes live in the special-token blob
 #define TK_DEC_BLOCK 2048        // tokens per workgroup of the scan passes (256 threads x 8)
@@ -68,7 +69,10 @@ __global__ __launch_bounds__(1024) void tk_k_dec_scan64(unsigned long long* __re
     if (threadIdx.x == 0) total_out[0] = carry_sh;
 }
 
-// byte offset of every token: workgroup base + local exclusive scan; then the copy
+// byte offset of every token: workgroup base + local exclusive scan; then the copy.  A lane owns eight consecutive tokens, so its bytes
+// are one contiguous stretch of the output: they stream through a 64-bit register aligned with the destination -- one aligned 8-byte
+// store per eight bytes (the first and the last word of the stretch, shared with the neighbours, go out byte by byte), sources read as
+// aligned words and shifted (tk_load8: the blobs are readable 16 bytes past their ends).
 __global__ __launch_bounds__(256) void tk_k_dec_copy(const uint32_t* __restrict__ tokens, uint64_t n, const uint2* __restrict__ dec,
                                                      const uint32_t* __restrict__ lens, const unsigned long long* __restrict__ bbase,
                                                      const uint8_t* __restrict__ tok_bytes, const uint8_t* __restrict__ spec_bytes,
@@ -84,17 +88,46 @@ __global__ __launch_bounds__(256) void tk_k_dec_copy(const uint32_t* __restrict_
     uint32_t tot;
     const uint32_t ex = tk_block_exscan_256(mine, &tot, sh);
     unsigned long long at = bbase[blockIdx.x] + ex;
+    // the stream: `acc` holds the bytes of the aligned word at `word` from byte `fill` on (bytes below `first_lo` of the first word are
+    // a neighbour's)
+    unsigned long long word = at & ~7ull;
+    const uint32_t first_lo = (uint32_t)(at & 7ull);
+    uint32_t fill = first_lo;
+    uint64_t acc = 0;
+    bool first = true;
+    auto flush = [&](uint32_t upto /* bytes of the word that are valid: fill */) {
+        if (!first && upto == 8u) {
+            *(uint64_t*)(out + word) = acc;
+        } else {
+            for (uint32_t b = first ? first_lo : 0u; b < upto; ++b) out[word + b] = (uint8_t)(acc >> (8u * b));
+        }
+        first = false;
+    };
 #pragma unroll
     for (int j = 0; j < 8; ++j) {
         const uint64_t i = i0 + j;
         if (i < n) {
             if (tok_byte_off) tok_byte_off[i] = at;
             const uint2 e = dec[tokens[i]];
-            const uint8_t* src = ((e.x & TK_DEC_SPEC) ? spec_bytes : tok_bytes) + (e.x & ~TK_DEC_SPEC);
-            for (uint32_t b = 0; b < len[j]; ++b) out[at + b] = src[b];
+            const uint8_t* src = ((e.x & TK_DEC_SPEC) ? spec_bytes : tok_bytes);
+            const uint64_t so = e.x & ~TK_DEC_SPEC;
+            for (uint32_t b = 0; b < len[j]; b += 8u) {
+                const uint32_t nb = len[j] - b < 8u ? len[j] - b : 8u;
+                const uint64_t w = tk_mask_low_bytes(tk_load8(src, so + b), nb);
+                acc |= w << (8u * fill);
+                if (fill + nb >= 8u) {
+                    flush(8u);
+                    acc = fill ? (w >> (8u * (8u - fill))) : 0ull;
+                    word += 8ull;
+                    fill = fill + nb - 8u;
+                } else {
+                    fill += nb;
+                }
+            }
             at += len[j];
         }
     }
+    if (fill > (first ? first_lo : 0u)) flush(fill);
 }
 
 // byte_off[d] = byte offset of the first token of document d (tok_off: n_docs + 1 token offsets, non-decreasing)
