@@ -366,7 +366,25 @@ def main():
         host_path["t2_tokens"] = int(len(h_tok))
         if parity is not None:  # (g_toks / g_tok_off: the device-resident result that was compared with the oracle above)
             host_path["t2_identical_to_checked_result"] = bool(np.array_equal(h_off, g_tok_off) and np.array_equal(h_tok, g_toks))
-        del h_tok, h_off
+        # decode (Encoding.decode_batch is one GPU call): token ids of the first 256 MiB of text in host memory -> bytes in host
+        # memory (PCIe both ways inside the call), compared with the text they came from; kernel times from one more, profiled call
+        ndd = max(int(np.searchsorted(doc_off, min(nbytes, 256 << 20), side="right")) - 1, 1)
+        d_tok, d_off = h_tok[: int(h_off[ndd])], h_off[: ndd + 1]
+        core.decode_batch_packed(d_tok[: 1 << 20], np.array([0, min(len(d_tok), 1 << 20)], np.uint64))
+        t0 = time.perf_counter()
+        d_bytes, d_boff = core.decode_batch_packed(d_tok, d_off)
+        dtd = time.perf_counter() - t0
+        core.set_profiling(True)
+        core.reset_kernel_ms()
+        core.decode_batch_packed(d_tok, d_off)
+        core.set_profiling(False)
+        host_path["decode_gbps"] = round(len(d_bytes) / dtd / 1e9, 3)
+        host_path["decode_ms"] = round(dtd * 1e3, 2)
+        host_path["decode_kernels_ms"] = {k: round(core.kernel_ms(k)[0], 4) for k in ("tk_k_dec_len", "tk_k_dec_copy")}
+        host_path["decode_what"] = (f"tk_decode_batch: {len(d_tok)} token ids of the first {ndd} documents in host memory -> {len(d_bytes)} bytes + offsets in host "
+                                    "memory (PCIe inclusive), one run; GB/s of decoded text")
+        host_path["decode_identical_to_the_text"] = bool(d_bytes == blob[: int(doc_off[ndd])].tobytes() and np.array_equal(d_boff, doc_off[: ndd + 1]))
+        del h_tok, h_off, d_tok, d_off, d_bytes
         nd3 = max(int(np.searchsorted(doc_off, min(nbytes, args.t3_sample_mib << 20), side="right")) - 1, 1)
         sb3 = int(doc_off[nd3])
         raw = blob[:sb3].tobytes()
@@ -426,7 +444,7 @@ def main():
         print(json.dumps(line), flush=True)
         hf = (cpu or {}).get("rust_cpu_tokenizer_for_context") or {}
         if parity is False or hf.get("same_ids_as_oracle_on_a_sample_of_documents") is False or \
-                (host_path or {}).get("t2_identical_to_checked_result") is False:
+                (host_path or {}).get("t2_identical_to_checked_result") is False or (host_path or {}).get("decode_identical_to_the_text") is False:
             print("bench: a parity check failed (see the line above)", file=sys.stderr)
             sys.exit(3)
     if dist:

@@ -25,6 +25,12 @@ if TYPE_CHECKING:
 _SURROGATE_FIX = ("utf-16", "surrogatepass", "utf-16", "replace")
 
 
+try:  # str / list marshalling of the batch entry points in C (host only; `make -C tiktoken_amd/csrc marshal`)
+    from . import _tk_marshal as _marshal
+except ImportError:  # pragma: no cover  -- not built: the Python forms in Encoding._pack / _unpack do the same
+    _marshal = None
+
+
 def _repair_surrogates(text: str) -> str:
     # same repair as core.py:79,135: join surrogate pairs, replace lone ones with U+FFFD
     return text.encode(_SURROGATE_FIX[0], _SURROGATE_FIX[1]).decode(_SURROGATE_FIX[2], _SURROGATE_FIX[3])
@@ -117,6 +123,11 @@ class Encoding:
 
     @staticmethod
     def _pack(texts: Sequence[str]):
+        """(UTF-8 of the texts back to back as uint8, uint64 offsets).  The native marshaller (csrc/tk_pymarshal.c) does it in two passes over
+        the str objects; the Python form below is what it replaces (and what runs where the extension has not been built)."""
+        if _marshal is not None:
+            blob, off = _marshal.pack(texts if isinstance(texts, (list, tuple)) else list(texts))
+            return np.frombuffer(blob, dtype=np.uint8), np.frombuffer(off, dtype=np.uint64)
         chunks = [_utf8(t) for t in texts]
         off = np.zeros(len(chunks) + 1, dtype=np.uint64)
         if chunks:
@@ -126,6 +137,8 @@ class Encoding:
 
     @staticmethod
     def _unpack(tokens: np.ndarray, tok_off: np.ndarray) -> list[list[int]]:
+        if _marshal is not None:  # one C loop builds the lists (src/py.rs:29-32 does the same from a Vec<Vec<Rank>>)
+            return _marshal.unpack(np.ascontiguousarray(tokens, dtype=np.uint32), np.ascontiguousarray(tok_off, dtype=np.uint64))
         # one tolist per document: the ints are created once, straight into their list (a flat list sliced afterwards costs twice)
         bounds = tok_off.tolist()
         return [tokens[a:b].tolist() for a, b in zip(bounds[:-1], bounds[1:])]
