@@ -372,18 +372,18 @@ def main():
         d_tok, d_off = h_tok[: int(h_off[ndd])], h_off[: ndd + 1]
         core.decode_batch_packed(d_tok[: 1 << 20], np.array([0, min(len(d_tok), 1 << 20)], np.uint64))
         t0 = time.perf_counter()
-        d_bytes, d_boff = core.decode_batch_packed(d_tok, d_off)
+        d_bytes, d_boff = core.decode_batch_packed(d_tok, d_off, as_array=True)  # (a uint8 view of the library's page-locked result buffer)
         dtd = time.perf_counter() - t0
         core.set_profiling(True)
         core.reset_kernel_ms()
-        core.decode_batch_packed(d_tok, d_off)
+        core.decode_batch_packed(d_tok, d_off, as_array=True)
         core.set_profiling(False)
         host_path["decode_gbps"] = round(len(d_bytes) / dtd / 1e9, 3)
         host_path["decode_ms"] = round(dtd * 1e3, 2)
         host_path["decode_kernels_ms"] = {k: round(core.kernel_ms(k)[0], 4) for k in ("tk_k_dec_len", "tk_k_dec_copy")}
         host_path["decode_what"] = (f"tk_decode_batch: {len(d_tok)} token ids of the first {ndd} documents in host memory -> {len(d_bytes)} bytes + offsets in host "
                                     "memory (PCIe inclusive), one run; GB/s of decoded text")
-        host_path["decode_identical_to_the_text"] = bool(d_bytes == blob[: int(doc_off[ndd])].tobytes() and np.array_equal(d_boff, doc_off[: ndd + 1]))
+        host_path["decode_identical_to_the_text"] = bool(np.array_equal(d_bytes, blob[: int(doc_off[ndd])]) and np.array_equal(d_boff, doc_off[: ndd + 1]))
         del h_tok, h_off, d_tok, d_off, d_bytes
         nd3 = max(int(np.searchsorted(doc_off, min(nbytes, args.t3_sample_mib << 20), side="right")) - 1, 1)
         sb3 = int(doc_off[nd3])

@@ -34,11 +34,13 @@ int tk_device_count(void);
  * specials likewise (UTF-8).  pat_str: the split regex, compiled once here (Regex::new, src/lib.rs:623).  The three families of
  * tiktoken_ext/openai_public.py:12-14,89,104-114 (stock strings, their other spellings, variations of the contraction list, digit
  * group, suffix set and white-space rules) run on hand-written scanners; any other pattern in the syntax fancy-regex shares with
- * Python `regex` -- classes (with && and --), \p{General_Category}, \p{Script}, alternation, groups, (?i: ), greedy / lazy / possessive quantifiers, atomic groups,
- * look-ahead, look-behind of fixed length, \b, ^ $ -- is compiled to a program for the generic GPU engine (tk_regex.cpp).  Refused with
- * TK_UNSUPPORTED and the reason: look-behind of variable length, back-references, binary properties, a pattern that can match the empty string.  A pattern that leaves
- * text unmatched (the reference drops such text silently) makes the encode call fail with TK_VALUE_ERROR and the byte offset.
- * Text must be valid UTF-8 (the reference's boundary is &str); other bytes never crash but their split is unspecified.
+ * Python `regex` -- classes (with && and --, POSIX classes), \p{General_Category}, \p{Script}, the binary properties of the UCD, alternation,
+ * groups, (?i: ), greedy / lazy / possessive quantifiers, atomic groups, look-ahead, look-behind of fixed length, \b, ^ $ -- is compiled
+ * to a program for the generic GPU engine (tk_regex.cpp).  Refused with TK_UNSUPPORTED and the reason: look-behind of variable length,
+ * back-references (fancy-regex has them; they stay refused here), a pattern that can match the empty string.  Text a pattern does not
+ * match yields no tokens, as the reference's find_iter skips it (src/lib.rs:365,405).
+ * Text must be valid UTF-8 (the reference's boundary is &str); other bytes never crash but their split is unspecified: a caller that
+ * cannot vouch for its bytes checks them with tk_validate_utf8 first.
  * Duplicate ranks -> TK_VALUE_ERROR (the reference panics, src/lib.rs:636-641).  device = HIP device ordinal. */
 int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uint32_t* ranks_ids, uint64_t n_ranks,
               const uint8_t* spec_blob, const uint64_t* spec_off, const uint32_t* spec_ids, uint64_t n_spec,
@@ -134,6 +136,11 @@ uint64_t tk_group_stat(tk_group* group, const char* name);
  * Replaces the per-line Python loop of tiktoken/load.py:159-171.  Release the three arrays with tk_free.  TK_VALUE_ERROR with
  * "Error parsing line N ..." on malformed input. */
 int tk_parse_tiktoken_bpe(const uint8_t* text, uint64_t len, uint8_t** blob_out, uint64_t** off_out, uint32_t** ids_out, uint64_t* n_out);
+
+/* The reference's text boundary is &str -- valid UTF-8 by construction (PyO3 extracts it, src/py.rs:29).  A C caller has bytes: 0 if
+ * utf8[0..len) is well-formed UTF-8 (no overlong forms, no surrogates, nothing above U+10FFFF, no truncated char), else TK_VALUE_ERROR
+ * with *bad_pos (may be null) = offset of the first byte that is not part of a well-formed char.  Host code; a few GB/s. */
+int tk_validate_utf8(const uint8_t* utf8, uint64_t len, uint64_t* bad_pos);
 
 void tk_free(void* p);
 

@@ -75,3 +75,36 @@ def test_product_never_imports_the_oracle():
         if f.endswith(".py") and "oracle" in open(os.path.join(ROOT, "tiktoken_ext", f)).read():
             bad.append(f)
     assert not bad, bad
+
+
+def test_validate_utf8_agrees_with_pythons_decoder():
+    """tk_validate_utf8: what a C caller uses in place of the reference's &str boundary (src/py.rs:29).  Host code: runs without a GPU."""
+    import ctypes
+    import random
+
+    from tiktoken_amd import _lib
+
+    L = _lib.lib()
+    rng = random.Random(8)
+
+    def check(b: bytes):
+        buf = (ctypes.c_uint8 * max(len(b), 1)).from_buffer_copy(b or b"\0")
+        pos = ctypes.c_uint64(0xFFFFFFFF)
+        rc = L.tk_validate_utf8(buf, len(b), ctypes.byref(pos))
+        try:
+            b.decode("utf-8")
+            assert rc == 0, b
+        except UnicodeDecodeError as e:
+            assert rc != 0 and pos.value == e.start, (b, pos.value, e.start)
+
+    for b in (b"", b"plain ascii, more than eight bytes of it", "żółć 中文 😀 é".encode(), b"\x80", b"\xc0\xaf", b"\xc1\xbf", b"\xe0\x9f\xbf", b"\xed\xa0\x80",
+              b"\xed\x9f\xbf", b"\xf0\x8f\xbf\xbf", b"\xf4\x8f\xbf\xbf", b"\xf4\x90\x80\x80", b"\xf5\x80\x80\x80", b"ab\xe4\xb8", b"abcdefgh\xe4\xb8\xadx\xff", b"\xe4\xb8\xad" * 5 + b"\xe4"):
+        check(b)
+    units = [b"a", b"hello wor", "é".encode(), "中".encode(), "😀".encode(), b"\x80", b"\xbf", b"\xc2", b"\xe0\xa0", b"\xed\xa0\x80", b"\xf0\x90\x80", b"\xf4\x90", b"\xff", b"\xc0\x80"]
+    for _ in range(3000):
+        check(b"".join(rng.choice(units) for _ in range(rng.randrange(0, 12))))
+    for _ in range(2000):
+        check(bytes(rng.randrange(256) for _ in range(rng.randrange(0, 24))))
+    big = ("The quick brown fox. " * 1000 + "中文").encode() * 20
+    check(big)
+    check(big[:-1])

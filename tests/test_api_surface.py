@@ -158,42 +158,3 @@ def test_rank_table_fills_itself_on_first_use():
     dup = vocab_io.parse_tiktoken_bpe(b"YQ== 0\nYg== 1\nYQ== 2\n")  # a token listed twice: the dict keeps the later rank
     assert dict(dup) == {b"a": 2, b"b": 1} and dup.packed is None
 
-
-def test_native_marshalling_equals_the_python_forms():
-    """tiktoken_amd/_tk_marshal (csrc/tk_pymarshal.c): list[str] -> packed UTF-8 + offsets and packed ids + offsets -> list[list[int]], the two
-    ends of encode_ordinary_batch / encode_batch (reference src/py.rs:29-49), against str.encode + the reference's surrogate repair
-    (core.py:79,135) and numpy's tolist."""
-    import random
-
-    from tiktoken_amd import core
-
-    m = core._marshal
-    assert m is not None, "run `make -C tiktoken_amd/csrc marshal` (or __graft_entry__.build())"
-    rng = random.Random(11)
-    pool = [lambda: chr(rng.randrange(0, 0x80)), lambda: chr(rng.randrange(0x80, 0x100)), lambda: chr(rng.randrange(0x100, 0x800)),
-            lambda: chr(rng.randrange(0x800, 0xD800)), lambda: chr(rng.randrange(0xE000, 0x10000)), lambda: chr(rng.randrange(0x10000, 0x110000)),
-            lambda: chr(rng.randrange(0xD800, 0xDC00)), lambda: chr(rng.randrange(0xDC00, 0xE000)),
-            lambda: chr(rng.randrange(0xD800, 0xDC00)) + chr(rng.randrange(0xDC00, 0xE000))]
-    texts = []
-    for _ in range(4000):
-        kinds = rng.choice([pool[:1], pool[:2], pool[:5], pool])
-        texts.append("".join(rng.choice(kinds)() for _ in range(rng.choice([0, 1, 2, 7, 8, 9, 33, 200]))))
-    blob, off = m.pack(texts)
-    want = [core._utf8(t) for t in texts]
-    assert blob == b"".join(want)
-    assert np.frombuffer(off, np.uint64).tolist() == [0] + list(np.cumsum([len(w) for w in want]))
-    assert m.pack([]) == (b"", bytes(8)) and m.pack(("a", "é"))[0] == "aé".encode()
-    with pytest.raises(TypeError):
-        m.pack(["a", b"b"])
-    b2, o2 = core.Encoding._pack(texts)
-    assert b2.tobytes() == blob and o2.dtype == np.uint64 and len(o2) == len(texts) + 1
-    toks = np.random.default_rng(3).integers(0, 2 ** 32, 50_000, dtype=np.uint64).astype(np.uint32)
-    cuts = np.sort(np.random.default_rng(4).integers(0, 50_001, 300))
-    offs = np.concatenate([[0], cuts, [50_000]]).astype(np.uint64)
-    got = m.unpack(toks, offs)
-    bounds = offs.tolist()
-    assert got == [toks[a:b].tolist() for a, b in zip(bounds[:-1], bounds[1:])]
-    assert m.unpack(np.zeros(0, np.uint32), np.zeros(1, np.uint64)) == []
-    for bad in (np.array([0, 5, 3], np.uint64), np.array([0, 50_001], np.uint64)):
-        with pytest.raises(ValueError):
-            m.unpack(toks, bad)

@@ -236,3 +236,55 @@ def test_golden_vectors_of_generic_patterns():
             assert core.encode_ordinary(c["text"].decode()) == c["tokens"], (p["pat_str"], c["text"])
         n += len(want)
     assert n > 100_000
+
+
+def generated_patterns_on_the_device(seed: int, n_patterns: int, with_tokens_every: int = 4):
+    """Random patterns over the whole supported syntax (the generator of the CPU test, tests/test_regex_engine.py::_gen_pattern) compiled
+    and run ON THE DEVICE: split and gap chars of a batch of short texts against Python `regex`, tokens of every few patterns against the
+    oracle's byte_pair_encode.  Returns (patterns run, patterns the device gave up on loudly)."""
+    from test_regex_engine import _gen_pattern
+
+    rng = random.Random(seed)
+    alphabet = list("abcxABCX12 \n\t'.,sSkK") + ["ſ", "K", "é", "中", "É", "٣", "\r\n", "  ", "ab", "'s"]
+    texts = ["".join(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 2, 4, 8, 20, 60, 400]))) for _ in range(150)]
+    texts += ["a" * 300, " " * 200 + "x", "ab" * 20, "x1" * 25 + "\n", "'s" * 12]
+    C = h.c_oracle_for(NAME)
+    ran = gave_up = 0
+    while ran + gave_up < n_patterns:
+        eng, py = _gen_pattern(rng)
+        if "(?i:" in eng and r"[^a\s]" in eng:  # (a scoping bug of `regex` 2026.7.19: see the CPU test)
+            continue
+        pyc = regex.compile(py)
+        try:
+            core = make_core(eng, {})
+        except ValueError:
+            continue  # refused by the compiler, with a reason (the CPU test checks the reasons)
+        good, want, wgap, base = [], [], [], 0
+        for t in texts:
+            try:
+                st, gp = py_starts_gaps(pyc, t, timeout=0.25)
+            except (TimeoutError, LookupError):
+                continue
+            good.append(t)
+            want += [base + s for s in st]
+            wgap += [base + s for s in gp]
+            base += len(t.encode())
+        blob, off = h.pack([t.encode() for t in good])
+        try:
+            got = core.pretokenize_packed(blob, off)
+        except ValueError as e:  # deep backtracking in a repeated group, or more of it than the budget: loud, as in the reference
+            assert "possessive" in str(e) or "backtrack limit" in str(e), (eng, str(e))
+            gave_up += 1
+            continue
+        assert got.tolist() == want + [len(blob)] and core.last_gaps.tolist() == wgap, (eng, py)
+        if ran % with_tokens_every == 0:
+            rt, ro = oracle_tokens(pyc, good, C, {})
+            toks, toff = core.encode_batch_packed(blob, off)
+            assert np.array_equal(toff, ro) and np.array_equal(toks, rt), (eng, py)
+        ran += 1
+    return ran, gave_up
+
+
+def test_generated_patterns_on_the_device():
+    ran, gave_up = generated_patterns_on_the_device(20260923, 40)
+    assert ran >= 30, (ran, gave_up)

@@ -90,6 +90,8 @@ def lib() -> ctypes.CDLL:
         L.tk_group_stat.argtypes = [vp, ctypes.c_char_p]
         L.tk_parse_tiktoken_bpe.restype = i32
         L.tk_parse_tiktoken_bpe.argtypes = [vp, u64, P(vp), P(vp), P(vp), P(u64)]
+        L.tk_validate_utf8.restype = i32
+        L.tk_validate_utf8.argtypes = [vp, u64, P(u64)]
         L.tk_free.argtypes = [vp]
         L.tk_set_profiling.argtypes = [vp, i32]
         L.tk_reset_kernel_ms.argtypes = [vp]

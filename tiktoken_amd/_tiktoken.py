@@ -33,9 +33,9 @@ class _OwnedBuffer:
     place, and it goes back to the library (tk_free) when the last view is gone.  The counterpart of the reference's TiktokenBuffer
     (src/py.rs:186-249)."""
 
-    def __init__(self, ptr: int, n: int):
+    def __init__(self, ptr: int, n: int, typestr: str = "<u4"):
         self._ptr = ptr
-        self.__array_interface__ = {"shape": (n,), "typestr": "<u4", "data": (ptr, True), "version": 3}
+        self.__array_interface__ = {"shape": (n,), "typestr": typestr, "data": (ptr, True), "version": 3}
 
     def __del__(self):
         ptr, self._ptr = getattr(self, "_ptr", None), None
@@ -66,6 +66,14 @@ def _check_packed(blob: np.ndarray, doc_off: np.ndarray) -> None:
         raise ValueError("doc_off[0] must be 0 and doc_off[-1] must equal len(blob)")
     if len(doc_off) > 1 and bool(np.any(doc_off[1:] < doc_off[:-1])):
         raise ValueError("doc_off must be non-decreasing")
+
+
+def invalid_utf8_at(data: bytes) -> int | None:
+    """Offset of the first byte of `data` that is not part of a well-formed UTF-8 char, or None (tk_validate_utf8: for callers that hand the
+    C ABI bytes they cannot vouch for -- a Python str is valid by construction, as the reference's &str is)."""
+    buf = np.frombuffer(data, dtype=np.uint8) if len(data) else np.zeros(1, dtype=np.uint8)
+    pos = ctypes.c_uint64()
+    return None if _lib.lib().tk_validate_utf8(buf.ctypes.data, len(data), ctypes.byref(pos)) == 0 else int(pos.value)
 
 
 def default_devices() -> list[int]:
@@ -400,8 +408,9 @@ class CoreBPE:
         self._L.tk_free(out)
         return data
 
-    def decode_batch_packed(self, tokens: np.ndarray, tok_off: np.ndarray) -> tuple[bytes, np.ndarray]:
-        """One GPU call for a packed batch: (all bytes back to back, byte_off uint64[n_docs + 1])  -- tk_decode_batch."""
+    def decode_batch_packed(self, tokens: np.ndarray, tok_off: np.ndarray, as_array: bool = False):
+        """One GPU call for a packed batch: (all bytes back to back, byte_off uint64[n_docs + 1])  -- tk_decode_batch.
+        as_array: the bytes as a read-only uint8 array over the library's (page-locked) result buffer instead of a `bytes` copy."""
         tokens = np.ascontiguousarray(tokens, dtype=np.uint32)
         tok_off = np.ascontiguousarray(tok_off, dtype=np.uint64)
         if tok_off.ndim != 1 or len(tok_off) < 1 or int(tok_off[-1]) != len(tokens):
@@ -412,9 +421,11 @@ class CoreBPE:
         rc = self._L.tk_decode_batch(self._h, src.ctypes.data, tok_off.ctypes.data, len(tok_off) - 1, ctypes.byref(out), ctypes.byref(n),
                                      byte_off.ctypes.data)
         _lib.raise_for(rc)
+        if as_array and n.value >= (1 << 16):
+            return np.asarray(_OwnedBuffer(out.value, n.value, "|u1")), byte_off
         data = ctypes.string_at(out, n.value)
         self._L.tk_free(out)
-        return data, byte_off
+        return (np.frombuffer(data, dtype=np.uint8) if as_array else data), byte_off
 
     def decode_single_token_bytes(self, token: int) -> bytes:
         if not 0 <= token <= 0xFFFFFFFF:

@@ -25,12 +25,6 @@ if TYPE_CHECKING:
 _SURROGATE_FIX = ("utf-16", "surrogatepass", "utf-16", "replace")
 
 
-try:  # str / list marshalling of the batch entry points in C (host only; `make -C tiktoken_amd/csrc marshal`)
-    from . import _tk_marshal as _marshal
-except ImportError:  # pragma: no cover  -- not built: the Python forms in Encoding._pack / _unpack do the same
-    _marshal = None
-
-
 def _repair_surrogates(text: str) -> str:
     # same repair as core.py:79,135: join surrogate pairs, replace lone ones with U+FFFD
     return text.encode(_SURROGATE_FIX[0], _SURROGATE_FIX[1]).decode(_SURROGATE_FIX[2], _SURROGATE_FIX[3])
@@ -123,11 +117,6 @@ class Encoding:
 
     @staticmethod
     def _pack(texts: Sequence[str]):
-        """(UTF-8 of the texts back to back as uint8, uint64 offsets).  The native marshaller (csrc/tk_pymarshal.c) does it in two passes over
-        the str objects; the Python form below is what it replaces (and what runs where the extension has not been built)."""
-        if _marshal is not None:
-            blob, off = _marshal.pack(texts if isinstance(texts, (list, tuple)) else list(texts))
-            return np.frombuffer(blob, dtype=np.uint8), np.frombuffer(off, dtype=np.uint64)
         chunks = [_utf8(t) for t in texts]
         off = np.zeros(len(chunks) + 1, dtype=np.uint64)
         if chunks:
@@ -137,8 +126,6 @@ class Encoding:
 
     @staticmethod
     def _unpack(tokens: np.ndarray, tok_off: np.ndarray) -> list[list[int]]:
-        if _marshal is not None:  # one C loop builds the lists (src/py.rs:29-32 does the same from a Vec<Vec<Rank>>)
-            return _marshal.unpack(np.ascontiguousarray(tokens, dtype=np.uint32), np.ascontiguousarray(tok_off, dtype=np.uint64))
         # one tolist per document: the ints are created once, straight into their list (a flat list sliced afterwards costs twice)
         bounds = tok_off.tolist()
         return [tokens[a:b].tolist() for a, b in zip(bounds[:-1], bounds[1:])]
@@ -211,10 +198,15 @@ class Encoding:
 
     def decode_batch(self, batch: Sequence[Sequence[int]], *, errors: str = "replace", num_threads: int = 8) -> list[str]:
         """Decode a batch; the whole batch goes to the GPU in one call (`num_threads` is accepted for compatibility)."""
-        return [b.decode("utf-8", errors=errors) for b in self.decode_bytes_batch(batch)]
+        data, bounds = self._decode_packed(batch)
+        if data is None:
+            return [self.decode_bytes(t).decode("utf-8", errors=errors) for t in batch]
+        view = memoryview(data)  # (str() decodes a slice of the result buffer in place: no bytes object per document in between)
+        return [str(view[a:b], "utf-8", errors) if b > a else "" for a, b in zip(bounds[:-1], bounds[1:])]
 
-    def decode_bytes_batch(self, batch: Sequence[Sequence[int]], *, num_threads: int = 8) -> list[bytes]:
-        """One GPU call for the whole batch (tk_decode_batch) instead of one pool task per document."""
+    def _decode_packed(self, batch: Sequence[Sequence[int]]):
+        """(uint8 array of all bytes back to back -- a view of the library's result buffer --, list of n + 1 byte offsets), or (None, None)
+        when the ids are too sparse for the device table."""
         import numpy as np
 
         lens = np.fromiter((len(t) for t in batch), dtype=np.uint64, count=len(batch))
@@ -222,11 +214,18 @@ class Encoding:
         np.cumsum(lens, out=tok_off[1:])
         flat = np.fromiter((t for doc in batch for t in doc), dtype=np.uint32, count=int(tok_off[-1]))
         try:
-            data, byte_off = self._core_bpe.decode_batch_packed(flat, tok_off)
+            data, byte_off = self._core_bpe.decode_batch_packed(flat, tok_off, as_array=True)
         except ValueError:  # (ids too sparse for the device table)
+            return None, None
+        return data, byte_off.tolist()
+
+    def decode_bytes_batch(self, batch: Sequence[Sequence[int]], *, num_threads: int = 8) -> list[bytes]:
+        """One GPU call for the whole batch (tk_decode_batch) instead of one pool task per document."""
+        data, bounds = self._decode_packed(batch)
+        if data is None:
             return [self.decode_bytes(t) for t in batch]
-        bounds = byte_off.tolist()
-        return [data[a:b] for a, b in zip(bounds[:-1], bounds[1:])]
+        view = memoryview(data)
+        return [bytes(view[a:b]) for a, b in zip(bounds[:-1], bounds[1:])]
 
     def token_byte_values(self) -> list[bytes]:
         return self._core_bpe.token_byte_values()

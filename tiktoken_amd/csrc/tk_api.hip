@@ -1513,7 +1513,8 @@ extern "C" int tk_decode_batch(tk_core* c, const uint32_t* tokens, const uint64_
                                c->d_tboff.as<unsigned long long>());
         }));
     }
-    uint8_t* host = (uint8_t*)malloc(nbytes ? nbytes : 1);
+    // (large results in page-locked memory: the copy back runs at the link's rate, and Python sees the buffer in place)
+    uint8_t* host = (uint8_t*)(nbytes >= (1u << 20) ? pinned_get(nbytes) : malloc(nbytes ? nbytes : 1));
     if (!host) return fail(TK_RUNTIME_ERROR, "out of host memory");
     hipError_t e = hipSuccess;
     if (byte_off_out) {
@@ -1528,7 +1529,7 @@ extern "C" int tk_decode_batch(tk_core* c, const uint32_t* tokens, const uint64_
     if (e == hipSuccess) e = hipStreamSynchronize(s);
     if (e == hipSuccess) e = hipGetLastError();
     if (e != hipSuccess) {
-        free(host);
+        tk_free(host);
         return fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e));
     }
     *bytes_out = host;
@@ -1874,6 +1875,49 @@ extern "C" int tk_parse_tiktoken_bpe(const uint8_t* text, uint64_t len, uint8_t*
 
 extern "C" void tk_free(void* p) {
     if (!pinned_release(p)) free(p);
+}
+
+// Well-formed UTF-8 (Unicode 15, table 3-7): what the reference gets for free from &str.  Eight ASCII bytes per step where there are any.
+extern "C" int tk_validate_utf8(const uint8_t* s, uint64_t n, uint64_t* bad_pos) {
+    if (!s && n) return fail(TK_VALUE_ERROR, "null argument");
+    uint64_t i = 0;
+    auto bad = [&](uint64_t at) {
+        if (bad_pos) *bad_pos = at;
+        return fail(TK_VALUE_ERROR, "invalid UTF-8 at byte " + std::to_string(at));
+    };
+    while (i < n) {
+        if (i + 8 <= n) {
+            uint64_t w;
+            memcpy(&w, s + i, 8);
+            if (!(w & 0x8080808080808080ull)) {
+                i += 8;
+                continue;
+            }
+        }
+        const uint8_t b = s[i];
+        if (b < 0x80) {
+            ++i;
+            continue;
+        }
+        uint32_t need;
+        uint8_t lo = 0x80, hi = 0xBF;  // bounds of the second byte
+        if (b >= 0xC2 && b <= 0xDF) need = 1;
+        else if (b >= 0xE0 && b <= 0xEF) {
+            need = 2;
+            if (b == 0xE0) lo = 0xA0;       // no overlong three-byte forms
+            else if (b == 0xED) hi = 0x9F;  // no surrogates
+        } else if (b >= 0xF0 && b <= 0xF4) {
+            need = 3;
+            if (b == 0xF0) lo = 0x90;       // no overlong four-byte forms
+            else if (b == 0xF4) hi = 0x8F;  // nothing above U+10FFFF
+        } else return bad(i);               // a continuation byte, 0xC0, 0xC1, 0xF5..0xFF
+        if (i + need >= n) return bad(i);  // truncated
+        if (s[i + 1] < lo || s[i + 1] > hi) return bad(i);
+        for (uint32_t k = 2; k <= need; ++k)
+            if ((s[i + k] & 0xC0) != 0x80) return bad(i);
+        i += need + 1;
+    }
+    return TK_OK;
 }
 
 extern "C" void tk_set_profiling(tk_core* c, int enabled) {

@@ -61,7 +61,40 @@ static size_t str_utf8_size(PyObject* s) {
         for (; i < n; ++i) total += 1u + (b[i] >> 7);
         return total;
     }
-    for (Py_ssize_t i = 0; i < n;) total += utf8_len(next_scalar(kind, data, n, &i));
+    // (wider kinds: mostly ASCII with a few chars beyond Latin-1 is the common case -- runs of ASCII code units are counted four / two at a time)
+    if (kind == PyUnicode_2BYTE_KIND) {
+        const uint16_t* u = (const uint16_t*)data;
+        Py_ssize_t i = 0;
+        while (i < n) {
+            if (i + 4 <= n) {
+                uint64_t w;
+                memcpy(&w, u + i, 8);
+                if (!(w & 0xFF80FF80FF80FF80ull)) {
+                    total += 4;
+                    i += 4;
+                    continue;
+                }
+            }
+            total += utf8_len(next_scalar(kind, data, n, &i));
+        }
+        return total;
+    }
+    {
+        const uint32_t* u = (const uint32_t*)data;
+        Py_ssize_t i = 0;
+        while (i < n) {
+            if (i + 2 <= n) {
+                uint64_t w;
+                memcpy(&w, u + i, 8);
+                if (!(w & 0xFFFFFF80FFFFFF80ull)) {
+                    total += 2;
+                    i += 2;
+                    continue;
+                }
+            }
+            total += utf8_len(next_scalar(kind, data, n, &i));
+        }
+    }
     return total;
 }
 static uint8_t* str_utf8_write(PyObject* s, uint8_t* p) {
@@ -90,7 +123,45 @@ static uint8_t* str_utf8_write(PyObject* s, uint8_t* p) {
         }
         return p;
     }
-    for (Py_ssize_t i = 0; i < n;) p = utf8_put(p, next_scalar(kind, data, n, &i));
+    if (kind == PyUnicode_2BYTE_KIND) {
+        const uint16_t* u = (const uint16_t*)data;
+        Py_ssize_t i = 0;
+        while (i < n) {
+            if (i + 4 <= n) {
+                uint64_t w;
+                memcpy(&w, u + i, 8);
+                if (!(w & 0xFF80FF80FF80FF80ull)) {
+                    p[0] = (uint8_t)w;
+                    p[1] = (uint8_t)(w >> 16);
+                    p[2] = (uint8_t)(w >> 32);
+                    p[3] = (uint8_t)(w >> 48);
+                    p += 4;
+                    i += 4;
+                    continue;
+                }
+            }
+            p = utf8_put(p, next_scalar(kind, data, n, &i));
+        }
+        return p;
+    }
+    {
+        const uint32_t* u = (const uint32_t*)data;
+        Py_ssize_t i = 0;
+        while (i < n) {
+            if (i + 2 <= n) {
+                uint64_t w;
+                memcpy(&w, u + i, 8);
+                if (!(w & 0xFFFFFF80FFFFFF80ull)) {
+                    p[0] = (uint8_t)w;
+                    p[1] = (uint8_t)(w >> 32);
+                    p += 2;
+                    i += 2;
+                    continue;
+                }
+            }
+            p = utf8_put(p, next_scalar(kind, data, n, &i));
+        }
+    }
     return p;
 }
 

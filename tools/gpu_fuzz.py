@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Randomised batches of awkward documents (tests/helpers.py fuzz_batch: runs of one class, chains of uncertain boundaries, contractions in
 every case, digits, white space with and without newlines, CJK, combining marks, specials, empty and tiny documents) through the whole
-pipeline, every token against the C oracle.  Deterministic per (encoding, seed).  Usage: gpu_fuzz.py [rounds] [MiB per batch] [first seed]"""
+pipeline, every token against the C oracle.  Deterministic per (encoding, seed).  Usage: gpu_fuzz.py [rounds] [MiB per batch] [first seed]   |   gpu_fuzz.py generic [patterns] [seed]"""
 import os, sys, time, zlib
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -9,6 +9,18 @@ import numpy as np
 import helpers as h
 from tiktoken_amd import CoreBPE
 
+if len(sys.argv) > 1 and sys.argv[1] == "generic":
+    # gpu_fuzz.py generic [patterns] [seed]: random pat_str over the whole supported syntax, compiled and run on the device, split + gaps +
+    # tokens against Python `regex` and the oracle (the loop of tests/test_gpu_regex.py::test_generated_patterns_on_the_device, more of it)
+    from test_gpu_regex import generated_patterns_on_the_device
+
+    n_pat = int(sys.argv[2]) if len(sys.argv) > 2 else 400
+    seed = int(sys.argv[3]) if len(sys.argv) > 3 else 1
+    t0 = time.perf_counter()
+    ran, gave_up = generated_patterns_on_the_device(seed, n_pat)
+    print(f"generic engine: {ran} generated patterns equal to Python regex (split, gaps, tokens of every fourth), {gave_up} given up loudly, "
+          f"{time.perf_counter() - t0:.1f} s", flush=True)
+    sys.exit(0)
 rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 4
 mib = int(sys.argv[2]) if len(sys.argv) > 2 else 24
 first = int(sys.argv[3]) if len(sys.argv) > 3 else 0
