@@ -216,8 +216,17 @@ def sim_lib():
         srcs = [os.path.join(d, "tk_hostsim.cpp")] + [os.path.join(ROOT, "tiktoken_amd", "csrc", f)
                                                        for f in ("tk_tables.cpp", "tk_pattern.cpp", "tk_regex.cpp", "tk_device.h", "tk_common.h", "tk_tables.h", "tk_chunk.h", "tk_regex.h",
                                                                  "tk_regex_split.h", "tk_regex_host.h")]
-        if not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs):
-            subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", srcs[0], srcs[1], srcs[2], srcs[3], "-o", so])
+        def stale():
+            return not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs)
+
+        if stale():  # (several pytest-xdist workers may get here at once: one builds, into a file of its own, and renames)
+            import fcntl
+            with open(so + ".lock", "w") as lk:
+                fcntl.flock(lk, fcntl.LOCK_EX)
+                if stale():
+                    tmp = f"{so}.{os.getpid()}.tmp"
+                    subprocess.check_call(["g++", "-O2", "-std=c++17", "-fPIC", "-shared", "-pthread", srcs[0], srcs[1], srcs[2], srcs[3], "-o", tmp])
+                    os.replace(tmp, so)
         L = ctypes.CDLL(so)
         vp, u64 = ctypes.c_void_p, ctypes.c_uint64
         L.tks_create.restype = vp
@@ -247,6 +256,8 @@ def sim_lib():
         L.tks_rx_free.argtypes = [vp]
         L.tks_rx_size.restype = u64
         L.tks_rx_size.argtypes = [vp]
+        L.tks_rx_dfa.restype = u64
+        L.tks_rx_dfa.argtypes = [vp, ctypes.c_char_p, u64]
         L.tks_rx_split.restype = u64
         L.tks_rx_split.argtypes = [vp, vp, u64, vp, u64, vp, vp, u64, ctypes.c_int, vp, vp]
         _sim_lib = L
@@ -346,17 +357,38 @@ class RxSim:
         self._L = L
         self.size = int(L.tks_rx_size(self._h))
         self.stats = (0, 0)
+        why = ctypes.create_string_buffer(256)
+        d = int(L.tks_rx_dfa(self._h, why, 256))
+        self.dfa = (d >> 32, d & 0xFFFFFFFF) if d else None  # (states, classes) of the pattern's DFA; None: it has none, dfa_why says why
+        self.dfa_why = why.value.decode()
 
     def __del__(self):
         if getattr(self, "_h", None):
             self._L.tks_rx_free(self._h)
             self._h = None
 
-    def split(self, docs: list[bytes], specials: list[tuple[int, int]] = (), speculate: int | bool = True) -> list[int]:
+    def split(self, docs: list[bytes], specials: list[tuple[int, int]] = (), speculate: int | bool = True, matcher: str = "both") -> list[int]:
         """Piece starts (byte offsets into the packed batch) of the documents -- gap chars included, listed in self.gaps as well;
         specials: (offset, length) of allowed special tokens.
         speculate: False = the matcher alone walks every document; True / 1 = with the speculative pass over 256-byte segments; 2 = 1 KiB;
-        + 4: with the link pass (what the device runs); + 8: documents resolved by groups of 64 lanes (the device's wavefront)."""
+        + 4: with the link pass (what the device runs); + 8: documents resolved by groups of 64 lanes (the device's wavefront).
+        matcher: "program" = the backtracking program; "dfa" = the pattern's DFA (self.dfa must not be None); "both" = the program, and where
+        the pattern has a DFA the same split through it as well, which has to give the same starts and gaps (self.stats are the program's)."""
+        if matcher == "dfa":
+            assert self.dfa, self.dfa_why
+            got = self._split(docs, specials, int(speculate) | 16)
+            if int(speculate) & 3:  # (the one-loop form of the speculative lanes, which is what the device runs)
+                gaps = self.gaps
+                assert self._split(docs, specials, int(speculate) | 48) == got and self.gaps == gaps, "the two forms of the DFA's speculative pass disagree"
+            return got
+        got = self._split(docs, specials, int(speculate))
+        if matcher == "both" and self.dfa:
+            gaps, stats = self.gaps, self.stats
+            assert self.split(docs, specials, speculate, matcher="dfa") == got and self.gaps == gaps, "the DFA and the program disagree"
+            self.stats = stats
+        return got
+
+    def _split(self, docs, specials, speculate: int) -> list[int]:
         blob, off = pack(docs)
         n = len(blob)
         starts = np.zeros(n + 1, np.uint8)
@@ -365,7 +397,7 @@ class RxSim:
         stats = np.zeros(2, np.uint64)
         buf = np.ascontiguousarray(blob) if n else np.zeros(1, np.uint8)
         rc = self._L.tks_rx_split(self._h, buf.ctypes.data, n, off.ctypes.data, len(off) - 1, sa.ctypes.data if len(sa) else None,
-                                  sl.ctypes.data if len(sl) else None, len(sa), int(speculate), starts.ctypes.data, stats.ctypes.data)
+                                  sl.ctypes.data if len(sl) else None, len(sa), speculate, starts.ctypes.data, stats.ctypes.data)
         self.stats = (int(stats[0]), int(stats[1]))
         if rc:
             raise RuntimeError(f"split error {rc & 255} at byte {rc >> 8}")

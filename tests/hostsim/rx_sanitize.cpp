@@ -8,6 +8,7 @@
 #include <string.h>
 
 #include <string>
+#include <type_traits>
 #include <vector>
 
 #include "../../tiktoken_amd/csrc/tk_regex_host.h"
@@ -77,7 +78,7 @@ static std::vector<uint8_t> random_text(uint32_t n) {
 
 int main(int argc, char** argv) {
     const int rounds = argc > 1 ? atoi(argv[1]) : 400;
-    uint64_t compiled = 0, splits = 0;
+    uint64_t compiled = 0, splits = 0, with_dfa = 0;
     for (int r = 0; r < rounds; ++r) {
         const std::string pat = random_pattern();
         TkRxCompiled c;
@@ -114,7 +115,8 @@ int main(int argc, char** argv) {
                     if (at + len < n) brk[(at + len) >> 5] |= 1u << ((at + len) & 31);
                     at += len;
                 }
-            for (uint32_t shift : {TK_RX_SEG_SHIFT_SMALL, TK_RX_SEG_SHIFT_LARGE}) {
+            auto run_lanes = [&](auto dfa_tag, uint32_t shift) {  // (the matcher: the program, or the pattern's DFA where it has one)
+                constexpr bool DFA = decltype(dfa_tag)::value;
                 const uint32_t nseg = (uint32_t)(((uint64_t)n + (1u << shift) - 1) >> shift);
                 uint32_t* xexit = (uint32_t*)malloc((nseg + 2) * 4);
                 uint32_t* lmerge = (uint32_t*)malloc((nseg + 2) * 4);
@@ -124,8 +126,12 @@ int main(int argc, char** argv) {
                 uint32_t* lnk = (uint32_t*)calloc(nw, 4);
                 uint32_t* lgap = (uint32_t*)calloc(nw, 4);
                 TkRxText t{text, n, brk, with_specials ? ss : nullptr, with_specials ? si : nullptr, 0xFFFFFFFFu, false};
-                for (uint32_t s = 0; s < nseg; ++s) tk_rx_speculate_lane(P, t, s, shift, spec, sgap, xexit);
-                for (uint32_t s = 0; s < nseg; ++s) tk_rx_link_lane(P, t, s, shift, spec, xexit, lnk, lgap, lmerge, lexit);
+                if constexpr (DFA) {  // (the device's form of the DFA's speculative lane: one loop over the segment)
+                    for (uint32_t s = 0; s < nseg; ++s) tk_rx_speculate_lane_flat(P, t, s, shift, spec, sgap, xexit);
+                } else {
+                    for (uint32_t s = 0; s < nseg; ++s) tk_rx_speculate_lane<DFA>(P, t, s, shift, spec, sgap, xexit);
+                }
+                for (uint32_t s = 0; s < nseg; ++s) tk_rx_link_lane<DFA>(P, t, s, shift, spec, xexit, lnk, lgap, lmerge, lexit);
                 const TkRxMaps M{spec, sgap, xexit, lnk, lgap, lmerge, lexit, shift};
                 for (int by_group = 0; by_group < 2; ++by_group) {  // (one lane per document; a group of lanes per document)
                     memset(gst, 0, nw * 4);
@@ -135,8 +141,8 @@ int main(int argc, char** argv) {
                             if (w >= nw || (gaps & ~(gst[w] | bits))) abort();  // (a gap char is a start)
                             gst[w] |= bits;
                         };
-                        if (by_group) (void)tk_rx_resolve_group_host(P, t, M, doc[d], doc[d + 1], orb, &err_pos);
-                        else (void)tk_rx_resolve_lane(P, t, M, doc[d], doc[d + 1], orb, &err_pos);
+                        if (by_group) (void)tk_rx_resolve_group_host<DFA>(P, t, M, doc[d], doc[d + 1], orb, &err_pos);
+                        else (void)tk_rx_resolve_lane<DFA>(P, t, M, doc[d], doc[d + 1], orb, &err_pos);
                     }
                 }
                 free(lmerge);
@@ -146,6 +152,10 @@ int main(int argc, char** argv) {
                 ++splits;
                 free(xexit);
                 free(sgap);
+            };
+            for (uint32_t shift : {TK_RX_SEG_SHIFT_SMALL, TK_RX_SEG_SHIFT_LARGE}) {
+                run_lanes(std::false_type{}, shift);
+                if (c.has_dfa()) run_lanes(std::true_type{}, shift), ++with_dfa;
             }
             free(text);
             free(brk);
@@ -155,6 +165,6 @@ int main(int argc, char** argv) {
             free(si);
         }
     }
-    printf("ok %llu %llu\n", (unsigned long long)compiled, (unsigned long long)splits);
+    printf("ok %llu %llu (%llu through a DFA)\n", (unsigned long long)compiled, (unsigned long long)splits, (unsigned long long)with_dfa);
     return 0;
 }

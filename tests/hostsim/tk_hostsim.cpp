@@ -654,13 +654,27 @@ void* tks_rx_compile(const char* pat_str, char* err, uint64_t errcap) {
 }
 void tks_rx_free(void* p) { delete (TkRxCompiled*)p; }
 uint64_t tks_rx_size(void* p) { return ((TkRxCompiled*)p)->ins.size(); }
-uint64_t tks_rx_steps() { return g_rx_steps; }  // matcher steps so far (instructions + chars of repeats + backtracks)
+uint64_t tks_rx_steps() { return g_rx_steps; }
+// the pattern's DFA (tk_regex_dfa.inc): states << 32 | classes, 0 when it has none (why: the reason, if `why` is given)
+uint64_t tks_rx_dfa(void* p, char* why, uint64_t cap) {
+    const TkRxCompiled* c = (const TkRxCompiled*)p;
+    if (why && cap) {
+        strncpy(why, c->dfa_why.c_str(), cap - 1);
+        why[cap - 1] = 0;
+    }
+    return c->has_dfa() ? (uint64_t)c->dfa_nstates << 32 | c->dfa_ncls : 0;
+}
+}  // extern "C"
+  // matcher steps so far (instructions + chars of repeats + backtracks)
 // Piece starts of a packed batch: a byte per position (1 = start).  spec_at / spec_len: occurrences of allowed special tokens (sorted).
 // speculate = 0: every document walked by the matcher alone; bits 0..1: 1 = speculative pass over 256-byte segments, 2 = over 1 KiB; bit 2: with
 // the link pass; bit 3: documents resolved by groups of 64 lanes (the host form of the device's wavefront).
+// bit 4: the matcher is the pattern's DFA (it must have one: tks_rx_dfa) instead of the program; bit 5 (with bit 4): the speculative lanes in
+// their one-loop form (tk_rx_speculate_lane_flat), compared bit for bit with the piece-by-piece form (error 0xFE if they differ).
 // stats[0] = matcher runs of the speculative (+ link) pass, [1] = of the resolving pass.  Returns 0, or error bits | position << 8.
-uint64_t tks_rx_split(void* p, const uint8_t* text_in, uint64_t n, const uint64_t* doc_off, uint64_t n_docs, const uint64_t* spec_at,
-                      const uint64_t* spec_len, uint64_t n_spec, int speculate, uint8_t* starts, uint64_t* stats) {
+template <bool DFA>
+static uint64_t rx_split_impl(void* p, const uint8_t* text_in, uint64_t n, const uint64_t* doc_off, uint64_t n_docs, const uint64_t* spec_at,
+                              const uint64_t* spec_len, uint64_t n_spec, int speculate, uint8_t* starts, uint64_t* stats) {
     const uint32_t seg_shift = (speculate & 3) == 2 ? TK_RX_SEG_SHIFT_LARGE : TK_RX_SEG_SHIFT_SMALL;
     const bool with_links = (speculate & 3) && (speculate & 4), by_group = (speculate & 8) != 0;
     const TkRxCompiled* c = (const TkRxCompiled*)p;
@@ -682,10 +696,19 @@ uint64_t tks_rx_split(void* p, const uint8_t* text_in, uint64_t n, const uint64_
     const uint32_t nseg = (uint32_t)((n + (1u << seg_shift) - 1) >> seg_shift);
     std::vector<uint32_t> xexit(nseg + 1, TK_RX_UNKNOWN), lmerge(nseg + 1, TK_RX_NOLINK), lexit(nseg + 1, TK_RX_UNKNOWN);
     g_rx_matches = 0;
-    if (speculate & 3)
-        for (uint32_t k = 0; k < nseg; ++k) tk_rx_speculate_lane(P, t, k, seg_shift, spec.data(), sgap.data(), xexit.data());
+    if ((speculate & 3) && (speculate & 32)) {  // the one-loop form of the DFA's speculative lane: the same bitmaps and exits, bit for bit
+        if constexpr (DFA) {
+            for (uint32_t k = 0; k < nseg; ++k) tk_rx_speculate_lane_flat(P, t, k, seg_shift, spec.data(), sgap.data(), xexit.data());
+            std::vector<uint32_t> spec2(nw, 0), sgap2(nw, 0), xexit2(nseg + 1, TK_RX_UNKNOWN);
+            for (uint32_t k = 0; k < nseg; ++k) tk_rx_speculate_lane<true>(P, t, k, seg_shift, spec2.data(), sgap2.data(), xexit2.data());
+            if (spec2 != spec || sgap2 != sgap || xexit2 != xexit) return 0xFEu;
+        } else {
+            return 0xFFu;
+        }
+    } else if (speculate & 3)
+        for (uint32_t k = 0; k < nseg; ++k) tk_rx_speculate_lane<DFA>(P, t, k, seg_shift, spec.data(), sgap.data(), xexit.data());
     if (with_links)
-        for (uint32_t k = 0; k < nseg; ++k) tk_rx_link_lane(P, t, k, seg_shift, spec.data(), xexit.data(), lnk.data(), lgap.data(), lmerge.data(), lexit.data());
+        for (uint32_t k = 0; k < nseg; ++k) tk_rx_link_lane<DFA>(P, t, k, seg_shift, spec.data(), xexit.data(), lnk.data(), lgap.data(), lmerge.data(), lexit.data());
     stats[0] = g_rx_matches;
     g_rx_matches = 0;
     const TkRxMaps M{(speculate & 3) ? spec.data() : nullptr, sgap.data(), xexit.data(), with_links ? lnk.data() : nullptr, lgap.data(), lmerge.data(), lexit.data(), seg_shift};
@@ -696,8 +719,8 @@ uint64_t tks_rx_split(void* p, const uint8_t* text_in, uint64_t n, const uint64_
             gst[w] |= bits;
             ggap[w] |= gaps;
         };
-        const uint32_t e = by_group ? tk_rx_resolve_group_host(P, t, M, (uint32_t)doc_off[d], (uint32_t)doc_off[d + 1], orb, &err_pos)
-                                    : tk_rx_resolve_lane(P, t, M, (uint32_t)doc_off[d], (uint32_t)doc_off[d + 1], orb, &err_pos);
+        const uint32_t e = by_group ? tk_rx_resolve_group_host<DFA>(P, t, M, (uint32_t)doc_off[d], (uint32_t)doc_off[d + 1], orb, &err_pos)
+                                    : tk_rx_resolve_lane<DFA>(P, t, M, (uint32_t)doc_off[d], (uint32_t)doc_off[d + 1], orb, &err_pos);
         if (e) rc = e | ((uint64_t)err_pos << 8);
     }
     stats[1] = g_rx_matches;
@@ -705,4 +728,11 @@ uint64_t tks_rx_split(void* p, const uint8_t* text_in, uint64_t n, const uint64_
     return rc;
 }
 
-}  // extern "C"
+extern "C" uint64_t tks_rx_split(void* p, const uint8_t* text_in, uint64_t n, const uint64_t* doc_off, uint64_t n_docs, const uint64_t* spec_at,
+                                 const uint64_t* spec_len, uint64_t n_spec, int speculate, uint8_t* starts, uint64_t* stats) {
+    if (speculate & 16) {
+        if (!((const TkRxCompiled*)p)->has_dfa()) return 0xFFu;
+        return rx_split_impl<true>(p, text_in, n, doc_off, n_docs, spec_at, spec_len, n_spec, speculate, starts, stats);
+    }
+    return rx_split_impl<false>(p, text_in, n, doc_off, n_docs, spec_at, spec_len, n_spec, speculate, starts, stats);
+}

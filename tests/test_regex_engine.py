@@ -267,8 +267,10 @@ def test_stock_patterns_through_the_generic_engine_equal_the_oracle_split(name, 
         assert resolve_runs < len(want) // 5, (resolve_runs, len(want))  # (most of the matching is done by the speculative lanes)
 
 
-def _gen_pattern(rng: random.Random):
-    """A random pattern of the supported syntax, as (engine pattern, Python pattern): the two differ in how they spell end / start of text."""
+def _gen_pattern(rng: random.Random, table_form: bool = False):
+    """A random pattern of the supported syntax, as (engine pattern, Python pattern): the two differ in how they spell end / start of text.
+    table_form: only what has a DFA (tk_regex_dfa.inc) -- no look-behind, no word boundaries, atomic groups and possessive quantifiers around
+    one class only, look-ahead of one char (a class, `$`, an alternation of those, a repeated class)."""
     lits = ["a", "b", "c", "x", "1", " ", r"\n", "'", r"\.", "s", "k", "é", "中"]
     sets = [r"[a-c]", r"[^a\s]", r"\s", r"\S", r"\d", r"\w", r"\p{L}", r"\p{Lu}", r"\P{N}", r"[\s\S]", r"[^\S\n]", r"[x1\p{Ll}]", r"\p{Nd}", r"[^\r\n\p{L}\p{N}]",
             r"[a\-c]", r"[\]x]", r"\pL", r"\x61", r"\u4e2d", r"[\x61-\x63]"]
@@ -284,16 +286,29 @@ def _gen_pattern(rng: random.Random):
         if r < 0.8:
             return "."
         kind = rng.choice(["(?:", "(?:", "(", "(?>", "(?i:", "(?s:"])
+        if kind == "(?>" and table_form:
+            return kind + rng.choice(sets) + rng.choice(["", "+", "*", "{1,3}", "+?", "{2,}?", "?+", "++"]) + ")"
         if kind == "(?i:":
             return kind + "|".join(rng.choice(["s", "k", "ab", "x1", "'s", "a b"]) for _ in range(rng.randint(1, 3))) + ")"
         return kind + alt(depth + 1, ci, rng.randint(1, 3)) + ")"
 
+    def quantified(depth, ci, qs):
+        a, q = atom(depth, ci), rng.choice(qs)
+        if table_form and a[0] == "(" and q[-1:] == "+" and len(q) > 1:  # (a possessive repeat of a group has no table form)
+            q = q[:-1]
+        return a + q
+
     def concat(depth, ci):
-        parts = [atom(depth, ci) + rng.choice(quants) for _ in range(rng.randint(0, 3))]
-        parts.insert(rng.randint(0, len(parts)), atom(depth, ci) + rng.choice(["", "", "+", "{2}", "{1,3}", "+?", "++"]))  # (at least one char)
-        if rng.random() < 0.2:
-            parts.append(rng.choice(["(?=", "(?!"]) + atom(depth + 1, ci) + ")")
-        if rng.random() < 0.2:  # word boundaries, one-char look-behind: anywhere between the atoms
+        parts = [quantified(depth, ci, quants) for _ in range(rng.randint(0, 3))]
+        parts.insert(rng.randint(0, len(parts)), quantified(depth, ci, ["", "", "+", "{2}", "{1,3}", "+?", "++"]))  # (at least one char)
+        if rng.random() < (0.35 if table_form else 0.2):
+            if table_form:
+                body = rng.choice([rng.choice(sets), rng.choice(lits), rng.choice(sets) + "|$", "$|" + rng.choice(lits), rng.choice(sets) + "+",
+                                   rng.choice(sets) + "|" + rng.choice(lits)])
+                parts.insert(rng.randint(1, len(parts)), rng.choice(["(?=", "(?!"]) + body + ")")
+            else:
+                parts.append(rng.choice(["(?=", "(?!"]) + atom(depth + 1, ci) + ")")
+        if rng.random() < 0.2 and not table_form:  # word boundaries, one-char look-behind: anywhere between the atoms
             parts.insert(rng.randint(0, len(parts)), rng.choice([r"\b", r"\B", r"(?<=\s)", r"(?<!\S)", r"(?<![a-c])", r"(?<=a|\p{Lu})", r"(?<!\w)", r"(?<=ab|\s)", r"(?<!\S{2})", r"(?<=[a-c]\p{L}|1)", r"(?<!\n\n)"]))
         return "".join(parts)
 
@@ -301,7 +316,7 @@ def _gen_pattern(rng: random.Random):
         return "|".join(concat(depth, ci) for _ in range(n))
 
     body = alt(0, False, rng.randint(1, 5))
-    eng = py = body
+    eng, py = body, body.replace("$", r"\Z")
     if rng.random() < 0.25:
         eng, py = eng + r"|\s+$", py + r"|\s+\Z"
     if rng.random() < 0.15:
@@ -319,7 +334,7 @@ def test_generated_patterns_equal_python_regex():
     alphabet = list("abcxABCX12 \n\t'.,sSkK") + ["ſ", "K", "é", "中", "É", "٣", "\r\n", "  ", "ab", "'s"]
     texts = ["".join(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 2, 4, 8, 20, 60]))) for _ in range(120)]
     texts += ["a" * 300, " " * 200 + "x", "ab" * 20, "x1" * 25 + "\n", "'s" * 12]
-    compiled = refused = deep = exploded = 0
+    compiled = refused = deep = exploded = with_dfa = 0
     for it in range(1000):
         eng, py = _gen_pattern(rng)
         if "(?i:" in eng and r"[^a\s]" in eng:
@@ -334,6 +349,7 @@ def test_generated_patterns_equal_python_regex():
             assert any(w in str(e) for w in ("empty string", "too large", "too many")), (eng, str(e))
             continue
         compiled += 1
+        with_dfa += rx.dfa is not None
         good, want, wgap, base = [], [], [], 0
         for t in texts:
             try:
@@ -351,15 +367,65 @@ def test_generated_patterns_equal_python_regex():
             want += [base + s for s in st]
             wgap += [base + s for s in gp]
             base += len(good[-1])
+        mode = (1 + (it & 1)) | (4 if it & 2 else 0) | (8 if it & 4 else 0)
         try:
-            got = rx.split(good, speculate=(1 + (it & 1)) | (4 if it & 2 else 0) | (8 if it & 4 else 0))
+            got = rx.split(good, speculate=mode)  # (where the pattern has a DFA: through it as well, with the same result)
         except RuntimeError as e:
             # a backtracking repeated group in the middle of an alternative on a long text (8), or more backtracking than the budget (16)
             assert "error 8" in str(e) or "error 16" in str(e), (eng, str(e))
             deep += 1
+            if rx.dfa:  # (the table form has neither a stack nor a budget)
+                assert rx.split(good, speculate=mode, matcher="dfa") == want and rx.gaps == wgap, (eng, py)
             continue
         assert got == want and rx.gaps == wgap, (eng, py)
     assert compiled > 750 and deep < compiled // 15, (compiled, refused, deep, exploded)
+    assert with_dfa > compiled // 5, (with_dfa, compiled)  # (the generated patterns are full of look-behind and word boundaries, which have no DFA)
+
+
+def test_generated_patterns_in_table_form_equal_python_regex():
+    """The same for patterns that have a DFA (tk_regex_dfa.inc): every one of them is split through the table AND through the program, in
+    every form of the split passes, and both have to agree with Python `regex` -- leftmost-first alternatives, lazy and possessive repeats,
+    atomic groups around a class, one-char look-ahead in the middle of an alternative, anchors."""
+    rng = random.Random(20260923)
+    alphabet = list("abcxABCX12 \n\t'.,sSkK") + ["ſ", "K", "é", "中", "É", "٣", "\r\n", "  ", "ab", "'s"]
+    texts = ["".join(rng.choice(alphabet) for _ in range(rng.choice([0, 1, 2, 4, 8, 20, 60, 300]))) for _ in range(120)]
+    texts += ["a" * 300, " " * 200 + "x", "ab" * 20, "x1" * 25 + "\n", "'s" * 12]
+    checked = tables = exploded = 0
+    for it in range(1500):
+        eng, py = _gen_pattern(rng, table_form=True)
+        if "(?i:" in eng and r"[^a\s]" in eng:  # (the `regex` quirk named above)
+            continue
+        pyc = regex.compile(py)
+        try:
+            rx = h.RxSim(eng)
+        except ValueError as e:
+            assert any(w in str(e) for w in ("empty string", "too large", "too many")), (eng, str(e))
+            continue
+        if rx.dfa is None:
+            assert "too large" in rx.dfa_why or "above 256" in rx.dfa_why, (eng, rx.dfa_why)  # (nothing else stands in the way of these patterns)
+            continue
+        tables += 1
+        good, want, wgap, base = [], [], [], 0
+        for t in texts:
+            try:
+                st, gp = py_starts_gaps(pyc, t, timeout=0.25)
+            except TimeoutError:
+                exploded += 1
+                continue
+            except LookupError:
+                continue
+            good.append(t.encode())
+            want += [base + s for s in st]
+            wgap += [base + s for s in gp]
+            base += len(good[-1])
+        for mode in ((0, 5, 14) if it % 10 == 0 else ((1 + (it & 1)) | (4 if it & 2 else 0) | (8 if it & 4 else 0),)):
+            assert rx.split(good, speculate=mode, matcher="dfa") == want and rx.gaps == wgap, (eng, py, mode)
+        try:
+            assert rx.split(good, speculate=5, matcher="program") == want, (eng, py)
+        except RuntimeError as e:
+            assert "error 8" in str(e) or "error 16" in str(e), (eng, str(e))
+        checked += 1
+    assert checked > 1000, (checked, tables, exploded)
 
 
 def test_compiler_and_lanes_under_the_sanitizers(tmp_path):

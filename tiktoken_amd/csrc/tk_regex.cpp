@@ -1017,6 +1017,8 @@ void annotate_first_bytes(TkRxCompiled* out) {
     if (out->first.empty()) out->first.assign(8, 0xFFFFFFFFu);  // (never indexed; keeps the upload simple)
 }
 
+#include "tk_regex_dfa.inc"
+
 }  // namespace
 
 const uint8_t* tk_rx_props_stage1() { return tk_rx_stage1; }
@@ -1074,10 +1076,19 @@ std::string tk_rx_compile(const char* pat_str, TkRxCompiled* out) {
     }
     if (out->ranges.size() / 2 > TK_RX_MAX_RANGES) return "the pattern has too many class ranges";
     annotate_first_bytes(out);
+    build_dfa(P, root, out);  // the table form of the same pattern, where it has one (tk_regex_dfa.inc)
     return "";
 }
 
 TkRxProg TkRxCompiled::view() const {
-    return TkRxProg{ins.data(), sets.data(), ranges.data(), tk_rx_stage1, tk_rx_stage2, (uint32_t)ins.size(), (uint32_t)sets.size(),
-                    (uint32_t)ranges.size() / 2, first.data(), (uint32_t)first.size() / 8};
+    TkRxProg P{ins.data(), sets.data(), ranges.data(), tk_rx_stage1, tk_rx_stage2, (uint32_t)ins.size(), (uint32_t)sets.size(),
+               (uint32_t)ranges.size() / 2, first.data(), (uint32_t)first.size() / 8};
+    if (has_dfa()) {
+        P.dfa_trans = dfa_trans.data();
+        P.dfa_ascii = dfa_ascii.data();
+        P.dfa_s1 = dfa_s1.data();
+        P.dfa_s2 = dfa_s2.data();
+        P.dfa_ncls = dfa_ncls;
+    }
+    return P;
 }

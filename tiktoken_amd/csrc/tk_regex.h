@@ -61,6 +61,15 @@ struct TkRxProg {
     uint32_t n_ins, n_sets, n_ranges;
     const uint32_t* first;  // first-byte bitmaps, 8 words each: the bytes with which a match of the rest of the program from some
     uint32_t n_first;       // instruction can begin (tk_regex.cpp: a fixpoint over the program; conservative, so skipping is exact)
+    // The same pattern as a DFA (tk_regex_dfa.inc; null: the pattern has none -- look-behind, \b, general atomic groups -- and the program
+    // above runs).  trans[state * ncls + cls]: bit 15 = "a match ends HERE, in front of this char", bits 0..14 = the next state (0: dead).
+    // State 1 starts a match inside a haystack, state 2 one at its first char (^, \A).  cls 0 is the end of the haystack, 1 .. ncls - 1 the
+    // classes of code points no set of the pattern tells apart: ASCII through dfa_ascii[128], the rest through the two-stage table.
+    const uint16_t* dfa_trans = nullptr;
+    const uint8_t* dfa_ascii = nullptr;
+    const uint16_t* dfa_s1 = nullptr;  // [0x1100] -> block of dfa_s2
+    const uint8_t* dfa_s2 = nullptr;   // blocks of 256 classes
+    uint32_t dfa_ncls = 0;
 };
 
 #define TK_RX_FAILED 0xFFFFFFFFu    // no match at this position
@@ -132,6 +141,38 @@ TK_HD uint32_t tk_rx_decode(A& t, uint32_t pos, uint32_t* len) {
     }
     *len = need;
     return cp;
+}
+
+// The DFA form of the matcher: one table look-up per char, no stack, no budget -- every lane of a wavefront runs the same loop whatever
+// alternative of the pattern its text is in.  Leftmost-first semantics are in the table (tk_regex_dfa.inc: a state is an ORDERED list of
+// NFA states, a match cuts off everything of lower priority, assertions about the next char are resolved by the class of that char), so
+// the end of the match is the last position at which a transition said "match": exactly what tk_rx_match returns for the same pattern.
+template <class A>
+TK_HD uint32_t tk_rx_match_dfa(const TkRxProg& P, A& t, uint32_t start) {
+    const uint32_t ncls = P.dfa_ncls;
+    uint32_t state = (start == 0u || t.hard(start)) ? 2u : 1u;
+    uint32_t pos = start, last = TK_RX_FAILED;
+    for (;;) {
+        uint32_t cls = 0u, len = 0u;  // (the end of the haystack)
+        if (pos < t.n && !(pos > start && t.hard(pos))) {
+            const uint32_t b0 = t.byte(pos);
+            if (b0 < 0x80u) {
+                cls = P.dfa_ascii[b0];
+                len = 1u;
+            } else {
+                uint32_t cp = tk_rx_decode(t, pos, &len);
+                if (cp > 0x10FFFFu) cp = 0xFFFDu;
+                cls = P.dfa_s2[(uint32_t)P.dfa_s1[cp >> 8] * 256u + (cp & 255u)];
+            }
+        }
+        const uint32_t e = P.dfa_trans[state * ncls + cls];
+        if (e & 0x8000u) last = pos;
+        state = e & 0x7FFFu;
+        if (state == 0u) break;  // (always behind the end of the haystack: nothing consumes it)
+        pos += len;
+    }
+    TK_RX_ON_DONE(pos - start + 1u);
+    return last;
 }
 
 // End of the match of P that starts at `start`, TK_RX_FAILED or TK_RX_OVERFLOW.  `t` gives the text: byte(pos), n, hard(pos) -- a
@@ -327,4 +368,11 @@ TK_HD uint32_t tk_rx_match(const TkRxProg& P, A& t, uint32_t start) {
             }  // F_ATOM: the group failed as a whole
         }
     }
+}
+
+// DFA: the table form (P.dfa_trans is there); otherwise the program
+template <bool DFA, class A>
+TK_HD uint32_t tk_rx_match_sel(const TkRxProg& P, A& t, uint32_t start) {
+    if constexpr (DFA) return tk_rx_match_dfa(P, t, start);
+    else return tk_rx_match(P, t, start);
 }

@@ -81,7 +81,9 @@ struct TkRxText {
     TK_HD bool inside_special(uint32_t p) const { return si && ((si[p >> 5] >> (p & 31u)) & 1u); }
 };
 
-// the start that follows the piece (or special token, or gap char) that starts at p; or an error code (TK_RX_IS_ERROR: stack, budget)
+// the start that follows the piece (or special token, or gap char) that starts at p; or an error code (TK_RX_IS_ERROR: stack, budget).
+// DFA (here and below): the matcher is the pattern's table form (tk_rx_match_dfa) instead of the program.
+template <bool DFA = false>
 TK_HD uint32_t tk_rx_next(const TkRxProg& P, TkRxText& t, uint32_t p, bool* gap) {
     *gap = false;
     if (t.special(p)) {
@@ -90,7 +92,7 @@ TK_HD uint32_t tk_rx_next(const TkRxProg& P, TkRxText& t, uint32_t p, bool* gap)
         return q;
     }
     TK_RX_ON_MATCH();
-    const uint32_t e = tk_rx_match(P, t, p);
+    const uint32_t e = tk_rx_match_sel<DFA>(P, t, p);
     if (e != TK_RX_FAILED) return e;
     // no match starts here: the char is skipped (find_iter tries the next position)
     *gap = true;
@@ -102,6 +104,30 @@ TK_HD uint32_t tk_rx_next(const TkRxProg& P, TkRxText& t, uint32_t p, bool* gap)
 // bit p of a bitmap
 TK_HD bool tk_rx_bit(const uint32_t* bm, uint32_t p) { return (bm[p >> 5] >> (p & 31u)) & 1u; }
 
+// the chain of segment [.., end) from its start p on (first: the segment's first start), as described above; returns the segment's exit
+template <bool DFA = false>
+TK_HD uint32_t tk_rx_speculate_chain(const TkRxProg& P, TkRxText& t, uint32_t p, uint32_t first, uint32_t end, uint32_t limit, uint32_t* spec, uint32_t* sgap) {
+    for (;;) {
+        spec[p >> 5] |= 1u << (p & 31u);  // (the words of a segment belong to its lane)
+        bool gap;
+        uint32_t q = tk_rx_next<DFA>(P, t, p, &gap);
+        if (t.hit && p != first && !TK_RX_IS_ERROR(q)) {
+            // A long piece (it reaches TK_RX_AHEAD bytes beyond the segment) that this lane has come to along its chain: very likely a
+            // true start, and nobody else will evaluate it in parallel -- the lanes of the segments inside the piece stop at their FIRST
+            // evaluation (below), so the text of a long piece is scanned once here instead of once by the resolving lane of its document.
+            t.limit = 0xFFFFFFFFu;
+            t.hit = false;
+            q = tk_rx_next<DFA>(P, t, p, &gap);
+            t.limit = limit;
+        }
+        if (TK_RX_IS_ERROR(q) || t.hit) return TK_RX_UNKNOWN;
+        if (gap) sgap[p >> 5] |= 1u << (p & 31u);
+        if (q >= end) return q;
+        p = q;
+    }
+}
+
+template <bool DFA = false>
 TK_HD void tk_rx_speculate_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint32_t seg_shift, uint32_t* spec, uint32_t* sgap, uint32_t* xexit) {
     const uint64_t a64 = (uint64_t)k << seg_shift;
     if (a64 >= t.n) return;
@@ -112,31 +138,103 @@ TK_HD void tk_rx_speculate_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint3
     t.hit = false;
     uint32_t p = a;
     while (p < end && ((t.byte(p) & 0xC0u) == 0x80u || t.inside_special(p))) ++p;
-    const uint32_t first = p;
+    xexit[k] = p < end ? tk_rx_speculate_chain<DFA>(P, t, p, p, end, limit, spec, sgap) : TK_RX_UNKNOWN;
+}
+
+// The same with the pattern's DFA, as ONE loop over the chars of the segment: where a piece ends the lane notes its start and goes on with
+// the next one in the same iteration scheme, so the lanes of a wavefront -- whose pieces begin and end at different places -- all do useful
+// work in every iteration (in the form above a wavefront takes as long for every piece as its longest piece, for every segment as many
+// pieces as its busiest lane has).  The bits of a bitmap word are collected in a register and stored once.  What is rare leaves the loop
+// and goes on in tk_rx_speculate_chain from the piece at hand: a special token, a match that looks TK_RX_AHEAD bytes beyond the segment.
+// Same bitmaps and exits as tk_rx_speculate_lane<true> (the CPU tests compare them bit for bit).
+TK_HD void tk_rx_speculate_lane_flat(const TkRxProg& P, TkRxText t, uint32_t k, uint32_t seg_shift, uint32_t* spec, uint32_t* sgap, uint32_t* xexit) {
+    const uint64_t a64 = (uint64_t)k << seg_shift;
+    if (a64 >= t.n) return;
+    const uint32_t seg = 1u << seg_shift;
+    const uint32_t a = (uint32_t)a64, end = t.n - a > seg ? a + seg : t.n;
+    const uint32_t limit = t.n - end > TK_RX_AHEAD ? end + TK_RX_AHEAD : t.n;
+    t.limit = limit;
+    t.hit = false;
+    uint32_t p = a;
+    while (p < end && ((t.byte(p) & 0xC0u) == 0x80u || t.inside_special(p))) ++p;
+    if (p >= end) {
+        xexit[k] = TK_RX_UNKNOWN;
+        return;
+    }
+    const uint32_t first = p, ncls = P.dfa_ncls;
+    uint32_t sw = p >> 5, sbits = 0u, gbits = 0u;  // the word of `spec` / `sgap` being filled
+    auto flush = [&]() {
+        if (sbits) spec[sw] |= sbits;
+        if (gbits) sgap[sw] |= gbits;
+        sbits = gbits = 0u;
+    };
+    auto note_start = [&](uint32_t q) {
+        if ((q >> 5) != sw) {
+            flush();
+            sw = q >> 5;
+        }
+        sbits |= 1u << (q & 31u);
+    };
+    note_start(p);
     uint32_t x = TK_RX_UNKNOWN;
-    if (p < end) {
-        for (;;) {
-            spec[p >> 5] |= 1u << (p & 31u);  // (the words of a segment belong to its lane)
-            bool gap;
-            uint32_t q = tk_rx_next(P, t, p, &gap);
-            if (t.hit && p != first && !TK_RX_IS_ERROR(q)) {
-                // A long piece (it reaches TK_RX_AHEAD bytes beyond the segment) that this lane has come to along its chain: very likely a
-                // true start, and nobody else will evaluate it in parallel -- the lanes of the segments inside the piece stop at their FIRST
-                // evaluation (below), so the text of a long piece is scanned once here instead of once by the resolving lane of its document.
-                t.limit = 0xFFFFFFFFu;
-                t.hit = false;
-                q = tk_rx_next(P, t, p, &gap);
-                t.limit = limit;
-            }
-            if (TK_RX_IS_ERROR(q) || t.hit) break;
-            if (gap) sgap[p >> 5] |= 1u << (p & 31u);
-            if (q >= end) {
-                x = q;
+    bool slow = t.special(p);
+    uint32_t pos = p, last = TK_RX_FAILED, state = (p == 0u || t.hard(p)) ? 2u : 1u;
+    while (!slow) {
+        uint32_t cls = 0u, len = 0u;  // (the end of the haystack)
+        if (pos < t.n) {
+            if (pos >= limit) {  // the match looks too far ahead: the general form decides what to do with this piece
+                slow = true;
                 break;
             }
-            p = q;
+            if (!(pos > p && t.hard(pos))) {
+                const uint32_t b0 = t.byte(pos);
+                if (b0 < 0x80u) {
+                    cls = P.dfa_ascii[b0];
+                    len = 1u;
+                } else {
+                    uint32_t cp = tk_rx_decode(t, pos, &len);
+                    if (cp > 0x10FFFFu) cp = 0xFFFDu;
+                    cls = P.dfa_s2[(uint32_t)P.dfa_s1[cp >> 8] * 256u + (cp & 255u)];
+                }
+            }
         }
+        const uint32_t e = P.dfa_trans[state * ncls + cls];
+        if (e & 0x8000u) last = pos;
+        state = e & 0x7FFFu;
+        if (state != 0u) {
+            pos += len;
+            continue;
+        }
+        // the piece that starts at p is finished: it ends at `last`, or p is a char the pattern does not match (a gap piece of one char)
+        TK_RX_ON_MATCH();
+        TK_RX_ON_DONE(pos - p + 1u);
+        uint32_t q = last;
+        if (last == TK_RX_FAILED) {
+            q = p + 1u;
+            while (q < t.n && !t.hard(q) && (t.byte(q) & 0xC0u) == 0x80u) ++q;
+            if (t.hit) {  // (the char ends at the look-ahead limit: cannot happen within a segment, kept for the general form to decide)
+                t.hit = false;
+                slow = true;
+                break;
+            }
+            gbits |= 1u << (p & 31u);
+        }
+        if (q >= end) {
+            x = q;
+            break;
+        }
+        p = q;
+        note_start(p);
+        if (t.special(p)) {
+            slow = true;
+            break;
+        }
+        pos = p;
+        last = TK_RX_FAILED;
+        state = t.hard(p) ? 2u : 1u;
     }
+    flush();
+    if (slow) x = tk_rx_speculate_chain<true>(P, t, p, first, end, limit, spec, sgap);
     xexit[k] = x;
 }
 
@@ -147,6 +245,7 @@ TK_HD void tk_rx_speculate_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint3
 // chain (lmerge[k] = end of the segment, lexit[k] = where to).  With the links the resolving pass runs the matcher only where a guess was
 // wrong: entering segment k at xexit[k - 1] it takes the link's steps, then the chain's from the meeting point on, and jumps to xexit[k].
 #define TK_RX_NOLINK 0xFFFFFFFFu
+template <bool DFA = false>
 TK_HD void tk_rx_link_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint32_t seg_shift, const uint32_t* spec, const uint32_t* xexit,
                            uint32_t* lnk, uint32_t* lgap, uint32_t* lmerge, uint32_t* lexit) {
     const uint64_t a64 = (uint64_t)k << seg_shift;
@@ -165,7 +264,7 @@ TK_HD void tk_rx_link_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint32_t s
             for (;;) {
                 lnk[p >> 5] |= 1u << (p & 31u);
                 bool gap;
-                const uint32_t q = tk_rx_next(P, t, p, &gap);
+                const uint32_t q = tk_rx_next<DFA>(P, t, p, &gap);
                 if (TK_RX_IS_ERROR(q) || t.hit) break;  // (no link: the resolving lane evaluates this stretch itself)
                 if (gap) lgap[p >> 5] |= 1u << (p & 31u);
                 if (q >= end) {
@@ -247,7 +346,7 @@ TK_HD uint32_t tk_rx_emit(const TkRxMaps& M, const TkRxPlan& R, uint32_t entry, 
 
 // One step of the true chain of the document [.., e) from the true start p: the whole rest of p's segment when the maps answer, one
 // match otherwise.  Returns the next true start (>= e: done) or, with *err set, the position of the failure.
-template <class Or>
+template <bool DFA = false, class Or>
 TK_HD uint32_t tk_rx_resolve_step(const TkRxProg& P, TkRxText& t, const TkRxMaps& M, uint32_t p, uint32_t e, Or&& orbits, uint32_t* err) {
     const TkRxPlan R = tk_rx_plan(M, t.n, p >> M.seg_shift, p, e);
     if (R.ok) {
@@ -258,7 +357,7 @@ TK_HD uint32_t tk_rx_resolve_step(const TkRxProg& P, TkRxText& t, const TkRxMaps
         orbits(p >> 5, 1u << (p & 31u), 0u);
     }
     bool gap;
-    const uint32_t q = tk_rx_next(P, t, p, &gap);
+    const uint32_t q = tk_rx_next<DFA>(P, t, p, &gap);
     if (TK_RX_IS_ERROR(q)) {
         *err = q == TK_RX_OVERFLOW ? TK_RX_ERR_STACK : TK_RX_ERR_LIMIT;
         return p;
@@ -269,13 +368,13 @@ TK_HD uint32_t tk_rx_resolve_step(const TkRxProg& P, TkRxText& t, const TkRxMaps
 
 // One document [b, e) of the chunk by one lane.  `orbits(word index, start bits, gap bits)` ORs into the bitmaps of true starts and of the
 // gap chars among them (shared words: atomic on the device).  Returns 0 or the error bits.
-template <class Or>
+template <bool DFA = false, class Or>
 TK_HD uint32_t tk_rx_resolve_lane(const TkRxProg& P, TkRxText t, const TkRxMaps& M, uint32_t b, uint32_t e, Or&& orbits, uint32_t* err_pos) {
     t.limit = 0xFFFFFFFFu;
     t.hit = false;
     uint32_t p = b, err = 0;
     while (p < e) {
-        p = tk_rx_resolve_step(P, t, M, p, e, orbits, &err);
+        p = tk_rx_resolve_step<DFA>(P, t, M, p, e, orbits, &err);
         if (err) {
             *err_pos = p;
             return err;
@@ -289,7 +388,7 @@ TK_HD uint32_t tk_rx_resolve_lane(const TkRxProg& P, TkRxText t, const TkRxMaps&
 // taken in one go, and the chain continues behind it.  Where lane 0 has no plan the group takes one step of the serial form.  The host
 // form runs the lanes one after the other (the CPU tests); the device form (tk_regex_kernels.h) ballots.
 #define TK_RX_WAVE 64u
-template <class Or>
+template <bool DFA = false, class Or>
 TK_HD uint32_t tk_rx_resolve_group_host(const TkRxProg& P, TkRxText t, const TkRxMaps& M, uint32_t b, uint32_t e, Or&& orbits, uint32_t* err_pos) {
     t.limit = 0xFFFFFFFFu;
     t.hit = false;
@@ -308,7 +407,7 @@ TK_HD uint32_t tk_rx_resolve_group_host(const TkRxProg& P, TkRxText t, const TkR
             --L;
         }
         if (L == 0) {
-            p = tk_rx_resolve_step(P, t, M, p, e, orbits, &err);
+            p = tk_rx_resolve_step<DFA>(P, t, M, p, e, orbits, &err);
             if (err) {
                 *err_pos = p;
                 return err;
