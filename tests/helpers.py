@@ -215,7 +215,7 @@ def sim_lib():
         so = os.path.join(d, "libtk_hostsim.so")
         srcs = [os.path.join(d, "tk_hostsim.cpp")] + [os.path.join(ROOT, "tiktoken_amd", "csrc", f)
                                                        for f in ("tk_tables.cpp", "tk_pattern.cpp", "tk_regex.cpp", "tk_device.h", "tk_common.h", "tk_tables.h", "tk_chunk.h", "tk_regex.h",
-                                                                 "tk_regex_split.h", "tk_regex_host.h")]
+                                                                 "tk_regex_split.h", "tk_regex_host.h", "tk_regex_dfa.inc")]
         def stale():
             return not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs)
 

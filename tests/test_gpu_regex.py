@@ -149,11 +149,23 @@ def test_text_the_pattern_does_not_match_yields_no_tokens():
         assert np.array_equal(toff, ro) and np.array_equal(toks, rt), pat
 
 
-def test_deep_backtracking_is_refused_loudly():
+def test_deep_backtracking_is_refused_loudly(monkeypatch):
+    """A backtracking repeated group in the middle of an alternative: the program keeps a frame per repetition and gives up loudly when its
+    stack is full.  The pattern's DFA (what runs unless $TIKTOKEN_AMD_RX_MATCHER says otherwise; the reference hands a pattern without
+    look-around to the `regex` crate, which does not backtrack either) has no stack to exhaust and splits the text."""
+    monkeypatch.setenv("TIKTOKEN_AMD_RX_MATCHER", "program")
     core = make_core(r"(?:\w\w)*\w!|\w|!")
     assert core.encode_ordinary("abc!abc!") == make_core(r"\w\w\w!").encode_ordinary("abc!abc!")
     with pytest.raises(ValueError, match="possessive"):
         core.encode_ordinary("ab" * 500)
+    monkeypatch.delenv("TIKTOKEN_AMD_RX_MATCHER")
+    table = make_core(r"(?:\w\w)*\w!|\w|!")
+    assert table.encode_ordinary("abc!abc!") == core.encode_ordinary("abc!abc!")
+    assert table.encode_ordinary("ab" * 500) == make_core(r"\w").encode_ordinary("ab" * 500)
+    # (a pattern without a DFA -- look-behind -- keeps the program and its limits)
+    behind = make_core(r"(?:\w\w)*\w!|(?<=b)a|\w|!")
+    with pytest.raises(ValueError, match="possessive"):
+        behind.encode_ordinary("ab" * 500)
     from tiktoken_amd import CoreBPE
 
     with pytest.raises(ValueError, match="look-behind"):
@@ -196,24 +208,37 @@ def test_stock_patterns_through_the_generic_engine_equal_the_scanners(name, mix,
     specials = {**g["special_tokens"], **{f"<|custom_{i}|>": top + 1 + i for i in range(8)}}
     scanners = CoreBPE(h.golden_vocab(name), specials, g["pat_str"])
     monkeypatch.setenv("TIKTOKEN_AMD_DEBUG", "1048576")
-    generic = CoreBPE(h.golden_vocab(name), specials, g["pat_str"])
+    generic = {}
+    for form in ("flat", "dfa", "program"):  # the pattern's DFA with the one-loop speculative pass (the default), piece by piece, the backtracking program
+        monkeypatch.setenv("TIKTOKEN_AMD_RX_MATCHER", form)
+        generic[form] = CoreBPE(h.golden_vocab(name), specials, g["pat_str"])
+    monkeypatch.delenv("TIKTOKEN_AMD_RX_MATCHER")
     monkeypatch.delenv("TIKTOKEN_AMD_DEBUG")
     for allowed in (None, "all"):
         t1, o1 = scanners.encode_batch_packed(blob, off, allowed)
-        t2, o2 = generic.encode_batch_packed(blob, off, allowed)
-        assert np.array_equal(o1, o2), allowed
-        assert np.array_equal(t1, t2), allowed
-        assert np.array_equal(scanners.pretokenize_packed(blob, off, allowed), generic.pretokenize_packed(blob, off, allowed))
+        p1 = scanners.pretokenize_packed(blob, off, allowed)
+        for form, core in generic.items():
+            t2, o2 = core.encode_batch_packed(blob, off, allowed)
+            assert np.array_equal(o1, o2), (allowed, form)
+            assert np.array_equal(t1, t2), (allowed, form)
+            assert np.array_equal(p1, core.pretokenize_packed(blob, off, allowed)), (allowed, form)
 
 
-def test_exploding_backtracking_is_stopped():
+def test_exploding_backtracking_is_stopped(monkeypatch):
     """Nested quantifiers on a text that makes them explode ((?:a+)+b on a run of a's): fancy-regex gives up after 1 000 000 backtracks
-    (Error::BacktrackLimitExceeded -- a panic in the reference, src/lib.rs:365); the GPU matcher has the same kind of budget, so the call
-    fails instead of hanging the device."""
+    (Error::BacktrackLimitExceeded -- a panic in the reference, src/lib.rs:365); the GPU program has the same kind of budget, so the call
+    fails instead of hanging the device.  A pattern that has a DFA never backtracks (nor does the reference for a pattern without
+    look-around: fancy-regex hands it to the `regex` crate): linear, and right."""
+    monkeypatch.setenv("TIKTOKEN_AMD_RX_MATCHER", "program")
     core = make_core(r"(?:a+)+b|[\s\S]")
     assert core.encode_ordinary("aaab aab") == make_core(r"a+b|[\s\S]").encode_ordinary("aaab aab")
     with pytest.raises(ValueError, match="backtrack limit"):
         core.encode_ordinary("a" * 26)
+    monkeypatch.delenv("TIKTOKEN_AMD_RX_MATCHER")
+    table = make_core(r"(?:a+)+b|[\s\S]")
+    assert table.encode_ordinary("a" * 26 + " aab") == make_core(r"[\s\S]").encode_ordinary("a" * 26 + " ") + make_core(r"a+b").encode_ordinary("aab")
+    with pytest.raises(ValueError, match="backtrack limit"):  # (look-ahead of two chars: no DFA)
+        make_core(r"(?:a+)+b(?!xy)|[\s\S]").encode_ordinary("a" * 26)
 
 
 def test_golden_vectors_of_generic_patterns():
@@ -238,10 +263,11 @@ def test_golden_vectors_of_generic_patterns():
     assert n > 100_000
 
 
-def generated_patterns_on_the_device(seed: int, n_patterns: int, with_tokens_every: int = 4):
+def generated_patterns_on_the_device(seed: int, n_patterns: int, with_tokens_every: int = 4, table_form: bool = False):
     """Random patterns over the whole supported syntax (the generator of the CPU test, tests/test_regex_engine.py::_gen_pattern) compiled
     and run ON THE DEVICE: split and gap chars of a batch of short texts against Python `regex`, tokens of every few patterns against the
-    oracle's byte_pair_encode.  Returns (patterns run, patterns the device gave up on loudly)."""
+    oracle's byte_pair_encode.  table_form: only patterns that have a DFA (the kernels' table form).  Returns (patterns run, patterns the
+    device gave up on loudly)."""
     from test_regex_engine import _gen_pattern
 
     rng = random.Random(seed)
@@ -251,7 +277,7 @@ def generated_patterns_on_the_device(seed: int, n_patterns: int, with_tokens_eve
     C = h.c_oracle_for(NAME)
     ran = gave_up = 0
     while ran + gave_up < n_patterns:
-        eng, py = _gen_pattern(rng)
+        eng, py = _gen_pattern(rng, table_form)
         if "(?i:" in eng and r"[^a\s]" in eng:  # (a scoping bug of `regex` 2026.7.19: see the CPU test)
             continue
         pyc = regex.compile(py)
@@ -288,3 +314,5 @@ def generated_patterns_on_the_device(seed: int, n_patterns: int, with_tokens_eve
 def test_generated_patterns_on_the_device():
     ran, gave_up = generated_patterns_on_the_device(20260923, 40)
     assert ran >= 30, (ran, gave_up)
+    ran, gave_up = generated_patterns_on_the_device(20260924, 40, table_form=True)
+    assert ran == 40 and gave_up == 0, (ran, gave_up)  # (a DFA has neither a stack nor a budget to exhaust)

@@ -117,7 +117,8 @@ struct tk_core {
     TkRxCompiled rx_fb;
     uint64_t st_fallbacks = 0;  // chunks that took that way
     TkRxDev rx{};
-    Buf t_rx_ins, t_rx_sets, t_rx_ranges, t_rx_first, t_rx_s1, t_rx_s2;
+    Buf t_rx_ins, t_rx_sets, t_rx_ranges, t_rx_first, t_rx_s1, t_rx_s2, t_rx_dtrans, t_rx_dascii, t_rx_ds1, t_rx_ds2;
+    int rx_form = TK_RX_FORM_PROGRAM;  // how the generic engine's kernels match: the pattern's DFA where it has one ($TIKTOKEN_AMD_RX_MATCHER)
     std::mutex mu;
     // workspace: per chunk in flight, and what a whole call shares
     WorkSet ws[TK_NSET];
@@ -319,7 +320,26 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
         TRY(upload(c->t_rx_s2, tk_rx_props_stage2(), (size_t)tk_rx_props_blocks() * 256));
         c->rx = TkRxDev{c->t_rx_ins.as<TkRxIns>(), c->t_rx_sets.as<TkRxSet>(), c->t_rx_ranges.as<uint32_t>(), c->t_rx_s1.as<uint8_t>(),
                         c->t_rx_s2.as<uint8_t>(), (uint32_t)X.ins.size(), (uint32_t)X.sets.size(), (uint32_t)X.ranges.size() / 2,
-                        c->t_rx_first.as<uint32_t>(), (uint32_t)X.first.size() / 8};
+                        c->t_rx_first.as<uint32_t>(), (uint32_t)X.first.size() / 8, nullptr, nullptr, nullptr, nullptr, 0u, 0u};
+        c->rx_form = TK_RX_FORM_PROGRAM;
+        // the pattern's DFA (tk_regex_dfa.inc), where it has one: $TIKTOKEN_AMD_RX_MATCHER = program | dfa | flat (the default) chooses the
+        // kernels' form -- "dfa" keeps the piece-by-piece speculative lane, "program" interprets the backtracking program as before
+        const char* want = getenv("TIKTOKEN_AMD_RX_MATCHER");
+        if (X.has_dfa() && !(want && !strcmp(want, "program"))) {
+            std::vector<uint16_t> tr(X.dfa_trans);
+            tr.resize((tr.size() + 1) & ~(size_t)1, 0);  // (whole 32-bit words: the kernels copy it to LDS word by word)
+            TRY(upload(c->t_rx_dtrans, tr.data(), tr.size() * 2));
+            TRY(upload(c->t_rx_dascii, X.dfa_ascii.data(), 128));
+            TRY(upload(c->t_rx_ds1, X.dfa_s1.data(), X.dfa_s1.size() * 2));
+            TRY(upload(c->t_rx_ds2, X.dfa_s2.data(), X.dfa_s2.size()));
+            c->rx.dfa_trans = c->t_rx_dtrans.as<uint16_t>();
+            c->rx.dfa_ascii = c->t_rx_dascii.as<uint8_t>();
+            c->rx.dfa_s1 = c->t_rx_ds1.as<uint16_t>();
+            c->rx.dfa_s2 = c->t_rx_ds2.as<uint8_t>();
+            c->rx.dfa_ncls = X.dfa_ncls;
+            c->rx.dfa_nstates = X.dfa_nstates;
+            c->rx_form = (want && !strcmp(want, "dfa")) ? TK_RX_FORM_DFA : TK_RX_FORM_DFA_FLAT;
+        }
         return TK_OK;
     };
     if (H.rx.empty()) {
@@ -425,7 +445,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
 extern "C" void tk_destroy(tk_core* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
-    for (Buf* b : {&c->t_rx_ins, &c->t_rx_sets, &c->t_rx_ranges, &c->t_rx_first, &c->t_rx_s1, &c->t_rx_s2}) release(*b);
+    for (Buf* b : {&c->t_rx_ins, &c->t_rx_sets, &c->t_rx_ranges, &c->t_rx_first, &c->t_rx_s1, &c->t_rx_s2, &c->t_rx_dtrans, &c->t_rx_dascii, &c->t_rx_ds1, &c->t_rx_ds2}) release(*b);
     for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_dec, &c->d_tok, &c->d_lens, &c->d_bsum, &c->d_tboff, &c->d_bytes, &c->d_boff, &c->t_piece,
                    &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2, &c->t_byte_rank, &c->t_hot, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off,
                    &c->out_tokens, &c->out_tok_off, &c->allowed, &c->tok_bases})
@@ -522,24 +542,38 @@ static int rx_split(tk_core* c, WorkSet& w, hipStream_t s, const uint8_t* d_text
     TRY(ensure(w.rx_exit, 3 * (nseg + 2) * 4));  // exit of every segment's chain; where the link met it; where the link left the segment
     uint32_t *spec = w.rx_spec.as<uint32_t>(), *gst = w.rx_gst.as<uint32_t>(), *xexit = w.rx_exit.as<uint32_t>();
     uint32_t *lnk = w.rx_lnk.as<uint32_t>(), *lmerge = xexit + nseg + 2, *lexit = xexit + 2 * (nseg + 2);
+    // (the kernels' form: the pattern's DFA in LDS -- its speculative pass as one loop -- or the backtracking program; tk_regex_kernels.h)
+    const uint32_t lds = c->rx_form == TK_RX_FORM_PROGRAM ? 0u : tk_rx_dfa_lds_bytes(c->rx);
+    auto by_form = [&](auto&& launch) {
+        if (c->rx_form == TK_RX_FORM_DFA_FLAT) launch(std::integral_constant<int, TK_RX_FORM_DFA_FLAT>{});
+        else if (c->rx_form == TK_RX_FORM_DFA) launch(std::integral_constant<int, TK_RX_FORM_DFA>{});
+        else launch(std::integral_constant<int, TK_RX_FORM_PROGRAM>{});
+    };
     TRY(timed(c, s, "tk_k_rx_speculate", [&] {
-        hipLaunchKernelGGL(tk_k_rx_speculate, dim3(grid_for(nseg, 256, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, seg_shift, spec, spec + nwords + 2, xexit);
+        by_form([&](auto form) {
+            hipLaunchKernelGGL(tk_k_rx_speculate<decltype(form)::value>, dim3(grid_for(nseg, 256, 65536)), dim3(256), lds, s, c->rx, d_text, (uint32_t)n, brk, ss, si, seg_shift,
+                               spec, spec + nwords + 2, xexit);
+        });
     }));
     const bool links = !(c->dbg & 0x20000);  // (debug bit 0x20000: no link pass -- the resolving pass matches its way from one chain to the next)
     if (links) {
         TRY(timed(c, s, "tk_k_rx_link", [&] {
-            hipLaunchKernelGGL(tk_k_rx_link, dim3(grid_for(nseg, 256, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, seg_shift, spec, xexit,
-                               lnk, lnk + nwords + 2, lmerge, lexit);
+            by_form([&](auto form) {
+                hipLaunchKernelGGL(tk_k_rx_link<decltype(form)::value>, dim3(grid_for(nseg, 256, 65536)), dim3(256), lds, s, c->rx, d_text, (uint32_t)n, brk, ss, si, seg_shift,
+                                   spec, xexit, lnk, lnk + nwords + 2, lmerge, lexit);
+            });
         }));
     }
     const TkRxMaps maps{spec, spec + nwords + 2, xexit, links ? lnk : (const uint32_t*)nullptr, lnk + nwords + 2, lmerge, lexit, seg_shift};
     TRY(timed(c, s, "tk_k_rx_resolve", [&] {
-        if (c->dbg & 0x40000)  // (debug bit 0x40000: one lane per document instead of one wavefront)
-            hipLaunchKernelGGL(tk_k_rx_resolve, dim3(grid_for(n_docs, 256, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, d_doc_off, n_docs,
-                               base, maps, gst, gst + nwords + 2, counters);
-        else
-            hipLaunchKernelGGL(tk_k_rx_resolve_wave, dim3(grid_for(n_docs, 4, 65536)), dim3(256), 0, s, c->rx, d_text, (uint32_t)n, brk, ss, si, d_doc_off, n_docs,
-                               base, maps, gst, gst + nwords + 2, counters);
+        by_form([&](auto form) {
+            if (c->dbg & 0x40000)  // (debug bit 0x40000: one lane per document instead of one wavefront)
+                hipLaunchKernelGGL(tk_k_rx_resolve<decltype(form)::value>, dim3(grid_for(n_docs, 256, 65536)), dim3(256), lds, s, c->rx, d_text, (uint32_t)n, brk, ss, si,
+                                   d_doc_off, n_docs, base, maps, gst, gst + nwords + 2, counters);
+            else
+                hipLaunchKernelGGL(tk_k_rx_resolve_wave<decltype(form)::value>, dim3(grid_for(n_docs, 4, 65536)), dim3(256), lds, s, c->rx, d_text, (uint32_t)n, brk, ss, si,
+                                   d_doc_off, n_docs, base, maps, gst, gst + nwords + 2, counters);
+        });
     }));
     TRY(timed(c, s, "tk_k_rx_merge", [&] { hipLaunchKernelGGL(tk_k_rx_merge, dim3(grid_for(nwords, 256, 4096)), dim3(256), 0, s, brk, gst, nwords); }));
     return TK_OK;

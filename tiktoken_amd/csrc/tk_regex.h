@@ -147,6 +147,16 @@ TK_HD uint32_t tk_rx_decode(A& t, uint32_t pos, uint32_t* len) {
 // alternative of the pattern its text is in.  Leftmost-first semantics are in the table (tk_regex_dfa.inc: a state is an ORDERED list of
 // NFA states, a match cuts off everything of lower priority, assertions about the next char are resolved by the class of that char), so
 // the end of the match is the last position at which a transition said "match": exactly what tk_rx_match returns for the same pattern.
+// class of an ASCII byte.  (Device: read as a word of the table in LDS -- a byte load here would be merged with the byte load of the
+// non-ASCII path, which reads global memory, into one load through a generic pointer.)
+TK_HD uint32_t tk_rx_ascii_cls(const TkRxProg& P, uint32_t b0) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return (((const uint32_t*)P.dfa_ascii)[b0 >> 2] >> (8u * (b0 & 3u))) & 0xFFu;
+#else
+    return P.dfa_ascii[b0];
+#endif
+}
+
 template <class A>
 TK_HD uint32_t tk_rx_match_dfa(const TkRxProg& P, A& t, uint32_t start) {
     const uint32_t ncls = P.dfa_ncls;
@@ -157,7 +167,7 @@ TK_HD uint32_t tk_rx_match_dfa(const TkRxProg& P, A& t, uint32_t start) {
         if (pos < t.n && !(pos > start && t.hard(pos))) {
             const uint32_t b0 = t.byte(pos);
             if (b0 < 0x80u) {
-                cls = P.dfa_ascii[b0];
+                cls = tk_rx_ascii_cls(P, b0);
                 len = 1u;
             } else {
                 uint32_t cp = tk_rx_decode(t, pos, &len);

@@ -13,9 +13,13 @@
 //                       in which every char is a letter: its scanners then cut at hard starts and nowhere else, and everything behind the
 //                       split -- whole-piece probe, de-duplication, merges, long pieces, token copy -- is the pipeline of the stock patterns.
 //
-// The program (<= 15 KiB) is copied to LDS by every workgroup; the property table (42 KiB) stays in global memory (L2).  Integer work,
-// data-dependent branches, one lane per unit: this path is bound by divergence and latency, not by HBM -- it exists so that no pat_str
-// is refused, the three stock families keep their hand-written scanners.
+// Two forms of every kernel (template parameter FORM).  Where the pattern has a DFA (tk_regex_dfa.inc: the stock patterns, Qwen / Llama /
+// DeepSeek / Kimi-style ones -- anything without look-behind, \b, look-ahead of several chars or atomic groups around groups) the matcher
+// is one table look-up per char: the transition table (states x classes x 2 bytes: 2 KiB for o200k's pat_str) and the ASCII class table sit
+// in LDS, the classes of non-ASCII chars come from a two-stage table in global memory (L2); every lane of a wavefront runs the same loop,
+// and the speculative pass is ONE loop over the chars of a lane's segment (tk_rx_speculate_lane_flat).  Otherwise the backtracking program
+// (<= 19 KiB) is copied to LDS by every workgroup and interpreted, the property table (42 KiB) stays in global memory: integer work,
+// data-dependent branches, every lane in a different instruction -- bound by divergence, it exists so that no pat_str is refused.
 #pragma once
 #include "tk_regex_host.h"
 #include "tk_regex_split.h"
@@ -29,7 +33,16 @@ struct TkRxDev {  // the compiled program in device memory
     uint32_t n_ins, n_sets, n_ranges;
     const uint32_t* first;
     uint32_t n_first;
+    // the DFA (null: none): the transition table padded to whole 32-bit words, the ASCII classes (128 bytes), the two-stage class table
+    const uint16_t* dfa_trans;
+    const uint8_t* dfa_ascii;
+    const uint16_t* dfa_s1;
+    const uint8_t* dfa_s2;
+    uint32_t dfa_ncls, dfa_nstates;
 };
+enum { TK_RX_FORM_PROGRAM = 0, TK_RX_FORM_DFA = 1, TK_RX_FORM_DFA_FLAT = 2 };  // (FLAT: the speculative pass as one loop; the other kernels as DFA)
+// bytes of dynamic LDS the DFA forms need
+static inline uint32_t tk_rx_dfa_lds_bytes(const TkRxDev& R) { return ((R.dfa_nstates * R.dfa_ncls + 1u) / 2u) * 4u + 128u; }
 
 struct TkRxLds {
     TkRxIns ins[TK_RX_MAX_INS];
@@ -51,41 +64,71 @@ __device__ __forceinline__ TkRxProg tk_rx_stage_program(const TkRxDev& R, TkRxLd
     return TkRxProg{L->ins, L->sets, L->ranges, R.stage1, R.stage2, R.n_ins, R.n_sets, R.n_ranges, L->first, R.n_first};
 }
 
+// the DFA's tables in (dynamic) LDS
+__device__ __forceinline__ TkRxProg tk_rx_stage_dfa(const TkRxDev& R, uint32_t* lds) {
+    // (the ASCII classes first: both tables at constant offsets from the start of LDS, so that every look-up is a ds_read)
+    const uint32_t nt = (R.dfa_nstates * R.dfa_ncls + 1u) / 2u;
+    const uint32_t* st = (const uint32_t*)R.dfa_trans;
+    const uint32_t* sa = (const uint32_t*)R.dfa_ascii;
+    for (uint32_t i = threadIdx.x; i < 32u; i += blockDim.x) lds[i] = sa[i];
+    for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[32u + i] = st[i];
+    __syncthreads();
+    TkRxProg P{};
+    P.dfa_ascii = (const uint8_t*)lds;
+    P.dfa_trans = (const uint16_t*)(lds + 32);
+    P.dfa_s1 = R.dfa_s1;
+    P.dfa_s2 = R.dfa_s2;
+    P.dfa_ncls = R.dfa_ncls;
+    return P;
+}
+extern __shared__ uint32_t tk_rx_dyn_lds[];
+#define TK_RX_STAGE(P, R)                                  \
+    TkRxProg P;                                            \
+    if constexpr (FORM != TK_RX_FORM_PROGRAM) {            \
+        P = tk_rx_stage_dfa(R, tk_rx_dyn_lds);             \
+    } else {                                               \
+        __shared__ TkRxLds L;                              \
+        P = tk_rx_stage_program(R, &L);                    \
+    }
+
+template <int FORM>
 __global__ __launch_bounds__(256) void tk_k_rx_speculate(TkRxDev R, const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ brk,
                                                          const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, uint32_t seg_shift,
                                                          uint32_t* __restrict__ spec, uint32_t* __restrict__ sgap, uint32_t* __restrict__ xexit) {
-    __shared__ TkRxLds L;
-    const TkRxProg P = tk_rx_stage_program(R, &L);
+    TK_RX_STAGE(P, R)
     const uint32_t nseg = (uint32_t)(((uint64_t)n + (1u << seg_shift) - 1u) >> seg_shift);
     const TkRxText t{text, n, brk, ss, si, 0xFFFFFFFFu, false};
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += gridDim.x * blockDim.x) tk_rx_speculate_lane(P, t, k, seg_shift, spec, sgap, xexit);
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += gridDim.x * blockDim.x) {
+        if constexpr (FORM == TK_RX_FORM_DFA_FLAT) tk_rx_speculate_lane_flat(P, t, k, seg_shift, spec, sgap, xexit);
+        else tk_rx_speculate_lane<FORM != TK_RX_FORM_PROGRAM>(P, t, k, seg_shift, spec, sgap, xexit);
+    }
 }
 
+template <int FORM>
 __global__ __launch_bounds__(256) void tk_k_rx_link(TkRxDev R, const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ brk,
                                                     const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, uint32_t seg_shift,
                                                     const uint32_t* __restrict__ spec, const uint32_t* __restrict__ xexit, uint32_t* __restrict__ lnk,
                                                     uint32_t* __restrict__ lgap, uint32_t* __restrict__ lmerge, uint32_t* __restrict__ lexit) {
-    __shared__ TkRxLds L;
-    const TkRxProg P = tk_rx_stage_program(R, &L);
+    TK_RX_STAGE(P, R)
     const uint32_t nseg = (uint32_t)(((uint64_t)n + (1u << seg_shift) - 1u) >> seg_shift);
     const TkRxText t{text, n, brk, ss, si, 0xFFFFFFFFu, false};
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += gridDim.x * blockDim.x)
-        tk_rx_link_lane(P, t, k, seg_shift, spec, xexit, lnk, lgap, lmerge, lexit);
+        tk_rx_link_lane<FORM != TK_RX_FORM_PROGRAM>(P, t, k, seg_shift, spec, xexit, lnk, lgap, lmerge, lexit);
 }
 
 // one lane per document (debug bit 0x40000; the CPU tests run this form lane by lane)
+template <int FORM>
 __global__ __launch_bounds__(256) void tk_k_rx_resolve(TkRxDev R, const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ brk,
                                                        const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si,
                                                        const uint64_t* __restrict__ doc_off, uint64_t n_docs, uint64_t base, TkRxMaps M,
                                                        uint32_t* __restrict__ gst, uint32_t* __restrict__ ggap, uint32_t* __restrict__ counters) {
-    __shared__ TkRxLds L;
-    const TkRxProg P = tk_rx_stage_program(R, &L);
+    TK_RX_STAGE(P, R)
     const TkRxText t{text, n, brk, ss, si, 0xFFFFFFFFu, false};
     for (uint64_t d = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; d < n_docs; d += (uint64_t)gridDim.x * blockDim.x) {
         const uint64_t b = doc_off[d] - base, e = doc_off[d + 1] - base;
         if (b >= e || e > n) continue;
         uint32_t err_pos = 0;
-        const uint32_t err = tk_rx_resolve_lane(P, t, M, (uint32_t)b, (uint32_t)e,
+        const uint32_t err = tk_rx_resolve_lane<FORM != TK_RX_FORM_PROGRAM>(P, t, M, (uint32_t)b, (uint32_t)e,
                                                 [&](uint32_t w, uint32_t bits, uint32_t gaps) {
                                                     if (bits) atomicOr(&gst[w], bits);
                                                     if (gaps) atomicOr(&ggap[w], gaps);
@@ -103,12 +146,12 @@ __global__ __launch_bounds__(256) void tk_k_rx_resolve(TkRxDev R, const uint8_t*
 // lane's entry -- is taken at once, 64 segments per step.  Where lane 0 has no plan the wavefront takes one step of the serial form (all
 // lanes run it on the same arguments: uniform control flow, lane 0 writes).  A single document of many megabytes is resolved by its
 // wavefront at the rate of its memory operations, not of one lane's matcher.
+template <int FORM>
 __global__ __launch_bounds__(256) void tk_k_rx_resolve_wave(TkRxDev R, const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ brk,
                                                             const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si,
                                                             const uint64_t* __restrict__ doc_off, uint64_t n_docs, uint64_t base, TkRxMaps M,
                                                             uint32_t* __restrict__ gst, uint32_t* __restrict__ ggap, uint32_t* __restrict__ counters) {
-    __shared__ TkRxLds L;
-    const TkRxProg P = tk_rx_stage_program(R, &L);
+    TK_RX_STAGE(P, R)
     const uint32_t lane = threadIdx.x & 63u;
     const uint64_t wave = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * blockDim.x) >> 6;
     auto orb_all = [&](uint32_t w, uint32_t bits, uint32_t gaps) {
@@ -137,7 +180,7 @@ __global__ __launch_bounds__(256) void tk_k_rx_resolve_wave(TkRxDev R, const uin
             uint32_t len = bad ? (uint32_t)__ffsll((unsigned long long)bad) - 1u : 64u;
             if (len && (uint32_t)__shfl((int)plan.exit, (int)len - 1, 64) == TK_RX_UNKNOWN) --len;  // (that segment's guess broke off: the serial step's)
             if (len == 0u) {
-                p = tk_rx_resolve_step(P, t, M, p, e, orb_lane0, &err);
+                p = tk_rx_resolve_step<FORM != TK_RX_FORM_PROGRAM>(P, t, M, p, e, orb_lane0, &err);
                 if (err) break;
                 continue;
             }

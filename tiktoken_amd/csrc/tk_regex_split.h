@@ -51,20 +51,34 @@ struct TkRxText {
     const uint32_t* si;   // special-token interiors
     uint32_t limit;       // a speculative match sees the end of the text here ...
     bool hit;             // ... and says so
-    // the text word and the bitmap word read last: a lane walks its text byte by byte, one load per four bytes / thirty-two positions
+    // the text and the bitmap word read last: a lane walks its text byte by byte, one load per sixteen bytes (device; the lanes of a
+    // wavefront read sixty-four different cache lines per load instruction: fewer, wider loads) / four bytes (host) / thirty-two positions
     uint32_t tw_at = 0xFFFFFFFFu, tw = 0, bw_at = 0xFFFFFFFFu, bw = 0;
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t tq1 = 0, tq2 = 0, tq3 = 0;  // (with tw: the sixteen bytes at 16 * tw_at)
+    TK_HD uint32_t byte(uint32_t p) {
+        const uint32_t i = p >> 4;
+        if (i != tw_at) {
+            tw_at = i;
+            const uint4 q = *(const uint4*)(text + 16u * (size_t)i);  // (the chunk's text is 16-byte aligned and readable 64 bytes past n)
+            tw = q.x;
+            tq1 = q.y;
+            tq2 = q.z;
+            tq3 = q.w;
+        }
+        const uint32_t lo = (p & 8u) ? tq2 : tw, hi = (p & 8u) ? tq3 : tq1;
+        return (((p & 4u) ? hi : lo) >> (8u * (p & 3u))) & 0xFFu;
+    }
+#else
     TK_HD uint32_t byte(uint32_t p) {
         const uint32_t i = p >> 2;
         if (i != tw_at) {
             tw_at = i;
-#if defined(__HIP_DEVICE_COMPILE__)
-            tw = *(const uint32_t*)(text + 4u * (size_t)i);  // (the chunk's text is 16-byte aligned and readable 64 bytes past n)
-#else
             __builtin_memcpy(&tw, text + 4u * (size_t)i, 4);
-#endif
         }
         return (tw >> (8u * (p & 3u))) & 0xFFu;
     }
+#endif
     TK_HD bool hard(uint32_t p) {
         if (p >= limit) {
             hit = true;
@@ -189,7 +203,7 @@ TK_HD void tk_rx_speculate_lane_flat(const TkRxProg& P, TkRxText t, uint32_t k, 
             if (!(pos > p && t.hard(pos))) {
                 const uint32_t b0 = t.byte(pos);
                 if (b0 < 0x80u) {
-                    cls = P.dfa_ascii[b0];
+                    cls = tk_rx_ascii_cls(P, b0);
                     len = 1u;
                 } else {
                     uint32_t cp = tk_rx_decode(t, pos, &len);
