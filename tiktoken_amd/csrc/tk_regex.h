@@ -67,7 +67,7 @@ struct TkRxProg {
     // classes of code points no set of the pattern tells apart: ASCII through dfa_ascii[128], the rest through the two-stage table.
     const uint16_t* dfa_trans = nullptr;
     const uint8_t* dfa_ascii = nullptr;
-    const uint16_t* dfa_s1 = nullptr;  // [0x1100] -> block of dfa_s2
+    const uint16_t* dfa_s1 = nullptr;  // [0x1100]: bit 15 set -> the class of all 256 code points (CJK, Hangul, unassigned planes: no second look-up); else block of dfa_s2
     const uint8_t* dfa_s2 = nullptr;   // blocks of 256 classes
     uint32_t dfa_ncls = 0;
 };
@@ -147,6 +147,12 @@ TK_HD uint32_t tk_rx_decode(A& t, uint32_t pos, uint32_t* len) {
 // alternative of the pattern its text is in.  Leftmost-first semantics are in the table (tk_regex_dfa.inc: a state is an ORDERED list of
 // NFA states, a match cuts off everything of lower priority, assertions about the next char are resolved by the class of that char), so
 // the end of the match is the last position at which a transition said "match": exactly what tk_rx_match returns for the same pattern.
+// class of a code point beyond ASCII
+TK_HD uint32_t tk_rx_dfa_cls(const TkRxProg& P, uint32_t cp) {
+    if (cp > 0x10FFFFu) cp = 0xFFFDu;
+    const uint32_t e = P.dfa_s1[cp >> 8];
+    return (e & 0x8000u) ? (e & 0xFFu) : P.dfa_s2[e * 256u + (cp & 255u)];
+}
 // class of an ASCII byte.  (Device: read as a word of the table in LDS -- a byte load here would be merged with the byte load of the
 // non-ASCII path, which reads global memory, into one load through a generic pointer.)
 TK_HD uint32_t tk_rx_ascii_cls(const TkRxProg& P, uint32_t b0) {
@@ -170,9 +176,7 @@ TK_HD uint32_t tk_rx_match_dfa(const TkRxProg& P, A& t, uint32_t start) {
                 cls = tk_rx_ascii_cls(P, b0);
                 len = 1u;
             } else {
-                uint32_t cp = tk_rx_decode(t, pos, &len);
-                if (cp > 0x10FFFFu) cp = 0xFFFDu;
-                cls = P.dfa_s2[(uint32_t)P.dfa_s1[cp >> 8] * 256u + (cp & 255u)];
+                cls = tk_rx_dfa_cls(P, tk_rx_decode(t, pos, &len));
             }
         }
         const uint32_t e = P.dfa_trans[state * ncls + cls];

@@ -42,7 +42,7 @@ struct TkRxDev {  // the compiled program in device memory
 };
 enum { TK_RX_FORM_PROGRAM = 0, TK_RX_FORM_DFA = 1, TK_RX_FORM_DFA_FLAT = 2 };  // (FLAT: the speculative pass as one loop; the other kernels as DFA)
 // bytes of dynamic LDS the DFA forms need
-static inline uint32_t tk_rx_dfa_lds_bytes(const TkRxDev& R) { return ((R.dfa_nstates * R.dfa_ncls + 1u) / 2u) * 4u + 128u; }
+static inline uint32_t tk_rx_dfa_lds_bytes(const TkRxDev& R) { return ((R.dfa_nstates * R.dfa_ncls + 1u) / 2u) * 4u + 128u + 0x1100u * 2u; }
 
 struct TkRxLds {
     TkRxIns ins[TK_RX_MAX_INS];
@@ -66,18 +66,21 @@ __device__ __forceinline__ TkRxProg tk_rx_stage_program(const TkRxDev& R, TkRxLd
 
 // the DFA's tables in (dynamic) LDS
 __device__ __forceinline__ TkRxProg tk_rx_stage_dfa(const TkRxDev& R, uint32_t* lds) {
-    // (the ASCII classes first: both tables at constant offsets from the start of LDS, so that every look-up is a ds_read)
+    // (the ASCII classes, then the first stage of the class table, then the transitions: all at constant offsets from the start of LDS,
+    // so that every look-up is a ds_read)
     const uint32_t nt = (R.dfa_nstates * R.dfa_ncls + 1u) / 2u;
     const uint32_t* st = (const uint32_t*)R.dfa_trans;
     const uint32_t* sa = (const uint32_t*)R.dfa_ascii;
+    const uint32_t* s1 = (const uint32_t*)R.dfa_s1;
     for (uint32_t i = threadIdx.x; i < 32u; i += blockDim.x) lds[i] = sa[i];
-    for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[32u + i] = st[i];
+    for (uint32_t i = threadIdx.x; i < 0x880u; i += blockDim.x) lds[32u + i] = s1[i];
+    for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[32u + 0x880u + i] = st[i];
     __syncthreads();
     TkRxProg P{};
     P.dfa_ascii = (const uint8_t*)lds;
-    P.dfa_trans = (const uint16_t*)(lds + 32);
-    P.dfa_s1 = R.dfa_s1;
-    P.dfa_s2 = R.dfa_s2;
+    P.dfa_s1 = (const uint16_t*)(lds + 32);
+    P.dfa_trans = (const uint16_t*)(lds + 32 + 0x880);
+    P.dfa_s2 = R.dfa_s2;  // (the second stage: global memory, L2)
     P.dfa_ncls = R.dfa_ncls;
     return P;
 }

@@ -206,9 +206,7 @@ TK_HD void tk_rx_speculate_lane_flat(const TkRxProg& P, TkRxText t, uint32_t k, 
                     cls = tk_rx_ascii_cls(P, b0);
                     len = 1u;
                 } else {
-                    uint32_t cp = tk_rx_decode(t, pos, &len);
-                    if (cp > 0x10FFFFu) cp = 0xFFFDu;
-                    cls = P.dfa_s2[(uint32_t)P.dfa_s1[cp >> 8] * 256u + (cp & 255u)];
+                    cls = tk_rx_dfa_cls(P, tk_rx_decode(t, pos, &len));
                 }
             }
         }
