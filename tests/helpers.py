@@ -377,9 +377,11 @@ class RxSim:
         if matcher == "dfa":
             assert self.dfa, self.dfa_why
             got = self._split(docs, specials, int(speculate) | 16)
+            gaps = self.gaps
             if int(speculate) & 3:  # (the one-loop form of the speculative lanes, which is what the device runs)
-                gaps = self.gaps
                 assert self._split(docs, specials, int(speculate) | 48) == got and self.gaps == gaps, "the two forms of the DFA's speculative pass disagree"
+            else:  # (no speculation, documents by groups of lanes: EVERY piece is matched by the group together -- tk_rx_match_dfa_coop)
+                assert self._split(docs, specials, 8 | 16) == got and self.gaps == gaps, "the group's matcher and the lane's disagree"
             return got
         got = self._split(docs, specials, int(speculate))
         if matcher == "both" and self.dfa:

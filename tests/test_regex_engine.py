@@ -477,7 +477,7 @@ def test_first_byte_pruning_is_exact(monkeypatch):
             monkeypatch.setenv("TIKTOKEN_AMD_RX_NO_PRUNING", "1")
         rx = h.RxSim(h.PAT_STR[2])
         s0 = L.tks_rx_steps()
-        work.append((rx.split(docs, speculate=0), L.tks_rx_steps() - s0))
+        work.append((rx.split(docs, speculate=0, matcher="program"), L.tks_rx_steps() - s0))  # (the program's steps: the table form has none to prune)
     assert work[0][0] == work[1][0]
     assert work[0][1] < 0.65 * work[1][1], (work[0][1], work[1][1])  # (o200k on web text: 17 steps per piece instead of 32)
 
@@ -629,3 +629,37 @@ def test_split_equals_oniguruma_where_the_dialects_agree(idx):
     quirk = r"(?i:k)|[^a\s]"
     onig = tokenizers.pre_tokenizers.Split(tokenizers.Regex(quirk), behavior="isolated")
     assert [a for _, (a, _b) in onig.pre_tokenize_str("AkK")] == h.RxSim(quirk).split([b"AkK"]) == [0, 1, 2]
+
+
+def test_long_runs_matched_by_a_group_of_lanes():
+    """tk_rx_match_dfa_coop: a piece that stays in one state of the pattern's DFA is scanned a KiB per step by the lanes of a group (the
+    resolving wavefront on the device).  Runs of chars of every UTF-8 length, of every length around the scan's window and block sizes,
+    ending at the end of the text, at a document boundary, at a special token, at a char of another class; a run with the odd char in it.
+    (split(..., speculate=0, matcher="dfa") walks every document with one lane AND with a group that matches every piece together.)"""
+    sp = "<|endoftext|>"
+    for pat in (h.PAT_STR[2], r"\w+|[^\w\s]+|\s+", r"\p{L}+(?!\p{N})|\p{N}{1,3}|\s+$|[\s\S]"):
+        rx = h.RxSim(pat)
+        assert rx.dfa
+        rng = random.Random(len(pat))
+        docs, specials, at = [], [], 0
+        for unit in ("a", "ǅ", "中", "😀", " ", "\n"):
+            for n in (15, 16, 17, 40, 500, 1023, 1024, 1025, 2050, 6000):
+                for tail in ("", "1", sp, "\r\n x"):
+                    lead = rng.choice(["", "x", " ", "12", "中"]) * rng.randrange(0, 4)
+                    body = unit * n
+                    if n > 1000 and rng.random() < 0.3:  # one odd char somewhere in the run
+                        k = rng.randrange(1, n)
+                        body = unit * k + rng.choice(["1", ".", "ő", " "]) + unit * (n - k)
+                    text = lead + body + tail
+                    if tail == sp:
+                        specials.append((at + len((lead + body).encode()), len(sp)))
+                    docs.append(text.encode())
+                    at += len(docs[-1])
+        want = rx.split(docs, specials, speculate=0, matcher="dfa")
+        assert want == rx.split(docs, specials, speculate=5, matcher="program")
+        for mode in (13, 14):  # (behind the speculative pass: the group matches where the guesses broke off)
+            assert rx.split(docs, specials, speculate=mode, matcher="dfa") == want, (pat, mode)
+        one = [("中" * 60_000 + " tail").encode(), ("x" * 200_000).encode(), b"", (" " * 50_000 + "a").encode()]
+        want = rx.split(one, speculate=0, matcher="dfa")
+        for mode in (13, 14):
+            assert rx.split(one, speculate=mode, matcher="dfa") == want, (pat, mode)

@@ -189,6 +189,141 @@ TK_HD uint32_t tk_rx_match_dfa(const TkRxProg& P, A& t, uint32_t start) {
     return last;
 }
 
+// ---- One piece matched by a GROUP of lanes (the resolving pass: a wavefront per document stands on a true piece start, all of its lanes
+// with the same arguments).  A long piece is, but for a few chars, a long run in ONE state that loops to itself -- \p{L}+ inside a word of
+// a megabyte, \s+ inside blank lines -- so when the table walk below has stayed in one state for TK_RX_COOP_STREAK chars the group scans
+// ahead together: lane j takes the 16-byte block j of the next KiB (one aligned 16-byte load per lane: 1 KiB per load instruction, coalesced),
+// finds the first position in it at which the run cannot go on (a char whose transition leaves the state, the end of the haystack, bytes
+// that are not well-formed UTF-8: everything a lane cannot judge on its own is left to the walk) and the last position at which a
+// transition flags a match; the minimum / maximum over the lanes say where the walk goes on.  Exact: the scan accepts only what the walk
+// would do char by char.
+#define TK_RX_COOP_LANES 64u
+#define TK_RX_COOP_STREAK 16u
+#define TK_RX_NONE 0xFFFFFFFFu
+
+// lane's block: the 16 bytes at blk (16-byte aligned, < t.n).  *bad: first position >= pos in it where the run in state S ends, or NONE;
+// *mat: last position in front of that at which the transition flags a match, or NONE; *endp: where the last char it accepted ends (a
+// char that begins in the last block of a scan may end in the next KiB: the scan goes on behind it).
+template <class A>
+TK_HD void tk_rx_run_lane(const TkRxProg& P, A& t, uint32_t S, uint32_t start, uint32_t pos, uint32_t blk, uint32_t* bad, uint32_t* mat, uint32_t* endp) {
+    *bad = *mat = TK_RX_NONE;
+    *endp = blk + 16u;
+    if (blk >= t.n) {
+        *bad = blk > pos ? blk : pos;
+        return;
+    }
+    uint32_t w[6];  // bytes blk - 4 .. blk + 19: the chars that reach into the block or out of it
+    w[0] = blk ? t.word(blk - 4u) : 0u;
+    t.block16(blk, w + 1);
+    w[5] = t.word(blk + 16u);  // (the text is readable 64 bytes past n)
+    const uint32_t hb = t.hard16(blk);
+    const uint32_t ncls = P.dfa_ncls;
+    bool done = false;
+#define TK_RX_B(i) ((w[((i) + 4) >> 2] >> (8u * (((i) + 4) & 3u))) & 0xFFu)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const uint32_t q = blk + (uint32_t)i;
+        if (done || q < pos) continue;
+        if (q >= t.n || (q > start && ((hb >> i) & 1u))) {
+            *bad = q;
+            done = true;
+            continue;
+        }
+        const uint32_t b = TK_RX_B(i);
+        uint32_t cls, len = 1u;
+        if (b < 0x80u) {
+            cls = tk_rx_ascii_cls(P, b);
+        } else if (b < 0xC0u) {
+            // a continuation byte: part of a char that begins at most three bytes earlier (at or behind pos) -- that char's own position
+            // answers for it; anything else is a stray byte, which the walk reads as a char of its own
+            bool covered = false;
+            const uint32_t b1 = TK_RX_B(i - 1), b2 = TK_RX_B(i - 2), b3 = TK_RX_B(i - 3);
+            if (q >= pos + 1u && b1 >= 0xC0u) covered = true;                                              // (every lead takes at least one)
+            else if (q >= pos + 2u && b1 >= 0x80u && b1 < 0xC0u && b2 >= 0xE0u) covered = true;
+            else if (q >= pos + 3u && b1 >= 0x80u && b1 < 0xC0u && b2 >= 0x80u && b2 < 0xC0u && b3 >= 0xF0u) covered = true;
+            if (!covered) {
+                *bad = q;
+                done = true;
+            }
+            continue;
+        } else {
+            const uint32_t need = b >= 0xF0u ? 4u : (b >= 0xE0u ? 3u : 2u);
+            const uint32_t c1 = TK_RX_B(i + 1), c2 = TK_RX_B(i + 2), c3 = TK_RX_B(i + 3);
+            bool ok = (uint64_t)q + need <= t.n && (c1 & 0xC0u) == 0x80u;
+            uint32_t cp = ((b & (0x7Fu >> need)) << 6) | (c1 & 0x3Fu);
+            if (need >= 3u) {
+                ok = ok && (c2 & 0xC0u) == 0x80u;
+                cp = (cp << 6) | (c2 & 0x3Fu);
+            }
+            if (need == 4u) {
+                ok = ok && (c3 & 0xC0u) == 0x80u;
+                cp = (cp << 6) | (c3 & 0x3Fu);
+            }
+            // (a hard start inside the char cannot be: it would cut a char in two; left to the walk all the same)
+            if (!ok || (hb >> (i + 1)) & ((1u << (need - 1u)) - 1u) & 0xFFFFu) {
+                *bad = q;
+                done = true;
+                continue;
+            }
+            cls = tk_rx_dfa_cls(P, cp);
+            len = need;
+        }
+        const uint32_t e = P.dfa_trans[S * ncls + cls];
+        if ((e & 0x7FFFu) != S) {
+            *bad = q;
+            done = true;
+            continue;
+        }
+        if (e & 0x8000u) *mat = q;
+        *endp = q + len;
+    }
+#undef TK_RX_B
+}
+
+// coop(S, start, pos, base, &pbad, &m1, &pnext): every lane j of the group runs tk_rx_run_lane on the block base + 16 j; pbad = the smallest
+// `bad` (NONE: the whole KiB is in the run -- pnext = the last lane's `endp` is where it goes on), m1 = 1 + the largest `mat` in front of pbad (0: none).
+template <class A, class Coop>
+TK_HD uint32_t tk_rx_match_dfa_coop(const TkRxProg& P, A& t, uint32_t start, Coop&& coop) {
+    const uint32_t ncls = P.dfa_ncls;
+    uint32_t state = (start == 0u || t.hard(start)) ? 2u : 1u;
+    uint32_t pos = start, last = TK_RX_FAILED, streak = 0u;
+    for (;;) {
+        uint32_t cls = 0u, len = 0u;  // (the end of the haystack)
+        if (pos < t.n && !(pos > start && t.hard(pos))) {
+            const uint32_t b0 = t.byte(pos);
+            if (b0 < 0x80u) {
+                cls = tk_rx_ascii_cls(P, b0);
+                len = 1u;
+            } else {
+                cls = tk_rx_dfa_cls(P, tk_rx_decode(t, pos, &len));
+            }
+        }
+        const uint32_t e = P.dfa_trans[state * ncls + cls];
+        if (e & 0x8000u) last = pos;
+        const uint32_t nx = e & 0x7FFFu;
+        if (nx == 0u) break;
+        streak = nx == state ? streak + 1u : 0u;
+        state = nx;
+        pos += len;
+        if (streak >= TK_RX_COOP_STREAK && t.limit == 0xFFFFFFFFu) {  // a run: the group scans ahead, a KiB per step
+            for (;;) {
+                const uint32_t base = pos & ~15u;
+                uint32_t pbad, m1, pnext;
+                coop(state, start, pos, base, &pbad, &m1, &pnext);
+                if (m1) last = m1 - 1u;
+                if (pbad != TK_RX_NONE) {
+                    pos = pbad;
+                    break;
+                }
+                pos = pnext;
+            }
+            streak = 0u;
+        }
+    }
+    TK_RX_ON_DONE(pos - start + 1u);
+    return last;
+}
+
 // End of the match of P that starts at `start`, TK_RX_FAILED or TK_RX_OVERFLOW.  `t` gives the text: byte(pos), n, hard(pos) -- a
 // position where a new haystack begins (document start, special-token edge): the match sees end-of-text there, exactly like the slice of
 // src/lib.rs:405.  Positions are 32-bit (a chunk is < 3 GiB).

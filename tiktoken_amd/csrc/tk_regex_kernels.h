@@ -183,7 +183,29 @@ __global__ __launch_bounds__(256) void tk_k_rx_resolve_wave(TkRxDev R, const uin
             uint32_t len = bad ? (uint32_t)__ffsll((unsigned long long)bad) - 1u : 64u;
             if (len && (uint32_t)__shfl((int)plan.exit, (int)len - 1, 64) == TK_RX_UNKNOWN) --len;  // (that segment's guess broke off: the serial step's)
             if (len == 0u) {
-                p = tk_rx_resolve_step<FORM != TK_RX_FORM_PROGRAM>(P, t, M, p, e, orb_lane0, &err);
+                if constexpr (FORM != TK_RX_FORM_PROGRAM) {
+                    // the wavefront matches the piece together: the table walk, and for a long run a KiB per step (tk_rx_match_dfa_coop)
+                    auto coop = [&](uint32_t S, uint32_t start, uint32_t pos, uint32_t base, uint32_t* pbad, uint32_t* m1, uint32_t* pnext) {
+                        uint32_t bad, mat, endp;
+                        tk_rx_run_lane(P, t, S, start, pos, base + 16u * lane, &bad, &mat, &endp);
+                        *pnext = (uint32_t)__shfl((int)endp, 63, 64);
+                        uint32_t pb = bad;
+                        for (int o = 32; o > 0; o >>= 1) {
+                            const uint32_t v = (uint32_t)__shfl_xor((int)pb, o, 64);
+                            pb = v < pb ? v : pb;
+                        }
+                        uint32_t m = (mat != TK_RX_NONE && mat < pb) ? mat + 1u : 0u;
+                        for (int o = 32; o > 0; o >>= 1) {
+                            const uint32_t v = (uint32_t)__shfl_xor((int)m, o, 64);
+                            m = v > m ? v : m;
+                        }
+                        *pbad = pb;
+                        *m1 = m;
+                    };
+                    p = tk_rx_resolve_step_with(P, t, M, p, e, orb_lane0, &err, [&](uint32_t at) { return tk_rx_match_dfa_coop(P, t, at, coop); });
+                } else {
+                    p = tk_rx_resolve_step<false>(P, t, M, p, e, orb_lane0, &err);
+                }
                 if (err) break;
                 continue;
             }

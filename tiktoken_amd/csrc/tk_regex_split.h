@@ -79,6 +79,28 @@ struct TkRxText {
         return (tw >> (8u * (p & 3u))) & 0xFFu;
     }
 #endif
+    // (for tk_rx_run_lane: an aligned word, an aligned 16-byte block, the hard bits of the 16 positions of a block -- not cached)
+    TK_HD uint32_t word(uint32_t p4) const {
+        uint32_t v;
+#if defined(__HIP_DEVICE_COMPILE__)
+        v = *(const uint32_t*)(text + (size_t)p4);
+#else
+        __builtin_memcpy(&v, text + (size_t)p4, 4);
+#endif
+        return v;
+    }
+    TK_HD void block16(uint32_t p16, uint32_t* w) const {
+#if defined(__HIP_DEVICE_COMPILE__)
+        const uint4 q = *(const uint4*)(text + (size_t)p16);
+        w[0] = q.x;
+        w[1] = q.y;
+        w[2] = q.z;
+        w[3] = q.w;
+#else
+        __builtin_memcpy(w, text + (size_t)p16, 16);
+#endif
+    }
+    TK_HD uint32_t hard16(uint32_t p16) const { return (brk[p16 >> 5] >> (p16 & 31u)) & 0xFFFFu; }
     TK_HD bool hard(uint32_t p) {
         if (p >= limit) {
             hit = true;
@@ -97,8 +119,9 @@ struct TkRxText {
 
 // the start that follows the piece (or special token, or gap char) that starts at p; or an error code (TK_RX_IS_ERROR: stack, budget).
 // DFA (here and below): the matcher is the pattern's table form (tk_rx_match_dfa) instead of the program.
-template <bool DFA = false>
-TK_HD uint32_t tk_rx_next(const TkRxProg& P, TkRxText& t, uint32_t p, bool* gap) {
+// (match(p): the end of the match that starts at p -- tk_rx_match_sel, or a group of lanes together: tk_rx_match_dfa_coop)
+template <class Match>
+TK_HD uint32_t tk_rx_next_with(const TkRxProg& P, TkRxText& t, uint32_t p, bool* gap, Match&& match) {
     *gap = false;
     if (t.special(p)) {
         uint32_t q = p + 1;
@@ -106,13 +129,18 @@ TK_HD uint32_t tk_rx_next(const TkRxProg& P, TkRxText& t, uint32_t p, bool* gap)
         return q;
     }
     TK_RX_ON_MATCH();
-    const uint32_t e = tk_rx_match_sel<DFA>(P, t, p);
+    const uint32_t e = match(p);
     if (e != TK_RX_FAILED) return e;
     // no match starts here: the char is skipped (find_iter tries the next position)
     *gap = true;
     uint32_t q = p + 1;
     while (q < t.n && !t.hard(q) && (t.byte(q) & 0xC0u) == 0x80u) ++q;
     return q;
+}
+
+template <bool DFA = false>
+TK_HD uint32_t tk_rx_next(const TkRxProg& P, TkRxText& t, uint32_t p, bool* gap) {
+    return tk_rx_next_with(P, t, p, gap, [&](uint32_t at) { return tk_rx_match_sel<DFA>(P, t, at); });
 }
 
 // bit p of a bitmap
@@ -125,10 +153,12 @@ TK_HD uint32_t tk_rx_speculate_chain(const TkRxProg& P, TkRxText& t, uint32_t p,
         spec[p >> 5] |= 1u << (p & 31u);  // (the words of a segment belong to its lane)
         bool gap;
         uint32_t q = tk_rx_next<DFA>(P, t, p, &gap);
-        if (t.hit && p != first && !TK_RX_IS_ERROR(q)) {
+        if (!DFA && t.hit && p != first && !TK_RX_IS_ERROR(q)) {
             // A long piece (it reaches TK_RX_AHEAD bytes beyond the segment) that this lane has come to along its chain: very likely a
             // true start, and nobody else will evaluate it in parallel -- the lanes of the segments inside the piece stop at their FIRST
             // evaluation (below), so the text of a long piece is scanned once here instead of once by the resolving lane of its document.
+            // (The program only: with the pattern's DFA the resolving pass takes a long piece a KiB per step, the lanes of its
+            // wavefront together -- tk_rx_match_dfa_coop -- and a lane on its own has no business with it.)
             t.limit = 0xFFFFFFFFu;
             t.hit = false;
             q = tk_rx_next<DFA>(P, t, p, &gap);
@@ -358,8 +388,8 @@ TK_HD uint32_t tk_rx_emit(const TkRxMaps& M, const TkRxPlan& R, uint32_t entry, 
 
 // One step of the true chain of the document [.., e) from the true start p: the whole rest of p's segment when the maps answer, one
 // match otherwise.  Returns the next true start (>= e: done) or, with *err set, the position of the failure.
-template <bool DFA = false, class Or>
-TK_HD uint32_t tk_rx_resolve_step(const TkRxProg& P, TkRxText& t, const TkRxMaps& M, uint32_t p, uint32_t e, Or&& orbits, uint32_t* err) {
+template <class Or, class Match>
+TK_HD uint32_t tk_rx_resolve_step_with(const TkRxProg& P, TkRxText& t, const TkRxMaps& M, uint32_t p, uint32_t e, Or&& orbits, uint32_t* err, Match&& match) {
     const TkRxPlan R = tk_rx_plan(M, t.n, p >> M.seg_shift, p, e);
     if (R.ok) {
         const uint32_t last = tk_rx_emit(M, R, p, orbits);
@@ -369,13 +399,17 @@ TK_HD uint32_t tk_rx_resolve_step(const TkRxProg& P, TkRxText& t, const TkRxMaps
         orbits(p >> 5, 1u << (p & 31u), 0u);
     }
     bool gap;
-    const uint32_t q = tk_rx_next<DFA>(P, t, p, &gap);
+    const uint32_t q = tk_rx_next_with(P, t, p, &gap, match);
     if (TK_RX_IS_ERROR(q)) {
         *err = q == TK_RX_OVERFLOW ? TK_RX_ERR_STACK : TK_RX_ERR_LIMIT;
         return p;
     }
     if (gap) orbits(p >> 5, 0u, 1u << (p & 31u));
     return q;
+}
+template <bool DFA = false, class Or>
+TK_HD uint32_t tk_rx_resolve_step(const TkRxProg& P, TkRxText& t, const TkRxMaps& M, uint32_t p, uint32_t e, Or&& orbits, uint32_t* err) {
+    return tk_rx_resolve_step_with(P, t, M, p, e, orbits, err, [&](uint32_t at) { return tk_rx_match_sel<DFA>(P, t, at); });
 }
 
 // One document [b, e) of the chunk by one lane.  `orbits(word index, start bits, gap bits)` ORs into the bitmaps of true starts and of the
@@ -419,7 +453,22 @@ TK_HD uint32_t tk_rx_resolve_group_host(const TkRxProg& P, TkRxText t, const TkR
             --L;
         }
         if (L == 0) {
-            p = tk_rx_resolve_step<DFA>(P, t, M, p, e, orbits, &err);
+            if constexpr (DFA) {  // the group matches the piece together (the host form runs the lanes of a scan one after the other)
+                auto coop = [&](uint32_t S, uint32_t start, uint32_t pos, uint32_t base, uint32_t* pbad, uint32_t* m1, uint32_t* pnext) {
+                    uint32_t bad[TK_RX_COOP_LANES], mat[TK_RX_COOP_LANES], pb = TK_RX_NONE, m = 0;
+                    for (uint32_t j = 0; j < TK_RX_COOP_LANES; ++j) {
+                        tk_rx_run_lane(P, t, S, start, pos, base + 16u * j, &bad[j], &mat[j], pnext);  // (*pnext: the last lane's)
+                        pb = bad[j] < pb ? bad[j] : pb;
+                    }
+                    for (uint32_t j = 0; j < TK_RX_COOP_LANES; ++j)
+                        if (mat[j] != TK_RX_NONE && mat[j] < pb && mat[j] + 1u > m) m = mat[j] + 1u;
+                    *pbad = pb;
+                    *m1 = m;
+                };
+                p = tk_rx_resolve_step_with(P, t, M, p, e, orbits, &err, [&](uint32_t at) { return tk_rx_match_dfa_coop(P, t, at, coop); });
+            } else {
+                p = tk_rx_resolve_step<DFA>(P, t, M, p, e, orbits, &err);
+            }
             if (err) {
                 *err_pos = p;
                 return err;
