@@ -380,6 +380,8 @@ class RxSim:
             gaps = self.gaps
             if int(speculate) & 3:  # (the one-loop form of the speculative lanes, which is what the device runs)
                 assert self._split(docs, specials, int(speculate) | 48) == got and self.gaps == gaps, "the two forms of the DFA's speculative pass disagree"
+                # (a speculative match may look 64 bytes beyond its segment instead of 2 KiB: many more pieces are left to the resolving pass)
+                assert self._split(docs, specials, int(speculate) | 48 | (6 << 8)) == got and self.gaps == gaps, "the split depends on the look-ahead limit"
             else:  # (no speculation, documents by groups of lanes: EVERY piece is matched by the group together -- tk_rx_match_dfa_coop)
                 assert self._split(docs, specials, 8 | 16) == got and self.gaps == gaps, "the group's matcher and the lane's disagree"
             return got

@@ -126,6 +126,7 @@ int main(int argc, char** argv) {
                 uint32_t* lnk = (uint32_t*)calloc(nw, 4);
                 uint32_t* lgap = (uint32_t*)calloc(nw, 4);
                 TkRxText t{text, n, brk, with_specials ? ss : nullptr, with_specials ? si : nullptr, 0xFFFFFFFFu, false};
+                t.ahead = (rnd() % 3 == 0) ? 64u : (DFA ? TK_RX_AHEAD_DFA : TK_RX_AHEAD);  // (bytes a speculative match may look beyond its segment)
                 if constexpr (DFA) {  // (the device's form of the DFA's speculative lane: one loop over the segment)
                     for (uint32_t s = 0; s < nseg; ++s) tk_rx_speculate_lane_flat(P, t, s, shift, spec, sgap, xexit);
                 } else {

@@ -669,6 +669,7 @@ uint64_t tks_rx_dfa(void* p, char* why, uint64_t cap) {
 // Piece starts of a packed batch: a byte per position (1 = start).  spec_at / spec_len: occurrences of allowed special tokens (sorted).
 // speculate = 0: every document walked by the matcher alone; bits 0..1: 1 = speculative pass over 256-byte segments, 2 = over 1 KiB; bit 2: with
 // the link pass; bit 3: documents resolved by groups of 64 lanes (the host form of the device's wavefront).
+// bits 8..12: log2 of TkRxText::ahead (0: the default of the matcher's form).
 // bit 4: the matcher is the pattern's DFA (it must have one: tks_rx_dfa) instead of the program; bit 5 (with bit 4): the speculative lanes in
 // their one-loop form (tk_rx_speculate_lane_flat), compared bit for bit with the piece-by-piece form (error 0xFE if they differ).
 // stats[0] = matcher runs of the speculative (+ link) pass, [1] = of the resolving pass.  Returns 0, or error bits | position << 8.
@@ -693,6 +694,8 @@ static uint64_t rx_split_impl(void* p, const uint8_t* text_in, uint64_t n, const
         if (spec_at[k] + spec_len[k] < n) setb(brk, spec_at[k] + spec_len[k]);
     }
     TkRxText t{text.data(), (uint32_t)n, brk.data(), n_spec ? ss.data() : nullptr, n_spec ? si.data() : nullptr, 0xFFFFFFFFu, false};
+    if (speculate >> 8) t.ahead = 1u << ((speculate >> 8) & 31);  // (bits 8..12: log2 of the bytes a speculative match may look beyond its segment; 0: the program's default)
+    else if (DFA) t.ahead = TK_RX_AHEAD_DFA;
     const uint32_t nseg = (uint32_t)((n + (1u << seg_shift) - 1) >> seg_shift);
     std::vector<uint32_t> xexit(nseg + 1, TK_RX_UNKNOWN), lmerge(nseg + 1, TK_RX_NOLINK), lexit(nseg + 1, TK_RX_UNKNOWN);
     g_rx_matches = 0;

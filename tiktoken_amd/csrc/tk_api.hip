@@ -127,6 +127,7 @@ struct tk_core {
     int dbg = 0;
     uint32_t n_cu = 256;             // compute units of the device
     uint32_t rx_seg_shift = 0;       // 0: by chunk size (tk_regex_split.h)
+    uint32_t rx_ahead = 0;           // 0: TK_RX_AHEAD / TK_RX_AHEAD_DFA by the kernels' form ($TIKTOKEN_AMD_RX_AHEAD: bytes)
     uint32_t front_wgs = TKF_OCC;    // workgroups per CU of the persistent front kernel ($TIKTOKEN_AMD_FRONT_WGS)
     uint32_t n_dec = 0;  // entries of the device decode table (0: ids too sparse for a direct table -- decode stays on the host)
     Buf d_tok, d_lens, d_bsum, d_tboff, d_bytes, d_boff;  // decode workspace
@@ -426,6 +427,10 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
         if (v >= 4096 && v <= (3ull << 30)) c->chunk_bytes = v;
     }
     if (const char* e = getenv("TIKTOKEN_AMD_DEBUG")) c->dbg = atoi(e);
+    if (const char* e = getenv("TIKTOKEN_AMD_RX_AHEAD")) {  // (experiments: bytes a speculative match may look beyond its segment)
+        const int k = atoi(e);
+        if (k >= 16 && k <= (1 << 20)) c->rx_ahead = (uint32_t)k;
+    }
     if (const char* e = getenv("TIKTOKEN_AMD_RX_SEG_SHIFT")) {  // (experiments: segment size of the generic engine's speculative pass, 2^k bytes)
         const int k = atoi(e);
         if (k >= 5 && k <= 14) c->rx_seg_shift = (uint32_t)k;
@@ -544,6 +549,7 @@ static int rx_split(tk_core* c, WorkSet& w, hipStream_t s, const uint8_t* d_text
     uint32_t *lnk = w.rx_lnk.as<uint32_t>(), *lmerge = xexit + nseg + 2, *lexit = xexit + 2 * (nseg + 2);
     // (the kernels' form: the pattern's DFA in LDS -- its speculative pass as one loop -- or the backtracking program; tk_regex_kernels.h)
     const uint32_t lds = c->rx_form == TK_RX_FORM_PROGRAM ? 0u : tk_rx_dfa_lds_bytes(c->rx);
+    const uint32_t ahead = c->rx_ahead ? c->rx_ahead : (c->rx_form == TK_RX_FORM_PROGRAM ? TK_RX_AHEAD : TK_RX_AHEAD_DFA);
     auto by_form = [&](auto&& launch) {
         if (c->rx_form == TK_RX_FORM_DFA_FLAT) launch(std::integral_constant<int, TK_RX_FORM_DFA_FLAT>{});
         else if (c->rx_form == TK_RX_FORM_DFA) launch(std::integral_constant<int, TK_RX_FORM_DFA>{});
@@ -552,7 +558,7 @@ static int rx_split(tk_core* c, WorkSet& w, hipStream_t s, const uint8_t* d_text
     TRY(timed(c, s, "tk_k_rx_speculate", [&] {
         by_form([&](auto form) {
             hipLaunchKernelGGL(tk_k_rx_speculate<decltype(form)::value>, dim3(grid_for(nseg, 256, 65536)), dim3(256), lds, s, c->rx, d_text, (uint32_t)n, brk, ss, si, seg_shift,
-                               spec, spec + nwords + 2, xexit);
+                               ahead, spec, spec + nwords + 2, xexit);
         });
     }));
     const bool links = !(c->dbg & 0x20000);  // (debug bit 0x20000: no link pass -- the resolving pass matches its way from one chain to the next)
@@ -560,7 +566,7 @@ static int rx_split(tk_core* c, WorkSet& w, hipStream_t s, const uint8_t* d_text
         TRY(timed(c, s, "tk_k_rx_link", [&] {
             by_form([&](auto form) {
                 hipLaunchKernelGGL(tk_k_rx_link<decltype(form)::value>, dim3(grid_for(nseg, 256, 65536)), dim3(256), lds, s, c->rx, d_text, (uint32_t)n, brk, ss, si, seg_shift,
-                                   spec, xexit, lnk, lnk + nwords + 2, lmerge, lexit);
+                                   ahead, spec, xexit, lnk, lnk + nwords + 2, lmerge, lexit);
             });
         }));
     }

@@ -96,11 +96,12 @@ extern __shared__ uint32_t tk_rx_dyn_lds[];
 
 template <int FORM>
 __global__ __launch_bounds__(256) void tk_k_rx_speculate(TkRxDev R, const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ brk,
-                                                         const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, uint32_t seg_shift,
+                                                         const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, uint32_t seg_shift, uint32_t ahead,
                                                          uint32_t* __restrict__ spec, uint32_t* __restrict__ sgap, uint32_t* __restrict__ xexit) {
     TK_RX_STAGE(P, R)
     const uint32_t nseg = (uint32_t)(((uint64_t)n + (1u << seg_shift) - 1u) >> seg_shift);
-    const TkRxText t{text, n, brk, ss, si, 0xFFFFFFFFu, false};
+    TkRxText t{text, n, brk, ss, si, 0xFFFFFFFFu, false};
+    t.ahead = ahead;
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += gridDim.x * blockDim.x) {
         if constexpr (FORM == TK_RX_FORM_DFA_FLAT) tk_rx_speculate_lane_flat(P, t, k, seg_shift, spec, sgap, xexit);
         else tk_rx_speculate_lane<FORM != TK_RX_FORM_PROGRAM>(P, t, k, seg_shift, spec, sgap, xexit);
@@ -109,12 +110,13 @@ __global__ __launch_bounds__(256) void tk_k_rx_speculate(TkRxDev R, const uint8_
 
 template <int FORM>
 __global__ __launch_bounds__(256) void tk_k_rx_link(TkRxDev R, const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ brk,
-                                                    const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, uint32_t seg_shift,
+                                                    const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, uint32_t seg_shift, uint32_t ahead,
                                                     const uint32_t* __restrict__ spec, const uint32_t* __restrict__ xexit, uint32_t* __restrict__ lnk,
                                                     uint32_t* __restrict__ lgap, uint32_t* __restrict__ lmerge, uint32_t* __restrict__ lexit) {
     TK_RX_STAGE(P, R)
     const uint32_t nseg = (uint32_t)(((uint64_t)n + (1u << seg_shift) - 1u) >> seg_shift);
-    const TkRxText t{text, n, brk, ss, si, 0xFFFFFFFFu, false};
+    TkRxText t{text, n, brk, ss, si, 0xFFFFFFFFu, false};
+    t.ahead = ahead;
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += gridDim.x * blockDim.x)
         tk_rx_link_lane<FORM != TK_RX_FORM_PROGRAM>(P, t, k, seg_shift, spec, xexit, lnk, lgap, lmerge, lexit);
 }

@@ -34,7 +34,8 @@
 #define TK_RX_SEG_SHIFT_SMALL 7u
 #define TK_RX_SEG_SHIFT_LARGE 10u
 #define TK_RX_SEG_SMALL_BELOW (4ull << 30)  // chunk bytes below which the SMALL segments are used: always
-#define TK_RX_AHEAD 16384u  // bytes a speculative match may look beyond its segment
+#define TK_RX_AHEAD 16384u  // bytes a speculative match may look beyond its segment: the program (its lanes evaluate longer pieces they come to in full)
+#define TK_RX_AHEAD_DFA 2048u  // ... the DFA forms: a longer piece is left to the resolving wavefront, which takes it a KiB per step (tk_rx_match_dfa_coop)
 #define TK_RX_UNKNOWN 0xFFFFFFFFu
 #define TK_RX_ERR_GAP 4u       // bits of the chunk's error word
 #define TK_RX_ERR_STACK 8u
@@ -54,6 +55,7 @@ struct TkRxText {
     // the text and the bitmap word read last: a lane walks its text byte by byte, one load per sixteen bytes (device; the lanes of a
     // wavefront read sixty-four different cache lines per load instruction: fewer, wider loads) / four bytes (host) / thirty-two positions
     uint32_t tw_at = 0xFFFFFFFFu, tw = 0, bw_at = 0xFFFFFFFFu, bw = 0;
+    uint32_t ahead = TK_RX_AHEAD;  // bytes a speculative match may look beyond its segment
 #if defined(__HIP_DEVICE_COMPILE__)
     uint32_t tq1 = 0, tq2 = 0, tq3 = 0;  // (with tw: the sixteen bytes at 16 * tw_at)
     TK_HD uint32_t byte(uint32_t p) {
@@ -177,7 +179,7 @@ TK_HD void tk_rx_speculate_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint3
     if (a64 >= t.n) return;
     const uint32_t seg = 1u << seg_shift;
     const uint32_t a = (uint32_t)a64, end = t.n - a > seg ? a + seg : t.n;
-    const uint32_t limit = t.n - end > TK_RX_AHEAD ? end + TK_RX_AHEAD : t.n;
+    const uint32_t limit = t.n - end > t.ahead ? end + t.ahead : t.n;
     t.limit = limit;
     t.hit = false;
     uint32_t p = a;
@@ -196,7 +198,7 @@ TK_HD void tk_rx_speculate_lane_flat(const TkRxProg& P, TkRxText t, uint32_t k, 
     if (a64 >= t.n) return;
     const uint32_t seg = 1u << seg_shift;
     const uint32_t a = (uint32_t)a64, end = t.n - a > seg ? a + seg : t.n;
-    const uint32_t limit = t.n - end > TK_RX_AHEAD ? end + TK_RX_AHEAD : t.n;
+    const uint32_t limit = t.n - end > t.ahead ? end + t.ahead : t.n;
     t.limit = limit;
     t.hit = false;
     uint32_t p = a;
@@ -300,7 +302,7 @@ TK_HD void tk_rx_link_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint32_t s
         if (tk_rx_bit(spec, e)) {
             m = e;  // on the chain as it is
         } else {
-            t.limit = t.n - end > TK_RX_AHEAD ? end + TK_RX_AHEAD : t.n;
+            t.limit = t.n - end > t.ahead ? end + t.ahead : t.n;
             t.hit = false;
             uint32_t p = e;
             for (;;) {
