@@ -191,14 +191,14 @@ TK_HD uint32_t tk_rx_match_dfa(const TkRxProg& P, A& t, uint32_t start) {
 
 // ---- One piece matched by a GROUP of lanes (the resolving pass: a wavefront per document stands on a true piece start, all of its lanes
 // with the same arguments).  A long piece is, but for a few chars, a long run in ONE state that loops to itself -- \p{L}+ inside a word of
-// a megabyte, \s+ inside blank lines -- so when the table walk below has stayed in one state for TK_RX_COOP_STREAK chars the group scans
+// a megabyte, \s+ inside blank lines -- so when the table walk below has stayed in one state for TK_RX_COOP_STREAK (8) chars the group scans
 // ahead together: lane j takes the 16-byte block j of the next KiB (one aligned 16-byte load per lane: 1 KiB per load instruction, coalesced),
 // finds the first position in it at which the run cannot go on (a char whose transition leaves the state, the end of the haystack, bytes
 // that are not well-formed UTF-8: everything a lane cannot judge on its own is left to the walk) and the last position at which a
 // transition flags a match; the minimum / maximum over the lanes say where the walk goes on.  Exact: the scan accepts only what the walk
 // would do char by char.
 #define TK_RX_COOP_LANES 64u
-#define TK_RX_COOP_STREAK 16u
+#define TK_RX_COOP_STREAK 8u
 #define TK_RX_NONE 0xFFFFFFFFu
 
 // lane's block: the 16 bytes at blk (16-byte aligned, < t.n).  *bad: first position >= pos in it where the run in state S ends, or NONE;
