@@ -321,7 +321,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
         TRY(upload(c->t_rx_s2, tk_rx_props_stage2(), (size_t)tk_rx_props_blocks() * 256));
         c->rx = TkRxDev{c->t_rx_ins.as<TkRxIns>(), c->t_rx_sets.as<TkRxSet>(), c->t_rx_ranges.as<uint32_t>(), c->t_rx_s1.as<uint8_t>(),
                         c->t_rx_s2.as<uint8_t>(), (uint32_t)X.ins.size(), (uint32_t)X.sets.size(), (uint32_t)X.ranges.size() / 2,
-                        c->t_rx_first.as<uint32_t>(), (uint32_t)X.first.size() / 8, nullptr, nullptr, nullptr, nullptr, 0u, 0u};
+                        c->t_rx_first.as<uint32_t>(), (uint32_t)X.first.size() / 8, nullptr, nullptr, nullptr, nullptr, 0u, 0u, 0u};
         c->rx_form = TK_RX_FORM_PROGRAM;
         // the pattern's DFA (tk_regex_dfa.inc), where it has one: $TIKTOKEN_AMD_RX_MATCHER = program | dfa | flat (the default) chooses the
         // kernels' form -- "dfa" keeps the piece-by-piece speculative lane, "program" interprets the backtracking program as before
@@ -330,7 +330,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
             std::vector<uint16_t> tr(X.dfa_trans);
             tr.resize((tr.size() + 1) & ~(size_t)1, 0);  // (whole 32-bit words: the kernels copy it to LDS word by word)
             TRY(upload(c->t_rx_dtrans, tr.data(), tr.size() * 2));
-            TRY(upload(c->t_rx_dascii, X.dfa_ascii.data(), 128));
+            TRY(upload(c->t_rx_dascii, X.dfa_ascii.data(), 384));
             TRY(upload(c->t_rx_ds1, X.dfa_s1.data(), X.dfa_s1.size() * 2));
             TRY(upload(c->t_rx_ds2, X.dfa_s2.data(), X.dfa_s2.size()));
             c->rx.dfa_trans = c->t_rx_dtrans.as<uint16_t>();
@@ -339,6 +339,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
             c->rx.dfa_s2 = c->t_rx_ds2.as<uint8_t>();
             c->rx.dfa_ncls = X.dfa_ncls;
             c->rx.dfa_nstates = X.dfa_nstates;
+            c->rx.dfa_flags = X.dfa_flags;
             c->rx_form = (want && !strcmp(want, "dfa")) ? TK_RX_FORM_DFA : TK_RX_FORM_DFA_FLAT;
         }
         return TK_OK;

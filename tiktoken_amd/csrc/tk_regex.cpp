@@ -1089,6 +1089,7 @@ TkRxProg TkRxCompiled::view() const {
         P.dfa_s1 = dfa_s1.data();
         P.dfa_s2 = dfa_s2.data();
         P.dfa_ncls = dfa_ncls;
+        P.dfa_flags = dfa_flags;
     }
     return P;
 }

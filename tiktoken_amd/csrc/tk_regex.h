@@ -63,13 +63,14 @@ struct TkRxProg {
     uint32_t n_first;       // instruction can begin (tk_regex.cpp: a fixpoint over the program; conservative, so skipping is exact)
     // The same pattern as a DFA (tk_regex_dfa.inc; null: the pattern has none -- look-behind, \b, general atomic groups -- and the program
     // above runs).  trans[state * ncls + cls]: bit 15 = "a match ends HERE, in front of this char", bits 0..14 = the next state (0: dead).
-    // State 1 starts a match inside a haystack, state 2 one at its first char (^, \A).  cls 0 is the end of the haystack, 1 .. ncls - 1 the
+    // State 1 starts a match at the first char of its haystack (^, \A), state 1 + g one behind a char of group g (one group, unless the
+    // pattern looks behind: dfa_flags bit 0, groups in dfa_ascii[128 + class]).  cls 0 is the end of the haystack, 1 .. ncls - 1 the
     // classes of code points no set of the pattern tells apart: ASCII through dfa_ascii[128], the rest through the two-stage table.
     const uint16_t* dfa_trans = nullptr;
     const uint8_t* dfa_ascii = nullptr;
     const uint16_t* dfa_s1 = nullptr;  // [0x1100]: bit 15 set -> the class of all 256 code points (CJK, Hangul, unassigned planes: no second look-up); else block of dfa_s2
     const uint8_t* dfa_s2 = nullptr;   // blocks of 256 classes
-    uint32_t dfa_ncls = 0;
+    uint32_t dfa_ncls = 0, dfa_flags = 0;
 };
 
 #define TK_RX_FAILED 0xFFFFFFFFu    // no match at this position
@@ -163,10 +164,24 @@ TK_HD uint32_t tk_rx_ascii_cls(const TkRxProg& P, uint32_t b0) {
 #endif
 }
 
+// the state in which a match that starts at `start` begins: 1 at the first char of a haystack, else 1 + the group of the char in front
+// (read only for a pattern that looks behind; as TK_RX_PREV reads it: a malformed char before the position counts as U+FFFD)
+template <class A>
+TK_HD uint32_t tk_rx_dfa_start(const TkRxProg& P, A& t, uint32_t start) {
+    if (start == 0u || t.hard(start)) return 1u;
+    if (!(P.dfa_flags & 1u)) return 2u;
+    uint32_t r = start - 1u, len;
+    for (int k = 0; k < 3 && r > 0u && (t.byte(r) & 0xC0u) == 0x80u && !t.hard(r); ++k) --r;
+    uint32_t cp = tk_rx_decode(t, r, &len);
+    if (r + len != start) cp = 0xFFFDu;
+    const uint32_t cls = cp < 0x80u ? tk_rx_ascii_cls(P, cp) : tk_rx_dfa_cls(P, cp);
+    return 1u + tk_rx_ascii_cls(P, 128u + cls);
+}
+
 template <class A>
 TK_HD uint32_t tk_rx_match_dfa(const TkRxProg& P, A& t, uint32_t start) {
     const uint32_t ncls = P.dfa_ncls;
-    uint32_t state = (start == 0u || t.hard(start)) ? 2u : 1u;
+    uint32_t state = tk_rx_dfa_start(P, t, start);
     uint32_t pos = start, last = TK_RX_FAILED;
     for (;;) {
         uint32_t cls = 0u, len = 0u;  // (the end of the haystack)
@@ -285,7 +300,7 @@ TK_HD void tk_rx_run_lane(const TkRxProg& P, A& t, uint32_t S, uint32_t start, u
 template <class A, class Coop>
 TK_HD uint32_t tk_rx_match_dfa_coop(const TkRxProg& P, A& t, uint32_t start, Coop&& coop) {
     const uint32_t ncls = P.dfa_ncls;
-    uint32_t state = (start == 0u || t.hard(start)) ? 2u : 1u;
+    uint32_t state = tk_rx_dfa_start(P, t, start);
     uint32_t pos = start, last = TK_RX_FAILED, streak = 0u;
     for (;;) {
         uint32_t cls = 0u, len = 0u;  // (the end of the haystack)

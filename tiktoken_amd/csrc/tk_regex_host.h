@@ -21,10 +21,10 @@ struct TkRxCompiled {
     std::vector<uint32_t> first;   // first-byte bitmaps, 8 words each (TkRxProg::first)
     // the pattern as a DFA (tk_regex_dfa.inc; TkRxProg::dfa_*): empty when the pattern has none -- dfa_why says what stands in the way
     std::vector<uint16_t> dfa_trans;  // [dfa_nstates * dfa_ncls]
-    std::vector<uint8_t> dfa_ascii;   // [128]
+    std::vector<uint8_t> dfa_ascii;   // [128] classes of ASCII bytes, [128 + class] the class's group as look-behind / \b see it
     std::vector<uint16_t> dfa_s1;     // [0x1100]
     std::vector<uint8_t> dfa_s2;      // blocks of 256
-    uint32_t dfa_ncls = 0, dfa_nstates = 0;
+    uint32_t dfa_ncls = 0, dfa_nstates = 0, dfa_flags = 0;  // flags bit 0: a match's start state depends on the char in front of it
     std::string dfa_why;
     bool has_dfa() const { return !dfa_trans.empty(); }
     bool empty() const { return ins.empty(); }

@@ -38,11 +38,11 @@ struct TkRxDev {  // the compiled program in device memory
     const uint8_t* dfa_ascii;
     const uint16_t* dfa_s1;
     const uint8_t* dfa_s2;
-    uint32_t dfa_ncls, dfa_nstates;
+    uint32_t dfa_ncls, dfa_nstates, dfa_flags;
 };
 enum { TK_RX_FORM_PROGRAM = 0, TK_RX_FORM_DFA = 1, TK_RX_FORM_DFA_FLAT = 2 };  // (FLAT: the speculative pass as one loop; the other kernels as DFA)
 // bytes of dynamic LDS the DFA forms need
-static inline uint32_t tk_rx_dfa_lds_bytes(const TkRxDev& R) { return ((R.dfa_nstates * R.dfa_ncls + 1u) / 2u) * 4u + 128u + 0x1100u * 2u; }
+static inline uint32_t tk_rx_dfa_lds_bytes(const TkRxDev& R) { return ((R.dfa_nstates * R.dfa_ncls + 1u) / 2u) * 4u + 384u + 0x1100u * 2u; }
 
 struct TkRxLds {
     TkRxIns ins[TK_RX_MAX_INS];
@@ -72,14 +72,15 @@ __device__ __forceinline__ TkRxProg tk_rx_stage_dfa(const TkRxDev& R, uint32_t* 
     const uint32_t* st = (const uint32_t*)R.dfa_trans;
     const uint32_t* sa = (const uint32_t*)R.dfa_ascii;
     const uint32_t* s1 = (const uint32_t*)R.dfa_s1;
-    for (uint32_t i = threadIdx.x; i < 32u; i += blockDim.x) lds[i] = sa[i];
-    for (uint32_t i = threadIdx.x; i < 0x880u; i += blockDim.x) lds[32u + i] = s1[i];
-    for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[32u + 0x880u + i] = st[i];
+    for (uint32_t i = threadIdx.x; i < 96u; i += blockDim.x) lds[i] = sa[i];  // (128 ASCII classes + 256 groups of classes)
+    for (uint32_t i = threadIdx.x; i < 0x880u; i += blockDim.x) lds[96u + i] = s1[i];
+    for (uint32_t i = threadIdx.x; i < nt; i += blockDim.x) lds[96u + 0x880u + i] = st[i];
     __syncthreads();
     TkRxProg P{};
     P.dfa_ascii = (const uint8_t*)lds;
-    P.dfa_s1 = (const uint16_t*)(lds + 32);
-    P.dfa_trans = (const uint16_t*)(lds + 32 + 0x880);
+    P.dfa_s1 = (const uint16_t*)(lds + 96);
+    P.dfa_trans = (const uint16_t*)(lds + 96 + 0x880);
+    P.dfa_flags = R.dfa_flags;
     P.dfa_s2 = R.dfa_s2;  // (the second stage: global memory, L2)
     P.dfa_ncls = R.dfa_ncls;
     return P;

@@ -224,7 +224,7 @@ TK_HD void tk_rx_speculate_lane_flat(const TkRxProg& P, TkRxText t, uint32_t k, 
     note_start(p);
     uint32_t x = TK_RX_UNKNOWN;
     bool slow = t.special(p);
-    uint32_t pos = p, last = TK_RX_FAILED, state = (p == 0u || t.hard(p)) ? 2u : 1u;
+    uint32_t pos = p, last = TK_RX_FAILED, state = tk_rx_dfa_start(P, t, p);
     while (!slow) {
         uint32_t cls = 0u, len = 0u;  // (the end of the haystack)
         if (pos < t.n) {
@@ -275,7 +275,7 @@ TK_HD void tk_rx_speculate_lane_flat(const TkRxProg& P, TkRxText t, uint32_t k, 
         }
         pos = p;
         last = TK_RX_FAILED;
-        state = t.hard(p) ? 2u : 1u;
+        state = tk_rx_dfa_start(P, t, p);
     }
     flush();
     if (slow) x = tk_rx_speculate_chain<true>(P, t, p, first, end, limit, spec, sgap);
