@@ -36,7 +36,9 @@ int tk_device_count(void);
  * group, suffix set and white-space rules) run on hand-written scanners; any other pattern in the syntax fancy-regex shares with
  * Python `regex` -- classes (with && and --, POSIX classes), \p{General_Category}, \p{Script}, the binary properties of the UCD, alternation,
  * groups, (?i: ), greedy / lazy / possessive quantifiers, atomic groups, look-ahead, look-behind of fixed length, \b, ^ $ -- is compiled
- * to a program for the generic GPU engine (tk_regex.cpp).  Refused with TK_UNSUPPORTED and the reason: look-behind of variable length,
+ * for the generic GPU engine (tk_regex.cpp): into a DFA (leftmost-first; tk_regex_dfa.inc) that every lane walks out of LDS, and -- for
+ * what a table cannot express: look-around of several chars, atomic groups and possessive repeats around groups -- into a backtracking
+ * program that the GPU interprets ($TIKTOKEN_AMD_RX_MATCHER=program forces the program for every pattern).  Refused with TK_UNSUPPORTED and the reason: look-behind of variable length,
  * back-references (fancy-regex has them; they stay refused here), a pattern that can match the empty string.  Text a pattern does not
  * match yields no tokens, as the reference's find_iter skips it (src/lib.rs:365,405).
  * Text must be valid UTF-8 (the reference's boundary is &str); other bytes never crash but their split is unspecified: a caller that
