@@ -116,7 +116,7 @@ int main(int argc, char** argv) {
                     at += len;
                 }
             auto run_lanes = [&](auto dfa_tag, uint32_t shift) {  // (the matcher: the program, or the pattern's DFA where it has one)
-                constexpr bool DFA = decltype(dfa_tag)::value;
+                constexpr int DFA = decltype(dfa_tag)::value;  // (TK_RX_M_PROGRAM, _DFA, _DFA_PREV)
                 const uint32_t nseg = (uint32_t)(((uint64_t)n + (1u << shift) - 1) >> shift);
                 uint32_t* xexit = (uint32_t*)malloc((nseg + 2) * 4);
                 uint32_t* lmerge = (uint32_t*)malloc((nseg + 2) * 4);
@@ -128,7 +128,7 @@ int main(int argc, char** argv) {
                 TkRxText t{text, n, brk, with_specials ? ss : nullptr, with_specials ? si : nullptr, 0xFFFFFFFFu, false};
                 t.ahead = (rnd() % 3 == 0) ? 64u : (DFA ? TK_RX_AHEAD_DFA : TK_RX_AHEAD);  // (bytes a speculative match may look beyond its segment)
                 if constexpr (DFA) {  // (the device's form of the DFA's speculative lane: one loop over the segment)
-                    for (uint32_t s = 0; s < nseg; ++s) tk_rx_speculate_lane_flat(P, t, s, shift, spec, sgap, xexit);
+                    for (uint32_t s = 0; s < nseg; ++s) tk_rx_speculate_lane_flat<DFA == TK_RX_M_DFA_PREV>(P, t, s, shift, spec, sgap, xexit);
                 } else {
                     for (uint32_t s = 0; s < nseg; ++s) tk_rx_speculate_lane<DFA>(P, t, s, shift, spec, sgap, xexit);
                 }
@@ -155,8 +155,9 @@ int main(int argc, char** argv) {
                 free(sgap);
             };
             for (uint32_t shift : {TK_RX_SEG_SHIFT_SMALL, TK_RX_SEG_SHIFT_LARGE}) {
-                run_lanes(std::false_type{}, shift);
-                if (c.has_dfa()) run_lanes(std::true_type{}, shift), ++with_dfa;
+                run_lanes(std::integral_constant<int, TK_RX_M_PROGRAM>{}, shift);
+                if (c.has_dfa() && (c.dfa_flags & 1u)) run_lanes(std::integral_constant<int, TK_RX_M_DFA_PREV>{}, shift), ++with_dfa;
+                else if (c.has_dfa()) run_lanes(std::integral_constant<int, TK_RX_M_DFA>{}, shift), ++with_dfa;
             }
             free(text);
             free(brk);

@@ -673,7 +673,7 @@ uint64_t tks_rx_dfa(void* p, char* why, uint64_t cap) {
 // bit 4: the matcher is the pattern's DFA (it must have one: tks_rx_dfa) instead of the program; bit 5 (with bit 4): the speculative lanes in
 // their one-loop form (tk_rx_speculate_lane_flat), compared bit for bit with the piece-by-piece form (error 0xFE if they differ).
 // stats[0] = matcher runs of the speculative (+ link) pass, [1] = of the resolving pass.  Returns 0, or error bits | position << 8.
-template <bool DFA>
+template <int DFA>  // 0: the program; 1: the pattern's table; 2: the table of a pattern that looks behind
 static uint64_t rx_split_impl(void* p, const uint8_t* text_in, uint64_t n, const uint64_t* doc_off, uint64_t n_docs, const uint64_t* spec_at,
                               const uint64_t* spec_len, uint64_t n_spec, int speculate, uint8_t* starts, uint64_t* stats) {
     const uint32_t seg_shift = (speculate & 3) == 2 ? TK_RX_SEG_SHIFT_LARGE : TK_RX_SEG_SHIFT_SMALL;
@@ -701,9 +701,9 @@ static uint64_t rx_split_impl(void* p, const uint8_t* text_in, uint64_t n, const
     g_rx_matches = 0;
     if ((speculate & 3) && (speculate & 32)) {  // the one-loop form of the DFA's speculative lane: the same bitmaps and exits, bit for bit
         if constexpr (DFA) {
-            for (uint32_t k = 0; k < nseg; ++k) tk_rx_speculate_lane_flat(P, t, k, seg_shift, spec.data(), sgap.data(), xexit.data());
+            for (uint32_t k = 0; k < nseg; ++k) tk_rx_speculate_lane_flat<DFA == TK_RX_M_DFA_PREV>(P, t, k, seg_shift, spec.data(), sgap.data(), xexit.data());
             std::vector<uint32_t> spec2(nw, 0), sgap2(nw, 0), xexit2(nseg + 1, TK_RX_UNKNOWN);
-            for (uint32_t k = 0; k < nseg; ++k) tk_rx_speculate_lane<true>(P, t, k, seg_shift, spec2.data(), sgap2.data(), xexit2.data());
+            for (uint32_t k = 0; k < nseg; ++k) tk_rx_speculate_lane<DFA>(P, t, k, seg_shift, spec2.data(), sgap2.data(), xexit2.data());
             if (spec2 != spec || sgap2 != sgap || xexit2 != xexit) return 0xFEu;
         } else {
             return 0xFFu;
@@ -735,7 +735,8 @@ extern "C" uint64_t tks_rx_split(void* p, const uint8_t* text_in, uint64_t n, co
                                  const uint64_t* spec_len, uint64_t n_spec, int speculate, uint8_t* starts, uint64_t* stats) {
     if (speculate & 16) {
         if (!((const TkRxCompiled*)p)->has_dfa()) return 0xFFu;
-        return rx_split_impl<true>(p, text_in, n, doc_off, n_docs, spec_at, spec_len, n_spec, speculate, starts, stats);
+        if (((const TkRxCompiled*)p)->dfa_flags & 1u) return rx_split_impl<TK_RX_M_DFA_PREV>(p, text_in, n, doc_off, n_docs, spec_at, spec_len, n_spec, speculate, starts, stats);
+        return rx_split_impl<TK_RX_M_DFA>(p, text_in, n, doc_off, n_docs, spec_at, spec_len, n_spec, speculate, starts, stats);
     }
-    return rx_split_impl<false>(p, text_in, n, doc_off, n_docs, spec_at, spec_len, n_spec, speculate, starts, stats);
+    return rx_split_impl<TK_RX_M_PROGRAM>(p, text_in, n, doc_off, n_docs, spec_at, spec_len, n_spec, speculate, starts, stats);
 }

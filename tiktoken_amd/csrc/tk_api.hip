@@ -341,6 +341,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
             c->rx.dfa_nstates = X.dfa_nstates;
             c->rx.dfa_flags = X.dfa_flags;
             c->rx_form = (want && !strcmp(want, "dfa")) ? TK_RX_FORM_DFA : TK_RX_FORM_DFA_FLAT;
+            if (X.dfa_flags & 1u) c->rx_form += TK_RX_FORM_DFA_PREV - TK_RX_FORM_DFA;  // (a pattern that looks behind: the instantiations that read the char in front of a match)
         }
         return TK_OK;
     };
@@ -554,6 +555,8 @@ static int rx_split(tk_core* c, WorkSet& w, hipStream_t s, const uint8_t* d_text
     auto by_form = [&](auto&& launch) {
         if (c->rx_form == TK_RX_FORM_DFA_FLAT) launch(std::integral_constant<int, TK_RX_FORM_DFA_FLAT>{});
         else if (c->rx_form == TK_RX_FORM_DFA) launch(std::integral_constant<int, TK_RX_FORM_DFA>{});
+        else if (c->rx_form == TK_RX_FORM_DFA_FLAT_PREV) launch(std::integral_constant<int, TK_RX_FORM_DFA_FLAT_PREV>{});
+        else if (c->rx_form == TK_RX_FORM_DFA_PREV) launch(std::integral_constant<int, TK_RX_FORM_DFA_PREV>{});
         else launch(std::integral_constant<int, TK_RX_FORM_PROGRAM>{});
     };
     TRY(timed(c, s, "tk_k_rx_speculate", [&] {

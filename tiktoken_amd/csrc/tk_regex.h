@@ -165,11 +165,13 @@ TK_HD uint32_t tk_rx_ascii_cls(const TkRxProg& P, uint32_t b0) {
 }
 
 // the state in which a match that starts at `start` begins: 1 at the first char of a haystack, else 1 + the group of the char in front
-// (read only for a pattern that looks behind; as TK_RX_PREV reads it: a malformed char before the position counts as U+FFFD)
-template <class A>
+// (PREV: the pattern looks behind -- dfa_flags bit 0 -- and the char is read, as TK_RX_PREV reads it: a malformed char before the position
+// counts as U+FFFD.  A compile-time choice: the look-up costs the speculative kernel of every OTHER pattern 12 % when it is compiled in,
+// profiles/r03_generic_engine.txt)
+template <bool PREV, class A>
 TK_HD uint32_t tk_rx_dfa_start(const TkRxProg& P, A& t, uint32_t start) {
     if (start == 0u || t.hard(start)) return 1u;
-    if (!(P.dfa_flags & 1u)) return 2u;
+    if constexpr (!PREV) return 2u;
     uint32_t r = start - 1u, len;
     for (int k = 0; k < 3 && r > 0u && (t.byte(r) & 0xC0u) == 0x80u && !t.hard(r); ++k) --r;
     uint32_t cp = tk_rx_decode(t, r, &len);
@@ -178,10 +180,10 @@ TK_HD uint32_t tk_rx_dfa_start(const TkRxProg& P, A& t, uint32_t start) {
     return 1u + tk_rx_ascii_cls(P, 128u + cls);
 }
 
-template <class A>
+template <bool PREV, class A>
 TK_HD uint32_t tk_rx_match_dfa(const TkRxProg& P, A& t, uint32_t start) {
     const uint32_t ncls = P.dfa_ncls;
-    uint32_t state = tk_rx_dfa_start(P, t, start);
+    uint32_t state = tk_rx_dfa_start<PREV>(P, t, start);
     uint32_t pos = start, last = TK_RX_FAILED;
     for (;;) {
         uint32_t cls = 0u, len = 0u;  // (the end of the haystack)
@@ -297,10 +299,10 @@ TK_HD void tk_rx_run_lane(const TkRxProg& P, A& t, uint32_t S, uint32_t start, u
 
 // coop(S, start, pos, base, &pbad, &m1, &pnext): every lane j of the group runs tk_rx_run_lane on the block base + 16 j; pbad = the smallest
 // `bad` (NONE: the whole KiB is in the run -- pnext = the last lane's `endp` is where it goes on), m1 = 1 + the largest `mat` in front of pbad (0: none).
-template <class A, class Coop>
+template <bool PREV, class A, class Coop>
 TK_HD uint32_t tk_rx_match_dfa_coop(const TkRxProg& P, A& t, uint32_t start, Coop&& coop) {
     const uint32_t ncls = P.dfa_ncls;
-    uint32_t state = tk_rx_dfa_start(P, t, start);
+    uint32_t state = tk_rx_dfa_start<PREV>(P, t, start);
     uint32_t pos = start, last = TK_RX_FAILED, streak = 0u;
     for (;;) {
         uint32_t cls = 0u, len = 0u;  // (the end of the haystack)
@@ -534,9 +536,13 @@ TK_HD uint32_t tk_rx_match(const TkRxProg& P, A& t, uint32_t start) {
     }
 }
 
-// DFA: the table form (P.dfa_trans is there); otherwise the program
-template <bool DFA, class A>
+// DFA: 0 = the program; 1 = the table form (P.dfa_trans is there); 2 = the table of a pattern that looks behind (P.dfa_flags bit 0)
+#define TK_RX_M_PROGRAM 0
+#define TK_RX_M_DFA 1
+#define TK_RX_M_DFA_PREV 2
+template <int DFA, class A>
 TK_HD uint32_t tk_rx_match_sel(const TkRxProg& P, A& t, uint32_t start) {
-    if constexpr (DFA) return tk_rx_match_dfa(P, t, start);
+    if constexpr (DFA == TK_RX_M_DFA_PREV) return tk_rx_match_dfa<true>(P, t, start);
+    else if constexpr (DFA == TK_RX_M_DFA) return tk_rx_match_dfa<false>(P, t, start);
     else return tk_rx_match(P, t, start);
 }

@@ -40,7 +40,10 @@ struct TkRxDev {  // the compiled program in device memory
     const uint8_t* dfa_s2;
     uint32_t dfa_ncls, dfa_nstates, dfa_flags;
 };
-enum { TK_RX_FORM_PROGRAM = 0, TK_RX_FORM_DFA = 1, TK_RX_FORM_DFA_FLAT = 2 };  // (FLAT: the speculative pass as one loop; the other kernels as DFA)
+// (FLAT: the speculative pass as one loop, the other kernels as DFA; _PREV: the table of a pattern that looks behind -- its matcher reads the
+// char in front of a match, an instantiation of its own so that the others do not carry that code)
+enum { TK_RX_FORM_PROGRAM = 0, TK_RX_FORM_DFA = 1, TK_RX_FORM_DFA_FLAT = 2, TK_RX_FORM_DFA_PREV = 3, TK_RX_FORM_DFA_FLAT_PREV = 4 };
+constexpr int tk_rx_matcher_of(int form) { return form == TK_RX_FORM_PROGRAM ? TK_RX_M_PROGRAM : (form >= TK_RX_FORM_DFA_PREV ? TK_RX_M_DFA_PREV : TK_RX_M_DFA); }
 // bytes of dynamic LDS the DFA forms need
 static inline uint32_t tk_rx_dfa_lds_bytes(const TkRxDev& R) { return ((R.dfa_nstates * R.dfa_ncls + 1u) / 2u) * 4u + 384u + 0x1100u * 2u; }
 
@@ -104,8 +107,9 @@ __global__ __launch_bounds__(256) void tk_k_rx_speculate(TkRxDev R, const uint8_
     TkRxText t{text, n, brk, ss, si, 0xFFFFFFFFu, false};
     t.ahead = ahead;
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += gridDim.x * blockDim.x) {
-        if constexpr (FORM == TK_RX_FORM_DFA_FLAT) tk_rx_speculate_lane_flat(P, t, k, seg_shift, spec, sgap, xexit);
-        else tk_rx_speculate_lane<FORM != TK_RX_FORM_PROGRAM>(P, t, k, seg_shift, spec, sgap, xexit);
+        if constexpr (FORM == TK_RX_FORM_DFA_FLAT) tk_rx_speculate_lane_flat<false>(P, t, k, seg_shift, spec, sgap, xexit);
+        else if constexpr (FORM == TK_RX_FORM_DFA_FLAT_PREV) tk_rx_speculate_lane_flat<true>(P, t, k, seg_shift, spec, sgap, xexit);
+        else tk_rx_speculate_lane<tk_rx_matcher_of(FORM)>(P, t, k, seg_shift, spec, sgap, xexit);
     }
 }
 
@@ -119,7 +123,7 @@ __global__ __launch_bounds__(256) void tk_k_rx_link(TkRxDev R, const uint8_t* __
     TkRxText t{text, n, brk, ss, si, 0xFFFFFFFFu, false};
     t.ahead = ahead;
     for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < nseg; k += gridDim.x * blockDim.x)
-        tk_rx_link_lane<FORM != TK_RX_FORM_PROGRAM>(P, t, k, seg_shift, spec, xexit, lnk, lgap, lmerge, lexit);
+        tk_rx_link_lane<tk_rx_matcher_of(FORM)>(P, t, k, seg_shift, spec, xexit, lnk, lgap, lmerge, lexit);
 }
 
 // one lane per document (debug bit 0x40000; the CPU tests run this form lane by lane)
@@ -134,7 +138,7 @@ __global__ __launch_bounds__(256) void tk_k_rx_resolve(TkRxDev R, const uint8_t*
         const uint64_t b = doc_off[d] - base, e = doc_off[d + 1] - base;
         if (b >= e || e > n) continue;
         uint32_t err_pos = 0;
-        const uint32_t err = tk_rx_resolve_lane<FORM != TK_RX_FORM_PROGRAM>(P, t, M, (uint32_t)b, (uint32_t)e,
+        const uint32_t err = tk_rx_resolve_lane<tk_rx_matcher_of(FORM)>(P, t, M, (uint32_t)b, (uint32_t)e,
                                                 [&](uint32_t w, uint32_t bits, uint32_t gaps) {
                                                     if (bits) atomicOr(&gst[w], bits);
                                                     if (gaps) atomicOr(&ggap[w], gaps);
@@ -205,7 +209,7 @@ __global__ __launch_bounds__(256) void tk_k_rx_resolve_wave(TkRxDev R, const uin
                         *pbad = pb;
                         *m1 = m;
                     };
-                    p = tk_rx_resolve_step_with(P, t, M, p, e, orb_lane0, &err, [&](uint32_t at) { return tk_rx_match_dfa_coop(P, t, at, coop); });
+                    p = tk_rx_resolve_step_with(P, t, M, p, e, orb_lane0, &err, [&](uint32_t at) { return tk_rx_match_dfa_coop<tk_rx_matcher_of(FORM) == TK_RX_M_DFA_PREV>(P, t, at, coop); });
                 } else {
                     p = tk_rx_resolve_step<false>(P, t, M, p, e, orb_lane0, &err);
                 }

@@ -120,7 +120,7 @@ struct TkRxText {
 };
 
 // the start that follows the piece (or special token, or gap char) that starts at p; or an error code (TK_RX_IS_ERROR: stack, budget).
-// DFA (here and below): the matcher is the pattern's table form (tk_rx_match_dfa) instead of the program.
+// DFA (here and below): 0 = the program, 1 = the pattern's table form (tk_rx_match_dfa), 2 = the table of a pattern that looks behind.
 // (match(p): the end of the match that starts at p -- tk_rx_match_sel, or a group of lanes together: tk_rx_match_dfa_coop)
 template <class Match>
 TK_HD uint32_t tk_rx_next_with(const TkRxProg& P, TkRxText& t, uint32_t p, bool* gap, Match&& match) {
@@ -140,7 +140,7 @@ TK_HD uint32_t tk_rx_next_with(const TkRxProg& P, TkRxText& t, uint32_t p, bool*
     return q;
 }
 
-template <bool DFA = false>
+template <int DFA = 0>
 TK_HD uint32_t tk_rx_next(const TkRxProg& P, TkRxText& t, uint32_t p, bool* gap) {
     return tk_rx_next_with(P, t, p, gap, [&](uint32_t at) { return tk_rx_match_sel<DFA>(P, t, at); });
 }
@@ -149,7 +149,7 @@ TK_HD uint32_t tk_rx_next(const TkRxProg& P, TkRxText& t, uint32_t p, bool* gap)
 TK_HD bool tk_rx_bit(const uint32_t* bm, uint32_t p) { return (bm[p >> 5] >> (p & 31u)) & 1u; }
 
 // the chain of segment [.., end) from its start p on (first: the segment's first start), as described above; returns the segment's exit
-template <bool DFA = false>
+template <int DFA = 0>
 TK_HD uint32_t tk_rx_speculate_chain(const TkRxProg& P, TkRxText& t, uint32_t p, uint32_t first, uint32_t end, uint32_t limit, uint32_t* spec, uint32_t* sgap) {
     for (;;) {
         spec[p >> 5] |= 1u << (p & 31u);  // (the words of a segment belong to its lane)
@@ -173,7 +173,7 @@ TK_HD uint32_t tk_rx_speculate_chain(const TkRxProg& P, TkRxText& t, uint32_t p,
     }
 }
 
-template <bool DFA = false>
+template <int DFA = 0>
 TK_HD void tk_rx_speculate_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint32_t seg_shift, uint32_t* spec, uint32_t* sgap, uint32_t* xexit) {
     const uint64_t a64 = (uint64_t)k << seg_shift;
     if (a64 >= t.n) return;
@@ -193,6 +193,7 @@ TK_HD void tk_rx_speculate_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint3
 // pieces as its busiest lane has).  The bits of a bitmap word are collected in a register and stored once.  What is rare leaves the loop
 // and goes on in tk_rx_speculate_chain from the piece at hand: a special token, a match that looks TK_RX_AHEAD bytes beyond the segment.
 // Same bitmaps and exits as tk_rx_speculate_lane<true> (the CPU tests compare them bit for bit).
+template <bool PREV = false>
 TK_HD void tk_rx_speculate_lane_flat(const TkRxProg& P, TkRxText t, uint32_t k, uint32_t seg_shift, uint32_t* spec, uint32_t* sgap, uint32_t* xexit) {
     const uint64_t a64 = (uint64_t)k << seg_shift;
     if (a64 >= t.n) return;
@@ -224,7 +225,7 @@ TK_HD void tk_rx_speculate_lane_flat(const TkRxProg& P, TkRxText t, uint32_t k, 
     note_start(p);
     uint32_t x = TK_RX_UNKNOWN;
     bool slow = t.special(p);
-    uint32_t pos = p, last = TK_RX_FAILED, state = tk_rx_dfa_start(P, t, p);
+    uint32_t pos = p, last = TK_RX_FAILED, state = tk_rx_dfa_start<PREV>(P, t, p);
     while (!slow) {
         uint32_t cls = 0u, len = 0u;  // (the end of the haystack)
         if (pos < t.n) {
@@ -275,10 +276,11 @@ TK_HD void tk_rx_speculate_lane_flat(const TkRxProg& P, TkRxText t, uint32_t k, 
         }
         pos = p;
         last = TK_RX_FAILED;
-        state = tk_rx_dfa_start(P, t, p);
+        if constexpr (PREV) state = tk_rx_dfa_start<true>(P, t, p);
+        else state = t.hard(p) ? 1u : 2u;  // (p > 0 here)
     }
     flush();
-    if (slow) x = tk_rx_speculate_chain<true>(P, t, p, first, end, limit, spec, sgap);
+    if (slow) x = tk_rx_speculate_chain<PREV ? TK_RX_M_DFA_PREV : TK_RX_M_DFA>(P, t, p, first, end, limit, spec, sgap);
     xexit[k] = x;
 }
 
@@ -289,7 +291,7 @@ TK_HD void tk_rx_speculate_lane_flat(const TkRxProg& P, TkRxText t, uint32_t k, 
 // chain (lmerge[k] = end of the segment, lexit[k] = where to).  With the links the resolving pass runs the matcher only where a guess was
 // wrong: entering segment k at xexit[k - 1] it takes the link's steps, then the chain's from the meeting point on, and jumps to xexit[k].
 #define TK_RX_NOLINK 0xFFFFFFFFu
-template <bool DFA = false>
+template <int DFA = 0>
 TK_HD void tk_rx_link_lane(const TkRxProg& P, TkRxText t, uint32_t k, uint32_t seg_shift, const uint32_t* spec, const uint32_t* xexit,
                            uint32_t* lnk, uint32_t* lgap, uint32_t* lmerge, uint32_t* lexit) {
     const uint64_t a64 = (uint64_t)k << seg_shift;
@@ -409,14 +411,14 @@ TK_HD uint32_t tk_rx_resolve_step_with(const TkRxProg& P, TkRxText& t, const TkR
     if (gap) orbits(p >> 5, 0u, 1u << (p & 31u));
     return q;
 }
-template <bool DFA = false, class Or>
+template <int DFA = 0, class Or>
 TK_HD uint32_t tk_rx_resolve_step(const TkRxProg& P, TkRxText& t, const TkRxMaps& M, uint32_t p, uint32_t e, Or&& orbits, uint32_t* err) {
     return tk_rx_resolve_step_with(P, t, M, p, e, orbits, err, [&](uint32_t at) { return tk_rx_match_sel<DFA>(P, t, at); });
 }
 
 // One document [b, e) of the chunk by one lane.  `orbits(word index, start bits, gap bits)` ORs into the bitmaps of true starts and of the
 // gap chars among them (shared words: atomic on the device).  Returns 0 or the error bits.
-template <bool DFA = false, class Or>
+template <int DFA = 0, class Or>
 TK_HD uint32_t tk_rx_resolve_lane(const TkRxProg& P, TkRxText t, const TkRxMaps& M, uint32_t b, uint32_t e, Or&& orbits, uint32_t* err_pos) {
     t.limit = 0xFFFFFFFFu;
     t.hit = false;
@@ -436,7 +438,7 @@ TK_HD uint32_t tk_rx_resolve_lane(const TkRxProg& P, TkRxText t, const TkRxMaps&
 // taken in one go, and the chain continues behind it.  Where lane 0 has no plan the group takes one step of the serial form.  The host
 // form runs the lanes one after the other (the CPU tests); the device form (tk_regex_kernels.h) ballots.
 #define TK_RX_WAVE 64u
-template <bool DFA = false, class Or>
+template <int DFA = 0, class Or>
 TK_HD uint32_t tk_rx_resolve_group_host(const TkRxProg& P, TkRxText t, const TkRxMaps& M, uint32_t b, uint32_t e, Or&& orbits, uint32_t* err_pos) {
     t.limit = 0xFFFFFFFFu;
     t.hit = false;
@@ -467,7 +469,7 @@ TK_HD uint32_t tk_rx_resolve_group_host(const TkRxProg& P, TkRxText t, const TkR
                     *pbad = pb;
                     *m1 = m;
                 };
-                p = tk_rx_resolve_step_with(P, t, M, p, e, orbits, &err, [&](uint32_t at) { return tk_rx_match_dfa_coop(P, t, at, coop); });
+                p = tk_rx_resolve_step_with(P, t, M, p, e, orbits, &err, [&](uint32_t at) { return tk_rx_match_dfa_coop<DFA == TK_RX_M_DFA_PREV>(P, t, at, coop); });
             } else {
                 p = tk_rx_resolve_step<DFA>(P, t, M, p, e, orbits, &err);
             }
