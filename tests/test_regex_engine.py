@@ -665,3 +665,32 @@ def test_long_runs_matched_by_a_group_of_lanes():
         want = rx.split(one, speculate=0, matcher="dfa")
         for mode in (13, 14):
             assert rx.split(one, speculate=mode, matcher="dfa") == want, (pat, mode)
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2, 16, 17])
+def test_tables_on_every_short_string(idx):
+    """Exhaustive: every string of at most four symbols over representatives of the classes the stock patterns tell apart (+ Kimi-K2's
+    pattern and the word-boundary one), packed into documents of their own -- the pattern's DFA (lane by lane and by groups) and the program
+    against Python `regex`.  What a table gets wrong it gets wrong on a short string: a priority among alternatives, a look-ahead at the
+    end of the text, a possessive repeat that gives something back."""
+    import itertools
+
+    pat, py = PATTERNS[idx]
+    py = py or pat
+    rx = h.RxSim(pat)
+    assert rx.dfa
+    syms = ["a", "A", "s", "'", "1", " ", "\n", "\r", ".", "é", "中", "́"]
+    pyc = regex.compile(py)
+    docs, want, wgap, base = [], [], [], 0
+    for n in range(1, 5):
+        for tup in itertools.product(syms, repeat=n):
+            t = "".join(tup)
+            st, gp = py_starts_gaps(pyc, t)
+            docs.append(t.encode())
+            want += [base + s for s in st]
+            wgap += [base + s for s in gp]
+            base += len(docs[-1])
+    assert len(docs) == 12 + 12 ** 2 + 12 ** 3 + 12 ** 4
+    for mode in (0, 5, 14):
+        assert rx.split(docs, speculate=mode, matcher="dfa") == want and rx.gaps == wgap, mode
+    assert rx.split(docs, speculate=5, matcher="program") == want
