@@ -15,4 +15,8 @@ timeout 300 python tools/stress_repeats.py o200k_shaped > gpurun_out/${TAG}_long
 timeout 300 python tools/generic_vs_scanners.py 256 > gpurun_out/${TAG}_generic_vs_scanners.txt 2>&1; cut -c1-400 gpurun_out/${TAG}_generic_vs_scanners.txt
 timeout 120 python tools/rx_diag.py > gpurun_out/${TAG}_generic_pat_small_batches.txt 2>&1; tail -3 gpurun_out/${TAG}_generic_pat_small_batches.txt | cut -c1-300
 timeout 300 python tools/gpu_fuzz.py 4 24 100 > gpurun_out/${TAG}_fuzz.txt 2>&1; tail -1 gpurun_out/${TAG}_fuzz.txt
+for F in flat dfa program; do  # the generic engine's kernels in their three forms (the pattern's DFA with the one-loop speculative pass, piece by piece, the program)
+  TIKTOKEN_AMD_RX_MATCHER=$F timeout 300 python bench.py --generic-engine --mib 256 --steps 3 --warmup 1 --no-host-path --no-hf --cpu-sample-mib 32 > gpurun_out/${TAG}_bench_generic_engine_256_$F.json 2> gpurun_out/${TAG}_bench_generic_engine_256_$F.err; cut -c100-300 gpurun_out/${TAG}_bench_generic_engine_256_$F.json
+done
+timeout 120 python tools/gpu_fuzz.py generic 60 777 > gpurun_out/${TAG}_fuzz_generic.txt 2>&1; tail -1 gpurun_out/${TAG}_fuzz_generic.txt
 timeout 600 python bench.py --generic-engine --steps 3 --warmup 1 --no-host-path > gpurun_out/${TAG}_bench_generic_engine.json 2> gpurun_out/${TAG}_bench_generic_engine.err; cut -c1-300 gpurun_out/${TAG}_bench_generic_engine.json
