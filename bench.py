@@ -146,6 +146,29 @@ def one_process(args, torch):
                                                       "gather": "rccl" if core.group_stat("gathers_rccl") else "peer copies"}}), flush=True)
 
 
+def generic_engine_figure(encoding: str, mib: int = 256):
+    """Never `value`: the same pat_str through the generic engine (where any pat_str outside the three scanner families runs: the pattern
+    as a DFA in LDS, tk_regex_dfa.inc) on the first `mib` MiB-sized corpus of the same generator, in a process of its own -- this very script
+    with --generic-engine, every token compared with the oracle there.  A failure of that process is reported, not raised: the line of
+    this run does not depend on it."""
+    import subprocess
+
+    cmd = [sys.executable, os.path.abspath(__file__), "--generic-engine", "--mib", str(mib), "--steps", "3", "--warmup", "1", "--no-host-path", "--no-hf",
+           "--cpu-sample-mib", "16", "--encoding", encoding]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    try:
+        r = subprocess.run(cmd, capture_output=True, text=True, timeout=240, env=env)
+        lines = [ln for ln in r.stdout.strip().splitlines() if ln.startswith("{")]
+        j = json.loads(lines[-1])
+        k = (j.get("roofline") or {}).get("kernels_ms_avg") or {}
+        return {"gbps": j["value"], "ms_per_step": j["ms_per_step"], "mib": mib, "all_tokens_equal_to_the_oracle": j.get("parity_all_tokens_vs_oracle"),
+                "kernels_ms_avg": {n: v for n, v in k.items() if "rx_" in n},
+                "what": f"bench.py --generic-engine --mib {mib} --steps 3 --warmup 1 in a process of its own: the encoding's pat_str forced through the generic "
+                        "regex engine (its DFA form) instead of the hand-written scanners, inputs resident in HBM, every token compared with the oracle"}
+    except Exception as e:  # (time-out, no line, ...)
+        return {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -423,6 +446,10 @@ def main():
                 del e2, kw
             cold = dict(best, what=f"{args.encoding}: vocabulary file -> Encoding -> first encode(), library loaded and device initialised, best of 3")
 
+    generic = None
+    if rank == 0 and world == 1 and not args.no_host_path and not args.generic_engine:
+        generic = generic_engine_figure(args.encoding)
+
     if rank == 0:
         line = {
             "metric": "GB/s text encoded (o200k_base-shaped vocab, 1 GiB corpus per GPU), bit-exact vs CoreBPE restatement",
@@ -437,14 +464,15 @@ def main():
                        "tokens_total": total_tokens, "pieces_rank0": stats["pieces"],
                        "parallelism": f"doc-sharded x{world}" + (" + RCCL gather of token ids to rank 0" if world > 1 else "")},
             "roofline": roofline, "cpu_baseline": cpu, "parity_all_tokens_vs_oracle": parity, "host_path": host_path,
-            "lds_piece_cache": hot, "cold_start": cold,
+            "lds_piece_cache": hot, "cold_start": cold, "generic_engine": generic,
             "host": {"cpus": ncpu, "nproc": os.cpu_count(), "cgroup_cpu_max": _read_first("/sys/fs/cgroup/cpu.max"),
                      "loadavg": _read_first("/proc/loadavg"), "corpus_gen_s": round(t_gen, 2)},
         }
         print(json.dumps(line), flush=True)
         hf = (cpu or {}).get("rust_cpu_tokenizer_for_context") or {}
         if parity is False or hf.get("same_ids_as_oracle_on_a_sample_of_documents") is False or \
-                (host_path or {}).get("t2_identical_to_checked_result") is False or (host_path or {}).get("decode_identical_to_the_text") is False:
+                (host_path or {}).get("t2_identical_to_checked_result") is False or (host_path or {}).get("decode_identical_to_the_text") is False or \
+                (generic or {}).get("all_tokens_equal_to_the_oracle") is False:
             print("bench: a parity check failed (see the line above)", file=sys.stderr)
             sys.exit(3)
     if dist:
