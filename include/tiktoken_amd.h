@@ -78,7 +78,8 @@ int tk_encode_batch_device(tk_core* core, const void* d_utf8, uint64_t n_bytes, 
 
 /* Test / debug entry with no reference counterpart: the piece boundaries the GPU pre-tokeniser
  * finds, i.e. what `regex.find_iter` yields at src/lib.rs:365 and :405.  *starts_out receives
- * n_pieces+1 ascending uint32 offsets (last = total bytes); release with tk_free.  Single chunk. */
+ * n_pieces+1 ascending uint32 offsets (last = total bytes); release with tk_free.  Single chunk, less
+ * than 2 GiB (bit 31 of an offset marks a char a generic pat_str does not match). */
 int tk_pretokenize_batch(tk_core* core, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special,
                          const uint32_t* allowed_ids, uint64_t n_allowed, uint32_t** starts_out, uint64_t* n_out);
 

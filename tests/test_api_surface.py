@@ -136,25 +136,34 @@ def test_model_table():
 
 
 def test_rank_table_fills_itself_on_first_use():
-    """vocab_io.RankTable: the parsed file stays in packed arrays (what tk_create takes) until somebody reads the dict."""
+    """vocab_io.RankTable: with lazy=True the parsed file stays in packed arrays (what tk_create takes) until somebody reads the dict;
+    the public default is a filled dict (C code that reads a dict's storage sees the real contents)."""
     src = {bytes([i]): i for i in range(256)}
     src.update({b"ab": 256, b"abc": 257, b"\xe4\xb8\xad": 258})
     text = b"".join(base64.b64encode(k) + b" %d\n" % v for k, v in src.items())
-    t = vocab_io.parse_tiktoken_bpe(text)
+    t = vocab_io.parse_tiktoken_bpe(text, lazy=True)
     assert t._pending is not None and t.max_rank() == 258 and t._pending is not None  # nothing walked the dict
     assert t.packed is not None and len(t.packed[2]) == len(src)
     assert len(t) == len(src) and t._pending is None  # the first use filled it
     assert t == src and src == t and dict(t) == src and t[b"abc"] == 257 and b"zz" not in t and t.get(b"zz", 7) == 7
     for fresh_use in (lambda x: x[b"ab"], lambda x: b"ab" in x, lambda x: list(x)[0], lambda x: {**x}, lambda x: x.items(), lambda x: repr(x), lambda x: x.copy()):
-        u = vocab_io.parse_tiktoken_bpe(text)
+        u = vocab_io.parse_tiktoken_bpe(text, lazy=True)
         fresh_use(u)
         assert u._pending is None and dict.__len__(u) == len(src)
-    u = vocab_io.parse_tiktoken_bpe(text)
+    u = vocab_io.parse_tiktoken_bpe(text, lazy=True)
     u[b"new"] = 300
     assert u.packed is None and len(u) == len(src) + 1 and u.max_rank() == 300
     import pickle
 
-    assert pickle.loads(pickle.dumps(vocab_io.parse_tiktoken_bpe(text))) == src
-    dup = vocab_io.parse_tiktoken_bpe(b"YQ== 0\nYg== 1\nYQ== 2\n")  # a token listed twice: the dict keeps the later rank
+    assert pickle.loads(pickle.dumps(vocab_io.parse_tiktoken_bpe(text, lazy=True))) == src
+    dup = vocab_io.parse_tiktoken_bpe(b"YQ== 0\nYg== 1\nYQ== 2\n", lazy=True)  # a token listed twice: the dict keeps the later rank
     assert dict(dup) == {b"a": 2, b"b": 1} and dup.packed is None
+    # the default: filled at once; two tables that are both still lazy compare by contents
+    e = vocab_io.parse_tiktoken_bpe(text)
+    assert e._pending is None and dict.__len__(e) == len(src) and e.packed is not None
+    assert vocab_io.parse_tiktoken_bpe(text, lazy=True) == vocab_io.parse_tiktoken_bpe(text, lazy=True)
+    assert not (vocab_io.parse_tiktoken_bpe(text, lazy=True) != vocab_io.parse_tiktoken_bpe(text, lazy=True))
+    assert (vocab_io.parse_tiktoken_bpe(text, lazy=True) | vocab_io.parse_tiktoken_bpe(b"eno= 999\n", lazy=True))[b"zz"] == 999
+    d5 = vocab_io.parse_tiktoken_bpe(b"YQ== 0\nYg== 5\nYg== 3\n")  # the largest rank belongs to a token that is listed again
+    assert d5.max_rank() == 3 and dict(d5) == {b"a": 0, b"b": 3}
 

@@ -351,13 +351,19 @@ def test_encoding_from_a_parsed_file_never_walks_the_dict():
     g = h.load_golden("cl100k_shaped")
     ranks = h.golden_vocab("cl100k_shaped")
     text = b"".join(base64.b64encode(k) + b" %d\n" % v for k, v in ranks.items())
-    table = vocab_io.parse_tiktoken_bpe(text)
+    table = vocab_io.parse_tiktoken_bpe(text, lazy=True)
     enc = tiktoken.Encoding("t1", pat_str=g["pat_str"], mergeable_ranks=table, special_tokens=g["special_tokens"])
     assert table._pending is not None  # still packed: nobody needed the dict
     ref = tiktoken.Encoding("t2", pat_str=g["pat_str"], mergeable_ranks=dict(ranks), special_tokens=g["special_tokens"])
     s = "The quick brown fox's 12345 jumps\n\n over the lazy dog. 中文 \U0001F600"
     assert enc.encode_ordinary(s) == ref.encode_ordinary(s)
     some = next(k for k in ranks if len(k) == 3)
-    dup = vocab_io.parse_tiktoken_bpe(text + base64.b64encode(some) + b" %d\n" % (max(ranks.values()) + 1))
+    dup = vocab_io.parse_tiktoken_bpe(text + base64.b64encode(some) + b" %d\n" % (max(ranks.values()) + 1), lazy=True)
     enc2 = tiktoken.Encoding("t3", pat_str=g["pat_str"], mergeable_ranks=dup, special_tokens={})
     assert enc2.encode_single_token(some) == max(ranks.values()) + 1
+    # the largest rank belongs to a token that is listed again with a smaller one: max_token_value follows the dict, as the reference's does
+    top = max(ranks.values())
+    first = next(k for k, v in ranks.items() if v == 0)
+    dup2 = vocab_io.parse_tiktoken_bpe(text + base64.b64encode(b"\xf5\xf6\xf7") + b" %d\n" % (top + 9) + base64.b64encode(b"\xf5\xf6\xf7") + b" %d\n" % (top + 1), lazy=True)
+    enc3 = tiktoken.Encoding("t4", pat_str=g["pat_str"], mergeable_ranks=dup2, special_tokens={})
+    assert enc3.max_token_value == top + 1 and first in enc3._mergeable_ranks and dict.__len__(enc3._mergeable_ranks) == len(ranks) + 1

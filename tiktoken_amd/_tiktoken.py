@@ -125,6 +125,8 @@ class CoreBPE:
                 continue
             break
         _lib.raise_for(rc)
+        if fresh:
+            encoder._distinct = True  # (tk_create refuses a token listed twice)
         self._h = h
         self._L = L
         self.device = device

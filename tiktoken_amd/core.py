@@ -55,15 +55,23 @@ class Encoding:
         """
         self.name = name
         self._pat_str = pat_str
-        self._mergeable_ranks = mergeable_ranks
+        self._ranks = mergeable_ranks
         self._special_tokens = special_tokens
-        top = mergeable_ranks.max_rank() if hasattr(mergeable_ranks, "max_rank") else max(mergeable_ranks.values())  # (vocab_io.RankTable: no dict walk)
+        self._special_token_values = set(special_tokens.values())
+        self._core_bpe = _tiktoken.CoreBPE(mergeable_ranks, special_tokens, pat_str)
+        # (vocab_io.RankTable: count and largest rank without a dict walk -- asked AFTER tk_create has seen the arrays: a file that lists a
+        # token twice has been collapsed to the dict by then, the later rank kept as in the reference's load.py:159-171)
+        top = mergeable_ranks.max_rank() if hasattr(mergeable_ranks, "max_rank") else max(mergeable_ranks.values())
         self.max_token_value = max(top, max(special_tokens.values(), default=0))
         if explicit_n_vocab:
             assert len(mergeable_ranks) + len(special_tokens) == explicit_n_vocab
             assert self.max_token_value == explicit_n_vocab - 1
-        self._special_token_values = set(special_tokens.values())
-        self._core_bpe = _tiktoken.CoreBPE(mergeable_ranks, special_tokens, pat_str)
+
+    @property
+    def _mergeable_ranks(self) -> dict[bytes, int]:
+        """(a RankTable is filled before it leaves: C code that reads a dict's storage directly would see it empty otherwise)"""
+        r = self._ranks
+        return r.materialize() if hasattr(r, "materialize") else r
 
     def __repr__(self) -> str:
         return f"<Encoding {self.name!r}>"

@@ -70,8 +70,8 @@ struct KernelStat {
 
 // Work buffers of ONE chunk in flight.
 struct WorkSet {
-    Buf text_al, tile_sum, wide_ws, scan_sums, row_base, brk, docb, cand, ss, si, starts, blockcnt, pstart, res, rflag, miss, staging, listB, listC, counters, total, g_id, g_rk,
-        g_nx, g_pv, g_lv, tile_np, tile_nt, tile_nmiss, mt_slots, wbin, wave_pieces, deferred, big, rx_spec, rx_gst, rx_lnk, rx_exit, merge_work;
+    Buf text_al, tile_sum, wide_ws, scan_sums, row_base, brk, docb, cand, ss, si, starts, blockcnt, pstart, res, staging, listB, listC, counters, total, g_id, g_rk,
+        g_nx, g_pv, g_lv, tile_np, tile_nt, mt_keys, mtab, movf, wbin, deferred, big, rx_spec, rx_gst, rx_lnk, rx_exit, merge_work;
     hipStream_t sb = nullptr;        // the set's back stage in a multi-chunk batch: back stages of different chunks overlap each other too
                                      // (they are chains of short latency-bound kernels, ~2 ms however small the chunk)
     hipEvent_t ev_front = nullptr;   // the front kernel is done
@@ -82,8 +82,8 @@ struct WorkSet {
     uint32_t* h_counters = nullptr;  // pinned [2][TK_CNT_N]
     uint64_t* h_total = nullptr;     // pinned [2]: tokens, pieces of the chunk
     std::vector<Buf*> all() {
-        return {&text_al, &tile_sum, &wide_ws, &scan_sums, &row_base, &brk, &docb, &cand, &ss, &si, &starts, &blockcnt, &pstart, &res, &rflag, &miss, &staging, &listB,
-                &listC, &counters, &total, &g_id, &g_rk, &g_nx, &g_pv, &g_lv, &tile_np, &tile_nt, &tile_nmiss, &mt_slots, &wbin, &wave_pieces, &deferred, &big, &rx_spec,
+        return {&text_al, &tile_sum, &wide_ws, &scan_sums, &row_base, &brk, &docb, &cand, &ss, &si, &starts, &blockcnt, &pstart, &res, &staging, &listB,
+                &listC, &counters, &total, &g_id, &g_rk, &g_nx, &g_pv, &g_lv, &tile_np, &tile_nt, &mt_keys, &mtab, &movf, &wbin, &deferred, &big, &rx_spec,
                 &rx_gst, &rx_lnk, &rx_exit, &merge_work};
     }
 };
@@ -93,12 +93,16 @@ struct ChunkJob {
     uint64_t n = 0, n_docs = 0, base = 0, ntiles = 0;
     const uint64_t* d_doc_off = nullptr;
     uint64_t* d_tok_off = nullptr;
-    bool single_piece = false, spec = false;
+    bool single_piece = false, spec = false, pretok = false;
     uint32_t index = 0;  // position of the chunk in its batch
     uint32_t mt_bits = 14;
-    TkMissSlot* mt = nullptr;
-    TkBins bins{};
+    TkMissKey* mt = nullptr;   // the in-call miss table's keys (null: no table -- every missed piece gets an overflow entry)
+    uint32_t ovf_base = 0;     // slots of the table = index of the first overflow entry of the miss data
+    uint32_t ovf_cap = 0;      // overflow entries there is room for
 };
+
+// the chunk's entries of distinct missed pieces, as the kernels take them
+static TkMiss miss_of(WorkSet& w, const ChunkJob& job) { return TkMiss{w.mtab.as<TkMissTab>(), w.movf.as<TkMissOvf>(), job.ovf_base}; }
 
 struct tk_core {
     int device = 0;
@@ -116,6 +120,7 @@ struct tk_core {
     bool has_rx_fb = false;  // a pat_str of the scanner families, compiled for the generic engine as well: the way out of stretches without certain starts (stage_deferred)
     TkRxCompiled rx_fb;
     uint64_t st_fallbacks = 0;  // chunks that took that way
+    uint64_t st_regrown = 0;    // batches repeated with a larger miss data (encode_device_locked)
     TkRxDev rx{};
     Buf t_rx_ins, t_rx_sets, t_rx_ranges, t_rx_first, t_rx_s1, t_rx_s2, t_rx_dtrans, t_rx_dascii, t_rx_ds1, t_rx_ds2;
     int rx_form = TK_RX_FORM_PROGRAM;  // how the generic engine's kernels match: the pattern's DFA where it has one ($TIKTOKEN_AMD_RX_MATCHER)
@@ -123,6 +128,7 @@ struct tk_core {
     // workspace: per chunk in flight, and what a whole call shares
     WorkSet ws[TK_NSET];
     Buf text, doc_off, out_tokens, out_tok_off, allowed, tok_bases;  // tok_bases[k]: tokens of the chunks before chunk k (on the device)
+    bool ovf_full = false;  // a batch has asked for more overflow entries of the miss data than the default: room for the worst case from then on
     uint64_t chunk_bytes = 1ull << 30;  // one chunk per GiB: smaller chunks pipeline (stage_front / stage_back) but pay the merge kernels' fixed latency per chunk
     int dbg = 0;
     uint32_t n_cu = 256;             // compute units of the device
@@ -143,6 +149,7 @@ struct tk_core {
         uint32_t seq = 0;
         Buf ws;
         hipStream_t s = nullptr;
+        bool ready = false;       // every piece above has been made (set last: a first use that failed half-way is repeated by the next caller)
     };
     SmallSlot small[TK_SMALL_SLOTS];
     std::vector<uint8_t> sorted_blob;  // token_byte_values(), packed (built on first use)
@@ -609,18 +616,19 @@ static int stage_deferred(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream
     // segment's guess is taken -- splits the chunk under the same pat_str, its piece starts become hard starts, and the tiles that gave up
     // run again: every piece start is certain now.  (Pieces that are already final are what they were: a hard start at the start of a
     // piece changes nothing, and the stock patterns match a piece the same way when the text ends behind it.)
-    const bool can_fall_back = c->has_rx_fb && job.n >= (256u << 10) && !(c->dbg & 0x400000);  // (debug bit 0x40000000: never)
+    const bool can_fall_back = c->has_rx_fb && job.n >= (256u << 10) && !(c->dbg & 0x400000);  // (debug bit 0x400000: never)
     if (job.n > 0 && !job.single_piece) {
-        TkFrontOut fo{w.starts.as<uint32_t>(), w.tile_np.as<uint32_t>(), w.res.as<uint32_t>(), w.tile_nmiss.as<uint32_t>(), w.tile_sum.as<uint8_t>(), w.miss.as<uint2>(),
+        TkFrontOut fo{w.starts.as<uint32_t>(), w.tile_np.as<uint32_t>(), w.res.as<uint32_t>(), w.tile_sum.as<uint8_t>(), miss_of(w, job), job.ovf_cap,
                       w.listC.as<uint32_t>(), w.counters.as<uint32_t>()};
         uint32_t *ss = job.spec ? w.ss.as<uint32_t>() : nullptr, *si = job.spec ? w.si.as<uint32_t>() : nullptr, *docb = job.spec ? w.docb.as<uint32_t>() : nullptr;
         const dim3 grid((uint32_t)(job.ntiles < 1024 ? job.ntiles : 1024));
         const int pat_id = T.pat.generic() ? TK_PAT_GENERIC : T.pattern;
-        TkMissSlot* mt_arg = (c->dbg & 256) ? (TkMissSlot*)nullptr : job.mt;
+        TkMissKey* mt_arg = (c->dbg & 256) ? (TkMissKey*)nullptr : job.mt;
         const uint32_t* gapb = c->has_rx ? w.rx_gst.as<uint32_t>() + (job.n + 31) / 32 + 2 : (const uint32_t*)nullptr;
+        const int fdbg = c->dbg | (job.pretok ? 8 : 0);  // (piece starts only: every probe counts as a hit, nothing is listed for the merges)
         TRY(timed(c, s, "tk_k_front_slow", [&] {
             launch_front<true>(pat_id, job.spec, grid, s, T, job.d_text, job.n, job.base, w.brk.as<uint32_t>(), docb, ss, si, fo, mt_arg, (1u << job.mt_bits) - 1u,
-                               w.deferred.as<uint32_t>(), gapb, (c->dbg & ~TKF_DBG_SECOND) | (can_fall_back ? TKF_DBG_MAY_GIVE_UP : 0));
+                               w.deferred.as<uint32_t>(), gapb, (fdbg & ~TKF_DBG_SECOND) | (can_fall_back ? TKF_DBG_MAY_GIVE_UP : 0));
         }));
         if (can_fall_back) {
             HIPCHK(hipMemcpyAsync(w.h_counters, w.counters.p, TK_CNT_N * 4, hipMemcpyDeviceToHost, s));
@@ -635,7 +643,7 @@ static int stage_deferred(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream
                 TRY(rx_split(c, w, s, job.d_text, job.n, w.brk.as<uint32_t>(), ss, si, job.d_doc_off, job.n_docs, job.base));
                 TRY(timed(c, s, "tk_k_front_slow", [&] {
                     launch_front<true>(pat_id, job.spec, grid, s, T, job.d_text, job.n, job.base, w.brk.as<uint32_t>(), docb, ss, si, fo, mt_arg, (1u << job.mt_bits) - 1u,
-                                       w.deferred.as<uint32_t>() + job.ntiles + 2, gapb, (c->dbg & ~TKF_DBG_MAY_GIVE_UP) | TKF_DBG_SECOND);
+                                       w.deferred.as<uint32_t>() + job.ntiles + 2, gapb, (fdbg & ~TKF_DBG_MAY_GIVE_UP) | TKF_DBG_SECOND);
                 }));
                 c->st_fallbacks += 1;
             }
@@ -666,23 +674,32 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
     TRY(ensure(w.starts, (nwords + 2) * 4));
     TRY(ensure(w.blockcnt, (nblk + 2) * 4));
     TRY(ensure(w.counters, TK_CNT_N * 4));
-    TRY(ensure(w.total, 16));
+    TRY(ensure(w.total, 32));
     TRY(ensure(w.tile_np, (ntiles + 2) * 4));
     TRY(ensure(w.tile_nt, (ntiles + 2) * 4));
-    TRY(ensure(w.tile_nmiss, (ntiles + 2) * 4));
     TRY(ensure(w.wbin, (TK_NBIN * TKD_WAVES + 2) * 4));
-    TRY(ensure(w.wave_pieces, 16384 * 4));
     const uint64_t pid_cap = tk_pid_cap(n);
     TRY(ensure(w.res, pid_cap * 4));
-    TRY(ensure(w.rflag, (ntiles + 1) * TKF_MISS_CAP * 8));
-    TRY(ensure(w.miss, (ntiles + 1) * TKF_MISS_CAP * 8 + 64));
     TRY(ensure(w.staging, (n + 64) * 4));
-    uint64_t pool = 0;
-    for (int b = 0; b < TK_NBIN; ++b) {
-        job.bins.off[b] = (uint32_t)pool;
-        pool += n / tk_bin_lo(b) + 64;
+    // The entries of the distinct missed pieces (tk_fused.h, TkMiss): one per slot of the in-call de-duplication table -- which pays for
+    // its reset (of the 16-byte keys: the 64-byte entries are written by whoever claims a slot, never cleared) only on real batches -- and
+    // the overflow entries behind them.  The table takes what repeats; the overflow entries are sized for a sixteenth of the worst case
+    // (every piece a distinct two-byte piece that is not a token) unless the chunk is small or a batch has already asked for more
+    // (c->ovf_full: encode_device_locked repeats such a batch once, with room for the worst case).
+    job.pretok = pretok_only;
+    if (n > 32768 && !single_piece && !pretok_only) {
+        while (job.mt_bits < TK_MT_BITS && (1ull << job.mt_bits) < n / 128) ++job.mt_bits;  // 4 Mi slots from 512 MiB up
+        job.ovf_base = 1u << job.mt_bits;
     }
-    TRY(ensure(w.listB, pool * 12));
+    {
+        const uint64_t worst = n / 2 + 64;
+        job.ovf_cap = (uint32_t)((n <= (1u << 20) || c->ovf_full) ? worst : std::min<uint64_t>(worst, std::max<uint64_t>(n >> 4, 1u << 16)));
+        if (pretok_only) job.ovf_cap = 64;
+    }
+    const uint64_t n_entries = (uint64_t)job.ovf_base + job.ovf_cap;
+    TRY(ensure(w.mtab, (uint64_t)job.ovf_base * sizeof(TkMissTab)));
+    TRY(ensure(w.movf, ((uint64_t)job.ovf_cap + 1) * sizeof(TkMissOvf)));
+    TRY(ensure(w.listB, (n_entries + 64) * 4));
     TRY(ensure(w.listC, (n / 1025 + 64) * 20));
     TRY(ensure(w.big, (1 + 3 * TK_BIGCOPY_CAP) * 4));
     TkClearArgs clr;
@@ -698,15 +715,19 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
     clear(w.big, 4, 0u);
     TRY(ensure(w.merge_work, 16 * TKM_WORK_STRIDE * 4));
     clear(w.merge_work, 16 * TKM_WORK_STRIDE * 4, 0u);
-    clear(w.total, 16, 0u);
+    clear(w.total, 32, 0u);
     uint32_t *brk = w.brk.as<uint32_t>(), *starts = w.starts.as<uint32_t>();
     uint32_t *ss = nullptr, *si = nullptr, *docb = nullptr;
     uint32_t* counters = w.counters.as<uint32_t>();
-    uint2* miss = w.miss.as<uint2>();  // per tile TKF_MISS_CAP entries of 8 bytes
     TRY(ensure(w.tile_sum, ntiles + 16));
-    TRY(ensure(w.row_base, (ntiles + 1) * (TKF_CAP / 256) * 8));
+    TRY(ensure(w.row_base, (ntiles + 1) * (TKF_CAP / 256) * 4));  // (tokens of a tile's rows of 256 pieces before each row: tk_k_count_tiles for tk_k_docoff)
     clear(w.tile_sum, ntiles + 16, 0xFFFFFFFFu);
-    TkFrontOut fo{starts, w.tile_np.as<uint32_t>(), w.res.as<uint32_t>(), w.tile_nmiss.as<uint32_t>(), w.tile_sum.as<uint8_t>(), miss, w.listC.as<uint32_t>(), counters};
+    if (job.ovf_base) {
+        TRY(ensure(w.mt_keys, sizeof(TkMissKey) * job.ovf_base));
+        clear(w.mt_keys, sizeof(TkMissKey) * job.ovf_base, 0xFFFFFFFFu);
+        job.mt = w.mt_keys.as<TkMissKey>();
+    }
+    TkFrontOut fo{starts, w.tile_np.as<uint32_t>(), w.res.as<uint32_t>(), w.tile_sum.as<uint8_t>(), miss_of(w, job), job.ovf_cap, w.listC.as<uint32_t>(), counters};
     if (n > 0 && !single_piece) {
         if (use_special) {
             TRY(ensure(w.docb, (nwords + 2) * 4));
@@ -727,12 +748,6 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
             clear(w.rx_gst, 2 * (nwords + 2) * 4, 0u);
             clear(w.rx_lnk, 2 * (nwords + 2) * 4, 0u);
         }
-        if (n > 32768 && !pretok_only) {  // in-call de-duplication of missed pieces pays for its table reset only on real batches
-            while (job.mt_bits < TK_MT_BITS && (1ull << job.mt_bits) < n / 128) ++job.mt_bits;  // 4 Mi slots from 512 MiB up
-            TRY(ensure(w.mt_slots, sizeof(TkMissSlot) << job.mt_bits));
-            clear(w.mt_slots, sizeof(TkMissSlot) << job.mt_bits, 0xFFFFFFFFu);
-            job.mt = w.mt_slots.as<TkMissSlot>();
-        }
         hipLaunchKernelGGL(tk_k_chunk_clear, dim3(grid_for(n / 64 + 1, 256, 2048)), dim3(256), 0, s, clr);
         clr.n = 0;
         TRY(timed(c, s, "tk_k_mark_docs", [&] {
@@ -752,13 +767,14 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
         if (c->has_rx) TRY(rx_split(c, w, s, d_text, n, brk, ss, si, d_doc_off, n_docs, base));  // the generic engine finds the piece starts; they join the hard starts in `brk`
         TRY(ensure(w.deferred, 2 * (ntiles + 2) * 4));  // (behind the list of deferred tiles: those that gave up their walk, stage_deferred)
         uint32_t* deferred = w.deferred.as<uint32_t>();
-        TkMissSlot* mt_arg = (c->dbg & 256) ? (TkMissSlot*)nullptr : job.mt;
+        TkMissKey* mt_arg = (c->dbg & 256) ? (TkMissKey*)nullptr : job.mt;
         TRY(timed(c, s, "tk_k_front", [&] {
             // (only the variant with the LDS piece cache, TKF_HOT_BITS > 0, which keeps the cache over all the tiles a workgroup walks)
             const uint64_t resident = TKF_HOT_BITS ? (uint64_t)c->n_cu * c->front_wgs : ntiles;
             const dim3 grid((uint32_t)(ntiles < resident ? ntiles : resident));
             launch_front<false>(T.pat.generic() ? TK_PAT_GENERIC : T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, fo,
-                                mt_arg, (1u << job.mt_bits) - 1u, deferred, c->has_rx ? w.rx_gst.as<uint32_t>() + nwords + 2 : (const uint32_t*)nullptr, c->dbg);
+                                mt_arg, (1u << job.mt_bits) - 1u, deferred, c->has_rx ? w.rx_gst.as<uint32_t>() + nwords + 2 : (const uint32_t*)nullptr,
+                                c->dbg | (pretok_only ? 8 : 0));
         }));
     } else if (n > 0) {
         hipLaunchKernelGGL(tk_k_chunk_clear, dim3(1), dim3(256), 0, s, clr);
@@ -804,36 +820,38 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
     const uint8_t* d_text = job.d_text;
     uint32_t* counters = w.counters.as<uint32_t>();
     uint32_t *res = w.res.as<uint32_t>(), *stg = w.staging.as<uint32_t>();
-    uint2 *rflag = w.rflag.as<uint2>(), *miss = w.miss.as<uint2>();
-    uint32_t *tile_np = w.tile_np.as<uint32_t>(), *tile_nt = w.tile_nt.as<uint32_t>(), *tile_nmiss = w.tile_nmiss.as<uint32_t>();
+    const TkMiss data = miss_of(w, job);
+    uint32_t *tile_np = w.tile_np.as<uint32_t>(), *tile_nt = w.tile_nt.as<uint32_t>();
     const unsigned long long* tok_base = c->tok_bases.as<unsigned long long>() + job.index;
     uint64_t nC = 0;
     TRY(stage_deferred(c, w, job, s));
     if (n > 0) {
         uint32_t* wbin = w.wbin.as<uint32_t>();
-        // the two list passes and the tile passes: as many workgroups as the chunk has work for (small calls are latency-bound)
-        const uint32_t tpg = ntiles > 16384 ? TKD_GROUP : 1;
-        const uint32_t dd_blocks = grid_for(ntiles, 4 * tpg, TKD_WAVES / 4), tf_blocks = grid_for(ntiles, 4, 4096);
+        uint32_t* listB = w.listB.as<uint32_t>();
+        // the two list passes walk the miss data (table slots + overflow entries): as many wavefronts as it has rows of 64 entries for
+        // (small calls are latency-bound: a workgroup or two)
+        const uint64_t n_entries = (uint64_t)job.ovf_base + job.ovf_cap;
+        const uint32_t dd_blocks = grid_for(n_entries, 4 * 256, TKD_WAVES / 4);
         TRY(timed(c, s, "tk_k_bincount", [&] {
-            hipLaunchKernelGGL(tk_k_bincount, dim3(dd_blocks), dim3(256), 0, s, ntiles, tile_nmiss, miss, wbin, tpg);
+            hipLaunchKernelGGL(tk_k_bincount, dim3(dd_blocks), dim3(256), 0, s, data, job.mt, job.ovf_cap, counters, wbin);
         }));
         TRY(scan_u32(c, w, s, wbin, (uint64_t)TK_NBIN * dd_blocks * 4 + 1, w.total.as<uint64_t>()));
         TRY(timed(c, s, "tk_k_binfill", [&] {
-            hipLaunchKernelGGL(tk_k_binfill, dim3(dd_blocks), dim3(256), 0, s, ntiles, tile_nmiss, miss, wbin, w.listB.as<uint32_t>(), job.bins, counters, tpg);
+            hipLaunchKernelGGL(tk_k_binfill, dim3(dd_blocks), dim3(256), 0, s, data, job.mt, job.ovf_cap, wbin, listB, counters);
         }));
         if (T.pair8 && !(c->dbg & 0x800000)) {
             // every bin in one launch (tk_k_merge_all); debug bit 0x800000: the kernel-per-bin form below
             uint64_t most_units = 0;
             for (int b = 0; b < TK_NBIN; ++b)
-                if (n >= tk_bin_lo(b)) most_units += (n / tk_bin_lo(b)) / (64u >> (b == 0 ? 0 : (b <= 2 ? 1 : (b <= 4 ? 2 : b - 2)))) + 1;
+                if (n >= tk_bin_lo(b)) most_units += std::min<uint64_t>(n / tk_bin_lo(b), n_entries) / (64u >> (b == 0 ? 0 : (b <= 2 ? 1 : (b <= 4 ? 2 : b - 2)))) + 1;
             uint32_t wgs = (uint32_t)std::min<uint64_t>((most_units + 3) / 4, (uint64_t)c->n_cu * TKM_WGS_PER_CU);
             wgs = std::max(4u, (wgs + 3u) & ~3u);  // (wavefronts: a multiple of 16, tk_k_merge_all's work counters rely on it)
             TRY(timed(c, s, "tk_k_merge_all", [&] {
-                hipLaunchKernelGGL(tk_k_merge_all, dim3(wgs), dim3(256), 0, s, T, d_text, w.listB.as<uint32_t>(), job.bins, counters, miss, stg, w.merge_work.as<uint32_t>(), c->dbg);
+                hipLaunchKernelGGL(tk_k_merge_all, dim3(wgs), dim3(256), 0, s, T, d_text, listB, counters, data, stg, w.merge_work.as<uint32_t>(), c->dbg);
             }));
         } else
         {
-            // The bins are independent: spread them over the side streams, longest-tailed kernels first.  List lengths are
+            // The bins are independent: spread them over the side streams, longest-tailed kernels first.  List starts and lengths are
             // read on the device, so nothing waits for the host here; grids are sized by the most a bin can hold.
             static const char* const names[TK_NBIN] = {"tk_k_merge_llane_16", "tk_k_merge_llane_24", "tk_k_merge_llane_32", "tk_k_merge_llane_48", "tk_k_merge_llane_64",
                                                        "tk_k_merge_group_8", "tk_k_merge_group_16", "tk_k_merge_group_32", "tk_k_merge_group_64"};
@@ -852,21 +870,19 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
             for (int oi = 0; oi < TK_NBIN; ++oi) {
                 const int b = order[oi];
                 if (n < tk_bin_lo(b) || (small && !small_counts[TK_CNT_BIN0 + b])) continue;
-                const uint64_t most = n / tk_bin_lo(b);
-                const uint32_t* lst = w.listB.as<uint32_t>() + 3 * (uint64_t)job.bins.off[b];
-                const uint32_t* cp = counters + TK_CNT_BIN0 + b;
+                const uint64_t most = std::min<uint64_t>(n / tk_bin_lo(b), n_entries);
                 hipStream_t sa = c->aux[stream_of[b]];
                 TRY(timed(c, sa, names[b], [&] {
                     switch (b) {
-                        case 0: hipLaunchKernelGGL((tk_k_merge_llane<16, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, miss, stg); break;
-                        case 1: hipLaunchKernelGGL((tk_k_merge_llane<24, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, miss, stg); break;
-                        case 2: hipLaunchKernelGGL((tk_k_merge_llane<32, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, miss, stg); break;
-                        case 3: hipLaunchKernelGGL((tk_k_merge_llane<48, 128>), dim3(grid_for(most, 128, 8192)), dim3(128), 0, sa, T, d_text, lst, cp, miss, stg); break;
-                        case 4: hipLaunchKernelGGL((tk_k_merge_llane<64, 128>), dim3(grid_for(most, 128, 8192)), dim3(128), 0, sa, T, d_text, lst, cp, miss, stg); break;
-                        case 5: hipLaunchKernelGGL((tk_k_merge_group<8>), dim3(grid_for(most, 32, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, miss, stg); break;
-                        case 6: hipLaunchKernelGGL((tk_k_merge_group<16>), dim3(grid_for(most, 16, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, miss, stg); break;
-                        case 7: hipLaunchKernelGGL((tk_k_merge_group<32>), dim3(grid_for(most, 8, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, miss, stg); break;
-                        default: hipLaunchKernelGGL((tk_k_merge_group<64>), dim3(grid_for(most, 4, 8192)), dim3(256), 0, sa, T, d_text, lst, cp, miss, stg); break;
+                        case 0: hipLaunchKernelGGL((tk_k_merge_llane<16, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, listB, counters, b, data, stg); break;
+                        case 1: hipLaunchKernelGGL((tk_k_merge_llane<24, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, listB, counters, b, data, stg); break;
+                        case 2: hipLaunchKernelGGL((tk_k_merge_llane<32, 256>), dim3(grid_for(most, 256, 8192)), dim3(256), 0, sa, T, d_text, listB, counters, b, data, stg); break;
+                        case 3: hipLaunchKernelGGL((tk_k_merge_llane<48, 128>), dim3(grid_for(most, 128, 8192)), dim3(128), 0, sa, T, d_text, listB, counters, b, data, stg); break;
+                        case 4: hipLaunchKernelGGL((tk_k_merge_llane<64, 128>), dim3(grid_for(most, 128, 8192)), dim3(128), 0, sa, T, d_text, listB, counters, b, data, stg); break;
+                        case 5: hipLaunchKernelGGL((tk_k_merge_group<8>), dim3(grid_for(most, 32, 8192)), dim3(256), 0, sa, T, d_text, listB, counters, b, data, stg); break;
+                        case 6: hipLaunchKernelGGL((tk_k_merge_group<16>), dim3(grid_for(most, 16, 8192)), dim3(256), 0, sa, T, d_text, listB, counters, b, data, stg); break;
+                        case 7: hipLaunchKernelGGL((tk_k_merge_group<32>), dim3(grid_for(most, 8, 8192)), dim3(256), 0, sa, T, d_text, listB, counters, b, data, stg); break;
+                        default: hipLaunchKernelGGL((tk_k_merge_group<64>), dim3(grid_for(most, 4, 8192)), dim3(256), 0, sa, T, d_text, listB, counters, b, data, stg); break;
                     }
                 }));
             }
@@ -896,7 +912,7 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
                 TRY(timed(c, s, "tk_k_merge_rounds", [&] {
                     hipLaunchKernelGGL(tk_k_merge_rounds, dim3(grid_for(nC, 1, 1024)), dim3(TKB_THREADS), 0, s, T, d_text, w.listC.as<uint32_t>(),
                                        (uint32_t)nC, w.g_id.as<uint32_t>(), w.g_rk.as<uint32_t>(), w.g_nx.as<uint32_t>(), w.g_pv.as<uint32_t>(),
-                                       miss, stg);
+                                       data, stg);
                 }));
             }
             if (rounds && n >= TK_WIDE_MIN) {  // (pieces of TK_WIDE_MIN bytes and more, if there are any: the whole grid on each)
@@ -905,40 +921,53 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
                 TRY(timed(c, s, "tk_k_merge_rounds_wide", [&] {
                     hipLaunchKernelGGL(tk_k_merge_rounds_wide, dim3(TK_WIDE_BLOCKS), dim3(TKB_THREADS), 0, s, T, d_text, w.listC.as<uint32_t>(),
                                        (uint32_t)nC, w.g_id.as<uint32_t>(), w.g_rk.as<uint32_t>(), w.g_nx.as<uint32_t>(), w.g_pv.as<uint32_t>(),
-                                       miss, stg, w.wide_ws.as<TkWideWs>());
+                                       data, stg, w.wide_ws.as<TkWideWs>());
                 }));
             }
             TRY(timed(c, s, "tk_k_merge_long", [&] {
                 hipLaunchKernelGGL(tk_k_merge_long, dim3(grid_for(nC, 4, 8192)), dim3(256), 0, s, T, d_text, w.listC.as<uint32_t>(), (uint32_t)nC,
                                    w.g_id.as<uint32_t>(), w.g_rk.as<uint32_t>(), w.g_nx.as<uint32_t>(), w.g_pv.as<uint32_t>(),
-                                   w.g_lv.as<uint64_t>(), miss, stg, rounds ? 1 : 0);
+                                   w.g_lv.as<uint64_t>(), data, stg, rounds ? 1 : 0);
             }));
         }
-        if (job.mt) {
-            TRY(timed(c, s, "tk_k_dup_publish", [&] { hipLaunchKernelGGL(tk_k_dup_publish, dim3(grid_for(1ull << job.mt_bits, 256, 4096)), dim3(256), 0, s, job.mt, 1u << job.mt_bits, miss); }));
-        }
-        TRY(timed(c, s, "tk_k_tile_finish", [&] {
-            hipLaunchKernelGGL(tk_k_tile_finish, dim3(tf_blocks), dim3(256), 0, s, ntiles, tile_np, job.mt, res, miss, rflag, tile_nt, w.wave_pieces.as<uint32_t>());
-        }));
-        hipLaunchKernelGGL(tk_k_sum_pieces, dim3(1), dim3(1024), 0, s, w.wave_pieces.as<uint32_t>(), tf_blocks * 4u, w.total.as<unsigned long long>() + 1);
-        TRY(scan_u32(c, w, s, tile_nt, ntiles, w.total.as<uint64_t>()));
     }
-    // the chunk's token count is known: the next chunk's base (its back stage may be running beside this one)
+    if (n > 0) {
+        // token count per tile (a missed piece's count from its entry), then the tiles' places (tk_fused.h: back end)
+        TRY(timed(c, s, "tk_k_count_tiles", [&] {
+            hipLaunchKernelGGL(tk_k_count_tiles, dim3(grid_for(ntiles, 4, 4096)), dim3(256), 0, s, ntiles, tile_np, res, data, tile_nt, w.row_base.as<uint32_t>(),
+                               w.total.as<unsigned long long>());
+        }));
+        TRY(scan_u32(c, w, s, tile_nt, ntiles, w.total.as<uint64_t>()));
+    } else {
+        HIPCHK(hipMemsetAsync(w.total.p, 0, 32, s));  // (the scan of the bin counts is not run for an empty chunk; be explicit)
+    }
+    // the chunk's token count is known: the next chunk's base.  Its tokens go behind those of the chunk before it (whose back stage may be
+    // running beside this one).
     if (prev_tot) HIPCHK(hipStreamWaitEvent(s, prev_tot, 0));
     hipLaunchKernelGGL(tk_k_advance, dim3(1), dim3(64), 0, s, c->tok_bases.as<unsigned long long>(), job.index, w.total.as<uint64_t>());
     HIPCHK(hipEventRecord(w.ev_tot, s));
+    // the document offsets need the tile counts, not the placed tokens: on a side stream beside tk_k_place (both wait for memory)
+    const bool side = job.d_tok_off && n > (1u << 20) && !c->profiling;
+    hipStream_t sd = side ? c->aux[0] : s;
+    if (side) {
+        HIPCHK(hipEventRecord(w.ev_fork, s));
+        HIPCHK(hipStreamWaitEvent(sd, w.ev_fork, 0));
+    }
+    if (job.d_tok_off) {
+        TRY(timed(c, sd, "tk_k_docoff", [&] {
+            hipLaunchKernelGGL(tk_k_docoff, dim3(grid_for(job.n_docs + 1, 4, 8192)), dim3(256), 0, sd, job.n_docs, job.d_doc_off, job.base, n, w.starts.as<uint32_t>(), tile_nt, res, data,
+                               (n > 0 && !job.single_piece) ? w.row_base.as<uint32_t>() : (const uint32_t*)nullptr, w.total.as<uint64_t>(), tok_base, job.d_tok_off);
+        }));
+    }
+    if (side) HIPCHK(hipEventRecord(w.ev_join[0], sd));
     if (n > 0) {
-        TRY(timed(c, s, "tk_k_back", [&] {
-            hipLaunchKernelGGL(tk_k_back, dim3(grid_for(ntiles, 4, 16384)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, rflag, stg, d_out, tok_base, w.big.as<uint32_t>(), w.row_base.as<uint2>());
-        }));
-        if (n > TK_BIGCOPY)  // (a token run of TK_BIGCOPY tokens needs at least as many bytes)
-            hipLaunchKernelGGL(tk_k_bigcopy, dim3(1024), dim3(256), 0, s, w.big.as<uint32_t>(), stg, d_out, tok_base);
-    }
-    if (job.d_tok_off) {  // (beside the token copy on a second stream it takes as long as behind it: both wait for the same memory system)
-        TRY(timed(c, s, "tk_k_docoff", [&] {
-            hipLaunchKernelGGL(tk_k_docoff, dim3(grid_for(job.n_docs + 1, 4, 8192)), dim3(256), 0, s, job.n_docs, job.d_doc_off, job.base, n, w.starts.as<uint32_t>(), tile_nt, res, rflag, (n > 0 && !job.single_piece) ? w.row_base.as<uint2>() : (const uint2*)nullptr, w.total.as<uint64_t>(), tok_base, job.d_tok_off);
+        TRY(timed(c, s, "tk_k_place", [&] {
+            hipLaunchKernelGGL(tk_k_place, dim3(grid_for(ntiles, 4, 4096)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, data, stg, d_out, tok_base, w.big.as<uint32_t>());
         }));
     }
+    if (n > TK_BIGCOPY)  // (a token run of TK_BIGCOPY tokens needs at least as many bytes)
+        hipLaunchKernelGGL(tk_k_bigcopy, dim3(1024), dim3(256), 0, s, w.big.as<uint32_t>(), stg, d_out, tok_base);
+    if (side) HIPCHK(hipStreamWaitEvent(s, w.ev_join[0], 0));
     HIPCHK(hipMemcpyAsync(w.h_total, w.total.p, 16, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(w.h_counters + TK_CNT_N, counters, TK_CNT_N * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(w.ev_done, s));
@@ -946,6 +975,7 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
     return TK_OK;
 }
 
+#define TK_GROW (-1000)  // (internal) the batch has to be repeated with a larger miss data: encode_device_locked
 // the chunk of `w` is complete: its totals, statistics and error flags (waits for its back stage)
 static int chunk_finish(tk_core* c, WorkSet& w, const ChunkJob& job, uint64_t* n_tokens_out) {
     HIPCHK(hipEventSynchronize(w.ev_done));
@@ -957,6 +987,10 @@ static int chunk_finish(tk_core* c, WorkSet& w, const ChunkJob& job, uint64_t* n
     }
     if (hb[TK_CNT_ERR] & (TK_RX_ERR_GAP | TK_RX_ERR_STACK | TK_RX_ERR_LIMIT)) return rx_failure(hb, job.base);
     if (hb[TK_CNT_ERR]) return fail(TK_RUNTIME_ERROR, "internal error in the front kernel (scanner list overflow, code " + std::to_string(hb[TK_CNT_ERR]) + ")");
+    if (hb[TK_CNT_OVF] > job.ovf_cap && !job.pretok) {  // more distinct missed pieces than the miss data has room for: the batch is repeated with room for the worst case
+        c->ovf_full = true;
+        return TK_GROW;
+    }
     c->st_bytes += job.n;
     c->st_pieces += w.h_total[1];
     c->st_tokens += w.h_total[0];
@@ -1007,9 +1041,9 @@ struct ChunkHooks {
 
 // Device-resident batch: cut into chunks at document boundaries and pipelined -- the front stage of chunk k + 1 is queued (on the
 // caller's stream) before the back stage of chunk k (on the back-stage stream), so the two overlap on the device; TK_NSET work sets.
-static int encode_device_locked(tk_core* c, hipStream_t s, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
-                                const uint64_t* h_doc_off, uint64_t n_docs, bool use_special, uint64_t* n_tokens_out,
-                                uint64_t chunk_bytes = 0, const ChunkHooks* hooks = nullptr) {
+static int encode_device_pass(tk_core* c, hipStream_t s, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
+                              const uint64_t* h_doc_off, uint64_t n_docs, bool use_special, uint64_t* n_tokens_out,
+                              uint64_t chunk_bytes, const ChunkHooks* hooks) {
     if (!chunk_bytes) chunk_bytes = c->chunk_bytes;
     c->st_bytes = c->st_pieces = c->st_tokens = c->st_medium = c->st_long = c->st_hot_probes = c->st_hot_hits = c->st_chunks = 0;
     c->st_docs = n_docs;
@@ -1103,6 +1137,24 @@ static int encode_device_locked(tk_core* c, hipStream_t s, const uint8_t* d_utf8
     return TK_OK;
 }
 
+// The miss data's overflow entries are sized for ordinary text (stage_front).  A batch with more distinct missed pieces than that -- the
+// counter on the device says so when a chunk is finished -- is run once more from its first chunk, with room for the worst case from
+// then on (c->ovf_full).  Everything a pass writes is written again by the next one, and the hooks are idempotent (text already sent
+// is not sent again; token ranges are copied again).
+static int encode_device_locked(tk_core* c, hipStream_t s, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
+                                const uint64_t* h_doc_off, uint64_t n_docs, bool use_special, uint64_t* n_tokens_out,
+                                uint64_t chunk_bytes = 0, const ChunkHooks* hooks = nullptr) {
+    int rc = encode_device_pass(c, s, d_utf8, n_bytes, d_doc_off, h_doc_off, n_docs, use_special, n_tokens_out, chunk_bytes, hooks);
+    if (rc == TK_GROW) {
+        HIPCHK(hipDeviceSynchronize());  // (chunks of the abandoned pass may still be in flight on the sets' streams)
+        (void)drain_events(c);
+        c->st_regrown += 1;
+        rc = encode_device_pass(c, s, d_utf8, n_bytes, d_doc_off, h_doc_off, n_docs, use_special, n_tokens_out, chunk_bytes, hooks);
+        if (rc == TK_GROW) return fail(TK_RUNTIME_ERROR, "internal error: the miss data overflowed at its largest size");
+    }
+    return rc;
+}
+
 extern "C" int tk_encode_batch_device(tk_core* c, const void* d_utf8, uint64_t n_bytes, const void* d_doc_off,
                                       const uint64_t* h_doc_off, uint64_t n_docs, int use_special, const uint32_t* allowed_ids,
                                       uint64_t n_allowed, void* stream, const uint32_t** d_tokens_out, uint64_t* n_tokens_out,
@@ -1169,15 +1221,20 @@ static int encode_small(tk_core* c, const uint8_t* utf8, uint32_t n, uint32_t** 
         ~Release() { s->busy.store(0, std::memory_order_release); }
     } release_slot{sl};
     HIPCHK(hipSetDevice(c->device));
-    if (!sl->in) {  // first use of the slot
-        HIPCHK(hipHostMalloc((void**)&sl->in, TK_SMALL_MAX + 64, hipHostMallocCoherent | hipHostMallocMapped));
-        memset(sl->in, 0, TK_SMALL_MAX + 64);
-        HIPCHK(hipHostMalloc((void**)&sl->out, (TK_SMALL_HDR + TK_SMALL_MAX + 16) * 4, hipHostMallocCoherent | hipHostMallocMapped));
-        memset(sl->out, 0, (TK_SMALL_HDR + TK_SMALL_MAX + 16) * 4);
+    if (!sl->ready) {  // first use of the slot (or a first use that failed: what it did make is kept, the rest is made now)
+        if (!sl->in) {
+            HIPCHK(hipHostMalloc((void**)&sl->in, TK_SMALL_MAX + 64, hipHostMallocCoherent | hipHostMallocMapped));
+            memset(sl->in, 0, TK_SMALL_MAX + 64);
+        }
+        if (!sl->out) {
+            HIPCHK(hipHostMalloc((void**)&sl->out, (TK_SMALL_HDR + TK_SMALL_MAX + 16) * 4, hipHostMallocCoherent | hipHostMallocMapped));
+            memset(sl->out, 0, (TK_SMALL_HDR + TK_SMALL_MAX + 16) * 4);
+        }
         TRY(ensure(sl->ws, 256 * TK_SMALL_PIECE * 4));
         HIPCHK(hipHostGetDevicePointer(&sl->d_in, sl->in, 0));
         HIPCHK(hipHostGetDevicePointer(&sl->d_out, sl->out, 0));
-        HIPCHK(hipStreamCreateWithFlags(&sl->s, hipStreamNonBlocking));
+        if (!sl->s) HIPCHK(hipStreamCreateWithFlags(&sl->s, hipStreamNonBlocking));
+        sl->ready = true;
     }
     memcpy(sl->in, utf8, n);
     memset(sl->in + n, 0, 8);
@@ -1385,6 +1442,7 @@ extern "C" int tk_pretokenize_batch(tk_core* c, const uint8_t* utf8, const uint6
         if (doc_off[d + 1] < doc_off[d]) return fail(TK_VALUE_ERROR, "doc_off must be non-decreasing");
     const uint64_t n_bytes = doc_off[n_docs];
     if (n_bytes > c->chunk_bytes) return fail(TK_VALUE_ERROR, "tk_pretokenize_batch handles a single chunk only");
+    if (n_bytes >= (1ull << 31)) return fail(TK_VALUE_ERROR, "tk_pretokenize_batch: less than 2 GiB per call (bit 31 of an offset marks a gap char)");
     std::lock_guard<std::mutex> lk(c->mu);
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
@@ -1576,9 +1634,13 @@ extern "C" int tk_decode_batch(tk_core* c, const uint32_t* tokens, const uint64_
         tk_free(host);
         return fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e));
     }
+    if (const int rc = drain_events(c)) {  // (before the outputs are published: a caller that gets an error owns nothing)
+        tk_free(host);
+        return rc;
+    }
     *bytes_out = host;
     *n_bytes_out = nbytes;
-    return drain_events(c);
+    return TK_OK;
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1599,8 +1661,10 @@ struct TkRccl {
     ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
-    bool load() {
-        if (lib) return true;
+    bool tried = false, ok = false;
+    bool load() {  // (the answer of the first call, whatever it was: a library without one of the symbols is not asked again)
+        if (tried) return ok;
+        tried = true;
         for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
             lib = dlopen(name, RTLD_NOW | RTLD_LOCAL);
             if (lib) break;
@@ -1613,7 +1677,12 @@ struct TkRccl {
         Send = (decltype(Send))dlsym(lib, "ncclSend");
         Recv = (decltype(Recv))dlsym(lib, "ncclRecv");
         GetErrorString = (decltype(GetErrorString))dlsym(lib, "ncclGetErrorString");
-        return CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv;
+        ok = CommInitAll && CommDestroy && GroupStart && GroupEnd && Send && Recv;
+        if (!ok) {
+            dlclose(lib);
+            lib = nullptr;
+        }
+        return ok;
     }
 };
 static TkRccl g_rccl;
@@ -2002,6 +2071,13 @@ extern "C" uint64_t tk_stat(tk_core* c, const char* name) {
     if (k == "front_wgs_per_cu") return c->front_wgs;
     if (k == "compute_units") return c->n_cu;
     if (k == "chunks") return c->st_chunks;
+    if (k == "regrown") return c->st_regrown;  // batches repeated with a larger miss data since the core was made (encode_device_locked)
+    if (k == "workspace_bytes") {             // device memory of the work sets (everything but the text, the tables and the outputs)
+        uint64_t t = 0;
+        for (auto& w : c->ws)
+            for (Buf* b : w.all()) t += b->cap;
+        return t;
+    }
     if (k == "fallbacks") return c->st_fallbacks;  // chunks re-split by the generic engine since the core was made (stage_deferred)
     if (k == "host_front_us") return (uint64_t)c->host_us[0];
     if (k == "host_back_us") return (uint64_t)c->host_us[1];

@@ -5,17 +5,15 @@
 //                         (regex pre-tokenisation, src/lib.rs:365), enumerate the pieces that START in the tile and
 //                         probe each one whole in the vocabulary (src/lib.rs:367) from the LDS copy of the text.
 //                         Results form a run at piece id  pid = tile * 4096 + k.  A piece that is not a token claims a
-//                         slot of the in-call miss table, or finds it claimed by identical bytes (exact: verified) and
-//                         records the slot; first occurrences go to the tile's miss list.  No piece offsets travel
-//                         through HBM.
-//   tk_k_bincount + tk_k_scan_small + tk_k_binfill   miss lists -> length-binned lists, without global atomics
-//   tk_k_merge_llane<N>  one LANE per 2..64-byte piece: byte_pair_merge in LDS           (src/lib.rs:140-196)
-//   tk_k_merge_group<G>  G lanes per 65..1024-byte piece
-//   tk_k_merge_long      one wavefront per longer piece, 64-ary min tree in HBM scratch  (same result as lib.rs:47-138)
-//   tk_k_dup_publish     claimant results -> miss-table slots
-//   tk_k_tile_finish      duplicates copy their claimant's result; token count per tile
-//   tk_k_scan_small       exclusive scan of the tile counts (262 144 entries per GiB)
-//   tk_k_back             per tile: local scan of the piece counts, tokens written to their final place
+//                         slot of the in-call miss table, or finds it claimed by identical bytes (exact: verified); its
+//                         result word refers to that slot either way (TkMissData).  No piece offsets travel through HBM.
+//   tk_k_bincount + tk_k_scan_small + tk_k_binfill   occupied slots -> length-binned lists, without global atomics
+//   tk_k_merge_all       every piece of 2..1024 bytes: byte_pair_merge in LDS, 1..64 lanes per piece (src/lib.rs:140-196)
+//   tk_k_merge_llane<N>, tk_k_merge_group<G>   the same, a kernel per length bin (vocabularies with ids above 2^21)
+//   tk_k_merge_rounds / _long   longer pieces: in rounds, or one merge at a time over a 64-ary min tree (same result as lib.rs:47-138)
+//   tk_k_count_tiles      token count per tile (a missed piece's count from its entry)
+//   tk_k_scan_*           exclusive scan of the tile counts
+//   tk_k_place            per tile: tokens to their final place (a missed piece's tokens from its entry)
 //   tk_k_docoff          per document: token offset of the piece that starts it
 //
 // Tile rule (checked on the CPU by tests/test_device_logic_sim.py): a tile derives exactly the piece starts
@@ -32,8 +30,7 @@
 #include "tk_kernels.h"
 
 #define TKF_NONE 0xFFFFFFFFu
-#define TKF_MISS_CAP 2048  // missed pieces per tile: each is at least two bytes long
-#define TK_MERGE_REDO 0xFFFFFFFFu  // miss[mi].x after tk_k_merge_rounds: the piece has to go through tk_k_merge_long
+#define TK_MERGE_REDO 0xFFFFFFFFu  // TkMissData::res_cnt after tk_k_merge_rounds: the piece has to go through tk_k_merge_long
 #define TK_BIGCOPY 4096      // token runs from this length on are copied by tk_k_bigcopy
 #define TK_BIGCOPY_CAP 1024  // entries of its list
 #define TKF_CHAIN_END 0xFFFFFFFFFFFFFFFFull
@@ -54,29 +51,56 @@
 
 // Per-piece result word res[piece id]: a token id (the piece is a vocabulary token, src/lib.rs:367), or a reference to where its
 // tokens will be once the merge kernels have run.
-#define TK_RES_FLAG 0x80000000u  // not a single token: TK_RES_FLAG | j = entry j of the tile's miss list (its result replaces the entry)
-#define TK_RES_DUP 0xC0000000u   // TK_RES_DUP | slot = duplicate of the piece that claimed this slot of the in-call miss table
+#define TK_RES_FLAG 0x80000000u  // not a single token: TK_RES_FLAG | i = entry i of the chunk's miss data (TkMissData: its result is there)
 #define TK_RES_GAP 0x7FFFFFFFu   // no token at all: a char at which a pat_str of the generic engine matches nothing (find_iter skips it, src/lib.rs:365)
+// Pieces that are not vocabulary tokens ("missed" pieces: they have to be merged, src/lib.rs:369).  A batch repeats them -- 30 M per GiB of
+// web text, 1.2 M distinct -- so each DISTINCT one is merged once: the front kernel claims a slot of an open-addressed table keyed by the
+// piece's bytes (TkMissKey; exact: equal hashes are verified byte for byte), every occurrence refers to the slot, the merge kernels leave
+// the result in it and tk_k_place reads it from there.  The slot index is the index of its TkMissData entry; behind the table's entries
+// the array goes on with the OVERFLOW entries, handed out by a counter: pieces the table does not take (longer than TK_GLANE_MAX bytes, a
+// full neighbourhood, chunks too small for a table).  No per-tile lists: the merge work list is a walk over this array.
+struct TkMissKey {           // 16 bytes, one load
+    unsigned long long key;  // ~0 = empty
+    unsigned long long aux;  // identity of the claimant, ~0 until it has written it: pieces of <= 7 bytes: the bytes themselves
+                             // | length << 56; longer ones: 1 << 63 | length << 32 | start (compared in the text)
+};
+// Where a distinct missed piece and its result live: a table slot has a 64-byte line of its own -- {start, len, count, tokens}: a piece of up
+// to TKD_INLINE tokens (97.5 % of the missed pieces of the web-text corpus) has them IN the entry, so an occurrence costs ONE random
+// access; an overflow entry is 16 bytes (sized for the worst case, n / 2 of them), its tokens are in the staging area.
+// res_cnt: the token count; with TKD_INLINE_BIT the tokens are tok[0 .. count); without it tok[0] (res_tok) is the token (count 1) or
+// the staging position of the tokens.  TK_MERGE_REDO: see above.
+#define TKD_INLINE 13
+#define TKD_INLINE_BIT 0x40000000u
+#define TKD_COUNT(w) ((w) & 0x3FFFFFFFu)
+struct TkMissTab {  // 64 bytes
+    uint32_t start, len, res_cnt, tok[TKD_INLINE];
+};
+struct TkMissOvf {  // 16 bytes
+    uint32_t start, len, res_cnt, res_tok;
+};
+struct TkMiss {
+    TkMissTab* tab;     // [ovf_base] the table's entries (slot index = entry index; written by whoever claims the slot: never cleared)
+    TkMissOvf* ovf;     // [..] the overflow entries, index i - ovf_base
+    uint32_t ovf_base;  // slots of the table (0 without one)
+    __device__ __forceinline__ uint32_t* head(uint32_t i) const { return i < ovf_base ? &tab[i].start : &ovf[i - ovf_base].start; }
+    __device__ __forceinline__ uint2 piece(uint32_t i) const { return *(const uint2*)head(i); }                 // {start, len}
+    __device__ __forceinline__ uint2 result(uint32_t i) const { return *(const uint2*)(head(i) + 2); }          // {res_cnt, tok[0]}
+    __device__ __forceinline__ void put(uint32_t i, uint32_t cnt, uint32_t tok) const { *(uint2*)(head(i) + 2) = make_uint2(cnt, tok); }
+    // where the merge kernels write a piece's `total` tokens: into the entry when they fit (then put(i, total | TKD_INLINE_BIT, ..) is
+    // only the count word: put_count), else to the staging area at the piece's text position s
+    __device__ __forceinline__ bool fits(uint32_t i, uint32_t total) const { return i < ovf_base && total <= (uint32_t)TKD_INLINE; }
+    __device__ __forceinline__ void put_count(uint32_t i, uint32_t w) const { head(i)[2] = w; }
+};
 struct TkFrontOut {
     uint32_t* starts;     // piece-start bitmap (n/32 words; each tile stores its own 120 words)
     uint32_t* tile_np;    // pieces per tile
     uint32_t* res;        // [piece id] see above
-    uint32_t* tile_nmiss; // entries on the tile's miss list: pieces that have to be merged (not a token, not a duplicate)
     uint8_t* tile_sum;    // per tile, written when a tile is deferred for a walk back: its class if the whole tile is one run of that
                           // class without a certain start (later tiles jump over it), 16 if not; 0xFF: not written
-    uint2* miss;          // [tile * TKF_MISS_CAP + j] {start, length}; the merge kernels replace it by {token count, token | staging position}
-    uint32_t* listC;      // {miss index, start, len, scratch bytes before, tree levels before} for > 1 KiB pieces
+    TkMiss data;          // table slots + overflow entries (data.ovf_base: index of the first overflow entry)
+    uint32_t ovf_cap;     // overflow entries there is room for (TK_CNT_OVF counts on beyond it: the host then repeats the batch with more)
+    uint32_t* listC;      // {data index, start, len, scratch bytes before, tree levels before} for > 1 KiB pieces
     uint32_t* counters;
-};
-// In-call de-duplication of missed pieces: open-addressed, one 32-byte slot per distinct piece.
-struct TkMissSlot {
-    unsigned long long key;  // ~0 = empty
-    unsigned long long aux;  // identity of the claimant, ~0 until it has written it: pieces of <= 7 bytes: the bytes themselves
-                             // | length << 56; longer ones: 1 << 63 | length << 32 | start (compared in the text)
-    uint32_t mi;             // claimant's miss-list entry (tile * TKF_MISS_CAP + j)
-    uint32_t res_cnt;        // claimant's result, published after the merges
-    uint32_t res_tok;
-    uint32_t pad;
 };
 
 // ------------------------------------------------------------------------------------------
@@ -505,7 +529,7 @@ template <int PAT, bool SPEC, bool SLOW>
 __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
                                                   const uint32_t* __restrict__ brk, const uint32_t* __restrict__ docb,
                                                   const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, TkFrontOut out,
-                                                  TkMissSlot* __restrict__ mt, uint32_t mt_mask, uint32_t* __restrict__ deferred,
+                                                  TkMissKey* __restrict__ mt, uint32_t mt_mask, uint32_t* __restrict__ deferred,
                                                   const uint32_t* __restrict__ gapb /* gap chars of the generic engine's split, or null */, int dbg) {
     // the pattern: a compile-time constant for the three stock patterns; PAT = TK_PAT_GENERIC reads family and parameters from the tables
     constexpr bool GEN = PAT == TK_PAT_GENERIC;
@@ -520,7 +544,7 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
     __shared__ uint32_t certw[TK2_WIN / 32];                                         // certain starts (hard starts included)
     __shared__ uint32_t bits[TK_TILE / 32];
     __shared__ uint8_t lastc_own[256];
-    __shared__ uint32_t np_sh, nmiss_sh, need_walk, last_end_sh, ncls_sh, nx_sh, ncont_sh;
+    __shared__ uint32_t np_sh, need_walk, last_end_sh, ncls_sh, nx_sh, ncont_sh;
     __shared__ uint16_t contl_own[SLOW ? TKF_CONT_CAP : 1], stop_own[SLOW ? 256 : 2];
     // second window of the deferred-tile variant: a stretch of text left of the tile, walked by tk_coop_window_walk
     __shared__ __attribute__((aligned(16))) uint8_t w2_raw[SLOW ? TK2_WIN + 16 : 16];
@@ -528,7 +552,9 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
     __shared__ uint16_t w2_jump[SLOW ? TK2_WIN : 2];
     __shared__ uint16_t slowl[TKF_SLOW_CAP];  // pieces that leave the window (window positions of their starts)
     __shared__ uint32_t nslow_sh;
-    __shared__ uint32_t brkw[TK2_WIN / 32 + 1], ssw[SPEC ? TK2_WIN / 32 + 1 : 1], siw[SPEC ? TK2_WIN / 32 + 1 : 1];
+    // (the special-token bitmaps have no copy of their own -- two more arrays of this size took the kernel over an eighth of the CU's LDS:
+    // phase C reads each lane's 16 bits from global memory, phase F finds the starts of special tokens in `brkw`, reloaded in phase E)
+    __shared__ uint32_t brkw[TK2_WIN / 32 + 1];
     __shared__ uint32_t scan_sh[8];
     // the LDS piece cache (tk_common.h): lives as long as the workgroup, i.e. over all the tiles it walks
     constexpr bool HOT = !SLOW && TKF_HOT_BITS > 0;
@@ -605,13 +631,8 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
         int64_t wgp = base + (int64_t)tid * 32;
         bool in = wgp >= 0 && (uint64_t)wgp < n;
         brkw[tid] = in ? brk[wgp >> 5] : 0u;
-        if constexpr (SPEC) {
-            ssw[tid] = in ? ss[wgp >> 5] : 0u;
-            siw[tid] = in ? si[wgp >> 5] : 0u;
-        }
     }
     if (tid == 0) {
-        nmiss_sh = 0;
         need_walk = 0;
         ncont_sh = 0;
         nslow_sh = 0;
@@ -624,7 +645,7 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
     if (tid < 4) planes[tid][TK2_NSEG] = planes[tid][TK2_NSEG + 1] = tid >= 2 ? ~0ull : 0ull;  // (class END)
     __syncthreads();
     if (dbg & 0x1000) {  // (perf experiments: stop after this phase)
-        if (tid == 0) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
+        if (tid == 0) out.tile_np[tile] = 0;
         continue;
     }
     // ---- B: classes of the lane's 16 bytes as 16-bit masks (tk_chunk.h): table pass, decode pass for non-ASCII chars
@@ -649,7 +670,7 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
         tk_chunk_decode(ch, prev, tid > 0, get4, cls_of);
     }
     if (dbg & 0x2000) {  // (perf experiments: stop after the classification)
-        if (tid == 0 || (ch.acc0 ^ ch.acc1) == 0xFFFFFFF1u) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
+        if (tid == 0 || (ch.acc0 ^ ch.acc1) == 0xFFFFFFF1u) out.tile_np[tile] = 0;
         continue;
     }
     // ---- C: masks of the chunk -> bitmaps in LDS; certain starts; the list of scan starts
@@ -657,7 +678,14 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
     {
         const uint32_t sh16 = (tid & 1u) * 16u;
         const uint32_t brk16 = (brkw[tid >> 1] >> sh16) & 0xFFFFu;
-        const uint32_t ss16 = SPEC ? (ssw[tid >> 1] >> sh16) & 0xFFFFu : 0u, si16 = SPEC ? (siw[tid >> 1] >> sh16) & 0xFFFFu : 0u;
+        uint32_t ss16 = 0u, si16 = 0u;
+        if constexpr (SPEC) {  // (the window base is 32-aligned: the lane's 16 positions are one half of a bitmap word)
+            const int64_t wgp = base + (int64_t)(tid >> 1) * 32;
+            if (wgp >= 0 && (uint64_t)wgp < n) {
+                ss16 = (ss[wgp >> 5] >> sh16) & 0xFFFFu;
+                si16 = (si[wgp >> 5] >> sh16) & 0xFFFFu;
+            }
+        }
         tk_chunk_finalize(ch, valid, past, brk16, ss16, si16, mk);
     }
     TkSets st;
@@ -765,7 +793,7 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
         continue;
     }
     if (dbg & 0x4000) {  // (perf experiments: stop after this phase)
-        if (tid == 0) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
+        if (tid == 0) out.tile_np[tile] = 0;
         continue;
     }
     // ---- D: one lane per scan start; only boundaries inside the tile are recorded
@@ -998,7 +1026,7 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
         continue;
     }
     if (dbg & 0x8000) {  // (perf experiments: stop after this phase)
-        if (tid == 0) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
+        if (tid == 0) out.tile_np[tile] = 0;
         continue;
     }
     // ---- E: enumerate the pieces of the tile (set bits of `bits`, in order) -> plist (aliases the bitmaps)
@@ -1023,9 +1051,15 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
         const uint64_t wgp = tile_start / 32 + tid;
         if (wgp * 32 < n) out.starts[wgp] = bits[tid];
     }
+    if constexpr (SPEC) {  // starts of special tokens in the window, for phase F (the break bitmap is dead since phase C)
+        if (tid < TK2_WIN / 32) {
+            const int64_t wgp = base + (int64_t)tid * 32;
+            brkw[tid] = (wgp >= 0 && (uint64_t)wgp < n) ? ss[wgp >> 5] : 0u;
+        }
+    }
     __syncthreads();
     if (dbg & 0x10000) {  // (perf experiments: stop after this phase)
-        if (tid == 0) { out.tile_np[tile] = 0; out.tile_nmiss[tile] = 0; }
+        if (tid == 0) out.tile_np[tile] = 0;
         continue;
     }
     // ---- F: whole-piece probe (src/lib.rs:367).  Pieces are first sorted by length class into LDS lists -- short (<= 4 bytes),
@@ -1077,7 +1111,7 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
                 const uint32_t s_loc = plist[k], e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
                 const uint32_t len = e_loc - s_loc;
                 cls = len <= 4u ? 0u : (len <= 8u ? 1u : 2u);
-                if (SPEC && ((ssw[s_loc >> 5] >> (s_loc & 31u)) & 1u)) {  // a special token: its id (src/lib.rs:426-434)
+                if (SPEC && ((brkw[s_loc >> 5] >> (s_loc & 31u)) & 1u)) {  // a special token: its id (src/lib.rs:426-434)
                     out.res[run_base + k] = tk_special_id(T, text, (uint64_t)(base + s_loc), len);
                     cls = 3;
                 } else if (GEN && gapb && ((gapb[(uint64_t)(base + s_loc) >> 5] >> ((uint32_t)(base + s_loc) & 31u)) & 1u)) {  // a gap char: no token
@@ -1090,7 +1124,7 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
                     const uint4 e = *(const uint4*)&hot[tk_hot_slot(k0, k1, k2) * 4];
                     ++hot_probes;
                     if (e.x == k0 && e.y == k1 && e.z == k2 && (e.w >> 28) == len) {
-                        out.res[run_base + k] = (e.w & TK_HOT_DUP) ? (TK_RES_DUP | (e.w & (TK_HOT_DUP - 1u))) : (e.w & TK_HOT_PAYLOAD);
+                        out.res[run_base + k] = (e.w & TK_HOT_DUP) ? (TK_RES_FLAG | (e.w & (TK_HOT_DUP - 1u))) : (e.w & TK_HOT_PAYLOAD);
                         ++hot_hits;
                         cls = 3;
                     }
@@ -1277,10 +1311,11 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
         }
 #endif
         __syncthreads();
-        // F4: pieces that are not tokens.  In-call de-duplication: claim a slot of the miss table (first occurrence: goes on the
-        // tile's miss list and gets merged) or find it claimed by IDENTICAL bytes -- pieces of <= 7 bytes carry their bytes in the
-        // slot, longer ones are compared with the claimant's text -- and only record the slot (resolved by tk_k_tile_finish).
-        // Slots are written once, so a cached load can only be stale towards "empty", where the atomic decides.
+        // F4: pieces that are not tokens.  In-call de-duplication: claim a slot of the miss table (first occurrence: the slot's data entry
+        // gets the piece, the merge kernels will find it there) or find it claimed by IDENTICAL bytes -- pieces of <= 7 bytes carry their
+        // bytes in the slot, longer ones are compared with the claimant's text; either way the piece's result word refers to the slot.
+        // Slots are written once, so a cached load can only be stale towards "empty", where the atomic decides.  What the table does
+        // not take gets an overflow entry behind the table's (one returning atomic per wavefront that has such pieces: rare).
         const uint32_t n_x = nx_sh;
 #if TKF_ROWS
         for (uint32_t q0 = (uint32_t)wid * 64u; q0 < n_x; q0 += 256u) {  // (rows of 64: a wavefront without pieces does not run the body)
@@ -1289,8 +1324,8 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
         for (uint32_t q0 = 0; q0 < n_x; q0 += 256) {
             const uint32_t q = q0 + tid;
 #endif
-            bool listed = false;
-            uint32_t k = 0, len = 0, slot = TKF_NONE, dup_slot = TKF_NONE, s_loc = 0;
+            bool over = false;  // needs an overflow entry
+            uint32_t k = 0, len = 0, ref = TKF_NONE, s_loc = 0;
             uint64_t gs = 0;
             if (q < n_x) {
                 k = kb + ord_x[q];
@@ -1298,7 +1333,7 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
                 const uint32_t e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
                 len = e_loc - s_loc;
                 gs = (uint64_t)(base + s_loc);
-                listed = true;
+                over = true;
                 if (mt && len <= TK_GLANE_MAX) {
                     const bool in_lds = e_loc + 8u <= (uint32_t)TK2_WIN;
                     const uint64_t key = in_lds ? tk_key_of_lds(raw, s_loc, len) : tk_key_of_text(text, gs, len);
@@ -1319,9 +1354,11 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
                         const ulonglong2 ka = *(const ulonglong2*)&mt[i].key;
                         unsigned long long cur = ka.x;
                         if (cur == TK_EMPTY_KEY) cur = atomicCAS(&mt[i].key, TK_EMPTY_KEY, kk);
-                        if (cur == TK_EMPTY_KEY) {
-                            slot = i;  // claimed: the miss entry is recorded below
+                        if (cur == TK_EMPTY_KEY) {  // claimed: this occurrence is the one that gets merged
                             __hip_atomic_store(&mt[i].aux, ident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                            *(uint2*)&out.data.tab[i].start = make_uint2((uint32_t)gs, len);
+                            ref = i;
+                            over = false;
                             break;
                         }
                         if (cur == kk) {
@@ -1332,9 +1369,8 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
                                                            (in_lds ? tk_equal_lds_text(raw, s_loc, text, (uint32_t)a, len)
                                                                    : tk_equal_bytes(text, gs, text, (uint32_t)a, len)));
                             if (a != TK_EMPTY_KEY && same) {
-                                out.res[run_base + k] = TK_RES_DUP | i;
-                                listed = false;
-                                dup_slot = i;
+                                ref = i;
+                                over = false;
                                 break;
                             }
                         }
@@ -1342,33 +1378,28 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
                     }
                 }
             }
-            const uint64_t m = __ballot(listed);
-            if (m) {  // the tile's own miss list (no global atomics)
+            const uint64_t m = __ballot(over);
+            if (m) {
                 const int leader = __ffsll((unsigned long long)m) - 1;
                 uint32_t at = 0;
-                if (lane == leader) at = atomicAdd(&nmiss_sh, (uint32_t)__popcll(m));
+                if (lane == leader) at = atomicAdd(&out.counters[TK_CNT_OVF], (uint32_t)__popcll(m));
                 at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (listed) {
-                    const uint32_t mi = (uint32_t)tile * TKF_MISS_CAP + at;
-                    out.miss[mi] = make_uint2((uint32_t)gs, len);
-                    out.res[run_base + k] = TK_RES_FLAG | at;
-                    if (slot != TKF_NONE) mt[slot].mi = mi;
-                    if (len > TK_GLANE_MAX) tk_append_tree(out.listC, out.counters, mi, (uint32_t)gs, len);
+                if (over && at < out.ovf_cap) {  // (beyond the capacity: the counter tells the host, which repeats the batch with more room)
+                    ref = out.data.ovf_base + at;
+                    *(uint4*)&out.data.ovf[at].start = make_uint4((uint32_t)gs, len, 0u, 0u);
+                    if (len > TK_GLANE_MAX) tk_append_tree(out.listC, out.counters, ref, (uint32_t)gs, len);
                 }
             }
+            if (q < n_x) out.res[run_base + k] = ref != TKF_NONE ? (TK_RES_FLAG | ref) : 0u;
             // its later occurrences in this workgroup's tiles are duplicates without a probe: the slot goes into the piece cache
-            if (use_hot && q < n_x && len <= TK_HOT_MAXLEN) {
-                const uint32_t sl = listed ? slot : dup_slot;
-                if (sl != TKF_NONE) {
-                    uint32_t k0, k1, k2;
-                    hot_key(s_loc, len, k0, k1, k2);
-                    hot_insert(k0, k1, k2, len, TK_HOT_DUP | sl);
-                }
+            if (use_hot && q < n_x && len <= TK_HOT_MAXLEN && ref != TKF_NONE && ref < out.data.ovf_base) {
+                uint32_t k0, k1, k2;
+                hot_key(s_loc, len, k0, k1, k2);
+                hot_insert(k0, k1, k2, len, TK_HOT_DUP | ref);
             }
         }
         __syncthreads();  // (the lists are reused by the next batch)
     }
-    if (tid == 0) out.tile_nmiss[tile] = nmiss_sh;
     } while (PERSIST && (item += gridDim.x) < n_items);
     if constexpr (HOT) {  // statistics of the piece cache (two fire-and-forget atomics per wavefront)
         hot_probes = tk_wave_sum_u32(hot_probes);
@@ -1380,57 +1411,52 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
     }
 }
 
-// The pieces on the tiles' miss lists (first occurrences: duplicates were resolved by the front kernel) have to be
-// listed by length bin for the merge kernels.  Same-address returning atomics run at only 25..130 M/s on this
-// multi-XCD part (one per (wave, bin) cost 4.5 ms per GiB, one per tile 8 ms), so the lists are built without
-// any: pass 1 (tk_k_bincount) counts per (wave, bin); tk_k_scan_small turns the counts into offsets; pass 2
-// (tk_k_binfill) walks the same lists in the same order and writes the entries.  Both passes use the same
-// fixed wave -> tile-group mapping.
-#define TKD_GROUP 4     // tiles per wave step
+// The distinct missed pieces -- the claimed slots of the miss table and the overflow entries behind them (TkMissData) -- have to be
+// listed by length bin for the merge kernels.  Same-address returning atomics run at only 25..130 M/s on this multi-XCD part (one per
+// (wave, bin) cost 4.5 ms per GiB), so the lists are built without any: pass 1 (tk_k_bincount) counts per (wave, bin);
+// tk_k_scan_small turns the counts into offsets -- bin-major, so that the bins lie back to back in ONE list sized by the entries, not by
+// the worst case of every bin; pass 2 (tk_k_binfill) walks the same entries in the same order and writes their indices.  Both passes
+// use the same wave -> range mapping: the entries that exist, in equal shares.
 #define TKD_WAVES 8192  // most waves of the two passes (2048 workgroups); small inputs launch fewer
 
-struct TkMissGroup {  // the miss lists of TKD_GROUP consecutive tiles, flattened
-    uint32_t pre[TKD_GROUP + 1];
-    __device__ __forceinline__ void load(const uint32_t* __restrict__ tile_nmiss, uint64_t t0, uint64_t ntiles, int lane, uint32_t tpg) {
-        uint32_t nm_l = 0;  // tpg = tiles per group: TKD_GROUP, or 1 for small chunks (more waves, shorter dependent chains)
-        if (lane < (int)tpg && t0 + lane < ntiles) nm_l = tile_nmiss[t0 + lane];
-        pre[0] = 0;
-#pragma unroll
-        for (int q = 0; q < TKD_GROUP; ++q) pre[q + 1] = pre[q] + __shfl(nm_l, q, 64);
+// entries of the miss data that exist: the table's slots and the overflow entries handed out
+__device__ __forceinline__ uint32_t tk_miss_entries(const uint32_t* __restrict__ counters, uint32_t ovf_base, uint32_t ovf_cap) {
+    const uint32_t no = counters[TK_CNT_OVF];
+    return ovf_base + (no < ovf_cap ? no : ovf_cap);
+}
+// length bin of entry i for lane (TK_NBIN: none -- a free slot, or a piece of more than TK_GLANE_MAX bytes, which is on the tree list)
+// (a table slot is read from the KEY table -- 16 bytes per slot, and its claimant's identity word holds the length -- so that the walk
+// over four million slots does not touch the 64-byte entries)
+__device__ __forceinline__ uint32_t tk_miss_bin(const TkMiss& data, const TkMissKey* __restrict__ mt, uint32_t i, uint32_t hi) {
+    if (i >= hi) return TK_NBIN;
+    uint32_t len;
+    if (i < data.ovf_base) {
+        const ulonglong2 ka = *(const ulonglong2*)&mt[i].key;
+        if (ka.x == TK_EMPTY_KEY) return TK_NBIN;
+        len = (ka.y >> 63) ? ((uint32_t)(ka.y >> 32) & 0x7FFFFFFFu) : (uint32_t)(ka.y >> 56);
+    } else {
+        len = data.ovf[i - data.ovf_base].len;
     }
-    __device__ __forceinline__ uint32_t total() const { return pre[TKD_GROUP]; }
-    // flat index -> miss-list entry
-    __device__ __forceinline__ uint32_t locate(uint32_t f, uint64_t t0) const {
-        uint32_t q = 0;
-#pragma unroll
-        for (int i = 1; i < TKD_GROUP; ++i) q += f >= pre[i];
-        return (uint32_t)(t0 + q) * TKF_MISS_CAP + (f - pre[q]);
-    }
-};
+    return len > TK_GLANE_MAX ? (uint32_t)TK_NBIN : (uint32_t)tk_bin_of(len);
+}
 
-__global__ __launch_bounds__(256) void tk_k_bincount(uint64_t ntiles, const uint32_t* __restrict__ tile_nmiss, const uint2* __restrict__ miss,
-                                                     uint32_t* __restrict__ wbin, uint32_t tpg) {
-    const uint32_t nwaves = gridDim.x * 4u;  // tk_k_binfill runs with the same grid: identical wave -> tile-group mapping
+__global__ __launch_bounds__(256) void tk_k_bincount(TkMiss data, const TkMissKey* __restrict__ mt, uint32_t ovf_cap,
+                                                     const uint32_t* __restrict__ counters, uint32_t* __restrict__ wbin) {
+    const uint32_t ovf_base = data.ovf_base;
+    const uint32_t nwaves = gridDim.x * 4u;  // tk_k_binfill runs with the same grid: identical wave -> range mapping
     const int lane = threadIdx.x & 63;
-    const uint64_t ngroups = (ntiles + tpg - 1) / tpg;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
+    const uint32_t E = tk_miss_entries(counters, ovf_base, ovf_cap);
+    const uint32_t per = ((E + nwaves - 1u) / nwaves + 63u) & ~63u;
+    const uint64_t lo64 = (uint64_t)wave * per;
+    const uint32_t lo = lo64 < E ? (uint32_t)lo64 : E, hi = lo64 + per < E ? (uint32_t)(lo64 + per) : E;
     uint32_t nb[TK_NBIN];
 #pragma unroll
     for (int b = 0; b < TK_NBIN; ++b) nb[b] = 0;
-    for (uint64_t g = wave; g < ngroups; g += nwaves) {
-        const uint64_t t0 = g * tpg;
-        TkMissGroup grp;
-        grp.load(tile_nmiss, t0, ntiles, lane, tpg);
-        for (uint32_t j0 = 0; j0 < grp.total(); j0 += 64) {
-            const uint32_t f = j0 + lane;
-            uint32_t bin = TK_NBIN;  // (pieces over TK_GLANE_MAX bytes are on the tree list: no bin)
-            if (f < grp.total()) {
-                const uint32_t len = miss[grp.locate(f, t0)].y;
-                if (len <= TK_GLANE_MAX) bin = (uint32_t)tk_bin_of(len);
-            }
+    for (uint32_t i0 = lo; i0 < hi; i0 += 64) {
+        const uint32_t bin = tk_miss_bin(data, mt, i0 + (uint32_t)lane, hi);
 #pragma unroll
-            for (int b = 0; b < TK_NBIN; ++b) nb[b] += (uint32_t)__popcll(__ballot(bin == (uint32_t)b));
-        }
+        for (int b = 0; b < TK_NBIN; ++b) nb[b] += (uint32_t)__popcll(__ballot(bin == (uint32_t)b));
     }
     if (lane == 0) {
 #pragma unroll
@@ -1438,72 +1464,67 @@ __global__ __launch_bounds__(256) void tk_k_bincount(uint64_t ntiles, const uint
     }
 }
 
-// pass 2: wscan = exclusive scan of wbin (TK_NBIN * nwaves + 1 entries; the last one is the grand total)
-__global__ __launch_bounds__(256) void tk_k_binfill(uint64_t ntiles, const uint32_t* __restrict__ tile_nmiss, const uint2* __restrict__ miss,
-                                                    const uint32_t* __restrict__ wscan, uint32_t* __restrict__ listM, TkBins bins,
-                                                    uint32_t* __restrict__ counters, uint32_t tpg) {
+// pass 2: wscan = exclusive scan of wbin (TK_NBIN * nwaves + 1 entries; the last one is the grand total).  listB[wscan[b * nwaves]...]
+// is bin b's list of data indices; its start and length go to the counters (TK_CNT_BOFF0 + b, TK_CNT_BIN0 + b) for the merge kernels.
+__global__ __launch_bounds__(256) void tk_k_binfill(TkMiss data, const TkMissKey* __restrict__ mt, uint32_t ovf_cap,
+                                                    const uint32_t* __restrict__ wscan, uint32_t* __restrict__ listB, uint32_t* __restrict__ counters) {
+    const uint32_t ovf_base = data.ovf_base;
     const int lane = threadIdx.x & 63;
-    const uint64_t ngroups = (ntiles + tpg - 1) / tpg;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6;
     const uint32_t nwaves = gridDim.x * 4u;
+    const uint32_t E = tk_miss_entries(counters, ovf_base, ovf_cap);
+    const uint32_t per = ((E + nwaves - 1u) / nwaves + 63u) & ~63u;
+    const uint64_t lo64 = (uint64_t)wave * per;
+    const uint32_t lo = lo64 < E ? (uint32_t)lo64 : E, hi = lo64 + per < E ? (uint32_t)(lo64 + per) : E;
     uint32_t at[TK_NBIN];
 #pragma unroll
-    for (int b = 0; b < TK_NBIN; ++b) at[b] = bins.off[b] + wscan[(uint32_t)b * nwaves + wave] - wscan[(uint32_t)b * nwaves];
-    if (wave == 0 && lane < TK_NBIN) counters[TK_CNT_BIN0 + lane] = wscan[(uint32_t)(lane + 1) * nwaves] - wscan[(uint32_t)lane * nwaves];
-    for (uint64_t g = wave; g < ngroups; g += nwaves) {
-        const uint64_t t0 = g * tpg;
-        TkMissGroup grp;
-        grp.load(tile_nmiss, t0, ntiles, lane, tpg);
-        for (uint32_t j0 = 0; j0 < grp.total(); j0 += 64) {
-            const uint32_t f = j0 + lane;
-            uint32_t bin = TK_NBIN, mi = 0, s = 0, len = 0;
-            if (f < grp.total()) {
-                mi = grp.locate(f, t0);
-                const uint2 e = miss[mi];
-                s = e.x;
-                len = e.y;
-                if (len <= TK_GLANE_MAX) bin = (uint32_t)tk_bin_of(len);
-            }
+    for (int b = 0; b < TK_NBIN; ++b) at[b] = wscan[(uint32_t)b * nwaves + wave];
+    if (wave == 0 && lane < TK_NBIN) {
+        counters[TK_CNT_BIN0 + lane] = wscan[(uint32_t)(lane + 1) * nwaves] - wscan[(uint32_t)lane * nwaves];
+        counters[TK_CNT_BOFF0 + lane] = wscan[(uint32_t)lane * nwaves];
+    }
+    for (uint32_t i0 = lo; i0 < hi; i0 += 64) {
+        const uint32_t i = i0 + (uint32_t)lane;
+        const uint32_t bin = tk_miss_bin(data, mt, i, hi);
 #pragma unroll
-            for (int b = 0; b < TK_NBIN; ++b) {
-                const uint64_t m = __ballot(bin == (uint32_t)b);
-                if (bin == (uint32_t)b) {
-                    uint32_t* q = listM + 3 * (uint64_t)(at[b] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull)));
-                    q[0] = mi;
-                    q[1] = s;
-                    q[2] = len;
-                }
-                at[b] += (uint32_t)__popcll(m);
-            }
+        for (int b = 0; b < TK_NBIN; ++b) {
+            const uint64_t m = __ballot(bin == (uint32_t)b);
+            if (bin == (uint32_t)b) listB[at[b] + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = i;
+            at[b] += (uint32_t)__popcll(m);
         }
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// merges on {miss index, start, len} entries: byte_pair_merge (src/lib.rs:140-196) of the piece text[start .. start + len)
-// result: miss[mi] = {token count, the token (count 1) | the staging position of the tokens}
+// merges on lists of miss-data indices: byte_pair_merge (src/lib.rs:140-196) of the piece text[start .. start + len) of entry i
+// result: data[i].res = {token count, the token (count 1) | the staging position of the tokens}
 // ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void tk_put_result(const TkMiss& data, uint32_t i, uint32_t cnt, uint32_t tok) { data.put(i, cnt, tok); }
 template <int NMAX, int THREADS>
-__global__ __launch_bounds__(THREADS) void tk_k_merge_llane(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ list,
-                                                             const uint32_t* __restrict__ count_ptr, uint2* __restrict__ miss,
+__global__ __launch_bounds__(THREADS) void tk_k_merge_llane(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listB,
+                                                             const uint32_t* __restrict__ counters, int bin, TkMiss data,
                                                              uint32_t* __restrict__ staging) {
-    const uint32_t count = *count_ptr;  // list length produced on the device (tk_k_binfill): no host round trip before the merges
+    const uint32_t count = counters[TK_CNT_BIN0 + bin];  // list start and length produced on the device (tk_k_binfill): no host round trip before the merges
+    const uint32_t* __restrict__ list = listB + counters[TK_CNT_BOFF0 + bin];
     __shared__ uint32_t s_id[NMAX * THREADS];
     __shared__ uint32_t s_rk[NMAX * THREADS];
     uint32_t* id = s_id + threadIdx.x;
     uint32_t* rk = s_rk + threadIdx.x;
     for (uint32_t it = blockIdx.x * THREADS + threadIdx.x; it < count; it += gridDim.x * THREADS) {
-        const uint32_t mi = list[3 * (uint64_t)it], s = list[3 * (uint64_t)it + 1], n = list[3 * (uint64_t)it + 2];
+        const uint32_t mi = list[it];
+        const uint2 pc = data.piece(mi);
+        const uint32_t s = pc.x, n = pc.y;
         const uint32_t t = tk_lane_merge<THREADS>(T, text, s, n, id, rk, staging + s);
-        miss[mi] = make_uint2(t, t == 1 ? id[0] : s);
+        tk_put_result(data, mi, t, t == 1 ? id[0] : s);
     }
 }
 
 template <int G>
-__global__ __launch_bounds__(256) void tk_k_merge_group(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ list,
-                                                         const uint32_t* __restrict__ count_ptr, uint2* __restrict__ miss,
+__global__ __launch_bounds__(256) void tk_k_merge_group(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listB,
+                                                         const uint32_t* __restrict__ counters, int bin, TkMiss data,
                                                          uint32_t* __restrict__ staging) {
-    const uint32_t count = *count_ptr;
+    const uint32_t count = counters[TK_CNT_BIN0 + bin];
+    const uint32_t* __restrict__ list = listB + counters[TK_CNT_BOFF0 + bin];
     constexpr int C = 16, NMAX = G * C, PPW = 64 / G;
     constexpr uint32_t NONE = 0xFFFFu;
     __shared__ __attribute__((aligned(16))) uint32_t s_id[4][1024];
@@ -1537,9 +1558,10 @@ __global__ __launch_bounds__(256) void tk_k_merge_group(TkTables T, const uint8_
         const bool valid = e < count;
         uint32_t mi = 0, s = 0, n = 0;
         if (valid) {
-            mi = list[3 * (uint64_t)e];
-            s = list[3 * (uint64_t)e + 1];
-            n = list[3 * (uint64_t)e + 2];
+            mi = list[e];
+            const uint2 pc = data.piece(mi);
+            s = pc.x;
+            n = pc.y;
         }
         uint32_t mask = 0;
 #pragma unroll 4
@@ -1647,7 +1669,7 @@ __global__ __launch_bounds__(256) void tk_k_merge_group(TkTables T, const uint8_
                 mm &= mm - 1;
                 staging[s + t++] = id[g * C + c];
             }
-            if (g == 0) miss[mi] = make_uint2(total, total == 1 ? id[0] : s);
+            if (g == 0) tk_put_result(data, mi, total, total == 1 ? id[0] : s);
         }
         __builtin_amdgcn_wave_barrier();
     }
@@ -1724,8 +1746,8 @@ __device__ __forceinline__ void tkm_probe2(const TkTables& T, uint32_t a0, uint3
 }
 #define TKM_WGS_PER_CU 5  // 32 KiB of LDS per workgroup
 #define TKM_WORK_STRIDE 64  // words between two work counters (256 bytes)
-__global__ __launch_bounds__(256, TKM_WGS_PER_CU) void tk_k_merge_all(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listB, TkBins bins,
-                                                                      uint32_t* __restrict__ counters, uint2* __restrict__ miss, uint32_t* __restrict__ staging,
+__global__ __launch_bounds__(256, TKM_WGS_PER_CU) void tk_k_merge_all(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listB,
+                                                                      uint32_t* __restrict__ counters, TkMiss data, uint32_t* __restrict__ staging,
                                                                       uint32_t* __restrict__ work /* 16 counters, TKM_WORK_STRIDE words apart, zero */, int dbg) {
     constexpr int C = 16;
     constexpr uint32_t NONE = 0xFFFFu;
@@ -1779,10 +1801,10 @@ __global__ __launch_bounds__(256, TKM_WGS_PER_CU) void tk_k_merge_all(TkTables T
         const bool valid = e < count;
         uint32_t mi = 0, s = 0, n = 0;
         if (valid) {
-            const uint32_t* le = listB + 3 * ((uint64_t)bins.off[b] + e);
-            mi = le[0];
-            s = le[1];
-            n = le[2];
+            mi = listB[counters[TK_CNT_BOFF0 + b] + e];
+            const uint2 pc = data.piece(mi);
+            s = pc.x;
+            n = pc.y;
         }
         // the lane's 16 parts: ids of the single bytes, keys of the 2-byte pairs (17 text bytes: three aligned words)
         uint32_t mask = 0;
@@ -1899,13 +1921,19 @@ __global__ __launch_bounds__(256, TKM_WGS_PER_CU) void tk_k_merge_all(TkTables T
         }
         const uint32_t total = __shfl(inc, gbase + G - 1, 64);
         if (valid) {
+            // (into the piece's entry when they fit: the back end then needs one access per occurrence, not a second one to the staging area)
+            const bool fits = data.fits(mi, total);
+            uint32_t* dst = fits ? data.tab[mi].tok : staging + s;
             uint32_t t = inc - mine, mm = mask;
             while (mm) {
                 const int c = __ffs((int)mm) - 1;
                 mm &= mm - 1;
-                staging[s + t++] = id[c];
+                dst[t++] = id[c];
             }
-            if (g == 0) miss[mi] = make_uint2(total, total == 1 ? id[0] : s);
+            if (g == 0) {
+                if (fits) data.put_count(mi, total | TKD_INLINE_BIT);
+                else tk_put_result(data, mi, total, total == 1 ? id[0] : s);
+            }
         }
         __builtin_amdgcn_wave_barrier();
         // The next unit: sixteen counters share the requests, each in a cache line of its own -- atomics on one LINE are served one after
@@ -1924,13 +1952,13 @@ __global__ __launch_bounds__(256, TKM_WGS_PER_CU) void tk_k_merge_all(TkTables T
 __global__ __launch_bounds__(256) void tk_k_merge_long(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listC,
                                                         uint32_t nC, uint32_t* __restrict__ g_id, uint32_t* __restrict__ g_rk,
                                                         uint32_t* __restrict__ g_nx, uint32_t* __restrict__ g_pv, uint64_t* __restrict__ g_lv,
-                                                        uint2* __restrict__ miss, uint32_t* __restrict__ staging, int redo_only) {
+                                                        TkMiss data, uint32_t* __restrict__ staging, int redo_only) {
     const int lane = threadIdx.x & 63;
     const uint32_t wave = (blockIdx.x * 256u + threadIdx.x) >> 6, nwaves = (gridDim.x * 256u) >> 6;
     for (uint32_t w = wave; w < nC; w += nwaves) {
         const uint32_t* ent = listC + 5 * (uint64_t)w;
         const uint32_t mi = ent[0], s = ent[1], n = ent[2];
-        if (redo_only && miss[mi].x != TK_MERGE_REDO) continue;
+        if (redo_only && data.result(mi).x != TK_MERGE_REDO) continue;
         uint32_t* id = g_id + ent[3];
         uint32_t* rk = g_rk + ent[3];
         uint32_t* nx = g_nx + ent[3];
@@ -2017,7 +2045,7 @@ __global__ __launch_bounds__(256) void tk_k_merge_long(TkTables T, const uint8_t
             if (v != TK_RANK_MAX) staging[s + t + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))] = v;
             t += (uint32_t)__popcll(m);
         }
-        if (lane == 0) miss[mi] = make_uint2(t, t == 1 ? id[0] : s);  // (the leftmost part always survives)
+        if (lane == 0) tk_put_result(data, mi, t, t == 1 ? id[0] : s);  // (the leftmost part always survives)
     }
 }
 
@@ -2078,7 +2106,7 @@ __device__ __forceinline__ void tk_grid_barrier(uint32_t* bar, uint32_t& epoch) 
 
 template <bool WIDE>
 __device__ __forceinline__ void tk_rounds_piece(const TkTables& T, const uint8_t* __restrict__ text, const uint32_t* ent, uint32_t* g_p0, uint32_t* g_r0,
-                                                uint32_t* g_p1, uint32_t* g_r1, uint2* __restrict__ miss, uint32_t* __restrict__ staging,
+                                                uint32_t* g_p1, uint32_t* g_r1, TkMiss data, uint32_t* __restrict__ staging,
                                                 TkWideWs* ws, uint32_t& epoch, uint32_t* red, uint32_t (*sc_lds)[TKB_THREADS / 64], uint32_t* viol_lds) {
     constexpr int NWB = TKB_THREADS / 64;                               // wavefronts per workgroup
     const uint32_t NWV = WIDE ? (uint32_t)NWB * gridDim.x : (uint32_t)NWB;  // wavefronts that share the piece
@@ -2321,10 +2349,10 @@ __device__ __forceinline__ void tk_rounds_piece(const TkTables& T, const uint8_t
         cnt = total;
     }
     if (redo) {
-        if (gtid == 0) miss[mi] = make_uint2(TK_MERGE_REDO, 0u);
+        if (gtid == 0) tk_put_result(data, mi, TK_MERGE_REDO, 0u);
     } else {
         for (uint32_t k = gtid; k < cnt; k += gthreads) staging[s + k] = P0[k] & ~MARK;
-        if (gtid == 0) miss[mi] = make_uint2(cnt, cnt == 1 ? (P0[0] & ~MARK) : s);
+        if (gtid == 0) tk_put_result(data, mi, cnt, cnt == 1 ? (P0[0] & ~MARK) : s);
     }
     sync();
 }
@@ -2333,7 +2361,7 @@ __device__ __forceinline__ void tk_rounds_piece(const TkTables& T, const uint8_t
 __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listC,
                                                                   uint32_t nC, uint32_t* __restrict__ g_p0, uint32_t* __restrict__ g_r0,
                                                                   uint32_t* __restrict__ g_p1, uint32_t* __restrict__ g_r1,
-                                                                  uint2* __restrict__ miss, uint32_t* __restrict__ staging) {
+                                                                  TkMiss data, uint32_t* __restrict__ staging) {
     __shared__ uint32_t red[TKB_THREADS / 64];
     __shared__ uint32_t sc[4][TKB_THREADS / 64];
     __shared__ uint32_t viol_sh;
@@ -2341,86 +2369,85 @@ __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds(TkTables T, con
     for (uint32_t w = blockIdx.x; w < nC; w += gridDim.x) {
         const uint32_t* ent = listC + 5 * (uint64_t)w;
         if (ent[2] >= TK_WIDE_MIN) continue;
-        tk_rounds_piece<false>(T, text, ent, g_p0, g_r0, g_p1, g_r1, miss, staging, nullptr, epoch, red, sc, &viol_sh);
+        tk_rounds_piece<false>(T, text, ent, g_p0, g_r0, g_p1, g_r1, data, staging, nullptr, epoch, red, sc, &viol_sh);
     }
 }
 // all workgroups of the launch (TK_WIDE_BLOCKS of them) on one piece after the other
 __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds_wide(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listC,
                                                                        uint32_t nC, uint32_t* __restrict__ g_p0, uint32_t* __restrict__ g_r0,
                                                                        uint32_t* __restrict__ g_p1, uint32_t* __restrict__ g_r1,
-                                                                       uint2* __restrict__ miss, uint32_t* __restrict__ staging, TkWideWs* __restrict__ ws) {
+                                                                       TkMiss data, uint32_t* __restrict__ staging, TkWideWs* __restrict__ ws) {
     __shared__ uint32_t red[TKB_THREADS / 64];
     uint32_t epoch = 0;
     for (uint32_t w = 0; w < nC; ++w) {
         const uint32_t* ent = listC + 5 * (uint64_t)w;
         if (ent[2] < TK_WIDE_MIN) continue;
-        tk_rounds_piece<true>(T, text, ent, g_p0, g_r0, g_p1, g_r1, miss, staging, ws, epoch, red, nullptr, nullptr);
+        tk_rounds_piece<true>(T, text, ent, g_p0, g_r0, g_p1, g_r1, data, staging, ws, epoch, red, nullptr, nullptr);
     }
 }
 
 // ------------------------------------------------------------------------------------------
-// back end
+// back end: tk_k_count_tiles -> exclusive scan of the tile counts -> tk_k_place (and, beside it, tk_k_docoff)
+//
+// The tokens of tile t go behind those of all the tiles before it, and a tile's token count is known only when the results of its
+// missed pieces are (a missed piece is two or more tokens).  Both passes read the per-piece result words -- four pieces per lane and
+// row of 256, one 16-byte load -- and, for a missed piece, the entry its word refers to (TkMiss): the first takes the count from it,
+// the second the tokens themselves, which a table entry holds inline (one random access per occurrence; earlier rounds copied every
+// result into a per-tile array first and moved 5 GB per GiB of text to place 1 GB of tokens).
+// Measured and dropped in round 4 (profiles/r04_place_single_pass.txt): ONE pass with a decoupled look-back over the tile counts --
+// 2.3 ms where these two passes take less, because a wavefront holds its tile while it waits for the tiles before it, and a kernel
+// whose workgroups wait for each other cannot share the device with another kernel (a chunk's back stage runs beside the next chunk's
+// front stage): its workgroups that are not resident yet never get the registers the waiting ones hold.
 // ------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void tk_k_dup_publish(TkMissSlot* __restrict__ mt, uint32_t mt_slots, const uint2* __restrict__ miss) {
-    for (uint32_t i = blockIdx.x * 256u + threadIdx.x; i < mt_slots; i += gridDim.x * 256u) {
-        if (mt[i].key == TK_EMPTY_KEY) continue;
-        const uint2 r = miss[mt[i].mi];
-        mt[i].res_cnt = r.x;
-        mt[i].res_tok = r.y;
+
+// result words of the lane's four pieces of one row -> per piece: its token count c[] and, for a missed piece, the head of its entry
+// (hd[j] = {res_cnt word, tok[0]}), all loads in flight together
+__device__ __forceinline__ void tk_row_counts(const uint32_t* __restrict__ res, const TkMiss& data, uint32_t rb, uint32_t np, uint32_t k, uint32_t tk[4], uint32_t c[4], uint2 hd[4]) {
+    uint4 t4 = make_uint4(0, 0, 0, 0);
+    if (k < np) t4 = *(const uint4*)(res + rb + k);  // (runs start 16-byte aligned, and a run's storage extends to the next multiple of four)
+    tk[0] = t4.x; tk[1] = t4.y; tk[2] = t4.z; tk[3] = t4.w;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const bool live = k + j < np;
+        c[j] = (live && tk[j] != TK_RES_GAP) ? 1u : 0u;
+        hd[j] = make_uint2(0u, 0u);
+        if (live && (tk[j] & TK_RES_FLAG)) hd[j] = data.result(tk[j] & ~TK_RES_FLAG);
+        else tk[j] &= ~TK_RES_FLAG;  // (a dead word is not a reference)
     }
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (tk[j] & TK_RES_FLAG) c[j] = TKD_COUNT(hd[j].x);
 }
 
-// one wavefront per tile, four consecutive pieces per lane (16-byte loads; runs start 16-byte aligned): the pieces that are not single
-// tokens get their result {count, token | staging position} -- from the tile's miss list or, for duplicates, from the claimant's slot --
-// appended IN PIECE ORDER to rflag[tile * TKF_MISS_CAP ...], so that the passes after this one read it sequentially; token count of the tile
-__global__ __launch_bounds__(256) void tk_k_tile_finish(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const TkMissSlot* __restrict__ mt,
-                                                        const uint32_t* __restrict__ res, const uint2* __restrict__ miss, uint2* __restrict__ rflag,
-                                                        uint32_t* __restrict__ tile_nt, uint32_t* __restrict__ wave_pieces) {
+// tile_nt[t] <- tokens of tile t; row_rel[t * (TKF_CAP / 256) + r] <- tokens of the tile's rows before row r (for tk_k_docoff);
+// total[1] += pieces of the chunk.  One wavefront per tile at a time.
+__global__ __launch_bounds__(256) void tk_k_count_tiles(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ res, TkMiss data,
+                                                        uint32_t* __restrict__ tile_nt, uint32_t* __restrict__ row_rel, unsigned long long* __restrict__ total) {
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
-    uint32_t pieces = 0;
+    unsigned long long pieces = 0;
     for (uint64_t t = wave; t < ntiles; t += nwaves) {
-        const uint32_t np = tile_np[t], rb = (uint32_t)t * TKF_CAP, mb = (uint32_t)t * TKF_MISS_CAP;
+        const uint32_t np = tile_np[t], rb = (uint32_t)t * TKF_CAP;
         pieces += np;
-        uint32_t sum = 0, fbase = 0;
-        for (uint32_t k = lane * 4; k - lane * 4 < np; k += 256) {  // (uniform trip count: the scan below needs every lane)
-            uint4 r4 = make_uint4(0, 0, 0, 0);
-            if (k < np) r4 = *(const uint4*)(res + rb + k);
-            const uint32_t r[4] = {r4.x, r4.y, r4.z, r4.w};
-            uint2 v[4];
-            uint32_t nf = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {  // all four loads in flight together
-                const bool live = k + j < np, flagged = live && (r[j] & TK_RES_FLAG);
-                v[j] = make_uint2(live && r[j] != TK_RES_GAP ? 1u : 0u, 0u);
-                if (flagged) {
-                    if ((r[j] & TK_RES_DUP) == TK_RES_DUP) v[j] = *(const uint2*)&mt[r[j] & ~TK_RES_DUP].res_cnt;
-                    else v[j] = miss[mb + (r[j] & ~TK_RES_FLAG)];
-                    ++nf;
-                }
-            }
-            const uint32_t inc = tk_wave_scan_u32(nf, lane);
-            uint32_t at = mb + fbase + inc - nf;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                if (k + j < np && (r[j] & TK_RES_FLAG)) rflag[at++] = v[j];
-                sum += v[j].x;
-            }
-            fbase += (uint32_t)__shfl((int)inc, 63, 64);
+        uint32_t run = 0;
+        for (uint32_t k0 = 0; k0 < np; k0 += 256) {
+            uint32_t tk[4], c[4];
+            uint2 hd[4];
+            tk_row_counts(res, data, rb, np, k0 + (uint32_t)lane * 4u, tk, c, hd);
+            if (lane == 0) row_rel[t * (TKF_CAP / 256) + (k0 >> 8)] = run;
+            run += tk_wave_sum_u32(c[0] + c[1] + c[2] + c[3]);
         }
-        sum = tk_wave_sum_u32(sum);
-        if (lane == 0) tile_nt[t] = sum;
+        if (lane == 0) tile_nt[t] = run;
     }
-    if (lane == 0) wave_pieces[wave] = pieces;  // (summed by tk_k_sum_pieces: no same-address atomics)
+    if (lane == 0 && pieces) atomicAdd(&total[1], pieces);  // (one fire-and-forget atomic per wavefront)
 }
 
-// one wavefront per tile, four consecutive pieces per lane: local scan of the piece counts, tokens to their final positions.
-// Single tokens go out as one 16-byte store per lane; the tokens of a multi-token piece are copied from the staging area by
-// eight lanes per piece.
-__global__ __launch_bounds__(256) void tk_k_back(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_tb,
-                                                 const uint32_t* __restrict__ res, const uint2* __restrict__ rflag, const uint32_t* __restrict__ staging,
-                                                 uint32_t* __restrict__ out_all, const unsigned long long* __restrict__ tok_base, uint32_t* __restrict__ big,
-                                                 uint2* __restrict__ row_base) {
+// tile_tb = exclusive scan of tile_nt.  One wavefront per tile at a time, row by row: single tokens go out as one 16-byte store per
+// lane; a missed piece's tokens come from its entry (three 16-byte loads at most: the line is in the cache, the count came from it);
+// what does not fit an entry -- more than TKD_INLINE tokens, overflow entries -- is copied from the staging area by 32 lanes per piece.
+__global__ __launch_bounds__(256) void tk_k_place(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_tb,
+                                                  const uint32_t* __restrict__ res, TkMiss data, const uint32_t* __restrict__ staging, uint32_t* __restrict__ out_all,
+                                                  const unsigned long long* __restrict__ tok_base, uint32_t* __restrict__ big) {
     __shared__ uint32_t mlist_sh[4][256 * 3];
     // the chunk's tokens follow those of the chunks before it: their number stays on the device (chunks are pipelined, the host does
     // not know it when it queues this kernel)
@@ -2429,58 +2456,65 @@ __global__ __launch_bounds__(256) void tk_k_back(uint64_t ntiles, const uint32_t
     uint32_t* mlist = mlist_sh[threadIdx.x >> 6];
     const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
     for (uint64_t t = wave; t < ntiles; t += nwaves) {
-        const uint32_t np = tile_np[t], rb = (uint32_t)t * TKF_CAP, mb = (uint32_t)t * TKF_MISS_CAP;
-        uint32_t run = tile_tb[t], fbase = 0;
+        const uint32_t np = tile_np[t], rb = (uint32_t)t * TKF_CAP;
+        uint32_t run = tile_tb[t];  // (token offsets within a chunk fit 32 bits: a chunk is less than 4 GiB of text)
         for (uint32_t k0 = 0; k0 < np; k0 += 256) {
-            const uint32_t k = k0 + lane * 4;
-            // (token offset and rflag position at which this row of 256 pieces starts: tk_k_docoff continues from there)
-            if (lane == 0) row_base[t * (TKF_CAP / 256) + (k0 >> 8)] = make_uint2(run, fbase);
-            uint4 t4 = make_uint4(0, 0, 0, 0);
-            if (k < np) t4 = *(const uint4*)(res + rb + k);
-            uint32_t tk[4] = {t4.x, t4.y, t4.z, t4.w};
-            uint32_t c[4];
-            uint32_t nf = 0;
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-                c[j] = (k + j < np && tk[j] != TK_RES_GAP) ? 1u : 0u;
-                nf += (c[j] && (tk[j] & TK_RES_FLAG)) ? 1u : 0u;
-            }
-            const uint32_t finc = tk_wave_scan_u32(nf, lane);
-            if (nf) {  // results of the flagged pieces: sequential in rflag
-                uint32_t at = mb + fbase + finc - nf;
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-                    if (c[j] && (tk[j] & TK_RES_FLAG)) {
-                        const uint2 v = rflag[at++];
-                        c[j] = v.x;
-                        tk[j] = v.y;
-                    }
-            }
-            fbase += (uint32_t)__shfl((int)finc, 63, 64);
+            uint32_t tk[4], c[4];
+            uint2 hd[4];
+            tk_row_counts(res, data, rb, np, k0 + (uint32_t)lane * 4u, tk, c, hd);
             const uint32_t mine = c[0] + c[1] + c[2] + c[3];
             const uint32_t inc = tk_wave_scan_u32(mine, lane);
             const uint32_t o = run + inc - mine;
-            const bool four = c[0] == 1u && c[1] == 1u && c[2] == 1u && c[3] == 1u;
-            if (four) {
+            if (c[0] == 1u && c[1] == 1u && c[2] == 1u && c[3] == 1u && !((tk[0] | tk[1] | tk[2] | tk[3]) & TK_RES_FLAG)) {
                 *(uint4*)(out + o) = make_uint4(tk[0], tk[1], tk[2], tk[3]);  // (4-byte aligned 16-byte store)
             } else {
                 uint32_t oo = o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (c[j] == 1u) out[oo] = tk[j];
+                    if (!(tk[j] & TK_RES_FLAG)) {
+                        if (c[j]) out[oo] = tk[j];
+                    } else if (c[j] == 1u) {  // (a missed piece is never ONE token; kept for entries written that way)
+                        out[oo] = hd[j].y;
+                    } else if (hd[j].x & TKD_INLINE_BIT) {
+                        const uint32_t* tokp = data.tab[tk[j] & ~TK_RES_FLAG].tok;
+                        uint4 a = make_uint4(0, 0, 0, 0), b = a, d = a;
+                        a = *(const uint4*)(tokp + 1);  // tok[1 .. 4] (the entry is a 64-byte line; tok[0] is its fourth word)
+                        if (c[j] > 5u) b = *(const uint4*)(tokp + 5);
+                        if (c[j] > 9u) d = *(const uint4*)(tokp + 9);
+                        uint32_t* q = out + oo;
+                        q[0] = hd[j].y;
+                        q[1] = a.x;
+                        if (c[j] > 2u) q[2] = a.y;
+                        if (c[j] > 3u) q[3] = a.z;
+                        if (c[j] > 4u) q[4] = a.w;
+                        if (c[j] > 5u) {
+                            q[5] = b.x;
+                            if (c[j] > 6u) q[6] = b.y;
+                            if (c[j] > 7u) q[7] = b.z;
+                            if (c[j] > 8u) q[8] = b.w;
+                            if (c[j] > 9u) {
+                                q[9] = d.x;
+                                if (c[j] > 10u) q[10] = d.y;
+                                if (c[j] > 11u) q[11] = d.z;
+                                if (c[j] > 12u) q[12] = d.w;
+                            }
+                        }
+                    }  // (else: tokens in the staging area, below)
                     oo += c[j];
                 }
             }
-            // multi-token pieces of this chunk -> a list in LDS, then eight lanes per piece copy its tokens
-            const uint32_t nmul = (c[0] > 1u) + (c[1] > 1u) + (c[2] > 1u) + (c[3] > 1u);
-            const uint32_t minc = tk_wave_scan_u32(nmul, lane);
-            const uint32_t ntot = __shfl(minc, 63, 64);
-            if (ntot) {
-                uint32_t at = minc - nmul, oj = o;
+            // pieces whose tokens are in the staging area -> a list in LDS, then 32 lanes per piece copy them
+            uint32_t nst = 0;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) nst += ((tk[j] & TK_RES_FLAG) && c[j] > 1u && !(hd[j].x & TKD_INLINE_BIT)) ? 1u : 0u;
+            if (__ballot(nst != 0u)) {
+                const uint32_t sinc = tk_wave_scan_u32(nst, lane);
+                const uint32_t ntot = __shfl(sinc, 63, 64);
+                uint32_t at = sinc - nst, oj = o;
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (c[j] > 1u) {
-                        mlist[at * 3] = tk[j];
+                    if ((tk[j] & TK_RES_FLAG) && c[j] > 1u && !(hd[j].x & TKD_INLINE_BIT)) {
+                        mlist[at * 3] = hd[j].y;
                         mlist[at * 3 + 1] = c[j];
                         mlist[at * 3 + 2] = oj;
                         ++at;
@@ -2488,18 +2522,18 @@ __global__ __launch_bounds__(256) void tk_k_back(uint64_t ntiles, const uint32_t
                     oj += c[j];
                 }
                 __builtin_amdgcn_wave_barrier();
-                for (uint32_t e0 = 0; e0 < ntot; e0 += 8) {
-                    const uint32_t e = e0 + (lane >> 3);
+                for (uint32_t e0 = 0; e0 < ntot; e0 += 2) {
+                    const uint32_t e = e0 + (uint32_t)(lane >> 5);
                     if (e < ntot) {
                         const uint32_t src = mlist[e * 3], cc = mlist[e * 3 + 1], dst = mlist[e * 3 + 2];
                         if (cc < TK_BIGCOPY) {
-                            for (uint32_t i = lane & 7; i < cc; i += 8) out[dst + i] = staging[src + i];
-                        } else if ((lane & 7) == 0) {  // thousands of tokens of one piece: copied by tk_k_bigcopy with the whole device
-                            const uint32_t at = atomicAdd(&big[0], 1u);
-                            if (at < TK_BIGCOPY_CAP) {
-                                big[1 + 3 * at] = src;
-                                big[2 + 3 * at] = dst;
-                                big[3 + 3 * at] = cc;
+                            for (uint32_t i = lane & 31; i < cc; i += 32) out[dst + i] = staging[src + i];
+                        } else if ((lane & 31) == 0) {  // thousands of tokens of one piece: copied by tk_k_bigcopy with the whole device
+                            const uint32_t bat = atomicAdd(&big[0], 1u);
+                            if (bat < TK_BIGCOPY_CAP) {
+                                big[1 + 3 * bat] = src;
+                                big[2 + 3 * bat] = dst;
+                                big[3 + 3 * bat] = cc;
                             } else {
                                 for (uint32_t i = 0; i < cc; ++i) out[dst + i] = staging[src + i];
                             }
@@ -2508,12 +2542,12 @@ __global__ __launch_bounds__(256) void tk_k_back(uint64_t ntiles, const uint32_t
                 }
                 __builtin_amdgcn_wave_barrier();
             }
-            run += __shfl(inc, 63, 64);
+            run += (uint32_t)__shfl((int)inc, 63, 64);
         }
     }
 }
 
-// the token runs of very long pieces (big[0] entries {staging position, output position, count} recorded by tk_k_back): every entry is
+// the token runs of very long pieces (big[0] entries {staging position, output position, count} recorded by tk_k_place): every entry is
 // copied by the whole grid
 __global__ __launch_bounds__(256) void tk_k_bigcopy(const uint32_t* __restrict__ big, const uint32_t* __restrict__ staging, uint32_t* __restrict__ out_all,
                                                     const unsigned long long* __restrict__ tok_base) {
@@ -2525,27 +2559,13 @@ __global__ __launch_bounds__(256) void tk_k_bigcopy(const uint32_t* __restrict__
     }
 }
 
-__global__ __launch_bounds__(1024) void tk_k_sum_pieces(const uint32_t* __restrict__ wave_pieces, uint32_t n, unsigned long long* __restrict__ out) {
-    __shared__ unsigned long long sh[16];
-    unsigned long long v = 0;
-    for (uint32_t i = threadIdx.x; i < n; i += 1024) v += wave_pieces[i];
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned long long t = 0;
-        for (int w = 0; w < 16; ++w) t += sh[w];
-        out[0] = t;
-    }
-}
-
 // tok_off[d] = tokens before the piece at which document d starts (one wavefront per document).  The piece is found in the piece-start
-// bitmap of the document's tile (a document start is a hard piece start); its token offset is the tile's base plus the counts of the
-// tile's pieces before it -- single tokens count one, the others are read from rflag in order.
+// bitmap of the document's tile (a document start is a hard piece start); its token offset is the tile's place (tile_tb) plus what
+// tk_k_count_tiles has left for the row of 256 pieces it lies in plus the counts of the row's pieces before it -- single tokens count
+// one, the others are read from their entries.  (Needs nothing of tk_k_place: the two run side by side.)
 __global__ __launch_bounds__(256) void tk_k_docoff(uint64_t n_docs, const uint64_t* __restrict__ doc_off, uint64_t chunk_base, uint64_t n,
                                                     const uint32_t* __restrict__ starts, const uint32_t* __restrict__ tile_tb,
-                                                    const uint32_t* __restrict__ res, const uint2* __restrict__ rflag, const uint2* __restrict__ row_base,
+                                                    const uint32_t* __restrict__ res, TkMiss data, const uint32_t* __restrict__ row_rel,
                                                     const uint64_t* __restrict__ total, const unsigned long long* __restrict__ tok_base, uint64_t* __restrict__ tok_off) {
     const uint64_t tok_base_global = tok_base[0];  // tokens of the chunks before this one
     const int lane = threadIdx.x & 63;
@@ -2556,33 +2576,29 @@ __global__ __launch_bounds__(256) void tk_k_docoff(uint64_t n_docs, const uint64
         if (pos >= n) {
             v = total[0];  // empty documents at the end of the chunk, and the closing offset
         } else {
-            const uint32_t t = (uint32_t)(pos / TK_TILE), in_tile = (uint32_t)(pos - (uint64_t)t * TK_TILE);
+            const uint32_t t = row_rel ? (uint32_t)(pos / TK_TILE) : 0u, in_tile = (uint32_t)(pos - (uint64_t)t * TK_TILE);  // (no rows: one piece)
             // pieces of the tile that start before pos
             uint32_t kp = 0;
-            const uint32_t* sw = starts + (uint64_t)t * (TK_TILE / 32);
-            for (uint32_t w = lane; w * 32 < in_tile; w += 64) {
-                const uint32_t bits = sw[w], rem = in_tile - w * 32;
-                kp += (uint32_t)__popc(rem >= 32u ? bits : (bits & ((1u << rem) - 1u)));
+            if (row_rel) {
+                const uint32_t* sw = starts + (uint64_t)t * (TK_TILE / 32);
+                for (uint32_t w = lane; w * 32 < in_tile; w += 64) {
+                    const uint32_t bits = sw[w], rem = in_tile - w * 32;
+                    kp += (uint32_t)__popc(rem >= 32u ? bits : (bits & ((1u << rem) - 1u)));
+                }
+                kp = tk_wave_sum_u32(kp);
             }
-            kp = tk_wave_sum_u32(kp);
-            const uint32_t rb = t * TKF_CAP, mb = t * TKF_MISS_CAP;
-            // the back kernel has left the token offset and the rflag position of every row of 256 pieces: count on from the row of kp
+            const uint32_t rb = t * TKF_CAP;
             uint64_t row_run = tile_tb[t];
-            uint32_t sum = 0, fbase = 0, kstart = 0;
-            if (row_base && kp >= 256u) {
-                const uint2 rbv = row_base[(uint64_t)t * (TKF_CAP / 256) + (kp >> 8)];
-                row_run = rbv.x;
-                fbase = rbv.y;
+            uint32_t sum = 0, kstart = 0;
+            if (row_rel && kp >= 256u) {
+                row_run += row_rel[(uint64_t)t * (TKF_CAP / 256) + (kp >> 8)];
                 kstart = kp & ~255u;
             }
             for (uint32_t k0 = kstart; k0 < kp; k0 += 64) {
                 const uint32_t k = k0 + lane;
                 const uint32_t rv = k < kp ? res[rb + k] : 0u;
-                const bool flagged = k < kp && (rv & TK_RES_FLAG);
-                const uint64_t fm = __ballot(flagged);
                 uint32_t c = (k < kp && rv != TK_RES_GAP) ? 1u : 0u;
-                if (flagged) c = rflag[mb + fbase + (uint32_t)__popcll(fm & ((1ull << lane) - 1ull))].x;
-                fbase += (uint32_t)__popcll(fm);
+                if (k < kp && (rv & TK_RES_FLAG)) c = TKD_COUNT(data.result(rv & ~TK_RES_FLAG).x);
                 sum += c;
             }
             v = row_run + tk_wave_sum_u32(sum);
@@ -2601,17 +2617,15 @@ __global__ void tk_k_advance(unsigned long long* __restrict__ tok_bases, uint32_
 __global__ void tk_k_single_front(TkTables T, const uint8_t* __restrict__ text, uint32_t n, TkFrontOut out, int no_lookup) {
     if (blockIdx.x || threadIdx.x) return;
     out.tile_np[0] = 1;
-    uint32_t nm = 0;
     const uint32_t r = (no_lookup && n > 1u) ? TK_RANK_MAX : tk_lookup_text_piece(T, text, 0, n);
     if (r != TK_RANK_MAX) {
         out.res[0] = r;
-    } else {
-        out.res[0] = TK_RES_FLAG | 0u;
-        out.miss[0] = make_uint2(0u, n);
-        if (n > TK_GLANE_MAX) tk_append_tree(out.listC, out.counters, 0, 0, n);
-        nm = 1;
+    } else {  // the one overflow entry of the chunk
+        out.res[0] = TK_RES_FLAG | out.data.ovf_base;
+        *(uint4*)&out.data.ovf[0].start = make_uint4(0u, n, 0u, 0u);
+        out.counters[TK_CNT_OVF] = 1;
+        if (n > TK_GLANE_MAX) tk_append_tree(out.listC, out.counters, out.data.ovf_base, 0, n);
     }
-    out.tile_nmiss[0] = nm;
 }
 
 // ------------------------------------------------------------------------------------------

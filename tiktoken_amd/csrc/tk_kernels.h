@@ -27,18 +27,21 @@ __device__ __forceinline__ int tk_bin_of(uint32_t len) {
     for (int i = 0; i < TK_NBIN - 1; ++i) b += len > tk_bin_hi(i);
     return b;
 }
-struct TkBins {
-    uint32_t off[TK_NBIN];  // start of each bin's list inside the pool
-};
 
 // counters (device uint32 array)
-enum { TK_CNT_B = 0, TK_CNT_C = 1, TK_CNT_CBYTES = 2, TK_CNT_CLEVELS = 3, TK_CNT_DUP = 4, TK_CNT_COLL = 5, TK_CNT_ERR = 6, TK_CNT_DEFER = 7, TK_CNT_BIN0 = 8, TK_CNT_RXPOS = 8 + TK_NBIN + 1, TK_CNT_HOT_PROBE = 8 + TK_NBIN + 2, TK_CNT_HOT_HIT = 8 + TK_NBIN + 3, TK_CNT_DEFER2 = 8 + TK_NBIN + 4, TK_CNT_N = 8 + TK_NBIN + 5 };
+enum {
+    TK_CNT_B = 0, TK_CNT_C = 1, TK_CNT_CBYTES = 2, TK_CNT_CLEVELS = 3, TK_CNT_DUP = 4, TK_CNT_COLL = 5, TK_CNT_ERR = 6, TK_CNT_DEFER = 7,
+    TK_CNT_BIN0 = 8,                      // [TK_NBIN] pieces per length bin (tk_k_binfill)
+    TK_CNT_RXPOS = 8 + TK_NBIN + 1, TK_CNT_HOT_PROBE = 8 + TK_NBIN + 2, TK_CNT_HOT_HIT = 8 + TK_NBIN + 3, TK_CNT_DEFER2 = 8 + TK_NBIN + 4,
+    TK_CNT_OVF = 8 + TK_NBIN + 5,         // overflow entries of the miss data asked for (may exceed the capacity: tk_fused.h, TkMissData)
+    TK_CNT_BOFF0 = 8 + TK_NBIN + 6,       // [TK_NBIN] start of each bin's list in listB (tk_k_binfill)
+    TK_CNT_N = 8 + 2 * TK_NBIN + 6
+};
 // (TK_CNT_DEFER2: deferred tiles that gave up their walk -- tk_fused.h, TKF_WALK_BUDGET;
 //  TK_CNT_ERR: bits 1, 2 scanner lists of the front kernel; bits 4, 8 the generic pat_str engine -- tk_regex_split.h; TK_CNT_RXPOS: ~position of its first error)
 
 #define TK_MT_BITS 22   // most slots of the in-call miss table (tk_fused.h); sized by the chunk
 #define TK_MT_PROBES 8
-#define TK_DUP_FLAG 0x80000000u  // cnt[pid] = TK_DUP_FLAG | miss-table slot: a duplicate, resolved by tk_k_tile_finish
 #define TK_MAX_LEVELS 6          // 64-ary min-tree levels of the long-piece merge
 
 // ------------------------------------------------------------------------------------------
@@ -107,7 +110,7 @@ __device__ __forceinline__ uint32_t tk_wave_append(bool want, uint32_t* counter,
 // Start of a chunk: every buffer that has to be zero (or all ones) before the kernels run, in ONE launch (a hipMemsetAsync per buffer
 // costs the host 30-60 us each, and with pipelined chunks the host's time per chunk is what bounds the pipeline).
 // ------------------------------------------------------------------------------------------
-#define TK_CLEAR_MAX 16
+#define TK_CLEAR_MAX 20
 struct TkClearArgs {
     uint4* p[TK_CLEAR_MAX];
     uint64_t n16[TK_CLEAR_MAX];  // 16-byte units

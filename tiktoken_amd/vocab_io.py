@@ -26,10 +26,13 @@ class RankTable(dict):
     -- what `tk_create` takes, so building an Encoding never walks 200 000 Python objects -- and fills the dict itself from them on
     first use (a fifth of a second for the o200k file; an `Encoding` needs only the count and the largest rank).  Any mutation drops
     the arrays, so a CoreBPE built from the table always sees the dict's current contents.  C code that reads a dict's storage
-    directly (`PyDict_Next`) must be handed `table.materialize()`; everything at Python level fills the dict by itself."""
+    directly (`PyDict_Next`, PyO3's HashMap extraction) sees an EMPTY dict until the table is filled, so the lazy form is an internal
+    fast path: `parse_tiktoken_bpe` / `load_tiktoken_bpe` return a filled table unless asked with `lazy=True` (the constructors under
+    tiktoken_ext do; `Encoding._mergeable_ranks` fills it before handing it out)."""
 
     packed = None  # (blob uint8[], off uint64[n+1], ranks uint32[n]) while they describe the dict exactly
     _pending = None  # the same arrays until the dict has been filled from them
+    _distinct = False  # tk_create has taken the arrays: no token is listed twice (the count is known without the dict)
 
     @classmethod
     def from_packed(cls, blob: bytes, off: np.ndarray, ids: np.ndarray) -> "RankTable":
@@ -54,8 +57,15 @@ class RankTable(dict):
             return int(self.packed[2].max()) if len(self.packed[2]) else 0
         return max(self.values())
 
+    def __len__(self):
+        if self._pending is not None and self._distinct:
+            return len(self._pending[2])
+        return dict.__len__(self.materialize())
+
     def _reading(name):  # noqa: N805
         def method(self, *a, **k):
+            # (dict's own comparison and union read the OTHER operand's storage at C level: fill that one too)
+            a = tuple(x.materialize() if isinstance(x, RankTable) else x for x in a)
             return getattr(dict, name)(self.materialize(), *a, **k)
 
         method.__name__ = name
@@ -70,7 +80,7 @@ class RankTable(dict):
         method.__name__ = name
         return method
 
-    for _n in ("__len__", "__getitem__", "__contains__", "__iter__", "__reversed__", "__eq__", "__ne__", "__repr__", "__or__", "__ror__", "keys", "values", "items", "get",
+    for _n in ("__getitem__", "__contains__", "__iter__", "__reversed__", "__eq__", "__ne__", "__repr__", "__or__", "__ror__", "keys", "values", "items", "get",
                "copy", "__sizeof__"):
         locals()[_n] = _reading(_n)
     for _n in ("__setitem__", "__delitem__", "pop", "popitem", "clear", "update", "setdefault", "__ior__"):
@@ -82,7 +92,8 @@ class RankTable(dict):
         return (dict, (dict(self.materialize()),))
 
 
-def parse_tiktoken_bpe(contents: bytes, source: str = "<bytes>") -> RankTable:
+def parse_tiktoken_bpe(contents: bytes, source: str = "<bytes>", *, lazy: bool = False) -> RankTable:
+    """`lazy=True`: the dict is filled on first use at Python level (RankTable) -- for tables that go straight into an Encoding."""
     L = _lib.lib()
     buf = np.frombuffer(contents, np.uint8) if contents else np.zeros(1, np.uint8)
     pb, po, pi, n = ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_void_p(), ctypes.c_uint64()
@@ -97,7 +108,8 @@ def parse_tiktoken_bpe(contents: bytes, source: str = "<bytes>") -> RankTable:
     finally:
         for p in (pb, po, pi):
             L.tk_free(p)
-    return RankTable.from_packed(blob, off, ids)
+    table = RankTable.from_packed(blob, off, ids)
+    return table if lazy else table.materialize()
 
 
 def dump_tiktoken_bpe(bpe_ranks: dict[bytes, int], tiktoken_bpe_file: str) -> None:
@@ -147,11 +159,11 @@ def fetch(location: str, expected_hash: str | None = None) -> bytes:
     return data
 
 
-def load_tiktoken_bpe(tiktoken_bpe_file: str, expected_hash: str | None = None) -> RankTable:
+def load_tiktoken_bpe(tiktoken_bpe_file: str, expected_hash: str | None = None, *, lazy: bool = False) -> RankTable:
     contents = fetch(tiktoken_bpe_file, expected_hash)
     if tiktoken_bpe_file.endswith(".gz"):
         contents = gzip.decompress(contents)
-    return parse_tiktoken_bpe(contents, tiktoken_bpe_file)
+    return parse_tiktoken_bpe(contents, tiktoken_bpe_file, lazy=lazy)
 
 
 def data_gym_byte_order() -> list[int]:

@@ -17,7 +17,7 @@ _VOCAB_DIR = os.path.join(os.path.dirname(os.path.abspath(tiktoken_amd.__file__)
 def _ranks(name):
     path = os.path.join(_VOCAB_DIR, name + ".tiktoken.gz")
     with open(path, "rb") as f:
-        return parse_tiktoken_bpe(gzip.decompress(f.read()), path)
+        return parse_tiktoken_bpe(gzip.decompress(f.read()), path, lazy=True)  # (goes straight into an Encoding)
 
 
 def gpt2_shaped():

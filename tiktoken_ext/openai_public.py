@@ -42,7 +42,7 @@ _TIKTOKEN_FILES = {
 
 def _ranks(key):
     url, sha256 = _TIKTOKEN_FILES[key]
-    return load_tiktoken_bpe(url, expected_hash=sha256)
+    return load_tiktoken_bpe(url, expected_hash=sha256, lazy=True)  # (goes straight into an Encoding)
 
 
 def gpt2():

@@ -14,7 +14,7 @@ g = h.load_golden(name)
 t = time.perf_counter(); blob, off = h.gen_corpus(0x5EED0003, 1, mib << 20, 32); print("corpus: %d MiB, %d documents, %.1f s" % (mib, len(off) - 1, time.perf_counter() - t), flush=True)
 NAMES = ["tk_k_mark_docs", "tk_k_rx_speculate", "tk_k_rx_resolve", "tk_k_rx_merge", "tk_k_front", "tk_k_front_slow", "tk_k_bincount", "tk_k_binfill",
          *[f"tk_k_merge_llane_{i}" for i in (16, 24, 32, 48, 64)], *[f"tk_k_merge_group_{i}" for i in (8, 16, 32, 64)], "tk_k_merge_rounds",
-         "tk_k_merge_rounds_wide", "tk_k_merge_long", "tk_k_dup_publish", "tk_k_tile_finish", "tk_k_back", "tk_k_docoff", "tk_k_scan_small"]
+         "tk_k_merge_rounds_wide", "tk_k_merge_long", "tk_k_place", "tk_k_docoff", "tk_k_scan_small"]
 res = {}
 for label, dbg in (("scanners", None), ("generic", "1048576")):
     if dbg: os.environ["TIKTOKEN_AMD_DEBUG"] = dbg

@@ -11,7 +11,7 @@ from tiktoken_amd import CoreBPE
 say("imports done")
 NAMES = ["tk_k_mark_docs", "tk_k_rx_speculate", "tk_k_rx_link", "tk_k_rx_resolve", "tk_k_rx_merge", "tk_k_front", "tk_k_front_slow", "tk_k_bincount", "tk_k_binfill",
          *[f"tk_k_merge_llane_{i}" for i in (16, 24, 32, 48, 64)], *[f"tk_k_merge_group_{i}" for i in (8, 16, 32, 64)], "tk_k_merge_rounds",
-         "tk_k_merge_rounds_wide", "tk_k_merge_long", "tk_k_dup_publish", "tk_k_tile_finish", "tk_k_back", "tk_k_docoff", "tk_k_count", "tk_k_emit", "tk_k_scan_small"]
+         "tk_k_merge_rounds_wide", "tk_k_merge_long", "tk_k_place", "tk_k_docoff", "tk_k_count", "tk_k_emit", "tk_k_scan_small"]
 pat = sys.argv[1] if len(sys.argv) > 1 else r"\w+|[^\w\s]+|\s+"
 vocab = h.golden_vocab("o200k_shaped")
 core = CoreBPE(vocab, {}, pat)

@@ -9,7 +9,7 @@ import numpy as np, helpers as h
 import tiktoken_amd
 
 names = sys.argv[1:] or ["o200k_shaped"]
-KERN = ["tk_k_front", "tk_k_front_slow", "tk_k_merge_rounds", "tk_k_merge_rounds_wide", "tk_k_merge_long", "tk_k_back"]
+KERN = ["tk_k_front", "tk_k_front_slow", "tk_k_merge_rounds", "tk_k_merge_rounds_wide", "tk_k_merge_long", "tk_k_place"]
 for name in names:
     enc = tiktoken_amd.get_encoding(name)
     C = h.c_oracle_for(name)
