@@ -147,6 +147,11 @@ int tk_validate_utf8(const uint8_t* utf8, uint64_t len, uint64_t* bad_pos);
 
 void tk_free(void* p);
 
+/* tk_encode_batch_device alternates between n (1 or 2; default 1) pairs of result buffers: with 2 the ids and offsets of call k stay valid
+ * while call k + 1 runs, so a consumer on another stream -- the RCCL send of a shard's ids to the root rank (tiktoken_amd/distributed.py) --
+ * overlaps the next encode without a copy of its own.  No reference counterpart (the reference returns owned Vec<u32>s, src/lib.rs:360). */
+int tk_set_output_buffers(tk_core* core, uint32_t n);
+
 /* Instrumentation for bench.py: when enabled, every kernel launch of the next encode call is
  * bracketed by HIP events on the stream it runs on; tk_get_kernel_ms returns the summed
  * duration and launch count per kernel name since the last tk_reset_kernel_ms. */

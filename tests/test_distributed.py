@@ -1,7 +1,7 @@
 """The N > 1 path on CPU: two processes, gloo backend, 127.0.0.1 rendezvous.
 
 What is exercised is the sharding and the exchange -- `partition_by_bytes`, the count all-gather and the
-single padded gather of token buffers (tiktoken_amd/distributed.py, the same functions bench.py uses with
+grouped send / recv of the token buffers at their exact lengths (and the earlier padded gather; tiktoken_amd/distributed.py, the same functions bench.py uses with
 the nccl/RCCL backend).  There is no CPU encode path in the product, so each rank's *encoder* here is the
 C oracle (tests may use it); the assertion is that the gathered result equals the oracle's encoding of
 the undivided batch, i.e. sharding + gather preserve order and content."""
@@ -56,6 +56,15 @@ def _worker(rank, world, port, q):
             q.put(bool(np.array_equal(np.concatenate(per_rank), rt)))
         else:
             assert all(g[0] is None for g in got)
+        # a rank without tokens; the padded form
+        for padded in (False, True):
+            t = torch.arange(5 if rank == 0 else 0, dtype=torch.int32) + 100 * rank
+            parts, counts = gather_tokens(t, t.numel(), rank, world, dist, torch, padded=padded)
+            assert counts == [5] + [0] * (world - 1)
+            t = torch.arange(3 + rank, dtype=torch.int32) + 100 * rank
+            parts, counts = gather_tokens(t, t.numel(), rank, world, dist, torch, padded=padded)
+            if rank == 0:
+                q.put(bool(all(np.array_equal(parts[r].numpy(), np.arange(3 + r) + 100 * r) for r in range(world))))
         dist.barrier()
     finally:
         dist.destroy_process_group()
@@ -69,7 +78,7 @@ def test_two_rank_gloo_shard_and_gather():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    ok = q.get(timeout=150) and q.get(timeout=150)  # plain and pipelined exchange
+    ok = all(q.get(timeout=150) for _ in range(4))  # plain and pipelined exchange; exact-length and padded form with uneven counts
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

@@ -93,6 +93,8 @@ def lib() -> ctypes.CDLL:
         L.tk_validate_utf8.restype = i32
         L.tk_validate_utf8.argtypes = [vp, u64, P(u64)]
         L.tk_free.argtypes = [vp]
+        L.tk_set_output_buffers.restype = i32
+        L.tk_set_output_buffers.argtypes = [vp, ctypes.c_uint32]
         L.tk_set_profiling.argtypes = [vp, i32]
         L.tk_reset_kernel_ms.argtypes = [vp]
         L.tk_get_kernel_ms.restype = i32

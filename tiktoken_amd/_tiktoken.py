@@ -452,6 +452,11 @@ class CoreBPE:
             cached = self._sorted_cache = [blob[a:b] for a, b in zip(bounds[:-1], bounds[1:])]
         return cached
 
+    def set_output_buffers(self, n: int):
+        """`encode_batch_device` alternates between n (1 or 2) pairs of result buffers: with 2 the result of a call stays valid while the
+        next call runs (tk_set_output_buffers; the several-process gather of tiktoken_amd.distributed sends from it without a copy)."""
+        _lib.raise_for(self._L.tk_set_output_buffers(self._h, int(n)))
+
     # ------------------------------------------------------------------ instrumentation
     def set_profiling(self, on: bool):
         self._L.tk_set_profiling(self._h, 1 if on else 0)

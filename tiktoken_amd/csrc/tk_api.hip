@@ -71,7 +71,7 @@ struct KernelStat {
 // Work buffers of ONE chunk in flight.
 struct WorkSet {
     Buf text_al, tile_sum, wide_ws, scan_sums, row_base, brk, docb, cand, ss, si, starts, blockcnt, pstart, res, staging, listB, listC, counters, total, g_id, g_rk,
-        g_nx, g_pv, g_lv, tile_np, tile_nt, mt_keys, mtab, movf, wbin, deferred, big, rx_spec, rx_gst, rx_lnk, rx_exit, merge_work;
+        g_nx, g_pv, g_lv, tile_np, tile_nt, mt_keys, mtab, movf, mcnt, wbin, deferred, big, rx_spec, rx_gst, rx_lnk, rx_exit, merge_work;
     hipStream_t sb = nullptr;        // the set's back stage in a multi-chunk batch: back stages of different chunks overlap each other too
                                      // (they are chains of short latency-bound kernels, ~2 ms however small the chunk)
     hipEvent_t ev_front = nullptr;   // the front kernel is done
@@ -83,7 +83,7 @@ struct WorkSet {
     uint64_t* h_total = nullptr;     // pinned [2]: tokens, pieces of the chunk
     std::vector<Buf*> all() {
         return {&text_al, &tile_sum, &wide_ws, &scan_sums, &row_base, &brk, &docb, &cand, &ss, &si, &starts, &blockcnt, &pstart, &res, &staging, &listB,
-                &listC, &counters, &total, &g_id, &g_rk, &g_nx, &g_pv, &g_lv, &tile_np, &tile_nt, &mt_keys, &mtab, &movf, &wbin, &deferred, &big, &rx_spec,
+                &listC, &counters, &total, &g_id, &g_rk, &g_nx, &g_pv, &g_lv, &tile_np, &tile_nt, &mt_keys, &mtab, &movf, &mcnt, &wbin, &deferred, &big, &rx_spec,
                 &rx_gst, &rx_lnk, &rx_exit, &merge_work};
     }
 };
@@ -102,7 +102,7 @@ struct ChunkJob {
 };
 
 // the chunk's entries of distinct missed pieces, as the kernels take them
-static TkMiss miss_of(WorkSet& w, const ChunkJob& job) { return TkMiss{w.mtab.as<TkMissTab>(), w.movf.as<TkMissOvf>(), job.ovf_base}; }
+static TkMiss miss_of(WorkSet& w, const ChunkJob& job) { return TkMiss{w.mtab.as<TkMissTab>(), w.movf.as<TkMissOvf>(), job.ovf_base, w.mcnt.as<uint8_t>()}; }
 
 struct tk_core {
     int device = 0;
@@ -128,6 +128,8 @@ struct tk_core {
     // workspace: per chunk in flight, and what a whole call shares
     WorkSet ws[TK_NSET];
     Buf text, doc_off, out_tokens, out_tok_off, allowed, tok_bases;  // tok_bases[k]: tokens of the chunks before chunk k (on the device)
+    Buf out_tokens_alt, out_tok_off_alt;  // the other pair of result buffers of tk_encode_batch_device (tk_set_output_buffers(core, 2))
+    uint32_t out_bufs = 1;
     bool ovf_full = false;  // a batch has asked for more overflow entries of the miss data than the default: room for the worst case from then on
     uint64_t chunk_bytes = 1ull << 30;  // one chunk per GiB: smaller chunks pipeline (stage_front / stage_back) but pay the merge kernels' fixed latency per chunk
     int dbg = 0;
@@ -462,7 +464,7 @@ extern "C" void tk_destroy(tk_core* c) {
     for (Buf* b : {&c->t_rx_ins, &c->t_rx_sets, &c->t_rx_ranges, &c->t_rx_first, &c->t_rx_s1, &c->t_rx_s2, &c->t_rx_dtrans, &c->t_rx_dascii, &c->t_rx_ds1, &c->t_rx_ds2}) release(*b);
     for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_dec, &c->d_tok, &c->d_lens, &c->d_bsum, &c->d_tboff, &c->d_bytes, &c->d_boff, &c->t_piece,
                    &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2, &c->t_byte_rank, &c->t_hot, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off,
-                   &c->out_tokens, &c->out_tok_off, &c->allowed, &c->tok_bases})
+                   &c->out_tokens, &c->out_tok_off, &c->out_tokens_alt, &c->out_tok_off_alt, &c->allowed, &c->tok_bases})
         release(*b);
     for (WorkSet& w : c->ws) {
         for (Buf* b : w.all()) release(*b);
@@ -698,6 +700,7 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
     }
     const uint64_t n_entries = (uint64_t)job.ovf_base + job.ovf_cap;
     TRY(ensure(w.mtab, (uint64_t)job.ovf_base * sizeof(TkMissTab)));
+    TRY(ensure(w.mcnt, (uint64_t)job.ovf_base + 16));
     TRY(ensure(w.movf, ((uint64_t)job.ovf_cap + 1) * sizeof(TkMissOvf)));
     TRY(ensure(w.listB, (n_entries + 64) * 4));
     TRY(ensure(w.listC, (n / 1025 + 64) * 20));
@@ -946,20 +949,6 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
     if (prev_tot) HIPCHK(hipStreamWaitEvent(s, prev_tot, 0));
     hipLaunchKernelGGL(tk_k_advance, dim3(1), dim3(64), 0, s, c->tok_bases.as<unsigned long long>(), job.index, w.total.as<uint64_t>());
     HIPCHK(hipEventRecord(w.ev_tot, s));
-    // the document offsets need the tile counts, not the placed tokens: on a side stream beside tk_k_place (both wait for memory)
-    const bool side = job.d_tok_off && n > (1u << 20) && !c->profiling;
-    hipStream_t sd = side ? c->aux[0] : s;
-    if (side) {
-        HIPCHK(hipEventRecord(w.ev_fork, s));
-        HIPCHK(hipStreamWaitEvent(sd, w.ev_fork, 0));
-    }
-    if (job.d_tok_off) {
-        TRY(timed(c, sd, "tk_k_docoff", [&] {
-            hipLaunchKernelGGL(tk_k_docoff, dim3(grid_for(job.n_docs + 1, 4, 8192)), dim3(256), 0, sd, job.n_docs, job.d_doc_off, job.base, n, w.starts.as<uint32_t>(), tile_nt, res, data,
-                               (n > 0 && !job.single_piece) ? w.row_base.as<uint32_t>() : (const uint32_t*)nullptr, w.total.as<uint64_t>(), tok_base, job.d_tok_off);
-        }));
-    }
-    if (side) HIPCHK(hipEventRecord(w.ev_join[0], sd));
     if (n > 0) {
         TRY(timed(c, s, "tk_k_place", [&] {
             hipLaunchKernelGGL(tk_k_place, dim3(grid_for(ntiles, 4, 4096)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, data, stg, d_out, tok_base, w.big.as<uint32_t>());
@@ -967,7 +956,14 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
     }
     if (n > TK_BIGCOPY)  // (a token run of TK_BIGCOPY tokens needs at least as many bytes)
         hipLaunchKernelGGL(tk_k_bigcopy, dim3(1024), dim3(256), 0, s, w.big.as<uint32_t>(), stg, d_out, tok_base);
-    if (side) HIPCHK(hipStreamWaitEvent(s, w.ev_join[0], 0));
+    // (the document offsets need the tile counts only, but beside tk_k_place on a second stream the two take as long as one after the
+    // other: both are bound by the rate of random accesses -- measured in round 4)
+    if (job.d_tok_off) {
+        TRY(timed(c, s, "tk_k_docoff", [&] {
+            hipLaunchKernelGGL(tk_k_docoff, dim3(grid_for(job.n_docs + 1, 4, 8192)), dim3(256), 0, s, job.n_docs, job.d_doc_off, job.base, n, w.starts.as<uint32_t>(), tile_nt, res, data,
+                               (n > 0 && !job.single_piece) ? w.row_base.as<uint32_t>() : (const uint32_t*)nullptr, w.total.as<uint64_t>(), tok_base, job.d_tok_off);
+        }));
+    }
     HIPCHK(hipMemcpyAsync(w.h_total, w.total.p, 16, hipMemcpyDeviceToHost, s));
     HIPCHK(hipMemcpyAsync(w.h_counters + TK_CNT_N, counters, TK_CNT_N * 4, hipMemcpyDeviceToHost, s));
     HIPCHK(hipEventRecord(w.ev_done, s));
@@ -1166,6 +1162,10 @@ extern "C" int tk_encode_batch_device(tk_core* c, const void* d_utf8, uint64_t n
     bool any = false;
     if (use_special) TRY(prepare_allowed(c, s, allowed_ids, n_allowed, &any));
     uint64_t total = 0;
+    if (c->out_bufs == 2) {  // (the previous call's result stays where it is: a consumer on another stream may still be reading it)
+        std::swap(c->out_tokens, c->out_tokens_alt);
+        std::swap(c->out_tok_off, c->out_tok_off_alt);
+    }
     TRY(encode_device_locked(c, s, (const uint8_t*)d_utf8, n_bytes, (const uint64_t*)d_doc_off, h_doc_off, n_docs, use_special && any, &total));
     if (d_tokens_out) *d_tokens_out = c->out_tokens.as<uint32_t>();
     if (d_tok_off_out) *d_tok_off_out = c->out_tok_off.as<uint64_t>();
@@ -2030,6 +2030,14 @@ extern "C" int tk_validate_utf8(const uint8_t* s, uint64_t n, uint64_t* bad_pos)
             if ((s[i + k] & 0xC0) != 0x80) return bad(i);
         i += need + 1;
     }
+    return TK_OK;
+}
+
+extern "C" int tk_set_output_buffers(tk_core* c, uint32_t n) {
+    if (!c) return fail(TK_VALUE_ERROR, "core is null");
+    if (n != 1 && n != 2) return fail(TK_VALUE_ERROR, "tk_set_output_buffers: 1 or 2");
+    std::lock_guard<std::mutex> lk(c->mu);
+    c->out_bufs = n;
     return TK_OK;
 }
 

@@ -82,14 +82,29 @@ struct TkMiss {
     TkMissTab* tab;     // [ovf_base] the table's entries (slot index = entry index; written by whoever claims the slot: never cleared)
     TkMissOvf* ovf;     // [..] the overflow entries, index i - ovf_base
     uint32_t ovf_base;  // slots of the table (0 without one)
+    uint8_t* cnt8;      // [ovf_base] token count of a table slot's piece once more, one BYTE per slot (255: look at the entry): the counting
+                        // pass of the back end needs nothing else of an entry, and four million of these stay in the L2
     __device__ __forceinline__ uint32_t* head(uint32_t i) const { return i < ovf_base ? &tab[i].start : &ovf[i - ovf_base].start; }
     __device__ __forceinline__ uint2 piece(uint32_t i) const { return *(const uint2*)head(i); }                 // {start, len}
     __device__ __forceinline__ uint2 result(uint32_t i) const { return *(const uint2*)(head(i) + 2); }          // {res_cnt, tok[0]}
-    __device__ __forceinline__ void put(uint32_t i, uint32_t cnt, uint32_t tok) const { *(uint2*)(head(i) + 2) = make_uint2(cnt, tok); }
+    __device__ __forceinline__ void put(uint32_t i, uint32_t cnt, uint32_t tok) const {
+        *(uint2*)(head(i) + 2) = make_uint2(cnt, tok);
+        if (i < ovf_base) cnt8[i] = (uint8_t)(TKD_COUNT(cnt) < 255u ? TKD_COUNT(cnt) : 255u);
+    }
     // where the merge kernels write a piece's `total` tokens: into the entry when they fit (then put(i, total | TKD_INLINE_BIT, ..) is
     // only the count word: put_count), else to the staging area at the piece's text position s
     __device__ __forceinline__ bool fits(uint32_t i, uint32_t total) const { return i < ovf_base && total <= (uint32_t)TKD_INLINE; }
-    __device__ __forceinline__ void put_count(uint32_t i, uint32_t w) const { head(i)[2] = w; }
+    __device__ __forceinline__ void put_count(uint32_t i, uint32_t w) const {
+        head(i)[2] = w;
+        if (i < ovf_base) cnt8[i] = (uint8_t)(TKD_COUNT(w) < 255u ? TKD_COUNT(w) : 255u);
+    }
+    __device__ __forceinline__ uint32_t count(uint32_t i) const {  // token count of entry i's piece
+        if (i < ovf_base) {
+            const uint32_t c = cnt8[i];
+            if (c != 255u) return c;
+        }
+        return TKD_COUNT(head(i)[2]);
+    }
 };
 struct TkFrontOut {
     uint32_t* starts;     // piece-start bitmap (n/32 words; each tile stores its own 120 words)
@@ -2400,27 +2415,17 @@ __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds_wide(TkTables T
 // front stage): its workgroups that are not resident yet never get the registers the waiting ones hold.
 // ------------------------------------------------------------------------------------------
 
-// result words of the lane's four pieces of one row -> per piece: its token count c[] and, for a missed piece, the head of its entry
-// (hd[j] = {res_cnt word, tok[0]}), all loads in flight together
-__device__ __forceinline__ void tk_row_counts(const uint32_t* __restrict__ res, const TkMiss& data, uint32_t rb, uint32_t np, uint32_t k, uint32_t tk[4], uint32_t c[4], uint2 hd[4]) {
-    uint4 t4 = make_uint4(0, 0, 0, 0);
-    if (k < np) t4 = *(const uint4*)(res + rb + k);  // (runs start 16-byte aligned, and a run's storage extends to the next multiple of four)
-    tk[0] = t4.x; tk[1] = t4.y; tk[2] = t4.z; tk[3] = t4.w;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-        const bool live = k + j < np;
-        c[j] = (live && tk[j] != TK_RES_GAP) ? 1u : 0u;
-        hd[j] = make_uint2(0u, 0u);
-        if (live && (tk[j] & TK_RES_FLAG)) hd[j] = data.result(tk[j] & ~TK_RES_FLAG);
-        else tk[j] &= ~TK_RES_FLAG;  // (a dead word is not a reference)
-    }
-#pragma unroll
-    for (int j = 0; j < 4; ++j)
-        if (tk[j] & TK_RES_FLAG) c[j] = TKD_COUNT(hd[j].x);
-}
+// rows of 256 pieces a wavefront has in flight together (a tile of web text has 580 pieces)
+#ifndef TKP_ROWS_COUNT
+#define TKP_ROWS_COUNT 3
+#endif
+#ifndef TKP_ROWS_PLACE
+#define TKP_ROWS_PLACE 3
+#endif
 
 // tile_nt[t] <- tokens of tile t; row_rel[t * (TKF_CAP / 256) + r] <- tokens of the tile's rows before row r (for tk_k_docoff);
-// total[1] += pieces of the chunk.  One wavefront per tile at a time.
+// total[1] += pieces of the chunk.  One wavefront per tile at a time; the loads of TKP_ROWS_COUNT rows are in flight together (the kernel waits
+// for memory: the result words stream from HBM, a missed piece's count is one byte of an L2-resident array).
 __global__ __launch_bounds__(256) void tk_k_count_tiles(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ res, TkMiss data,
                                                         uint32_t* __restrict__ tile_nt, uint32_t* __restrict__ row_rel, unsigned long long* __restrict__ total) {
     const int lane = threadIdx.x & 63;
@@ -2430,21 +2435,43 @@ __global__ __launch_bounds__(256) void tk_k_count_tiles(uint64_t ntiles, const u
         const uint32_t np = tile_np[t], rb = (uint32_t)t * TKF_CAP;
         pieces += np;
         uint32_t run = 0;
-        for (uint32_t k0 = 0; k0 < np; k0 += 256) {
-            uint32_t tk[4], c[4];
-            uint2 hd[4];
-            tk_row_counts(res, data, rb, np, k0 + (uint32_t)lane * 4u, tk, c, hd);
-            if (lane == 0) row_rel[t * (TKF_CAP / 256) + (k0 >> 8)] = run;
-            run += tk_wave_sum_u32(c[0] + c[1] + c[2] + c[3]);
+        for (uint32_t k0 = 0; k0 < np; k0 += 256u * TKP_ROWS_COUNT) {
+            uint4 t4[TKP_ROWS_COUNT];
+#pragma unroll
+            for (int r = 0; r < TKP_ROWS_COUNT; ++r) {
+                const uint32_t k = k0 + (uint32_t)r * 256u + (uint32_t)lane * 4u;
+                t4[r] = make_uint4(TK_RES_GAP, TK_RES_GAP, TK_RES_GAP, TK_RES_GAP);
+                if (k < np) t4[r] = *(const uint4*)(res + rb + k);  // (runs start 16-byte aligned, and a run's storage extends to the next multiple of four)
+            }
+            uint32_t c[TKP_ROWS_COUNT][4];
+#pragma unroll
+            for (int r = 0; r < TKP_ROWS_COUNT; ++r) {
+                const uint32_t k = k0 + (uint32_t)r * 256u + (uint32_t)lane * 4u;
+                const uint32_t w[4] = {t4[r].x, t4[r].y, t4[r].z, t4[r].w};
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool live = k + j < np;
+                    c[r][j] = (live && w[j] != TK_RES_GAP) ? 1u : 0u;
+                    if (live && (w[j] & TK_RES_FLAG)) c[r][j] = data.count(w[j] & ~TK_RES_FLAG);
+                }
+            }
+#pragma unroll
+            for (int r = 0; r < TKP_ROWS_COUNT; ++r) {
+                if (k0 + (uint32_t)r * 256u < np) {
+                    if (lane == 0) row_rel[t * (TKF_CAP / 256) + (k0 >> 8) + r] = run;
+                    run += tk_wave_sum_u32(c[r][0] + c[r][1] + c[r][2] + c[r][3]);
+                }
+            }
         }
         if (lane == 0) tile_nt[t] = run;
     }
     if (lane == 0 && pieces) atomicAdd(&total[1], pieces);  // (one fire-and-forget atomic per wavefront)
 }
 
-// tile_tb = exclusive scan of tile_nt.  One wavefront per tile at a time, row by row: single tokens go out as one 16-byte store per
-// lane; a missed piece's tokens come from its entry (three 16-byte loads at most: the line is in the cache, the count came from it);
-// what does not fit an entry -- more than TKD_INLINE tokens, overflow entries -- is copied from the staging area by 32 lanes per piece.
+// tile_tb = exclusive scan of tile_nt.  One wavefront per tile at a time, TKP_ROWS_PLACE rows in flight: the result words, then the heads of
+// the missed pieces' entries {count, first token}, then row by row: single tokens go out as one 16-byte store per lane; a missed
+// piece's other tokens come from its entry (three 16-byte loads at most: the line is in the cache, the head came from it); what does
+// not fit an entry -- more than TKD_INLINE tokens, overflow entries -- is copied from the staging area by 32 lanes per piece.
 __global__ __launch_bounds__(256) void tk_k_place(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_tb,
                                                   const uint32_t* __restrict__ res, TkMiss data, const uint32_t* __restrict__ staging, uint32_t* __restrict__ out_all,
                                                   const unsigned long long* __restrict__ tok_base, uint32_t* __restrict__ big) {
@@ -2458,91 +2485,115 @@ __global__ __launch_bounds__(256) void tk_k_place(uint64_t ntiles, const uint32_
     for (uint64_t t = wave; t < ntiles; t += nwaves) {
         const uint32_t np = tile_np[t], rb = (uint32_t)t * TKF_CAP;
         uint32_t run = tile_tb[t];  // (token offsets within a chunk fit 32 bits: a chunk is less than 4 GiB of text)
-        for (uint32_t k0 = 0; k0 < np; k0 += 256) {
-            uint32_t tk[4], c[4];
-            uint2 hd[4];
-            tk_row_counts(res, data, rb, np, k0 + (uint32_t)lane * 4u, tk, c, hd);
-            const uint32_t mine = c[0] + c[1] + c[2] + c[3];
-            const uint32_t inc = tk_wave_scan_u32(mine, lane);
-            const uint32_t o = run + inc - mine;
-            if (c[0] == 1u && c[1] == 1u && c[2] == 1u && c[3] == 1u && !((tk[0] | tk[1] | tk[2] | tk[3]) & TK_RES_FLAG)) {
-                *(uint4*)(out + o) = make_uint4(tk[0], tk[1], tk[2], tk[3]);  // (4-byte aligned 16-byte store)
-            } else {
-                uint32_t oo = o;
+        for (uint32_t k0 = 0; k0 < np; k0 += 256u * TKP_ROWS_PLACE) {
+            uint32_t tk[TKP_ROWS_PLACE][4];
+            uint2 hd[TKP_ROWS_PLACE][4];
+#pragma unroll
+            for (int r = 0; r < TKP_ROWS_PLACE; ++r) {
+                const uint32_t k = k0 + (uint32_t)r * 256u + (uint32_t)lane * 4u;
+                uint4 t4 = make_uint4(TK_RES_GAP, TK_RES_GAP, TK_RES_GAP, TK_RES_GAP);
+                if (k < np) t4 = *(const uint4*)(res + rb + k);
+                tk[r][0] = k < np ? t4.x : TK_RES_GAP;  // (dead words of a run's last four count as "no token")
+                tk[r][1] = k + 1 < np ? t4.y : TK_RES_GAP;
+                tk[r][2] = k + 2 < np ? t4.z : TK_RES_GAP;
+                tk[r][3] = k + 3 < np ? t4.w : TK_RES_GAP;
+            }
+#pragma unroll
+            for (int r = 0; r < TKP_ROWS_PLACE; ++r) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    if (!(tk[j] & TK_RES_FLAG)) {
-                        if (c[j]) out[oo] = tk[j];
-                    } else if (c[j] == 1u) {  // (a missed piece is never ONE token; kept for entries written that way)
-                        out[oo] = hd[j].y;
-                    } else if (hd[j].x & TKD_INLINE_BIT) {
-                        const uint32_t* tokp = data.tab[tk[j] & ~TK_RES_FLAG].tok;
-                        uint4 a = make_uint4(0, 0, 0, 0), b = a, d = a;
-                        a = *(const uint4*)(tokp + 1);  // tok[1 .. 4] (the entry is a 64-byte line; tok[0] is its fourth word)
-                        if (c[j] > 5u) b = *(const uint4*)(tokp + 5);
-                        if (c[j] > 9u) d = *(const uint4*)(tokp + 9);
-                        uint32_t* q = out + oo;
-                        q[0] = hd[j].y;
-                        q[1] = a.x;
-                        if (c[j] > 2u) q[2] = a.y;
-                        if (c[j] > 3u) q[3] = a.z;
-                        if (c[j] > 4u) q[4] = a.w;
-                        if (c[j] > 5u) {
-                            q[5] = b.x;
-                            if (c[j] > 6u) q[6] = b.y;
-                            if (c[j] > 7u) q[7] = b.z;
-                            if (c[j] > 8u) q[8] = b.w;
-                            if (c[j] > 9u) {
-                                q[9] = d.x;
-                                if (c[j] > 10u) q[10] = d.y;
-                                if (c[j] > 11u) q[11] = d.z;
-                                if (c[j] > 12u) q[12] = d.w;
-                            }
-                        }
-                    }  // (else: tokens in the staging area, below)
-                    oo += c[j];
+                    hd[r][j] = make_uint2(0u, 0u);
+                    if (tk[r][j] & TK_RES_FLAG) hd[r][j] = data.result(tk[r][j] & ~TK_RES_FLAG);
                 }
             }
-            // pieces whose tokens are in the staging area -> a list in LDS, then 32 lanes per piece copy them
-            uint32_t nst = 0;
 #pragma unroll
-            for (int j = 0; j < 4; ++j) nst += ((tk[j] & TK_RES_FLAG) && c[j] > 1u && !(hd[j].x & TKD_INLINE_BIT)) ? 1u : 0u;
-            if (__ballot(nst != 0u)) {
-                const uint32_t sinc = tk_wave_scan_u32(nst, lane);
-                const uint32_t ntot = __shfl(sinc, 63, 64);
-                uint32_t at = sinc - nst, oj = o;
+            for (int r = 0; r < TKP_ROWS_PLACE; ++r) {
+                if (k0 + (uint32_t)r * 256u >= np) break;
+                uint32_t c[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    if ((tk[j] & TK_RES_FLAG) && c[j] > 1u && !(hd[j].x & TKD_INLINE_BIT)) {
-                        mlist[at * 3] = hd[j].y;
-                        mlist[at * 3 + 1] = c[j];
-                        mlist[at * 3 + 2] = oj;
-                        ++at;
+                for (int j = 0; j < 4; ++j) c[j] = (tk[r][j] & TK_RES_FLAG) ? TKD_COUNT(hd[r][j].x) : (tk[r][j] != TK_RES_GAP ? 1u : 0u);
+                const uint32_t mine = c[0] + c[1] + c[2] + c[3];
+                const uint32_t inc = tk_wave_scan_u32(mine, lane);
+                const uint32_t o = run + inc - mine;
+                uint32_t nst = 0;  // pieces of the lane whose tokens are in the staging area
+                if (c[0] == 1u && c[1] == 1u && c[2] == 1u && c[3] == 1u && !((tk[r][0] | tk[r][1] | tk[r][2] | tk[r][3]) & TK_RES_FLAG)) {
+                    *(uint4*)(out + o) = make_uint4(tk[r][0], tk[r][1], tk[r][2], tk[r][3]);  // (4-byte aligned 16-byte store)
+                } else {
+                    uint32_t oo = o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if (!(tk[r][j] & TK_RES_FLAG)) {
+                            if (c[j]) out[oo] = tk[r][j];
+                        } else if (c[j] == 1u) {  // (a missed piece is never ONE token; kept for entries written that way)
+                            out[oo] = hd[r][j].y;
+                        } else if (hd[r][j].x & TKD_INLINE_BIT) {
+                            const uint32_t* tokp = data.tab[tk[r][j] & ~TK_RES_FLAG].tok;
+                            uint4 a = make_uint4(0, 0, 0, 0), b = a, d = a;
+                            a = *(const uint4*)(tokp + 1);  // tok[1 .. 4] (the entry is a 64-byte line; tok[0] is its fourth word)
+                            if (c[j] > 5u) b = *(const uint4*)(tokp + 5);
+                            if (c[j] > 9u) d = *(const uint4*)(tokp + 9);
+                            uint32_t* q = out + oo;
+                            q[0] = hd[r][j].y;
+                            q[1] = a.x;
+                            if (c[j] > 2u) q[2] = a.y;
+                            if (c[j] > 3u) q[3] = a.z;
+                            if (c[j] > 4u) q[4] = a.w;
+                            if (c[j] > 5u) {
+                                q[5] = b.x;
+                                if (c[j] > 6u) q[6] = b.y;
+                                if (c[j] > 7u) q[7] = b.z;
+                                if (c[j] > 8u) q[8] = b.w;
+                                if (c[j] > 9u) {
+                                    q[9] = d.x;
+                                    if (c[j] > 10u) q[10] = d.y;
+                                    if (c[j] > 11u) q[11] = d.z;
+                                    if (c[j] > 12u) q[12] = d.w;
+                                }
+                            }
+                        } else {
+                            ++nst;
+                        }
+                        oo += c[j];
                     }
-                    oj += c[j];
                 }
-                __builtin_amdgcn_wave_barrier();
-                for (uint32_t e0 = 0; e0 < ntot; e0 += 2) {
-                    const uint32_t e = e0 + (uint32_t)(lane >> 5);
-                    if (e < ntot) {
-                        const uint32_t src = mlist[e * 3], cc = mlist[e * 3 + 1], dst = mlist[e * 3 + 2];
-                        if (cc < TK_BIGCOPY) {
-                            for (uint32_t i = lane & 31; i < cc; i += 32) out[dst + i] = staging[src + i];
-                        } else if ((lane & 31) == 0) {  // thousands of tokens of one piece: copied by tk_k_bigcopy with the whole device
-                            const uint32_t bat = atomicAdd(&big[0], 1u);
-                            if (bat < TK_BIGCOPY_CAP) {
-                                big[1 + 3 * bat] = src;
-                                big[2 + 3 * bat] = dst;
-                                big[3 + 3 * bat] = cc;
-                            } else {
-                                for (uint32_t i = 0; i < cc; ++i) out[dst + i] = staging[src + i];
+                // pieces whose tokens are in the staging area -> a list in LDS, then 32 lanes per piece copy them
+                if (__ballot(nst != 0u)) {
+                    const uint32_t sinc = tk_wave_scan_u32(nst, lane);
+                    const uint32_t ntot = __shfl(sinc, 63, 64);
+                    uint32_t at = sinc - nst, oj = o;
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        if ((tk[r][j] & TK_RES_FLAG) && c[j] > 1u && !(hd[r][j].x & TKD_INLINE_BIT)) {
+                            mlist[at * 3] = hd[r][j].y;
+                            mlist[at * 3 + 1] = c[j];
+                            mlist[at * 3 + 2] = oj;
+                            ++at;
+                        }
+                        oj += c[j];
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    for (uint32_t e0 = 0; e0 < ntot; e0 += 2) {
+                        const uint32_t e = e0 + (uint32_t)(lane >> 5);
+                        if (e < ntot) {
+                            const uint32_t src = mlist[e * 3], cc = mlist[e * 3 + 1], dst = mlist[e * 3 + 2];
+                            if (cc < TK_BIGCOPY) {
+                                for (uint32_t i = lane & 31; i < cc; i += 32) out[dst + i] = staging[src + i];
+                            } else if ((lane & 31) == 0) {  // thousands of tokens of one piece: copied by tk_k_bigcopy with the whole device
+                                const uint32_t bat = atomicAdd(&big[0], 1u);
+                                if (bat < TK_BIGCOPY_CAP) {
+                                    big[1 + 3 * bat] = src;
+                                    big[2 + 3 * bat] = dst;
+                                    big[3 + 3 * bat] = cc;
+                                } else {
+                                    for (uint32_t i = 0; i < cc; ++i) out[dst + i] = staging[src + i];
+                                }
                             }
                         }
                     }
+                    __builtin_amdgcn_wave_barrier();
                 }
-                __builtin_amdgcn_wave_barrier();
+                run += (uint32_t)__shfl((int)inc, 63, 64);
             }
-            run += (uint32_t)__shfl((int)inc, 63, 64);
         }
     }
 }
@@ -2598,7 +2649,7 @@ __global__ __launch_bounds__(256) void tk_k_docoff(uint64_t n_docs, const uint64
                 const uint32_t k = k0 + lane;
                 const uint32_t rv = k < kp ? res[rb + k] : 0u;
                 uint32_t c = (k < kp && rv != TK_RES_GAP) ? 1u : 0u;
-                if (k < kp && (rv & TK_RES_FLAG)) c = TKD_COUNT(data.result(rv & ~TK_RES_FLAG).x);
+                if (k < kp && (rv & TK_RES_FLAG)) c = data.count(rv & ~TK_RES_FLAG);
                 sum += c;
             }
             v = row_run + tk_wave_sum_u32(sum);

@@ -2,8 +2,11 @@
 
 The encode path shards by document and needs no data-path collective (documents never interact,
 reference tiktoken/core.py:174-176); the only exchange is returning the token-id buffers to a root
-rank: one count all-gather (8 bytes per rank) plus ONE padded gather of the u32 buffers -- 7 peers
-send to the root over 7 separate xGMI links, so nothing is ring-serialised.
+rank: one count all-gather (8 bytes per rank) plus ONE grouped exchange of the u32 buffers at their exact
+lengths (send / recv pairs: on RCCL one ncclGroup, the same calls the one-process entry
+tk_group_encode_batch_device makes) -- 7 peers send to the root over 7 separate xGMI links, so nothing
+is ring-serialised.  What the root's links can take bounds it: a rank's ids are about as many bytes as
+its text (4 bytes per 4.2-byte token), so gathering 7 shards of 1 GiB moves 7 GB into one device per step.
 """
 from __future__ import annotations
 
@@ -28,39 +31,54 @@ def partition_by_bytes(doc_off: np.ndarray, world: int) -> list[tuple[int, int]]
 class PendingGather:
     """Handle of a token gather that may still be in flight (gather_tokens(..., async_op=True))."""
 
-    def __init__(self, work, bufs, counts, keep):
-        self._work, self._bufs, self.counts, self._keep = work, bufs, counts, keep
+    def __init__(self, works, bufs, counts, keep):
+        self._works, self._bufs, self.counts, self._keep = list(works or []), bufs, counts, keep
 
     def wait(self):
         """Blocks until the gather has completed.  Returns (per-rank tensors in rank order, counts) on the
         destination rank and (None, counts) elsewhere."""
-        if self._work is not None:
-            self._work.wait()
-            self._work = None
+        for w in self._works:
+            w.wait()
+        self._works = []
         self._keep = None
         if self._bufs is None:
             return None, self.counts
         return [b[:c] for b, c in zip(self._bufs, self.counts)], self.counts
 
 
-def gather_tokens(tokens, n_tokens: int, rank: int, world: int, dist, torch, dst: int = 0, async_op: bool = False):
+def gather_tokens(tokens, n_tokens: int, rank: int, world: int, dist, torch, dst: int = 0, async_op: bool = False, padded: bool = False):
     """Gather per-rank token buffers (1-D integer tensors, first n_tokens entries valid) on rank `dst`.
     Returns (list of per-rank tensors in rank order, counts) on dst and (None, counts) elsewhere; with
     async_op=True returns a PendingGather instead, so that the transfer over xGMI overlaps with the encode of the
-    next sub-batch (the counts are exchanged synchronously: 8 bytes per rank)."""
+    next sub-batch (the counts are exchanged synchronously: 8 bytes per rank).  The buffers travel at their exact
+    lengths (grouped send / recv); padded=True is the earlier form, one dist.gather of max(count) entries per rank.
+    `tokens` is read until the gather has completed: the caller keeps it unchanged until wait() returns."""
     mine = torch.tensor([n_tokens], dtype=torch.int64, device=tokens.device)
     parts = [torch.zeros(1, dtype=torch.int64, device=tokens.device) for _ in range(world)]
     dist.all_gather(parts, mine)
     counts = [int(p.item()) for p in parts]
-    cmax = max(max(counts), 1)
-    if tokens.numel() >= cmax:
-        send = tokens[:cmax].contiguous()
-    else:
-        send = torch.cat([tokens, tokens.new_zeros(cmax - tokens.numel())])
-    bufs = [torch.empty(cmax, dtype=tokens.dtype, device=tokens.device) for _ in range(world)] if rank == dst else None
-    work = dist.gather(send, bufs, dst=dst, async_op=async_op)
-    pending = PendingGather(work if async_op else None, bufs, counts, send)
-    return pending if async_op else pending.wait()
+    if padded:
+        cmax = max(max(counts), 1)
+        if tokens.numel() >= cmax:
+            send = tokens[:cmax].contiguous()
+        else:
+            send = torch.cat([tokens, tokens.new_zeros(cmax - tokens.numel())])
+        bufs = [torch.empty(cmax, dtype=tokens.dtype, device=tokens.device) for _ in range(world)] if rank == dst else None
+        work = dist.gather(send, bufs, dst=dst, async_op=async_op)
+        pending = PendingGather([work] if async_op else [], bufs, counts, send)
+        return pending if async_op else pending.wait()
+    own = tokens[:n_tokens]
+    ops, bufs = [], None
+    if rank == dst:
+        bufs = [own if r == dst else torch.empty(counts[r], dtype=tokens.dtype, device=tokens.device) for r in range(world)]
+        ops = [dist.P2POp(dist.irecv, bufs[r], r) for r in range(world) if r != dst and counts[r]]
+    elif n_tokens:
+        ops = [dist.P2POp(dist.isend, own.contiguous(), dst)]
+    works = dist.batch_isend_irecv(ops) if ops else []
+    pending = PendingGather(works, bufs, counts, own)
+    if async_op:
+        return pending
+    return pending.wait()
 
 
 def encode_ordinary_batch_sharded(encode_packed, blob: np.ndarray, doc_off: np.ndarray, rank: int, world: int, dist, torch,
