@@ -623,7 +623,8 @@ static int stage_deferred(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream
         TkFrontOut fo{w.starts.as<uint32_t>(), w.tile_np.as<uint32_t>(), w.res.as<uint32_t>(), w.tile_sum.as<uint8_t>(), miss_of(w, job), job.ovf_cap,
                       w.listC.as<uint32_t>(), w.counters.as<uint32_t>()};
         uint32_t *ss = job.spec ? w.ss.as<uint32_t>() : nullptr, *si = job.spec ? w.si.as<uint32_t>() : nullptr, *docb = job.spec ? w.docb.as<uint32_t>() : nullptr;
-        const dim3 grid((uint32_t)(job.ntiles < 1024 ? job.ntiles : 1024));
+        const uint32_t slow_wgs = 256u * TKF_SLOW_OCC;
+        const dim3 grid((uint32_t)(job.ntiles < slow_wgs ? job.ntiles : slow_wgs));
         const int pat_id = T.pat.generic() ? TK_PAT_GENERIC : T.pattern;
         TkMissKey* mt_arg = (c->dbg & 256) ? (TkMissKey*)nullptr : job.mt;
         const uint32_t* gapb = c->has_rx ? w.rx_gst.as<uint32_t>() + (job.n + 31) / 32 + 2 : (const uint32_t*)nullptr;

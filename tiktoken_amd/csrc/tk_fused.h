@@ -537,11 +537,14 @@ __device__ __forceinline__ bool tk_equal_lds_text(const uint8_t* raw, uint32_t o
 #ifndef TKF_OCC
 #define TKF_OCC 8
 #endif
+#ifndef TKF_SLOW_OCC
+#define TKF_SLOW_OCC 4  // workgroups per CU of the deferred-tile variant (its grid: tk_api.hip, stage_deferred)
+#endif
 #ifndef TKF_ROWS
 #define TKF_ROWS 1  // phase F: one length class per row of 64 pieces (0: the three classes side by side in every lane)
 #endif
 template <int PAT, bool SPEC, bool SLOW>
-__global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
+__global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
                                                   const uint32_t* __restrict__ brk, const uint32_t* __restrict__ docb,
                                                   const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, TkFrontOut out,
                                                   TkMissKey* __restrict__ mt, uint32_t mt_mask, uint32_t* __restrict__ deferred,
@@ -560,7 +563,7 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
     __shared__ uint32_t bits[TK_TILE / 32];
     __shared__ uint8_t lastc_own[256];
     __shared__ uint32_t np_sh, need_walk, last_end_sh, ncls_sh, nx_sh, ncont_sh;
-    __shared__ uint16_t contl_own[SLOW ? TKF_CONT_CAP : 1], stop_own[SLOW ? 256 : 2];
+    __shared__ __attribute__((aligned(8))) uint16_t contl_own[SLOW ? TKF_CONT_CAP : 4], stop_own[SLOW ? 256 : 4];  // (read as 32-bit words)
     // second window of the deferred-tile variant: a stretch of text left of the tile, walked by tk_coop_window_walk
     __shared__ __attribute__((aligned(16))) uint8_t w2_raw[SLOW ? TK2_WIN + 16 : 16];
     __shared__ uint32_t w2_planes[SLOW ? 4 * TK2_PLW : 1], w2_start[SLOW ? TK2_WIN / 32 + 4 : 1], w2_hard[SLOW ? TK2_WIN / 32 + 4 : 1];
@@ -576,7 +579,6 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
     __shared__ __attribute__((aligned(16))) uint32_t hot[HOT ? TKF_HOT_SLOTS * 4 : 4];
     __shared__ __attribute__((aligned(16))) uint32_t hot_mask[HOT ? 16 * 4 : 4];  // [len] -> byte masks of the three key words
     uint64_t(*bm)[NW] = (uint64_t(*)[NW])pool;
-    uint16_t* clist = (uint16_t*)(pool + BM_BYTES);
     uint16_t* plist = (uint16_t*)pool;  // valid after the scanners are done
     uint32_t* woff = certw;             // (phase E; the certain-start bitmap is dead by then)
     uint8_t* lastc = lastc_own;
@@ -752,9 +754,9 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
     constexpr uint32_t T0 = TK2_LEFT / 16, T1 = (TK2_LEFT + TK_TILE) / 16;  // chunks [T0, T1) are the tile
     const bool in_tile = tid >= T0 && tid < T1;
     if (in_tile) ((uint16_t*)bits)[tid - T0] = (uint16_t)cert;
-    // scan starts of this lane: its certain starts inside the tile; plus, for the first chunk of the tile, the start of the piece
-    // that crosses in from the left when the first char of the tile is not certain itself: the last certain start of the left
-    // context, else a walk back through HBM
+    // scan starts: the certain starts inside the tile (phase D takes them 64 positions at a time); plus the start of the piece that
+    // crosses in from the left when the first char of the tile is not certain itself: the last certain start of the left context,
+    // else a walk back through HBM
     uint32_t mine = in_tile ? cert : 0u;
     uint32_t extra = TKF_NONE;
     if (wid == 0) {
@@ -768,27 +770,6 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
                 if (lm) extra = (uint32_t)ll * 16u + 31u - (uint32_t)__clz((int)lc);
                 else need_walk = 1;
             }
-        }
-    }
-    // kind of scan a start will run (a guess from the class of the next byte: only the grouping depends on it), so that the
-    // scanners of a wavefront mostly follow the same branch: word-like starts fill the list from the front, the rest from the back
-    constexpr uint32_t PREFIX_OK = ~(TK_CB(TK_C_NL) | TK_CB(TK_C_NU));
-    const uint32_t prefix_ok = (st.sp | st.wso | st.ap | st.sl | st.ot | st.mk | st.l) & 0xFFFFu;  // classes of PREFIX_OK that occur in text
-    (void)PREFIX_OK;
-    const uint32_t wordish = mine & (st.word | (prefix_ok & (st.word >> 1)));
-    const uint32_t nw = (uint32_t)__popc(wordish), nr = (uint32_t)__popc(mine & ~wordish) + (extra != TKF_NONE ? 1u : 0u);
-    uint32_t tot2;
-    const uint32_t ex2 = tk_block_exscan_256(nw | (nr << 16), &tot2, scan_sh);
-    const uint32_t n_front = tot2 & 0xFFFFu, n_back = tot2 >> 16;
-    const bool listed = n_front + n_back <= TK2_CLIST;
-    if (listed) {
-        uint32_t at_w = ex2 & 0xFFFFu, at_r = TK2_CLIST - 1u - (ex2 >> 16);
-        if (extra != TKF_NONE) clist[at_r--] = (uint16_t)extra;
-        for (uint32_t m = mine; m; m &= m - 1) {
-            const uint32_t j = (uint32_t)__ffs((int)m) - 1u;
-            const uint16_t pos = (uint16_t)(tid * 16u + j);
-            if ((wordish >> j) & 1u) clist[at_w++] = pos;
-            else clist[at_r--] = pos;
         }
     }
     __syncthreads();
@@ -947,23 +928,68 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
         if (tid == 0) deferred[(n + TK_TILE - 1) / TK_TILE + 2 + atomicAdd(&out.counters[TK_CNT_DEFER2], 1u)] = (uint32_t)tile;
         continue;
     }
-    // Rounds around ONE instance of the lanes' evaluation (the scanner is big: a second inlined copy spills registers).
-    //   round 0: one piece per scan start, all lanes busy.  94..98 % of the pieces end at a certain start; a chain that goes on (an
-    //            uncertain boundary) is put on the continuation list -- a wavefront does not repeat the evaluation for its slowest lane;
-    //   round 1+: the listed chains (and, when the start list overflowed, every lane's own starts), walked to their ends.
-    // After each round the workgroup answers the pieces that left the window; those can add continuations for one more round.
-    uint32_t own = listed ? 0u : mine;
-    bool own_extra = !listed && extra != TKF_NONE;
+    // Round 0, for all the certain starts of the tile at once: between a piece start and the next position at which a piece MAY start
+    // (`stop16`) there is no boundary, so a piece that starts at a certain start ends at the next stop whenever that stop is a certain
+    // start too -- 85 % of the pieces, and nothing has to be recorded for them: the certain starts are in `bits` already.  A lane looks at
+    // the 64 positions from its chunk on: adding the starts, shifted by one, to the complement of the stops carries each of them up
+    // to its next stop.  Starts whose next stop is not certain (or lies further away) go on the continuation list.
+    uint32_t own = 0u;           // starts of the lane that did not fit the list: evaluated by the lane itself
+    bool own_extra = false;
+    {
+        const uint32_t te = (uint32_t)(tile_end - tile_start) + (uint32_t)TK2_LEFT;  // window position of the tile's end
+        uint32_t sm = mine;                                                          // certain starts of the lane's chunk before the tile's end
+        if (tid * 16u + 16u > te) sm &= tid * 16u >= te ? 0u : ((1u << (te - tid * 16u)) - 1u);
+        uint32_t needm = 0u;  // starts that have to be evaluated
+        if (sm) {
+            const uint32_t* sw = (const uint32_t*)stop16;
+            const uint32_t* cw = certw;
+            const uint32_t wi = tid >> 1, sh = (tid & 1u) * 16u;
+            const uint32_t s0 = sw[wi], s1 = sw[wi + 1], s2 = sw[wi + 2], c0 = cw[wi], c1 = cw[wi + 1], c2 = cw[wi + 2];  // (tid < T1: at most word 126 of 128)
+            const uint64_t x = (uint64_t)__builtin_amdgcn_alignbit(s1, s0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(s2, s1, sh) << 32);
+            const uint64_t cx = (uint64_t)__builtin_amdgcn_alignbit(c1, c0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(c2, c1, sh) << 32);
+            const uint64_t gaps = ~x;
+            const uint64_t sum = gaps + ((uint64_t)sm << 1);
+            const uint64_t nxt = sum & x;           // the next stop of every start (a start is a stop: no carry passes one)
+            if (sum < gaps) needm = 1u << (31 - __clz((int)sm));  // the carry of the last start left the 64 positions: no stop in sight
+            uint64_t unc = nxt & ~cx;               // next stops that are not certain
+            while (unc) {
+                const uint32_t u = (uint32_t)__ffsll((unsigned long long)unc) - 1u;
+                unc &= unc - 1ull;
+                const uint32_t below = sm & (u >= 16u ? 0xFFFFu : ((1u << u) - 1u));
+                needm |= 1u << (31 - __clz((int)below));  // (the stop was reached from the last start below it)
+            }
+            // the tile's last piece ends at a certain start at or behind the tile's end: its end is remembered for the probe
+            const uint32_t k = te - tid * 16u;  // (sm != 0: the chunk starts before the tile's end)
+            const uint64_t ce = nxt & cx & (k < 64u ? ~((1ull << k) - 1ull) : 0ull);
+            if (ce) last_end_sh = tid * 16u + (uint32_t)__ffsll((unsigned long long)ce) - 1u;
+        }
+        const uint32_t cnt = (uint32_t)__popc(needm) + ((tid == T0 && extra != TKF_NONE) ? 1u : 0u);
+        if (cnt) {
+            uint32_t at = atomicAdd(&ncont_sh, cnt);
+            if (tid == T0 && extra != TKF_NONE) {
+                if (at < CONT_CAP) contl[at++] = (uint16_t)extra;
+                else own_extra = true;
+            }
+            for (uint32_t m = needm; m; m &= m - 1) {
+                if (at < CONT_CAP) contl[at++] = (uint16_t)(tid * 16u + (uint32_t)__ffs((int)m) - 1u);
+                else own |= m & (0u - m);
+            }
+        }
+    }
+    __syncthreads();
+    // Rounds around ONE instance of the lanes' evaluation (the scanner is big: a second inlined copy spills registers): the listed
+    // chains (and what did not fit the list: every lane's own), walked to their ends.  After each round the workgroup answers the pieces
+    // that left the window; those can add continuations for one more round.
     uint32_t cont_done = 0, slow_done = 0;
-    for (int round = 0;; ++round) {
+    for (int round = 1;; ++round) {
         const uint32_t cont_n = ncont_sh < CONT_CAP ? ncont_sh : CONT_CAP;
-        const uint32_t lo = round == 0 ? 0u : cont_done, hi = round == 0 ? (listed ? n_front + n_back : 0u) : cont_n;
-        if (round) cont_done = cont_n;
+        const uint32_t lo = cont_done, hi = cont_n;
+        cont_done = cont_n;
         uint32_t i = lo + tid;
         for (;;) {
             uint64_t p = TKF_CHAIN_END;
             if (i < hi) {
-                p = (uint64_t)(base + (round == 0 ? (i < n_front ? clist[i] : clist[TK2_CLIST - 1u - (i - n_front)]) : contl[i]));
+                p = (uint64_t)(base + contl[i]);
                 i += 256;
             } else if (round == 1) {
                 if (own_extra) {
@@ -975,55 +1001,9 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
                 }
             }
             if (!__any(p != TKF_CHAIN_END)) break;
-            if (round == 0) {
-                // Short cut: the first position after p at which a piece may start.  If it is a certain start, the piece ends there
-                // and nothing else has to be found out (85 % of the pieces).  The others go on the continuation list, so that the
-                // scanner below runs in round 1 with all lanes of a wavefront busy instead of here for a few lanes of each.
-                bool need = p != TKF_CHAIN_END;
-                const uint32_t r = need ? (uint32_t)((int64_t)p - base) : 0u;
-                if (need && r + 32u < (uint32_t)TK2_WIN) {
-                    const uint32_t* sw = (const uint32_t*)stop16;
-                    const uint32_t w = __builtin_amdgcn_alignbit(sw[(r >> 5) + 1u], sw[r >> 5], r & 31u) & ~1u;
-                    if (w) {
-                        const uint32_t re = r + (uint32_t)__ffs((int)w) - 1u;
-                        if ((certw[re >> 5] >> (re & 31u)) & 1u) {
-                            chain_step(p, (uint64_t)(base + (int64_t)re));  // (a certain start: the chain ends; the tile's last end is noted)
-                            need = false;
-                        }
-                    }
-                }
-                const uint64_t m = __ballot(need);
-                if (m) {
-                    uint32_t at = 0;
-                    const int leader = __ffsll((unsigned long long)m) - 1;
-                    if (lane == leader) at = atomicAdd(&ncont_sh, (uint32_t)__popcll(m));
-                    at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                    if (need && at < CONT_CAP) {
-                        contl[at] = (uint16_t)r;
-                        need = false;
-                    }
-                }
-                p = need ? p : TKF_CHAIN_END;
-                if (!__any(p != TKF_CHAIN_END)) continue;
-            }
-            for (;;) {  // (round 0: only when the continuation list is full)
+            for (;;) {
                 const uint64_t e = p != TKF_CHAIN_END ? piece_from(p) : TKF_CHAIN_END;
-                bool go_on = e != TKF_CHAIN_END;
-                if (round == 0) {
-                    const uint64_t m = __ballot(go_on);
-                    if (m) {
-                        uint32_t at = 0;
-                        const int leader = __ffsll((unsigned long long)m) - 1;
-                        if (lane == leader) at = atomicAdd(&ncont_sh, (uint32_t)__popcll(m));
-                        at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                        // (a chain that goes on is left of the tile end and inside the window)
-                        if (go_on && at < CONT_CAP) {
-                            contl[at] = (uint16_t)(e - (uint64_t)base);
-                            go_on = false;
-                        }
-                    }
-                }
-                p = go_on ? e : TKF_CHAIN_END;
+                p = e;
                 if (!__any(p != TKF_CHAIN_END)) break;
             }
         }
@@ -1034,7 +1014,7 @@ __global__ __launch_bounds__(256, SLOW ? 4 : TKF_OCC) void tk_k_front(TkTables T
         slow_done = slow_n;
         __syncthreads();
         const uint32_t cont_now = ncont_sh < CONT_CAP ? ncont_sh : CONT_CAP;
-        if (round >= 1 && cont_now == cont_done) break;
+        if (cont_now == cont_done) break;
     }
     if (!SLOW && nslow_sh) {
         defer_tile();
