@@ -128,6 +128,15 @@ struct tk_core {
     // workspace: per chunk in flight, and what a whole call shares
     WorkSet ws[TK_NSET];
     Buf text, doc_off, out_tokens, out_tok_off, allowed, tok_bases;  // tok_bases[k]: tokens of the chunks before chunk k (on the device)
+    // Streams of the back stages of a multi-chunk batch.  HIP multiplexes its streams onto a few hardware queues (four by default), and
+    // two streams that share a queue run one after the other: the back stage of chunk k, queued behind the front kernel of chunk
+    // k + 1, then waits for that kernel to END instead of running beside it (seen in the kernel timeline of round 4: no overlap at all).
+    // Which streams share a queue cannot be asked; it is found out once per caller's stream (pick_back_streams).
+    hipStream_t back_for = nullptr;  // the front stream the choice was made for
+    bool back_probed = false;
+    hipStream_t back_s[3] = {};      // streams that share a queue neither with back_for nor with each other (as far as the pool has any)
+    int n_back = 0;
+    uint32_t* h_probe = nullptr;     // page-locked words of the probe: [0] the gate, [1 ..] one per candidate
     Buf out_tokens_alt, out_tok_off_alt;  // the other pair of result buffers of tk_encode_batch_device (tk_set_output_buffers(core, 2))
     uint32_t out_bufs = 1;
     bool ovf_full = false;  // a batch has asked for more overflow entries of the miss data than the default: room for the worst case from then on
@@ -466,6 +475,7 @@ extern "C" void tk_destroy(tk_core* c) {
                    &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2, &c->t_byte_rank, &c->t_hot, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off,
                    &c->out_tokens, &c->out_tok_off, &c->out_tokens_alt, &c->out_tok_off_alt, &c->allowed, &c->tok_bases})
         release(*b);
+    if (c->h_probe) (void)hipHostFree(c->h_probe);
     for (WorkSet& w : c->ws) {
         for (Buf* b : w.all()) release(*b);
         for (hipEvent_t e : {w.ev_front, w.ev_cnt, w.ev_tot, w.ev_done, w.ev_fork})
@@ -524,16 +534,16 @@ static void launch_front(int pattern, bool spec, dim3 grid, hipStream_t s, A... 
 
 // exclusive prefix sum of a uint32 array in place, total -> total_out[0]
 static int scan_u32(tk_core* c, WorkSet& w, hipStream_t s, uint32_t* a, uint64_t n, uint64_t* total_out) {
-    if (n <= 16 * (uint64_t)TK_SCAN_BLOCK) {  // (one workgroup walks up to 128 Ki values in ~20 us: cheaper than three launches)
-        TRY(timed(c, s, "tk_k_scan_small", [&] { hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, a, n, total_out); }));
+    if (n <= 8 * (uint64_t)TK_SCAN_BLOCK) {  // (one workgroup walks up to 32 Ki values in ~15 us: cheaper than three launches)
+        TRY(timed(c, s, "tk_k_scan_small", [&] { hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(TK_SCAN_THREADS), 0, s, a, n, total_out); }));
         return TK_OK;
     }
     const uint64_t nb = (n + TK_SCAN_BLOCK - 1) / TK_SCAN_BLOCK;
     TRY(ensure(w.scan_sums, (nb + 2) * 4));
     uint32_t* sums = w.scan_sums.as<uint32_t>();
-    TRY(timed(c, s, "tk_k_scan_sums", [&] { hipLaunchKernelGGL(tk_k_scan_sums, dim3((uint32_t)nb), dim3(1024), 0, s, a, n, sums); }));
-    TRY(timed(c, s, "tk_k_scan_small", [&] { hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, sums, nb, total_out); }));
-    TRY(timed(c, s, "tk_k_scan_apply", [&] { hipLaunchKernelGGL(tk_k_scan_apply, dim3((uint32_t)nb), dim3(1024), 0, s, a, n, sums); }));
+    TRY(timed(c, s, "tk_k_scan_sums", [&] { hipLaunchKernelGGL(tk_k_scan_sums, dim3((uint32_t)nb), dim3(TK_SCAN_THREADS), 0, s, a, n, sums); }));
+    TRY(timed(c, s, "tk_k_scan_small", [&] { hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(TK_SCAN_THREADS), 0, s, sums, nb, total_out); }));
+    TRY(timed(c, s, "tk_k_scan_apply", [&] { hipLaunchKernelGGL(tk_k_scan_apply, dim3((uint32_t)nb), dim3(TK_SCAN_THREADS), 0, s, a, n, sums); }));
     return TK_OK;
 }
 
@@ -797,7 +807,7 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
                 hipLaunchKernelGGL(tk_k_count, dim3((uint32_t)nblk), dim3(256), 0, s, starts, nwords, w.blockcnt.as<uint32_t>());
             }));
             TRY(timed(c, s, "tk_k_scan_small", [&] {
-                hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(1024), 0, s, w.blockcnt.as<uint32_t>(), nblk, w.total.as<uint64_t>());
+                hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(TK_SCAN_THREADS), 0, s, w.blockcnt.as<uint32_t>(), nblk, w.total.as<uint64_t>());
             }));
             HIPCHK(hipMemcpyAsync(&P, w.total.p, 8, hipMemcpyDeviceToHost, s));
             HIPCHK(hipStreamSynchronize(s));
@@ -848,10 +858,10 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
             uint64_t most_units = 0;
             for (int b = 0; b < TK_NBIN; ++b)
                 if (n >= tk_bin_lo(b)) most_units += std::min<uint64_t>(n / tk_bin_lo(b), n_entries) / (64u >> (b == 0 ? 0 : (b <= 2 ? 1 : (b <= 4 ? 2 : b - 2)))) + 1;
-            uint32_t wgs = (uint32_t)std::min<uint64_t>((most_units + 3) / 4, (uint64_t)c->n_cu * TKM_WGS_PER_CU);
-            wgs = std::max(4u, (wgs + 3u) & ~3u);  // (wavefronts: a multiple of 16, tk_k_merge_all's work counters rely on it)
+            uint32_t wgs = (uint32_t)std::min<uint64_t>((most_units + TKM_WAVES - 1) / TKM_WAVES, (uint64_t)c->n_cu * TKM_WGS_PER_CU);
+            wgs = std::max(16u / TKM_WAVES, (wgs + 16u / TKM_WAVES - 1u) / (16u / TKM_WAVES) * (16u / TKM_WAVES));  // (wavefronts: a multiple of 16, tk_k_merge_all's work counters rely on it)
             TRY(timed(c, s, "tk_k_merge_all", [&] {
-                hipLaunchKernelGGL(tk_k_merge_all, dim3(wgs), dim3(256), 0, s, T, d_text, listB, counters, data, stg, w.merge_work.as<uint32_t>(), c->dbg);
+                hipLaunchKernelGGL(tk_k_merge_all, dim3(wgs), dim3(64 * TKM_WAVES), TKM_LDS_BYTES, s, T, d_text, listB, counters, data, stg, w.merge_work.as<uint32_t>(), c->dbg);
             }));
         } else
         {
@@ -1029,6 +1039,69 @@ static int prepare_allowed(tk_core* c, hipStream_t s, const uint32_t* allowed_id
     return TK_OK;
 }
 
+// ---- which of the library's streams run BESIDE a given stream (see tk_core::back_s) ----
+// A gate kernel spins on `on` until the host opens the gate (or 4 ms have passed: 100 MHz counter); a one-thread kernel on every
+// candidate stream sets a word of its own.  Candidates whose word arrives while the gate is closed do not share `on`'s hardware queue.
+__global__ void tk_k_gate(volatile uint32_t* gate, uint64_t max_ticks) {
+    const uint64_t t0 = wall_clock64();
+    while (!*gate && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(16);
+}
+__global__ void tk_k_touch(uint32_t* p) { *p = 1u; }
+
+static int streams_beside(tk_core* c, hipStream_t on, const std::vector<hipStream_t>& cand, std::vector<hipStream_t>* beside) {
+    beside->clear();
+    if (cand.empty()) return TK_OK;
+    if (!c->h_probe) HIPCHK(hipHostMalloc((void**)&c->h_probe, 64 * 4, hipHostMallocCoherent | hipHostMallocMapped));
+    volatile uint32_t* h = c->h_probe;
+    uint32_t* d = nullptr;
+    HIPCHK(hipHostGetDevicePointer((void**)&d, c->h_probe, 0));
+    for (int i = 0; i < 64; ++i) h[i] = 0;
+    hipLaunchKernelGGL(tk_k_gate, dim3(1), dim3(1), 0, on, (volatile uint32_t*)d, (uint64_t)400000);
+    for (size_t i = 0; i < cand.size(); ++i) hipLaunchKernelGGL(tk_k_touch, dim3(1), dim3(1), 0, cand[i], d + 1 + i);
+    // wait until the words have stopped arriving (a launch reaches the device within tens of microseconds)
+    const double t0 = now_us();
+    size_t seen = 0;
+    double t_last = t0;
+    for (;;) {
+        size_t n = 0;
+        for (size_t i = 0; i < cand.size(); ++i) n += h[1 + i] ? 1 : 0;
+        const double t = now_us();
+        if (n != seen) {
+            seen = n;
+            t_last = t;
+        }
+        if (n == cand.size() || (t - t0 > 200.0 && t - t_last > 100.0) || t - t0 > 2000.0) break;
+    }
+    std::vector<bool> ok(cand.size());
+    for (size_t i = 0; i < cand.size(); ++i) ok[i] = h[1 + i] != 0;
+    h[0] = 1u;  // open the gate
+    HIPCHK(hipStreamSynchronize(on));
+    for (hipStream_t q : cand) HIPCHK(hipStreamSynchronize(q));
+    for (size_t i = 0; i < cand.size(); ++i)
+        if (ok[i]) beside->push_back(cand[i]);
+    return TK_OK;
+}
+
+// back-stage streams for front stream s: first those that run beside s, among them those that run beside each other
+static int pick_back_streams(tk_core* c, hipStream_t s) {
+    if (c->back_probed && c->back_for == s) return TK_OK;
+    std::vector<hipStream_t> pool, f;
+    for (WorkSet& w : c->ws) pool.push_back(w.sb);
+    for (int i = 0; i < TK_NAUX; ++i) pool.push_back(c->aux[i]);
+    c->n_back = 0;
+    hipStream_t on = s;
+    for (int r = 0; r < 3 && !pool.empty(); ++r) {
+        TRY(streams_beside(c, on, pool, &f));
+        if (f.empty()) break;
+        c->back_s[c->n_back++] = on = f[0];
+        pool.assign(f.begin() + 1, f.end());
+    }
+    if (c->n_back == 0) c->back_s[c->n_back++] = c->ws[0].sb;  // (nothing runs beside s: the stages take turns, as before)
+    c->back_for = s;
+    c->back_probed = true;
+    return TK_OK;
+}
+
 // Hooks of the host-buffer entry point: the text of a chunk must have arrived before its kernels start, and its tokens can start
 // their way back while the next chunk is being encoded.
 struct ChunkHooks {
@@ -1059,10 +1132,15 @@ static int encode_device_pass(tk_core* c, hipStream_t s, const uint8_t* d_utf8, 
         if (n_bytes > chunk_bytes && n_bytes >= (3ull << 30)) return fail(TK_VALUE_ERROR, "h_doc_off is required when n_bytes exceeds the chunk size");
         cuts.push_back(Cut{0, n_docs, 0, n_bytes});
     } else {
+        // (chunks of equal size, cut at the document boundaries next to j * n / N: a last chunk of a few KiB would still pay the back
+        // stage's fixed latencies, about a millisecond; a chunk may exceed chunk_bytes by less than a document)
+        const uint64_t n_cuts = (n_bytes + chunk_bytes - 1) / chunk_bytes;
         uint64_t d0 = 0;
         while (d0 < n_docs) {
             uint64_t d1 = d0 + 1;
-            while (d1 < n_docs && h_doc_off[d1 + 1] - h_doc_off[d0] <= chunk_bytes) ++d1;
+            const uint64_t j = cuts.size() + 1;
+            const uint64_t until = j >= n_cuts ? n_bytes : (uint64_t)((unsigned __int128)n_bytes * j / n_cuts);
+            while (d1 < n_docs && h_doc_off[d1] < until && h_doc_off[d1 + 1] - h_doc_off[d0] <= chunk_bytes + (chunk_bytes >> 3)) ++d1;
             if (d1 < n_docs)  // an aligned cut a little earlier saves the next chunk its copy
                 for (uint64_t q = d1; q > d0 + 1 && d1 - q < 256; --q)
                     if ((((uintptr_t)d_utf8 + h_doc_off[q]) & 15u) == 0) {
@@ -1077,6 +1155,7 @@ static int encode_device_pass(tk_core* c, hipStream_t s, const uint8_t* d_utf8, 
         if (cuts.empty()) cuts.push_back(Cut{0, 0, 0, 0});
     }
     const size_t N = cuts.size();
+    if (N > 1) TRY(pick_back_streams(c, s));
     TRY(ensure(c->tok_bases, (N + 2) * 8));
     HIPCHK(hipMemsetAsync(c->tok_bases.p, 0, 8, s));  // (before the first front stage on the same stream, which every back stage waits for)
     ChunkJob jobs[TK_NSET];
@@ -1119,7 +1198,7 @@ static int encode_device_pass(tk_core* c, hipStream_t s, const uint8_t* d_utf8, 
         const double tb0 = now_us();
         // a single chunk keeps both stages on the caller's stream; otherwise every set's back stage has a stream of its own
         WorkSet& w = c->ws[k % TK_NSET];
-        hipStream_t sb = N > 1 ? w.sb : s;
+        hipStream_t sb = N > 1 ? c->back_s[k % (size_t)c->n_back] : s;
         if (N > 1) HIPCHK(hipStreamWaitEvent(sb, w.ev_front, 0));
         TRY(stage_back(c, w, jobs[k % TK_NSET], sb, d_out, (N > 1 && k > 0) ? c->ws[(k - 1) % TK_NSET].ev_tot : (hipEvent_t) nullptr));
         c->host_us[1] += now_us() - tb0;
@@ -2080,6 +2159,7 @@ extern "C" uint64_t tk_stat(tk_core* c, const char* name) {
     if (k == "front_wgs_per_cu") return c->front_wgs;
     if (k == "compute_units") return c->n_cu;
     if (k == "chunks") return c->st_chunks;
+    if (k == "back_streams") return (uint64_t)c->n_back;  // streams found to run beside the front stream (0: no multi-chunk batch yet)
     if (k == "regrown") return c->st_regrown;  // batches repeated with a larger miss data since the core was made (encode_device_locked)
     if (k == "workspace_bytes") {             // device memory of the work sets (everything but the text, the tables and the outputs)
         uint64_t t = 0;

@@ -1739,21 +1739,33 @@ __device__ __forceinline__ void tkm_probe2(const TkTables& T, uint32_t a0, uint3
         }
     }
 }
-#define TKM_WGS_PER_CU 5  // 32 KiB of LDS per workgroup
+#ifndef TKM_WAVES
+#define TKM_WAVES 4       // wavefronts per workgroup (8 KiB of LDS each)
+#endif
+#ifndef TKM_WGS_PER_CU
+#define TKM_WGS_PER_CU (20 / TKM_WAVES)  // 32 KiB of LDS per workgroup of four
+#endif
+#define TKM_LDS_BYTES (TKM_WAVES * 2 * 1024 * 4)
+#ifndef TKM_MIN_WAVES_EU
+#define TKM_MIN_WAVES_EU 5  // (the second launch bound is wavefronts per SIMD in HIP)
+#endif
 #define TKM_WORK_STRIDE 64  // words between two work counters (256 bytes)
-__global__ __launch_bounds__(256, TKM_WGS_PER_CU) void tk_k_merge_all(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listB,
+__global__ __launch_bounds__(64 * TKM_WAVES, TKM_MIN_WAVES_EU) void tk_k_merge_all(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listB,
                                                                       uint32_t* __restrict__ counters, TkMiss data, uint32_t* __restrict__ staging,
                                                                       uint32_t* __restrict__ work /* 16 counters, TKM_WORK_STRIDE words apart, zero */, int dbg) {
     constexpr int C = 16;
     constexpr uint32_t NONE = 0xFFFFu;
-    __shared__ __attribute__((aligned(16))) uint32_t s_id[4][1024];
-    __shared__ __attribute__((aligned(16))) uint32_t s_key[4][1024];
+    // (dynamic LDS, TKM_LDS_BYTES at the launch: with a static size the compiler derives the occupancy from it and lets the registers
+    // grow to match -- the launch bounds are what shall limit them: a workgroup has to fit the place a front-kernel workgroup leaves)
+    extern __shared__ __attribute__((aligned(16))) uint32_t tkm_lds[];
+    uint32_t(*s_id)[1024] = (uint32_t(*)[1024])tkm_lds;
+    uint32_t(*s_key)[1024] = s_id + TKM_WAVES;
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint32_t* id = s_id[wid] + lane * C;   // the lane's 16 positions (a piece's G lanes are neighbours: its positions are contiguous)
     uint32_t* key = s_key[wid] + lane * C;
     const uint32_t* idw = s_id[wid];
     uint32_t* keyw = s_key[wid];
-    const uint32_t nwaves = gridDim.x * 4u;  // (a multiple of 16: see the work counters)
+    const uint32_t nwaves = gridDim.x * (uint32_t)TKM_WAVES;  // (a multiple of 16: see the work counters)
     // units, longest bin first (wave-uniform; the counts were left by tk_k_binfill)
     uint32_t ustart[TK_NBIN + 1];  // ustart[q]: first unit of the q-th bin in processing order (bin TK_NBIN - 1 - q)
     ustart[0] = 0;
@@ -1764,7 +1776,7 @@ __global__ __launch_bounds__(256, TKM_WGS_PER_CU) void tk_k_merge_all(TkTables T
         ustart[q + 1] = ustart[q] + ((cnt + (1u << sh) - 1u) >> sh);
     }
     const uint32_t total_units = ustart[TK_NBIN];
-    uint32_t u = blockIdx.x * 4u + (uint32_t)wid;
+    uint32_t u = blockIdx.x * (uint32_t)TKM_WAVES + (uint32_t)wid;
     auto local_min = [&]() -> uint32_t {
         const uint4* q = (const uint4*)key;
         const uint4 a = q[0], b = q[1], c = q[2], d = q[3];
@@ -1870,24 +1882,123 @@ __global__ __launch_bounds__(256, TKM_WGS_PER_CU) void tk_k_merge_all(TkTables T
                 const uint32_t fl = __shfl(my_last, gbase + lp, 64);
                 pp = lo ? ob * C + 31u - (uint32_t)__clz((int)lo) : (lb ? fl : NONE);
             }
-            // the two new pairs: (merged, next) and (previous, merged)
             const uint32_t* pid = idw + gbase * C;  // the piece's positions
+            uint32_t* pkey = keyw + gbase * C;
+            if (lg >= 2 && !(dbg & 0x100000)) {
+                // TWO merges per step (pieces of four lanes and more; debug bit 0x100000: one).  The step's time is the latency of its
+                // table probes, and a long piece is a chain of hundreds of steps.  What the reference merges next (lib.rs:151,190) is the
+                // lowest key once more: either the lowest of the keys this merge leaves untouched -- known now -- or one of the two it
+                // creates.  So the second-lowest untouched key's merge is prepared at once, its neighbours taken from the state this
+                // merge leaves behind and its two probes sent along by lanes 2 and 3, and it is carried out iff both new keys of the first
+                // merge come out above it: then it IS the reference's next merge.  (Keys hold the position: no ties.)
+                // merge 1, the part that does not wait for a probe: the merged token's id, the absorbed part
+                if (!fin) {
+                    if (g == ob) {
+                        id[bl] = brank;
+                        key[bl] = TKM_NOKEY;  // (until the probe is back: not a candidate for the second merge)
+                    }
+                    if (g == oj) {
+                        mask &= ~(1u << jl);
+                        key[jl] = TKM_NOKEY;
+                    }
+                    if (pp != NONE && g == pp / C) pkey[pp] = TKM_NOKEY;
+                }
+                __builtin_amdgcn_wave_barrier();
+                const bool touched1 = !fin && (g == ob || g == oj || (pp != NONE && g == pp / C));
+                const uint32_t lkey2 = touched1 ? local_min() : lkey;
+                const uint32_t best2 = fin ? TKM_NOKEY : tkm_group_min(lkey2, lg);
+                const bool has2 = best2 != TKM_NOKEY;
+                const uint32_t bi2 = best2 & (NMAX - 1u), rank2 = best2 >> 10, ob2 = bi2 / C, bl2 = bi2 % C;
+                uint32_t j2 = 0, nn2 = NONE, pp2 = NONE;
+                {
+                    const uint64_t nbw2 = __ballot(mask != 0);
+                    const uint64_t nb2 = lg == 6 ? nbw2 : ((nbw2 >> gbase) & ((1ull << G) - 1ull));
+                    const uint32_t first2 = mask ? (uint32_t)(g * C + __ffs((int)mask) - 1) : NONE;
+                    const uint32_t last2 = mask ? (uint32_t)(g * C + 31 - __clz((int)mask)) : NONE;
+                    const uint32_t om2 = __shfl(mask, gbase + (int)ob2, 64);
+                    {
+                        const uint32_t hi = om2 & ~((2u << bl2) - 1u);
+                        const uint64_t la = nb2 & ~((2ull << ob2) - 1ull);
+                        const int lj = la ? __ffsll((unsigned long long)la) - 1 : 0;
+                        const uint32_t fj = __shfl(first2, gbase + lj, 64);
+                        j2 = (hi ? ob2 * C + (uint32_t)__ffs((int)hi) - 1u : fj) & (NMAX - 1u);
+                    }
+                    const uint32_t oj2 = j2 / C, jl2 = j2 % C;
+                    {
+                        const uint32_t ojm = __shfl(mask, gbase + (int)oj2, 64);
+                        const uint32_t hi = ojm & ~((2u << jl2) - 1u);
+                        const uint64_t la = nb2 & ~((2ull << oj2) - 1ull);
+                        const int ln = la ? __ffsll((unsigned long long)la) - 1 : 0;
+                        const uint32_t fn = __shfl(first2, gbase + ln, 64);
+                        nn2 = hi ? oj2 * C + (uint32_t)__ffs((int)hi) - 1u : (la ? fn : NONE);
+                    }
+                    {
+                        const uint32_t lo = om2 & ((1u << bl2) - 1u);
+                        const uint64_t lb = nb2 & ((1ull << ob2) - 1ull);
+                        const int lp = lb ? 63 - __clzll((long long)lb) : 0;
+                        const uint32_t fl = __shfl(last2, gbase + lp, 64);
+                        pp2 = lo ? ob2 * C + 31u - (uint32_t)__clz((int)lo) : (lb ? fl : NONE);
+                    }
+                }
+                // (ONE probe region for the four lanes: four `if (g == ..) probe` statements run one after the other, each waiting for its own
+                // loads -- the step would take four table latencies instead of one)
+                uint32_t newr = TK_RANK_MAX;
+                {
+                    const uint32_t nb_pos = g == 0 ? nn : (g == 1 ? pp : (g == 2 ? nn2 : pp2));  // the neighbour this lane's pair is made with
+                    const bool second = g >= 2, left = (g & 1u) != 0;                             // lanes 1, 3: (previous, merged)
+                    const bool on = !fin && g < 4u && nb_pos != NONE && (!second || has2) && !(dbg & 0x1000000);  // (0x1000000, perf experiments: no probes)
+                    const uint32_t nid = pid[nb_pos != NONE ? nb_pos : 0u], mid = second ? rank2 : brank;
+                    if (on) newr = tk_probe_pair(T, left ? nid : mid, left ? mid : nid);
+                }
+                const uint32_t newr_i = __shfl(newr, gbase, 64), newr_p = __shfl(newr, gbase + 1, 64);
+                const uint32_t newr_i2 = __shfl(newr, gbase + 2, 64), newr_p2 = __shfl(newr, gbase + 3, 64);
+                const uint32_t nk_i = tkm_key(newr_i, bi), nk_p = pp != NONE ? tkm_key(newr_p, pp) : TKM_NOKEY;
+                const bool take2 = !fin && has2 && best2 < nk_i && best2 < nk_p;
+                __builtin_amdgcn_wave_barrier();
+                bool touched = touched1;
+                if (!fin) {
+                    if (g == ob) key[bl] = nk_i;
+                    if (pp != NONE && g == pp / C) pkey[pp] = nk_p;
+                    if (take2) {  // (after the first merge's keys: a position the two share ends up with the second's)
+                        const uint32_t oj2 = j2 / C, jl2 = j2 % C;
+                        if (g == ob2) {
+                            id[bl2] = rank2;
+                            key[bl2] = tkm_key(newr_i2, bi2);
+                            touched = true;
+                        }
+                        if (g == oj2) {
+                            mask &= ~(1u << jl2);
+                            key[jl2] = TKM_NOKEY;
+                            touched = true;
+                        }
+                        if (pp2 != NONE && g == pp2 / C) {
+                            pkey[pp2] = tkm_key(newr_p2, pp2);
+                            touched = true;
+                        }
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+                if (touched) lkey = local_min();
+                continue;
+            }
+            // the two new pairs: (merged, next) and (previous, merged)
             uint32_t newr_i = TK_RANK_MAX, newr_p = TK_RANK_MAX;
             if (dbg & 0x1000000) {  // (perf experiments: no probes -- wrong tokens, the cost of everything else)
             } else if (lg == 0) {
                 if (!fin) tkm_probe2(T, brank, nn != NONE ? pid[nn & (NMAX - 1u)] : 0u, nn != NONE, pp != NONE ? pid[pp & (NMAX - 1u)] : 0u, brank, pp != NONE, newr_i, newr_p);
             } else {
                 uint32_t newr = TK_RANK_MAX;
-                if (!fin) {
-                    if (g == 0 && nn != NONE) newr = tk_probe_pair(T, brank, pid[nn]);
-                    if (g == 1 && pp != NONE) newr = tk_probe_pair(T, pid[pp], brank);
+                {  // (one probe region for both lanes: see above)
+                    const uint32_t nb_pos = g == 0 ? nn : pp;
+                    const bool on = !fin && g < 2u && nb_pos != NONE;
+                    const uint32_t nid = pid[nb_pos != NONE ? nb_pos : 0u];
+                    if (on) newr = tk_probe_pair(T, g ? nid : brank, g ? brank : nid);
                 }
                 newr_i = __shfl(newr, gbase, 64);
                 newr_p = __shfl(newr, gbase + 1, 64);
             }
             __builtin_amdgcn_wave_barrier();
             bool touched = false;
-            uint32_t* pkey = keyw + gbase * C;
             if (!fin) {
                 if (g == ob) {
                     id[bl] = brank;
@@ -1936,7 +2047,7 @@ __global__ __launch_bounds__(256, TKM_WGS_PER_CU) void tk_k_merge_all(TkTables T
         // units nwaves + c, nwaves + c + 16, ...
         uint32_t nu = 0;
         {
-            const uint32_t cidx = (blockIdx.x * 4u + (uint32_t)wid) & 15u;
+            const uint32_t cidx = (blockIdx.x * (uint32_t)TKM_WAVES + (uint32_t)wid) & 15u;
             if (lane == 0) nu = nwaves + cidx + 16u * atomicAdd(&work[cidx * TKM_WORK_STRIDE], 1u);
         }
         u = (uint32_t)__shfl((int)nu, 0, 64);
@@ -2452,7 +2563,10 @@ __global__ __launch_bounds__(256) void tk_k_count_tiles(uint64_t ntiles, const u
 // the missed pieces' entries {count, first token}, then row by row: single tokens go out as one 16-byte store per lane; a missed
 // piece's other tokens come from its entry (three 16-byte loads at most: the line is in the cache, the head came from it); what does
 // not fit an entry -- more than TKD_INLINE tokens, overflow entries -- is copied from the staging area by 32 lanes per piece.
-__global__ __launch_bounds__(256) void tk_k_place(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_tb,
+#ifndef TKP_PLACE_OCC
+#define TKP_PLACE_OCC 1
+#endif
+__global__ __launch_bounds__(256, TKP_PLACE_OCC) void tk_k_place(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_tb,
                                                   const uint32_t* __restrict__ res, TkMiss data, const uint32_t* __restrict__ staging, uint32_t* __restrict__ out_all,
                                                   const unsigned long long* __restrict__ tok_base, uint32_t* __restrict__ big) {
     __shared__ uint32_t mlist_sh[4][256 * 3];

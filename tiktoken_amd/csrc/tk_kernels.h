@@ -330,15 +330,20 @@ __global__ __launch_bounds__(256) void tk_k_count(const uint32_t* __restrict__ s
     if (threadIdx.x == 0) blockcnt[blockIdx.x] = sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// The scan kernels run with workgroups of 256 threads: in a multi-chunk batch they are queued beside the next chunk's front kernel, whose
+// workgroups (256 threads, 64 registers) fill the device -- a workgroup of the same shape gets the place of one that ends, one of 1024
+// threads waits until the front kernel is over (seen in round 4: 2.3 ms for a 20 us scan).
+#define TK_SCAN_THREADS 256
 // single-workgroup exclusive scan of a (small) uint32 array in place; total -> total_out[0] (u64)
-__global__ __launch_bounds__(1024) void tk_k_scan_small(uint32_t* __restrict__ a, uint64_t n, uint64_t* __restrict__ total_out) {
-    __shared__ uint32_t wsum[16];
+__global__ __launch_bounds__(TK_SCAN_THREADS) void tk_k_scan_small(uint32_t* __restrict__ a, uint64_t n, uint64_t* __restrict__ total_out) {
+    constexpr int NW = TK_SCAN_THREADS / 64;
+    __shared__ uint32_t wsum[NW];
     __shared__ uint64_t carry_sh;
     if (threadIdx.x == 0) carry_sh = 0;
     __syncthreads();
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    constexpr int E = 8;  // consecutive elements per thread
-    for (uint64_t base = 0; base < n; base += 1024 * E) {
+    constexpr int E = 16;  // consecutive elements per thread
+    for (uint64_t base = 0; base < n; base += TK_SCAN_THREADS * E) {
         const uint64_t i0 = base + (uint64_t)threadIdx.x * E;
         uint32_t v[E], mine = 0;
 #pragma unroll
@@ -350,7 +355,8 @@ __global__ __launch_bounds__(1024) void tk_k_scan_small(uint32_t* __restrict__ a
         if (lane == 63) wsum[wid] = inc;
         __syncthreads();
         uint32_t wbase = 0, tot = 0;
-        for (int w = 0; w < 16; ++w) {
+#pragma unroll
+        for (int w = 0; w < NW; ++w) {
             if (w < wid) wbase += wsum[w];
             tot += wsum[w];
         }
@@ -369,30 +375,33 @@ __global__ __launch_bounds__(1024) void tk_k_scan_small(uint32_t* __restrict__ a
 }
 
 // Larger arrays: reduce, scan the sums, scan again with the bases (three short launches instead of one workgroup walking everything).
-#define TK_SCAN_BLOCK 8192  // elements per workgroup of the two wide passes (1024 threads x 8)
-__global__ __launch_bounds__(1024) void tk_k_scan_sums(const uint32_t* __restrict__ a, uint64_t n, uint32_t* __restrict__ sums) {
-    __shared__ uint32_t wsum[16];
-    const uint64_t i0 = (uint64_t)blockIdx.x * TK_SCAN_BLOCK + (uint64_t)threadIdx.x * 8;
+#define TK_SCAN_BLOCK 4096  // elements per workgroup of the two wide passes (256 threads x 16)
+__global__ __launch_bounds__(TK_SCAN_THREADS) void tk_k_scan_sums(const uint32_t* __restrict__ a, uint64_t n, uint32_t* __restrict__ sums) {
+    constexpr int NW = TK_SCAN_THREADS / 64, E = TK_SCAN_BLOCK / TK_SCAN_THREADS;
+    __shared__ uint32_t wsum[NW];
+    const uint64_t i0 = (uint64_t)blockIdx.x * TK_SCAN_BLOCK + (uint64_t)threadIdx.x * E;
     uint32_t mine = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) mine += i0 + j < n ? a[i0 + j] : 0u;
+    for (int j = 0; j < E; ++j) mine += i0 + j < n ? a[i0 + j] : 0u;
     mine = tk_wave_sum_u32(mine);
     if ((threadIdx.x & 63) == 0) wsum[threadIdx.x >> 6] = mine;
     __syncthreads();
     if (threadIdx.x == 0) {
         uint32_t t = 0;
-        for (int w = 0; w < 16; ++w) t += wsum[w];
+#pragma unroll
+        for (int w = 0; w < NW; ++w) t += wsum[w];
         sums[blockIdx.x] = t;
     }
 }
 // bases[b] = exclusive prefix of the sums (tk_k_scan_small over them); a <- exclusive prefix of a, in place
-__global__ __launch_bounds__(1024) void tk_k_scan_apply(uint32_t* __restrict__ a, uint64_t n, const uint32_t* __restrict__ bases) {
-    __shared__ uint32_t wsum[16];
+__global__ __launch_bounds__(TK_SCAN_THREADS) void tk_k_scan_apply(uint32_t* __restrict__ a, uint64_t n, const uint32_t* __restrict__ bases) {
+    constexpr int NW = TK_SCAN_THREADS / 64, E = TK_SCAN_BLOCK / TK_SCAN_THREADS;
+    __shared__ uint32_t wsum[NW];
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
-    const uint64_t i0 = (uint64_t)blockIdx.x * TK_SCAN_BLOCK + (uint64_t)threadIdx.x * 8;
-    uint32_t v[8], mine = 0;
+    const uint64_t i0 = (uint64_t)blockIdx.x * TK_SCAN_BLOCK + (uint64_t)threadIdx.x * E;
+    uint32_t v[E], mine = 0;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < E; ++j) {
         v[j] = i0 + j < n ? a[i0 + j] : 0u;
         mine += v[j];
     }
@@ -403,7 +412,7 @@ __global__ __launch_bounds__(1024) void tk_k_scan_apply(uint32_t* __restrict__ a
     for (int w = 0; w < wid; ++w) wbase += wsum[w];
     uint32_t run = bases[blockIdx.x] + wbase + inc - mine;
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
+    for (int j = 0; j < E; ++j) {
         if (i0 + j < n) a[i0 + j] = run;
         run += v[j];
     }

@@ -47,7 +47,7 @@ def main():
         dt, nt, do = run()
     torch.cuda.synchronize()
     ms = (time.perf_counter() - t0) / args.steps * 1e3
-    host = {k: core.stat(k) for k in ("chunks", "host_front_us", "host_back_us", "host_back_wait_us", "host_finish_us", "host_tail_us", "host_total_us")}
+    host = {k: core.stat(k) for k in ("chunks", "back_streams", "host_front_us", "host_back_us", "host_back_wait_us", "host_finish_us", "host_tail_us", "host_total_us")}
     core.set_profiling(True)
     core.reset_kernel_ms()
     for _ in range(2):
