@@ -2522,8 +2522,10 @@ __global__ __launch_bounds__(256) void tk_k_count_tiles(uint64_t ntiles, const u
     const int lane = threadIdx.x & 63;
     const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
     unsigned long long pieces = 0;
+    uint32_t np_next = wave < ntiles ? tile_np[wave] : 0u;
     for (uint64_t t = wave; t < ntiles; t += nwaves) {
-        const uint32_t np = tile_np[t], rb = (uint32_t)t * TKF_CAP;
+        const uint32_t np = np_next, rb = (uint32_t)t * TKF_CAP;
+        np_next = t + nwaves < ntiles ? tile_np[t + nwaves] : 0u;  // (the next tile's size is on its way while this tile is counted)
         pieces += np;
         uint32_t run = 0;
         for (uint32_t k0 = 0; k0 < np; k0 += 256u * TKP_ROWS_COUNT) {
@@ -2531,19 +2533,34 @@ __global__ __launch_bounds__(256) void tk_k_count_tiles(uint64_t ntiles, const u
 #pragma unroll
             for (int r = 0; r < TKP_ROWS_COUNT; ++r) {
                 const uint32_t k = k0 + (uint32_t)r * 256u + (uint32_t)lane * 4u;
-                t4[r] = make_uint4(TK_RES_GAP, TK_RES_GAP, TK_RES_GAP, TK_RES_GAP);
-                if (k < np) t4[r] = *(const uint4*)(res + rb + k);  // (runs start 16-byte aligned, and a run's storage extends to the next multiple of four)
+                t4[r] = *(const uint4*)(res + rb + (k < np ? k : 0u));  // (runs start 16-byte aligned, and a run's storage extends to the next multiple of four; no `if` around the load)
             }
+            // (the count bytes of all the missed pieces by loads that do not depend on anything but the result words: a load inside an
+            // `if` of its own waits for its data before the next `if` is even looked at -- twelve latencies one after the other)
             uint32_t c[TKP_ROWS_COUNT][4];
+            bool escape = false;  // a piece whose count is not in the byte array (an overflow entry, 255 tokens and more)
 #pragma unroll
             for (int r = 0; r < TKP_ROWS_COUNT; ++r) {
                 const uint32_t k = k0 + (uint32_t)r * 256u + (uint32_t)lane * 4u;
                 const uint32_t w[4] = {t4[r].x, t4[r].y, t4[r].z, t4[r].w};
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
-                    const bool live = k + j < np;
-                    c[r][j] = (live && w[j] != TK_RES_GAP) ? 1u : 0u;
-                    if (live && (w[j] & TK_RES_FLAG)) c[r][j] = data.count(w[j] & ~TK_RES_FLAG);
+                    const bool live = k + j < np, flagged = live && (w[j] & TK_RES_FLAG), in_tab = flagged && (w[j] & ~TK_RES_FLAG) < data.ovf_base;
+                    const uint32_t cb = data.cnt8[in_tab ? (w[j] & ~TK_RES_FLAG) : 0u];
+                    c[r][j] = flagged ? cb : ((live && w[j] != TK_RES_GAP) ? 1u : 0u);
+                    if (flagged && (!in_tab || cb == 255u)) {
+                        c[r][j] = 0xFFFFFFFFu;
+                        escape = true;
+                    }
+                }
+            }
+            if (__ballot(escape)) {
+#pragma unroll
+                for (int r = 0; r < TKP_ROWS_COUNT; ++r) {
+                    const uint32_t w[4] = {t4[r].x, t4[r].y, t4[r].z, t4[r].w};
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (c[r][j] == 0xFFFFFFFFu) c[r][j] = TKD_COUNT(data.head(w[j] & ~TK_RES_FLAG)[2]);
                 }
             }
 #pragma unroll
@@ -2576,17 +2593,19 @@ __global__ __launch_bounds__(256, TKP_PLACE_OCC) void tk_k_place(uint64_t ntiles
     const int lane = threadIdx.x & 63;
     uint32_t* mlist = mlist_sh[threadIdx.x >> 6];
     const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
+    uint32_t np_next = wave < ntiles ? tile_np[wave] : 0u, tb_next = wave < ntiles ? tile_tb[wave] : 0u;
     for (uint64_t t = wave; t < ntiles; t += nwaves) {
-        const uint32_t np = tile_np[t], rb = (uint32_t)t * TKF_CAP;
-        uint32_t run = tile_tb[t];  // (token offsets within a chunk fit 32 bits: a chunk is less than 4 GiB of text)
+        const uint32_t np = np_next, rb = (uint32_t)t * TKF_CAP;
+        uint32_t run = tb_next;  // (token offsets within a chunk fit 32 bits: a chunk is less than 4 GiB of text)
+        np_next = t + nwaves < ntiles ? tile_np[t + nwaves] : 0u;  // (the next tile's size and base are on their way while this tile is placed)
+        tb_next = t + nwaves < ntiles ? tile_tb[t + nwaves] : 0u;
         for (uint32_t k0 = 0; k0 < np; k0 += 256u * TKP_ROWS_PLACE) {
             uint32_t tk[TKP_ROWS_PLACE][4];
             uint2 hd[TKP_ROWS_PLACE][4];
 #pragma unroll
             for (int r = 0; r < TKP_ROWS_PLACE; ++r) {
                 const uint32_t k = k0 + (uint32_t)r * 256u + (uint32_t)lane * 4u;
-                uint4 t4 = make_uint4(TK_RES_GAP, TK_RES_GAP, TK_RES_GAP, TK_RES_GAP);
-                if (k < np) t4 = *(const uint4*)(res + rb + k);
+                const uint4 t4 = *(const uint4*)(res + rb + (k < np ? k : 0u));  // (no `if` around the load: the rows are in flight together)
                 tk[r][0] = k < np ? t4.x : TK_RES_GAP;  // (dead words of a run's last four count as "no token")
                 tk[r][1] = k + 1 < np ? t4.y : TK_RES_GAP;
                 tk[r][2] = k + 2 < np ? t4.z : TK_RES_GAP;
@@ -2595,10 +2614,8 @@ __global__ __launch_bounds__(256, TKP_PLACE_OCC) void tk_k_place(uint64_t ntiles
 #pragma unroll
             for (int r = 0; r < TKP_ROWS_PLACE; ++r) {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    hd[r][j] = make_uint2(0u, 0u);
-                    if (tk[r][j] & TK_RES_FLAG) hd[r][j] = data.result(tk[r][j] & ~TK_RES_FLAG);
-                }
+                for (int j = 0; j < 4; ++j)  // (no `if` around the load: all the heads are in flight together; a piece without an entry reads the first overflow entry)
+                    hd[r][j] = data.result((tk[r][j] & TK_RES_FLAG) ? (tk[r][j] & ~TK_RES_FLAG) : data.ovf_base);
             }
 #pragma unroll
             for (int r = 0; r < TKP_ROWS_PLACE; ++r) {
@@ -2610,6 +2627,12 @@ __global__ __launch_bounds__(256, TKP_PLACE_OCC) void tk_k_place(uint64_t ntiles
                 const uint32_t inc = tk_wave_scan_u32(mine, lane);
                 const uint32_t o = run + inc - mine;
                 uint32_t nst = 0;  // pieces of the lane whose tokens are in the staging area
+                uint4 a4[4];       // tok[1 .. 4] of the lane's pieces whose tokens lie in their entries: four loads in flight
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool inl = (tk[r][j] & TK_RES_FLAG) && c[j] > 1u && (hd[r][j].x & TKD_INLINE_BIT);
+                    a4[j] = *(const uint4*)(inl ? (const uint32_t*)(data.tab[tk[r][j] & ~TK_RES_FLAG].tok + 1) : (const uint32_t*)data.ovf);
+                }
                 if (c[0] == 1u && c[1] == 1u && c[2] == 1u && c[3] == 1u && !((tk[r][0] | tk[r][1] | tk[r][2] | tk[r][3]) & TK_RES_FLAG)) {
                     *(uint4*)(out + o) = make_uint4(tk[r][0], tk[r][1], tk[r][2], tk[r][3]);  // (4-byte aligned 16-byte store)
                 } else {
@@ -2622,8 +2645,8 @@ __global__ __launch_bounds__(256, TKP_PLACE_OCC) void tk_k_place(uint64_t ntiles
                             out[oo] = hd[r][j].y;
                         } else if (hd[r][j].x & TKD_INLINE_BIT) {
                             const uint32_t* tokp = data.tab[tk[r][j] & ~TK_RES_FLAG].tok;
-                            uint4 a = make_uint4(0, 0, 0, 0), b = a, d = a;
-                            a = *(const uint4*)(tokp + 1);  // tok[1 .. 4] (the entry is a 64-byte line; tok[0] is its fourth word)
+                            const uint4 a = a4[j];  // tok[1 .. 4] (the entry is a 64-byte line; tok[0] is its fourth word)
+                            uint4 b = make_uint4(0, 0, 0, 0), d = b;
                             if (c[j] > 5u) b = *(const uint4*)(tokp + 5);
                             if (c[j] > 9u) d = *(const uint4*)(tokp + 9);
                             uint32_t* q = out + oo;
