@@ -168,6 +168,24 @@ def generic_engine_figure(encoding: str, mib: int = 256):
         return {"error": f"{type(e).__name__}: {str(e)[:200]}"}
 
 
+def other_configs_figure():
+    """BASELINE.json's other configurations at their full sizes -- C1 (gpt2-shaped, one 1 MiB document), C2 (cl100k-shaped, 64 MiB mixed
+    UTF-8), C5 (o200k-shaped + 8 custom special tokens, 256 MiB, allowed_special="all") -- by tools/bench_configs.py in a process of its own:
+    rate from HBM-resident inputs and every token against the oracle.  Reported beside the headline, never part of `value`."""
+    import subprocess
+
+    try:
+        r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "bench_configs.py")], capture_output=True, text=True, timeout=400)
+        out = {}
+        for ln in r.stdout.strip().splitlines():
+            if ln.startswith("{"):
+                j = json.loads(ln)
+                out[j["config"].split()[0]] = {k: j[k] for k in ("config", "bytes", "docs", "tokens", "ms_per_step", "GBps", "parity_all_tokens", "kernels_ms_avg") if k in j}
+        return out or {"error": (r.stderr or "no output")[-200:]}
+    except Exception as e:
+        return {"error": f"{type(e).__name__}: {str(e)[:200]}"}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -230,24 +248,28 @@ def main():
     d_off = torch.from_numpy(doc_off.view(np.int64)).cuda()
     torch.cuda.synchronize()
 
-    # N > 1: rank 0 gathers every rank's token ids (one padded RCCL gather per step: 7 senders -> 7 xGMI links).  The
-    # transfer of step k runs while step k + 1 is being encoded (the library reuses its output buffer, so the ids
-    # are copied to a tensor first); drain() waits for the last one INSIDE the timed region.
+    # N > 1: rank 0 gathers every rank's token ids -- one grouped RCCL send / recv per step at the exact lengths (7 senders -> 7 xGMI
+    # links into rank 0).  The transfer of step k runs while step k + 1 is being encoded: the library alternates between two pairs of
+    # result buffers (tk_set_output_buffers), so the ids are sent from where the encoder left them, without a copy; drain() waits for
+    # the last transfer INSIDE the timed region.  `value` includes the gather; `value_encode_only` (below) is the same loop without it.
     pending = [None]
+    if world > 1:
+        core.set_output_buffers(2)
 
-    def step():
+    def step(gather=True):
         dt, nt, do = core.encode_batch_device(d_text.data_ptr(), nbytes, d_off.data_ptr(), doc_off, n_docs)
-        if world > 1:
-            toks = torch.as_tensor(DevArray(dt, max(nt, 1), "<i4"), device="cuda").clone()
-            cur = gather_tokens(toks, nt, rank, world, dist, torch, async_op=True)
+        if world > 1 and gather:
+            toks = torch.as_tensor(DevArray(dt, max(nt, 1), "<i4"), device="cuda")  # (a view of the library's buffer: valid until the call after the next)
             if pending[0] is not None:
                 pending[0].wait()
-            pending[0] = cur
+                torch.cuda.current_stream().synchronize()  # (wait() orders torch's stream only; the encoder runs on the library's: the buffer of step k - 1 is written again by step k + 1)
+            pending[0] = gather_tokens(toks, nt, rank, world, dist, torch, async_op=True)
         return dt, nt, do
 
     def drain():
         if pending[0] is not None:
             pending[0].wait()
+            torch.cuda.current_stream().synchronize()
             pending[0] = None
 
     for _ in range(args.warmup):
@@ -275,6 +297,18 @@ def main():
         total_bytes, total_tokens = nbytes, nt
     ms_per_step = elapsed / args.steps * 1e3
     value = total_bytes * args.steps / elapsed / 1e9
+    value_encode_only = None
+    if dist:  # the same K steps without the gather: what the encoders do when nobody collects the ids on one rank
+        torch.cuda.synchronize()
+        dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            step(gather=False)
+        torch.cuda.synchronize()
+        dist.barrier()
+        el2 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        dist.all_reduce(el2, op=dist.ReduceOp.MAX)
+        value_encode_only = round(total_bytes * args.steps / float(el2.item()) / 1e9, 3)
 
     # ---- per-kernel durations (HIP events on the library's stream), one profiled pass
     core.set_profiling(True)
@@ -446,14 +480,17 @@ def main():
             cold = dict(best, what=f"{args.encoding}: vocabulary file -> Encoding -> first encode(), library loaded and device initialised, best of 3")
 
     generic = None
+    configs = None
     if rank == 0 and world == 1 and not args.no_host_path and not args.generic_engine:
         generic = generic_engine_figure(args.encoding)
+        configs = other_configs_figure()
 
     if rank == 0:
         line = {
             "metric": "GB/s text encoded (o200k_base-shaped vocab, 1 GiB corpus per GPU), bit-exact vs CoreBPE restatement",
             "value": round(value, 3), "unit": "GB/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "value_encode_only": value_encode_only,
             "dtype": "u8", "data": "synthetic",
             "config": {"workload": f"{args.encoding} encode_ordinary_batch, {args.mib} MiB synthetic web-text per GPU "
                                    f"(tkc_generate mix=1, seed {'0x5EED0003' if world == 1 else '0x5EED0004+rank'}), "
@@ -463,7 +500,7 @@ def main():
                        "tokens_total": total_tokens, "pieces_rank0": stats["pieces"],
                        "parallelism": f"doc-sharded x{world}" + (" + RCCL gather of token ids to rank 0" if world > 1 else "")},
             "roofline": roofline, "cpu_baseline": cpu, "parity_all_tokens_vs_oracle": parity, "host_path": host_path,
-            "lds_piece_cache": hot, "cold_start": cold, "generic_engine": generic,
+            "lds_piece_cache": hot, "cold_start": cold, "generic_engine": generic, "configs": configs,
             "host": {"cpus": ncpu, "nproc": os.cpu_count(), "cgroup_cpu_max": _read_first("/sys/fs/cgroup/cpu.max"),
                      "loadavg": _read_first("/proc/loadavg"), "corpus_gen_s": round(t_gen, 2)},
         }
@@ -471,7 +508,8 @@ def main():
         hf = (cpu or {}).get("rust_cpu_tokenizer_for_context") or {}
         if parity is False or hf.get("same_ids_as_oracle_on_a_sample_of_documents") is False or \
                 (host_path or {}).get("t2_identical_to_checked_result") is False or (host_path or {}).get("decode_identical_to_the_text") is False or \
-                (generic or {}).get("all_tokens_equal_to_the_oracle") is False:
+                (generic or {}).get("all_tokens_equal_to_the_oracle") is False or \
+                any(c.get("parity_all_tokens") is False for c in (configs or {}).values() if isinstance(c, dict)):
             print("bench: a parity check failed (see the line above)", file=sys.stderr)
             sys.exit(3)
     if dist:

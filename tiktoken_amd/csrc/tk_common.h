@@ -217,5 +217,11 @@ TK_HD uint64_t tk_hash_step(uint64_t h, uint64_t w) {
     return x + 0x9E3779B97F4A7C15ull;
 }
 #define TK_HASH_SEED 0x243F6A8885A308D3ull
+// Keys of pieces longer than TK_KEY_SAMPLED bytes hash the length and four 8-byte words -- the first sixteen and the last sixteen bytes --
+// instead of every byte: a key only selects the slots to look at (vocabulary entries are verified against the token blob, missed pieces
+// against the claimant's text), and on the device a row of 64 pieces pays for the hash of its LONGEST piece (25 instructions per 8 bytes:
+// 50 rounds for a 400-byte run of Thai letters).  The three forms of the function (tk_key_of_bytes on the host, tk_key_of_text, tk_key_of_lds)
+// follow this one rule.
+#define TK_KEY_SAMPLED 32u
 #define TK_PAIR8_ID_BITS 21
 #define TK_PAIR8_MAX_ID ((1u << TK_PAIR8_ID_BITS) - 2u)  // ids above this force the wide format

@@ -835,6 +835,14 @@ TK_HD uint64_t tk_mask_low_bytes(uint64_t w, uint32_t nbytes) {  // keep the low
 // key of text[pos .. pos+len) (same function as host tk_key_of_bytes)
 TK_HD uint64_t tk_key_of_text(const uint8_t* __restrict__ text, uint64_t pos, uint32_t len) {
     if (len <= 8u) return tk_mask_low_bytes(tk_load8(text, pos), len);
+    if (len > TK_KEY_SAMPLED) {
+        uint64_t h = TK_HASH_SEED ^ ((uint64_t)len << 32);
+        h = tk_hash_step(h, tk_load8(text, pos));
+        h = tk_hash_step(h, tk_load8(text, pos + 8u));
+        h = tk_hash_step(h, tk_load8(text, pos + len - 16u));
+        h = tk_hash_step(h, tk_load8(text, pos + len - 8u));
+        return h == TK_EMPTY_KEY ? 0 : h;
+    }
     uint64_t h = TK_HASH_SEED;
     uint32_t i = 0;
     for (; i + 8u <= len; i += 8u) h = tk_hash_step(h, tk_load8(text, pos + i));

@@ -467,6 +467,14 @@ __device__ __forceinline__ uint64_t tk_lds_load8(const uint8_t* raw, uint32_t o)
 }
 __device__ __forceinline__ uint64_t tk_key_of_lds(const uint8_t* raw, uint32_t o, uint32_t len) {
     if (len <= 8u) return tk_mask_low_bytes(tk_lds_load8(raw, o), len);
+    if (len > TK_KEY_SAMPLED) {  // (tk_common.h: the length and four words)
+        uint64_t h = TK_HASH_SEED ^ ((uint64_t)len << 32);
+        h = tk_hash_step(h, tk_lds_load8(raw, o));
+        h = tk_hash_step(h, tk_lds_load8(raw, o + 8u));
+        h = tk_hash_step(h, tk_lds_load8(raw, o + len - 16u));
+        h = tk_hash_step(h, tk_lds_load8(raw, o + len - 8u));
+        return h == TK_EMPTY_KEY ? 0 : h;
+    }
     uint64_t h = TK_HASH_SEED;
     uint32_t i = 0;
     for (; i + 8u <= len; i += 8u) h = tk_hash_step(h, tk_lds_load8(raw, o + i));
@@ -1884,8 +1892,8 @@ __global__ __launch_bounds__(64 * TKM_WAVES, TKM_MIN_WAVES_EU) void tk_k_merge_a
             }
             const uint32_t* pid = idw + gbase * C;  // the piece's positions
             uint32_t* pkey = keyw + gbase * C;
-            if (lg >= 2 && !(dbg & 0x100000)) {
-                // TWO merges per step (pieces of four lanes and more; debug bit 0x100000: one).  The step's time is the latency of its
+            if (lg >= 2 && !(dbg & 0x80000)) {
+                // TWO merges per step (pieces of four lanes and more; debug bit 0x80000: one).  The step's time is the latency of its
                 // table probes, and a long piece is a chain of hundreds of steps.  What the reference merges next (lib.rs:151,190) is the
                 // lowest key once more: either the lowest of the keys this merge leaves untouched -- known now -- or one of the two it
                 // creates.  So the second-lowest untouched key's merge is prepared at once, its neighbours taken from the state this

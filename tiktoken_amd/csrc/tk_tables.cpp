@@ -43,6 +43,15 @@ uint64_t tk_key_of_bytes(const uint8_t* p, uint32_t len) {
         memcpy(&k, p, len);
         return k;
     }
+    if (len > TK_KEY_SAMPLED) {
+        uint64_t h = TK_HASH_SEED ^ ((uint64_t)len << 32);
+        for (uint32_t o : {0u, 8u, len - 16u, len - 8u}) {
+            uint64_t w;
+            memcpy(&w, p + o, 8);
+            h = tk_hash_step(h, w);
+        }
+        return h == TK_EMPTY_KEY ? 0 : h;
+    }
     uint64_t h = TK_HASH_SEED;
     uint32_t i = 0;
     for (; i + 8 <= len; i += 8) {

@@ -25,7 +25,7 @@ def main():
     import torch
 
     import helpers as h
-    from bench import DevArray
+    from bench import DevArray, KERNELS
     from tiktoken_amd._tiktoken import CoreBPE
     from tiktoken_ext import amd_shaped
 
@@ -45,6 +45,11 @@ def main():
             dt, nt, do = core.encode_batch_device(d_text.data_ptr(), n, d_off.data_ptr(), off, nd, allowed)
         torch.cuda.synchronize()
         el = (time.perf_counter() - t0) / steps
+        core.set_profiling(True)
+        core.reset_kernel_ms()
+        core.encode_batch_device(d_text.data_ptr(), n, d_off.data_ptr(), off, nd, allowed)
+        core.set_profiling(False)
+        kern = {k: round(core.kernel_ms(k)[0], 4) for k in KERNELS + ["tk_k_spec_cand", "tk_k_spec_resolve"] if core.kernel_ms(k)[1]}
         # parity: every document, every token
         pat_id = {"gpt2_shaped": 0, "cl100k_shaped": 1, "o200k_shaped": 2, "o200k_custom8": 2}[enc_name]
         C = h.c_oracle.COracle(pat_id, spec["mergeable_ranks"], spec["special_tokens"])
@@ -55,7 +60,7 @@ def main():
         g_tok = torch.as_tensor(DevArray(dt, max(nt, 1), "<i4"), device="cuda")[: int(g_off[-1])].cpu().numpy().view(np.uint32)
         ok = bool(np.array_equal(g_off, ro) and np.array_equal(g_tok, rt))
         print(json.dumps({"config": name, "encoding": enc_name, "bytes": n, "docs": nd, "tokens": nt, "ms_per_step": round(el * 1e3, 3),
-                          "GBps": round(n / el / 1e9, 3), "parity_all_tokens": ok}), flush=True)
+                          "GBps": round(n / el / 1e9, 3), "parity_all_tokens": ok, "kernels_ms_avg": kern}), flush=True)
 
     for cfg, title, enc_name, steps in (("C1", "C1 gpt2 1MiB lorem, 1 doc", "gpt2_shaped", 10), ("C2", "C2 cl100k 64MiB mixed UTF-8", "cl100k_shaped", 3),
                                        ("C5", "C5 o200k+8 specials 256MiB, allowed_special=all", "o200k_custom8", 3)):

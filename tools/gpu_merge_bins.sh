@@ -1,6 +1,6 @@
 #!/bin/bash
 # usage: bash tools/gpu_merge_bins.sh [DEBUG VALUES...] -- tk_k_merge_all with only ONE length bin merged (debug bits 25..28 = bin + 1; wrong tokens: timing only);
-# further bits: 0x1000000 no probes, 0x100000 one merge per step
+# further bits: 0x1000000 no probes, 0x80000 one merge per step
 cd $GRAFT_REPO_ROOT; mkdir -p gpurun_out/mbins; : > gpurun_out/mbins/out.txt
 for D in "$@"; do
   TIKTOKEN_AMD_DEBUG=$((D)) timeout 120 python tools/exp_front.py --tag d$D --steps 2 --no-parity 2>/dev/null | grep '^EXP ' | sed 's/^EXP //' | python -c "
