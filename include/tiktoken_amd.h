@@ -105,6 +105,12 @@ int tk_decode_bytes(tk_core* core, const uint32_t* tokens, uint64_t n, uint8_t**
  * when the ids are too sparse for a direct table (>= 2^26). */
 int tk_decode_batch(tk_core* core, const uint32_t* tokens, const uint64_t* tok_off, uint64_t n_docs, uint8_t** bytes_out,
                     uint64_t* n_bytes_out, uint64_t* byte_off_out);
+/* The same with everything resident in HBM: ids (uint32) and token offsets (uint64[n_docs + 1], may be null) on the core's device in,
+ * *d_bytes_out / *d_byte_off_out (library-owned device buffers, valid until the core's next decode call; *d_byte_off_out null without
+ * d_tok_off) and *n_bytes_out out.  `stream`: a hipStream_t or null (the core's).  The counterpart of tk_encode_batch_device for a
+ * consumer that keeps text on the device; no reference counterpart (the reference returns owned Vec<u8>s, src/lib.rs:345-358). */
+int tk_decode_batch_device(tk_core* core, const void* d_tokens, uint64_t n_tokens, const void* d_tok_off, uint64_t n_docs, void* stream,
+                           const uint8_t** d_bytes_out, uint64_t* n_bytes_out, const uint64_t** d_byte_off_out);
 /* CoreBPE.decode_single_token_bytes(token)  (pointer into the core; do not free)  src/py.rs:164-172 */
 int tk_decode_single_token_bytes(tk_core* core, uint32_t token, const uint8_t** bytes_out, uint64_t* len_out);
 /* CoreBPE.token_byte_values(): tokens in lexicographic byte order                  src/py.rs:178-183, lib.rs:648-650 */

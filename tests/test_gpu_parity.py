@@ -445,6 +445,43 @@ def test_decode_batch_on_device(cores):
     assert data == b"" and boff.tolist() == [0, 0, 0]
 
 
+def test_decode_in_ranges_and_on_the_device(cores):
+    """A batch of more than 16 Mi ids is decoded in ranges whose copies overlap (tk_decode_batch: ids in through page-locked staging, or
+    straight from a page-locked caller's buffer; bytes out while the next range is decoded); tk_decode_batch_device leaves ids and bytes
+    in HBM.  All of them: the text, byte for byte (src/lib.rs:345-358)."""
+    import torch
+
+    core = cores["o200k_shaped"]
+    blob, off = h.gen_corpus(0xDEC0DF, 1, 96 << 20)
+    n = int(off[-1])
+    toks, toff = core.encode_batch_packed(blob, off)  # (views of page-locked memory)
+    assert len(toks) > (16 << 20) + 1000
+    for src in (toks, np.array(toks)):  # the caller's buffer page-locked, then pageable
+        data, boff = core.decode_batch_packed(src, toff, as_array=True)
+        assert len(data) == n and np.array_equal(data, blob[:n]) and np.array_equal(boff, off)
+        del data
+    # an unknown id in the second range: the reference's KeyError with that id
+    bad = np.array(toks)
+    bad[(16 << 20) + 777] = 1999980
+    with pytest.raises(KeyError, match="Invalid token for decoding: 1999980"):
+        core.decode_batch_packed(bad, toff)
+    del bad
+    d_tok = torch.from_numpy(np.array(toks).view(np.int32)).cuda()
+    d_off = torch.from_numpy(np.array(toff).view(np.int64)).cuda()
+    torch.cuda.synchronize()
+    db, nb, do = core.decode_batch_device(d_tok.data_ptr(), len(toks), d_off.data_ptr(), len(toff) - 1)
+    assert nb == n and do
+    got = torch.as_tensor(h._DevArray(db, nb, "|u1"), device="cuda").cpu().numpy()
+    assert np.array_equal(got, blob[:n])
+    assert np.array_equal(h.dev_u64(do, len(toff)), off)
+    db, nb, do = core.decode_batch_device(d_tok.data_ptr(), 1000, 0, 0)  # no offsets: the bytes only
+    assert do == 0 and bytes(torch.as_tensor(h._DevArray(db, nb, "|u1"), device="cuda").cpu().numpy()) == core.decode_bytes(toks[:1000].tolist())
+    d_tok[5] = 1999980
+    torch.cuda.synchronize()
+    with pytest.raises(KeyError, match="Invalid token for decoding: 1999980"):
+        core.decode_batch_device(d_tok.data_ptr(), 1000, 0, 0)
+
+
 # ---------------------------------------------------------------- several devices in one process (virtual ranks on one GPU here)
 def test_multi_device_group_equals_single_device():
     """CoreBPE(devices=[...]): documents split into contiguous ranges of about equal bytes, one replica per device (tk_group_encode_batch);

@@ -69,6 +69,8 @@ def lib() -> ctypes.CDLL:
         L.tk_decode_bytes.argtypes = [vp, vp, u64, P(vp), P(u64)]
         L.tk_decode_batch.restype = i32
         L.tk_decode_batch.argtypes = [vp, vp, vp, u64, P(vp), P(u64), vp]
+        L.tk_decode_batch_device.restype = i32
+        L.tk_decode_batch_device.argtypes = [vp, vp, u64, vp, u64, vp, P(vp), P(u64), P(vp)]
         L.tk_decode_single_token_bytes.restype = i32
         L.tk_decode_single_token_bytes.argtypes = [vp, u32, P(vp), P(u64)]
         L.tk_n_tokens.restype = u64

@@ -429,6 +429,16 @@ class CoreBPE:
         self._L.tk_free(out)
         return (np.frombuffer(data, dtype=np.uint8) if as_array else data), byte_off
 
+    def decode_batch_device(self, d_tokens: int, n_tokens: int, d_tok_off: int, n_docs: int, stream: int = 0):
+        """Device-resident decode (tk_decode_batch_device): pointers to uint32 ids and uint64 token offsets (0: none) on this core's device ->
+        (device pointer to the bytes, number of bytes, device pointer to the n_docs + 1 byte offsets or 0).  The buffers are the library's and
+        stay valid until the next decode call."""
+        db, nb, do = ctypes.c_void_p(), ctypes.c_uint64(), ctypes.c_void_p()
+        rc = self._L.tk_decode_batch_device(self._h, d_tokens or None, n_tokens, d_tok_off or None, n_docs, stream or None, ctypes.byref(db),
+                                            ctypes.byref(nb), ctypes.byref(do))
+        _lib.raise_for(rc)
+        return db.value or 0, nb.value, do.value or 0
+
     def decode_single_token_bytes(self, token: int) -> bytes:
         if not 0 <= token <= 0xFFFFFFFF:
             raise KeyError(str(token))

@@ -147,7 +147,7 @@ struct tk_core {
     uint32_t rx_ahead = 0;           // 0: TK_RX_AHEAD / TK_RX_AHEAD_DFA by the kernels' form ($TIKTOKEN_AMD_RX_AHEAD: bytes)
     uint32_t front_wgs = TKF_OCC;    // workgroups per CU of the persistent front kernel ($TIKTOKEN_AMD_FRONT_WGS)
     uint32_t n_dec = 0;  // entries of the device decode table (0: ids too sparse for a direct table -- decode stays on the host)
-    Buf d_tok, d_lens, d_bsum, d_tboff, d_bytes, d_boff;  // decode workspace
+    Buf d_tok, d_lens, d_bsum, d_tboff, d_bytes, d_bytes_alt, d_boff;  // decode workspace (d_bytes_alt: the other range's bytes on their way to the host)
     // Small calls (tk_k_small) do not take `mu`: the reference's normal use is several threads on one Encoding (core.py:175, a thread pool
     // over encode; lib.rs:232-238 keeps a regex per thread for it), and a small call needs nothing of the shared workspace -- a slot of its
     // own (page-locked text and result buffers the kernel reads and writes directly, merge scratch, a stream) is all.  A caller takes a
@@ -471,7 +471,7 @@ extern "C" void tk_destroy(tk_core* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (Buf* b : {&c->t_rx_ins, &c->t_rx_sets, &c->t_rx_ranges, &c->t_rx_first, &c->t_rx_s1, &c->t_rx_s2, &c->t_rx_dtrans, &c->t_rx_dascii, &c->t_rx_ds1, &c->t_rx_ds2}) release(*b);
-    for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_dec, &c->d_tok, &c->d_lens, &c->d_bsum, &c->d_tboff, &c->d_bytes, &c->d_boff, &c->t_piece,
+    for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_dec, &c->d_tok, &c->d_lens, &c->d_bsum, &c->d_tboff, &c->d_bytes, &c->d_bytes_alt, &c->d_boff, &c->t_piece,
                    &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2, &c->t_byte_rank, &c->t_hot, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off,
                    &c->out_tokens, &c->out_tok_off, &c->out_tokens_alt, &c->out_tok_off_alt, &c->allowed, &c->tok_bases})
         release(*b);
@@ -1652,6 +1652,76 @@ extern "C" int tk_decode_bytes(tk_core* c, const uint32_t* tokens, uint64_t n, u
 }
 
 // CoreBPE.decode_bytes over a packed batch (Encoding.decode_bytes_batch / decode_batch, tiktoken/core.py:331-350), on the device.
+// One range of a packed batch on the device: lengths and their block sums, the scan, then (decode_range_copy) the bytes.
+//   d_tok: the batch's ids on the device; [a, a + cnt) the range (a: a multiple of TK_DEC_BLOCK); `tot`: two device words {bytes of the
+//   range, first invalid position (the caller sets it to ~0 once)}
+static int decode_range_len(tk_core* c, hipStream_t s, const uint32_t* d_tok, uint64_t a, uint64_t cnt, unsigned long long* tot) {
+    const uint64_t nb = (cnt + TK_DEC_BLOCK - 1) / TK_DEC_BLOCK;
+    unsigned long long* bsum = c->d_bsum.as<unsigned long long>() + a / TK_DEC_BLOCK;
+    TRY(timed(c, s, "tk_k_dec_len", [&] {
+        hipLaunchKernelGGL(tk_k_dec_len, dim3((uint32_t)nb), dim3(256), 0, s, d_tok + a, cnt, c->t_dec.as<uint2>(), c->n_dec, c->d_lens.as<uint32_t>() + a, bsum, tot + 1, a);
+    }));
+    hipLaunchKernelGGL(tk_k_dec_scan64, dim3(1), dim3(1024), 0, s, bsum, nb, tot);
+    return TK_OK;
+}
+static int decode_range_copy(tk_core* c, hipStream_t s, const uint32_t* d_tok, uint64_t a, uint64_t cnt, uint8_t* d_out, unsigned long long* d_tboff,
+                             uint64_t byte_base) {
+    const uint64_t nb = (cnt + TK_DEC_BLOCK - 1) / TK_DEC_BLOCK;
+    TRY(timed(c, s, "tk_k_dec_copy", [&] {
+        hipLaunchKernelGGL(tk_k_dec_copy, dim3((uint32_t)nb), dim3(256), 0, s, d_tok + a, cnt, c->t_dec.as<uint2>(), c->d_lens.as<uint32_t>() + a,
+                           c->d_bsum.as<unsigned long long>() + a / TK_DEC_BLOCK, c->D.tok_bytes, c->D.spec_bytes, d_out, d_tboff ? d_tboff + a : nullptr,
+                           (unsigned long long)byte_base);
+    }));
+    return TK_OK;
+}
+
+// Device-resident decode: ids and token offsets in HBM in, bytes and byte offsets in HBM out (library-owned buffers, valid until the core's
+// next decode call).  The host learns the byte count (one 16-byte copy): the output buffer is sized by it.
+extern "C" int tk_decode_batch_device(tk_core* c, const void* d_tokens, uint64_t n_tokens, const void* d_tok_off, uint64_t n_docs, void* stream,
+                                      const uint8_t** d_bytes_out, uint64_t* n_bytes_out, const uint64_t** d_byte_off_out) {
+    if (!c) return fail(TK_VALUE_ERROR, "core is null");
+    if (!n_bytes_out || (n_tokens && !d_tokens)) return fail(TK_VALUE_ERROR, "null argument");
+    if (!c->n_dec) return fail(TK_UNSUPPORTED, "token ids are too sparse for the device decode table");
+    std::lock_guard<std::mutex> lk(c->mu);
+    HIPCHK(hipSetDevice(c->device));
+    hipStream_t s = stream ? (hipStream_t)stream : c->stream;
+    const uint64_t n = n_tokens, nb = (n + TK_DEC_BLOCK - 1) / TK_DEC_BLOCK;
+    TRY(ensure(c->d_lens, (n + 1) * 4));
+    TRY(ensure(c->d_bsum, (nb + 8) * 8));
+    if (d_tok_off) TRY(ensure(c->d_tboff, (n + 1) * 8));
+    TRY(ensure(c->d_boff, (n_docs + 2) * 8 * 2));
+    unsigned long long* tot = c->d_bsum.as<unsigned long long>() + nb + 2;
+    unsigned long long h_tot[2] = {0, ~0ull};
+    HIPCHK(hipMemcpyAsync(tot, h_tot, 16, hipMemcpyHostToDevice, s));
+    if (n) TRY(decode_range_len(c, s, (const uint32_t*)d_tokens, 0, n, tot));
+    HIPCHK(hipMemcpyAsync(h_tot, tot, 16, hipMemcpyDeviceToHost, s));
+    HIPCHK(hipStreamSynchronize(s));
+    if (h_tot[1] != ~0ull) {
+        uint32_t bad_tok = 0;
+        (void)hipMemcpy(&bad_tok, (const uint32_t*)d_tokens + h_tot[1], 4, hipMemcpyDeviceToHost);
+        return fail(TK_KEY_ERROR, "Invalid token for decoding: " + std::to_string(bad_tok));
+    }
+    const uint64_t nbytes = h_tot[0];
+    TRY(ensure(c->d_bytes, nbytes + 16));
+    if (n) TRY(decode_range_copy(c, s, (const uint32_t*)d_tokens, 0, n, c->d_bytes.as<uint8_t>(), d_tok_off ? c->d_tboff.as<unsigned long long>() : nullptr, 0));
+    uint64_t* d_byte_off = c->d_boff.as<uint64_t>() + n_docs + 1;
+    if (d_tok_off)
+        hipLaunchKernelGGL(tk_k_dec_docoff, dim3(grid_for(n_docs + 1, 256, 4096)), dim3(256), 0, s, (const uint64_t*)d_tok_off, n_docs, n,
+                           c->d_tboff.as<unsigned long long>(), tot, d_byte_off);
+    HIPCHK(hipStreamSynchronize(s));
+    HIPCHK(hipGetLastError());
+    TRY(drain_events(c));
+    if (d_bytes_out) *d_bytes_out = c->d_bytes.as<uint8_t>();
+    if (d_byte_off_out) *d_byte_off_out = d_tok_off ? d_byte_off : nullptr;
+    *n_bytes_out = nbytes;
+    return TK_OK;
+}
+
+// Host buffers in, host buffers out.  The batch is decoded in ranges of 16 Mi ids: the ids of range k + 1 travel to the device (through
+// two page-locked staging buffers filled by a few host threads, or straight from the caller's buffer when that is page-locked itself:
+// the result of an encode call is) while range k is decoded and the bytes of range k - 1 travel back -- both directions of the link at
+// once.  The result buffer is page-locked and sized by the density of the ranges seen so far (grown by a copy if a later range is
+// denser).  A batch of less than two ranges takes one copy each way.
 extern "C" int tk_decode_batch(tk_core* c, const uint32_t* tokens, const uint64_t* tok_off, uint64_t n_docs, uint8_t** bytes_out,
                                uint64_t* n_bytes_out, uint64_t* byte_off_out) {
     if (!c) return fail(TK_VALUE_ERROR, "core is null");
@@ -1665,61 +1735,156 @@ extern "C" int tk_decode_batch(tk_core* c, const uint32_t* tokens, const uint64_
     HIPCHK(hipSetDevice(c->device));
     hipStream_t s = c->stream;
     const uint64_t nb = (n + TK_DEC_BLOCK - 1) / TK_DEC_BLOCK;
+    constexpr uint64_t RANGE = TK_STAGE_BYTES / 4;  // ids per range (a multiple of TK_DEC_BLOCK)
+    const uint64_t n_ranges = n ? (n + RANGE - 1) / RANGE : 0;
     TRY(ensure(c->d_tok, (n + 1) * 4));
     TRY(ensure(c->d_lens, (n + 1) * 4));
-    TRY(ensure(c->d_bsum, (nb + 4) * 8));
-    TRY(ensure(c->d_tboff, (n + 1) * 8));
+    TRY(ensure(c->d_bsum, (nb + 8 + 2 * n_ranges) * 8));
+    if (byte_off_out) TRY(ensure(c->d_tboff, (n + 1) * 8));
     TRY(ensure(c->d_boff, (n_docs + 2) * 8 * 2));
-    unsigned long long* total = c->d_bsum.as<unsigned long long>() + nb + 1;  // [0] total bytes, [1] first invalid position
-    unsigned long long h_tot[2] = {0, ~0ull};
-    HIPCHK(hipMemcpyAsync(total, h_tot, 16, hipMemcpyHostToDevice, s));
-    if (n) {
-        HIPCHK(hipMemcpyAsync(c->d_tok.p, tokens, n * 4, hipMemcpyHostToDevice, s));
-        TRY(timed(c, s, "tk_k_dec_len", [&] {
-            hipLaunchKernelGGL(tk_k_dec_len, dim3((uint32_t)nb), dim3(256), 0, s, c->d_tok.as<uint32_t>(), n, c->t_dec.as<uint2>(), c->n_dec,
-                               c->d_lens.as<uint32_t>(), c->d_bsum.as<unsigned long long>(), total + 1);
-        }));
-        hipLaunchKernelGGL(tk_k_dec_scan64, dim3(1), dim3(1024), 0, s, c->d_bsum.as<unsigned long long>(), nb, total);
+    unsigned long long* tots = c->d_bsum.as<unsigned long long>() + nb + 2;  // per range {bytes, first invalid position}; [0 .. 1] also the batch's
+    unsigned long long* d_tboff = byte_off_out ? c->d_tboff.as<unsigned long long>() : nullptr;
+    if (!c->cs_h2d) {
+        HIPCHK(hipStreamCreateWithFlags(&c->cs_h2d, hipStreamNonBlocking));
+        HIPCHK(hipStreamCreateWithFlags(&c->cs_d2h, hipStreamNonBlocking));
+        for (int i = 0; i < 2; ++i) {
+            HIPCHK(hipHostMalloc(&c->stage[i], TK_STAGE_BYTES, hipHostMallocPortable));
+            HIPCHK(hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming));
+        }
     }
-    HIPCHK(hipMemcpyAsync(h_tot, total, 16, hipMemcpyDeviceToHost, s));
-    HIPCHK(hipStreamSynchronize(s));
-    if (h_tot[1] != ~0ull) return fail(TK_KEY_ERROR, "Invalid token for decoding: " + std::to_string(tokens[h_tot[1]]));
-    const uint64_t nbytes = h_tot[0];
-    TRY(ensure(c->d_bytes, nbytes + 16));
-    uint64_t* d_tok_off = c->d_boff.as<uint64_t>();
-    uint64_t* d_byte_off = d_tok_off + n_docs + 1;
-    if (n) {
-        TRY(timed(c, s, "tk_k_dec_copy", [&] {
-            hipLaunchKernelGGL(tk_k_dec_copy, dim3((uint32_t)nb), dim3(256), 0, s, c->d_tok.as<uint32_t>(), n, c->t_dec.as<uint2>(), c->d_lens.as<uint32_t>(),
-                               c->d_bsum.as<unsigned long long>(), c->D.tok_bytes, c->D.spec_bytes, c->d_bytes.as<uint8_t>(),
-                               c->d_tboff.as<unsigned long long>());
-        }));
+    // is the caller's buffer page-locked (then the DMA engine reads it directly)?
+    bool src_pinned = false;
+    {
+        hipPointerAttribute_t at;
+        if (n && hipPointerGetAttributes(&at, tokens) == hipSuccess) src_pinned = at.type == hipMemoryTypeHost;
+        else (void)hipGetLastError();
     }
-    // (large results in page-locked memory: the copy back runs at the link's rate, and Python sees the buffer in place)
-    uint8_t* host = (uint8_t*)(nbytes >= (1u << 20) ? pinned_get(nbytes) : malloc(nbytes ? nbytes : 1));
-    if (!host) return fail(TK_RUNTIME_ERROR, "out of host memory");
-    hipError_t e = hipSuccess;
-    if (byte_off_out) {
-        e = hipMemcpyAsync(d_tok_off, tok_off, (n_docs + 1) * 8, hipMemcpyHostToDevice, s);
+    std::vector<hipEvent_t> ev_in(n_ranges, nullptr), ev_out(2, nullptr);
+    for (auto& e : ev_in) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    for (auto& e : ev_out) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    hipEvent_t ev_copy = nullptr;
+    HIPCHK(hipEventCreateWithFlags(&ev_copy, hipEventDisableTiming));
+    auto drop_events = [&]() {
+        for (auto e : ev_in) (void)hipEventDestroy(e);
+        for (auto e : ev_out) (void)hipEventDestroy(e);
+        (void)hipEventDestroy(ev_copy);
+    };
+    std::atomic<int> h2d_rc{TK_OK};
+    std::atomic<uint64_t> sent{0};
+    const int dev = c->device;
+    unsigned nth = std::thread::hardware_concurrency();
+    nth = nth == 0 ? 4 : (nth > 8 ? 8 : nth);
+    std::thread producer([&]() {
+        (void)hipSetDevice(dev);
+        for (uint64_t k = 0; k < n_ranges; ++k) {
+            const uint64_t a = k * RANGE, cnt = a + RANGE < n ? RANGE : n - a;
+            const void* src = tokens + a;
+            if (!src_pinned) {
+                const int slot = (int)(k & 1);
+                if (k >= 2 && hipEventSynchronize(c->ev_stage[slot]) != hipSuccess) h2d_rc = TK_RUNTIME_ERROR;
+                parallel_memcpy(c->stage[slot], tokens + a, cnt * 4, nth);
+                src = c->stage[slot];
+                if (hipMemcpyAsync(c->d_tok.as<uint32_t>() + a, src, cnt * 4, hipMemcpyHostToDevice, c->cs_h2d) != hipSuccess) h2d_rc = TK_RUNTIME_ERROR;
+                (void)hipEventRecord(c->ev_stage[slot], c->cs_h2d);
+            } else if (hipMemcpyAsync(c->d_tok.as<uint32_t>() + a, src, cnt * 4, hipMemcpyHostToDevice, c->cs_h2d) != hipSuccess) {
+                h2d_rc = TK_RUNTIME_ERROR;
+            }
+            (void)hipEventRecord(ev_in[k], c->cs_h2d);
+            sent.store(k + 1, std::memory_order_release);
+        }
+    });
+    uint8_t* host = nullptr;
+    uint64_t host_cap = 0, base = 0;
+    Buf* dout[2] = {&c->d_bytes, &c->d_bytes_alt};
+    int rc = TK_OK;
+    uint64_t bad_pos = ~0ull;
+    {
+        unsigned long long init[2] = {0, ~0ull};
+        std::vector<unsigned long long> initv(2 * (n_ranges + 1));
+        for (size_t i = 0; i < initv.size(); i += 2) initv[i] = init[0], initv[i + 1] = init[1];
+        hipError_t e = hipMemcpyAsync(tots, initv.data(), initv.size() * 8, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipStreamSynchronize(s);  // (initv leaves scope)
+        if (e != hipSuccess) rc = fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e));
+    }
+    const double t_call = now_us();
+    auto step = [&](uint64_t k) -> int {
+        const uint64_t a = k * RANGE, cnt = a + RANGE < n ? RANGE : n - a;
+        const double t_0 = now_us();
+        while (sent.load(std::memory_order_acquire) <= k) std::this_thread::yield();
+        const double t_1 = now_us();
+        if (h2d_rc.load() != TK_OK) return fail(TK_RUNTIME_ERROR, "host-to-device copy failed");
+        HIPCHK(hipStreamWaitEvent(s, ev_in[k], 0));
+        unsigned long long* tot = tots + 2 * (k + 1);
+        TRY(decode_range_len(c, s, c->d_tok.as<uint32_t>(), a, cnt, tot));
+        unsigned long long h_tot[2] = {0, ~0ull};
+        HIPCHK(hipMemcpyAsync(h_tot, tot, 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipStreamSynchronize(s));
+        if (h_tot[1] != ~0ull) {
+            bad_pos = h_tot[1];
+            return TK_KEY_ERROR;
+        }
+        const uint64_t nbk = h_tot[0];
+        const double t_2 = now_us();
+        Buf& d = *dout[k & 1];
+        if (k >= 2) HIPCHK(hipEventSynchronize(ev_out[k & 1]));  // the buffer's previous bytes have left
+        TRY(ensure(d, nbk + 16));
+        TRY(decode_range_copy(c, s, c->d_tok.as<uint32_t>(), a, cnt, d.as<uint8_t>(), d_tboff, base));
+        HIPCHK(hipEventRecord(ev_copy, s));
+        // the result buffer: sized by the density so far
+        const uint64_t need = base + nbk, done = a + cnt;
+        if (need > host_cap || !host) {
+            uint64_t est = done == n ? need : (uint64_t)((double)need / (double)done * (double)n * 1.06) + 4096;
+            if (est < need) est = need;
+            uint8_t* nh = (uint8_t*)(est >= (1u << 20) || n_ranges > 1 ? pinned_get(est ? est : 1) : malloc(est ? est : 1));
+            if (!nh) return fail(TK_RUNTIME_ERROR, "out of host memory");
+            if (host) {
+                HIPCHK(hipStreamSynchronize(c->cs_d2h));
+                if (base) parallel_memcpy(nh, host, base, nth);
+                tk_free(host);
+            }
+            host = nh;
+            host_cap = est;
+        }
+        const double t_3 = now_us();
+        if (c->dbg & 64)
+            fprintf(stderr, "decode range %llu: at %.0f us; ids waited %.0f us, lengths %.0f us, buffers %.0f us\n", (unsigned long long)k, t_0 - t_call, t_1 - t_0,
+                    t_2 - t_1, t_3 - t_2);
+        HIPCHK(hipStreamWaitEvent(c->cs_d2h, ev_copy, 0));
+        if (nbk) HIPCHK(hipMemcpyAsync(host + base, d.p, nbk, hipMemcpyDeviceToHost, c->cs_d2h));
+        HIPCHK(hipEventRecord(ev_out[k & 1], c->cs_d2h));
+        base = need;
+        return TK_OK;
+    };
+    for (uint64_t k = 0; k < n_ranges && rc == TK_OK; ++k) rc = step(k);
+    producer.join();
+    hipError_t e = hipStreamSynchronize(c->cs_h2d);
+    if (rc == TK_OK && byte_off_out) {
+        uint64_t* d_tok_off = c->d_boff.as<uint64_t>();
+        uint64_t* d_byte_off = d_tok_off + n_docs + 1;
+        unsigned long long h_total = base;
+        if (e == hipSuccess) e = hipMemcpyAsync(tots, &h_total, 8, hipMemcpyHostToDevice, s);
+        if (e == hipSuccess) e = hipMemcpyAsync(d_tok_off, tok_off, (n_docs + 1) * 8, hipMemcpyHostToDevice, s);
         if (e == hipSuccess) {
-            hipLaunchKernelGGL(tk_k_dec_docoff, dim3(grid_for(n_docs + 1, 256, 4096)), dim3(256), 0, s, d_tok_off, n_docs, n,
-                               c->d_tboff.as<unsigned long long>(), total, d_byte_off);
+            hipLaunchKernelGGL(tk_k_dec_docoff, dim3(grid_for(n_docs + 1, 256, 4096)), dim3(256), 0, s, d_tok_off, n_docs, n, d_tboff, tots, d_byte_off);
             e = hipMemcpyAsync(byte_off_out, d_byte_off, (n_docs + 1) * 8, hipMemcpyDeviceToHost, s);
         }
     }
-    if (e == hipSuccess && nbytes) e = hipMemcpyAsync(host, c->d_bytes.p, nbytes, hipMemcpyDeviceToHost, s);
     if (e == hipSuccess) e = hipStreamSynchronize(s);
+    if (e == hipSuccess) e = hipStreamSynchronize(c->cs_d2h);
     if (e == hipSuccess) e = hipGetLastError();
-    if (e != hipSuccess) {
-        tk_free(host);
-        return fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e));
-    }
-    if (const int rc = drain_events(c)) {  // (before the outputs are published: a caller that gets an error owns nothing)
-        tk_free(host);
+    drop_events();
+    if (c->dbg & 64) fprintf(stderr, "decode: %llu ranges, ids %s, %.0f us\n", (unsigned long long)n_ranges, src_pinned ? "page-locked" : "staged", now_us() - t_call);
+    if (rc == TK_KEY_ERROR && bad_pos != ~0ull) rc = fail(TK_KEY_ERROR, "Invalid token for decoding: " + std::to_string(tokens[bad_pos]));
+    if (rc == TK_OK && e != hipSuccess) rc = fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(e));
+    if (rc == TK_OK) rc = drain_events(c);  // (before the outputs are published: a caller that gets an error owns nothing)
+    else (void)drain_events(c);
+    if (rc != TK_OK) {
+        if (host) tk_free(host);
         return rc;
     }
+    if (!host) host = (uint8_t*)malloc(1);
     *bytes_out = host;
-    *n_bytes_out = nbytes;
+    *n_bytes_out = base;
     return TK_OK;
 }
 

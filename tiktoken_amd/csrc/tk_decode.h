@@ -15,7 +15,8 @@
 
 __global__ __launch_bounds__(256) void tk_k_dec_len(const uint32_t* __restrict__ tokens, uint64_t n, const uint2* __restrict__ dec,
                                                     uint32_t n_ids, uint32_t* __restrict__ lens, unsigned long long* __restrict__ bsum,
-                                                    unsigned long long* __restrict__ bad /* position of the first token without entry; ~0 = none */) {
+                                                    unsigned long long* __restrict__ bad /* position of the first token without entry; ~0 = none */,
+                                                    uint64_t pos_base /* position of tokens[0] in the caller's batch (a batch is decoded in ranges) */) {
     __shared__ uint32_t sh[4];
     const uint64_t i0 = (uint64_t)blockIdx.x * TK_DEC_BLOCK + (uint64_t)threadIdx.x * 8;
     uint32_t sum = 0;
@@ -26,7 +27,7 @@ __global__ __launch_bounds__(256) void tk_k_dec_len(const uint32_t* __restrict__
         if (i < n) {
             const uint32_t t = tokens[i];
             len = t < n_ids ? dec[t].y : 0u;
-            if (len == 0u) atomicMin(bad, (unsigned long long)i);  // (every real token has at least one byte)
+            if (len == 0u) atomicMin(bad, (unsigned long long)(pos_base + i));  // (every real token has at least one byte)
             lens[i] = len;
         }
         sum += len;
@@ -76,7 +77,8 @@ __global__ __launch_bounds__(1024) void tk_k_dec_scan64(unsigned long long* __re
 __global__ __launch_bounds__(256) void tk_k_dec_copy(const uint32_t* __restrict__ tokens, uint64_t n, const uint2* __restrict__ dec,
                                                      const uint32_t* __restrict__ lens, const unsigned long long* __restrict__ bbase,
                                                      const uint8_t* __restrict__ tok_bytes, const uint8_t* __restrict__ spec_bytes,
-                                                     uint8_t* __restrict__ out, unsigned long long* __restrict__ tok_byte_off /* may be null */) {
+                                                     uint8_t* __restrict__ out, unsigned long long* __restrict__ tok_byte_off /* may be null */,
+                                                     unsigned long long off_base /* bytes of the batch before this range (added to tok_byte_off only) */) {
     __shared__ uint32_t sh[8];
     const uint64_t i0 = (uint64_t)blockIdx.x * TK_DEC_BLOCK + (uint64_t)threadIdx.x * 8;
     uint32_t len[8], mine = 0;
@@ -107,7 +109,7 @@ __global__ __launch_bounds__(256) void tk_k_dec_copy(const uint32_t* __restrict_
     for (int j = 0; j < 8; ++j) {
         const uint64_t i = i0 + j;
         if (i < n) {
-            if (tok_byte_off) tok_byte_off[i] = at;
+            if (tok_byte_off) tok_byte_off[i] = off_base + at;
             const uint2 e = dec[tokens[i]];
             const uint8_t* src = ((e.x & TK_DEC_SPEC) ? spec_bytes : tok_bytes);
             const uint64_t so = e.x & ~TK_DEC_SPEC;
