@@ -426,6 +426,20 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     D.spec_id = c->t_spec_id.as<uint32_t>();
     D.n_spec = (uint32_t)H.spec_id.size();
     memcpy(D.spec_first, H.spec_first, sizeof D.spec_first);
+    D.spec_fb = 0;
+    D.n_spec_fb = 0;
+    for (uint32_t b = 0; b < 256; ++b)
+        if ((H.spec_first[b >> 5] >> (b & 31)) & 1u) {
+            if (D.n_spec_fb < 4) D.spec_fb |= b << (8 * D.n_spec_fb);
+            D.n_spec_fb += 1;
+        }
+    if (D.n_spec_fb > 4) D.n_spec_fb = 0xFF;
+    memset(D.spec_second, 0, sizeof D.spec_second);
+    for (size_t k = 0; k + 1 < H.spec_off.size(); ++k) {
+        const uint32_t o = H.spec_off[k], len = H.spec_off[k + 1] - o;
+        if (len < 2) memset(D.spec_second, 0xFF, sizeof D.spec_second);
+        else D.spec_second[H.spec_bytes[o + 1] >> 5] |= 1u << (H.spec_bytes[o + 1] & 31);
+    }
     D.pattern = H.pattern;
     D.pat = H.pat;
     memcpy(D.cert, H.cert, sizeof D.cert);
@@ -744,11 +758,12 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
     TkFrontOut fo{starts, w.tile_np.as<uint32_t>(), w.res.as<uint32_t>(), w.tile_sum.as<uint8_t>(), miss_of(w, job), job.ovf_cap, w.listC.as<uint32_t>(), counters};
     if (n > 0 && !single_piece) {
         if (use_special) {
-            TRY(ensure(w.docb, (nwords + 2) * 4));
-            TRY(ensure(w.cand, (nwords + 2) * 4));
+            TRY(ensure(w.docb, (nwords + 4) * 4));  // (tk_bits64 reads two words past the one a position lies in)
+            TRY(ensure(w.cand, (nwords + 4) * 4));
             TRY(ensure(w.ss, (nwords + 2) * 4));
             TRY(ensure(w.si, (nwords + 2) * 4));
-            for (Buf* b : {&w.docb, &w.cand, &w.ss, &w.si}) clear(*b, (nwords + 2) * 4, 0u);
+            for (Buf* b : {&w.docb, &w.cand}) clear(*b, (nwords + 4) * 4, 0u);
+            for (Buf* b : {&w.ss, &w.si}) clear(*b, (nwords + 2) * 4, 0u);
             docb = w.docb.as<uint32_t>();
             ss = w.ss.as<uint32_t>();
             si = w.si.as<uint32_t>();
@@ -948,7 +963,7 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
     if (n > 0) {
         // token count per tile (a missed piece's count from its entry), then the tiles' places (tk_fused.h: back end)
         TRY(timed(c, s, "tk_k_count_tiles", [&] {
-            hipLaunchKernelGGL(tk_k_count_tiles, dim3(grid_for(ntiles, 4, 4096)), dim3(256), 0, s, ntiles, tile_np, res, data, tile_nt, w.row_base.as<uint32_t>(),
+            hipLaunchKernelGGL(tk_k_count_tiles, dim3(grid_for(ntiles, 4, 2048)), dim3(256), 0, s, ntiles, tile_np, res, data, tile_nt, w.row_base.as<uint32_t>(),
                                w.total.as<unsigned long long>());
         }));
         TRY(scan_u32(c, w, s, tile_nt, ntiles, w.total.as<uint64_t>()));

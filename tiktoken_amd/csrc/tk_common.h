@@ -135,6 +135,9 @@ struct TkTables {
     const uint32_t* spec_id;   // [n_spec]
     uint32_t n_spec;
     uint32_t spec_first[8];  // 256-bit set of first bytes
+    uint32_t spec_fb;        // the first bytes once more, packed, when there are at most four of them (n_spec_fb; all the stock encodings: '<')
+    uint32_t n_spec_fb;      // 0xFF: more than four (the bitmap decides)
+    uint32_t spec_second[8]; // 256-bit set of second bytes (all bytes when some special token is a single byte): every stock special token starts "<|"
     int pattern;             // family of the split pattern (TK_PAT_*)
     TkPat pat;               // the pattern itself
     uint16_t cert[16];       // certain piece starts: cert[a] = classes that always start a piece after a char of class a

@@ -2562,13 +2562,16 @@ __global__ __launch_bounds__(256) void tk_k_count_tiles(uint64_t ntiles, const u
                     }
                 }
             }
-            if (__ballot(escape)) {
+            if (__ballot(escape)) {  // (again without an `if` per load: a batch of many distinct pieces has most of them in overflow entries)
 #pragma unroll
                 for (int r = 0; r < TKP_ROWS_COUNT; ++r) {
                     const uint32_t w[4] = {t4[r].x, t4[r].y, t4[r].z, t4[r].w};
 #pragma unroll
-                    for (int j = 0; j < 4; ++j)
-                        if (c[r][j] == 0xFFFFFFFFu) c[r][j] = TKD_COUNT(data.head(w[j] & ~TK_RES_FLAG)[2]);
+                    for (int j = 0; j < 4; ++j) {
+                        const bool esc = c[r][j] == 0xFFFFFFFFu;
+                        const uint32_t cw = data.head(esc ? (w[j] & ~TK_RES_FLAG) : data.ovf_base)[2];
+                        if (esc) c[r][j] = TKD_COUNT(cw);
+                    }
                 }
             }
 #pragma unroll
@@ -2581,7 +2584,15 @@ __global__ __launch_bounds__(256) void tk_k_count_tiles(uint64_t ntiles, const u
         }
         if (lane == 0) tile_nt[t] = run;
     }
-    if (lane == 0 && pieces) atomicAdd(&total[1], pieces);  // (one fire-and-forget atomic per wavefront)
+    // (one atomic per WORKGROUP: same-address atomics are served one after the other at ~10 M/s on this part -- one per wavefront of a
+    // 4096-workgroup grid was 0.2 ms, the floor of this kernel however small the chunk)
+    __shared__ unsigned long long pieces_sh[4];
+    if (lane == 0) pieces_sh[threadIdx.x >> 6] = pieces;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned long long p = pieces_sh[0] + pieces_sh[1] + pieces_sh[2] + pieces_sh[3];
+        if (p) atomicAdd(&total[1], p);
+    }
 }
 
 // tile_tb = exclusive scan of tile_nt.  One wavefront per tile at a time, TKP_ROWS_PLACE rows in flight: the result words, then the heads of

@@ -143,19 +143,39 @@ __global__ void tk_k_mark_docs(const uint64_t* __restrict__ doc_off, uint64_t n_
 // special tokens (encode() with allowed_special; src/lib.rs:386-402, 426-434)
 // ------------------------------------------------------------------------------------------
 // Longest allowed special token that matches at text[pos..] without crossing a document start.
-// Returns its length (0 = none) and index.
+// Returns its length (0 = none) and index.  The next 32 text bytes and the document starts among the next 64 positions are read once; a
+// special token of at most 32 bytes is compared with them word by word (four independent loads of its bytes instead of a load per byte
+// that waits for the byte before it: the resolving pass calls this two or three times per candidate, one lane of a wavefront at a time).
+__device__ __forceinline__ uint64_t tk_bits64(const uint32_t* __restrict__ bm, uint64_t pos) {  // bits [pos, pos + 64) of a bitmap (readable two words past them)
+    const uint64_t wi = pos >> 5;
+    const uint32_t sh = (uint32_t)(pos & 31);
+    const uint32_t w0 = bm[wi], w1 = bm[wi + 1], w2 = bm[wi + 2];
+    const uint64_t lo = ((uint64_t)w1 << 32) | w0;
+    return sh ? ((lo >> sh) | ((uint64_t)w2 << (64u - sh))) : lo;
+}
 __device__ __forceinline__ uint32_t tk_special_at(const TkTables& T, const uint8_t* __restrict__ text, uint64_t pos, uint64_t n,
                                                   const uint8_t* __restrict__ allowed, const uint32_t* __restrict__ docb,
                                                   uint32_t* idx_out) {
     uint32_t b0 = text[pos];
     if (!((T.spec_first[b0 >> 5] >> (b0 & 31)) & 1u)) return 0;
+    uint64_t tw[4];  // (the text is readable 64 bytes past n)
+#pragma unroll
+    for (int i = 0; i < 4; ++i) tw[i] = tk_load8(text, pos + 8u * i);
+    const uint64_t db = docb ? tk_bits64(docb, pos + 1) : 0ull;  // document starts at pos + 1 .. pos + 64
     uint32_t best = 0, bi = 0;
     for (uint32_t k = 0; k < T.n_spec; ++k) {
         if (allowed && !allowed[k]) continue;
         uint32_t o = T.spec_off[k], len = T.spec_off[k + 1] - o;
         if (len <= best || pos + len > n || T.spec_bytes[o] != b0) continue;
         bool ok = true;
-        for (uint32_t i = 1; i < len && ok; ++i) ok = (text[pos + i] == T.spec_bytes[o + i]) && !(docb && tk_bit(docb, pos + i));
+        if (len <= 32u) {
+#pragma unroll
+            for (int i = 0; i < 4; ++i)
+                if (8u * i < len) ok = ok && tk_mask_low_bytes(tw[i] ^ tk_load8(T.spec_bytes, (uint64_t)o + 8u * i), len - 8u * i) == 0ull;
+            ok = ok && (db & ((1ull << (len - 1u)) - 1ull)) == 0ull;
+        } else {
+            for (uint32_t i = 1; i < len && ok; ++i) ok = (text[pos + i] == T.spec_bytes[o + i]) && !(docb && tk_bit(docb, pos + i));
+        }
         if (ok) {
             best = len;
             bi = k;
@@ -165,17 +185,43 @@ __device__ __forceinline__ uint32_t tk_special_at(const TkTables& T, const uint8
     return best;
 }
 
+// Candidates: positions at which an allowed special token matches.  16 text bytes per thread; almost every byte fails the first-byte
+// test, so the kernel is one coalesced read of the text.  With at most four distinct first bytes (every stock encoding: '<') the test is
+// four byte-equality tests per 32-bit word (x ^ c has a zero byte; the borrow may mark a byte above a true hit as well: a false
+// candidate, which tk_special_at rejects); otherwise the 256-bit set decides byte by byte.
 __global__ void tk_k_spec_cand(TkTables T, const uint8_t* __restrict__ text, uint64_t n, const uint8_t* __restrict__ allowed,
                                const uint32_t* __restrict__ docb, uint32_t* __restrict__ cand) {
-    // 16 text bytes per thread: almost every byte fails the first-byte test, so the kernel is one coalesced read of the text
     for (uint64_t p0 = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) * 16; p0 < n; p0 += (uint64_t)gridDim.x * blockDim.x * 16) {
         const uint4 v = *(const uint4*)(text + p0);  // (text is readable 64 bytes past n)
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         uint32_t hits = 0;
+        if (T.n_spec_fb <= 4u) {
+            for (uint32_t f = 0; f < T.n_spec_fb; ++f) {
+                const uint32_t c4 = ((T.spec_fb >> (8u * f)) & 0xFFu) * 0x01010101u;
 #pragma unroll
-        for (int k = 0; k < 16; ++k) {
-            const uint32_t b = (w[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
-            hits |= ((T.spec_first[b >> 5] >> (b & 31)) & 1u) << k;
+                for (int d = 0; d < 4; ++d) {
+                    const uint32_t x = w[d] ^ c4;
+                    const uint32_t z = (x - 0x01010101u) & ~x & 0x80808080u;  // bit 7 of every zero byte (and, rarely, of a 0x01 above one)
+                    // bits 7, 15, 23, 31 -> bits 0..3
+                    hits |= (((z >> 7) | (z >> 14) | (z >> 21) | (z >> 28)) & 0xFu) << (4 * d);
+                }
+            }
+        } else {
+#pragma unroll
+            for (int k = 0; k < 16; ++k) {
+                const uint32_t b = (w[k >> 2] >> ((k & 3) * 8)) & 0xFFu;
+                hits |= ((T.spec_first[b >> 5] >> (b & 31)) & 1u) << k;
+            }
+        }
+        if (hits) {  // the byte behind a hit must be some special token's second byte ("<" is common in web text, "<|" is not)
+            const uint32_t nxt = text[p0 + 16];
+            uint32_t keep = 0;
+            for (uint32_t m = hits; m; m &= m - 1) {
+                const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
+                const uint32_t b1 = k < 15u ? (w[(k + 1) >> 2] >> (((k + 1) & 3u) * 8u)) & 0xFFu : nxt;
+                keep |= ((T.spec_second[b1 >> 5] >> (b1 & 31u)) & 1u) << k;
+            }
+            hits = keep;
         }
         while (hits) {
             const uint64_t pos = p0 + (uint32_t)(__ffs((int)hits) - 1);
@@ -188,7 +234,8 @@ __global__ void tk_k_spec_cand(TkTables T, const uint8_t* __restrict__ text, uin
 
 // Resolve overlapping candidates exactly as a left-to-right search would (src/lib.rs:389-401,432):
 // a candidate is taken iff the greedy non-overlapping walk from the head of its overlap cluster
-// lands on it.
+// lands on it.  (Earlier candidates are looked for in the 64 bits of the bitmap before the position -- two loads, not one per bit;
+// special tokens of 66 bytes and more take the walk bit by bit.)
 __global__ void tk_k_spec_resolve(TkTables T, const uint8_t* __restrict__ text, uint64_t n, const uint8_t* __restrict__ allowed,
                                   const uint32_t* __restrict__ docb, const uint32_t* __restrict__ cand, uint32_t max_len,
                                   uint32_t* __restrict__ spec_start, uint32_t* __restrict__ spec_in, uint32_t* __restrict__ brk) {
@@ -203,11 +250,26 @@ __global__ void tk_k_spec_resolve(TkTables T, const uint8_t* __restrict__ text, 
         for (;;) {
             bool moved = false;
             uint64_t lo = h >= (uint64_t)(max_len - 1) ? h - (max_len - 1) : 0;
-            for (uint64_t j = h; j-- > lo;) {
-                if (tk_bit(cand, j) && j + tk_special_at(T, text, j, n, allowed, docb, &idx) > h) {
-                    h = j;
-                    moved = true;
-                    break;
+            if (max_len <= 65u && h >= 64u) {
+                uint64_t before = tk_bits64(cand, h - 64u);          // candidates at h - 64 .. h - 1 (bit 63 = h - 1)
+                before = h > lo ? (before & (~0ull << (64u - (uint32_t)(h - lo)))) : 0ull;  // only those at lo .. h - 1
+                while (before) {  // nearest first
+                    const uint32_t b = 63u - (uint32_t)__clzll((long long)before);
+                    before &= ~(1ull << b);
+                    const uint64_t j = h - 64u + b;
+                    if (j + tk_special_at(T, text, j, n, allowed, docb, &idx) > h) {
+                        h = j;
+                        moved = true;
+                        break;
+                    }
+                }
+            } else {
+                for (uint64_t j = h; j-- > lo;) {
+                    if (tk_bit(cand, j) && j + tk_special_at(T, text, j, n, allowed, docb, &idx) > h) {
+                        h = j;
+                        moved = true;
+                        break;
+                    }
                 }
             }
             if (!moved) break;
