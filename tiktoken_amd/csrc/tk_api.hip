@@ -714,7 +714,9 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
     // (every piece a distinct two-byte piece that is not a token) unless the chunk is small or a batch has already asked for more
     // (c->ovf_full: encode_device_locked repeats such a batch once, with room for the worst case).
     job.pretok = pretok_only;
-    if (n > 32768 && !single_piece && !pretok_only) {
+    // (small chunks too: without the table every missed piece has an overflow entry, whose tokens tk_k_place copies from the staging area two
+    // pieces at a time -- 92 us for a 4 KiB call, against 4 us for clearing 16 Ki keys)
+    if (n >= 512 && !single_piece && !pretok_only) {
         while (job.mt_bits < TK_MT_BITS && (1ull << job.mt_bits) < n / 128) ++job.mt_bits;  // 4 Mi slots from 512 MiB up
         job.ovf_base = 1u << job.mt_bits;
     }
@@ -960,10 +962,13 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
             }));
         }
     }
+    const bool small_rows = n < (8u << 20);  // (the one-row instances: a third of the code to fetch for a kernel that runs over a few tiles)
     if (n > 0) {
         // token count per tile (a missed piece's count from its entry), then the tiles' places (tk_fused.h: back end)
         TRY(timed(c, s, "tk_k_count_tiles", [&] {
-            hipLaunchKernelGGL(tk_k_count_tiles, dim3(grid_for(ntiles, 4, 2048)), dim3(256), 0, s, ntiles, tile_np, res, data, tile_nt, w.row_base.as<uint32_t>(),
+            if (small_rows) hipLaunchKernelGGL(tk_k_count_tiles<1>, dim3(grid_for(ntiles, 4, 2048)), dim3(256), 0, s, ntiles, tile_np, res, data, tile_nt, w.row_base.as<uint32_t>(),
+                               w.total.as<unsigned long long>());
+            else hipLaunchKernelGGL(tk_k_count_tiles<TKP_ROWS_COUNT>, dim3(grid_for(ntiles, 4, 2048)), dim3(256), 0, s, ntiles, tile_np, res, data, tile_nt, w.row_base.as<uint32_t>(),
                                w.total.as<unsigned long long>());
         }));
         TRY(scan_u32(c, w, s, tile_nt, ntiles, w.total.as<uint64_t>()));
@@ -977,7 +982,8 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
     HIPCHK(hipEventRecord(w.ev_tot, s));
     if (n > 0) {
         TRY(timed(c, s, "tk_k_place", [&] {
-            hipLaunchKernelGGL(tk_k_place, dim3(grid_for(ntiles, 4, 4096)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, data, stg, d_out, tok_base, w.big.as<uint32_t>());
+            if (small_rows) hipLaunchKernelGGL(tk_k_place<1>, dim3(grid_for(ntiles, 4, 4096)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, data, stg, d_out, tok_base, w.big.as<uint32_t>());
+            else hipLaunchKernelGGL(tk_k_place<TKP_ROWS_PLACE>, dim3(grid_for(ntiles, 4, 4096)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, data, stg, d_out, tok_base, w.big.as<uint32_t>());
         }));
     }
     if (n > TK_BIGCOPY)  // (a token run of TK_BIGCOPY tokens needs at least as many bytes)

@@ -2514,7 +2514,9 @@ __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds_wide(TkTables T
 // front stage): its workgroups that are not resident yet never get the registers the waiting ones hold.
 // ------------------------------------------------------------------------------------------
 
-// rows of 256 pieces a wavefront has in flight together (a tile of web text has 580 pieces)
+// rows of 256 pieces a wavefront has in flight together (a tile of web text has 580 pieces): three for chunks, one for small inputs
+// (template parameter ROWS: a kernel that runs once over a few tiles pays for the code it has to fetch, and the three-row form is three
+// times the code -- 96 us for a 4 KiB call)
 #ifndef TKP_ROWS_COUNT
 #define TKP_ROWS_COUNT 3
 #endif
@@ -2525,6 +2527,7 @@ __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds_wide(TkTables T
 // tile_nt[t] <- tokens of tile t; row_rel[t * (TKF_CAP / 256) + r] <- tokens of the tile's rows before row r (for tk_k_docoff);
 // total[1] += pieces of the chunk.  One wavefront per tile at a time; the loads of TKP_ROWS_COUNT rows are in flight together (the kernel waits
 // for memory: the result words stream from HBM, a missed piece's count is one byte of an L2-resident array).
+template <int ROWS>
 __global__ __launch_bounds__(256) void tk_k_count_tiles(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ res, TkMiss data,
                                                         uint32_t* __restrict__ tile_nt, uint32_t* __restrict__ row_rel, unsigned long long* __restrict__ total) {
     const int lane = threadIdx.x & 63;
@@ -2536,19 +2539,19 @@ __global__ __launch_bounds__(256) void tk_k_count_tiles(uint64_t ntiles, const u
         np_next = t + nwaves < ntiles ? tile_np[t + nwaves] : 0u;  // (the next tile's size is on its way while this tile is counted)
         pieces += np;
         uint32_t run = 0;
-        for (uint32_t k0 = 0; k0 < np; k0 += 256u * TKP_ROWS_COUNT) {
-            uint4 t4[TKP_ROWS_COUNT];
+        for (uint32_t k0 = 0; k0 < np; k0 += 256u * ROWS) {
+            uint4 t4[ROWS];
 #pragma unroll
-            for (int r = 0; r < TKP_ROWS_COUNT; ++r) {
+            for (int r = 0; r < ROWS; ++r) {
                 const uint32_t k = k0 + (uint32_t)r * 256u + (uint32_t)lane * 4u;
                 t4[r] = *(const uint4*)(res + rb + (k < np ? k : 0u));  // (runs start 16-byte aligned, and a run's storage extends to the next multiple of four; no `if` around the load)
             }
             // (the count bytes of all the missed pieces by loads that do not depend on anything but the result words: a load inside an
             // `if` of its own waits for its data before the next `if` is even looked at -- twelve latencies one after the other)
-            uint32_t c[TKP_ROWS_COUNT][4];
+            uint32_t c[ROWS][4];
             bool escape = false;  // a piece whose count is not in the byte array (an overflow entry, 255 tokens and more)
 #pragma unroll
-            for (int r = 0; r < TKP_ROWS_COUNT; ++r) {
+            for (int r = 0; r < ROWS; ++r) {
                 const uint32_t k = k0 + (uint32_t)r * 256u + (uint32_t)lane * 4u;
                 const uint32_t w[4] = {t4[r].x, t4[r].y, t4[r].z, t4[r].w};
 #pragma unroll
@@ -2564,7 +2567,7 @@ __global__ __launch_bounds__(256) void tk_k_count_tiles(uint64_t ntiles, const u
             }
             if (__ballot(escape)) {  // (again without an `if` per load: a batch of many distinct pieces has most of them in overflow entries)
 #pragma unroll
-                for (int r = 0; r < TKP_ROWS_COUNT; ++r) {
+                for (int r = 0; r < ROWS; ++r) {
                     const uint32_t w[4] = {t4[r].x, t4[r].y, t4[r].z, t4[r].w};
 #pragma unroll
                     for (int j = 0; j < 4; ++j) {
@@ -2575,7 +2578,7 @@ __global__ __launch_bounds__(256) void tk_k_count_tiles(uint64_t ntiles, const u
                 }
             }
 #pragma unroll
-            for (int r = 0; r < TKP_ROWS_COUNT; ++r) {
+            for (int r = 0; r < ROWS; ++r) {
                 if (k0 + (uint32_t)r * 256u < np) {
                     if (lane == 0) row_rel[t * (TKF_CAP / 256) + (k0 >> 8) + r] = run;
                     run += tk_wave_sum_u32(c[r][0] + c[r][1] + c[r][2] + c[r][3]);
@@ -2602,6 +2605,7 @@ __global__ __launch_bounds__(256) void tk_k_count_tiles(uint64_t ntiles, const u
 #ifndef TKP_PLACE_OCC
 #define TKP_PLACE_OCC 1
 #endif
+template <int ROWS>
 __global__ __launch_bounds__(256, TKP_PLACE_OCC) void tk_k_place(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_tb,
                                                   const uint32_t* __restrict__ res, TkMiss data, const uint32_t* __restrict__ staging, uint32_t* __restrict__ out_all,
                                                   const unsigned long long* __restrict__ tok_base, uint32_t* __restrict__ big) {
@@ -2618,11 +2622,11 @@ __global__ __launch_bounds__(256, TKP_PLACE_OCC) void tk_k_place(uint64_t ntiles
         uint32_t run = tb_next;  // (token offsets within a chunk fit 32 bits: a chunk is less than 4 GiB of text)
         np_next = t + nwaves < ntiles ? tile_np[t + nwaves] : 0u;  // (the next tile's size and base are on their way while this tile is placed)
         tb_next = t + nwaves < ntiles ? tile_tb[t + nwaves] : 0u;
-        for (uint32_t k0 = 0; k0 < np; k0 += 256u * TKP_ROWS_PLACE) {
-            uint32_t tk[TKP_ROWS_PLACE][4];
-            uint2 hd[TKP_ROWS_PLACE][4];
+        for (uint32_t k0 = 0; k0 < np; k0 += 256u * ROWS) {
+            uint32_t tk[ROWS][4];
+            uint2 hd[ROWS][4];
 #pragma unroll
-            for (int r = 0; r < TKP_ROWS_PLACE; ++r) {
+            for (int r = 0; r < ROWS; ++r) {
                 const uint32_t k = k0 + (uint32_t)r * 256u + (uint32_t)lane * 4u;
                 const uint4 t4 = *(const uint4*)(res + rb + (k < np ? k : 0u));  // (no `if` around the load: the rows are in flight together)
                 tk[r][0] = k < np ? t4.x : TK_RES_GAP;  // (dead words of a run's last four count as "no token")
@@ -2631,13 +2635,20 @@ __global__ __launch_bounds__(256, TKP_PLACE_OCC) void tk_k_place(uint64_t ntiles
                 tk[r][3] = k + 3 < np ? t4.w : TK_RES_GAP;
             }
 #pragma unroll
-            for (int r = 0; r < TKP_ROWS_PLACE; ++r) {
+            for (int r = 0; r < ROWS; ++r) {
 #pragma unroll
                 for (int j = 0; j < 4; ++j)  // (no `if` around the load: all the heads are in flight together; a piece without an entry reads the first overflow entry)
+#ifdef TKP_COND_HEADS
+                {
+                    hd[r][j] = make_uint2(0u, 0u);
+                    if (tk[r][j] & TK_RES_FLAG) hd[r][j] = data.result(tk[r][j] & ~TK_RES_FLAG);
+                }
+#else
                     hd[r][j] = data.result((tk[r][j] & TK_RES_FLAG) ? (tk[r][j] & ~TK_RES_FLAG) : data.ovf_base);
+#endif
             }
 #pragma unroll
-            for (int r = 0; r < TKP_ROWS_PLACE; ++r) {
+            for (int r = 0; r < ROWS; ++r) {
                 if (k0 + (uint32_t)r * 256u >= np) break;
                 uint32_t c[4];
 #pragma unroll
@@ -2650,7 +2661,12 @@ __global__ __launch_bounds__(256, TKP_PLACE_OCC) void tk_k_place(uint64_t ntiles
 #pragma unroll
                 for (int j = 0; j < 4; ++j) {
                     const bool inl = (tk[r][j] & TK_RES_FLAG) && c[j] > 1u && (hd[r][j].x & TKD_INLINE_BIT);
+#ifdef TKP_COND_A4
+                    a4[j] = make_uint4(0, 0, 0, 0);
+                    if (inl) a4[j] = *(const uint4*)(data.tab[tk[r][j] & ~TK_RES_FLAG].tok + 1);
+#else
                     a4[j] = *(const uint4*)(inl ? (const uint32_t*)(data.tab[tk[r][j] & ~TK_RES_FLAG].tok + 1) : (const uint32_t*)data.ovf);
+#endif
                 }
                 if (c[0] == 1u && c[1] == 1u && c[2] == 1u && c[3] == 1u && !((tk[r][0] | tk[r][1] | tk[r][2] | tk[r][3]) & TK_RES_FLAG)) {
                     *(uint4*)(out + o) = make_uint4(tk[r][0], tk[r][1], tk[r][2], tk[r][3]);  // (4-byte aligned 16-byte store)
