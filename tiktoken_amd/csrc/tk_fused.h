@@ -2797,12 +2797,29 @@ __global__ __launch_bounds__(256) void tk_k_docoff(uint64_t n_docs, const uint64
                 row_run += row_rel[(uint64_t)t * (TKF_CAP / 256) + (kp >> 8)];
                 kstart = kp & ~255u;
             }
-            for (uint32_t k0 = kstart; k0 < kp; k0 += 64) {
-                const uint32_t k = k0 + lane;
-                const uint32_t rv = k < kp ? res[rb + k] : 0u;
-                uint32_t c = (k < kp && rv != TK_RES_GAP) ? 1u : 0u;
-                if (k < kp && (rv & TK_RES_FLAG)) c = data.count(rv & ~TK_RES_FLAG);
-                sum += c;
+            {  // the row's pieces before the document's: at most 255, four per lane, all loads without an `if` of their own (in flight together)
+                uint32_t rv[4], cb[4];
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const uint32_t k = kstart + (uint32_t)j * 64u + (uint32_t)lane;
+                    rv[j] = res[rb + (k < kp ? k : kstart)];
+                    if (k >= kp) rv[j] = TK_RES_GAP;
+                }
+                bool escape = false;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const bool flagged = rv[j] != TK_RES_GAP && (rv[j] & TK_RES_FLAG), in_tab = flagged && (rv[j] & ~TK_RES_FLAG) < data.ovf_base;
+                    cb[j] = data.cnt8[in_tab ? (rv[j] & ~TK_RES_FLAG) : 0u];
+                    if (flagged && (!in_tab || cb[j] == 255u)) escape = true;
+                    else sum += flagged ? cb[j] : (rv[j] != TK_RES_GAP ? 1u : 0u);
+                }
+                if (__ballot(escape)) {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        const bool flagged = rv[j] != TK_RES_GAP && (rv[j] & TK_RES_FLAG), in_tab = flagged && (rv[j] & ~TK_RES_FLAG) < data.ovf_base;
+                        if (flagged && (!in_tab || cb[j] == 255u)) sum += TKD_COUNT(data.head(rv[j] & ~TK_RES_FLAG)[2]);
+                    }
+                }
             }
             v = row_run + tk_wave_sum_u32(sum);
         }

@@ -1,9 +1,11 @@
 #!/bin/bash
+# usage: bash tools/gpu_pmc.sh -- SQ counters (three passes) and cache counters (two passes: hits and misses of the L2, requests of the L1 to it) of
+# bench.py --steps 1 --mib 1024, one rocprofv3 --pmc run per set; tools/summarize_pmc.py turns gpurun_out/pmc2 into profiles/<tag>_sq_counters.csv
 R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/pmc2
 cd /tmp && export TMPDIR=/tmp
-rocprofv3 -L 2>/dev/null | grep -oE "\b(SQ_[A-Z_0-9]+|GRBM_[A-Z_]+|TCP_[A-Z_0-9]+|TCC_[A-Z_0-9]+)\b" | sort -u > $R/gpurun_out/pmc2/counters.txt
+rocprofv3 -L 2>/dev/null | grep -oE "\b(SQ_[A-Z_0-9]+|GRBM_[A-Z_]+|TCP_[A-Za-z_0-9]+|TCC_[A-Za-z_0-9]+)\b" | sort -u > $R/gpurun_out/pmc2/counters.txt
 wc -l $R/gpurun_out/pmc2/counters.txt
-for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE"; do
+for SET in "SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_SALU SQ_WAVES" "SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA SQ_INST_CYCLES_SALU" "SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE" "TCC_HIT_sum TCC_MISS_sum TCC_REQ_sum TCC_READ_sum" "TCP_TCC_READ_REQ_sum TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_WRITE_REQ_sum"; do
   T=$(echo $SET | cut -d' ' -f1)
   rocprofv3 --pmc $SET --output-format csv -d $R/gpurun_out/pmc2/$T -o p -- python $R/bench.py --gpus 1 --steps 1 --warmup 0 --mib 1024 --no-cpu-baseline --no-host-path > $R/gpurun_out/pmc2/$T.log 2>&1
 done
