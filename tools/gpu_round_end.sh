@@ -11,6 +11,8 @@ timeout 900 bash tools/gpu_pmc.sh > gpurun_out/${TAG}_pmc.log 2>&1; tail -5 gpur
 timeout 600 python bench.py > gpurun_out/${TAG}_bench_1gpu.json 2> gpurun_out/${TAG}_bench.err; cat gpurun_out/${TAG}_bench_1gpu.json
 timeout 600 python tools/bench_configs.py > gpurun_out/${TAG}_configs.jsonl 2> gpurun_out/${TAG}_configs.err; cat gpurun_out/${TAG}_configs.jsonl | cut -c1-300
 timeout 300 python tools/small_call.py > gpurun_out/${TAG}_small_calls.txt 2>&1; cat gpurun_out/${TAG}_small_calls.txt
+timeout 300 python tools/mid_call.py > gpurun_out/${TAG}_mid_calls.txt 2>&1; cat gpurun_out/${TAG}_mid_calls.txt
+timeout 120 python tools/decode_path.py > gpurun_out/${TAG}_decode_path.txt 2>&1; cat gpurun_out/${TAG}_decode_path.txt
 timeout 300 python tools/stress_repeats.py o200k_shaped > gpurun_out/${TAG}_long_runs.txt 2>&1; cat gpurun_out/${TAG}_long_runs.txt
 timeout 300 python tools/generic_vs_scanners.py 256 > gpurun_out/${TAG}_generic_vs_scanners.txt 2>&1; cut -c1-400 gpurun_out/${TAG}_generic_vs_scanners.txt
 timeout 120 python tools/rx_diag.py > gpurun_out/${TAG}_generic_pat_small_batches.txt 2>&1; tail -3 gpurun_out/${TAG}_generic_pat_small_batches.txt | cut -c1-300
