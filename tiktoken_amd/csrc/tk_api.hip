@@ -805,7 +805,7 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
             const dim3 grid((uint32_t)(ntiles < resident ? ntiles : resident));
             launch_front<false>(T.pat.generic() ? TK_PAT_GENERIC : T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, fo,
                                 mt_arg, (1u << job.mt_bits) - 1u, deferred, c->has_rx ? w.rx_gst.as<uint32_t>() + nwords + 2 : (const uint32_t*)nullptr,
-                                c->dbg | (pretok_only ? 8 : 0));
+                                c->dbg | (pretok_only ? 8 : 0) | ((c->has_rx && !(c->dbg & 4)) ? TKF_DBG_HARD_ONLY : 0));  // (debug bit 4: the scanners run even so)
         }));
     } else if (n > 0) {
         hipLaunchKernelGGL(tk_k_chunk_clear, dim3(1), dim3(256), 0, s, clr);

@@ -46,6 +46,10 @@
 #define TKF_DBG_MAY_GIVE_UP 0x8000000
 #define TKF_DBG_SECOND 0x10000000
 #define TKF_DBG_NO_BUDGET 0x20000000
+// Every piece start of the chunk is a hard start already (the generic engine has split it: tk_api.hip, rx_split): the tile's piece starts
+// ARE its hard starts, phases B-D (classes, certain starts, scanners: 2 of the kernel's 5.3 ms per GiB) are skipped by the one-tile-per-
+// workgroup instances.  The deferred-tile instance never takes this way (it is the general one).
+#define TKF_DBG_HARD_ONLY 0x40000000
 #define TKF_BATCH 960  // pieces per probe batch of the front kernel (the class lists hold 1024 entries, their packed counter 1023)
 #define TKF_CAP 4096  // piece ids per tile: pid = tile * TKF_CAP + k (a 4096-byte tile starts at most 4096 pieces)
 
@@ -673,6 +677,35 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
         if (tid == 0) out.tile_np[tile] = 0;
         continue;
     }
+    if (!SLOW && (dbg & TKF_DBG_HARD_ONLY)) {
+        // ---- hard starts only: the pieces that start in the tile begin at its hard starts; the last of them ends at the first hard start
+        // at or behind the tile's end -- in the 128 bytes of look-ahead, or the tile is one for the workgroup-wide scanner
+        const uint32_t te = (uint32_t)(tile_end - tile_start) + (uint32_t)TK2_LEFT;
+        uint32_t mine_w = 0;
+        if (tid < TK_TILE / 32) {
+            const uint32_t lo = (uint32_t)TK2_LEFT + tid * 32u;  // window position of the word's first bit
+            mine_w = brkw[lo >> 5];
+            if (lo + 32u > te) mine_w &= lo >= te ? 0u : ((1u << (te - lo)) - 1u);
+            bits[tid] = mine_w;
+            if (mine_w) need_walk = 1u;  // (the flag of the other branch, zero since phase A: here "the tile has a piece start"; no __syncthreads_or: it costs 256 B of LDS)
+        }
+        __syncthreads();
+        if (need_walk && tile_end < n) {  // (a tile that ends with the text keeps last_end_sh = the end of the text)
+            if (tid == 0) {
+                uint32_t e = 0xFFFFFFFFu;
+                for (uint32_t w = te >> 5; w < (uint32_t)TK2_WIN / 32u && e == 0xFFFFFFFFu; ++w) {  // (te is a multiple of 32 here: a full tile)
+                    const uint32_t v = brkw[w];
+                    if (v) e = w * 32u + (uint32_t)__ffs((int)v) - 1u;
+                }
+                last_end_sh = e;
+            }
+            __syncthreads();
+            if (last_end_sh == 0xFFFFFFFFu) {  // the last piece leaves the window
+                defer_tile();
+                continue;
+            }
+        }
+    } else {
     // ---- B: classes of the lane's 16 bytes as 16-bit masks (tk_chunk.h): table pass, decode pass for non-ASCII chars
     TkChunk ch;
     {
@@ -1027,6 +1060,7 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
     if (!SLOW && nslow_sh) {
         defer_tile();
         continue;
+    }
     }
     if (dbg & 0x8000) {  // (perf experiments: stop after this phase)
         if (tid == 0) out.tile_np[tile] = 0;
