@@ -992,7 +992,7 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
     // other: both are bound by the rate of random accesses -- measured in round 4)
     if (job.d_tok_off) {
         TRY(timed(c, s, "tk_k_docoff", [&] {
-            hipLaunchKernelGGL(tk_k_docoff, dim3(grid_for(job.n_docs + 1, 4, 8192)), dim3(256), 0, s, job.n_docs, job.d_doc_off, job.base, n, w.starts.as<uint32_t>(), tile_nt, res, data,
+            hipLaunchKernelGGL(tk_k_docoff, dim3(grid_for(job.n_docs + 1, 16, 4096)), dim3(256), 0, s, job.n_docs, job.d_doc_off, job.base, n, w.starts.as<uint32_t>(), tile_nt, res, data,
                                (n > 0 && !job.single_piece) ? w.row_base.as<uint32_t>() : (const uint32_t*)nullptr, w.total.as<uint64_t>(), tok_base, job.d_tok_off);
         }));
     }

@@ -677,7 +677,10 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
         if (tid == 0) out.tile_np[tile] = 0;
         continue;
     }
-    if (!SLOW && (dbg & TKF_DBG_HARD_ONLY)) {
+#ifndef TKF_HARD_ONLY
+#define TKF_HARD_ONLY 1
+#endif
+    if (TKF_HARD_ONLY && !SLOW && (dbg & TKF_DBG_HARD_ONLY)) {
         // ---- hard starts only: the pieces that start in the tile begin at its hard starts; the last of them ends at the first hard start
         // at or behind the tile's end -- in the 128 bytes of look-ahead, or the tile is one for the workgroup-wide scanner
         const uint32_t te = (uint32_t)(tile_end - tile_start) + (uint32_t)TK2_LEFT;
@@ -2796,68 +2799,80 @@ __global__ __launch_bounds__(256) void tk_k_bigcopy(const uint32_t* __restrict__
     }
 }
 
-// tok_off[d] = tokens before the piece at which document d starts (one wavefront per document).  The piece is found in the piece-start
-// bitmap of the document's tile (a document start is a hard piece start); its token offset is the tile's place (tile_tb) plus what
-// tk_k_count_tiles has left for the row of 256 pieces it lies in plus the counts of the row's pieces before it -- single tokens count
-// one, the others are read from their entries.  (Needs nothing of tk_k_place: the two run side by side.)
+// tok_off[d] = tokens before the piece at which document d starts.  SIXTEEN LANES per document (round 4; a wavefront per document before:
+// the kernel waits for a chain of five dependent loads per document, so four documents per wavefront are four times the documents in flight).
+// The piece is found in the piece-start bitmap of the document's tile (a document start is a hard piece start); its token offset is the tile's
+// place (tile_tb) plus what tk_k_count_tiles has left for the row of 256 pieces it lies in plus the counts of the row's pieces before it --
+// single tokens count one, the others what their count byte says.  (Needs nothing of tk_k_place.)
+__device__ __forceinline__ uint32_t tk_row16_sum(uint32_t v) {  // sum over the aligned 16 lanes of a DPP row, in every lane of it
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: lane ^ 1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]: lane ^ 2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror: the other quad of 8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);  // row_mirror: the other half of 16
+    return v;
+}
 __global__ __launch_bounds__(256) void tk_k_docoff(uint64_t n_docs, const uint64_t* __restrict__ doc_off, uint64_t chunk_base, uint64_t n,
                                                     const uint32_t* __restrict__ starts, const uint32_t* __restrict__ tile_tb,
                                                     const uint32_t* __restrict__ res, TkMiss data, const uint32_t* __restrict__ row_rel,
                                                     const uint64_t* __restrict__ total, const unsigned long long* __restrict__ tok_base, uint64_t* __restrict__ tok_off) {
     const uint64_t tok_base_global = tok_base[0];  // tokens of the chunks before this one
-    const int lane = threadIdx.x & 63;
-    const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
-    for (uint64_t d = wave; d <= n_docs; d += nwaves) {
-        const uint64_t pos = d < n_docs ? doc_off[d] - chunk_base : n;
-        uint64_t v;
-        if (pos >= n) {
-            v = total[0];  // empty documents at the end of the chunk, and the closing offset
-        } else {
-            const uint32_t t = row_rel ? (uint32_t)(pos / TK_TILE) : 0u, in_tile = (uint32_t)(pos - (uint64_t)t * TK_TILE);  // (no rows: one piece)
-            // pieces of the tile that start before pos
-            uint32_t kp = 0;
-            if (row_rel) {
-                const uint32_t* sw = starts + (uint64_t)t * (TK_TILE / 32);
-                for (uint32_t w = lane; w * 32 < in_tile; w += 64) {
-                    const uint32_t bits = sw[w], rem = in_tile - w * 32;
-                    kp += (uint32_t)__popc(rem >= 32u ? bits : (bits & ((1u << rem) - 1u)));
-                }
-                kp = tk_wave_sum_u32(kp);
-            }
-            const uint32_t rb = t * TKF_CAP;
-            uint64_t row_run = tile_tb[t];
-            uint32_t sum = 0, kstart = 0;
-            if (row_rel && kp >= 256u) {
-                row_run += row_rel[(uint64_t)t * (TKF_CAP / 256) + (kp >> 8)];
-                kstart = kp & ~255u;
-            }
-            {  // the row's pieces before the document's: at most 255, four per lane, all loads without an `if` of their own (in flight together)
-                uint32_t rv[4], cb[4];
+    const uint32_t sl = threadIdx.x & 15u;
+    const uint64_t grp = (blockIdx.x * 256ull + threadIdx.x) >> 4, ngrp = ((uint64_t)gridDim.x * 256) >> 4;
+    const uint64_t rounds = (n_docs + 1 + ngrp - 1) / ngrp;  // (every group runs the same number of rounds: the row sums are wave-wide instructions)
+    for (uint64_t r = 0; r < rounds; ++r) {
+        const uint64_t d = grp + r * ngrp;
+        const bool have = d <= n_docs;
+        const uint64_t pos = (have && d < n_docs) ? doc_off[d] - chunk_base : n;
+        const bool inside = pos < n;  // (else: empty documents at the end of the chunk, and the closing offset -> the chunk's total)
+        const uint32_t t = (inside && row_rel) ? (uint32_t)(pos / TK_TILE) : 0u, in_tile = inside ? (uint32_t)(pos - (uint64_t)t * TK_TILE) : 0u;  // (no rows: one piece)
+        // pieces of the tile that start before pos: eight words of the tile's 120 per lane
+        uint32_t kp = 0;
+        if (row_rel) {
+            const uint32_t* sw = starts + (uint64_t)t * (TK_TILE / 32) + sl * 8u;
+            const bool any = sl * 256u < in_tile;
+            const uint4 a = *(const uint4*)(any ? sw : starts), b = *(const uint4*)(any && sl * 256u + 128u < in_tile ? sw + 4 : starts);
+            const uint32_t w[8] = {a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w};
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const uint32_t k = kstart + (uint32_t)j * 64u + (uint32_t)lane;
-                    rv[j] = res[rb + (k < kp ? k : kstart)];
-                    if (k >= kp) rv[j] = TK_RES_GAP;
-                }
-                bool escape = false;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool flagged = rv[j] != TK_RES_GAP && (rv[j] & TK_RES_FLAG), in_tab = flagged && (rv[j] & ~TK_RES_FLAG) < data.ovf_base;
-                    cb[j] = data.cnt8[in_tab ? (rv[j] & ~TK_RES_FLAG) : 0u];
-                    if (flagged && (!in_tab || cb[j] == 255u)) escape = true;
-                    else sum += flagged ? cb[j] : (rv[j] != TK_RES_GAP ? 1u : 0u);
-                }
-                if (__ballot(escape)) {
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool flagged = rv[j] != TK_RES_GAP && (rv[j] & TK_RES_FLAG), in_tab = flagged && (rv[j] & ~TK_RES_FLAG) < data.ovf_base;
-                        if (flagged && (!in_tab || cb[j] == 255u)) sum += TKD_COUNT(data.head(rv[j] & ~TK_RES_FLAG)[2]);
-                    }
-                }
+            for (int j = 0; j < 8; ++j) {
+                const uint32_t lo = sl * 256u + (uint32_t)j * 32u;
+                if (lo < in_tile) kp += (uint32_t)__popc(in_tile - lo >= 32u ? w[j] : (w[j] & ((1u << (in_tile - lo)) - 1u)));
             }
-            v = row_run + tk_wave_sum_u32(sum);
+            kp = tk_row16_sum(kp);
         }
-        if (lane == 0) tok_off[d] = tok_base_global + v;
+        const uint32_t rb = t * TKF_CAP;
+        uint64_t row_run = tile_tb[t];
+        uint32_t kstart = 0;
+        if (row_rel && kp >= 256u) {
+            row_run += row_rel[(uint64_t)t * (TKF_CAP / 256) + (kp >> 8)];
+            kstart = kp & ~255u;
+        }
+        // the row's pieces before the document's: at most 255, sixteen per lane, all loads without an `if` of their own
+        uint32_t sum = 0;
+        {
+            const uint32_t k0 = kstart + sl * 16u;
+            const uint32_t* rp = res + rb + (k0 < kp ? k0 : kstart);
+            const uint4 q0 = ((const uint4*)rp)[0], q1 = ((const uint4*)rp)[1], q2 = ((const uint4*)rp)[2], q3 = ((const uint4*)rp)[3];
+            uint32_t rv[16] = {q0.x, q0.y, q0.z, q0.w, q1.x, q1.y, q1.z, q1.w, q2.x, q2.y, q2.z, q2.w, q3.x, q3.y, q3.z, q3.w};
+            uint32_t cb[16];
+            bool escape = false;
+#pragma unroll
+            for (int j = 0; j < 16; ++j) {
+                if (k0 + (uint32_t)j >= kp) rv[j] = TK_RES_GAP;
+                const bool flagged = rv[j] != TK_RES_GAP && (rv[j] & TK_RES_FLAG), in_tab = flagged && (rv[j] & ~TK_RES_FLAG) < data.ovf_base;
+                cb[j] = data.cnt8[in_tab ? (rv[j] & ~TK_RES_FLAG) : 0u];
+                if (flagged && (!in_tab || cb[j] == 255u)) escape = true;
+                else sum += flagged ? cb[j] : (rv[j] != TK_RES_GAP ? 1u : 0u);
+            }
+            if (escape) {  // (rare: an overflow entry, a piece of 255 tokens and more)
+#pragma unroll
+                for (int j = 0; j < 16; ++j) {
+                    const bool flagged = rv[j] != TK_RES_GAP && (rv[j] & TK_RES_FLAG), in_tab = flagged && (rv[j] & ~TK_RES_FLAG) < data.ovf_base;
+                    if (flagged && (!in_tab || cb[j] == 255u)) sum += TKD_COUNT(data.head(rv[j] & ~TK_RES_FLAG)[2]);
+                }
+            }
+        }
+        const uint64_t v = inside ? row_run + tk_row16_sum(sum) : total[0];
+        if (have && sl == 0) tok_off[d] = tok_base_global + v;
     }
 }
 
