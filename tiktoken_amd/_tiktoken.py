@@ -7,12 +7,28 @@ Same constructor and the same eleven methods, same exception types.  Two additiv
 """
 from __future__ import annotations
 
+import atexit
 import ctypes
+import weakref
 from typing import AbstractSet, Sequence
 
 import numpy as np
 
 from . import _lib
+
+# Cores that are still alive when the interpreter shuts down are destroyed by an atexit handler -- i.e. BEFORE the HIP runtime's own static
+# destructors run at process exit.  A tk_destroy from a late __del__ (module teardown, or later still) would free streams and page-locked
+# buffers of a runtime that is already gone.
+_live_cores: "weakref.WeakSet[CoreBPE]" = weakref.WeakSet()
+
+
+@atexit.register
+def _destroy_live_cores():
+    for core in sorted(_live_cores, key=lambda c: getattr(c, "_group", None) is None):  # (a group before the replicas it refers to)
+        try:
+            core.close()
+        except Exception:
+            pass
 
 # char::is_whitespace (Rust, lib.rs:583) = the Unicode White_Space property
 _WHITE_SPACE = frozenset(map(chr, [9, 10, 11, 12, 13, 32, 0x85, 0xA0, 0x1680, *range(0x2000, 0x200B), 0x2028, 0x2029, 0x202F, 0x205F, 0x3000]))
@@ -129,6 +145,7 @@ class CoreBPE:
             encoder._distinct = True  # (tk_create refuses a token listed twice)
         self._h = h
         self._L = L
+        _live_cores.add(self)
         self.device = device
         self.devices = devices
         if len(devices) > 1:
@@ -139,6 +156,10 @@ class CoreBPE:
             self._group = grp
 
     def __del__(self):
+        self.close()
+
+    def close(self):
+        """Releases the native core (tables, workspace, streams).  Idempotent; the object is unusable afterwards."""
         g, self._group = getattr(self, "_group", None), None
         if g:
             try:
