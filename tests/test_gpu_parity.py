@@ -206,6 +206,40 @@ def test_text_at_any_device_address():
         assert np.array_equal(toff, ro) and np.array_equal(toks, rt), shift
 
 
+def test_alternating_result_buffers(cores):
+    """tk_set_output_buffers(core, 2): the ids and offsets of a device-resident call stay where they are while the NEXT call runs (a consumer
+    on another stream -- the gather of the several-process bench -- reads them without a copy); with one pair (the default) the next call
+    writes over them."""
+    import torch
+
+    core = cores["o200k_shaped"]
+    C = h.c_oracle_for("o200k_shaped")
+    batches = []
+    for seed in (0xB0F1, 0xB0F2, 0xB0F3):
+        blob, off = h.gen_corpus(seed, 1, 3 << 20)
+        host = np.zeros(len(blob) + 64, np.uint8)
+        host[: len(blob)] = blob
+        batches.append((torch.from_numpy(host).cuda(), torch.from_numpy(off.view(np.int64)).cuda(), off, int(off[-1]), C.encode_batch(blob[: int(off[-1])], off, None, 8)))
+    core.set_output_buffers(2)
+    try:
+        prev = None
+        for d_text, d_off, off, n, (rt, ro) in batches:
+            dt, nt, do = core.encode_batch_device(d_text.data_ptr(), n, d_off.data_ptr(), off, len(off) - 1)
+            if prev is not None:  # the call before this one: still intact, and not the same buffers
+                pdt, pnt, pdo, prt, pro, pnd = prev
+                assert pdt != dt and pdo != do
+                assert np.array_equal(h.dev_u32(pdt, pnt), prt) and np.array_equal(h.dev_u64(pdo, pnd + 1), pro)
+            assert np.array_equal(h.dev_u32(dt, nt), rt) and np.array_equal(h.dev_u64(do, len(off)), ro)
+            prev = (dt, nt, do, rt, ro, len(off) - 1)
+    finally:
+        core.set_output_buffers(1)
+    a = core.encode_batch_device(batches[0][0].data_ptr(), batches[0][3], batches[0][1].data_ptr(), batches[0][2], len(batches[0][2]) - 1)
+    b = core.encode_batch_device(batches[1][0].data_ptr(), batches[1][3], batches[1][1].data_ptr(), batches[1][2], len(batches[1][2]) - 1)
+    assert a[0] == b[0]  # one pair again
+    with pytest.raises(ValueError):
+        core.set_output_buffers(3)
+
+
 def test_multi_chunk_batches(monkeypatch):
     """Batches larger than the per-launch chunk are cut at document boundaries (tk_api.hip); force a tiny
     chunk so that a 3 MiB batch needs many launches, incl. documents larger than the chunk itself."""
