@@ -1874,10 +1874,11 @@ __global__ __launch_bounds__(64 * TKM_WAVES, TKM_MIN_WAVES_EU) void tk_k_merge_a
                 const uint32_t k = k0 + c;
                 const uint32_t b0 = (uint32_t)((c < 8 ? w0 >> (8 * c) : w1 >> (8 * (c - 8))) & 0xFFu);
                 const uint32_t b1 = (uint32_t)((c < 7 ? w0 >> (8 * (c + 1)) : (c < 15 ? w1 >> (8 * (c - 7)) : w2)) & 0xFFu);
-                rr[c] = TK_RANK_MAX;
+                // (both look-ups by loads that stand in no `if` of their own: the sixteen positions' loads are in flight together)
+                const uint32_t br = T.byte_rank[k < n ? b0 : 0u], p2 = T.pair2[k + 1 < n ? ((b0 << 8) | b1) : 0u];
+                rr[c] = k + 1 < n ? p2 : TK_RANK_MAX;
                 if (k < n) {
-                    id[c] = T.byte_rank[b0];
-                    if (k + 1 < n) rr[c] = T.pair2[(b0 << 8) | b1];
+                    id[c] = br;
                     mask |= 1u << c;
                 }
             }
