@@ -966,9 +966,9 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
     if (n > 0) {
         // token count per tile (a missed piece's count from its entry), then the tiles' places (tk_fused.h: back end)
         TRY(timed(c, s, "tk_k_count_tiles", [&] {
-            if (small_rows) hipLaunchKernelGGL(tk_k_count_tiles<1>, dim3(grid_for(ntiles, 4, 2048)), dim3(256), 0, s, ntiles, tile_np, res, data, tile_nt, w.row_base.as<uint32_t>(),
+            if (small_rows) hipLaunchKernelGGL(tk_k_count_tiles<1>, dim3(grid_for(ntiles, 4, 2048)), dim3(256), 0, s, ntiles, tile_np, res, data, tile_nt,
                                w.total.as<unsigned long long>());
-            else hipLaunchKernelGGL(tk_k_count_tiles<TKP_ROWS_COUNT>, dim3(grid_for(ntiles, 4, 2048)), dim3(256), 0, s, ntiles, tile_np, res, data, tile_nt, w.row_base.as<uint32_t>(),
+            else hipLaunchKernelGGL(tk_k_count_tiles<TKP_ROWS_COUNT>, dim3(grid_for(ntiles, 4, 2048)), dim3(256), 0, s, ntiles, tile_np, res, data, tile_nt,
                                w.total.as<unsigned long long>());
         }));
         TRY(scan_u32(c, w, s, tile_nt, ntiles, w.total.as<uint64_t>()));
@@ -982,8 +982,8 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
     HIPCHK(hipEventRecord(w.ev_tot, s));
     if (n > 0) {
         TRY(timed(c, s, "tk_k_place", [&] {
-            if (small_rows) hipLaunchKernelGGL(tk_k_place<1>, dim3(grid_for(ntiles, 4, 4096)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, data, stg, d_out, tok_base, w.big.as<uint32_t>());
-            else hipLaunchKernelGGL(tk_k_place<TKP_ROWS_PLACE>, dim3(grid_for(ntiles, 4, 4096)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, data, stg, d_out, tok_base, w.big.as<uint32_t>());
+            if (small_rows) hipLaunchKernelGGL(tk_k_place<1>, dim3(grid_for(ntiles, 4, 4096)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, data, stg, d_out, tok_base, w.big.as<uint32_t>(), w.row_base.as<uint32_t>());
+            else hipLaunchKernelGGL(tk_k_place<TKP_ROWS_PLACE>, dim3(grid_for(ntiles, 4, 4096)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, data, stg, d_out, tok_base, w.big.as<uint32_t>(), w.row_base.as<uint32_t>());
         }));
     }
     if (n > TK_BIGCOPY)  // (a token run of TK_BIGCOPY tokens needs at least as many bytes)

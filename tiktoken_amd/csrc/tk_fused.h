@@ -52,6 +52,13 @@
 #define TKF_DBG_HARD_ONLY 0x40000000
 #define TKF_BATCH 960  // pieces per probe batch of the front kernel (the class lists hold 1024 entries, their packed counter 1023)
 #define TKF_CAP 4096  // piece ids per tile: pid = tile * TKF_CAP + k (a 4096-byte tile starts at most 4096 pieces)
+// The tail of a tile's run of result words holds, from the back: the number of its pieces that are not tokens (TKF_TAIL_NMISS), the number
+// of its gap chars (TKF_TAIL_NGAP), then the entries of the pieces that are not tokens once more, in no particular order -- what the counting
+// pass of the back end needs, 0.12 GB per GiB instead of all the result words (0.65 GB).  It always fits: a piece that is not a token has at
+// least two bytes, so pieces + missed pieces <= the tile's 3840 bytes.
+#define TKF_TAIL_NMISS (TKF_CAP - 1)
+#define TKF_TAIL_NGAP (TKF_CAP - 2)
+#define TKF_TAIL_REFS (TKF_CAP - 3)  // the q-th missed piece's entry: res[run + TKF_TAIL_REFS - q]
 
 // Per-piece result word res[piece id]: a token id (the piece is a vocabulary token, src/lib.rs:367), or a reference to where its
 // tokens will be once the merge kernels have run.
@@ -574,7 +581,7 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
     __shared__ uint32_t certw[TK2_WIN / 32];                                         // certain starts (hard starts included)
     __shared__ uint32_t bits[TK_TILE / 32];
     __shared__ uint8_t lastc_own[256];
-    __shared__ uint32_t np_sh, need_walk, last_end_sh, ncls_sh, nx_sh, ncont_sh;
+    __shared__ uint32_t np_sh, need_walk, last_end_sh, ncls_sh, nx_sh, ncont_sh, ngap_sh;
     __shared__ __attribute__((aligned(8))) uint16_t contl_own[SLOW ? TKF_CONT_CAP : 4], stop_own[SLOW ? 256 : 4];  // (read as 32-bit words)
     // second window of the deferred-tile variant: a stretch of text left of the tile, walked by tk_coop_window_walk
     __shared__ __attribute__((aligned(16))) uint8_t w2_raw[SLOW ? TK2_WIN + 16 : 16];
@@ -1135,6 +1142,8 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
             }
         }
     };
+    uint32_t miss_total = 0;  // pieces of the tile that are not tokens, so far (uniform)
+    if (GEN && tid == 0) ngap_sh = 0;
     for (uint32_t kb = 0; kb < np; kb += TKF_BATCH) {
         const uint32_t nb = np - kb < TKF_BATCH ? np - kb : (uint32_t)TKF_BATCH;
         if (tid == 0) {
@@ -1157,6 +1166,7 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
                 } else if (GEN && gapb && ((gapb[(uint64_t)(base + s_loc) >> 5] >> ((uint32_t)(base + s_loc) & 31u)) & 1u)) {  // a gap char: no token
                     // (read from global memory per piece: only a pat_str of the generic engine has the bitmap, and LDS is what this kernel lacks)
                     out.res[run_base + k] = TK_RES_GAP;
+                    atomicAdd(&ngap_sh, 1u);  // (LDS; gap chars are rare)
                     cls = 3;
                 } else if (HOT && use_hot && len <= TK_HOT_MAXLEN) {  // the piece cache in LDS first; the tables in HBM only on a miss
                     uint32_t k0, k1, k2;
@@ -1430,7 +1440,10 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
                     if (len > TK_GLANE_MAX) tk_append_tree(out.listC, out.counters, ref, (uint32_t)gs, len);
                 }
             }
-            if (q < n_x) out.res[run_base + k] = ref != TKF_NONE ? (TK_RES_FLAG | ref) : 0u;
+            if (q < n_x) {
+                out.res[run_base + k] = ref != TKF_NONE ? (TK_RES_FLAG | ref) : 0u;
+                out.res[run_base + TKF_TAIL_REFS - (miss_total + q)] = ref;  // (TKF_NONE = 0xFFFFFFFF: counts as the one token 0 the result word holds; the batch is repeated with more room)
+            }
             // its later occurrences in this workgroup's tiles are duplicates without a probe: the slot goes into the piece cache
             if (use_hot && q < n_x && len <= TK_HOT_MAXLEN && ref != TKF_NONE && ref < out.data.ovf_base) {
                 uint32_t k0, k1, k2;
@@ -1438,7 +1451,12 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
                 hot_insert(k0, k1, k2, len, TK_HOT_DUP | ref);
             }
         }
+        miss_total += n_x;
         __syncthreads();  // (the lists are reused by the next batch)
+    }
+    if (tid == 0 && np) {
+        out.res[run_base + TKF_TAIL_NMISS] = miss_total;
+        out.res[run_base + TKF_TAIL_NGAP] = GEN ? ngap_sh : 0u;
     }
     } while (PERSIST && (item += gridDim.x) < n_items);
     if constexpr (HOT) {  // statistics of the piece cache (two fire-and-forget atomics per wavefront)
@@ -2562,76 +2580,70 @@ __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds_wide(TkTables T
 #define TKP_ROWS_PLACE 3
 #endif
 
-// tile_nt[t] <- tokens of tile t; row_rel[t * (TKF_CAP / 256) + r] <- tokens of the tile's rows before row r (for tk_k_docoff);
-// total[1] += pieces of the chunk.  One wavefront per tile at a time; the loads of TKP_ROWS_COUNT rows are in flight together (the kernel waits
-// for memory: the result words stream from HBM, a missed piece's count is one byte of an L2-resident array).
+// tile_nt[t] <- tokens of tile t = its pieces - its gap chars + what its pieces that are not tokens have beyond one token each; total[1] +=
+// pieces of the chunk.  One wavefront per tile at a time.  Round 4, second form: the front kernel leaves the entries of a tile's missed pieces
+// once more at the tail of the tile's run of result words (TKF_TAIL_*), so this pass reads 0.12 GB per GiB instead of every result word
+// (0.65 GB), four refs per lane and their count bytes (an L2-resident array) in flight together.  (The sums of a tile's rows of 256 pieces,
+// which the document offsets need, come from tk_k_place now.)
 template <int ROWS>
 __global__ __launch_bounds__(256) void tk_k_count_tiles(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ res, TkMiss data,
-                                                        uint32_t* __restrict__ tile_nt, uint32_t* __restrict__ row_rel, unsigned long long* __restrict__ total) {
+                                                        uint32_t* __restrict__ tile_nt, unsigned long long* __restrict__ total) {
+    // HALF a wavefront per tile (a tile of web text has ~110 missed pieces; the pass is a chain of four dependent loads per tile, so two tiles
+    // per wavefront are twice the tiles in flight); every half runs the same number of rounds (the sums are wave-wide instructions)
     const int lane = threadIdx.x & 63;
-    const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
+    const uint32_t hl = (uint32_t)lane & 31u;
+    const uint64_t half = (blockIdx.x * 256ull + threadIdx.x) >> 5, nhalves = ((uint64_t)gridDim.x * 256) >> 5;
+    const uint64_t rounds = (ntiles + nhalves - 1) / nhalves;
     unsigned long long pieces = 0;
-    uint32_t np_next = wave < ntiles ? tile_np[wave] : 0u;
-    for (uint64_t t = wave; t < ntiles; t += nwaves) {
-        const uint32_t np = np_next, rb = (uint32_t)t * TKF_CAP;
-        np_next = t + nwaves < ntiles ? tile_np[t + nwaves] : 0u;  // (the next tile's size is on its way while this tile is counted)
-        pieces += np;
-        uint32_t run = 0;
-        for (uint32_t k0 = 0; k0 < np; k0 += 256u * ROWS) {
-            uint4 t4[ROWS];
+    uint32_t np_next = half < ntiles ? tile_np[half] : 0u;
+    for (uint64_t r = 0; r < rounds; ++r) {
+        const uint64_t t = half + r * nhalves;
+        const bool have = t < ntiles;
+        const uint32_t np = np_next, rb = have ? (uint32_t)t * TKF_CAP : 0u;
+        np_next = t + nhalves < ntiles ? tile_np[t + nhalves] : 0u;  // (the next tile's size is on its way while this tile is counted)
+        if (hl == 0) pieces += np;
+        uint2 tail = make_uint2(0u, 0u);  // {gap chars, missed pieces}
+        if (np) tail = *(const uint2*)(res + rb + TKF_TAIL_NGAP);
+        const uint32_t ng = tail.x, nm = tail.y;
+        uint32_t extra = 0;
+        const uint32_t nm_max = max(nm, (uint32_t)__shfl_xor((int)nm, 32, 64));  // (both halves walk the longer list)
+        for (uint32_t q0 = 0; q0 < nm_max; q0 += 32u * ROWS * 2u) {
+            uint32_t ref[ROWS * 2], cb[ROWS * 2];
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const uint32_t k = k0 + (uint32_t)r * 256u + (uint32_t)lane * 4u;
-                t4[r] = *(const uint4*)(res + rb + (k < np ? k : 0u));  // (runs start 16-byte aligned, and a run's storage extends to the next multiple of four; no `if` around the load)
+            for (int j = 0; j < ROWS * 2; ++j) {
+                const uint32_t q = q0 + (uint32_t)j * 32u + hl;
+                ref[j] = res[rb + TKF_TAIL_REFS - (q < nm ? q : 0u)];
+                if (q >= nm) ref[j] = 0xFFFFFFFFu;  // (also what the front kernel leaves for a piece it had no entry for: one token)
             }
-            // (the count bytes of all the missed pieces by loads that do not depend on anything but the result words: a load inside an
-            // `if` of its own waits for its data before the next `if` is even looked at -- twelve latencies one after the other)
-            uint32_t c[ROWS][4];
-            bool escape = false;  // a piece whose count is not in the byte array (an overflow entry, 255 tokens and more)
+            bool escape = false;
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const uint32_t k = k0 + (uint32_t)r * 256u + (uint32_t)lane * 4u;
-                const uint32_t w[4] = {t4[r].x, t4[r].y, t4[r].z, t4[r].w};
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool live = k + j < np, flagged = live && (w[j] & TK_RES_FLAG), in_tab = flagged && (w[j] & ~TK_RES_FLAG) < data.ovf_base;
-                    const uint32_t cb = data.cnt8[in_tab ? (w[j] & ~TK_RES_FLAG) : 0u];
-                    c[r][j] = flagged ? cb : ((live && w[j] != TK_RES_GAP) ? 1u : 0u);
-                    if (flagged && (!in_tab || cb == 255u)) {
-                        c[r][j] = 0xFFFFFFFFu;
-                        escape = true;
-                    }
-                }
+            for (int j = 0; j < ROWS * 2; ++j) {
+                const bool in_tab = ref[j] < data.ovf_base;
+                cb[j] = data.cnt8[in_tab ? ref[j] : 0u];
+                if (ref[j] != 0xFFFFFFFFu && (!in_tab || cb[j] == 255u)) escape = true;
+                else if (in_tab) extra += cb[j] - 1u;
             }
-            if (__ballot(escape)) {  // (again without an `if` per load: a batch of many distinct pieces has most of them in overflow entries)
+            if (__ballot(escape)) {  // (an overflow entry, a piece of 255 tokens and more: the entry itself)
 #pragma unroll
-                for (int r = 0; r < ROWS; ++r) {
-                    const uint32_t w[4] = {t4[r].x, t4[r].y, t4[r].z, t4[r].w};
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        const bool esc = c[r][j] == 0xFFFFFFFFu;
-                        const uint32_t cw = data.head(esc ? (w[j] & ~TK_RES_FLAG) : data.ovf_base)[2];
-                        if (esc) c[r][j] = TKD_COUNT(cw);
-                    }
-                }
-            }
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                if (k0 + (uint32_t)r * 256u < np) {
-                    if (lane == 0) row_rel[t * (TKF_CAP / 256) + (k0 >> 8) + r] = run;
-                    run += tk_wave_sum_u32(c[r][0] + c[r][1] + c[r][2] + c[r][3]);
+                for (int j = 0; j < ROWS * 2; ++j) {
+                    const bool in_tab = ref[j] < data.ovf_base, esc = ref[j] != 0xFFFFFFFFu && (!in_tab || cb[j] == 255u);
+                    const uint32_t cw = data.head(esc ? ref[j] : data.ovf_base)[2];
+                    if (esc) extra += TKD_COUNT(cw) - 1u;
                 }
             }
         }
-        if (lane == 0) tile_nt[t] = run;
+        extra = tk_row16_sum(extra);                                   // the sixteen lanes of a DPP row
+        extra += (uint32_t)__shfl_xor((int)extra, 16, 64);             // ... and the other row of the half
+        if (have && hl == 0) tile_nt[t] = np - ng + extra;
     }
     // (one atomic per WORKGROUP: same-address atomics are served one after the other at ~10 M/s on this part -- one per wavefront of a
     // 4096-workgroup grid was 0.2 ms, the floor of this kernel however small the chunk)
-    __shared__ unsigned long long pieces_sh[4];
-    if (lane == 0) pieces_sh[threadIdx.x >> 6] = pieces;
+    __shared__ unsigned long long pieces_sh[8];
+    if (hl == 0) pieces_sh[threadIdx.x >> 5] = pieces;
     __syncthreads();
     if (threadIdx.x == 0) {
-        const unsigned long long p = pieces_sh[0] + pieces_sh[1] + pieces_sh[2] + pieces_sh[3];
+        unsigned long long p = 0;
+        for (int i = 0; i < 8; ++i) p += pieces_sh[i];
         if (p) atomicAdd(&total[1], p);
     }
 }
@@ -2646,7 +2658,8 @@ __global__ __launch_bounds__(256) void tk_k_count_tiles(uint64_t ntiles, const u
 template <int ROWS>
 __global__ __launch_bounds__(256, TKP_PLACE_OCC) void tk_k_place(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_tb,
                                                   const uint32_t* __restrict__ res, TkMiss data, const uint32_t* __restrict__ staging, uint32_t* __restrict__ out_all,
-                                                  const unsigned long long* __restrict__ tok_base, uint32_t* __restrict__ big) {
+                                                  const unsigned long long* __restrict__ tok_base, uint32_t* __restrict__ big,
+                                                  uint32_t* __restrict__ row_abs /* [tile * 16 + r]: tokens of the chunk before row r of the tile (for tk_k_docoff) */) {
     __shared__ uint32_t mlist_sh[4][256 * 3];
     // the chunk's tokens follow those of the chunks before it: their number stays on the device (chunks are pipelined, the host does
     // not know it when it queues this kernel)
@@ -2688,6 +2701,7 @@ __global__ __launch_bounds__(256, TKP_PLACE_OCC) void tk_k_place(uint64_t ntiles
 #pragma unroll
             for (int r = 0; r < ROWS; ++r) {
                 if (k0 + (uint32_t)r * 256u >= np) break;
+                if (lane == 0) row_abs[t * (TKF_CAP / 256) + (k0 >> 8) + (uint32_t)r] = run;
                 uint32_t c[4];
 #pragma unroll
                 for (int j = 0; j < 4; ++j) c[j] = (tk[r][j] & TK_RES_FLAG) ? TKD_COUNT(hd[r][j].x) : (tk[r][j] != TK_RES_GAP ? 1u : 0u);
@@ -2805,16 +2819,9 @@ __global__ __launch_bounds__(256) void tk_k_bigcopy(const uint32_t* __restrict__
 // The piece is found in the piece-start bitmap of the document's tile (a document start is a hard piece start); its token offset is the tile's
 // place (tile_tb) plus what tk_k_count_tiles has left for the row of 256 pieces it lies in plus the counts of the row's pieces before it --
 // single tokens count one, the others what their count byte says.  (Needs nothing of tk_k_place.)
-__device__ __forceinline__ uint32_t tk_row16_sum(uint32_t v) {  // sum over the aligned 16 lanes of a DPP row, in every lane of it
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: lane ^ 1
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]: lane ^ 2
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror: the other quad of 8
-    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);  // row_mirror: the other half of 16
-    return v;
-}
 __global__ __launch_bounds__(256) void tk_k_docoff(uint64_t n_docs, const uint64_t* __restrict__ doc_off, uint64_t chunk_base, uint64_t n,
                                                     const uint32_t* __restrict__ starts, const uint32_t* __restrict__ tile_tb,
-                                                    const uint32_t* __restrict__ res, TkMiss data, const uint32_t* __restrict__ row_rel,
+                                                    const uint32_t* __restrict__ res, TkMiss data, const uint32_t* __restrict__ row_rel /* tk_k_place's row_abs */,
                                                     const uint64_t* __restrict__ total, const unsigned long long* __restrict__ tok_base, uint64_t* __restrict__ tok_off) {
     const uint64_t tok_base_global = tok_base[0];  // tokens of the chunks before this one
     const uint32_t sl = threadIdx.x & 15u;
@@ -2843,8 +2850,8 @@ __global__ __launch_bounds__(256) void tk_k_docoff(uint64_t n_docs, const uint64
         const uint32_t rb = t * TKF_CAP;
         uint64_t row_run = tile_tb[t];
         uint32_t kstart = 0;
-        if (row_rel && kp >= 256u) {
-            row_run += row_rel[(uint64_t)t * (TKF_CAP / 256) + (kp >> 8)];
+        if (row_rel && kp >= 256u) {  // (the row's place in the chunk, left by tk_k_place: the document's first piece is piece kp of the tile, so the row exists)
+            row_run = row_rel[(uint64_t)t * (TKF_CAP / 256) + (kp >> 8)];
             kstart = kp & ~255u;
         }
         // the row's pieces before the document's: at most 255, sixteen per lane, all loads without an `if` of their own
@@ -2888,9 +2895,12 @@ __global__ void tk_k_single_front(TkTables T, const uint8_t* __restrict__ text, 
     if (blockIdx.x || threadIdx.x) return;
     out.tile_np[0] = 1;
     const uint32_t r = (no_lookup && n > 1u) ? TK_RANK_MAX : tk_lookup_text_piece(T, text, 0, n);
+    out.res[TKF_TAIL_NGAP] = 0;
+    out.res[TKF_TAIL_NMISS] = r != TK_RANK_MAX ? 0u : 1u;  // (the tail of the one tile's run: what tk_k_count_tiles reads)
     if (r != TK_RANK_MAX) {
         out.res[0] = r;
     } else {  // the one overflow entry of the chunk
+        out.res[TKF_TAIL_REFS] = out.data.ovf_base;
         out.res[0] = TK_RES_FLAG | out.data.ovf_base;
         *(uint4*)&out.data.ovf[0].start = make_uint4(0u, n, 0u, 0u);
         out.counters[TK_CNT_OVF] = 1;

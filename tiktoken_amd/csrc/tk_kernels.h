@@ -68,6 +68,13 @@ __device__ __forceinline__ uint32_t tk_wave_sum_u32(uint32_t v) {
     for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
     return v;
 }
+__device__ __forceinline__ uint32_t tk_row16_sum(uint32_t v) {  // sum over the aligned 16 lanes of a DPP row, in every lane of it
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, true);   // quad_perm [1,0,3,2]: lane ^ 1
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, true);   // quad_perm [2,3,0,1]: lane ^ 2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x141, 0xF, 0xF, true);  // row_half_mirror: the other quad of 8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, true);  // row_mirror: the other half of 16
+    return v;
+}
 // inclusive prefix sum across the wave
 __device__ __forceinline__ uint32_t tk_wave_scan_u32(uint32_t v, int lane) {
 #pragma unroll
