@@ -263,6 +263,48 @@ def test_small_calls_of_several_threads_overlap():
     assert t8 < t1 / 1.4, (t1, t8)  # (measured 2.2-2.8x: profiles/r03_small_calls.txt; the launch path of the HIP runtime is the shared part)
 
 
+def test_small_calls_scale_with_native_threads(tmp_path):
+    """The same without an interpreter in the loop (tools/ubench/small_threads.c, built here with gcc): Python threads stop at ~85 k calls/s
+    whatever the library does, because every call's marshalling holds the GIL.  Callers that arrive together share a launch (flat
+    combining, tk_api.hip encode_small).  Measured: 1 thread 26 k calls/s, 8 threads 143 k (5.5x), 16 threads 218 k (8.4x)
+    (profiles/r04_small_calls.txt); asserted: every result right, and 8 threads at least 3x one."""
+    import ctypes
+    import shutil
+    import subprocess
+
+    if not shutil.which("gcc"):
+        pytest.skip("no gcc on this box")
+    so = str(tmp_path / "tk_small_threads.so")
+    subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-pthread", os.path.join(h.ROOT, "tools", "ubench", "small_threads.c"), "-o", so])
+    H = ctypes.CDLL(so)
+    H.tk_small_threads.restype = ctypes.c_double
+    H.tk_small_threads.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                                   ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]
+    enc = tiktoken.get_encoding("o200k_shaped")
+    core = enc._core_bpe
+    text = ("The quick brown fox jumps over the lazy dog; 3.14159 and so on, ünïcödé too. " * 3)[:180]
+    data = np.frombuffer(text.encode(), np.uint8)
+    want = len(oracle_encode("o200k_shaped", text))
+    assert enc.encode_ordinary(text) == oracle_encode("o200k_shaped", text)
+    L = core._L
+    fe, ff = ctypes.cast(L.tk_encode_ordinary, ctypes.c_void_p), ctypes.cast(L.tk_free, ctypes.c_void_p)
+
+    def rate(nth, per):
+        tok, bad = ctypes.c_uint64(), ctypes.c_int()
+        r = H.tk_small_threads(fe, ff, core._h, data.ctypes.data, len(data), nth, per, ctypes.byref(tok), ctypes.byref(bad))
+        assert bad.value == 0 and tok.value == want * nth * per
+        return r
+
+    rate(8, 200)
+    r1 = max(rate(1, 4000) for _ in range(2))
+    r8 = max(rate(8, 1500) for _ in range(2))
+    l0, c0 = core.stat("small_launches"), core.stat("small_calls")
+    r16 = rate(16, 1000)
+    l1, c1 = core.stat("small_launches"), core.stat("small_calls")
+    print(f"native threads: 1 -> {r1:.0f} calls/s, 8 -> {r8:.0f} ({r8 / r1:.2f}x), 16 -> {r16:.0f} ({r16 / r1:.2f}x, {(c1 - c0) / max(l1 - l0, 1):.2f} calls per launch)")
+    assert r8 >= 3.0 * r1, (r1, r8)
+
+
 def test_real_vocab_known_answers_if_available():
     """Appendix B of SURVEY.md: runs only when the sha256-pinned stock files are in $TIKTOKEN_CACHE_DIR."""
     cache = os.environ.get("TIKTOKEN_CACHE_DIR")

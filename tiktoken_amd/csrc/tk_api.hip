@@ -65,7 +65,7 @@ struct KernelStat {
 };
 
 #define TK_NAUX 6  // side streams of the merge kernels
-#define TK_SMALL_SLOTS 8  // small calls in flight at the same time (tk_core::SmallSlot)
+#define TK_SMALL_SLOTS 16  // small calls in flight at the same time (tk_core::SmallSlot; = TK_SMALL_BATCH: one launch can carry them all)
 #define TK_NSET 4  // chunks in flight (work sets): the front kernel of chunk k + 1 runs while chunk k is merged and its tokens are placed
 
 // Work buffers of ONE chunk in flight.
@@ -154,15 +154,24 @@ struct tk_core {
     // free slot (one atomic exchange), launches, watches the slot's completion word.
     struct SmallSlot {
         std::atomic<int> busy{0};
+        std::atomic<int> state{0};  // 0 idle, 1 ready (input written, waiting for a launch), 2 launched
         uint8_t* in = nullptr;    // page-locked, device-visible: text of the call
         uint32_t* out = nullptr;  // page-locked, device-visible: its result
         void *d_in = nullptr, *d_out = nullptr;
-        uint32_t seq = 0;
+        uint32_t seq = 0, n = 0;
         Buf ws;
         hipStream_t s = nullptr;
         bool ready = false;       // every piece above has been made (set last: a first use that failed half-way is repeated by the next caller)
     };
     SmallSlot small[TK_SMALL_SLOTS];
+    // Callers of small calls that arrive together go out in ONE launch (flat combining): whoever gets this mutex -- try_lock: nobody waits for
+    // it -- launches every slot that is ready, his own included or not (someone else may have taken it along already); the others watch
+    // their completion words.  The streams of the launches take turns so that consecutive batches overlap on the device.
+    std::mutex small_launch_mu;
+    std::atomic<int> small_active{0};  // callers inside encode_small
+    hipStream_t small_s[4] = {};
+    uint32_t small_turn = 0;
+    uint64_t st_small_launches = 0, st_small_calls = 0;
     std::vector<uint8_t> sorted_blob;  // token_byte_values(), packed (built on first use)
     std::vector<uint64_t> sorted_off;
     // instrumentation
@@ -505,6 +514,10 @@ extern "C" void tk_destroy(tk_core* c) {
         if (sl.out) (void)hipHostFree(sl.out);
         if (sl.ws.p) (void)hipFree(sl.ws.p);
         if (sl.s) (void)hipStreamDestroy(sl.s);
+    }
+    for (hipStream_t& ls : c->small_s) {
+        if (ls) (void)hipStreamDestroy(ls);
+        ls = nullptr;
     }
     if (c->stream) (void)hipStreamDestroy(c->stream);
     for (int i = 0; i < TK_NAUX; ++i)
@@ -1319,8 +1332,13 @@ static int encode_small(tk_core* c, const uint8_t* utf8, uint32_t n, uint32_t** 
     }
     struct Release {
         tk_core::SmallSlot* s;
-        ~Release() { s->busy.store(0, std::memory_order_release); }
-    } release_slot{sl};
+        std::atomic<int>* active;
+        ~Release() {
+            s->busy.store(0, std::memory_order_release);
+            active->fetch_sub(1, std::memory_order_relaxed);
+        }
+    } release_slot{sl, &c->small_active};
+    c->small_active.fetch_add(1, std::memory_order_relaxed);
     HIPCHK(hipSetDevice(c->device));
     if (!sl->ready) {  // first use of the slot (or a first use that failed: what it did make is kept, the rest is made now)
         if (!sl->in) {
@@ -1334,38 +1352,60 @@ static int encode_small(tk_core* c, const uint8_t* utf8, uint32_t n, uint32_t** 
         TRY(ensure(sl->ws, 256 * TK_SMALL_PIECE * 4));
         HIPCHK(hipHostGetDevicePointer(&sl->d_in, sl->in, 0));
         HIPCHK(hipHostGetDevicePointer(&sl->d_out, sl->out, 0));
-        if (!sl->s) HIPCHK(hipStreamCreateWithFlags(&sl->s, hipStreamNonBlocking));
         sl->ready = true;
     }
     memcpy(sl->in, utf8, n);
     memset(sl->in + n, 0, 8);
     const uint32_t seq = ++sl->seq ? sl->seq : ++sl->seq;  // (never 0: the buffer starts zeroed)
-    hipStream_t s = sl->s;
-    if (c->profiling) {  // (kernel times are collected in the core's shared list: one caller at a time then)
+    sl->n = n;
+    if (c->profiling) {  // (kernel times are collected in the core's shared list: one caller at a time then, every call a launch of its own)
         std::lock_guard<std::mutex> lk(c->mu);
-        TRY(timed(c, s, "tk_k_small", [&] {
-            hipLaunchKernelGGL(tk_k_small, dim3(1), dim3(256), 0, s, c->D, (const uint8_t*)sl->d_in, n, seq, (uint32_t*)sl->d_out, sl->ws.as<uint32_t>());
-        }));
-        HIPCHK(hipStreamSynchronize(s));
+        if (!sl->s) HIPCHK(hipStreamCreateWithFlags(&sl->s, hipStreamNonBlocking));
+        TkSmallReqs R{};
+        R.r[0] = TkSmallReq{(const uint8_t*)sl->d_in, (uint32_t*)sl->d_out, sl->ws.as<uint32_t>(), n, seq};
+        TRY(timed(c, sl->s, "tk_k_small", [&] { hipLaunchKernelGGL(tk_k_small, dim3(1), dim3(256), 0, sl->s, c->D, R); }));
+        HIPCHK(hipStreamSynchronize(sl->s));
         TRY(drain_events(c));
     } else {
-        hipLaunchKernelGGL(tk_k_small, dim3(1), dim3(256), 0, s, c->D, (const uint8_t*)sl->d_in, n, seq, (uint32_t*)sl->d_out, sl->ws.as<uint32_t>());
-        const hipError_t le = hipGetLastError();
-        if (le != hipSuccess) return fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(le) + " in tk_k_small");
+        sl->state.store(1, std::memory_order_release);  // ready: whoever launches next takes it along
     }
-    // the kernel's last store is the sequence number (system scope): watch for it instead of waiting on the stream
+    // the kernel's last store is the sequence number (system scope): watch for it instead of waiting on a stream; while the call has not been
+    // launched, try to be the one who launches
     const auto t0 = std::chrono::steady_clock::now();
     uint32_t spins = 0;
     while (__atomic_load_n(&sl->out[2], __ATOMIC_ACQUIRE) != seq) {
+        if (sl->state.load(std::memory_order_acquire) == 1 && c->small_launch_mu.try_lock()) {
+            std::lock_guard<std::mutex> lk(c->small_launch_mu, std::adopt_lock);
+            TkSmallReqs R{};
+            uint32_t cnt = 0;
+            for (uint32_t k = 0; k < TK_SMALL_SLOTS && cnt < TK_SMALL_BATCH; ++k) {
+                tk_core::SmallSlot& q = c->small[k];
+                int expect = 1;
+                if (q.state.load(std::memory_order_acquire) == 1 && q.state.compare_exchange_strong(expect, 2, std::memory_order_acq_rel))
+                    R.r[cnt++] = TkSmallReq{(const uint8_t*)q.d_in, (uint32_t*)q.d_out, q.ws.as<uint32_t>(), q.n, q.seq};
+            }
+            if (cnt) {
+                hipStream_t& ls = c->small_s[c->small_turn++ & 3u];
+                if (!ls) HIPCHK(hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
+                hipLaunchKernelGGL(tk_k_small, dim3(cnt), dim3(256), 0, ls, c->D, R);
+                const hipError_t le = hipGetLastError();
+                if (le != hipSuccess) return fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(le) + " in tk_k_small");
+                c->st_small_launches += 1;
+                c->st_small_calls += cnt;
+            }
+            continue;
+        }
         if ((++spins & 0xFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
-            HIPCHK(hipStreamSynchronize(s));
+            if (sl->state.load(std::memory_order_acquire) == 2) (void)hipDeviceSynchronize();
             if (__atomic_load_n(&sl->out[2], __ATOMIC_ACQUIRE) != seq) return fail(TK_RUNTIME_ERROR, "the small-call kernel did not complete");
             break;
         }
+        if ((spins & 127u) == 127u && c->small_active.load(std::memory_order_relaxed) > 8) std::this_thread::yield();  // (many callers, maybe more than cores: a spinning waiter must not keep the launcher off its core; a lone caller never yields)
 #if defined(__x86_64__)
         __builtin_ia32_pause();
 #endif
     }
+    sl->state.store(0, std::memory_order_release);
     if (sl->out[0] != 1u) return TK_OK;  // a long piece that is not a token: general path
     const uint64_t nt = sl->out[1];
     uint32_t* host = (uint32_t*)malloc((nt ? nt : 1) * 4);
@@ -2345,6 +2385,8 @@ extern "C" uint64_t tk_stat(tk_core* c, const char* name) {
     if (k == "front_wgs_per_cu") return c->front_wgs;
     if (k == "compute_units") return c->n_cu;
     if (k == "chunks") return c->st_chunks;
+    if (k == "small_launches") return c->st_small_launches;  // launches of tk_k_small and the calls they carried (several callers share a launch)
+    if (k == "small_calls") return c->st_small_calls;
     if (k == "back_streams") return (uint64_t)c->n_back;  // streams found to run beside the front stream (0: no multi-chunk batch yet)
     if (k == "regrown") return c->st_regrown;  // batches repeated with a larger miss data since the core was made (encode_device_locked)
     if (k == "workspace_bytes") {             // device memory of the work sets (everything but the text, the tables and the outputs)

@@ -2926,8 +2926,23 @@ struct TkSmallAcc {
     __device__ __forceinline__ uint32_t cls(uint64_t pos) const { return pos < n ? (uint32_t)c[pos] : (uint32_t)TK_C_END; }
     __device__ __forceinline__ uint32_t byte(uint64_t pos) const { return pos < n ? (uint32_t)raw[pos] : 0u; }
 };
-__global__ __launch_bounds__(256) void tk_k_small(TkTables T, const uint8_t* __restrict__ text, uint32_t n, uint32_t seq, uint32_t* __restrict__ out,
-                                                   uint32_t* __restrict__ ws /* [256][TK_SMALL_PIECE] */) {
+// Up to TK_SMALL_BATCH calls in ONE launch, a workgroup each: callers that arrive together are served by whichever of them gets to launch
+// (tk_api.hip, encode_small: the launch path of the HIP runtime is what several threads on one Encoding queue up at).
+#define TK_SMALL_BATCH 16
+struct TkSmallReq {
+    const uint8_t* text;  // the call's text (page-locked, device-visible)
+    uint32_t* out;        // its result buffer
+    uint32_t* ws;         // merge scratch [256][TK_SMALL_PIECE]
+    uint32_t n, seq;
+};
+struct TkSmallReqs {
+    TkSmallReq r[TK_SMALL_BATCH];
+};
+__global__ __launch_bounds__(256) void tk_k_small(TkTables T, TkSmallReqs R) {
+    const uint8_t* __restrict__ text = R.r[blockIdx.x].text;
+    uint32_t* __restrict__ out = R.r[blockIdx.x].out;
+    uint32_t* __restrict__ ws = R.r[blockIdx.x].ws;
+    const uint32_t n = R.r[blockIdx.x].n, seq = R.r[blockIdx.x].seq;
     __shared__ __attribute__((aligned(16))) uint8_t raw[TK_SMALL_MAX + 16];
     __shared__ uint8_t cls[TK_SMALL_MAX + 16];
     __shared__ uint16_t nxt[TK_SMALL_MAX];

@@ -58,7 +58,34 @@ def rate(f, nth, total=24000):
     return total / (time.perf_counter() - t0)
 print(f"threads on one Encoding, {len(b)}-byte calls (calls per second):")
 base_raw = base_py = None
-for nth in (1, 2, 4, 8, 16):
-    r_raw, r_py = rate(raw_call, nth), rate(lambda: enc.encode_ordinary(text), nth)
+for nth in (1, 2, 4, 8, 16, 32):
+    l0, c0 = core.stat("small_launches"), core.stat("small_calls")
+    r_raw = rate(raw_call, nth)
+    l1, c1 = core.stat("small_launches"), core.stat("small_calls")
+    r_py = rate(lambda: enc.encode_ordinary(text), nth)
     base_raw = base_raw or r_raw; base_py = base_py or r_py
-    print(f"   {nth:2d} threads: C ABI {r_raw:9.0f}/s ({r_raw / base_raw:4.2f}x)   Encoding.encode_ordinary {r_py:9.0f}/s ({r_py / base_py:4.2f}x)")
+    print(f"   {nth:2d} threads: C ABI {r_raw:9.0f}/s ({r_raw / base_raw:4.2f}x, {(c1 - c0) / max(l1 - l0, 1):4.2f} calls per launch)   "
+          f"Encoding.encode_ordinary {r_py:9.0f}/s ({r_py / base_py:4.2f}x)")
+
+# the same from NATIVE threads (tools/ubench/small_threads.c: no interpreter in the loop): what the C ABI itself scales to
+import subprocess, tempfile
+so = os.path.join(tempfile.gettempdir(), "tk_small_threads.so")
+subprocess.check_call(["gcc", "-O2", "-shared", "-fPIC", "-pthread", os.path.join(ROOT, "tools", "ubench", "small_threads.c"), "-o", so])
+H = ctypes.CDLL(so)
+H.tk_small_threads.restype = ctypes.c_double
+H.tk_small_threads.argtypes = [ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_void_p, ctypes.c_uint64, ctypes.c_int, ctypes.c_int,
+                               ctypes.POINTER(ctypes.c_uint64), ctypes.POINTER(ctypes.c_int)]
+enc_p = ctypes.cast(L.tk_encode_ordinary, ctypes.c_void_p)
+free_p = ctypes.cast(L.tk_free, ctypes.c_void_p)
+want = len(enc.encode_ordinary(text))
+print(f"native threads on one core, {len(b)}-byte calls (calls per second through the C ABI):")
+base = None
+for nth in (1, 2, 4, 8, 16, 32, 64):
+    l0, c0 = core.stat("small_launches"), core.stat("small_calls")
+    tok, bad = ctypes.c_uint64(), ctypes.c_int()
+    per = max(20000 // nth, 500)
+    r = H.tk_small_threads(enc_p, free_p, core._h, buf.ctypes.data, len(b), nth, per, ctypes.byref(tok), ctypes.byref(bad))
+    l1, c1 = core.stat("small_launches"), core.stat("small_calls")
+    base = base or r
+    ok = bad.value == 0 and tok.value == want * nth * per
+    print(f"   {nth:2d} threads: {r:9.0f}/s ({r / base:5.2f}x, {(c1 - c0) / max(l1 - l0, 1):4.2f} calls per launch, results {'ok' if ok else 'WRONG'})")
