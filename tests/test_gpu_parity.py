@@ -206,6 +206,54 @@ def test_text_at_any_device_address():
         assert np.array_equal(toff, ro) and np.array_equal(toks, rt), shift
 
 
+def test_mid_size_documents_as_segments_in_one_launch(cores):
+    """One document of 2 .. 72 KiB without special tokens is cut at piece starts that are certain whatever stands on either side (an ASCII
+    letter followed by a space) into segments of at most 2 KiB, which go out as so many small calls in ONE launch (tk_api.hip, encode_mid);
+    text without such cuts, and segments the small kernel does not do, take the general path.  Either way: the oracle's tokens."""
+    for name in ("o200k_shaped", "cl100k_shaped", "gpt2_shaped"):
+        core = cores[name]
+        C = h.c_oracle_for(name)
+        blob, off = h.gen_corpus(0x51D0 + len(name), 1, 1 << 20)
+        text = blob[: int(off[-1])].tobytes()
+        lorem = h.lorem(80000)
+        before = core.stat("mid_calls")
+        taken = 0
+        for base, src in ((0, lorem), (0, text), (100_000, text)):
+            for n in (2049, 2500, 4096, 5000, 10_000, 33_333, 65_536, 70_000, 73_728, 73_729):
+                data = src[base: base + n].decode("utf-8", errors="ignore").encode()  # (a whole number of chars: the boundary is &str)
+                got = core._encode_np(data, None)
+                assert np.array_equal(got, C.encode_ordinary(data)), (name, base, n)
+        taken = core.stat("mid_calls") - before
+        assert taken >= 6, taken  # (the Lorem ipsum cases; the corpus is full of long pieces that are not tokens, which the small kernel leaves to the
+        # general pipeline: after such a call the next sixteen do not even try)
+        # random documents made of vocabulary words, numbers, punctuation, newlines, contractions and short non-ASCII words: nothing the small
+        # kernel leaves out, so the segments are what is tested -- every cut, every size from 2 to 72 KiB
+        import random
+        rng = random.Random(0x51D0 ^ len(name))
+        vocab = [t for t in h.golden_vocab(name) if 2 <= len(t) <= 10 and t.isalpha() and t.isascii()]
+        rng.shuffle(vocab)
+        words = [w.decode() for w in vocab[:3000]] + ["don't", "I'll", "we've", "IT'S", "x'Re", "caf\u00e9", "na\u00efve", "\u4e2d\u6587", "\u043f\u0440\u0438\u0432\u0435\u0442", "3.14", "12345", "2024",
+                                                       "a", "I", "e.g.", "(see", "note)", "\u2014", "...", "!?", "#tag", "@you", "x_y", "CamelCase", "ALLCAPS", "\U0001F600"]
+        seps = [" "] * 12 + ["\n", "\n\n", "  ", ", ", ". ", "; ", ": ", "\t", " \n", "\r\n", " - "]
+        before = core.stat("mid_calls")
+        n_docs = 0
+        for _ in range(120):
+            target = rng.choice((2100, 3000, 4096, 6000, 9000, 15000, 30000, 50000, 65536, 72000))
+            parts, size = [], 0
+            while size < target:
+                w = rng.choice(words) + rng.choice(seps)
+                parts.append(w)
+                size += len(w.encode())
+            data = "".join(parts).encode()[:73728].decode("utf-8", errors="ignore").encode()
+            assert np.array_equal(core._encode_np(data, None), C.encode_ordinary(data)), (name, len(data), data[:60])
+            n_docs += 1
+        assert core.stat("mid_calls") - before >= n_docs * 3 // 4, (core.stat("mid_calls") - before, n_docs)
+        # no space anywhere / no ASCII letter before a space / one word of 3 KB / spaces only: the general path, the same tokens
+        for data in (("\u4e2d\u6587" * 2000).encode(), ("\u00e9t\u00e9 " * 900).encode(), b"x" * 3000, b" " * 5000, ("ab " * 20000).encode()[:70000],
+                     ("word " * 300 + "y" * 3000 + " tail" * 300).encode()):
+            assert np.array_equal(core._encode_np(data, None), C.encode_ordinary(data)), data[:20]
+
+
 def test_alternating_result_buffers(cores):
     """tk_set_output_buffers(core, 2): the ids and offsets of a device-resident call stay where they are while the NEXT call runs (a consumer
     on another stream -- the gather of the several-process bench -- reads them without a copy); with one pair (the default) the next call

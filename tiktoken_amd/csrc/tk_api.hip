@@ -65,7 +65,8 @@ struct KernelStat {
 };
 
 #define TK_NAUX 6  // side streams of the merge kernels
-#define TK_SMALL_SLOTS 16  // small calls in flight at the same time (tk_core::SmallSlot; = TK_SMALL_BATCH: one launch can carry them all)
+#define TK_MID_SEGMENTS 36  // most segments a document of 2 .. 72 KiB is planned in (encode_mid)
+#define TK_SMALL_SLOTS 40  // small calls in flight at the same time (tk_core::SmallSlot; = TK_SMALL_BATCH: one launch can carry them all)
 #define TK_NSET 4  // chunks in flight (work sets): the front kernel of chunk k + 1 runs while chunk k is merged and its tokens are placed
 
 // Work buffers of ONE chunk in flight.
@@ -168,7 +169,10 @@ struct tk_core {
     // it -- launches every slot that is ready, his own included or not (someone else may have taken it along already); the others watch
     // their completion words.  The streams of the launches take turns so that consecutive batches overlap on the device.
     std::mutex small_launch_mu;
-    std::atomic<int> small_active{0};  // callers inside encode_small
+    std::atomic<int> small_active{0};  // callers inside encode_small / encode_mid
+    std::atomic<int> mid_skip{0};     // calls that skip encode_mid (set when an attempt found the text unfit for the small kernel)
+    bool mid_cut = false;             // an ASCII letter followed by a space is a certain piece start of this pattern: documents of 2 .. 64 KiB are cut there
+    uint64_t st_mid_calls = 0;
     hipStream_t small_s[4] = {};
     uint32_t small_turn = 0;
     uint64_t st_small_launches = 0, st_small_calls = 0;
@@ -452,6 +456,9 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     D.pattern = H.pattern;
     D.pat = H.pat;
     memcpy(D.cert, H.cert, sizeof D.cert);
+    // a document of a few KiB is cut at "letter, then space" when that is a certain piece start of the pattern (encode_mid): both cases of letter,
+    // in the family's table and in what was derived for this pattern
+    c->mid_cut = ((H.cert[TK_C_LL] >> TK_C_SP) & 1u) && ((H.cert[TK_C_LU] >> TK_C_SP) & 1u) && !(c->dbg & 0x4000000);  // (debug bit 0x4000000: never)
     for (size_t k = 0; k + 1 < H.spec_off.size(); ++k) c->spec_max_len = std::max(c->spec_max_len, H.spec_off[k + 1] - H.spec_off[k]);
     {  // decode table: id -> {offset into the token / special blob, length}
         uint32_t max_id = 0;
@@ -1309,6 +1316,193 @@ static void parallel_memcpy(void* dst, const void* src, size_t n, unsigned nth) 
     for (auto& t : th) t.join();
 }
 
+static int encode_batch_impl(tk_core* c, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special, const uint32_t* allowed_ids,
+                             uint64_t n_allowed, uint32_t** tokens_out, uint64_t* n_tokens_out, uint64_t* tok_off_out, bool device_result, bool no_small);
+// ---- the slots of the small-call path (tk_core::SmallSlot) ----
+static int small_slot_init(tk_core* c, tk_core::SmallSlot* sl) {
+    if (sl->ready) return TK_OK;  // (a first use that failed: what it did make is kept, the rest is made now)
+    if (!sl->in) {
+        HIPCHK(hipHostMalloc((void**)&sl->in, TK_SMALL_MAX + 64, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(sl->in, 0, TK_SMALL_MAX + 64);
+    }
+    if (!sl->out) {
+        HIPCHK(hipHostMalloc((void**)&sl->out, (TK_SMALL_HDR + TK_SMALL_MAX + 16) * 4, hipHostMallocCoherent | hipHostMallocMapped));
+        memset(sl->out, 0, (TK_SMALL_HDR + TK_SMALL_MAX + 16) * 4);
+    }
+    TRY(ensure(sl->ws, 256 * TK_SMALL_PIECE * 4));
+    HIPCHK(hipHostGetDevicePointer(&sl->d_in, sl->in, 0));
+    HIPCHK(hipHostGetDevicePointer(&sl->d_out, sl->out, 0));
+    sl->ready = true;
+    return TK_OK;
+}
+// text -> the slot, marked ready: whoever launches next takes it along
+static void small_slot_submit(tk_core::SmallSlot* sl, const uint8_t* utf8, uint32_t n) {
+    memcpy(sl->in, utf8, n);
+    memset(sl->in + n, 0, 8);
+    sl->seq = ++sl->seq ? sl->seq : ++sl->seq;  // (never 0: the buffer starts zeroed)
+    sl->n = n;
+    sl->state.store(1, std::memory_order_release);
+}
+// Waits until every one of the caller's slots has completed (the kernel's last store is the slot's sequence number, system scope: watched
+// instead of a stream); while one of them has not been launched, tries to be the one who launches -- EVERY ready slot of the core, the
+// caller's or not (flat combining: try_lock, nobody waits for the mutex).
+static int small_wait(tk_core* c, tk_core::SmallSlot* const* mine, uint32_t k) {
+    const auto t0 = std::chrono::steady_clock::now();
+    uint32_t spins = 0;
+    for (;;) {
+        bool all = true, unlaunched = false;
+        for (uint32_t i = 0; i < k; ++i) {
+            if (__atomic_load_n(&mine[i]->out[2], __ATOMIC_ACQUIRE) != mine[i]->seq) all = false;
+            if (mine[i]->state.load(std::memory_order_acquire) == 1) unlaunched = true;
+        }
+        if (all) break;
+        if (unlaunched && c->small_launch_mu.try_lock()) {
+            std::lock_guard<std::mutex> lk(c->small_launch_mu, std::adopt_lock);
+            TkSmallReqs R{};
+            uint32_t cnt = 0;
+            for (uint32_t j = 0; j < TK_SMALL_SLOTS && cnt < TK_SMALL_BATCH; ++j) {
+                tk_core::SmallSlot& q = c->small[j];
+                int expect = 1;
+                if (q.state.load(std::memory_order_acquire) == 1 && q.state.compare_exchange_strong(expect, 2, std::memory_order_acq_rel))
+                    R.r[cnt++] = TkSmallReq{(const uint8_t*)q.d_in, (uint32_t*)q.d_out, q.ws.as<uint32_t>(), q.n, q.seq};
+            }
+            if (cnt) {
+                hipStream_t& ls = c->small_s[c->small_turn++ & 3u];
+                if (!ls) HIPCHK(hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
+                hipLaunchKernelGGL(tk_k_small, dim3(cnt), dim3(256), 0, ls, c->D, R);
+                const hipError_t le = hipGetLastError();
+                if (le != hipSuccess) return fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(le) + " in tk_k_small");
+                c->st_small_launches += 1;
+                c->st_small_calls += cnt;
+            }
+            continue;
+        }
+        if ((++spins & 0xFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
+            (void)hipDeviceSynchronize();
+            for (uint32_t i = 0; i < k; ++i)
+                if (__atomic_load_n(&mine[i]->out[2], __ATOMIC_ACQUIRE) != mine[i]->seq) return fail(TK_RUNTIME_ERROR, "the small-call kernel did not complete");
+            break;
+        }
+        if ((spins & 127u) == 127u && c->small_active.load(std::memory_order_relaxed) > 8) std::this_thread::yield();  // (many callers, maybe more than cores: a spinning waiter must not keep the launcher off its core; a lone caller never yields)
+#if defined(__x86_64__)
+        __builtin_ia32_pause();
+#endif
+    }
+    for (uint32_t i = 0; i < k; ++i) mine[i]->state.store(0, std::memory_order_release);
+    return TK_OK;
+}
+
+// One document of 2 .. 64 KiB without special tokens: cut into segments of at most TK_SMALL_MAX bytes at piece starts that are certain whatever
+// stands on either side (an ASCII letter followed by a space, where the pattern's table says so: c->mid_cut), the segments encoded as so
+// many small calls in ONE launch (a workgroup each), their tokens put together on the host.  The general pipeline costs a dozen dependent
+// launches -- 0.15 ms for 4 KiB; this is one.  *handled = false: no cut where one is needed, not enough free slots, or a segment
+// the small kernel does not do (a long piece that is not a token): the general path takes the call.
+static int encode_mid(tk_core* c, const uint8_t* utf8, uint32_t n, uint32_t** tokens_out, uint64_t* n_tokens_out, bool* handled) {
+    *handled = false;
+    auto why = [&](const char* r) {
+        if (c->dbg & 64) fprintf(stderr, "encode_mid: %u bytes not taken: %s\n", n, r);
+        return TK_OK;
+    };
+    if (!c->mid_cut) return why("letter -> space is not a certain start of this pattern");
+    // (text full of long pieces that are not tokens -- URLs, runs of a script without spaces -- is not for the small kernel: after a call that
+    // found that out, the next sixteen go straight to the general pipeline instead of paying for a launch first)
+    if (c->mid_skip.load(std::memory_order_relaxed) > 0) {
+        c->mid_skip.fetch_sub(1, std::memory_order_relaxed);
+        return why("the last attempt met too many long pieces that are not tokens");
+    }
+    // cuts: about equal segments, as many as there are slots for, at least 1 KiB each (a segment costs what its pieces cost one after the
+    // other: shorter segments, shorter call)
+    uint32_t want = (n + 1023u) / 1024u;
+    if (want > TK_MID_SEGMENTS) want = TK_MID_SEGMENTS;  // (a few slots more than that exist: segments end a word short of their limit)
+    const uint32_t target = (n + want - 1u) / want;
+    uint32_t cuts[TK_SMALL_SLOTS + 1];
+    uint32_t k = 0, pos = 0;
+    cuts[0] = 0;
+    while (n - pos > TK_SMALL_MAX || (k + 1 < want && n - pos > target + target / 2u)) {
+        if (k + 1 >= TK_SMALL_SLOTS) return why("more segments than slots");
+        const uint32_t hi = pos + (n - pos > TK_SMALL_MAX && target > TK_SMALL_MAX ? (uint32_t)TK_SMALL_MAX : std::min<uint32_t>(target + target / 4u, TK_SMALL_MAX));
+        const uint32_t lo = pos + std::max<uint32_t>(target / 2u, 64u);
+        uint32_t cut = 0;
+        for (uint32_t i = std::min(hi, n - 1u); i > lo; --i) {
+            const uint8_t p = utf8[i - 1];
+            if (utf8[i] == ' ' && ((p >= 'a' && p <= 'z') || (p >= 'A' && p <= 'Z'))) {
+                cut = i;
+                break;
+            }
+        }
+        if (!cut) return why("no cut in a window");
+        cuts[++k] = pos = cut;
+    }
+    cuts[++k] = n;  // k segments
+    if (k < 2) return why("one segment");
+    // k free slots, or none
+    tk_core::SmallSlot* mine[TK_SMALL_SLOTS];
+    uint32_t got = 0;
+    for (uint32_t j = 0; j < TK_SMALL_SLOTS && got < k; ++j) {
+        tk_core::SmallSlot& cand = c->small[j];
+        if (!cand.busy.load(std::memory_order_relaxed) && !cand.busy.exchange(1, std::memory_order_acquire)) mine[got++] = &cand;
+    }
+    struct Release {
+        tk_core::SmallSlot** s;
+        uint32_t* n;
+        std::atomic<int>* active;
+        ~Release() {
+            for (uint32_t i = 0; i < *n; ++i) s[i]->busy.store(0, std::memory_order_release);
+            active->fetch_sub(1, std::memory_order_relaxed);
+        }
+    } release_slots{mine, &got, &c->small_active};
+    c->small_active.fetch_add(1, std::memory_order_relaxed);
+    if (got < k) return why("not enough free slots");  // (other callers hold them: the general path)
+    HIPCHK(hipSetDevice(c->device));
+    for (uint32_t i = 0; i < k; ++i) TRY(small_slot_init(c, mine[i]));
+    for (uint32_t i = 0; i < k; ++i) small_slot_submit(mine[i], utf8 + cuts[i], cuts[i + 1] - cuts[i]);
+    TRY(small_wait(c, mine, k));
+    // the segments' tokens; a segment the small kernel does not do (a piece of more than TK_SMALL_PIECE bytes that is not a token) goes through
+    // the general pipeline on its own -- it starts and ends at certain piece starts, so whoever encodes it gets the same tokens
+    std::vector<std::vector<uint32_t>> parts(k);
+    bool bad[TK_SMALL_SLOTS] = {};
+    uint32_t redo = 0;
+    for (uint32_t i = 0; i < k; ++i) {
+        if (mine[i]->out[0] == 1u) parts[i].assign(mine[i]->out + TK_SMALL_HDR, mine[i]->out + TK_SMALL_HDR + mine[i]->out[1]);
+        else bad[i] = true, ++redo;
+    }
+    if (redo * 4u > k) {  // (many of them: the whole document through the general pipeline at once is cheaper)
+        c->mid_skip.store(16, std::memory_order_relaxed);
+        return why("many segments with long pieces that are not tokens");
+    }
+    if (redo) {
+        for (uint32_t i = 0; i < got; ++i) mine[i]->busy.store(0, std::memory_order_release);  // (the slots go back first: the general path below takes its own way)
+        got = 0;
+        for (uint32_t i = 0; i < k; ++i) {
+            if (!bad[i]) continue;
+            const uint64_t off2[2] = {0, (uint64_t)(cuts[i + 1] - cuts[i])};
+            uint32_t* t = nullptr;
+            uint64_t tn = 0;
+            TRY(encode_batch_impl(c, utf8 + cuts[i], off2, 1, 0, nullptr, 0, &t, &tn, nullptr, false, true));
+            parts[i].assign(t, t + tn);
+            tk_free(t);
+        }
+    }
+    uint64_t nt = 0;
+    for (uint32_t i = 0; i < k; ++i) nt += parts[i].size();
+    uint32_t* host = (uint32_t*)malloc((nt ? nt : 1) * 4);
+    if (!host) return fail(TK_RUNTIME_ERROR, "out of host memory");
+    uint64_t at = 0;
+    for (uint32_t i = 0; i < k; ++i) {
+        if (!parts[i].empty()) memcpy(host + at, parts[i].data(), parts[i].size() * 4);
+        at += parts[i].size();
+    }
+    __atomic_store_n(&c->st_bytes, (uint64_t)n, __ATOMIC_RELAXED);
+    __atomic_store_n(&c->st_tokens, nt, __ATOMIC_RELAXED);
+    __atomic_store_n(&c->st_docs, (uint64_t)1, __ATOMIC_RELAXED);
+    __atomic_store_n(&c->st_pieces, (uint64_t)0, __ATOMIC_RELAXED);
+    __atomic_fetch_add(&c->st_mid_calls, (uint64_t)1, __ATOMIC_RELAXED);
+    *tokens_out = host;
+    *n_tokens_out = nt;
+    *handled = true;
+    return TK_OK;
+}
+
 // One short document without special tokens: one launch, no copies, no stream synchronisation (tk_k_small, tk_fused.h), and no lock: the
 // call runs on a slot of its own (tk_core::SmallSlot), so the threads of a caller's pool overlap (core.py:175).
 // Returns TK_OK with *handled = false when the call has to take the general path.
@@ -1340,72 +1534,23 @@ static int encode_small(tk_core* c, const uint8_t* utf8, uint32_t n, uint32_t** 
     } release_slot{sl, &c->small_active};
     c->small_active.fetch_add(1, std::memory_order_relaxed);
     HIPCHK(hipSetDevice(c->device));
-    if (!sl->ready) {  // first use of the slot (or a first use that failed: what it did make is kept, the rest is made now)
-        if (!sl->in) {
-            HIPCHK(hipHostMalloc((void**)&sl->in, TK_SMALL_MAX + 64, hipHostMallocCoherent | hipHostMallocMapped));
-            memset(sl->in, 0, TK_SMALL_MAX + 64);
-        }
-        if (!sl->out) {
-            HIPCHK(hipHostMalloc((void**)&sl->out, (TK_SMALL_HDR + TK_SMALL_MAX + 16) * 4, hipHostMallocCoherent | hipHostMallocMapped));
-            memset(sl->out, 0, (TK_SMALL_HDR + TK_SMALL_MAX + 16) * 4);
-        }
-        TRY(ensure(sl->ws, 256 * TK_SMALL_PIECE * 4));
-        HIPCHK(hipHostGetDevicePointer(&sl->d_in, sl->in, 0));
-        HIPCHK(hipHostGetDevicePointer(&sl->d_out, sl->out, 0));
-        sl->ready = true;
-    }
-    memcpy(sl->in, utf8, n);
-    memset(sl->in + n, 0, 8);
-    const uint32_t seq = ++sl->seq ? sl->seq : ++sl->seq;  // (never 0: the buffer starts zeroed)
-    sl->n = n;
+    TRY(small_slot_init(c, sl));
     if (c->profiling) {  // (kernel times are collected in the core's shared list: one caller at a time then, every call a launch of its own)
         std::lock_guard<std::mutex> lk(c->mu);
+        memcpy(sl->in, utf8, n);
+        memset(sl->in + n, 0, 8);
+        sl->seq = ++sl->seq ? sl->seq : ++sl->seq;
+        sl->n = n;
         if (!sl->s) HIPCHK(hipStreamCreateWithFlags(&sl->s, hipStreamNonBlocking));
         TkSmallReqs R{};
-        R.r[0] = TkSmallReq{(const uint8_t*)sl->d_in, (uint32_t*)sl->d_out, sl->ws.as<uint32_t>(), n, seq};
+        R.r[0] = TkSmallReq{(const uint8_t*)sl->d_in, (uint32_t*)sl->d_out, sl->ws.as<uint32_t>(), n, sl->seq};
         TRY(timed(c, sl->s, "tk_k_small", [&] { hipLaunchKernelGGL(tk_k_small, dim3(1), dim3(256), 0, sl->s, c->D, R); }));
         HIPCHK(hipStreamSynchronize(sl->s));
         TRY(drain_events(c));
     } else {
-        sl->state.store(1, std::memory_order_release);  // ready: whoever launches next takes it along
+        small_slot_submit(sl, utf8, n);
     }
-    // the kernel's last store is the sequence number (system scope): watch for it instead of waiting on a stream; while the call has not been
-    // launched, try to be the one who launches
-    const auto t0 = std::chrono::steady_clock::now();
-    uint32_t spins = 0;
-    while (__atomic_load_n(&sl->out[2], __ATOMIC_ACQUIRE) != seq) {
-        if (sl->state.load(std::memory_order_acquire) == 1 && c->small_launch_mu.try_lock()) {
-            std::lock_guard<std::mutex> lk(c->small_launch_mu, std::adopt_lock);
-            TkSmallReqs R{};
-            uint32_t cnt = 0;
-            for (uint32_t k = 0; k < TK_SMALL_SLOTS && cnt < TK_SMALL_BATCH; ++k) {
-                tk_core::SmallSlot& q = c->small[k];
-                int expect = 1;
-                if (q.state.load(std::memory_order_acquire) == 1 && q.state.compare_exchange_strong(expect, 2, std::memory_order_acq_rel))
-                    R.r[cnt++] = TkSmallReq{(const uint8_t*)q.d_in, (uint32_t*)q.d_out, q.ws.as<uint32_t>(), q.n, q.seq};
-            }
-            if (cnt) {
-                hipStream_t& ls = c->small_s[c->small_turn++ & 3u];
-                if (!ls) HIPCHK(hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
-                hipLaunchKernelGGL(tk_k_small, dim3(cnt), dim3(256), 0, ls, c->D, R);
-                const hipError_t le = hipGetLastError();
-                if (le != hipSuccess) return fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(le) + " in tk_k_small");
-                c->st_small_launches += 1;
-                c->st_small_calls += cnt;
-            }
-            continue;
-        }
-        if ((++spins & 0xFFFu) == 0 && std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) {
-            if (sl->state.load(std::memory_order_acquire) == 2) (void)hipDeviceSynchronize();
-            if (__atomic_load_n(&sl->out[2], __ATOMIC_ACQUIRE) != seq) return fail(TK_RUNTIME_ERROR, "the small-call kernel did not complete");
-            break;
-        }
-        if ((spins & 127u) == 127u && c->small_active.load(std::memory_order_relaxed) > 8) std::this_thread::yield();  // (many callers, maybe more than cores: a spinning waiter must not keep the launcher off its core; a lone caller never yields)
-#if defined(__x86_64__)
-        __builtin_ia32_pause();
-#endif
-    }
-    sl->state.store(0, std::memory_order_release);
+    TRY(small_wait(c, &sl, 1));
     if (sl->out[0] != 1u) return TK_OK;  // a long piece that is not a token: general path
     const uint64_t nt = sl->out[1];
     uint32_t* host = (uint32_t*)malloc((nt ? nt : 1) * 4);
@@ -1429,16 +1574,18 @@ static int encode_small(tk_core* c, const uint8_t* utf8, uint32_t n, uint32_t** 
 // several-GPU gather needs; the one-launch small path (which writes straight to host memory) is not taken then.
 static int encode_batch_impl(tk_core* c, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special,
                              const uint32_t* allowed_ids, uint64_t n_allowed, uint32_t** tokens_out, uint64_t* n_tokens_out,
-                             uint64_t* tok_off_out, bool device_result) {
+                             uint64_t* tok_off_out, bool device_result, bool no_small) {
     if (!c) return fail(TK_VALUE_ERROR, "core is null");
     if (!doc_off || (!device_result && !tokens_out) || !n_tokens_out) return fail(TK_VALUE_ERROR, "null argument");
     if (doc_off[0] != 0) return fail(TK_VALUE_ERROR, "doc_off[0] must be 0");
     for (uint64_t d = 0; d < n_docs; ++d)
         if (doc_off[d + 1] < doc_off[d]) return fail(TK_VALUE_ERROR, "doc_off must be non-decreasing");
     const uint64_t n_bytes = doc_off[n_docs];
-    if (!device_result && n_docs == 1 && n_bytes > 0 && n_bytes <= TK_SMALL_MAX && !(use_special && n_allowed) && !(c->dbg & 2048) && !c->has_rx) {
+    if (!no_small && !device_result && n_docs == 1 && n_bytes > 0 && n_bytes <= (uint64_t)TK_SMALL_MAX * TK_MID_SEGMENTS && !(use_special && n_allowed) && !(c->dbg & 2048) && !c->has_rx &&
+        (n_bytes <= TK_SMALL_MAX || !c->profiling)) {
         bool handled = false;  // (before the lock: small calls of several threads run side by side)
-        TRY(encode_small(c, utf8, (uint32_t)n_bytes, tokens_out, n_tokens_out, &handled));
+        if (n_bytes <= TK_SMALL_MAX) TRY(encode_small(c, utf8, (uint32_t)n_bytes, tokens_out, n_tokens_out, &handled));
+        else TRY(encode_mid(c, utf8, (uint32_t)n_bytes, tokens_out, n_tokens_out, &handled));
         if (handled) {
             if (tok_off_out) {
                 tok_off_out[0] = 0;
@@ -1568,7 +1715,7 @@ static int encode_batch_impl(tk_core* c, const uint8_t* utf8, const uint64_t* do
 extern "C" int tk_encode_batch(tk_core* c, const uint8_t* utf8, const uint64_t* doc_off, uint64_t n_docs, int use_special,
                                const uint32_t* allowed_ids, uint64_t n_allowed, uint32_t** tokens_out, uint64_t* n_tokens_out,
                                uint64_t* tok_off_out) {
-    return encode_batch_impl(c, utf8, doc_off, n_docs, use_special, allowed_ids, n_allowed, tokens_out, n_tokens_out, tok_off_out, false);
+    return encode_batch_impl(c, utf8, doc_off, n_docs, use_special, allowed_ids, n_allowed, tokens_out, n_tokens_out, tok_off_out, false, false);
 }
 
 // Debug / test entry: the piece-start offsets the GPU pre-tokeniser produces for a packed batch
@@ -2080,7 +2227,7 @@ static int group_encode(tk_group* g, const uint8_t* utf8, const uint64_t* doc_of
             ShardResult& o = res[r];
             if (!on_device) o.tok_off.assign(nd + 1, 0);
             o.rc = encode_batch_impl(g->cores[r], utf8 + doc_off[d0], off.data(), nd, use_special, allowed_ids, n_allowed, &o.tokens, &o.n_tokens,
-                                     on_device ? nullptr : o.tok_off.data(), on_device);
+                                     on_device ? nullptr : o.tok_off.data(), on_device, false);
             if (o.rc != TK_OK) o.err = tk_last_error();  // (thread-local message of this worker)
         });
     }
@@ -2387,6 +2534,7 @@ extern "C" uint64_t tk_stat(tk_core* c, const char* name) {
     if (k == "chunks") return c->st_chunks;
     if (k == "small_launches") return c->st_small_launches;  // launches of tk_k_small and the calls they carried (several callers share a launch)
     if (k == "small_calls") return c->st_small_calls;
+    if (k == "mid_calls") return c->st_mid_calls;  // documents of 2 .. 64 KiB encoded as segments in one launch
     if (k == "back_streams") return (uint64_t)c->n_back;  // streams found to run beside the front stream (0: no multi-chunk batch yet)
     if (k == "regrown") return c->st_regrown;  // batches repeated with a larger miss data since the core was made (encode_device_locked)
     if (k == "workspace_bytes") {             // device memory of the work sets (everything but the text, the tables and the outputs)
