@@ -46,8 +46,9 @@ int tk_device_count(void);
  * Duplicate ranks -> TK_VALUE_ERROR (the reference panics, src/lib.rs:636-641).  device = HIP device ordinal.
  * Threads: a core may be used from several threads (src/lib.rs:232-238).  Calls on one document of at most 2 KiB without special tokens take
  * no lock (sixteen slots per core; callers that arrive together share one launch); every other call on a core is serialised by the core's mutex.
- * What a call costs: one kernel launch for a short document (~22 us for 11 bytes), the general pipeline's dozen launches from 2 KiB up
- * (~0.15 ms for 4 KiB: about what one host core of the reference needs): the path is for batches. */
+ * What a call costs: one kernel launch for a document of up to 128 KiB without special tokens (~22 us for 11 bytes, ~70 us for 4 KiB, ~110 us
+ * for 64 KiB: cut at certain piece starts into segments, a workgroup each), the general pipeline's dozen launches otherwise (~0.15 ms and up):
+ * the path is for batches. */
 int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uint32_t* ranks_ids, uint64_t n_ranks,
               const uint8_t* spec_blob, const uint64_t* spec_off, const uint32_t* spec_ids, uint64_t n_spec,
               const char* pat_str, int device, tk_core** out);

@@ -207,7 +207,7 @@ def test_text_at_any_device_address():
 
 
 def test_mid_size_documents_as_segments_in_one_launch(cores):
-    """One document of 2 .. 72 KiB without special tokens is cut at piece starts that are certain whatever stands on either side (an ASCII
+    """One document of 2 .. 128 KiB without special tokens is cut at piece starts that are certain whatever stands on either side (an ASCII
     letter followed by a space) into segments of at most 2 KiB, which go out as so many small calls in ONE launch (tk_api.hip, encode_mid);
     text without such cuts, and segments the small kernel does not do, take the general path.  Either way: the oracle's tokens."""
     for name in ("o200k_shaped", "cl100k_shaped", "gpt2_shaped"):
@@ -215,11 +215,11 @@ def test_mid_size_documents_as_segments_in_one_launch(cores):
         C = h.c_oracle_for(name)
         blob, off = h.gen_corpus(0x51D0 + len(name), 1, 1 << 20)
         text = blob[: int(off[-1])].tobytes()
-        lorem = h.lorem(80000)
+        lorem = h.lorem(140000)
         before = core.stat("mid_calls")
         taken = 0
         for base, src in ((0, lorem), (0, text), (100_000, text)):
-            for n in (2049, 2500, 4096, 5000, 10_000, 33_333, 65_536, 70_000, 73_728, 73_729):
+            for n in (2049, 2500, 4096, 5000, 10_000, 33_333, 65_536, 100_000, 131_072, 131_073):
                 data = src[base: base + n].decode("utf-8", errors="ignore").encode()  # (a whole number of chars: the boundary is &str)
                 got = core._encode_np(data, None)
                 assert np.array_equal(got, C.encode_ordinary(data)), (name, base, n)
@@ -227,7 +227,7 @@ def test_mid_size_documents_as_segments_in_one_launch(cores):
         assert taken >= 6, taken  # (the Lorem ipsum cases; the corpus is full of long pieces that are not tokens, which the small kernel leaves to the
         # general pipeline: after such a call the next sixteen do not even try)
         # random documents made of vocabulary words, numbers, punctuation, newlines, contractions and short non-ASCII words: nothing the small
-        # kernel leaves out, so the segments are what is tested -- every cut, every size from 2 to 72 KiB
+        # kernel leaves out, so the segments are what is tested -- every cut, every size from 2 to 128 KiB
         import random
         rng = random.Random(0x51D0 ^ len(name))
         vocab = [t for t in h.golden_vocab(name) if 2 <= len(t) <= 10 and t.isalpha() and t.isascii()]
@@ -238,13 +238,13 @@ def test_mid_size_documents_as_segments_in_one_launch(cores):
         before = core.stat("mid_calls")
         n_docs = 0
         for _ in range(120):
-            target = rng.choice((2100, 3000, 4096, 6000, 9000, 15000, 30000, 50000, 65536, 72000))
+            target = rng.choice((2100, 3000, 4096, 6000, 9000, 15000, 30000, 65536, 100000, 131072))
             parts, size = [], 0
             while size < target:
                 w = rng.choice(words) + rng.choice(seps)
                 parts.append(w)
                 size += len(w.encode())
-            data = "".join(parts).encode()[:73728].decode("utf-8", errors="ignore").encode()
+            data = "".join(parts).encode()[:131072].decode("utf-8", errors="ignore").encode()
             assert np.array_equal(core._encode_np(data, None), C.encode_ordinary(data)), (name, len(data), data[:60])
             n_docs += 1
         assert core.stat("mid_calls") - before >= n_docs * 3 // 4, (core.stat("mid_calls") - before, n_docs)

@@ -65,8 +65,8 @@ struct KernelStat {
 };
 
 #define TK_NAUX 6  // side streams of the merge kernels
-#define TK_MID_SEGMENTS 36  // most segments a document of 2 .. 72 KiB is planned in (encode_mid)
-#define TK_SMALL_SLOTS 40  // small calls in flight at the same time (tk_core::SmallSlot; = TK_SMALL_BATCH: one launch can carry them all)
+#define TK_MID_SEGMENTS 64  // most segments a document of 2 .. 128 KiB is planned in (encode_mid)
+#define TK_SMALL_SLOTS 72  // small calls in flight at the same time (tk_core::SmallSlot; = TK_SMALL_BATCH: one launch can carry them all)
 #define TK_NSET 4  // chunks in flight (work sets): the front kernel of chunk k + 1 runs while chunk k is merged and its tokens are placed
 
 // Work buffers of ONE chunk in flight.
@@ -171,7 +171,7 @@ struct tk_core {
     std::mutex small_launch_mu;
     std::atomic<int> small_active{0};  // callers inside encode_small / encode_mid
     std::atomic<int> mid_skip{0};     // calls that skip encode_mid (set when an attempt found the text unfit for the small kernel)
-    bool mid_cut = false;             // an ASCII letter followed by a space is a certain piece start of this pattern: documents of 2 .. 64 KiB are cut there
+    bool mid_cut = false;             // an ASCII letter followed by a space is a certain piece start of this pattern: documents of 2 .. 128 KiB are cut there
     uint64_t st_mid_calls = 0;
     hipStream_t small_s[4] = {};
     uint32_t small_turn = 0;
@@ -1392,7 +1392,7 @@ static int small_wait(tk_core* c, tk_core::SmallSlot* const* mine, uint32_t k) {
     return TK_OK;
 }
 
-// One document of 2 .. 64 KiB without special tokens: cut into segments of at most TK_SMALL_MAX bytes at piece starts that are certain whatever
+// One document of 2 .. 128 KiB without special tokens: cut into segments of at most TK_SMALL_MAX bytes at piece starts that are certain whatever
 // stands on either side (an ASCII letter followed by a space, where the pattern's table says so: c->mid_cut), the segments encoded as so
 // many small calls in ONE launch (a workgroup each), their tokens put together on the host.  The general pipeline costs a dozen dependent
 // launches -- 0.15 ms for 4 KiB; this is one.  *handled = false: no cut where one is needed, not enough free slots, or a segment
@@ -2534,7 +2534,7 @@ extern "C" uint64_t tk_stat(tk_core* c, const char* name) {
     if (k == "chunks") return c->st_chunks;
     if (k == "small_launches") return c->st_small_launches;  // launches of tk_k_small and the calls they carried (several callers share a launch)
     if (k == "small_calls") return c->st_small_calls;
-    if (k == "mid_calls") return c->st_mid_calls;  // documents of 2 .. 64 KiB encoded as segments in one launch
+    if (k == "mid_calls") return c->st_mid_calls;  // documents of 2 .. 128 KiB encoded as segments in one launch
     if (k == "back_streams") return (uint64_t)c->n_back;  // streams found to run beside the front stream (0: no multi-chunk batch yet)
     if (k == "regrown") return c->st_regrown;  // batches repeated with a larger miss data since the core was made (encode_device_locked)
     if (k == "workspace_bytes") {             // device memory of the work sets (everything but the text, the tables and the outputs)

@@ -2928,7 +2928,7 @@ struct TkSmallAcc {
 };
 // Up to TK_SMALL_BATCH calls in ONE launch, a workgroup each: callers that arrive together are served by whichever of them gets to launch
 // (tk_api.hip, encode_small: the launch path of the HIP runtime is what several threads on one Encoding queue up at).
-#define TK_SMALL_BATCH 40
+#define TK_SMALL_BATCH 72
 struct TkSmallReq {
     const uint8_t* text;  // the call's text (page-locked, device-visible)
     uint32_t* out;        // its result buffer
