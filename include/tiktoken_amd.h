@@ -44,8 +44,8 @@ int tk_device_count(void);
  * Text must be valid UTF-8 (the reference's boundary is &str); other bytes never crash but their split is unspecified: a caller that
  * cannot vouch for its bytes checks them with tk_validate_utf8 first.
  * Duplicate ranks -> TK_VALUE_ERROR (the reference panics, src/lib.rs:636-641).  device = HIP device ordinal.
- * Threads: a core may be used from several threads (src/lib.rs:232-238).  Calls on one document of at most 2 KiB without special tokens take
- * no lock (sixteen slots per core; callers that arrive together share one launch); every other call on a core is serialised by the core's mutex.
+ * Threads: a core may be used from several threads (src/lib.rs:232-238).  Calls on one document of at most 128 KiB without special tokens take
+ * no lock (seventy-two slots per core; callers that arrive together share one launch); every other call on a core is serialised by the core's mutex.
  * What a call costs: one kernel launch for a document of up to 128 KiB without special tokens (~22 us for 11 bytes, ~70 us for 4 KiB, ~110 us
  * for 64 KiB: cut at certain piece starts into segments, a workgroup each), the general pipeline's dozen launches otherwise (~0.15 ms and up):
  * the path is for batches. */
