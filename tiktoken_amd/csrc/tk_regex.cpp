@@ -25,6 +25,7 @@
 #include "tk_regex_props.inc"
 #include "tk_regex_scripts.inc"
 #include "tk_regex_binprops.inc"
+#include "tk_regex_casefold.inc"
 
 namespace {
 
@@ -96,49 +97,32 @@ struct Parser {
         for (int k = c.and_set; in && k >= 0; k = sets[k].and_set) in = sets[k].raw(cp) != sets[k].neg;
         return in != c.neg;
     }
+    // simple case folding (tk_regex_casefold.inc: what Python `regex` matches under (?i), one char for one char, minus the Turkic i's -- the Rust
+    // crate's CaseFolding C + S): the equivalents of code points [lo, hi] join the set
+    static void add_equivalents(CharSet& c, uint32_t lo, uint32_t hi) {
+        uint32_t a = 0, b = TK_RX_NCASEFOLD;
+        while (a < b) {  // first entry with code point >= lo
+            const uint32_t m = (a + b) / 2;
+            if (tk_rx_casefold[m][0] < lo) a = m + 1;
+            else b = m;
+        }
+        for (; a < TK_RX_NCASEFOLD && tk_rx_casefold[a][0] <= hi; ++a) c.ranges.push_back({tk_rx_casefold[a][1], tk_rx_casefold[a][1]});
+    }
     bool add_char(CharSet& c, uint32_t cp, bool ci) {
         c.ranges.push_back({cp, cp});
         if (!ci) return true;
-        if (cp < 128u) {
-            if ((cp >= 'a' && cp <= 'z') || (cp >= 'A' && cp <= 'Z')) c.ranges.push_back({cp ^ 0x20u, cp ^ 0x20u});
-            // simple case folding reaches two letters beyond ASCII: U+017F (long s) folds to s, U+212A (Kelvin sign) to k
-            if ((cp | 0x20u) == 's') c.ranges.push_back({0x17Fu, 0x17Fu});
-            if ((cp | 0x20u) == 'k') c.ranges.push_back({0x212Au, 0x212Au});
-            return true;
-        }
-        if (cp == 0x17Fu) {
-            c.ranges.push_back({'s', 's'});
-            c.ranges.push_back({'S', 'S'});
-            return true;
-        }
-        if (cp == 0x212Au) {
-            c.ranges.push_back({'k', 'k'});
-            c.ranges.push_back({'K', 'K'});
-            return true;
-        }
-        const uint32_t gc = prop_of(cp) & 31u;
-        if (gc <= 2u) return fail("case-insensitive matching of a non-ASCII cased letter is not supported");
+        if (cp < 128u && ((cp >= 'a' && cp <= 'z') || (cp >= 'A' && cp <= 'Z'))) c.ranges.push_back({cp ^ 0x20u, cp ^ 0x20u});
+        add_equivalents(c, cp, cp);  // (beyond ASCII, and the two letters ASCII shares a class with: U+017F long s, U+212A Kelvin sign)
         return true;
     }
     bool add_range(CharSet& c, uint32_t lo, uint32_t hi, bool ci) {
         if (lo > hi) return fail("class range out of order");
-        if (!ci) {
-            c.ranges.push_back({lo, hi});
-            return true;
-        }
-        // the ASCII part is folded char by char; beyond ASCII a range is taken as it is when it holds no cased letter
+        if (hi > 0x10FFFFu) return fail("class range beyond U+10FFFF");
+        c.ranges.push_back({lo, hi});
+        if (!ci) return true;
         for (uint32_t cp = lo; cp <= hi && cp < 128u; ++cp)
-            if (!add_char(c, cp, true)) return false;
-        if (hi >= 128u) {
-            if (hi > 0x10FFFFu) return fail("class range beyond U+10FFFF");
-            const uint32_t from = lo < 128u ? 128u : lo;
-            for (uint32_t cp = from; cp <= hi; ++cp)
-                if ((prop_of(cp) & 31u) <= 2u && cp != 0x17Fu && cp != 0x212Au)
-                    return fail("case-insensitive class range with non-ASCII cased letters is not supported");
-            c.ranges.push_back({from, hi});
-            if (from <= 0x17Fu && hi >= 0x17Fu) add_char(c, 0x17Fu, true);
-            if (from <= 0x212Au && hi >= 0x212Au) add_char(c, 0x212Au, true);
-        }
+            if ((cp >= 'a' && cp <= 'z') || (cp >= 'A' && cp <= 'Z')) c.ranges.push_back({cp ^ 0x20u, cp ^ 0x20u});
+        add_equivalents(c, lo, hi);
         return true;
     }
     bool hexval(uint32_t ch, uint32_t* v) {
