@@ -305,6 +305,20 @@ def test_small_calls_scale_with_native_threads(tmp_path):
     assert r8 >= 3.0 * r1, (r1, r8)
 
 
+def test_close_is_idempotent_and_calls_after_it_fail_cleanly():
+    """CoreBPE.close() releases the native core (an atexit handler does the same for cores still alive at interpreter shutdown, before the HIP
+    runtime is gone); a call on a closed core is an error, not a crash."""
+    from tiktoken_amd import CoreBPE
+
+    g = h.load_golden("gpt2_shaped")
+    core = CoreBPE(h.golden_vocab("gpt2_shaped"), g["special_tokens"], g["pat_str"])
+    assert core._encode_np(b"hello world", None).tolist() == oracle_encode("gpt2_shaped", "hello world")
+    core.close()
+    core.close()
+    with pytest.raises((ValueError, RuntimeError)):
+        core._encode_np(b"hello world", None)
+
+
 def test_real_vocab_known_answers_if_available():
     """Appendix B of SURVEY.md: runs only when the sha256-pinned stock files are in $TIKTOKEN_CACHE_DIR."""
     cache = os.environ.get("TIKTOKEN_CACHE_DIR")
