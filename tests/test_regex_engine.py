@@ -214,6 +214,29 @@ def test_binary_properties_equal_python_regex():
     assert h.RxSim(r"(?i)\p{Alphabetic}+|.").split([b"aB1"]) == [0, 2]
 
 
+def test_casefold_table_is_what_python_regex_does():
+    """tk_regex_casefold.inc (tools/gen_regex_casefold.py): every pair {a, b} of the table is a pair Python `regex` matches under (?i), and every
+    one-char case variant of every code point (lower / upper / title / casefold) that `regex` accepts is in the table -- but for the Turkic
+    i's, which Unicode's simple case folding (the Rust crate's) leaves alone."""
+    import os
+    import re as _re
+
+    src = open(os.path.join(h.ROOT, "tiktoken_amd", "csrc", "tk_regex_casefold.inc")).read()
+    pairs = {(int(a, 16), int(b, 16)) for a, b in _re.findall(r"\{0x([0-9A-F]+), 0x([0-9A-F]+)\}", src)}
+    assert len(pairs) > 2500 and int(_re.search(r"TK_RX_NCASEFOLD = (\d+)", src).group(1)) == len(pairs)
+    for a, b in sorted(pairs)[::7]:
+        assert regex.fullmatch("(?i)" + regex.escape(chr(a)), chr(b)), (hex(a), hex(b))
+    missing = []
+    for cp in range(0x80, 0x30000):
+        if 0xD800 <= cp <= 0xDFFF or cp in (0x130, 0x131):
+            continue
+        c = chr(cp)
+        for m in {c.lower(), c.upper(), c.title(), c.casefold()}:
+            if len(m) == 1 and m != c and ord(m) not in (0x130, 0x131) and (cp, ord(m)) not in pairs and regex.fullmatch("(?i)" + regex.escape(c), m):
+                missing.append((hex(cp), hex(ord(m))))
+    assert not missing, missing[:5]
+
+
 def test_case_insensitive_matching_beyond_ascii():
     """(?i) folds one char to one char (simple case folding, as the Rust `regex` crate does for the reference's pat_str, src/lib.rs:623):
     tk_regex_casefold.inc is generated from what Python `regex` matches, minus the two Turkic i's (U+0130, U+0131), which Python puts into
