@@ -305,6 +305,42 @@ def test_small_calls_scale_with_native_threads(tmp_path):
     assert r8 >= 3.0 * r1, (r1, r8)
 
 
+def test_small_and_mid_size_calls_of_many_threads_share_the_slots():
+    """Eight threads on one core, calls of 100 bytes to 40 KiB mixed: short ones take a slot, longer ones a slot per segment (or the general
+    pipeline when the slots are taken), whoever launches takes every ready slot along.  Every result: the oracle's."""
+    import random
+    import threading
+
+    enc = tiktoken.get_encoding("cl100k_shaped")
+    core = enc._core_bpe
+    base = h.lorem(60000)
+    rng = random.Random(5)
+    cases = []
+    for _ in range(40):
+        n = rng.choice((100, 700, 1500, 2047, 2049, 3000, 9000, 20000, 40000))
+        at = rng.randrange(0, len(base) - n)
+        d = base[at: at + n]
+        cases.append((d, np.asarray(oracle_encode("cl100k_shaped", d.decode()), np.uint32)))
+    bad = []
+
+    def work(k):
+        r = random.Random(k)
+        for _ in range(120):
+            d, want = cases[r.randrange(len(cases))]
+            got = core._encode_np(d, None)
+            if not np.array_equal(got, want):
+                bad.append((k, len(d)))
+
+    before = core.stat("mid_calls")
+    th = [threading.Thread(target=work, args=(k,)) for k in range(8)]
+    for t in th:
+        t.start()
+    for t in th:
+        t.join()
+    assert not bad, bad[:5]
+    assert core.stat("mid_calls") > before  # (some of the longer ones did find their slots)
+
+
 def test_close_is_idempotent_and_calls_after_it_fail_cleanly():
     """CoreBPE.close() releases the native core (an atexit handler does the same for cores still alive at interpreter shutdown, before the HIP
     runtime is gone); a call on a closed core is an error, not a crash."""
