@@ -256,6 +256,8 @@ def main():
     if world > 1:
         core.set_output_buffers(2)
 
+    gather_mode = {"form": os.environ.get("TIKTOKEN_AMD_BENCH_GATHER", "exact")}  # "exact" | "padded" (the earlier form: a copy of the ids, one padded dist.gather)
+
     def step(gather=True):
         dt, nt, do = core.encode_batch_device(d_text.data_ptr(), nbytes, d_off.data_ptr(), doc_off, n_docs)
         if world > 1 and gather:
@@ -263,7 +265,14 @@ def main():
             if pending[0] is not None:
                 pending[0].wait()
                 torch.cuda.current_stream().synchronize()  # (wait() orders torch's stream only; the encoder runs on the library's: the buffer of step k - 1 is written again by step k + 1)
-            pending[0] = gather_tokens(toks, nt, rank, world, dist, torch, async_op=True)
+            if gather_mode["form"] == "exact":
+                try:
+                    pending[0] = gather_tokens(toks, nt, rank, world, dist, torch, async_op=True)
+                except Exception as e:  # (a collective library that will not send from memory torch did not allocate: the earlier form, said in the line)
+                    print(f"bench: exact-length gather failed on rank {rank} ({type(e).__name__}: {str(e)[:120]}); padded gather of a copy from here on", file=sys.stderr)
+                    gather_mode["form"] = "padded (the exact-length exchange raised)"
+            if gather_mode["form"] != "exact":
+                pending[0] = gather_tokens(toks.clone(), nt, rank, world, dist, torch, async_op=True, padded=True)
         return dt, nt, do
 
     def drain():
@@ -519,7 +528,7 @@ def main():
                        "encoding": args.encoding, "pat_str_runs_on": "generic regex engine (--generic-engine)" if args.generic_engine else "hand-written scanners",
                        "bytes_per_gpu": nbytes, "docs_rank0": n_docs,
                        "tokens_total": total_tokens, "pieces_rank0": stats["pieces"],
-                       "parallelism": f"doc-sharded x{world}" + (" + RCCL gather of token ids to rank 0" if world > 1 else "")},
+                       "parallelism": f"doc-sharded x{world}" + (f" + RCCL gather of token ids to rank 0 ({gather_mode['form']} lengths)" if world > 1 else "")},
             "roofline": roofline, "cpu_baseline": cpu, "parity_all_tokens_vs_oracle": parity, "host_path": host_path,
             "lds_piece_cache": hot, "cold_start": cold, "generic_engine": generic, "configs": configs,
             "host": {"cpus": ncpu, "nproc": os.cpu_count(), "cgroup_cpu_max": _read_first("/sys/fs/cgroup/cpu.max"),
