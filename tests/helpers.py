@@ -215,7 +215,7 @@ def sim_lib():
         so = os.path.join(d, "libtk_hostsim.so")
         srcs = [os.path.join(d, "tk_hostsim.cpp")] + [os.path.join(ROOT, "tiktoken_amd", "csrc", f)
                                                        for f in ("tk_tables.cpp", "tk_pattern.cpp", "tk_regex.cpp", "tk_device.h", "tk_common.h", "tk_tables.h", "tk_chunk.h", "tk_regex.h",
-                                                                 "tk_regex_split.h", "tk_regex_host.h", "tk_regex_dfa.inc")]
+                                                                 "tk_regex_split.h", "tk_regex_host.h", "tk_regex_dfa.inc", "tk_mid_plan.h", "tk_regex_casefold.inc")]
         def stale():
             return not os.path.exists(so) or os.path.getmtime(so) < max(os.path.getmtime(s) for s in srcs)
 
@@ -260,6 +260,10 @@ def sim_lib():
         L.tks_rx_dfa.argtypes = [vp, ctypes.c_char_p, u64]
         L.tks_rx_split.restype = u64
         L.tks_rx_split.argtypes = [vp, vp, u64, vp, u64, vp, vp, u64, ctypes.c_int, vp, vp]
+        L.tks_mid_plan.restype = u64
+        L.tks_mid_plan.argtypes = [vp, vp, u64, vp, ctypes.c_char_p, u64]
+        for f in (L.tks_mid_slots, L.tks_mid_segment_max, L.tks_mid_segments):
+            f.restype = u64
         _sim_lib = L
     return _sim_lib
 
@@ -285,6 +289,15 @@ class HostSim:
     def lookup(self, piece: bytes) -> int:
         b = np.frombuffer(piece, np.uint8) if piece else np.zeros(1, np.uint8)
         return sim_lib().tks_lookup(self._h, b.ctypes.data, len(piece))
+
+    def mid_plan(self, doc: bytes):
+        """encode_mid's cuts for one document (tk_mid_plan.h): ([0, c1, ..., n], "") or (None, reason)."""
+        L = sim_lib()
+        cuts = np.zeros(L.tks_mid_slots() + 1, np.uint32)
+        why = ctypes.create_string_buffer(128)
+        b = np.frombuffer(doc, np.uint8) if doc else np.zeros(1, np.uint8)
+        k = L.tks_mid_plan(self._h, b.ctypes.data, len(doc), cuts.ctypes.data, why, 128)
+        return (cuts[:k + 1].tolist(), "") if k else (None, why.value.decode())
 
     def piece_ends(self, blob: np.ndarray, doc_off: np.ndarray, bits: bool = False):
         """Piece end offsets from the simulated pre-tokeniser; bits=True mirrors the bit-parallel kernel

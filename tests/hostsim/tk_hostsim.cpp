@@ -15,6 +15,7 @@ static uint64_t g_rx_matches = 0, g_rx_steps = 0;
 #define TK_RX_ON_MATCH() (++g_rx_matches)
 #define TK_RX_ON_DONE(steps) (g_rx_steps += (steps))
 #include "../../tiktoken_amd/csrc/tk_chunk.h"
+#include "../../tiktoken_amd/csrc/tk_mid_plan.h"
 #include "../../tiktoken_amd/csrc/tk_regex_host.h"
 #include "../../tiktoken_amd/csrc/tk_regex_split.h"
 #include "../../tiktoken_amd/csrc/tk_device.h"
@@ -664,6 +665,24 @@ uint64_t tks_rx_dfa(void* p, char* why, uint64_t cap) {
     }
     return c->has_dfa() ? (uint64_t)c->dfa_nstates << 32 | c->dfa_ncls : 0;
 }
+// encode_mid's plan for one document (tk_mid_plan.h): the number of segments and cuts[0..k], or 0 and the reason.  Also 0 when the pattern's
+// table does not make "letter, then space" a certain start (reason says so).
+uint64_t tks_mid_plan(void* p, const uint8_t* text, uint64_t n, uint32_t* cuts /* [tks_mid_slots() + 1] */, char* why, uint64_t cap) {
+    const Sim* s = (const Sim*)p;
+    const char* reason = "";
+    uint32_t k = 0;
+    if (!s->H.rx.empty()) reason = "a pattern of the generic engine";
+    else if (!tk_mid_cut_certain(s->H.cert)) reason = "letter -> space is not a certain start of this pattern";
+    else k = tk_mid_plan(text, (uint32_t)n, cuts, &reason);
+    if (why && cap) {
+        strncpy(why, k ? "" : reason, cap - 1);
+        why[cap - 1] = 0;
+    }
+    return k;
+}
+uint64_t tks_mid_slots() { return TK_SMALL_SLOTS; }
+uint64_t tks_mid_segment_max() { return TK_MID_SEGMENT_MAX; }
+uint64_t tks_mid_segments() { return TK_MID_SEGMENTS; }
 }  // extern "C"
   // matcher steps so far (instructions + chars of repeats + backtracks)
 // Piece starts of a packed batch: a byte per position (1 = start).  spec_at / spec_len: occurrences of allowed special tokens (sorted).

@@ -312,3 +312,76 @@ def test_tables_do_not_depend_on_the_thread_count(monkeypatch):
         sim = h.HostSim(g["pat_str"], ranks, g["special_tokens"])
         digests.append((sim.n_pairs(), h.sim_lib().tks_tables_digest(sim._h)))
     assert len(set(digests)) == 1, digests
+
+
+# ---------------------------------------------------------------- encode_mid's plan (tk_mid_plan.h)
+def _mid_docs():
+    """Documents of 2 .. 128 KiB: Lorem ipsum at the sizes around the limits, slices of the synthetic corpora, random awkward text."""
+    rng = random.Random(23)
+    docs = [h.lorem(n) for n in (2049, 2050, 2100, 3000, 3071, 3072, 3073, 4096, 10000, 65536, 131071, 131072)]
+    for mix in (0, 1):
+        blob, _ = h.gen_corpus(0x5EED0100 + mix, mix, 1 << 20, 4)
+        raw = blob.tobytes()
+        for _ in range(40):
+            n = rng.choice([2100, 4096, 9000, 20000, 65536, 131072])
+            a = rng.randrange(0, len(raw) - n)
+            docs.append(raw[a:a + n].decode(errors="ignore").encode())
+    for _ in range(120):
+        want, parts, size = rng.choice([2100, 3000, 5000, 12000, 40000]), [], 0
+        while size < want:
+            u = rng.choice(h.ADV + h.FUZZ_UNITS + [" ", "a ", "Z ", "b  ", "c \n", "d's ", "E'LL ", "é ", "f ", "g 　"])
+            parts.append(u)
+            size += len(u.encode())
+        docs.append("".join(parts).encode())
+    return docs
+
+
+@pytest.mark.parametrize("name", h.ENCODING_NAMES)
+def test_mid_plan_cuts_only_where_a_piece_starts_whatever_surrounds_it(sims, name):
+    """encode_mid (tk_api.hip) encodes the segments of tk_mid_plan as so many small calls and concatenates their tokens: right only if every cut
+    is a piece start of the whole document AND the pieces of a segment on its own are the document's (reference src/lib.rs:236-249: pieces
+    are encoded one by one).  Checked with the oracle on both sides; plus the plan's own promises."""
+    sim, C = sims[name], h.c_oracle_for(name)
+    L = h.sim_lib()
+    seg_max, slots, planned = L.tks_mid_segment_max(), L.tks_mid_slots(), L.tks_mid_segments()
+    assert (seg_max, slots, planned) == (2048, 72, 64)
+    taken = 0
+    for doc in _mid_docs():
+        cuts, why = sim.mid_plan(doc)
+        if cuts is None:
+            assert why in ("no cut in a window", "more segments than slots"), why
+            continue
+        taken += 1
+        n = len(doc)
+        assert cuts[0] == 0 and cuts[-1] == n and 3 <= len(cuts) <= slots + 1
+        assert all(0 < b - a <= seg_max for a, b in zip(cuts, cuts[1:])), cuts
+        for c in cuts[1:-1]:
+            assert doc[c:c + 1] == b" " and doc[c - 1:c].isalpha() and doc[c - 1] < 0x80, (c, doc[c - 2:c + 2])
+        starts = {0, *C.split(doc)}  # (split gives piece ends = the next piece's start)
+        assert all(c in starts for c in cuts[1:-1])
+        whole = C.encode_ordinary(doc).tolist()
+        parts = [t for a, b in zip(cuts, cuts[1:]) for t in C.encode_ordinary(doc[a:b]).tolist()]
+        assert parts == whole
+    assert taken > 100  # (the corpora and Lorem ipsum are all taken)
+
+
+def test_mid_plan_refuses_what_it_cannot_cut(sims):
+    sim = sims["cl100k_shaped"]
+    for doc, reason in [(b"a" * 5000, "no cut in a window"), (b"1 " * 3000, "no cut in a window"), ("中文 ".encode() * 900, "no cut in a window"),
+                        (b"ab " * 20 + b"x" * 4000, "no cut in a window"), (b"ab " * 600, None), (b"ab " * 683, None),
+                        # cuts only in the first half of every 2 KiB; one cut every 1030 bytes: segments of 1030, the slots run out before the text does
+                        ((b"ab " * 300 + b"x" * 1148) * 64, None), ((b"x" * 1028 + b"b ") * 127, "more segments than slots")]:
+        cuts, why = sim.mid_plan(doc)
+        if reason is None:
+            assert cuts is not None, why
+            assert cuts[-1] == len(doc) and all(b - a <= 2048 for a, b in zip(cuts, cuts[1:]))
+        else:
+            assert cuts is None and why == reason, (why, cuts)
+    # one segment's worth and less never gets here in the product; the plan says "one segment"
+    assert sim.mid_plan(b"ab " * 300) == (None, "one segment")
+
+
+def test_mid_plan_is_off_for_patterns_without_the_rule():
+    """A pattern of the generic engine has no class table to vouch for the cut: no plan (tk_core::mid_cut is false; has_rx keeps encode_mid out)."""
+    rx = h.HostSim(r"\w+|\s+|[^\w\s]+", h.load_vocab("gpt2_shaped"), {})
+    assert rx.mid_plan(h.lorem(5000)) == (None, "a pattern of the generic engine")

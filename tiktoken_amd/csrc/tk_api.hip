@@ -20,6 +20,7 @@
 #include "../../include/tiktoken_amd.h"
 #include "tk_decode.h"
 #include "tk_fused.h"
+#include "tk_mid_plan.h"
 #include "tk_tables.h"
 #include "tk_unicode_tables.inc"
 #include "tk_regex_kernels.h"
@@ -65,8 +66,6 @@ struct KernelStat {
 };
 
 #define TK_NAUX 6  // side streams of the merge kernels
-#define TK_MID_SEGMENTS 64  // most segments a document of 2 .. 128 KiB is planned in (encode_mid)
-#define TK_SMALL_SLOTS 72  // small calls in flight at the same time (tk_core::SmallSlot; = TK_SMALL_BATCH: one launch can carry them all)
 #define TK_NSET 4  // chunks in flight (work sets): the front kernel of chunk k + 1 runs while chunk k is merged and its tokens are placed
 
 // Work buffers of ONE chunk in flight.
@@ -458,7 +457,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     memcpy(D.cert, H.cert, sizeof D.cert);
     // a document of a few KiB is cut at "letter, then space" when that is a certain piece start of the pattern (encode_mid): both cases of letter,
     // in the family's table and in what was derived for this pattern
-    c->mid_cut = ((H.cert[TK_C_LL] >> TK_C_SP) & 1u) && ((H.cert[TK_C_LU] >> TK_C_SP) & 1u) && !(c->dbg & 0x4000000);  // (debug bit 0x4000000: never)
+    c->mid_cut = tk_mid_cut_certain(H.cert) && !(c->dbg & 0x4000000);  // (debug bit 0x4000000: never)
     for (size_t k = 0; k + 1 < H.spec_off.size(); ++k) c->spec_max_len = std::max(c->spec_max_len, H.spec_off[k + 1] - H.spec_off[k]);
     {  // decode table: id -> {offset into the token / special blob, length}
         uint32_t max_id = 0;
@@ -1410,31 +1409,12 @@ static int encode_mid(tk_core* c, const uint8_t* utf8, uint32_t n, uint32_t** to
         c->mid_skip.fetch_sub(1, std::memory_order_relaxed);
         return why("the last attempt met too many long pieces that are not tokens");
     }
-    // cuts: about equal segments, as many as there are slots for, at least 1 KiB each (a segment costs what its pieces cost one after the
-    // other: shorter segments, shorter call)
-    uint32_t want = (n + 1023u) / 1024u;
-    if (want > TK_MID_SEGMENTS) want = TK_MID_SEGMENTS;  // (a few slots more than that exist: segments end a word short of their limit)
-    const uint32_t target = (n + want - 1u) / want;
+    // cuts: about equal segments, each from one certain piece start to the next (tk_mid_plan.h)
+    static_assert(TK_MID_SEGMENT_MAX == TK_SMALL_MAX && TK_SMALL_SLOTS == TK_SMALL_BATCH, "a segment is one small call; one launch carries every slot");
     uint32_t cuts[TK_SMALL_SLOTS + 1];
-    uint32_t k = 0, pos = 0;
-    cuts[0] = 0;
-    while (n - pos > TK_SMALL_MAX || (k + 1 < want && n - pos > target + target / 2u)) {
-        if (k + 1 >= TK_SMALL_SLOTS) return why("more segments than slots");
-        const uint32_t hi = pos + (n - pos > TK_SMALL_MAX && target > TK_SMALL_MAX ? (uint32_t)TK_SMALL_MAX : std::min<uint32_t>(target + target / 4u, TK_SMALL_MAX));
-        const uint32_t lo = pos + std::max<uint32_t>(target / 2u, 64u);
-        uint32_t cut = 0;
-        for (uint32_t i = std::min(hi, n - 1u); i > lo; --i) {
-            const uint8_t p = utf8[i - 1];
-            if (utf8[i] == ' ' && ((p >= 'a' && p <= 'z') || (p >= 'A' && p <= 'Z'))) {
-                cut = i;
-                break;
-            }
-        }
-        if (!cut) return why("no cut in a window");
-        cuts[++k] = pos = cut;
-    }
-    cuts[++k] = n;  // k segments
-    if (k < 2) return why("one segment");
+    const char* reason = nullptr;
+    const uint32_t k = tk_mid_plan(utf8, n, cuts, &reason);
+    if (!k) return why(reason);
     // k free slots, or none
     tk_core::SmallSlot* mine[TK_SMALL_SLOTS];
     uint32_t got = 0;
