@@ -224,8 +224,8 @@ def test_mid_size_documents_as_segments_in_one_launch(cores):
                 got = core._encode_np(data, None)
                 assert np.array_equal(got, C.encode_ordinary(data)), (name, base, n)
         taken = core.stat("mid_calls") - before
-        assert taken >= 6, taken  # (the Lorem ipsum cases; the corpus is full of long pieces that are not tokens, which the small kernel leaves to the
-        # general pipeline: after such a call the next sixteen do not even try)
+        assert taken >= 6, taken  # (the Lorem ipsum cases; the corpus is full of long pieces that are not tokens, which a segment leaves to the
+        # general pipeline -- the whole document then: after such a call the next 16 .. 64 do not even try)
         # random documents made of vocabulary words, numbers, punctuation, newlines, contractions and short non-ASCII words: nothing the small
         # kernel leaves out, so the segments are what is tested -- every cut, every size from 2 to 128 KiB
         import random
@@ -247,7 +247,7 @@ def test_mid_size_documents_as_segments_in_one_launch(cores):
             data = "".join(parts).encode()[:131072].decode("utf-8", errors="ignore").encode()
             assert np.array_equal(core._encode_np(data, None), C.encode_ordinary(data)), (name, len(data), data[:60])
             n_docs += 1
-        assert core.stat("mid_calls") - before >= n_docs * 3 // 4, (core.stat("mid_calls") - before, n_docs)
+        assert core.stat("mid_calls") - before >= n_docs // 3, (core.stat("mid_calls") - before, n_docs)  # (up to 64 of them still skip after the corpus)
         # no space anywhere / no ASCII letter before a space / one word of 3 KB / spaces only: the general path, the same tokens
         for data in (("\u4e2d\u6587" * 2000).encode(), ("\u00e9t\u00e9 " * 900).encode(), b"x" * 3000, b" " * 5000, ("ab " * 20000).encode()[:70000],
                      ("word " * 300 + "y" * 3000 + " tail" * 300).encode()):
@@ -607,8 +607,8 @@ def test_multi_device_group_equals_single_device():
 # ---------------------------------------------------------------- small calls: one launch (tk_k_small)
 def test_small_calls_one_launch_same_tokens(monkeypatch):
     """A single document of up to 2 KiB without special tokens is encoded by ONE workgroup in ONE launch (tk_k_small); the result is
-    the oracle's, and the general pipeline's (debug bit 2048 switches the short cut off).  Pieces that are not tokens and longer than
-    24 bytes send the call to the general path."""
+    the oracle's, and the general pipeline's (debug bit 2048 switches the short cut off).  Pieces that are not tokens are merged in the
+    kernel: one lane each up to 24 bytes, sixteen lanes each up to 256 bytes; longer ones send the call to the general path."""
     from tiktoken_amd import CoreBPE
 
     rng = np.random.default_rng(11)
@@ -633,7 +633,7 @@ def test_small_calls_one_launch_same_tokens(monkeypatch):
             assert a.encode_ordinary(t) == want, (name, t)
             assert b.encode_ordinary(t) == want, (name, t)
         assert a.kernel_ms("tk_k_small")[1] >= len(texts)
-        assert a.kernel_ms("tk_k_front")[1] < len(texts) // 4  # (only the few calls with long non-token pieces)
+        assert a.kernel_ms("tk_k_front")[1] <= 8  # (only "x" * 2048, "ab" * 1000, the Chinese run and " " * 2048 where they are not tokens)
         a.set_profiling(False)
 
 

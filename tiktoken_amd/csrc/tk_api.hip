@@ -170,6 +170,7 @@ struct tk_core {
     std::mutex small_launch_mu;
     std::atomic<int> small_active{0};  // callers inside encode_small / encode_mid
     std::atomic<int> mid_skip{0};     // calls that skip encode_mid (set when an attempt found the text unfit for the small kernel)
+    std::atomic<int> mid_fail_run{0};  // such attempts in a row
     bool mid_cut = false;             // an ASCII letter followed by a space is a certain piece start of this pattern: documents of 2 .. 128 KiB are cut there
     uint64_t st_mid_calls = 0;
     hipStream_t small_s[4] = {};
@@ -1335,11 +1336,11 @@ static int small_slot_init(tk_core* c, tk_core::SmallSlot* sl) {
     return TK_OK;
 }
 // text -> the slot, marked ready: whoever launches next takes it along
-static void small_slot_submit(tk_core::SmallSlot* sl, const uint8_t* utf8, uint32_t n) {
+static void small_slot_submit(tk_core::SmallSlot* sl, const uint8_t* utf8, uint32_t n, bool no_long = false) {
     memcpy(sl->in, utf8, n);
     memset(sl->in + n, 0, 8);
     sl->seq = ++sl->seq ? sl->seq : ++sl->seq;  // (never 0: the buffer starts zeroed)
-    sl->n = n;
+    sl->n = n | (no_long ? TK_SMALL_NO_LONG : 0u);
     sl->state.store(1, std::memory_order_release);
 }
 // Waits until every one of the caller's slots has completed (the kernel's last store is the slot's sequence number, system scope: watched
@@ -1404,10 +1405,10 @@ static int encode_mid(tk_core* c, const uint8_t* utf8, uint32_t n, uint32_t** to
     };
     if (!c->mid_cut) return why("letter -> space is not a certain start of this pattern");
     // (text full of long pieces that are not tokens -- URLs, runs of a script without spaces -- is not for the small kernel: after a call that
-    // found that out, the next sixteen go straight to the general pipeline instead of paying for a launch first)
+    // found that out, the next 16 .. 64 go straight to the general pipeline instead of paying for a launch first)
     if (c->mid_skip.load(std::memory_order_relaxed) > 0) {
         c->mid_skip.fetch_sub(1, std::memory_order_relaxed);
-        return why("the last attempt met too many long pieces that are not tokens");
+        return why("the last attempt met a long piece that is not a token");
     }
     // cuts: about equal segments, each from one certain piece start to the next (tk_mid_plan.h)
     static_assert(TK_MID_SEGMENT_MAX == TK_SMALL_MAX && TK_SMALL_SLOTS == TK_SMALL_BATCH, "a segment is one small call; one launch carries every slot");
@@ -1435,42 +1436,33 @@ static int encode_mid(tk_core* c, const uint8_t* utf8, uint32_t n, uint32_t** to
     if (got < k) return why("not enough free slots");  // (other callers hold them: the general path)
     HIPCHK(hipSetDevice(c->device));
     for (uint32_t i = 0; i < k; ++i) TRY(small_slot_init(c, mine[i]));
-    for (uint32_t i = 0; i < k; ++i) small_slot_submit(mine[i], utf8 + cuts[i], cuts[i + 1] - cuts[i]);
+    // (segments leave EVERY piece of more than TK_SMALL_PIECE bytes that is not a token to the general pipeline: sixty-four workgroups each
+    // waiting for its longest chain of merges cost more than the pipeline, whose merge kernel runs all the chains of the document side by side
+    // -- measured on web text, profiles/r04_mid_calls_corpus.txt)
+    for (uint32_t i = 0; i < k; ++i) small_slot_submit(mine[i], utf8 + cuts[i], cuts[i + 1] - cuts[i], true);
     TRY(small_wait(c, mine, k));
-    // the segments' tokens; a segment the small kernel does not do (a piece of more than TK_SMALL_PIECE bytes that is not a token) goes through
-    // the general pipeline on its own -- it starts and ends at certain piece starts, so whoever encodes it gets the same tokens
-    std::vector<std::vector<uint32_t>> parts(k);
-    bool bad[TK_SMALL_SLOTS] = {};
-    uint32_t redo = 0;
-    for (uint32_t i = 0; i < k; ++i) {
-        if (mine[i]->out[0] == 1u) parts[i].assign(mine[i]->out + TK_SMALL_HDR, mine[i]->out + TK_SMALL_HDR + mine[i]->out[1]);
-        else bad[i] = true, ++redo;
-    }
-    if (redo * 4u > k) {  // (many of them: the whole document through the general pipeline at once is cheaper)
-        c->mid_skip.store(16, std::memory_order_relaxed);
-        return why("many segments with long pieces that are not tokens");
-    }
-    if (redo) {
-        for (uint32_t i = 0; i < got; ++i) mine[i]->busy.store(0, std::memory_order_release);  // (the slots go back first: the general path below takes its own way)
-        got = 0;
-        for (uint32_t i = 0; i < k; ++i) {
-            if (!bad[i]) continue;
-            const uint64_t off2[2] = {0, (uint64_t)(cuts[i + 1] - cuts[i])};
-            uint32_t* t = nullptr;
-            uint64_t tn = 0;
-            TRY(encode_batch_impl(c, utf8 + cuts[i], off2, 1, 0, nullptr, 0, &t, &tn, nullptr, false, true));
-            parts[i].assign(t, t + tn);
-            tk_free(t);
-        }
-    }
+    // the segments' tokens, one after the other.  A segment the small kernel did not do sends the WHOLE document to the general pipeline (one pass
+    // over 64 KiB costs it little more than one over 2 KiB; segment by segment it was 1.4x the pipeline on web text), and the next calls do not
+    // even try: 16 of them after the first such document, 32 and then 64 after further ones in a row, 16 again after a success
     uint64_t nt = 0;
-    for (uint32_t i = 0; i < k; ++i) nt += parts[i].size();
+    bool all_done = true;
+    for (uint32_t i = 0; i < k; ++i) {
+        if (mine[i]->out[0] != 1u) all_done = false;
+        else nt += mine[i]->out[1];
+    }
+    if (!all_done) {
+        const int run = std::min(c->mid_fail_run.fetch_add(1, std::memory_order_relaxed), 2);
+        c->mid_skip.store(16 << run, std::memory_order_relaxed);
+        return why("a segment with a long piece that is not a token");
+    }
+    c->mid_fail_run.store(0, std::memory_order_relaxed);
     uint32_t* host = (uint32_t*)malloc((nt ? nt : 1) * 4);
     if (!host) return fail(TK_RUNTIME_ERROR, "out of host memory");
     uint64_t at = 0;
     for (uint32_t i = 0; i < k; ++i) {
-        if (!parts[i].empty()) memcpy(host + at, parts[i].data(), parts[i].size() * 4);
-        at += parts[i].size();
+        const uint32_t cnt = mine[i]->out[1];
+        if (cnt) memcpy(host + at, mine[i]->out + TK_SMALL_HDR, (size_t)cnt * 4);
+        at += cnt;
     }
     __atomic_store_n(&c->st_bytes, (uint64_t)n, __ATOMIC_RELAXED);
     __atomic_store_n(&c->st_tokens, nt, __ATOMIC_RELAXED);

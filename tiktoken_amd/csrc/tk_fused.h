@@ -2913,12 +2913,20 @@ __global__ void tk_k_single_front(TkTables T, const uint8_t* __restrict__ text, 
 // pipeline of twenty launches costs a hundred times what the work does.  One workgroup does the whole job for a single document of up
 // to TK_SMALL_MAX bytes without special tokens: text from page-locked host memory straight into LDS, a class per byte, the end of the
 // piece that would start at every char (tk_piece_end: the byte-walk scanner, all positions in parallel), one lane follows the chain of
-// true piece starts, then one lane per piece: vocabulary probe, else byte_pair_merge in LDS (pieces of up to TK_SMALL_PIECE bytes;
-// anything longer that is not a token sends the call to the general path: status 2).  Tokens, their count and the completion word go
-// straight to page-locked host memory, so the host needs neither a copy nor a stream synchronisation: it watches the completion word.
+// true piece starts, then the pieces: vocabulary probe, else byte_pair_merge in LDS --
+//   * pieces of up to TK_SMALL_PIECE bytes: one lane per piece (tk_lane_merge), 256 at a time;
+//   * pieces of up to TK_SMALL_LONG bytes (a URL, an identifier, a word of a script without spaces): sixteen lanes per piece, sixteen
+//     pieces at a time, BEFORE the others -- parts as a linked list at the piece's text positions, the leftmost lowest rank by two
+//     reductions over the sixteen lanes (lib.rs:151,190), the two new pairs probed by two lanes at the same time;
+//   * anything longer that is not a token sends the call to the general path (status 2): a chain of a thousand merges, one after the
+//     other, is what tk_k_merge_rounds is for.
+// Tokens, their count and the completion word go straight to page-locked host memory, so the host needs neither a copy nor a stream
+// synchronisation: it watches the completion word.
 // ------------------------------------------------------------------------------------------
 #define TK_SMALL_MAX 2048
 #define TK_SMALL_PIECE 24
+#define TK_SMALL_LONG 256  // (a multiple of 16)
+#define TK_SMALL_NO_LONG 0x80000000u  // TkSmallReq::n bit: a piece of more than TK_SMALL_PIECE bytes that is not a token ends the call (status 2)
 #define TK_SMALL_HDR 4  // result words before the tokens: status (1 done, 2 not handled), token count, completion sequence number, 0
 struct TkSmallAcc {
     const uint8_t *c, *raw;
@@ -2942,17 +2950,25 @@ __global__ __launch_bounds__(256) void tk_k_small(TkTables T, TkSmallReqs R) {
     const uint8_t* __restrict__ text = R.r[blockIdx.x].text;
     uint32_t* __restrict__ out = R.r[blockIdx.x].out;
     uint32_t* __restrict__ ws = R.r[blockIdx.x].ws;
-    const uint32_t n = R.r[blockIdx.x].n, seq = R.r[blockIdx.x].seq;
+    const uint32_t n = R.r[blockIdx.x].n & ~TK_SMALL_NO_LONG, seq = R.r[blockIdx.x].seq;
+    const uint32_t long_max = (R.r[blockIdx.x].n & TK_SMALL_NO_LONG) ? (uint32_t)TK_SMALL_PIECE : (uint32_t)TK_SMALL_LONG;
     __shared__ __attribute__((aligned(16))) uint8_t raw[TK_SMALL_MAX + 16];
     __shared__ uint8_t cls[TK_SMALL_MAX + 16];
     __shared__ uint16_t nxt[TK_SMALL_MAX];
     __shared__ uint16_t plist[TK_SMALL_MAX + 1];
     __shared__ uint32_t idb[TK_SMALL_PIECE * 256], rkb[TK_SMALL_PIECE * 256];
-    __shared__ uint32_t np_sh, bail_sh, scan_sh[8];
+    __shared__ uint32_t lid[TK_SMALL_MAX];  // long pieces: the parts' ids at their text positions; in the end the piece's tokens from its start on
+    __shared__ uint16_t llist[TK_SMALL_MAX / (TK_SMALL_PIECE + 1) + 3];  // the long pieces that are not tokens (indices into plist)
+    __shared__ uint32_t np_sh, bail_sh, nlong_sh, scan_sh[8];
+    // (work arrays of the long pieces, free until the one-lane merges start: ranks where rkb is, the list links where idb is)
+    static_assert(TK_SMALL_PIECE * 256 >= TK_SMALL_MAX, "the long pieces' work arrays lie in idb / rkb");
+    uint32_t* const lrk = rkb;
+    uint16_t* const lnx = (uint16_t*)idb;
+    uint16_t* const lpv = lnx + TK_SMALL_MAX;
     const uint32_t tid = threadIdx.x;
     const TkPat pat = T.pat;
     for (uint32_t i = tid * 4u; i < TK_SMALL_MAX + 16u; i += 1024u) *(uint32_t*)(raw + i) = i < n ? *(const uint32_t*)(text + i) : 0u;  // (input buffer is padded)
-    if (tid == 0) bail_sh = 0;
+    if (tid == 0) bail_sh = 0, nlong_sh = 0;
     __syncthreads();
     if (tid < 16u && n + tid < TK_SMALL_MAX + 16u) raw[n + tid] = 0;  // (bytes of the last word beyond the text)
     __syncthreads();
@@ -2985,22 +3001,118 @@ __global__ __launch_bounds__(256) void tk_k_small(TkTables T, TkSmallReqs R) {
     }
     __syncthreads();
     const uint32_t np = np_sh;
+    // the long pieces (nxt has done its job: from here on nxt[start of a long piece] = 0 for a token, else the number of its tokens in lid)
+    for (uint32_t i = tid; i < np; i += 256u) {
+        const uint32_t s0 = plist[i], len = (uint32_t)plist[i + 1] - s0;
+        if (len > TK_SMALL_PIECE) {
+            if (tk_lookup_text_piece(T, raw, s0, len) != TK_RANK_MAX) nxt[s0] = 0;
+            else if (len > long_max) bail_sh = 1;
+            else llist[atomicAdd(&nlong_sh, 1u)] = (uint16_t)i;
+        }
+    }
+    __syncthreads();
+    const bool bail = bail_sh != 0;
+    const uint32_t nlong = bail ? 0u : nlong_sh;
+    {
+        const uint32_t g = tid & 15u, grp = tid >> 4, gsh = tid & 48u;  // lane of the piece, piece of the sixteen, the group's first lane in the wavefront
+        for (uint32_t w0 = 0; w0 < nlong; w0 += 16u) {
+            const bool valid = w0 + grp < nlong;
+            uint32_t s0 = 0, len = 0;
+            if (valid) {
+                const uint32_t i = llist[w0 + grp];
+                s0 = plist[i];
+                len = (uint32_t)plist[i + 1] - s0;
+            }
+            uint32_t* const id = lid + s0;
+            uint32_t* const rk = lrk + s0;
+            uint16_t* const nx = lnx + s0;
+            uint16_t* const pv = lpv + s0;
+            for (uint32_t k = g; k < len; k += 16u) {
+                const uint32_t b0 = raw[s0 + k], b1 = raw[s0 + k + 1u];
+                id[k] = T.byte_rank[b0];
+                rk[k] = k + 1u < len ? T.pair2[(b0 << 8) | b1] : TK_RANK_MAX;
+                nx[k] = (uint16_t)(k + 1u);
+                pv[k] = (uint16_t)(k ? k - 1u : 0xFFFFu);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            for (;;) {
+                // the leftmost lowest rank: the lane's own (positions g, g + 16, ... in rising order, strict '<'), then the sixteen lanes'
+                uint32_t br = TK_RANK_MAX, bk = 0xFFFFFFFFu;
+                for (uint32_t k = g; k < len; k += 16u) {
+                    const uint32_t r = rk[k];
+                    if (r < br) br = r, bk = k;
+                }
+                const uint32_t m = tkm_group_min(br, 4);
+                const bool on = m != TK_RANK_MAX;  // (uniform over the piece's lanes)
+                if (!__any(on)) break;
+                const uint32_t i = tkm_group_min(br == m ? bk : 0xFFFFFFFFu, 4);
+                uint32_t j = 0, nn = len, pp = 0xFFFFu, idn = 0, idp = 0;
+                if (on) {
+                    j = nx[i];
+                    nn = nx[j];
+                    pp = pv[i];
+                    idn = id[nn < len ? nn : i];
+                    idp = id[pp != 0xFFFFu ? pp : i];
+                }
+                // the two pairs the merge creates, by two lanes in ONE region (two `if`s of their own would wait one after the other)
+                const bool right = g == 0u, probe = on && (right ? nn < len : (g == 1u && pp != 0xFFFFu));
+                uint32_t newr = TK_RANK_MAX;
+                if (probe) newr = tk_probe_pair(T, right ? m : idp, right ? idn : m);
+                if (on && g == 0u) {
+                    id[i] = m;
+                    nx[i] = (uint16_t)nn;
+                    if (nn < len) pv[nn] = (uint16_t)i;
+                    rk[j] = TK_RANK_MAX;
+                    id[j] = TK_RANK_MAX;  // absorbed (no token has this id): the compaction below drops it
+                    rk[i] = newr;
+                }
+                if (on && g == 1u && pp != 0xFFFFu) rk[pp] = newr;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+            // the surviving parts, in order, from the piece's start on (in place: a part moves left or stays, and the sixteen positions of a
+            // step are read before any of them is written)
+            uint32_t t = 0;
+            for (uint32_t k0 = 0; __any(k0 < len); k0 += 16u) {
+                const uint32_t k = k0 + g;
+                const uint32_t v = k < len ? id[k] : (uint32_t)TK_RANK_MAX;
+                const uint32_t mine = (uint32_t)((__ballot(v != TK_RANK_MAX) >> gsh) & 0xFFFFull);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if (v != TK_RANK_MAX) id[t + (uint32_t)__popc(mine & ((1u << g) - 1u))] = v;
+                t += (uint32_t)__popc(mine);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (valid && g == 0u) nxt[s0] = (uint16_t)t;
+        }
+    }
+    __syncthreads();
     uint32_t base = 0;
-    for (uint32_t r0 = 0; r0 < np; r0 += 256u) {
+    for (uint32_t r0 = 0; r0 < np && !bail; r0 += 256u) {
         const uint32_t i = r0 + tid;
-        uint32_t cnt = 0, tok = 0;
+        uint32_t cnt = 0, tok = TK_RANK_MAX, s0 = 0;
+        bool from_lid = false;
         if (i < np) {
-            const uint32_t s0 = plist[i], len = (uint32_t)plist[i + 1] - s0;
-            tok = tk_lookup_text_piece(T, raw, s0, len);
-            if (tok != TK_RANK_MAX) cnt = 1;
-            else if (len <= TK_SMALL_PIECE) cnt = tk_lane_merge<256>(T, raw, s0, len, idb + tid, rkb + tid, ws + tid * TK_SMALL_PIECE);
-            else bail_sh = 1;
+            s0 = plist[i];
+            const uint32_t len = (uint32_t)plist[i + 1] - s0;
+            from_lid = len > TK_SMALL_PIECE && nxt[s0] != 0;
+            if (from_lid) {
+                cnt = nxt[s0];
+            } else {
+                tok = tk_lookup_text_piece(T, raw, s0, len);
+                if (tok != TK_RANK_MAX) cnt = 1;
+                else cnt = tk_lane_merge<256>(T, raw, s0, len, idb + tid, rkb + tid, ws + tid * TK_SMALL_PIECE);
+            }
         }
         uint32_t tot;
         const uint32_t ex = tk_block_exscan_256(cnt, &tot, scan_sh);
-        if (i < np && !bail_sh) {
+        if (i < np) {
             uint32_t* o = out + TK_SMALL_HDR + base + ex;
             if (tok != TK_RANK_MAX) o[0] = tok;
+            else if (from_lid)
+                for (uint32_t j = 0; j < cnt; ++j) o[j] = lid[s0 + j];
             else
                 for (uint32_t j = 0; j < cnt; ++j) o[j] = ws[tid * TK_SMALL_PIECE + j];
         }
