@@ -57,6 +57,9 @@ PATTERNS = [
      r"(?V1)\p{Uppercase}\p{Lowercase}*|\p{Lower}+|[\p{XID_Continue}&&\P{Alphabetic}]+|\p{Extended_Pictographic}\p{Emoji_Modifier}?|[^\p{Cased}]"),
     # POSIX classes are ASCII in the Rust `regex` crate (Python `regex` makes them Unicode: spelled out for it)
     (r"[[:alpha:]]+|[[:digit:][:punct:]]+|[[:^alnum:][:space:]]|[[:word:]]", r"[A-Za-z]+|[0-9!-/:-@\[-`{-~]+|[^0-9A-Za-z]|[0-9A-Za-z_]"),
+    # \h / \H are the hex digits and their complement in fancy-regex (Oniguruma's meaning; Python `regex` reads horizontal white space: spelled out
+    # for it), \O any char whatever (?s) says
+    (r"0[xX]\h+|\h{2}|[\H\d]{1,6}?(?=\h)|(?i)\H|\O", r"0[xX][0-9A-Fa-f]+|[0-9A-Fa-f]{2}|[^A-Fa-f]{1,6}?(?=[0-9A-Fa-f])|(?i)[^0-9A-Fa-f]|[\s\S]"),
 ]
 
 

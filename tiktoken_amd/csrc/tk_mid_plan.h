@@ -1,5 +1,5 @@
 // Where a document of 2 .. 128 KiB is cut into segments for the small kernel (encode_mid, tk_api.hip).  Host-only and free of HIP: the CPU tests
-// drive it through tests/hostsim (tks_mid_plan).
+// compile it into their host build of the device logic and drive it from there (tks_mid_plan).
 //
 // A cut may only stand where a piece starts whatever is on either side, so that the segments' tokens put together ARE the document's tokens
 // (reference src/lib.rs:236-249: the pieces of the regex, each encoded on its own).  The one place used: an ASCII letter followed by a space

@@ -279,10 +279,17 @@ struct Parser {
             case 'S': c.flags |= 0x20u; *negated = true; ++i; return true;
             case 'w': c.flags |= 0x40u; ++i; return true;
             case 'W': c.flags |= 0x40u; *negated = true; ++i; return true;
+            // fancy-regex: \h = hex digit [0-9A-Fa-f], \H = [^0-9A-Fa-f] (Oniguruma's meaning -- not PCRE's horizontal white space).  Both as plain
+            // ranges (the complement of three ranges is four), so that they may stand inside a class as well; closed under simple case folding
+            // as they are, (?i) changes nothing
+            case 'h': c.ranges.insert(c.ranges.end(), {{'0', '9'}, {'A', 'F'}, {'a', 'f'}}); ++i; return true;
+            case 'H': c.ranges.insert(c.ranges.end(), {{0u, '0' - 1u}, {'9' + 1u, 'A' - 1u}, {'F' + 1u, 'a' - 1u}, {'f' + 1u, 0x10FFFFu}}); ++i; return true;
             default: return property(c, ci, negated);
         }
     }
-    static bool is_class_escape(uint32_t e) { return e == 'd' || e == 'D' || e == 's' || e == 'S' || e == 'w' || e == 'W' || e == 'p' || e == 'P'; }
+    static bool is_class_escape(uint32_t e) {
+        return e == 'd' || e == 'D' || e == 's' || e == 'S' || e == 'w' || e == 'W' || e == 'p' || e == 'P' || e == 'h' || e == 'H';
+    }
     bool scalar(uint32_t cp) {
         if (cp > 0x10FFFFu || (cp >= 0xD800u && cp <= 0xDFFFu)) return fail("escape is not a Unicode scalar value");
         return true;
@@ -307,7 +314,7 @@ struct Parser {
         }
         if (e >= '1' && e <= '9') return fail("back-references are not supported");
         if (e == 'b' || e == 'B') return fail("\\b inside a class is not supported");
-        if (e == 'G' || e == 'K' || e == 'Z' || e == 'k' || e == 'g' || e == 'X' || e == 'R' || e == 'h' || e == 'H' || e == 'N')
+        if (e == 'G' || e == 'K' || e == 'Z' || e == 'k' || e == 'g' || e == 'X' || e == 'R' || e == 'N')
             return fail(std::string("the escape \\") + (char)e + " is not supported");
         if ((e >= 'a' && e <= 'z') || (e >= 'A' && e <= 'Z')) return fail(std::string("unknown escape \\") + (char)e);
         *cp = e;  // escaped punctuation
@@ -671,6 +678,12 @@ struct Parser {
                 Node n;
                 n.kind = e == 'A' ? Node::START : Node::END;
                 return add(n);
+            }
+            if (e == 'O') {  // fancy-regex: any char, newline included, whatever (?s) says
+                ++i;
+                CharSet cs;
+                cs.neg = true;
+                return add_set(cs);
             }
             if (e == 'b' || e == 'B') {
                 ++i;
