@@ -1451,7 +1451,8 @@ static int encode_mid(tk_core* c, const uint8_t* utf8, uint32_t n, uint32_t** to
         else nt += mine[i]->out[1];
     }
     if (!all_done) {
-        const int run = std::min(c->mid_fail_run.fetch_add(1, std::memory_order_relaxed), 2);
+        const int run = std::min(std::max(c->mid_fail_run.load(std::memory_order_relaxed), 0), 2);  // (a lost update between two threads costs a launch, no more)
+        c->mid_fail_run.store(std::min(run + 1, 2), std::memory_order_relaxed);
         c->mid_skip.store(16 << run, std::memory_order_relaxed);
         return why("a segment with a long piece that is not a token");
     }
