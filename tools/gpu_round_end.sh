@@ -12,6 +12,7 @@ timeout 600 python bench.py > gpurun_out/${TAG}_bench_1gpu.json 2> gpurun_out/${
 timeout 600 python tools/bench_configs.py > gpurun_out/${TAG}_configs.jsonl 2> gpurun_out/${TAG}_configs.err; cat gpurun_out/${TAG}_configs.jsonl | cut -c1-300
 timeout 300 python tools/small_call.py > gpurun_out/${TAG}_small_calls.txt 2>&1; cat gpurun_out/${TAG}_small_calls.txt
 timeout 300 python tools/mid_call.py > gpurun_out/${TAG}_mid_calls.txt 2>&1; cat gpurun_out/${TAG}_mid_calls.txt
+timeout 120 python tools/mid_corpus.py > gpurun_out/${TAG}_mid_calls_corpus.txt 2>&1; cat gpurun_out/${TAG}_mid_calls_corpus.txt
 timeout 120 python tools/decode_path.py > gpurun_out/${TAG}_decode_path.txt 2>&1; cat gpurun_out/${TAG}_decode_path.txt
 timeout 300 python tools/stress_repeats.py o200k_shaped > gpurun_out/${TAG}_long_runs.txt 2>&1; cat gpurun_out/${TAG}_long_runs.txt
 timeout 300 python tools/generic_vs_scanners.py 256 > gpurun_out/${TAG}_generic_vs_scanners.txt 2>&1; cut -c1-400 gpurun_out/${TAG}_generic_vs_scanners.txt
