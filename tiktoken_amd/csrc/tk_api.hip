@@ -1439,7 +1439,8 @@ static int encode_mid(tk_core* c, const uint8_t* utf8, uint32_t n, uint32_t** to
     // (segments leave EVERY piece of more than TK_SMALL_PIECE bytes that is not a token to the general pipeline: sixty-four workgroups each
     // waiting for its longest chain of merges cost more than the pipeline, whose merge kernel runs all the chains of the document side by side
     // -- measured on web text, profiles/r04_mid_calls_corpus.txt)
-    for (uint32_t i = 0; i < k; ++i) small_slot_submit(mine[i], utf8 + cuts[i], cuts[i + 1] - cuts[i], true);
+    // (debug bit 0x20000000: the segments keep their long pieces -- for the experiment with both kinds of merge in one phase, TK_SMALL_ONE_PHASE)
+    for (uint32_t i = 0; i < k; ++i) small_slot_submit(mine[i], utf8 + cuts[i], cuts[i + 1] - cuts[i], !(c->dbg & 0x20000000));
     TRY(small_wait(c, mine, k));
     // the segments' tokens, one after the other.  A segment the small kernel did not do sends the WHOLE document to the general pipeline (one pass
     // over 64 KiB costs it little more than one over 2 KiB; segment by segment it was 1.4x the pipeline on web text), and the next calls do not

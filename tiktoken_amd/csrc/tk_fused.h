@@ -2926,6 +2926,9 @@ __global__ void tk_k_single_front(TkTables T, const uint8_t* __restrict__ text, 
 #define TK_SMALL_MAX 2048
 #define TK_SMALL_PIECE 24
 #define TK_SMALL_LONG 256  // (a multiple of 16)
+#ifndef TK_SMALL_ONE_PHASE
+#define TK_SMALL_ONE_PHASE 0  // 1: the experiment in tk_k_small (both kinds of merge in one phase); variants only
+#endif
 #define TK_SMALL_NO_LONG 0x80000000u  // TkSmallReq::n bit: a piece of more than TK_SMALL_PIECE bytes that is not a token ends the call (status 2)
 #define TK_SMALL_HDR 4  // result words before the tokens: status (1 done, 2 not handled), token count, completion sequence number, 0
 struct TkSmallAcc {
@@ -2956,15 +2959,24 @@ __global__ __launch_bounds__(256) void tk_k_small(TkTables T, TkSmallReqs R) {
     __shared__ uint8_t cls[TK_SMALL_MAX + 16];
     __shared__ uint16_t nxt[TK_SMALL_MAX];
     __shared__ uint16_t plist[TK_SMALL_MAX + 1];
-    __shared__ uint32_t idb[TK_SMALL_PIECE * 256], rkb[TK_SMALL_PIECE * 256];
     __shared__ uint32_t lid[TK_SMALL_MAX];  // long pieces: the parts' ids at their text positions; in the end the piece's tokens from its start on
     __shared__ uint16_t llist[TK_SMALL_MAX / (TK_SMALL_PIECE + 1) + 3];  // the long pieces that are not tokens (indices into plist)
     __shared__ uint32_t np_sh, bail_sh, nlong_sh, scan_sh[8];
+#if TK_SMALL_ONE_PHASE
+    // (every merge at the piece's text positions: ids in lid, ranks in lrk -- the one-lane merges as well, so that both kinds run side by side)
+    __shared__ uint32_t lrk[TK_SMALL_MAX];
+    __shared__ uint16_t lnx[TK_SMALL_MAX], lpv[TK_SMALL_MAX];
+    __shared__ uint16_t slist[TK_SMALL_MAX / 2];  // the pieces of 2 .. TK_SMALL_PIECE bytes that are not tokens (indices into plist)
+    __shared__ uint32_t nshort_sh;
+    (void)ws;
+#else
+    __shared__ uint32_t idb[TK_SMALL_PIECE * 256], rkb[TK_SMALL_PIECE * 256];
     // (work arrays of the long pieces, free until the one-lane merges start: ranks where rkb is, the list links where idb is)
     static_assert(TK_SMALL_PIECE * 256 >= TK_SMALL_MAX, "the long pieces' work arrays lie in idb / rkb");
     uint32_t* const lrk = rkb;
     uint16_t* const lnx = (uint16_t*)idb;
     uint16_t* const lpv = lnx + TK_SMALL_MAX;
+#endif
     const uint32_t tid = threadIdx.x;
     const TkPat pat = T.pat;
     for (uint32_t i = tid * 4u; i < TK_SMALL_MAX + 16u; i += 1024u) *(uint32_t*)(raw + i) = i < n ? *(const uint32_t*)(text + i) : 0u;  // (input buffer is padded)
@@ -3001,6 +3013,129 @@ __global__ __launch_bounds__(256) void tk_k_small(TkTables T, TkSmallReqs R) {
     }
     __syncthreads();
     const uint32_t np = np_sh;
+#if TK_SMALL_ONE_PHASE
+    // EXPERIMENT (tools/build_variant.sh small1 -DTK_SMALL_ONE_PHASE=1; not in the shipped library): the one-lane merges and the sixteen-lane
+    // merges in ONE phase -- a wavefront takes units, first the long pieces (four to a unit), then the short ones (sixty-four to a unit) --
+    // so that the call waits for its longest chain of merges once, not for the long pieces' and then for every round of 256 short ones
+    // (profiles/r04_mid_calls_corpus.txt: 2 KiB of web text 250 us against the pipeline's 160).  Every piece's tokens end up in lid from the
+    // piece's start on, their number in nxt[start].
+    if (tid == 0) nshort_sh = 0;
+    __syncthreads();
+    for (uint32_t i = tid; i < np; i += 256u) {
+        const uint32_t s0 = plist[i], len = (uint32_t)plist[i + 1] - s0;
+        const uint32_t tok = tk_lookup_text_piece(T, raw, s0, len);
+        if (tok != TK_RANK_MAX) {
+            lid[s0] = tok;
+            nxt[s0] = 1;
+        } else if (len <= TK_SMALL_PIECE) {
+            slist[atomicAdd(&nshort_sh, 1u)] = (uint16_t)i;
+        } else if (len > long_max) {
+            bail_sh = 1;
+        } else {
+            llist[atomicAdd(&nlong_sh, 1u)] = (uint16_t)i;
+        }
+    }
+    __syncthreads();
+    const bool bail = bail_sh != 0;
+    const uint32_t nlong = bail ? 0u : nlong_sh, nshort = bail ? 0u : nshort_sh;
+    {
+        const uint32_t lane = tid & 63u, wid = tid >> 6;
+        const uint32_t g = tid & 15u, gsh = tid & 48u;
+        const uint32_t ul = (nlong + 3u) >> 2, units = ul + ((nshort + 63u) >> 6);
+        for (uint32_t u = wid; u < units; u += 4u) {  // (wave-uniform)
+            if (u >= ul) {
+                const uint32_t e = (u - ul) * 64u + lane;
+                if (e < nshort) {
+                    const uint32_t i = slist[e], s0 = plist[i], len = (uint32_t)plist[i + 1] - s0;
+                    nxt[s0] = (uint16_t)tk_lane_merge<1>(T, raw, s0, len, lid + s0, lrk + s0, lid + s0);  // (in place: a part moves left or stays)
+                }
+                continue;
+            }
+            const uint32_t w = u * 4u + (lane >> 4);
+            const bool valid = w < nlong;
+            uint32_t s0 = 0, len = 0;
+            if (valid) {
+                const uint32_t i = llist[w];
+                s0 = plist[i];
+                len = (uint32_t)plist[i + 1] - s0;
+            }
+            uint32_t* const id = lid + s0;
+            uint32_t* const rk = lrk + s0;
+            uint16_t* const nx = lnx + s0;
+            uint16_t* const pv = lpv + s0;
+            for (uint32_t k = g; k < len; k += 16u) {
+                const uint32_t b0 = raw[s0 + k], b1 = raw[s0 + k + 1u];
+                id[k] = T.byte_rank[b0];
+                rk[k] = k + 1u < len ? T.pair2[(b0 << 8) | b1] : TK_RANK_MAX;
+                nx[k] = (uint16_t)(k + 1u);
+                pv[k] = (uint16_t)(k ? k - 1u : 0xFFFFu);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            for (;;) {
+                uint32_t br = TK_RANK_MAX, bk = 0xFFFFFFFFu;
+                for (uint32_t k = g; k < len; k += 16u) {
+                    const uint32_t r = rk[k];
+                    if (r < br) br = r, bk = k;
+                }
+                const uint32_t m = tkm_group_min(br, 4);
+                const bool on = m != TK_RANK_MAX;
+                if (!__any(on)) break;
+                const uint32_t i = tkm_group_min(br == m ? bk : 0xFFFFFFFFu, 4);
+                uint32_t j = 0, nn = len, pp = 0xFFFFu, idn = 0, idp = 0;
+                if (on) {
+                    j = nx[i];
+                    nn = nx[j];
+                    pp = pv[i];
+                    idn = id[nn < len ? nn : i];
+                    idp = id[pp != 0xFFFFu ? pp : i];
+                }
+                const bool right = g == 0u, probe = on && (right ? nn < len : (g == 1u && pp != 0xFFFFu));
+                uint32_t newr = TK_RANK_MAX;
+                if (probe) newr = tk_probe_pair(T, right ? m : idp, right ? idn : m);
+                if (on && g == 0u) {
+                    id[i] = m;
+                    nx[i] = (uint16_t)nn;
+                    if (nn < len) pv[nn] = (uint16_t)i;
+                    rk[j] = TK_RANK_MAX;
+                    id[j] = TK_RANK_MAX;
+                    rk[i] = newr;
+                }
+                if (on && g == 1u && pp != 0xFFFFu) rk[pp] = newr;
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+            uint32_t t = 0;
+            for (uint32_t k0 = 0; __any(k0 < len); k0 += 16u) {
+                const uint32_t k = k0 + g;
+                const uint32_t v = k < len ? id[k] : (uint32_t)TK_RANK_MAX;
+                const uint32_t mine = (uint32_t)((__ballot(v != TK_RANK_MAX) >> gsh) & 0xFFFFull);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+                if (v != TK_RANK_MAX) id[t + (uint32_t)__popc(mine & ((1u << g) - 1u))] = v;
+                t += (uint32_t)__popc(mine);
+                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                __builtin_amdgcn_wave_barrier();
+            }
+            if (valid && g == 0u) nxt[s0] = (uint16_t)t;
+        }
+    }
+    __syncthreads();
+    uint32_t base = 0;
+    for (uint32_t r0 = 0; r0 < np && !bail; r0 += 256u) {
+        const uint32_t i = r0 + tid;
+        uint32_t cnt = 0, s0 = 0;
+        if (i < np) {
+            s0 = plist[i];
+            cnt = nxt[s0];
+        }
+        uint32_t tot;
+        const uint32_t ex = tk_block_exscan_256(cnt, &tot, scan_sh);
+        uint32_t* o = out + TK_SMALL_HDR + base + ex;
+        for (uint32_t j = 0; j < cnt; ++j) o[j] = lid[s0 + j];
+        base += tot;
+    }
+#else
     // the long pieces (nxt has done its job: from here on nxt[start of a long piece] = 0 for a token, else the number of its tokens in lid)
     for (uint32_t i = tid; i < np; i += 256u) {
         const uint32_t s0 = plist[i], len = (uint32_t)plist[i + 1] - s0;
@@ -3118,6 +3253,7 @@ __global__ __launch_bounds__(256) void tk_k_small(TkTables T, TkSmallReqs R) {
         }
         base += tot;
     }
+#endif
     __threadfence_system();
     __syncthreads();
     if (tid == 0) {
