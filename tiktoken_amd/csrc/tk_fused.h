@@ -2927,7 +2927,10 @@ __global__ void tk_k_single_front(TkTables T, const uint8_t* __restrict__ text, 
 #define TK_SMALL_PIECE 24
 #define TK_SMALL_LONG 256  // (a multiple of 16)
 #ifndef TK_SMALL_ONE_PHASE
-#define TK_SMALL_ONE_PHASE 0  // 1: the experiment in tk_k_small (both kinds of merge in one phase); variants only
+#define TK_SMALL_ONE_PHASE 0  // 1: the experiment in tk_k_small (both kinds of merge in one phase), 2: ... and TK_SMALL_K merges per round; variants only
+#endif
+#ifndef TK_SMALL_K
+#define TK_SMALL_K 4
 #endif
 #define TK_SMALL_NO_LONG 0x80000000u  // TkSmallReq::n bit: a piece of more than TK_SMALL_PIECE bytes that is not a token ends the call (status 2)
 #define TK_SMALL_HDR 4  // result words before the tokens: status (1 done, 2 not handled), token count, completion sequence number, 0
@@ -2968,6 +2971,9 @@ __global__ __launch_bounds__(256) void tk_k_small(TkTables T, TkSmallReqs R) {
     __shared__ uint16_t lnx[TK_SMALL_MAX], lpv[TK_SMALL_MAX];
     __shared__ uint16_t slist[TK_SMALL_MAX / 2];  // the pieces of 2 .. TK_SMALL_PIECE bytes that are not tokens (indices into plist)
     __shared__ uint32_t nshort_sh;
+#if TK_SMALL_ONE_PHASE >= 2
+    __shared__ uint16_t lst[TK_SMALL_MAX];  // the round that last barred the part at this position (see the K merges per round below)
+#endif
     (void)ws;
 #else
     __shared__ uint32_t idb[TK_SMALL_PIECE * 256], rkb[TK_SMALL_PIECE * 256];
@@ -3072,6 +3078,104 @@ __global__ __launch_bounds__(256) void tk_k_small(TkTables T, TkSmallReqs R) {
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             __builtin_amdgcn_wave_barrier();
+#if TK_SMALL_ONE_PHASE >= 2
+            // EXPERIMENT, level 2 (-DTK_SMALL_ONE_PHASE=2): TK_SMALL_K merges per round of probes.  A merge is the latency of its two probes
+            // (~1 us); the round's merges are CHOSEN before any probe is answered -- the t-th choice is the lowest pair whose two parts no
+            // earlier choice has barred (barred: the part before, the merged part, the absorbed part, the part behind) --, all the new pairs
+            // are probed at once (lanes 2t and 2t + 1 of the piece's sixteen) with the ids of before the round, and the choices are carried
+            // out in order as long as each is the lowest pair of the state it meets: then it IS the reference's next merge (lib.rs:151,190).
+            // Simulated on the CPU first (tools/sim_merge_steps.py, tests/test_merge_schedule_sim.py: exact; 2.9 merges per round for K = 4).
+            constexpr int K = TK_SMALL_K;
+            static_assert(K >= 1 && K <= 8, "two lanes of sixteen per merge");
+            uint16_t* const st = lst + s0;
+            for (uint32_t k = g; k < len; k += 16u) st[k] = 0;
+            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+            __builtin_amdgcn_wave_barrier();
+            for (uint32_t round = 1;; ++round) {  // (at most len - 1 rounds: every round merges)
+                uint32_t ci[K], cm[K];
+#pragma unroll
+                for (int t = 0; t < K; ++t) ci[t] = 0xFFFFFFFFu, cm[t] = TK_RANK_MAX;
+                uint32_t nc = 0;   // the piece's choices this round (uniform over its lanes)
+                bool more = true;  // (uniform over the piece's lanes)
+#pragma unroll
+                for (int t = 0; t < K; ++t) {
+                    uint32_t br = TK_RANK_MAX, bk = 0xFFFFFFFFu;
+                    if (more)
+                        for (uint32_t k = g; k < len; k += 16u) {
+                            const uint32_t r = rk[k];
+                            if (r < br && st[k] != (uint16_t)round && st[nx[k]] != (uint16_t)round) br = r, bk = k;  // (a pair: nx[k] < len)
+                        }
+                    const uint32_t m = tkm_group_min(br, 4);
+                    const bool have = m != TK_RANK_MAX;
+                    const uint32_t i = tkm_group_min(br == m ? bk : 0xFFFFFFFFu, 4);
+                    if (have) {
+                        ci[t] = i;
+                        cm[t] = m;
+                        nc = (uint32_t)t + 1u;
+                        if (g == 0u) {
+                            const uint32_t j = nx[i], nn = nx[j], pp = pv[i];
+                            st[i] = (uint16_t)round;
+                            st[j] = (uint16_t)round;
+                            if (pp != 0xFFFFu) st[pp] = (uint16_t)round;
+                            if (nn < len) st[nn] = (uint16_t)round;
+                        }
+                    }
+                    more = have;
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                }
+                if (!__any(nc != 0u)) break;
+                // the probes: lane 2t the pair (merged part, part behind), lane 2t + 1 the pair (part before, merged part) of choice t
+                const uint32_t tt = g >> 1;
+                uint32_t pi = 0xFFFFFFFFu, pm = 0;
+#pragma unroll
+                for (int t = 0; t < K; ++t)
+                    if (tt == (uint32_t)t) pi = ci[t], pm = cm[t];
+                const bool mine = pi != 0xFFFFFFFFu;
+                uint32_t pj = 0, pnn = len, ppp = 0xFFFFu, idn = 0, idp = 0;
+                if (mine) {
+                    pj = nx[pi];
+                    pnn = nx[pj];
+                    ppp = pv[pi];
+                    idn = id[pnn < len ? pnn : pi];
+                    idp = id[ppp != 0xFFFFu ? ppp : pi];
+                }
+                const bool right = !(g & 1u), probe = mine && (right ? pnn < len : ppp != 0xFFFFu);
+                uint32_t newr = TK_RANK_MAX;
+                if (probe) newr = tk_probe_pair(T, right ? pm : idp, right ? idn : pm);
+                // carried out in order; from the second on only while the choice is the lowest pair of what the earlier ones have left
+#pragma unroll
+                for (int t = 0; t < K; ++t) {
+                    bool go = (uint32_t)t < nc;
+                    if (t > 0) {
+                        uint32_t br = TK_RANK_MAX, bk = 0xFFFFFFFFu;
+                        if (go)
+                            for (uint32_t k = g; k < len; k += 16u) {
+                                const uint32_t r = rk[k];
+                                if (r < br) br = r, bk = k;
+                            }
+                        const uint32_t m = tkm_group_min(br, 4);
+                        const uint32_t i = tkm_group_min(br == m ? bk : 0xFFFFFFFFu, 4);
+                        go = go && m == cm[t] && i == ci[t];
+                        if (!go && nc > (uint32_t)t) nc = (uint32_t)t;  // (the round ends here for this piece)
+                    }
+                    if (go && tt == (uint32_t)t) {
+                        if (right) {
+                            id[pi] = pm;
+                            nx[pi] = (uint16_t)pnn;
+                            if (pnn < len) pv[pnn] = (uint16_t)pi;
+                            rk[pj] = TK_RANK_MAX;
+                            id[pj] = TK_RANK_MAX;
+                            rk[pi] = newr;
+                        } else if (ppp != 0xFFFFu) {
+                            rk[ppp] = newr;
+                        }
+                    }
+                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+                    __builtin_amdgcn_wave_barrier();
+                }
+            }
+#else
             for (;;) {
                 uint32_t br = TK_RANK_MAX, bk = 0xFFFFFFFFu;
                 for (uint32_t k = g; k < len; k += 16u) {
@@ -3105,6 +3209,7 @@ __global__ __launch_bounds__(256) void tk_k_small(TkTables T, TkSmallReqs R) {
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 __builtin_amdgcn_wave_barrier();
             }
+#endif
             uint32_t t = 0;
             for (uint32_t k0 = 0; __any(k0 < len); k0 += 16u) {
                 const uint32_t k = k0 + g;
