@@ -738,3 +738,18 @@ def test_tables_on_every_short_string(idx):
     for mode in (0, 5, 14):
         assert rx.split(docs, speculate=mode, matcher="dfa") == want and rx.gaps == wgap, mode
     assert rx.split(docs, speculate=5, matcher="program") == want
+
+
+def test_look_ahead_of_a_repeat_is_one_char_only_when_the_repeat_starts_at_one():
+    """(?=X+) and (?=X{1,3}) ask for one char and may live in the table; (?=X{2}) and (?!X{2,}) look at two and keep the program.  Found by
+    tools/fuzz_regex.py (other seeds of the generated-pattern test): the table had taken (?!\\pL{2}) for (?!\\pL) -- a ',' in front of "K'" was a gap."""
+    doc = "bs  ٣Cskb,K'sKcb's 'sXa٣ 12345 1234 ab,cd"
+    for pat, has_table in [(r"c?[^\r\n\p{L}\p{N}]{1,3}(?!(?:\pL{2}))|\pL|\pN", False), (r"\d{1,3}(?=\d{3})|\d+|\D", False), (r"\d(?=\d{1,3})|\d+|\D", True),
+                           (r"[^\s\d]+(?!\pL+)|\s(?=(?:\S{2,})+)|[\s\S]", False), (r"\pL+(?=(?:\d+)+)|[\s\S]", True)]:
+        rx = h.RxSim(pat)
+        assert (rx.dfa is not None) == has_table, (pat, rx.dfa_why)
+        if not has_table:
+            assert "look-ahead of more than one char" in rx.dfa_why
+        want = py_starts_gaps(regex.compile(pat.replace(r"[\s\S]", r"(?s:.)")), doc)
+        for sp in (0, 1, 5, 13):
+            assert rx.split([doc.encode()], speculate=sp) == want[0] and rx.gaps == want[1], (pat, sp)
