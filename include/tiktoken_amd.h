@@ -147,8 +147,11 @@ int tk_group_encode_batch_device(tk_group* group, const uint8_t* utf8, const uin
 uint64_t tk_group_stat(tk_group* group, const char* name);
 
 /* Vocabulary wire format: the text of a `.tiktoken` file (`base64(token) SP rank` per line) -> the packed arrays tk_create takes.
- * Replaces the per-line Python loop of tiktoken/load.py:159-171.  Release the three arrays with tk_free.  TK_VALUE_ERROR with
- * "Error parsing line N ..." on malformed input. */
+ * Replaces the per-line Python loop of tiktoken/load.py:159-171, and reads what that loop reads: lines ending in \n, \r or \r\n, two fields
+ * between runs of ASCII white space, base64 as b64decode() takes it without validation (bytes outside the alphabet skipped, anything behind
+ * the padding ignored), the rank as int() takes it (sign, underscores between digits).  Release the three arrays with tk_free.
+ * TK_VALUE_ERROR with "Error parsing line N ..." on malformed input, and on a rank that is negative or does not fit 32 bits (where the
+ * reference fails one step later, in CoreBPE's constructor). */
 int tk_parse_tiktoken_bpe(const uint8_t* text, uint64_t len, uint8_t** blob_out, uint64_t** off_out, uint32_t** ids_out, uint64_t* n_out);
 
 /* The reference's text boundary is &str -- valid UTF-8 by construction (PyO3 extracts it, src/py.rs:29).  A C caller has bytes: 0 if

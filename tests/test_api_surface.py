@@ -104,6 +104,49 @@ def test_tiktoken_file_roundtrip_and_cache(tmp_path, monkeypatch):
     assert vocab_io.load_tiktoken_bpe(url, expected_hash=sha) == ranks
 
 
+def test_native_parser_is_as_lenient_as_the_references_python_calls():
+    """reference load.py:162-171 reads a `.tiktoken` file with contents.splitlines(), line.split(), base64.b64decode(token) (which skips bytes
+    outside the alphabet and ignores what follows the padding) and int(rank) (sign, underscores): a file it loads has to load here, with the same
+    table, and what it refuses has to be refused here.  Differential, on hand-picked lines and 40 000 random ones; the one difference by
+    design: a negative rank is an error at parse time here (the reference fails in CoreBPE's constructor: OverflowError)."""
+    import random
+
+    def ref(contents: bytes):
+        ret = {}
+        for line in contents.splitlines():
+            if not line:
+                continue
+            token, rank = line.split()
+            ret[base64.b64decode(token)] = int(rank)
+        return ret
+
+    cases = [b"YQ==\t7\n", b"YQ==  7\n", b" YQ== 7\n", b"YQ== 7 \n", b"YQ== +7\n", b"YQ== 007\n", b"YQ== 1_0\n", b"YQ== 1__0\n", b"YQ== _1\n", b"YQ== 1_\n",
+             b"YQ== 7\rYg== 8\n", b"YQ== 7\r\nYg== 8\r\n", b"YQ== 7\x0bYg== 8\n", b"YQ== 7\x0c\n", b"Y!Q== 7\n", b"YQ==YQ== 7\n", b"YQ 7\n", b"YQ= 7\n",
+             b"YQ=== 7\n", b"= 7\n", b"YWI 7\n", b"YWI= 7\n", b"YWJj 7\n", b"Y 7\n", b"YQ== 7\n\x00", b"YQ== 7\nYQ== 8\n", b"\xef\xbb\xbfYQ== 7\n", b"YQ== 4294967295\n",
+             b"YQ== 0x10\n", b"YQ== 7.0\n", b"YQ== 1e3\n", b"YQ==\x1c7\n", b"YQ==\xa07\n", b"YQ== 7\x85", b"Y Q== 7\n", b"YQ==\n7\n", b"-_-_ 7\n", b"+/+/ 7\n",
+             b"YQ== -0\n", b"YQ== +\n", b"YQ== 7 8\n", b"\r\r\n\n", b"YQ== 7"]
+    rng = random.Random(3)
+    alphabet = b"YQWJj=+/ \t\r\n0123456789_!x"
+    cases += [bytes(rng.choice(alphabet) for _ in range(rng.randint(0, 14))) for _ in range(40000)]
+    both_ok = 0
+    for c in cases:
+        try:
+            want = ref(c)
+        except Exception:
+            want = None
+        try:
+            got = dict(vocab_io.parse_tiktoken_bpe(c))
+        except ValueError as e:
+            assert "Error parsing line" in str(e)
+            got = None
+        assert got == want, c
+        both_ok += want is not None
+    assert both_ok > 2000
+    for c in (b"YQ== -1\n", b"YQ== 4294967296\n", b"YQ== 99999999999999999999999\n"):
+        with pytest.raises(ValueError, match="Error parsing line 1"):
+            vocab_io.parse_tiktoken_bpe(c)
+
+
 def test_native_parser_equals_python_on_the_shipped_vocabularies():
     import gzip
 

@@ -407,7 +407,15 @@ const std::vector<uint32_t>& TkHostTables::sorted_ranks() const {
 // ------------------------------------------------------------------------------------------
 std::string tk_parse_tiktoken(const uint8_t* text, uint64_t len, std::vector<uint8_t>* blob, std::vector<uint64_t>* off,
                               std::vector<uint32_t>* ids) {
-    // (built once, thread-safe: initialisation of a function-local static)
+    // As lenient as the reference's three Python calls per line are (tiktoken/load.py:162-171: `contents.splitlines()`, `line.split()`,
+    // `base64.b64decode(token)`, `int(rank)`), so that a file the reference loads loads here as well:
+    //   * lines end at \n, \r or \r\n; empty lines are skipped;
+    //   * a line is exactly two fields between runs of ASCII white space (blank, \t, \n, \r, \v, \f), leading and trailing runs allowed;
+    //   * base64 the way binascii.a2b_base64 reads it when it does not validate: bytes outside the alphabet are skipped (a byte-order
+    //     mark, a '!'), a '=' ends the data once it completes a quad's padding and is skipped before that, what follows is ignored,
+    //     and data that stops one or two sextets into a quad without padding is an error;
+    //   * the rank as int() reads it: an optional sign, decimal digits, single underscores between digits.  A negative rank or one
+    //     beyond 32 bits is an error HERE (the reference gets as far as CoreBPE's constructor with it: OverflowError, src/py.rs:20).
     static const std::array<int8_t, 256> dec = [] {
         std::array<int8_t, 256> d;
         d.fill(-1);
@@ -415,6 +423,7 @@ std::string tk_parse_tiktoken(const uint8_t* text, uint64_t len, std::vector<uin
         for (int i = 0; i < 64; ++i) d[(unsigned char)al[i]] = (int8_t)i;
         return d;
     }();
+    auto is_ws = [](uint8_t c) { return c == ' ' || (c >= 9 && c <= 13); };
     blob->clear();
     off->assign(1, 0);
     ids->clear();
@@ -424,39 +433,65 @@ std::string tk_parse_tiktoken(const uint8_t* text, uint64_t len, std::vector<uin
     while (i < len) {
         ++line_no;
         uint64_t e = i;
-        while (e < len && text[e] != '\n') ++e;
-        uint64_t a = i, b = e;
-        if (b > a && text[b - 1] == '\r') --b;
+        while (e < len && text[e] != '\n' && text[e] != '\r') ++e;
+        const uint64_t a0 = i, b0 = e;
         i = e + 1;
-        if (a == b) continue;  // empty line
+        if (e < len && text[e] == '\r' && i < len && text[i] == '\n') ++i;
+        if (a0 == b0) continue;  // empty line
+        // the two fields
+        uint64_t a = a0;
+        while (a < b0 && is_ws(text[a])) ++a;
         uint64_t sp = a;
-        while (sp < b && text[sp] != ' ') ++sp;
-        if (sp == a || sp == b) return bad("expected `base64 SP rank`");
-        // base64 (standard alphabet, '=' padding)
-        uint64_t q = sp;
-        while (q > a && text[q - 1] == '=') --q;
-        const uint64_t n64 = q - a, pad = sp - q;
-        if ((n64 + pad) % 4 != 0 || pad > 2 || n64 % 4 == 1) return bad("bad base64 length");
-        uint32_t acc = 0;
-        int bits = 0;
-        for (uint64_t k = a; k < q; ++k) {
-            const int v = dec[text[k]];
-            if (v < 0) return bad("bad base64 character");
-            acc = (acc << 6) | (uint32_t)v;
-            bits += 6;
-            if (bits >= 8) {
-                bits -= 8;
-                blob->push_back((uint8_t)(acc >> bits));
+        while (sp < b0 && !is_ws(text[sp])) ++sp;
+        uint64_t ra = sp;
+        while (ra < b0 && is_ws(text[ra])) ++ra;
+        uint64_t rb = ra;
+        while (rb < b0 && !is_ws(text[rb])) ++rb;
+        uint64_t rest = rb;
+        while (rest < b0 && is_ws(text[rest])) ++rest;
+        if (a == sp || ra == rb || rest != b0) return bad("expected `base64 SP rank`");
+        // the token
+        const size_t blob_before = blob->size();
+        uint32_t acc = 0, quad = 0, pads = 0;
+        bool done = false;
+        for (uint64_t k = a; k < sp && !done; ++k) {
+            const uint8_t ch = text[k];
+            if (ch == '=') {
+                if (quad >= 2 && quad + ++pads >= 4) done = true;  // (the quad's data bytes are out already)
+                continue;
+            }
+            const int v = dec[ch];
+            if (v < 0) continue;
+            pads = 0;
+            switch (quad) {
+                case 0: acc = (uint32_t)v; quad = 1; break;
+                case 1: blob->push_back((uint8_t)((acc << 2) | ((uint32_t)v >> 4))); acc = (uint32_t)v & 15u; quad = 2; break;
+                case 2: blob->push_back((uint8_t)((acc << 4) | ((uint32_t)v >> 2))); acc = (uint32_t)v & 3u; quad = 3; break;
+                default: blob->push_back((uint8_t)((acc << 6) | (uint32_t)v)); acc = 0; quad = 0; break;
             }
         }
-        // rank: decimal, fits u32
-        uint64_t r = 0, k = sp + 1;
-        if (k == b) return bad("missing rank");
-        for (; k < b; ++k) {
+        if (!done && quad != 0) {
+            blob->resize(blob_before);
+            return bad(quad == 1 ? "base64: one character more than a multiple of four" : "base64: incorrect padding");
+        }
+        // the rank
+        uint64_t k = ra;
+        bool neg = false;
+        if (text[k] == '+' || text[k] == '-') neg = text[k++] == '-';
+        if (k == rb || text[k] < '0' || text[k] > '9') return bad("rank is not a decimal number");
+        uint64_t r = 0;
+        bool wide = false;
+        for (; k < rb; ++k) {
+            if (text[k] == '_') {  // (between two digits only)
+                if (k + 1 == rb || text[k + 1] < '0' || text[k + 1] > '9') return bad("rank is not a decimal number");
+                continue;
+            }
             if (text[k] < '0' || text[k] > '9') return bad("rank is not a decimal number");
             r = r * 10 + (uint64_t)(text[k] - '0');
-            if (r > 0xFFFFFFFFull) return bad("rank does not fit 32 bits");
+            if (r > 0xFFFFFFFFull) wide = true, r = 0x100000000ull;  // (keep reading: "not a number" comes first if it is not one)
         }
+        if (wide) return bad("rank does not fit 32 bits");
+        if (neg && r != 0) return bad("rank is negative");
         off->push_back(blob->size());
         ids->push_back((uint32_t)r);
     }
