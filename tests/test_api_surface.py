@@ -166,6 +166,69 @@ def test_shaped_vocab_files_parse_like_reference_format():
     assert [ranks[bytes([b])] for b in order] == list(range(256))
 
 
+def test_data_gym_conversion_equals_the_references(tmp_path, monkeypatch):
+    """vocab.bpe + encoder.json -> ranks (reference load.py:84-144), on a synthetic vocabulary: against the reference's own function where its
+    source tree is at hand (this container), and against the table the files were made from everywhere."""
+    import importlib.util
+    import json
+    import random
+
+    rng = random.Random(7)
+    order = vocab_io.data_gym_byte_order()
+    to_char = {b: chr(b) for b in order[:188]}
+    to_char.update({b: chr(256 + i) for i, b in enumerate(order[188:])})
+    assert len([b for b in range(256) if chr(b).isprintable() and chr(b) != " "]) == 188
+
+    def gym(tok: bytes) -> str:
+        return "".join(to_char[b] for b in tok)
+
+    toks = [bytes([b]) for b in order]
+    ranks = {t: i for i, t in enumerate(toks)}
+    lines = ["#version: 0.2"]
+    while len(ranks) < 900:
+        a, b = rng.choice(toks), rng.choice(toks)
+        if a + b in ranks or len(a + b) > 12:
+            continue
+        ranks[a + b] = len(ranks)
+        toks.append(a + b)
+        lines.append(gym(a) + " " + gym(b))
+    bpe, enc = tmp_path / "vocab.bpe", tmp_path / "encoder.json"
+    bpe.write_text("\n".join(lines) + "\n", encoding="utf-8")
+    table = {gym(t): r for t, r in ranks.items()}
+    table["<|endoftext|>"] = len(ranks)
+    enc.write_text(json.dumps(table), encoding="utf-8")
+    monkeypatch.setenv("TIKTOKEN_CACHE_DIR", "")  # (no cache: local files)
+    got = vocab_io.data_gym_to_mergeable_bpe_ranks(str(bpe), str(enc))
+    assert got == ranks
+    assert vocab_io.data_gym_to_mergeable_bpe_ranks(str(bpe), str(enc), clobber_one_byte_tokens=True) == ranks
+    # a merge listed twice takes a number both times (the later ones move up by one): encoder.json numbered that way is accepted, as in the reference
+    dup = lines[:400] + [lines[300]] + lines[400:]
+    bpe2, enc2 = tmp_path / "vocab2.bpe", tmp_path / "encoder2.json"
+    bpe2.write_text("\n".join(dup) + "\n", encoding="utf-8")
+    first, second = lines[300].split()
+    back = {v: k for k, v in to_char.items()}
+    dup_tok = bytes(back[c] for c in first) + bytes(back[c] for c in second)
+    ranks2 = {t: (r if r < 256 + 399 else r + 1) for t, r in ranks.items()}
+    ranks2[dup_tok] = 256 + 399
+    enc2.write_text(json.dumps({gym(t): r for t, r in ranks2.items()}), encoding="utf-8")
+    assert vocab_io.data_gym_to_mergeable_bpe_ranks(str(bpe2), str(enc2)) == ranks2
+    with pytest.raises(AssertionError):
+        vocab_io.data_gym_to_mergeable_bpe_ranks(str(bpe2), str(enc))  # (files that do not belong together)
+    ref_path = "/root/reference/tiktoken/load.py"
+    if os.path.exists(ref_path):
+        spec = importlib.util.spec_from_file_location("reference_load", ref_path)
+        ref = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref)
+        assert ref.data_gym_to_mergeable_bpe_ranks(str(bpe), str(enc)) == got
+        assert ref.data_gym_to_mergeable_bpe_ranks(str(bpe2), str(enc2)) == ranks2
+        with pytest.raises(AssertionError):
+            ref.data_gym_to_mergeable_bpe_ranks(str(bpe2), str(enc))
+        # and the .tiktoken wire format through the reference's loader, on a file written here
+        path = tmp_path / "t.tiktoken"
+        vocab_io.dump_tiktoken_bpe(ranks, str(path))
+        assert ref.load_tiktoken_bpe(str(path)) == ranks == vocab_io.load_tiktoken_bpe(str(path))
+
+
 def test_model_table():
     """reference tiktoken/model.py:88-105 and tests/test_misc.py: exact names, dated versions through prefixes, the longest prefix decides."""
     f = tiktoken_amd.encoding_name_for_model

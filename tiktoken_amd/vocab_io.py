@@ -186,8 +186,10 @@ def data_gym_to_mergeable_bpe_ranks(vocab_bpe_file: str, encoder_json_file: str,
     merges_text = fetch(vocab_bpe_file, vocab_bpe_hash).decode()
     merges = [tuple(line.split()) for line in merges_text.split("\n")[1:-1]]
     ranks = {bytes([b]): i for i, b in enumerate(rank_to_byte)}
-    for first, second in merges:
-        ranks[to_bytes(first) + to_bytes(second)] = len(ranks)
+    n = len(ranks)
+    for first, second in merges:  # (a counter, not len(ranks): a merge listed twice takes a number both times -- load.py:116-119)
+        ranks[to_bytes(first) + to_bytes(second)] = n
+        n += 1
     encoder = {to_bytes(k): v for k, v in json.loads(fetch(encoder_json_file, encoder_json_hash)).items()}
     encoder.pop(b"<|endoftext|>", None)
     encoder.pop(b"<|startoftext|>", None)
