@@ -35,6 +35,7 @@ def test_k_merges_per_step_equal_the_plain_loop_on_adversarial_vocabularies():
                 steps, merges, parts = sim.steps_as_a_kernel_would(p, K)
                 assert parts == want, (V, p, K)
                 assert merges == len(p) - len(want) and steps <= max(merges, 1)
+                assert sim.steps_lane_by_lane(p, K) == (steps, merges, parts), (V, p, K)  # (the kernel's bookkeeping, lane by lane: same rounds, same parts)
                 trials += 1
     assert trials > 50000
 
@@ -68,6 +69,8 @@ def test_k_merges_per_step_on_the_corpus_long_pieces():
         assert [t for q in want for t in [V[q]]] == C.encode_piece(p)  # (the simulation's plain loop is the oracle's)
         st4, mg4, parts = sim.steps_as_a_kernel_would(p, 4)
         assert parts == want
+        if len(p) <= 256:
+            assert sim.steps_lane_by_lane(p, 4) == (st4, mg4, parts)
         one += mg4
         four += st4
         merges += mg4

@@ -11,10 +11,19 @@ for off in [int(a) for a in sys.argv[1:]]:
     shim = types.SimpleNamespace(**{k: getattr(random, k) for k in dir(random) if not k.startswith("__")})
     shim.Random = lambda seed=None, _off=off: random.Random(None if seed is None else seed + _off)
     t.random = shim
-    for fn in (t.test_generated_patterns_equal_python_regex, t.test_generated_patterns_in_table_form_equal_python_regex):
+    fns = [t.test_generated_patterns_equal_python_regex, t.test_generated_patterns_in_table_form_equal_python_regex]
+    if os.environ.get("FUZZ_FIXED_PATTERNS"):  # the hand-written pattern list on other texts (and with special tokens at other places) instead
+        import functools
+        which = [i for i in range(len(t.PATTERNS))]
+        fns = [functools.partial(f, i) for i in which for f in (t.test_split_equals_python_regex, t.test_special_tokens_at_random_places)]
+        for f in fns:
+            f.__name__ = f"{f.func.__name__}[{f.args[0]}]"
+    for fn in fns:
         try:
             fn()
             print(f"offset {off}: {fn.__name__} ok", flush=True)
+        except LookupError:
+            print(f"offset {off}: {fn.__name__} skipped (the pattern leaves gaps on these texts)", flush=True)
         except AssertionError as e:
             # (the tests' closing assertions are about the yield of the seed's patterns -- how many compile, how many have a table; a mismatch shows the pattern)
             msg = str(e)

@@ -144,6 +144,76 @@ def steps_as_a_kernel_would(piece: bytes, K: int):
 
 
 
+def steps_lane_by_lane(piece: bytes, K: int):
+    """tk_k_small's sixteen-lane merge with K merges per round (tk_fused.h, -DTK_SMALL_ONE_PHASE=2) transliterated lane by lane: the arrays at
+    the piece's positions (id, rk, nx, pv, the round stamps st), what each of the sixteen lanes scans (positions g, g + 16, ...), which lane
+    probes and writes what, in the kernel's order of statements.  A check of the kernel's bookkeeping, not only of the schedule.
+    Returns (rounds, merges, parts)."""
+    n, G, MAXR, NONE = len(piece), 16, INF, 0xFFFF
+    id_ = [piece[i:i + 1] for i in range(n)]
+    rk = [rank(id_[k], id_[k + 1]) if k + 1 < n else MAXR for k in range(n)]
+    nx = [k + 1 for k in range(n)]
+    pv = [k - 1 if k else NONE for k in range(n)]
+    st = [0] * n
+    rounds = merges = 0
+    rnd = 0
+    while True:
+        rnd += 1
+        ci, cm, nc, more = [None] * K, [MAXR] * K, 0, True
+        for t in range(K):
+            br, bk = [MAXR] * G, [None] * G
+            if more:
+                for g in range(G):
+                    for k in range(g, n, G):
+                        r = rk[k]
+                        if r < br[g] and st[k] != rnd and st[nx[k]] != rnd:
+                            br[g], bk[g] = r, k
+            m = min(br)                                                    # tkm_group_min(br, 4)
+            have = m != MAXR
+            i = min([bk[g] for g in range(G) if br[g] == m and bk[g] is not None], default=None)
+            if have:
+                ci[t], cm[t], nc = i, m, t + 1
+                j = nx[i]; nn = nx[j]; pp = pv[i]                          # lane 0 of the piece
+                st[i] = rnd; st[j] = rnd
+                if pp != NONE: st[pp] = rnd
+                if nn < n: st[nn] = rnd
+            more = have
+        if nc == 0:
+            break
+        # the probes: lane 2t the right pair, lane 2t + 1 the left pair of choice t -- with the arrays as they are BEFORE any commit
+        newr, loc = [MAXR] * G, [None] * G
+        for g in range(G):
+            tt = g >> 1
+            if tt >= K or ci[tt] is None:
+                continue
+            pi, pm = ci[tt], cm[tt]
+            pj = nx[pi]; pnn = nx[pj]; ppp = pv[pi]
+            merged = id_[pi] + id_[pj]
+            assert V.get(merged, INF) == pm
+            right = not (g & 1)
+            loc[g] = (pi, pj, pnn, ppp, merged)
+            if right and pnn < n: newr[g] = rank(merged, id_[pnn])
+            if not right and ppp != NONE: newr[g] = rank(id_[ppp], merged)
+        done = 0
+        for t in range(K):
+            go = t < nc
+            if t > 0 and go:
+                best = min(((rk[k], k) for k in range(n)), default=(MAXR, None))   # the sixteen lanes' scans + two reductions
+                go = best[0] == cm[t] and best[1] == ci[t]
+                if not go: nc = t
+            if go:
+                pi, pj, pnn, ppp, merged = loc[2 * t]
+                assert nx[pi] == pj and nx[pj] == pnn and pv[pi] == ppp and id_[pi] + id_[pj] == merged  # (the probes' operands are what the merge meets)
+                id_[pi] = merged; nx[pi] = pnn                               # lane 2t
+                if pnn < n: pv[pnn] = pi
+                rk[pj] = MAXR; id_[pj] = None; rk[pi] = newr[2 * t]
+                if ppp != NONE: rk[ppp] = newr[2 * t + 1]                   # lane 2t + 1
+                done += 1
+        rounds += 1
+        merges += done
+    return rounds, merges, [x for x in id_ if x is not None]
+
+
 def main():
     global APART, steps_with
     name = sys.argv[1] if len(sys.argv) > 1 else "o200k_shaped"
