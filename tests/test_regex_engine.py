@@ -260,7 +260,7 @@ def test_case_insensitive_matching_beyond_ascii():
 
 @pytest.mark.parametrize("pat,why", [
     (r"(?<=a+b)c|.", "look-behind has to be"), (r"[\b]|.", "inside a class"), (r"(?<=a*)c|.", "fixed-length"), (r"(?<=a(?=b))c|.", "fixed-length"), (r"(a)\1|.", "back-references"), (r"a*", "empty string"),
-    (r"(?:a*)+|.", "empty string"), (r"\p{Alphabetical}+|.", "a script or a binary property"), (r"[\P{Han}x]|.", "negated script"),
+    (r"(?:a*)+|.", "empty string"), (r"(?:\pL?+(?!\d)|(\s\p{Lu}){2}){1,3}\w+?|.", "empty string"), (r"(?:a?|b){2}c|.", "empty string"), (r"\p{Alphabetical}+|.", "a script or a binary property"), (r"[\P{Han}x]|.", "negated script"),
     (r"\p{scx=Han}|.", "a script or a binary property"), (r"(?i)\p{Lowercase}|.", "under (?i)"), (r"[[:alfa:]]|.", "unknown POSIX class"), (r"[a-z~~[b]]|.", "~~"), (r"[a-z&&[b&&[c]]]|.", "inside the operand"), (r"[a&&b]|.", "right side"), (r"(?U)a|.", "(?U)"),
     (r"[[:alpha]]|.", "malformed POSIX"), (r"(a|b", "unterminated group"), (r"a)|b", "unbalanced"),
     (r"x{3,2}|.", "out of order"), (r"a**|.", "quantifier behind"), (r"[z-a]|.", "out of order"), (r"(?=a)|.", "empty string"),
