@@ -227,13 +227,15 @@ def main():
         APART = True
         steps_with = steps_as_a_kernel_would
     classes = [(25, 32), (33, 48), (49, 64), (65, 128), (129, 256), (257, 1 << 30)]
+    if os.environ.get("SIM_SHORT"):  # the pieces of the one-lane merges instead
+        classes = [(2, 4), (5, 8), (9, 16), (17, 24)]
     acc = {K: {c: [0, 0] for c in classes} for K in KS}
     pieces = {c: 0 for c in classes}
     s, bad, seen = 0, 0, set()
     for e in C.split(text):
         p = text[s:e]
         s = e
-        if len(p) < 25 or p in V or p in seen:
+        if len(p) < classes[0][0] or len(p) > classes[-1][1] or p in V or p in seen:
             continue
         seen.add(p)
         c = next(c for c in classes if c[0] <= len(p) <= c[1])
