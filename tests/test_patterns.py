@@ -314,3 +314,34 @@ def test_pattern_parsers_under_the_sanitizers(tmp_path):
     assert cc.returncode == 0, cc.stderr[-2000:]
     run = subprocess.run([exe, R50K, CL100K, O200K], capture_output=True, text=True, timeout=900, env={**os.environ, "TK_SAN_ROUNDS": "8000"})
     assert run.returncode == 0 and run.stdout.startswith("ok 8000 "), (run.stdout[-300:], run.stderr[-3000:])
+
+
+@pytest.mark.parametrize("name,pat", VARIANTS, ids=[v[0] for v in VARIANTS])
+def test_mid_size_cuts_are_piece_starts_under_a_variation(name, pat):
+    """encode_mid (tk_api.hip) cuts a document of 2 .. 128 KiB at "ASCII letter, then space" whenever the PATTERN's table of certain starts says
+    that a space behind a letter always starts a piece -- for a custom pattern of the families that table is derived by tk_pattern.cpp.  The
+    premise, with Python `regex` on both sides: the pieces of the segments, one after the other, are the pieces of the document."""
+    sim = h.HostSim(pat, TINY, {})
+    rng = random.Random(len(name))
+    words = ["the", "of", "Lorem", "ipsum", "x", "I", "don't", "DON'T", "we'LL", "a's", "12", "3.14", "2024", "é", "中文", "naïve", "(see", "note)", "...", "!?", "#tag",
+             "a/b", "CamelCase", "ALLCAPS", "tail/", "end.\n", "x'", "'em", "'nt", "ǅ", "ʰ", "²", "ſ"]
+    seps = [" "] * 10 + ["\n", "\n\n", "  ", ", ", ". ", "\t", " \n", "\r\n", " - ", "   ", " \r", "/ ", "' "]
+    taken = 0
+    for _ in range(12):
+        parts, size, want = [], 0, rng.choice([2100, 3000, 6000, 20000])
+        while size < want:
+            w = rng.choice(words) + rng.choice(seps)
+            parts.append(w)
+            size += len(w.encode())
+        text = "".join(parts)
+        doc = text.encode()
+        cuts, why = sim.mid_plan(doc)
+        if cuts is None:
+            assert why in ("no cut in a window", "letter -> space is not a certain start of this pattern"), why
+            continue
+        taken += 1
+        whole = regex.findall(pat, text)
+        assert "".join(whole) == text
+        split = [p for a, b in zip(cuts, cuts[1:]) for p in regex.findall(pat, doc[a:b].decode())]
+        assert split == whole, (name, cuts)
+    assert taken >= 6, taken  # (every variation here keeps the rule: a blank behind a letter starts a piece)
