@@ -137,12 +137,29 @@ def one_process(args, torch):
     for _ in range(args.steps):
         dt, nt, do = core.encode_batch_gathered(blob, doc_off)
     el = time.perf_counter() - t0
+    # what device 0 holds after the gather against the oracle's encoding of the undivided batch (outside the timed region)
+    parity = None
+    if not args.no_cpu_baseline:
+        from oracle import c_oracle
+
+        pat_id = {"gpt2_shaped": 0, "cl100k_shaped": 1, "o200k_shaped": 2, "o200k_custom8": 2}[args.encoding]
+        C = c_oracle.COracle(pat_id, spec["mergeable_ranks"], spec["special_tokens"])
+        ctoks, coff = C.encode_batch(blob, doc_off, None, ncpu)
+        torch.cuda.set_device(devices[0])
+        nd_all = len(doc_off) - 1
+        g_off = torch.as_tensor(DevArray(do, nd_all + 1, "<i8"), device=f"cuda:{devices[0]}").cpu().numpy().astype(np.uint64)
+        g_tok = torch.as_tensor(DevArray(dt, max(nt, 1), "<i4"), device=f"cuda:{devices[0]}")[:nt].cpu().numpy().view(np.uint32)
+        parity = bool(np.array_equal(g_off, coff) and np.array_equal(g_tok, ctoks))
     print(json.dumps({"metric": "GB/s text encoded, one process driving N devices (host text in, ids gathered on device 0): PCIe-inclusive",
                       "value": round(base * args.steps / el / 1e9, 3), "unit": "GB/s", "n_gpus": n, "steps": args.steps, "warmup": args.warmup,
                       "ms_per_step": round(el / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "u8",
                       "data": "synthetic", "config": {"workload": f"{args.encoding}, {n} shards of {args.mib} MiB, tk_group_encode_batch_device",
                                                       "devices": devices, "tokens_total": int(nt),
-                                                      "gather": "rccl" if core.group_stat("gathers_rccl") else "peer copies"}}), flush=True)
+                                                      "gather": "rccl" if core.group_stat("gathers_rccl") else "peer copies"},
+                      "parity_all_tokens_vs_oracle": parity, "gather_verified": parity}), flush=True)
+    if parity is False:
+        print("bench: the gathered result differs from the oracle's", file=sys.stderr)
+        sys.exit(3)
 
 
 def generic_engine_figure(encoding: str, mib: int = 256):
@@ -195,6 +212,8 @@ def main():
     ap.add_argument("--encoding", default="o200k_shaped")
     ap.add_argument("--cpu-sample-mib", type=int, default=256)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--parity-sample-mib", type=int, default=0,
+                    help="N > 1: every rank compares the first this-many MiB of its shard with the oracle (0 = the whole shard, the default)")
     ap.add_argument("--no-host-path", action="store_true", help="skip the T2 / T3 host-boundary timings")
     ap.add_argument("--t3-sample-mib", type=int, default=64)
     ap.add_argument("--no-hf", action="store_true", help="skip the HF tokenizers context figure of the CPU baseline")
@@ -214,6 +233,12 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         print(f"warning: --gpus {args.gpus} but WORLD_SIZE={world}", file=sys.stderr)
+    # $TIKTOKEN_AMD_BENCH_BACKEND=gloo (a dry run of the N > 1 leg on a box with fewer GPUs than ranks: tools/gpu_bench_n2_dry.sh): the ranks
+    # share the devices there are, collectives and the gather go through host copies over gloo.  Never the driver's mode, said in the line.
+    backend = os.environ.get("TIKTOKEN_AMD_BENCH_BACKEND", "nccl")
+    if backend != "nccl":
+        local_rank %= max(torch.cuda.device_count(), 1)
+    cdev = "cuda" if backend == "nccl" else "cpu"  # where the collectives' tensors live
     torch.cuda.set_device(local_rank)
     dist = None
     if world > 1:
@@ -221,7 +246,10 @@ def main():
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        else:
+            dist.init_process_group(backend)
 
     import tiktoken_amd  # noqa: F401
     from tiktoken_amd.distributed import gather_tokens
@@ -253,6 +281,7 @@ def main():
     # result buffers (tk_set_output_buffers), so the ids are sent from where the encoder left them, without a copy; drain() waits for
     # the last transfer INSIDE the timed region.  `value` includes the gather; `value_encode_only` (below) is the same loop without it.
     pending = [None]
+    last_gather = [None]  # (per-rank tensors, counts) of the last completed gather (rank 0: what it RECEIVED)
     if world > 1:
         core.set_output_buffers(2)
 
@@ -263,23 +292,41 @@ def main():
         if world > 1 and gather:
             toks = torch.as_tensor(DevArray(dt, max(nt, 1), "<i4"), device="cuda")  # (a view of the library's buffer: valid until the call after the next)
             if pending[0] is not None:
-                pending[0].wait()
+                last_gather[0] = pending[0].wait()
                 torch.cuda.current_stream().synchronize()  # (wait() orders torch's stream only; the encoder runs on the library's: the buffer of step k - 1 is written again by step k + 1)
+            if backend != "nccl":
+                toks = toks[: max(nt, 1)].cpu()
             if gather_mode["form"] == "exact":
-                try:
-                    pending[0] = gather_tokens(toks, nt, rank, world, dist, torch, async_op=True)
-                except Exception as e:  # (a collective library that will not send from memory torch did not allocate: the earlier form, said in the line)
-                    print(f"bench: exact-length gather failed on rank {rank} ({type(e).__name__}: {str(e)[:120]}); padded gather of a copy from here on", file=sys.stderr)
-                    gather_mode["form"] = "padded (the exact-length exchange raised)"
-            if gather_mode["form"] != "exact":
+                pending[0] = gather_tokens(toks, nt, rank, world, dist, torch, async_op=True)
+            else:
                 pending[0] = gather_tokens(toks.clone(), nt, rank, world, dist, torch, async_op=True, padded=True)
         return dt, nt, do
 
     def drain():
         if pending[0] is not None:
-            pending[0].wait()
+            last_gather[0] = pending[0].wait()
             torch.cuda.current_stream().synchronize()
             pending[0] = None
+
+    if world > 1 and gather_mode["form"] == "exact":
+        # The form of the gather is agreed on by ALL ranks before anything is timed (a rank that fell back on its own would leave the
+        # others inside a collective it never joins): one untimed exact-length exchange of a small buffer torch did not allocate --
+        # the library's own result buffer, which is what a collective library may refuse -- then the failure flags are summed.
+        failed = 0
+        try:
+            dt0, nt0, _ = core.encode_batch_device(d_text.data_ptr(), nbytes, d_off.data_ptr(), doc_off, n_docs)
+            probe = torch.as_tensor(DevArray(dt0, max(nt0, 1), "<i4"), device="cuda")[: min(nt0, 1 << 16)]
+            if backend != "nccl":
+                probe = probe.cpu()
+            gather_tokens(probe, int(probe.numel()) if nt0 else 0, rank, world, dist, torch, async_op=True).wait()
+            torch.cuda.current_stream().synchronize()
+        except Exception as e:
+            print(f"bench: exact-length gather failed on rank {rank} ({type(e).__name__}: {str(e)[:120]})", file=sys.stderr)
+            failed = 1
+        flag = torch.tensor([failed], dtype=torch.int64, device=cdev)
+        dist.all_reduce(flag)
+        if int(flag.item()):
+            gather_mode["form"] = f"padded (the exact-length exchange raised on {int(flag.item())} rank(s))"
 
     for _ in range(args.warmup):
         step()
@@ -296,10 +343,10 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t0
     if dist:
-        tmax = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tmax = torch.tensor([elapsed], dtype=torch.float64, device=cdev)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         elapsed = float(tmax.item())
-        tot = torch.tensor([nbytes, nt], dtype=torch.int64, device="cuda")
+        tot = torch.tensor([nbytes, nt], dtype=torch.int64, device=cdev)
         dist.all_reduce(tot)
         total_bytes, total_tokens = int(tot[0].item()), int(tot[1].item())
     else:
@@ -307,6 +354,17 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = total_bytes * args.steps / elapsed / 1e9
     value_encode_only = None
+    # N > 1: the result of the last TIMED step -- this rank's ids and offsets, and on rank 0 what the gather delivered -- goes to host
+    # memory now, before further steps write the (alternating) result buffers again; compared further down, outside every timed region
+    own_result, gather_check = None, None
+    if dist and not args.no_cpu_baseline:
+        from tiktoken_amd.distributed import exchange_verdicts, ids_digest, verify_gathered
+
+        own_result = (torch.as_tensor(DevArray(dt, max(nt, 1), "<i4"), device="cuda")[: nt].cpu().numpy().view(np.uint32),
+                      torch.as_tensor(DevArray(do, n_docs + 1, "<i8"), device="cuda").cpu().numpy().astype(np.uint64))
+        if rank == 0 and last_gather[0] is not None and last_gather[0][0] is not None:
+            gather_check = [ids_digest(p.cpu().numpy()) for p in last_gather[0][0]]  # (count, digest) of what was RECEIVED, per rank
+        last_gather[0] = None
     if dist:  # the same K steps without the gather: what the encoders do when nobody collects the ids on one rank
         torch.cuda.synchronize()
         dist.barrier()
@@ -315,7 +373,7 @@ def main():
             step(gather=False)
         torch.cuda.synchronize()
         dist.barrier()
-        el2 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device="cuda")
+        el2 = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=cdev)
         dist.all_reduce(el2, op=dist.ReduceOp.MAX)
         value_encode_only = round(total_bytes * args.steps / float(el2.item()) / 1e9, 3)
 
@@ -364,6 +422,39 @@ def main():
     # ---- parity of the WHOLE result + CPU baseline (rank 0, N = 1 only)
     cpu = None
     parity = None
+    gather_verified = None
+    parity_detail = None
+    if dist and own_result is not None:
+        # Every rank compares ITS shard of the last timed step with the oracle (the host threads are shared between the ranks: ncpu / world
+        # each; the whole shard unless --parity-sample-mib bounds it, the token count and a digest of the full id stream either way), the
+        # verdicts travel in one all-gather, and rank 0 compares what it RECEIVED from each peer with what that peer says it sent.
+        from oracle import c_oracle
+
+        pat_id = {"gpt2_shaped": 0, "cl100k_shaped": 1, "o200k_shaped": 2, "o200k_custom8": 2}[args.encoding]
+        C = c_oracle.COracle(pat_id, spec["mergeable_ranks"], spec["special_tokens"])
+        g_toks, g_tok_off = own_result
+        want = nbytes if args.parity_sample_mib <= 0 else min(nbytes, args.parity_sample_mib << 20)
+        nd_s = n_docs if want >= nbytes else max(int(np.searchsorted(doc_off, want, side="right")) - 1, 1)
+        sb = int(doc_off[nd_s])
+        ctoks, coff = C.encode_batch(blob[:sb], doc_off[: nd_s + 1], None, max(1, ncpu // world))
+        ok = bool(np.array_equal(g_tok_off[: nd_s + 1], coff) and np.array_equal(g_toks[: int(coff[-1])], ctoks))
+        if not ok:
+            print(f"PARITY MISMATCH on rank {rank} (seed {seed:#x}, first {nd_s} documents)", file=sys.stderr)
+        cnt, dig = ids_digest(g_toks)
+        verdicts = exchange_verdicts(cnt, dig, ok, rank, world, dist, torch, device=cdev)
+        parity = bool(all(v[2] for v in verdicts))
+        if rank == 0:
+            parity_detail = {"documents_compared_on_rank0": nd_s, "bytes_compared_on_rank0": sb, "of_bytes": nbytes,
+                             "per_rank_ok": [v[2] for v in verdicts], "tokens_per_rank": [v[0] for v in verdicts]}
+            if gather_check is not None:
+                per = [{"rank": r, "tokens_sent": v[0], "tokens_received": g[0], "digest_equal": bool(g == (v[0], v[1]))}
+                       for r, (g, v) in enumerate(zip(gather_check, verdicts))]
+                gather_verified = bool(len(per) == world and all(x["digest_equal"] for x in per))
+                parity_detail["gather"] = per
+            else:
+                gather_verified = False
+        del ctoks, coff, g_toks, g_tok_off
+        own_result = None
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
         from oracle import c_oracle
 
@@ -528,15 +619,16 @@ def main():
                        "encoding": args.encoding, "pat_str_runs_on": "generic regex engine (--generic-engine)" if args.generic_engine else "hand-written scanners",
                        "bytes_per_gpu": nbytes, "docs_rank0": n_docs,
                        "tokens_total": total_tokens, "pieces_rank0": stats["pieces"],
-                       "parallelism": f"doc-sharded x{world}" + (f" + RCCL gather of token ids to rank 0 ({gather_mode['form']} lengths)" if world > 1 else "")},
-            "roofline": roofline, "cpu_baseline": cpu, "parity_all_tokens_vs_oracle": parity, "host_path": host_path,
+                       "parallelism": f"doc-sharded x{world}" + (f" + {'RCCL' if backend == 'nccl' else backend + ' (DRY RUN through host copies)'} gather of token ids to rank 0 ({gather_mode['form']} lengths)" if world > 1 else "")},
+            "roofline": roofline, "cpu_baseline": cpu, "parity_all_tokens_vs_oracle": parity, "gather_verified": gather_verified,
+            "parity_detail": parity_detail, "host_path": host_path,
             "lds_piece_cache": hot, "cold_start": cold, "generic_engine": generic, "configs": configs,
             "host": {"cpus": ncpu, "nproc": os.cpu_count(), "cgroup_cpu_max": _read_first("/sys/fs/cgroup/cpu.max"),
                      "loadavg": _read_first("/proc/loadavg"), "corpus_gen_s": round(t_gen, 2)},
         }
         print(json.dumps(line), flush=True)
         hf = (cpu or {}).get("rust_cpu_tokenizer_for_context") or {}
-        if parity is False or hf.get("same_ids_as_oracle_on_a_sample_of_documents") is False or \
+        if parity is False or gather_verified is False or hf.get("same_ids_as_oracle_on_a_sample_of_documents") is False or \
                 (host_path or {}).get("t2_identical_to_checked_result") is False or (host_path or {}).get("decode_identical_to_the_text") is False or \
                 (host_path or {}).get("decode_device_identical_to_the_text") is False or \
                 (generic or {}).get("all_tokens_equal_to_the_oracle") is False or \

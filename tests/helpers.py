@@ -134,6 +134,9 @@ def baseline_config(cfg: str, threads: int = 16):
     if cfg == "C3":
         blob, off = gen_corpus(0x5EED0003, 1, 1 << 30, threads)
         return "o200k_shaped", 2, SPECIALS["o200k_shaped"], blob, off, None
+    if cfg.startswith("C4r"):  # C4: 8 GiB doc-sharded over 8 GPUs = rank r's 1 GiB shard, the seeds bench.py --gpus N uses (0x5EED0004 + rank)
+        blob, off = gen_corpus(0x5EED0004 + int(cfg[3:]), 1, 1 << 30, threads)
+        return "o200k_shaped", 2, SPECIALS["o200k_shaped"], blob, off, None
     if cfg == "C5":
         blob, off = insert_specials(*gen_corpus(0x5EED0005, 1, 256 << 20, threads))
         return "o200k_shaped", 2, CUSTOM8, blob, off, "all"

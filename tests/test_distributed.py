@@ -15,7 +15,7 @@ import torch.distributed as dist
 import torch.multiprocessing as mp
 
 import helpers as h
-from tiktoken_amd.distributed import encode_ordinary_batch_sharded, gather_tokens, partition_by_bytes
+from tiktoken_amd.distributed import encode_ordinary_batch_sharded, exchange_verdicts, gather_tokens, ids_digest, partition_by_bytes, verify_gathered
 
 
 def _free_port():
@@ -56,6 +56,24 @@ def _worker(rank, world, port, q):
             q.put(bool(np.array_equal(np.concatenate(per_rank), rt)))
         else:
             assert all(g[0] is None for g in got)
+        # what bench.py --gpus N does after its timed region: every rank checks its OWN shard against the oracle and digests its id
+        # stream, the verdicts travel in one all-gather, and the destination compares what it RECEIVED per peer with what was sent
+        lo, hi = int(mine_off[0]), int(mine_off[-1])
+        own, _ = C.encode_batch(blob[lo:hi], (mine_off - mine_off[0]).astype(np.uint64), None, 1)
+        ref, _ = C.encode_batch(blob[lo:hi], (mine_off - mine_off[0]).astype(np.uint64), None, 1)
+        cnt, dig = ids_digest(own)
+        verdicts = exchange_verdicts(cnt, dig, bool(np.array_equal(own, ref)), rank, world, dist, torch)
+        assert verdicts[rank] == (cnt, dig, True) and all(v[2] for v in verdicts)
+        parts, counts = gather_tokens(torch.from_numpy(np.ascontiguousarray(own).view(np.int32).copy()), len(own), rank, world, dist, torch)
+        if rank == 0:
+            good = verify_gathered(parts, verdicts)
+            # ... and a gather that went wrong is seen: one peer's ids delivered twice, a flipped id, a dropped tail
+            twice = verify_gathered([parts[0]] * world, verdicts)
+            flipped = [p.clone() for p in parts]
+            flipped[-1][len(flipped[-1]) // 2] ^= 1
+            short = list(parts[:-1]) + [parts[-1][:-1]]
+            q.put(bool(good["gather_verified"] and counts == [v[0] for v in verdicts] and not twice["gather_verified"]
+                       and not verify_gathered(flipped, verdicts)["gather_verified"] and not verify_gathered(short, verdicts)["gather_verified"]))
         # a rank without tokens; the padded form
         for padded in (False, True):
             t = torch.arange(5 if rank == 0 else 0, dtype=torch.int32) + 100 * rank
@@ -78,7 +96,7 @@ def test_two_rank_gloo_shard_and_gather():
     procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
     for p in procs:
         p.start()
-    ok = all(q.get(timeout=150) for _ in range(4))  # plain and pipelined exchange; exact-length and padded form with uneven counts
+    ok = all(q.get(timeout=150) for _ in range(5))  # plain and pipelined exchange; the digest exchange; exact-length and padded form with uneven counts
     for p in procs:
         p.join(60)
         assert p.exitcode == 0

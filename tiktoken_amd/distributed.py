@@ -101,3 +101,44 @@ def encode_ordinary_batch_sharded(encode_packed, blob: np.ndarray, doc_off: np.n
     tok_off = np.zeros(len(all_counts) + 1, np.uint64)
     np.cumsum(all_counts, out=tok_off[1:])
     return all_toks, tok_off
+
+
+def ids_digest(ids) -> tuple[int, int]:
+    """(count, 64-bit digest) of a flat id stream (any integer array of 4-byte items; the bytes are what is hashed).
+    xxhash64 when the package is there (SURVEY.md 8(d) names it for 1 GB+ comparisons), else blake2b truncated to 8 bytes --
+    every rank of a job runs the same interpreter, so the two sides of a comparison always use the same function."""
+    a = np.ascontiguousarray(np.asarray(ids)).view(np.uint8)
+    try:
+        import xxhash
+
+        return int(a.size // 4), int(xxhash.xxh64(memoryview(a)).intdigest())
+    except ImportError:  # pragma: no cover
+        import hashlib
+
+        return int(a.size // 4), int.from_bytes(hashlib.blake2b(memoryview(a), digest_size=8).digest(), "little")
+
+
+def exchange_verdicts(n_tokens: int, digest: int, ok: bool, rank: int, world: int, dist, torch, device="cpu"):
+    """Every rank tells every rank (count, digest of its own id stream, did its own shard equal the oracle's): one all-gather of
+    four int64 per rank.  Returns [(count, digest, ok)] in rank order."""
+    mine = torch.tensor([n_tokens, digest & 0xFFFFFFFF, digest >> 32, 1 if ok else 0], dtype=torch.int64, device=device)
+    parts = [torch.zeros(4, dtype=torch.int64, device=device) for _ in range(world)]
+    dist.all_gather(parts, mine)
+    out = []
+    for p in parts:
+        c, lo, hi, k = (int(x) for x in p.cpu().tolist())
+        out.append((c, (hi << 32) | lo, bool(k)))
+    return out
+
+
+def verify_gathered(parts, verdicts) -> dict:
+    """On the destination rank: what was RECEIVED per peer (`parts`: the per-rank tensors / arrays a gather returned, rank order) against
+    what the ranks say they sent (`verdicts`: exchange_verdicts()).  A gather that delivered one rank's ids twice, dropped a tail or
+    mixed two buffers fails here; the ranks' own comparisons with the oracle make the received ids the oracle's by transitivity.
+    Returns {"gather_verified": bool, "per_rank": [...]}."""
+    per = []
+    for r, (p, (cnt, dig, ok)) in enumerate(zip(parts, verdicts)):
+        a = p.cpu().numpy() if hasattr(p, "cpu") else np.asarray(p)
+        c, d = ids_digest(a)
+        per.append({"rank": r, "tokens_sent": cnt, "tokens_received": c, "digest_equal": bool(c == cnt and d == dig), "shard_equal_to_oracle": ok})
+    return {"gather_verified": bool(len(per) == len(verdicts) and all(x["digest_equal"] for x in per)), "per_rank": per}
