@@ -250,6 +250,8 @@ def sim_lib():
         L.tks_table_stats.argtypes = [vp, vp, vp]
         L.tks_lookup.restype = ctypes.c_uint32
         L.tks_lookup.argtypes = [vp, vp, ctypes.c_uint32]
+        L.tks_lookup_xl.restype = ctypes.c_uint32
+        L.tks_lookup_xl.argtypes = [vp, vp, ctypes.c_uint32, ctypes.c_uint8, vp]
         L.tks_chunk_check.restype = u64
         L.tks_chunk_check.argtypes = [vp, vp, u64, vp, u64, vp, vp, ctypes.c_uint32, ctypes.c_uint32, ctypes.c_uint32, vp, vp]
         L.tks_encode_piece.restype = ctypes.c_int64
@@ -292,6 +294,13 @@ class HostSim:
     def lookup(self, piece: bytes) -> int:
         b = np.frombuffer(piece, np.uint8) if piece else np.zeros(1, np.uint8)
         return sim_lib().tks_lookup(self._h, b.ctypes.data, len(piece))
+
+    def lookup_xl(self, piece: bytes, fill: int = 0):
+        """(rank or 0xFFFFFFFF, (w0, w1, w2, hash)) of the front kernel's identity lookup (pieces of 9..23 bytes; longer ones: identity only)."""
+        b = np.frombuffer(piece, np.uint8) if piece else np.zeros(1, np.uint8)
+        ident = np.zeros(4, np.uint64)
+        r = sim_lib().tks_lookup_xl(self._h, b.ctypes.data, len(piece), fill, ident.ctypes.data)
+        return r, tuple(int(x) for x in ident)
 
     def mid_plan(self, doc: bytes):
         """encode_mid's cuts for one document (tk_mid_plan.h): ([0, c1, ..., n], "") or (None, reason)."""

@@ -97,6 +97,8 @@ void* tks_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uin
     D.piece = H.piece.data();
     D.piece_off = H.piece_off.data();
     D.piece_mask = H.piece_mask;
+    D.xl = H.xl.data();
+    D.xl_mask = H.xl_mask;
     D.max_token_len = H.max_token_len;
     D.tok_bytes = H.tok_bytes.data();
     D.pair = H.pair8.empty() ? H.pair.data() : nullptr;
@@ -128,6 +130,7 @@ uint64_t tks_tables_digest(void* p) {
     for (const TkPieceSlot& e : H.mid_tab) { mix(&e.key, 8); mix(&e.rank, 4); mix(&e.len, 4); }
     for (const TkPieceSlot& e : H.piece) { mix(&e.key, 8); mix(&e.rank, 4); mix(&e.len, 4); }
     mix(H.piece_off.data(), H.piece_off.size() * 4);
+    for (const TkXlSlot& e : H.xl) { mix(&e.w0, 8); mix(&e.w1, 8); mix(&e.w2, 8); mix(&e.rank, 4); }
     mix(H.pair8.data(), H.pair8.size() * 8);
     for (const TkPairSlot& e : H.pair) { mix(&e.key, 8); mix(&e.rank, 4); }
     mix(H.pair2.data(), H.pair2.size() * 4);
@@ -149,6 +152,21 @@ uint32_t tks_lookup(void* p, const uint8_t* piece, uint32_t len) {
     std::vector<uint8_t> text(piece, piece + len);
     text.resize(len + 64, 0);
     return tk_lookup_text_piece(s->T, text.data(), 0, len);
+}
+
+// The front kernel's lookup of a piece of TK_XL_MIN..TK_XL_MAX bytes: its identity (tk_ident, from eight-byte loads of a text in which
+// `fill` bytes FOLLOW the piece -- whatever stands there must not matter), then the identity table.  Also returns the identity and its hash.
+uint32_t tks_lookup_xl(void* p, const uint8_t* piece, uint32_t len, uint8_t fill, uint64_t* ident4) {
+    Sim* s = (Sim*)p;
+    std::vector<uint8_t> text(piece, piece + len);
+    text.resize(len + 64, fill);
+    uint64_t w0, w1, w2;
+    tk_ident([&](uint32_t o) { return tk_load8(text.data(), o); }, len, 0u, w0, w1, w2);
+    if (ident4) {
+        ident4[0] = w0; ident4[1] = w1; ident4[2] = w2; ident4[3] = tk_ident_hash(w0, w1, w2, len <= TK_XL_MAX);
+    }
+    if (len < TK_XL_MIN || len > TK_XL_MAX) return TK_RANK_MAX;
+    return tk_probe_xl(s->T, w0, w1, w2);
 }
 
 // Mirror of the byte-walking scanner (the fallback of tk_k_front): class bytes, certain starts, scanner from each certain start.

@@ -148,6 +148,52 @@ def test_piece_encode_sim_on_golden_pieces(sims, name):
         assert got == c["tokens"], c["name"]
 
 
+@pytest.mark.parametrize("name", ["o200k_shaped", "cl100k_shaped"])
+def test_identity_lookup_of_long_pieces_is_exact(sims, name):
+    """The front kernel looks pieces of 9..23 bytes up by their IDENTITY (tk_common.h tk_ident: the bytes themselves in three words) in a
+    table of 32-byte slots, and keys its in-call table of pieces that are not tokens by the same identity: (i) every vocabulary token of
+    those lengths is found with its rank, whatever bytes follow it in the text; (ii) strings that are not tokens -- tokens with a byte
+    changed, cut short, extended, random bytes -- are not found; (iii) the identity is injective: different byte strings of up to 23 bytes
+    never share one, equal strings always do (which is what makes a duplicate in the in-call table a duplicate); (iv) a longer piece's
+    identity carries its length and its first and last eight bytes."""
+    sim, ranks = sims[name], h.load_vocab(name)
+    rng = np.random.default_rng(5)
+    toks = [t for t in ranks if 9 <= len(t) <= 23]
+    assert len(toks) > 1000
+    pick = [toks[i] for i in rng.choice(len(toks), size=min(len(toks), 6000), replace=False)]
+    seen = {}
+    for t in pick:
+        r0, id0 = sim.lookup_xl(t, 0)
+        r1, id1 = sim.lookup_xl(t, 0xFF)
+        r2, id2 = sim.lookup_xl(t, 0x41)
+        assert r0 == r1 == r2 == ranks[t] and id0 == id1 == id2, t
+        assert seen.setdefault(id0[:3], t) == t
+    n_absent = 0
+    for t in pick[:3000]:
+        for v in (t[:-1] + bytes([t[-1] ^ 1]), bytes([t[0] ^ 0x20]) + t[1:], t[:-1], t + b"x", t[: len(t) // 2] + b"\x00" + t[len(t) // 2 + 1:], bytes(rng.integers(0, 256, len(t), dtype=np.uint8))):
+            if not 9 <= len(v) <= 23:
+                continue
+            r, idv = sim.lookup_xl(v, int(rng.integers(0, 256)))
+            assert r == ranks.get(v, 0xFFFFFFFF), v
+            assert seen.setdefault(idv[:3], v) == v  # (injective: an identity seen before belongs to these very bytes)
+            n_absent += v not in ranks
+    assert n_absent > 5000
+    # every length 1..23: identities of different strings differ, a zero byte at the end or in the middle is not padding
+    for L in range(1, 24):
+        base = bytes(rng.integers(1, 256, L, dtype=np.uint8))
+        ids = {}
+        for v in {base, base[:-1] + b"\x00", b"\x00" + base[1:], base[: L // 2] + b"\x00" + base[L // 2 + 1:], base[:-1], base + b"\x00"}:
+            if 1 <= len(v) <= 23:
+                _, idv = sim.lookup_xl(v, 0xA5)
+                assert ids.setdefault(idv[:3], v) == v
+                assert idv[2] >> 56 == len(v)
+    for L in (24, 25, 31, 32, 33, 100, 1024):
+        v = bytes(rng.integers(0, 256, L, dtype=np.uint8))
+        r, idv = sim.lookup_xl(v, 7)
+        assert r == 0xFFFFFFFF and idv[0] == int.from_bytes(v[:8], "little") and idv[1] == int.from_bytes(v[-8:], "little")
+        assert idv[2] >> 63 == 1 and (idv[2] >> 32) & 0x7FFFFFFF == L
+
+
 def test_pair_table_is_exactly_the_set_of_token_splits():
     """(id_a, id_b) -> id_ab must exist iff bytes(a)+bytes(b) is a vocabulary key (tk_common.h)."""
     ranks = h.load_vocab("gpt2_shaped")

@@ -114,7 +114,7 @@ struct tk_core {
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
     TkHostTables H;
     TkTables D;  // device view
-    Buf t_stage1, t_stage2, t_byte_tab, t_short, t_mid, t_dec, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_hot, t_spec_bytes, t_spec_off, t_spec_id;
+    Buf t_stage1, t_stage2, t_byte_tab, t_short, t_mid, t_dec, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_xl, t_spec_bytes, t_spec_off, t_spec_id;
     uint32_t spec_max_len = 0;
     bool has_rx = false;  // the pat_str runs on the generic engine (tk_regex_kernels.h)
     bool has_rx_fb = false;  // a pat_str of the scanner families, compiled for the generic engine as well: the way out of stretches without certain starts (stage_deferred)
@@ -183,7 +183,7 @@ struct tk_core {
     std::map<std::string, KernelStat> stats;
     std::vector<std::pair<std::string, std::pair<hipEvent_t, hipEvent_t>>> pending;
     uint64_t st_bytes = 0, st_pieces = 0, st_tokens = 0, st_docs = 0, st_medium = 0, st_long = 0;
-    uint64_t st_hot_probes = 0, st_hot_hits = 0, st_chunks = 0;
+    uint64_t st_chunks = 0;
     double host_us[6] = {0, 0, 0, 0, 0, 0};  // host time of the last call: front stages, back stages (of which: waiting for the front kernel), finish waits, total
 };
 
@@ -409,7 +409,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
                      H.pair8.empty() ? H.pair.size() * sizeof(TkPairSlot) : H.pair8.size() * 8))) return bail(rc);
     if ((rc = upload(c->t_pair2, H.pair2.data(), H.pair2.size() * 4))) return bail(rc);
     if ((rc = upload(c->t_byte_rank, H.byte_rank, sizeof H.byte_rank))) return bail(rc);
-    if (!H.hot.empty() && (rc = upload(c->t_hot, H.hot.data(), H.hot.size() * 4))) return bail(rc);
+    if ((rc = upload(c->t_xl, H.xl.data(), H.xl.size() * sizeof(TkXlSlot)))) return bail(rc);
     if ((rc = upload(c->t_spec_bytes, H.spec_bytes.data(), H.spec_bytes.size()))) return bail(rc);
     if ((rc = upload(c->t_spec_off, H.spec_off.data(), H.spec_off.size() * 4))) return bail(rc);
     if ((rc = upload(c->t_spec_id, H.spec_id.data(), H.spec_id.size() * 4))) return bail(rc);
@@ -433,7 +433,8 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     D.pair_mask = H.pair_mask;
     D.pair2 = c->t_pair2.as<uint32_t>();
     D.byte_rank = c->t_byte_rank.as<uint32_t>();
-    D.hot = H.hot.empty() ? nullptr : c->t_hot.as<uint32_t>();
+    D.xl = c->t_xl.as<TkXlSlot>();
+    D.xl_mask = H.xl_mask;
     D.spec_bytes = c->t_spec_bytes.as<uint8_t>();
     D.spec_off = c->t_spec_off.as<uint32_t>();
     D.spec_id = c->t_spec_id.as<uint32_t>();
@@ -502,7 +503,7 @@ extern "C" void tk_destroy(tk_core* c) {
     (void)hipSetDevice(c->device);
     for (Buf* b : {&c->t_rx_ins, &c->t_rx_sets, &c->t_rx_ranges, &c->t_rx_first, &c->t_rx_s1, &c->t_rx_s2, &c->t_rx_dtrans, &c->t_rx_dascii, &c->t_rx_ds1, &c->t_rx_ds2}) release(*b);
     for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_dec, &c->d_tok, &c->d_lens, &c->d_bsum, &c->d_tboff, &c->d_bytes, &c->d_bytes_alt, &c->d_boff, &c->t_piece,
-                   &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2, &c->t_byte_rank, &c->t_hot, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off,
+                   &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2, &c->t_byte_rank, &c->t_xl, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off,
                    &c->out_tokens, &c->out_tok_off, &c->out_tokens_alt, &c->out_tok_off_alt, &c->allowed, &c->tok_bases})
         release(*b);
     if (c->h_probe) (void)hipHostFree(c->h_probe);
@@ -737,7 +738,10 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
     // (small chunks too: without the table every missed piece has an overflow entry, whose tokens tk_k_place copies from the staging area two
     // pieces at a time -- 92 us for a 4 KiB call, against 4 us for clearing 16 Ki keys)
     if (n >= 512 && !single_piece && !pretok_only) {
-        while (job.mt_bits < TK_MT_BITS && (1ull << job.mt_bits) < n / 128) ++job.mt_bits;  // 4 Mi slots from 512 MiB up
+#ifndef TK_MT_DIV
+#define TK_MT_DIV 128
+#endif
+        while (job.mt_bits < TK_MT_BITS && (1ull << job.mt_bits) < n / TK_MT_DIV) ++job.mt_bits;  // 4 Mi slots from 512 MiB up
         job.ovf_base = 1u << job.mt_bits;
     }
     {
@@ -820,9 +824,7 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
         uint32_t* deferred = w.deferred.as<uint32_t>();
         TkMissKey* mt_arg = (c->dbg & 256) ? (TkMissKey*)nullptr : job.mt;
         TRY(timed(c, s, "tk_k_front", [&] {
-            // (only the variant with the LDS piece cache, TKF_HOT_BITS > 0, which keeps the cache over all the tiles a workgroup walks)
-            const uint64_t resident = TKF_HOT_BITS ? (uint64_t)c->n_cu * c->front_wgs : ntiles;
-            const dim3 grid((uint32_t)(ntiles < resident ? ntiles : resident));
+            const dim3 grid((uint32_t)ntiles);
             launch_front<false>(T.pat.generic() ? TK_PAT_GENERIC : T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, fo,
                                 mt_arg, (1u << job.mt_bits) - 1u, deferred, c->has_rx ? w.rx_gst.as<uint32_t>() + nwords + 2 : (const uint32_t*)nullptr,
                                 c->dbg | (pretok_only ? 8 : 0) | ((c->has_rx && !(c->dbg & 4)) ? TKF_DBG_HARD_ONLY : 0));  // (debug bit 4: the scanners run even so)
@@ -876,6 +878,19 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
     const unsigned long long* tok_base = c->tok_bases.as<unsigned long long>() + job.index;
     uint64_t nC = 0;
     TRY(stage_deferred(c, w, job, s));
+    // (perf experiments, tools/gpu_phases.sh: debug bits 0x1000 .. 0x10000 stop the front kernel after one of its phases -- its outputs are
+    // incomplete, so nothing behind it runs: the call returns zero tokens and offsets that mean nothing)
+    const bool front_only = (c->dbg & 0x1F000) != 0;
+    if (front_only) {
+        HIPCHK(hipMemsetAsync(w.total.p, 0, 32, s));
+        if (prev_tot) HIPCHK(hipStreamWaitEvent(s, prev_tot, 0));
+        hipLaunchKernelGGL(tk_k_advance, dim3(1), dim3(64), 0, s, c->tok_bases.as<unsigned long long>(), job.index, w.total.as<uint64_t>());
+        HIPCHK(hipEventRecord(w.ev_tot, s));
+        HIPCHK(hipMemcpyAsync(w.h_total, w.total.p, 16, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipMemcpyAsync(w.h_counters + TK_CNT_N, counters, TK_CNT_N * 4, hipMemcpyDeviceToHost, s));
+        HIPCHK(hipEventRecord(w.ev_done, s));
+        return TK_OK;
+    }
     if (n > 0) {
         uint32_t* wbin = w.wbin.as<uint32_t>();
         uint32_t* listB = w.listB.as<uint32_t>();
@@ -884,11 +899,11 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
         const uint64_t n_entries = (uint64_t)job.ovf_base + job.ovf_cap;
         const uint32_t dd_blocks = grid_for(n_entries, 4 * 256, TKD_WAVES / 4);
         TRY(timed(c, s, "tk_k_bincount", [&] {
-            hipLaunchKernelGGL(tk_k_bincount, dim3(dd_blocks), dim3(256), 0, s, data, job.mt, job.ovf_cap, counters, wbin);
+            hipLaunchKernelGGL(tk_k_bincount, dim3(dd_blocks), dim3(256), 0, s, T, d_text, data, job.mt, job.ovf_cap, counters, wbin);
         }));
         TRY(scan_u32(c, w, s, wbin, (uint64_t)TK_NBIN * dd_blocks * 4 + 1, w.total.as<uint64_t>()));
         TRY(timed(c, s, "tk_k_binfill", [&] {
-            hipLaunchKernelGGL(tk_k_binfill, dim3(dd_blocks), dim3(256), 0, s, data, job.mt, job.ovf_cap, wbin, listB, counters);
+            hipLaunchKernelGGL(tk_k_binfill, dim3(dd_blocks), dim3(256), 0, s, T, d_text, data, job.mt, job.ovf_cap, wbin, listB, counters);
         }));
         if (T.pair8 && !(c->dbg & 0x800000)) {
             // every bin in one launch (tk_k_merge_all); debug bit 0x800000: the kernel-per-bin form below
@@ -1043,8 +1058,6 @@ static int chunk_finish(tk_core* c, WorkSet& w, const ChunkJob& job, uint64_t* n
     c->st_pieces += w.h_total[1];
     c->st_tokens += w.h_total[0];
     c->st_medium += nB;
-    c->st_hot_probes += hb[TK_CNT_HOT_PROBE];
-    c->st_hot_hits += hb[TK_CNT_HOT_HIT];
     c->st_chunks += 1;
     *n_tokens_out = w.h_total[0];
     return TK_OK;
@@ -1156,7 +1169,7 @@ static int encode_device_pass(tk_core* c, hipStream_t s, const uint8_t* d_utf8, 
                               const uint64_t* h_doc_off, uint64_t n_docs, bool use_special, uint64_t* n_tokens_out,
                               uint64_t chunk_bytes, const ChunkHooks* hooks) {
     if (!chunk_bytes) chunk_bytes = c->chunk_bytes;
-    c->st_bytes = c->st_pieces = c->st_tokens = c->st_medium = c->st_long = c->st_hot_probes = c->st_hot_hits = c->st_chunks = 0;
+    c->st_bytes = c->st_pieces = c->st_tokens = c->st_medium = c->st_long = c->st_chunks = 0;
     c->st_docs = n_docs;
     TRY(ensure(c->out_tokens, (n_bytes + 64) * 4));  // (a token is at least one byte of text)
     TRY(ensure(c->out_tok_off, (n_docs + 2) * 8));
@@ -2499,10 +2512,6 @@ extern "C" void tk_last_stats(tk_core* c, uint64_t* n_bytes, uint64_t* n_pieces,
 extern "C" uint64_t tk_stat(tk_core* c, const char* name) {
     if (!c || !name) return 0;
     const std::string k(name);
-    if (k == "hot_probes") return c->st_hot_probes;
-    if (k == "hot_hits") return c->st_hot_hits;
-    if (k == "hot_slots") return TKF_HOT_BITS ? TKF_HOT_SLOTS : 0;
-    if (k == "hot_seed") return c->H.n_hot;
     if (k == "front_wgs_per_cu") return c->front_wgs;
     if (k == "compute_units") return c->n_cu;
     if (k == "chunks") return c->st_chunks;

@@ -71,6 +71,18 @@ struct TkShortSlot {  // 8 bytes
 };
 #define TK_SHORT_EMPTY 0xFFFFFFFFu
 #define TK_SHORT_MAX_RANK 0x3FFFFFFFu  // larger ranks: no short table, pieces of <= 4 bytes live in the mid table
+// Pieces of 9..23 bytes -- a fifth of the pieces of web text, and three in five of them are NOT tokens -- are looked up by their IDENTITY:
+// three words that hold the bytes themselves and the length (tk_ident), so that a slot answers exactly without a look at the token blob
+// (the 16-byte slots of `piece` hold a hash; their candidates are verified in the blob: a chain of dependent loads, and a hash over all
+// the bytes first).  The front kernel's in-call table of the pieces that are not tokens is keyed by the same identity (tk_fused.h,
+// TkMissKey): one identity, one hash, both slots fetched together.
+#define TK_XL_MIN 9u
+#define TK_XL_MAX 23u
+struct alignas(16) TkXlSlot {  // 32 bytes
+    uint64_t w0, w1, w2;  // tk_ident of the token's bytes (w2's top byte is the length)
+    uint32_t rank;        // TK_RANK_MAX = empty
+    uint32_t pad;
+};
 struct TkPairSlot {  // 16 bytes
     uint64_t key;    // (id_left << 32) | id_right; ~0 = empty
     uint32_t rank;
@@ -142,36 +154,9 @@ struct TkTables {
     TkPat pat;               // the pattern itself
     uint16_t cert[16];       // certain piece starts: cert[a] = classes that always start a piece after a char of class a
                              // (the family's table for the stock patterns; derived per pattern otherwise: tk_pattern.cpp)
-    const uint32_t* hot;     // [TKF_HOT_SLOTS * 4] seed of the front kernel's LDS piece cache (below); null: the cache starts empty
+    const struct TkXlSlot* xl;  // [xl_mask+1] tokens of TK_XL_MIN..TK_XL_MAX bytes once more, 32-byte slots that hold the bytes (below)
+    uint32_t xl_mask;
 };
-
-// ------------------------------------------------------------------------------------------
-// The LDS-resident piece cache of the front kernel: an open-addressed (direct-mapped) hash bytes -> rank in the workgroup's LDS, the
-// device form of the reference's "encoder map as a cache" (src/lib.rs:245-260, 367-368).  A workgroup is persistent (it walks over
-// a few hundred tiles), loads the seed -- the lowest-ranked tokens of up to TK_HOT_MAXLEN bytes, placed at tk_create -- once, and
-// then keeps the table current with the pieces its text actually uses: every piece that had to go to the vocabulary tables in HBM
-// replaces the entry of its slot, and so does a piece that is NOT a token once it has its slot of the in-call miss table (its later
-// occurrences in the workgroup's tiles are then duplicates without a probe).  Keys are the piece's bytes, zero padded, plus its
-// length: a hit is an exact match, never a fingerprint.
-//   entry (16 bytes): k0 k1 k2 = the bytes, little-endian; w = len << 28 | payload:
-//     payload bit 27 clear: the token id (ids of 2^27 and above are not cached);
-//     payload bit 27 set  : TK_RES_DUP reference to miss-table slot payload & 0x7FFFFFF (valid for this launch only: the cache dies with it);
-//     len 0 = empty, len 15 = entry being replaced (never equal to a piece's length).
-// ------------------------------------------------------------------------------------------
-#ifndef TKF_HOT_BITS
-#define TKF_HOT_BITS 0  // log2 of the slots per workgroup (10: 16 KiB of LDS); 0 compiles the cache out -- the default, see tk_fused.h
-#endif
-#define TKF_HOT_SLOTS (1u << TKF_HOT_BITS)
-#define TK_HOT_MAXLEN 12u
-#define TK_HOT_DUP (1u << 27)
-#define TK_HOT_PAYLOAD 0x0FFFFFFFu
-#define TK_HOT_LOCK 0xF0000000u
-TK_HD uint32_t tk_hot_slot(uint32_t k0, uint32_t k1, uint32_t k2) {
-    uint32_t h = k0 * 0x9E3779B1u + k1 * 0x85EBCA77u + k2 * 0xC2B2AE3Du;
-    h ^= h >> 15;
-    h *= 0x27D4EB2Fu;
-    return TKF_HOT_BITS ? h >> (32 - (TKF_HOT_BITS ? TKF_HOT_BITS : 1)) : 0u;
-}
 
 TK_HD uint64_t tk_mix64(uint64_t x) {
     x ^= x >> 32;
@@ -211,6 +196,41 @@ TK_HD uint64_t tk_pair_slot_hash(uint64_t key) {
     x *= 0x297A2D39u;
     x ^= x >> 15;
     return x;
+}
+
+// ---- identity of a piece (the front kernel's exact keys: TkXlSlot, TkMissKey) ----
+// the low clamp(r, 0, 8) bytes of x, left-aligned (r <= 0: nothing; r >= 8: x)
+TK_HD uint64_t tk_keep_bytes(uint64_t x, int r) {
+    const uint32_t t4 = 4u * (8u - (uint32_t)(r < 0 ? 0 : (r > 8 ? 8 : r)));
+    return (x << t4) << t4;
+}
+// Identity of the piece of `len` bytes whose eight bytes at offset o are ld8(o) (bytes behind the piece may be anything; ld8(16) is
+// called for pieces of at most TK_XL_MAX bytes only).  Up to TK_XL_MAX bytes the identity IS the piece: w0, w1 = bytes 0..15, w2 = bytes
+// 16..22 below the length in the top byte (each word's bytes left-aligned, the rest zero).  Longer pieces: the first and the last eight
+// bytes, and 1 << 63 | length << 32 | `where` (the piece's place in the text, for whoever has to compare the rest).
+template <class Ld8>
+TK_HD void tk_ident(Ld8&& ld8, uint32_t len, uint32_t where, uint64_t& w0, uint64_t& w1, uint64_t& w2) {
+    const bool exact = len <= TK_XL_MAX;
+    const uint64_t x0 = ld8(0u), x1 = ld8(exact ? 8u : len - 8u);
+    w0 = tk_keep_bytes(x0, (int)len);
+    w1 = exact ? tk_keep_bytes(x1, (int)len - 8) : x1;
+    w2 = (1ull << 63) | ((uint64_t)len << 32) | where;
+    if (exact) w2 = (tk_keep_bytes(ld8(16u), (int)len - 16) >> 8) | ((uint64_t)len << 56);
+}
+// two 32-bit hashes of an identity (equal identities are compared word for word anyway): the low word selects the slot of the
+// vocabulary's table (TkTables::xl), both the slot of the in-call table
+TK_HD uint64_t tk_ident_hash(uint64_t w0, uint64_t w1, uint64_t w2, bool exact) {
+    const uint32_t a = (uint32_t)w0, b = (uint32_t)(w0 >> 32), c = (uint32_t)w1, d = (uint32_t)(w1 >> 32);
+    const uint32_t e = exact ? (uint32_t)w2 : 0u, f = (uint32_t)(w2 >> 32);  // (where a long piece stands is not part of what it is)
+    uint32_t h1 = a * 0x9E3779B1u + b * 0x85EBCA77u + c * 0xC2B2AE3Du + d * 0x27D4EB2Fu + e * 0x165667B1u + f * 0xD3A2646Du;
+    h1 ^= h1 >> 15;
+    h1 *= 0x2C1B3C6Du;
+    h1 ^= h1 >> 12;
+    uint32_t h2 = (a ^ 0x5BD1E995u) * 0x7FEB352Du + (b + d) * 0x846CA68Bu + (c ^ f) * 0xFD7046C5u + (e + ((a >> 19) | (a << 13))) * 0xB55A4F09u;
+    h2 ^= h2 >> 13;
+    h2 *= 0x9E3779B1u;
+    h2 ^= h2 >> 16;
+    return ((uint64_t)h2 << 32) | h1;
 }
 
 // streaming hash for keys longer than 8 bytes: fold 8-byte little-endian words (last one zero padded)

@@ -783,6 +783,21 @@ TK_HD uint32_t tk_probe_piece(const TkTables& T, uint64_t key, uint32_t len, Ver
     return tk_probe_piece_from(T, key, len, i, T.piece[i], verify);
 }
 
+// Tokens of TK_XL_MIN..TK_XL_MAX bytes by identity (tk_common.h, tk_ident): the slot holds the bytes, a match is exact.  `s` = slot i,
+// which the caller has loaded (together with whatever else it needs: one memory round trip).
+TK_HD uint32_t tk_probe_xl_from(const TkTables& T, uint64_t w0, uint64_t w1, uint64_t w2, uint32_t i, TkXlSlot s) {
+    for (;;) {
+        if (s.rank == TK_RANK_MAX) return TK_RANK_MAX;
+        if (s.w0 == w0 && s.w1 == w1 && s.w2 == w2) return s.rank;
+        i = (i + 1u) & T.xl_mask;
+        s = T.xl[i];
+    }
+}
+TK_HD uint32_t tk_probe_xl(const TkTables& T, uint64_t w0, uint64_t w1, uint64_t w2) {
+    const uint32_t i = (uint32_t)tk_ident_hash(w0, w1, w2, true) & T.xl_mask;
+    return tk_probe_xl_from(T, w0, w1, w2, i, T.xl[i]);
+}
+
 // Pair probe.  Packed format: 4-slot (32-byte, 32-byte-aligned) buckets; a bucket is fetched with two
 // 16-byte loads issued together, so a probe is one memory round trip.  A key lives in the first bucket
 // of its probe sequence that had a free slot at build time, so a bucket with a free slot ends the search.

@@ -70,10 +70,16 @@
 // the result in it and tk_k_place reads it from there.  The slot index is the index of its TkMissData entry; behind the table's entries
 // the array goes on with the OVERFLOW entries, handed out by a counter: pieces the table does not take (longer than TK_GLANE_MAX bytes, a
 // full neighbourhood, chunks too small for a table).  No per-tile lists: the merge work list is a walk over this array.
-struct TkMissKey {           // 16 bytes, one load
+// Round 5: a slot is 32 bytes and holds the claimant's IDENTITY -- for a piece of at most TK_XL_MAX bytes the bytes themselves
+// (w0, w1: bytes 0..15, w2: bytes 16..22 and the length in the top byte; each word's bytes left-aligned, the rest zero), so that a later
+// occurrence is recognised from the slot alone: no look at the claimant's text (a dependent random line, and a compare loop whose trip
+// count was the longest piece's of a row of 64), no hash over all the bytes (25 instructions per 8 bytes).  Longer pieces: w0 / w1 = the
+// first / last eight bytes, w2 = 1 << 63 | length << 32 | start, compared in the text as before.  The key word is a hash of the identity
+// (without the start); ~0 = empty.  The identity words are ~0 until the claimant has written them (a word of bytes is never ~0 together
+// with a valid w2: w2's top byte is a length <= 23, or bit 63 with bits 42..62 clear).
+struct TkMissKey {
     unsigned long long key;  // ~0 = empty
-    unsigned long long aux;  // identity of the claimant, ~0 until it has written it: pieces of <= 7 bytes: the bytes themselves
-                             // | length << 56; longer ones: 1 << 63 | length << 32 | start (compared in the text)
+    unsigned long long w0, w1, w2;
 };
 // Where a distinct missed piece and its result live: a table slot has a 64-byte line of its own -- {start, len, count, tokens}: a piece of up
 // to TKD_INLINE tokens (97.5 % of the missed pieces of the web-text corpus) has them IN the entry, so an occurrence costs ONE random
@@ -533,14 +539,29 @@ struct TkWinLds32 {  // 32 positions from window offset r (the bitmaps seen as 3
     }
 };
 
-// exact compare of the piece at LDS offset o with text[pos .. pos+len) in HBM
-__device__ __forceinline__ bool tk_equal_lds_text(const uint8_t* raw, uint32_t o, const uint8_t* text, uint64_t pos, uint32_t len) {
-    uint32_t i = 0;
-    for (; i + 8u <= len; i += 8u)
-        if (tk_lds_load8(raw, o + i) != tk_load8(text, pos + i)) return false;
-    if (i < len) {
-        const uint32_t r = len - i;
-        if (tk_mask_low_bytes(tk_lds_load8(raw, o + i), r) != tk_mask_low_bytes(tk_load8(text, pos + i), r)) return false;
+// eight text bytes at any position: one 12-byte load and two byte-aligns, no branch (the text is readable 64 bytes past its end)
+__device__ __forceinline__ uint64_t tk_text_load8(const uint8_t* __restrict__ text, uint64_t pos) {
+    const uintptr_t a = (uintptr_t)(text + pos);
+    const uint32_t* w = (const uint32_t*)(a & ~(uintptr_t)3);
+    const uint32_t sft = (uint32_t)a & 3u;
+    const uint32_t d0 = w[0], d1 = w[1], d2 = w[2];
+    return ((uint64_t)__builtin_amdgcn_alignbyte(d2, d1, sft) << 32) | __builtin_amdgcn_alignbyte(d1, d0, sft);
+}
+// exact compare of the piece at LDS offset o with text[pos .. pos+len) in HBM: 8 * TKF_CMP_WORDS bytes per step, the loads of a step in flight
+// together and no way out between them (round 4 compared eight bytes per step and left at the first difference: a chain of len / 8
+// dependent loads in the one phase of the kernel that waits for memory; what lies behind the piece on either side is masked away)
+#ifndef TKF_CMP_WORDS
+#define TKF_CMP_WORDS 2
+#endif
+__device__ __forceinline__ bool tk_equal_lds_text(const uint8_t* raw, uint32_t o, const uint8_t* __restrict__ text, uint64_t pos, uint32_t len) {
+    for (uint32_t i = 0; i < len; i += 8u * TKF_CMP_WORDS) {
+        uint64_t g[TKF_CMP_WORDS];
+#pragma unroll
+        for (int j = 0; j < TKF_CMP_WORDS; ++j) g[j] = tk_text_load8(text, pos + i + 8u * (uint32_t)j);
+        uint64_t diff = 0;
+#pragma unroll
+        for (int j = 0; j < TKF_CMP_WORDS; ++j) diff |= tk_keep_bytes(tk_lds_load8(raw, o + i + 8u * (uint32_t)j) ^ g[j], (int)len - (int)(i + 8u * (uint32_t)j));
+        if (diff) return false;
     }
     return true;
 }
@@ -593,10 +614,6 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
     // phase C reads each lane's 16 bits from global memory, phase F finds the starts of special tokens in `brkw`, reloaded in phase E)
     __shared__ uint32_t brkw[TK2_WIN / 32 + 1];
     __shared__ uint32_t scan_sh[8];
-    // the LDS piece cache (tk_common.h): lives as long as the workgroup, i.e. over all the tiles it walks
-    constexpr bool HOT = !SLOW && TKF_HOT_BITS > 0;
-    __shared__ __attribute__((aligned(16))) uint32_t hot[HOT ? TKF_HOT_SLOTS * 4 : 4];
-    __shared__ __attribute__((aligned(16))) uint32_t hot_mask[HOT ? 16 * 4 : 4];  // [len] -> byte masks of the three key words
     uint64_t(*bm)[NW] = (uint64_t(*)[NW])pool;
     uint16_t* plist = (uint16_t*)pool;  // valid after the scanners are done
     uint32_t* woff = certw;             // (phase E; the certain-start bitmap is dead by then)
@@ -609,23 +626,11 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     uint32_t item = blockIdx.x;
-    // SLOW, and the variant with the piece cache: persistent, a fixed grid walks the deferred list / the tiles with the stride of the
-    // grid.  Otherwise one tile per workgroup (the loop's state would cost registers the kernel does not have at eight workgroups per CU).
-    constexpr bool PERSIST = SLOW || HOT;
-    const uint32_t n_items = SLOW ? out.counters[(dbg & TKF_DBG_SECOND) ? TK_CNT_DEFER2 : TK_CNT_DEFER] : (PERSIST ? (uint32_t)((n + TK_TILE - 1) / TK_TILE) : gridDim.x);
+    // SLOW: persistent, a fixed grid walks the deferred list with the stride of the grid.  Otherwise one tile per workgroup (the loop's
+    // state would cost registers the kernel does not have at eight workgroups per CU).
+    constexpr bool PERSIST = SLOW;
+    const uint32_t n_items = SLOW ? out.counters[(dbg & TKF_DBG_SECOND) ? TK_CNT_DEFER2 : TK_CNT_DEFER] : gridDim.x;
     if (PERSIST && item >= n_items) return;
-    const bool use_hot = HOT && !(dbg & 0x200000);  // (debug bit 0x200000: the piece cache is never consulted)
-    uint32_t hot_probes = 0, hot_hits = 0;         // per lane; summed into the counters when the workgroup is done
-    if constexpr (HOT) {
-        for (uint32_t i = tid; i < TKF_HOT_SLOTS; i += 256)
-            *(uint4*)&hot[i * 4] = (T.hot && use_hot) ? *(const uint4*)&T.hot[i * 4] : make_uint4(0, 0, 0, 0);
-        if (tid < 16) {
-            uint32_t m[3];
-#pragma unroll
-            for (int j = 0; j < 3; ++j) m[j] = tid >= 4u * j + 4u ? 0xFFFFFFFFu : (tid <= 4u * j ? 0u : ((1u << (8u * (tid - 4u * j))) - 1u));
-            *(uint4*)&hot_mask[tid * 4] = make_uint4(m[0], m[1], m[2], 0u);
-        }
-    }
     do {
     if (PERSIST && item != blockIdx.x) __syncthreads();  // (the shared arrays are reused by the next tile)
     const uint64_t tile = SLOW ? (uint64_t)deferred[item] : (uint64_t)item;
@@ -1110,56 +1115,94 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
         continue;
     }
     // ---- F: whole-piece probe (src/lib.rs:367).  Pieces are first sorted by length class into LDS lists -- short (<= 4 bytes),
-    // mid (5..8), long -- so that every wavefront runs ONE probe path with all lanes busy; pieces that are not tokens go to a
-    // fourth list and get their de-duplication pass the same way.  Batches of 1024 pieces bound the lists.
+    // mid (5..8), long (9..TK_XL_MAX) -- so that every wavefront runs ONE probe path with all lanes busy.  Round 5: the long class --
+    // a fifth of the pieces of web text, three in five of them not tokens, three quarters of all the pieces that are not -- is looked up
+    // by IDENTITY (tk_common.h, tk_ident: the bytes themselves in three words), and the same identity and hash key the in-call table of
+    // the pieces that are not tokens: a lane fetches the vocabulary's slot and the in-call table's slot TOGETHER and settles the piece
+    // there and then -- one memory round trip where there were a hash over all the bytes, a probe, a verification in the token blob
+    // (dependent loads), then a barrier, the hash once more, the in-call table, and a comparison with the claimant's text (dependent
+    // loads again).  Pieces of more than TK_XL_MAX bytes (2 % of the pieces, next to none of them tokens) go to the in-call table without
+    // a look at the vocabulary: whether such a piece is a token is asked ONCE per distinct piece, when the entries are listed for the merge
+    // kernels (tk_miss_bin).  What is left for the list of pieces that are not tokens (`ord_x`, F4): the short and mid ones, those long ones.
     const uint32_t last_end = last_end_sh;
     uint16_t* ord_sl = (uint16_t*)btab;        // [1024] short pieces from the front, long ones from the back (the byte table is dead)
     uint16_t* ord_m = (uint16_t*)planes;       // [1024] mid pieces (the planes are dead)
     uint16_t* ord_x = (uint16_t*)(pool + TK_TILE * 2);  // [1024] pieces that are not tokens (behind the piece list)
     const uint32_t* dwr = (const uint32_t*)raw;
     const bool short_tab = T.short_tab != nullptr;
-    // key of the piece cache: the (at most twelve) bytes at window offset s_loc, zero padded
-    auto hot_key = [&](uint32_t s_loc, uint32_t len, uint32_t& k0, uint32_t& k1, uint32_t& k2) {
-        const uint32_t wi = s_loc >> 2, sft = s_loc & 3u;
-        const uint32_t d0 = dwr[wi], d1 = dwr[wi + 1], d2 = dwr[wi + 2], d3 = dwr[wi + 3];
-        const uint4 m = *(const uint4*)&hot_mask[len * 4];
-        k0 = __builtin_amdgcn_alignbyte(d1, d0, sft) & m.x;
-        k1 = __builtin_amdgcn_alignbyte(d2, d1, sft) & m.y;
-        k2 = __builtin_amdgcn_alignbyte(d3, d2, sft) & m.z;
+    uint32_t& ntail_sh = ncont_sh;  // pieces of the tile that are not tokens, so far = entries at the tail of its run (the scanners' counter is dead)
+    if (tid == 0) {
+        ntail_sh = 0;
+        if (GEN) ngap_sh = 0;
+    }
+    // A piece that is not a token, by its identity (w0, w1, w2; kk = tk_ident_hash): claim a slot of the in-call table (first occurrence:
+    // the slot's entry gets the piece, the merge kernels will find it there) or find it claimed by IDENTICAL bytes; `k0` / `k1` = the two
+    // halves of slot i, which the caller has loaded.  Returns the slot, or TKF_NONE when the neighbourhood is full.  Slots are written
+    // once, so a cached load can only be stale towards "empty" / "not written yet", where the atomic (the load at the memory side) decides.
+    auto claim = [&](uint64_t w0, uint64_t w1, uint64_t w2, unsigned long long kk, bool exact, bool in_lds, uint32_t s_loc, uint64_t gs, uint32_t len,
+                     uint32_t i, ulonglong2 k0, ulonglong2 k1) -> uint32_t {
+        for (int p = 0;;) {
+            unsigned long long cur = k0.x;
+            if (cur == TK_EMPTY_KEY) cur = atomicCAS(&mt[i].key, TK_EMPTY_KEY, kk);
+            if (cur == TK_EMPTY_KEY) {  // claimed: this occurrence is the one that gets merged
+                __hip_atomic_store(&mt[i].w0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&mt[i].w1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&mt[i].w2, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *(uint2*)&out.data.tab[i].start = make_uint2((uint32_t)gs, len);
+                return i;
+            }
+            if (cur == kk) {
+                unsigned long long a0 = k0.y, a1 = k1.x, a2 = k1.y;
+                if (a2 == TK_EMPTY_KEY || a0 == TK_EMPTY_KEY || a1 == TK_EMPTY_KEY) {  // (a line cached before the claimant had written: once more, at the memory side)
+                    a0 = __hip_atomic_load(&mt[i].w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a1 = __hip_atomic_load(&mt[i].w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    a2 = __hip_atomic_load(&mt[i].w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                }
+                bool same = a0 == w0 && a1 == w1 && a2 != TK_EMPTY_KEY && (exact ? a2 == w2 : (a2 >> 32) == (w2 >> 32));
+                if (same && !exact)
+                    same = in_lds ? tk_equal_lds_text(raw, s_loc + 8u, text, (uint64_t)(uint32_t)a2 + 8u, len - 16u)  // (w0 and w1 are the first and the last eight bytes)
+                                  : tk_equal_bytes(text, gs, text, (uint32_t)a2, len);
+                if (same) return i;
+            }
+            if (++p == TK_MT_PROBES) return TKF_NONE;
+            i = (i + 1) & mt_mask;
+            k0 = *(const ulonglong2*)&mt[i].key;
+            k1 = *(const ulonglong2*)&mt[i].w1;
+        }
     };
-    // A piece that went to the tables in HBM replaces the entry of its slot.  Lanes of any wavefront may do this at the same time (never
-    // while anyone probes: barriers separate the phases): the exchange of the entry's last word makes ONE of them the writer -- whoever
-    // finds the "being replaced" mark backs off, and the writer's final store of that word (after the key words) lifts the mark.
-    auto hot_insert = [&](uint32_t k0, uint32_t k1, uint32_t k2, uint32_t len, uint32_t payload) {
-        if constexpr (HOT) {
-            uint32_t* e = &hot[tk_hot_slot(k0, k1, k2) * 4];
-            const uint32_t old = __hip_atomic_exchange(&e[3], TK_HOT_LOCK, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_WORKGROUP);
-            if ((old >> 28) != 15u) {
-                e[0] = k0;
-                e[1] = k1;
-                e[2] = k2;
-                __hip_atomic_store(&e[3], (len << 28) | payload, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_WORKGROUP);
+    // the result of a piece that is not a token: its word, and its entry once more at the tail of the run (one LDS atomic per wavefront)
+    auto put_ref = [&](bool on, uint32_t k, uint32_t ref) {
+        const uint64_t m = __ballot(on);
+        if (m) {
+            uint32_t at = 0;
+            const int leader = __ffsll((unsigned long long)m) - 1;
+            if (lane == leader) at = atomicAdd(&ntail_sh, (uint32_t)__popcll(m));
+            at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (on) {
+                out.res[run_base + k] = ref != TKF_NONE ? (TK_RES_FLAG | ref) : 0u;
+                out.res[run_base + TKF_TAIL_REFS - at] = ref;  // (TKF_NONE = 0xFFFFFFFF: counts as the one token 0 the result word holds; the batch is repeated with more room)
             }
         }
     };
-    uint32_t miss_total = 0;  // pieces of the tile that are not tokens, so far (uniform)
-    if (GEN && tid == 0) ngap_sh = 0;
+    uint32_t& nxl_sh = nslow_sh;  // pieces of more than TK_XL_MAX bytes in the batch (the counter of the pieces that left the window is dead)
     for (uint32_t kb = 0; kb < np; kb += TKF_BATCH) {
         const uint32_t nb = np - kb < TKF_BATCH ? np - kb : (uint32_t)TKF_BATCH;
         if (tid == 0) {
             ncls_sh = 0;
             nx_sh = 0;
+            nxl_sh = 0;
         }
         __syncthreads();
-        // F0: length class of every piece of the batch -> lists (one packed LDS counter: short | mid << 11 | long << 22)
+        // F0: length class of every piece of the batch -> lists (one packed LDS counter: short | mid << 11 | long << 22; the pieces of more
+        // than TK_XL_MAX bytes, a dozen per tile, have a counter of their own)
         for (uint32_t i0 = 0; i0 < nb; i0 += 256) {
             const uint32_t i = i0 + tid;
-            uint32_t cls = 3;  // 0 short, 1 mid, 2 long, 3 none
+            uint32_t cls = 3;  // 0 short, 1 mid, 2 long, 3 none, 4 longer than TK_XL_MAX
             if (i < nb) {
                 const uint32_t k = kb + i;
                 const uint32_t s_loc = plist[k], e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
                 const uint32_t len = e_loc - s_loc;
-                cls = len <= 4u ? 0u : (len <= 8u ? 1u : 2u);
+                cls = len <= 4u ? 0u : (len <= 8u ? 1u : (len <= TK_XL_MAX ? 2u : 4u));
                 if (SPEC && ((brkw[s_loc >> 5] >> (s_loc & 31u)) & 1u)) {  // a special token: its id (src/lib.rs:426-434)
                     out.res[run_base + k] = tk_special_id(T, text, (uint64_t)(base + s_loc), len);
                     cls = 3;
@@ -1168,31 +1211,28 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
                     out.res[run_base + k] = TK_RES_GAP;
                     atomicAdd(&ngap_sh, 1u);  // (LDS; gap chars are rare)
                     cls = 3;
-                } else if (HOT && use_hot && len <= TK_HOT_MAXLEN) {  // the piece cache in LDS first; the tables in HBM only on a miss
-                    uint32_t k0, k1, k2;
-                    hot_key(s_loc, len, k0, k1, k2);
-                    const uint4 e = *(const uint4*)&hot[tk_hot_slot(k0, k1, k2) * 4];
-                    ++hot_probes;
-                    if (e.x == k0 && e.y == k1 && e.z == k2 && (e.w >> 28) == len) {
-                        out.res[run_base + k] = (e.w & TK_HOT_DUP) ? (TK_RES_FLAG | (e.w & (TK_HOT_DUP - 1u))) : (e.w & TK_HOT_PAYLOAD);
-                        ++hot_hits;
-                        cls = 3;
-                    }
                 }
             }
-            const uint64_t m0 = __ballot(cls == 0u), m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u);
+            const uint64_t m0 = __ballot(cls == 0u), m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u), m4 = __ballot(cls == 4u);
             const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2);
-            uint32_t at = 0;
-            if (lane == 0) at = atomicAdd(&ncls_sh, c0 | (c1 << 11) | (c2 << 22));
+            uint32_t at = 0, at4 = 0;
+            if (lane == 0) {
+                at = atomicAdd(&ncls_sh, c0 | (c1 << 11) | (c2 << 22));
+                if (m4) at4 = atomicAdd(&nxl_sh, (uint32_t)__popcll(m4));
+            }
             at = (uint32_t)__shfl((int)at, 0, 64);
             const uint64_t below = (1ull << lane) - 1ull;
             if (cls == 0u) ord_sl[(at & 2047u) + (uint32_t)__popcll(m0 & below)] = (uint16_t)i;
             else if (cls == 1u) ord_m[((at >> 11) & 2047u) + (uint32_t)__popcll(m1 & below)] = (uint16_t)i;
             else if (cls == 2u) ord_sl[1023u - (at >> 22) - (uint32_t)__popcll(m2 & below)] = (uint16_t)i;
+            if (m4) {  // (mid pieces from the front of their list, these from the back: 5 n_m + 24 n_xl <= the window's bytes, so the two never meet)
+                at4 = (uint32_t)__shfl((int)at4, 0, 64);
+                if (cls == 4u) ord_m[1023u - at4 - (uint32_t)__popcll(m4 & below)] = (uint16_t)i;
+            }
         }
         __syncthreads();
-        const uint32_t n_s = ncls_sh & 2047u, n_m = (ncls_sh >> 11) & 2047u, n_l = ncls_sh >> 22;
-        // a piece that is not a token: remembered for the de-duplication pass
+        const uint32_t n_s = ncls_sh & 2047u, n_m = (ncls_sh >> 11) & 2047u, n_l = ncls_sh >> 22, n_xl = nxl_sh;
+        // a piece for the list of F4
         auto not_a_token = [&](bool miss, uint32_t i) {
             const uint64_t m = __ballot(miss);
             if (m) {
@@ -1203,228 +1243,131 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
                 if (miss) ord_x[at] = (uint16_t)i;
             }
         };
-#if TKF_ROWS
-        // F1..F3 by rows of 64 pieces of ONE length class: a wavefront takes every fourth row (long pieces first: the dearest rows are
-        // spread evenly) and runs that class's probe only -- a third of the instructions of the earlier form, in which every lane ran
-        // the short, the mid and the long path in every round however few pieces of a class were left (the kernel is bound by the
-        // vector ALU's issue rate; the eight wavefronts per SIMD keep enough probes in flight).
+        // F1..F3 by rows of 64 pieces of ONE length class: a wavefront takes every fourth row -- the dearest rows first, so that they are
+        // spread evenly and run side by side -- and runs that class's probe only; the lanes whose piece is not a token then claim or
+        // find their slot of the in-call table in the same row, by the piece's identity (tk_common.h, tk_ident).  Nothing waits for a
+        // barrier in between: the chains of dependent accesses of the four wavefronts overlap (round 4 listed the pieces that are not
+        // tokens and gave the list to one wavefront behind a barrier: 0.9 ms of the kernel's 5 for a third of them, measured).
+        //   longer than TK_XL_MAX: no look at the vocabulary (see above); identity = first and last eight bytes, length, place
+        //   long : identity = the bytes, 32-byte slots that hold them
+        //   mid  : 64-bit key = the bytes, 16-byte slots
         //   short: the bytes are the key (one unaligned LDS dword), 8-byte slots
-        //   mid  : 64-bit key, 16-byte slots
-        //   long : hash of the bytes, candidates verified against the token blob
-        const uint32_t rows_l = (n_l + 63u) >> 6, rows_m = (n_m + 63u) >> 6, rows_s = (n_s + 63u) >> 6;
-        for (uint32_t r = (uint32_t)wid; r < rows_l + rows_m + rows_s; r += 4u) {
-            bool miss = false;
-            uint32_t i_p = 0;
-            if (r < rows_l) {
+        const uint32_t rows_x = (n_xl + 63u) >> 6, rows_l = (n_l + 63u) >> 6, rows_m = (n_m + 63u) >> 6, rows_s = (n_s + 63u) >> 6;
+        const bool use_mt = mt != nullptr && !(dbg & 8);
+        for (uint32_t r = (uint32_t)wid; r < rows_x + rows_l + rows_m + rows_s; r += 4u) {
+            bool miss = false, exact = true, in_lds = true;
+            uint32_t i_p = 0, k = 0, len = 0, s_loc = 0;
+            uint64_t w0 = 0, w1 = 0, w2 = 0;
+            if (r < rows_x) {
                 const uint32_t q = r * 64u + (uint32_t)lane;
+                if (q < n_xl) {
+                    i_p = ord_m[1023u - q];
+                    k = kb + i_p;
+                    s_loc = plist[k];
+                    const uint32_t e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
+                    len = e_loc - s_loc;
+                    in_lds = e_loc + 8u <= (uint32_t)TK2_WIN;
+                    exact = false;
+                    if (dbg & (2 | 8)) {  // (perf experiments / piece starts only: every probe counts as a hit)
+                        out.res[run_base + k] = (dbg & 2) ? len : 0u;
+                    } else {
+                        miss = true;
+                        if (len <= TK_GLANE_MAX) {
+                            const uint64_t gs = (uint64_t)(base + s_loc);
+                            tk_ident([&](uint32_t o) { return in_lds ? tk_lds_load8(raw, s_loc + o) : tk_load8(text, gs + o); }, len, (uint32_t)gs, w0, w1, w2);
+                        }
+                    }
+                }
+            } else if (r < rows_x + rows_l) {
+                const uint32_t q = (r - rows_x) * 64u + (uint32_t)lane;
                 if (q < n_l) {
                     i_p = ord_sl[1023u - q];
-                    const uint32_t k_l = kb + i_p, sloc_l = plist[k_l];
-                    const uint32_t e_loc = k_l + 1 < np ? (uint32_t)plist[k_l + 1] : last_end;
-                    const uint32_t len_l = e_loc - sloc_l;
-                    const uint64_t gs_l = (uint64_t)(base + sloc_l);
-                    const bool in_lds = e_loc + 8u <= (uint32_t)TK2_WIN;
-                    uint32_t rk = TK_RANK_MAX;
-                    if (dbg & 2) rk = len_l;
-                    else if (len_l <= T.max_token_len) {  // (longer than every token: not a token, and no reason to hash a megabyte)
-                        const uint64_t key_l = in_lds ? tk_key_of_lds(raw, sloc_l, len_l) : tk_key_of_text(text, gs_l, len_l);
-                        const uint64_t at_l = tk_piece_slot_hash(key_l, len_l) & T.piece_mask;
-                        rk = tk_probe_piece_from(T, key_l, len_l, at_l, T.piece[at_l], [&](uint32_t off) {
-                            return in_lds ? tk_equal_lds_text(raw, sloc_l, T.tok_bytes, off, len_l) : tk_equal_bytes(text, gs_l, T.tok_bytes, off, len_l);
-                        });
+                    k = kb + i_p;
+                    s_loc = plist[k];
+                    const uint32_t e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
+                    len = e_loc - s_loc;
+                    in_lds = e_loc + 8u <= (uint32_t)TK2_WIN;
+                    uint32_t rk = len;
+                    if (!(dbg & 2)) {
+                        const uint64_t gs = (uint64_t)(base + s_loc);
+                        tk_ident([&](uint32_t o) { return in_lds ? tk_lds_load8(raw, s_loc + o) : tk_load8(text, gs + o); }, len, 0u, w0, w1, w2);
+                        rk = tk_probe_xl(T, w0, w1, w2);
                     }
-                    if (rk != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k_l] = rk == TK_RANK_MAX ? 0u : rk;
+                    if (rk != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k] = rk == TK_RANK_MAX ? 0u : rk;
                     else miss = true;
-                    if (use_hot && rk < TK_HOT_DUP && len_l <= TK_HOT_MAXLEN) {
-                        uint32_t k0, k1, k2;
-                        hot_key(sloc_l, len_l, k0, k1, k2);
-                        hot_insert(k0, k1, k2, len_l, rk);
-                    }
                 }
-            } else if (r < rows_l + rows_m) {
-                const uint32_t q = (r - rows_l) * 64u + (uint32_t)lane;
+            } else if (r < rows_x + rows_l + rows_m) {
+                const uint32_t q = (r - rows_x - rows_l) * 64u + (uint32_t)lane;
                 if (q < n_m) {
                     i_p = ord_m[q];
-                    const uint32_t k_m = kb + i_p;
-                    const uint32_t s_loc = plist[k_m], e_loc = k_m + 1 < np ? (uint32_t)plist[k_m + 1] : last_end;
-                    const uint32_t len_m = e_loc - s_loc;
-                    const uint64_t key_m = tk_mask_low_bytes(tk_lds_load8(raw, s_loc), len_m);
-                    const uint32_t rk = (dbg & 2) ? len_m : tk_probe_mid(T, key_m, len_m);
-                    if (rk != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k_m] = rk == TK_RANK_MAX ? 0u : rk;
-                    else miss = true;
-                    if (use_hot && rk < TK_HOT_DUP) hot_insert((uint32_t)key_m, (uint32_t)(key_m >> 32), 0u, len_m, rk);
+                    k = kb + i_p;
+                    s_loc = plist[k];
+                    const uint32_t e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
+                    len = e_loc - s_loc;
+                    const uint64_t key_m = tk_mask_low_bytes(tk_lds_load8(raw, s_loc), len);
+                    const uint32_t rk = (dbg & 2) ? len : tk_probe_mid(T, key_m, len);
+                    if (rk != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k] = rk == TK_RANK_MAX ? 0u : rk;
+                    else {
+                        miss = true;
+                        w0 = tk_keep_bytes(key_m, (int)len);  // (tk_ident of a piece of at most eight bytes)
+                        w2 = (uint64_t)len << 56;
+                    }
                 }
             } else {
-                const uint32_t q = (r - rows_l - rows_m) * 64u + (uint32_t)lane;
+                const uint32_t q = (r - rows_x - rows_l - rows_m) * 64u + (uint32_t)lane;
                 if (q < n_s) {
                     i_p = ord_sl[q];
-                    const uint32_t k_s = kb + i_p;
-                    const uint32_t s_loc = plist[k_s], e_loc = k_s + 1 < np ? (uint32_t)plist[k_s + 1] : last_end;
-                    const uint32_t len_s = e_loc - s_loc;
+                    k = kb + i_p;
+                    s_loc = plist[k];
+                    const uint32_t e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
+                    len = e_loc - s_loc;
                     const uint32_t v = __builtin_amdgcn_alignbyte(dwr[(s_loc >> 2) + 1], dwr[s_loc >> 2], s_loc & 3u);
-                    const uint32_t key_s = v & (0xFFFFFFFFu >> (32u - 8u * len_s));
-                    const uint32_t rk = (dbg & 2) ? len_s : (short_tab ? tk_probe_short(T, key_s, len_s) : tk_probe_mid(T, (uint64_t)key_s, len_s));
-                    if (rk != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k_s] = rk == TK_RANK_MAX ? 0u : rk;
-                    else miss = true;
-                    if (use_hot && rk < TK_HOT_DUP) hot_insert(key_s, 0u, 0u, len_s, rk);
+                    const uint32_t key_s = v & (0xFFFFFFFFu >> (32u - 8u * len));
+                    const uint32_t rk = (dbg & 2) ? len : (short_tab ? tk_probe_short(T, key_s, len) : tk_probe_mid(T, (uint64_t)key_s, len));
+                    if (rk != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k] = rk == TK_RANK_MAX ? 0u : rk;
+                    else {
+                        miss = true;
+                        w0 = tk_keep_bytes((uint64_t)key_s, (int)len);
+                        w2 = (uint64_t)len << 56;
+                    }
                 }
             }
-            not_a_token(miss, i_p);
+            // the pieces of the row that are not tokens: their slots of the in-call table
+            uint32_t ref = TKF_NONE;
+            if (miss && use_mt && len <= TK_GLANE_MAX) {
+                unsigned long long kk = tk_ident_hash(w0, w1, w2, exact);
+                if (dbg & 512) kk &= 0xFFFull;  // test hook: force collisions between different pieces
+                if (kk == TK_EMPTY_KEY) kk = 0;
+                const uint32_t i = ((uint32_t)kk ^ (uint32_t)(kk >> 40)) & mt_mask;
+                ref = claim(w0, w1, w2, kk, exact, in_lds, s_loc, (uint64_t)(base + s_loc), len, i, *(const ulonglong2*)&mt[i].key, *(const ulonglong2*)&mt[i].w1);
+            }
+            put_ref(ref != TKF_NONE, k, ref);
+            not_a_token(miss && ref == TKF_NONE, i_p);  // (no table, a full neighbourhood, more than TK_GLANE_MAX bytes: F4)
         }
-#else
-        // F1..F3 in one loop: a lane takes the q-th short, mid and long piece together, so that the first table loads of the three
-        // independent probes are in flight at the same time (the probes are latency-bound: profiles/r02_front_phases_*.csv).
-        //   short: the bytes are the key (one unaligned LDS dword), 8-byte slots
-        //   mid  : 64-bit key, 16-byte slots
-        //   long : hash of the bytes, candidates verified against the token blob
-        const uint32_t n_max = n_s > n_m ? (n_s > n_l ? n_s : n_l) : (n_m > n_l ? n_m : n_l);
-        for (uint32_t q0 = 0; q0 < n_max; q0 += 256) {
-            const uint32_t q = q0 + tid;
-            const bool has_s = q < n_s, has_m = q < n_m, has_l = q < n_l;
-            uint32_t i_s = 0, i_m = 0, i_l = 0;
-            // short: key and first slot
-            uint32_t k_s = 0, len_s = 1, key_s = 0, at_s = 0;
-            if (has_s) {
-                i_s = ord_sl[q];
-                k_s = kb + i_s;
-                const uint32_t s_loc = plist[k_s], e_loc = k_s + 1 < np ? (uint32_t)plist[k_s + 1] : last_end;
-                len_s = e_loc - s_loc;
-                const uint32_t v = __builtin_amdgcn_alignbyte(dwr[(s_loc >> 2) + 1], dwr[s_loc >> 2], s_loc & 3u);
-                key_s = v & (0xFFFFFFFFu >> (32u - 8u * len_s));
-                at_s = short_tab ? tk_short_slot(key_s, T.short_shift) : tk_mid_slot((uint64_t)key_s, T.mid_shift);
-            }
-            TkShortSlot slot_s{0, 0};
-            TkPieceSlot slot_sm{0, 0, 0};
-            if (short_tab) slot_s = T.short_tab[at_s];
-            else slot_sm = T.mid_tab[at_s];
-            // mid: key and first slot
-            uint32_t k_m = 0, len_m = 5, at_m = 0;
-            uint64_t key_m = 0;
-            if (has_m) {
-                i_m = ord_m[q];
-                k_m = kb + i_m;
-                const uint32_t s_loc = plist[k_m], e_loc = k_m + 1 < np ? (uint32_t)plist[k_m + 1] : last_end;
-                len_m = e_loc - s_loc;
-                key_m = tk_mask_low_bytes(tk_lds_load8(raw, s_loc), len_m);
-                at_m = tk_mid_slot(key_m, T.mid_shift);
-            }
-            const TkPieceSlot slot_m = T.mid_tab[at_m];
-            // long: hash and first slot
-            uint32_t k_l = 0, len_l = 9, sloc_l = 0;
-            uint64_t key_l = 0, at_l = 0, gs_l = 0;
-            bool in_lds = true, too_long = false;
-            if (has_l) {
-                i_l = ord_sl[1023u - q];
-                k_l = kb + i_l;
-                sloc_l = plist[k_l];
-                const uint32_t e_loc = k_l + 1 < np ? (uint32_t)plist[k_l + 1] : last_end;
-                len_l = e_loc - sloc_l;
-                gs_l = (uint64_t)(base + sloc_l);
-                in_lds = e_loc + 8u <= (uint32_t)TK2_WIN;
-                too_long = len_l > T.max_token_len;  // (longer than every token: not a token, and no reason to hash a megabyte)
-                if (!too_long) {
-                    key_l = in_lds ? tk_key_of_lds(raw, sloc_l, len_l) : tk_key_of_text(text, gs_l, len_l);
-                    at_l = tk_piece_slot_hash(key_l, len_l) & T.piece_mask;
-                }
-            }
-            const TkPieceSlot slot_l = T.piece[at_l];
-            // resolve
-            bool miss_s = false, miss_m = false, miss_l = false;
-            if (has_s) {
-                const uint32_t r = (dbg & 2) ? len_s : (short_tab ? tk_probe_short_from(T, key_s, len_s, at_s, slot_s)
-                                                                  : tk_probe_mid_from(T, (uint64_t)key_s, len_s, at_s, slot_sm));
-                if (r != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k_s] = r == TK_RANK_MAX ? 0u : r;
-                else miss_s = true;
-                if (use_hot && r < TK_HOT_DUP) hot_insert(key_s, 0u, 0u, len_s, r);
-            }
-            if (has_m) {
-                const uint32_t r = (dbg & 2) ? len_m : tk_probe_mid_from(T, key_m, len_m, at_m, slot_m);
-                if (r != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k_m] = r == TK_RANK_MAX ? 0u : r;
-                else miss_m = true;
-                if (use_hot && r < TK_HOT_DUP) hot_insert((uint32_t)key_m, (uint32_t)(key_m >> 32), 0u, len_m, r);
-            }
-            if (has_l) {
-                const uint32_t r = (dbg & 2) ? len_l : too_long ? TK_RANK_MAX : tk_probe_piece_from(T, key_l, len_l, at_l, slot_l, [&](uint32_t off) {
-                    return in_lds ? tk_equal_lds_text(raw, sloc_l, T.tok_bytes, off, len_l) : tk_equal_bytes(text, gs_l, T.tok_bytes, off, len_l);
-                });
-                if (r != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k_l] = r == TK_RANK_MAX ? 0u : r;
-                else miss_l = true;
-                if (use_hot && r < TK_HOT_DUP && len_l <= TK_HOT_MAXLEN) {
-                    uint32_t k0, k1, k2;
-                    hot_key(sloc_l, len_l, k0, k1, k2);
-                    hot_insert(k0, k1, k2, len_l, r);
-                }
-            }
-            not_a_token(miss_s, i_s);
-            not_a_token(miss_m, i_m);
-            not_a_token(miss_l, i_l);
-        }
-#endif
         __syncthreads();
-        // F4: pieces that are not tokens.  In-call de-duplication: claim a slot of the miss table (first occurrence: the slot's data entry
-        // gets the piece, the merge kernels will find it there) or find it claimed by IDENTICAL bytes -- pieces of <= 7 bytes carry their
-        // bytes in the slot, longer ones are compared with the claimant's text; either way the piece's result word refers to the slot.
-        // Slots are written once, so a cached load can only be stale towards "empty", where the atomic decides.  What the table does
-        // not take gets an overflow entry behind the table's (one returning atomic per wavefront that has such pieces: rare).
+        // F4: what the rows above could not settle (next to nothing: chunks too small for a table, a full neighbourhood of the table, pieces
+        // of more than TK_GLANE_MAX bytes): an overflow entry behind the table's (one returning atomic per wavefront that has such pieces).
         const uint32_t n_x = nx_sh;
-#if TKF_ROWS
         for (uint32_t q0 = (uint32_t)wid * 64u; q0 < n_x; q0 += 256u) {  // (rows of 64: a wavefront without pieces does not run the body)
             const uint32_t q = q0 + (uint32_t)lane;
-#else
-        for (uint32_t q0 = 0; q0 < n_x; q0 += 256) {
-            const uint32_t q = q0 + tid;
-#endif
             bool over = false;  // needs an overflow entry
-            uint32_t k = 0, len = 0, ref = TKF_NONE, s_loc = 0;
+            uint32_t k = TKF_NONE, len = 0, ref = TKF_NONE;
             uint64_t gs = 0;
             if (q < n_x) {
                 k = kb + ord_x[q];
-                s_loc = plist[k];
+                const uint32_t s_loc = plist[k];
                 const uint32_t e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
                 len = e_loc - s_loc;
                 gs = (uint64_t)(base + s_loc);
                 over = true;
-                if (mt && len <= TK_GLANE_MAX) {
-                    const bool in_lds = e_loc + 8u <= (uint32_t)TK2_WIN;
-                    const uint64_t key = in_lds ? tk_key_of_lds(raw, s_loc, len) : tk_key_of_text(text, gs, len);
-                    const unsigned long long ident = len <= 7u ? (key | ((unsigned long long)len << 56))
-                                                               : ((1ull << 63) | ((unsigned long long)len << 32) | (uint32_t)gs);
-                    // slot key: two independent 32-bit hashes of (bytes, length) -- equal bytes are verified anyway
-                    const uint32_t klo = (uint32_t)key, khi = (uint32_t)(key >> 32);
-                    uint32_t h1 = klo * 0x9E3779B1u + khi * 0x85EBCA77u + len * 0xC2B2AE3Du;
-                    h1 ^= h1 >> 15;
-                    h1 *= 0x27D4EB2Fu;
-                    uint32_t h2 = (klo ^ 0x5BD1E995u) * 0x165667B1u + (khi + len) * 0xD3A2646Du;
-                    h2 ^= h2 >> 13;
-                    unsigned long long kk = ((unsigned long long)h2 << 32) | h1;
-                    if (dbg & 512) kk &= 0xFFFull;  // test hook: force collisions between different pieces
-                    if (kk == TK_EMPTY_KEY) kk = 0;
-                    uint32_t i = ((uint32_t)kk ^ (uint32_t)(kk >> 40)) & mt_mask;
-                    for (int p = 0; p < TK_MT_PROBES; ++p) {
-                        const ulonglong2 ka = *(const ulonglong2*)&mt[i].key;
-                        unsigned long long cur = ka.x;
-                        if (cur == TK_EMPTY_KEY) cur = atomicCAS(&mt[i].key, TK_EMPTY_KEY, kk);
-                        if (cur == TK_EMPTY_KEY) {  // claimed: this occurrence is the one that gets merged
-                            __hip_atomic_store(&mt[i].aux, ident, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            *(uint2*)&out.data.tab[i].start = make_uint2((uint32_t)gs, len);
-                            ref = i;
-                            over = false;
-                            break;
-                        }
-                        if (cur == kk) {
-                            unsigned long long a = ka.y;
-                            if (a == TK_EMPTY_KEY) a = __hip_atomic_load(&mt[i].aux, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                            const bool same = len <= 7u ? a == ident
-                                                        : ((a >> 32) == (ident >> 32) &&
-                                                           (in_lds ? tk_equal_lds_text(raw, s_loc, text, (uint32_t)a, len)
-                                                                   : tk_equal_bytes(text, gs, text, (uint32_t)a, len)));
-                            if (a != TK_EMPTY_KEY && same) {
-                                ref = i;
-                                over = false;
-                                break;
-                            }
-                        }
-                        i = (i + 1) & mt_mask;
+                if (len > TK_XL_MAX && len <= T.max_token_len && (len > TK_GLANE_MAX || !mt)) {
+                    // (nobody else will ask whether it is a token: tk_k_bincount looks at table slots and overflow entries of at most TK_GLANE_MAX
+                    // bytes -- the latter is asked twice then, harmlessly)
+                    const uint32_t rk = tk_lookup_text_piece(T, text, gs, len);
+                    if (rk != TK_RANK_MAX) {
+                        out.res[run_base + k] = rk;
+                        over = false;
+                        k = TKF_NONE;  // (settled: a token after all)
                     }
                 }
             }
@@ -1440,33 +1383,15 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
                     if (len > TK_GLANE_MAX) tk_append_tree(out.listC, out.counters, ref, (uint32_t)gs, len);
                 }
             }
-            if (q < n_x) {
-                out.res[run_base + k] = ref != TKF_NONE ? (TK_RES_FLAG | ref) : 0u;
-                out.res[run_base + TKF_TAIL_REFS - (miss_total + q)] = ref;  // (TKF_NONE = 0xFFFFFFFF: counts as the one token 0 the result word holds; the batch is repeated with more room)
-            }
-            // its later occurrences in this workgroup's tiles are duplicates without a probe: the slot goes into the piece cache
-            if (use_hot && q < n_x && len <= TK_HOT_MAXLEN && ref != TKF_NONE && ref < out.data.ovf_base) {
-                uint32_t k0, k1, k2;
-                hot_key(s_loc, len, k0, k1, k2);
-                hot_insert(k0, k1, k2, len, TK_HOT_DUP | ref);
-            }
+            put_ref(k != TKF_NONE, k, ref);
         }
-        miss_total += n_x;
         __syncthreads();  // (the lists are reused by the next batch)
     }
     if (tid == 0 && np) {
-        out.res[run_base + TKF_TAIL_NMISS] = miss_total;
+        out.res[run_base + TKF_TAIL_NMISS] = ntail_sh;
         out.res[run_base + TKF_TAIL_NGAP] = GEN ? ngap_sh : 0u;
     }
     } while (PERSIST && (item += gridDim.x) < n_items);
-    if constexpr (HOT) {  // statistics of the piece cache (two fire-and-forget atomics per wavefront)
-        hot_probes = tk_wave_sum_u32(hot_probes);
-        hot_hits = tk_wave_sum_u32(hot_hits);
-        if (lane == 0 && hot_probes) {
-            __hip_atomic_fetch_add(&out.counters[TK_CNT_HOT_PROBE], hot_probes, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-            __hip_atomic_fetch_add(&out.counters[TK_CNT_HOT_HIT], hot_hits, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        }
-    }
 }
 
 // The distinct missed pieces -- the claimed slots of the miss table and the overflow entries behind them (TkMissData) -- have to be
@@ -1482,23 +1407,33 @@ __device__ __forceinline__ uint32_t tk_miss_entries(const uint32_t* __restrict__
     const uint32_t no = counters[TK_CNT_OVF];
     return ovf_base + (no < ovf_cap ? no : ovf_cap);
 }
-// length bin of entry i for lane (TK_NBIN: none -- a free slot, or a piece of more than TK_GLANE_MAX bytes, which is on the tree list)
-// (a table slot is read from the KEY table -- 16 bytes per slot, and its claimant's identity word holds the length -- so that the walk
+// The length bin of an entry (TK_NBIN: none -- a free slot, or a piece of more than TK_GLANE_MAX bytes, which is on the tree list)
+// (a table slot is read from the KEY table -- the last word of its 32 bytes: the claimant's identity holds the length -- so that the walk
 // over four million slots does not touch the 64-byte entries)
-__device__ __forceinline__ uint32_t tk_miss_bin(const TkMiss& data, const TkMissKey* __restrict__ mt, uint32_t i, uint32_t hi) {
-    if (i >= hi) return TK_NBIN;
-    uint32_t len;
+// Round 5: the front kernel sends every piece of more than TK_XL_MAX bytes here without a look at the vocabulary (2 % of the pieces, next to
+// none of them tokens).  Whether such a piece IS a token (src/lib.rs:367) is asked here, once per distinct piece: then its entry gets the
+// one token and the merge kernels never see it.
+// length (0: a free slot / no entry) and, for a piece of more than TK_XL_MAX bytes, start of entry i
+__device__ __forceinline__ uint32_t tk_miss_len(const TkMiss& data, const TkMissKey* __restrict__ mt, uint32_t i, uint32_t hi, uint32_t& start) {
+    start = 0;
+    if (i >= hi) return 0u;
     if (i < data.ovf_base) {
-        const ulonglong2 ka = *(const ulonglong2*)&mt[i].key;
-        if (ka.x == TK_EMPTY_KEY) return TK_NBIN;
-        len = (ka.y >> 63) ? ((uint32_t)(ka.y >> 32) & 0x7FFFFFFFu) : (uint32_t)(ka.y >> 56);
-    } else {
-        len = data.ovf[i - data.ovf_base].len;
+        const unsigned long long w2 = mt[i].w2;  // (written by whoever claimed the slot; ~0: nobody did -- or tk_k_bincount has found the piece to be a token)
+        if (w2 == TK_EMPTY_KEY) return 0u;
+        start = (uint32_t)w2;
+        return (w2 >> 63) ? ((uint32_t)(w2 >> 32) & 0x7FFFFFFFu) : (uint32_t)(w2 >> 56);
     }
-    return len > TK_GLANE_MAX ? (uint32_t)TK_NBIN : (uint32_t)tk_bin_of(len);
+    const uint2 sl = *(const uint2*)&data.ovf[i - data.ovf_base].start;
+    start = sl.x;
+    return sl.y;
 }
+__device__ __forceinline__ bool tk_miss_may_be_token(const TkTables& T, uint32_t len) { return len > TK_XL_MAX && len <= T.max_token_len && len <= TK_GLANE_MAX; }
+__device__ __forceinline__ uint32_t tk_miss_bin_of_len(uint32_t len) { return (len == 0u || len > TK_GLANE_MAX) ? (uint32_t)TK_NBIN : (uint32_t)tk_bin_of(len); }
 
-__global__ __launch_bounds__(256) void tk_k_bincount(TkMiss data, const TkMissKey* __restrict__ mt, uint32_t ovf_cap,
+// pass 1, and the look-up of the long pieces: a wavefront takes 256 entries at a time (four loads per lane in flight), a lane then looks its
+// candidates up one after the other (a wavefront has one or two among 256 slots); a piece that IS a token gets the token as its result and
+// its slot's identity word is wiped, so that pass 2 takes the slot for a free one (overflow entries are looked up again there: rare).
+__global__ __launch_bounds__(256) void tk_k_bincount(TkTables T, const uint8_t* __restrict__ text, TkMiss data, TkMissKey* mt, uint32_t ovf_cap,
                                                      const uint32_t* __restrict__ counters, uint32_t* __restrict__ wbin) {
     const uint32_t ovf_base = data.ovf_base;
     const uint32_t nwaves = gridDim.x * 4u;  // tk_k_binfill runs with the same grid: identical wave -> range mapping
@@ -1511,10 +1446,36 @@ __global__ __launch_bounds__(256) void tk_k_bincount(TkMiss data, const TkMissKe
     uint32_t nb[TK_NBIN];
 #pragma unroll
     for (int b = 0; b < TK_NBIN; ++b) nb[b] = 0;
-    for (uint32_t i0 = lo; i0 < hi; i0 += 64) {
-        const uint32_t bin = tk_miss_bin(data, mt, i0 + (uint32_t)lane, hi);
+    for (uint32_t i0 = lo; i0 < hi; i0 += 256) {
+        uint32_t len[4], start[4], cand = 0;
 #pragma unroll
-        for (int b = 0; b < TK_NBIN; ++b) nb[b] += (uint32_t)__popcll(__ballot(bin == (uint32_t)b));
+        for (int j = 0; j < 4; ++j) {
+            len[j] = tk_miss_len(data, mt, i0 + (uint32_t)j * 64u + (uint32_t)lane, hi, start[j]);
+            if (tk_miss_may_be_token(T, len[j])) cand |= 1u << j;
+        }
+        while (__ballot(cand != 0u)) {
+            if (cand) {
+                const uint32_t j = (uint32_t)__ffs((int)cand) - 1u;
+                cand &= cand - 1u;
+                const uint32_t st = j == 0u ? start[0] : (j == 1u ? start[1] : (j == 2u ? start[2] : start[3]));
+                const uint32_t ln = j == 0u ? len[0] : (j == 1u ? len[1] : (j == 2u ? len[2] : len[3]));
+                const uint32_t rk = tk_lookup_text_piece(T, text, st, ln);
+                if (rk != TK_RANK_MAX) {
+                    const uint32_t i = i0 + j * 64u + (uint32_t)lane;
+                    data.put(i, 1u, rk);
+                    if (i < ovf_base) mt[i].w2 = TK_EMPTY_KEY;
+#pragma unroll
+                    for (int jj = 0; jj < 4; ++jj)
+                        if (j == (uint32_t)jj) len[jj] = 0u;
+                }
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+            const uint32_t bin = tk_miss_bin_of_len(len[j]);
+#pragma unroll
+            for (int b = 0; b < TK_NBIN; ++b) nb[b] += (uint32_t)__popcll(__ballot(bin == (uint32_t)b));
+        }
     }
     if (lane == 0) {
 #pragma unroll
@@ -1524,7 +1485,7 @@ __global__ __launch_bounds__(256) void tk_k_bincount(TkMiss data, const TkMissKe
 
 // pass 2: wscan = exclusive scan of wbin (TK_NBIN * nwaves + 1 entries; the last one is the grand total).  listB[wscan[b * nwaves]...]
 // is bin b's list of data indices; its start and length go to the counters (TK_CNT_BOFF0 + b, TK_CNT_BIN0 + b) for the merge kernels.
-__global__ __launch_bounds__(256) void tk_k_binfill(TkMiss data, const TkMissKey* __restrict__ mt, uint32_t ovf_cap,
+__global__ __launch_bounds__(256) void tk_k_binfill(TkTables T, const uint8_t* __restrict__ text, TkMiss data, const TkMissKey* __restrict__ mt, uint32_t ovf_cap,
                                                     const uint32_t* __restrict__ wscan, uint32_t* __restrict__ listB, uint32_t* __restrict__ counters) {
     const uint32_t ovf_base = data.ovf_base;
     const int lane = threadIdx.x & 63;
@@ -1543,7 +1504,9 @@ __global__ __launch_bounds__(256) void tk_k_binfill(TkMiss data, const TkMissKey
     }
     for (uint32_t i0 = lo; i0 < hi; i0 += 64) {
         const uint32_t i = i0 + (uint32_t)lane;
-        const uint32_t bin = tk_miss_bin(data, mt, i, hi);
+        uint32_t start, len = tk_miss_len(data, mt, i, hi, start);
+        if (i >= ovf_base && tk_miss_may_be_token(T, len) && tk_lookup_text_piece(T, text, start, len) != TK_RANK_MAX) len = 0u;  // (pass 1 has given it its token)
+        const uint32_t bin = tk_miss_bin_of_len(len);
 #pragma unroll
         for (int b = 0; b < TK_NBIN; ++b) {
             const uint64_t m = __ballot(bin == (uint32_t)b);

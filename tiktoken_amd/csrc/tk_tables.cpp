@@ -152,11 +152,12 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
 
     // piece tables (bytes -> rank), split by length
     uint32_t max_rank = 0;
-    uint64_t n_short = 0, n_mid = 0, n_long = 0;
+    uint64_t n_short = 0, n_mid = 0, n_long = 0, n_xl = 0;
     for (uint64_t k = 0; k < n_ranks; ++k) {
         max_rank = std::max(max_rank, ranks_ids[k] == TK_RANK_MAX ? 0u : ranks_ids[k]);
         const uint64_t len = ranks_off[k + 1] - ranks_off[k];
         (len <= 4 ? n_short : (len <= 8 ? n_mid : n_long)) += 1;
+        if (len >= TK_XL_MIN && len <= TK_XL_MAX) ++n_xl;
     }
     for (uint64_t k = 0; k < n_spec; ++k) max_rank = std::max(max_rank, spec_ids[k]);
     if (max_rank >= 0x7FFFFFFFu)
@@ -181,6 +182,12 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
     T.piece_mask = cap - 1;
     T.piece.assign(cap, TkPieceSlot{TK_EMPTY_KEY, TK_RANK_MAX, 0});
     T.piece_off.assign(cap, 0);
+    {  // (load factor <= 0.4: three in five probes of this table are for pieces that are not tokens, and such a probe ends at a free slot)
+        uint64_t xcap = 64;
+        while (2 * xcap < 5 * n_xl + 2) xcap <<= 1;
+        T.xl_mask = (uint32_t)(xcap - 1);
+        T.xl.assign(xcap, TkXlSlot{~0ull, ~0ull, ~0ull, TK_RANK_MAX, 0u});
+    }
     for (int b = 0; b < 256; ++b) T.byte_rank[b] = TK_RANK_MAX;
     T.pair2.assign(65536, TK_RANK_MAX);
     {
@@ -191,7 +198,7 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
         if (T.dec_is_dense) T.dec_dense.assign((size_t)mr + 1, std::make_pair(0u, 0u));
         else T.dec_sparse.reserve(n_ranks * 2);
     }
-    uint64_t pr_short = 0, pr_mid = 0, pr_long = 0;
+    uint64_t pr_short = 0, pr_mid = 0, pr_long = 0, pr_xl = 0;
     for (uint64_t k = 0; k < n_ranks; ++k) {
         uint64_t o = ranks_off[k], len64 = ranks_off[k + 1] - o;
         if (len64 == 0) return "mergeable_ranks contains an empty key";
@@ -239,6 +246,21 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
             }
             T.piece[i] = TkPieceSlot{key, rank, len};
             T.piece_off[i] = (uint32_t)o;
+            if (len >= TK_XL_MIN && len <= TK_XL_MAX) {
+                uint64_t w0, w1, w2;
+                tk_ident([&](uint32_t at) {  // (eight bytes at offset `at`; what lies behind the token is masked away by tk_ident)
+                    uint64_t w = 0;
+                    memcpy(&w, p + at, at < len ? std::min<uint32_t>(8u, len - at) : 0u);
+                    return w;
+                }, len, 0u, w0, w1, w2);
+                uint32_t j = (uint32_t)tk_ident_hash(w0, w1, w2, true) & T.xl_mask;
+                ++pr_xl;
+                while (T.xl[j].rank != TK_RANK_MAX) {
+                    j = (j + 1) & T.xl_mask;
+                    ++pr_xl;
+                }
+                T.xl[j] = TkXlSlot{w0, w1, w2, rank, 0u};
+            }
         }
         if (len == 1) T.byte_rank[p[0]] = rank;
         if (len == 2) T.pair2[((uint32_t)p[0] << 8) | p[1]] = rank;
@@ -247,35 +269,13 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
     T.probes_short = n_short ? (double)pr_short / (double)n_short : 0;
     T.probes_mid = n_mid ? (double)pr_mid / (double)n_mid : 0;
     T.probes_long = n_long ? (double)pr_long / (double)n_long : 0;
+    T.probes_xl = n_xl ? (double)pr_xl / (double)n_xl : 0;
     for (int b = 0; b < 256; ++b)
         if (T.byte_rank[b] == TK_RANK_MAX)
             return "every single byte must be a key of mergeable_ranks (byte_pair_encode indexes ranks[piece] for "
                    "1-byte pieces, src/lib.rs:201-203)";
 
     lap("piece tables + decoder");
-    // Seed of the LDS piece cache (tk_common.h): tokens of up to TK_HOT_MAXLEN bytes in rank order -- a low rank is a frequent
-    // string of the training text -- each into the slot of its bytes while that slot is free.  The kernel replaces entries with
-    // the pieces its text really uses, so the seed only has to be a fair first guess.
-    if (TKF_HOT_BITS) {
-        T.hot.assign((size_t)TKF_HOT_SLOTS * 4, 0u);
-        std::vector<uint64_t> by_rank(n_ranks);
-        std::iota(by_rank.begin(), by_rank.end(), 0);
-        std::sort(by_rank.begin(), by_rank.end(), [&](uint64_t a, uint64_t b) { return ranks_ids[a] < ranks_ids[b]; });
-        for (uint64_t k : by_rank) {
-            const uint32_t len = (uint32_t)(ranks_off[k + 1] - ranks_off[k]), rank = ranks_ids[k];
-            if (len > TK_HOT_MAXLEN || rank >= TK_HOT_DUP) continue;
-            uint32_t kw[3] = {0, 0, 0};
-            memcpy(kw, ranks_blob + ranks_off[k], len);
-            uint32_t* e = &T.hot[(size_t)tk_hot_slot(kw[0], kw[1], kw[2]) * 4];
-            if (e[3]) continue;
-            e[0] = kw[0];
-            e[1] = kw[1];
-            e[2] = kw[2];
-            e[3] = (len << 28) | rank;
-            if (++T.n_hot == TKF_HOT_SLOTS) break;
-        }
-    }
-
     // pair table: all splits of all tokens into two vocabulary tokens (read-only lookups: split over host threads)
     std::vector<TkPairSlot> entries;
     {

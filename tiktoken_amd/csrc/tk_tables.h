@@ -25,15 +25,15 @@ struct TkHostTables {
     std::vector<TkPieceSlot> piece;      // tokens of more than 8 bytes
     std::vector<uint32_t> piece_off;
     uint64_t piece_mask = 0;
-    double probes_short = 0, probes_mid = 0, probes_long = 0;  // average slots inspected per stored token (build statistics)
+    std::vector<TkXlSlot> xl;            // tokens of TK_XL_MIN..TK_XL_MAX bytes once more, by identity (tk_common.h)
+    uint32_t xl_mask = 0;
+    double probes_short = 0, probes_mid = 0, probes_long = 0, probes_xl = 0;  // average slots inspected per stored token (build statistics)
     std::vector<TkPairSlot> pair;   // wide format (empty when packed)
     std::vector<uint64_t> pair8;    // packed format (empty when wide)
     uint64_t pair_mask = 0;
     uint64_t n_pairs = 0;
     std::vector<uint32_t> pair2;
     uint32_t byte_rank[256];
-    std::vector<uint32_t> hot;  // seed of the front kernel's LDS piece cache: TKF_HOT_SLOTS entries of four words (tk_common.h)
-    uint32_t n_hot = 0;         // tokens placed in it
     std::vector<uint8_t> spec_bytes;
     std::vector<uint32_t> spec_off, spec_id;
     uint32_t spec_first[8];
