@@ -296,9 +296,10 @@ class HostSim:
         return sim_lib().tks_lookup(self._h, b.ctypes.data, len(piece))
 
     def lookup_xl(self, piece: bytes, fill: int = 0):
-        """(rank or 0xFFFFFFFF, (w0, w1, w2, hash)) of the front kernel's identity lookup (pieces of 9..23 bytes; longer ones: identity only)."""
+        """(rank or 0xFFFFFFFF, (w0, w1, w2, hash, filter bit)) of the front kernel's identity lookup (pieces of 9..23 bytes; longer ones: identity
+        and whether the filter of the long tokens lets them through)."""
         b = np.frombuffer(piece, np.uint8) if piece else np.zeros(1, np.uint8)
-        ident = np.zeros(4, np.uint64)
+        ident = np.zeros(5, np.uint64)
         r = sim_lib().tks_lookup_xl(self._h, b.ctypes.data, len(piece), fill, ident.ctypes.data)
         return r, tuple(int(x) for x in ident)
 

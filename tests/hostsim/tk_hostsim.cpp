@@ -99,6 +99,7 @@ void* tks_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, const uin
     D.piece_mask = H.piece_mask;
     D.xl = H.xl.data();
     D.xl_mask = H.xl_mask;
+    D.xfilter = H.xfilter.data();
     D.max_token_len = H.max_token_len;
     D.tok_bytes = H.tok_bytes.data();
     D.pair = H.pair8.empty() ? H.pair.data() : nullptr;
@@ -131,6 +132,7 @@ uint64_t tks_tables_digest(void* p) {
     for (const TkPieceSlot& e : H.piece) { mix(&e.key, 8); mix(&e.rank, 4); mix(&e.len, 4); }
     mix(H.piece_off.data(), H.piece_off.size() * 4);
     for (const TkXlSlot& e : H.xl) { mix(&e.w0, 8); mix(&e.w1, 8); mix(&e.w2, 8); mix(&e.rank, 4); }
+    mix(H.xfilter.data(), H.xfilter.size() * 4);
     mix(H.pair8.data(), H.pair8.size() * 8);
     for (const TkPairSlot& e : H.pair) { mix(&e.key, 8); mix(&e.rank, 4); }
     mix(H.pair2.data(), H.pair2.size() * 4);
@@ -163,7 +165,11 @@ uint32_t tks_lookup_xl(void* p, const uint8_t* piece, uint32_t len, uint8_t fill
     uint64_t w0, w1, w2;
     tk_ident([&](uint32_t o) { return tk_load8(text.data(), o); }, len, 0u, w0, w1, w2);
     if (ident4) {
-        ident4[0] = w0; ident4[1] = w1; ident4[2] = w2; ident4[3] = tk_ident_hash(w0, w1, w2, len <= TK_XL_MAX);
+        uint64_t hh = tk_ident_hash(w0, w1, w2, len <= TK_XL_MAX);
+        ident4[0] = w0; ident4[1] = w1; ident4[2] = w2; ident4[3] = hh;
+        if (hh == TK_EMPTY_KEY) hh = 0;
+        const uint32_t bit = tk_xfilter_bit(hh);
+        ident4[4] = (s->T.xfilter[bit >> 5] >> (bit & 31u)) & 1u;  // (means something for pieces of more than TK_XL_MAX bytes)
     }
     if (len < TK_XL_MIN || len > TK_XL_MAX) return TK_RANK_MAX;
     return tk_probe_xl(s->T, w0, w1, w2);

@@ -187,6 +187,11 @@ def test_identity_lookup_of_long_pieces_is_exact(sims, name):
                 _, idv = sim.lookup_xl(v, 0xA5)
                 assert ids.setdefault(idv[:3], v) == v
                 assert idv[2] >> 56 == len(v)
+    # tokens of more than 23 bytes pass the filter tk_k_bincount asks before it looks a piece up; few other strings do
+    longs = [t for t in ranks if len(t) > 23]
+    assert all(sim.lookup_xl(t, int(rng.integers(0, 256)))[1][4] == 1 for t in longs[:4000])
+    passed = sum(sim.lookup_xl(bytes(rng.integers(0, 256, int(rng.integers(24, 200)), dtype=np.uint8)), 0)[1][4] for _ in range(4000))
+    assert passed < 400, passed
     for L in (24, 25, 31, 32, 33, 100, 1024):
         v = bytes(rng.integers(0, 256, L, dtype=np.uint8))
         r, idv = sim.lookup_xl(v, 7)

@@ -114,7 +114,7 @@ struct tk_core {
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
     TkHostTables H;
     TkTables D;  // device view
-    Buf t_stage1, t_stage2, t_byte_tab, t_short, t_mid, t_dec, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_xl, t_spec_bytes, t_spec_off, t_spec_id;
+    Buf t_stage1, t_stage2, t_byte_tab, t_short, t_mid, t_dec, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_xl, t_xfilter, t_spec_bytes, t_spec_off, t_spec_id;
     uint32_t spec_max_len = 0;
     bool has_rx = false;  // the pat_str runs on the generic engine (tk_regex_kernels.h)
     bool has_rx_fb = false;  // a pat_str of the scanner families, compiled for the generic engine as well: the way out of stretches without certain starts (stage_deferred)
@@ -410,6 +410,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     if ((rc = upload(c->t_pair2, H.pair2.data(), H.pair2.size() * 4))) return bail(rc);
     if ((rc = upload(c->t_byte_rank, H.byte_rank, sizeof H.byte_rank))) return bail(rc);
     if ((rc = upload(c->t_xl, H.xl.data(), H.xl.size() * sizeof(TkXlSlot)))) return bail(rc);
+    if ((rc = upload(c->t_xfilter, H.xfilter.data(), H.xfilter.size() * 4))) return bail(rc);
     if ((rc = upload(c->t_spec_bytes, H.spec_bytes.data(), H.spec_bytes.size()))) return bail(rc);
     if ((rc = upload(c->t_spec_off, H.spec_off.data(), H.spec_off.size() * 4))) return bail(rc);
     if ((rc = upload(c->t_spec_id, H.spec_id.data(), H.spec_id.size() * 4))) return bail(rc);
@@ -435,6 +436,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     D.byte_rank = c->t_byte_rank.as<uint32_t>();
     D.xl = c->t_xl.as<TkXlSlot>();
     D.xl_mask = H.xl_mask;
+    D.xfilter = c->t_xfilter.as<uint32_t>();
     D.spec_bytes = c->t_spec_bytes.as<uint8_t>();
     D.spec_off = c->t_spec_off.as<uint32_t>();
     D.spec_id = c->t_spec_id.as<uint32_t>();
@@ -503,7 +505,7 @@ extern "C" void tk_destroy(tk_core* c) {
     (void)hipSetDevice(c->device);
     for (Buf* b : {&c->t_rx_ins, &c->t_rx_sets, &c->t_rx_ranges, &c->t_rx_first, &c->t_rx_s1, &c->t_rx_s2, &c->t_rx_dtrans, &c->t_rx_dascii, &c->t_rx_ds1, &c->t_rx_ds2}) release(*b);
     for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_dec, &c->d_tok, &c->d_lens, &c->d_bsum, &c->d_tboff, &c->d_bytes, &c->d_bytes_alt, &c->d_boff, &c->t_piece,
-                   &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2, &c->t_byte_rank, &c->t_xl, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off,
+                   &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2, &c->t_byte_rank, &c->t_xl, &c->t_xfilter, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off,
                    &c->out_tokens, &c->out_tok_off, &c->out_tokens_alt, &c->out_tok_off_alt, &c->allowed, &c->tok_bases})
         release(*b);
     if (c->h_probe) (void)hipHostFree(c->h_probe);
@@ -899,7 +901,7 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
         const uint64_t n_entries = (uint64_t)job.ovf_base + job.ovf_cap;
         const uint32_t dd_blocks = grid_for(n_entries, 4 * 256, TKD_WAVES / 4);
         TRY(timed(c, s, "tk_k_bincount", [&] {
-            hipLaunchKernelGGL(tk_k_bincount, dim3(dd_blocks), dim3(256), 0, s, T, d_text, data, job.mt, job.ovf_cap, counters, wbin);
+            hipLaunchKernelGGL(tk_k_bincount, dim3(dd_blocks), dim3(256), 0, s, T, d_text, data, job.mt, job.ovf_cap, counters, wbin, (c->dbg & 512) ? 0 : 1);
         }));
         TRY(scan_u32(c, w, s, wbin, (uint64_t)TK_NBIN * dd_blocks * 4 + 1, w.total.as<uint64_t>()));
         TRY(timed(c, s, "tk_k_binfill", [&] {

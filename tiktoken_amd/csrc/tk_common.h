@@ -156,7 +156,11 @@ struct TkTables {
                              // (the family's table for the stock patterns; derived per pattern otherwise: tk_pattern.cpp)
     const struct TkXlSlot* xl;  // [xl_mask+1] tokens of TK_XL_MIN..TK_XL_MAX bytes once more, 32-byte slots that hold the bytes (below)
     uint32_t xl_mask;
+    const uint32_t* xfilter;    // [TK_XFILTER_BITS / 32] bit tk_xfilter_bit(hash of the identity) of every token of more than TK_XL_MAX bytes: a
+                                // piece whose bit is clear is not such a token (tk_k_bincount asks before it looks one up)
 };
+#define TK_XFILTER_BITS (1u << 20)
+TK_HD uint32_t tk_xfilter_bit(uint64_t ident_hash) { return (uint32_t)(ident_hash >> 32) & (TK_XFILTER_BITS - 1u); }
 
 TK_HD uint64_t tk_mix64(uint64_t x) {
     x ^= x >> 32;

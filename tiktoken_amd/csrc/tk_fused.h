@@ -1433,8 +1433,10 @@ __device__ __forceinline__ uint32_t tk_miss_bin_of_len(uint32_t len) { return (l
 // pass 1, and the look-up of the long pieces: a wavefront takes 256 entries at a time (four loads per lane in flight), a lane then looks its
 // candidates up one after the other (a wavefront has one or two among 256 slots); a piece that IS a token gets the token as its result and
 // its slot's identity word is wiped, so that pass 2 takes the slot for a free one (overflow entries are looked up again there: rare).
+// Before a table slot's piece is looked up, the filter of the long tokens is asked with the hash the slot was claimed under (use_filter = 0:
+// the test hook that truncates those hashes is on): one in sixty of the candidates passes.
 __global__ __launch_bounds__(256) void tk_k_bincount(TkTables T, const uint8_t* __restrict__ text, TkMiss data, TkMissKey* mt, uint32_t ovf_cap,
-                                                     const uint32_t* __restrict__ counters, uint32_t* __restrict__ wbin) {
+                                                     const uint32_t* __restrict__ counters, uint32_t* __restrict__ wbin, int use_filter) {
     const uint32_t ovf_base = data.ovf_base;
     const uint32_t nwaves = gridDim.x * 4u;  // tk_k_binfill runs with the same grid: identical wave -> range mapping
     const int lane = threadIdx.x & 63;
@@ -1450,8 +1452,16 @@ __global__ __launch_bounds__(256) void tk_k_bincount(TkTables T, const uint8_t* 
         uint32_t len[4], start[4], cand = 0;
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-            len[j] = tk_miss_len(data, mt, i0 + (uint32_t)j * 64u + (uint32_t)lane, hi, start[j]);
-            if (tk_miss_may_be_token(T, len[j])) cand |= 1u << j;
+            const uint32_t i = i0 + (uint32_t)j * 64u + (uint32_t)lane;
+            len[j] = tk_miss_len(data, mt, i, hi, start[j]);
+            if (tk_miss_may_be_token(T, len[j])) {
+                bool pass = true;
+                if (use_filter && i < ovf_base) {
+                    const uint32_t bit = tk_xfilter_bit(mt[i].key);
+                    pass = (T.xfilter[bit >> 5] >> (bit & 31u)) & 1u;
+                }
+                if (pass) cand |= 1u << j;
+            }
         }
         while (__ballot(cand != 0u)) {
             if (cand) {

@@ -76,6 +76,20 @@ __device__ __forceinline__ uint32_t tk_row16_sum(uint32_t v) {  // sum over the 
     return v;
 }
 // inclusive prefix sum across the wave
+// inclusive prefix sum over the wavefront: four DPP row shifts inside the rows of sixteen lanes, then the last lane of a row to the rows
+// behind it (row_bcast:15 to rows 1 and 3, row_bcast:31 to rows 2 and 3) -- six full-rate instructions (round 4: six __shfl_up, each a
+// ds_bpermute through the LDS crossbar plus a compare and a select)
+#ifndef TK_SCAN_SHFL
+__device__ __forceinline__ uint32_t tk_wave_scan_u32(uint32_t v, int /*lane*/) {
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1 (a lane without a source adds nothing)
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x112, 0xF, 0xF, true);   // row_shr:2
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x114, 0xF, 0xF, true);   // row_shr:4
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x118, 0xF, 0xF, true);   // row_shr:8
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x142, 0xA, 0xF, false);  // row_bcast:15 -> rows 1, 3
+    v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x143, 0xC, 0xF, false);  // row_bcast:31 -> rows 2, 3
+    return v;
+}
+#else
 __device__ __forceinline__ uint32_t tk_wave_scan_u32(uint32_t v, int lane) {
 #pragma unroll
     for (int o = 1; o < 64; o <<= 1) {
@@ -84,6 +98,7 @@ __device__ __forceinline__ uint32_t tk_wave_scan_u32(uint32_t v, int lane) {
     }
     return v;
 }
+#endif
 // block-wide (256 threads) exclusive scan; returns the exclusive prefix, *total gets the block sum
 __device__ __forceinline__ uint32_t tk_block_exscan_256(uint32_t v, uint32_t* total, uint32_t* sh /*[8]*/) {
     int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;

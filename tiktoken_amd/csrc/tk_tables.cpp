@@ -187,6 +187,7 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
         while (2 * xcap < 5 * n_xl + 2) xcap <<= 1;
         T.xl_mask = (uint32_t)(xcap - 1);
         T.xl.assign(xcap, TkXlSlot{~0ull, ~0ull, ~0ull, TK_RANK_MAX, 0u});
+        T.xfilter.assign(TK_XFILTER_BITS / 32, 0u);
     }
     for (int b = 0; b < 256; ++b) T.byte_rank[b] = TK_RANK_MAX;
     T.pair2.assign(65536, TK_RANK_MAX);
@@ -246,13 +247,19 @@ std::string tk_build_tables(const uint8_t* ranks_blob, const uint64_t* ranks_off
             }
             T.piece[i] = TkPieceSlot{key, rank, len};
             T.piece_off[i] = (uint32_t)o;
+            uint64_t w0, w1, w2;
+            tk_ident([&](uint32_t at) {  // (eight bytes at offset `at`; what lies behind the token is masked away by tk_ident)
+                uint64_t w = 0;
+                memcpy(&w, p + at, at < len ? std::min<uint32_t>(8u, len - at) : 0u);
+                return w;
+            }, len, 0u, w0, w1, w2);
+            if (len > TK_XL_MAX) {
+                uint64_t hh = tk_ident_hash(w0, w1, w2, false);
+                if (hh == TK_EMPTY_KEY) hh = 0;  // (as the front kernel stores it)
+                const uint32_t bit = tk_xfilter_bit(hh);
+                T.xfilter[bit >> 5] |= 1u << (bit & 31u);
+            }
             if (len >= TK_XL_MIN && len <= TK_XL_MAX) {
-                uint64_t w0, w1, w2;
-                tk_ident([&](uint32_t at) {  // (eight bytes at offset `at`; what lies behind the token is masked away by tk_ident)
-                    uint64_t w = 0;
-                    memcpy(&w, p + at, at < len ? std::min<uint32_t>(8u, len - at) : 0u);
-                    return w;
-                }, len, 0u, w0, w1, w2);
                 uint32_t j = (uint32_t)tk_ident_hash(w0, w1, w2, true) & T.xl_mask;
                 ++pr_xl;
                 while (T.xl[j].rank != TK_RANK_MAX) {

@@ -27,6 +27,7 @@ struct TkHostTables {
     uint64_t piece_mask = 0;
     std::vector<TkXlSlot> xl;            // tokens of TK_XL_MIN..TK_XL_MAX bytes once more, by identity (tk_common.h)
     uint32_t xl_mask = 0;
+    std::vector<uint32_t> xfilter;       // which identity hashes tokens of more than TK_XL_MAX bytes have (tk_common.h)
     double probes_short = 0, probes_mid = 0, probes_long = 0, probes_xl = 0;  // average slots inspected per stored token (build statistics)
     std::vector<TkPairSlot> pair;   // wide format (empty when packed)
     std::vector<uint64_t> pair8;    // packed format (empty when wide)
