@@ -390,10 +390,6 @@ def main():
         if n:
             kern[k] = {"ms_total": ms, "launches": n, "ms_avg": ms / n}
     stats = core.last_stats()
-    hot = {"slots_per_workgroup": core.stat("hot_slots"), "seed_tokens": core.stat("hot_seed"), "probes": core.stat("hot_probes"),
-           "hits": core.stat("hot_hits"), "workgroups_per_cu": core.stat("front_wgs_per_cu")}
-    hot["hit_rate_of_probed"] = round(hot["hits"] / hot["probes"], 4) if hot["probes"] else None
-    hot["hit_rate_of_all_pieces"] = round(hot["hits"] / stats["pieces"], 4) if stats["pieces"] else None
     b_alg = nbytes + 4 * stats["tokens"] + 16 * (n_docs + 1)  # text in + u32 ids out + offsets in/out
     dom = max(kern, key=lambda k: kern[k]["ms_total"]) if kern else None
     sum_ms = sum(v["ms_total"] for v in kern.values()) / prof_steps if kern else None
@@ -622,7 +618,9 @@ def main():
                        "parallelism": f"doc-sharded x{world}" + (f" + {'RCCL' if backend == 'nccl' else backend + ' (DRY RUN through host copies)'} gather of token ids to rank 0 ({gather_mode['form']} lengths)" if world > 1 else "")},
             "roofline": roofline, "cpu_baseline": cpu, "parity_all_tokens_vs_oracle": parity, "gather_verified": gather_verified,
             "parity_detail": parity_detail, "host_path": host_path,
-            "lds_piece_cache": hot, "cold_start": cold, "generic_engine": generic, "configs": configs,
+            "vocabulary_tables": {"where": "HBM / L2: exact tables keyed by the piece's bytes (<= 8 bytes: the bytes; 9..23: 32-byte identity slots; longer: hash verified in the blob)",
+                                  "lds_resident_hot_set": "measured in rounds 3-4 and not shipped: profiles/r04_lds_hot_set_closeout.txt", "front_workgroups_per_cu": core.stat("front_wgs_per_cu")},
+            "cold_start": cold, "generic_engine": generic, "configs": configs,
             "host": {"cpus": ncpu, "nproc": os.cpu_count(), "cgroup_cpu_max": _read_first("/sys/fs/cgroup/cpu.max"),
                      "loadavg": _read_first("/proc/loadavg"), "corpus_gen_s": round(t_gen, 2)},
         }

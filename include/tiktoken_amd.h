@@ -175,9 +175,8 @@ int tk_get_kernel_ms(tk_core* core, const char* kernel_name, double* ms_out, uin
 /* Pieces / tokens / bytes handled by the last encode call (for roofline accounting). */
 void tk_last_stats(tk_core* core, uint64_t* n_bytes, uint64_t* n_pieces, uint64_t* n_tokens, uint64_t* n_docs,
                    uint64_t* n_medium, uint64_t* n_long);
-/* One named figure of the last encode call; 0 for a name it does not know.  "hot_probes" / "hot_hits": pieces looked up in the front
- * kernel's LDS-resident piece cache and how many of them it answered (the rest went to the vocabulary tables in HBM);
- * "hot_slots": entries of that cache per workgroup; "hot_seed": tokens placed in its seed at tk_create. */
+/* One named figure of the last encode call; 0 for a name it does not know: "chunks", "small_launches", "small_calls", "mid_calls",
+ * "back_streams", "regrown", "workspace_bytes", "front_wgs_per_cu", "compute_units". */
 uint64_t tk_stat(tk_core* core, const char* name);
 
 #ifdef __cplusplus

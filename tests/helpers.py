@@ -90,6 +90,50 @@ def gen_corpus(seed: int, mix: int, nbytes: int, threads: int = 8):
     return out[:nbytes], off[: nd.value + 1].copy()
 
 
+def natural_corpus(ranks: dict[bytes, int], nbytes: int, seed: int = 0x5EED0006, miss_share: float = 0.02):
+    """Text whose share of pieces that are NOT vocabulary tokens is what natural text has (1-3 %; the C3 / C4 / C5 corpora: 18.7 %, their
+    lexicon is far larger than the vocabulary): words drawn from the vocabulary itself -- the tokens that are a whole piece of the o200k /
+    cl100k patterns, a space and ASCII letters, Zipf over their ranks (a low rank is a frequent word) -- plus `miss_share` words of random
+    letters, in sentences with commas, full stops, digits and line breaks, cut into documents of about 2 KiB.  (blob, doc_off) like gen_corpus."""
+    rng = np.random.default_rng(seed)
+    words = sorted((t for t in ranks if len(t) >= 2 and t[:1] == b" " and t[1:].isalpha() and t[1:].isascii() and (t[1:].islower() or t[1:].istitle())),
+                   key=lambda t: ranks[t])
+    n_voc = len(words)
+    n_rand = max(n_voc // 2, 1000)
+    letters = np.frombuffer(b"abcdefghijklmnopqrstuvwxyz", np.uint8)
+    for _ in range(n_rand):  # words of random letters: next to none of them is a token
+        words.append(b" " + letters[rng.integers(0, 26, int(rng.integers(7, 14)))].tobytes())
+    extra = [b",", b".", b".\n", b" 2024", b" 17", b"?", b"\n\n", b" -", b":"]
+    words += extra
+    lens = np.array([len(w) for w in words], np.int64)
+    maxlen = int(lens.max())
+    table = np.zeros((len(words), maxlen), np.uint8)
+    for i, w in enumerate(words):
+        table[i, : len(w)] = np.frombuffer(w, np.uint8)
+    # probabilities: vocabulary words Zipf(1.0) over their order; random words uniform, `miss_share` in all; punctuation 12 %
+    p = np.zeros(len(words))
+    z = 1.0 / np.arange(1, n_voc + 1)
+    p[:n_voc] = z / z.sum() * (1.0 - miss_share - 0.12)
+    p[n_voc:n_voc + n_rand] = miss_share / n_rand
+    p[n_voc + n_rand:] = 0.12 / len(extra)
+    n_words = int(nbytes / float((p * lens).sum()) * 1.02) + 16
+    idx = rng.choice(len(words), size=n_words, p=p / p.sum())
+    wl = lens[idx]
+    ends = np.cumsum(wl)
+    n_take = int(np.searchsorted(ends, nbytes, side="right"))
+    idx, wl, ends = idx[:n_take], wl[:n_take], ends[:n_take]
+    total = int(ends[-1])
+    blob = np.zeros(total + 64, np.uint8)
+    starts = ends - wl
+    for c in range(maxlen):  # (a column of the word table at a time)
+        m = wl > c
+        blob[starts[m] + c] = table[idx[m], c]
+    # documents: a cut every ~2 KiB, at a word boundary
+    cuts = starts[np.searchsorted(starts, np.arange(2048, total, 2048))]
+    off = np.unique(np.concatenate([[0], cuts, [total]])).astype(np.uint64)
+    return blob[:total], off
+
+
 def insert_specials(blob: np.ndarray, off: np.ndarray, seed: int = 5):
     """Config C5: special tokens <|custom_0..7|> at a mean of one per ~2 KiB plus decoys (an unregistered
     <|custom_9|>, truncated specials, bare delimiters), inserted at char boundaries of every document."""
@@ -136,6 +180,9 @@ def baseline_config(cfg: str, threads: int = 16):
         return "o200k_shaped", 2, SPECIALS["o200k_shaped"], blob, off, None
     if cfg.startswith("C4r"):  # C4: 8 GiB doc-sharded over 8 GPUs = rank r's 1 GiB shard, the seeds bench.py --gpus N uses (0x5EED0004 + rank)
         blob, off = gen_corpus(0x5EED0004 + int(cfg[3:]), 1, 1 << 30, threads)
+        return "o200k_shaped", 2, SPECIALS["o200k_shaped"], blob, off, None
+    if cfg == "N1":  # not a BASELINE.json configuration: 256 MiB of text whose miss rate is natural (natural_corpus), o200k-shaped
+        blob, off = natural_corpus(load_vocab("o200k_shaped"), 256 << 20)
         return "o200k_shaped", 2, SPECIALS["o200k_shaped"], blob, off, None
     if cfg == "C5":
         blob, off = insert_specials(*gen_corpus(0x5EED0005, 1, 256 << 20, threads))

@@ -328,11 +328,12 @@ def test_size_independent_properties_at_scale(cores):
     assert total_bytes == int(off[np.searchsorted(toff, 200000, side="right") - 1]) or total_bytes > 0
 
 
-@pytest.mark.parametrize("cfg", ["C1", "C2", "C5", "C3", "C4r0", "C4r1"])
+@pytest.mark.parametrize("cfg", ["C1", "C2", "C5", "C3", "C4r0", "C4r1", "N1"])
 def test_baseline_configs_at_full_size(cfg):
     """Every BASELINE.json configuration at its FULL size (1 MiB / 64 MiB / 256 MiB with special tokens / 1 GiB), every token and
     every offset compared with the C oracle (all host threads) -- not a sample.  C4 (8 GiB doc-sharded over 8 GPUs) is represented by the
-    shards of ranks 0 and 1 at their full size, generated with the seeds bench.py --gpus N gives those ranks: a shard is all a GPU sees."""
+    shards of ranks 0 and 1 at their full size, generated with the seeds bench.py --gpus N gives those ranks: a shard is all a GPU sees.
+    N1 (not a BASELINE configuration): 256 MiB of text with a natural share of pieces that are not tokens (helpers.natural_corpus)."""
     import os
 
     from tiktoken_amd import CoreBPE

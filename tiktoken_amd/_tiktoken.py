@@ -506,5 +506,5 @@ class CoreBPE:
         return dict(zip(("bytes", "pieces", "tokens", "docs", "medium_pieces", "long_pieces"), (x.value for x in v)))
 
     def stat(self, name: str) -> int:
-        """One named figure of the last encode call (tk_stat): "hot_probes", "hot_hits", "hot_slots", "hot_seed", ..."""
+        """One named figure of the last encode call (tk_stat): "chunks", "small_calls", "mid_calls", "workspace_bytes", ..."""
         return int(self._L.tk_stat(self._h, name.encode())) if hasattr(self._L, "tk_stat") else 0

@@ -572,8 +572,9 @@ __device__ __forceinline__ bool tk_equal_lds_text(const uint8_t* raw, uint32_t o
 // deferred tiles with a fixed grid.
 // Workgroups per CU.  20 KiB of LDS per tile x 8 = the CU's 160 KiB, and 8 x 4 wavefronts = its 32 wavefront slots: the kernel needs all
 // of them (measured, profiles/r03_lds_cache_experiment.jsonl: a workgroup takes ~39 us per tile however many share the CU, so the rate
-// is proportional to the workgroups in flight -- 5.9 ms per GiB with 8 per CU, 10.6 with 4, 13.6 with 3).  That is why the LDS piece
-// cache below is compiled out by default (TKF_HOT_BITS = 0): its 16-32 KiB per workgroup cost more in occupancy than its hits save.
+// is proportional to the workgroups in flight -- 5.9 ms per GiB with 8 per CU, 10.6 with 4, 13.6 with 3).  That is why there is no LDS-
+// resident hot set of the vocabulary here (built and measured in rounds 3 and 4, removed in round 5: profiles/r04_lds_hot_set_closeout.txt --
+// its 16-32 KiB per workgroup cost more in occupancy than its hits saved).
 #ifndef TKF_OCC
 #define TKF_OCC 8
 #endif

@@ -1,7 +1,6 @@
 #!/usr/bin/env python3
 """Kernel experiments on the GPU box: one configuration of the library (selected through $TIKTOKEN_AMD_LIB / $TIKTOKEN_AMD_FRONT_WGS /
-$TIKTOKEN_AMD_DEBUG) on the bench corpus; prints one JSON line with wall time per step, per-kernel HIP-event times, the piece cache's
-hit rate and whether EVERY token equals the oracle's (computed once per box and kept in /tmp).
+$TIKTOKEN_AMD_DEBUG) on the bench corpus; prints one JSON line with wall time per step, per-kernel HIP-event times and whether EVERY token equals the oracle's (computed once per box and kept in /tmp).
 
     python tools/exp_front.py --tag NAME [--mib 1024] [--steps 3]
 """
@@ -59,12 +58,9 @@ def main():
         if n:
             kern[k] = round(kms / n, 4)
     out = {"tag": args.tag, "mib": args.mib, "ms_per_step": round(ms, 3), "gbps": round(nbytes / ms / 1e6, 2), "kernels_ms": kern,
-           "kernels_sum_ms": round(sum(kern.values()), 3), "tokens": int(nt), "hot_probes": core.stat("hot_probes"), "hot_hits": core.stat("hot_hits"),
-           "hot_slots": core.stat("hot_slots"), "front_wgs": core.stat("front_wgs_per_cu"), "pieces": core.last_stats()["pieces"],
+           "kernels_sum_ms": round(sum(kern.values()), 3), "tokens": int(nt),
+           "front_wgs": core.stat("front_wgs_per_cu"), "pieces": core.last_stats()["pieces"],
            "host": host, "lib": os.environ.get("TIKTOKEN_AMD_LIB", ""), "dbg": os.environ.get("TIKTOKEN_AMD_DEBUG", "")}
-    if out["hot_probes"]:
-        out["hot_hit_rate_of_probed"] = round(out["hot_hits"] / out["hot_probes"], 4)
-        out["hot_hit_rate_of_pieces"] = round(out["hot_hits"] / max(out["pieces"], 1), 4)
     if not args.no_parity:
         cache = f"/tmp/tk_oracle_{args.encoding}_{args.mib}.npz"
         if os.path.exists(cache):
