@@ -26,6 +26,8 @@
 // with integer flags instead of short-circuit control flow; and same-address returning atomics run at only
 // 25..130 M/s on this multi-XCD part, so nothing on the path allocates through a global counter.
 #pragma once
+#include <type_traits>
+
 #include "tk_chunk.h"
 #include "tk_kernels.h"
 
@@ -2551,7 +2553,7 @@ __global__ __launch_bounds__(TKB_THREADS) void tk_k_merge_rounds_wide(TkTables T
 #define TKP_ROWS_COUNT 3
 #endif
 #ifndef TKP_ROWS_PLACE
-#define TKP_ROWS_PLACE 3
+#define TKP_ROWS_PLACE 1
 #endif
 
 // tile_nt[t] <- tokens of tile t = its pieces - its gap chars + what its pieces that are not tokens have beyond one token each; total[1] +=
@@ -2622,157 +2624,207 @@ __global__ __launch_bounds__(256) void tk_k_count_tiles(uint64_t ntiles, const u
     }
 }
 
-// tile_tb = exclusive scan of tile_nt.  One wavefront per tile at a time, TKP_ROWS_PLACE rows in flight: the result words, then the heads of
-// the missed pieces' entries {count, first token}, then row by row: single tokens go out as one 16-byte store per lane; a missed
-// piece's other tokens come from its entry (three 16-byte loads at most: the line is in the cache, the head came from it); what does
-// not fit an entry -- more than TKD_INLINE tokens, overflow entries -- is copied from the staging area by 32 lanes per piece.
-#ifndef TKP_PLACE_OCC
-#define TKP_PLACE_OCC 1
+// tile_tb = exclusive scan of tile_nt.  One wavefront per tile at a time, 256 * ROWS pieces per step.  Round 5, rebuilt twice over:
+//  * the pieces that are not single tokens -- a fifth of them on web text, and gap chars -- are taken out of the rows into a LIST (in
+//    piece order) and handled by dense lanes: head {count, first token} and the entry's next sixteen bytes in one go, a prefix sum of
+//    `count - 1` over the list, the tokens to their place.  A piece's place is its index plus the sum of `count - 1` over the listed pieces
+//    before it, so the single tokens of the rows need nothing but that sum (an LDS word the dense lanes leave).  Round 4 kept four pieces
+//    per lane and row side by side: twelve head loads, twelve entry loads and twelve times thirteen predicated stores per lane and step,
+//    115 registers;
+//  * a tile's tokens are put together in LDS and leave in whole lines when there are at most TKP_STAGE of them (a tile of web text has
+//    ~900; other tiles write them lane by lane as before): a lane's own stores are 4 bytes every 16, each wavefront instruction a
+//    partial write of sixteen lines -- 136 M write requests per GiB where the tokens need 16 M (TCP_TCC_WRITE_REQ, profiles/r04_sq_counters.csv).
+// 1.21 -> 0.78 ms per GiB.  Neither half alone moved it (the list without the staging: 1.14 ms; round 4's kernel with every store sent to one
+// 4 KiB window: 1.06), nor did more rows in flight or a staging per step, which loads every head twice (0.97): profiles/r05_place_experiments.txt.
+#ifndef TKP_STAGE
+#define TKP_STAGE 1024
 #endif
 template <int ROWS>
-__global__ __launch_bounds__(256, TKP_PLACE_OCC) void tk_k_place(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_tb,
+__global__ __launch_bounds__(256) void tk_k_place(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_tb,
                                                   const uint32_t* __restrict__ res, TkMiss data, const uint32_t* __restrict__ staging, uint32_t* __restrict__ out_all,
                                                   const unsigned long long* __restrict__ tok_base, uint32_t* __restrict__ big,
                                                   uint32_t* __restrict__ row_abs /* [tile * 16 + r]: tokens of the chunk before row r of the tile (for tk_k_docoff) */) {
-    __shared__ uint32_t mlist_sh[4][256 * 3];
+    constexpr uint32_t CAP = 256u * ROWS, SCAP = (uint32_t)TKP_STAGE;
+    __shared__ __attribute__((aligned(16))) uint32_t stage_sh[4][SCAP + 4];
+    __shared__ uint32_t ref_sh[4][CAP];  // the listed pieces' result words, in piece order
+    __shared__ uint32_t cum_sh[4][CAP];  // sum of `count - 1` over the list up to and including each of them
+    __shared__ uint16_t idx_sh[4][CAP];  // their index among the step's pieces
     // the chunk's tokens follow those of the chunks before it: their number stays on the device (chunks are pipelined, the host does
     // not know it when it queues this kernel)
     uint32_t* __restrict__ out = out_all + tok_base[0];
     const int lane = threadIdx.x & 63;
-    uint32_t* mlist = mlist_sh[threadIdx.x >> 6];
+    uint32_t* refl = ref_sh[threadIdx.x >> 6];
+    uint32_t* cuml = cum_sh[threadIdx.x >> 6];
+    uint16_t* idxl = idx_sh[threadIdx.x >> 6];
+    uint32_t* stl = stage_sh[threadIdx.x >> 6];
     const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
     uint32_t np_next = wave < ntiles ? tile_np[wave] : 0u, tb_next = wave < ntiles ? tile_tb[wave] : 0u;
+    uint32_t te_next = wave + 1 < ntiles ? tile_tb[wave + 1] : 0xFFFFFFFFu;  // where the tile's tokens end (the chunk's last tile: unknown here, never staged)
     for (uint64_t t = wave; t < ntiles; t += nwaves) {
-        const uint32_t np = np_next, rb = (uint32_t)t * TKF_CAP;
-        uint32_t run = tb_next;  // (token offsets within a chunk fit 32 bits: a chunk is less than 4 GiB of text)
+        const uint32_t np = np_next, rb = (uint32_t)t * TKF_CAP, run0 = tb_next;  // (token offsets within a chunk fit 32 bits: a chunk is less than 4 GiB of text)
+        const uint32_t nt_tile = te_next - run0;
         np_next = t + nwaves < ntiles ? tile_np[t + nwaves] : 0u;  // (the next tile's size and base are on their way while this tile is placed)
         tb_next = t + nwaves < ntiles ? tile_tb[t + nwaves] : 0u;
-        for (uint32_t k0 = 0; k0 < np; k0 += 256u * ROWS) {
-            uint32_t tk[ROWS][4];
-            uint2 hd[ROWS][4];
+        te_next = t + nwaves + 1 < ntiles ? tile_tb[t + nwaves + 1] : 0xFFFFFFFFu;
+        auto place_tile = [&](auto staged_c) {
+            constexpr bool ST = decltype(staged_c)::value;
+            auto W = [&](uint32_t off, uint32_t v) {  // token number `off` of the tile
+                if constexpr (ST) stl[off] = v;
+                else out[run0 + off] = v;
+            };
+            uint32_t run = 0;  // tokens of the tile's steps so far
+            for (uint32_t k0 = 0; k0 < np; k0 += CAP) {
+                // the step's result words: four pieces per lane and row (no `if` around the loads: the rows are in flight together)
+                uint32_t tk[ROWS][4];
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                const uint32_t k = k0 + (uint32_t)r * 256u + (uint32_t)lane * 4u;
-                const uint4 t4 = *(const uint4*)(res + rb + (k < np ? k : 0u));  // (no `if` around the load: the rows are in flight together)
-                tk[r][0] = k < np ? t4.x : TK_RES_GAP;  // (dead words of a run's last four count as "no token")
-                tk[r][1] = k + 1 < np ? t4.y : TK_RES_GAP;
-                tk[r][2] = k + 2 < np ? t4.z : TK_RES_GAP;
-                tk[r][3] = k + 3 < np ? t4.w : TK_RES_GAP;
-            }
-#pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-#pragma unroll
-                for (int j = 0; j < 4; ++j)  // (no `if` around the load: all the heads are in flight together; a piece without an entry reads the first overflow entry)
-#ifdef TKP_COND_HEADS
-                {
-                    hd[r][j] = make_uint2(0u, 0u);
-                    if (tk[r][j] & TK_RES_FLAG) hd[r][j] = data.result(tk[r][j] & ~TK_RES_FLAG);
+                for (int r = 0; r < ROWS; ++r) {
+                    const uint32_t k = k0 + (uint32_t)r * 256u + (uint32_t)lane * 4u;
+                    const uint4 t4 = *(const uint4*)(res + rb + (k < np ? k : 0u));
+                    tk[r][0] = k < np ? t4.x : TK_RES_GAP;  // (dead words of a run's last four count as "no token")
+                    tk[r][1] = k + 1 < np ? t4.y : TK_RES_GAP;
+                    tk[r][2] = k + 2 < np ? t4.z : TK_RES_GAP;
+                    tk[r][3] = k + 3 < np ? t4.w : TK_RES_GAP;
                 }
-#else
-                    hd[r][j] = data.result((tk[r][j] & TK_RES_FLAG) ? (tk[r][j] & ~TK_RES_FLAG) : data.ovf_base);
-#endif
-            }
+                // the list: pieces that are not one token (a reference to an entry; no token at all), row by row = in piece order
+                uint32_t fm[ROWS], lbase[ROWS], nlist = 0;
 #pragma unroll
-            for (int r = 0; r < ROWS; ++r) {
-                if (k0 + (uint32_t)r * 256u >= np) break;
-                if (lane == 0) row_abs[t * (TKF_CAP / 256) + (k0 >> 8) + (uint32_t)r] = run;
-                uint32_t c[4];
+                for (int r = 0; r < ROWS; ++r) {
+                    fm[r] = 0;
 #pragma unroll
-                for (int j = 0; j < 4; ++j) c[j] = (tk[r][j] & TK_RES_FLAG) ? TKD_COUNT(hd[r][j].x) : (tk[r][j] != TK_RES_GAP ? 1u : 0u);
-                const uint32_t mine = c[0] + c[1] + c[2] + c[3];
-                const uint32_t inc = tk_wave_scan_u32(mine, lane);
-                const uint32_t o = run + inc - mine;
-                uint32_t nst = 0;  // pieces of the lane whose tokens are in the staging area
-                uint4 a4[4];       // tok[1 .. 4] of the lane's pieces whose tokens lie in their entries: four loads in flight
+                    for (int j = 0; j < 4; ++j)
+                        if ((tk[r][j] & TK_RES_FLAG) || tk[r][j] == TK_RES_GAP) fm[r] |= 1u << j;
+                    const uint32_t nf = (uint32_t)__popc(fm[r]);
+                    const uint32_t inc = tk_wave_scan_u32(nf, lane);
+                    lbase[r] = nlist + inc - nf;
+                    nlist += (uint32_t)__shfl((int)inc, 63, 64);
+                    uint32_t at = lbase[r];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const bool inl = (tk[r][j] & TK_RES_FLAG) && c[j] > 1u && (hd[r][j].x & TKD_INLINE_BIT);
-#ifdef TKP_COND_A4
-                    a4[j] = make_uint4(0, 0, 0, 0);
-                    if (inl) a4[j] = *(const uint4*)(data.tab[tk[r][j] & ~TK_RES_FLAG].tok + 1);
-#else
-                    a4[j] = *(const uint4*)(inl ? (const uint32_t*)(data.tab[tk[r][j] & ~TK_RES_FLAG].tok + 1) : (const uint32_t*)data.ovf);
-#endif
-                }
-                if (c[0] == 1u && c[1] == 1u && c[2] == 1u && c[3] == 1u && !((tk[r][0] | tk[r][1] | tk[r][2] | tk[r][3]) & TK_RES_FLAG)) {
-                    *(uint4*)(out + o) = make_uint4(tk[r][0], tk[r][1], tk[r][2], tk[r][3]);  // (4-byte aligned 16-byte store)
-                } else {
-                    uint32_t oo = o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if (!(tk[r][j] & TK_RES_FLAG)) {
-                            if (c[j]) out[oo] = tk[r][j];
-                        } else if (c[j] == 1u) {  // (a missed piece is never ONE token; kept for entries written that way)
-                            out[oo] = hd[r][j].y;
-                        } else if (hd[r][j].x & TKD_INLINE_BIT) {
-                            const uint32_t* tokp = data.tab[tk[r][j] & ~TK_RES_FLAG].tok;
-                            const uint4 a = a4[j];  // tok[1 .. 4] (the entry is a 64-byte line; tok[0] is its fourth word)
-                            uint4 b = make_uint4(0, 0, 0, 0), d = b;
-                            if (c[j] > 5u) b = *(const uint4*)(tokp + 5);
-                            if (c[j] > 9u) d = *(const uint4*)(tokp + 9);
-                            uint32_t* q = out + oo;
-                            q[0] = hd[r][j].y;
-                            q[1] = a.x;
-                            if (c[j] > 2u) q[2] = a.y;
-                            if (c[j] > 3u) q[3] = a.z;
-                            if (c[j] > 4u) q[4] = a.w;
-                            if (c[j] > 5u) {
-                                q[5] = b.x;
-                                if (c[j] > 6u) q[6] = b.y;
-                                if (c[j] > 7u) q[7] = b.z;
-                                if (c[j] > 8u) q[8] = b.w;
-                                if (c[j] > 9u) {
-                                    q[9] = d.x;
-                                    if (c[j] > 10u) q[10] = d.y;
-                                    if (c[j] > 11u) q[11] = d.z;
-                                    if (c[j] > 12u) q[12] = d.w;
-                                }
-                            }
-                        } else {
-                            ++nst;
-                        }
-                        oo += c[j];
-                    }
-                }
-                // pieces whose tokens are in the staging area -> a list in LDS, then 32 lanes per piece copy them
-                if (__ballot(nst != 0u)) {
-                    const uint32_t sinc = tk_wave_scan_u32(nst, lane);
-                    const uint32_t ntot = __shfl(sinc, 63, 64);
-                    uint32_t at = sinc - nst, oj = o;
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) {
-                        if ((tk[r][j] & TK_RES_FLAG) && c[j] > 1u && !(hd[r][j].x & TKD_INLINE_BIT)) {
-                            mlist[at * 3] = hd[r][j].y;
-                            mlist[at * 3 + 1] = c[j];
-                            mlist[at * 3 + 2] = oj;
+                    for (int j = 0; j < 4; ++j)
+                        if ((fm[r] >> j) & 1u) {
+                            refl[at] = tk[r][j];
+                            idxl[at] = (uint16_t)((uint32_t)r * 256u + (uint32_t)lane * 4u + (uint32_t)j);
                             ++at;
                         }
-                        oj += c[j];
-                    }
-                    __builtin_amdgcn_wave_barrier();
-                    for (uint32_t e0 = 0; e0 < ntot; e0 += 2) {
-                        const uint32_t e = e0 + (uint32_t)(lane >> 5);
-                        if (e < ntot) {
-                            const uint32_t src = mlist[e * 3], cc = mlist[e * 3 + 1], dst = mlist[e * 3 + 2];
-                            if (cc < TK_BIGCOPY) {
-                                for (uint32_t i = lane & 31; i < cc; i += 32) out[dst + i] = staging[src + i];
-                            } else if ((lane & 31) == 0) {  // thousands of tokens of one piece: copied by tk_k_bigcopy with the whole device
-                                const uint32_t bat = atomicAdd(&big[0], 1u);
-                                if (bat < TK_BIGCOPY_CAP) {
-                                    big[1 + 3 * bat] = src;
-                                    big[2 + 3 * bat] = dst;
-                                    big[3 + 3 * bat] = cc;
-                                } else {
-                                    for (uint32_t i = 0; i < cc; ++i) out[dst + i] = staging[src + i];
+                }
+                __builtin_amdgcn_wave_barrier();
+                // the listed pieces, sixty-four at a time: entry -> count and tokens, prefix sum of count - 1 (a gap char: minus one), tokens to their place
+                uint32_t carry = 0;  // the sum so far (wave-uniform)
+                for (uint32_t d0 = 0; d0 < nlist; d0 += 64u) {
+                    const uint32_t d = d0 + (uint32_t)lane;
+                    const bool have = d < nlist;
+                    const uint32_t w = have ? refl[d] : TK_RES_GAP;
+                    const uint32_t pidx = have ? (uint32_t)idxl[d] : 0u;
+                    const bool flagged = (w & TK_RES_FLAG) != 0u;
+                    const uint32_t e = w & ~TK_RES_FLAG;
+                    const bool in_tab = flagged && e < data.ovf_base;
+                    // (no `if` around the loads: the head and the entry's next sixteen bytes are in flight together; a lane without an entry
+                    // reads the first overflow entry)
+                    const uint2 hd = data.result(flagged ? e : data.ovf_base);
+                    const uint4 a = *(const uint4*)(in_tab ? (const uint32_t*)(data.tab[e].tok + 1) : (const uint32_t*)data.ovf);
+                    const uint32_t cnt = flagged ? TKD_COUNT(hd.x) : 0u;
+                    const uint32_t extra = have ? cnt - 1u : 0u;
+                    const uint32_t incx = tk_wave_scan_u32(extra, lane);
+                    const uint32_t cum = carry + incx;
+                    if (have) cuml[d] = cum;
+                    carry += (uint32_t)__shfl((int)incx, 63, 64);
+                    const uint32_t off = run + pidx + (cum - extra);
+                    bool stg = false;  // its tokens are in the staging area
+                    if (flagged) {
+                        if (cnt == 1u) {  // (a long piece that is a token after all, tk_k_bincount; entries written that way)
+                            W(off, hd.y);
+                        } else if (hd.x & TKD_INLINE_BIT) {
+                            W(off, hd.y);
+                            W(off + 1u, a.x);
+                            if (cnt > 2u) W(off + 2u, a.y);
+                            if (cnt > 3u) W(off + 3u, a.z);
+                            if (cnt > 4u) W(off + 4u, a.w);
+                            if (cnt > 5u) {
+                                const uint32_t* tokp = data.tab[e].tok;
+                                const uint4 b = *(const uint4*)(tokp + 5);
+                                uint4 c4 = make_uint4(0, 0, 0, 0);
+                                if (cnt > 9u) c4 = *(const uint4*)(tokp + 9);
+                                W(off + 5u, b.x);
+                                if (cnt > 6u) W(off + 6u, b.y);
+                                if (cnt > 7u) W(off + 7u, b.z);
+                                if (cnt > 8u) W(off + 8u, b.w);
+                                if (cnt > 9u) {
+                                    W(off + 9u, c4.x);
+                                    if (cnt > 10u) W(off + 10u, c4.y);
+                                    if (cnt > 11u) W(off + 11u, c4.z);
+                                    if (cnt > 12u) W(off + 12u, c4.w);
                                 }
+                            }
+                        } else if (cnt > 1u) {
+                            stg = true;
+                        }
+                    }
+                    // what does not fit an entry -- more than TKD_INLINE tokens, overflow entries -- is copied from the staging area by the
+                    // whole wavefront, a piece at a time (a few per tile); thousands of tokens of one piece by tk_k_bigcopy with the whole device
+                    for (uint64_t m = __ballot(stg); m; m &= m - 1ull) {
+                        const int l = __ffsll((unsigned long long)m) - 1;
+                        const uint32_t src = (uint32_t)__shfl((int)hd.y, l, 64), cc = (uint32_t)__shfl((int)cnt, l, 64), dst = (uint32_t)__shfl((int)off, l, 64);
+                        if (ST || cc < TK_BIGCOPY) {  // (a tile that goes through LDS holds no piece that long)
+                            for (uint32_t i = (uint32_t)lane; i < cc; i += 64u) W(dst + i, staging[src + i]);
+                        } else if (lane == 0) {
+                            const uint32_t bat = atomicAdd(&big[0], 1u);
+                            if (bat < TK_BIGCOPY_CAP) {
+                                big[1 + 3 * bat] = src;
+                                big[2 + 3 * bat] = run0 + dst;
+                                big[3 + 3 * bat] = cc;
+                            } else {
+                                for (uint32_t i = 0; i < cc; ++i) out[run0 + dst + i] = staging[src + i];
                             }
                         }
                     }
-                    __builtin_amdgcn_wave_barrier();
                 }
-                run += (uint32_t)__shfl((int)inc, 63, 64);
+                __builtin_amdgcn_wave_barrier();
+                // the single tokens of the rows: place = index + the sum over the listed pieces before
+#pragma unroll
+                for (int r = 0; r < ROWS; ++r) {
+                    const uint32_t kr = (uint32_t)r * 256u;
+                    if (k0 + kr >= np) break;
+                    uint32_t rk = lbase[r];
+                    uint32_t ex = rk ? cuml[rk - 1u] : 0u;
+                    if (lane == 0) row_abs[t * (TKF_CAP / 256) + ((k0 + kr) >> 8)] = run0 + run + kr + ex;
+                    const uint32_t o = run + kr + (uint32_t)lane * 4u;
+                    if (fm[r] == 0u) {
+                        if constexpr (ST) {
+                            W(o + ex, tk[r][0]);
+                            W(o + ex + 1u, tk[r][1]);
+                            W(o + ex + 2u, tk[r][2]);
+                            W(o + ex + 3u, tk[r][3]);
+                        } else {
+                            // (the sum in 32 bits FIRST: `ex` is negative behind gap chars, as an unsigned number that only works modulo 2^32)
+                            *(uint4*)(out + (uint32_t)(run0 + o + ex)) = make_uint4(tk[r][0], tk[r][1], tk[r][2], tk[r][3]);  // (4-byte aligned 16-byte store)
+                        }
+                    } else if (fm[r] != 15u) {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j) {
+                            if ((fm[r] >> j) & 1u) ex = cuml[rk++];
+                            else W(o + (uint32_t)j + ex, tk[r][j]);
+                        }
+                    }
+                }
+                run += CAP + carry;  // (a step's dead words cancel out: one piece, minus one)
+                __builtin_amdgcn_wave_barrier();  // (the list is reused by the next step)
             }
-        }
+            if constexpr (ST) {  // LDS -> the output, sixteen bytes a lane
+                for (uint32_t i = (uint32_t)lane * 4u; i < nt_tile; i += 256u) {
+                    const uint4 v = *(const uint4*)(stl + i);
+                    uint32_t* q = out + run0 + i;
+                    if (i + 4u <= nt_tile) {
+                        *(uint4*)q = v;  // (4-byte aligned 16-byte store)
+                    } else {
+                        q[0] = v.x;
+                        if (i + 1u < nt_tile) q[1] = v.y;
+                        if (i + 2u < nt_tile) q[2] = v.z;
+                    }
+                }
+                __builtin_amdgcn_wave_barrier();
+            }
+        };
+        if (np != 0u && nt_tile <= SCAP) place_tile(std::true_type{});
+        else place_tile(std::false_type{});
     }
 }
 
