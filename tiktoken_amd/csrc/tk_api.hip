@@ -1386,7 +1386,15 @@ static int small_wait(tk_core* c, tk_core::SmallSlot* const* mine, uint32_t k) {
                 if (!ls) HIPCHK(hipStreamCreateWithFlags(&ls, hipStreamNonBlocking));
                 hipLaunchKernelGGL(tk_k_small, dim3(cnt), dim3(256), 0, ls, c->D, R);
                 const hipError_t le = hipGetLastError();
-                if (le != hipSuccess) return fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(le) + " in tk_k_small");
+                if (le != hipSuccess) {
+                    // (the slots this launcher took go back to "ready": their owners try the launch themselves instead of waiting two seconds)
+                    for (uint32_t j = 0; j < TK_SMALL_SLOTS; ++j) {
+                        int two = 2;
+                        for (uint32_t q = 0; q < cnt; ++q)
+                            if (R.r[q].out == (uint32_t*)c->small[j].d_out) c->small[j].state.compare_exchange_strong(two, 1, std::memory_order_acq_rel);
+                    }
+                    return fail(TK_RUNTIME_ERROR, std::string("HIP error: ") + hipGetErrorString(le) + " in tk_k_small");
+                }
                 c->st_small_launches += 1;
                 c->st_small_calls += cnt;
             }
@@ -1443,7 +1451,10 @@ static int encode_mid(tk_core* c, const uint8_t* utf8, uint32_t n, uint32_t** to
         uint32_t* n;
         std::atomic<int>* active;
         ~Release() {
-            for (uint32_t i = 0; i < *n; ++i) s[i]->busy.store(0, std::memory_order_release);
+            for (uint32_t i = 0; i < *n; ++i) {
+                s[i]->state.store(0, std::memory_order_release);  // (also when small_wait left early -- a failed launch, its time-out: the next owner must not be launched with this call's text)
+                s[i]->busy.store(0, std::memory_order_release);
+            }
             active->fetch_sub(1, std::memory_order_relaxed);
         }
     } release_slots{mine, &got, &c->small_active};
@@ -1517,6 +1528,7 @@ static int encode_small(tk_core* c, const uint8_t* utf8, uint32_t n, uint32_t** 
         tk_core::SmallSlot* s;
         std::atomic<int>* active;
         ~Release() {
+            s->state.store(0, std::memory_order_release);  // (see encode_mid's guard)
             s->busy.store(0, std::memory_order_release);
             active->fetch_sub(1, std::memory_order_relaxed);
         }
