@@ -1782,11 +1782,19 @@ __device__ __forceinline__ void tkm_probe2(const TkTables& T, uint32_t a0, uint3
 #define TKM_WAVES 4       // wavefronts per workgroup (8 KiB of LDS each)
 #endif
 #ifndef TKM_WGS_PER_CU
-#define TKM_WGS_PER_CU (20 / TKM_WAVES)  // 32 KiB of LDS per workgroup of four
+#define TKM_WGS_PER_CU (16 / TKM_WAVES)  // 40 KiB of LDS per workgroup of four
 #endif
-#define TKM_LDS_BYTES (TKM_WAVES * 2 * 1024 * 4)
+#define TKM_LDS_BYTES (TKM_WAVES * (2 * 1024 * 4 + 1024 * 2))
+// Round 5: a part's neighbours are LINKS in LDS -- the position of the next part in the upper eleven bits of its id word (ids of the packed
+// pair table have 21 bits), the previous part's in a halfword of its own -- read by all lanes of the piece at once.  Round 4 found them
+// through the lanes' alive masks: a ballot and three __shfl per neighbour (bpermutes through the LDS crossbar), a dozen in a row per
+// step of two merges -- more of a step's time than its table probes.
+#define TKM_ID_BITS 21
+#define TKM_ID_MASK ((1u << TKM_ID_BITS) - 1u)
+#define TKM_NO_NEXT 0x7FFu
+#define TKM_NO_PREV 0xFFFFu
 #ifndef TKM_MIN_WAVES_EU
-#define TKM_MIN_WAVES_EU 5  // (the second launch bound is wavefronts per SIMD in HIP)
+#define TKM_MIN_WAVES_EU 4  // (the second launch bound is wavefronts per SIMD in HIP)
 #endif
 #define TKM_WORK_STRIDE 64  // words between two work counters (256 bytes)
 __global__ __launch_bounds__(64 * TKM_WAVES, TKM_MIN_WAVES_EU) void tk_k_merge_all(TkTables T, const uint8_t* __restrict__ text, const uint32_t* __restrict__ listB,
@@ -1799,11 +1807,13 @@ __global__ __launch_bounds__(64 * TKM_WAVES, TKM_MIN_WAVES_EU) void tk_k_merge_a
     extern __shared__ __attribute__((aligned(16))) uint32_t tkm_lds[];
     uint32_t(*s_id)[1024] = (uint32_t(*)[1024])tkm_lds;
     uint32_t(*s_key)[1024] = s_id + TKM_WAVES;
+    uint16_t(*s_prv)[1024] = (uint16_t(*)[1024])(s_key + TKM_WAVES);
     const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6;
     uint32_t* id = s_id[wid] + lane * C;   // the lane's 16 positions (a piece's G lanes are neighbours: its positions are contiguous)
     uint32_t* key = s_key[wid] + lane * C;
     const uint32_t* idw = s_id[wid];
     uint32_t* keyw = s_key[wid];
+    uint16_t* prvw = s_prv[wid];
     const uint32_t nwaves = gridDim.x * (uint32_t)TKM_WAVES;  // (a multiple of 16: see the work counters)
     // units, longest bin first (wave-uniform; the counts were left by tk_k_binfill)
     uint32_t ustart[TK_NBIN + 1];  // ustart[q]: first unit of the q-th bin in processing order (bin TK_NBIN - 1 - q)
@@ -1872,7 +1882,8 @@ __global__ __launch_bounds__(64 * TKM_WAVES, TKM_MIN_WAVES_EU) void tk_k_merge_a
                 const uint32_t br = T.byte_rank[k < n ? b0 : 0u], p2 = T.pair2[k + 1 < n ? ((b0 << 8) | b1) : 0u];
                 rr[c] = k + 1 < n ? p2 : TK_RANK_MAX;
                 if (k < n) {
-                    id[c] = br;
+                    id[c] = br | ((k + 1 < n ? k + 1u : TKM_NO_NEXT) << TKM_ID_BITS);  // (positions are relative to the piece: k = g * C + c)
+                    prvw[gbase * C + k] = (uint16_t)(k ? k - 1u : TKM_NO_PREV);
                     mask |= 1u << c;
                 }
             }
@@ -1889,41 +1900,14 @@ __global__ __launch_bounds__(64 * TKM_WAVES, TKM_MIN_WAVES_EU) void tk_k_merge_a
             const bool fin = best == TKM_NOKEY;
             if (__all(fin)) break;
             const uint32_t bi = best & (NMAX - 1u), brank = best >> 10, ob = bi / C, bl = bi % C;
-            // neighbours through the lanes' alive masks: j = the part being absorbed, nn = the part after it, pp = the part before bi
-            const uint64_t nbw = __ballot(mask != 0);
-            const uint64_t nb = lg == 6 ? nbw : ((nbw >> gbase) & ((1ull << G) - 1ull));
-            const uint32_t my_first = mask ? (uint32_t)(g * C + __ffs((int)mask) - 1) : NONE;
-            const uint32_t my_last = mask ? (uint32_t)(g * C + 31 - __clz((int)mask)) : NONE;
-            const uint32_t om = __shfl(mask, gbase + (int)ob, 64);
-            uint32_t j;
-            {
-                const uint32_t hi = om & ~((2u << bl) - 1u);
-                const uint64_t la = nb & ~((2ull << ob) - 1ull);
-                const int lj = la ? __ffsll((unsigned long long)la) - 1 : 0;
-                const uint32_t fj = __shfl(my_first, gbase + lj, 64);
-                j = hi ? ob * C + (uint32_t)__ffs((int)hi) - 1u : fj;
-            }
-            j &= (NMAX - 1u);
-            const uint32_t oj = j / C, jl = j % C;
-            uint32_t nn;
-            {
-                const uint32_t ojm = __shfl(mask, gbase + (int)oj, 64);
-                const uint32_t hi = ojm & ~((2u << jl) - 1u);
-                const uint64_t la = nb & ~((2ull << oj) - 1ull);
-                const int ln = la ? __ffsll((unsigned long long)la) - 1 : 0;
-                const uint32_t fn = __shfl(my_first, gbase + ln, 64);
-                nn = hi ? oj * C + (uint32_t)__ffs((int)hi) - 1u : (la ? fn : NONE);
-            }
-            uint32_t pp;
-            {
-                const uint32_t lo = om & ((1u << bl) - 1u);
-                const uint64_t lb = nb & ((1ull << ob) - 1ull);
-                const int lp = lb ? 63 - __clzll((long long)lb) : 0;
-                const uint32_t fl = __shfl(my_last, gbase + lp, 64);
-                pp = lo ? ob * C + 31u - (uint32_t)__clz((int)lo) : (lb ? fl : NONE);
-            }
+            // neighbours through the links: j = the part being absorbed, nn = the part after it, pp = the part before bi
             const uint32_t* pid = idw + gbase * C;  // the piece's positions
             uint32_t* pkey = keyw + gbase * C;
+            uint16_t* pprv = prvw + gbase * C;
+            const uint32_t j = (pid[bi] >> TKM_ID_BITS) & (NMAX - 1u);  // (a key at bi means there is a part behind it)
+            const uint32_t oj = j / C, jl = j % C;
+            const uint32_t nn_raw = pid[j] >> TKM_ID_BITS, pp_raw = pprv[bi];
+            const uint32_t nn = nn_raw == TKM_NO_NEXT ? NONE : nn_raw, pp = pp_raw == TKM_NO_PREV ? NONE : pp_raw;
             if (lg >= 2 && !(dbg & 0x80000)) {
                 // TWO merges per step (pieces of four lanes and more; debug bit 0x80000: one).  The step's time is the latency of its
                 // table probes, and a long piece is a chain of hundreds of steps.  What the reference merges next (lib.rs:151,190) is the
@@ -1934,7 +1918,7 @@ __global__ __launch_bounds__(64 * TKM_WAVES, TKM_MIN_WAVES_EU) void tk_k_merge_a
                 // merge 1, the part that does not wait for a probe: the merged token's id, the absorbed part
                 if (!fin) {
                     if (g == ob) {
-                        id[bl] = brank;
+                        id[bl] = brank | ((nn == NONE ? TKM_NO_NEXT : nn) << TKM_ID_BITS);
                         key[bl] = TKM_NOKEY;  // (until the probe is back: not a candidate for the second merge)
                     }
                     if (g == oj) {
@@ -1942,6 +1926,7 @@ __global__ __launch_bounds__(64 * TKM_WAVES, TKM_MIN_WAVES_EU) void tk_k_merge_a
                         key[jl] = TKM_NOKEY;
                     }
                     if (pp != NONE && g == pp / C) pkey[pp] = TKM_NOKEY;
+                    if (nn != NONE && g == nn / C) pprv[nn] = (uint16_t)bi;
                 }
                 __builtin_amdgcn_wave_barrier();
                 const bool touched1 = !fin && (g == ob || g == oj || (pp != NONE && g == pp / C));
@@ -1949,37 +1934,10 @@ __global__ __launch_bounds__(64 * TKM_WAVES, TKM_MIN_WAVES_EU) void tk_k_merge_a
                 const uint32_t best2 = fin ? TKM_NOKEY : tkm_group_min(lkey2, lg);
                 const bool has2 = best2 != TKM_NOKEY;
                 const uint32_t bi2 = best2 & (NMAX - 1u), rank2 = best2 >> 10, ob2 = bi2 / C, bl2 = bi2 % C;
-                uint32_t j2 = 0, nn2 = NONE, pp2 = NONE;
-                {
-                    const uint64_t nbw2 = __ballot(mask != 0);
-                    const uint64_t nb2 = lg == 6 ? nbw2 : ((nbw2 >> gbase) & ((1ull << G) - 1ull));
-                    const uint32_t first2 = mask ? (uint32_t)(g * C + __ffs((int)mask) - 1) : NONE;
-                    const uint32_t last2 = mask ? (uint32_t)(g * C + 31 - __clz((int)mask)) : NONE;
-                    const uint32_t om2 = __shfl(mask, gbase + (int)ob2, 64);
-                    {
-                        const uint32_t hi = om2 & ~((2u << bl2) - 1u);
-                        const uint64_t la = nb2 & ~((2ull << ob2) - 1ull);
-                        const int lj = la ? __ffsll((unsigned long long)la) - 1 : 0;
-                        const uint32_t fj = __shfl(first2, gbase + lj, 64);
-                        j2 = (hi ? ob2 * C + (uint32_t)__ffs((int)hi) - 1u : fj) & (NMAX - 1u);
-                    }
-                    const uint32_t oj2 = j2 / C, jl2 = j2 % C;
-                    {
-                        const uint32_t ojm = __shfl(mask, gbase + (int)oj2, 64);
-                        const uint32_t hi = ojm & ~((2u << jl2) - 1u);
-                        const uint64_t la = nb2 & ~((2ull << oj2) - 1ull);
-                        const int ln = la ? __ffsll((unsigned long long)la) - 1 : 0;
-                        const uint32_t fn = __shfl(first2, gbase + ln, 64);
-                        nn2 = hi ? oj2 * C + (uint32_t)__ffs((int)hi) - 1u : (la ? fn : NONE);
-                    }
-                    {
-                        const uint32_t lo = om2 & ((1u << bl2) - 1u);
-                        const uint64_t lb = nb2 & ((1ull << ob2) - 1ull);
-                        const int lp = lb ? 63 - __clzll((long long)lb) : 0;
-                        const uint32_t fl = __shfl(last2, gbase + lp, 64);
-                        pp2 = lo ? ob2 * C + 31u - (uint32_t)__clz((int)lo) : (lb ? fl : NONE);
-                    }
-                }
+                // (its neighbours from the state the first merge leaves behind: the links have been updated above)
+                const uint32_t j2 = (pid[bi2] >> TKM_ID_BITS) & (NMAX - 1u);
+                const uint32_t nn2_raw = pid[j2] >> TKM_ID_BITS, pp2_raw = pprv[bi2];
+                const uint32_t nn2 = nn2_raw == TKM_NO_NEXT ? NONE : nn2_raw, pp2 = pp2_raw == TKM_NO_PREV ? NONE : pp2_raw;
                 // (ONE probe region for the four lanes: four `if (g == ..) probe` statements run one after the other, each waiting for its own
                 // loads -- the step would take four table latencies instead of one)
                 uint32_t newr = TK_RANK_MAX;
@@ -1987,7 +1945,7 @@ __global__ __launch_bounds__(64 * TKM_WAVES, TKM_MIN_WAVES_EU) void tk_k_merge_a
                     const uint32_t nb_pos = g == 0 ? nn : (g == 1 ? pp : (g == 2 ? nn2 : pp2));  // the neighbour this lane's pair is made with
                     const bool second = g >= 2, left = (g & 1u) != 0;                             // lanes 1, 3: (previous, merged)
                     const bool on = !fin && g < 4u && nb_pos != NONE && (!second || has2) && !(dbg & 0x1000000);  // (0x1000000, perf experiments: no probes)
-                    const uint32_t nid = pid[nb_pos != NONE ? nb_pos : 0u], mid = second ? rank2 : brank;
+                    const uint32_t nid = pid[nb_pos != NONE ? nb_pos : 0u] & TKM_ID_MASK, mid = second ? rank2 : brank;
                     if (on) newr = tk_probe_pair(T, left ? nid : mid, left ? mid : nid);
                 }
                 const uint32_t newr_i = __shfl(newr, gbase, 64), newr_p = __shfl(newr, gbase + 1, 64);
@@ -2002,7 +1960,7 @@ __global__ __launch_bounds__(64 * TKM_WAVES, TKM_MIN_WAVES_EU) void tk_k_merge_a
                     if (take2) {  // (after the first merge's keys: a position the two share ends up with the second's)
                         const uint32_t oj2 = j2 / C, jl2 = j2 % C;
                         if (g == ob2) {
-                            id[bl2] = rank2;
+                            id[bl2] = rank2 | ((nn2 == NONE ? TKM_NO_NEXT : nn2) << TKM_ID_BITS);
                             key[bl2] = tkm_key(newr_i2, bi2);
                             touched = true;
                         }
@@ -2015,6 +1973,7 @@ __global__ __launch_bounds__(64 * TKM_WAVES, TKM_MIN_WAVES_EU) void tk_k_merge_a
                             pkey[pp2] = tkm_key(newr_p2, pp2);
                             touched = true;
                         }
+                        if (nn2 != NONE && g == nn2 / C) pprv[nn2] = (uint16_t)bi2;
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
@@ -2025,13 +1984,13 @@ __global__ __launch_bounds__(64 * TKM_WAVES, TKM_MIN_WAVES_EU) void tk_k_merge_a
             uint32_t newr_i = TK_RANK_MAX, newr_p = TK_RANK_MAX;
             if (dbg & 0x1000000) {  // (perf experiments: no probes -- wrong tokens, the cost of everything else)
             } else if (lg == 0) {
-                if (!fin) tkm_probe2(T, brank, nn != NONE ? pid[nn & (NMAX - 1u)] : 0u, nn != NONE, pp != NONE ? pid[pp & (NMAX - 1u)] : 0u, brank, pp != NONE, newr_i, newr_p);
+                if (!fin) tkm_probe2(T, brank, nn != NONE ? (pid[nn & (NMAX - 1u)] & TKM_ID_MASK) : 0u, nn != NONE, pp != NONE ? (pid[pp & (NMAX - 1u)] & TKM_ID_MASK) : 0u, brank, pp != NONE, newr_i, newr_p);
             } else {
                 uint32_t newr = TK_RANK_MAX;
                 {  // (one probe region for both lanes: see above)
                     const uint32_t nb_pos = g == 0 ? nn : pp;
                     const bool on = !fin && g < 2u && nb_pos != NONE;
-                    const uint32_t nid = pid[nb_pos != NONE ? nb_pos : 0u];
+                    const uint32_t nid = pid[nb_pos != NONE ? nb_pos : 0u] & TKM_ID_MASK;
                     if (on) newr = tk_probe_pair(T, g ? nid : brank, g ? brank : nid);
                 }
                 newr_i = __shfl(newr, gbase, 64);
@@ -2041,7 +2000,7 @@ __global__ __launch_bounds__(64 * TKM_WAVES, TKM_MIN_WAVES_EU) void tk_k_merge_a
             bool touched = false;
             if (!fin) {
                 if (g == ob) {
-                    id[bl] = brank;
+                    id[bl] = brank | ((nn == NONE ? TKM_NO_NEXT : nn) << TKM_ID_BITS);
                     key[bl] = tkm_key(newr_i, bi);
                     touched = true;
                 }
@@ -2054,6 +2013,7 @@ __global__ __launch_bounds__(64 * TKM_WAVES, TKM_MIN_WAVES_EU) void tk_k_merge_a
                     pkey[pp] = tkm_key(newr_p, pp);
                     touched = true;
                 }
+                if (nn != NONE && g == nn / C) pprv[nn] = (uint16_t)bi;
             }
             __builtin_amdgcn_wave_barrier();
             if (touched) lkey = local_min();
@@ -2074,11 +2034,11 @@ __global__ __launch_bounds__(64 * TKM_WAVES, TKM_MIN_WAVES_EU) void tk_k_merge_a
             while (mm) {
                 const int c = __ffs((int)mm) - 1;
                 mm &= mm - 1;
-                dst[t++] = id[c];
+                dst[t++] = id[c] & TKM_ID_MASK;
             }
             if (g == 0) {
                 if (fits) data.put_count(mi, total | TKD_INLINE_BIT);
-                else tk_put_result(data, mi, total, total == 1 ? id[0] : s);
+                else tk_put_result(data, mi, total, total == 1 ? (id[0] & TKM_ID_MASK) : s);
             }
         }
         __builtin_amdgcn_wave_barrier();
