@@ -34,7 +34,7 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBPS = 8000.0  # MI355X HBM3E spec (/opt/skills/guides/MI355X_MICROARCH.md)
-KERNELS = ["tk_k_mark_docs", "tk_k_front", "tk_k_front_slow", "tk_k_single_front", "tk_k_bincount", "tk_k_binfill", *[f"tk_k_merge_llane_{i}" for i in (16, 24, 32, 48, 64)],
+KERNELS = ["tk_k_mark_docs", "tk_k_front", "tk_k_front_slow", "tk_k_front_given", "tk_k_single_front", "tk_k_bincount", "tk_k_binfill", *[f"tk_k_merge_llane_{i}" for i in (16, 24, 32, 48, 64)],
            *[f"tk_k_merge_group_{i}" for i in (8, 16, 32, 64)], "tk_k_merge_all", "tk_k_merge_rounds", "tk_k_merge_rounds_wide", "tk_k_merge_long", "tk_k_count_tiles", "tk_k_scan_small", "tk_k_scan_sums", "tk_k_scan_apply", "tk_k_place", "tk_k_docoff",
            "tk_k_rx_speculate", "tk_k_rx_link", "tk_k_rx_resolve", "tk_k_rx_merge"]  # (the last four only run for a pat_str on the generic engine)
 

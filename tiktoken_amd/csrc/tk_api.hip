@@ -675,7 +675,12 @@ static int stage_deferred(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream
         const int pat_id = T.pat.generic() ? TK_PAT_GENERIC : T.pattern;
         TkMissKey* mt_arg = (c->dbg & 256) ? (TkMissKey*)nullptr : job.mt;
         const uint32_t* gapb = c->has_rx ? w.rx_gst.as<uint32_t>() + (job.n + 31) / 32 + 2 : (const uint32_t*)nullptr;
-        const int fdbg = c->dbg | (job.pretok ? 8 : 0);  // (piece starts only: every probe counts as a hit, nothing is listed for the merges)
+        int fdbg = c->dbg | (job.pretok ? 8 : 0);  // (piece starts only: every probe counts as a hit, nothing is listed for the merges)
+        // (the deferred tiles in two kernels -- starts by the deferred-tile instance, the rest by the one-tile-per-workgroup instance, whose
+        // grid is the list's length -- where the host reads the counters anyway; debug bit 16: one kernel as before)
+        const bool split = can_fall_back && !(c->dbg & 16) && !(c->dbg & 0x1F000);
+        fdbg &= ~TKF_DBG_GIVEN;  // (an internal flag, not one of $TIKTOKEN_AMD_DEBUG's)
+        if (split) fdbg |= TKF_DBG_GIVEN;
         TRY(timed(c, s, "tk_k_front_slow", [&] {
             launch_front<true>(pat_id, job.spec, grid, s, T, job.d_text, job.n, job.base, w.brk.as<uint32_t>(), docb, ss, si, fo, mt_arg, (1u << job.mt_bits) - 1u,
                                w.deferred.as<uint32_t>(), gapb, (fdbg & ~TKF_DBG_SECOND) | (can_fall_back ? TKF_DBG_MAY_GIVE_UP : 0));
@@ -696,6 +701,13 @@ static int stage_deferred(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream
                                        w.deferred.as<uint32_t>() + job.ntiles + 2, gapb, (fdbg & ~TKF_DBG_MAY_GIVE_UP) | TKF_DBG_SECOND);
                 }));
                 c->st_fallbacks += 1;
+            }
+            const uint32_t n_def = w.h_counters[TK_CNT_DEFER];
+            if (split && n_def) {
+                TRY(timed(c, s, "tk_k_front_given", [&] {
+                    launch_front<false>(pat_id, job.spec, dim3(n_def), s, T, job.d_text, job.n, job.base, w.brk.as<uint32_t>(), docb, ss, si, fo, mt_arg,
+                                        (1u << job.mt_bits) - 1u, w.deferred.as<uint32_t>(), gapb, (fdbg & ~(TKF_DBG_SECOND | TKF_DBG_MAY_GIVE_UP)) | TKF_DBG_GIVEN);
+                }));
             }
         }
     }
@@ -829,7 +841,7 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
             const dim3 grid((uint32_t)ntiles);
             launch_front<false>(T.pat.generic() ? TK_PAT_GENERIC : T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, fo,
                                 mt_arg, (1u << job.mt_bits) - 1u, deferred, c->has_rx ? w.rx_gst.as<uint32_t>() + nwords + 2 : (const uint32_t*)nullptr,
-                                c->dbg | (pretok_only ? 8 : 0) | ((c->has_rx && !(c->dbg & 4)) ? TKF_DBG_HARD_ONLY : 0));  // (debug bit 4: the scanners run even so)
+                                (c->dbg & ~TKF_DBG_GIVEN) | (pretok_only ? 8 : 0) | ((c->has_rx && !(c->dbg & 4)) ? TKF_DBG_HARD_ONLY : 0));  // (debug bit 4: the scanners run even so)
         }));
     } else if (n > 0) {
         hipLaunchKernelGGL(tk_k_chunk_clear, dim3(1), dim3(256), 0, s, clr);
@@ -1465,8 +1477,11 @@ static int encode_mid(tk_core* c, const uint8_t* utf8, uint32_t n, uint32_t** to
     // (segments leave EVERY piece of more than TK_SMALL_PIECE bytes that is not a token to the general pipeline: sixty-four workgroups each
     // waiting for its longest chain of merges cost more than the pipeline, whose merge kernel runs all the chains of the document side by side
     // -- measured on web text, profiles/r04_mid_calls_corpus.txt)
-    // (debug bit 0x20000000: the segments keep their long pieces -- for the experiment with both kinds of merge in one phase, TK_SMALL_ONE_PHASE)
-    for (uint32_t i = 0; i < k; ++i) small_slot_submit(mine[i], utf8 + cuts[i], cuts[i + 1] - cuts[i], !(c->dbg & 0x20000000));
+    // (documents of up to 6 KiB: the segments merge their long pieces themselves -- 4 KiB of web text 140 us against 162 when a segment gives the
+    // document up at such a piece, and 170 through the general pipeline; from 16 KiB on the pipeline wins on such text either way:
+    // profiles/r05_small_variants.txt.  Debug bit 0x20000000: always.)
+    const bool keep_long = n <= 6144u || (c->dbg & 0x20000000);
+    for (uint32_t i = 0; i < k; ++i) small_slot_submit(mine[i], utf8 + cuts[i], cuts[i + 1] - cuts[i], !keep_long);
     TRY(small_wait(c, mine, k));
     // the segments' tokens, one after the other.  A segment the small kernel did not do sends the WHOLE document to the general pipeline (one pass
     // over 64 KiB costs it little more than one over 2 KiB; segment by segment it was 1.4x the pipeline on web text), and the next calls do not

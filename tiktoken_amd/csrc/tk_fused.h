@@ -52,6 +52,11 @@
 // ARE its hard starts, phases B-D (classes, certain starts, scanners: 2 of the kernel's 5.3 ms per GiB) are skipped by the one-tile-per-
 // workgroup instances.  The deferred-tile instance never takes this way (it is the general one).
 #define TKF_DBG_HARD_ONLY 0x40000000
+// The deferred tiles in TWO kernels (round 5; the deferred-tile instance compiles at 128 registers with ~90 spilled, four workgroups per
+// CU): with this bit the deferred-tile instance only FINDS the piece starts with the workgroup-wide scanner -- it leaves the tile's start
+// bitmap and, in tile_np, where the tile's last piece ends -- and the one-tile-per-workgroup instance, given the same bit and the deferred
+// list, takes starts and end from there and does the rest (phases E and F) at its eight workgroups per CU.
+#define TKF_DBG_GIVEN 0x200000
 #define TKF_BATCH 960  // pieces per probe batch of the front kernel (the class lists hold 1024 entries, their packed counter 1023)
 #define TKF_CAP 4096  // piece ids per tile: pid = tile * TKF_CAP + k (a 4096-byte tile starts at most 4096 pieces)
 // The tail of a tile's run of result words holds, from the back: the number of its pieces that are not tokens (TKF_TAIL_NMISS), the number
@@ -636,7 +641,7 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
     if (PERSIST && item >= n_items) return;
     do {
     if (PERSIST && item != blockIdx.x) __syncthreads();  // (the shared arrays are reused by the next tile)
-    const uint64_t tile = SLOW ? (uint64_t)deferred[item] : (uint64_t)item;
+    const uint64_t tile = (SLOW || (dbg & TKF_DBG_GIVEN)) ? (uint64_t)deferred[item] : (uint64_t)item;
     auto defer_tile = [&]() {
         if (tid == 0) deferred[atomicAdd(&out.counters[TK_CNT_DEFER], 1u)] = (uint32_t)tile;
     };
@@ -695,7 +700,15 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
 #ifndef TKF_HARD_ONLY
 #define TKF_HARD_ONLY 1
 #endif
-    if (TKF_HARD_ONLY && !SLOW && (dbg & TKF_DBG_HARD_ONLY)) {
+    if (!SLOW && (dbg & TKF_DBG_GIVEN)) {
+        // ---- the tile's piece starts and the end of its last piece are given (the deferred-tile instance has found them)
+        if (tid < TK_TILE / 32) {
+            const uint64_t wgp = tile_start / 32 + tid;
+            bits[tid] = wgp * 32 < n ? out.starts[wgp] : 0u;
+        }
+        if (tid == 0) last_end_sh = out.tile_np[tile];
+        __syncthreads();
+    } else if (TKF_HARD_ONLY && !SLOW && (dbg & TKF_DBG_HARD_ONLY)) {
         // ---- hard starts only: the pieces that start in the tile begin at its hard starts; the last of them ends at the first hard start
         // at or behind the tile's end -- in the 128 bytes of look-ahead, or the tile is one for the workgroup-wide scanner
         const uint32_t te = (uint32_t)(tile_end - tile_start) + (uint32_t)TK2_LEFT;
@@ -1082,6 +1095,14 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
     }
     if (dbg & 0x8000) {  // (perf experiments: stop after this phase)
         if (tid == 0) out.tile_np[tile] = 0;
+        continue;
+    }
+    if (SLOW && (dbg & TKF_DBG_GIVEN)) {  // the starts are found: the rest is the other instance's (see TKF_DBG_GIVEN)
+        if (tid < TK_TILE / 32) {
+            const uint64_t wgp = tile_start / 32 + tid;
+            if (wgp * 32 < n) out.starts[wgp] = bits[tid];
+        }
+        if (tid == 0) out.tile_np[tile] = last_end_sh;
         continue;
     }
     // ---- E: enumerate the pieces of the tile (set bits of `bits`, in order) -> plist (aliases the bitmaps)
@@ -1735,8 +1756,14 @@ __device__ __forceinline__ uint32_t tkm_group_min(uint32_t v, int lg) {
     if (lg >= 2) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x4E, 0xF, 0xF, false));   // quad_perm [2,3,0,1]: lane ^ 2
     if (lg >= 3) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x141, 0xF, 0xF, false));  // row_half_mirror: the other quad of 8
     if (lg >= 4) v = min(v, (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, 0x140, 0xF, 0xF, false));  // row_mirror: the other half of 16
-    if (lg >= 5) v = min(v, (uint32_t)__shfl_xor((int)v, 16, 64));
-    if (lg >= 6) v = min(v, (uint32_t)__shfl_xor((int)v, 32, 64));
+    if (lg >= 5) {
+        // (32 and 64 lanes: the rows' minima through the scalar unit -- four v_readlane and three s_min -- instead of two dependent bpermutes
+        // through the LDS crossbar, on the chain of every merge of the longest pieces)
+        const uint32_t r0 = (uint32_t)__builtin_amdgcn_readlane((int)v, 0), r1 = (uint32_t)__builtin_amdgcn_readlane((int)v, 16);
+        const uint32_t r2 = (uint32_t)__builtin_amdgcn_readlane((int)v, 32), r3 = (uint32_t)__builtin_amdgcn_readlane((int)v, 48);
+        const uint32_t lo = min(r0, r1), hi = min(r2, r3);
+        v = lg >= 6 ? min(lo, hi) : ((threadIdx.x & 32u) ? hi : lo);
+    }
     return v;
 }
 // both probes of a merge by one lane: the first buckets of the two in flight together (packed table)
@@ -2912,12 +2939,6 @@ __global__ void tk_k_single_front(TkTables T, const uint8_t* __restrict__ text, 
 #define TK_SMALL_MAX 2048
 #define TK_SMALL_PIECE 24
 #define TK_SMALL_LONG 256  // (a multiple of 16)
-#ifndef TK_SMALL_ONE_PHASE
-#define TK_SMALL_ONE_PHASE 0  // 1: the experiment in tk_k_small (both kinds of merge in one phase), 2: ... and TK_SMALL_K merges per round; variants only
-#endif
-#ifndef TK_SMALL_K
-#define TK_SMALL_K 4
-#endif
 #define TK_SMALL_NO_LONG 0x80000000u  // TkSmallReq::n bit: a piece of more than TK_SMALL_PIECE bytes that is not a token ends the call (status 2)
 #define TK_SMALL_HDR 4  // result words before the tokens: status (1 done, 2 not handled), token count, completion sequence number, 0
 struct TkSmallAcc {
@@ -2951,24 +2972,12 @@ __global__ __launch_bounds__(256) void tk_k_small(TkTables T, TkSmallReqs R) {
     __shared__ uint32_t lid[TK_SMALL_MAX];  // long pieces: the parts' ids at their text positions; in the end the piece's tokens from its start on
     __shared__ uint16_t llist[TK_SMALL_MAX / (TK_SMALL_PIECE + 1) + 3];  // the long pieces that are not tokens (indices into plist)
     __shared__ uint32_t np_sh, bail_sh, nlong_sh, scan_sh[8];
-#if TK_SMALL_ONE_PHASE
     // (every merge at the piece's text positions: ids in lid, ranks in lrk -- the one-lane merges as well, so that both kinds run side by side)
     __shared__ uint32_t lrk[TK_SMALL_MAX];
     __shared__ uint16_t lnx[TK_SMALL_MAX], lpv[TK_SMALL_MAX];
     __shared__ uint16_t slist[TK_SMALL_MAX / 2];  // the pieces of 2 .. TK_SMALL_PIECE bytes that are not tokens (indices into plist)
     __shared__ uint32_t nshort_sh;
-#if TK_SMALL_ONE_PHASE >= 2
-    __shared__ uint16_t lst[TK_SMALL_MAX];  // the round that last barred the part at this position (see the K merges per round below)
-#endif
     (void)ws;
-#else
-    __shared__ uint32_t idb[TK_SMALL_PIECE * 256], rkb[TK_SMALL_PIECE * 256];
-    // (work arrays of the long pieces, free until the one-lane merges start: ranks where rkb is, the list links where idb is)
-    static_assert(TK_SMALL_PIECE * 256 >= TK_SMALL_MAX, "the long pieces' work arrays lie in idb / rkb");
-    uint32_t* const lrk = rkb;
-    uint16_t* const lnx = (uint16_t*)idb;
-    uint16_t* const lpv = lnx + TK_SMALL_MAX;
-#endif
     const uint32_t tid = threadIdx.x;
     const TkPat pat = T.pat;
     for (uint32_t i = tid * 4u; i < TK_SMALL_MAX + 16u; i += 1024u) *(uint32_t*)(raw + i) = i < n ? *(const uint32_t*)(text + i) : 0u;  // (input buffer is padded)
@@ -3005,9 +3014,8 @@ __global__ __launch_bounds__(256) void tk_k_small(TkTables T, TkSmallReqs R) {
     }
     __syncthreads();
     const uint32_t np = np_sh;
-#if TK_SMALL_ONE_PHASE
-    // EXPERIMENT (tools/build_variant.sh small1 -DTK_SMALL_ONE_PHASE=1; not in the shipped library): the one-lane merges and the sixteen-lane
-    // merges in ONE phase -- a wavefront takes units, first the long pieces (four to a unit), then the short ones (sixty-four to a unit) --
+    // The one-lane merges and the sixteen-lane merges in ONE phase (written at the end of round 4, first run and shipped in round 5:
+    // profiles/r05_small_variants.txt) -- a wavefront takes units, first the long pieces (four to a unit), then the short ones (sixty-four to a unit) --
     // so that the call waits for its longest chain of merges once, not for the long pieces' and then for every round of 256 short ones
     // (profiles/r04_mid_calls_corpus.txt: 2 KiB of web text 250 us against the pipeline's 160).  Every piece's tokens end up in lid from the
     // piece's start on, their number in nxt[start].
@@ -3064,104 +3072,6 @@ __global__ __launch_bounds__(256) void tk_k_small(TkTables T, TkSmallReqs R) {
             }
             __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
             __builtin_amdgcn_wave_barrier();
-#if TK_SMALL_ONE_PHASE >= 2
-            // EXPERIMENT, level 2 (-DTK_SMALL_ONE_PHASE=2): TK_SMALL_K merges per round of probes.  A merge is the latency of its two probes
-            // (~1 us); the round's merges are CHOSEN before any probe is answered -- the t-th choice is the lowest pair whose two parts no
-            // earlier choice has barred (barred: the part before, the merged part, the absorbed part, the part behind) --, all the new pairs
-            // are probed at once (lanes 2t and 2t + 1 of the piece's sixteen) with the ids of before the round, and the choices are carried
-            // out in order as long as each is the lowest pair of the state it meets: then it IS the reference's next merge (lib.rs:151,190).
-            // Simulated on the CPU first (tools/sim_merge_steps.py, tests/test_merge_schedule_sim.py: exact; 2.9 merges per round for K = 4).
-            constexpr int K = TK_SMALL_K;
-            static_assert(K >= 1 && K <= 8, "two lanes of sixteen per merge");
-            uint16_t* const st = lst + s0;
-            for (uint32_t k = g; k < len; k += 16u) st[k] = 0;
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            for (uint32_t round = 1;; ++round) {  // (at most len - 1 rounds: every round merges)
-                uint32_t ci[K], cm[K];
-#pragma unroll
-                for (int t = 0; t < K; ++t) ci[t] = 0xFFFFFFFFu, cm[t] = TK_RANK_MAX;
-                uint32_t nc = 0;   // the piece's choices this round (uniform over its lanes)
-                bool more = true;  // (uniform over the piece's lanes)
-#pragma unroll
-                for (int t = 0; t < K; ++t) {
-                    uint32_t br = TK_RANK_MAX, bk = 0xFFFFFFFFu;
-                    if (more)
-                        for (uint32_t k = g; k < len; k += 16u) {
-                            const uint32_t r = rk[k];
-                            if (r < br && st[k] != (uint16_t)round && st[nx[k]] != (uint16_t)round) br = r, bk = k;  // (a pair: nx[k] < len)
-                        }
-                    const uint32_t m = tkm_group_min(br, 4);
-                    const bool have = m != TK_RANK_MAX;
-                    const uint32_t i = tkm_group_min(br == m ? bk : 0xFFFFFFFFu, 4);
-                    if (have) {
-                        ci[t] = i;
-                        cm[t] = m;
-                        nc = (uint32_t)t + 1u;
-                        if (g == 0u) {
-                            const uint32_t j = nx[i], nn = nx[j], pp = pv[i];
-                            st[i] = (uint16_t)round;
-                            st[j] = (uint16_t)round;
-                            if (pp != 0xFFFFu) st[pp] = (uint16_t)round;
-                            if (nn < len) st[nn] = (uint16_t)round;
-                        }
-                    }
-                    more = have;
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                }
-                if (!__any(nc != 0u)) break;
-                // the probes: lane 2t the pair (merged part, part behind), lane 2t + 1 the pair (part before, merged part) of choice t
-                const uint32_t tt = g >> 1;
-                uint32_t pi = 0xFFFFFFFFu, pm = 0;
-#pragma unroll
-                for (int t = 0; t < K; ++t)
-                    if (tt == (uint32_t)t) pi = ci[t], pm = cm[t];
-                const bool mine = pi != 0xFFFFFFFFu;
-                uint32_t pj = 0, pnn = len, ppp = 0xFFFFu, idn = 0, idp = 0;
-                if (mine) {
-                    pj = nx[pi];
-                    pnn = nx[pj];
-                    ppp = pv[pi];
-                    idn = id[pnn < len ? pnn : pi];
-                    idp = id[ppp != 0xFFFFu ? ppp : pi];
-                }
-                const bool right = !(g & 1u), probe = mine && (right ? pnn < len : ppp != 0xFFFFu);
-                uint32_t newr = TK_RANK_MAX;
-                if (probe) newr = tk_probe_pair(T, right ? pm : idp, right ? idn : pm);
-                // carried out in order; from the second on only while the choice is the lowest pair of what the earlier ones have left
-#pragma unroll
-                for (int t = 0; t < K; ++t) {
-                    bool go = (uint32_t)t < nc;
-                    if (t > 0) {
-                        uint32_t br = TK_RANK_MAX, bk = 0xFFFFFFFFu;
-                        if (go)
-                            for (uint32_t k = g; k < len; k += 16u) {
-                                const uint32_t r = rk[k];
-                                if (r < br) br = r, bk = k;
-                            }
-                        const uint32_t m = tkm_group_min(br, 4);
-                        const uint32_t i = tkm_group_min(br == m ? bk : 0xFFFFFFFFu, 4);
-                        go = go && m == cm[t] && i == ci[t];
-                        if (!go && nc > (uint32_t)t) nc = (uint32_t)t;  // (the round ends here for this piece)
-                    }
-                    if (go && tt == (uint32_t)t) {
-                        if (right) {
-                            id[pi] = pm;
-                            nx[pi] = (uint16_t)pnn;
-                            if (pnn < len) pv[pnn] = (uint16_t)pi;
-                            rk[pj] = TK_RANK_MAX;
-                            id[pj] = TK_RANK_MAX;
-                            rk[pi] = newr;
-                        } else if (ppp != 0xFFFFu) {
-                            rk[ppp] = newr;
-                        }
-                    }
-                    __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                    __builtin_amdgcn_wave_barrier();
-                }
-            }
-#else
             for (;;) {
                 uint32_t br = TK_RANK_MAX, bk = 0xFFFFFFFFu;
                 for (uint32_t k = g; k < len; k += 16u) {
@@ -3195,7 +3105,6 @@ __global__ __launch_bounds__(256) void tk_k_small(TkTables T, TkSmallReqs R) {
                 __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
                 __builtin_amdgcn_wave_barrier();
             }
-#endif
             uint32_t t = 0;
             for (uint32_t k0 = 0; __any(k0 < len); k0 += 16u) {
                 const uint32_t k = k0 + g;
@@ -3226,125 +3135,6 @@ __global__ __launch_bounds__(256) void tk_k_small(TkTables T, TkSmallReqs R) {
         for (uint32_t j = 0; j < cnt; ++j) o[j] = lid[s0 + j];
         base += tot;
     }
-#else
-    // the long pieces (nxt has done its job: from here on nxt[start of a long piece] = 0 for a token, else the number of its tokens in lid)
-    for (uint32_t i = tid; i < np; i += 256u) {
-        const uint32_t s0 = plist[i], len = (uint32_t)plist[i + 1] - s0;
-        if (len > TK_SMALL_PIECE) {
-            if (tk_lookup_text_piece(T, raw, s0, len) != TK_RANK_MAX) nxt[s0] = 0;
-            else if (len > long_max) bail_sh = 1;
-            else llist[atomicAdd(&nlong_sh, 1u)] = (uint16_t)i;
-        }
-    }
-    __syncthreads();
-    const bool bail = bail_sh != 0;
-    const uint32_t nlong = bail ? 0u : nlong_sh;
-    {
-        const uint32_t g = tid & 15u, grp = tid >> 4, gsh = tid & 48u;  // lane of the piece, piece of the sixteen, the group's first lane in the wavefront
-        for (uint32_t w0 = 0; w0 < nlong; w0 += 16u) {
-            const bool valid = w0 + grp < nlong;
-            uint32_t s0 = 0, len = 0;
-            if (valid) {
-                const uint32_t i = llist[w0 + grp];
-                s0 = plist[i];
-                len = (uint32_t)plist[i + 1] - s0;
-            }
-            uint32_t* const id = lid + s0;
-            uint32_t* const rk = lrk + s0;
-            uint16_t* const nx = lnx + s0;
-            uint16_t* const pv = lpv + s0;
-            for (uint32_t k = g; k < len; k += 16u) {
-                const uint32_t b0 = raw[s0 + k], b1 = raw[s0 + k + 1u];
-                id[k] = T.byte_rank[b0];
-                rk[k] = k + 1u < len ? T.pair2[(b0 << 8) | b1] : TK_RANK_MAX;
-                nx[k] = (uint16_t)(k + 1u);
-                pv[k] = (uint16_t)(k ? k - 1u : 0xFFFFu);
-            }
-            __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-            __builtin_amdgcn_wave_barrier();
-            for (;;) {
-                // the leftmost lowest rank: the lane's own (positions g, g + 16, ... in rising order, strict '<'), then the sixteen lanes'
-                uint32_t br = TK_RANK_MAX, bk = 0xFFFFFFFFu;
-                for (uint32_t k = g; k < len; k += 16u) {
-                    const uint32_t r = rk[k];
-                    if (r < br) br = r, bk = k;
-                }
-                const uint32_t m = tkm_group_min(br, 4);
-                const bool on = m != TK_RANK_MAX;  // (uniform over the piece's lanes)
-                if (!__any(on)) break;
-                const uint32_t i = tkm_group_min(br == m ? bk : 0xFFFFFFFFu, 4);
-                uint32_t j = 0, nn = len, pp = 0xFFFFu, idn = 0, idp = 0;
-                if (on) {
-                    j = nx[i];
-                    nn = nx[j];
-                    pp = pv[i];
-                    idn = id[nn < len ? nn : i];
-                    idp = id[pp != 0xFFFFu ? pp : i];
-                }
-                // the two pairs the merge creates, by two lanes in ONE region (two `if`s of their own would wait one after the other)
-                const bool right = g == 0u, probe = on && (right ? nn < len : (g == 1u && pp != 0xFFFFu));
-                uint32_t newr = TK_RANK_MAX;
-                if (probe) newr = tk_probe_pair(T, right ? m : idp, right ? idn : m);
-                if (on && g == 0u) {
-                    id[i] = m;
-                    nx[i] = (uint16_t)nn;
-                    if (nn < len) pv[nn] = (uint16_t)i;
-                    rk[j] = TK_RANK_MAX;
-                    id[j] = TK_RANK_MAX;  // absorbed (no token has this id): the compaction below drops it
-                    rk[i] = newr;
-                }
-                if (on && g == 1u && pp != 0xFFFFu) rk[pp] = newr;
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-            }
-            // the surviving parts, in order, from the piece's start on (in place: a part moves left or stays, and the sixteen positions of a
-            // step are read before any of them is written)
-            uint32_t t = 0;
-            for (uint32_t k0 = 0; __any(k0 < len); k0 += 16u) {
-                const uint32_t k = k0 + g;
-                const uint32_t v = k < len ? id[k] : (uint32_t)TK_RANK_MAX;
-                const uint32_t mine = (uint32_t)((__ballot(v != TK_RANK_MAX) >> gsh) & 0xFFFFull);
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-                if (v != TK_RANK_MAX) id[t + (uint32_t)__popc(mine & ((1u << g) - 1u))] = v;
-                t += (uint32_t)__popc(mine);
-                __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
-                __builtin_amdgcn_wave_barrier();
-            }
-            if (valid && g == 0u) nxt[s0] = (uint16_t)t;
-        }
-    }
-    __syncthreads();
-    uint32_t base = 0;
-    for (uint32_t r0 = 0; r0 < np && !bail; r0 += 256u) {
-        const uint32_t i = r0 + tid;
-        uint32_t cnt = 0, tok = TK_RANK_MAX, s0 = 0;
-        bool from_lid = false;
-        if (i < np) {
-            s0 = plist[i];
-            const uint32_t len = (uint32_t)plist[i + 1] - s0;
-            from_lid = len > TK_SMALL_PIECE && nxt[s0] != 0;
-            if (from_lid) {
-                cnt = nxt[s0];
-            } else {
-                tok = tk_lookup_text_piece(T, raw, s0, len);
-                if (tok != TK_RANK_MAX) cnt = 1;
-                else cnt = tk_lane_merge<256>(T, raw, s0, len, idb + tid, rkb + tid, ws + tid * TK_SMALL_PIECE);
-            }
-        }
-        uint32_t tot;
-        const uint32_t ex = tk_block_exscan_256(cnt, &tot, scan_sh);
-        if (i < np) {
-            uint32_t* o = out + TK_SMALL_HDR + base + ex;
-            if (tok != TK_RANK_MAX) o[0] = tok;
-            else if (from_lid)
-                for (uint32_t j = 0; j < cnt; ++j) o[j] = lid[s0 + j];
-            else
-                for (uint32_t j = 0; j < cnt; ++j) o[j] = ws[tid * TK_SMALL_PIECE + j];
-        }
-        base += tot;
-    }
-#endif
     __threadfence_system();
     __syncthreads();
     if (tid == 0) {

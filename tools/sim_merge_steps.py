@@ -145,7 +145,7 @@ def steps_as_a_kernel_would(piece: bytes, K: int):
 
 
 def steps_lane_by_lane(piece: bytes, K: int):
-    """tk_k_small's sixteen-lane merge with K merges per round (tk_fused.h, -DTK_SMALL_ONE_PHASE=2) transliterated lane by lane: the arrays at
+    """tk_k_small's sixteen-lane merge with K merges per round (round 4: written for tk_fused.h behind -DTK_SMALL_ONE_PHASE=2; measured in round 5 -- slower than two merges per round, profiles/r05_small_variants.txt -- and removed there) transliterated lane by lane: the arrays at
     the piece's positions (id, rk, nx, pv, the round stamps st), what each of the sixteen lanes scans (positions g, g + 16, ...), which lane
     probes and writes what, in the kernel's order of statements.  A check of the kernel's bookkeeping, not only of the schedule.
     Returns (rounds, merges, parts)."""
