@@ -1031,8 +1031,8 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
     HIPCHK(hipEventRecord(w.ev_tot, s));
     if (n > 0) {
         TRY(timed(c, s, "tk_k_place", [&] {
-            if (small_rows) hipLaunchKernelGGL(tk_k_place<1>, dim3(grid_for(ntiles, 4, 4096)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, data, stg, d_out, tok_base, w.big.as<uint32_t>(), w.row_base.as<uint32_t>());
-            else hipLaunchKernelGGL(tk_k_place<TKP_ROWS_PLACE>, dim3(grid_for(ntiles, 4, 4096)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, data, stg, d_out, tok_base, w.big.as<uint32_t>(), w.row_base.as<uint32_t>());
+            // (one instance for every size: three rows per step for inputs of a few tiles measured slower -- C1 0.082 ms against 0.060 --, profiles/r05_place_experiments.txt)
+            hipLaunchKernelGGL(tk_k_place<TKP_ROWS_PLACE>, dim3(grid_for(ntiles, 4, 4096)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, data, stg, d_out, tok_base, w.big.as<uint32_t>(), w.row_base.as<uint32_t>());
         }));
     }
     if (n > TK_BIGCOPY)  // (a token run of TK_BIGCOPY tokens needs at least as many bytes)
@@ -1327,6 +1327,15 @@ extern "C" int tk_encode_batch_device(tk_core* c, const void* d_utf8, uint64_t n
 #define TK_STAGE_BYTES (64ull << 20)
 #define TK_HOST_CHUNK (128ull << 20)
 
+// host threads of the staging copies (text into / ids out of the page-locked buffers): the copy, not the link, bounds the host-buffer
+// entries (round 4: 8 threads, 25-34 GB/s of text; a GPU box gives the container 16 cores); $TIKTOKEN_AMD_COPY_THREADS overrides
+static unsigned copy_threads(unsigned hw) {
+    if (const char* e = getenv("TIKTOKEN_AMD_COPY_THREADS")) {
+        const int v = atoi(e);
+        if (v >= 1 && v <= 64) return (unsigned)v;
+    }
+    return hw == 0 ? 4u : (hw > 16u ? 16u : hw);
+}
 static void parallel_memcpy(void* dst, const void* src, size_t n, unsigned nth) {
     if (n < (8u << 20) || nth <= 1) {
         memcpy(dst, src, n);
@@ -1662,7 +1671,7 @@ static int encode_batch_impl(tk_core* c, const uint8_t* utf8, const uint64_t* do
     std::atomic<uint64_t> blocks_sent{0};
     const int dev = c->device;
     unsigned nth = std::thread::hardware_concurrency();
-    nth = nth == 0 ? 4 : (nth > 8 ? 8 : nth);
+    nth = copy_threads(nth);
     std::thread producer([&]() {
         (void)hipSetDevice(dev);
         for (uint64_t b = 0; b < n_blocks; ++b) {
@@ -1997,7 +2006,7 @@ extern "C" int tk_decode_batch(tk_core* c, const uint32_t* tokens, const uint64_
     std::atomic<uint64_t> sent{0};
     const int dev = c->device;
     unsigned nth = std::thread::hardware_concurrency();
-    nth = nth == 0 ? 4 : (nth > 8 ? 8 : nth);
+    nth = copy_threads(nth);
     std::thread producer([&]() {
         (void)hipSetDevice(dev);
         for (uint64_t k = 0; k < n_ranges; ++k) {
