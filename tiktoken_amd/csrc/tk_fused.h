@@ -1106,16 +1106,29 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
         continue;
     }
     // ---- E: enumerate the pieces of the tile (set bits of `bits`, in order) -> plist (aliases the bitmaps)
-    {
-        uint32_t pc = tid < TK_TILE / 32 ? __popc(bits[tid]) : 0u, tot;
-        uint32_t ex = tk_block_exscan_256(pc, &tot, scan_sh);
-        if (tid < TK_TILE / 32) woff[tid] = ex;
-        if (tid == 0) {
-            np_sh = tot;
-            out.tile_np[tile] = tot;
+    // (the prefix sums over the 120 words' counts by ONE wavefront, two words a lane: no block-wide scan with its two barriers -- a tile
+    // passes a dozen barriers, and at each the four wavefronts wait for the slowest)
+    if (wid == 0) {
+        const uint32_t i0 = 2u * (uint32_t)lane, i1 = i0 + 1u;
+        const uint32_t c0 = i0 < (uint32_t)TK_TILE / 32u ? (uint32_t)__popc(bits[i0]) : 0u, c1 = i1 < (uint32_t)TK_TILE / 32u ? (uint32_t)__popc(bits[i1]) : 0u;
+        const uint32_t inc = tk_wave_scan_u32(c0 + c1, lane);
+        if (i0 < (uint32_t)TK_TILE / 32u) {  // (TK_TILE / 32 is even)
+            woff[i0] = inc - c0 - c1;
+            woff[i1] = inc - c1;
+        }
+        if (lane == 63) {
+            np_sh = inc;
+            out.tile_np[tile] = inc;
         }
     }
     __syncthreads();
+    if (tid == 0) {  // (counters of phase F: everybody has left the scanners; the barrier at the end of this phase stands before their first use)
+        ncls_sh = 0;
+        nx_sh = 0;
+        nslow_sh = 0;
+        ncont_sh = 0;
+        if (GEN) ngap_sh = 0;
+    }
     const uint32_t np = np_sh, run_base = (uint32_t)tile * TKF_CAP;
     if (tid < TK_TILE / 32) {
         uint32_t v = bits[tid], o = woff[tid];
@@ -1154,11 +1167,7 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
     uint16_t* ord_x = (uint16_t*)(pool + TK_TILE * 2);  // [1024] pieces that are not tokens (behind the piece list)
     const uint32_t* dwr = (const uint32_t*)raw;
     const bool short_tab = T.short_tab != nullptr;
-    uint32_t& ntail_sh = ncont_sh;  // pieces of the tile that are not tokens, so far = entries at the tail of its run (the scanners' counter is dead)
-    if (tid == 0) {
-        ntail_sh = 0;
-        if (GEN) ngap_sh = 0;
-    }
+    uint32_t& ntail_sh = ncont_sh;  // pieces of the tile that are not tokens, so far = entries at the tail of its run (the scanners' counter is dead; zeroed in phase E)
     // A piece that is not a token, by its identity (w0, w1, w2; kk = tk_ident_hash): claim a slot of the in-call table (first occurrence:
     // the slot's entry gets the piece, the merge kernels will find it there) or find it claimed by IDENTICAL bytes; `k0` / `k1` = the two
     // halves of slot i, which the caller has loaded.  Returns the slot, or TKF_NONE when the neighbourhood is full.  Slots are written
@@ -1211,12 +1220,14 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
     uint32_t& nxl_sh = nslow_sh;  // pieces of more than TK_XL_MAX bytes in the batch (the counter of the pieces that left the window is dead)
     for (uint32_t kb = 0; kb < np; kb += TKF_BATCH) {
         const uint32_t nb = np - kb < TKF_BATCH ? np - kb : (uint32_t)TKF_BATCH;
-        if (tid == 0) {
-            ncls_sh = 0;
-            nx_sh = 0;
-            nxl_sh = 0;
+        if (kb) {  // (the first batch's counters were zeroed in phase E)
+            if (tid == 0) {
+                ncls_sh = 0;
+                nx_sh = 0;
+                nxl_sh = 0;
+            }
+            __syncthreads();
         }
-        __syncthreads();
         // F0: length class of every piece of the batch -> lists (one packed LDS counter: short | mid << 11 | long << 22; the pieces of more
         // than TK_XL_MAX bytes, a dozen per tile, have a counter of their own)
         for (uint32_t i0 = 0; i0 < nb; i0 += 256) {
@@ -1409,7 +1420,7 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
             }
             put_ref(k != TKF_NONE, k, ref);
         }
-        __syncthreads();  // (the lists are reused by the next batch)
+        if (n_x || kb + TKF_BATCH < np) __syncthreads();  // (the lists are reused by the next batch; what F4 has counted is read below)
     }
     if (tid == 0 && np) {
         out.res[run_base + TKF_TAIL_NMISS] = ntail_sh;
