@@ -714,8 +714,15 @@ uint64_t tks_mid_segments() { return TK_MID_SEGMENTS; }
 // the link pass; bit 3: documents resolved by groups of 64 lanes (the host form of the device's wavefront).
 // bits 8..12: log2 of TkRxText::ahead (0: the default of the matcher's form).
 // bit 4: the matcher is the pattern's DFA (it must have one: tks_rx_dfa) instead of the program; bit 5 (with bit 4): the speculative lanes in
-// their one-loop form (tk_rx_speculate_lane_flat), compared bit for bit with the piece-by-piece form (error 0xFE if they differ).
+// their one-loop form (tk_rx_speculate_lane_flat), compared bit for bit with the piece-by-piece form (error 0xFE if they differ), and
+// once more over staged text (tk_rx_speculate_lane_codes: error 0xFD).
 // stats[0] = matcher runs of the speculative (+ link) pass, [1] = of the resolving pass.  Returns 0, or error bits | position << 8.
+static uint64_t g_rx_staged[2];  // lanes of the staged speculative pass that finished / that gave their segment to the one-loop lane
+extern "C" void tks_rx_staged_stats(uint64_t* out, int reset) {
+    out[0] = g_rx_staged[0];
+    out[1] = g_rx_staged[1];
+    if (reset) g_rx_staged[0] = g_rx_staged[1] = 0;
+}
 template <int DFA>  // 0: the program; 1: the pattern's table; 2: the table of a pattern that looks behind
 static uint64_t rx_split_impl(void* p, const uint8_t* text_in, uint64_t n, const uint64_t* doc_off, uint64_t n_docs, const uint64_t* spec_at,
                               const uint64_t* spec_len, uint64_t n_spec, int speculate, uint8_t* starts, uint64_t* stats) {
@@ -748,6 +755,37 @@ static uint64_t rx_split_impl(void* p, const uint8_t* text_in, uint64_t n, const
             std::vector<uint32_t> spec2(nw, 0), sgap2(nw, 0), xexit2(nseg + 1, TK_RX_UNKNOWN);
             for (uint32_t k = 0; k < nseg; ++k) tk_rx_speculate_lane<DFA>(P, t, k, seg_shift, spec2.data(), sgap2.data(), xexit2.data());
             if (spec2 != spec || sgap2 != sgap || xexit2 != xexit) return 0xFEu;
+            // ... and the lanes over STAGED text (tk_k_rx_speculate_staged: a workgroup's 256 segments as codes, the one-loop lane wherever a lane gives up)
+            if constexpr (DFA == TK_RX_M_DFA) {
+                if (seg_shift == TK_RX_SEG_SHIFT_SMALL && P.dfa_ncls <= TK_RX_CODE_MAX_CLS + 1u) {
+                    std::vector<uint32_t> spec3(nw, 0), sgap3(nw, 0), xexit3(nseg + 1, TK_RX_UNKNOWN);
+                    std::vector<uint8_t> codes(TK_RX_STAGE_BYTES);
+                    for (uint32_t s0 = 0; s0 < nseg; s0 += TK_RX_STAGE_SEGS) {
+                        const uint32_t r0 = s0 << TK_RX_SEG_SHIFT_SMALL;
+                        for (uint32_t b = 0; b < TK_RX_STAGE_BYTES; b += 16) {
+                            uint32_t o[4] = {0, 0, 0, 0};
+                            if ((uint64_t)r0 + b < n) tk_rx_codes16(P, t, r0 + b, o);
+                            tk_rx_codes_store(codes.data(), b, o);
+                        }
+                        const TkRxCodes C{codes.data(), r0, TK_RX_STAGE_BYTES};
+                        for (uint32_t k = s0; k < s0 + TK_RX_STAGE_SEGS && k < nseg; ++k) {
+                            uint32_t sb[4], gb[4], x;
+                            if (tk_rx_speculate_lane_codes(P, C, (uint32_t)n, t.ahead, k, sb, gb, &x)) {
+                                for (uint32_t i = 0; i < 4; ++i) {
+                                    if (sb[i]) spec3[4 * (size_t)k + i] |= sb[i];
+                                    if (gb[i]) sgap3[4 * (size_t)k + i] |= gb[i];
+                                }
+                                xexit3[k] = x;
+                                ++g_rx_staged[0];
+                            } else {
+                                tk_rx_speculate_lane_flat<false>(P, t, k, seg_shift, spec3.data(), sgap3.data(), xexit3.data());
+                                ++g_rx_staged[1];
+                            }
+                        }
+                    }
+                    if (spec3 != spec || sgap3 != sgap || xexit3 != xexit) return 0xFDu;
+                }
+            }
         } else {
             return 0xFFu;
         }

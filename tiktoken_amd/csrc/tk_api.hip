@@ -552,20 +552,20 @@ static uint32_t grid_for(uint64_t items, uint32_t per_block, uint32_t cap) {
     return (uint32_t)g;
 }
 
-template <bool SLOW, class... A>
+template <int MODE, class... A>
 static void launch_front(int pattern, bool spec, dim3 grid, hipStream_t s, A... a) {
     if (pattern == TK_PAT_R50K) {
-        if (spec) hipLaunchKernelGGL((tk_k_front<TK_PAT_R50K, true, SLOW>), grid, dim3(256), 0, s, a...);
-        else hipLaunchKernelGGL((tk_k_front<TK_PAT_R50K, false, SLOW>), grid, dim3(256), 0, s, a...);
+        if (spec) hipLaunchKernelGGL((tk_k_front<TK_PAT_R50K, true, MODE>), grid, dim3(256), 0, s, a...);
+        else hipLaunchKernelGGL((tk_k_front<TK_PAT_R50K, false, MODE>), grid, dim3(256), 0, s, a...);
     } else if (pattern == TK_PAT_CL100K) {
-        if (spec) hipLaunchKernelGGL((tk_k_front<TK_PAT_CL100K, true, SLOW>), grid, dim3(256), 0, s, a...);
-        else hipLaunchKernelGGL((tk_k_front<TK_PAT_CL100K, false, SLOW>), grid, dim3(256), 0, s, a...);
+        if (spec) hipLaunchKernelGGL((tk_k_front<TK_PAT_CL100K, true, MODE>), grid, dim3(256), 0, s, a...);
+        else hipLaunchKernelGGL((tk_k_front<TK_PAT_CL100K, false, MODE>), grid, dim3(256), 0, s, a...);
     } else if (pattern == TK_PAT_O200K) {
-        if (spec) hipLaunchKernelGGL((tk_k_front<TK_PAT_O200K, true, SLOW>), grid, dim3(256), 0, s, a...);
-        else hipLaunchKernelGGL((tk_k_front<TK_PAT_O200K, false, SLOW>), grid, dim3(256), 0, s, a...);
+        if (spec) hipLaunchKernelGGL((tk_k_front<TK_PAT_O200K, true, MODE>), grid, dim3(256), 0, s, a...);
+        else hipLaunchKernelGGL((tk_k_front<TK_PAT_O200K, false, MODE>), grid, dim3(256), 0, s, a...);
     } else {  // a pattern of the family that is not one of the stock three: family and parameters are run-time values
-        if (spec) hipLaunchKernelGGL((tk_k_front<TK_PAT_GENERIC, true, SLOW>), grid, dim3(256), 0, s, a...);
-        else hipLaunchKernelGGL((tk_k_front<TK_PAT_GENERIC, false, SLOW>), grid, dim3(256), 0, s, a...);
+        if (spec) hipLaunchKernelGGL((tk_k_front<TK_PAT_GENERIC, true, MODE>), grid, dim3(256), 0, s, a...);
+        else hipLaunchKernelGGL((tk_k_front<TK_PAT_GENERIC, false, MODE>), grid, dim3(256), 0, s, a...);
     }
 }
 
@@ -676,20 +676,20 @@ static int stage_deferred(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream
         TkMissKey* mt_arg = (c->dbg & 256) ? (TkMissKey*)nullptr : job.mt;
         const uint32_t* gapb = c->has_rx ? w.rx_gst.as<uint32_t>() + (job.n + 31) / 32 + 2 : (const uint32_t*)nullptr;
         int fdbg = c->dbg | (job.pretok ? 8 : 0);  // (piece starts only: every probe counts as a hit, nothing is listed for the merges)
-        // (the deferred tiles in two kernels -- starts by the deferred-tile instance, the rest by the one-tile-per-workgroup instance, whose
-        // grid is the list's length -- where the host reads the counters anyway; debug bit 16: one kernel as before)
-        const bool split = can_fall_back && !(c->dbg & 16) && !(c->dbg & 0x1F000);
-        fdbg &= ~TKF_DBG_GIVEN;  // (an internal flag, not one of $TIKTOKEN_AMD_DEBUG's)
-        if (split) fdbg |= TKF_DBG_GIVEN;
+        // The deferred tiles in two kernels: the deferred-tile instance finds a tile's piece starts (the workgroup-wide scanner: 128 registers,
+        // four workgroups per CU), the one-tile-per-workgroup instance does the rest from the starts it is given (phases E and F, at eight
+        // workgroups per CU).  Its grid is the list's length where the host reads the counters (inputs of 256 KiB and more); otherwise one
+        // workgroup per tile of the chunk, of which all but the list's length return at once.
         TRY(timed(c, s, "tk_k_front_slow", [&] {
-            launch_front<true>(pat_id, job.spec, grid, s, T, job.d_text, job.n, job.base, w.brk.as<uint32_t>(), docb, ss, si, fo, mt_arg, (1u << job.mt_bits) - 1u,
+            launch_front<TKF_MODE_STARTS>(pat_id, job.spec, grid, s, T, job.d_text, job.n, job.base, w.brk.as<uint32_t>(), docb, ss, si, fo, mt_arg, (1u << job.mt_bits) - 1u,
                                w.deferred.as<uint32_t>(), gapb, (fdbg & ~TKF_DBG_SECOND) | (can_fall_back ? TKF_DBG_MAY_GIVE_UP : 0));
         }));
-        if (can_fall_back) {
+        uint64_t n_given = job.ntiles;
+        if (can_fall_back || job.n >= (256u << 10)) {  // (small inputs do not wait for the host: a few dozen workgroups that return at once)
             HIPCHK(hipMemcpyAsync(w.h_counters, w.counters.p, TK_CNT_N * 4, hipMemcpyDeviceToHost, s));
             HIPCHK(hipEventRecord(w.ev_cnt, s));
             HIPCHK(hipEventSynchronize(w.ev_cnt));
-            if (w.h_counters[TK_CNT_DEFER2]) {
+            if (can_fall_back && w.h_counters[TK_CNT_DEFER2]) {
                 const uint64_t nwords = (job.n + 31) / 32;
                 for (Buf* b : {&w.rx_spec, &w.rx_gst, &w.rx_lnk}) {
                     TRY(ensure(*b, 2 * (nwords + 2) * 4));
@@ -697,18 +697,18 @@ static int stage_deferred(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream
                 }
                 TRY(rx_split(c, w, s, job.d_text, job.n, w.brk.as<uint32_t>(), ss, si, job.d_doc_off, job.n_docs, job.base));
                 TRY(timed(c, s, "tk_k_front_slow", [&] {
-                    launch_front<true>(pat_id, job.spec, grid, s, T, job.d_text, job.n, job.base, w.brk.as<uint32_t>(), docb, ss, si, fo, mt_arg, (1u << job.mt_bits) - 1u,
+                    launch_front<TKF_MODE_STARTS>(pat_id, job.spec, grid, s, T, job.d_text, job.n, job.base, w.brk.as<uint32_t>(), docb, ss, si, fo, mt_arg, (1u << job.mt_bits) - 1u,
                                        w.deferred.as<uint32_t>() + job.ntiles + 2, gapb, (fdbg & ~TKF_DBG_MAY_GIVE_UP) | TKF_DBG_SECOND);
                 }));
                 c->st_fallbacks += 1;
             }
-            const uint32_t n_def = w.h_counters[TK_CNT_DEFER];
-            if (split && n_def) {
-                TRY(timed(c, s, "tk_k_front_given", [&] {
-                    launch_front<false>(pat_id, job.spec, dim3(n_def), s, T, job.d_text, job.n, job.base, w.brk.as<uint32_t>(), docb, ss, si, fo, mt_arg,
-                                        (1u << job.mt_bits) - 1u, w.deferred.as<uint32_t>(), gapb, (fdbg & ~(TKF_DBG_SECOND | TKF_DBG_MAY_GIVE_UP)) | TKF_DBG_GIVEN);
-                }));
-            }
+            n_given = w.h_counters[TK_CNT_DEFER];
+        }
+        if (n_given && !(c->dbg & 0x1F000)) {  // (debug bits 0x1000 .. 0x10000: the kernels stop after a phase, there are no starts to go on from)
+            TRY(timed(c, s, "tk_k_front_given", [&] {
+                launch_front<TKF_MODE_GIVEN>(pat_id, job.spec, dim3((uint32_t)n_given), s, T, job.d_text, job.n, job.base, w.brk.as<uint32_t>(), docb, ss, si, fo, mt_arg,
+                                    (1u << job.mt_bits) - 1u, w.deferred.as<uint32_t>(), gapb, fdbg & ~(TKF_DBG_SECOND | TKF_DBG_MAY_GIVE_UP));
+            }));
         }
     }
     HIPCHK(hipMemcpyAsync(w.h_counters, w.counters.p, TK_CNT_N * 4, hipMemcpyDeviceToHost, s));
@@ -839,9 +839,9 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
         TkMissKey* mt_arg = (c->dbg & 256) ? (TkMissKey*)nullptr : job.mt;
         TRY(timed(c, s, "tk_k_front", [&] {
             const dim3 grid((uint32_t)ntiles);
-            launch_front<false>(T.pat.generic() ? TK_PAT_GENERIC : T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, fo,
+            launch_front<TKF_MODE_TILE>(T.pat.generic() ? TK_PAT_GENERIC : T.pattern, ss != nullptr, grid, s, T, d_text, n, base, brk, docb, ss, si, fo,
                                 mt_arg, (1u << job.mt_bits) - 1u, deferred, c->has_rx ? w.rx_gst.as<uint32_t>() + nwords + 2 : (const uint32_t*)nullptr,
-                                (c->dbg & ~TKF_DBG_GIVEN) | (pretok_only ? 8 : 0) | ((c->has_rx && !(c->dbg & 4)) ? TKF_DBG_HARD_ONLY : 0));  // (debug bit 4: the scanners run even so)
+                                c->dbg | (pretok_only ? 8 : 0) | ((c->has_rx && !(c->dbg & 4)) ? TKF_DBG_HARD_ONLY : 0));  // (debug bit 4: the scanners run even so)
         }));
     } else if (n > 0) {
         hipLaunchKernelGGL(tk_k_chunk_clear, dim3(1), dim3(256), 0, s, clr);

@@ -52,11 +52,14 @@
 // ARE its hard starts, phases B-D (classes, certain starts, scanners: 2 of the kernel's 5.3 ms per GiB) are skipped by the one-tile-per-
 // workgroup instances.  The deferred-tile instance never takes this way (it is the general one).
 #define TKF_DBG_HARD_ONLY 0x40000000
-// The deferred tiles in TWO kernels (round 5; the deferred-tile instance compiles at 128 registers with ~90 spilled, four workgroups per
-// CU): with this bit the deferred-tile instance only FINDS the piece starts with the workgroup-wide scanner -- it leaves the tile's start
-// bitmap and, in tile_np, where the tile's last piece ends -- and the one-tile-per-workgroup instance, given the same bit and the deferred
-// list, takes starts and end from there and does the rest (phases E and F) at its eight workgroups per CU.
-#define TKF_DBG_GIVEN 0x200000
+// The deferred tiles in TWO kernels (round 5).  The scanner of the deferred tiles compiles at 128 registers with ~70 spilled, four
+// workgroups per CU: so its instance (TKF_MODE_STARTS) only FINDS the piece starts -- it leaves the tile's start bitmap and, in tile_np,
+// where the tile's last piece ends -- and a third instance (TKF_MODE_GIVEN), launched over the deferred list, takes starts and end from
+// there and does the rest (phases E and F) at the eight workgroups per CU of the common instance (TKF_MODE_TILE: one workgroup per tile,
+// phases A-F).  Three instances, three kernel names in a trace.
+#define TKF_MODE_TILE 0
+#define TKF_MODE_STARTS 1
+#define TKF_MODE_GIVEN 2
 #define TKF_BATCH 960  // pieces per probe batch of the front kernel (the class lists hold 1024 entries, their packed counter 1023)
 #define TKF_CAP 4096  // piece ids per tile: pid = tile * TKF_CAP + k (a 4096-byte tile starts at most 4096 pieces)
 // The tail of a tile's run of result words holds, from the back: the number of its pieces that are not tokens (TKF_TAIL_NMISS), the number
@@ -591,14 +594,15 @@ __device__ __forceinline__ bool tk_equal_lds_text(const uint8_t* raw, uint32_t o
 #ifndef TKF_ROWS
 #define TKF_ROWS 1  // phase F: one length class per row of 64 pieces (0: the three classes side by side in every lane)
 #endif
-template <int PAT, bool SPEC, bool SLOW>
-__global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
+template <int PAT, bool SPEC, int MODE>
+__global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
                                                   const uint32_t* __restrict__ brk, const uint32_t* __restrict__ docb,
                                                   const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, TkFrontOut out,
                                                   TkMissKey* __restrict__ mt, uint32_t mt_mask, uint32_t* __restrict__ deferred,
                                                   const uint32_t* __restrict__ gapb /* gap chars of the generic engine's split, or null */, int dbg) {
     // the pattern: a compile-time constant for the three stock patterns; PAT = TK_PAT_GENERIC reads family and parameters from the tables
     constexpr bool GEN = PAT == TK_PAT_GENERIC;
+    constexpr bool SLOW = MODE == TKF_MODE_STARTS, GIVEN = MODE == TKF_MODE_GIVEN;
     const TkPat pat = GEN ? T.pat : tk_stock_pat(PAT);
     const int fam = GEN ? T.pat.fam() : PAT;
     constexpr int NW = TK2_NSEG + 2;            // 64-bit words per bitmap (two sentinel words beyond the window)
@@ -639,9 +643,11 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
     constexpr bool PERSIST = SLOW;
     const uint32_t n_items = SLOW ? out.counters[(dbg & TKF_DBG_SECOND) ? TK_CNT_DEFER2 : TK_CNT_DEFER] : gridDim.x;
     if (PERSIST && item >= n_items) return;
+    // (the rest of the deferred tiles where the host has not read their number: a grid of one workgroup per tile of the chunk, the list's length decides)
+    if (GIVEN && item >= out.counters[TK_CNT_DEFER]) return;
     do {
     if (PERSIST && item != blockIdx.x) __syncthreads();  // (the shared arrays are reused by the next tile)
-    const uint64_t tile = (SLOW || (dbg & TKF_DBG_GIVEN)) ? (uint64_t)deferred[item] : (uint64_t)item;
+    const uint64_t tile = (SLOW || GIVEN) ? (uint64_t)deferred[item] : (uint64_t)item;
     auto defer_tile = [&]() {
         if (tid == 0) deferred[atomicAdd(&out.counters[TK_CNT_DEFER], 1u)] = (uint32_t)tile;
     };
@@ -700,7 +706,7 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
 #ifndef TKF_HARD_ONLY
 #define TKF_HARD_ONLY 1
 #endif
-    if (!SLOW && (dbg & TKF_DBG_GIVEN)) {
+    if constexpr (GIVEN) {
         // ---- the tile's piece starts and the end of its last piece are given (the deferred-tile instance has found them)
         if (tid < TK_TILE / 32) {
             const uint64_t wgp = tile_start / 32 + tid;
@@ -1097,14 +1103,14 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
         if (tid == 0) out.tile_np[tile] = 0;
         continue;
     }
-    if (SLOW && (dbg & TKF_DBG_GIVEN)) {  // the starts are found: the rest is the other instance's (see TKF_DBG_GIVEN)
+    if constexpr (SLOW) {  // the starts are found: the rest is the other instance's (TKF_MODE_GIVEN)
         if (tid < TK_TILE / 32) {
             const uint64_t wgp = tile_start / 32 + tid;
             if (wgp * 32 < n) out.starts[wgp] = bits[tid];
         }
         if (tid == 0) out.tile_np[tile] = last_end_sh;
         continue;
-    }
+    } else {
     // ---- E: enumerate the pieces of the tile (set bits of `bits`, in order) -> plist (aliases the bitmaps)
     // (the prefix sums over the 120 words' counts by ONE wavefront, two words a lane: no block-wide scan with its two barriers -- a tile
     // passes a dozen barriers, and at each the four wavefronts wait for the slowest)
@@ -1426,6 +1432,7 @@ __global__ __launch_bounds__(256, SLOW ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front
         out.res[run_base + TKF_TAIL_NMISS] = ntail_sh;
         out.res[run_base + TKF_TAIL_NGAP] = GEN ? ngap_sh : 0u;
     }
+    }  // (!SLOW)
     } while (PERSIST && (item += gridDim.x) < n_items);
 }
 

@@ -284,6 +284,187 @@ TK_HD void tk_rx_speculate_lane_flat(const TkRxProg& P, TkRxText t, uint32_t k, 
     xexit[k] = x;
 }
 
+// ---- The speculative pass over STAGED text (round 5: tk_k_rx_speculate_staged, tk_regex_kernels.h) ----------------------------------
+// The one-loop lane above reads its text, its bits of `brk` and its words of `spec` from global memory as it walks: sixty-four different
+// cache lines per load instruction, and a wait in nearly every iteration of the wavefront's loop.  Here a workgroup first turns the 32 KiB of
+// its 256 segments (plus TK_RX_STAGE_HALO bytes behind them) into one CODE per byte, in LDS -- whole 16-byte blocks per lane, every load
+// coalesced, the UTF-8 decoding and the class look-ups done once per char instead of once per visit -- and the lanes then walk codes:
+//   0 .. TK_RX_CODE_MAX_CLS   the DFA class of the char that starts at this byte (0: the end of the text)
+//   | TK_RX_CODE_HARD         ... and a hard start (a document begins, the edge of a special token)
+//   TK_RX_CODE_CONT           a continuation byte of a well-formed char (the walk steps over it)
+//   TK_RX_CODE_ESC            anything else: a special token, bytes that are not well-formed UTF-8, a hard start inside a char
+// A lane that meets TK_RX_CODE_ESC, leaves the staged stretch or looks further ahead than the one-loop lane may (TkRxText::ahead) gives
+// its segment to that lane -- whatever is unusual is decided by the code that has been compared with the matcher for four rounds, and the
+// new loop only ever does what that code does on plain text.  It keeps the bits of its four words of `spec` / `sgap` in registers and
+// stores them once.  The CPU tests run both forms side by side on every text they split (tests/hostsim, tks_rx_split bit 5) and compare
+// bitmaps and exits bit for bit.
+#define TK_RX_CODE_CONT 0x7Fu
+#define TK_RX_CODE_ESC 0x7Eu
+#define TK_RX_CODE_HARD 0x80u
+#define TK_RX_CODE_MAX_CLS 0x7Du
+#define TK_RX_STAGE_SEGS 256u   // segments (of 1 << TK_RX_SEG_SHIFT_SMALL bytes) per workgroup
+#define TK_RX_STAGE_HALO 256u   // bytes staged behind them (a multiple of the segment)
+#define TK_RX_STAGE_BYTES ((TK_RX_STAGE_SEGS << TK_RX_SEG_SHIFT_SMALL) + TK_RX_STAGE_HALO)
+
+// Where the code of the byte at offset o of the staged stretch lives: the lanes of a wavefront stand at about the same offset of their
+// segments, 128 bytes apart -- one LDS bank -- so segment s is rotated by 4 s bytes within itself.
+TK_HD uint32_t tk_rx_code_addr(uint32_t o) { return (o & ~127u) | ((o + 4u * (o >> 7)) & 127u); }
+
+struct TkRxCodes {
+    const uint8_t* c;  // codes of the positions [r0, r0 + len)
+    uint32_t r0, len;
+    TK_HD uint32_t at(uint32_t pos) const {
+        const uint32_t o = pos - r0;
+        return o < len ? (uint32_t)c[tk_rx_code_addr(o)] : TK_RX_CODE_ESC;
+    }
+};
+// the four words of codes of the 16-byte block at offset o (a multiple of 16)
+TK_HD void tk_rx_codes_store(uint8_t* c, uint32_t o, const uint32_t w[4]) {
+#pragma unroll
+    for (uint32_t i = 0; i < 4u; ++i) *(uint32_t*)(c + tk_rx_code_addr(o + 4u * i)) = w[i];  // (a word never wraps: the rotation is a multiple of four)
+}
+
+// bits of a bitmap for the 24 positions blk - 4 .. blk + 19 (blk a multiple of 16; the bitmaps have two words of slack)
+TK_HD uint32_t tk_rx_bits24(const uint32_t* bm, uint32_t blk) {
+    if (blk == 0u) return (bm[0] << 4) & 0xFFFFFFu;
+    const uint32_t q = blk - 4u;
+    const uint64_t v = (uint64_t)bm[q >> 5] | ((uint64_t)bm[(q >> 5) + 1u] << 32);
+    return (uint32_t)(v >> (q & 31u)) & 0xFFFFFFu;
+}
+// bits 7, 15, 23, 31 of m -> bits 0 .. 3
+TK_HD uint32_t tk_rx_pack4(uint32_t m) { return ((((m >> 7) & 0x01010101u) * 0x01020408u) >> 24) & 0xFu; }
+
+// the codes of the 16-byte block at blk (a multiple of 16), four to a word
+template <class A>
+TK_HD void tk_rx_codes16(const TkRxProg& P, const A& t, uint32_t blk, uint32_t out[4]) {
+    out[0] = out[1] = out[2] = out[3] = 0u;
+    if (blk >= t.n) return;
+    uint32_t w[6];  // bytes blk - 4 .. blk + 19: the chars that reach into the block or out of it
+    w[0] = blk ? t.word(blk - 4u) : 0u;
+    t.block16(blk, w + 1);
+    w[5] = t.word(blk + 16u);  // (the text is readable 64 bytes past n)
+    const uint32_t hard = tk_rx_bits24(t.brk, blk);
+    const uint32_t spc = t.ss ? (tk_rx_bits24(t.ss, blk) | tk_rx_bits24(t.si, blk)) : 0u;
+    const uint32_t left = t.n - blk;  // (> 0)
+    uint32_t valid = left >= 20u ? 0xFFFFFFu : ((1u << (left + 4u)) - 1u);  // window positions that are text
+    if (blk == 0u) valid &= ~0xFu;
+    // byte kinds over the window, a bit per position
+    uint32_t hi = 0u, isc = 0u, l2 = 0u, l3 = 0u, l4 = 0u;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+        const uint32_t m80 = w[i] & 0x80808080u, m40 = (w[i] << 1) & 0x80808080u, m20 = (w[i] << 2) & 0x80808080u, m10 = (w[i] << 3) & 0x80808080u;
+        const uint32_t lead = m80 & m40;
+        hi |= tk_rx_pack4(m80) << (4 * i);
+        isc |= tk_rx_pack4(m80 & ~m40) << (4 * i);
+        l2 |= tk_rx_pack4(lead & ~m20) << (4 * i);
+        l3 |= tk_rx_pack4(lead & m20 & ~m10) << (4 * i);
+        l4 |= tk_rx_pack4(lead & m20 & m10) << (4 * i);
+    }
+    hi &= valid;
+    isc &= valid;
+    l2 &= valid;
+    l3 &= valid;
+    l4 &= valid;
+    // a lead is well formed when the bytes it needs are continuation bytes of the text without a hard start or a special token on them;
+    // a continuation byte is part of a char when such a lead covers it
+    const uint32_t clean = isc & ~(hard | spc);
+    const uint32_t c1 = clean >> 1, c2 = clean >> 2, c3 = clean >> 3;
+    const uint32_t ok2 = l2 & c1, ok3 = l3 & c1 & c2, ok4 = l4 & c1 & c2 & c3;
+    const uint32_t cov = (ok2 << 1) | (ok3 << 1) | (ok3 << 2) | (ok4 << 1) | (ok4 << 2) | (ok4 << 3);
+    const uint32_t esc = ((isc & ~cov) | ((l2 | l3 | l4) & ~(ok2 | ok3 | ok4)) | spc) & valid;
+#define TK_RX_B(j) ((w[(j) >> 2] >> (8u * ((j) & 3u))) & 0xFFu)
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int j = i + 4;
+        uint32_t code;
+        if (!((valid >> j) & 1u)) code = 0u;  // (at or behind the end of the text)
+        else if ((esc >> j) & 1u) code = TK_RX_CODE_ESC;
+        else if ((isc >> j) & 1u) code = TK_RX_CODE_CONT;
+        else {
+            const uint32_t b = TK_RX_B(j);
+            uint32_t cls;
+            if (b < 0x80u) {
+                cls = tk_rx_ascii_cls(P, b);
+            } else {
+                const uint32_t need = ((l2 >> j) & 1u) ? 2u : (((l3 >> j) & 1u) ? 3u : 4u);
+                uint32_t cp = ((b & (0x7Fu >> need)) << 6) | (TK_RX_B(j + 1) & 0x3Fu);
+                if (need >= 3u) cp = (cp << 6) | (TK_RX_B(j + 2) & 0x3Fu);
+                if (need == 4u) cp = (cp << 6) | (TK_RX_B(j + 3) & 0x3Fu);
+                cls = tk_rx_dfa_cls(P, cp);
+            }
+            code = cls | (((hard >> j) & 1u) ? TK_RX_CODE_HARD : 0u);
+        }
+        out[i >> 2] |= code << (8u * ((uint32_t)i & 3u));
+    }
+#undef TK_RX_B
+}
+
+// Lane k over the codes: the chain of segment k as tk_rx_speculate_lane_flat<false> finds it -- its bits of the segment's four words of
+// `spec` / `sgap` in sb / gb, its exit in *xout -- or false: the segment is that lane's (nothing has been written).
+TK_HD bool tk_rx_speculate_lane_codes(const TkRxProg& P, const TkRxCodes& C, uint32_t n, uint32_t ahead, uint32_t k, uint32_t sb[4], uint32_t gb[4], uint32_t* xout) {
+    const uint32_t a = k << TK_RX_SEG_SHIFT_SMALL, seg = 1u << TK_RX_SEG_SHIFT_SMALL;
+    const uint32_t end = n - a > seg ? a + seg : n;
+    const uint32_t limit = n - end > ahead ? end + ahead : n;
+    const uint32_t ncls = P.dfa_ncls;
+    sb[0] = sb[1] = sb[2] = sb[3] = gb[0] = gb[1] = gb[2] = gb[3] = 0u;
+    *xout = TK_RX_UNKNOWN;
+    auto note = [&](uint32_t* v, uint32_t q) {
+        const uint32_t wq = (q >> 5) & 3u, m = 1u << (q & 31u);  // (the segment starts at a multiple of 128)
+        v[0] |= wq == 0u ? m : 0u;
+        v[1] |= wq == 1u ? m : 0u;
+        v[2] |= wq == 2u ? m : 0u;
+        v[3] |= wq == 3u ? m : 0u;
+    };
+    uint32_t p = a, code;
+    for (;;) {  // the first char of the segment
+        if (p >= end) return true;
+        code = C.at(p);
+        if (code == TK_RX_CODE_ESC) return false;
+        if (code != TK_RX_CODE_CONT) break;
+        ++p;
+    }
+    note(sb, p);
+    uint32_t pos = p, last = TK_RX_FAILED, state = (p == 0u || (code & TK_RX_CODE_HARD)) ? 1u : 2u;
+    for (;;) {  // `code` is the code at pos: a class, never TK_RX_CODE_CONT or TK_RX_CODE_ESC
+        if (pos >= limit && pos < n) return false;  // the match looks too far ahead: the general form decides what to do with this piece
+        const uint32_t c = ((code & TK_RX_CODE_HARD) && pos > p) ? 0u : (code & 0x7Fu);  // (class 0: the end of the haystack)
+        const uint32_t e = P.dfa_trans[state * ncls + c];
+        if (e & 0x8000u) last = pos;
+        state = e & 0x7FFFu;
+        if (state != 0u) {
+            if (c != 0u) {  // over the char (nothing consumes the end of the haystack: the state dies there after a step or two)
+                do code = C.at(++pos);
+                while (code == TK_RX_CODE_CONT);
+                if (code == TK_RX_CODE_ESC) return false;
+            }
+            continue;
+        }
+        // the piece that starts at p is finished: it ends at `last`, or p is a char the pattern does not match (a gap piece of one char)
+        uint32_t q = last;
+        if (last == TK_RX_FAILED) {
+            q = p + 1u;
+            for (;;) {
+                const uint32_t cq = C.at(q);
+                if (cq == TK_RX_CODE_ESC) return false;
+                if (cq != TK_RX_CODE_CONT) break;
+                ++q;
+            }
+            note(gb, p);
+        }
+        if (q >= end) {
+            *xout = q;
+            return true;
+        }
+        p = q;
+        note(sb, p);
+        code = C.at(p);
+        if (code == TK_RX_CODE_ESC) return false;
+        pos = p;
+        last = TK_RX_FAILED;
+        state = (code & TK_RX_CODE_HARD) ? 1u : 2u;  // (p > 0 here)
+    }
+}
+
 // Links between consecutive segments.  The true chain enters segment k where segment k - 1 was left -- at xexit[k - 1], if that guess was
 // right -- and that position is usually NOT on segment k's own speculative chain (which started at the segment's first char): the chains
 // meet a few pieces later.  Lane k walks from xexit[k - 1] until it stands on a start of segment k's chain, noting its steps in `lnk`

@@ -64,10 +64,13 @@ def main():
         print(json.dumps({"config": name, "encoding": enc_name, "bytes": n, "docs": nd, "tokens": nt, "ms_per_step": round(el * 1e3, 3),
                           "GBps": round(n / el / 1e9, 3), "parity_all_tokens": ok, "kernels_ms_avg": kern}), flush=True)
 
+    only = set(sys.argv[1:])  # (python tools/bench_configs.py C2 C5: those configs only)
     for cfg, title, enc_name, steps in (("C1", "C1 gpt2 1MiB lorem, 1 doc", "gpt2_shaped", 10), ("C2", "C2 cl100k 64MiB mixed UTF-8", "cl100k_shaped", 3),
                                        ("C5", "C5 o200k+8 specials 256MiB, allowed_special=all", "o200k_custom8", 3),
                                        ("N1", "N1 o200k 256MiB of text with a natural miss rate (2.3 % of its pieces are not tokens; C3: 18.7 %): not a BASELINE configuration",
                                         "o200k_shaped", 3)):
+        if only and cfg not in only:
+            continue
         _, _, _, blob, off, allowed = h.baseline_config(cfg)
         run(title, enc_name, blob, off, allowed, steps=steps)
 

@@ -29,7 +29,7 @@ for V in sys.argv[2:]:
     agg = collections.defaultdict(list)
     for f in glob.glob(f"{O}/pmc_{V}/**/p_counter_collection.csv", recursive=True):
         for r in csv.DictReader(open(f)):
-            if "tk_k_front" in r["Kernel_Name"] and "true>" not in r["Kernel_Name"].split("(")[0]:
+            if "tk_k_front<" in r["Kernel_Name"] and r["Kernel_Name"].split("(")[0].replace(" ", "").endswith(",0>"):
                 agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
     g = lambda c: ("%.0f" % max(agg[c])) if agg.get(c) else ""
     print(",".join(map(str, [V, fm, am, g("SQ_INSTS_VALU"), g("SQ_INSTS_SALU"), g("SQ_INSTS_LDS"), g("SQ_INSTS_VMEM_RD"), g("SQ_WAVE_CYCLES"), g("SQ_WAIT_ANY"), g("SQ_WAIT_INST_ANY"), g("SQ_ACTIVE_INST_VALU")])))

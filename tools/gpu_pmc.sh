@@ -17,7 +17,7 @@ for f in glob.glob("gpurun_out/pmc2/*/p_counter_collection.csv"):
         k = r["Kernel_Name"].split("(")[0]
         if k.startswith("void "):
             k = k[5:]
-        k = "tk_k_front_slow" if k.startswith("tk_k_front<") and k.split(">")[0].replace(" ", "").endswith(("true", ",1")) else k.split("<")[0]
+        k = ("tk_k_front_slow" if k.split(">")[0].replace(" ", "").endswith(("true", ",1")) else "tk_k_front_given" if k.split(">")[0].replace(" ", "").endswith(",2") else "tk_k_front") if k.startswith("tk_k_front<") else k.split("<")[0]
         if k.startswith("tk_k_"):
             agg[k][r["Counter_Name"]].append(float(r["Counter_Value"]))
 for k, d in agg.items():

@@ -26,9 +26,10 @@ def canonical(name):
     """Kernel names as bench.py reports them: the pattern / special-token instances of the front kernel under one
     name, merge kernels by their piece-length class."""
     import re
-    if name.startswith("tk_k_front<"):  # <pattern, specials, slow>: the deferred-tile variant is reported under its own name
+    if name.startswith("tk_k_front<"):  # <pattern, specials, mode>: the two instances of the deferred tiles are reported under their own names
         args = name[len("tk_k_front<"):].split(">")[0].replace(" ", "").split(",")
-        return "tk_k_front_slow" if len(args) >= 3 and args[2] in ("true", "1") else "tk_k_front"
+        mode = args[2] if len(args) >= 3 else "0"
+        return "tk_k_front_slow" if mode in ("true", "1") else ("tk_k_front_given" if mode == "2" else "tk_k_front")
     m = re.match(r"tk_k_merge_llane<(\d+)", name)
     if m:
         return "tk_k_merge_llane_" + m.group(1)
