@@ -310,6 +310,7 @@ def sim_lib():
         L.tks_rx_size.argtypes = [vp]
         L.tks_rx_dfa.restype = u64
         L.tks_rx_dfa.argtypes = [vp, ctypes.c_char_p, u64]
+        L.tks_rx_staged_stats.argtypes = [vp, ctypes.c_int]
         L.tks_rx_split.restype = u64
         L.tks_rx_split.argtypes = [vp, vp, u64, vp, u64, vp, vp, u64, ctypes.c_int, vp, vp]
         L.tks_mid_plan.restype = u64

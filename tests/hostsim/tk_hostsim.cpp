@@ -757,9 +757,11 @@ static uint64_t rx_split_impl(void* p, const uint8_t* text_in, uint64_t n, const
             if (spec2 != spec || sgap2 != sgap || xexit2 != xexit) return 0xFEu;
             // ... and the lanes over STAGED text (tk_k_rx_speculate_staged: a workgroup's 256 segments as codes, the one-loop lane wherever a lane gives up)
             if constexpr (DFA == TK_RX_M_DFA) {
-                if (seg_shift == TK_RX_SEG_SHIFT_SMALL && P.dfa_ncls <= TK_RX_CODE_MAX_CLS + 1u) {
+                if (seg_shift == TK_RX_SEG_SHIFT_SMALL && P.dfa_ncls <= TK_RX_CODE_MAX_CLS + 1u && c->dfa_trans.size() < 32768u) {
                     std::vector<uint32_t> spec3(nw, 0), sgap3(nw, 0), xexit3(nseg + 1, TK_RX_UNKNOWN);
                     std::vector<uint8_t> codes(TK_RX_STAGE_BYTES);
+                    std::vector<uint16_t> trans_pm(c->dfa_trans.size());
+                    for (size_t i = 0; i < trans_pm.size(); ++i) trans_pm[i] = tk_rx_trans_premultiplied(c->dfa_trans[i], P.dfa_ncls);
                     for (uint32_t s0 = 0; s0 < nseg; s0 += TK_RX_STAGE_SEGS) {
                         const uint32_t r0 = s0 << TK_RX_SEG_SHIFT_SMALL;
                         for (uint32_t b = 0; b < TK_RX_STAGE_BYTES; b += 16) {
@@ -770,7 +772,7 @@ static uint64_t rx_split_impl(void* p, const uint8_t* text_in, uint64_t n, const
                         const TkRxCodes C{codes.data(), r0, TK_RX_STAGE_BYTES};
                         for (uint32_t k = s0; k < s0 + TK_RX_STAGE_SEGS && k < nseg; ++k) {
                             uint32_t sb[4], gb[4], x;
-                            if (tk_rx_speculate_lane_codes(P, C, (uint32_t)n, t.ahead, k, sb, gb, &x)) {
+                            if (tk_rx_speculate_lane_codes(trans_pm.data(), P.dfa_ncls, C, (uint32_t)n, t.ahead, k, sb, gb, &x)) {
                                 for (uint32_t i = 0; i < 4; ++i) {
                                     if (sb[i]) spec3[4 * (size_t)k + i] |= sb[i];
                                     if (gb[i]) sgap3[4 * (size_t)k + i] |= gb[i];

@@ -753,3 +753,52 @@ def test_look_ahead_of_a_repeat_is_one_char_only_when_the_repeat_starts_at_one()
         want = py_starts_gaps(regex.compile(pat.replace(r"[\s\S]", r"(?s:.)")), doc)
         for sp in (0, 1, 5, 13):
             assert rx.split([doc.encode()], speculate=sp) == want[0] and rx.gaps == want[1], (pat, sp)
+
+
+def test_staged_speculative_lanes_do_the_work_on_plain_text():
+    """tk_k_rx_speculate_staged's lane (tk_rx_speculate_lane_codes: a workgroup's 256 segments as one code per byte) is compared bit for bit
+    with the one-loop lane by EVERY split of this file that goes through the DFA (tks_rx_split, bit 5: error 0xFD).  That comparison would
+    also hold if every lane gave its segment up -- so here: on the bench corpora next to all lanes finish over the codes; with special
+    tokens, bytes that are not UTF-8 and runs longer than the look-ahead the lanes that meet them give up (and the split is still exact)."""
+    L = h.sim_lib()
+    st = np.zeros(2, np.uint64)
+    for name, mix in (("o200k_shaped", 1), ("cl100k_shaped", 0)):
+        rx = h.RxSim(h.load_golden(name)["pat_str"])
+        blob, off = h.gen_corpus(0x5EED0300 + mix, mix, 3 << 20)
+        bb = blob.tobytes()
+        docs = [bb[int(off[d]):int(off[d + 1])] for d in range(len(off) - 1)]
+        L.tks_rx_staged_stats(st.ctypes.data, 1)
+        want = rx.split(docs, speculate=0, matcher="dfa")
+        assert rx.split(docs, speculate=5, matcher="dfa") == want
+        L.tks_rx_staged_stats(st.ctypes.data, 1)
+        done, gave_up = int(st[0]), int(st[1])
+        assert done + gave_up >= 2 * ((3 << 20) >> 7), (done, gave_up)  # (twice: the second time with a look-ahead of 64 bytes)
+        assert gave_up * 50 < done, (name, done, gave_up)  # (the look-ahead of 64 bytes of the second run is what makes lanes give up here)
+    # what makes a lane give up, all of it in one text
+    rx = h.RxSim(h.PAT_STR[2])
+    rng = random.Random(77)
+    parts = []
+    for i in range(3000):
+        r = rng.random()
+        if r < 0.05:
+            parts.append(bytes([rng.choice([0x80, 0xBF, 0xC3, 0xE2, 0xF0, 0xFF, 0xC0])]) * rng.randrange(1, 4))
+        elif r < 0.1:
+            parts.append(b" " * rng.randrange(100, 5000))
+        elif r < 0.2:
+            parts.append("é中😀ß".encode() * rng.randrange(1, 5))
+        else:
+            parts.append(rng.choice([b"hello", b" world", b"'ll", b"123456", b"\n\n", b" The", b"...", b"x"]) * rng.randrange(1, 6))
+    text = b"".join(parts)
+    specials = []
+    at = 500
+    while at + 13 < len(text):  # (special tokens at char starts of well-formed stretches only: put where the bytes are ASCII)
+        if all(b < 0x80 for b in text[at - 1:at + 14]):
+            text = text[:at] + b"<|endoftext|>" + text[at + 13:]
+            specials.append((at, 13))
+        at += rng.randrange(3000, 9000)
+    L.tks_rx_staged_stats(st.ctypes.data, 1)
+    want = rx.split([text], specials, speculate=0, matcher="dfa")
+    for mode in (1, 5, 13):
+        assert rx.split([text], specials, speculate=mode, matcher="dfa") == want, mode
+    L.tks_rx_staged_stats(st.ctypes.data, 1)
+    assert int(st[1]) > 100 and int(st[0]) > 100, st  # (most of this text is blank runs longer than the look-ahead: more lanes give up than finish)

@@ -123,6 +123,7 @@ struct tk_core {
     uint64_t st_regrown = 0;    // batches repeated with a larger miss data (encode_device_locked)
     TkRxDev rx{};
     Buf t_rx_ins, t_rx_sets, t_rx_ranges, t_rx_first, t_rx_s1, t_rx_s2, t_rx_dtrans, t_rx_dascii, t_rx_ds1, t_rx_ds2;
+    bool rx_staged = true;  // the speculative pass over text staged in LDS where the pattern's DFA allows it ($TIKTOKEN_AMD_RX_STAGED=0: never)
     int rx_form = TK_RX_FORM_PROGRAM;  // how the generic engine's kernels match: the pattern's DFA where it has one ($TIKTOKEN_AMD_RX_MATCHER)
     std::mutex mu;
     // workspace: per chunk in flight, and what a whole call shares
@@ -357,6 +358,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
         // the pattern's DFA (tk_regex_dfa.inc), where it has one: $TIKTOKEN_AMD_RX_MATCHER = program | dfa | flat (the default) chooses the
         // kernels' form -- "dfa" keeps the piece-by-piece speculative lane, "program" interprets the backtracking program as before
         const char* want = getenv("TIKTOKEN_AMD_RX_MATCHER");
+        if (const char* st = getenv("TIKTOKEN_AMD_RX_STAGED")) c->rx_staged = strcmp(st, "0") != 0;
         if (X.has_dfa() && !(want && !strcmp(want, "program"))) {
             std::vector<uint16_t> tr(X.dfa_trans);
             tr.resize((tr.size() + 1) & ~(size_t)1, 0);  // (whole 32-bit words: the kernels copy it to LDS word by word)
@@ -615,11 +617,17 @@ static int rx_split(tk_core* c, WorkSet& w, hipStream_t s, const uint8_t* d_text
         else if (c->rx_form == TK_RX_FORM_DFA_PREV) launch(std::integral_constant<int, TK_RX_FORM_DFA_PREV>{});
         else launch(std::integral_constant<int, TK_RX_FORM_PROGRAM>{});
     };
+    // (the pattern's DFA without look-behind over 128-byte segments: the lanes walk codes staged in LDS -- tk_k_rx_speculate_staged; $TIKTOKEN_AMD_RX_STAGED=0: the one-loop lanes over global memory)
+    const bool staged = c->rx_staged && c->rx_form == TK_RX_FORM_DFA_FLAT && seg_shift == TK_RX_SEG_SHIFT_SMALL && tk_rx_staged_fits(c->rx);
     TRY(timed(c, s, "tk_k_rx_speculate", [&] {
-        by_form([&](auto form) {
-            hipLaunchKernelGGL(tk_k_rx_speculate<decltype(form)::value>, dim3(grid_for(nseg, 256, 65536)), dim3(256), lds, s, c->rx, d_text, (uint32_t)n, brk, ss, si, seg_shift,
-                               ahead, spec, spec + nwords + 2, xexit);
-        });
+        if (staged)
+            hipLaunchKernelGGL(tk_k_rx_speculate_staged, dim3(grid_for(nseg, TK_RX_STAGE_SEGS, 65536)), dim3(TK_RX_STAGE_SEGS), tk_rx_staged_lds_bytes(c->rx), s, c->rx, d_text, (uint32_t)n, brk, ss,
+                               si, ahead, spec, spec + nwords + 2, xexit);
+        else
+            by_form([&](auto form) {
+                hipLaunchKernelGGL(tk_k_rx_speculate<decltype(form)::value>, dim3(grid_for(nseg, 256, 65536)), dim3(256), lds, s, c->rx, d_text, (uint32_t)n, brk, ss, si, seg_shift,
+                                   ahead, spec, spec + nwords + 2, xexit);
+            });
     }));
     const bool links = !(c->dbg & 0x20000);  // (debug bit 0x20000: no link pass -- the resolving pass matches its way from one chain to the next)
     if (links) {

@@ -591,6 +591,9 @@ __device__ __forceinline__ bool tk_equal_lds_text(const uint8_t* raw, uint32_t o
 #ifndef TKF_SLOW_OCC
 #define TKF_SLOW_OCC 4  // workgroups per CU of the deferred-tile variant (its grid: tk_api.hip, stage_deferred)
 #endif
+#ifndef TKF_CLAIM_SPIN
+#define TKF_CLAIM_SPIN 0  // looks a duplicate takes at a slot whose claimant has not written its words yet (see `claim`)
+#endif
 #ifndef TKF_ROWS
 #define TKF_ROWS 1  // phase F: one length class per row of 64 pieces (0: the three classes side by side in every lane)
 #endif
@@ -1193,9 +1196,17 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
             if (cur == kk) {
                 unsigned long long a0 = k0.y, a1 = k1.x, a2 = k1.y;
                 if (a2 == TK_EMPTY_KEY || a0 == TK_EMPTY_KEY || a1 == TK_EMPTY_KEY) {  // (a line cached before the claimant had written: once more, at the memory side)
-                    a0 = __hip_atomic_load(&mt[i].w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    a1 = __hip_atomic_load(&mt[i].w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                    a2 = __hip_atomic_load(&mt[i].w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                    // The claimant writes its words right behind its compare-and-swap: whoever loses that race by a few hundred nanoseconds --
+                    // every tile of a text that repeats itself reaches its first missed piece at the same moment -- would find them empty, take
+                    // the piece for another one and claim the next slot for the same bytes (exact, but a merge per slot, and a full
+                    // neighbourhood sends the piece to the overflow entries).  So it looks again a few times (bounded: never a dead lock).
+                    for (int spin = 0;; ++spin) {
+                        a0 = __hip_atomic_load(&mt[i].w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a1 = __hip_atomic_load(&mt[i].w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a2 = __hip_atomic_load(&mt[i].w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((a2 != TK_EMPTY_KEY && a0 != TK_EMPTY_KEY && a1 != TK_EMPTY_KEY) || spin >= TKF_CLAIM_SPIN) break;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
                 }
                 bool same = a0 == w0 && a1 == w1 && a2 != TK_EMPTY_KEY && (exact ? a2 == w2 : (a2 >> 32) == (w2 >> 32));
                 if (same && !exact)

@@ -113,6 +113,67 @@ __global__ __launch_bounds__(256) void tk_k_rx_speculate(TkRxDev R, const uint8_
     }
 }
 
+// The speculative pass over STAGED text (tk_regex_split.h, "The speculative pass over STAGED text"): a workgroup turns the 32 KiB of its 256
+// segments into one code per byte in LDS -- 16 bytes per lane and step: 4 KiB per load instruction, coalesced, every char decoded and
+// classified once -- and its lanes then walk codes: two LDS reads per char (the code, the transition), the bits of the segment's words in
+// registers, one store at the end; nothing in the loop waits for global memory.  LDS: the ASCII classes and the transitions as in the
+// other kernels (the first stage of the class table stays in global memory: only phase 1 reads it, for chars beyond ASCII), then the codes.
+// For the pattern's DFA without look-behind, 128-byte segments and at most TK_RX_CODE_MAX_CLS + 1 classes (tk_api.hip, rx_split).
+static inline uint32_t tk_rx_staged_lds_bytes(const TkRxDev& R) { return 384u + ((R.dfa_nstates * R.dfa_ncls + 1u) / 2u) * 4u + TK_RX_STAGE_BYTES; }
+static inline bool tk_rx_staged_fits(const TkRxDev& R) {
+    return R.dfa_trans && !(R.dfa_flags & 1u) && R.dfa_ncls <= TK_RX_CODE_MAX_CLS + 1u && tk_rx_staged_lds_bytes(R) <= 56u * 1024u && R.dfa_nstates * R.dfa_ncls < 32768u;
+}
+
+__global__ __launch_bounds__(TK_RX_STAGE_SEGS) void tk_k_rx_speculate_staged(TkRxDev R, const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ brk,
+                                                                const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, uint32_t ahead,
+                                                                uint32_t* __restrict__ spec, uint32_t* __restrict__ sgap, uint32_t* __restrict__ xexit) {
+    uint32_t* lds = tk_rx_dyn_lds;
+    const uint32_t nt = (R.dfa_nstates * R.dfa_ncls + 1u) / 2u;
+    {
+        const uint32_t* sa = (const uint32_t*)R.dfa_ascii;
+        for (uint32_t i = threadIdx.x; i < 96u; i += blockDim.x) lds[i] = sa[i];  // (128 ASCII classes + 256 groups of classes)
+        uint16_t* tp = (uint16_t*)(lds + 96);  // the transitions with row offsets for state numbers (tk_rx_trans_premultiplied)
+        for (uint32_t i = threadIdx.x; i < 2u * nt; i += blockDim.x) tp[i] = tk_rx_trans_premultiplied(R.dfa_trans[i], R.dfa_ncls);
+    }
+    TkRxProg P{};  // (for the codes -- the class tables -- and for the one-loop lane: its transitions, like the two stages of the class table, in global memory)
+    P.dfa_ascii = (const uint8_t*)lds;
+    P.dfa_trans = R.dfa_trans;
+    P.dfa_s1 = R.dfa_s1;
+    P.dfa_s2 = R.dfa_s2;
+    P.dfa_flags = R.dfa_flags;
+    P.dfa_ncls = R.dfa_ncls;
+    const uint16_t* trans_pm = (const uint16_t*)(lds + 96);
+    uint8_t* codes = (uint8_t*)(lds + 96u + nt);
+    const uint32_t nseg = (uint32_t)(((uint64_t)n + (1u << TK_RX_SEG_SHIFT_SMALL) - 1u) >> TK_RX_SEG_SHIFT_SMALL);
+    TkRxText t{text, n, brk, ss, si, 0xFFFFFFFFu, false};
+    t.ahead = ahead;
+    for (uint32_t s0 = blockIdx.x * TK_RX_STAGE_SEGS; s0 < nseg; s0 += gridDim.x * TK_RX_STAGE_SEGS) {
+        const uint32_t r0 = s0 << TK_RX_SEG_SHIFT_SMALL;
+        __syncthreads();  // (the tables are in place; the lanes of the stretch before are done with its codes)
+        for (uint32_t b = threadIdx.x * 16u; b < TK_RX_STAGE_BYTES; b += TK_RX_STAGE_SEGS * 16u) {
+            uint32_t o[4] = {0u, 0u, 0u, 0u};
+            if ((uint64_t)r0 + b < n) tk_rx_codes16(P, t, r0 + b, o);
+            tk_rx_codes_store(codes, b, o);
+        }
+        __syncthreads();
+        const uint32_t k = s0 + threadIdx.x;
+        if (k < nseg) {
+            const TkRxCodes C{codes, r0, TK_RX_STAGE_BYTES};
+            uint32_t sb[4], gb[4], x;
+            if (tk_rx_speculate_lane_codes(trans_pm, R.dfa_ncls, C, n, ahead, k, sb, gb, &x)) {
+#pragma unroll
+                for (uint32_t i = 0; i < 4u; ++i) {  // (the bitmaps start out zero and these words are the lane's: plain stores; a bit is a position of the text)
+                    if (sb[i]) spec[4u * (size_t)k + i] = sb[i];
+                    if (gb[i]) sgap[4u * (size_t)k + i] = gb[i];
+                }
+                xexit[k] = x;
+            } else {
+                tk_rx_speculate_lane_flat<false>(P, t, k, TK_RX_SEG_SHIFT_SMALL, spec, sgap, xexit);
+            }
+        }
+    }
+}
+
 template <int FORM>
 __global__ __launch_bounds__(256) void tk_k_rx_link(TkRxDev R, const uint8_t* __restrict__ text, uint32_t n, const uint32_t* __restrict__ brk,
                                                     const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, uint32_t seg_shift, uint32_t ahead,

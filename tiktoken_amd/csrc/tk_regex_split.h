@@ -296,19 +296,21 @@ TK_HD void tk_rx_speculate_lane_flat(const TkRxProg& P, TkRxText t, uint32_t k, 
 // A lane that meets TK_RX_CODE_ESC, leaves the staged stretch or looks further ahead than the one-loop lane may (TkRxText::ahead) gives
 // its segment to that lane -- whatever is unusual is decided by the code that has been compared with the matcher for four rounds, and the
 // new loop only ever does what that code does on plain text.  It keeps the bits of its four words of `spec` / `sgap` in registers and
-// stores them once.  The CPU tests run both forms side by side on every text they split (tests/hostsim, tks_rx_split bit 5) and compare
+// stores them once.  The CPU tests run both forms side by side on every text they split and compare
 // bitmaps and exits bit for bit.
 #define TK_RX_CODE_CONT 0x7Fu
 #define TK_RX_CODE_ESC 0x7Eu
 #define TK_RX_CODE_HARD 0x80u
 #define TK_RX_CODE_MAX_CLS 0x7Du
-#define TK_RX_STAGE_SEGS 256u   // segments (of 1 << TK_RX_SEG_SHIFT_SMALL bytes) per workgroup
+#ifndef TK_RX_STAGE_SEGS
+#define TK_RX_STAGE_SEGS 256u   // segments (of 1 << TK_RX_SEG_SHIFT_SMALL bytes) per workgroup = its lanes
+#endif
 #define TK_RX_STAGE_HALO 256u   // bytes staged behind them (a multiple of the segment)
 #define TK_RX_STAGE_BYTES ((TK_RX_STAGE_SEGS << TK_RX_SEG_SHIFT_SMALL) + TK_RX_STAGE_HALO)
 
 // Where the code of the byte at offset o of the staged stretch lives: the lanes of a wavefront stand at about the same offset of their
-// segments, 128 bytes apart -- one LDS bank -- so segment s is rotated by 4 s bytes within itself.
-TK_HD uint32_t tk_rx_code_addr(uint32_t o) { return (o & ~127u) | ((o + 4u * (o >> 7)) & 127u); }
+// segments, 128 bytes apart -- one LDS bank -- so the words of segment s are permuted by s (an exclusive-or: three instructions).
+TK_HD uint32_t tk_rx_code_addr(uint32_t o) { return o ^ (((o >> 7) & 31u) << 2); }
 
 struct TkRxCodes {
     const uint8_t* c;  // codes of the positions [r0, r0 + len)
@@ -321,7 +323,7 @@ struct TkRxCodes {
 // the four words of codes of the 16-byte block at offset o (a multiple of 16)
 TK_HD void tk_rx_codes_store(uint8_t* c, uint32_t o, const uint32_t w[4]) {
 #pragma unroll
-    for (uint32_t i = 0; i < 4u; ++i) *(uint32_t*)(c + tk_rx_code_addr(o + 4u * i)) = w[i];  // (a word never wraps: the rotation is a multiple of four)
+    for (uint32_t i = 0; i < 4u; ++i) *(uint32_t*)(c + tk_rx_code_addr(o + 4u * i)) = w[i];  // (whole words move: the permutation leaves the low two bits alone)
 }
 
 // bits of a bitmap for the 24 positions blk - 4 .. blk + 19 (blk a multiple of 16; the bitmaps have two words of slack)
@@ -349,18 +351,16 @@ TK_HD void tk_rx_codes16(const TkRxProg& P, const A& t, uint32_t blk, uint32_t o
     uint32_t valid = left >= 20u ? 0xFFFFFFu : ((1u << (left + 4u)) - 1u);  // window positions that are text
     if (blk == 0u) valid &= ~0xFu;
     // byte kinds over the window, a bit per position
-    uint32_t hi = 0u, isc = 0u, l2 = 0u, l3 = 0u, l4 = 0u;
+    uint32_t isc = 0u, l2 = 0u, l3 = 0u, l4 = 0u;
 #pragma unroll
     for (int i = 0; i < 6; ++i) {
         const uint32_t m80 = w[i] & 0x80808080u, m40 = (w[i] << 1) & 0x80808080u, m20 = (w[i] << 2) & 0x80808080u, m10 = (w[i] << 3) & 0x80808080u;
         const uint32_t lead = m80 & m40;
-        hi |= tk_rx_pack4(m80) << (4 * i);
         isc |= tk_rx_pack4(m80 & ~m40) << (4 * i);
         l2 |= tk_rx_pack4(lead & ~m20) << (4 * i);
         l3 |= tk_rx_pack4(lead & m20 & ~m10) << (4 * i);
         l4 |= tk_rx_pack4(lead & m20 & m10) << (4 * i);
     }
-    hi &= valid;
     isc &= valid;
     l2 &= valid;
     l3 &= valid;
@@ -373,27 +373,32 @@ TK_HD void tk_rx_codes16(const TkRxProg& P, const A& t, uint32_t blk, uint32_t o
     const uint32_t cov = (ok2 << 1) | (ok3 << 1) | (ok3 << 2) | (ok4 << 1) | (ok4 << 2) | (ok4 << 3);
     const uint32_t esc = ((isc & ~cov) | ((l2 | l3 | l4) & ~(ok2 | ok3 | ok4)) | spc) & valid;
 #define TK_RX_B(j) ((w[(j) >> 2] >> (8u * ((j) & 3u))) & 0xFFu)
+    // the ASCII classes of all sixteen bytes first -- sixteen independent look-ups in flight, one wait -- then chars beyond ASCII, where the block has any
+    uint32_t cls[16];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) {
-        const int j = i + 4;
-        uint32_t code;
-        if (!((valid >> j) & 1u)) code = 0u;  // (at or behind the end of the text)
-        else if ((esc >> j) & 1u) code = TK_RX_CODE_ESC;
-        else if ((isc >> j) & 1u) code = TK_RX_CODE_CONT;
-        else {
-            const uint32_t b = TK_RX_B(j);
-            uint32_t cls;
-            if (b < 0x80u) {
-                cls = tk_rx_ascii_cls(P, b);
-            } else {
+    for (int i = 0; i < 16; ++i) cls[i] = tk_rx_ascii_cls(P, TK_RX_B(i + 4) & 0x7Fu);
+    const uint32_t leads = ((ok2 | ok3 | ok4) >> 4) & 0xFFFFu;
+    if (leads) {
+#pragma unroll
+        for (int i = 0; i < 16; ++i) {
+            const int j = i + 4;
+            if ((leads >> i) & 1u) {
+                const uint32_t b = TK_RX_B(j);
                 const uint32_t need = ((l2 >> j) & 1u) ? 2u : (((l3 >> j) & 1u) ? 3u : 4u);
                 uint32_t cp = ((b & (0x7Fu >> need)) << 6) | (TK_RX_B(j + 1) & 0x3Fu);
                 if (need >= 3u) cp = (cp << 6) | (TK_RX_B(j + 2) & 0x3Fu);
                 if (need == 4u) cp = (cp << 6) | (TK_RX_B(j + 3) & 0x3Fu);
-                cls = tk_rx_dfa_cls(P, cp);
+                cls[i] = tk_rx_dfa_cls(P, cp);
             }
-            code = cls | (((hard >> j) & 1u) ? TK_RX_CODE_HARD : 0u);
         }
+    }
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        const int j = i + 4;
+        uint32_t code = cls[i] | (((hard >> j) & 1u) ? TK_RX_CODE_HARD : 0u);
+        if ((isc >> j) & 1u) code = TK_RX_CODE_CONT;
+        if ((esc >> j) & 1u) code = TK_RX_CODE_ESC;
+        if (!((valid >> j) & 1u)) code = 0u;  // (at or behind the end of the text)
         out[i >> 2] |= code << (8u * ((uint32_t)i & 3u));
     }
 #undef TK_RX_B
@@ -401,11 +406,13 @@ TK_HD void tk_rx_codes16(const TkRxProg& P, const A& t, uint32_t blk, uint32_t o
 
 // Lane k over the codes: the chain of segment k as tk_rx_speculate_lane_flat<false> finds it -- its bits of the segment's four words of
 // `spec` / `sgap` in sb / gb, its exit in *xout -- or false: the segment is that lane's (nothing has been written).
-TK_HD bool tk_rx_speculate_lane_codes(const TkRxProg& P, const TkRxCodes& C, uint32_t n, uint32_t ahead, uint32_t k, uint32_t sb[4], uint32_t gb[4], uint32_t* xout) {
+// trans_pm: the transition table with the ROW OFFSET of the next state in place of its number (tk_rx_trans_premultiplied: the look-up is
+// trans_pm[row + class], no multiplication in the chain from one char to the next).
+TK_HD uint16_t tk_rx_trans_premultiplied(uint16_t e, uint32_t ncls) { return (uint16_t)((e & 0x8000u) | ((e & 0x7FFFu) * ncls)); }  // (states x classes < 32768: tk_rx_staged_fits)
+TK_HD bool tk_rx_speculate_lane_codes(const uint16_t* trans_pm, uint32_t ncls, const TkRxCodes& C, uint32_t n, uint32_t ahead, uint32_t k, uint32_t sb[4], uint32_t gb[4], uint32_t* xout) {
     const uint32_t a = k << TK_RX_SEG_SHIFT_SMALL, seg = 1u << TK_RX_SEG_SHIFT_SMALL;
     const uint32_t end = n - a > seg ? a + seg : n;
     const uint32_t limit = n - end > ahead ? end + ahead : n;
-    const uint32_t ncls = P.dfa_ncls;
     sb[0] = sb[1] = sb[2] = sb[3] = gb[0] = gb[1] = gb[2] = gb[3] = 0u;
     *xout = TK_RX_UNKNOWN;
     auto note = [&](uint32_t* v, uint32_t q) {
@@ -424,45 +431,57 @@ TK_HD bool tk_rx_speculate_lane_codes(const TkRxProg& P, const TkRxCodes& C, uin
         ++p;
     }
     note(sb, p);
-    uint32_t pos = p, last = TK_RX_FAILED, state = (p == 0u || (code & TK_RX_CODE_HARD)) ? 1u : 2u;
-    for (;;) {  // `code` is the code at pos: a class, never TK_RX_CODE_CONT or TK_RX_CODE_ESC
-        if (pos >= limit && pos < n) return false;  // the match looks too far ahead: the general form decides what to do with this piece
-        const uint32_t c = ((code & TK_RX_CODE_HARD) && pos > p) ? 0u : (code & 0x7Fu);  // (class 0: the end of the haystack)
-        const uint32_t e = P.dfa_trans[state * ncls + c];
+    // ONE loop, one code per iteration: a continuation byte is a step of its own, the first char of a piece sets the state
+    uint32_t pos = p, last = TK_RX_FAILED, state = 0u;
+    bool ok = true;
+    // where the lane gives up: the end of the staged stretch, or the limit of the look-ahead where the text goes on behind it (pos moves a
+    // byte at a time and never passes the end of the text: it meets `limit` before it could pass it)
+    uint32_t stop = C.len;
+    if (limit < n && limit - C.r0 < stop) stop = limit - C.r0;
+    for (;;) {
+        const uint32_t o = pos - C.r0;
+        code = C.c[tk_rx_code_addr(o < C.len ? o : C.len - 1u)];
+        if (o >= stop) code = TK_RX_CODE_ESC;
+        if (code == TK_RX_CODE_ESC) {  // (the general form decides what to do with this piece)
+            ok = false;
+            break;
+        }
+        if (code == TK_RX_CODE_CONT) {  // (never at pos == p: a piece starts at a char)
+            ++pos;
+            continue;
+        }
+        const bool hard = (code & TK_RX_CODE_HARD) != 0u;
+        if (pos == p) state = (p == 0u || hard) ? ncls : 2u * ncls;  // (state 1 or 2, as a row offset; a char has a class > 0 and is consumed: pos == p at the first step of a piece only)
+        const uint32_t c = (hard && pos > p) ? 0u : (code & 0x7Fu);  // (class 0: the end of the haystack)
+        const uint32_t e = trans_pm[state + c];
         if (e & 0x8000u) last = pos;
         state = e & 0x7FFFu;
         if (state != 0u) {
-            if (c != 0u) {  // over the char (nothing consumes the end of the haystack: the state dies there after a step or two)
-                do code = C.at(++pos);
-                while (code == TK_RX_CODE_CONT);
-                if (code == TK_RX_CODE_ESC) return false;
-            }
+            pos += c != 0u ? 1u : 0u;  // (nothing consumes the end of the haystack: the state dies there after a step or two)
             continue;
         }
         // the piece that starts at p is finished: it ends at `last`, or p is a char the pattern does not match (a gap piece of one char)
         uint32_t q = last;
         if (last == TK_RX_FAILED) {
             q = p + 1u;
-            for (;;) {
-                const uint32_t cq = C.at(q);
-                if (cq == TK_RX_CODE_ESC) return false;
-                if (cq != TK_RX_CODE_CONT) break;
-                ++q;
+            uint32_t cq;
+            while ((cq = C.at(q)) == TK_RX_CODE_CONT) ++q;
+            if (cq == TK_RX_CODE_ESC) {
+                ok = false;
+                break;
             }
             note(gb, p);
         }
         if (q >= end) {
             *xout = q;
-            return true;
+            break;
         }
         p = q;
         note(sb, p);
-        code = C.at(p);
-        if (code == TK_RX_CODE_ESC) return false;
         pos = p;
         last = TK_RX_FAILED;
-        state = (code & TK_RX_CODE_HARD) ? 1u : 2u;  // (p > 0 here)
     }
+    return ok;
 }
 
 // Links between consecutive segments.  The true chain enters segment k where segment k - 1 was left -- at xexit[k - 1], if that guess was
