@@ -592,7 +592,7 @@ __device__ __forceinline__ bool tk_equal_lds_text(const uint8_t* raw, uint32_t o
 #define TKF_SLOW_OCC 4  // workgroups per CU of the deferred-tile variant (its grid: tk_api.hip, stage_deferred)
 #endif
 #ifndef TKF_CLAIM_SPIN
-#define TKF_CLAIM_SPIN 0  // looks a duplicate takes at a slot whose claimant has not written its words yet (see `claim`)
+#define TKF_CLAIM_SPIN 8  // looks a duplicate takes at a slot whose claimant has not written its words yet (see `claim`)
 #endif
 #ifndef TKF_ROWS
 #define TKF_ROWS 1  // phase F: one length class per row of 64 pieces (0: the three classes side by side in every lane)
