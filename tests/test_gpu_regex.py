@@ -44,7 +44,7 @@ def oracle_tokens(py_pat, docs, C, cache):
 
 
 # (patterns 9 and 13 leave gaps on most texts: test_text_the_pattern_does_not_match_yields_no_tokens)
-@pytest.mark.parametrize("idx", [5, 6, 7, 8, 10, 11, 12, 14, 16, 17, 18, 19, 23, 25])  # (23: binary properties, 25: POSIX classes)
+@pytest.mark.parametrize("idx", [5, 6, 7, 8, 10, 11, 12, 14, 15, 16, 17, 18, 19, 20, 23, 25, 26, 27])  # (23: binary properties, 25: POSIX classes, 26: \h \H \O, 15 / 27: (?i) beyond ASCII)
 def test_split_and_tokens_equal_python_regex_plus_oracle(idx):
     pat, py = PATTERNS[idx]
     py = py or pat

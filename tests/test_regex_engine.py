@@ -60,6 +60,8 @@ PATTERNS = [
     # \h / \H are the hex digits and their complement in fancy-regex (Oniguruma's meaning; Python `regex` reads horizontal white space: spelled out
     # for it), \O any char whatever (?s) says
     (r"0[xX]\h+|\h{2}|[\H\d]{1,6}?(?=\h)|(?i)\H|\O", r"0[xX][0-9A-Fa-f]+|[0-9A-Fa-f]{2}|[^A-Fa-f]{1,6}?(?=[0-9A-Fa-f])|(?i)[^0-9A-Fa-f]|[\s\S]"),
+    # (?i) beyond ASCII: literals and a range fold one char to one char (simple case folding, as in the Rust crate: STRAẞE, not STRASSE)
+    (r"(?i:straße|école|ωμέγα|[а-я]{2,3})|\p{L}|\p{N}+|[\s\S]", None),
 ]
 
 
