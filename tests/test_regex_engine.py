@@ -240,6 +240,15 @@ def test_casefold_table_is_what_python_regex_does():
             if len(m) == 1 and m != c and ord(m) not in (0x130, 0x131) and (cp, ord(m)) not in pairs and regex.fullmatch("(?i)" + regex.escape(c), m):
                 missing.append((hex(cp), hex(ord(m))))
     assert not missing, missing[:5]
+    # ... and against a second implementation of Unicode's case folding, the interpreter's own `str.casefold()` (full folding, its own
+    # Unicode database): two chars that simple folding -- the Rust crate's, CaseFolding.txt status C + S -- puts together have the same FULL
+    # folding as well (F replaces S consistently: U+1E9E and U+00DF both fold to "ss").  Code points this interpreter's database does not
+    # know yet are left out.  (The advisor's finding of round 4: the table must not rest on the `regex` module alone.)
+    import unicodedata
+
+    odd = [(hex(a), hex(b)) for a, b in sorted(pairs)
+           if unicodedata.category(chr(a)) != "Cn" and unicodedata.category(chr(b)) != "Cn" and chr(a).casefold() != chr(b).casefold()]
+    assert not odd, odd[:8]
 
 
 def test_case_insensitive_matching_beyond_ascii():

@@ -134,6 +134,11 @@ struct tk_core {
     // k + 1, then waits for that kernel to END instead of running beside it (seen in the kernel timeline of round 4: no overlap at all).
     // Which streams share a queue cannot be asked; it is found out once per caller's stream (pick_back_streams).
     hipStream_t back_for = nullptr;  // the front stream the choice was made for
+    struct BackChoice {
+        hipStream_t s[3];
+        int n;
+    };
+    std::map<hipStream_t, BackChoice> back_known;  // ... and the choices made for other front streams before
     bool back_probed = false;
     hipStream_t back_s[3] = {};      // streams that share a queue neither with back_for nor with each other (as far as the pool has any)
     int n_back = 0;
@@ -1118,11 +1123,12 @@ static int prepare_allowed(tk_core* c, hipStream_t s, const uint32_t* allowed_id
 // ---- which of the library's streams run BESIDE a given stream (see tk_core::back_s) ----
 // A gate kernel spins on `on` until the host opens the gate (or 4 ms have passed: 100 MHz counter); a one-thread kernel on every
 // candidate stream sets a word of its own.  Candidates whose word arrives while the gate is closed do not share `on`'s hardware queue.
+// (the probe's words live in mapped host memory: system-scope atomics, so that neither side looks at a cached copy)
 __global__ void tk_k_gate(volatile uint32_t* gate, uint64_t max_ticks) {
     const uint64_t t0 = wall_clock64();
-    while (!*gate && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(16);
+    while (!__hip_atomic_load((const uint32_t*)gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM) && wall_clock64() - t0 < max_ticks) __builtin_amdgcn_s_sleep(16);
 }
-__global__ void tk_k_touch(uint32_t* p) { *p = 1u; }
+__global__ void tk_k_touch(uint32_t* p) { __hip_atomic_store(p, 1u, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM); }
 
 static int streams_beside(tk_core* c, hipStream_t on, const std::vector<hipStream_t>& cand, std::vector<hipStream_t>* beside) {
     beside->clear();
@@ -1161,6 +1167,16 @@ static int streams_beside(tk_core* c, hipStream_t on, const std::vector<hipStrea
 // back-stage streams for front stream s: first those that run beside s, among them those that run beside each other
 static int pick_back_streams(tk_core* c, hipStream_t s) {
     if (c->back_probed && c->back_for == s) return TK_OK;
+    {  // (a caller that alternates between streams: what was found for a stream is kept)
+        auto it = c->back_known.find(s);
+        if (it != c->back_known.end()) {
+            c->n_back = it->second.n;
+            for (int i = 0; i < 3; ++i) c->back_s[i] = it->second.s[i];
+            c->back_for = s;
+            c->back_probed = true;
+            return TK_OK;
+        }
+    }
     std::vector<hipStream_t> pool, f;
     for (WorkSet& w : c->ws) pool.push_back(w.sb);
     for (int i = 0; i < TK_NAUX; ++i) pool.push_back(c->aux[i]);
@@ -1175,6 +1191,10 @@ static int pick_back_streams(tk_core* c, hipStream_t s) {
     if (c->n_back == 0) c->back_s[c->n_back++] = c->ws[0].sb;  // (nothing runs beside s: the stages take turns, as before)
     c->back_for = s;
     c->back_probed = true;
+    tk_core::BackChoice bc{};
+    bc.n = c->n_back;
+    for (int i = 0; i < 3; ++i) bc.s[i] = c->back_s[i];
+    if (c->back_known.size() < 64) c->back_known[s] = bc;
     return TK_OK;
 }
 

@@ -1,30 +1,33 @@
 // The encode pipeline (one launch sequence per chunk of packed documents).  Hot path of
 // Encoding.encode_ordinary_batch / encode_batch (tiktoken/core.py:164-206 -> src/lib.rs:360-457).
 //
-//   tk_k_front<PAT,SPEC>  per 4 KiB tile: classify every byte, build the class-set bitmaps, find the piece starts
-//                         (regex pre-tokenisation, src/lib.rs:365), enumerate the pieces that START in the tile and
-//                         probe each one whole in the vocabulary (src/lib.rs:367) from the LDS copy of the text.
-//                         Results form a run at piece id  pid = tile * 4096 + k.  A piece that is not a token claims a
-//                         slot of the in-call miss table, or finds it claimed by identical bytes (exact: verified); its
-//                         result word refers to that slot either way (TkMissData).  No piece offsets travel through HBM.
+//   tk_k_front<PAT,SPEC,MODE>  per 4 KiB window (a tile of 3840 bytes + 128 of context on either side): classify every byte, build the
+//                         class-set bitmaps, find the piece starts (regex pre-tokenisation, src/lib.rs:365), enumerate the pieces that
+//                         START in the tile and probe each one whole in the vocabulary (src/lib.rs:367) from the LDS copy of the text.
+//                         Results form a run at piece id  pid = tile * 4096 + k.  A piece that is not a token claims a slot of the
+//                         in-call table of missed pieces, or finds it claimed by identical bytes (exact: the slot holds the bytes of
+//                         pieces of up to 23 bytes, longer ones are compared in the text); its result word refers to that slot either way
+//                         (TkMissData).  No piece offsets travel through HBM.  Three instances (TKF_MODE_*): one workgroup per tile;
+//                         the deferred tiles' piece starts by the workgroup-wide scanner; the rest of the deferred tiles from given starts.
 //   tk_k_bincount + tk_k_scan_small + tk_k_binfill   occupied slots -> length-binned lists, without global atomics
 //   tk_k_merge_all       every piece of 2..1024 bytes: byte_pair_merge in LDS, 1..64 lanes per piece (src/lib.rs:140-196)
 //   tk_k_merge_llane<N>, tk_k_merge_group<G>   the same, a kernel per length bin (vocabularies with ids above 2^21)
 //   tk_k_merge_rounds / _long   longer pieces: in rounds, or one merge at a time over a 64-ary min tree (same result as lib.rs:47-138)
 //   tk_k_count_tiles      token count per tile (a missed piece's count from its entry)
 //   tk_k_scan_*           exclusive scan of the tile counts
-//   tk_k_place            per tile: tokens to their final place (a missed piece's tokens from its entry)
+//   tk_k_place            per tile: tokens to their final place (a missed piece's tokens from its entry), whole lines through LDS
 //   tk_k_docoff          per document: token offset of the piece that starts it
+//   tk_k_small            one document of up to 2 KiB (or one segment of a mid-size document) by one workgroup, start to finish
 //
 // Tile rule (checked on the CPU by tests/test_device_logic_sim.py): a tile derives exactly the piece starts
 // inside its own byte range.  Scanners start at the tile's certain starts plus the last certain start before the
-// tile (64-byte left context, else a walk back through HBM), record only boundaries inside the tile and stop at
-// its end.  Nothing crosses tiles, so tiles are fully independent.
+// tile (128 bytes of left context, else the tile is deferred to the workgroup-wide scanner), record only boundaries
+// inside the tile and stop at its end.  Nothing crosses tiles, so tiles are fully independent.
 //
-// Two hardware facts shape the code (measured): tk_k_front is VALU-bound (a wave64 VALU
-// instruction occupies a SIMD16 for four cycles; 85-90 % VALU utilisation), so the classification loop is written
+// Two hardware facts shape the code (measured): tk_k_front is bound by vector issue (a wave64 VALU
+// instruction occupies a SIMD16 for four cycles; 82 % of the issue slots busy), so the classification loop is written
 // with integer flags instead of short-circuit control flow; and same-address returning atomics run at only
-// 25..130 M/s on this multi-XCD part, so nothing on the path allocates through a global counter.
+// 10..130 M/s on this multi-XCD part, so nothing on the path allocates through a global counter.
 #pragma once
 #include <type_traits>
 
