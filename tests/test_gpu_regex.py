@@ -224,6 +224,37 @@ def test_stock_patterns_through_the_generic_engine_equal_the_scanners(name, mix,
             assert np.array_equal(p1, core.pretokenize_packed(blob, off, allowed)), (allowed, form)
 
 
+def test_staged_speculative_pass_with_several_stretches_per_workgroup(monkeypatch):
+    """tk_k_rx_speculate_staged walks the chunk with the stride of its grid: a workgroup takes a second stretch of 256 segments only in
+    chunks of more than 2 GiB (65 536 workgroups x 32 KiB).  $TIKTOKEN_AMD_RX_GRID_CAP makes that loop run on a small input: three
+    workgroups over 6 MiB (64 stretches each; the codes in LDS and the barrier between two stretches are what this covers), special tokens
+    and documents that end inside a stretch included -- every token and every piece start equal to the default grid's and the scanners'."""
+    from tiktoken_amd import CoreBPE
+
+    name = "o200k_shaped"
+    g = h.load_golden(name)
+    blob, off = h.gen_corpus(0x5EED0177, 1, (6 << 20) + 777)
+    blob, off = h.insert_specials(blob, off)
+    top = max(max(g["special_tokens"].values()), max(h.golden_vocab(name).values()))
+    specials = {**g["special_tokens"], **{f"<|custom_{i}|>": top + 1 + i for i in range(8)}}
+    scanners = CoreBPE(h.golden_vocab(name), specials, g["pat_str"])
+    monkeypatch.setenv("TIKTOKEN_AMD_DEBUG", "1048576")
+    wide = CoreBPE(h.golden_vocab(name), specials, g["pat_str"])
+    monkeypatch.setenv("TIKTOKEN_AMD_RX_GRID_CAP", "3")
+    narrow = CoreBPE(h.golden_vocab(name), specials, g["pat_str"])
+    monkeypatch.setenv("TIKTOKEN_AMD_RX_GRID_CAP", "1")
+    one = CoreBPE(h.golden_vocab(name), specials, g["pat_str"])
+    monkeypatch.delenv("TIKTOKEN_AMD_RX_GRID_CAP")
+    monkeypatch.delenv("TIKTOKEN_AMD_DEBUG")
+    for allowed in (None, "all"):
+        t1, o1 = scanners.encode_batch_packed(blob, off, allowed)
+        p1 = scanners.pretokenize_packed(blob, off, allowed)
+        for core in (wide, narrow, one):
+            t2, o2 = core.encode_batch_packed(blob, off, allowed)
+            assert np.array_equal(o1, o2) and np.array_equal(t1, t2), allowed
+            assert np.array_equal(p1, core.pretokenize_packed(blob, off, allowed)), allowed
+
+
 def test_exploding_backtracking_is_stopped(monkeypatch):
     """Nested quantifiers on a text that makes them explode ((?:a+)+b on a run of a's): fancy-regex gives up after 1 000 000 backtracks
     (Error::BacktrackLimitExceeded -- a panic in the reference, src/lib.rs:365); the GPU program has the same kind of budget, so the call

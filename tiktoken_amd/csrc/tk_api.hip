@@ -149,6 +149,7 @@ struct tk_core {
     uint64_t chunk_bytes = 1ull << 30;  // one chunk per GiB: smaller chunks pipeline (stage_front / stage_back) but pay the merge kernels' fixed latency per chunk
     int dbg = 0;
     uint32_t n_cu = 256;             // compute units of the device
+    uint32_t rx_grid_cap = 65536;    // most workgroups of tk_k_rx_speculate_staged (each walks the stretches with the stride of the grid: a chunk of more than 2 GiB, or $TIKTOKEN_AMD_RX_GRID_CAP)
     uint32_t rx_seg_shift = 0;       // 0: by chunk size (tk_regex_split.h)
     uint32_t rx_ahead = 0;           // 0: TK_RX_AHEAD / TK_RX_AHEAD_DFA by the kernels' form ($TIKTOKEN_AMD_RX_AHEAD: bytes)
     uint32_t front_wgs = TKF_OCC;    // workgroups per CU of the persistent front kernel ($TIKTOKEN_AMD_FRONT_WGS)
@@ -491,6 +492,10 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
         const int k = atoi(e);
         if (k >= 16 && k <= (1 << 20)) c->rx_ahead = (uint32_t)k;
     }
+    if (const char* e = getenv("TIKTOKEN_AMD_RX_GRID_CAP")) {  // (tests: most workgroups of the staged speculative pass, so that a small input makes every workgroup take several stretches)
+        const int k = atoi(e);
+        if (k >= 1 && k <= 65536) c->rx_grid_cap = (uint32_t)k;
+    }
     if (const char* e = getenv("TIKTOKEN_AMD_RX_SEG_SHIFT")) {  // (experiments: segment size of the generic engine's speculative pass, 2^k bytes)
         const int k = atoi(e);
         if (k >= 5 && k <= 14) c->rx_seg_shift = (uint32_t)k;
@@ -626,7 +631,7 @@ static int rx_split(tk_core* c, WorkSet& w, hipStream_t s, const uint8_t* d_text
     const bool staged = c->rx_staged && c->rx_form == TK_RX_FORM_DFA_FLAT && seg_shift == TK_RX_SEG_SHIFT_SMALL && tk_rx_staged_fits(c->rx);
     TRY(timed(c, s, "tk_k_rx_speculate", [&] {
         if (staged)
-            hipLaunchKernelGGL(tk_k_rx_speculate_staged, dim3(grid_for(nseg, TK_RX_STAGE_SEGS, 65536)), dim3(TK_RX_STAGE_SEGS), tk_rx_staged_lds_bytes(c->rx), s, c->rx, d_text, (uint32_t)n, brk, ss,
+            hipLaunchKernelGGL(tk_k_rx_speculate_staged, dim3(grid_for(nseg, TK_RX_STAGE_SEGS, c->rx_grid_cap)), dim3(TK_RX_STAGE_SEGS), tk_rx_staged_lds_bytes(c->rx), s, c->rx, d_text, (uint32_t)n, brk, ss,
                                si, ahead, spec, spec + nwords + 2, xexit);
         else
             by_form([&](auto form) {
