@@ -96,6 +96,34 @@ def hf_tokenizers_rate(encoding, spec, blob, doc_off, nbytes, ctoks, coff, sampl
         return {"value": None, "why": f"{type(e).__name__}: {e}"[:200]}
 
 
+def csrc_digest() -> str:
+    """sha256 over the product's native sources (tiktoken_amd/csrc: *.hip *.h *.cpp *.inc Makefile, names and contents): what `roofline.traffic`
+    -- read from profiles/traffic.json, not measured in this run -- is tied to.  tools/gpu_prof.sh records it beside the counters."""
+    import hashlib
+
+    d = os.path.join(ROOT, "tiktoken_amd", "csrc")
+    h = hashlib.sha256()
+    for name in sorted(os.listdir(d)):
+        if name.endswith((".hip", ".h", ".cpp", ".inc")) or name == "Makefile":
+            h.update(name.encode() + b"\0")
+            with open(os.path.join(d, name), "rb") as f:
+                h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def host_cores(ncpu_affinity: int) -> float:
+    """CPU cores this process may actually use: min(scheduler affinity, cgroup v2 quota).  A box that shows 64 CPUs to a container whose
+    cpu.max is "1600000 100000" gives it 16 cores' worth of time however many threads run."""
+    q = _read_first("/sys/fs/cgroup/cpu.max")
+    try:
+        quota, period = q.split()
+        if quota != "max":
+            return min(float(ncpu_affinity), round(int(quota) / int(period), 2))
+    except Exception:
+        pass
+    return float(ncpu_affinity)
+
+
 def _read_first(path):
     try:
         return open(path).readline().strip()
@@ -220,9 +248,13 @@ def main():
     ap.add_argument("--one-process", action="store_true",
                     help="NOT the driver's mode: drive the product's several-GPU entry (CoreBPE(devices=...), tk_group_encode_batch_device: host text in, "
                          "ids gathered on device 0 over xGMI) from this one process; a device is named several times when the box has fewer GPUs")
+    ap.add_argument("--csrc-digest", action="store_true", help="print the digest of the kernel sources (what profiles/traffic.json is tied to) and exit")
     ap.add_argument("--generic-engine", action="store_true",
                     help="NOT the headline: run the encoding's pat_str on the generic regex engine instead of the hand-written scanners")
     args = ap.parse_args()
+    if args.csrc_digest:
+        print(csrc_digest())
+        return
 
     import torch
 
@@ -312,21 +344,43 @@ def main():
         # The form of the gather is agreed on by ALL ranks before anything is timed (a rank that fell back on its own would leave the
         # others inside a collective it never joins): one untimed exact-length exchange of a small buffer torch did not allocate --
         # the library's own result buffer, which is what a collective library may refuse -- then the failure flags are summed.
-        failed = 0
+        # Two phases, so that a rank that fails cannot leave its peers inside an exchange it never joins: (1) everything LOCAL the exchange
+        # needs (the encode, torch's view of the library's buffer, the host copy of the dry run) under try/except, the failure flags summed
+        # by an all_reduce every rank reaches; (2) only if all ranks got that far, the exchange itself, waited for with a time limit -- a
+        # rank whose peers never answer leaves with an error after a minute instead of sitting out the collective library's own time-out.
+        import datetime
+
+        failed, probe, nt0 = 0, None, 0
         try:
             dt0, nt0, _ = core.encode_batch_device(d_text.data_ptr(), nbytes, d_off.data_ptr(), doc_off, n_docs)
             probe = torch.as_tensor(DevArray(dt0, max(nt0, 1), "<i4"), device="cuda")[: min(nt0, 1 << 16)]
-            if backend != "nccl":
-                probe = probe.cpu()
-            gather_tokens(probe, int(probe.numel()) if nt0 else 0, rank, world, dist, torch, async_op=True).wait()
+            probe = probe.contiguous() if backend == "nccl" else probe.cpu()
             torch.cuda.current_stream().synchronize()
         except Exception as e:
-            print(f"bench: exact-length gather failed on rank {rank} ({type(e).__name__}: {str(e)[:120]})", file=sys.stderr)
+            print(f"bench: rank {rank} cannot hand the library's result buffer to torch ({type(e).__name__}: {str(e)[:120]})", file=sys.stderr)
             failed = 1
         flag = torch.tensor([failed], dtype=torch.int64, device=cdev)
         dist.all_reduce(flag)
         if int(flag.item()):
-            gather_mode["form"] = f"padded (the exact-length exchange raised on {int(flag.item())} rank(s))"
+            gather_mode["form"] = f"padded (the library's buffer could not be wrapped on {int(flag.item())} rank(s))"
+        else:
+            try:
+                pend = gather_tokens(probe, int(probe.numel()) if nt0 else 0, rank, world, dist, torch, async_op=True)
+                for w in pend._works:
+                    if w.wait(timeout=datetime.timedelta(seconds=60)) is False:
+                        raise TimeoutError("the exact-length exchange did not complete within 60 s")
+                pend.wait()
+                torch.cuda.current_stream().synchronize()
+            except Exception as e:
+                print(f"bench: exact-length gather failed on rank {rank} ({type(e).__name__}: {str(e)[:120]})", file=sys.stderr)
+                failed = 1
+            flag = torch.tensor([failed], dtype=torch.int64, device=cdev)
+            work = dist.all_reduce(flag, async_op=True)
+            if work.wait(timeout=datetime.timedelta(seconds=60)) is False:
+                print(f"bench: rank {rank}: the ranks could not agree on the form of the gather (a peer is stuck in the exchange): giving up", file=sys.stderr)
+                os._exit(4)
+            if int(flag.item()):
+                gather_mode["form"] = f"padded (the exact-length exchange raised on {int(flag.item())} rank(s))"
 
     for _ in range(args.warmup):
         step()
@@ -393,13 +447,18 @@ def main():
     b_alg = nbytes + 4 * stats["tokens"] + 16 * (n_docs + 1)  # text in + u32 ids out + offsets in/out
     dom = max(kern, key=lambda k: kern[k]["ms_total"]) if kern else None
     sum_ms = sum(v["ms_total"] for v in kern.values()) / prof_steps if kern else None
-    traffic = None
+    traffic, traffic_at, traffic_current = None, None, None
     tpath = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tpath) and dom:
         try:
             tj = json.load(open(tpath))
             if tj.get("workload_mib") == args.mib and tj.get("encoding") == args.encoding:
                 traffic = tj.get("kernels", {}).get(dom, {}).get("hbm_bytes_per_launch")
+                traffic_at = tj.get("measured_at_git")
+                traffic_current = bool(tj.get("csrc_digest") == csrc_digest())
+                if traffic is not None and not traffic_current and rank == 0:
+                    print(f"bench: WARNING: profiles/traffic.json was measured on other kernel sources (csrc digest {tj.get('csrc_digest')}, "
+                          f"git {traffic_at}) than this build ({csrc_digest()}): roofline.traffic is stale", file=sys.stderr)
         except Exception:
             traffic = None
     roofline = None
@@ -408,6 +467,7 @@ def main():
         roofline = {"bound": "hbm", "kernel": dom, "achieved": round(achieved, 2), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
                     "frac": round(achieved / HBM_PEAK_GBPS, 5), "traffic": traffic,
                     "traffic_source": "profiles/traffic.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes, not measured in this run)" if traffic else None,
+                    "traffic_measured_at": traffic_at, "traffic_measured_on_these_kernel_sources": traffic_current,
                     "algorithmic_bytes_per_launch": b_alg, "kernel_ms_avg": round(kern[dom]["ms_avg"], 4),
                     "all_kernels_ms_per_step": round(sum_ms, 4),
                     "pipeline_achieved": round(b_alg / (ms_per_step * 1e-3) / 1e9, 2),  # whole pipeline: algorithmic bytes over the wall time of a step
@@ -472,7 +532,7 @@ def main():
         # sample; the single-thread rate on a smaller sample beside it
         # Thread sweep (the timed runs write into buffers of their OWN: `ctoks` / `coff` above are views of `bufs` and are compared
         # again below).  A thread count gets a sample in proportion (about 0.3 s of work each), capped at --cpu-sample-mib; the best
-        # rate of the sweep is the baseline and `cores` is the thread count that achieved it.
+        # rate of the sweep is the baseline, `threads` the thread count that achieved it, `cores` what the box really gives (host_cores).
         sample_cap = min(nbytes, args.cpu_sample_mib << 20)
         tb = (np.empty(sample_cap + 64, np.uint32), np.empty(n_docs + 1, np.uint64))
         sweep = {}
@@ -489,7 +549,8 @@ def main():
             sweep[str(thr)] = round(sb / best / 1e9, 5)
             if sb / best / 1e9 > best_rate:
                 best_rate, best_thr, best_sb, best_nd = sb / best / 1e9, thr, sb, nd_s
-        cpu = {"value": round(best_rate, 4), "unit": "GB/s", "cores": best_thr, "kind": "port",
+        cpu = {"value": round(best_rate, 4), "unit": "GB/s", "cores": host_cores(ncpu), "threads": best_thr, "kind": "port",
+               "cores_what": "min(scheduler affinity, cgroup cpu.max quota) of this box; `threads` = the thread count of the sweep that gave the best rate",
                "single_thread_value": sweep.get("1"), "thread_sweep_gbps": sweep,
                "sample": f"first {best_nd} documents ({best_sb} bytes) of the same corpus, C restatement of CoreBPE (oracle/tk_oracle.c), one thread "
                          f"pool over documents (core.py:175), per-document encode phase only (timed in C), best of 3; sweep over thread counts "
@@ -614,6 +675,7 @@ def main():
                                    f"{n_docs} docs on rank 0, inputs resident in HBM, packed u32 output",
                        "encoding": args.encoding, "pat_str_runs_on": "generic regex engine (--generic-engine)" if args.generic_engine else "hand-written scanners",
                        "bytes_per_gpu": nbytes, "docs_rank0": n_docs,
+                       "rccl_ranks": (dist.get_world_size() if dist and backend == "nccl" else 0), "devices_visible": torch.cuda.device_count(),
                        "tokens_total": total_tokens, "pieces_rank0": stats["pieces"],
                        "parallelism": f"doc-sharded x{world}" + (f" + {'RCCL' if backend == 'nccl' else backend + ' (DRY RUN through host copies)'} gather of token ids to rank 0 ({gather_mode['form']} lengths)" if world > 1 else "")},
             "roofline": roofline, "cpu_baseline": cpu, "parity_all_tokens_vs_oracle": parity, "gather_verified": gather_verified,

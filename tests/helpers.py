@@ -165,6 +165,11 @@ def insert_specials(blob: np.ndarray, off: np.ndarray, seed: int = 5):
 CUSTOM8 = {**SPECIALS["o200k_shaped"], **{f"<|custom_{i}|>": 200019 + i for i in range(8)}}
 
 
+@functools.lru_cache(maxsize=1)
+def _n1_corpus():
+    return natural_corpus(load_vocab("o200k_shaped"), 256 << 20)
+
+
 def baseline_config(cfg: str, threads: int = 16):
     """(encoding name for the vocabulary, pattern id, special tokens, blob, doc_off, allowed_special) of a BASELINE.json config at its
     FULL size (SURVEY.md 8d): C1 gpt2 1 MiB Lorem ipsum (one document); C2 cl100k 64 MiB mixed UTF-8; C3 o200k 1 GiB web text;
@@ -182,8 +187,23 @@ def baseline_config(cfg: str, threads: int = 16):
         blob, off = gen_corpus(0x5EED0004 + int(cfg[3:]), 1, 1 << 30, threads)
         return "o200k_shaped", 2, SPECIALS["o200k_shaped"], blob, off, None
     if cfg == "N1":  # not a BASELINE.json configuration: 256 MiB of text whose miss rate is natural (natural_corpus), o200k-shaped
-        blob, off = natural_corpus(load_vocab("o200k_shaped"), 256 << 20)
+        blob, off = _n1_corpus()
         return "o200k_shaped", 2, SPECIALS["o200k_shaped"], blob, off, None
+    if cfg == "N1g":  # the same text at the headline's size (1 GiB), so that the 18.7 %-miss headline corpus and the natural-miss-rate figure stand
+        # side by side at one size: N1's 256 MiB four times, each copy with its documents rotated by a quarter (the generator takes 30 s per 256 MiB;
+        # its pool of words is finite, so a longer run of it repeats its words just the same)
+        b, o = _n1_corpus()
+        nd = len(o) - 1
+        parts, lens = [], []
+        ln = np.diff(o.astype(np.int64))
+        for k in range(4):
+            d = nd * k // 4
+            cut = int(o[d])
+            parts += [b[cut:], b[:cut]]
+            lens += [ln[d:], ln[:d]]
+        off = np.zeros(4 * nd + 1, np.uint64)
+        off[1:] = np.cumsum(np.concatenate(lens))
+        return "o200k_shaped", 2, SPECIALS["o200k_shaped"], np.concatenate(parts), off, None
     if cfg == "C5":
         blob, off = insert_specials(*gen_corpus(0x5EED0005, 1, 256 << 20, threads))
         return "o200k_shaped", 2, CUSTOM8, blob, off, "all"

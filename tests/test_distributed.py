@@ -59,11 +59,20 @@ def _worker(rank, world, port, q):
         # what bench.py --gpus N does after its timed region: every rank checks its OWN shard against the oracle and digests its id
         # stream, the verdicts travel in one all-gather, and the destination compares what it RECEIVED per peer with what was sent
         lo, hi = int(mine_off[0]), int(mine_off[-1])
-        own, _ = C.encode_batch(blob[lo:hi], (mine_off - mine_off[0]).astype(np.uint64), None, 1)
-        ref, _ = C.encode_batch(blob[lo:hi], (mine_off - mine_off[0]).astype(np.uint64), None, 1)
+        # (the rank's "encoder" is the piece-by-piece Python restatement here, the checker the C one: two implementations, as on the GPU box)
+        doc_lo = mine_off - mine_off[0]
+        own = np.concatenate([np.asarray(h.py_oracle.encode_ordinary(blob[lo + int(a):lo + int(b)].tobytes().decode(), h.PAT_STR[1], h.load_vocab("cl100k_shaped")), np.uint32)
+                              for a, b in zip(doc_lo[:-1], doc_lo[1:])] + [np.zeros(0, np.uint32)])
+        ref, _ = C.encode_batch(blob[lo:hi], doc_lo.astype(np.uint64), None, 1)
         cnt, dig = ids_digest(own)
         verdicts = exchange_verdicts(cnt, dig, bool(np.array_equal(own, ref)), rank, world, dist, torch)
         assert verdicts[rank] == (cnt, dig, True) and all(v[2] for v in verdicts)
+        # a rank whose shard is wrong says so, and every rank hears it
+        wrong = own.copy()
+        if rank == world - 1 and len(wrong):
+            wrong[len(wrong) // 3] ^= 1
+        bad = exchange_verdicts(*ids_digest(wrong), bool(np.array_equal(wrong, ref)), rank, world, dist, torch)
+        assert [v[2] for v in bad] == [True] * (world - 1) + [False] and bad[-1][1] != verdicts[-1][1]
         parts, counts = gather_tokens(torch.from_numpy(np.ascontiguousarray(own).view(np.int32).copy()), len(own), rank, world, dist, torch)
         if rank == 0:
             good = verify_gathered(parts, verdicts)

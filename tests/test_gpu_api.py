@@ -355,16 +355,7 @@ def test_close_is_idempotent_and_calls_after_it_fail_cleanly():
         core._encode_np(b"hello world", None)
 
 
-def test_real_vocab_known_answers_if_available():
-    """Appendix B of SURVEY.md: runs only when the sha256-pinned stock files are in $TIKTOKEN_CACHE_DIR."""
-    cache = os.environ.get("TIKTOKEN_CACHE_DIR")
-    if not cache or not os.path.exists(os.path.join(cache, "9b5ad71b2ce5302211f9c61530b329a4922fc6a4")):
-        pytest.skip("stock vocabulary files not available offline")
-    enc = tiktoken.get_encoding("cl100k_base")
-    assert enc.encode("hello world") == [15339, 1917]
-    assert enc.encode("rer") == [38149] and enc.encode("'rer") == [2351, 81]
-    assert enc.encode("today\n ") == [31213, 198, 220] and enc.encode("today\n \n") == [31213, 27907]
-    assert enc.encode(" \x850") == [220, 126, 227, 15]
+# (the real-vocabulary known answers of SURVEY.md Appendix B: tests/test_real_vocab.py -- each encoding skipped on its own while its file is absent)
 
 
 # ---------------------------------------------------------------- byte-level / unstable entry points vs the oracle

@@ -606,6 +606,34 @@ def test_multi_device_group_equals_single_device():
     assert core.group_stat("gathers_peer") > 0 and core.group_stat("gathers_rccl") == 0  # (virtual ranks share a device: no RCCL here)
 
 
+def test_distinct_devices_gather_over_rccl():
+    """The branch no one-GPU box can take: CoreBPE(devices=[0, 1, ...]) on pairwise distinct devices gathers the token ids with ONE grouped
+    ncclSend / ncclRecv over xGMI (tk_group_encode_batch_device).  Skipped below two devices; the first box that has them runs it."""
+    import torch
+
+    from bench import DevArray
+    from tiktoken_amd import CoreBPE, _lib
+
+    n = min(_lib.device_count(), 8)
+    if n < 2:
+        pytest.skip(f"{n} HIP device(s) visible: the RCCL gather needs at least two distinct ones")
+    g = h.load_golden("o200k_shaped")
+    C = h.c_oracle_for("o200k_shaped")
+    blob, off = h.gen_corpus(0x5EED0003, 1, 64 << 20)
+    rt, ro = C.encode_batch(blob, off, None, 8)
+    core = CoreBPE(h.golden_vocab("o200k_shaped"), g["special_tokens"], g["pat_str"], devices=list(range(n)))
+    for rep in range(2):  # (the second call re-uses communicators and buffers)
+        dt, nt, do = core.encode_batch_gathered(blob, off)
+        assert nt == len(rt)
+        with torch.cuda.device(0):
+            assert np.array_equal(torch.as_tensor(DevArray(dt, nt, "<i4"), device="cuda:0").cpu().numpy().view(np.uint32), rt)
+            assert np.array_equal(torch.as_tensor(DevArray(do, len(off), "<i8"), device="cuda:0").cpu().numpy().astype(np.uint64), ro)
+    assert core.group_stat("gathers_rccl") >= 2 and core.group_stat("gathers_peer") == 0
+    toks, toff = core.encode_batch_packed(blob, off, "all")  # the host-gather form on the same replicas
+    st, so = C.encode_batch(blob, off, "all", 8)
+    assert np.array_equal(toff, so) and np.array_equal(toks, st)
+
+
 # ---------------------------------------------------------------- small calls: one launch (tk_k_small)
 def test_small_calls_one_launch_same_tokens(monkeypatch):
     """A single document of up to 2 KiB without special tokens is encoded by ONE workgroup in ONE launch (tk_k_small); the result is

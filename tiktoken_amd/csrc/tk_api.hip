@@ -703,7 +703,10 @@ static int stage_deferred(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream
                                w.deferred.as<uint32_t>(), gapb, (fdbg & ~TKF_DBG_SECOND) | (can_fall_back ? TKF_DBG_MAY_GIVE_UP : 0));
         }));
         uint64_t n_given = job.ntiles;
-        if (can_fall_back || job.n >= (256u << 10)) {  // (small inputs do not wait for the host: a few dozen workgroups that return at once)
+        // The host waits for the counters only where it has a decision to take (the way out of a stretch without certain starts); the length
+        // of the list is read on that occasion.  Everywhere else -- small inputs, a pat_str without that way out -- nothing blocks the
+        // queueing of the next chunk: one workgroup per tile, of which all but the list's length return at once.
+        if (can_fall_back) {
             HIPCHK(hipMemcpyAsync(w.h_counters, w.counters.p, TK_CNT_N * 4, hipMemcpyDeviceToHost, s));
             HIPCHK(hipEventRecord(w.ev_cnt, s));
             HIPCHK(hipEventSynchronize(w.ev_cnt));
@@ -1412,6 +1415,25 @@ static void small_slot_submit(tk_core::SmallSlot* sl, const uint8_t* utf8, uint3
     sl->n = n | (no_long ? TK_SMALL_NO_LONG : 0u);
     sl->state.store(1, std::memory_order_release);
 }
+// Hands a slot back on any exit path.  A slot that was submitted and never launched goes from "ready" to idle by compare-and-swap: a launcher
+// that is taking it along at this very moment (1 -> 2) either loses that race or is seen.  A slot in state 2 whose kernel has not written
+// the call's sequence number yet is IN FLIGHT on this call's buffers (the owner left early: its time-out); the next owner's text must not
+// meet that kernel, so the slot is waited for (bounded) and, if the kernel never completes, stays busy for good (quarantined: the
+// other slots remain).
+static void small_slot_release(tk_core::SmallSlot* sl) {
+    int st = 1;
+    if (!sl->state.compare_exchange_strong(st, 0, std::memory_order_acq_rel)) {
+        if (st == 2 && sl->out && __atomic_load_n(&sl->out[2], __ATOMIC_ACQUIRE) != sl->seq) {
+            const auto t0 = std::chrono::steady_clock::now();
+            while (__atomic_load_n(&sl->out[2], __ATOMIC_ACQUIRE) != sl->seq) {
+                if (std::chrono::steady_clock::now() - t0 > std::chrono::seconds(2)) return;  // (quarantined: busy stays set)
+                std::this_thread::yield();
+            }
+        }
+        sl->state.store(0, std::memory_order_release);
+    }
+    sl->busy.store(0, std::memory_order_release);
+}
 // Waits until every one of the caller's slots has completed (the kernel's last store is the slot's sequence number, system scope: watched
 // instead of a stream); while one of them has not been launched, tries to be the one who launches -- EVERY ready slot of the core, the
 // caller's or not (flat combining: try_lock, nobody waits for the mutex).
@@ -1505,10 +1527,7 @@ static int encode_mid(tk_core* c, const uint8_t* utf8, uint32_t n, uint32_t** to
         uint32_t* n;
         std::atomic<int>* active;
         ~Release() {
-            for (uint32_t i = 0; i < *n; ++i) {
-                s[i]->state.store(0, std::memory_order_release);  // (also when small_wait left early -- a failed launch, its time-out: the next owner must not be launched with this call's text)
-                s[i]->busy.store(0, std::memory_order_release);
-            }
+            for (uint32_t i = 0; i < *n; ++i) small_slot_release(s[i]);  // (also when small_wait left early -- a failed launch, its time-out: the next owner must not be launched with this call's text)
             active->fetch_sub(1, std::memory_order_relaxed);
         }
     } release_slots{mine, &got, &c->small_active};
@@ -1585,8 +1604,7 @@ static int encode_small(tk_core* c, const uint8_t* utf8, uint32_t n, uint32_t** 
         tk_core::SmallSlot* s;
         std::atomic<int>* active;
         ~Release() {
-            s->state.store(0, std::memory_order_release);  // (see encode_mid's guard)
-            s->busy.store(0, std::memory_order_release);
+            small_slot_release(s);  // (see encode_mid's guard)
             active->fetch_sub(1, std::memory_order_relaxed);
         }
     } release_slot{sl, &c->small_active};

@@ -79,6 +79,11 @@ __device__ __forceinline__ uint32_t tk_row16_sum(uint32_t v) {  // sum over the 
 // inclusive prefix sum over the wavefront: four DPP row shifts inside the rows of sixteen lanes, then the last lane of a row to the rows
 // behind it (row_bcast:15 to rows 1 and 3, row_bcast:31 to rows 2 and 3) -- six full-rate instructions (round 4: six __shfl_up, each a
 // ds_bpermute through the LDS crossbar plus a compare and a select)
+// (row_bcast:15 / row_bcast:31 are DPP controls of the GFX9 / CDNA encodings only -- the library is built for gfx950; a wave64 target without
+// them takes the shuffle form by itself instead of failing in the assembler)
+#if !defined(TK_SCAN_SHFL) && defined(__HIP_DEVICE_COMPILE__) && !defined(__GFX9__)
+#define TK_SCAN_SHFL 1
+#endif
 #ifndef TK_SCAN_SHFL
 __device__ __forceinline__ uint32_t tk_wave_scan_u32(uint32_t v, int /*lane*/) {
     v += (uint32_t)__builtin_amdgcn_update_dpp(0, (int)v, 0x111, 0xF, 0xF, true);   // row_shr:1 (a lane without a source adds nothing)

@@ -103,31 +103,45 @@ def encode_ordinary_batch_sharded(encode_packed, blob: np.ndarray, doc_off: np.n
     return all_toks, tok_off
 
 
-def ids_digest(ids) -> tuple[int, int]:
-    """(count, 64-bit digest) of a flat id stream (any integer array of 4-byte items; the bytes are what is hashed).
-    xxhash64 when the package is there (SURVEY.md 8(d) names it for 1 GB+ comparisons), else blake2b truncated to 8 bytes --
-    every rank of a job runs the same interpreter, so the two sides of a comparison always use the same function."""
-    a = np.ascontiguousarray(np.asarray(ids)).view(np.uint8)
+def digest_algorithm() -> int:
+    """Which function ids_digest uses in THIS interpreter: 1 = xxhash64 (SURVEY.md 8(d) names it for 1 GB+ comparisons), 2 = blake2b truncated
+    to 8 bytes (the package is missing).  Travels with every verdict: ranks of one job that disagree are an error, not a "gather mismatch"."""
     try:
+        import xxhash  # noqa: F401
+
+        return 1
+    except ImportError:  # pragma: no cover
+        return 2
+
+
+def ids_digest(ids) -> tuple[int, int]:
+    """(count, 64-bit digest) of a flat id stream (any integer array of 4-byte items; the bytes are what is hashed); digest_algorithm() says
+    with which function."""
+    a = np.ascontiguousarray(np.asarray(ids)).view(np.uint8)
+    if digest_algorithm() == 1:
         import xxhash
 
         return int(a.size // 4), int(xxhash.xxh64(memoryview(a)).intdigest())
-    except ImportError:  # pragma: no cover
-        import hashlib
+    import hashlib  # pragma: no cover
 
-        return int(a.size // 4), int.from_bytes(hashlib.blake2b(memoryview(a), digest_size=8).digest(), "little")
+    return int(a.size // 4), int.from_bytes(hashlib.blake2b(memoryview(a), digest_size=8).digest(), "little")  # pragma: no cover
 
 
 def exchange_verdicts(n_tokens: int, digest: int, ok: bool, rank: int, world: int, dist, torch, device="cpu"):
     """Every rank tells every rank (count, digest of its own id stream, did its own shard equal the oracle's): one all-gather of
-    four int64 per rank.  Returns [(count, digest, ok)] in rank order."""
-    mine = torch.tensor([n_tokens, digest & 0xFFFFFFFF, digest >> 32, 1 if ok else 0], dtype=torch.int64, device=device)
-    parts = [torch.zeros(4, dtype=torch.int64, device=device) for _ in range(world)]
+    five int64 per rank (the fifth: the digest function's id).  Returns [(count, digest, ok)] in rank order; RuntimeError when the ranks do
+    not all digest with the same function (a job over mixed environments: every comparison of digests would be a false mismatch)."""
+    algo = digest_algorithm()
+    mine = torch.tensor([n_tokens, digest & 0xFFFFFFFF, digest >> 32, 1 if ok else 0, algo], dtype=torch.int64, device=device)
+    parts = [torch.zeros(5, dtype=torch.int64, device=device) for _ in range(world)]
     dist.all_gather(parts, mine)
-    out = []
+    out, algos = [], []
     for p in parts:
-        c, lo, hi, k = (int(x) for x in p.cpu().tolist())
+        c, lo, hi, k, a = (int(x) for x in p.cpu().tolist())
         out.append((c, (hi << 32) | lo, bool(k)))
+        algos.append(a)
+    if len(set(algos)) != 1:
+        raise RuntimeError(f"the ranks digest their id streams with different functions ({algos}: 1 = xxhash64, 2 = blake2b): install the same packages on every rank")
     return out
 
 

@@ -5,6 +5,7 @@
   C2  cl100k-shaped, encode_ordinary_batch on 64 MiB mixed UTF-8
   C5  o200k + 8 custom special tokens (encode_batch, allowed_special="all"), 256 MiB web text with one
       special per ~2 KiB plus decoys
+  N1g the same generator as N1 at 1 GiB, the headline's size
   N1  (beside them, not one of BASELINE.json's) o200k-shaped on 256 MiB of text whose share of pieces that are not tokens is natural
       (tests/helpers.py natural_corpus: 2.3 %; the synthetic web text of C3 / C4 / C5: 18.7 %)
 
@@ -68,8 +69,12 @@ def main():
     for cfg, title, enc_name, steps in (("C1", "C1 gpt2 1MiB lorem, 1 doc", "gpt2_shaped", 10), ("C2", "C2 cl100k 64MiB mixed UTF-8", "cl100k_shaped", 3),
                                        ("C5", "C5 o200k+8 specials 256MiB, allowed_special=all", "o200k_custom8", 3),
                                        ("N1", "N1 o200k 256MiB of text with a natural miss rate (2.3 % of its pieces are not tokens; C3: 18.7 %): not a BASELINE configuration",
+                                        "o200k_shaped", 3),
+                                       ("N1g", "N1g the same text generator at the headline's size, 1 GiB (2.3 % of the pieces are not tokens; the headline corpus C3: 18.7 %): not a BASELINE configuration",
                                         "o200k_shaped", 3)):
         if only and cfg not in only:
+            continue
+        if cfg == "N1g" and "N1g" not in only and os.environ.get("TIKTOKEN_AMD_BENCH_N1G", "1") == "0":
             continue
         _, _, _, blob, off, allowed = h.baseline_config(cfg)
         run(title, enc_name, blob, off, allowed, steps=steps)

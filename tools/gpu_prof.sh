@@ -2,6 +2,7 @@
 # usage: bash tools/gpu_prof.sh [MIB] [TAG] -- rocprofv3 kernel-trace stats + HBM traffic counters (separate passes)
 MIB=${1:-1024}; TAG=${2:-r01}
 R=$GRAFT_REPO_ROOT; mkdir -p $R/gpurun_out/prof_$TAG
+python $R/bench.py --csrc-digest > $R/gpurun_out/prof_$TAG/csrc_digest.txt  # (the sources these counters are measured on: bench.py ties roofline.traffic to it)
 cd /tmp && export TMPDIR=/tmp
 rocprofv3 --kernel-trace --stats --output-format csv -d $R/gpurun_out/prof_$TAG/trace -o $TAG -- python $R/bench.py --gpus 1 --steps 3 --warmup 1 --mib $MIB --no-cpu-baseline --no-host-path > $R/gpurun_out/prof_$TAG/trace.log 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do

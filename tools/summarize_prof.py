@@ -71,7 +71,15 @@ def main():
             hbm = int((2 * fk + wk) * 1024)
             fo.write(f"{k},{len(f.get(k, []))},{fk:.1f},{wk:.1f},{hbm}\n")
             out[k] = {"hbm_bytes_per_launch": hbm, "fetch_kb_raw": fk, "write_kb": wk}
+    import subprocess
+    try:
+        digest = open(os.path.join(d, "csrc_digest.txt")).read().strip()
+    except OSError:
+        digest = None
+    git = subprocess.run(["git", "-C", ROOT, "rev-parse", "--short", "HEAD"], capture_output=True, text=True).stdout.strip()
+    dirty = bool(subprocess.run(["git", "-C", ROOT, "status", "--porcelain", "--", "tiktoken_amd/csrc"], capture_output=True, text=True).stdout.strip())
     json.dump({"tag": tag, "workload_mib": mib, "encoding": enc, "correction": "(2*FETCH_SIZE + WRITE_SIZE) * 1024",
+               "csrc_digest": digest, "measured_at_git": git + ("+uncommitted changes under csrc/" if dirty else ""),
                "kernels": out}, open(os.path.join(ROOT, "profiles", "traffic.json"), "w"), indent=1)
     print(open(os.path.join(ROOT, "profiles", f"{tag}_hbm_traffic.csv")).read())
 
