@@ -3,6 +3,15 @@ import sys
 
 import pytest
 
+# PyTorch's ROCm wheels bundle a HIP runtime of their own, the product library links the system's: two runtimes in one process.  That works
+# when torch's is loaded first; a process that initialises the system's first (the device count below, at collection) and imports torch
+# afterwards finds "No HIP GPUs are available" in torch.  A run of the whole directory imports torch at collection anyway
+# (test_distributed.py); a run of a single file gets the same order from here.
+try:
+    import torch  # noqa: F401
+except ImportError:  # (the CPU-only tests do not need it)
+    pass
+
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 for p in (ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:

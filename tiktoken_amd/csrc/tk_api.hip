@@ -114,7 +114,7 @@ struct tk_core {
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
     TkHostTables H;
     TkTables D;  // device view
-    Buf t_stage1, t_stage2, t_byte_tab, t_short, t_mid, t_dec, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_xl, t_xfilter, t_spec_bytes, t_spec_off, t_spec_id;
+    Buf t_stage1, t_stage2, t_bmp, t_byte_tab, t_short, t_mid, t_dec, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_xl, t_xfilter, t_spec_bytes, t_spec_off, t_spec_id;
     uint32_t spec_max_len = 0;
     bool has_rx = false;  // the pat_str runs on the generic engine (tk_regex_kernels.h)
     bool has_rx_fb = false;  // a pat_str of the scanner families, compiled for the generic engine as well: the way out of stretches without certain starts (stage_deferred)
@@ -384,6 +384,12 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
         }
         return TK_OK;
     };
+    // the class of every code point below U+10000 in one table (TkTables::uc_bmp), from the two stages
+    auto upload_bmp = [&](const uint8_t* s1, const uint8_t* s2) -> int {
+        std::vector<uint8_t> bmp(65536);
+        for (uint32_t cp = 0; cp < 65536u; ++cp) bmp[cp] = s2[(uint32_t)s1[cp >> 8] * 256u + (cp & 255u)];
+        return upload(c->t_bmp, bmp.data(), bmp.size());
+    };
     if (H.rx.empty()) {
         // a pattern of the scanner families: compiled for the generic engine as well, for stretches of text without certain starts
         // (stage_deferred); a family member the generic compiler cannot take keeps its scanners alone
@@ -393,6 +399,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
         }
         if ((rc = upload(c->t_stage1, tk_uc_stage1, sizeof tk_uc_stage1))) return bail(rc);
         if ((rc = upload(c->t_stage2, tk_uc_stage2, sizeof tk_uc_stage2))) return bail(rc);
+        if ((rc = upload_bmp(tk_uc_stage1, tk_uc_stage2))) return bail(rc);
         uint32_t bt[256 * 2];
         tk_build_byte_table(tk_uc_stage1, tk_uc_stage2, bt);
         if ((rc = upload(c->t_byte_tab, bt, sizeof bt))) return bail(rc);
@@ -402,6 +409,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
         std::vector<uint8_t> s1(0x1100, 0), s2(256, (uint8_t)TK_C_LL);
         if ((rc = upload(c->t_stage1, s1.data(), s1.size()))) return bail(rc);
         if ((rc = upload(c->t_stage2, s2.data(), s2.size()))) return bail(rc);
+        if ((rc = upload_bmp(s1.data(), s2.data()))) return bail(rc);
         uint32_t bt[256 * 2];
         tk_build_byte_table(s1.data(), s2.data(), bt);
         if ((rc = upload(c->t_byte_tab, bt, sizeof bt))) return bail(rc);
@@ -425,6 +433,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     TkTables& D = c->D;
     D.uc_stage1 = c->t_stage1.as<uint8_t>();
     D.uc_stage2 = c->t_stage2.as<uint8_t>();
+    D.uc_bmp = c->t_bmp.as<uint8_t>();
     D.byte_tab = c->t_byte_tab.as<uint32_t>();
     D.short_tab = H.short_tab.empty() ? nullptr : c->t_short.as<TkShortSlot>();
     D.short_mask = H.short_mask;
@@ -516,7 +525,7 @@ extern "C" void tk_destroy(tk_core* c) {
     if (!c) return;
     (void)hipSetDevice(c->device);
     for (Buf* b : {&c->t_rx_ins, &c->t_rx_sets, &c->t_rx_ranges, &c->t_rx_first, &c->t_rx_s1, &c->t_rx_s2, &c->t_rx_dtrans, &c->t_rx_dascii, &c->t_rx_ds1, &c->t_rx_ds2}) release(*b);
-    for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_dec, &c->d_tok, &c->d_lens, &c->d_bsum, &c->d_tboff, &c->d_bytes, &c->d_bytes_alt, &c->d_boff, &c->t_piece,
+    for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_bmp, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_dec, &c->d_tok, &c->d_lens, &c->d_bsum, &c->d_tboff, &c->d_bytes, &c->d_bytes_alt, &c->d_boff, &c->t_piece,
                    &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2, &c->t_byte_rank, &c->t_xl, &c->t_xfilter, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off,
                    &c->out_tokens, &c->out_tok_off, &c->out_tokens_alt, &c->out_tok_off_alt, &c->allowed, &c->tok_bases})
         release(*b);
@@ -2623,5 +2632,22 @@ extern "C" uint64_t tk_stat(tk_core* c, const char* name) {
     if (k == "host_tail_us") return (uint64_t)c->host_us[4];
     if (k == "host_total_us") return (uint64_t)c->host_us[5];
     if (k == "chunk_bytes") return c->chunk_bytes;
+#ifdef TKF_TIMING
+    if (k.rfind("time_", 0) == 0) {  // (experiments: tk_fused.h, TKT)
+        static unsigned long long acc[1024 * 16];
+        (void)hipSetDevice(c->device);
+        (void)hipDeviceSynchronize();
+        if (k == "time_reset") {
+            memset(acc, 0, sizeof(acc));
+            (void)hipMemcpyToSymbol(HIP_SYMBOL(tk_time_acc), acc, sizeof(acc));
+            return 0;
+        }
+        (void)hipMemcpyFromSymbol(acc, HIP_SYMBOL(tk_time_acc), sizeof(acc));
+        const int i = atoi(k.c_str() + 5);
+        unsigned long long sum = 0;
+        for (int b = 0; b < 1024 && i >= 0 && i < 16; ++b) sum += acc[b * 16 + i];
+        return sum;
+    }
+#endif
     return 0;
 }

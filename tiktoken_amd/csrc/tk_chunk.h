@@ -92,26 +92,38 @@ TK_HD void tk_chunk_apply(TkChunk& c, int k, uint32_t len, uint32_t cls) {
 // 2. decode pass.  get4(k) -> the four text bytes at chunk-relative offset k (-3 <= k <= 15), cls_of(cp) -> class nibble.
 // prev: the four bytes before the chunk (byte 3 of `prev` = position -1) locate the lead of a char that straddles in from the
 // previous chunk (has_prev: those bytes exist).
+// TWO chars per step (round 6): a step is a chain of dependent table loads, and a wavefront takes as many steps as its lane with the
+// most chars (a chunk of CJK text has five or six; the average lane of web text less than two) -- with two chars per step the loads of
+// both are in flight together and the steps are half as many.  A lane with an odd number applies its last char twice (an OR: harmless).
 template <class Get4, class ClsOf>
 TK_HD void tk_chunk_decode(TkChunk& c, uint32_t prev, bool has_prev, Get4& get4, ClsOf& cls_of) {
     const uint32_t cont = tk_plane16(c.f0, c.f1, 0);
     uint32_t leads = tk_plane16(c.f0, c.f1, 1) | tk_plane16(c.f0, c.f1, 2) | tk_plane16(c.f0, c.f1, 3);
-    if ((cont & 1u) && has_prev) {
-        const int k = (prev >> 24) >= 0xC0u ? -1 : (((prev >> 16) & 0xFFu) >= 0xC0u ? -2 : -3);
-        uint32_t len;
-        const uint32_t cp = tk_utf8_cp(get4(k), &len);
-        tk_chunk_apply(c, k, len, cls_of(cp));
-    }
-    while (leads) {
+    bool pend = (cont & 1u) && has_prev;  // the char that straddles in: its lead is one to three bytes before the chunk
+    const int kprev = (prev >> 24) >= 0xC0u ? -1 : (((prev >> 16) & 0xFFu) >= 0xC0u ? -2 : -3);
+    auto next_lead = [&]() -> int {
 #if defined(__HIP_DEVICE_COMPILE__)
         const int k = __ffs((int)leads) - 1;
 #else
         const int k = __builtin_ctz(leads);
 #endif
         leads &= leads - 1;
-        uint32_t len;
-        const uint32_t cp = tk_utf8_cp(get4(k), &len);
-        tk_chunk_apply(c, k, len, cls_of(cp));
+        return k;
+    };
+    while (pend || leads) {
+        int k1;
+        if (pend) {
+            k1 = kprev;
+            pend = false;
+        } else {
+            k1 = next_lead();
+        }
+        const int k2 = leads ? next_lead() : k1;
+        uint32_t len1, len2;
+        const uint32_t cp1 = tk_utf8_cp(get4(k1), &len1), cp2 = tk_utf8_cp(get4(k2), &len2);
+        const uint32_t c1 = cls_of(cp1), c2 = cls_of(cp2);
+        tk_chunk_apply(c, k1, len1, c1);
+        tk_chunk_apply(c, k2, len2, c2);
     }
 }
 

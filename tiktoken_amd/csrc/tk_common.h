@@ -126,6 +126,8 @@ TK_HD constexpr TkPat tk_stock_pat(int fam) {
 struct TkTables {
     const uint8_t* uc_stage1;   // [0x1100]
     const uint8_t* uc_stage2;   // [nblocks*256]
+    const uint8_t* uc_bmp;      // [65536] the class of every code point below U+10000 once more, directly (one load where the two stages are two
+                                // dependent ones: the classification of the front kernel waits for a chain of them per wavefront); null on the host
     const uint32_t* byte_tab;   // [256 * 2] per-byte {class planes, flag planes} of the 16-bytes-per-lane classifier (tk_chunk.h)
     const TkShortSlot* short_tab;  // [short_mask+1] tokens of 1..4 bytes (null when some rank exceeds TK_SHORT_MAX_RANK)
     uint32_t short_mask, short_shift;  // slot = (key32 * K) >> short_shift

@@ -63,7 +63,15 @@
 #define TKF_MODE_TILE 0
 #define TKF_MODE_STARTS 1
 #define TKF_MODE_GIVEN 2
+#ifndef TKF_EF
+#define TKF_EF 1  // phases E / F of round 6: class lists from the start bitmap by bit operations, the pieces that are not tokens claimed in dense rows (0: round 5's form)
+#endif
+#if TKF_EF
+#define TKF_BATCH 896  // pieces per part of a tile in the front kernel's phase F (the class lists hold 1024 entries)
+#define TKF_BL 14      // ... = the 28 bitmap words = 896 positions of this many lanes of phase E, when a tile has more pieces than that
+#else
 #define TKF_BATCH 960  // pieces per probe batch of the front kernel (the class lists hold 1024 entries, their packed counter 1023)
+#endif
 #define TKF_CAP 4096  // piece ids per tile: pid = tile * TKF_CAP + k (a 4096-byte tile starts at most 4096 pieces)
 // The tail of a tile's run of result words holds, from the back: the number of its pieces that are not tokens (TKF_TAIL_NMISS), the number
 // of its gap chars (TKF_TAIL_NGAP), then the entries of the pieces that are not tokens once more, in no particular order -- what the counting
@@ -600,6 +608,22 @@ __device__ __forceinline__ bool tk_equal_lds_text(const uint8_t* raw, uint32_t o
 #ifndef TKF_ROWS
 #define TKF_ROWS 1  // phase F: one length class per row of 64 pieces (0: the three classes side by side in every lane)
 #endif
+// Experiments only (-DTKF_TIMING, tools/build_variant.sh): where a workgroup's time per tile goes.  Thread 0 reads the shader clock at the phase
+// boundaries of the one-tile-per-workgroup instance and adds the differences up in tk_time_acc (read and reset through tk_stat "time_<i>" /
+// "time_reset"); slot 15 counts the tiles.
+#ifdef TKF_TIMING
+__device__ unsigned long long tk_time_acc[1024 * 16];  // (spread over 1024 lines by workgroup: same-address atomics would be what is measured)
+#define TKT(i)                                                                  \
+    do {                                                                        \
+        if (MODE == TKF_MODE_TILE && tid == 0) {                                \
+            const unsigned long long tkt_now = __builtin_readcyclecounter();    \
+            atomicAdd(&tk_time_acc[(blockIdx.x & 1023u) * 16u + i], tkt_now - tkt_prev); \
+            tkt_prev = tkt_now;                                                 \
+        }                                                                       \
+    } while (0)
+#else
+#define TKT(i) do { } while (0)
+#endif
 template <int PAT, bool SPEC, int MODE>
 __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
                                                   const uint32_t* __restrict__ brk, const uint32_t* __restrict__ docb,
@@ -644,6 +668,10 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
     const uint32_t tid = threadIdx.x;
     const int lane = tid & 63, wid = tid >> 6;
     uint32_t item = blockIdx.x;
+#ifdef TKF_TIMING
+    unsigned long long tkt_prev = __builtin_readcyclecounter();
+    if (MODE == TKF_MODE_TILE && tid == 0) atomicAdd(&tk_time_acc[(blockIdx.x & 1023u) * 16u + 15u], 1ull);
+#endif
     // SLOW: persistent, a fixed grid walks the deferred list with the stride of the grid.  Otherwise one tile per workgroup (the loop's
     // state would cost registers the kernel does not have at eight workgroups per CU).
     constexpr bool PERSIST = SLOW;
@@ -705,6 +733,7 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
     }
     if (tid < 4) planes[tid][TK2_NSEG] = planes[tid][TK2_NSEG + 1] = tid >= 2 ? ~0ull : 0ull;  // (class END)
     __syncthreads();
+    TKT(0);
     if (dbg & 0x1000) {  // (perf experiments: stop after this phase)
         if (tid == 0) out.tile_np[tile] = 0;
         continue;
@@ -763,13 +792,15 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
             const uint32_t o = tid * 16u + (uint32_t)k;
             return __builtin_amdgcn_alignbyte(dw[(o >> 2) + 1], dw[o >> 2], o & 3u);
         };
-        auto cls_of = [&](uint32_t cp) -> uint32_t {
-            if (cp > 0x10FFFFu) cp = 0xFFFFu;
-            return T.uc_stage2[(uint32_t)T.uc_stage1[cp >> 8] * 256u + (cp & 255u)];
+        auto cls_of = [&](uint32_t cp) -> uint32_t {  // (one load below U+10000 -- no `if` around it: the loads of a step are in flight together)
+            uint32_t cl = T.uc_bmp[cp < 0x10000u ? cp : 0xFFFFu];
+            if (cp >= 0x10000u && cp <= 0x10FFFFu) cl = T.uc_stage2[(uint32_t)T.uc_stage1[cp >> 8] * 256u + (cp & 255u)];
+            return cl;
         };
         const uint32_t prev = tid ? dw[tid * 4u - 1u] : 0u;
         tk_chunk_decode(ch, prev, tid > 0, get4, cls_of);
     }
+    TKT(1);
     if (dbg & 0x2000) {  // (perf experiments: stop after the classification)
         if (tid == 0 || (ch.acc0 ^ ch.acc1) == 0xFFFFFFF1u) out.tile_np[tile] = 0;
         continue;
@@ -872,6 +903,7 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
         defer_tile();
         continue;
     }
+    TKT(2);
     if (dbg & 0x4000) {  // (perf experiments: stop after this phase)
         if (tid == 0) out.tile_np[tile] = 0;
         continue;
@@ -1060,7 +1092,9 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
             }
         }
     }
+    TKT(12);  // (round 0 without the barrier)
     __syncthreads();
+    TKT(11);  // (round 0 and its barrier)
     // Rounds around ONE instance of the lanes' evaluation (the scanner is big: a second inlined copy spills registers): the listed
     // chains (and what did not fit the list: every lane's own), walked to their ends.  After each round the workgroup answers the pieces
     // that left the window; those can add continuations for one more round.
@@ -1091,6 +1125,7 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
                 if (!__any(p != TKF_CHAIN_END)) break;
             }
         }
+        TKT(13);  // (the evaluations of a round)
         __syncthreads();
         if (!SLOW && nslow_sh) break;  // a piece leaves the window: the tile is deferred (below)
         const uint32_t slow_n = nslow_sh < TKF_SLOW_CAP ? nslow_sh : (uint32_t)TKF_SLOW_CAP;
@@ -1105,6 +1140,7 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
         continue;
     }
     }
+    TKT(3);
     if (dbg & 0x8000) {  // (perf experiments: stop after this phase)
         if (tid == 0) out.tile_np[tile] = 0;
         continue;
@@ -1117,6 +1153,376 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
         if (tid == 0) out.tile_np[tile] = last_end_sh;
         continue;
     } else {
+#if TKF_EF
+    // ---- E (round 6): the tile's pieces by length class, straight from the start bitmap.  Rounds 2-5 wrote a list of piece starts (a
+    // lane per bitmap word, a store per set bit) and then classified every piece from it -- two reads of the list, four ballots and
+    // their prefix counts per row of 256 pieces: 1240 of the kernel's 8200 vector instructions per tile.  Here ONE wavefront (the other three
+    // wait at the barrier: vector instructions are paid per wavefront) takes two words per lane and derives the classes as bit
+    // operations: "a start follows within d positions" = the bitmap OR-ed with its own shifts (doubling: 1-2, 1-4, 1-8, 1-16, 16-23),
+    // so a piece of at most 4 / 8 / TK_XL_MAX bytes is a set bit under the mask of that distance and under no shorter one; counts by
+    // v_bcnt, places by two wave scans, and a lane then writes the positions of ITS set bits of one class after the other.  A list
+    // entry is the piece's window position (its length is the distance to the next set bit: one funnel shift and a count of trailing
+    // zeros where the row needs it), beside it the piece's index k in the tile (its result word is res[run + k]).
+    constexpr uint32_t NWB = (uint32_t)TK_TILE / 32u;  // words of the tile's bitmap (even)
+    const uint32_t run_base = (uint32_t)tile * TKF_CAP;
+    uint32_t* bx = certw;                            // [128] the start bitmap once more, plus the END of the tile's last piece (the certain starts are dead)
+    uint16_t* ord_sl = (uint16_t*)btab;              // [1024] short pieces from the front, long ones from the back: window positions (the byte table is dead)
+    uint16_t* ord_m = (uint16_t*)planes;             // [1024] mid pieces (the planes are dead)
+    uint16_t* ordk_sl = (uint16_t*)pool;             // [1024] their indices k (the bitmaps are dead)
+    uint16_t* ordk_m = (uint16_t*)(pool + 2048);     // [1024]
+    uint32_t* mlist = (uint32_t*)(pool + 4096);      // [TKF_BATCH] pieces that are not tokens: position | k << 12 | class << 24 (3: more than TK_XL_MAX bytes) | "no slot" << 31
+    uint32_t& ntail_sh = ncont_sh;   // pieces of the tile that are not tokens, so far = entries at the tail of its run (the scanners' counter is dead)
+    if (wid == 0) {
+        const uint32_t i0 = 2u * (uint32_t)lane, last_end0 = last_end_sh;
+        const uint32_t v0 = i0 < NWB ? bits[i0] : 0u, v1 = i0 < NWB ? bits[i0 + 1u] : 0u;
+        const uint32_t le = last_end0 - (uint32_t)TK2_LEFT;  // (tile-relative; beyond the bitmap when the last piece leaves the window: a tile of the deferred list)
+        bx[i0] = v0 | ((le >> 5) == i0 ? 1u << (le & 31u) : 0u);
+        bx[i0 + 1u] = v1 | ((le >> 5) == i0 + 1u ? 1u << (le & 31u) : 0u);
+        const uint32_t inc = tk_wave_scan_u32((uint32_t)__popc(v0) + (uint32_t)__popc(v1), lane);
+        const uint64_t wgp = tile_start / 32 + i0;
+        if (i0 < NWB && wgp * 32 < n) *(uint2*)(out.starts + wgp) = make_uint2(v0, v1);  // (8-byte aligned: 120 words per tile; the array has two words to spare)
+        if (lane == 63) {
+            np_sh = inc;
+            out.tile_np[tile] = inc;
+        }
+        if (lane == 0) {
+            ntail_sh = 0;
+            if (GEN) ngap_sh = 0;
+        }
+    }
+    if constexpr (SPEC) {  // starts of special tokens in the window, for the lists (the break bitmap is dead since phase C)
+        if (tid < TK2_WIN / 32) {
+            const int64_t wgp = base + (int64_t)tid * 32;
+            brkw[tid] = (wgp >= 0 && (uint64_t)wgp < n) ? ss[wgp >> 5] : 0u;
+        }
+    }
+    __syncthreads();
+    TKT(4);
+    if (dbg & 0x10000) {  // (perf experiments: stop after this phase)
+        if (tid == 0) out.tile_np[tile] = 0;
+        continue;
+    }
+    const uint32_t np = np_sh, last_end = last_end_sh;
+    const uint32_t* dwr = (const uint32_t*)raw;
+    const bool short_tab = T.short_tab != nullptr;
+    // length of the piece at window position pos when the next start lies within 31 positions (every piece of the class lists)
+    auto near_len = [&](uint32_t pos) -> uint32_t {
+        const uint32_t t = pos - (uint32_t)TK2_LEFT, wi = t >> 5;
+        return (uint32_t)__ffs((int)(__builtin_amdgcn_alignbit(bx[wi + 1u], bx[wi], t & 31u) >> 1));
+    };
+    // end (window position) of the piece that starts at pos, however long
+    auto far_end = [&](uint32_t pos) -> uint32_t {
+        const uint32_t t = pos - (uint32_t)TK2_LEFT;
+        uint32_t wi = t >> 5;
+        uint32_t x = (bx[wi] >> (t & 31u)) >> 1;
+        if (x) return pos + (uint32_t)__ffs((int)x);
+        for (++wi; wi < (uint32_t)TK2_WIN / 32u; ++wi) {
+            x = bx[wi];
+            if (x) return (uint32_t)TK2_LEFT + wi * 32u + (uint32_t)__ffs((int)x) - 1u;
+        }
+        return last_end;
+    };
+    // A piece that is not a token, by its identity (w0, w1, w2; kk = tk_ident_hash): claim a slot of the in-call table (first occurrence:
+    // the slot's entry gets the piece, the merge kernels will find it there) or find it claimed by IDENTICAL bytes; `k0` / `k1` = the two
+    // halves of slot i, which the caller has loaded.  Returns the slot, or TKF_NONE when the neighbourhood is full.  Slots are written
+    // once, so a cached load can only be stale towards "empty" / "not written yet", where the atomic (the load at the memory side) decides.
+    auto claim = [&](uint64_t w0, uint64_t w1, uint64_t w2, unsigned long long kk, bool exact, bool in_lds, uint32_t s_loc, uint64_t gs, uint32_t len,
+                     uint32_t i, ulonglong2 k0, ulonglong2 k1) -> uint32_t {
+        for (int p = 0;;) {
+            unsigned long long cur = k0.x;
+            if (cur == TK_EMPTY_KEY) cur = atomicCAS(&mt[i].key, TK_EMPTY_KEY, kk);
+            if (cur == TK_EMPTY_KEY) {  // claimed: this occurrence is the one that gets merged
+                __hip_atomic_store(&mt[i].w0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&mt[i].w1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                __hip_atomic_store(&mt[i].w2, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                *(uint2*)&out.data.tab[i].start = make_uint2((uint32_t)gs, len);
+                return i;
+            }
+            if (cur == kk) {
+                unsigned long long a0 = k0.y, a1 = k1.x, a2 = k1.y;
+                if (a2 == TK_EMPTY_KEY || a0 == TK_EMPTY_KEY || a1 == TK_EMPTY_KEY) {  // (a line cached before the claimant had written: once more, at the memory side)
+                    // The claimant writes its words right behind its compare-and-swap: whoever loses that race by a few hundred nanoseconds --
+                    // every tile of a text that repeats itself reaches its first missed piece at the same moment -- would find them empty, take
+                    // the piece for another one and claim the next slot for the same bytes (exact, but a merge per slot, and a full
+                    // neighbourhood sends the piece to the overflow entries).  So it looks again a few times (bounded: never a dead lock).
+                    for (int spin = 0;; ++spin) {
+                        a0 = __hip_atomic_load(&mt[i].w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a1 = __hip_atomic_load(&mt[i].w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        a2 = __hip_atomic_load(&mt[i].w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+                        if ((a2 != TK_EMPTY_KEY && a0 != TK_EMPTY_KEY && a1 != TK_EMPTY_KEY) || spin >= TKF_CLAIM_SPIN) break;
+                        __builtin_amdgcn_s_sleep(2);
+                    }
+                }
+                bool same = a0 == w0 && a1 == w1 && a2 != TK_EMPTY_KEY && (exact ? a2 == w2 : (a2 >> 32) == (w2 >> 32));
+                if (same && !exact)
+                    same = in_lds ? tk_equal_lds_text(raw, s_loc + 8u, text, (uint64_t)(uint32_t)a2 + 8u, len - 16u)  // (w0 and w1 are the first and the last eight bytes)
+                                  : tk_equal_bytes(text, gs, text, (uint32_t)a2, len);
+                if (same) return i;
+            }
+            if (++p == TK_MT_PROBES) return TKF_NONE;
+            i = (i + 1) & mt_mask;
+            k0 = *(const ulonglong2*)&mt[i].key;
+            k1 = *(const ulonglong2*)&mt[i].w1;
+        }
+    };
+    // the result of a piece that is not a token: its word, and its entry once more at the tail of the run (one LDS atomic per wavefront)
+    auto put_ref = [&](bool on, uint32_t k, uint32_t ref) {
+        const uint64_t m = __ballot(on);
+        if (m) {
+            uint32_t at = 0;
+            const int leader = __ffsll((unsigned long long)m) - 1;
+            if (lane == leader) at = atomicAdd(&ntail_sh, (uint32_t)__popcll(m));
+            at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+            if (on) {
+                out.res[run_base + k] = ref != TKF_NONE ? (TK_RES_FLAG | ref) : 0u;
+                out.res[run_base + TKF_TAIL_REFS - at] = ref;  // (TKF_NONE = 0xFFFFFFFF: counts as the one token 0 the result word holds; the batch is repeated with more room)
+            }
+        }
+    };
+    // A tile of more than TKF_BATCH pieces (lists of 1024 entries; rare: a table of digits, a page of one-letter words) goes through the lists
+    // in parts of TKF_BL lanes = 28 bitmap words = 896 positions each.
+    const uint32_t nbatch = np <= (uint32_t)TKF_BATCH ? 1u : (NWB / 2u + (uint32_t)TKF_BL - 1u) / (uint32_t)TKF_BL;
+    // The pieces that are not tokens: a list per WAVEFRONT (no barrier between the rows and their claims, no atomic to append), drained in
+    // dense passes of sixty-four -- when the wavefront's rows are done, or before a row that might not fit.
+    constexpr uint32_t MLW = (uint32_t)TKF_BATCH / 4u;  // entries of a wavefront's list
+    uint32_t* mlw = mlist + (uint32_t)wid * MLW;
+    for (uint32_t bt = 0; bt < nbatch; ++bt) {
+        // ---- the lists.  Every wavefront derives the masks (two words per lane) and the places; wavefront 0 then writes the short pieces,
+        // 1 the mid ones, 2 the long ones, 3 those of more than TK_XL_MAX bytes (and special tokens, gap chars): the serial part -- a lane
+        // writes its set bits one after the other -- is as long as the longest of the four, not as their sum.
+        uint32_t n_mine = 0;  // entries of this wavefront's list of the pieces that are not tokens
+        {
+            // (the lane number as a value the compiler cannot see through: it would compute the lane's LDS addresses once, before this loop that
+            // runs once, keep them across the whole of it -- and, out of registers, put them in scratch memory: four dependent reloads here)
+            uint32_t lane_e = (uint32_t)lane;
+            asm volatile("" : "+v"(lane_e));
+            const uint32_t i0 = 2u * lane_e;
+            const bool inb = nbatch == 1u || (lane_e >= bt * (uint32_t)TKF_BL && lane_e < (bt + 1u) * (uint32_t)TKF_BL);
+            const uint32_t q0 = i0 < NWB ? bits[i0] : 0u, q1 = i0 < NWB ? bits[i0 + 1u] : 0u;  // the lane's pieces (all of them count towards k)
+            const uint32_t cq = (uint32_t)__popc(q0) + (uint32_t)__popc(q1);
+            const uint32_t kb0 = tk_wave_scan_u32(cq, lane) - cq, kb1 = kb0 + (uint32_t)__popc(q0);  // k of the first piece of either word
+            const uint32_t x1 = bx[i0 + 1u], x2 = bx[i0 + 2u < (uint32_t)TK2_WIN / 32u ? i0 + 2u : i0];
+            uint32_t p0 = inb ? q0 : 0u, p1 = inb ? q1 : 0u;
+            const uint32_t posb = (uint32_t)TK2_LEFT + 32u * i0;  // window position of bit 0 of the lane's first word
+            auto each = [&](uint32_t m, uint32_t qw, uint32_t kb, uint32_t pb, auto&& put) {
+                while (m) {
+                    const uint32_t b = (uint32_t)__ffs((int)m) - 1u;
+                    m &= m - 1u;
+                    put(pb + b, kb + (uint32_t)__popc(qw & ((1u << b) - 1u)));
+                }
+            };
+            if constexpr (SPEC) {  // a special token: its id (src/lib.rs:426-434)
+                const uint32_t s0 = i0 < NWB ? p0 & brkw[4u + i0] : 0u, s1 = i0 < NWB ? p1 & brkw[5u + i0] : 0u;
+                if (wid == 3 && __ballot((s0 | s1) != 0u)) {
+                    auto put = [&](uint32_t pos, uint32_t k) { out.res[run_base + k] = tk_special_id(T, text, (uint64_t)(base + pos), far_end(pos) - pos); };
+                    each(s0, q0, kb0, posb, put);
+                    each(s1, q1, kb1, posb + 32u, put);
+                }
+                p0 &= ~s0;
+                p1 &= ~s1;
+            }
+            if constexpr (GEN) {  // a gap char (a char at which a pat_str of the generic engine matches nothing): no token
+                if (gapb) {
+                    const uint64_t wgp = tile_start / 32 + i0;
+                    const uint32_t g0 = (i0 < NWB && wgp * 32 < n) ? p0 & gapb[wgp] : 0u, g1 = (i0 < NWB && (wgp + 1) * 32 < n) ? p1 & gapb[wgp + 1] : 0u;
+                    if (wid == 3 && __ballot((g0 | g1) != 0u)) {
+                        auto put = [&](uint32_t, uint32_t k) { out.res[run_base + k] = TK_RES_GAP; };
+                        each(g0, q0, kb0, posb, put);
+                        each(g1, q1, kb1, posb + 32u, put);
+                        if (g0 | g1) atomicAdd(&ngap_sh, (uint32_t)__popc(g0) + (uint32_t)__popc(g1));  // (LDS; gap chars are rare)
+                    }
+                    p0 &= ~g0;
+                    p1 &= ~g1;
+                }
+            }
+            // pieces of the word A (B = the 32 positions behind it) whose next start is at most 4 / 8 / TK_XL_MAX positions away
+            uint32_t n4a, n8a, n23a, n4b, n8b, n23b;
+            auto reach = [&](uint32_t A, uint32_t B, uint32_t& n4, uint32_t& n8, uint32_t& n23) {
+                const uint32_t s1 = __builtin_amdgcn_alignbit(B, A, 1), b1 = B >> 1;                       // distance 1
+                const uint32_t n2l = s1 | __builtin_amdgcn_alignbit(b1, s1, 1), n2h = b1 | (b1 >> 1);     // 1 .. 2
+                const uint32_t n4l = n2l | __builtin_amdgcn_alignbit(n2h, n2l, 2), n4h = n2h | (n2h >> 2);  // 1 .. 4
+                const uint32_t n8l = n4l | __builtin_amdgcn_alignbit(n4h, n4l, 4), n8h = n4h | (n4h >> 4);  // 1 .. 8
+                const uint32_t n16l = n8l | __builtin_amdgcn_alignbit(n8h, n8l, 8);                        // 1 .. 16
+                static_assert(TK_XL_MAX == 23u && TK_XL_MIN == 9u, "the doubling ends at 23");
+                n4 = n4l;
+                n8 = n8l;
+                n23 = n16l | __builtin_amdgcn_alignbit(n8h, n8l, 15);                                      // 1 .. 23
+            };
+            reach(bx[i0], x1, n4a, n8a, n23a);
+            reach(x1, x2, n4b, n8b, n23b);
+            // this wavefront's class: its pieces of the two words, their number, their places
+            const uint32_t c0 = wid == 0 ? p0 & n4a : (wid == 1 ? p0 & n8a & ~n4a : (wid == 2 ? p0 & n23a & ~n8a : p0 & ~n23a));
+            const uint32_t c1 = wid == 0 ? p1 & n4b : (wid == 1 ? p1 & n8b & ~n4b : (wid == 2 ? p1 & n23b & ~n8b : p1 & ~n23b));
+            const uint32_t nc = (uint32_t)__popc(c0) + (uint32_t)__popc(c1);
+            const uint32_t inc = tk_wave_scan_u32(nc, lane);
+            if (lane == 63) scan_sh[wid] = inc;  // (n_s, n_m, n_l, n_xl)
+            uint32_t o = inc - nc;
+            if (wid == 0) {
+                auto put = [&](uint32_t pos, uint32_t k) { ord_sl[o] = (uint16_t)pos; ordk_sl[o] = (uint16_t)k; ++o; };
+                each(c0, q0, kb0, posb, put);
+                each(c1, q1, kb1, posb + 32u, put);
+            } else if (wid == 1) {
+                auto put = [&](uint32_t pos, uint32_t k) { ord_m[o] = (uint16_t)pos; ordk_m[o] = (uint16_t)k; ++o; };
+                each(c0, q0, kb0, posb, put);
+                each(c1, q1, kb1, posb + 32u, put);
+            } else if (wid == 2) {
+                auto put = [&](uint32_t pos, uint32_t k) { ord_sl[1023u - o] = (uint16_t)pos; ordk_sl[1023u - o] = (uint16_t)k; ++o; };
+                each(c0, q0, kb0, posb, put);
+                each(c1, q1, kb1, posb + 32u, put);
+            } else {
+                // the pieces of more than TK_XL_MAX bytes are on the lists of the pieces that are not tokens from the start (the j-th on the list
+                // of wavefront j & 3): no look at the vocabulary (2 % of the pieces, next to none of them tokens; tk_k_bincount asks once per DISTINCT piece)
+                auto put = [&](uint32_t pos, uint32_t k) { mlist[(o & 3u) * MLW + (o >> 2)] = pos | (k << 12) | (3u << 24); ++o; };
+                each(c0, q0, kb0, posb, put);
+                each(c1, q1, kb1, posb + 32u, put);
+            }
+        }
+        TKT(5);
+        __syncthreads();
+        TKT(6);
+        // ---- F: whole-piece probe (src/lib.rs:367) by rows of 64 pieces of ONE length class: a wavefront takes every fourth row -- the
+        // dearest rows first, so that they are spread evenly and run side by side -- and runs that class's probe only, with all lanes busy:
+        //   long : identity = the bytes (tk_common.h, tk_ident), 32-byte slots that hold them
+        //   mid  : 64-bit key = the bytes, 16-byte slots
+        //   short: the bytes are the key (one unaligned LDS dword), 8-byte slots
+        // A piece that is not a token goes on the wavefront's list.
+        const uint32_t n_s = scan_sh[0], n_m = scan_sh[1], n_l = scan_sh[2], n_xl = scan_sh[3];
+        const uint32_t rows_l = (n_l + 63u) >> 6, rows_m = (n_m + 63u) >> 6, rows_s = (n_s + 63u) >> 6, rows_all = rows_l + rows_m + rows_s;
+        const bool use_mt = mt != nullptr && !(dbg & 8);
+        n_mine = (n_xl + 3u - (uint32_t)wid) >> 2;
+        for (uint32_t r = (uint32_t)wid;; r += 4u) {
+            const bool more = r < rows_all;
+            if (!more || n_mine + 64u > MLW) {
+                // The listed pieces, sixty-four at a time whatever rows they came from: each claims a slot of the in-call table or finds it
+                // claimed by identical bytes (by the piece's identity: the bytes themselves up to TK_XL_MAX of them; longer pieces: the first
+                // and the last eight bytes, the length, and a comparison in the text).  Round 5 did this inside every row, for the 19 % of its
+                // lanes whose piece was not a token -- eleven sparse passes through this code per tile where these are four.
+                for (uint32_t c0 = 0; c0 < n_mine; c0 += 64u) {
+                    const uint32_t q = c0 + (uint32_t)lane;
+                    const bool have = q < n_mine;
+                    const uint32_t e = mlw[have ? q : 0u];
+                    const uint32_t pos = e & 4095u;
+                    uint32_t k = (e >> 12) & 4095u, len = 0, ref = TKF_NONE;
+                    uint64_t gs = 0;
+                    bool fail = false;
+                    if (have) {
+                        const uint32_t e_loc = (e >> 24) == 3u ? far_end(pos) : pos + near_len(pos);
+                        len = e_loc - pos;
+                        gs = (uint64_t)(base + pos);
+                        if (dbg & (2 | 8)) {  // (perf experiments / piece starts only: every probe counts as a hit -- only the longest pieces get here)
+                            out.res[run_base + k] = (dbg & 2) ? len : 0u;
+                        } else {
+                            fail = true;
+                            if (use_mt && len <= TK_GLANE_MAX) {
+                                const bool in_lds = e_loc + 8u <= (uint32_t)TK2_WIN, exact = len <= TK_XL_MAX;
+                                uint64_t w0, w1, w2;
+                                tk_ident([&](uint32_t o) { return in_lds ? tk_lds_load8(raw, pos + o) : tk_load8(text, gs + o); }, len, (uint32_t)gs, w0, w1, w2);
+                                unsigned long long kk = tk_ident_hash(w0, w1, w2, exact);
+                                if (dbg & 512) kk &= 0xFFFull;  // test hook: force collisions between different pieces
+                                if (kk == TK_EMPTY_KEY) kk = 0;
+                                const uint32_t i = ((uint32_t)kk ^ (uint32_t)(kk >> 40)) & mt_mask;
+                                ref = claim(w0, w1, w2, kk, exact, in_lds, pos, gs, len, i, *(const ulonglong2*)&mt[i].key, *(const ulonglong2*)&mt[i].w1);
+                                fail = ref == TKF_NONE;
+                            }
+                        }
+                    }
+                    put_ref(ref != TKF_NONE, k, ref);
+                    if (__ballot(fail)) {
+                        // What the in-call table could not take (next to nothing: chunks too small for a table, a full neighbourhood, pieces of more
+                        // than TK_GLANE_MAX bytes): an overflow entry behind the table's (one returning atomic per wavefront that has such pieces).
+                        bool over = fail;
+                        ref = TKF_NONE;
+                        if (over && len > TK_XL_MAX && len <= T.max_token_len && (len > TK_GLANE_MAX || !mt)) {
+                            // (nobody else will ask whether it is a token: tk_k_bincount looks at table slots and overflow entries of at most
+                            // TK_GLANE_MAX bytes -- the latter is asked twice then, harmlessly)
+                            const uint32_t rk = tk_lookup_text_piece(T, text, gs, len);
+                            if (rk != TK_RANK_MAX) {
+                                out.res[run_base + k] = rk;
+                                over = false;  // (settled: a token after all)
+                            }
+                        }
+                        const uint64_t m = __ballot(over);
+                        if (m) {
+                            const int leader = __ffsll((unsigned long long)m) - 1;
+                            uint32_t at = 0;
+                            if (lane == leader) at = atomicAdd(&out.counters[TK_CNT_OVF], (uint32_t)__popcll(m));
+                            at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+                            if (over && at < out.ovf_cap) {  // (beyond the capacity: the counter tells the host, which repeats the batch with more room)
+                                ref = out.data.ovf_base + at;
+                                *(uint4*)&out.data.ovf[at].start = make_uint4((uint32_t)gs, len, 0u, 0u);
+                                if (len > TK_GLANE_MAX) tk_append_tree(out.listC, out.counters, ref, (uint32_t)gs, len);
+                            }
+                        }
+                        put_ref(over, k, ref);
+                    }
+                }
+                n_mine = 0;
+                TKT(9);
+            }
+            if (!more) break;
+            bool miss = false;
+            uint32_t e = 0;
+            if (r < rows_l) {
+                const uint32_t q = r * 64u + (uint32_t)lane;
+                if (q < n_l) {
+                    const uint32_t pos = ord_sl[1023u - q], k = ordk_sl[1023u - q];
+                    const uint32_t len = near_len(pos);
+                    const bool in_lds = pos + len + 8u <= (uint32_t)TK2_WIN;
+                    uint32_t rk = len;
+                    if (!(dbg & 2)) {
+                        const uint64_t gs = (uint64_t)(base + pos);
+                        uint64_t w0, w1, w2;
+                        tk_ident([&](uint32_t o) { return in_lds ? tk_lds_load8(raw, pos + o) : tk_load8(text, gs + o); }, len, 0u, w0, w1, w2);
+                        rk = tk_probe_xl(T, w0, w1, w2);
+                    }
+                    if (rk != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k] = rk == TK_RANK_MAX ? 0u : rk;
+                    else {
+                        miss = true;
+                        e = pos | (k << 12) | (2u << 24);
+                    }
+                }
+            } else if (r < rows_l + rows_m) {
+                const uint32_t q = (r - rows_l) * 64u + (uint32_t)lane;
+                if (q < n_m) {
+                    const uint32_t pos = ord_m[q], k = ordk_m[q];
+                    const uint32_t len = near_len(pos);
+                    const uint64_t key_m = tk_mask_low_bytes(tk_lds_load8(raw, pos), len);
+                    const uint32_t rk = (dbg & 2) ? len : tk_probe_mid(T, key_m, len);
+                    if (rk != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k] = rk == TK_RANK_MAX ? 0u : rk;
+                    else {
+                        miss = true;
+                        e = pos | (k << 12) | (1u << 24);
+                    }
+                }
+            } else {
+                const uint32_t q = (r - rows_l - rows_m) * 64u + (uint32_t)lane;
+                if (q < n_s) {
+                    const uint32_t pos = ord_sl[q], k = ordk_sl[q];
+                    const uint32_t len = near_len(pos);
+                    const uint32_t v = __builtin_amdgcn_alignbyte(dwr[(pos >> 2) + 1], dwr[pos >> 2], pos & 3u);
+                    const uint32_t key_s = v & (0xFFFFFFFFu >> (32u - 8u * len));
+                    const uint32_t rk = (dbg & 2) ? len : (short_tab ? tk_probe_short(T, key_s, len) : tk_probe_mid(T, (uint64_t)key_s, len));
+                    if (rk != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k] = rk == TK_RANK_MAX ? 0u : rk;
+                    else {
+                        miss = true;
+                        e = pos | (k << 12);
+                    }
+                }
+            }
+            const uint64_t mm = __ballot(miss);
+            if (miss) mlw[n_mine + (uint32_t)__popcll(mm & ((1ull << lane) - 1ull))] = e;
+            n_mine += (uint32_t)__popcll(mm);
+            TKT(10);
+        }
+        TKT(7);
+        __syncthreads();  // (the lists are reused by the next part; the counts of the entries at the tail are read below)
+        TKT(8);
+    }
+    if (tid == 0 && np) {
+        out.res[run_base + TKF_TAIL_NMISS] = ntail_sh;
+        out.res[run_base + TKF_TAIL_NGAP] = GEN ? ngap_sh : 0u;
+    }
+#else
     // ---- E: enumerate the pieces of the tile (set bits of `bits`, in order) -> plist (aliases the bitmaps)
     // (the prefix sums over the 120 words' counts by ONE wavefront, two words a lane: no block-wide scan with its two barriers -- a tile
     // passes a dozen barriers, and at each the four wavefronts wait for the slowest)
@@ -1159,6 +1565,7 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
         }
     }
     __syncthreads();
+    TKT(4);
     if (dbg & 0x10000) {  // (perf experiments: stop after this phase)
         if (tid == 0) out.tile_np[tile] = 0;
         continue;
@@ -1286,6 +1693,7 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
             }
         }
         __syncthreads();
+        TKT(6);
         const uint32_t n_s = ncls_sh & 2047u, n_m = (ncls_sh >> 11) & 2047u, n_l = ncls_sh >> 22, n_xl = nxl_sh;
         // a piece for the list of F4
         auto not_a_token = [&](bool miss, uint32_t i) {
@@ -1399,7 +1807,9 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
             put_ref(ref != TKF_NONE, k, ref);
             not_a_token(miss && ref == TKF_NONE, i_p);  // (no table, a full neighbourhood, more than TK_GLANE_MAX bytes: F4)
         }
+        TKT(7);
         __syncthreads();
+        TKT(8);
         // F4: what the rows above could not settle (next to nothing: chunks too small for a table, a full neighbourhood of the table, pieces
         // of more than TK_GLANE_MAX bytes): an overflow entry behind the table's (one returning atomic per wavefront that has such pieces).
         const uint32_t n_x = nx_sh;
@@ -1446,6 +1856,7 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
         out.res[run_base + TKF_TAIL_NMISS] = ntail_sh;
         out.res[run_base + TKF_TAIL_NGAP] = GEN ? ngap_sh : 0u;
     }
+#endif
     }  // (!SLOW)
     } while (PERSIST && (item += gridDim.x) < n_items);
 }

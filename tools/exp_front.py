@@ -61,6 +61,12 @@ def main():
            "kernels_sum_ms": round(sum(kern.values()), 3), "tokens": int(nt),
            "front_wgs": core.stat("front_wgs_per_cu"), "pieces": core.last_stats()["pieces"],
            "host": host, "lib": os.environ.get("TIKTOKEN_AMD_LIB", ""), "dbg": os.environ.get("TIKTOKEN_AMD_DEBUG", "")}
+    if core.stat("time_15") or os.environ.get("TKF_TIMING"):  # (a -DTKF_TIMING build: cycles per tile and phase, thread 0's clock at the phase boundaries)
+        core.stat("time_reset")
+        run()
+        torch.cuda.synchronize()
+        tiles = max(core.stat("time_15"), 1)
+        out["cycles_per_tile"] = {str(i): round(core.stat(f"time_{i}") / tiles, 1) for i in range(15)}
     if not args.no_parity:
         cache = f"/tmp/tk_oracle_{args.encoding}_{args.mib}.npz"
         if os.path.exists(cache):

@@ -7,3 +7,4 @@ MIB=${1:-256}
 cd "$(dirname "$0")/.."
 TIKTOKEN_AMD_BENCH_BACKEND=gloo timeout 600 python -m torch.distributed.run --nnodes=1 --nproc-per-node 2 --master-addr 127.0.0.1 --master-port 29517 \
     bench.py --gpus 2 --steps 2 --warmup 1 --mib $MIB
+echo "torchrun rc=$?"
