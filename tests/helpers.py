@@ -312,6 +312,8 @@ def sim_lib():
         L.tks_pretok_bits.argtypes = [vp, vp, u64, vp, u64, vp]
         L.tks_pretok_tiles.restype = u64
         L.tks_pretok_tiles.argtypes = [vp, vp, u64, vp, u64, vp, ctypes.c_uint32, ctypes.c_uint32]
+        L.tks_second_stop_check.restype = u64
+        L.tks_second_stop_check.argtypes = [vp, vp, u64, vp, u64, vp]
         L.tks_runs_mismatches.restype = u64
         L.tks_never_violations.restype = u64
         L.tks_table_stats.argtypes = [vp, vp, vp]
@@ -400,6 +402,14 @@ class HostSim:
         nw = sim_lib().tks_pretok_tiles(self._h, b.ctypes.data, n, doc_off.ctypes.data, len(doc_off) - 1, starts.ctypes.data, tile, left)
         idx = np.flatnonzero(starts[:n])
         return (np.concatenate([idx[1:], [n]]).astype(np.uint64) if n else np.zeros(0, np.uint64)), nw
+
+    def second_stop_check(self, blob: np.ndarray, doc_off: np.ndarray):
+        """The "second stop" rule of the front kernel's phase D against the sequential scanner: (violations, places where it applied)."""
+        n = len(blob)
+        b = np.ascontiguousarray(blob) if n else np.zeros(1, np.uint8)
+        applied = ctypes.c_uint64()
+        bad = sim_lib().tks_second_stop_check(self._h, b.ctypes.data, n, doc_off.ctypes.data, len(doc_off) - 1, ctypes.byref(applied))
+        return int(bad), int(applied.value)
 
     def chunk_check(self, blob: np.ndarray, doc_off: np.ndarray, ss=None, si=None, tile: int = 3840, left: int = 64, win: int = 4096):
         """Phases A-C of tk_k_front (16 bytes per lane, tk_chunk.h) against the per-byte reference: (mismatches, first position, code)."""

@@ -462,6 +462,65 @@ uint64_t tks_pretok_tiles(void* pv, const uint8_t* text_in, uint64_t n, const ui
 }
 
 
+// The "second stop" rule of the front kernel's phase D (tk_chunk.h, tk_chunk_second_stop), checked position by position against the
+// sequential scanner: wherever the rule applies -- a certain start that is a one-byte char of a prefix class, the next byte a letter and an
+// uncertain stop, the stop behind it certain -- the piece that starts there must end at that second stop.  Returns the violations;
+// *applied gets the number of places where the rule applied.
+uint64_t tks_second_stop_check(void* pv, const uint8_t* text_in, uint64_t n, const uint64_t* doc_off, uint64_t n_docs, uint64_t* applied) {
+    Sim* s = (Sim*)pv;
+    const int pat = s->T.pattern;
+    std::vector<uint8_t> text(text_in, text_in + n);
+    text.resize(n + 64, 0);
+    std::vector<uint32_t> brk((n + 31) / 32 + 2, 0);
+    for (uint64_t d = 0; d < n_docs; ++d)
+        if (doc_off[d] < n) brk[doc_off[d] >> 5] |= 1u << (doc_off[d] & 31);
+    std::vector<uint8_t> cls2(n + 80, TK_C_END | 0x80);
+    uint8_t last = TK_C_OT;
+    for (uint64_t i = 0; i < n; ++i) {
+        uint32_t c = tk_class_byte(s->T, text.data(), i, n, brk.data(), nullptr, nullptr);
+        if ((c & 15u) == TK_C_CONT) cls2[i] = (uint8_t)(last | 0x40);
+        else {
+            cls2[i] = (uint8_t)c;
+            last = (uint8_t)(c & 15u);
+        }
+    }
+    PropAcc acc{cls2.data(), text.data(), n};
+    auto is_start = [&](uint64_t i) { return i >= n || !(cls2[i] & 0x40u); };
+    auto certain_at = [&](uint64_t i) -> bool {
+        if (i >= n) return true;
+        uint32_t c = cls2[i];
+        if (c & 0x40u) return false;
+        if (c & 0x80u) return true;
+        if (i == 0) return false;
+        return tk_certain_ctx(s->T, cls2[i - 1] & 15u, c & 15u, text.data(), i);
+    };
+    auto near = [&](uint64_t i) { return (i >= 2 && text[i - 2] == '\'') || (i >= 3 && text[i - 3] == '\''); };
+    auto stop_at = [&](uint64_t i) -> bool {
+        if (i >= n) return true;
+        if (!is_start(i)) return false;
+        if (certain_at(i) || i == 0) return true;
+        const uint32_t a = cls2[i - 1] & 15u, b = cls2[i] & 15u;
+        return !(((tk_never_mask(pat, a) >> b) & 1u) && !near(i));
+    };
+    const uint32_t pc = s->T.pat.generic() ? 0u : tk_second_stop_prefix_classes(pat), lc = tk_second_stop_letter_classes(pat);
+    uint64_t bad = 0, app = 0;
+    for (uint64_t i = 0; i + 1 < n; ++i) {
+        if (!is_start(i) || !is_start(i + 1) || !certain_at(i)) continue;
+        if (!((pc >> (cls2[i] & 15u)) & 1u) || !((lc >> (cls2[i + 1] & 15u)) & 1u)) continue;
+        if ((cls2[i + 1] & 0x80u) || certain_at(i + 1) || !stop_at(i + 1)) continue;
+        uint64_t u2 = i + 2;
+        while (u2 < n && !stop_at(u2)) ++u2;
+        if (!certain_at(u2)) continue;
+        ++app;
+        uint64_t e = tk_piece_end(acc, i, s->T.pat);
+        if (e <= i) e = tk_next_char(acc, i);
+        if (e > n) e = n;
+        if (e != u2) ++bad;
+    }
+    if (applied) *applied = app;
+    return bad;
+}
+
 // Mirror of phases A-C of tk_k_front: the text is classified 16 bytes per "lane" with the functions of tk_chunk.h (table pass,
 // decode pass, final masks, set algebra, certain starts) over every tile's 4096-byte window, and compared position by position
 // with the per-byte reference (tk_class_byte + propagation, tk_certain_start).  ss / si (may be null): special-token bitmaps.

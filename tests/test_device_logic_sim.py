@@ -86,6 +86,33 @@ def test_tile_rule_of_the_front_kernel(sims, name):
     assert walked < len(blob) // 4096  # the walk-back is the exception, not the rule
 
 
+@pytest.mark.parametrize("name", h.ENCODING_NAMES)
+def test_second_stop_rule_of_the_scanners_short_cut(sims, name):
+    """Phase D of tk_k_front decides a piece without a scanner when it starts at a certain start and the next stop is certain -- and (round
+    6) when the start is a one-byte char of a prefix class, the next byte a letter and an uncertain stop, and the stop BEHIND that one is
+    certain: the piece then ends there (tk_chunk.h, tk_chunk_second_stop).  Checked against the sequential scanner wherever the rule
+    applies: every string of up to four class representatives around a prefix char and a letter, 40 000 random adversarial strings, the
+    corpora.  (gpt2 / r50k: the rule never applies.)"""
+    sim = sims[name]
+    alpha = [c for v in REPS.values() for c in v]
+    docs = ["".join(t).encode() for k in (2, 3, 4) for t in itertools.product(alpha, repeat=k)] if name != "gpt2_shaped" else []
+    rng = random.Random(17)
+    docs += ["".join(rng.choice(h.ADV) for _ in range(rng.randint(2, 40))).encode() for _ in range(40000)]
+    docs += ["".join(rng.choice(alpha) for _ in range(rng.randint(5, 12))).encode() for _ in range(40000)]
+    total_applied = 0
+    for i in range(0, len(docs), 4096):
+        blob, off = h.pack(docs[i:i + 4096])
+        bad, applied = sim.second_stop_check(blob, off)
+        assert bad == 0, (name, i)
+        total_applied += applied
+    for mix in (0, 1):
+        blob, off = h.gen_corpus(91 + mix, mix, 2 << 20)
+        bad, applied = sim.second_stop_check(blob, off)
+        assert bad == 0
+        total_applied += applied
+    assert (total_applied > 20000) == (name != "gpt2_shaped"), total_applied
+
+
 REPS = {  # one or two representatives per character class, incl. every contraction letter in both cases
     "NL": ["\n", "\r"], "SP": [" "], "WSO": ["\t", "　"], "LU": ["S", "L", "E", "Z", "ǅ"], "LL": ["s", "l", "e", "ſ", "x", "t"],
     "LC": ["中", "ʰ"], "MK": ["́"], "NU": ["1", "²"], "AP": ["'"], "SL": ["/"], "OT": ["!", "\x1c"],

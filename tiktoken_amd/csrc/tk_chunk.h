@@ -256,6 +256,32 @@ TK_HD uint32_t tk_chunk_never(int pat, const TkSets& s, uint32_t prevc, uint32_t
     return nev & ~near;  // (the end of a contraction is a boundary whatever the classes say)
 }
 
+// The "second stop" rule (round 6).  A piece that starts at a certain start ends at the next stop when that stop is certain (the scanners'
+// short cut, tk_fused.h phase D).  When it is not, one case is still decided without a scanner: the start is a one-byte char of a class
+// the pattern's letter alternative takes as its optional PREFIX (`[^\r\n\p{L}\p{N}]?` of the cl100k / o200k patterns), and the stop is
+// the very next byte, a letter.  Then the piece is the prefix char plus at least one letter (an alternative with the prefix matches
+// whenever a letter follows), so it does not end at that stop: it ends at the stop BEHIND it -- if that one is certain; every piece end is
+// a stop, and there is no other in between.  41 % of the starts the scanners were given on web text (".com", "(x", "\"hello").
+//   o200k : prefix classes SP WSO AP SL OT (no alternative of its own for "'s": the contraction is a suffix), letters LU LL LC MK
+//   cl100k: the same without AP (an apostrophe may start the contraction alternative, which comes first), letters LU LL LC
+//   r50k  : none (its only prefix is a space, and space -> letter is never a stop)
+// The unit tests check the rule against the sequential scanner on adversarial text (tests/test_device_logic_sim.py).
+TK_HD uint32_t tk_second_stop_prefix_classes(int pat) {
+    const uint32_t x = TK_CB(TK_C_SP) | TK_CB(TK_C_WSO) | TK_CB(TK_C_SL) | TK_CB(TK_C_OT);
+    return pat == TK_PAT_O200K ? (x | TK_CB(TK_C_AP)) : (pat == TK_PAT_CL100K ? x : 0u);
+}
+TK_HD uint32_t tk_second_stop_letter_classes(int pat) {
+    return pat == TK_PAT_O200K ? (TK_M_L | TK_CB(TK_C_MK)) : (pat == TK_PAT_CL100K ? TK_M_L : 0u);
+}
+// positions of the chunk that are such a stop: uncertain (`stop_unc`), a letter, and the byte before it a certain start of a prefix class
+// that is a whole char (position 0 of a chunk never qualifies: its predecessor is another lane's)
+TK_HD uint32_t tk_chunk_second_stop(int pat, const TkSets& s, uint32_t start, uint32_t cert, uint32_t stop_unc) {
+    if (pat == TK_PAT_R50K) return 0u;
+    const uint32_t prefix = pat == TK_PAT_O200K ? (s.sp | s.wso | s.ap | s.sl | s.ot) : (s.sp | s.wso | s.sl | s.ot);
+    const uint32_t letter = pat == TK_PAT_O200K ? (s.l | s.mk) : s.l;
+    return ((cert & prefix & start) << 1) & stop_unc & letter & start & 0xFFFFu;
+}
+
 // The same from a table given at run time (generic patterns: cert[a] = class mask, TkTables::cert)
 TK_HD uint32_t tk_chunk_certain_rt(const uint16_t* cm, const TkSets& s, uint32_t start, uint32_t hard, uint32_t prevc) {
     const uint32_t set_of[12] = {0u, s.nl, s.sp, s.wso, s.lu, s.ll, s.lc, s.mk, s.nu, s.ap, s.sl, s.ot};

@@ -861,10 +861,14 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
     ((uint16_t*)certw)[tid] = (uint16_t)cert;
     // The scanners' short cut: between a piece start and the next position at which a piece MAY start there is no boundary.  "May
     // start" = every char start except those whose class pair never has one (tk_chunk_never; generic patterns: every char start).
+    // (round 6) ... and the stops behind which a piece certainly goes on to the NEXT stop (tk_chunk.h, tk_chunk_second_stop): a bitmap of its
+    // own, in the place of one the pattern's scanner does not use (o200k: the letters; cl100k: the upper-case-ish set)
+    constexpr int TKB_QUAL = GEN ? -1 : (PAT == TK_PAT_O200K ? (int)TKB_L : (PAT == TK_PAT_CL100K ? (int)TKB_UP : -1));
     {
         uint32_t stopm = mk.start;
         if (!GEN) stopm &= ~tk_chunk_never(fam, st, prevc, near);
         stop16[tid] = (uint16_t)(stopm | cert);  // (a hard start -- a document begins -- is a start whatever the classes on its two sides)
+        if constexpr (TKB_QUAL >= 0) ((uint16_t*)pool)[TKB_QUAL * (NW * 4) + tid] = (uint16_t)tk_chunk_second_stop(PAT, st, mk.text, cert, stopm & ~cert);
     }
     constexpr uint32_t T0 = TK2_LEFT / 16, T1 = (TK2_LEFT + TK_TILE) / 16;  // chunks [T0, T1) are the tile
     const bool in_tile = tid >= T0 && tid < T1;
@@ -1065,9 +1069,24 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
             const uint64_t cx = (uint64_t)__builtin_amdgcn_alignbit(c1, c0, sh) | ((uint64_t)__builtin_amdgcn_alignbit(c2, c1, sh) << 32);
             const uint64_t gaps = ~x;
             const uint64_t sum = gaps + ((uint64_t)sm << 1);
-            const uint64_t nxt = sum & x;           // the next stop of every start (a start is a stop: no carry passes one)
+            uint64_t nxt = sum & x;                 // the next stop of every start (a start is a stop: no carry passes one)
             if (sum < gaps) needm = 1u << (31 - __clz((int)sm));  // the carry of the last start left the 64 positions: no stop in sight
             uint64_t unc = nxt & ~cx;               // next stops that are not certain
+            if constexpr (TKB_QUAL >= 0) {
+                // ... of which some are known not to end the piece (a prefix char and its letter): the piece ends at the stop behind -- the same
+                // addition once more, from those stops.  One whose next stop is certain is settled; the others stay "not certain", and the
+                // start they are reached from (the last one below: there is no start between the two stops) is evaluated after all.
+                const uint32_t* qw = (const uint32_t*)bm[TKB_QUAL];
+                const uint32_t q0 = qw[wi], q1 = qw[wi + 1], q2 = qw[wi + 2];
+                const uint64_t q = unc & ((uint64_t)__builtin_amdgcn_alignbit(q1, q0, sh) | ((uint64_t)(__builtin_amdgcn_alignbit(q2, q1, sh) & 0x7FFFFFFFu) << 32));  // (not the window's last position: nothing behind it is in sight)
+                if (q) {
+                    const uint64_t sum2 = gaps + (q << 1);
+                    const uint64_t nxt2 = sum2 & x;
+                    unc = (unc & ~q) | (nxt2 & ~cx);
+                    if (sum2 < gaps) unc |= 1ull << (63 - __clzll((long long)q));  // (no stop in sight behind the last of them)
+                    nxt |= nxt2;
+                }
+            }
             while (unc) {
                 const uint32_t u = (uint32_t)__ffsll((unsigned long long)unc) - 1u;
                 unc &= unc - 1ull;

@@ -40,7 +40,9 @@ enum {
 // (TK_CNT_DEFER2: deferred tiles that gave up their walk -- tk_fused.h, TKF_WALK_BUDGET;
 //  TK_CNT_ERR: bits 1, 2 scanner lists of the front kernel; bits 4, 8 the generic pat_str engine -- tk_regex_split.h; TK_CNT_RXPOS: ~position of its first error)
 
+#ifndef TK_MT_BITS
 #define TK_MT_BITS 22   // most slots of the in-call miss table (tk_fused.h); sized by the chunk
+#endif
 #define TK_MT_PROBES 8
 #define TK_MAX_LEVELS 6          // 64-ary min-tree levels of the long-piece merge
 
