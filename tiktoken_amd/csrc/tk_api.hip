@@ -1372,6 +1372,13 @@ extern "C" int tk_encode_batch_device(tk_core* c, const void* d_utf8, uint64_t n
 #define TK_STAGE_BYTES (64ull << 20)
 #define TK_HOST_CHUNK (128ull << 20)
 
+static uint64_t host_chunk_bytes(bool direct) {  // ($TIKTOKEN_AMD_HOST_CHUNK_MIB: experiments)
+    if (const char* e = getenv("TIKTOKEN_AMD_HOST_CHUNK_MIB")) {
+        const long v = atol(e);
+        if (v >= 8 && v <= 2048) return (uint64_t)v << 20;
+    }
+    return direct ? (32ull << 20) : TK_HOST_CHUNK;
+}
 // host threads of the staging copies (text into / ids out of the page-locked buffers): the copy, not the link, bounds the host-buffer
 // entries (round 4: 8 threads, 25-34 GB/s of text; a GPU box gives the container 16 cores); $TIKTOKEN_AMD_COPY_THREADS overrides
 static unsigned copy_threads(unsigned hw) {
@@ -1719,7 +1726,16 @@ static int encode_batch_impl(tk_core* c, const uint8_t* utf8, const uint64_t* do
             HIPCHK(hipEventCreateWithFlags(&c->ev_stage[i], hipEventDisableTiming));
         }
     }
-    const uint64_t n_blocks = (n_bytes + TK_STAGE_BYTES - 1) / TK_STAGE_BYTES;
+    // How the text gets to the device.  Round 6 measured the link on the bench's box (tools/ubench/pcie_rates.hip, profiles/r06_pcie_link.txt):
+    // 57 GB/s either way alone, 48 GB/s each way with both directions busy -- and hipMemcpyAsync straight from PAGEABLE memory at 56.5 GB/s,
+    // the runtime's own staging.  So the default is that copy, in blocks of 64 MiB (smaller ones cost the copy its rate: 28 ms with 16 MiB), and
+    // chunks of 32 MiB: 25 ms per GiB = 0.88 of what the link gives in both directions at once, where the staging buffers of rounds 2-5
+    // (filled by host threads, 64 MiB at a time, chunks of 128 MiB) took 32 ms.  $TIKTOKEN_AMD_H2D_DIRECT=0 brings those back.
+    const bool h2d_direct = !(getenv("TIKTOKEN_AMD_H2D_DIRECT") && atoi(getenv("TIKTOKEN_AMD_H2D_DIRECT")) == 0);
+    uint64_t block_bytes = TK_STAGE_BYTES;
+    if (const char* e = getenv("TIKTOKEN_AMD_H2D_BLOCK_MIB"))  // (experiments; the staging buffers bound it)
+        if (h2d_direct && atol(e) >= 4 && atol(e) <= 1024) block_bytes = (uint64_t)atol(e) << 20;
+    const uint64_t n_blocks = (n_bytes + block_bytes - 1) / block_bytes;
     std::vector<hipEvent_t> ev_block(n_blocks, nullptr);
     for (auto& e : ev_block) HIPCHK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
     auto drop_events = [&]() {
@@ -1736,10 +1752,14 @@ static int encode_batch_impl(tk_core* c, const uint8_t* utf8, const uint64_t* do
         (void)hipSetDevice(dev);
         for (uint64_t b = 0; b < n_blocks; ++b) {
             const int slot = (int)(b & 1);
-            const uint64_t a = b * TK_STAGE_BYTES, len = a + TK_STAGE_BYTES < n_bytes ? TK_STAGE_BYTES : n_bytes - a;
-            if (b >= 2 && hipEventSynchronize(c->ev_stage[slot]) != hipSuccess) h2d_rc = TK_RUNTIME_ERROR;  // the slot's previous DMA is done
-            parallel_memcpy(c->stage[slot], utf8 + a, len, nth);
-            if (hipMemcpyAsync((uint8_t*)c->text.p + a, c->stage[slot], len, hipMemcpyHostToDevice, c->cs_h2d) != hipSuccess) h2d_rc = TK_RUNTIME_ERROR;
+            const uint64_t a = b * block_bytes, len = a + block_bytes < n_bytes ? block_bytes : n_bytes - a;
+            if (h2d_direct) {  // (the runtime's own way from pageable memory: measured at the link's rate on this platform, tools/ubench/pcie_rates.hip)
+                if (hipMemcpyAsync((uint8_t*)c->text.p + a, utf8 + a, len, hipMemcpyHostToDevice, c->cs_h2d) != hipSuccess) h2d_rc = TK_RUNTIME_ERROR;
+            } else {
+                if (b >= 2 && hipEventSynchronize(c->ev_stage[slot]) != hipSuccess) h2d_rc = TK_RUNTIME_ERROR;  // the slot's previous DMA is done
+                parallel_memcpy(c->stage[slot], utf8 + a, len, nth);
+                if (hipMemcpyAsync((uint8_t*)c->text.p + a, c->stage[slot], len, hipMemcpyHostToDevice, c->cs_h2d) != hipSuccess) h2d_rc = TK_RUNTIME_ERROR;
+            }
             (void)hipEventRecord(c->ev_stage[slot], c->cs_h2d);
             (void)hipEventRecord(ev_block[b], c->cs_h2d);
             blocks_sent.store(b + 1, std::memory_order_release);
@@ -1750,7 +1770,7 @@ static int encode_batch_impl(tk_core* c, const uint8_t* utf8, const uint64_t* do
     uint64_t host_cap = 0;  // tokens
     ChunkHooks hooks;
     hooks.before = [&](uint64_t byte_end) -> int {
-        const uint64_t need = (byte_end + TK_STAGE_BYTES - 1) / TK_STAGE_BYTES;  // blocks [0, need) must have been sent
+        const uint64_t need = (byte_end + block_bytes - 1) / block_bytes;  // blocks [0, need) must have been sent
         while (blocks_sent.load(std::memory_order_acquire) < need) std::this_thread::yield();
         if (need) HIPCHK(hipStreamWaitEvent(s, ev_block[need - 1], 0));
         return h2d_rc.load() == TK_OK ? TK_OK : fail(TK_RUNTIME_ERROR, "host-to-device copy failed");
@@ -1776,7 +1796,7 @@ static int encode_batch_impl(tk_core* c, const uint8_t* utf8, const uint64_t* do
         return TK_OK;
     };
     int rc = encode_device_locked(c, s, c->text.as<uint8_t>(), n_bytes, c->doc_off.as<uint64_t>(), doc_off, n_docs, use_special && any, &total,
-                                  TK_HOST_CHUNK, &hooks);
+                                  host_chunk_bytes(h2d_direct), &hooks);
     producer.join();
     hipError_t e = hipStreamSynchronize(c->cs_h2d);
     if (e == hipSuccess) e = hipStreamSynchronize(c->cs_d2h);

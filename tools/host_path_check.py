@@ -19,7 +19,7 @@ d_text = torch.from_numpy(blob).cuda(); d_off = torch.from_numpy(off.view(np.int
 dt, nt, do = core.encode_batch_device(d_text.data_ptr(), n, d_off.data_ptr(), off, nd)
 ref_off = torch.as_tensor(DevArray(do, nd + 1, "<i8"), device="cuda").cpu().numpy().astype(np.uint64)
 ref_tok = torch.as_tensor(DevArray(dt, max(nt, 1), "<i4"), device="cuda")[:nt].cpu().numpy().view(np.uint32)
-for it in range(3):
+for it in range(5):
     t0 = time.perf_counter(); tok, toff = core.encode_batch_packed(blob[:n], off); dt_ = time.perf_counter() - t0
     same = np.array_equal(toff, ref_off) and np.array_equal(tok, ref_tok)
     print(f"run {it}: {dt_*1e3:.1f} ms  tokens {len(tok)} vs {nt}  identical {same}", flush=True)
