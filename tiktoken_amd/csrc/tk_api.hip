@@ -114,7 +114,7 @@ struct tk_core {
     hipEvent_t ev_stage[2] = {nullptr, nullptr};
     TkHostTables H;
     TkTables D;  // device view
-    Buf t_stage1, t_stage2, t_bmp, t_byte_tab, t_short, t_mid, t_dec, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_xl, t_xfilter, t_spec_bytes, t_spec_off, t_spec_id;
+    Buf t_stage1, t_stage2, t_bmp, t_byte_tab, t_short, t_mid, t_dec, t_piece, t_piece_off, t_tok_bytes, t_pair, t_pair2, t_byte_rank, t_xl, t_xfilter, t_spec_bytes, t_spec_off, t_spec_id, t_spec_head;
     uint32_t spec_max_len = 0;
     bool has_rx = false;  // the pat_str runs on the generic engine (tk_regex_kernels.h)
     bool has_rx_fb = false;  // a pat_str of the scanner families, compiled for the generic engine as well: the way out of stretches without certain starts (stage_deferred)
@@ -457,6 +457,20 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
     D.spec_bytes = c->t_spec_bytes.as<uint8_t>();
     D.spec_off = c->t_spec_off.as<uint32_t>();
     D.spec_id = c->t_spec_id.as<uint32_t>();
+    {
+        std::vector<uint32_t> head(4 * (H.spec_id.size() + 1), 0u);
+        for (size_t k = 0; k < H.spec_id.size(); ++k) {
+            const uint32_t o = H.spec_off[k], len = H.spec_off[k + 1] - o;
+            uint64_t h8 = 0;
+            for (uint32_t i = 0; i < len && i < 8u; ++i) h8 |= (uint64_t)H.spec_bytes[o + i] << (8u * i);
+            head[4 * k] = (uint32_t)h8;
+            head[4 * k + 1] = (uint32_t)(h8 >> 32);
+            head[4 * k + 2] = len;
+            head[4 * k + 3] = o;
+        }
+        if ((rc = upload(c->t_spec_head, head.data(), head.size() * 4))) return bail(rc);
+        D.spec_head = c->t_spec_head.as<uint32_t>();
+    }
     D.n_spec = (uint32_t)H.spec_id.size();
     memcpy(D.spec_first, H.spec_first, sizeof D.spec_first);
     D.spec_fb = 0;
@@ -526,7 +540,7 @@ extern "C" void tk_destroy(tk_core* c) {
     (void)hipSetDevice(c->device);
     for (Buf* b : {&c->t_rx_ins, &c->t_rx_sets, &c->t_rx_ranges, &c->t_rx_first, &c->t_rx_s1, &c->t_rx_s2, &c->t_rx_dtrans, &c->t_rx_dascii, &c->t_rx_ds1, &c->t_rx_ds2}) release(*b);
     for (Buf* b : {&c->t_stage1, &c->t_stage2, &c->t_bmp, &c->t_byte_tab, &c->t_short, &c->t_mid, &c->t_dec, &c->d_tok, &c->d_lens, &c->d_bsum, &c->d_tboff, &c->d_bytes, &c->d_bytes_alt, &c->d_boff, &c->t_piece,
-                   &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2, &c->t_byte_rank, &c->t_xl, &c->t_xfilter, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->text, &c->doc_off,
+                   &c->t_piece_off, &c->t_tok_bytes, &c->t_pair, &c->t_pair2, &c->t_byte_rank, &c->t_xl, &c->t_xfilter, &c->t_spec_bytes, &c->t_spec_off, &c->t_spec_id, &c->t_spec_head, &c->text, &c->doc_off,
                    &c->out_tokens, &c->out_tok_off, &c->out_tokens_alt, &c->out_tok_off_alt, &c->allowed, &c->tok_bases})
         release(*b);
     if (c->h_probe) (void)hipHostFree(c->h_probe);

@@ -147,6 +147,8 @@ struct TkTables {
     const uint8_t* spec_bytes;
     const uint32_t* spec_off;  // [n_spec+1]
     const uint32_t* spec_id;   // [n_spec]
+    const uint32_t* spec_head; // [4 * n_spec] {first eight bytes (zero-padded), length, offset}: what tk_special_at asks per special token, in ONE
+                               // load that depends on nothing (offsets, then first byte, then the bytes were a chain of four per token; null on the host)
     uint32_t n_spec;
     uint32_t spec_first[8];  // 256-bit set of first bytes
     uint32_t spec_fb;        // the first bytes once more, packed, when there are at most four of them (n_spec_fb; all the stock encodings: '<')

@@ -193,13 +193,17 @@ __device__ __forceinline__ uint32_t tk_special_at(const TkTables& T, const uint8
     const uint64_t db = docb ? tk_bits64(docb, pos + 1) : 0ull;  // document starts at pos + 1 .. pos + 64
     uint32_t best = 0, bi = 0;
     for (uint32_t k = 0; k < T.n_spec; ++k) {
+        // (round 6: a token's first eight bytes, length and offset in one load that depends on nothing -- the loads of all tokens are in flight
+        // together; a candidate that is no special token, "<|x", leaves after it.  Offsets, first byte and bytes were four dependent loads per token.)
+        const uint4 hd = ((const uint4*)T.spec_head)[k];
+        const uint32_t o = hd.w, len = hd.z;
+        if (len <= best || pos + len > n) continue;
+        if (tk_mask_low_bytes(tw[0] ^ (((uint64_t)hd.y << 32) | hd.x), len < 8u ? len : 8u) != 0ull) continue;
         if (allowed && !allowed[k]) continue;
-        uint32_t o = T.spec_off[k], len = T.spec_off[k + 1] - o;
-        if (len <= best || pos + len > n || T.spec_bytes[o] != b0) continue;
         bool ok = true;
         if (len <= 32u) {
 #pragma unroll
-            for (int i = 0; i < 4; ++i)
+            for (int i = 1; i < 4; ++i)
                 if (8u * i < len) ok = ok && tk_mask_low_bytes(tw[i] ^ tk_load8(T.spec_bytes, (uint64_t)o + 8u * i), len - 8u * i) == 0ull;
             ok = ok && (db & ((1ull << (len - 1u)) - 1ull)) == 0ull;
         } else {
@@ -222,6 +226,7 @@ __global__ void tk_k_spec_cand(TkTables T, const uint8_t* __restrict__ text, uin
                                const uint32_t* __restrict__ docb, uint32_t* __restrict__ cand) {
     for (uint64_t p0 = (blockIdx.x * (uint64_t)blockDim.x + threadIdx.x) * 16; p0 < n; p0 += (uint64_t)gridDim.x * blockDim.x * 16) {
         const uint4 v = *(const uint4*)(text + p0);  // (text is readable 64 bytes past n)
+        const uint32_t nxt = *(const uint32_t*)(text + p0 + 16) & 0xFFu;  // (the byte behind the sixteen, asked for together with them: inside `if (hits)` it was a second trip for every wavefront with a '<')
         const uint32_t w[4] = {v.x, v.y, v.z, v.w};
         uint32_t hits = 0;
         if (T.n_spec_fb <= 4u) {
@@ -243,7 +248,6 @@ __global__ void tk_k_spec_cand(TkTables T, const uint8_t* __restrict__ text, uin
             }
         }
         if (hits) {  // the byte behind a hit must be some special token's second byte ("<" is common in web text, "<|" is not)
-            const uint32_t nxt = text[p0 + 16];
             uint32_t keep = 0;
             for (uint32_t m = hits; m; m &= m - 1) {
                 const uint32_t k = (uint32_t)__ffs((int)m) - 1u;
@@ -319,7 +323,12 @@ __global__ void tk_k_spec_resolve(TkTables T, const uint8_t* __restrict__ text, 
         uint32_t len = tk_special_at(T, text, pos, n, allowed, docb, &idx);
         atomicOr(&spec_start[pos >> 5], 1u << (pos & 31));
         atomicOr(&brk[pos >> 5], 1u << (pos & 31));
-        for (uint64_t j = pos + 1; j < pos + len; ++j) atomicOr(&spec_in[j >> 5], 1u << (j & 31));
+        for (uint64_t a = pos + 1, b = pos + len; a < b;) {  // the token's interior, a word of the bitmap at a time
+            const uint64_t we = (a | 31u) + 1u, hi = we < b ? we : b;
+            const uint32_t cnt = (uint32_t)(hi - a);
+            atomicOr(&spec_in[a >> 5], (cnt >= 32u ? 0xFFFFFFFFu : ((1u << cnt) - 1u)) << (a & 31u));
+            a = hi;
+        }
         if (pos + len < n) atomicOr(&brk[(pos + len) >> 5], 1u << ((pos + len) & 31));
     }
 }
