@@ -600,7 +600,8 @@ __device__ __forceinline__ bool tk_equal_lds_text(const uint8_t* raw, uint32_t o
 #define TKF_OCC 8
 #endif
 #ifndef TKF_SLOW_OCC
-#define TKF_SLOW_OCC 4  // workgroups per CU of the deferred-tile variant (its grid: tk_api.hip, stage_deferred)
+#define TKF_SLOW_OCC 3  // workgroups per CU of the deferred-tile variant (its grid: tk_api.hip, stage_deferred).  Round 6, on one box (tools/gpu_slowocc.sh):
+                        // 3 against 4 -- C2 78.5 / 77.0 GB/s, C5 its kernel 0.168 / 0.188 ms, C3 0.40 / 0.38 ms (within the noise of the box)
 #endif
 #ifndef TKF_CLAIM_SPIN
 #define TKF_CLAIM_SPIN 8  // looks a duplicate takes at a slot whose claimant has not written its words yet (see `claim`)
