@@ -107,6 +107,31 @@ int main(int argc, char** argv) {
         }
         wave_iters_dense += (chains.size() + tile_unc + 63) / 64;
     }
+    // why tiles are deferred to the workgroup-wide scanner: (a) no certain start in the 128 bytes of left context while the tile's first char is not one;
+    // (b) a piece that starts in the tile (or covers its start) ends more than 128 bytes behind the tile's end
+    {
+        uint64_t walk = 0, leave = 0, both = 0;
+        std::vector<uint8_t> is_piece_start(n + 1, 0);
+        for (uint64_t qq = 0; qq < n;) { is_piece_start[qq] = 1; uint64_t e = tk_piece_end(acc, qq, pat); if (e <= qq) e = tk_next_char(acc, qq); qq = e; }
+        for (uint64_t t0 = TILE; t0 + TILE <= n; t0 += TILE) {
+            uint64_t f = t0;
+            while (f < t0 + TILE && !is_start(f)) ++f;
+            bool w = false, l = false;
+            if (!certain_at(f)) {
+                w = true;
+                for (uint64_t j = t0 - 1; j + 128 > t0 && j > 0; --j)
+                    if (certain_at(j)) { w = false; break; }
+            }
+            // the last piece that starts before the tile's end: where does it end?
+            uint64_t ls = t0 + TILE - 1;
+            while (ls > t0 && !is_piece_start[ls]) --ls;
+            uint64_t e = tk_piece_end(acc, ls, pat);
+            if (e > t0 + TILE + 128 - 8) l = true;
+            walk += w; leave += l; both += w && l;
+        }
+        printf("deferred tiles (of %llu): no certain start in the left context %.2f %%, last piece leaves the window %.2f %%, both %.2f %%\n", (unsigned long long)tiles,
+               100.0 * walk / tiles, 100.0 * leave / tiles, 100.0 * both / tiles);
+    }
     // pieces
     uint64_t q = 0;
     while (q < tiles * TILE) { uint64_t e = tk_piece_end(acc, q, pat); if (e <= q) e = tk_next_char(acc, q); ++pieces; q = e; }
