@@ -606,7 +606,7 @@ static void launch_front(int pattern, bool spec, dim3 grid, hipStream_t s, A... 
 
 // exclusive prefix sum of a uint32 array in place, total -> total_out[0]
 static int scan_u32(tk_core* c, WorkSet& w, hipStream_t s, uint32_t* a, uint64_t n, uint64_t* total_out) {
-    if (n <= 8 * (uint64_t)TK_SCAN_BLOCK) {  // (one workgroup walks up to 32 Ki values in ~15 us: cheaper than three launches)
+    if (n <= 2 * (uint64_t)TK_SCAN_BLOCK) {  // (one workgroup walks 8 Ki values in ~7 us: cheaper than three launches of 6-8 us each; 17.5 Ki -- the tiles of 64 MiB -- took it 27 us)
         TRY(timed(c, s, "tk_k_scan_small", [&] { hipLaunchKernelGGL(tk_k_scan_small, dim3(1), dim3(TK_SCAN_THREADS), 0, s, a, n, total_out); }));
         return TK_OK;
     }
@@ -2668,7 +2668,7 @@ extern "C" uint64_t tk_stat(tk_core* c, const char* name) {
     if (k == "chunk_bytes") return c->chunk_bytes;
 #ifdef TKF_TIMING
     if (k.rfind("time_", 0) == 0) {  // (experiments: tk_fused.h, TKT)
-        static unsigned long long acc[1024 * 16];
+        static unsigned long long acc[2 * 1024 * 16];
         (void)hipSetDevice(c->device);
         (void)hipDeviceSynchronize();
         if (k == "time_reset") {
@@ -2677,9 +2677,10 @@ extern "C" uint64_t tk_stat(tk_core* c, const char* name) {
             return 0;
         }
         (void)hipMemcpyFromSymbol(acc, HIP_SYMBOL(tk_time_acc), sizeof(acc));
-        const int i = atoi(k.c_str() + 5);
+        const bool starts = k.rfind("time_s", 0) == 0;  // ("time_s<i>": the deferred-tile instance)
+        const int i = atoi(k.c_str() + (starts ? 6 : 5));
         unsigned long long sum = 0;
-        for (int b = 0; b < 1024 && i >= 0 && i < 16; ++b) sum += acc[b * 16 + i];
+        for (int b = 0; b < 1024 && i >= 0 && i < 16; ++b) sum += acc[(starts ? 16384 : 0) + b * 16 + i];
         return sum;
     }
 #endif

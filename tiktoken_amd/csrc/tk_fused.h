@@ -613,12 +613,12 @@ __device__ __forceinline__ bool tk_equal_lds_text(const uint8_t* raw, uint32_t o
 // boundaries of the one-tile-per-workgroup instance and adds the differences up in tk_time_acc (read and reset through tk_stat "time_<i>" /
 // "time_reset"); slot 15 counts the tiles.
 #ifdef TKF_TIMING
-__device__ unsigned long long tk_time_acc[1024 * 16];  // (spread over 1024 lines by workgroup: same-address atomics would be what is measured)
+__device__ unsigned long long tk_time_acc[2 * 1024 * 16];  // (spread over 1024 lines by workgroup: same-address atomics would be what is measured)
 #define TKT(i)                                                                  \
     do {                                                                        \
-        if (MODE == TKF_MODE_TILE && tid == 0) {                                \
+        if ((MODE == TKF_MODE_TILE || MODE == TKF_MODE_STARTS) && tid == 0) {   \
             const unsigned long long tkt_now = __builtin_readcyclecounter();    \
-            atomicAdd(&tk_time_acc[(blockIdx.x & 1023u) * 16u + i], tkt_now - tkt_prev); \
+            atomicAdd(&tk_time_acc[(MODE == TKF_MODE_STARTS ? 16384u : 0u) + (blockIdx.x & 1023u) * 16u + i], tkt_now - tkt_prev); \
             tkt_prev = tkt_now;                                                 \
         }                                                                       \
     } while (0)
@@ -678,13 +678,33 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
     constexpr bool PERSIST = SLOW;
     const uint32_t n_items = SLOW ? out.counters[(dbg & TKF_DBG_SECOND) ? TK_CNT_DEFER2 : TK_CNT_DEFER] : gridDim.x;
     if (PERSIST && item >= n_items) return;
+    // (round 6) The deferred tiles differ a lot -- a walk back through a megabyte of one class, or nothing of the kind: 30 000 to 400 000 cycles -- and
+    // there are few of them (0.75 % of the tiles of web text: 2.7 per workgroup of this grid).  With the stride of the grid the kernel lasted as long as
+    // the workgroup with the three dearest; now a workgroup takes its first tile by its index and every further one from a counter.
+    __shared__ uint32_t next_item_sh;
+    auto next_item = [&]() -> bool {
+        __syncthreads();
+        if (tid == 0) next_item_sh = gridDim.x + atomicAdd(&out.counters[TK_CNT_SLOWQ + ((dbg & TKF_DBG_SECOND) ? 1 : 0)], 1u);
+        __syncthreads();
+        item = next_item_sh;
+        return item < n_items;
+    };
     // (the rest of the deferred tiles where the host has not read their number: a grid of one workgroup per tile of the chunk, the list's length decides)
     if (GIVEN && item >= out.counters[TK_CNT_DEFER]) return;
     do {
     if (PERSIST && item != blockIdx.x) __syncthreads();  // (the shared arrays are reused by the next tile)
+#ifdef TKF_TIMING
+    if (MODE == TKF_MODE_STARTS && tid == 0) {
+        atomicAdd(&tk_time_acc[16384u + (blockIdx.x & 1023u) * 16u + 15u], 1ull);
+        tkt_prev = __builtin_readcyclecounter();
+    }
+#endif
     const uint64_t tile = (SLOW || GIVEN) ? (uint64_t)deferred[item] : (uint64_t)item;
     auto defer_tile = [&]() {
         if (tid == 0) deferred[atomicAdd(&out.counters[TK_CNT_DEFER], 1u)] = (uint32_t)tile;
+#ifdef TKF_TIMING
+        if (tid == 0) atomicAdd(&tk_time_acc[(blockIdx.x & 1023u) * 16u + 14u], need_walk ? 1ull : (1ull << 32));  // (experiments: why tiles are deferred -- low word: no certain start in the left context; high word: a piece leaves the window)
+#endif
     };
     const uint64_t tile_start = tile * TK_TILE;
     const uint64_t tile_end = tile_start + TK_TILE < n ? tile_start + TK_TILE : n;
@@ -1045,6 +1065,7 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
             if (!covered) coop_chain(p0);
         }
     }
+    TKT(10);  // (deferred-tile instance: the walk back and the chain towards the tile)
     if (SLOW && gave_up) {  // on the second list: the tile runs again when the generic engine has split the chunk (tk_api.hip, stage_deferred)
         if (tid == 0) deferred[(n + TK_TILE - 1) / TK_TILE + 2 + atomicAdd(&out.counters[TK_CNT_DEFER2], 1u)] = (uint32_t)tile;
         continue;
@@ -1878,7 +1899,7 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
     }
 #endif
     }  // (!SLOW)
-    } while (PERSIST && (item += gridDim.x) < n_items);
+    } while (PERSIST && next_item());
 }
 
 // The distinct missed pieces -- the claimed slots of the miss table and the overflow entries behind them (TkMissData) -- have to be

@@ -32,7 +32,7 @@ __device__ __forceinline__ int tk_bin_of(uint32_t len) {
 enum {
     TK_CNT_B = 0, TK_CNT_C = 1, TK_CNT_CBYTES = 2, TK_CNT_CLEVELS = 3, TK_CNT_DUP = 4, TK_CNT_COLL = 5, TK_CNT_ERR = 6, TK_CNT_DEFER = 7,
     TK_CNT_BIN0 = 8,                      // [TK_NBIN] pieces per length bin (tk_k_binfill)
-    TK_CNT_RXPOS = 8 + TK_NBIN + 1, TK_CNT_DEFER2 = 8 + TK_NBIN + 4,
+    TK_CNT_RXPOS = 8 + TK_NBIN + 1, TK_CNT_SLOWQ = 8 + TK_NBIN + 2 /* and + 3: the deferred-tile instance's work counters (first list, second list) */, TK_CNT_DEFER2 = 8 + TK_NBIN + 4,
     TK_CNT_OVF = 8 + TK_NBIN + 5,         // overflow entries of the miss data asked for (may exceed the capacity: tk_fused.h, TkMissData)
     TK_CNT_BOFF0 = 8 + TK_NBIN + 6,       // [TK_NBIN] start of each bin's list in listB (tk_k_binfill)
     TK_CNT_N = 8 + 2 * TK_NBIN + 6

@@ -66,7 +66,11 @@ def main():
         run()
         torch.cuda.synchronize()
         tiles = max(core.stat("time_15"), 1)
-        out["cycles_per_tile"] = {str(i): round(core.stat(f"time_{i}") / tiles, 1) for i in range(15)}
+        out["cycles_per_tile"] = {str(i): round(core.stat(f"time_{i}") / tiles, 1) for i in range(14)}
+        ts = max(core.stat("time_s15"), 1)
+        out["deferred_tiles"], out["cycles_per_deferred_tile"] = ts, {str(i): round(core.stat(f"time_s{i}") / ts, 1) for i in range(14)}
+        d = core.stat("time_14")
+        out["tiles"], out["deferred_no_certain_start_in_left_context"], out["deferred_piece_leaves_window"] = tiles, d & 0xFFFFFFFF, d >> 32
     if not args.no_parity:
         cache = f"/tmp/tk_oracle_{args.encoding}_{args.mib}.npz"
         if os.path.exists(cache):
