@@ -24,10 +24,14 @@
 // tile (128 bytes of left context, else the tile is deferred to the workgroup-wide scanner), record only boundaries
 // inside the tile and stop at its end.  Nothing crosses tiles, so tiles are fully independent.
 //
-// Two hardware facts shape the code (measured): tk_k_front is bound by vector issue (a wave64 VALU
-// instruction occupies a SIMD16 for four cycles; 82 % of the issue slots busy), so the classification loop is written
-// with integer flags instead of short-circuit control flow; and same-address returning atomics run at only
-// 10..130 M/s on this multi-XCD part, so nothing on the path allocates through a global counter.
+// Three measured facts shape the code: (1) tk_k_front runs at the hardware's eight wavefronts per SIMD and its time is the
+// time a workgroup needs for its tile -- 80 000 cycles, of which its own vector instructions are a ninth; the rest is waiting for its turn
+// on the SIMD (eight wavefronts share it, the vector ALU is busy 80 % of the time) and for memory.  What shortens it is fewer
+// instructions ON THE LONGEST WAVEFRONT'S PATH of every phase and fewer dependent memory round trips (-DTKF_TIMING: cycles per phase,
+// profiles/r06_front_cycles.txt): an instruction moved onto one wavefront while three wait at a barrier is not saved.  (2) The classification
+// loop is written with integer flags instead of short-circuit control flow (a wave64 VALU instruction occupies its SIMD for four cycles
+// whatever the lanes do).  (3) Same-address returning atomics run at only 10..130 M/s on this multi-XCD part, so nothing on the path
+// allocates through a global counter.
 #pragma once
 #include <type_traits>
 
@@ -63,15 +67,8 @@
 #define TKF_MODE_TILE 0
 #define TKF_MODE_STARTS 1
 #define TKF_MODE_GIVEN 2
-#ifndef TKF_EF
-#define TKF_EF 1  // phases E / F of round 6: class lists from the start bitmap by bit operations, the pieces that are not tokens claimed in dense rows (0: round 5's form)
-#endif
-#if TKF_EF
 #define TKF_BATCH 896  // pieces per part of a tile in the front kernel's phase F (the class lists hold 1024 entries)
 #define TKF_BL 14      // ... = the 28 bitmap words = 896 positions of this many lanes of phase E, when a tile has more pieces than that
-#else
-#define TKF_BATCH 960  // pieces per probe batch of the front kernel (the class lists hold 1024 entries, their packed counter 1023)
-#endif
 #define TKF_CAP 4096  // piece ids per tile: pid = tile * TKF_CAP + k (a 4096-byte tile starts at most 4096 pieces)
 // The tail of a tile's run of result words holds, from the back: the number of its pieces that are not tokens (TKF_TAIL_NMISS), the number
 // of its gap chars (TKF_TAIL_NGAP), then the entries of the pieces that are not tokens once more, in no particular order -- what the counting
@@ -606,9 +603,6 @@ __device__ __forceinline__ bool tk_equal_lds_text(const uint8_t* raw, uint32_t o
 #ifndef TKF_CLAIM_SPIN
 #define TKF_CLAIM_SPIN 8  // looks a duplicate takes at a slot whose claimant has not written its words yet (see `claim`)
 #endif
-#ifndef TKF_ROWS
-#define TKF_ROWS 1  // phase F: one length class per row of 64 pieces (0: the three classes side by side in every lane)
-#endif
 // Experiments only (-DTKF_TIMING, tools/build_variant.sh): where a workgroup's time per tile goes.  Thread 0 reads the shader clock at the phase
 // boundaries of the one-tile-per-workgroup instance and adds the differences up in tk_time_acc (read and reset through tk_stat "time_<i>" /
 // "time_reset"); slot 15 counts the tiles.
@@ -645,7 +639,7 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
     __shared__ uint32_t certw[TK2_WIN / 32];                                         // certain starts (hard starts included)
     __shared__ uint32_t bits[TK_TILE / 32];
     __shared__ uint8_t lastc_own[256];
-    __shared__ uint32_t np_sh, need_walk, last_end_sh, ncls_sh, nx_sh, ncont_sh, ngap_sh;
+    __shared__ uint32_t np_sh, need_walk, last_end_sh, ncont_sh, ngap_sh;
     __shared__ __attribute__((aligned(8))) uint16_t contl_own[SLOW ? TKF_CONT_CAP : 4], stop_own[SLOW ? 256 : 4];  // (read as 32-bit words)
     // second window of the deferred-tile variant: a stretch of text left of the tile, walked by tk_coop_window_walk
     __shared__ __attribute__((aligned(16))) uint8_t w2_raw[SLOW ? TK2_WIN + 16 : 16];
@@ -658,8 +652,6 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
     __shared__ uint32_t brkw[TK2_WIN / 32 + 1];
     __shared__ uint32_t scan_sh[8];
     uint64_t(*bm)[NW] = (uint64_t(*)[NW])pool;
-    uint16_t* plist = (uint16_t*)pool;  // valid after the scanners are done
-    uint32_t* woff = certw;             // (phase E; the certain-start bitmap is dead by then)
     uint8_t* lastc = lastc_own;
     // From phase C on the byte table is dead in the one-tile-per-workgroup variant: its 2 KiB hold the "stop" bitmap of the scanners'
     // short cut (256 halfwords) and the continuation list; the deferred-tile variant still classifies text with it (tk_coop_chunk).
@@ -1194,7 +1186,6 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
         if (tid == 0) out.tile_np[tile] = last_end_sh;
         continue;
     } else {
-#if TKF_EF
     // ---- E (round 6): the tile's pieces by length class, straight from the start bitmap.  Rounds 2-5 wrote a list of piece starts (a
     // lane per bitmap word, a store per set bit) and then classified every piece from it -- two reads of the list, four ballots and
     // their prefix counts per row of 256 pieces: 1240 of the kernel's 8200 vector instructions per tile.  Here ONE wavefront (the other three
@@ -1563,341 +1554,6 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
         out.res[run_base + TKF_TAIL_NMISS] = ntail_sh;
         out.res[run_base + TKF_TAIL_NGAP] = GEN ? ngap_sh : 0u;
     }
-#else
-    // ---- E: enumerate the pieces of the tile (set bits of `bits`, in order) -> plist (aliases the bitmaps)
-    // (the prefix sums over the 120 words' counts by ONE wavefront, two words a lane: no block-wide scan with its two barriers -- a tile
-    // passes a dozen barriers, and at each the four wavefronts wait for the slowest)
-    if (wid == 0) {
-        const uint32_t i0 = 2u * (uint32_t)lane, i1 = i0 + 1u;
-        const uint32_t c0 = i0 < (uint32_t)TK_TILE / 32u ? (uint32_t)__popc(bits[i0]) : 0u, c1 = i1 < (uint32_t)TK_TILE / 32u ? (uint32_t)__popc(bits[i1]) : 0u;
-        const uint32_t inc = tk_wave_scan_u32(c0 + c1, lane);
-        if (i0 < (uint32_t)TK_TILE / 32u) {  // (TK_TILE / 32 is even)
-            woff[i0] = inc - c0 - c1;
-            woff[i1] = inc - c1;
-        }
-        if (lane == 63) {
-            np_sh = inc;
-            out.tile_np[tile] = inc;
-        }
-    }
-    __syncthreads();
-    if (tid == 0) {  // (counters of phase F: everybody has left the scanners; the barrier at the end of this phase stands before their first use)
-        ncls_sh = 0;
-        nx_sh = 0;
-        nslow_sh = 0;
-        ncont_sh = 0;
-        if (GEN) ngap_sh = 0;
-    }
-    const uint32_t np = np_sh, run_base = (uint32_t)tile * TKF_CAP;
-    if (tid < TK_TILE / 32) {
-        uint32_t v = bits[tid], o = woff[tid];
-        while (v) {
-            const uint32_t b = __ffs((int)v) - 1;
-            v &= v - 1;
-            plist[o++] = (uint16_t)(TK2_LEFT + tid * 32 + b);
-        }
-        const uint64_t wgp = tile_start / 32 + tid;
-        if (wgp * 32 < n) out.starts[wgp] = bits[tid];
-    }
-    if constexpr (SPEC) {  // starts of special tokens in the window, for phase F (the break bitmap is dead since phase C)
-        if (tid < TK2_WIN / 32) {
-            const int64_t wgp = base + (int64_t)tid * 32;
-            brkw[tid] = (wgp >= 0 && (uint64_t)wgp < n) ? ss[wgp >> 5] : 0u;
-        }
-    }
-    __syncthreads();
-    TKT(4);
-    if (dbg & 0x10000) {  // (perf experiments: stop after this phase)
-        if (tid == 0) out.tile_np[tile] = 0;
-        continue;
-    }
-    // ---- F: whole-piece probe (src/lib.rs:367).  Pieces are first sorted by length class into LDS lists -- short (<= 4 bytes),
-    // mid (5..8), long (9..TK_XL_MAX) -- so that every wavefront runs ONE probe path with all lanes busy.  Round 5: the long class --
-    // a fifth of the pieces of web text, three in five of them not tokens, three quarters of all the pieces that are not -- is looked up
-    // by IDENTITY (tk_common.h, tk_ident: the bytes themselves in three words), and the same identity and hash key the in-call table of
-    // the pieces that are not tokens: a lane fetches the vocabulary's slot and the in-call table's slot TOGETHER and settles the piece
-    // there and then -- one memory round trip where there were a hash over all the bytes, a probe, a verification in the token blob
-    // (dependent loads), then a barrier, the hash once more, the in-call table, and a comparison with the claimant's text (dependent
-    // loads again).  Pieces of more than TK_XL_MAX bytes (2 % of the pieces, next to none of them tokens) go to the in-call table without
-    // a look at the vocabulary: whether such a piece is a token is asked ONCE per distinct piece, when the entries are listed for the merge
-    // kernels (tk_miss_bin).  What is left for the list of pieces that are not tokens (`ord_x`, F4): the short and mid ones, those long ones.
-    const uint32_t last_end = last_end_sh;
-    uint16_t* ord_sl = (uint16_t*)btab;        // [1024] short pieces from the front, long ones from the back (the byte table is dead)
-    uint16_t* ord_m = (uint16_t*)planes;       // [1024] mid pieces (the planes are dead)
-    uint16_t* ord_x = (uint16_t*)(pool + TK_TILE * 2);  // [1024] pieces that are not tokens (behind the piece list)
-    const uint32_t* dwr = (const uint32_t*)raw;
-    const bool short_tab = T.short_tab != nullptr;
-    uint32_t& ntail_sh = ncont_sh;  // pieces of the tile that are not tokens, so far = entries at the tail of its run (the scanners' counter is dead; zeroed in phase E)
-    // A piece that is not a token, by its identity (w0, w1, w2; kk = tk_ident_hash): claim a slot of the in-call table (first occurrence:
-    // the slot's entry gets the piece, the merge kernels will find it there) or find it claimed by IDENTICAL bytes; `k0` / `k1` = the two
-    // halves of slot i, which the caller has loaded.  Returns the slot, or TKF_NONE when the neighbourhood is full.  Slots are written
-    // once, so a cached load can only be stale towards "empty" / "not written yet", where the atomic (the load at the memory side) decides.
-    auto claim = [&](uint64_t w0, uint64_t w1, uint64_t w2, unsigned long long kk, bool exact, bool in_lds, uint32_t s_loc, uint64_t gs, uint32_t len,
-                     uint32_t i, ulonglong2 k0, ulonglong2 k1) -> uint32_t {
-        for (int p = 0;;) {
-            unsigned long long cur = k0.x;
-            if (cur == TK_EMPTY_KEY) cur = atomicCAS(&mt[i].key, TK_EMPTY_KEY, kk);
-            if (cur == TK_EMPTY_KEY) {  // claimed: this occurrence is the one that gets merged
-                __hip_atomic_store(&mt[i].w0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&mt[i].w1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                __hip_atomic_store(&mt[i].w2, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                *(uint2*)&out.data.tab[i].start = make_uint2((uint32_t)gs, len);
-                return i;
-            }
-            if (cur == kk) {
-                unsigned long long a0 = k0.y, a1 = k1.x, a2 = k1.y;
-                if (a2 == TK_EMPTY_KEY || a0 == TK_EMPTY_KEY || a1 == TK_EMPTY_KEY) {  // (a line cached before the claimant had written: once more, at the memory side)
-                    // The claimant writes its words right behind its compare-and-swap: whoever loses that race by a few hundred nanoseconds --
-                    // every tile of a text that repeats itself reaches its first missed piece at the same moment -- would find them empty, take
-                    // the piece for another one and claim the next slot for the same bytes (exact, but a merge per slot, and a full
-                    // neighbourhood sends the piece to the overflow entries).  So it looks again a few times (bounded: never a dead lock).
-                    for (int spin = 0;; ++spin) {
-                        a0 = __hip_atomic_load(&mt[i].w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        a1 = __hip_atomic_load(&mt[i].w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        a2 = __hip_atomic_load(&mt[i].w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-                        if ((a2 != TK_EMPTY_KEY && a0 != TK_EMPTY_KEY && a1 != TK_EMPTY_KEY) || spin >= TKF_CLAIM_SPIN) break;
-                        __builtin_amdgcn_s_sleep(2);
-                    }
-                }
-                bool same = a0 == w0 && a1 == w1 && a2 != TK_EMPTY_KEY && (exact ? a2 == w2 : (a2 >> 32) == (w2 >> 32));
-                if (same && !exact)
-                    same = in_lds ? tk_equal_lds_text(raw, s_loc + 8u, text, (uint64_t)(uint32_t)a2 + 8u, len - 16u)  // (w0 and w1 are the first and the last eight bytes)
-                                  : tk_equal_bytes(text, gs, text, (uint32_t)a2, len);
-                if (same) return i;
-            }
-            if (++p == TK_MT_PROBES) return TKF_NONE;
-            i = (i + 1) & mt_mask;
-            k0 = *(const ulonglong2*)&mt[i].key;
-            k1 = *(const ulonglong2*)&mt[i].w1;
-        }
-    };
-    // the result of a piece that is not a token: its word, and its entry once more at the tail of the run (one LDS atomic per wavefront)
-    auto put_ref = [&](bool on, uint32_t k, uint32_t ref) {
-        const uint64_t m = __ballot(on);
-        if (m) {
-            uint32_t at = 0;
-            const int leader = __ffsll((unsigned long long)m) - 1;
-            if (lane == leader) at = atomicAdd(&ntail_sh, (uint32_t)__popcll(m));
-            at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-            if (on) {
-                out.res[run_base + k] = ref != TKF_NONE ? (TK_RES_FLAG | ref) : 0u;
-                out.res[run_base + TKF_TAIL_REFS - at] = ref;  // (TKF_NONE = 0xFFFFFFFF: counts as the one token 0 the result word holds; the batch is repeated with more room)
-            }
-        }
-    };
-    uint32_t& nxl_sh = nslow_sh;  // pieces of more than TK_XL_MAX bytes in the batch (the counter of the pieces that left the window is dead)
-    for (uint32_t kb = 0; kb < np; kb += TKF_BATCH) {
-        const uint32_t nb = np - kb < TKF_BATCH ? np - kb : (uint32_t)TKF_BATCH;
-        if (kb) {  // (the first batch's counters were zeroed in phase E)
-            if (tid == 0) {
-                ncls_sh = 0;
-                nx_sh = 0;
-                nxl_sh = 0;
-            }
-            __syncthreads();
-        }
-        // F0: length class of every piece of the batch -> lists (one packed LDS counter: short | mid << 11 | long << 22; the pieces of more
-        // than TK_XL_MAX bytes, a dozen per tile, have a counter of their own)
-        for (uint32_t i0 = 0; i0 < nb; i0 += 256) {
-            const uint32_t i = i0 + tid;
-            uint32_t cls = 3;  // 0 short, 1 mid, 2 long, 3 none, 4 longer than TK_XL_MAX
-            if (i < nb) {
-                const uint32_t k = kb + i;
-                const uint32_t s_loc = plist[k], e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
-                const uint32_t len = e_loc - s_loc;
-                cls = len <= 4u ? 0u : (len <= 8u ? 1u : (len <= TK_XL_MAX ? 2u : 4u));
-                if (SPEC && ((brkw[s_loc >> 5] >> (s_loc & 31u)) & 1u)) {  // a special token: its id (src/lib.rs:426-434)
-                    out.res[run_base + k] = tk_special_id(T, text, (uint64_t)(base + s_loc), len);
-                    cls = 3;
-                } else if (GEN && gapb && ((gapb[(uint64_t)(base + s_loc) >> 5] >> ((uint32_t)(base + s_loc) & 31u)) & 1u)) {  // a gap char: no token
-                    // (read from global memory per piece: only a pat_str of the generic engine has the bitmap, and LDS is what this kernel lacks)
-                    out.res[run_base + k] = TK_RES_GAP;
-                    atomicAdd(&ngap_sh, 1u);  // (LDS; gap chars are rare)
-                    cls = 3;
-                }
-            }
-            const uint64_t m0 = __ballot(cls == 0u), m1 = __ballot(cls == 1u), m2 = __ballot(cls == 2u), m4 = __ballot(cls == 4u);
-            const uint32_t c0 = (uint32_t)__popcll(m0), c1 = (uint32_t)__popcll(m1), c2 = (uint32_t)__popcll(m2);
-            uint32_t at = 0, at4 = 0;
-            if (lane == 0) {
-                at = atomicAdd(&ncls_sh, c0 | (c1 << 11) | (c2 << 22));
-                if (m4) at4 = atomicAdd(&nxl_sh, (uint32_t)__popcll(m4));
-            }
-            at = (uint32_t)__shfl((int)at, 0, 64);
-            const uint64_t below = (1ull << lane) - 1ull;
-            if (cls == 0u) ord_sl[(at & 2047u) + (uint32_t)__popcll(m0 & below)] = (uint16_t)i;
-            else if (cls == 1u) ord_m[((at >> 11) & 2047u) + (uint32_t)__popcll(m1 & below)] = (uint16_t)i;
-            else if (cls == 2u) ord_sl[1023u - (at >> 22) - (uint32_t)__popcll(m2 & below)] = (uint16_t)i;
-            if (m4) {  // (mid pieces from the front of their list, these from the back: 5 n_m + 24 n_xl <= the window's bytes, so the two never meet)
-                at4 = (uint32_t)__shfl((int)at4, 0, 64);
-                if (cls == 4u) ord_m[1023u - at4 - (uint32_t)__popcll(m4 & below)] = (uint16_t)i;
-            }
-        }
-        __syncthreads();
-        TKT(6);
-        const uint32_t n_s = ncls_sh & 2047u, n_m = (ncls_sh >> 11) & 2047u, n_l = ncls_sh >> 22, n_xl = nxl_sh;
-        // a piece for the list of F4
-        auto not_a_token = [&](bool miss, uint32_t i) {
-            const uint64_t m = __ballot(miss);
-            if (m) {
-                uint32_t at = 0;
-                const int leader = __ffsll((unsigned long long)m) - 1;
-                if (lane == leader) at = atomicAdd(&nx_sh, (uint32_t)__popcll(m));
-                at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (miss) ord_x[at] = (uint16_t)i;
-            }
-        };
-        // F1..F3 by rows of 64 pieces of ONE length class: a wavefront takes every fourth row -- the dearest rows first, so that they are
-        // spread evenly and run side by side -- and runs that class's probe only; the lanes whose piece is not a token then claim or
-        // find their slot of the in-call table in the same row, by the piece's identity (tk_common.h, tk_ident).  Nothing waits for a
-        // barrier in between: the chains of dependent accesses of the four wavefronts overlap (round 4 listed the pieces that are not
-        // tokens and gave the list to one wavefront behind a barrier: 0.9 ms of the kernel's 5 for a third of them, measured).
-        //   longer than TK_XL_MAX: no look at the vocabulary (see above); identity = first and last eight bytes, length, place
-        //   long : identity = the bytes, 32-byte slots that hold them
-        //   mid  : 64-bit key = the bytes, 16-byte slots
-        //   short: the bytes are the key (one unaligned LDS dword), 8-byte slots
-        const uint32_t rows_x = (n_xl + 63u) >> 6, rows_l = (n_l + 63u) >> 6, rows_m = (n_m + 63u) >> 6, rows_s = (n_s + 63u) >> 6;
-        const bool use_mt = mt != nullptr && !(dbg & 8);
-        for (uint32_t r = (uint32_t)wid; r < rows_x + rows_l + rows_m + rows_s; r += 4u) {
-            bool miss = false, exact = true, in_lds = true;
-            uint32_t i_p = 0, k = 0, len = 0, s_loc = 0;
-            uint64_t w0 = 0, w1 = 0, w2 = 0;
-            if (r < rows_x) {
-                const uint32_t q = r * 64u + (uint32_t)lane;
-                if (q < n_xl) {
-                    i_p = ord_m[1023u - q];
-                    k = kb + i_p;
-                    s_loc = plist[k];
-                    const uint32_t e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
-                    len = e_loc - s_loc;
-                    in_lds = e_loc + 8u <= (uint32_t)TK2_WIN;
-                    exact = false;
-                    if (dbg & (2 | 8)) {  // (perf experiments / piece starts only: every probe counts as a hit)
-                        out.res[run_base + k] = (dbg & 2) ? len : 0u;
-                    } else {
-                        miss = true;
-                        if (len <= TK_GLANE_MAX) {
-                            const uint64_t gs = (uint64_t)(base + s_loc);
-                            tk_ident([&](uint32_t o) { return in_lds ? tk_lds_load8(raw, s_loc + o) : tk_load8(text, gs + o); }, len, (uint32_t)gs, w0, w1, w2);
-                        }
-                    }
-                }
-            } else if (r < rows_x + rows_l) {
-                const uint32_t q = (r - rows_x) * 64u + (uint32_t)lane;
-                if (q < n_l) {
-                    i_p = ord_sl[1023u - q];
-                    k = kb + i_p;
-                    s_loc = plist[k];
-                    const uint32_t e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
-                    len = e_loc - s_loc;
-                    in_lds = e_loc + 8u <= (uint32_t)TK2_WIN;
-                    uint32_t rk = len;
-                    if (!(dbg & 2)) {
-                        const uint64_t gs = (uint64_t)(base + s_loc);
-                        tk_ident([&](uint32_t o) { return in_lds ? tk_lds_load8(raw, s_loc + o) : tk_load8(text, gs + o); }, len, 0u, w0, w1, w2);
-                        rk = tk_probe_xl(T, w0, w1, w2);
-                    }
-                    if (rk != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k] = rk == TK_RANK_MAX ? 0u : rk;
-                    else miss = true;
-                }
-            } else if (r < rows_x + rows_l + rows_m) {
-                const uint32_t q = (r - rows_x - rows_l) * 64u + (uint32_t)lane;
-                if (q < n_m) {
-                    i_p = ord_m[q];
-                    k = kb + i_p;
-                    s_loc = plist[k];
-                    const uint32_t e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
-                    len = e_loc - s_loc;
-                    const uint64_t key_m = tk_mask_low_bytes(tk_lds_load8(raw, s_loc), len);
-                    const uint32_t rk = (dbg & 2) ? len : tk_probe_mid(T, key_m, len);
-                    if (rk != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k] = rk == TK_RANK_MAX ? 0u : rk;
-                    else {
-                        miss = true;
-                        w0 = tk_keep_bytes(key_m, (int)len);  // (tk_ident of a piece of at most eight bytes)
-                        w2 = (uint64_t)len << 56;
-                    }
-                }
-            } else {
-                const uint32_t q = (r - rows_x - rows_l - rows_m) * 64u + (uint32_t)lane;
-                if (q < n_s) {
-                    i_p = ord_sl[q];
-                    k = kb + i_p;
-                    s_loc = plist[k];
-                    const uint32_t e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
-                    len = e_loc - s_loc;
-                    const uint32_t v = __builtin_amdgcn_alignbyte(dwr[(s_loc >> 2) + 1], dwr[s_loc >> 2], s_loc & 3u);
-                    const uint32_t key_s = v & (0xFFFFFFFFu >> (32u - 8u * len));
-                    const uint32_t rk = (dbg & 2) ? len : (short_tab ? tk_probe_short(T, key_s, len) : tk_probe_mid(T, (uint64_t)key_s, len));
-                    if (rk != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k] = rk == TK_RANK_MAX ? 0u : rk;
-                    else {
-                        miss = true;
-                        w0 = tk_keep_bytes((uint64_t)key_s, (int)len);
-                        w2 = (uint64_t)len << 56;
-                    }
-                }
-            }
-            // the pieces of the row that are not tokens: their slots of the in-call table
-            uint32_t ref = TKF_NONE;
-            if (miss && use_mt && len <= TK_GLANE_MAX) {
-                unsigned long long kk = tk_ident_hash(w0, w1, w2, exact);
-                if (dbg & 512) kk &= 0xFFFull;  // test hook: force collisions between different pieces
-                if (kk == TK_EMPTY_KEY) kk = 0;
-                const uint32_t i = ((uint32_t)kk ^ (uint32_t)(kk >> 40)) & mt_mask;
-                ref = claim(w0, w1, w2, kk, exact, in_lds, s_loc, (uint64_t)(base + s_loc), len, i, *(const ulonglong2*)&mt[i].key, *(const ulonglong2*)&mt[i].w1);
-            }
-            put_ref(ref != TKF_NONE, k, ref);
-            not_a_token(miss && ref == TKF_NONE, i_p);  // (no table, a full neighbourhood, more than TK_GLANE_MAX bytes: F4)
-        }
-        TKT(7);
-        __syncthreads();
-        TKT(8);
-        // F4: what the rows above could not settle (next to nothing: chunks too small for a table, a full neighbourhood of the table, pieces
-        // of more than TK_GLANE_MAX bytes): an overflow entry behind the table's (one returning atomic per wavefront that has such pieces).
-        const uint32_t n_x = nx_sh;
-        for (uint32_t q0 = (uint32_t)wid * 64u; q0 < n_x; q0 += 256u) {  // (rows of 64: a wavefront without pieces does not run the body)
-            const uint32_t q = q0 + (uint32_t)lane;
-            bool over = false;  // needs an overflow entry
-            uint32_t k = TKF_NONE, len = 0, ref = TKF_NONE;
-            uint64_t gs = 0;
-            if (q < n_x) {
-                k = kb + ord_x[q];
-                const uint32_t s_loc = plist[k];
-                const uint32_t e_loc = k + 1 < np ? (uint32_t)plist[k + 1] : last_end;
-                len = e_loc - s_loc;
-                gs = (uint64_t)(base + s_loc);
-                over = true;
-                if (len > TK_XL_MAX && len <= T.max_token_len && (len > TK_GLANE_MAX || !mt)) {
-                    // (nobody else will ask whether it is a token: tk_k_bincount looks at table slots and overflow entries of at most TK_GLANE_MAX
-                    // bytes -- the latter is asked twice then, harmlessly)
-                    const uint32_t rk = tk_lookup_text_piece(T, text, gs, len);
-                    if (rk != TK_RANK_MAX) {
-                        out.res[run_base + k] = rk;
-                        over = false;
-                        k = TKF_NONE;  // (settled: a token after all)
-                    }
-                }
-            }
-            const uint64_t m = __ballot(over);
-            if (m) {
-                const int leader = __ffsll((unsigned long long)m) - 1;
-                uint32_t at = 0;
-                if (lane == leader) at = atomicAdd(&out.counters[TK_CNT_OVF], (uint32_t)__popcll(m));
-                at = (uint32_t)__shfl((int)at, leader, 64) + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-                if (over && at < out.ovf_cap) {  // (beyond the capacity: the counter tells the host, which repeats the batch with more room)
-                    ref = out.data.ovf_base + at;
-                    *(uint4*)&out.data.ovf[at].start = make_uint4((uint32_t)gs, len, 0u, 0u);
-                    if (len > TK_GLANE_MAX) tk_append_tree(out.listC, out.counters, ref, (uint32_t)gs, len);
-                }
-            }
-            put_ref(k != TKF_NONE, k, ref);
-        }
-        if (n_x || kb + TKF_BATCH < np) __syncthreads();  // (the lists are reused by the next batch; what F4 has counted is read below)
-    }
-    if (tid == 0 && np) {
-        out.res[run_base + TKF_TAIL_NMISS] = ntail_sh;
-        out.res[run_base + TKF_TAIL_NGAP] = GEN ? ngap_sh : 0u;
-    }
-#endif
     }  // (!SLOW)
     } while (PERSIST && next_item());
 }
