@@ -832,7 +832,11 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
     uint32_t *ss = nullptr, *si = nullptr, *docb = nullptr;
     uint32_t* counters = w.counters.as<uint32_t>();
     TRY(ensure(w.tile_sum, ntiles + 16));
-    TRY(ensure(w.row_base, (ntiles + 1) * (TKF_CAP / 256) * 4));  // (tokens of a tile's rows of 256 pieces before each row: tk_k_count_tiles for tk_k_docoff)
+    // (round 6) the first document that starts in every tile (tk_k_mark_docs), for tk_k_place, which writes the documents' token offsets as it
+    // passes their pieces; one piece without pre-tokenisation and empty chunks keep tk_k_docoff
+    const bool docs_in_place = n > 0 && !single_piece && d_tok_off != nullptr;
+    TRY(ensure(w.row_base, (ntiles + 4) * 4));
+    if (docs_in_place) clear(w.row_base, (ntiles + 2) * 4, 0xFFFFFFFFu);
     clear(w.tile_sum, ntiles + 16, 0xFFFFFFFFu);
     if (job.ovf_base) {
         TRY(ensure(w.mt_keys, sizeof(TkMissKey) * job.ovf_base));
@@ -864,7 +868,8 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
         hipLaunchKernelGGL(tk_k_chunk_clear, dim3(grid_for(n / 64 + 1, 256, 2048)), dim3(256), 0, s, clr);
         clr.n = 0;
         TRY(timed(c, s, "tk_k_mark_docs", [&] {
-            hipLaunchKernelGGL(tk_k_mark_docs, dim3(grid_for(n_docs, 256, 4096)), dim3(256), 0, s, d_doc_off, n_docs, base, n, brk, docb);
+            hipLaunchKernelGGL(tk_k_mark_docs, dim3(grid_for(n_docs, 256, 4096)), dim3(256), 0, s, d_doc_off, n_docs, base, n, brk, docb,
+                               docs_in_place ? w.row_base.as<uint32_t>() : (uint32_t*)nullptr, ntiles);
         }));
         if (use_special) {
             const uint8_t* allowed = c->allowed.as<uint8_t>();
@@ -1076,14 +1081,16 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
     if (n > 0) {
         TRY(timed(c, s, "tk_k_place", [&] {
             // (one instance for every size: three rows per step for inputs of a few tiles measured slower -- C1 0.082 ms against 0.060 --, profiles/r05_place_experiments.txt)
-            hipLaunchKernelGGL(tk_k_place<TKP_ROWS_PLACE>, dim3(grid_for(ntiles, 4, 4096)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, data, stg, d_out, tok_base, w.big.as<uint32_t>(), w.row_base.as<uint32_t>());
+            const bool docs_in_place = !job.single_piece && job.d_tok_off != nullptr;
+            const TkPlaceDocs docs{job.d_doc_off, job.base, n, job.n_docs, w.row_base.as<uint32_t>(), w.starts.as<uint32_t>(), w.total.as<uint64_t>(), docs_in_place ? job.d_tok_off : (uint64_t*)nullptr};
+            hipLaunchKernelGGL(tk_k_place<TKP_ROWS_PLACE>, dim3(grid_for(ntiles, 4, 4096)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, data, stg, d_out, tok_base, w.big.as<uint32_t>(), docs);
         }));
     }
     if (n > TK_BIGCOPY)  // (a token run of TK_BIGCOPY tokens needs at least as many bytes)
         hipLaunchKernelGGL(tk_k_bigcopy, dim3(1024), dim3(256), 0, s, w.big.as<uint32_t>(), stg, d_out, tok_base);
     // (the document offsets need the tile counts only, but beside tk_k_place on a second stream the two take as long as one after the
     // other: both are bound by the rate of random accesses -- measured in round 4)
-    if (job.d_tok_off) {
+    if (job.d_tok_off && (n == 0 || job.single_piece)) {  // (else tk_k_place has written them)
         TRY(timed(c, s, "tk_k_docoff", [&] {
             hipLaunchKernelGGL(tk_k_docoff, dim3(grid_for(job.n_docs + 1, 16, 4096)), dim3(256), 0, s, job.n_docs, job.d_doc_off, job.base, n, w.starts.as<uint32_t>(), tile_nt, res, data,
                                (n > 0 && !job.single_piece) ? w.row_base.as<uint32_t>() : (const uint32_t*)nullptr, w.total.as<uint64_t>(), tok_base, job.d_tok_off);

@@ -2766,11 +2766,22 @@ __global__ __launch_bounds__(256) void tk_k_count_tiles(uint64_t ntiles, const u
 #ifndef TKP_STAGE
 #define TKP_STAGE 1024
 #endif
+struct TkPlaceDocs {
+    const uint64_t* doc_off;    // [n_docs + 1] offsets of the chunk's documents (absolute: chunk_base is subtracted)
+    uint64_t chunk_base, n, n_docs;
+    const uint32_t* doc_first;  // [ntiles + 1] tk_k_mark_docs: first document that starts in the tile (0xFFFFFFFF: none); [ntiles]: at or behind the end
+    const uint32_t* starts;     // piece-start bitmap, 120 words per tile
+    const uint64_t* total;      // [0]: the chunk's token count
+    uint64_t* tok_off;          // [n_docs + 1] out (null: not asked for)
+};
 template <int ROWS>
 __global__ __launch_bounds__(256) void tk_k_place(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_tb,
                                                   const uint32_t* __restrict__ res, TkMiss data, const uint32_t* __restrict__ staging, uint32_t* __restrict__ out_all,
                                                   const unsigned long long* __restrict__ tok_base, uint32_t* __restrict__ big,
-                                                  uint32_t* __restrict__ row_abs /* [tile * 16 + r]: tokens of the chunk before row r of the tile (for tk_k_docoff) */) {
+                                                  // (round 6) the document offsets, written here as a tile's pieces are placed: tok_off[d] = tokens before the piece
+                                                  // that starts document d.  tk_k_docoff found that piece again per document -- five dependent loads, the result
+                                                  // words of up to 255 pieces before it read once more: 0.15 ms and 0.36 GB per GiB.  docs.tok_off == nullptr: not asked for.
+                                                  TkPlaceDocs docs) {
     constexpr uint32_t CAP = 256u * ROWS, SCAP = (uint32_t)TKP_STAGE;
     __shared__ __attribute__((aligned(16))) uint32_t stage_sh[4][SCAP + 4];
     __shared__ uint32_t ref_sh[4][CAP];  // the listed pieces' result words, in piece order
@@ -2787,12 +2798,45 @@ __global__ __launch_bounds__(256) void tk_k_place(uint64_t ntiles, const uint32_
     const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
     uint32_t np_next = wave < ntiles ? tile_np[wave] : 0u, tb_next = wave < ntiles ? tile_tb[wave] : 0u;
     uint32_t te_next = wave + 1 < ntiles ? tile_tb[wave + 1] : 0xFFFFFFFFu;  // where the tile's tokens end (the chunk's last tile: unknown here, never staged)
+    const bool want_docs = docs.tok_off != nullptr;
+    uint32_t df_next = (want_docs && wave < ntiles) ? docs.doc_first[wave] : 0xFFFFFFFFu;
+    const uint64_t tok_base_global = tok_base[0];
     for (uint64_t t = wave; t < ntiles; t += nwaves) {
         const uint32_t np = np_next, rb = (uint32_t)t * TKF_CAP, run0 = tb_next;  // (token offsets within a chunk fit 32 bits: a chunk is less than 4 GiB of text)
         const uint32_t nt_tile = te_next - run0;
+        const uint32_t dfirst = df_next;
         np_next = t + nwaves < ntiles ? tile_np[t + nwaves] : 0u;  // (the next tile's size and base are on their way while this tile is placed)
         tb_next = t + nwaves < ntiles ? tile_tb[t + nwaves] : 0u;
         te_next = t + nwaves + 1 < ntiles ? tile_tb[t + nwaves + 1] : 0xFFFFFFFFu;
+        df_next = (want_docs && t + nwaves < ntiles) ? docs.doc_first[t + nwaves] : 0xFFFFFFFFu;
+        // The documents that start in this tile: the piece index kp of each (its start is a piece start: the number of set bits of the tile's
+        // start bitmap before it), for the first sixty-four of them before the tile's steps (a tile of web text has one or two), further ones
+        // -- a tile full of tiny documents -- inside every step.  A document's offset is written by the step that holds its piece.
+        const bool has_docs = dfirst != 0xFFFFFFFFu;  // (wave-uniform)
+        uint32_t sb0 = 0, sb1 = 0, spx = 0;           // the lane's two words of the start bitmap, set bits in the words before them
+        if (has_docs) {
+            if (lane < (int)(TK_TILE / 64)) {
+                const uint2 sw = *(const uint2*)(docs.starts + t * (TK_TILE / 32) + 2u * (uint32_t)lane);
+                sb0 = sw.x;
+                sb1 = sw.y;
+            }
+            const uint32_t c = (uint32_t)__popc(sb0) + (uint32_t)__popc(sb1);
+            spx = tk_wave_scan_u32(c, lane) - c;
+        }
+        const uint64_t tile_lo = t * (uint64_t)TK_TILE, tile_hi = tile_lo + TK_TILE < docs.n ? tile_lo + TK_TILE : docs.n;
+        // kp of document dfirst + 64 c + lane, or 0xFFFFFFFF when it does not start in this tile (every lane takes part: the shuffles read all lanes)
+        auto doc_piece = [&](uint32_t c) -> uint32_t {
+            const uint64_t d = (uint64_t)dfirst + 64u * c + (uint32_t)lane;
+            const uint64_t pos = d < docs.n_docs ? docs.doc_off[d] - docs.chunk_base : ~0ull;
+            const bool in = pos >= tile_lo && pos < tile_hi;
+            const uint32_t it = in ? (uint32_t)(pos - tile_lo) : 0u, w = it >> 5;
+            const uint32_t a0 = (uint32_t)__shfl((int)sb0, (int)(w >> 1), 64), a1 = (uint32_t)__shfl((int)sb1, (int)(w >> 1), 64);
+            const uint32_t px = (uint32_t)__shfl((int)spx, (int)(w >> 1), 64);
+            const uint32_t kp = px + ((w & 1u) ? (uint32_t)__popc(a0) + (uint32_t)__popc(a1 & ((1u << (it & 31u)) - 1u)) : (uint32_t)__popc(a0 & ((1u << (it & 31u)) - 1u)));
+            return in ? kp : 0xFFFFFFFFu;
+        };
+        const uint32_t kp0 = has_docs ? doc_piece(0u) : 0xFFFFFFFFu;
+        const bool more_docs = has_docs && __ballot(kp0 != 0xFFFFFFFFu) == ~0ull;  // (all sixty-four start here: there may be more)
         auto place_tile = [&](auto staged_c) {
             constexpr bool ST = decltype(staged_c)::value;
             auto W = [&](uint32_t off, uint32_t v) {  // token number `off` of the tile
@@ -2905,6 +2949,34 @@ __global__ __launch_bounds__(256) void tk_k_place(uint64_t ntiles, const uint32_
                     }
                 }
                 __builtin_amdgcn_wave_barrier();
+                if (has_docs) {
+                    // the documents whose first piece lies in this step: tokens before it = tokens of the steps so far + its index in the step + the
+                    // sum of `count - 1` over the listed pieces before it (their number: the list base of the lane that holds it + its flagged
+                    // pieces before -- shuffled from that lane)
+                    auto emit = [&](uint32_t kp, uint32_t c) {
+                        const bool mine = kp != 0xFFFFFFFFu && kp >= k0 && kp < k0 + CAP;
+                        const uint32_t j = mine ? kp - k0 : 0u, src = (j & 255u) >> 2;
+                        uint32_t lb = 0, fmv = 0;
+#pragma unroll
+                        for (int r = 0; r < ROWS; ++r) {
+                            const uint32_t lbr = (uint32_t)__shfl((int)lbase[r], (int)src, 64), fmr = (uint32_t)__shfl((int)fm[r], (int)src, 64);
+                            if ((j >> 8) == (uint32_t)r) {
+                                lb = lbr;
+                                fmv = fmr;
+                            }
+                        }
+                        const uint32_t nl = lb + (uint32_t)__popc(fmv & ((1u << (j & 3u)) - 1u));
+                        const uint32_t ex = (mine && nl) ? cuml[nl - 1u] : 0u;
+                        if (mine) docs.tok_off[(uint64_t)dfirst + 64u * c + (uint32_t)lane] = tok_base_global + (uint64_t)(uint32_t)(run0 + run + j + ex);  // (32-bit sum first: `ex` is negative behind gap chars)
+                    };
+                    emit(kp0, 0u);
+                    if (more_docs)
+                        for (uint32_t c = 1;; ++c) {
+                            const uint32_t kp = doc_piece(c);
+                            emit(kp, c);
+                            if (__ballot(kp != 0xFFFFFFFFu) != ~0ull) break;
+                        }
+                }
                 // the single tokens of the rows: place = index + the sum over the listed pieces before
 #pragma unroll
                 for (int r = 0; r < ROWS; ++r) {
@@ -2912,7 +2984,7 @@ __global__ __launch_bounds__(256) void tk_k_place(uint64_t ntiles, const uint32_
                     if (k0 + kr >= np) break;
                     uint32_t rk = lbase[r];
                     uint32_t ex = rk ? cuml[rk - 1u] : 0u;
-                    if (lane == 0) row_abs[t * (TKF_CAP / 256) + ((k0 + kr) >> 8)] = run0 + run + kr + ex;
+
                     const uint32_t o = run + kr + (uint32_t)lane * 4u;
                     if (fm[r] == 0u) {
                         if constexpr (ST) {
@@ -2952,6 +3024,11 @@ __global__ __launch_bounds__(256) void tk_k_place(uint64_t ntiles, const uint32_
         };
         if (np != 0u && nt_tile <= SCAP) place_tile(std::true_type{});
         else place_tile(std::false_type{});
+        if (want_docs && t + 1 == ntiles) {  // documents at or behind the end of the text (empty ones), and the closing offset: the chunk's token count
+            const uint32_t dl = docs.doc_first[ntiles];
+            const uint64_t v = tok_base_global + docs.total[0];
+            for (uint64_t d = (dl == 0xFFFFFFFFu ? docs.n_docs : (uint64_t)dl) + (uint32_t)lane; d <= docs.n_docs; d += 64u) docs.tok_off[d] = v;
+        }
     }
 }
 

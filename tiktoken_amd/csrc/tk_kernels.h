@@ -157,14 +157,18 @@ __global__ __launch_bounds__(256) void tk_k_chunk_clear(TkClearArgs a) {
 // ------------------------------------------------------------------------------------------
 // document starts -> bitmaps
 // ------------------------------------------------------------------------------------------
+// (round 6) ... and, for the back end, the FIRST document that starts in every tile (doc_first[t]; [ntiles]: the first one at or behind the end of
+// the text -- empty documents at the end): documents are in the order of their offsets, so a tile's documents are doc_first[t], + 1, ...
+// while they start inside it.  tk_k_place writes their token offsets as it passes their pieces (tk_fused.h).
 __global__ void tk_k_mark_docs(const uint64_t* __restrict__ doc_off, uint64_t n_docs, uint64_t base, uint64_t n,
-                               uint32_t* __restrict__ brk, uint32_t* __restrict__ docb) {
+                               uint32_t* __restrict__ brk, uint32_t* __restrict__ docb, uint32_t* __restrict__ doc_first, uint64_t ntiles) {
     for (uint64_t d = blockIdx.x * (uint64_t)blockDim.x + threadIdx.x; d < n_docs; d += (uint64_t)gridDim.x * blockDim.x) {
         uint64_t pos = doc_off[d] - base;
         if (pos < n) {
             atomicOr(&brk[pos >> 5], 1u << (pos & 31));
             if (docb) atomicOr(&docb[pos >> 5], 1u << (pos & 31));
         }
+        if (doc_first) atomicMin(&doc_first[pos < n ? pos / TK_TILE : ntiles], (uint32_t)d);
     }
 }
 

@@ -11,5 +11,5 @@ python - <<'PY'
 import json
 for l in open('gpurun_out/ab/exp.jsonl'):
     j=json.loads(l); k=j["kernels_ms"]
-    print("%-14s %7.3f ch %s bs %s front %.3f slow %.3f+%.3f lists %.3f merges %.3f count %.3f scans %.3f place %.3f docoff %.3f parity %s" % (j["tag"], j["ms_per_step"], j["host"].get("chunks"), j["host"].get("back_streams"), k["tk_k_front"], k["tk_k_front_slow"], k.get("tk_k_front_given",0), k.get("tk_k_bincount",0)+k.get("tk_k_binfill",0), sum(v for n,v in k.items() if "merge" in n), k.get("tk_k_count_tiles",0), sum(v for n,v in k.items() if "scan" in n), k["tk_k_place"], k["tk_k_docoff"], j.get("parity")))
+    print("%-14s %7.3f ch %s bs %s front %.3f slow %.3f+%.3f lists %.3f merges %.3f count %.3f scans %.3f place %.3f docoff %.3f parity %s" % (j["tag"], j["ms_per_step"], j["host"].get("chunks"), j["host"].get("back_streams"), k["tk_k_front"], k["tk_k_front_slow"], k.get("tk_k_front_given",0), k.get("tk_k_bincount",0)+k.get("tk_k_binfill",0), sum(v for n,v in k.items() if "merge" in n), k.get("tk_k_count_tiles",0), sum(v for n,v in k.items() if "scan" in n), k["tk_k_place"], k.get("tk_k_docoff", 0), j.get("parity")))
 PY
