@@ -427,6 +427,28 @@ def test_ten_megabytes_without_a_certain_start_take_the_generic_way():
         assert np.array_equal(toff, ro) and np.array_equal(toks, rt), allowed
 
 
+def test_a_tile_that_gives_up_while_the_host_is_not_waiting_repeats_the_batch():
+    """Round 6: the host no longer waits for the deferred tiles' counters between the two kernels (tk_api.hip, stage_deferred).  A core's first
+    batch with a stretch that makes a tile give up runs to its end on what the kernels had (the tiles that gave up: empty), is found out by
+    chunk_finish and repeated once, waiting; from then on the core waits in every chunk.  Same tokens as the oracle both times."""
+    from tiktoken_amd import CoreBPE
+
+    name = "o200k_shaped"
+    g = h.load_golden(name)
+    core, C = CoreBPE(h.golden_vocab(name), g["special_tokens"], h.PAT_STR[h.ENCODING_NAMES.index(name)]), h.c_oracle_for(name)
+    plain = ("The quick brown fox, 12345 times. " * 20_000).encode()
+    assert np.array_equal(core._encode_np(plain, None), C.encode_ordinary(plain))
+    assert core.stat("resynced") == 0 and core.stat("fallbacks") == 0
+    docs = [b"before ", ("x'll" * 300_000).encode(), plain[:100_000], b""]
+    blob, off = h.pack(docs)
+    rt, ro = C.encode_batch(blob, off, None, 4)
+    for k in range(2):
+        toks, toff = core.encode_batch_packed(blob, off, None)
+        assert np.array_equal(toff, ro) and np.array_equal(toks, rt), k
+        assert core.stat("resynced") == 1 and core.stat("fallbacks") == k + 1, (k, core.stat("resynced"), core.stat("fallbacks"))
+    assert np.array_equal(core._encode_np(plain, None), C.encode_ordinary(plain))
+
+
 @pytest.mark.parametrize("name", h.ENCODING_NAMES)
 def test_ordinary_text_through_the_give_up_path(monkeypatch, name):
     """TIKTOKEN_AMD_DEBUG bit 0x20000000: a walk budget of zero windows -- every deferred tile that would walk a window gives up, and the

@@ -99,6 +99,7 @@ struct ChunkJob {
     TkMissKey* mt = nullptr;   // the in-call miss table's keys (null: no table -- every missed piece gets an overflow entry)
     uint32_t ovf_base = 0;     // slots of the table = index of the first overflow entry of the miss data
     uint32_t ovf_cap = 0;      // overflow entries there is room for
+    bool optimistic = false;   // the host has not waited for the deferred tiles' counters (stage_deferred): chunk_finish looks at them
 };
 
 // the chunk's entries of distinct missed pieces, as the kernels take them
@@ -121,6 +122,9 @@ struct tk_core {
     TkRxCompiled rx_fb;
     uint64_t st_fallbacks = 0;  // chunks that took that way
     uint64_t st_regrown = 0;    // batches repeated with a larger miss data (encode_device_locked)
+    uint64_t st_resynced = 0;   // batches repeated because a deferred tile gave up its walk while the host was not waiting for the counters (stage_deferred)
+    bool defer_sync = false;    // ... from then on the host waits for them in every chunk, as it did up to round 5
+    uint32_t defer_ppm = 1u << 14;  // deferred tiles per 2^20 tiles of the last chunk (the grid of the kernel that finishes them; first guess: a sixty-fourth)
     TkRxDev rx{};
     Buf t_rx_ins, t_rx_sets, t_rx_ranges, t_rx_first, t_rx_s1, t_rx_s2, t_rx_dtrans, t_rx_dascii, t_rx_ds1, t_rx_ds2;
     bool rx_staged = true;  // the speculative pass over text staged in LDS where the pattern's DFA allows it ($TIKTOKEN_AMD_RX_STAGED=0: never)
@@ -511,6 +515,7 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
         if (v >= 4096 && v <= (3ull << 30)) c->chunk_bytes = v;
     }
     if (const char* e = getenv("TIKTOKEN_AMD_DEBUG")) c->dbg = atoi(e);
+    if (const char* e = getenv("TIKTOKEN_AMD_DEFER_SYNC")) c->defer_sync = atoi(e) != 0;  // (experiments: the host waits for the deferred tiles' counters in every chunk)
     if (const char* e = getenv("TIKTOKEN_AMD_RX_AHEAD")) {  // (experiments: bytes a speculative match may look beyond its segment)
         const int k = atoi(e);
         if (k >= 16 && k <= (1 << 20)) c->rx_ahead = (uint32_t)k;
@@ -698,7 +703,7 @@ static int rx_split(tk_core* c, WorkSet& w, hipStream_t s, const uint8_t* d_text
 // The tiles the front kernel has deferred (they need the workgroup-wide scanner: long pieces, far-away piece starts; their number stays
 // on the device), then the counters of both kernels -- pieces for the tree kernel, errors of the generic engine -- on their way to the host.
 // A kernel of a few hundred workgroups that each take ~0.3 ms: it belongs to the back stage, beside the next chunk's front kernel.
-static int stage_deferred(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s) {
+static int stage_deferred(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s) {
     const TkTables& T = c->D;
     // A stretch without certain starts ("x'llx'll...": whether 'll ends a piece depends on everything before it) makes every deferred tile
     // inside it walk from the stretch's start -- quadratic in its length, seconds for 10 MB.  A tile whose walk exceeds TKF_WALK_BUDGET
@@ -726,10 +731,18 @@ static int stage_deferred(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream
                                w.deferred.as<uint32_t>(), gapb, (fdbg & ~TKF_DBG_SECOND) | (can_fall_back ? TKF_DBG_MAY_GIVE_UP : 0));
         }));
         uint64_t n_given = job.ntiles;
-        // The host waits for the counters only where it has a decision to take (the way out of a stretch without certain starts); the length
-        // of the list is read on that occasion.  Everywhere else -- small inputs, a pat_str without that way out -- nothing blocks the
-        // queueing of the next chunk: one workgroup per tile, of which all but the list's length return at once.
-        if (can_fall_back) {
+        // (round 6) The host does not wait for the counters here any more: the wait cost every chunk ~25 us of an idle device between the two kernels
+        // (3 % of a 64 MiB batch) and kept the host from queueing the next chunk -- for a decision that ordinary text never needs.  The kernel that
+        // finishes the deferred tiles walks the list with a grid sized from the chunk before (the same kind of text: a quarter more than it needed),
+        // and chunk_finish looks at the counter of tiles that gave up: if there is one the batch is repeated (encode_device_locked) and the core waits
+        // here from then on (c->defer_sync), as it did up to round 5.  Small inputs, a pat_str without that way out: one workgroup per tile.
+        const bool sync_now = can_fall_back && (c->defer_sync || job.pretok);  // ($TIKTOKEN_AMD_DEFER_SYNC=1: from the start; the piece-offsets entry has no chunk_finish)
+        job.optimistic = can_fall_back && !sync_now;
+        if (job.optimistic) {
+            const uint64_t guess = ((job.ntiles * (uint64_t)c->defer_ppm) >> 20) * 5 / 4 + 64;
+            n_given = guess < job.ntiles ? guess : job.ntiles;
+        }
+        if (sync_now) {
             HIPCHK(hipMemcpyAsync(w.h_counters, w.counters.p, TK_CNT_N * 4, hipMemcpyDeviceToHost, s));
             HIPCHK(hipEventRecord(w.ev_cnt, s));
             HIPCHK(hipEventSynchronize(w.ev_cnt));
@@ -759,6 +772,7 @@ static int stage_deferred(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream
     HIPCHK(hipEventRecord(w.ev_cnt, s));
     return TK_OK;
 }
+#define TK_RESYNC (-1001)  // (internal) a deferred tile gave up while the host was not waiting: the batch is repeated, encode_device_locked
 
 static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, const uint8_t* d_text, uint64_t n, const uint64_t* d_doc_off, uint64_t n_docs,
                        uint64_t base, bool use_special, bool single_piece, uint64_t* d_tok_off, bool pretok_only, bool no_lookup,
@@ -930,7 +944,7 @@ static int stage_front(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, con
 // Second stage of a chunk, on stream s (the front stage's stream for a single chunk, the set's own otherwise; the caller has made it wait
 // for w.ev_front).  d_out: the batch's token buffer; the chunk's tokens go behind tok_bases[job.index] of them, which the previous chunk's
 // back stage writes (prev_tot: the event to wait for, null for the first chunk or on a single stream).
-static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s, uint32_t* d_out, hipEvent_t prev_tot) {
+static int stage_back(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s, uint32_t* d_out, hipEvent_t prev_tot) {
     const TkTables& T = c->D;
     const uint64_t n = job.n, ntiles = job.ntiles;
     const uint8_t* d_text = job.d_text;
@@ -1083,7 +1097,9 @@ static int stage_back(tk_core* c, WorkSet& w, const ChunkJob& job, hipStream_t s
             // (one instance for every size: three rows per step for inputs of a few tiles measured slower -- C1 0.082 ms against 0.060 --, profiles/r05_place_experiments.txt)
             const bool docs_in_place = !job.single_piece && job.d_tok_off != nullptr;
             const TkPlaceDocs docs{job.d_doc_off, job.base, n, job.n_docs, w.row_base.as<uint32_t>(), w.starts.as<uint32_t>(), w.total.as<uint64_t>(), docs_in_place ? job.d_tok_off : (uint64_t*)nullptr};
-            hipLaunchKernelGGL(tk_k_place<TKP_ROWS_PLACE>, dim3(grid_for(ntiles, 4, 4096)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, data, stg, d_out, tok_base, w.big.as<uint32_t>(), docs);
+            // (six workgroups per CU: 80 registers, 26 688 B of LDS; a grid of four times what is resident -- 0.84 ms with 4096 workgroups, 0.81 with 1536 or 3072,
+            // 0.80 with 6144 or 12 288, round 6)
+            hipLaunchKernelGGL(tk_k_place<TKP_ROWS_PLACE>, dim3(grid_for(ntiles, 4, 6144)), dim3(256), 0, s, ntiles, tile_np, tile_nt, res, data, stg, d_out, tok_base, w.big.as<uint32_t>(), docs);
         }));
     }
     if (n > TK_BIGCOPY)  // (a token run of TK_BIGCOPY tokens needs at least as many bytes)
@@ -1115,6 +1131,13 @@ static int chunk_finish(tk_core* c, WorkSet& w, const ChunkJob& job, uint64_t* n
     }
     if (hb[TK_CNT_ERR] & (TK_RX_ERR_GAP | TK_RX_ERR_STACK | TK_RX_ERR_LIMIT)) return rx_failure(hb, job.base);
     if (hb[TK_CNT_ERR]) return fail(TK_RUNTIME_ERROR, "internal error in the front kernel (scanner list overflow, code " + std::to_string(hb[TK_CNT_ERR]) + ")");
+    if (job.optimistic) {  // (stage_deferred did not wait for these)
+        if (hb[TK_CNT_DEFER2]) {
+            c->defer_sync = true;
+            return TK_RESYNC;
+        }
+        c->defer_ppm = (uint32_t)std::min<uint64_t>(((uint64_t)hb[TK_CNT_DEFER] << 20) / (job.ntiles ? job.ntiles : 1), 1u << 20);
+    }
     if (hb[TK_CNT_OVF] > job.ovf_cap && !job.pretok) {  // more distinct missed pieces than the miss data has room for: the batch is repeated with room for the worst case
         c->ovf_full = true;
         return TK_GROW;
@@ -1354,14 +1377,18 @@ static int encode_device_pass(tk_core* c, hipStream_t s, const uint8_t* d_utf8, 
 static int encode_device_locked(tk_core* c, hipStream_t s, const uint8_t* d_utf8, uint64_t n_bytes, const uint64_t* d_doc_off,
                                 const uint64_t* h_doc_off, uint64_t n_docs, bool use_special, uint64_t* n_tokens_out,
                                 uint64_t chunk_bytes = 0, const ChunkHooks* hooks = nullptr) {
+    // (round 6) ... and so is a batch in which a deferred tile gave up its walk while the host was not waiting for the counters (TK_RESYNC,
+    // stage_deferred): once more, waiting -- at most one repeat of either kind.
     int rc = encode_device_pass(c, s, d_utf8, n_bytes, d_doc_off, h_doc_off, n_docs, use_special, n_tokens_out, chunk_bytes, hooks);
-    if (rc == TK_GROW) {
+    for (int again = 0; (rc == TK_GROW || rc == TK_RESYNC) && again < 2; ++again) {
         HIPCHK(hipDeviceSynchronize());  // (chunks of the abandoned pass may still be in flight on the sets' streams)
         (void)drain_events(c);
-        c->st_regrown += 1;
+        if (rc == TK_GROW) c->st_regrown += 1;
+        else c->st_resynced += 1;
         rc = encode_device_pass(c, s, d_utf8, n_bytes, d_doc_off, h_doc_off, n_docs, use_special, n_tokens_out, chunk_bytes, hooks);
-        if (rc == TK_GROW) return fail(TK_RUNTIME_ERROR, "internal error: the miss data overflowed at its largest size");
     }
+    if (rc == TK_GROW) return fail(TK_RUNTIME_ERROR, "internal error: the miss data overflowed at its largest size");
+    if (rc == TK_RESYNC) return fail(TK_RUNTIME_ERROR, "internal error: a deferred tile gave up although the host was waiting");
     return rc;
 }
 
@@ -2658,6 +2685,7 @@ extern "C" uint64_t tk_stat(tk_core* c, const char* name) {
     if (k == "small_calls") return c->st_small_calls;
     if (k == "mid_calls") return c->st_mid_calls;  // documents of 2 .. 128 KiB encoded as segments in one launch
     if (k == "back_streams") return (uint64_t)c->n_back;  // streams found to run beside the front stream (0: no multi-chunk batch yet)
+    if (k == "resynced") return c->st_resynced;  // batches repeated because a deferred tile gave up while the host was not waiting (stage_deferred)
     if (k == "regrown") return c->st_regrown;  // batches repeated with a larger miss data since the core was made (encode_device_locked)
     if (k == "workspace_bytes") {             // device memory of the work sets (everything but the text, the tables and the outputs)
         uint64_t t = 0;

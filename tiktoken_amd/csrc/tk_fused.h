@@ -596,6 +596,9 @@ __device__ __forceinline__ bool tk_equal_lds_text(const uint8_t* raw, uint32_t o
 #ifndef TKF_OCC
 #define TKF_OCC 8
 #endif
+#ifndef TKF_GIVEN_OCC
+#define TKF_GIVEN_OCC TKF_OCC  // ... of the instance that finishes the deferred tiles (round 6: its loop over the list spills 26 registers at eight per CU; at six or five it spills fewer or none and is no faster -- 0.068 ms either way, tools/gpu_r6_call6.sh)
+#endif
 #ifndef TKF_SLOW_OCC
 #define TKF_SLOW_OCC 3  // workgroups per CU of the deferred-tile variant (its grid: tk_api.hip, stage_deferred).  Round 6, on one box (tools/gpu_slowocc.sh):
                         // 3 against 4 -- C2 78.5 / 77.0 GB/s, C5 its kernel 0.168 / 0.188 ms, C3 0.40 / 0.38 ms (within the noise of the box)
@@ -620,7 +623,7 @@ __device__ unsigned long long tk_time_acc[2 * 1024 * 16];  // (spread over 1024 
 #define TKT(i) do { } while (0)
 #endif
 template <int PAT, bool SPEC, int MODE>
-__global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_OCC) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
+__global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE == TKF_MODE_GIVEN ? TKF_GIVEN_OCC : TKF_OCC)) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
                                                   const uint32_t* __restrict__ brk, const uint32_t* __restrict__ docb,
                                                   const uint32_t* __restrict__ ss, const uint32_t* __restrict__ si, TkFrontOut out,
                                                   TkMissKey* __restrict__ mt, uint32_t mt_mask, uint32_t* __restrict__ deferred,
@@ -667,22 +670,26 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
 #endif
     // SLOW: persistent, a fixed grid walks the deferred list with the stride of the grid.  Otherwise one tile per workgroup (the loop's
     // state would cost registers the kernel does not have at eight workgroups per CU).
-    constexpr bool PERSIST = SLOW;
-    const uint32_t n_items = SLOW ? out.counters[(dbg & TKF_DBG_SECOND) ? TK_CNT_DEFER2 : TK_CNT_DEFER] : gridDim.x;
+    // (round 6) GIVEN as well: the host launches it without having read the list's length (a grid from the chunk before, stage_deferred) and the grid
+    // walks the list with its stride -- an instance of its own, whose loop state costs the common instance nothing.
+    constexpr bool PERSIST = SLOW || GIVEN;
+    const uint32_t n_items = SLOW ? out.counters[(dbg & TKF_DBG_SECOND) ? TK_CNT_DEFER2 : TK_CNT_DEFER] : (GIVEN ? (uint32_t)__builtin_amdgcn_readfirstlane((int)out.counters[TK_CNT_DEFER]) : gridDim.x);
     if (PERSIST && item >= n_items) return;
     // (round 6) The deferred tiles differ a lot -- a walk back through a megabyte of one class, or nothing of the kind: 30 000 to 400 000 cycles -- and
     // there are few of them (0.75 % of the tiles of web text: 2.7 per workgroup of this grid).  With the stride of the grid the kernel lasted as long as
     // the workgroup with the three dearest; now a workgroup takes its first tile by its index and every further one from a counter.
     __shared__ uint32_t next_item_sh;
     auto next_item = [&]() -> bool {
+        if constexpr (GIVEN) {
+            item += gridDim.x;
+            return item < n_items;
+        }
         __syncthreads();
         if (tid == 0) next_item_sh = gridDim.x + atomicAdd(&out.counters[TK_CNT_SLOWQ + ((dbg & TKF_DBG_SECOND) ? 1 : 0)], 1u);
         __syncthreads();
         item = next_item_sh;
         return item < n_items;
     };
-    // (the rest of the deferred tiles where the host has not read their number: a grid of one workgroup per tile of the chunk, the list's length decides)
-    if (GIVEN && item >= out.counters[TK_CNT_DEFER]) return;
     do {
     if (PERSIST && item != blockIdx.x) __syncthreads();  // (the shared arrays are reused by the next tile)
 #ifdef TKF_TIMING
@@ -1060,6 +1067,13 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : TKF_O
     TKT(10);  // (deferred-tile instance: the walk back and the chain towards the tile)
     if (SLOW && gave_up) {  // on the second list: the tile runs again when the generic engine has split the chunk (tk_api.hip, stage_deferred)
         if (tid == 0) deferred[(n + TK_TILE - 1) / TK_TILE + 2 + atomicAdd(&out.counters[TK_CNT_DEFER2], 1u)] = (uint32_t)tile;
+        // (round 6) ... and is left without piece starts: where the host has not waited for this kernel's counters (stage_deferred) the kernels behind
+        // it run over the tile before the host learns that the batch has to be repeated -- what they read has to be a tile, if an empty one
+        if (tid < TK_TILE / 32) {
+            const uint64_t wgp = tile_start / 32 + tid;
+            if (wgp * 32 < n) out.starts[wgp] = 0u;
+        }
+        if (tid == 0) out.tile_np[tile] = (uint32_t)(tile_end - tile_start) + (uint32_t)TK2_LEFT;
         continue;
     }
     // Round 0, for all the certain starts of the tile at once: between a piece start and the next position at which a piece MAY start
@@ -2775,7 +2789,7 @@ struct TkPlaceDocs {
     uint64_t* tok_off;          // [n_docs + 1] out (null: not asked for)
 };
 template <int ROWS>
-__global__ __launch_bounds__(256) void tk_k_place(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_tb,
+__global__ __launch_bounds__(256, 6) void tk_k_place(uint64_t ntiles, const uint32_t* __restrict__ tile_np, const uint32_t* __restrict__ tile_tb,
                                                   const uint32_t* __restrict__ res, TkMiss data, const uint32_t* __restrict__ staging, uint32_t* __restrict__ out_all,
                                                   const unsigned long long* __restrict__ tok_base, uint32_t* __restrict__ big,
                                                   // (round 6) the document offsets, written here as a tile's pieces are placed: tok_off[d] = tokens before the piece
@@ -2795,7 +2809,9 @@ __global__ __launch_bounds__(256) void tk_k_place(uint64_t ntiles, const uint32_
     uint32_t* cuml = cum_sh[threadIdx.x >> 6];
     uint16_t* idxl = idx_sh[threadIdx.x >> 6];
     uint32_t* stl = stage_sh[threadIdx.x >> 6];
-    const uint64_t wave = (blockIdx.x * 256ull + threadIdx.x) >> 6, nwaves = ((uint64_t)gridDim.x * 256) >> 6;
+    // (the wavefront's index as a scalar: the tile's index, its sizes and bases and everything derived from them live in scalar registers -- with
+    // the document offsets written here the kernel had grown from 74 to 98 vector registers, from six workgroups per CU to four)
+    const uint64_t wave = (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)((blockIdx.x * 256u + threadIdx.x) >> 6)), nwaves = ((uint64_t)gridDim.x * 256) >> 6;
     uint32_t np_next = wave < ntiles ? tile_np[wave] : 0u, tb_next = wave < ntiles ? tile_tb[wave] : 0u;
     uint32_t te_next = wave + 1 < ntiles ? tile_tb[wave + 1] : 0xFFFFFFFFu;  // where the tile's tokens end (the chunk's last tile: unknown here, never staged)
     const bool want_docs = docs.tok_off != nullptr;
@@ -2813,19 +2829,19 @@ __global__ __launch_bounds__(256) void tk_k_place(uint64_t ntiles, const uint32_
         // start bitmap before it), for the first sixty-four of them before the tile's steps (a tile of web text has one or two), further ones
         // -- a tile full of tiny documents -- inside every step.  A document's offset is written by the step that holds its piece.
         const bool has_docs = dfirst != 0xFFFFFFFFu;  // (wave-uniform)
-        uint32_t sb0 = 0, sb1 = 0, spx = 0;           // the lane's two words of the start bitmap, set bits in the words before them
-        if (has_docs) {
+        const uint64_t tile_lo = t * (uint64_t)TK_TILE, tile_hi = tile_lo + TK_TILE < docs.n ? tile_lo + TK_TILE : docs.n;
+        // kp of document dfirst + 64 c + lane, or 0xFFFFFFFF when it does not start in this tile (every lane takes part: the shuffles read all lanes).
+        // The lane's two words of the start bitmap and the set bits before them are loaded where they are needed (once per tile with documents; a
+        // tile with more than sixty-four loads them again in every step) and are not carried through the tile's steps.
+        auto doc_piece = [&](uint32_t c) -> uint32_t {
+            uint32_t sb0 = 0, sb1 = 0;
             if (lane < (int)(TK_TILE / 64)) {
                 const uint2 sw = *(const uint2*)(docs.starts + t * (TK_TILE / 32) + 2u * (uint32_t)lane);
                 sb0 = sw.x;
                 sb1 = sw.y;
             }
-            const uint32_t c = (uint32_t)__popc(sb0) + (uint32_t)__popc(sb1);
-            spx = tk_wave_scan_u32(c, lane) - c;
-        }
-        const uint64_t tile_lo = t * (uint64_t)TK_TILE, tile_hi = tile_lo + TK_TILE < docs.n ? tile_lo + TK_TILE : docs.n;
-        // kp of document dfirst + 64 c + lane, or 0xFFFFFFFF when it does not start in this tile (every lane takes part: the shuffles read all lanes)
-        auto doc_piece = [&](uint32_t c) -> uint32_t {
+            const uint32_t cb = (uint32_t)__popc(sb0) + (uint32_t)__popc(sb1);
+            const uint32_t spx = tk_wave_scan_u32(cb, lane) - cb;
             const uint64_t d = (uint64_t)dfirst + 64u * c + (uint32_t)lane;
             const uint64_t pos = d < docs.n_docs ? docs.doc_off[d] - docs.chunk_base : ~0ull;
             const bool in = pos >= tile_lo && pos < tile_hi;
