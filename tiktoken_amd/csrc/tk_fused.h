@@ -622,6 +622,57 @@ __device__ unsigned long long tk_time_acc[2 * 1024 * 16];  // (spread over 1024 
 #else
 #define TKT(i) do { } while (0)
 #endif
+// (round 6, TKF_EXTEND) Where does the run of letters that reaches the end of a front-kernel window end?  One wavefront reads on from `from` (8-byte
+// aligned), eight bytes per lane and 512 per step, a class lookup per char, up to 2 KiB.  CL (cl100k): letters of any kind, ended by anything else;
+// otherwise (o200k) letters without case and marks, ended by anything but a cased letter or an apostrophe.  Returns the end relative to `from - TK2_WIN`
+// (the window's base), or 0 when the run goes on differently or for too long.  The table and bitmap pointers come from LDS (ext_sh in tk_k_front): as
+// kernel arguments kept alive up to this rare path they cost the kernel 2 % (4.38 -> 4.46 ms per GiB: 135 more reloads of spilled scalar registers in the
+// paths that every tile takes); a call instead of inlined code changed nothing.
+template <bool CL>
+__device__ __forceinline__ uint32_t tk_extend_letter_run(const uint8_t* __restrict__ uc_bmp, const uint8_t* __restrict__ uc_stage1, const uint8_t* __restrict__ uc_stage2, const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ brk, uint64_t from, int lane) {
+    constexpr uint32_t SET = CL ? TK_M_L : (TK_CB(TK_C_LC) | TK_CB(TK_C_MK));
+    constexpr uint32_t GOES_ON = CL ? 0u : (TK_CB(TK_C_LU) | TK_CB(TK_C_LL) | TK_CB(TK_C_AP));
+    auto cls_cp = [&](uint32_t cpt) -> uint32_t {
+        uint32_t cl = uc_bmp[cpt < 0x10000u ? cpt : 0xFFFFu];
+        if (cpt >= 0x10000u && cpt <= 0x10FFFFu) cl = uc_stage2[(uint32_t)uc_stage1[cpt >> 8] * 256u + (cpt & 255u)];
+        return cl;
+    };
+    for (uint32_t it = 0; it < 4u; ++it) {
+        const uint64_t g = from + 512u * it + 8u * (uint32_t)lane;
+        uint32_t d0 = 0, d1 = 0, d2 = 0, hb = 0;
+        if (g < n) {  // (the text is readable 64 bytes past its end)
+            const uint2 v = *(const uint2*)(text + g);
+            d0 = v.x;
+            d1 = v.y;
+            d2 = *(const uint32_t*)(text + g + 8);
+            hb = (brk[g >> 5] >> (g & 31u)) & 0xFFu;  // hard starts (documents, special tokens) among the eight positions
+        }
+        uint32_t bad = 8u, badc = 0u;
+#pragma unroll
+        for (int j = 7; j >= 0; --j) {
+            const uint32_t four = j == 0 ? d0 : (j < 4 ? __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)j) : (j == 4 ? d1 : __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)(j - 4))));
+            const uint32_t b0 = four & 0xFFu;
+            uint32_t ln;
+            const uint32_t cpt = b0 < 0x80u ? b0 : tk_utf8_cp(four, &ln);
+            uint32_t cl = cls_cp((b0 & 0xC0u) == 0x80u ? 0u : cpt);
+            if (g + (uint32_t)j >= n || ((hb >> j) & 1u)) cl = TK_C_END;
+            if ((b0 & 0xC0u) != 0x80u || g + (uint32_t)j >= n) {  // a char start (or the end of the text)
+                if (!((SET >> cl) & 1u)) {
+                    bad = (uint32_t)j;
+                    badc = cl;
+                }
+            }
+        }
+        const uint64_t m = __ballot(bad < 8u);
+        if (m) {
+            const int l2 = __ffsll((unsigned long long)m) - 1;
+            const uint32_t bj = (uint32_t)__shfl((int)bad, l2, 64), bc = (uint32_t)__shfl((int)badc, l2, 64);
+            if ((GOES_ON >> bc) & 1u) return 0u;
+            return (uint32_t)TK2_WIN + 512u * it + 8u * (uint32_t)l2 + bj;
+        }
+    }
+    return 0u;
+}
 template <int PAT, bool SPEC, int MODE>
 __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE == TKF_MODE_GIVEN ? TKF_GIVEN_OCC : TKF_OCC)) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
                                                   const uint32_t* __restrict__ brk, const uint32_t* __restrict__ docb,
@@ -654,6 +705,9 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
     // phase C reads each lane's 16 bits from global memory, phase F finds the starts of special tokens in `brkw`, reloaded in phase E)
     __shared__ uint32_t brkw[TK2_WIN / 32 + 1];
     __shared__ uint32_t scan_sh[8];
+    // (TKF_EXTEND) four pointers the rare way out of "a piece leaves the window" needs, parked in LDS by phase A: kept in scalar registers up to that point
+    // of the kernel they made it spill 135 more scalar reloads into the paths that every tile takes (4.38 -> 4.46 ms per GiB)
+    __shared__ uint64_t ext_sh[4];
     uint64_t(*bm)[NW] = (uint64_t(*)[NW])pool;
     uint8_t* lastc = lastc_own;
     // From phase C on the byte table is dead in the one-tile-per-workgroup variant: its 2 KiB hold the "stop" bitmap of the scanners'
@@ -662,7 +716,10 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
     uint16_t* stop16 = SLOW ? stop_own : (uint16_t*)btab;          // [256] char starts at which a piece may start (16 per lane)
     uint16_t* contl = SLOW ? contl_own : (uint16_t*)btab + 256;    // [CONT_CAP] scan chains still to be walked (window positions)
     const uint32_t tid = threadIdx.x;
-    const int lane = tid & 63, wid = tid >> 6;
+#ifndef TKF_SCALAR_WID
+#define TKF_SCALAR_WID 1
+#endif
+    const int lane = tid & 63, wid = TKF_SCALAR_WID ? __builtin_amdgcn_readfirstlane((int)(tid >> 6)) : (int)(tid >> 6);
     uint32_t item = blockIdx.x;
 #ifdef TKF_TIMING
     unsigned long long tkt_prev = __builtin_readcyclecounter();
@@ -742,6 +799,12 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
         brkw[tid] = in ? brk[wgp >> 5] : 0u;
     }
     if (tid == 0) {
+        if (!SLOW && !GIVEN) {
+            ext_sh[0] = (uint64_t)(uintptr_t)brk;
+            ext_sh[1] = (uint64_t)(uintptr_t)T.uc_bmp;
+            ext_sh[2] = (uint64_t)(uintptr_t)T.uc_stage1;
+            ext_sh[3] = (uint64_t)(uintptr_t)T.uc_stage2;
+        }
         need_walk = 0;
         ncont_sh = 0;
         nslow_sh = 0;
@@ -903,13 +966,66 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
         const uint64_t lm = __ballot(cert != 0u) & ((1ull << T0) - 1ull);
         const int ll = lm ? 63 - __clzll((long long)lm) : 0;
         const uint32_t lc = (uint32_t)__shfl((int)cert, ll, 64);
+        bool walk = false;
         if (tid == T0 && tile_start > 0 && tile_start < n) {
             const bool first_cert = mk.text && ((cert >> (__ffs((int)mk.text) - 1)) & 1u);
             if (!first_cert) {
                 if (lm) extra = (uint32_t)ll * 16u + 31u - (uint32_t)__clz((int)lc);
-                else need_walk = 1;
+                else walk = true;
             }
         }
+#ifndef TKF_SYNC_POINTS
+#define TKF_SYNC_POINTS 1
+#endif
+        if constexpr (TKF_SYNC_POINTS && (PAT == TK_PAT_O200K || PAT == TK_PAT_CL100K) && !SLOW) {
+            // (round 6) No certain start in the left context -- the inside of a sentence of a script without spaces (a piece of 120 to 1000 bytes: half of the
+            // tiles that went to the workgroup-wide scanner on web text).  A scan does not need a piece START to be in phase with the sequential regex, only a
+            // position at which the matcher's state is known: a lower-case letter (LL) that follows a letter of class LL or LC, with no apostrophe in the three
+            // bytes before it, is INSIDE a piece of the letter alternatives (no alternative ends between two such letters except behind a contraction), and
+            // behind it the matcher is in the alternative's lower-case part -- exactly where a match that starts AT that letter is after its first char (the
+            // optional prefix cannot take a letter, the upper-case part takes nothing): the piece ends where a scan from there ends.  A letter without case (LC,
+            // in both parts) leaves one ambiguity -- an upper-case letter right behind the run of LC / mark chars that starts at it goes on in the upper-case
+            // part and ends the lower-case one -- so it qualifies when that run ends inside the window and not at an upper-case letter.  The chain from such a
+            // position records only true boundaries (its own start lies left of the tile).  Checked on 64 MiB of the bench corpus: 35.7 M such positions, the
+            // scan from every one ends where its piece ends (tools/experiments/sync_points.cpp); 78 of the 84 tiles per 17 475 without a certain start have one.
+            if (__ballot(walk) != 0ull) {  // (wave-uniform and rare: 0.5 % of the tiles)
+                uint32_t s_ll = 0u, s_lc = 0u;
+                if (tid < T0) {
+                    if constexpr (PAT == TK_PAT_CL100K) {  // (cl100k: `\p{L}++` -- any letter behind a letter is inside it, and a scan from it ends where the run ends)
+                        s_ll = tk_prev_set(st.l, TK_M_L, prevc) & mk.text & ~near & st.l;
+                    } else {
+                        const uint32_t after_letter = tk_prev_set(st.ll | st.lc, TK_CB(TK_C_LL) | TK_CB(TK_C_LC), prevc) & mk.text & ~near;
+                        s_ll = after_letter & st.ll;
+                        s_lc = after_letter & st.lc;
+                    }
+                }
+                uint32_t at = TKF_NONE;
+                const uint64_t b_ll = __ballot(s_ll != 0u), b_lc = __ballot(s_lc != 0u);
+                if (b_ll) {
+                    const int l2 = 63 - __clzll((long long)b_ll);
+                    at = (uint32_t)l2 * 16u + 31u - (uint32_t)__clz((int)(uint32_t)__shfl((int)s_ll, l2, 64));
+                } else if (b_lc) {
+                    const int l2 = 63 - __clzll((long long)b_lc);
+                    const uint32_t sp = (uint32_t)l2 * 16u + 31u - (uint32_t)__clz((int)(uint32_t)__shfl((int)s_lc, l2, 64));
+                    // the end of the run of LC / mark bytes from there (the bitmaps are in LDS since the barrier above)
+                    uint32_t j = (uint32_t)TK2_WIN;
+                    for (uint32_t wq = sp >> 6; wq < (uint32_t)TK2_NSEG; ++wq) {
+                        uint64_t v = ~bm[TKB_CAS][wq];
+                        if (wq == (sp >> 6)) v &= ~0ull << (sp & 63u);
+                        if (v) {
+                            j = wq * 64u + (uint32_t)__ffsll((unsigned long long)v) - 1u;
+                            break;
+                        }
+                    }
+                    if (j < (uint32_t)TK2_WIN && !((bm[TKB_UP][j >> 6] >> (j & 63u)) & 1ull)) at = sp;  // (UP and not CAS: an upper-case letter)
+                }
+                if (walk && at != TKF_NONE) {
+                    extra = at;
+                    walk = false;
+                }
+            }
+        }
+        if (walk) need_walk = 1;
     }
     __syncthreads();
     if (!SLOW && need_walk) {  // no certain start in the left context: a tile for the workgroup-wide scanner
@@ -978,10 +1094,8 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
             e = tk_piece_end_slow(&acc, p, pat);  // byte walk inside the window
             if (acc.left) {
                 const uint32_t at = atomicAdd(&nslow_sh, 1u);
-                if (SLOW) {
-                    if (at < TKF_SLOW_CAP) slowl[at] = (uint16_t)r;
-                    else atomicOr(&out.counters[TK_CNT_ERR], 1u);  // (cannot happen: at most two pieces of a tile can leave its window)
-                }
+                if (at < TKF_SLOW_CAP) slowl[at] = (uint16_t)r;
+                else if (SLOW) atomicOr(&out.counters[TK_CNT_ERR], 1u);  // (cannot happen: at most two pieces of a tile can leave its window)
                 return TKF_CHAIN_END;
             }
         }
@@ -1183,8 +1297,52 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
         if (cont_now == cont_done) break;
     }
     if (!SLOW && nslow_sh) {
-        defer_tile();
-        continue;
+#ifndef TKF_EXTEND
+#define TKF_EXTEND 1
+#endif
+        // (round 6) A piece leaves the window.  The other half of the tiles that went to the workgroup-wide scanner on web text: a sentence of a script without
+        // spaces (120 to 1000 bytes, one piece) that starts near the tile's end.  Everything else about the tile is known -- what is missing is where that piece
+        // ends, and for a letter piece that runs into the window's end inside a run of letters of ONE kind that is the end of the run: cl100k (`\p{L}++`) any
+        // letters, ended by whatever is not a letter; o200k letters without case and marks (LC, MK: in the upper-case AND the lower-case part of its
+        // alternatives, so the matcher's state does not matter), ended by anything but a cased letter or an apostrophe (those go on: the tile is deferred as
+        // before).  One wavefront reads on from the window's end, eight bytes per lane and 512 per step, a class lookup per char, up to 2 KiB.  The piece must
+        // be a letter piece: it starts with a letter, or with one char of a prefix class whose next char is a letter.  Checked on the bench corpora
+        // (tools/experiments/extend_piece.cpp): applies to 68 of 78 such tiles per 17 474 (o200k web text) and 23 of 23 (cl100k mixed text), right every time.
+        bool extended = false;
+        if constexpr (TKF_EXTEND && (PAT == TK_PAT_O200K || PAT == TK_PAT_CL100K)) {
+            constexpr bool CL = PAT == TK_PAT_CL100K;
+            constexpr uint32_t SET = CL ? TK_M_L : (TK_CB(TK_C_LC) | TK_CB(TK_C_MK));
+            constexpr uint32_t LETTER = CL ? TK_M_L : (TK_M_L | TK_CB(TK_C_MK));
+            constexpr uint32_t PREFIX = TK_CB(TK_C_SP) | TK_CB(TK_C_WSO) | TK_CB(TK_C_SL) | TK_CB(TK_C_OT) | (CL ? TK_CB(TK_C_MK) : 0u);
+            constexpr uint32_t GOES_ON = CL ? 0u : (TK_CB(TK_C_LU) | TK_CB(TK_C_LL) | TK_CB(TK_C_AP));
+            if (wid == 0) {
+                uint32_t end_rel = 0u;  // the piece's end, relative to the window's base (0: the rule does not apply)
+                const uint32_t* st32 = (const uint32_t*)bm[TKB_START];
+                const uint32_t r = slowl[0];
+                const uint32_t lastw = st32[TK2_WIN / 32 - 1];
+                bool ok = nslow_sh == 1u && lastw != 0u && (uint64_t)(base + TK2_WIN) < n;
+                if (ok) {
+                    const uint32_t cp = tk_class_at_lds(planes32, r);
+                    uint32_t x = (st32[r >> 5] >> (r & 31u)) >> 1;
+                    const uint32_t nx = x ? r + (uint32_t)__ffs((int)x) : ((r >> 5) + 1u) * 32u + (uint32_t)__ffs((int)st32[(r >> 5) + 1u]) - 1u;  // the next char start
+                    const uint32_t cn = nx < (uint32_t)TK2_WIN ? tk_class_at_lds(planes32, nx) : 0u;
+                    const bool hard_nx = nx < (uint32_t)TK2_WIN && ((((const uint32_t*)bm[TKB_HARD])[nx >> 5] >> (nx & 31u)) & 1u);
+                    const uint32_t lastc = tk_class_at_lds(planes32, (uint32_t)TK2_WIN - 32u + 31u - (uint32_t)__clz((int)lastw));
+                    ok = (((LETTER >> cp) & 1u) || (((PREFIX >> cp) & 1u) && ((LETTER >> cn) & 1u) && !hard_nx)) && ((SET >> lastc) & 1u);
+                }
+                if (ok) end_rel = tk_extend_letter_run<CL>((const uint8_t*)(uintptr_t)ext_sh[1], (const uint8_t*)(uintptr_t)ext_sh[2], (const uint8_t*)(uintptr_t)ext_sh[3], text, n, (const uint32_t*)(uintptr_t)ext_sh[0], (uint64_t)(base + TK2_WIN), lane);
+                if (lane == 0) {
+                    scan_sh[0] = end_rel;
+                    if (end_rel) last_end_sh = end_rel;
+                }
+            }
+            __syncthreads();
+            extended = scan_sh[0] != 0u;
+        }
+        if (!extended) {
+            defer_tile();
+            continue;
+        }
     }
     }
     TKT(3);
