@@ -427,6 +427,40 @@ def test_ten_megabytes_without_a_certain_start_take_the_generic_way():
         assert np.array_equal(toff, ro) and np.array_equal(toks, rt), allowed
 
 
+def test_letter_runs_around_tile_ends(cores):
+    """Round 6, tk_fused.h: a tile whose left context holds no certain start begins its scan at a position where the matcher's state is known (a letter
+    behind a letter, TKF_SYNC_POINTS), and a letter run that leaves a tile's window is read on to its end (TKF_EXTEND) -- unless what ends the run lets
+    the piece go on (o200k: a cased letter, an apostrophe), more than 2 KiB follow, or the run is not of the kind the rule is about: then the tile goes to
+    the workgroup-wide scanner as before.  Runs of every such kind and ending, at every offset against the tiles' ends (3840 bytes), documents and special
+    tokens inside them; every token compared with the oracle."""
+    runs = ["\u5b57", "\u0e01\u0e31", "\u3042\u30a2\u4e9c", "x", "X", "xY", "\u00e9", "\u0416", "\u5b57x", "x\u0301", "a\u5b57", "\u5b57A"]
+    ends = ["", " ", "A", "Ab", "a", "'s", "'ll ", "'S", "\u2019s", "1", "12345", "\n", "\r\n\n", "\u3002", "\u0301", ".", "/", "'", "''", " '", "\t", "\u00a0", "\u017f", "'\u017f"]
+    for name in h.ENCODING_NAMES:
+        core, C = cores[name], h.c_oracle_for(name)
+        specials = h.load_golden(name)["special_tokens"]
+        docs, k = [], 0
+        for unit in runs:
+            for reps in (45, 130, 400, 900, 3000):
+                for end in ends:
+                    k += 1
+                    pad = "the quick brown fox " * (k % 7) + "a" * (k % 13) + " "
+                    body = unit * (reps // max(1, len(unit.encode()) // 3 or 1)) + end + unit * (k % 5) + " tail"
+                    if k % 11 == 0:
+                        body = body[: len(body) // 2] + "<|endoftext|>" + body[len(body) // 2:]
+                    docs.append((pad + body).encode())
+                    if k % 17 == 0:  # the same run split by a document boundary: the run ends with the document
+                        docs.append((unit * reps).encode())
+        blob, off = h.pack(docs)
+        assert len(blob) > (1 << 20)
+        for allowed in (None, "all"):
+            toks, toff = core.encode_batch_packed(blob, off, allowed)
+            rt, ro = C.encode_batch(blob, off, None if allowed is None else set(specials), 8)
+            assert np.array_equal(toff, ro) and np.array_equal(toks, rt), (name, allowed)
+        # one document: the runs follow each other without a hard start between them
+        one = b" ".join(docs[::3])
+        assert np.array_equal(core._encode_np(one, None), C.encode_ordinary(one)), name
+
+
 def test_a_tile_that_gives_up_while_the_host_is_not_waiting_repeats_the_batch():
     """Round 6: the host no longer waits for the deferred tiles' counters between the two kernels (tk_api.hip, stage_deferred).  A core's first
     batch with a stretch that makes a tile give up runs to its end on what the kernels had (the tiles that gave up: empty), is found out by

@@ -708,6 +708,12 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
     // (TKF_EXTEND) four pointers the rare way out of "a piece leaves the window" needs, parked in LDS by phase A: kept in scalar registers up to that point
     // of the kernel they made it spill 135 more scalar reloads into the paths that every tile takes (4.38 -> 4.46 ms per GiB)
     __shared__ uint64_t ext_sh[4];
+#ifndef TKF_PARK_ARGS
+#define TKF_PARK_ARGS 1
+#endif
+    // (experiment, round 6) what only phases E and F need of the kernel's arguments, parked in LDS by phase A and read back where phase E begins: kept in scalar
+    // registers from the kernel's first instruction they are part of the 150 scalar values the kernel spills into vector-register lanes
+    __shared__ uint64_t park_sh[TKF_PARK_ARGS ? 18 : 1];
     uint64_t(*bm)[NW] = (uint64_t(*)[NW])pool;
     uint8_t* lastc = lastc_own;
     // From phase C on the byte table is dead in the one-tile-per-workgroup variant: its 2 KiB hold the "stop" bitmap of the scanners'
@@ -804,6 +810,25 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
             ext_sh[1] = (uint64_t)(uintptr_t)T.uc_bmp;
             ext_sh[2] = (uint64_t)(uintptr_t)T.uc_stage1;
             ext_sh[3] = (uint64_t)(uintptr_t)T.uc_stage2;
+        }
+        if (TKF_PARK_ARGS && !SLOW) {
+            park_sh[0] = (uint64_t)(uintptr_t)T.short_tab;
+            park_sh[1] = (uint64_t)(uintptr_t)T.mid_tab;
+            park_sh[2] = (uint64_t)(uintptr_t)T.xl;
+            park_sh[3] = (uint64_t)(uintptr_t)T.tok_bytes;
+            park_sh[4] = (uint64_t)(uintptr_t)mt;
+            park_sh[5] = (uint64_t)(uintptr_t)out.res;
+            park_sh[6] = (uint64_t)(uintptr_t)out.data.tab;
+            park_sh[7] = (uint64_t)(uintptr_t)out.data.ovf;
+            park_sh[8] = (uint64_t)(uintptr_t)out.listC;
+            park_sh[9] = (uint64_t)T.short_mask | ((uint64_t)T.short_shift << 32);
+            park_sh[10] = (uint64_t)T.mid_mask | ((uint64_t)T.mid_shift << 32);
+            park_sh[11] = (uint64_t)T.xl_mask | ((uint64_t)T.max_token_len << 32);
+            park_sh[12] = (uint64_t)mt_mask | ((uint64_t)out.data.ovf_base << 32);
+            park_sh[13] = (uint64_t)out.ovf_cap;
+            park_sh[14] = (uint64_t)(uintptr_t)T.piece;  // (the probe of a piece of more than TK_XL_MAX bytes where there is no in-call table: small chunks)
+            park_sh[15] = (uint64_t)(uintptr_t)T.piece_off;
+            park_sh[16] = T.piece_mask;
         }
         need_walk = 0;
         ncont_sh = 0;
@@ -1369,6 +1394,47 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
     // zeros where the row needs it), beside it the piece's index k in the tile (its result word is res[run + k]).
     constexpr uint32_t NWB = (uint32_t)TK_TILE / 32u;  // words of the tile's bitmap (even)
     const uint32_t run_base = (uint32_t)tile * TKF_CAP;
+#if TKF_PARK_ARGS
+    // (the names of the kernel's arguments, shadowed by what was parked: the code below reads as before)
+    auto unpark = [&](int i) -> uint64_t {
+        const uint64_t v = park_sh[i];
+        return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
+    };
+    TkTables T_f{};
+    TkFrontOut out_f{};
+    TkMissKey* __restrict__ mt_f = nullptr;
+    uint32_t mt_mask_f = 0;
+    if constexpr (!SLOW) {
+        T_f.short_tab = (const TkShortSlot*)(uintptr_t)unpark(0);
+        T_f.mid_tab = (const TkPieceSlot*)(uintptr_t)unpark(1);
+        T_f.xl = (const TkXlSlot*)(uintptr_t)unpark(2);
+        T_f.tok_bytes = (const uint8_t*)(uintptr_t)unpark(3);
+        mt_f = (TkMissKey*)(uintptr_t)unpark(4);
+        out_f.res = (uint32_t*)(uintptr_t)unpark(5);
+        out_f.data.tab = (TkMissTab*)(uintptr_t)unpark(6);
+        out_f.data.ovf = (TkMissOvf*)(uintptr_t)unpark(7);
+        out_f.listC = (uint32_t*)(uintptr_t)unpark(8);
+        const uint64_t a = unpark(9), b = unpark(10), c = unpark(11), d = unpark(12);
+        T_f.short_mask = (uint32_t)a; T_f.short_shift = (uint32_t)(a >> 32);
+        T_f.mid_mask = (uint32_t)b; T_f.mid_shift = (uint32_t)(b >> 32);
+        T_f.xl_mask = (uint32_t)c; T_f.max_token_len = (uint32_t)(c >> 32);
+        mt_mask_f = (uint32_t)d; out_f.data.ovf_base = (uint32_t)(d >> 32);
+        out_f.ovf_cap = (uint32_t)unpark(13);
+        T_f.piece = (const TkPieceSlot*)(uintptr_t)unpark(14);
+        T_f.piece_off = (const uint32_t*)(uintptr_t)unpark(15);
+        T_f.piece_mask = unpark(16);
+        out_f.starts = out.starts; out_f.tile_np = out.tile_np; out_f.counters = out.counters;
+        if constexpr (SPEC) {  // (the instances with allowed special tokens look their ids up here: tk_special_id)
+            T_f.n_spec = T.n_spec; T_f.spec_bytes = T.spec_bytes; T_f.spec_id = T.spec_id; T_f.spec_off = T.spec_off;
+        }
+    }
+    const TkTables& T_outer = T;
+    (void)T_outer;
+    const TkTables& T = T_f;
+    const TkFrontOut& out = out_f;
+    TkMissKey* __restrict__ mt = mt_f;
+    const uint32_t mt_mask = mt_mask_f;
+#endif
     uint32_t* bx = certw;                            // [128] the start bitmap once more, plus the END of the tile's last piece (the certain starts are dead)
     uint16_t* ord_sl = (uint16_t*)btab;              // [1024] short pieces from the front, long ones from the back: window positions (the byte table is dead)
     uint16_t* ord_m = (uint16_t*)planes;             // [1024] mid pieces (the planes are dead)
