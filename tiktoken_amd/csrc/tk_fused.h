@@ -1339,7 +1339,6 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
             constexpr uint32_t SET = CL ? TK_M_L : (TK_CB(TK_C_LC) | TK_CB(TK_C_MK));
             constexpr uint32_t LETTER = CL ? TK_M_L : (TK_M_L | TK_CB(TK_C_MK));
             constexpr uint32_t PREFIX = TK_CB(TK_C_SP) | TK_CB(TK_C_WSO) | TK_CB(TK_C_SL) | TK_CB(TK_C_OT) | (CL ? TK_CB(TK_C_MK) : 0u);
-            constexpr uint32_t GOES_ON = CL ? 0u : (TK_CB(TK_C_LU) | TK_CB(TK_C_LL) | TK_CB(TK_C_AP));
             if (wid == 0) {
                 uint32_t end_rel = 0u;  // the piece's end, relative to the window's base (0: the rule does not apply)
                 const uint32_t* st32 = (const uint32_t*)bm[TKB_START];
