@@ -629,9 +629,11 @@ __device__ unsigned long long tk_time_acc[2 * 1024 * 16];  // (spread over 1024 
 // kernel arguments kept alive up to this rare path they cost the kernel 2 % (4.38 -> 4.46 ms per GiB: 135 more reloads of spilled scalar registers in the
 // paths that every tile takes); a call instead of inlined code changed nothing.
 template <bool CL>
-__device__ __forceinline__ uint32_t tk_extend_letter_run(const uint8_t* __restrict__ uc_bmp, const uint8_t* __restrict__ uc_stage1, const uint8_t* __restrict__ uc_stage2, const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ brk, uint64_t from, int lane) {
-    constexpr uint32_t SET = CL ? TK_M_L : (TK_CB(TK_C_LC) | TK_CB(TK_C_MK));
-    constexpr uint32_t GOES_ON = CL ? 0u : (TK_CB(TK_C_LU) | TK_CB(TK_C_LL) | TK_CB(TK_C_AP));
+__device__ __forceinline__ uint32_t tk_extend_letter_run(const uint8_t* __restrict__ uc_bmp, const uint8_t* __restrict__ uc_stage1, const uint8_t* __restrict__ uc_stage2, const uint8_t* __restrict__ text, uint64_t n, const uint32_t* __restrict__ brk, uint64_t from, int lane, bool seen_ll) {
+    // (o200k: the run may go on with lower-case letters, LL.  From the first of them on the matcher is in the alternative's lower-case part, where an upper-case
+    // letter ENDS the piece; before it -- LC and MK are in both parts, the state is not known -- an upper-case letter lets the piece go on: not decided here.
+    // seen_ll: the window's last char was one.)
+    constexpr uint32_t SET = CL ? TK_M_L : (TK_CB(TK_C_LC) | TK_CB(TK_C_MK) | TK_CB(TK_C_LL));
     auto cls_cp = [&](uint32_t cpt) -> uint32_t {
         uint32_t cl = uc_bmp[cpt < 0x10000u ? cpt : 0xFFFFu];
         if (cpt >= 0x10000u && cpt <= 0x10FFFFu) cl = uc_stage2[(uint32_t)uc_stage1[cpt >> 8] * 256u + (cpt & 255u)];
@@ -647,7 +649,7 @@ __device__ __forceinline__ uint32_t tk_extend_letter_run(const uint8_t* __restri
             d2 = *(const uint32_t*)(text + g + 8);
             hb = (brk[g >> 5] >> (g & 31u)) & 0xFFu;  // hard starts (documents, special tokens) among the eight positions
         }
-        uint32_t bad = 8u, badc = 0u;
+        uint32_t bad = 8u, badc = 0u, llm = 0u;  // (llm: the lane's char starts of class LL)
 #pragma unroll
         for (int j = 7; j >= 0; --j) {
             const uint32_t four = j == 0 ? d0 : (j < 4 ? __builtin_amdgcn_alignbyte(d1, d0, (uint32_t)j) : (j == 4 ? d1 : __builtin_amdgcn_alignbyte(d2, d1, (uint32_t)(j - 4))));
@@ -661,15 +663,23 @@ __device__ __forceinline__ uint32_t tk_extend_letter_run(const uint8_t* __restri
                     bad = (uint32_t)j;
                     badc = cl;
                 }
+                if (!CL && cl == (uint32_t)TK_C_LL) llm |= 1u << j;
             }
         }
         const uint64_t m = __ballot(bad < 8u);
         if (m) {
             const int l2 = __ffsll((unsigned long long)m) - 1;
             const uint32_t bj = (uint32_t)__shfl((int)bad, l2, 64), bc = (uint32_t)__shfl((int)badc, l2, 64);
-            if ((GOES_ON >> bc) & 1u) return 0u;
+            if constexpr (!CL) {
+                if (bc == (uint32_t)TK_C_AP) return 0u;  // (a contraction may follow)
+                if (bc == (uint32_t)TK_C_LU) {
+                    const bool before = lane < l2 ? llm != 0u : (lane == l2 && (llm & ((1u << bj) - 1u)) != 0u);
+                    if (!seen_ll && __ballot(before) == 0ull) return 0u;
+                }
+            }
             return (uint32_t)TK2_WIN + 512u * it + 8u * (uint32_t)l2 + bj;
         }
+        if (!CL && __ballot(llm != 0u) != 0ull) seen_ll = true;
     }
     return 0u;
 }
@@ -1042,7 +1052,8 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
                             break;
                         }
                     }
-                    if (j < (uint32_t)TK2_WIN && !((bm[TKB_UP][j >> 6] >> (j & 63u)) & 1ull)) at = sp;  // (UP and not CAS: an upper-case letter)
+                    // (UP and not CAS: an upper-case letter.  A run that reaches the window's end is a piece that leaves the window: decided there, below)
+                    if (j >= (uint32_t)TK2_WIN || !((bm[TKB_UP][j >> 6] >> (j & 63u)) & 1ull)) at = sp;
                 }
                 if (walk && at != TKF_NONE) {
                     extra = at;
@@ -1329,14 +1340,16 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
         // spaces (120 to 1000 bytes, one piece) that starts near the tile's end.  Everything else about the tile is known -- what is missing is where that piece
         // ends, and for a letter piece that runs into the window's end inside a run of letters of ONE kind that is the end of the run: cl100k (`\p{L}++`) any
         // letters, ended by whatever is not a letter; o200k letters without case and marks (LC, MK: in the upper-case AND the lower-case part of its
-        // alternatives, so the matcher's state does not matter), ended by anything but a cased letter or an apostrophe (those go on: the tile is deferred as
-        // before).  One wavefront reads on from the window's end, eight bytes per lane and 512 per step, a class lookup per char, up to 2 KiB.  The piece must
-        // be a letter piece: it starts with a letter, or with one char of a prefix class whose next char is a letter.  Checked on the bench corpora
-        // (tools/experiments/extend_piece.cpp): applies to 68 of 78 such tiles per 17 474 (o200k web text) and 23 of 23 (cl100k mixed text), right every time.
+        // alternatives, so the matcher's state does not matter) and lower-case letters (LL: from the first of them on the matcher is in the lower-case part),
+        // ended by anything but an apostrophe (a contraction may follow) or an upper-case letter before the first lower-case one (the piece may go on): then
+        // the tile is deferred as before.  One wavefront reads on from the window's end, eight bytes per lane and 512 per step, a class lookup per char, up to
+        // 2 KiB.  The piece must be a letter piece: it starts with a letter, or with one char of a prefix class whose next char is a letter.  Checked on the
+        // bench corpora (tools/experiments/extend_piece.cpp): applies to 78 of 78 such tiles per 17 474 (o200k web text) and 23 of 23 (cl100k mixed text), right
+        // every time.
         bool extended = false;
         if constexpr (TKF_EXTEND && (PAT == TK_PAT_O200K || PAT == TK_PAT_CL100K)) {
             constexpr bool CL = PAT == TK_PAT_CL100K;
-            constexpr uint32_t SET = CL ? TK_M_L : (TK_CB(TK_C_LC) | TK_CB(TK_C_MK));
+            constexpr uint32_t SET = CL ? TK_M_L : (TK_CB(TK_C_LC) | TK_CB(TK_C_MK) | TK_CB(TK_C_LL));
             constexpr uint32_t LETTER = CL ? TK_M_L : (TK_M_L | TK_CB(TK_C_MK));
             constexpr uint32_t PREFIX = TK_CB(TK_C_SP) | TK_CB(TK_C_WSO) | TK_CB(TK_C_SL) | TK_CB(TK_C_OT) | (CL ? TK_CB(TK_C_MK) : 0u);
             if (wid == 0) {
@@ -1345,6 +1358,7 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
                 const uint32_t r = slowl[0];
                 const uint32_t lastw = st32[TK2_WIN / 32 - 1];
                 bool ok = nslow_sh == 1u && lastw != 0u && (uint64_t)(base + TK2_WIN) < n;
+                bool last_ll = false;
                 if (ok) {
                     const uint32_t cp = tk_class_at_lds(planes32, r);
                     uint32_t x = (st32[r >> 5] >> (r & 31u)) >> 1;
@@ -1353,8 +1367,9 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
                     const bool hard_nx = nx < (uint32_t)TK2_WIN && ((((const uint32_t*)bm[TKB_HARD])[nx >> 5] >> (nx & 31u)) & 1u);
                     const uint32_t lastc = tk_class_at_lds(planes32, (uint32_t)TK2_WIN - 32u + 31u - (uint32_t)__clz((int)lastw));
                     ok = (((LETTER >> cp) & 1u) || (((PREFIX >> cp) & 1u) && ((LETTER >> cn) & 1u) && !hard_nx)) && ((SET >> lastc) & 1u);
+                    last_ll = !CL && lastc == (uint32_t)TK_C_LL;
                 }
-                if (ok) end_rel = tk_extend_letter_run<CL>((const uint8_t*)(uintptr_t)ext_sh[1], (const uint8_t*)(uintptr_t)ext_sh[2], (const uint8_t*)(uintptr_t)ext_sh[3], text, n, (const uint32_t*)(uintptr_t)ext_sh[0], (uint64_t)(base + TK2_WIN), lane);
+                if (ok) end_rel = tk_extend_letter_run<CL>((const uint8_t*)(uintptr_t)ext_sh[1], (const uint8_t*)(uintptr_t)ext_sh[2], (const uint8_t*)(uintptr_t)ext_sh[3], text, n, (const uint32_t*)(uintptr_t)ext_sh[0], (uint64_t)(base + TK2_WIN), lane, last_ll);
                 if (lane == 0) {
                     scan_sh[0] = end_rel;
                     if (end_rel) last_end_sh = end_rel;
