@@ -716,7 +716,14 @@ static int stage_deferred(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s) 
         TkFrontOut fo{w.starts.as<uint32_t>(), w.tile_np.as<uint32_t>(), w.res.as<uint32_t>(), w.tile_sum.as<uint8_t>(), miss_of(w, job), job.ovf_cap,
                       w.listC.as<uint32_t>(), w.counters.as<uint32_t>()};
         uint32_t *ss = job.spec ? w.ss.as<uint32_t>() : nullptr, *si = job.spec ? w.si.as<uint32_t>() : nullptr, *docb = job.spec ? w.docb.as<uint32_t>() : nullptr;
-        const uint32_t slow_wgs = 256u * TKF_SLOW_OCC;
+        // (the grid: what is resident -- or, where the host does not wait for the counters, as many workgroups as the chunks before had deferred tiles (at
+        // least 64: they take their tiles from a counter).  On ordinary text no tile is deferred since round 6, and an empty grid of 768 such workgroups
+        // -- 168 registers, 37 KiB of LDS, scratch -- costs 12.6 us against the 7 of 64.)
+        const uint64_t defer_guess = ((job.ntiles * (uint64_t)c->defer_ppm) >> 20) * 5 / 4 + 64;
+        const bool sync_now = can_fall_back && (c->defer_sync || job.pretok);  // ($TIKTOKEN_AMD_DEFER_SYNC=1: from the start; the piece-offsets entry has no chunk_finish)
+        job.optimistic = can_fall_back && !sync_now;
+        uint64_t slow_wgs = 256u * TKF_SLOW_OCC;
+        if (job.optimistic && defer_guess < slow_wgs) slow_wgs = defer_guess;
         const dim3 grid((uint32_t)(job.ntiles < slow_wgs ? job.ntiles : slow_wgs));
         const int pat_id = T.pat.generic() ? TK_PAT_GENERIC : T.pattern;
         TkMissKey* mt_arg = (c->dbg & 256) ? (TkMissKey*)nullptr : job.mt;
@@ -736,12 +743,7 @@ static int stage_deferred(tk_core* c, WorkSet& w, ChunkJob& job, hipStream_t s) 
         // finishes the deferred tiles walks the list with a grid sized from the chunk before (the same kind of text: a quarter more than it needed),
         // and chunk_finish looks at the counter of tiles that gave up: if there is one the batch is repeated (encode_device_locked) and the core waits
         // here from then on (c->defer_sync), as it did up to round 5.  Small inputs, a pat_str without that way out: one workgroup per tile.
-        const bool sync_now = can_fall_back && (c->defer_sync || job.pretok);  // ($TIKTOKEN_AMD_DEFER_SYNC=1: from the start; the piece-offsets entry has no chunk_finish)
-        job.optimistic = can_fall_back && !sync_now;
-        if (job.optimistic) {
-            const uint64_t guess = ((job.ntiles * (uint64_t)c->defer_ppm) >> 20) * 5 / 4 + 64;
-            n_given = guess < job.ntiles ? guess : job.ntiles;
-        }
+        if (job.optimistic) n_given = defer_guess < job.ntiles ? defer_guess : job.ntiles;
         if (sync_now) {
             HIPCHK(hipMemcpyAsync(w.h_counters, w.counters.p, TK_CNT_N * 4, hipMemcpyDeviceToHost, s));
             HIPCHK(hipEventRecord(w.ev_cnt, s));
@@ -1136,7 +1138,9 @@ static int chunk_finish(tk_core* c, WorkSet& w, const ChunkJob& job, uint64_t* n
             c->defer_sync = true;
             return TK_RESYNC;
         }
-        c->defer_ppm = (uint32_t)std::min<uint64_t>(((uint64_t)hb[TK_CNT_DEFER] << 20) / (job.ntiles ? job.ntiles : 1), 1u << 20);
+        // (at once upwards, to a quarter per chunk downwards: chunks of two kinds of text in turn keep the larger grid)
+        const uint32_t ppm = (uint32_t)std::min<uint64_t>(((uint64_t)hb[TK_CNT_DEFER] << 20) / (job.ntiles ? job.ntiles : 1), 1u << 20);
+        c->defer_ppm = std::max(ppm, c->defer_ppm / 4);
     }
     if (hb[TK_CNT_OVF] > job.ovf_cap && !job.pretok) {  // more distinct missed pieces than the miss data has room for: the batch is repeated with room for the worst case
         c->ovf_full = true;
@@ -2692,6 +2696,14 @@ extern "C" uint64_t tk_stat(tk_core* c, const char* name) {
         for (auto& w : c->ws)
             for (Buf* b : w.all()) t += b->cap;
         return t;
+    }
+    // (experiments) the deferred tiles of the last chunk of work set 0: "deferred_count", "deferred_tile_<i>" (read from the device: the caller has waited for the call)
+    if (k == "deferred_count") return c->ws[0].h_counters ? c->ws[0].h_counters[TK_CNT_N + TK_CNT_DEFER] : 0;
+    if (k.rfind("deferred_tile_", 0) == 0) {
+        uint32_t v = 0;
+        const uint64_t i = strtoull(k.c_str() + 14, nullptr, 10);
+        if (c->ws[0].deferred.p && (i + 1) * 4 <= c->ws[0].deferred.cap && hipMemcpy(&v, c->ws[0].deferred.as<uint32_t>() + i, 4, hipMemcpyDeviceToHost) != hipSuccess) v = 0xFFFFFFFFu;
+        return v;
     }
     if (k == "fallbacks") return c->st_fallbacks;  // chunks re-split by the generic engine since the core was made (stage_deferred)
     if (k == "host_front_us") return (uint64_t)c->host_us[0];

@@ -1053,7 +1053,8 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
                         }
                     }
                     // (UP and not CAS: an upper-case letter.  A run that reaches the window's end is a piece that leaves the window: decided there, below)
-                    if (j >= (uint32_t)TK2_WIN || !((bm[TKB_UP][j >> 6] >> (j & 63u)) & 1ull)) at = sp;
+                    // (... and an upper-case letter that begins a document ends the run like anything else: documents begin with one)
+                    if (j >= (uint32_t)TK2_WIN || ((bm[TKB_HARD][j >> 6] >> (j & 63u)) & 1ull) || !((bm[TKB_UP][j >> 6] >> (j & 63u)) & 1ull)) at = sp;
                 }
                 if (walk && at != TKF_NONE) {
                     extra = at;

@@ -4,9 +4,9 @@ sys.path[:0]=[ROOT, ROOT+"/tests"]
 import helpers as h
 from tiktoken_amd._tiktoken import CoreBPE
 from tiktoken_ext import amd_shaped
-for cfg in ("C2","C5"):
+for cfg in (sys.argv[1:] or ["C2","C5"]):
     enc_name, pat, specs, blob, off, allowed = h.baseline_config(cfg)
-    en = {"C2":"cl100k_shaped","C5":"o200k_custom8"}[cfg]
+    en = {"C2":"cl100k_shaped","C5":"o200k_custom8","C3":"o200k_shaped","N1":"o200k_shaped"}[cfg]
     spec = amd_shaped.ENCODING_CONSTRUCTORS[en]()
     core = CoreBPE(spec["mergeable_ranks"], spec["special_tokens"], spec["pat_str"])
     n=len(blob); host=np.zeros(n+64,np.uint8); host[:n]=blob
