@@ -124,7 +124,7 @@ struct tk_core {
     uint64_t st_regrown = 0;    // batches repeated with a larger miss data (encode_device_locked)
     uint64_t st_resynced = 0;   // batches repeated because a deferred tile gave up its walk while the host was not waiting for the counters (stage_deferred)
     bool defer_sync = false;    // ... from then on the host waits for them in every chunk, as it did up to round 5
-    uint32_t defer_ppm = 1u << 14;  // deferred tiles per 2^20 tiles of the last chunk (the grid of the kernel that finishes them; first guess: a sixty-fourth)
+    uint32_t defer_ppm = 1u << 12;  // deferred tiles per 2^20 tiles of the last chunk (the grid of the kernel that finishes them; first guess: one in 256 -- 4400 empty workgroups of that kernel were 0.06 ms of a first 1 GiB call)
     TkRxDev rx{};
     Buf t_rx_ins, t_rx_sets, t_rx_ranges, t_rx_first, t_rx_s1, t_rx_s2, t_rx_dtrans, t_rx_dascii, t_rx_ds1, t_rx_ds2;
     bool rx_staged = true;  // the speculative pass over text staged in LDS where the pattern's DFA allows it ($TIKTOKEN_AMD_RX_STAGED=0: never)
