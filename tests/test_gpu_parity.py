@@ -483,6 +483,27 @@ def test_a_tile_that_gives_up_while_the_host_is_not_waiting_repeats_the_batch():
     assert np.array_equal(core._encode_np(plain, None), C.encode_ordinary(plain))
 
 
+def test_a_late_chunk_that_gives_up_repeats_the_whole_batch(monkeypatch):
+    """The same with a batch of several chunks (1 MiB each): the stretch lies in a late chunk, the chunks before it have been finished and their ids sent
+    to the host when chunk_finish finds the tile that gave up; the pass is abandoned and run once more from the first chunk, waiting."""
+    from tiktoken_amd import CoreBPE
+
+    monkeypatch.setenv("TIKTOKEN_AMD_CHUNK_BYTES", str(1 << 20))
+    name = "o200k_shaped"
+    g = h.load_golden(name)
+    core, C = CoreBPE(h.golden_vocab(name), g["special_tokens"], h.PAT_STR[h.ENCODING_NAMES.index(name)]), h.c_oracle_for(name)
+    monkeypatch.delenv("TIKTOKEN_AMD_CHUNK_BYTES")
+    blob, off = h.gen_corpus(0xC0FFEE, 1, 6 << 20)
+    docs = [blob[int(off[i]):int(off[i + 1])].tobytes() for i in range(len(off) - 1)]
+    docs.insert(len(docs) * 3 // 4, ("x'll" * 200_000).encode())
+    blob, off = h.pack(docs)
+    rt, ro = C.encode_batch(blob, off, None, 8)
+    for k in range(2):
+        toks, toff = core.encode_batch_packed(blob, off, None)
+        assert np.array_equal(toff, ro) and np.array_equal(toks, rt), k
+        assert core.stat("resynced") == 1 and core.stat("chunks") >= 6, (k, core.stat("resynced"), core.stat("chunks"))
+
+
 @pytest.mark.parametrize("name", h.ENCODING_NAMES)
 def test_ordinary_text_through_the_give_up_path(monkeypatch, name):
     """TIKTOKEN_AMD_DEBUG bit 0x20000000: a walk budget of zero windows -- every deferred tile that would walk a window gives up, and the
