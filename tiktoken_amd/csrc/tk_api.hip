@@ -536,6 +536,35 @@ extern "C" int tk_create(const uint8_t* ranks_blob, const uint64_t* ranks_off, c
             if (v >= 1 && v <= 8) c->front_wgs = (uint32_t)v;
         }
     }
+    {
+        // tk_k_front reads some of its arguments from the kernarg segment again, at offsets taken from TkFrontArgs (tk_fused.h, TKF_PARK_ARGS): one launch
+        // of a kernel with the same parameter list and arguments of distinct values checks that the compiler lays the segment out that way
+        TkTables Tt{};
+        uint64_t v = 0x1000;
+        auto nextp = [&]() { v += 0x1010; return (uintptr_t)v; };
+        Tt.short_tab = (const TkShortSlot*)nextp(); Tt.short_mask = (uint32_t)nextp(); Tt.short_shift = (uint32_t)nextp();
+        Tt.mid_tab = (const TkPieceSlot*)nextp(); Tt.mid_mask = (uint32_t)nextp(); Tt.mid_shift = (uint32_t)nextp();
+        Tt.xl = (decltype(Tt.xl))nextp(); Tt.xl_mask = (uint32_t)nextp(); Tt.max_token_len = (uint32_t)nextp();
+        Tt.tok_bytes = (const uint8_t*)nextp(); Tt.piece = (const TkPieceSlot*)nextp(); Tt.piece_off = (const uint32_t*)nextp(); Tt.piece_mask = nextp();
+        Tt.n_spec = (uint32_t)nextp(); Tt.spec_bytes = (const uint8_t*)nextp(); Tt.spec_id = (const uint32_t*)nextp(); Tt.spec_off = (const uint32_t*)nextp();
+        TkFrontOut fo{};
+        fo.starts = (uint32_t*)nextp(); fo.tile_np = (uint32_t*)nextp(); fo.res = (uint32_t*)nextp(); fo.tile_sum = (uint8_t*)nextp();
+        fo.data.tab = (TkMissTab*)nextp(); fo.data.ovf = (TkMissOvf*)nextp(); fo.data.ovf_base = (uint32_t)nextp(); fo.ovf_cap = (uint32_t)nextp();
+        fo.listC = (uint32_t*)nextp(); fo.counters = (uint32_t*)nextp();
+        Buf okb;
+        if (ensure(okb, 64) != TK_OK) { tk_destroy(c); return TK_RUNTIME_ERROR; }
+        (void)hipMemsetAsync(okb.p, 0, 4, c->stream);
+        hipLaunchKernelGGL(tk_k_front_args_check, dim3(1), dim3(64), 0, c->stream, Tt, (const uint8_t*)nextp(), (uint64_t)nextp(), (uint64_t)nextp(), (const uint32_t*)nextp(),
+                           (const uint32_t*)nextp(), (const uint32_t*)nextp(), (const uint32_t*)nextp(), fo, (TkMissKey*)nextp(), (uint32_t)nextp(), (uint32_t*)nextp(),
+                           (const uint32_t*)nextp(), (int)nextp(), okb.as<uint32_t>());
+        uint32_t ok = 0;
+        const bool copied = hipMemcpyAsync(&ok, okb.p, 4, hipMemcpyDeviceToHost, c->stream) == hipSuccess && hipStreamSynchronize(c->stream) == hipSuccess;
+        release(okb);
+        if (!copied || ok != 1u) {
+            tk_destroy(c);
+            return fail(TK_RUNTIME_ERROR, "internal error: the front kernel's arguments do not lie in the kernarg segment as TkFrontArgs says");
+        }
+    }
     *out = c;
     return TK_OK;
 }

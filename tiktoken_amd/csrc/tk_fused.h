@@ -683,6 +683,20 @@ __device__ __forceinline__ uint32_t tk_extend_letter_run(const uint8_t* __restri
     }
     return 0u;
 }
+// The kernel's arguments as the kernarg segment lays them out (TKF_PARK_ARGS == 2: phase E reads what it needs of them from there again, by scalar loads
+// at the point of use, instead of carrying them in registers from the kernel's entry; the static_asserts in tk_k_front tie the offsets to the signature).
+struct TkFrontArgs {
+    TkTables T;
+    const uint8_t* text;
+    uint64_t n, chunk_base;
+    const uint32_t *brk, *docb, *ss, *si;
+    TkFrontOut out;
+    TkMissKey* mt;
+    uint32_t mt_mask;
+    uint32_t* deferred;
+    const uint32_t* gapb;
+    int dbg;
+};
 template <int PAT, bool SPEC, int MODE>
 __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE == TKF_MODE_GIVEN ? TKF_GIVEN_OCC : TKF_OCC)) void tk_k_front(TkTables T, const uint8_t* __restrict__ text, uint64_t n, uint64_t chunk_base,
                                                   const uint32_t* __restrict__ brk, const uint32_t* __restrict__ docb,
@@ -719,11 +733,17 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
     // of the kernel they made it spill 135 more scalar reloads into the paths that every tile takes (4.38 -> 4.46 ms per GiB)
     __shared__ uint64_t ext_sh[4];
 #ifndef TKF_PARK_ARGS
-#define TKF_PARK_ARGS 1
+#define TKF_PARK_ARGS 2  // 0: the arguments stay in registers; 1: parked in LDS (park_sh); 2: read from the kernarg segment again where phase E begins
 #endif
     // (experiment, round 6) what only phases E and F need of the kernel's arguments, parked in LDS by phase A and read back where phase E begins: kept in scalar
     // registers from the kernel's first instruction they are part of the 150 scalar values the kernel spills into vector-register lanes
-    __shared__ uint64_t park_sh[TKF_PARK_ARGS ? 18 : 1];
+    // ... and better still (TKF_PARK_ARGS == 2, shipped): they are in memory already -- the kernarg segment -- and a scalar load at the point of use costs
+    // neither LDS traffic nor the thirty-four v_readfirstlane of the LDS form: front 4.39 -> 4.35 ms per GiB on one box.  The compiler must not see that the
+    // pointer is the kernarg segment's (it would load at the kernel's entry again): it goes through an empty asm statement.  tk_k_front_args_check
+    // (run once by tk_create) compares what the offsets of TkFrontArgs give with the arguments themselves.
+#if TKF_PARK_ARGS == 1
+    __shared__ uint64_t park_sh[18];
+#endif
     uint64_t(*bm)[NW] = (uint64_t(*)[NW])pool;
     uint8_t* lastc = lastc_own;
     // From phase C on the byte table is dead in the one-tile-per-workgroup variant: its 2 KiB hold the "stop" bitmap of the scanners'
@@ -821,7 +841,8 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
             ext_sh[2] = (uint64_t)(uintptr_t)T.uc_stage1;
             ext_sh[3] = (uint64_t)(uintptr_t)T.uc_stage2;
         }
-        if (TKF_PARK_ARGS && !SLOW) {
+#if TKF_PARK_ARGS == 1
+        if (!SLOW) {
             park_sh[0] = (uint64_t)(uintptr_t)T.short_tab;
             park_sh[1] = (uint64_t)(uintptr_t)T.mid_tab;
             park_sh[2] = (uint64_t)(uintptr_t)T.xl;
@@ -840,6 +861,7 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
             park_sh[15] = (uint64_t)(uintptr_t)T.piece_off;
             park_sh[16] = T.piece_mask;
         }
+#endif
         need_walk = 0;
         ncont_sh = 0;
         nslow_sh = 0;
@@ -1433,14 +1455,53 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
     const uint32_t run_base = (uint32_t)tile * TKF_CAP;
 #if TKF_PARK_ARGS
     // (the names of the kernel's arguments, shadowed by what was parked: the code below reads as before)
+#if TKF_PARK_ARGS == 1
     auto unpark = [&](int i) -> uint64_t {
         const uint64_t v = park_sh[i];
         return (uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)v) | ((uint64_t)(uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)(v >> 32)) << 32);
     };
+#endif
     TkTables T_f{};
     TkFrontOut out_f{};
     TkMissKey* __restrict__ mt_f = nullptr;
     uint32_t mt_mask_f = 0;
+#if TKF_PARK_ARGS == 2
+    if constexpr (!SLOW) {
+        // the kernarg segment once more: a pointer the compiler cannot see through (the loads stay here), in the constant address space (scalar loads)
+        typedef const __attribute__((address_space(4))) uint8_t* KArg;
+        KArg ka = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+        asm volatile("" : "+s"(ka));
+#define TKF_KA64(off) (*(const __attribute__((address_space(4))) uint64_t*)(ka + (off)))
+#define TKF_KA32(off) (*(const __attribute__((address_space(4))) uint32_t*)(ka + (off)))
+#define TKF_KA_TP(member) ((decltype(TkTables::member))(uintptr_t)TKF_KA64(offsetof(TkFrontArgs, T) + offsetof(TkTables, member)))
+#define TKF_KA_T32(member) TKF_KA32(offsetof(TkFrontArgs, T) + offsetof(TkTables, member))
+#define TKF_KA_OP(type, member) ((type)(uintptr_t)TKF_KA64(offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, member)))
+        T_f.short_tab = TKF_KA_TP(short_tab); T_f.short_mask = TKF_KA_T32(short_mask); T_f.short_shift = TKF_KA_T32(short_shift);
+        T_f.mid_tab = TKF_KA_TP(mid_tab); T_f.mid_mask = TKF_KA_T32(mid_mask); T_f.mid_shift = TKF_KA_T32(mid_shift);
+        T_f.xl = TKF_KA_TP(xl); T_f.xl_mask = TKF_KA_T32(xl_mask); T_f.max_token_len = TKF_KA_T32(max_token_len);
+        T_f.tok_bytes = TKF_KA_TP(tok_bytes); T_f.piece = TKF_KA_TP(piece); T_f.piece_off = TKF_KA_TP(piece_off);
+        T_f.piece_mask = TKF_KA64(offsetof(TkFrontArgs, T) + offsetof(TkTables, piece_mask));
+        mt_f = (TkMissKey*)(uintptr_t)TKF_KA64(offsetof(TkFrontArgs, mt));
+        mt_mask_f = TKF_KA32(offsetof(TkFrontArgs, mt_mask));
+        out_f.starts = TKF_KA_OP(uint32_t*, starts);
+        out_f.tile_np = TKF_KA_OP(uint32_t*, tile_np);
+        out_f.res = TKF_KA_OP(uint32_t*, res);
+        out_f.data.tab = (TkMissTab*)(uintptr_t)TKF_KA64(offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, data) + offsetof(TkMiss, tab));
+        out_f.data.ovf = (TkMissOvf*)(uintptr_t)TKF_KA64(offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, data) + offsetof(TkMiss, ovf));
+        out_f.data.ovf_base = TKF_KA32(offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, data) + offsetof(TkMiss, ovf_base));
+        out_f.ovf_cap = TKF_KA32(offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, ovf_cap));
+        out_f.listC = TKF_KA_OP(uint32_t*, listC);
+        out_f.counters = TKF_KA_OP(uint32_t*, counters);
+        if constexpr (SPEC) {
+            T_f.n_spec = TKF_KA_T32(n_spec); T_f.spec_bytes = TKF_KA_TP(spec_bytes); T_f.spec_id = TKF_KA_TP(spec_id); T_f.spec_off = TKF_KA_TP(spec_off);
+        }
+#undef TKF_KA_OP
+#undef TKF_KA_T32
+#undef TKF_KA_TP
+#undef TKF_KA32
+#undef TKF_KA64
+    }
+#else
     if constexpr (!SLOW) {
         T_f.short_tab = (const TkShortSlot*)(uintptr_t)unpark(0);
         T_f.mid_tab = (const TkPieceSlot*)(uintptr_t)unpark(1);
@@ -1465,6 +1526,7 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
             T_f.n_spec = T.n_spec; T_f.spec_bytes = T.spec_bytes; T_f.spec_id = T.spec_id; T_f.spec_off = T.spec_off;
         }
     }
+#endif
     const TkTables& T_outer = T;
     (void)T_outer;
     const TkTables& T = T_f;
@@ -1831,6 +1893,40 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
     }
     }  // (!SLOW)
     } while (PERSIST && next_item());
+}
+
+// The kernarg offsets TKF_PARK_ARGS == 2 relies on, checked on the device (tk_create runs this once with arguments of distinct values): the same
+// parameter list as tk_k_front, so the same kernarg layout.  ok[0] = 1 when every field read through TkFrontArgs' offsets equals the argument.
+__global__ void tk_k_front_args_check(TkTables T, const uint8_t* text, uint64_t n, uint64_t chunk_base, const uint32_t* brk, const uint32_t* docb, const uint32_t* ss,
+                                      const uint32_t* si, TkFrontOut out, TkMissKey* mt, uint32_t mt_mask, uint32_t* deferred, const uint32_t* gapb, int dbg, uint32_t* ok) {
+    typedef const __attribute__((address_space(4))) uint8_t* KArg;
+    KArg ka = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka));
+    auto q = [&](size_t off) { return *(const __attribute__((address_space(4))) uint64_t*)(ka + off); };
+    auto d = [&](size_t off) { return *(const __attribute__((address_space(4))) uint32_t*)(ka + off); };
+    const size_t t0 = offsetof(TkFrontArgs, T), o0 = offsetof(TkFrontArgs, out);
+    bool good = q(t0 + offsetof(TkTables, short_tab)) == (uint64_t)(uintptr_t)T.short_tab && d(t0 + offsetof(TkTables, short_mask)) == T.short_mask &&
+                d(t0 + offsetof(TkTables, short_shift)) == T.short_shift && q(t0 + offsetof(TkTables, mid_tab)) == (uint64_t)(uintptr_t)T.mid_tab &&
+                d(t0 + offsetof(TkTables, mid_mask)) == T.mid_mask && d(t0 + offsetof(TkTables, mid_shift)) == T.mid_shift &&
+                q(t0 + offsetof(TkTables, xl)) == (uint64_t)(uintptr_t)T.xl && d(t0 + offsetof(TkTables, xl_mask)) == T.xl_mask &&
+                d(t0 + offsetof(TkTables, max_token_len)) == T.max_token_len && q(t0 + offsetof(TkTables, tok_bytes)) == (uint64_t)(uintptr_t)T.tok_bytes &&
+                q(t0 + offsetof(TkTables, piece)) == (uint64_t)(uintptr_t)T.piece && q(t0 + offsetof(TkTables, piece_off)) == (uint64_t)(uintptr_t)T.piece_off &&
+                q(t0 + offsetof(TkTables, piece_mask)) == T.piece_mask && d(t0 + offsetof(TkTables, n_spec)) == T.n_spec &&
+                q(t0 + offsetof(TkTables, spec_bytes)) == (uint64_t)(uintptr_t)T.spec_bytes && q(t0 + offsetof(TkTables, spec_id)) == (uint64_t)(uintptr_t)T.spec_id &&
+                q(t0 + offsetof(TkTables, spec_off)) == (uint64_t)(uintptr_t)T.spec_off;
+    good = good && q(offsetof(TkFrontArgs, text)) == (uint64_t)(uintptr_t)text && q(offsetof(TkFrontArgs, n)) == n && q(offsetof(TkFrontArgs, chunk_base)) == chunk_base &&
+           q(offsetof(TkFrontArgs, brk)) == (uint64_t)(uintptr_t)brk && q(offsetof(TkFrontArgs, docb)) == (uint64_t)(uintptr_t)docb &&
+           q(offsetof(TkFrontArgs, ss)) == (uint64_t)(uintptr_t)ss && q(offsetof(TkFrontArgs, si)) == (uint64_t)(uintptr_t)si &&
+           q(offsetof(TkFrontArgs, mt)) == (uint64_t)(uintptr_t)mt && d(offsetof(TkFrontArgs, mt_mask)) == mt_mask &&
+           q(offsetof(TkFrontArgs, deferred)) == (uint64_t)(uintptr_t)deferred && q(offsetof(TkFrontArgs, gapb)) == (uint64_t)(uintptr_t)gapb &&
+           d(offsetof(TkFrontArgs, dbg)) == (uint32_t)dbg;
+    good = good && q(o0 + offsetof(TkFrontOut, starts)) == (uint64_t)(uintptr_t)out.starts && q(o0 + offsetof(TkFrontOut, tile_np)) == (uint64_t)(uintptr_t)out.tile_np &&
+           q(o0 + offsetof(TkFrontOut, res)) == (uint64_t)(uintptr_t)out.res && q(o0 + offsetof(TkFrontOut, tile_sum)) == (uint64_t)(uintptr_t)out.tile_sum &&
+           q(o0 + offsetof(TkFrontOut, data) + offsetof(TkMiss, tab)) == (uint64_t)(uintptr_t)out.data.tab &&
+           q(o0 + offsetof(TkFrontOut, data) + offsetof(TkMiss, ovf)) == (uint64_t)(uintptr_t)out.data.ovf &&
+           d(o0 + offsetof(TkFrontOut, data) + offsetof(TkMiss, ovf_base)) == out.data.ovf_base && d(o0 + offsetof(TkFrontOut, ovf_cap)) == out.ovf_cap &&
+           q(o0 + offsetof(TkFrontOut, listC)) == (uint64_t)(uintptr_t)out.listC && q(o0 + offsetof(TkFrontOut, counters)) == (uint64_t)(uintptr_t)out.counters;
+    if (threadIdx.x == 0 && blockIdx.x == 0) ok[0] = good ? 1u : 0u;
 }
 
 // The distinct missed pieces -- the claimed slots of the miss table and the overflow entries behind them (TkMissData) -- have to be
