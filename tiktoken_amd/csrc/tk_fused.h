@@ -1466,40 +1466,55 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
     TkMissKey* __restrict__ mt_f = nullptr;
     uint32_t mt_mask_f = 0;
 #if TKF_PARK_ARGS == 2
-    if constexpr (!SLOW) {
-        // the kernarg segment once more: a pointer the compiler cannot see through (the loads stay here), in the constant address space (scalar loads)
-        typedef const __attribute__((address_space(4))) uint8_t* KArg;
-        KArg ka = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+    // The kernarg segment once more: a pointer the compiler cannot see through, in the constant address space (scalar loads).  What the rows and the dense
+    // passes need of the tables is loaded WHERE IT IS USED (fresh_T(): the pointer goes through an empty asm statement every time, so the loads are not
+    // moved out of the loop of the rows -- which uses a different table in each of its branches: all of them alive across the whole loop were spilled
+    // scalar registers reloaded by vector instructions in every branch); what is used everywhere (the result words' base) once, here.
+    typedef const __attribute__((address_space(4))) uint8_t* KArg;
+    KArg ka_e = (KArg)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(ka_e));
+#define TKF_KA64(ka, off) (*(const __attribute__((address_space(4))) uint64_t*)((ka) + (off)))
+#define TKF_KA32(ka, off) (*(const __attribute__((address_space(4))) uint32_t*)((ka) + (off)))
+#define TKF_KA_TP(ka, member) ((decltype(TkTables::member))(uintptr_t)TKF_KA64(ka, offsetof(TkFrontArgs, T) + offsetof(TkTables, member)))
+#define TKF_KA_T32(ka, member) TKF_KA32(ka, offsetof(TkFrontArgs, T) + offsetof(TkTables, member))
+#define TKF_KA_OP(ka, type, member) ((type)(uintptr_t)TKF_KA64(ka, offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, member)))
+    auto fresh_T = [&]() -> TkTables {
+        KArg ka = ka_e;
         asm volatile("" : "+s"(ka));
-#define TKF_KA64(off) (*(const __attribute__((address_space(4))) uint64_t*)(ka + (off)))
-#define TKF_KA32(off) (*(const __attribute__((address_space(4))) uint32_t*)(ka + (off)))
-#define TKF_KA_TP(member) ((decltype(TkTables::member))(uintptr_t)TKF_KA64(offsetof(TkFrontArgs, T) + offsetof(TkTables, member)))
-#define TKF_KA_T32(member) TKF_KA32(offsetof(TkFrontArgs, T) + offsetof(TkTables, member))
-#define TKF_KA_OP(type, member) ((type)(uintptr_t)TKF_KA64(offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, member)))
-        T_f.short_tab = TKF_KA_TP(short_tab); T_f.short_mask = TKF_KA_T32(short_mask); T_f.short_shift = TKF_KA_T32(short_shift);
-        T_f.mid_tab = TKF_KA_TP(mid_tab); T_f.mid_mask = TKF_KA_T32(mid_mask); T_f.mid_shift = TKF_KA_T32(mid_shift);
-        T_f.xl = TKF_KA_TP(xl); T_f.xl_mask = TKF_KA_T32(xl_mask); T_f.max_token_len = TKF_KA_T32(max_token_len);
-        T_f.tok_bytes = TKF_KA_TP(tok_bytes); T_f.piece = TKF_KA_TP(piece); T_f.piece_off = TKF_KA_TP(piece_off);
-        T_f.piece_mask = TKF_KA64(offsetof(TkFrontArgs, T) + offsetof(TkTables, piece_mask));
-        mt_f = (TkMissKey*)(uintptr_t)TKF_KA64(offsetof(TkFrontArgs, mt));
-        mt_mask_f = TKF_KA32(offsetof(TkFrontArgs, mt_mask));
-        out_f.starts = TKF_KA_OP(uint32_t*, starts);
-        out_f.tile_np = TKF_KA_OP(uint32_t*, tile_np);
-        out_f.res = TKF_KA_OP(uint32_t*, res);
-        out_f.data.tab = (TkMissTab*)(uintptr_t)TKF_KA64(offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, data) + offsetof(TkMiss, tab));
-        out_f.data.ovf = (TkMissOvf*)(uintptr_t)TKF_KA64(offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, data) + offsetof(TkMiss, ovf));
-        out_f.data.ovf_base = TKF_KA32(offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, data) + offsetof(TkMiss, ovf_base));
-        out_f.ovf_cap = TKF_KA32(offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, ovf_cap));
-        out_f.listC = TKF_KA_OP(uint32_t*, listC);
-        out_f.counters = TKF_KA_OP(uint32_t*, counters);
+        TkTables t{};
+        t.short_tab = TKF_KA_TP(ka, short_tab); t.short_mask = TKF_KA_T32(ka, short_mask); t.short_shift = TKF_KA_T32(ka, short_shift);
+        t.mid_tab = TKF_KA_TP(ka, mid_tab); t.mid_mask = TKF_KA_T32(ka, mid_mask); t.mid_shift = TKF_KA_T32(ka, mid_shift);
+        t.xl = TKF_KA_TP(ka, xl); t.xl_mask = TKF_KA_T32(ka, xl_mask); t.max_token_len = TKF_KA_T32(ka, max_token_len);
+        t.tok_bytes = TKF_KA_TP(ka, tok_bytes); t.piece = TKF_KA_TP(ka, piece); t.piece_off = TKF_KA_TP(ka, piece_off);
+        t.piece_mask = TKF_KA64(ka, offsetof(TkFrontArgs, T) + offsetof(TkTables, piece_mask));
         if constexpr (SPEC) {
-            T_f.n_spec = TKF_KA_T32(n_spec); T_f.spec_bytes = TKF_KA_TP(spec_bytes); T_f.spec_id = TKF_KA_TP(spec_id); T_f.spec_off = TKF_KA_TP(spec_off);
+            t.n_spec = TKF_KA_T32(ka, n_spec); t.spec_bytes = TKF_KA_TP(ka, spec_bytes); t.spec_id = TKF_KA_TP(ka, spec_id); t.spec_off = TKF_KA_TP(ka, spec_off);
         }
-#undef TKF_KA_OP
-#undef TKF_KA_T32
-#undef TKF_KA_TP
-#undef TKF_KA32
-#undef TKF_KA64
+        return t;  // (the loads of the fields a caller does not use are dead code)
+    };
+    auto fresh_out = [&]() -> TkFrontOut {  // (the rare ways: a claim that succeeds, an overflow entry)
+        KArg ka = ka_e;
+        asm volatile("" : "+s"(ka));
+        TkFrontOut o{};
+        o.data.tab = (TkMissTab*)(uintptr_t)TKF_KA64(ka, offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, data) + offsetof(TkMiss, tab));
+        o.data.ovf = (TkMissOvf*)(uintptr_t)TKF_KA64(ka, offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, data) + offsetof(TkMiss, ovf));
+        o.data.ovf_base = TKF_KA32(ka, offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, data) + offsetof(TkMiss, ovf_base));
+        o.ovf_cap = TKF_KA32(ka, offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, ovf_cap));
+        o.listC = TKF_KA_OP(ka, uint32_t*, listC);
+        o.counters = TKF_KA_OP(ka, uint32_t*, counters);
+        return o;
+    };
+    auto fresh_mt = [&](uint32_t& mask_out) -> TkMissKey* {
+        KArg ka = ka_e;
+        asm volatile("" : "+s"(ka));
+        mask_out = TKF_KA32(ka, offsetof(TkFrontArgs, mt_mask));
+        return (TkMissKey*)(uintptr_t)TKF_KA64(ka, offsetof(TkFrontArgs, mt));
+    };
+    if constexpr (!SLOW) {
+        out_f.starts = TKF_KA_OP(ka_e, uint32_t*, starts);
+        out_f.tile_np = TKF_KA_OP(ka_e, uint32_t*, tile_np);
+        out_f.res = TKF_KA_OP(ka_e, uint32_t*, res);
+        mt_f = fresh_mt(mt_mask_f);
     }
 #else
     if constexpr (!SLOW) {
@@ -1529,10 +1544,15 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
 #endif
     const TkTables& T_outer = T;
     (void)T_outer;
+#if TKF_PARK_ARGS == 2
+    (void)T_f;
+#define T fresh_T()  /* (undefined again where the kernel's loop ends) */
+#else
     const TkTables& T = T_f;
+#endif
     const TkFrontOut& out = out_f;
     TkMissKey* __restrict__ mt = mt_f;
-    const uint32_t mt_mask = mt_mask_f;
+    uint32_t mt_mask = mt_mask_f;
 #endif
     uint32_t* bx = certw;                            // [128] the start bitmap once more, plus the END of the tile's last piece (the certain starts are dead)
     uint16_t* ord_sl = (uint16_t*)btab;              // [1024] short pieces from the front, long ones from the back: window positions (the byte table is dead)
@@ -1604,7 +1624,11 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
                 __hip_atomic_store(&mt[i].w0, w0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&mt[i].w1, w1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
                 __hip_atomic_store(&mt[i].w2, w2, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+#if TKF_PARK_ARGS == 2
+                *(uint2*)&fresh_out().data.tab[i].start = make_uint2((uint32_t)gs, len);
+#else
                 *(uint2*)&out.data.tab[i].start = make_uint2((uint32_t)gs, len);
+#endif
                 return i;
             }
             if (cur == kk) {
@@ -1767,6 +1791,9 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
                 // and the last eight bytes, the length, and a comparison in the text).  Round 5 did this inside every row, for the 19 % of its
                 // lanes whose piece was not a token -- eleven sparse passes through this code per tile where these are four.
                 for (uint32_t c0 = 0; c0 < n_mine; c0 += 64u) {
+#if TKF_PARK_ARGS == 2
+                    mt = fresh_mt(mt_mask);  // (the in-call table's base and mask: alive inside a dense pass only)
+#endif
                     const uint32_t q = c0 + (uint32_t)lane;
                     const bool have = q < n_mine;
                     const uint32_t e = mlw[have ? q : 0u];
@@ -1812,6 +1839,9 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
                         }
                         const uint64_t m = __ballot(over);
                         if (m) {
+#if TKF_PARK_ARGS == 2
+                            const TkFrontOut out = fresh_out();  // (shadows the view that holds the result words' base only)
+#endif
                             const int leader = __ffsll((unsigned long long)m) - 1;
                             uint32_t at = 0;
                             if (lane == leader) at = atomicAdd(&out.counters[TK_CNT_OVF], (uint32_t)__popcll(m));
@@ -1832,6 +1862,7 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
             bool miss = false;
             uint32_t e = 0;
             if (r < rows_l) {
+                const TkTables Tr = T;  // (TKF_PARK_ARGS == 2: this row's table, loaded here -- on its way while the row reads its list)
                 const uint32_t q = r * 64u + (uint32_t)lane;
                 if (q < n_l) {
                     const uint32_t pos = ord_sl[1023u - q], k = ordk_sl[1023u - q];
@@ -1842,7 +1873,7 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
                         const uint64_t gs = (uint64_t)(base + pos);
                         uint64_t w0, w1, w2;
                         tk_ident([&](uint32_t o) { return in_lds ? tk_lds_load8(raw, pos + o) : tk_load8(text, gs + o); }, len, 0u, w0, w1, w2);
-                        rk = tk_probe_xl(T, w0, w1, w2);
+                        rk = tk_probe_xl(Tr, w0, w1, w2);
                     }
                     if (rk != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k] = rk == TK_RANK_MAX ? 0u : rk;
                     else {
@@ -1851,12 +1882,13 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
                     }
                 }
             } else if (r < rows_l + rows_m) {
+                const TkTables Tr = T;
                 const uint32_t q = (r - rows_l) * 64u + (uint32_t)lane;
                 if (q < n_m) {
                     const uint32_t pos = ord_m[q], k = ordk_m[q];
                     const uint32_t len = near_len(pos);
                     const uint64_t key_m = tk_mask_low_bytes(tk_lds_load8(raw, pos), len);
-                    const uint32_t rk = (dbg & 2) ? len : tk_probe_mid(T, key_m, len);
+                    const uint32_t rk = (dbg & 2) ? len : tk_probe_mid(Tr, key_m, len);
                     if (rk != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k] = rk == TK_RANK_MAX ? 0u : rk;
                     else {
                         miss = true;
@@ -1864,13 +1896,14 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
                     }
                 }
             } else {
+                const TkTables Tr = T;
                 const uint32_t q = (r - rows_l - rows_m) * 64u + (uint32_t)lane;
                 if (q < n_s) {
                     const uint32_t pos = ord_sl[q], k = ordk_sl[q];
                     const uint32_t len = near_len(pos);
                     const uint32_t v = __builtin_amdgcn_alignbyte(dwr[(pos >> 2) + 1], dwr[pos >> 2], pos & 3u);
                     const uint32_t key_s = v & (0xFFFFFFFFu >> (32u - 8u * len));
-                    const uint32_t rk = (dbg & 2) ? len : (short_tab ? tk_probe_short(T, key_s, len) : tk_probe_mid(T, (uint64_t)key_s, len));
+                    const uint32_t rk = (dbg & 2) ? len : (short_tab ? tk_probe_short(Tr, key_s, len) : tk_probe_mid(Tr, (uint64_t)key_s, len));
                     if (rk != TK_RANK_MAX || (dbg & 8)) out.res[run_base + k] = rk == TK_RANK_MAX ? 0u : rk;
                     else {
                         miss = true;
@@ -1892,6 +1925,14 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
         out.res[run_base + TKF_TAIL_NGAP] = GEN ? ngap_sh : 0u;
     }
     }  // (!SLOW)
+#if TKF_PARK_ARGS == 2
+#undef T
+#undef TKF_KA_OP
+#undef TKF_KA_T32
+#undef TKF_KA_TP
+#undef TKF_KA32
+#undef TKF_KA64
+#endif
     } while (PERSIST && next_item());
 }
 
