@@ -801,6 +801,20 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
     const uint64_t tile_start = tile * TK_TILE;
     const uint64_t tile_end = tile_start + TK_TILE < n ? tile_start + TK_TILE : n;
     const int64_t base = (int64_t)tile_start - TK2_LEFT;
+#ifndef TKF_FRESH_SCALARS
+#define TKF_FRESH_SCALARS 0  // experiment (see below): 0 off, 1 in phases E and F, 2 in the whole kernel
+#endif
+#if TKF_FRESH_SCALARS == 2
+    // (round 6) What the compiler derives from the tile's index and keeps for the whole kernel -- the tile's first byte (tile x TK_TILE, 64 bits), its end, the
+    // window's base -- were scalar registers spilled at the kernel's entry and reloaded by vector instructions wherever they are used (74 of the kernel's 150
+    // v_readlane).  Through an empty asm statement at the point of use they are two scalar multiplications there and nothing is kept but the index.
+    auto tile_start_fresh = [&]() -> uint64_t { uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tile); asm volatile("" : "+s"(t)); return (uint64_t)t * (uint64_t)TK_TILE; };
+    auto tile_end_fresh = [&]() -> uint64_t { const uint64_t e = tile_start_fresh() + TK_TILE; return e < n ? e : n; };
+    auto base_fresh = [&]() -> int64_t { return (int64_t)tile_start_fresh() - TK2_LEFT; };
+#define tile_start tile_start_fresh()
+#define tile_end tile_end_fresh()
+#define base base_fresh()
+#endif
     // ---- A: every lane owns 16 bytes of the window (kept in registers and copied to LDS)
     const int64_t gp = base + (int64_t)tid * 16;
     uint32_t w[4] = {0, 0, 0, 0};
@@ -1547,6 +1561,18 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
 #if TKF_PARK_ARGS == 2
     (void)T_f;
 #define T fresh_T()  /* (undefined again where the kernel's loop ends) */
+#if TKF_FRESH_SCALARS
+    // The same for the tests of the debug word's bits in phases E and F: each was a 64-bit lane mask computed before the loop of the rows, spilled, and
+    // reloaded by two vector instructions in every row and every dense pass.  Through an empty asm statement they are a scalar test at the point of use.
+    auto dbg_fresh = [&]() -> int { int d = dbg; asm volatile("" : "+s"(d)); return d; };
+#define dbg dbg_fresh()
+#if TKF_FRESH_SCALARS == 1
+    auto tile_start_fresh = [&]() -> uint64_t { uint32_t t = (uint32_t)__builtin_amdgcn_readfirstlane((int)(uint32_t)tile); asm volatile("" : "+s"(t)); return (uint64_t)t * (uint64_t)TK_TILE; };
+    auto base_fresh = [&]() -> int64_t { return (int64_t)tile_start_fresh() - TK2_LEFT; };
+#define tile_start tile_start_fresh()
+#define base base_fresh()
+#endif
+#endif
 #else
     const TkTables& T = T_f;
 #endif
@@ -1927,11 +1953,19 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
     }  // (!SLOW)
 #if TKF_PARK_ARGS == 2
 #undef T
+#if TKF_FRESH_SCALARS
+#undef dbg
+#endif
 #undef TKF_KA_OP
 #undef TKF_KA_T32
 #undef TKF_KA_TP
 #undef TKF_KA32
 #undef TKF_KA64
+#endif
+#if TKF_FRESH_SCALARS
+#undef tile_start
+#undef tile_end
+#undef base
 #endif
     } while (PERSIST && next_item());
 }
