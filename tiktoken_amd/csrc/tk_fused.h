@@ -603,6 +603,17 @@ __device__ __forceinline__ bool tk_equal_lds_text(const uint8_t* raw, uint32_t o
 #define TKF_SLOW_OCC 3  // workgroups per CU of the deferred-tile variant (its grid: tk_api.hip, stage_deferred).  Round 6, on one box (tools/gpu_slowocc.sh):
                         // 3 against 4 -- C2 78.5 / 77.0 GB/s, C5 its kernel 0.168 / 0.188 ms, C3 0.40 / 0.38 ms (within the noise of the box)
 #endif
+// A pointer put together from an integer (the kernarg segment read again, a word parked in LDS) is a GENERIC pointer to the compiler: its loads and stores
+// become flat_* instructions -- a 64-bit address in vector registers for every access (no scalar base + 32-bit offset form), and counted by lgkmcnt as well as
+// vmcnt, so that every wait for an LDS read also waits for the table probes in flight.  Through a pointer of the global address space they are global_* again.
+#ifndef TKF_GLOBAL_PTRS
+#define TKF_GLOBAL_PTRS 1
+#endif
+#if TKF_GLOBAL_PTRS
+#define TKF_PTR(type, v) ((type)(__attribute__((address_space(1))) void*)(uintptr_t)(v))
+#else
+#define TKF_PTR(type, v) ((type)(uintptr_t)(v))
+#endif
 #ifndef TKF_CLAIM_SPIN
 #define TKF_CLAIM_SPIN 8  // looks a duplicate takes at a slot whose claimant has not written its words yet (see `claim`)
 #endif
@@ -930,7 +941,7 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
                 // (round 6) ... and ends at the next hard start all the same: one wavefront reads the break bitmap on, 2048 positions a step, up to 8 KiB
                 // (the tiles of the generic engine's split that went to the workgroup-wide scanner for this: 0.32 of its 11.0 ms per GiB)
                 if (wid == 0) {
-                    const uint32_t* brk_g = (const uint32_t*)(uintptr_t)ext_sh[0];
+                    const uint32_t* brk_g = TKF_PTR(const uint32_t*, ext_sh[0]);
                     const uint64_t w0 = (uint64_t)(base + TK2_WIN) >> 5, nw = (n + 31) >> 5;
                     uint32_t e = 0xFFFFFFFFu;
                     for (uint32_t it = 0; it < 4u && e == 0xFFFFFFFFu; ++it) {
@@ -1428,7 +1439,7 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
                     ok = (((LETTER >> cp) & 1u) || (((PREFIX >> cp) & 1u) && ((LETTER >> cn) & 1u) && !hard_nx)) && ((SET >> lastc) & 1u);
                     last_ll = !CL && lastc == (uint32_t)TK_C_LL;
                 }
-                if (ok) end_rel = tk_extend_letter_run<CL>((const uint8_t*)(uintptr_t)ext_sh[1], (const uint8_t*)(uintptr_t)ext_sh[2], (const uint8_t*)(uintptr_t)ext_sh[3], text, n, (const uint32_t*)(uintptr_t)ext_sh[0], (uint64_t)(base + TK2_WIN), lane, last_ll);
+                if (ok) end_rel = tk_extend_letter_run<CL>(TKF_PTR(const uint8_t*, ext_sh[1]), TKF_PTR(const uint8_t*, ext_sh[2]), TKF_PTR(const uint8_t*, ext_sh[3]), text, n, TKF_PTR(const uint32_t*, ext_sh[0]), (uint64_t)(base + TK2_WIN), lane, last_ll);
                 if (lane == 0) {
                     scan_sh[0] = end_rel;
                     if (end_rel) last_end_sh = end_rel;
@@ -1489,9 +1500,9 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
     asm volatile("" : "+s"(ka_e));
 #define TKF_KA64(ka, off) (*(const __attribute__((address_space(4))) uint64_t*)((ka) + (off)))
 #define TKF_KA32(ka, off) (*(const __attribute__((address_space(4))) uint32_t*)((ka) + (off)))
-#define TKF_KA_TP(ka, member) ((decltype(TkTables::member))(uintptr_t)TKF_KA64(ka, offsetof(TkFrontArgs, T) + offsetof(TkTables, member)))
+#define TKF_KA_TP(ka, member) TKF_PTR(decltype(TkTables::member), TKF_KA64(ka, offsetof(TkFrontArgs, T) + offsetof(TkTables, member)))
 #define TKF_KA_T32(ka, member) TKF_KA32(ka, offsetof(TkFrontArgs, T) + offsetof(TkTables, member))
-#define TKF_KA_OP(ka, type, member) ((type)(uintptr_t)TKF_KA64(ka, offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, member)))
+#define TKF_KA_OP(ka, type, member) TKF_PTR(type, TKF_KA64(ka, offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, member)))
     auto fresh_T = [&]() -> TkTables {
         KArg ka = ka_e;
         asm volatile("" : "+s"(ka));
@@ -1510,8 +1521,8 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
         KArg ka = ka_e;
         asm volatile("" : "+s"(ka));
         TkFrontOut o{};
-        o.data.tab = (TkMissTab*)(uintptr_t)TKF_KA64(ka, offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, data) + offsetof(TkMiss, tab));
-        o.data.ovf = (TkMissOvf*)(uintptr_t)TKF_KA64(ka, offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, data) + offsetof(TkMiss, ovf));
+        o.data.tab = TKF_PTR(TkMissTab*, TKF_KA64(ka, offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, data) + offsetof(TkMiss, tab)));
+        o.data.ovf = TKF_PTR(TkMissOvf*, TKF_KA64(ka, offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, data) + offsetof(TkMiss, ovf)));
         o.data.ovf_base = TKF_KA32(ka, offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, data) + offsetof(TkMiss, ovf_base));
         o.ovf_cap = TKF_KA32(ka, offsetof(TkFrontArgs, out) + offsetof(TkFrontOut, ovf_cap));
         o.listC = TKF_KA_OP(ka, uint32_t*, listC);
@@ -1522,7 +1533,7 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
         KArg ka = ka_e;
         asm volatile("" : "+s"(ka));
         mask_out = TKF_KA32(ka, offsetof(TkFrontArgs, mt_mask));
-        return (TkMissKey*)(uintptr_t)TKF_KA64(ka, offsetof(TkFrontArgs, mt));
+        return TKF_PTR(TkMissKey*, TKF_KA64(ka, offsetof(TkFrontArgs, mt)));
     };
     if constexpr (!SLOW) {
         out_f.starts = TKF_KA_OP(ka_e, uint32_t*, starts);
