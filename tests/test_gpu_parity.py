@@ -427,6 +427,36 @@ def test_ten_megabytes_without_a_certain_start_take_the_generic_way():
         assert np.array_equal(toff, ro) and np.array_equal(toks, rt), allowed
 
 
+def test_sparse_non_ascii_chars_by_dense_lanes(cores):
+    """Round 6, tk_fused.h phase B (TKF_DENSE_DECODE): a wavefront whose 1024 bytes hold few non-ASCII chars lists their lead bytes and decodes them by
+    dense lanes -- the class goes into the class planes by LDS atomics at the char's position, whichever lane holds its bytes -- while a wavefront with more
+    than TKF_DENSE_MAX of them keeps the loop per lane.  Chars of two, three and four bytes (letters with and without case, digits, marks, white space,
+    punctuation, astral letters and emoji) at EVERY offset against the lanes' sixteen bytes, the wavefronts' 1024 and the planes' 32-bit words, sparse
+    (dense lanes), dense (the loop) and changing between the two inside a tile; every token compared with the oracle."""
+    chars = ["\u00e9", "\u0416", "\u00a0", "\u0663", "\u0301", "\u2019", "\u4e2d", "\u3000", "\u0e01", "\u2028", "\U00010400", "\U0001f600", "\U0001d7ce", "\u01c5", "\u017f"]
+    for name in h.ENCODING_NAMES:
+        core, C = cores[name], h.c_oracle_for(name)
+        docs = []
+        for shift in range(0, 70):
+            parts, k = ["x" * shift], shift
+            for i in range(260):  # ~ 11 KiB: three tiles, every char at a new offset against 16, 32 and 1024
+                c = chars[(i + shift) % len(chars)]
+                gap = 5 + (i * 7 + shift) % 23
+                k += 1
+                filler = (" word" * 8)[: gap] if i % 3 else "a" * gap
+                parts.append(filler + c + (chars[(i * 5 + 1) % len(chars)] if i % 4 == 0 else "") + ("'s" if i % 9 == 0 else ""))
+            docs.append("".join(parts).encode())
+            if shift % 7 == 0:  # sparse text that turns dense and back: the two paths side by side in one tile
+                dense = "".join(chars[(j + shift) % len(chars)] for j in range(700))
+                docs.append(("".join(parts[:90]) + dense + " " + "".join(parts[90:200]) + dense[:333] + "".join(parts[200:])).encode())
+        blob, off = h.pack(docs)
+        toks, toff = core.encode_batch_packed(blob, off, None)
+        rt, ro = C.encode_batch(blob, off, None, 8)
+        assert np.array_equal(toff, ro) and np.array_equal(toks, rt), name
+        one = b"\n".join(docs[::5])  # one document: the chars at other offsets again, no hard start between the parts
+        assert np.array_equal(core._encode_np(one, None), C.encode_ordinary(one)), name
+
+
 def test_letter_runs_around_tile_ends(cores):
     """Round 6, tk_fused.h: a tile whose left context holds no certain start begins its scan at a position where the matcher's state is known (a letter
     behind a letter, TKF_SYNC_POINTS), and a letter run that leaves a tile's window is read on to its end (TKF_EXTEND) -- unless what ends the run lets

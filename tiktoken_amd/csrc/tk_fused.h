@@ -985,7 +985,80 @@ __global__ __launch_bounds__(256, MODE == TKF_MODE_STARTS ? TKF_SLOW_OCC : (MODE
             return cl;
         };
         const uint32_t prev = tid ? dw[tid * 4u - 1u] : 0u;
-        tk_chunk_decode(ch, prev, tid > 0, get4, cls_of);
+#ifndef TKF_DENSE_DECODE
+#define TKF_DENSE_DECODE 1
+#endif
+        bool decoded = false;
+        if constexpr (TKF_DENSE_DECODE && MODE == TKF_MODE_TILE) {
+            // (round 6) The non-ASCII chars of a wavefront's 1024 bytes by DENSE lanes.  tk_chunk_decode is a loop of ~100 vector instructions per two chars of
+            // a lane that runs as long as the lane with the most chars (up to eight in sixteen bytes) while the average lane of web text has fewer than two:
+            // most of its instructions are issued for a handful of active lanes.  Here the lanes list the window positions of their lead bytes (a prefix sum
+            // of the counts; five instructions per own lead), lane i decodes the i-th listed char whichever lane holds it and ORs its class into the
+            // wavefront's span of the class planes (LDS atomics on words nobody else touches before phase C rewrites them from the registers), and every lane
+            // reads its sixteen bits of the four planes back.  A char that straddles two lanes is decoded once (by the lead's position); the char that
+            // straddles in from the wavefront before is an entry of the wavefront's first lane, as in tk_chunk_decode.
+            const uint32_t cont = tk_plane16(ch.f0, ch.f1, 0);
+            const uint32_t leads16 = tk_plane16(ch.f0, ch.f1, 1) | tk_plane16(ch.f0, ch.f1, 2) | tk_plane16(ch.f0, ch.f1, 3);
+            const bool pend0 = (cont & 1u) && tid > 0 && lane == 0;
+            decoded = true;
+            if (__ballot(leads16 != 0u || pend0)) {
+                const uint32_t cnt = (uint32_t)__popc(leads16) + (pend0 ? 1u : 0u);
+                const uint32_t inc = tk_wave_scan_u32(cnt, lane);
+                const uint32_t total = (uint32_t)__builtin_amdgcn_readlane((int)inc, 63);
+#ifndef TKF_DENSE_MAX
+#define TKF_DENSE_MAX 128  // (at most 512: the list's size.  One box, front kernel in ms per GiB: 64 -> 4.27, 96 -> 4.29, 128 -> 4.24, 192 -> 4.26, 512 -> 4.33; without: 4.28-4.29)
+#endif
+                if (total > (uint32_t)TKF_DENSE_MAX) {
+                    decoded = false;  // (text that is all non-ASCII: every lane is busy in tk_chunk_decode's loop as well, and its step costs less per char)
+                } else {
+                    uint16_t* dl = (uint16_t*)(pool + BM_BYTES) + (uint32_t)wid * 512u;  // (the certain list's place: unused before phase E)
+                    uint32_t* pl32 = (uint32_t*)planes;                                   // (rows of 2 * NW words; words 32 wid .. 32 wid + 31 are this wavefront's)
+                    constexpr uint32_t ROW = 2u * (uint32_t)NW;
+                    const uint32_t w0 = 32u * (uint32_t)wid;
+                    pl32[((uint32_t)lane >> 5) * ROW + w0 + ((uint32_t)lane & 31u)] = 0u;
+                    pl32[(((uint32_t)lane >> 5) + 2u) * ROW + w0 + ((uint32_t)lane & 31u)] = 0u;
+                    uint32_t o = inc - cnt;
+                    if (pend0) {
+                        const int kprev = (prev >> 24) >= 0xC0u ? -1 : (((prev >> 16) & 0xFFu) >= 0xC0u ? -2 : -3);
+                        dl[o++] = (uint16_t)(tid * 16u + (uint32_t)kprev);
+                    }
+                    for (uint32_t m = leads16; m; m &= m - 1u) dl[o++] = (uint16_t)(tid * 16u + (uint32_t)__ffs((int)m) - 1u);
+                    __builtin_amdgcn_wave_barrier();
+                    for (uint32_t e0 = 0; e0 < total; e0 += 64u) {
+                        const uint32_t e = e0 + (uint32_t)lane;
+                        if (e < total) {
+                            const uint32_t pos = dl[e];
+                            uint32_t len;
+                            const uint32_t cp = tk_utf8_cp(__builtin_amdgcn_alignbyte(dw[(pos >> 2) + 1], dw[pos >> 2], pos & 3u), &len);
+                            const uint32_t cl = cls_of(cp);
+                            int rel = (int)pos - (int)(1024u * (uint32_t)wid);
+                            uint32_t ones = (1u << len) - 1u;
+                            if (rel < 0) {
+                                ones >>= (uint32_t)(-rel);
+                                rel = 0;
+                            }
+                            const uint32_t wq = (uint32_t)rel >> 5;
+                            const uint64_t M = (uint64_t)ones << ((uint32_t)rel & 31u);
+                            const uint32_t lo = (uint32_t)M, hi = wq < 31u ? (uint32_t)(M >> 32) : 0u;
+#pragma unroll
+                            for (uint32_t pq = 0; pq < 4u; ++pq) {
+                                const uint32_t bit = 0u - ((cl >> pq) & 1u);
+                                atomicOr(&pl32[pq * ROW + w0 + wq], lo & bit);
+                                if (hi & bit) atomicOr(&pl32[pq * ROW + w0 + wq + 1u], hi & bit);  // (a char across two words of the planes; all four behind ONE test of `hi`: slower)
+                            }
+                        }
+                    }
+                    __builtin_amdgcn_wave_barrier();
+                    const uint32_t hw16 = (tid & 1u) * 16u;
+                    uint32_t v[4];
+#pragma unroll
+                    for (uint32_t pq = 0; pq < 4u; ++pq) v[pq] = (pl32[pq * ROW + (tid >> 1)] >> hw16) & 0xFFFFu;
+                    ch.acc0 |= (v[0] & 0xFFu) | ((v[1] & 0xFFu) << 8) | ((v[2] & 0xFFu) << 16) | ((v[3] & 0xFFu) << 24);
+                    ch.acc1 |= (v[0] >> 8) | ((v[1] >> 8) << 8) | ((v[2] >> 8) << 16) | ((v[3] >> 8) << 24);
+                }
+            }
+        }
+        if (!decoded) tk_chunk_decode(ch, prev, tid > 0, get4, cls_of);
     }
     TKT(1);
     if (dbg & 0x2000) {  // (perf experiments: stop after the classification)
